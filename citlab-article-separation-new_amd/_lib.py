@@ -1,0 +1,99 @@
+"""ctypes binding of ``csrc/libasep_hip.so`` (declared in ``include/asep_hip.h``).
+
+There is deliberately NO CPU fallback: if the HIP library is missing, cannot be loaded, or no
+gfx950 device is present, every compute entry point raises (the oracle under ``oracle/`` is test
+infrastructure and is never imported from here).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libasep_hip.so")
+
+
+class AsepError(RuntimeError):
+    pass
+
+
+class AruCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "channels", "n_classes", "feat_root", "scale_space_num", "res_depth", "num_scales_att",
+        "use_attention", "mvn", "apply_softmax", "compute_dtype")]
+
+
+class GnnCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "node_feature_dim", "edge_feature_dim", "num_transition_steps", "hidden_dim", "interaction_dim",
+        "interaction_hidden", "cls_hidden1", "cls_hidden2", "num_classes", "undirected_graph")]
+
+
+# name -> (restype, argtypes); mirrors include/asep_hip.h one to one
+_P = C.c_void_p
+SIGNATURES = {
+    "asep_device_count": (C.c_int, []),
+    "asep_init": (C.c_int, [C.c_int]),
+    "asep_last_error": (C.c_char_p, []),
+    "asep_version": (C.c_char_p, []),
+    "asep_aru_load": (_P, [_P, C.c_size_t, C.POINTER(AruCfg)]),
+    "asep_aru_free": (None, [_P]),
+    "asep_aru_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_float]),
+    "asep_aru_forward_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_float, _P]),
+    "asep_aru_get_endpoint": (C.c_long, [_P, C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_int32)]),
+    "asep_aru_flops": (C.c_double, [_P, C.c_int, C.c_int]),
+    "asep_gnn_load": (_P, [_P, C.c_size_t, C.POINTER(GnnCfg)]),
+    "asep_gnn_free": (None, [_P]),
+    "asep_gnn_correct_edges": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "asep_gnn_forward": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P]),
+    "asep_gnn_forward_dev": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P]),
+    "asep_gnn_get_hidden": (C.c_int, [_P, _P, C.c_size_t]),
+    "asep_gnn_flops": (C.c_double, [_P, C.c_int, C.c_int, C.c_int]),
+}
+
+_lib = None
+
+
+def load_library(path: str = None):
+    """dlopen the HIP library (once).  ``torch`` is imported first on purpose: PyTorch-ROCm ships its
+    own ``libamdhip64`` and both runtimes must resolve to the same copy inside one process."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get("ASEP_HIP_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise AsepError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C {os.path.dirname(LIB_PATH)}`); there is no CPU fallback")
+    try:
+        import torch  # noqa: F401  (HIP runtime de-duplication, see docstring)
+    except Exception:  # pragma: no cover - torch is plumbing only
+        pass
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load_library().asep_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str):
+    if rc < 0:
+        raise AsepError(f"{what} failed ({rc}): {last_error()}")
+    return rc
+
+
+_initialised = {}
+
+
+def init_device(device_id: int = 0):
+    lib = load_library()
+    if device_id not in _initialised:
+        if lib.asep_device_count() <= 0:
+            raise AsepError("no HIP device visible: the MI355X (gfx950) engine has no CPU fallback")
+        check(lib.asep_init(device_id), "asep_init")
+        _initialised[device_id] = True
+    return lib

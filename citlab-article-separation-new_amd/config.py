@@ -1,0 +1,65 @@
+"""Model hyper-parameters of the two hot-path nets.
+
+Defaults follow the reference's defaults:
+  * ARU-Net: ``article_separation/backbones/ARU_v1.py:35-43`` (graph 'ARU' switches the
+    attention branch on, ``ARU_v1.py:94-98``).
+  * GNN: ``gnn/model/graph/graph_gnn.py:19-25``, ``message_fn_chunk.py:13-40``,
+    ``update_fn_lstm.py:12-19``, ``gnn/trainer/trainer_rel.py:15-17``.
+"""
+from dataclasses import dataclass, field, asdict
+from typing import List
+
+
+@dataclass
+class AruConfig:
+    graph: str = "ARU"            # 'U' is not supported; 'RU' (no attention) or 'ARU'
+    channels: int = 1             # image channels (the attention branch needs 1)
+    n_classes: int = 2
+    feat_root: int = 8
+    scale_space_num: int = 5
+    res_depth: int = 3
+    num_scales_att: int = 3
+    filter_size: int = 3
+    pool_size: int = 2
+    mvn: bool = False
+    apply_softmax: bool = True    # export-time class softmax -> 'output:0'
+
+    @property
+    def use_attention(self) -> bool:
+        return "ARU" in self.graph
+
+    def feat(self, level: int) -> int:
+        return self.feat_root * (self.pool_size ** level)
+
+    def to_dict(self):
+        return asdict(self)
+
+
+@dataclass
+class GnnConfig:
+    node_feature_dim: int = 7         # after masking (vn7e2: 7 of 15, nets/README.md:24-27)
+    edge_feature_dim: int = 2
+    num_transition_steps: int = 3
+    hidden_dim: int = 32              # hidden_node_feature_dim
+    interaction_dim: int = 32         # interaction_feature_dim
+    interaction_hidden: List[int] = field(default_factory=lambda: [32])
+    classifier_hidden: List[int] = field(default_factory=lambda: [64, 32])
+    num_classes: int = 2
+    undirected_graph: bool = True
+    # visual branch (GraphRelation image_input); 0 maps -> disabled
+    visual_dims: List[int] = field(default_factory=list)   # layer_compressed_dim per feature map
+
+    @property
+    def u_dim(self) -> int:
+        return self.node_feature_dim + sum(self.visual_dims)
+
+    @property
+    def message_in_dim(self) -> int:
+        return 4 * self.u_dim + self.edge_feature_dim + 4 * self.hidden_dim
+
+    @property
+    def update_in_dim(self) -> int:
+        return self.interaction_dim + self.hidden_dim + self.u_dim
+
+    def to_dict(self):
+        return asdict(self)

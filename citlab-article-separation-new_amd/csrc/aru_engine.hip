@@ -1,0 +1,551 @@
+// ARU-Net inference engine (host side): weight packing for the MFMA fragment order, buffer
+// management and the layer schedule of ARU_v1.py:62-294.  Entry points: include/asep_hip.h.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+#include "aru_kernels.h"
+#include "asep_common.h"
+
+using namespace asep;
+
+namespace {
+
+struct Tensor {
+    float* p = nullptr;
+    int H = 0, W = 0, C = 0;
+    size_t count() const { return (size_t)H * W * C; }
+};
+
+// A convolution whose weights are packed as the A operand of v_mfma_f32_16x16x4_f32.
+struct PackedConv {
+    int kh = 0, kw = 0, cin = 0, cout = 0;
+    bool c8 = false;       // Cin == 8: two taps per 16-slot chunk
+    bool deconv = false;
+    int groups = 0, mtiles = 0, nchunks = 0;
+    float* d_w = nullptr;
+    float* d_b = nullptr;
+};
+
+struct DirectConv {        // Cin == 1 first layers
+    int k = 0, cout = 0;
+    float* d_w = nullptr;  // [k*k][cout]
+    float* d_b = nullptr;
+};
+
+int upload(const std::vector<float>& h, float** d) {
+    ASEP_HIP_CHECK(hipMalloc((void**)d, std::max<size_t>(h.size(), 4) * sizeof(float)));
+    ASEP_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return ASEP_OK;
+}
+
+}  // namespace
+
+struct asep_aru {
+    asep_aru_cfg cfg{};
+    std::map<std::string, PackedConv> convs;   // keyed by variable scope, e.g. "aru_net/featMapG/unet_down_1/convR_0"
+    DirectConv det_first, att_first;
+    float* d_logit_w = nullptr;
+    float* d_logit_b = nullptr;
+    float* d_stats = nullptr;      // mvn {mean, 1/std}
+    double* d_sums = nullptr;
+    BufferPool pool;
+    std::map<std::string, Tensor> endpoints;
+    hipStream_t stream = nullptr;
+    std::vector<void*> owned;
+
+    ~asep_aru() {
+        for (void* p : owned)
+            if (p) (void)hipFree(p);
+    }
+    int feat(int l) const { return cfg.feat_root << l; }
+};
+
+namespace {
+
+// ---- weight packing -----------------------------------------------------------------------------
+// conv   W[kh][kw][cin][cout]  (layers.py:219);  deconv W[kh][kw][cout][cin] (layers.py:352, ARU_v1.py:257)
+int pack_conv(asep_aru* m, const std::map<std::string, HostTensor>& blob, const std::string& scope,
+              const char* bias_name, bool deconv) {
+    auto wi = blob.find(scope + "/weights");
+    auto bi = blob.find(scope + "/" + bias_name);
+    if (wi == blob.end() || bi == blob.end()) {
+        set_error("weights: missing tensor %s/{weights,%s}", scope.c_str(), bias_name);
+        return ASEP_ERR_WEIGHTS;
+    }
+    const HostTensor& w = wi->second;
+    if (w.dims.size() != 4) {
+        set_error("weights: %s/weights must have rank 4", scope.c_str());
+        return ASEP_ERR_WEIGHTS;
+    }
+    PackedConv pc;
+    pc.kh = w.dims[0];
+    pc.kw = w.dims[1];
+    pc.deconv = deconv;
+    pc.cin = deconv ? w.dims[3] : w.dims[2];
+    pc.cout = deconv ? w.dims[2] : w.dims[3];
+    if ((int)bi->second.count() != pc.cout) {
+        set_error("weights: %s bias has %zu elements, expected %d", scope.c_str(), bi->second.count(), pc.cout);
+        return ASEP_ERR_WEIGHTS;
+    }
+    if (pc.cin % 4 != 0) {
+        set_error("weights: %s has Cin=%d; the MFMA path needs Cin %% 4 == 0", scope.c_str(), pc.cin);
+        return ASEP_ERR_UNSUPPORTED;
+    }
+    const int taps = pc.kh * pc.kw;
+    pc.c8 = (!deconv && pc.cin == 8);
+    pc.mtiles = cdiv(pc.cout, 16);
+    pc.groups = pc.c8 ? 1 : cdiv(pc.cin, 16);
+    pc.nchunks = pc.c8 ? (taps + 1) / 2 : pc.groups * taps;
+    auto W = [&](int tap, int ci, int co) -> float {
+        if (ci >= pc.cin || co >= pc.cout || tap >= taps) return 0.f;
+        return deconv ? w.data[((size_t)tap * pc.cout + co) * pc.cin + ci]
+                      : w.data[((size_t)tap * pc.cin + ci) * pc.cout + co];
+    };
+    std::vector<float> pk((size_t)pc.nchunks * pc.mtiles * 64 * 4);
+    for (int ch = 0; ch < pc.nchunks; ++ch)
+        for (int mt = 0; mt < pc.mtiles; ++mt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    const int kk = lane >> 4, co = mt * 16 + (lane & 15);
+                    int tap, ci;
+                    if (pc.c8) {
+                        tap = 2 * ch + (kk >> 1);
+                        ci = 4 * (kk & 1) + r;
+                    } else {
+                        const int g = ch / taps;
+                        tap = ch % taps;
+                        ci = 16 * g + 4 * kk + r;
+                    }
+                    pk[(((size_t)ch * pc.mtiles + mt) * 64 + lane) * 4 + r] = W(tap, ci, co);
+                }
+    int rc = upload(pk, &pc.d_w);
+    if (rc) return rc;
+    rc = upload(bi->second.data, &pc.d_b);
+    if (rc) return rc;
+    m->owned.push_back(pc.d_w);
+    m->owned.push_back(pc.d_b);
+    m->convs[scope] = pc;
+    return ASEP_OK;
+}
+
+int pack_direct(asep_aru* m, const std::map<std::string, HostTensor>& blob, const std::string& scope,
+                DirectConv* dc) {
+    auto wi = blob.find(scope + "/weights");
+    auto bi = blob.find(scope + "/biases");
+    if (wi == blob.end() || bi == blob.end()) {
+        set_error("weights: missing tensor %s/{weights,biases}", scope.c_str());
+        return ASEP_ERR_WEIGHTS;
+    }
+    const HostTensor& w = wi->second;
+    if (w.dims.size() != 4 || w.dims[2] != 1 || w.dims[0] != w.dims[1]) {
+        set_error("weights: %s must be [k,k,1,cout]", scope.c_str());
+        return ASEP_ERR_UNSUPPORTED;
+    }
+    dc->k = w.dims[0];
+    dc->cout = w.dims[3];
+    int rc = upload(w.data, &dc->d_w);
+    if (rc) return rc;
+    rc = upload(bi->second.data, &dc->d_b);
+    if (rc) return rc;
+    m->owned.push_back(dc->d_w);
+    m->owned.push_back(dc->d_b);
+    return ASEP_OK;
+}
+
+// ---- kernel launchers ---------------------------------------------------------------------------
+Tensor new_tensor(asep_aru* m, int H, int W, int C) {
+    Tensor t;
+    t.H = H; t.W = W; t.C = C;
+    t.p = (float*)m->pool.get(t.count() * sizeof(float));
+    return t;
+}
+
+template <int KH, int KW>
+void launch_conv_k(const PackedConv& pc, const ConvArgs& a, dim3 grid_xy, hipStream_t s) {
+    int mt = pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1);
+    dim3 grid(grid_xy.x, grid_xy.y, pc.mtiles / mt);
+    if (pc.c8) {
+        // Cin == 8 always comes with a single m-tile per block here (cout 8 or 16)
+        dim3 g1(grid_xy.x, grid_xy.y, pc.mtiles);
+        hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, true>), g1, dim3(256), 0, s, a);
+        return;
+    }
+    if (mt == 4) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 4, false>), grid, dim3(256), 0, s, a);
+    else if (mt == 2) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 2, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false>), grid, dim3(256), 0, s, a);
+}
+
+// stride-1 SAME conv on the (optionally concatenated) inputs
+Tensor run_conv(asep_aru* m, const std::string& scope, const Tensor& in0, const Tensor* in1, bool relu_in,
+                bool relu_out, const Tensor* res) {
+    auto it = m->convs.find(scope);
+    if (it == m->convs.end()) { set_error("internal: conv %s not packed", scope.c_str()); throw ArgError(); }
+    const PackedConv& pc = it->second;
+    const int cin = in0.C + (in1 ? in1->C : 0);
+    if (cin != pc.cin) {
+        set_error("internal: conv %s expects Cin=%d, got %d", scope.c_str(), pc.cin, cin);
+        throw ArgError();
+    }
+    Tensor out = new_tensor(m, in0.H, in0.W, pc.cout);
+    ConvArgs a{};
+    a.in0 = in0.p; a.c0 = in0.C;
+    a.in1 = in1 ? in1->p : nullptr; a.c1 = in1 ? in1->C : 0;
+    a.wpk = (const f32x4*)pc.d_w; a.bias = pc.d_b; a.res = res ? res->p : nullptr; a.out = out.p;
+    a.H = in0.H; a.W = in0.W; a.Ho = in0.H; a.Wo = in0.W;
+    a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
+    a.relu_in = relu_in; a.relu_out = relu_out;
+    dim3 gxy(cdiv(in0.W, CONV_TW), cdiv(in0.H, CONV_TH));
+    if (pc.kh == 3 && pc.kw == 3) launch_conv_k<3, 3>(pc, a, gxy, m->stream);
+    else if (pc.kh == 4 && pc.kw == 4) launch_conv_k<4, 4>(pc, a, gxy, m->stream);
+    else { set_error("conv %s: unsupported kernel size %dx%d", scope.c_str(), pc.kh, pc.kw); throw ArgError(); }
+    return out;
+}
+
+// conv2d_transpose 3x3 stride 2 SAME to the spatial size of `like` (ARU_v1.py:255-259)
+Tensor run_deconv(asep_aru* m, const std::string& scope, const Tensor& in, int Ho, int Wo, bool relu_out) {
+    auto it = m->convs.find(scope);
+    if (it == m->convs.end()) { set_error("internal: deconv %s not packed", scope.c_str()); throw ArgError(); }
+    const PackedConv& pc = it->second;
+    if (pc.kh != 3 || pc.kw != 3 || in.C != pc.cin) {
+        set_error("deconv %s: unsupported shape (k=%d, Cin %d vs %d)", scope.c_str(), pc.kh, pc.cin, in.C);
+        throw ArgError();
+    }
+    if (cdiv(Ho, 2) != in.H || cdiv(Wo, 2) != in.W) {
+        set_error("deconv %s: output %dx%d incompatible with input %dx%d", scope.c_str(), Ho, Wo, in.H, in.W);
+        throw ArgError();
+    }
+    Tensor out = new_tensor(m, Ho, Wo, pc.cout);
+    ConvArgs a{};
+    a.in0 = in.p; a.c0 = in.C; a.in1 = nullptr; a.c1 = 0;
+    a.wpk = (const f32x4*)pc.d_w; a.bias = pc.d_b; a.res = nullptr; a.out = out.p;
+    a.H = in.H; a.W = in.W; a.Ho = Ho; a.Wo = Wo;
+    a.pbh = std::max((in.H - 1) * 2 + 3 - Ho, 0) / 2;
+    a.pbw = std::max((in.W - 1) * 2 + 3 - Wo, 0) / 2;
+    a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
+    a.relu_in = 0; a.relu_out = relu_out;
+    const int mt = pc.mtiles % 2 == 0 ? 2 : 1;
+    dim3 grid(cdiv(in.W, DC_TW), cdiv(in.H, DC_TH), pc.mtiles / mt);
+    if (mt == 2) hipLaunchKernelGGL((deconv_mfma_kernel<2>), grid, dim3(256), 0, m->stream, a);
+    else hipLaunchKernelGGL((deconv_mfma_kernel<1>), grid, dim3(256), 0, m->stream, a);
+    return out;
+}
+
+Tensor run_direct(asep_aru* m, const DirectConv& dc, const Tensor& img, bool relu, const float* stats) {
+    Tensor out = new_tensor(m, img.H, img.W, dc.cout);
+    dim3 grid(cdiv(img.W, 64), cdiv(img.H, 4));
+#define ASEP_C1(K, CO)                                                                               \
+    if (dc.k == K && dc.cout == CO) {                                                                \
+        hipLaunchKernelGGL((conv_c1_kernel<K, CO>), grid, dim3(256), 0, m->stream, img.p, img.H, img.W, \
+                           dc.d_w, dc.d_b, out.p, relu ? 1 : 0, stats);                                 \
+        return out;                                                                                  \
+    }
+    ASEP_C1(3, 8) ASEP_C1(3, 16) ASEP_C1(4, 12)
+#undef ASEP_C1
+    set_error("first-layer conv k=%d cout=%d not instantiated", dc.k, dc.cout);
+    throw ArgError();
+}
+
+int grid_1d(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); }
+
+Tensor run_maxpool(asep_aru* m, const Tensor& in) {
+    Tensor out = new_tensor(m, cdiv(in.H, 2), cdiv(in.W, 2), in.C);
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_1d(out.count() / 4)), dim3(256), 0, m->stream, in.p, in.H, in.W,
+                       in.C, out.p, out.H, out.W);
+    return out;
+}
+
+Tensor run_avgpool_c1(asep_aru* m, const Tensor& in) {
+    Tensor out = new_tensor(m, cdiv(in.H, 2), cdiv(in.W, 2), 1);
+    hipLaunchKernelGGL(avgpool2_c1_kernel, dim3(grid_1d(out.count())), dim3(256), 0, m->stream, in.p, in.H, in.W,
+                       out.p, out.H, out.W);
+    return out;
+}
+
+// ---- network schedule (ARU_v1.py) ---------------------------------------------------------------
+// residual block: conv1 (identity) -> t ; relu ; (res_depth-1) x conv+relu ; conv (identity) ; +t ; relu
+Tensor res_block_tail(asep_aru* m, const std::string& scope, const Tensor& t) {
+    Tensor r = t;
+    const int rd = m->cfg.res_depth;
+    for (int i = 0; i < rd; ++i) {
+        const bool last = (i == rd - 1);
+        r = run_conv(m, scope + "/convR_" + std::to_string(i), r, nullptr, /*relu_in=*/i == 0,
+                     /*relu_out=*/true, last ? &t : nullptr);
+    }
+    return r;
+}
+
+Tensor det_cnn(asep_aru* m, const Tensor& img, int sc, const float* stats) {
+    const int n = m->cfg.scale_space_num;
+    std::vector<Tensor> skips;
+    Tensor u = img;
+    for (int l = 0; l < n; ++l) {
+        const std::string scope = "aru_net/featMapG/unet_down_" + std::to_string(l);
+        Tensor t = (l == 0) ? run_direct(m, m->det_first, img, false, stats)
+                            : run_conv(m, scope + "/conv1", u, nullptr, false, false, nullptr);
+        Tensor d = res_block_tail(m, scope, t);
+        skips.push_back(d);
+        m->endpoints["scale_" + std::to_string(sc) + "_unet_down_" + std::to_string(l) + "_conv"] = d;
+        u = (l < n - 1) ? run_maxpool(m, d) : d;
+    }
+    for (int l = n - 2; l >= 0; --l) {
+        const std::string scope = "aru_net/featMapG/unet_up_" + std::to_string(l);
+        const Tensor& skip = skips[l];
+        Tensor v = run_deconv(m, scope + "/deconv", u, skip.H, skip.W, true);
+        m->endpoints["scale_" + std::to_string(sc) + "_unet_up_" + std::to_string(l) + "_deconv"] = v;
+        Tensor t = run_conv(m, scope + "/conv1", skip, &v, false, false, nullptr);   // concat [skip, deconv]
+        u = res_block_tail(m, scope, t);
+        m->endpoints["scale_" + std::to_string(sc) + "_unet_up_" + std::to_string(l) + "_conv"] = u;
+    }
+    return u;
+}
+
+Tensor att_cnn(asep_aru* m, const Tensor& img, const float* stats) {
+    const std::string p = "aru_net/attMapG/attPart/conv";
+    Tensor y = run_direct(m, m->att_first, img, true, stats);
+    y = run_maxpool(m, y);
+    y = run_conv(m, p + "2", y, nullptr, false, true, nullptr);
+    y = run_maxpool(m, y);
+    y = run_conv(m, p + "3", y, nullptr, false, true, nullptr);
+    y = run_maxpool(m, y);
+    y = run_conv(m, p + "4", y, nullptr, false, true, nullptr);
+    return y;
+}
+
+int forward_impl(asep_aru* m, const float* d_img, int H, int W, float* d_out, uint8_t* d_u8, uint8_t* d_mask,
+                 float threshold, hipStream_t stream) {
+    const asep_aru_cfg& cfg = m->cfg;
+    m->stream = stream;
+    m->pool.begin();
+    m->endpoints.clear();
+    try {
+        Tensor img;
+        img.p = const_cast<float*>(d_img);
+        img.H = H; img.W = W; img.C = 1;
+        const float* stats = nullptr;
+        if (cfg.mvn) {
+            ASEP_HIP_CHECK(hipMemsetAsync(m->d_sums, 0, 2 * sizeof(double), stream));
+            hipLaunchKernelGGL(moments_kernel, dim3(grid_1d(img.count())), dim3(256), 0, stream, img.p, img.count(),
+                               m->d_sums);
+            hipLaunchKernelGGL(moments_finish_kernel, dim3(1), dim3(1), 0, stream, m->d_sums, img.count(), m->d_stats);
+            stats = m->d_stats;
+        }
+        const int nsc = cfg.use_attention ? cfg.num_scales_att : 1;
+        if (nsc > MAX_SCALES) { set_error("num_scales_att %d > %d", nsc, MAX_SCALES); return ASEP_ERR_UNSUPPORTED; }
+        // image pyramid.  With mvn the pyramid is built from the standardised image; avg-pooling commutes
+        // with the affine map, so scales >= 1 standardise on load with the same statistics.
+        std::vector<Tensor> scales{img};
+        for (int s = 1; s < nsc; ++s) scales.push_back(run_avgpool_c1(m, scales.back()));
+
+        CombineArgs ca{};
+        ca.nsc = nsc; ca.H = H; ca.W = W;
+        if (cfg.use_attention) {
+            int up = 8;
+            for (int s = 0; s < nsc; ++s) {
+                Tensor a = att_cnn(m, scales[s], stats);
+                m->endpoints["att_" + std::to_string(s)] = a;
+                if (cdiv(H, up) != a.H || cdiv(W, up) != a.W) { set_error("internal: attention map shape"); return ASEP_ERR_ARG; }
+                ca.att[s] = a.p; ca.ah[s] = a.H; ca.aw[s] = a.W; ca.aup[s] = up;
+                ca.aph[s] = (a.H * up - H) / 2; ca.apw[s] = (a.W * up - W) / 2;
+                up *= 2;
+            }
+        }
+        Tensor f0 = det_cnn(m, scales[0], 0, stats);
+        ca.f0 = f0.p;
+        int up = 1;
+        for (int s = 1; s < nsc; ++s) {
+            Tensor f = det_cnn(m, scales[s], s, stats);
+            up *= 2;
+            Tensor fs = new_tensor(m, f.H, f.W, 1);
+            hipLaunchKernelGGL(chansum_kernel, dim3(grid_1d(fs.count())), dim3(256), 0, stream, f.p, fs.count(), f.C, fs.p);
+            ca.fsum[s] = fs.p; ca.fh[s] = f.H; ca.fw[s] = f.W; ca.fup[s] = up;
+            ca.fph[s] = (f.H * up - H) / 2; ca.fpw[s] = (f.W * up - W) / 2;
+        }
+        ca.wl = m->d_logit_w; ca.bl = m->d_logit_b;
+        ca.out = d_out; ca.out_u8 = d_u8; ca.out_mask = d_mask;
+        ca.thr255 = (double)threshold * 255.0;
+        ca.softmax = cfg.apply_softmax;
+        dim3 grid(cdiv(W, 16), cdiv(H, 16));
+#define ASEP_COMB(FR, NC)                                                                          \
+    if (cfg.feat_root == FR && cfg.n_classes == NC) {                                              \
+        hipLaunchKernelGGL((combine_kernel<FR, NC>), grid, dim3(256), 0, stream, ca);              \
+    } else
+        ASEP_COMB(8, 1) ASEP_COMB(8, 2) ASEP_COMB(8, 3) ASEP_COMB(8, 4) ASEP_COMB(16, 2)
+        { set_error("combine: feat_root=%d n_classes=%d not instantiated", cfg.feat_root, cfg.n_classes); return ASEP_ERR_UNSUPPORTED; }
+#undef ASEP_COMB
+        ASEP_HIP_CHECK(hipGetLastError());
+    } catch (const HipError&) {
+        return ASEP_ERR_HIP;
+    } catch (const ArgError&) {
+        return ASEP_ERR_ARG;
+    }
+    return ASEP_OK;
+}
+
+// 2*MAC of every conv / deconv of one forward (SURVEY.md section 8d formula)
+double flops_impl(const asep_aru_cfg& cfg, int H, int W) {
+    auto det = [&](int h, int w) {
+        double mac = 0;
+        int last = cfg.channels;
+        std::vector<std::pair<int, int>> dims;
+        int hh = h, ww = w;
+        for (int l = 0; l < cfg.scale_space_num; ++l) {
+            const int f = cfg.feat_root << l;
+            dims.push_back({hh, ww});
+            mac += (double)hh * ww * (9.0 * last * f + cfg.res_depth * 9.0 * f * f);
+            last = f;
+            if (l < cfg.scale_space_num - 1) { hh = cdiv(hh, 2); ww = cdiv(ww, 2); }
+        }
+        for (int l = cfg.scale_space_num - 2; l >= 0; --l) {
+            const int f = cfg.feat_root << l;
+            const auto& di = dims[l + 1];
+            const auto& d = dims[l];
+            mac += (double)di.first * di.second * 9.0 * last * f;                       // deconv, input resolution
+            mac += (double)d.first * d.second * (9.0 * 2 * f * f + cfg.res_depth * 9.0 * f * f);
+            last = f;
+        }
+        return mac;
+    };
+    auto att = [&](int h, int w) {
+        double mac = 0;
+        int chans[5] = {cfg.channels, 12, 16, 32, 1};
+        int hh = h, ww = w;
+        for (int i = 0; i < 4; ++i) {
+            mac += (double)hh * ww * 16.0 * chans[i] * chans[i + 1];
+            if (i < 3) { hh = cdiv(hh, 2); ww = cdiv(ww, 2); }
+        }
+        return mac;
+    };
+    double mac = 0;
+    const int nsc = cfg.use_attention ? cfg.num_scales_att : 1;
+    int h = H, w = W;
+    for (int s = 0; s < nsc; ++s) {
+        mac += det(h, w);
+        if (cfg.use_attention) mac += att(h, w);
+        h = cdiv(h, 2); w = cdiv(w, 2);
+    }
+    mac += (double)H * W * 16.0 * cfg.feat_root * cfg.n_classes;
+    return 2.0 * mac;
+}
+
+}  // namespace
+
+extern "C" {
+
+asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_cfg* cfg) {
+    if (!cfg || !weight_blob) { set_error("asep_aru_load: null argument"); return nullptr; }
+    if (cfg->channels != 1) { set_error("asep_aru_load: only 1-channel input is supported (ARU_v1.py:115)"); return nullptr; }
+    if (cfg->compute_dtype != 0) { set_error("asep_aru_load: compute_dtype %d not available yet (fp32 only)", cfg->compute_dtype); return nullptr; }
+    if (cfg->scale_space_num < 1 || cfg->res_depth < 1) { set_error("asep_aru_load: bad cfg"); return nullptr; }
+    std::map<std::string, HostTensor> blob;
+    if (!parse_blob(weight_blob, nbytes, blob)) return nullptr;
+    std::unique_ptr<asep_aru> m(new asep_aru());
+    m->cfg = *cfg;
+    int rc = ASEP_OK;
+    const int n = cfg->scale_space_num;
+    if (cfg->use_attention) {
+        rc = pack_direct(m.get(), blob, "aru_net/attMapG/attPart/conv1", &m->att_first);
+        for (int i = 2; i <= 4 && !rc; ++i)
+            rc = pack_conv(m.get(), blob, "aru_net/attMapG/attPart/conv" + std::to_string(i), "biases", false);
+    }
+    if (!rc) rc = pack_direct(m.get(), blob, "aru_net/featMapG/unet_down_0/conv1", &m->det_first);
+    for (int l = 0; l < n && !rc; ++l) {
+        const std::string s = "aru_net/featMapG/unet_down_" + std::to_string(l);
+        if (l > 0) rc = pack_conv(m.get(), blob, s + "/conv1", "biases", false);
+        for (int r = 0; r < cfg->res_depth && !rc; ++r)
+            rc = pack_conv(m.get(), blob, s + "/convR_" + std::to_string(r), "biases", false);
+    }
+    for (int l = n - 2; l >= 0 && !rc; --l) {
+        const std::string s = "aru_net/featMapG/unet_up_" + std::to_string(l);
+        rc = pack_conv(m.get(), blob, s + "/deconv", "bias", true);
+        if (!rc) rc = pack_conv(m.get(), blob, s + "/conv1", "biases", false);
+        for (int r = 0; r < cfg->res_depth && !rc; ++r)
+            rc = pack_conv(m.get(), blob, s + "/convR_" + std::to_string(r), "biases", false);
+    }
+    if (rc) return nullptr;
+    auto lw = blob.find("aru_net/logit/class/weights");
+    auto lb = blob.find("aru_net/logit/class/biases");
+    if (lw == blob.end() || lb == blob.end()) { set_error("weights: missing aru_net/logit/class"); return nullptr; }
+    const auto& d = lw->second.dims;
+    if (d.size() != 4 || d[0] != 4 || d[1] != 4 || d[2] != cfg->feat_root || d[3] != cfg->n_classes) {
+        set_error("weights: aru_net/logit/class/weights must be [4,4,%d,%d]", cfg->feat_root, cfg->n_classes);
+        return nullptr;
+    }
+    if (upload(lw->second.data, &m->d_logit_w) || upload(lb->second.data, &m->d_logit_b)) return nullptr;
+    m->owned.push_back(m->d_logit_w);
+    m->owned.push_back(m->d_logit_b);
+    if (hipMalloc((void**)&m->d_stats, 2 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&m->d_sums, 2 * sizeof(double)) != hipSuccess) {
+        set_error("asep_aru_load: hipMalloc failed");
+        return nullptr;
+    }
+    m->owned.push_back(m->d_stats);
+    m->owned.push_back(m->d_sums);
+    return m.release();
+}
+
+void asep_aru_free(asep_aru* m) { delete m; }
+
+int asep_aru_forward_dev(asep_aru* m, const float* d_img, int H, int W, float* d_out, uint8_t* d_out_u8,
+                         uint8_t* d_out_mask, float threshold, void* stream) {
+    if (!m || !d_img || !d_out || H < 1 || W < 1) { set_error("asep_aru_forward_dev: bad argument"); return ASEP_ERR_ARG; }
+    return forward_impl(m, d_img, H, W, d_out, d_out_u8, d_out_mask, threshold, (hipStream_t)stream);
+}
+
+int asep_aru_forward(asep_aru* m, const float* img_hw, int H, int W, float* out_hwc, uint8_t* out_u8,
+                     uint8_t* out_mask, float threshold) {
+    if (!m || !img_hw || !out_hwc || H < 1 || W < 1) { set_error("asep_aru_forward: bad argument"); return ASEP_ERR_ARG; }
+    const size_t npix = (size_t)H * W, nout = npix * m->cfg.n_classes;
+    float *d_img = nullptr, *d_out = nullptr;
+    uint8_t *d_u8 = nullptr, *d_mask = nullptr;
+    int rc = ASEP_OK;
+    auto cleanup = [&]() {
+        if (d_img) (void)hipFree(d_img);
+        if (d_out) (void)hipFree(d_out);
+        if (d_u8) (void)hipFree(d_u8);
+        if (d_mask) (void)hipFree(d_mask);
+    };
+#define ASEP_TRY(expr)                                                                      \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            set_error("%s failed: %s", #expr, hipGetErrorString(_e));                       \
+            cleanup();                                                                      \
+            return ASEP_ERR_HIP;                                                            \
+        }                                                                                   \
+    } while (0)
+    ASEP_TRY(hipMalloc((void**)&d_img, npix * sizeof(float)));
+    ASEP_TRY(hipMalloc((void**)&d_out, nout * sizeof(float)));
+    if (out_u8) ASEP_TRY(hipMalloc((void**)&d_u8, nout));
+    if (out_mask) ASEP_TRY(hipMalloc((void**)&d_mask, nout));
+    ASEP_TRY(hipMemcpy(d_img, img_hw, npix * sizeof(float), hipMemcpyHostToDevice));
+    rc = forward_impl(m, d_img, H, W, d_out, d_u8, d_mask, threshold, nullptr);
+    if (rc) { cleanup(); return rc; }
+    ASEP_TRY(hipStreamSynchronize(nullptr));
+    ASEP_TRY(hipMemcpy(out_hwc, d_out, nout * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_u8) ASEP_TRY(hipMemcpy(out_u8, d_u8, nout, hipMemcpyDeviceToHost));
+    if (out_mask) ASEP_TRY(hipMemcpy(out_mask, d_mask, nout, hipMemcpyDeviceToHost));
+#undef ASEP_TRY
+    cleanup();
+    return ASEP_OK;
+}
+
+long asep_aru_get_endpoint(asep_aru* m, const char* name, float* out, size_t max_floats, int32_t dims[3]) {
+    if (!m || !name) { set_error("asep_aru_get_endpoint: bad argument"); return ASEP_ERR_ARG; }
+    auto it = m->endpoints.find(name);
+    if (it == m->endpoints.end()) { set_error("asep_aru_get_endpoint: unknown end point '%s'", name); return ASEP_ERR_ARG; }
+    const Tensor& t = it->second;
+    if (dims) { dims[0] = t.H; dims[1] = t.W; dims[2] = t.C; }
+    if (!out) return (long)t.count();
+    if (max_floats < t.count()) { set_error("asep_aru_get_endpoint: buffer too small"); return ASEP_ERR_ARG; }
+    ASEP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    ASEP_HIP_CHECK(hipMemcpy(out, t.p, t.count() * sizeof(float), hipMemcpyDeviceToHost));
+    return (long)t.count();
+}
+
+double asep_aru_flops(const asep_aru* m, int H, int W) {
+    if (!m) return 0.0;
+    return flops_impl(m->cfg, H, W);
+}
+
+}  // extern "C"

@@ -1,0 +1,521 @@
+// ARU-Net device kernels for gfx950 (CDNA4).  fp32 path: implicit-GEMM convolutions on the
+// f32 MFMA (v_mfma_f32_16x16x4_f32), NHWC activations, LDS-staged halo tiles.
+//
+// Reference semantics implemented here (file:line in /root/reference):
+//   layers.py:191-247   conv2d (SAME, stride 1) + bias + activation      -> conv_mfma_kernel / conv_c1_kernel
+//   layers.py:342-367   deconv2d (conv2d_transpose 3x3, stride 2, SAME)   -> deconv_mfma_kernel
+//   layers.py:526-544   avg/max pool 2x2 s2 SAME                          -> avgpool2_kernel / maxpool2_kernel
+//   layers.py:716-720   upsample_simple (NN upsample + channel sum)       -> chansum_kernel + combine_kernel
+//   ARU_v1.py:141-160   softmax over scales, weighted sum, 4x4 logits conv -> combine_kernel
+//   net_post_processing_helper.py:75-78 + separator_net_post_processor.py:147 -> combine_kernel epilogue
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace asep {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution, D[cout][pixel] = sum_k A[cout][k] * B[k][pixel]
+//   A = packed weights (MFMA A operand, M = 16 output channels per tile),
+//   B = activations from the LDS halo tile (N = 16 consecutive pixels of one row per tile),
+//   K is consumed in chunks of 16 "slots": slot s = 4*kk + r  (kk = lane>>4, r = MFMA index 0..3),
+//     C16 mode: chunk = (channel group g of 16, tap)        slot -> channel 16g + s
+//     C8  mode: chunk = tap pair (Cin == 8)                  slot -> tap 2c + (s>>3), channel s&7
+// One lane's 16-byte LDS read / 16-byte weight load therefore feeds four MFMAs.
+// ------------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float* in0;      // source 0, NHWC with c0 channels
+    const float* in1;      // source 1 (channel concat behind source 0) or nullptr
+    const f32x4* wpk;      // packed weights [chunk][mtile][lane] x 4 floats
+    const float* bias;     // [cout]
+    const float* res;      // residual NHWC [Ho,Wo,cout] added before the output activation, or nullptr
+    float* out;            // NHWC [Ho,Wo,cout]
+    int c0, c1;
+    int H, W;              // input spatial size
+    int Ho, Wo;            // output spatial size (== H, W for stride-1 conv)
+    int pbh, pbw;          // deconv: pad_before (rows, cols)
+    int cout;              // real output channels (store bound)
+    int mtiles;            // number of 16-channel output tiles in wpk
+    int groups;            // number of 16-channel input groups (C16 mode)
+    int relu_in;           // apply ReLU while staging the input (pre-activation tensors)
+    int relu_out;
+};
+
+constexpr int CONV_TH = 8;
+constexpr int CONV_TW = 32;
+constexpr int CONV_NT = 4;     // n-tiles (16 pixels each) per wave; 4 waves -> 256 pixels per block
+
+template <int KH, int KW, int MT, bool C8>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+    constexpr int TH = CONV_TH, TW = CONV_TW, NT = CONV_NT;
+    constexpr int LH = TH + KH - 1, LW = TW + KW - 1;
+    constexpr int CPP = C8 ? 8 : 16;                    // channels per pixel held in LDS
+    constexpr int PT = (KH - 1) / 2, PL = (KW - 1) / 2;  // TF SAME: pad_before = (k-1)/2
+    constexpr int TAPS = KH * KW;
+    __shared__ __attribute__((aligned(16))) float lds[LH * LW * CPP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, mt0 = blockIdx.z * MT;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int nbase[NT];   // LDS float index of (row, col + j) of each n-tile of this wave
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int id = wave * NT + n;
+        nbase[n] = ((id >> 1) * LW + (id & 1) * 16 + j) * CPP;
+    }
+
+    const int ngroups = C8 ? 1 : a.groups;
+    for (int g = 0; g < ngroups; ++g) {
+        if (g > 0) __syncthreads();
+        // ---- stage the halo tile of channel group g (zero outside the image = SAME padding) ----
+        constexpr int SUBS = CPP / 4;
+        for (int idx = tid; idx < LH * LW * SUBS; idx += 256) {
+            const int pix = idx / SUBS, sub = idx - pix * SUBS;
+            const int ly = pix / LW, lx = pix - ly * LW;
+            const int gy = y0 - PT + ly, gx = x0 - PL + lx;
+            const int c = g * 16 + sub * 4;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const size_t p = (size_t)gy * a.W + gx;
+                if (c < a.c0)
+                    v = *reinterpret_cast<const f32x4*>(a.in0 + p * a.c0 + c);
+                else if (c - a.c0 < a.c1)
+                    v = *reinterpret_cast<const f32x4*>(a.in1 + p * a.c1 + (c - a.c0));
+            }
+            if (a.relu_in) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            *reinterpret_cast<f32x4*>(lds + pix * CPP + sub * 4) = v;
+        }
+        __syncthreads();
+
+        if constexpr (!C8) {
+            const f32x4* wg = a.wpk + ((size_t)g * TAPS * a.mtiles + mt0) * 64 + lane;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int ky = tap / KW, kx = tap % KW;
+                f32x4 af[MT], bf[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) af[m] = wg[((size_t)tap * a.mtiles + m) * 64];
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    bf[n] = *reinterpret_cast<const f32x4*>(lds + nbase[n] + (ky * LW + kx) * 16 + kk * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][r], bf[n][r], acc[m][n], 0, 0, 0);
+            }
+        } else {
+            constexpr int NCH = (TAPS + 1) / 2;
+            const f32x4* wg = a.wpk + (size_t)mt0 * 64 + lane;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                int tap = 2 * c + (kk >> 1);
+                tap = tap < TAPS ? tap : TAPS - 1;       // padded slot: weights are zero, data must be finite
+                const int ky = tap / KW, kx = tap - ky * KW;
+                const int toff = (ky * LW + kx) * 8 + (kk & 1) * 4;
+                f32x4 af[MT], bf[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) af[m] = wg[((size_t)c * a.mtiles + m) * 64];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const f32x4*>(lds + nbase[n] + toff);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][r], bf[n][r], acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: D layout col = lane&15 -> pixel, row = 4*(lane>>4)+reg -> output channel ----
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int id = wave * NT + n;
+        const int y = y0 + (id >> 1), x = x0 + (id & 1) * 16 + j;
+        if (y >= a.Ho || x >= a.Wo) continue;
+        const size_t p = (size_t)y * a.Wo + x;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int c = (mt0 + m) * 16 + kk * 4;
+            if (c >= a.cout) continue;
+            f32x4 v = acc[m][n];
+            if (c + 3 < a.cout) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + c);
+                v += b;
+                if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + p * a.cout + c);
+                if (a.relu_out) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                *reinterpret_cast<f32x4*>(a.out + p * a.cout + c) = v;
+            } else {
+                for (int r = 0; r < 4 && c + r < a.cout; ++r) {
+                    float s = v[r] + a.bias[c + r];
+                    if (a.res) s += a.res[p * a.cout + c + r];
+                    if (a.relu_out) s = fmaxf(s, 0.f);
+                    a.out[p * a.cout + c + r] = s;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv2d_transpose 3x3, stride 2, SAME (layers.py:362).  With I = i + pad_before:
+//   I = 2*o + k  ->  k odd <=> I odd;  I even: k in {0 (o = I/2), 2 (o = I/2 - 1)};  I odd: k = 1.
+// The block works on a tile of q = floor(I/2) positions; every q yields the four outputs
+// (2q+ry-pbh, 2q+rx-pbw), ry,rx in {0,1} ("parity classes"), each with its own accumulator.
+// ------------------------------------------------------------------------------------------------
+constexpr int DC_TH = 8;
+constexpr int DC_TW = 16;
+
+template <int MT>
+__global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
+    constexpr int TH = DC_TH, TW = DC_TW, NT = 2;
+    constexpr int LH = TH + 1, LW = TW + 1;   // one halo row/column before the tile (o = q - 1)
+    __shared__ __attribute__((aligned(16))) float lds[LH * LW * 16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int qx0 = blockIdx.x * TW, qy0 = blockIdx.y * TH, mt0 = blockIdx.z * MT;
+
+    f32x4 acc[MT][NT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[m][n][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int nbase[NT];   // LDS float index of o = (q_row, q_col) itself (halo offset +1,+1)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) nbase[n] = ((wave * NT + n + 1) * LW + j + 1) * 16;
+
+    for (int g = 0; g < a.groups; ++g) {
+        if (g > 0) __syncthreads();
+        for (int idx = tid; idx < LH * LW * 4; idx += 256) {
+            const int pix = idx >> 2, sub = idx & 3;
+            const int ly = pix / LW, lx = pix - ly * LW;
+            const int gy = qy0 - 1 + ly, gx = qx0 - 1 + lx;
+            const int c = g * 16 + sub * 4;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.c0)
+                v = *reinterpret_cast<const f32x4*>(a.in0 + ((size_t)gy * a.W + gx) * a.c0 + c);
+            if (a.relu_in) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            *reinterpret_cast<f32x4*>(lds + pix * 16 + sub * 4) = v;
+        }
+        __syncthreads();
+
+        const f32x4* wg = a.wpk + ((size_t)g * 9 * a.mtiles + mt0) * 64 + lane;
+        f32x4 bf[NT][4];   // shifts: 0:(0,0) 1:(0,-1) 2:(-1,0) 3:(-1,-1)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            bf[n][0] = *reinterpret_cast<const f32x4*>(lds + nbase[n] + kk * 4);
+            bf[n][1] = *reinterpret_cast<const f32x4*>(lds + nbase[n] - 16 + kk * 4);
+            bf[n][2] = *reinterpret_cast<const f32x4*>(lds + nbase[n] - LW * 16 + kk * 4);
+            bf[n][3] = *reinterpret_cast<const f32x4*>(lds + nbase[n] - LW * 16 - 16 + kk * 4);
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int cls = (ky & 1) * 2 + (kx & 1);
+            const int sh = (ky == 2 ? 2 : 0) + (kx == 2 ? 1 : 0);
+            f32x4 af[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[m] = wg[((size_t)tap * a.mtiles + m) * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n][cls] =
+                            __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][r], bf[n][sh][r], acc[m][n][cls], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int qy = qy0 + wave * NT + n, qx = qx0 + j;
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {
+            const int y = 2 * qy + (cls >> 1) - a.pbh, x = 2 * qx + (cls & 1) - a.pbw;
+            if (y < 0 || y >= a.Ho || x < 0 || x >= a.Wo) continue;
+            const size_t p = (size_t)y * a.Wo + x;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int c = (mt0 + m) * 16 + kk * 4;
+                if (c >= a.cout) continue;
+                f32x4 v = acc[m][n][cls];
+                if (c + 3 < a.cout) {
+                    v += *reinterpret_cast<const f32x4*>(a.bias + c);
+                    if (a.relu_out) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(a.out + p * a.cout + c) = v;
+                } else {
+                    for (int r = 0; r < 4 && c + r < a.cout; ++r) {
+                        float s = v[r] + a.bias[c + r];
+                        if (a.relu_out) s = fmaxf(s, 0.f);
+                        a.out[p * a.cout + c + r] = s;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// First layer (Cin == 1): direct KxK convolution, one thread per pixel, all COUT channels.
+// Optional per-image standardisation (layers.py:672-711): stats = {mean, 1/max(std,1e-4)}.
+// ------------------------------------------------------------------------------------------------
+template <int K, int COUT>
+__global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ img, int H, int W,
+                                                      const float* __restrict__ w,     // [K*K][COUT]
+                                                      const float* __restrict__ bias,  // [COUT]
+                                                      float* __restrict__ out, int relu,
+                                                      const float* __restrict__ stats) {
+    __shared__ float sw[K * K * COUT + COUT];
+    for (int i = threadIdx.x; i < K * K * COUT; i += 256) sw[i] = w[i];
+    for (int i = threadIdx.x; i < COUT; i += 256) sw[K * K * COUT + i] = bias[i];
+    __syncthreads();
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    constexpr int PB = (K - 1) / 2;
+    float mean = 0.f, inv = 1.f;
+    if (stats) { mean = stats[0]; inv = stats[1]; }
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        const int gy = y + ky - PB;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const int gx = x + kx - PB;
+            float v = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = (img[(size_t)gy * W + gx] - mean) * inv;
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v, sw[(ky * K + kx) * COUT + c], acc[c]);
+        }
+    }
+    float* o = out + ((size_t)y * W + x) * COUT;
+#pragma unroll
+    for (int c = 0; c < COUT; c += 4) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = acc[c + r] + sw[K * K * COUT + c + r];
+            v[r] = relu ? fmaxf(s, 0.f) : s;
+        }
+        *reinterpret_cast<f32x4*>(o + c) = v;
+    }
+}
+
+// mean / E[x^2] partial sums for per-image standardisation (double accumulation on the host side)
+__global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ x, size_t n, double* __restrict__ sums) {
+    double s = 0.0, s2 = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double v = x[i];
+        s += v;
+        s2 += v * v;
+    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[0], sh[0][0]);
+        atomicAdd(&sums[1], sh[1][0]);
+    }
+}
+
+__global__ void moments_finish_kernel(const double* __restrict__ sums, size_t n, float* __restrict__ stats) {
+    const double mean = sums[0] / (double)n;
+    double var = sums[1] / (double)n - mean * mean;
+    if (var < 0) var = 0;
+    const float sd = fmaxf((float)sqrt(var), 1e-4f);
+    stats[0] = (float)mean;
+    stats[1] = 1.0f / sd;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2x2 / stride 2 / SAME pools (ceil mode, padding at the end only)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ in, int H, int W, int C,
+                                                       float* __restrict__ out, int Ho, int Wo) {
+    const int c4n = C >> 2;
+    const size_t total = (size_t)Ho * Wo * c4n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % c4n);
+        const size_t p = i / c4n;
+        const int x = (int)(p % Wo), y = (int)(p / Wo);
+        const int y1 = 2 * y + 1 < H ? 2 * y + 1 : 2 * y, x1 = 2 * x + 1 < W ? 2 * x + 1 : 2 * x;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(in + ((size_t)(2 * y) * W + 2 * x) * C + c4 * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(in + ((size_t)(2 * y) * W + x1) * C + c4 * 4);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(in + ((size_t)y1 * W + 2 * x) * C + c4 * 4);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(in + ((size_t)y1 * W + x1) * C + c4 * 4);
+        f32x4 m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = fmaxf(fmaxf(a[r], b[r]), fmaxf(c[r], d[r]));
+        *reinterpret_cast<f32x4*>(out + p * C + c4 * 4) = m;
+    }
+}
+
+// single-channel average pool; divisor = number of valid elements (tf.nn.avg_pool2d SAME)
+__global__ __launch_bounds__(256) void avgpool2_c1_kernel(const float* __restrict__ in, int H, int W,
+                                                          float* __restrict__ out, int Ho, int Wo) {
+    const size_t total = (size_t)Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % Wo), y = (int)(i / Wo);
+        float s = 0.f;
+        int n = 0;
+        for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 2; ++dx) {
+                const int yy = 2 * y + dy, xx = 2 * x + dx;
+                if (yy < H && xx < W) { s += in[(size_t)yy * W + xx]; ++n; }
+            }
+        out[i] = s / (float)n;
+    }
+}
+
+// channel sum [H,W,C] -> [H,W]  (the channel-summing half of upsample_simple, layers.py:716-720)
+__global__ __launch_bounds__(256) void chansum_kernel(const float* __restrict__ in, size_t npix, int C,
+                                                      float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += in[i * C + c];
+        out[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention combine + logits + class softmax + uint8/threshold (ARU_v1.py:141-160, helper:75-78)
+// ------------------------------------------------------------------------------------------------
+constexpr int MAX_SCALES = 5;
+struct CombineArgs {
+    const float* f0;                 // scale-0 feature map [H,W,FR]
+    const float* fsum[MAX_SCALES];   // [s>=1] channel sums of scale-s feature maps [fh,fw]
+    const float* att[MAX_SCALES];    // attention maps [ah,aw] (1 channel)
+    int fh[MAX_SCALES], fw[MAX_SCALES], fup[MAX_SCALES], fph[MAX_SCALES], fpw[MAX_SCALES];
+    int ah[MAX_SCALES], aw[MAX_SCALES], aup[MAX_SCALES], aph[MAX_SCALES], apw[MAX_SCALES];
+    int nsc;                         // number of scales (1 = no attention)
+    int H, W;
+    const float* wl;                 // [4*4][FR][NC]
+    const float* bl;                 // [NC]
+    float* out;                      // [H,W,NC] probabilities (or logits)
+    uint8_t* out_u8;                 // optional
+    uint8_t* out_mask;               // optional
+    double thr255;
+    int softmax;
+};
+
+template <int FR, int NC>
+__global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
+    constexpr int T = 16, L = T + 3;     // 4x4 SAME: pad 1 before, 2 after
+    __shared__ __attribute__((aligned(16))) float m[L * L * FR];
+    __shared__ float swl[16 * FR * NC + NC];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * T, y0 = blockIdx.y * T;
+    for (int i = tid; i < 16 * FR * NC; i += 256) swl[i] = a.wl[i];
+    if (tid < NC) swl[16 * FR * NC + tid] = a.bl[tid];
+
+    for (int pix = tid; pix < L * L; pix += 256) {
+        const int ly = pix / L, lx = pix - ly * L;
+        const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+        float v[FR];
+#pragma unroll
+        for (int c = 0; c < FR; ++c) v[c] = 0.f;
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+            const float* f = a.f0 + ((size_t)gy * a.W + gx) * FR;
+            if (a.nsc <= 1) {
+#pragma unroll
+                for (int c = 0; c < FR; ++c) v[c] = f[c];
+            } else {
+                float av[MAX_SCALES], mx = -INFINITY;
+                for (int s = 0; s < a.nsc; ++s) {
+                    const int ay = (gy + a.aph[s]) / a.aup[s], ax = (gx + a.apw[s]) / a.aup[s];
+                    av[s] = a.att[s][(size_t)ay * a.aw[s] + ax];
+                    mx = fmaxf(mx, av[s]);
+                }
+                float den = 0.f;
+                for (int s = 0; s < a.nsc; ++s) { av[s] = expf(av[s] - mx); den += av[s]; }
+                float add = 0.f;
+                for (int s = 1; s < a.nsc; ++s) {
+                    const int fy = (gy + a.fph[s]) / a.fup[s], fx = (gx + a.fpw[s]) / a.fup[s];
+                    add += a.fsum[s][(size_t)fy * a.fw[s] + fx] * (av[s] / den);
+                }
+                const float w0 = av[0] / den;
+#pragma unroll
+                for (int c = 0; c < FR; ++c) v[c] = f[c] * w0 + add;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < FR; ++c) m[pix * FR + c] = v[c];
+    }
+    __syncthreads();
+
+    const int tx = tid & 15, ty = tid >> 4;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= a.W || y >= a.H) return;
+    float lg[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) lg[k] = swl[16 * FR * NC + k];
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const float* mp = m + ((ty + ky) * L + tx + kx) * FR;
+            const float* wp = swl + (ky * 4 + kx) * FR * NC;
+#pragma unroll
+            for (int c = 0; c < FR; ++c)
+#pragma unroll
+                for (int k = 0; k < NC; ++k) lg[k] = fmaf(mp[c], wp[c * NC + k], lg[k]);
+        }
+    if (a.softmax) {
+        float mx = lg[0];
+#pragma unroll
+        for (int k = 1; k < NC; ++k) mx = fmaxf(mx, lg[k]);
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) { lg[k] = expf(lg[k] - mx); den += lg[k]; }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) lg[k] = lg[k] / den;
+    }
+    const size_t p = ((size_t)y * a.W + x) * NC;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        a.out[p + k] = lg[k];
+        if (a.out_u8 || a.out_mask) {
+            const uint8_t u = (uint8_t)(lg[k] * 255.0f);          // np.array(p*255, dtype=uint8)
+            if (a.out_u8) a.out_u8[p + k] = u;
+            if (a.out_mask) a.out_mask[p + k] = ((double)u > a.thr255) ? 255 : 0;
+        }
+    }
+}
+
+}  // namespace asep

@@ -1,0 +1,71 @@
+// Shared host-side helpers of libasep_hip.so (error reporting, weight-blob parsing, device buffers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/asep_hip.h"
+
+namespace asep {
+
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define ASEP_HIP_CHECK(expr)                                                                    \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            asep::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
+                            __LINE__);                                                          \
+            return ASEP_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+#define ASEP_HIP_CHECK_THROW(expr)                                                              \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            asep::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
+                            __LINE__);                                                          \
+            throw asep::HipError();                                                             \
+        }                                                                                       \
+    } while (0)
+
+struct HipError {};
+struct ArgError {};
+
+struct HostTensor {
+    std::vector<int> dims;
+    std::vector<float> data;       // copied out of the caller's blob (payloads may be unaligned)
+    size_t count() const {
+        size_t n = 1;
+        for (int d : dims) n *= (size_t)d;
+        return n;
+    }
+};
+
+// Parses the "ASEPW001" container (weights.py).  Returns false (and sets the error) on malformed input.
+bool parse_blob(const void* blob, size_t nbytes, std::map<std::string, HostTensor>& out);
+
+// Buffers requested in a deterministic order by a forward pass; re-used across calls.
+class BufferPool {
+public:
+    ~BufferPool() { release(); }
+    void begin() { next_ = 0; }
+    void* get(size_t bytes);   // throws HipError
+    void release();
+    size_t total_bytes() const;
+private:
+    struct Buf { void* p; size_t n; };
+    std::vector<Buf> bufs_;
+    size_t next_ = 0;
+};
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace asep

@@ -1,0 +1,120 @@
+// Runtime entry points and shared helpers of libasep_hip.so.
+#include "asep_common.h"
+
+namespace asep {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+bool parse_blob(const void* blob, size_t nbytes, std::map<std::string, HostTensor>& out) {
+    const uint8_t* p = (const uint8_t*)blob;
+    if (!p || nbytes < 12 || memcmp(p, "ASEPW001", 8) != 0) {
+        set_error("weight blob: bad magic (expected ASEPW001)");
+        return false;
+    }
+    uint32_t n;
+    memcpy(&n, p + 8, 4);
+    size_t off = 12;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (off + 2 > nbytes) { set_error("weight blob: truncated"); return false; }
+        uint16_t nl;
+        memcpy(&nl, p + off, 2);
+        off += 2;
+        if (off + nl + 1 > nbytes) { set_error("weight blob: truncated"); return false; }
+        std::string name((const char*)p + off, nl);
+        off += nl;
+        uint8_t nd = p[off];
+        off += 1;
+        HostTensor t;
+        if (off + 4u * nd > nbytes) { set_error("weight blob: truncated"); return false; }
+        for (int d = 0; d < nd; ++d) {
+            uint32_t v;
+            memcpy(&v, p + off, 4);
+            off += 4;
+            t.dims.push_back((int)v);
+        }
+        size_t cnt = t.count();
+        if (off + 4 * cnt > nbytes) { set_error("weight blob: truncated in %s", name.c_str()); return false; }
+        t.data.resize(cnt);
+        memcpy(t.data.data(), p + off, 4 * cnt);
+        off += 4 * cnt;
+        out[name] = std::move(t);
+    }
+    if (off != nbytes) { set_error("weight blob: %zu trailing bytes", nbytes - off); return false; }
+    return true;
+}
+
+void* BufferPool::get(size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (next_ < bufs_.size()) {
+        Buf& b = bufs_[next_];
+        if (b.n < bytes) {
+            if (b.p) (void)hipFree(b.p);
+            b.p = nullptr;
+            b.n = 0;
+            ASEP_HIP_CHECK_THROW(hipMalloc(&b.p, bytes));
+            b.n = bytes;
+        }
+        ++next_;
+        return b.p;
+    }
+    Buf b{nullptr, 0};
+    ASEP_HIP_CHECK_THROW(hipMalloc(&b.p, bytes));
+    b.n = bytes;
+    bufs_.push_back(b);
+    ++next_;
+    return b.p;
+}
+
+void BufferPool::release() {
+    for (auto& b : bufs_)
+        if (b.p) (void)hipFree(b.p);
+    bufs_.clear();
+    next_ = 0;
+}
+
+size_t BufferPool::total_bytes() const {
+    size_t t = 0;
+    for (auto& b : bufs_) t += b.n;
+    return t;
+}
+
+}  // namespace asep
+
+extern "C" {
+
+const char* asep_last_error(void) { return asep::get_error(); }
+const char* asep_version(void) { return "asep_hip 0.1 (gfx950)"; }
+
+int asep_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int asep_init(int device_id) {
+    int n = 0;
+    ASEP_HIP_CHECK(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) {
+        asep::set_error("asep_init: device %d out of range (%d devices)", device_id, n);
+        return ASEP_ERR_ARG;
+    }
+    ASEP_HIP_CHECK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    ASEP_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        asep::set_error("asep_init: device %d is %s; this library is built for gfx950 only", device_id,
+                        prop.gcnArchName);
+        return ASEP_ERR_UNSUPPORTED;
+    }
+    return ASEP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,165 @@
+"""Drop-in mirror of the reference's ARU-Net inference boundary
+
+    article_separation/image_segmentation/net_post_processing/net_post_processing_helper.py
+
+Same function names, argument meaning and return types; the TensorFlow session underneath is
+replaced by the gfx950 engine in ``csrc/libasep_hip.so`` (C ABI: ``include/asep_hip.h``).
+
+    load_graph(path)                      helper:36-53   -> AruGraph (weights + config + device handle)
+    get_net_output(image, graph, gpu)     helper:56-72   -> float32 [H, W, n_classes]
+    apply_threshold(net_output, thr)      helper:75-78
+    get_scaling_factor(...)               python_util/image_processing/image_stats.py:10-20
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from .config import AruConfig
+from .weights import load_weights, pack_blob
+
+
+class AruGraph:
+    """What ``load_graph`` returns in place of a ``tf.Graph``: named weights + hyper-parameters.
+    Device handles are created lazily per GPU (one model instance per (process, device))."""
+
+    def __init__(self, tensors, cfg: AruConfig, path: str = None):
+        self.tensors = tensors
+        self.cfg = cfg
+        self.path = path
+        self._blob = None
+        self._handles = {}
+
+    # -- tensor-name contract of the frozen graph (helper:69-70) ------------------------------
+    input_name = "inImg:0"
+    output_name = "output:0"
+
+    def blob(self) -> bytes:
+        if self._blob is None:
+            self._blob = pack_blob(self.tensors)
+        return self._blob
+
+    def handle(self, device_id: int = 0):
+        if device_id not in self._handles:
+            lib = _lib.init_device(device_id)
+            c = self.cfg
+            cfg = _lib.AruCfg(c.channels, c.n_classes, c.feat_root, c.scale_space_num, c.res_depth,
+                              c.num_scales_att, int(c.use_attention), int(c.mvn), int(c.apply_softmax), 0)
+            blob = self.blob()
+            h = lib.asep_aru_load(blob, len(blob), C.byref(cfg))
+            if not h:
+                raise _lib.AsepError("asep_aru_load failed: " + _lib.last_error())
+            self._handles[device_id] = h
+        return self._handles[device_id]
+
+    def close(self):
+        if self._handles:
+            lib = _lib.load_library()
+            for h in self._handles.values():
+                lib.asep_aru_free(h)
+            self._handles = {}
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def flops(self, H: int, W: int) -> float:
+        return _lib.load_library().asep_aru_flops(self.handle(_device_of(None)), H, W)
+
+
+def load_graph(path_to_pb) -> AruGraph:
+    """helper:36-53.  Accepts the engine's weight container (``*.asepw`` + ``.json`` side-car written
+    by ``weights.save_weights``).  A TF1 frozen ``.pb`` needs the GraphDef constant importer
+    (SURVEY.md row f1), which is not part of this round."""
+    if isinstance(path_to_pb, AruGraph):
+        return path_to_pb
+    if not os.path.isfile(path_to_pb):
+        raise IOError(f"No such model file: {path_to_pb}")
+    if str(path_to_pb).endswith(".pb"):
+        raise IOError(f"{path_to_pb}: importing TensorFlow frozen graphs is not implemented yet; "
+                      f"convert the weights to an .asepw container")
+    tensors, meta = load_weights(path_to_pb)
+    cfg = AruConfig(**(meta or {}).get("aru_cfg", {}))
+    return AruGraph(tensors, cfg, path_to_pb)
+
+
+def _device_of(gpu_device) -> int:
+    """Reference semantics (helper:58-66): a string like "0" selects the visible device list; ''/None
+    meant "CPU only" for TensorFlow.  This engine has no CPU path, so ''/None map to device 0."""
+    if gpu_device in (None, ""):
+        return 0
+    return int(str(gpu_device).split(",")[0])
+
+
+def get_net_output(image, pb_graph: AruGraph, gpu_device="0"):
+    """helper:56-72: image [H,W] (or [1,H,W,1]) -> net output [H,W,n_classes] float32."""
+    out, _, _ = get_net_output_fused(image, pb_graph, gpu_device, want_u8=False, threshold=None)
+    return out
+
+
+def get_net_output_fused(image, pb_graph: AruGraph, gpu_device="0", want_u8=True, threshold=0.05):
+    """One engine call that also returns the two direct consumers of the probability map:
+    ``uint8(prob*255)`` (separator_net_post_processor.py:147) and ``apply_threshold`` of it
+    (helper:75-78), computed in the net's epilogue on the device."""
+    image = np.asarray(image)
+    if image.ndim == 4:
+        if image.shape[0] != 1:
+            raise ValueError("batch size must be 1 (as in the reference)")
+        image = image[0]
+    if image.ndim == 3:
+        if image.shape[2] != pb_graph.cfg.channels:
+            raise ValueError(f"expected {pb_graph.cfg.channels} channel(s), got {image.shape[2]}")
+        image = image[:, :, 0] if pb_graph.cfg.channels == 1 else image
+    if image.ndim != 2:
+        raise ValueError(f"unsupported image shape {image.shape}")
+    H, W = image.shape
+    img = np.ascontiguousarray(image, dtype=np.float32)      # the feed casts float64 -> float32
+    ncls = pb_graph.cfg.n_classes
+    out = np.empty((H, W, ncls), dtype=np.float32)
+    u8 = np.empty((H, W, ncls), dtype=np.uint8) if want_u8 else None
+    mask = np.empty((H, W, ncls), dtype=np.uint8) if (want_u8 and threshold is not None) else None
+    dev = _device_of(gpu_device)
+    lib = _lib.init_device(dev)
+    rc = lib.asep_aru_forward(pb_graph.handle(dev), img.ctypes.data, H, W, out.ctypes.data,
+                              u8.ctypes.data if u8 is not None else None,
+                              mask.ctypes.data if mask is not None else None,
+                              float(threshold) if threshold is not None else 0.0)
+    _lib.check(rc, "asep_aru_forward")
+    return out, u8, mask
+
+
+def get_endpoint(pb_graph: AruGraph, name: str, gpu_device="0"):
+    """Named intermediate tensor of the last forward (ARU_v1.py:11-29 end-point names), NHWC."""
+    dev = _device_of(gpu_device)
+    lib = _lib.init_device(dev)
+    dims = (C.c_int32 * 3)()
+    n = _lib.check(lib.asep_aru_get_endpoint(pb_graph.handle(dev), name.encode(), None, 0, dims),
+                   "asep_aru_get_endpoint")
+    out = np.empty((dims[0], dims[1], dims[2]), dtype=np.float32)
+    _lib.check(lib.asep_aru_get_endpoint(pb_graph.handle(dev), name.encode(), out.ctypes.data, n, dims),
+               "asep_aru_get_endpoint")
+    return out
+
+
+def apply_threshold(net_output, threshold):
+    """helper:75-78."""
+    if net_output.dtype == np.uint8:
+        threshold *= 255
+    return np.array((net_output > threshold) * 255, dtype=np.uint8)
+
+
+def get_scaling_factor(image_height, image_width, scaling_factor, fixed_height=None, fixed_width=None):
+    """python_util/image_processing/image_stats.py:10-20."""
+    if fixed_height is not None and scaling_factor is not None and 0.1 < scaling_factor:
+        return scaling_factor * fixed_height / image_height
+    if fixed_width is not None and scaling_factor is not None and 0.1 < scaling_factor:
+        return scaling_factor * fixed_width / image_width
+    if fixed_height:
+        return fixed_height / image_height
+    if fixed_width:
+        return fixed_width / image_width
+    if scaling_factor:
+        return scaling_factor

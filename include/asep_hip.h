@@ -1,0 +1,132 @@
+/* asep_hip.h -- C ABI of libasep_hip.so: the MI355X (gfx950) replacement for the two
+ * TensorFlow session calls on the article-separation hot path.
+ *
+ * The reference has no FFI of its own; its seam is two Python call sites that hand numpy arrays
+ * to tf.Session.run.  Each entry point below names the reference call it replaces:
+ *
+ *   ARU-Net   article_separation/image_segmentation/net_post_processing/net_post_processing_helper.py
+ *             :36-53  load_graph(path_to_pb)                    -> asep_aru_load
+ *             :56-72  get_net_output(image, pb_graph, gpu)      -> asep_aru_forward[_dev]
+ *             :75-78  apply_threshold + separator_net_post_processor.py:147 (uint8 truncation)
+ *                                                               -> fused u8 outputs of asep_aru_forward
+ *   GNN       article_separation/gnn/io.py:12-25 load_graph     -> asep_gnn_load
+ *             article_separation/gnn/run_gnn_clustering.py:259-269 sess.run(
+ *                 'output_belong_to_same_instance:0', feed_dict) -> asep_gnn_forward[_dev]
+ *             article_separation/gnn/model/graph_util/misc.py:7-151
+ *                 check_and_correct_interacting_nodes           -> asep_gnn_correct_edges
+ *
+ * Conventions: plain pointers and sizes; caller-owned buffers; 0 = success, negative = error
+ * (text via asep_last_error()); no exceptions cross the ABI; one handle per (process, device);
+ * a handle is re-entrant but must not be used concurrently from two threads.
+ * Pointers named d_* are device (HBM) pointers; all others are host pointers.
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ */
+#ifndef ASEP_HIP_H
+#define ASEP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASEP_OK 0
+#define ASEP_ERR_ARG -1
+#define ASEP_ERR_HIP -2
+#define ASEP_ERR_WEIGHTS -3
+#define ASEP_ERR_UNSUPPORTED -4
+
+/* ---- runtime ------------------------------------------------------------------------------- */
+int asep_device_count(void);
+int asep_init(int device_id);                 /* hipSetDevice + arch check (gfx950) */
+const char* asep_last_error(void);
+const char* asep_version(void);
+
+/* ---- ARU-Net (ARU_v1.py:35-43 hyper-parameters) ---------------------------------------------- */
+typedef struct asep_aru_cfg {
+    int32_t channels;          /* image channels, 1 */
+    int32_t n_classes;
+    int32_t feat_root;         /* 8 */
+    int32_t scale_space_num;   /* 5 */
+    int32_t res_depth;         /* 3 */
+    int32_t num_scales_att;    /* 3; 0/1 with use_attention=0 */
+    int32_t use_attention;     /* graph contains 'ARU' */
+    int32_t mvn;               /* per-image standardisation of the input */
+    int32_t apply_softmax;     /* export-time class softmax */
+    int32_t compute_dtype;     /* 0 = fp32 (f32 MFMA), 1 = bf16 MFMA with fp32 accumulation */
+} asep_aru_cfg;
+
+typedef struct asep_aru asep_aru;
+
+/* weight_blob: "ASEPW001" container (see citlab-article-separation-new_amd/weights.py) holding
+ * the tensors of ARU_v1.py under the reference's variable-scope names. */
+asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_cfg* cfg);
+void asep_aru_free(asep_aru* m);
+
+/* Host-buffer call == get_net_output(): img_hw is H*W*channels floats (row major, values as fed to
+ * 'inImg:0'); out_hwc receives H*W*n_classes floats ('output:0'[0]).  The optional u8 outputs are
+ * the two consumers that directly follow the net in the reference:
+ *   out_u8   = uint8(prob*255)               (truncation, separator_net_post_processor.py:147)
+ *   out_mask = (out_u8 > threshold*255)*255  (net_post_processing_helper.py:75-78)
+ * Pass NULL to skip either. */
+int asep_aru_forward(asep_aru* m, const float* img_hw, int H, int W,
+                     float* out_hwc, uint8_t* out_u8, uint8_t* out_mask, float threshold);
+
+/* Device-resident variant (input and outputs already in HBM); asynchronous on `stream`. */
+int asep_aru_forward_dev(asep_aru* m, const float* d_img, int H, int W,
+                         float* d_out, uint8_t* d_out_u8, uint8_t* d_out_mask, float threshold,
+                         void* stream);
+
+/* Named intermediate tensors of the last forward (tests / GNN visual branch): copies the NHWC fp32
+ * tensor `name` (e.g. "scale_0_unet_up_0_conv", ARU_v1.py:11-29 end-point names) to host.
+ * Returns the number of floats written, or a negative error; dims receives {H, W, C}. */
+long asep_aru_get_endpoint(asep_aru* m, const char* name, float* out, size_t max_floats, int32_t dims[3]);
+
+/* Algorithmic FLOPs (2*MAC of conv/deconv layers) of one forward at H x W. */
+double asep_aru_flops(const asep_aru* m, int H, int W);
+
+/* ---- GNN relation predictor ------------------------------------------------------------------ */
+typedef struct asep_gnn_cfg {
+    int32_t node_feature_dim;      /* u (after masking), e.g. 7 */
+    int32_t edge_feature_dim;      /* e, e.g. 2 */
+    int32_t num_transition_steps;  /* 3 */
+    int32_t hidden_dim;            /* 32 */
+    int32_t interaction_dim;       /* 32 */
+    int32_t interaction_hidden;    /* one hidden layer of this width (32) */
+    int32_t cls_hidden1;           /* 64 */
+    int32_t cls_hidden2;           /* 32 */
+    int32_t num_classes;           /* 2 */
+    int32_t undirected_graph;      /* 1 */
+} asep_gnn_cfg;
+
+typedef struct asep_gnn asep_gnn;
+
+asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_cfg* cfg);
+void asep_gnn_free(asep_gnn* g);
+
+/* misc.py:7-151 on the device: symmetrise (if undirected), de-duplicate, drop self loops, sort by
+ * from*N+to, first-occurrence edge features.  out_edges must hold 2*E*2 ints, out_feat 2*E*e
+ * floats (may be NULL).  Returns E' (>= 0) or a negative error. */
+int asep_gnn_correct_edges(asep_gnn* g, int N, int E, const int32_t* edges, const float* edge_feat,
+                           int32_t* out_edges, float* out_feat);
+
+/* One page: == sess.run('output_belong_to_same_instance:0', feed_dict) at batch size 1.
+ *   edges [E,2] (from,to), node_feat [N,u], edge_feat [E,e], relations [R,2] -> probs_out [R,num_classes].
+ * relations == NULL means "all N*N ordered pairs, row major" (input_dataset.py:444-457). */
+int asep_gnn_forward(asep_gnn* g, int N, int E, const int32_t* edges, const float* node_feat,
+                     const float* edge_feat, int R, const int32_t* relations, float* probs_out);
+
+int asep_gnn_forward_dev(asep_gnn* g, int N, int E, const int32_t* d_edges, const float* d_node_feat,
+                         const float* d_edge_feat, int R, const int32_t* d_relations, float* d_probs_out,
+                         void* stream);
+
+/* Final hidden node states h [N, hidden_dim] of the last forward (tests). */
+int asep_gnn_get_hidden(asep_gnn* g, float* out, size_t max_floats);
+
+double asep_gnn_flops(const asep_gnn* g, int N, int E_corrected, int R);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASEP_HIP_H */
