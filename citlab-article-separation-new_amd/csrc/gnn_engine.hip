@@ -1,14 +1,295 @@
-// GNN relation predictor engine -- entry points (kernels follow in the next milestone).
+// GNN relation-predictor engine (host side).  Entry points: include/asep_hip.h.
+// Schedule of one page (batch size 1, graph_gnn.py:46-167 + graph_relation.py:194-203):
+//   edge correction -> T x (message, LSTM update) -> per-node first classifier layer -> per-pair classifier.
+#include <algorithm>
+#include <memory>
+
 #include "asep_common.h"
 #include "gnn_kernels.h"
+
 using namespace asep;
-struct asep_gnn { asep_gnn_cfg cfg; };
-extern "C" {
-asep_gnn* asep_gnn_load(const void*, size_t, const asep_gnn_cfg*) { set_error("GNN engine not built yet"); return nullptr; }
-void asep_gnn_free(asep_gnn* g) { delete g; }
-int asep_gnn_correct_edges(asep_gnn*, int, int, const int32_t*, const float*, int32_t*, float*) { set_error("GNN engine not built yet"); return ASEP_ERR_UNSUPPORTED; }
-int asep_gnn_forward(asep_gnn*, int, int, const int32_t*, const float*, const float*, int, const int32_t*, float*) { set_error("GNN engine not built yet"); return ASEP_ERR_UNSUPPORTED; }
-int asep_gnn_forward_dev(asep_gnn*, int, int, const int32_t*, const float*, const float*, int, const int32_t*, float*, void*) { set_error("GNN engine not built yet"); return ASEP_ERR_UNSUPPORTED; }
-int asep_gnn_get_hidden(asep_gnn*, float*, size_t) { return ASEP_ERR_UNSUPPORTED; }
-double asep_gnn_flops(const asep_gnn*, int, int, int) { return 0.0; }
+
+struct asep_gnn {
+    asep_gnn_cfg cfg{};
+    int K = 0, V = 0;                 // message-MLP input width, LSTM input width
+    float *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
+    float* Wg[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* bg[4] = {nullptr, nullptr, nullptr, nullptr};
+    float *C1 = nullptr, *cb1 = nullptr, *C2 = nullptr, *cb2 = nullptr, *C3 = nullptr, *cb3 = nullptr;
+    std::vector<void*> owned;
+    BufferPool pool;
+    // state of the last forward
+    int N = 0, Ecorr = -1;
+    float* d_h = nullptr;
+    int* d_rowptr = nullptr;
+    hipStream_t stream = nullptr;
+    ~asep_gnn() {
+        for (void* p : owned)
+            if (p) (void)hipFree(p);
+    }
+};
+
+namespace {
+
+const char* MSG = "GraphLSTM1/message_fn_default/head_0/calculation_interaction_features/concat_u_and_h/interaction_features";
+const char* UPD = "GraphLSTM1/update_function_LSTM";
+const char* CLS = "Classification/logits";
+
+int upload_named(asep_gnn* g, const std::map<std::string, HostTensor>& blob, const std::string& name,
+                 std::vector<int> dims, float** d) {
+    auto it = blob.find(name);
+    if (it == blob.end()) { set_error("weights: missing tensor %s", name.c_str()); return ASEP_ERR_WEIGHTS; }
+    if (it->second.dims != dims) {
+        std::string want, got;
+        for (int v : dims) want += std::to_string(v) + ",";
+        for (int v : it->second.dims) got += std::to_string(v) + ",";
+        set_error("weights: %s has shape [%s] expected [%s]", name.c_str(), got.c_str(), want.c_str());
+        return ASEP_ERR_WEIGHTS;
+    }
+    const auto& h = it->second.data;
+    ASEP_HIP_CHECK(hipMalloc((void**)d, std::max<size_t>(h.size(), 4) * sizeof(float)));
+    g->owned.push_back(*d);
+    ASEP_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return ASEP_OK;
 }
+
+struct EdgeBufs {
+    int* table; int* rowcnt; int* colcnt; int* rowptr; int* colptr;
+    int32_t* sorted; int* sfirst; int* tsrc; int* tfirst;
+};
+
+// misc.py:7-151 on the device; fills the CSR-by-target used by the message kernel
+int correct_edges_dev(asep_gnn* g, int N, int E, const int32_t* d_edges, EdgeBufs& eb, hipStream_t s) {
+    const int und = g->cfg.undirected_graph ? 1 : 0;
+    const size_t maxE = (size_t)(und ? 2 : 1) * std::max(E, 1);
+    eb.table = (int*)g->pool.get((size_t)N * N * sizeof(int));
+    eb.rowcnt = (int*)g->pool.get((size_t)N * sizeof(int));
+    eb.colcnt = (int*)g->pool.get((size_t)N * sizeof(int));
+    eb.rowptr = (int*)g->pool.get((size_t)(N + 1) * sizeof(int));
+    eb.colptr = (int*)g->pool.get((size_t)(N + 1) * sizeof(int));
+    eb.sorted = (int32_t*)g->pool.get(maxE * 2 * sizeof(int32_t));
+    eb.sfirst = (int*)g->pool.get(maxE * sizeof(int));
+    eb.tsrc = (int*)g->pool.get(maxE * sizeof(int));
+    eb.tfirst = (int*)g->pool.get(maxE * sizeof(int));
+    ASEP_HIP_CHECK(hipMemsetAsync(eb.table, 0x7f, (size_t)N * N * sizeof(int), s));
+    if (E > 0) {
+        const int total = und ? 2 * E : E;
+        hipLaunchKernelGGL(edge_table_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, s, d_edges, E, N, und,
+                           eb.table);
+    }
+    hipLaunchKernelGGL(edge_count_kernel, dim3(N), dim3(64), 0, s, eb.table, N, eb.rowcnt, eb.colcnt);
+    hipLaunchKernelGGL(edge_scan_kernel, dim3(1), dim3(1024), 0, s, eb.rowcnt, eb.colcnt, N, eb.rowptr, eb.colptr);
+    hipLaunchKernelGGL(edge_emit_kernel, dim3(N), dim3(64), 0, s, eb.table, N, eb.rowptr, eb.colptr, eb.sorted,
+                       eb.sfirst, eb.tsrc, eb.tfirst);
+    ASEP_HIP_CHECK(hipGetLastError());
+    g->d_rowptr = eb.rowptr;
+    return ASEP_OK;
+}
+
+int forward_impl(asep_gnn* g, int N, int E, const int32_t* d_edges, const float* d_u, const float* d_ef, int R,
+                 const int32_t* d_rel, float* d_out, hipStream_t s) {
+    const asep_gnn_cfg& c = g->cfg;
+    if (N < 1 || E < 0 || R < 0) { set_error("asep_gnn_forward: bad sizes N=%d E=%d R=%d", N, E, R); return ASEP_ERR_ARG; }
+    if ((size_t)N * N > (size_t)1 << 30) { set_error("asep_gnn_forward: N=%d too large for the dense edge table", N); return ASEP_ERR_UNSUPPORTED; }
+    g->stream = s;
+    g->N = N;
+    g->Ecorr = -1;
+    try {
+        g->pool.begin();
+        EdgeBufs eb{};
+        int rc = correct_edges_dev(g, N, E, d_edges, eb, s);
+        if (rc) return rc;
+        const size_t nh = (size_t)N * GNN_H;
+        float* h[2] = {(float*)g->pool.get(nh * 4), (float*)g->pool.get(nh * 4)};
+        float* cs[2] = {(float*)g->pool.get(nh * 4), (float*)g->pool.get(nh * 4)};
+        float* x = (float*)g->pool.get(nh * 4);
+        float* Pt = (float*)g->pool.get((size_t)N * c.cls_hidden1 * 4);
+        float* Qt = (float*)g->pool.get((size_t)N * c.cls_hidden1 * 4);
+        ASEP_HIP_CHECK(hipMemsetAsync(h[0], 0, nh * 4, s));
+        ASEP_HIP_CHECK(hipMemsetAsync(cs[0], 0, nh * 4, s));
+        int cur = 0;
+        for (int t = 0; t < c.num_transition_steps; ++t) {
+            MsgArgs ma{};
+            ma.u = d_u; ma.h = h[cur]; ma.ef = d_ef; ma.tptr = eb.colptr; ma.tsrc = eb.tsrc; ma.tfirst = eb.tfirst;
+            ma.W1 = g->W1; ma.b1 = g->b1; ma.W2 = g->W2; ma.b2 = g->b2; ma.x = x;
+            ma.N = N; ma.U = c.node_feature_dim; ma.Ed = c.edge_feature_dim; ma.E = std::max(E, 1); ma.K = g->K;
+            const size_t lds = ((size_t)g->K * 32 + 32 * 32 + 8 * (size_t)g->K + 8 * 32) * sizeof(float);
+            hipLaunchKernelGGL(gnn_message_kernel, dim3(N), dim3(256), lds, s, ma);
+            LstmArgs la{};
+            la.x = x; la.h_in = h[cur]; la.c_in = cs[cur]; la.u = d_u;
+            for (int q = 0; q < 4; ++q) { la.Wg[q] = g->Wg[q]; la.bg[q] = g->bg[q]; }
+            la.h_out = h[cur ^ 1]; la.c_out = cs[cur ^ 1]; la.N = N; la.U = c.node_feature_dim;
+            hipLaunchKernelGGL(gnn_lstm_kernel, dim3(cdiv(N, 8)), dim3(256), 0, s, la);
+            cur ^= 1;
+        }
+        g->d_h = h[cur];
+        if (R > 0) {
+            hipLaunchKernelGGL(gnn_pair_pre_kernel, dim3(std::min(cdiv(N * c.cls_hidden1, 256), 1024)), dim3(256), 0, s,
+                               h[cur], N, g->C1, c.cls_hidden1, Pt, Qt);
+            PairArgs pa{};
+            pa.Pt = Pt; pa.Qt = Qt; pa.b1 = g->cb1; pa.W2 = g->C2; pa.b2 = g->cb2; pa.W3 = g->C3; pa.b3 = g->cb3;
+            pa.rel = d_rel; pa.out = d_out; pa.N = N; pa.R = R;
+            dim3 grid(cdiv(R, 256));
+            if (c.cls_hidden1 == 64 && c.cls_hidden2 == 32 && c.num_classes == 2)
+                hipLaunchKernelGGL((gnn_pair_cls_kernel<64, 32, 2>), grid, dim3(256), 0, s, pa);
+            else { set_error("classifier %d,%d -> %d not instantiated", c.cls_hidden1, c.cls_hidden2, c.num_classes); return ASEP_ERR_UNSUPPORTED; }
+        }
+        ASEP_HIP_CHECK(hipGetLastError());
+    } catch (const HipError&) {
+        return ASEP_ERR_HIP;
+    }
+    return ASEP_OK;
+}
+
+}  // namespace
+
+namespace {
+struct DevCopy {
+    std::vector<void*> ptrs;
+    ~DevCopy() { for (void* p : ptrs) if (p) (void)hipFree(p); }
+    template <typename T> int up(const T* h, size_t n, T** d) {
+        *d = nullptr;
+        if (n == 0 || !h) return ASEP_OK;
+        ASEP_HIP_CHECK(hipMalloc((void**)d, n * sizeof(T)));
+        ptrs.push_back(*d);
+        ASEP_HIP_CHECK(hipMemcpy(*d, h, n * sizeof(T), hipMemcpyHostToDevice));
+        return ASEP_OK;
+    }
+    template <typename T> int alloc(size_t n, T** d) {
+        ASEP_HIP_CHECK(hipMalloc((void**)d, std::max<size_t>(n, 1) * sizeof(T)));
+        ptrs.push_back(*d);
+        return ASEP_OK;
+    }
+};
+}  // namespace
+
+extern "C" {
+
+asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_cfg* cfg) {
+    if (!cfg || !weight_blob) { set_error("asep_gnn_load: null argument"); return nullptr; }
+    if (cfg->hidden_dim != GNN_H || cfg->interaction_dim != GNN_H || cfg->interaction_hidden != GNN_H) {
+        set_error("asep_gnn_load: hidden/interaction widths must be %d (got %d/%d/%d)", GNN_H, cfg->hidden_dim,
+                  cfg->interaction_dim, cfg->interaction_hidden);
+        return nullptr;
+    }
+    if (cfg->node_feature_dim < 1 || cfg->edge_feature_dim < 0 || cfg->num_transition_steps < 0) {
+        set_error("asep_gnn_load: bad cfg");
+        return nullptr;
+    }
+    std::map<std::string, HostTensor> blob;
+    if (!parse_blob(weight_blob, nbytes, blob)) return nullptr;
+    std::unique_ptr<asep_gnn> g(new asep_gnn());
+    g->cfg = *cfg;
+    const int U = cfg->node_feature_dim, Ed = cfg->edge_feature_dim;
+    g->K = 4 * U + Ed + 4 * GNN_H;
+    g->V = 2 * GNN_H + U;
+    if (((size_t)g->K * 40 + 32 * 32 + 8 * 32) * 4 > 150 * 1024) { set_error("asep_gnn_load: node feature width %d too large for LDS", U); return nullptr; }
+    const std::string m = MSG, u = UPD, c = CLS;
+    int rc = upload_named(g.get(), blob, m + "/fully_connected_layer_h1/weights", {g->K, GNN_H}, &g->W1);
+    if (!rc) rc = upload_named(g.get(), blob, m + "/fully_connected_layer_h1/bias", {GNN_H}, &g->b1);
+    if (!rc) rc = upload_named(g.get(), blob, m + "/fully_connected_logit_layer_out/weights", {GNN_H, GNN_H}, &g->W2);
+    if (!rc) rc = upload_named(g.get(), blob, m + "/fully_connected_logit_layer_out/bias", {GNN_H}, &g->b2);
+    const char* gates[4] = {"ingate", "outgate", "forgetgate", "cellinput"};
+    for (int q = 0; q < 4 && !rc; ++q) {
+        rc = upload_named(g.get(), blob, u + "/" + gates[q] + "_activation/dense/weights", {g->V, GNN_H}, &g->Wg[q]);
+        if (!rc) rc = upload_named(g.get(), blob, u + "/" + gates[q] + "_activation/dense/bias", {GNN_H}, &g->bg[q]);
+    }
+    if (!rc) rc = upload_named(g.get(), blob, c + "/fully_connected_layer_h1/weights", {2 * GNN_H, cfg->cls_hidden1}, &g->C1);
+    if (!rc) rc = upload_named(g.get(), blob, c + "/fully_connected_layer_h1/bias", {cfg->cls_hidden1}, &g->cb1);
+    if (!rc) rc = upload_named(g.get(), blob, c + "/fully_connected_layer_h2/weights", {cfg->cls_hidden1, cfg->cls_hidden2}, &g->C2);
+    if (!rc) rc = upload_named(g.get(), blob, c + "/fully_connected_layer_h2/bias", {cfg->cls_hidden2}, &g->cb2);
+    if (!rc) rc = upload_named(g.get(), blob, c + "/fully_connected_logit_layer_out/weights", {cfg->cls_hidden2, cfg->num_classes}, &g->C3);
+    if (!rc) rc = upload_named(g.get(), blob, c + "/fully_connected_logit_layer_out/bias", {cfg->num_classes}, &g->cb3);
+    if (rc) return nullptr;
+    // the message kernel needs up to ~50 KB of dynamic LDS
+    const size_t lds = ((size_t)g->K * 32 + 32 * 32 + 8 * (size_t)g->K + 8 * 32) * sizeof(float);
+    if (hipFuncSetAttribute((const void*)gnn_message_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        set_error("asep_gnn_load: cannot reserve %zu bytes of LDS", lds);
+        return nullptr;
+    }
+    return g.release();
+}
+
+void asep_gnn_free(asep_gnn* g) { delete g; }
+
+int asep_gnn_forward_dev(asep_gnn* g, int N, int E, const int32_t* d_edges, const float* d_node_feat,
+                         const float* d_edge_feat, int R, const int32_t* d_relations, float* d_probs_out, void* stream) {
+    if (!g || !d_node_feat || (E > 0 && !d_edges) || (R > 0 && !d_probs_out)) { set_error("asep_gnn_forward_dev: null argument"); return ASEP_ERR_ARG; }
+    if (g->cfg.edge_feature_dim > 0 && E > 0 && !d_edge_feat) { set_error("asep_gnn_forward_dev: edge features required"); return ASEP_ERR_ARG; }
+    return forward_impl(g, N, E, d_edges, d_node_feat, d_edge_feat, R, d_relations, d_probs_out, (hipStream_t)stream);
+}
+
+
+int asep_gnn_forward(asep_gnn* g, int N, int E, const int32_t* edges, const float* node_feat, const float* edge_feat,
+                     int R, const int32_t* relations, float* probs_out) {
+    if (!g || !node_feat || (E > 0 && !edges) || (R > 0 && !probs_out)) { set_error("asep_gnn_forward: null argument"); return ASEP_ERR_ARG; }
+    DevCopy dc;
+    int32_t *d_e = nullptr, *d_r = nullptr;
+    float *d_u = nullptr, *d_f = nullptr, *d_o = nullptr;
+    int rc;
+    if ((rc = dc.up(edges, (size_t)E * 2, &d_e))) return rc;
+    if ((rc = dc.up(node_feat, (size_t)N * g->cfg.node_feature_dim, &d_u))) return rc;
+    if ((rc = dc.up(edge_feat, (size_t)E * g->cfg.edge_feature_dim, &d_f))) return rc;
+    if ((rc = dc.up(relations, (size_t)R * 2, &d_r))) return rc;
+    if ((rc = dc.alloc((size_t)R * g->cfg.num_classes, &d_o))) return rc;
+    rc = asep_gnn_forward_dev(g, N, E, d_e, d_u, d_f, R, d_r, d_o, nullptr);
+    if (rc) return rc;
+    ASEP_HIP_CHECK(hipStreamSynchronize(nullptr));
+    if (R > 0) ASEP_HIP_CHECK(hipMemcpy(probs_out, d_o, (size_t)R * g->cfg.num_classes * sizeof(float), hipMemcpyDeviceToHost));
+    return ASEP_OK;
+}
+
+int asep_gnn_correct_edges(asep_gnn* g, int N, int E, const int32_t* edges, const float* edge_feat, int32_t* out_edges,
+                           float* out_feat) {
+    if (!g || N < 1 || E < 0 || (E > 0 && !edges) || !out_edges) { set_error("asep_gnn_correct_edges: bad argument"); return ASEP_ERR_ARG; }
+    if ((size_t)N * N > (size_t)1 << 30) { set_error("asep_gnn_correct_edges: N too large"); return ASEP_ERR_UNSUPPORTED; }
+    DevCopy dc;
+    int32_t* d_e = nullptr;
+    float* d_f = nullptr;
+    int rc;
+    if ((rc = dc.up(edges, (size_t)E * 2, &d_e))) return rc;
+    const int Ed = g->cfg.edge_feature_dim;
+    if (out_feat && Ed > 0 && (rc = dc.up(edge_feat, (size_t)E * Ed, &d_f))) return rc;
+    try {
+        g->pool.begin();
+        EdgeBufs eb{};
+        rc = correct_edges_dev(g, N, E, d_e, eb, nullptr);
+        if (rc) return rc;
+        int ecorr = 0;
+        ASEP_HIP_CHECK(hipStreamSynchronize(nullptr));
+        ASEP_HIP_CHECK(hipMemcpy(&ecorr, eb.rowptr + N, sizeof(int), hipMemcpyDeviceToHost));
+        if (ecorr > 0) {
+            ASEP_HIP_CHECK(hipMemcpy(out_edges, eb.sorted, (size_t)ecorr * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+            if (out_feat && Ed > 0 && d_f) {
+                float* d_of = (float*)g->pool.get((size_t)ecorr * Ed * sizeof(float));
+                hipLaunchKernelGGL(edge_feat_gather_kernel, dim3(std::min(cdiv(ecorr * Ed, 256), 1024)), dim3(256), 0, nullptr,
+                                   d_f, E, Ed, eb.sfirst, ecorr, d_of);
+                ASEP_HIP_CHECK(hipMemcpy(out_feat, d_of, (size_t)ecorr * Ed * sizeof(float), hipMemcpyDeviceToHost));
+            }
+        }
+        return ecorr;
+    } catch (const HipError&) {
+        return ASEP_ERR_HIP;
+    }
+}
+
+int asep_gnn_get_hidden(asep_gnn* g, float* out, size_t max_floats) {
+    if (!g || !out || !g->d_h) { set_error("asep_gnn_get_hidden: no forward has run"); return ASEP_ERR_ARG; }
+    const size_t n = (size_t)g->N * GNN_H;
+    if (max_floats < n) { set_error("asep_gnn_get_hidden: buffer too small"); return ASEP_ERR_ARG; }
+    ASEP_HIP_CHECK(hipStreamSynchronize(g->stream));
+    ASEP_HIP_CHECK(hipMemcpy(out, g->d_h, n * sizeof(float), hipMemcpyDeviceToHost));
+    return ASEP_OK;
+}
+
+double asep_gnn_flops(const asep_gnn* g, int N, int E_corrected, int R) {
+    if (!g) return 0.0;
+    const asep_gnn_cfg& c = g->cfg;
+    double mac = (double)c.num_transition_steps *
+                 ((double)E_corrected * ((double)g->K * GNN_H + GNN_H * GNN_H) + (double)N * 4.0 * g->V * GNN_H);
+    mac += (double)R * ((double)2 * GNN_H * c.cls_hidden1 + (double)c.cls_hidden1 * c.cls_hidden2 +
+                        (double)c.cls_hidden2 * c.num_classes);
+    return 2.0 * mac;
+}
+
+}  // extern "C"

@@ -1,2 +1,306 @@
-// GNN device kernels (placeholder until the message-passing kernels land).
+// GNN relation-predictor device kernels for gfx950.
+//
+// Reference semantics (file:line in /root/reference):
+//   gnn/model/graph_util/misc.py:7-151       edge-list correction      -> edge_table / edge_count / edge_scan / edge_emit
+//   gnn/model/graph/message_fn_chunk.py:148-418  edge MLP + 1/indeg + segmented sum -> gnn_message_kernel
+//   gnn/model/graph/update_fn_lstm.py:31-101     LSTM node update        -> gnn_lstm_kernel
+//   gnn/model/graph/graph_relation.py:229-287    pair classifier + softmax -> gnn_pair_pre / gnn_pair_cls
+//
+// The message-passing aggregation is a segmented reduction over edges grouped by TARGET node
+// (column 1 of the edge list): one workgroup per target, node state of the target kept in registers,
+// the edge-MLP weights staged once per workgroup in LDS.
 #pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace asep {
+
+constexpr int GNN_H = 32;            // hidden / interaction width handled by the lane mapping
+constexpr int EMPTY_SLOT = 0x7f7f7f7f;
+
+// table[from*N+to] = first index of that directed edge in the (symmetrised) list  (misc.py:47-88)
+__global__ __launch_bounds__(256) void edge_table_kernel(const int32_t* __restrict__ edges, int E, int N,
+                                                         int undirected, int* __restrict__ table) {
+    const int total = undirected ? 2 * E : E;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        int f, t;
+        if (idx < E) { f = edges[2 * idx]; t = edges[2 * idx + 1]; }
+        else { f = edges[2 * (idx - E) + 1]; t = edges[2 * (idx - E)]; }
+        if (f == t || f < 0 || t < 0 || f >= N || t >= N) continue;     // self loops are removed (misc.py:68-72)
+        atomicMin(&table[(size_t)f * N + t], idx);
+    }
+}
+
+// per-row (from) and per-column (to) counts of occupied table cells; one wave per row / column
+__global__ __launch_bounds__(64) void edge_count_kernel(const int* __restrict__ table, int N,
+                                                        int* __restrict__ rowcnt, int* __restrict__ colcnt) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    int rc = 0, cc = 0;
+    for (int k = lane; k < N; k += 64) {
+        rc += table[(size_t)r * N + k] != EMPTY_SLOT;
+        cc += table[(size_t)k * N + r] != EMPTY_SLOT;
+    }
+    for (int o = 32; o > 0; o >>= 1) { rc += __shfl_down(rc, o); cc += __shfl_down(cc, o); }
+    if (lane == 0) { rowcnt[r] = rc; colcnt[r] = cc; }
+}
+
+// exclusive scans of rowcnt / colcnt (N is a few hundred: one workgroup)
+__global__ __launch_bounds__(1024) void edge_scan_kernel(const int* __restrict__ rowcnt, const int* __restrict__ colcnt,
+                                                         int N, int* __restrict__ rowptr, int* __restrict__ colptr) {
+    __shared__ int sa[1024], sb[1024];
+    const int tid = threadIdx.x;
+    const int per = (N + 1023) / 1024;
+    int a = 0, b = 0;
+    for (int k = tid * per; k < min(N, (tid + 1) * per); ++k) { a += rowcnt[k]; b += colcnt[k]; }
+    sa[tid] = a; sb[tid] = b;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int va = tid >= o ? sa[tid - o] : 0, vb = tid >= o ? sb[tid - o] : 0;
+        __syncthreads();
+        sa[tid] += va; sb[tid] += vb;
+        __syncthreads();
+    }
+    int pa = sa[tid] - a, pb = sb[tid] - b;
+    for (int k = tid * per; k < min(N, (tid + 1) * per); ++k) {
+        rowptr[k] = pa; colptr[k] = pb;
+        pa += rowcnt[k]; pb += colcnt[k];
+    }
+    if (tid == 1023) { rowptr[N] = sa[1023]; colptr[N] = sb[1023]; }
+}
+
+// emit (a) the corrected edge list sorted by from*N+to with first-occurrence indices (misc.py:91-104)
+//      (b) the same edges grouped by target (CSR over column 1) for the aggregation
+__global__ __launch_bounds__(64) void edge_emit_kernel(const int* __restrict__ table, int N,
+                                                       const int* __restrict__ rowptr, const int* __restrict__ colptr,
+                                                       int32_t* __restrict__ sorted_edges, int* __restrict__ sorted_first,
+                                                       int* __restrict__ tsrc, int* __restrict__ tfirst) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    int wr = rowptr[r], wc = colptr[r];
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        const int k = k0 + lane;
+        const int vr = k < N ? table[(size_t)r * N + k] : EMPTY_SLOT;
+        const int vc = k < N ? table[(size_t)k * N + r] : EMPTY_SLOT;
+        const unsigned long long mr = __ballot(vr != EMPTY_SLOT), mc = __ballot(vc != EMPTY_SLOT);
+        const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+        if (vr != EMPTY_SLOT) {
+            const int p = wr + __popcll(mr & below);
+            sorted_edges[2 * p] = r; sorted_edges[2 * p + 1] = k; sorted_first[p] = vr;
+        }
+        if (vc != EMPTY_SLOT) {
+            const int p = wc + __popcll(mc & below);
+            tsrc[p] = k; tfirst[p] = vc;
+        }
+        wr += __popcll(mr); wc += __popcll(mc);
+    }
+}
+
+__global__ __launch_bounds__(256) void edge_feat_gather_kernel(const float* __restrict__ ef, int E, int Ed,
+                                                               const int* __restrict__ first, int n,
+                                                               float* __restrict__ out) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n * Ed; i += gridDim.x * 256) {
+        const int e = i / Ed, d = i - e * Ed;
+        const int src = first[e] % E;            // tiled x2 for the reversed half (misc.py:56)
+        out[i] = ef[(size_t)src * Ed + d];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// message function: one workgroup per target node j, eight half-waves process eight in-edges at a
+// time; lane o of a half-wave owns hidden unit / output unit o.
+// ------------------------------------------------------------------------------------------------
+struct MsgArgs {
+    const float* u;      // [N,U] node input features
+    const float* h;      // [N,32] hidden state
+    const float* ef;     // [E,Ed] original edge features (indexed by first-occurrence % E)
+    const int* tptr;     // [N+1] CSR over targets
+    const int* tsrc;     // [E'] source node of each in-edge
+    const int* tfirst;   // [E'] first-occurrence index -> edge feature row (% E)
+    const float* W1; const float* b1;   // [K,32], [32]
+    const float* W2; const float* b2;   // [32,32], [32]
+    float* x;            // [N,32] aggregated messages
+    int N, U, Ed, E, K;
+};
+
+__global__ __launch_bounds__(256) void gnn_message_kernel(const MsgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* W1s = sm;                       // K*32
+    float* W2s = W1s + a.K * 32;           // 32*32
+    float* zs = W2s + 32 * 32;             // 8*K
+    float* hs = zs + 8 * a.K;              // 8*32
+    const int tid = threadIdx.x, half = tid >> 5, o = tid & 31;
+    const int j = blockIdx.x;
+    for (int i = tid; i < a.K * 32; i += 256) W1s[i] = a.W1[i];
+    for (int i = tid; i < 32 * 32; i += 256) W2s[i] = a.W2[i];
+    const int beg = a.tptr[j], end = a.tptr[j + 1];
+    const int U = a.U, Ed = a.Ed, K = a.K;
+    const float bias1 = a.b1[o], bias2 = a.b2[o];
+    float xacc = 0.f;
+    float* z = zs + half * K;
+    const float* uj = a.u + (size_t)j * U;
+    const float* hj = a.h + (size_t)j * 32;
+    for (int base = beg; base < end; base += 8) {
+        const int e = base + half;
+        const bool valid = e < end;
+        __syncthreads();                   // previous round's z / hs fully consumed (also covers weight staging)
+        if (valid) {
+            const int i = a.tsrc[e];
+            const float* ui = a.u + (size_t)i * U;
+            const float* hi = a.h + (size_t)i * 32;
+            const float* efr = a.ef + (size_t)(a.tfirst[e] % a.E) * Ed;
+            // z = [u_i, u_j, u_j-u_i, (u_j-u_i)^2, ef, h_i, h_j, h_j-h_i, (h_j-h_i)^2]  (message_fn_chunk.py:313-350)
+            for (int k = o; k < U; k += 32) {
+                const float vi = ui[k], vj = uj[k], d = vj - vi;
+                z[k] = vi; z[U + k] = vj; z[2 * U + k] = d; z[3 * U + k] = d * d;
+            }
+            for (int k = o; k < Ed; k += 32) z[4 * U + k] = efr[k];
+            {
+                const float vi = hi[o], vj = hj[o], d = vj - vi;
+                float* zh = z + 4 * U + Ed;
+                zh[o] = vi; zh[32 + o] = vj; zh[64 + o] = d; zh[96 + o] = d * d;
+            }
+        }
+        __syncthreads();
+        float acc = bias1;
+        if (valid) {
+            for (int k = 0; k < K; ++k) acc = fmaf(z[k], W1s[k * 32 + o], acc);
+            hs[half * 32 + o] = fmaxf(acc, 0.f);
+        }
+        __syncthreads();
+        if (valid) {
+            float acc2 = bias2;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) acc2 = fmaf(hs[half * 32 + k], W2s[k * 32 + o], acc2);
+            xacc += tanhf(acc2);
+        }
+    }
+    __syncthreads();
+    hs[half * 32 + o] = xacc;
+    __syncthreads();
+    if (tid < 32) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += hs[q * 32 + tid];
+        const int deg = end - beg;
+        a.x[(size_t)j * 32 + tid] = deg > 0 ? s / (float)deg : 0.f;   // a_ij = 1/indeg(j) (message_fn_chunk.py:369-386)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LSTM update (update_fn_lstm.py:55-76): v = [x, h, u]; four dense gates; c = f*c + i*g; h = o*tanh(c)
+// one thread per (node, unit); gate order in Wg/bg: ingate, outgate, forgetgate, cellinput
+// ------------------------------------------------------------------------------------------------
+struct LstmArgs {
+    const float* x; const float* h_in; const float* c_in; const float* u;
+    const float* Wg[4]; const float* bg[4];     // [V,32], [32]
+    float* h_out; float* c_out;
+    int N, U;
+};
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void gnn_lstm_kernel(const LstmArgs a) {
+    const int tid = threadIdx.x, o = tid & 31;
+    const int node = blockIdx.x * 8 + (tid >> 5);
+    if (node >= a.N) return;
+    float g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] = a.bg[q][o];
+    const float* xr = a.x + (size_t)node * 32;
+    const float* hr = a.h_in + (size_t)node * 32;
+    const float* ur = a.u + (size_t)node * a.U;
+    for (int k = 0; k < 32; ++k) {
+        const float v = xr[k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = fmaf(v, a.Wg[q][k * 32 + o], g[q]);
+    }
+    for (int k = 0; k < 32; ++k) {
+        const float v = hr[k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = fmaf(v, a.Wg[q][(32 + k) * 32 + o], g[q]);
+    }
+    for (int k = 0; k < a.U; ++k) {
+        const float v = ur[k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = fmaf(v, a.Wg[q][(64 + k) * 32 + o], g[q]);
+    }
+    const float ig = sigmoidf_(g[0]), og = sigmoidf_(g[1]), fg = sigmoidf_(g[2]), cg = tanhf(g[3]);
+    const float c = fg * a.c_in[(size_t)node * 32 + o] + ig * cg;
+    a.c_out[(size_t)node * 32 + o] = c;
+    a.h_out[(size_t)node * 32 + o] = og * tanhf(c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair classifier (graph_relation.py:253-266): logits = MLP([h_a || h_b]).  The first layer is linear in
+// the concatenation, so it is evaluated once per node:  P[a] = h_a . W1[0:32],  Q[b] = h_b . W1[32:64]
+// (stored transposed [H1][N] for coalesced per-pair reads); per pair: relu(P+Q+b1) -> H2 -> classes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gnn_pair_pre_kernel(const float* __restrict__ h, int N, const float* __restrict__ W1,
+                                                           int H1, float* __restrict__ Pt, float* __restrict__ Qt) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N * H1; i += gridDim.x * 256) {
+        const int n = i % N, k = i / N;
+        float p = 0.f, q = 0.f;
+        for (int d = 0; d < 32; ++d) {
+            const float hv = h[(size_t)n * 32 + d];
+            p = fmaf(hv, W1[d * H1 + k], p);
+            q = fmaf(hv, W1[(32 + d) * H1 + k], q);
+        }
+        Pt[(size_t)k * N + n] = p;
+        Qt[(size_t)k * N + n] = q;
+    }
+}
+
+struct PairArgs {
+    const float* Pt; const float* Qt;   // [H1][N]
+    const float* b1;                    // [H1]
+    const float* W2; const float* b2;   // [H1,H2], [H2]
+    const float* W3; const float* b3;   // [H2,NC], [NC]
+    const int32_t* rel;                 // [R,2] or nullptr = all ordered pairs row major
+    float* out;                         // [R,NC]
+    int N, R;
+};
+
+template <int H1, int H2, int NC>
+__global__ __launch_bounds__(256) void gnn_pair_cls_kernel(const PairArgs a) {
+    __shared__ __attribute__((aligned(16))) float W2s[H1 * H2];
+    __shared__ float misc[H1 + H2 + H2 * NC + NC];
+    float* b1s = misc; float* b2s = b1s + H1; float* W3s = b2s + H2; float* b3s = W3s + H2 * NC;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < H1 * H2; i += 256) W2s[i] = a.W2[i];
+    for (int i = tid; i < H1; i += 256) b1s[i] = a.b1[i];
+    for (int i = tid; i < H2; i += 256) b2s[i] = a.b2[i];
+    for (int i = tid; i < H2 * NC; i += 256) W3s[i] = a.W3[i];
+    for (int i = tid; i < NC; i += 256) b3s[i] = a.b3[i];
+    __syncthreads();
+    const int r = blockIdx.x * 256 + tid;
+    if (r >= a.R) return;
+    int na, nb;
+    if (a.rel) { na = a.rel[2 * r]; nb = a.rel[2 * r + 1]; }
+    else { na = r / a.N; nb = r - na * a.N; }
+    float acc[H2];
+#pragma unroll
+    for (int k = 0; k < H2; ++k) acc[k] = b2s[k];
+    for (int d = 0; d < H1; ++d) {
+        const float v = fmaxf(a.Pt[(size_t)d * a.N + na] + a.Qt[(size_t)d * a.N + nb] + b1s[d], 0.f);
+#pragma unroll
+        for (int k = 0; k < H2; ++k) acc[k] = fmaf(v, W2s[d * H2 + k], acc[k]);
+    }
+    float lg[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) lg[c] = b3s[c];
+#pragma unroll
+    for (int k = 0; k < H2; ++k) {
+        const float v = fmaxf(acc[k], 0.f);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) lg[c] = fmaf(v, W3s[k * NC + c], lg[c]);
+    }
+    float mx = lg[0];
+#pragma unroll
+    for (int c = 1; c < NC; ++c) mx = fmaxf(mx, lg[c]);
+    float den = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { lg[c] = expf(lg[c] - mx); den += lg[c]; }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) a.out[(size_t)r * NC + c] = lg[c] / den;
+}
+
+}  // namespace asep

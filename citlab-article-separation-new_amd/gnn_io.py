@@ -1,0 +1,182 @@
+"""Drop-in mirror of the reference's GNN inference boundary
+
+    article_separation/gnn/io.py:12-25            load_graph(pb_path)
+    article_separation/gnn/run_gnn_clustering.py:216-269
+        sess = tf.Session(graph=graph); out = sess.run(output_node, feed_dict=...)
+
+``load_graph`` returns a :class:`GnnGraph`; ``GnnSession(graph).run(fetch, feed_dict)`` accepts the
+reference's feed keys *by tensor name* (``run_gnn_clustering.py:76-148``, names fixed at export time by
+``model_relation.py:258-337``) and returns ``[1, R, num_classes]`` float32 like the frozen graph did.
+The TensorFlow runtime underneath is replaced by ``csrc/libasep_hip.so`` (``include/asep_hip.h``).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from .config import GnnConfig
+from .weights import load_weights, pack_blob
+
+OUTPUT_NODE = "output_belong_to_same_instance:0"
+FEED_NAMES = (
+    "num_nodes:0", "num_interacting_nodes:0", "interacting_nodes:0", "node_features:0", "edge_features:0",
+    "image:0", "image_shape:0", "visual_regions_nodes:0", "num_points_visual_regions_nodes:0",
+    "visual_regions_edges:0", "num_points_visual_regions_edges:0",
+    "relations_to_consider_belong_to_same_instance:0",
+)
+
+
+class GnnGraph:
+    def __init__(self, tensors, cfg: GnnConfig, path: str = None):
+        self.tensors = tensors
+        self.cfg = cfg
+        self.path = path
+        self._blob = None
+        self._handles = {}
+
+    def blob(self) -> bytes:
+        if self._blob is None:
+            self._blob = pack_blob(self.tensors)
+        return self._blob
+
+    def handle(self, device_id: int = 0):
+        if device_id not in self._handles:
+            lib = _lib.init_device(device_id)
+            c = self.cfg
+            if len(c.interaction_hidden) != 1 or len(c.classifier_hidden) != 2:
+                raise _lib.AsepError("engine supports one interaction hidden layer and two classifier hidden layers")
+            if c.visual_dims:
+                raise _lib.AsepError("visual node features (image_input) are not supported by this build")
+            cfg = _lib.GnnCfg(c.node_feature_dim, c.edge_feature_dim, c.num_transition_steps, c.hidden_dim,
+                              c.interaction_dim, c.interaction_hidden[0], c.classifier_hidden[0],
+                              c.classifier_hidden[1], c.num_classes, int(c.undirected_graph))
+            blob = self.blob()
+            h = lib.asep_gnn_load(blob, len(blob), C.byref(cfg))
+            if not h:
+                raise _lib.AsepError("asep_gnn_load failed: " + _lib.last_error())
+            self._handles[device_id] = h
+        return self._handles[device_id]
+
+    def close(self):
+        if self._handles:
+            lib = _lib.load_library()
+            for h in self._handles.values():
+                lib.asep_gnn_free(h)
+            self._handles = {}
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def load_graph(pb_path) -> GnnGraph:
+    """gnn/io.py:12-25.  Accepts the engine's ``*.asepw`` container (+ ``.json`` side-car)."""
+    if isinstance(pb_path, GnnGraph):
+        return pb_path
+    if not os.path.isfile(pb_path):
+        raise IOError(f"No such model file: {pb_path}")
+    if str(pb_path).endswith(".pb"):
+        raise IOError(f"{pb_path}: importing TensorFlow frozen graphs is not implemented yet; "
+                      f"convert the weights to an .asepw container")
+    tensors, meta = load_weights(pb_path)
+    cfg = GnnConfig(**(meta or {}).get("gnn_cfg", {}))
+    return GnnGraph(tensors, cfg, pb_path)
+
+
+def _key(k):
+    """feed_dict keys may be tensor names ('num_nodes:0'), bare names, or objects with a .name."""
+    name = getattr(k, "name", k)
+    if not isinstance(name, str):
+        raise KeyError(f"unsupported feed key {k!r}")
+    return name if ":" in name else name + ":0"
+
+
+class GnnSession:
+    """Stands in for ``tf.Session(graph=graph)`` in ``run_gnn_clustering.py:221``."""
+
+    def __init__(self, graph: GnnGraph, gpu_devices="0"):
+        self.graph = graph
+        self.device = 0 if gpu_devices in (None, "") else int(str(gpu_devices).split(",")[0])
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def run(self, fetches, feed_dict):
+        name = _key(fetches)
+        if name != OUTPUT_NODE:
+            raise KeyError(f"The name '{name}' refers to a Tensor which does not exist (only {OUTPUT_NODE})")
+        feed = {_key(k): v for k, v in feed_dict.items()}
+        for k in feed:
+            if k not in FEED_NAMES:
+                raise KeyError(f"The name '{k}' refers to a Tensor which does not exist")
+        cfg = self.graph.cfg
+        num_nodes = np.asarray(feed["num_nodes:0"]).reshape(-1)
+        if num_nodes.shape[0] != 1:
+            raise ValueError("batch size must be 1 (input_dataset.py:134)")
+        N = int(num_nodes[0])
+        E = int(np.asarray(feed["num_interacting_nodes:0"]).reshape(-1)[0])
+        edges = np.ascontiguousarray(np.asarray(feed["interacting_nodes:0"], dtype=np.int32)[0][:E])
+        u = np.ascontiguousarray(np.asarray(feed["node_features:0"], dtype=np.float32)[0][:N])
+        if u.shape[1] != cfg.node_feature_dim:
+            raise ValueError(f"node_features has dim {u.shape[1]}, model expects {cfg.node_feature_dim}")
+        ef = None
+        if cfg.edge_feature_dim:
+            ef = np.ascontiguousarray(np.asarray(feed["edge_features:0"], dtype=np.float32)[0][:E])
+            if ef.shape[1] != cfg.edge_feature_dim:
+                raise ValueError(f"edge_features has dim {ef.shape[1]}, model expects {cfg.edge_feature_dim}")
+        rel = np.ascontiguousarray(
+            np.asarray(feed["relations_to_consider_belong_to_same_instance:0"], dtype=np.int32)[0])
+        probs = gnn_forward(self.graph, N, edges, u, ef, rel, self.device)
+        return probs[None]
+
+
+def gnn_forward(graph: GnnGraph, num_nodes, edges, node_feat, edge_feat, relations=None, device=0):
+    """One page through the engine -> probabilities [R, num_classes] (R = N*N when relations is None)."""
+    lib = _lib.init_device(device)
+    N = int(num_nodes)
+    edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
+    E = edges.shape[0]
+    u = np.ascontiguousarray(node_feat, dtype=np.float32).reshape(N, -1)
+    ef = np.ascontiguousarray(edge_feat, dtype=np.float32).reshape(E, -1) if edge_feat is not None else None
+    if relations is None:
+        R, rel_p = N * N, None
+    else:
+        rel = np.ascontiguousarray(relations, dtype=np.int32).reshape(-1, 2)
+        R, rel_p = rel.shape[0], rel.ctypes.data
+    out = np.empty((R, graph.cfg.num_classes), dtype=np.float32)
+    rc = lib.asep_gnn_forward(graph.handle(device), N, E, edges.ctypes.data if E else None, u.ctypes.data,
+                              ef.ctypes.data if (ef is not None and E) else None, R, rel_p, out.ctypes.data)
+    _lib.check(rc, "asep_gnn_forward")
+    return out
+
+
+def gnn_hidden(graph: GnnGraph, num_nodes, device=0):
+    lib = _lib.init_device(device)
+    out = np.empty((int(num_nodes), graph.cfg.hidden_dim), dtype=np.float32)
+    _lib.check(lib.asep_gnn_get_hidden(graph.handle(device), out.ctypes.data, out.size), "asep_gnn_get_hidden")
+    return out
+
+
+def correct_edges(graph: GnnGraph, num_nodes, edges, edge_feat=None, device=0):
+    """Device version of misc.py:7-151 -> (edges' [E',2] int32, features' [E',e] float32 or None)."""
+    lib = _lib.init_device(device)
+    edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
+    E = edges.shape[0]
+    mult = 2 if graph.cfg.undirected_graph else 1
+    out_e = np.empty((max(mult * E, 1), 2), dtype=np.int32)
+    ed = graph.cfg.edge_feature_dim
+    ef = out_f = None
+    if edge_feat is not None and ed:
+        ef = np.ascontiguousarray(edge_feat, dtype=np.float32).reshape(E, ed)
+        out_f = np.empty((max(mult * E, 1), ed), dtype=np.float32)
+    n = lib.asep_gnn_correct_edges(graph.handle(device), int(num_nodes), E, edges.ctypes.data if E else None,
+                                   ef.ctypes.data if ef is not None and E else None, out_e.ctypes.data,
+                                   out_f.ctypes.data if out_f is not None else None)
+    _lib.check(n, "asep_gnn_correct_edges")
+    return out_e[:n].copy(), (out_f[:n].copy() if out_f is not None else None)

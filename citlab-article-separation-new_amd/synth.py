@@ -1,0 +1,79 @@
+"""Seeded synthetic workloads of the shapes BASELINE.json names.
+
+No network, no datasets, no shipped nets: pages, graphs and weights are generated.
+"""
+import numpy as np
+
+
+def synth_page(k: int = 0, W: int = 3000, H: int = 4500, seed0: int = 20261002):
+    """Newspaper-like uint8 grayscale scan: paper background, 5-7 text columns with glyph boxes, headings,
+    vertical separators in gutters and horizontal rules between articles, blur + salt noise."""
+    rng = np.random.default_rng(seed0 + k)
+    img = np.clip(rng.normal(225, 6, size=(H, W)), 0, 255).astype(np.float32)
+    ncol = int(rng.integers(5, 8))
+    gutter = 40
+    margin = 60
+    colw = (W - 2 * margin - (ncol - 1) * gutter) // ncol
+    for c in range(ncol):
+        x0 = margin + c * (colw + gutter)
+        y = margin
+        blocks = 0
+        next_heading = int(rng.integers(3, 7))
+        while y < H - margin - 80:
+            nlines = int(rng.integers(4, 41))
+            pitch = int(rng.integers(28, 37))
+            heading = blocks == next_heading
+            if heading:
+                next_heading += int(rng.integers(3, 7))
+                nlines = int(rng.integers(1, 3))
+                pitch = int(rng.integers(70, 100))
+            for _ in range(nlines):
+                if y + pitch >= H - margin:
+                    break
+                x = x0
+                gh_lo, gh_hi = (40, 71) if heading else (14, 23)
+                while x < x0 + colw - 24:
+                    gw = int(rng.integers(6, 23)) * (3 if heading else 1)
+                    gh = int(rng.integers(gh_lo, gh_hi))
+                    if rng.random() < 0.85:
+                        img[y + pitch - gh:y + pitch, x:min(x + gw, x0 + colw)] = np.clip(rng.normal(60, 25), 0, 255)
+                    x += gw + int(rng.integers(2, 6))
+                y += pitch
+            blocks += 1
+            y += int(rng.integers(20, 60))
+            if rng.random() < 0.5 and y < H - margin - 10:
+                t = int(rng.integers(2, 4))
+                img[y:y + t, x0:x0 + colw] = 30            # horizontal rule between articles
+                y += t + int(rng.integers(15, 40))
+        if c < ncol - 1 and rng.random() < 0.7:
+            t = int(rng.integers(2, 5))
+            xs = x0 + colw + gutter // 2
+            img[margin:H - margin, xs:xs + t] = 30            # vertical separator in the gutter
+    # separable gaussian blur, sigma 0.8
+    r = 2
+    kx = np.exp(-0.5 * (np.arange(-r, r + 1) / 0.8) ** 2)
+    kx /= kx.sum()
+    pad = np.pad(img, ((r, r), (0, 0)), mode="edge")
+    img = sum(kx[i] * pad[i:i + H] for i in range(2 * r + 1))
+    pad = np.pad(img, ((0, 0), (r, r)), mode="edge")
+    img = sum(kx[i] * pad[:, i:i + W] for i in range(2 * r + 1))
+    salt = rng.random((H, W)) < 0.001
+    img[salt] = 255
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def synth_graph(k: int = 0, N: int = 200, n_pairs: int = 10000, node_dim: int = 7, edge_dim: int = 2,
+                seed0: int = 4321):
+    """C4 graph: N nodes, `n_pairs` distinct unordered pairs emitted in one direction and shuffled
+    (-> 2*n_pairs directed edges after correction), U(0,1) node features, Bernoulli(0.15) edge features."""
+    rng = np.random.default_rng(seed0 + k)
+    iu, ju = np.triu_indices(N, k=1)
+    n_pairs = min(n_pairs, iu.shape[0])
+    sel = rng.choice(iu.shape[0], size=n_pairs, replace=False)
+    a, b = iu[sel], ju[sel]
+    flip = rng.random(n_pairs) < 0.5
+    edges = np.stack([np.where(flip, b, a), np.where(flip, a, b)], axis=1).astype(np.int32)
+    rng.shuffle(edges, axis=0)
+    node_feat = rng.random((N, node_dim), dtype=np.float32)
+    edge_feat = (rng.random((n_pairs, edge_dim)) < 0.15).astype(np.float32)
+    return {"num_nodes": N, "interacting_nodes": edges, "node_features": node_feat, "edge_features": edge_feat}

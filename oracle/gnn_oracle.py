@@ -1,0 +1,114 @@
+"""CPU ORACLE (test infrastructure, NOT product code) -- GNN relation predictor forward pass.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module.
+
+PARITY UNPINNED for the float path: the reference graph needs TensorFlow 1.x and the frozen
+``mixed_gnn_vn7e*.pb`` (absent); the reference has no tests for it.  This is a numpy restatement of
+
+    article_separation/gnn/model/graph_util/misc.py:7-151     check_and_correct_interacting_nodes
+    article_separation/gnn/model/graph/graph_gnn.py:46-167     GraphGNN.infer (batch size 1)
+    article_separation/gnn/model/graph/message_fn_chunk.py:148-418  default message function
+    article_separation/gnn/model/graph/update_fn_lstm.py:31-101     LSTM update
+    article_separation/gnn/model/graph/graph_relation.py:229-287    pair classifier
+    article_separation/gnn/model/model_relation.py:326-328          softmax output node
+    article_separation/gnn/input/input_dataset.py:444-457          build_full_relations
+
+The integer part (edge correction) is pinned by hand-checkable cases in tests/test_oracle_gnn.py
+(the toy inputs of misc.py:641-704 carry no expected outputs in the reference).
+"""
+import numpy as np
+
+MSG = ("GraphLSTM1/message_fn_default/head_0/calculation_interaction_features/"
+       "concat_u_and_h/interaction_features")
+UPD = "GraphLSTM1/update_function_LSTM"
+CLS = "Classification/logits"
+
+
+def correct_edges(edges, edge_feat, num_nodes, undirected=True):
+    """misc.py:7-151 for one sample.
+
+    symmetrise (append reversed edges, tile features x2, :47-58) -> encode from*N+to (:60) ->
+    unique (:64) -> remove self loops with tf.sets.difference, whose result is sorted ascending
+    (:68-72) -> for every surviving code the FIRST index in the (symmetrised) list (:76-88) ->
+    gather edge features with those indices (:104) -> decode (:91)."""
+    edges = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
+    E = edges.shape[0]
+    if edge_feat is not None:
+        edge_feat = np.asarray(edge_feat, dtype=np.float32)
+        edge_feat = edge_feat.reshape(E, edge_feat.shape[-1] if edge_feat.ndim > 1 else 1)
+    if undirected:
+        full = np.concatenate([edges, edges[:, ::-1]], axis=0)
+        feat_full = np.tile(edge_feat, (2, 1)) if edge_feat is not None else None
+    else:
+        full, feat_full = edges, edge_feat
+    codes_full = full[:, 0] * num_nodes + full[:, 1]
+    codes, first = np.unique(codes_full, return_index=True)          # sorted + first occurrence
+    keep = (codes // num_nodes) != (codes % num_nodes)
+    codes, first = codes[keep], first[keep]
+    out = np.stack([codes // num_nodes, codes % num_nodes], axis=1).astype(np.int32)
+    out_feat = feat_full[first] if feat_full is not None else None
+    return out, out_feat
+
+
+def build_full_relations(num_nodes):
+    """input_dataset.py:444-457: all N*N ordered pairs, row major."""
+    a = np.repeat(np.arange(num_nodes, dtype=np.int32), num_nodes)
+    b = np.tile(np.arange(num_nodes, dtype=np.int32), num_nodes)
+    return np.stack([a, b], axis=1)
+
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def _softmax(x):
+    m = x.max(axis=-1, keepdims=True)
+    e = np.exp(x - m)
+    return e / e.sum(axis=-1, keepdims=True)
+
+
+def forward(num_nodes, edges, node_feat, edge_feat, relations, w, cfg, dtype=np.float32,
+            return_hidden=False):
+    """== sess.run('output_belong_to_same_instance:0') at batch size 1 -> probs [R, num_classes]."""
+    N = int(num_nodes)
+    w = {k: v.astype(dtype) for k, v in w.items()}
+    u = np.asarray(node_feat, dtype=dtype).reshape(N, -1)
+    ce, cf = correct_edges(edges, edge_feat, N, cfg.undirected_graph)
+    cf = cf.astype(dtype) if cf is not None else np.zeros((ce.shape[0], 0), dtype)
+    frm, to = ce[:, 0], ce[:, 1]
+    H = cfg.hidden_dim
+    h = np.zeros((N, H), dtype)
+    c = np.zeros((N, H), dtype)
+    deg = np.bincount(to, minlength=N).astype(dtype)                 # in-degree (message_fn_chunk.py:369-386)
+    for _ in range(cfg.num_transition_steps):
+        du = u[to] - u[frm]
+        dh = h[to] - h[frm]
+        # order fixed by message_fn_chunk.py:313-350: u_from,u_to,u_diff,u_sq | edge | h_from,h_to,h_diff,h_sq
+        z = np.concatenate([u[frm], u[to], du, du * du, cf, h[frm], h[to], dh, dh * dh], axis=1)
+        hid = z
+        for i in range(1, len(cfg.interaction_hidden) + 1):
+            hid = np.maximum(hid @ w[f"{MSG}/fully_connected_layer_h{i}/weights"]
+                             + w[f"{MSG}/fully_connected_layer_h{i}/bias"], 0)
+        m = np.tanh(hid @ w[f"{MSG}/fully_connected_logit_layer_out/weights"]
+                    + w[f"{MSG}/fully_connected_logit_layer_out/bias"])
+        x = np.zeros((N, cfg.interaction_dim), dtype)
+        if len(to):
+            np.add.at(x, to, m * (1.0 / deg[to])[:, None].astype(dtype))
+        v = np.concatenate([x, h, u], axis=1)                        # update_fn_lstm.py:41-50
+        gate = {g: v @ w[f"{UPD}/{g}_activation/dense/weights"] + w[f"{UPD}/{g}_activation/dense/bias"]
+                for g in ("ingate", "outgate", "forgetgate", "cellinput")}
+        i_g, o_g, f_g = _sigmoid(gate["ingate"]), _sigmoid(gate["outgate"]), _sigmoid(gate["forgetgate"])
+        g_g = np.tanh(gate["cellinput"])
+        c = f_g * c + i_g * g_g                                      # update_fn_lstm.py:74-76
+        h = o_g * np.tanh(c)
+    rel = build_full_relations(N) if relations is None else np.asarray(relations, dtype=np.int64).reshape(-1, 2)
+    feat = np.concatenate([h[rel[:, 0]], h[rel[:, 1]]], axis=1)
+    for i in range(1, len(cfg.classifier_hidden) + 1):
+        feat = np.maximum(feat @ w[f"{CLS}/fully_connected_layer_h{i}/weights"]
+                          + w[f"{CLS}/fully_connected_layer_h{i}/bias"], 0)
+    logits = feat @ w[f"{CLS}/fully_connected_logit_layer_out/weights"] + w[f"{CLS}/fully_connected_logit_layer_out/bias"]
+    probs = _softmax(logits).astype(dtype)
+    if return_hidden:
+        return probs, h
+    return probs

@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from citlab_article_separation_new_amd.config import AruConfig
 from citlab_article_separation_new_amd.weights import init_aru_weights

@@ -1,0 +1,134 @@
+"""GPU parity: HIP GNN (through the C ABI) vs the numpy oracle on the same seeded inputs.
+
+Integer work (edge correction) is bit-exact; probabilities/hidden states within 1e-5."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-5
+
+
+def _setup(seed=99, **cfg_kw):
+    from citlab_article_separation_new_amd.config import GnnConfig
+    from citlab_article_separation_new_amd.weights import init_gnn_weights
+    from citlab_article_separation_new_amd.gnn_io import GnnGraph
+    cfg = GnnConfig(**cfg_kw)
+    w = init_gnn_weights(cfg, seed, bias_jitter=0.05)
+    return cfg, w, GnnGraph(w, cfg)
+
+
+def _random_graph(rng, N, E, node_dim=7, edge_dim=2, dup=True):
+    edges = rng.integers(0, N, size=(E, 2)).astype(np.int32)       # duplicates, reversed duplicates, self loops
+    if dup and E > 4:
+        edges[1] = edges[0]
+        edges[2] = edges[0][::-1]
+        edges[3] = [min(3, N - 1), min(3, N - 1)]
+    u = rng.random((N, node_dim), dtype=np.float32)
+    ef = rng.random((E, edge_dim), dtype=np.float32)
+    return edges, u, ef
+
+
+@pytest.mark.parametrize("N,E", [(4, 5), (12, 30), (50, 400), (200, 10000), (333, 2000), (3, 0)])
+def test_edge_correction_bit_exact(N, E):
+    from citlab_article_separation_new_amd import gnn_io
+    from oracle import gnn_oracle
+    cfg, w, graph = _setup()
+    rng = np.random.default_rng(N * 7 + E)
+    edges, u, ef = _random_graph(rng, N, E)
+    want_e, want_f = gnn_oracle.correct_edges(edges, ef, N, True)
+    got_e, got_f = gnn_io.correct_edges(graph, N, edges, ef)
+    assert np.array_equal(got_e, want_e)
+    if E:
+        assert np.array_equal(got_f, want_f)
+    graph.close()
+
+
+def test_edge_correction_directed():
+    from citlab_article_separation_new_amd import gnn_io
+    from oracle import gnn_oracle
+    cfg, w, graph = _setup(undirected_graph=False)
+    rng = np.random.default_rng(5)
+    edges, u, ef = _random_graph(rng, 20, 90)
+    want_e, want_f = gnn_oracle.correct_edges(edges, ef, 20, False)
+    got_e, got_f = gnn_io.correct_edges(graph, 20, edges, ef)
+    assert np.array_equal(got_e, want_e) and np.array_equal(got_f, want_f)
+    graph.close()
+
+
+@pytest.mark.parametrize("N,E", [(4, 5), (12, 30), (50, 400), (200, 10000), (77, 150)])
+def test_probabilities_match_oracle(N, E):
+    from citlab_article_separation_new_amd import gnn_io
+    from oracle import gnn_oracle
+    cfg, w, graph = _setup()
+    rng = np.random.default_rng(N + E)
+    edges, u, ef = _random_graph(rng, N, E)
+    want, want_h = gnn_oracle.forward(N, edges, u, ef, None, w, cfg, dtype=np.float64, return_hidden=True)
+    got = gnn_io.gnn_forward(graph, N, edges, u, ef, None)
+    got_h = gnn_io.gnn_hidden(graph, N)
+    assert got.shape == (N * N, 2)
+    assert float(np.abs(got_h - want_h).max()) <= PROB_TOL
+    assert float(np.abs(got - want).max()) <= PROB_TOL
+    graph.close()
+
+
+def test_c4_synthetic_graph_and_session_interface():
+    """BASELINE config 4 shape through the reference's sess.run-by-tensor-name interface."""
+    from citlab_article_separation_new_amd import gnn_io, synth
+    from oracle import gnn_oracle
+    cfg, w, graph = _setup(seed=1234)
+    g = synth.synth_graph(0)
+    N = g["num_nodes"]
+    rel = gnn_oracle.build_full_relations(N)
+    feed = {
+        "num_nodes:0": np.array([N], np.int32),
+        "num_interacting_nodes:0": np.array([g["interacting_nodes"].shape[0]], np.int32),
+        "interacting_nodes:0": g["interacting_nodes"][None],
+        "node_features:0": g["node_features"][None],
+        "edge_features:0": g["edge_features"][None],
+        "relations_to_consider_belong_to_same_instance:0": rel[None],
+    }
+    sess = gnn_io.GnnSession(graph, "0")
+    out = sess.run("output_belong_to_same_instance:0", feed_dict=feed)
+    assert out.shape == (1, N * N, 2)
+    want = gnn_oracle.forward(N, g["interacting_nodes"], g["node_features"], g["edge_features"], rel, w, cfg)
+    ce, _ = gnn_oracle.correct_edges(g["interacting_nodes"], g["edge_features"], N, True)
+    assert ce.shape[0] == 20000
+    assert float(np.abs(out[0] - want).max()) <= PROB_TOL
+    with pytest.raises(KeyError):
+        sess.run("no_such_node:0", feed_dict=feed)
+    with pytest.raises(KeyError):
+        sess.run("output_belong_to_same_instance:0", feed_dict={**feed, "bogus:0": 1})
+    graph.close()
+
+
+def test_relation_subset_and_isolated_nodes():
+    from citlab_article_separation_new_amd import gnn_io
+    from oracle import gnn_oracle
+    cfg, w, graph = _setup()
+    rng = np.random.default_rng(3)
+    N = 30
+    edges = rng.integers(0, 10, size=(40, 2)).astype(np.int32)      # nodes 10..29 are isolated (x = 0)
+    u = rng.random((N, 7), dtype=np.float32)
+    ef = rng.random((40, 2), dtype=np.float32)
+    rel = rng.integers(0, N, size=(123, 2)).astype(np.int32)
+    want = gnn_oracle.forward(N, edges, u, ef, rel, w, cfg, dtype=np.float64)
+    got = gnn_io.gnn_forward(graph, N, edges, u, ef, rel)
+    assert float(np.abs(got - want).max()) <= PROB_TOL
+    graph.close()
+
+
+def test_permutation_equivariance():
+    """Relabelling the nodes permutes the confidence matrix accordingly (property test at full C4 size)."""
+    from citlab_article_separation_new_amd import gnn_io, synth
+    cfg, w, graph = _setup(seed=1234)
+    g = synth.synth_graph(1)
+    N = g["num_nodes"]
+    p0 = gnn_io.gnn_forward(graph, N, g["interacting_nodes"], g["node_features"], g["edge_features"])[:, 1].reshape(N, N)
+    perm = np.random.default_rng(0).permutation(N)
+    inv = np.argsort(perm)
+    edges2 = inv[g["interacting_nodes"]].astype(np.int32)          # node i becomes inv[i]
+    u2 = g["node_features"][perm]
+    p1 = gnn_io.gnn_forward(graph, N, edges2, u2, g["edge_features"])[:, 1].reshape(N, N)
+    assert float(np.abs(p1 - p0[np.ix_(perm, perm)]).max()) <= 2e-5
+    graph.close()
