@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- pages/sec of the ARU-Net (+ GNN relation) hot path on synthetic 3000x4500 newspaper scans.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
+
+A "step" = one pass of the hot path over one batch of `--pages-per-step` device-resident pages on every rank:
+per page one ARU-Net forward (fp32, fused uint8/threshold epilogue) + one GNN forward on that page's text-block
+graph (N=200 nodes, 20 000 directed edges after correction, all 40 000 ordered pairs).  Pages are independent, so
+ranks shard the page list (weak scaling) and the only collective is the weight broadcast at start-up.
+
+Prints ONE JSON line on rank 0: BASELINE.json's metric + `roofline` (dominant kernel, timed live with HIP events on
+the launch stream) + `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample; rank 0,
+N == 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+METRIC = "newspaper pages/sec (ARU-Net seg + GNN relation) at 3000x4500 px"
+PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pages-per-step", type=int, default=2, help="pages per rank and step")
+    ap.add_argument("--height", type=int, default=4500)
+    ap.add_argument("--width", type=int, default=3000)
+    ap.add_argument("--no-gnn", action="store_true", help="ARU-Net only (diagnostic; not the headline metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event per-kernel timing")
+    ap.add_argument("--cpu-sample-height", type=int, default=0, help="rows of page 0 for the CPU baseline (0 = full page)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from citlab_article_separation_new_amd import _lib, synth
+    from citlab_article_separation_new_amd.config import AruConfig, GnnConfig
+    from citlab_article_separation_new_amd.weights import init_aru_weights, init_gnn_weights, pack_blob, unpack_blob
+    from citlab_article_separation_new_amd.net_post_processing_helper import AruGraph
+    from citlab_article_separation_new_amd.gnn_io import GnnGraph
+
+    H, W, B = args.height, args.width, args.pages_per_step
+    aru_cfg, gnn_cfg = AruConfig(), GnnConfig()
+
+    # ---- weights: rank 0 creates them, every other rank receives the blob over RCCL (the only collective) ----
+    if rank == 0:
+        blobs = [pack_blob(init_aru_weights(aru_cfg, 1234)), pack_blob(init_gnn_weights(gnn_cfg, 1234))]
+    else:
+        blobs = [None, None]
+    if distributed:
+        for i in range(2):
+            n = torch.tensor([len(blobs[i]) if rank == 0 else 0], dtype=torch.int64, device=dev)
+            dist.broadcast(n, 0)
+            buf = (torch.frombuffer(bytearray(blobs[i]), dtype=torch.uint8).to(dev) if rank == 0
+                   else torch.empty(int(n.item()), dtype=torch.uint8, device=dev))
+            dist.broadcast(buf, 0)
+            blobs[i] = bytes(buf.cpu().numpy().tobytes())
+    aru = AruGraph(unpack_blob(blobs[0]), aru_cfg)
+    gnn = GnnGraph(unpack_blob(blobs[1]), gnn_cfg)
+    lib = _lib.init_device(local_rank)
+    h_aru, h_gnn = aru.handle(local_rank), gnn.handle(local_rank)
+
+    # ---- synthetic inputs, resident in HBM before the timed region ------------------------------------------
+    pages_u8 = [synth.synth_page(rank * B + k, W, H) for k in range(B)]
+    imgs = [torch.from_numpy(p).to(dev).float().div_(255.0).contiguous() for p in pages_u8]
+    graphs = [synth.synth_graph(rank * B + k) for k in range(B)]
+    N = graphs[0]["num_nodes"]
+    g_edges = [torch.from_numpy(g["interacting_nodes"]).to(dev) for g in graphs]
+    g_u = [torch.from_numpy(g["node_features"]).to(dev) for g in graphs]
+    g_ef = [torch.from_numpy(g["edge_features"]).to(dev) for g in graphs]
+    E = [int(g["interacting_nodes"].shape[0]) for g in graphs]
+    ncls = aru_cfg.n_classes
+    out_prob = [torch.empty(H, W, ncls, device=dev) for _ in range(B)]
+    out_u8 = [torch.empty(H, W, ncls, device=dev, dtype=torch.uint8) for _ in range(B)]
+    out_mask = [torch.empty(H, W, ncls, device=dev, dtype=torch.uint8) for _ in range(B)]
+    out_conf = [torch.empty(N * N, gnn_cfg.num_classes, device=dev) for _ in range(B)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        for k in range(B):
+            _lib.check(lib.asep_aru_forward_dev(h_aru, imgs[k].data_ptr(), H, W, out_prob[k].data_ptr(),
+                                                out_u8[k].data_ptr(), out_mask[k].data_ptr(), 0.05, stream),
+                       "asep_aru_forward_dev")
+            if not args.no_gnn:
+                _lib.check(lib.asep_gnn_forward_dev(h_gnn, N, E[k], g_edges[k].data_ptr(), g_u[k].data_ptr(),
+                                                    g_ef[k].data_ptr(), N * N, None, out_conf[k].data_ptr(), stream),
+                           "asep_gnn_forward_dev")
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    pages = world * B * args.steps
+    value = pages / dt
+
+    # ---- per-kernel timing with HIP events on the launch stream (same workload, separate pass so that the
+    #      events do not perturb `value`) -----------------------------------------------------------------------
+    roofline = None
+    kernels = []
+    if rank == 0 and not args.no_kernel_timing:
+        lib.asep_aru_profile(h_aru, 1)
+        n_prof = max(1, min(args.steps, 3))
+        for _ in range(n_prof):
+            step()
+        torch.cuda.synchronize()
+        buf = C.create_string_buffer(1 << 16)
+        _lib.check(lib.asep_aru_profile_report(h_aru, buf, len(buf)), "asep_aru_profile_report")
+        lib.asep_aru_profile(h_aru, 0)
+        kernels = json.loads(buf.value.decode())
+        for k in kernels:
+            k["avg_us"] = 1e3 * k["total_ms"] / k["calls"]
+            k["tflops"] = k["flops"] / (k["total_ms"] * 1e-3) / 1e12 if k["total_ms"] > 0 else 0.0
+        kernels.sort(key=lambda k: -k["total_ms"])
+        dom = kernels[0]
+        roofline = {
+            "bound": "mfma", "kernel": dom["kernel"],
+            "achieved": round(dom["tflops"], 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
+            "avg_launch_us": round(dom["avg_us"], 2), "flops_per_launch": dom["flops"] / dom["calls"],
+            "share_of_gpu_time": round(dom["total_ms"] / sum(k["total_ms"] for k in kernels), 4),
+            "traffic": None,
+        }
+        tp = os.path.join(ROOT, "profiles", "traffic_dominant_kernel.json")
+        if os.path.exists(tp):      # HBM bytes/launch from a separate rocprofv3 --pmc pass (see profiles/README.md)
+            try:
+                tj = json.load(open(tp))
+                if tj.get("kernel") == dom["kernel"]:
+                    roofline["traffic"] = tj.get("bytes_per_launch")
+            except Exception:
+                pass
+
+    # ---- CPU baseline: the oracle (a port, kind="port") on this box's host cores, bounded sample --------------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import aru_oracle, gnn_oracle
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        sample_h = args.cpu_sample_height or H
+        img = pages_u8[0][:sample_h].astype(np.float32) / 255.0
+        w_aru = unpack_blob(blobs[0])
+        aru_oracle.forward_torch(img[:256, :256], w_aru, aru_cfg)          # warm-up (thread pool, allocator)
+        t1 = time.perf_counter()
+        aru_oracle.forward_torch(img, w_aru, aru_cfg)
+        t_aru = (time.perf_counter() - t1) * (H / sample_h)
+        t_gnn = 0.0
+        if not args.no_gnn:
+            g = graphs[0]
+            t1 = time.perf_counter()
+            gnn_oracle.forward(N, g["interacting_nodes"], g["node_features"], g["edge_features"], None,
+                               unpack_blob(blobs[1]), gnn_cfg)
+            t_gnn = time.perf_counter() - t1
+        cpu_baseline = {
+            "value": round(1.0 / (t_aru + t_gnn), 5), "unit": "pages/s", "cores": cores, "kind": "port",
+            "sample": f"1 page: ARU-Net oracle (torch-CPU fp32, {cores} threads) on rows 0..{sample_h} of page 0 "
+                      f"({W}x{sample_h}px, scaled x{H / sample_h:.2f}) + GNN numpy oracle on graph 0; "
+                      f"aru {t_aru:.2f}s gnn {t_gnn:.3f}s",
+        }
+
+    if rank == 0:
+        flops_page = lib.asep_aru_flops(h_aru, H, W) + (0 if args.no_gnn else lib.asep_gnn_flops(h_gnn, N, 2 * E[0], N * N))
+        line = {
+            "metric": METRIC, "value": round(value, 4), "unit": "pages/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": ("BASELINE configs[1]: ARU-Net separator detection on 3000x4500 px pages, fp32, "
+                             "+ configs[3]-shaped GNN relation graph per page (200 nodes / 20k edges / 40k pairs)"
+                             if not args.no_gnn else "ARU-Net only (diagnostic)"),
+                "height": H, "width": W, "pages_per_step_per_gpu": B, "sharding": f"pages over {world} rank(s)",
+                "aru_cfg": "ARU featRoot=8 levels=5 res_depth=3 att_scales=3 n_classes=2",
+                "gflop_per_page": round(flops_page / 1e9, 2),
+                "whole_page_tflops_per_gpu": round(flops_page * value / world / 1e12, 3),
+            },
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "kernels": [{"kernel": k["kernel"], "calls": k["calls"], "avg_us": round(k["avg_us"], 2),
+                         "tflops": round(k["tflops"], 2)} for k in kernels[:8]],
+        }
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

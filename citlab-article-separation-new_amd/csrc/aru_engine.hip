@@ -54,14 +54,57 @@ struct asep_aru {
     hipStream_t stream = nullptr;
     std::vector<void*> owned;
 
+    // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
+    struct ProfRec { int kid; double flops; hipEvent_t a, b; };
+    bool profiling = false;
+    std::vector<std::string> prof_names;
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_next = 0;
+
     ~asep_aru() {
         for (void* p : owned)
             if (p) (void)hipFree(p);
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+    }
+    hipEvent_t next_event() {
+        if (ev_next == ev_pool.size()) {
+            hipEvent_t e;
+            ASEP_HIP_CHECK_THROW(hipEventCreate(&e));
+            ev_pool.push_back(e);
+        }
+        return ev_pool[ev_next++];
+    }
+    int prof_kid(const std::string& name) {
+        for (size_t i = 0; i < prof_names.size(); ++i)
+            if (prof_names[i] == name) return (int)i;
+        prof_names.push_back(name);
+        return (int)prof_names.size() - 1;
     }
     int feat(int l) const { return cfg.feat_root << l; }
 };
 
 namespace {
+
+// Brackets one kernel launch with two events when profiling is on (no-op otherwise).
+struct ProfScope {
+    asep_aru* m;
+    hipEvent_t a = nullptr, b = nullptr;
+    int kid = -1;
+    double flops;
+    ProfScope(asep_aru* m_, const std::string& name, double flops_) : m(m_), flops(flops_) {
+        if (!m->profiling) return;
+        kid = m->prof_kid(name);
+        a = m->next_event();
+        b = m->next_event();
+        ASEP_HIP_CHECK_THROW(hipEventRecord(a, m->stream));
+    }
+    ~ProfScope() {
+        if (kid < 0) return;
+        (void)hipEventRecord(b, m->stream);
+        m->prof_recs.push_back({kid, flops, a, b});
+    }
+};
 
 // ---- weight packing -----------------------------------------------------------------------------
 // conv   W[kh][kw][cin][cout]  (layers.py:219);  deconv W[kh][kw][cout][cin] (layers.py:352, ARU_v1.py:257)
@@ -162,9 +205,13 @@ Tensor new_tensor(asep_aru* m, int H, int W, int C) {
 }
 
 template <int KH, int KW>
-void launch_conv_k(const PackedConv& pc, const ConvArgs& a, dim3 grid_xy, hipStream_t s) {
+void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, dim3 grid_xy, hipStream_t s) {
     int mt = pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1);
     dim3 grid(grid_xy.x, grid_xy.y, pc.mtiles / mt);
+    const double flops = 2.0 * a.H * a.W * KH * KW * (double)pc.cin * pc.cout;
+    char name[64];
+    snprintf(name, sizeof(name), "conv_mfma_kernel<%d,%d,%d,%s>", KH, KW, pc.c8 ? 1 : mt, pc.c8 ? "true" : "false");
+    ProfScope ps(m, name, flops);
     if (pc.c8) {
         // Cin == 8 always comes with a single m-tile per block here (cout 8 or 16)
         dim3 g1(grid_xy.x, grid_xy.y, pc.mtiles);
@@ -196,8 +243,8 @@ Tensor run_conv(asep_aru* m, const std::string& scope, const Tensor& in0, const 
     a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
     a.relu_in = relu_in; a.relu_out = relu_out;
     dim3 gxy(cdiv(in0.W, CONV_TW), cdiv(in0.H, CONV_TH));
-    if (pc.kh == 3 && pc.kw == 3) launch_conv_k<3, 3>(pc, a, gxy, m->stream);
-    else if (pc.kh == 4 && pc.kw == 4) launch_conv_k<4, 4>(pc, a, gxy, m->stream);
+    if (pc.kh == 3 && pc.kw == 3) launch_conv_k<3, 3>(m, pc, a, gxy, m->stream);
+    else if (pc.kh == 4 && pc.kw == 4) launch_conv_k<4, 4>(m, pc, a, gxy, m->stream);
     else { set_error("conv %s: unsupported kernel size %dx%d", scope.c_str(), pc.kh, pc.kw); throw ArgError(); }
     return out;
 }
@@ -226,6 +273,7 @@ Tensor run_deconv(asep_aru* m, const std::string& scope, const Tensor& in, int H
     a.relu_in = 0; a.relu_out = relu_out;
     const int mt = pc.mtiles % 2 == 0 ? 2 : 1;
     dim3 grid(cdiv(in.W, DC_TW), cdiv(in.H, DC_TH), pc.mtiles / mt);
+    ProfScope ps(m, mt == 2 ? "deconv_mfma_kernel<2>" : "deconv_mfma_kernel<1>", 2.0 * in.H * in.W * 9.0 * pc.cin * pc.cout);
     if (mt == 2) hipLaunchKernelGGL((deconv_mfma_kernel<2>), grid, dim3(256), 0, m->stream, a);
     else hipLaunchKernelGGL((deconv_mfma_kernel<1>), grid, dim3(256), 0, m->stream, a);
     return out;
@@ -234,6 +282,8 @@ Tensor run_deconv(asep_aru* m, const std::string& scope, const Tensor& in, int H
 Tensor run_direct(asep_aru* m, const DirectConv& dc, const Tensor& img, bool relu, const float* stats) {
     Tensor out = new_tensor(m, img.H, img.W, dc.cout);
     dim3 grid(cdiv(img.W, 64), cdiv(img.H, 4));
+    ProfScope ps(m, "conv_c1_kernel<" + std::to_string(dc.k) + "," + std::to_string(dc.cout) + ">",
+                 2.0 * img.H * img.W * dc.k * dc.k * dc.cout);
 #define ASEP_C1(K, CO)                                                                               \
     if (dc.k == K && dc.cout == CO) {                                                                \
         hipLaunchKernelGGL((conv_c1_kernel<K, CO>), grid, dim3(256), 0, m->stream, img.p, img.H, img.W, \
@@ -250,6 +300,7 @@ int grid_1d(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); 
 
 Tensor run_maxpool(asep_aru* m, const Tensor& in) {
     Tensor out = new_tensor(m, cdiv(in.H, 2), cdiv(in.W, 2), in.C);
+    ProfScope ps(m, "maxpool2_kernel", 0.0);
     hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_1d(out.count() / 4)), dim3(256), 0, m->stream, in.p, in.H, in.W,
                        in.C, out.p, out.H, out.W);
     return out;
@@ -366,6 +417,7 @@ int forward_impl(asep_aru* m, const float* d_img, int H, int W, float* d_out, ui
         ca.thr255 = (double)threshold * 255.0;
         ca.softmax = cfg.apply_softmax;
         dim3 grid(cdiv(W, 16), cdiv(H, 16));
+        ProfScope ps(m, "combine_kernel", 2.0 * H * W * 16.0 * cfg.feat_root * cfg.n_classes);
 #define ASEP_COMB(FR, NC)                                                                          \
     if (cfg.feat_root == FR && cfg.n_classes == NC) {                                              \
         hipLaunchKernelGGL((combine_kernel<FR, NC>), grid, dim3(256), 0, stream, ca);              \
@@ -541,6 +593,38 @@ long asep_aru_get_endpoint(asep_aru* m, const char* name, float* out, size_t max
     ASEP_HIP_CHECK(hipStreamSynchronize(m->stream));
     ASEP_HIP_CHECK(hipMemcpy(out, t.p, t.count() * sizeof(float), hipMemcpyDeviceToHost));
     return (long)t.count();
+}
+
+int asep_aru_profile(asep_aru* m, int enable) {
+    if (!m) { set_error("asep_aru_profile: null handle"); return ASEP_ERR_ARG; }
+    m->profiling = enable != 0;
+    if (enable) { m->prof_recs.clear(); m->ev_next = 0; }
+    return ASEP_OK;
+}
+
+long asep_aru_profile_report(asep_aru* m, char* buf, size_t buflen) {
+    if (!m || !buf || buflen < 2) { set_error("asep_aru_profile_report: bad argument"); return ASEP_ERR_ARG; }
+    ASEP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    const size_t nk = m->prof_names.size();
+    std::vector<double> ms(nk, 0.0), fl(nk, 0.0);
+    std::vector<long> calls(nk, 0);
+    for (const auto& r : m->prof_recs) {
+        float t = 0.f;
+        ASEP_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
+        ms[r.kid] += t; fl[r.kid] += r.flops; calls[r.kid] += 1;
+    }
+    std::string js = "[";
+    for (size_t i = 0; i < nk; ++i) {
+        if (!calls[i]) continue;
+        char line[256];
+        snprintf(line, sizeof(line), "%s{\"kernel\":\"%s\",\"calls\":%ld,\"total_ms\":%.6f,\"flops\":%.6e}",
+                 js.size() > 1 ? "," : "", m->prof_names[i].c_str(), calls[i], ms[i], fl[i]);
+        js += line;
+    }
+    js += "]";
+    if (js.size() + 1 > buflen) { set_error("asep_aru_profile_report: buffer too small (%zu needed)", js.size() + 1); return ASEP_ERR_ARG; }
+    memcpy(buf, js.c_str(), js.size() + 1);
+    return (long)js.size();
 }
 
 double asep_aru_flops(const asep_aru* m, int H, int W) {

@@ -116,8 +116,12 @@ def _init_from_shapes(shapes, seed: int, bias_value: float = 0.1) -> "OrderedDic
     return out
 
 
-def init_aru_weights(cfg: AruConfig, seed: int = 1234, bias_jitter: float = 0.0):
+def init_aru_weights(cfg: AruConfig, seed: int = 1234, bias_jitter: float = 0.0, logit_scale: float = 1.0):
+    """`logit_scale` < 1 shrinks the class-logit filter so that random-weight probabilities do not saturate
+    at 0/1 (used by the parity tests to keep the probability comparison sensitive)."""
     w = _init_from_shapes(aru_tensor_shapes(cfg), seed)
+    if logit_scale != 1.0:
+        w["aru_net/logit/class/weights"] = (w["aru_net/logit/class/weights"] * logit_scale).astype(np.float32)
     if bias_jitter:
         # optional: non-constant biases make parity tests sensitive to bias indexing errors
         rng = np.random.default_rng(seed + 1)

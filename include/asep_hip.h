@@ -83,6 +83,12 @@ int asep_aru_forward_dev(asep_aru* m, const float* d_img, int H, int W,
  * Returns the number of floats written, or a negative error; dims receives {H, W, C}. */
 long asep_aru_get_endpoint(asep_aru* m, const char* name, float* out, size_t max_floats, int32_t dims[3]);
 
+/* Per-launch timing with HIP events recorded on the launch stream (measurement aid for bench.py).
+ * asep_aru_profile(m,1) clears the records and starts recording; (m,0) stops.  The report is a JSON
+ * array [{"kernel","calls","total_ms","flops"}] aggregated per kernel; returns its length. */
+int asep_aru_profile(asep_aru* m, int enable);
+long asep_aru_profile_report(asep_aru* m, char* buf, size_t buflen);
+
 /* Algorithmic FLOPs (2*MAC of conv/deconv layers) of one forward at H x W. */
 double asep_aru_flops(const asep_aru* m, int H, int W);
 

@@ -1,0 +1,92 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol declared in include/asep_hip.h
+(no compute calls without a GPU), the ctypes signature table matches the header, weight containers round-trip."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+
+def _header_functions(repo_root):
+    src = open(os.path.join(repo_root, "include", "asep_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(asep_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(repo_root):
+    from citlab_article_separation_new_amd import _lib
+    names = _header_functions(repo_root)
+    assert len(names) >= 17
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = _lib.load_library()
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.asep_version().decode().startswith("asep_hip")
+    assert lib.asep_device_count() >= 0
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a GPU the product path must fail loudly instead of computing on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from citlab_article_separation_new_amd import _lib, net_post_processing_helper as helper
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    cfg = AruConfig()
+    g = helper.AruGraph(init_aru_weights(cfg, 1), cfg)
+    with pytest.raises(_lib.AsepError):
+        helper.get_net_output(np.zeros((16, 16), np.float32), g, "0")
+
+
+def test_product_code_never_imports_the_oracle(repo_root):
+    pkg = os.path.join(repo_root, "citlab-article-separation-new_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "oracle/" not in text.replace("the oracle under ``oracle/``", ""), f
+
+
+def test_weight_inventory_and_blob_roundtrip(tmp_path):
+    from citlab_article_separation_new_amd.config import AruConfig, GnnConfig
+    from citlab_article_separation_new_amd import weights as W
+    cfg = AruConfig()
+    w = W.init_aru_weights(cfg, 1234)
+    assert sum(v.size for v in w.values()) == 1043839           # 1 031 552 + 12 029 + 258
+    assert w["aru_net/featMapG/unet_up_0/deconv/weights"].shape == (3, 3, 8, 16)     # [kh,kw,Cout,Cin]
+    assert w["aru_net/featMapG/unet_up_0/conv1/weights"].shape == (3, 3, 16, 8)
+    assert np.all(w["aru_net/logit/class/biases"] == np.float32(0.1))
+    back = W.unpack_blob(W.pack_blob(w))
+    assert list(back) == list(w) and all(np.array_equal(back[k], w[k]) for k in w)
+    g = W.init_gnn_weights(GnnConfig(), 7)
+    assert g["GraphLSTM1/message_fn_default/head_0/calculation_interaction_features/concat_u_and_h/"
+             "interaction_features/fully_connected_layer_h1/weights"].shape == (158, 32)
+    assert g["GraphLSTM1/update_function_LSTM/ingate_activation/dense/weights"].shape == (71, 32)
+    assert g["Classification/logits/fully_connected_layer_h1/weights"].shape == (64, 64)
+    p = str(tmp_path / "m.asepw")
+    W.save_weights(p, w, {"aru_cfg": cfg.to_dict()})
+    t, meta = W.load_weights(p)
+    assert meta["aru_cfg"]["feat_root"] == 8 and np.array_equal(t["aru_net/logit/class/weights"], w["aru_net/logit/class/weights"])
+    with pytest.raises(IOError):
+        W.unpack_blob(b"garbage!" + b"\0" * 16)
+
+
+def test_load_graph_accepts_container_and_rejects_pb(tmp_path):
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd import weights as W, net_post_processing_helper as helper
+    cfg = AruConfig(n_classes=3)
+    p = str(tmp_path / "sep.asepw")
+    W.save_weights(p, W.init_aru_weights(cfg, 3), {"aru_cfg": cfg.to_dict()})
+    g = helper.load_graph(p)
+    assert g.cfg.n_classes == 3 and g.input_name == "inImg:0" and g.output_name == "output:0"
+    with pytest.raises(IOError):
+        helper.load_graph(str(tmp_path / "missing.pb"))
+    (tmp_path / "x.pb").write_bytes(b"\x0a\x00")
+    with pytest.raises(IOError):
+        helper.load_graph(str(tmp_path / "x.pb"))
+    assert helper.get_scaling_factor(4500, 3000, 1.0, fixed_height=1500) == pytest.approx(1 / 3)

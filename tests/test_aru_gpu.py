@@ -15,7 +15,7 @@ def _setup(cfg_kwargs=None, seed=1234):
     from citlab_article_separation_new_amd.weights import init_aru_weights
     from citlab_article_separation_new_amd.net_post_processing_helper import AruGraph
     cfg = AruConfig(**(cfg_kwargs or {}))
-    w = init_aru_weights(cfg, seed, bias_jitter=0.05)
+    w = init_aru_weights(cfg, seed, bias_jitter=0.05, logit_scale=0.05)
     return cfg, w, AruGraph(w, cfg)
 
 

@@ -1,0 +1,65 @@
+"""GNN oracle: hand-checkable edge-correction cases (misc.py:7-151) and structural properties."""
+import numpy as np
+
+from oracle import gnn_oracle as G
+
+
+def _cfg_w(seed=5):
+    from citlab_article_separation_new_amd.config import GnnConfig
+    from citlab_article_separation_new_amd.weights import init_gnn_weights
+    cfg = GnnConfig()
+    return cfg, init_gnn_weights(cfg, seed, bias_jitter=0.05)
+
+
+def test_edge_correction_hand_case():
+    # N=4; edges with a duplicate, a reversed duplicate and a self loop
+    edges = np.array([[2, 1], [0, 3], [1, 2], [2, 2], [2, 1]], np.int32)
+    feat = np.array([[10.], [20.], [30.], [40.], [50.]], np.float32)
+    e, f = G.correct_edges(edges, feat, 4, undirected=True)
+    # symmetrised list: idx0 (2,1) 1 (0,3) 2 (1,2) 3 (2,2) 4 (2,1) | 5 (1,2) 6 (3,0) 7 (2,1) 8 (2,2) 9 (1,2)
+    # sorted codes without self loops: (0,3) (1,2) (2,1) (3,0); first occurrences: 1, 2, 0, 6 -> feats 20, 30, 10, 20
+    assert e.tolist() == [[0, 3], [1, 2], [2, 1], [3, 0]]
+    assert f[:, 0].tolist() == [20., 30., 10., 20.]
+    e2, f2 = G.correct_edges(edges, feat, 4, undirected=False)
+    assert e2.tolist() == [[0, 3], [1, 2], [2, 1]]
+    assert f2[:, 0].tolist() == [20., 30., 10.]
+
+
+def test_reference_toy_graph_is_already_canonical():
+    # the 4-node / 8-edge toy graph of message_fn_chunk.py:456-483 is symmetric, sorted and loop free
+    edges = np.array([[0, 1], [0, 2], [0, 3], [1, 0], [1, 2], [2, 0], [2, 1], [3, 0]], np.int32)
+    e, _ = G.correct_edges(edges, None, 4, undirected=True)
+    assert e.tolist() == edges.tolist()
+
+
+def test_full_relations_order():
+    r = G.build_full_relations(3)
+    assert r.tolist() == [[0, 0], [0, 1], [0, 2], [1, 0], [1, 1], [1, 2], [2, 0], [2, 1], [2, 2]]
+
+
+def test_forward_shapes_precision_and_isolated_nodes():
+    cfg, w = _cfg_w()
+    rng = np.random.default_rng(1)
+    N = 9
+    edges = rng.integers(0, 6, size=(14, 2)).astype(np.int32)        # nodes 6..8 isolated
+    u = rng.random((N, 7), dtype=np.float32)
+    ef = rng.random((14, 2), dtype=np.float32)
+    p32, h32 = G.forward(N, edges, u, ef, None, w, cfg, return_hidden=True)
+    p64, h64 = G.forward(N, edges, u, ef, None, w, cfg, dtype=np.float64, return_hidden=True)
+    assert p32.shape == (N * N, 2)
+    assert np.allclose(p32.sum(axis=1), 1.0, atol=1e-6)
+    assert np.abs(p32 - p64).max() < 1e-5 and np.abs(h32 - h64).max() < 1e-5
+
+
+def test_permutation_equivariance_of_the_oracle():
+    cfg, w = _cfg_w()
+    rng = np.random.default_rng(2)
+    N = 12
+    edges = rng.integers(0, N, size=(30, 2)).astype(np.int32)
+    u = rng.random((N, 7), dtype=np.float32)
+    ef = rng.random((30, 2), dtype=np.float32)
+    p0 = G.forward(N, edges, u, ef, None, w, cfg, dtype=np.float64)[:, 1].reshape(N, N)
+    perm = rng.permutation(N)
+    inv = np.argsort(perm)
+    p1 = G.forward(N, inv[edges], u[perm], ef, None, w, cfg, dtype=np.float64)[:, 1].reshape(N, N)
+    assert np.abs(p1 - p0[np.ix_(perm, perm)]).max() < 1e-12
