@@ -47,6 +47,37 @@ def parse_args():
     return ap.parse_args()
 
 
+def run_cpu_baseline(args):
+    """Mirrors the reference's process fan-out (run_net_post_processing.py:61-82): P worker processes, each timing
+    the torch-CPU ARU-Net oracle on a band of `rows` page rows (+ the numpy GNN oracle on one graph).
+    pages/s = P * (rows/H page) / slowest worker."""
+    import subprocess
+    cores = os.cpu_count() or 1
+    threads = min(16, cores)                       # torch-CPU convs of this net stop scaling at ~16 threads
+    workers = max(1, min(8, (cores // 2 or 1) // threads)) if cores > threads else 1
+    rows = args.cpu_sample_height or max(256, args.height // 3)
+    cmd = [sys.executable, "-m", "oracle.cpu_worker", "--threads", str(threads), "--rows", str(rows),
+           "--width", str(args.width), "--height", str(args.height)] + ([] if args.no_gnn else ["--gnn"])
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen(cmd + ["--page", str(i)], cwd=ROOT, stdout=subprocess.PIPE, text=True) for i in range(workers)]
+    res = []
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        if p.returncode == 0 and out.strip():
+            res.append(json.loads(out.strip().splitlines()[-1]))
+    wall = time.perf_counter() - t0
+    if not res:
+        return None
+    frac = rows / args.height
+    t_page = max(r["t_aru"] / frac + r["t_gnn"] for r in res)      # slowest worker, scaled to a whole page
+    return {
+        "value": round(len(res) / t_page, 5), "unit": "pages/s", "cores": threads * len(res), "kind": "port",
+        "sample": (f"{len(res)} worker processes x {threads} threads, each: torch-CPU fp32 ARU-Net oracle on a "
+                   f"{args.width}x{rows}px band (scaled x{1 / frac:.2f} to a page) + numpy GNN oracle on one graph; "
+                   f"slowest worker {t_page:.2f}s/page; {wall:.1f}s wall incl. start-up; box has {cores} logical CPUs"),
+    }
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -56,6 +87,13 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     distributed = world > 1
+
+    # ---- CPU baseline first (rank 0, N == 1), BEFORE this process touches the GPU: the CPU oracle (a port of the
+    #      reference graph, kind="port") in worker processes on this box's host cores, bounded sample -------------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(args)
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local_rank)
@@ -65,7 +103,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from citlab_article_separation_new_amd import _lib, synth
+    from citlab_article_separation_new_amd import _lib, sharding, synth
     from citlab_article_separation_new_amd.config import AruConfig, GnnConfig
     from citlab_article_separation_new_amd.weights import init_aru_weights, init_gnn_weights, pack_blob, unpack_blob
     from citlab_article_separation_new_amd.net_post_processing_helper import AruGraph
@@ -80,13 +118,7 @@ def main():
     else:
         blobs = [None, None]
     if distributed:
-        for i in range(2):
-            n = torch.tensor([len(blobs[i]) if rank == 0 else 0], dtype=torch.int64, device=dev)
-            dist.broadcast(n, 0)
-            buf = (torch.frombuffer(bytearray(blobs[i]), dtype=torch.uint8).to(dev) if rank == 0
-                   else torch.empty(int(n.item()), dtype=torch.uint8, device=dev))
-            dist.broadcast(buf, 0)
-            blobs[i] = bytes(buf.cpu().numpy().tobytes())
+        blobs = [sharding.broadcast_blob(b or b"", rank, dev) for b in blobs]
     aru = AruGraph(unpack_blob(blobs[0]), aru_cfg)
     gnn = GnnGraph(unpack_blob(blobs[1]), gnn_cfg)
     lib = _lib.init_device(local_rank)
@@ -133,9 +165,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = sharding.max_over_ranks(dt, dev)
     pages = world * B * args.steps
     value = pages / dt
 
@@ -174,33 +204,6 @@ def main():
                     roofline["traffic"] = tj.get("bytes_per_launch")
             except Exception:
                 pass
-
-    # ---- CPU baseline: the oracle (a port, kind="port") on this box's host cores, bounded sample --------------
-    cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import aru_oracle, gnn_oracle
-        cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
-        sample_h = args.cpu_sample_height or H
-        img = pages_u8[0][:sample_h].astype(np.float32) / 255.0
-        w_aru = unpack_blob(blobs[0])
-        aru_oracle.forward_torch(img[:256, :256], w_aru, aru_cfg)          # warm-up (thread pool, allocator)
-        t1 = time.perf_counter()
-        aru_oracle.forward_torch(img, w_aru, aru_cfg)
-        t_aru = (time.perf_counter() - t1) * (H / sample_h)
-        t_gnn = 0.0
-        if not args.no_gnn:
-            g = graphs[0]
-            t1 = time.perf_counter()
-            gnn_oracle.forward(N, g["interacting_nodes"], g["node_features"], g["edge_features"], None,
-                               unpack_blob(blobs[1]), gnn_cfg)
-            t_gnn = time.perf_counter() - t1
-        cpu_baseline = {
-            "value": round(1.0 / (t_aru + t_gnn), 5), "unit": "pages/s", "cores": cores, "kind": "port",
-            "sample": f"1 page: ARU-Net oracle (torch-CPU fp32, {cores} threads) on rows 0..{sample_h} of page 0 "
-                      f"({W}x{sample_h}px, scaled x{H / sample_h:.2f}) + GNN numpy oracle on graph 0; "
-                      f"aru {t_aru:.2f}s gnn {t_gnn:.3f}s",
-        }
 
     if rank == 0:
         flops_page = lib.asep_aru_flops(h_aru, H, W) + (0 if args.no_gnn else lib.asep_gnn_flops(h_gnn, N, 2 * E[0], N * N))

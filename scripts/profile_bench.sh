@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): kernel-trace stats of the default bench command, then two PMC passes
+# (FETCH_SIZE, WRITE_SIZE) in their own runs, as /opt/skills/guides prescribe.  Output -> gpurun_out/<tag>/
+set -u
+TAG=${1:-r1}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH --no-kernel-timing > /dev/null 2> $OUT/pmc_fetch.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH --no-kernel-timing > /dev/null 2> $OUT/pmc_write.log
+find $OUT -name "*.csv" | head -20
+# keep only what fits the 64 MiB merge limit: drop the per-dispatch traces of the PMC passes after summarising
+python3 $R/scripts/summarize_pmc.py $OUT > $OUT/pmc_summary.json
+rm -f $OUT/pmc_fetch/*/*kernel_trace.csv $OUT/pmc_write/*/*kernel_trace.csv
+ls -la $OUT $OUT/*/* | head -40
