@@ -57,6 +57,7 @@ struct asep_aru {
     // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
     struct ProfRec { int kid; double flops; hipEvent_t a, b; };
     bool profiling = false;
+    bool prof_detail = false;      // per-layer names (scope + spatial size) instead of per-kernel names
     std::vector<std::string> prof_names;
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> ev_pool;
@@ -196,7 +197,9 @@ int pack_direct(asep_aru* m, const std::map<std::string, HostTensor>& blob, cons
     return ASEP_OK;
 }
 
-// ---- kernel launchers ---------------------------------------------------------------------------
+// ---- kernel launchers: every launch covers one layer of a LIST of problems (pages x scales) -----------------
+typedef std::vector<Tensor> TL;
+
 Tensor new_tensor(asep_aru* m, int H, int W, int C) {
     Tensor t;
     t.H = H; t.W = W; t.C = C;
@@ -204,119 +207,188 @@ Tensor new_tensor(asep_aru* m, int H, int W, int C) {
     return t;
 }
 
+std::string dims_of(const TL& l) {
+    std::string d;
+    for (size_t i = 0; i < l.size() && i < 3; ++i) d += (i ? "+" : "") + std::to_string(l[i].H) + "x" + std::to_string(l[i].W);
+    if (l.size() > 3) d += "+..(" + std::to_string(l.size()) + ")";
+    return d;
+}
+
 template <int KH, int KW>
-void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, dim3 grid_xy, hipStream_t s) {
-    int mt = pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1);
-    dim3 grid(grid_xy.x, grid_xy.y, pc.mtiles / mt);
-    const double flops = 2.0 * a.H * a.W * KH * KW * (double)pc.cin * pc.cout;
+void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, int total_tiles, double flops,
+                   const std::string& scope, const TL& in0) {
+    const int mt = pc.c8 ? 1 : (pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1));
+    dim3 grid(total_tiles, pc.mtiles / mt);
     char name[64];
-    snprintf(name, sizeof(name), "conv_mfma_kernel<%d,%d,%d,%s>", KH, KW, pc.c8 ? 1 : mt, pc.c8 ? "true" : "false");
-    ProfScope ps(m, name, flops);
-    if (pc.c8) {
-        // Cin == 8 always comes with a single m-tile per block here (cout 8 or 16)
-        dim3 g1(grid_xy.x, grid_xy.y, pc.mtiles);
-        hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, true>), g1, dim3(256), 0, s, a);
-        return;
-    }
-    if (mt == 4) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 4, false>), grid, dim3(256), 0, s, a);
+    snprintf(name, sizeof(name), "conv_mfma_kernel<%d,%d,%d,%s>", KH, KW, mt, pc.c8 ? "true" : "false");
+    std::string pname = name;
+    if (m->prof_detail) pname += " " + scope + " " + dims_of(in0) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
+    ProfScope ps(m, pname, flops);
+    hipStream_t s = m->stream;
+    if (pc.c8) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, true>), grid, dim3(256), 0, s, a);
+    else if (mt == 4) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 4, false>), grid, dim3(256), 0, s, a);
     else if (mt == 2) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 2, false>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false>), grid, dim3(256), 0, s, a);
 }
 
-// stride-1 SAME conv on the (optionally concatenated) inputs
-Tensor run_conv(asep_aru* m, const std::string& scope, const Tensor& in0, const Tensor* in1, bool relu_in,
-                bool relu_out, const Tensor* res) {
+// stride-1 SAME conv on the (optionally concatenated) inputs of every problem
+TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1, bool relu_in, bool relu_out,
+            const TL* res) {
     auto it = m->convs.find(scope);
     if (it == m->convs.end()) { set_error("internal: conv %s not packed", scope.c_str()); throw ArgError(); }
     const PackedConv& pc = it->second;
-    const int cin = in0.C + (in1 ? in1->C : 0);
+    const int cin = in0[0].C + (in1 ? (*in1)[0].C : 0);
     if (cin != pc.cin) {
         set_error("internal: conv %s expects Cin=%d, got %d", scope.c_str(), pc.cin, cin);
         throw ArgError();
     }
-    Tensor out = new_tensor(m, in0.H, in0.W, pc.cout);
-    ConvArgs a{};
-    a.in0 = in0.p; a.c0 = in0.C;
-    a.in1 = in1 ? in1->p : nullptr; a.c1 = in1 ? in1->C : 0;
-    a.wpk = (const f32x4*)pc.d_w; a.bias = pc.d_b; a.res = res ? res->p : nullptr; a.out = out.p;
-    a.H = in0.H; a.W = in0.W; a.Ho = in0.H; a.Wo = in0.W;
-    a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
-    a.relu_in = relu_in; a.relu_out = relu_out;
-    dim3 gxy(cdiv(in0.W, CONV_TW), cdiv(in0.H, CONV_TH));
-    if (pc.kh == 3 && pc.kw == 3) launch_conv_k<3, 3>(m, pc, a, gxy, m->stream);
-    else if (pc.kh == 4 && pc.kw == 4) launch_conv_k<4, 4>(m, pc, a, gxy, m->stream);
-    else { set_error("conv %s: unsupported kernel size %dx%d", scope.c_str(), pc.kh, pc.kw); throw ArgError(); }
+    if (!((pc.kh == 3 && pc.kw == 3) || (pc.kh == 4 && pc.kw == 4))) {
+        set_error("conv %s: unsupported kernel size %dx%d", scope.c_str(), pc.kh, pc.kw);
+        throw ArgError();
+    }
+    TL out;
+    for (const Tensor& t : in0) out.push_back(new_tensor(m, t.H, t.W, pc.cout));
+    for (size_t b0 = 0; b0 < in0.size(); b0 += MAXP) {
+        const size_t b1 = std::min(in0.size(), b0 + MAXP);
+        ConvArgs a{};
+        int tiles = 0;
+        double flops = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            ConvProb& p = a.p[i - b0];
+            p.in0 = in0[i].p; p.in1 = in1 ? (*in1)[i].p : nullptr; p.res = res ? (*res)[i].p : nullptr; p.out = out[i].p;
+            p.H = p.Ho = in0[i].H; p.W = p.Wo = in0[i].W;
+            p.tiles_x = cdiv(in0[i].W, CONV_TW);
+            p.tile_begin = tiles;
+            tiles += p.tiles_x * cdiv(in0[i].H, CONV_TH);
+            flops += 2.0 * in0[i].H * in0[i].W * pc.kh * pc.kw * (double)pc.cin * pc.cout;
+        }
+        a.nprob = (int)(b1 - b0);
+        a.c0 = in0[0].C; a.c1 = in1 ? (*in1)[0].C : 0;
+        a.wpk = (const f32x4*)pc.d_w; a.bias = pc.d_b;
+        a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
+        a.relu_in = relu_in; a.relu_out = relu_out;
+        TL sub(in0.begin() + b0, in0.begin() + b1);
+        if (pc.kh == 3) launch_conv_k<3, 3>(m, pc, a, tiles, flops, scope, sub);
+        else launch_conv_k<4, 4>(m, pc, a, tiles, flops, scope, sub);
+    }
     return out;
 }
 
-// conv2d_transpose 3x3 stride 2 SAME to the spatial size of `like` (ARU_v1.py:255-259)
-Tensor run_deconv(asep_aru* m, const std::string& scope, const Tensor& in, int Ho, int Wo, bool relu_out) {
+// conv2d_transpose 3x3 stride 2 SAME to the spatial sizes of `like` (ARU_v1.py:255-259)
+TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& like, bool relu_out) {
     auto it = m->convs.find(scope);
     if (it == m->convs.end()) { set_error("internal: deconv %s not packed", scope.c_str()); throw ArgError(); }
     const PackedConv& pc = it->second;
-    if (pc.kh != 3 || pc.kw != 3 || in.C != pc.cin) {
-        set_error("deconv %s: unsupported shape (k=%d, Cin %d vs %d)", scope.c_str(), pc.kh, pc.cin, in.C);
+    if (pc.kh != 3 || pc.kw != 3 || in[0].C != pc.cin) {
+        set_error("deconv %s: unsupported shape (k=%d, Cin %d vs %d)", scope.c_str(), pc.kh, pc.cin, in[0].C);
         throw ArgError();
     }
-    if (cdiv(Ho, 2) != in.H || cdiv(Wo, 2) != in.W) {
-        set_error("deconv %s: output %dx%d incompatible with input %dx%d", scope.c_str(), Ho, Wo, in.H, in.W);
-        throw ArgError();
+    TL out;
+    for (size_t i = 0; i < in.size(); ++i) {
+        if (cdiv(like[i].H, 2) != in[i].H || cdiv(like[i].W, 2) != in[i].W) {
+            set_error("deconv %s: output %dx%d incompatible with input %dx%d", scope.c_str(), like[i].H, like[i].W, in[i].H, in[i].W);
+            throw ArgError();
+        }
+        out.push_back(new_tensor(m, like[i].H, like[i].W, pc.cout));
     }
-    Tensor out = new_tensor(m, Ho, Wo, pc.cout);
-    ConvArgs a{};
-    a.in0 = in.p; a.c0 = in.C; a.in1 = nullptr; a.c1 = 0;
-    a.wpk = (const f32x4*)pc.d_w; a.bias = pc.d_b; a.res = nullptr; a.out = out.p;
-    a.H = in.H; a.W = in.W; a.Ho = Ho; a.Wo = Wo;
-    a.pbh = std::max((in.H - 1) * 2 + 3 - Ho, 0) / 2;
-    a.pbw = std::max((in.W - 1) * 2 + 3 - Wo, 0) / 2;
-    a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
-    a.relu_in = 0; a.relu_out = relu_out;
     const int mt = pc.mtiles % 2 == 0 ? 2 : 1;
-    dim3 grid(cdiv(in.W, DC_TW), cdiv(in.H, DC_TH), pc.mtiles / mt);
-    ProfScope ps(m, mt == 2 ? "deconv_mfma_kernel<2>" : "deconv_mfma_kernel<1>", 2.0 * in.H * in.W * 9.0 * pc.cin * pc.cout);
-    if (mt == 2) hipLaunchKernelGGL((deconv_mfma_kernel<2>), grid, dim3(256), 0, m->stream, a);
-    else hipLaunchKernelGGL((deconv_mfma_kernel<1>), grid, dim3(256), 0, m->stream, a);
+    for (size_t b0 = 0; b0 < in.size(); b0 += MAXP) {
+        const size_t b1 = std::min(in.size(), b0 + MAXP);
+        ConvArgs a{};
+        int tiles = 0;
+        double flops = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            ConvProb& p = a.p[i - b0];
+            p.in0 = in[i].p; p.in1 = nullptr; p.res = nullptr; p.out = out[i].p;
+            p.H = in[i].H; p.W = in[i].W; p.Ho = out[i].H; p.Wo = out[i].W;
+            p.pbh = std::max((in[i].H - 1) * 2 + 3 - out[i].H, 0) / 2;
+            p.pbw = std::max((in[i].W - 1) * 2 + 3 - out[i].W, 0) / 2;
+            p.tiles_x = cdiv(in[i].W, DC_TW);
+            p.tile_begin = tiles;
+            tiles += p.tiles_x * cdiv(in[i].H, DC_TH);
+            flops += 2.0 * in[i].H * in[i].W * 9.0 * pc.cin * pc.cout;
+        }
+        a.nprob = (int)(b1 - b0);
+        a.c0 = in[0].C; a.c1 = 0;
+        a.wpk = (const f32x4*)pc.d_w; a.bias = pc.d_b;
+        a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
+        a.relu_in = 0; a.relu_out = relu_out;
+        dim3 grid(tiles, pc.mtiles / mt);
+        std::string dname = mt == 2 ? "deconv_mfma_kernel<2>" : "deconv_mfma_kernel<1>";
+        TL sub(in.begin() + b0, in.begin() + b1);
+        if (m->prof_detail) dname += " " + scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
+        ProfScope ps(m, dname, flops);
+        if (mt == 2) hipLaunchKernelGGL((deconv_mfma_kernel<2>), grid, dim3(256), 0, m->stream, a);
+        else hipLaunchKernelGGL((deconv_mfma_kernel<1>), grid, dim3(256), 0, m->stream, a);
+    }
     return out;
 }
 
-Tensor run_direct(asep_aru* m, const DirectConv& dc, const Tensor& img, bool relu, const float* stats) {
-    Tensor out = new_tensor(m, img.H, img.W, dc.cout);
-    dim3 grid(cdiv(img.W, 64), cdiv(img.H, 4));
-    ProfScope ps(m, "conv_c1_kernel<" + std::to_string(dc.k) + "," + std::to_string(dc.cout) + ">",
-                 2.0 * img.H * img.W * dc.k * dc.k * dc.cout);
-#define ASEP_C1(K, CO)                                                                               \
-    if (dc.k == K && dc.cout == CO) {                                                                \
-        hipLaunchKernelGGL((conv_c1_kernel<K, CO>), grid, dim3(256), 0, m->stream, img.p, img.H, img.W, \
-                           dc.d_w, dc.d_b, out.p, relu ? 1 : 0, stats);                                 \
-        return out;                                                                                  \
+// first layer (Cin == 1); stats[i] = per-problem {mean, 1/std} pointer or nullptr
+TL run_direct(asep_aru* m, const DirectConv& dc, const TL& imgs, bool relu, const std::vector<const float*>& stats) {
+    TL out;
+    for (const Tensor& t : imgs) out.push_back(new_tensor(m, t.H, t.W, dc.cout));
+    for (size_t b0 = 0; b0 < imgs.size(); b0 += MAXP) {
+        const size_t b1 = std::min(imgs.size(), b0 + MAXP);
+        C1Args a{};
+        int tiles = 0;
+        double flops = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            C1Prob& p = a.p[i - b0];
+            p.img = imgs[i].p; p.out = out[i].p; p.stats = stats.empty() ? nullptr : stats[i];
+            p.H = imgs[i].H; p.W = imgs[i].W;
+            p.tiles_x = cdiv(imgs[i].W, 64);
+            p.tile_begin = tiles;
+            tiles += p.tiles_x * cdiv(imgs[i].H, 4);
+            flops += 2.0 * imgs[i].H * imgs[i].W * dc.k * dc.k * dc.cout;
+        }
+        a.nprob = (int)(b1 - b0);
+        a.w = dc.d_w; a.bias = dc.d_b; a.relu = relu ? 1 : 0;
+        ProfScope ps(m, "conv_c1_kernel<" + std::to_string(dc.k) + "," + std::to_string(dc.cout) + ">", flops);
+        dim3 grid(tiles);
+        if (dc.k == 3 && dc.cout == 8) hipLaunchKernelGGL((conv_c1_kernel<3, 8>), grid, dim3(256), 0, m->stream, a);
+        else if (dc.k == 3 && dc.cout == 16) hipLaunchKernelGGL((conv_c1_kernel<3, 16>), grid, dim3(256), 0, m->stream, a);
+        else if (dc.k == 4 && dc.cout == 12) hipLaunchKernelGGL((conv_c1_kernel<4, 12>), grid, dim3(256), 0, m->stream, a);
+        else { set_error("first-layer conv k=%d cout=%d not instantiated", dc.k, dc.cout); throw ArgError(); }
     }
-    ASEP_C1(3, 8) ASEP_C1(3, 16) ASEP_C1(4, 12)
-#undef ASEP_C1
-    set_error("first-layer conv k=%d cout=%d not instantiated", dc.k, dc.cout);
-    throw ArgError();
+    return out;
+}
+
+enum PoolKind { POOL_MAX, POOL_AVG_C1, POOL_CHANSUM };
+
+TL run_pool(asep_aru* m, const TL& in, PoolKind kind) {
+    TL out;
+    for (const Tensor& t : in) {
+        if (kind == POOL_CHANSUM) out.push_back(new_tensor(m, t.H, t.W, 1));
+        else out.push_back(new_tensor(m, cdiv(t.H, 2), cdiv(t.W, 2), t.C));
+    }
+    for (size_t b0 = 0; b0 < in.size(); b0 += MAXP) {
+        const size_t b1 = std::min(in.size(), b0 + MAXP);
+        PoolArgs a{};
+        int blocks = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            PoolProb& p = a.p[i - b0];
+            p.in = in[i].p; p.out = out[i].p; p.H = in[i].H; p.W = in[i].W; p.Ho = out[i].H; p.Wo = out[i].W;
+            p.blk_begin = blocks;
+            const size_t items = kind == POOL_MAX ? out[i].count() / 4 : (size_t)out[i].H * out[i].W;
+            blocks += (int)((items + POOL_ITEMS - 1) / POOL_ITEMS);
+        }
+        a.nprob = (int)(b1 - b0);
+        a.C = in[0].C;
+        ProfScope ps(m, kind == POOL_MAX ? "maxpool2_kernel" : (kind == POOL_AVG_C1 ? "avgpool2_c1_kernel" : "chansum_kernel"), 0.0);
+        if (kind == POOL_MAX) hipLaunchKernelGGL(maxpool2_kernel, dim3(blocks), dim3(256), 0, m->stream, a);
+        else if (kind == POOL_AVG_C1) hipLaunchKernelGGL(avgpool2_c1_kernel, dim3(blocks), dim3(256), 0, m->stream, a);
+        else hipLaunchKernelGGL(chansum_kernel, dim3(blocks), dim3(256), 0, m->stream, a);
+    }
+    return out;
 }
 
 int grid_1d(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); }
 
-Tensor run_maxpool(asep_aru* m, const Tensor& in) {
-    Tensor out = new_tensor(m, cdiv(in.H, 2), cdiv(in.W, 2), in.C);
-    ProfScope ps(m, "maxpool2_kernel", 0.0);
-    hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_1d(out.count() / 4)), dim3(256), 0, m->stream, in.p, in.H, in.W,
-                       in.C, out.p, out.H, out.W);
-    return out;
-}
-
-Tensor run_avgpool_c1(asep_aru* m, const Tensor& in) {
-    Tensor out = new_tensor(m, cdiv(in.H, 2), cdiv(in.W, 2), 1);
-    hipLaunchKernelGGL(avgpool2_c1_kernel, dim3(grid_1d(out.count())), dim3(256), 0, m->stream, in.p, in.H, in.W,
-                       out.p, out.H, out.W);
-    return out;
-}
-
-// ---- network schedule (ARU_v1.py) ---------------------------------------------------------------
+// ---- network schedule (ARU_v1.py), evaluated for all problems in lock step ---------------------------------
 // residual block: conv1 (identity) -> t ; relu ; (res_depth-1) x conv+relu ; conv (identity) ; +t ; relu
-Tensor res_block_tail(asep_aru* m, const std::string& scope, const Tensor& t) {
-    Tensor r = t;
+TL res_block_tail(asep_aru* m, const std::string& scope, const TL& t) {
+    TL r = t;
     const int rd = m->cfg.res_depth;
     for (int i = 0; i < rd; ++i) {
         const bool last = (i == rd - 1);
@@ -326,105 +398,138 @@ Tensor res_block_tail(asep_aru* m, const std::string& scope, const Tensor& t) {
     return r;
 }
 
-Tensor det_cnn(asep_aru* m, const Tensor& img, int sc, const float* stats) {
+// names[i] = end-point prefix of problem i ("scale_<s>" for page 0, "p<b>/scale_<s>" otherwise)
+TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, const std::vector<const float*>& stats) {
     const int n = m->cfg.scale_space_num;
-    std::vector<Tensor> skips;
-    Tensor u = img;
+    std::vector<TL> skips;
+    TL u = imgs;
+    auto publish = [&](const TL& l, const std::string& suffix) {
+        for (size_t i = 0; i < l.size(); ++i) m->endpoints[names[i] + suffix] = l[i];
+    };
     for (int l = 0; l < n; ++l) {
         const std::string scope = "aru_net/featMapG/unet_down_" + std::to_string(l);
-        Tensor t = (l == 0) ? run_direct(m, m->det_first, img, false, stats)
-                            : run_conv(m, scope + "/conv1", u, nullptr, false, false, nullptr);
-        Tensor d = res_block_tail(m, scope, t);
+        TL t = (l == 0) ? run_direct(m, m->det_first, imgs, false, stats)
+                        : run_conv(m, scope + "/conv1", u, nullptr, false, false, nullptr);
+        TL d = res_block_tail(m, scope, t);
         skips.push_back(d);
-        m->endpoints["scale_" + std::to_string(sc) + "_unet_down_" + std::to_string(l) + "_conv"] = d;
-        u = (l < n - 1) ? run_maxpool(m, d) : d;
+        publish(d, "_unet_down_" + std::to_string(l) + "_conv");
+        u = (l < n - 1) ? run_pool(m, d, POOL_MAX) : d;
     }
     for (int l = n - 2; l >= 0; --l) {
         const std::string scope = "aru_net/featMapG/unet_up_" + std::to_string(l);
-        const Tensor& skip = skips[l];
-        Tensor v = run_deconv(m, scope + "/deconv", u, skip.H, skip.W, true);
-        m->endpoints["scale_" + std::to_string(sc) + "_unet_up_" + std::to_string(l) + "_deconv"] = v;
-        Tensor t = run_conv(m, scope + "/conv1", skip, &v, false, false, nullptr);   // concat [skip, deconv]
+        const TL& skip = skips[l];
+        TL v = run_deconv(m, scope + "/deconv", u, skip, true);
+        publish(v, "_unet_up_" + std::to_string(l) + "_deconv");
+        TL t = run_conv(m, scope + "/conv1", skip, &v, false, false, nullptr);   // concat [skip, deconv]
         u = res_block_tail(m, scope, t);
-        m->endpoints["scale_" + std::to_string(sc) + "_unet_up_" + std::to_string(l) + "_conv"] = u;
+        publish(u, "_unet_up_" + std::to_string(l) + "_conv");
     }
     return u;
 }
 
-Tensor att_cnn(asep_aru* m, const Tensor& img, const float* stats) {
+TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) {
     const std::string p = "aru_net/attMapG/attPart/conv";
-    Tensor y = run_direct(m, m->att_first, img, true, stats);
-    y = run_maxpool(m, y);
+    TL y = run_direct(m, m->att_first, imgs, true, stats);
+    y = run_pool(m, y, POOL_MAX);
     y = run_conv(m, p + "2", y, nullptr, false, true, nullptr);
-    y = run_maxpool(m, y);
+    y = run_pool(m, y, POOL_MAX);
     y = run_conv(m, p + "3", y, nullptr, false, true, nullptr);
-    y = run_maxpool(m, y);
+    y = run_pool(m, y, POOL_MAX);
     y = run_conv(m, p + "4", y, nullptr, false, true, nullptr);
     return y;
 }
 
-int forward_impl(asep_aru* m, const float* d_img, int H, int W, float* d_out, uint8_t* d_u8, uint8_t* d_mask,
-                 float threshold, hipStream_t stream) {
+// B pages of identical size through the net; problems = pages x scales
+int forward_impl(asep_aru* m, int B, const float* const* d_imgs, int H, int W, float* const* d_outs,
+                 uint8_t* const* d_u8s, uint8_t* const* d_masks, float threshold, hipStream_t stream) {
     const asep_aru_cfg& cfg = m->cfg;
     m->stream = stream;
     m->pool.begin();
     m->endpoints.clear();
     try {
-        Tensor img;
-        img.p = const_cast<float*>(d_img);
-        img.H = H; img.W = W; img.C = 1;
-        const float* stats = nullptr;
-        if (cfg.mvn) {
-            ASEP_HIP_CHECK(hipMemsetAsync(m->d_sums, 0, 2 * sizeof(double), stream));
-            hipLaunchKernelGGL(moments_kernel, dim3(grid_1d(img.count())), dim3(256), 0, stream, img.p, img.count(),
-                               m->d_sums);
-            hipLaunchKernelGGL(moments_finish_kernel, dim3(1), dim3(1), 0, stream, m->d_sums, img.count(), m->d_stats);
-            stats = m->d_stats;
-        }
         const int nsc = cfg.use_attention ? cfg.num_scales_att : 1;
         if (nsc > MAX_SCALES) { set_error("num_scales_att %d > %d", nsc, MAX_SCALES); return ASEP_ERR_UNSUPPORTED; }
-        // image pyramid.  With mvn the pyramid is built from the standardised image; avg-pooling commutes
-        // with the affine map, so scales >= 1 standardise on load with the same statistics.
-        std::vector<Tensor> scales{img};
-        for (int s = 1; s < nsc; ++s) scales.push_back(run_avgpool_c1(m, scales.back()));
-
-        CombineArgs ca{};
-        ca.nsc = nsc; ca.H = H; ca.W = W;
-        if (cfg.use_attention) {
-            int up = 8;
+        // problem order: page-major, scale-minor
+        TL level0;
+        std::vector<const float*> stats0;
+        for (int b = 0; b < B; ++b) {
+            Tensor img;
+            img.p = const_cast<float*>(d_imgs[b]);
+            img.H = H; img.W = W; img.C = 1;
+            level0.push_back(img);
+            const float* st = nullptr;
+            if (cfg.mvn) {
+                double* sums = (double*)m->pool.get(2 * sizeof(double));
+                float* stt = (float*)m->pool.get(2 * sizeof(float));
+                ASEP_HIP_CHECK(hipMemsetAsync(sums, 0, 2 * sizeof(double), stream));
+                hipLaunchKernelGGL(moments_kernel, dim3(grid_1d(img.count())), dim3(256), 0, stream, img.p, img.count(), sums);
+                hipLaunchKernelGGL(moments_finish_kernel, dim3(1), dim3(1), 0, stream, sums, img.count(), stt);
+                st = stt;
+            }
+            stats0.push_back(st);
+        }
+        // image pyramid.  With mvn the pyramid is built from the standardised image; avg-pooling commutes with
+        // the affine map, so scales >= 1 standardise on load with the page's statistics.
+        std::vector<TL> pyr{level0};
+        for (int s = 1; s < nsc; ++s) pyr.push_back(run_pool(m, pyr.back(), POOL_AVG_C1));
+        TL all;
+        std::vector<std::string> names;
+        std::vector<const float*> stats;
+        for (int b = 0; b < B; ++b)
             for (int s = 0; s < nsc; ++s) {
-                Tensor a = att_cnn(m, scales[s], stats);
-                m->endpoints["att_" + std::to_string(s)] = a;
+                all.push_back(pyr[s][b]);
+                names.push_back((b ? "p" + std::to_string(b) + "/" : std::string()) + "scale_" + std::to_string(s));
+                stats.push_back(stats0[b]);
+            }
+        if (!cfg.mvn) stats.clear();
+
+        TL att;
+        if (cfg.use_attention) {
+            att = att_cnn(m, all, stats);
+            for (size_t i = 0; i < att.size(); ++i)
+                m->endpoints[(i / nsc ? "p" + std::to_string(i / nsc) + "/" : std::string()) + "att_" + std::to_string(i % nsc)] = att[i];
+        }
+        TL feat = det_cnn(m, all, names, stats);
+        TL fsum;
+        if (nsc > 1) {
+            TL coarse;
+            for (int b = 0; b < B; ++b)
+                for (int s = 1; s < nsc; ++s) coarse.push_back(feat[b * nsc + s]);
+            fsum = run_pool(m, coarse, POOL_CHANSUM);
+        }
+        for (int b = 0; b < B; ++b) {
+            CombineArgs ca{};
+            ca.nsc = nsc; ca.H = H; ca.W = W;
+            ca.f0 = feat[b * nsc].p;
+            int up = 8;
+            for (int s = 0; s < nsc && cfg.use_attention; ++s) {
+                const Tensor& a = att[b * nsc + s];
                 if (cdiv(H, up) != a.H || cdiv(W, up) != a.W) { set_error("internal: attention map shape"); return ASEP_ERR_ARG; }
                 ca.att[s] = a.p; ca.ah[s] = a.H; ca.aw[s] = a.W; ca.aup[s] = up;
                 ca.aph[s] = (a.H * up - H) / 2; ca.apw[s] = (a.W * up - W) / 2;
                 up *= 2;
             }
-        }
-        Tensor f0 = det_cnn(m, scales[0], 0, stats);
-        ca.f0 = f0.p;
-        int up = 1;
-        for (int s = 1; s < nsc; ++s) {
-            Tensor f = det_cnn(m, scales[s], s, stats);
-            up *= 2;
-            Tensor fs = new_tensor(m, f.H, f.W, 1);
-            hipLaunchKernelGGL(chansum_kernel, dim3(grid_1d(fs.count())), dim3(256), 0, stream, f.p, fs.count(), f.C, fs.p);
-            ca.fsum[s] = fs.p; ca.fh[s] = f.H; ca.fw[s] = f.W; ca.fup[s] = up;
-            ca.fph[s] = (f.H * up - H) / 2; ca.fpw[s] = (f.W * up - W) / 2;
-        }
-        ca.wl = m->d_logit_w; ca.bl = m->d_logit_b;
-        ca.out = d_out; ca.out_u8 = d_u8; ca.out_mask = d_mask;
-        ca.thr255 = (double)threshold * 255.0;
-        ca.softmax = cfg.apply_softmax;
-        dim3 grid(cdiv(W, 16), cdiv(H, 16));
-        ProfScope ps(m, "combine_kernel", 2.0 * H * W * 16.0 * cfg.feat_root * cfg.n_classes);
+            up = 1;
+            for (int s = 1; s < nsc; ++s) {
+                const Tensor& f = feat[b * nsc + s];
+                up *= 2;
+                ca.fsum[s] = fsum[b * (nsc - 1) + (s - 1)].p; ca.fh[s] = f.H; ca.fw[s] = f.W; ca.fup[s] = up;
+                ca.fph[s] = (f.H * up - H) / 2; ca.fpw[s] = (f.W * up - W) / 2;
+            }
+            ca.wl = m->d_logit_w; ca.bl = m->d_logit_b;
+            ca.out = d_outs[b]; ca.out_u8 = d_u8s ? d_u8s[b] : nullptr; ca.out_mask = d_masks ? d_masks[b] : nullptr;
+            ca.thr255 = (double)threshold * 255.0;
+            ca.softmax = cfg.apply_softmax;
+            dim3 grid(cdiv(W, 16), cdiv(H, 16));
+            ProfScope ps(m, "combine_kernel", 2.0 * H * W * 16.0 * cfg.feat_root * cfg.n_classes);
 #define ASEP_COMB(FR, NC)                                                                          \
     if (cfg.feat_root == FR && cfg.n_classes == NC) {                                              \
         hipLaunchKernelGGL((combine_kernel<FR, NC>), grid, dim3(256), 0, stream, ca);              \
     } else
-        ASEP_COMB(8, 1) ASEP_COMB(8, 2) ASEP_COMB(8, 3) ASEP_COMB(8, 4) ASEP_COMB(16, 2)
-        { set_error("combine: feat_root=%d n_classes=%d not instantiated", cfg.feat_root, cfg.n_classes); return ASEP_ERR_UNSUPPORTED; }
+            ASEP_COMB(8, 1) ASEP_COMB(8, 2) ASEP_COMB(8, 3) ASEP_COMB(8, 4) ASEP_COMB(16, 2)
+            { set_error("combine: feat_root=%d n_classes=%d not instantiated", cfg.feat_root, cfg.n_classes); return ASEP_ERR_UNSUPPORTED; }
 #undef ASEP_COMB
+        }
         ASEP_HIP_CHECK(hipGetLastError());
     } catch (const HipError&) {
         return ASEP_ERR_HIP;
@@ -541,7 +646,19 @@ void asep_aru_free(asep_aru* m) { delete m; }
 int asep_aru_forward_dev(asep_aru* m, const float* d_img, int H, int W, float* d_out, uint8_t* d_out_u8,
                          uint8_t* d_out_mask, float threshold, void* stream) {
     if (!m || !d_img || !d_out || H < 1 || W < 1) { set_error("asep_aru_forward_dev: bad argument"); return ASEP_ERR_ARG; }
-    return forward_impl(m, d_img, H, W, d_out, d_out_u8, d_out_mask, threshold, (hipStream_t)stream);
+    return forward_impl(m, 1, &d_img, H, W, &d_out, d_out_u8 ? &d_out_u8 : nullptr, d_out_mask ? &d_out_mask : nullptr,
+                        threshold, (hipStream_t)stream);
+}
+
+int asep_aru_forward_batch_dev(asep_aru* m, int n_pages, const float* const* d_imgs, int H, int W, float* const* d_outs,
+                               uint8_t* const* d_out_u8, uint8_t* const* d_out_mask, float threshold, void* stream) {
+    if (!m || !d_imgs || !d_outs || n_pages < 1 || H < 1 || W < 1) { set_error("asep_aru_forward_batch_dev: bad argument"); return ASEP_ERR_ARG; }
+    for (int b = 0; b < n_pages; ++b)
+        if (!d_imgs[b] || !d_outs[b] || (d_out_u8 && !d_out_u8[b]) || (d_out_mask && !d_out_mask[b])) {
+            set_error("asep_aru_forward_batch_dev: null page pointer at %d", b);
+            return ASEP_ERR_ARG;
+        }
+    return forward_impl(m, n_pages, d_imgs, H, W, d_outs, d_out_u8, d_out_mask, threshold, (hipStream_t)stream);
 }
 
 int asep_aru_forward(asep_aru* m, const float* img_hw, int H, int W, float* out_hwc, uint8_t* out_u8,
@@ -571,7 +688,7 @@ int asep_aru_forward(asep_aru* m, const float* img_hw, int H, int W, float* out_
     if (out_u8) ASEP_TRY(hipMalloc((void**)&d_u8, nout));
     if (out_mask) ASEP_TRY(hipMalloc((void**)&d_mask, nout));
     ASEP_TRY(hipMemcpy(d_img, img_hw, npix * sizeof(float), hipMemcpyHostToDevice));
-    rc = forward_impl(m, d_img, H, W, d_out, d_u8, d_mask, threshold, nullptr);
+    rc = asep_aru_forward_dev(m, d_img, H, W, d_out, d_u8, d_mask, threshold, nullptr);
     if (rc) { cleanup(); return rc; }
     ASEP_TRY(hipStreamSynchronize(nullptr));
     ASEP_TRY(hipMemcpy(out_hwc, d_out, nout * sizeof(float), hipMemcpyDeviceToHost));
@@ -598,7 +715,8 @@ long asep_aru_get_endpoint(asep_aru* m, const char* name, float* out, size_t max
 int asep_aru_profile(asep_aru* m, int enable) {
     if (!m) { set_error("asep_aru_profile: null handle"); return ASEP_ERR_ARG; }
     m->profiling = enable != 0;
-    if (enable) { m->prof_recs.clear(); m->ev_next = 0; }
+    m->prof_detail = enable == 2;
+    if (enable) { m->prof_recs.clear(); m->ev_next = 0; m->prof_names.clear(); }
     return ASEP_OK;
 }
 
@@ -616,7 +734,7 @@ long asep_aru_profile_report(asep_aru* m, char* buf, size_t buflen) {
     std::string js = "[";
     for (size_t i = 0; i < nk; ++i) {
         if (!calls[i]) continue;
-        char line[256];
+        char line[512];
         snprintf(line, sizeof(line), "%s{\"kernel\":\"%s\",\"calls\":%ld,\"total_ms\":%.6f,\"flops\":%.6e}",
                  js.size() > 1 ? "," : "", m->prof_names[i].c_str(), calls[i], ms[i], fl[i]);
         js += line;

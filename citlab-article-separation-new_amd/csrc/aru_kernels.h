@@ -25,17 +25,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //     C8  mode: chunk = tap pair (Cin == 8)                  slot -> tap 2c + (s>>3), channel s&7
 // One lane's 16-byte LDS read / 16-byte weight load therefore feeds four MFMAs.
 // ------------------------------------------------------------------------------------------------
-struct ConvArgs {
+// One launch covers the same layer of several independent "problems" (pages x scale-space levels share
+// the layer's weights): blockIdx.x walks the concatenated tile lists, blockIdx.y the output-channel blocks.
+constexpr int MAXP = 12;
+struct ConvProb {
     const float* in0;      // source 0, NHWC with c0 channels
     const float* in1;      // source 1 (channel concat behind source 0) or nullptr
-    const f32x4* wpk;      // packed weights [chunk][mtile][lane] x 4 floats
-    const float* bias;     // [cout]
     const float* res;      // residual NHWC [Ho,Wo,cout] added before the output activation, or nullptr
     float* out;            // NHWC [Ho,Wo,cout]
-    int c0, c1;
     int H, W;              // input spatial size
     int Ho, Wo;            // output spatial size (== H, W for stride-1 conv)
+    int tiles_x;           // tiles per row of this problem
+    int tile_begin;        // first blockIdx.x of this problem
     int pbh, pbw;          // deconv: pad_before (rows, cols)
+};
+struct ConvArgs {
+    ConvProb p[MAXP];
+    int nprob;
+    const f32x4* wpk;      // packed weights [chunk][mtile][lane] x 4 floats
+    const float* bias;     // [cout]
+    int c0, c1;
     int cout;              // real output channels (store bound)
     int mtiles;            // number of 16-channel output tiles in wpk
     int groups;            // number of 16-channel input groups (C16 mode)
@@ -47,6 +56,14 @@ constexpr int CONV_TH = 8;
 constexpr int CONV_TW = 32;
 constexpr int CONV_NT = 4;     // n-tiles (16 pixels each) per wave; 4 waves -> 256 pixels per block
 
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    return v;
+}
+
+// Software pipeline: the halo tile of channel group g+1 is fetched into registers while group g is multiplied
+// out of LDS (two LDS buffers, one barrier per group); the weight fragments of tap t+1 are requested before the
+// MFMAs of tap t are issued.
 template <int KH, int KW, int MT, bool C8>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int TH = CONV_TH, TW = CONV_TW, NT = CONV_NT;
@@ -54,11 +71,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int CPP = C8 ? 8 : 16;                    // channels per pixel held in LDS
     constexpr int PT = (KH - 1) / 2, PL = (KW - 1) / 2;  // TF SAME: pad_before = (k-1)/2
     constexpr int TAPS = KH * KW;
-    __shared__ __attribute__((aligned(16))) float lds[LH * LW * CPP];
+    constexpr int SUBS = CPP / 4;
+    constexpr int NV = LH * LW * SUBS;                   // float4 slots of one halo tile
+    constexpr int NLOAD = (NV + 255) / 256;
+    constexpr int LBUF = LH * LW * CPP;
+    __shared__ __attribute__((aligned(16))) float lds[2 * LBUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, mt0 = blockIdx.z * MT;
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    const ConvProb& P = a.p[pi];
+    const int tile = blockIdx.x - P.tile_begin;
+    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH, mt0 = blockIdx.y * MT;
+    const int H = P.H, W = P.W;
+    const float* __restrict__ in0 = P.in0;
+    const float* __restrict__ in1 = P.in1;
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -73,101 +102,117 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         nbase[n] = ((id >> 1) * LW + (id & 1) * 16 + j) * CPP;
     }
 
-    const int ngroups = C8 ? 1 : a.groups;
-    for (int g = 0; g < ngroups; ++g) {
-        if (g > 0) __syncthreads();
-        // ---- stage the halo tile of channel group g (zero outside the image = SAME padding) ----
-        constexpr int SUBS = CPP / 4;
-        for (int idx = tid; idx < LH * LW * SUBS; idx += 256) {
+    f32x4 st[NLOAD];
+    auto stage_load = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int idx = tid + i * 256;
             const int pix = idx / SUBS, sub = idx - pix * SUBS;
             const int ly = pix / LW, lx = pix - ly * LW;
             const int gy = y0 - PT + ly, gx = x0 - PL + lx;
             const int c = g * 16 + sub * 4;
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                const size_t p = (size_t)gy * a.W + gx;
+            if (idx < NV && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const size_t p = (size_t)gy * W + gx;
                 if (c < a.c0)
-                    v = *reinterpret_cast<const f32x4*>(a.in0 + p * a.c0 + c);
+                    v = *reinterpret_cast<const f32x4*>(in0 + p * a.c0 + c);
                 else if (c - a.c0 < a.c1)
-                    v = *reinterpret_cast<const f32x4*>(a.in1 + p * a.c1 + (c - a.c0));
+                    v = *reinterpret_cast<const f32x4*>(in1 + p * a.c1 + (c - a.c0));
             }
-            if (a.relu_in) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
-            *reinterpret_cast<f32x4*>(lds + pix * CPP + sub * 4) = v;
+            st[i] = v;
         }
-        __syncthreads();
-
-        if constexpr (!C8) {
-            const f32x4* wg = a.wpk + ((size_t)g * TAPS * a.mtiles + mt0) * 64 + lane;
+    };
+    auto stage_store = [&](int buf) {
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                const int ky = tap / KW, kx = tap % KW;
-                f32x4 af[MT], bf[NT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) af[m] = wg[((size_t)tap * a.mtiles + m) * 64];
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    bf[n] = *reinterpret_cast<const f32x4*>(lds + nbase[n] + (ky * LW + kx) * 16 + kk * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int n = 0; n < NT; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][r], bf[n][r], acc[m][n], 0, 0, 0);
+        for (int i = 0; i < NLOAD; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < NV) {
+                f32x4 v = st[i];
+                if (a.relu_in) v = relu4(v);
+                *reinterpret_cast<f32x4*>(lds + buf * LBUF + idx * 4) = v;   // idx*4 == pix*CPP + sub*4
             }
-        } else {
-            constexpr int NCH = (TAPS + 1) / 2;
-            const f32x4* wg = a.wpk + (size_t)mt0 * 64 + lane;
+        }
+    };
+
+    const int ngroups = C8 ? 1 : a.groups;
+    constexpr int CPG = C8 ? (TAPS + 1) / 2 : TAPS;       // K chunks per channel group
+    const int nchunks = ngroups * CPG;
+    const f32x4* __restrict__ wbase = a.wpk + (size_t)mt0 * 64 + lane;
+    const size_t wstride = (size_t)a.mtiles * 64;          // f32x4 elements per chunk
+
+    stage_load(0);
+    f32x4 af[MT];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                int tap = 2 * c + (kk >> 1);
+    for (int m = 0; m < MT; ++m) af[m] = wbase[(size_t)m * 64];
+    stage_store(0);
+    __syncthreads();
+
+    for (int g = 0; g < ngroups; ++g) {
+        const float* __restrict__ lb = lds + (g & 1) * LBUF;
+        if (g + 1 < ngroups) stage_load(g + 1);
+#pragma unroll
+        for (int t = 0; t < CPG; ++t) {
+            const int chunk = g * CPG + t;
+            f32x4 an[MT];
+            if (chunk + 1 < nchunks) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) an[m] = wbase[(size_t)(chunk + 1) * wstride + (size_t)m * 64];
+            } else {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) an[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            int toff;
+            if constexpr (!C8) {
+                const int ky = t / KW, kx = t % KW;
+                toff = (ky * LW + kx) * 16 + kk * 4;
+            } else {
+                int tap = 2 * t + (kk >> 1);
                 tap = tap < TAPS ? tap : TAPS - 1;       // padded slot: weights are zero, data must be finite
                 const int ky = tap / KW, kx = tap - ky * KW;
-                const int toff = (ky * LW + kx) * 8 + (kk & 1) * 4;
-                f32x4 af[MT], bf[NT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) af[m] = wg[((size_t)c * a.mtiles + m) * 64];
-#pragma unroll
-                for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const f32x4*>(lds + nbase[n] + toff);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int n = 0; n < NT; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][r], bf[n][r], acc[m][n], 0, 0, 0);
+                toff = (ky * LW + kx) * 8 + (kk & 1) * 4;
             }
+            f32x4 bf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const f32x4*>(lb + nbase[n] + toff);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][r], bf[n][r], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[m] = an[m];
         }
+        if (g + 1 < ngroups) stage_store((g + 1) & 1);
+        __syncthreads();
     }
 
     // ---- epilogue: D layout col = lane&15 -> pixel, row = 4*(lane>>4)+reg -> output channel ----
+    float* __restrict__ out = P.out;
+    const float* __restrict__ res = P.res;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int id = wave * NT + n;
         const int y = y0 + (id >> 1), x = x0 + (id & 1) * 16 + j;
-        if (y >= a.Ho || x >= a.Wo) continue;
-        const size_t p = (size_t)y * a.Wo + x;
+        if (y >= P.Ho || x >= P.Wo) continue;
+        const size_t p = (size_t)y * P.Wo + x;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int c = (mt0 + m) * 16 + kk * 4;
             if (c >= a.cout) continue;
             f32x4 v = acc[m][n];
             if (c + 3 < a.cout) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + c);
-                v += b;
-                if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + p * a.cout + c);
-                if (a.relu_out) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-                *reinterpret_cast<f32x4*>(a.out + p * a.cout + c) = v;
+                v += *reinterpret_cast<const f32x4*>(a.bias + c);
+                if (res) v += *reinterpret_cast<const f32x4*>(res + p * a.cout + c);
+                if (a.relu_out) v = relu4(v);
+                *reinterpret_cast<f32x4*>(out + p * a.cout + c) = v;
             } else {
                 for (int r = 0; r < 4 && c + r < a.cout; ++r) {
                     float s = v[r] + a.bias[c + r];
-                    if (a.res) s += a.res[p * a.cout + c + r];
+                    if (res) s += res[p * a.cout + c + r];
                     if (a.relu_out) s = fmaxf(s, 0.f);
-                    a.out[p * a.cout + c + r] = s;
+                    out[p * a.cout + c + r] = s;
                 }
             }
         }
@@ -191,7 +236,12 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
-    const int qx0 = blockIdx.x * TW, qy0 = blockIdx.y * TH, mt0 = blockIdx.z * MT;
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    const ConvProb& P = a.p[pi];
+    const int tile = blockIdx.x - P.tile_begin;
+    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const int qx0 = tx * TW, qy0 = ty * TH, mt0 = blockIdx.y * MT;
 
     f32x4 acc[MT][NT][4];
 #pragma unroll
@@ -213,11 +263,9 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
             const int gy = qy0 - 1 + ly, gx = qx0 - 1 + lx;
             const int c = g * 16 + sub * 4;
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.c0)
-                v = *reinterpret_cast<const f32x4*>(a.in0 + ((size_t)gy * a.W + gx) * a.c0 + c);
-            if (a.relu_in) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
+            if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < a.c0)
+                v = *reinterpret_cast<const f32x4*>(P.in0 + ((size_t)gy * P.W + gx) * a.c0 + c);
+            if (a.relu_in) v = relu4(v);
             *reinterpret_cast<f32x4*>(lds + pix * 16 + sub * 4) = v;
         }
         __syncthreads();
@@ -231,14 +279,18 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
             bf[n][2] = *reinterpret_cast<const f32x4*>(lds + nbase[n] - LW * 16 + kk * 4);
             bf[n][3] = *reinterpret_cast<const f32x4*>(lds + nbase[n] - LW * 16 - 16 + kk * 4);
         }
+        f32x4 af[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = wg[(size_t)m * 64];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
             const int cls = (ky & 1) * 2 + (kx & 1);
             const int sh = (ky == 2 ? 2 : 0) + (kx == 2 ? 1 : 0);
-            f32x4 af[MT];
+            f32x4 an[MT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) af[m] = wg[((size_t)tap * a.mtiles + m) * 64];
+            for (int m = 0; m < MT; ++m)
+                an[m] = tap + 1 < 9 ? wg[((size_t)(tap + 1) * a.mtiles + m) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -247,6 +299,8 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
                     for (int n = 0; n < NT; ++n)
                         acc[m][n][cls] =
                             __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][r], bf[n][sh][r], acc[m][n][cls], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[m] = an[m];
         }
     }
 
@@ -255,9 +309,9 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
         const int qy = qy0 + wave * NT + n, qx = qx0 + j;
 #pragma unroll
         for (int cls = 0; cls < 4; ++cls) {
-            const int y = 2 * qy + (cls >> 1) - a.pbh, x = 2 * qx + (cls & 1) - a.pbw;
-            if (y < 0 || y >= a.Ho || x < 0 || x >= a.Wo) continue;
-            const size_t p = (size_t)y * a.Wo + x;
+            const int y = 2 * qy + (cls >> 1) - P.pbh, x = 2 * qx + (cls & 1) - P.pbw;
+            if (y < 0 || y >= P.Ho || x < 0 || x >= P.Wo) continue;
+            const size_t p = (size_t)y * P.Wo + x;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int c = (mt0 + m) * 16 + kk * 4;
@@ -265,15 +319,13 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
                 f32x4 v = acc[m][n][cls];
                 if (c + 3 < a.cout) {
                     v += *reinterpret_cast<const f32x4*>(a.bias + c);
-                    if (a.relu_out) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
-                    *reinterpret_cast<f32x4*>(a.out + p * a.cout + c) = v;
+                    if (a.relu_out) v = relu4(v);
+                    *reinterpret_cast<f32x4*>(P.out + p * a.cout + c) = v;
                 } else {
                     for (int r = 0; r < 4 && c + r < a.cout; ++r) {
                         float s = v[r] + a.bias[c + r];
                         if (a.relu_out) s = fmaxf(s, 0.f);
-                        a.out[p * a.cout + c + r] = s;
+                        P.out[p * a.cout + c + r] = s;
                     }
                 }
             }
@@ -285,22 +337,41 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
 // First layer (Cin == 1): direct KxK convolution, one thread per pixel, all COUT channels.
 // Optional per-image standardisation (layers.py:672-711): stats = {mean, 1/max(std,1e-4)}.
 // ------------------------------------------------------------------------------------------------
+struct C1Prob {
+    const float* img;      // [H,W] single channel
+    float* out;            // [H,W,COUT]
+    const float* stats;    // {mean, 1/std} or nullptr
+    int H, W;
+    int tiles_x;           // 64-pixel-wide, 4-row blocks per row
+    int tile_begin;
+};
+struct C1Args {
+    C1Prob p[MAXP];
+    int nprob;
+    const float* w;        // [K*K][COUT]
+    const float* bias;     // [COUT]
+    int relu;
+};
+
 template <int K, int COUT>
-__global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ img, int H, int W,
-                                                      const float* __restrict__ w,     // [K*K][COUT]
-                                                      const float* __restrict__ bias,  // [COUT]
-                                                      float* __restrict__ out, int relu,
-                                                      const float* __restrict__ stats) {
+__global__ __launch_bounds__(256) void conv_c1_kernel(const C1Args a) {
     __shared__ float sw[K * K * COUT + COUT];
-    for (int i = threadIdx.x; i < K * K * COUT; i += 256) sw[i] = w[i];
-    for (int i = threadIdx.x; i < COUT; i += 256) sw[K * K * COUT + i] = bias[i];
+    for (int i = threadIdx.x; i < K * K * COUT; i += 256) sw[i] = a.w[i];
+    for (int i = threadIdx.x; i < COUT; i += 256) sw[K * K * COUT + i] = a.bias[i];
     __syncthreads();
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    const C1Prob& P = a.p[pi];
+    const int tile = blockIdx.x - P.tile_begin;
+    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const int x = tx * 64 + (threadIdx.x & 63);
+    const int y = ty * 4 + (threadIdx.x >> 6);
+    const int H = P.H, W = P.W;
     if (x >= W || y >= H) return;
     constexpr int PB = (K - 1) / 2;
     float mean = 0.f, inv = 1.f;
-    if (stats) { mean = stats[0]; inv = stats[1]; }
+    if (P.stats) { mean = P.stats[0]; inv = P.stats[1]; }
+    const float* __restrict__ img = P.img;
     float acc[COUT];
 #pragma unroll
     for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
@@ -316,14 +387,14 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const float* __restrict__ 
             for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v, sw[(ky * K + kx) * COUT + c], acc[c]);
         }
     }
-    float* o = out + ((size_t)y * W + x) * COUT;
+    float* o = P.out + ((size_t)y * W + x) * COUT;
 #pragma unroll
     for (int c = 0; c < COUT; c += 4) {
         f32x4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float s = acc[c + r] + sw[K * K * COUT + c + r];
-            v[r] = relu ? fmaxf(s, 0.f) : s;
+            v[r] = a.relu ? fmaxf(s, 0.f) : s;
         }
         *reinterpret_cast<f32x4*>(o + c) = v;
     }
@@ -364,52 +435,84 @@ __global__ void moments_finish_kernel(const double* __restrict__ sums, size_t n,
 }
 
 // ------------------------------------------------------------------------------------------------
-// 2x2 / stride 2 / SAME pools (ceil mode, padding at the end only)
+// 2x2 / stride 2 / SAME pools (ceil mode, padding at the end only) and the channel sum, grouped over problems
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ in, int H, int W, int C,
-                                                       float* __restrict__ out, int Ho, int Wo) {
-    const int c4n = C >> 2;
-    const size_t total = (size_t)Ho * Wo * c4n;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+struct PoolProb {
+    const float* in;
+    float* out;
+    int H, W, Ho, Wo;
+    int blk_begin;         // first blockIdx.x of this problem; each block covers 1024 work items
+    int pad_;
+};
+struct PoolArgs {
+    PoolProb p[MAXP];
+    int nprob;
+    int C;
+};
+constexpr int POOL_ITEMS = 1024;
+
+__global__ __launch_bounds__(256) void maxpool2_kernel(const PoolArgs a) {
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].blk_begin) ++pi;
+    const PoolProb& P = a.p[pi];
+    const int C = a.C, c4n = C >> 2, H = P.H, W = P.W, Wo = P.Wo;
+    const size_t total = (size_t)P.Ho * Wo * c4n;
+    const float* __restrict__ in = P.in;
+    const size_t base = (size_t)(blockIdx.x - P.blk_begin) * POOL_ITEMS;
+    for (int k = 0; k < POOL_ITEMS / 256; ++k) {
+        const size_t i = base + k * 256 + threadIdx.x;
+        if (i >= total) break;
         const int c4 = (int)(i % c4n);
         const size_t p = i / c4n;
         const int x = (int)(p % Wo), y = (int)(p / Wo);
         const int y1 = 2 * y + 1 < H ? 2 * y + 1 : 2 * y, x1 = 2 * x + 1 < W ? 2 * x + 1 : 2 * x;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(in + ((size_t)(2 * y) * W + 2 * x) * C + c4 * 4);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(in + ((size_t)(2 * y) * W + x1) * C + c4 * 4);
-        const f32x4 c = *reinterpret_cast<const f32x4*>(in + ((size_t)y1 * W + 2 * x) * C + c4 * 4);
-        const f32x4 d = *reinterpret_cast<const f32x4*>(in + ((size_t)y1 * W + x1) * C + c4 * 4);
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(in + ((size_t)(2 * y) * W + 2 * x) * C + c4 * 4);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(in + ((size_t)(2 * y) * W + x1) * C + c4 * 4);
+        const f32x4 q2 = *reinterpret_cast<const f32x4*>(in + ((size_t)y1 * W + 2 * x) * C + c4 * 4);
+        const f32x4 q3 = *reinterpret_cast<const f32x4*>(in + ((size_t)y1 * W + x1) * C + c4 * 4);
         f32x4 m;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m[r] = fmaxf(fmaxf(a[r], b[r]), fmaxf(c[r], d[r]));
-        *reinterpret_cast<f32x4*>(out + p * C + c4 * 4) = m;
+        for (int r = 0; r < 4; ++r) m[r] = fmaxf(fmaxf(q0[r], q1[r]), fmaxf(q2[r], q3[r]));
+        *reinterpret_cast<f32x4*>(P.out + p * C + c4 * 4) = m;
     }
 }
 
 // single-channel average pool; divisor = number of valid elements (tf.nn.avg_pool2d SAME)
-__global__ __launch_bounds__(256) void avgpool2_c1_kernel(const float* __restrict__ in, int H, int W,
-                                                          float* __restrict__ out, int Ho, int Wo) {
-    const size_t total = (size_t)Ho * Wo;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+__global__ __launch_bounds__(256) void avgpool2_c1_kernel(const PoolArgs a) {
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].blk_begin) ++pi;
+    const PoolProb& P = a.p[pi];
+    const int H = P.H, W = P.W, Wo = P.Wo;
+    const size_t total = (size_t)P.Ho * Wo;
+    const size_t base = (size_t)(blockIdx.x - P.blk_begin) * POOL_ITEMS;
+    for (int k = 0; k < POOL_ITEMS / 256; ++k) {
+        const size_t i = base + k * 256 + threadIdx.x;
+        if (i >= total) break;
         const int x = (int)(i % Wo), y = (int)(i / Wo);
         float s = 0.f;
         int n = 0;
         for (int dy = 0; dy < 2; ++dy)
             for (int dx = 0; dx < 2; ++dx) {
                 const int yy = 2 * y + dy, xx = 2 * x + dx;
-                if (yy < H && xx < W) { s += in[(size_t)yy * W + xx]; ++n; }
+                if (yy < H && xx < W) { s += P.in[(size_t)yy * W + xx]; ++n; }
             }
-        out[i] = s / (float)n;
+        P.out[i] = s / (float)n;
     }
 }
 
 // channel sum [H,W,C] -> [H,W]  (the channel-summing half of upsample_simple, layers.py:716-720)
-__global__ __launch_bounds__(256) void chansum_kernel(const float* __restrict__ in, size_t npix, int C,
-                                                      float* __restrict__ out) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+__global__ __launch_bounds__(256) void chansum_kernel(const PoolArgs a) {
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].blk_begin) ++pi;
+    const PoolProb& P = a.p[pi];
+    const size_t total = (size_t)P.H * P.W;
+    const size_t base = (size_t)(blockIdx.x - P.blk_begin) * POOL_ITEMS;
+    for (int k = 0; k < POOL_ITEMS / 256; ++k) {
+        const size_t i = base + k * 256 + threadIdx.x;
+        if (i >= total) break;
         float s = 0.f;
-        for (int c = 0; c < C; ++c) s += in[i * C + c];
-        out[i] = s;
+        for (int c = 0; c < a.C; ++c) s += P.in[i * a.C + c];
+        P.out[i] = s;
     }
 }
 

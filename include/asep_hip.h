@@ -78,6 +78,14 @@ int asep_aru_forward_dev(asep_aru* m, const float* d_img, int H, int W,
                          float* d_out, uint8_t* d_out_u8, uint8_t* d_out_mask, float threshold,
                          void* stream);
 
+/* A batch of n_pages equally sized device-resident pages in one call (BASELINE configs[1]: "batch of
+ * 3000x4500 px full pages").  Every layer is launched once for all pages and scale-space levels, which keeps
+ * the coarse levels from under-filling the 256 CUs.  d_imgs / d_outs / d_out_u8 / d_out_mask are host arrays
+ * of n_pages device pointers (the u8 arrays themselves may be NULL). */
+int asep_aru_forward_batch_dev(asep_aru* m, int n_pages, const float* const* d_imgs, int H, int W,
+                               float* const* d_outs, uint8_t* const* d_out_u8, uint8_t* const* d_out_mask,
+                               float threshold, void* stream);
+
 /* Named intermediate tensors of the last forward (tests / GNN visual branch): copies the NHWC fp32
  * tensor `name` (e.g. "scale_0_unet_up_0_conv", ARU_v1.py:11-29 end-point names) to host.
  * Returns the number of floats written, or a negative error; dims receives {H, W, C}. */
