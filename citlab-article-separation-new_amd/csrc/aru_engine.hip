@@ -2,6 +2,7 @@
 // management and the layer schedule of ARU_v1.py:62-294.  Entry points: include/asep_hip.h.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 
 #include "aru_kernels.h"
@@ -25,6 +26,7 @@ struct PackedConv {
     int groups = 0, mtiles = 0, nchunks = 0;
     float* d_w = nullptr;
     float* d_b = nullptr;
+    float* d_wino = nullptr;   // Winograd F(2x2,3x3) transformed weights U = G g G^T, packed [g][pos][mtile][lane][4]
 };
 
 struct DirectConv {        // Cin == 1 first layers
@@ -56,6 +58,8 @@ struct asep_aru {
 
     // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
     struct ProfRec { int kid; double flops; hipEvent_t a, b; };
+    int wino_blocks = 512;         // resident Winograd blocks (256 CUs x 2); ASEP_WINO_BLOCKS overrides
+    bool use_winograd = true;      // ASEP_WINOGRAD=0 selects the direct implicit-GEMM kernels everywhere
     bool profiling = false;
     bool prof_detail = false;      // per-layer names (scope + spatial size) instead of per-kernel names
     std::vector<std::string> prof_names;
@@ -169,6 +173,26 @@ int pack_conv(asep_aru* m, const std::map<std::string, HostTensor>& blob, const 
     if (rc) return rc;
     m->owned.push_back(pc.d_w);
     m->owned.push_back(pc.d_b);
+    if (!deconv && pc.kh == 3 && pc.kw == 3 && pc.cin % 16 == 0 && pc.cout % 32 == 0) {
+        // U[a][b] = sum_ij G[a][i] g[i][j] G[b][j], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] (double accumulation)
+        static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        std::vector<float> wk((size_t)pc.groups * 16 * pc.mtiles * 64 * 4);
+        for (int g = 0; g < pc.groups; ++g)
+            for (int pos = 0; pos < 16; ++pos)
+                for (int mt = 0; mt < pc.mtiles; ++mt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int r = 0; r < 4; ++r) {
+                            const int ci = 16 * g + 4 * (lane >> 4) + r, co = mt * 16 + (lane & 15);
+                            const int ua = pos >> 2, ub = pos & 3;
+                            double u = 0;
+                            for (int i = 0; i < 3; ++i)
+                                for (int j2 = 0; j2 < 3; ++j2) u += G[ua][i] * (double)W(i * 3 + j2, ci, co) * G[ub][j2];
+                            wk[((((size_t)g * 16 + pos) * pc.mtiles + mt) * 64 + lane) * 4 + r] = (float)u;
+                        }
+        rc = upload(wk, &pc.d_wino);
+        if (rc) return rc;
+        m->owned.push_back(pc.d_wino);
+    }
     m->convs[scope] = pc;
     return ASEP_OK;
 }
@@ -268,7 +292,26 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
         a.relu_in = relu_in; a.relu_out = relu_out;
         TL sub(in0.begin() + b0, in0.begin() + b1);
-        if (pc.kh == 3) launch_conv_k<3, 3>(m, pc, a, tiles, flops, scope, sub);
+        if (pc.d_wino && m->use_winograd) {
+            a.wpk = (const f32x4*)pc.d_wino;
+            int wt = 0;
+            for (size_t i = b0; i < b1; ++i) {              // Winograd blocks are 4 x 32 output pixels
+                ConvProb& p = a.p[i - b0];
+                p.tiles_x = cdiv(in0[i].W, WINO_TW);
+                p.tile_begin = wt;
+                wt += p.tiles_x * cdiv(in0[i].H, WINO_TH);
+            }
+            const int mt = pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1);
+            a.total_tiles = wt;
+            const int ny = pc.mtiles / mt;
+            dim3 grid(wt, ny);
+            std::string pname = "conv_wino_kernel<" + std::to_string(mt) + ">";
+            if (m->prof_detail) pname += " " + scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
+            ProfScope ps(m, pname, flops);
+            if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4, false>), grid, dim3(256), 0, m->stream, a);
+            else if (mt == 2) hipLaunchKernelGGL((conv_wino_kernel<2, false>), grid, dim3(256), 0, m->stream, a);
+            else hipLaunchKernelGGL((conv_wino_kernel<1, false>), grid, dim3(256), 0, m->stream, a);
+        } else if (pc.kh == 3) launch_conv_k<3, 3>(m, pc, a, tiles, flops, scope, sub);
         else launch_conv_k<4, 4>(m, pc, a, tiles, flops, scope, sub);
     }
     return out;
@@ -598,6 +641,8 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (!parse_blob(weight_blob, nbytes, blob)) return nullptr;
     std::unique_ptr<asep_aru> m(new asep_aru());
     m->cfg = *cfg;
+    if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_WINO_BLOCKS")) m->wino_blocks = std::max(1, atoi(e));
     int rc = ASEP_OK;
     const int n = cfg->scale_space_num;
     if (cfg->use_attention) {

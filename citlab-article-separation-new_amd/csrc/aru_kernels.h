@@ -42,6 +42,7 @@ struct ConvProb {
 struct ConvArgs {
     ConvProb p[MAXP];
     int nprob;
+    int total_tiles;       // sum of the problems' tile counts (persistent kernels walk them with a grid stride)
     const f32x4* wpk;      // packed weights [chunk][mtile][lane] x 4 floats
     const float* bias;     // [cout]
     int c0, c1;
@@ -216,6 +217,219 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Winograd F(2x2,3x3) for the 3x3 stride-1 SAME convolutions with Cin % 16 == 0 and Cout % 16 == 0:
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A      per 4x4 input patch d -> 2x2 outputs,
+// i.e. 16 independent [Cout x Cin] x [Cin x tiles] products instead of 9 taps -> 2.25x fewer MFMA FLOPs, fp32.
+// One 256-thread block = 4 x 32 output pixels = 2 x 16 Winograd tiles, MT 16-channel output tiles.
+//   transform role : thread (tile, channel pair) loads its 4x4x2 patch straight from global memory one channel
+//                    group AHEAD (the loads fly during the MFMA phase), forms V = B^T d B and writes
+//                    V[pos][tile][16 ch] into the other LDS buffer (2 x 32 KB, one barrier per group);
+//   MFMA role      : wave w owns the 4 positions 4w..4w+3 for all 32 tiles: acc[4][MT][2 n-tiles];
+//                    A = packed U = G g G^T fragments from global (L2), B = V from LDS;
+//   output (once)  : accumulators are exchanged through the LDS image so that thread (tile, channel pair)
+//                    holds all 16 positions, applies A^T . A, bias / residual / ReLU, stores 2x2 pixels.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int WINO_TH = 4;
+constexpr int WINO_TW = 32;
+
+template <int MT, bool PERSIST>
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
+    constexpr int TH = WINO_TH, TW = WINO_TW;
+    constexpr int TILES = (TH / 2) * (TW / 2);            // 32 Winograd tiles
+    constexpr int VBUF = 16 * TILES * 16;                 // floats per V image (32 KB)
+    __shared__ __attribute__((aligned(16))) float V[2 * VBUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int mt0 = blockIdx.y * MT;
+    // transform role: tile tt (row-major in the 2 x 16 tile grid), channel pair cp (channels 2cp, 2cp+1 of the group)
+    const int tt = tid >> 3, cp = tid & 7;
+
+    // per-block-tile geometry (the block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... : persistent loop, so that
+    // the first patch of the next tile is fetched under the last MFMA phase and the stores drain under the next tile)
+    struct Geo { const float* in0; const float* in1; const float* res; float* out; int H, W, Ho, Wo, x0, y0; };
+    auto locate = [&](int tile_id) {
+        int pi = 0;
+        while (pi + 1 < a.nprob && tile_id >= a.p[pi + 1].tile_begin) ++pi;
+        const ConvProb& P = a.p[pi];
+        const int t = tile_id - P.tile_begin;
+        const int tyb = t / P.tiles_x, txb = t - tyb * P.tiles_x;
+        Geo g;
+        g.in0 = P.in0; g.in1 = P.in1; g.res = P.res; g.out = P.out;
+        g.H = P.H; g.W = P.W; g.Ho = P.Ho; g.Wo = P.Wo; g.x0 = txb * TW; g.y0 = tyb * TH;
+        return g;
+    };
+
+    f32x2 d[4][4];
+    auto patch_load = [&](const Geo& G, int g) {
+        const int c = g * 16 + cp * 2;
+        const float* __restrict__ src = c < a.c0 ? G.in0 + c : G.in1 + (c - a.c0);
+        const int cs = c < a.c0 ? a.c0 : a.c1;
+        const int py = G.y0 + 2 * (tt >> 4) - 1, px = G.x0 + 2 * (tt & 15) - 1;   // patch origin (SAME: pad 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int gy = py + r, gx = px + s;
+                f32x2 v = f32x2{0.f, 0.f};
+                if (gy >= 0 && gy < G.H && gx >= 0 && gx < G.W)
+                    v = *reinterpret_cast<const f32x2*>(src + ((size_t)gy * G.W + gx) * cs);
+                d[r][s] = v;
+            }
+    };
+    auto transform_store = [&](int buf) {
+        if (a.relu_in) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { d[r][s].x = fmaxf(d[r][s].x, 0.f); d[r][s].y = fmaxf(d[r][s].y, 0.f); }
+        }
+        f32x2 t[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            t[0][s] = d[0][s] - d[2][s];
+            t[1][s] = d[1][s] + d[2][s];
+            t[2][s] = d[2][s] - d[1][s];
+            t[3][s] = d[1][s] - d[3][s];
+        }
+        float* vb = V + buf * VBUF + tt * 16 + cp * 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            *reinterpret_cast<f32x2*>(vb + (r * 4 + 0) * TILES * 16) = t[r][0] - t[r][2];
+            *reinterpret_cast<f32x2*>(vb + (r * 4 + 1) * TILES * 16) = t[r][1] + t[r][2];
+            *reinterpret_cast<f32x2*>(vb + (r * 4 + 2) * TILES * 16) = t[r][2] - t[r][1];
+            *reinterpret_cast<f32x2*>(vb + (r * 4 + 3) * TILES * 16) = t[r][1] - t[r][3];
+        }
+    };
+
+    const f32x4* __restrict__ wbase = a.wpk + (size_t)mt0 * 64 + lane;
+    const size_t wstride = (size_t)a.mtiles * 64;          // f32x4 per (group, pos)
+    const int G = a.groups;
+
+    int tile_id = blockIdx.x;
+    if (tile_id >= a.total_tiles) return;
+    Geo cur = locate(tile_id);
+    patch_load(cur, 0);
+    f32x4 af[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) af[m] = wbase[((size_t)wave * 4) * wstride + (size_t)m * 64];
+
+    while (true) {
+        const int next_id = tile_id + gridDim.x;
+        const bool has_next = PERSIST && next_id < a.total_tiles;
+        Geo nxt = cur;
+        if (has_next) nxt = locate(next_id);
+
+        f32x4 acc[4][MT][2];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[p][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        transform_store(0);                                // V[0] is free: the epilogue of the previous tile ended with a barrier
+        __syncthreads();
+
+        for (int g = 0; g < G; ++g) {
+            const bool more = g + 1 < G;
+            if (more) patch_load(cur, g + 1);              // global loads in flight during the MFMA phase
+            else if (has_next) patch_load(nxt, 0);
+            // ---- MFMA phase: positions 4*wave .. 4*wave+3 of group g ---------------------------------------
+            const float* __restrict__ vcur = V + (g & 1) * VBUF;
+            const f32x4* __restrict__ wg = wbase + ((size_t)g * 16 + wave * 4) * wstride;
+            const f32x4* __restrict__ wnext = wbase + ((size_t)(more ? g + 1 : 0) * 16 + wave * 4) * wstride;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                f32x4 an[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    an[m] = p + 1 < 4 ? wg[(size_t)(p + 1) * wstride + (size_t)m * 64] : wnext[(size_t)m * 64];
+                const float* vb = vcur + ((wave * 4 + p) * TILES + j) * 16 + kk * 4;
+                f32x4 bf[2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) bf[n] = *reinterpret_cast<const f32x4*>(vb + n * 16 * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            acc[p][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][r], bf[n][r], acc[p][m][n], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) af[m] = an[m];
+                __builtin_amdgcn_sched_barrier(0);         // keep the scheduler from hoisting the next positions' loads (VGPR pressure)
+            }
+            if (more) transform_store((g + 1) & 1);        // the other buffer: last read in iteration g-1
+            __syncthreads();
+        }
+
+        // ---- output phase: exchange through LDS (two m-tiles per round), inverse transform, epilogue ---------
+        const int oy = cur.y0 + 2 * (tt >> 4), ox = cur.x0 + 2 * (tt & 15);
+        constexpr int ROUNDS = (MT + 1) / 2;
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int m = rd * 2 + h;
+                if (m < MT) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            *reinterpret_cast<f32x4*>(V + h * VBUF + ((wave * 4 + p) * TILES + n * 16 + j) * 16 + kk * 4) = acc[p][m][n];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int m = rd * 2 + h;
+                if (m >= MT) continue;
+                f32x2 M[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        M[r][s] = *reinterpret_cast<const f32x2*>(V + h * VBUF + ((r * 4 + s) * TILES + tt) * 16 + cp * 2);
+                f32x2 s0[4], s1[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    s0[s] = M[0][s] + M[1][s] + M[2][s];
+                    s1[s] = M[1][s] - M[2][s] - M[3][s];
+                }
+                f32x2 y[2][2];
+                y[0][0] = s0[0] + s0[1] + s0[2];
+                y[0][1] = s0[1] - s0[2] - s0[3];
+                y[1][0] = s1[0] + s1[1] + s1[2];
+                y[1][1] = s1[1] - s1[2] - s1[3];
+                const int co = (mt0 + m) * 16 + cp * 2;
+                if (co < a.cout) {
+                    const f32x2 b = *reinterpret_cast<const f32x2*>(a.bias + co);
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int yy = oy + dy, xx = ox + dx;
+                            if (yy < cur.Ho && xx < cur.Wo) {
+                                const size_t p = (size_t)yy * cur.Wo + xx;
+                                f32x2 v = y[dy][dx] + b;
+                                if (cur.res) v += *reinterpret_cast<const f32x2*>(cur.res + p * a.cout + co);
+                                if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+                                *reinterpret_cast<f32x2*>(cur.out + p * a.cout + co) = v;
+                            }
+                        }
+                }
+            }
+            __syncthreads();                               // V may be rewritten (next round / next tile's transform)
+        }
+        if (!has_next) break;
+        tile_id = next_id;
+        cur = nxt;
     }
 }
 
