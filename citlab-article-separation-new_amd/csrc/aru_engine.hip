@@ -6,6 +6,7 @@
 #include <memory>
 
 #include "aru_kernels.h"
+#include "res8_kernels.h"
 #include "asep_common.h"
 
 using namespace asep;
@@ -47,6 +48,10 @@ struct asep_aru {
     asep_aru_cfg cfg{};
     std::map<std::string, PackedConv> convs;   // keyed by variable scope, e.g. "aru_net/featMapG/unet_down_1/convR_0"
     DirectConv det_first, att_first;
+    // fused level-0 residual blocks (feat_root == 8, res_depth == 3): pixel-pair MFMA fragments
+    float* d_r8_down_wr = nullptr;   // [3][6][64][4]
+    float* d_r8_down_br = nullptr;   // [3][8]
+    bool use_fused8 = true;          // ASEP_FUSED8=0 falls back to the layer-by-layer kernels
     float* d_logit_w = nullptr;
     float* d_logit_b = nullptr;
     float* d_stats = nullptr;      // mvn {mean, 1/std}
@@ -58,6 +63,8 @@ struct asep_aru {
 
     // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
     struct ProfRec { int kid; double flops; hipEvent_t a, b; };
+    int num_cus = 256;
+    int persist_mt1 = 3, persist_mt2 = 2;   // resident blocks per CU assumed by the persistent conv grids
     int wino_blocks = 512;         // resident Winograd blocks (256 CUs x 2); ASEP_WINO_BLOCKS overrides
     bool use_winograd = true;      // ASEP_WINOGRAD=0 selects the direct implicit-GEMM kernels everywhere
     bool profiling = false;
@@ -287,6 +294,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             flops += 2.0 * in0[i].H * in0[i].W * pc.kh * pc.kw * (double)pc.cin * pc.cout;
         }
         a.nprob = (int)(b1 - b0);
+        a.total_tiles = tiles;
         a.c0 = in0[0].C; a.c1 = in1 ? (*in1)[0].C : 0;
         a.wpk = (const f32x4*)pc.d_w; a.bias = pc.d_b;
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
@@ -428,6 +436,77 @@ TL run_pool(asep_aru* m, const TL& in, PoolKind kind) {
 
 int grid_1d(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); }
 
+// pixel-pair A fragments of a 3x3 conv with 8 input channels starting at input channel ci0 of W[3][3][cin][8]:
+// rows = (pixel parity e, cout), chunk = (ky, h), slot s: kx' = 2h + (s>>3), ci = s&7, kx = kx' - e
+void pack_pair8(const HostTensor& w, int cin, int ci0, std::vector<float>& dst) {
+    for (int ky = 0; ky < 3; ++ky)
+        for (int h = 0; h < 2; ++h)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    const int row = lane & 15, kk = lane >> 4, s = 4 * kk + r;
+                    const int e = row >> 3, co = row & 7;
+                    const int kx = 2 * h + (s >> 3) - e, ci = s & 7;
+                    float v = 0.f;
+                    if (kx >= 0 && kx <= 2) v = w.data[(((size_t)ky * 3 + kx) * cin + ci0 + ci) * 8 + co];
+                    dst.push_back(v);
+                }
+}
+
+int pack_res8(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
+    const std::string s = "aru_net/featMapG/unet_down_0";
+    std::vector<float> wr, br;
+    for (int r = 0; r < 3; ++r) {
+        auto wi = blob.find(s + "/convR_" + std::to_string(r) + "/weights");
+        auto bi = blob.find(s + "/convR_" + std::to_string(r) + "/biases");
+        if (wi == blob.end() || bi == blob.end()) { set_error("weights: missing %s/convR_%d", s.c_str(), r); return ASEP_ERR_WEIGHTS; }
+        pack_pair8(wi->second, 8, 0, wr);
+        br.insert(br.end(), bi->second.data.begin(), bi->second.data.end());
+    }
+    int rc = upload(wr, &m->d_r8_down_wr);
+    if (!rc) rc = upload(br, &m->d_r8_down_br);
+    if (rc) return rc;
+    m->owned.push_back(m->d_r8_down_wr);
+    m->owned.push_back(m->d_r8_down_br);
+    if (hipFuncSetAttribute((const void*)res8_down_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess) {
+        set_error("cannot reserve %zu bytes of LDS for the fused residual block", R8_DOWN_LDS);
+        return ASEP_ERR_HIP;
+    }
+    return ASEP_OK;
+}
+
+// fused level-0 down block: images -> d0 (and maxpool2(d0) if want_pool)
+void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats, bool want_pool, TL* d_out, TL* pool_out) {
+    for (const Tensor& t : imgs) {
+        d_out->push_back(new_tensor(m, t.H, t.W, 8));
+        if (want_pool) pool_out->push_back(new_tensor(m, cdiv(t.H, 2), cdiv(t.W, 2), 8));
+    }
+    for (size_t b0 = 0; b0 < imgs.size(); b0 += MAXP) {
+        const size_t b1 = std::min(imgs.size(), b0 + MAXP);
+        Res8Args a{};
+        int tiles = 0;
+        double flops = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            Res8Prob& p = a.p[i - b0];
+            p.img = imgs[i].p; p.in1 = nullptr; p.stats = stats.empty() ? nullptr : stats[i];
+            p.out = (*d_out)[i].p; p.pool = want_pool ? (*pool_out)[i].p : nullptr;
+            p.H = imgs[i].H; p.W = imgs[i].W;
+            p.tiles_x = cdiv(imgs[i].W, R8_OW);
+            p.tile_begin = tiles;
+            tiles += p.tiles_x * cdiv(imgs[i].H, R8_OH);
+            flops += 2.0 * imgs[i].H * imgs[i].W * (9.0 * 8 + 3 * 9.0 * 64);
+        }
+        a.nprob = (int)(b1 - b0);
+        a.total_tiles = tiles;
+        a.w1 = m->det_first.d_w; a.b1 = m->det_first.d_b;
+        a.wr = (const f32x4*)m->d_r8_down_wr; a.br = m->d_r8_down_br;
+        TL sub(imgs.begin() + b0, imgs.begin() + b1);
+        std::string pname = "res8_down_kernel";
+        if (m->prof_detail) pname += " unet_down_0 (conv1+3xconvR+add+pool) " + dims_of(sub);
+        ProfScope ps(m, pname, flops);
+        hipLaunchKernelGGL(res8_down_kernel, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
+    }
+}
+
 // ---- network schedule (ARU_v1.py), evaluated for all problems in lock step ---------------------------------
 // residual block: conv1 (identity) -> t ; relu ; (res_depth-1) x conv+relu ; conv (identity) ; +t ; relu
 TL res_block_tail(asep_aru* m, const std::string& scope, const TL& t) {
@@ -451,6 +530,14 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
     };
     for (int l = 0; l < n; ++l) {
         const std::string scope = "aru_net/featMapG/unet_down_" + std::to_string(l);
+        if (l == 0 && m->use_fused8 && m->d_r8_down_wr) {
+            TL d, pooled;
+            run_res8_down(m, imgs, stats, n > 1, &d, &pooled);
+            skips.push_back(d);
+            publish(d, "_unet_down_0_conv");
+            u = n > 1 ? pooled : d;
+            continue;
+        }
         TL t = (l == 0) ? run_direct(m, m->det_first, imgs, false, stats)
                         : run_conv(m, scope + "/conv1", u, nullptr, false, false, nullptr);
         TL d = res_block_tail(m, scope, t);
@@ -642,6 +729,9 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     std::unique_ptr<asep_aru> m(new asep_aru());
     m->cfg = *cfg;
     if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_PERSIST1")) m->persist_mt1 = std::max(1, atoi(e));
+    if (const char* e = getenv("ASEP_PERSIST2")) m->persist_mt2 = std::max(1, atoi(e));
     if (const char* e = getenv("ASEP_WINO_BLOCKS")) m->wino_blocks = std::max(1, atoi(e));
     int rc = ASEP_OK;
     const int n = cfg->scale_space_num;
@@ -664,7 +754,14 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
         for (int r = 0; r < cfg->res_depth && !rc; ++r)
             rc = pack_conv(m.get(), blob, s + "/convR_" + std::to_string(r), "biases", false);
     }
+    if (!rc && cfg->feat_root == 8 && cfg->res_depth == 3 && m->det_first.k == 3) rc = pack_res8(m.get(), blob);
     if (rc) return nullptr;
+    {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            m->num_cus = prop.multiProcessorCount;
+    }
     auto lw = blob.find("aru_net/logit/class/weights");
     auto lb = blob.find("aru_net/logit/class/biases");
     if (lw == blob.end() || lb == blob.end()) { set_error("weights: missing aru_net/logit/class"); return nullptr; }

@@ -1,0 +1,184 @@
+// Fused level-0 residual blocks of the ARU-Net (8 feature channels, ARU_v1.py:208-245 and :266-281).
+//
+// The 8-channel layers at full page resolution are HBM-bound when run layer by layer (18 FLOP/B) and fill only
+// half of a 16-row MFMA tile.  This kernel keeps the whole block
+//     t = conv1(x) ; r0 = relu(conv(relu(t))) ; r1 = relu(conv(r0)) ; d = relu(conv(r1) + t) [; pool = maxpool2(d)]
+// in LDS for a 16 x 58 pixel output tile (halo recomputation: 22/20/18/16 rows x 64 columns per stage) and maps
+// each 3x3x8->8 convolution onto v_mfma_f32_16x16x4_f32 with M = 8 output channels x 2 horizontally adjacent
+// pixels ("pixel pair"), N = 16 pixel pairs, K = 3 rows x 4 columns x 8 channels = 96 (75 % useful MACs instead
+// of 45 % for the generic kernel).  All three 8->8 filters live in registers (72 VGPRs) for the lifetime of the
+// persistent block.
+#pragma once
+#include "aru_kernels.h"
+
+namespace asep {
+
+constexpr int R8_OH = 16, R8_OW = 58;          // output tile
+constexpr int R8_FH = R8_OH + 8;               // frame rows (4 halo rows each side)
+constexpr int R8_PITCH = 72;                   // pixels per LDS row (frame columns 0..71)
+constexpr int R8_IMGP = 76;                    // image tile pitch (frame columns -2..73)
+constexpr int R8_WAVES = 8;                    // 512 threads: two waves per SIMD hide the LDS->MFMA latency
+constexpr int R8_THREADS = R8_WAVES * 64;
+
+struct Res8Prob {
+    const float* img;      // DOWN: [H,W] single-channel input.  UP: skip tensor d0 [H,W,8]
+    const float* in1;      // UP: deconv output v [H,W,8]
+    const float* stats;    // DOWN: per-image standardisation {mean, 1/std} or nullptr
+    float* out;            // block output [H,W,8]
+    float* pool;           // DOWN: maxpool2(out) [ceil(H/2), ceil(W/2), 8] or nullptr
+    int H, W;
+    int tiles_x, tile_begin;
+};
+struct Res8Args {
+    Res8Prob p[MAXP];
+    int nprob, total_tiles;
+    const float* w1;       // DOWN: conv1 [9][8] ; UP: packed pair-fragments of conv1 (12 chunks x 64 lanes x 4)
+    const float* b1;       // [8]
+    const f32x4* wr;       // convR_0..2 packed pair-fragments: [3][6 chunks][64 lanes] x 4
+    const float* br;       // [3][8]
+};
+
+// one 3x3 8->8 convolution stage on LDS tiles.  IN holds rows in_r0.. of the frame, OUT rows out_r0.. ;
+// computes rows [out_r0, out_r0+NROWS) x columns [out_c0, out_c0+64).  FINAL: add T centre, store to global.
+template <int NROWS, bool RELU_IN, bool FINAL, bool POOL>
+__device__ __forceinline__ void res8_stage(const float* __restrict__ IN, int in_r0, float* __restrict__ OUT, int out_r0,
+                                           int out_c0, const f32x4 (&A)[6], const f32x4 bias4, int wave, int lane,
+                                           int fy0, int fx0, int H, int W, const float* __restrict__ T, int t_r0,
+                                           float* __restrict__ gout, float* __restrict__ gpool) {
+    const int j = lane & 15, kk = lane >> 4;
+    const int e = kk >> 1, ch = (kk & 1) * 4;
+    for (int pu = wave; pu < NROWS; pu += R8_WAVES) {   // pu enumerates (row pair, n-tile): NROWS/2 pairs x 2 n-tiles
+        const int rp = pu >> 1, nt = pu & 1;
+        const int row0 = out_r0 + 2 * rp;            // rows row0, row0+1
+        const int colb = out_c0 + nt * 32 + 2 * j;   // this lane's pixel pair starts at colb
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = ky * 2 + h;
+                const int cin_col = colb + 2 * h + e - 1;
+                const float* p0 = IN + ((row0 + ky - 1 - in_r0) * R8_PITCH + cin_col) * 8 + ch;
+                f32x4 b0 = *reinterpret_cast<const f32x4*>(p0);
+                f32x4 b1 = *reinterpret_cast<const f32x4*>(p0 + R8_PITCH * 8);
+                if (RELU_IN) { b0 = relu4(b0); b1 = relu4(b1); }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][r], b0[r], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][r], b1[r], acc1, 0, 0, 0);
+                }
+            }
+        // D layout: lane (pair j, kk): pixel colb + e, channels ch..ch+3
+        const int col = colb + e;
+        const int gx = fx0 + col;
+        f32x4 v0 = acc0 + bias4, v1 = acc1 + bias4;
+        if (!FINAL) {
+            const int gy0 = fy0 + row0;
+            const bool okx = gx >= 0 && gx < W;
+            v0 = (okx && gy0 >= 0 && gy0 < H) ? relu4(v0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            v1 = (okx && gy0 + 1 >= 0 && gy0 + 1 < H) ? relu4(v1) : f32x4{0.f, 0.f, 0.f, 0.f};
+            float* o = OUT + ((row0 - out_r0) * R8_PITCH + col) * 8 + ch;
+            *reinterpret_cast<f32x4*>(o) = v0;
+            *reinterpret_cast<f32x4*>(o + R8_PITCH * 8) = v1;
+        } else {
+            const float* tp = T + ((row0 - t_r0) * R8_PITCH + col) * 8 + ch;
+            v0 = relu4(v0 + *reinterpret_cast<const f32x4*>(tp));
+            v1 = relu4(v1 + *reinterpret_cast<const f32x4*>(tp + R8_PITCH * 8));
+            const int gy0 = fy0 + row0;
+            // only the OW valid columns of the tile (frame columns 4 .. 4+OW-1) are stored
+            const bool okx = col >= 4 && col < 4 + R8_OW && gx < W;
+            if (okx && gy0 < H) *reinterpret_cast<f32x4*>(gout + ((size_t)gy0 * W + gx) * 8 + ch) = v0;
+            if (okx && gy0 + 1 < H) *reinterpret_cast<f32x4*>(gout + ((size_t)(gy0 + 1) * W + gx) * 8 + ch) = v1;
+            if (POOL && gpool) {
+                // 2x2 max: rows in registers, the x neighbour (e = 1) sits in lane ^ 32; windows never straddle tiles
+                f32x4 m = (gy0 + 1 < H) ? f32x4{fmaxf(v0.x, v1.x), fmaxf(v0.y, v1.y), fmaxf(v0.z, v1.z), fmaxf(v0.w, v1.w)} : v0;
+                f32x4 o;
+                o.x = __shfl_xor(m.x, 32); o.y = __shfl_xor(m.y, 32); o.z = __shfl_xor(m.z, 32); o.w = __shfl_xor(m.w, 32);
+                if (e == 0 && okx && gy0 < H) {
+                    if (gx + 1 < W) { m.x = fmaxf(m.x, o.x); m.y = fmaxf(m.y, o.y); m.z = fmaxf(m.z, o.z); m.w = fmaxf(m.w, o.w); }
+                    const int Wp = (W + 1) >> 1;
+                    *reinterpret_cast<f32x4*>(gpool + ((size_t)(gy0 >> 1) * Wp + (gx >> 1)) * 8 + ch) = m;
+                }
+            }
+        }
+    }
+}
+
+// DOWN block of level 0: image (1 channel) -> d0 [H,W,8] (+ maxpool2)
+__global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* IMG = sm;                                         // [24][76]
+    float* T = IMG + R8_FH * R8_IMGP;                        // frame rows 1..22  [22][72][8]
+    float* R0 = T + 22 * R8_PITCH * 8;                       // frame rows 2..21  [20][72][8]
+    float* R1 = R0 + 20 * R8_PITCH * 8;                      // frame rows 3..20  [18][72][8]
+    __shared__ float w1s[9 * 8 + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kk = lane >> 4;
+    if (tid < 72) w1s[tid] = a.w1[tid];
+    if (tid < 8) w1s[72 + tid] = a.b1[tid];
+    // the three 8->8 filters as pixel-pair A fragments, resident in registers
+    f32x4 A0[6], A1[6], A2[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        A0[c] = a.wr[(0 * 6 + c) * 64 + lane];
+        A1[c] = a.wr[(1 * 6 + c) * 64 + lane];
+        A2[c] = a.wr[(2 * 6 + c) * 64 + lane];
+    }
+    const int ch = (kk & 1) * 4;
+    const f32x4 bias0 = *reinterpret_cast<const f32x4*>(a.br + 0 + ch);
+    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(a.br + 8 + ch);
+    const f32x4 bias2 = *reinterpret_cast<const f32x4*>(a.br + 16 + ch);
+
+    for (int tile_id = blockIdx.x; tile_id < a.total_tiles; tile_id += gridDim.x) {
+        int pi = 0;
+        while (pi + 1 < a.nprob && tile_id >= a.p[pi + 1].tile_begin) ++pi;
+        const Res8Prob& P = a.p[pi];
+        const int t = tile_id - P.tile_begin;
+        const int tyb = t / P.tiles_x, txb = t - tyb * P.tiles_x;
+        const int H = P.H, W = P.W;
+        const int fy0 = tyb * R8_OH - 4, fx0 = txb * R8_OW - 4;      // image coordinates of frame (0,0)
+        float mean = 0.f, inv = 1.f;
+        if (P.stats) { mean = P.stats[0]; inv = P.stats[1]; }
+        __syncthreads();                                     // previous tile finished with all LDS buffers
+        // ---- image tile: frame rows 0..23, frame columns -2..73 (zero outside the image = SAME padding) ----
+        for (int i = tid; i < R8_FH * R8_IMGP; i += R8_THREADS) {
+            const int r = i / R8_IMGP, c = i - r * R8_IMGP;
+            const int gy = fy0 + r, gx = fx0 + c - 2;
+            float v = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = (P.img[(size_t)gy * W + gx] - mean) * inv;
+            IMG[i] = v;
+        }
+        __syncthreads();
+        // ---- t = conv1(image) (identity activation), frame rows 1..22, all 72 columns; zero outside the image ----
+        for (int i = tid; i < 22 * R8_PITCH; i += R8_THREADS) {
+            const int r = i / R8_PITCH, c = i - r * R8_PITCH;   // frame row r+1, frame column c
+            const int gy = fy0 + r + 1, gx = fx0 + c;
+            float acc[8];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) acc[o] = w1s[72 + o];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float v = IMG[(r + ky) * R8_IMGP + c + kx + 1];       // frame (r+1+ky-1, c+kx-1) -> IMG col +2
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) acc[o] = fmaf(v, w1s[(ky * 3 + kx) * 8 + o], acc[o]);
+                }
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            f32x4 lo = ok ? f32x4{acc[0], acc[1], acc[2], acc[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 hi = ok ? f32x4{acc[4], acc[5], acc[6], acc[7]} : f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(T + i * 8) = lo;
+            *reinterpret_cast<f32x4*>(T + i * 8 + 4) = hi;
+        }
+        __syncthreads();
+        res8_stage<20, true, false, false>(T, 1, R0, 2, 2, A0, bias0, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+        __syncthreads();
+        res8_stage<18, false, false, false>(R0, 2, R1, 3, 3, A1, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+        __syncthreads();
+        res8_stage<16, false, true, true>(R1, 3, nullptr, 4, 4, A2, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, P.pool);
+    }
+}
+
+constexpr size_t R8_DOWN_LDS = (size_t)(R8_FH * R8_IMGP + (22 + 20 + 18) * R8_PITCH * 8) * sizeof(float);
+
+}  // namespace asep
