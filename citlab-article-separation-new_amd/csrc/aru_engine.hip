@@ -52,6 +52,7 @@ struct asep_aru {
     float* d_r8_down_wr = nullptr;   // [3][6][64][4]
     float* d_r8_down_br = nullptr;   // [3][8]
     bool use_fused8 = true;          // ASEP_FUSED8=0 falls back to the layer-by-layer kernels
+    float* d_att_head = nullptr;     // A fragment of attPart/conv1 for att_head_kernel (12 output channels, 4x4 taps)
     float* d_logit_w = nullptr;
     float* d_logit_b = nullptr;
     float* d_stats = nullptr;      // mvn {mean, 1/std}
@@ -559,8 +560,33 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
 
 TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) {
     const std::string p = "aru_net/attMapG/attPart/conv";
-    TL y = run_direct(m, m->att_first, imgs, true, stats);
-    y = run_pool(m, y, POOL_MAX);
+    TL y;
+    if (m->d_att_head && m->use_fused8) {
+        // conv1 + ReLU + pool1 fused (the full-resolution 12-channel tensor is never materialised)
+        for (const Tensor& t : imgs) y.push_back(new_tensor(m, cdiv(t.H, 2), cdiv(t.W, 2), 12));
+        for (size_t b0 = 0; b0 < imgs.size(); b0 += MAXP) {
+            const size_t b1 = std::min(imgs.size(), b0 + MAXP);
+            AttHeadArgs a{};
+            int tiles = 0;
+            double flops = 0;
+            for (size_t i = b0; i < b1; ++i) {
+                C1Prob& q = a.p[i - b0];
+                q.img = imgs[i].p; q.out = y[i].p; q.stats = stats.empty() ? nullptr : stats[i];
+                q.H = imgs[i].H; q.W = imgs[i].W;
+                q.tiles_x = cdiv(imgs[i].W, ATT_TW);
+                q.tile_begin = tiles;
+                tiles += q.tiles_x * cdiv(imgs[i].H, ATT_TH);
+                flops += 2.0 * imgs[i].H * imgs[i].W * 16.0 * 12;
+            }
+            a.nprob = (int)(b1 - b0);
+            a.wpk = (const f32x4*)m->d_att_head; a.bias = m->att_first.d_b;
+            ProfScope ps(m, "att_head_kernel", flops);
+            hipLaunchKernelGGL(att_head_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
+        }
+    } else {
+        y = run_direct(m, m->att_first, imgs, true, stats);
+        y = run_pool(m, y, POOL_MAX);
+    }
     y = run_conv(m, p + "2", y, nullptr, false, true, nullptr);
     y = run_pool(m, y, POOL_MAX);
     y = run_conv(m, p + "3", y, nullptr, false, true, nullptr);
@@ -737,6 +763,17 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     const int n = cfg->scale_space_num;
     if (cfg->use_attention) {
         rc = pack_direct(m.get(), blob, "aru_net/attMapG/attPart/conv1", &m->att_first);
+        if (!rc && m->att_first.k == 4 && m->att_first.cout == 12) {
+            const HostTensor& w = blob.find("aru_net/attMapG/attPart/conv1/weights")->second;   // [4][4][1][12]
+            std::vector<float> pk(64 * 4, 0.f);
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    const int co = lane & 15, ky = lane >> 4, kx = r;
+                    if (co < 12) pk[lane * 4 + r] = w.data[(size_t)(ky * 4 + kx) * 12 + co];
+                }
+            rc = upload(pk, &m->d_att_head);
+            if (!rc) m->owned.push_back(m->d_att_head);
+        }
         for (int i = 2; i <= 4 && !rc; ++i)
             rc = pack_conv(m.get(), blob, "aru_net/attMapG/attPart/conv" + std::to_string(i), "biases", false);
     }

@@ -145,6 +145,26 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     f32x4 af[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) af[m] = wbase[(size_t)m * 64];
+    // residual operand of the epilogue: requested now so that its HBM latency hides under the MFMA phases
+    constexpr bool RES_PREFETCH = (MT * NT <= 8);
+    f32x4 resv[RES_PREFETCH ? MT : 1][RES_PREFETCH ? NT : 1];
+    if constexpr (RES_PREFETCH) {
+        if (P.res) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int id = wave * NT + n;
+                const int y = y0 + (id >> 1), x = x0 + (id & 1) * 16 + j;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int c = (mt0 + m) * 16 + kk * 4;
+                    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (y < P.Ho && x < P.Wo && c + 3 < a.cout)
+                        v = *reinterpret_cast<const f32x4*>(P.res + ((size_t)y * P.Wo + x) * a.cout + c);
+                    resv[m][n] = v;
+                }
+            }
+        }
+    }
     stage_store(0);
     __syncthreads();
 
@@ -205,7 +225,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             f32x4 v = acc[m][n];
             if (c + 3 < a.cout) {
                 v += *reinterpret_cast<const f32x4*>(a.bias + c);
-                if (res) v += *reinterpret_cast<const f32x4*>(res + p * a.cout + c);
+                if constexpr (RES_PREFETCH) {
+                    if (res) v += resv[m][n];
+                } else {
+                    if (res) v += *reinterpret_cast<const f32x4*>(res + p * a.cout + c);
+                }
                 if (a.relu_out) v = relu4(v);
                 *reinterpret_cast<f32x4*>(out + p * a.cout + c) = v;
             } else {
@@ -612,6 +636,71 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const C1Args a) {
         }
         *reinterpret_cast<f32x4*>(o + c) = v;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention CNN head (ARU_v1.py:173-175): 4x4 conv 1->12 + ReLU + 2x2 max pool in one pass.  The 12-channel
+// full-resolution tensor (648 MB per page) is never written: the conv runs on the MFMA with K = the 16 taps
+// (slot 4*kk+r -> tap row kk, tap column r), M = 12 (of 16) output channels, N = 16 pixels of one row, and the
+// pool is taken in registers (two rows per unit) and across lanes j ^ 1.
+// ------------------------------------------------------------------------------------------------
+constexpr int ATT_TH = 32, ATT_TW = 64;                      // output (pre-pool) tile; tile origins are even
+struct AttHeadArgs {
+    C1Prob p[MAXP];        // img, out = pooled [ceil(H/2), ceil(W/2), 12], stats, H, W, tiles_x, tile_begin
+    int nprob;
+    const f32x4* wpk;      // [64 lanes] A fragment: row = cout (12 real), slots = taps
+    const float* bias;     // [12]
+};
+
+__global__ __launch_bounds__(256) void att_head_kernel(const AttHeadArgs a) {
+    constexpr int LH = ATT_TH + 3, LW = ATT_TW + 4;          // SAME for 4x4: 1 before, 2 after (+1 col of slack)
+    __shared__ float img[LH * LW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    const C1Prob& P = a.p[pi];
+    const int tile = blockIdx.x - P.tile_begin;
+    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const int x0 = tx * ATT_TW, y0 = ty * ATT_TH;
+    const int H = P.H, W = P.W;
+    float mean = 0.f, inv = 1.f;
+    if (P.stats) { mean = P.stats[0]; inv = P.stats[1]; }
+    for (int i = tid; i < LH * LW; i += 256) {
+        const int r = i / LW, c = i - r * LW;
+        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = (P.img[(size_t)gy * W + gx] - mean) * inv;
+        img[i] = v;
+    }
+    const f32x4 A = a.wpk[lane];
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (kk < 3) bias4 = *reinterpret_cast<const f32x4*>(a.bias + kk * 4);
+    __syncthreads();
+    const int Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+    // units: (row pair, 16-pixel column block): 16 x 4 = 64 units, 16 per wave
+    for (int u = wave; u < (ATT_TH / 2) * (ATT_TW / 16); u += 4) {
+        const int rp = u >> 2, cb = u & 3;
+        const int ly = 2 * rp, lx = cb * 16 + j;              // output pixel (ly, lx) of the tile; taps start at img[ly + kk][lx + r]
+        const float* p0 = img + (ly + kk) * LW + lx;
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[r], p0[r], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[r], p0[LW + r], acc1, 0, 0, 0);
+        }
+        const int gy = y0 + ly, gx = x0 + lx;
+        f32x4 v0 = relu4(acc0 + bias4), v1 = relu4(acc1 + bias4);
+        // pool: rows in registers (second row only if inside the image), x neighbour in lane j ^ 1
+        f32x4 m = (gy + 1 < H) ? f32x4{fmaxf(v0.x, v1.x), fmaxf(v0.y, v1.y), fmaxf(v0.z, v1.z), fmaxf(v0.w, v1.w)} : v0;
+        f32x4 o;
+        o.x = __shfl_xor(m.x, 1); o.y = __shfl_xor(m.y, 1); o.z = __shfl_xor(m.z, 1); o.w = __shfl_xor(m.w, 1);
+        if ((j & 1) == 0 && kk < 3 && gy < H && gx < W) {
+            if (gx + 1 < W) { m.x = fmaxf(m.x, o.x); m.y = fmaxf(m.y, o.y); m.z = fmaxf(m.z, o.z); m.w = fmaxf(m.w, o.w); }
+            *reinterpret_cast<f32x4*>(P.out + ((size_t)(gy >> 1) * Wp + (gx >> 1)) * 12 + kk * 4) = m;
+        }
+    }
+    (void)Hp;
 }
 
 // mean / E[x^2] partial sums for per-image standardisation (double accumulation on the host side)
