@@ -140,11 +140,17 @@ def main():
     out_conf = [torch.empty(N * N, gnn_cfg.num_classes, device=dev) for _ in range(B)]
     stream = torch.cuda.current_stream().cuda_stream
 
+    PtrArr = C.c_void_p * B
+    p_img = PtrArr(*[t.data_ptr() for t in imgs])
+    p_out = PtrArr(*[t.data_ptr() for t in out_prob])
+    p_u8 = PtrArr(*[t.data_ptr() for t in out_u8])
+    p_mask = PtrArr(*[t.data_ptr() for t in out_mask])
+
     def step():
+        # one batched ARU-Net call: every layer is launched once for all B pages x 3 scale-space levels
+        _lib.check(lib.asep_aru_forward_batch_dev(h_aru, B, p_img, H, W, p_out, p_u8, p_mask, 0.05, stream),
+                   "asep_aru_forward_batch_dev")
         for k in range(B):
-            _lib.check(lib.asep_aru_forward_dev(h_aru, imgs[k].data_ptr(), H, W, out_prob[k].data_ptr(),
-                                                out_u8[k].data_ptr(), out_mask[k].data_ptr(), 0.05, stream),
-                       "asep_aru_forward_dev")
             if not args.no_gnn:
                 _lib.check(lib.asep_gnn_forward_dev(h_gnn, N, E[k], g_edges[k].data_ptr(), g_u[k].data_ptr(),
                                                     g_ef[k].data_ptr(), N * N, None, out_conf[k].data_ptr(), stream),

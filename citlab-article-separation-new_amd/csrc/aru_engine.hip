@@ -51,6 +51,10 @@ struct asep_aru {
     // fused level-0 residual blocks (feat_root == 8, res_depth == 3): pixel-pair MFMA fragments
     float* d_r8_down_wr = nullptr;   // [3][6][64][4]
     float* d_r8_down_br = nullptr;   // [3][8]
+    float* d_r8_up_w1 = nullptr;     // unet_up_0/conv1 as two 8-channel pixel-pair passes [2][6][64][4]
+    float* d_r8_up_wr = nullptr;     // [3][6][64][4]
+    float* d_r8_up_br = nullptr;     // [3][8]
+    float* d_r8_up_b1 = nullptr;     // [8]
     bool use_fused8 = true;          // ASEP_FUSED8=0 falls back to the layer-by-layer kernels
     float* d_att_head = nullptr;     // A fragment of attPart/conv1 for att_head_kernel (12 output channels, 4x4 taps)
     float* d_logit_w = nullptr;
@@ -468,6 +472,33 @@ int pack_res8(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
     if (rc) return rc;
     m->owned.push_back(m->d_r8_down_wr);
     m->owned.push_back(m->d_r8_down_br);
+    if (m->cfg.scale_space_num > 1) {
+        const std::string u = "aru_net/featMapG/unet_up_0";
+        auto w1 = blob.find(u + "/conv1/weights");
+        auto b1 = blob.find(u + "/conv1/biases");
+        if (w1 == blob.end() || b1 == blob.end()) { set_error("weights: missing %s/conv1", u.c_str()); return ASEP_ERR_WEIGHTS; }
+        std::vector<float> pw1, pwr, pbr;
+        pack_pair8(w1->second, 16, 0, pw1);      // skip channels 0..7
+        pack_pair8(w1->second, 16, 8, pw1);      // deconv channels 8..15
+        for (int r = 0; r < 3; ++r) {
+            auto wi = blob.find(u + "/convR_" + std::to_string(r) + "/weights");
+            auto bi = blob.find(u + "/convR_" + std::to_string(r) + "/biases");
+            if (wi == blob.end() || bi == blob.end()) { set_error("weights: missing %s/convR_%d", u.c_str(), r); return ASEP_ERR_WEIGHTS; }
+            pack_pair8(wi->second, 8, 0, pwr);
+            pbr.insert(pbr.end(), bi->second.data.begin(), bi->second.data.end());
+        }
+        rc = upload(pw1, &m->d_r8_up_w1);
+        if (!rc) rc = upload(pwr, &m->d_r8_up_wr);
+        if (!rc) rc = upload(pbr, &m->d_r8_up_br);
+        if (!rc) rc = upload(b1->second.data, &m->d_r8_up_b1);
+        if (rc) return rc;
+        m->owned.push_back(m->d_r8_up_w1); m->owned.push_back(m->d_r8_up_wr);
+        m->owned.push_back(m->d_r8_up_br); m->owned.push_back(m->d_r8_up_b1);
+        if (hipFuncSetAttribute((const void*)res8_up_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess) {
+            set_error("cannot reserve %zu bytes of LDS for the fused up block", R8_UP_LDS);
+            return ASEP_ERR_HIP;
+        }
+    }
     if (hipFuncSetAttribute((const void*)res8_down_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess) {
         set_error("cannot reserve %zu bytes of LDS for the fused residual block", R8_DOWN_LDS);
         return ASEP_ERR_HIP;
@@ -506,6 +537,37 @@ void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>&
         ProfScope ps(m, pname, flops);
         hipLaunchKernelGGL(res8_down_kernel, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
     }
+}
+
+// fused level-0 up block: [skip, deconv] -> block output
+TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
+    TL out;
+    for (const Tensor& t : skip) out.push_back(new_tensor(m, t.H, t.W, 8));
+    for (size_t b0 = 0; b0 < skip.size(); b0 += MAXP) {
+        const size_t b1 = std::min(skip.size(), b0 + MAXP);
+        Res8Args a{};
+        int tiles = 0;
+        double flops = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            Res8Prob& p = a.p[i - b0];
+            p.img = skip[i].p; p.in1 = v[i].p; p.stats = nullptr; p.out = out[i].p; p.pool = nullptr;
+            p.H = skip[i].H; p.W = skip[i].W;
+            p.tiles_x = cdiv(skip[i].W, R8_OW);
+            p.tile_begin = tiles;
+            tiles += p.tiles_x * cdiv(skip[i].H, R8_OH);
+            flops += 2.0 * skip[i].H * skip[i].W * (9.0 * 16 * 8 + 3 * 9.0 * 64);
+        }
+        a.nprob = (int)(b1 - b0);
+        a.total_tiles = tiles;
+        a.w1 = m->d_r8_up_w1; a.b1 = m->d_r8_up_b1;
+        a.wr = (const f32x4*)m->d_r8_up_wr; a.br = m->d_r8_up_br;
+        TL sub(skip.begin() + b0, skip.begin() + b1);
+        std::string pname = "res8_up_kernel";
+        if (m->prof_detail) pname += " unet_up_0 (conv1[16->8]+3xconvR+add) " + dims_of(sub);
+        ProfScope ps(m, pname, flops);
+        hipLaunchKernelGGL(res8_up_kernel, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
+    }
+    return out;
 }
 
 // ---- network schedule (ARU_v1.py), evaluated for all problems in lock step ---------------------------------
@@ -551,8 +613,12 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
         const TL& skip = skips[l];
         TL v = run_deconv(m, scope + "/deconv", u, skip, true);
         publish(v, "_unet_up_" + std::to_string(l) + "_deconv");
-        TL t = run_conv(m, scope + "/conv1", skip, &v, false, false, nullptr);   // concat [skip, deconv]
-        u = res_block_tail(m, scope, t);
+        if (l == 0 && m->use_fused8 && m->d_r8_up_w1) {
+            u = run_res8_up(m, skip, v);
+        } else {
+            TL t = run_conv(m, scope + "/conv1", skip, &v, false, false, nullptr);   // concat [skip, deconv]
+            u = res_block_tail(m, scope, t);
+        }
         publish(u, "_unet_up_" + std::to_string(l) + "_conv");
     }
     return u;

@@ -179,6 +179,108 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args
     }
 }
 
+// UP block of level 0 (ARU_v1.py:262-281): t = conv1(concat[skip, deconv]) ; 3 x convR ; + t ; ReLU.
+// The 16-channel concatenation is consumed as two 8-channel passes through one LDS input tile (skip, then the
+// deconvolution output) that accumulate into the same registers; afterwards that tile buffer holds r1.
+__global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Pb = sm;                                          // frame rows 0..23  [24][72][8]  (later r1: rows 3..20)
+    float* T = Pb + R8_FH * R8_PITCH * 8;                    // frame rows 1..22  [22][72][8]
+    float* R0 = T + 22 * R8_PITCH * 8;                       // frame rows 2..21  [20][72][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int e = kk >> 1, ch = (kk & 1) * 4;
+    const f32x4* w1 = reinterpret_cast<const f32x4*>(a.w1);  // [2 sources][6 chunks][64 lanes]
+    f32x4 A0[6], A1[6], A2[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        A0[c] = a.wr[(0 * 6 + c) * 64 + lane];
+        A1[c] = a.wr[(1 * 6 + c) * 64 + lane];
+        A2[c] = a.wr[(2 * 6 + c) * 64 + lane];
+    }
+    const f32x4 biasT = *reinterpret_cast<const f32x4*>(a.b1 + ch);
+    const f32x4 bias0 = *reinterpret_cast<const f32x4*>(a.br + 0 + ch);
+    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(a.br + 8 + ch);
+    const f32x4 bias2 = *reinterpret_cast<const f32x4*>(a.br + 16 + ch);
+
+    for (int tile_id = blockIdx.x; tile_id < a.total_tiles; tile_id += gridDim.x) {
+        int pi = 0;
+        while (pi + 1 < a.nprob && tile_id >= a.p[pi + 1].tile_begin) ++pi;
+        const Res8Prob& P = a.p[pi];
+        const int t = tile_id - P.tile_begin;
+        const int tyb = t / P.tiles_x, txb = t - tyb * P.tiles_x;
+        const int H = P.H, W = P.W;
+        const int fy0 = tyb * R8_OH - 4, fx0 = txb * R8_OW - 4;
+
+        // t accumulators of this wave's pair-units (row pairs 1..22 x 2 n-tiles = 22 units; <= 3 per wave)
+        f32x4 tacc[3][2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { tacc[q][0] = f32x4{0.f, 0.f, 0.f, 0.f}; tacc[q][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+#pragma unroll
+        for (int src = 0; src < 2; ++src) {
+            const float* __restrict__ g = src == 0 ? P.img : P.in1;
+            __syncthreads();                                 // the tile buffer is free (previous pass / previous tile done)
+            for (int i = tid; i < R8_FH * R8_PITCH * 2; i += R8_THREADS) {
+                const int pix = i >> 1, half = i & 1;
+                const int r = pix / R8_PITCH, c = pix - r * R8_PITCH;
+                const int gy = fy0 + r, gx = fx0 + c;
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const f32x4*>(g + ((size_t)gy * W + gx) * 8 + half * 4);
+                *reinterpret_cast<f32x4*>(Pb + i * 4) = v;
+            }
+            __syncthreads();
+            f32x4 Aw[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Aw[c] = w1[(src * 6 + c) * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int pu = wave + q * R8_WAVES;
+                if (pu < 22) {
+                    const int rp = pu >> 1, nt = pu & 1;
+                    const int row0 = 1 + 2 * rp;
+                    const int colb = 1 + nt * 32 + 2 * j;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const float* p0 = Pb + ((row0 + ky - 1) * R8_PITCH + colb + 2 * h + e - 1) * 8 + ch;
+                            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p0);
+                            const f32x4 b1 = *reinterpret_cast<const f32x4*>(p0 + R8_PITCH * 8);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                tacc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[ky * 2 + h][r], b0[r], tacc[q][0], 0, 0, 0);
+                                tacc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[ky * 2 + h][r], b1[r], tacc[q][1], 0, 0, 0);
+                            }
+                        }
+                }
+            }
+        }
+        // ---- write raw t (identity activation), zero outside the image ----
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int pu = wave + q * R8_WAVES;
+            if (pu < 22) {
+                const int rp = pu >> 1, nt = pu & 1;
+                const int row0 = 1 + 2 * rp, col = 1 + nt * 32 + 2 * j + e;
+                const int gy0 = fy0 + row0, gx = fx0 + col;
+                const bool okx = gx >= 0 && gx < W;
+                const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                float* o = T + ((row0 - 1) * R8_PITCH + col) * 8 + ch;
+                *reinterpret_cast<f32x4*>(o) = (okx && gy0 >= 0 && gy0 < H) ? tacc[q][0] + biasT : z;
+                *reinterpret_cast<f32x4*>(o + R8_PITCH * 8) = (okx && gy0 + 1 >= 0 && gy0 + 1 < H) ? tacc[q][1] + biasT : z;
+            }
+        }
+        __syncthreads();
+        res8_stage<20, true, false, false>(T, 1, R0, 2, 2, A0, bias0, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+        __syncthreads();
+        res8_stage<18, false, false, false>(R0, 2, Pb, 3, 3, A1, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+        __syncthreads();
+        res8_stage<16, false, true, false>(Pb, 3, nullptr, 4, 4, A2, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, nullptr);
+    }
+}
+
+constexpr size_t R8_UP_LDS = (size_t)((R8_FH + 22 + 20) * R8_PITCH * 8) * sizeof(float);
 constexpr size_t R8_DOWN_LDS = (size_t)(R8_FH * R8_IMGP + (22 + 20 + 18) * R8_PITCH * 8) * sizeof(float);
 
 }  // namespace asep
