@@ -86,7 +86,11 @@ __device__ __forceinline__ void res8_stage(const float* __restrict__ IN, int in_
             v1 = relu4(v1 + *reinterpret_cast<const f32x4*>(tp + R8_PITCH * 8));
             const int gy0 = fy0 + row0;
             // only the OW valid columns of the tile (frame columns 4 .. 4+OW-1) are stored
+#ifdef R8_ABL_ST
+            const bool okx = col >= 4 && col < 4 + R8_OW && gx < W && gy0 < -5;
+#else
             const bool okx = col >= 4 && col < 4 + R8_OW && gx < W;
+#endif
             if (okx && gy0 < H) *reinterpret_cast<f32x4*>(gout + ((size_t)gy0 * W + gx) * 8 + ch) = v0;
             if (okx && gy0 + 1 < H) *reinterpret_cast<f32x4*>(gout + ((size_t)(gy0 + 1) * W + gx) * 8 + ch) = v1;
             if (POOL && gpool) {
@@ -129,6 +133,31 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args
     const f32x4 bias1 = *reinterpret_cast<const f32x4*>(a.br + 8 + ch);
     const f32x4 bias2 = *reinterpret_cast<const f32x4*>(a.br + 16 + ch);
 
+    constexpr int NPRE = (R8_FH * R8_IMGP + R8_THREADS - 1) / R8_THREADS;
+    float pre[NPRE];
+    auto image_load = [&](int tile_id) {                    // next tile's image values -> registers (in flight under the MFMA stages)
+        int pi = 0;
+        while (pi + 1 < a.nprob && tile_id >= a.p[pi + 1].tile_begin) ++pi;
+        const Res8Prob& Q = a.p[pi];
+        const int t = tile_id - Q.tile_begin;
+        const int tyb = t / Q.tiles_x, txb = t - tyb * Q.tiles_x;
+        const int qy0 = tyb * R8_OH - 4, qx0 = txb * R8_OW - 4;
+        float mean = 0.f, inv = 1.f;
+        if (Q.stats) { mean = Q.stats[0]; inv = Q.stats[1]; }
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int i = tid + k * R8_THREADS;
+            const int r = i / R8_IMGP, c = i - r * R8_IMGP;
+            const int gy = qy0 + r, gx = qx0 + c - 2;
+            float v = 0.f;
+#ifndef R8_ABL_IMG
+            if (i < R8_FH * R8_IMGP && gy >= 0 && gy < Q.H && gx >= 0 && gx < Q.W) v = (Q.img[(size_t)gy * Q.W + gx] - mean) * inv;
+#endif
+            pre[k] = v;
+        }
+    };
+    if ((int)blockIdx.x < a.total_tiles) image_load(blockIdx.x);
+
     for (int tile_id = blockIdx.x; tile_id < a.total_tiles; tile_id += gridDim.x) {
         int pi = 0;
         while (pi + 1 < a.nprob && tile_id >= a.p[pi + 1].tile_begin) ++pi;
@@ -137,16 +166,12 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args
         const int tyb = t / P.tiles_x, txb = t - tyb * P.tiles_x;
         const int H = P.H, W = P.W;
         const int fy0 = tyb * R8_OH - 4, fx0 = txb * R8_OW - 4;      // image coordinates of frame (0,0)
-        float mean = 0.f, inv = 1.f;
-        if (P.stats) { mean = P.stats[0]; inv = P.stats[1]; }
         __syncthreads();                                     // previous tile finished with all LDS buffers
         // ---- image tile: frame rows 0..23, frame columns -2..73 (zero outside the image = SAME padding) ----
-        for (int i = tid; i < R8_FH * R8_IMGP; i += R8_THREADS) {
-            const int r = i / R8_IMGP, c = i - r * R8_IMGP;
-            const int gy = fy0 + r, gx = fx0 + c - 2;
-            float v = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = (P.img[(size_t)gy * W + gx] - mean) * inv;
-            IMG[i] = v;
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int i = tid + k * R8_THREADS;
+            if (i < R8_FH * R8_IMGP) IMG[i] = pre[k];
         }
         __syncthreads();
         // ---- t = conv1(image) (identity activation), frame rows 1..22, all 72 columns; zero outside the image ----
@@ -156,6 +181,9 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args
             float acc[8];
 #pragma unroll
             for (int o = 0; o < 8; ++o) acc[o] = w1s[72 + o];
+#ifdef R8_ABL_T
+            if (a.nprob < 0)
+#endif
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -175,6 +203,7 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args
         __syncthreads();
         res8_stage<18, false, false, false>(R0, 2, R1, 3, 3, A1, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
         __syncthreads();
+        if (tile_id + (int)gridDim.x < a.total_tiles) image_load(tile_id + gridDim.x);
         res8_stage<16, false, true, true>(R1, 3, nullptr, 4, 4, A2, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, P.pool);
     }
 }
@@ -199,6 +228,29 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
         A2[c] = a.wr[(2 * 6 + c) * 64 + lane];
     }
     const f32x4 biasT = *reinterpret_cast<const f32x4*>(a.b1 + ch);
+    constexpr int NPF = (R8_FH * R8_PITCH * 2 + R8_THREADS - 1) / R8_THREADS;
+    f32x4 pf[NPF];
+    auto tile_load = [&](const float* __restrict__ g, int H_, int W_, int qy0, int qx0) {   // 8-channel halo tile -> registers
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int i = tid + k * R8_THREADS;
+            const int pix = i >> 1, half = i & 1;
+            const int r = pix / R8_PITCH, c = pix - r * R8_PITCH;
+            const int gy = qy0 + r, gx = qx0 + c;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < R8_FH * R8_PITCH * 2 && gy >= 0 && gy < H_ && gx >= 0 && gx < W_)
+                v = *reinterpret_cast<const f32x4*>(g + ((size_t)gy * W_ + gx) * 8 + half * 4);
+            pf[k] = v;
+        }
+    };
+    if ((int)blockIdx.x < a.total_tiles) {
+        int qi = 0;
+        while (qi + 1 < a.nprob && (int)blockIdx.x >= a.p[qi + 1].tile_begin) ++qi;
+        const Res8Prob& Q = a.p[qi];
+        const int tq = blockIdx.x - Q.tile_begin;
+        const int qyb = tq / Q.tiles_x, qxb = tq - qyb * Q.tiles_x;
+        tile_load(Q.img, Q.H, Q.W, qyb * R8_OH - 4, qxb * R8_OW - 4);
+    }
     const f32x4 bias0 = *reinterpret_cast<const f32x4*>(a.br + 0 + ch);
     const f32x4 bias1 = *reinterpret_cast<const f32x4*>(a.br + 8 + ch);
     const f32x4 bias2 = *reinterpret_cast<const f32x4*>(a.br + 16 + ch);
@@ -212,6 +264,7 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
         const int H = P.H, W = P.W;
         const int fy0 = tyb * R8_OH - 4, fx0 = txb * R8_OW - 4;
 
+        const int next_id = tile_id + gridDim.x;
         // t accumulators of this wave's pair-units (row pairs 1..22 x 2 n-tiles = 22 units; <= 3 per wave)
         f32x4 tacc[3][2];
 #pragma unroll
@@ -219,16 +272,13 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
 
 #pragma unroll
         for (int src = 0; src < 2; ++src) {
-            const float* __restrict__ g = src == 0 ? P.img : P.in1;
             __syncthreads();                                 // the tile buffer is free (previous pass / previous tile done)
-            for (int i = tid; i < R8_FH * R8_PITCH * 2; i += R8_THREADS) {
-                const int pix = i >> 1, half = i & 1;
-                const int r = pix / R8_PITCH, c = pix - r * R8_PITCH;
-                const int gy = fy0 + r, gx = fx0 + c;
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const f32x4*>(g + ((size_t)gy * W + gx) * 8 + half * 4);
-                *reinterpret_cast<f32x4*>(Pb + i * 4) = v;
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) {
+                const int i = tid + k * R8_THREADS;
+                if (i < R8_FH * R8_PITCH * 2) *reinterpret_cast<f32x4*>(Pb + i * 4) = pf[k];
             }
+            if (src == 0) tile_load(P.in1, H, W, fy0, fx0);  // the deconv half flies while the skip half is multiplied
             __syncthreads();
             f32x4 Aw[6];
 #pragma unroll
@@ -276,6 +326,14 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
         __syncthreads();
         res8_stage<18, false, false, false>(R0, 2, Pb, 3, 3, A1, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
         __syncthreads();
+        if (next_id < a.total_tiles) {                       // next tile's skip half flies under the last stage
+            int qi = 0;
+            while (qi + 1 < a.nprob && next_id >= a.p[qi + 1].tile_begin) ++qi;
+            const Res8Prob& Q = a.p[qi];
+            const int tq = next_id - Q.tile_begin;
+            const int qyb = tq / Q.tiles_x, qxb = tq - qyb * Q.tiles_x;
+            tile_load(Q.img, Q.H, Q.W, qyb * R8_OH - 4, qxb * R8_OW - 4);
+        }
         res8_stage<16, false, true, false>(Pb, 3, nullptr, 4, 4, A2, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, nullptr);
     }
 }
