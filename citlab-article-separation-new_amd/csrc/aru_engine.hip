@@ -71,6 +71,7 @@ struct asep_aru {
     int num_cus = 256;
     int persist_mt1 = 3, persist_mt2 = 2;   // resident blocks per CU assumed by the persistent conv grids
     int wino_blocks = 512;         // resident Winograd blocks (256 CUs x 2); ASEP_WINO_BLOCKS overrides
+    bool big_tile = true;          // ASEP_BIGTILE=0 disables the 16x32 single-buffer variant
     bool use_winograd = true;      // ASEP_WINOGRAD=0 selects the direct implicit-GEMM kernels everywhere
     bool profiling = false;
     bool prof_detail = false;      // per-layer names (scope + spatial size) instead of per-kernel names
@@ -252,16 +253,17 @@ std::string dims_of(const TL& l) {
 
 template <int KH, int KW>
 void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, int total_tiles, double flops,
-                   const std::string& scope, const TL& in0) {
+                   const std::string& scope, const TL& in0, bool big_tile) {
     const int mt = pc.c8 ? 1 : (pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1));
     dim3 grid(total_tiles, pc.mtiles / mt);
     char name[64];
-    snprintf(name, sizeof(name), "conv_mfma_kernel<%d,%d,%d,%s>", KH, KW, mt, pc.c8 ? "true" : "false");
+    snprintf(name, sizeof(name), "conv_mfma_kernel<%d,%d,%d,%s%s>", KH, KW, mt, pc.c8 ? "true" : "false", big_tile ? ",16,false" : "");
     std::string pname = name;
     if (m->prof_detail) pname += " " + scope + " " + dims_of(in0) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
     ProfScope ps(m, pname, flops);
     hipStream_t s = m->stream;
     if (pc.c8) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, true>), grid, dim3(256), 0, s, a);
+    else if (mt == 1 && big_tile) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false, 16, false>), grid, dim3(256), 0, s, a);
     else if (mt == 4) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 4, false>), grid, dim3(256), 0, s, a);
     else if (mt == 2) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 2, false>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false>), grid, dim3(256), 0, s, a);
@@ -284,6 +286,11 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
     }
     TL out;
     for (const Tensor& t : in0) out.push_back(new_tensor(m, t.H, t.W, pc.cout));
+    const bool wino = pc.d_wino && m->use_winograd;
+    // single channel group, one 16-channel output tile: 16 x 32 pixel blocks, single LDS buffer (more MFMA work per
+    // block against the fixed load latency of these short blocks)
+    const bool big_tile = !wino && !pc.c8 && pc.groups == 1 && pc.mtiles == 1 && m->big_tile;
+    const int th = big_tile ? 16 : CONV_TH;
     for (size_t b0 = 0; b0 < in0.size(); b0 += MAXP) {
         const size_t b1 = std::min(in0.size(), b0 + MAXP);
         ConvArgs a{};
@@ -295,7 +302,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             p.H = p.Ho = in0[i].H; p.W = p.Wo = in0[i].W;
             p.tiles_x = cdiv(in0[i].W, CONV_TW);
             p.tile_begin = tiles;
-            tiles += p.tiles_x * cdiv(in0[i].H, CONV_TH);
+            tiles += p.tiles_x * cdiv(in0[i].H, th);
             flops += 2.0 * in0[i].H * in0[i].W * pc.kh * pc.kw * (double)pc.cin * pc.cout;
         }
         a.nprob = (int)(b1 - b0);
@@ -305,7 +312,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
         a.relu_in = relu_in; a.relu_out = relu_out;
         TL sub(in0.begin() + b0, in0.begin() + b1);
-        if (pc.d_wino && m->use_winograd) {
+        if (wino) {
             a.wpk = (const f32x4*)pc.d_wino;
             int wt = 0;
             for (size_t i = b0; i < b1; ++i) {              // Winograd blocks are 4 x 32 output pixels
@@ -324,8 +331,8 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4, false>), grid, dim3(256), 0, m->stream, a);
             else if (mt == 2) hipLaunchKernelGGL((conv_wino_kernel<2, false>), grid, dim3(256), 0, m->stream, a);
             else hipLaunchKernelGGL((conv_wino_kernel<1, false>), grid, dim3(256), 0, m->stream, a);
-        } else if (pc.kh == 3) launch_conv_k<3, 3>(m, pc, a, tiles, flops, scope, sub);
-        else launch_conv_k<4, 4>(m, pc, a, tiles, flops, scope, sub);
+        } else if (pc.kh == 3) launch_conv_k<3, 3>(m, pc, a, tiles, flops, scope, sub, big_tile);
+        else launch_conv_k<4, 4>(m, pc, a, tiles, flops, scope, sub, big_tile);
     }
     return out;
 }
@@ -822,6 +829,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     m->cfg = *cfg;
     if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_BIGTILE")) m->big_tile = atoi(e) != 0;
     if (const char* e = getenv("ASEP_PERSIST1")) m->persist_mt1 = std::max(1, atoi(e));
     if (const char* e = getenv("ASEP_PERSIST2")) m->persist_mt2 = std::max(1, atoi(e));
     if (const char* e = getenv("ASEP_WINO_BLOCKS")) m->wino_blocks = std::max(1, atoi(e));

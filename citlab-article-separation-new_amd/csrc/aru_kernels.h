@@ -65,9 +65,9 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 // Software pipeline: the halo tile of channel group g+1 is fetched into registers while group g is multiplied
 // out of LDS (two LDS buffers, one barrier per group); the weight fragments of tap t+1 are requested before the
 // MFMAs of tap t are issued.
-template <int KH, int KW, int MT, bool C8>
+template <int KH, int KW, int MT, bool C8, int TH = CONV_TH, bool DBUF = true>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
-    constexpr int TH = CONV_TH, TW = CONV_TW, NT = CONV_NT;
+    constexpr int TW = CONV_TW, NT = TH / 2;             // TH rows x 2 column blocks of 16 pixels, 4 waves
     constexpr int LH = TH + KH - 1, LW = TW + KW - 1;
     constexpr int CPP = C8 ? 8 : 16;                    // channels per pixel held in LDS
     constexpr int PT = (KH - 1) / 2, PL = (KW - 1) / 2;  // TF SAME: pad_before = (k-1)/2
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int NV = LH * LW * SUBS;                   // float4 slots of one halo tile
     constexpr int NLOAD = (NV + 255) / 256;
     constexpr int LBUF = LH * LW * CPP;
-    __shared__ __attribute__((aligned(16))) float lds[2 * LBUF];
+    __shared__ __attribute__((aligned(16))) float lds[(DBUF ? 2 : 1) * LBUF];   // DBUF=false: single channel group only
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
@@ -169,9 +169,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     __syncthreads();
 
     for (int g = 0; g < ngroups; ++g) {
-        const float* __restrict__ lb = lds + (g & 1) * LBUF;
-        if (g + 1 < ngroups) stage_load(g + 1);
-#pragma unroll
+        const float* __restrict__ lb = lds + (DBUF ? (g & 1) : 0) * LBUF;
+        if (DBUF && g + 1 < ngroups) stage_load(g + 1);
+#pragma unroll NT >= 8 ? 1 : CPG
         for (int t = 0; t < CPG; ++t) {
             const int chunk = g * CPG + t;
             f32x4 an[MT];
@@ -205,8 +205,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) af[m] = an[m];
         }
-        if (g + 1 < ngroups) stage_store((g + 1) & 1);
-        __syncthreads();
+        if (DBUF && g + 1 < ngroups) stage_store((g + 1) & 1);
+        if (DBUF) __syncthreads();
     }
 
     // ---- epilogue: D layout col = lane&15 -> pixel, row = 4*(lane>>4)+reg -> output channel ----
