@@ -261,7 +261,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int WINO_TH = 4;
 constexpr int WINO_TW = 32;
 
-template <int MT, bool PERSIST>
+template <int MT>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
     constexpr int TH = WINO_TH, TW = WINO_TW;
     constexpr int TILES = (TH / 2) * (TW / 2);            // 32 Winograd tiles
@@ -270,39 +270,41 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
-    const int mt0 = blockIdx.y * MT;
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    const ConvProb& P = a.p[pi];
+    const int tile = blockIdx.x - P.tile_begin;
+    const int tyb = tile / P.tiles_x, txb = tile - tyb * P.tiles_x;
+    const int x0 = txb * TW, y0 = tyb * TH, mt0 = blockIdx.y * MT;
+    const int H = P.H, W = P.W;
+
     // transform role: tile tt (row-major in the 2 x 16 tile grid), channel pair cp (channels 2cp, 2cp+1 of the group)
     const int tt = tid >> 3, cp = tid & 7;
+    const int py = y0 + 2 * (tt >> 4) - 1, px = x0 + 2 * (tt & 15) - 1;   // patch origin (SAME: pad 1)
+    // one 32-bit element offset per thread; rows/columns of the patch are uniform multiples of the pixel stride
+    const int off00 = py * W + px;
 
-    // per-block-tile geometry (the block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... : persistent loop, so that
-    // the first patch of the next tile is fetched under the last MFMA phase and the stores drain under the next tile)
-    struct Geo { const float* in0; const float* in1; const float* res; float* out; int H, W, Ho, Wo, x0, y0; };
-    auto locate = [&](int tile_id) {
-        int pi = 0;
-        while (pi + 1 < a.nprob && tile_id >= a.p[pi + 1].tile_begin) ++pi;
-        const ConvProb& P = a.p[pi];
-        const int t = tile_id - P.tile_begin;
-        const int tyb = t / P.tiles_x, txb = t - tyb * P.tiles_x;
-        Geo g;
-        g.in0 = P.in0; g.in1 = P.in1; g.res = P.res; g.out = P.out;
-        g.H = P.H; g.W = P.W; g.Ho = P.Ho; g.Wo = P.Wo; g.x0 = txb * TW; g.y0 = tyb * TH;
-        return g;
-    };
+    f32x4 acc[4][MT][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[p][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     f32x2 d[4][4];
-    auto patch_load = [&](const Geo& G, int g) {
+    auto patch_load = [&](int g) {
         const int c = g * 16 + cp * 2;
-        const float* __restrict__ src = c < a.c0 ? G.in0 + c : G.in1 + (c - a.c0);
+        const float* __restrict__ src = c < a.c0 ? P.in0 + c : P.in1 + (c - a.c0);
         const int cs = c < a.c0 ? a.c0 : a.c1;
-        const int py = G.y0 + 2 * (tt >> 4) - 1, px = G.x0 + 2 * (tt & 15) - 1;   // patch origin (SAME: pad 1)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int gy = py + r, gx = px + s;
                 f32x2 v = f32x2{0.f, 0.f};
-                if (gy >= 0 && gy < G.H && gx >= 0 && gx < G.W)
-                    v = *reinterpret_cast<const f32x2*>(src + ((size_t)gy * G.W + gx) * cs);
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                    v = *reinterpret_cast<const f32x2*>(src + (size_t)(off00 + r * W + s) * cs);
                 d[r][s] = v;
             }
     };
@@ -313,21 +315,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) { d[r][s].x = fmaxf(d[r][s].x, 0.f); d[r][s].y = fmaxf(d[r][s].y, 0.f); }
         }
-        f32x2 t[4][4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            t[0][s] = d[0][s] - d[2][s];
-            t[1][s] = d[1][s] + d[2][s];
-            t[2][s] = d[2][s] - d[1][s];
-            t[3][s] = d[1][s] - d[3][s];
-        }
         float* vb = V + buf * VBUF + tt * 16 + cp * 2;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            *reinterpret_cast<f32x2*>(vb + (r * 4 + 0) * TILES * 16) = t[r][0] - t[r][2];
-            *reinterpret_cast<f32x2*>(vb + (r * 4 + 1) * TILES * 16) = t[r][1] + t[r][2];
-            *reinterpret_cast<f32x2*>(vb + (r * 4 + 2) * TILES * 16) = t[r][2] - t[r][1];
-            *reinterpret_cast<f32x2*>(vb + (r * 4 + 3) * TILES * 16) = t[r][1] - t[r][3];
+            // row r of B^T d, then times B, written straight out (keeps at most one row of temporaries live)
+            f32x2 t0, t1, t2, t3;
+            if (r == 0) { t0 = d[0][0] - d[2][0]; t1 = d[0][1] - d[2][1]; t2 = d[0][2] - d[2][2]; t3 = d[0][3] - d[2][3]; }
+            else if (r == 1) { t0 = d[1][0] + d[2][0]; t1 = d[1][1] + d[2][1]; t2 = d[1][2] + d[2][2]; t3 = d[1][3] + d[2][3]; }
+            else if (r == 2) { t0 = d[2][0] - d[1][0]; t1 = d[2][1] - d[1][1]; t2 = d[2][2] - d[1][2]; t3 = d[2][3] - d[1][3]; }
+            else { t0 = d[1][0] - d[3][0]; t1 = d[1][1] - d[3][1]; t2 = d[1][2] - d[3][2]; t3 = d[1][3] - d[3][3]; }
+            *reinterpret_cast<f32x2*>(vb + (r * 4 + 0) * TILES * 16) = t0 - t2;
+            *reinterpret_cast<f32x2*>(vb + (r * 4 + 1) * TILES * 16) = t1 + t2;
+            *reinterpret_cast<f32x2*>(vb + (r * 4 + 2) * TILES * 16) = t2 - t1;
+            *reinterpret_cast<f32x2*>(vb + (r * 4 + 3) * TILES * 16) = t1 - t3;
         }
     };
 
@@ -335,125 +335,102 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
     const size_t wstride = (size_t)a.mtiles * 64;          // f32x4 per (group, pos)
     const int G = a.groups;
 
-    int tile_id = blockIdx.x;
-    if (tile_id >= a.total_tiles) return;
-    Geo cur = locate(tile_id);
-    patch_load(cur, 0);
+    patch_load(0);
     f32x4 af[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) af[m] = wbase[((size_t)wave * 4) * wstride + (size_t)m * 64];
+    transform_store(0);
+    __syncthreads();
 
-    while (true) {
-        const int next_id = tile_id + gridDim.x;
-        const bool has_next = PERSIST && next_id < a.total_tiles;
-        Geo nxt = cur;
-        if (has_next) nxt = locate(next_id);
-
-        f32x4 acc[4][MT][2];
+    for (int g = 0; g < G; ++g) {
+        const bool more = g + 1 < G;
+        if (more) patch_load(g + 1);                       // global loads in flight during the MFMA phase
+        // ---- MFMA phase: positions 4*wave .. 4*wave+3 of group g -------------------------------------------
+        const float* __restrict__ vcur = V + (g & 1) * VBUF;
+        const f32x4* __restrict__ wg = wbase + ((size_t)g * 16 + wave * 4) * wstride;
+        const f32x4* __restrict__ wnext = wbase + ((size_t)(more ? g + 1 : g) * 16 + wave * 4) * wstride;
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int p = 0; p < 4; ++p) {
+            f32x4 an[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m)
+                an[m] = p + 1 < 4 ? wg[(size_t)(p + 1) * wstride + (size_t)m * 64] : wnext[(size_t)m * 64];
+            const float* vb = vcur + ((wave * 4 + p) * TILES + j) * 16 + kk * 4;
+            f32x4 bf[2];
 #pragma unroll
-                for (int n = 0; n < 2; ++n) acc[p][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        transform_store(0);                                // V[0] is free: the epilogue of the previous tile ended with a barrier
-        __syncthreads();
-
-        for (int g = 0; g < G; ++g) {
-            const bool more = g + 1 < G;
-            if (more) patch_load(cur, g + 1);              // global loads in flight during the MFMA phase
-            else if (has_next) patch_load(nxt, 0);
-            // ---- MFMA phase: positions 4*wave .. 4*wave+3 of group g ---------------------------------------
-            const float* __restrict__ vcur = V + (g & 1) * VBUF;
-            const f32x4* __restrict__ wg = wbase + ((size_t)g * 16 + wave * 4) * wstride;
-            const f32x4* __restrict__ wnext = wbase + ((size_t)(more ? g + 1 : 0) * 16 + wave * 4) * wstride;
+            for (int n = 0; n < 2; ++n) bf[n] = *reinterpret_cast<const f32x4*>(vb + n * 16 * 16);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                f32x4 an[MT];
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    an[m] = p + 1 < 4 ? wg[(size_t)(p + 1) * wstride + (size_t)m * 64] : wnext[(size_t)m * 64];
-                const float* vb = vcur + ((wave * 4 + p) * TILES + j) * 16 + kk * 4;
-                f32x4 bf[2];
 #pragma unroll
-                for (int n = 0; n < 2; ++n) bf[n] = *reinterpret_cast<const f32x4*>(vb + n * 16 * 16);
+                    for (int n = 0; n < 2; ++n)
+                        acc[p][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][r], bf[n][r], acc[p][m][n], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int n = 0; n < 2; ++n)
-                            acc[p][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][r], bf[n][r], acc[p][m][n], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) af[m] = an[m];
-                __builtin_amdgcn_sched_barrier(0);         // keep the scheduler from hoisting the next positions' loads (VGPR pressure)
-            }
-            if (more) transform_store((g + 1) & 1);        // the other buffer: last read in iteration g-1
-            __syncthreads();
+            for (int m = 0; m < MT; ++m) af[m] = an[m];
         }
+        if (more) transform_store((g + 1) & 1);            // the other buffer: last read in iteration g-1
+        __syncthreads();
+    }
 
-        // ---- output phase: exchange through LDS (two m-tiles per round), inverse transform, epilogue ---------
-        const int oy = cur.y0 + 2 * (tt >> 4), ox = cur.x0 + 2 * (tt & 15);
-        constexpr int ROUNDS = (MT + 1) / 2;
+    // ---- output phase: exchange through LDS (two m-tiles per round), inverse transform, epilogue -------------
+    const int oy = y0 + 2 * (tt >> 4), ox = x0 + 2 * (tt & 15);
+    float* __restrict__ out = P.out;
+    const float* __restrict__ res = P.res;
+    constexpr int ROUNDS = (MT + 1) / 2;
 #pragma unroll
-        for (int rd = 0; rd < ROUNDS; ++rd) {
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        if (rd > 0) __syncthreads();                       // readers of the previous round are done
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int m = rd * 2 + h;
-                if (m < MT) {
+        for (int h = 0; h < 2; ++h) {
+            const int m = rd * 2 + h;
+            if (m < MT) {
 #pragma unroll
-                    for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < 4; ++p)
 #pragma unroll
-                        for (int n = 0; n < 2; ++n)
-                            *reinterpret_cast<f32x4*>(V + h * VBUF + ((wave * 4 + p) * TILES + n * 16 + j) * 16 + kk * 4) = acc[p][m][n];
-                }
+                    for (int n = 0; n < 2; ++n)
+                        *reinterpret_cast<f32x4*>(V + h * VBUF + ((wave * 4 + p) * TILES + n * 16 + j) * 16 + kk * 4) = acc[p][m][n];
             }
-            __syncthreads();
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int m = rd * 2 + h;
-                if (m >= MT) continue;
-                f32x2 M[4][4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        M[r][s] = *reinterpret_cast<const f32x2*>(V + h * VBUF + ((r * 4 + s) * TILES + tt) * 16 + cp * 2);
-                f32x2 s0[4], s1[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    s0[s] = M[0][s] + M[1][s] + M[2][s];
-                    s1[s] = M[1][s] - M[2][s] - M[3][s];
-                }
-                f32x2 y[2][2];
-                y[0][0] = s0[0] + s0[1] + s0[2];
-                y[0][1] = s0[1] - s0[2] - s0[3];
-                y[1][0] = s1[0] + s1[1] + s1[2];
-                y[1][1] = s1[1] - s1[2] - s1[3];
-                const int co = (mt0 + m) * 16 + cp * 2;
-                if (co < a.cout) {
-                    const f32x2 b = *reinterpret_cast<const f32x2*>(a.bias + co);
-#pragma unroll
-                    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                        for (int dx = 0; dx < 2; ++dx) {
-                            const int yy = oy + dy, xx = ox + dx;
-                            if (yy < cur.Ho && xx < cur.Wo) {
-                                const size_t p = (size_t)yy * cur.Wo + xx;
-                                f32x2 v = y[dy][dx] + b;
-                                if (cur.res) v += *reinterpret_cast<const f32x2*>(cur.res + p * a.cout + co);
-                                if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
-                                *reinterpret_cast<f32x2*>(cur.out + p * a.cout + co) = v;
-                            }
-                        }
-                }
-            }
-            __syncthreads();                               // V may be rewritten (next round / next tile's transform)
         }
-        if (!has_next) break;
-        tile_id = next_id;
-        cur = nxt;
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = rd * 2 + h;
+            if (m >= MT) continue;
+            const float* mb = V + h * VBUF + tt * 16 + cp * 2;
+            f32x2 s0[4], s1[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f32x2 m0 = *reinterpret_cast<const f32x2*>(mb + (0 * 4 + s) * TILES * 16);
+                const f32x2 m1 = *reinterpret_cast<const f32x2*>(mb + (1 * 4 + s) * TILES * 16);
+                const f32x2 m2 = *reinterpret_cast<const f32x2*>(mb + (2 * 4 + s) * TILES * 16);
+                const f32x2 m3 = *reinterpret_cast<const f32x2*>(mb + (3 * 4 + s) * TILES * 16);
+                s0[s] = m0 + m1 + m2;
+                s1[s] = m1 - m2 - m3;
+            }
+            f32x2 y[2][2];
+            y[0][0] = s0[0] + s0[1] + s0[2];
+            y[0][1] = s0[1] - s0[2] - s0[3];
+            y[1][0] = s1[0] + s1[1] + s1[2];
+            y[1][1] = s1[1] - s1[2] - s1[3];
+            const int co = (mt0 + m) * 16 + cp * 2;
+            if (co < a.cout) {
+                const f32x2 b = *reinterpret_cast<const f32x2*>(a.bias + co);
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int yy = oy + dy, xx = ox + dx;
+                        if (yy < P.Ho && xx < P.Wo) {
+                            const size_t p = (size_t)yy * P.Wo + xx;
+                            f32x2 v = y[dy][dx] + b;
+                            if (res) v += *reinterpret_cast<const f32x2*>(res + p * a.cout + co);
+                            if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+                            *reinterpret_cast<f32x2*>(out + p * a.cout + co) = v;
+                        }
+                    }
+            }
+        }
     }
 }
 

@@ -1,0 +1,63 @@
+"""GPU parity of the batched device-resident entry point (asep_aru_forward_batch_dev): several pages in one call
+must give exactly what the single-page call gives, page by page (bit-identical: same kernels, same order)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batch_equals_single_pages_and_oracle():
+    import torch
+    from citlab_article_separation_new_amd import _lib, net_post_processing_helper as helper
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    from oracle import aru_oracle
+    cfg = AruConfig()
+    w = init_aru_weights(cfg, 1234, bias_jitter=0.05, logit_scale=0.05)
+    graph = helper.AruGraph(w, cfg)
+    lib = _lib.init_device(0)
+    h = graph.handle(0)
+    H, W, B = 75, 131, 5                      # 5 pages x 3 scales = 15 problems > MAXP (12): exercises launch splitting
+    rng = np.random.default_rng(0)
+    pages = [rng.random((H, W), dtype=np.float32) for _ in range(B)]
+    d_in = [torch.from_numpy(p).cuda() for p in pages]
+    d_out = [torch.empty(H, W, 2, device="cuda") for _ in range(B)]
+    d_u8 = [torch.empty(H, W, 2, device="cuda", dtype=torch.uint8) for _ in range(B)]
+    Arr = C.c_void_p * B
+    rc = lib.asep_aru_forward_batch_dev(h, B, Arr(*[t.data_ptr() for t in d_in]), H, W, Arr(*[t.data_ptr() for t in d_out]),
+                                        Arr(*[t.data_ptr() for t in d_u8]), None, 0.05, None)
+    _lib.check(rc, "asep_aru_forward_batch_dev")
+    torch.cuda.synchronize()
+    for b in range(B):
+        single = helper.get_net_output(pages[b], graph, "0")
+        got = d_out[b].cpu().numpy()
+        assert np.array_equal(got, single), f"page {b}: batched result differs from the single-page call"
+        ref = aru_oracle.forward_torch(pages[b], w, cfg)
+        assert float(np.abs(got - ref).max()) <= 1e-4
+        assert np.array_equal(d_u8[b].cpu().numpy(), aru_oracle.to_uint8(got))
+    with pytest.raises(_lib.AsepError):
+        _lib.check(lib.asep_aru_forward_batch_dev(h, 0, None, H, W, None, None, None, 0.05, None), "batch")
+    graph.close()
+
+
+@pytest.mark.parametrize("H,W", [(16, 58), (17, 59), (33, 117), (200, 64)])
+def test_fused_block_tile_boundaries(H, W):
+    """Sizes around the 16 x 58 tile of the fused level-0 blocks and the 4 x 32 Winograd tile."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    from oracle import aru_oracle
+    cfg = AruConfig()
+    w = init_aru_weights(cfg, 77, bias_jitter=0.05, logit_scale=0.05)
+    graph = helper.AruGraph(w, cfg)
+    img = np.random.default_rng(H * W).random((H, W), dtype=np.float32)
+    ref, inter = aru_oracle.forward_torch(img, w, cfg, return_intermediates=True)
+    out = helper.get_net_output(img, graph, "0")
+    for name in ("scale_0_unet_down_0_conv", "scale_0_unet_up_0_conv", "scale_1_unet_down_0_conv", "scale_0_unet_down_3_conv"):
+        got = helper.get_endpoint(graph, name)
+        scale = max(1.0, float(np.abs(inter[name]).max()))
+        assert float(np.abs(got - inter[name]).max()) <= 2e-5 * scale, name
+    assert float(np.abs(out - ref).max()) <= 1e-4
+    graph.close()
