@@ -380,6 +380,24 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
     constexpr int ROUNDS = (MT + 1) / 2;
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
+        // residual operand of this round: requested before the LDS exchange so that its latency hides under it
+        f32x2 rv[2][2][2];
+        if (res) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int co = (mt0 + rd * 2 + h) * 16 + cp * 2;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int yy = oy + dy, xx = ox + dx;
+                        f32x2 v = f32x2{0.f, 0.f};
+                        if (rd * 2 + h < MT && co < a.cout && yy < P.Ho && xx < P.Wo)
+                            v = *reinterpret_cast<const f32x2*>(res + ((size_t)yy * P.Wo + xx) * a.cout + co);
+                        rv[h][dy][dx] = v;
+                    }
+            }
+        }
         if (rd > 0) __syncthreads();                       // readers of the previous round are done
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -424,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
                         if (yy < P.Ho && xx < P.Wo) {
                             const size_t p = (size_t)yy * P.Wo + xx;
                             f32x2 v = y[dy][dx] + b;
-                            if (res) v += *reinterpret_cast<const f32x2*>(res + p * a.cout + co);
+                            if (res) v += rv[h][dy][dx];
                             if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
                             *reinterpret_cast<f32x2*>(out + p * a.cout + co) = v;
                         }
