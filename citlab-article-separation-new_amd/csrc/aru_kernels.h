@@ -260,6 +260,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int WINO_TH = 4;
 constexpr int WINO_TW = 32;
+#ifndef WINO_XFORM_AT
+#define WINO_XFORM_AT 1
+#endif
 
 template <int MT>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
@@ -368,8 +371,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
                         acc[p][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][r], bf[n][r], acc[p][m][n], 0, 0, 0);
 #pragma unroll
             for (int m = 0; m < MT; ++m) af[m] = an[m];
+            // transform of the next group in the shadow of this phase's MFMAs (its patch loads were issued at the top;
+            // it writes the other V buffer, last read in iteration g-1)
+            if (p == WINO_XFORM_AT && more) transform_store((g + 1) & 1);
         }
-        if (more) transform_store((g + 1) & 1);            // the other buffer: last read in iteration g-1
         __syncthreads();
     }
 
