@@ -64,6 +64,9 @@ struct asep_aru {
     BufferPool pool;
     std::map<std::string, Tensor> endpoints;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;   // the attention branch runs here, concurrently with the feature branch
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool use_side_stream = true;         // ASEP_SIDE_STREAM=0 serialises everything on the caller's stream
     std::vector<void*> owned;
 
     // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
@@ -84,6 +87,9 @@ struct asep_aru {
         for (void* p : owned)
             if (p) (void)hipFree(p);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
     }
     hipEvent_t next_event() {
         if (ev_next == ev_pool.size()) {
@@ -713,12 +719,27 @@ int forward_impl(asep_aru* m, int B, const float* const* d_imgs, int H, int W, f
         if (!cfg.mvn) stats.clear();
 
         TL att;
+        bool forked = false;
         if (cfg.use_attention) {
+            // the attention CNN is a chain of small launches that cannot fill the chip: run it on a side stream next
+            // to the feature branch (fork after the pyramid, join before the combine).  Per-launch profiling keeps
+            // everything on one stream so that kernel times are not inflated by the overlap.
+            if (m->use_side_stream && !m->profiling && m->side_stream) {
+                ASEP_HIP_CHECK(hipEventRecord(m->ev_fork, stream));
+                ASEP_HIP_CHECK(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
+                m->stream = m->side_stream;
+                forked = true;
+            }
             att = att_cnn(m, all, stats);
+            if (forked) {
+                ASEP_HIP_CHECK(hipEventRecord(m->ev_join, m->side_stream));
+                m->stream = stream;
+            }
             for (size_t i = 0; i < att.size(); ++i)
                 m->endpoints[(i / nsc ? "p" + std::to_string(i / nsc) + "/" : std::string()) + "att_" + std::to_string(i % nsc)] = att[i];
         }
         TL feat = det_cnn(m, all, names, stats);
+        if (forked) ASEP_HIP_CHECK(hipStreamWaitEvent(stream, m->ev_join, 0));
         TL fsum;
         if (nsc > 1) {
             TL coarse;
@@ -830,6 +851,13 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BIGTILE")) m->big_tile = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_SIDE_STREAM")) m->use_side_stream = atoi(e) != 0;
+    if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) {
+        set_error("asep_aru_load: cannot create the side stream");
+        return nullptr;
+    }
     if (const char* e = getenv("ASEP_PERSIST1")) m->persist_mt1 = std::max(1, atoi(e));
     if (const char* e = getenv("ASEP_PERSIST2")) m->persist_mt2 = std::max(1, atoi(e));
     if (const char* e = getenv("ASEP_WINO_BLOCKS")) m->wino_blocks = std::max(1, atoi(e));
