@@ -61,11 +61,28 @@ struct asep_aru {
     float* d_logit_b = nullptr;
     float* d_stats = nullptr;      // mvn {mean, 1/std}
     double* d_sums = nullptr;
-    BufferPool pool;
+    // A lane = one in-order chain of launches (stream + its buffer pool + a side stream for the attention branch).
+    // A batch of pages is split over the lanes so that two independent chains fill each other's launch tails.
+    struct Lane {
+        hipStream_t s = nullptr;         // lane 0 uses the caller's stream
+        bool own_stream = false;
+        hipStream_t side = nullptr;
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_begin = nullptr, ev_done = nullptr;
+        BufferPool pool;
+        ~Lane() {
+            if (ev_fork) (void)hipEventDestroy(ev_fork);
+            if (ev_join) (void)hipEventDestroy(ev_join);
+            if (ev_begin) (void)hipEventDestroy(ev_begin);
+            if (ev_done) (void)hipEventDestroy(ev_done);
+            if (side) (void)hipStreamDestroy(side);
+            if (own_stream && s) (void)hipStreamDestroy(s);
+        }
+    };
+    std::vector<std::unique_ptr<Lane>> lanes;
+    Lane* cur = nullptr;
+    int num_lanes = 1;                   // ASEP_LANES (2 lanes measured +0.4 %: the launches already fill the chip)
     std::map<std::string, Tensor> endpoints;
     hipStream_t stream = nullptr;
-    hipStream_t side_stream = nullptr;   // the attention branch runs here, concurrently with the feature branch
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool use_side_stream = true;         // ASEP_SIDE_STREAM=0 serialises everything on the caller's stream
     std::vector<void*> owned;
 
@@ -87,9 +104,6 @@ struct asep_aru {
         for (void* p : owned)
             if (p) (void)hipFree(p);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (side_stream) (void)hipStreamDestroy(side_stream);
     }
     hipEvent_t next_event() {
         if (ev_next == ev_pool.size()) {
@@ -246,7 +260,7 @@ typedef std::vector<Tensor> TL;
 Tensor new_tensor(asep_aru* m, int H, int W, int C) {
     Tensor t;
     t.H = H; t.W = W; t.C = C;
-    t.p = (float*)m->pool.get(t.count() * sizeof(float));
+    t.p = (float*)m->cur->pool.get(t.count() * sizeof(float));
     return t;
 }
 
@@ -675,12 +689,13 @@ TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) 
 }
 
 // B pages of identical size through the net; problems = pages x scales
-int forward_impl(asep_aru* m, int B, const float* const* d_imgs, int H, int W, float* const* d_outs,
-                 uint8_t* const* d_u8s, uint8_t* const* d_masks, float threshold, hipStream_t stream) {
+int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* const* d_imgs, int H, int W,
+                 float* const* d_outs, uint8_t* const* d_u8s, uint8_t* const* d_masks, float threshold) {
     const asep_aru_cfg& cfg = m->cfg;
+    hipStream_t stream = L.s;
     m->stream = stream;
-    m->pool.begin();
-    m->endpoints.clear();
+    m->cur = &L;
+    L.pool.begin();
     try {
         const int nsc = cfg.use_attention ? cfg.num_scales_att : 1;
         if (nsc > MAX_SCALES) { set_error("num_scales_att %d > %d", nsc, MAX_SCALES); return ASEP_ERR_UNSUPPORTED; }
@@ -694,8 +709,8 @@ int forward_impl(asep_aru* m, int B, const float* const* d_imgs, int H, int W, f
             level0.push_back(img);
             const float* st = nullptr;
             if (cfg.mvn) {
-                double* sums = (double*)m->pool.get(2 * sizeof(double));
-                float* stt = (float*)m->pool.get(2 * sizeof(float));
+                double* sums = (double*)L.pool.get(2 * sizeof(double));
+                float* stt = (float*)L.pool.get(2 * sizeof(float));
                 ASEP_HIP_CHECK(hipMemsetAsync(sums, 0, 2 * sizeof(double), stream));
                 hipLaunchKernelGGL(moments_kernel, dim3(grid_1d(img.count())), dim3(256), 0, stream, img.p, img.count(), sums);
                 hipLaunchKernelGGL(moments_finish_kernel, dim3(1), dim3(1), 0, stream, sums, img.count(), stt);
@@ -713,7 +728,7 @@ int forward_impl(asep_aru* m, int B, const float* const* d_imgs, int H, int W, f
         for (int b = 0; b < B; ++b)
             for (int s = 0; s < nsc; ++s) {
                 all.push_back(pyr[s][b]);
-                names.push_back((b ? "p" + std::to_string(b) + "/" : std::string()) + "scale_" + std::to_string(s));
+                names.push_back((page0 + b ? "p" + std::to_string(page0 + b) + "/" : std::string()) + "scale_" + std::to_string(s));
                 stats.push_back(stats0[b]);
             }
         if (!cfg.mvn) stats.clear();
@@ -724,22 +739,24 @@ int forward_impl(asep_aru* m, int B, const float* const* d_imgs, int H, int W, f
             // the attention CNN is a chain of small launches that cannot fill the chip: run it on a side stream next
             // to the feature branch (fork after the pyramid, join before the combine).  Per-launch profiling keeps
             // everything on one stream so that kernel times are not inflated by the overlap.
-            if (m->use_side_stream && !m->profiling && m->side_stream) {
-                ASEP_HIP_CHECK(hipEventRecord(m->ev_fork, stream));
-                ASEP_HIP_CHECK(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
-                m->stream = m->side_stream;
+            if (m->use_side_stream && !m->profiling && L.side) {
+                ASEP_HIP_CHECK(hipEventRecord(L.ev_fork, stream));
+                ASEP_HIP_CHECK(hipStreamWaitEvent(L.side, L.ev_fork, 0));
+                m->stream = L.side;
                 forked = true;
             }
             att = att_cnn(m, all, stats);
             if (forked) {
-                ASEP_HIP_CHECK(hipEventRecord(m->ev_join, m->side_stream));
+                ASEP_HIP_CHECK(hipEventRecord(L.ev_join, L.side));
                 m->stream = stream;
             }
-            for (size_t i = 0; i < att.size(); ++i)
-                m->endpoints[(i / nsc ? "p" + std::to_string(i / nsc) + "/" : std::string()) + "att_" + std::to_string(i % nsc)] = att[i];
+            for (size_t i = 0; i < att.size(); ++i) {
+                const int pg = page0 + (int)i / nsc;
+                m->endpoints[(pg ? "p" + std::to_string(pg) + "/" : std::string()) + "att_" + std::to_string(i % nsc)] = att[i];
+            }
         }
         TL feat = det_cnn(m, all, names, stats);
-        if (forked) ASEP_HIP_CHECK(hipStreamWaitEvent(stream, m->ev_join, 0));
+        if (forked) ASEP_HIP_CHECK(hipStreamWaitEvent(stream, L.ev_join, 0));
         TL fsum;
         if (nsc > 1) {
             TL coarse;
@@ -852,12 +869,19 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BIGTILE")) m->big_tile = atoi(e) != 0;
     if (const char* e = getenv("ASEP_SIDE_STREAM")) m->use_side_stream = atoi(e) != 0;
-    if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) {
-        set_error("asep_aru_load: cannot create the side stream");
-        return nullptr;
+    if (const char* e = getenv("ASEP_LANES")) m->num_lanes = std::max(1, std::min(4, atoi(e)));
+    for (int l = 0; l < m->num_lanes; ++l) {
+        std::unique_ptr<asep_aru::Lane> L(new asep_aru::Lane());
+        bool ok = hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&L->ev_join, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&L->ev_begin, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&L->ev_done, hipEventDisableTiming) == hipSuccess;
+        if (ok && l > 0) { ok = hipStreamCreateWithFlags(&L->s, hipStreamNonBlocking) == hipSuccess; L->own_stream = ok; }
+        if (!ok) { set_error("asep_aru_load: cannot create streams/events for lane %d", l); return nullptr; }
+        m->lanes.push_back(std::move(L));
     }
+    m->cur = m->lanes[0].get();
     if (const char* e = getenv("ASEP_PERSIST1")) m->persist_mt1 = std::max(1, atoi(e));
     if (const char* e = getenv("ASEP_PERSIST2")) m->persist_mt2 = std::max(1, atoi(e));
     if (const char* e = getenv("ASEP_WINO_BLOCKS")) m->wino_blocks = std::max(1, atoi(e));
@@ -924,11 +948,38 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
 
 void asep_aru_free(asep_aru* m) { delete m; }
 
+// splits the pages over the lanes (lane 0 = the caller's stream), forks / joins with events
+static int forward_lanes(asep_aru* m, int n_pages, const float* const* d_imgs, int H, int W, float* const* d_outs,
+                         uint8_t* const* d_u8, uint8_t* const* d_mask, float threshold, hipStream_t stream) {
+    m->endpoints.clear();
+    const int nl = (m->profiling || n_pages < 2) ? 1 : std::min<int>((int)m->lanes.size(), n_pages);
+    asep_aru::Lane& L0 = *m->lanes[0];
+    L0.s = stream;
+    if (nl == 1) return forward_impl(m, L0, 0, n_pages, d_imgs, H, W, d_outs, d_u8, d_mask, threshold);
+    ASEP_HIP_CHECK(hipEventRecord(L0.ev_begin, stream));
+    int page0 = 0;
+    for (int l = 0; l < nl; ++l) {
+        asep_aru::Lane& L = *m->lanes[l];
+        const int cnt = n_pages / nl + (l < n_pages % nl ? 1 : 0);
+        if (l > 0) ASEP_HIP_CHECK(hipStreamWaitEvent(L.s, L0.ev_begin, 0));
+        int rc = forward_impl(m, L, page0, cnt, d_imgs + page0, H, W, d_outs + page0, d_u8 ? d_u8 + page0 : nullptr,
+                              d_mask ? d_mask + page0 : nullptr, threshold);
+        if (rc) return rc;
+        if (l > 0) {
+            ASEP_HIP_CHECK(hipEventRecord(L.ev_done, L.s));
+            ASEP_HIP_CHECK(hipStreamWaitEvent(stream, L.ev_done, 0));
+        }
+        page0 += cnt;
+    }
+    m->stream = stream;
+    return ASEP_OK;
+}
+
 int asep_aru_forward_dev(asep_aru* m, const float* d_img, int H, int W, float* d_out, uint8_t* d_out_u8,
                          uint8_t* d_out_mask, float threshold, void* stream) {
     if (!m || !d_img || !d_out || H < 1 || W < 1) { set_error("asep_aru_forward_dev: bad argument"); return ASEP_ERR_ARG; }
-    return forward_impl(m, 1, &d_img, H, W, &d_out, d_out_u8 ? &d_out_u8 : nullptr, d_out_mask ? &d_out_mask : nullptr,
-                        threshold, (hipStream_t)stream);
+    return forward_lanes(m, 1, &d_img, H, W, &d_out, d_out_u8 ? &d_out_u8 : nullptr, d_out_mask ? &d_out_mask : nullptr,
+                         threshold, (hipStream_t)stream);
 }
 
 int asep_aru_forward_batch_dev(asep_aru* m, int n_pages, const float* const* d_imgs, int H, int W, float* const* d_outs,
@@ -939,7 +990,7 @@ int asep_aru_forward_batch_dev(asep_aru* m, int n_pages, const float* const* d_i
             set_error("asep_aru_forward_batch_dev: null page pointer at %d", b);
             return ASEP_ERR_ARG;
         }
-    return forward_impl(m, n_pages, d_imgs, H, W, d_outs, d_out_u8, d_out_mask, threshold, (hipStream_t)stream);
+    return forward_lanes(m, n_pages, d_imgs, H, W, d_outs, d_out_u8, d_out_mask, threshold, (hipStream_t)stream);
 }
 
 int asep_aru_forward(asep_aru* m, const float* img_hw, int H, int W, float* out_hwc, uint8_t* out_u8,
