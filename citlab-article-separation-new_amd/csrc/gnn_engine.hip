@@ -16,6 +16,11 @@ struct asep_gnn {
     float* Wg[4] = {nullptr, nullptr, nullptr, nullptr};
     float* bg[4] = {nullptr, nullptr, nullptr, nullptr};
     float *C1 = nullptr, *cb1 = nullptr, *C2 = nullptr, *cb2 = nullptr, *C3 = nullptr, *cb3 = nullptr;
+    // fused MFMA step kernel (U <= 8, Ed <= 4): permuted W1 / W2 fragments + quad descriptors
+    float *A1 = nullptr, *A2 = nullptr;
+    unsigned char* qdesc = nullptr;
+    int nch = 0;
+    bool use_step = true;             // ASEP_GNN_STEP=0 selects the separate message / LSTM kernels
     std::vector<void*> owned;
     BufferPool pool;
     // state of the last forward
@@ -109,6 +114,19 @@ int forward_impl(asep_gnn* g, int N, int E, const int32_t* d_edges, const float*
         ASEP_HIP_CHECK(hipMemsetAsync(cs[0], 0, nh * 4, s));
         int cur = 0;
         for (int t = 0; t < c.num_transition_steps; ++t) {
+            if (g->use_step && g->A1 && g->nch > 0) {
+                StepArgs sa{};
+                sa.u = d_u; sa.h_in = h[cur]; sa.c_in = cs[cur]; sa.ef = d_ef;
+                sa.tptr = eb.colptr; sa.tsrc = eb.tsrc; sa.tfirst = eb.tfirst;
+                sa.A1 = (const gf32x4*)g->A1; sa.A2 = (const gf32x4*)g->A2; sa.b1 = g->b1; sa.b2 = g->b2;
+                for (int q = 0; q < 4; ++q) { sa.Wg[q] = g->Wg[q]; sa.bg[q] = g->bg[q]; }
+                sa.h_out = h[cur ^ 1]; sa.c_out = cs[cur ^ 1];
+                sa.N = N; sa.U = c.node_feature_dim; sa.Ed = c.edge_feature_dim; sa.E = std::max(E, 1); sa.nch = g->nch;
+                sa.qdesc = g->qdesc;
+                hipLaunchKernelGGL(gnn_step_kernel, dim3(N), dim3(256), 0, s, sa);
+                cur ^= 1;
+                continue;
+            }
             MsgArgs ma{};
             ma.u = d_u; ma.h = h[cur]; ma.ef = d_ef; ma.tptr = eb.colptr; ma.tsrc = eb.tsrc; ma.tfirst = eb.tfirst;
             ma.W1 = g->W1; ma.b1 = g->b1; ma.W2 = g->W2; ma.b2 = g->b2; ma.x = x;
@@ -201,6 +219,66 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
     if (!rc) rc = upload_named(g.get(), blob, c + "/fully_connected_logit_layer_out/weights", {cfg->cls_hidden2, cfg->num_classes}, &g->C3);
     if (!rc) rc = upload_named(g.get(), blob, c + "/fully_connected_logit_layer_out/bias", {cfg->num_classes}, &g->cb3);
     if (rc) return nullptr;
+    if (const char* ev = getenv("ASEP_GNN_STEP")) g->use_step = atoi(ev) != 0;
+    if (U <= 8 && Ed <= 4) {
+        // quads of 4 consecutive features; H-type quads come as whole chunks (lane kk owns h[16c'+4kk ..])
+        struct Quad { int type, off; };
+        std::vector<Quad> quads;
+        const int uq = (U + 3) / 4;
+        for (int t : {GQ_UI, GQ_UJ, GQ_DU, GQ_DU2})
+            for (int q = 0; q < uq; ++q) quads.push_back({t, 4 * q});
+        if (Ed > 0) quads.push_back({GQ_EF, 0});
+        while (quads.size() % 4) quads.push_back({GQ_ZERO, 0});
+        for (int t : {GQ_HI, GQ_HJ, GQ_DH, GQ_DH2})
+            for (int c = 0; c < 2; ++c)
+                for (int k4 = 0; k4 < 4; ++k4) quads.push_back({t, 16 * c});
+        g->nch = (int)quads.size() / 4;
+        if (g->nch <= GNN_MAXCH) {
+            const HostTensor& W1h = blob.find(m + "/fully_connected_layer_h1/weights")->second;   // [K,32]
+            const HostTensor& W2h = blob.find(m + "/fully_connected_logit_layer_out/weights")->second;   // [32,32]
+            auto w1row = [&](const Quad& q, int kk4, int r) -> int {       // original row of W1 or -1 (zero)
+                switch (q.type) {
+                    case GQ_UI: return q.off + r < U ? 0 * U + q.off + r : -1;
+                    case GQ_UJ: return q.off + r < U ? 1 * U + q.off + r : -1;
+                    case GQ_DU: return q.off + r < U ? 2 * U + q.off + r : -1;
+                    case GQ_DU2: return q.off + r < U ? 3 * U + q.off + r : -1;
+                    case GQ_EF: return r < Ed ? 4 * U + r : -1;
+                    case GQ_HI: return 4 * U + Ed + 0 * 32 + q.off + 4 * kk4 + r;
+                    case GQ_HJ: return 4 * U + Ed + 1 * 32 + q.off + 4 * kk4 + r;
+                    case GQ_DH: return 4 * U + Ed + 2 * 32 + q.off + 4 * kk4 + r;
+                    case GQ_DH2: return 4 * U + Ed + 3 * 32 + q.off + 4 * kk4 + r;
+                    default: return -1;
+                }
+            };
+            std::vector<float> a1((size_t)g->nch * 2 * 64 * 4), a2((size_t)2 * 2 * 64 * 4);
+            std::vector<unsigned char> qd((size_t)g->nch * 4 * 2);
+            for (int c = 0; c < g->nch; ++c)
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const Quad& q = quads[c * 4 + k4];
+                    qd[(c * 4 + k4) * 2] = (unsigned char)q.type;
+                    qd[(c * 4 + k4) * 2 + 1] = (unsigned char)q.off;
+                    for (int mt = 0; mt < 2; ++mt)
+                        for (int i = 0; i < 16; ++i)
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = w1row(q, k4, r), lane = k4 * 16 + i;
+                                a1[(((size_t)c * 2 + mt) * 64 + lane) * 4 + r] = row < 0 ? 0.f : W1h.data[(size_t)row * GNN_H + 16 * mt + i];
+                            }
+                }
+            for (int c = 0; c < 2; ++c)
+                for (int mt = 0; mt < 2; ++mt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int r = 0; r < 4; ++r)
+                            a2[(((size_t)c * 2 + mt) * 64 + lane) * 4 + r] = W2h.data[(size_t)(16 * c + 4 * (lane >> 4) + r) * GNN_H + 16 * mt + (lane & 15)];
+            if (hipMalloc((void**)&g->A1, a1.size() * 4) != hipSuccess || hipMalloc((void**)&g->A2, a2.size() * 4) != hipSuccess ||
+                hipMalloc((void**)&g->qdesc, qd.size()) != hipSuccess) { set_error("asep_gnn_load: hipMalloc failed"); return nullptr; }
+            g->owned.push_back(g->A1); g->owned.push_back(g->A2); g->owned.push_back(g->qdesc);
+            if (hipMemcpy(g->A1, a1.data(), a1.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(g->A2, a2.data(), a2.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(g->qdesc, qd.data(), qd.size(), hipMemcpyHostToDevice) != hipSuccess) { set_error("asep_gnn_load: upload failed"); return nullptr; }
+        } else {
+            g->nch = 0;
+        }
+    }
     // the message kernel needs up to ~50 KB of dynamic LDS
     const size_t lds = ((size_t)g->K * 32 + 32 * 32 + 8 * (size_t)g->K + 8 * 32) * sizeof(float);
     if (hipFuncSetAttribute((const void*)gnn_message_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {

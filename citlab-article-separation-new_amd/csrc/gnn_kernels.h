@@ -186,6 +186,165 @@ __global__ __launch_bounds__(256) void gnn_message_kernel(const MsgArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused message passing step (message_fn_chunk.py:148-418 + update_fn_lstm.py:31-85), MFMA version.
+// One workgroup per target node j; each of its 4 waves walks the in-edges of j in tiles of 16 edges:
+//   layer 1  D1[unit][edge] = W1^T z        v_mfma_f32_16x16x4_f32, A = W1 fragments held in registers,
+//                                            B = z built in registers from gathered node rows (no LDS);
+//   layer 2  D2 = W2^T relu(D1 + b1)        the D layout of layer 1 IS the B layout of layer 2 (rows 4kk+r);
+//   tanh, masked by edge validity, accumulated in registers; one cross-lane + cross-wave reduction per target
+//   gives x_j = (1/indeg) sum_i m_ij; the same workgroup then applies the LSTM update of node j.
+// The K axis (rows of W1) is permuted into "quads" of 4 consecutive features so that every lane builds its
+// 4 slots of a 16-slot chunk from one 16-byte piece of a node row: quad descriptor = (type, element offset).
+// ------------------------------------------------------------------------------------------------
+typedef float gf32x4 __attribute__((ext_vector_type(4)));
+enum { GQ_ZERO = 0, GQ_UI, GQ_UJ, GQ_DU, GQ_DU2, GQ_EF, GQ_HI, GQ_HJ, GQ_DH, GQ_DH2 };
+constexpr int GNN_MAXCH = 16;          // K chunks of 16 slots (U <= 8, Ed <= 4 -> 11 chunks)
+
+struct StepArgs {
+    const float* u; const float* h_in; const float* c_in; const float* ef;
+    const int* tptr; const int* tsrc; const int* tfirst;
+    const gf32x4* A1;      // [nch][2 m-tiles][64 lanes]
+    const gf32x4* A2;      // [2 chunks][2 m-tiles][64 lanes]
+    const float* b1; const float* b2;
+    const float* Wg[4]; const float* bg[4];
+    float* h_out; float* c_out;
+    int N, U, Ed, E, nch;
+    const unsigned char* qdesc;   // [nch*4][2] = (type, offset) of every quad, device memory
+};
+
+__device__ __forceinline__ float gsig(float v) { return 1.f / (1.f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void gnn_step_kernel(const StepArgs a) {
+    __shared__ float xs[4][32];
+    __shared__ float vs[32 + 32 + 64];
+    __shared__ float gs[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int tgt = blockIdx.x;
+    const int beg = a.tptr[tgt], end = a.tptr[tgt + 1];
+    const int U = a.U, Ed = a.Ed;
+
+    gf32x4 xacc[2] = {gf32x4{0.f, 0.f, 0.f, 0.f}, gf32x4{0.f, 0.f, 0.f, 0.f}};
+    const int ntiles = (end - beg + 15) >> 4;
+    if (wave < ntiles) {
+        gf32x4 A1[GNN_MAXCH][2];
+#pragma unroll
+        for (int c = 0; c < GNN_MAXCH; ++c)
+            if (c < a.nch) { A1[c][0] = a.A1[(c * 2 + 0) * 64 + lane]; A1[c][1] = a.A1[(c * 2 + 1) * 64 + lane]; }
+        gf32x4 A2[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { A2[c][0] = a.A2[(c * 2 + 0) * 64 + lane]; A2[c][1] = a.A2[(c * 2 + 1) * 64 + lane]; }
+        const gf32x4 b1v[2] = {*reinterpret_cast<const gf32x4*>(a.b1 + kk * 4), *reinterpret_cast<const gf32x4*>(a.b1 + 16 + kk * 4)};
+        const gf32x4 b2v[2] = {*reinterpret_cast<const gf32x4*>(a.b2 + kk * 4), *reinterpret_cast<const gf32x4*>(a.b2 + 16 + kk * 4)};
+        // target-side rows (identical for every edge of this block)
+        const float* hjp = a.h_in + (size_t)tgt * 32;
+        const gf32x4 hj[2] = {*reinterpret_cast<const gf32x4*>(hjp + kk * 4), *reinterpret_cast<const gf32x4*>(hjp + 16 + kk * 4)};
+        float uj[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) uj[q] = q < U ? a.u[(size_t)tgt * U + q] : 0.f;
+
+        for (int t = wave; t < ntiles; t += 4) {
+            const int e = beg + t * 16 + j;
+            const bool valid = e < end;
+            const int ec = valid ? e : beg;                        // clamp: padded columns read a real edge, masked later
+            const int src = a.tsrc[ec];
+            const int fi = a.tfirst[ec] % a.E;
+            const float* hip = a.h_in + (size_t)src * 32;
+            const gf32x4 hi[2] = {*reinterpret_cast<const gf32x4*>(hip + kk * 4), *reinterpret_cast<const gf32x4*>(hip + 16 + kk * 4)};
+            float ui[8], efv[4];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ui[q] = q < U ? a.u[(size_t)src * U + q] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) efv[q] = q < Ed ? a.ef[(size_t)fi * Ed + q] : 0.f;
+
+            gf32x4 acc1[2] = {gf32x4{0.f, 0.f, 0.f, 0.f}, gf32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int c = 0; c < GNN_MAXCH; ++c) {
+                if (c < a.nch) {
+                    const int ty = a.qdesc[(c * 4 + kk) * 2], off = a.qdesc[(c * 4 + kk) * 2 + 1];
+                    gf32x4 z;
+                    if (ty >= GQ_HI) {
+                        const gf32x4 x0 = off ? hi[1] : hi[0], x1 = off ? hj[1] : hj[0];   // off = 16*c' (+4kk implied)
+                        const gf32x4 dd = x1 - x0;
+                        z = ty == GQ_HI ? x0 : (ty == GQ_HJ ? x1 : (ty == GQ_DH ? dd : dd * dd));
+                    } else if (ty == GQ_EF) {
+                        z = gf32x4{efv[0], efv[1], efv[2], efv[3]};
+                    } else if (ty == GQ_ZERO) {
+                        z = gf32x4{0.f, 0.f, 0.f, 0.f};
+                    } else {
+                        const gf32x4 x0 = off ? gf32x4{ui[4], ui[5], ui[6], ui[7]} : gf32x4{ui[0], ui[1], ui[2], ui[3]};
+                        const gf32x4 x1 = off ? gf32x4{uj[4], uj[5], uj[6], uj[7]} : gf32x4{uj[0], uj[1], uj[2], uj[3]};
+                        const gf32x4 dd = x1 - x0;
+                        z = ty == GQ_UI ? x0 : (ty == GQ_UJ ? x1 : (ty == GQ_DU ? dd : dd * dd));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[c][0][r], z[r], acc1[0], 0, 0, 0);
+                        acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[c][1][r], z[r], acc1[1], 0, 0, 0);
+                    }
+                }
+            }
+            // hidden = relu(D1 + b1): rows 4kk+r of m-tile m == B slots 4kk+r of chunk m of the second layer
+            gf32x4 hid[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                hid[m] = acc1[m] + b1v[m];
+                hid[m].x = fmaxf(hid[m].x, 0.f); hid[m].y = fmaxf(hid[m].y, 0.f); hid[m].z = fmaxf(hid[m].z, 0.f); hid[m].w = fmaxf(hid[m].w, 0.f);
+            }
+            gf32x4 acc2[2] = {gf32x4{0.f, 0.f, 0.f, 0.f}, gf32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[c][0][r], hid[c][r], acc2[0], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[c][1][r], hid[c][r], acc2[1], 0, 0, 0);
+                }
+            if (valid) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const gf32x4 v = acc2[m] + b2v[m];
+                    xacc[m].x += tanhf(v.x); xacc[m].y += tanhf(v.y); xacc[m].z += tanhf(v.z); xacc[m].w += tanhf(v.w);
+                }
+            }
+        }
+    }
+    // ---- sum over the 16 edge columns (lanes j), then over the 4 waves ----
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = xacc[m][r];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (j == 0) xs[wave][16 * m + 4 * kk + r] = v;
+        }
+    __syncthreads();
+    if (tid < 32) {
+        const int deg = end - beg;
+        const float s = xs[0][tid] + xs[1][tid] + xs[2][tid] + xs[3][tid];
+        vs[tid] = deg > 0 ? s / (float)deg : 0.f;                    // a_ij = 1/indeg(j)
+        vs[32 + tid] = a.h_in[(size_t)tgt * 32 + tid];
+    }
+    if (tid >= 64 && tid < 64 + U) vs[tid] = a.u[(size_t)tgt * U + (tid - 64)];
+    __syncthreads();
+    // ---- LSTM update of node tgt: v = [x, h, u] ; gate order ingate, outgate, forgetgate, cellinput ----
+    if (tid < 128) {
+        const int q = tid >> 5, o = tid & 31;
+        const float* Wq = a.Wg[q];
+        float g = a.bg[q][o];
+        const int V = 64 + U;
+        for (int k = 0; k < V; ++k) g = fmaf(vs[k], Wq[k * 32 + o], g);
+        gs[q][o] = g;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const float ig = gsig(gs[0][tid]), og = gsig(gs[1][tid]), fg = gsig(gs[2][tid]), cg = tanhf(gs[3][tid]);
+        const float c = fg * a.c_in[(size_t)tgt * 32 + tid] + ig * cg;
+        a.c_out[(size_t)tgt * 32 + tid] = c;
+        a.h_out[(size_t)tgt * 32 + tid] = og * tanhf(c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LSTM update (update_fn_lstm.py:55-76): v = [x, h, u]; four dense gates; c = f*c + i*g; h = o*tanh(c)
 // one thread per (node, unit); gate order in Wg/bg: ingate, outgate, forgetgate, cellinput
 // ------------------------------------------------------------------------------------------------
