@@ -73,14 +73,16 @@ class GnnGraph:
 
 
 def load_graph(pb_path) -> GnnGraph:
-    """gnn/io.py:12-25.  Accepts the engine's ``*.asepw`` container (+ ``.json`` side-car)."""
+    """gnn/io.py:12-25.  Accepts a TF1 frozen graph (``*.pb``, decoded without TensorFlow by ``pb_import.py``)
+    or the engine's ``*.asepw`` container (+ ``.json`` side-car)."""
     if isinstance(pb_path, GnnGraph):
         return pb_path
     if not os.path.isfile(pb_path):
         raise IOError(f"No such model file: {pb_path}")
     if str(pb_path).endswith(".pb"):
-        raise IOError(f"{pb_path}: importing TensorFlow frozen graphs is not implemented yet; "
-                      f"convert the weights to an .asepw container")
+        from . import pb_import
+        tensors, cfg = pb_import.gnn_from_nodes(pb_import.read_graph(pb_path))
+        return GnnGraph(tensors, cfg, pb_path)
     tensors, meta = load_weights(pb_path)
     cfg = GnnConfig(**(meta or {}).get("gnn_cfg", {}))
     return GnnGraph(tensors, cfg, pb_path)

@@ -71,16 +71,17 @@ class AruGraph:
 
 
 def load_graph(path_to_pb) -> AruGraph:
-    """helper:36-53.  Accepts the engine's weight container (``*.asepw`` + ``.json`` side-car written
-    by ``weights.save_weights``).  A TF1 frozen ``.pb`` needs the GraphDef constant importer
-    (SURVEY.md row f1), which is not part of this round."""
+    """helper:36-53.  Accepts a TF1 frozen graph (``*.pb``: the constants are extracted without TensorFlow,
+    ``pb_import.py``) or the engine's own weight container (``*.asepw`` + ``.json`` side-car written by
+    ``weights.save_weights``)."""
     if isinstance(path_to_pb, AruGraph):
         return path_to_pb
     if not os.path.isfile(path_to_pb):
         raise IOError(f"No such model file: {path_to_pb}")
     if str(path_to_pb).endswith(".pb"):
-        raise IOError(f"{path_to_pb}: importing TensorFlow frozen graphs is not implemented yet; "
-                      f"convert the weights to an .asepw container")
+        from . import pb_import
+        tensors, cfg = pb_import.aru_from_nodes(pb_import.read_graph(path_to_pb))
+        return AruGraph(tensors, cfg, path_to_pb)
     tensors, meta = load_weights(path_to_pb)
     cfg = AruConfig(**(meta or {}).get("aru_cfg", {}))
     return AruGraph(tensors, cfg, path_to_pb)

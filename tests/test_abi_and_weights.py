@@ -86,7 +86,7 @@ def test_load_graph_accepts_container_and_rejects_pb(tmp_path):
     assert g.cfg.n_classes == 3 and g.input_name == "inImg:0" and g.output_name == "output:0"
     with pytest.raises(IOError):
         helper.load_graph(str(tmp_path / "missing.pb"))
-    (tmp_path / "x.pb").write_bytes(b"\x0a\x00")
+    (tmp_path / "x.pb").write_bytes(b"\x0a\x00")              # a GraphDef with one empty node: no ARU-Net constants
     with pytest.raises(IOError):
         helper.load_graph(str(tmp_path / "x.pb"))
     assert helper.get_scaling_factor(4500, 3000, 1.0, fixed_height=1500) == pytest.approx(1 / 3)
