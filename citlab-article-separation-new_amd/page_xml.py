@@ -1,0 +1,264 @@
+"""PAGE-XML reader / writer on ``xml.etree.ElementTree`` (no lxml / cssutils), SURVEY.md row f2.
+
+Re-states the subset of ``python_util/parser/xml/page/{page,page_objects,page_util}.py`` that the two hot-path
+pipelines touch: loading text regions / text lines / separator regions with their ``custom`` attributes
+(``page.py:300-321,479-590``), setting article ids on text lines (``page_objects.py:426-445``), heading tags
+(``heading_net_post_processor.py:175-195``), replacing separator regions (``separator_region_to_page_writer.py:340-358``)
+and writing the document back (``page.py:841-851``).  Region objects keep a reference to their DOM node and are
+written back in place, so untouched content of the file survives a round trip.
+
+``custom`` attribute grammar: ``name {key:value; key:value;} name2 {...}`` (``page_util.py:5-21``).
+"""
+import datetime
+import re
+import xml.etree.ElementTree as ET
+
+NS_PAGE_XML = "http://schema.primaresearch.org/PAGE/gts/pagecontent/2013-07-15"      # page_constants.py:9
+CREATOR = "CITlab"
+
+REGION_TYPES = ("TextRegion", "ImageRegion", "LineDrawingRegion", "GraphicRegion", "TableRegion", "ChartRegion",
+                "SeparatorRegion", "MathsRegion", "ChemRegion", "MusicRegion", "AdvertRegion", "NoiseRegion",
+                "UnknownRegion")
+
+
+class PageXmlException(Exception):
+    pass
+
+
+def parse_custom_attr(s):
+    """'readingOrder {index:1;} structure {type:article; id:a1;}' -> {'readingOrder': {'index': '1'}, ...}"""
+    out = {}
+    if not s:
+        return out
+    for name, body in re.findall(r"([\w-]+)\s*\{([^}]*)\}", s):
+        d = out.setdefault(name, {})
+        for item in body.split(";"):
+            if ":" in item:
+                k, v = item.split(":", 1)
+                d[k.strip()] = v.strip()
+    return out
+
+
+def format_custom_attr(ddic):
+    """page_util.py:5-21."""
+    parts = []
+    for k1, d2 in ddic.items():
+        parts.append("%s {%s}" % (k1, " ".join("%s:%s;" % (k2, v2) for k2, v2 in d2.items())))
+    return " ".join(parts)
+
+
+def parse_points(s):
+    """'x1,y1 x2,y2 ...' -> [(x1, y1), ...] (ints)"""
+    pts = []
+    for tok in (s or "").split():
+        x, y = tok.split(",")
+        pts.append((int(float(x)), int(float(y))))
+    return pts
+
+
+def format_points(pts):
+    return " ".join("%d,%d" % (int(x), int(y)) for x, y in pts)
+
+
+class TextLine:
+    def __init__(self, node, page):
+        self.node = node
+        self._page = page
+        self.id = node.get("id")
+        self.custom = parse_custom_attr(node.get("custom"))
+        coords = node.find(page._q("Coords"))
+        self.surr_p = parse_points(coords.get("points")) if coords is not None else []
+        bl = node.find(page._q("Baseline"))
+        self.baseline = parse_points(bl.get("points")) if bl is not None else []
+        self.text = page._text_equiv(node)
+
+    def get_article_id(self):
+        st = self.custom.get("structure", {})
+        return st.get("id") if st.get("type") == "article" else None
+
+    def set_article_id(self, article_id=None):
+        """page_objects.py:426-445."""
+        if article_id:
+            st = self.custom.setdefault("structure", {})
+            st["id"] = str(article_id)
+            st["type"] = "article"
+        else:
+            st = self.custom.get("structure")
+            if st is not None and "id" in st:
+                st.pop("id")
+                if not st:
+                    self.custom.pop("structure")
+
+    def get_semantic_type(self):
+        return self.custom.get("structure", {}).get("semantic_type")
+
+    def set_structure_attribute(self, name, value):
+        self.custom.setdefault("structure", {})[name] = str(value)
+
+    def get_bounding_box(self):
+        xs = [p[0] for p in self.surr_p]
+        ys = [p[1] for p in self.surr_p]
+        return min(xs), min(ys), max(xs) - min(xs) + 1, max(ys) - min(ys) + 1     # polygon.py:91-92: width = max-min+1
+
+    def flush(self):
+        if self.custom:
+            self.node.set("custom", format_custom_attr(self.custom))
+        elif "custom" in self.node.attrib:
+            del self.node.attrib["custom"]
+
+
+class Region:
+    def __init__(self, node, page, kind):
+        self.node = node
+        self._page = page
+        self.kind = kind
+        self.id = node.get("id")
+        self.custom = parse_custom_attr(node.get("custom"))
+        coords = node.find(page._q("Coords"))
+        self.points = parse_points(coords.get("points")) if coords is not None else []
+
+    def get_bounding_box(self):
+        xs = [p[0] for p in self.points]
+        ys = [p[1] for p in self.points]
+        return min(xs), min(ys), max(xs) - min(xs) + 1, max(ys) - min(ys) + 1
+
+    def flush(self):
+        if self.custom:
+            self.node.set("custom", format_custom_attr(self.custom))
+
+
+class TextRegion(Region):
+    def __init__(self, node, page):
+        super().__init__(node, page, "TextRegion")
+        self.region_type = node.get("type")
+        self.text_lines = [TextLine(n, page) for n in node.findall(page._q("TextLine"))]
+
+    def flush(self):
+        super().flush()
+        if self.region_type:
+            self.node.set("type", self.region_type)
+        for tl in self.text_lines:
+            tl.flush()
+
+
+class SeparatorRegion(Region):
+    def __init__(self, node, page):
+        super().__init__(node, page, "SeparatorRegion")
+
+    def get_orientation(self):
+        return self.custom.get("structure", {}).get("orientation")
+
+
+class Page:
+    """page.py:27-851 (subset)."""
+
+    def __init__(self, path_to_xml=None, creator_name=CREATOR, img_filename=None, img_w=None, img_h=None):
+        self.ns = NS_PAGE_XML
+        if path_to_xml is not None:
+            self.tree = ET.parse(path_to_xml)
+            root = self.tree.getroot()
+            m = re.match(r"\{(.*)\}", root.tag)
+            self.ns = m.group(1) if m else ""
+        else:
+            self.tree = ET.ElementTree(self._create_document(creator_name, img_filename, img_w or 0, img_h or 0))
+        ET.register_namespace("", self.ns)
+        self.page_node = self.tree.getroot().find(self._q("Page"))
+        if self.page_node is None:
+            raise PageXmlException("no <Page> element")
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _q(self, tag):
+        return "{%s}%s" % (self.ns, tag) if self.ns else tag
+
+    def _text_equiv(self, node):
+        te = node.find(self._q("TextEquiv"))
+        if te is None:
+            return ""
+        u = te.find(self._q("Unicode"))
+        return (u.text or "") if u is not None else ""
+
+    def _create_document(self, creator, filename, w, h):
+        root = ET.Element("{%s}PcGts" % NS_PAGE_XML)
+        md = ET.SubElement(root, "{%s}Metadata" % NS_PAGE_XML)
+        now = datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%M:%S")
+        ET.SubElement(md, "{%s}Creator" % NS_PAGE_XML).text = creator
+        ET.SubElement(md, "{%s}Created" % NS_PAGE_XML).text = now
+        ET.SubElement(md, "{%s}LastChange" % NS_PAGE_XML).text = now
+        ET.SubElement(root, "{%s}Page" % NS_PAGE_XML, {"imageFilename": filename or "", "imageWidth": str(int(w)),
+                                                        "imageHeight": str(int(h))})
+        return root
+
+    # -- queries -------------------------------------------------------------------------------
+    def get_image_resolution(self):
+        return int(self.page_node.get("imageWidth")), int(self.page_node.get("imageHeight"))
+
+    def get_text_regions(self, text_region_type=None):
+        """Document order of './/TextRegion' (nested regions included), page.py:479-506."""
+        regs = [TextRegion(n, self) for n in self.page_node.iter(self._q("TextRegion"))]
+        if text_region_type:
+            regs = [r for r in regs if r.region_type == text_region_type]
+        return regs
+
+    def get_regions(self):
+        """page.py:528-550: {'TextRegion': [...], 'SeparatorRegion': [...], ...} (only types that occur)."""
+        out = {}
+        for kind in REGION_TYPES:
+            nodes = list(self.page_node.iter(self._q(kind)))
+            if not nodes:
+                continue
+            if kind == "TextRegion":
+                out[kind] = [TextRegion(n, self) for n in nodes]
+            elif kind == "SeparatorRegion":
+                out[kind] = [SeparatorRegion(n, self) for n in nodes]
+            else:
+                out[kind] = [Region(n, self, kind) for n in nodes]
+        return out
+
+    def get_textlines(self):
+        return [TextLine(n, self) for n in self.page_node.iter(self._q("TextLine"))]
+
+    def get_ids(self):
+        return {n.get("id") for n in self.tree.getroot().iter() if n.get("id")}
+
+    def get_unique_id(self, page_object_name):
+        ids = self.get_ids()
+        i = 1
+        while f"{page_object_name}_{i}" in ids:
+            i += 1
+        return f"{page_object_name}_{i}"
+
+    # -- modification --------------------------------------------------------------------------
+    def set_text_regions(self, text_regions, overwrite=False):
+        """Write the (modified) region / line objects back into their DOM nodes (page.py:682-700)."""
+        for r in text_regions:
+            r.flush()
+
+    def set_textline_attr(self, textlines):
+        for tl in textlines:
+            tl.flush()
+
+    def remove_regions(self, region_type):
+        parents = {c: p for p in self.tree.getroot().iter() for c in p}
+        for n in list(self.page_node.iter(self._q(region_type))):
+            parents[n].remove(n)
+
+    def add_separator_region(self, points, orientation):
+        """separator_region_to_page_writer.py:340-358: id 'SeparatorRegion_<n>', custom structure {orientation:...}."""
+        rid = self.get_unique_id("SeparatorRegion")
+        node = ET.SubElement(self.page_node, self._q("SeparatorRegion"),
+                             {"id": rid, "custom": format_custom_attr({"structure": {"orientation": orientation}})})
+        ET.SubElement(node, self._q("Coords"), {"points": format_points(points)})
+        return rid
+
+    def write_page_xml(self, save_path, creator=CREATOR, comments=None):
+        md = self.tree.getroot().find(self._q("Metadata"))
+        if md is not None:
+            lc = md.find(self._q("LastChange"))
+            if lc is None:
+                lc = ET.SubElement(md, self._q("LastChange"))
+            lc.text = datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%M:%S")
+        try:
+            ET.indent(self.tree, space="  ")
+        except AttributeError:  # pragma: no cover (python < 3.9)
+            pass
+        self.tree.write(save_path, encoding="UTF-8", xml_declaration=True)

@@ -1,0 +1,140 @@
+"""CLI mirror of ``article_separation/gnn/run_gnn_clustering.py`` on the MI355X engine.
+
+    python -m citlab_article_separation_new_amd.run_gnn_clustering --model_dir net.pb --eval_list jsons.lst \\
+        --input_params node_feature_dim=15 edge_feature_dim=2 node_input_feature_mask=[1,1,1,1,0,0,0,0,0,0,0,0,1,1,1] \\
+        --clustering_method dbscan --out_dir out
+
+Same flags (``run_gnn_clustering.py:19-73``), same per-page loop (``:237-300``): json -> feed dict -> engine ->
+confidences [N,N] -> (optional json) -> TextblockClustering -> ``<out_dir>/.../clustering/<info>/<name>_clustering.xml``.
+Pages are sharded over ``--num_workers`` processes, worker k on GPU ``gpu_devices[k % len]`` (the reference forks
+``mp.Process`` per sub-list, ``:322-340``).  Worker errors are surfaced (the reference drops them).
+"""
+import logging
+import multiprocessing as mp
+import os
+import sys
+import time
+
+from . import cli_flags
+from .host_util import split_list
+from .path_util import get_page_from_json_path, get_path_from_exportdir, load_list_file
+
+
+def build_parser():
+    p = cli_flags.LineArgumentParser(fromfile_prefix_chars="@")
+    p.add_argument("--model_dir", type=str, default="")
+    p.add_argument("--eval_list", type=str, default="")
+    p.add_argument("--batch_size", type=int, default=1)
+    p.add_argument("--num_classes", type=int, default=2)
+    p.add_argument("--num_relation_components", type=int, default=2)
+    p.add_argument("--sample_num_relations_to_consider", type=int, default=100)
+    p.add_argument("--sample_relations", type=cli_flags.str2bool, default=False)
+    p.add_argument("--image_input", type=cli_flags.str2bool, default=False)
+    p.add_argument("--assign_visual_features_to_nodes", type=cli_flags.str2bool, default=True)
+    p.add_argument("--assign_visual_features_to_edges", type=cli_flags.str2bool, default=False)
+    p.add_argument("--mvn", type=cli_flags.str2bool, default=True)
+    cli_flags.define_dict(p, "input_params", {})
+    p.add_argument("--clustering_method", type=str, default="dbscan", choices=["dbscan", "linkage", "greedy", "dbscan_std"])
+    p.add_argument("--mask_horizontally_separated_confs", type=cli_flags.str2bool, default=False)
+    p.add_argument("--mask_heading_separated_confs", type=cli_flags.str2bool, default=False)
+    cli_flags.define_dict(p, "clustering_params", {})
+    p.add_argument("--out_dir", type=str, default="")
+    p.add_argument("--save_conf", type=str, default="no_conf", choices=["no_conf", "with_conf", "only_conf"])
+    p.add_argument("--num_workers", type=int, default=1)
+    p.add_argument("--gpu_devices", type=int, nargs="*", default=[])
+    p.add_argument("--gpu_memory_fraction", type=float, default=0.95)
+    p.add_argument("--batch_limiter", type=int, default=-1)
+    p.add_argument("--try_gpu", type=cli_flags.str2bool, default=None)
+    return p
+
+
+def resolve_model_path(flags):
+    """run_gnn_clustering.py:191-204 (also accepts the engine's .asepw container)."""
+    if os.path.isfile(flags.model_dir):
+        ext = os.path.splitext(os.path.basename(flags.model_dir))[1]
+        if ext not in (".pb", ".asepw"):
+            raise IOError(f"Given model path {flags.model_dir} is not a .pb")
+        return flags.model_dir
+    pb = None
+    try_gpu = flags.try_gpu if flags.try_gpu is not None else bool(flags.gpu_devices)
+    if try_gpu:
+        try:
+            pb = get_path_from_exportdir(flags.model_dir, "*_gpu.pb", "cpu")
+        except IOError:
+            logging.warning("Could not find gpu-model-pb-file, continue with cpu-model-pb-file")
+    return pb or get_path_from_exportdir(flags.model_dir, "*best*.pb", "_gpu.pb")
+
+
+def gnn_clustering(json_paths, flags, device="0"):
+    from . import gnn_io, gnn_results
+    from .clustering import TextblockClustering
+    from .gnn_input import InputGNN
+    if flags.mask_heading_separated_confs or flags.mask_horizontally_separated_confs:
+        raise NotImplementedError("confidence masking needs the separator feature rules of feature_generation.py "
+                                  "(SURVEY row f4), not part of this build")
+    graph = gnn_io.load_graph(resolve_model_path(flags))
+    input_fn = InputGNN(flags)
+    tb = TextblockClustering(flags)
+    sess = gnn_io.GnnSession(graph, device)
+    results = []
+    t0 = time.time()
+    for count, json_path in enumerate(list(json_paths)):
+        if flags.batch_limiter != -1 and flags.batch_limiter <= count:
+            break
+        page_path = get_page_from_json_path(json_path)
+        if not os.path.isfile(json_path):
+            logging.warning(f"No json file found to given pageXML {page_path}. Skipping.")
+            continue
+        feed = input_fn.feed_from_json(json_path)
+        output = sess.run("output_belong_to_same_instance:0", feed_dict=feed)
+        n = feed["node_features:0"].shape[1] if "node_features:0" in feed else int(feed["num_nodes:0"][0])
+        confidences = gnn_results.confidences_from_output(output, n)
+        if flags.save_conf != "no_conf":
+            gnn_results.save_conf_to_json(confidences, page_path, flags.out_dir)
+            if flags.save_conf == "only_conf":
+                continue
+        tb.set_confs(confidences)
+        tb.calc(method=flags.clustering_method)
+        out = gnn_results.save_clustering_to_page(tb.tb_labels, page_path, flags.out_dir,
+                                                  info=tb.get_info(flags.clustering_method))
+        results.append(out)
+    logging.info(f"Time: {time.time() - t0:.2f} seconds")
+    return results
+
+
+def _worker(json_paths, argv, device, q):
+    try:
+        flags = build_parser().parse_known_args(argv)[0]
+        q.put(("ok", gnn_clustering(json_paths, flags, device)))
+    except Exception as e:  # surfaced to the parent instead of being dropped
+        q.put(("err", repr(e)))
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    flags = build_parser().parse_known_args(argv)[0]
+    logging.getLogger().setLevel(logging.INFO)
+    json_paths = [p for p in load_list_file(flags.eval_list) if p]
+    devices = [str(d) for d in flags.gpu_devices] or ["0"]
+    if flags.num_workers <= 1:
+        return gnn_clustering(json_paths, flags, devices[0])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = []
+    for k, part in enumerate(split_list(json_paths, flags.num_workers)):
+        pr = ctx.Process(target=_worker, args=(part, argv, devices[k % len(devices)], q))
+        pr.start()
+        procs.append(pr)
+    out, errors = [], []
+    for _ in procs:
+        status, payload = q.get()
+        (out.extend if status == "ok" else errors.append)(payload)
+    for pr in procs:
+        pr.join()
+    if errors:
+        raise RuntimeError("worker failure: " + "; ".join(errors))
+    return out
+
+
+if __name__ == "__main__":
+    main()

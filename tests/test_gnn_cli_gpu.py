@@ -1,0 +1,84 @@
+"""End to end on the GPU: graph jsons + PAGE-XML + a frozen-graph .pb -> run_gnn_clustering CLI -> PAGE-XML with
+article ids; the ids must equal what the CPU oracle + the same clustering code produce (article ids identical)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_page(path, n_regions):
+    regs = []
+    for i in range(n_regions):
+        x, y = 100 + (i % 5) * 550, 100 + (i // 5) * 100
+        regs.append(f'<TextRegion id="tr{i}"><Coords points="{x},{y} {x+500},{y} {x+500},{y+80} {x},{y+80}"/>'
+                    f'<TextLine id="tr{i}l0"><Coords points="{x},{y} {x+500},{y} {x+500},{y+40} {x},{y+40}"/></TextLine>'
+                    f'<TextLine id="tr{i}l1"><Coords points="{x},{y+40} {x+500},{y+40} {x+500},{y+80} {x},{y+80}"/></TextLine>'
+                    f'</TextRegion>')
+    path.write_text('<?xml version="1.0" encoding="UTF-8"?>\n<PcGts xmlns="http://schema.primaresearch.org/PAGE/gts/'
+                    'pagecontent/2013-07-15"><Metadata><Creator>t</Creator><Created>2020-01-01T00:00:00</Created>'
+                    '<LastChange>2020-01-01T00:00:00</LastChange></Metadata><Page imageFilename="x.png" '
+                    'imageWidth="3000" imageHeight="4500">' + "".join(regs) + '</Page></PcGts>')
+
+
+def test_cli_end_to_end_article_ids_identical(tmp_path):
+    from citlab_article_separation_new_amd import pb_import, run_gnn_clustering, synth
+    from citlab_article_separation_new_amd.clustering import TextblockClustering
+    from citlab_article_separation_new_amd.config import GnnConfig
+    from citlab_article_separation_new_amd.page_xml import Page
+    from citlab_article_separation_new_amd.weights import init_gnn_weights
+    from oracle import gnn_oracle
+    cfg = GnnConfig()
+    w = init_gnn_weights(cfg, 4242, bias_jitter=0.05)
+    model = tmp_path / "model" / "export"
+    model.mkdir(parents=True)
+    (model / "gnn_best_2026.pb").write_bytes(pb_import.weights_to_graphdef(w, "graph/"))
+    data = tmp_path / "data"
+    (data / "page").mkdir(parents=True)
+    (data / "json15d2bb").mkdir()
+    mask = [1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1]
+    keep = [i for i, m in enumerate(mask) if m]
+    json_paths, expected = [], {}
+    for k, n in enumerate((40, 25, 3)):
+        g = synth.synth_graph(k, N=n, n_pairs=min(150, n * (n - 1) // 2), node_dim=15)
+        name = f"page{k}"
+        _write_page(data / "page" / f"{name}.xml", n)
+        jp = data / "json15d2bb" / f"{name}.json"
+        jp.write_text(json.dumps({"num_nodes": n, "interacting_nodes": g["interacting_nodes"].tolist(),
+                                  "num_interacting_nodes": int(g["interacting_nodes"].shape[0]),
+                                  "node_features": g["node_features"].tolist(), "edge_features": g["edge_features"].tolist(),
+                                  "gt_relations": [], "gt_num_relations": 0}))
+        json_paths.append(str(jp))
+        probs = gnn_oracle.forward(n, g["interacting_nodes"], g["node_features"][:, keep], g["edge_features"], None, w, cfg)
+
+        class F:
+            clustering_params = {}
+        tb = TextblockClustering(F())
+        tb.set_confs(probs[:, 1].reshape(n, n))
+        tb.calc("dbscan")
+        expected[name] = [int(v) for v in tb.tb_labels]
+    lst = tmp_path / "eval.lst"
+    lst.write_text("\n".join(json_paths) + "\n")
+    cwd = os.getcwd()
+    os.chdir(tmp_path)                      # outputs are placed relative to the cwd, like the reference
+    try:
+        outs = run_gnn_clustering.main([
+            "--model_dir", str(tmp_path / "model"), "--eval_list", str(lst), "--out_dir", "out", "--save_conf", "with_conf",
+            "--input_params", "node_feature_dim=15", "edge_feature_dim=2", "node_input_feature_mask=" + str(mask).replace(" ", ""),
+            "--clustering_method", "dbscan", "--gpu_devices", "0"])
+    finally:
+        os.chdir(cwd)
+    assert len(outs) == 3
+    for out in outs:
+        out = os.path.join(tmp_path, out) if not os.path.isabs(out) else out
+        assert "clustering/dbscan_conf0.5_cluster0.5" in out and out.endswith("_clustering.xml")
+        name = os.path.basename(out).replace("_clustering.xml", "")
+        page = Page(out)
+        got = [r.text_lines[0].get_article_id() for r in page.get_regions()["TextRegion"]]
+        assert got == [f"a{l}" for l in expected[name]], name
+        assert all(tl.get_article_id() == r.text_lines[0].get_article_id()
+                   for r in page.get_regions()["TextRegion"] for tl in r.text_lines)
+    conf_files = [f for _, _, fs in os.walk(tmp_path) for f in fs if f.endswith("_confidences.json")]
+    assert len(conf_files) == 3
