@@ -50,6 +50,19 @@ SIGNATURES = {
     "asep_gnn_forward_dev": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P]),
     "asep_gnn_get_hidden": (C.c_int, [_P, _P, C.c_size_t]),
     "asep_gnn_flops": (C.c_double, [_P, C.c_int, C.c_int, C.c_int]),
+    "asep_post_create": (_P, []),
+    "asep_post_free": (None, [_P]),
+    "asep_prep_scaled_size": (C.c_int, [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "asep_prep_scale_gray": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P]),
+    "asep_prep_scale_gray_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, _P]),
+    "asep_post_cc_filter": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "asep_post_morph_rect": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "asep_post_separator": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, _P, _P]),
+    "asep_post_separator_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, _P, _P, _P]),
+    "asep_swt_distance_transform": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.POINTER(C.c_int32), _P]),
+    "asep_swt_distance_transform_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
 }
 
 _lib = None

@@ -1,0 +1,477 @@
+// Classical (non-neural) image stages either side of the ARU-Net, as HBM-bound byte / bit kernels for gfx950.
+//
+//   a1   scale_image + BGR2GRAY/255           net_post_processing_helper.py:14-33
+//   a9   apply_cc_analysis                    region_net_post_processor_base.py:230-251
+//        post_process (openings, subtract)    separator_net_post_processor.py:26-97
+//   a12  StrokeWidthDistanceTransform         swt_dist_trafo.py:18-29
+//
+// Binary images are kept as bit planes (one uint64 per 64 pixels of a row, LSB = smallest x): a 3000x4500 mask
+// is 1.7 MB, so rectangular morphology is word-parallel AND/OR of shifted words out of L2 instead of byte traffic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace asep {
+
+// --------------------------------------------------------------------------------------------------------------
+// bit planes
+// --------------------------------------------------------------------------------------------------------------
+// grid (WW, ceil(H/4)), block 256: one wave packs 64 pixels of one row.
+__global__ void __launch_bounds__(256)
+post_pack_kernel(const uint8_t* __restrict__ in, int H, int W, int stride, int ch, uint64_t* __restrict__ bits,
+                 int WW) {
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= H) return;
+    const int x = blockIdx.x * 64 + lane;
+    const bool fg = x < W && in[((size_t)y * W + x) * stride + ch] != 0;
+    const uint64_t m = __ballot(fg);
+    if (lane == 0) bits[(size_t)y * WW + blockIdx.x] = m;
+}
+
+__global__ void __launch_bounds__(256)
+post_unpack_kernel(const uint64_t* __restrict__ bits, int H, int W, int WW, uint8_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // one thread = 4 pixels
+    const int W4 = (W + 3) >> 2;
+    if (i >= (size_t)H * W4) return;
+    const int y = (int)(i / W4), x = (int)(i % W4) * 4;
+    const uint64_t w = bits[(size_t)y * WW + (x >> 6)] >> (x & 63);
+    uint8_t* o = out + (size_t)y * W + x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (x + k < W) o[k] = ((w >> k) & 1) ? 255 : 0;
+}
+
+// bit i of the result = source bit (64*wx + i + o); `fill` is the value of bits outside [0, W).
+__device__ __forceinline__ uint64_t post_row_word(const uint64_t* __restrict__ row, int WW, int W, int q,
+                                                  uint64_t fill) {
+    if (q < 0 || q >= WW) return fill;
+    uint64_t w = row[q];
+    const int tail = W - q * 64;                                  // valid bits in this word
+    if (tail < 64) {
+        const uint64_t valid = (tail <= 0) ? 0ull : ((1ull << tail) - 1ull);
+        w = (w & valid) | (fill & ~valid);
+    }
+    return w;
+}
+
+__device__ __forceinline__ uint64_t post_shifted(const uint64_t* __restrict__ row, int WW, int W, int wx, int o,
+                                                 uint64_t fill) {
+    const int p = wx * 64 + o;                                    // first source bit
+    const int q = p >> 6;                                         // floor division (arithmetic shift)
+    const int r = p & 63;
+    const uint64_t lo = post_row_word(row, WW, W, q, fill);
+    if (r == 0) return lo;
+    const uint64_t hi = post_row_word(row, WW, W, q + 1, fill);
+    return (lo >> r) | (hi << (64 - r));
+}
+
+// cv window along x: offsets [-a, b], a = k/2, b = k-1-a.  ERODE: AND with +inf border; DILATE: OR with -inf border.
+template <bool ERODE>
+__global__ void __launch_bounds__(256)
+post_morph_h_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int H, int W, int WW, int a,
+                    int b) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)H * WW) return;
+    const int y = (int)(i / WW), wx = (int)(i % WW);
+    const uint64_t* row = in + (size_t)y * WW;
+    const uint64_t fill = ERODE ? ~0ull : 0ull;
+    uint64_t acc = fill;
+    for (int o = -a; o <= b; ++o) {
+        const uint64_t s = post_shifted(row, WW, W, wx, o, fill);
+        acc = ERODE ? (acc & s) : (acc | s);
+    }
+    const int tail = W - wx * 64;
+    if (tail < 64) acc &= (1ull << tail) - 1ull;
+    out[i] = acc;
+}
+
+template <bool ERODE>
+__global__ void __launch_bounds__(256)
+post_morph_v_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int H, int W, int WW, int a,
+                    int b) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)H * WW) return;
+    const int y = (int)(i / WW), wx = (int)(i % WW);
+    const int y0 = max(y - a, 0), y1 = min(y + b, H - 1);
+    uint64_t acc = ERODE ? ~0ull : 0ull;
+    for (int yy = y0; yy <= y1; ++yy) {
+        const uint64_t s = in[(size_t)yy * WW + wx];
+        acc = ERODE ? (acc & s) : (acc | s);
+    }
+    const int tail = W - wx * 64;
+    if (tail < 64) acc &= (1ull << tail) - 1ull;
+    out[i] = acc;
+}
+
+// cv2.subtract on 0/255 masks == a AND NOT b.
+__global__ void __launch_bounds__(256)
+post_andnot_kernel(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ out,
+                   size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] & ~b[i];
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// 8-connected components: lock-free union-find on pixel indices (label = smallest index of the component)
+// --------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+cc_init_kernel(const uint8_t* __restrict__ in, int stride, int ch, size_t n, int32_t* __restrict__ L) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) L[i] = in[i * stride + ch] != 0 ? (int32_t)i : -1;
+}
+
+__device__ __forceinline__ int32_t cc_find(const int32_t* L, int32_t i) {
+    int32_t p = __atomic_load_n(&L[i], __ATOMIC_RELAXED);
+    while (p != i) {
+        i = p;
+        p = __atomic_load_n(&L[i], __ATOMIC_RELAXED);
+    }
+    return i;
+}
+
+__device__ __forceinline__ void cc_union(int32_t* L, int32_t a, int32_t b) {
+    for (;;) {
+        a = cc_find(L, a);
+        b = cc_find(L, b);
+        if (a == b) return;
+        if (a > b) {
+            const int32_t t = a;
+            a = b;
+            b = t;
+        }
+        const int32_t old = atomicMin(&L[b], a);                // b was a root when we looked
+        if (old == b) return;
+        b = old;                                                  // somebody re-parented b meanwhile: retry
+    }
+}
+
+__global__ void __launch_bounds__(256)
+cc_union_kernel(int32_t* L, int H, int W) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)H * W) return;
+    if (L[i] < 0) return;
+    const int y = (int)(i / W), x = (int)(i % W);
+    const int32_t me = (int32_t)i;
+    if (x > 0 && L[i - 1] >= 0) cc_union(L, me, me - 1);
+    if (y > 0) {
+        const int32_t up = me - W;
+        if (L[up] >= 0) {
+            cc_union(L, me, up);
+        } else {
+            if (x > 0 && L[up - 1] >= 0) cc_union(L, me, up - 1);
+            if (x + 1 < W && L[up + 1] >= 0) cc_union(L, me, up + 1);
+        }
+    }
+}
+
+// flatten every pixel onto its root and zero the per-root area counters
+__global__ void __launch_bounds__(256)
+cc_flatten_kernel(int32_t* L, int32_t* __restrict__ area, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (L[i] < 0) return;
+    const int32_t r = cc_find(L, (int32_t)i);
+    L[i] = r;
+    if (r == (int32_t)i) area[i] = 0;
+}
+
+__global__ void __launch_bounds__(256)
+cc_area_kernel(const int32_t* __restrict__ L, int32_t* __restrict__ area, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int32_t r = i < n ? L[i] : -1;
+    // consecutive pixels of a run share the root: one atomic per run segment inside the wave
+    const int lane = threadIdx.x & 63;
+    const int32_t prev = __shfl_up(r, 1);
+    const bool brk = lane == 0 || prev != r;
+    const uint64_t brks = __ballot(brk);
+    if (brk && r >= 0) {
+        const uint64_t above = lane == 63 ? 0ull : (brks >> (lane + 1));
+        const int len = above ? __ffsll((long long)above) : 64 - lane;
+        atomicAdd(&area[r], len);
+    }
+}
+
+// grid (WW, ceil(H/4)): keep pixels of components with area >= min_size; emit the bit plane (and optional u8).
+__global__ void __launch_bounds__(256)
+cc_filter_kernel(const int32_t* __restrict__ L, const int32_t* __restrict__ area, int H, int W, int min_size,
+                 uint64_t* __restrict__ bits, int WW, uint8_t* __restrict__ out_u8) {
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= H) return;
+    const int x = blockIdx.x * 64 + lane;
+    bool keep = false;
+    if (x < W) {
+        const int32_t r = L[(size_t)y * W + x];
+        keep = r >= 0 && area[r] >= min_size;
+        if (out_u8) out_u8[(size_t)y * W + x] = keep ? 255 : 0;
+    }
+    const uint64_t m = __ballot(keep);
+    if (lane == 0) bits[(size_t)y * WW + blockIdx.x] = m;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// a1: resize + gray
+// --------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t sat_u8_rn(float v) {
+    const int r = __float2int_rn(v);                              // round half to even (cvRound)
+    return (uint8_t)min(max(r, 0), 255);
+}
+
+// INTER_AREA, integer scale s (ResizeAreaFast): full blocks sum*float(1/(s*s)) (2x2: (sum+2)>>2), ragged border
+// blocks sum/count.
+__global__ void __launch_bounds__(256)
+prep_area_int_kernel(const uint8_t* __restrict__ src, int H, int W, int C, int s, uint8_t* __restrict__ dst, int dh,
+                     int dw) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)dh * dw * C) return;
+    const int c = (int)(i % C);
+    const int dx = (int)((i / C) % dw), dy = (int)(i / ((size_t)C * dw));
+    const int y0 = dy * s, y1 = min(y0 + s, H), x0 = dx * s, x1 = min(x0 + s, W);
+    int sum = 0;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) sum += src[((size_t)y * W + x) * C + c];
+    uint8_t v;
+    if (y1 - y0 == s && x1 - x0 == s) {
+        if (s == 2) v = (uint8_t)((sum + 2) >> 2);
+        else v = sat_u8_rn(__fmul_rn((float)sum, 1.0f / (float)(s * s)));
+    } else {
+        const int cnt = max((y1 - y0) * (x1 - x0), 1);
+        v = sat_u8_rn(__fdiv_rn((float)sum, (float)cnt));
+    }
+    dst[i] = v;
+}
+
+// INTER_AREA, fractional scale: per-axis tables (start offsets per destination index, source index, weight).
+__global__ void __launch_bounds__(256)
+prep_area_tab_kernel(const uint8_t* __restrict__ src, int H, int W, int C, uint8_t* __restrict__ dst, int dh, int dw,
+                     const int32_t* __restrict__ xofs, const int32_t* __restrict__ xsrc,
+                     const float* __restrict__ xw, const int32_t* __restrict__ yofs,
+                     const int32_t* __restrict__ ysrc, const float* __restrict__ yw) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)dh * dw * C) return;
+    const int c = (int)(i % C);
+    const int dx = (int)((i / C) % dw), dy = (int)(i / ((size_t)C * dw));
+    const int xb = xofs[dx], xe = xofs[dx + 1];
+    float sum = 0.f;
+    bool first = true;
+    for (int j = yofs[dy]; j < yofs[dy + 1]; ++j) {
+        const uint8_t* row = src + (size_t)ysrc[j] * W * C + c;
+        float buf = 0.f;
+        for (int k = xb; k < xe; ++k) buf = __fadd_rn(buf, __fmul_rn((float)row[(size_t)xsrc[k] * C], xw[k]));
+        const float t = __fmul_rn(yw[j], buf);
+        sum = first ? t : __fadd_rn(sum, t);
+        first = false;
+    }
+    dst[i] = sat_u8_rn(sum);
+}
+
+// INTER_CUBIC (a = -0.75) with OpenCV's 11-bit fixed-point taps; tables hold the floor index and 4 taps.
+__global__ void __launch_bounds__(256)
+prep_cubic_kernel(const uint8_t* __restrict__ src, int H, int W, int C, uint8_t* __restrict__ dst, int dh, int dw,
+                  const int32_t* __restrict__ xi, const int16_t* __restrict__ xw, const int32_t* __restrict__ yi,
+                  const int16_t* __restrict__ yw) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)dh * dw * C) return;
+    const int c = (int)(i % C);
+    const int dx = (int)((i / C) % dw), dy = (int)(i / ((size_t)C * dw));
+    const int sx = xi[dx], sy = yi[dy];
+    long long acc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int yy = min(max(sy - 1 + j, 0), H - 1);
+        const uint8_t* row = src + (size_t)yy * W * C + c;
+        int h = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xx = min(max(sx - 1 + k, 0), W - 1);
+            h += (int)row[(size_t)xx * C] * (int)xw[dx * 4 + k];
+        }
+        acc += (long long)h * (long long)yw[dy * 4 + j];
+    }
+    const long long v = (acc + (1ll << 21)) >> 22;
+    dst[i] = (uint8_t)min(max(v, 0ll), 255ll);
+}
+
+// BGR2GRAY (OpenCV 4.x 15-bit fixed point) and /255.0 in double like the reference, then the feed's float32 cast.
+__global__ void __launch_bounds__(256)
+prep_gray_kernel(const uint8_t* __restrict__ img, size_t n, int C, float* __restrict__ gray,
+                 uint8_t* __restrict__ gray_u8) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int g;
+    if (C == 3) {
+        const uint8_t* p = img + i * 3;
+        g = ((int)p[0] * 3735 + (int)p[1] * 19235 + (int)p[2] * 9798 + 16384) >> 15;
+    } else {
+        g = img[i];
+    }
+    if (gray) gray[i] = (float)((double)g / 255.0);
+    if (gray_u8) gray_u8[i] = (uint8_t)g;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// a12: 255-gray -> Gaussian 5x5 -> Otsu -> exact Euclidean distance transform -> uint8
+// --------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+
+// inverted input, taps [1,4,6,4,1]^2, (sum + 128) >> 8; also accumulates the 256-bin histogram of the result.
+__global__ void __launch_bounds__(256)
+swt_blur_hist_kernel(const uint8_t* __restrict__ gray, int H, int W, uint8_t* __restrict__ blur,
+                     unsigned int* __restrict__ hist) {
+    __shared__ unsigned int lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)H * W) {
+        const int y = (int)(i / W), x = (int)(i % W);
+        const int taps[5] = {1, 4, 6, 4, 1};
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const uint8_t* row = gray + (size_t)reflect101(y + j - 2, H) * W;
+            int h = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) h += taps[k] * (255 - (int)row[reflect101(x + k - 2, W)]);
+            acc += taps[j] * h;
+        }
+        const int v = (acc + 128) >> 8;
+        blur[i] = (uint8_t)v;
+        atomicAdd(&lh[v], 1u);
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+
+// getThreshVal_Otsu_8u in double, one thread; no fused multiply-adds so the host restatement matches bit for bit.
+__global__ void swt_otsu_kernel(const unsigned int* __restrict__ hist, int* __restrict__ thr_out) {
+    if (threadIdx.x || blockIdx.x) return;
+    double n = 0;
+    for (int i = 0; i < 256; ++i) n += (double)hist[i];
+    const double scale = 1.0 / n;
+    double mu = 0;
+    for (int i = 0; i < 256; ++i) mu = __dadd_rn(mu, __dmul_rn((double)i, (double)hist[i]));
+    mu = __dmul_rn(mu, scale);
+    double mu1 = 0, q1 = 0, max_sigma = 0;
+    int max_val = 0;
+    const double eps = 1.1920928955078125e-07;
+    for (int i = 0; i < 256; ++i) {
+        const double p_i = __dmul_rn((double)hist[i], scale);
+        mu1 = __dmul_rn(mu1, q1);
+        q1 = __dadd_rn(q1, p_i);
+        const double q2 = __dsub_rn(1.0, q1);
+        if (fmin(q1, q2) < eps || fmax(q1, q2) > 1.0 - eps) continue;
+        mu1 = __ddiv_rn(__dadd_rn(mu1, __dmul_rn((double)i, p_i)), q1);
+        const double mu2 = __ddiv_rn(__dsub_rn(mu, __dmul_rn(q1, mu1)), q2);
+        const double d = __dsub_rn(mu1, mu2);
+        const double sigma = __dmul_rn(__dmul_rn(__dmul_rn(q1, q2), d), d);
+        if (sigma > max_sigma) {
+            max_sigma = sigma;
+            max_val = i;
+        }
+    }
+    *thr_out = max_val;
+}
+
+// vertical pass in two kernels so that a page-high column is not one serial walk:
+//   swt_edt_seg_kernel   per (column, 32-row segment): first / last zero row inside the segment (-1 = none)
+//   swt_edt_cols_kernel  per (column, segment): nearest zero above / below from the segment table, then
+//                        g[y][x] = min(y - zero_above, zero_below - y), capped at SWT_INF (= no zero in the column)
+#define SWT_INF 0x3fff
+#define SWT_SEG 32
+__global__ void __launch_bounds__(256)
+swt_edt_seg_kernel(const uint8_t* __restrict__ blur, const int* __restrict__ thr, int H, int W,
+                   int32_t* __restrict__ seg_first, int32_t* __restrict__ seg_last) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int sg = blockIdx.y;
+    if (x >= W) return;
+    const int t = *thr;
+    const int y0 = sg * SWT_SEG, y1 = min(y0 + SWT_SEG, H);
+    int first = -1, last = -1;
+    for (int y = y0; y < y1; ++y) {
+        if ((int)blur[(size_t)y * W + x] <= t) {
+            if (first < 0) first = y;
+            last = y;
+        }
+    }
+    seg_first[(size_t)sg * W + x] = first;
+    seg_last[(size_t)sg * W + x] = last;
+}
+
+__global__ void __launch_bounds__(256)
+swt_edt_cols_kernel(const uint8_t* __restrict__ blur, const int* __restrict__ thr, int H, int W, int nseg,
+                    const int32_t* __restrict__ seg_first, const int32_t* __restrict__ seg_last,
+                    uint16_t* __restrict__ g) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int sg = blockIdx.y;
+    if (x >= W) return;
+    const int t = *thr;
+    const int y0 = sg * SWT_SEG, y1 = min(y0 + SWT_SEG, H);
+    int above = -(1 << 20), below = 1 << 20;                      // nearest zero rows outside the segment
+    for (int s = sg - 1; s >= 0; --s) {
+        const int v = seg_last[(size_t)s * W + x];
+        if (v >= 0) { above = v; break; }
+    }
+    for (int s = sg + 1; s < nseg; ++s) {
+        const int v = seg_first[(size_t)s * W + x];
+        if (v >= 0) { below = v; break; }
+    }
+    int dn[SWT_SEG];
+    int z = above;
+#pragma unroll
+    for (int r = 0; r < SWT_SEG; ++r) {
+        const int y = y0 + r;
+        if (y < y1) {
+            if ((int)blur[(size_t)y * W + x] <= t) z = y;
+            dn[r] = y - z;
+        } else {
+            dn[r] = 0;
+        }
+    }
+    z = below;
+#pragma unroll
+    for (int r = SWT_SEG - 1; r >= 0; --r) {
+        const int y = y0 + r;
+        if (y < y1) {
+            if (dn[r] == 0) z = y;
+            const int d = min(min(dn[r], z - y), SWT_INF);
+            g[(size_t)y * W + x] = (uint16_t)d;
+        }
+    }
+}
+
+// horizontal pass: d2 = min_x' (x-x')^2 + g(x')^2, searched outwards until (x-x')^2 >= best (exact);
+// result trunc(sqrt(d2)) mod 256 like ``dist.astype(np.uint8)``.
+__global__ void __launch_bounds__(256)
+swt_edt_rows_kernel(const uint16_t* __restrict__ g, int H, int W, uint8_t* __restrict__ out,
+                    int32_t* __restrict__ d2_out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)H * W) return;
+    const int y = (int)(i / W), x = (int)(i % W);
+    const uint16_t* row = g + (size_t)y * W;
+    const int g0 = row[x];
+    long long best = g0 >= SWT_INF ? (1ll << 40) : (long long)g0 * g0;
+    if (best) {
+        for (int dx = 1; (long long)dx * dx < best && (x - dx >= 0 || x + dx < W); ++dx) {
+            const long long dd = (long long)dx * dx;
+            if (x - dx >= 0) {
+                const int gv = row[x - dx];
+                if (gv < SWT_INF) best = min(best, dd + (long long)gv * gv);
+            }
+            if (x + dx < W) {
+                const int gv = row[x + dx];
+                if (gv < SWT_INF) best = min(best, dd + (long long)gv * gv);
+            }
+        }
+    }
+    const int32_t b32 = best > 0x7fffffffll ? 0x7fffffff : (int32_t)best;
+    if (d2_out) d2_out[i] = b32;
+    const float d = __fsqrt_rn((float)b32);
+    out[i] = (uint8_t)(((int)d) & 255);
+}
+
+}  // namespace asep

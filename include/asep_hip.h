@@ -140,6 +140,52 @@ int asep_gnn_get_hidden(asep_gnn* g, float* out, size_t max_floats);
 
 double asep_gnn_flops(const asep_gnn* g, int N, int E_corrected, int R);
 
+/* ---- classical image stages around the ARU-Net ---------------------
+ * The reference runs these on the host with OpenCV; here they are byte / bit kernels next to the nets so that a
+ * page never leaves HBM between decode and polygon extraction.  Binary images: 0 = background, non-zero =
+ * foreground on input; 0 / 255 on output.  One workspace handle per (process, device); buffers grow on demand. */
+typedef struct asep_post asep_post;
+asep_post* asep_post_create(void);
+void asep_post_free(asep_post* p);
+
+/* net_post_processing_helper.py:14-33 (scale_image + cvtColor(BGR2GRAY)/255.0) without the file decode.
+ * img: uint8 [H,W,C] with C = 3 (BGR) or 1 (gray).  sc < 1: cv2 INTER_AREA, sc > 1: INTER_CUBIC, sc == 1: copy.
+ * Output size (round-half-even of H*sc, W*sc) is returned by asep_prep_scaled_size.
+ * out_image (optional): uint8 [h,w,C]; out_gray: float32 [h,w] = gray/255 (the net input). */
+int asep_prep_scaled_size(int H, int W, double sc, int32_t* out_h, int32_t* out_w);
+int asep_prep_scale_gray(asep_post* p, const uint8_t* img, int H, int W, int C, double sc,
+                         uint8_t* out_image, float* out_gray);
+int asep_prep_scale_gray_dev(asep_post* p, const uint8_t* d_img, int H, int W, int C, double sc,
+                             uint8_t* d_out_image, float* d_out_gray, void* stream);
+
+/* region_net_post_processor_base.py:230-251 apply_cc_analysis: drop 8-connected components whose pixel count is
+ * below min_size (the caller evaluates int(size * threshold) in double like the reference).
+ * mask: uint8 [H,W,pix_stride], channel `channel` is used. */
+int asep_post_cc_filter(asep_post* p, const uint8_t* mask, int H, int W, int pix_stride, int channel,
+                        int min_size, uint8_t* out);
+
+/* cv2.erode / dilate / morphologyEx(MORPH_OPEN | MORPH_CLOSE) with a kw x kh rectangle, default anchor
+ * (kw/2, kh/2), default constant border; op: 0 erode, 1 dilate, 2 open, 3 close. */
+int asep_post_morph_rect(asep_post* p, int op, const uint8_t* mask, int H, int W, int kw, int kh, uint8_t* out);
+
+/* separator_net_post_processor.py:26-97 post_process: CC filter, horizontal opening (k_h x 1), vertical opening
+ * (1 x k_v), horizontal minus vertical, clean-up opening (k_clean x 1).  mask: uint8 [H,W,pix_stride] (the
+ * thresholded net output, channel 0 is the separator class).  Outputs uint8 [H,W] each. */
+int asep_post_separator(asep_post* p, const uint8_t* mask, int H, int W, int pix_stride, int channel,
+                        int min_size, int k_h, int k_v, int k_clean, uint8_t* out_horizontal,
+                        uint8_t* out_vertical);
+int asep_post_separator_dev(asep_post* p, const uint8_t* d_mask, int H, int W, int pix_stride, int channel,
+                            int min_size, int k_h, int k_v, int k_clean, uint8_t* d_out_horizontal,
+                            uint8_t* d_out_vertical, void* stream);
+
+/* swt_dist_trafo.py:18-29 distance_transform without the file decode: gray uint8 [H,W] -> 255-gray ->
+ * GaussianBlur 5x5 -> Otsu -> exact Euclidean distance to the nearest zero pixel -> astype(uint8).
+ * out_otsu (optional) receives the Otsu threshold; out_d2 (optional) the exact squared distances (int32). */
+int asep_swt_distance_transform(asep_post* p, const uint8_t* gray, int H, int W, uint8_t* out,
+                                int32_t* out_otsu, int32_t* out_d2);
+int asep_swt_distance_transform_dev(asep_post* p, const uint8_t* d_gray, int H, int W, uint8_t* d_out,
+                                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif
