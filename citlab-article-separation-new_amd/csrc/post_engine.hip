@@ -1,6 +1,6 @@
 // Host side of the classical image stages (include/asep_hip.h, "classical image stages" block).
 // Compiled with -ffp-contract=off: the float / double sequences below restate OpenCV's scalar code paths and must
-// not be fused into FMAs (the oracle in oracle/classical_oracle.py evaluates them step by step).
+// not be fused into FMAs (the CPU restatement used by the parity tests evaluates them step by step).
 #include <cmath>
 #include <vector>
 

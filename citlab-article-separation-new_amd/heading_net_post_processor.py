@@ -1,0 +1,243 @@
+"""Heading detection pipeline: image -> ARU-Net heading probability + stroke-width transform -> PAGE-XML tags.
+
+Mirror of ``article_separation/image_segmentation/net_post_processing/heading_net_post_processor.py`` (same class /
+method names, fusion rule and output file ``<dir>/page/<name>.xml.xml``) and of
+``python_util/image_processing/swt_dist_trafo.py``.  The net and the stroke-width distance transform (Gaussian ->
+Otsu -> exact Euclidean distance transform on the full-resolution scan) run on the GPU; the per-text-line
+statistics are host numpy on small crops, evaluated with the reference's own numpy expressions so that the
+threshold comparisons see identical doubles.
+"""
+import ctypes as C
+from collections import Counter
+
+import numpy as np
+from scipy import ndimage
+
+from . import _lib, image_ops
+from .host_util import rescale_points
+from .image_io import load_image_bgr
+from .net_post_processing_helper import get_scaling_factor
+from .path_util import get_page_path
+from .region_to_page_writer import RegionToPageWriter
+from .separator_net_post_processor import RegionNetPostProcessor
+
+HEADING = "heading"          # page_constants.py:58-59 TextRegionTypes
+PARAGRAPH = "paragraph"
+_EIGHT = np.ones((3, 3), dtype=bool)
+
+
+def bgr_to_gray_u8(img):
+    """cv2.imread(path, IMREAD_GRAYSCALE) of an already decoded BGR image (OpenCV 4.x fixed-point weights)."""
+    if img.ndim == 2:
+        return img
+    b, g, r = (img[:, :, i].astype(np.int32) for i in range(3))
+    return ((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8)
+
+
+class StrokeWidthDistanceTransform:
+    """swt_dist_trafo.py:5-66."""
+
+    def __init__(self, dark_on_bright=True, clean_ccs=2, device=0):
+        if not dark_on_bright:
+            raise NotImplementedError("only dark text on bright paper (the reference's only use)")
+        self._clean_ccs = clean_ccs
+        self.device = device
+
+    def distance_transform(self, img_or_path):
+        """:18-24 -- accepts a file path like the reference, or an already decoded gray / BGR uint8 array."""
+        if isinstance(img_or_path, str):
+            img_or_path = load_image_bgr(img_or_path)
+        return image_ops.swt_distance_transform(bgr_to_gray_u8(np.asarray(img_or_path)), self.device)
+
+    def connected_components_cv(self, image, connectivity=8):
+        """:31-41: (x, y, w, h) of every connected component of non-zero pixels."""
+        assert connectivity in (4, 8), f"Connectivity has to be 4 or 8 (was {connectivity})."
+        lab, _ = ndimage.label(np.asarray(image) != 0, structure=_EIGHT if connectivity == 8 else None)
+        return [(sl[1].start, sl[0].start, sl[1].stop - sl[1].start, sl[0].stop - sl[0].start)
+                for sl in ndimage.find_objects(lab)]
+
+    def clean_connected_components(self, components):
+        """:43-66."""
+        out = []
+        for component in components:
+            width, height = component[2], component[3]
+            if self._clean_ccs > 0 and (width < 3 or height < 3 or height > 500 or width > 500):
+                continue
+            if self._clean_ccs > 1 and (width / height > 8 or height / width > 8):
+                continue
+            out.append(component)
+        return out
+
+
+class HeadingNetPostProcessor(RegionNetPostProcessor):
+    def __init__(self, image_list, path_to_pb, fixed_height, scaling_factor, weight_dict=None, threshold=0.5,
+                 thresh_dict=None, text_line_percentage=None):
+        super().__init__(image_list, path_to_pb, fixed_height, scaling_factor)
+        self.SWT = StrokeWidthDistanceTransform(dark_on_bright=True)
+        self.weight_dict = weight_dict if weight_dict is not None else {"net": 0.33, "stroke_width": 0.33,
+                                                                        "text_height": 0.33}
+        self.threshold = threshold
+        self.thresh_dict = thresh_dict if thresh_dict is not None else {"net_thresh": 0.9, "stroke_width_thresh": 0.9,
+                                                                        "text_height_thresh": 0.9,
+                                                                        "sw_th_thresh": 0.8}
+        self.text_line_percentage = text_line_percentage if text_line_percentage is not None else 1.0
+
+    def scale_to_new_interval(self, data, old_min, old_max, new_min=0, new_max=1):
+        """:50-63."""
+        if old_max - old_min == 0:
+            return data
+        return (new_max - new_min) / (old_max - old_min) * (data - old_min) + new_min
+
+    def post_process(self, net_output):
+        """:202-208."""
+        return net_output[:, :, 0] / 255
+
+    def get_swt_features_image(self, image_path):
+        return self.SWT.distance_transform(image_path)
+
+    def get_swt_features_textline(self, swt_feature_image, text_line):
+        """:218-245."""
+        x, y, w, h = text_line.get_bounding_box()
+        xa, xb = x, x + w
+        ya, yb = y, y + h
+        text_line_swt = swt_feature_image[ya:yb + 1, xa:xb + 1]
+        text_line_ccs = self.SWT.clean_connected_components(self.SWT.connected_components_cv(text_line_swt))
+        swt_cc_values = []
+        text_line_height = 0
+        for cc in text_line_ccs:
+            swt_cc_values.append(np.max(text_line_swt[cc[1]: cc[1] + cc[3], cc[0]: cc[0] + cc[2]]))
+            if cc[3] > text_line_height:
+                text_line_height = cc[3]
+        text_line_stroke_width = np.median(swt_cc_values) if swt_cc_values else 0.0
+        return text_line_stroke_width, text_line_height
+
+    def get_net_prob_for_text_line(self, net_output, text_line, scaling_factor):
+        """:247-270: mean net confidence over the rescaled bounding box (divided by its nominal size)."""
+        if not text_line.surr_p:
+            return 0
+        pts = rescale_points(text_line.surr_p, scaling_factor)
+        xs = [p[0] for p in pts]
+        ys = [p[1] for p in pts]
+        xa, ya = min(xs), min(ys)
+        width, height = max(xs) - xa + 1, max(ys) - ya + 1
+        net_output_text_line = net_output[ya:ya + height, xa:xa + width]
+        return np.sum(net_output_text_line) / (width * height)
+
+    def to_page_xml(self, page_path, image_path=None, net_output_post=None, swt_feature_image=None, *args, **kwargs):
+        """:66-200."""
+        writer = RegionToPageWriter(page_path, path_to_image=image_path, fixed_height=self.fixed_height,
+                                    scaling_factor=self.scaling_factor)
+        if swt_feature_image is None:
+            swt_feature_image = self.get_swt_features_image(image_path)
+        page_object = writer.page_object
+        text_lines = page_object.get_textlines()
+
+        stroke_width_dict, height_dict, net_prob_dict = {}, {}, {}
+        for text_line in text_lines:
+            if not text_line.surr_p:
+                stroke_width, height = 0, 0
+            else:
+                stroke_width, height = self.get_swt_features_textline(swt_feature_image, text_line)
+            stroke_width_dict[text_line.id] = stroke_width
+            height_dict[text_line.id] = height
+            if self.weight_dict['net'] == 0 or net_output_post is None:
+                net_prob_dict[text_line.id] = 0
+            else:
+                net_prob_dict[text_line.id] = self.get_net_prob_for_text_line(net_output_post, text_line,
+                                                                              writer.scaling_factor)
+
+        stroke_width_list = list(stroke_width_dict.values())
+        use_swt_features = len(stroke_width_list) > 0
+        if use_swt_features:
+            stroke_width_mode = Counter(stroke_width_list).most_common(1)[0][0]
+            height_mode = Counter(list(height_dict.values())).most_common(1)[0][0]
+            for text_line in text_lines:
+                stroke_width_dict[text_line.id] = stroke_width_dict[text_line.id] - stroke_width_mode
+                height_dict[text_line.id] = height_dict[text_line.id] - height_mode
+            stroke_width_list = list(stroke_width_dict.values())
+            stroke_width_min, stroke_width_max = np.min(stroke_width_list), np.max(stroke_width_list)
+            height_list = list(height_dict.values())
+            height_min, height_max = np.min(height_list), np.max(height_list)
+            net_weight = self.weight_dict["net"]
+            stroke_width_weight = self.weight_dict["stroke_width"]
+            height_weight = self.weight_dict["text_height"]
+            net_thresh = self.thresh_dict["net_thresh"]
+            stroke_width_thresh = self.thresh_dict["stroke_width_thresh"]
+            height_thresh = self.thresh_dict["text_height_thresh"]
+            sw_th_thresh = self.thresh_dict["sw_th_thresh"]
+
+        for text_line in text_lines:
+            net_conf = net_prob_dict[text_line.id]
+            if use_swt_features:
+                sw_conf = self.scale_to_new_interval(stroke_width_dict[text_line.id], old_min=stroke_width_min,
+                                                     old_max=stroke_width_max)
+                th_conf = self.scale_to_new_interval(height_dict[text_line.id], old_min=height_min,
+                                                     old_max=height_max)
+                if sw_conf >= stroke_width_thresh or th_conf >= height_thresh or \
+                        (sw_conf + th_conf) / 2 >= sw_th_thresh or net_conf >= net_thresh:
+                    is_heading_confidence = 1.0
+                else:
+                    is_heading_confidence = net_weight * net_conf + stroke_width_weight * sw_conf \
+                        + height_weight * th_conf
+            else:
+                is_heading_confidence = net_conf
+            if is_heading_confidence > self.threshold:
+                text_line.set_structure_attribute("semantic_type", HEADING)
+                text_line.flush()
+
+        for text_region in page_object.get_text_regions():
+            text_region.region_type = PARAGRAPH
+            if text_region.text_lines:
+                num_headings = sum(1 for tl in text_region.text_lines if tl.get_semantic_type() == HEADING)
+                if num_headings / len(text_region.text_lines) >= self.text_line_percentage:
+                    text_region.region_type = HEADING
+            text_region.node.set("type", text_region.region_type)
+
+        writer.save_page_xml(page_path + ".xml")
+        return page_object
+
+    def heading_probability(self, image):
+        """decoded image -> uint8 net output [h,w,n_cls] at the scaled size (:285-288), device resident in between."""
+        import torch
+        dev = self.device
+        lib = _lib.init_device(dev)
+        tdev = torch.device("cuda", dev)
+        image = np.require(image, dtype=np.uint8, requirements=['C', 'W'])   # Pillow hands out read-only views
+        if image.ndim == 2:
+            image = image[:, :, None]
+        H, W, Cn = image.shape
+        sc = get_scaling_factor(H, W, self.scaling_factor, fixed_height=self.fixed_height)
+        h, w = image_ops.scaled_size(H, W, sc)
+        ncls = self.pb_graph.cfg.n_classes
+        _, ws = image_ops._workspace(dev)
+        with torch.cuda.device(tdev):
+            sp = C.c_void_p(torch.cuda.current_stream(tdev).cuda_stream)
+            d_img = torch.from_numpy(image).to(tdev)
+            d_gray = torch.empty((h, w), dtype=torch.float32, device=tdev)
+            _lib.check(lib.asep_prep_scale_gray_dev(ws, d_img.data_ptr(), H, W, Cn, float(sc), None,
+                                                    d_gray.data_ptr(), sp), "asep_prep_scale_gray_dev")
+            d_out = torch.empty((h, w, ncls), dtype=torch.float32, device=tdev)
+            d_u8 = torch.empty((h, w, ncls), dtype=torch.uint8, device=tdev)
+            _lib.check(lib.asep_aru_forward_dev(self.pb_graph.handle(dev), d_gray.data_ptr(), h, w, d_out.data_ptr(),
+                                                d_u8.data_ptr(), None, 0.0, sp), "asep_aru_forward_dev")
+            return d_u8.cpu().numpy()
+
+    def run(self, gpu_device='0'):
+        """:272-303."""
+        self.gpu_devices = gpu_device
+        self.SWT.device = self.device
+        new_page_objects = []
+        for image_path in self.image_paths:
+            image = load_image_bgr(image_path)
+            if self.weight_dict['net'] > 0:
+                net_output = self.heading_probability(image)
+                net_output_post = self.post_process(net_output)
+                if self.keep_outputs:
+                    self.net_outputs.append(net_output)
+                    self.net_outputs_post.append(net_output_post)
+            else:
+                net_output_post = None
+            swt_feature_image = self.SWT.distance_transform(image)
+            new_page_objects.append(self.to_page_xml(get_page_path(image_path), image_path, net_output_post,
+                                                     swt_feature_image))
+        return new_page_objects

@@ -1,0 +1,49 @@
+"""Image file decode for the two ARU-Net pipelines (host side, Pillow instead of ``cv2.imread``).
+
+    load_image_bgr          cv2.imread(path)                         helper:29   (8-bit, BGR channel order)
+    load_image_gray         cv2.imread(path, IMREAD_GRAYSCALE)       swt_dist_trafo.py:19
+    get_image_dimensions    image_stats.py:23-29                     (width, height)
+    load_and_scale_image    helper:28-33                             decode here, scale + gray on the GPU
+
+Grayscale files are kept single-channel: ``cv2.imread`` would replicate the channel three times and BGR2GRAY of
+equal channels returns the value itself (3735 + 19235 + 9798 = 2^15), so the net input is identical.
+JPEG decoders differ between libjpeg builds by +-1 in places; PNG / TIFF inputs are bit-identical.
+"""
+import numpy as np
+from PIL import Image
+
+from . import image_ops
+
+Image.MAX_IMAGE_PIXELS = None        # newspaper scans exceed Pillow's decompression-bomb guard
+
+
+def get_image_dimensions(image_path):
+    with Image.open(image_path) as im:
+        return im.size
+
+
+def load_image_bgr(path_to_image):
+    """uint8 [H,W,3] in BGR order, or uint8 [H,W] for single-channel files."""
+    with Image.open(path_to_image) as im:
+        if im.mode in ("L", "1", "I;16", "I", "F", "P") and im.mode != "P":
+            if im.mode != "L":
+                im = im.convert("L")
+            return np.asarray(im, dtype=np.uint8)
+        rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def load_image_gray(path_to_image):
+    """8-bit gray like ``cv2.imread(path, cv2.IMREAD_GRAYSCALE)``: colour files go through the BGR2GRAY weights
+    (OpenCV converts inside the decoder; for PNG/TIFF that is the same fixed-point formula)."""
+    img = load_image_bgr(path_to_image)
+    if img.ndim == 2:
+        return img
+    b, g, r = (img[:, :, i].astype(np.int32) for i in range(3))
+    return ((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8)
+
+
+def load_and_scale_image(path_to_image, fixed_height, scaling_factor, device=0):
+    """helper:28-33 -> (image uint8 scaled, image_grey float32 [h,w] in 0..1, sc)."""
+    image = load_image_bgr(path_to_image)
+    return image_ops.scale_and_gray(image, fixed_height, scaling_factor, device=device)

@@ -220,8 +220,9 @@ class Page:
     def get_ids(self):
         return {n.get("id") for n in self.tree.getroot().iter() if n.get("id")}
 
-    def get_unique_id(self, page_object_name):
-        ids = self.get_ids()
+    def get_unique_id(self, page_object_name, ids=None):
+        """page.py:464-477: smallest free '<name>_<n>', n >= 1 (the reference gives up after n = 1000)."""
+        ids = self.get_ids() if ids is None else ids
         i = 1
         while f"{page_object_name}_{i}" in ids:
             i += 1
@@ -241,12 +242,18 @@ class Page:
         parents = {c: p for p in self.tree.getroot().iter() for c in p}
         for n in list(self.page_node.iter(self._q(region_type))):
             parents[n].remove(n)
+        self._sep_ids = None
 
     def add_separator_region(self, points, orientation):
         """separator_region_to_page_writer.py:340-358: id 'SeparatorRegion_<n>', custom structure {orientation:...}."""
-        rid = self.get_unique_id("SeparatorRegion")
-        node = ET.SubElement(self.page_node, self._q("SeparatorRegion"),
-                             {"id": rid, "custom": format_custom_attr({"structure": {"orientation": orientation}})})
+        if getattr(self, "_sep_ids", None) is None:
+            self._sep_ids = self.get_ids()               # one DOM walk per batch of additions
+        rid = self.get_unique_id("SeparatorRegion", self._sep_ids)
+        self._sep_ids.add(rid)
+        attrib = {"id": rid}
+        if orientation:
+            attrib["custom"] = format_custom_attr({"structure": {"orientation": orientation}})
+        node = ET.SubElement(self.page_node, self._q("SeparatorRegion"), attrib)
         ET.SubElement(node, self._q("Coords"), {"points": format_points(points)})
         return rid
 

@@ -1,0 +1,103 @@
+"""CLI mirror of ``article_separation/image_segmentation/net_post_processing/run_net_post_processing.py``.
+
+Same flags and defaults (``--fixed_height`` defaults to 900 for headings and 1500 for separators, threshold 0.05).
+The reference fans image sub-lists out over a ``ProcessPoolExecutor(num_processes)`` of TensorFlow-CPU workers
+(``gpu_devices=''``); here a worker is one process per GPU: sub-lists are built exactly like the reference's
+(``:64-72``) and dealt round-robin to the visible devices, ``--num_processes`` caps the number of workers.
+"""
+import argparse
+import multiprocessing as mp
+
+from .path_util import load_list_file
+
+MAX_SUBLIST_SIZE = 50
+
+
+def run_separator(image_list, path_to_pb, fixed_height, scaling_factor, threshold, gpu_devices='0'):
+    from .separator_net_post_processor import SeparatorNetPostProcessor
+    SeparatorNetPostProcessor(image_list, path_to_pb, fixed_height, scaling_factor, threshold,
+                              gpu_devices=gpu_devices).run()
+
+
+def run_heading(image_list, path_to_pb, fixed_height=900, scaling_factor=1, is_heading_threshold=0.4,
+                weight_dict=None, thresh_dict=None, text_line_percentage=0.8, gpu_devices='0'):
+    from .heading_net_post_processor import HeadingNetPostProcessor
+    if thresh_dict is None:
+        thresh_dict = {'net_thresh': 1.0, 'stroke_width_thresh': 1.0, 'text_height_thresh': 0.9, 'sw_th_thresh': 0.9}
+    if weight_dict is None:
+        weight_dict = {'net': 0.8, 'stroke_width': 0.0, 'text_height': 0.2}
+    HeadingNetPostProcessor(image_list, path_to_pb, fixed_height, scaling_factor, weight_dict, is_heading_threshold,
+                            thresh_dict, text_line_percentage).run(gpu_device=gpu_devices)
+
+
+def build_parser():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--path_to_image_list", type=str, required=True,
+                        help="Path to the list file holding the image paths.")
+    parser.add_argument("--path_to_pb", type=str, required=True,
+                        help="Path to the pixel labelling graph (TF1 frozen .pb or .asepw).")
+    parser.add_argument("--num_processes", type=int, required=False, default=8,
+                        help="Upper bound on the number of worker processes (one per GPU is used).")
+    parser.add_argument("--fixed_height", type=int, required=False, help="Input image height")
+    parser.add_argument("--scaling_factor", type=float, required=False, default=1.0, help="Scaling factor of images.")
+    parser.add_argument("--mode", type=str, required=True, choices=['heading', 'separator'],
+                        help="Which information should be processed, e.g. headings or separator.")
+    parser.add_argument("--threshold", type=float, required=False, default=0.05,
+                        help="Threshold for binarization of net output.")
+    return parser
+
+
+def build_sub_lists(image_path_list, num_processes):
+    """:64-72."""
+    size_sub_lists = len(image_path_list) // num_processes
+    if size_sub_lists == 0:
+        size_sub_lists = 1
+        num_processes = len(image_path_list)
+    size_sub_lists = min(MAX_SUBLIST_SIZE, size_sub_lists)
+    return [image_path_list[i: i + size_sub_lists] for i in range(0, len(image_path_list), size_sub_lists)]
+
+
+def _worker(mode, sub_lists, path_to_pb, fixed_height, scaling_factor, threshold, gpu):
+    for sub in sub_lists:
+        if mode == 'separator':
+            run_separator(sub, path_to_pb, fixed_height, scaling_factor, threshold, gpu_devices=str(gpu))
+        else:
+            run_heading(sub, path_to_pb, fixed_height, scaling_factor, 0.4, None, None, 0.8, gpu_devices=str(gpu))
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    mode = args.mode
+    image_path_list = load_list_file(args.path_to_image_list)
+    if args.fixed_height is None:
+        fixed_height = 900 if mode == 'heading' else 1500
+    else:
+        fixed_height = args.fixed_height
+    if not image_path_list:
+        return 0
+    sub_lists = build_sub_lists(image_path_list, args.num_processes)
+    from . import _lib
+    import torch
+    # torch.cuda.device_count() does not initialise the GPU, so worker processes can still be spawned afterwards
+    n_gpus = torch.cuda.device_count()
+    if n_gpus <= 0:
+        raise _lib.AsepError("no HIP device visible: the MI355X (gfx950) engine has no CPU fallback")
+    n_workers = max(1, min(n_gpus, args.num_processes, len(sub_lists)))
+    per_worker = [sub_lists[i::n_workers] for i in range(n_workers)]
+    if n_workers == 1:
+        _worker(mode, per_worker[0], args.path_to_pb, fixed_height, args.scaling_factor, args.threshold, 0)
+        return 0
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(mode, per_worker[i], args.path_to_pb, fixed_height,
+                                               args.scaling_factor, args.threshold, i)) for i in range(n_workers)]
+    for p in procs:
+        p.start()
+    rc = 0
+    for p in procs:
+        p.join()
+        rc = rc or p.exitcode
+    return rc
+
+
+if __name__ == '__main__':
+    raise SystemExit(main())

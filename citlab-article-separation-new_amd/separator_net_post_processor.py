@@ -1,0 +1,160 @@
+"""Separator detection pipeline: image -> ARU-Net -> classical post-processing -> polygons -> PAGE-XML.
+
+Mirror of ``article_separation/image_segmentation/net_post_processing/separator_net_post_processor.py`` and its
+base class ``region_net_post_processor_base.py`` (same class / method names, argument meaning and output files:
+``<dir>/page/<name>.xml.xml``).  Between the decoded image and the two binary separator masks nothing leaves the
+GPU: uint8 upload -> resize + gray (a1) -> ARU-Net with fused uint8 / threshold epilogue (a3-a8) -> CC filter and
+rectangular openings on bit planes (a9); only the two masks come back for polygon extraction (a10).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, image_ops, polygonize
+from .host_util import rescale_points
+from .image_io import load_image_bgr
+from .net_post_processing_helper import (AruGraph, _device_of, apply_threshold, get_net_output, get_scaling_factor,
+                                         load_graph)
+from .path_util import get_page_path, load_list_file
+from .region_to_page_writer import SEPARATOR_REGION, SeparatorRegionToPageWriter
+
+
+class RegionNetPostProcessor:
+    """region_net_post_processor_base.py:17-268 (the parts the separator pipeline uses)."""
+
+    def __init__(self, image_list, path_to_pb, fixed_height, scaling_factor, threshold=None, gpu_devices='0'):
+        self.image_paths = load_list_file(image_list) if isinstance(image_list, str) else list(image_list)
+        self.fixed_height = fixed_height
+        self.scaling_factor = scaling_factor
+        self.threshold = threshold
+        self.pb_graph = load_graph(path_to_pb)
+        self.gpu_devices = gpu_devices
+        # the reference keeps every image / net output of a run in memory (base:33-35); here that is opt-in
+        self.keep_outputs = False
+        self.images = []
+        self.net_outputs = []
+        self.net_outputs_post = []
+
+    @property
+    def device(self):
+        return _device_of(self.gpu_devices)
+
+    def apply_cc_analysis(self, net_output, threshold):
+        return image_ops.apply_cc_analysis(net_output, threshold, self.device)
+
+    def apply_contour_detection2(self, binary_image):
+        """base:186-197: polygons (exterior + interior rings) of the regions with value 255."""
+        return polygonize.shapes(binary_image, value=255, connectivity=8)
+
+    def apply_contour_detection(self, image, use_alpha_shape=False):
+        """base:163-184 without the alpha-shape option (needs shapely / Delaunay alpha complexes)."""
+        if use_alpha_shape:
+            raise NotImplementedError("alpha shapes are not part of this build")
+        return [p[0] for p in polygonize.shapes(image, value=255, connectivity=8)]
+
+    def rescale_polygons(self, polygons_dict, scaling_factor):
+        """base:253-268: every ring times ``scaling_factor`` with int() truncation."""
+        for region_name, polygon_list in polygons_dict.items():
+            polygons_dict[region_name] = [[rescale_points(ring, scaling_factor) for ring in polygon]
+                                          for polygon in polygon_list]
+        return polygons_dict
+
+
+class SeparatorNetPostProcessor(RegionNetPostProcessor):
+    def __init__(self, image_list, path_to_pb, fixed_height, scaling_factor, threshold, gpu_devices):
+        super().__init__(image_list, path_to_pb, fixed_height, scaling_factor, threshold, gpu_devices)
+
+    def post_process(self, net_output):
+        """:26-97 on a thresholded uint8 HWC net output (host array) -> {"horizontal", "vertical"}."""
+        return image_ops.separator_post_process(net_output, self.device)
+
+    def to_polygons(self, net_output, separator_type=None):
+        contours = self.apply_contour_detection2(net_output)
+        if separator_type is None:
+            return {SEPARATOR_REGION: contours}
+        return {SEPARATOR_REGION + "_" + separator_type: contours}
+
+    def to_page_xml(self, page_path, image_path=None, polygons_dict=None, *args, **kwargs):
+        writer = SeparatorRegionToPageWriter(page_path, image_path, self.fixed_height, self.scaling_factor,
+                                             polygons_dict)
+        writer.remove_separator_regions_from_page()
+        writer.merge_regions()
+        writer.save_page_xml(page_path + ".xml")
+        return writer.page_object
+
+    # -- the fused device path ---------------------------------------------------------------------------------
+    def separator_masks(self, image):
+        """decoded image (uint8 [H,W,3] BGR or [H,W]) -> ({"horizontal", "vertical"} uint8 [h,w], sc, extras).
+
+        Same arithmetic as load_and_scale_image -> get_net_output -> uint8(x*255) -> apply_threshold -> post_process
+        (:141-151), executed without leaving HBM."""
+        import torch
+        dev = self.device
+        lib = _lib.init_device(dev)
+        tdev = torch.device("cuda", dev)
+        image = np.require(image, dtype=np.uint8, requirements=['C', 'W'])   # Pillow hands out read-only views
+        if image.ndim == 2:
+            image = image[:, :, None]
+        H, W, Cn = image.shape
+        sc = get_scaling_factor(H, W, self.scaling_factor, fixed_height=self.fixed_height)
+        h, w = image_ops.scaled_size(H, W, sc)
+        ncls = self.pb_graph.cfg.n_classes
+        _, ws = image_ops._workspace(dev)
+        with torch.cuda.device(tdev):
+            stream = torch.cuda.current_stream(tdev)
+            sp = C.c_void_p(stream.cuda_stream)
+            d_img = torch.from_numpy(image).to(tdev, non_blocking=False)
+            d_gray = torch.empty((h, w), dtype=torch.float32, device=tdev)
+            _lib.check(lib.asep_prep_scale_gray_dev(ws, d_img.data_ptr(), H, W, Cn, float(sc), None,
+                                                    d_gray.data_ptr(), sp), "asep_prep_scale_gray_dev")
+            d_out = torch.empty((h, w, ncls), dtype=torch.float32, device=tdev)
+            d_u8 = torch.empty((h, w, ncls), dtype=torch.uint8, device=tdev)
+            d_mask = torch.empty((h, w, ncls), dtype=torch.uint8, device=tdev)
+            _lib.check(lib.asep_aru_forward_dev(self.pb_graph.handle(dev), d_gray.data_ptr(), h, w, d_out.data_ptr(),
+                                                d_u8.data_ptr(), d_mask.data_ptr(), float(self.threshold), sp),
+                       "asep_aru_forward_dev")
+            size = h * w
+            min_size = int(size * (1 / size * 100))
+            k_h, k_v, k_c = image_ops.separator_kernel_sizes(h, w)
+            d_hz = torch.empty((h, w), dtype=torch.uint8, device=tdev)
+            d_vt = torch.empty((h, w), dtype=torch.uint8, device=tdev)
+            _lib.check(lib.asep_post_separator_dev(ws, d_mask.data_ptr(), h, w, ncls, 0, min_size, k_h, k_v, k_c,
+                                                   d_hz.data_ptr(), d_vt.data_ptr(), sp), "asep_post_separator_dev")
+            masks = {"horizontal": d_hz.cpu().numpy(), "vertical": d_vt.cpu().numpy()}
+            extras = {"net_output_u8": d_u8.cpu().numpy()} if self.keep_outputs else {}
+        return masks, sc, extras
+
+    def run(self):
+        """:135-159."""
+        page_objects = []
+        for image_path in self.image_paths:
+            image = load_image_bgr(image_path)
+            masks, sc, extras = self.separator_masks(image)
+            if self.keep_outputs:
+                self.net_outputs.append(extras["net_output_u8"])
+                self.net_outputs_post.append(masks)
+            polygons_dict = {}
+            for separator_type, net_output_post in masks.items():
+                polygons_dict.update(self.to_polygons(net_output_post, separator_type))
+            polygons_dict = self.rescale_polygons(polygons_dict, scaling_factor=1 / sc)
+            page_objects.append(self.to_page_xml(get_page_path(image_path), image_path=image_path,
+                                                 polygons_dict=polygons_dict))
+        return page_objects
+
+
+def build_parser():
+    import argparse
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--image_list', type=str, required=False)
+    parser.add_argument('--path_to_pb', type=str, required=False)
+    parser.add_argument('--fixed_height', type=int, required=False, default=1500)
+    parser.add_argument('--scaling_factor', type=float, required=False, default=1.0)
+    parser.add_argument('--threshold', type=float, required=False, default=0.05)
+    parser.add_argument('--gpu_devices', type=str, required=False, default='')
+    return parser
+
+
+if __name__ == '__main__':
+    args = build_parser().parse_args()
+    SeparatorNetPostProcessor(args.image_list, args.path_to_pb, args.fixed_height, args.scaling_factor,
+                              args.threshold, args.gpu_devices).run()

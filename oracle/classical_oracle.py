@@ -32,7 +32,11 @@ def cv_round(x):
 
 
 def bgr2gray(bgr):
-    """cv2.cvtColor(BGR2GRAY) on uint8, OpenCV 4.x 15-bit fixed point."""
+    """cv2.cvtColor(BGR2GRAY) on uint8, OpenCV 4.x 15-bit fixed point.  A 2-D input is a gray file that cv2.imread
+    would have replicated to three equal channels: the weights sum to 2^15, so the value comes back unchanged."""
+    bgr = np.asarray(bgr)
+    if bgr.ndim == 2:
+        return bgr.astype(np.uint8)
     b = bgr[..., 0].astype(np.int64)
     g = bgr[..., 1].astype(np.int64)
     r = bgr[..., 2].astype(np.int64)
@@ -349,7 +353,7 @@ def edt_sq(binary):
 def swt_distance_transform(gray):
     """swt_dist_trafo.py:18-29 minus the file decode: 255-gray -> blur -> Otsu -> exact EDT -> astype(uint8)
     (truncation; values >= 256 wrap like the C cast)."""
-    inv = (255 - np.asarray(gray, dtype=np.uint8).astype(np.int64)).astype(np.uint8)
+    inv = (255 - bgr2gray(np.asarray(gray, dtype=np.uint8)).astype(np.int64)).astype(np.uint8)
     blur = gaussian5(inv)
     thr = otsu_threshold(blur)
     binary = ((blur > thr) * 255).astype(np.uint8)

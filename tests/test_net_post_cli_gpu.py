@@ -1,0 +1,122 @@
+"""End to end on the GPU through the reference's CLI surface (run_net_post_processing.py --mode separator|heading):
+image file + frozen graph (.pb) -> PAGE-XML.  The fused device path (uint8 upload -> resize/gray -> ARU-Net -> uint8
++ threshold epilogue -> CC filter / openings) must give exactly what the reference's step-by-step sequence gives
+when each step is evaluated separately (net through get_net_output, classical steps by the CPU oracle)."""
+import numpy as np
+import pytest
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+
+def _page_xml(path, W, H, lines):
+    regs = []
+    for i, (x0, y0, x1, y1) in enumerate(lines):
+        regs.append(f'<TextRegion id="r{i}"><Coords points="{x0},{y0} {x1},{y0} {x1},{y1} {x0},{y1}"/>'
+                    f'<TextLine id="r{i}l0"><Coords points="{x0},{y0} {x1},{y0} {x1},{y1} {x0},{y1}"/>'
+                    f'<Baseline points="{x0},{y1 - 3} {x1},{y1 - 3}"/></TextLine></TextRegion>')
+    path.write_text('<?xml version="1.0" encoding="UTF-8"?>\n<PcGts xmlns="http://schema.primaresearch.org/PAGE/gts/'
+                    'pagecontent/2013-07-15"><Metadata><Creator>t</Creator><Created>2020-01-01T00:00:00</Created>'
+                    '<LastChange>2020-01-01T00:00:00</LastChange></Metadata>'
+                    f'<Page imageFilename="x.png" imageWidth="{W}" imageHeight="{H}">' + "".join(regs)
+                    + '<SeparatorRegion id="old"><Coords points="1,1 5,1 5,5 1,5"/></SeparatorRegion></Page></PcGts>')
+
+
+def _setup(tmp_path, W=600, H=900, color=False):
+    from citlab_article_separation_new_amd import pb_import, synth
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    cfg = AruConfig()
+    w = init_aru_weights(cfg, 77, bias_jitter=0.05, logit_scale=0.05)
+    extra = [{"name": f"graph/aru_net/attMapG/AvgPool_{i}", "op": "AvgPool"} for i in range(cfg.num_scales_att - 1)]
+    extra.append({"name": "output", "op": "Softmax", "input": ["graph/aru_net/logit/logits"]})
+    pb = tmp_path / "separator_aru.pb"
+    pb.write_bytes(pb_import.weights_to_graphdef(w, "graph/", extra))
+    data = tmp_path / "data"
+    (data / "page").mkdir(parents=True)
+    gray = synth.synth_page(3, W=W, H=H)
+    if color:
+        rng = np.random.default_rng(0)
+        rgb = np.stack([gray, np.clip(gray.astype(int) - 10, 0, 255).astype(np.uint8),
+                        np.clip(gray.astype(int) + rng.integers(-5, 6, gray.shape), 0, 255).astype(np.uint8)], axis=-1)
+        Image.fromarray(rgb).save(data / "p0.png")
+    else:
+        Image.fromarray(gray).save(data / "p0.png")
+    lines = [(60, 70 + 60 * i, 300, 110 + 60 * i) for i in range(6)] + [(320, 80, 560, 170)]
+    _page_xml(data / "page" / "p0.xml", W, H, lines)
+    lst = tmp_path / "images.lst"
+    lst.write_text(str(data / "p0.png") + "\n")
+    return str(pb), str(lst), data
+
+
+@pytest.mark.parametrize("fixed_height,color", [(300, False), (400, True)])
+def test_separator_cli_matches_stepwise_reference_sequence(tmp_path, fixed_height, color):
+    from citlab_article_separation_new_amd import image_io, net_post_processing_helper as helper, polygonize
+    from citlab_article_separation_new_amd import run_net_post_processing as cli
+    from citlab_article_separation_new_amd.host_util import rescale_points
+    from citlab_article_separation_new_amd.page_xml import Page
+    from oracle import classical_oracle as co
+    pb, lst, data = _setup(tmp_path, color=color)
+    img = image_io.load_image_bgr(str(data / "p0.png"))
+    # step-by-step sequence of separator_net_post_processor.py:141-151 (oracle for the classical steps)
+    _, grey, sc = co.scale_and_gray(img, fixed_height, 1.0)
+    graph = helper.load_graph(pb)
+    prob = helper.get_net_output(grey, graph, "0")
+    thr = round(float(np.median(prob[:, :, 0])), 3)                 # random weights: put the threshold mid-range
+    net_u8 = np.array(prob * 255, dtype=np.uint8)
+    mask = helper.apply_threshold(net_u8, thr)
+    post = co.separator_post_process(mask)
+    assert 0.02 < (mask[:, :, 0] > 0).mean() < 0.98
+    expected = []
+    for orient in ("horizontal", "vertical"):
+        for poly in polygonize.shapes(post[orient]):
+            expected.append((orient, rescale_points(poly[0], 1 / sc)))
+    assert expected, "test page produced no separators; adjust the threshold"
+
+    rc = cli.main(["--path_to_image_list", lst, "--path_to_pb", pb, "--mode", "separator",
+                   "--fixed_height", str(fixed_height), "--threshold", str(thr), "--num_processes", "1"])
+    assert rc == 0
+    out = Page(str(data / "page" / "p0.xml.xml"))
+    seps = out.get_regions()["SeparatorRegion"]
+    assert "old" not in [s.id for s in seps]
+    got = [(s.get_orientation(), s.points) for s in seps]
+    assert got == expected
+    assert len(out.get_textlines()) == 7
+
+
+def test_heading_cli_matches_stepwise_reference_sequence(tmp_path):
+    from citlab_article_separation_new_amd import image_io, net_post_processing_helper as helper
+    from citlab_article_separation_new_amd import run_net_post_processing as cli
+    from citlab_article_separation_new_amd.heading_net_post_processor import HeadingNetPostProcessor
+    from citlab_article_separation_new_amd.page_xml import Page
+    from oracle import classical_oracle as co
+    pb, lst, data = _setup(tmp_path)
+    img = image_io.load_image_bgr(str(data / "p0.png"))
+    _, grey, sc = co.scale_and_gray(img, 450, 1.0)
+    graph = helper.load_graph(pb)
+    net_u8 = np.array(helper.get_net_output(grey, graph, "0") * 255, dtype=np.uint8)
+    swt = co.swt_distance_transform(img)
+    # expected tags: the same fusion code fed with oracle-side feature images, written to a scratch copy
+    ref_dir = tmp_path / "ref"
+    (ref_dir / "page").mkdir(parents=True)
+    (ref_dir / "p0.png").write_bytes((data / "p0.png").read_bytes())
+    (ref_dir / "page" / "p0.xml").write_text((data / "page" / "p0.xml").read_text())
+    proc = HeadingNetPostProcessor([], pb, 450, 1.0, {'net': 0.8, 'stroke_width': 0.0, 'text_height': 0.2}, 0.4,
+                                   {'net_thresh': 1.0, 'stroke_width_thresh': 1.0, 'text_height_thresh': 0.9,
+                                    'sw_th_thresh': 0.9}, 0.8)
+    proc.to_page_xml(str(ref_dir / "page" / "p0.xml"), str(ref_dir / "p0.png"), net_u8[:, :, 0] / 255, swt)
+    ref = Page(str(ref_dir / "page" / "p0.xml.xml"))
+
+    rc = cli.main(["--path_to_image_list", lst, "--path_to_pb", pb, "--mode", "heading", "--fixed_height", "450",
+                   "--num_processes", "1"])
+    assert rc == 0
+    out = Page(str(data / "page" / "p0.xml.xml"))
+    assert [(t.id, t.get_semantic_type()) for t in out.get_textlines()] == \
+           [(t.id, t.get_semantic_type()) for t in ref.get_textlines()]
+    assert [(r.id, r.region_type) for r in out.get_text_regions()] == \
+           [(r.id, r.region_type) for r in ref.get_text_regions()]
+    assert {r.region_type for r in out.get_text_regions()} <= {"heading", "paragraph"}
+    # the two device-side inputs of the fusion are the oracle's, bit for bit
+    hp = HeadingNetPostProcessor([str(data / "p0.png")], pb, 450, 1.0)
+    assert np.array_equal(hp.heading_probability(img), net_u8)
+    assert np.array_equal(hp.SWT.distance_transform(img), swt)
