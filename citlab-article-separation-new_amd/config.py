@@ -48,6 +48,28 @@ class GnnConfig:
     undirected_graph: bool = True
     # visual branch (GraphRelation image_input); 0 maps -> disabled
     visual_dims: List[int] = field(default_factory=list)   # layer_compressed_dim per feature map
+    # feature_map_generation_params from_layer (layer_depth -1): backbone end points, e.g. scale_0_unet_up_2_conv
+    visual_layers: List[str] = field(default_factory=list)
+    mvn: bool = False                 # GraphRelation flag: per-image standardisation of the fed image
+    backbone: dict = field(default_factory=dict)            # AruConfig fields of the ARU_v1 backbone (graph 'RU')
+
+    def backbone_cfg(self) -> "AruConfig":
+        kw = dict(graph="RU", apply_softmax=False)
+        kw.update(self.backbone)
+        kw["mvn"] = bool(kw.get("mvn", False) or self.mvn)
+        return AruConfig(**kw)
+
+    def visual_channels(self) -> List[int]:
+        """Channels of the selected end points: feat_root * 2^level (ARU_v1.py:208-292)."""
+        import re
+        bc = self.backbone_cfg()
+        out = []
+        for name in self.visual_layers:
+            m = re.fullmatch(r"scale_\d+_unet_(down|up)_(\d+)_(conv|deconv)", name)
+            if not m or int(m.group(2)) >= bc.scale_space_num:
+                raise ValueError(f"'{name}' is not a feature-map end point of the ARU_v1 backbone")
+            out.append(bc.feat(int(m.group(2))))
+        return out
 
     @property
     def u_dim(self) -> int:

@@ -854,6 +854,29 @@ double flops_impl(const asep_aru_cfg& cfg, int H, int W) {
 
 }  // namespace
 
+namespace asep {
+
+int aru_endpoint_dev(asep_aru* m, const char* name, const float** d_ptr, int dims[3]) {
+    if (!m || !name || !d_ptr) { set_error("aru_endpoint_dev: bad argument"); return ASEP_ERR_ARG; }
+    auto it = m->endpoints.find(name);
+    if (it == m->endpoints.end()) { set_error("backbone has no end point '%s' (run a forward first)", name); return ASEP_ERR_ARG; }
+    *d_ptr = it->second.p;
+    if (dims) { dims[0] = it->second.H; dims[1] = it->second.W; dims[2] = it->second.C; }
+    return ASEP_OK;
+}
+
+// "scale_<s>_unet_{down,up}_<l>_{conv,deconv}" -> feat_root * 2^l (ARU_v1.py:208-292)
+int aru_endpoint_channels(const asep_aru* m, const char* name) {
+    if (!m || !name) return -1;
+    int s = 0, l = 0;
+    char kind[16] = {0}, what[16] = {0};
+    if (sscanf(name, "scale_%d_unet_%15[a-z]_%d_%15[a-z]", &s, kind, &l, what) != 4) return -1;
+    if (l < 0 || l >= m->cfg.scale_space_num) return -1;
+    return m->cfg.feat_root << l;
+}
+
+}  // namespace asep
+
 extern "C" {
 
 asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_cfg* cfg) {

@@ -28,6 +28,14 @@ struct asep_gnn {
     float* d_h = nullptr;
     int* d_rowptr = nullptr;
     hipStream_t stream = nullptr;
+    // visual branch (graph_relation.py:84-139): backbone + per-map compression layers
+    std::map<std::string, HostTensor> vis_blob;      // visual_node_feature_compression_fm_<i>/dense/{weights,bias}
+    asep_aru* backbone = nullptr;                    // not owned
+    std::vector<std::string> vis_names;
+    std::vector<float*> vis_W, vis_b;
+    std::vector<int> vis_C, vis_d;
+    int vis_total = 0;
+    float* d_u_cat = nullptr;                        // concatenated node features of the last visual forward
     ~asep_gnn() {
         for (void* p : owned)
             if (p) (void)hipFree(p);
@@ -219,6 +227,8 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
     if (!rc) rc = upload_named(g.get(), blob, c + "/fully_connected_logit_layer_out/weights", {cfg->cls_hidden2, cfg->num_classes}, &g->C3);
     if (!rc) rc = upload_named(g.get(), blob, c + "/fully_connected_logit_layer_out/bias", {cfg->num_classes}, &g->cb3);
     if (rc) return nullptr;
+    for (auto& kv : blob)
+        if (kv.first.rfind("visual_node_feature_compression_fm_", 0) == 0) g->vis_blob[kv.first] = kv.second;
     if (const char* ev = getenv("ASEP_GNN_STEP")) g->use_step = atoi(ev) != 0;
     if (U <= 8 && Ed <= 4) {
         // quads of 4 consecutive features; H-type quads come as whole chunks (lane kk owns h[16c'+4kk ..])
@@ -357,6 +367,102 @@ int asep_gnn_get_hidden(asep_gnn* g, float* out, size_t max_floats) {
     if (max_floats < n) { set_error("asep_gnn_get_hidden: buffer too small"); return ASEP_ERR_ARG; }
     ASEP_HIP_CHECK(hipStreamSynchronize(g->stream));
     ASEP_HIP_CHECK(hipMemcpy(out, g->d_h, n * sizeof(float), hipMemcpyDeviceToHost));
+    return ASEP_OK;
+}
+
+int asep_gnn_attach_backbone(asep_gnn* g, asep_aru* backbone, int n_maps, const char* const* endpoint_names) {
+    if (!g || !backbone || n_maps < 1 || !endpoint_names) { set_error("asep_gnn_attach_backbone: bad argument"); return ASEP_ERR_ARG; }
+    g->backbone = nullptr;
+    g->vis_names.clear(); g->vis_W.clear(); g->vis_b.clear(); g->vis_C.clear(); g->vis_d.clear();
+    g->vis_total = 0;
+    for (int i = 0; i < n_maps; ++i) {
+        if (!endpoint_names[i]) { set_error("asep_gnn_attach_backbone: null end-point name"); return ASEP_ERR_ARG; }
+        const int C = aru_endpoint_channels(backbone, endpoint_names[i]);
+        if (C < 1 || C > 256) {
+            set_error("asep_gnn_attach_backbone: '%s' is not a feature map of this backbone (only unet conv/deconv "
+                      "end points with layer_depth -1 are supported)", endpoint_names[i]);
+            return ASEP_ERR_UNSUPPORTED;
+        }
+        const std::string scope = "visual_node_feature_compression_fm_" + std::to_string(i) + "/dense/";
+        auto w = g->vis_blob.find(scope + "weights"), b = g->vis_blob.find(scope + "bias");
+        if (w == g->vis_blob.end() || b == g->vis_blob.end()) { set_error("weights: missing tensor %sweights|bias", scope.c_str()); return ASEP_ERR_WEIGHTS; }
+        if (w->second.dims.size() != 2 || w->second.dims[0] != C || b->second.dims.size() != 1 || b->second.dims[0] != w->second.dims[1]) {
+            set_error("weights: %sweights must be [%d, d] with a matching bias", scope.c_str(), C);
+            return ASEP_ERR_WEIGHTS;
+        }
+        float *dW = nullptr, *db = nullptr;
+        int rc = upload_named(g, g->vis_blob, scope + "weights", w->second.dims, &dW);
+        if (!rc) rc = upload_named(g, g->vis_blob, scope + "bias", b->second.dims, &db);
+        if (rc) return rc;
+        g->vis_names.push_back(endpoint_names[i]);
+        g->vis_W.push_back(dW); g->vis_b.push_back(db);
+        g->vis_C.push_back(C); g->vis_d.push_back(w->second.dims[1]);
+        g->vis_total += w->second.dims[1];
+    }
+    if (g->vis_total >= g->cfg.node_feature_dim + 1) {
+        set_error("asep_gnn_attach_backbone: %d visual dims exceed node_feature_dim %d", g->vis_total, g->cfg.node_feature_dim);
+        return ASEP_ERR_ARG;
+    }
+    g->backbone = backbone;
+    return ASEP_OK;
+}
+
+int asep_gnn_forward_visual(asep_gnn* g, int N, int E, const int32_t* edges, const float* node_feat, const float* edge_feat,
+                            const float* image, int h, int w, const float* regions, int P, const int32_t* num_points,
+                            int R, const int32_t* relations, float* probs_out) {
+    if (!g || !g->backbone) { set_error("asep_gnn_forward_visual: no backbone attached"); return ASEP_ERR_ARG; }
+    const int U = g->cfg.node_feature_dim, ug = U - g->vis_total;
+    if (N < 1 || h < 1 || w < 1 || P < 1 || !image || !regions || !num_points || (ug > 0 && !node_feat) || (E > 0 && !edges) ||
+        (R > 0 && !probs_out)) { set_error("asep_gnn_forward_visual: bad argument"); return ASEP_ERR_ARG; }
+    DevCopy dc;
+    int32_t *d_e = nullptr, *d_r = nullptr, *d_np = nullptr;
+    float *d_ug = nullptr, *d_f = nullptr, *d_o = nullptr, *d_img = nullptr, *d_reg = nullptr, *d_u = nullptr, *d_bo = nullptr;
+    int rc;
+    if ((rc = dc.up(edges, (size_t)E * 2, &d_e))) return rc;
+    if ((rc = dc.up(node_feat, (size_t)N * ug, &d_ug))) return rc;
+    if ((rc = dc.up(edge_feat, (size_t)E * g->cfg.edge_feature_dim, &d_f))) return rc;
+    if ((rc = dc.up(relations, (size_t)R * 2, &d_r))) return rc;
+    if ((rc = dc.up(image, (size_t)h * w, &d_img))) return rc;
+    if ((rc = dc.up(regions, (size_t)N * 2 * P, &d_reg))) return rc;
+    if ((rc = dc.up(num_points, (size_t)N, &d_np))) return rc;
+    if ((rc = dc.alloc((size_t)R * g->cfg.num_classes, &d_o))) return rc;
+    if ((rc = dc.alloc((size_t)N * U, &d_u))) return rc;
+    if ((rc = dc.alloc((size_t)h * w * 8, &d_bo))) return rc;          // backbone logits (unused by this path)
+    // backbone forward (per-image standardisation happens inside when the model was loaded with mvn)
+    rc = asep_aru_forward_dev(g->backbone, d_img, h, w, d_bo, nullptr, nullptr, 0.f, nullptr);
+    if (rc) return rc;
+    if (ug > 0) hipLaunchKernelGGL(gnn_copy_cols_kernel, dim3(cdiv(N * ug, 256)), dim3(256), 0, nullptr, d_ug, N, ug, d_u, U);
+    int col = ug;
+    for (size_t i = 0; i < g->vis_names.size(); ++i) {
+        const float* fm = nullptr;
+        int dims[3];
+        if ((rc = aru_endpoint_dev(g->backbone, g->vis_names[i].c_str(), &fm, dims))) return rc;
+        if (dims[2] != g->vis_C[i]) { set_error("end point %s has %d channels, expected %d", g->vis_names[i].c_str(), dims[2], g->vis_C[i]); return ASEP_ERR_ARG; }
+        RoiArgs a{};
+        a.fm = fm; a.fh = dims[0]; a.fw = dims[1]; a.C = dims[2];
+        a.regions = d_reg; a.P = P; a.npts = d_np; a.Wc = g->vis_W[i]; a.bc = g->vis_b[i]; a.d = g->vis_d[i];
+        a.u_out = d_u; a.ustride = U; a.col0 = col; a.vmax_out = nullptr;
+        hipLaunchKernelGGL(gnn_roi_compress_kernel, dim3(N), dim3(256), 0, nullptr, a);
+        col += g->vis_d[i];
+    }
+    ASEP_HIP_CHECK(hipGetLastError());
+    rc = asep_gnn_forward_dev(g, N, E, d_e, d_u, d_f, R, d_r, d_o, nullptr);
+    if (rc) return rc;
+    ASEP_HIP_CHECK(hipStreamSynchronize(nullptr));
+    if (R > 0) ASEP_HIP_CHECK(hipMemcpy(probs_out, d_o, (size_t)R * g->cfg.num_classes * sizeof(float), hipMemcpyDeviceToHost));
+    // keep the concatenated features readable for asep_gnn_get_node_features
+    try {
+        g->d_u_cat = (float*)g->pool.get((size_t)N * U * sizeof(float));
+    } catch (const HipError&) { return ASEP_ERR_HIP; }
+    ASEP_HIP_CHECK(hipMemcpy(g->d_u_cat, d_u, (size_t)N * U * sizeof(float), hipMemcpyDeviceToDevice));
+    return ASEP_OK;
+}
+
+int asep_gnn_get_node_features(asep_gnn* g, float* out, size_t max_floats) {
+    if (!g || !out || !g->d_u_cat) { set_error("asep_gnn_get_node_features: no visual forward has run"); return ASEP_ERR_ARG; }
+    const size_t n = (size_t)g->N * g->cfg.node_feature_dim;
+    if (max_floats < n) { set_error("asep_gnn_get_node_features: buffer too small"); return ASEP_ERR_ARG; }
+    ASEP_HIP_CHECK(hipMemcpy(out, g->d_u_cat, n * sizeof(float), hipMemcpyDeviceToHost));
     return ASEP_OK;
 }
 

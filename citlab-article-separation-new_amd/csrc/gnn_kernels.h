@@ -462,4 +462,87 @@ __global__ __launch_bounds__(256) void gnn_pair_cls_kernel(const PairArgs a) {
     for (int c = 0; c < NC; ++c) a.out[(size_t)r * NC + c] = lg[c] / den;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// visual node features (graph_relation.py:84-139, misc.py:282-381): per node the paraxial bounding rectangle of
+// its region (relative coordinates) -> floor-scaled ROI on a backbone feature map -> per-channel max over the ROI
+// -> ff(ReLU) compression -> columns [col0, col0 + d) of the node feature matrix.
+// ---------------------------------------------------------------------------------------------------------------
+struct RoiArgs {
+    const float* fm;          // [fh, fw, C] NHWC
+    int fh, fw, C;
+    const float* regions;     // [N, 2, P]: row 0 = x, row 1 = y, relative to the image size
+    int P;
+    const int32_t* npts;      // [N]
+    const float* Wc;          // [C, d]
+    const float* bc;          // [d]
+    int d;
+    float* u_out;             // [N, ustride]
+    int ustride, col0;
+    float* vmax_out;          // optional [N, C] (tests)
+};
+
+__global__ void __launch_bounds__(256) gnn_roi_compress_kernel(RoiArgs a) {
+    __shared__ float red[256];
+    __shared__ float vmax[256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int np = min(a.npts[n], a.P);
+    float xmin = 0.f, xmax = 0.f, ymin = 0.f, ymax = 0.f;     // misc.py:503-508: no points -> zeros
+    if (np > 0) {
+        const float* rx = a.regions + (size_t)n * 2 * a.P;
+        const float* ry = rx + a.P;
+        xmin = xmax = rx[0];
+        ymin = ymax = ry[0];
+        for (int i = 1; i < np; ++i) {
+            xmin = fminf(xmin, rx[i]); xmax = fmaxf(xmax, rx[i]);
+            ymin = fminf(ymin, ry[i]); ymax = fmaxf(ymax, ry[i]);
+        }
+    }
+    // misc.py:322-337: floor(rel * size) clamped into the map; at least one cell
+    const int x0 = max(min((int)floorf(xmin * (float)a.fw), a.fw - 1), 0);
+    const int x1 = max(min((int)floorf(xmax * (float)a.fw), a.fw - 1), 0);
+    const int y0 = max(min((int)floorf(ymin * (float)a.fh), a.fh - 1), 0);
+    const int y1 = max(min((int)floorf(ymax * (float)a.fh), a.fh - 1), 0);
+    const int nx = max(x1 - x0 + 1, 1), ny = max(y1 - y0 + 1, 1);
+    const int C = a.C;
+    float m = -INFINITY;
+    if (256 % C == 0) {
+        // a thread keeps one channel: rows of nx*C contiguous floats are read coalesced
+        const int rowlen = nx * C;
+        for (int y = 0; y < ny; ++y) {
+            const float* row = a.fm + ((size_t)(y0 + y) * a.fw + x0) * C;
+            for (int i = tid; i < rowlen; i += 256) m = fmaxf(m, row[i]);
+        }
+        red[tid] = m;
+        __syncthreads();
+        if (tid < C) {
+            float v = red[tid];
+            for (int k = tid + C; k < 256; k += C) v = fmaxf(v, red[k]);
+            vmax[tid] = v;
+        }
+    } else {
+        for (int c = tid; c < C; c += 256) {
+            float v = -INFINITY;
+            for (int y = 0; y < ny; ++y)
+                for (int x = 0; x < nx; ++x) v = fmaxf(v, a.fm[((size_t)(y0 + y) * a.fw + x0 + x) * C + c]);
+            vmax[c] = v;
+        }
+    }
+    __syncthreads();
+    if (a.vmax_out && tid < C) a.vmax_out[(size_t)n * C + tid] = vmax[tid];
+    for (int j = tid; j < a.d; j += 256) {
+        float acc = a.bc[j];
+        for (int c = 0; c < C; ++c) acc = fmaf(vmax[c], a.Wc[(size_t)c * a.d + j], acc);
+        a.u_out[(size_t)n * a.ustride + a.col0 + j] = fmaxf(acc, 0.f);
+    }
+}
+
+// copies the geometric node features into the first `ug` columns of the concatenated node feature matrix
+__global__ void __launch_bounds__(256)
+gnn_copy_cols_kernel(const float* __restrict__ src, int N, int ug, float* __restrict__ dst, int ustride) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * ug) return;
+    dst[(size_t)(i / ug) * ustride + i % ug] = src[i];
+}
+
 }  // namespace asep

@@ -34,11 +34,19 @@ class GnnGraph:
         self.path = path
         self._blob = None
         self._handles = {}
+        self._backbones = {}
 
     def blob(self) -> bytes:
+        """GNN + compression-layer tensors (the backbone goes into its own ARU-Net handle)."""
         if self._blob is None:
-            self._blob = pack_blob(self.tensors)
+            self._blob = pack_blob({k: v for k, v in self.tensors.items() if not k.startswith("aru_net/")})
         return self._blob
+
+    def backbone_graph(self):
+        """ARU-Net over the ``aru_net/...`` tensors of the same frozen graph (graph_relation.py:17-22)."""
+        from .net_post_processing_helper import AruGraph
+        return AruGraph({k: v for k, v in self.tensors.items() if k.startswith("aru_net/")}, self.cfg.backbone_cfg(),
+                        self.path)
 
     def handle(self, device_id: int = 0):
         if device_id not in self._handles:
@@ -46,15 +54,21 @@ class GnnGraph:
             c = self.cfg
             if len(c.interaction_hidden) != 1 or len(c.classifier_hidden) != 2:
                 raise _lib.AsepError("engine supports one interaction hidden layer and two classifier hidden layers")
-            if c.visual_dims:
-                raise _lib.AsepError("visual node features (image_input) are not supported by this build")
-            cfg = _lib.GnnCfg(c.node_feature_dim, c.edge_feature_dim, c.num_transition_steps, c.hidden_dim,
+            cfg = _lib.GnnCfg(c.u_dim, c.edge_feature_dim, c.num_transition_steps, c.hidden_dim,
                               c.interaction_dim, c.interaction_hidden[0], c.classifier_hidden[0],
                               c.classifier_hidden[1], c.num_classes, int(c.undirected_graph))
             blob = self.blob()
             h = lib.asep_gnn_load(blob, len(blob), C.byref(cfg))
             if not h:
                 raise _lib.AsepError("asep_gnn_load failed: " + _lib.last_error())
+            if c.visual_dims:
+                bb = self.backbone_graph()
+                names = (C.c_char_p * len(c.visual_layers))(*[n.encode() for n in c.visual_layers])
+                rc = lib.asep_gnn_attach_backbone(h, bb.handle(device_id), len(c.visual_layers), names)
+                if rc < 0:
+                    lib.asep_gnn_free(h)
+                    raise _lib.AsepError("asep_gnn_attach_backbone failed: " + _lib.last_error())
+                self._backbones[device_id] = bb          # keeps the ARU-Net handle alive
             self._handles[device_id] = h
         return self._handles[device_id]
 
@@ -64,6 +78,9 @@ class GnnGraph:
             for h in self._handles.values():
                 lib.asep_gnn_free(h)
             self._handles = {}
+            for bb in self._backbones.values():
+                bb.close()
+            self._backbones = {}
 
     def __del__(self):  # pragma: no cover
         try:
@@ -72,16 +89,18 @@ class GnnGraph:
             pass
 
 
-def load_graph(pb_path) -> GnnGraph:
+def load_graph(pb_path, visual_layers=None) -> GnnGraph:
     """gnn/io.py:12-25.  Accepts a TF1 frozen graph (``*.pb``, decoded without TensorFlow by ``pb_import.py``)
-    or the engine's ``*.asepw`` container (+ ``.json`` side-car)."""
+    or the engine's ``*.asepw`` container (+ ``.json`` side-car).  ``visual_layers`` names the backbone end points
+    of a graph exported with ``--image_input`` (``--feature_map_generation_params from_layer=[...]``); the names
+    are not recoverable from the constants alone, the default is ``scale_0_unet_up_<level>_conv`` per map."""
     if isinstance(pb_path, GnnGraph):
         return pb_path
     if not os.path.isfile(pb_path):
         raise IOError(f"No such model file: {pb_path}")
     if str(pb_path).endswith(".pb"):
         from . import pb_import
-        tensors, cfg = pb_import.gnn_from_nodes(pb_import.read_graph(pb_path))
+        tensors, cfg = pb_import.gnn_from_nodes(pb_import.read_graph(pb_path), visual_layers=visual_layers)
         return GnnGraph(tensors, cfg, pb_path)
     tensors, meta = load_weights(pb_path)
     cfg = GnnConfig(**(meta or {}).get("gnn_cfg", {}))
@@ -124,7 +143,12 @@ class GnnSession:
         N = int(num_nodes[0])
         E = int(np.asarray(feed["num_interacting_nodes:0"]).reshape(-1)[0])
         edges = np.ascontiguousarray(np.asarray(feed["interacting_nodes:0"], dtype=np.int32)[0][:E])
-        u = np.ascontiguousarray(np.asarray(feed["node_features:0"], dtype=np.float32)[0][:N])
+        if "node_features:0" in feed:
+            u = np.ascontiguousarray(np.asarray(feed["node_features:0"], dtype=np.float32)[0][:N])
+        elif cfg.visual_dims and cfg.node_feature_dim == 0:
+            u = np.zeros((N, 0), dtype=np.float32)
+        else:
+            raise KeyError("feed_dict lacks node_features:0")
         if u.shape[1] != cfg.node_feature_dim:
             raise ValueError(f"node_features has dim {u.shape[1]}, model expects {cfg.node_feature_dim}")
         ef = None
@@ -134,7 +158,22 @@ class GnnSession:
                 raise ValueError(f"edge_features has dim {ef.shape[1]}, model expects {cfg.edge_feature_dim}")
         rel = np.ascontiguousarray(
             np.asarray(feed["relations_to_consider_belong_to_same_instance:0"], dtype=np.int32)[0])
-        probs = gnn_forward(self.graph, N, edges, u, ef, rel, self.device)
+        if cfg.visual_dims:
+            for k in ("image:0", "visual_regions_nodes:0", "num_points_visual_regions_nodes:0"):
+                if k not in feed:
+                    raise KeyError(f"this graph was exported with image_input: feed_dict lacks {k}")
+            image = np.asarray(feed["image:0"], dtype=np.float32)
+            if image.shape[0] != 1:
+                raise ValueError("batch size must be 1 (input_dataset.py:134)")
+            image = image[0]
+            if "image_shape:0" in feed:                     # crop to the true shape (no padding at batch size 1)
+                ish = np.asarray(feed["image_shape:0"]).reshape(-1, 3)[0]
+                image = image[:int(ish[0]), :int(ish[1])]
+            regions = np.asarray(feed["visual_regions_nodes:0"], dtype=np.float32)[0][:N]
+            npts = np.asarray(feed["num_points_visual_regions_nodes:0"], dtype=np.int32)[0][:N]
+            probs = gnn_forward_visual(self.graph, N, edges, u, ef, image, regions, npts, rel, self.device)
+        else:
+            probs = gnn_forward(self.graph, N, edges, u, ef, rel, self.device)
         return probs[None]
 
 
@@ -155,6 +194,51 @@ def gnn_forward(graph: GnnGraph, num_nodes, edges, node_feat, edge_feat, relatio
     rc = lib.asep_gnn_forward(graph.handle(device), N, E, edges.ctypes.data if E else None, u.ctypes.data,
                               ef.ctypes.data if (ef is not None and E) else None, R, rel_p, out.ctypes.data)
     _lib.check(rc, "asep_gnn_forward")
+    return out
+
+
+def gnn_forward_visual(graph: GnnGraph, num_nodes, edges, node_feat, edge_feat, image, regions, num_points,
+                       relations=None, device=0):
+    """graph_relation.py:84-139 + GNN: image float32 [h,w(,1)] as fed (0..255), regions [N,2,P] relative
+    coordinates, num_points [N] -> probabilities [R, num_classes]."""
+    lib = _lib.init_device(device)
+    cfg = graph.cfg
+    N = int(num_nodes)
+    edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
+    E = edges.shape[0]
+    u = np.ascontiguousarray(node_feat, dtype=np.float32).reshape(N, cfg.node_feature_dim)
+    ef = np.ascontiguousarray(edge_feat, dtype=np.float32).reshape(E, -1) if edge_feat is not None else None
+    img = np.asarray(image, dtype=np.float32)
+    if img.ndim == 3:
+        if img.shape[2] != 1:
+            raise ValueError("the ARU_v1 backbone takes one image channel")
+        img = img[:, :, 0]
+    img = np.ascontiguousarray(img)
+    reg = np.ascontiguousarray(regions, dtype=np.float32)
+    if reg.ndim != 3 or reg.shape[0] != N or reg.shape[1] != 2:
+        raise ValueError(f"visual_regions_nodes must be [N, 2, P], got {reg.shape}")
+    npts = np.ascontiguousarray(num_points, dtype=np.int32).reshape(N)
+    if relations is None:
+        R, rel_p = N * N, None
+    else:
+        rel = np.ascontiguousarray(relations, dtype=np.int32).reshape(-1, 2)
+        R, rel_p = rel.shape[0], rel.ctypes.data
+    out = np.empty((R, cfg.num_classes), dtype=np.float32)
+    rc = lib.asep_gnn_forward_visual(graph.handle(device), N, E, edges.ctypes.data if E else None,
+                                     u.ctypes.data if u.size else None,
+                                     ef.ctypes.data if (ef is not None and E) else None, img.ctypes.data,
+                                     img.shape[0], img.shape[1], reg.ctypes.data, reg.shape[2], npts.ctypes.data, R,
+                                     rel_p, out.ctypes.data)
+    _lib.check(rc, "asep_gnn_forward_visual")
+    return out
+
+
+def gnn_node_features(graph: GnnGraph, num_nodes, device=0):
+    """Concatenated [geometric | visual] node features of the last visual forward (tests)."""
+    lib = _lib.init_device(device)
+    out = np.empty((int(num_nodes), graph.cfg.u_dim), dtype=np.float32)
+    _lib.check(lib.asep_gnn_get_node_features(graph.handle(device), out.ctypes.data, out.size),
+               "asep_gnn_get_node_features")
     return out
 
 

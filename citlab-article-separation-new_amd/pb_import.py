@@ -230,7 +230,7 @@ def aru_from_nodes(nodes, num_scales_att=None, apply_softmax=None):
     return tensors, cfg
 
 
-def gnn_from_nodes(nodes, undirected_graph=True):
+def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None):
     consts = const_tensors(nodes)
     pref = ("GraphLSTM1/message_fn_default/head_0/calculation_interaction_features/concat_u_and_h/"
             "interaction_features")
@@ -247,11 +247,37 @@ def gnn_from_nodes(nodes, undirected_graph=True):
         cls_hidden.append(int(_find(consts, f"Classification/logits/fully_connected_layer_h{i}/weights").shape[1]))
         i += 1
     wo = _find(consts, "Classification/logits/fully_connected_logit_layer_out/weights")
+    vis_kw = {}
     if any("visual_node_feature_compression" in k for k in consts):
-        raise IOError("this frozen GNN uses visual node features (image_input); not supported by this build")
+        # graph exported with --image_input (graph_relation.py:17-37): backbone + one compression layer per map
+        _, bcfg = aru_from_nodes(nodes)
+        dims, chans = [], []
+        i = 0
+        while _find(consts, f"visual_node_feature_compression_fm_{i}/dense/weights") is not None:
+            wv = _find(consts, f"visual_node_feature_compression_fm_{i}/dense/weights")
+            chans.append(int(wv.shape[0]))
+            dims.append(int(wv.shape[1]))
+            i += 1
+        if visual_layers is None:
+            # the from_layer names are not stored with the constants; assume the up-path block outputs of scale 0
+            visual_layers = []
+            for c in chans:
+                lvl = int(round(np.log2(c / bcfg.feat_root)))
+                visual_layers.append(f"scale_0_unet_up_{lvl}_conv")
+        if len(visual_layers) != len(dims):
+            raise IOError(f"{len(dims)} compression layers in the graph but {len(visual_layers)} visual_layers given")
+        mvn = any("per_image_standardization" in n.get("name", "") and "aru_net" not in n.get("name", "")
+                  for n in nodes)
+        backbone = {k: v for k, v in bcfg.to_dict().items() if k not in ("apply_softmax", "mvn")}
+        backbone["mvn"] = bool(bcfg.mvn)
+        vis_kw = dict(visual_dims=dims, visual_layers=list(visual_layers), mvn=mvn, backbone=backbone)
+        u_dim -= sum(dims)
     cfg = GnnConfig(node_feature_dim=u_dim, edge_feature_dim=e_dim, hidden_dim=hidden, interaction_dim=hidden,
                     interaction_hidden=[int(w1.shape[1])], classifier_hidden=cls_hidden,
-                    num_classes=int(wo.shape[1]), undirected_graph=undirected_graph)
+                    num_classes=int(wo.shape[1]), undirected_graph=undirected_graph, **vis_kw)
+    if vis_kw and cfg.visual_channels() != chans:
+        raise IOError(f"visual_layers {cfg.visual_layers} have {cfg.visual_channels()} channels, the compression "
+                      f"layers expect {chans}")
     tensors = OrderedDict()
     for name, shape in gnn_tensor_shapes(cfg).items():
         t = _find(consts, name)

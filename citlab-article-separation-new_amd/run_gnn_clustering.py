@@ -10,6 +10,8 @@ Pages are sharded over ``--num_workers`` processes, worker k on GPU ``gpu_device
 ``mp.Process`` per sub-list, ``:322-340``).  Worker errors are surfaced (the reference drops them).
 """
 import logging
+
+import numpy as np
 import multiprocessing as mp
 import os
 import sys
@@ -30,6 +32,9 @@ def build_parser():
     p.add_argument("--sample_num_relations_to_consider", type=int, default=100)
     p.add_argument("--sample_relations", type=cli_flags.str2bool, default=False)
     p.add_argument("--image_input", type=cli_flags.str2bool, default=False)
+    # extension: the backbone end points a graph exported with --image_input reads its visual node features from
+    # (the reference fixed them at training time with --feature_map_generation_params from_layer=[...])
+    p.add_argument("--visual_layers", type=str, nargs="*", default=None)
     p.add_argument("--assign_visual_features_to_nodes", type=cli_flags.str2bool, default=True)
     p.add_argument("--assign_visual_features_to_edges", type=cli_flags.str2bool, default=False)
     p.add_argument("--mvn", type=cli_flags.str2bool, default=True)
@@ -72,7 +77,9 @@ def gnn_clustering(json_paths, flags, device="0"):
     if flags.mask_heading_separated_confs or flags.mask_horizontally_separated_confs:
         raise NotImplementedError("confidence masking needs the separator feature rules of feature_generation.py "
                                   "(SURVEY row f4), not part of this build")
-    graph = gnn_io.load_graph(resolve_model_path(flags))
+    graph = gnn_io.load_graph(resolve_model_path(flags), visual_layers=flags.visual_layers or None)
+    if graph.cfg.visual_dims and not flags.image_input:
+        raise ValueError("this model was exported with image_input: pass --image_input True")
     input_fn = InputGNN(flags)
     tb = TextblockClustering(flags)
     sess = gnn_io.GnnSession(graph, device)
@@ -85,7 +92,13 @@ def gnn_clustering(json_paths, flags, device="0"):
         if not os.path.isfile(json_path):
             logging.warning(f"No json file found to given pageXML {page_path}. Skipping.")
             continue
-        feed = input_fn.feed_from_json(json_path)
+        image = None
+        if flags.image_input:
+            from PIL import Image
+            from .path_util import get_img_from_json_path
+            with Image.open(get_img_from_json_path(json_path)) as im:       # input_dataset.py:279-280
+                image = np.asarray(im.convert("L"), dtype=np.float32)
+        feed = input_fn.feed_from_json(json_path, image)
         output = sess.run("output_belong_to_same_instance:0", feed_dict=feed)
         n = feed["node_features:0"].shape[1] if "node_features:0" in feed else int(feed["num_nodes:0"][0])
         confidences = gnn_results.confidences_from_output(output, n)

@@ -71,9 +71,14 @@ GATES = ("ingate", "outgate", "forgetgate", "cellinput")
 
 def gnn_tensor_shapes(cfg: GnnConfig) -> "OrderedDict[str, tuple]":
     shapes = OrderedDict()
-    for i, d in enumerate(cfg.visual_dims):                         # misc.py:365-368
-        # the feature-map channel count is model specific; filled by the caller via `fm_channels`
-        pass
+    if cfg.visual_dims:
+        if len(cfg.visual_layers) != len(cfg.visual_dims):
+            raise ValueError("visual_layers and visual_dims must have the same length")
+        for name, shp in aru_tensor_shapes(cfg.backbone_cfg()).items():   # backbone variables live in the same graph
+            shapes[name] = shp
+        for i, (c, d) in enumerate(zip(cfg.visual_channels(), cfg.visual_dims)):      # misc.py:365-368
+            shapes[f"visual_node_feature_compression_fm_{i}/dense/weights"] = (c, d)
+            shapes[f"visual_node_feature_compression_fm_{i}/dense/bias"] = (d,)
     d_in = cfg.message_in_dim
     for i, h in enumerate(cfg.interaction_hidden, start=1):         # layers.py:477-480
         shapes[f"{_MSG}/fully_connected_layer_h{i}/weights"] = (d_in, h)

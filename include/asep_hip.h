@@ -140,6 +140,23 @@ int asep_gnn_get_hidden(asep_gnn* g, float* out, size_t max_floats);
 
 double asep_gnn_flops(const asep_gnn* g, int N, int E_corrected, int R);
 
+/* Visual node features (graph_relation.py:84-139 with image_input; misc.py:272-381): `backbone` is an ARU-Net
+ * handle loaded from the `aru_net/...` tensors of the same frozen graph (graph 'RU'/'ARU', mvn per the GNN's flag,
+ * apply_softmax 0); endpoint_names are the `feature_map_generation_params from_layer` entries (layer_depth -1),
+ * e.g. "scale_0_unet_up_2_conv".  The compression layers visual_node_feature_compression_fm_<i>/dense/{weights,bias} come from
+ * the GNN's own weight blob.  cfg.node_feature_dim counts geometric + compressed visual dims (e.g. 7 + 3*16). */
+int asep_gnn_attach_backbone(asep_gnn* g, asep_aru* backbone, int n_maps, const char* const* endpoint_names);
+
+/* run_gnn_clustering.py:259-269 with the image feeds: node_feat [N, node_feature_dim - visual dims],
+ * image float32 [h,w] (0..255 as fed, input_dataset.py:279-280), regions [N,2,P] relative coordinates (row 0 = x,
+ * row 1 = y), num_points [N].  Backbone -> ROI max -> compression -> concat -> GNN -> probabilities [R, classes]. */
+int asep_gnn_forward_visual(asep_gnn* g, int N, int E, const int32_t* edges, const float* node_feat,
+                            const float* edge_feat, const float* image, int h, int w, const float* regions, int P,
+                            const int32_t* num_points, int R, const int32_t* relations, float* probs_out);
+
+/* Concatenated node features [N, node_feature_dim] of the last asep_gnn_forward_visual (tests). */
+int asep_gnn_get_node_features(asep_gnn* g, float* out, size_t max_floats);
+
 /* ---- classical image stages around the ARU-Net ---------------------
  * The reference runs these on the host with OpenCV; here they are byte / bit kernels next to the nets so that a
  * page never leaves HBM between decode and polygon extraction.  Binary images: 0 = background, non-zero =

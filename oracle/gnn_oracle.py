@@ -112,3 +112,56 @@ def forward(num_nodes, edges, node_feat, edge_feat, relations, w, cfg, dtype=np.
     if return_hidden:
         return probs, h
     return probs
+
+
+def visual_node_features(image, regions, num_points, w, cfg, return_maps=False):
+    """graph_relation.py:84-127 + misc.py:249-381 at batch size 1 -> [N, sum(layer_compressed_dim)] float32.
+
+    image [h,w] float32 as fed (0..255) -> (normalize_image when cfg.mvn: per-image standardisation over the true
+    shape, misc.py:272-279; folded into the backbone config) -> ARU_v1 backbone end points -> per node the paraxial
+    rectangle of its region (relative coordinates, misc.py:486-508; no points -> zeros) -> floor-scaled ROI clamped
+    into the map, at least one cell (misc.py:322-341) -> per-channel max (misc.py:345-359) -> ff + ReLU
+    (misc.py:365-368)."""
+    from oracle import aru_oracle
+    bcfg = cfg.backbone_cfg()
+    wb = {k: v for k, v in w.items() if k.startswith("aru_net/")}
+    img = np.asarray(image, dtype=np.float32)
+    if img.ndim == 3:
+        img = img[:, :, 0]
+    _, inter = aru_oracle.forward_torch(img, wb, bcfg, return_intermediates=True)
+    regions = np.asarray(regions, dtype=np.float32)
+    N = regions.shape[0]
+    feats, maps = [], []
+    for i, name in enumerate(cfg.visual_layers):
+        fm = inter[name]                                   # [fh, fw, C]
+        fh, fw, _ = fm.shape
+        vmax = np.empty((N, fm.shape[2]), dtype=np.float32)
+        for n in range(N):
+            k = int(num_points[n])
+            if k == 0:
+                xmin = xmax = ymin = ymax = np.float32(0)
+            else:
+                xmin, xmax = regions[n, 0, :k].min(), regions[n, 0, :k].max()
+                ymin, ymax = regions[n, 1, :k].min(), regions[n, 1, :k].max()
+            x0 = max(min(int(np.floor(np.float32(xmin) * np.float32(fw))), fw - 1), 0)
+            x1 = max(min(int(np.floor(np.float32(xmax) * np.float32(fw))), fw - 1), 0)
+            y0 = max(min(int(np.floor(np.float32(ymin) * np.float32(fh))), fh - 1), 0)
+            y1 = max(min(int(np.floor(np.float32(ymax) * np.float32(fh))), fh - 1), 0)
+            nx, ny = max(x1 - x0 + 1, 1), max(y1 - y0 + 1, 1)
+            vmax[n] = fm[y0:y0 + ny, x0:x0 + nx].max(axis=(0, 1))
+        scope = f"visual_node_feature_compression_fm_{i}/dense"
+        feats.append(np.maximum(vmax @ w[scope + "/weights"].astype(np.float32)
+                                + w[scope + "/bias"].astype(np.float32), 0).astype(np.float32))
+        maps.append(vmax)
+    out = np.concatenate(feats, axis=1)
+    return (out, maps) if return_maps else out
+
+
+def forward_visual(num_nodes, edges, node_feat, edge_feat, image, regions, num_points, relations, w, cfg):
+    """== sess.run('output_belong_to_same_instance:0') of a graph exported with image_input, batch size 1."""
+    N = int(num_nodes)
+    vis = visual_node_features(image, regions, num_points, w, cfg)
+    geo = np.asarray(node_feat, dtype=np.float32).reshape(N, -1) if node_feat is not None else np.zeros((N, 0), np.float32)
+    u = np.concatenate([geo, vis], axis=1)
+    probs = forward(N, edges, u, edge_feat, relations, w, cfg)
+    return probs, u
