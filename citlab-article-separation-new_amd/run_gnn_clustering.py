@@ -10,12 +10,12 @@ Pages are sharded over ``--num_workers`` processes, worker k on GPU ``gpu_device
 ``mp.Process`` per sub-list, ``:322-340``).  Worker errors are surfaced (the reference drops them).
 """
 import logging
-
-import numpy as np
 import multiprocessing as mp
 import os
 import sys
 import time
+
+import numpy as np
 
 from . import cli_flags
 from .host_util import split_list
@@ -74,9 +74,6 @@ def gnn_clustering(json_paths, flags, device="0"):
     from . import gnn_io, gnn_results
     from .clustering import TextblockClustering
     from .gnn_input import InputGNN
-    if flags.mask_heading_separated_confs or flags.mask_horizontally_separated_confs:
-        raise NotImplementedError("confidence masking needs the separator feature rules of feature_generation.py "
-                                  "(SURVEY row f4), not part of this build")
     graph = gnn_io.load_graph(resolve_model_path(flags), visual_layers=flags.visual_layers or None)
     if graph.cfg.visual_dims and not flags.image_input:
         raise ValueError("this model was exported with image_input: pass --image_input True")
@@ -102,6 +99,11 @@ def gnn_clustering(json_paths, flags, device="0"):
         output = sess.run("output_belong_to_same_instance:0", feed_dict=feed)
         n = feed["node_features:0"].shape[1] if "node_features:0" in feed else int(feed["num_nodes:0"][0])
         confidences = gnn_results.confidences_from_output(output, n)
+        if flags.mask_heading_separated_confs or flags.mask_horizontally_separated_confs:      # :279-281
+            from .feature_generation import mask_horizontally_separated_confs
+            confidences = mask_horizontally_separated_confs(confidences, page_path,
+                                                            mask_heading=flags.mask_heading_separated_confs,
+                                                            mask_horizontal=flags.mask_horizontally_separated_confs)
         if flags.save_conf != "no_conf":
             gnn_results.save_conf_to_json(confidences, page_path, flags.out_dir)
             if flags.save_conf == "only_conf":
