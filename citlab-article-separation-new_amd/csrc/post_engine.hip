@@ -170,10 +170,10 @@ void cc_filter_dev(asep_post* p, hipStream_t st, const uint8_t* d_mask, int H, i
     const size_t n = (size_t)H * W;
     int32_t* L = (int32_t*)p->pool.get(n * sizeof(int32_t));
     int32_t* area = (int32_t*)p->pool.get(n * sizeof(int32_t));
-    cc_init_kernel<<<blocks_for(n), 256, 0, st>>>(d_mask, stride, ch, n, L);
+    cc_init_kernel<<<dim3(WW, cdiv(H, 4)), 256, 0, st>>>(d_mask, stride, ch, H, W, L);
     cc_union_kernel<<<blocks_for(n), 256, 0, st>>>(L, H, W);
     cc_flatten_kernel<<<blocks_for(n), 256, 0, st>>>(L, area, n);
-    cc_area_kernel<<<blocks_for(n), 256, 0, st>>>(L, area, n);
+    cc_area_kernel<<<dim3(WW, cdiv(H, 16)), 256, 0, st>>>(L, area, H, W);
     cc_filter_kernel<<<dim3(WW, cdiv(H, 4)), 256, 0, st>>>(L, area, H, W, min_size, bits, WW, d_out_u8);
 }
 
@@ -297,7 +297,7 @@ int swt_dev(asep_post* p, hipStream_t st, const uint8_t* d_gray, int H, int W, u
     int32_t* seg_last = (int32_t*)p->pool.get((size_t)nseg * W * sizeof(int32_t));
     uint16_t* g = (uint16_t*)p->pool.get(n * sizeof(uint16_t));
     ASEP_HIP_CHECK(hipMemsetAsync(hist, 0, 257 * sizeof(unsigned int), st));
-    swt_blur_hist_kernel<<<blocks_for(n), 256, 0, st>>>(d_gray, H, W, blur, hist);
+    swt_blur_hist_kernel<<<dim3(cdiv(W, 64), cdiv(H, 16)), 256, 0, st>>>(d_gray, H, W, blur, hist);
     swt_otsu_kernel<<<1, 64, 0, st>>>(hist, thr);
     swt_edt_seg_kernel<<<dim3(cdiv(W, 256), nseg), 256, 0, st>>>(blur, thr, H, W, seg_first, seg_last);
     swt_edt_cols_kernel<<<dim3(cdiv(W, 256), nseg), 256, 0, st>>>(blur, thr, H, W, nseg, seg_first, seg_last, g);
@@ -499,6 +499,62 @@ int asep_post_separator(asep_post* p, const uint8_t* mask, int H, int W, int pix
     ASEP_HIP_CHECK(hipMemcpyAsync(out_vertical, dv.p, n, hipMemcpyDeviceToHost, p->s));
     ASEP_HIP_CHECK(hipStreamSynchronize(p->s));
     return ASEP_OK;
+    POST_GUARD_END
+}
+
+long asep_post_boundary_segments_dev(asep_post* p, const uint8_t* d_mask, int H, int W, int value, int32_t* d_starts,
+                                     int32_t* d_ends, long capacity, void* stream) {
+    if (!p || !d_mask || capacity < 0 || (capacity > 0 && (!d_starts || !d_ends))) {
+        set_error("asep_post_boundary_segments_dev: bad arguments");
+        return ASEP_ERR_ARG;
+    }
+    if (int rc = check_image("asep_post_boundary_segments_dev", H, W)) return rc;
+    if ((size_t)(H + 1) * (W + 1) * 4 > 0x7fffffffull) {
+        set_error("asep_post_boundary_segments_dev: image too large for 32-bit vertex keys");
+        return ASEP_ERR_UNSUPPORTED;
+    }
+    POST_GUARD_BEGIN
+    hipStream_t st = (hipStream_t)stream;
+    p->pool.begin();
+    unsigned long long* counter = (unsigned long long*)p->pool.get(2 * sizeof(unsigned long long));
+    ASEP_HIP_CHECK(hipMemsetAsync(counter, 0, 2 * sizeof(unsigned long long), st));
+    post_boundary_segments_kernel<<<blocks_for((size_t)H * W), 256, 0, st>>>(d_mask, H, W, value, d_starts, d_ends,
+                                                                             (unsigned long long)capacity, counter);
+    ASEP_HIP_CHECK(hipGetLastError());
+    unsigned long long total[2] = {0, 0};
+    ASEP_HIP_CHECK(hipMemcpyAsync(total, counter, sizeof(total), hipMemcpyDeviceToHost, st));
+    ASEP_HIP_CHECK(hipStreamSynchronize(st));
+    if (total[0] != total[1]) {
+        set_error("boundary segments: %llu starts but %llu ends", total[0], total[1]);
+        return ASEP_ERR_HIP;
+    }
+    return (long)total[0];
+    POST_GUARD_END
+}
+
+long asep_post_boundary_segments(asep_post* p, const uint8_t* mask, int H, int W, int value, int32_t* out_starts,
+                                 int32_t* out_ends, long capacity) {
+    if (!p || !mask || capacity < 0 || (capacity > 0 && (!out_starts || !out_ends))) {
+        set_error("asep_post_boundary_segments: bad arguments");
+        return ASEP_ERR_ARG;
+    }
+    if (int rc = check_image("asep_post_boundary_segments", H, W)) return rc;
+    POST_GUARD_BEGIN
+    const size_t n = (size_t)H * W;
+    Staged din, ds, de;
+    if (int rc = din.alloc(n)) return rc;
+    if (int rc = ds.alloc((size_t)capacity * sizeof(int32_t))) return rc;
+    if (int rc = de.alloc((size_t)capacity * sizeof(int32_t))) return rc;
+    ASEP_HIP_CHECK(hipMemcpyAsync(din.p, mask, n, hipMemcpyHostToDevice, p->s));
+    const long total = asep_post_boundary_segments_dev(p, (const uint8_t*)din.p, H, W, value, (int32_t*)ds.p,
+                                                       (int32_t*)de.p, capacity, p->s);
+    if (total < 0) return total;
+    const long ncopy = total < capacity ? total : capacity;
+    if (ncopy > 0) {
+        ASEP_HIP_CHECK(hipMemcpy(out_starts, ds.p, (size_t)ncopy * sizeof(int32_t), hipMemcpyDeviceToHost));
+        ASEP_HIP_CHECK(hipMemcpy(out_ends, de.p, (size_t)ncopy * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    return total;
     POST_GUARD_END
 }
 

@@ -113,21 +113,41 @@ post_andnot_kernel(const uint64_t* __restrict__ a, const uint64_t* __restrict__ 
 }
 
 // --------------------------------------------------------------------------------------------------------------
-// 8-connected components: lock-free union-find on pixel indices (label = smallest index of the component)
+// 8-connected components: lock-free union-find on pixel indices (label = smallest index of the component).
+//   init     every pixel starts on the first pixel of its horizontal run inside a 64-pixel row segment (one ballot)
+//   union    only run contacts are linked: the segment's first pixel with its left neighbour, and per run of the
+//            row above the left-most pixel that touches it (8-neighbourhood) -- O(#runs) unions, not O(#pixels)
+//   find     path halving with atomicMin stores (labels only ever decrease, so concurrent writers cannot lose links)
+//   area     per 64x16 tile the runs are accumulated in an LDS hash (root -> pixels), one global atomic per
+//            (tile, component) instead of one per run
 // --------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-cc_init_kernel(const uint8_t* __restrict__ in, int stride, int ch, size_t n, int32_t* __restrict__ L) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) L[i] = in[i * stride + ch] != 0 ? (int32_t)i : -1;
+cc_init_kernel(const uint8_t* __restrict__ in, int stride, int ch, int H, int W, int32_t* __restrict__ L) {
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= H) return;
+    const int x = blockIdx.x * 64 + lane;
+    const bool fg = x < W && in[((size_t)y * W + x) * stride + ch] != 0;
+    const uint64_t m = __ballot(fg);
+    if (x >= W) return;
+    int32_t lab = -1;
+    if (fg) {
+        const uint64_t below = ~m & ((1ull << lane) - 1ull);     // background lanes to my left
+        const int start = below ? 64 - __clzll((long long)below) : 0;
+        lab = (int32_t)((size_t)y * W + blockIdx.x * 64 + start);
+    }
+    L[(size_t)y * W + x] = lab;
 }
 
-__device__ __forceinline__ int32_t cc_find(const int32_t* L, int32_t i) {
-    int32_t p = __atomic_load_n(&L[i], __ATOMIC_RELAXED);
-    while (p != i) {
-        i = p;
-        p = __atomic_load_n(&L[i], __ATOMIC_RELAXED);
+__device__ __forceinline__ int32_t cc_find(int32_t* L, int32_t i) {
+    for (;;) {
+        const int32_t p = __atomic_load_n(&L[i], __ATOMIC_RELAXED);
+        if (p == i) return i;
+        const int32_t gp = __atomic_load_n(&L[p], __ATOMIC_RELAXED);
+        if (gp == p) return p;
+        atomicMin(&L[i], gp);                                     // halve the path (monotone, race-free)
+        i = gp;
     }
-    return i;
 }
 
 __device__ __forceinline__ void cc_union(int32_t* L, int32_t a, int32_t b) {
@@ -142,7 +162,7 @@ __device__ __forceinline__ void cc_union(int32_t* L, int32_t a, int32_t b) {
         }
         const int32_t old = atomicMin(&L[b], a);                // b was a root when we looked
         if (old == b) return;
-        b = old;                                                  // somebody re-parented b meanwhile: retry
+        b = old;                                                  // somebody re-parented b meanwhile: link that too
     }
 }
 
@@ -150,17 +170,23 @@ __global__ void __launch_bounds__(256)
 cc_union_kernel(int32_t* L, int H, int W) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)H * W) return;
-    if (L[i] < 0) return;
+    if (__atomic_load_n(&L[i], __ATOMIC_RELAXED) < 0) return;
     const int y = (int)(i / W), x = (int)(i % W);
     const int32_t me = (int32_t)i;
-    if (x > 0 && L[i - 1] >= 0) cc_union(L, me, me - 1);
+    const bool left = x > 0 && __atomic_load_n(&L[i - 1], __ATOMIC_RELAXED) >= 0;
+    if (left && (x & 63) == 0) cc_union(L, me, me - 1);          // runs are pre-joined inside a 64-pixel segment
     if (y > 0) {
         const int32_t up = me - W;
-        if (L[up] >= 0) {
-            cc_union(L, me, up);
+        const bool n = __atomic_load_n(&L[up], __ATOMIC_RELAXED) >= 0;
+        const bool ne = x + 1 < W && __atomic_load_n(&L[up + 1], __ATOMIC_RELAXED) >= 0;
+        if (left) {
+            // my left neighbour already sees the upper pixels x-1 and x; only a run starting at x+1 is new
+            if (!n && ne) cc_union(L, me, up + 1);
+        } else if (n) {
+            cc_union(L, me, up);                                  // nw / ne belong to the same upper run
         } else {
-            if (x > 0 && L[up - 1] >= 0) cc_union(L, me, up - 1);
-            if (x + 1 < W && L[up + 1] >= 0) cc_union(L, me, up + 1);
+            if (x > 0 && __atomic_load_n(&L[up - 1], __ATOMIC_RELAXED) >= 0) cc_union(L, me, up - 1);
+            if (ne) cc_union(L, me, up + 1);
         }
     }
 }
@@ -170,26 +196,49 @@ __global__ void __launch_bounds__(256)
 cc_flatten_kernel(int32_t* L, int32_t* __restrict__ area, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    if (L[i] < 0) return;
+    if (__atomic_load_n(&L[i], __ATOMIC_RELAXED) < 0) return;
     const int32_t r = cc_find(L, (int32_t)i);
     L[i] = r;
     if (r == (int32_t)i) area[i] = 0;
 }
 
+// grid (WW, ceil(H/16)), block 256: wave w handles rows 4w..4w+3 of a 64 x 16 tile
+#define CC_HASH 128
 __global__ void __launch_bounds__(256)
-cc_area_kernel(const int32_t* __restrict__ L, int32_t* __restrict__ area, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int32_t r = i < n ? L[i] : -1;
-    // consecutive pixels of a run share the root: one atomic per run segment inside the wave
-    const int lane = threadIdx.x & 63;
-    const int32_t prev = __shfl_up(r, 1);
-    const bool brk = lane == 0 || prev != r;
-    const uint64_t brks = __ballot(brk);
-    if (brk && r >= 0) {
-        const uint64_t above = lane == 63 ? 0ull : (brks >> (lane + 1));
-        const int len = above ? __ffsll((long long)above) : 64 - lane;
-        atomicAdd(&area[r], len);
+cc_area_kernel(const int32_t* __restrict__ L, int32_t* __restrict__ area, int H, int W) {
+    __shared__ int32_t keys[CC_HASH];
+    __shared__ int32_t vals[CC_HASH];
+    if (threadIdx.x < CC_HASH) {
+        keys[threadIdx.x] = -1;
+        vals[threadIdx.x] = 0;
     }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    for (int k = 0; k < 4; ++k) {
+        const int y = blockIdx.y * 16 + wave * 4 + k;
+        const int32_t r = (y < H && x < W) ? L[(size_t)y * W + x] : -1;
+        const int32_t prev = __shfl_up(r, 1);
+        const bool brk = lane == 0 || prev != r;
+        const uint64_t brks = __ballot(brk);
+        if (brk && r >= 0) {
+            const uint64_t above = lane == 63 ? 0ull : (brks >> (lane + 1));
+            const int len = above ? __ffsll((long long)above) : 64 - lane;
+            unsigned slot = ((unsigned)r * 2654435761u) >> 25;   // 7 bits
+            bool done = false;
+            for (int probe = 0; probe < CC_HASH && !done; ++probe) {
+                const int32_t old = atomicCAS(&keys[slot], -1, r);
+                if (old == -1 || old == r) {
+                    atomicAdd(&vals[slot], len);
+                    done = true;
+                }
+                slot = (slot + 1) & (CC_HASH - 1);
+            }
+            if (!done) atomicAdd(&area[r], len);                  // table full (very noisy tile)
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < CC_HASH && keys[threadIdx.x] >= 0) atomicAdd(&area[keys[threadIdx.x]], vals[threadIdx.x]);
 }
 
 // grid (WW, ceil(H/4)): keep pixels of components with area >= min_size; emit the bit plane (and optional u8).
@@ -320,31 +369,39 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 }
 
 // inverted input, taps [1,4,6,4,1]^2, (sum + 128) >> 8; also accumulates the 256-bin histogram of the result.
+// grid (ceil(W/64), ceil(H/16)), block 256: 64 x 16 output tile, (64+4) x (16+4) inverted input tile in LDS,
+// horizontal pass into LDS, vertical pass from LDS.
 __global__ void __launch_bounds__(256)
 swt_blur_hist_kernel(const uint8_t* __restrict__ gray, int H, int W, uint8_t* __restrict__ blur,
                      unsigned int* __restrict__ hist) {
     __shared__ unsigned int lh[256];
-    lh[threadIdx.x] = 0;
-    __syncthreads();
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < (size_t)H * W) {
-        const int y = (int)(i / W), x = (int)(i % W);
-        const int taps[5] = {1, 4, 6, 4, 1};
-        int acc = 0;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const uint8_t* row = gray + (size_t)reflect101(y + j - 2, H) * W;
-            int h = 0;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) h += taps[k] * (255 - (int)row[reflect101(x + k - 2, W)]);
-            acc += taps[j] * h;
-        }
-        const int v = (acc + 128) >> 8;
-        blur[i] = (uint8_t)v;
-        atomicAdd(&lh[v], 1u);
+    __shared__ uint8_t tin[20][72];
+    __shared__ uint16_t th[20][64];
+    const int tid = threadIdx.x;
+    lh[tid] = 0;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+    for (int i = tid; i < 20 * 68; i += 256) {
+        const int r = i / 68, c = i % 68;
+        tin[r][c] = (uint8_t)(255 - gray[(size_t)reflect101(y0 + r - 2, H) * W + reflect101(x0 + c - 2, W)]);
     }
     __syncthreads();
-    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+    for (int i = tid; i < 20 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        th[r][c] = (uint16_t)(tin[r][c] + 4 * tin[r][c + 1] + 6 * tin[r][c + 2] + 4 * tin[r][c + 3] + tin[r][c + 4]);
+    }
+    __syncthreads();
+    for (int i = tid; i < 16 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const int y = y0 + r, x = x0 + c;
+        if (y < H && x < W) {
+            const int acc = th[r][c] + 4 * th[r + 1][c] + 6 * th[r + 2][c] + 4 * th[r + 3][c] + th[r + 4][c];
+            const int v = (acc + 128) >> 8;
+            blur[(size_t)y * W + x] = (uint8_t)v;
+            atomicAdd(&lh[v], 1u);
+        }
+    }
+    __syncthreads();
+    if (lh[tid]) atomicAdd(&hist[tid], lh[tid]);
 }
 
 // getThreshVal_Otsu_8u in double, one thread; no fused multiply-adds so the host restatement matches bit for bit.
@@ -472,6 +529,72 @@ swt_edt_rows_kernel(const uint16_t* __restrict__ g, int H, int W, uint8_t* __res
     if (d2_out) d2_out[i] = b32;
     const float d = __fsqrt_rn((float)b32);
     out[i] = (uint8_t)(((int)d) & 255);
+}
+
+
+// --------------------------------------------------------------------------------------------------------------
+// a10 (device half): boundary of the pixels equal to `value` as maximal straight segments.  A unit edge is the side
+// of a foreground pixel that faces background (or the image border), directed so that the foreground lies to its
+// right: heading 0 (+x) top side, 1 (+y) right side, 2 (-x) bottom side, 3 (-y) left side.  Collinear unit edges of
+// one heading form a segment; only its first and last unit edge are emitted:
+//   starts[] = ((vy * (W + 1) + vx) * 4 + heading) of the segment's start vertex
+//   ends[]   = the same encoding of its end vertex
+// in arbitrary order (the host sorts both per heading; segments of one heading on one grid line are disjoint, so
+// the k-th start pairs with the k-th end).  counter[0] / counter[1] count starts / ends even beyond `capacity`.
+// --------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void post_wave_append(int n, unsigned long long* counter, unsigned long long& first) {
+    const int lane = threadIdx.x & 63;
+    int incl = n;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    const int total = __shfl(incl, 63);
+    unsigned long long base = 0;
+    if (lane == 63 && total > 0) base = atomicAdd(counter, (unsigned long long)total);
+    base = __shfl(base, 63);
+    first = base + (unsigned long long)(incl - n);
+}
+
+__global__ void __launch_bounds__(256)
+post_boundary_segments_kernel(const uint8_t* __restrict__ mask, int H, int W, int value, int32_t* __restrict__ starts,
+                              int32_t* __restrict__ ends, unsigned long long capacity,
+                              unsigned long long* __restrict__ counter) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int sk[4], ek[4];
+    int ns = 0, ne = 0;
+    if (i < (size_t)H * W && mask[i] == value) {
+        const int y = (int)(i / W), x = (int)(i % W);
+        auto fg = [&](int yy, int xx) -> bool {
+            return yy >= 0 && yy < H && xx >= 0 && xx < W && mask[(size_t)yy * W + xx] == value;
+        };
+        const bool n = fg(y - 1, x), s = fg(y + 1, x), w = fg(y, x - 1), e = fg(y, x + 1);
+        const bool nw = fg(y - 1, x - 1), nev = fg(y - 1, x + 1), sw = fg(y + 1, x - 1), se = fg(y + 1, x + 1);
+        const int VW = W + 1;
+        if (!n) {                                                 // top side, +x: (x, y) -> (x+1, y)
+            if (!(w && !nw)) sk[ns++] = (y * VW + x) * 4 + 0;
+            if (!(e && !nev)) ek[ne++] = (y * VW + x + 1) * 4 + 0;
+        }
+        if (!e) {                                                 // right side, +y: (x+1, y) -> (x+1, y+1)
+            if (!(n && !nev)) sk[ns++] = (y * VW + x + 1) * 4 + 1;
+            if (!(s && !se)) ek[ne++] = ((y + 1) * VW + x + 1) * 4 + 1;
+        }
+        if (!s) {                                                 // bottom side, -x: (x+1, y+1) -> (x, y+1)
+            if (!(e && !se)) sk[ns++] = ((y + 1) * VW + x + 1) * 4 + 2;
+            if (!(w && !sw)) ek[ne++] = ((y + 1) * VW + x) * 4 + 2;
+        }
+        if (!w) {                                                 // left side, -y: (x, y+1) -> (x, y)
+            if (!(s && !sw)) sk[ns++] = ((y + 1) * VW + x) * 4 + 3;
+            if (!(n && !nw)) ek[ne++] = (y * VW + x) * 4 + 3;
+        }
+    }
+    unsigned long long o;
+    post_wave_append(ns, counter, o);
+    for (int k = 0; k < ns; ++k, ++o)
+        if (o < capacity) starts[o] = sk[k];
+    post_wave_append(ne, counter + 1, o);
+    for (int k = 0; k < ne; ++k, ++o)
+        if (o < capacity) ends[o] = ek[k];
 }
 
 }  // namespace asep

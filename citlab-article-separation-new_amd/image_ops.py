@@ -114,6 +114,41 @@ def separator_post_process(net_output, device=0):
     return {"horizontal": hz, "vertical": vt}
 
 
+def boundary_segments(mask, value=255, device=0):
+    """Maximal straight boundary segments of the pixels equal to ``value`` (device half of
+    ``rasterio.features.shapes``, base:186-197) -> (starts, ends) int32 key arrays for
+    ``polygonize.shapes_from_segments``."""
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    H, W = m.shape
+    lib, ws = _workspace(device)
+    cap = 1 << 14
+    while True:
+        st = np.empty(cap, dtype=np.int32)
+        en = np.empty(cap, dtype=np.int32)
+        n = _lib.check(lib.asep_post_boundary_segments(ws, m.ctypes.data, H, W, int(value), st.ctypes.data,
+                                                       en.ctypes.data, cap), "asep_post_boundary_segments")
+        if n <= cap:
+            return st[:n], en[:n]
+        cap = int(n)
+
+
+def boundary_segments_dev(d_mask_ptr, H, W, value=255, device=0, stream=None, capacity=None):
+    """Same on a device-resident uint8 mask; only the segment end points cross PCIe."""
+    import torch
+    lib, ws = _workspace(device)
+    cap = int(capacity or (1 << 14))
+    tdev = torch.device("cuda", device)
+    while True:
+        d_keys = torch.empty((2, cap), dtype=torch.int32, device=tdev)
+        n = _lib.check(lib.asep_post_boundary_segments_dev(ws, d_mask_ptr, H, W, int(value), d_keys[0].data_ptr(),
+                                                           d_keys[1].data_ptr(), cap, stream),
+                       "asep_post_boundary_segments_dev")
+        if n <= cap:
+            host = d_keys[:, :n].cpu().numpy()
+            return host[0], host[1]
+        cap = int(n)
+
+
 def swt_distance_transform(gray, device=0, return_details=False):
     """swt_dist_trafo.py:18-29 on an already decoded uint8 gray image."""
     g = np.ascontiguousarray(gray, dtype=np.uint8)

@@ -54,6 +54,110 @@ def shapes(mask, value=255, connectivity=8):
         return []
     p, ys, xs = _foreground(fg)
     vx, vy, hd, owner = _boundary_edges(p, ys, xs)
+    return _rings_from_edges(vx, vy, hd, ys[owner], xs[owner], W, connectivity)
+
+
+def shapes_from_segments(starts, ends, H, W, connectivity=8):
+    """Same result as :func:`shapes` from the maximal straight boundary segments extracted on the GPU
+    (``asep_post_boundary_segments``: keys ((vy*(W+1)+vx)*4 + heading) of the start and end vertices, any order).
+    The work here is proportional to the number of polygon corners, not to the image or boundary size."""
+    if connectivity not in (4, 8):
+        raise ValueError("connectivity must be 4 or 8")
+    starts = np.asarray(starts, dtype=np.int64)
+    ends = np.asarray(ends, dtype=np.int64)
+    if starts.size != ends.size:
+        raise ValueError("starts and ends must have the same length")
+    if starts.size == 0:
+        return []
+    VW = W + 1
+    parts = []
+    for h in range(4):
+        s = starts[(starts & 3) == h] >> 2
+        e = ends[(ends & 3) == h] >> 2
+        if s.size != e.size:
+            raise ValueError("unbalanced boundary segments")
+        sy, sx, ey, ex = s // VW, s % VW, e // VW, e % VW
+        # segments of one heading on one grid line are disjoint: order both ends along the line and pair them
+        so = np.lexsort((sx, sy)) if h in (0, 2) else np.lexsort((sy, sx))
+        eo = np.lexsort((ex, ey)) if h in (0, 2) else np.lexsort((ey, ex))
+        parts.append((sx[so], sy[so], ex[eo], ey[eo], np.full(s.size, h, dtype=np.int64)))
+    svx, svy, evx, evy, hd = (np.concatenate([p[i] for p in parts]) for i in range(5))
+    ns = svx.size
+    skey = (svy * VW + svx) * 4 + hd
+    order = np.argsort(skey, kind="stable")
+    sorted_keys = skey[order]
+    end_v = evy * VW + evx
+
+    def lookup(heading):
+        k = end_v * 4 + heading
+        pos = np.minimum(np.searchsorted(sorted_keys, k), ns - 1)
+        return np.where(sorted_keys[pos] == k, order[pos], -1)
+
+    # every segment end is a corner: the ring turns left (8-connectivity keeps diagonal pixels together) or right
+    first, second = ((hd + 3) % 4, (hd + 1) % 4) if connectivity == 8 else ((hd + 1) % 4, (hd + 3) % 4)
+    nxt = lookup(first)
+    nxt = np.where(nxt < 0, lookup(second), nxt)
+    if (nxt < 0).any():                                    # pragma: no cover - would be a logic error
+        raise RuntimeError("open boundary chain")
+    cidx = np.argsort(skey[nxt], kind="stable")            # rings start at their top-left-most vertex
+    nxt_l = nxt.tolist()
+    ex_l, ey_l = evx.tolist(), evy.tolist()
+    visited = bytearray(ns)
+    ring_of = np.full(ns, -1, dtype=np.int64)
+    rings, ring_area, ring_first = [], [], []
+    for c0 in cidx.tolist():
+        if visited[c0]:
+            continue
+        members = []
+        pts = []
+        c = c0
+        while not visited[c]:
+            visited[c] = 1
+            members.append(c)
+            pts.append((float(ex_l[c]), float(ey_l[c])))
+            c = nxt_l[c]
+        pts.append(pts[0])
+        area2 = 0.0
+        for (x0, y0), (x1, y1) in zip(pts[:-1], pts[1:]):
+            area2 += x0 * y1 - x1 * y0
+        ring_of[members] = len(rings)
+        rings.append(pts)
+        ring_area.append(area2)
+        ring_first.append(c0)
+    # holes: the foreground pixel that owns the last unit edge of the ring's first segment; walk left along its row
+    # to the nearest left-facing (heading 3) boundary segment -- its ring is the exterior or a hole that starts higher
+    left = np.flatnonzero(hd == 3)
+    lx, ltop, lbot = svx[left], evy[left], svy[left]       # covers pixel rows ltop <= row < lbot, pixel column lx
+    parent = {}
+
+    def exterior_of(r):
+        chain = []
+        while ring_area[r] < 0:
+            if r in parent:
+                r = parent[r]
+                continue
+            chain.append(r)
+            c = ring_first[r]
+            h = int(hd[c])
+            ux, uy = int(evx[c]) - int(_DX[h]), int(evy[c]) - int(_DY[h])      # start of the last unit edge
+            oy, ox = uy - (1 if h >= 2 else 0), ux - (1 if h in (1, 2) else 0)
+            cand = np.flatnonzero((ltop <= oy) & (oy < lbot) & (lx <= ox))
+            r = int(ring_of[left[cand[np.argmax(lx[cand])]]])
+        for hole in chain:
+            parent[hole] = r
+        return r
+
+    polys = {}
+    for r, pts in enumerate(rings):
+        if ring_area[r] > 0:
+            polys[r] = [pts]
+    for r, pts in enumerate(rings):
+        if ring_area[r] < 0:
+            polys[exterior_of(r)].append(pts)
+    return [polys[r] for r in sorted(polys)]
+
+
+def _rings_from_edges(vx, vy, hd, oy, ox, W, connectivity):
     ne = vx.shape[0]
     VW = W + 1
     start_key = (vy * VW + vx) * 4 + hd
@@ -120,7 +224,6 @@ def shapes(mask, value=255, connectivity=8):
     # pixel lies strictly higher (so the walk terminates).
     ring_all = np.where(corner, ring_of, ring_of[jump])
     left = np.flatnonzero(hd == 3)
-    oy, ox = ys[owner], xs[owner]
     left_keys = oy[left] * W + ox[left]
     lorder = np.argsort(left_keys, kind="stable")
     left_sorted = left_keys[lorder]

@@ -83,7 +83,7 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
         return writer.page_object
 
     # -- the fused device path ---------------------------------------------------------------------------------
-    def separator_masks(self, image):
+    def separator_masks(self, image, edges_only=False):
         """decoded image (uint8 [H,W,3] BGR or [H,W]) -> ({"horizontal", "vertical"} uint8 [h,w], sc, extras).
 
         Same arithmetic as load_and_scale_image -> get_net_output -> uint8(x*255) -> apply_threshold -> post_process
@@ -120,8 +120,14 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
             d_vt = torch.empty((h, w), dtype=torch.uint8, device=tdev)
             _lib.check(lib.asep_post_separator_dev(ws, d_mask.data_ptr(), h, w, ncls, 0, min_size, k_h, k_v, k_c,
                                                    d_hz.data_ptr(), d_vt.data_ptr(), sp), "asep_post_separator_dev")
-            masks = {"horizontal": d_hz.cpu().numpy(), "vertical": d_vt.cpu().numpy()}
+            if edges_only:
+                # polygon extraction needs only the boundary segments: the masks stay in HBM
+                masks = {"horizontal": image_ops.boundary_segments_dev(d_hz.data_ptr(), h, w, 255, dev, sp),
+                         "vertical": image_ops.boundary_segments_dev(d_vt.data_ptr(), h, w, 255, dev, sp)}
+            else:
+                masks = {"horizontal": d_hz.cpu().numpy(), "vertical": d_vt.cpu().numpy()}
             extras = {"net_output_u8": d_u8.cpu().numpy()} if self.keep_outputs else {}
+            extras["size"] = (h, w)
         return masks, sc, extras
 
     def run(self):
@@ -129,13 +135,18 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
         page_objects = []
         for image_path in self.image_paths:
             image = load_image_bgr(image_path)
-            masks, sc, extras = self.separator_masks(image)
+            masks, sc, extras = self.separator_masks(image, edges_only=not self.keep_outputs)
+            polygons_dict = {}
             if self.keep_outputs:
                 self.net_outputs.append(extras["net_output_u8"])
                 self.net_outputs_post.append(masks)
-            polygons_dict = {}
-            for separator_type, net_output_post in masks.items():
-                polygons_dict.update(self.to_polygons(net_output_post, separator_type))
+                for separator_type, net_output_post in masks.items():
+                    polygons_dict.update(self.to_polygons(net_output_post, separator_type))
+            else:
+                h, w = extras["size"]
+                for separator_type, (starts, ends) in masks.items():
+                    polygons_dict[SEPARATOR_REGION + "_" + separator_type] = \
+                        polygonize.shapes_from_segments(starts, ends, h, w, connectivity=8)
             polygons_dict = self.rescale_polygons(polygons_dict, scaling_factor=1 / sc)
             page_objects.append(self.to_page_xml(get_page_path(image_path), image_path=image_path,
                                                  polygons_dict=polygons_dict))

@@ -195,6 +195,18 @@ int asep_post_separator_dev(asep_post* p, const uint8_t* d_mask, int H, int W, i
                             int min_size, int k_h, int k_v, int k_clean, uint8_t* d_out_horizontal,
                             uint8_t* d_out_vertical, void* stream);
 
+/* Device half of region_net_post_processor_base.py:186-197 (rasterio.features.shapes): the boundary of the pixels
+ * equal to `value` as maximal straight segments, each directed with the foreground on its right (heading 0 = +x top
+ * sides, 1 = +y right sides, 2 = -x bottom sides, 3 = -y left sides).  out_starts / out_ends receive the keys
+ * ((vy*(W+1)+vx)*4 + heading) of the start / end vertices in arbitrary order; segments of one heading on one grid
+ * line are disjoint, so after sorting both arrays per heading the k-th start pairs with the k-th end.  Returns the
+ * number of segments (may exceed `capacity`: call again with larger buffers) or a negative error.  The host chains
+ * the segments into exterior / interior rings (polygonize.py). */
+long asep_post_boundary_segments(asep_post* p, const uint8_t* mask, int H, int W, int value, int32_t* out_starts,
+                                 int32_t* out_ends, long capacity);
+long asep_post_boundary_segments_dev(asep_post* p, const uint8_t* d_mask, int H, int W, int value, int32_t* d_starts,
+                                     int32_t* d_ends, long capacity, void* stream);
+
 /* swt_dist_trafo.py:18-29 distance_transform without the file decode: gray uint8 [H,W] -> 255-gray ->
  * GaussianBlur 5x5 -> Otsu -> exact Euclidean distance to the nearest zero pixel -> astype(uint8).
  * out_otsu (optional) receives the Otsu threshold; out_d2 (optional) the exact squared distances (int32). */

@@ -181,3 +181,31 @@ def test_swt_degenerate_images():
     g = np.full((50, 50), 255, np.uint8)
     g[:, :25] = 0                                            # left half dark: distances grow to 25
     assert np.array_equal(image_ops.swt_distance_transform(g), co.swt_distance_transform(g))
+
+
+@pytest.mark.parametrize("H,W,density", [(1, 1, 1.0), (37, 130, 0.3), (64, 64, 0.6), (200, 333, 0.9), (90, 70, 0.5)])
+def test_boundary_segments_give_the_same_polygons(H, W, density):
+    from citlab_article_separation_new_amd import image_ops, polygonize
+    rng = np.random.default_rng(H * 7 + W)
+    m = ((rng.random((H, W)) < density) * 255).astype(np.uint8)
+    m[rng.random((H, W)) < 0.05] = 77                       # other values are background for value == 255
+    if H == 90:
+        m[10:60, 5:60] = 255                                # a big blob with holes and islands inside
+        m[20:50, 15:50][rng.random((30, 35)) < 0.3] = 0
+    starts, ends = image_ops.boundary_segments(m, 255)
+    assert starts.dtype == np.int32 and starts.size == ends.size
+    assert polygonize.shapes_from_segments(starts, ends, H, W) == polygonize.shapes(m)
+    assert polygonize.shapes_from_segments(starts, ends, H, W, connectivity=4) == polygonize.shapes(m, connectivity=4)
+
+
+def test_boundary_segments_page_sized_and_capacity_retry():
+    from citlab_article_separation_new_amd import image_ops, polygonize
+    rng = np.random.default_rng(3)
+    m = _separator_mask(rng, 1500, 1000, noise=0.01)         # ~60k one-pixel specks: exceeds the first capacity guess
+    starts, ends = image_ops.boundary_segments(m, 255)
+    assert starts.size > (1 << 14)
+    polys = polygonize.shapes_from_segments(starts, ends, 1500, 1000)
+    assert np.array_equal(polygonize.rasterize(polys, 1500, 1000), m)
+    assert polys == polygonize.shapes(m)
+    s0, e0 = image_ops.boundary_segments(np.zeros((50, 60), np.uint8))
+    assert s0.size == 0 and polygonize.shapes_from_segments(s0, e0, 50, 60) == []
