@@ -29,6 +29,7 @@ import torch  # noqa: E402
 
 METRIC = "newspaper pages/sec (ARU-Net seg + GNN relation) at 3000x4500 px"
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # same guide: dense bf16 matrix peak (not the 2:1-sparsity headline)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -41,6 +42,9 @@ def parse_args():
     ap.add_argument("--height", type=int, default=4500)
     ap.add_argument("--width", type=int, default=3000)
     ap.add_argument("--no-gnn", action="store_true", help="ARU-Net only (diagnostic; not the headline metric)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = BASELINE configs[1] (the headline); bf16 = configs[4] 'bf16 convs': bf16 MFMA operands, "
+                         "fp32 accumulation / storage, probability maps within 2e-2 (reported with dtype bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event per-kernel timing")
     ap.add_argument("--cpu-sample-height", type=int, default=0, help="rows of page 0 for the CPU baseline (0 = full page)")
@@ -110,7 +114,7 @@ def main():
     from citlab_article_separation_new_amd.gnn_io import GnnGraph
 
     H, W, B = args.height, args.width, args.pages_per_step
-    aru_cfg, gnn_cfg = AruConfig(), GnnConfig()
+    aru_cfg, gnn_cfg = AruConfig(compute_dtype=args.dtype), GnnConfig()
 
     # ---- weights: rank 0 creates them, every other rank receives the blob over RCCL (the only collective) ----
     if rank == 0:
@@ -194,10 +198,11 @@ def main():
             k["tflops"] = k["flops"] / (k["total_ms"] * 1e-3) / 1e12 if k["total_ms"] > 0 else 0.0
         kernels.sort(key=lambda k: -k["total_ms"])
         dom = kernels[0]
+        peak_tf = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         roofline = {
             "bound": "mfma", "kernel": dom["kernel"],
-            "achieved": round(dom["tflops"], 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
+            "achieved": round(dom["tflops"], 3), "peak": peak_tf, "unit": "TFLOP/s",
+            "frac": round(dom["tflops"] / peak_tf, 4),
             "avg_launch_us": round(dom["avg_us"], 2), "flops_per_launch": dom["flops"] / dom["calls"],
             "share_of_gpu_time": round(dom["total_ms"] / sum(k["total_ms"] for k in kernels), 4),
             "traffic": None,
@@ -216,10 +221,13 @@ def main():
         line = {
             "metric": METRIC, "value": round(value, 4), "unit": "pages/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {
-                "workload": ("BASELINE configs[1]: ARU-Net separator detection on 3000x4500 px pages, fp32, "
-                             "+ configs[3]-shaped GNN relation graph per page (200 nodes / 20k edges / 40k pairs)"
+                "workload": (("BASELINE configs[1]: ARU-Net separator detection on 3000x4500 px pages, fp32, "
+                              if args.dtype == "f32" else
+                              "BASELINE configs[4] precision (bf16 MFMA convs, fp32 accumulate/storage): ARU-Net separator "
+                              "detection on 3000x4500 px pages, ")
+                             + "+ configs[3]-shaped GNN relation graph per page (200 nodes / 20k edges / 40k pairs)"
                              if not args.no_gnn else "ARU-Net only (diagnostic)"),
                 "height": H, "width": W, "pages_per_step_per_gpu": B, "sharding": f"pages over {world} rank(s)",
                 "aru_cfg": "ARU featRoot=8 levels=5 res_depth=3 att_scales=3 n_classes=2",

@@ -23,6 +23,9 @@ class AruConfig:
     pool_size: int = 2
     mvn: bool = False
     apply_softmax: bool = True    # export-time class softmax -> 'output:0'
+    # 'f32' (v_mfma_f32_16x16x4_f32, the reference's precision) or 'bf16' (BASELINE config 5: bf16 MFMA operands,
+    # fp32 accumulation, fp32 activations in HBM); an engine option, not a property of the weights
+    compute_dtype: str = "f32"
 
     @property
     def use_attention(self) -> bool:

@@ -92,6 +92,7 @@ struct asep_aru {
     int persist_mt1 = 3, persist_mt2 = 2;   // resident blocks per CU assumed by the persistent conv grids
     int wino_blocks = 512;         // resident Winograd blocks (256 CUs x 2); ASEP_WINO_BLOCKS overrides
     bool big_tile = true;          // ASEP_BIGTILE=0 disables the 16x32 single-buffer variant
+    bool bf16 = false;             // cfg.compute_dtype == 1: bf16 MFMA operands, fp32 accumulation and storage
     bool use_winograd = true;      // ASEP_WINOGRAD=0 selects the direct implicit-GEMM kernels everywhere
     bool profiling = false;
     bool prof_detail = false;      // per-layer names (scope + spatial size) instead of per-kernel names
@@ -282,6 +283,14 @@ void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, int tot
     if (m->prof_detail) pname += " " + scope + " " + dims_of(in0) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
     ProfScope ps(m, pname, flops);
     hipStream_t s = m->stream;
+    if (m->bf16) {
+        if (pc.c8) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, true, CONV_TH, true, true>), grid, dim3(256), 0, s, a);
+        else if (mt == 1 && big_tile) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false, 16, false, true>), grid, dim3(256), 0, s, a);
+        else if (mt == 4) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 4, false, CONV_TH, true, true>), grid, dim3(256), 0, s, a);
+        else if (mt == 2) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 2, false, CONV_TH, true, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false, CONV_TH, true, true>), grid, dim3(256), 0, s, a);
+        return;
+    }
     if (pc.c8) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, true>), grid, dim3(256), 0, s, a);
     else if (mt == 1 && big_tile) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false, 16, false>), grid, dim3(256), 0, s, a);
     else if (mt == 4) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 4, false>), grid, dim3(256), 0, s, a);
@@ -348,7 +357,11 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             std::string pname = "conv_wino_kernel<" + std::to_string(mt) + ">";
             if (m->prof_detail) pname += " " + scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
             ProfScope ps(m, pname, flops);
-            if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4>), grid, dim3(256), 0, m->stream, a);
+            if (m->bf16) {
+                if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4, true>), grid, dim3(256), 0, m->stream, a);
+                else if (mt == 2) hipLaunchKernelGGL((conv_wino_kernel<2, true>), grid, dim3(256), 0, m->stream, a);
+                else hipLaunchKernelGGL((conv_wino_kernel<1, true>), grid, dim3(256), 0, m->stream, a);
+            } else if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4>), grid, dim3(256), 0, m->stream, a);
             else if (mt == 2) hipLaunchKernelGGL((conv_wino_kernel<2>), grid, dim3(256), 0, m->stream, a);
             else hipLaunchKernelGGL((conv_wino_kernel<1>), grid, dim3(256), 0, m->stream, a);
         } else if (pc.kh == 3) launch_conv_k<3, 3>(m, pc, a, tiles, flops, scope, sub, big_tile);
@@ -401,7 +414,10 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
         TL sub(in.begin() + b0, in.begin() + b1);
         if (m->prof_detail) dname += " " + scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
         ProfScope ps(m, dname, flops);
-        if (mt == 2) hipLaunchKernelGGL((deconv_mfma_kernel<2>), grid, dim3(256), 0, m->stream, a);
+        if (m->bf16) {
+            if (mt == 2) hipLaunchKernelGGL((deconv_mfma_kernel<2, true>), grid, dim3(256), 0, m->stream, a);
+            else hipLaunchKernelGGL((deconv_mfma_kernel<1, true>), grid, dim3(256), 0, m->stream, a);
+        } else if (mt == 2) hipLaunchKernelGGL((deconv_mfma_kernel<2>), grid, dim3(256), 0, m->stream, a);
         else hipLaunchKernelGGL((deconv_mfma_kernel<1>), grid, dim3(256), 0, m->stream, a);
     }
     return out;
@@ -521,12 +537,14 @@ int pack_res8(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
         if (rc) return rc;
         m->owned.push_back(m->d_r8_up_w1); m->owned.push_back(m->d_r8_up_wr);
         m->owned.push_back(m->d_r8_up_br); m->owned.push_back(m->d_r8_up_b1);
-        if (hipFuncSetAttribute((const void*)res8_up_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)res8_up_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)res8_up_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess) {
             set_error("cannot reserve %zu bytes of LDS for the fused up block", R8_UP_LDS);
             return ASEP_ERR_HIP;
         }
     }
-    if (hipFuncSetAttribute((const void*)res8_down_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)res8_down_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)res8_down_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess) {
         set_error("cannot reserve %zu bytes of LDS for the fused residual block", R8_DOWN_LDS);
         return ASEP_ERR_HIP;
     }
@@ -562,7 +580,8 @@ void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>&
         std::string pname = "res8_down_kernel";
         if (m->prof_detail) pname += " unet_down_0 (conv1+3xconvR+add+pool) " + dims_of(sub);
         ProfScope ps(m, pname, flops);
-        hipLaunchKernelGGL(res8_down_kernel, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
+        if (m->bf16) hipLaunchKernelGGL(res8_down_kernel<true>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
+        else hipLaunchKernelGGL(res8_down_kernel<false>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
     }
 }
 
@@ -592,7 +611,8 @@ TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
         std::string pname = "res8_up_kernel";
         if (m->prof_detail) pname += " unet_up_0 (conv1[16->8]+3xconvR+add) " + dims_of(sub);
         ProfScope ps(m, pname, flops);
-        hipLaunchKernelGGL(res8_up_kernel, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
+        if (m->bf16) hipLaunchKernelGGL(res8_up_kernel<true>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
+        else hipLaunchKernelGGL(res8_up_kernel<false>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
     }
     return out;
 }
@@ -882,12 +902,13 @@ extern "C" {
 asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_cfg* cfg) {
     if (!cfg || !weight_blob) { set_error("asep_aru_load: null argument"); return nullptr; }
     if (cfg->channels != 1) { set_error("asep_aru_load: only 1-channel input is supported (ARU_v1.py:115)"); return nullptr; }
-    if (cfg->compute_dtype != 0) { set_error("asep_aru_load: compute_dtype %d not available yet (fp32 only)", cfg->compute_dtype); return nullptr; }
+    if (cfg->compute_dtype != 0 && cfg->compute_dtype != 1) { set_error("asep_aru_load: compute_dtype %d unknown (0 = fp32, 1 = bf16 MFMA)", cfg->compute_dtype); return nullptr; }
     if (cfg->scale_space_num < 1 || cfg->res_depth < 1) { set_error("asep_aru_load: bad cfg"); return nullptr; }
     std::map<std::string, HostTensor> blob;
     if (!parse_blob(weight_blob, nbytes, blob)) return nullptr;
     std::unique_ptr<asep_aru> m(new asep_aru());
     m->cfg = *cfg;
+    m->bf16 = cfg->compute_dtype == 1;
     if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BIGTILE")) m->big_tile = atoi(e) != 0;

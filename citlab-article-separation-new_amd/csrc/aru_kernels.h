@@ -15,6 +15,26 @@
 namespace asep {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// bf16 variant (asep_aru_cfg.compute_dtype = 1): activations and weights stay fp32 in HBM / LDS; a lane's 16-byte
+// fragment (4 consecutive k-slots) is rounded to 4 bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) right before the
+// MFMA, and ONE v_mfma_f32_16x16x16_bf16 (fp32 accumulate) replaces the four v_mfma_f32_16x16x4_f32 of a K chunk:
+// the K-slot numbering (slot = 4*kk + r) is exactly that instruction's operand layout.
+__device__ __forceinline__ s16x4 bf16pack(f32x4 v) {
+    // two-element vector conversions select one v_cvt_pk_bf16_f32 each (and, unlike inline asm, let the compiler
+    // schedule the VALU-write -> MFMA-read hazard)
+    const bf16x2_t lo = __builtin_convertvector(f32x2_t{v.x, v.y}, bf16x2_t);
+    const bf16x2_t hi = __builtin_convertvector(f32x2_t{v.z, v.w}, bf16x2_t);
+    const u32x2 p = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+    return __builtin_bit_cast(s16x4, p);
+}
+__device__ __forceinline__ f32x4 mfma_bf16(s16x4 a, s16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution, D[cout][pixel] = sum_k A[cout][k] * B[k][pixel]
@@ -65,7 +85,7 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 // Software pipeline: the halo tile of channel group g+1 is fetched into registers while group g is multiplied
 // out of LDS (two LDS buffers, one barrier per group); the weight fragments of tap t+1 are requested before the
 // MFMAs of tap t are issued.
-template <int KH, int KW, int MT, bool C8, int TH = CONV_TH, bool DBUF = true>
+template <int KH, int KW, int MT, bool C8, int TH = CONV_TH, bool DBUF = true, bool BF = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int TW = CONV_TW, NT = TH / 2;             // TH rows x 2 column blocks of 16 pixels, 4 waves
     constexpr int LH = TH + KH - 1, LW = TW + KW - 1;
@@ -195,6 +215,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             f32x4 bf[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const f32x4*>(lb + nbase[n] + toff);
+            if constexpr (BF) {
+                s16x4 pa[MT], pb[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) pa[m] = bf16pack(af[m]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) pb[n] = bf16pack(bf[n]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n] = mfma_bf16(pa[m], pb[n], acc[m][n]);
+            } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -202,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][r], bf[n][r], acc[m][n], 0, 0, 0);
+            }
 #pragma unroll
             for (int m = 0; m < MT; ++m) af[m] = an[m];
         }
@@ -264,7 +296,7 @@ constexpr int WINO_TW = 32;
 #define WINO_XFORM_AT 1
 #endif
 
-template <int MT>
+template <int MT, bool BF = false>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
     constexpr int TH = WINO_TH, TW = WINO_TW;
     constexpr int TILES = (TH / 2) * (TW / 2);            // 32 Winograd tiles
@@ -362,6 +394,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
             f32x4 bf[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) bf[n] = *reinterpret_cast<const f32x4*>(vb + n * 16 * 16);
+            if constexpr (BF) {
+                s16x4 pa[MT], pb[2];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) pa[m] = bf16pack(af[m]);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) pb[n] = bf16pack(bf[n]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[p][m][n] = mfma_bf16(pa[m], pb[n], acc[p][m][n]);
+            } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -369,6 +412,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
                         acc[p][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][r], bf[n][r], acc[p][m][n], 0, 0, 0);
+            }
 #pragma unroll
             for (int m = 0; m < MT; ++m) af[m] = an[m];
             // transform of the next group in the shadow of this phase's MFMAs (its patch loads were issued at the top;
@@ -466,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 constexpr int DC_TH = 8;
 constexpr int DC_TW = 16;
 
-template <int MT>
+template <int MT, bool BF = false>
 __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
     constexpr int TH = DC_TH, TW = DC_TW, NT = 2;
     constexpr int LH = TH + 1, LW = TW + 1;   // one halo row/column before the tile (o = q - 1)
@@ -529,6 +573,14 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
                 an[m] = tap + 1 < 9 ? wg[((size_t)(tap + 1) * a.mtiles + m) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BF) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const s16x4 pa = bf16pack(af[m]);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n][cls] = mfma_bf16(pa, bf16pack(bf[n][sh]), acc[m][n][cls]);
+                }
+            } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -537,6 +589,7 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
                     for (int n = 0; n < NT; ++n)
                         acc[m][n][cls] =
                             __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][r], bf[n][sh][r], acc[m][n][cls], 0, 0, 0);
+            }
 #pragma unroll
             for (int m = 0; m < MT; ++m) af[m] = an[m];
         }

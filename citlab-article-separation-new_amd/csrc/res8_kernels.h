@@ -40,7 +40,7 @@ struct Res8Args {
 
 // one 3x3 8->8 convolution stage on LDS tiles.  IN holds rows in_r0.. of the frame, OUT rows out_r0.. ;
 // computes rows [out_r0, out_r0+NROWS) x columns [out_c0, out_c0+64).  FINAL: add T centre, store to global.
-template <int NROWS, bool RELU_IN, bool FINAL, bool POOL>
+template <int NROWS, bool RELU_IN, bool FINAL, bool POOL, bool BF = false>
 __device__ __forceinline__ void res8_stage(const float* __restrict__ IN, int in_r0, float* __restrict__ OUT, int out_r0,
                                            int out_c0, const f32x4 (&A)[6], const f32x4 bias4, int wave, int lane,
                                            int fy0, int fx0, int H, int W, const float* __restrict__ T, int t_r0,
@@ -62,10 +62,16 @@ __device__ __forceinline__ void res8_stage(const float* __restrict__ IN, int in_
                 f32x4 b0 = *reinterpret_cast<const f32x4*>(p0);
                 f32x4 b1 = *reinterpret_cast<const f32x4*>(p0 + R8_PITCH * 8);
                 if (RELU_IN) { b0 = relu4(b0); b1 = relu4(b1); }
+                if constexpr (BF) {
+                    const s16x4 pa = bf16pack(A[c]);
+                    acc0 = mfma_bf16(pa, bf16pack(b0), acc0);
+                    acc1 = mfma_bf16(pa, bf16pack(b1), acc1);
+                } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][r], b0[r], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][r], b1[r], acc1, 0, 0, 0);
+                }
                 }
             }
         // D layout: lane (pair j, kk): pixel colb + e, channels ch..ch+3
@@ -109,6 +115,7 @@ __device__ __forceinline__ void res8_stage(const float* __restrict__ IN, int in_
 }
 
 // DOWN block of level 0: image (1 channel) -> d0 [H,W,8] (+ maxpool2)
+template <bool BF = false>
 __global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* IMG = sm;                                         // [24][76]
@@ -199,18 +206,19 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args
             *reinterpret_cast<f32x4*>(T + i * 8 + 4) = hi;
         }
         __syncthreads();
-        res8_stage<20, true, false, false>(T, 1, R0, 2, 2, A0, bias0, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+        res8_stage<20, true, false, false, BF>(T, 1, R0, 2, 2, A0, bias0, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
         __syncthreads();
-        res8_stage<18, false, false, false>(R0, 2, R1, 3, 3, A1, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+        res8_stage<18, false, false, false, BF>(R0, 2, R1, 3, 3, A1, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
         __syncthreads();
         if (tile_id + (int)gridDim.x < a.total_tiles) image_load(tile_id + gridDim.x);
-        res8_stage<16, false, true, true>(R1, 3, nullptr, 4, 4, A2, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, P.pool);
+        res8_stage<16, false, true, true, BF>(R1, 3, nullptr, 4, 4, A2, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, P.pool);
     }
 }
 
 // UP block of level 0 (ARU_v1.py:262-281): t = conv1(concat[skip, deconv]) ; 3 x convR ; + t ; ReLU.
 // The 16-channel concatenation is consumed as two 8-channel passes through one LDS input tile (skip, then the
 // deconvolution output) that accumulate into the same registers; afterwards that tile buffer holds r1.
+template <bool BF = false>
 __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Pb = sm;                                          // frame rows 0..23  [24][72][8]  (later r1: rows 3..20)
@@ -297,10 +305,16 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
                             const float* p0 = Pb + ((row0 + ky - 1) * R8_PITCH + colb + 2 * h + e - 1) * 8 + ch;
                             const f32x4 b0 = *reinterpret_cast<const f32x4*>(p0);
                             const f32x4 b1 = *reinterpret_cast<const f32x4*>(p0 + R8_PITCH * 8);
+                            if constexpr (BF) {
+                                const s16x4 pa = bf16pack(Aw[ky * 2 + h]);
+                                tacc[q][0] = mfma_bf16(pa, bf16pack(b0), tacc[q][0]);
+                                tacc[q][1] = mfma_bf16(pa, bf16pack(b1), tacc[q][1]);
+                            } else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 tacc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[ky * 2 + h][r], b0[r], tacc[q][0], 0, 0, 0);
                                 tacc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[ky * 2 + h][r], b1[r], tacc[q][1], 0, 0, 0);
+                            }
                             }
                         }
                 }
@@ -322,9 +336,9 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
             }
         }
         __syncthreads();
-        res8_stage<20, true, false, false>(T, 1, R0, 2, 2, A0, bias0, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+        res8_stage<20, true, false, false, BF>(T, 1, R0, 2, 2, A0, bias0, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
         __syncthreads();
-        res8_stage<18, false, false, false>(R0, 2, Pb, 3, 3, A1, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+        res8_stage<18, false, false, false, BF>(R0, 2, Pb, 3, 3, A1, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
         __syncthreads();
         if (next_id < a.total_tiles) {                       // next tile's skip half flies under the last stage
             int qi = 0;
@@ -334,7 +348,7 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
             const int qyb = tq / Q.tiles_x, qxb = tq - qyb * Q.tiles_x;
             tile_load(Q.img, Q.H, Q.W, qyb * R8_OH - 4, qxb * R8_OW - 4);
         }
-        res8_stage<16, false, true, false>(Pb, 3, nullptr, 4, 4, A2, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, nullptr);
+        res8_stage<16, false, true, false, BF>(Pb, 3, nullptr, 4, 4, A2, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, nullptr);
     }
 }
 

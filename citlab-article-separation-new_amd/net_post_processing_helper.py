@@ -44,8 +44,11 @@ class AruGraph:
         if device_id not in self._handles:
             lib = _lib.init_device(device_id)
             c = self.cfg
+            if c.compute_dtype not in ("f32", "bf16"):
+                raise ValueError(f"compute_dtype must be 'f32' or 'bf16', got {c.compute_dtype!r}")
             cfg = _lib.AruCfg(c.channels, c.n_classes, c.feat_root, c.scale_space_num, c.res_depth,
-                              c.num_scales_att, int(c.use_attention), int(c.mvn), int(c.apply_softmax), 0)
+                              c.num_scales_att, int(c.use_attention), int(c.mvn), int(c.apply_softmax),
+                              1 if c.compute_dtype == "bf16" else 0)
             blob = self.blob()
             h = lib.asep_aru_load(blob, len(blob), C.byref(cfg))
             if not h:

@@ -6,7 +6,8 @@ from citlab_article_separation_new_amd.config import AruConfig
 from citlab_article_separation_new_amd.weights import init_aru_weights
 from citlab_article_separation_new_amd import net_post_processing_helper as helper, _lib
 H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4500, 3000)
-cfg = AruConfig()
+dtype = sys.argv[3] if len(sys.argv) > 3 else 'f32'
+cfg = AruConfig(compute_dtype=dtype)
 g = helper.AruGraph(init_aru_weights(cfg, 1234), cfg)
 lib = _lib.init_device(0); h = g.handle(0)
 img = torch.rand(H, W, device='cuda'); out = torch.empty(H, W, 2, device='cuda')

@@ -94,3 +94,28 @@ def test_input_forms_and_errors():
     with pytest.raises(IOError):
         helper.load_graph("/nonexistent/model.pb")
     graph.close()
+
+
+@pytest.mark.parametrize("H,W", [(96, 80), (250, 333)])
+def test_bf16_mfma_variant_within_stated_tolerance(H, W):
+    """BASELINE config 5 ("bf16 convs"): bf16 MFMA operands with fp32 accumulation and fp32 activations.
+    Tolerance 2e-2 on the probability map; the fp32 path of the same engine is the 1e-4 one."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from oracle import aru_oracle
+    cfg, w, graph = _setup()
+    cfg_bf = type(cfg)(**{**cfg.to_dict(), "compute_dtype": "bf16"})
+    graph_bf = helper.AruGraph(w, cfg_bf)
+    img = _image(H, W, 5)
+    ref = aru_oracle.forward_torch(img, w, cfg)
+    out_bf = helper.get_net_output(img, graph_bf, "0")
+    out_f32 = helper.get_net_output(img, graph, "0")
+    err_bf = np.abs(out_bf - ref).max()
+    err_f32 = np.abs(out_f32 - ref).max()
+    print(f"bf16 max|dp| = {err_bf:.2e}, f32 max|dp| = {err_f32:.2e}")
+    assert err_f32 <= 1e-4
+    assert err_bf <= 2e-2
+    assert err_bf > err_f32                       # the variant really computes in reduced precision
+    # the thresholded uint8 masks agree except where the probability is within the tolerance of the threshold
+    m_bf = aru_oracle.apply_threshold(aru_oracle.to_uint8(out_bf), 0.5)
+    m_ref = aru_oracle.apply_threshold(aru_oracle.to_uint8(ref), 0.5)
+    assert (m_bf != m_ref).mean() <= 0.05
