@@ -570,6 +570,68 @@ int asep_swt_distance_transform_dev(asep_post* p, const uint8_t* d_gray, int H, 
     POST_GUARD_END
 }
 
+int asep_swt_line_features_dev(asep_post* p, const uint8_t* d_swt, int H, int W, int n_lines, const int32_t* boxes,
+                                float* out_stroke_width, int32_t* out_height, int32_t* out_flag, void* stream) {
+    if (!p || !d_swt || n_lines < 0 || (n_lines > 0 && (!boxes || !out_stroke_width || !out_height || !out_flag))) {
+        set_error("asep_swt_line_features_dev: bad arguments");
+        return ASEP_ERR_ARG;
+    }
+    if (int rc = check_image("asep_swt_line_features_dev", H, W)) return rc;
+    if (n_lines == 0) return ASEP_OK;
+    POST_GUARD_BEGIN
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<SwtLineBox> hb(n_lines);
+    std::vector<unsigned long long> ofs(n_lines);
+    unsigned long long total = 0;
+    for (int i = 0; i < n_lines; ++i) {
+        // numpy slicing semantics of swt[y0:y1, x0:x1]: bounds are clipped to the image
+        SwtLineBox b{boxes[4 * i + 0], boxes[4 * i + 1], boxes[4 * i + 2], boxes[4 * i + 3]};
+        b.x0 = std::min(std::max(b.x0, 0), W); b.x1 = std::min(std::max(b.x1, 0), W);
+        b.y0 = std::min(std::max(b.y0, 0), H); b.y1 = std::min(std::max(b.y1, 0), H);
+        hb[i] = b;
+        ofs[i] = total;
+        const long long cw = b.x1 - b.x0, chh = b.y1 - b.y0;
+        if (cw > 0 && chh > 0) {
+            if (cw * chh > 0x3fffffffll) { set_error("asep_swt_line_features_dev: line %d crop too large", i); return ASEP_ERR_UNSUPPORTED; }
+            total += 2ull * (unsigned long long)(cw * chh);
+        }
+    }
+    p->pool.begin();
+    SwtLineBox* d_boxes = (SwtLineBox*)p->pool.get((size_t)n_lines * sizeof(SwtLineBox));
+    unsigned long long* d_ofs = (unsigned long long*)p->pool.get((size_t)n_lines * sizeof(unsigned long long));
+    int32_t* d_scratch = (int32_t*)p->pool.get(std::max<size_t>((size_t)total, 1) * sizeof(int32_t));
+    float* d_sw = (float*)p->pool.get((size_t)n_lines * sizeof(float));
+    int32_t* d_h = (int32_t*)p->pool.get((size_t)n_lines * sizeof(int32_t));
+    int32_t* d_f = (int32_t*)p->pool.get((size_t)n_lines * sizeof(int32_t));
+    ASEP_HIP_CHECK(hipMemcpyAsync(d_boxes, hb.data(), (size_t)n_lines * sizeof(SwtLineBox), hipMemcpyHostToDevice, st));
+    ASEP_HIP_CHECK(hipMemcpyAsync(d_ofs, ofs.data(), (size_t)n_lines * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    ASEP_HIP_CHECK(hipStreamSynchronize(st));          // hb / ofs are stack-owned: finish the copies before they die
+    swt_line_features_kernel<<<n_lines, 256, 0, st>>>(d_swt, W, d_boxes, d_ofs, d_scratch, d_sw, d_h, d_f);
+    ASEP_HIP_CHECK(hipGetLastError());
+    ASEP_HIP_CHECK(hipMemcpyAsync(out_stroke_width, d_sw, (size_t)n_lines * sizeof(float), hipMemcpyDeviceToHost, st));
+    ASEP_HIP_CHECK(hipMemcpyAsync(out_height, d_h, (size_t)n_lines * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ASEP_HIP_CHECK(hipMemcpyAsync(out_flag, d_f, (size_t)n_lines * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ASEP_HIP_CHECK(hipStreamSynchronize(st));
+    return ASEP_OK;
+    POST_GUARD_END
+}
+
+int asep_swt_line_features(asep_post* p, const uint8_t* swt, int H, int W, int n_lines, const int32_t* boxes,
+                            float* out_stroke_width, int32_t* out_height, int32_t* out_flag) {
+    if (!p || !swt) {
+        set_error("asep_swt_line_features: null argument");
+        return ASEP_ERR_ARG;
+    }
+    if (int rc = check_image("asep_swt_line_features", H, W)) return rc;
+    POST_GUARD_BEGIN
+    Staged din;
+    if (int rc = din.alloc((size_t)H * W)) return rc;
+    ASEP_HIP_CHECK(hipMemcpyAsync(din.p, swt, (size_t)H * W, hipMemcpyHostToDevice, p->s));
+    return asep_swt_line_features_dev(p, (const uint8_t*)din.p, H, W, n_lines, boxes, out_stroke_width, out_height,
+                                      out_flag, p->s);
+    POST_GUARD_END
+}
+
 int asep_swt_distance_transform(asep_post* p, const uint8_t* gray, int H, int W, uint8_t* out, int32_t* out_otsu,
                                 int32_t* out_d2) {
     if (!p || !gray || !out) {

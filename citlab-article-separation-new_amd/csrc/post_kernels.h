@@ -597,4 +597,121 @@ post_boundary_segments_kernel(const uint8_t* __restrict__ mask, int H, int W, in
         if (o < capacity) ends[o] = ek[k];
 }
 
+
+// --------------------------------------------------------------------------------------------------------------
+// a11 / f4: per text line statistics on the stroke-width image (heading_net_post_processor.py:218-245,
+// feature_generation.py:106-159): inside the line's crop, 8-connected components of the non-zero pixels ->
+// bounding boxes -> reject (w < 3 or h < 3 or w > 500 or h > 500, then w/h > 8 or h/w > 8) -> per accepted
+// component the maximum of the crop over its bounding box -> median of those maxima and the largest height.
+// One workgroup per line; labels live in a global scratch slice of the line, component boxes in LDS.
+// --------------------------------------------------------------------------------------------------------------
+#define SWTL_MAXC 1024
+struct SwtLineBox { int x0, y0, x1, y1; };      // crop = rows [y0, y1), columns [x0, x1), already clipped
+
+__global__ void __launch_bounds__(256)
+swt_line_features_kernel(const uint8_t* __restrict__ swt, int W, const SwtLineBox* __restrict__ boxes,
+                         const unsigned long long* __restrict__ scratch_ofs, int32_t* scratch,
+                         float* __restrict__ out_sw, int32_t* __restrict__ out_h, int32_t* __restrict__ out_flag) {
+    __shared__ int ncomp;
+    __shared__ int maxh;
+    __shared__ int bx0[SWTL_MAXC], bx1[SWTL_MAXC], by0[SWTL_MAXC], by1[SWTL_MAXC];
+    __shared__ unsigned int hist[256];
+    const int line = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const SwtLineBox b = boxes[line];
+    const int cw = b.x1 - b.x0, chh = b.y1 - b.y0;
+    const int n = cw > 0 && chh > 0 ? cw * chh : 0;
+    if (tid == 0) { ncomp = 0; maxh = 0; }
+    hist[tid] = 0;
+    if (n == 0) {
+        if (tid == 0) { out_sw[line] = 0.f; out_h[line] = 0; out_flag[line] = 0; }
+        return;
+    }
+    int32_t* L = scratch + scratch_ofs[line];
+    int32_t* aux = L + n;
+    const uint8_t* src = swt + (size_t)b.y0 * W + b.x0;
+    for (int p = tid; p < n; p += 256) {
+        const int y = p / cw, x = p - y * cw;
+        L[p] = src[(size_t)y * W + x] != 0 ? p : -1;
+    }
+    __syncthreads();
+    for (int p = tid; p < n; p += 256) {
+        if (__atomic_load_n(&L[p], __ATOMIC_RELAXED) < 0) continue;
+        const int y = p / cw, x = p - y * cw;
+        const bool left = x > 0 && __atomic_load_n(&L[p - 1], __ATOMIC_RELAXED) >= 0;
+        if (left) cc_union(L, p, p - 1);
+        if (y > 0) {
+            const int up = p - cw;
+            const bool nn = __atomic_load_n(&L[up], __ATOMIC_RELAXED) >= 0;
+            const bool ne = x + 1 < cw && __atomic_load_n(&L[up + 1], __ATOMIC_RELAXED) >= 0;
+            if (left) {
+                if (!nn && ne) cc_union(L, p, up + 1);
+            } else if (nn) {
+                cc_union(L, p, up);
+            } else {
+                if (x > 0 && __atomic_load_n(&L[up - 1], __ATOMIC_RELAXED) >= 0) cc_union(L, p, up - 1);
+                if (ne) cc_union(L, p, up + 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int p = tid; p < n; p += 256) {
+        if (__atomic_load_n(&L[p], __ATOMIC_RELAXED) < 0) continue;
+        const int r = cc_find(L, p);
+        L[p] = r;
+        if (r == p) aux[p] = atomicAdd(&ncomp, 1);
+    }
+    __syncthreads();
+    const int nc = ncomp;
+    if (nc > SWTL_MAXC) {                       // pathological crop: the host falls back for this line
+        if (tid == 0) { out_sw[line] = 0.f; out_h[line] = 0; out_flag[line] = 1; }
+        return;
+    }
+    for (int c = tid; c < nc; c += 256) { bx0[c] = 1 << 30; by0[c] = 1 << 30; bx1[c] = -1; by1[c] = -1; }
+    __syncthreads();
+    for (int p = tid; p < n; p += 256) {
+        const int r = L[p];
+        if (r < 0) continue;
+        const int c = aux[r];
+        const int y = p / cw, x = p - y * cw;
+        atomicMin(&bx0[c], x); atomicMax(&bx1[c], x);
+        atomicMin(&by0[c], y); atomicMax(&by1[c], y);
+    }
+    __syncthreads();
+    for (int c = wave; c < nc; c += 4) {
+        const int w = bx1[c] - bx0[c] + 1, h = by1[c] - by0[c] + 1;
+        if (w < 3 || h < 3 || h > 500 || w > 500) continue;           // swt_dist_trafo.py:53-56
+        if (w > 8 * h || h > 8 * w) continue;                           // :57-60 (w/h > 8 <=> w > 8h for positive ints)
+        int m = 0;
+        for (int i = lane; i < w * h; i += 64) {
+            const int yy = i / w, xx = i - yy * w;
+            m = max(m, (int)src[(size_t)(by0[c] + yy) * W + bx0[c] + xx]);
+        }
+        for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d));
+        if (lane == 0) {
+            atomicAdd(&hist[m], 1u);
+            atomicMax(&maxh, h);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int total = 0;
+        for (int v = 0; v < 256; ++v) total += hist[v];
+        float med = 0.f;
+        if (total > 0) {
+            const unsigned int k1 = (total - 1) / 2, k2 = total / 2;   // np.median: mean of the two middle values
+            unsigned int cum = 0;
+            int v1 = -1, v2 = -1;
+            for (int v = 0; v < 256; ++v) {
+                cum += hist[v];
+                if (v1 < 0 && cum > k1) v1 = v;
+                if (v2 < 0 && cum > k2) { v2 = v; break; }
+            }
+            med = 0.5f * (float)(v1 + v2);
+        }
+        out_sw[line] = med;
+        out_h[line] = maxh;
+        out_flag[line] = 0;
+    }
+}
+
 }  // namespace asep

@@ -142,7 +142,14 @@ def get_textline_stroke_widths_heights_dist_trafo(page_path, text_lines, img_pat
             img_path = get_img_from_page_path(page_path)
         if not img_path:
             raise ValueError(f"Could not find corresponding image file to pagexml '{page_path}'")
-        swt_img = image_ops.swt_distance_transform(bgr_to_gray_u8(load_image_bgr(img_path)), device)
+        d_swt = image_ops.swt_distance_transform_device(bgr_to_gray_u8(load_image_bgr(img_path)), device)
+        boxes = []
+        for text_line in text_lines:
+            min_x, max_x, min_y, max_y = get_bounding_box(np.asarray(text_line.surr_p, dtype=np.int32))
+            boxes.append([min_x, min_y, max_x + 1, max_y + 1])
+        sws, hts = image_ops.swt_line_features(d_swt, boxes, device=device)
+        return ({tl.id: sws[i] for i, tl in enumerate(text_lines)},
+                {tl.id: int(hts[i]) for i, tl in enumerate(text_lines)})
     stroke_widths, heights = {}, {}
     for text_line in text_lines:
         min_x, max_x, min_y, max_y = get_bounding_box(np.asarray(text_line.surr_p, dtype=np.int32))

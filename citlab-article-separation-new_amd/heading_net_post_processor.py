@@ -43,11 +43,15 @@ class StrokeWidthDistanceTransform:
         self._clean_ccs = clean_ccs
         self.device = device
 
-    def distance_transform(self, img_or_path):
-        """:18-24 -- accepts a file path like the reference, or an already decoded gray / BGR uint8 array."""
+    def distance_transform(self, img_or_path, on_device=False):
+        """:18-24 -- accepts a file path like the reference, or an already decoded gray / BGR uint8 array.
+        ``on_device`` leaves the result in HBM (``image_ops.DeviceImage``) for the batched per-line statistics."""
         if isinstance(img_or_path, str):
             img_or_path = load_image_bgr(img_or_path)
-        return image_ops.swt_distance_transform(bgr_to_gray_u8(np.asarray(img_or_path)), self.device)
+        gray = bgr_to_gray_u8(np.asarray(img_or_path))
+        if on_device:
+            return image_ops.swt_distance_transform_device(gray, self.device)
+        return image_ops.swt_distance_transform(gray, self.device)
 
     def connected_components_cv(self, image, connectivity=8):
         """:31-41: (x, y, w, h) of every connected component of non-zero pixels."""
@@ -133,9 +137,21 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
         text_lines = page_object.get_textlines()
 
         stroke_width_dict, height_dict, net_prob_dict = {}, {}, {}
+        batched = {}
+        if isinstance(swt_feature_image, image_ops.DeviceImage):
+            # all lines of the page in one kernel launch on the device-resident distance transform
+            with_coords = [tl for tl in text_lines if tl.surr_p]
+            boxes = []
+            for tl in with_coords:
+                x, y, w, h = tl.get_bounding_box()
+                boxes.append([x, y, x + w + 1, y + h + 1])         # the crop [ya:yb+1, xa:xb+1] of :232-236
+            sws, hts = image_ops.swt_line_features(swt_feature_image, boxes, device=swt_feature_image.device)
+            batched = {tl.id: (sws[i], int(hts[i])) for i, tl in enumerate(with_coords)}
         for text_line in text_lines:
             if not text_line.surr_p:
                 stroke_width, height = 0, 0
+            elif batched:
+                stroke_width, height = batched[text_line.id]
             else:
                 stroke_width, height = self.get_swt_features_textline(swt_feature_image, text_line)
             stroke_width_dict[text_line.id] = stroke_width
@@ -237,7 +253,7 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
                     self.net_outputs_post.append(net_output_post)
             else:
                 net_output_post = None
-            swt_feature_image = self.SWT.distance_transform(image)
+            swt_feature_image = self.SWT.distance_transform(image, on_device=True)
             new_page_objects.append(self.to_page_xml(get_page_path(image_path), image_path, net_output_post,
                                                      swt_feature_image))
         return new_page_objects

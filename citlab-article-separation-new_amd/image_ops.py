@@ -149,6 +149,39 @@ def boundary_segments_dev(d_mask_ptr, H, W, value=255, device=0, stream=None, ca
         cap = int(n)
 
 
+class DeviceImage:
+    """A uint8 image that lives in HBM (held by a torch tensor); ``numpy()`` copies it back on demand."""
+
+    def __init__(self, tensor, device=0):
+        self.tensor = tensor
+        self.device = device
+        self.shape = tuple(tensor.shape)
+
+    @property
+    def ptr(self):
+        return self.tensor.data_ptr()
+
+    def numpy(self):
+        return self.tensor.cpu().numpy()
+
+
+def swt_distance_transform_device(gray, device=0):
+    """swt_dist_trafo.py:18-29 with the result left on the GPU -> :class:`DeviceImage` (for ``swt_line_features``)."""
+    import torch
+    g = np.require(gray, dtype=np.uint8, requirements=["C", "W"])
+    H, W = g.shape
+    lib, ws = _workspace(device)
+    tdev = torch.device("cuda", device)
+    with torch.cuda.device(tdev):
+        sp = C.c_void_p(torch.cuda.current_stream(tdev).cuda_stream)
+        d_g = torch.from_numpy(g).to(tdev)
+        d_out = torch.empty((H, W), dtype=torch.uint8, device=tdev)
+        _lib.check(lib.asep_swt_distance_transform_dev(ws, d_g.data_ptr(), H, W, d_out.data_ptr(), sp),
+                   "asep_swt_distance_transform_dev")
+        torch.cuda.current_stream(tdev).synchronize()
+    return DeviceImage(d_out, device)
+
+
 def swt_distance_transform(gray, device=0, return_details=False):
     """swt_dist_trafo.py:18-29 on an already decoded uint8 gray image."""
     g = np.ascontiguousarray(gray, dtype=np.uint8)
@@ -163,3 +196,54 @@ def swt_distance_transform(gray, device=0, return_details=False):
     if return_details:
         return out, thr.value, d2
     return out
+
+
+def _line_features_host(swt, box):
+    """Reference arithmetic for one crop (heading_net_post_processor.py:218-245) -- used for the rare lines the
+    device kernel flags (more than 1024 components in one crop)."""
+    from scipy import ndimage
+    x0, y0, x1, y1 = box
+    crop = swt[max(y0, 0):max(y1, 0), max(x0, 0):max(x1, 0)]
+    lab, _ = ndimage.label(crop != 0, structure=np.ones((3, 3), dtype=bool))
+    vals, height = [], 0
+    for sl in ndimage.find_objects(lab):
+        w, h = sl[1].stop - sl[1].start, sl[0].stop - sl[0].start
+        if w < 3 or h < 3 or h > 500 or w > 500 or w / h > 8 or h / w > 8:
+            continue
+        vals.append(np.max(crop[sl]))
+        height = max(height, h)
+    return (float(np.median(vals)) if vals else 0.0), height
+
+
+def swt_line_features(swt, boxes, device=0, d_swt_ptr=None, shape=None, stream=None):
+    """Stroke width (median of the per-component maxima) and text height (largest component height) of every text
+    line crop ``swt[y0:y1, x0:x1]``; ``boxes`` = [[x0, y0, x1, y1], ...].  ``swt`` may be a host uint8 image, or
+    None together with ``d_swt_ptr`` / ``shape`` for a device-resident image (``swt`` is then fetched lazily, only if
+    a line has to fall back to the host).  -> (stroke_widths float64 [L], heights int [L])"""
+    boxes = np.ascontiguousarray(np.asarray(boxes, dtype=np.int32).reshape(-1, 4))
+    n = boxes.shape[0]
+    sw = np.zeros(n, dtype=np.float32)
+    hh = np.zeros(n, dtype=np.int32)
+    flag = np.zeros(n, dtype=np.int32)
+    if n == 0:
+        return sw.astype(np.float64), hh
+    lib, ws = _workspace(device)
+    if isinstance(swt, DeviceImage):
+        d_swt_ptr, shape, dimg = swt.ptr, swt.shape, swt
+        swt = dimg.numpy
+    if d_swt_ptr is not None:
+        H, W = shape
+        _lib.check(lib.asep_swt_line_features_dev(ws, d_swt_ptr, H, W, n, boxes.ctypes.data, sw.ctypes.data,
+                                                  hh.ctypes.data, flag.ctypes.data, stream),
+                   "asep_swt_line_features_dev")
+    else:
+        g = np.ascontiguousarray(swt, dtype=np.uint8)
+        H, W = g.shape
+        _lib.check(lib.asep_swt_line_features(ws, g.ctypes.data, H, W, n, boxes.ctypes.data, sw.ctypes.data,
+                                              hh.ctypes.data, flag.ctypes.data), "asep_swt_line_features")
+    sw = sw.astype(np.float64)
+    if flag.any():
+        host = swt() if callable(swt) else swt
+        for i in np.flatnonzero(flag):
+            sw[i], hh[i] = _line_features_host(host, boxes[i])
+    return sw, hh

@@ -215,6 +215,19 @@ int asep_swt_distance_transform(asep_post* p, const uint8_t* gray, int H, int W,
 int asep_swt_distance_transform_dev(asep_post* p, const uint8_t* d_gray, int H, int W, uint8_t* d_out,
                                     void* stream);
 
+/* heading_net_post_processor.py:218-245 / feature_generation.py:106-159 for all text lines of a page at once.
+ * swt: the uint8 distance-transform image [H,W]; boxes: n_lines x {x0, y0, x1, y1} = the crop swt[y0:y1, x0:x1]
+ * the reference takes per line (numpy slicing: bounds are clipped to the image).  Per line: 8-connected components
+ * of the non-zero crop pixels (connected_components_cv), size / aspect cleaning (clean_connected_components),
+ * the crop's maximum over each surviving component's bounding box; out_stroke_width = median of those maxima
+ * (0.0 if none), out_height = largest surviving component height.  out_flag[i] = 1 marks a line with more than
+ * 1024 components whose results were not computed (the caller evaluates that line on the host).
+ * boxes and the three outputs are host pointers in both variants. */
+int asep_swt_line_features(asep_post* p, const uint8_t* swt, int H, int W, int n_lines, const int32_t* boxes,
+                           float* out_stroke_width, int32_t* out_height, int32_t* out_flag);
+int asep_swt_line_features_dev(asep_post* p, const uint8_t* d_swt, int H, int W, int n_lines, const int32_t* boxes,
+                               float* out_stroke_width, int32_t* out_height, int32_t* out_flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

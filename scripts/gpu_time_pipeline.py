@@ -89,3 +89,22 @@ print("--- heading: stroke-width distance transform at full resolution")
 d_swt = torch.empty((H, W), dtype=torch.uint8, device="cuda")
 timed("a12 255-gray, blur, Otsu, exact EDT", lambda: _lib.check(lib.asep_swt_distance_transform_dev(
     ws, d_gray_u8.data_ptr(), H, W, d_swt.data_ptr(), sp), "swt"))
+
+# per text line statistics: 3000 line crops of ~600 x 40 px on the device-resident distance transform
+rng = np.random.default_rng(1)
+boxes = []
+for _ in range(3000):
+    w_, h_ = int(rng.integers(300, 900)), int(rng.integers(28, 50))
+    x_, y_ = int(rng.integers(0, W - w_)), int(rng.integers(0, H - h_))
+    boxes.append([x_, y_, x_ + w_ + 1, y_ + h_ + 1])
+dimg = image_ops.DeviceImage(d_swt, 0)
+image_ops.swt_line_features(dimg, boxes)
+t0 = time.time()
+sw, hh = image_ops.swt_line_features(dimg, boxes)
+t1 = time.time()
+print(f"{'a11 per-line CC statistics, 3000 lines (GPU)':44s} {(t1 - t0) * 1e3:9.3f} ms")
+swt_host = d_swt.cpu().numpy()
+t0 = time.time()
+for b in boxes[:300]:
+    image_ops._line_features_host(swt_host, b)
+print(f"{'    same on the host (scipy), scaled x10':44s} {(time.time() - t0) * 1e4:9.3f} ms")
