@@ -92,6 +92,8 @@ struct asep_aru {
     int persist_mt1 = 3, persist_mt2 = 2;   // resident blocks per CU assumed by the persistent conv grids
     int wino_blocks = 512;         // resident Winograd blocks (256 CUs x 2); ASEP_WINO_BLOCKS overrides
     bool big_tile = true;          // ASEP_BIGTILE=0 disables the 16x32 single-buffer variant
+    bool use_xcd_sched = true;     // ASEP_XCD_SCHED=0: identity tile order in the persistent fused kernels
+    std::map<std::string, const int32_t*> sched_cache;
     bool bf16 = false;             // cfg.compute_dtype == 1: bf16 MFMA operands, fp32 accumulation and storage
     bool use_winograd = true;      // ASEP_WINOGRAD=0 selects the direct implicit-GEMM kernels everywhere
     bool profiling = false;
@@ -552,6 +554,44 @@ int pack_res8(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
 }
 
 // fused level-0 down block: images -> d0 (and maxpool2(d0) if want_pool)
+// XCD-aware order of the persistent fused kernels' tiles.  Workgroups are dealt round-robin to the 8 XCDs (block b
+// runs on XCD b % 8, each with its own 4 MB L2).  The tiles of every problem are first put into "super-tile" order
+// (groups of 4 x 8 tiles, groups walked down a column of groups first), the concatenated list is cut into 8 equal
+// chunks, and the k-th unit of work (k = block + i * grid) takes the (k / 8)-th tile of chunk k % 8: the 32 blocks of
+// an XCD work on spatially adjacent tiles at the same time, and on the rows just below right after, so the 8-row /
+// 14-column halo overlap of neighbouring tiles is served by that XCD's L2 instead of being fetched again.
+const int32_t* tile_schedule(asep_aru* m, const Res8Args& a, int nblocks) {
+    if (!m->use_xcd_sched || nblocks % 8 != 0 || a.total_tiles < 2 * nblocks) return nullptr;
+    std::string key = std::to_string(nblocks);
+    for (int i = 0; i < a.nprob; ++i) key += ":" + std::to_string(a.p[i].tiles_x) + "x" + std::to_string((a.p[i].H + R8_OH - 1) / R8_OH);
+    auto it = m->sched_cache.find(key);
+    if (it != m->sched_cache.end()) return it->second;
+    std::vector<int32_t> order;
+    order.reserve(a.total_tiles);
+    for (int i = 0; i < a.nprob; ++i) {
+        const int TX = a.p[i].tiles_x, TY = (a.p[i].H + R8_OH - 1) / R8_OH, base = a.p[i].tile_begin;
+        for (int gc = 0; gc * 8 < TX; ++gc)
+            for (int gr = 0; gr * 4 < TY; ++gr)
+                for (int r = 0; r < 4; ++r)
+                    for (int c = 0; c < 8; ++c) {
+                        const int ty = gr * 4 + r, tx = gc * 8 + c;
+                        if (ty < TY && tx < TX) order.push_back(base + ty * TX + tx);
+                    }
+    }
+    const int T = a.total_tiles;
+    std::vector<int32_t> sched(T);
+    int off[9];
+    off[0] = 0;
+    for (int x = 0; x < 8; ++x) off[x + 1] = off[x] + (T - x + 7) / 8;
+    for (int k = 0; k < T; ++k) sched[k] = order[off[k % 8] + k / 8];
+    int32_t* d = nullptr;
+    if (hipMalloc((void**)&d, (size_t)T * sizeof(int32_t)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, sched.data(), (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    m->owned.push_back(d);
+    m->sched_cache[key] = d;
+    return d;
+}
+
 void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats, bool want_pool, TL* d_out, TL* pool_out) {
     for (const Tensor& t : imgs) {
         d_out->push_back(new_tensor(m, t.H, t.W, 8));
@@ -580,6 +620,7 @@ void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>&
         std::string pname = "res8_down_kernel";
         if (m->prof_detail) pname += " unet_down_0 (conv1+3xconvR+add+pool) " + dims_of(sub);
         ProfScope ps(m, pname, flops);
+        a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus));
         if (m->bf16) hipLaunchKernelGGL(res8_down_kernel<true>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
         else hipLaunchKernelGGL(res8_down_kernel<false>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
     }
@@ -611,6 +652,7 @@ TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
         std::string pname = "res8_up_kernel";
         if (m->prof_detail) pname += " unet_up_0 (conv1[16->8]+3xconvR+add) " + dims_of(sub);
         ProfScope ps(m, pname, flops);
+        a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus));
         if (m->bf16) hipLaunchKernelGGL(res8_up_kernel<true>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
         else hipLaunchKernelGGL(res8_up_kernel<false>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
     }
@@ -911,6 +953,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     m->bf16 = cfg->compute_dtype == 1;
     if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BIGTILE")) m->big_tile = atoi(e) != 0;
     if (const char* e = getenv("ASEP_SIDE_STREAM")) m->use_side_stream = atoi(e) != 0;
     if (const char* e = getenv("ASEP_LANES")) m->num_lanes = std::max(1, std::min(4, atoi(e)));

@@ -36,7 +36,12 @@ struct Res8Args {
     const float* b1;       // [8]
     const f32x4* wr;       // convR_0..2 packed pair-fragments: [3][6 chunks][64 lanes] x 4
     const float* br;       // [3][8]
+    const int32_t* sched;  // XCD-aware schedule: the k-th unit of work (k = blockIdx.x + i * gridDim.x) is tile
+                           // sched[k]; nullptr = identity.  Blocks are dealt round-robin to the 8 XCDs, so the table
+                           // gives every XCD one compact region of the page (its halo re-reads hit its own L2).
 };
+
+__device__ __forceinline__ int res8_tile_of(const Res8Args& a, int k) { return a.sched ? a.sched[k] : k; }
 
 // one 3x3 8->8 convolution stage on LDS tiles.  IN holds rows in_r0.. of the frame, OUT rows out_r0.. ;
 // computes rows [out_r0, out_r0+NROWS) x columns [out_c0, out_c0+64).  FINAL: add T centre, store to global.
@@ -163,9 +168,12 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args
             pre[k] = v;
         }
     };
-    if ((int)blockIdx.x < a.total_tiles) image_load(blockIdx.x);
+    int tile_id = (int)blockIdx.x < a.total_tiles ? res8_tile_of(a, blockIdx.x) : 0;
+    if ((int)blockIdx.x < a.total_tiles) image_load(tile_id);
 
-    for (int tile_id = blockIdx.x; tile_id < a.total_tiles; tile_id += gridDim.x) {
+    for (int k = blockIdx.x; k < a.total_tiles; k += gridDim.x) {
+        const bool has_next = k + (int)gridDim.x < a.total_tiles;
+        const int next_id = has_next ? res8_tile_of(a, k + gridDim.x) : 0;   // requested a whole tile ahead of its use
         int pi = 0;
         while (pi + 1 < a.nprob && tile_id >= a.p[pi + 1].tile_begin) ++pi;
         const Res8Prob& P = a.p[pi];
@@ -210,8 +218,9 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args
         __syncthreads();
         res8_stage<18, false, false, false, BF>(R0, 2, R1, 3, 3, A1, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
         __syncthreads();
-        if (tile_id + (int)gridDim.x < a.total_tiles) image_load(tile_id + gridDim.x);
+        if (has_next) image_load(next_id);
         res8_stage<16, false, true, true, BF>(R1, 3, nullptr, 4, 4, A2, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, P.pool);
+        tile_id = next_id;
     }
 }
 
@@ -251,11 +260,13 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
             pf[k] = v;
         }
     };
+    int tile_id = (int)blockIdx.x < a.total_tiles ? res8_tile_of(a, blockIdx.x) : 0;
     if ((int)blockIdx.x < a.total_tiles) {
+        const int first_id = tile_id;
         int qi = 0;
-        while (qi + 1 < a.nprob && (int)blockIdx.x >= a.p[qi + 1].tile_begin) ++qi;
+        while (qi + 1 < a.nprob && first_id >= a.p[qi + 1].tile_begin) ++qi;
         const Res8Prob& Q = a.p[qi];
-        const int tq = blockIdx.x - Q.tile_begin;
+        const int tq = first_id - Q.tile_begin;
         const int qyb = tq / Q.tiles_x, qxb = tq - qyb * Q.tiles_x;
         tile_load(Q.img, Q.H, Q.W, qyb * R8_OH - 4, qxb * R8_OW - 4);
     }
@@ -263,7 +274,9 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
     const f32x4 bias1 = *reinterpret_cast<const f32x4*>(a.br + 8 + ch);
     const f32x4 bias2 = *reinterpret_cast<const f32x4*>(a.br + 16 + ch);
 
-    for (int tile_id = blockIdx.x; tile_id < a.total_tiles; tile_id += gridDim.x) {
+    for (int k = blockIdx.x; k < a.total_tiles; k += gridDim.x) {
+        const bool has_next = k + (int)gridDim.x < a.total_tiles;
+        const int next_id = has_next ? res8_tile_of(a, k + gridDim.x) : 0;   // requested a whole tile ahead of its use
         int pi = 0;
         while (pi + 1 < a.nprob && tile_id >= a.p[pi + 1].tile_begin) ++pi;
         const Res8Prob& P = a.p[pi];
@@ -272,7 +285,6 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
         const int H = P.H, W = P.W;
         const int fy0 = tyb * R8_OH - 4, fx0 = txb * R8_OW - 4;
 
-        const int next_id = tile_id + gridDim.x;
         // t accumulators of this wave's pair-units (row pairs 1..22 x 2 n-tiles = 22 units; <= 3 per wave)
         f32x4 tacc[3][2];
 #pragma unroll
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
         __syncthreads();
         res8_stage<18, false, false, false, BF>(R0, 2, Pb, 3, 3, A1, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
         __syncthreads();
-        if (next_id < a.total_tiles) {                       // next tile's skip half flies under the last stage
+        if (has_next) {                                      // next tile's skip half flies under the last stage
             int qi = 0;
             while (qi + 1 < a.nprob && next_id >= a.p[qi + 1].tile_begin) ++qi;
             const Res8Prob& Q = a.p[qi];
@@ -349,6 +361,7 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
             tile_load(Q.img, Q.H, Q.W, qyb * R8_OH - 4, qxb * R8_OW - 4);
         }
         res8_stage<16, false, true, false, BF>(Pb, 3, nullptr, 4, 4, A2, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, nullptr);
+        tile_id = next_id;
     }
 }
 
