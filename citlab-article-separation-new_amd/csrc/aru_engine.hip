@@ -89,8 +89,6 @@ struct asep_aru {
     // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
     struct ProfRec { int kid; double flops; hipEvent_t a, b; };
     int num_cus = 256;
-    int persist_mt1 = 3, persist_mt2 = 2;   // resident blocks per CU assumed by the persistent conv grids
-    int wino_blocks = 512;         // resident Winograd blocks (256 CUs x 2); ASEP_WINO_BLOCKS overrides
     bool big_tile = true;          // ASEP_BIGTILE=0 disables the 16x32 single-buffer variant
     bool use_xcd_sched = true;     // ASEP_XCD_SCHED=0: identity tile order in the persistent fused kernels
     std::map<std::string, const int32_t*> sched_cache;
@@ -969,9 +967,6 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
         m->lanes.push_back(std::move(L));
     }
     m->cur = m->lanes[0].get();
-    if (const char* e = getenv("ASEP_PERSIST1")) m->persist_mt1 = std::max(1, atoi(e));
-    if (const char* e = getenv("ASEP_PERSIST2")) m->persist_mt2 = std::max(1, atoi(e));
-    if (const char* e = getenv("ASEP_WINO_BLOCKS")) m->wino_blocks = std::max(1, atoi(e));
     int rc = ASEP_OK;
     const int n = cfg->scale_space_num;
     if (cfg->use_attention) {

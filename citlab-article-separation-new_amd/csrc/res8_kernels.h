@@ -97,11 +97,7 @@ __device__ __forceinline__ void res8_stage(const float* __restrict__ IN, int in_
             v1 = relu4(v1 + *reinterpret_cast<const f32x4*>(tp + R8_PITCH * 8));
             const int gy0 = fy0 + row0;
             // only the OW valid columns of the tile (frame columns 4 .. 4+OW-1) are stored
-#ifdef R8_ABL_ST
-            const bool okx = col >= 4 && col < 4 + R8_OW && gx < W && gy0 < -5;
-#else
             const bool okx = col >= 4 && col < 4 + R8_OW && gx < W;
-#endif
             if (okx && gy0 < H) *reinterpret_cast<f32x4*>(gout + ((size_t)gy0 * W + gx) * 8 + ch) = v0;
             if (okx && gy0 + 1 < H) *reinterpret_cast<f32x4*>(gout + ((size_t)(gy0 + 1) * W + gx) * 8 + ch) = v1;
             if (POOL && gpool) {
@@ -162,9 +158,7 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args
             const int r = i / R8_IMGP, c = i - r * R8_IMGP;
             const int gy = qy0 + r, gx = qx0 + c - 2;
             float v = 0.f;
-#ifndef R8_ABL_IMG
             if (i < R8_FH * R8_IMGP && gy >= 0 && gy < Q.H && gx >= 0 && gx < Q.W) v = (Q.img[(size_t)gy * Q.W + gx] - mean) * inv;
-#endif
             pre[k] = v;
         }
     };
@@ -196,9 +190,6 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args
             float acc[8];
 #pragma unroll
             for (int o = 0; o < 8; ++o) acc[o] = w1s[72 + o];
-#ifdef R8_ABL_T
-            if (a.nprob < 0)
-#endif
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
