@@ -119,3 +119,27 @@ def test_bf16_mfma_variant_within_stated_tolerance(H, W):
     m_bf = aru_oracle.apply_threshold(aru_oracle.to_uint8(out_bf), 0.5)
     m_ref = aru_oracle.apply_threshold(aru_oracle.to_uint8(ref), 0.5)
     assert (m_bf != m_ref).mean() <= 0.05
+
+
+@pytest.mark.parametrize("kw", [
+    {"feat_root": 16}, {"res_depth": 2}, {"res_depth": 4}, {"scale_space_num": 3},
+    {"scale_space_num": 6, "num_scales_att": 5},            # the upstream ARU-Net paper layout
+    {"n_classes": 3}, {"n_classes": 1}, {"num_scales_att": 2}, {"scale_space_num": 2}, {"scale_space_num": 1, "graph": "RU"},
+], ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
+def test_non_default_hyper_parameters(kw):
+    """ARU_v1.py:35-43 graph_params other than the defaults (the shipped nets' true values are unknown)."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from oracle import aru_oracle
+    cfg, w, graph = _setup(kw, seed=3)
+    img = _image(150, 131, 9)
+    out = helper.get_net_output(img, graph, "0")
+    ref = aru_oracle.forward_torch(img, w, cfg)
+    assert out.shape == (150, 131, cfg.n_classes)
+    assert np.abs(out - ref).max() <= PROB_TOL
+
+
+def test_unsupported_width_is_rejected_loudly():
+    from citlab_article_separation_new_amd import _lib, net_post_processing_helper as helper
+    cfg, w, graph = _setup({"feat_root": 4})
+    with pytest.raises(_lib.AsepError):
+        helper.get_net_output(_image(32, 32, 0), graph, "0")
