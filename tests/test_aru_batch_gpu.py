@@ -61,3 +61,34 @@ def test_fused_block_tile_boundaries(H, W):
         assert float(np.abs(got - inter[name]).max()) <= 2e-5 * scale, name
     assert float(np.abs(out - ref).max()) <= 1e-4
     graph.close()
+
+
+@pytest.mark.parametrize("graph,ch,cw,margin", [("RU", 1620, 1592, 512), ("ARU", 2068, 2104, 896)])
+def test_full_page_interior_matches_oracle_on_a_crop(graph, ch, cw, margin):
+    """BASELINE size (3000x4500): the oracle cannot run a whole page in test time, but the net is translation
+    equivariant for shifts that are multiples of 64 px (2x2 pools over 5 levels x 4 for the scale pyramid), and its
+    receptive field is bounded (radius ~210 px per scale, x4 for scale 2): the page's interior must equal the
+    oracle's output on a crop around it, away from the crop's own borders.  The crop differs from the page by
+    multiples of 64 in both dimensions, so every level has the page's size parity (TF's SAME transposed convolution
+    pads by one more row / column when the output size is odd)."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper, synth
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    from oracle import aru_oracle
+    cfg = AruConfig(graph=graph)
+    w = init_aru_weights(cfg, 1234, bias_jitter=0.05, logit_scale=0.05)
+    g = helper.AruGraph(w, cfg)
+    H, W = 4500, 3000
+    page = synth.synth_page(0, W, H).astype(np.float32) / 255.0
+    out = helper.get_net_output(page, g, "0")
+    assert out.shape == (H, W, 2) and np.isfinite(out).all()
+    y0, x0 = 1280, 448                                   # multiples of 64
+    assert (H - ch) % 64 == 0 and (W - cw) % 64 == 0
+    sub = np.ascontiguousarray(page[y0:y0 + ch, x0:x0 + cw])
+    ref = aru_oracle.forward_torch(sub, w, cfg)
+    iy, ix = slice(margin, ch - margin), slice(margin, cw - margin)
+    got = out[y0:y0 + ch, x0:x0 + cw][iy, ix]
+    err = np.abs(got - ref[iy, ix]).max()
+    assert err <= 1e-4, err
+    # and the run is bit-reproducible (no atomics on the float path)
+    assert np.array_equal(out, helper.get_net_output(page, g, "0"))
