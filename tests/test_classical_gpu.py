@@ -250,3 +250,62 @@ def test_swt_line_features_overflow_falls_back_to_the_host():
     sw, hh = image_ops.swt_line_features(swt, [[0, 0, 900, 200], [90, 40, 130, 80]])
     assert (sw[0], hh[0]) == co.swt_features_textline(swt, (0, 0, 899, 199))
     assert (sw[1], hh[1]) == co.swt_features_textline(swt, (90, 40, 39, 39))
+
+
+def _spiral(n):
+    m = np.zeros((n, n), np.uint8)
+    x0, y0, x1, y1 = 0, 0, n - 1, n - 1
+    while x0 <= x1 and y0 <= y1:
+        m[y0, x0:x1 + 1] = 255
+        m[y0:y1 + 1, x1] = 255
+        if y1 > y0:
+            m[y1, x0 + 2:x1 + 1] = 255
+        if x1 > x0 + 2 and y1 > y0 + 2:
+            m[y0 + 2:y1 + 1, x0 + 2] = 255
+        x0, y0, x1, y1 = x0 + 4, y0 + 4, x1 - 4, y1 - 4    # loosely nested rings joined at one corner each turn
+        if x0 <= x1:
+            m[y0 - 2, x0 - 2:x0 + 1] = 255
+            m[y0 - 2:y0 + 1, x0] = 255
+    return m
+
+
+@pytest.mark.parametrize("name", ["spiral", "diagonals", "comb", "checker", "staircase"])
+def test_cc_filter_adversarial_shapes(name):
+    """Shapes that stress the lock-free union-find: long dependency chains, components that only connect through
+    diagonal pixels, thousands of runs merging into one root, and many tiny components."""
+    from citlab_article_separation_new_amd import image_ops
+    from oracle import classical_oracle as co
+    n = 257
+    if name == "spiral":
+        m = _spiral(n)
+    elif name == "diagonals":
+        m = np.zeros((n, n), np.uint8)
+        idx = np.arange(n)
+        m[idx, idx] = 255
+        m[idx, (n - 1 - idx)] = 255
+        m[idx[:-3], idx[:-3] + 3] = 255
+    elif name == "comb":
+        m = np.zeros((n, n), np.uint8)
+        m[:, ::2] = 255                                   # 129 vertical teeth ...
+        m[n - 1, :] = 255                                 # ... joined only by the last row
+    elif name == "checker":
+        m = (np.indices((n, n)).sum(axis=0) % 2 * 255).astype(np.uint8)   # one diagonal-connected component
+    else:
+        m = np.zeros((n, n), np.uint8)
+        for k in range(0, n - 2, 2):
+            m[k, k:k + 2] = 255
+            m[k + 1, k + 1:k + 3] = 255
+    for min_size in (1, 50, 5000, n * n):
+        got = image_ops.apply_cc_analysis(m, min_size / m.size * (1 + 1e-9))
+        assert np.array_equal(got, co.cc_filter(m, min_size)), (name, min_size)
+
+
+def test_swt_line_features_on_adversarial_crop():
+    from citlab_article_separation_new_amd import image_ops
+    from oracle import classical_oracle as co
+    swt = (_spiral(200) // 255 * 5).astype(np.uint8)
+    swt[::7, ::5] = 9
+    boxes = [[0, 0, 200, 200], [10, 10, 150, 60], [100, 0, 200, 200]]
+    sw, hh = image_ops.swt_line_features(swt, boxes)
+    for i, (x0, y0, x1, y1) in enumerate(boxes):
+        assert (sw[i], hh[i]) == co.swt_features_textline(swt, (x0, y0, x1 - x0 - 1, y1 - y0 - 1))
