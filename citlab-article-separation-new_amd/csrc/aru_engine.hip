@@ -558,16 +558,16 @@ int pack_res8(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
 // chunks, and the k-th unit of work (k = block + i * grid) takes the (k / 8)-th tile of chunk k % 8: the 32 blocks of
 // an XCD work on spatially adjacent tiles at the same time, and on the rows just below right after, so the 8-row /
 // 14-column halo overlap of neighbouring tiles is served by that XCD's L2 instead of being fetched again.
-const int32_t* tile_schedule(asep_aru* m, const Res8Args& a, int nblocks) {
+const int32_t* tile_schedule(asep_aru* m, const Res8Args& a, int nblocks, int unit_h) {
     if (!m->use_xcd_sched || nblocks % 8 != 0 || a.total_tiles < 2 * nblocks) return nullptr;
-    std::string key = std::to_string(nblocks);
-    for (int i = 0; i < a.nprob; ++i) key += ":" + std::to_string(a.p[i].tiles_x) + "x" + std::to_string((a.p[i].H + R8_OH - 1) / R8_OH);
+    std::string key = std::to_string(nblocks) + "/" + std::to_string(unit_h);
+    for (int i = 0; i < a.nprob; ++i) key += ":" + std::to_string(a.p[i].tiles_x) + "x" + std::to_string((a.p[i].H + unit_h - 1) / unit_h);
     auto it = m->sched_cache.find(key);
     if (it != m->sched_cache.end()) return it->second;
     std::vector<int32_t> order;
     order.reserve(a.total_tiles);
     for (int i = 0; i < a.nprob; ++i) {
-        const int TX = a.p[i].tiles_x, TY = (a.p[i].H + R8_OH - 1) / R8_OH, base = a.p[i].tile_begin;
+        const int TX = a.p[i].tiles_x, TY = (a.p[i].H + unit_h - 1) / unit_h, base = a.p[i].tile_begin;
         for (int gc = 0; gc * 8 < TX; ++gc)
             for (int gr = 0; gr * 4 < TY; ++gr)
                 for (int r = 0; r < 4; ++r)
@@ -607,7 +607,7 @@ void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>&
             p.H = imgs[i].H; p.W = imgs[i].W;
             p.tiles_x = cdiv(imgs[i].W, R8_OW);
             p.tile_begin = tiles;
-            tiles += p.tiles_x * cdiv(imgs[i].H, R8_OH);
+            tiles += p.tiles_x * cdiv(imgs[i].H, R8_OH * R8_NP);
             flops += 2.0 * imgs[i].H * imgs[i].W * (9.0 * 8 + 3 * 9.0 * 64);
         }
         a.nprob = (int)(b1 - b0);
@@ -618,7 +618,7 @@ void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>&
         std::string pname = "res8_down_kernel";
         if (m->prof_detail) pname += " unet_down_0 (conv1+3xconvR+add+pool) " + dims_of(sub);
         ProfScope ps(m, pname, flops);
-        a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus));
+        a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH * R8_NP);
         if (m->bf16) hipLaunchKernelGGL(res8_down_kernel<true>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
         else hipLaunchKernelGGL(res8_down_kernel<false>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
     }
@@ -650,7 +650,7 @@ TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
         std::string pname = "res8_up_kernel";
         if (m->prof_detail) pname += " unet_up_0 (conv1[16->8]+3xconvR+add) " + dims_of(sub);
         ProfScope ps(m, pname, flops);
-        a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus));
+        a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH);
         if (m->bf16) hipLaunchKernelGGL(res8_up_kernel<true>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
         else hipLaunchKernelGGL(res8_up_kernel<false>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
     }

@@ -19,6 +19,11 @@ constexpr int R8_PITCH = 72;                   // pixels per LDS row (frame colu
 constexpr int R8_IMGP = 76;                    // image tile pitch (frame columns -2..73)
 constexpr int R8_WAVES = 8;                    // 512 threads: two waves per SIMD hide the LDS->MFMA latency
 constexpr int R8_THREADS = R8_WAVES * 64;
+constexpr int R8_NP = 4;                       // vertical passes per work unit: a unit is R8_NP * R8_OH = 64 rows x 58 columns.
+                                               // Pass 0 recomputes the 4-row halo above the unit; every further pass
+                                               // carries the 2-3 bottom rows of t / r0 / r1 over from the pass above
+                                               // instead of recomputing them: 16 rows per stage (two units per wave,
+                                               // perfectly balanced) instead of 22 / 20 / 18 / 16.
 
 struct Res8Prob {
     const float* img;      // DOWN: [H,W] single-channel input.  UP: skip tensor d0 [H,W,8]
@@ -44,17 +49,17 @@ struct Res8Args {
 __device__ __forceinline__ int res8_tile_of(const Res8Args& a, int k) { return a.sched ? a.sched[k] : k; }
 
 // one 3x3 8->8 convolution stage on LDS tiles.  IN holds rows in_r0.. of the frame, OUT rows out_r0.. ;
-// computes rows [out_r0, out_r0+NROWS) x columns [out_c0, out_c0+64).  FINAL: add T centre, store to global.
+// computes rows [row_start, row_start+NROWS) x columns [out_c0, out_c0+64).  FINAL: add T centre, store to global.
 template <int NROWS, bool RELU_IN, bool FINAL, bool POOL, bool BF = false>
 __device__ __forceinline__ void res8_stage(const float* __restrict__ IN, int in_r0, float* __restrict__ OUT, int out_r0,
-                                           int out_c0, const f32x4 (&A)[6], const f32x4 bias4, int wave, int lane,
+                                           int row_start, int out_c0, const f32x4 (&A)[6], const f32x4 bias4, int wave, int lane,
                                            int fy0, int fx0, int H, int W, const float* __restrict__ T, int t_r0,
                                            float* __restrict__ gout, float* __restrict__ gpool) {
     const int j = lane & 15, kk = lane >> 4;
     const int e = kk >> 1, ch = (kk & 1) * 4;
     for (int pu = wave; pu < NROWS; pu += R8_WAVES) {   // pu enumerates (row pair, n-tile): NROWS/2 pairs x 2 n-tiles
         const int rp = pu >> 1, nt = pu & 1;
-        const int row0 = out_r0 + 2 * rp;            // rows row0, row0+1
+        const int row0 = row_start + 2 * rp;         // rows row0, row0+1
         const int colb = out_c0 + nt * 32 + 2 * j;   // this lane's pixel pair starts at colb
         f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -143,13 +148,14 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args
 
     constexpr int NPRE = (R8_FH * R8_IMGP + R8_THREADS - 1) / R8_THREADS;
     float pre[NPRE];
-    auto image_load = [&](int tile_id) {                    // next tile's image values -> registers (in flight under the MFMA stages)
+    // frame = one 24-row window of a work unit: (tile, pass) -> image rows [(tyb * NP + pass) * OH - 4, +24)
+    auto image_load = [&](int tile_id, int pass) {          // next frame's image values -> registers (in flight under the MFMA stages)
         int pi = 0;
         while (pi + 1 < a.nprob && tile_id >= a.p[pi + 1].tile_begin) ++pi;
         const Res8Prob& Q = a.p[pi];
         const int t = tile_id - Q.tile_begin;
         const int tyb = t / Q.tiles_x, txb = t - tyb * Q.tiles_x;
-        const int qy0 = tyb * R8_OH - 4, qx0 = txb * R8_OW - 4;
+        const int qy0 = (tyb * R8_NP + pass) * R8_OH - 4, qx0 = txb * R8_OW - 4;
         float mean = 0.f, inv = 1.f;
         if (Q.stats) { mean = Q.stats[0]; inv = Q.stats[1]; }
 #pragma unroll
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args
         }
     };
     int tile_id = (int)blockIdx.x < a.total_tiles ? res8_tile_of(a, blockIdx.x) : 0;
-    if ((int)blockIdx.x < a.total_tiles) image_load(tile_id);
+    if ((int)blockIdx.x < a.total_tiles) image_load(tile_id, 0);
 
     for (int k = blockIdx.x; k < a.total_tiles; k += gridDim.x) {
         const bool has_next = k + (int)gridDim.x < a.total_tiles;
@@ -174,43 +180,66 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args
         const int t = tile_id - P.tile_begin;
         const int tyb = t / P.tiles_x, txb = t - tyb * P.tiles_x;
         const int H = P.H, W = P.W;
-        const int fy0 = tyb * R8_OH - 4, fx0 = txb * R8_OW - 4;      // image coordinates of frame (0,0)
-        __syncthreads();                                     // previous tile finished with all LDS buffers
-        // ---- image tile: frame rows 0..23, frame columns -2..73 (zero outside the image = SAME padding) ----
-#pragma unroll
-        for (int k = 0; k < NPRE; ++k) {
-            const int i = tid + k * R8_THREADS;
-            if (i < R8_FH * R8_IMGP) IMG[i] = pre[k];
-        }
-        __syncthreads();
-        // ---- t = conv1(image) (identity activation), frame rows 1..22, all 72 columns; zero outside the image ----
-        for (int i = tid; i < 22 * R8_PITCH; i += R8_THREADS) {
-            const int r = i / R8_PITCH, c = i - r * R8_PITCH;   // frame row r+1, frame column c
-            const int gy = fy0 + r + 1, gx = fx0 + c;
-            float acc[8];
-#pragma unroll
-            for (int o = 0; o < 8; ++o) acc[o] = w1s[72 + o];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float v = IMG[(r + ky) * R8_IMGP + c + kx + 1];       // frame (r+1+ky-1, c+kx-1) -> IMG col +2
-#pragma unroll
-                    for (int o = 0; o < 8; ++o) acc[o] = fmaf(v, w1s[(ky * 3 + kx) * 8 + o], acc[o]);
+        const int fx0 = txb * R8_OW - 4;
+#pragma unroll 1
+        for (int pass = 0; pass < R8_NP; ++pass) {
+            const int fy0 = (tyb * R8_NP + pass) * R8_OH - 4;        // image coordinates of frame (0,0)
+            if (fy0 + 4 >= H) break;                                 // no output rows left in this unit
+            const bool more_passes = pass + 1 < R8_NP && fy0 + 4 + R8_OH < H;
+            const bool first = pass == 0;
+            __syncthreads();                                 // previous pass / tile finished with all LDS buffers
+            if (!first) {
+                // rows carried over from the pass above (frame rows shift by OH = 16):
+                //   t  rows 20..22 -> 4..6,   r0 rows 20,21 -> 4,5,   r1 rows 19,20 -> 3,4
+                constexpr int ROWV = R8_PITCH * 2;                   // f32x4 per row
+                for (int i = tid; i < 7 * ROWV; i += R8_THREADS) {
+                    const int r = i / ROWV, c = i - r * ROWV;
+                    f32x4* base = reinterpret_cast<f32x4*>(r < 3 ? T : (r < 5 ? R0 : R1));
+                    const int src = r < 3 ? 19 + r : (r < 5 ? 18 + (r - 3) : 16 + (r - 5));
+                    const int dst = r < 3 ? 3 + r : (r < 5 ? 2 + (r - 3) : (r - 5));
+                    base[dst * ROWV + c] = base[src * ROWV + c];
                 }
-            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            f32x4 lo = ok ? f32x4{acc[0], acc[1], acc[2], acc[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 hi = ok ? f32x4{acc[4], acc[5], acc[6], acc[7]} : f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(T + i * 8) = lo;
-            *reinterpret_cast<f32x4*>(T + i * 8 + 4) = hi;
+            }
+            // ---- image tile: frame rows 0..23, frame columns -2..73 (zero outside the image = SAME padding) ----
+#pragma unroll
+            for (int q = 0; q < NPRE; ++q) {
+                const int i = tid + q * R8_THREADS;
+                if (i < R8_FH * R8_IMGP) IMG[i] = pre[q];
+            }
+            __syncthreads();
+            // ---- t = conv1(image) (identity activation): frame rows 1..22 (first pass) or the 16 new rows 7..22 ----
+            const int t_lo = first ? 0 : 6 * R8_PITCH;
+            for (int i = t_lo + tid; i < 22 * R8_PITCH; i += R8_THREADS) {
+                const int r = i / R8_PITCH, c = i - r * R8_PITCH;   // frame row r+1, frame column c
+                const int gy = fy0 + r + 1, gx = fx0 + c;
+                float acc[8];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) acc[o] = w1s[72 + o];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float v = IMG[(r + ky) * R8_IMGP + c + kx + 1];       // frame (r+1+ky-1, c+kx-1) -> IMG col +2
+#pragma unroll
+                        for (int o = 0; o < 8; ++o) acc[o] = fmaf(v, w1s[(ky * 3 + kx) * 8 + o], acc[o]);
+                    }
+                const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                f32x4 lo = ok ? f32x4{acc[0], acc[1], acc[2], acc[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 hi = ok ? f32x4{acc[4], acc[5], acc[6], acc[7]} : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(T + i * 8) = lo;
+                *reinterpret_cast<f32x4*>(T + i * 8 + 4) = hi;
+            }
+            __syncthreads();
+            if (first) res8_stage<20, true, false, false, BF>(T, 1, R0, 2, 2, 2, A0, bias0, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            else res8_stage<16, true, false, false, BF>(T, 1, R0, 2, 6, 2, A0, bias0, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            __syncthreads();
+            if (first) res8_stage<18, false, false, false, BF>(R0, 2, R1, 3, 3, 3, A1, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            else res8_stage<16, false, false, false, BF>(R0, 2, R1, 3, 5, 3, A1, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            __syncthreads();
+            if (more_passes) image_load(tile_id, pass + 1);
+            else if (has_next) image_load(next_id, 0);
+            res8_stage<16, false, true, true, BF>(R1, 3, nullptr, 4, 4, 4, A2, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, P.pool);
         }
-        __syncthreads();
-        res8_stage<20, true, false, false, BF>(T, 1, R0, 2, 2, A0, bias0, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
-        __syncthreads();
-        res8_stage<18, false, false, false, BF>(R0, 2, R1, 3, 3, A1, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
-        __syncthreads();
-        if (has_next) image_load(next_id);
-        res8_stage<16, false, true, true, BF>(R1, 3, nullptr, 4, 4, A2, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, P.pool);
         tile_id = next_id;
     }
 }
@@ -339,9 +368,9 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
             }
         }
         __syncthreads();
-        res8_stage<20, true, false, false, BF>(T, 1, R0, 2, 2, A0, bias0, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+        res8_stage<20, true, false, false, BF>(T, 1, R0, 2, 2, 2, A0, bias0, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
         __syncthreads();
-        res8_stage<18, false, false, false, BF>(R0, 2, Pb, 3, 3, A1, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+        res8_stage<18, false, false, false, BF>(R0, 2, Pb, 3, 3, 3, A1, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
         __syncthreads();
         if (has_next) {                                      // next tile's skip half flies under the last stage
             int qi = 0;
@@ -351,7 +380,7 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
             const int qyb = tq / Q.tiles_x, qxb = tq - qyb * Q.tiles_x;
             tile_load(Q.img, Q.H, Q.W, qyb * R8_OH - 4, qxb * R8_OW - 4);
         }
-        res8_stage<16, false, true, false, BF>(Pb, 3, nullptr, 4, 4, A2, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, nullptr);
+        res8_stage<16, false, true, false, BF>(Pb, 3, nullptr, 4, 4, 4, A2, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, nullptr);
         tile_id = next_id;
     }
 }
