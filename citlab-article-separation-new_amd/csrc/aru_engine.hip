@@ -639,7 +639,7 @@ TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
             p.H = skip[i].H; p.W = skip[i].W;
             p.tiles_x = cdiv(skip[i].W, R8_OW);
             p.tile_begin = tiles;
-            tiles += p.tiles_x * cdiv(skip[i].H, R8_OH);
+            tiles += p.tiles_x * cdiv(skip[i].H, R8_OH * R8_NP);
             flops += 2.0 * skip[i].H * skip[i].W * (9.0 * 16 * 8 + 3 * 9.0 * 64);
         }
         a.nprob = (int)(b1 - b0);
@@ -650,7 +650,7 @@ TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
         std::string pname = "res8_up_kernel";
         if (m->prof_detail) pname += " unet_up_0 (conv1[16->8]+3xconvR+add) " + dims_of(sub);
         ProfScope ps(m, pname, flops);
-        a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH);
+        a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH * R8_NP);
         if (m->bf16) hipLaunchKernelGGL(res8_up_kernel<true>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
         else hipLaunchKernelGGL(res8_up_kernel<false>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
     }

@@ -253,6 +253,7 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
     float* Pb = sm;                                          // frame rows 0..23  [24][72][8]  (later r1: rows 3..20)
     float* T = Pb + R8_FH * R8_PITCH * 8;                    // frame rows 1..22  [22][72][8]
     float* R0 = T + 22 * R8_PITCH * 8;                       // frame rows 2..21  [20][72][8]
+    float* R1K = R0 + 20 * R8_PITCH * 8;                     // two r1 rows parked between passes [2][72][8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
     const int e = kk >> 1, ch = (kk & 1) * 4;
@@ -264,7 +265,6 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
         A1[c] = a.wr[(1 * 6 + c) * 64 + lane];
         A2[c] = a.wr[(2 * 6 + c) * 64 + lane];
     }
-    const f32x4 biasT = *reinterpret_cast<const f32x4*>(a.b1 + ch);
     constexpr int NPF = (R8_FH * R8_PITCH * 2 + R8_THREADS - 1) / R8_THREADS;
     f32x4 pf[NPF];
     auto tile_load = [&](const float* __restrict__ g, int H_, int W_, int qy0, int qx0) {   // 8-channel halo tile -> registers
@@ -288,11 +288,16 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
         const Res8Prob& Q = a.p[qi];
         const int tq = first_id - Q.tile_begin;
         const int qyb = tq / Q.tiles_x, qxb = tq - qyb * Q.tiles_x;
-        tile_load(Q.img, Q.H, Q.W, qyb * R8_OH - 4, qxb * R8_OW - 4);
+        tile_load(Q.img, Q.H, Q.W, qyb * R8_NP * R8_OH - 4, qxb * R8_OW - 4);
     }
-    const f32x4 bias0 = *reinterpret_cast<const f32x4*>(a.br + 0 + ch);
-    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(a.br + 8 + ch);
-    const f32x4 bias2 = *reinterpret_cast<const f32x4*>(a.br + 16 + ch);
+    // the stage biases are re-read from L2 at each use (16 VGPRs that would otherwise live across the whole loop)
+    const float* __restrict__ brp = a.br + ch;
+    auto bias_of = [&](int s) {
+        const float* q = brp + 8 * s;
+        asm volatile("" : "+v"(q));                          // keep the load inside the loop
+        return *reinterpret_cast<const f32x4*>(q);
+    };
+    constexpr int ROWV = R8_PITCH * 2;                       // f32x4 per LDS row
 
     for (int k = blockIdx.x; k < a.total_tiles; k += gridDim.x) {
         const bool has_next = k + (int)gridDim.x < a.total_tiles;
@@ -303,89 +308,124 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
         const int t = tile_id - P.tile_begin;
         const int tyb = t / P.tiles_x, txb = t - tyb * P.tiles_x;
         const int H = P.H, W = P.W;
-        const int fy0 = tyb * R8_OH - 4, fx0 = txb * R8_OW - 4;
+        const int fx0 = txb * R8_OW - 4;
+#pragma unroll 1
+        for (int pass = 0; pass < R8_NP; ++pass) {
+            const int fy0 = (tyb * R8_NP + pass) * R8_OH - 4;
+            if (fy0 + 4 >= H) break;                         // no output rows left in this unit
+            const bool more_passes = pass + 1 < R8_NP && fy0 + 4 + R8_OH < H;
+            const bool first = pass == 0;
+            // conv1 covers frame rows 1..22 in the first pass and only the 16 new rows 7..22 afterwards
+            const int c1_row = first ? 1 : 7, c1_units = first ? 22 : 16;
 
-        // t accumulators of this wave's pair-units (row pairs 1..22 x 2 n-tiles = 22 units; <= 3 per wave)
-        f32x4 tacc[3][2];
+            // t accumulators of this wave's pair-units (<= 3 per wave)
+            f32x4 tacc[3][2];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { tacc[q][0] = f32x4{0.f, 0.f, 0.f, 0.f}; tacc[q][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int q = 0; q < 3; ++q) { tacc[q][0] = f32x4{0.f, 0.f, 0.f, 0.f}; tacc[q][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
 #pragma unroll
-        for (int src = 0; src < 2; ++src) {
-            __syncthreads();                                 // the tile buffer is free (previous pass / previous tile done)
+            for (int src = 0; src < 2; ++src) {
+                __syncthreads();                             // the tile buffer is free (previous pass / previous tile done)
+                if (src == 0 && !first) {
+                    // rows carried over from the pass above: t rows 20..22 -> 4..6, r0 rows 20,21 -> 4,5
+                    // (r1 rows 19,20 were parked in R1K during the previous pass' last stage)
+                    for (int i = tid; i < 5 * ROWV; i += R8_THREADS) {
+                        const int r = i / ROWV, c = i - r * ROWV;
+                        f32x4* base = reinterpret_cast<f32x4*>(r < 3 ? T : R0);
+                        const int srow = r < 3 ? 19 + r : 18 + (r - 3), drow = r < 3 ? 3 + r : 2 + (r - 3);
+                        base[drow * ROWV + c] = base[srow * ROWV + c];
+                    }
+                }
 #pragma unroll
-            for (int k = 0; k < NPF; ++k) {
-                const int i = tid + k * R8_THREADS;
-                if (i < R8_FH * R8_PITCH * 2) *reinterpret_cast<f32x4*>(Pb + i * 4) = pf[k];
+                for (int q = 0; q < NPF; ++q) {
+                    const int i = tid + q * R8_THREADS;
+                    if (i < R8_FH * R8_PITCH * 2) *reinterpret_cast<f32x4*>(Pb + i * 4) = pf[q];
+                }
+                if (src == 0) tile_load(P.in1, H, W, fy0, fx0);  // the deconv half flies while the skip half is multiplied
+                __syncthreads();
+                f32x4 Aw[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) Aw[c] = w1[(src * 6 + c) * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int pu = wave + q * R8_WAVES;
+                    if (pu < c1_units) {
+                        const int rp = pu >> 1, nt = pu & 1;
+                        const int row0 = c1_row + 2 * rp;
+                        const int colb = 1 + nt * 32 + 2 * j;
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const float* p0 = Pb + ((row0 + ky - 1) * R8_PITCH + colb + 2 * h + e - 1) * 8 + ch;
+                                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p0);
+                                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p0 + R8_PITCH * 8);
+                                if constexpr (BF) {
+                                    const s16x4 pa = bf16pack(Aw[ky * 2 + h]);
+                                    tacc[q][0] = mfma_bf16(pa, bf16pack(b0), tacc[q][0]);
+                                    tacc[q][1] = mfma_bf16(pa, bf16pack(b1), tacc[q][1]);
+                                } else {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        tacc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[ky * 2 + h][r], b0[r], tacc[q][0], 0, 0, 0);
+                                        tacc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[ky * 2 + h][r], b1[r], tacc[q][1], 0, 0, 0);
+                                    }
+                                }
+                            }
+                    }
+                }
             }
-            if (src == 0) tile_load(P.in1, H, W, fy0, fx0);  // the deconv half flies while the skip half is multiplied
-            __syncthreads();
-            f32x4 Aw[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) Aw[c] = w1[(src * 6 + c) * 64 + lane];
+            // ---- write raw t (identity activation), zero outside the image ----
+            const f32x4 biasT = *reinterpret_cast<const f32x4*>(a.b1 + ch);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int pu = wave + q * R8_WAVES;
-                if (pu < 22) {
+                if (pu < c1_units) {
                     const int rp = pu >> 1, nt = pu & 1;
-                    const int row0 = 1 + 2 * rp;
-                    const int colb = 1 + nt * 32 + 2 * j;
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const float* p0 = Pb + ((row0 + ky - 1) * R8_PITCH + colb + 2 * h + e - 1) * 8 + ch;
-                            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p0);
-                            const f32x4 b1 = *reinterpret_cast<const f32x4*>(p0 + R8_PITCH * 8);
-                            if constexpr (BF) {
-                                const s16x4 pa = bf16pack(Aw[ky * 2 + h]);
-                                tacc[q][0] = mfma_bf16(pa, bf16pack(b0), tacc[q][0]);
-                                tacc[q][1] = mfma_bf16(pa, bf16pack(b1), tacc[q][1]);
-                            } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                tacc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[ky * 2 + h][r], b0[r], tacc[q][0], 0, 0, 0);
-                                tacc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[ky * 2 + h][r], b1[r], tacc[q][1], 0, 0, 0);
-                            }
-                            }
-                        }
+                    const int row0 = c1_row + 2 * rp, col = 1 + nt * 32 + 2 * j + e;
+                    const int gy0 = fy0 + row0, gx = fx0 + col;
+                    const bool okx = gx >= 0 && gx < W;
+                    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                    float* o = T + ((row0 - 1) * R8_PITCH + col) * 8 + ch;
+                    *reinterpret_cast<f32x4*>(o) = (okx && gy0 >= 0 && gy0 < H) ? tacc[q][0] + biasT : z;
+                    *reinterpret_cast<f32x4*>(o + R8_PITCH * 8) = (okx && gy0 + 1 >= 0 && gy0 + 1 < H) ? tacc[q][1] + biasT : z;
                 }
             }
-        }
-        // ---- write raw t (identity activation), zero outside the image ----
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int pu = wave + q * R8_WAVES;
-            if (pu < 22) {
-                const int rp = pu >> 1, nt = pu & 1;
-                const int row0 = 1 + 2 * rp, col = 1 + nt * 32 + 2 * j + e;
-                const int gy0 = fy0 + row0, gx = fx0 + col;
-                const bool okx = gx >= 0 && gx < W;
-                const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-                float* o = T + ((row0 - 1) * R8_PITCH + col) * 8 + ch;
-                *reinterpret_cast<f32x4*>(o) = (okx && gy0 >= 0 && gy0 < H) ? tacc[q][0] + biasT : z;
-                *reinterpret_cast<f32x4*>(o + R8_PITCH * 8) = (okx && gy0 + 1 >= 0 && gy0 + 1 < H) ? tacc[q][1] + biasT : z;
+            __syncthreads();
+            if (first) res8_stage<20, true, false, false, BF>(T, 1, R0, 2, 2, 2, A0, bias_of(0), wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            else res8_stage<16, true, false, false, BF>(T, 1, R0, 2, 6, 2, A0, bias_of(0), wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            __syncthreads();
+            if (first) {
+                res8_stage<18, false, false, false, BF>(R0, 2, Pb, 3, 3, 3, A1, bias_of(1), wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            } else {
+                res8_stage<16, false, false, false, BF>(R0, 2, Pb, 3, 5, 3, A1, bias_of(1), wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+                // r1 rows 3,4 of this frame = rows 19,20 of the previous one (the tile buffer is free of conv1 readers here)
+                for (int i = tid; i < 2 * ROWV; i += R8_THREADS)
+                    reinterpret_cast<f32x4*>(Pb)[i] = reinterpret_cast<const f32x4*>(R1K)[i];
             }
+            __syncthreads();
+            if (more_passes) {                               // the next frame's skip half flies under the last stage
+                tile_load(P.img, H, W, fy0 + R8_OH, fx0);
+            } else if (has_next) {
+                int qi = 0;
+                while (qi + 1 < a.nprob && next_id >= a.p[qi + 1].tile_begin) ++qi;
+                const Res8Prob& Q = a.p[qi];
+                const int tq = next_id - Q.tile_begin;
+                const int qyb = tq / Q.tiles_x, qxb = tq - qyb * Q.tiles_x;
+                tile_load(Q.img, Q.H, Q.W, qyb * R8_NP * R8_OH - 4, qxb * R8_OW - 4);
+            }
+            if (more_passes) {
+                // park r1 rows 19,20 (tile-buffer rows 16,17) for the next pass: only read, like the stage below
+                for (int i = tid; i < 2 * ROWV; i += R8_THREADS)
+                    reinterpret_cast<f32x4*>(R1K)[i] = reinterpret_cast<const f32x4*>(Pb)[16 * ROWV + i];
+            }
+            res8_stage<16, false, true, false, BF>(Pb, 3, nullptr, 4, 4, 4, A2, bias_of(2), wave, lane, fy0, fx0, H, W, T, 1, P.out, nullptr);
         }
-        __syncthreads();
-        res8_stage<20, true, false, false, BF>(T, 1, R0, 2, 2, 2, A0, bias0, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
-        __syncthreads();
-        res8_stage<18, false, false, false, BF>(R0, 2, Pb, 3, 3, 3, A1, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
-        __syncthreads();
-        if (has_next) {                                      // next tile's skip half flies under the last stage
-            int qi = 0;
-            while (qi + 1 < a.nprob && next_id >= a.p[qi + 1].tile_begin) ++qi;
-            const Res8Prob& Q = a.p[qi];
-            const int tq = next_id - Q.tile_begin;
-            const int qyb = tq / Q.tiles_x, qxb = tq - qyb * Q.tiles_x;
-            tile_load(Q.img, Q.H, Q.W, qyb * R8_OH - 4, qxb * R8_OW - 4);
-        }
-        res8_stage<16, false, true, false, BF>(Pb, 3, nullptr, 4, 4, 4, A2, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, nullptr);
         tile_id = next_id;
     }
 }
 
-constexpr size_t R8_UP_LDS = (size_t)((R8_FH + 22 + 20) * R8_PITCH * 8) * sizeof(float);
+constexpr size_t R8_UP_LDS = (size_t)((R8_FH + 22 + 20 + 2) * R8_PITCH * 8) * sizeof(float);
 constexpr size_t R8_DOWN_LDS = (size_t)(R8_FH * R8_IMGP + (22 + 20 + 18) * R8_PITCH * 8) * sizeof(float);
 
 }  // namespace asep
