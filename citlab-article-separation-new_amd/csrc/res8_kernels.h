@@ -267,7 +267,8 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
     }
     constexpr int NPF = (R8_FH * R8_PITCH * 2 + R8_THREADS - 1) / R8_THREADS;
     f32x4 pf[NPF];
-    auto tile_load = [&](const float* __restrict__ g, int H_, int W_, int qy0, int qx0) {   // 8-channel halo tile -> registers
+    // row_lo: first frame row that is needed (6 for the passes that carry rows over: conv1 then reads rows 6..23 only)
+    auto tile_load = [&](const float* __restrict__ g, int H_, int W_, int qy0, int qx0, int row_lo) {   // 8-channel halo tile -> registers
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             const int i = tid + k * R8_THREADS;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
             const int r = pix / R8_PITCH, c = pix - r * R8_PITCH;
             const int gy = qy0 + r, gx = qx0 + c;
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (i < R8_FH * R8_PITCH * 2 && gy >= 0 && gy < H_ && gx >= 0 && gx < W_)
+            if (i < R8_FH * R8_PITCH * 2 && r >= row_lo && gy >= 0 && gy < H_ && gx >= 0 && gx < W_)
                 v = *reinterpret_cast<const f32x4*>(g + ((size_t)gy * W_ + gx) * 8 + half * 4);
             pf[k] = v;
         }
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
         const Res8Prob& Q = a.p[qi];
         const int tq = first_id - Q.tile_begin;
         const int qyb = tq / Q.tiles_x, qxb = tq - qyb * Q.tiles_x;
-        tile_load(Q.img, Q.H, Q.W, qyb * R8_NP * R8_OH - 4, qxb * R8_OW - 4);
+        tile_load(Q.img, Q.H, Q.W, qyb * R8_NP * R8_OH - 4, qxb * R8_OW - 4, 0);
     }
     // the stage biases are re-read from L2 at each use (16 VGPRs that would otherwise live across the whole loop)
     const float* __restrict__ brp = a.br + ch;
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
                     const int i = tid + q * R8_THREADS;
                     if (i < R8_FH * R8_PITCH * 2) *reinterpret_cast<f32x4*>(Pb + i * 4) = pf[q];
                 }
-                if (src == 0) tile_load(P.in1, H, W, fy0, fx0);  // the deconv half flies while the skip half is multiplied
+                if (src == 0) tile_load(P.in1, H, W, fy0, fx0, first ? 0 : 6);  // the deconv half flies while the skip half is multiplied
                 __syncthreads();
                 f32x4 Aw[6];
 #pragma unroll
@@ -405,14 +406,14 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
             }
             __syncthreads();
             if (more_passes) {                               // the next frame's skip half flies under the last stage
-                tile_load(P.img, H, W, fy0 + R8_OH, fx0);
+                tile_load(P.img, H, W, fy0 + R8_OH, fx0, 6);
             } else if (has_next) {
                 int qi = 0;
                 while (qi + 1 < a.nprob && next_id >= a.p[qi + 1].tile_begin) ++qi;
                 const Res8Prob& Q = a.p[qi];
                 const int tq = next_id - Q.tile_begin;
                 const int qyb = tq / Q.tiles_x, qxb = tq - qyb * Q.tiles_x;
-                tile_load(Q.img, Q.H, Q.W, qyb * R8_NP * R8_OH - 4, qxb * R8_OW - 4);
+                tile_load(Q.img, Q.H, Q.W, qyb * R8_NP * R8_OH - 4, qxb * R8_OW - 4, 0);
             }
             if (more_passes) {
                 // park r1 rows 19,20 (tile-buffer rows 16,17) for the next pass: only read, like the stage below
