@@ -8,7 +8,9 @@ from citlab_article_separation_new_amd import net_post_processing_helper as help
 H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4500, 3000)
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dtype = sys.argv[4] if len(sys.argv) > 4 else 'f32'
-cfg = AruConfig(compute_dtype=dtype)
+levels = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+att = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+cfg = AruConfig(compute_dtype=dtype, scale_space_num=levels, num_scales_att=att)
 g = helper.AruGraph(init_aru_weights(cfg, 1234), cfg)
 lib = _lib.init_device(0)
 h = g.handle(0)
@@ -24,4 +26,4 @@ for _ in range(iters): step()
 torch.cuda.synchronize()
 dt = (time.time() - t0) / iters
 fl = lib.asep_aru_flops(h, H, W)
-print(f"{H}x{W} [{dtype}]: {dt*1e3:.2f} ms/page  {1/dt:.2f} pages/s  {fl/1e9:.1f} GFLOP -> {fl/dt/1e12:.1f} TFLOP/s  mem {torch.cuda.memory_allocated()/1e9:.2f} GB torch")
+print(f"{H}x{W} [{dtype}, {levels} levels, {att} attention scales]: {dt*1e3:.2f} ms/page  {1/dt:.2f} pages/s  {fl/1e9:.1f} GFLOP -> {fl/dt/1e12:.1f} TFLOP/s  mem {torch.cuda.memory_allocated()/1e9:.2f} GB torch")
