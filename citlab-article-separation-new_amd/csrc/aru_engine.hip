@@ -90,6 +90,7 @@ struct asep_aru {
     struct ProfRec { int kid; double flops; hipEvent_t a, b; };
     int num_cus = 256;
     bool big_tile = true;          // ASEP_BIGTILE=0 disables the 16x32 single-buffer variant
+    BufferPool host_stage;         // device staging of the host-pointer entry point (grow-only)
     bool use_xcd_sched = true;     // ASEP_XCD_SCHED=0: identity tile order in the persistent fused kernels
     std::map<std::string, const int32_t*> sched_cache;
     bool bf16 = false;             // cfg.compute_dtype == 1: bf16 MFMA operands, fp32 accumulation and storage
@@ -1079,37 +1080,27 @@ int asep_aru_forward(asep_aru* m, const float* img_hw, int H, int W, float* out_
                      uint8_t* out_mask, float threshold) {
     if (!m || !img_hw || !out_hwc || H < 1 || W < 1) { set_error("asep_aru_forward: bad argument"); return ASEP_ERR_ARG; }
     const size_t npix = (size_t)H * W, nout = npix * m->cfg.n_classes;
+    // staging buffers live in the handle and only grow (a page-sized hipMalloc / hipFree pair per call costs
+    // milliseconds, comparable to the net itself on small inputs)
     float *d_img = nullptr, *d_out = nullptr;
     uint8_t *d_u8 = nullptr, *d_mask = nullptr;
-    int rc = ASEP_OK;
-    auto cleanup = [&]() {
-        if (d_img) (void)hipFree(d_img);
-        if (d_out) (void)hipFree(d_out);
-        if (d_u8) (void)hipFree(d_u8);
-        if (d_mask) (void)hipFree(d_mask);
-    };
-#define ASEP_TRY(expr)                                                                      \
-    do {                                                                                    \
-        hipError_t _e = (expr);                                                             \
-        if (_e != hipSuccess) {                                                             \
-            set_error("%s failed: %s", #expr, hipGetErrorString(_e));                       \
-            cleanup();                                                                      \
-            return ASEP_ERR_HIP;                                                            \
-        }                                                                                   \
-    } while (0)
-    ASEP_TRY(hipMalloc((void**)&d_img, npix * sizeof(float)));
-    ASEP_TRY(hipMalloc((void**)&d_out, nout * sizeof(float)));
-    if (out_u8) ASEP_TRY(hipMalloc((void**)&d_u8, nout));
-    if (out_mask) ASEP_TRY(hipMalloc((void**)&d_mask, nout));
-    ASEP_TRY(hipMemcpy(d_img, img_hw, npix * sizeof(float), hipMemcpyHostToDevice));
-    rc = asep_aru_forward_dev(m, d_img, H, W, d_out, d_u8, d_mask, threshold, nullptr);
-    if (rc) { cleanup(); return rc; }
-    ASEP_TRY(hipStreamSynchronize(nullptr));
-    ASEP_TRY(hipMemcpy(out_hwc, d_out, nout * sizeof(float), hipMemcpyDeviceToHost));
-    if (out_u8) ASEP_TRY(hipMemcpy(out_u8, d_u8, nout, hipMemcpyDeviceToHost));
-    if (out_mask) ASEP_TRY(hipMemcpy(out_mask, d_mask, nout, hipMemcpyDeviceToHost));
-#undef ASEP_TRY
-    cleanup();
+    try {
+        m->host_stage.begin();
+        d_img = (float*)m->host_stage.get(npix * sizeof(float));
+        d_out = (float*)m->host_stage.get(nout * sizeof(float));
+        d_u8 = (uint8_t*)m->host_stage.get(nout);
+        d_mask = (uint8_t*)m->host_stage.get(nout);
+    } catch (const HipError&) {
+        return ASEP_ERR_HIP;
+    }
+    ASEP_HIP_CHECK(hipMemcpy(d_img, img_hw, npix * sizeof(float), hipMemcpyHostToDevice));
+    const int rc = asep_aru_forward_dev(m, d_img, H, W, d_out, out_u8 ? d_u8 : nullptr, out_mask ? d_mask : nullptr,
+                                        threshold, nullptr);
+    if (rc) return rc;
+    ASEP_HIP_CHECK(hipStreamSynchronize(nullptr));
+    ASEP_HIP_CHECK(hipMemcpy(out_hwc, d_out, nout * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_u8) ASEP_HIP_CHECK(hipMemcpy(out_u8, d_u8, nout, hipMemcpyDeviceToHost));
+    if (out_mask) ASEP_HIP_CHECK(hipMemcpy(out_mask, d_mask, nout, hipMemcpyDeviceToHost));
     return ASEP_OK;
 }
 
