@@ -23,6 +23,7 @@ struct asep_gnn {
     bool use_step = true;             // ASEP_GNN_STEP=0 selects the separate message / LSTM kernels
     std::vector<void*> owned;
     BufferPool pool;
+    BufferPool host_stage;            // device staging of the host-pointer entry point (grow-only)
     // state of the last forward
     int N = 0, Ecorr = -1;
     float* d_h = nullptr;
@@ -311,19 +312,31 @@ int asep_gnn_forward_dev(asep_gnn* g, int N, int E, const int32_t* d_edges, cons
 int asep_gnn_forward(asep_gnn* g, int N, int E, const int32_t* edges, const float* node_feat, const float* edge_feat,
                      int R, const int32_t* relations, float* probs_out) {
     if (!g || !node_feat || (E > 0 && !edges) || (R > 0 && !probs_out)) { set_error("asep_gnn_forward: null argument"); return ASEP_ERR_ARG; }
-    DevCopy dc;
+    if (N < 1 || E < 0 || R < 0) { set_error("asep_gnn_forward: bad sizes N=%d E=%d R=%d", N, E, R); return ASEP_ERR_ARG; }
+    // grow-only device staging in the handle: seven hipMalloc / hipFree pairs per page would cost more than the GNN
     int32_t *d_e = nullptr, *d_r = nullptr;
     float *d_u = nullptr, *d_f = nullptr, *d_o = nullptr;
-    int rc;
-    if ((rc = dc.up(edges, (size_t)E * 2, &d_e))) return rc;
-    if ((rc = dc.up(node_feat, (size_t)N * g->cfg.node_feature_dim, &d_u))) return rc;
-    if ((rc = dc.up(edge_feat, (size_t)E * g->cfg.edge_feature_dim, &d_f))) return rc;
-    if ((rc = dc.up(relations, (size_t)R * 2, &d_r))) return rc;
-    if ((rc = dc.alloc((size_t)R * g->cfg.num_classes, &d_o))) return rc;
-    rc = asep_gnn_forward_dev(g, N, E, d_e, d_u, d_f, R, d_r, d_o, nullptr);
+    const size_t ne = (size_t)E * 2, nu = (size_t)N * g->cfg.node_feature_dim, nf = (size_t)E * g->cfg.edge_feature_dim;
+    const size_t nr = relations ? (size_t)R * 2 : 0, no = (size_t)R * g->cfg.num_classes;
+    try {
+        g->host_stage.begin();
+        d_e = (int32_t*)g->host_stage.get(std::max<size_t>(ne, 1) * sizeof(int32_t));
+        d_u = (float*)g->host_stage.get(std::max<size_t>(nu, 1) * sizeof(float));
+        d_f = (float*)g->host_stage.get(std::max<size_t>(nf, 1) * sizeof(float));
+        d_r = (int32_t*)g->host_stage.get(std::max<size_t>(nr, 1) * sizeof(int32_t));
+        d_o = (float*)g->host_stage.get(std::max<size_t>(no, 1) * sizeof(float));
+    } catch (const HipError&) {
+        return ASEP_ERR_HIP;
+    }
+    if (ne) ASEP_HIP_CHECK(hipMemcpyAsync(d_e, edges, ne * sizeof(int32_t), hipMemcpyHostToDevice, nullptr));
+    ASEP_HIP_CHECK(hipMemcpyAsync(d_u, node_feat, nu * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    if (nf && edge_feat) ASEP_HIP_CHECK(hipMemcpyAsync(d_f, edge_feat, nf * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    if (nr) ASEP_HIP_CHECK(hipMemcpyAsync(d_r, relations, nr * sizeof(int32_t), hipMemcpyHostToDevice, nullptr));
+    const int rc = asep_gnn_forward_dev(g, N, E, ne ? d_e : nullptr, d_u, (nf && edge_feat) ? d_f : nullptr, R,
+                                        nr ? d_r : nullptr, d_o, nullptr);
     if (rc) return rc;
+    if (R > 0) ASEP_HIP_CHECK(hipMemcpyAsync(probs_out, d_o, no * sizeof(float), hipMemcpyDeviceToHost, nullptr));
     ASEP_HIP_CHECK(hipStreamSynchronize(nullptr));
-    if (R > 0) ASEP_HIP_CHECK(hipMemcpy(probs_out, d_o, (size_t)R * g->cfg.num_classes * sizeof(float), hipMemcpyDeviceToHost));
     return ASEP_OK;
 }
 
