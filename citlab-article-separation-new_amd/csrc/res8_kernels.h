@@ -15,6 +15,7 @@ namespace asep {
 
 #ifdef ASEP_R8_TIMELINE   // development aid (scripts/ubench/res8_timeline.hip): per-wave cycle stamps of the first units
 __device__ unsigned long long r8_tl[16][8][64];
+__device__ unsigned long long r8_clk[4];   // block 0: {clock64, wall_clock64} at kernel start and end
 #define R8_MARK() do { if (blockIdx.x < 16 && lane == 0 && tl_n < 64) r8_tl[blockIdx.x][wave][tl_n++] = clock64(); } while (0)
 #else
 #define R8_MARK() do { } while (0)
@@ -112,7 +113,8 @@ __device__ __forceinline__ void r8_mma(const f32x4 (&A)[6], f32x4 (&b)[4][2], f3
 // one 3x3 8->8 convolution stage on LDS tiles.  IN holds rows in_r0.. of the frame, OUT rows out_r0.. ;
 // computes rows [row_start, row_start+NROWS) x columns [out_c0, out_c0+64).  FINAL: add T centre, store to global.
 // The fragments of a wave's next unit are requested before the MFMAs of the current one; wnext != nullptr: the next
-// stage's filter is requested into An before the last unit (its latency hides under that unit and the barrier).
+// stage's filter (wnext; every stage but the FINAL one) is requested into An together with the fragments, so that its
+// latency hides under the MFMAs and the barrier.
 // INTERIOR: the whole frame lies inside the image (scalar per pass): no zero masks, unconditional stores.
 template <int NROWS, bool RELU_IN, bool FINAL, bool POOL, bool BF = false, bool INTERIOR = false>
 __device__ __forceinline__ void res8_stage(const float* __restrict__ IN, int in_r0, float* __restrict__ OUT, int out_r0,
@@ -186,19 +188,19 @@ __device__ __forceinline__ void res8_stage(const float* __restrict__ IN, int in_
     f32x4 bA[4][2], bB[4][2];
     r8_load_frags(frag_ptr(wave), bA);
     r8_load_frags(frag_ptr(wave + R8_WAVES), bB);       // NROWS >= 16: every wave has two units
-    if (!has3 && wnext) r8_load_w(wnext, lane, An);
+    // (unconditional and at one place for every wave: behind a run-time branch the compiler's wait counters become
+    // conservative and the first MFMA would wait for the filter that was only just requested)
+    if (!FINAL) r8_load_w(wnext, lane, An);
+    __builtin_amdgcn_sched_barrier(0);                  // all requests go out first (the scheduler otherwise sinks the reads to their uses in some instantiations)
     unit(wave, bA);
-    if (THIRD && has3) {
-        r8_load_frags(frag_ptr(wave + 2 * R8_WAVES), bA);
-        if (wnext) r8_load_w(wnext, lane, An);
-    }
+    if (THIRD && has3) r8_load_frags(frag_ptr(wave + 2 * R8_WAVES), bA);
     unit(wave + R8_WAVES, bB);
     if (THIRD && has3) unit(wave + 2 * R8_WAVES, bA);
 }
 
 // DOWN block of level 0: image (1 channel) -> d0 [H,W,8] (+ maxpool2)
 template <bool BF = false>
-__global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args a) {
+__global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void res8_down_kernel(const Res8Args a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* IMG = sm;                                         // [24][76]
     float* T = IMG + R8_FH * R8_IMGP;                        // frame rows 1..22  [22][72][8]
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_down_kernel(const Res8Args
 // The 16-channel concatenation is consumed as two 8-channel passes through one LDS input tile (skip, then the
 // deconvolution output) that accumulate into the same registers; afterwards that tile buffer holds r1.
 template <bool BF = false>
-__global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a) {
+__global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void res8_up_kernel(const Res8Args a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Pb = sm;                                          // frame rows 0..23  [24][72][8]  (later r1: rows 3..20)
     float* T = Pb + R8_FH * R8_PITCH * 8;                    // frame rows 1..22  [22][72][8]
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: unit numbers and their branches stay on the SALU
 #ifdef ASEP_R8_TIMELINE
     int tl_n = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { r8_clk[0] = clock64(); r8_clk[1] = wall_clock64(); }
 #endif
     int j = lane & 15, kk = lane >> 4;
     int e = kk >> 1, ch = (kk & 1) * 4;
@@ -427,6 +430,7 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
                 f32x4 bA[4][2], bB[4][2];
                 r8_load_frags(frag_ptr(wave), bA);
                 r8_load_frags(frag_ptr(wave + R8_WAVES), bB);
+                __builtin_amdgcn_sched_barrier(0);
                 r8_mma<false, BF>(Aw, bA, tacc[0][0], tacc[0][1]);
                 if (has3) r8_load_frags(frag_ptr(wave + 2 * R8_WAVES), bA);
                 r8_mma<false, BF>(Aw, bB, tacc[1][0], tacc[1][1]);
@@ -525,6 +529,9 @@ __global__ __launch_bounds__(R8_THREADS, 2) void res8_up_kernel(const Res8Args a
         }
         tile_id = next_id;
     }
+#ifdef ASEP_R8_TIMELINE
+    if (blockIdx.x == 0 && threadIdx.x == 0) { r8_clk[2] = clock64(); r8_clk[3] = wall_clock64(); }
+#endif
 }
 
 constexpr size_t R8_UP_LDS = (size_t)((R8_FH + 22 + 20 + 2) * R8_PITCH * 8) * sizeof(float);

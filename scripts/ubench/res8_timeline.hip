@@ -44,6 +44,10 @@ int main(int argc, char** argv) {
     }
     static unsigned long long tl[16][8][64];
     CK(hipMemcpyFromSymbol(tl, HIP_SYMBOL(r8_tl), sizeof(tl)));
+    unsigned long long clk[4];
+    CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(r8_clk), sizeof(clk)));
+    printf("block 0: %llu shader-clock ticks in %llu wall-clock ticks (100 MHz) -> clock64 runs at %.0f MHz\n", clk[2] - clk[0], clk[3] - clk[1],
+           (double)(clk[2] - clk[0]) / (double)(clk[3] - clk[1]) * 100.0);
     const char* names[15] = {"pass start", "barrier A0 passed", "tile0 in LDS (barrier)", "conv1 src0 done", "barrier A1 passed",
                              "tile1 in LDS (barrier)", "conv1 src1 done", "t written", "barrier", "stage0 done", "barrier",
                              "stage1 done", "barrier", "prefetch issued", "stage2 done"};
