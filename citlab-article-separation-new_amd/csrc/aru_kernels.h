@@ -390,6 +390,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
                 an[m] = p + 1 < 4 ? wg[(size_t)(p + 1) * wstride + (size_t)m * 64] : wnext[(size_t)m * 64];
+            // the requests stay here, one position ahead of their use (left alone, the scheduler sinks them to just
+            // before the MFMAs that need them and every position waits for an L2 round trip)
+            __builtin_amdgcn_sched_barrier(0);
             const float* vb = vcur + ((wave * 4 + p) * TILES + j) * 16 + kk * 4;
             f32x4 bf[2];
 #pragma unroll
