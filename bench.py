@@ -207,12 +207,12 @@ def main():
             "share_of_gpu_time": round(dom["total_ms"] / sum(k["total_ms"] for k in kernels), 4),
             "traffic": None,
         }
-        tp = os.path.join(ROOT, "profiles", "traffic_dominant_kernel.json")
-        if os.path.exists(tp):      # HBM bytes/launch from a separate rocprofv3 --pmc pass (see profiles/README.md)
+        tp = os.path.join(ROOT, "profiles", "traffic_per_kernel.json")
+        if os.path.exists(tp):      # HBM bytes/launch from separate rocprofv3 --pmc passes (profiles/README.md, scripts/make_traffic_json.py)
             try:
-                tj = json.load(open(tp))
-                if tj.get("kernel") == dom["kernel"]:
-                    roofline["traffic"] = tj.get("bytes_per_launch")
+                tj = json.load(open(tp))["kernels"].get(dom["kernel"])
+                if tj and args.dtype == "f32":
+                    roofline["traffic"] = tj["bytes_per_launch"]
             except Exception:
                 pass
 
