@@ -81,6 +81,14 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     return v;
 }
+// max(x, lim) on the bit patterns (one v_max_i32 per element; fmaxf costs a second, canonicalising v_max_f32):
+// lim = 0 is ReLU, lim = INT_MIN the identity, so that a run-time "relu?" flag needs no branch
+__device__ __forceinline__ f32x4 imax4(f32x4 v, int lim) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 i = __builtin_bit_cast(i32x4, v);
+    i.x = max(i.x, lim); i.y = max(i.y, lim); i.z = max(i.z, lim); i.w = max(i.w, lim);
+    return __builtin_bit_cast(f32x4, i);
+}
 
 // Software pipeline: the halo tile of channel group g+1 is fetched into registers while group g is multiplied
 // out of LDS (two LDS buffers, one barrier per group); the weight fragments of tap t+1 are requested before the
@@ -123,34 +131,40 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         nbase[n] = ((id >> 1) * LW + (id & 1) * 16 + j) * CPP;
     }
 
+    // halo loader: slot idx = tid + 256 i -> (pixel, 4-channel sub-block); the pixel advances by a constant per i, so (ly, lx)
+    // are updated incrementally (one division per thread instead of one per slot), and both inputs of a concatenation
+    // are served by ONE predicated load through a selected pointer (the one-shot blocks are short: the ~1200
+    // instructions of the naive prologue cost as much issue time as half of the MFMA phase)
     f32x4 st[NLOAD];
+    constexpr int PSTEP = 256 / SUBS, QD = PSTEP / LW, RD = PSTEP % LW;
+    const int pix0 = tid / SUBS, sub0 = tid % SUBS;
+    const int ly0 = pix0 / LW, lx0 = pix0 - ly0 * LW;
     auto stage_load = [&](int g) {
+        const int c = g * 16 + sub0 * 4;
+        const bool from0 = c < a.c0;
+        const bool cok = from0 || c - a.c0 < a.c1;
+        // branch-free: the address is clamped into the image (always valid), out-of-image slots are zeroed by a select
+        const float* __restrict__ src = (from0 || !cok) ? in0 + (from0 ? c : 0) : in1 + (c - a.c0);
+        const int cs = (from0 || !cok) ? a.c0 : a.c1;
+        int ly = ly0, lx = lx0;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
-            const int idx = tid + i * 256;
-            const int pix = idx / SUBS, sub = idx - pix * SUBS;
-            const int ly = pix / LW, lx = pix - ly * LW;
             const int gy = y0 - PT + ly, gx = x0 - PL + lx;
-            const int c = g * 16 + sub * 4;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (idx < NV && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const size_t p = (size_t)gy * W + gx;
-                if (c < a.c0)
-                    v = *reinterpret_cast<const f32x4*>(in0 + p * a.c0 + c);
-                else if (c - a.c0 < a.c1)
-                    v = *reinterpret_cast<const f32x4*>(in1 + p * a.c1 + (c - a.c0));
-            }
-            st[i] = v;
+            const bool ok = cok && (i * 256 + 255 < NV || tid + i * 256 < NV) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)(cy * W + cx) * cs);
+            st[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            lx += RD; ly += QD;
+            if (lx >= LW) { lx -= LW; ++ly; }
         }
     };
+    const int relu_lim = a.relu_in ? 0 : (int)0x80000000;
     auto stage_store = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             const int idx = tid + i * 256;
             if (idx < NV) {
-                f32x4 v = st[i];
-                if (a.relu_in) v = relu4(v);
-                *reinterpret_cast<f32x4*>(lds + buf * LBUF + idx * 4) = v;   // idx*4 == pix*CPP + sub*4
+                *reinterpret_cast<f32x4*>(lds + buf * LBUF + idx * 4) = imax4(st[i], relu_lim);   // idx*4 == pix*CPP + sub*4
             }
         }
     };
@@ -169,19 +183,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     constexpr bool RES_PREFETCH = (MT * NT <= 8);
     f32x4 resv[RES_PREFETCH ? MT : 1][RES_PREFETCH ? NT : 1];
     if constexpr (RES_PREFETCH) {
-        if (P.res) {
+        // branch-free: clamped addresses; without a residual operand the (ignored) values are read from the input
+        const float* __restrict__ rp = P.res ? P.res : in0;
+        const int rcs = P.res ? a.cout : a.c0;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int id = wave * NT + n;
-                const int y = y0 + (id >> 1), x = x0 + (id & 1) * 16 + j;
+        for (int n = 0; n < NT; ++n) {
+            const int id = wave * NT + n;
+            const int y = min(y0 + (id >> 1), P.Ho - 1), x = min(x0 + (id & 1) * 16 + j, P.Wo - 1);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int c = (mt0 + m) * 16 + kk * 4;
-                    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (y < P.Ho && x < P.Wo && c + 3 < a.cout)
-                        v = *reinterpret_cast<const f32x4*>(P.res + ((size_t)y * P.Wo + x) * a.cout + c);
-                    resv[m][n] = v;
-                }
+            for (int m = 0; m < MT; ++m) {
+                const int c = (mt0 + m) * 16 + kk * 4;
+                resv[m][n] = *reinterpret_cast<const f32x4*>(rp + ((size_t)y * P.Wo + x) * rcs + (c + 3 < rcs ? c : 0));
             }
         }
     }
