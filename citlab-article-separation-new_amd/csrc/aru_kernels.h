@@ -305,7 +305,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int WINO_TH = 4;
 constexpr int WINO_TW = 32;
 #ifndef WINO_XFORM_AT
-#define WINO_XFORM_AT 1
+#define WINO_XFORM_AT 2
+#endif
+#ifndef WINO_STORE_AT
+#define WINO_STORE_AT 1
+#endif
+
+#ifdef ASEP_WINO_TIMELINE   // development aid (scripts/ubench/wino_timeline.hip): per-wave cycle stamps of the first blocks
+__device__ unsigned long long wino_tl[512][4][32];
+#define WINO_MARK() do { if (blockIdx.x >= 4096 && blockIdx.x < 4608 && lane == 0 && tl_n < 32) wino_tl[blockIdx.x - 4096][wave][tl_n++] = clock64(); } while (0)
+#else
+#define WINO_MARK() do { } while (0)
 #endif
 
 template <int MT, bool BF = false>
@@ -313,9 +323,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
     constexpr int TH = WINO_TH, TW = WINO_TW;
     constexpr int TILES = (TH / 2) * (TW / 2);            // 32 Winograd tiles
     constexpr int VBUF = 16 * TILES * 16;                 // floats per V image (32 KB)
+    // input window of one channel group: 6 x 34 pixels x 16 channels, pixel pitch 20 floats (the 8-byte patch reads of
+    // four neighbouring tiles then fall into different bank groups)
+    constexpr int HH = TH + 2, HW = TW + 2, HP = 20;
+    constexpr int NH = HH * HW * 4;                       // float4 slots of the window
+    constexpr int NHL = (NH + 255) / 256;
     __shared__ __attribute__((aligned(16))) float V[2 * VBUF];
+    __shared__ __attribute__((aligned(16))) float HALO[HH * HW * HP > TH * TW * 32 ? HH * HW * HP : TH * TW * 32];   // also the output tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef ASEP_WINO_TIMELINE
+    int tl_n = 0;
+#endif
+    WINO_MARK();   // 0 start
     const int j = lane & 15, kk = lane >> 4;
     int pi = 0;
     while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
@@ -327,9 +347,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 
     // transform role: tile tt (row-major in the 2 x 16 tile grid), channel pair cp (channels 2cp, 2cp+1 of the group)
     const int tt = tid >> 3, cp = tid & 7;
-    const int py = y0 + 2 * (tt >> 4) - 1, px = x0 + 2 * (tt & 15) - 1;   // patch origin (SAME: pad 1)
-    // one 32-bit element offset per thread; rows/columns of the patch are uniform multiples of the pixel stride
-    const int off00 = py * W + px;
 
     f32x4 acc[4][MT][2];
 #pragma unroll
@@ -339,29 +356,46 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
             for (int n = 0; n < 2; ++n) acc[p][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x2 d[4][4];
-    auto patch_load = [&](int g) {
-        const int c = g * 16 + cp * 2;
-        const float* __restrict__ src = c < a.c0 ? P.in0 + c : P.in1 + (c - a.c0);
-        const int cs = c < a.c0 ? a.c0 : a.c1;
+    // The input window travels HBM -> registers (16 B per lane, coalesced, one channel group ahead) -> LDS, and the
+    // 4x4 patches are read from LDS.  (Every thread fetching its own patch with sixteen 8-byte loads made the blocks
+    // vector-memory-issue-bound: scripts/ubench/wino_timeline.hip showed 6100 + 2500 cycles spent just issuing them.)
+    f32x4 st[NHL];
+    const int pix0 = tid >> 2, sub0 = tid & 3;
+    const int hy0 = pix0 / HW, hx0 = pix0 - hy0 * HW;
+    constexpr int QD = 64 / HW, RD = 64 % HW;              // the pixel index advances by 64 per slot
+    const int relu_lim = a.relu_in ? 0 : (int)0x80000000;
+    auto halo_load = [&](int g) {
+        const int c = g * 16 + sub0 * 4;
+        const bool from0 = c < a.c0;
+        const float* __restrict__ src = from0 ? P.in0 + c : P.in1 + (c - a.c0);
+        const int cs = from0 ? a.c0 : a.c1;
+        int hy = hy0, hx = hx0;
+#pragma unroll
+        for (int i = 0; i < NHL; ++i) {
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;  // SAME: pad 1
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);   // clamped: always a valid address
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)(cy * W + cx) * cs);
+            st[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            hx += RD; hy += QD;
+            if (hx >= HW) { hx -= HW; ++hy; }
+        }
+    };
+    auto halo_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NHL; ++i) {
+            const int idx = tid + i * 256;
+            if (i * 256 + 255 < NH || idx < NH)
+                *reinterpret_cast<f32x4*>(HALO + (idx >> 2) * HP + sub0 * 4) = imax4(st[i], relu_lim);
+        }
+    };
+    auto transform_store = [&](int buf) {
+        f32x2 d[4][4];
+        const float* hb = HALO + ((2 * (tt >> 4)) * HW + 2 * (tt & 15)) * HP + cp * 2;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int gy = py + r, gx = px + s;
-                f32x2 v = f32x2{0.f, 0.f};
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                    v = *reinterpret_cast<const f32x2*>(src + (size_t)(off00 + r * W + s) * cs);
-                d[r][s] = v;
-            }
-    };
-    auto transform_store = [&](int buf) {
-        if (a.relu_in) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) { d[r][s].x = fmaxf(d[r][s].x, 0.f); d[r][s].y = fmaxf(d[r][s].y, 0.f); }
-        }
+            for (int s2 = 0; s2 < 4; ++s2) d[r][s2] = *reinterpret_cast<const f32x2*>(hb + (r * HW + s2) * HP);
         float* vb = V + buf * VBUF + tt * 16 + cp * 2;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -382,16 +416,22 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
     const size_t wstride = (size_t)a.mtiles * 64;          // f32x4 per (group, pos)
     const int G = a.groups;
 
-    patch_load(0);
+    halo_load(0);
+    WINO_MARK();   // 1 first window requested
     f32x4 af[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) af[m] = wbase[((size_t)wave * 4) * wstride + (size_t)m * 64];
-    transform_store(0);
+    halo_store();
     __syncthreads();
+    transform_store(0);
+    WINO_MARK();   // 2 first transform written
+    __syncthreads();
+    WINO_MARK();   // 3 barrier
 
     for (int g = 0; g < G; ++g) {
         const bool more = g + 1 < G;
-        if (more) patch_load(g + 1);                       // global loads in flight during the MFMA phase
+        if (more) halo_load(g + 1);                        // global loads in flight during the MFMA phase
+        WINO_MARK();   // g: window requested
         // ---- MFMA phase: positions 4*wave .. 4*wave+3 of group g -------------------------------------------
         const float* __restrict__ vcur = V + (g & 1) * VBUF;
         const f32x4* __restrict__ wg = wbase + ((size_t)g * 16 + wave * 4) * wstride;
@@ -430,41 +470,44 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m) af[m] = an[m];
-            // transform of the next group in the shadow of this phase's MFMAs (its patch loads were issued at the top;
-            // it writes the other V buffer, last read in iteration g-1)
-            if (p == WINO_XFORM_AT && more) transform_store((g + 1) & 1);
+            WINO_MARK();   // g: position p multiplied
+            // the next group's window goes registers -> LDS after position WINO_STORE_AT (the window buffer was last
+            // read by the previous transform, a barrier ago), its transform into the other V buffer follows one
+            // position later, in the shadow of the remaining MFMAs
+            if (p == WINO_STORE_AT && more) { halo_store(); __syncthreads(); }
+            if (p == WINO_XFORM_AT && more) { transform_store((g + 1) & 1); WINO_MARK(); }
         }
         __syncthreads();
+        WINO_MARK();   // g: barrier
     }
 
-    // ---- output phase: exchange through LDS (two m-tiles per round), inverse transform, epilogue -------------
-    const int oy = y0 + 2 * (tt >> 4), ox = x0 + 2 * (tt & 15);
+    // ---- output phase: exchange through LDS (two m-tiles per round), inverse transform, then a second pass through
+    //      LDS so that the tile leaves as 16-byte stores that cover whole pixels (the 8-byte stores of the
+    //      (tile, channel pair) layout were half cache lines and twice as many instructions) -------------------------
     float* __restrict__ out = P.out;
     const float* __restrict__ res = P.res;
     constexpr int ROUNDS = (MT + 1) / 2;
+    constexpr int MPR = MT >= 2 ? 2 : 1;                  // m-tiles per round
+    constexpr int CPR = MPR * 16, QPP = CPR / 4;          // channels / channel quads per pixel and round
+    constexpr int NSLOT = TH * TW * QPP / 256;            // float4 slots per thread and round (4 or 2)
+    float* OT = HALO;                                     // output tile [4 x 32 pixels][CPR channels] (the window buffer is free by now)
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
-        // residual operand of this round: requested before the LDS exchange so that its latency hides under it
-        f32x2 rv[2][2][2];
-        if (res) {
+        // residual operand of this round in the store layout: requested before the LDS exchange so that its latency hides under it
+        f32x4 rv[NSLOT];
+        const int cbase = (mt0 + rd * 2) * 16;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int co = (mt0 + rd * 2 + h) * 16 + cp * 2;
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
-                        const int yy = oy + dy, xx = ox + dx;
-                        f32x2 v = f32x2{0.f, 0.f};
-                        if (rd * 2 + h < MT && co < a.cout && yy < P.Ho && xx < P.Wo)
-                            v = *reinterpret_cast<const f32x2*>(res + ((size_t)yy * P.Wo + xx) * a.cout + co);
-                        rv[h][dy][dx] = v;
-                    }
-            }
+        for (int i = 0; i < NSLOT; ++i) {
+            const int k = tid + i * 256;
+            const int pix = k / QPP, q = k % QPP;
+            const int yy = y0 + (pix >> 5), xx = x0 + (pix & 31);
+            rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (res && yy < P.Ho && xx < P.Wo)
+                rv[i] = *reinterpret_cast<const f32x4*>(res + ((size_t)yy * P.Wo + xx) * a.cout + cbase + q * 4);
         }
         if (rd > 0) __syncthreads();                       // readers of the previous round are done
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < MPR; ++h) {
             const int m = rd * 2 + h;
             if (m < MT) {
 #pragma unroll
@@ -474,9 +517,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
                         *reinterpret_cast<f32x4*>(V + h * VBUF + ((wave * 4 + p) * TILES + n * 16 + j) * 16 + kk * 4) = acc[p][m][n];
             }
         }
+        WINO_MARK();   // exchange written
         __syncthreads();
+        WINO_MARK();   // barrier
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < MPR; ++h) {
             const int m = rd * 2 + h;
             if (m >= MT) continue;
             const float* mb = V + h * VBUF + tt * 16 + cp * 2;
@@ -490,30 +535,29 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
                 s0[s] = m0 + m1 + m2;
                 s1[s] = m1 - m2 - m3;
             }
-            f32x2 y[2][2];
-            y[0][0] = s0[0] + s0[1] + s0[2];
-            y[0][1] = s0[1] - s0[2] - s0[3];
-            y[1][0] = s1[0] + s1[1] + s1[2];
-            y[1][1] = s1[1] - s1[2] - s1[3];
-            const int co = (mt0 + m) * 16 + cp * 2;
-            if (co < a.cout) {
-                const f32x2 b = *reinterpret_cast<const f32x2*>(a.bias + co);
+            // 2 x 2 output pixels of tile tt, channels 2cp, 2cp+1 of m-tile h -> output tile
+            float* ob = OT + ((2 * (tt >> 4)) * TW + 2 * (tt & 15)) * CPR + h * 16 + cp * 2;
+            *reinterpret_cast<f32x2*>(ob) = s0[0] + s0[1] + s0[2];
+            *reinterpret_cast<f32x2*>(ob + CPR) = s0[1] - s0[2] - s0[3];
+            *reinterpret_cast<f32x2*>(ob + TW * CPR) = s1[0] + s1[1] + s1[2];
+            *reinterpret_cast<f32x2*>(ob + TW * CPR + CPR) = s1[1] - s1[2] - s1[3];
+        }
+        __syncthreads();
 #pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
-                        const int yy = oy + dy, xx = ox + dx;
-                        if (yy < P.Ho && xx < P.Wo) {
-                            const size_t p = (size_t)yy * P.Wo + xx;
-                            f32x2 v = y[dy][dx] + b;
-                            if (res) v += rv[h][dy][dx];
-                            if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
-                            *reinterpret_cast<f32x2*>(out + p * a.cout + co) = v;
-                        }
-                    }
+        for (int i = 0; i < NSLOT; ++i) {
+            const int k = tid + i * 256;
+            const int pix = k / QPP, q = k % QPP;
+            const int yy = y0 + (pix >> 5), xx = x0 + (pix & 31);
+            const int co = cbase + q * 4;
+            if (yy < P.Ho && xx < P.Wo && co < a.cout) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(OT + pix * CPR + q * 4) + *reinterpret_cast<const f32x4*>(a.bias + co);
+                if (res) v += rv[i];
+                if (a.relu_out) v = relu4(v);
+                *reinterpret_cast<f32x4*>(out + ((size_t)yy * P.Wo + xx) * a.cout + co) = v;
             }
         }
     }
+    WINO_MARK();   // done
 }
 
 // ------------------------------------------------------------------------------------------------
