@@ -359,12 +359,12 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             if (m->prof_detail) pname += " " + scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
             ProfScope ps(m, pname, flops);
             if (m->bf16) {
-                if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4, true>), grid, dim3(WINO_THREADS), 0, m->stream, a);
-                else if (mt == 2) hipLaunchKernelGGL((conv_wino_kernel<2, true>), grid, dim3(WINO_THREADS), 0, m->stream, a);
-                else hipLaunchKernelGGL((conv_wino_kernel<1, true>), grid, dim3(WINO_THREADS), 0, m->stream, a);
-            } else if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4>), grid, dim3(WINO_THREADS), 0, m->stream, a);
-            else if (mt == 2) hipLaunchKernelGGL((conv_wino_kernel<2>), grid, dim3(WINO_THREADS), 0, m->stream, a);
-            else hipLaunchKernelGGL((conv_wino_kernel<1>), grid, dim3(WINO_THREADS), 0, m->stream, a);
+                if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4, true>), grid, dim3(256), 0, m->stream, a);
+                else if (mt == 2) hipLaunchKernelGGL((conv_wino_kernel<2, true>), grid, dim3(256), 0, m->stream, a);
+                else hipLaunchKernelGGL((conv_wino_kernel<1, true>), grid, dim3(256), 0, m->stream, a);
+            } else if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4>), grid, dim3(256), 0, m->stream, a);
+            else if (mt == 2) hipLaunchKernelGGL((conv_wino_kernel<2>), grid, dim3(256), 0, m->stream, a);
+            else hipLaunchKernelGGL((conv_wino_kernel<1>), grid, dim3(256), 0, m->stream, a);
         } else if (pc.kh == 3) launch_conv_k<3, 3>(m, pc, a, tiles, flops, scope, sub, big_tile);
         else launch_conv_k<4, 4>(m, pc, a, tiles, flops, scope, sub, big_tile);
     }

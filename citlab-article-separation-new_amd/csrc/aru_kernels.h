@@ -312,33 +312,26 @@ constexpr int WINO_TW = 32;
 #endif
 
 #ifdef ASEP_WINO_TIMELINE   // development aid (scripts/ubench/wino_timeline.hip): per-wave cycle stamps of the first blocks
-__device__ unsigned long long wino_tl[512][8][32];
+__device__ unsigned long long wino_tl[512][4][32];
 #define WINO_MARK() do { if (blockIdx.x >= 4096 && blockIdx.x < 4608 && lane == 0 && tl_n < 32) wino_tl[blockIdx.x - 4096][wave][tl_n++] = clock64(); } while (0)
 #else
 #define WINO_MARK() do { } while (0)
 #endif
 
-constexpr int WINO_THREADS = 512;
-
-// 512 threads = 8 waves per block, two blocks per CU (80 KB of LDS each): FOUR waves per SIMD.  With 256-thread blocks a
-// SIMD held two waves, each a long chain of dependent latencies (window load -> LDS -> transform -> LDS -> MFMA ->
-// LDS exchange -> inverse -> LDS -> store); the timeline showed every phase taking 2-3x its issue time and the block
-// time equal to one wave's serialised instruction stream.  Wave w owns positions 2w, 2w+1.
 template <int MT, bool BF = false>
-__global__ __launch_bounds__(WINO_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_wino_kernel(const ConvArgs a) {
-    constexpr int TH = WINO_TH, TW = WINO_TW, NTH = WINO_THREADS;
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
+    constexpr int TH = WINO_TH, TW = WINO_TW;
     constexpr int TILES = (TH / 2) * (TW / 2);            // 32 Winograd tiles
     constexpr int VBUF = 16 * TILES * 16;                 // floats per V image (32 KB)
-    // input window of one channel group: 6 x 34 pixels x 16 channels, pixel pitch 20 floats (the patch reads of
-    // neighbouring tiles then fall into different bank groups)
+    // input window of one channel group: 6 x 34 pixels x 16 channels, pixel pitch 20 floats (the 8-byte patch reads of
+    // four neighbouring tiles then fall into different bank groups)
     constexpr int HH = TH + 2, HW = TW + 2, HP = 20;
     constexpr int NH = HH * HW * 4;                       // float4 slots of the window
-    constexpr int NHL = (NH + NTH - 1) / NTH;
+    constexpr int NHL = (NH + 255) / 256;
     __shared__ __attribute__((aligned(16))) float V[2 * VBUF];
     __shared__ __attribute__((aligned(16))) float HALO[HH * HW * HP > TH * TW * 32 ? HH * HW * HP : TH * TW * 32];   // also the output tile
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef ASEP_WINO_TIMELINE
     int tl_n = 0;
 #endif
@@ -352,12 +345,12 @@ __global__ __launch_bounds__(WINO_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     const int x0 = txb * TW, y0 = tyb * TH, mt0 = blockIdx.y * MT;
     const int H = P.H, W = P.W;
 
-    // transform role: tile tt (row-major in the 2 x 16 tile grid), channel ch of the group
-    const int tt = tid >> 4, ch = tid & 15;
+    // transform role: tile tt (row-major in the 2 x 16 tile grid), channel pair cp (channels 2cp, 2cp+1 of the group)
+    const int tt = tid >> 3, cp = tid & 7;
 
-    f32x4 acc[2][MT][2];
+    f32x4 acc[4][MT][2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -369,7 +362,7 @@ __global__ __launch_bounds__(WINO_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     f32x4 st[NHL];
     const int pix0 = tid >> 2, sub0 = tid & 3;
     const int hy0 = pix0 / HW, hx0 = pix0 - hy0 * HW;
-    constexpr int QD = (NTH / 4) / HW, RD = (NTH / 4) % HW;   // the pixel index advances by NTH / 4 per slot
+    constexpr int QD = 64 / HW, RD = 64 % HW;              // the pixel index advances by 64 per slot
     const int relu_lim = a.relu_in ? 0 : (int)0x80000000;
     auto halo_load = [&](int g) {
         const int c = g * 16 + sub0 * 4;
@@ -391,31 +384,31 @@ __global__ __launch_bounds__(WINO_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     auto halo_store = [&]() {
 #pragma unroll
         for (int i = 0; i < NHL; ++i) {
-            const int idx = tid + i * NTH;
-            if (i * NTH + NTH - 1 < NH || idx < NH)
+            const int idx = tid + i * 256;
+            if (i * 256 + 255 < NH || idx < NH)
                 *reinterpret_cast<f32x4*>(HALO + (idx >> 2) * HP + sub0 * 4) = imax4(st[i], relu_lim);
         }
     };
     auto transform_store = [&](int buf) {
-        float d[4][4];
-        const float* hb = HALO + ((2 * (tt >> 4)) * HW + 2 * (tt & 15)) * HP + ch;
+        f32x2 d[4][4];
+        const float* hb = HALO + ((2 * (tt >> 4)) * HW + 2 * (tt & 15)) * HP + cp * 2;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) d[r][s2] = hb[(r * HW + s2) * HP];
-        float* vb = V + buf * VBUF + tt * 16 + ch;
+            for (int s2 = 0; s2 < 4; ++s2) d[r][s2] = *reinterpret_cast<const f32x2*>(hb + (r * HW + s2) * HP);
+        float* vb = V + buf * VBUF + tt * 16 + cp * 2;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             // row r of B^T d, then times B, written straight out (keeps at most one row of temporaries live)
-            float t0, t1, t2, t3;
+            f32x2 t0, t1, t2, t3;
             if (r == 0) { t0 = d[0][0] - d[2][0]; t1 = d[0][1] - d[2][1]; t2 = d[0][2] - d[2][2]; t3 = d[0][3] - d[2][3]; }
             else if (r == 1) { t0 = d[1][0] + d[2][0]; t1 = d[1][1] + d[2][1]; t2 = d[1][2] + d[2][2]; t3 = d[1][3] + d[2][3]; }
             else if (r == 2) { t0 = d[2][0] - d[1][0]; t1 = d[2][1] - d[1][1]; t2 = d[2][2] - d[1][2]; t3 = d[2][3] - d[1][3]; }
             else { t0 = d[1][0] - d[3][0]; t1 = d[1][1] - d[3][1]; t2 = d[1][2] - d[3][2]; t3 = d[1][3] - d[3][3]; }
-            vb[(r * 4 + 0) * TILES * 16] = t0 - t2;
-            vb[(r * 4 + 1) * TILES * 16] = t1 + t2;
-            vb[(r * 4 + 2) * TILES * 16] = t2 - t1;
-            vb[(r * 4 + 3) * TILES * 16] = t1 - t3;
+            *reinterpret_cast<f32x2*>(vb + (r * 4 + 0) * TILES * 16) = t0 - t2;
+            *reinterpret_cast<f32x2*>(vb + (r * 4 + 1) * TILES * 16) = t1 + t2;
+            *reinterpret_cast<f32x2*>(vb + (r * 4 + 2) * TILES * 16) = t2 - t1;
+            *reinterpret_cast<f32x2*>(vb + (r * 4 + 3) * TILES * 16) = t1 - t3;
         }
     };
 
@@ -427,7 +420,7 @@ __global__ __launch_bounds__(WINO_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     WINO_MARK();   // 1 first window requested
     f32x4 af[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) af[m] = wbase[((size_t)wave * 2) * wstride + (size_t)m * 64];
+    for (int m = 0; m < MT; ++m) af[m] = wbase[((size_t)wave * 4) * wstride + (size_t)m * 64];
     halo_store();
     __syncthreads();
     transform_store(0);
@@ -439,20 +432,20 @@ __global__ __launch_bounds__(WINO_THREADS) __attribute__((amdgpu_waves_per_eu(4,
         const bool more = g + 1 < G;
         if (more) halo_load(g + 1);                        // global loads in flight during the MFMA phase
         WINO_MARK();   // g: window requested
-        // ---- MFMA phase: positions 2*wave, 2*wave+1 of group g -------------------------------------------------
+        // ---- MFMA phase: positions 4*wave .. 4*wave+3 of group g -------------------------------------------
         const float* __restrict__ vcur = V + (g & 1) * VBUF;
-        const f32x4* __restrict__ wg = wbase + ((size_t)g * 16 + wave * 2) * wstride;
-        const f32x4* __restrict__ wnext = wbase + ((size_t)(more ? g + 1 : g) * 16 + wave * 2) * wstride;
+        const f32x4* __restrict__ wg = wbase + ((size_t)g * 16 + wave * 4) * wstride;
+        const f32x4* __restrict__ wnext = wbase + ((size_t)(more ? g + 1 : g) * 16 + wave * 4) * wstride;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < 4; ++p) {
             f32x4 an[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m)
-                an[m] = p + 1 < 2 ? wg[(size_t)(p + 1) * wstride + (size_t)m * 64] : wnext[(size_t)m * 64];
+                an[m] = p + 1 < 4 ? wg[(size_t)(p + 1) * wstride + (size_t)m * 64] : wnext[(size_t)m * 64];
             // the requests stay here, one position ahead of their use (left alone, the scheduler sinks them to just
             // before the MFMAs that need them and every position waits for an L2 round trip)
             __builtin_amdgcn_sched_barrier(0);
-            const float* vb = vcur + ((wave * 2 + p) * TILES + j) * 16 + kk * 4;
+            const float* vb = vcur + ((wave * 4 + p) * TILES + j) * 16 + kk * 4;
             f32x4 bf[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) bf[n] = *reinterpret_cast<const f32x4*>(vb + n * 16 * 16);
@@ -478,23 +471,25 @@ __global__ __launch_bounds__(WINO_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 #pragma unroll
             for (int m = 0; m < MT; ++m) af[m] = an[m];
             WINO_MARK();   // g: position p multiplied
-            // the next group's window goes registers -> LDS after the first position (the window buffer was last read by
-            // the previous transform, a barrier ago); its transform into the other V buffer follows the second one
-            if (p == 0 && more) { halo_store(); __syncthreads(); }
-            if (p == 1 && more) { transform_store((g + 1) & 1); WINO_MARK(); }
+            // the next group's window goes registers -> LDS after position WINO_STORE_AT (the window buffer was last
+            // read by the previous transform, a barrier ago), its transform into the other V buffer follows one
+            // position later, in the shadow of the remaining MFMAs
+            if (p == WINO_STORE_AT && more) { halo_store(); __syncthreads(); }
+            if (p == WINO_XFORM_AT && more) { transform_store((g + 1) & 1); WINO_MARK(); }
         }
         __syncthreads();
         WINO_MARK();   // g: barrier
     }
 
     // ---- output phase: exchange through LDS (two m-tiles per round), inverse transform, then a second pass through
-    //      LDS so that the tile leaves as 16-byte stores that cover whole pixels -----------------------------------
+    //      LDS so that the tile leaves as 16-byte stores that cover whole pixels (the 8-byte stores of the
+    //      (tile, channel pair) layout were half cache lines and twice as many instructions) -------------------------
     float* __restrict__ out = P.out;
     const float* __restrict__ res = P.res;
     constexpr int ROUNDS = (MT + 1) / 2;
     constexpr int MPR = MT >= 2 ? 2 : 1;                  // m-tiles per round
     constexpr int CPR = MPR * 16, QPP = CPR / 4;          // channels / channel quads per pixel and round
-    constexpr int NSLOT = TH * TW * QPP / NTH;            // float4 slots per thread and round (2 or 1)
+    constexpr int NSLOT = TH * TW * QPP / 256;            // float4 slots per thread and round (4 or 2)
     float* OT = HALO;                                     // output tile [4 x 32 pixels][CPR channels] (the window buffer is free by now)
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
@@ -503,7 +498,7 @@ __global__ __launch_bounds__(WINO_THREADS) __attribute__((amdgpu_waves_per_eu(4,
         const int cbase = (mt0 + rd * 2) * 16;
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
-            const int k = tid + i * NTH;
+            const int k = tid + i * 256;
             const int pix = k / QPP, q = k % QPP;
             const int yy = y0 + (pix >> 5), xx = x0 + (pix & 31);
             rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -516,10 +511,10 @@ __global__ __launch_bounds__(WINO_THREADS) __attribute__((amdgpu_waves_per_eu(4,
             const int m = rd * 2 + h;
             if (m < MT) {
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
+                for (int p = 0; p < 4; ++p)
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
-                        *reinterpret_cast<f32x4*>(V + h * VBUF + ((wave * 2 + p) * TILES + n * 16 + j) * 16 + kk * 4) = acc[p][m][n];
+                        *reinterpret_cast<f32x4*>(V + h * VBUF + ((wave * 4 + p) * TILES + n * 16 + j) * 16 + kk * 4) = acc[p][m][n];
             }
         }
         WINO_MARK();   // exchange written
@@ -529,28 +524,28 @@ __global__ __launch_bounds__(WINO_THREADS) __attribute__((amdgpu_waves_per_eu(4,
         for (int h = 0; h < MPR; ++h) {
             const int m = rd * 2 + h;
             if (m >= MT) continue;
-            const float* mb = V + h * VBUF + tt * 16 + ch;
-            float s0[4], s1[4];
+            const float* mb = V + h * VBUF + tt * 16 + cp * 2;
+            f32x2 s0[4], s1[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float m0 = mb[(0 * 4 + s) * TILES * 16];
-                const float m1 = mb[(1 * 4 + s) * TILES * 16];
-                const float m2 = mb[(2 * 4 + s) * TILES * 16];
-                const float m3 = mb[(3 * 4 + s) * TILES * 16];
+                const f32x2 m0 = *reinterpret_cast<const f32x2*>(mb + (0 * 4 + s) * TILES * 16);
+                const f32x2 m1 = *reinterpret_cast<const f32x2*>(mb + (1 * 4 + s) * TILES * 16);
+                const f32x2 m2 = *reinterpret_cast<const f32x2*>(mb + (2 * 4 + s) * TILES * 16);
+                const f32x2 m3 = *reinterpret_cast<const f32x2*>(mb + (3 * 4 + s) * TILES * 16);
                 s0[s] = m0 + m1 + m2;
                 s1[s] = m1 - m2 - m3;
             }
-            // 2 x 2 output pixels of tile tt, channel ch of m-tile h -> output tile
-            float* ob = OT + ((2 * (tt >> 4)) * TW + 2 * (tt & 15)) * CPR + h * 16 + ch;
-            ob[0] = s0[0] + s0[1] + s0[2];
-            ob[CPR] = s0[1] - s0[2] - s0[3];
-            ob[TW * CPR] = s1[0] + s1[1] + s1[2];
-            ob[TW * CPR + CPR] = s1[1] - s1[2] - s1[3];
+            // 2 x 2 output pixels of tile tt, channels 2cp, 2cp+1 of m-tile h -> output tile
+            float* ob = OT + ((2 * (tt >> 4)) * TW + 2 * (tt & 15)) * CPR + h * 16 + cp * 2;
+            *reinterpret_cast<f32x2*>(ob) = s0[0] + s0[1] + s0[2];
+            *reinterpret_cast<f32x2*>(ob + CPR) = s0[1] - s0[2] - s0[3];
+            *reinterpret_cast<f32x2*>(ob + TW * CPR) = s1[0] + s1[1] + s1[2];
+            *reinterpret_cast<f32x2*>(ob + TW * CPR + CPR) = s1[1] - s1[2] - s1[3];
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
-            const int k = tid + i * NTH;
+            const int k = tid + i * 256;
             const int pix = k / QPP, q = k % QPP;
             const int yy = y0 + (pix >> 5), xx = x0 + (pix & 31);
             const int co = cbase + q * 4;

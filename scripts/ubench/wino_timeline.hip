@@ -32,31 +32,32 @@ int main() {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 3; ++it) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((conv_wino_kernel<2, false>), dim3(a.total_tiles, 1), dim3(WINO_THREADS), 0, 0, a);
+        hipLaunchKernelGGL((conv_wino_kernel<2, false>), dim3(a.total_tiles, 1), dim3(256), 0, 0, a);
         hipEventRecord(e1); CK(hipEventSynchronize(e1));
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("launch %d: %.3f ms, %d blocks (%.1f TFLOP/s-equivalent)\n", it, ms, a.total_tiles, 2.0 * H * W * 9 * C * C / (ms * 1e-3) / 1e12);
     }
-    static unsigned long long tl[512][8][32];
+    static unsigned long long tl[512][4][32];
     CK(hipMemcpyFromSymbol(tl, HIP_SYMBOL(wino_tl), sizeof(tl)));
-    const char* names[16] = {"start", "window(0) requested", "transform(0) written", "barrier", "g0 window(1) requested", "g0 p0", "g0 p1",
-                             "g0 transform(1)", "g0 barrier", "g1 (no request)", "g1 p0", "g1 p1", "g1 barrier", "exchange written", "barrier",
-                             "inverse + stores"};
+    const char* names[20] = {"start", "patch(0) requested", "transform(0) written", "barrier", "g0 patch(1) requested", "g0 p0", "g0 p1", "g0 transform(1)",
+                             "g0 p2", "g0 p3", "g0 barrier", "g1 (no request)", "g1 p0", "g1 p1", "g1 p2", "g1 p3", "g1 barrier", "exchange written",
+                             "barrier", "inverse + stores"};
     // median over the recorded blocks of each phase's duration (last wave of the block), and of the block lifetime
     printf("phase durations, cycles (median over 512 steady-state blocks; per block: last wave's stamp - previous phase's last stamp)\n");
-        for (int m = 1; m < 16; ++m) {
+    std::vector<double> life;
+    for (int m = 1; m < 20; ++m) {
         std::vector<long long> dv;
         for (int b = 0; b < 512; ++b) {
             unsigned long long hi = 0, ph = 0;
-            for (int w = 0; w < 8; ++w) { hi = std::max(hi, tl[b][w][m]); ph = std::max(ph, tl[b][w][m - 1]); }
+            for (int w = 0; w < 4; ++w) { hi = std::max(hi, tl[b][w][m]); ph = std::max(ph, tl[b][w][m - 1]); }
             if (tl[b][0][0]) dv.push_back((long long)(hi - ph));
         }
         std::sort(dv.begin(), dv.end());
         if (!dv.empty()) printf("  %-24s %8lld   (p10 %lld, p90 %lld)\n", names[m], dv[dv.size() / 2], dv[dv.size() / 10], dv[dv.size() * 9 / 10]);
     }
     std::vector<long long> lv;
-    for (int b = 0; b < 512; ++b) if (tl[b][0][0]) { unsigned long long hi = 0, lo = ~0ull; for (int w = 0; w < 8; ++w) { hi = std::max(hi, tl[b][w][15]); lo = std::min(lo, tl[b][w][0]); } lv.push_back((long long)(hi - lo)); }
+    for (int b = 0; b < 512; ++b) if (tl[b][0][0]) { unsigned long long hi = 0, lo = ~0ull; for (int w = 0; w < 4; ++w) { hi = std::max(hi, tl[b][w][19]); lo = std::min(lo, tl[b][w][0]); } lv.push_back((long long)(hi - lo)); }
     std::sort(lv.begin(), lv.end());
-    if (!lv.empty()) printf("block lifetime: median %lld cycles (MFMA issue per wave: 2 groups x 32 x 32 = 2048)\n", lv[lv.size() / 2]);
+    if (!lv.empty()) printf("block lifetime: median %lld cycles (MFMA issue per wave: 2 groups x 64 x 32 = 4096)\n", lv[lv.size() / 2]);
     return 0;
 }
