@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     // are served by ONE predicated load through a selected pointer (the one-shot blocks are short: the ~1200
     // instructions of the naive prologue cost as much issue time as half of the MFMA phase)
     f32x4 st[NLOAD];
+    const bool interior = y0 - PT >= 0 && y0 - PT + LH <= H && x0 - PL >= 0 && x0 - PL + LW <= W;
     constexpr int PSTEP = 256 / SUBS, QD = PSTEP / LW, RD = PSTEP % LW;
     const int pix0 = tid / SUBS, sub0 = tid % SUBS;
     const int ly0 = pix0 / LW, lx0 = pix0 - ly0 * LW;
@@ -147,6 +148,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         const float* __restrict__ src = (from0 || !cok) ? in0 + (from0 ? c : 0) : in1 + (c - a.c0);
         const int cs = (from0 || !cok) ? a.c0 : a.c1;
         int ly = ly0, lx = lx0;
+        if (interior) {
+            // the whole halo window lies inside the image (scalar test, ~90 % of the tiles): no clamps, compares or selects
+            const float* __restrict__ q = src + (size_t)((y0 - PT + ly0) * W + x0 - PL + lx0) * cs;
+            const ptrdiff_t step = (ptrdiff_t)(QD * W + RD) * cs, wrap = (ptrdiff_t)(W - LW) * cs;
+#pragma unroll
+            for (int i = 0; i < NLOAD; ++i) {
+                // threads past the last slot of the window re-read the last row's tail (a valid address inside the image)
+                const bool have = cok && (i * 256 + 255 < NV || tid + i * 256 < NV);
+                st[i] = have ? *reinterpret_cast<const f32x4*>(q) : f32x4{0.f, 0.f, 0.f, 0.f};
+                lx += RD;
+                q += step;
+                if (lx >= LW) { lx -= LW; q += wrap; }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             const int gy = y0 - PT + ly, gx = x0 - PL + lx;
@@ -256,6 +272,30 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     // ---- epilogue: D layout col = lane&15 -> pixel, row = 4*(lane>>4)+reg -> output channel ----
     float* __restrict__ out = P.out;
     const float* __restrict__ res = P.res;
+    if (interior && a.cout % 16 == 0) {
+        // interior tile, whole 16-channel output tiles: no bounds tests, one base pointer
+        const int relu_o = a.relu_out ? 0 : (int)0x80000000;
+        const size_t p00 = (size_t)(y0 + ((wave * NT) >> 1)) * P.Wo + x0 + j;   // NT is even: n-tile 0 of a wave is column block 0
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int c = (mt0 + m) * 16 + kk * 4;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c);
+            float* __restrict__ o = out + p00 * a.cout + c;
+            const float* __restrict__ rp = res + p00 * a.cout + c;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const size_t d = ((size_t)(n >> 1) * P.Wo + (n & 1) * 16) * a.cout;
+                f32x4 v = acc[m][n] + b4;
+                if constexpr (RES_PREFETCH) {
+                    if (res) v += resv[m][n];
+                } else {
+                    if (res) v += *reinterpret_cast<const f32x4*>(rp + d);
+                }
+                *reinterpret_cast<f32x4*>(o + d) = imax4(v, relu_o);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int id = wave * NT + n;
