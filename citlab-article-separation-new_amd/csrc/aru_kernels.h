@@ -636,18 +636,38 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) nbase[n] = ((wave * NT + n + 1) * LW + j + 1) * 16;
 
+    // halo loader (same instruction diet as conv_mfma_kernel: incremental (ly, lx), clamped branch-free loads, all slots
+    // requested before the first is written to LDS)
+    constexpr int NV = LH * LW * 4, NLOAD = (NV + 255) / 256;
+    constexpr int QD = 64 / LW, RD = 64 % LW;
+    const int pix0 = tid >> 2, sub0 = tid & 3;
+    const int ly0 = pix0 / LW, lx0 = pix0 - ly0 * LW;
+    const int relu_lim = a.relu_in ? 0 : (int)0x80000000;
+    const int H = P.H, W = P.W;
+
     for (int g = 0; g < a.groups; ++g) {
         if (g > 0) __syncthreads();
-        for (int idx = tid; idx < LH * LW * 4; idx += 256) {
-            const int pix = idx >> 2, sub = idx & 3;
-            const int ly = pix / LW, lx = pix - ly * LW;
-            const int gy = qy0 - 1 + ly, gx = qx0 - 1 + lx;
-            const int c = g * 16 + sub * 4;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < a.c0)
-                v = *reinterpret_cast<const f32x4*>(P.in0 + ((size_t)gy * P.W + gx) * a.c0 + c);
-            if (a.relu_in) v = relu4(v);
-            *reinterpret_cast<f32x4*>(lds + pix * 16 + sub * 4) = v;
+        {
+            const int c = g * 16 + sub0 * 4;
+            const bool cok = c < a.c0;
+            const float* __restrict__ src = P.in0 + (cok ? c : 0);
+            f32x4 st[NLOAD];
+            int ly = ly0, lx = lx0;
+#pragma unroll
+            for (int i = 0; i < NLOAD; ++i) {
+                const int gy = qy0 - 1 + ly, gx = qx0 - 1 + lx;
+                const bool ok = cok && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)(cy * W + cx) * a.c0);
+                st[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                lx += RD; ly += QD;
+                if (lx >= LW) { lx -= LW; ++ly; }
+            }
+#pragma unroll
+            for (int i = 0; i < NLOAD; ++i) {
+                const int idx = tid + i * 256;
+                if (i * 256 + 255 < NV || idx < NV) *reinterpret_cast<f32x4*>(lds + idx * 4) = imax4(st[i], relu_lim);
+            }
         }
         __syncthreads();
 
@@ -694,6 +714,23 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
         }
     }
 
+    // tiles whose 16 x 32 output pixels all exist and whose channels fill the lanes' quads: no bounds tests
+    if (2 * qy0 - P.pbh >= 0 && 2 * (qy0 + TH) - P.pbh <= P.Ho && 2 * qx0 - P.pbw >= 0 && 2 * (qx0 + TW) - P.pbw <= P.Wo && a.cout % 16 == 0) {
+        const int relu_o = a.relu_out ? 0 : (int)0x80000000;
+        const size_t p00 = (size_t)(2 * (qy0 + wave * NT) - P.pbh) * P.Wo + 2 * (qx0 + j) - P.pbw;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int c = (mt0 + m) * 16 + kk * 4;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c);
+            float* __restrict__ o = P.out + p00 * a.cout + c;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int cls = 0; cls < 4; ++cls)
+                    *reinterpret_cast<f32x4*>(o + ((size_t)(2 * n + (cls >> 1)) * P.Wo + (cls & 1)) * a.cout) = imax4(acc[m][n][cls] + b4, relu_o);
+        }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int qy = qy0 + wave * NT + n, qx = qx0 + j;
