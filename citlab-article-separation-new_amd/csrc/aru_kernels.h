@@ -731,6 +731,29 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
         }
         return;
     }
+    if constexpr (MT == 1) {
+        // 8 output channels (level 0): lanes kk = 2, 3 hold no channels.  They take over the odd-column parity class from
+        // lanes kk = 0, 1 (cross-lane move), so that one store instruction writes 16 pixel pairs x 8 channels = 1 KB
+        // contiguous with all 64 lanes instead of two half-empty ones with 32-byte pieces at a 64-byte stride.
+        if (a.cout == 8 && mt0 == 0 && 2 * qy0 - P.pbh >= 0 && 2 * (qy0 + TH) - P.pbh <= P.Ho && 2 * qx0 - P.pbw >= 0 &&
+            2 * (qx0 + TW) - P.pbw <= P.Wo) {
+            const int relu_o = a.relu_out ? 0 : (int)0x80000000;
+            const int hi = kk >> 1, src_lane = lane - 32 * hi;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + (kk & 1) * 4);
+            float* __restrict__ o = P.out + ((size_t)(2 * (qy0 + wave * NT) - P.pbh) * P.Wo + 2 * (qx0 + j) - P.pbw + hi) * 8 + (kk & 1) * 4;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int ry = 0; ry < 2; ++ry) {
+                    const f32x4 e = acc[0][n][ry * 2], od = acc[0][n][ry * 2 + 1];
+                    f32x4 t;
+                    t.x = __shfl(od.x, src_lane); t.y = __shfl(od.y, src_lane); t.z = __shfl(od.z, src_lane); t.w = __shfl(od.w, src_lane);
+                    const f32x4 v = hi ? t : e;
+                    *reinterpret_cast<f32x4*>(o + (size_t)(2 * n + ry) * P.Wo * 8) = imax4(v + b4, relu_o);
+                }
+            return;
+        }
+    }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int qy = qy0 + wave * NT + n, qx = qx0 + j;
