@@ -833,7 +833,7 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
             for (int s = 0; s < nsc && cfg.use_attention; ++s) {
                 const Tensor& a = att[b * nsc + s];
                 if (cdiv(H, up) != a.H || cdiv(W, up) != a.W) { set_error("internal: attention map shape"); return ASEP_ERR_ARG; }
-                ca.att[s] = a.p; ca.ah[s] = a.H; ca.aw[s] = a.W; ca.aup[s] = up;
+                ca.att[s] = a.p; ca.ah[s] = a.H; ca.aw[s] = a.W; ca.aup[s] = up; ca.ash[s] = 3 + s;
                 ca.aph[s] = (a.H * up - H) / 2; ca.apw[s] = (a.W * up - W) / 2;
                 up *= 2;
             }
@@ -841,7 +841,7 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
             for (int s = 1; s < nsc; ++s) {
                 const Tensor& f = feat[b * nsc + s];
                 up *= 2;
-                ca.fsum[s] = fsum[b * (nsc - 1) + (s - 1)].p; ca.fh[s] = f.H; ca.fw[s] = f.W; ca.fup[s] = up;
+                ca.fsum[s] = fsum[b * (nsc - 1) + (s - 1)].p; ca.fh[s] = f.H; ca.fw[s] = f.W; ca.fup[s] = up; ca.fsh[s] = s;
                 ca.fph[s] = (f.H * up - H) / 2; ca.fpw[s] = (f.W * up - W) / 2;
             }
             ca.wl = m->d_logit_w; ca.bl = m->d_logit_b;

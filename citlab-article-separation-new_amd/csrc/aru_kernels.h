@@ -1041,6 +1041,7 @@ struct CombineArgs {
     const float* att[MAX_SCALES];    // attention maps [ah,aw] (1 channel)
     int fh[MAX_SCALES], fw[MAX_SCALES], fup[MAX_SCALES], fph[MAX_SCALES], fpw[MAX_SCALES];
     int ah[MAX_SCALES], aw[MAX_SCALES], aup[MAX_SCALES], aph[MAX_SCALES], apw[MAX_SCALES];
+    int ash[MAX_SCALES], fsh[MAX_SCALES];   // log2 of aup / fup
     int nsc;                         // number of scales (1 = no attention)
     int H, W;
     const float* wl;                 // [4*4][FR][NC]
@@ -1059,7 +1060,6 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
     __shared__ float swl[16 * FR * NC + NC];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * T, y0 = blockIdx.y * T;
-    for (int i = tid; i < 16 * FR * NC; i += 256) swl[i] = a.wl[i];
     if (tid < NC) swl[16 * FR * NC + tid] = a.bl[tid];
 
     for (int pix = tid; pix < L * L; pix += 256) {
@@ -1074,20 +1074,29 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
 #pragma unroll
                 for (int c = 0; c < FR; ++c) v[c] = f[c];
             } else {
+                // the up-sampling factors are powers of two (8 * 2^s for the attention maps, 2^s for the feature maps):
+                // shifts instead of six run-time integer divisions per pixel; one reciprocal instead of three divisions
                 float av[MAX_SCALES], mx = -INFINITY;
-                for (int s = 0; s < a.nsc; ++s) {
-                    const int ay = (gy + a.aph[s]) / a.aup[s], ax = (gx + a.apw[s]) / a.aup[s];
-                    av[s] = a.att[s][(size_t)ay * a.aw[s] + ax];
-                    mx = fmaxf(mx, av[s]);
-                }
+#pragma unroll
+                for (int s = 0; s < MAX_SCALES; ++s)
+                    if (s < a.nsc) {
+                        const int ay = (gy + a.aph[s]) >> a.ash[s], ax = (gx + a.apw[s]) >> a.ash[s];
+                        av[s] = a.att[s][(size_t)ay * a.aw[s] + ax];
+                        mx = fmaxf(mx, av[s]);
+                    }
                 float den = 0.f;
-                for (int s = 0; s < a.nsc; ++s) { av[s] = expf(av[s] - mx); den += av[s]; }
+#pragma unroll
+                for (int s = 0; s < MAX_SCALES; ++s)
+                    if (s < a.nsc) { av[s] = expf(av[s] - mx); den += av[s]; }
+                const float inv = 1.f / den;
                 float add = 0.f;
-                for (int s = 1; s < a.nsc; ++s) {
-                    const int fy = (gy + a.fph[s]) / a.fup[s], fx = (gx + a.fpw[s]) / a.fup[s];
-                    add += a.fsum[s][(size_t)fy * a.fw[s] + fx] * (av[s] / den);
-                }
-                const float w0 = av[0] / den;
+#pragma unroll
+                for (int s = 1; s < MAX_SCALES; ++s)
+                    if (s < a.nsc) {
+                        const int fy = (gy + a.fph[s]) >> a.fsh[s], fx = (gx + a.fpw[s]) >> a.fsh[s];
+                        add += a.fsum[s][(size_t)fy * a.fw[s] + fx] * (av[s] * inv);
+                    }
+                const float w0 = av[0] * inv;
 #pragma unroll
                 for (int c = 0; c < FR; ++c) v[c] = f[c] * w0 + add;
             }
@@ -1108,7 +1117,9 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
 #pragma unroll
         for (int kx = 0; kx < 4; ++kx) {
             const float* mp = m + ((ty + ky) * L + tx + kx) * FR;
-            const float* wp = swl + (ky * 4 + kx) * FR * NC;
+            // uniform addresses: scalar loads, the weights are SGPR operands of the FMAs (read from LDS they took two
+            // thirds of the kernel's LDS bandwidth, which is what bounds it)
+            const float* __restrict__ wp = a.wl + (ky * 4 + kx) * FR * NC;
 #pragma unroll
             for (int c = 0; c < FR; ++c)
 #pragma unroll
