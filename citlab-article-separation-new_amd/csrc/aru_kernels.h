@@ -81,6 +81,14 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     return v;
 }
+// value of the same lane in the lower / upper half of the wave (lane & 31 / lane | 32) for every lane: one
+// v_permlane32_swap_b32 (gfx950) instead of a ds_bpermute through the LDS pipe and its lgkmcnt wait
+__device__ __forceinline__ float from_lower_half(float v) {
+    return __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false)[0]);
+}
+__device__ __forceinline__ float from_upper_half(float v) {
+    return __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false)[1]);
+}
 // max(x, lim) on the bit patterns (one v_max_i32 per element; fmaxf costs a second, canonicalising v_max_f32):
 // lim = 0 is ReLU, lim = INT_MIN the identity, so that a run-time "relu?" flag needs no branch
 __device__ __forceinline__ f32x4 imax4(f32x4 v, int lim) {
@@ -738,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
         if (a.cout == 8 && mt0 == 0 && 2 * qy0 - P.pbh >= 0 && 2 * (qy0 + TH) - P.pbh <= P.Ho && 2 * qx0 - P.pbw >= 0 &&
             2 * (qx0 + TW) - P.pbw <= P.Wo) {
             const int relu_o = a.relu_out ? 0 : (int)0x80000000;
-            const int hi = kk >> 1, src_lane = lane - 32 * hi;
+            const int hi = kk >> 1;
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + (kk & 1) * 4);
             float* __restrict__ o = P.out + ((size_t)(2 * (qy0 + wave * NT) - P.pbh) * P.Wo + 2 * (qx0 + j) - P.pbw + hi) * 8 + (kk & 1) * 4;
 #pragma unroll
@@ -747,7 +755,7 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
                 for (int ry = 0; ry < 2; ++ry) {
                     const f32x4 e = acc[0][n][ry * 2], od = acc[0][n][ry * 2 + 1];
                     f32x4 t;
-                    t.x = __shfl(od.x, src_lane); t.y = __shfl(od.y, src_lane); t.z = __shfl(od.z, src_lane); t.w = __shfl(od.w, src_lane);
+                    t.x = from_lower_half(od.x); t.y = from_lower_half(od.y); t.z = from_lower_half(od.z); t.w = from_lower_half(od.w);
                     const f32x4 v = hi ? t : e;
                     *reinterpret_cast<f32x4*>(o + (size_t)(2 * n + ry) * P.Wo * 8) = imax4(v + b4, relu_o);
                 }

@@ -172,7 +172,7 @@ __device__ __forceinline__ void res8_stage(const float* __restrict__ IN, int in_
                 // 2x2 max: rows in registers, the x neighbour (e = 1) sits in lane ^ 32; windows never straddle tiles
                 f32x4 m = oky1 ? f32x4{fmaxf(v0.x, v1.x), fmaxf(v0.y, v1.y), fmaxf(v0.z, v1.z), fmaxf(v0.w, v1.w)} : v0;
                 f32x4 o;
-                o.x = __shfl_xor(m.x, 32); o.y = __shfl_xor(m.y, 32); o.z = __shfl_xor(m.z, 32); o.w = __shfl_xor(m.w, 32);
+                o.x = from_upper_half(m.x); o.y = from_upper_half(m.y); o.z = from_upper_half(m.z); o.w = from_upper_half(m.w);   // only lanes < 32 (e == 0) use it
                 if (e == 0 && okx && oky0) {
                     if (okx1) { m.x = fmaxf(m.x, o.x); m.y = fmaxf(m.y, o.y); m.z = fmaxf(m.z, o.z); m.w = fmaxf(m.w, o.w); }
                     const int Wp = (W + 1) >> 1;
@@ -208,6 +208,9 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     float* R1 = R0 + 20 * R8_PITCH * 8;                      // frame rows 3..20  [18][72][8]
     __shared__ float w1s[9 * 8 + 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef ASEP_R8_TIMELINE
+    int tl_n = 0;
+#endif
     const int kk = lane >> 4;
     if (tid < 72) w1s[tid] = a.w1[tid];
     if (tid < 8) w1s[72 + tid] = a.b1[tid];
@@ -218,7 +221,8 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const f32x4 bias2 = *reinterpret_cast<const f32x4*>(a.br + 16 + ch);
 
     constexpr int NPRE = (R8_FH * R8_IMGP + R8_THREADS - 1) / R8_THREADS;
-    float pre[NPRE];
+    float pre[NPRE], pre_mean = 0.f, pre_inv = 1.f;
+    unsigned pre_mask = 0;
     // frame = one 24-row window of a work unit: (tile, pass) -> image rows [(tyb * NP + pass) * OH - 4, +24)
     auto image_load = [&](int tile_id, int pass) {          // next frame's image values -> registers (in flight under the MFMA stages)
         int pi = 0;
@@ -227,16 +231,18 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const int t = tile_id - Q.tile_begin;
         const int tyb = t / Q.tiles_x, txb = t - tyb * Q.tiles_x;
         const int qy0 = (tyb * R8_NP + pass) * R8_OH - 4, qx0 = txb * R8_OW - 4;
-        float mean = 0.f, inv = 1.f;
-        if (Q.stats) { mean = Q.stats[0]; inv = Q.stats[1]; }
+        // the standardisation is applied when the registers are written to LDS, not here: arithmetic on the loaded value
+        // would make this phase wait for the loads it has only just issued (5 k cycles per pass in the timeline)
+        pre_mean = 0.f; pre_inv = 1.f; pre_mask = 0;
+        if (Q.stats) { pre_mean = Q.stats[0]; pre_inv = Q.stats[1]; }
 #pragma unroll
         for (int k = 0; k < NPRE; ++k) {
             const int i = tid + k * R8_THREADS;
             const int r = i / R8_IMGP, c = i - r * R8_IMGP;
             const int gy = qy0 + r, gx = qx0 + c - 2;
-            float v = 0.f;
-            if (i < R8_FH * R8_IMGP && gy >= 0 && gy < Q.H && gx >= 0 && gx < Q.W) v = (Q.img[(size_t)gy * Q.W + gx] - mean) * inv;
-            pre[k] = v;
+            const bool ok = i < R8_FH * R8_IMGP && gy >= 0 && gy < Q.H && gx >= 0 && gx < Q.W;
+            pre[k] = Q.img[(size_t)min(max(gy, 0), Q.H - 1) * Q.W + min(max(gx, 0), Q.W - 1)];   // clamped: always a valid address
+            pre_mask |= (ok ? 1u : 0u) << k;
         }
     };
     int tile_id = (int)blockIdx.x < a.total_tiles ? res8_tile_of(a, blockIdx.x) : 0;
@@ -260,7 +266,9 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             const bool first = pass == 0;
             // a frame that lies inside the image needs no zero masks (scalar condition; carried passes only, to bound the code size)
             const bool interior = !first && fy0 >= 0 && fy0 + R8_FH <= H && fx0 - 2 >= 0 && fx0 + R8_PITCH + 2 <= W;
+            R8_MARK();   // 0 pass start
             __syncthreads();                                 // previous pass / tile finished with all LDS buffers
+            R8_MARK();   // 1 barrier
             if (!first) {
                 // rows carried over from the pass above (frame rows shift by OH = 16):
                 //   t  rows 20..22 -> 4..6,   r0 rows 20,21 -> 4,5,   r1 rows 19,20 -> 3,4
@@ -277,9 +285,10 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
             for (int q = 0; q < NPRE; ++q) {
                 const int i = tid + q * R8_THREADS;
-                if (i < R8_FH * R8_IMGP) IMG[i] = pre[q];
+                if (i < R8_FH * R8_IMGP) IMG[i] = ((pre_mask >> q) & 1u) ? (pre[q] - pre_mean) * pre_inv : 0.f;
             }
             __syncthreads();
+            R8_MARK();   // 2 image tile + carried rows in LDS
             r8_load_w(a.wr, lane, Wa);                       // convR_0's filter flies under the scalar conv1
             // ---- t = conv1(image) (identity activation): frame rows 1..22 (first pass) or the 16 new rows 7..22 ----
             const int t_lo = first ? 0 : 6 * R8_PITCH;
@@ -303,19 +312,27 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 *reinterpret_cast<f32x4*>(T + i * 8) = lo;
                 *reinterpret_cast<f32x4*>(T + i * 8 + 4) = hi;
             }
+            R8_MARK();   // 3 conv1 (VALU) done
             __syncthreads();
+            R8_MARK();   // 4 barrier
             if (first) res8_stage<20, true, false, false, BF>(T, 1, R0, 2, 2, 2, Wa, bias0, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr, a.wr + 6 * 64, Wb);
             else if (interior) res8_stage<16, true, false, false, BF, true>(T, 1, R0, 2, 6, 2, Wa, bias0, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr, a.wr + 6 * 64, Wb);
             else res8_stage<16, true, false, false, BF>(T, 1, R0, 2, 6, 2, Wa, bias0, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr, a.wr + 6 * 64, Wb);
+            R8_MARK();   // 5 stage0
             __syncthreads();
+            R8_MARK();   // 6 barrier
             if (first) res8_stage<18, false, false, false, BF>(R0, 2, R1, 3, 3, 3, Wb, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr, a.wr + 12 * 64, Wa);
             else if (interior) res8_stage<16, false, false, false, BF, true>(R0, 2, R1, 3, 5, 3, Wb, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr, a.wr + 12 * 64, Wa);
             else res8_stage<16, false, false, false, BF>(R0, 2, R1, 3, 5, 3, Wb, bias1, wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr, a.wr + 12 * 64, Wa);
+            R8_MARK();   // 7 stage1
             __syncthreads();
+            R8_MARK();   // 8 barrier
             if (more_passes) image_load(tile_id, pass + 1);
             else if (has_next) image_load(next_id, 0);
+            R8_MARK();   // 8b image prefetch issued
             if (interior) res8_stage<16, false, true, true, BF, true>(R1, 3, nullptr, 4, 4, 4, Wa, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, P.pool, nullptr, Wb);
             else res8_stage<16, false, true, true, BF>(R1, 3, nullptr, 4, 4, 4, Wa, bias2, wave, lane, fy0, fx0, H, W, T, 1, P.out, P.pool, nullptr, Wb);
+            R8_MARK();   // 9 stage2
         }
         tile_id = next_id;
     }
