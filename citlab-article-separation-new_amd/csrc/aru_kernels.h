@@ -143,7 +143,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     // are updated incrementally (one division per thread instead of one per slot), and both inputs of a concatenation
     // are served by ONE predicated load through a selected pointer (the one-shot blocks are short: the ~1200
     // instructions of the naive prologue cost as much issue time as half of the MFMA phase)
+    // NOTHING is computed from the loaded values here (the zero padding is applied from stmask when the registers are
+    // written to LDS): any arithmetic or select on them would make the wave wait for the loads it has just issued,
+    // which defeats the prefetch of the next channel group under the MFMAs
     f32x4 st[NLOAD];
+    unsigned stmask = 0;
     const bool interior = y0 - PT >= 0 && y0 - PT + LH <= H && x0 - PL >= 0 && x0 - PL + LW <= W;
     constexpr int PSTEP = 256 / SUBS, QD = PSTEP / LW, RD = PSTEP % LW;
     const int pix0 = tid / SUBS, sub0 = tid % SUBS;
@@ -162,22 +166,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             const ptrdiff_t step = (ptrdiff_t)(QD * W + RD) * cs, wrap = (ptrdiff_t)(W - LW) * cs;
 #pragma unroll
             for (int i = 0; i < NLOAD; ++i) {
-                // threads past the last slot of the window re-read the last row's tail (a valid address inside the image)
-                const bool have = cok && (i * 256 + 255 < NV || tid + i * 256 < NV);
-                st[i] = have ? *reinterpret_cast<const f32x4*>(q) : f32x4{0.f, 0.f, 0.f, 0.f};
+                // threads past the last slot of the window read the tile's first pixel instead (a valid address; never stored)
+                const bool have = i * 256 + 255 < NV || tid + i * 256 < NV;
+                st[i] = *reinterpret_cast<const f32x4*>(have ? q : src);
                 lx += RD;
                 q += step;
                 if (lx >= LW) { lx -= LW; q += wrap; }
             }
+            stmask = cok ? ~0u : 0u;
             return;
         }
+        stmask = 0;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             const int gy = y0 - PT + ly, gx = x0 - PL + lx;
             const bool ok = cok && (i * 256 + 255 < NV || tid + i * 256 < NV) && gy >= 0 && gy < H && gx >= 0 && gx < W;
             const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)(cy * W + cx) * cs);
-            st[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            st[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(cy * W + cx) * cs);
+            stmask |= (ok ? 1u : 0u) << i;
             lx += RD; ly += QD;
             if (lx >= LW) { lx -= LW; ++ly; }
         }
@@ -188,7 +194,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         for (int i = 0; i < NLOAD; ++i) {
             const int idx = tid + i * 256;
             if (idx < NV) {
-                *reinterpret_cast<f32x4*>(lds + buf * LBUF + idx * 4) = imax4(st[i], relu_lim);   // idx*4 == pix*CPP + sub*4
+                const f32x4 v = ((stmask >> i) & 1u) ? st[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(lds + buf * LBUF + idx * 4) = imax4(v, relu_lim);   // idx*4 == pix*CPP + sub*4
             }
         }
     };
@@ -408,6 +415,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
     // 4x4 patches are read from LDS.  (Every thread fetching its own patch with sixteen 8-byte loads made the blocks
     // vector-memory-issue-bound: scripts/ubench/wino_timeline.hip showed 6100 + 2500 cycles spent just issuing them.)
     f32x4 st[NHL];
+    unsigned stmask = 0;
     const int pix0 = tid >> 2, sub0 = tid & 3;
     const int hy0 = pix0 / HW, hx0 = pix0 - hy0 * HW;
     constexpr int QD = 64 / HW, RD = 64 % HW;              // the pixel index advances by 64 per slot
@@ -418,13 +426,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
         const float* __restrict__ src = from0 ? P.in0 + c : P.in1 + (c - a.c0);
         const int cs = from0 ? a.c0 : a.c1;
         int hy = hy0, hx = hx0;
+        stmask = 0;
 #pragma unroll
         for (int i = 0; i < NHL; ++i) {
             const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;  // SAME: pad 1
             const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
             const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);   // clamped: always a valid address
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)(cy * W + cx) * cs);
-            st[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            st[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(cy * W + cx) * cs);
+            stmask |= (ok ? 1u : 0u) << i;                 // (no select on the loaded value here: it would wait for the load)
             hx += RD; hy += QD;
             if (hx >= HW) { hx -= HW; ++hy; }
         }
@@ -433,8 +442,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < NHL; ++i) {
             const int idx = tid + i * 256;
-            if (i * 256 + 255 < NH || idx < NH)
-                *reinterpret_cast<f32x4*>(HALO + (idx >> 2) * HP + sub0 * 4) = imax4(st[i], relu_lim);
+            if (i * 256 + 255 < NH || idx < NH) {
+                const f32x4 v = ((stmask >> i) & 1u) ? st[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(HALO + (idx >> 2) * HP + sub0 * 4) = imax4(v, relu_lim);
+            }
         }
     };
     auto transform_store = [&](int buf) {
@@ -660,21 +671,25 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
             const bool cok = c < a.c0;
             const float* __restrict__ src = P.in0 + (cok ? c : 0);
             f32x4 st[NLOAD];
+            unsigned stmask = 0;
             int ly = ly0, lx = lx0;
 #pragma unroll
             for (int i = 0; i < NLOAD; ++i) {
                 const int gy = qy0 - 1 + ly, gx = qx0 - 1 + lx;
                 const bool ok = cok && gy >= 0 && gy < H && gx >= 0 && gx < W;
                 const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)(cy * W + cx) * a.c0);
-                st[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                st[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(cy * W + cx) * a.c0);
+                stmask |= (ok ? 1u : 0u) << i;
                 lx += RD; ly += QD;
                 if (lx >= LW) { lx -= LW; ++ly; }
             }
 #pragma unroll
             for (int i = 0; i < NLOAD; ++i) {
                 const int idx = tid + i * 256;
-                if (i * 256 + 255 < NV || idx < NV) *reinterpret_cast<f32x4*>(lds + idx * 4) = imax4(st[i], relu_lim);
+                if (i * 256 + 255 < NV || idx < NV) {
+                    const f32x4 v = ((stmask >> i) & 1u) ? st[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(lds + idx * 4) = imax4(v, relu_lim);
+                }
             }
         }
         __syncthreads();
