@@ -6,8 +6,8 @@
 // in LDS for a 16 x 58 pixel output tile (halo recomputation: 22/20/18/16 rows x 64 columns per stage) and maps
 // each 3x3x8->8 convolution onto v_mfma_f32_16x16x4_f32 with M = 8 output channels x 2 horizontally adjacent
 // pixels ("pixel pair"), N = 16 pixel pairs, K = 3 rows x 4 columns x 8 channels = 96 (75 % useful MACs instead
-// of 45 % for the generic kernel).  All three 8->8 filters live in registers (72 VGPRs) for the lifetime of the
-// persistent block.
+// of 45 % for the generic kernel).  A stage's 8->8 filter lives in registers for that stage only (24 VGPRs, requested
+// one stage ahead); a wave's two pixel-pair units per stage have their LDS fragments requested up front.
 #pragma once
 #include "aru_kernels.h"
 
