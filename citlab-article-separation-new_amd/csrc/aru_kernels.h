@@ -569,11 +569,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
         for (int h = 0; h < MPR; ++h) {
             const int m = rd * 2 + h;
             if (m < MT) {
+                // a wave holds one ROW of the 4 x 4 position grid: the column half of A^T M A (positions s = 0..3 -> output
+                // columns dx = 0, 1) is formed in registers, so only 2 instead of 4 vectors per (m, n) cross the LDS
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        *reinterpret_cast<f32x4*>(V + h * VBUF + ((wave * 4 + p) * TILES + n * 16 + j) * 16 + kk * 4) = acc[p][m][n];
+                for (int n = 0; n < 2; ++n) {
+                    const f32x4 z0 = acc[0][m][n] + acc[1][m][n] + acc[2][m][n];
+                    const f32x4 z1 = acc[1][m][n] - acc[2][m][n] - acc[3][m][n];
+                    float* xb = V + h * VBUF + ((wave * 2) * TILES + n * 16 + j) * 16 + kk * 4;
+                    *reinterpret_cast<f32x4*>(xb) = z0;
+                    *reinterpret_cast<f32x4*>(xb + TILES * 16) = z1;
+                }
             }
         }
         WINO_MARK();   // exchange written
@@ -584,22 +589,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
             const int m = rd * 2 + h;
             if (m >= MT) continue;
             const float* mb = V + h * VBUF + tt * 16 + cp * 2;
-            f32x2 s0[4], s1[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const f32x2 m0 = *reinterpret_cast<const f32x2*>(mb + (0 * 4 + s) * TILES * 16);
-                const f32x2 m1 = *reinterpret_cast<const f32x2*>(mb + (1 * 4 + s) * TILES * 16);
-                const f32x2 m2 = *reinterpret_cast<const f32x2*>(mb + (2 * 4 + s) * TILES * 16);
-                const f32x2 m3 = *reinterpret_cast<const f32x2*>(mb + (3 * 4 + s) * TILES * 16);
-                s0[s] = m0 + m1 + m2;
-                s1[s] = m1 - m2 - m3;
-            }
+            // row half of the inverse transform: rows r = 0..3 (one per wave) -> output rows dy = 0, 1
             // 2 x 2 output pixels of tile tt, channels 2cp, 2cp+1 of m-tile h -> output tile
             float* ob = OT + ((2 * (tt >> 4)) * TW + 2 * (tt & 15)) * CPR + h * 16 + cp * 2;
-            *reinterpret_cast<f32x2*>(ob) = s0[0] + s0[1] + s0[2];
-            *reinterpret_cast<f32x2*>(ob + CPR) = s0[1] - s0[2] - s0[3];
-            *reinterpret_cast<f32x2*>(ob + TW * CPR) = s1[0] + s1[1] + s1[2];
-            *reinterpret_cast<f32x2*>(ob + TW * CPR + CPR) = s1[1] - s1[2] - s1[3];
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const f32x2 z0 = *reinterpret_cast<const f32x2*>(mb + (0 * 2 + dx) * TILES * 16);
+                const f32x2 z1 = *reinterpret_cast<const f32x2*>(mb + (1 * 2 + dx) * TILES * 16);
+                const f32x2 z2 = *reinterpret_cast<const f32x2*>(mb + (2 * 2 + dx) * TILES * 16);
+                const f32x2 z3 = *reinterpret_cast<const f32x2*>(mb + (3 * 2 + dx) * TILES * 16);
+                *reinterpret_cast<f32x2*>(ob + dx * CPR) = z0 + z1 + z2;
+                *reinterpret_cast<f32x2*>(ob + TW * CPR + dx * CPR) = z1 - z2 - z3;
+            }
         }
         __syncthreads();
 #pragma unroll
