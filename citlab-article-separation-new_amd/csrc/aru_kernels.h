@@ -591,7 +591,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
             const float* mb = V + h * VBUF + tt * 16 + cp * 2;
             // row half of the inverse transform: rows r = 0..3 (one per wave) -> output rows dy = 0, 1
             // 2 x 2 output pixels of tile tt, channels 2cp, 2cp+1 of m-tile h -> output tile
-            float* ob = OT + ((2 * (tt >> 4)) * TW + 2 * (tt & 15)) * CPR + h * 16 + cp * 2;
+            // (pixels of odd tiles keep their two 16-channel halves swapped: the four tiles of a half-wave then use both
+            // halves of the 32 banks instead of all writing the same 16)
+            float* ob = OT + ((2 * (tt >> 4)) * TW + 2 * (tt & 15)) * CPR + ((h * 16 + cp * 2) ^ (CPR == 32 ? (tt & 1) << 4 : 0));
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 const f32x2 z0 = *reinterpret_cast<const f32x2*>(mb + (0 * 2 + dx) * TILES * 16);
@@ -610,7 +612,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
             const int yy = y0 + (pix >> 5), xx = x0 + (pix & 31);
             const int co = cbase + q * 4;
             if (yy < P.Ho && xx < P.Wo && co < a.cout) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(OT + pix * CPR + q * 4) + *reinterpret_cast<const f32x4*>(a.bias + co);
+                f32x4 v = *reinterpret_cast<const f32x4*>(OT + pix * CPR + ((q * 4) ^ (CPR == 32 ? ((pix >> 1) & 1) << 4 : 0))) +
+                          *reinterpret_cast<const f32x4*>(a.bias + co);
                 if (res) v += rv[i];
                 if (a.relu_out) v = relu4(v);
                 *reinterpret_cast<f32x4*>(out + ((size_t)yy * P.Wo + xx) * a.cout + co) = v;
