@@ -94,6 +94,7 @@ struct asep_aru {
     bool use_xcd_sched = true;     // ASEP_XCD_SCHED=0: identity tile order in the persistent fused kernels
     std::map<std::string, const int32_t*> sched_cache;
     bool bf16 = false;             // cfg.compute_dtype == 1: bf16 MFMA operands, fp32 accumulation and storage
+    bool wino_reg = true;          // ASEP_WINO_REG=0: LDS-image Winograd kernel also for the 32-channel level
     bool use_winograd = true;      // ASEP_WINOGRAD=0 selects the direct implicit-GEMM kernels everywhere
     bool profiling = false;
     bool prof_detail = false;      // per-layer names (scope + spatial size) instead of per-kernel names
@@ -358,7 +359,11 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             std::string pname = "conv_wino_kernel<" + std::to_string(mt) + ">";
             if (m->prof_detail) pname += " " + scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
             ProfScope ps(m, pname, flops);
-            if (m->bf16) {
+            if (mt == 2 && m->wino_reg) {
+                // register-resident variant: a wave per (tile row, m-tile); grid.y counts pairs of m-tiles
+                if (m->bf16) hipLaunchKernelGGL((conv_winor_kernel<true>), grid, dim3(256), 0, m->stream, a);
+                else hipLaunchKernelGGL((conv_winor_kernel<false>), grid, dim3(256), 0, m->stream, a);
+            } else if (m->bf16) {
                 if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4, true>), grid, dim3(256), 0, m->stream, a);
                 else if (mt == 2) hipLaunchKernelGGL((conv_wino_kernel<2, true>), grid, dim3(256), 0, m->stream, a);
                 else hipLaunchKernelGGL((conv_wino_kernel<1, true>), grid, dim3(256), 0, m->stream, a);
@@ -951,6 +956,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     m->cfg = *cfg;
     m->bf16 = cfg->compute_dtype == 1;
     if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_WINO_REG")) m->wino_reg = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BIGTILE")) m->big_tile = atoi(e) != 0;

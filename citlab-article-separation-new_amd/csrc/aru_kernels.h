@@ -624,6 +624,183 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Register-resident Winograd F(2x2,3x3) (MT = 2: the 32-channel level).  conv_wino_kernel above is bound by LDS traffic
+// (3 KB per output pixel: V written and read, accumulators exchanged, output tile), not by MFMAs or memory.  Here a
+// lane keeps a whole tile column in registers:
+//   wave w = (tile row n = w & 1, m-tile mh = w >> 1);  lane (j, kk) = (tile j of that row, channel quad kk)
+//   * reads its 4x4 patch x 4 channels from the LDS window (16 x ds_read_b128), forms V = B^T d B for ALL 16 positions
+//     in registers: these are exactly the B fragments of the MFMAs (k-slot kk = channels 4kk..4kk+3);
+//   * multiplies all 16 positions for its m-tile (A = packed U fragments from L2, one position ahead);
+//   * holds M[16 positions] for (tile j, output channels 4kk..4kk+3) at the end: A^T M A, bias, residual, ReLU and
+//     16-byte stores happen in registers.
+// No V image, no accumulator exchange, no output tile: the only LDS traffic is the input window (13 KB written, 64 KB
+// read per channel group instead of ~160 KB), at the price of forming V twice (once per m-tile wave).
+// ------------------------------------------------------------------------------------------------
+template <bool BF = false>
+__global__ __launch_bounds__(256, 2) void conv_winor_kernel(const ConvArgs a) {
+    constexpr int TH = WINO_TH, TW = WINO_TW;
+    constexpr int HH = TH + 2, HW = TW + 2, HP = 20;      // window: 6 x 34 pixels x 16 channels, pixel pitch 20 floats
+    constexpr int NH = HH * HW * 4;                       // float4 slots of the window
+    constexpr int NHL = (NH + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float HALO[HH * HW * HP];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, kk = lane >> 4;
+    const int n = wave & 1, mh = wave >> 1;
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    const ConvProb& P = a.p[pi];
+    const int tile = blockIdx.x - P.tile_begin;
+    const int tyb = tile / P.tiles_x, txb = tile - tyb * P.tiles_x;
+    const int x0 = txb * TW, y0 = tyb * TH, mt = blockIdx.y * 2 + mh;      // this wave's 16-channel output tile
+    const int H = P.H, W = P.W;
+
+    // window: HBM -> registers (16 B per lane, coalesced, one channel group ahead) -> LDS; raw values + validity mask
+    f32x4 st[NHL];
+    unsigned stmask = 0;
+    const int pix0 = tid >> 2, sub0 = tid & 3;
+    const int hy0 = pix0 / HW, hx0 = pix0 - hy0 * HW;
+    constexpr int QD = 64 / HW, RD = 64 % HW;
+    const int relu_lim = a.relu_in ? 0 : (int)0x80000000;
+    auto halo_load = [&](int g) {
+        const int c = g * 16 + sub0 * 4;
+        const bool from0 = c < a.c0;
+        const float* __restrict__ src = from0 ? P.in0 + c : P.in1 + (c - a.c0);
+        const int cs = from0 ? a.c0 : a.c1;
+        int hy = hy0, hx = hx0;
+        stmask = 0;
+#pragma unroll
+        for (int i = 0; i < NHL; ++i) {
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;  // SAME: pad 1
+            const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);   // clamped: always a valid address
+            st[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(cy * W + cx) * cs);
+            stmask |= (ok ? 1u : 0u) << i;
+            hx += RD; hy += QD;
+            if (hx >= HW) { hx -= HW; ++hy; }
+        }
+    };
+    auto halo_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NHL; ++i) {
+            const int idx = tid + i * 256;
+            if (i * 256 + 255 < NH || idx < NH) {
+                const f32x4 v = ((stmask >> i) & 1u) ? st[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(HALO + (idx >> 2) * HP + sub0 * 4) = imax4(v, relu_lim);
+            }
+        }
+    };
+
+    f32x4 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const f32x4* __restrict__ wbase = a.wpk + (size_t)mt * 64 + lane;
+    const size_t wstride = (size_t)a.mtiles * 64;          // f32x4 per (group, pos)
+    const int G = a.groups;
+    const float* hb = HALO + ((2 * n) * HW + 2 * j) * HP + kk * 4;   // this lane's patch origin in the window
+
+    const int co = mt * 16 + kk * 4;                       // this lane's 4 output channels
+    const int oy = y0 + 2 * n, ox = x0 + 2 * j;            // and the top-left output pixel of its tile
+    f32x4 rv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    halo_load(0);
+    f32x4 af = wbase[0];
+    halo_store();
+    __syncthreads();
+
+    for (int g = 0; g < G; ++g) {
+        const bool more = g + 1 < G;
+        // ---- V = B^T d B of this lane's tile, 4 channels wide: row pass while reading, then the column pass ------
+        f32x4 V[4][4];
+        {
+            f32x4 d0[4], d1[4], d2[4], d3[4];
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                d0[s2] = *reinterpret_cast<const f32x4*>(hb + (0 * HW + s2) * HP);
+                d1[s2] = *reinterpret_cast<const f32x4*>(hb + (1 * HW + s2) * HP);
+                d2[s2] = *reinterpret_cast<const f32x4*>(hb + (2 * HW + s2) * HP);
+                d3[s2] = *reinterpret_cast<const f32x4*>(hb + (3 * HW + s2) * HP);
+            }
+            if (more) halo_load(g + 1);                    // global loads in flight during the MFMA phase
+            else if (P.res) {                              // last group: the residual operand flies under its MFMAs
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int yy = min(oy + (q >> 1), P.Ho - 1), xx = min(ox + (q & 1), P.Wo - 1);
+                    rv[q] = *reinterpret_cast<const f32x4*>(P.res + ((size_t)yy * P.Wo + xx) * a.cout + co);
+                }
+            }
+            f32x4 t[4][4];
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                t[0][s2] = d0[s2] - d2[s2];
+                t[1][s2] = d1[s2] + d2[s2];
+                t[2][s2] = d2[s2] - d1[s2];
+                t[3][s2] = d1[s2] - d3[s2];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                V[r][0] = t[r][0] - t[r][2];
+                V[r][1] = t[r][1] + t[r][2];
+                V[r][2] = t[r][2] - t[r][1];
+                V[r][3] = t[r][1] - t[r][3];
+            }
+        }
+        // ---- 16 positions x (K = 16 channels) for this wave's m-tile; the filter fragment is requested one position ahead ----
+        const f32x4* __restrict__ wg = wbase + (size_t)g * 16 * wstride;
+        const f32x4* __restrict__ wfirst_next = wbase + (size_t)(more ? g + 1 : g) * 16 * wstride;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const f32x4 an = p + 1 < 16 ? wg[(size_t)(p + 1) * wstride] : wfirst_next[0];
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 b = V[p >> 2][p & 3];
+            if constexpr (BF) {
+                acc[p] = mfma_bf16(bf16pack(af), bf16pack(b), acc[p]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], b[r], acc[p], 0, 0, 0);
+            }
+            af = an;
+        }
+        if (more) {
+            __syncthreads();                               // every wave has read its patches of group g
+            halo_store();
+            __syncthreads();
+        }
+    }
+
+    // ---- A^T M A in registers: lane (j, kk) holds tile (n, j), output channels 4kk..4kk+3 of m-tile mt ----------------
+    if (co >= a.cout) return;                              // (cout is a multiple of 16 on this path)
+    f32x4 s0[4], s1[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+        s0[s2] = acc[0 * 4 + s2] + acc[1 * 4 + s2] + acc[2 * 4 + s2];
+        s1[s2] = acc[1 * 4 + s2] - acc[2 * 4 + s2] - acc[3 * 4 + s2];
+    }
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + co);
+    f32x4 y[2][2];
+    y[0][0] = s0[0] + s0[1] + s0[2] + b4;
+    y[0][1] = s0[1] - s0[2] - s0[3] + b4;
+    y[1][0] = s1[0] + s1[1] + s1[2] + b4;
+    y[1][1] = s1[1] - s1[2] - s1[3] + b4;
+    const int relu_o = a.relu_out ? 0 : (int)0x80000000;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int yy = oy + dy, xx = ox + dx;
+            if (yy < P.Ho && xx < P.Wo) {
+                const size_t pp = ((size_t)yy * P.Wo + xx) * a.cout + co;
+                const f32x4 v = y[dy][dx] + rv[dy * 2 + dx];
+                *reinterpret_cast<f32x4*>(P.out + pp) = imax4(v, relu_o);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv2d_transpose 3x3, stride 2, SAME (layers.py:362).  With I = i + pad_before:
 //   I = 2*o + k  ->  k odd <=> I odd;  I even: k in {0 (o = I/2), 2 (o = I/2 - 1)};  I odd: k = 1.
 // The block works on a tile of q = floor(I/2) positions; every q yields the four outputs
