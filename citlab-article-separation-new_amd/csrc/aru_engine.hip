@@ -356,7 +356,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             a.total_tiles = wt;
             const int ny = pc.mtiles / mt;
             dim3 grid(wt, ny);
-            std::string pname = "conv_wino_kernel<" + std::to_string(mt) + ">";
+            std::string pname = (mt == 2 && m->wino_reg) ? std::string("conv_winor_kernel") : "conv_wino_kernel<" + std::to_string(mt) + ">";
             if (m->prof_detail) pname += " " + scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
             ProfScope ps(m, pname, flops);
             if (mt == 2 && m->wino_reg) {

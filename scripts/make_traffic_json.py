@@ -12,7 +12,7 @@ def bench_name(rocprof_name):
     if not m:
         return n
     base, targs = m.group(1), [t.strip() for t in m.group(2).split(",")]
-    if base in ("res8_up_kernel", "res8_down_kernel"):
+    if base in ("res8_up_kernel", "res8_down_kernel", "conv_winor_kernel"):
         return base
     if base in ("conv_wino_kernel", "deconv_mfma_kernel"):
         return f"{base}<{targs[0]}>"
