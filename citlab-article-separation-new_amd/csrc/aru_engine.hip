@@ -317,7 +317,9 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
     }
     TL out;
     for (const Tensor& t : in0) out.push_back(new_tensor(m, t.H, t.W, pc.cout));
-    const bool wino = pc.d_wino && m->use_winograd;
+    // bf16 MFMAs are so much faster that the LDS-bound Winograd kernels only pay at 128 channels (and they amplify the
+    // bf16 rounding): the bf16 variant takes the direct kernels below that
+    const bool wino = pc.d_wino && m->use_winograd && (!m->bf16 || pc.mtiles >= 8);
     // single channel group, one 16-channel output tile: 16 x 32 pixel blocks, single LDS buffer (more MFMA work per
     // block against the fixed load latency of these short blocks)
     const bool big_tile = !wino && !pc.c8 && pc.groups == 1 && pc.mtiles == 1 && m->big_tile;
