@@ -90,7 +90,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
-    distributed = world > 1
+    # ASEP_BENCH_FORCE_DIST=1 runs the RCCL code path (init, weight broadcast, barrier, max-reduction) with one rank too
+    distributed = world > 1 or os.environ.get("ASEP_BENCH_FORCE_DIST") == "1"
 
     # ---- CPU baseline first (rank 0, N == 1), BEFORE this process touches the GPU: the CPU oracle (a port of the
     #      reference graph, kind="port") in worker processes on this box's host cores, bounded sample -------------
@@ -102,9 +103,15 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    stdout_fd = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL writes a version banner to STDOUT when its first communicator is created; stdout carries exactly one JSON
+        # line, so fd 1 points at stderr until the communicator exists (restored after the weight broadcast below)
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from citlab_article_separation_new_amd import _lib, sharding, synth
@@ -123,6 +130,11 @@ def main():
         blobs = [None, None]
     if distributed:
         blobs = [sharding.broadcast_blob(b or b"", rank, dev) for b in blobs]
+        dist.barrier()
+        torch.cuda.synchronize()
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
+        os.close(stdout_fd)
     aru = AruGraph(unpack_blob(blobs[0]), aru_cfg)
     gnn = GnnGraph(unpack_blob(blobs[1]), gnn_cfg)
     lib = _lib.init_device(local_rank)
