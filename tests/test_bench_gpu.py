@@ -1,0 +1,40 @@
+"""bench.py contract on a GPU box: ONE JSON line on stdout carrying the driver's keys, with and without the RCCL code path
+(torch.distributed.run with one rank and ASEP_BENCH_FORCE_DIST=1: init, weight broadcast, barrier, max-reduction)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline"}
+
+
+def _one_json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f"stdout must hold exactly one line, got {len(lines)}: {lines[:3]}"
+    line = json.loads(lines[0])
+    assert KEYS <= set(line), KEYS - set(line)
+    assert line["unit"] == "pages/s" and line["value"] > 0 and line["n_gpus"] == 1 and line["scaling"] == "weak"
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+    return line
+
+
+def test_single_process_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _one_json_line(r.stdout)
+    assert line["steps"] == 2 and line["warmup"] == 1 and line["dtype"] == "f32"
+
+
+def test_rccl_path_with_one_rank_keeps_stdout_clean():
+    env = dict(os.environ, ASEP_BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _one_json_line(r.stdout)
