@@ -92,3 +92,28 @@ def test_full_page_interior_matches_oracle_on_a_crop(graph, ch, cw, margin):
     assert err <= 1e-4, err
     # and the run is bit-reproducible (no atomics on the float path)
     assert np.array_equal(out, helper.get_net_output(page, g, "0"))
+
+
+@pytest.mark.parametrize("H,W,graph", [(203, 310, "ARU"), (256, 384, "ARU"), (331, 277, "RU")])
+def test_medium_pages_interior_and_border_tiles(H, W, graph):
+    """Sizes at which every level down to 1/8 resolution has both interior tiles (mask-free loaders / epilogues, packed
+    deconv stores, register Winograd) and border tiles, checked end point by end point against the oracle."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    from oracle import aru_oracle
+    cfg = AruConfig(graph=graph)
+    w = init_aru_weights(cfg, 4242, bias_jitter=0.05, logit_scale=0.05)
+    g = helper.AruGraph(w, cfg)
+    img = np.random.default_rng(H + W).random((H, W), dtype=np.float32)
+    ref, inter = aru_oracle.forward_torch(img, w, cfg, return_intermediates=True)
+    out = helper.get_net_output(img, g, "0")
+    names = ["scale_0_unet_down_0_conv", "scale_0_unet_down_1_conv", "scale_0_unet_down_2_conv", "scale_0_unet_down_3_conv",
+             "scale_0_unet_down_4_conv", "scale_0_unet_up_3_conv", "scale_0_unet_up_2_conv", "scale_0_unet_up_1_conv",
+             "scale_0_unet_up_0_conv"]
+    for name in names:
+        got = helper.get_endpoint(g, name)
+        scale = max(1.0, float(np.abs(inter[name]).max()))
+        assert float(np.abs(got - inter[name]).max()) <= 3e-5 * scale, name
+    assert float(np.abs(out - ref).max()) <= 1e-4
+    g.close()
