@@ -703,12 +703,16 @@ __global__ __launch_bounds__(256, 2) void conv_winor_kernel(const ConvArgs a) {
 
     const int co = mt * 16 + kk * 4;                       // this lane's 4 output channels
     const int oy = y0 + 2 * n, ox = x0 + 2 * j;            // and the top-left output pixel of its tile
-    f32x4 rv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) rv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     halo_load(0);
     f32x4 af = wbase[0];
+    // residual operand: requested once, up front (requested inside the group loop it became a loop-carried register set
+    // that the compiler copied - and waited for - in every iteration)
+    f32x4 rv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int yy = min(oy + (q >> 1), P.Ho - 1), xx = min(ox + (q & 1), P.Wo - 1);
+        rv[q] = P.res ? *reinterpret_cast<const f32x4*>(P.res + ((size_t)yy * P.Wo + xx) * a.cout + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     halo_store();
     __syncthreads();
 
@@ -726,13 +730,6 @@ __global__ __launch_bounds__(256, 2) void conv_winor_kernel(const ConvArgs a) {
                 d3[s2] = *reinterpret_cast<const f32x4*>(hb + (3 * HW + s2) * HP);
             }
             if (more) halo_load(g + 1);                    // global loads in flight during the MFMA phase
-            else if (P.res) {                              // last group: the residual operand flies under its MFMAs
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int yy = min(oy + (q >> 1), P.Ho - 1), xx = min(ox + (q & 1), P.Wo - 1);
-                    rv[q] = *reinterpret_cast<const f32x4*>(P.res + ((size_t)yy * P.Wo + xx) * a.cout + co);
-                }
-            }
             f32x4 t[4][4];
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
