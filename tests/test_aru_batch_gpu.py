@@ -117,3 +117,22 @@ def test_medium_pages_interior_and_border_tiles(H, W, graph):
         assert float(np.abs(got - inter[name]).max()) <= 3e-5 * scale, name
     assert float(np.abs(out - ref).max()) <= 1e-4
     g.close()
+
+
+def test_bf16_variant_medium_page_within_stated_tolerance():
+    """bf16 MFMA operands (fp32 accumulation and storage): direct kernels up to 64 channels, Winograd at 128; the stated
+    tolerance of the bf16 variant is 2e-2 on the probabilities."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    from oracle import aru_oracle
+    cfg = AruConfig(compute_dtype="bf16")
+    w = init_aru_weights(cfg, 4242, bias_jitter=0.05, logit_scale=0.05)
+    g = helper.AruGraph(w, cfg)
+    img = np.random.default_rng(5).random((256, 384), dtype=np.float32)
+    ref = aru_oracle.forward_torch(img, w, AruConfig())
+    out = helper.get_net_output(img, g, "0")
+    err = float(np.abs(out - ref).max())
+    assert err <= 2e-2, err
+    assert err > 1e-6          # it really is the reduced-precision path
+    g.close()
