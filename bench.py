@@ -155,6 +155,10 @@ def main():
     out_mask = [torch.empty(H, W, ncls, device=dev, dtype=torch.uint8) for _ in range(B)]
     out_conf = [torch.empty(N * N, gnn_cfg.num_classes, device=dev) for _ in range(B)]
     stream = torch.cuda.current_stream().cuda_stream
+    # the relation graphs do not depend on the segmentation of the same step (different command lines in the pipeline): they
+    # run on a second stream and fill the launch tails of the CNN
+    gnn_torch_stream = torch.cuda.Stream()
+    gnn_stream = gnn_torch_stream.cuda_stream
 
     PtrArr = C.c_void_p * B
     p_img = PtrArr(*[t.data_ptr() for t in imgs])
@@ -169,7 +173,7 @@ def main():
         for k in range(B):
             if not args.no_gnn:
                 _lib.check(lib.asep_gnn_forward_dev(h_gnn, N, E[k], g_edges[k].data_ptr(), g_u[k].data_ptr(),
-                                                    g_ef[k].data_ptr(), N * N, None, out_conf[k].data_ptr(), stream),
+                                                    g_ef[k].data_ptr(), N * N, None, out_conf[k].data_ptr(), gnn_stream),
                            "asep_gnn_forward_dev")
 
     def sync_all():
