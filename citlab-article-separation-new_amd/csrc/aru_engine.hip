@@ -948,6 +948,7 @@ int aru_endpoint_channels(const asep_aru* m, const char* name) {
 extern "C" {
 
 asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_cfg* cfg) {
+    ASEP_GUARD_BEGIN
     if (!cfg || !weight_blob) { set_error("asep_aru_load: null argument"); return nullptr; }
     if (cfg->channels != 1) { set_error("asep_aru_load: only 1-channel input is supported (ARU_v1.py:115)"); return nullptr; }
     if (cfg->compute_dtype != 0 && cfg->compute_dtype != 1) { set_error("asep_aru_load: compute_dtype %d unknown (0 = fp32, 1 = bf16 MFMA)", cfg->compute_dtype); return nullptr; }
@@ -1035,6 +1036,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     m->owned.push_back(m->d_stats);
     m->owned.push_back(m->d_sums);
     return m.release();
+    ASEP_GUARD_END_PTR
 }
 
 void asep_aru_free(asep_aru* m) { delete m; }
@@ -1068,13 +1070,16 @@ static int forward_lanes(asep_aru* m, int n_pages, const float* const* d_imgs, i
 
 int asep_aru_forward_dev(asep_aru* m, const float* d_img, int H, int W, float* d_out, uint8_t* d_out_u8,
                          uint8_t* d_out_mask, float threshold, void* stream) {
+    ASEP_GUARD_BEGIN
     if (!m || !d_img || !d_out || H < 1 || W < 1) { set_error("asep_aru_forward_dev: bad argument"); return ASEP_ERR_ARG; }
     return forward_lanes(m, 1, &d_img, H, W, &d_out, d_out_u8 ? &d_out_u8 : nullptr, d_out_mask ? &d_out_mask : nullptr,
                          threshold, (hipStream_t)stream);
+    ASEP_GUARD_END
 }
 
 int asep_aru_forward_batch_dev(asep_aru* m, int n_pages, const float* const* d_imgs, int H, int W, float* const* d_outs,
                                uint8_t* const* d_out_u8, uint8_t* const* d_out_mask, float threshold, void* stream) {
+    ASEP_GUARD_BEGIN
     if (!m || !d_imgs || !d_outs || n_pages < 1 || H < 1 || W < 1) { set_error("asep_aru_forward_batch_dev: bad argument"); return ASEP_ERR_ARG; }
     for (int b = 0; b < n_pages; ++b)
         if (!d_imgs[b] || !d_outs[b] || (d_out_u8 && !d_out_u8[b]) || (d_out_mask && !d_out_mask[b])) {
@@ -1082,10 +1087,12 @@ int asep_aru_forward_batch_dev(asep_aru* m, int n_pages, const float* const* d_i
             return ASEP_ERR_ARG;
         }
     return forward_lanes(m, n_pages, d_imgs, H, W, d_outs, d_out_u8, d_out_mask, threshold, (hipStream_t)stream);
+    ASEP_GUARD_END
 }
 
 int asep_aru_forward(asep_aru* m, const float* img_hw, int H, int W, float* out_hwc, uint8_t* out_u8,
                      uint8_t* out_mask, float threshold) {
+    ASEP_GUARD_BEGIN
     if (!m || !img_hw || !out_hwc || H < 1 || W < 1) { set_error("asep_aru_forward: bad argument"); return ASEP_ERR_ARG; }
     const size_t npix = (size_t)H * W, nout = npix * m->cfg.n_classes;
     // staging buffers live in the handle and only grow (a page-sized hipMalloc / hipFree pair per call costs
@@ -1110,9 +1117,11 @@ int asep_aru_forward(asep_aru* m, const float* img_hw, int H, int W, float* out_
     if (out_u8) ASEP_HIP_CHECK(hipMemcpy(out_u8, d_u8, nout, hipMemcpyDeviceToHost));
     if (out_mask) ASEP_HIP_CHECK(hipMemcpy(out_mask, d_mask, nout, hipMemcpyDeviceToHost));
     return ASEP_OK;
+    ASEP_GUARD_END
 }
 
 long asep_aru_get_endpoint(asep_aru* m, const char* name, float* out, size_t max_floats, int32_t dims[3]) {
+    ASEP_GUARD_BEGIN
     if (!m || !name) { set_error("asep_aru_get_endpoint: bad argument"); return ASEP_ERR_ARG; }
     auto it = m->endpoints.find(name);
     if (it == m->endpoints.end()) { set_error("asep_aru_get_endpoint: unknown end point '%s'", name); return ASEP_ERR_ARG; }
@@ -1123,17 +1132,21 @@ long asep_aru_get_endpoint(asep_aru* m, const char* name, float* out, size_t max
     ASEP_HIP_CHECK(hipStreamSynchronize(m->stream));
     ASEP_HIP_CHECK(hipMemcpy(out, t.p, t.count() * sizeof(float), hipMemcpyDeviceToHost));
     return (long)t.count();
+    ASEP_GUARD_END
 }
 
 int asep_aru_profile(asep_aru* m, int enable) {
+    ASEP_GUARD_BEGIN
     if (!m) { set_error("asep_aru_profile: null handle"); return ASEP_ERR_ARG; }
     m->profiling = enable != 0;
     m->prof_detail = enable == 2;
     if (enable) { m->prof_recs.clear(); m->ev_next = 0; m->prof_names.clear(); }
     return ASEP_OK;
+    ASEP_GUARD_END
 }
 
 long asep_aru_profile_report(asep_aru* m, char* buf, size_t buflen) {
+    ASEP_GUARD_BEGIN
     if (!m || !buf || buflen < 2) { set_error("asep_aru_profile_report: bad argument"); return ASEP_ERR_ARG; }
     ASEP_HIP_CHECK(hipStreamSynchronize(m->stream));
     const size_t nk = m->prof_names.size();
@@ -1156,6 +1169,7 @@ long asep_aru_profile_report(asep_aru* m, char* buf, size_t buflen) {
     if (js.size() + 1 > buflen) { set_error("asep_aru_profile_report: buffer too small (%zu needed)", js.size() + 1); return ASEP_ERR_ARG; }
     memcpy(buf, js.c_str(), js.size() + 1);
     return (long)js.size();
+    ASEP_GUARD_END
 }
 
 double asep_aru_flops(const asep_aru* m, int H, int W) {

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -38,6 +40,28 @@ const char* get_error();
 
 struct HipError {};
 struct ArgError {};
+
+// Every extern "C" entry runs its body between these two: no C++ exception (HipError / ArgError of the helpers,
+// std::bad_alloc or std::length_error of the std::vector / std::map / std::string code) crosses the C ABI.
+#define ASEP_GUARD_BEGIN try {
+#define ASEP_GUARD_END_WITH(HIP_RC, ARG_RC)                                                     \
+    }                                                                                           \
+    catch (const asep::HipError&) { return HIP_RC; }                                            \
+    catch (const asep::ArgError&) { return ARG_RC; }                                            \
+    catch (const std::bad_alloc&) {                                                             \
+        asep::set_error("%s: out of host memory", __func__);                                    \
+        return HIP_RC;                                                                          \
+    }                                                                                           \
+    catch (const std::exception& e) {                                                           \
+        asep::set_error("%s: exception: %s", __func__, e.what());                               \
+        return HIP_RC;                                                                          \
+    }                                                                                           \
+    catch (...) {                                                                               \
+        asep::set_error("%s: unknown exception", __func__);                                     \
+        return HIP_RC;                                                                          \
+    }
+#define ASEP_GUARD_END ASEP_GUARD_END_WITH(ASEP_ERR_HIP, ASEP_ERR_ARG)
+#define ASEP_GUARD_END_PTR ASEP_GUARD_END_WITH(nullptr, nullptr)
 
 struct HostTensor {
     std::vector<int> dims;

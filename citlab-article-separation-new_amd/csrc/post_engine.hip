@@ -321,15 +321,8 @@ struct Staged {
 
 }  // namespace
 
-#define POST_GUARD_BEGIN try {
-#define POST_GUARD_END                                             \
-    }                                                              \
-    catch (const HipError&) { return ASEP_ERR_HIP; }               \
-    catch (const ArgError&) { return ASEP_ERR_ARG; }               \
-    catch (const std::exception& e) {                              \
-        set_error("exception: %s", e.what());                      \
-        return ASEP_ERR_HIP;                                       \
-    }
+#define POST_GUARD_BEGIN ASEP_GUARD_BEGIN
+#define POST_GUARD_END ASEP_GUARD_END
 
 extern "C" {
 

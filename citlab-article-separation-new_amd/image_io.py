@@ -10,7 +10,7 @@ equal channels returns the value itself (3735 + 19235 + 9798 = 2^15), so the net
 JPEG decoders differ between libjpeg builds by +-1 in places; PNG / TIFF inputs are bit-identical.
 """
 import numpy as np
-from PIL import Image
+from PIL import Image, ImageOps
 
 from . import image_ops
 
@@ -22,13 +22,24 @@ def get_image_dimensions(image_path):
         return im.size
 
 
+_DEEP_GRAY = ("I;16", "I;16L", "I;16B", "I;16N", "I")      # Pillow modes of 16-bit (and wider) single-channel files
+
+
 def load_image_bgr(path_to_image):
-    """uint8 [H,W,3] in BGR order, or uint8 [H,W] for single-channel files."""
+    """uint8 [H,W,3] in BGR order, or uint8 [H,W] for single-channel files.
+
+    Like ``cv2.imread`` with its default flags: the EXIF orientation is applied, an alpha channel is dropped, palette
+    files are expanded, and 16-bit samples are reduced to their high byte (libpng's ``strip_16``; Pillow's own
+    ``convert('L')`` would clip everything above 255 to white instead)."""
     with Image.open(path_to_image) as im:
-        if im.mode in ("L", "1", "I;16", "I", "F", "P") and im.mode != "P":
-            if im.mode != "L":
-                im = im.convert("L")
-            return np.asarray(im, dtype=np.uint8)
+        im = ImageOps.exif_transpose(im)
+        if im.mode in _DEEP_GRAY:
+            deep = np.asarray(im).astype(np.int64)
+            return np.clip(deep >> 8, 0, 255).astype(np.uint8)
+        if im.mode == "F":
+            return np.clip(np.rint(np.asarray(im, dtype=np.float64)), 0, 255).astype(np.uint8)
+        if im.mode in ("L", "1", "LA", "La"):
+            return np.asarray(im if im.mode == "L" else im.convert("L"), dtype=np.uint8)
         rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
     return np.ascontiguousarray(rgb[:, :, ::-1])
 

@@ -156,14 +156,15 @@ def apply_threshold(net_output, threshold):
 
 
 def get_scaling_factor(image_height, image_width, scaling_factor, fixed_height=None, fixed_width=None):
-    """python_util/image_processing/image_stats.py:10-20."""
-    if fixed_height is not None and scaling_factor is not None and 0.1 < scaling_factor:
-        return scaling_factor * fixed_height / image_height
-    if fixed_width is not None and scaling_factor is not None and 0.1 < scaling_factor:
-        return scaling_factor * fixed_width / image_width
-    if fixed_height:
-        return fixed_height / image_height
-    if fixed_width:
-        return fixed_width / image_width
-    if scaling_factor:
-        return scaling_factor
+    """Resize factor of a page (``python_util/image_processing/image_stats.py:10-20``; pinned by
+    ``tests/golden/pathutil_golden.json``): a relative ``scaling_factor`` above 0.1 multiplies the factor that brings
+    the page to the fixed height (else width); without it the fixed extent alone decides, then the bare factor."""
+    extents = ((fixed_height, image_height), (fixed_width, image_width))
+    if scaling_factor is not None and scaling_factor > 0.1:
+        for target, extent in extents:
+            if target is not None:
+                return scaling_factor * target / extent
+    for target, extent in extents:
+        if target:
+            return target / extent
+    return scaling_factor or None

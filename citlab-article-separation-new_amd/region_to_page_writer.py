@@ -18,21 +18,26 @@ SEPARATOR_REGION = "SeparatorRegion"
 
 
 class RegionToPageWriter:
-    def __init__(self, path_to_page, path_to_image=None, fixed_height=None, scaling_factor=None, *args, **kwargs):
-        self.scaling_factor = None
-        if path_to_image is not None:
-            image_width, image_height = get_image_dimensions(path_to_image)
-            self.scaling_factor = get_scaling_factor(image_height, image_width, scaling_factor, fixed_height)
-        self.path_to_page = path_to_page
-        self.page_object = self.load_page_object(path_to_page, path_to_image)
+    """Owns the Page object a post-processor writes its regions into (``region_to_page_writer.py:13-46``)."""
 
-    def load_page_object(self, path_to_page, path_to_image):
-        """:23-38: a missing PAGE file is created from the image (with the *scaled* size, like the reference)."""
-        if not os.path.exists(path_to_page):
-            image_width, image_height = get_image_dimensions(path_to_image)
-            return Page(img_filename=path_to_image, img_w=int(self.scaling_factor * image_width),
-                        img_h=int(self.scaling_factor * image_height))
-        return Page(path_to_page)
+    def __init__(self, path_to_page, path_to_image=None, fixed_height=None, scaling_factor=None, *args, **kwargs):
+        self.path_to_page = path_to_page
+        self.scaling_factor = None
+        size = None
+        if path_to_image is not None:
+            size = get_image_dimensions(path_to_image)          # (width, height)
+            self.scaling_factor = get_scaling_factor(size[1], size[0], scaling_factor, fixed_height)
+        self.page_object = self.load_page_object(path_to_page, path_to_image, size)
+
+    def load_page_object(self, path_to_page, path_to_image, size=None):
+        """An existing PAGE file is parsed; a missing one becomes an empty page that names the image and carries the
+        image size multiplied by the scaling factor and truncated (the reference writes the
+        *scaled* size there, kept)."""
+        if os.path.exists(path_to_page):
+            return Page(path_to_page)
+        width, height = size if size is not None else get_image_dimensions(path_to_image)
+        return Page(img_filename=path_to_image, img_w=int(self.scaling_factor * width),
+                    img_h=int(self.scaling_factor * height))
 
     def save_page_xml(self, save_path):
         folder = os.path.dirname(save_path)

@@ -11,6 +11,7 @@ Pages are sharded over ``--num_workers`` processes, worker k on GPU ``gpu_device
 """
 import logging
 import multiprocessing as mp
+import queue
 import os
 import sys
 import time
@@ -125,6 +126,29 @@ def _worker(json_paths, argv, device, q):
         q.put(("err", repr(e)))
 
 
+def _collect_results(procs, q):
+    """One ("ok" | "err", payload) message per worker; a worker that ends without one is an error."""
+    out, errors = [], []
+    pending = len(procs)
+    while pending:
+        try:
+            status, payload = q.get(timeout=1.0)
+        except queue.Empty:
+            # a worker that died without posting (native crash, OOM kill, HIP abort) must fail the run, not hang it
+            dead = [pr for pr in procs if not pr.is_alive() and pr.exitcode not in (0, None)]
+            if dead and q.empty():
+                errors.extend(f"worker pid {pr.pid} ended with exit code {pr.exitcode} without a result" for pr in dead)
+                break
+            continue
+        pending -= 1
+        (out.extend if status == "ok" else errors.append)(payload)
+    for pr in procs:
+        if errors and pr.is_alive():
+            pr.terminate()
+        pr.join()
+    return out, errors
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     flags = build_parser().parse_known_args(argv)[0]
@@ -140,12 +164,7 @@ def main(argv=None):
         pr = ctx.Process(target=_worker, args=(part, argv, devices[k % len(devices)], q))
         pr.start()
         procs.append(pr)
-    out, errors = [], []
-    for _ in procs:
-        status, payload = q.get()
-        (out.extend if status == "ok" else errors.append)(payload)
-    for pr in procs:
-        pr.join()
+    out, errors = _collect_results(procs, q)
     if errors:
         raise RuntimeError("worker failure: " + "; ".join(errors))
     return out

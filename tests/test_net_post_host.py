@@ -51,6 +51,53 @@ def test_image_decode_conventions(tmp_path):
     assert g[0, 0] == (50 * 3735 + 100 * 19235 + 200 * 9798 + 16384) >> 15
 
 
+def test_image_decode_deep_palette_alpha_and_exif(tmp_path):
+    """cv2.imread conventions Pillow does not follow by itself: 16-bit samples keep their high byte (not clipped to
+    white), palette / alpha files become 3-channel BGR, the EXIF orientation is applied."""
+    from citlab_article_separation_new_amd import image_io
+    deep = (np.arange(20, dtype=np.uint16).reshape(4, 5) * 3000 + 17)
+    Image.fromarray(deep).save(tmp_path / "d16.png")
+    Image.fromarray(deep).save(tmp_path / "d16.tif")
+    for name in ("d16.png", "d16.tif"):
+        got = image_io.load_image_bgr(str(tmp_path / name))
+        assert got.dtype == np.uint8 and np.array_equal(got, (deep >> 8).astype(np.uint8)), name
+    assert image_io.load_image_bgr(str(tmp_path / "d16.png")).max() < 255          # nothing saturates
+    pal = Image.fromarray(np.array([[0, 1], [1, 0]], np.uint8), mode="P")
+    pal.putpalette([10, 20, 30, 200, 150, 100] + [0] * 756)
+    pal.save(tmp_path / "p.png")
+    got = image_io.load_image_bgr(str(tmp_path / "p.png"))
+    assert got.shape == (2, 2, 3) and got[0, 0].tolist() == [30, 20, 10] and got[0, 1].tolist() == [100, 150, 200]
+    rgba = np.zeros((2, 3, 4), np.uint8)
+    rgba[..., 0], rgba[..., 3] = 90, 7
+    Image.fromarray(rgba).save(tmp_path / "a.png")
+    assert image_io.load_image_bgr(str(tmp_path / "a.png"))[0, 0].tolist() == [0, 0, 90]
+    Image.fromarray(np.array([[0, 255]], np.uint8)).convert("1").save(tmp_path / "b.png")
+    assert image_io.load_image_bgr(str(tmp_path / "b.png")).tolist() == [[0, 255]]
+    # EXIF orientation 6 = "rotate 90 clockwise to display": a 2x3 file decodes to 3x2
+    img = Image.fromarray(np.arange(6, dtype=np.uint8).reshape(2, 3) * 40)
+    exif = Image.Exif()
+    exif[0x0112] = 6
+    img.save(tmp_path / "r.png", exif=exif)
+    got = image_io.load_image_bgr(str(tmp_path / "r.png"))
+    assert got.shape == (3, 2) and np.array_equal(got, np.rot90(np.arange(6, dtype=np.uint8).reshape(2, 3) * 40, -1))
+
+
+def test_worker_that_dies_without_result_fails_the_run_instead_of_hanging():
+    import multiprocessing as mp
+    from citlab_article_separation_new_amd import run_gnn_clustering as cli
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_post_ok, args=(q,)), ctx.Process(target=os._exit, args=(3,))]
+    for pr in procs:
+        pr.start()
+    out, errors = cli._collect_results(procs, q)
+    assert out == ["fine"] and len(errors) == 1 and "exit code 3" in errors[0]
+
+
+def _post_ok(q):
+    q.put(("ok", ["fine"]))
+
+
 def test_cli_sub_lists_match_reference_arithmetic():
     from citlab_article_separation_new_amd.run_net_post_processing import build_parser, build_sub_lists
     imgs = [f"i{k}" for k in range(23)]
