@@ -58,8 +58,6 @@ def test_full_chain(tmp_path):
         (tmp_path / name).write_bytes(pb_import.weights_to_graphdef(
             init_aru_weights(acfg, seed, bias_jitter=0.05, logit_scale=0.05), "graph/", extra))
     gcfg = GnnConfig()
-    gw = init_gnn_weights(gcfg, 23, bias_jitter=0.05)
-    (tmp_path / "gnn.pb").write_bytes(pb_import.weights_to_graphdef(gw, "graph/"))
 
     # 1. separators (threshold mid-range so random weights give structure), output page/p0.xml.xml
     assert run_net_post_processing.main(["--path_to_image_list", str(lst), "--path_to_pb", str(tmp_path / "sep.pb"),
@@ -86,6 +84,15 @@ def test_full_chain(tmp_path):
     assert np.array_equal(np.array(feat["node_features"], np.float32), ref[3])
     assert np.array_equal(np.array(feat["interacting_nodes"]), ref[1])
     assert np.array_equal(np.array(feat["edge_features"], np.float32), ref[4])
+    # the relation net for THIS page graph: seeded weights whose pair classifier is calibrated (oracle/gnn_cases.py) so that
+    # blocks of one column mostly get confidences above 0.5 and the rest below -- the ids compared below then come from
+    # a clustering that is neither "one article" nor "all singletons"
+    from oracle import gnn_cases
+    keep = [i for i, m in enumerate(MASK) if m]
+    column = np.array([i % 3 for i in range(15)])
+    gw = gnn_cases.calibrate_l1_classifier(init_gnn_weights(gcfg, 23, bias_jitter=0.05), gcfg, 15, ref[1], ref[3][:, keep],
+                                           ref[4], column[:, None] == column[None, :], wrong_side=0.2, seed=5)
+    (tmp_path / "gnn.pb").write_bytes(pb_import.weights_to_graphdef(gw, "graph/"))
     # 4. GNN + clustering with masking
     jl = tmp_path / "eval.lst"
     jl.write_text(str(jpath) + "\n")
@@ -102,7 +109,6 @@ def test_full_chain(tmp_path):
     assert len(outs) == 1
     out = outs[0] if os.path.isabs(outs[0]) else os.path.join(tmp_path, outs[0])
     got = [r.text_lines[0].get_article_id() for r in Page(out).get_regions()["TextRegion"]]
-    keep = [i for i, m in enumerate(MASK) if m]
     probs = gnn_oracle.forward(15, ref[1], ref[3][:, keep], ref[4], None, gw, gcfg)
     confs = probs[:, 1].reshape(15, 15)
     if "SeparatorRegion" in Page(str(data / "page" / "p0.xml")).get_regions():
@@ -114,3 +120,6 @@ def test_full_chain(tmp_path):
     tb.set_confs(confs)
     tb.calc("dbscan")
     assert got == [f"a{l}" for l in tb.tb_labels]
+    sizes = np.bincount(np.asarray(tb.tb_labels))[1:]
+    print("full chain article sizes:", sizes.tolist(), "min|conf-0.5| = %.2e" % np.abs(probs[:, 1] - 0.5).min())
+    assert 2 <= len(sizes) < 15 and sizes.max() >= 2, "degenerate clustering"

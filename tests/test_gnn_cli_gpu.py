@@ -26,12 +26,16 @@ def _write_page(path, n_regions):
 def test_cli_end_to_end_article_ids_identical(tmp_path):
     from citlab_article_separation_new_amd import pb_import, run_gnn_clustering, synth
     from citlab_article_separation_new_amd.clustering import TextblockClustering
-    from citlab_article_separation_new_amd.config import GnnConfig
     from citlab_article_separation_new_amd.page_xml import Page
-    from citlab_article_separation_new_amd.weights import init_gnn_weights
     from oracle import gnn_oracle
-    cfg = GnnConfig()
-    w = init_gnn_weights(cfg, 4242, bias_jitter=0.05)
+    # page 0 is a planted-article graph (oracle/gnn_cases.py): its weights serve the whole run, so the ids the CLI writes
+    # come from confidences on both sides of 0.5 (several articles + singletons), not from a degenerate clustering
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import gnn_article_cases as gac
+    from oracle import gnn_cases
+    case = next(c for c in gac.CASES if c["name"] == "n60")
+    g0, w, cfg, _ = gac.build(case)
     model = tmp_path / "model" / "export"
     model.mkdir(parents=True)
     (model / "gnn_best_2026.pb").write_bytes(pb_import.weights_to_graphdef(w, "graph/"))
@@ -41,17 +45,21 @@ def test_cli_end_to_end_article_ids_identical(tmp_path):
     mask = [1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1]
     keep = [i for i, m in enumerate(mask) if m]
     json_paths, expected = [], {}
-    for k, n in enumerate((40, 25, 3)):
-        g = synth.synth_graph(k, N=n, n_pairs=min(150, n * (n - 1) // 2), node_dim=15)
+    graphs = [g0, gnn_cases.planted_graph(91, N=25, n_pairs=150, n_articles=3, n_outliers=1),
+              synth.synth_graph(2, N=3, n_pairs=3, node_dim=7)]
+    for k, g in enumerate(graphs):
+        n = int(g["num_nodes"])
+        feats15 = np.random.default_rng(k).random((n, 15)).astype(np.float32)      # masked-out columns: anything
+        feats15[:, keep] = g["node_features"]
         name = f"page{k}"
         _write_page(data / "page" / f"{name}.xml", n)
         jp = data / "json15d2bb" / f"{name}.json"
         jp.write_text(json.dumps({"num_nodes": n, "interacting_nodes": g["interacting_nodes"].tolist(),
                                   "num_interacting_nodes": int(g["interacting_nodes"].shape[0]),
-                                  "node_features": g["node_features"].tolist(), "edge_features": g["edge_features"].tolist(),
+                                  "node_features": feats15.tolist(), "edge_features": g["edge_features"].tolist(),
                                   "gt_relations": [], "gt_num_relations": 0}))
         json_paths.append(str(jp))
-        probs = gnn_oracle.forward(n, g["interacting_nodes"], g["node_features"][:, keep], g["edge_features"], None, w, cfg)
+        probs = gnn_oracle.forward(n, g["interacting_nodes"], g["node_features"], g["edge_features"], None, w, cfg)
 
         class F:
             clustering_params = {}
@@ -59,6 +67,9 @@ def test_cli_end_to_end_article_ids_identical(tmp_path):
         tb.set_confs(probs[:, 1].reshape(n, n))
         tb.calc("dbscan")
         expected[name] = [int(v) for v in tb.tb_labels]
+    sizes = np.bincount(expected["page0"])[1:]
+    assert (sizes >= 2).sum() >= 3 and (sizes == 1).sum() >= 1, "page0 must not cluster degenerately"
+    assert len(set(expected["page1"])) >= 2
     lst = tmp_path / "eval.lst"
     lst.write_text("\n".join(json_paths) + "\n")
     cwd = os.getcwd()
