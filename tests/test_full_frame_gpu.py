@@ -1,0 +1,144 @@
+"""Whole-frame parity at the sizes BASELINE.json names -- no interior crops.
+
+  * configs[1]/[4]: one whole 3000 x 4500 page against ``oracle.aru_oracle.forward_torch`` on the same page: fp32 MFMA path
+    max|dp| <= 1e-4, bf16 MFMA path <= 2e-2, on every pixel including the page's borders at the odd pyramid levels
+    (1125, 563, 282 rows; 375, 188 columns), plus the uint8 / threshold-mask mismatch RATE against the oracle
+    (a truncation ``uint8(p * 255)`` flips wherever p * 255 sits within the float error of an integer,
+    so the rate is reported and bounded rather than required to be zero).
+  * configs[0]: the 512 x 768 crop through ``run_net_post_processing --mode separator --fixed_height 768`` (net input =
+    the crop itself) against the reference's step sequence evaluated with the oracle for EVERY step (net included).
+  * configs[2]: the stroke-width distance transform and the connected-component / opening stage at 3000 x 4500 against
+    ``oracle.classical_oracle``, bit for bit.
+"""
+import numpy as np
+import pytest
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+H, W = 4500, 3000
+
+
+@pytest.fixture(scope="module")
+def whole_page():
+    """page, weights and the oracle's output for the whole frame (one oracle run serves the fp32 and the bf16 test)"""
+    from citlab_article_separation_new_amd import synth
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    from oracle import aru_oracle
+    cfg = AruConfig()
+    w = init_aru_weights(cfg, 1234, bias_jitter=0.05, logit_scale=0.05)
+    page = synth.synth_page(0, W, H).astype(np.float32) / 255.0
+    ref = aru_oracle.forward_torch(page, w, cfg)
+    assert ref.shape == (H, W, 2)
+    return page, w, ref
+
+
+def _report(tag, out, ref, thr):
+    from oracle import aru_oracle
+    err = np.abs(out - ref)
+    u8, u8_ref = aru_oracle.to_uint8(out), aru_oracle.to_uint8(ref)
+    u8_rate = float((u8 != u8_ref).mean())
+    u8_max = int(np.abs(u8.astype(np.int16) - u8_ref.astype(np.int16)).max())
+    m_rate = float((aru_oracle.apply_threshold(u8, thr) != aru_oracle.apply_threshold(u8_ref, thr)).mean())
+    border = np.ones((H, W), bool)
+    border[64:-64, 64:-64] = False
+    print(f"\n{tag} whole frame {W}x{H}: max|dp| = {err.max():.3e} (border band 64 px: {err[border].max():.3e}, "
+          f"interior: {err[~border].max():.3e}); uint8 mismatch rate = {u8_rate:.3e} (max step {u8_max}); "
+          f"threshold-mask mismatch rate @thr={thr} = {m_rate:.3e}")
+    return float(err.max()), u8_rate, u8_max, m_rate
+
+
+def test_whole_page_fp32_vs_oracle(whole_page):
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from citlab_article_separation_new_amd.config import AruConfig
+    from oracle import aru_oracle
+    page, w, ref = whole_page
+    g = helper.AruGraph(w, AruConfig())
+    thr = round(float(np.median(ref[:, :, 0])), 3)
+    out, u8, mask = helper.get_net_output_fused(page, g, "0", want_u8=True, threshold=thr)
+    err, u8_rate, u8_max, m_rate = _report("fp32", out, ref, thr)
+    assert err <= 1e-4
+    assert u8_max <= 1 and u8_rate <= 2e-3 and m_rate <= 2e-3
+    # the fused epilogue is exactly uint8(p * 255) / apply_threshold of the engine's own float output
+    assert np.array_equal(u8, aru_oracle.to_uint8(out)) and np.array_equal(mask, aru_oracle.apply_threshold(u8, thr))
+    g.close()
+
+
+def test_whole_page_bf16_vs_oracle(whole_page):
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from citlab_article_separation_new_amd.config import AruConfig
+    page, w, ref = whole_page
+    g = helper.AruGraph(w, AruConfig(compute_dtype="bf16"))
+    out = helper.get_net_output(page, g, "0")
+    thr = round(float(np.median(ref[:, :, 0])), 3)
+    err, u8_rate, u8_max, m_rate = _report("bf16", out, ref, thr)
+    assert 1e-6 < err <= 2e-2
+    g.close()
+
+
+def test_c1_crop_512x768_through_the_separator_cli(tmp_path):
+    """BASELINE configs[0]: one 512 x 768 crop, --fixed_height 768 so that the net sees the crop itself."""
+    from citlab_article_separation_new_amd import image_io, pb_import, polygonize, synth
+    from citlab_article_separation_new_amd import run_net_post_processing as cli
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.host_util import rescale_points
+    from citlab_article_separation_new_amd.page_xml import Page
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    from oracle import aru_oracle, classical_oracle as co
+    cfg = AruConfig()
+    w = init_aru_weights(cfg, 77, bias_jitter=0.05, logit_scale=0.05)
+    extra = [{"name": f"graph/aru_net/attMapG/AvgPool_{i}", "op": "AvgPool"} for i in range(cfg.num_scales_att - 1)]
+    extra.append({"name": "output", "op": "Softmax", "input": ["graph/aru_net/logit/logits"]})
+    pb = tmp_path / "separator_aru.pb"
+    pb.write_bytes(pb_import.weights_to_graphdef(w, "graph/", extra))
+    data = tmp_path / "data"
+    (data / "page").mkdir(parents=True)
+    crop = np.ascontiguousarray(synth.synth_page(0, W, H)[0:768, 0:512])          # C1 = page 0 [0:768, 0:512]
+    Image.fromarray(crop).save(data / "c1.png")
+    lst = tmp_path / "images.lst"
+    lst.write_text(str(data / "c1.png") + "\n")
+    # the reference's sequence (separator_net_post_processor.py:141-157) with the oracle at every step
+    img = image_io.load_image_bgr(str(data / "c1.png"))
+    _, grey, sc = co.scale_and_gray(img, 768, 1.0)
+    assert sc == 1.0 and grey.shape == (768, 512)
+    prob = aru_oracle.forward_torch(grey.astype(np.float32), w, cfg)
+    thr = round(float(np.median(prob[:, :, 0])), 3)
+    net_u8 = aru_oracle.to_uint8(prob)
+    post = co.separator_post_process(aru_oracle.apply_threshold(net_u8, thr))
+    expected = [(o, rescale_points(poly[0], 1 / sc)) for o in ("horizontal", "vertical") for poly in polygonize.shapes(post[o])]
+    assert expected, "no separators on the crop; adjust the threshold"
+    assert co.cc_min_size(768 * 512, 1 / (768 * 512) * 100) == 99     # float64 gives 99 at this size
+    rc = cli.main(["--path_to_image_list", str(lst), "--path_to_pb", str(pb), "--mode", "separator",
+                   "--fixed_height", "768", "--threshold", str(thr), "--num_processes", "1"])
+    assert rc == 0
+    seps = Page(str(data / "page" / "c1.xml.xml")).get_regions()["SeparatorRegion"]
+    got = [(s.get_orientation(), s.points) for s in seps]
+    # uint8 truncation may flip single pixels where p * 255 is within 1e-6 of an integer AND that integer is the
+    # threshold; with identical masks the polygons are identical
+    assert got == expected
+
+
+def test_swt_and_separator_stage_at_full_size_bit_exact():
+    """configs[2] size: 255 - gray -> Gaussian -> Otsu -> exact EDT -> uint8 on a 3000 x 4500 scan, and CC filter +
+    openings on a 3000 x 4500 two-class mask, both bit-identical to the classical oracle."""
+    from citlab_article_separation_new_amd import image_ops, synth
+    from oracle import classical_oracle as co
+    g = synth.synth_page(1, W, H)
+    g[900:1500, 300:1100] = 12                               # a dark picture block: distances beyond 255 wrap in uint8
+    out, thr, d2 = image_ops.swt_distance_transform(g, return_details=True)
+    inv = (255 - g.astype(np.int64)).astype(np.uint8)
+    blur = co.gaussian5(inv)
+    assert thr == co.otsu_threshold(blur)
+    assert np.array_equal(d2.astype(np.int64), co.edt_sq(((blur > thr) * 255).astype(np.uint8)))
+    ref = co.swt_distance_transform(g)
+    assert np.array_equal(out, ref)
+    assert int(np.sqrt(d2.max())) > 255 and out.max() > 200, "the wrap-around case must be exercised"
+    # separator stage on a mask made from the page itself: dark pixels + their horizontal / vertical rules
+    mask = np.zeros((H, W, 2), np.uint8)
+    mask[:, :, 0] = (g < 120) * 255
+    mask[:, :, 1] = (g < 60) * 255
+    post, post_ref = image_ops.separator_post_process(mask), co.separator_post_process(mask)
+    for k in ("horizontal", "vertical"):
+        assert np.array_equal(post[k], post_ref[k]), k
+        assert post_ref[k].any()
