@@ -8,11 +8,26 @@ constants and maps them onto the engine's named weight set (``weights.py``) by t
 (any graph prefix such as ``graph/`` is ignored), and derives the model hyper-parameters from tensor shapes and the
 op list.
 
-Only the message fields needed for that are decoded (field numbers from tensorflow/core/framework/*.proto):
+Two ways onto the engine's weight set:
+
+  * by NAME (``aru_from_constants`` / ``gnn_from_nodes``): graphs frozen by this repository's own exporter keep the
+    variable scopes of ``ARU_v1.py`` / ``graph_relation.py`` (``aru_net/featMapG/unet_down_0/conv1/weights`` ...);
+  * by TOPOLOGY (``aru_from_topology``): the shipped separator / heading nets were exported by another project
+    (``region_net_post_processor_base.py:278-290``), only ``inImg`` / ``output`` are known
+    (``net_post_processing_helper.py:69-70``).  The op graph between the two is walked: every Conv2D /
+    Conv2DBackpropInput with a constant filter is a layer, its bias (BiasAdd / Add with a constant), an optional
+    inference-mode batch normalisation (FusedBatchNorm*, or the Mul / Add pair it is usually folded into) and its
+    activation are read off its consumers, layers are ordered by their conv depth below ``inImg`` (the ARU-Net is one
+    chain with skip connections, so the depth order IS the creation order), the hyper-parameters follow from the
+    filter shapes and the weights are assigned by position.  Batch normalisation is folded into weights and bias.
+    Anything that does not fit the ARU_v1 family raises ``IOError`` with the reason -- nothing is guessed.
+
+Message fields decoded (field numbers from tensorflow/core/framework/*.proto); everything else is skipped:
     GraphDef.node = 1 ; NodeDef{name=1, op=2, input=3, attr=5(map<string,AttrValue>)}
-    AttrValue{tensor=8, type=6, shape=7, s=2, i=3, f=4, b=5}
+    AttrValue{list=1{s=2,i=3,f=4,b=5,type=6,shape=7}, s=2, i=3, f=4, b=5, type=6, shape=7, tensor=8}
     TensorProto{dtype=1, tensor_shape=2, tensor_content=4, float_val=5, double_val=6, int_val=7, int64_val=10}
     TensorShapeProto{dim=2{size=1}}
+The reader is cross-checked against GraphDefs serialised by ``google.protobuf`` (tests/test_pb_import_protobuf.py).
 """
 import struct
 from collections import OrderedDict
@@ -136,13 +151,67 @@ def _parse_tensor(buf):
     return arr.reshape(shape)
 
 
+def _scalars(val, wt, fmt, size):
+    """repeated scalar field: one element (wire type 0 / 1 / 5) or a packed run (wire type 2)"""
+    if wt == 2:
+        if fmt is None:
+            out, p = [], 0
+            while p < len(val):
+                v, p = _varint(val, p)
+                out.append(_signed(v))
+            return out
+        return list(struct.unpack(f"<{len(val) // size}{fmt}", bytes(val)))
+    if fmt is None:
+        return [_signed(val)]
+    return [struct.unpack("<" + fmt, bytes(val))[0]]
+
+
+def _parse_attr(buf, want_tensor):
+    """AttrValue -> python value: bytes -> str, int, float, bool, ('type', enum), ('shape', dims), list of those,
+    ndarray for a tensor (only decoded when ``want_tensor``)"""
+    out = None
+    for fno, wt, val in _fields(buf):
+        if fno == 1 and wt == 2:                                   # ListValue
+            items = []
+            for f2, w2, v2 in _fields(val):
+                if f2 == 2 and w2 == 2:
+                    items.append(bytes(v2).decode("utf-8", "replace"))
+                elif f2 == 3:
+                    items.extend(_scalars(v2, w2, None, 0))
+                elif f2 == 4:
+                    items.extend(_scalars(v2, w2, "f", 4))
+                elif f2 == 5:
+                    items.extend(bool(v) for v in _scalars(v2, w2, None, 0))
+                elif f2 == 6:
+                    items.extend(("type", v) for v in _scalars(v2, w2, None, 0))
+                elif f2 == 7 and w2 == 2:
+                    items.append(("shape", _parse_shape(v2)))
+            out = items
+        elif fno == 2 and wt == 2:
+            out = bytes(val).decode("utf-8", "replace")
+        elif fno == 3 and wt == 0:
+            out = _signed(val)
+        elif fno == 4 and wt == 5:
+            out = struct.unpack("<f", bytes(val))[0]
+        elif fno == 5 and wt == 0:
+            out = bool(val)
+        elif fno == 6 and wt == 0:
+            out = ("type", val)
+        elif fno == 7 and wt == 2:
+            out = ("shape", _parse_shape(val))
+        elif fno == 8 and wt == 2 and want_tensor:
+            out = _parse_tensor(val)
+    return out
+
+
 def parse_graphdef(data: bytes):
-    """-> list of nodes: {'name', 'op', 'input': [...], 'value': ndarray or None}"""
+    """-> list of nodes: {'name', 'op', 'input': [...], 'attr': {key: value}, 'value': ndarray or None (Const only)}"""
     nodes = []
     for fno, wt, val in _fields(memoryview(data)):
         if fno != 1 or wt != 2:
             continue
-        node = {"name": "", "op": "", "input": [], "value": None}
+        node = {"name": "", "op": "", "input": [], "attr": {}, "value": None}
+        raw_attrs = []
         for f2, w2, v2 in _fields(val):
             if f2 == 1 and w2 == 2:
                 node["name"] = bytes(v2).decode("utf-8", "replace")
@@ -157,12 +226,15 @@ def parse_graphdef(data: bytes):
                         key = bytes(v3).decode("utf-8", "replace")
                     elif f3 == 2 and w3 == 2:
                         attr = v3
-                if key == "value" and attr is not None and node["op"] in ("", "Const"):
-                    for f4, w4, v4 in _fields(attr):
-                        if f4 == 8 and w4 == 2:
-                            node["value"] = _parse_tensor(v4)
-        if node["op"] != "Const":
-            node["value"] = None
+                if key is not None and attr is not None:
+                    raw_attrs.append((key, attr))
+        for key, attr in raw_attrs:                          # the op may come after the attrs on the wire
+            is_value = key == "value" and node["op"] == "Const"
+            parsed = _parse_attr(attr, want_tensor=is_value)
+            if is_value:
+                node["value"] = parsed
+            else:
+                node["attr"][key] = parsed
         nodes.append(node)
     if not nodes:
         raise IOError("no NodeDef found: not a GraphDef")
@@ -189,7 +261,30 @@ def _find(consts, suffix):
     return consts[hits[0]] if hits else None
 
 
-def aru_from_nodes(nodes, num_scales_att=None, apply_softmax=None):
+def _hint_num_scales(nodes, use_att):
+    """constants-only containers carry one AvgPool node per extra pyramid scale (ARU_v1.py:106-109) as a hint"""
+    if not use_att:
+        return 1
+    n = sum(1 for n in nodes if n["op"] == "AvgPool")
+    return 1 + n if n else None
+
+
+def _hint_softmax(nodes):
+    by_name = {n["name"]: n for n in nodes}
+    node = by_name.get("output")
+    hops = 0
+    while node is not None and node["op"] == "Identity" and node["input"] and hops < 64:
+        node = by_name.get(node["input"][0].lstrip("^").split(":")[0])
+        hops += 1
+    if node is None:
+        return None
+    return node["op"] == "Softmax"
+
+
+def aru_from_constants(nodes, num_scales_att=None, apply_softmax=None):
+    """Mapping by variable NAME (graphs frozen with the scopes of ARU_v1.py; also the engine's own export, which holds
+    constants only).  What the constants cannot tell -- the number of pyramid scales and whether ``output`` is behind a
+    class softmax -- must be passed in or be readable from the op list; it is never defaulted."""
     consts = const_tensors(nodes)
     if _find(consts, "aru_net/featMapG/unet_down_0/conv1/weights") is None:
         raise IOError("no ARU-Net variables (aru_net/featMapG/...) among the graph constants; "
@@ -206,15 +301,14 @@ def aru_from_nodes(nodes, num_scales_att=None, apply_softmax=None):
         raise IOError("aru_net/logit/class/weights missing")
     use_att = _find(consts, "aru_net/attMapG/attPart/conv1/weights") is not None
     if num_scales_att is None:
-        # one AvgPool per extra scale of the image pyramid (ARU_v1.py:106-109)
-        num_scales_att = 1 + sum(1 for n in nodes if n["op"] == "AvgPool" and "attMapG" in n["name"]) if use_att else 1
-        if use_att and num_scales_att == 1:
-            num_scales_att = 3
+        num_scales_att = _hint_num_scales(nodes, use_att)
+        if num_scales_att is None:
+            raise IOError("the graph has attention variables but no AvgPool op tells the number of pyramid scales: "
+                          "pass num_scales_att explicitly")
     if apply_softmax is None:
-        out = [n for n in nodes if n["name"] == "output"]
-        apply_softmax = True
-        if out and out[0]["op"] not in ("Softmax", "Identity"):
-            apply_softmax = False
+        apply_softmax = _hint_softmax(nodes)
+        if apply_softmax is None:
+            raise IOError("the graph has no 'output' node: pass apply_softmax explicitly")
     cfg = AruConfig(graph="ARU" if use_att else "RU", channels=int(w0.shape[2]), n_classes=int(wl.shape[3]),
                     feat_root=int(w0.shape[3]), scale_space_num=levels, res_depth=res_depth,
                     num_scales_att=int(num_scales_att), filter_size=int(w0.shape[0]),
@@ -227,6 +321,417 @@ def aru_from_nodes(nodes, num_scales_att=None, apply_softmax=None):
         if tuple(t.shape) != tuple(shape):
             raise IOError(f"{name}: shape {tuple(t.shape)} in the graph, {tuple(shape)} expected")
         tensors[name] = np.ascontiguousarray(t, dtype=np.float32)
+    return tensors, cfg
+
+
+# ----------------------------------------------------------------------------------------------
+# mapping by topology (graphs whose variable scopes are unknown)
+# ----------------------------------------------------------------------------------------------
+_PASS_OPS = ("Identity", "StopGradient", "PlaceholderWithDefault", "CheckNumerics", "Snapshot", "PreventGradient")
+_SHAPE_OPS = ("Shape", "ShapeN", "Size", "Rank")
+_BN_OPS = ("FusedBatchNorm", "FusedBatchNormV2", "FusedBatchNormV3")
+_ADD_OPS = ("Add", "AddV2", "BiasAdd")
+# every op type that may sit on the data path of an ARU_v1 graph (ARU_v1.py:62-294, layers.py); anything else is refused
+_KNOWN_OPS = set(_PASS_OPS + _SHAPE_OPS + _BN_OPS + _ADD_OPS + (
+    "Placeholder", "Const", "Fill", "Conv2D", "Conv2DBackpropInput", "Relu", "MaxPool", "AvgPool", "ConcatV2", "Softmax",
+    "Split", "SplitV", "Mul", "AddN", "StridedSlice", "Pack"))
+_MVN_OPS = {"Mean", "Square", "Sqrt", "Rsqrt", "Sub", "RealDiv", "Maximum", "Enter", "Exit", "Merge", "Switch",
+            "NextIteration", "LoopCond", "Less", "LogicalAnd", "Range", "TensorArrayV3", "TensorArrayReadV3",
+            "TensorArrayWriteV3", "TensorArrayScatterV3", "TensorArrayGatherV3", "TensorArraySizeV3",
+            "TensorArrayUnstack", "Cast", "Reshape", "Squeeze", "ExpandDims"}
+_UNSUPPORTED_ACT = {"Elu": "elu", "LeakyRelu": "leaky", "Selu": "selu", "Relu6": "relu6", "Tanh": "tanh",
+                    "Sigmoid": "sigmoid"}
+
+
+class _Layer:
+    __slots__ = ("filter_name", "kind", "w", "b", "bias_name", "scale", "shift", "depth", "preds", "ops", "tail")
+
+    def __init__(self, filter_name, kind, w):
+        self.filter_name, self.kind, self.w = filter_name, kind, w
+        self.b = self.bias_name = self.scale = self.shift = None
+        self.depth, self.preds, self.ops, self.tail = 0, set(), [], None
+
+    @property
+    def cout(self):
+        return int(self.w.shape[3] if self.kind == "conv" else self.w.shape[2])
+
+
+class _Graph:
+    def __init__(self, nodes):
+        self.nodes = {}
+        for n in nodes:
+            if n["name"] in self.nodes:
+                raise IOError(f"duplicate node name {n['name']} in the GraphDef")
+            self.nodes[n["name"]] = n
+        self.consumers = {}
+        for n in nodes:
+            for ref in n["input"]:
+                if not ref.startswith("^"):
+                    self.consumers.setdefault(self.base(ref), []).append(n)
+
+    @staticmethod
+    def base(ref):
+        return ref.lstrip("^").split(":")[0]
+
+    def src(self, ref):
+        n = self.nodes.get(self.base(ref))
+        if n is None:
+            raise IOError(f"input {ref} refers to a node that is not in the graph")
+        return n
+
+    def skip_pass(self, node):
+        hops = 0
+        while node["op"] in _PASS_OPS and node["input"] and hops < 256:
+            node = self.src(node["input"][0])
+            hops += 1
+        return node
+
+    def const_of(self, ref):
+        """(name, ndarray) of the constant ``ref`` resolves to through pass-through ops / Fill, else (None, None)"""
+        n = self.skip_pass(self.src(ref))
+        if n["op"] == "Const" and n["value"] is not None:
+            return n["name"], n["value"]
+        if n["op"] == "Fill" and len(n["input"]) == 2:
+            _, dims = self.const_of(n["input"][0])
+            _, val = self.const_of(n["input"][1])
+            if dims is not None and val is not None and val.size == 1:
+                return n["name"], np.full([int(d) for d in dims.reshape(-1)], val.reshape(-1)[0], dtype=val.dtype)
+        return None, None
+
+    def data_inputs(self, node):
+        """references that carry image data into ``node`` (no control edges, shape operands or constants)"""
+        op, ins = node["op"], [r for r in node["input"] if not r.startswith("^")]
+        if op in _SHAPE_OPS or op in ("Const", "Placeholder", "Fill"):
+            return []
+        if op == "Conv2D":
+            return ins[:1]
+        if op == "Conv2DBackpropInput":
+            return ins[2:3]
+        if op == "ConcatV2":
+            return ins[:-1]
+        if op == "Split":
+            return ins[1:2]
+        if op in ("SplitV", "StridedSlice", "Mean", "Reshape", "ExpandDims", "Squeeze"):
+            return ins[:1]
+        if op in _BN_OPS:
+            return ins[:1]
+        return ins
+
+    def data_consumers(self, node):
+        out = []
+        for c in self.consumers.get(node["name"], []):
+            if c["op"] in _SHAPE_OPS:
+                continue
+            if any(self.base(r) == node["name"] for r in self.data_inputs(c)):
+                out.append(c)
+        return out
+
+
+def _attr_list(node, key, default):
+    v = node["attr"].get(key)
+    return list(v) if isinstance(v, list) and v else list(default)
+
+
+def _check_conv_attrs(node, kind):
+    a = node["attr"]
+    fmt = a.get("data_format") or "NHWC"
+    if fmt != "NHWC":
+        raise IOError(f"{node['name']}: data_format {fmt}; the engine's layout is NHWC")
+    if (a.get("padding") or "SAME") != "SAME":
+        raise IOError(f"{node['name']}: padding {a.get('padding')}; every ARU_v1 layer uses SAME")
+    want = [1, 1, 1, 1] if kind == "conv" else [1, 2, 2, 1]
+    if _attr_list(node, "strides", want) != want:
+        raise IOError(f"{node['name']}: strides {a.get('strides')} (expected {want})")
+    if _attr_list(node, "dilations", [1, 1, 1, 1]) != [1, 1, 1, 1]:
+        raise IOError(f"{node['name']}: dilated convolutions are not part of ARU_v1")
+
+
+def _vec(graph, ref, n):
+    """constant vector of length n (or a scalar) behind ``ref`` -> float64 [n], else None"""
+    _, v = graph.const_of(ref)
+    if v is None or v.dtype.kind != "f" or v.size not in (1, n) or (v.ndim > 1 and v.size != max(v.shape)):
+        return None
+    return np.broadcast_to(v.reshape(-1).astype(np.float64), (n,)).copy()
+
+
+def _read_layer_tail(graph, layer, op):
+    """bias / batch-norm constants behind one use of the layer; returns the last node of the conv -> bias -> bn run"""
+    n = layer.cout
+    cur, bias, scale, shift, bias_name = op, None, None, None, None
+
+    def sole(node, ops):
+        cs = [c for c in graph.data_consumers(node) if c["op"] in ops]
+        return cs[0] if len(cs) == 1 and len(graph.data_consumers(node)) == 1 else None
+
+    c = sole(cur, _ADD_OPS)
+    if c is not None:
+        other = [r for r in c["input"] if not r.startswith("^") and graph.base(r) != cur["name"]]
+        v = _vec(graph, other[0], n) if len(other) == 1 else None
+        if v is not None:
+            bias, bias_name, cur = v, graph.const_of(other[0])[0], c
+    c = sole(cur, _BN_OPS)
+    if c is not None:
+        if c["attr"].get("is_training") is True:
+            raise IOError(f"{c['name']}: batch normalisation in training mode; freeze the graph for inference")
+        parts = [_vec(graph, r, n) for r in c["input"][1:5]]
+        if any(p is None for p in parts):
+            raise IOError(f"{c['name']}: batch-norm statistics are not constants")
+        gamma, beta, mean, var = parts
+        eps = c["attr"].get("epsilon")
+        eps = 1e-3 if eps is None else float(eps)
+        scale = gamma / np.sqrt(var + eps)
+        shift = beta - mean * scale
+        cur = c
+    else:
+        c = sole(cur, ("Mul",))
+        if c is not None:
+            other = [r for r in c["input"] if graph.base(r) != cur["name"]]
+            v = _vec(graph, other[0], n) if len(other) == 1 else None
+            c2 = sole(c, _ADD_OPS) if v is not None else None
+            if c2 is not None:
+                other2 = [r for r in c2["input"] if graph.base(r) != c["name"]]
+                v2 = _vec(graph, other2[0], n) if len(other2) == 1 else None
+                if v2 is not None:
+                    scale, shift, cur = v, v2, c2
+    return cur, bias, bias_name, scale, shift
+
+
+def _collect_layers(graph, on_path):
+    layers, op_layer = OrderedDict(), {}
+    for node in on_path:
+        if node["op"] not in ("Conv2D", "Conv2DBackpropInput"):
+            continue
+        kind = "conv" if node["op"] == "Conv2D" else "deconv"
+        fname, w = graph.const_of(node["input"][1])
+        if w is None or w.ndim != 4:
+            raise IOError(f"{node['name']}: the filter is not a 4-D constant (is this graph frozen?)")
+        if kind == "deconv" and np.all(w == 1.0) and w.shape[0] == w.shape[1]:
+            continue                                        # upsample_simple (layers.py:716-720): not a parameter
+        _check_conv_attrs(node, kind)
+        layer = layers.get(fname)
+        if layer is None:
+            layer = layers[fname] = _Layer(fname, kind, w)
+        elif layer.kind != kind:
+            raise IOError(f"constant {fname} is used by a Conv2D and by a Conv2DBackpropInput")
+        tail, bias, bias_name, scale, shift = _read_layer_tail(graph, layer, node)
+        if layer.ops:
+            if bias_name != layer.bias_name or (scale is None) != (layer.scale is None):
+                raise IOError(f"the uses of filter {fname} do not share one bias / batch norm")
+        else:
+            layer.b, layer.bias_name, layer.scale, layer.shift = bias, bias_name, scale, shift
+        layer.ops.append(node)
+        op_layer[node["name"]] = layer
+    return layers, op_layer
+
+
+def _path_nodes(graph, start, end):
+    """nodes on a data path start -> end (both included), in an order where producers come first"""
+    fwd, stack = set(), [start]
+    while stack:
+        n = stack.pop()
+        if n["name"] in fwd:
+            continue
+        fwd.add(n["name"])
+        stack.extend(graph.data_consumers(n))
+    order, seen = [], set()
+    stack = [(end, False)]
+    while stack:
+        n, done = stack.pop()
+        if done:
+            order.append(n)
+            continue
+        if n["name"] in seen:
+            continue
+        seen.add(n["name"])
+        stack.append((n, True))
+        for r in graph.data_inputs(n):
+            p = graph.src(r)
+            if p["name"] in fwd and p["name"] not in seen:
+                stack.append((p, False))
+    if start["name"] not in seen:
+        raise IOError(f"no data path from {start['name']} to {end['name']}")
+    return order
+
+
+def aru_from_topology(nodes, input_name="inImg", output_name="output"):
+    """ARU_v1 weights + hyper-parameters from the op graph between ``inImg`` and ``output``, whatever the scopes are
+    called (module docstring).  Returns (tensors under the engine's names, AruConfig)."""
+    graph = _Graph(nodes)
+    if input_name not in graph.nodes or output_name not in graph.nodes:
+        raise IOError(f"the graph has no '{input_name}' / '{output_name}' node (net_post_processing_helper.py:69-70)")
+    start, end = graph.nodes[input_name], graph.nodes[output_name]
+    path = _path_nodes(graph, start, end)
+    ops_on_path = {n["op"] for n in path}
+    bad_act = sorted(_UNSUPPORTED_ACT[o] for o in ops_on_path if o in _UNSUPPORTED_ACT)
+    if bad_act:
+        raise IOError(f"activation {bad_act} on the path: the engine implements ARU_v1 with relu only (ARU_v1.py:70-75)")
+    mvn = bool(ops_on_path & {"Enter", "Mean", "Sqrt", "Rsqrt", "RealDiv"})
+    unknown = sorted(ops_on_path - _KNOWN_OPS - (_MVN_OPS if mvn else set()))
+    if unknown:
+        raise IOError(f"ops {unknown} between {input_name} and {output_name} are not part of the ARU_v1 family")
+    for n in path:
+        if n["op"] in ("MaxPool", "AvgPool"):
+            if _attr_list(n, "ksize", [1, 2, 2, 1]) != [1, 2, 2, 1] or _attr_list(n, "strides", [1, 2, 2, 1]) != [1, 2, 2, 1] \
+                    or (n["attr"].get("padding") or "SAME") != "SAME":
+                raise IOError(f"{n['name']}: only 2x2 / stride 2 / SAME pooling is supported")
+    layers, op_layer = _collect_layers(graph, path)
+    if not layers:
+        raise IOError("no convolution with a constant filter between inImg and output")
+    # conv depth of every node on the path and, per layer, the layers whose output reaches it without another layer
+    depth, reach = {}, {}
+    for n in path:                                          # producers first
+        d, rs = 0, set()
+        for r in graph.data_inputs(n):
+            p = graph.src(r)
+            if p["name"] not in depth:
+                continue
+            d = max(d, depth[p["name"]])
+            rs |= reach[p["name"]]
+        lay = op_layer.get(n["name"])
+        if lay is not None:
+            if lay.depth and lay.depth != d + 1:
+                raise IOError(f"filter {lay.filter_name} is used at conv depths {lay.depth} and {d + 1}")
+            lay.depth = d + 1
+            lay.preds |= rs
+            d, rs = d + 1, {lay.filter_name}
+        depth[n["name"]], reach[n["name"]] = d, rs
+    by_depth = {}
+    for lay in layers.values():
+        by_depth.setdefault(lay.depth, []).append(lay)
+
+    def follow(root):
+        chain = [root]
+        while True:
+            nxt = [c for c in by_depth.get(chain[-1].depth + 1, []) if chain[-1].filter_name in c.preds]
+            if len(nxt) != 1:
+                if len(nxt) > 1:
+                    raise IOError(f"two layers at conv depth {chain[-1].depth + 1} consume {chain[-1].filter_name}")
+                return chain
+            chain.append(nxt[0])
+
+    roots = by_depth.get(1, [])
+    if not 1 <= len(roots) <= 2:
+        raise IOError(f"{len(roots)} different filters are applied to the image; ARU_v1 has one (RU) or two (ARU)")
+    chains = sorted((follow(r) for r in roots), key=len)
+    last = max(layers.values(), key=lambda l: l.depth)
+    if sum(1 for l in layers.values() if l.depth == last.depth) != 1 or chains[-1][-1] is not last:
+        raise IOError("the graph does not end in one classification convolution")
+    det = chains[-1][:-1]
+    att = []
+    if len(chains) == 2:
+        att = chains[0][:-1] if chains[0][-1] is last else chains[0]
+        if len(att) != 4 or att[-1].cout != 1 or any(l.kind != "conv" for l in att):
+            raise IOError("the second branch on the image is not the 4-layer attention CNN of ARU_v1.py:165-184")
+    if len(det) + len(att) + 1 != len(layers):
+        stray = [l.filter_name for l in layers.values() if l not in det and l not in att and l is not last]
+        raise IOError(f"layers outside the U-Net chain / attention chain: {stray[:4]}")
+    # hyper-parameters from the chain's filter shapes
+    k, _, channels, feat_root = (int(v) for v in det[0].w.shape)
+    res_depth = 0
+    while 1 + res_depth < len(det) and det[1 + res_depth].kind == "conv" and \
+            tuple(det[1 + res_depth].w.shape) == (k, k, feat_root, feat_root):
+        res_depth += 1
+    n_dec = sum(1 for l in det if l.kind == "deconv")
+    n_levels = n_dec + 1
+    if res_depth < 1 or len(det) != n_levels * (1 + res_depth) + n_dec * (2 + res_depth):
+        raise IOError(f"{len(det)} U-Net layers do not form {n_levels} levels of 1 + {res_depth} residual convolutions")
+    n_scales = len(det[0].ops)
+    if att and len(att[0].ops) != n_scales:
+        raise IOError(f"attention CNN applied {len(att[0].ops)} times, U-Net {n_scales} times")
+    if not att and n_scales != 1:
+        raise IOError("a graph without attention branch applies the U-Net once")
+    # class softmax between the last layer and `output`?
+    node, softmax = graph.skip_pass(end), False
+    if node["op"] == "Softmax":
+        softmax, node = True, graph.skip_pass(graph.src(node["input"][0]))
+    if node is not last.ops[0] and node is not _read_layer_tail(graph, last, last.ops[0])[0]:
+        raise IOError(f"'{output_name}' is not the (softmax of the) classification layer but {node['op']} {node['name']}")
+    cfg = AruConfig(graph="ARU" if att else "RU", channels=channels, n_classes=last.cout, feat_root=feat_root,
+                    scale_space_num=n_levels, res_depth=res_depth, num_scales_att=n_scales, filter_size=k, mvn=mvn,
+                    apply_softmax=softmax)
+    # assign by position and verify the skip / residual wiring against the template
+    names = list(aru_tensor_shapes(cfg))
+    wnames = [n for n in names if n.endswith("/weights")]
+    ordered = att + det + [last]
+    if len(wnames) != len(ordered):
+        raise IOError(f"{len(ordered)} layers in the graph, {len(wnames)} in ARU_v1 with {cfg}")
+    shapes = aru_tensor_shapes(cfg)
+    tensors = OrderedDict()
+    name_of = {}
+    for wname, lay in zip(wnames, ordered):
+        scope = wname[:-len("/weights")]
+        if ("/deconv" in scope) != (lay.kind == "deconv"):
+            raise IOError(f"{scope}: expected a {'transposed ' if '/deconv' in scope else ''}convolution at conv depth "
+                          f"{lay.depth}, found {lay.ops[0]['op']} ({lay.filter_name})")
+        if tuple(lay.w.shape) != tuple(shapes[wname]):
+            raise IOError(f"{scope}: filter {lay.filter_name} has shape {tuple(lay.w.shape)}, ARU_v1 expects "
+                          f"{tuple(shapes[wname])}")
+        name_of[lay.filter_name] = scope
+        w = lay.w.astype(np.float64)
+        b = lay.b if lay.b is not None else np.zeros(lay.cout)
+        if lay.scale is not None:                          # y = s * (conv + b) + t, folded
+            w = w * (lay.scale[None, None, None, :] if lay.kind == "conv" else lay.scale[None, None, :, None])
+            b = b * lay.scale + lay.shift
+        tensors[wname] = np.ascontiguousarray(w, dtype=np.float32)
+        bname = scope + ("/bias" if lay.kind == "deconv" else "/biases")
+        tensors[bname] = np.ascontiguousarray(b, dtype=np.float32)
+    tensors = OrderedDict((n, tensors[n]) for n in names)
+    _check_wiring(cfg, ordered, name_of)
+    return tensors, cfg
+
+
+def _check_wiring(cfg, ordered, name_of):
+    """which layers feed which (through bias / relu / pool / add / concat only) must be ARU_v1's residual U-Net"""
+    got = {name_of[l.filter_name]: {name_of[p] for p in l.preds} for l in ordered}
+    n, R = cfg.scale_space_num, cfg.res_depth
+    want = {}
+    block_out = None                                        # layers whose sum is the previous block's output
+    det = "aru_net/featMapG/"
+    for l in range(n):
+        s = f"{det}unet_down_{l}"
+        want[s + "/conv1"] = set(block_out or ())
+        for r in range(R):
+            want[s + f"/convR_{r}"] = {s + ("/conv1" if r == 0 else f"/convR_{r - 1}")}
+        block_out = {s + "/conv1", s + f"/convR_{R - 1}"}
+    for l in range(n - 2, -1, -1):
+        s, skip = f"{det}unet_up_{l}", f"{det}unet_down_{l}"
+        want[s + "/deconv"] = set(block_out)
+        want[s + "/conv1"] = {s + "/deconv", skip + "/conv1", skip + f"/convR_{R - 1}"}
+        for r in range(R):
+            want[s + f"/convR_{r}"] = {s + ("/conv1" if r == 0 else f"/convR_{r - 1}")}
+        block_out = {s + "/conv1", s + f"/convR_{R - 1}"}
+    logit_in = set(block_out)
+    if cfg.use_attention:
+        a = "aru_net/attMapG/attPart/conv"
+        want[a + "1"] = set()
+        for i in (2, 3, 4):
+            want[a + str(i)] = {a + str(i - 1)}
+        logit_in.add(a + "4")
+    want["aru_net/logit/class"] = logit_in
+    for scope, preds in want.items():
+        if got.get(scope) != preds:
+            raise IOError(f"{scope} is fed by {sorted(got.get(scope, ()))} in the graph, ARU_v1 wires it to {sorted(preds)} "
+                          f"(non-residual 'U' graphs and other variants are not supported)")
+
+
+def aru_from_nodes(nodes, num_scales_att=None, apply_softmax=None):
+    """Frozen ARU-Net -> (tensors, AruConfig).  A graph with its op structure is mapped by topology; when it also
+    carries ARU_v1's variable names both mappings must agree.  A constants-only container is mapped by name."""
+    has_ops = any(n["op"] == "Conv2D" for n in nodes)
+    named = any(n["op"] == "Const" and n["name"].endswith("aru_net/featMapG/unet_down_0/conv1/weights") for n in nodes)
+    if not has_ops:
+        return aru_from_constants(nodes, num_scales_att, apply_softmax)
+    tensors, cfg = aru_from_topology(nodes)
+    if num_scales_att is not None and int(num_scales_att) != cfg.num_scales_att:
+        raise IOError(f"num_scales_att={num_scales_att} given, the graph applies the nets to {cfg.num_scales_att} scales")
+    if apply_softmax is not None and bool(apply_softmax) != cfg.apply_softmax:
+        raise IOError(f"apply_softmax={apply_softmax} given, the graph says {cfg.apply_softmax}")
+    if named:
+        by_name, _ = aru_from_constants(nodes, cfg.num_scales_att, cfg.apply_softmax)
+        folded = any(n["op"] in _BN_OPS for n in nodes)
+        for k in tensors:
+            if not folded and not np.array_equal(by_name[k], tensors[k]):
+                raise IOError(f"{k}: the constant of that name is not the one the op graph uses at this position")
     return tensors, cfg
 
 
