@@ -755,7 +755,8 @@ def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None):
     vis_kw = {}
     if any("visual_node_feature_compression" in k for k in consts):
         # graph exported with --image_input (graph_relation.py:17-37): backbone + one compression layer per map
-        _, bcfg = aru_from_nodes(nodes)
+        # the backbone's logits are not used by the relation graph (only its end points): no class softmax to look for
+        _, bcfg = aru_from_constants(nodes, apply_softmax=False)
         dims, chans = [], []
         i = 0
         while _find(consts, f"visual_node_feature_compression_fm_{i}/dense/weights") is not None:

@@ -268,7 +268,10 @@ def _t_upsample(x, out_hw, up, torch):
     return s[:, :, iy][:, :, :, ix]                                # [1,1,Ho,Wo]; caller broadcasts
 
 
-def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermediates=False):
+def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermediates=False, bn=None):
+    """``bn``: optional {layer scope: (gamma, beta, moving_mean, moving_variance, epsilon)} -- inference-mode batch
+    normalisation applied UNFOLDED between bias and activation (layers.py:241-242 ``batchNorm`` switch); the importer
+    folds it into the weights, this is the independent evaluation it is compared with."""
     import torch
     import torch.nn.functional as F
     if num_threads:
@@ -283,8 +286,14 @@ def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermedia
         H, W = x.shape[2], x.shape[3]
         inter = {}
 
+        def batch_norm(y, p):
+            if not bn or p not in bn:
+                return y
+            gamma, beta, mean, var = (torch.as_tensor(np.asarray(v)).to(dtype).view(1, -1, 1, 1) for v in bn[p][:4])
+            return (y - mean) / torch.sqrt(var + float(bn[p][4])) * gamma + beta
+
         def conv(x, p, bias_name="biases"):
-            return _t_conv(x, tw[p + "/weights"], tw[p + "/" + bias_name], F, torch)
+            return batch_norm(_t_conv(x, tw[p + "/weights"], tw[p + "/" + bias_name], F, torch), p)
 
         def block(x, p):
             t = conv(x, p + "/conv1")
@@ -307,8 +316,8 @@ def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermedia
             for l in range(n - 2, -1, -1):
                 p = f"aru_net/featMapG/unet_up_{l}"
                 skip = skips[l]
-                v = F.relu(_t_deconv(u, tw[p + "/deconv/weights"], tw[p + "/deconv/bias"],
-                                     skip.shape[2:], cfg.pool_size, F, torch))
+                v = F.relu(batch_norm(_t_deconv(u, tw[p + "/deconv/weights"], tw[p + "/deconv/bias"],
+                                                skip.shape[2:], cfg.pool_size, F, torch), p + "/deconv"))
                 inter[f"scale_{sc}_unet_up_{l}_deconv"] = v
                 u = block(torch.cat([skip, v], dim=1), p)
                 inter[f"scale_{sc}_unet_up_{l}_conv"] = u

@@ -52,11 +52,12 @@ def test_full_chain(tmp_path):
     lst.write_text(str(data / "p0.png") + "\n")
     # models: two ARU-Nets (separator / heading) and the GNN as frozen graphs
     acfg = AruConfig()
-    extra = [{"name": f"graph/aru_net/attMapG/AvgPool_{i}", "op": "AvgPool"} for i in range(acfg.num_scales_att - 1)]
-    extra.append({"name": "output", "op": "Softmax", "input": ["graph/aru_net/logit/logits"]})
-    for name, seed in (("sep.pb", 21), ("head.pb", 22)):
-        (tmp_path / name).write_bytes(pb_import.weights_to_graphdef(
-            init_aru_weights(acfg, seed, bias_jitter=0.05, logit_scale=0.05), "graph/", extra))
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import tf_aru_graph
+    for name, seed in (("sep.pb", 21), ("head.pb", 22)):          # frozen graphs in TF1 layout, serialised by protobuf
+        (tmp_path / name).write_bytes(tf_aru_graph.build_aru_pb(
+            init_aru_weights(acfg, seed, bias_jitter=0.05, logit_scale=0.05), acfg))
     gcfg = GnnConfig()
 
     # 1. separators (threshold mid-range so random weights give structure), output page/p0.xml.xml

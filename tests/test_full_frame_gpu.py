@@ -16,6 +16,11 @@ from PIL import Image
 
 pytestmark = pytest.mark.gpu
 
+import os  # noqa: E402
+import sys  # noqa: E402
+sys.path.insert(0, os.path.dirname(__file__))
+import tf_aru_graph  # noqa: E402
+
 H, W = 4500, 3000
 
 
@@ -88,10 +93,8 @@ def test_c1_crop_512x768_through_the_separator_cli(tmp_path):
     from oracle import aru_oracle, classical_oracle as co
     cfg = AruConfig()
     w = init_aru_weights(cfg, 77, bias_jitter=0.05, logit_scale=0.05)
-    extra = [{"name": f"graph/aru_net/attMapG/AvgPool_{i}", "op": "AvgPool"} for i in range(cfg.num_scales_att - 1)]
-    extra.append({"name": "output", "op": "Softmax", "input": ["graph/aru_net/logit/logits"]})
     pb = tmp_path / "separator_aru.pb"
-    pb.write_bytes(pb_import.weights_to_graphdef(w, "graph/", extra))
+    pb.write_bytes(tf_aru_graph.build_aru_pb(w, cfg))      # laid out like a TF1 freeze, serialised by protobuf
     data = tmp_path / "data"
     (data / "page").mkdir(parents=True)
     crop = np.ascontiguousarray(synth.synth_page(0, W, H)[0:768, 0:512])          # C1 = page 0 [0:768, 0:512]

@@ -8,6 +8,11 @@ from PIL import Image
 
 pytestmark = pytest.mark.gpu
 
+import os  # noqa: E402
+import sys  # noqa: E402
+sys.path.insert(0, os.path.dirname(__file__))
+import tf_aru_graph  # noqa: E402
+
 
 def _page_xml(path, W, H, lines):
     regs = []
@@ -28,10 +33,8 @@ def _setup(tmp_path, W=600, H=900, color=False):
     from citlab_article_separation_new_amd.weights import init_aru_weights
     cfg = AruConfig()
     w = init_aru_weights(cfg, 77, bias_jitter=0.05, logit_scale=0.05)
-    extra = [{"name": f"graph/aru_net/attMapG/AvgPool_{i}", "op": "AvgPool"} for i in range(cfg.num_scales_att - 1)]
-    extra.append({"name": "output", "op": "Softmax", "input": ["graph/aru_net/logit/logits"]})
     pb = tmp_path / "separator_aru.pb"
-    pb.write_bytes(pb_import.weights_to_graphdef(w, "graph/", extra))
+    pb.write_bytes(tf_aru_graph.build_aru_pb(w, cfg))      # laid out like a TF1 freeze, serialised by protobuf
     data = tmp_path / "data"
     (data / "page").mkdir(parents=True)
     gray = synth.synth_page(3, W=W, H=H)

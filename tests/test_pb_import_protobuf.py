@@ -1,0 +1,227 @@
+"""The TF-free ``.pb`` reader against an INDEPENDENT encoder, and the topology-driven ARU-Net mapper against graphs laid
+out the way TensorFlow 1.x freezes ``ARU_v1`` (tests/tf_aru_graph.py), serialised by google.protobuf
+(tests/tf_graphdef_proto.py) -- not by the product's own ``encode_graphdef`` (that self round-trip is
+tests/test_pb_import.py)."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytest.importorskip("google.protobuf")
+sys.path.insert(0, os.path.dirname(__file__))
+import tf_aru_graph  # noqa: E402
+import tf_graphdef_proto as tp  # noqa: E402
+
+from citlab_article_separation_new_amd import pb_import  # noqa: E402
+from citlab_article_separation_new_amd.config import AruConfig  # noqa: E402
+from citlab_article_separation_new_amd.weights import init_aru_weights  # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# wire format
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("packed", [True, False])
+@pytest.mark.parametrize("encoding", ["content", "repeated"])
+def test_reader_against_protobuf_encoder(packed, encoding):
+    ns = tp.build_messages(packed)
+    rng = np.random.default_rng(3)
+    f32 = rng.normal(size=(3, 3, 4, 5)).astype(np.float32)
+    f64 = rng.normal(size=(2, 3))
+    i32 = rng.integers(-5, 5, size=(7,)).astype(np.int32)           # negative varints: 10 bytes each
+    i64 = np.array([[-1, 2 ** 40], [3, -2 ** 35]], np.int64)
+    nodes = [
+        tp.node(ns, "inImg", "Placeholder", dtype=tp.DType(1), shape=tp.Shape(-1, -1, -1, 1)),
+        tp.node(ns, "w", "Const", tensor_encoding=encoding, dtype=tp.DType(1), value=f32, device="/device:CPU:0", debug=True),
+        tp.node(ns, "d", "Const", tensor_encoding=encoding, dtype=tp.DType(2), value=f64),
+        tp.node(ns, "i", "Const", tensor_encoding=encoding, dtype=tp.DType(3), value=i32),
+        tp.node(ns, "l", "Const", tensor_encoding=encoding, dtype=tp.DType(9), value=i64),
+        tp.node(ns, "ones", "Const", tensor_encoding="splat", dtype=tp.DType(1), value=np.full((8, 8, 1, 1), 1.0, np.float32)),
+        tp.node(ns, "scalar", "Const", tensor_encoding=encoding, dtype=tp.DType(1), value=np.array(2.5, np.float32)),
+        tp.node(ns, "empty", "Const", tensor_encoding=encoding, dtype=tp.DType(1), value=np.zeros((0, 4), np.float32)),
+        tp.node(ns, "w/read", "Identity", ["w", "^inImg"], T=tp.DType(1), _class=["loc:@w"]),
+        tp.node(ns, "conv", "Conv2D", ["inImg", "w/read"], T=tp.DType(1), strides=[1, 1, 1, 1], padding="SAME",
+                data_format="NHWC", dilations=[1, 1, 1, 1], use_cudnn_on_gpu=True, zero=0, off=False, eps=0.001),
+        tp.node(ns, "bn", "FusedBatchNormV3", ["conv", "a", "b", "c", "d"], epsilon=1.0009999641624745e-03, is_training=False),
+        tp.node(ns, "split", "Split", ["i", "conv"], num_split=3),
+        tp.node(ns, "mul", "Mul", ["split:2", "d"], T=tp.DType(1)),
+    ]
+    data = tp.graphdef(ns, nodes).SerializeToString()
+    got = pb_import.parse_graphdef(data)
+    assert [n["name"] for n in got] == [n.name for n in nodes]
+    assert [n["op"] for n in got] == [n.op for n in nodes]
+    by = {n["name"]: n for n in got}
+    for name, arr in (("w", f32), ("d", f64), ("i", i32), ("l", i64)):
+        assert by[name]["value"].dtype == arr.dtype and np.array_equal(by[name]["value"], arr), name
+    assert by["ones"]["value"].shape == (8, 8, 1, 1) and np.all(by["ones"]["value"] == 1.0)
+    assert by["scalar"]["value"].shape == () and by["scalar"]["value"] == np.float32(2.5)
+    assert by["empty"]["value"].shape == (0, 4)
+    assert by["w/read"]["input"] == ["w", "^inImg"] and by["mul"]["input"] == ["split:2", "d"]
+    a = by["conv"]["attr"]
+    assert a["strides"] == [1, 1, 1, 1] and a["padding"] == "SAME" and a["data_format"] == "NHWC"
+    assert a["use_cudnn_on_gpu"] is True and a["off"] is False and a["zero"] == 0 and a["T"] == ("type", 1)
+    assert abs(a["eps"] - 0.001) < 1e-9
+    assert by["inImg"]["attr"]["shape"] == ("shape", [-1, -1, -1, 1])
+    assert by["bn"]["attr"]["is_training"] is False and abs(by["bn"]["attr"]["epsilon"] - 1.001e-3) < 1e-8
+    assert by["split"]["attr"]["num_split"] == 3
+
+
+def test_protobuf_decodes_the_products_encoder():
+    """the other direction: what ``encode_graphdef`` writes is a GraphDef a real protobuf parser accepts"""
+    ns = tp.build_messages()
+    w = init_aru_weights(AruConfig(scale_space_num=2, res_depth=1), 3)
+    g = ns.GraphDef()
+    g.ParseFromString(pb_import.weights_to_graphdef(w, "graph/"))
+    consts = {n.name: n for n in g.node if n.op == "Const"}
+    assert set(consts) == {"graph/" + k for k in w}
+    for k, v in w.items():
+        t = consts["graph/" + k].attr["value"].tensor
+        arr = np.frombuffer(t.tensor_content, "<f4") if t.tensor_content else np.array(t.float_val, np.float32)
+        assert [d.size for d in t.tensor_shape.dim] == list(v.shape) and np.array_equal(arr.reshape(v.shape), v)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# topology-driven mapping
+# ------------------------------------------------------------------------------------------------------------------
+def _hashed(scope):
+    """scope names as another exporter might choose them: nothing of ARU_v1's naming survives"""
+    return "net/" + "/".join("n" + hashlib.md5(p.encode()).hexdigest()[:6] for p in scope.split("/"))
+
+
+CFGS = [{}, {"graph": "RU"}, {"scale_space_num": 3, "res_depth": 2, "n_classes": 3, "num_scales_att": 2}, {"feat_root": 16},
+        {"scale_space_num": 1, "res_depth": 3}, {"scale_space_num": 2, "res_depth": 1, "num_scales_att": 1}]
+
+
+@pytest.mark.parametrize("kw", CFGS, ids=str)
+@pytest.mark.parametrize("style", ["tf_names", "hashed_names", "no_read_addv2", "unpacked"])
+def test_topology_mapping_recovers_weights_and_config(kw, style):
+    cfg = AruConfig(**kw)
+    w = init_aru_weights(cfg, 11, bias_jitter=0.05)
+    opts = {"tf_names": {}, "hashed_names": {"rename": _hashed},
+            "no_read_addv2": {"rename": _hashed, "read_identities": False, "add_op": "AddV2", "bias_op": "Add",
+                              "tensor_encoding": "repeated"},
+            "unpacked": {"packed_repeated": False, "tensor_encoding": "repeated", "output_softmax": False}}[style]
+    nodes = pb_import.parse_graphdef(tf_aru_graph.build_aru_pb(w, cfg, **opts))
+    tensors, got = pb_import.aru_from_nodes(nodes)
+    assert list(tensors) == list(w)
+    for k in w:
+        assert np.array_equal(tensors[k], w[k]), k
+    for f in ("graph", "channels", "n_classes", "feat_root", "scale_space_num", "res_depth", "filter_size", "mvn"):
+        assert getattr(got, f) == getattr(cfg, f), f
+    assert got.num_scales_att == (cfg.num_scales_att if cfg.use_attention else 1)
+    assert got.apply_softmax == (style != "unpacked")
+
+
+def _bn_params(cfg, w, seed):
+    rng = np.random.default_rng(seed)
+    bn = {}
+    for name, arr in w.items():
+        if not name.endswith("/weights") or "logit" in name:
+            continue
+        scope = name[:-len("/weights")]
+        c = arr.shape[2] if "/deconv" in scope else arr.shape[3]
+        bn[scope] = (rng.uniform(0.5, 1.5, c).astype(np.float32), rng.normal(0, 0.1, c).astype(np.float32),
+                     rng.normal(0, 0.2, c).astype(np.float32), rng.uniform(0.5, 2.0, c).astype(np.float32), 1e-3)
+    return bn
+
+
+@pytest.mark.parametrize("bn_style", ["fused", "mul_add"])
+def test_batch_norm_is_folded(bn_style):
+    cfg = AruConfig(scale_space_num=3, res_depth=2)
+    w = init_aru_weights(cfg, 5, bias_jitter=0.05)
+    bn = _bn_params(cfg, w, 9)
+    nodes = pb_import.parse_graphdef(tf_aru_graph.build_aru_pb(w, cfg, rename=_hashed, bn=bn, bn_style=bn_style))
+    tensors, got = pb_import.aru_from_nodes(nodes)
+    assert got.scale_space_num == 3 and got.res_depth == 2
+    for scope, (gamma, beta, mean, var, eps) in bn.items():
+        s = gamma.astype(np.float64) / np.sqrt(var.astype(np.float64) + (np.float32(eps) if bn_style == "mul_add" else eps))
+        t = beta - mean * s
+        deconv = "/deconv" in scope
+        wk = w[scope + "/weights"].astype(np.float64)
+        want_w = wk * (s[None, None, :, None] if deconv else s[None, None, None, :])
+        want_b = w[scope + ("/bias" if deconv else "/biases")] * s + t
+        np.testing.assert_allclose(tensors[scope + "/weights"], want_w, rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(tensors[scope + ("/bias" if deconv else "/biases")], want_b, rtol=2e-6, atol=1e-6)
+    assert np.array_equal(tensors["aru_net/logit/class/weights"], w["aru_net/logit/class/weights"])
+
+
+def _edit(data, fn):
+    ns = tp.build_messages()
+    g = ns.GraphDef()
+    g.ParseFromString(data)
+    fn(g, ns)
+    return pb_import.parse_graphdef(g.SerializeToString())
+
+
+def test_refuses_what_it_cannot_map():
+    cfg = AruConfig(scale_space_num=2, res_depth=2)
+    w = init_aru_weights(cfg, 1)
+    good = tf_aru_graph.build_aru_pb(w, cfg)
+    pb_import.aru_from_nodes(pb_import.parse_graphdef(good))
+    with pytest.raises(IOError, match="relu only"):
+        pb_import.aru_from_nodes(pb_import.parse_graphdef(tf_aru_graph.build_aru_pb(w, cfg, activation="Elu")))
+
+    def nchw(g, ns):
+        next(n for n in g.node if n.op == "Conv2D").attr["data_format"].s = b"NCHW"
+    with pytest.raises(IOError, match="NHWC"):
+        pb_import.aru_from_nodes(_edit(good, nchw))
+
+    def valid(g, ns):
+        [n for n in g.node if n.op == "Conv2D"][3].attr["padding"].s = b"VALID"
+    with pytest.raises(IOError, match="SAME"):
+        pb_import.aru_from_nodes(_edit(good, valid))
+
+    def sigmoid_out(g, ns):
+        out = next(n for n in g.node if n.name == "output")
+        out.op = "Sigmoid"
+    with pytest.raises(IOError):
+        pb_import.aru_from_nodes(_edit(good, sigmoid_out))
+
+    def no_residual(g, ns):                                   # a plain 'U' block: the Add reads the last convR twice
+        for add in (n for n in g.node if n.op == "Add" and "/unet_down_0/" in n.name):      # one per pyramid scale
+            add.input[1] = add.input[0]
+    with pytest.raises(IOError, match="wires it to"):
+        pb_import.aru_from_nodes(_edit(good, no_residual))
+
+    def swapped_names(g, ns):                                 # ARU_v1 names present but attached to the wrong layers
+        a = next(n for n in g.node if n.name == "aru_net/featMapG/unet_down_0/convR_0/weights")
+        b = next(n for n in g.node if n.name == "aru_net/featMapG/unet_down_0/convR_1/weights")
+        va, vb = a.attr["value"].tensor.tensor_content, b.attr["value"].tensor.tensor_content
+        a.attr["value"].tensor.tensor_content, b.attr["value"].tensor.tensor_content = vb, va
+        for n in g.node:
+            for k, ref in enumerate(n.input):
+                if ref == "aru_net/featMapG/unet_down_0/convR_0/weights/read":
+                    n.input[k] = "aru_net/featMapG/unet_down_0/convR_1/weights/read"
+                elif ref == "aru_net/featMapG/unet_down_0/convR_1/weights/read":
+                    n.input[k] = "aru_net/featMapG/unet_down_0/convR_0/weights/read"
+    # the graph still computes the same function; the topology mapping wins and is self-consistent, so the names
+    # are reported as inconsistent rather than silently trusted
+    with pytest.raises(IOError, match="not the one the op graph uses"):
+        pb_import.aru_from_nodes(_edit(good, swapped_names))
+
+    bn = _bn_params(cfg, w, 2)
+    data = tf_aru_graph.build_aru_pb(w, cfg, bn=bn)
+
+    def train(g, ns):
+        next(n for n in g.node if n.op == "FusedBatchNormV3").attr["is_training"].b = True
+    with pytest.raises(IOError, match="training mode"):
+        pb_import.aru_from_nodes(_edit(data, train))
+
+    def drop_output(g, ns):
+        out = next(n for n in g.node if n.name == "output")
+        out.name = "probs"
+    with pytest.raises(IOError, match="inImg"):
+        pb_import.aru_from_nodes(_edit(good, drop_output))
+
+
+def test_constants_only_container_never_defaults():
+    cfg = AruConfig()
+    w = init_aru_weights(cfg, 1)
+    nodes = pb_import.parse_graphdef(pb_import.weights_to_graphdef(w, "graph/"))
+    with pytest.raises(IOError, match="num_scales_att"):
+        pb_import.aru_from_nodes(nodes)
+    with pytest.raises(IOError, match="apply_softmax"):
+        pb_import.aru_from_nodes(nodes, num_scales_att=3)
+    tensors, got = pb_import.aru_from_nodes(nodes, num_scales_att=3, apply_softmax=False)
+    assert got.num_scales_att == 3 and got.apply_softmax is False
