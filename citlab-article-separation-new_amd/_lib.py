@@ -53,6 +53,9 @@ SIGNATURES = {
     "asep_gnn_attach_backbone": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_char_p)]),
     "asep_gnn_forward_visual": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P,
                                           C.c_int, _P, _P]),
+    "asep_gnn_forward_visual_dev": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P,
+                                              C.c_int, _P, _P, _P]),
+    "asep_gnn_step_mode": (C.c_int, [_P]),
     "asep_gnn_get_node_features": (C.c_int, [_P, _P, C.c_size_t]),
     "asep_post_create": (_P, []),
     "asep_post_free": (None, [_P]),

@@ -943,6 +943,8 @@ int aru_endpoint_channels(const asep_aru* m, const char* name) {
     return m->cfg.feat_root << l;
 }
 
+int aru_num_classes(const asep_aru* m) { return m ? m->cfg.n_classes : -1; }
+
 }  // namespace asep
 
 extern "C" {

@@ -96,5 +96,7 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 int aru_endpoint_dev(asep_aru* m, const char* name, const float** d_ptr, int dims[3]);
 // Number of channels the end point `name` will have for this model's configuration, or -1 if unknown.
 int aru_endpoint_channels(const asep_aru* m, const char* name);
+// Number of output classes (channels of the logits / probability map) of the model.
+int aru_num_classes(const asep_aru* m);
 
 }  // namespace asep

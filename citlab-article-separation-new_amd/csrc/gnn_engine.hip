@@ -1,6 +1,11 @@
 // GNN relation-predictor engine (host side).  Entry points: include/asep_hip.h.
 // Schedule of one page (batch size 1, graph_gnn.py:46-167 + graph_relation.py:194-203):
+//   [visual branch: backbone -> ROI max -> compression -> concat]
 //   edge correction -> T x (message, LSTM update) -> per-node first classifier layer -> per-pair classifier.
+// Three step kernels, chosen at load time:
+//   STEP_SMALL  gnn_step_kernel      widths 32/32/32, U <= 8, Ed <= 4: W1 fragments in registers (the 7-feature nets)
+//   STEP_BIG    gnn_step_big_kernel  widths 32/32/32, U <= 120, Ed <= 4: W1 fragments in LDS (visual nets, U = 55)
+//   STEP_GENERIC  gnn_message_generic_kernel + gnn_lstm_generic_kernel: any widths (plain FMA loops)
 #include <algorithm>
 #include <memory>
 
@@ -9,23 +14,29 @@
 
 using namespace asep;
 
+enum { STEP_GENERIC = 0, STEP_SMALL = 1, STEP_BIG = 2 };
+
 struct asep_gnn {
     asep_gnn_cfg cfg{};
+    int U = 0, Ed = 0, H = 0, I = 0, Hm = 0;   // node / edge feature widths, hidden, interaction, MLP hidden
     int K = 0, V = 0;                 // message-MLP input width, LSTM input width
     float *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
     float* Wg[4] = {nullptr, nullptr, nullptr, nullptr};
     float* bg[4] = {nullptr, nullptr, nullptr, nullptr};
     float *C1 = nullptr, *cb1 = nullptr, *C2 = nullptr, *cb2 = nullptr, *C3 = nullptr, *cb3 = nullptr;
-    // fused MFMA step kernel (U <= 8, Ed <= 4): permuted W1 / W2 fragments + quad descriptors
+    // fused MFMA step kernels: permuted W1 / W2 fragments + quad descriptors
     float *A1 = nullptr, *A2 = nullptr;
     unsigned char* qdesc = nullptr;
-    int nch = 0;
-    bool use_step = true;             // ASEP_GNN_STEP=0 selects the separate message / LSTM kernels
+    int nch = 0, Upad = 0;
+    int mode = STEP_GENERIC;
+    size_t big_lds = 0;
+    bool use_step = true;             // ASEP_GNN_STEP=0 selects the separate (generic) message / LSTM kernels
     std::vector<void*> owned;
-    BufferPool pool;
-    BufferPool host_stage;            // device staging of the host-pointer entry point (grow-only)
+    BufferPool pool;                  // buffers of one forward (requested in a fixed order)
+    BufferPool vis_pool;              // buffers of the visual stage in front of it
+    BufferPool host_stage;            // device staging of the host-pointer entry points (grow-only)
     // state of the last forward
-    int N = 0, Ecorr = -1;
+    int N = 0;
     float* d_h = nullptr;
     int* d_rowptr = nullptr;
     hipStream_t stream = nullptr;
@@ -33,11 +44,22 @@ struct asep_gnn {
     std::map<std::string, HostTensor> vis_blob;      // visual_node_feature_compression_fm_<i>/dense/{weights,bias}
     asep_aru* backbone = nullptr;                    // not owned
     std::vector<std::string> vis_names;
-    std::vector<float*> vis_W, vis_b;
+    std::vector<float*> vis_W, vis_b;                // owned through vis_owned
+    std::vector<void*> vis_owned;
     std::vector<int> vis_C, vis_d;
     int vis_total = 0;
-    float* d_u_cat = nullptr;                        // concatenated node features of the last visual forward
+    float* d_u_cat = nullptr;                        // concatenated node features of the last visual forward (own buffer)
+    size_t u_cat_cap = 0;
+    void free_visual() {
+        for (void* p : vis_owned)
+            if (p) (void)hipFree(p);
+        vis_owned.clear(); vis_W.clear(); vis_b.clear(); vis_names.clear(); vis_C.clear(); vis_d.clear();
+        vis_total = 0;
+        backbone = nullptr;
+    }
     ~asep_gnn() {
+        free_visual();
+        if (d_u_cat) (void)hipFree(d_u_cat);
         for (void* p : owned)
             if (p) (void)hipFree(p);
     }
@@ -49,7 +71,7 @@ const char* MSG = "GraphLSTM1/message_fn_default/head_0/calculation_interaction_
 const char* UPD = "GraphLSTM1/update_function_LSTM";
 const char* CLS = "Classification/logits";
 
-int upload_named(asep_gnn* g, const std::map<std::string, HostTensor>& blob, const std::string& name,
+int upload_named(std::vector<void*>& owner, const std::map<std::string, HostTensor>& blob, const std::string& name,
                  std::vector<int> dims, float** d) {
     auto it = blob.find(name);
     if (it == blob.end()) { set_error("weights: missing tensor %s", name.c_str()); return ASEP_ERR_WEIGHTS; }
@@ -62,9 +84,77 @@ int upload_named(asep_gnn* g, const std::map<std::string, HostTensor>& blob, con
     }
     const auto& h = it->second.data;
     ASEP_HIP_CHECK(hipMalloc((void**)d, std::max<size_t>(h.size(), 4) * sizeof(float)));
-    g->owned.push_back(*d);
+    owner.push_back(*d);
     ASEP_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     return ASEP_OK;
+}
+
+template <typename T>
+int upload_vec(asep_gnn* g, const std::vector<T>& v, T** d) {
+    ASEP_HIP_CHECK(hipMalloc((void**)d, std::max<size_t>(v.size(), 4) * sizeof(T)));
+    g->owned.push_back(*d);
+    ASEP_HIP_CHECK(hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return ASEP_OK;
+}
+
+// K axis of the edge MLP permuted into quads of four consecutive features (gnn_kernels.h): fragments + descriptors
+struct Quad { int type, off; };
+
+int pack_step_fragments(asep_gnn* g, const std::map<std::string, HostTensor>& blob, bool big) {
+    const int U = g->U, Ed = g->Ed;
+    const std::string m = MSG;
+    std::vector<Quad> quads;
+    const int uq = (U + 3) / 4;
+    for (int t : {GQ_UI, GQ_UJ, GQ_DU, GQ_DU2})
+        for (int q = 0; q < uq; ++q) quads.push_back({t, 4 * q});
+    if (Ed > 0) quads.push_back({GQ_EF, 0});
+    while (quads.size() % 4) quads.push_back({GQ_ZERO, 0});
+    // H-type quads come as whole chunks: lane group k4 owns h[16c' + 4 k4 ..]
+    for (int t : {GQ_HI, GQ_HJ, GQ_DH, GQ_DH2})
+        for (int c = 0; c < 2; ++c)
+            for (int k4 = 0; k4 < 4; ++k4) quads.push_back({t, big ? 16 * c + 4 * k4 : 16 * c});
+    g->nch = (int)quads.size() / 4;
+    const HostTensor& W1h = blob.find(m + "/fully_connected_layer_h1/weights")->second;            // [K,32]
+    const HostTensor& W2h = blob.find(m + "/fully_connected_logit_layer_out/weights")->second;     // [32,32]
+    auto w1row = [&](const Quad& q, int k4, int r) -> int {              // original row of W1 or -1 (zero)
+        const int hoff = big ? q.off + r : q.off + 4 * k4 + r;
+        switch (q.type) {
+            case GQ_UI: return q.off + r < U ? 0 * U + q.off + r : -1;
+            case GQ_UJ: return q.off + r < U ? 1 * U + q.off + r : -1;
+            case GQ_DU: return q.off + r < U ? 2 * U + q.off + r : -1;
+            case GQ_DU2: return q.off + r < U ? 3 * U + q.off + r : -1;
+            case GQ_EF: return r < Ed ? 4 * U + r : -1;
+            case GQ_HI: return 4 * U + Ed + 0 * 32 + hoff;
+            case GQ_HJ: return 4 * U + Ed + 1 * 32 + hoff;
+            case GQ_DH: return 4 * U + Ed + 2 * 32 + hoff;
+            case GQ_DH2: return 4 * U + Ed + 3 * 32 + hoff;
+            default: return -1;
+        }
+    };
+    std::vector<float> a1((size_t)g->nch * 2 * 64 * 4), a2((size_t)2 * 2 * 64 * 4);
+    const int dstride = big ? 4 : 2;
+    std::vector<unsigned char> qd((size_t)g->nch * 4 * dstride, 0);
+    for (int c = 0; c < g->nch; ++c)
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const Quad& q = quads[c * 4 + k4];
+            qd[(c * 4 + k4) * dstride] = (unsigned char)q.type;
+            qd[(c * 4 + k4) * dstride + 1] = (unsigned char)(big ? q.off / 4 : q.off);
+            for (int mt = 0; mt < 2; ++mt)
+                for (int i = 0; i < 16; ++i)
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = w1row(q, k4, r), lane = k4 * 16 + i;
+                        a1[(((size_t)c * 2 + mt) * 64 + lane) * 4 + r] = row < 0 ? 0.f : W1h.data[(size_t)row * GNN_H + 16 * mt + i];
+                    }
+        }
+    for (int c = 0; c < 2; ++c)
+        for (int mt = 0; mt < 2; ++mt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r)
+                    a2[(((size_t)c * 2 + mt) * 64 + lane) * 4 + r] = W2h.data[(size_t)(16 * c + 4 * (lane >> 4) + r) * GNN_H + 16 * mt + (lane & 15)];
+    int rc = upload_vec(g, a1, &g->A1);
+    if (!rc) rc = upload_vec(g, a2, &g->A2);
+    if (!rc) rc = upload_vec(g, qd, &g->qdesc);
+    return rc;
 }
 
 struct EdgeBufs {
@@ -107,344 +197,100 @@ int forward_impl(asep_gnn* g, int N, int E, const int32_t* d_edges, const float*
     if ((size_t)N * N > (size_t)1 << 30) { set_error("asep_gnn_forward: N=%d too large for the dense edge table", N); return ASEP_ERR_UNSUPPORTED; }
     g->stream = s;
     g->N = N;
-    g->Ecorr = -1;
-    try {
-        g->pool.begin();
-        EdgeBufs eb{};
-        int rc = correct_edges_dev(g, N, E, d_edges, eb, s);
-        if (rc) return rc;
-        const size_t nh = (size_t)N * GNN_H;
-        float* h[2] = {(float*)g->pool.get(nh * 4), (float*)g->pool.get(nh * 4)};
-        float* cs[2] = {(float*)g->pool.get(nh * 4), (float*)g->pool.get(nh * 4)};
-        float* x = (float*)g->pool.get(nh * 4);
-        float* Pt = (float*)g->pool.get((size_t)N * c.cls_hidden1 * 4);
-        float* Qt = (float*)g->pool.get((size_t)N * c.cls_hidden1 * 4);
-        ASEP_HIP_CHECK(hipMemsetAsync(h[0], 0, nh * 4, s));
-        ASEP_HIP_CHECK(hipMemsetAsync(cs[0], 0, nh * 4, s));
-        int cur = 0;
-        for (int t = 0; t < c.num_transition_steps; ++t) {
-            if (g->use_step && g->A1 && g->nch > 0) {
-                StepArgs sa{};
-                sa.u = d_u; sa.h_in = h[cur]; sa.c_in = cs[cur]; sa.ef = d_ef;
-                sa.tptr = eb.colptr; sa.tsrc = eb.tsrc; sa.tfirst = eb.tfirst;
-                sa.A1 = (const gf32x4*)g->A1; sa.A2 = (const gf32x4*)g->A2; sa.b1 = g->b1; sa.b2 = g->b2;
-                for (int q = 0; q < 4; ++q) { sa.Wg[q] = g->Wg[q]; sa.bg[q] = g->bg[q]; }
-                sa.h_out = h[cur ^ 1]; sa.c_out = cs[cur ^ 1];
-                sa.N = N; sa.U = c.node_feature_dim; sa.Ed = c.edge_feature_dim; sa.E = std::max(E, 1); sa.nch = g->nch;
-                sa.qdesc = g->qdesc;
-                hipLaunchKernelGGL(gnn_step_kernel, dim3(N), dim3(256), 0, s, sa);
-                cur ^= 1;
-                continue;
-            }
-            MsgArgs ma{};
+    g->pool.begin();
+    EdgeBufs eb{};
+    int rc = correct_edges_dev(g, N, E, d_edges, eb, s);
+    if (rc) return rc;
+    const int H = g->H, I = g->I;
+    const size_t nh = (size_t)N * H;
+    float* h[2] = {(float*)g->pool.get(nh * 4), (float*)g->pool.get(nh * 4)};
+    float* cs[2] = {(float*)g->pool.get(nh * 4), (float*)g->pool.get(nh * 4)};
+    float* x = (float*)g->pool.get((size_t)N * I * 4);
+    float* Pt = (float*)g->pool.get((size_t)N * c.cls_hidden1 * 4);
+    float* Qt = (float*)g->pool.get((size_t)N * c.cls_hidden1 * 4);
+    float* upad = nullptr;
+    const int mode = g->use_step ? g->mode : STEP_GENERIC;
+    if (mode == STEP_BIG) {
+        upad = (float*)g->pool.get((size_t)N * g->Upad * 4);
+        hipLaunchKernelGGL(gnn_pad_rows_kernel, dim3(cdiv(N * g->Upad, 256)), dim3(256), 0, s, d_u, N, g->U, upad, g->Upad);
+    }
+    ASEP_HIP_CHECK(hipMemsetAsync(h[0], 0, nh * 4, s));
+    ASEP_HIP_CHECK(hipMemsetAsync(cs[0], 0, nh * 4, s));
+    int cur = 0;
+    for (int t = 0; t < c.num_transition_steps; ++t) {
+        if (mode == STEP_SMALL) {
+            StepArgs sa{};
+            sa.u = d_u; sa.h_in = h[cur]; sa.c_in = cs[cur]; sa.ef = d_ef;
+            sa.tptr = eb.colptr; sa.tsrc = eb.tsrc; sa.tfirst = eb.tfirst;
+            sa.A1 = (const gf32x4*)g->A1; sa.A2 = (const gf32x4*)g->A2; sa.b1 = g->b1; sa.b2 = g->b2;
+            for (int q = 0; q < 4; ++q) { sa.Wg[q] = g->Wg[q]; sa.bg[q] = g->bg[q]; }
+            sa.h_out = h[cur ^ 1]; sa.c_out = cs[cur ^ 1];
+            sa.N = N; sa.U = g->U; sa.Ed = g->Ed; sa.E = std::max(E, 1); sa.nch = g->nch;
+            sa.qdesc = g->qdesc;
+            hipLaunchKernelGGL(gnn_step_kernel, dim3(N), dim3(256), 0, s, sa);
+        } else if (mode == STEP_BIG) {
+            StepBigArgs sa{};
+            sa.u = upad; sa.h_in = h[cur]; sa.c_in = cs[cur]; sa.ef = d_ef;
+            sa.tptr = eb.colptr; sa.tsrc = eb.tsrc; sa.tfirst = eb.tfirst;
+            sa.A1 = (const gf32x4*)g->A1; sa.A2 = (const gf32x4*)g->A2; sa.b1 = g->b1; sa.b2 = g->b2;
+            for (int q = 0; q < 4; ++q) { sa.Wg[q] = g->Wg[q]; sa.bg[q] = g->bg[q]; }
+            sa.h_out = h[cur ^ 1]; sa.c_out = cs[cur ^ 1];
+            sa.N = N; sa.U = g->U; sa.Upad = g->Upad; sa.Ed = g->Ed; sa.E = std::max(E, 1); sa.nch = g->nch;
+            sa.qdesc = g->qdesc;
+            hipLaunchKernelGGL(gnn_step_big_kernel, dim3(N), dim3(256), g->big_lds, s, sa);
+        } else {
+            MsgGenArgs ma{};
             ma.u = d_u; ma.h = h[cur]; ma.ef = d_ef; ma.tptr = eb.colptr; ma.tsrc = eb.tsrc; ma.tfirst = eb.tfirst;
             ma.W1 = g->W1; ma.b1 = g->b1; ma.W2 = g->W2; ma.b2 = g->b2; ma.x = x;
-            ma.N = N; ma.U = c.node_feature_dim; ma.Ed = c.edge_feature_dim; ma.E = std::max(E, 1); ma.K = g->K;
-            const size_t lds = ((size_t)g->K * 32 + 32 * 32 + 8 * (size_t)g->K + 8 * 32) * sizeof(float);
-            hipLaunchKernelGGL(gnn_message_kernel, dim3(N), dim3(256), lds, s, ma);
-            LstmArgs la{};
+            ma.N = N; ma.U = g->U; ma.Ed = g->Ed; ma.E = std::max(E, 1); ma.H = H; ma.Hm = g->Hm; ma.I = I;
+            const size_t lds = ((size_t)g->K + g->Hm + I) * sizeof(float);
+            hipLaunchKernelGGL(gnn_message_generic_kernel, dim3(N), dim3(256), lds, s, ma);
+            LstmGenArgs la{};
             la.x = x; la.h_in = h[cur]; la.c_in = cs[cur]; la.u = d_u;
             for (int q = 0; q < 4; ++q) { la.Wg[q] = g->Wg[q]; la.bg[q] = g->bg[q]; }
-            la.h_out = h[cur ^ 1]; la.c_out = cs[cur ^ 1]; la.N = N; la.U = c.node_feature_dim;
-            hipLaunchKernelGGL(gnn_lstm_kernel, dim3(cdiv(N, 8)), dim3(256), 0, s, la);
-            cur ^= 1;
+            la.h_out = h[cur ^ 1]; la.c_out = cs[cur ^ 1]; la.N = N; la.U = g->U; la.H = H; la.I = I;
+            hipLaunchKernelGGL(gnn_lstm_generic_kernel, dim3(cdiv(N * H, 256)), dim3(256), 0, s, la);
         }
-        g->d_h = h[cur];
-        if (R > 0) {
-            hipLaunchKernelGGL(gnn_pair_pre_kernel, dim3(std::min(cdiv(N * c.cls_hidden1, 256), 1024)), dim3(256), 0, s,
-                               h[cur], N, g->C1, c.cls_hidden1, Pt, Qt);
-            PairArgs pa{};
-            pa.Pt = Pt; pa.Qt = Qt; pa.b1 = g->cb1; pa.W2 = g->C2; pa.b2 = g->cb2; pa.W3 = g->C3; pa.b3 = g->cb3;
-            pa.rel = d_rel; pa.out = d_out; pa.N = N; pa.R = R;
-            dim3 grid(cdiv(R, 256));
-            if (c.cls_hidden1 == 64 && c.cls_hidden2 == 32 && c.num_classes == 2)
-                hipLaunchKernelGGL((gnn_pair_cls_kernel<64, 32, 2>), grid, dim3(256), 0, s, pa);
-            else { set_error("classifier %d,%d -> %d not instantiated", c.cls_hidden1, c.cls_hidden2, c.num_classes); return ASEP_ERR_UNSUPPORTED; }
-        }
-        ASEP_HIP_CHECK(hipGetLastError());
-    } catch (const HipError&) {
-        return ASEP_ERR_HIP;
+        cur ^= 1;
     }
-    return ASEP_OK;
-}
-
-}  // namespace
-
-namespace {
-struct DevCopy {
-    std::vector<void*> ptrs;
-    ~DevCopy() { for (void* p : ptrs) if (p) (void)hipFree(p); }
-    template <typename T> int up(const T* h, size_t n, T** d) {
-        *d = nullptr;
-        if (n == 0 || !h) return ASEP_OK;
-        ASEP_HIP_CHECK(hipMalloc((void**)d, n * sizeof(T)));
-        ptrs.push_back(*d);
-        ASEP_HIP_CHECK(hipMemcpy(*d, h, n * sizeof(T), hipMemcpyHostToDevice));
-        return ASEP_OK;
-    }
-    template <typename T> int alloc(size_t n, T** d) {
-        ASEP_HIP_CHECK(hipMalloc((void**)d, std::max<size_t>(n, 1) * sizeof(T)));
-        ptrs.push_back(*d);
-        return ASEP_OK;
-    }
-};
-}  // namespace
-
-extern "C" {
-
-asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_cfg* cfg) {
-    if (!cfg || !weight_blob) { set_error("asep_gnn_load: null argument"); return nullptr; }
-    if (cfg->hidden_dim != GNN_H || cfg->interaction_dim != GNN_H || cfg->interaction_hidden != GNN_H) {
-        set_error("asep_gnn_load: hidden/interaction widths must be %d (got %d/%d/%d)", GNN_H, cfg->hidden_dim,
-                  cfg->interaction_dim, cfg->interaction_hidden);
-        return nullptr;
-    }
-    if (cfg->node_feature_dim < 1 || cfg->edge_feature_dim < 0 || cfg->num_transition_steps < 0) {
-        set_error("asep_gnn_load: bad cfg");
-        return nullptr;
-    }
-    std::map<std::string, HostTensor> blob;
-    if (!parse_blob(weight_blob, nbytes, blob)) return nullptr;
-    std::unique_ptr<asep_gnn> g(new asep_gnn());
-    g->cfg = *cfg;
-    const int U = cfg->node_feature_dim, Ed = cfg->edge_feature_dim;
-    g->K = 4 * U + Ed + 4 * GNN_H;
-    g->V = 2 * GNN_H + U;
-    if (((size_t)g->K * 40 + 32 * 32 + 8 * 32) * 4 > 150 * 1024) { set_error("asep_gnn_load: node feature width %d too large for LDS", U); return nullptr; }
-    const std::string m = MSG, u = UPD, c = CLS;
-    int rc = upload_named(g.get(), blob, m + "/fully_connected_layer_h1/weights", {g->K, GNN_H}, &g->W1);
-    if (!rc) rc = upload_named(g.get(), blob, m + "/fully_connected_layer_h1/bias", {GNN_H}, &g->b1);
-    if (!rc) rc = upload_named(g.get(), blob, m + "/fully_connected_logit_layer_out/weights", {GNN_H, GNN_H}, &g->W2);
-    if (!rc) rc = upload_named(g.get(), blob, m + "/fully_connected_logit_layer_out/bias", {GNN_H}, &g->b2);
-    const char* gates[4] = {"ingate", "outgate", "forgetgate", "cellinput"};
-    for (int q = 0; q < 4 && !rc; ++q) {
-        rc = upload_named(g.get(), blob, u + "/" + gates[q] + "_activation/dense/weights", {g->V, GNN_H}, &g->Wg[q]);
-        if (!rc) rc = upload_named(g.get(), blob, u + "/" + gates[q] + "_activation/dense/bias", {GNN_H}, &g->bg[q]);
-    }
-    if (!rc) rc = upload_named(g.get(), blob, c + "/fully_connected_layer_h1/weights", {2 * GNN_H, cfg->cls_hidden1}, &g->C1);
-    if (!rc) rc = upload_named(g.get(), blob, c + "/fully_connected_layer_h1/bias", {cfg->cls_hidden1}, &g->cb1);
-    if (!rc) rc = upload_named(g.get(), blob, c + "/fully_connected_layer_h2/weights", {cfg->cls_hidden1, cfg->cls_hidden2}, &g->C2);
-    if (!rc) rc = upload_named(g.get(), blob, c + "/fully_connected_layer_h2/bias", {cfg->cls_hidden2}, &g->cb2);
-    if (!rc) rc = upload_named(g.get(), blob, c + "/fully_connected_logit_layer_out/weights", {cfg->cls_hidden2, cfg->num_classes}, &g->C3);
-    if (!rc) rc = upload_named(g.get(), blob, c + "/fully_connected_logit_layer_out/bias", {cfg->num_classes}, &g->cb3);
-    if (rc) return nullptr;
-    for (auto& kv : blob)
-        if (kv.first.rfind("visual_node_feature_compression_fm_", 0) == 0) g->vis_blob[kv.first] = kv.second;
-    if (const char* ev = getenv("ASEP_GNN_STEP")) g->use_step = atoi(ev) != 0;
-    if (U <= 8 && Ed <= 4) {
-        // quads of 4 consecutive features; H-type quads come as whole chunks (lane kk owns h[16c'+4kk ..])
-        struct Quad { int type, off; };
-        std::vector<Quad> quads;
-        const int uq = (U + 3) / 4;
-        for (int t : {GQ_UI, GQ_UJ, GQ_DU, GQ_DU2})
-            for (int q = 0; q < uq; ++q) quads.push_back({t, 4 * q});
-        if (Ed > 0) quads.push_back({GQ_EF, 0});
-        while (quads.size() % 4) quads.push_back({GQ_ZERO, 0});
-        for (int t : {GQ_HI, GQ_HJ, GQ_DH, GQ_DH2})
-            for (int c = 0; c < 2; ++c)
-                for (int k4 = 0; k4 < 4; ++k4) quads.push_back({t, 16 * c});
-        g->nch = (int)quads.size() / 4;
-        if (g->nch <= GNN_MAXCH) {
-            const HostTensor& W1h = blob.find(m + "/fully_connected_layer_h1/weights")->second;   // [K,32]
-            const HostTensor& W2h = blob.find(m + "/fully_connected_logit_layer_out/weights")->second;   // [32,32]
-            auto w1row = [&](const Quad& q, int kk4, int r) -> int {       // original row of W1 or -1 (zero)
-                switch (q.type) {
-                    case GQ_UI: return q.off + r < U ? 0 * U + q.off + r : -1;
-                    case GQ_UJ: return q.off + r < U ? 1 * U + q.off + r : -1;
-                    case GQ_DU: return q.off + r < U ? 2 * U + q.off + r : -1;
-                    case GQ_DU2: return q.off + r < U ? 3 * U + q.off + r : -1;
-                    case GQ_EF: return r < Ed ? 4 * U + r : -1;
-                    case GQ_HI: return 4 * U + Ed + 0 * 32 + q.off + 4 * kk4 + r;
-                    case GQ_HJ: return 4 * U + Ed + 1 * 32 + q.off + 4 * kk4 + r;
-                    case GQ_DH: return 4 * U + Ed + 2 * 32 + q.off + 4 * kk4 + r;
-                    case GQ_DH2: return 4 * U + Ed + 3 * 32 + q.off + 4 * kk4 + r;
-                    default: return -1;
-                }
-            };
-            std::vector<float> a1((size_t)g->nch * 2 * 64 * 4), a2((size_t)2 * 2 * 64 * 4);
-            std::vector<unsigned char> qd((size_t)g->nch * 4 * 2);
-            for (int c = 0; c < g->nch; ++c)
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    const Quad& q = quads[c * 4 + k4];
-                    qd[(c * 4 + k4) * 2] = (unsigned char)q.type;
-                    qd[(c * 4 + k4) * 2 + 1] = (unsigned char)q.off;
-                    for (int mt = 0; mt < 2; ++mt)
-                        for (int i = 0; i < 16; ++i)
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = w1row(q, k4, r), lane = k4 * 16 + i;
-                                a1[(((size_t)c * 2 + mt) * 64 + lane) * 4 + r] = row < 0 ? 0.f : W1h.data[(size_t)row * GNN_H + 16 * mt + i];
-                            }
-                }
-            for (int c = 0; c < 2; ++c)
-                for (int mt = 0; mt < 2; ++mt)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int r = 0; r < 4; ++r)
-                            a2[(((size_t)c * 2 + mt) * 64 + lane) * 4 + r] = W2h.data[(size_t)(16 * c + 4 * (lane >> 4) + r) * GNN_H + 16 * mt + (lane & 15)];
-            if (hipMalloc((void**)&g->A1, a1.size() * 4) != hipSuccess || hipMalloc((void**)&g->A2, a2.size() * 4) != hipSuccess ||
-                hipMalloc((void**)&g->qdesc, qd.size()) != hipSuccess) { set_error("asep_gnn_load: hipMalloc failed"); return nullptr; }
-            g->owned.push_back(g->A1); g->owned.push_back(g->A2); g->owned.push_back(g->qdesc);
-            if (hipMemcpy(g->A1, a1.data(), a1.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(g->A2, a2.data(), a2.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(g->qdesc, qd.data(), qd.size(), hipMemcpyHostToDevice) != hipSuccess) { set_error("asep_gnn_load: upload failed"); return nullptr; }
+    g->d_h = h[cur];
+    if (R > 0) {
+        hipLaunchKernelGGL(gnn_pair_pre_kernel, dim3(std::min(cdiv(N * c.cls_hidden1, 256), 1024)), dim3(256), 0, s,
+                           h[cur], N, H, g->C1, c.cls_hidden1, Pt, Qt);
+        PairArgs pa{};
+        pa.Pt = Pt; pa.Qt = Qt; pa.b1 = g->cb1; pa.W2 = g->C2; pa.b2 = g->cb2; pa.W3 = g->C3; pa.b3 = g->cb3;
+        pa.rel = d_rel; pa.out = d_out; pa.N = N; pa.R = R;
+        dim3 grid(cdiv(R, 256));
+        if (c.cls_hidden1 == 64 && c.cls_hidden2 == 32 && c.num_classes == 2) {
+            hipLaunchKernelGGL((gnn_pair_cls_kernel<64, 32, 2>), grid, dim3(256), 0, s, pa);
         } else {
-            g->nch = 0;
+            PairGenArgs pg{pa, c.cls_hidden1, c.cls_hidden2, c.num_classes};
+            hipLaunchKernelGGL(gnn_pair_cls_generic_kernel, grid, dim3(256), 0, s, pg);
         }
     }
-    // the message kernel needs up to ~50 KB of dynamic LDS
-    const size_t lds = ((size_t)g->K * 32 + 32 * 32 + 8 * (size_t)g->K + 8 * 32) * sizeof(float);
-    if (hipFuncSetAttribute((const void*)gnn_message_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        set_error("asep_gnn_load: cannot reserve %zu bytes of LDS", lds);
-        return nullptr;
-    }
-    return g.release();
+    ASEP_HIP_CHECK(hipGetLastError());
+    return ASEP_OK;
 }
 
-void asep_gnn_free(asep_gnn* g) { delete g; }
-
-int asep_gnn_forward_dev(asep_gnn* g, int N, int E, const int32_t* d_edges, const float* d_node_feat,
-                         const float* d_edge_feat, int R, const int32_t* d_relations, float* d_probs_out, void* stream) {
-    if (!g || !d_node_feat || (E > 0 && !d_edges) || (R > 0 && !d_probs_out)) { set_error("asep_gnn_forward_dev: null argument"); return ASEP_ERR_ARG; }
-    if (g->cfg.edge_feature_dim > 0 && E > 0 && !d_edge_feat) { set_error("asep_gnn_forward_dev: edge features required"); return ASEP_ERR_ARG; }
-    return forward_impl(g, N, E, d_edges, d_node_feat, d_edge_feat, R, d_relations, d_probs_out, (hipStream_t)stream);
-}
-
-
-int asep_gnn_forward(asep_gnn* g, int N, int E, const int32_t* edges, const float* node_feat, const float* edge_feat,
-                     int R, const int32_t* relations, float* probs_out) {
-    if (!g || !node_feat || (E > 0 && !edges) || (R > 0 && !probs_out)) { set_error("asep_gnn_forward: null argument"); return ASEP_ERR_ARG; }
-    if (N < 1 || E < 0 || R < 0) { set_error("asep_gnn_forward: bad sizes N=%d E=%d R=%d", N, E, R); return ASEP_ERR_ARG; }
-    // grow-only device staging in the handle: seven hipMalloc / hipFree pairs per page would cost more than the GNN
-    int32_t *d_e = nullptr, *d_r = nullptr;
-    float *d_u = nullptr, *d_f = nullptr, *d_o = nullptr;
-    const size_t ne = (size_t)E * 2, nu = (size_t)N * g->cfg.node_feature_dim, nf = (size_t)E * g->cfg.edge_feature_dim;
-    const size_t nr = relations ? (size_t)R * 2 : 0, no = (size_t)R * g->cfg.num_classes;
-    try {
-        g->host_stage.begin();
-        d_e = (int32_t*)g->host_stage.get(std::max<size_t>(ne, 1) * sizeof(int32_t));
-        d_u = (float*)g->host_stage.get(std::max<size_t>(nu, 1) * sizeof(float));
-        d_f = (float*)g->host_stage.get(std::max<size_t>(nf, 1) * sizeof(float));
-        d_r = (int32_t*)g->host_stage.get(std::max<size_t>(nr, 1) * sizeof(int32_t));
-        d_o = (float*)g->host_stage.get(std::max<size_t>(no, 1) * sizeof(float));
-    } catch (const HipError&) {
-        return ASEP_ERR_HIP;
+// graph_relation.py:84-139 in front of the graph: backbone, ROI max + compression per feature map, concatenation.
+// d_ug [N, U - visual dims]; everything on stream s; returns the concatenated features [N, U] in *d_u_out.
+int visual_features_dev(asep_gnn* g, int N, const float* d_ug, const float* d_img, int h, int w, const float* d_reg, int P,
+                        const int32_t* d_np, float** d_u_out, hipStream_t s) {
+    const int U = g->U, ug = U - g->vis_total;
+    g->vis_pool.begin();
+    const int ncls = std::max(1, aru_num_classes(g->backbone));
+    float* d_bo = (float*)g->vis_pool.get((size_t)h * w * ncls * sizeof(float));   // backbone logits (not used by the graph)
+    const size_t nu = (size_t)N * U;
+    if (g->u_cat_cap < nu) {
+        if (g->d_u_cat) (void)hipFree(g->d_u_cat);
+        g->d_u_cat = nullptr; g->u_cat_cap = 0;
+        ASEP_HIP_CHECK(hipMalloc((void**)&g->d_u_cat, nu * sizeof(float)));
+        g->u_cat_cap = nu;
     }
-    if (ne) ASEP_HIP_CHECK(hipMemcpyAsync(d_e, edges, ne * sizeof(int32_t), hipMemcpyHostToDevice, nullptr));
-    ASEP_HIP_CHECK(hipMemcpyAsync(d_u, node_feat, nu * sizeof(float), hipMemcpyHostToDevice, nullptr));
-    if (nf && edge_feat) ASEP_HIP_CHECK(hipMemcpyAsync(d_f, edge_feat, nf * sizeof(float), hipMemcpyHostToDevice, nullptr));
-    if (nr) ASEP_HIP_CHECK(hipMemcpyAsync(d_r, relations, nr * sizeof(int32_t), hipMemcpyHostToDevice, nullptr));
-    const int rc = asep_gnn_forward_dev(g, N, E, ne ? d_e : nullptr, d_u, (nf && edge_feat) ? d_f : nullptr, R,
-                                        nr ? d_r : nullptr, d_o, nullptr);
+    float* d_u = g->d_u_cat;
+    int rc = asep_aru_forward_dev(g->backbone, d_img, h, w, d_bo, nullptr, nullptr, 0.f, s);
     if (rc) return rc;
-    if (R > 0) ASEP_HIP_CHECK(hipMemcpyAsync(probs_out, d_o, no * sizeof(float), hipMemcpyDeviceToHost, nullptr));
-    ASEP_HIP_CHECK(hipStreamSynchronize(nullptr));
-    return ASEP_OK;
-}
-
-int asep_gnn_correct_edges(asep_gnn* g, int N, int E, const int32_t* edges, const float* edge_feat, int32_t* out_edges,
-                           float* out_feat) {
-    if (!g || N < 1 || E < 0 || (E > 0 && !edges) || !out_edges) { set_error("asep_gnn_correct_edges: bad argument"); return ASEP_ERR_ARG; }
-    if ((size_t)N * N > (size_t)1 << 30) { set_error("asep_gnn_correct_edges: N too large"); return ASEP_ERR_UNSUPPORTED; }
-    DevCopy dc;
-    int32_t* d_e = nullptr;
-    float* d_f = nullptr;
-    int rc;
-    if ((rc = dc.up(edges, (size_t)E * 2, &d_e))) return rc;
-    const int Ed = g->cfg.edge_feature_dim;
-    if (out_feat && Ed > 0 && (rc = dc.up(edge_feat, (size_t)E * Ed, &d_f))) return rc;
-    try {
-        g->pool.begin();
-        EdgeBufs eb{};
-        rc = correct_edges_dev(g, N, E, d_e, eb, nullptr);
-        if (rc) return rc;
-        int ecorr = 0;
-        ASEP_HIP_CHECK(hipStreamSynchronize(nullptr));
-        ASEP_HIP_CHECK(hipMemcpy(&ecorr, eb.rowptr + N, sizeof(int), hipMemcpyDeviceToHost));
-        if (ecorr > 0) {
-            ASEP_HIP_CHECK(hipMemcpy(out_edges, eb.sorted, (size_t)ecorr * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
-            if (out_feat && Ed > 0 && d_f) {
-                float* d_of = (float*)g->pool.get((size_t)ecorr * Ed * sizeof(float));
-                hipLaunchKernelGGL(edge_feat_gather_kernel, dim3(std::min(cdiv(ecorr * Ed, 256), 1024)), dim3(256), 0, nullptr,
-                                   d_f, E, Ed, eb.sfirst, ecorr, d_of);
-                ASEP_HIP_CHECK(hipMemcpy(out_feat, d_of, (size_t)ecorr * Ed * sizeof(float), hipMemcpyDeviceToHost));
-            }
-        }
-        return ecorr;
-    } catch (const HipError&) {
-        return ASEP_ERR_HIP;
-    }
-}
-
-int asep_gnn_get_hidden(asep_gnn* g, float* out, size_t max_floats) {
-    if (!g || !out || !g->d_h) { set_error("asep_gnn_get_hidden: no forward has run"); return ASEP_ERR_ARG; }
-    const size_t n = (size_t)g->N * GNN_H;
-    if (max_floats < n) { set_error("asep_gnn_get_hidden: buffer too small"); return ASEP_ERR_ARG; }
-    ASEP_HIP_CHECK(hipStreamSynchronize(g->stream));
-    ASEP_HIP_CHECK(hipMemcpy(out, g->d_h, n * sizeof(float), hipMemcpyDeviceToHost));
-    return ASEP_OK;
-}
-
-int asep_gnn_attach_backbone(asep_gnn* g, asep_aru* backbone, int n_maps, const char* const* endpoint_names) {
-    if (!g || !backbone || n_maps < 1 || !endpoint_names) { set_error("asep_gnn_attach_backbone: bad argument"); return ASEP_ERR_ARG; }
-    g->backbone = nullptr;
-    g->vis_names.clear(); g->vis_W.clear(); g->vis_b.clear(); g->vis_C.clear(); g->vis_d.clear();
-    g->vis_total = 0;
-    for (int i = 0; i < n_maps; ++i) {
-        if (!endpoint_names[i]) { set_error("asep_gnn_attach_backbone: null end-point name"); return ASEP_ERR_ARG; }
-        const int C = aru_endpoint_channels(backbone, endpoint_names[i]);
-        if (C < 1 || C > 256) {
-            set_error("asep_gnn_attach_backbone: '%s' is not a feature map of this backbone (only unet conv/deconv "
-                      "end points with layer_depth -1 are supported)", endpoint_names[i]);
-            return ASEP_ERR_UNSUPPORTED;
-        }
-        const std::string scope = "visual_node_feature_compression_fm_" + std::to_string(i) + "/dense/";
-        auto w = g->vis_blob.find(scope + "weights"), b = g->vis_blob.find(scope + "bias");
-        if (w == g->vis_blob.end() || b == g->vis_blob.end()) { set_error("weights: missing tensor %sweights|bias", scope.c_str()); return ASEP_ERR_WEIGHTS; }
-        if (w->second.dims.size() != 2 || w->second.dims[0] != C || b->second.dims.size() != 1 || b->second.dims[0] != w->second.dims[1]) {
-            set_error("weights: %sweights must be [%d, d] with a matching bias", scope.c_str(), C);
-            return ASEP_ERR_WEIGHTS;
-        }
-        float *dW = nullptr, *db = nullptr;
-        int rc = upload_named(g, g->vis_blob, scope + "weights", w->second.dims, &dW);
-        if (!rc) rc = upload_named(g, g->vis_blob, scope + "bias", b->second.dims, &db);
-        if (rc) return rc;
-        g->vis_names.push_back(endpoint_names[i]);
-        g->vis_W.push_back(dW); g->vis_b.push_back(db);
-        g->vis_C.push_back(C); g->vis_d.push_back(w->second.dims[1]);
-        g->vis_total += w->second.dims[1];
-    }
-    if (g->vis_total >= g->cfg.node_feature_dim + 1) {
-        set_error("asep_gnn_attach_backbone: %d visual dims exceed node_feature_dim %d", g->vis_total, g->cfg.node_feature_dim);
-        return ASEP_ERR_ARG;
-    }
-    g->backbone = backbone;
-    return ASEP_OK;
-}
-
-int asep_gnn_forward_visual(asep_gnn* g, int N, int E, const int32_t* edges, const float* node_feat, const float* edge_feat,
-                            const float* image, int h, int w, const float* regions, int P, const int32_t* num_points,
-                            int R, const int32_t* relations, float* probs_out) {
-    if (!g || !g->backbone) { set_error("asep_gnn_forward_visual: no backbone attached"); return ASEP_ERR_ARG; }
-    const int U = g->cfg.node_feature_dim, ug = U - g->vis_total;
-    if (N < 1 || h < 1 || w < 1 || P < 1 || !image || !regions || !num_points || (ug > 0 && !node_feat) || (E > 0 && !edges) ||
-        (R > 0 && !probs_out)) { set_error("asep_gnn_forward_visual: bad argument"); return ASEP_ERR_ARG; }
-    DevCopy dc;
-    int32_t *d_e = nullptr, *d_r = nullptr, *d_np = nullptr;
-    float *d_ug = nullptr, *d_f = nullptr, *d_o = nullptr, *d_img = nullptr, *d_reg = nullptr, *d_u = nullptr, *d_bo = nullptr;
-    int rc;
-    if ((rc = dc.up(edges, (size_t)E * 2, &d_e))) return rc;
-    if ((rc = dc.up(node_feat, (size_t)N * ug, &d_ug))) return rc;
-    if ((rc = dc.up(edge_feat, (size_t)E * g->cfg.edge_feature_dim, &d_f))) return rc;
-    if ((rc = dc.up(relations, (size_t)R * 2, &d_r))) return rc;
-    if ((rc = dc.up(image, (size_t)h * w, &d_img))) return rc;
-    if ((rc = dc.up(regions, (size_t)N * 2 * P, &d_reg))) return rc;
-    if ((rc = dc.up(num_points, (size_t)N, &d_np))) return rc;
-    if ((rc = dc.alloc((size_t)R * g->cfg.num_classes, &d_o))) return rc;
-    if ((rc = dc.alloc((size_t)N * U, &d_u))) return rc;
-    if ((rc = dc.alloc((size_t)h * w * 8, &d_bo))) return rc;          // backbone logits (unused by this path)
-    // backbone forward (per-image standardisation happens inside when the model was loaded with mvn)
-    rc = asep_aru_forward_dev(g->backbone, d_img, h, w, d_bo, nullptr, nullptr, 0.f, nullptr);
-    if (rc) return rc;
-    if (ug > 0) hipLaunchKernelGGL(gnn_copy_cols_kernel, dim3(cdiv(N * ug, 256)), dim3(256), 0, nullptr, d_ug, N, ug, d_u, U);
+    if (ug > 0) hipLaunchKernelGGL(gnn_copy_cols_kernel, dim3(cdiv(N * ug, 256)), dim3(256), 0, s, d_ug, N, ug, d_u, U);
     int col = ug;
     for (size_t i = 0; i < g->vis_names.size(); ++i) {
         const float* fm = nullptr;
@@ -455,36 +301,290 @@ int asep_gnn_forward_visual(asep_gnn* g, int N, int E, const int32_t* edges, con
         a.fm = fm; a.fh = dims[0]; a.fw = dims[1]; a.C = dims[2];
         a.regions = d_reg; a.P = P; a.npts = d_np; a.Wc = g->vis_W[i]; a.bc = g->vis_b[i]; a.d = g->vis_d[i];
         a.u_out = d_u; a.ustride = U; a.col0 = col; a.vmax_out = nullptr;
-        hipLaunchKernelGGL(gnn_roi_compress_kernel, dim3(N), dim3(256), 0, nullptr, a);
+        hipLaunchKernelGGL(gnn_roi_compress_kernel, dim3(N), dim3(256), 0, s, a);
         col += g->vis_d[i];
     }
     ASEP_HIP_CHECK(hipGetLastError());
-    rc = asep_gnn_forward_dev(g, N, E, d_e, d_u, d_f, R, d_r, d_o, nullptr);
-    if (rc) return rc;
-    ASEP_HIP_CHECK(hipStreamSynchronize(nullptr));
-    if (R > 0) ASEP_HIP_CHECK(hipMemcpy(probs_out, d_o, (size_t)R * g->cfg.num_classes * sizeof(float), hipMemcpyDeviceToHost));
-    // keep the concatenated features readable for asep_gnn_get_node_features
-    try {
-        g->d_u_cat = (float*)g->pool.get((size_t)N * U * sizeof(float));
-    } catch (const HipError&) { return ASEP_ERR_HIP; }
-    ASEP_HIP_CHECK(hipMemcpy(g->d_u_cat, d_u, (size_t)N * U * sizeof(float), hipMemcpyDeviceToDevice));
+    *d_u_out = d_u;
     return ASEP_OK;
 }
 
+// host-side checks of the index arrays (the reference's tf.gather would raise on them)
+int check_indices(const char* what, const int32_t* idx, size_t n_pairs, int N) {
+    for (size_t i = 0; i < 2 * n_pairs; ++i)
+        if (idx[i] < 0 || idx[i] >= N) {
+            set_error("%s[%zu] = (%d, %d) names a node outside 0..%d", what, i / 2, idx[i & ~(size_t)1], idx[i | 1], N - 1);
+            return ASEP_ERR_ARG;
+        }
+    return ASEP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_cfg* cfg) {
+    ASEP_GUARD_BEGIN
+    if (!cfg || !weight_blob) { set_error("asep_gnn_load: null argument"); return nullptr; }
+    if (cfg->node_feature_dim < 1 || cfg->edge_feature_dim < 0 || cfg->num_transition_steps < 0 || cfg->hidden_dim < 1 ||
+        cfg->interaction_dim < 1 || cfg->interaction_hidden < 1 || cfg->cls_hidden1 < 1 || cfg->cls_hidden2 < 1 ||
+        cfg->num_classes < 1 || cfg->num_classes > 16) {
+        set_error("asep_gnn_load: bad cfg");
+        return nullptr;
+    }
+    std::map<std::string, HostTensor> blob;
+    if (!parse_blob(weight_blob, nbytes, blob)) return nullptr;
+    std::unique_ptr<asep_gnn> g(new asep_gnn());
+    g->cfg = *cfg;
+    const int U = g->U = cfg->node_feature_dim, Ed = g->Ed = cfg->edge_feature_dim;
+    const int H = g->H = cfg->hidden_dim, I = g->I = cfg->interaction_dim, Hm = g->Hm = cfg->interaction_hidden;
+    g->K = 4 * U + Ed + 4 * H;
+    g->V = I + H + U;
+    if (((size_t)g->K + Hm + I) * sizeof(float) > 60 * 1024) { set_error("asep_gnn_load: edge-MLP input width %d too large", g->K); return nullptr; }
+    const std::string m = MSG, u = UPD, c = CLS;
+    int rc = upload_named(g->owned, blob, m + "/fully_connected_layer_h1/weights", {g->K, Hm}, &g->W1);
+    if (!rc) rc = upload_named(g->owned, blob, m + "/fully_connected_layer_h1/bias", {Hm}, &g->b1);
+    if (!rc) rc = upload_named(g->owned, blob, m + "/fully_connected_logit_layer_out/weights", {Hm, I}, &g->W2);
+    if (!rc) rc = upload_named(g->owned, blob, m + "/fully_connected_logit_layer_out/bias", {I}, &g->b2);
+    const char* gates[4] = {"ingate", "outgate", "forgetgate", "cellinput"};
+    for (int q = 0; q < 4 && !rc; ++q) {
+        rc = upload_named(g->owned, blob, u + "/" + gates[q] + "_activation/dense/weights", {g->V, H}, &g->Wg[q]);
+        if (!rc) rc = upload_named(g->owned, blob, u + "/" + gates[q] + "_activation/dense/bias", {H}, &g->bg[q]);
+    }
+    if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_layer_h1/weights", {2 * H, cfg->cls_hidden1}, &g->C1);
+    if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_layer_h1/bias", {cfg->cls_hidden1}, &g->cb1);
+    if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_layer_h2/weights", {cfg->cls_hidden1, cfg->cls_hidden2}, &g->C2);
+    if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_layer_h2/bias", {cfg->cls_hidden2}, &g->cb2);
+    if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_logit_layer_out/weights", {cfg->cls_hidden2, cfg->num_classes}, &g->C3);
+    if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_logit_layer_out/bias", {cfg->num_classes}, &g->cb3);
+    if (rc) return nullptr;
+    for (auto& kv : blob)
+        if (kv.first.rfind("visual_node_feature_compression_fm_", 0) == 0) g->vis_blob[kv.first] = kv.second;
+    if (const char* ev = getenv("ASEP_GNN_STEP")) g->use_step = atoi(ev) != 0;
+    const bool default_widths = H == GNN_H && I == GNN_H && Hm == GNN_H;
+    g->mode = STEP_GENERIC;
+    if (default_widths && Ed <= 4) {
+        if (U <= 8) {
+            if (pack_step_fragments(g.get(), blob, false)) return nullptr;
+            if (g->nch <= GNN_MAXCH) g->mode = STEP_SMALL;
+        }
+        if (g->mode == STEP_GENERIC && U <= 120) {
+            g->Upad = (U + 3) & ~3;
+            if (pack_step_fragments(g.get(), blob, true)) return nullptr;
+            g->big_lds = ((size_t)g->nch * 512 + g->Upad + 32) * sizeof(float);
+            if (g->big_lds <= 150 * 1024 &&
+                hipFuncSetAttribute((const void*)gnn_step_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->big_lds) == hipSuccess)
+                g->mode = STEP_BIG;
+        }
+    }
+    const size_t lds = ((size_t)g->K + Hm + I) * sizeof(float);
+    if (hipFuncSetAttribute((const void*)gnn_message_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        set_error("asep_gnn_load: cannot reserve %zu bytes of LDS", lds);
+        return nullptr;
+    }
+    return g.release();
+    ASEP_GUARD_END_PTR
+}
+
+void asep_gnn_free(asep_gnn* g) { delete g; }
+
+int asep_gnn_forward_dev(asep_gnn* g, int N, int E, const int32_t* d_edges, const float* d_node_feat,
+                         const float* d_edge_feat, int R, const int32_t* d_relations, float* d_probs_out, void* stream) {
+    ASEP_GUARD_BEGIN
+    if (!g || !d_node_feat || (E > 0 && !d_edges) || (R > 0 && !d_probs_out)) { set_error("asep_gnn_forward_dev: null argument"); return ASEP_ERR_ARG; }
+    if (g->cfg.edge_feature_dim > 0 && E > 0 && !d_edge_feat) { set_error("asep_gnn_forward_dev: edge features required"); return ASEP_ERR_ARG; }
+    return forward_impl(g, N, E, d_edges, d_node_feat, d_edge_feat, R, d_relations, d_probs_out, (hipStream_t)stream);
+    ASEP_GUARD_END
+}
+
+int asep_gnn_forward(asep_gnn* g, int N, int E, const int32_t* edges, const float* node_feat, const float* edge_feat,
+                     int R, const int32_t* relations, float* probs_out) {
+    ASEP_GUARD_BEGIN
+    if (!g || !node_feat || (E > 0 && !edges) || (R > 0 && !probs_out)) { set_error("asep_gnn_forward: null argument"); return ASEP_ERR_ARG; }
+    if (N < 1 || E < 0 || R < 0) { set_error("asep_gnn_forward: bad sizes N=%d E=%d R=%d", N, E, R); return ASEP_ERR_ARG; }
+    int rc;
+    if (E > 0 && (rc = check_indices("interacting_nodes", edges, (size_t)E, N))) return rc;
+    if (relations && R > 0 && (rc = check_indices("relations", relations, (size_t)R, N))) return rc;
+    // grow-only device staging in the handle: seven hipMalloc / hipFree pairs per page would cost more than the GNN
+    const size_t ne = (size_t)E * 2, nu = (size_t)N * g->U, nf = (size_t)E * g->Ed;
+    const size_t nr = relations ? (size_t)R * 2 : 0, no = (size_t)R * g->cfg.num_classes;
+    g->host_stage.begin();
+    int32_t* d_e = (int32_t*)g->host_stage.get(std::max<size_t>(ne, 1) * sizeof(int32_t));
+    float* d_u = (float*)g->host_stage.get(std::max<size_t>(nu, 1) * sizeof(float));
+    float* d_f = (float*)g->host_stage.get(std::max<size_t>(nf, 1) * sizeof(float));
+    int32_t* d_r = (int32_t*)g->host_stage.get(std::max<size_t>(nr, 1) * sizeof(int32_t));
+    float* d_o = (float*)g->host_stage.get(std::max<size_t>(no, 1) * sizeof(float));
+    if (ne) ASEP_HIP_CHECK(hipMemcpyAsync(d_e, edges, ne * sizeof(int32_t), hipMemcpyHostToDevice, nullptr));
+    ASEP_HIP_CHECK(hipMemcpyAsync(d_u, node_feat, nu * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    if (nf && edge_feat) ASEP_HIP_CHECK(hipMemcpyAsync(d_f, edge_feat, nf * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    if (nr) ASEP_HIP_CHECK(hipMemcpyAsync(d_r, relations, nr * sizeof(int32_t), hipMemcpyHostToDevice, nullptr));
+    rc = asep_gnn_forward_dev(g, N, E, ne ? d_e : nullptr, d_u, (nf && edge_feat) ? d_f : nullptr, R,
+                              nr ? d_r : nullptr, d_o, nullptr);
+    if (rc) return rc;
+    if (R > 0) ASEP_HIP_CHECK(hipMemcpyAsync(probs_out, d_o, no * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    ASEP_HIP_CHECK(hipStreamSynchronize(nullptr));
+    return ASEP_OK;
+    ASEP_GUARD_END
+}
+
+int asep_gnn_correct_edges(asep_gnn* g, int N, int E, const int32_t* edges, const float* edge_feat, int32_t* out_edges,
+                           float* out_feat) {
+    ASEP_GUARD_BEGIN
+    if (!g || N < 1 || E < 0 || (E > 0 && !edges) || !out_edges) { set_error("asep_gnn_correct_edges: bad argument"); return ASEP_ERR_ARG; }
+    if ((size_t)N * N > (size_t)1 << 30) { set_error("asep_gnn_correct_edges: N too large"); return ASEP_ERR_UNSUPPORTED; }
+    const int Ed = g->Ed;
+    const bool feats = out_feat && Ed > 0 && edge_feat;
+    g->host_stage.begin();
+    int32_t* d_e = (int32_t*)g->host_stage.get(std::max<size_t>((size_t)E * 2, 1) * sizeof(int32_t));
+    float* d_f = (float*)g->host_stage.get(std::max<size_t>(feats ? (size_t)E * Ed : 0, 1) * sizeof(float));
+    float* d_of = (float*)g->host_stage.get(std::max<size_t>(feats ? (size_t)E * 2 * Ed : 0, 1) * sizeof(float));
+    if (E > 0) ASEP_HIP_CHECK(hipMemcpy(d_e, edges, (size_t)E * 2 * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (feats && E > 0) ASEP_HIP_CHECK(hipMemcpy(d_f, edge_feat, (size_t)E * Ed * sizeof(float), hipMemcpyHostToDevice));
+    g->pool.begin();
+    EdgeBufs eb{};
+    int rc = correct_edges_dev(g, N, E, d_e, eb, nullptr);
+    if (rc) return rc;
+    int ecorr = 0;
+    ASEP_HIP_CHECK(hipStreamSynchronize(nullptr));
+    ASEP_HIP_CHECK(hipMemcpy(&ecorr, eb.rowptr + N, sizeof(int), hipMemcpyDeviceToHost));
+    if (ecorr > 0) {
+        ASEP_HIP_CHECK(hipMemcpy(out_edges, eb.sorted, (size_t)ecorr * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (feats) {
+            hipLaunchKernelGGL(edge_feat_gather_kernel, dim3(std::min(cdiv(ecorr * Ed, 256), 1024)), dim3(256), 0, nullptr,
+                               d_f, E, Ed, eb.sfirst, ecorr, d_of);
+            ASEP_HIP_CHECK(hipMemcpy(out_feat, d_of, (size_t)ecorr * Ed * sizeof(float), hipMemcpyDeviceToHost));
+        }
+    }
+    return ecorr;
+    ASEP_GUARD_END
+}
+
+int asep_gnn_get_hidden(asep_gnn* g, float* out, size_t max_floats) {
+    ASEP_GUARD_BEGIN
+    if (!g || !out || !g->d_h) { set_error("asep_gnn_get_hidden: no forward has run"); return ASEP_ERR_ARG; }
+    const size_t n = (size_t)g->N * g->H;
+    if (max_floats < n) { set_error("asep_gnn_get_hidden: buffer too small"); return ASEP_ERR_ARG; }
+    ASEP_HIP_CHECK(hipStreamSynchronize(g->stream));
+    ASEP_HIP_CHECK(hipMemcpy(out, g->d_h, n * sizeof(float), hipMemcpyDeviceToHost));
+    return ASEP_OK;
+    ASEP_GUARD_END
+}
+
+int asep_gnn_step_mode(const asep_gnn* g) { return g ? (g->use_step ? g->mode : STEP_GENERIC) : ASEP_ERR_ARG; }
+
+int asep_gnn_attach_backbone(asep_gnn* g, asep_aru* backbone, int n_maps, const char* const* endpoint_names) {
+    ASEP_GUARD_BEGIN
+    if (!g || !backbone || n_maps < 1 || !endpoint_names) { set_error("asep_gnn_attach_backbone: bad argument"); return ASEP_ERR_ARG; }
+    g->free_visual();                                   // a second attach replaces (and frees) the first one's uploads
+    for (int i = 0; i < n_maps; ++i) {
+        if (!endpoint_names[i]) { set_error("asep_gnn_attach_backbone: null end-point name"); g->free_visual(); return ASEP_ERR_ARG; }
+        const int C = aru_endpoint_channels(backbone, endpoint_names[i]);
+        if (C < 1 || C > 256) {
+            set_error("asep_gnn_attach_backbone: '%s' is not a feature map of this backbone (only unet conv/deconv "
+                      "end points with layer_depth -1 are supported)", endpoint_names[i]);
+            g->free_visual();
+            return ASEP_ERR_UNSUPPORTED;
+        }
+        const std::string scope = "visual_node_feature_compression_fm_" + std::to_string(i) + "/dense/";
+        auto w = g->vis_blob.find(scope + "weights"), b = g->vis_blob.find(scope + "bias");
+        if (w == g->vis_blob.end() || b == g->vis_blob.end()) { set_error("weights: missing tensor %sweights|bias", scope.c_str()); g->free_visual(); return ASEP_ERR_WEIGHTS; }
+        if (w->second.dims.size() != 2 || w->second.dims[0] != C || b->second.dims.size() != 1 || b->second.dims[0] != w->second.dims[1]) {
+            set_error("weights: %sweights must be [%d, d] with a matching bias", scope.c_str(), C);
+            g->free_visual();
+            return ASEP_ERR_WEIGHTS;
+        }
+        float *dW = nullptr, *db = nullptr;
+        int rc = upload_named(g->vis_owned, g->vis_blob, scope + "weights", w->second.dims, &dW);
+        if (!rc) rc = upload_named(g->vis_owned, g->vis_blob, scope + "bias", b->second.dims, &db);
+        if (rc) { g->free_visual(); return rc; }
+        g->vis_names.push_back(endpoint_names[i]);
+        g->vis_W.push_back(dW); g->vis_b.push_back(db);
+        g->vis_C.push_back(C); g->vis_d.push_back(w->second.dims[1]);
+        g->vis_total += w->second.dims[1];
+    }
+    if (g->vis_total >= g->U + 1) {
+        set_error("asep_gnn_attach_backbone: %d visual dims exceed node_feature_dim %d", g->vis_total, g->U);
+        g->free_visual();
+        return ASEP_ERR_ARG;
+    }
+    g->backbone = backbone;
+    return ASEP_OK;
+    ASEP_GUARD_END
+}
+
+int asep_gnn_forward_visual_dev(asep_gnn* g, int N, int E, const int32_t* d_edges, const float* d_node_feat,
+                                const float* d_edge_feat, const float* d_image, int h, int w, const float* d_regions, int P,
+                                const int32_t* d_num_points, int R, const int32_t* d_relations, float* d_probs_out,
+                                void* stream) {
+    ASEP_GUARD_BEGIN
+    if (!g || !g->backbone) { set_error("asep_gnn_forward_visual_dev: no backbone attached"); return ASEP_ERR_ARG; }
+    const int ug = g->U - g->vis_total;
+    if (N < 1 || h < 1 || w < 1 || P < 1 || !d_image || !d_regions || !d_num_points || (ug > 0 && !d_node_feat) ||
+        (E > 0 && !d_edges) || (R > 0 && !d_probs_out) || (g->Ed > 0 && E > 0 && !d_edge_feat)) {
+        set_error("asep_gnn_forward_visual_dev: bad argument");
+        return ASEP_ERR_ARG;
+    }
+    float* d_u = nullptr;
+    int rc = visual_features_dev(g, N, d_node_feat, d_image, h, w, d_regions, P, d_num_points, &d_u, (hipStream_t)stream);
+    if (rc) return rc;
+    return forward_impl(g, N, E, d_edges, d_u, d_edge_feat, R, d_relations, d_probs_out, (hipStream_t)stream);
+    ASEP_GUARD_END
+}
+
+int asep_gnn_forward_visual(asep_gnn* g, int N, int E, const int32_t* edges, const float* node_feat, const float* edge_feat,
+                            const float* image, int h, int w, const float* regions, int P, const int32_t* num_points,
+                            int R, const int32_t* relations, float* probs_out) {
+    ASEP_GUARD_BEGIN
+    if (!g || !g->backbone) { set_error("asep_gnn_forward_visual: no backbone attached"); return ASEP_ERR_ARG; }
+    const int U = g->U, ug = U - g->vis_total;
+    if (N < 1 || E < 0 || R < 0 || h < 1 || w < 1 || P < 1 || !image || !regions || !num_points || (ug > 0 && !node_feat) ||
+        (E > 0 && !edges) || (R > 0 && !probs_out)) { set_error("asep_gnn_forward_visual: bad argument"); return ASEP_ERR_ARG; }
+    int rc;
+    if (E > 0 && (rc = check_indices("interacting_nodes", edges, (size_t)E, N))) return rc;
+    if (relations && R > 0 && (rc = check_indices("relations", relations, (size_t)R, N))) return rc;
+    const size_t ne = (size_t)E * 2, nug = (size_t)N * ug, nf = edge_feat ? (size_t)E * g->Ed : 0;
+    const size_t nr = relations ? (size_t)R * 2 : 0, no = (size_t)R * g->cfg.num_classes, ni = (size_t)h * w;
+    const size_t nreg = (size_t)N * 2 * P;
+    auto up = [&](const void* src, size_t bytes) -> void* {          // grow-only staging + async copy on the null stream
+        void* d = g->host_stage.get(std::max<size_t>(bytes, 4));
+        if (bytes && src) ASEP_HIP_CHECK_THROW(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, nullptr));
+        return d;
+    };
+    g->host_stage.begin();
+    int32_t* d_e = (int32_t*)up(edges, ne * 4);
+    float* d_ug = (float*)up(node_feat, nug * 4);
+    float* d_f = (float*)up(edge_feat, nf * 4);
+    int32_t* d_r = (int32_t*)up(relations, nr * 4);
+    float* d_img = (float*)up(image, ni * 4);
+    float* d_reg = (float*)up(regions, nreg * 4);
+    int32_t* d_np = (int32_t*)up(num_points, (size_t)N * 4);
+    float* d_o = (float*)up(nullptr, no * 4);
+    rc = asep_gnn_forward_visual_dev(g, N, E, ne ? d_e : nullptr, nug ? d_ug : nullptr, nf ? d_f : nullptr, d_img, h, w, d_reg,
+                                     P, d_np, R, nr ? d_r : nullptr, d_o, nullptr);
+    if (rc) return rc;
+    if (R > 0) ASEP_HIP_CHECK(hipMemcpyAsync(probs_out, d_o, no * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    ASEP_HIP_CHECK(hipStreamSynchronize(nullptr));
+    return ASEP_OK;
+    ASEP_GUARD_END
+}
+
 int asep_gnn_get_node_features(asep_gnn* g, float* out, size_t max_floats) {
+    ASEP_GUARD_BEGIN
     if (!g || !out || !g->d_u_cat) { set_error("asep_gnn_get_node_features: no visual forward has run"); return ASEP_ERR_ARG; }
-    const size_t n = (size_t)g->N * g->cfg.node_feature_dim;
+    const size_t n = (size_t)g->N * g->U;
     if (max_floats < n) { set_error("asep_gnn_get_node_features: buffer too small"); return ASEP_ERR_ARG; }
+    ASEP_HIP_CHECK(hipStreamSynchronize(g->stream));
     ASEP_HIP_CHECK(hipMemcpy(out, g->d_u_cat, n * sizeof(float), hipMemcpyDeviceToHost));
     return ASEP_OK;
+    ASEP_GUARD_END
 }
 
 double asep_gnn_flops(const asep_gnn* g, int N, int E_corrected, int R) {
     if (!g) return 0.0;
     const asep_gnn_cfg& c = g->cfg;
     double mac = (double)c.num_transition_steps *
-                 ((double)E_corrected * ((double)g->K * GNN_H + GNN_H * GNN_H) + (double)N * 4.0 * g->V * GNN_H);
-    mac += (double)R * ((double)2 * GNN_H * c.cls_hidden1 + (double)c.cls_hidden1 * c.cls_hidden2 +
+                 ((double)E_corrected * ((double)g->K * g->Hm + (double)g->Hm * g->I) + (double)N * 4.0 * g->V * g->H);
+    mac += (double)R * ((double)2 * g->H * c.cls_hidden1 + (double)c.cls_hidden1 * c.cls_hidden2 +
                         (double)c.cls_hidden2 * c.num_classes);
     return 2.0 * mac;
 }

@@ -345,6 +345,255 @@ __global__ __launch_bounds__(256) void gnn_step_kernel(const StepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same fused step for WIDE node features (visual branch: 7 geometric + 3 x 16 visual = 55 features, K = 350;
+// graph_relation.py:84-139).  W1's A fragments no longer fit the register file (23 chunks x 2 m-tiles x 4 VGPRs), so
+// they are staged once per workgroup in LDS ([nch][2][64 lanes] x 16 B = 46 KB at U = 55) and read one chunk ahead of
+// their MFMAs; a quad of z is built from ONE 16-byte load of the source node's row (rows are padded to a multiple of
+// four floats, u_pad) and one LDS read of the target's row instead of from register copies of whole rows.
+// Quad descriptor (4 bytes): kind (GQ_*), offset / 4 inside the row, unused, unused.
+// ------------------------------------------------------------------------------------------------
+struct StepBigArgs {
+    const float* u;        // [N, Upad] zero-padded node features
+    const float* h_in; const float* c_in; const float* ef;
+    const int* tptr; const int* tsrc; const int* tfirst;
+    const gf32x4* A1; const gf32x4* A2;
+    const float* b1; const float* b2;
+    const float* Wg[4]; const float* bg[4];
+    float* h_out; float* c_out;
+    int N, U, Upad, Ed, E, nch;
+    const unsigned char* qdesc;    // [nch*4][4]
+};
+
+__global__ __launch_bounds__(256) void gnn_step_big_kernel(const StepBigArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm_big[];
+    gf32x4* A1s = reinterpret_cast<gf32x4*>(sm_big);                   // [nch][2][64]
+    float* trow = sm_big + (size_t)a.nch * 2 * 64 * 4;                  // target row: [Upad] u | [32] h
+    __shared__ float xs[4][32];
+    __shared__ float gs[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int tgt = blockIdx.x;
+    const int beg = a.tptr[tgt], end = a.tptr[tgt + 1];
+    const int Upad = a.Upad, Ed = a.Ed, nch = a.nch;
+    const int ntiles = (end - beg + 15) >> 4;
+    if (ntiles > 0)
+        for (int i = tid; i < nch * 128; i += 256) A1s[i] = a.A1[i];
+    for (int i = tid; i < Upad; i += 256) trow[i] = a.u[(size_t)tgt * Upad + i];
+    if (tid < 32) trow[Upad + tid] = a.h_in[(size_t)tgt * 32 + tid];
+    __syncthreads();
+
+    gf32x4 xacc[2] = {gf32x4{0.f, 0.f, 0.f, 0.f}, gf32x4{0.f, 0.f, 0.f, 0.f}};
+    if (wave < ntiles) {
+        gf32x4 A2[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { A2[c][0] = a.A2[(c * 2 + 0) * 64 + lane]; A2[c][1] = a.A2[(c * 2 + 1) * 64 + lane]; }
+        const gf32x4 b1v[2] = {*reinterpret_cast<const gf32x4*>(a.b1 + kk * 4), *reinterpret_cast<const gf32x4*>(a.b1 + 16 + kk * 4)};
+        const gf32x4 b2v[2] = {*reinterpret_cast<const gf32x4*>(a.b2 + kk * 4), *reinterpret_cast<const gf32x4*>(a.b2 + 16 + kk * 4)};
+        const uchar4* qd = reinterpret_cast<const uchar4*>(a.qdesc);
+        for (int t = wave; t < ntiles; t += 4) {
+            const int e = beg + t * 16 + j;
+            const bool valid = e < end;
+            const int ec = valid ? e : beg;
+            const int src = a.tsrc[ec];
+            const int fi = a.tfirst[ec] % a.E;
+            const float* urow = a.u + (size_t)src * Upad;
+            const float* hrow = a.h_in + (size_t)src * 32;
+            gf32x4 efv = gf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q < Ed) efv[q] = a.ef[(size_t)fi * Ed + q];
+            // quad fetch: source-side piece from global (L1 / L2), target-side piece from the LDS row
+            auto fetch = [&](int c, gf32x4& x0, gf32x4& x1, int& kind) {
+                const uchar4 d = qd[c * 4 + kk];
+                kind = d.x;
+                const int off = 4 * (int)d.y;
+                const bool is_h = kind >= GQ_HI;
+                const float* p0 = is_h ? hrow + off : urow + off;
+                x0 = (kind == GQ_ZERO || kind == GQ_EF) ? efv : *reinterpret_cast<const gf32x4*>(p0);
+                x1 = *reinterpret_cast<const gf32x4*>(trow + (is_h ? Upad + off : ((kind == GQ_ZERO || kind == GQ_EF) ? 0 : off)));
+            };
+            gf32x4 acc1[2] = {gf32x4{0.f, 0.f, 0.f, 0.f}, gf32x4{0.f, 0.f, 0.f, 0.f}};
+            gf32x4 x0, x1, a0, a1;
+            int kind;
+            fetch(0, x0, x1, kind);
+            a0 = A1s[lane]; a1 = A1s[64 + lane];
+#pragma unroll 1
+            for (int c = 0; c < nch; ++c) {
+                gf32x4 nx0 = x0, nx1 = x1, na0 = a0, na1 = a1;
+                int nkind = kind;
+                if (c + 1 < nch) {                                    // next chunk's operands fly under this chunk's MFMAs
+                    fetch(c + 1, nx0, nx1, nkind);
+                    na0 = A1s[(c + 1) * 128 + lane]; na1 = A1s[(c + 1) * 128 + 64 + lane];
+                }
+                const gf32x4 dd = x1 - x0;
+                const int role = kind == GQ_EF ? 0 : (kind >= GQ_HI ? kind - GQ_HI : kind - GQ_UI);   // 0 i, 1 j, 2 d, 3 d^2
+                gf32x4 z = role == 0 ? x0 : (role == 1 ? x1 : (role == 2 ? dd : dd * dd));
+                if (kind == GQ_ZERO) z = gf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r], z[r], acc1[0], 0, 0, 0);
+                    acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r], z[r], acc1[1], 0, 0, 0);
+                }
+                x0 = nx0; x1 = nx1; a0 = na0; a1 = na1; kind = nkind;
+            }
+            gf32x4 hid[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                hid[m] = acc1[m] + b1v[m];
+                hid[m].x = fmaxf(hid[m].x, 0.f); hid[m].y = fmaxf(hid[m].y, 0.f); hid[m].z = fmaxf(hid[m].z, 0.f); hid[m].w = fmaxf(hid[m].w, 0.f);
+            }
+            gf32x4 acc2[2] = {gf32x4{0.f, 0.f, 0.f, 0.f}, gf32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[c][0][r], hid[c][r], acc2[0], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[c][1][r], hid[c][r], acc2[1], 0, 0, 0);
+                }
+            if (valid) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const gf32x4 v = acc2[m] + b2v[m];
+                    xacc[m].x += tanhf(v.x); xacc[m].y += tanhf(v.y); xacc[m].z += tanhf(v.z); xacc[m].w += tanhf(v.w);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = xacc[m][r];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (j == 0) xs[wave][16 * m + 4 * kk + r] = v;
+        }
+    __syncthreads();
+    // v = [x (32) | h (32) | u (U)] for the LSTM gates: x into the A1 area (free now), h / u are in trow
+    float* xv = sm_big;
+    if (tid < 32) {
+        const int deg = end - beg;
+        const float s = xs[0][tid] + xs[1][tid] + xs[2][tid] + xs[3][tid];
+        xv[tid] = deg > 0 ? s / (float)deg : 0.f;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int q = tid >> 5, o = tid & 31;
+        const float* Wq = a.Wg[q];
+        float g = a.bg[q][o];
+        for (int k = 0; k < 32; ++k) g = fmaf(xv[k], Wq[k * 32 + o], g);
+        for (int k = 0; k < 32; ++k) g = fmaf(trow[Upad + k], Wq[(32 + k) * 32 + o], g);
+        for (int k = 0; k < a.U; ++k) g = fmaf(trow[k], Wq[(64 + k) * 32 + o], g);
+        gs[q][o] = g;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const float ig = gsig(gs[0][tid]), og = gsig(gs[1][tid]), fg = gsig(gs[2][tid]), cg = tanhf(gs[3][tid]);
+        const float c = fg * a.c_in[(size_t)tgt * 32 + tid] + ig * cg;
+        a.c_out[(size_t)tgt * 32 + tid] = c;
+        a.h_out[(size_t)tgt * 32 + tid] = og * tanhf(c);
+    }
+}
+
+// zero-padded copy of the node features: [N, U] -> [N, Upad]
+__global__ __launch_bounds__(256) void gnn_pad_rows_kernel(const float* __restrict__ src, int N, int U, float* __restrict__ dst, int Upad) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * Upad) return;
+    const int n = i / Upad, k = i - n * Upad;
+    dst[i] = k < U ? src[(size_t)n * U + k] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic-width fallbacks (hidden_node_feature_dim / interaction_feature_dim / hidden layer of the edge MLP other
+// than 32; message_fn_chunk.py:13-40): plain FMA loops, one workgroup per target node / node.  Correct for any
+// width; the MFMA kernels above are the path for the reference's default widths.
+// ------------------------------------------------------------------------------------------------
+struct MsgGenArgs {
+    const float* u; const float* h; const float* ef;
+    const int* tptr; const int* tsrc; const int* tfirst;
+    const float* W1; const float* b1;   // [K, Hm], [Hm]
+    const float* W2; const float* b2;   // [Hm, I], [I]
+    float* x;                           // [N, I]
+    int N, U, Ed, E, H, Hm, I;
+};
+
+__global__ __launch_bounds__(256) void gnn_message_generic_kernel(const MsgGenArgs a) {
+    extern __shared__ float smg[];
+    const int K = 4 * a.U + a.Ed + 4 * a.H;
+    float* z = smg;                 // K
+    float* hid = z + K;             // Hm
+    float* acc = hid + a.Hm;        // I
+    const int tid = threadIdx.x, tgt = blockIdx.x;
+    const int beg = a.tptr[tgt], end = a.tptr[tgt + 1];
+    for (int o = tid; o < a.I; o += 256) acc[o] = 0.f;
+    const float* uj = a.u + (size_t)tgt * a.U;
+    const float* hj = a.h + (size_t)tgt * a.H;
+    for (int e = beg; e < end; ++e) {
+        const int i = a.tsrc[e];
+        const float* ui = a.u + (size_t)i * a.U;
+        const float* hi = a.h + (size_t)i * a.H;
+        const float* efr = a.ef + (size_t)(a.tfirst[e] % a.E) * a.Ed;
+        __syncthreads();
+        for (int k = tid; k < a.U; k += 256) {
+            const float vi = ui[k], vj = uj[k], d = vj - vi;
+            z[k] = vi; z[a.U + k] = vj; z[2 * a.U + k] = d; z[3 * a.U + k] = d * d;
+        }
+        for (int k = tid; k < a.Ed; k += 256) z[4 * a.U + k] = efr[k];
+        for (int k = tid; k < a.H; k += 256) {
+            const float vi = hi[k], vj = hj[k], d = vj - vi;
+            float* zh = z + 4 * a.U + a.Ed;
+            zh[k] = vi; zh[a.H + k] = vj; zh[2 * a.H + k] = d; zh[3 * a.H + k] = d * d;
+        }
+        __syncthreads();
+        for (int o = tid; o < a.Hm; o += 256) {
+            float s = a.b1[o];
+            for (int k = 0; k < K; ++k) s = fmaf(z[k], a.W1[(size_t)k * a.Hm + o], s);
+            hid[o] = fmaxf(s, 0.f);
+        }
+        __syncthreads();
+        for (int o = tid; o < a.I; o += 256) {
+            float s = a.b2[o];
+            for (int k = 0; k < a.Hm; ++k) s = fmaf(hid[k], a.W2[(size_t)k * a.I + o], s);
+            acc[o] += tanhf(s);
+        }
+    }
+    __syncthreads();
+    const int deg = end - beg;
+    for (int o = tid; o < a.I; o += 256) a.x[(size_t)tgt * a.I + o] = deg > 0 ? acc[o] / (float)deg : 0.f;
+}
+
+struct LstmGenArgs {
+    const float* x; const float* h_in; const float* c_in; const float* u;
+    const float* Wg[4]; const float* bg[4];     // [I + H + U, H], [H]
+    float* h_out; float* c_out;
+    int N, U, H, I;
+};
+
+__global__ __launch_bounds__(256) void gnn_lstm_generic_kernel(const LstmGenArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.N * a.H) return;
+    const int node = idx / a.H, o = idx - node * a.H;
+    float g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] = a.bg[q][o];
+    const float* xr = a.x + (size_t)node * a.I;
+    const float* hr = a.h_in + (size_t)node * a.H;
+    const float* ur = a.u + (size_t)node * a.U;
+    for (int k = 0; k < a.I; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = fmaf(xr[k], a.Wg[q][(size_t)k * a.H + o], g[q]);
+    for (int k = 0; k < a.H; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = fmaf(hr[k], a.Wg[q][(size_t)(a.I + k) * a.H + o], g[q]);
+    for (int k = 0; k < a.U; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = fmaf(ur[k], a.Wg[q][(size_t)(a.I + a.H + k) * a.H + o], g[q]);
+    const float ig = gsig(g[0]), og = gsig(g[1]), fg = gsig(g[2]), cg = tanhf(g[3]);
+    const float c = fg * a.c_in[idx] + ig * cg;
+    a.c_out[idx] = c;
+    a.h_out[idx] = og * tanhf(c);
+}
+
+// ------------------------------------------------------------------------------------------------
 // LSTM update (update_fn_lstm.py:55-76): v = [x, h, u]; four dense gates; c = f*c + i*g; h = o*tanh(c)
 // one thread per (node, unit); gate order in Wg/bg: ingate, outgate, forgetgate, cellinput
 // ------------------------------------------------------------------------------------------------
@@ -393,15 +642,15 @@ __global__ __launch_bounds__(256) void gnn_lstm_kernel(const LstmArgs a) {
 // the concatenation, so it is evaluated once per node:  P[a] = h_a . W1[0:32],  Q[b] = h_b . W1[32:64]
 // (stored transposed [H1][N] for coalesced per-pair reads); per pair: relu(P+Q+b1) -> H2 -> classes.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gnn_pair_pre_kernel(const float* __restrict__ h, int N, const float* __restrict__ W1,
+__global__ __launch_bounds__(256) void gnn_pair_pre_kernel(const float* __restrict__ h, int N, int H, const float* __restrict__ W1,
                                                            int H1, float* __restrict__ Pt, float* __restrict__ Qt) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < N * H1; i += gridDim.x * 256) {
         const int n = i % N, k = i / N;
         float p = 0.f, q = 0.f;
-        for (int d = 0; d < 32; ++d) {
-            const float hv = h[(size_t)n * 32 + d];
+        for (int d = 0; d < H; ++d) {
+            const float hv = h[(size_t)n * H + d];
             p = fmaf(hv, W1[d * H1 + k], p);
-            q = fmaf(hv, W1[(32 + d) * H1 + k], q);
+            q = fmaf(hv, W1[(H + d) * H1 + k], q);
         }
         Pt[(size_t)k * N + n] = p;
         Qt[(size_t)k * N + n] = q;
@@ -435,6 +684,11 @@ __global__ __launch_bounds__(256) void gnn_pair_cls_kernel(const PairArgs a) {
     int na, nb;
     if (a.rel) { na = a.rel[2 * r]; nb = a.rel[2 * r + 1]; }
     else { na = r / a.N; nb = r - na * a.N; }
+    if ((unsigned)na >= (unsigned)a.N || (unsigned)nb >= (unsigned)a.N) {      // a pair that names no node: visible, not UB
+#pragma unroll
+        for (int c = 0; c < NC; ++c) a.out[(size_t)r * NC + c] = __builtin_nanf("");
+        return;
+    }
     float acc[H2];
 #pragma unroll
     for (int k = 0; k < H2; ++k) acc[k] = b2s[k];
@@ -460,6 +714,42 @@ __global__ __launch_bounds__(256) void gnn_pair_cls_kernel(const PairArgs a) {
     for (int c = 0; c < NC; ++c) { lg[c] = expf(lg[c] - mx); den += lg[c]; }
 #pragma unroll
     for (int c = 0; c < NC; ++c) a.out[(size_t)r * NC + c] = lg[c] / den;
+}
+
+// any classifier widths (trainer_rel.py:17 num_hidden_units is a free parameter): one thread per pair, the second
+// layer recomputes the first layer's activations per output unit (L1-resident P / Q columns) -- a fallback
+struct PairGenArgs {
+    PairArgs p;
+    int H1, H2, NC;
+};
+
+__global__ __launch_bounds__(256) void gnn_pair_cls_generic_kernel(const PairGenArgs g) {
+    const PairArgs& a = g.p;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.R) return;
+    int na, nb;
+    if (a.rel) { na = a.rel[2 * r]; nb = a.rel[2 * r + 1]; }
+    else { na = r / a.N; nb = r - na * a.N; }
+    float lg[16];
+    if ((unsigned)na >= (unsigned)a.N || (unsigned)nb >= (unsigned)a.N) {
+        for (int c = 0; c < g.NC; ++c) a.out[(size_t)r * g.NC + c] = __builtin_nanf("");
+        return;
+    }
+    for (int c = 0; c < g.NC; ++c) lg[c] = a.b3[c];
+    for (int k = 0; k < g.H2; ++k) {
+        float s = a.b2[k];
+        for (int d = 0; d < g.H1; ++d) {
+            const float v = fmaxf(a.Pt[(size_t)d * a.N + na] + a.Qt[(size_t)d * a.N + nb] + a.b1[d], 0.f);
+            s = fmaf(v, a.W2[(size_t)d * g.H2 + k], s);
+        }
+        s = fmaxf(s, 0.f);
+        for (int c = 0; c < g.NC; ++c) lg[c] = fmaf(s, a.W3[(size_t)k * g.NC + c], lg[c]);
+    }
+    float mx = lg[0];
+    for (int c = 1; c < g.NC; ++c) mx = fmaxf(mx, lg[c]);
+    float den = 0.f;
+    for (int c = 0; c < g.NC; ++c) { lg[c] = expf(lg[c] - mx); den += lg[c]; }
+    for (int c = 0; c < g.NC; ++c) a.out[(size_t)r * g.NC + c] = lg[c] / den;
 }
 
 

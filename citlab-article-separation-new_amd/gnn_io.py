@@ -233,6 +233,26 @@ def gnn_forward_visual(graph: GnnGraph, num_nodes, edges, node_feat, edge_feat, 
     return out
 
 
+def gnn_forward_visual_dev(graph: GnnGraph, num_nodes, num_edges, d_edges, d_node_feat, d_edge_feat, d_image, h, w, d_regions,
+                           num_region_points, d_num_points, num_relations, d_relations, d_probs_out, stream=None, device=0):
+    """``asep_gnn_forward_visual_dev``: every array is a device address (int), nothing is synchronised -- the call returns
+    once backbone, ROI kernels and the graph are queued on ``stream`` (a hipStream_t handle as int, None = null stream)."""
+    lib = _lib.init_device(device)
+    rc = lib.asep_gnn_forward_visual_dev(graph.handle(device), int(num_nodes), int(num_edges), d_edges, d_node_feat,
+                                         d_edge_feat, d_image, int(h), int(w), d_regions, int(num_region_points),
+                                         d_num_points, int(num_relations), d_relations, d_probs_out, stream)
+    _lib.check(rc, "asep_gnn_forward_visual_dev")
+
+
+STEP_MODES = {0: "generic", 1: "mfma_registers", 2: "mfma_lds"}
+
+
+def step_mode(graph: GnnGraph, device=0) -> str:
+    """which message-passing kernel the engine picked for this model (include/asep_hip.h asep_gnn_step_mode)"""
+    lib = _lib.init_device(device)
+    return STEP_MODES[_lib.check(lib.asep_gnn_step_mode(graph.handle(device)), "asep_gnn_step_mode")]
+
+
 def gnn_node_features(graph: GnnGraph, num_nodes, device=0):
     """Concatenated [geometric | visual] node features of the last visual forward (tests)."""
     lib = _lib.init_device(device)

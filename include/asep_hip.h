@@ -105,12 +105,12 @@ typedef struct asep_gnn_cfg {
     int32_t node_feature_dim;      /* u (after masking), e.g. 7 */
     int32_t edge_feature_dim;      /* e, e.g. 2 */
     int32_t num_transition_steps;  /* 3 */
-    int32_t hidden_dim;            /* 32 */
+    int32_t hidden_dim;            /* 32 (any width; the fused MFMA kernels serve 32/32/32) */
     int32_t interaction_dim;       /* 32 */
     int32_t interaction_hidden;    /* one hidden layer of this width (32) */
-    int32_t cls_hidden1;           /* 64 */
+    int32_t cls_hidden1;           /* 64 (any widths; 64,32 -> 2 has a specialised kernel) */
     int32_t cls_hidden2;           /* 32 */
-    int32_t num_classes;           /* 2 */
+    int32_t num_classes;           /* 2 (<= 16) */
     int32_t undirected_graph;      /* 1 */
 } asep_gnn_cfg;
 
@@ -154,7 +154,20 @@ int asep_gnn_forward_visual(asep_gnn* g, int N, int E, const int32_t* edges, con
                             const float* edge_feat, const float* image, int h, int w, const float* regions, int P,
                             const int32_t* num_points, int R, const int32_t* relations, float* probs_out);
 
-/* Concatenated node features [N, node_feature_dim] of the last asep_gnn_forward_visual (tests). */
+/* The same with every array already in HBM (image [h,w] float32 included), launched on `stream` without any host
+ * synchronisation: backbone, ROI kernels and the graph are queued back to back.  Index arrays are not validated here:
+ * an edge that names a node outside 0..N-1 is ignored, a relation that does yields NaN probabilities. */
+int asep_gnn_forward_visual_dev(asep_gnn* g, int N, int E, const int32_t* d_edges, const float* d_node_feat,
+                                const float* d_edge_feat, const float* d_image, int h, int w, const float* d_regions,
+                                int P, const int32_t* d_num_points, int R, const int32_t* d_relations,
+                                float* d_probs_out, void* stream);
+
+/* Which message-passing kernel the handle uses: 0 = generic FMA kernels (any widths), 1 = fused MFMA step with the
+ * edge-MLP filter in registers (widths 32, node_feature_dim <= 8), 2 = fused MFMA step with the filter in LDS (widths 32,
+ * node_feature_dim <= 120: the visual nets). */
+int asep_gnn_step_mode(const asep_gnn* g);
+
+/* Concatenated node features [N, node_feature_dim] of the last asep_gnn_forward_visual[_dev] (tests). */
 int asep_gnn_get_node_features(asep_gnn* g, float* out, size_t max_floats);
 
 /* ---- classical image stages around the ARU-Net ---------------------

@@ -132,3 +132,50 @@ def test_permutation_equivariance():
     p1 = gnn_io.gnn_forward(graph, N, edges2, u2, g["edge_features"])[:, 1].reshape(N, N)
     assert float(np.abs(p1 - p0[np.ix_(perm, perm)]).max()) <= 2e-5
     graph.close()
+
+
+@pytest.mark.parametrize("kw,mode", [
+    (dict(), "mfma_registers"),
+    (dict(node_feature_dim=20), "mfma_lds"),                                   # wide node features without an image
+    (dict(node_feature_dim=55, edge_feature_dim=4), "mfma_lds"),
+    (dict(node_feature_dim=9, edge_feature_dim=0), "mfma_lds"),
+    (dict(hidden_dim=16, interaction_dim=24, interaction_hidden=[40]), "generic"),
+    (dict(hidden_dim=48, interaction_dim=32, interaction_hidden=[32], edge_feature_dim=5), "generic"),
+    (dict(classifier_hidden=[48, 20], num_classes=3), "mfma_registers"),      # generic pair classifier
+])
+def test_hyper_parameters_other_than_the_defaults(kw, mode):
+    """message_fn_chunk.py:13-40, trainer_rel.py:15-17: every width is a free parameter of the reference; the engine picks
+    the fused MFMA step where the widths allow it and plain FMA kernels elsewhere -- all against the oracle."""
+    from citlab_article_separation_new_amd import gnn_io
+    from oracle import gnn_oracle
+    cfg, w, graph = _setup(seed=17, **kw)
+    assert gnn_io.step_mode(graph) == mode
+    rng = np.random.default_rng(len(str(kw)))
+    N, E = 60, 500
+    edges, u, ef = _random_graph(rng, N, E, node_dim=cfg.node_feature_dim, edge_dim=max(cfg.edge_feature_dim, 1))
+    ef = ef if cfg.edge_feature_dim else None
+    probs = gnn_io.gnn_forward(graph, N, edges, u, ef)
+    ref, href = gnn_oracle.forward(N, edges, u, ef, None, w, cfg, return_hidden=True)
+    h = gnn_io.gnn_hidden(graph, N)
+    assert h.shape == href.shape and float(np.abs(h - href).max()) <= PROB_TOL
+    assert probs.shape == (N * N, cfg.num_classes) and float(np.abs(probs - ref).max()) <= PROB_TOL
+    graph.close()
+
+
+def test_index_arrays_are_validated_at_the_host_entry():
+    """the reference's gather ops raise on an index outside the node range; so does the host entry (the device entry
+    documents what it does instead: edge ignored, NaN for the relation)"""
+    from citlab_article_separation_new_amd import _lib, gnn_io
+    cfg, w, graph = _setup()
+    rng = np.random.default_rng(1)
+    edges, u, ef = _random_graph(rng, 10, 20)
+    bad = edges.copy()
+    bad[7, 1] = 10
+    with pytest.raises(_lib.AsepError, match="interacting_nodes"):
+        gnn_io.gnn_forward(graph, 10, bad, u, ef)
+    rel = np.array([[0, 1], [2, -1]], np.int32)
+    with pytest.raises(_lib.AsepError, match="relations"):
+        gnn_io.gnn_forward(graph, 10, edges, u, ef, rel)
+    ok = gnn_io.gnn_forward(graph, 10, edges, u, ef, np.array([[0, 1], [9, 9]], np.int32))
+    assert ok.shape == (2, 2) and np.isfinite(ok).all()
+    graph.close()
