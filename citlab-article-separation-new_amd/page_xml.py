@@ -9,6 +9,7 @@ written back in place, so untouched content of the file survives a round trip.
 
 ``custom`` attribute grammar: ``name {key:value; key:value;} name2 {...}`` (``page_util.py:5-21``).
 """
+import copy
 import datetime
 import re
 import xml.etree.ElementTree as ET
@@ -60,6 +61,18 @@ def format_points(pts):
     return " ".join("%d,%d" % (int(x), int(y)) for x, y in pts)
 
 
+class Word:
+    """page_objects.py:447-550 (subset): id, surrounding polygon, text"""
+
+    def __init__(self, node, page):
+        self.node = node
+        self.id = node.get("id")
+        self.custom = parse_custom_attr(node.get("custom"))
+        coords = node.find(page._q("Coords"))
+        self.surr_p = parse_points(coords.get("points")) if coords is not None else []
+        self.text = page._text_equiv(node)
+
+
 class TextLine:
     def __init__(self, node, page):
         self.node = node
@@ -71,6 +84,25 @@ class TextLine:
         bl = node.find(page._q("Baseline"))
         self.baseline = parse_points(bl.get("points")) if bl is not None else []
         self.text = page._text_equiv(node)
+        self.words = [Word(n, page) for n in node.findall(page._q("Word"))]
+
+    def split_copy(self, new_id, points, baseline, words, text):
+        """A new TextLine (own DOM node, not yet attached) that carries this line's attributes and custom tags with another
+        outline: what ``_create_page_objects`` + ``set_points`` / ``set_baseline`` produce in
+        separator_region_to_page_writer.py:133-143.  Children are written in schema order (page_objects.py:317-353):
+        Coords, Baseline, Word*, TextEquiv."""
+        q = self._page._q
+        node = ET.Element(self.node.tag, dict(self.node.attrib))
+        node.set("id", new_id)
+        ET.SubElement(node, q("Coords"), {"points": format_points(points)})
+        if baseline:
+            ET.SubElement(node, q("Baseline"), {"points": format_points(baseline)})
+        for w in words:
+            node.append(copy.deepcopy(w.node))
+        if text is not None:
+            te = ET.SubElement(node, q("TextEquiv"))
+            ET.SubElement(te, q("Unicode")).text = text
+        return TextLine(node, self._page)
 
     def get_article_id(self):
         st = self.custom.get("structure", {})
@@ -139,6 +171,29 @@ class TextRegion(Region):
             self.node.set("type", self.region_type)
         for tl in self.text_lines:
             tl.flush()
+
+    def replace_text_lines(self, text_lines):
+        """The region's TextLine children become exactly ``text_lines`` (kept lines stay where they are, new ones take
+        the place of the first removed line or go behind the last line): page.py:682-700 with overwrite=True."""
+        q = self._page._q("TextLine")
+        old = [n for n in self.node if n.tag == q]
+        keep = {id(tl.node) for tl in text_lines}
+        pos = None
+        for n in old:
+            if id(n) not in keep:
+                if pos is None:
+                    pos = list(self.node).index(n)
+                self.node.remove(n)
+        if pos is None:
+            pos = (list(self.node).index(old[-1]) + 1) if old else len(self.node)
+        present = {id(n) for n in self.node}
+        for tl in text_lines:
+            if id(tl.node) not in present:
+                self.node.insert(pos, tl.node)
+                pos += 1
+            else:
+                pos = max(pos, list(self.node).index(tl.node) + 1)
+        self.text_lines = list(text_lines)
 
 
 class SeparatorRegion(Region):

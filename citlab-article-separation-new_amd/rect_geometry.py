@@ -243,7 +243,8 @@ def clip_polyline_outside(points, region):
     pieces = []
     for n, (k, a, b) in enumerate(subs):
         (x0, y0), (x1, y1) = pts[k], pts[k + 1]
-        at = lambda t: pts[k] if t == 0.0 else (pts[k + 1] if t == 1.0 else (x0 + (x1 - x0) * t, y0 + (y1 - y0) * t))
+        at = lambda t: pts[k] if t == 0.0 else (pts[k + 1] if t == 1.0 else
+                                                (_snap(x0 + (x1 - x0) * t, region.xs), _snap(y0 + (y1 - y0) * t, region.ys)))
         joins = n > 0 and subs[n - 1][0] == k - 1 and subs[n - 1][2] == 1.0 and a == 0.0
         if joins:
             pieces[-1].append(at(b))
@@ -258,6 +259,15 @@ def clip_polyline_outside(points, region):
         if len(dedup) > 1:
             out.append(dedup)
     return out
+
+
+def _snap(v, grid):
+    """a cut lies on a grid line of the region: undo the rounding of ``p0 + (p1 - p0) * t``"""
+    k = int(np.searchsorted(grid, v))
+    for c in (k - 1, k):
+        if 0 <= c < len(grid) and abs(grid[c] - v) <= 1e-9 * max(1.0, abs(v)):
+            return float(grid[c])
+    return v
 
 
 def polyline_touches(points, region):

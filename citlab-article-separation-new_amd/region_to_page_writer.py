@@ -3,16 +3,21 @@
     RegionToPageWriter             region_to_page_writer.py:13-46
     SeparatorRegionToPageWriter    separator_region_to_page_writer.py:11-25,107-386
 
-Deviation (documented in DESIGN.md): ``merge_regions`` adds the separator regions but does not split the text lines
-a vertical separator runs through -- the reference does that with shapely's polygon difference, and shapely/GEOS is
-not available to this build.  Polygons with holes are written by their exterior ring (the reference additionally
-cuts a polygon at holes larger than 1000 px^2, ``:329-337``).
+``merge_regions`` does what the reference does with shapely, for the rectilinear case (``rect_geometry.py``; no GEOS in
+this build): text lines that a VERTICAL separator runs through are cut into the parts left and right of it (``:156-227``),
+words and text follow the part they overlap most, the baseline is cut with the line and parts without a baseline piece
+are dropped; separator polygons with holes larger than 1000 px^2 are cut at the holes (``:30-70,329-337``).  A text line
+whose outline is not rectilinear is left as it is (logged) -- the one deviation, it needs a general polygon clipper.
+Where GEOS' output order is an implementation detail (parts of a MultiPolygon, ring start vertex) parts are ordered left
+to right and rings start at their top-left corner, running clockwise on screen.
 """
+import logging
 import os
 
 from .image_io import get_image_dimensions
 from .net_post_processing_helper import get_scaling_factor
 from .page_xml import Page
+from .rect_geometry import Region, clip_polyline_outside, cut_at_holes, is_rectilinear, polyline_touches
 
 SEPARATOR_REGION = "SeparatorRegion"
 
@@ -54,15 +59,102 @@ class SeparatorRegionToPageWriter(RegionToPageWriter):
     def remove_separator_regions_from_page(self):
         self.page_object.remove_regions(SEPARATOR_REGION)
 
+    # -- text lines vs. vertical separators (separator_region_to_page_writer.py:156-227) --------------------------
+    @staticmethod
+    def _split_text_lines(lines, separator_rings):
+        """``lines``: the current parts of ONE original text line; returns the parts after cutting at one separator."""
+        sep = Region.from_rings(separator_rings)
+        if sep.is_empty():
+            return lines
+        out = []
+        for line in lines:
+            if not is_rectilinear(line.surr_p):
+                logging.warning("text line %s is not rectilinear: not cut at vertical separators", line.id)
+                out.append(line)
+                continue
+            outline = Region.from_rings([line.surr_p])
+            if sep.contains(outline):                        # swallowed by the separator: the line disappears (:172-174)
+                continue
+            if not outline.overlaps(sep):
+                out.append(line)
+                continue
+            parts = outline.difference(sep).polygons()
+            part_regions = [Region.from_rings(p) for p in parts]
+            words = [[] for _ in parts]
+            if len(parts) != 1:
+                for word in line.words:                      # a word goes to the part it overlaps most (:190-197)
+                    wreg = Region.from_rings([word.surr_p]) if is_rectilinear(word.surr_p) else \
+                        Region.box(*_bbox(word.surr_p))
+                    areas = [wreg.intersection(pr).area for pr in part_regions]
+                    words[max(range(len(parts)), key=lambda k: areas[k])].append(word)
+            else:
+                words[0] = list(line.words)
+            # baseline pieces -> the first part they run through; parts without a piece are dropped (:203-224)
+            pieces = clip_polyline_outside(line.baseline, sep) if line.baseline else []
+            owner = {}
+            for piece in pieces:
+                for k, pr in enumerate(part_regions):
+                    if k not in owner and _polyline_in(piece, pr):
+                        owner[k] = piece
+                        break
+            if not line.baseline:
+                owner = {k: None for k in range(len(parts))}  # (the reference reads an unset variable here: kept all)
+            for k in sorted(owner):
+                text = line.text
+                if len(parts) != 1 and line.words:
+                    text = " ".join(w.text for w in words[k])
+                new_id = line.id if len(parts) == 1 else f"{line.id}_{k + 1}"
+                out.append(line.split_copy(new_id, parts[k][0], owner[k], words[k], text))
+        return out
+
     def merge_regions(self, remove_holes=True):
-        """:359-386 order: plain, horizontal, vertical; every polygon becomes one SeparatorRegion whose custom tag
-        carries the orientation."""
+        """:359-386 order: plain, horizontal, vertical separators; vertical ones first cut the text lines they cross;
+        every polygon (cut at its large holes) becomes one SeparatorRegion whose custom tag carries the orientation."""
         for separator_type in (SEPARATOR_REGION, SEPARATOR_REGION + "_horizontal", SEPARATOR_REGION + "_vertical"):
             polygons = self.region_dict.get(separator_type)
             if polygons is None:
                 continue
+            polygons = [_as_rings(p) for p in polygons]
             orientation = separator_type[len(SEPARATOR_REGION) + 1:] or None
-            for polygon in polygons:
-                rings = polygon if (polygon and isinstance(polygon[0], (list, tuple))
-                                    and polygon[0] and isinstance(polygon[0][0], (list, tuple))) else [polygon]
-                self.page_object.add_separator_region(rings[0], orientation)
+            if orientation == "vertical":
+                for region in self.page_object.get_text_regions():
+                    if not region.text_lines:
+                        continue
+                    parts_of = {id(tl): [tl] for tl in region.text_lines}
+                    for rings in polygons:
+                        if not rings or not all(is_rectilinear(r) for r in rings):
+                            continue
+                        for key in parts_of:
+                            parts_of[key] = self._split_text_lines(parts_of[key], rings)
+                    final = [tl for tl0 in region.text_lines for tl in parts_of[id(tl0)]]
+                    if [id(t) for t in final] != [id(t) for t in region.text_lines]:
+                        region.replace_text_lines(final)
+            for rings in polygons:
+                if not rings:
+                    continue
+                if remove_holes and len(rings) > 1 and all(is_rectilinear(r) for r in rings):
+                    for exterior in cut_at_holes(rings, min_hole_area=1000):
+                        self.page_object.add_separator_region(exterior, orientation)
+                else:
+                    self.page_object.add_separator_region(rings[0], orientation)
+
+
+def _as_rings(polygon):
+    """a polygon is a list of rings (exterior first) or, for convenience, a bare ring"""
+    if polygon and isinstance(polygon[0], (list, tuple)) and polygon[0] and isinstance(polygon[0][0], (list, tuple)):
+        return [list(r) for r in polygon]
+    return [list(polygon)]
+
+
+def _bbox(points):
+    xs, ys = [p[0] for p in points], [p[1] for p in points]
+    return min(xs), min(ys), max(xs), max(ys)
+
+
+def _polyline_in(points, region):
+    """does the poly-line touch the (closed) region?  -- ``intersects`` of :109-113"""
+    if polyline_touches(points, region):
+        return True
+    x0, y0, x1, y1 = region.bounds() if not region.is_empty() else (0, 0, -1, -1)
+    rects = region.rectangles()
+    return any(rx0 <= px <= rx1 and ry0 <= py <= ry1 for px, py in points for rx0, ry0, rx1, ry1 in rects)

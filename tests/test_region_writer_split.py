@@ -1,0 +1,163 @@
+"""separator_region_to_page_writer.py:107-227,329-337 without GEOS: text lines cut at vertical separators, separator
+polygons cut at large holes.  Expected PAGE-XML content is derived by hand for axis-parallel cases (what shapely's
+``difference`` / ``intersection`` give there is unambiguous up to ring start / part order, which are normalised:
+rings start top-left and run clockwise on screen, parts go left to right)."""
+import numpy as np
+import pytest
+
+from citlab_article_separation_new_amd import rect_geometry as rg
+from citlab_article_separation_new_amd.page_xml import Page
+from citlab_article_separation_new_amd.region_to_page_writer import SeparatorRegionToPageWriter
+
+PAGE = """<?xml version="1.0" encoding="UTF-8"?>
+<PcGts xmlns="http://schema.primaresearch.org/PAGE/gts/pagecontent/2013-07-15">
+  <Metadata><Creator>t</Creator><Created>2020-01-01T00:00:00</Created><LastChange>2020-01-01T00:00:00</LastChange></Metadata>
+  <Page imageFilename="img.png" imageWidth="400" imageHeight="300">
+    <TextRegion id="r1" type="paragraph"><Coords points="5,5 210,5 210,260 5,260"/>
+      <TextLine id="A" custom="readingOrder {index:0;} structure {id:a1; type:article;}"><Coords points="10,10 200,10 200,40 10,40"/>
+        <Baseline points="10,35 200,35"/>
+        <Word id="w1"><Coords points="10,10 90,10 90,40 10,40"/><TextEquiv><Unicode>Hello</Unicode></TextEquiv></Word>
+        <Word id="w2"><Coords points="110,10 200,10 200,40 110,40"/><TextEquiv><Unicode>World</Unicode></TextEquiv></Word>
+        <TextEquiv><Unicode>Hello World</Unicode></TextEquiv></TextLine>
+      <TextLine id="B"><Coords points="10,50 90,50 90,80 10,80"/><Baseline points="10,75 90,75"/>
+        <TextEquiv><Unicode>left only</Unicode></TextEquiv></TextLine>
+      <TextLine id="C"><Coords points="99,90 101,90 101,120 99,120"/><Baseline points="99,118 101,118"/></TextLine>
+      <TextLine id="D"><Coords points="10,130 200,130 200,150 120,150 120,170 10,170"/><Baseline points="10,165 120,165 200,145"/>
+        <TextEquiv><Unicode>no words here</Unicode></TextEquiv></TextLine>
+      <TextLine id="E"><Coords points="10,180 200,185 200,215 10,210"/><Baseline points="10,205 200,210"/></TextLine>
+      <TextLine id="F"><Coords points="102,220 200,220 200,250 102,250"/><Baseline points="102,245 200,245"/></TextLine>
+      <TextEquiv><Unicode>region text</Unicode></TextEquiv>
+    </TextRegion>
+    <TextRegion id="r2"><Coords points="220,5 390,5 390,100 220,100"/>
+      <TextLine id="G"><Coords points="230,10 380,10 380,40 230,40"/><Baseline points="230,35 380,35"/></TextLine>
+    </TextRegion>
+    <SeparatorRegion id="SeparatorRegion_7"><Coords points="1,1 5,1 5,5 1,5"/></SeparatorRegion>
+  </Page>
+</PcGts>
+"""
+
+VSEP = [(98, 0), (102, 0), (102, 300), (98, 300), (98, 0)]                    # x in [98, 102]
+HSEP_HOLE = [[(220, 120), (320, 120), (320, 220), (220, 220), (220, 120)],       # 100 x 100 ring
+             [(240, 140), (240, 190), (280, 190), (280, 140), (240, 140)]]       # hole 40 x 50 = 2000 px^2
+HSEP_SMALL = [[(220, 230), (320, 230), (320, 260), (220, 260), (220, 230)],
+              [(230, 240), (230, 250), (240, 250), (240, 240), (230, 240)]]       # hole 100 px^2: filled
+
+
+def _run(tmp_path, region_dict, remove_holes=True):
+    (tmp_path / "page").mkdir(exist_ok=True)
+    src = tmp_path / "page" / "img.xml"
+    src.write_text(PAGE)
+    w = SeparatorRegionToPageWriter(str(src), None, None, None, region_dict)
+    w.remove_separator_regions_from_page()
+    w.merge_regions(remove_holes)
+    out = tmp_path / "page" / "out.xml"
+    w.save_page_xml(str(out))
+    return Page(str(out))
+
+
+def test_text_lines_are_cut_at_a_vertical_separator(tmp_path):
+    page = _run(tmp_path, {"SeparatorRegion_vertical": [[VSEP]]})
+    r1, r2 = page.get_text_regions()
+    got = {tl.id: tl for tl in r1.text_lines}
+    assert [tl.id for tl in r1.text_lines] == ["A_1", "A_2", "B", "D_1", "D_2", "E", "F"]        # C is swallowed
+    a1, a2 = got["A_1"], got["A_2"]
+    assert a1.surr_p == [(10, 10), (98, 10), (98, 40), (10, 40), (10, 10)]
+    assert a2.surr_p == [(102, 10), (200, 10), (200, 40), (102, 40), (102, 10)]
+    assert a1.baseline == [(10, 35), (98, 35)] and a2.baseline == [(102, 35), (200, 35)]
+    assert [w.id for w in a1.words] == ["w1"] and [w.id for w in a2.words] == ["w2"]
+    assert a1.text == "Hello" and a2.text == "World"
+    assert a1.get_article_id() == "a1" and a2.get_article_id() == "a1"                          # custom tags travel
+    assert a1.custom["readingOrder"] == {"index": "0"}
+    # untouched lines keep their nodes, text and coordinates
+    assert got["B"].surr_p == [(10, 50), (90, 50), (90, 80), (10, 80)] and got["B"].text == "left only"
+    # L-shaped line: the left part keeps the foot, the slanted baseline piece is cut at x = 102 (y = 165 - 20 * 18 / 80)
+    d1, d2 = got["D_1"], got["D_2"]
+    assert d1.surr_p == [(10, 130), (98, 130), (98, 170), (10, 170), (10, 130)]
+    assert d2.surr_p == [(102, 130), (200, 130), (200, 150), (120, 150), (120, 170), (102, 170), (102, 130)]
+    assert d1.baseline == [(10, 165), (98, 165)] and d2.baseline == [(102, 165), (120, 165), (200, 145)]
+    assert d1.text == "no words here" and d2.text == "no words here"          # no Word elements: text is copied (:199-201)
+    # a line that is not rectilinear is left alone; a line that only touches the separator is not cut
+    assert got["E"].surr_p == [(10, 180), (200, 185), (200, 215), (10, 210)]
+    assert got["F"].surr_p == [(102, 220), (200, 220), (200, 250), (102, 250)]
+    assert [tl.id for tl in r2.text_lines] == ["G"]
+    seps = page.get_regions()["SeparatorRegion"]
+    assert [(s.id, s.get_orientation(), s.points) for s in seps] == [("SeparatorRegion_1", "vertical", VSEP)]
+    # XML layout of a split line: Coords, Baseline, Word*, TextEquiv
+    tags = [c.tag.split("}")[1] for c in a1.node]
+    assert tags == ["Coords", "Baseline", "Word", "TextEquiv"]
+    # the region's own TextEquiv stays behind its lines
+    assert [c.tag.split("}")[1] for c in r1.node][-1] == "TextEquiv"
+
+
+def test_two_separators_cut_one_line_into_three(tmp_path):
+    second = [(150, 0), (153, 0), (153, 300), (150, 300), (150, 0)]
+    page = _run(tmp_path, {"SeparatorRegion_vertical": [[VSEP], [second]]})
+    r1 = page.get_text_regions()[0]
+    ids = [tl.id for tl in r1.text_lines]
+    assert ids[:3] == ["A_1", "A_2_1", "A_2_2"]
+    parts = {tl.id: tl for tl in r1.text_lines}
+    assert parts["A_2_1"].surr_p[0] == (102, 10) and parts["A_2_1"].surr_p[1] == (150, 10)
+    assert parts["A_2_2"].surr_p[0] == (153, 10) and parts["A_2_2"].baseline == [(153, 35), (200, 35)]
+    # w2 spans x 110..200: 40 px of it lie in the middle piece, 47 px in the right one -> it goes right (:190-197)
+    assert parts["A_2_1"].text == "" and parts["A_2_2"].text == "World"
+    assert [w.id for w in parts["A_2_2"].words] == ["w2"] and parts["A_2_1"].words == []
+    assert sum(rg.Region.from_rings([parts[i].surr_p]).area for i in ("A_1", "A_2_1", "A_2_2")) == 190 * 30 - 4 * 30 - 3 * 30
+
+
+def test_horizontal_separators_do_not_cut_and_holes_are_handled(tmp_path):
+    page = _run(tmp_path, {"SeparatorRegion_horizontal": [HSEP_HOLE, HSEP_SMALL], "SeparatorRegion": [[VSEP]]})
+    assert [tl.id for tl in page.get_text_regions()[0].text_lines] == ["A", "B", "C", "D", "E", "F"]
+    seps = page.get_regions()["SeparatorRegion"]
+    # plain separators first, then horizontal (merge order :359); the ring with the 2000 px^2 hole is cut at the
+    # hole's line centroid x = 260 into a left and a right part, the 100 px^2 hole is filled
+    assert [s.get_orientation() for s in seps] == [None, "horizontal", "horizontal", "horizontal"]
+    left, right, small = seps[1].points, seps[2].points, seps[3].points
+    assert left == [(220, 120), (260, 120), (260, 140), (240, 140), (240, 190), (260, 190), (260, 220), (220, 220), (220, 120)]
+    assert right == [(260, 120), (320, 120), (320, 220), (260, 220), (260, 190), (280, 190), (280, 140), (260, 140), (260, 120)]
+    assert small == HSEP_SMALL[0]
+    whole = rg.Region.from_rings(HSEP_HOLE)
+    assert rg.Region.from_rings([left]).area + rg.Region.from_rings([right]).area == whole.area == 100 * 100 - 2000
+    # without hole removal only the exterior ring is written (:349-351)
+    page = _run(tmp_path, {"SeparatorRegion_horizontal": [HSEP_HOLE]}, remove_holes=False)
+    assert [s.points for s in page.get_regions()["SeparatorRegion"]] == [HSEP_HOLE[0]]
+
+
+def test_region_algebra_against_rasterisation():
+    """difference / intersection / contains on random rectilinear polygons == the same on pixel masks"""
+    from citlab_article_separation_new_amd import polygonize
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        masks = []
+        for _ in range(2):
+            m = np.zeros((40, 50), bool)
+            for _ in range(int(rng.integers(1, 5))):
+                y0, x0 = int(rng.integers(0, 30)), int(rng.integers(0, 40))
+                m[y0:y0 + int(rng.integers(2, 15)), x0:x0 + int(rng.integers(2, 15))] = True
+            masks.append(m)
+        regs = []
+        for m in masks:
+            polys = polygonize.shapes(m.astype(np.uint8) * 255, 255, connectivity=4)
+            r = rg.Region.from_rings(polys[0])
+            for p in polys[1:]:
+                r = r.union(rg.Region.from_rings(p))
+            regs.append(r)
+            assert r.area == m.sum()
+        a, b = regs
+        for op, ref in ((a.difference(b), masks[0] & ~masks[1]), (a.intersection(b), masks[0] & masks[1]),
+                        (a.union(b), masks[0] | masks[1])):
+            assert op.area == ref.sum()
+            back = polygonize.rasterize(op.polygons(), 40, 50) > 0
+            assert np.array_equal(back, ref)
+        assert a.contains(b) == bool((masks[1] & ~masks[0]).sum() == 0)
+        assert a.overlaps(b) == bool((masks[0] & masks[1]).any())
+
+
+def test_polyline_clipping():
+    sep = rg.Region.from_rings([VSEP])
+    assert rg.clip_polyline_outside([(0, 10), (300, 10)], sep) == [[(0, 10), (98, 10)], [(102, 10), (300, 10)]]
+    assert rg.clip_polyline_outside([(0, 10), (50, 10), (50, 20)], sep) == [[(0, 10), (50, 10), (50, 20)]]
+    assert rg.clip_polyline_outside([(99, 10), (101, 10)], sep) == []
+    assert rg.clip_polyline_outside([(100, 10), (200, 10)], sep) == [[(102, 10), (200, 10)]]
+    assert rg.clip_polyline_outside([(0, 0), (200, 100)], sep) == [[(0, 0), (98, 49)], [(102, 51), (200, 100)]]
+    assert rg.ring_line_centroid([(0, 0), (4, 0), (4, 2), (0, 2)]) == (2.0, 1.0)
+    assert not rg.is_rectilinear([(0, 0), (4, 1), (4, 2), (0, 2)]) and rg.is_rectilinear(VSEP)
