@@ -36,9 +36,11 @@ PEAK_HBM_GBS = 8000.0
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pages-per-step", type=int, default=2, help="pages per rank and step")
+    ap.add_argument("--pages-per-step", type=int, default=16,
+                    help="pages per rank and step (16 x 20 steps = 320 pages: a timed region of ~3 s, long enough for "
+                         "sustained clocks and for an external smi sampler; ~6 GB of HBM per page in flight)")
     ap.add_argument("--height", type=int, default=4500)
     ap.add_argument("--width", type=int, default=3000)
     ap.add_argument("--no-gnn", action="store_true", help="ARU-Net only (diagnostic; not the headline metric)")
@@ -47,7 +49,11 @@ def parse_args():
                          "fp32 accumulation / storage, probability maps within 2e-2 (reported with dtype bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event per-kernel timing")
-    ap.add_argument("--cpu-sample-height", type=int, default=0, help="rows of page 0 for the CPU baseline (0 = full page)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurements (bf16 variant, heading net + stroke-width fusion, visual GNN)")
+    ap.add_argument("--cpu-sample-height", type=int, default=0,
+                    help="rows of a page for the CPU baseline (0 = one whole page per worker on boxes with >= 64 cores, "
+                         "a third of a page on smaller ones)")
     return ap.parse_args()
 
 
@@ -59,7 +65,7 @@ def run_cpu_baseline(args):
     cores = os.cpu_count() or 1
     threads = min(16, cores)                       # torch-CPU convs of this net stop scaling at ~16 threads
     workers = max(1, min(8, (cores // 2 or 1) // threads)) if cores > threads else 1
-    rows = args.cpu_sample_height or max(256, args.height // 3)
+    rows = args.cpu_sample_height or (args.height if cores >= 64 else max(256, args.height // 3))
     cmd = [sys.executable, "-m", "oracle.cpu_worker", "--threads", str(threads), "--rows", str(rows),
            "--width", str(args.width), "--height", str(args.height)] + ([] if args.no_gnn else ["--gnn"])
     t0 = time.perf_counter()
@@ -73,13 +79,108 @@ def run_cpu_baseline(args):
     if not res:
         return None
     frac = rows / args.height
-    t_page = max(r["t_aru"] / frac + r["t_gnn"] for r in res)      # slowest worker, scaled to a whole page
+    t_page = max(r["t_aru"] / frac + r["t_gnn"] for r in res)      # slowest worker (scaled to a whole page if a band)
     return {
         "value": round(len(res) / t_page, 5), "unit": "pages/s", "cores": threads * len(res), "kind": "port",
-        "sample": (f"{len(res)} worker processes x {threads} threads, each: torch-CPU fp32 ARU-Net oracle on a "
-                   f"{args.width}x{rows}px band (scaled x{1 / frac:.2f} to a page) + numpy GNN oracle on one graph; "
+        "sample": (f"{len(res)} worker processes x {threads} threads, each: torch-CPU fp32 ARU-Net oracle on "
+                   + (f"one whole {args.width}x{args.height}px page" if rows >= args.height else
+                      f"a {args.width}x{rows}px band (scaled x{1 / frac:.2f} to a page)")
+                   + " + numpy GNN oracle on one graph; "
                    f"slowest worker {t_page:.2f}s/page; {wall:.1f}s wall incl. start-up; box has {cores} logical CPUs"),
     }
+
+
+def _timed(fn, iters, warmup=1):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs):
+    """Not the headline: the other BASELINE.json configs on the same box, each a short timed loop after the main
+    measurement (device-resident inputs, same conventions).
+      configs[4] precision: bf16 MFMA operands (fp32 accumulation / storage) at 3000 x 4500
+      configs[2]: heading net + stroke-width distance transform + per-line statistics of ~700 text lines
+      configs[3]: the VISUAL relation net (mixed_gnn_vn7e2 shape: 7 + 3 x 16 node features, backbone on 683 x 1024)"""
+    from citlab_article_separation_new_amd import _lib, gnn_io, image_ops, synth
+    from citlab_article_separation_new_amd.config import AruConfig, GnnConfig
+    from citlab_article_separation_new_amd.net_post_processing_helper import AruGraph
+    from citlab_article_separation_new_amd.weights import init_aru_weights, init_gnn_weights
+    H, W = args.height, args.width
+    out = {}
+    s = torch.cuda.current_stream().cuda_stream
+    B2 = min(2, len(imgs))
+    Arr = C.c_void_p * B2
+    prob = [torch.empty(H, W, 2, device=dev) for _ in range(B2)]
+    u8 = [torch.empty(H, W, 2, device=dev, dtype=torch.uint8) for _ in range(B2)]
+    p_img, p_out, p_u8 = Arr(*[t.data_ptr() for t in imgs[:B2]]), Arr(*[t.data_ptr() for t in prob]), Arr(*[t.data_ptr() for t in u8])
+    try:
+        # ---- bf16 variant ----
+        cfg16 = AruConfig(compute_dtype="bf16")
+        g16 = AruGraph(init_aru_weights(cfg16, 1234), cfg16)
+        h16 = g16.handle(dev.index or 0)
+        dt = _timed(lambda: _lib.check(lib.asep_aru_forward_batch_dev(h16, B2, p_img, H, W, p_out, p_u8, None, 0.05, s), "bf16"), 6)
+        out["aru_bf16_mfma"] = {"pages_per_s": round(B2 / dt, 2), "ms_per_page": round(1e3 * dt / B2, 3), "dtype": "bf16",
+                                "note": "BASELINE configs[4] precision; probability maps within 2e-2 of the fp32 oracle "
+                                        "(tests/test_full_frame_gpu.py)"}
+        g16.close()
+        # ---- heading pipeline on one page: net + SWT + per-line features ----
+        cfg = AruConfig()
+        gh = AruGraph(init_aru_weights(cfg, 22), cfg)
+        hh = gh.handle(dev.index or 0)
+        _, ws = image_ops._workspace(dev.index or 0)
+        d_gray = torch.from_numpy(pages_u8[0]).to(dev)
+        d_swt = torch.empty(H, W, device=dev, dtype=torch.uint8)
+        rng = np.random.default_rng(0)
+        n_lines = 700
+        x0 = rng.integers(40, W - 500, n_lines)
+        y0 = rng.integers(40, H - 80, n_lines)
+        boxes = np.stack([x0, y0, x0 + rng.integers(200, 450, n_lines), y0 + rng.integers(24, 40, n_lines)], axis=1).astype(np.int32)
+        sw, hgt, flag = np.empty(n_lines, np.float32), np.empty(n_lines, np.int32), np.empty(n_lines, np.int32)
+        sp = C.c_void_p(s)
+
+        def heading_page():
+            _lib.check(lib.asep_aru_forward_dev(hh, imgs[0].data_ptr(), H, W, prob[0].data_ptr(), u8[0].data_ptr(), None, 0.05, sp), "heading net")
+            _lib.check(lib.asep_swt_distance_transform_dev(ws, d_gray.data_ptr(), H, W, d_swt.data_ptr(), sp), "swt")
+            _lib.check(lib.asep_swt_line_features_dev(ws, d_swt.data_ptr(), H, W, n_lines, boxes.ctypes.data, sw.ctypes.data,
+                                                      hgt.ctypes.data, flag.ctypes.data, sp), "line features")
+        dt = _timed(heading_page, 5)
+        out["heading_net_plus_swt_fusion"] = {"pages_per_s": round(1.0 / dt, 2), "ms_per_page": round(1e3 * dt, 3), "dtype": "f32/u8",
+                                              "note": f"BASELINE configs[2]: heading ARU-Net at {W}x{H} + stroke-width distance "
+                                                      f"transform + per-line statistics of {n_lines} text lines (host gets the statistics)"}
+        gh.close()
+        # ---- visual GNN ----
+        vcfg = GnnConfig(visual_dims=[16, 16, 16], mvn=True,
+                         visual_layers=["scale_0_unet_up_2_conv", "scale_0_unet_up_1_conv", "scale_0_unet_up_0_conv"])
+        vg = gnn_io.GnnGraph(init_gnn_weights(vcfg, 1234), vcfg)
+        g = graphs[0]
+        N, E = g["num_nodes"], int(g["interacting_nodes"].shape[0])
+        vh, vw, P = 1024, 683, 4
+        img_small = torch.nn.functional.interpolate(imgs[0][None, None] * 255.0, size=(vh, vw), mode="bilinear")[0, 0].contiguous()
+        reg = np.zeros((N, 2, P), np.float32)
+        for n in range(N):
+            bx, by = rng.random() * 0.8, rng.random() * 0.8
+            reg[n, 0] = [bx, bx + 0.15, bx + 0.15, bx]
+            reg[n, 1] = [by, by, by + 0.05, by + 0.05]
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        d_e, d_u, d_f, d_reg, d_np = t(g["interacting_nodes"]), t(g["node_features"]), t(g["edge_features"]), t(reg), t(np.full(N, P, np.int32))
+        d_conf = torch.empty(N * N, 2, device=dev)
+        dt = _timed(lambda: gnn_io.gnn_forward_visual_dev(vg, N, E, d_e.data_ptr(), d_u.data_ptr(), d_f.data_ptr(), img_small.data_ptr(),
+                                                          vh, vw, d_reg.data_ptr(), P, d_np.data_ptr(), N * N, None, d_conf.data_ptr(), s,
+                                                          dev.index or 0), 20, warmup=2)
+        out["visual_gnn_vn7e2_shape"] = {"pages_per_s": round(1.0 / dt, 1), "us_per_page": round(1e6 * dt, 1), "dtype": "f32",
+                                         "step_kernel": gnn_io.step_mode(vg, dev.index or 0),
+                                         "note": "BASELINE configs[3] as named (mixed_gnn_vn7e2 = visual net): RU backbone on 683x1024 + "
+                                                 "ROI max / compression + graph with 55 node features, 200 nodes / 20k edges / 40k pairs"}
+        vg.close()
+    except Exception as e:  # a secondary figure must never take the headline line down
+        out["error"] = repr(e)
+    return out
 
 
 def main():
@@ -141,7 +242,10 @@ def main():
     h_aru, h_gnn = aru.handle(local_rank), gnn.handle(local_rank)
 
     # ---- synthetic inputs, resident in HBM before the timed region ------------------------------------------
-    pages_u8 = [synth.synth_page(rank * B + k, W, H) for k in range(B)]
+    # (the page generator costs ~3 s of numpy per page: four distinct pages per rank, every page of the batch has its own
+    # buffers in HBM)
+    distinct = [synth.synth_page(rank * 4 + k, W, H) for k in range(min(B, 4))]
+    pages_u8 = [distinct[k % len(distinct)] for k in range(B)]
     imgs = [torch.from_numpy(p).to(dev).float().div_(255.0).contiguous() for p in pages_u8]
     graphs = [synth.synth_graph(rank * B + k) for k in range(B)]
     N = graphs[0]["num_nodes"]
@@ -166,12 +270,12 @@ def main():
     p_u8 = PtrArr(*[t.data_ptr() for t in out_u8])
     p_mask = PtrArr(*[t.data_ptr() for t in out_mask])
 
-    def step():
+    def step(with_gnn=True):
         # one batched ARU-Net call: every layer is launched once for all B pages x 3 scale-space levels
         _lib.check(lib.asep_aru_forward_batch_dev(h_aru, B, p_img, H, W, p_out, p_u8, p_mask, 0.05, stream),
                    "asep_aru_forward_batch_dev")
         for k in range(B):
-            if not args.no_gnn:
+            if with_gnn and not args.no_gnn:
                 _lib.check(lib.asep_gnn_forward_dev(h_gnn, N, E[k], g_edges[k].data_ptr(), g_u[k].data_ptr(),
                                                     g_ef[k].data_ptr(), N * N, None, out_conf[k].data_ptr(), gnn_stream),
                            "asep_gnn_forward_dev")
@@ -203,7 +307,7 @@ def main():
         lib.asep_aru_profile(h_aru, 1)
         n_prof = max(1, min(args.steps, 3))
         for _ in range(n_prof):
-            step()
+            step(with_gnn=False)          # the events bracket ARU-Net kernels: nothing else may run beside them
         torch.cuda.synchronize()
         buf = C.create_string_buffer(1 << 16)
         _lib.check(lib.asep_aru_profile_report(h_aru, buf, len(buf)), "asep_aru_profile_report")
@@ -212,6 +316,9 @@ def main():
         for k in kernels:
             k["avg_us"] = 1e3 * k["total_ms"] / k["calls"]
             k["tflops"] = k["flops"] / (k["total_ms"] * 1e-3) / 1e12 if k["total_ms"] > 0 else 0.0
+            # Winograd F(2x2,3x3) kernels are credited with the direct-convolution FLOPs of their layers (the algorithmic
+            # work) but execute 2.25x fewer multiplications on the MFMA: report both
+            k["executed_tflops"] = k["tflops"] / 2.25 if "wino" in k["kernel"] else k["tflops"]
         kernels.sort(key=lambda k: -k["total_ms"])
         dom = kernels[0]
         peak_tf = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
@@ -221,16 +328,27 @@ def main():
             "frac": round(dom["tflops"] / peak_tf, 4),
             "avg_launch_us": round(dom["avg_us"], 2), "flops_per_launch": dom["flops"] / dom["calls"],
             "share_of_gpu_time": round(dom["total_ms"] / sum(k["total_ms"] for k in kernels), 4),
-            "traffic": None,
+            "pages_per_launch": B,
+            "traffic": None, "traffic_source": None,
         }
         tp = os.path.join(ROOT, "profiles", "traffic_per_kernel.json")
         if os.path.exists(tp):      # HBM bytes/launch from separate rocprofv3 --pmc passes (profiles/README.md, scripts/make_traffic_json.py)
             try:
-                tj = json.load(open(tp))["kernels"].get(dom["kernel"])
+                tj_all = json.load(open(tp))
+                tj = tj_all["kernels"].get(dom["kernel"])
+                # the counters cannot be read from inside this process: the figure comes from the committed rocprofv3 --pmc
+                # summary of the same workload, scaled to this run's pages per launch
                 if tj and args.dtype == "f32":
-                    roofline["traffic"] = tj["bytes_per_launch"]
+                    ppl = tj_all.get("pages_per_launch", 2)
+                    roofline["traffic"] = tj["bytes_per_launch"] * B / ppl
+                    roofline["traffic_source"] = (f"offline: {tj_all.get('source')} (commit {tj_all.get('commit', 'n/a')}, "
+                                                  f"{ppl} pages per launch there, scaled x{B / ppl:g})")
             except Exception:
                 pass
+
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary and not args.no_gnn:
+        secondary = secondary_measurements(args, lib, dev, imgs, pages_u8, graphs)
 
     if rank == 0:
         flops_page = lib.asep_aru_flops(h_aru, H, W) + (0 if args.no_gnn else lib.asep_gnn_flops(h_gnn, N, 2 * E[0], N * N))
@@ -252,7 +370,11 @@ def main():
             },
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "kernels": [{"kernel": k["kernel"], "calls": k["calls"], "avg_us": round(k["avg_us"], 2),
-                         "tflops": round(k["tflops"], 2)} for k in kernels[:8]],
+                         "tflops": round(k["tflops"], 2), "executed_tflops": round(k["executed_tflops"], 2),
+                         "executed_frac_of_peak": round(k["executed_tflops"] / (PEAK_F32_MFMA_TFLOPS if args.dtype == "f32"
+                                                                              else PEAK_BF16_MFMA_TFLOPS), 4)}
+                        for k in kernels[:8]],
+            "secondary": secondary,
         }
         print(json.dumps(line), flush=True)
     if distributed:

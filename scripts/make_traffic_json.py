@@ -1,5 +1,5 @@
 """profiles/traffic_per_kernel.json from a rocprofv3 PMC summary (scripts/summarize_pmc.py output):
-    python scripts/make_traffic_json.py profiles/<tag>/pmc_summary.json <tag>
+    python scripts/make_traffic_json.py profiles/<tag>/pmc_summary.json <tag> [commit]
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the dispatches of a kernel (FETCH_SIZE doubled: the gfx950
 correction of /opt/skills/guides/MI355X_MICROARCH.md).  Keys are the kernel names bench.py reports."""
 import json, os, re, sys
@@ -24,8 +24,11 @@ def bench_name(rocprof_name):
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
+    commit = sys.argv[3] if len(sys.argv) > 3 else "n/a"          # the build the counters were collected on
     s = json.load(open(src))
-    out = {"source": f"profiles/{tag}/pmc_summary.json", "unit": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024, mean over dispatches",
+    out = {"source": f"profiles/{tag}/pmc_summary.json", "commit": commit, "pages_per_launch": 2,
+           "unit": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024, mean over dispatches "
+                   "(scripts/profile_bench.sh: bench.py --pages-per-step 2)",
            "kernels": {}}
     for name, f in s["FETCH_SIZE"].items():
         w = s["WRITE_SIZE"].get(name)

@@ -7,7 +7,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline"
+# 2 pages per launch under the profiler (the default of 16 only lengthens the trace); bench.py scales the PMC bytes to its own batch
+BENCH="python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --pages-per-step 2"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH --no-kernel-timing > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH --no-kernel-timing > /dev/null 2> $OUT/pmc_write.log

@@ -24,17 +24,24 @@ def _one_json_line(stdout):
 
 
 def test_single_process_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
-                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--pages-per-step", "3"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = _one_json_line(r.stdout)
     assert line["steps"] == 2 and line["warmup"] == 1 and line["dtype"] == "f32"
+    assert line["config"]["pages_per_step_per_gpu"] == 3 and line["roofline"]["pages_per_launch"] == 3
+    # secondary figures (bf16 variant, heading net + stroke-width fusion, the visual relation net) ride on the same line
+    sec = line["secondary"]
+    assert "error" not in sec, sec
+    assert sec["aru_bf16_mfma"]["pages_per_s"] > 0 and sec["heading_net_plus_swt_fusion"]["pages_per_s"] > 0
+    assert sec["visual_gnn_vn7e2_shape"]["step_kernel"] == "mfma_lds" and sec["visual_gnn_vn7e2_shape"]["us_per_page"] > 0
+    assert all("executed_tflops" in k for k in line["kernels"])
 
 
 def test_rccl_path_with_one_rank_keeps_stdout_clean():
     env = dict(os.environ, ASEP_BENCH_FORCE_DIST="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline", "--no-secondary", "--pages-per-step", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     _one_json_line(r.stdout)
