@@ -56,7 +56,6 @@ struct asep_aru {
     float* d_r8_up_br = nullptr;     // [3][8]
     float* d_r8_up_b1 = nullptr;     // [8]
     bool use_fused8 = true;          // ASEP_FUSED8=0 falls back to the layer-by-layer kernels
-    bool r8_w16 = false;             // ASEP_R8_W16=1: 16-wave variant of the fused up block (four waves per SIMD)
     float* d_att_head = nullptr;     // A fragment of attPart/conv1 for att_head_kernel (12 output channels, 4x4 taps)
     float* d_logit_w = nullptr;
     float* d_logit_b = nullptr;
@@ -547,9 +546,7 @@ int pack_res8(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
         m->owned.push_back(m->d_r8_up_w1); m->owned.push_back(m->d_r8_up_wr);
         m->owned.push_back(m->d_r8_up_br); m->owned.push_back(m->d_r8_up_b1);
         if (hipFuncSetAttribute((const void*)res8_up_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)res8_up_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)res8_up16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)res8_up16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess) {
+            hipFuncSetAttribute((const void*)res8_up_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess) {
             set_error("cannot reserve %zu bytes of LDS for the fused up block", R8_UP_LDS);
             return ASEP_ERR_HIP;
         }
@@ -663,10 +660,7 @@ TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
         ProfScope ps(m, pname, flops);
         a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH * R8_NP);
         const dim3 grid(std::min(tiles, m->num_cus));
-        if (m->r8_w16) {
-            if (m->bf16) hipLaunchKernelGGL(res8_up16_kernel<true>, grid, dim3(R16_THREADS), R8_UP_LDS, m->stream, a);
-            else hipLaunchKernelGGL(res8_up16_kernel<false>, grid, dim3(R16_THREADS), R8_UP_LDS, m->stream, a);
-        } else if (m->bf16) hipLaunchKernelGGL(res8_up_kernel<true>, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
+        if (m->bf16) hipLaunchKernelGGL(res8_up_kernel<true>, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
         else hipLaunchKernelGGL(res8_up_kernel<false>, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
     }
     return out;
@@ -970,7 +964,6 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO_REG")) m->wino_reg = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;
-    if (const char* e = getenv("ASEP_R8_W16")) m->r8_w16 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BIGTILE")) m->big_tile = atoi(e) != 0;
     if (const char* e = getenv("ASEP_SIDE_STREAM")) m->use_side_stream = atoi(e) != 0;

@@ -551,224 +551,6 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// 16-wave variant of the UP block (experiment r2): four waves per SIMD instead of two.  The 8-wave kernel's waves each
-// carry ~20 k cycles of non-MFMA work per pass (LDS waits, barriers, epilogues, fills) next to 15 k cycles of MFMA issue,
-// so even a perfect overlap of the two waves of a SIMD leaves the pipe idle a third of the time.  With four waves per
-// SIMD the per-wave chain is half as long and three other waves can fill its gaps -- provided the kernel fits 128 VGPRs:
-// one pixel-pair unit per wave and stage (no second fragment set), ONE filter in registers that is re-loaded for the
-// next stage as soon as the unit's MFMAs have been issued, and half as many tile-prefetch registers per thread.
-// LDS layout, frame geometry and arithmetic order are those of res8_up_kernel (bit-identical results).
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int R16_WAVES = 16, R16_THREADS = R16_WAVES * 64;
-
-template <int NROWS, bool RELU_IN, bool FINAL, bool BF, bool INTERIOR>
-__device__ __forceinline__ void res16_stage(const float* __restrict__ IN, int in_r0, float* __restrict__ OUT, int out_r0,
-                                            int row_start, int out_c0, f32x4 (&A)[6], const f32x4 bias4, int wave, int lane,
-                                            int fy0, int fx0, int H, int W, const float* __restrict__ T, int t_r0,
-                                            float* __restrict__ gout, const f32x4* __restrict__ wnext) {
-    const int j = lane & 15, kk = lane >> 4;
-    const int e = kk >> 1, ch = (kk & 1) * 4;
-#pragma unroll 1
-    for (int pu = wave; pu < NROWS; pu += R16_WAVES) {
-        const int rp = pu >> 1, nt = pu & 1;
-        f32x4 b[4][2];
-        r8_load_frags(IN + ((row_start + 2 * rp - 1 - in_r0) * R8_PITCH + out_c0 + nt * 32 + 2 * j + e - 1) * 8 + ch, b);
-        const int row0 = row_start + 2 * rp;
-        const int colb = out_c0 + nt * 32 + 2 * j;
-        f32x4 v0 = bias4, v1 = bias4;
-        r8_mma<RELU_IN, BF>(A, b, v0, v1);
-        if (!FINAL && pu + R16_WAVES >= NROWS) r8_load_w(wnext, lane, A);   // the filter registers are free: next stage's filter
-        const int col = colb + e;
-        const int gx = fx0 + col;
-        const int gy0 = fy0 + row0;
-        if (!FINAL) {
-            if (INTERIOR) {
-                v0 = relu4i(v0); v1 = relu4i(v1);
-            } else {
-                const bool okx = gx >= 0 && gx < W;
-                v0 = (okx && gy0 >= 0 && gy0 < H) ? relu4i(v0) : f32x4{0.f, 0.f, 0.f, 0.f};
-                v1 = (okx && gy0 + 1 >= 0 && gy0 + 1 < H) ? relu4i(v1) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            float* o = OUT + ((row0 - out_r0) * R8_PITCH + col) * 8 + ch;
-            *reinterpret_cast<f32x4*>(o) = v0;
-            *reinterpret_cast<f32x4*>(o + R8_PITCH * 8) = v1;
-        } else {
-            const float* tp = T + ((row0 - t_r0) * R8_PITCH + col) * 8 + ch;
-            v0 = relu4i(v0 + *reinterpret_cast<const f32x4*>(tp));
-            v1 = relu4i(v1 + *reinterpret_cast<const f32x4*>(tp + R8_PITCH * 8));
-            const bool okx = col >= 4 && col < 4 + R8_OW && (INTERIOR || gx < W);
-            if (okx && (INTERIOR || gy0 < H)) *reinterpret_cast<f32x4*>(gout + ((size_t)gy0 * W + gx) * 8 + ch) = v0;
-            if (okx && (INTERIOR || gy0 + 1 < H)) *reinterpret_cast<f32x4*>(gout + ((size_t)(gy0 + 1) * W + gx) * 8 + ch) = v1;
-        }
-    }
-}
-
-template <bool BF = false>
-__global__ __launch_bounds__(R16_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void res8_up16_kernel(const Res8Args a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Pb = sm;                                          // frame rows 0..23  [24][72][8]  (later r1: rows 3..20)
-    float* T = Pb + R8_FH * R8_PITCH * 8;                    // frame rows 1..22
-    float* R0 = T + 22 * R8_PITCH * 8;                       // frame rows 2..21
-    float* R1K = R0 + 20 * R8_PITCH * 8;                     // two r1 rows parked between passes
-    int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int j = lane & 15, kk = lane >> 4;
-    int e = kk >> 1, ch = (kk & 1) * 4;
-    const f32x4* w1 = reinterpret_cast<const f32x4*>(a.w1);
-    constexpr int ROWV = R8_PITCH * 2;                       // f32x4 per LDS row
-    constexpr int NRG = R16_THREADS / ROWV;                  // 7 row groups of 144 loader threads
-    constexpr int NPF = (R8_FH + NRG - 1) / NRG;             // 4 rows per loader thread
-    f32x4 pf[NPF];
-    int rg = tid / ROWV, cs = tid - rg * ROWV;
-    auto tile_load = [&](const float* __restrict__ g, int H_, int W_, int qy0, int qx0, bool carried) {
-        const int gx = qx0 + (cs >> 1);
-        const bool okc = rg < NRG && gx >= 0 && gx < W_;
-        const float* __restrict__ gp = g + ((ptrdiff_t)gx * 8 + (cs & 1) * 4);
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-            const int r = rg + NRG * k;
-            const int gy = qy0 + r;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (okc && r < R8_FH && !(carried && r < 6) && gy >= 0 && gy < H_) v = *reinterpret_cast<const f32x4*>(gp + (ptrdiff_t)gy * W_ * 8);
-            pf[k] = v;
-        }
-    };
-    auto tile_store = [&](bool carried) {
-        if (rg < NRG) {
-#pragma unroll
-            for (int k = 0; k < NPF; ++k) {
-                const int r = rg + NRG * k;
-                if (r < R8_FH && !(carried && r < 6)) reinterpret_cast<f32x4*>(Pb)[r * ROWV + cs] = pf[k];
-            }
-        }
-    };
-    int tile_id = (int)blockIdx.x < a.total_tiles ? res8_tile_of(a, blockIdx.x) : 0;
-    if ((int)blockIdx.x < a.total_tiles) {
-        int qi = 0;
-        while (qi + 1 < a.nprob && tile_id >= a.p[qi + 1].tile_begin) ++qi;
-        const Res8Prob& Q = a.p[qi];
-        const int tq = tile_id - Q.tile_begin;
-        const int qyb = tq / Q.tiles_x, qxb = tq - qyb * Q.tiles_x;
-        tile_load(Q.img, Q.H, Q.W, qyb * R8_NP * R8_OH - 4, qxb * R8_OW - 4, false);
-    }
-    __shared__ __attribute__((aligned(16))) float bsh[32];
-    if (tid < 24) bsh[tid] = a.br[tid];
-    if (tid < 8) bsh[24 + tid] = a.b1[tid];
-    __syncthreads();
-    auto bias_of = [&](int s) { return *reinterpret_cast<const f32x4*>(bsh + 8 * s + ch); };
-    for (int k = blockIdx.x; k < a.total_tiles; k += gridDim.x) {
-        const bool has_next = k + (int)gridDim.x < a.total_tiles;
-        const int next_id = has_next ? res8_tile_of(a, k + gridDim.x) : 0;
-        int pi = 0;
-        while (pi + 1 < a.nprob && tile_id >= a.p[pi + 1].tile_begin) ++pi;
-        const Res8Prob& P = a.p[pi];
-        const int t = tile_id - P.tile_begin;
-        const int tyb = t / P.tiles_x, txb = t - tyb * P.tiles_x;
-        const int H = P.H, W = P.W;
-        const int fx0 = txb * R8_OW - 4;
-#pragma unroll 1
-        for (int pass = 0; pass < R8_NP; ++pass) {
-            const int fy0 = (tyb * R8_NP + pass) * R8_OH - 4;
-            if (fy0 + 4 >= H) break;
-            const bool more_passes = pass + 1 < R8_NP && fy0 + 4 + R8_OH < H;
-            const bool first = pass == 0;
-            const int c1_row = first ? 1 : 7, c1_units = first ? 22 : 16;
-            asm volatile("" : "+v"(tid));
-            lane = tid & 63; j = lane & 15; kk = lane >> 4; e = kk >> 1; ch = (kk & 1) * 4;
-            rg = tid / ROWV; cs = tid - rg * ROWV;
-            const bool interior = !first && fy0 >= 0 && fy0 + R8_FH <= H && fx0 >= 0 && fx0 + R8_PITCH <= W;
-            const f32x4 biasT = bias_of(3);
-            f32x4 tacc[2][2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) { tacc[q][0] = biasT; tacc[q][1] = biasT; }
-            f32x4 Wa[6];                                      // the one filter in registers
-            auto conv1_half = [&](const f32x4 (&Aw)[6]) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int pu = wave + q * R16_WAVES;
-                    if (pu < c1_units) {
-                        const int rp = pu >> 1, nt = pu & 1;
-                        f32x4 b[4][2];
-                        r8_load_frags(Pb + ((c1_row + 2 * rp - 1) * R8_PITCH + 1 + nt * 32 + 2 * j + e - 1) * 8 + ch, b);
-                        r8_mma<false, BF>(Aw, b, tacc[q][0], tacc[q][1]);
-                    }
-                }
-            };
-            __syncthreads();                                 // the tile buffer is free
-            if (!first) {
-                for (int i = tid; i < 5 * ROWV; i += R16_THREADS) {
-                    const int r = i / ROWV, c = i - r * ROWV;
-                    f32x4* base = reinterpret_cast<f32x4*>(r < 3 ? T : R0);
-                    const int srow = r < 3 ? 19 + r : 18 + (r - 3), drow = r < 3 ? 3 + r : 2 + (r - 3);
-                    base[drow * ROWV + c] = base[srow * ROWV + c];
-                }
-            }
-            tile_store(!first);
-            r8_load_w(w1, lane, Wa);
-            tile_load(P.in1, H, W, fy0, fx0, !first);      // the deconv half flies while the skip half is multiplied
-            __syncthreads();
-            conv1_half(Wa);
-            r8_load_w(w1 + 6 * 64, lane, Wa);                // the deconv half's filter flies across the refill of the tile buffer
-            __syncthreads();
-            tile_store(!first);
-            __syncthreads();
-            conv1_half(Wa);
-            r8_load_w(a.wr, lane, Wa);                       // convR_0's filter flies under the t write
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int pu = wave + q * R16_WAVES;
-                if (pu < c1_units) {
-                    const int rp = pu >> 1, nt = pu & 1;
-                    const int row0 = c1_row + 2 * rp, col = 1 + nt * 32 + 2 * j + e;
-                    float* o = T + ((row0 - 1) * R8_PITCH + col) * 8 + ch;
-                    if (interior) {
-                        *reinterpret_cast<f32x4*>(o) = tacc[q][0];
-                        *reinterpret_cast<f32x4*>(o + R8_PITCH * 8) = tacc[q][1];
-                    } else {
-                        const int gy0 = fy0 + row0, gx = fx0 + col;
-                        const bool okx = gx >= 0 && gx < W;
-                        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-                        *reinterpret_cast<f32x4*>(o) = (okx && gy0 >= 0 && gy0 < H) ? tacc[q][0] : z;
-                        *reinterpret_cast<f32x4*>(o + R8_PITCH * 8) = (okx && gy0 + 1 >= 0 && gy0 + 1 < H) ? tacc[q][1] : z;
-                    }
-                }
-            }
-            __syncthreads();
-            if (first) res16_stage<20, true, false, BF, false>(T, 1, R0, 2, 2, 2, Wa, bias_of(0), wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, a.wr + 6 * 64);
-            else if (interior) res16_stage<16, true, false, BF, true>(T, 1, R0, 2, 6, 2, Wa, bias_of(0), wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, a.wr + 6 * 64);
-            else res16_stage<16, true, false, BF, false>(T, 1, R0, 2, 6, 2, Wa, bias_of(0), wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, a.wr + 6 * 64);
-            __syncthreads();
-            if (first) {
-                res16_stage<18, false, false, BF, false>(R0, 2, Pb, 3, 3, 3, Wa, bias_of(1), wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, a.wr + 12 * 64);
-            } else {
-                if (interior) res16_stage<16, false, false, BF, true>(R0, 2, Pb, 3, 5, 3, Wa, bias_of(1), wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, a.wr + 12 * 64);
-                else res16_stage<16, false, false, BF, false>(R0, 2, Pb, 3, 5, 3, Wa, bias_of(1), wave, lane, fy0, fx0, H, W, nullptr, 0, nullptr, a.wr + 12 * 64);
-                for (int i = tid; i < 2 * ROWV; i += R16_THREADS)
-                    reinterpret_cast<f32x4*>(Pb)[i] = reinterpret_cast<const f32x4*>(R1K)[i];
-            }
-            __syncthreads();
-            if (more_passes) {
-                tile_load(P.img, H, W, fy0 + R8_OH, fx0, true);
-            } else if (has_next) {
-                int qi = 0;
-                while (qi + 1 < a.nprob && next_id >= a.p[qi + 1].tile_begin) ++qi;
-                const Res8Prob& Q = a.p[qi];
-                const int tq = next_id - Q.tile_begin;
-                const int qyb = tq / Q.tiles_x, qxb = tq - qyb * Q.tiles_x;
-                tile_load(Q.img, Q.H, Q.W, qyb * R8_NP * R8_OH - 4, qxb * R8_OW - 4, false);
-            }
-            if (more_passes) {
-                for (int i = tid; i < 2 * ROWV; i += R16_THREADS)
-                    reinterpret_cast<f32x4*>(R1K)[i] = reinterpret_cast<const f32x4*>(Pb)[16 * ROWV + i];
-            }
-            if (interior) res16_stage<16, false, true, BF, true>(Pb, 3, nullptr, 4, 4, 4, Wa, bias_of(2), wave, lane, fy0, fx0, H, W, T, 1, P.out, nullptr);
-            else res16_stage<16, false, true, BF, false>(Pb, 3, nullptr, 4, 4, 4, Wa, bias_of(2), wave, lane, fy0, fx0, H, W, T, 1, P.out, nullptr);
-        }
-        tile_id = next_id;
-    }
-}
-
 constexpr size_t R8_UP_LDS = (size_t)((R8_FH + 22 + 20 + 2) * R8_PITCH * 8) * sizeof(float);
 constexpr size_t R8_DOWN_LDS = (size_t)(R8_FH * R8_IMGP + (22 + 20 + 18) * R8_PITCH * 8) * sizeof(float);
 
