@@ -43,6 +43,10 @@ SIGNATURES = {
     "asep_aru_profile": (C.c_int, [_P, C.c_int]),
     "asep_aru_profile_report": (C.c_long, [_P, C.c_char_p, C.c_size_t]),
     "asep_aru_flops": (C.c_double, [_P, C.c_int, C.c_int]),
+    "asep_host_alloc": (_P, [C.c_size_t]),
+    "asep_host_free": (None, [_P]),
+    "asep_host_register": (C.c_int, [_P, C.c_size_t]),
+    "asep_host_unregister": (C.c_int, [_P]),
     "asep_gnn_load": (_P, [_P, C.c_size_t, C.POINTER(GnnCfg)]),
     "asep_gnn_free": (None, [_P]),
     "asep_gnn_correct_edges": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),

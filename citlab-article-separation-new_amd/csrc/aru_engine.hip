@@ -91,6 +91,7 @@ struct asep_aru {
     int num_cus = 256;
     bool big_tile = true;          // ASEP_BIGTILE=0 disables the 16x32 single-buffer variant
     BufferPool host_stage;         // device staging of the host-pointer entry point (grow-only)
+    hipStream_t host_stream = nullptr;   // transfers + forward of the host-pointer entry point (created on first use)
     bool use_xcd_sched = true;     // ASEP_XCD_SCHED=0: identity tile order in the persistent fused kernels
     std::map<std::string, const int32_t*> sched_cache;
     bool bf16 = false;             // cfg.compute_dtype == 1: bf16 MFMA operands, fp32 accumulation and storage
@@ -107,6 +108,7 @@ struct asep_aru {
         for (void* p : owned)
             if (p) (void)hipFree(p);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        if (host_stream) (void)hipStreamDestroy(host_stream);
     }
     hipEvent_t next_event() {
         if (ev_next == ev_pool.size()) {
@@ -1111,14 +1113,20 @@ int asep_aru_forward(asep_aru* m, const float* img_hw, int H, int W, float* out_
     } catch (const HipError&) {
         return ASEP_ERR_HIP;
     }
-    ASEP_HIP_CHECK(hipMemcpy(d_img, img_hw, npix * sizeof(float), hipMemcpyHostToDevice));
+    // all transfers and the forward are queued on one stream, one synchronisation at the end: with page-locked caller
+    // buffers (asep_host_alloc / asep_host_register) the copies are DMAs at link speed, with pageable ones the runtime
+    // stages them exactly as a synchronous hipMemcpy would
+    if (!m->host_stream) ASEP_HIP_CHECK(hipStreamCreateWithFlags(&m->host_stream, hipStreamNonBlocking));
+    hipStream_t hs = m->host_stream;
+    ASEP_HIP_CHECK(hipMemcpyAsync(d_img, img_hw, npix * sizeof(float), hipMemcpyHostToDevice, hs));
     const int rc = asep_aru_forward_dev(m, d_img, H, W, d_out, out_u8 ? d_u8 : nullptr, out_mask ? d_mask : nullptr,
-                                        threshold, nullptr);
+                                        threshold, hs);
     if (rc) return rc;
-    ASEP_HIP_CHECK(hipStreamSynchronize(nullptr));
-    ASEP_HIP_CHECK(hipMemcpy(out_hwc, d_out, nout * sizeof(float), hipMemcpyDeviceToHost));
-    if (out_u8) ASEP_HIP_CHECK(hipMemcpy(out_u8, d_u8, nout, hipMemcpyDeviceToHost));
-    if (out_mask) ASEP_HIP_CHECK(hipMemcpy(out_mask, d_mask, nout, hipMemcpyDeviceToHost));
+    // the small uint8 results first: a caller that only needs the masks can start on them while the floats arrive
+    if (out_u8) ASEP_HIP_CHECK(hipMemcpyAsync(out_u8, d_u8, nout, hipMemcpyDeviceToHost, hs));
+    if (out_mask) ASEP_HIP_CHECK(hipMemcpyAsync(out_mask, d_mask, nout, hipMemcpyDeviceToHost, hs));
+    ASEP_HIP_CHECK(hipMemcpyAsync(out_hwc, d_out, nout * sizeof(float), hipMemcpyDeviceToHost, hs));
+    ASEP_HIP_CHECK(hipStreamSynchronize(hs));
     return ASEP_OK;
     ASEP_GUARD_END
 }

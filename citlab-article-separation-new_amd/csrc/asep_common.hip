@@ -117,4 +117,30 @@ int asep_init(int device_id) {
     return ASEP_OK;
 }
 
+// ---- page-locked host memory: what makes the host-pointer entry points and the decode slots DMA-able ------------
+void* asep_host_alloc(size_t nbytes) {
+    void* p = nullptr;
+    if (nbytes == 0 || hipHostMalloc(&p, nbytes, hipHostMallocDefault) != hipSuccess) {
+        asep::set_error("asep_host_alloc: cannot page-lock %zu bytes", nbytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void asep_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+int asep_host_register(void* p, size_t nbytes) {
+    if (!p || nbytes == 0) { asep::set_error("asep_host_register: bad argument"); return ASEP_ERR_ARG; }
+    ASEP_HIP_CHECK(hipHostRegister(p, nbytes, hipHostRegisterDefault));
+    return ASEP_OK;
+}
+
+int asep_host_unregister(void* p) {
+    if (!p) return ASEP_ERR_ARG;
+    ASEP_HIP_CHECK(hipHostUnregister(p));
+    return ASEP_OK;
+}
+
 }  // extern "C"

@@ -243,8 +243,13 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
         self.gpu_devices = gpu_device
         self.SWT.device = self.device
         new_page_objects = []
-        for image_path in self.image_paths:
-            image = load_image_bgr(image_path)
+        # images are decoded ahead of the GPU by worker processes when host_workers > 1 (host_pipeline.py); the fusion
+        # itself needs the device again (per-line statistics), so the PAGE-XML part stays in this process
+        from .host_pipeline import DecodePool, pin_callbacks
+        pipelined = getattr(self, "host_workers", 0) > 1
+        reg, unreg = pin_callbacks(self.device) if pipelined else (None, None)
+        for image_path, image in DecodePool(self.image_paths, self.host_workers if pipelined else 0, register=reg,
+                                            unregister=unreg):
             if self.weight_dict['net'] > 0:
                 net_output = self.heading_probability(image)
                 net_output_post = self.post_process(net_output)

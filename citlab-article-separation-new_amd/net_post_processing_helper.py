@@ -12,6 +12,7 @@ replaced by the gfx950 engine in ``csrc/libasep_hip.so`` (C ABI: ``include/asep_
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -98,6 +99,43 @@ def _device_of(gpu_device) -> int:
     return int(str(gpu_device).split(",")[0])
 
 
+class _PinnedPool:
+    """Page-locked numpy buffers (``asep_host_alloc``).  An array handed out owns its buffer until the last view of it
+    is garbage-collected; the buffer then returns to the pool, so a loop over pages re-uses the same few buffers and
+    every transfer of ``get_net_output`` is a DMA instead of a staged copy from / to pageable memory."""
+    KEEP = 4                                  # free buffers kept per size
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.free = {}
+
+    def _give(self, ptr, nbytes):
+        lst = self.free.setdefault(nbytes, [])
+        if len(lst) < self.KEEP:
+            lst.append(ptr)
+        else:
+            self.lib.asep_host_free(ptr)
+
+    def array(self, shape, dtype):
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        lst = self.free.get(nbytes)
+        ptr = lst.pop() if lst else self.lib.asep_host_alloc(nbytes)
+        if not ptr:
+            return np.empty(shape, dtype=dtype)               # pageable fallback: correct, only slower
+        buf = (C.c_char * nbytes).from_address(ptr)
+        weakref.finalize(buf, self._give, ptr, nbytes)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+_pinned = {}
+
+
+def _pinned_pool(dev, lib):
+    if dev not in _pinned:
+        _pinned[dev] = _PinnedPool(lib)
+    return _pinned[dev]
+
+
 def get_net_output(image, pb_graph: AruGraph, gpu_device="0"):
     """helper:56-72: image [H,W] (or [1,H,W,1]) -> net output [H,W,n_classes] float32."""
     out, _, _ = get_net_output_fused(image, pb_graph, gpu_device, want_u8=False, threshold=None)
@@ -120,13 +158,16 @@ def get_net_output_fused(image, pb_graph: AruGraph, gpu_device="0", want_u8=True
     if image.ndim != 2:
         raise ValueError(f"unsupported image shape {image.shape}")
     H, W = image.shape
-    img = np.ascontiguousarray(image, dtype=np.float32)      # the feed casts float64 -> float32
     ncls = pb_graph.cfg.n_classes
-    out = np.empty((H, W, ncls), dtype=np.float32)
-    u8 = np.empty((H, W, ncls), dtype=np.uint8) if want_u8 else None
-    mask = np.empty((H, W, ncls), dtype=np.uint8) if (want_u8 and threshold is not None) else None
     dev = _device_of(gpu_device)
     lib = _lib.init_device(dev)
+    pool = _pinned_pool(dev, lib)
+    # the feed casts float64 -> float32: done while copying into a page-locked staging buffer (one pass over the page)
+    img = pool.array((H, W), np.float32)
+    np.copyto(img, image, casting="unsafe")
+    out = pool.array((H, W, ncls), np.float32)
+    u8 = pool.array((H, W, ncls), np.uint8) if want_u8 else None
+    mask = pool.array((H, W, ncls), np.uint8) if (want_u8 and threshold is not None) else None
     rc = lib.asep_aru_forward(pb_graph.handle(dev), img.ctypes.data, H, W, out.ctypes.data,
                               u8.ctypes.data if u8 is not None else None,
                               mask.ctypes.data if mask is not None else None,

@@ -2,8 +2,10 @@
 
 Same flags and defaults (``--fixed_height`` defaults to 900 for headings and 1500 for separators, threshold 0.05).
 The reference fans image sub-lists out over a ``ProcessPoolExecutor(num_processes)`` of TensorFlow-CPU workers
-(``gpu_devices=''``); here a worker is one process per GPU: sub-lists are built exactly like the reference's
-(``:64-72``) and dealt round-robin to the visible devices, ``--num_processes`` caps the number of workers.
+(``gpu_devices=''``).  Here ONE process per GPU owns the device and ``--num_processes`` is the number of HOST worker
+processes in total: they decode images ahead of the GPU owners and write PAGE-XML behind them (``host_pipeline.py``),
+because a page costs ~110 ms of decode against single-digit milliseconds on the GPU.  Sub-lists are built exactly like
+the reference's (``:64-72``) and dealt round-robin to the GPU owners.
 """
 import argparse
 import multiprocessing as mp
@@ -13,21 +15,23 @@ from .path_util import load_list_file
 MAX_SUBLIST_SIZE = 50
 
 
-def run_separator(image_list, path_to_pb, fixed_height, scaling_factor, threshold, gpu_devices='0'):
+def run_separator(image_list, path_to_pb, fixed_height, scaling_factor, threshold, gpu_devices='0', host_workers=0):
     from .separator_net_post_processor import SeparatorNetPostProcessor
     SeparatorNetPostProcessor(image_list, path_to_pb, fixed_height, scaling_factor, threshold,
-                              gpu_devices=gpu_devices).run()
+                              gpu_devices=gpu_devices, host_workers=host_workers).run()
 
 
 def run_heading(image_list, path_to_pb, fixed_height=900, scaling_factor=1, is_heading_threshold=0.4,
-                weight_dict=None, thresh_dict=None, text_line_percentage=0.8, gpu_devices='0'):
+                weight_dict=None, thresh_dict=None, text_line_percentage=0.8, gpu_devices='0', host_workers=0):
     from .heading_net_post_processor import HeadingNetPostProcessor
     if thresh_dict is None:
         thresh_dict = {'net_thresh': 1.0, 'stroke_width_thresh': 1.0, 'text_height_thresh': 0.9, 'sw_th_thresh': 0.9}
     if weight_dict is None:
         weight_dict = {'net': 0.8, 'stroke_width': 0.0, 'text_height': 0.2}
-    HeadingNetPostProcessor(image_list, path_to_pb, fixed_height, scaling_factor, weight_dict, is_heading_threshold,
-                            thresh_dict, text_line_percentage).run(gpu_device=gpu_devices)
+    proc = HeadingNetPostProcessor(image_list, path_to_pb, fixed_height, scaling_factor, weight_dict, is_heading_threshold,
+                                   thresh_dict, text_line_percentage)
+    proc.host_workers = host_workers
+    proc.run(gpu_device=gpu_devices)
 
 
 def build_parser():
@@ -37,7 +41,8 @@ def build_parser():
     parser.add_argument("--path_to_pb", type=str, required=True,
                         help="Path to the pixel labelling graph (TF1 frozen .pb or .asepw).")
     parser.add_argument("--num_processes", type=int, required=False, default=8,
-                        help="Upper bound on the number of worker processes (one per GPU is used).")
+                        help="Host worker processes in total (image decode ahead of / PAGE-XML behind the GPU owners; "
+                             "one GPU-owning process per visible device is started besides them).")
     parser.add_argument("--fixed_height", type=int, required=False, help="Input image height")
     parser.add_argument("--scaling_factor", type=float, required=False, default=1.0, help="Scaling factor of images.")
     parser.add_argument("--mode", type=str, required=True, choices=['heading', 'separator'],
@@ -57,12 +62,16 @@ def build_sub_lists(image_path_list, num_processes):
     return [image_path_list[i: i + size_sub_lists] for i in range(0, len(image_path_list), size_sub_lists)]
 
 
-def _worker(mode, sub_lists, path_to_pb, fixed_height, scaling_factor, threshold, gpu):
-    for sub in sub_lists:
-        if mode == 'separator':
-            run_separator(sub, path_to_pb, fixed_height, scaling_factor, threshold, gpu_devices=str(gpu))
-        else:
-            run_heading(sub, path_to_pb, fixed_height, scaling_factor, 0.4, None, None, 0.8, gpu_devices=str(gpu))
+def _worker(mode, sub_lists, path_to_pb, fixed_height, scaling_factor, threshold, gpu, host_workers=0):
+    # one model per GPU owner: its sub-lists are processed as one stream so that the decode workers never run dry at a
+    # sub-list boundary (the 50-page cap of :70 only bounded the memory of the reference's per-run image lists)
+    images = [p for sub in sub_lists for p in sub]
+    if mode == 'separator':
+        run_separator(images, path_to_pb, fixed_height, scaling_factor, threshold, gpu_devices=str(gpu),
+                      host_workers=host_workers)
+    else:
+        run_heading(images, path_to_pb, fixed_height, scaling_factor, 0.4, None, None, 0.8, gpu_devices=str(gpu),
+                    host_workers=host_workers)
 
 
 def main(argv=None):
@@ -82,14 +91,16 @@ def main(argv=None):
     n_gpus = torch.cuda.device_count()
     if n_gpus <= 0:
         raise _lib.AsepError("no HIP device visible: the MI355X (gfx950) engine has no CPU fallback")
-    n_workers = max(1, min(n_gpus, args.num_processes, len(sub_lists)))
+    n_workers = max(1, min(n_gpus, len(sub_lists)))                 # GPU owners
+    host_workers = max(1, args.num_processes) // n_workers            # decode / XML workers per owner (<= 1: inline)
     per_worker = [sub_lists[i::n_workers] for i in range(n_workers)]
     if n_workers == 1:
-        _worker(mode, per_worker[0], args.path_to_pb, fixed_height, args.scaling_factor, args.threshold, 0)
+        _worker(mode, per_worker[0], args.path_to_pb, fixed_height, args.scaling_factor, args.threshold, 0, host_workers)
         return 0
     ctx = mp.get_context("spawn")
     procs = [ctx.Process(target=_worker, args=(mode, per_worker[i], args.path_to_pb, fixed_height,
-                                               args.scaling_factor, args.threshold, i)) for i in range(n_workers)]
+                                               args.scaling_factor, args.threshold, i, host_workers))
+             for i in range(n_workers)]
     for p in procs:
         p.start()
     rc = 0

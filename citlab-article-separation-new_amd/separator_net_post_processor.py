@@ -7,6 +7,7 @@ GPU: uint8 upload -> resize + gray (a1) -> ARU-Net with fused uint8 / threshold 
 rectangular openings on bit planes (a9); only the two masks come back for polygon extraction (a10).
 """
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -22,8 +23,13 @@ from .region_to_page_writer import SEPARATOR_REGION, SeparatorRegionToPageWriter
 class RegionNetPostProcessor:
     """region_net_post_processor_base.py:17-268 (the parts the separator pipeline uses)."""
 
-    def __init__(self, image_list, path_to_pb, fixed_height, scaling_factor, threshold=None, gpu_devices='0'):
+    def __init__(self, image_list, path_to_pb, fixed_height, scaling_factor, threshold=None, gpu_devices='0',
+                 host_workers=0):
         self.image_paths = load_list_file(image_list) if isinstance(image_list, str) else list(image_list)
+        # worker processes that decode images ahead of the GPU and write PAGE-XML behind it (host_pipeline.py);
+        # 0 / 1 = everything inline in this process
+        self.host_workers = host_workers
+        self.device_seconds = 0.0      # wall time this process spent inside the device stages (upload .. results back)
         self.fixed_height = fixed_height
         self.scaling_factor = scaling_factor
         self.threshold = threshold
@@ -60,9 +66,18 @@ class RegionNetPostProcessor:
         return polygons_dict
 
 
+def write_separator_page(page_path, image_path, fixed_height, scaling_factor, polygons_dict):
+    """:120-133 as a plain function (runs in a WritePool worker): regions into the PAGE-XML next to the image"""
+    writer = SeparatorRegionToPageWriter(page_path, image_path, fixed_height, scaling_factor, polygons_dict)
+    writer.remove_separator_regions_from_page()
+    writer.merge_regions()
+    writer.save_page_xml(page_path + ".xml")
+    return writer.page_object
+
+
 class SeparatorNetPostProcessor(RegionNetPostProcessor):
-    def __init__(self, image_list, path_to_pb, fixed_height, scaling_factor, threshold, gpu_devices):
-        super().__init__(image_list, path_to_pb, fixed_height, scaling_factor, threshold, gpu_devices)
+    def __init__(self, image_list, path_to_pb, fixed_height, scaling_factor, threshold, gpu_devices, host_workers=0):
+        super().__init__(image_list, path_to_pb, fixed_height, scaling_factor, threshold, gpu_devices, host_workers)
 
     def post_process(self, net_output):
         """:26-97 on a thresholded uint8 HWC net output (host array) -> {"horizontal", "vertical"}."""
@@ -75,12 +90,7 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
         return {SEPARATOR_REGION + "_" + separator_type: contours}
 
     def to_page_xml(self, page_path, image_path=None, polygons_dict=None, *args, **kwargs):
-        writer = SeparatorRegionToPageWriter(page_path, image_path, self.fixed_height, self.scaling_factor,
-                                             polygons_dict)
-        writer.remove_separator_regions_from_page()
-        writer.merge_regions()
-        writer.save_page_xml(page_path + ".xml")
-        return writer.page_object
+        return write_separator_page(page_path, image_path, self.fixed_height, self.scaling_factor, polygons_dict)
 
     # -- the fused device path ---------------------------------------------------------------------------------
     def separator_masks(self, image, edges_only=False):
@@ -131,25 +141,37 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
         return masks, sc, extras
 
     def run(self):
-        """:135-159."""
+        """:135-159.  With ``host_workers`` > 1 the images are decoded ahead of the GPU by worker processes (DMA-able
+        shared-memory slots) and the PAGE-XML files are written behind it; the GPU-owning process only runs the device
+        stages and chains the polygon rings."""
+        from .host_pipeline import DecodePool, WritePool, pin_callbacks
         page_objects = []
-        for image_path in self.image_paths:
-            image = load_image_bgr(image_path)
-            masks, sc, extras = self.separator_masks(image, edges_only=not self.keep_outputs)
-            polygons_dict = {}
-            if self.keep_outputs:
-                self.net_outputs.append(extras["net_output_u8"])
-                self.net_outputs_post.append(masks)
-                for separator_type, net_output_post in masks.items():
-                    polygons_dict.update(self.to_polygons(net_output_post, separator_type))
-            else:
-                h, w = extras["size"]
-                for separator_type, (starts, ends) in masks.items():
-                    polygons_dict[SEPARATOR_REGION + "_" + separator_type] = \
-                        polygonize.shapes_from_segments(starts, ends, h, w, connectivity=8)
-            polygons_dict = self.rescale_polygons(polygons_dict, scaling_factor=1 / sc)
-            page_objects.append(self.to_page_xml(get_page_path(image_path), image_path=image_path,
-                                                 polygons_dict=polygons_dict))
+        pipelined = self.host_workers > 1 and not self.keep_outputs
+        reg, unreg = pin_callbacks(self.device) if pipelined else (None, None)
+        decode = DecodePool(self.image_paths, self.host_workers if pipelined else 0, register=reg, unregister=unreg)
+        with WritePool(self.host_workers if pipelined else 0) as writers:
+            for image_path, image in decode:
+                t_dev = time.perf_counter()
+                masks, sc, extras = self.separator_masks(image, edges_only=not self.keep_outputs)
+                self.device_seconds += time.perf_counter() - t_dev
+                polygons_dict = {}
+                if self.keep_outputs:
+                    self.net_outputs.append(extras["net_output_u8"])
+                    self.net_outputs_post.append(masks)
+                    for separator_type, net_output_post in masks.items():
+                        polygons_dict.update(self.to_polygons(net_output_post, separator_type))
+                else:
+                    h, w = extras["size"]
+                    for separator_type, (starts, ends) in masks.items():
+                        polygons_dict[SEPARATOR_REGION + "_" + separator_type] = \
+                            polygonize.shapes_from_segments(starts, ends, h, w, connectivity=8)
+                polygons_dict = self.rescale_polygons(polygons_dict, scaling_factor=1 / sc)
+                if pipelined:
+                    writers.submit(write_separator_page, get_page_path(image_path), image_path, self.fixed_height,
+                                   self.scaling_factor, polygons_dict)
+                else:
+                    page_objects.append(self.to_page_xml(get_page_path(image_path), image_path=image_path,
+                                                         polygons_dict=polygons_dict))
         return page_objects
 
 

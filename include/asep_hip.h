@@ -43,6 +43,15 @@ int asep_init(int device_id);                 /* hipSetDevice + arch check (gfx9
 const char* asep_last_error(void);
 const char* asep_version(void);
 
+/* Page-locked host memory.  The host-pointer entry points (asep_aru_forward, asep_gnn_forward ...) copy with
+ * asynchronous transfers on one stream: from / to page-locked buffers these are DMAs at link speed, from / to ordinary
+ * (pageable) memory the runtime stages them.  asep_host_alloc returns page-locked memory; asep_host_register page-locks
+ * a range the caller already owns (e.g. a shared-memory slot that decoded pages arrive in). */
+void* asep_host_alloc(size_t nbytes);
+void asep_host_free(void* p);
+int asep_host_register(void* p, size_t nbytes);
+int asep_host_unregister(void* p);
+
 /* ---- ARU-Net (ARU_v1.py:35-43 hyper-parameters) ---------------------------------------------- */
 typedef struct asep_aru_cfg {
     int32_t channels;          /* image channels, 1 */

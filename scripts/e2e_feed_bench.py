@@ -1,0 +1,92 @@
+"""Files in, files out on ONE GPU: how fast does `run_net_post_processing --mode separator` turn scan files into PAGE-XML
+when worker processes decode ahead of / write behind the GPU owner (host_pipeline.py), and how busy is the GPU?
+
+    python scripts/e2e_feed_bench.py [n_pages=32] [host_workers=12] [fixed_height=4500]
+
+Prints pages/s and the GPU-busy fraction (time inside the device stages / wall) for host_workers = 0 (everything
+inline, the round-1 behaviour) and for the requested number of workers; also the seam cost of `get_net_output` on host
+arrays (page-locked transfers) and the batched small-page rate (CLI default size 1000 x 1500)."""
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from PIL import Image
+
+n_pages = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+workers = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+fixed_height = int(sys.argv[3]) if len(sys.argv) > 3 else 4500
+W, H = 3000, 4500
+
+
+def main():
+    import ctypes as C
+    import torch
+    from citlab_article_separation_new_amd import _lib, net_post_processing_helper as helper, synth
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.separator_net_post_processor import SeparatorNetPostProcessor
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    cfg = AruConfig()
+    graph = helper.AruGraph(init_aru_weights(cfg, 21, logit_scale=0.05), cfg)
+    with tempfile.TemporaryDirectory(prefix="asep_feed_") as tmp:
+        os.makedirs(os.path.join(tmp, "page"))
+        base = [synth.synth_page(k, W, H) for k in range(4)]
+        paths = []
+        for k in range(n_pages):
+            p = os.path.join(tmp, f"p{k:03d}.png")
+            Image.fromarray(base[k % 4]).save(p, compress_level=1)
+            paths.append(p)
+        t0 = time.perf_counter()
+        from citlab_article_separation_new_amd import image_io
+        for p in paths[:4]:
+            image_io.load_image_bgr(p)
+        print(f"PNG decode alone: {(time.perf_counter() - t0) / 4 * 1e3:.1f} ms/page (one process)")
+        for hw in (0, workers):
+            proc = SeparatorNetPostProcessor(paths[:2], graph, fixed_height, 1.0, 0.5, "0", host_workers=0)
+            proc.run()                                   # warm-up: library, pools, first-touch allocations
+            proc = SeparatorNetPostProcessor(paths, graph, fixed_height, 1.0, 0.5, "0", host_workers=hw)
+            t0 = time.perf_counter()
+            proc.run()
+            dt = time.perf_counter() - t0
+            n_xml = len([f for f in os.listdir(os.path.join(tmp, "page")) if f.endswith(".xml.xml")])
+            print(f"separator CLI path, fixed_height {fixed_height}, host_workers {hw:2d}: {n_pages / dt:6.2f} pages/s "
+                  f"({dt / n_pages * 1e3:6.1f} ms/page); GPU-owner busy in device stages {proc.device_seconds / dt:5.1%}; "
+                  f"{n_xml} PAGE-XML files written")
+        # ---- seam: get_net_output on host arrays (float64 in, float32 out), page-locked staging ----
+        img = (base[0] / 255.0)
+        helper.get_net_output(img, graph, "0")
+        t0 = time.perf_counter()
+        for _ in range(5):
+            out = helper.get_net_output(img, graph, "0")
+        print(f"get_net_output(float64 {W}x{H}) -> float32 [{H},{W},2]: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms/page "
+              f"(device-resident forward alone: see bench.py)")
+        img32 = img.astype(np.float32)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            out = helper.get_net_output(img32, graph, "0")
+        print(f"get_net_output(float32 {W}x{H}): {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms/page")
+        # ---- batched small pages: the CLI default net input 1000 x 1500 ----
+        lib = _lib.init_device(0)
+        h = graph.handle(0)
+        for hh, ww in ((1500, 1000), (900, 600), (768, 512)):
+            for B in (1, 16):
+                ins = [torch.rand(hh, ww, device="cuda") for _ in range(B)]
+                outs = [torch.empty(hh, ww, 2, device="cuda") for _ in range(B)]
+                Arr = C.c_void_p * B
+                pi, po = Arr(*[t.data_ptr() for t in ins]), Arr(*[t.data_ptr() for t in outs])
+                s = torch.cuda.current_stream().cuda_stream
+                step = lambda: _lib.check(lib.asep_aru_forward_batch_dev(h, B, pi, hh, ww, po, None, None, 0.05, s), "batch")
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    step()
+                torch.cuda.synchronize()
+                print(f"net input {ww}x{hh}, batch {B:2d}: {(time.perf_counter() - t0) / 20 / B * 1e3:.3f} ms/page")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,65 @@
+"""host_pipeline.py on the CPU: worker processes decode ahead into shared-memory slots (order of the list kept,
+pixels identical to an inline decode, failures surfaced with the file name), write tasks run in worker processes."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from citlab_article_separation_new_amd import host_pipeline, image_io
+
+
+def _touch(path, text):
+    with open(path, "w") as f:
+        f.write(text)
+
+
+def test_decode_pool_keeps_order_and_pixels(tmp_path):
+    rng = np.random.default_rng(0)
+    paths, want = [], []
+    for k in range(7):
+        if k % 3 == 2:
+            arr = rng.integers(0, 255, (40 + k, 30, 3), dtype=np.uint8)
+        else:
+            arr = rng.integers(0, 255, (33, 50 + k), dtype=np.uint8)
+        p = tmp_path / f"img{k}.png"
+        Image.fromarray(arr).save(p)
+        paths.append(str(p))
+        want.append(image_io.load_image_bgr(str(p)))
+    pinned, released = [], []
+    pool = host_pipeline.DecodePool(paths, n_workers=3, slot_bytes=1 << 16,
+                                    register=lambda a, n: pinned.append((a, n)) or True, unregister=released.append)
+    got = [(p, img.copy()) for p, img in pool]
+    assert [p for p, _ in got] == paths
+    for (_, img), ref in zip(got, want):
+        assert img.dtype == np.uint8 and np.array_equal(img, ref)
+    assert len(pinned) == pool.n_slots and sorted(released) == sorted(a for a, _ in pinned)
+    # inline mode gives the same
+    inline = [img for _, img in host_pipeline.DecodePool(paths, n_workers=0)]
+    assert all(np.array_equal(a, b) for a, b in zip(inline, want))
+
+
+def test_decode_pool_reports_failures(tmp_path):
+    ok = tmp_path / "a.png"
+    Image.fromarray(np.zeros((4, 4), np.uint8)).save(ok)
+    paths = [str(ok), str(tmp_path / "missing.png"), str(ok)]
+    with pytest.raises(IOError, match="missing.png"):
+        list(host_pipeline.DecodePool(paths, n_workers=2, slot_bytes=1 << 12))
+    big = tmp_path / "big.png"
+    Image.fromarray(np.zeros((100, 100), np.uint8)).save(big)
+    with pytest.raises(IOError, match="exceeds"):
+        list(host_pipeline.DecodePool([str(ok), str(big)], n_workers=2, slot_bytes=1 << 12))
+
+
+def test_write_pool_runs_tasks_and_surfaces_errors(tmp_path):
+    with host_pipeline.WritePool(2) as w:
+        for k in range(5):
+            w.submit(_touch, str(tmp_path / f"f{k}.txt"), f"page {k}")
+    assert sorted(os.listdir(tmp_path)) == [f"f{k}.txt" for k in range(5)]
+    assert (tmp_path / "f3.txt").read_text() == "page 3"
+    with pytest.raises(FileNotFoundError):
+        with host_pipeline.WritePool(2) as w:
+            w.submit(_touch, str(tmp_path / "no_such_dir" / "x.txt"), "x")
+    with host_pipeline.WritePool(0) as w:                    # inline
+        w.submit(_touch, str(tmp_path / "inline.txt"), "i")
+    assert (tmp_path / "inline.txt").read_text() == "i"
