@@ -328,7 +328,7 @@ def main():
             "frac": round(dom["tflops"] / peak_tf, 4),
             "avg_launch_us": round(dom["avg_us"], 2), "flops_per_launch": dom["flops"] / dom["calls"],
             "share_of_gpu_time": round(dom["total_ms"] / sum(k["total_ms"] for k in kernels), 4),
-            "pages_per_launch": B,
+            "pages_per_launch": B * n_prof / dom["calls"],      # a launch carries at most 12 problems = 4 pages x 3 scales
             "traffic": None, "traffic_source": None,
         }
         tp = os.path.join(ROOT, "profiles", "traffic_per_kernel.json")
@@ -340,9 +340,10 @@ def main():
                 # summary of the same workload, scaled to this run's pages per launch
                 if tj and args.dtype == "f32":
                     ppl = tj_all.get("pages_per_launch", 2)
-                    roofline["traffic"] = tj["bytes_per_launch"] * B / ppl
+                    mine = roofline["pages_per_launch"]
+                    roofline["traffic"] = tj["bytes_per_launch"] * mine / ppl
                     roofline["traffic_source"] = (f"offline: {tj_all.get('source')} (commit {tj_all.get('commit', 'n/a')}, "
-                                                  f"{ppl} pages per launch there, scaled x{B / ppl:g})")
+                                                  f"{ppl} pages per launch there, scaled x{mine / ppl:g})")
             except Exception:
                 pass
 

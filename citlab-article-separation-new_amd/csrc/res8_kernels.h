@@ -27,7 +27,10 @@ constexpr int R8_PITCH = 72;                   // pixels per LDS row (frame colu
 constexpr int R8_IMGP = 76;                    // image tile pitch (frame columns -2..73)
 constexpr int R8_WAVES = 8;                    // 512 threads: two waves per SIMD hide the LDS->MFMA latency
 constexpr int R8_THREADS = R8_WAVES * 64;
-constexpr int R8_NP = 4;                       // vertical passes per work unit: a unit is R8_NP * R8_OH = 64 rows x 58 columns.
+#ifndef R8_NP_VALUE
+#define R8_NP_VALUE 4
+#endif
+constexpr int R8_NP = R8_NP_VALUE;                       // vertical passes per work unit: a unit is R8_NP * R8_OH = 64 rows x 58 columns.
                                                // Pass 0 recomputes the 4-row halo above the unit; every further pass
                                                // carries the 2-3 bottom rows of t / r0 / r1 over from the pass above
                                                // instead of recomputing them: 16 rows per stage (two units per wave,

@@ -30,6 +30,8 @@ class RegionNetPostProcessor:
         # 0 / 1 = everything inline in this process
         self.host_workers = host_workers
         self.device_seconds = 0.0      # wall time this process spent inside the device stages (upload .. results back)
+        self.wait_seconds = 0.0        # ... waiting for the next decoded image
+        self.host_seconds = 0.0        # ... chaining polygon rings / handing the page to the writers
         self.fixed_height = fixed_height
         self.scaling_factor = scaling_factor
         self.threshold = threshold
@@ -150,10 +152,13 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
         reg, unreg = pin_callbacks(self.device) if pipelined else (None, None)
         decode = DecodePool(self.image_paths, self.host_workers if pipelined else 0, register=reg, unregister=unreg)
         with WritePool(self.host_workers if pipelined else 0) as writers:
+            t_prev = time.perf_counter()
             for image_path, image in decode:
                 t_dev = time.perf_counter()
+                self.wait_seconds += t_dev - t_prev
                 masks, sc, extras = self.separator_masks(image, edges_only=not self.keep_outputs)
-                self.device_seconds += time.perf_counter() - t_dev
+                t_host = time.perf_counter()
+                self.device_seconds += t_host - t_dev
                 polygons_dict = {}
                 if self.keep_outputs:
                     self.net_outputs.append(extras["net_output_u8"])
@@ -172,6 +177,8 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
                 else:
                     page_objects.append(self.to_page_xml(get_page_path(image_path), image_path=image_path,
                                                          polygons_dict=polygons_dict))
+                t_prev = time.perf_counter()
+                self.host_seconds += t_prev - t_host
         return page_objects
 
 

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from PIL import Image
 
-n_pages = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+n_pages = int(sys.argv[1]) if len(sys.argv) > 1 else 192
 workers = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 fixed_height = int(sys.argv[3]) if len(sys.argv) > 3 else 4500
 W, H = 3000, 4500
@@ -34,9 +34,12 @@ def main():
         os.makedirs(os.path.join(tmp, "page"))
         base = [synth.synth_page(k, W, H) for k in range(4)]
         paths = []
-        for k in range(n_pages):
+        for k in range(n_pages):                       # four real files, the rest are links to them (own PAGE-XML each)
             p = os.path.join(tmp, f"p{k:03d}.png")
-            Image.fromarray(base[k % 4]).save(p, compress_level=1)
+            if k < 4:
+                Image.fromarray(base[k]).save(p, compress_level=1)
+            else:
+                os.symlink(os.path.join(tmp, f"p{k % 4:03d}.png"), p)
             paths.append(p)
         t0 = time.perf_counter()
         from citlab_article_separation_new_amd import image_io
@@ -46,14 +49,16 @@ def main():
         for hw in (0, workers):
             proc = SeparatorNetPostProcessor(paths[:2], graph, fixed_height, 1.0, 0.5, "0", host_workers=0)
             proc.run()                                   # warm-up: library, pools, first-touch allocations
-            proc = SeparatorNetPostProcessor(paths, graph, fixed_height, 1.0, 0.5, "0", host_workers=hw)
+            proc = SeparatorNetPostProcessor(paths if hw else paths[:24], graph, fixed_height, 1.0, 0.5, "0", host_workers=hw)
             t0 = time.perf_counter()
             proc.run()
             dt = time.perf_counter() - t0
             n_xml = len([f for f in os.listdir(os.path.join(tmp, "page")) if f.endswith(".xml.xml")])
-            print(f"separator CLI path, fixed_height {fixed_height}, host_workers {hw:2d}: {n_pages / dt:6.2f} pages/s "
-                  f"({dt / n_pages * 1e3:6.1f} ms/page); GPU-owner busy in device stages {proc.device_seconds / dt:5.1%}; "
-                  f"{n_xml} PAGE-XML files written")
+            n_run = len(proc.image_paths)
+            print(f"separator CLI path, fixed_height {fixed_height}, host_workers {hw:2d}: {n_run / dt:6.2f} pages/s "
+                  f"({dt / n_run * 1e3:6.1f} ms/page incl. worker start-up); GPU owner: device stages {proc.device_seconds / dt:5.1%} "
+                  f"({proc.device_seconds / n_run * 1e3:.1f} ms/page), waiting for decoded images {proc.wait_seconds / dt:5.1%}, "
+                  f"rings + hand-over {proc.host_seconds / dt:5.1%}; {n_xml} PAGE-XML files written")
         # ---- seam: get_net_output on host arrays (float64 in, float32 out), page-locked staging ----
         img = (base[0] / 255.0)
         helper.get_net_output(img, graph, "0")

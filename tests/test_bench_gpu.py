@@ -29,7 +29,7 @@ def test_single_process_line():
     assert r.returncode == 0, r.stderr[-2000:]
     line = _one_json_line(r.stdout)
     assert line["steps"] == 2 and line["warmup"] == 1 and line["dtype"] == "f32"
-    assert line["config"]["pages_per_step_per_gpu"] == 3 and line["roofline"]["pages_per_launch"] == 3
+    assert line["config"]["pages_per_step_per_gpu"] == 3 and line["roofline"]["pages_per_launch"] == 3.0
     # secondary figures (bf16 variant, heading net + stroke-width fusion, the visual relation net) ride on the same line
     sec = line["secondary"]
     assert "error" not in sec, sec
