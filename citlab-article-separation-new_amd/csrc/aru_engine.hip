@@ -1113,19 +1113,28 @@ int asep_aru_forward(asep_aru* m, const float* img_hw, int H, int W, float* out_
     } catch (const HipError&) {
         return ASEP_ERR_HIP;
     }
-    // all transfers and the forward are queued on one stream, one synchronisation at the end: with page-locked caller
-    // buffers (asep_host_alloc / asep_host_register) the copies are DMAs at link speed, with pageable ones the runtime
-    // stages them exactly as a synchronous hipMemcpy would
+    // All transfers and the forward are queued on one stream, one synchronisation at the end.  Page-locked caller buffers
+    // (asep_host_alloc / asep_host_register) are device-visible: the net's last kernel then writes its outputs straight
+    // into them over the link (no staging buffer, no separate download: 108 MB of probabilities leave while the kernel
+    // runs); the input is still copied once (it is read by several kernels).  Pageable buffers take staged copies.
     if (!m->host_stream) ASEP_HIP_CHECK(hipStreamCreateWithFlags(&m->host_stream, hipStreamNonBlocking));
     hipStream_t hs = m->host_stream;
+    auto device_view = [](void* host) -> void* {
+        if (!host) return nullptr;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+    };
+    float* v_out = (float*)device_view(out_hwc);
+    uint8_t* v_u8 = (uint8_t*)device_view(out_u8);
+    uint8_t* v_mask = (uint8_t*)device_view(out_mask);
     ASEP_HIP_CHECK(hipMemcpyAsync(d_img, img_hw, npix * sizeof(float), hipMemcpyHostToDevice, hs));
-    const int rc = asep_aru_forward_dev(m, d_img, H, W, d_out, out_u8 ? d_u8 : nullptr, out_mask ? d_mask : nullptr,
-                                        threshold, hs);
+    const int rc = asep_aru_forward_dev(m, d_img, H, W, v_out ? v_out : d_out, out_u8 ? (v_u8 ? v_u8 : d_u8) : nullptr,
+                                        out_mask ? (v_mask ? v_mask : d_mask) : nullptr, threshold, hs);
     if (rc) return rc;
-    // the small uint8 results first: a caller that only needs the masks can start on them while the floats arrive
-    if (out_u8) ASEP_HIP_CHECK(hipMemcpyAsync(out_u8, d_u8, nout, hipMemcpyDeviceToHost, hs));
-    if (out_mask) ASEP_HIP_CHECK(hipMemcpyAsync(out_mask, d_mask, nout, hipMemcpyDeviceToHost, hs));
-    ASEP_HIP_CHECK(hipMemcpyAsync(out_hwc, d_out, nout * sizeof(float), hipMemcpyDeviceToHost, hs));
+    if (out_u8 && !v_u8) ASEP_HIP_CHECK(hipMemcpyAsync(out_u8, d_u8, nout, hipMemcpyDeviceToHost, hs));
+    if (out_mask && !v_mask) ASEP_HIP_CHECK(hipMemcpyAsync(out_mask, d_mask, nout, hipMemcpyDeviceToHost, hs));
+    if (!v_out) ASEP_HIP_CHECK(hipMemcpyAsync(out_hwc, d_out, nout * sizeof(float), hipMemcpyDeviceToHost, hs));
     ASEP_HIP_CHECK(hipStreamSynchronize(hs));
     return ASEP_OK;
     ASEP_GUARD_END

@@ -128,6 +128,22 @@ class _PinnedPool:
 
 
 _pinned = {}
+_copy_threads = None
+
+
+def _parallel_copy(dst, src, min_rows=512, n_threads=4):
+    """dst[...] = src (with dtype conversion) in row bands on a few threads: numpy releases the GIL while it copies, and
+    one core moves only ~10 GB/s -- a 3000 x 4500 float page would spend 5 ms here, half of the net's run time"""
+    global _copy_threads
+    rows = dst.shape[0]
+    if rows < 2 * min_rows:
+        np.copyto(dst, src, casting="unsafe")
+        return
+    if _copy_threads is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _copy_threads = ThreadPoolExecutor(n_threads)
+    step = -(-rows // n_threads)
+    list(_copy_threads.map(lambda a: np.copyto(dst[a:a + step], src[a:a + step], casting="unsafe"), range(0, rows, step)))
 
 
 def _pinned_pool(dev, lib):
@@ -164,7 +180,7 @@ def get_net_output_fused(image, pb_graph: AruGraph, gpu_device="0", want_u8=True
     pool = _pinned_pool(dev, lib)
     # the feed casts float64 -> float32: done while copying into a page-locked staging buffer (one pass over the page)
     img = pool.array((H, W), np.float32)
-    np.copyto(img, image, casting="unsafe")
+    _parallel_copy(img, image)
     out = pool.array((H, W, ncls), np.float32)
     u8 = pool.array((H, W, ncls), np.uint8) if want_u8 else None
     mask = pool.array((H, W, ncls), np.uint8) if (want_u8 and threshold is not None) else None
