@@ -132,14 +132,12 @@ __device__ __forceinline__ void res8_stage(const float* __restrict__ IN, int in_
         const int rp = pu >> 1, nt = pu & 1;
         return IN + ((row_start + 2 * rp - 1 - in_r0) * R8_PITCH + out_c0 + nt * 32 + 2 * j + e - 1) * 8 + ch;
     };
-    auto unit_mma = [&](f32x4 (&b)[4][2], f32x4& v0, f32x4& v1) {
-        v0 = bias4; v1 = bias4;                      // the bias is the accumulators' initial value
-        r8_mma<RELU_IN, BF>(A, b, v0, v1);
-    };
-    auto unit_epilogue = [&](int pu, f32x4 v0, f32x4 v1) {
+    auto unit = [&](int pu, f32x4 (&b)[4][2]) {
         const int rp = pu >> 1, nt = pu & 1;
         const int row0 = row_start + 2 * rp;         // rows row0, row0+1
         const int colb = out_c0 + nt * 32 + 2 * j;   // this lane's pixel pair starts at colb
+        f32x4 v0 = bias4, v1 = bias4;                // the bias is the accumulators' initial value
+        r8_mma<RELU_IN, BF>(A, b, v0, v1);
         // D layout: lane (pair j, kk): pixel colb + e, channels ch..ch+3
         const int col = colb + e;
         const int gx = fx0 + col;
@@ -186,11 +184,6 @@ __device__ __forceinline__ void res8_stage(const float* __restrict__ IN, int in_
             }
         }
     };
-    auto unit = [&](int pu, f32x4 (&b)[4][2]) {
-        f32x4 v0, v1;
-        unit_mma(b, v0, v1);
-        unit_epilogue(pu, v0, v1);
-    };
     // two fragment sets in flight: a unit's LDS reads are requested one unit ahead of its MFMAs (straight-line code,
     // no loop-carried arrays: a copy between the sets would make the wave wait for the reads at once)
     constexpr bool THIRD = NROWS > 2 * R8_WAVES;
@@ -202,20 +195,6 @@ __device__ __forceinline__ void res8_stage(const float* __restrict__ IN, int in_
     // conservative and the first MFMA would wait for the filter that was only just requested)
     if (!FINAL) r8_load_w(wnext, lane, An);
     __builtin_amdgcn_sched_barrier(0);                  // all requests go out first (the scheduler otherwise sinks the reads to their uses in some instantiations)
-#ifdef R8_STAGGER
-    // the two waves of a SIMD (w, w + 4) run the same program between the same barriers and fall into lock step: both in
-    // their epilogues at once, the MFMA pipe idle.  The second half of the block defers the first unit's epilogue behind
-    // the second unit's MFMAs, so that one wave's epilogue lies beside the other's MFMAs (MI355X_MICROARCH.md, two waves
-    // per SIMD, item 9)
-    if (!THIRD && wave >= R8_WAVES / 2) {
-        f32x4 a0, a1, c0, c1;
-        unit_mma(bA, a0, a1);
-        unit_mma(bB, c0, c1);
-        unit_epilogue(wave, a0, a1);
-        unit_epilogue(wave + R8_WAVES, c0, c1);
-        return;
-    }
-#endif
     unit(wave, bA);
     if (THIRD && has3) r8_load_frags(frag_ptr(wave + 2 * R8_WAVES), bA);
     unit(wave + R8_WAVES, bB);
