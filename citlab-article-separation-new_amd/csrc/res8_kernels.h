@@ -80,12 +80,29 @@ __device__ __forceinline__ void r8_load_w(const f32x4* __restrict__ base, int la
     for (int c = 0; c < 6; ++c) A[c] = q[c * 64];
 }
 
-// B fragments of one pixel-pair unit (2 output rows x 32 columns): 4 input rows x 2 column halves, p = first of them
-__device__ __forceinline__ void r8_load_frags(const float* __restrict__ p, f32x4 (&b)[4][2]) {
+// Float offset of the 16-byte piece (pixel x of the row, channel half hf) inside an LDS row.  A B-fragment read takes,
+// for 16 consecutive pixel PAIRS, the same piece of each pair: at the natural layout (64 bytes per pair) those sixteen
+// 16-byte reads fall into two bank groups (rocprofv3: SQ_LDS_BANK_CONFLICT = 53 % of SQ_LDS_IDX_ACTIVE in res8_up,
+// profiles/r2i_instruction_mix).  The four pieces of a pair are therefore permuted by the pair's index: piece k of pair p
+// sits in slot k ^ ((p >> 1) & 3), so that eight consecutive pairs present eight different bank groups.  Whole-row
+// copies (carried rows) are layout-preserving and need no change.
+__device__ __forceinline__ int r8_px(int x, int hf) {
+#ifdef R8_NO_SWIZZLE
+    return x * 8 + hf * 4;
+#else
+    return ((x >> 1) << 4) + (((((x & 1) << 1) | hf) ^ ((x >> 2) & 3)) << 2);
+#endif
+}
+
+// B fragments of one pixel-pair unit (2 output rows x 32 columns): 4 input rows x 2 column halves; `row` = first input
+// row, the lane's pixel x and x + 2, channel half hf
+__device__ __forceinline__ void r8_load_frags(const float* __restrict__ row, int x, int hf, f32x4 (&b)[4][2]) {
+    const int o0 = r8_px(x, hf), o1 = r8_px(x + 2, hf);
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) b[rr][h] = *reinterpret_cast<const f32x4*>(p + (rr * R8_PITCH + 2 * h) * 8);
+    for (int rr = 0; rr < 4; ++rr) {
+        b[rr][0] = *reinterpret_cast<const f32x4*>(row + rr * R8_PITCH * 8 + o0);
+        b[rr][1] = *reinterpret_cast<const f32x4*>(row + rr * R8_PITCH * 8 + o1);
+    }
 }
 
 template <bool RELU_IN, bool BF>
@@ -128,9 +145,10 @@ __device__ __forceinline__ void res8_stage(const float* __restrict__ IN, int in_
     const int j = lane & 15, kk = lane >> 4;
     const int e = kk >> 1, ch = (kk & 1) * 4;
     // pu enumerates (row pair, n-tile): NROWS/2 pairs x 2 n-tiles; a wave owns units wave, wave + 8 (, wave + 16)
-    auto frag_ptr = [&](int pu) {
+    const int hf = kk & 1;
+    auto load_unit = [&](int pu, f32x4 (&b)[4][2]) {
         const int rp = pu >> 1, nt = pu & 1;
-        return IN + ((row_start + 2 * rp - 1 - in_r0) * R8_PITCH + out_c0 + nt * 32 + 2 * j + e - 1) * 8 + ch;
+        r8_load_frags(IN + (row_start + 2 * rp - 1 - in_r0) * R8_PITCH * 8, out_c0 + nt * 32 + 2 * j + e - 1, hf, b);
     };
     auto unit = [&](int pu, f32x4 (&b)[4][2]) {
         const int rp = pu >> 1, nt = pu & 1;
@@ -150,11 +168,11 @@ __device__ __forceinline__ void res8_stage(const float* __restrict__ IN, int in_
                 v0 = (okx && gy0 >= 0 && gy0 < H) ? relu4i(v0) : f32x4{0.f, 0.f, 0.f, 0.f};
                 v1 = (okx && gy0 + 1 >= 0 && gy0 + 1 < H) ? relu4i(v1) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            float* o = OUT + ((row0 - out_r0) * R8_PITCH + col) * 8 + ch;
+            float* o = OUT + (row0 - out_r0) * R8_PITCH * 8 + r8_px(col, hf);
             *reinterpret_cast<f32x4*>(o) = v0;
             *reinterpret_cast<f32x4*>(o + R8_PITCH * 8) = v1;
         } else {
-            const float* tp = T + ((row0 - t_r0) * R8_PITCH + col) * 8 + ch;
+            const float* tp = T + (row0 - t_r0) * R8_PITCH * 8 + r8_px(col, hf);
             v0 = relu4i(v0 + *reinterpret_cast<const f32x4*>(tp));
             v1 = relu4i(v1 + *reinterpret_cast<const f32x4*>(tp + R8_PITCH * 8));
             const int gy0 = fy0 + row0;
@@ -189,14 +207,14 @@ __device__ __forceinline__ void res8_stage(const float* __restrict__ IN, int in_
     constexpr bool THIRD = NROWS > 2 * R8_WAVES;
     const bool has3 = THIRD && wave + 2 * R8_WAVES < NROWS;
     f32x4 bA[4][2], bB[4][2];
-    r8_load_frags(frag_ptr(wave), bA);
-    r8_load_frags(frag_ptr(wave + R8_WAVES), bB);       // NROWS >= 16: every wave has two units
+    load_unit(wave, bA);
+    load_unit(wave + R8_WAVES, bB);                     // NROWS >= 16: every wave has two units
     // (unconditional and at one place for every wave: behind a run-time branch the compiler's wait counters become
     // conservative and the first MFMA would wait for the filter that was only just requested)
     if (!FINAL) r8_load_w(wnext, lane, An);
     __builtin_amdgcn_sched_barrier(0);                  // all requests go out first (the scheduler otherwise sinks the reads to their uses in some instantiations)
     unit(wave, bA);
-    if (THIRD && has3) r8_load_frags(frag_ptr(wave + 2 * R8_WAVES), bA);
+    if (THIRD && has3) load_unit(wave + 2 * R8_WAVES, bA);
     unit(wave + R8_WAVES, bB);
     if (THIRD && has3) unit(wave + 2 * R8_WAVES, bA);
 }
@@ -312,8 +330,8 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
                 f32x4 lo = ok ? f32x4{acc[0], acc[1], acc[2], acc[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
                 f32x4 hi = ok ? f32x4{acc[4], acc[5], acc[6], acc[7]} : f32x4{0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4*>(T + i * 8) = lo;
-                *reinterpret_cast<f32x4*>(T + i * 8 + 4) = hi;
+                *reinterpret_cast<f32x4*>(T + r * R8_PITCH * 8 + r8_px(c, 0)) = lo;
+                *reinterpret_cast<f32x4*>(T + r * R8_PITCH * 8 + r8_px(c, 1)) = hi;
             }
             R8_MARK();   // 3 conv1 (VALU) done
             __syncthreads();
@@ -385,7 +403,7 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
             for (int k = 0; k < NPF; ++k) {
                 if (k < 2 && carried) continue;
-                reinterpret_cast<f32x4*>(Pb)[(rg + 3 * k) * ROWV + cs] = pf[k];
+                *reinterpret_cast<f32x4*>(Pb + (rg + 3 * k) * R8_PITCH * 8 + r8_px(cs >> 1, cs & 1)) = pf[k];
             }
         }
     };
@@ -442,17 +460,17 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             f32x4 Wa[6], Wb[6];                               // the current / next filter (pixel-pair A fragments)
             // one 8-channel half of conv1 out of the tile buffer, accumulated into tacc
             auto conv1_half = [&](const f32x4 (&Aw)[6]) {
-                auto frag_ptr = [&](int pu) {
+                auto load_unit = [&](int pu, f32x4 (&b)[4][2]) {
                     const int rp = pu >> 1, nt = pu & 1;
-                    return Pb + ((c1_row + 2 * rp - 1) * R8_PITCH + 1 + nt * 32 + 2 * j + e - 1) * 8 + ch;
+                    r8_load_frags(Pb + (c1_row + 2 * rp - 1) * R8_PITCH * 8, nt * 32 + 2 * j + e, ch >> 2, b);
                 };
                 const bool has3 = wave + 2 * R8_WAVES < c1_units;
                 f32x4 bA[4][2], bB[4][2];
-                r8_load_frags(frag_ptr(wave), bA);
-                r8_load_frags(frag_ptr(wave + R8_WAVES), bB);
+                load_unit(wave, bA);
+                load_unit(wave + R8_WAVES, bB);
                 __builtin_amdgcn_sched_barrier(0);
                 r8_mma<false, BF>(Aw, bA, tacc[0][0], tacc[0][1]);
-                if (has3) r8_load_frags(frag_ptr(wave + 2 * R8_WAVES), bA);
+                if (has3) load_unit(wave + 2 * R8_WAVES, bA);
                 r8_mma<false, BF>(Aw, bB, tacc[1][0], tacc[1][1]);
                 if (has3) r8_mma<false, BF>(Aw, bA, tacc[2][0], tacc[2][1]);
             };
@@ -493,7 +511,7 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 if (pu < c1_units) {
                     const int rp = pu >> 1, nt = pu & 1;
                     const int row0 = c1_row + 2 * rp, col = 1 + nt * 32 + 2 * j + e;
-                    float* o = T + ((row0 - 1) * R8_PITCH + col) * 8 + ch;
+                    float* o = T + (row0 - 1) * R8_PITCH * 8 + r8_px(col, ch >> 2);
                     if (interior) {
                         *reinterpret_cast<f32x4*>(o) = tacc[q][0];
                         *reinterpret_cast<f32x4*>(o + R8_PITCH * 8) = tacc[q][1];
