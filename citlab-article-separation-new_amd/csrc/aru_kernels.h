@@ -132,6 +132,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // (16-channel mode: a B-fragment read takes the same 16-byte quad of 16 consecutive 64-byte pixel records and is 2-way
+    // bank conflicted -- SQ_LDS_BANK_CONFLICT = 44-46 % of SQ_LDS_IDX_ACTIVE, 0 % in the 32-byte C8 mode.  Permuting the
+    // quads by the pixel index removes the conflicts but costs ~5 VALU per fragment address inside the tap loop, where
+    // the offsets are otherwise immediates: measured +6 % (16 -> 16, 16 x 32 tiles) to +17 % (8 x 32 tiles) slower, not
+    // kept.  The fused level-0 kernels and the Winograd V image, where the permutation is a per-unit / per-thread
+    // constant, do use it.)
     int nbase[NT];   // LDS float index of (row, col + j) of each n-tile of this wave
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -402,6 +408,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 
     // transform role: tile tt (row-major in the 2 x 16 tile grid), channel pair cp (channels 2cp, 2cp+1 of the group)
     const int tt = tid >> 3, cp = tid & 7;
+    // Bank-conflict-free V image: an MFMA B-fragment read takes, for 16 consecutive tiles, the same 16-byte channel quad
+    // of each tile's 64-byte record -- at the natural layout those reads fall into two bank groups (rocprofv3:
+    // SQ_LDS_BANK_CONFLICT = 45 % of SQ_LDS_IDX_ACTIVE, profiles/r2i_instruction_mix).  Quad q of tile t is therefore
+    // stored in slot q ^ ((t >> 1) & 3): eight consecutive tiles then present eight different bank groups.  Both roles
+    // apply the permutation as a per-thread constant (no cost inside the loops).
+    const int cp_sw = ((((cp >> 1) ^ (((tt & 15) >> 1) & 3)) << 2) | ((cp & 1) << 1));   // float offset of the pair inside the record
+    const int kk_sw = (kk ^ ((j >> 1) & 3)) << 2;                                        // float offset of the lane's quad
 
     f32x4 acc[4][MT][2];
 #pragma unroll
@@ -455,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) d[r][s2] = *reinterpret_cast<const f32x2*>(hb + (r * HW + s2) * HP);
-        float* vb = V + buf * VBUF + tt * 16 + cp * 2;
+        float* vb = V + buf * VBUF + tt * 16 + cp_sw;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             // row r of B^T d, then times B, written straight out (keeps at most one row of temporaries live)
@@ -504,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
             // the requests stay here, one position ahead of their use (left alone, the scheduler sinks them to just
             // before the MFMAs that need them and every position waits for an L2 round trip)
             __builtin_amdgcn_sched_barrier(0);
-            const float* vb = vcur + ((wave * 4 + p) * TILES + j) * 16 + kk * 4;
+            const float* vb = vcur + ((wave * 4 + p) * TILES + j) * 16 + kk_sw;
             f32x4 bf[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) bf[n] = *reinterpret_cast<const f32x4*>(vb + n * 16 * 16);
@@ -575,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
                 for (int n = 0; n < 2; ++n) {
                     const f32x4 z0 = acc[0][m][n] + acc[1][m][n] + acc[2][m][n];
                     const f32x4 z1 = acc[1][m][n] - acc[2][m][n] - acc[3][m][n];
-                    float* xb = V + h * VBUF + ((wave * 2) * TILES + n * 16 + j) * 16 + kk * 4;
+                    float* xb = V + h * VBUF + ((wave * 2) * TILES + n * 16 + j) * 16 + kk_sw;
                     *reinterpret_cast<f32x4*>(xb) = z0;
                     *reinterpret_cast<f32x4*>(xb + TILES * 16) = z1;
                 }
@@ -588,7 +601,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
         for (int h = 0; h < MPR; ++h) {
             const int m = rd * 2 + h;
             if (m >= MT) continue;
-            const float* mb = V + h * VBUF + tt * 16 + cp * 2;
+            const float* mb = V + h * VBUF + tt * 16 + cp_sw;
             // row half of the inverse transform: rows r = 0..3 (one per wave) -> output rows dy = 0, 1
             // 2 x 2 output pixels of tile tt, channels 2cp, 2cp+1 of m-tile h -> output tile
             // (pixels of odd tiles keep their two 16-channel halves swapped: the four tiles of a half-wave then use both
