@@ -73,6 +73,97 @@ class StrokeWidthDistanceTransform:
         return out
 
 
+def _scale_to_new_interval(data, old_min, old_max, new_min=0, new_max=1):
+    """:50-63."""
+    if old_max - old_min == 0:
+        return data
+    return (new_max - new_min) / (old_max - old_min) * (data - old_min) + new_min
+
+
+def apply_heading_values(writer, text_lines, values, weight_dict, threshold, thresh_dict, text_line_percentage, save_path):
+    """:121-200: fusion rule on the per-line measurements, heading tags on lines and regions, PAGE-XML written."""
+    stroke_width_dict, height_dict, net_prob_dict = (dict(v) for v in values)
+    page_object = writer.page_object
+    stroke_width_list = list(stroke_width_dict.values())
+    use_swt_features = len(stroke_width_list) > 0
+    if use_swt_features:
+        stroke_width_mode = Counter(stroke_width_list).most_common(1)[0][0]
+        height_mode = Counter(list(height_dict.values())).most_common(1)[0][0]
+        for text_line in text_lines:
+            stroke_width_dict[text_line.id] = stroke_width_dict[text_line.id] - stroke_width_mode
+            height_dict[text_line.id] = height_dict[text_line.id] - height_mode
+        stroke_width_list = list(stroke_width_dict.values())
+        stroke_width_min, stroke_width_max = np.min(stroke_width_list), np.max(stroke_width_list)
+        height_list = list(height_dict.values())
+        height_min, height_max = np.min(height_list), np.max(height_list)
+        net_weight = weight_dict["net"]
+        stroke_width_weight = weight_dict["stroke_width"]
+        height_weight = weight_dict["text_height"]
+        net_thresh = thresh_dict["net_thresh"]
+        stroke_width_thresh = thresh_dict["stroke_width_thresh"]
+        height_thresh = thresh_dict["text_height_thresh"]
+        sw_th_thresh = thresh_dict["sw_th_thresh"]
+
+    for text_line in text_lines:
+        net_conf = net_prob_dict[text_line.id]
+        if use_swt_features:
+            sw_conf = _scale_to_new_interval(stroke_width_dict[text_line.id], old_min=stroke_width_min,
+                                             old_max=stroke_width_max)
+            th_conf = _scale_to_new_interval(height_dict[text_line.id], old_min=height_min, old_max=height_max)
+            if sw_conf >= stroke_width_thresh or th_conf >= height_thresh or \
+                    (sw_conf + th_conf) / 2 >= sw_th_thresh or net_conf >= net_thresh:
+                is_heading_confidence = 1.0
+            else:
+                is_heading_confidence = net_weight * net_conf + stroke_width_weight * sw_conf \
+                    + height_weight * th_conf
+        else:
+            is_heading_confidence = net_conf
+        if is_heading_confidence > threshold:
+            text_line.set_structure_attribute("semantic_type", HEADING)
+            text_line.flush()
+
+    for text_region in page_object.get_text_regions():
+        text_region.region_type = PARAGRAPH
+        if text_region.text_lines:
+            num_headings = sum(1 for tl in text_region.text_lines if tl.get_semantic_type() == HEADING)
+            if num_headings / len(text_region.text_lines) >= text_line_percentage:
+                text_region.region_type = HEADING
+        text_region.node.set("type", text_region.region_type)
+
+    writer.save_page_xml(save_path)
+    return page_object
+
+
+class LineGeometry:
+    """what the measurements need of a text line (picklable: travels from a worker that parsed the PAGE-XML)"""
+    __slots__ = ("id", "surr_p")
+
+    def __init__(self, line_id, surr_p):
+        self.id, self.surr_p = line_id, surr_p
+
+    def get_bounding_box(self):
+        xs = [p[0] for p in self.surr_p]
+        ys = [p[1] for p in self.surr_p]
+        return min(xs), min(ys), max(xs) - min(xs) + 1, max(ys) - min(ys) + 1
+
+
+def read_line_geometry(page_path):
+    """worker task: (id, outline) of every text line of a PAGE-XML in document order, or None if the file is missing"""
+    import os
+    from .page_xml import Page
+    if not os.path.exists(page_path):
+        return None
+    return [(tl.id, tl.surr_p) for tl in Page(page_path).get_textlines()]
+
+
+def write_heading_page(page_path, image_path, fixed_height, scaling_factor, values, weight_dict, threshold, thresh_dict,
+                       text_line_percentage):
+    """worker task: fusion + tags + PAGE-XML of one page from the measurements the GPU owner made"""
+    writer = RegionToPageWriter(page_path, path_to_image=image_path, fixed_height=fixed_height, scaling_factor=scaling_factor)
+    text_lines = writer.page_object.get_textlines()
+    apply_heading_values(writer, text_lines, values, weight_dict, threshold, thresh_dict, text_line_percentage, page_path + ".xml")
+
+
 class HeadingNetPostProcessor(RegionNetPostProcessor):
     def __init__(self, image_list, path_to_pb, fixed_height, scaling_factor, weight_dict=None, threshold=0.5,
                  thresh_dict=None, text_line_percentage=None):
@@ -88,9 +179,7 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
 
     def scale_to_new_interval(self, data, old_min, old_max, new_min=0, new_max=1):
         """:50-63."""
-        if old_max - old_min == 0:
-            return data
-        return (new_max - new_min) / (old_max - old_min) * (data - old_min) + new_min
+        return _scale_to_new_interval(data, old_min, old_max, new_min, new_max)
 
     def post_process(self, net_output):
         """:202-208."""
@@ -127,15 +216,9 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
         net_output_text_line = net_output[ya:ya + height, xa:xa + width]
         return np.sum(net_output_text_line) / (width * height)
 
-    def to_page_xml(self, page_path, image_path=None, net_output_post=None, swt_feature_image=None, *args, **kwargs):
-        """:66-200."""
-        writer = RegionToPageWriter(page_path, path_to_image=image_path, fixed_height=self.fixed_height,
-                                    scaling_factor=self.scaling_factor)
-        if swt_feature_image is None:
-            swt_feature_image = self.get_swt_features_image(image_path)
-        page_object = writer.page_object
-        text_lines = page_object.get_textlines()
-
+    def line_values(self, text_lines, scaling_factor, net_output_post, swt_feature_image):
+        """The three per-line measurements of :94-119 for ``text_lines`` (objects with ``id``, ``surr_p`` and
+        ``get_bounding_box``): stroke width, text height, mean net confidence -> three dicts keyed by line id."""
         stroke_width_dict, height_dict, net_prob_dict = {}, {}, {}
         batched = {}
         if isinstance(swt_feature_image, image_ops.DeviceImage):
@@ -159,58 +242,19 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
             if self.weight_dict['net'] == 0 or net_output_post is None:
                 net_prob_dict[text_line.id] = 0
             else:
-                net_prob_dict[text_line.id] = self.get_net_prob_for_text_line(net_output_post, text_line,
-                                                                              writer.scaling_factor)
+                net_prob_dict[text_line.id] = self.get_net_prob_for_text_line(net_output_post, text_line, scaling_factor)
+        return stroke_width_dict, height_dict, net_prob_dict
 
-        stroke_width_list = list(stroke_width_dict.values())
-        use_swt_features = len(stroke_width_list) > 0
-        if use_swt_features:
-            stroke_width_mode = Counter(stroke_width_list).most_common(1)[0][0]
-            height_mode = Counter(list(height_dict.values())).most_common(1)[0][0]
-            for text_line in text_lines:
-                stroke_width_dict[text_line.id] = stroke_width_dict[text_line.id] - stroke_width_mode
-                height_dict[text_line.id] = height_dict[text_line.id] - height_mode
-            stroke_width_list = list(stroke_width_dict.values())
-            stroke_width_min, stroke_width_max = np.min(stroke_width_list), np.max(stroke_width_list)
-            height_list = list(height_dict.values())
-            height_min, height_max = np.min(height_list), np.max(height_list)
-            net_weight = self.weight_dict["net"]
-            stroke_width_weight = self.weight_dict["stroke_width"]
-            height_weight = self.weight_dict["text_height"]
-            net_thresh = self.thresh_dict["net_thresh"]
-            stroke_width_thresh = self.thresh_dict["stroke_width_thresh"]
-            height_thresh = self.thresh_dict["text_height_thresh"]
-            sw_th_thresh = self.thresh_dict["sw_th_thresh"]
-
-        for text_line in text_lines:
-            net_conf = net_prob_dict[text_line.id]
-            if use_swt_features:
-                sw_conf = self.scale_to_new_interval(stroke_width_dict[text_line.id], old_min=stroke_width_min,
-                                                     old_max=stroke_width_max)
-                th_conf = self.scale_to_new_interval(height_dict[text_line.id], old_min=height_min,
-                                                     old_max=height_max)
-                if sw_conf >= stroke_width_thresh or th_conf >= height_thresh or \
-                        (sw_conf + th_conf) / 2 >= sw_th_thresh or net_conf >= net_thresh:
-                    is_heading_confidence = 1.0
-                else:
-                    is_heading_confidence = net_weight * net_conf + stroke_width_weight * sw_conf \
-                        + height_weight * th_conf
-            else:
-                is_heading_confidence = net_conf
-            if is_heading_confidence > self.threshold:
-                text_line.set_structure_attribute("semantic_type", HEADING)
-                text_line.flush()
-
-        for text_region in page_object.get_text_regions():
-            text_region.region_type = PARAGRAPH
-            if text_region.text_lines:
-                num_headings = sum(1 for tl in text_region.text_lines if tl.get_semantic_type() == HEADING)
-                if num_headings / len(text_region.text_lines) >= self.text_line_percentage:
-                    text_region.region_type = HEADING
-            text_region.node.set("type", text_region.region_type)
-
-        writer.save_page_xml(page_path + ".xml")
-        return page_object
+    def to_page_xml(self, page_path, image_path=None, net_output_post=None, swt_feature_image=None, *args, **kwargs):
+        """:66-200."""
+        writer = RegionToPageWriter(page_path, path_to_image=image_path, fixed_height=self.fixed_height,
+                                    scaling_factor=self.scaling_factor)
+        if swt_feature_image is None:
+            swt_feature_image = self.get_swt_features_image(image_path)
+        text_lines = writer.page_object.get_textlines()
+        values = self.line_values(text_lines, writer.scaling_factor, net_output_post, swt_feature_image)
+        return apply_heading_values(writer, text_lines, values, self.weight_dict, self.threshold, self.thresh_dict,
+                                    self.text_line_percentage, page_path + ".xml")
 
     def heading_probability(self, image):
         """decoded image -> uint8 net output [h,w,n_cls] at the scaled size (:285-288), device resident in between."""
@@ -245,20 +289,51 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
         new_page_objects = []
         # images are decoded ahead of the GPU by worker processes when host_workers > 1 (host_pipeline.py); the fusion
         # itself needs the device again (per-line statistics), so the PAGE-XML part stays in this process
-        from .host_pipeline import DecodePool, pin_callbacks
-        pipelined = getattr(self, "host_workers", 0) > 1
+        from .host_pipeline import DecodePool, WritePool, pin_callbacks
+        from .net_post_processing_helper import get_scaling_factor
+        pipelined = getattr(self, "host_workers", 0) > 1 and not self.keep_outputs
         reg, unreg = pin_callbacks(self.device) if pipelined else (None, None)
-        for image_path, image in DecodePool(self.image_paths, self.host_workers if pipelined else 0, register=reg,
-                                            unregister=unreg):
-            if self.weight_dict['net'] > 0:
-                net_output = self.heading_probability(image)
-                net_output_post = self.post_process(net_output)
-                if self.keep_outputs:
-                    self.net_outputs.append(net_output)
-                    self.net_outputs_post.append(net_output_post)
-            else:
-                net_output_post = None
-            swt_feature_image = self.SWT.distance_transform(image, on_device=True)
-            new_page_objects.append(self.to_page_xml(get_page_path(image_path), image_path, net_output_post,
-                                                     swt_feature_image))
+        n_workers = self.host_workers if pipelined else 0
+        geometry = {}                                        # page path -> future of read_line_geometry, a few pages ahead
+        with WritePool(n_workers) as writers:
+            if pipelined:
+                from concurrent.futures import ProcessPoolExecutor
+                import multiprocessing as mp
+                parsers = ProcessPoolExecutor(max(1, n_workers // 4), mp_context=mp.get_context("spawn"))
+            try:
+                ahead = iter(self.image_paths)
+
+                def prefetch_geometry(k):
+                    for _ in range(k):
+                        nxt = next(ahead, None)
+                        if nxt is not None:
+                            geometry[nxt] = parsers.submit(read_line_geometry, get_page_path(nxt))
+                if pipelined:
+                    prefetch_geometry(2 * n_workers)
+                for image_path, image in DecodePool(self.image_paths, n_workers, register=reg, unregister=unreg):
+                    if self.weight_dict['net'] > 0:
+                        net_output = self.heading_probability(image)
+                        net_output_post = self.post_process(net_output)
+                        if self.keep_outputs:
+                            self.net_outputs.append(net_output)
+                            self.net_outputs_post.append(net_output_post)
+                    else:
+                        net_output_post = None
+                    swt_feature_image = self.SWT.distance_transform(image, on_device=True)
+                    page_path = get_page_path(image_path)
+                    lines = geometry.pop(image_path).result() if pipelined else None
+                    if pipelined:
+                        prefetch_geometry(1)
+                    if lines is None:                       # inline, or no PAGE-XML yet (the writer creates one)
+                        new_page_objects.append(self.to_page_xml(page_path, image_path, net_output_post, swt_feature_image))
+                        continue
+                    # the GPU owner only measures; parsing happened in a worker, fusion + tags + XML go to a worker
+                    sc = get_scaling_factor(image.shape[0], image.shape[1], self.scaling_factor, self.fixed_height)
+                    values = self.line_values([LineGeometry(i, p) for i, p in lines], sc, net_output_post, swt_feature_image)
+                    writers.submit(write_heading_page, page_path, image_path, self.fixed_height, self.scaling_factor,
+                                   [{k: float(v) for k, v in d.items()} for d in values], self.weight_dict, self.threshold,
+                                   self.thresh_dict, self.text_line_percentage)
+            finally:
+                if pipelined:
+                    parsers.shutdown()
         return new_page_objects

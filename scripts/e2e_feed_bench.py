@@ -59,6 +59,42 @@ def main():
                   f"({dt / n_run * 1e3:6.1f} ms/page incl. worker start-up); GPU owner: device stages {proc.device_seconds / dt:5.1%} "
                   f"({proc.device_seconds / n_run * 1e3:.1f} ms/page), waiting for decoded images {proc.wait_seconds / dt:5.1%}, "
                   f"rings + hand-over {proc.host_seconds / dt:5.1%}; {n_xml} PAGE-XML files written")
+        # ---- heading mode: needs PAGE-XML with text lines; parsing and writing happen in workers, the owner measures ----
+        from citlab_article_separation_new_amd.heading_net_post_processor import HeadingNetPostProcessor
+        rng = np.random.default_rng(0)
+        colw = (W - 120 - 5 * 40) // 6
+        for k in range(n_pages):
+            regs, rid = [], 0
+            for c in range(6):
+                x0, y = 60 + c * (colw + 40), 60
+                while y < H - 300:
+                    nl, pitch = int(rng.integers(4, 13)), int(rng.integers(28, 37))
+                    y1 = y + nl * pitch
+                    lines = "".join(
+                        f'<TextLine id="r{rid}l{i}"><Coords points="{x0},{y + i * pitch} {x0 + colw},{y + i * pitch} '
+                        f'{x0 + colw},{y + (i + 1) * pitch - 4} {x0},{y + (i + 1) * pitch - 4}"/>'
+                        f'<Baseline points="{x0},{y + (i + 1) * pitch - 8} {x0 + colw},{y + (i + 1) * pitch - 8}"/></TextLine>'
+                        for i in range(nl))
+                    regs.append(f'<TextRegion id="r{rid}"><Coords points="{x0},{y} {x0 + colw},{y} {x0 + colw},{y1} {x0},{y1}"/>'
+                                + lines + '</TextRegion>')
+                    rid += 1
+                    y = y1 + int(rng.integers(20, 60))
+            with open(os.path.join(tmp, "page", f"p{k:03d}.xml"), "w") as f:
+                f.write('<?xml version="1.0" encoding="UTF-8"?>\n<PcGts xmlns="http://schema.primaresearch.org/PAGE/gts/'
+                        'pagecontent/2013-07-15"><Metadata><Creator>t</Creator><Created>2020-01-01T00:00:00</Created>'
+                        '<LastChange>2020-01-01T00:00:00</LastChange></Metadata>'
+                        f'<Page imageFilename="x.png" imageWidth="{W}" imageHeight="{H}">' + "".join(regs) + '</Page></PcGts>')
+        wd = {'net': 0.8, 'stroke_width': 0.0, 'text_height': 0.2}
+        td = {'net_thresh': 1.0, 'stroke_width_thresh': 1.0, 'text_height_thresh': 0.9, 'sw_th_thresh': 0.9}
+        for hw in (0, workers):
+            proc = HeadingNetPostProcessor(paths if hw else paths[:16], graph, 900, 1.0, wd, 0.4, td, 0.8)
+            proc.host_workers = hw
+            t0 = time.perf_counter()
+            proc.run(gpu_device="0")
+            dt = time.perf_counter() - t0
+            n_run = len(proc.image_paths)
+            print(f"heading CLI path, fixed_height 900 (default), host_workers {hw:2d}: {n_run / dt:6.2f} pages/s "
+                  f"({dt / n_run * 1e3:6.1f} ms/page incl. worker start-up)")
         # ---- seam: get_net_output on host arrays (float64 in, float32 out), page-locked staging ----
         img = (base[0] / 255.0)
         helper.get_net_output(img, graph, "0")

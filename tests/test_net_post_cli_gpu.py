@@ -133,3 +133,33 @@ def test_heading_cli_matches_stepwise_reference_sequence(tmp_path):
     hp = HeadingNetPostProcessor([str(data / "p0.png")], pb, 450, 1.0)
     assert np.array_equal(hp.heading_probability(img), net_u8)
     assert np.array_equal(hp.SWT.distance_transform(img), swt)
+
+
+@pytest.mark.parametrize("mode", ["separator", "heading"])
+def test_host_workers_write_the_same_files_as_the_inline_run(tmp_path, mode):
+    """--num_processes = host workers around the GPU owner (host_pipeline.py): images decoded ahead into page-locked
+    shared-memory slots, PAGE-XML parsed / written by worker processes.  The files must equal those of the inline run."""
+    import re
+    import shutil
+    from citlab_article_separation_new_amd import run_net_post_processing as cli
+    from citlab_article_separation_new_amd import synth
+    pb, _, data = _setup(tmp_path)
+    names = []
+    for k in range(5):                                       # five pages, different content
+        name = f"q{k}"
+        Image.fromarray(synth.synth_page(10 + k, W=600, H=900)).save(data / f"{name}.png")
+        shutil.copy(data / "page" / "p0.xml", data / "page" / f"{name}.xml")
+        names.append(name)
+    lst = tmp_path / "five.lst"
+    lst.write_text("\n".join(str(data / f"{n}.png") for n in names) + "\n")
+    outs = {}
+    for workers in (1, 6):
+        assert cli.main(["--path_to_image_list", str(lst), "--path_to_pb", pb, "--mode", mode, "--fixed_height", "450",
+                         "--threshold", "0.5", "--num_processes", str(workers)]) == 0
+        outs[workers] = {}
+        for n in names:
+            f = data / "page" / f"{n}.xml.xml"
+            outs[workers][n] = re.sub(r"<LastChange>[^<]*</LastChange>", "", f.read_text())
+            f.unlink()
+    assert outs[1] == outs[6]
+    assert any("SeparatorRegion" in v or "heading" in v for v in outs[6].values())
