@@ -7,6 +7,7 @@
 
 #include "aru_kernels.h"
 #include "res8_kernels.h"
+#include "res8v_kernels.h"
 #include "asep_common.h"
 
 using namespace asep;
@@ -55,6 +56,11 @@ struct asep_aru {
     float* d_r8_up_wr = nullptr;     // [3][6][64][4]
     float* d_r8_up_br = nullptr;     // [3][8]
     float* d_r8_up_b1 = nullptr;     // [8]
+    // the same filters in scalar layout for the fp32 vector-ALU kernels (res8v_kernels.h)
+    float* d_r8v_down_wr = nullptr;  // [3][576]
+    float* d_r8v_up_w1 = nullptr;    // [2][576]
+    float* d_r8v_up_wr = nullptr;    // [3][576]
+    bool r8_valu = true;             // fp32 only; ASEP_R8_VALU=0 runs the fp32 MFMA variants instead
     bool use_fused8 = true;          // ASEP_FUSED8=0 falls back to the layer-by-layer kernels
     float* d_att_head = nullptr;     // A fragment of attPart/conv1 for att_head_kernel (12 output channels, 4x4 taps)
     float* d_logit_w = nullptr;
@@ -510,51 +516,72 @@ void pack_pair8(const HostTensor& w, int cin, int ci0, std::vector<float>& dst) 
                 }
 }
 
+// scalar layout of a 3x3 conv with 8 input channels starting at input channel ci0 of W[3][3][cin][8] (res8v_kernels.h):
+// [g = (ky*2 + hf)*3 + kx][c][co], input channel ci0 + hf*4 + c
+void pack_scalar8(const HostTensor& w, int cin, int ci0, std::vector<float>& dst) {
+    for (int g = 0; g < 18; ++g) {
+        const int ky = g / 6, hf = (g / 3) % 2, kx = g % 3;
+        for (int c = 0; c < 4; ++c)
+            for (int co = 0; co < 8; ++co) dst.push_back(w.data[(((size_t)ky * 3 + kx) * cin + ci0 + hf * 4 + c) * 8 + co]);
+    }
+}
+
 int pack_res8(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
     const std::string s = "aru_net/featMapG/unet_down_0";
-    std::vector<float> wr, br;
+    std::vector<float> wr, br, vwr;
     for (int r = 0; r < 3; ++r) {
         auto wi = blob.find(s + "/convR_" + std::to_string(r) + "/weights");
         auto bi = blob.find(s + "/convR_" + std::to_string(r) + "/biases");
         if (wi == blob.end() || bi == blob.end()) { set_error("weights: missing %s/convR_%d", s.c_str(), r); return ASEP_ERR_WEIGHTS; }
         pack_pair8(wi->second, 8, 0, wr);
+        pack_scalar8(wi->second, 8, 0, vwr);
         br.insert(br.end(), bi->second.data.begin(), bi->second.data.end());
     }
     int rc = upload(wr, &m->d_r8_down_wr);
     if (!rc) rc = upload(br, &m->d_r8_down_br);
+    if (!rc) rc = upload(vwr, &m->d_r8v_down_wr);
     if (rc) return rc;
     m->owned.push_back(m->d_r8_down_wr);
     m->owned.push_back(m->d_r8_down_br);
+    m->owned.push_back(m->d_r8v_down_wr);
     if (m->cfg.scale_space_num > 1) {
         const std::string u = "aru_net/featMapG/unet_up_0";
         auto w1 = blob.find(u + "/conv1/weights");
         auto b1 = blob.find(u + "/conv1/biases");
         if (w1 == blob.end() || b1 == blob.end()) { set_error("weights: missing %s/conv1", u.c_str()); return ASEP_ERR_WEIGHTS; }
-        std::vector<float> pw1, pwr, pbr;
+        std::vector<float> pw1, pwr, pbr, vw1, vwr2;
         pack_pair8(w1->second, 16, 0, pw1);      // skip channels 0..7
         pack_pair8(w1->second, 16, 8, pw1);      // deconv channels 8..15
+        pack_scalar8(w1->second, 16, 0, vw1);
+        pack_scalar8(w1->second, 16, 8, vw1);
         for (int r = 0; r < 3; ++r) {
             auto wi = blob.find(u + "/convR_" + std::to_string(r) + "/weights");
             auto bi = blob.find(u + "/convR_" + std::to_string(r) + "/biases");
             if (wi == blob.end() || bi == blob.end()) { set_error("weights: missing %s/convR_%d", u.c_str(), r); return ASEP_ERR_WEIGHTS; }
             pack_pair8(wi->second, 8, 0, pwr);
+            pack_scalar8(wi->second, 8, 0, vwr2);
             pbr.insert(pbr.end(), bi->second.data.begin(), bi->second.data.end());
         }
         rc = upload(pw1, &m->d_r8_up_w1);
         if (!rc) rc = upload(pwr, &m->d_r8_up_wr);
         if (!rc) rc = upload(pbr, &m->d_r8_up_br);
         if (!rc) rc = upload(b1->second.data, &m->d_r8_up_b1);
+        if (!rc) rc = upload(vw1, &m->d_r8v_up_w1);
+        if (!rc) rc = upload(vwr2, &m->d_r8v_up_wr);
         if (rc) return rc;
+        m->owned.push_back(m->d_r8v_up_w1); m->owned.push_back(m->d_r8v_up_wr);
         m->owned.push_back(m->d_r8_up_w1); m->owned.push_back(m->d_r8_up_wr);
         m->owned.push_back(m->d_r8_up_br); m->owned.push_back(m->d_r8_up_b1);
         if (hipFuncSetAttribute((const void*)res8_up_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)res8_up_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess) {
+            hipFuncSetAttribute((const void*)res8_up_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)res8v_up_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess) {
             set_error("cannot reserve %zu bytes of LDS for the fused up block", R8_UP_LDS);
             return ASEP_ERR_HIP;
         }
     }
     if (hipFuncSetAttribute((const void*)res8_down_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)res8_down_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess) {
+        hipFuncSetAttribute((const void*)res8_down_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)res8v_down_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess) {
         set_error("cannot reserve %zu bytes of LDS for the fused residual block", R8_DOWN_LDS);
         return ASEP_ERR_HIP;
     }
@@ -623,13 +650,15 @@ void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>&
         a.nprob = (int)(b1 - b0);
         a.total_tiles = tiles;
         a.w1 = m->det_first.d_w; a.b1 = m->det_first.d_b;
-        a.wr = (const f32x4*)m->d_r8_down_wr; a.br = m->d_r8_down_br;
+        const bool valu = m->r8_valu && !m->bf16;
+        a.wr = (const f32x4*)(valu ? m->d_r8v_down_wr : m->d_r8_down_wr); a.br = m->d_r8_down_br;
         TL sub(imgs.begin() + b0, imgs.begin() + b1);
-        std::string pname = "res8_down_kernel";
+        std::string pname = valu ? "res8v_down_kernel" : "res8_down_kernel";
         if (m->prof_detail) pname += " unet_down_0 (conv1+3xconvR+add+pool) " + dims_of(sub);
         ProfScope ps(m, pname, flops);
         a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH * R8_NP);
         if (m->bf16) hipLaunchKernelGGL(res8_down_kernel<true>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
+        else if (valu) hipLaunchKernelGGL(res8v_down_kernel, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
         else hipLaunchKernelGGL(res8_down_kernel<false>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
     }
 }
@@ -654,15 +683,17 @@ TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
         }
         a.nprob = (int)(b1 - b0);
         a.total_tiles = tiles;
-        a.w1 = m->d_r8_up_w1; a.b1 = m->d_r8_up_b1;
-        a.wr = (const f32x4*)m->d_r8_up_wr; a.br = m->d_r8_up_br;
+        const bool valu = m->r8_valu && !m->bf16;
+        a.w1 = valu ? m->d_r8v_up_w1 : m->d_r8_up_w1; a.b1 = m->d_r8_up_b1;
+        a.wr = (const f32x4*)(valu ? m->d_r8v_up_wr : m->d_r8_up_wr); a.br = m->d_r8_up_br;
         TL sub(skip.begin() + b0, skip.begin() + b1);
-        std::string pname = "res8_up_kernel";
+        std::string pname = valu ? "res8v_up_kernel" : "res8_up_kernel";
         if (m->prof_detail) pname += " unet_up_0 (conv1[16->8]+3xconvR+add) " + dims_of(sub);
         ProfScope ps(m, pname, flops);
         a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH * R8_NP);
         const dim3 grid(std::min(tiles, m->num_cus));
         if (m->bf16) hipLaunchKernelGGL(res8_up_kernel<true>, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
+        else if (valu) hipLaunchKernelGGL(res8v_up_kernel, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
         else hipLaunchKernelGGL(res8_up_kernel<false>, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
     }
     return out;
@@ -966,6 +997,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO_REG")) m->wino_reg = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_R8_VALU")) m->r8_valu = atoi(e) != 0;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BIGTILE")) m->big_tile = atoi(e) != 0;
     if (const char* e = getenv("ASEP_SIDE_STREAM")) m->use_side_stream = atoi(e) != 0;

@@ -50,7 +50,7 @@ struct Res8Args {
     int nprob, total_tiles;
     const float* w1;       // DOWN: conv1 [9][8] ; UP: packed pair-fragments of conv1 (12 chunks x 64 lanes x 4)
     const float* b1;       // [8]
-    const f32x4* wr;       // convR_0..2 packed pair-fragments: [3][6 chunks][64 lanes] x 4
+    const f32x4* wr;       // convR_0..2 packed pair-fragments: [3][6 chunks][64 lanes] x 4 (res8v_kernels.h: scalar layout, see there)
     const float* br;       // [3][8]
     const int32_t* sched;  // XCD-aware schedule: the k-th unit of work (k = blockIdx.x + i * gridDim.x) is tile
                            // sched[k]; nullptr = identity.  Blocks are dealt round-robin to the 8 XCDs, so the table

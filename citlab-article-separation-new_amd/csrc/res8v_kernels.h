@@ -1,0 +1,432 @@
+// Fused level-0 residual blocks of the ARU-Net in fp32 on the VECTOR ALU (ARU_v1.py:208-245 and :266-281).
+//
+// Same tiling, LDS buffers and pass structure as res8_kernels.h (16 x 58 pixel output tiles, R8_NP carried passes), but
+// every 3x3 8->8 convolution runs as packed FMAs instead of v_mfma_f32_16x16x4_f32.  Eight output channels fill half of a
+// 16-row MFMA tile (the pixel-pair mapping recovers 75 %: 6.1 k cycles of MFMA issue per 16 x 64 pixel stage, 7.5-8.2 k
+// measured), while v_pk_fma_f32 has no such granularity and the f32 vector peak of gfx950 equals the f32 matrix peak
+// (157 TFLOP/s).  A thread owns two horizontally adjacent pixels x 8 output channels; a weight pair (two output channels
+// of one (tap, input channel)) is a scalar register pair, the input value is broadcast to both halves (op_sel_hi), so
+// one v_pk_fma_f32 = 2 output channels x 64 lanes and a stage is 576 of them per thread: 4.6 k cycles per stage at
+// 4 cycles per instruction (scripts/ubench/pk_fma_issue.hip measures 4.38 at two waves per SIMD), 6.1 k measured
+// (scripts/ubench/valu_conv8.hip).  bf16 keeps the MFMA kernels (res8_kernels.h): there the matrix rate is 8x the vector rate.
+#pragma once
+#include "res8_kernels.h"
+
+namespace asep {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef const float __attribute__((address_space(4)))* r8v_cptr;   // constant address space: stays on s_load
+
+constexpr int R8V_FILTER = 576;     // floats per 8->8 filter in scalar layout [g = (ky*2 + hf)*3 + kx][c = ci & 3][co], ci = hf*4 + c
+
+// The kernels take Res8Args like the MFMA kernels; the filters behind w1 (UP) and wr are in scalar layout instead of
+// pixel-pair fragments: UP w1 = [2 sources][R8V_FILTER], wr = [3][R8V_FILTER] floats.
+
+// acc[px][2q..2q+1] += sum over the 3x3 window and 8 input channels, for the thread's two pixels.  in0 = LDS address of
+// the first input row (output row - 1), off[i][hf] = float offset of (pixel x - 1 + i, channel half hf) inside a row.
+//
+// Explicit software pipeline: scalar loads return out of order, so every wait on them is lgkmcnt(0) and covers the LDS
+// reads as well.  Per weight group (16 scalars = 2 input channels x 8 output channels, 16 packed FMAs) there is ONE wait,
+// placed first (the empty asm "uses" the group's registers), and only then are the next group's weights and the next
+// row-half's four input pieces requested; left to the compiler the request goes out BEFORE the wait, which then covers
+// it.  The double buffer is 2 x 16 SGPRs: the kernels carry ~40 scalars of their own and the file has 102 (with 2 x 32
+// the allocator spilled weights to VGPR lanes, thousands of v_readlane); the stage time is the same (6.0 k cycles).
+template <bool RELU_IN>
+__device__ __forceinline__ void r8v_conv(const float* __restrict__ in0, const int (&off)[4][2], r8v_cptr wl,
+                                         f32x2 (&acc0)[4], f32x2 (&acc1)[4]) {
+    float wc[16], wn[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wc[k] = wl[k];
+    f32x4 dA[4], dB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dA[i] = *reinterpret_cast<const f32x4*>(in0 + off[i][0]);
+#pragma unroll
+    for (int g2 = 0; g2 < 36; ++g2) {
+        const int g = g2 >> 1, ch = g2 & 1, kx = g % 3, rh = g / 3;           // rh = ky * 2 + hf
+        asm volatile("" :: "s"(wc[0]), "v"(dA[0]), "v"(dA[1]), "v"(dA[2]), "v"(dA[3]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (g2 + 1 < 36) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) wn[k] = wl[(g2 + 1) * 16 + k];
+        }
+        if (kx == 0 && ch == 0 && rh + 1 < 6) {
+            const int ky2 = (rh + 1) >> 1, hf2 = (rh + 1) & 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dB[i] = *reinterpret_cast<const f32x4*>(in0 + ky2 * R8_PITCH * 8 + off[i][hf2]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (RELU_IN && kx == 0 && ch == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dA[i] = relu4i(dA[i]);
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int c = ch * 2 + c2;
+            const f32x2 a0 = f32x2{dA[kx][c], dA[kx][c]}, a1 = f32x2{dA[kx + 1][c], dA[kx + 1][c]};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x2 wv = f32x2{wc[c2 * 8 + 2 * q], wc[c2 * 8 + 2 * q + 1]};
+                acc0[q] = __builtin_elementwise_fma(a0, wv, acc0[q]);
+                acc1[q] = __builtin_elementwise_fma(a1, wv, acc1[q]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wc[k] = wn[k];
+        if (kx == 2 && ch == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dA[i] = dB[i];
+        }
+    }
+    // pin the accumulators here: without a use in this block the compiler SINKS all 576 FMAs past the next branch (to the
+    // first use of the sums), away from their weights, which it then parks in VGPR lanes (thousands of v_readlane)
+    asm volatile("" : "+v"(acc0[0]), "+v"(acc0[1]), "+v"(acc0[2]), "+v"(acc0[3]), "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]));
+}
+
+__device__ __forceinline__ f32x4 r8v_lo(const f32x2 (&a)[4]) { return f32x4{a[0].x, a[0].y, a[1].x, a[1].y}; }
+__device__ __forceinline__ f32x4 r8v_hi(const f32x2 (&a)[4]) { return f32x4{a[2].x, a[2].y, a[3].x, a[3].y}; }
+__device__ __forceinline__ f32x4 r8v_max4(f32x4 a, f32x4 b) { return f32x4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)}; }
+__device__ __forceinline__ f32x4 r8v_upper4(f32x4 v) {
+    return f32x4{from_upper_half(v.x), from_upper_half(v.y), from_upper_half(v.z), from_upper_half(v.w)};
+}
+
+// one 3x3 8->8 convolution stage on LDS tiles.  IN holds rows in_r0.. of the frame, OUT rows out_r0.. ; computes rows
+// [row_start, row_start + nrows) x columns [out_c0, out_c0 + 64): thread -> (row tid >> 5 (+16), pixels out_c0 + 2 (tid & 31), +1).
+// FINAL: add T centre, ReLU, store the OW valid columns to global (+ 2x2 max pool).  Otherwise ReLU into OUT, zero outside
+// the image (= the SAME padding of the next convolution).
+template <bool RELU_IN, bool FINAL, bool POOL>
+__device__ __forceinline__ void res8v_stage(const float* __restrict__ IN, int in_r0, float* __restrict__ OUT, int out_r0,
+                                            int row_start, int nrows, int out_c0, const float* __restrict__ w,
+                                            const float* __restrict__ bias, int tid, int fy0, int fx0, int H, int W,
+                                            const float* __restrict__ T, int t_r0, float* __restrict__ gout, float* __restrict__ gpool) {
+    const int x = out_c0 + 2 * (tid & 31);
+    int off[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { off[i][0] = r8_px(x - 1 + i, 0); off[i][1] = r8_px(x - 1 + i, 1); }
+    const int gx = fx0 + x;
+#pragma unroll 1
+    for (int r = tid >> 5; r < nrows; r += 16) {
+        r8v_cptr wl = (r8v_cptr)w, bl = (r8v_cptr)bias;
+        asm volatile("" : "+s"(wl));                  // the loads stay inside the loop (hoisted they would be spilled to VGPR lanes)
+        f32x2 acc0[4], acc1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc0[q] = f32x2{bl[2 * q], bl[2 * q + 1]}; acc1[q] = acc0[q]; }
+        const int row = row_start + r;               // frame row
+        r8v_conv<RELU_IN>(IN + (row - 1 - in_r0) * R8_PITCH * 8, off, wl, acc0, acc1);
+        const int gy = fy0 + row;
+        f32x4 p0l = r8v_lo(acc0), p0h = r8v_hi(acc0), p1l = r8v_lo(acc1), p1h = r8v_hi(acc1);
+        if (!FINAL) {
+            const bool oky = gy >= 0 && gy < H;
+            const bool ok0 = oky && gx >= 0 && gx < W, ok1 = oky && gx + 1 >= 0 && gx + 1 < W;
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            float* o = OUT + (row - out_r0) * R8_PITCH * 8;
+            *reinterpret_cast<f32x4*>(o + off[1][0]) = ok0 ? relu4i(p0l) : z;
+            *reinterpret_cast<f32x4*>(o + off[1][1]) = ok0 ? relu4i(p0h) : z;
+            *reinterpret_cast<f32x4*>(o + off[2][0]) = ok1 ? relu4i(p1l) : z;
+            *reinterpret_cast<f32x4*>(o + off[2][1]) = ok1 ? relu4i(p1h) : z;
+        } else {
+            const float* tp = T + (row - t_r0) * R8_PITCH * 8;
+            p0l = relu4i(p0l + *reinterpret_cast<const f32x4*>(tp + off[1][0]));
+            p0h = relu4i(p0h + *reinterpret_cast<const f32x4*>(tp + off[1][1]));
+            p1l = relu4i(p1l + *reinterpret_cast<const f32x4*>(tp + off[2][0]));
+            p1h = relu4i(p1h + *reinterpret_cast<const f32x4*>(tp + off[2][1]));
+            // only the OW valid columns of the tile (frame columns 4 .. 4+OW-1) are stored; gy >= 0 and gx >= 0 there
+            const bool oky = gy < H;
+            const bool ok0 = x >= 4 && x < 4 + R8_OW && gx < W, ok1 = x + 1 >= 4 && x + 1 < 4 + R8_OW && gx + 1 < W;
+            float* o = gout + ((size_t)gy * W + gx) * 8;
+            if (ok0 && oky) { *reinterpret_cast<f32x4*>(o) = p0l; *reinterpret_cast<f32x4*>(o + 4) = p0h; }
+            if (ok1 && oky) { *reinterpret_cast<f32x4*>(o + 8) = p1l; *reinterpret_cast<f32x4*>(o + 12) = p1h; }
+            if (POOL && gpool) {
+                // 2x2 max: the x neighbour is the thread's second pixel (gx is even), the row below sits in lane + 32
+                // (gy is even for lanes < 32: a wave holds rows 2 * wave and 2 * wave + 1); windows never straddle tiles
+                f32x4 ml = ok1 ? r8v_max4(p0l, p1l) : p0l, mh = ok1 ? r8v_max4(p0h, p1h) : p0h;
+                const f32x4 ul = r8v_upper4(ml), uh = r8v_upper4(mh);     // only lanes < 32 use it
+                if ((tid & 32) == 0 && ok0 && oky) {
+                    if (gy + 1 < H) { ml = r8v_max4(ml, ul); mh = r8v_max4(mh, uh); }
+                    const int Wp = (W + 1) >> 1;
+                    float* po = gpool + ((size_t)(gy >> 1) * Wp + (gx >> 1)) * 8;
+                    *reinterpret_cast<f32x4*>(po) = ml;
+                    *reinterpret_cast<f32x4*>(po + 4) = mh;
+                }
+            }
+        }
+    }
+}
+
+// DOWN block of level 0: image (1 channel) -> d0 [H,W,8] (+ maxpool2)
+__global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void res8v_down_kernel(const Res8Args a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const float* wr = reinterpret_cast<const float*>(a.wr);
+    float* IMG = sm;                                         // [24][76]
+    float* T = IMG + R8_FH * R8_IMGP;                        // frame rows 1..22  [22][72][8]
+    float* R0 = T + 22 * R8_PITCH * 8;                       // frame rows 2..21  [20][72][8]
+    float* R1 = R0 + 20 * R8_PITCH * 8;                      // frame rows 3..20  [18][72][8]
+    __shared__ float w1s[9 * 8 + 8];
+    const int tid = threadIdx.x;
+    if (tid < 72) w1s[tid] = a.w1[tid];
+    if (tid < 8) w1s[72 + tid] = a.b1[tid];
+
+    constexpr int NPRE = (R8_FH * R8_IMGP + R8_THREADS - 1) / R8_THREADS;
+    float pre[NPRE], pre_mean = 0.f, pre_inv = 1.f;
+    unsigned pre_mask = 0;
+    // frame = one 24-row window of a work unit: (tile, pass) -> image rows [(tyb * NP + pass) * OH - 4, +24)
+    auto image_load = [&](int tile_id, int pass) {          // next frame's image values -> registers (in flight under the stages)
+        int pi = 0;
+        while (pi + 1 < a.nprob && tile_id >= a.p[pi + 1].tile_begin) ++pi;
+        const Res8Prob& Q = a.p[pi];
+        const int t = tile_id - Q.tile_begin;
+        const int tyb = t / Q.tiles_x, txb = t - tyb * Q.tiles_x;
+        const int qy0 = (tyb * R8_NP + pass) * R8_OH - 4, qx0 = txb * R8_OW - 4;
+        // the standardisation is applied when the registers are written to LDS, not here (arithmetic on the loaded value
+        // would make this phase wait for the loads it has only just issued)
+        pre_mean = 0.f; pre_inv = 1.f; pre_mask = 0;
+        if (Q.stats) { pre_mean = Q.stats[0]; pre_inv = Q.stats[1]; }
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) {
+            const int i = tid + k * R8_THREADS;
+            const int r = i / R8_IMGP, c = i - r * R8_IMGP;
+            const int gy = qy0 + r, gx = qx0 + c - 2;
+            const bool ok = i < R8_FH * R8_IMGP && gy >= 0 && gy < Q.H && gx >= 0 && gx < Q.W;
+            pre[k] = Q.img[(size_t)min(max(gy, 0), Q.H - 1) * Q.W + min(max(gx, 0), Q.W - 1)];   // clamped: always a valid address
+            pre_mask |= (ok ? 1u : 0u) << k;
+        }
+    };
+    int tile_id = (int)blockIdx.x < a.total_tiles ? res8_tile_of(a, blockIdx.x) : 0;
+    if ((int)blockIdx.x < a.total_tiles) image_load(tile_id, 0);
+
+    for (int k = blockIdx.x; k < a.total_tiles; k += gridDim.x) {
+        const bool has_next = k + (int)gridDim.x < a.total_tiles;
+        const int next_id = has_next ? res8_tile_of(a, k + gridDim.x) : 0;   // requested a whole tile ahead of its use
+        int pi = 0;
+        while (pi + 1 < a.nprob && tile_id >= a.p[pi + 1].tile_begin) ++pi;
+        const Res8Prob& P = a.p[pi];
+        const int t = tile_id - P.tile_begin;
+        const int tyb = t / P.tiles_x, txb = t - tyb * P.tiles_x;
+        const int H = P.H, W = P.W;
+        const int fx0 = txb * R8_OW - 4;
+#pragma unroll 1
+        for (int pass = 0; pass < R8_NP; ++pass) {
+            const int fy0 = (tyb * R8_NP + pass) * R8_OH - 4;        // image coordinates of frame (0,0)
+            if (fy0 + 4 >= H) break;                                 // no output rows left in this unit
+            const bool more_passes = pass + 1 < R8_NP && fy0 + 4 + R8_OH < H;
+            const bool first = pass == 0;
+            __syncthreads();                                 // previous pass / tile finished with all LDS buffers
+            if (!first) {
+                // rows carried over from the pass above (frame rows shift by OH = 16):
+                //   t  rows 20..22 -> 4..6,   r0 rows 20,21 -> 4,5,   r1 rows 19,20 -> 3,4
+                constexpr int ROWV = R8_PITCH * 2;                   // f32x4 per row
+                for (int i = tid; i < 7 * ROWV; i += R8_THREADS) {
+                    const int r = i / ROWV, c = i - r * ROWV;
+                    f32x4* base = reinterpret_cast<f32x4*>(r < 3 ? T : (r < 5 ? R0 : R1));
+                    const int src = r < 3 ? 19 + r : (r < 5 ? 18 + (r - 3) : 16 + (r - 5));
+                    const int dst = r < 3 ? 3 + r : (r < 5 ? 2 + (r - 3) : (r - 5));
+                    base[dst * ROWV + c] = base[src * ROWV + c];
+                }
+            }
+            // ---- image tile: frame rows 0..23, frame columns -2..73 (zero outside the image = SAME padding) ----
+#pragma unroll
+            for (int q = 0; q < NPRE; ++q) {
+                const int i = tid + q * R8_THREADS;
+                if (i < R8_FH * R8_IMGP) IMG[i] = ((pre_mask >> q) & 1u) ? (pre[q] - pre_mean) * pre_inv : 0.f;
+            }
+            __syncthreads();
+            // ---- t = conv1(image) (identity activation): frame rows 1..22 (first pass) or the 16 new rows 7..22 ----
+            const int t_lo = first ? 0 : 6 * R8_PITCH;
+            for (int i = t_lo + tid; i < 22 * R8_PITCH; i += R8_THREADS) {
+                const int r = i / R8_PITCH, c = i - r * R8_PITCH;   // frame row r+1, frame column c
+                const int gy = fy0 + r + 1, gx = fx0 + c;
+                float acc[8];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) acc[o] = w1s[72 + o];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float v = IMG[(r + ky) * R8_IMGP + c + kx + 1];       // frame (r+1+ky-1, c+kx-1) -> IMG col +2
+#pragma unroll
+                        for (int o = 0; o < 8; ++o) acc[o] = fmaf(v, w1s[(ky * 3 + kx) * 8 + o], acc[o]);
+                    }
+                const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                f32x4 lo = ok ? f32x4{acc[0], acc[1], acc[2], acc[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 hi = ok ? f32x4{acc[4], acc[5], acc[6], acc[7]} : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(T + r * R8_PITCH * 8 + r8_px(c, 0)) = lo;
+                *reinterpret_cast<f32x4*>(T + r * R8_PITCH * 8 + r8_px(c, 1)) = hi;
+            }
+            __syncthreads();
+            res8v_stage<true, false, false>(T, 1, R0, 2, first ? 2 : 6, first ? 20 : 16, 2, wr, a.br, tid, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            __syncthreads();
+            res8v_stage<false, false, false>(R0, 2, R1, 3, first ? 3 : 5, first ? 18 : 16, 3, wr + R8V_FILTER, a.br + 8, tid, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            __syncthreads();
+            if (more_passes) image_load(tile_id, pass + 1);
+            else if (has_next) image_load(next_id, 0);
+            res8v_stage<false, true, true>(R1, 3, nullptr, 4, 4, 16, 4, wr + 2 * R8V_FILTER, a.br + 16, tid, fy0, fx0, H, W, T, 1, P.out, P.pool);
+        }
+        tile_id = next_id;
+    }
+}
+
+// UP block of level 0 (ARU_v1.py:262-281): t = conv1(concat[skip, deconv]) ; 3 x convR ; + t ; ReLU.
+// The 16-channel concatenation is consumed as two 8-channel passes through one LDS input tile (skip, then the
+// deconvolution output) that accumulate into the same registers; afterwards that tile buffer holds r1.
+__global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void res8v_up_kernel(const Res8Args a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const float* wr = reinterpret_cast<const float*>(a.wr);
+    float* Pb = sm;                                          // frame rows 0..23  [24][72][8]  (later r1: rows 3..20)
+    float* T = Pb + R8_FH * R8_PITCH * 8;                    // frame rows 1..22  [22][72][8]
+    float* R0 = T + 22 * R8_PITCH * 8;                       // frame rows 2..21  [20][72][8]
+    float* R1K = R0 + 20 * R8_PITCH * 8;                     // two r1 rows parked between passes [2][72][8]
+    int tid = threadIdx.x;
+    // halo tile loader: thread -> (row group rg = tid / 144, slot cs = tid % 144 = pixel column x 2 halves), rows rg + 3k:
+    // one division per pass, then a constant row stride (432 of the 512 threads load, 8 x 16 B each)
+    constexpr int ROWV = R8_PITCH * 2;                       // f32x4 per LDS row
+    constexpr int NPF = R8_FH / 3;
+    f32x4 pf[NPF];
+    int rg = tid / ROWV, cs = tid - rg * ROWV;
+    // carried: only frame rows 6..23 are needed (conv1 then reads rows 6..23 only), i.e. k >= 2
+    auto tile_load = [&](const float* __restrict__ g, int H_, int W_, int qy0, int qx0, bool carried) {   // 8-channel halo tile -> registers
+        const int gx = qx0 + (cs >> 1);
+        const bool okc = rg < 3 && gx >= 0 && gx < W_;
+        const float* __restrict__ gp = g + ((ptrdiff_t)gx * 8 + (cs & 1) * 4);
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            if (k < 2 && carried) continue;
+            const int gy = qy0 + rg + 3 * k;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (okc && gy >= 0 && gy < H_) v = *reinterpret_cast<const f32x4*>(gp + (ptrdiff_t)gy * W_ * 8);
+            pf[k] = v;
+        }
+    };
+    auto tile_store = [&](bool carried) {                    // registers -> tile buffer
+        if (rg < 3) {
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) {
+                if (k < 2 && carried) continue;
+                *reinterpret_cast<f32x4*>(Pb + (rg + 3 * k) * R8_PITCH * 8 + r8_px(cs >> 1, cs & 1)) = pf[k];
+            }
+        }
+    };
+    int tile_id = (int)blockIdx.x < a.total_tiles ? res8_tile_of(a, blockIdx.x) : 0;
+    if ((int)blockIdx.x < a.total_tiles) {
+        const int first_id = tile_id;
+        int qi = 0;
+        while (qi + 1 < a.nprob && first_id >= a.p[qi + 1].tile_begin) ++qi;
+        const Res8Prob& Q = a.p[qi];
+        const int tq = first_id - Q.tile_begin;
+        const int qyb = tq / Q.tiles_x, qxb = tq - qyb * Q.tiles_x;
+        tile_load(Q.img, Q.H, Q.W, qyb * R8_NP * R8_OH - 4, qxb * R8_OW - 4, false);
+    }
+    for (int k = blockIdx.x; k < a.total_tiles; k += gridDim.x) {
+        const bool has_next = k + (int)gridDim.x < a.total_tiles;
+        const int next_id = has_next ? res8_tile_of(a, k + gridDim.x) : 0;   // requested a whole tile ahead of its use
+        int pi = 0;
+        while (pi + 1 < a.nprob && tile_id >= a.p[pi + 1].tile_begin) ++pi;
+        const Res8Prob& P = a.p[pi];
+        const int t = tile_id - P.tile_begin;
+        const int tyb = t / P.tiles_x, txb = t - tyb * P.tiles_x;
+        const int H = P.H, W = P.W;
+        const int fx0 = txb * R8_OW - 4;
+#pragma unroll 1
+        for (int pass = 0; pass < R8_NP; ++pass) {
+            const int fy0 = (tyb * R8_NP + pass) * R8_OH - 4;
+            if (fy0 + 4 >= H) break;                         // no output rows left in this unit
+            const bool more_passes = pass + 1 < R8_NP && fy0 + 4 + R8_OH < H;
+            const bool first = pass == 0;
+            // conv1 covers frame rows 1..22 in the first pass and only the 16 new rows 7..22 afterwards
+            const int c1_row = first ? 1 : 7, c1_rows = first ? 22 : 16;
+            // everything derived from the thread index is recomputed per pass (hoisted out of the persistent loop it would
+            // occupy registers across the whole pass)
+            asm volatile("" : "+v"(tid));
+            rg = tid / ROWV; cs = tid - rg * ROWV;
+            const int r0 = tid >> 5;
+            const bool has2 = r0 + 16 < c1_rows;              // first pass: threads of rows 0..5 own a second row (16..21)
+            int off[4][2];                                    // conv1 output pixels: frame columns 1 + 2p, 2 + 2p
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { off[i][0] = r8_px(2 * (tid & 31) + i, 0); off[i][1] = r8_px(2 * (tid & 31) + i, 1); }
+            // t accumulators: [row slot][pixel][channel pair]; conv1's bias is the initial value
+            f32x2 ta0[4], ta1[4], tb0[4], tb1[4];
+            {
+                r8v_cptr bl = (r8v_cptr)a.b1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ta0[q] = f32x2{bl[2 * q], bl[2 * q + 1]}; ta1[q] = ta0[q]; tb0[q] = ta0[q]; tb1[q] = ta0[q]; }
+            }
+            // ---- conv1: skip half, then deconv half, out of the same tile buffer ----
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                __syncthreads();                             // the tile buffer is free (previous pass / tile / half done)
+                if (half == 0 && !first) {
+                    // rows carried over from the pass above: t rows 20..22 -> 4..6, r0 rows 20,21 -> 4,5
+                    // (r1 rows 19,20 were parked in R1K during the previous pass' last stage)
+                    for (int i = tid; i < 5 * ROWV; i += R8_THREADS) {
+                        const int r = i / ROWV, c = i - r * ROWV;
+                        f32x4* base = reinterpret_cast<f32x4*>(r < 3 ? T : R0);
+                        const int srow = r < 3 ? 19 + r : 18 + (r - 3), drow = r < 3 ? 3 + r : 2 + (r - 3);
+                        base[drow * ROWV + c] = base[srow * ROWV + c];
+                    }
+                }
+                tile_store(!first);
+                if (half == 0) tile_load(P.in1, H, W, fy0, fx0, !first);  // the deconv half flies while the skip half is multiplied
+                __syncthreads();
+                r8v_cptr wl = (r8v_cptr)(a.w1 + half * R8V_FILTER);
+                asm volatile("" : "+s"(wl));
+                r8v_conv<false>(Pb + (c1_row + r0 - 1) * R8_PITCH * 8, off, wl, ta0, ta1);
+                if (has2) {
+                    asm volatile("" : "+s"(wl));
+                    r8v_conv<false>(Pb + (c1_row + r0 + 15) * R8_PITCH * 8, off, wl, tb0, tb1);
+                }
+            }
+            // ---- write raw t (identity activation), zero outside the image ----
+            {
+                const int gx = fx0 + 1 + 2 * (tid & 31);
+                const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                {
+                    const int row = c1_row + r0, gy = fy0 + row;
+                    const bool oky = gy >= 0 && gy < H;
+                    const bool ok0 = oky && gx >= 0 && gx < W, ok1 = oky && gx + 1 >= 0 && gx + 1 < W;
+                    float* o = T + (row - 1) * R8_PITCH * 8;
+                    *reinterpret_cast<f32x4*>(o + off[1][0]) = ok0 ? r8v_lo(ta0) : z;
+                    *reinterpret_cast<f32x4*>(o + off[1][1]) = ok0 ? r8v_hi(ta0) : z;
+                    *reinterpret_cast<f32x4*>(o + off[2][0]) = ok1 ? r8v_lo(ta1) : z;
+                    *reinterpret_cast<f32x4*>(o + off[2][1]) = ok1 ? r8v_hi(ta1) : z;
+                }
+                if (has2) {
+                    const int row = c1_row + r0 + 16, gy = fy0 + row;
+                    const bool oky = gy >= 0 && gy < H;
+                    const bool ok0 = oky && gx >= 0 && gx < W, ok1 = oky && gx + 1 >= 0 && gx + 1 < W;
+                    float* o = T + (row - 1) * R8_PITCH * 8;
+                    *reinterpret_cast<f32x4*>(o + off[1][0]) = ok0 ? r8v_lo(tb0) : z;
+                    *reinterpret_cast<f32x4*>(o + off[1][1]) = ok0 ? r8v_hi(tb0) : z;
+                    *reinterpret_cast<f32x4*>(o + off[2][0]) = ok1 ? r8v_lo(tb1) : z;
+                    *reinterpret_cast<f32x4*>(o + off[2][1]) = ok1 ? r8v_hi(tb1) : z;
+                }
+            }
+            __syncthreads();
+            res8v_stage<true, false, false>(T, 1, R0, 2, first ? 2 : 6, first ? 20 : 16, 2, wr, a.br, tid, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            __syncthreads();
+            res8v_stage<false, false, false>(R0, 2, Pb, 3, first ? 3 : 5, first ? 18 : 16, 3, wr + R8V_FILTER, a.br + 8, tid, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            if (!first) {
+                // r1 rows 3,4 of this frame = rows 19,20 of the previous one (the tile buffer is free of conv1 readers here)
+                for (int i = tid; i < 2 * ROWV; i += R8_THREADS)
+                    reinterpret_cast<f32x4*>(Pb)[i] = reinterpret_cast<const f32x4*>(R1K)[i];
+            }
+            __syncthreads();
+            if (more_passes) {                               // the next frame's skip half flies under the last stage
+                tile_load(P.img, H, W, fy0 + R8_OH, fx0, true);
+            } else if (has_next) {
+                int qi = 0;
+                while (qi + 1 < a.nprob && next_id >= a.p[qi + 1].tile_begin) ++qi;
+                const Res8Prob& Q = a.p[qi];
+                const int tq = next_id - Q.tile_begin;
+                const int qyb = tq / Q.tiles_x, qxb = tq - qyb * Q.tiles_x;
+                tile_load(Q.img, Q.H, Q.W, qyb * R8_NP * R8_OH - 4, qxb * R8_OW - 4, false);
+            }
+            if (more_passes) {
+                // park r1 rows 19,20 (tile-buffer rows 16,17) for the next pass: only read, like the stage below
+                for (int i = tid; i < 2 * ROWV; i += R8_THREADS)
+                    reinterpret_cast<f32x4*>(R1K)[i] = reinterpret_cast<const f32x4*>(Pb)[16 * ROWV + i];
+            }
+            res8v_stage<false, true, false>(Pb, 3, nullptr, 4, 4, 16, 4, wr + 2 * R8V_FILTER, a.br + 16, tid, fy0, fx0, H, W, T, 1, P.out, nullptr);
+        }
+        tile_id = next_id;
+    }
+}
+
+}  // namespace asep
