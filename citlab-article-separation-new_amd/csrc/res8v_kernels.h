@@ -22,8 +22,18 @@ constexpr int R8V_FILTER = 576;     // floats per 8->8 filter in scalar layout [
 // The kernels take Res8Args like the MFMA kernels; the filters behind w1 (UP) and wr are in scalar layout instead of
 // pixel-pair fragments: UP w1 = [2 sources][R8V_FILTER], wr = [3][R8V_FILTER] floats.
 
-// acc[px][2q..2q+1] += sum over the 3x3 window and 8 input channels, for the thread's two pixels.  in0 = LDS address of
-// the first input row (output row - 1), off[i][hf] = float offset of (pixel x - 1 + i, channel half hf) inside a row.
+// one packed FMA: acc += {v, v} * w, v = element (odd ? 1 : 0) of the 64-bit register pair `pair` (two neighbouring input
+// channels).  Written as asm: left to instruction selection, some of the odd elements were first copied to the low half
+// of another pair (a v_mov per 8 FMAs; the vector ALU is the bound here, every extra instruction costs its 4 cycles).
+template <int ODD>
+__device__ __forceinline__ void r8v_fma(f32x2& acc, f32x2 pair, f32x2 w) {
+    if (ODD) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc) : "v"(pair), "s"(w));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(pair), "s"(w));
+}
+
+// acc[px][2q..2q+1] += sum over the 3x3 window and 8 input channels, for the thread's two pixels.  a[i][hf] = LDS byte
+// offset (from smb, the dynamic LDS base) of (first input row = output row - 1, pixel x - 1 + i, channel half hf); the
+// rows below are immediate offsets of the same eight address registers.
 //
 // Explicit software pipeline: scalar loads return out of order, so every wait on them is lgkmcnt(0) and covers the LDS
 // reads as well.  Per weight group (16 scalars = 2 input channels x 8 output channels, 16 packed FMAs) there is ONE wait,
@@ -32,14 +42,14 @@ constexpr int R8V_FILTER = 576;     // floats per 8->8 filter in scalar layout [
 // it.  The double buffer is 2 x 16 SGPRs: the kernels carry ~40 scalars of their own and the file has 102 (with 2 x 32
 // the allocator spilled weights to VGPR lanes, thousands of v_readlane); the stage time is the same (6.0 k cycles).
 template <bool RELU_IN>
-__device__ __forceinline__ void r8v_conv(const float* __restrict__ in0, const int (&off)[4][2], r8v_cptr wl,
+__device__ __forceinline__ void r8v_conv(const char* __restrict__ smb, const int (&a)[4][2], r8v_cptr wl,
                                          f32x2 (&acc0)[4], f32x2 (&acc1)[4]) {
     float wc[16], wn[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) wc[k] = wl[k];
     f32x4 dA[4], dB[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dA[i] = *reinterpret_cast<const f32x4*>(in0 + off[i][0]);
+    for (int i = 0; i < 4; ++i) dA[i] = *reinterpret_cast<const f32x4*>(smb + a[i][0]);
 #pragma unroll
     for (int g2 = 0; g2 < 36; ++g2) {
         const int g = g2 >> 1, ch = g2 & 1, kx = g % 3, rh = g / 3;           // rh = ky * 2 + hf
@@ -52,23 +62,27 @@ __device__ __forceinline__ void r8v_conv(const float* __restrict__ in0, const in
         if (kx == 0 && ch == 0 && rh + 1 < 6) {
             const int ky2 = (rh + 1) >> 1, hf2 = (rh + 1) & 1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dB[i] = *reinterpret_cast<const f32x4*>(in0 + ky2 * R8_PITCH * 8 + off[i][hf2]);
+            for (int i = 0; i < 4; ++i) dB[i] = *reinterpret_cast<const f32x4*>(smb + a[i][hf2] + ky2 * R8_PITCH * 32);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (RELU_IN && kx == 0 && ch == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) dA[i] = relu4i(dA[i]);
         }
+        // the group's two input channels are one register pair of each pixel: (x, y) for ch = 0, (z, w) for ch = 1
+        const f32x2 in0 = ch ? f32x2{dA[kx].z, dA[kx].w} : f32x2{dA[kx].x, dA[kx].y};
+        const f32x2 in1 = ch ? f32x2{dA[kx + 1].z, dA[kx + 1].w} : f32x2{dA[kx + 1].x, dA[kx + 1].y};
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-            const int c = ch * 2 + c2;
-            const f32x2 a0 = f32x2{dA[kx][c], dA[kx][c]}, a1 = f32x2{dA[kx + 1][c], dA[kx + 1][c]};
+        for (int q = 0; q < 4; ++q) {
+            const f32x2 wv = f32x2{wc[2 * q], wc[2 * q + 1]};
+            r8v_fma<0>(acc0[q], in0, wv);
+            r8v_fma<0>(acc1[q], in1, wv);
+        }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x2 wv = f32x2{wc[c2 * 8 + 2 * q], wc[c2 * 8 + 2 * q + 1]};
-                acc0[q] = __builtin_elementwise_fma(a0, wv, acc0[q]);
-                acc1[q] = __builtin_elementwise_fma(a1, wv, acc1[q]);
-            }
+        for (int q = 0; q < 4; ++q) {
+            const f32x2 wv = f32x2{wc[8 + 2 * q], wc[8 + 2 * q + 1]};
+            r8v_fma<1>(acc0[q], in0, wv);
+            r8v_fma<1>(acc1[q], in1, wv);
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) wc[k] = wn[k];
@@ -89,20 +103,38 @@ __device__ __forceinline__ f32x4 r8v_upper4(f32x4 v) {
     return f32x4{from_upper_half(v.x), from_upper_half(v.y), from_upper_half(v.z), from_upper_half(v.w)};
 }
 
+// byte offsets inside an LDS row of the seven pixels 2p .. 2p + 6 (p = tid & 31) a thread ever touches, both channel halves:
+// a stage with first output column c0 reads pixels c0 - 1 + 2p + i (i = 0..3) = entries c0 - 1 + i.  Computed once per kernel.
+__device__ __forceinline__ void r8v_pixel_offsets(int tid, int (&poff)[7][2]) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) { poff[j][0] = r8_px(2 * (tid & 31) + j, 0) * 4; poff[j][1] = r8_px(2 * (tid & 31) + j, 1) * 4; }
+}
+// the eight address registers of a window: row_bytes = byte offset of the first input row from the LDS base.  Laundered
+// so that the compiler keeps the sums in registers (re-associated, every LDS access would pay a v_add of its own: the
+// buffers lie beyond the 64 KiB reach of the instruction's offset field)
+__device__ __forceinline__ void r8v_window(int (&a)[4][2], const int (&poff)[7][2], int j0, int row_bytes) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) { a[i][hf] = poff[j0 + i][hf] + row_bytes; asm volatile("" : "+v"(a[i][hf])); }
+}
+
 // one 3x3 8->8 convolution stage on LDS tiles.  IN holds rows in_r0.. of the frame, OUT rows out_r0.. ; computes rows
 // [row_start, row_start + nrows) x columns [out_c0, out_c0 + 64): thread -> (row tid >> 5 (+16), pixels out_c0 + 2 (tid & 31), +1).
 // FINAL: add T centre, ReLU, store the OW valid columns to global (+ 2x2 max pool).  Otherwise ReLU into OUT, zero outside
-// the image (= the SAME padding of the next convolution).
+// the image (= the SAME padding of the next convolution).  interior (scalar): the whole frame lies inside the image.
 template <bool RELU_IN, bool FINAL, bool POOL>
-__device__ __forceinline__ void res8v_stage(const float* __restrict__ IN, int in_r0, float* __restrict__ OUT, int out_r0,
+__device__ __forceinline__ void res8v_stage(float* __restrict__ sm, const float* __restrict__ IN, int in_r0, float* __restrict__ OUT, int out_r0,
                                             int row_start, int nrows, int out_c0, const float* __restrict__ w,
-                                            const float* __restrict__ bias, int tid, int fy0, int fx0, int H, int W,
+                                            const float* __restrict__ bias, int tid, const int (&poff)[7][2], bool interior,
+                                            int fy0, int fx0, int H, int W,
                                             const float* __restrict__ T, int t_r0, float* __restrict__ gout, float* __restrict__ gpool) {
+    char* smb = reinterpret_cast<char*>(sm);
     const int x = out_c0 + 2 * (tid & 31);
-    int off[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { off[i][0] = r8_px(x - 1 + i, 0); off[i][1] = r8_px(x - 1 + i, 1); }
     const int gx = fx0 + x;
+    // centre pixels of OUT / T relative to the window's address registers: compile-time constants
+    const int d_out = FINAL ? 0 : (int)(OUT - IN) * 4 + (in_r0 + 1 - out_r0) * R8_PITCH * 32;
+    const int d_t = FINAL ? (int)(T - IN) * 4 + (in_r0 + 1 - t_r0) * R8_PITCH * 32 : 0;
 #pragma unroll 1
     for (int r = tid >> 5; r < nrows; r += 16) {
         r8v_cptr wl = (r8v_cptr)w, bl = (r8v_cptr)bias;
@@ -111,28 +143,33 @@ __device__ __forceinline__ void res8v_stage(const float* __restrict__ IN, int in
 #pragma unroll
         for (int q = 0; q < 4; ++q) { acc0[q] = f32x2{bl[2 * q], bl[2 * q + 1]}; acc1[q] = acc0[q]; }
         const int row = row_start + r;               // frame row
-        r8v_conv<RELU_IN>(IN + (row - 1 - in_r0) * R8_PITCH * 8, off, wl, acc0, acc1);
+        int a[4][2];
+        r8v_window(a, poff, out_c0 - 1, ((int)(IN - sm) + (row - 1 - in_r0) * R8_PITCH * 8) * 4);
+        r8v_conv<RELU_IN>(smb, a, wl, acc0, acc1);
         const int gy = fy0 + row;
         f32x4 p0l = r8v_lo(acc0), p0h = r8v_hi(acc0), p1l = r8v_lo(acc1), p1h = r8v_hi(acc1);
         if (!FINAL) {
-            const bool oky = gy >= 0 && gy < H;
-            const bool ok0 = oky && gx >= 0 && gx < W, ok1 = oky && gx + 1 >= 0 && gx + 1 < W;
-            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-            float* o = OUT + (row - out_r0) * R8_PITCH * 8;
-            *reinterpret_cast<f32x4*>(o + off[1][0]) = ok0 ? relu4i(p0l) : z;
-            *reinterpret_cast<f32x4*>(o + off[1][1]) = ok0 ? relu4i(p0h) : z;
-            *reinterpret_cast<f32x4*>(o + off[2][0]) = ok1 ? relu4i(p1l) : z;
-            *reinterpret_cast<f32x4*>(o + off[2][1]) = ok1 ? relu4i(p1h) : z;
+            p0l = relu4i(p0l); p0h = relu4i(p0h); p1l = relu4i(p1l); p1h = relu4i(p1h);
+            if (!interior) {
+                const bool oky = gy >= 0 && gy < H;
+                const bool ok0 = oky && gx >= 0 && gx < W, ok1 = oky && gx + 1 >= 0 && gx + 1 < W;
+                const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                p0l = ok0 ? p0l : z; p0h = ok0 ? p0h : z; p1l = ok1 ? p1l : z; p1h = ok1 ? p1h : z;
+            }
+            *reinterpret_cast<f32x4*>(smb + a[1][0] + d_out) = p0l;
+            *reinterpret_cast<f32x4*>(smb + a[1][1] + d_out) = p0h;
+            *reinterpret_cast<f32x4*>(smb + a[2][0] + d_out) = p1l;
+            *reinterpret_cast<f32x4*>(smb + a[2][1] + d_out) = p1h;
         } else {
-            const float* tp = T + (row - t_r0) * R8_PITCH * 8;
-            p0l = relu4i(p0l + *reinterpret_cast<const f32x4*>(tp + off[1][0]));
-            p0h = relu4i(p0h + *reinterpret_cast<const f32x4*>(tp + off[1][1]));
-            p1l = relu4i(p1l + *reinterpret_cast<const f32x4*>(tp + off[2][0]));
-            p1h = relu4i(p1h + *reinterpret_cast<const f32x4*>(tp + off[2][1]));
-            // only the OW valid columns of the tile (frame columns 4 .. 4+OW-1) are stored; gy >= 0 and gx >= 0 there
-            const bool oky = gy < H;
-            const bool ok0 = x >= 4 && x < 4 + R8_OW && gx < W, ok1 = x + 1 >= 4 && x + 1 < 4 + R8_OW && gx + 1 < W;
-            float* o = gout + ((size_t)gy * W + gx) * 8;
+            p0l = relu4i(p0l + *reinterpret_cast<const f32x4*>(smb + a[1][0] + d_t));
+            p0h = relu4i(p0h + *reinterpret_cast<const f32x4*>(smb + a[1][1] + d_t));
+            p1l = relu4i(p1l + *reinterpret_cast<const f32x4*>(smb + a[2][0] + d_t));
+            p1h = relu4i(p1h + *reinterpret_cast<const f32x4*>(smb + a[2][1] + d_t));
+            // only the OW valid columns of the tile (frame columns 4 .. 4+OW-1) are stored; gy >= 0 and gx >= 0 there.
+            // Element offsets fit 32 bits (the launcher sends larger tensors to the MFMA kernels).
+            const bool oky = interior || gy < H;
+            const bool ok0 = x >= 4 && x < 4 + R8_OW && (interior || gx < W), ok1 = x + 1 >= 4 && x + 1 < 4 + R8_OW && (interior || gx + 1 < W);
+            float* o = gout + ((unsigned)gy * (unsigned)W + (unsigned)gx) * 8u;
             if (ok0 && oky) { *reinterpret_cast<f32x4*>(o) = p0l; *reinterpret_cast<f32x4*>(o + 4) = p0h; }
             if (ok1 && oky) { *reinterpret_cast<f32x4*>(o + 8) = p1l; *reinterpret_cast<f32x4*>(o + 12) = p1h; }
             if (POOL && gpool) {
@@ -141,9 +178,9 @@ __device__ __forceinline__ void res8v_stage(const float* __restrict__ IN, int in
                 f32x4 ml = ok1 ? r8v_max4(p0l, p1l) : p0l, mh = ok1 ? r8v_max4(p0h, p1h) : p0h;
                 const f32x4 ul = r8v_upper4(ml), uh = r8v_upper4(mh);     // only lanes < 32 use it
                 if ((tid & 32) == 0 && ok0 && oky) {
-                    if (gy + 1 < H) { ml = r8v_max4(ml, ul); mh = r8v_max4(mh, uh); }
-                    const int Wp = (W + 1) >> 1;
-                    float* po = gpool + ((size_t)(gy >> 1) * Wp + (gx >> 1)) * 8;
+                    if (interior || gy + 1 < H) { ml = r8v_max4(ml, ul); mh = r8v_max4(mh, uh); }
+                    const unsigned Wp = (unsigned)(W + 1) >> 1;
+                    float* po = gpool + ((unsigned)(gy >> 1) * Wp + (unsigned)(gx >> 1)) * 8u;
                     *reinterpret_cast<f32x4*>(po) = ml;
                     *reinterpret_cast<f32x4*>(po + 4) = mh;
                 }
@@ -164,6 +201,8 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const int tid = threadIdx.x;
     if (tid < 72) w1s[tid] = a.w1[tid];
     if (tid < 8) w1s[72 + tid] = a.b1[tid];
+    int poff[7][2];
+    r8v_pixel_offsets(tid, poff);
 
     constexpr int NPRE = (R8_FH * R8_IMGP + R8_THREADS - 1) / R8_THREADS;
     float pre[NPRE], pre_mean = 0.f, pre_inv = 1.f;
@@ -209,6 +248,8 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             if (fy0 + 4 >= H) break;                                 // no output rows left in this unit
             const bool more_passes = pass + 1 < R8_NP && fy0 + 4 + R8_OH < H;
             const bool first = pass == 0;
+            // a frame that lies inside the image needs no zero masks (scalar condition)
+            const bool interior = fy0 >= 0 && fy0 + R8_FH <= H && fx0 >= 0 && fx0 + R8_PITCH <= W;
             __syncthreads();                                 // previous pass / tile finished with all LDS buffers
             if (!first) {
                 // rows carried over from the pass above (frame rows shift by OH = 16):
@@ -252,13 +293,13 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 *reinterpret_cast<f32x4*>(T + r * R8_PITCH * 8 + r8_px(c, 1)) = hi;
             }
             __syncthreads();
-            res8v_stage<true, false, false>(T, 1, R0, 2, first ? 2 : 6, first ? 20 : 16, 2, wr, a.br, tid, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            res8v_stage<true, false, false>(sm, T, 1, R0, 2, first ? 2 : 6, first ? 20 : 16, 2, wr, a.br, tid, poff, interior, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
             __syncthreads();
-            res8v_stage<false, false, false>(R0, 2, R1, 3, first ? 3 : 5, first ? 18 : 16, 3, wr + R8V_FILTER, a.br + 8, tid, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            res8v_stage<false, false, false>(sm, R0, 2, R1, 3, first ? 3 : 5, first ? 18 : 16, 3, wr + R8V_FILTER, a.br + 8, tid, poff, interior, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
             __syncthreads();
             if (more_passes) image_load(tile_id, pass + 1);
             else if (has_next) image_load(next_id, 0);
-            res8v_stage<false, true, true>(R1, 3, nullptr, 4, 4, 16, 4, wr + 2 * R8V_FILTER, a.br + 16, tid, fy0, fx0, H, W, T, 1, P.out, P.pool);
+            res8v_stage<false, true, true>(sm, R1, 3, nullptr, 4, 4, 16, 4, wr + 2 * R8V_FILTER, a.br + 16, tid, poff, interior, fy0, fx0, H, W, T, 1, P.out, P.pool);
         }
         tile_id = next_id;
     }
@@ -274,24 +315,35 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     float* T = Pb + R8_FH * R8_PITCH * 8;                    // frame rows 1..22  [22][72][8]
     float* R0 = T + 22 * R8_PITCH * 8;                       // frame rows 2..21  [20][72][8]
     float* R1K = R0 + 20 * R8_PITCH * 8;                     // two r1 rows parked between passes [2][72][8]
-    int tid = threadIdx.x;
-    // halo tile loader: thread -> (row group rg = tid / 144, slot cs = tid % 144 = pixel column x 2 halves), rows rg + 3k:
-    // one division per pass, then a constant row stride (432 of the 512 threads load, 8 x 16 B each)
+    char* smb = reinterpret_cast<char*>(sm);
+    const int tid = threadIdx.x;
+#ifdef ASEP_R8_TIMELINE
+    int tl_n = 0;
+    const int lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { r8_clk[0] = clock64(); r8_clk[1] = wall_clock64(); }
+#endif
+    int poff[7][2];
+    r8v_pixel_offsets(tid, poff);
+    // halo tile loader: thread -> (row group rg = tid / 144, slot cs = tid % 144 = pixel column x 2 halves), rows rg + 3k
+    // (432 of the 512 threads load, 8 x 16 B each)
     constexpr int ROWV = R8_PITCH * 2;                       // f32x4 per LDS row
     constexpr int NPF = R8_FH / 3;
     f32x4 pf[NPF];
-    int rg = tid / ROWV, cs = tid - rg * ROWV;
-    // carried: only frame rows 6..23 are needed (conv1 then reads rows 6..23 only), i.e. k >= 2
+    const int rg = tid / ROWV, cs = tid - rg * ROWV;
+    const int pf_dst = (rg * R8_PITCH * 8 + r8_px(cs >> 1, cs & 1)) * 4;      // byte offset of the thread's piece in tile row rg
+    // carried: only frame rows 6..23 are needed (conv1 then reads rows 6..23 only), i.e. k >= 2.  ONE code path for
+    // both kinds of frame (a run-time predicate, not two call sites): with two, the register allocator gave the eight
+    // destinations different registers per path, and the wait-count pass then made the following stage wait for the
+    // loads just issued (a vmcnt(0) in front of its first instruction: 3 k cycles per pass)
     auto tile_load = [&](const float* __restrict__ g, int H_, int W_, int qy0, int qx0, bool carried) {   // 8-channel halo tile -> registers
         const int gx = qx0 + (cs >> 1);
         const bool okc = rg < 3 && gx >= 0 && gx < W_;
         const float* __restrict__ gp = g + ((ptrdiff_t)gx * 8 + (cs & 1) * 4);
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
-            if (k < 2 && carried) continue;
             const int gy = qy0 + rg + 3 * k;
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (okc && gy >= 0 && gy < H_) v = *reinterpret_cast<const f32x4*>(gp + (ptrdiff_t)gy * W_ * 8);
+            if (okc && gy >= 0 && gy < H_ && !(k < 2 && carried)) v = *reinterpret_cast<const f32x4*>(gp + (ptrdiff_t)gy * W_ * 8);
             pf[k] = v;
         }
     };
@@ -300,7 +352,7 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
             for (int k = 0; k < NPF; ++k) {
                 if (k < 2 && carried) continue;
-                *reinterpret_cast<f32x4*>(Pb + (rg + 3 * k) * R8_PITCH * 8 + r8_px(cs >> 1, cs & 1)) = pf[k];
+                *reinterpret_cast<f32x4*>(smb + pf_dst + 3 * k * R8_PITCH * 32) = pf[k];
             }
         }
     };
@@ -330,17 +382,16 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             if (fy0 + 4 >= H) break;                         // no output rows left in this unit
             const bool more_passes = pass + 1 < R8_NP && fy0 + 4 + R8_OH < H;
             const bool first = pass == 0;
+            // a frame that lies inside the image needs no zero masks (scalar condition)
+            const bool interior = fy0 >= 0 && fy0 + R8_FH <= H && fx0 >= 0 && fx0 + R8_PITCH <= W;
             // conv1 covers frame rows 1..22 in the first pass and only the 16 new rows 7..22 afterwards
             const int c1_row = first ? 1 : 7, c1_rows = first ? 22 : 16;
-            // everything derived from the thread index is recomputed per pass (hoisted out of the persistent loop it would
-            // occupy registers across the whole pass)
-            asm volatile("" : "+v"(tid));
-            rg = tid / ROWV; cs = tid - rg * ROWV;
+            R8_MARK();   // 0 pass start
             const int r0 = tid >> 5;
             const bool has2 = r0 + 16 < c1_rows;              // first pass: threads of rows 0..5 own a second row (16..21)
-            int off[4][2];                                    // conv1 output pixels: frame columns 1 + 2p, 2 + 2p
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { off[i][0] = r8_px(2 * (tid & 31) + i, 0); off[i][1] = r8_px(2 * (tid & 31) + i, 1); }
+            // conv1 output pixels: frame columns 1 + 2p, 2 + 2p; window = tile pixels 2p .. 2p + 3 of rows c1_row + r0 - 1 ..
+            int wa[4][2];
+            r8v_window(wa, poff, 0, (c1_row + r0 - 1) * R8_PITCH * 32);
             // t accumulators: [row slot][pixel][channel pair]; conv1's bias is the initial value
             f32x2 ta0[4], ta1[4], tb0[4], tb1[4];
             {
@@ -352,6 +403,7 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll 1
             for (int half = 0; half < 2; ++half) {
                 __syncthreads();                             // the tile buffer is free (previous pass / tile / half done)
+                R8_MARK();   // 1 / 4 barrier passed
                 if (half == 0 && !first) {
                     // rows carried over from the pass above: t rows 20..22 -> 4..6, r0 rows 20,21 -> 4,5
                     // (r1 rows 19,20 were parked in R1K during the previous pass' last stage)
@@ -365,68 +417,95 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 tile_store(!first);
                 if (half == 0) tile_load(P.in1, H, W, fy0, fx0, !first);  // the deconv half flies while the skip half is multiplied
                 __syncthreads();
+                R8_MARK();   // 2 / 5 tile in LDS
                 r8v_cptr wl = (r8v_cptr)(a.w1 + half * R8V_FILTER);
                 asm volatile("" : "+s"(wl));
-                r8v_conv<false>(Pb + (c1_row + r0 - 1) * R8_PITCH * 8, off, wl, ta0, ta1);
+                r8v_conv<false>(smb, wa, wl, ta0, ta1);
                 if (has2) {
+                    int wb[4][2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { wb[i][0] = wa[i][0] + 16 * R8_PITCH * 32; wb[i][1] = wa[i][1] + 16 * R8_PITCH * 32; }
                     asm volatile("" : "+s"(wl));
-                    r8v_conv<false>(Pb + (c1_row + r0 + 15) * R8_PITCH * 8, off, wl, tb0, tb1);
+                    r8v_conv<false>(smb, wb, wl, tb0, tb1);
                 }
+                R8_MARK();   // 3 / 6 conv1 half done
             }
-            // ---- write raw t (identity activation), zero outside the image ----
+            // ---- write raw t (identity activation), zero outside the image: T row (row - 1) = the window's first row ----
             {
+                constexpr int DT = R8_FH * R8_PITCH * 32;     // T - Pb in bytes
                 const int gx = fx0 + 1 + 2 * (tid & 31);
                 const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
                 {
-                    const int row = c1_row + r0, gy = fy0 + row;
-                    const bool oky = gy >= 0 && gy < H;
-                    const bool ok0 = oky && gx >= 0 && gx < W, ok1 = oky && gx + 1 >= 0 && gx + 1 < W;
-                    float* o = T + (row - 1) * R8_PITCH * 8;
-                    *reinterpret_cast<f32x4*>(o + off[1][0]) = ok0 ? r8v_lo(ta0) : z;
-                    *reinterpret_cast<f32x4*>(o + off[1][1]) = ok0 ? r8v_hi(ta0) : z;
-                    *reinterpret_cast<f32x4*>(o + off[2][0]) = ok1 ? r8v_lo(ta1) : z;
-                    *reinterpret_cast<f32x4*>(o + off[2][1]) = ok1 ? r8v_hi(ta1) : z;
+                    f32x4 v0l = r8v_lo(ta0), v0h = r8v_hi(ta0), v1l = r8v_lo(ta1), v1h = r8v_hi(ta1);
+                    if (!interior) {
+                        const int gy = fy0 + c1_row + r0;
+                        const bool oky = gy >= 0 && gy < H;
+                        const bool ok0 = oky && gx >= 0 && gx < W, ok1 = oky && gx + 1 >= 0 && gx + 1 < W;
+                        v0l = ok0 ? v0l : z; v0h = ok0 ? v0h : z; v1l = ok1 ? v1l : z; v1h = ok1 ? v1h : z;
+                    }
+                    *reinterpret_cast<f32x4*>(smb + wa[1][0] + DT) = v0l;
+                    *reinterpret_cast<f32x4*>(smb + wa[1][1] + DT) = v0h;
+                    *reinterpret_cast<f32x4*>(smb + wa[2][0] + DT) = v1l;
+                    *reinterpret_cast<f32x4*>(smb + wa[2][1] + DT) = v1h;
                 }
                 if (has2) {
-                    const int row = c1_row + r0 + 16, gy = fy0 + row;
-                    const bool oky = gy >= 0 && gy < H;
-                    const bool ok0 = oky && gx >= 0 && gx < W, ok1 = oky && gx + 1 >= 0 && gx + 1 < W;
-                    float* o = T + (row - 1) * R8_PITCH * 8;
-                    *reinterpret_cast<f32x4*>(o + off[1][0]) = ok0 ? r8v_lo(tb0) : z;
-                    *reinterpret_cast<f32x4*>(o + off[1][1]) = ok0 ? r8v_hi(tb0) : z;
-                    *reinterpret_cast<f32x4*>(o + off[2][0]) = ok1 ? r8v_lo(tb1) : z;
-                    *reinterpret_cast<f32x4*>(o + off[2][1]) = ok1 ? r8v_hi(tb1) : z;
+                    f32x4 v0l = r8v_lo(tb0), v0h = r8v_hi(tb0), v1l = r8v_lo(tb1), v1h = r8v_hi(tb1);
+                    if (!interior) {
+                        const int gy = fy0 + c1_row + r0 + 16;
+                        const bool oky = gy >= 0 && gy < H;
+                        const bool ok0 = oky && gx >= 0 && gx < W, ok1 = oky && gx + 1 >= 0 && gx + 1 < W;
+                        v0l = ok0 ? v0l : z; v0h = ok0 ? v0h : z; v1l = ok1 ? v1l : z; v1h = ok1 ? v1h : z;
+                    }
+                    constexpr int D2 = DT + 16 * R8_PITCH * 32;
+                    *reinterpret_cast<f32x4*>(smb + wa[1][0] + D2) = v0l;
+                    *reinterpret_cast<f32x4*>(smb + wa[1][1] + D2) = v0h;
+                    *reinterpret_cast<f32x4*>(smb + wa[2][0] + D2) = v1l;
+                    *reinterpret_cast<f32x4*>(smb + wa[2][1] + D2) = v1h;
                 }
             }
+            R8_MARK();   // 7 t written
             __syncthreads();
-            res8v_stage<true, false, false>(T, 1, R0, 2, first ? 2 : 6, first ? 20 : 16, 2, wr, a.br, tid, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            R8_MARK();   // 8
+            res8v_stage<true, false, false>(sm, T, 1, R0, 2, first ? 2 : 6, first ? 20 : 16, 2, wr, a.br, tid, poff, interior, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            R8_MARK();   // 9 stage0 done
             __syncthreads();
-            res8v_stage<false, false, false>(R0, 2, Pb, 3, first ? 3 : 5, first ? 18 : 16, 3, wr + R8V_FILTER, a.br + 8, tid, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            R8_MARK();   // 10
+            res8v_stage<false, false, false>(sm, R0, 2, Pb, 3, first ? 3 : 5, first ? 18 : 16, 3, wr + R8V_FILTER, a.br + 8, tid, poff, interior, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
             if (!first) {
                 // r1 rows 3,4 of this frame = rows 19,20 of the previous one (the tile buffer is free of conv1 readers here)
                 for (int i = tid; i < 2 * ROWV; i += R8_THREADS)
                     reinterpret_cast<f32x4*>(Pb)[i] = reinterpret_cast<const f32x4*>(R1K)[i];
             }
+            R8_MARK();   // 11 stage1 done
             __syncthreads();
-            if (more_passes) {                               // the next frame's skip half flies under the last stage
-                tile_load(P.img, H, W, fy0 + R8_OH, fx0, true);
-            } else if (has_next) {
-                int qi = 0;
-                while (qi + 1 < a.nprob && next_id >= a.p[qi + 1].tile_begin) ++qi;
-                const Res8Prob& Q = a.p[qi];
-                const int tq = next_id - Q.tile_begin;
-                const int qyb = tq / Q.tiles_x, qxb = tq - qyb * Q.tiles_x;
-                tile_load(Q.img, Q.H, Q.W, qyb * R8_NP * R8_OH - 4, qxb * R8_OW - 4, false);
-            }
+            R8_MARK();   // 12
             if (more_passes) {
                 // park r1 rows 19,20 (tile-buffer rows 16,17) for the next pass: only read, like the stage below
                 for (int i = tid; i < 2 * ROWV; i += R8_THREADS)
                     reinterpret_cast<f32x4*>(R1K)[i] = reinterpret_cast<const f32x4*>(Pb)[16 * ROWV + i];
             }
-            res8v_stage<false, true, false>(Pb, 3, nullptr, 4, 4, 16, 4, wr + 2 * R8V_FILTER, a.br + 16, tid, fy0, fx0, H, W, T, 1, P.out, nullptr);
+            if (more_passes || has_next) {                   // the next frame's skip half flies under the last stage
+                const float* g = P.img;
+                int H_ = H, W_ = W, qy0 = fy0 + R8_OH, qx0 = fx0;
+                if (!more_passes) {
+                    int qi = 0;
+                    while (qi + 1 < a.nprob && next_id >= a.p[qi + 1].tile_begin) ++qi;
+                    const Res8Prob& Q = a.p[qi];
+                    const int tq = next_id - Q.tile_begin;
+                    const int qyb = tq / Q.tiles_x, qxb = tq - qyb * Q.tiles_x;
+                    g = Q.img; H_ = Q.H; W_ = Q.W; qy0 = qyb * R8_NP * R8_OH - 4; qx0 = qxb * R8_OW - 4;
+                }
+                tile_load(g, H_, W_, qy0, qx0, more_passes);
+            }
+            R8_MARK();   // 13 prefetch issued
+            res8v_stage<false, true, false>(sm, Pb, 3, nullptr, 4, 4, 16, 4, wr + 2 * R8V_FILTER, a.br + 16, tid, poff, interior, fy0, fx0, H, W, T, 1, P.out, nullptr);
+            R8_MARK();   // 14 stage2 done
         }
         tile_id = next_id;
     }
+#ifdef ASEP_R8_TIMELINE
+    if (blockIdx.x == 0 && threadIdx.x == 0) { r8_clk[2] = clock64(); r8_clk[3] = wall_clock64(); }
+#endif
 }
 
 }  // namespace asep

@@ -3,11 +3,17 @@
 // how long every phase of a pass takes and how long the waves wait at each barrier.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DASEP_R8_TIMELINE -I citlab-article-separation-new_amd/csrc \
 //         scripts/ubench/res8_timeline.hip -o /tmp/res8_timeline && /tmp/res8_timeline [H W]
-#include "res8_kernels.h"
+// -DR8V: the vector-ALU kernel (res8v_up_kernel) instead of the MFMA one.
+#include "res8v_kernels.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 using namespace asep;
+#ifdef R8V
+#define UP_KERNEL res8v_up_kernel
+#else
+#define UP_KERNEL res8_up_kernel<false>
+#endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 int main(int argc, char** argv) {
@@ -33,11 +39,11 @@ int main(int argc, char** argv) {
     a.p[0].tiles_x = (W + R8_OW - 1) / R8_OW; a.p[0].tile_begin = 0;
     a.total_tiles = a.p[0].tiles_x * ((H + R8_OH * R8_NP - 1) / (R8_OH * R8_NP));
     a.w1 = w1; a.b1 = b1; a.wr = reinterpret_cast<const f32x4*>(wr); a.br = br; a.sched = nullptr;
-    CK(hipFuncSetAttribute((const void*)res8_up_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS));
+    CK(hipFuncSetAttribute((const void*)UP_KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 3; ++it) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(res8_up_kernel<false>, dim3(256), dim3(R8_THREADS), R8_UP_LDS, 0, a);
+        hipLaunchKernelGGL(UP_KERNEL, dim3(256), dim3(R8_THREADS), R8_UP_LDS, 0, a);
         hipEventRecord(e1); CK(hipEventSynchronize(e1));
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("launch %d: %.3f ms, %d units\n", it, ms, a.total_tiles);
