@@ -650,7 +650,8 @@ void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>&
         a.nprob = (int)(b1 - b0);
         a.total_tiles = tiles;
         a.w1 = m->det_first.d_w; a.b1 = m->det_first.d_b;
-        const bool valu = m->r8_valu && !m->bf16;
+        bool valu = m->r8_valu && !m->bf16;      // fp32: vector-ALU kernels (32-bit element offsets: < 2^29 pixels per tensor)
+        for (size_t i = b0; i < b1; ++i) valu = valu && (size_t)imgs[i].H * imgs[i].W < ((size_t)1 << 28);
         a.wr = (const f32x4*)(valu ? m->d_r8v_down_wr : m->d_r8_down_wr); a.br = m->d_r8_down_br;
         TL sub(imgs.begin() + b0, imgs.begin() + b1);
         std::string pname = valu ? "res8v_down_kernel" : "res8_down_kernel";
@@ -683,7 +684,8 @@ TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
         }
         a.nprob = (int)(b1 - b0);
         a.total_tiles = tiles;
-        const bool valu = m->r8_valu && !m->bf16;
+        bool valu = m->r8_valu && !m->bf16;      // fp32: vector-ALU kernels (32-bit element offsets: < 2^29 pixels per tensor)
+        for (size_t i = b0; i < b1; ++i) valu = valu && (size_t)skip[i].H * skip[i].W < ((size_t)1 << 28);
         a.w1 = valu ? m->d_r8v_up_w1 : m->d_r8_up_w1; a.b1 = m->d_r8_up_b1;
         a.wr = (const f32x4*)(valu ? m->d_r8v_up_wr : m->d_r8_up_wr); a.br = m->d_r8_up_br;
         TL sub(skip.begin() + b0, skip.begin() + b1);

@@ -16,6 +16,7 @@ namespace asep {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const float __attribute__((address_space(4)))* r8v_cptr;   // constant address space: stays on s_load
+typedef char __attribute__((address_space(3)))* r8v_lds;           // LDS byte address (32 bits, one VGPR)
 
 constexpr int R8V_FILTER = 576;     // floats per 8->8 filter in scalar layout [g = (ky*2 + hf)*3 + kx][c = ci & 3][co], ci = hf*4 + c
 
@@ -31,9 +32,9 @@ __device__ __forceinline__ void r8v_fma(f32x2& acc, f32x2 pair, f32x2 w) {
     else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(pair), "s"(w));
 }
 
-// acc[px][2q..2q+1] += sum over the 3x3 window and 8 input channels, for the thread's two pixels.  a[i][hf] = LDS byte
-// offset (from smb, the dynamic LDS base) of (first input row = output row - 1, pixel x - 1 + i, channel half hf); the
-// rows below are immediate offsets of the same eight address registers.
+// acc[px][2q..2q+1] += sum over the 3x3 window and 8 input channels, for the thread's two pixels.  a[i][hf] = LDS address
+// of (first input row = output row - 1, pixel x - 1 + i, channel half hf); the rows below are immediate offsets of the
+// same eight address registers.
 //
 // Explicit software pipeline: scalar loads return out of order, so every wait on them is lgkmcnt(0) and covers the LDS
 // reads as well.  Per weight group (16 scalars = 2 input channels x 8 output channels, 16 packed FMAs) there is ONE wait,
@@ -42,14 +43,14 @@ __device__ __forceinline__ void r8v_fma(f32x2& acc, f32x2 pair, f32x2 w) {
 // it.  The double buffer is 2 x 16 SGPRs: the kernels carry ~40 scalars of their own and the file has 102 (with 2 x 32
 // the allocator spilled weights to VGPR lanes, thousands of v_readlane); the stage time is the same (6.0 k cycles).
 template <bool RELU_IN>
-__device__ __forceinline__ void r8v_conv(const char* __restrict__ smb, const int (&a)[4][2], r8v_cptr wl,
+__device__ __forceinline__ void r8v_conv(const r8v_lds (&a)[4][2], r8v_cptr wl,
                                          f32x2 (&acc0)[4], f32x2 (&acc1)[4]) {
     float wc[16], wn[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) wc[k] = wl[k];
     f32x4 dA[4], dB[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dA[i] = *reinterpret_cast<const f32x4*>(smb + a[i][0]);
+    for (int i = 0; i < 4; ++i) dA[i] = *reinterpret_cast<const f32x4 __attribute__((address_space(3)))*>(a[i][0]);
 #pragma unroll
     for (int g2 = 0; g2 < 36; ++g2) {
         const int g = g2 >> 1, ch = g2 & 1, kx = g % 3, rh = g / 3;           // rh = ky * 2 + hf
@@ -62,7 +63,7 @@ __device__ __forceinline__ void r8v_conv(const char* __restrict__ smb, const int
         if (kx == 0 && ch == 0 && rh + 1 < 6) {
             const int ky2 = (rh + 1) >> 1, hf2 = (rh + 1) & 1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dB[i] = *reinterpret_cast<const f32x4*>(smb + a[i][hf2] + ky2 * R8_PITCH * 32);
+            for (int i = 0; i < 4; ++i) dB[i] = *reinterpret_cast<const f32x4 __attribute__((address_space(3)))*>(a[i][hf2] + ky2 * R8_PITCH * 32);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (RELU_IN && kx == 0 && ch == 0) {
@@ -112,12 +113,15 @@ __device__ __forceinline__ void r8v_pixel_offsets(int tid, int (&poff)[7][2]) {
 // the eight address registers of a window: row_bytes = byte offset of the first input row from the LDS base.  Laundered
 // so that the compiler keeps the sums in registers (re-associated, every LDS access would pay a v_add of its own: the
 // buffers lie beyond the 64 KiB reach of the instruction's offset field)
-__device__ __forceinline__ void r8v_window(int (&a)[4][2], const int (&poff)[7][2], int j0, int row_bytes) {
+__device__ __forceinline__ void r8v_window(r8v_lds (&a)[4][2], float* sm, const int (&poff)[7][2], int j0, int row_bytes) {
+    asm volatile("" : "+v"(row_bytes));   // one row term, eight sums (not eight induction variables in the callers' row loops)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) { a[i][hf] = poff[j0 + i][hf] + row_bytes; asm volatile("" : "+v"(a[i][hf])); }
+        for (int hf = 0; hf < 2; ++hf) { a[i][hf] = (r8v_lds)reinterpret_cast<char*>(sm) + (poff[j0 + i][hf] + row_bytes); asm volatile("" : "+v"(a[i][hf])); }
 }
+__device__ __forceinline__ f32x4 r8v_ld(r8v_lds p) { return *reinterpret_cast<const f32x4 __attribute__((address_space(3)))*>(p); }
+__device__ __forceinline__ void r8v_st(r8v_lds p, f32x4 v) { *reinterpret_cast<f32x4 __attribute__((address_space(3)))*>(p) = v; }
 
 // one 3x3 8->8 convolution stage on LDS tiles.  IN holds rows in_r0.. of the frame, OUT rows out_r0.. ; computes rows
 // [row_start, row_start + nrows) x columns [out_c0, out_c0 + 64): thread -> (row tid >> 5 (+16), pixels out_c0 + 2 (tid & 31), +1).
@@ -129,7 +133,6 @@ __device__ __forceinline__ void res8v_stage(float* __restrict__ sm, const float*
                                             const float* __restrict__ bias, int tid, const int (&poff)[7][2], bool interior,
                                             int fy0, int fx0, int H, int W,
                                             const float* __restrict__ T, int t_r0, float* __restrict__ gout, float* __restrict__ gpool) {
-    char* smb = reinterpret_cast<char*>(sm);
     const int x = out_c0 + 2 * (tid & 31);
     const int gx = fx0 + x;
     // centre pixels of OUT / T relative to the window's address registers: compile-time constants
@@ -143,9 +146,9 @@ __device__ __forceinline__ void res8v_stage(float* __restrict__ sm, const float*
 #pragma unroll
         for (int q = 0; q < 4; ++q) { acc0[q] = f32x2{bl[2 * q], bl[2 * q + 1]}; acc1[q] = acc0[q]; }
         const int row = row_start + r;               // frame row
-        int a[4][2];
-        r8v_window(a, poff, out_c0 - 1, ((int)(IN - sm) + (row - 1 - in_r0) * R8_PITCH * 8) * 4);
-        r8v_conv<RELU_IN>(smb, a, wl, acc0, acc1);
+        r8v_lds a[4][2];
+        r8v_window(a, sm, poff, out_c0 - 1, ((int)(IN - sm) + (row - 1 - in_r0) * R8_PITCH * 8) * 4);
+        r8v_conv<RELU_IN>(a, wl, acc0, acc1);
         const int gy = fy0 + row;
         f32x4 p0l = r8v_lo(acc0), p0h = r8v_hi(acc0), p1l = r8v_lo(acc1), p1h = r8v_hi(acc1);
         if (!FINAL) {
@@ -156,15 +159,15 @@ __device__ __forceinline__ void res8v_stage(float* __restrict__ sm, const float*
                 const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
                 p0l = ok0 ? p0l : z; p0h = ok0 ? p0h : z; p1l = ok1 ? p1l : z; p1h = ok1 ? p1h : z;
             }
-            *reinterpret_cast<f32x4*>(smb + a[1][0] + d_out) = p0l;
-            *reinterpret_cast<f32x4*>(smb + a[1][1] + d_out) = p0h;
-            *reinterpret_cast<f32x4*>(smb + a[2][0] + d_out) = p1l;
-            *reinterpret_cast<f32x4*>(smb + a[2][1] + d_out) = p1h;
+            r8v_st(a[1][0] + d_out, p0l);
+            r8v_st(a[1][1] + d_out, p0h);
+            r8v_st(a[2][0] + d_out, p1l);
+            r8v_st(a[2][1] + d_out, p1h);
         } else {
-            p0l = relu4i(p0l + *reinterpret_cast<const f32x4*>(smb + a[1][0] + d_t));
-            p0h = relu4i(p0h + *reinterpret_cast<const f32x4*>(smb + a[1][1] + d_t));
-            p1l = relu4i(p1l + *reinterpret_cast<const f32x4*>(smb + a[2][0] + d_t));
-            p1h = relu4i(p1h + *reinterpret_cast<const f32x4*>(smb + a[2][1] + d_t));
+            p0l = relu4i(p0l + r8v_ld(a[1][0] + d_t));
+            p0h = relu4i(p0h + r8v_ld(a[1][1] + d_t));
+            p1l = relu4i(p1l + r8v_ld(a[2][0] + d_t));
+            p1h = relu4i(p1h + r8v_ld(a[2][1] + d_t));
             // only the OW valid columns of the tile (frame columns 4 .. 4+OW-1) are stored; gy >= 0 and gx >= 0 there.
             // Element offsets fit 32 bits (the launcher sends larger tensors to the MFMA kernels).
             const bool oky = interior || gy < H;
@@ -390,8 +393,8 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             const int r0 = tid >> 5;
             const bool has2 = r0 + 16 < c1_rows;              // first pass: threads of rows 0..5 own a second row (16..21)
             // conv1 output pixels: frame columns 1 + 2p, 2 + 2p; window = tile pixels 2p .. 2p + 3 of rows c1_row + r0 - 1 ..
-            int wa[4][2];
-            r8v_window(wa, poff, 0, (c1_row + r0 - 1) * R8_PITCH * 32);
+            r8v_lds wa[4][2];
+            r8v_window(wa, sm, poff, 0, (c1_row + r0 - 1) * R8_PITCH * 32);
             // t accumulators: [row slot][pixel][channel pair]; conv1's bias is the initial value
             f32x2 ta0[4], ta1[4], tb0[4], tb1[4];
             {
@@ -420,13 +423,13 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 R8_MARK();   // 2 / 5 tile in LDS
                 r8v_cptr wl = (r8v_cptr)(a.w1 + half * R8V_FILTER);
                 asm volatile("" : "+s"(wl));
-                r8v_conv<false>(smb, wa, wl, ta0, ta1);
+                r8v_conv<false>(wa, wl, ta0, ta1);
                 if (has2) {
-                    int wb[4][2];
+                    r8v_lds wb[4][2];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { wb[i][0] = wa[i][0] + 16 * R8_PITCH * 32; wb[i][1] = wa[i][1] + 16 * R8_PITCH * 32; }
                     asm volatile("" : "+s"(wl));
-                    r8v_conv<false>(smb, wb, wl, tb0, tb1);
+                    r8v_conv<false>(wb, wl, tb0, tb1);
                 }
                 R8_MARK();   // 3 / 6 conv1 half done
             }
@@ -443,10 +446,10 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                         const bool ok0 = oky && gx >= 0 && gx < W, ok1 = oky && gx + 1 >= 0 && gx + 1 < W;
                         v0l = ok0 ? v0l : z; v0h = ok0 ? v0h : z; v1l = ok1 ? v1l : z; v1h = ok1 ? v1h : z;
                     }
-                    *reinterpret_cast<f32x4*>(smb + wa[1][0] + DT) = v0l;
-                    *reinterpret_cast<f32x4*>(smb + wa[1][1] + DT) = v0h;
-                    *reinterpret_cast<f32x4*>(smb + wa[2][0] + DT) = v1l;
-                    *reinterpret_cast<f32x4*>(smb + wa[2][1] + DT) = v1h;
+                    r8v_st(wa[1][0] + DT, v0l);
+                    r8v_st(wa[1][1] + DT, v0h);
+                    r8v_st(wa[2][0] + DT, v1l);
+                    r8v_st(wa[2][1] + DT, v1h);
                 }
                 if (has2) {
                     f32x4 v0l = r8v_lo(tb0), v0h = r8v_hi(tb0), v1l = r8v_lo(tb1), v1h = r8v_hi(tb1);
@@ -457,10 +460,10 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                         v0l = ok0 ? v0l : z; v0h = ok0 ? v0h : z; v1l = ok1 ? v1l : z; v1h = ok1 ? v1h : z;
                     }
                     constexpr int D2 = DT + 16 * R8_PITCH * 32;
-                    *reinterpret_cast<f32x4*>(smb + wa[1][0] + D2) = v0l;
-                    *reinterpret_cast<f32x4*>(smb + wa[1][1] + D2) = v0h;
-                    *reinterpret_cast<f32x4*>(smb + wa[2][0] + D2) = v1l;
-                    *reinterpret_cast<f32x4*>(smb + wa[2][1] + D2) = v1h;
+                    r8v_st(wa[1][0] + D2, v0l);
+                    r8v_st(wa[1][1] + D2, v0h);
+                    r8v_st(wa[2][0] + D2, v1l);
+                    r8v_st(wa[2][1] + D2, v1h);
                 }
             }
             R8_MARK();   // 7 t written
