@@ -103,6 +103,8 @@ struct asep_aru {
     bool bf16 = false;             // cfg.compute_dtype == 1: bf16 MFMA operands, fp32 accumulation and storage
     bool wino_reg = true;          // ASEP_WINO_REG=0: LDS-image Winograd kernel also for the 32-channel level
     bool use_winograd = true;      // ASEP_WINOGRAD=0 selects the direct implicit-GEMM kernels everywhere
+    bool wino16 = false;           // ASEP_WINO16=1: register-resident Winograd also at the 16-channel level (measured: 99 vs
+                                   // 103 TFLOP/s-equivalent for the direct kernels, parity-green; kept as an experiment switch)
     bool profiling = false;
     bool prof_detail = false;      // per-layer names (scope + spatial size) instead of per-kernel names
     std::vector<std::string> prof_names;
@@ -217,7 +219,7 @@ int pack_conv(asep_aru* m, const std::map<std::string, HostTensor>& blob, const 
     if (rc) return rc;
     m->owned.push_back(pc.d_w);
     m->owned.push_back(pc.d_b);
-    if (!deconv && pc.kh == 3 && pc.kw == 3 && pc.cin % 16 == 0 && pc.cout % 32 == 0) {
+    if (!deconv && pc.kh == 3 && pc.kw == 3 && pc.cin % 16 == 0 && pc.cout % 16 == 0) {
         // U[a][b] = sum_ij G[a][i] g[i][j] G[b][j], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] (double accumulation)
         static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
         std::vector<float> wk((size_t)pc.groups * 16 * pc.mtiles * 64 * 4);
@@ -327,7 +329,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
     for (const Tensor& t : in0) out.push_back(new_tensor(m, t.H, t.W, pc.cout));
     // bf16 MFMAs are so much faster that the LDS-bound Winograd kernels only pay at 128 channels (and they amplify the
     // bf16 rounding): the bf16 variant takes the direct kernels below that
-    const bool wino = pc.d_wino && m->use_winograd && (!m->bf16 || pc.mtiles >= 8);
+    const bool wino = pc.d_wino && m->use_winograd && (!m->bf16 || pc.mtiles >= 8) && (pc.mtiles > 1 || (m->wino16 && m->wino_reg));
     // single channel group, one 16-channel output tile: 16 x 32 pixel blocks, single LDS buffer (more MFMA work per
     // block against the fixed load latency of these short blocks)
     const bool big_tile = !wino && !pc.c8 && pc.groups == 1 && pc.mtiles == 1 && m->big_tile;
@@ -363,13 +365,23 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
                 wt += p.tiles_x * cdiv(in0[i].H, WINO_TH);
             }
             const int mt = pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1);
+            if (mt == 1) {                                   // register-resident variant for one m-tile: 8 x 32 pixel blocks
+                wt = 0;
+                for (size_t i = b0; i < b1; ++i) {
+                    ConvProb& p = a.p[i - b0];
+                    p.tile_begin = wt;
+                    wt += p.tiles_x * cdiv(in0[i].H, 2 * WINO_TH);
+                }
+            }
             a.total_tiles = wt;
             const int ny = pc.mtiles / mt;
             dim3 grid(wt, ny);
-            std::string pname = (mt == 2 && m->wino_reg) ? std::string("conv_winor_kernel") : "conv_wino_kernel<" + std::to_string(mt) + ">";
+            std::string pname = mt == 1 ? std::string("conv_winor_kernel<1>") : (mt == 2 && m->wino_reg) ? std::string("conv_winor_kernel") : "conv_wino_kernel<" + std::to_string(mt) + ">";
             if (m->prof_detail) pname += " " + scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
             ProfScope ps(m, pname, flops);
-            if (mt == 2 && m->wino_reg) {
+            if (mt == 1) {
+                hipLaunchKernelGGL((conv_winor_kernel<false, 1>), grid, dim3(256), 0, m->stream, a);
+            } else if (mt == 2 && m->wino_reg) {
                 // register-resident variant: a wave per (tile row, m-tile); grid.y counts pairs of m-tiles
                 if (m->bf16) hipLaunchKernelGGL((conv_winor_kernel<true>), grid, dim3(256), 0, m->stream, a);
                 else hipLaunchKernelGGL((conv_winor_kernel<false>), grid, dim3(256), 0, m->stream, a);
@@ -998,6 +1010,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     m->bf16 = cfg->compute_dtype == 1;
     if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO_REG")) m->wino_reg = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_WINO16")) m->wino16 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_R8_VALU")) m->r8_valu = atoi(e) != 0;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;

@@ -649,9 +649,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 // No V image, no accumulator exchange, no output tile: the only LDS traffic is the input window (13 KB written, 64 KB
 // read per channel group instead of ~160 KB), at the price of forming V twice (once per m-tile wave).
 // ------------------------------------------------------------------------------------------------
-template <bool BF = false>
+// MH = 16-channel output tiles per block: 2 (the 32-channel level, 4 x 32 pixel blocks) or 1 (the 16-channel level: the four
+// waves are four tile rows of an 8 x 32 pixel block, V is formed once per tile)
+template <bool BF = false, int MH = 2>
 __global__ __launch_bounds__(256, 2) void conv_winor_kernel(const ConvArgs a) {
-    constexpr int TH = WINO_TH, TW = WINO_TW;
+    constexpr int NTR = 4 / MH;                           // tile rows (waves per m-tile)
+    constexpr int TH = 2 * NTR, TW = WINO_TW;
     constexpr int HH = TH + 2, HW = TW + 2, HP = 20;      // window: 6 x 34 pixels x 16 channels, pixel pitch 20 floats
     constexpr int NH = HH * HW * 4;                       // float4 slots of the window
     constexpr int NHL = (NH + 255) / 256;
@@ -660,13 +663,13 @@ __global__ __launch_bounds__(256, 2) void conv_winor_kernel(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, kk = lane >> 4;
-    const int n = wave & 1, mh = wave >> 1;
+    const int n = wave % NTR, mh = wave / NTR;
     int pi = 0;
     while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
     const ConvProb& P = a.p[pi];
     const int tile = blockIdx.x - P.tile_begin;
     const int tyb = tile / P.tiles_x, txb = tile - tyb * P.tiles_x;
-    const int x0 = txb * TW, y0 = tyb * TH, mt = blockIdx.y * 2 + mh;      // this wave's 16-channel output tile
+    const int x0 = txb * TW, y0 = tyb * TH, mt = blockIdx.y * MH + mh;     // this wave's 16-channel output tile
     const int H = P.H, W = P.W;
 
     // window: HBM -> registers (16 B per lane, coalesced, one channel group ahead) -> LDS; raw values + validity mask
