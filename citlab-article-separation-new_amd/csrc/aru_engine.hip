@@ -57,9 +57,9 @@ struct asep_aru {
     float* d_r8_up_br = nullptr;     // [3][8]
     float* d_r8_up_b1 = nullptr;     // [8]
     // the same filters in scalar layout for the fp32 vector-ALU kernels (res8v_kernels.h)
-    float* d_r8v_down_wr = nullptr;  // [3][576]
-    float* d_r8v_up_w1 = nullptr;    // [2][576]
-    float* d_r8v_up_wr = nullptr;    // [3][576]
+    float* d_r8v_down_wr = nullptr;  // [3][R8V_FILTER]
+    float* d_r8v_up_w1 = nullptr;    // [2][R8V_FILTER]
+    float* d_r8v_up_wr = nullptr;    // [3][R8V_FILTER]
     bool r8_valu = true;             // fp32 only; ASEP_R8_VALU=0 runs the fp32 MFMA variants instead
     bool use_fused8 = true;          // ASEP_FUSED8=0 falls back to the layer-by-layer kernels
     float* d_att_head = nullptr;     // A fragment of attPart/conv1 for att_head_kernel (12 output channels, 4x4 taps)
@@ -528,13 +528,27 @@ void pack_pair8(const HostTensor& w, int cin, int ci0, std::vector<float>& dst) 
                 }
 }
 
-// scalar layout of a 3x3 conv with 8 input channels starting at input channel ci0 of W[3][3][cin][8] (res8v_kernels.h):
-// [g = (ky*2 + hf)*3 + kx][c][co], input channel ci0 + hf*4 + c
+// scalar layout of a 3x3 conv with 8 input channels starting at input channel ci0 of W[3][3][cin][8] (res8v_kernels.h).
+// Direct: [g = (ky*2 + hf)*3 + kx][c][co], input channel ci0 + hf*4 + c.  Winograd F(2,3) along x: [(ky*2 + hf)*4 + j][c][co],
+// U_j = sum_kx G[j][kx] g[ky][kx], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] (double accumulation)
 void pack_scalar8(const HostTensor& w, int cin, int ci0, std::vector<float>& dst) {
+    auto W = [&](int ky, int kx, int ci, int co) { return (double)w.data[(((size_t)ky * 3 + kx) * cin + ci0 + ci) * 8 + co]; };
+    if (R8V_WINO) {
+        static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        for (int rh = 0; rh < 6; ++rh)
+            for (int j = 0; j < 4; ++j)
+                for (int c = 0; c < 4; ++c)
+                    for (int co = 0; co < 8; ++co) {
+                        double u = 0;
+                        for (int kx = 0; kx < 3; ++kx) u += G[j][kx] * W(rh >> 1, kx, (rh & 1) * 4 + c, co);
+                        dst.push_back((float)u);
+                    }
+        return;
+    }
     for (int g = 0; g < 18; ++g) {
         const int ky = g / 6, hf = (g / 3) % 2, kx = g % 3;
         for (int c = 0; c < 4; ++c)
-            for (int co = 0; co < 8; ++co) dst.push_back(w.data[(((size_t)ky * 3 + kx) * cin + ci0 + hf * 4 + c) * 8 + co]);
+            for (int co = 0; co < 8; ++co) dst.push_back((float)W(ky, kx, hf * 4 + c, co));
     }
 }
 

@@ -18,10 +18,21 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const float __attribute__((address_space(4)))* r8v_cptr;   // constant address space: stays on s_load
 typedef char __attribute__((address_space(3)))* r8v_lds;           // LDS byte address (32 bits, one VGPR)
 
-constexpr int R8V_FILTER = 576;     // floats per 8->8 filter in scalar layout [g = (ky*2 + hf)*3 + kx][c = ci & 3][co], ci = hf*4 + c
+#ifndef R8V_WINO
+#define R8V_WINO 0                  // 1: Winograd F(2,3) along x (r8v_conv_wino) instead of the direct form: an experiment, see there
+#endif
+#ifndef R8V_WINO_GS
+#define R8V_WINO_GS 16              // scalars per weight group of r8v_conv_wino (16 or 32)
+#endif
+// floats per 8->8 filter in scalar layout.  Direct: [g = (ky*2 + hf)*3 + kx][c = ci & 3][co], ci = hf*4 + c.
+// Winograd: [(ky*2 + hf)*4 + j][c][co], j = position of F(2,3): U_j = sum_kx G[j][kx] g[ky][kx] (packed in double by the engine)
+constexpr int R8V_FILTER = R8V_WINO ? 768 : 576;
 
 // The kernels take Res8Args like the MFMA kernels; the filters behind w1 (UP) and wr are in scalar layout instead of
 // pixel-pair fragments: UP w1 = [2 sources][R8V_FILTER], wr = [3][R8V_FILTER] floats.
+
+__device__ __forceinline__ f32x4 r8v_ld(r8v_lds p) { return *reinterpret_cast<const f32x4 __attribute__((address_space(3)))*>(p); }
+__device__ __forceinline__ void r8v_st(r8v_lds p, f32x4 v) { *reinterpret_cast<f32x4 __attribute__((address_space(3)))*>(p) = v; }
 
 // one packed FMA: acc += {v, v} * w, v = element (odd ? 1 : 0) of the 64-bit register pair `pair` (two neighbouring input
 // channels).  Written as asm: left to instruction selection, some of the odd elements were first copied to the low half
@@ -43,7 +54,7 @@ __device__ __forceinline__ void r8v_fma(f32x2& acc, f32x2 pair, f32x2 w) {
 // it.  The double buffer is 2 x 16 SGPRs: the kernels carry ~40 scalars of their own and the file has 102 (with 2 x 32
 // the allocator spilled weights to VGPR lanes, thousands of v_readlane); the stage time is the same (6.0 k cycles).
 template <bool RELU_IN>
-__device__ __forceinline__ void r8v_conv(const r8v_lds (&a)[4][2], r8v_cptr wl,
+__device__ __forceinline__ void r8v_conv_direct(const r8v_lds (&a)[4][2], r8v_cptr wl,
                                          f32x2 (&acc0)[4], f32x2 (&acc1)[4]) {
     float wc[16], wn[16];
 #pragma unroll
@@ -97,6 +108,96 @@ __device__ __forceinline__ void r8v_conv(const r8v_lds (&a)[4][2], r8v_cptr wl,
     asm volatile("" : "+v"(acc0[0]), "+v"(acc0[1]), "+v"(acc0[2]), "+v"(acc0[3]), "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]));
 }
 
+// first product of an accumulator: acc = {v, v} * w (no zero-initialisation of the 16 Winograd sums)
+template <int ODD>
+__device__ __forceinline__ void r8v_mul(f32x2& acc, f32x2 pair, f32x2 w) {
+    if (ODD) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(acc) : "v"(pair), "s"(w));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(acc) : "v"(pair), "s"(w));
+}
+
+// The same sums by Winograd F(2,3) ALONG X: the thread's two output pixels y0, y1 of a row come from its four window
+// pixels d0..d3 as  y0 = m0 + m1 + m2,  y1 = m1 - m2 - m3  with  m_j = V_j * U_j,  V = (d0 - d2, d1 + d2, d2 - d1, d1 - d3),
+// U = (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2)  per (ky, ci, co): 4 instead of 6 products per row and channel.
+// Per thread and stage: 48 packed adds for V (on channel pairs), 384 packed FMAs, 24 for the output: 456 vector
+// instructions instead of 576.  One-dimensional on purpose: the thread mapping, the LDS reads and the epilogues stay
+// those of the direct form (a 2-D tile would need 2 x 2 pixels per thread: half the threads, or the output channels
+// split across waves with the input transform done twice).  fp32 throughout; the transform matrices hold 0, +-1, 1/2.
+// Measured (parity-green, profiles/r2p_valu): a stage whose weights hit the scalar cache gains 6-9 % (conv1 5.7 -> 5.2 k cycles,
+// stage 1 6.5 -> 6.1 k: the waits now come every 8 FMAs), res8v_down 3.76 -> 3.69 ms; but the UP block's five filters grow
+// from 11.5 to 15.4 KB, which no longer fits the 16 KB scalar data cache: its second conv1 half went from 5.8 to 9.1 k
+// cycles, the last stage from 6.8 to 9.7 k, the kernel from 5.40 to 6.33 ms.  Not used (-DR8V_WINO=1 builds it).
+template <bool RELU_IN>
+__device__ __forceinline__ void r8v_conv_wino(const r8v_lds (&a)[4][2], r8v_cptr wl,
+                                              f32x2 (&acc0)[4], f32x2 (&acc1)[4]) {
+    constexpr int GS = R8V_WINO_GS, NG = 768 / GS, GPR = 128 / GS;           // groups per (ky, hf) row-half
+    float wc[GS], wn[GS];
+#pragma unroll
+    for (int k = 0; k < GS; ++k) wc[k] = wl[k];
+    f32x4 dA[4], dB[4], V[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dA[i] = r8v_ld(a[i][0]);
+    f32x2 M[4][4];                                      // [position][output channel pair]
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int rh = g / GPR, gi = g % GPR;           // rh = ky * 2 + hf
+        const int j = GS == 32 ? gi : gi >> 1;
+        asm volatile("" :: "s"(wc[0]), "v"(dA[0]), "v"(dA[1]), "v"(dA[2]), "v"(dA[3]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int k = 0; k < GS; ++k) wn[k] = wl[(g + 1) * GS + k];
+        }
+        if (gi == 0 && rh + 1 < 6) {
+            const int ky2 = (rh + 1) >> 1, hf2 = (rh + 1) & 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dB[i] = r8v_ld(a[i][hf2] + ky2 * R8_PITCH * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (gi == 0) {
+            if (RELU_IN) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dA[i] = relu4i(dA[i]);
+            }
+            V[0] = dA[0] - dA[2]; V[1] = dA[1] + dA[2]; V[2] = dA[2] - dA[1]; V[3] = dA[1] - dA[3];
+        }
+#pragma unroll
+        for (int cc = 0; cc < GS / 16; ++cc) {
+            const int ch = GS == 32 ? cc : gi & 1;          // channel pair of the half: (x, y) or (z, w)
+            const f32x2 in = ch ? f32x2{V[j].z, V[j].w} : f32x2{V[j].x, V[j].y};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x2 wv = f32x2{wc[cc * 16 + 2 * q], wc[cc * 16 + 2 * q + 1]};
+                if (rh == 0 && ch == 0) r8v_mul<0>(M[j][q], in, wv);
+                else r8v_fma<0>(M[j][q], in, wv);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x2 wv = f32x2{wc[cc * 16 + 8 + 2 * q], wc[cc * 16 + 8 + 2 * q + 1]};
+                r8v_fma<1>(M[j][q], in, wv);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < GS; ++k) wc[k] = wn[k];
+        if (gi == GPR - 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dA[i] = dB[i];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        acc0[q] += M[0][q] + M[1][q] + M[2][q];
+        acc1[q] += M[1][q] - M[2][q] - M[3][q];
+    }
+    // pinned like the direct form (see there)
+    asm volatile("" : "+v"(acc0[0]), "+v"(acc0[1]), "+v"(acc0[2]), "+v"(acc0[3]), "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]));
+}
+
+template <bool RELU_IN>
+__device__ __forceinline__ void r8v_conv(const r8v_lds (&a)[4][2], r8v_cptr wl, f32x2 (&acc0)[4], f32x2 (&acc1)[4]) {
+    if constexpr (R8V_WINO) r8v_conv_wino<RELU_IN>(a, wl, acc0, acc1);
+    else r8v_conv_direct<RELU_IN>(a, wl, acc0, acc1);
+}
+
 __device__ __forceinline__ f32x4 r8v_lo(const f32x2 (&a)[4]) { return f32x4{a[0].x, a[0].y, a[1].x, a[1].y}; }
 __device__ __forceinline__ f32x4 r8v_hi(const f32x2 (&a)[4]) { return f32x4{a[2].x, a[2].y, a[3].x, a[3].y}; }
 __device__ __forceinline__ f32x4 r8v_max4(f32x4 a, f32x4 b) { return f32x4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)}; }
@@ -120,8 +221,7 @@ __device__ __forceinline__ void r8v_window(r8v_lds (&a)[4][2], float* sm, const 
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) { a[i][hf] = (r8v_lds)reinterpret_cast<char*>(sm) + (poff[j0 + i][hf] + row_bytes); asm volatile("" : "+v"(a[i][hf])); }
 }
-__device__ __forceinline__ f32x4 r8v_ld(r8v_lds p) { return *reinterpret_cast<const f32x4 __attribute__((address_space(3)))*>(p); }
-__device__ __forceinline__ void r8v_st(r8v_lds p, f32x4 v) { *reinterpret_cast<f32x4 __attribute__((address_space(3)))*>(p) = v; }
+
 
 // one 3x3 8->8 convolution stage on LDS tiles.  IN holds rows in_r0.. of the frame, OUT rows out_r0.. ; computes rows
 // [row_start, row_start + nrows) x columns [out_c0, out_c0 + 64): thread -> (row tid >> 5 (+16), pixels out_c0 + 2 (tid & 31), +1).
