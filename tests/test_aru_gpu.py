@@ -143,3 +143,23 @@ def test_unsupported_width_is_rejected_loudly():
     cfg, w, graph = _setup({"feat_root": 4})
     with pytest.raises(_lib.AsepError):
         helper.get_net_output(_image(32, 32, 0), graph, "0")
+
+
+@pytest.mark.parametrize("H,W", [(200, 150), (70, 300)])
+def test_fp32_level0_mfma_variant_agrees_with_the_vector_alu_kernels(H, W, monkeypatch):
+    """The fp32 level-0 blocks run on the vector ALU (res8v_kernels.h); the MFMA kernels of the same blocks serve bf16 and
+    tensors of >= 2^28 pixels, and ASEP_R8_VALU=0 selects them for fp32: both must meet the oracle tolerance, and agree with
+    each other far inside it (same sums, different order)."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from oracle import aru_oracle
+    img = _image(H, W, 77)
+    outs = {}
+    for valu in ("1", "0"):
+        monkeypatch.setenv("ASEP_R8_VALU", valu)          # read when the engine is created
+        cfg, w, graph = _setup()
+        outs[valu] = helper.get_net_output(img, graph, "0")
+        graph.close()
+    ref = aru_oracle.forward_torch(img, w, cfg)
+    for valu, out in outs.items():
+        assert float(np.abs(out - ref).max()) <= PROB_TOL, valu
+    assert float(np.abs(outs["1"] - outs["0"]).max()) <= 1e-5
