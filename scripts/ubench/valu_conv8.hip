@@ -51,7 +51,12 @@ void stage_kernel(const float* __restrict__ w, const float* __restrict__ bias, c
         for (int k = 0; k < 16; ++k) hc[k] = wl[k];
         f32x4 dA[4], dB[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dA[i] = *reinterpret_cast<const f32x4*>(IN + r * PITCH * 8 + off[i][0]);
+#ifdef ROWSWZ
+#define RS(ky) ((((r + (ky)) & 1) ? 8 : 0))
+#else
+#define RS(ky) 0
+#endif
+        for (int i = 0; i < 4; ++i) dA[i] = *reinterpret_cast<const f32x4*>(IN + r * PITCH * 8 + (off[i][0] ^ RS(0)));
 #pragma unroll
         for (int g2 = 0; g2 < 36; ++g2) {
             const int g = g2 >> 1, ch = g2 & 1, kx = g % 3, rh = g / 3;
@@ -64,7 +69,7 @@ void stage_kernel(const float* __restrict__ w, const float* __restrict__ bias, c
             if (kx == 0 && ch == 0 && rh + 1 < 6) {
                 const int ky2 = (rh + 1) >> 1, hf2 = (rh + 1) & 1;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dB[i] = *reinterpret_cast<const f32x4*>(IN + (r + ky2) * PITCH * 8 + off[i][hf2]);
+                for (int i = 0; i < 4; ++i) dB[i] = *reinterpret_cast<const f32x4*>(IN + (r + ky2) * PITCH * 8 + (off[i][hf2] ^ RS(ky2)));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -186,11 +191,16 @@ void stage_kernel(const float* __restrict__ w, const float* __restrict__ bias, c
 #endif
         // ReLU, write both pixels (whole 32-byte pixels) to the output tile
         float* o = OUT + r * PITCH * 8;
+#ifdef ROWSWZ
+        const int ws = (r & 1) ? 8 : 0;
+#else
+        const int ws = 0;
+#endif
         f32x4 v;
-        v = f32x4{fmaxf(acc0[0].x, 0.f), fmaxf(acc0[0].y, 0.f), fmaxf(acc0[1].x, 0.f), fmaxf(acc0[1].y, 0.f)}; *reinterpret_cast<f32x4*>(o + off[1][0]) = v;
-        v = f32x4{fmaxf(acc0[2].x, 0.f), fmaxf(acc0[2].y, 0.f), fmaxf(acc0[3].x, 0.f), fmaxf(acc0[3].y, 0.f)}; *reinterpret_cast<f32x4*>(o + off[1][1]) = v;
-        v = f32x4{fmaxf(acc1[0].x, 0.f), fmaxf(acc1[0].y, 0.f), fmaxf(acc1[1].x, 0.f), fmaxf(acc1[1].y, 0.f)}; *reinterpret_cast<f32x4*>(o + off[2][0]) = v;
-        v = f32x4{fmaxf(acc1[2].x, 0.f), fmaxf(acc1[2].y, 0.f), fmaxf(acc1[3].x, 0.f), fmaxf(acc1[3].y, 0.f)}; *reinterpret_cast<f32x4*>(o + off[2][1]) = v;
+        v = f32x4{fmaxf(acc0[0].x, 0.f), fmaxf(acc0[0].y, 0.f), fmaxf(acc0[1].x, 0.f), fmaxf(acc0[1].y, 0.f)}; *reinterpret_cast<f32x4*>(o + (off[1][0] ^ ws)) = v;
+        v = f32x4{fmaxf(acc0[2].x, 0.f), fmaxf(acc0[2].y, 0.f), fmaxf(acc0[3].x, 0.f), fmaxf(acc0[3].y, 0.f)}; *reinterpret_cast<f32x4*>(o + (off[1][1] ^ ws)) = v;
+        v = f32x4{fmaxf(acc1[0].x, 0.f), fmaxf(acc1[0].y, 0.f), fmaxf(acc1[1].x, 0.f), fmaxf(acc1[1].y, 0.f)}; *reinterpret_cast<f32x4*>(o + (off[2][0] ^ ws)) = v;
+        v = f32x4{fmaxf(acc1[2].x, 0.f), fmaxf(acc1[2].y, 0.f), fmaxf(acc1[3].x, 0.f), fmaxf(acc1[3].y, 0.f)}; *reinterpret_cast<f32x4*>(o + (off[2][1] ^ ws)) = v;
         __syncthreads();
     }
     if (tid == 0) cyc[blockIdx.x] = clock64() - t0;
@@ -226,13 +236,18 @@ int main() {
     std::vector<float> ho(ROWS_OUT * PITCH * 8);
     CK(hipMemcpy(ho.data(), out, ho.size() * 4, hipMemcpyDeviceToHost));
     double maxerr = 0;
-    auto IN = [&](int row, int x, int c) { const int hf = c >> 2; const int off = ((x >> 1) << 4) + (((((x & 1) << 1) | hf) ^ ((x >> 2) & 3)) << 2); return hin[row * PITCH * 8 + off + (c & 3)]; };
+#ifdef ROWSWZ
+    const int rsw = 8;
+#else
+    const int rsw = 0;
+#endif
+    auto IN = [&](int row, int x, int c) { const int hf = c >> 2; const int off = (((x >> 1) << 4) + (((((x & 1) << 1) | hf) ^ ((x >> 2) & 3)) << 2)) ^ ((row & 1) ? rsw : 0); return hin[row * PITCH * 8 + off + (c & 3)]; };
     for (int r = 0; r < 16; ++r) for (int x = 1; x <= 64; ++x) for (int co = 0; co < 8; ++co) {
         double s = hb[co];
         for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) for (int ci = 0; ci < 8; ++ci)
             s += (double)IN(r + ky, x - 1 + kx, ci) * hw[((((ky * 2 + (ci >> 2)) * 3 + kx) * 4 + (ci & 3)) * 8) + co];
         s = s > 0 ? s : 0;
-        const int hf = co >> 2; const int off = ((x >> 1) << 4) + (((((x & 1) << 1) | hf) ^ ((x >> 2) & 3)) << 2);
+        const int hf = co >> 2; const int off = (((x >> 1) << 4) + (((((x & 1) << 1) | hf) ^ ((x >> 2) & 3)) << 2)) ^ ((r & 1) ? rsw : 0);
         maxerr = std::max(maxerr, std::abs(s - (double)ho[r * PITCH * 8 + off + (co & 3)]));
     }
     printf("max |err| vs host double: %.2e\n", maxerr);
