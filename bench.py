@@ -379,7 +379,7 @@ def main():
                          "tflops": round(k["tflops"], 2), "executed_tflops": round(k["executed_tflops"], 2),
                          "executed_frac_of_peak": round(k["executed_tflops"] / (PEAK_F32_MFMA_TFLOPS if args.dtype == "f32"
                                                                               else PEAK_BF16_MFMA_TFLOPS), 4)}
-                        for k in kernels[:8]],
+                        for k in kernels[:12]],
             "secondary": secondary,
         }
         print(json.dumps(line), flush=True)

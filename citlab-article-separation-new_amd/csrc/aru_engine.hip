@@ -802,9 +802,12 @@ TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) 
                 flops += 2.0 * imgs[i].H * imgs[i].W * 16.0 * 12;
             }
             a.nprob = (int)(b1 - b0);
-            a.wpk = (const f32x4*)m->d_att_head; a.bias = m->att_first.d_b;
-            ProfScope ps(m, "att_head_kernel", flops);
-            hipLaunchKernelGGL(att_head_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
+            a.wpk = (const f32x4*)m->d_att_head; a.bias = m->att_first.d_b; a.w = m->att_first.d_w;
+            bool valu = m->r8_valu && !m->bf16;              // fp32: vector-ALU form (32-bit output offsets, see run_res8_down)
+            for (size_t i = b0; i < b1; ++i) valu = valu && (size_t)imgs[i].H * imgs[i].W < ((size_t)1 << 28);
+            ProfScope ps(m, valu ? "att_headv_kernel" : "att_head_kernel", flops);
+            if (valu) hipLaunchKernelGGL(att_headv_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
+            else hipLaunchKernelGGL(att_head_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
         }
     } else {
         y = run_direct(m, m->att_first, imgs, true, stats);

@@ -18,6 +18,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
 // bf16 variant (asep_aru_cfg.compute_dtype = 1): activations and weights stay fp32 in HBM / LDS; a lane's 16-byte
@@ -88,6 +89,18 @@ __device__ __forceinline__ float from_lower_half(float v) {
 }
 __device__ __forceinline__ float from_upper_half(float v) {
     return __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false)[1]);
+}
+// a - b as ONE packed instruction per two floats: hipcc selects v_pk_add_f32 for vector sums but a v_sub_f32 per element for
+// vector differences, and on gfx950 every vector instruction of an fp32 MFMA kernel is paid out of the MFMA's own datapath
+// time (DESIGN lesson 15).  Same result bit for bit (a + (-b)).
+__device__ __forceinline__ f32x2 psub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x4 psub(f32x4 a, f32x4 b) {
+    const f32x2 lo = psub(f32x2{a.x, a.y}, f32x2{b.x, b.y}), hi = psub(f32x2{a.z, a.w}, f32x2{b.z, b.w});
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
 // max(x, lim) on the bit patterns (one v_max_i32 per element; fmaxf costs a second, canonicalising v_max_f32):
 // lim = 0 is ReLU, lim = INT_MIN the identity, so that a run-time "relu?" flag needs no branch
@@ -473,14 +486,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
         for (int r = 0; r < 4; ++r) {
             // row r of B^T d, then times B, written straight out (keeps at most one row of temporaries live)
             f32x2 t0, t1, t2, t3;
-            if (r == 0) { t0 = d[0][0] - d[2][0]; t1 = d[0][1] - d[2][1]; t2 = d[0][2] - d[2][2]; t3 = d[0][3] - d[2][3]; }
+            if (r == 0) { t0 = psub(d[0][0], d[2][0]); t1 = psub(d[0][1], d[2][1]); t2 = psub(d[0][2], d[2][2]); t3 = psub(d[0][3], d[2][3]); }
             else if (r == 1) { t0 = d[1][0] + d[2][0]; t1 = d[1][1] + d[2][1]; t2 = d[1][2] + d[2][2]; t3 = d[1][3] + d[2][3]; }
-            else if (r == 2) { t0 = d[2][0] - d[1][0]; t1 = d[2][1] - d[1][1]; t2 = d[2][2] - d[1][2]; t3 = d[2][3] - d[1][3]; }
-            else { t0 = d[1][0] - d[3][0]; t1 = d[1][1] - d[3][1]; t2 = d[1][2] - d[3][2]; t3 = d[1][3] - d[3][3]; }
-            *reinterpret_cast<f32x2*>(vb + (r * 4 + 0) * TILES * 16) = t0 - t2;
+            else if (r == 2) { t0 = psub(d[2][0], d[1][0]); t1 = psub(d[2][1], d[1][1]); t2 = psub(d[2][2], d[1][2]); t3 = psub(d[2][3], d[1][3]); }
+            else { t0 = psub(d[1][0], d[3][0]); t1 = psub(d[1][1], d[3][1]); t2 = psub(d[1][2], d[3][2]); t3 = psub(d[1][3], d[3][3]); }
+            *reinterpret_cast<f32x2*>(vb + (r * 4 + 0) * TILES * 16) = psub(t0, t2);
             *reinterpret_cast<f32x2*>(vb + (r * 4 + 1) * TILES * 16) = t1 + t2;
-            *reinterpret_cast<f32x2*>(vb + (r * 4 + 2) * TILES * 16) = t2 - t1;
-            *reinterpret_cast<f32x2*>(vb + (r * 4 + 3) * TILES * 16) = t1 - t3;
+            *reinterpret_cast<f32x2*>(vb + (r * 4 + 2) * TILES * 16) = psub(t2, t1);
+            *reinterpret_cast<f32x2*>(vb + (r * 4 + 3) * TILES * 16) = psub(t1, t3);
         }
     };
 
@@ -587,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const f32x4 z0 = acc[0][m][n] + acc[1][m][n] + acc[2][m][n];
-                    const f32x4 z1 = acc[1][m][n] - acc[2][m][n] - acc[3][m][n];
+                    const f32x4 z1 = psub(psub(acc[1][m][n], acc[2][m][n]), acc[3][m][n]);
                     float* xb = V + h * VBUF + ((wave * 2) * TILES + n * 16 + j) * 16 + kk_sw;
                     *reinterpret_cast<f32x4*>(xb) = z0;
                     *reinterpret_cast<f32x4*>(xb + TILES * 16) = z1;
@@ -614,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
                 const f32x2 z2 = *reinterpret_cast<const f32x2*>(mb + (2 * 2 + dx) * TILES * 16);
                 const f32x2 z3 = *reinterpret_cast<const f32x2*>(mb + (3 * 2 + dx) * TILES * 16);
                 *reinterpret_cast<f32x2*>(ob + dx * CPR) = z0 + z1 + z2;
-                *reinterpret_cast<f32x2*>(ob + TW * CPR + dx * CPR) = z1 - z2 - z3;
+                *reinterpret_cast<f32x2*>(ob + TW * CPR + dx * CPR) = psub(psub(z1, z2), z3);
             }
         }
         __syncthreads();
@@ -749,17 +762,17 @@ __global__ __launch_bounds__(256, 2) void conv_winor_kernel(const ConvArgs a) {
             f32x4 t[4][4];
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
-                t[0][s2] = d0[s2] - d2[s2];
+                t[0][s2] = psub(d0[s2], d2[s2]);
                 t[1][s2] = d1[s2] + d2[s2];
-                t[2][s2] = d2[s2] - d1[s2];
-                t[3][s2] = d1[s2] - d3[s2];
+                t[2][s2] = psub(d2[s2], d1[s2]);
+                t[3][s2] = psub(d1[s2], d3[s2]);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                V[r][0] = t[r][0] - t[r][2];
+                V[r][0] = psub(t[r][0], t[r][2]);
                 V[r][1] = t[r][1] + t[r][2];
-                V[r][2] = t[r][2] - t[r][1];
-                V[r][3] = t[r][1] - t[r][3];
+                V[r][2] = psub(t[r][2], t[r][1]);
+                V[r][3] = psub(t[r][1], t[r][3]);
             }
         }
         // ---- 16 positions x (K = 16 channels) for this wave's m-tile; the filter fragment is requested one position ahead ----
@@ -791,14 +804,14 @@ __global__ __launch_bounds__(256, 2) void conv_winor_kernel(const ConvArgs a) {
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) {
         s0[s2] = acc[0 * 4 + s2] + acc[1 * 4 + s2] + acc[2 * 4 + s2];
-        s1[s2] = acc[1 * 4 + s2] - acc[2 * 4 + s2] - acc[3 * 4 + s2];
+        s1[s2] = psub(psub(acc[1 * 4 + s2], acc[2 * 4 + s2]), acc[3 * 4 + s2]);
     }
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + co);
     f32x4 y[2][2];
     y[0][0] = s0[0] + s0[1] + s0[2] + b4;
-    y[0][1] = s0[1] - s0[2] - s0[3] + b4;
+    y[0][1] = psub(psub(s0[1], s0[2]), s0[3]) + b4;
     y[1][0] = s1[0] + s1[1] + s1[2] + b4;
-    y[1][1] = s1[1] - s1[2] - s1[3] + b4;
+    y[1][1] = psub(psub(s1[1], s1[2]), s1[3]) + b4;
     const int relu_o = a.relu_out ? 0 : (int)0x80000000;
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
@@ -1079,6 +1092,7 @@ struct AttHeadArgs {
     int nprob;
     const f32x4* wpk;      // [64 lanes] A fragment: row = cout (12 real), slots = taps
     const float* bias;     // [12]
+    const float* w;        // [16 taps][12] (att_headv_kernel: scalar operands)
 };
 
 __global__ __launch_bounds__(256) void att_head_kernel(const AttHeadArgs a) {
