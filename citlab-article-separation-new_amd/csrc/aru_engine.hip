@@ -103,6 +103,7 @@ struct asep_aru {
     bool bf16 = false;             // cfg.compute_dtype == 1: bf16 MFMA operands, fp32 accumulation and storage
     bool wino_reg = true;          // ASEP_WINO_REG=0: LDS-image Winograd kernel also for the 32-channel level
     bool use_winograd = true;      // ASEP_WINOGRAD=0 selects the direct implicit-GEMM kernels everywhere
+    bool fuse_pool = true;         // ASEP_FUSE_POOL=0: separate maxpool2_kernel after every conv
     bool wino16 = false;           // ASEP_WINO16=1: register-resident Winograd also at the 16-channel level (measured: 99 vs
                                    // 103 TFLOP/s-equivalent for the direct kernels, parity-green; kept as an experiment switch)
     bool profiling = false;
@@ -311,8 +312,15 @@ void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, int tot
 }
 
 // stride-1 SAME conv on the (optionally concatenated) inputs of every problem
+enum PoolKind { POOL_MAX, POOL_AVG_C1, POOL_CHANSUM };
+TL run_pool(asep_aru* m, const TL& in, PoolKind kind);
+
+// pooled != nullptr: also produce maxpool2 of the output.  The direct kernels and the register-resident Winograd kernel take
+// the 2x2 max in their epilogue (ConvProb::pool); the others are followed by maxpool2_kernel.  keep_full = false: the caller
+// reads only the pooled tensor (attention CNN), so the unpooled one is not stored (and the returned list is empty) when the
+// pool is fused.
 TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1, bool relu_in, bool relu_out,
-            const TL* res) {
+            const TL* res, TL* pooled = nullptr, bool keep_full = true) {
     auto it = m->convs.find(scope);
     if (it == m->convs.end()) { set_error("internal: conv %s not packed", scope.c_str()); throw ArgError(); }
     const PackedConv& pc = it->second;
@@ -325,11 +333,18 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
         set_error("conv %s: unsupported kernel size %dx%d", scope.c_str(), pc.kh, pc.kw);
         throw ArgError();
     }
-    TL out;
-    for (const Tensor& t : in0) out.push_back(new_tensor(m, t.H, t.W, pc.cout));
     // bf16 MFMAs are so much faster that the LDS-bound Winograd kernels only pay at 128 channels (and they amplify the
     // bf16 rounding): the bf16 variant takes the direct kernels below that
     const bool wino = pc.d_wino && m->use_winograd && (!m->bf16 || pc.mtiles >= 8) && (pc.mtiles > 1 || (m->wino16 && m->wino_reg));
+    const int wino_mt = pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1);
+    const bool fuse_pool = pooled && m->fuse_pool && pc.cout % 4 == 0 && (!wino || (wino_mt <= 2 && m->wino_reg));
+    TL out;
+    if (keep_full || !fuse_pool)
+        for (const Tensor& t : in0) out.push_back(new_tensor(m, t.H, t.W, pc.cout));
+    if (fuse_pool) {
+        pooled->clear();
+        for (const Tensor& t : in0) pooled->push_back(new_tensor(m, cdiv(t.H, 2), cdiv(t.W, 2), pc.cout));
+    }
     // single channel group, one 16-channel output tile: 16 x 32 pixel blocks, single LDS buffer (more MFMA work per
     // block against the fixed load latency of these short blocks)
     const bool big_tile = !wino && !pc.c8 && pc.groups == 1 && pc.mtiles == 1 && m->big_tile;
@@ -341,7 +356,9 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
         double flops = 0;
         for (size_t i = b0; i < b1; ++i) {
             ConvProb& p = a.p[i - b0];
-            p.in0 = in0[i].p; p.in1 = in1 ? (*in1)[i].p : nullptr; p.res = res ? (*res)[i].p : nullptr; p.out = out[i].p;
+            p.in0 = in0[i].p; p.in1 = in1 ? (*in1)[i].p : nullptr; p.res = res ? (*res)[i].p : nullptr;
+            p.out = out.empty() ? nullptr : out[i].p;
+            p.pool = fuse_pool ? (*pooled)[i].p : nullptr;
             p.H = p.Ho = in0[i].H; p.W = p.Wo = in0[i].W;
             p.tiles_x = cdiv(in0[i].W, CONV_TW);
             p.tile_begin = tiles;
@@ -354,6 +371,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
         a.wpk = (const f32x4*)pc.d_w; a.bias = pc.d_b;
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
         a.relu_in = relu_in; a.relu_out = relu_out;
+        a.skip_full = fuse_pool && !keep_full;
         TL sub(in0.begin() + b0, in0.begin() + b1);
         if (wino) {
             a.wpk = (const f32x4*)pc.d_wino;
@@ -364,7 +382,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
                 p.tile_begin = wt;
                 wt += p.tiles_x * cdiv(in0[i].H, WINO_TH);
             }
-            const int mt = pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1);
+            const int mt = wino_mt;
             if (mt == 1) {                                   // register-resident variant for one m-tile: 8 x 32 pixel blocks
                 wt = 0;
                 for (size_t i = b0; i < b1; ++i) {
@@ -395,6 +413,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
         } else if (pc.kh == 3) launch_conv_k<3, 3>(m, pc, a, tiles, flops, scope, sub, big_tile);
         else launch_conv_k<4, 4>(m, pc, a, tiles, flops, scope, sub, big_tile);
     }
+    if (pooled && !fuse_pool) *pooled = run_pool(m, out, POOL_MAX);
     return out;
 }
 
@@ -480,8 +499,6 @@ TL run_direct(asep_aru* m, const DirectConv& dc, const TL& imgs, bool relu, cons
     }
     return out;
 }
-
-enum PoolKind { POOL_MAX, POOL_AVG_C1, POOL_CHANSUM };
 
 TL run_pool(asep_aru* m, const TL& in, PoolKind kind) {
     TL out;
@@ -729,13 +746,13 @@ TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
 
 // ---- network schedule (ARU_v1.py), evaluated for all problems in lock step ---------------------------------
 // residual block: conv1 (identity) -> t ; relu ; (res_depth-1) x conv+relu ; conv (identity) ; +t ; relu
-TL res_block_tail(asep_aru* m, const std::string& scope, const TL& t) {
+TL res_block_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled = nullptr) {
     TL r = t;
     const int rd = m->cfg.res_depth;
     for (int i = 0; i < rd; ++i) {
         const bool last = (i == rd - 1);
         r = run_conv(m, scope + "/convR_" + std::to_string(i), r, nullptr, /*relu_in=*/i == 0,
-                     /*relu_out=*/true, last ? &t : nullptr);
+                     /*relu_out=*/true, last ? &t : nullptr, last ? pooled : nullptr);
     }
     return r;
 }
@@ -760,10 +777,11 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
         }
         TL t = (l == 0) ? run_direct(m, m->det_first, imgs, false, stats)
                         : run_conv(m, scope + "/conv1", u, nullptr, false, false, nullptr);
-        TL d = res_block_tail(m, scope, t);
+        TL pooled;
+        TL d = res_block_tail(m, scope, t, l < n - 1 ? &pooled : nullptr);    // the block's last conv also emits maxpool2(d)
         skips.push_back(d);
         publish(d, "_unet_down_" + std::to_string(l) + "_conv");
-        u = (l < n - 1) ? run_pool(m, d, POOL_MAX) : d;
+        u = (l < n - 1) ? pooled : d;
     }
     for (int l = n - 2; l >= 0; --l) {
         const std::string scope = "aru_net/featMapG/unet_up_" + std::to_string(l);
@@ -813,10 +831,11 @@ TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) 
         y = run_direct(m, m->att_first, imgs, true, stats);
         y = run_pool(m, y, POOL_MAX);
     }
-    y = run_conv(m, p + "2", y, nullptr, false, true, nullptr);
-    y = run_pool(m, y, POOL_MAX);
-    y = run_conv(m, p + "3", y, nullptr, false, true, nullptr);
-    y = run_pool(m, y, POOL_MAX);
+    TL pooled;
+    run_conv(m, p + "2", y, nullptr, false, true, nullptr, &pooled, /*keep_full=*/false);   // conv + ReLU + pool in one kernel
+    y = pooled;
+    run_conv(m, p + "3", y, nullptr, false, true, nullptr, &pooled, /*keep_full=*/false);
+    y = pooled;
     y = run_conv(m, p + "4", y, nullptr, false, true, nullptr);
     return y;
 }
@@ -1028,6 +1047,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO_REG")) m->wino_reg = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO16")) m->wino16 = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_FUSE_POOL")) m->fuse_pool = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_R8_VALU")) m->r8_valu = atoi(e) != 0;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;

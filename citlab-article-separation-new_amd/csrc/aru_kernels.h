@@ -54,6 +54,7 @@ struct ConvProb {
     const float* in1;      // source 1 (channel concat behind source 0) or nullptr
     const float* res;      // residual NHWC [Ho,Wo,cout] added before the output activation, or nullptr
     float* out;            // NHWC [Ho,Wo,cout]
+    float* pool;           // conv_mfma_kernel / conv_winor_kernel: maxpool2(out) [ceil(Ho/2), ceil(Wo/2), cout] or nullptr
     int H, W;              // input spatial size
     int Ho, Wo;            // output spatial size (== H, W for stride-1 conv)
     int tiles_x;           // tiles per row of this problem
@@ -72,6 +73,7 @@ struct ConvArgs {
     int groups;            // number of 16-channel input groups (C16 mode)
     int relu_in;           // apply ReLU while staging the input (pre-activation tensors)
     int relu_out;
+    int skip_full;         // with p[].pool: do not store the unpooled output (nobody reads it)
 };
 
 constexpr int CONV_TH = 8;
@@ -101,6 +103,19 @@ __device__ __forceinline__ f32x2 psub(f32x2 a, f32x2 b) {
 __device__ __forceinline__ f32x4 psub(f32x4 a, f32x4 b) {
     const f32x2 lo = psub(f32x2{a.x, a.y}, f32x2{b.x, b.y}), hi = psub(f32x2{a.z, a.w}, f32x2{b.z, b.w});
     return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+// value of lane ^ 1 (DPP quad_perm [1,0,3,2]: one VALU instruction, no LDS)
+__device__ __forceinline__ float lane_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ f32x4 max4(f32x4 a, f32x4 b) { return f32x4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)}; }
+// 2x2 max pool fused into a conv epilogue whose lanes hold pixel x (even/odd in lanes j, j ^ 1) of rows y (v0) and y + 1 (v1),
+// y and the even lane's x even: the even lane stores max over the window's pixels that lie inside the image (ceil mode,
+// like maxpool2_kernel).  Called by ALL lanes (the DPP exchange needs its neighbour active).
+__device__ __forceinline__ void pool2_store(f32x4 v0, f32x4 v1, bool row1, bool col1, bool store, float* __restrict__ dst) {
+    f32x4 mm = row1 ? max4(v0, v1) : v0;
+    const f32x4 nb = f32x4{lane_xor1(mm.x), lane_xor1(mm.y), lane_xor1(mm.z), lane_xor1(mm.w)};
+    if (store) *reinterpret_cast<f32x4*>(dst) = col1 ? max4(mm, nb) : mm;
 }
 // max(x, lim) on the bit patterns (one v_max_i32 per element; fmaxf costs a second, canonicalising v_max_f32):
 // lim = 0 is ReLU, lim = INT_MIN the identity, so that a run-time "relu?" flag needs no branch
@@ -325,7 +340,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                 } else {
                     if (res) v += *reinterpret_cast<const f32x4*>(rp + d);
                 }
-                *reinterpret_cast<f32x4*>(o + d) = imax4(v, relu_o);
+                v = imax4(v, relu_o);
+                acc[m][n] = v;
+                if (!a.skip_full) *reinterpret_cast<f32x4*>(o + d) = v;
+            }
+            if (P.pool) {
+                // a wave's n-tiles n, n + 2 are the same 16 columns of rows y, y + 1 (y even): the 2x2 max needs the row
+                // partner from registers and the column partner from lane j ^ 1
+                const int Wp = (P.Wo + 1) >> 1;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    if (n & 2) continue;
+                    const int id = wave * NT + n;
+                    const int y = y0 + (id >> 1), x = x0 + (id & 1) * 16 + j;
+                    pool2_store(acc[m][n], acc[m][n + 2], true, true, (j & 1) == 0,
+                                P.pool + ((size_t)(y >> 1) * Wp + (x >> 1)) * a.cout + c);
+                }
             }
         }
         return;
@@ -349,7 +379,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                     if (res) v += *reinterpret_cast<const f32x4*>(res + p * a.cout + c);
                 }
                 if (a.relu_out) v = relu4(v);
-                *reinterpret_cast<f32x4*>(out + p * a.cout + c) = v;
+                acc[m][n] = v;
+                if (!a.skip_full) *reinterpret_cast<f32x4*>(out + p * a.cout + c) = v;
             } else {
                 for (int r = 0; r < 4 && c + r < a.cout; ++r) {
                     float s = v[r] + a.bias[c + r];
@@ -357,6 +388,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                     if (a.relu_out) s = fmaxf(s, 0.f);
                     out[p * a.cout + c + r] = s;
                 }
+            }
+        }
+    }
+    if (P.pool) {
+        // border tiles (the host requests the fused pool only for cout % 4 == 0): every lane takes part in the exchange,
+        // pixels outside the image are excluded by the row / column flags
+        const int Wp = (P.Wo + 1) >> 1;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            if (n & 2) continue;
+            const int id = wave * NT + n;
+            const int y = y0 + (id >> 1), x = x0 + (id & 1) * 16 + j;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int c = (mt0 + m) * 16 + kk * 4;
+                const bool ok = (j & 1) == 0 && y < P.Ho && x < P.Wo && c < a.cout;
+                pool2_store(acc[m][n], acc[m][n + 2], y + 1 < P.Ho, x + 1 < P.Wo, ok,
+                            P.pool + ((size_t)(y >> 1) * Wp + (x >> 1)) * a.cout + c);
             }
         }
     }
@@ -818,12 +867,22 @@ __global__ __launch_bounds__(256, 2) void conv_winor_kernel(const ConvArgs a) {
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
             const int yy = oy + dy, xx = ox + dx;
-            if (yy < P.Ho && xx < P.Wo) {
+            y[dy][dx] = imax4(y[dy][dx] + rv[dy * 2 + dx], relu_o);
+            if (yy < P.Ho && xx < P.Wo && !a.skip_full) {
                 const size_t pp = ((size_t)yy * P.Wo + xx) * a.cout + co;
-                const f32x4 v = y[dy][dx] + rv[dy * 2 + dx];
-                *reinterpret_cast<f32x4*>(P.out + pp) = imax4(v, relu_o);
+                *reinterpret_cast<f32x4*>(P.out + pp) = y[dy][dx];
             }
         }
+    if (P.pool && oy < P.Ho && ox < P.Wo) {
+        // the lane's 2x2 output tile IS a pool window (oy, ox even); ceil mode at the right / bottom border
+        f32x4 mm = y[0][0];
+        if (ox + 1 < P.Wo) mm = max4(mm, y[0][1]);
+        if (oy + 1 < P.Ho) {
+            mm = max4(mm, y[1][0]);
+            if (ox + 1 < P.Wo) mm = max4(mm, y[1][1]);
+        }
+        *reinterpret_cast<f32x4*>(P.pool + ((size_t)(oy >> 1) * ((P.Wo + 1) >> 1) + (ox >> 1)) * a.cout + co) = mm;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
