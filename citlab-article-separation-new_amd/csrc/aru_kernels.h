@@ -104,6 +104,14 @@ __device__ __forceinline__ f32x4 psub(f32x4 a, f32x4 b) {
     const f32x2 lo = psub(f32x2{a.x, a.y}, f32x2{b.x, b.y}), hi = psub(f32x2{a.z, a.w}, f32x2{b.z, b.w});
     return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
+// acc += {v, v} * w with v = element ODD of the register pair `pair` and w a scalar-register pair: one v_pk_fma_f32 with an
+// op_sel broadcast.  Written as asm because instruction selection copies some odd elements to the low half of another pair
+// first (a v_mov per two FMAs in combine_kernel).  res8v_kernels.h has the same helper for its stages.
+template <int ODD>
+__device__ __forceinline__ void pk_fma_bcast(f32x2& acc, f32x2 pair, f32x2 w) {
+    if (ODD) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc) : "v"(pair), "s"(w));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(pair), "s"(w));
+}
 // value of lane ^ 1 (DPP quad_perm [1,0,3,2]: one VALU instruction, no LDS)
 __device__ __forceinline__ float lane_xor1(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
@@ -1402,6 +1410,28 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
     float lg[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) lg[k] = swl[16 * FR * NC + k];
+    if constexpr (NC == 2 && FR % 4 == 0) {
+        // the two classes are one packed accumulator; four independent chains (one per channel of a quad) are summed at the end
+        typedef const float __attribute__((address_space(4)))* cptr;
+        f32x2 l2[4] = {f32x2{lg[0], lg[1]}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                const float* mp = m + ((ty + ky) * L + tx + kx) * FR;
+                cptr wp = (cptr)(a.wl + (ky * 4 + kx) * FR * 2);
+#pragma unroll
+                for (int c4 = 0; c4 < FR; c4 += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(mp + c4);
+                    pk_fma_bcast<0>(l2[0], f32x2{v.x, v.y}, f32x2{wp[(c4 + 0) * 2], wp[(c4 + 0) * 2 + 1]});
+                    pk_fma_bcast<1>(l2[1], f32x2{v.x, v.y}, f32x2{wp[(c4 + 1) * 2], wp[(c4 + 1) * 2 + 1]});
+                    pk_fma_bcast<0>(l2[2], f32x2{v.z, v.w}, f32x2{wp[(c4 + 2) * 2], wp[(c4 + 2) * 2 + 1]});
+                    pk_fma_bcast<1>(l2[3], f32x2{v.z, v.w}, f32x2{wp[(c4 + 3) * 2], wp[(c4 + 3) * 2 + 1]});
+                }
+            }
+        const f32x2 t = (l2[0] + l2[1]) + (l2[2] + l2[3]);
+        lg[0] = t.x; lg[1] = t.y;
+    } else {
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
@@ -1415,6 +1445,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
 #pragma unroll
                 for (int k = 0; k < NC; ++k) lg[k] = fmaf(mp[c], wp[c * NC + k], lg[k]);
         }
+    }
     if (a.softmax) {
         float mx = lg[0];
 #pragma unroll
