@@ -939,7 +939,7 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
             ca.out = d_outs[b]; ca.out_u8 = d_u8s ? d_u8s[b] : nullptr; ca.out_mask = d_masks ? d_masks[b] : nullptr;
             ca.thr255 = (double)threshold * 255.0;
             ca.softmax = cfg.apply_softmax;
-            dim3 grid(cdiv(W, 16), cdiv(H, 16));
+            dim3 grid(cdiv(W, COMBINE_TW), cdiv(H, 16));
             ProfScope ps(m, "combine_kernel", 2.0 * H * W * 16.0 * cfg.feat_root * cfg.n_classes);
 #define ASEP_COMB(FR, NC)                                                                          \
     if (cfg.feat_root == FR && cfg.n_classes == NC) {                                              \

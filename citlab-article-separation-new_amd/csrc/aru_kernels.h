@@ -1351,17 +1351,20 @@ struct CombineArgs {
     int softmax;
 };
 
+constexpr int COMBINE_TW = 32;   // tile width of combine_kernel (16 rows)
 template <int FR, int NC>
 __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
-    constexpr int T = 16, L = T + 3;     // 4x4 SAME: pad 1 before, 2 after
-    __shared__ __attribute__((aligned(16))) float m[L * L * FR];
+    // 32 x 16 pixel tile, two horizontally adjacent pixels per thread (their 4 x 5 pixel window is read from LDS once: the
+    // kernel is bound by LDS reads, 32 x 16 B per pixel in the one-pixel form)
+    constexpr int TW = COMBINE_TW, T = 16, LW = TW + 3, L = T + 3;     // 4x4 SAME: pad 1 before, 2 after
+    __shared__ __attribute__((aligned(16))) float m[L * LW * FR];
     __shared__ float swl[16 * FR * NC + NC];
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * T, y0 = blockIdx.y * T;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * T;
     if (tid < NC) swl[16 * FR * NC + tid] = a.bl[tid];
 
-    for (int pix = tid; pix < L * L; pix += 256) {
-        const int ly = pix / L, lx = pix - ly * L;
+    for (int pix = tid; pix < L * LW; pix += 256) {
+        const int ly = pix / LW, lx = pix - ly * LW;
         const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
         float v[FR];
 #pragma unroll
@@ -1405,65 +1408,89 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
     __syncthreads();
 
     const int tx = tid & 15, ty = tid >> 4;
-    const int x = x0 + tx, y = y0 + ty;
-    if (x >= a.W || y >= a.H) return;
-    float lg[NC];
+    const int xb = x0 + 2 * tx, y = y0 + ty;
+    if (xb >= a.W || y >= a.H) return;
+    float lg[2][NC];
 #pragma unroll
-    for (int k = 0; k < NC; ++k) lg[k] = swl[16 * FR * NC + k];
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) lg[q][k] = swl[16 * FR * NC + k];
     if constexpr (NC == 2 && FR % 4 == 0) {
-        // the two classes are one packed accumulator; four independent chains (one per channel of a quad) are summed at the end
+        // the two classes are one packed accumulator; four independent chains per pixel (one per channel of a quad) are
+        // summed at the end.  Weights: uniform addresses -> scalar loads, SGPR operands of the FMAs.
         typedef const float __attribute__((address_space(4)))* cptr;
-        f32x2 l2[4] = {f32x2{lg[0], lg[1]}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+        f32x2 l2[2][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { l2[q][0] = f32x2{lg[q][0], lg[q][1]}; l2[q][1] = l2[q][2] = l2[q][3] = f32x2{0.f, 0.f}; }
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            f32x4 v[5][FR / 4];                                   // the row's five window pixels
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int c4 = 0; c4 < FR / 4; ++c4) v[i][c4] = *reinterpret_cast<const f32x4*>(m + ((ty + ky) * LW + 2 * tx + i) * FR + c4 * 4);
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                cptr wp = (cptr)(a.wl + (ky * 4 + kx) * FR * 2);
+#pragma unroll
+                for (int c4 = 0; c4 < FR / 4; ++c4) {
+                    const f32x2 w0 = f32x2{wp[(c4 * 4 + 0) * 2], wp[(c4 * 4 + 0) * 2 + 1]}, w1 = f32x2{wp[(c4 * 4 + 1) * 2], wp[(c4 * 4 + 1) * 2 + 1]};
+                    const f32x2 w2 = f32x2{wp[(c4 * 4 + 2) * 2], wp[(c4 * 4 + 2) * 2 + 1]}, w3 = f32x2{wp[(c4 * 4 + 3) * 2], wp[(c4 * 4 + 3) * 2 + 1]};
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const f32x4 d = v[kx + q][c4];
+                        pk_fma_bcast<0>(l2[q][0], f32x2{d.x, d.y}, w0);
+                        pk_fma_bcast<1>(l2[q][1], f32x2{d.x, d.y}, w1);
+                        pk_fma_bcast<0>(l2[q][2], f32x2{d.z, d.w}, w2);
+                        pk_fma_bcast<1>(l2[q][3], f32x2{d.z, d.w}, w3);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x2 t = (l2[q][0] + l2[q][1]) + (l2[q][2] + l2[q][3]);
+            lg[q][0] = t.x; lg[q][1] = t.y;
+        }
+    } else {
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 4; ++kx) {
-                const float* mp = m + ((ty + ky) * L + tx + kx) * FR;
-                cptr wp = (cptr)(a.wl + (ky * 4 + kx) * FR * 2);
+                const float* __restrict__ wp = a.wl + (ky * 4 + kx) * FR * NC;
 #pragma unroll
-                for (int c4 = 0; c4 < FR; c4 += 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(mp + c4);
-                    pk_fma_bcast<0>(l2[0], f32x2{v.x, v.y}, f32x2{wp[(c4 + 0) * 2], wp[(c4 + 0) * 2 + 1]});
-                    pk_fma_bcast<1>(l2[1], f32x2{v.x, v.y}, f32x2{wp[(c4 + 1) * 2], wp[(c4 + 1) * 2 + 1]});
-                    pk_fma_bcast<0>(l2[2], f32x2{v.z, v.w}, f32x2{wp[(c4 + 2) * 2], wp[(c4 + 2) * 2 + 1]});
-                    pk_fma_bcast<1>(l2[3], f32x2{v.z, v.w}, f32x2{wp[(c4 + 3) * 2], wp[(c4 + 3) * 2 + 1]});
+                for (int q = 0; q < 2; ++q) {
+                    const float* mp = m + ((ty + ky) * LW + 2 * tx + q + kx) * FR;
+#pragma unroll
+                    for (int c = 0; c < FR; ++c)
+#pragma unroll
+                        for (int k = 0; k < NC; ++k) lg[q][k] = fmaf(mp[c], wp[c * NC + k], lg[q][k]);
                 }
             }
-        const f32x2 t = (l2[0] + l2[1]) + (l2[2] + l2[3]);
-        lg[0] = t.x; lg[1] = t.y;
-    } else {
+    }
 #pragma unroll
-    for (int ky = 0; ky < 4; ++ky)
+    for (int q = 0; q < 2; ++q) {
+        const int x = xb + q;
+        if (x >= a.W) break;
+        if (a.softmax) {
+            float mx = lg[q][0];
 #pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-            const float* mp = m + ((ty + ky) * L + tx + kx) * FR;
-            // uniform addresses: scalar loads, the weights are SGPR operands of the FMAs (read from LDS they took two
-            // thirds of the kernel's LDS bandwidth, which is what bounds it)
-            const float* __restrict__ wp = a.wl + (ky * 4 + kx) * FR * NC;
+            for (int k = 1; k < NC; ++k) mx = fmaxf(mx, lg[q][k]);
+            float den = 0.f;
 #pragma unroll
-            for (int c = 0; c < FR; ++c)
+            for (int k = 0; k < NC; ++k) { lg[q][k] = expf(lg[q][k] - mx); den += lg[q][k]; }
 #pragma unroll
-                for (int k = 0; k < NC; ++k) lg[k] = fmaf(mp[c], wp[c * NC + k], lg[k]);
+            for (int k = 0; k < NC; ++k) lg[q][k] = lg[q][k] / den;
         }
-    }
-    if (a.softmax) {
-        float mx = lg[0];
+        const size_t p = ((size_t)y * a.W + x) * NC;
 #pragma unroll
-        for (int k = 1; k < NC; ++k) mx = fmaxf(mx, lg[k]);
-        float den = 0.f;
-#pragma unroll
-        for (int k = 0; k < NC; ++k) { lg[k] = expf(lg[k] - mx); den += lg[k]; }
-#pragma unroll
-        for (int k = 0; k < NC; ++k) lg[k] = lg[k] / den;
-    }
-    const size_t p = ((size_t)y * a.W + x) * NC;
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        a.out[p + k] = lg[k];
-        if (a.out_u8 || a.out_mask) {
-            const uint8_t u = (uint8_t)(lg[k] * 255.0f);          // np.array(p*255, dtype=uint8)
-            if (a.out_u8) a.out_u8[p + k] = u;
-            if (a.out_mask) a.out_mask[p + k] = ((double)u > a.thr255) ? 255 : 0;
+        for (int k = 0; k < NC; ++k) {
+            a.out[p + k] = lg[q][k];
+            if (a.out_u8 || a.out_mask) {
+                const uint8_t u = (uint8_t)(lg[q][k] * 255.0f);          // np.array(p*255, dtype=uint8)
+                if (a.out_u8) a.out_u8[p + k] = u;
+                if (a.out_mask) a.out_mask[p + k] = ((double)u > a.thr255) ? 255 : 0;
+            }
         }
     }
 }
