@@ -333,7 +333,10 @@ def main():
             "pipe": "valu v_pk_fma_f32" if dom["kernel"].startswith("res8v") else "mfma",
             "avg_launch_us": round(dom["avg_us"], 2), "flops_per_launch": dom["flops"] / dom["calls"],
             "share_of_gpu_time": round(dom["total_ms"] / sum(k["total_ms"] for k in kernels), 4),
-            "pages_per_launch": B * n_prof / dom["calls"],      # a launch carries at most 12 problems = 4 pages x 3 scales
+            # a launch carries at most 12 problems = 4 pages x 3 scales; the level-0 block kernels are launched exactly once
+            # per such group (a multi-layer kernel like conv_wino_kernel<4> several times), so they count the groups
+            "pages_per_launch": B * n_prof / next((k["calls"] for k in kernels if k["kernel"].startswith("res8") and "up" in k["kernel"]),
+                                                  dom["calls"]),
             "traffic": None, "traffic_source": None,
         }
         tp = os.path.join(ROOT, "profiles", "traffic_per_kernel.json")
