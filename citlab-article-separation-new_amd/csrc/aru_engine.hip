@@ -29,6 +29,7 @@ struct PackedConv {
     float* d_w = nullptr;
     float* d_b = nullptr;
     float* d_wino = nullptr;   // Winograd F(2x2,3x3) transformed weights U = G g G^T, packed [g][pos][mtile][lane][4]
+    float* d_wv = nullptr;     // deconv 16 -> 8 only: [tap][ci][co] for deconv8v_kernel (scalar operands)
 };
 
 struct DirectConv {        // Cin == 1 first layers
@@ -240,6 +241,15 @@ int pack_conv(asep_aru* m, const std::map<std::string, HostTensor>& blob, const 
         if (rc) return rc;
         m->owned.push_back(pc.d_wino);
     }
+    if (deconv && pc.kh == 3 && pc.kw == 3 && pc.cin == 16 && pc.cout == 8) {
+        std::vector<float> wv;
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ci = 0; ci < 16; ++ci)
+                for (int co = 0; co < 8; ++co) wv.push_back(W(tap, ci, co));
+        rc = upload(wv, &pc.d_wv);
+        if (rc) return rc;
+        m->owned.push_back(pc.d_wv);
+    }
     m->convs[scope] = pc;
     return ASEP_OK;
 }
@@ -435,6 +445,7 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
         out.push_back(new_tensor(m, like[i].H, like[i].W, pc.cout));
     }
     const int mt = pc.mtiles % 2 == 0 ? 2 : 1;
+    const bool valu = pc.d_wv && m->r8_valu && !m->bf16;     // level 0, fp32: one input position per thread on the vector ALU
     for (size_t b0 = 0; b0 < in.size(); b0 += MAXP) {
         const size_t b1 = std::min(in.size(), b0 + MAXP);
         ConvArgs a{};
@@ -446,9 +457,9 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
             p.H = in[i].H; p.W = in[i].W; p.Ho = out[i].H; p.Wo = out[i].W;
             p.pbh = std::max((in[i].H - 1) * 2 + 3 - out[i].H, 0) / 2;
             p.pbw = std::max((in[i].W - 1) * 2 + 3 - out[i].W, 0) / 2;
-            p.tiles_x = cdiv(in[i].W, DC_TW);
+            p.tiles_x = cdiv(in[i].W, valu ? DCV_T : DC_TW);
             p.tile_begin = tiles;
-            tiles += p.tiles_x * cdiv(in[i].H, DC_TH);
+            tiles += p.tiles_x * cdiv(in[i].H, valu ? DCV_T : DC_TH);
             flops += 2.0 * in[i].H * in[i].W * 9.0 * pc.cin * pc.cout;
         }
         a.nprob = (int)(b1 - b0);
@@ -457,11 +468,14 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
         a.relu_in = 0; a.relu_out = relu_out;
         dim3 grid(tiles, pc.mtiles / mt);
-        std::string dname = mt == 2 ? "deconv_mfma_kernel<2>" : "deconv_mfma_kernel<1>";
+        std::string dname = valu ? "deconv8v_kernel" : (mt == 2 ? "deconv_mfma_kernel<2>" : "deconv_mfma_kernel<1>");
         TL sub(in.begin() + b0, in.begin() + b1);
         if (m->prof_detail) dname += " " + scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
         ProfScope ps(m, dname, flops);
-        if (m->bf16) {
+        if (valu) {
+            a.wpk = (const f32x4*)pc.d_wv;
+            hipLaunchKernelGGL(deconv8v_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
+        } else if (m->bf16) {
             if (mt == 2) hipLaunchKernelGGL((deconv_mfma_kernel<2, true>), grid, dim3(256), 0, m->stream, a);
             else hipLaunchKernelGGL((deconv_mfma_kernel<1, true>), grid, dim3(256), 0, m->stream, a);
         } else if (mt == 2) hipLaunchKernelGGL((deconv_mfma_kernel<2>), grid, dim3(256), 0, m->stream, a);

@@ -709,4 +709,102 @@ __global__ __launch_bounds__(256) void att_headv_kernel(const AttHeadArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Level-0 deconvolution on the vector ALU (fp32): conv2d_transpose 3x3, stride 2, SAME, 16 -> 8 channels (layers.py:362;
+// index algebra as deconv_mfma_kernel).  With 8 output channels the MFMA form fills half of its 16 rows (MFMA 47 % + VALU
+// 15 % of the SIMD cycles for 23 % useful work); here a thread owns one input position q = its 2 x 2 output pixels x 8
+// channels = 16 packed accumulators, and takes the 9 taps x 16 input channels from scalar registers: 576 v_pk_fma_f32 per
+// thread, the four input pixels (q, q - 1 in x / y / both) from an LDS tile.
+// ------------------------------------------------------------------------------------------------
+constexpr int DCV_T = 16;                                  // 16 x 16 input positions per block, one per thread
+
+__global__ __launch_bounds__(256) void deconv8v_kernel(const ConvArgs a) {
+    constexpr int T = DCV_T, L = T + 1;                      // one halo row / column before the tile (o = q - 1)
+    // input tile (17 x 17 pixels x 16 channels), later the output tile (32 x 32 pixels x 8 channels = 32 KB)
+    __shared__ __attribute__((aligned(16))) float lds[2 * T * 2 * T * 8];
+    static_assert(L * L * 16 <= 2 * T * 2 * T * 8, "input tile must fit");
+    const int tid = threadIdx.x;
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    const ConvProb& P = a.p[pi];
+    const int tile = blockIdx.x - P.tile_begin;
+    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const int qx0 = tx * T, qy0 = ty * T;
+    const int H = P.H, W = P.W;
+    const int relu_lim = a.relu_in ? 0 : (int)0x80000000;
+    // tile -> LDS: (pixel, channel quad) slots, zero outside the image
+    for (int idx = tid; idx < L * L * 4; idx += 256) {
+        const int pix = idx >> 2, sub = idx & 3;
+        const int ly = pix / L, lx = pix - ly * L;
+        const int gy = qy0 - 1 + ly, gx = qx0 - 1 + lx;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const f32x4*>(P.in0 + ((size_t)gy * W + gx) * 16 + sub * 4);
+        *reinterpret_cast<f32x4*>(lds + idx * 4) = imax4(v, relu_lim);
+    }
+    __syncthreads();
+    const int qx = tid & 15, qy = tid >> 4;
+    // the four input pixels of this position: shift 0 (q), 1 (x - 1), 2 (y - 1), 3 (both); 16 channels each
+    f32x4 d[4][4];
+#pragma unroll
+    for (int sh = 0; sh < 4; ++sh)
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
+            d[sh][c4] = *reinterpret_cast<const f32x4*>(lds + ((qy + 1 - (sh >> 1)) * L + qx + 1 - (sh & 1)) * 16 + c4 * 4);
+    r8v_cptr bl = (r8v_cptr)a.bias;
+    f32x2 acc[4][4];                                         // [parity class (ry, rx)][output channel pair]; bias = initial value
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { acc[0][q] = f32x2{bl[2 * q], bl[2 * q + 1]}; acc[1][q] = acc[0][q]; acc[2][q] = acc[0][q]; acc[3][q] = acc[0][q]; }
+    // weights [tap][ci][co] through a 2 x 32-SGPR double buffer, one wait per group (see r8v_conv_direct)
+    r8v_cptr wl = (r8v_cptr) reinterpret_cast<const float*>(a.wpk);
+    asm volatile("" : "+s"(wl));
+    float wc[32], wn[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) wc[k] = wl[k];
+#pragma unroll
+    for (int g = 0; g < 36; ++g) {
+        const int tap = g >> 2, c4 = g & 3;
+        const int ky = tap / 3, kx = tap % 3;
+        const int cls = (ky & 1) * 2 + (kx & 1), sh = (ky == 2 ? 2 : 0) + (kx == 2 ? 1 : 0);
+        asm volatile("" :: "s"(wc[0]), "s"(wc[16]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < 36) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) wn[k] = wl[(g + 1) * 32 + k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 v = d[sh][c4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            r8v_fma<0>(acc[cls][q], f32x2{v.x, v.y}, f32x2{wc[2 * q], wc[2 * q + 1]});
+            r8v_fma<1>(acc[cls][q], f32x2{v.x, v.y}, f32x2{wc[8 + 2 * q], wc[8 + 2 * q + 1]});
+            r8v_fma<0>(acc[cls][q], f32x2{v.z, v.w}, f32x2{wc[16 + 2 * q], wc[16 + 2 * q + 1]});
+            r8v_fma<1>(acc[cls][q], f32x2{v.z, v.w}, f32x2{wc[24 + 2 * q], wc[24 + 2 * q + 1]});
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) wc[k] = wn[k];
+    }
+    // through an LDS output tile, so that one store instruction of a wave writes 1 KB of ONE output row (a thread's own
+    // pixels are 64 contiguous bytes per row: stored directly, every instruction would scatter 16-byte pieces at a 64-byte
+    // stride over sixteen cache lines)
+    const int relu_o = a.relu_out ? 0 : (int)0x80000000;
+    __syncthreads();                                         // every thread has its input pixels in registers (read above)
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+        float* o = lds + ((2 * qy + (cls >> 1)) * (2 * T) + 2 * qx + (cls & 1)) * 8;
+        *reinterpret_cast<f32x4*>(o) = imax4(r8v_lo(acc[cls]), relu_o);
+        *reinterpret_cast<f32x4*>(o + 4) = imax4(r8v_hi(acc[cls]), relu_o);
+    }
+    __syncthreads();
+    const int oy0 = 2 * qy0 - P.pbh, ox0 = 2 * qx0 - P.pbw;   // image coordinates of the output tile's origin
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * 256;                       // row = idx / 64, 16-byte piece of the row = idx % 64
+        const int row = idx >> 6, piece = idx & 63;
+        const int y = oy0 + row, x = ox0 + (piece >> 1);
+        // rows / columns of positions beyond the input (q >= H, W) are not outputs of this layer
+        if (y >= 0 && y < P.Ho && x >= 0 && x < P.Wo && qy0 + (row >> 1) < H && qx0 + (piece >> 2) < W)
+            *reinterpret_cast<f32x4*>(P.out + ((size_t)y * P.Wo + x) * 8 + (piece & 1) * 4) = *reinterpret_cast<const f32x4*>(lds + idx * 4);
+    }
+}
+
 }  // namespace asep
