@@ -24,6 +24,7 @@ struct Tensor {
 struct PackedConv {
     int kh = 0, kw = 0, cin = 0, cout = 0;
     bool c8 = false;       // Cin == 8: two taps per 16-slot chunk
+    bool c12 = false;      // Cin == 12, 4x4 taps (attention conv2): dense rows of 48 floats = 3 chunks, no channel padding
     bool deconv = false;
     int groups = 0, mtiles = 0, nchunks = 0;
     float* d_w = nullptr;
@@ -104,6 +105,7 @@ struct asep_aru {
     bool bf16 = false;             // cfg.compute_dtype == 1: bf16 MFMA operands, fp32 accumulation and storage
     bool wino_reg = true;          // ASEP_WINO_REG=0: LDS-image Winograd kernel also for the 32-channel level
     bool use_winograd = true;      // ASEP_WINOGRAD=0 selects the direct implicit-GEMM kernels everywhere
+    bool use_c12 = true;           // ASEP_C12=0: 12-channel inputs padded to a 16-channel group (read when the weights are packed)
     bool fuse_pool = true;         // ASEP_FUSE_POOL=0: separate maxpool2_kernel after every conv
     bool wino16 = false;           // ASEP_WINO16=1: register-resident Winograd also at the 16-channel level (measured: 99 vs
                                    // 103 TFLOP/s-equivalent for the direct kernels, parity-green; kept as an experiment switch)
@@ -190,9 +192,10 @@ int pack_conv(asep_aru* m, const std::map<std::string, HostTensor>& blob, const 
     }
     const int taps = pc.kh * pc.kw;
     pc.c8 = (!deconv && pc.cin == 8);
+    pc.c12 = (!deconv && pc.cin == 12 && pc.kh == 4 && pc.kw == 4 && pc.cout <= 16 && m->use_c12);
     pc.mtiles = cdiv(pc.cout, 16);
-    pc.groups = pc.c8 ? 1 : cdiv(pc.cin, 16);
-    pc.nchunks = pc.c8 ? (taps + 1) / 2 : pc.groups * taps;
+    pc.groups = (pc.c8 || pc.c12) ? 1 : cdiv(pc.cin, 16);
+    pc.nchunks = pc.c8 ? (taps + 1) / 2 : (pc.c12 ? pc.kh * (pc.kw * 12 / 16) : pc.groups * taps);
     auto W = [&](int tap, int ci, int co) -> float {
         if (ci >= pc.cin || co >= pc.cout || tap >= taps) return 0.f;
         return deconv ? w.data[((size_t)tap * pc.cout + co) * pc.cin + ci]
@@ -208,6 +211,10 @@ int pack_conv(asep_aru* m, const std::map<std::string, HostTensor>& blob, const 
                     if (pc.c8) {
                         tap = 2 * ch + (kk >> 1);
                         ci = 4 * (kk & 1) + r;
+                    } else if (pc.c12) {
+                        const int cpr = pc.kw * 12 / 16, ky = ch / cpr, flat = (ch % cpr) * 16 + 4 * kk + r;   // float of the row's run
+                        tap = ky * pc.kw + flat / 12;
+                        ci = flat % 12;
                     } else {
                         const int g = ch / taps;
                         tap = ch % taps;
@@ -301,11 +308,18 @@ void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, int tot
     const int mt = pc.c8 ? 1 : (pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1));
     dim3 grid(total_tiles, pc.mtiles / mt);
     char name[64];
-    snprintf(name, sizeof(name), "conv_mfma_kernel<%d,%d,%d,%s%s>", KH, KW, mt, pc.c8 ? "true" : "false", big_tile ? ",16,false" : "");
+    snprintf(name, sizeof(name), "conv_mfma_kernel<%d,%d,%d,%s%s>", KH, KW, mt, pc.c12 ? "c12" : (pc.c8 ? "true" : "false"), big_tile ? ",16,false" : "");
     std::string pname = name;
     if (m->prof_detail) pname += " " + scope + " " + dims_of(in0) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
     ProfScope ps(m, pname, flops);
     hipStream_t s = m->stream;
+    if constexpr (KW == 4) {
+        if (pc.c12) {                                        // one m-tile, one channel group: 16 x 32 tiles, single LDS buffer
+            if (m->bf16) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false, 16, false, true, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false, 16, false, false, true>), grid, dim3(256), 0, s, a);
+            return;
+        }
+    }
     if (m->bf16) {
         if (pc.c8) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, true, CONV_TH, true, true>), grid, dim3(256), 0, s, a);
         else if (mt == 1 && big_tile) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false, 16, false, true>), grid, dim3(256), 0, s, a);
@@ -357,7 +371,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
     }
     // single channel group, one 16-channel output tile: 16 x 32 pixel blocks, single LDS buffer (more MFMA work per
     // block against the fixed load latency of these short blocks)
-    const bool big_tile = !wino && !pc.c8 && pc.groups == 1 && pc.mtiles == 1 && m->big_tile;
+    const bool big_tile = !wino && !pc.c8 && pc.groups == 1 && pc.mtiles == 1 && (m->big_tile || pc.c12);
     const int th = big_tile ? 16 : CONV_TH;
     for (size_t b0 = 0; b0 < in0.size(); b0 += MAXP) {
         const size_t b1 = std::min(in0.size(), b0 + MAXP);
@@ -1062,6 +1076,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_WINO_REG")) m->wino_reg = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO16")) m->wino16 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSE_POOL")) m->fuse_pool = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_C12")) m->use_c12 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_R8_VALU")) m->r8_valu = atoi(e) != 0;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;

@@ -44,6 +44,9 @@ __device__ __forceinline__ f32x4 mfma_bf16(s16x4 a, s16x4 b, f32x4 c) {
 //   K is consumed in chunks of 16 "slots": slot s = 4*kk + r  (kk = lane>>4, r = MFMA index 0..3),
 //     C16 mode: chunk = (channel group g of 16, tap)        slot -> channel 16g + s
 //     C8  mode: chunk = tap pair (Cin == 8)                  slot -> tap 2c + (s>>3), channel s&7
+//     C12 mode: Cin == 12, KW == 4 (attention conv2): pixels are 12 floats apart in LDS, so the four taps of a filter ROW
+//               are 48 contiguous floats = 3 chunks with no padding: chunk = (ky, c), slot s -> float 16c + s of that run
+//               (kx = (16c + s) / 12, channel (16c + s) % 12): 12 instead of 16 chunks
 // One lane's 16-byte LDS read / 16-byte weight load therefore feeds four MFMAs.
 // ------------------------------------------------------------------------------------------------
 // One launch covers the same layer of several independent "problems" (pages x scale-space levels share
@@ -137,16 +140,18 @@ __device__ __forceinline__ f32x4 imax4(f32x4 v, int lim) {
 // Software pipeline: the halo tile of channel group g+1 is fetched into registers while group g is multiplied
 // out of LDS (two LDS buffers, one barrier per group); the weight fragments of tap t+1 are requested before the
 // MFMAs of tap t are issued.
-template <int KH, int KW, int MT, bool C8, int TH = CONV_TH, bool DBUF = true, bool BF = false>
+template <int KH, int KW, int MT, bool C8, int TH = CONV_TH, bool DBUF = true, bool BF = false, bool C12 = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+    static_assert(!C12 || (!C8 && KW * 12 % 16 == 0), "C12: dense rows of KW x 12 floats");
     constexpr int TW = CONV_TW, NT = TH / 2;             // TH rows x 2 column blocks of 16 pixels, 4 waves
     constexpr int LH = TH + KH - 1, LW = TW + KW - 1;
-    constexpr int CPP = C8 ? 8 : 16;                    // channels per pixel held in LDS
+    constexpr int CPP = C8 ? 8 : (C12 ? 12 : 16);       // channels per pixel held in LDS
     constexpr int PT = (KH - 1) / 2, PL = (KW - 1) / 2;  // TF SAME: pad_before = (k-1)/2
     constexpr int TAPS = KH * KW;
     constexpr int SUBS = CPP / 4;
     constexpr int NV = LH * LW * SUBS;                   // float4 slots of one halo tile
-    constexpr int NLOAD = (NV + 255) / 256;
+    constexpr int STR = C12 ? 255 : 256;                 // loader stride: a multiple of SUBS, so that a thread keeps its sub-block
+    constexpr int NLOAD = (NV + STR - 1) / STR;
     constexpr int LBUF = LH * LW * CPP;
     __shared__ __attribute__((aligned(16))) float lds[(DBUF ? 2 : 1) * LBUF];   // DBUF=false: single channel group only
 
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     f32x4 st[NLOAD];
     unsigned stmask = 0;
     const bool interior = y0 - PT >= 0 && y0 - PT + LH <= H && x0 - PL >= 0 && x0 - PL + LW <= W;
-    constexpr int PSTEP = 256 / SUBS, QD = PSTEP / LW, RD = PSTEP % LW;
+    constexpr int PSTEP = STR / SUBS, QD = PSTEP / LW, RD = PSTEP % LW;
     const int pix0 = tid / SUBS, sub0 = tid % SUBS;
     const int ly0 = pix0 / LW, lx0 = pix0 - ly0 * LW;
     auto stage_load = [&](int g) {
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < NLOAD; ++i) {
                 // threads past the last slot of the window read the tile's first pixel instead (a valid address; never stored)
-                const bool have = i * 256 + 255 < NV || tid + i * 256 < NV;
+                const bool have = tid < STR && (i * STR + STR - 1 < NV || tid + i * STR < NV);
                 st[i] = *reinterpret_cast<const f32x4*>(have ? q : src);
                 lx += RD;
                 q += step;
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             const int gy = y0 - PT + ly, gx = x0 - PL + lx;
-            const bool ok = cok && (i * 256 + 255 < NV || tid + i * 256 < NV) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const bool ok = cok && tid < STR && (i * STR + STR - 1 < NV || tid + i * STR < NV) && gy >= 0 && gy < H && gx >= 0 && gx < W;
             const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
             st[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(cy * W + cx) * cs);
             stmask |= (ok ? 1u : 0u) << i;
@@ -234,16 +239,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     auto stage_store = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < NV) {
+            const int idx = tid + i * STR;
+            if (idx < NV && tid < STR) {
                 const f32x4 v = ((stmask >> i) & 1u) ? st[i] : f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4*>(lds + buf * LBUF + idx * 4) = imax4(v, relu_lim);   // idx*4 == pix*CPP + sub*4
             }
         }
     };
 
-    const int ngroups = C8 ? 1 : a.groups;
-    constexpr int CPG = C8 ? (TAPS + 1) / 2 : TAPS;       // K chunks per channel group
+    const int ngroups = (C8 || C12) ? 1 : a.groups;
+    constexpr int CPG = C8 ? (TAPS + 1) / 2 : (C12 ? KH * (KW * 12 / 16) : TAPS);       // K chunks per channel group
     const int nchunks = ngroups * CPG;
     const f32x4* __restrict__ wbase = a.wpk + (size_t)mt0 * 64 + lane;
     const size_t wstride = (size_t)a.mtiles * 64;          // f32x4 elements per chunk
@@ -288,7 +293,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                 for (int m = 0; m < MT; ++m) an[m] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             int toff;
-            if constexpr (!C8) {
+            if constexpr (C12) {
+                constexpr int CPR = KW * 12 / 16;              // chunks per filter row
+                const int ky = t / CPR, c = t % CPR;
+                toff = ky * LW * 12 + c * 16 + kk * 4;
+            } else if constexpr (!C8) {
                 const int ky = t / KW, kx = t % KW;
                 toff = (ky * LW + kx) * 16 + kk * 4;
             } else {
