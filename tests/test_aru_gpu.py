@@ -163,3 +163,23 @@ def test_fp32_level0_mfma_variant_agrees_with_the_vector_alu_kernels(H, W, monke
     for valu, out in outs.items():
         assert float(np.abs(out - ref).max()) <= PROB_TOL, valu
     assert float(np.abs(outs["1"] - outs["0"]).max()) <= 1e-5
+
+
+@pytest.mark.parametrize("H,W", [(200, 150), (67, 131)])
+def test_fused_pool_and_dense_12_channel_mode_match_their_plain_forms(H, W, monkeypatch):
+    """Two engine switches that must not change results: ASEP_FUSE_POOL=0 runs maxpool2_kernel after every conv instead of the
+    2x2 max in the conv epilogues (same values, so the outputs are bit-identical), ASEP_C12=0 pads the attention conv2's 12
+    input channels to 16 instead of the dense K mapping (another summation order: equal to 1e-5)."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    img = _image(H, W, 91)
+    outs = {}
+    for name, env in (("default", {}), ("plain_pool", {"ASEP_FUSE_POOL": "0"}), ("padded_c12", {"ASEP_C12": "0"})):
+        for k in ("ASEP_FUSE_POOL", "ASEP_C12"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)                       # read when the engine is created
+        cfg, w, graph = _setup()
+        outs[name] = helper.get_net_output(img, graph, "0")
+        graph.close()
+    assert np.array_equal(outs["default"], outs["plain_pool"])
+    assert float(np.abs(outs["default"] - outs["padded_c12"]).max()) <= 1e-5
