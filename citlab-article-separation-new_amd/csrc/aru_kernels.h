@@ -140,8 +140,12 @@ __device__ __forceinline__ f32x4 imax4(f32x4 v, int lim) {
 // Software pipeline: the halo tile of channel group g+1 is fetched into registers while group g is multiplied
 // out of LDS (two LDS buffers, one barrier per group); the weight fragments of tap t+1 are requested before the
 // MFMAs of tap t are issued.
+#ifndef CONV_BIG_BLOCKS
+#define CONV_BIG_BLOCKS 2
+#endif
+#define CONV_MFMA_MIN_BLOCKS(TH) ((TH) == 16 ? CONV_BIG_BLOCKS : 2)
 template <int KH, int KW, int MT, bool C8, int TH = CONV_TH, bool DBUF = true, bool BF = false, bool C12 = false>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, CONV_MFMA_MIN_BLOCKS(TH)) void conv_mfma_kernel(const ConvArgs a) {
     static_assert(!C12 || (!C8 && KW * 12 % 16 == 0), "C12: dense rows of KW x 12 floats");
     constexpr int TW = CONV_TW, NT = TH / 2;             // TH rows x 2 column blocks of 16 pixels, 4 waves
     constexpr int LH = TH + KH - 1, LW = TW + KW - 1;
