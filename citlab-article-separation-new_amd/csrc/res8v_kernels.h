@@ -733,23 +733,27 @@ __global__ __launch_bounds__(256) void deconv8v_kernel(const ConvArgs a) {
     const int H = P.H, W = P.W;
     const int relu_lim = a.relu_in ? 0 : (int)0x80000000;
     // tile -> LDS: (pixel, channel quad) slots, zero outside the image
+    // (the four 16-byte quads of a 64-byte pixel record are permuted by the pixel's column, like r8_px: the lanes of a read
+    // or write are consecutive pixels taking the SAME quad, 64 bytes apart = two bank groups without the permutation)
     for (int idx = tid; idx < L * L * 4; idx += 256) {
         const int pix = idx >> 2, sub = idx & 3;
         const int ly = pix / L, lx = pix - ly * L;
         const int gy = qy0 - 1 + ly, gx = qx0 - 1 + lx;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const f32x4*>(P.in0 + ((size_t)gy * W + gx) * 16 + sub * 4);
-        *reinterpret_cast<f32x4*>(lds + idx * 4) = imax4(v, relu_lim);
+        *reinterpret_cast<f32x4*>(lds + pix * 16 + ((sub ^ ((lx >> 1) & 3)) << 2)) = imax4(v, relu_lim);
     }
     __syncthreads();
     const int qx = tid & 15, qy = tid >> 4;
     // the four input pixels of this position: shift 0 (q), 1 (x - 1), 2 (y - 1), 3 (both); 16 channels each
     f32x4 d[4][4];
 #pragma unroll
-    for (int sh = 0; sh < 4; ++sh)
+    for (int sh = 0; sh < 4; ++sh) {
+        const int lx = qx + 1 - (sh & 1);
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4)
-            d[sh][c4] = *reinterpret_cast<const f32x4*>(lds + ((qy + 1 - (sh >> 1)) * L + qx + 1 - (sh & 1)) * 16 + c4 * 4);
+            d[sh][c4] = *reinterpret_cast<const f32x4*>(lds + ((qy + 1 - (sh >> 1)) * L + lx) * 16 + ((c4 ^ ((lx >> 1) & 3)) << 2));
+    }
     r8v_cptr bl = (r8v_cptr)a.bias;
     f32x2 acc[4][4];                                         // [parity class (ry, rx)][output channel pair]; bias = initial value
 #pragma unroll
@@ -788,11 +792,14 @@ __global__ __launch_bounds__(256) void deconv8v_kernel(const ConvArgs a) {
     // stride over sixteen cache lines)
     const int relu_o = a.relu_out ? 0 : (int)0x80000000;
     __syncthreads();                                         // every thread has its input pixels in registers (read above)
+    // output tile: a thread's two pixels of a row are one 64-byte record (four 16-byte pieces); piece k of record qx sits in
+    // slot k ^ ((qx >> 1) & 3), undone by the row-wise reader below
 #pragma unroll
     for (int cls = 0; cls < 4; ++cls) {
-        float* o = lds + ((2 * qy + (cls >> 1)) * (2 * T) + 2 * qx + (cls & 1)) * 8;
-        *reinterpret_cast<f32x4*>(o) = imax4(r8v_lo(acc[cls]), relu_o);
-        *reinterpret_cast<f32x4*>(o + 4) = imax4(r8v_hi(acc[cls]), relu_o);
+        float* o = lds + ((2 * qy + (cls >> 1)) * (2 * T) + 2 * qx) * 8;
+        const int k = (cls & 1) * 2, sw = (qx >> 1) & 3;
+        *reinterpret_cast<f32x4*>(o + ((k ^ sw) << 2)) = imax4(r8v_lo(acc[cls]), relu_o);
+        *reinterpret_cast<f32x4*>(o + (((k + 1) ^ sw) << 2)) = imax4(r8v_hi(acc[cls]), relu_o);
     }
     __syncthreads();
     const int oy0 = 2 * qy0 - P.pbh, ox0 = 2 * qx0 - P.pbw;   // image coordinates of the output tile's origin
@@ -803,7 +810,8 @@ __global__ __launch_bounds__(256) void deconv8v_kernel(const ConvArgs a) {
         const int y = oy0 + row, x = ox0 + (piece >> 1);
         // rows / columns of positions beyond the input (q >= H, W) are not outputs of this layer
         if (y >= 0 && y < P.Ho && x >= 0 && x < P.Wo && qy0 + (row >> 1) < H && qx0 + (piece >> 2) < W)
-            *reinterpret_cast<f32x4*>(P.out + ((size_t)y * P.Wo + x) * 8 + (piece & 1) * 4) = *reinterpret_cast<const f32x4*>(lds + idx * 4);
+            *reinterpret_cast<f32x4*>(P.out + ((size_t)y * P.Wo + x) * 8 + (piece & 1) * 4) =
+                *reinterpret_cast<const f32x4*>(lds + (idx & ~3) * 4 + (((piece & 3) ^ ((piece >> 3) & 3)) << 2));
     }
 }
 
