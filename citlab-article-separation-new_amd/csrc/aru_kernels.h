@@ -1370,34 +1370,66 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
     // 32 x 16 pixel tile, two horizontally adjacent pixels per thread (their 4 x 5 pixel window is read from LDS once: the
     // kernel is bound by LDS reads, 32 x 16 B per pixel in the one-pixel form)
     constexpr int TW = COMBINE_TW, T = 16, LW = TW + 3, L = T + 3;     // 4x4 SAME: pad 1 before, 2 after
-    __shared__ __attribute__((aligned(16))) float m[L * LW * FR];
+    constexpr int LWP = LW + 1;                                       // row pitch in pixels (even: 64-byte pixel-pair records)
+    __shared__ __attribute__((aligned(16))) float m[L * LWP * FR];
+    // float index of (row, pixel, channel quad).  FR == 8: the quads of a 64-byte pixel pair are permuted by the pair's index
+    // (the second phase reads, per instruction, the same quad of 8 consecutive pairs: two bank groups without it)
+    auto mi = [](int ly, int lx, int c4) {
+        if constexpr (FR == 8) return ly * LWP * 8 + ((lx >> 1) << 4) + (((((lx & 1) << 1) | c4) ^ ((lx >> 2) & 3)) << 2);
+        else return (ly * LWP + lx) * FR + c4 * 4;
+    };
     __shared__ float swl[16 * FR * NC + NC];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * T;
     if (tid < NC) swl[16 * FR * NC + tid] = a.bl[tid];
 
-    for (int pix = tid; pix < L * LW; pix += 256) {
+    // phase 1 in two sweeps over the thread's (at most NPX) window pixels: ALL loads first -- feature pixel, attention
+    // values, channel sums, from clamped (always valid) addresses --, then the arithmetic.  As one loop the three dependent
+    // rounds of gathers of every pixel were exposed one after the other (the kernel was latency-bound in this phase).
+    constexpr int NPX = (L * LW + 255) / 256;
+    f32x4 fv[NPX][FR / 4];
+    float avv[NPX][MAX_SCALES], fsv[NPX][MAX_SCALES];
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+        const int pix = min(tid + i * 256, L * LW - 1);
+        const int ly = pix / LW, lx = pix - ly * LW;
+        const int gy = min(max(y0 - 1 + ly, 0), a.H - 1), gx = min(max(x0 - 1 + lx, 0), a.W - 1);
+        const float* f = a.f0 + ((size_t)gy * a.W + gx) * FR;
+#pragma unroll
+        for (int c4 = 0; c4 < FR / 4; ++c4) fv[i][c4] = *reinterpret_cast<const f32x4*>(f + c4 * 4);
+#pragma unroll
+        for (int s = 0; s < MAX_SCALES; ++s) {
+            avv[i][s] = 0.f; fsv[i][s] = 0.f;
+            if (a.nsc > 1 && s < a.nsc) {
+                const int ay = (gy + a.aph[s]) >> a.ash[s], ax = (gx + a.apw[s]) >> a.ash[s];
+                avv[i][s] = a.att[s][(size_t)ay * a.aw[s] + ax];
+                if (s >= 1) {
+                    const int fy = (gy + a.fph[s]) >> a.fsh[s], fx = (gx + a.fpw[s]) >> a.fsh[s];
+                    fsv[i][s] = a.fsum[s][(size_t)fy * a.fw[s] + fx];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+        const int pix = tid + i * 256;
+        if (pix >= L * LW) break;
         const int ly = pix / LW, lx = pix - ly * LW;
         const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
         float v[FR];
 #pragma unroll
         for (int c = 0; c < FR; ++c) v[c] = 0.f;
         if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-            const float* f = a.f0 + ((size_t)gy * a.W + gx) * FR;
             if (a.nsc <= 1) {
 #pragma unroll
-                for (int c = 0; c < FR; ++c) v[c] = f[c];
+                for (int c = 0; c < FR; ++c) v[c] = fv[i][c >> 2][c & 3];
             } else {
-                // the up-sampling factors are powers of two (8 * 2^s for the attention maps, 2^s for the feature maps):
-                // shifts instead of six run-time integer divisions per pixel; one reciprocal instead of three divisions
+                // (the up-sampling factors are powers of two -- 8 * 2^s for the attention maps, 2^s for the feature maps --:
+                // shifts instead of run-time integer divisions above; one reciprocal instead of three divisions here)
                 float av[MAX_SCALES], mx = -INFINITY;
 #pragma unroll
                 for (int s = 0; s < MAX_SCALES; ++s)
-                    if (s < a.nsc) {
-                        const int ay = (gy + a.aph[s]) >> a.ash[s], ax = (gx + a.apw[s]) >> a.ash[s];
-                        av[s] = a.att[s][(size_t)ay * a.aw[s] + ax];
-                        mx = fmaxf(mx, av[s]);
-                    }
+                    if (s < a.nsc) { av[s] = avv[i][s]; mx = fmaxf(mx, av[s]); }
                 float den = 0.f;
 #pragma unroll
                 for (int s = 0; s < MAX_SCALES; ++s)
@@ -1406,17 +1438,15 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
                 float add = 0.f;
 #pragma unroll
                 for (int s = 1; s < MAX_SCALES; ++s)
-                    if (s < a.nsc) {
-                        const int fy = (gy + a.fph[s]) >> a.fsh[s], fx = (gx + a.fpw[s]) >> a.fsh[s];
-                        add += a.fsum[s][(size_t)fy * a.fw[s] + fx] * (av[s] * inv);
-                    }
+                    if (s < a.nsc) add += fsv[i][s] * (av[s] * inv);
                 const float w0 = av[0] * inv;
 #pragma unroll
-                for (int c = 0; c < FR; ++c) v[c] = f[c] * w0 + add;
+                for (int c = 0; c < FR; ++c) v[c] = fv[i][c >> 2][c & 3] * w0 + add;
             }
         }
 #pragma unroll
-        for (int c = 0; c < FR; ++c) m[pix * FR + c] = v[c];
+        for (int c4 = 0; c4 < FR / 4; ++c4)
+            *reinterpret_cast<f32x4*>(m + mi(ly, lx, c4)) = f32x4{v[c4 * 4], v[c4 * 4 + 1], v[c4 * 4 + 2], v[c4 * 4 + 3]};
     }
     __syncthreads();
 
@@ -1441,7 +1471,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
 #pragma unroll
             for (int i = 0; i < 5; ++i)
 #pragma unroll
-                for (int c4 = 0; c4 < FR / 4; ++c4) v[i][c4] = *reinterpret_cast<const f32x4*>(m + ((ty + ky) * LW + 2 * tx + i) * FR + c4 * 4);
+                for (int c4 = 0; c4 < FR / 4; ++c4) v[i][c4] = *reinterpret_cast<const f32x4*>(m + mi(ty + ky, 2 * tx + i, c4));
 #pragma unroll
             for (int kx = 0; kx < 4; ++kx) {
                 cptr wp = (cptr)(a.wl + (ky * 4 + kx) * FR * 2);
@@ -1473,11 +1503,12 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
                 const float* __restrict__ wp = a.wl + (ky * 4 + kx) * FR * NC;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const float* mp = m + ((ty + ky) * LW + 2 * tx + q + kx) * FR;
 #pragma unroll
-                    for (int c = 0; c < FR; ++c)
+                    for (int c = 0; c < FR; ++c) {
+                        const float mv = m[mi(ty + ky, 2 * tx + q + kx, c >> 2) + (c & 3)];
 #pragma unroll
-                        for (int k = 0; k < NC; ++k) lg[q][k] = fmaf(mp[c], wp[c * NC + k], lg[q][k]);
+                        for (int k = 0; k < NC; ++k) lg[q][k] = fmaf(mv, wp[c * NC + k], lg[q][k]);
+                    }
                 }
             }
     }
