@@ -632,12 +632,23 @@ __global__ __launch_bounds__(256) void att_headv_kernel(const AttHeadArgs a) {
     const int H = P.H, W = P.W;
     float mean = 0.f, inv = 1.f;
     if (P.stats) { mean = P.stats[0]; inv = P.stats[1]; }
-    for (int i = tid; i < LH * LW; i += 256) {
-        const int r = i / LW, c = i - r * LW;
-        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-        float v = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = (P.img[(size_t)gy * W + gx] - mean) * inv;
-        img[i] = v;
+    {   // requests first, LDS writes afterwards (see deconv8v_kernel)
+        constexpr int NSL = (LH * LW + 255) / 256;
+        float st[NSL];
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            const int i = min(tid + k * 256, LH * LW - 1);
+            const int r = i / LW, c = i - r * LW;
+            st[k] = P.img[(size_t)min(max(y0 - 1 + r, 0), H - 1) * W + min(max(x0 - 1 + c, 0), W - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            const int i = tid + k * 256;
+            if (i >= LH * LW) break;
+            const int r = i / LW, c = i - r * LW;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            img[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (st[k] - mean) * inv : 0.f;
+        }
     }
     __syncthreads();
     const bool interior = y0 + ATT_TH <= H && x0 + ATT_TW <= W;   // every 2x2 window of the tile is complete
@@ -735,12 +746,26 @@ __global__ __launch_bounds__(256) void deconv8v_kernel(const ConvArgs a) {
     // tile -> LDS: (pixel, channel quad) slots, zero outside the image
     // (the four 16-byte quads of a 64-byte pixel record are permuted by the pixel's column, like r8_px: the lanes of a read
     // or write are consecutive pixels taking the SAME quad, 64 bytes apart = two bank groups without the permutation)
-    for (int idx = tid; idx < L * L * 4; idx += 256) {
+    // all of a thread's slots are requested (from clamped, always valid addresses) before the first is written to LDS: as
+    // one load-store loop the five round trips to memory were exposed one after the other
+    constexpr int NSL = (L * L * 4 + 255) / 256;
+    f32x4 st[NSL];
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+        const int idx = min(tid + i * 256, L * L * 4 - 1);
+        const int pix = idx >> 2, sub = idx & 3;
+        const int ly = pix / L, lx = pix - ly * L;
+        const int gy = min(max(qy0 - 1 + ly, 0), H - 1), gx = min(max(qx0 - 1 + lx, 0), W - 1);
+        st[i] = *reinterpret_cast<const f32x4*>(P.in0 + ((size_t)gy * W + gx) * 16 + sub * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+        const int idx = tid + i * 256;
+        if (idx >= L * L * 4) break;
         const int pix = idx >> 2, sub = idx & 3;
         const int ly = pix / L, lx = pix - ly * L;
         const int gy = qy0 - 1 + ly, gx = qx0 - 1 + lx;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const f32x4*>(P.in0 + ((size_t)gy * W + gx) * 16 + sub * 4);
+        const f32x4 v = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? st[i] : f32x4{0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(lds + pix * 16 + ((sub ^ ((lx >> 1) & 3)) << 2)) = imax4(v, relu_lim);
     }
     __syncthreads();
