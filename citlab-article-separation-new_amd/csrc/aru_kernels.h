@@ -1333,6 +1333,24 @@ __global__ __launch_bounds__(256) void chansum_kernel(const PoolArgs a) {
     const PoolProb& P = a.p[pi];
     const size_t total = (size_t)P.H * P.W;
     const size_t base = (size_t)(blockIdx.x - P.blk_begin) * POOL_ITEMS;
+    if (a.C == 8) {
+        // the usual case (feat_root 8): two 16-byte loads per pixel, all four pixels of a thread requested before the sums
+        // (same association as the scalar loop: ((((((c0 + c1) + c2) + c3) + c4) + c5) + c6) + c7)
+        f32x4 v[POOL_ITEMS / 256][2];
+#pragma unroll
+        for (int k = 0; k < POOL_ITEMS / 256; ++k) {
+            const size_t i = min(base + k * 256 + threadIdx.x, total - 1);
+            v[k][0] = *reinterpret_cast<const f32x4*>(P.in + i * 8);
+            v[k][1] = *reinterpret_cast<const f32x4*>(P.in + i * 8 + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < POOL_ITEMS / 256; ++k) {
+            const size_t i = base + k * 256 + threadIdx.x;
+            if (i >= total) break;
+            P.out[i] = ((((((v[k][0].x + v[k][0].y) + v[k][0].z) + v[k][0].w) + v[k][1].x) + v[k][1].y) + v[k][1].z) + v[k][1].w;
+        }
+        return;
+    }
     for (int k = 0; k < POOL_ITEMS / 256; ++k) {
         const size_t i = base + k * 256 + threadIdx.x;
         if (i >= total) break;
