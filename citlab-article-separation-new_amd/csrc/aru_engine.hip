@@ -30,7 +30,8 @@ struct PackedConv {
     float* d_w = nullptr;
     float* d_b = nullptr;
     float* d_wino = nullptr;   // Winograd F(2x2,3x3) transformed weights U = G g G^T, packed [g][pos][mtile][lane][4]
-    float* d_wv = nullptr;     // deconv 16 -> 8 only: [tap][ci][co] for deconv8v_kernel (scalar operands)
+    float* d_wv = nullptr;     // scalar-operand filters of the vector-ALU kernels: deconv 16 -> 8 [tap][ci][co] (deconv8v_kernel),
+                               // 4x4 conv 32 -> 1 [tap][ci] (conv_c1out_kernel)
 };
 
 struct DirectConv {        // Cin == 1 first layers
@@ -257,6 +258,14 @@ int pack_conv(asep_aru* m, const std::map<std::string, HostTensor>& blob, const 
         if (rc) return rc;
         m->owned.push_back(pc.d_wv);
     }
+    if (!deconv && pc.kh == 4 && pc.kw == 4 && pc.cin == 32 && pc.cout == 1) {
+        std::vector<float> wv;
+        for (int tap = 0; tap < 16; ++tap)
+            for (int ci = 0; ci < 32; ++ci) wv.push_back(W(tap, ci, 0));
+        rc = upload(wv, &pc.d_wv);
+        if (rc) return rc;
+        m->owned.push_back(pc.d_wv);
+    }
     m->convs[scope] = pc;
     return ASEP_OK;
 }
@@ -356,6 +365,36 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
     if (!((pc.kh == 3 && pc.kw == 3) || (pc.kh == 4 && pc.kw == 4))) {
         set_error("conv %s: unsupported kernel size %dx%d", scope.c_str(), pc.kh, pc.kw);
         throw ArgError();
+    }
+    if (pc.d_wv && pc.cout == 1 && m->r8_valu && !m->bf16 && !in1 && !res && !pooled) {
+        // single output channel (attention conv4): one pixel per thread on the vector ALU
+        TL out1;
+        for (const Tensor& t : in0) out1.push_back(new_tensor(m, t.H, t.W, 1));
+        for (size_t b0 = 0; b0 < in0.size(); b0 += MAXP) {
+            const size_t b1 = std::min(in0.size(), b0 + MAXP);
+            ConvArgs a{};
+            int tiles = 0;
+            double flops = 0;
+            for (size_t i = b0; i < b1; ++i) {
+                ConvProb& p = a.p[i - b0];
+                p.in0 = in0[i].p; p.out = out1[i].p;
+                p.H = p.Ho = in0[i].H; p.W = p.Wo = in0[i].W;
+                p.tiles_x = cdiv(in0[i].W, C1O_T);
+                p.tile_begin = tiles;
+                tiles += p.tiles_x * cdiv(in0[i].H, C1O_T);
+                flops += 2.0 * in0[i].H * in0[i].W * 16.0 * pc.cin;
+            }
+            a.nprob = (int)(b1 - b0);
+            a.total_tiles = tiles;
+            a.c0 = pc.cin; a.cout = 1;
+            a.wpk = (const f32x4*)pc.d_wv; a.bias = pc.d_b;
+            a.relu_in = relu_in; a.relu_out = relu_out;
+            std::string pname = "conv_c1out_kernel";
+            if (m->prof_detail) pname += " " + scope;
+            ProfScope ps(m, pname, flops);
+            hipLaunchKernelGGL(conv_c1out_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
+        }
+        return out1;
     }
     // bf16 MFMAs are so much faster that the LDS-bound Winograd kernels only pay at 128 channels (and they amplify the
     // bf16 rounding): the bf16 variant takes the direct kernels below that

@@ -840,4 +840,73 @@ __global__ __launch_bounds__(256) void deconv8v_kernel(const ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Last layer of the attention CNN on the vector ALU (fp32): 4x4 conv, SAME, 32 -> 1 channel (ARU_v1.py:183).  On the MFMA
+// path a single output channel occupies one of 16 rows (5 TFLOP/s, 57 us per page); here a thread owns one output pixel,
+// sums channel PAIRS in packed accumulators (v_pk_fma_f32, the filter in scalar registers) and adds the halves at the end.
+// ------------------------------------------------------------------------------------------------
+constexpr int C1O_T = 16;                                  // 16 x 16 output pixels per block, one per thread
+
+__global__ __launch_bounds__(256) void conv_c1out_kernel(const ConvArgs a) {
+    constexpr int T = C1O_T, L = T + 3, CIN = 32, Q = CIN / 4;   // 4x4 SAME: pad 1 before, 2 after
+    __shared__ __attribute__((aligned(16))) float lds[L * L * CIN];
+    const int tid = threadIdx.x;
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    const ConvProb& P = a.p[pi];
+    const int tile = blockIdx.x - P.tile_begin;
+    const int ty0 = tile / P.tiles_x, tx0 = tile - ty0 * P.tiles_x;
+    const int x0 = tx0 * T, y0 = ty0 * T;
+    const int H = P.H, W = P.W;
+    const int relu_lim = a.relu_in ? 0 : (int)0x80000000;
+    // halo tile: 128-byte pixel records, their eight 16-byte quads permuted by the pixel's column (a read takes the same
+    // quad of consecutive pixels: without the permutation all lanes of a pass hit one bank group); requests first
+    constexpr int NSL = (L * L * Q + 255) / 256;
+    f32x4 st[NSL];
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+        const int idx = min(tid + i * 256, L * L * Q - 1);
+        const int pix = idx / Q, sub = idx - pix * Q;
+        const int ly = pix / L, lx = pix - ly * L;
+        const int gy = min(max(y0 - 1 + ly, 0), H - 1), gx = min(max(x0 - 1 + lx, 0), W - 1);
+        st[i] = *reinterpret_cast<const f32x4*>(P.in0 + ((size_t)gy * W + gx) * CIN + sub * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+        const int idx = tid + i * 256;
+        if (idx >= L * L * Q) break;
+        const int pix = idx / Q, sub = idx - pix * Q;
+        const int ly = pix / L, lx = pix - ly * L;
+        const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+        const f32x4 v = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? st[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(lds + pix * CIN + ((sub ^ (lx & 7)) << 2)) = imax4(v, relu_lim);
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    r8v_cptr wl = (r8v_cptr) reinterpret_cast<const float*>(a.wpk);   // [16 taps][32]
+    f32x2 acc0 = f32x2{0.f, 0.f}, acc1 = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            asm volatile("" : "+s"(wl));                      // this tap's 32 scalars are loaded here, not hoisted (and spilled)
+            float w[CIN];
+#pragma unroll
+            for (int k = 0; k < CIN; ++k) w[k] = wl[(ky * 4 + kx) * CIN + k];
+            const int lx = tx + kx;
+            const float* p = lds + ((ty + ky) * L + lx) * CIN;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p + ((q ^ (lx & 7)) << 2));
+                asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc0) : "v"(f32x2{v.x, v.y}), "s"(f32x2{w[4 * q], w[4 * q + 1]}));
+                asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc1) : "v"(f32x2{v.z, v.w}), "s"(f32x2{w[4 * q + 2], w[4 * q + 3]}));
+            }
+        }
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= W || y >= H) return;
+    float s = ((acc0.x + acc0.y) + (acc1.x + acc1.y)) + a.bias[0];
+    if (a.relu_out) s = fmaxf(s, 0.f);
+    P.out[(size_t)y * W + x] = s;
+}
+
 }  // namespace asep
