@@ -140,12 +140,11 @@ __device__ __forceinline__ f32x4 imax4(f32x4 v, int lim) {
 // Software pipeline: the halo tile of channel group g+1 is fetched into registers while group g is multiplied
 // out of LDS (two LDS buffers, one barrier per group); the weight fragments of tap t+1 are requested before the
 // MFMAs of tap t are issued.
-#ifndef CONV_BIG_BLOCKS
-#define CONV_BIG_BLOCKS 2
-#endif
-#define CONV_MFMA_MIN_BLOCKS(TH) ((TH) == 16 ? CONV_BIG_BLOCKS : 2)
-template <int KH, int KW, int MT, bool C8, int TH = CONV_TH, bool DBUF = true, bool BF = false, bool C12 = false>
-__global__ __launch_bounds__(256, CONV_MFMA_MIN_BLOCKS(TH)) void conv_mfma_kernel(const ConvArgs a) {
+// MINB = blocks per CU the register allocation is bounded for: 2, or 4 for the 16 x 32-pixel single-group variant when the
+// layer has no residual operand (the 32 registers of the residual prefetch go, 106 VGPRs, four 39 KB blocks per CU:
+// 216 -> 203 us for a 16 -> 16 layer at 2250 x 1500; with a residual operand its latency would be exposed: 2 blocks)
+template <int KH, int KW, int MT, bool C8, int TH = CONV_TH, bool DBUF = true, bool BF = false, bool C12 = false, int MINB = 2>
+__global__ __launch_bounds__(256, MINB) void conv_mfma_kernel(const ConvArgs a) {
     static_assert(!C12 || (!C8 && KW * 12 % 16 == 0), "C12: dense rows of KW x 12 floats");
     constexpr int TW = CONV_TW, NT = TH / 2;             // TH rows x 2 column blocks of 16 pixels, 4 waves
     constexpr int LH = TH + KH - 1, LW = TW + KW - 1;
@@ -262,7 +261,7 @@ __global__ __launch_bounds__(256, CONV_MFMA_MIN_BLOCKS(TH)) void conv_mfma_kerne
 #pragma unroll
     for (int m = 0; m < MT; ++m) af[m] = wbase[(size_t)m * 64];
     // residual operand of the epilogue: requested now so that its HBM latency hides under the MFMA phases
-    constexpr bool RES_PREFETCH = (MT * NT <= 8);
+    constexpr bool RES_PREFETCH = (MT * NT <= 8) && MINB <= 2;
     f32x4 resv[RES_PREFETCH ? MT : 1][RES_PREFETCH ? NT : 1];
     if constexpr (RES_PREFETCH) {
         // branch-free: clamped addresses; without a residual operand the (ignored) values are read from the input
