@@ -322,7 +322,8 @@ void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, int tot
     if (m->prof_detail) pname += " " + scope + " " + dims_of(in0) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
     ProfScope ps(m, pname, flops);
     hipStream_t s = m->stream;
-    const bool has_res = a.p[0].res != nullptr || KH != 3;      // (the four-blocks-per-CU variant exists for 3x3 only: 4x4 needs 140 VGPRs)
+    const bool res_op = a.p[0].res != nullptr;
+    const bool has_res = res_op || KH != 3;      // (the four-blocks-per-CU variant exists for 3x3 only: 4x4 needs 140 VGPRs)
     if constexpr (KW == 4) {
         if (pc.c12) {                                        // one m-tile, one channel group: 16 x 32 tiles, single LDS buffer
             if (m->bf16) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false, 16, false, true, true>), grid, dim3(256), 0, s, a);
@@ -335,6 +336,7 @@ void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, int tot
         else if (mt == 1 && big_tile && !has_res) hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 1, false, 16, false, true, false, 4>), grid, dim3(256), 0, s, a);
         else if (mt == 1 && big_tile) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false, 16, false, true>), grid, dim3(256), 0, s, a);
         else if (mt == 4) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 4, false, CONV_TH, true, true>), grid, dim3(256), 0, s, a);
+        else if (mt == 2 && !res_op) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 2, false, CONV_TH, true, true, false, 3>), grid, dim3(256), 0, s, a);
         else if (mt == 2) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 2, false, CONV_TH, true, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false, CONV_TH, true, true>), grid, dim3(256), 0, s, a);
         return;
@@ -343,6 +345,7 @@ void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, int tot
     else if (mt == 1 && big_tile && !has_res) hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 1, false, 16, false, false, false, 4>), grid, dim3(256), 0, s, a);
     else if (mt == 1 && big_tile) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false, 16, false>), grid, dim3(256), 0, s, a);
     else if (mt == 4) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 4, false>), grid, dim3(256), 0, s, a);
+    else if (mt == 2 && !res_op) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 2, false, CONV_TH, true, false, false, 3>), grid, dim3(256), 0, s, a);   // no residual prefetch: three blocks per CU
     else if (mt == 2) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 2, false>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false>), grid, dim3(256), 0, s, a);
 }
