@@ -471,6 +471,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             } else if (mt == 2 && m->wino_reg) {
                 // register-resident variant: a wave per (tile row, m-tile); grid.y counts pairs of m-tiles
                 if (m->bf16) hipLaunchKernelGGL((conv_winor_kernel<true>), grid, dim3(256), 0, m->stream, a);
+                else if (!res) hipLaunchKernelGGL((conv_winor_kernel<false, 2, false>), grid, dim3(256), 0, m->stream, a);
                 else hipLaunchKernelGGL((conv_winor_kernel<false>), grid, dim3(256), 0, m->stream, a);
             } else if (m->bf16) {
                 if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4, true>), grid, dim3(256), 0, m->stream, a);

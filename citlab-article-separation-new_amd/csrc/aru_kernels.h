@@ -733,8 +733,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 // ------------------------------------------------------------------------------------------------
 // MH = 16-channel output tiles per block: 2 (the 32-channel level, 4 x 32 pixel blocks) or 1 (the 16-channel level: the four
 // waves are four tile rows of an 8 x 32 pixel block, V is formed once per tile)
-template <bool BF = false, int MH = 2>
-__global__ __launch_bounds__(256, 2) void conv_winor_kernel(const ConvArgs a) {
+// RESP = false: the layer has no residual operand; without the 16 registers of its prefetch the kernel is bounded for three
+// blocks per CU instead of two
+template <bool BF = false, int MH = 2, bool RESP = true>
+__global__ __launch_bounds__(256, RESP ? 2 : 3) void conv_winor_kernel(const ConvArgs a) {
     constexpr int NTR = 4 / MH;                           // tile rows (waves per m-tile)
     constexpr int TH = 2 * NTR, TW = WINO_TW;
     constexpr int HH = TH + 2, HW = TW + 2, HP = 20;      // window: 6 x 34 pixels x 16 channels, pixel pitch 20 floats
@@ -809,56 +811,50 @@ __global__ __launch_bounds__(256, 2) void conv_winor_kernel(const ConvArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int yy = min(oy + (q >> 1), P.Ho - 1), xx = min(ox + (q & 1), P.Wo - 1);
-        rv[q] = P.res ? *reinterpret_cast<const f32x4*>(P.res + ((size_t)yy * P.Wo + xx) * a.cout + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+        rv[q] = (RESP && P.res) ? *reinterpret_cast<const f32x4*>(P.res + ((size_t)yy * P.Wo + xx) * a.cout + co) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     halo_store();
     __syncthreads();
 
     for (int g = 0; g < G; ++g) {
         const bool more = g + 1 < G;
-        // ---- V = B^T d B of this lane's tile, 4 channels wide: row pass while reading, then the column pass ------
-        f32x4 V[4][4];
-        {
-            f32x4 d0[4], d1[4], d2[4], d3[4];
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                d0[s2] = *reinterpret_cast<const f32x4*>(hb + (0 * HW + s2) * HP);
-                d1[s2] = *reinterpret_cast<const f32x4*>(hb + (1 * HW + s2) * HP);
-                d2[s2] = *reinterpret_cast<const f32x4*>(hb + (2 * HW + s2) * HP);
-                d3[s2] = *reinterpret_cast<const f32x4*>(hb + (3 * HW + s2) * HP);
-            }
-            if (more) halo_load(g + 1);                    // global loads in flight during the MFMA phase
-            f32x4 t[4][4];
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                t[0][s2] = psub(d0[s2], d2[s2]);
-                t[1][s2] = d1[s2] + d2[s2];
-                t[2][s2] = psub(d2[s2], d1[s2]);
-                t[3][s2] = psub(d1[s2], d3[s2]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                V[r][0] = psub(t[r][0], t[r][2]);
-                V[r][1] = t[r][1] + t[r][2];
-                V[r][2] = psub(t[r][2], t[r][1]);
-                V[r][3] = psub(t[r][1], t[r][3]);
-            }
-        }
-        // ---- 16 positions x (K = 16 channels) for this wave's m-tile; the filter fragment is requested one position ahead ----
+        // ---- V = B^T d B of this lane's tile, 4 channels wide, ONE ROW OF POSITIONS AT A TIME: row r of B^T d needs two
+        //      rows of the patch (re-read from LDS: 32 instead of 16 reads per group, the LDS pipe is 9 % busy here), its
+        //      four V values are the B fragments of the next 16 MFMAs.  Only 4 of the 16 V live at a time: with the
+        //      residual prefetch gone too (RESP = false) the kernel fits three blocks per CU.
         const f32x4* __restrict__ wg = wbase + (size_t)g * 16 * wstride;
         const f32x4* __restrict__ wfirst_next = wbase + (size_t)(more ? g + 1 : g) * 16 * wstride;
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const f32x4 an = p + 1 < 16 ? wg[(size_t)(p + 1) * wstride] : wfirst_next[0];
-            __builtin_amdgcn_sched_barrier(0);
-            const f32x4 b = V[p >> 2][p & 3];
-            if constexpr (BF) {
-                acc[p] = mfma_bf16(bf16pack(af), bf16pack(b), acc[p]);
-            } else {
+        for (int r = 0; r < 4; ++r) {
+            constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};     // t[r] = d[RA] (- or +) d[RB]
+            f32x4 t[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r], b[r], acc[p], 0, 0, 0);
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const f32x4 da = *reinterpret_cast<const f32x4*>(hb + (RA[r] * HW + s2) * HP);
+                const f32x4 db = *reinterpret_cast<const f32x4*>(hb + (RB[r] * HW + s2) * HP);
+                t[s2] = r == 1 ? da + db : psub(da, db);
             }
-            af = an;
+            if (r == 0 && more) halo_load(g + 1);          // global loads in flight during the MFMA phase
+            f32x4 Vr[4];
+            Vr[0] = psub(t[0], t[2]);
+            Vr[1] = t[1] + t[2];
+            Vr[2] = psub(t[2], t[1]);
+            Vr[3] = psub(t[1], t[3]);
+            // ---- 4 positions x (K = 16 channels) for this wave's m-tile; the filter fragment is requested one position ahead ----
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int p = r * 4 + c;
+                const f32x4 an = p + 1 < 16 ? wg[(size_t)(p + 1) * wstride] : wfirst_next[0];
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 b = Vr[c];
+                if constexpr (BF) {
+                    acc[p] = mfma_bf16(bf16pack(af), bf16pack(b), acc[p]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], b[q], acc[p], 0, 0, 0);
+                }
+                af = an;
+            }
         }
         if (more) {
             __syncthreads();                               // every wave has read its patches of group g
