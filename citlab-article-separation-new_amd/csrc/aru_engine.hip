@@ -106,6 +106,7 @@ struct asep_aru {
     bool bf16 = false;             // cfg.compute_dtype == 1: bf16 MFMA operands, fp32 accumulation and storage
     bool wino_reg = true;          // ASEP_WINO_REG=0: LDS-image Winograd kernel also for the 32-channel level
     bool use_winograd = true;      // ASEP_WINOGRAD=0 selects the direct implicit-GEMM kernels everywhere
+    bool big_tile2 = true;         // ASEP_BIGTILE2=0: 8 x 32 double-buffered blocks for 32 -> 16 convs without residual operand
     bool use_c12 = true;           // ASEP_C12=0: 12-channel inputs padded to a 16-channel group (read when the weights are packed)
     bool fuse_pool = true;         // ASEP_FUSE_POOL=0: separate maxpool2_kernel after every conv
     bool wino16 = false;           // ASEP_WINO16=1: register-resident Winograd also at the 16-channel level (measured: 99 vs
@@ -416,7 +417,8 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
     }
     // single channel group, one 16-channel output tile: 16 x 32 pixel blocks, single LDS buffer (more MFMA work per
     // block against the fixed load latency of these short blocks)
-    const bool big_tile = !wino && !pc.c8 && pc.groups == 1 && pc.mtiles == 1 && (m->big_tile || pc.c12);
+    // (two channel groups only for the residual-free 3x3 variant: four blocks per CU hide the refill of its single LDS buffer)
+    const bool big_tile = !wino && !pc.c8 && (pc.groups == 1 || (pc.groups == 2 && !res && pc.kh == 3 && m->big_tile2)) && pc.mtiles == 1 && (m->big_tile || pc.c12);
     const int th = big_tile ? 16 : CONV_TH;
     for (size_t b0 = 0; b0 < in0.size(); b0 += MAXP) {
         const size_t b1 = std::min(in0.size(), b0 + MAXP);
@@ -1123,6 +1125,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_WINO16")) m->wino16 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSE_POOL")) m->fuse_pool = atoi(e) != 0;
     if (const char* e = getenv("ASEP_C12")) m->use_c12 = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_BIGTILE2")) m->big_tile2 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_R8_VALU")) m->r8_valu = atoi(e) != 0;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, MINB) void conv_mfma_kernel(const ConvArgs a) 
     constexpr int STR = C12 ? 255 : 256;                 // loader stride: a multiple of SUBS, so that a thread keeps its sub-block
     constexpr int NLOAD = (NV + STR - 1) / STR;
     constexpr int LBUF = LH * LW * CPP;
-    __shared__ __attribute__((aligned(16))) float lds[(DBUF ? 2 : 1) * LBUF];   // DBUF=false: single channel group only
+    __shared__ __attribute__((aligned(16))) float lds[(DBUF ? 2 : 1) * LBUF];   // DBUF=false: one buffer, refilled between channel groups
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
@@ -336,6 +336,14 @@ __global__ __launch_bounds__(256, MINB) void conv_mfma_kernel(const ConvArgs a) 
         }
         if (DBUF && g + 1 < ngroups) stage_store((g + 1) & 1);
         if (DBUF) __syncthreads();
+        if (!DBUF && g + 1 < ngroups) {
+            // single LDS buffer, several channel groups (the four-blocks-per-CU variant on a 32-channel input): the next
+            // group is fetched after this one's readers are done; its latency is covered by the other blocks of the CU
+            __syncthreads();
+            stage_load(g + 1);
+            stage_store(0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: D layout col = lane&15 -> pixel, row = 4*(lane>>4)+reg -> output channel ----
