@@ -332,6 +332,13 @@ void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, int tot
             return;
         }
     }
+    if constexpr (KH == 3) {
+        if (pc.c8 && big_tile && !res_op) {                  // 8 -> 16 (level-1 conv1): 16 x 32-pixel blocks, four per CU
+            if (m->bf16) hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 1, true, 16, false, true, false, 4>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 1, true, 16, false, false, false, 4>), grid, dim3(256), 0, s, a);
+            return;
+        }
+    }
     if (m->bf16) {
         if (pc.c8) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, true, CONV_TH, true, true>), grid, dim3(256), 0, s, a);
         else if (mt == 1 && big_tile && !has_res) hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 1, false, 16, false, true, false, 4>), grid, dim3(256), 0, s, a);
@@ -418,7 +425,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
     // single channel group, one 16-channel output tile: 16 x 32 pixel blocks, single LDS buffer (more MFMA work per
     // block against the fixed load latency of these short blocks)
     // (two channel groups only for the residual-free 3x3 variant: four blocks per CU hide the refill of its single LDS buffer)
-    const bool big_tile = !wino && !pc.c8 && (pc.groups == 1 || (pc.groups == 2 && !res && pc.kh == 3 && m->big_tile2)) && pc.mtiles == 1 && (m->big_tile || pc.c12);
+    const bool big_tile = !wino && (!pc.c8 || (pc.kh == 3 && !res && m->big_tile2)) && (pc.groups == 1 || (pc.groups == 2 && !res && pc.kh == 3 && m->big_tile2)) && pc.mtiles == 1 && (m->big_tile || pc.c12);
     const int th = big_tile ? 16 : CONV_TH;
     for (size_t b0 = 0; b0 < in0.size(); b0 += MAXP) {
         const size_t b1 = std::min(in0.size(), b0 + MAXP);
