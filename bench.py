@@ -352,6 +352,9 @@ def main():
                     roofline["traffic"] = tj["bytes_per_launch"] * mine / ppl
                     roofline["traffic_source"] = (f"offline: {tj_all.get('source')} (commit {tj_all.get('commit', 'n/a')}, "
                                                   f"{ppl} pages per launch there, scaled x{mine / ppl:g})")
+                    # the same launch against the other roof (HBM ~ 8 TB/s): the level-1 convs sit near half of both
+                    roofline["hbm_tb_per_s"] = round(roofline["traffic"] / (dom["avg_us"] * 1e-6) / 1e12, 3)
+                    roofline["hbm_frac"] = round(roofline["hbm_tb_per_s"] / 8.0, 4)
             except Exception:
                 pass
 
