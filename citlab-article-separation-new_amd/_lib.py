@@ -27,6 +27,13 @@ class GnnCfg(C.Structure):
         "interaction_hidden", "cls_hidden1", "cls_hidden2", "num_classes", "undirected_graph")]
 
 
+class GnnPage(C.Structure):
+    """asep_gnn_page (include/asep_hip.h): one page of asep_gnn_forward_visual_batch_dev, device addresses"""
+    _fields_ = [("N", C.c_int32), ("E", C.c_int32), ("R", C.c_int32), ("d_edges", C.c_void_p), ("d_node_feat", C.c_void_p),
+                ("d_edge_feat", C.c_void_p), ("d_image", C.c_void_p), ("d_regions", C.c_void_p), ("d_num_points", C.c_void_p),
+                ("d_relations", C.c_void_p), ("d_probs_out", C.c_void_p)]
+
+
 # name -> (restype, argtypes); mirrors include/asep_hip.h one to one
 _P = C.c_void_p
 SIGNATURES = {
@@ -59,6 +66,7 @@ SIGNATURES = {
                                           C.c_int, _P, _P]),
     "asep_gnn_forward_visual_dev": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P,
                                               C.c_int, _P, _P, _P]),
+    "asep_gnn_forward_visual_batch_dev": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "asep_gnn_step_mode": (C.c_int, [_P]),
     "asep_gnn_get_node_features": (C.c_int, [_P, _P, C.c_size_t]),
     "asep_post_create": (_P, []),

@@ -113,6 +113,7 @@ struct asep_aru {
                                    // 103 TFLOP/s-equivalent for the direct kernels, parity-green; kept as an experiment switch)
     bool profiling = false;
     bool prof_detail = false;      // per-layer names (scope + spatial size) instead of per-kernel names
+    bool prof_in_situ = false;     // keep the attention side stream while recording (times include what shares the chip)
     std::vector<std::string> prof_names;
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> ev_pool;
@@ -144,24 +145,36 @@ struct asep_aru {
 namespace {
 
 // Brackets one kernel launch with two events when profiling is on (no-op otherwise).
+// Names are the kernels' rocprofv3 names without "void ", "asep::", blanks and the argument list (every template
+// argument spelled out), so that scripts/roofline_from_profiles.py can join the two sources without a name table.
 struct ProfScope {
     asep_aru* m;
     hipEvent_t a = nullptr, b = nullptr;
-    int kid = -1;
+    bool on = false;
     double flops;
-    ProfScope(asep_aru* m_, const std::string& name, double flops_) : m(m_), flops(flops_) {
+    std::string name, detail;
+    ProfScope(asep_aru* m_, const std::string& name_, double flops_, const std::string& detail_ = std::string())
+        : m(m_), flops(flops_), name(name_), detail(detail_) {
         if (!m->profiling) return;
-        kid = m->prof_kid(name);
+        on = true;
         a = m->next_event();
         b = m->next_event();
         ASEP_HIP_CHECK_THROW(hipEventRecord(a, m->stream));
     }
+    void set_name(const std::string& n) { name = n; }
     ~ProfScope() {
-        if (kid < 0) return;
+        if (!on) return;
         (void)hipEventRecord(b, m->stream);
-        m->prof_recs.push_back({kid, flops, a, b});
+        m->prof_recs.push_back({m->prof_kid(m->prof_detail && !detail.empty() ? name + " " + detail : name), flops, a, b});
     }
 };
+std::string targs(std::initializer_list<std::string> l) {
+    std::string s = "<";
+    for (const std::string& x : l) s += (s.size() > 1 ? "," : "") + x;
+    return s + ">";
+}
+inline std::string tb(bool b) { return b ? "true" : "false"; }
+inline std::string ti(int i) { return std::to_string(i); }
 
 // ---- weight packing -----------------------------------------------------------------------------
 // conv   W[kh][kw][cin][cout]  (layers.py:219);  deconv W[kh][kw][cout][cin] (layers.py:352, ARU_v1.py:257)
@@ -312,50 +325,53 @@ std::string dims_of(const TL& l) {
     return d;
 }
 
+// launches conv_mfma_kernel<...> and gives the profiler record that instantiation's exact name
+#define ASEP_CONV_LAUNCH(KH_, KW_, MT_, C8_, TH_, DB_, BF_, C12_, MB_)                                                   \
+    do {                                                                                                                 \
+        ps.set_name("conv_mfma_kernel" + targs({ti(KH_), ti(KW_), ti(MT_), tb(C8_), ti(TH_), tb(DB_), tb(BF_), tb(C12_), ti(MB_)})); \
+        hipLaunchKernelGGL((conv_mfma_kernel<KH_, KW_, MT_, C8_, TH_, DB_, BF_, C12_, MB_>), grid, dim3(256), 0, s, a);  \
+    } while (0)
+
 template <int KH, int KW>
 void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, int total_tiles, double flops,
                    const std::string& scope, const TL& in0, bool big_tile) {
     const int mt = pc.c8 ? 1 : (pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1));
     dim3 grid(total_tiles, pc.mtiles / mt);
-    char name[64];
-    snprintf(name, sizeof(name), "conv_mfma_kernel<%d,%d,%d,%s%s>", KH, KW, mt, pc.c12 ? "c12" : (pc.c8 ? "true" : "false"), big_tile ? ",16,false" : "");
-    std::string pname = name;
-    if (m->prof_detail) pname += " " + scope + " " + dims_of(in0) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
-    ProfScope ps(m, pname, flops);
+    ProfScope ps(m, "conv_mfma_kernel", flops, scope + " " + dims_of(in0) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
     hipStream_t s = m->stream;
     const bool res_op = a.p[0].res != nullptr;
     const bool has_res = res_op || KH != 3;      // (the four-blocks-per-CU variant exists for 3x3 only: 4x4 needs 140 VGPRs)
     if constexpr (KW == 4) {
         if (pc.c12) {                                        // one m-tile, one channel group: 16 x 32 tiles, single LDS buffer
-            if (m->bf16) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false, 16, false, true, true>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false, 16, false, false, true>), grid, dim3(256), 0, s, a);
+            if (m->bf16) ASEP_CONV_LAUNCH(KH, KW, 1, false, 16, false, true, true, 2);
+            else ASEP_CONV_LAUNCH(KH, KW, 1, false, 16, false, false, true, 2);
             return;
         }
     }
     if constexpr (KH == 3) {
         if (pc.c8 && big_tile && !res_op) {                  // 8 -> 16 (level-1 conv1): 16 x 32-pixel blocks, four per CU
-            if (m->bf16) hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 1, true, 16, false, true, false, 4>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 1, true, 16, false, false, false, 4>), grid, dim3(256), 0, s, a);
+            if (m->bf16) ASEP_CONV_LAUNCH(3, 3, 1, true, 16, false, true, false, 4);
+            else ASEP_CONV_LAUNCH(3, 3, 1, true, 16, false, false, false, 4);
             return;
         }
     }
     if (m->bf16) {
-        if (pc.c8) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, true, CONV_TH, true, true>), grid, dim3(256), 0, s, a);
-        else if (mt == 1 && big_tile && !has_res) hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 1, false, 16, false, true, false, 4>), grid, dim3(256), 0, s, a);
-        else if (mt == 1 && big_tile) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false, 16, false, true>), grid, dim3(256), 0, s, a);
-        else if (mt == 4) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 4, false, CONV_TH, true, true>), grid, dim3(256), 0, s, a);
-        else if (mt == 2 && !res_op) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 2, false, CONV_TH, true, true, false, 3>), grid, dim3(256), 0, s, a);
-        else if (mt == 2) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 2, false, CONV_TH, true, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false, CONV_TH, true, true>), grid, dim3(256), 0, s, a);
+        if (pc.c8) ASEP_CONV_LAUNCH(KH, KW, 1, true, CONV_TH, true, true, false, 2);
+        else if (mt == 1 && big_tile && !has_res) ASEP_CONV_LAUNCH(3, 3, 1, false, 16, false, true, false, 4);
+        else if (mt == 1 && big_tile) ASEP_CONV_LAUNCH(KH, KW, 1, false, 16, false, true, false, 2);
+        else if (mt == 4) ASEP_CONV_LAUNCH(KH, KW, 4, false, CONV_TH, true, true, false, 2);
+        else if (mt == 2 && !res_op) ASEP_CONV_LAUNCH(KH, KW, 2, false, CONV_TH, true, true, false, 3);
+        else if (mt == 2) ASEP_CONV_LAUNCH(KH, KW, 2, false, CONV_TH, true, true, false, 2);
+        else ASEP_CONV_LAUNCH(KH, KW, 1, false, CONV_TH, true, true, false, 2);
         return;
     }
-    if (pc.c8) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, true>), grid, dim3(256), 0, s, a);
-    else if (mt == 1 && big_tile && !has_res) hipLaunchKernelGGL((conv_mfma_kernel<3, 3, 1, false, 16, false, false, false, 4>), grid, dim3(256), 0, s, a);
-    else if (mt == 1 && big_tile) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false, 16, false>), grid, dim3(256), 0, s, a);
-    else if (mt == 4) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 4, false>), grid, dim3(256), 0, s, a);
-    else if (mt == 2 && !res_op) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 2, false, CONV_TH, true, false, false, 3>), grid, dim3(256), 0, s, a);   // no residual prefetch: three blocks per CU
-    else if (mt == 2) hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 2, false>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, 1, false>), grid, dim3(256), 0, s, a);
+    if (pc.c8) ASEP_CONV_LAUNCH(KH, KW, 1, true, CONV_TH, true, false, false, 2);
+    else if (mt == 1 && big_tile && !has_res) ASEP_CONV_LAUNCH(3, 3, 1, false, 16, false, false, false, 4);
+    else if (mt == 1 && big_tile) ASEP_CONV_LAUNCH(KH, KW, 1, false, 16, false, false, false, 2);
+    else if (mt == 4) ASEP_CONV_LAUNCH(KH, KW, 4, false, CONV_TH, true, false, false, 2);
+    else if (mt == 2 && !res_op) ASEP_CONV_LAUNCH(KH, KW, 2, false, CONV_TH, true, false, false, 3);   // no residual prefetch: three blocks per CU
+    else if (mt == 2) ASEP_CONV_LAUNCH(KH, KW, 2, false, CONV_TH, true, false, false, 2);
+    else ASEP_CONV_LAUNCH(KH, KW, 1, false, CONV_TH, true, false, false, 2);
 }
 
 // stride-1 SAME conv on the (optionally concatenated) inputs of every problem
@@ -403,9 +419,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             a.c0 = pc.cin; a.cout = 1;
             a.wpk = (const f32x4*)pc.d_wv; a.bias = pc.d_b;
             a.relu_in = relu_in; a.relu_out = relu_out;
-            std::string pname = "conv_c1out_kernel";
-            if (m->prof_detail) pname += " " + scope;
-            ProfScope ps(m, pname, flops);
+            ProfScope ps(m, "conv_c1out_kernel", flops, scope);
             hipLaunchKernelGGL(conv_c1out_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
         }
         return out1;
@@ -472,16 +486,18 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             a.total_tiles = wt;
             const int ny = pc.mtiles / mt;
             dim3 grid(wt, ny);
-            std::string pname = mt == 1 ? std::string("conv_winor_kernel<1>") : (mt == 2 && m->wino_reg) ? std::string("conv_winor_kernel") : "conv_wino_kernel<" + std::to_string(mt) + ">";
-            if (m->prof_detail) pname += " " + scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
-            ProfScope ps(m, pname, flops);
+            std::string pname;
+            if (mt == 1) pname = "conv_winor_kernel<false,1,true>";
+            else if (mt == 2 && m->wino_reg) pname = m->bf16 ? "conv_winor_kernel<true,2,true>" : (!res ? "conv_winor_kernel<false,2,false>" : "conv_winor_kernel<false,2,true>");
+            else pname = "conv_wino_kernel" + targs({ti(mt), tb(m->bf16)});
+            ProfScope ps(m, pname, flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
             if (mt == 1) {
-                hipLaunchKernelGGL((conv_winor_kernel<false, 1>), grid, dim3(256), 0, m->stream, a);
+                hipLaunchKernelGGL((conv_winor_kernel<false, 1, true>), grid, dim3(256), 0, m->stream, a);
             } else if (mt == 2 && m->wino_reg) {
                 // register-resident variant: a wave per (tile row, m-tile); grid.y counts pairs of m-tiles
-                if (m->bf16) hipLaunchKernelGGL((conv_winor_kernel<true>), grid, dim3(256), 0, m->stream, a);
+                if (m->bf16) hipLaunchKernelGGL((conv_winor_kernel<true, 2, true>), grid, dim3(256), 0, m->stream, a);
                 else if (!res) hipLaunchKernelGGL((conv_winor_kernel<false, 2, false>), grid, dim3(256), 0, m->stream, a);
-                else hipLaunchKernelGGL((conv_winor_kernel<false>), grid, dim3(256), 0, m->stream, a);
+                else hipLaunchKernelGGL((conv_winor_kernel<false, 2, true>), grid, dim3(256), 0, m->stream, a);
             } else if (m->bf16) {
                 if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4, true>), grid, dim3(256), 0, m->stream, a);
                 else if (mt == 2) hipLaunchKernelGGL((conv_wino_kernel<2, true>), grid, dim3(256), 0, m->stream, a);
@@ -537,10 +553,9 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
         a.relu_in = 0; a.relu_out = relu_out;
         dim3 grid(tiles, pc.mtiles / mt);
-        std::string dname = valu ? "deconv8v_kernel" : (mt == 2 ? "deconv_mfma_kernel<2>" : "deconv_mfma_kernel<1>");
+        const std::string dname = valu ? std::string("deconv8v_kernel") : "deconv_mfma_kernel" + targs({ti(mt), tb(m->bf16)});
         TL sub(in.begin() + b0, in.begin() + b1);
-        if (m->prof_detail) dname += " " + scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout);
-        ProfScope ps(m, dname, flops);
+        ProfScope ps(m, dname, flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
         if (valu) {
             a.wpk = (const f32x4*)pc.d_wv;
             hipLaunchKernelGGL(deconv8v_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
@@ -780,9 +795,8 @@ void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>&
         for (size_t i = b0; i < b1; ++i) valu = valu && (size_t)imgs[i].H * imgs[i].W < ((size_t)1 << 28);
         a.wr = (const f32x4*)(valu ? m->d_r8v_down_wr : m->d_r8_down_wr); a.br = m->d_r8_down_br;
         TL sub(imgs.begin() + b0, imgs.begin() + b1);
-        std::string pname = valu ? "res8v_down_kernel" : "res8_down_kernel";
-        if (m->prof_detail) pname += " unet_down_0 (conv1+3xconvR+add+pool) " + dims_of(sub);
-        ProfScope ps(m, pname, flops);
+        const std::string pname = valu ? std::string("res8v_down_kernel") : "res8_down_kernel" + targs({tb(m->bf16)});
+        ProfScope ps(m, pname, flops, "unet_down_0 (conv1+3xconvR+add+pool) " + dims_of(sub));
         a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH * R8_NP);
         if (m->bf16) hipLaunchKernelGGL(res8_down_kernel<true>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
         else if (valu) hipLaunchKernelGGL(res8v_down_kernel, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
@@ -815,9 +829,8 @@ TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
         a.w1 = valu ? m->d_r8v_up_w1 : m->d_r8_up_w1; a.b1 = m->d_r8_up_b1;
         a.wr = (const f32x4*)(valu ? m->d_r8v_up_wr : m->d_r8_up_wr); a.br = m->d_r8_up_br;
         TL sub(skip.begin() + b0, skip.begin() + b1);
-        std::string pname = valu ? "res8v_up_kernel" : "res8_up_kernel";
-        if (m->prof_detail) pname += " unet_up_0 (conv1[16->8]+3xconvR+add) " + dims_of(sub);
-        ProfScope ps(m, pname, flops);
+        const std::string pname = valu ? std::string("res8v_up_kernel") : "res8_up_kernel" + targs({tb(m->bf16)});
+        ProfScope ps(m, pname, flops, "unet_up_0 (conv1[16->8]+3xconvR+add) " + dims_of(sub));
         a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH * R8_NP);
         const dim3 grid(std::min(tiles, m->num_cus));
         if (m->bf16) hipLaunchKernelGGL(res8_up_kernel<true>, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
@@ -974,7 +987,7 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
             // the attention CNN is a chain of small launches that cannot fill the chip: run it on a side stream next
             // to the feature branch (fork after the pyramid, join before the combine).  Per-launch profiling keeps
             // everything on one stream so that kernel times are not inflated by the overlap.
-            if (m->use_side_stream && !m->profiling && L.side) {
+            if (m->use_side_stream && (!m->profiling || m->prof_in_situ) && L.side) {
                 ASEP_HIP_CHECK(hipEventRecord(L.ev_fork, stream));
                 ASEP_HIP_CHECK(hipStreamWaitEvent(L.side, L.ev_fork, 0));
                 m->stream = L.side;
@@ -1023,7 +1036,7 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
             ca.thr255 = (double)threshold * 255.0;
             ca.softmax = cfg.apply_softmax;
             dim3 grid(cdiv(W, COMBINE_TW), cdiv(H, 16));
-            ProfScope ps(m, "combine_kernel", 2.0 * H * W * 16.0 * cfg.feat_root * cfg.n_classes);
+            ProfScope ps(m, "combine_kernel" + targs({ti(cfg.feat_root), ti(cfg.n_classes)}), 2.0 * H * W * 16.0 * cfg.feat_root * cfg.n_classes);
 #define ASEP_COMB(FR, NC)                                                                          \
     if (cfg.feat_root == FR && cfg.n_classes == NC) {                                              \
         hipLaunchKernelGGL((combine_kernel<FR, NC>), grid, dim3(256), 0, stream, ca);              \
@@ -1329,6 +1342,7 @@ int asep_aru_profile(asep_aru* m, int enable) {
     if (!m) { set_error("asep_aru_profile: null handle"); return ASEP_ERR_ARG; }
     m->profiling = enable != 0;
     m->prof_detail = enable == 2;
+    m->prof_in_situ = enable == 3;
     if (enable) { m->prof_recs.clear(); m->ev_next = 0; m->prof_names.clear(); }
     return ASEP_OK;
     ASEP_GUARD_END

@@ -273,29 +273,18 @@ int forward_impl(asep_gnn* g, int N, int E, const int32_t* d_edges, const float*
 }
 
 // graph_relation.py:84-139 in front of the graph: backbone, ROI max + compression per feature map, concatenation.
-// d_ug [N, U - visual dims]; everything on stream s; returns the concatenated features [N, U] in *d_u_out.
-int visual_features_dev(asep_gnn* g, int N, const float* d_ug, const float* d_img, int h, int w, const float* d_reg, int P,
-                        const int32_t* d_np, float** d_u_out, hipStream_t s) {
+// ROI max + compression of one page's nodes from the backbone end points "<prefix><name>" of the forward that is queued
+// on s; d_ug [N, U - visual dims] -> d_u [N, U]
+int visual_rois_dev(asep_gnn* g, int N, const float* d_ug, const std::string& prefix, const float* d_reg, int P,
+                    const int32_t* d_np, float* d_u, hipStream_t s) {
     const int U = g->U, ug = U - g->vis_total;
-    g->vis_pool.begin();
-    const int ncls = std::max(1, aru_num_classes(g->backbone));
-    float* d_bo = (float*)g->vis_pool.get((size_t)h * w * ncls * sizeof(float));   // backbone logits (not used by the graph)
-    const size_t nu = (size_t)N * U;
-    if (g->u_cat_cap < nu) {
-        if (g->d_u_cat) (void)hipFree(g->d_u_cat);
-        g->d_u_cat = nullptr; g->u_cat_cap = 0;
-        ASEP_HIP_CHECK(hipMalloc((void**)&g->d_u_cat, nu * sizeof(float)));
-        g->u_cat_cap = nu;
-    }
-    float* d_u = g->d_u_cat;
-    int rc = asep_aru_forward_dev(g->backbone, d_img, h, w, d_bo, nullptr, nullptr, 0.f, s);
-    if (rc) return rc;
     if (ug > 0) hipLaunchKernelGGL(gnn_copy_cols_kernel, dim3(cdiv(N * ug, 256)), dim3(256), 0, s, d_ug, N, ug, d_u, U);
     int col = ug;
     for (size_t i = 0; i < g->vis_names.size(); ++i) {
         const float* fm = nullptr;
         int dims[3];
-        if ((rc = aru_endpoint_dev(g->backbone, g->vis_names[i].c_str(), &fm, dims))) return rc;
+        int rc = aru_endpoint_dev(g->backbone, (prefix + g->vis_names[i]).c_str(), &fm, dims);
+        if (rc) return rc;
         if (dims[2] != g->vis_C[i]) { set_error("end point %s has %d channels, expected %d", g->vis_names[i].c_str(), dims[2], g->vis_C[i]); return ASEP_ERR_ARG; }
         RoiArgs a{};
         a.fm = fm; a.fh = dims[0]; a.fw = dims[1]; a.C = dims[2];
@@ -305,7 +294,32 @@ int visual_features_dev(asep_gnn* g, int N, const float* d_ug, const float* d_im
         col += g->vis_d[i];
     }
     ASEP_HIP_CHECK(hipGetLastError());
-    *d_u_out = d_u;
+    return ASEP_OK;
+}
+
+int reserve_u_cat(asep_gnn* g, size_t nu) {
+    if (g->u_cat_cap < nu) {
+        if (g->d_u_cat) (void)hipFree(g->d_u_cat);
+        g->d_u_cat = nullptr; g->u_cat_cap = 0;
+        ASEP_HIP_CHECK(hipMalloc((void**)&g->d_u_cat, nu * sizeof(float)));
+        g->u_cat_cap = nu;
+    }
+    return ASEP_OK;
+}
+
+// d_ug [N, U - visual dims]; everything on stream s; returns the concatenated features [N, U] in *d_u_out.
+int visual_features_dev(asep_gnn* g, int N, const float* d_ug, const float* d_img, int h, int w, const float* d_reg, int P,
+                        const int32_t* d_np, float** d_u_out, hipStream_t s) {
+    g->vis_pool.begin();
+    const int ncls = std::max(1, aru_num_classes(g->backbone));
+    float* d_bo = (float*)g->vis_pool.get((size_t)h * w * ncls * sizeof(float));   // backbone logits (not used by the graph)
+    int rc = reserve_u_cat(g, (size_t)N * g->U);
+    if (rc) return rc;
+    rc = asep_aru_forward_dev(g->backbone, d_img, h, w, d_bo, nullptr, nullptr, 0.f, s);
+    if (rc) return rc;
+    rc = visual_rois_dev(g, N, d_ug, std::string(), d_reg, P, d_np, g->d_u_cat, s);
+    if (rc) return rc;
+    *d_u_out = g->d_u_cat;
     return ASEP_OK;
 }
 
@@ -528,6 +542,49 @@ int asep_gnn_forward_visual_dev(asep_gnn* g, int N, int E, const int32_t* d_edge
     int rc = visual_features_dev(g, N, d_node_feat, d_image, h, w, d_regions, P, d_num_points, &d_u, (hipStream_t)stream);
     if (rc) return rc;
     return forward_impl(g, N, E, d_edges, d_u, d_edge_feat, R, d_relations, d_probs_out, (hipStream_t)stream);
+    ASEP_GUARD_END
+}
+
+int asep_gnn_forward_visual_batch_dev(asep_gnn* g, int n_pages, const asep_gnn_page* pages, int h, int w, int P, void* stream) {
+    ASEP_GUARD_BEGIN
+    if (!g || !g->backbone) { set_error("asep_gnn_forward_visual_batch_dev: no backbone attached"); return ASEP_ERR_ARG; }
+    if (n_pages < 1 || !pages || h < 1 || w < 1 || P < 1) { set_error("asep_gnn_forward_visual_batch_dev: bad argument"); return ASEP_ERR_ARG; }
+    const int ug = g->U - g->vis_total;
+    size_t nu = 0;
+    for (int b = 0; b < n_pages; ++b) {
+        const asep_gnn_page& q = pages[b];
+        if (q.N < 1 || !q.d_image || !q.d_regions || !q.d_num_points || (ug > 0 && !q.d_node_feat) || (q.E > 0 && !q.d_edges) ||
+            (q.R > 0 && !q.d_probs_out) || (g->Ed > 0 && q.E > 0 && !q.d_edge_feat)) {
+            set_error("asep_gnn_forward_visual_batch_dev: bad argument in page %d", b);
+            return ASEP_ERR_ARG;
+        }
+        nu += (size_t)q.N * g->U;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    g->vis_pool.begin();
+    const int ncls = std::max(1, aru_num_classes(g->backbone));
+    std::vector<const float*> imgs(n_pages);
+    std::vector<float*> outs(n_pages);
+    for (int b = 0; b < n_pages; ++b) {
+        imgs[b] = pages[b].d_image;
+        outs[b] = (float*)g->vis_pool.get((size_t)h * w * ncls * sizeof(float));      // backbone logits (not used by the graph)
+    }
+    int rc = reserve_u_cat(g, nu);
+    if (rc) return rc;
+    // ONE grouped backbone forward for all pages (every layer is one launch over the page list), then per page the ROI
+    // kernels and the graph, queued back to back on the same stream
+    rc = asep_aru_forward_batch_dev(g->backbone, n_pages, imgs.data(), h, w, outs.data(), nullptr, nullptr, 0.f, s);
+    if (rc) return rc;
+    float* d_u = g->d_u_cat;
+    for (int b = 0; b < n_pages; ++b) {
+        const asep_gnn_page& q = pages[b];
+        rc = visual_rois_dev(g, q.N, q.d_node_feat, b ? "p" + std::to_string(b) + "/" : std::string(), q.d_regions, P, q.d_num_points, d_u, s);
+        if (rc) return rc;
+        rc = forward_impl(g, q.N, q.E, q.d_edges, d_u, q.d_edge_feat, q.R, q.d_relations, q.d_probs_out, s);
+        if (rc) return rc;
+        d_u += (size_t)q.N * g->U;
+    }
+    return ASEP_OK;
     ASEP_GUARD_END
 }
 

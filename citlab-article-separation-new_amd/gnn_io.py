@@ -244,6 +244,23 @@ def gnn_forward_visual_dev(graph: GnnGraph, num_nodes, num_edges, d_edges, d_nod
     _lib.check(rc, "asep_gnn_forward_visual_dev")
 
 
+def gnn_forward_visual_batch_dev(graph: GnnGraph, pages, h, w, num_region_points, stream=None, device=0):
+    """``asep_gnn_forward_visual_batch_dev``: ``pages`` is a sequence of dicts with the fields of ``asep_gnn_page`` (device
+    addresses as ints; ``d_relations`` may be None = all N*N ordered pairs) or a ready ``(_lib.GnnPage * n)`` array.  The
+    backbones of all pages run as one grouped forward; nothing is synchronised."""
+    lib = _lib.init_device(device)
+    if not isinstance(pages, C.Array):
+        arr = (_lib.GnnPage * len(pages))()
+        for q, d in zip(arr, pages):
+            for k, v in d.items():
+                setattr(q, k, v)
+        pages = arr
+    rc = lib.asep_gnn_forward_visual_batch_dev(graph.handle(device), len(pages), pages, int(h), int(w), int(num_region_points),
+                                               stream)
+    _lib.check(rc, "asep_gnn_forward_visual_batch_dev")
+    return pages
+
+
 STEP_MODES = {0: "generic", 1: "mfma_registers", 2: "mfma_lds"}
 
 

@@ -21,13 +21,43 @@ from multiprocessing import shared_memory
 
 import numpy as np
 
-SLOT_BYTES = 64 << 20            # one decoded page: 3000 x 4500 x 3 uint8 = 40.5 MB
+SLOT_BYTES = 64 << 20            # default slot: one decoded page, 3000 x 4500 x 3 uint8 = 40.5 MB
+SLOT_BYTES_MAX = 1 << 30         # larger scans are decoded inline by the owner instead of page-locking GBs per slot
+_TOO_BIG = "__too_big__"
+
+
+def needed_slot_bytes(paths, default=SLOT_BYTES, limit=SLOT_BYTES_MAX, probe=64):
+    """Slot size from the image HEADERS (width x height x 3 channels, the widest thing a loader returns): the largest of
+    the first ``probe`` files and of ``probe`` more spread over the list, rounded up to 1 MiB, never above ``limit``.  A
+    scan beyond the slot is not an error: the worker reports it and the owner decodes that file inline."""
+    from . import image_io
+    paths = list(paths)
+    pick = paths[:probe] + paths[probe::max(1, (len(paths) - probe) // probe)][:probe] if len(paths) > probe else paths
+    need = 0
+    for p in pick:
+        try:
+            w, h = image_io.get_image_dimensions(p)
+            need = max(need, int(w) * int(h) * 3)
+        except Exception:                                   # unreadable header: the decode itself reports the file
+            pass
+    if need == 0:
+        need = default
+    return min(limit, (need + (1 << 20) - 1) >> 20 << 20)
+
+
+def _resolve_loader(name):
+    """``name`` of a function in image_io, or ``"package.module:function"``"""
+    if ":" in name:
+        import importlib
+        mod, fn = name.split(":", 1)
+        return getattr(importlib.import_module(mod), fn)
+    from . import image_io
+    return getattr(image_io, name)
 
 
 def _decode_worker(tasks, ready, loader_name):
     """worker process: (seq, path, slot name) -> decode -> pixels into the slot -> (seq, shape, dtype, error)"""
-    from . import image_io
-    loader = getattr(image_io, loader_name)
+    loader = _resolve_loader(loader_name)
     slots = {}
     while True:
         item = tasks.get()
@@ -41,7 +71,7 @@ def _decode_worker(tasks, ready, loader_name):
             if shm is None:
                 shm = slots[slot] = shared_memory.SharedMemory(name=slot)
             if img.nbytes > shm.size:
-                ready.put((seq, None, None, f"{path}: decoded image of {img.nbytes} bytes exceeds the {shm.size}-byte slot"))
+                ready.put((seq, None, None, _TOO_BIG))
                 continue
             np.ndarray(img.shape, img.dtype, buffer=shm.buf)[...] = img
             ready.put((seq, img.shape, img.dtype.str, None))
@@ -55,30 +85,53 @@ class DecodePool:
     """Iterate ``(path, image)`` over ``paths`` in order while ``n_workers`` processes decode ahead.
 
     ``image`` is a numpy view into a shared-memory slot: valid until the next item is requested.  ``register`` /
-    ``unregister`` (optional callables ``(address, nbytes)``) page-lock the slots for DMA uploads."""
+    ``unregister`` (optional callables ``(address, nbytes)``) page-lock the slots for DMA uploads.  ``slot_bytes`` None:
+    sized from the image headers (``needed_slot_bytes``).  An image that does not fit its slot is decoded inline by the
+    owner; if the shared-memory slots cannot be created (a small /dev/shm) the whole list is decoded inline; if a worker
+    process dies (OOM kill, SIGBUS, decoder crash) the iteration raises instead of waiting for its page forever."""
 
-    def __init__(self, paths, n_workers=0, loader="load_image_bgr", n_slots=None, slot_bytes=SLOT_BYTES,
-                 register=None, unregister=None):
+    def __init__(self, paths, n_workers=0, loader="load_image_bgr", n_slots=None, slot_bytes=None,
+                 register=None, unregister=None, strict_slots=False):
         self.paths = list(paths)
         self.n_workers = max(0, int(n_workers)) if len(self.paths) > 1 else 0
         self.loader = loader
         self.n_slots = n_slots or max(2, self.n_workers + 2)
         self.slot_bytes = slot_bytes
+        self.strict_slots = strict_slots                    # True: an image beyond the slot is an IOError (tests)
+        self.inline_decodes = 0                             # pages the owner had to decode itself
         self._register, self._unregister = register, unregister
+
+    def _inline(self, start=0):
+        load = _resolve_loader(self.loader)
+        for p in self.paths[start:]:
+            yield p, load(p)
 
     def __iter__(self):
         if self.n_workers <= 1:
-            from . import image_io
-            load = getattr(image_io, self.loader)
-            for p in self.paths:
-                yield p, load(p)
+            yield from self._inline()
+            return
+        load = _resolve_loader(self.loader)
+        slot_bytes = self.slot_bytes or needed_slot_bytes(self.paths)
+        slots = []
+        try:
+            for _ in range(self.n_slots):
+                s = shared_memory.SharedMemory(create=True, size=slot_bytes)
+                slots.append(s)
+                np.ndarray((s.size,), np.uint8, buffer=s.buf)[::4096] = 0     # touch every page now: a /dev/shm that is too
+                                                                               # small fails here, not as SIGBUS in a worker
+        except (OSError, MemoryError, ValueError):
+            for s in slots:
+                s.close()
+                s.unlink()
+            self.inline_decodes = len(self.paths)
+            yield from self._inline()
             return
         ctx = mp.get_context("spawn")                       # the owner may have initialised HIP: never fork it
-        tasks, ready = ctx.Queue(), ctx.Queue()
-        slots = [shared_memory.SharedMemory(create=True, size=self.slot_bytes) for _ in range(self.n_slots)]
+        # one task queue per worker: the owner knows which worker holds which page, so a dead worker's pages can be named
+        tasks, ready = [ctx.Queue() for _ in range(self.n_workers)], ctx.Queue()
         registered = []
-        procs = [ctx.Process(target=_decode_worker, args=(tasks, ready, self.loader), daemon=True)
-                 for _ in range(self.n_workers)]
+        procs = [ctx.Process(target=_decode_worker, args=(tasks[i], ready, self.loader), daemon=True)
+                 for i in range(self.n_workers)]
         try:
             if self._register:
                 for s in slots:
@@ -89,35 +142,49 @@ class DecodePool:
                 p.start()
             free = list(range(self.n_slots))
             slot_of, done, next_task, next_out = {}, {}, 0, 0
+            outstanding = [set() for _ in procs]            # pages handed to each worker and not yet reported
+            worker_of = {}
             held = None
             n = len(self.paths)
             while next_out < n:
                 while free and next_task < n:               # keep every free slot busy
                     k = free.pop()
                     slot_of[next_task] = k
-                    tasks.put((next_task, self.paths[next_task], slots[k].name))
+                    wi = min(range(len(procs)), key=lambda i: len(outstanding[i]))
+                    outstanding[wi].add(next_task)
+                    worker_of[next_task] = wi
+                    tasks[wi].put((next_task, self.paths[next_task], slots[k].name))
                     next_task += 1
                 while next_out not in done:
                     try:
                         seq, shape, dtype, err = ready.get(timeout=1.0)
                     except queue.Empty:
-                        if not any(p.is_alive() for p in procs):
-                            raise RuntimeError("image decode workers died")
+                        dead = [i for i, p in enumerate(procs) if not p.is_alive() and outstanding[i]]
+                        if dead:                            # a worker died holding pages: they would never arrive
+                            lost = sorted(self.paths[q] for i in dead for q in outstanding[i])
+                            raise RuntimeError(f"{len(dead)} of {len(procs)} image decode workers died (exit codes "
+                                               f"{[procs[i].exitcode for i in dead]}) while holding {lost}")
                         continue
+                    outstanding[worker_of.pop(seq)].discard(seq)
                     done[seq] = (shape, dtype, err)
                 shape, dtype, err = done.pop(next_out)
-                if err:
-                    raise IOError("image decode failed: " + err)
                 if held is not None:                        # the previous page's slot is free again
                     free.append(held)
                 held = slot_of.pop(next_out)
-                img = np.ndarray(shape, np.dtype(dtype), buffer=slots[held].buf)
+                if err == _TOO_BIG and not self.strict_slots:
+                    self.inline_decodes += 1
+                    img = load(self.paths[next_out])        # the owner decodes what no slot can hold
+                elif err:
+                    raise IOError("image decode failed: " + (f"{self.paths[next_out]}: decoded image exceeds the "
+                                                             f"{slot_bytes}-byte slot" if err == _TOO_BIG else err))
+                else:
+                    img = np.ndarray(shape, np.dtype(dtype), buffer=slots[held].buf)
                 yield self.paths[next_out], img
                 del img
                 next_out += 1
         finally:
-            for _ in procs:
-                tasks.put(None)
+            for q in tasks:
+                q.put(None)
             for p in procs:
                 p.join(timeout=5)
                 if p.is_alive():

@@ -101,8 +101,11 @@ int asep_aru_forward_batch_dev(asep_aru* m, int n_pages, const float* const* d_i
 long asep_aru_get_endpoint(asep_aru* m, const char* name, float* out, size_t max_floats, int32_t dims[3]);
 
 /* Per-launch timing with HIP events recorded on the launch stream (measurement aid for bench.py).
- * asep_aru_profile(m,1) clears the records and starts recording; (m,0) stops.  The report is a JSON
- * array [{"kernel","calls","total_ms","flops"}] aggregated per kernel; returns its length. */
+ * asep_aru_profile(m,1) clears the records and starts recording; (m,0) stops.  Mode 1 serialises the net on the
+ * launch stream (isolated kernel times), mode 2 additionally names every layer, mode 3 keeps the attention side
+ * stream running ("in situ": what rocprofv3 sees in the real schedule).  The report is a JSON array
+ * [{"kernel","calls","total_ms","flops"}] aggregated per kernel, "kernel" being the rocprofv3 name without
+ * "void ", "asep::", blanks and the argument list; returns its length. */
 int asep_aru_profile(asep_aru* m, int enable);
 long asep_aru_profile_report(asep_aru* m, char* buf, size_t buflen);
 
@@ -170,6 +173,25 @@ int asep_gnn_forward_visual_dev(asep_gnn* g, int N, int E, const int32_t* d_edge
                                 const float* d_edge_feat, const float* d_image, int h, int w, const float* d_regions,
                                 int P, const int32_t* d_num_points, int R, const int32_t* d_relations,
                                 float* d_probs_out, void* stream);
+
+/* A batch of pages through the visual net (bench.py's step; a GPU owner that holds several decoded pages): the backbones
+ * of all pages run as ONE grouped forward (asep_aru_forward_batch_dev: every layer is one launch over the page list, so the
+ * small 683 x 1024 images fill the chip together), then ROI kernels + graph per page, all queued on `stream`, no host
+ * synchronisation.  Every image is [h,w] float32 and every region array [N,2,P]; the other sizes are per page.
+ * asep_gnn_get_node_features afterwards returns page 0's features. */
+typedef struct asep_gnn_page {
+    int32_t N, E, R;
+    const int32_t* d_edges;        /* [E,2] */
+    const float* d_node_feat;      /* [N, node_feature_dim - visual dims] */
+    const float* d_edge_feat;      /* [E, edge_feature_dim] */
+    const float* d_image;          /* [h,w] */
+    const float* d_regions;        /* [N,2,P] */
+    const int32_t* d_num_points;   /* [N] */
+    const int32_t* d_relations;    /* [R,2] or NULL = all N*N ordered pairs (then R must be N*N) */
+    float* d_probs_out;            /* [R, num_classes] */
+} asep_gnn_page;
+int asep_gnn_forward_visual_batch_dev(asep_gnn* g, int n_pages, const asep_gnn_page* pages, int h, int w, int P,
+                                      void* stream);
 
 /* Which message-passing kernel the handle uses: 0 = generic FMA kernels (any widths), 1 = fused MFMA step with the
  * edge-MLP filter in registers (widths 32, node_feature_dim <= 8), 2 = fused MFMA step with the filter in LDS (widths 32,

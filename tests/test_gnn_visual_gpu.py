@@ -172,3 +172,41 @@ def test_reattach_and_feature_readback_are_stable():
     p2 = gnn_io.gnn_forward_visual(graph, N, g["interacting_nodes"], g["node_features"], g["edge_features"], img, regions, npts)
     assert np.array_equal(p1, p2)
     graph.close()
+
+
+def test_batched_visual_forward_equals_the_single_page_calls():
+    """asep_gnn_forward_visual_batch_dev (bench.py's step): the backbones of all pages as one grouped forward, then ROI
+    kernels + graph per page.  Pages with different graphs / images / node counts must come out exactly as from
+    asep_gnn_forward_visual (bit-identical: same kernels on the same values), and page 0 also matches the oracle."""
+    import torch
+    from citlab_article_separation_new_amd import gnn_io, synth
+    from oracle import gnn_oracle
+    cfg, w, graph = _setup(mvn=True)
+    rng = np.random.default_rng(29)
+    h, wd = 160, 112
+    pages, keep, singles = [], [], []
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for b, N in enumerate((24, 17, 31)):
+        g = synth.synth_graph(40 + b, N=N, n_pairs=3 * N, node_dim=7)
+        img, regions, npts = _page(rng, N, h, wd)
+        img = np.ascontiguousarray(np.roll(img, 9 * b, axis=1))       # a different image per page
+        singles.append(gnn_io.gnn_forward_visual(graph, N, g["interacting_nodes"], g["node_features"], g["edge_features"], img,
+                                                 regions, npts))
+        if b == 0:
+            ref, _ = gnn_oracle.forward_visual(N, g["interacting_nodes"], g["node_features"], g["edge_features"], img, regions,
+                                               npts, None, w, cfg)
+            assert float(np.abs(singles[0] - ref).max()) <= 1e-5
+        t = [dev(g["interacting_nodes"]), dev(g["node_features"]), dev(g["edge_features"]), dev(img), dev(regions), dev(npts),
+             torch.zeros(N * N, 2, device="cuda")]
+        keep.append(t)
+        pages.append(dict(N=N, E=int(t[0].shape[0]), R=N * N, d_edges=t[0].data_ptr(), d_node_feat=t[1].data_ptr(),
+                          d_edge_feat=t[2].data_ptr(), d_image=t[3].data_ptr(), d_regions=t[4].data_ptr(),
+                          d_num_points=t[5].data_ptr(), d_relations=None, d_probs_out=t[6].data_ptr()))
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    for _ in range(2):                                                # the second call reuses every buffer
+        gnn_io.gnn_forward_visual_batch_dev(graph, pages, h, wd, 4, stream.cuda_stream)
+    stream.synchronize()
+    for t, single in zip(keep, singles):
+        assert np.array_equal(t[6].cpu().numpy(), single)
+    graph.close()

@@ -48,7 +48,43 @@ def test_decode_pool_reports_failures(tmp_path):
     big = tmp_path / "big.png"
     Image.fromarray(np.zeros((100, 100), np.uint8)).save(big)
     with pytest.raises(IOError, match="exceeds"):
-        list(host_pipeline.DecodePool([str(ok), str(big)], n_workers=2, slot_bytes=1 << 12))
+        list(host_pipeline.DecodePool([str(ok), str(big)], n_workers=2, slot_bytes=1 << 12, strict_slots=True))
+    # default: an image beyond the slot is decoded inline by the owner (the reference processes such scans)
+    pool = host_pipeline.DecodePool([str(ok), str(big), str(ok)], n_workers=2, slot_bytes=1 << 12)
+    got = [img.copy() for _, img in pool]
+    assert [g.shape for g in got] == [(4, 4), (100, 100), (4, 4)] and pool.inline_decodes == 1
+
+
+def test_slots_are_sized_from_the_image_headers(tmp_path):
+    small, large = tmp_path / "s.png", tmp_path / "l.png"
+    Image.fromarray(np.zeros((10, 10), np.uint8)).save(small)
+    Image.fromarray(np.zeros((700, 900, 3), np.uint8)).save(large)
+    assert host_pipeline.needed_slot_bytes([str(small)] * 3) == 1 << 20
+    assert host_pipeline.needed_slot_bytes([str(small), str(large)]) == 2 << 20          # 1.89 MB -> 2 MiB
+    assert host_pipeline.needed_slot_bytes([str(large)], limit=1 << 20) == 1 << 20        # capped: that scan goes inline
+    pool = host_pipeline.DecodePool([str(small), str(large), str(small)], n_workers=2)    # slot_bytes None
+    assert [img.shape for _, img in pool] == [(10, 10), (700, 900, 3), (10, 10)] and pool.inline_decodes == 0
+
+
+def _die_on_second(path):
+    """loader that kills its own process on files named kill*: stands for an OOM kill / SIGBUS / decoder crash"""
+    if os.path.basename(path).startswith("kill"):
+        os.kill(os.getpid(), 9)
+    return image_io.load_image_bgr(path)
+
+
+def test_a_dead_decode_worker_raises_instead_of_hanging(tmp_path):
+    """with one of two workers SIGKILLed while holding a page the owner used to spin forever."""
+    import time
+    paths = []
+    for k in range(6):
+        p = tmp_path / (f"kill{k}.png" if k == 2 else f"ok{k}.png")
+        Image.fromarray(np.full((8, 8), k, np.uint8)).save(p)
+        paths.append(str(p))
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="decode workers died.*kill2.png"):
+        list(host_pipeline.DecodePool(paths, n_workers=2, loader=__name__ + ":_die_on_second", slot_bytes=1 << 12))
+    assert time.time() - t0 < 60
 
 
 def test_write_pool_runs_tasks_and_surfaces_errors(tmp_path):
