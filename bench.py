@@ -6,13 +6,16 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
   (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
 
 A "step" = one pass of the hot path over one batch of `--pages-per-step` device-resident pages on every rank:
-per page one ARU-Net forward (fp32, fused uint8/threshold epilogue) + one GNN forward on that page's text-block
-graph (N=200 nodes, 20 000 directed edges after correction, all 40 000 ordered pairs).  Pages are independent, so
-ranks shard the page list (weak scaling) and the only collective is the weight broadcast at start-up.
+per page one ARU-Net forward (fp32, fused uint8/threshold epilogue) + one forward of the VISUAL relation net
+BASELINE configs[3] names (mixed_gnn_vn7e2: RU backbone on the page image at 683 x 1024, ROI max + compression to
+3 x 16 visual node features, graph with 7 + 48 = 55 node features, N=200 nodes, 20 000 directed edges after
+correction, all 40 000 ordered pairs).  Pages are independent, so ranks shard the page list (weak scaling) and the only
+collective is the weight broadcast at start-up.
 
 Prints ONE JSON line on rank 0: BASELINE.json's metric + `roofline` (dominant kernel, timed live with HIP events on
-the launch stream) + `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample; rank 0,
-N == 1 only).
+the launch streams: in situ = in the real schedule beside the other streams, and isolated) + `cpu_baseline` (the CPU
+oracle timed on this box's host cores on a bounded sample; rank 0, N == 1 only).  scripts/roofline_from_profiles.py
+recomputes the roofline block from the rocprofv3 summaries under profiles/<tag>/.
 """
 import argparse
 import ctypes as C
@@ -36,7 +39,8 @@ PEAK_HBM_GBS = 8000.0
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=80,
+                    help="timed steps (80 x 16 pages = 1280 pages: a timed region of >= 10 s)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pages-per-step", type=int, default=16,
                     help="pages per rank and step (16 x 20 steps = 320 pages: a timed region of ~3 s, long enough for "
@@ -44,11 +48,19 @@ def parse_args():
     ap.add_argument("--height", type=int, default=4500)
     ap.add_argument("--width", type=int, default=3000)
     ap.add_argument("--no-gnn", action="store_true", help="ARU-Net only (diagnostic; not the headline metric)")
+    ap.add_argument("--gnn", choices=["visual", "geometric"], default="visual",
+                    help="visual = the net configs[3] names (mixed_gnn_vn7e2: backbone on 683 x 1024 + 55 node features; the "
+                         "headline); geometric = the 7-feature net without image input (round-2 workload, diagnostic)")
+    ap.add_argument("--kernel-timing", choices=["both", "in-situ", "isolated", "none"], default="both",
+                    help="HIP-event per-kernel passes after the timed region (in-situ only under rocprofv3, so that every launch of "
+                         "the traced process runs in the same schedule)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = BASELINE configs[1] (the headline); bf16 = configs[4] 'bf16 convs': bf16 MFMA operands, "
                          "fp32 accumulation / storage, probability maps within 2e-2 (reported with dtype bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event per-kernel timing")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="same as --kernel-timing none")
+    ap.add_argument("--e2e-pages", type=int, default=96,
+                    help="scans of the files-in / files-out secondary figure (separator CLI path with host workers; 0 = skip)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements (bf16 variant, heading net + stroke-width fusion, visual GNN)")
     ap.add_argument("--cpu-sample-height", type=int, default=0,
@@ -59,7 +71,8 @@ def parse_args():
 
 def run_cpu_baseline(args):
     """Mirrors the reference's process fan-out (run_net_post_processing.py:61-82): P worker processes, each timing
-    the torch-CPU ARU-Net oracle on a band of `rows` page rows (+ the numpy GNN oracle on one graph).
+    the torch-CPU ARU-Net oracle on a band of `rows` rows of the same synthetic scan the GPU path gets (+ the relation-net
+    oracle on one graph: visual net incl. its backbone on 683 x 1024, or the geometric net).
     pages/s = P * (rows/H page) / slowest worker."""
     import subprocess
     cores = os.cpu_count() or 1
@@ -67,12 +80,14 @@ def run_cpu_baseline(args):
     workers = max(1, min(8, (cores // 2 or 1) // threads)) if cores > threads else 1
     rows = args.cpu_sample_height or (args.height if cores >= 64 else max(256, args.height // 3))
     cmd = [sys.executable, "-m", "oracle.cpu_worker", "--threads", str(threads), "--rows", str(rows),
-           "--width", str(args.width), "--height", str(args.height)] + ([] if args.no_gnn else ["--gnn"])
+           "--width", str(args.width), "--height", str(args.height)]
+    if not args.no_gnn:
+        cmd += ["--gnn"] + (["--visual"] if args.gnn == "visual" else [])
     t0 = time.perf_counter()
     procs = [subprocess.Popen(cmd + ["--page", str(i)], cwd=ROOT, stdout=subprocess.PIPE, text=True) for i in range(workers)]
     res = []
     for p in procs:
-        out, _ = p.communicate(timeout=600)
+        out, _ = p.communicate(timeout=900)
         if p.returncode == 0 and out.strip():
             res.append(json.loads(out.strip().splitlines()[-1]))
     wall = time.perf_counter() - t0
@@ -80,13 +95,17 @@ def run_cpu_baseline(args):
         return None
     frac = rows / args.height
     t_page = max(r["t_aru"] / frac + r["t_gnn"] for r in res)      # slowest worker (scaled to a whole page if a band)
+    used = threads * len(res)
     return {
-        "value": round(len(res) / t_page, 5), "unit": "pages/s", "cores": threads * len(res), "kind": "port",
-        "sample": (f"{len(res)} worker processes x {threads} threads, each: torch-CPU fp32 ARU-Net oracle on "
-                   + (f"one whole {args.width}x{args.height}px page" if rows >= args.height else
-                      f"a {args.width}x{rows}px band (scaled x{1 / frac:.2f} to a page)")
-                   + " + numpy GNN oracle on one graph; "
-                   f"slowest worker {t_page:.2f}s/page; {wall:.1f}s wall incl. start-up; box has {cores} logical CPUs"),
+        "value": round(len(res) / t_page, 5), "unit": "pages/s", "cores": used, "cores_of": cores, "kind": "port",
+        "sample": (f"{used} of the box's {cores} logical CPUs: {len(res)} worker processes x {threads} threads, each: torch-CPU "
+                   "fp32 ARU-Net oracle on "
+                   + (f"one whole synthetic {args.width}x{args.height}px scan" if rows >= args.height else
+                      f"a {args.width}x{rows}px band of a synthetic scan (scaled x{1 / frac:.2f} to a page)")
+                   + ("" if args.no_gnn else (" + the visual relation-net oracle (torch-CPU backbone on 683x1024 + numpy graph)"
+                                             if args.gnn == "visual" else " + numpy GNN oracle on one graph"))
+                   + f"; no decode / post-processing; slowest worker {t_page:.2f}s/page (relation net "
+                   f"{max(r['t_gnn'] for r in res):.2f}s); {wall:.1f}s wall incl. start-up and page generation"),
     }
 
 
@@ -101,13 +120,57 @@ def _timed(fn, iters, warmup=1):
     return (time.perf_counter() - t0) / iters
 
 
-def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs):
+VISUAL_LAYERS = ["scale_0_unet_up_2_conv", "scale_0_unet_up_1_conv", "scale_0_unet_up_0_conv"]
+
+
+def e2e_files(args, dev):
+    """Files in, files out through the separator CLI path (SeparatorNetPostProcessor = run_net_post_processing.py --mode
+    separator --fixed_height 4500): PNG scans on disk -> decode in host workers -> GPU stages -> PAGE-XML files.  Four real
+    files, the rest links to them (each with its own PAGE-XML output)."""
+    import tempfile
+    from PIL import Image
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper, synth
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.host_pipeline import host_workers_default
+    from citlab_article_separation_new_amd.separator_net_post_processor import SeparatorNetPostProcessor
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    H, W, n = args.height, args.width, args.e2e_pages
+    cfg = AruConfig()
+    graph = helper.AruGraph(init_aru_weights(cfg, 21, logit_scale=0.05), cfg)
+    workers = host_workers_default()
+    with tempfile.TemporaryDirectory(prefix="asep_e2e_") as tmp:
+        os.makedirs(os.path.join(tmp, "page"))
+        paths = []
+        for k in range(n):
+            q = os.path.join(tmp, f"p{k:03d}.png")
+            if k < 4:
+                Image.fromarray(synth.cached_synth_page(k, W, H)).save(q, compress_level=1)
+            else:
+                os.symlink(os.path.join(tmp, f"p{k % 4:03d}.png"), q)
+            paths.append(q)
+        SeparatorNetPostProcessor(paths[:2], graph, H, 1.0, 0.5, str(dev.index or 0), host_workers=0).run()    # warm-up
+        proc = SeparatorNetPostProcessor(paths, graph, H, 1.0, 0.5, str(dev.index or 0), host_workers=workers)
+        t0 = time.perf_counter()
+        proc.run()
+        dt = time.perf_counter() - t0
+        n_xml = len([f for f in os.listdir(os.path.join(tmp, "page")) if f.endswith(".xml.xml")])
+    graph.close()
+    return {"pages_per_s": round(n / dt, 2), "ms_per_page": round(1e3 * dt / n, 2), "scans": n, "host_workers": workers,
+            "page_xml_written": n_xml, "gpu_owner_device_stage_share": round(proc.device_seconds / dt, 3),
+            "gpu_owner_waiting_for_decode_share": round(proc.wait_seconds / dt, 3),
+            "note": f"separator CLI path, --fixed_height {H} (net on the full {W}x{H} page): PNG files -> {workers} decode / XML "
+                    f"worker processes around ONE GPU owner -> PAGE-XML files; worker start-up inside the timed region; "
+                    f"box has {os.cpu_count()} logical CPUs"}
+
+
+def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages):
     """Not the headline: the other BASELINE.json configs on the same box, each a short timed loop after the main
     measurement (device-resident inputs, same conventions).
       configs[4] precision: bf16 MFMA operands (fp32 accumulation / storage) at 3000 x 4500
       configs[2]: heading net + stroke-width distance transform + per-line statistics of ~700 text lines
-      configs[3]: the VISUAL relation net (mixed_gnn_vn7e2 shape: 7 + 3 x 16 node features, backbone on 683 x 1024)"""
-    from citlab_article_separation_new_amd import _lib, gnn_io, image_ops, synth
+      configs[3] alone: the visual relation net, one page per call and 16 pages per grouped call; the geometric 7-feature net
+      files in / files out: the separator CLI path on PNG scans with host workers"""
+    from citlab_article_separation_new_amd import _lib, gnn_io, image_ops
     from citlab_article_separation_new_amd.config import AruConfig, GnnConfig
     from citlab_article_separation_new_amd.net_post_processing_helper import AruGraph
     from citlab_article_separation_new_amd.weights import init_aru_weights, init_gnn_weights
@@ -120,14 +183,16 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs):
     u8 = [torch.empty(H, W, 2, device=dev, dtype=torch.uint8) for _ in range(B2)]
     p_img, p_out, p_u8 = Arr(*[t.data_ptr() for t in imgs[:B2]]), Arr(*[t.data_ptr() for t in prob]), Arr(*[t.data_ptr() for t in u8])
     try:
-        # ---- bf16 variant ----
-        cfg16 = AruConfig(compute_dtype="bf16")
+        # ---- the other precision ----
+        other = "bf16" if args.dtype == "f32" else "f32"
+        cfg16 = AruConfig(compute_dtype=other)
         g16 = AruGraph(init_aru_weights(cfg16, 1234), cfg16)
         h16 = g16.handle(dev.index or 0)
-        dt = _timed(lambda: _lib.check(lib.asep_aru_forward_batch_dev(h16, B2, p_img, H, W, p_out, p_u8, None, 0.05, s), "bf16"), 8, warmup=2)
-        out["aru_bf16_mfma"] = {"pages_per_s": round(B2 / dt, 2), "ms_per_page": round(1e3 * dt / B2, 3), "dtype": "bf16",
-                                "note": "BASELINE configs[4] precision; probability maps within 2e-2 of the fp32 oracle "
-                                        "(tests/test_full_frame_gpu.py)"}
+        dt = _timed(lambda: _lib.check(lib.asep_aru_forward_batch_dev(h16, B2, p_img, H, W, p_out, p_u8, None, 0.05, s), other), 8, warmup=2)
+        out["aru_bf16_mfma" if other == "bf16" else "aru_f32"] = {
+            "pages_per_s": round(B2 / dt, 2), "ms_per_page": round(1e3 * dt / B2, 3), "dtype": other,
+            "note": ("BASELINE configs[4] precision; probability maps within 2e-2 of the fp32 oracle (tests/test_full_frame_gpu.py); "
+                     if other == "bf16" else "") + "ARU-Net alone, no relation net beside it"}
         g16.close()
         # ---- heading pipeline on one page: net + SWT + per-line features ----
         cfg = AruConfig()
@@ -154,30 +219,37 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs):
                                               "note": f"BASELINE configs[2]: heading ARU-Net at {W}x{H} + stroke-width distance "
                                                       f"transform + per-line statistics of {n_lines} text lines (host gets the statistics)"}
         gh.close()
-        # ---- visual GNN ----
-        vcfg = GnnConfig(visual_dims=[16, 16, 16], mvn=True,
-                         visual_layers=["scale_0_unet_up_2_conv", "scale_0_unet_up_1_conv", "scale_0_unet_up_0_conv"])
-        vg = gnn_io.GnnGraph(init_gnn_weights(vcfg, 1234), vcfg)
+        # ---- the relation nets alone ----
         g = graphs[0]
         N, E = g["num_nodes"], int(g["interacting_nodes"].shape[0])
-        vh, vw, P = 1024, 683, 4
-        img_small = torch.nn.functional.interpolate(imgs[0][None, None] * 255.0, size=(vh, vw), mode="bilinear")[0, 0].contiguous()
-        reg = np.zeros((N, 2, P), np.float32)
-        for n in range(N):
-            bx, by = rng.random() * 0.8, rng.random() * 0.8
-            reg[n, 0] = [bx, bx + 0.15, bx + 0.15, bx]
-            reg[n, 1] = [by, by, by + 0.05, by + 0.05]
+        if visual_pages is not None:
+            vg, vpages, vh, vw, P = visual_pages
+            q = vpages[0]
+            dt = _timed(lambda: gnn_io.gnn_forward_visual_dev(vg, q.N, q.E, q.d_edges, q.d_node_feat, q.d_edge_feat, q.d_image, vh, vw,
+                                                              q.d_regions, P, q.d_num_points, q.R, None, q.d_probs_out, s,
+                                                              dev.index or 0), 20, warmup=2)
+            dtb = _timed(lambda: gnn_io.gnn_forward_visual_batch_dev(vg, vpages, vh, vw, P, s, dev.index or 0), 5, warmup=1)
+            out["visual_gnn_vn7e2_shape"] = {
+                "pages_per_s": round(1.0 / dt, 1), "us_per_page": round(1e6 * dt, 1), "dtype": "f32",
+                "us_per_page_grouped": round(1e6 * dtb / len(vpages), 1), "pages_per_grouped_call": len(vpages),
+                "step_kernel": gnn_io.step_mode(vg, dev.index or 0),
+                "note": "BASELINE configs[3] as named (mixed_gnn_vn7e2 = visual net), alone on the chip: RU backbone on 683x1024 + "
+                        "ROI max / compression + graph with 55 node features, 200 nodes / 20k edges / 40k pairs; one page per call "
+                        "and (grouped) the step's pages in one asep_gnn_forward_visual_batch_dev call"}
+        gcfg = GnnConfig()
+        gg = gnn_io.GnnGraph(init_gnn_weights(gcfg, 1234), gcfg)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        d_e, d_u, d_f, d_reg, d_np = t(g["interacting_nodes"]), t(g["node_features"]), t(g["edge_features"]), t(reg), t(np.full(N, P, np.int32))
+        d_e, d_u, d_f = t(g["interacting_nodes"]), t(g["node_features"]), t(g["edge_features"])
         d_conf = torch.empty(N * N, 2, device=dev)
-        dt = _timed(lambda: gnn_io.gnn_forward_visual_dev(vg, N, E, d_e.data_ptr(), d_u.data_ptr(), d_f.data_ptr(), img_small.data_ptr(),
-                                                          vh, vw, d_reg.data_ptr(), P, d_np.data_ptr(), N * N, None, d_conf.data_ptr(), s,
-                                                          dev.index or 0), 20, warmup=2)
-        out["visual_gnn_vn7e2_shape"] = {"pages_per_s": round(1.0 / dt, 1), "us_per_page": round(1e6 * dt, 1), "dtype": "f32",
-                                         "step_kernel": gnn_io.step_mode(vg, dev.index or 0),
-                                         "note": "BASELINE configs[3] as named (mixed_gnn_vn7e2 = visual net): RU backbone on 683x1024 + "
-                                                 "ROI max / compression + graph with 55 node features, 200 nodes / 20k edges / 40k pairs"}
-        vg.close()
+        hg = gg.handle(dev.index or 0)
+        dt = _timed(lambda: _lib.check(lib.asep_gnn_forward_dev(hg, N, E, d_e.data_ptr(), d_u.data_ptr(), d_f.data_ptr(), N * N, None,
+                                                                d_conf.data_ptr(), s), "gnn"), 50, warmup=3)
+        out["geometric_gnn_7_features"] = {"us_per_page": round(1e6 * dt, 1), "dtype": "f32",
+                                           "note": "the relation net without image input (round-2 headline workload), alone on the chip"}
+        gg.close()
+        # ---- files in, files out ----
+        if args.e2e_pages > 0:
+            out["e2e_files"] = e2e_files(args, dev)
     except Exception as e:  # a secondary figure must never take the headline line down
         out["error"] = repr(e)
     return out
@@ -185,6 +257,8 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs):
 
 def main():
     args = parse_args()
+    if args.no_kernel_timing:
+        args.kernel_timing = "none"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -202,8 +276,10 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # ASEP_BENCH_DEVICE pins every rank to one device (two-rank test of the N > 1 code path on a one-GPU box)
+    dev_index = int(os.environ["ASEP_BENCH_DEVICE"]) if "ASEP_BENCH_DEVICE" in os.environ else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     stdout_fd = None
     if distributed:
         import torch.distributed as dist
@@ -213,16 +289,24 @@ def main():
         sys.stdout.flush()
         stdout_fd = os.dup(1)
         os.dup2(2, 1)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # two ranks on one device (ASEP_BENCH_DEVICE) cannot form an RCCL communicator: that test uses gloo for the
+        # broadcast / barrier / max-reduction, everything else is the same code
+        backend = os.environ.get("ASEP_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from citlab_article_separation_new_amd import _lib, sharding, synth
+    from citlab_article_separation_new_amd import _lib, gnn_io, sharding, synth
     from citlab_article_separation_new_amd.config import AruConfig, GnnConfig
     from citlab_article_separation_new_amd.weights import init_aru_weights, init_gnn_weights, pack_blob, unpack_blob
     from citlab_article_separation_new_amd.net_post_processing_helper import AruGraph
     from citlab_article_separation_new_amd.gnn_io import GnnGraph
 
     H, W, B = args.height, args.width, args.pages_per_step
-    aru_cfg, gnn_cfg = AruConfig(compute_dtype=args.dtype), GnnConfig()
+    visual = args.gnn == "visual" and not args.no_gnn
+    aru_cfg = AruConfig(compute_dtype=args.dtype)
+    gnn_cfg = GnnConfig(visual_dims=[16, 16, 16], mvn=True, visual_layers=VISUAL_LAYERS) if visual else GnnConfig()
 
     # ---- weights: rank 0 creates them, every other rank receives the blob over RCCL (the only collective) ----
     if rank == 0:
@@ -230,21 +314,22 @@ def main():
     else:
         blobs = [None, None]
     if distributed:
-        blobs = [sharding.broadcast_blob(b or b"", rank, dev) for b in blobs]
+        bdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        blobs = [sharding.broadcast_blob(b or b"", rank, bdev) for b in blobs]
         dist.barrier()
         torch.cuda.synchronize()
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         os.close(stdout_fd)
     aru = AruGraph(unpack_blob(blobs[0]), aru_cfg)
-    gnn = GnnGraph(unpack_blob(blobs[1]), gnn_cfg)
-    lib = _lib.init_device(local_rank)
-    h_aru, h_gnn = aru.handle(local_rank), gnn.handle(local_rank)
+    gnn = GnnGraph(unpack_blob(blobs[1]), gnn_cfg)       # visual: holds the backbone's aru_net/... tensors too
+    lib = _lib.init_device(dev_index)
+    h_aru, h_gnn = aru.handle(dev_index), gnn.handle(dev_index)
 
     # ---- synthetic inputs, resident in HBM before the timed region ------------------------------------------
-    # (the page generator costs ~3 s of numpy per page: four distinct pages per rank, every page of the batch has its own
-    # buffers in HBM)
-    distinct = [synth.synth_page(rank * 4 + k, W, H) for k in range(min(B, 4))]
+    # (the page generator costs ~3 s of numpy per page: four distinct pages per rank through a per-seed file cache that ranks
+    # and runs on one box share; every page of the batch has its own buffers in HBM)
+    distinct = [synth.cached_synth_page(rank * 4 + k, W, H) for k in range(min(B, 4))]
     pages_u8 = [distinct[k % len(distinct)] for k in range(B)]
     imgs = [torch.from_numpy(p).to(dev).float().div_(255.0).contiguous() for p in pages_u8]
     graphs = [synth.synth_graph(rank * B + k) for k in range(B)]
@@ -258,6 +343,22 @@ def main():
     out_u8 = [torch.empty(H, W, ncls, device=dev, dtype=torch.uint8) for _ in range(B)]
     out_mask = [torch.empty(H, W, ncls, device=dev, dtype=torch.uint8) for _ in range(B)]
     out_conf = [torch.empty(N * N, gnn_cfg.num_classes, device=dev) for _ in range(B)]
+    vpages, vkeep, vh, vw, VP = None, [], 0, 0, 4
+    if visual:
+        # image feeds of the visual net: the page after the input pipeline's resize (3000 x 4500 -> 683 x 1024, values 0..255)
+        # and one rectangular region per text block
+        small = [synth.visual_inputs(p, N, rank * 4 + k) for k, p in enumerate(distinct)]
+        vh, vw = small[0][0].shape
+        vpages = (_lib.GnnPage * B)()
+        for k in range(B):
+            im, reg, npts = small[k % len(small)]
+            t = [torch.from_numpy(im).to(dev), torch.from_numpy(reg).to(dev), torch.from_numpy(npts).to(dev)]
+            vkeep.append(t)
+            q = vpages[k]
+            q.N, q.E, q.R = N, E[k], N * N
+            q.d_edges, q.d_node_feat, q.d_edge_feat = g_edges[k].data_ptr(), g_u[k].data_ptr(), g_ef[k].data_ptr()
+            q.d_image, q.d_regions, q.d_num_points = t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr()
+            q.d_relations, q.d_probs_out = None, out_conf[k].data_ptr()
     stream = torch.cuda.current_stream().cuda_stream
     # the relation graphs do not depend on the segmentation of the same step (different command lines in the pipeline): they
     # run on a second stream and fill the launch tails of the CNN
@@ -274,8 +375,13 @@ def main():
         # one batched ARU-Net call: every layer is launched once for all B pages x 3 scale-space levels
         _lib.check(lib.asep_aru_forward_batch_dev(h_aru, B, p_img, H, W, p_out, p_u8, p_mask, 0.05, stream),
                    "asep_aru_forward_batch_dev")
-        for k in range(B):
-            if with_gnn and not args.no_gnn:
+        if not with_gnn or args.no_gnn:
+            return
+        if visual:
+            # the step's relation nets: ONE grouped backbone forward over the B resized page images, then ROI + graph per page
+            _lib.check(lib.asep_gnn_forward_visual_batch_dev(h_gnn, B, vpages, vh, vw, VP, gnn_stream), "asep_gnn_forward_visual_batch_dev")
+        else:
+            for k in range(B):
                 _lib.check(lib.asep_gnn_forward_dev(h_gnn, N, E[k], g_edges[k].data_ptr(), g_u[k].data_ptr(),
                                                     g_ef[k].data_ptr(), N * N, None, out_conf[k].data_ptr(), gnn_stream),
                            "asep_gnn_forward_dev")
@@ -295,48 +401,75 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if distributed:
-        dt = sharding.max_over_ranks(dt, dev)
+        dt = sharding.max_over_ranks(dt, dev if dist.get_backend() == "nccl" else torch.device("cpu"))
     pages = world * B * args.steps
     value = pages / dt
 
-    # ---- per-kernel timing with HIP events on the launch stream (same workload, separate pass so that the
-    #      events do not perturb `value`) -----------------------------------------------------------------------
-    roofline = None
-    kernels = []
-    if rank == 0 and not args.no_kernel_timing:
-        lib.asep_aru_profile(h_aru, 1)
-        n_prof = max(1, min(args.steps, 3))
-        for _ in range(n_prof):
-            step(with_gnn=False)          # the events bracket ARU-Net kernels: nothing else may run beside them
+    # ---- per-kernel timing with HIP events on the launch streams (same workload, separate passes so that the events do not
+    #      perturb `value`): "in situ" = the real schedule (attention branch on its side stream, relation nets on theirs: what
+    #      rocprofv3 sees), "isolated" = everything serialised on one stream, nothing beside the bracketed kernel ----------
+    peak_tf = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+
+    def kernel_pass(mode, with_gnn):
+        lib.asep_aru_profile(h_aru, mode)
+        n = max(1, min(args.steps, 3))
+        for _ in range(n):
+            step(with_gnn=with_gnn)
         torch.cuda.synchronize()
         buf = C.create_string_buffer(1 << 16)
         _lib.check(lib.asep_aru_profile_report(h_aru, buf, len(buf)), "asep_aru_profile_report")
         lib.asep_aru_profile(h_aru, 0)
-        kernels = json.loads(buf.value.decode())
-        for k in kernels:
+        ks = json.loads(buf.value.decode())
+        for k in ks:
             k["avg_us"] = 1e3 * k["total_ms"] / k["calls"]
             k["tflops"] = k["flops"] / (k["total_ms"] * 1e-3) / 1e12 if k["total_ms"] > 0 else 0.0
             # Winograd F(2x2,3x3) kernels are credited with the direct-convolution FLOPs of their layers (the algorithmic
             # work) but execute 2.25x fewer multiplications on the MFMA: report both
+            k["executed_flops"] = k["flops"] / 2.25 if "wino" in k["kernel"] else k["flops"]
             k["executed_tflops"] = k["tflops"] / 2.25 if "wino" in k["kernel"] else k["tflops"]
-        kernels.sort(key=lambda k: -k["total_ms"])
+        return {k["kernel"]: k for k in ks}, n
+
+    roofline = None
+    kernels = []
+    if rank == 0 and args.kernel_timing != "none":
+        iso = situ = None
+        if args.kernel_timing in ("both", "isolated"):
+            iso, n_prof = kernel_pass(1, False)
+        if args.kernel_timing in ("both", "in-situ"):
+            situ, n_prof = kernel_pass(3, True)
+        base = iso or situ                          # the dominant kernel is chosen on the isolated times when both exist
+        kernels = sorted(base.values(), key=lambda k: -k["total_ms"])
         dom = kernels[0]
-        peak_tf = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        d_iso, d_situ = (iso or {}).get(dom["kernel"]), (situ or {}).get(dom["kernel"])
+        lead = d_situ or d_iso                      # `achieved` / `frac` are the in-situ figures when measured (the lower ones)
+        groups = next((k["calls"] for k in kernels if k["kernel"].startswith("res8") and "_up_" in k["kernel"]), dom["calls"])
+        exec_flops_page = sum(k["executed_flops"] for k in kernels) / (B * n_prof)
         # `achieved` counts the multiply-adds the kernel EXECUTES (a Winograd kernel's direct-convolution credit is in
         # `algorithmic_tflops`).  The fp32 level-0 kernels (res8v_*) issue v_pk_fma_f32 instead of MFMAs: on gfx950 both use
         # the same fp32 datapath and have the same peak (scripts/ubench/mfma_valu_coissue.hip), so the bound keeps its name.
         roofline = {
             "bound": "mfma", "kernel": dom["kernel"],
-            "achieved": round(dom["executed_tflops"], 3), "peak": peak_tf, "unit": "TFLOP/s",
-            "frac": round(dom["executed_tflops"] / peak_tf, 4),
-            "algorithmic_tflops": round(dom["tflops"], 3),
+            "achieved": round(lead["executed_tflops"], 3), "peak": peak_tf, "unit": "TFLOP/s",
+            "frac": round(lead["executed_tflops"] / peak_tf, 4),
+            "timing": "in situ" if d_situ else "isolated",
+            "frac_in_situ": round(d_situ["executed_tflops"] / peak_tf, 4) if d_situ else None,
+            "frac_isolated": round(d_iso["executed_tflops"] / peak_tf, 4) if d_iso else None,
+            "avg_launch_us": round(lead["avg_us"], 2),
+            "avg_launch_us_in_situ": round(d_situ["avg_us"], 2) if d_situ else None,
+            "avg_launch_us_isolated": round(d_iso["avg_us"], 2) if d_iso else None,
+            "algorithmic_tflops": round(lead["tflops"], 3),
             "pipe": "valu v_pk_fma_f32" if dom["kernel"].startswith("res8v") else "mfma",
-            "avg_launch_us": round(dom["avg_us"], 2), "flops_per_launch": dom["flops"] / dom["calls"],
+            "flops_per_launch": dom["flops"] / dom["calls"],
+            "executed_flops_per_launch": dom["executed_flops"] / dom["calls"],
             "share_of_gpu_time": round(dom["total_ms"] / sum(k["total_ms"] for k in kernels), 4),
+            "event_timed_steps": n_prof * ((iso is not None) + (situ is not None)),
             # a launch carries at most 12 problems = 4 pages x 3 scales; the level-0 block kernels are launched exactly once
-            # per such group (a multi-layer kernel like conv_wino_kernel<4> several times), so they count the groups
-            "pages_per_launch": B * n_prof / next((k["calls"] for k in kernels if k["kernel"].startswith("res8") and "up" in k["kernel"]),
-                                                  dom["calls"]),
+            # per such group (a multi-layer kernel like conv_wino_kernel<4,false> several times), so they count the groups
+            "pages_per_launch": B * n_prof / groups,
+            # the whole page against the same peak: executed FLOPs of ALL ARU-Net kernels of a page x pages/s of the timed region
+            "whole_page_executed_gflop": round(exec_flops_page / 1e9, 2),
+            "whole_page_executed_tflops": round(exec_flops_page * value / world / 1e12, 3),
+            "whole_page_executed_frac": round(exec_flops_page * value / world / 1e12 / peak_tf, 4),
             "traffic": None, "traffic_source": None,
         }
         tp = os.path.join(ROOT, "profiles", "traffic_per_kernel.json")
@@ -346,24 +479,47 @@ def main():
                 tj = tj_all["kernels"].get(dom["kernel"])
                 # the counters cannot be read from inside this process: the figure comes from the committed rocprofv3 --pmc
                 # summary of the same workload, scaled to this run's pages per launch
-                if tj and args.dtype == "f32":
-                    ppl = tj_all.get("pages_per_launch", 2)
+                if tj and tj_all.get("dtype", "f32") == args.dtype:
+                    ppl = tj_all.get("pages_per_launch", 4)
                     mine = roofline["pages_per_launch"]
                     roofline["traffic"] = tj["bytes_per_launch"] * mine / ppl
                     roofline["traffic_source"] = (f"offline: {tj_all.get('source')} (commit {tj_all.get('commit', 'n/a')}, "
                                                   f"{ppl} pages per launch there, scaled x{mine / ppl:g})")
-                    # the same launch against the other roof (HBM ~ 8 TB/s): the level-1 convs sit near half of both
-                    roofline["hbm_tb_per_s"] = round(roofline["traffic"] / (dom["avg_us"] * 1e-6) / 1e12, 3)
-                    roofline["hbm_frac"] = round(roofline["hbm_tb_per_s"] / 8.0, 4)
+                    # the same launch against the other roof (HBM ~ 8 TB/s)
+                    roofline["hbm_tb_per_s"] = round(roofline["traffic"] / (lead["avg_us"] * 1e-6) / 1e12, 3)
+                    roofline["hbm_frac"] = round(roofline["hbm_tb_per_s"] / (PEAK_HBM_GBS / 1e3), 4)
+                    if tj_all.get("page_bytes"):
+                        roofline["whole_page_traffic_gb"] = round(tj_all["page_bytes"] / 1e9, 2)
+                        roofline["whole_page_hbm_frac"] = round(tj_all["page_bytes"] * value / world / 1e9 / PEAK_HBM_GBS, 4)
             except Exception:
                 pass
+        for k in kernels:
+            o = (situ or {}).get(k["kernel"])
+            k["avg_us_in_situ"] = o["avg_us"] if (o and iso) else (k["avg_us"] if situ and not iso else None)
+            if not iso:
+                k["avg_us_isolated"] = None
+            else:
+                k["avg_us_isolated"] = k["avg_us"]
 
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary and not args.no_gnn:
-        secondary = secondary_measurements(args, lib, dev, imgs, pages_u8, graphs)
+        secondary = secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, (gnn, vpages, vh, vw, VP) if visual else None)
 
     if rank == 0:
-        flops_page = lib.asep_aru_flops(h_aru, H, W) + (0 if args.no_gnn else lib.asep_gnn_flops(h_gnn, N, 2 * E[0], N * N))
+        gnn_flops = 0.0
+        if not args.no_gnn:
+            gnn_flops = lib.asep_gnn_flops(h_gnn, N, 2 * E[0], N * N)
+            if visual:
+                gnn_flops += lib.asep_aru_flops(gnn._backbones[dev_index].handle(dev_index), vh, vw)
+        flops_page = lib.asep_aru_flops(h_aru, H, W) + gnn_flops
+        if args.no_gnn:
+            rel = "ARU-Net only (diagnostic)"
+        elif visual:
+            rel = ("+ per page the relation net BASELINE configs[3] names (mixed_gnn_vn7e2 = VISUAL net: RU backbone on the page at "
+                   f"{vw}x{vh} + ROI max / compression to 3x16 visual features + graph with 55 node features, 200 nodes / 20k edges / "
+                   "40k pairs), the step's relation nets as one grouped call on a second stream")
+        else:
+            rel = "+ geometric 7-feature relation graph per page (200 nodes / 20k edges / 40k pairs; diagnostic: not the net configs[3] names)"
         line = {
             "metric": METRIC, "value": round(value, 4), "unit": "pages/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
@@ -371,21 +527,22 @@ def main():
             "config": {
                 "workload": (("BASELINE configs[1]: ARU-Net separator detection on 3000x4500 px pages, fp32, "
                               if args.dtype == "f32" else
-                              "BASELINE configs[4] precision (bf16 MFMA convs, fp32 accumulate/storage): ARU-Net separator "
-                              "detection on 3000x4500 px pages, ")
-                             + "+ configs[3]-shaped GNN relation graph per page (200 nodes / 20k edges / 40k pairs)"
-                             if not args.no_gnn else "ARU-Net only (diagnostic)"),
+                              "BASELINE configs[4] precision (bf16 activations / MFMA convs, fp32 accumulate): ARU-Net separator "
+                              "detection on 3000x4500 px pages, ") + rel),
                 "height": H, "width": W, "pages_per_step_per_gpu": B, "sharding": f"pages over {world} rank(s)",
+                "relation_net": "none" if args.no_gnn else args.gnn,
+                "timed_region_s": round(dt, 3),
                 "aru_cfg": "ARU featRoot=8 levels=5 res_depth=3 att_scales=3 n_classes=2",
                 "gflop_per_page": round(flops_page / 1e9, 2),
                 "whole_page_tflops_per_gpu": round(flops_page * value / world / 1e12, 3),
             },
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "kernels": [{"kernel": k["kernel"], "calls": k["calls"], "avg_us": round(k["avg_us"], 2),
-                         "tflops": round(k["tflops"], 2), "executed_tflops": round(k["executed_tflops"], 2),
-                         "executed_frac_of_peak": round(k["executed_tflops"] / (PEAK_F32_MFMA_TFLOPS if args.dtype == "f32"
-                                                                              else PEAK_BF16_MFMA_TFLOPS), 4)}
-                        for k in kernels[:12]],
+                         "avg_us_in_situ": None if k.get("avg_us_in_situ") is None else round(k["avg_us_in_situ"], 2),
+                         "avg_us_isolated": None if k.get("avg_us_isolated") is None else round(k["avg_us_isolated"], 2),
+                         "flops": k["flops"], "tflops": round(k["tflops"], 2), "executed_tflops": round(k["executed_tflops"], 2),
+                         "executed_frac_of_peak": round(k["executed_tflops"] / peak_tf, 4)}
+                        for k in kernels],
             "secondary": secondary,
         }
         print(json.dumps(line), flush=True)

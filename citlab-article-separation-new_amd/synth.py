@@ -62,6 +62,47 @@ def synth_page(k: int = 0, W: int = 3000, H: int = 4500, seed0: int = 20261002):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
+def cached_synth_page(k: int = 0, W: int = 3000, H: int = 4500, cache_dir=None):
+    """``synth_page`` through a per-seed file cache (the generator costs ~3 s of numpy per 3000 x 4500 page; bench.py's ranks
+    and repeated runs on one box share the files).  Writes are atomic (rename), a corrupt file is regenerated."""
+    import os
+    import tempfile
+    d = cache_dir or os.path.join(tempfile.gettempdir(), "asep_synth_cache")
+    path = os.path.join(d, f"page_{k}_{W}x{H}.npy")
+    try:
+        a = np.load(path)
+        if a.shape == (H, W) and a.dtype == np.uint8:
+            return a
+    except Exception:
+        pass
+    a = synth_page(k, W, H)
+    try:
+        os.makedirs(d, exist_ok=True)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            np.save(f, a)
+        os.replace(tmp, path)
+    except OSError:
+        pass
+    return a
+
+
+def visual_inputs(page_u8, N: int, k: int = 0, max_dim: int = 1024, P: int = 4, seed0: int = 977):
+    """Image feeds of the visual relation net for one synthetic scan: the page resized like the GNN input pipeline does
+    (longer side -> ``max_dim``, TF1 bilinear without half-pixel offset, image_resizer.py:197-223; values 0..255 as fed,
+    input_dataset.py:279-280) and one rectangular visual region per node in RELATIVE coordinates [N,2,P]."""
+    from .gnn_input import compute_new_size, resize_bilinear_tf1
+    nh, nw = compute_new_size(page_u8.shape[0], page_u8.shape[1], 256, max_dim)
+    small = resize_bilinear_tf1(page_u8.astype(np.float32), nh, nw)[:, :, 0]
+    rng = np.random.default_rng(seed0 + k)
+    reg = np.zeros((N, 2, P), np.float32)
+    for n in range(N):
+        bx, by = rng.random() * 0.8, rng.random() * 0.8
+        reg[n, 0] = [bx, bx + 0.15, bx + 0.15, bx]
+        reg[n, 1] = [by, by, by + 0.05, by + 0.05]
+    return np.ascontiguousarray(small, dtype=np.float32), reg, np.full(N, P, np.int32)
+
+
 def synth_graph(k: int = 0, N: int = 200, n_pairs: int = 10000, node_dim: int = 7, edge_dim: int = 2,
                 seed0: int = 4321):
     """C4 graph: N nodes, `n_pairs` distinct unordered pairs emitted in one direction and shuffled

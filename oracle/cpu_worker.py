@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--width", type=int, default=3000)
     ap.add_argument("--height", type=int, default=4500)
     ap.add_argument("--gnn", action="store_true")
+    ap.add_argument("--visual", action="store_true", help="the visual relation net (backbone on 683 x 1024 + 55 features)")
     a = ap.parse_args()
     os.environ["OMP_NUM_THREADS"] = str(a.threads)
     import numpy as np
@@ -35,21 +36,29 @@ def main():
     from oracle import aru_oracle, gnn_oracle
     cfg = AruConfig()
     w = init_aru_weights(cfg, 1234)
-    # a cheap page stand-in of the right statistics is enough for timing; the real generator costs 4 s/page
-    rng = np.random.default_rng(20261002 + a.page)
-    img = np.clip(rng.normal(0.88, 0.03, size=(a.rows, a.width)), 0, 1).astype(np.float32)
-    img[::31, :] = 0.2
-    aru_oracle.forward_torch(img[:128, :256], w, cfg)        # warm-up
+    # the same synthetic scan the GPU path is timed on (generated outside the timed region); a band of it if rows < height
+    page = synth.synth_page(a.page, a.width, a.height)
+    img = (page[:a.rows].astype(np.float32) / np.float32(255.0))
+    aru_oracle.forward_torch(img[:256, :512], w, cfg)        # warm-up (thread pool, first-touch allocations)
     t0 = time.perf_counter()
     aru_oracle.forward_torch(img, w, cfg)
     t_aru = time.perf_counter() - t0
     t_gnn = 0.0
     if a.gnn:
-        gcfg = GnnConfig()
-        gw = init_gnn_weights(gcfg, 1234)
         g = synth.synth_graph(a.page)
-        t0 = time.perf_counter()
-        gnn_oracle.forward(g["num_nodes"], g["interacting_nodes"], g["node_features"], g["edge_features"], None, gw, gcfg)
+        if a.visual:
+            gcfg = GnnConfig(visual_dims=[16, 16, 16], mvn=True,
+                             visual_layers=["scale_0_unet_up_2_conv", "scale_0_unet_up_1_conv", "scale_0_unet_up_0_conv"])
+            gw = init_gnn_weights(gcfg, 1234)
+            small, regions, npts = synth.visual_inputs(page, g["num_nodes"], a.page)
+            t0 = time.perf_counter()
+            gnn_oracle.forward_visual(g["num_nodes"], g["interacting_nodes"], g["node_features"], g["edge_features"], small, regions,
+                                      npts, None, gw, gcfg)
+        else:
+            gcfg = GnnConfig()
+            gw = init_gnn_weights(gcfg, 1234)
+            t0 = time.perf_counter()
+            gnn_oracle.forward(g["num_nodes"], g["interacting_nodes"], g["node_features"], g["edge_features"], None, gw, gcfg)
         t_gnn = time.perf_counter() - t0
     print(json.dumps({"t_aru": t_aru, "t_gnn": t_gnn, "rows": a.rows, "threads": a.threads}), flush=True)
 

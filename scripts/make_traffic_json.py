@@ -1,45 +1,63 @@
 """profiles/traffic_per_kernel.json from a rocprofv3 PMC summary (scripts/summarize_pmc.py output):
-    python scripts/make_traffic_json.py profiles/<tag>/pmc_summary.json <tag> [commit]
+    python scripts/make_traffic_json.py profiles/<tag> [commit]
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the dispatches of a kernel (FETCH_SIZE doubled: the gfx950
-correction of /opt/skills/guides/MI355X_MICROARCH.md).  Keys are the kernel names bench.py reports."""
-import json, os, re, sys
+correction of /opt/skills/guides/MI355X_MICROARCH.md, section HBM).  Keys are the kernels' rocprofv3 names without "void ", "asep::",
+blanks and the argument list -- exactly what the engine's profiler (asep_aru_profile_report) and bench.py report, so no two
+instantiations share a key (round 2's shortened names made conv_mfma_kernel<...,4> and <...,2> collide)."""
+import json
+import os
+import re
+import sys
 
 
-def bench_name(rocprof_name):
-    n = rocprof_name.replace("void ", "").replace("asep::", "")
-    n = n[:n.index("(")] if "(" in n else n
-    m = re.match(r"(\w+)<(.*)>$", n)
-    if not m:
-        return n
-    base, targs = m.group(1), [t.strip() for t in m.group(2).split(",")]
-    if base in ("res8_up_kernel", "res8_down_kernel", "conv_winor_kernel"):
-        return base
-    if base in ("conv_wino_kernel", "deconv_mfma_kernel"):
-        return f"{base}<{targs[0]}>"
-    if base == "conv_mfma_kernel":
-        head = ",".join(targs[:4])
-        return f"{base}<{head},16,false>" if targs[4] == "16" else f"{base}<{head}>"
+def kernel_key(rocprof_name):
+    """'void asep::conv_mfma_kernel<3, 3, 1, false, 16, false, false, false, 4>(asep::ConvArgs)' -> 'conv_mfma_kernel<3,3,1,false,16,false,false,false,4>'"""
+    n = rocprof_name.strip()
+    if n.startswith("void "):
+        n = n[5:]
+    depth, cut = 0, len(n)
+    for i, ch in enumerate(n):                      # the argument list starts at the first '(' outside the template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    n = n[:cut].replace("asep::", "").replace(" ", "")
     return n
 
 
-def main():
-    src, tag = sys.argv[1], sys.argv[2]
-    commit = sys.argv[3] if len(sys.argv) > 3 else "n/a"          # the build the counters were collected on
-    s = json.load(open(src))
-    out = {"source": f"profiles/{tag}/pmc_summary.json", "commit": commit, "pages_per_launch": 2,
-           "unit": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024, mean over dispatches "
-                   "(scripts/profile_bench.sh: bench.py --pages-per-step 2)",
-           "kernels": {}}
-    for name, f in s["FETCH_SIZE"].items():
-        w = s["WRITE_SIZE"].get(name)
+def traffic_table(pmc_summary, pages_in_run):
+    """-> ({key: {...}}, bytes of all asep:: kernels per page)"""
+    kernels, total = {}, 0.0
+    for name, f in pmc_summary["FETCH_SIZE"].items():
+        w = pmc_summary["WRITE_SIZE"].get(name)
         if w is None or "asep::" not in name:
             continue
-        out["kernels"][bench_name(name)] = {
-            "bytes_per_launch": (2.0 * f["avg_per_dispatch"] + w["avg_per_dispatch"]) * 1024.0,
-            "fetch_size_kb": f["avg_per_dispatch"], "write_size_kb": w["avg_per_dispatch"], "dispatches": f["dispatches"]}
+        per_launch = (2.0 * f["avg_per_dispatch"] + w["avg_per_dispatch"]) * 1024.0
+        kernels[kernel_key(name)] = {"bytes_per_launch": per_launch, "fetch_size_kb": f["avg_per_dispatch"],
+                                     "write_size_kb": w["avg_per_dispatch"], "dispatches": f["dispatches"]}
+        total += (2.0 * f["sum"] + w["sum"]) * 1024.0
+    return kernels, total / pages_in_run
+
+
+def main():
+    tagdir = sys.argv[1].rstrip("/")
+    commit = sys.argv[2] if len(sys.argv) > 2 else "n/a"          # the build the counters were collected on
+    s = json.load(open(os.path.join(tagdir, "pmc_summary.json")))
+    line = json.loads(open(os.path.join(tagdir, "bench_under_trace.json")).read().strip().splitlines()[-1])
+    # pages of the profiled process: (warm-up + timed + event-timed steps) x pages per step
+    ppl = line["roofline"]["pages_per_launch"]
+    B = line["config"]["pages_per_step_per_gpu"]
+    steps_total = line["warmup"] + line["steps"] + line["roofline"].get("event_timed_steps", 0)
+    kernels, page_bytes = traffic_table(s, steps_total * B)
+    out = {"source": f"{tagdir}/pmc_summary.json", "commit": commit, "pages_per_launch": ppl, "dtype": line["dtype"],
+           "unit": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024, mean over dispatches (scripts/profile_bench.sh)",
+           "page_bytes": page_bytes, "pages_in_profiled_run": steps_total * B, "kernels": kernels}
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_per_kernel.json")
     json.dump(out, open(dst, "w"), indent=1)
-    print(dst, len(out["kernels"]), "kernels")
+    print(dst, len(kernels), "kernels;", f"{page_bytes / 1e9:.2f} GB per page")
 
 
 if __name__ == "__main__":

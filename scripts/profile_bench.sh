@@ -1,22 +1,27 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): kernel-trace stats of the default bench command, then two PMC passes
-# (FETCH_SIZE, WRITE_SIZE) in their own runs, as /opt/skills/guides prescribe.  Output -> gpurun_out/<tag>/
+# Runs on the GPU box (via gpurun): kernel-trace stats of the bench command, then two PMC passes (FETCH_SIZE, WRITE_SIZE) in
+# their own runs, as /opt/skills/guides prescribe, then the SQ pass.  Output -> gpurun_out/<tag>/
+#   scripts/profile_bench.sh <tag> [extra bench flags, e.g. --dtype bf16]
 set -u
-TAG=${1:-r1}
+TAG=${1:-r3}
+shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# 2 pages per launch under the profiler (the default of 16 only lengthens the trace); bench.py scales the PMC bytes to its own batch
-BENCH="python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --pages-per-step 2"
+# 4 pages per step = one launch group per layer, the same launch shape as the default 16-page step (4 groups of 4 pages);
+# --kernel-timing in-situ: every launch of the traced process runs in the real schedule (side stream + relation nets), so
+# rocprofv3's AverageNs and the line's HIP-event averages describe the same launches (scripts/roofline_from_profiles.py)
+BENCH="python3 $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-secondary --pages-per-step 4 --kernel-timing in-situ $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.log
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH --no-kernel-timing > /dev/null 2> $OUT/pmc_fetch.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH --no-kernel-timing > /dev/null 2> $OUT/pmc_write.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > /dev/null 2> $OUT/pmc_fetch.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > /dev/null 2> $OUT/pmc_write.log
 # SQ / GRBM pass: MFMA pipe occupancy and wave stall buckets per kernel
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $BENCH --no-kernel-timing > /dev/null 2> $OUT/pmc_sq.log
-find $OUT -name "*.csv" | head -20
-# keep only what fits the 64 MiB merge limit: drop the per-dispatch traces of the PMC passes after summarising
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $BENCH > /dev/null 2> $OUT/pmc_sq.log
+# keep only what fits the 64 MiB merge limit: summarise, then drop the per-dispatch traces
 python3 $R/scripts/summarize_pmc.py $OUT > $OUT/pmc_summary.json
 python3 $R/scripts/summarize_pmc.py $OUT sq > $OUT/pmc_sq_summary.json
-rm -f $OUT/pmc_fetch/*/*kernel_trace.csv $OUT/pmc_write/*/*kernel_trace.csv $OUT/pmc_sq/*/*kernel_trace.csv $OUT/pmc_sq/*/*counter_collection.csv
-ls -la $OUT $OUT/*/* | head -40
+cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
+python3 $R/scripts/roofline_from_profiles.py $OUT > $OUT/roofline_recomputed.json
+ls -la $OUT

@@ -1,0 +1,106 @@
+"""Recompute the `roofline` block of a bench.py line from the rocprofv3 summaries of the SAME run.
+
+    python scripts/roofline_from_profiles.py profiles/<tag> [--tol 0.03]
+
+Inputs (written by scripts/profile_bench.sh):
+    <tag>/bench_under_trace.json   the bench line printed by the process rocprofv3 traced (--kernel-timing in-situ: every launch of
+                                   that process runs in the real schedule, so rocprofv3's averages and the HIP-event averages of the
+                                   line describe the same thing)
+    <tag>/kernel_stats.csv         rocprofv3 --kernel-trace --stats: Name, Calls, TotalDurationNs, AverageNs
+    <tag>/pmc_summary.json         FETCH_SIZE / WRITE_SIZE per kernel from their own --pmc passes (scripts/summarize_pmc.py)
+
+Every field is recomputed WITHOUT the line's own timings: the launch duration from rocprofv3's AverageNs, the FLOPs per launch
+from the line's per-kernel FLOP totals (they are shape arithmetic, not measurements), HBM bytes per launch as
+(2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction of MI355X_MICROARCH.md), the whole page from the sums over all asep::
+kernels.  Prints a JSON report; exit code 1 if a compared field deviates by more than --tol (default 3 %).
+The un-traced default run of the same build is <tag>/bench.json; it carries the isolated figure as well and differs from the
+traced run by clocks (profiled passes run ~2-3 % slower, guide section 'Clocks')."""
+import csv
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from make_traffic_json import kernel_key, traffic_table  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0
+
+
+def load_line(path):
+    return json.loads(open(path).read().strip().splitlines()[-1])
+
+
+def recompute(tagdir):
+    line = load_line(os.path.join(tagdir, "bench_under_trace.json"))
+    r = line["roofline"]
+    stats = {}
+    for row in csv.DictReader(open(os.path.join(tagdir, "kernel_stats.csv"))):
+        if "asep::" in row["Name"]:
+            stats[kernel_key(row["Name"])] = {"calls": int(row["Calls"]), "total_ns": float(row["TotalDurationNs"]),
+                                              "avg_ns": float(row["AverageNs"])}
+    B = line["config"]["pages_per_step_per_gpu"]
+    pages = (line["warmup"] + line["steps"] + r.get("event_timed_steps", 0)) * B
+    kernels, page_bytes = traffic_table(json.load(open(os.path.join(tagdir, "pmc_summary.json"))), pages)
+    k = r["kernel"]
+    if k not in stats:
+        raise SystemExit(f"{k} not in kernel_stats.csv (have: {sorted(stats)[:6]} ...)")
+    avg_us = stats[k]["avg_ns"] / 1e3
+    lk = {q["kernel"]: q for q in line["kernels"]}
+    exec_fl = r["executed_flops_per_launch"]
+    peak = r["peak"]
+    achieved = exec_fl / (avg_us * 1e-6) / 1e12
+    # whole page: executed FLOPs of all ARU-Net kernels per page (Winograd kernels execute 1/2.25 of their direct-conv credit)
+    ev_steps = max(1, r.get("event_timed_steps", 1))
+    exec_page = sum((q["flops"] / 2.25 if "wino" in q["kernel"] else q["flops"]) for q in line["kernels"]) / (B * ev_steps)
+    out = {
+        "kernel": k,
+        "avg_launch_us": avg_us,
+        "achieved": achieved,
+        "frac": achieved / peak,
+        "whole_page_executed_gflop": exec_page / 1e9,
+        "whole_page_executed_frac": exec_page * line["value"] / line["n_gpus"] / 1e12 / peak,
+    }
+    if k in kernels:
+        out["traffic"] = kernels[k]["bytes_per_launch"]
+        out["hbm_tb_per_s"] = out["traffic"] / (avg_us * 1e-6) / 1e12
+        out["hbm_frac"] = out["hbm_tb_per_s"] / (PEAK_HBM_GBS / 1e3)
+    out["whole_page_traffic_gb"] = page_bytes / 1e9
+    out["whole_page_hbm_frac"] = page_bytes * line["value"] / line["n_gpus"] / 1e9 / PEAK_HBM_GBS
+    # chip time per page by rocprofv3 (sum of all asep:: kernel durations; streams overlap, so this is >= the wall time per page)
+    out["kernel_time_ms_per_page"] = sum(v["total_ns"] for v in stats.values()) / 1e6 / pages
+    out["wall_ms_per_page"] = 1e3 / line["value"] * line["n_gpus"]
+    # per-kernel table: rocprofv3 average vs the line's in-situ HIP-event average
+    table = []
+    for name, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ns"]):
+        q = lk.get(name)
+        ev = q and (q.get("avg_us_in_situ") or q.get("avg_us"))
+        table.append({"kernel": name, "rocprof_avg_us": round(v["avg_ns"] / 1e3, 2), "hip_event_avg_us": ev,
+                      "rel_dev": None if not ev else round(v["avg_ns"] / 1e3 / ev - 1.0, 4),
+                      "hbm_bytes_per_launch": kernels.get(name, {}).get("bytes_per_launch")})
+    return line, out, table
+
+
+def compare(line, rec, tol):
+    r = line["roofline"]
+    pairs = {"avg_launch_us": r.get("avg_launch_us_in_situ") or r["avg_launch_us"], "achieved": r["achieved"], "frac": r["frac"],
+             "whole_page_executed_gflop": r["whole_page_executed_gflop"], "whole_page_executed_frac": r["whole_page_executed_frac"]}
+    for f in ("traffic", "hbm_tb_per_s", "hbm_frac", "whole_page_traffic_gb", "whole_page_hbm_frac"):
+        if r.get(f) is not None and f in rec:
+            pairs[f] = r[f]
+    dev = {f: (rec[f] / v - 1.0 if v else None) for f, v in pairs.items()}
+    ok = all(d is not None and abs(d) <= tol for d in dev.values())
+    return pairs, dev, ok
+
+
+def main(argv):
+    tagdir = argv[1].rstrip("/")
+    tol = float(argv[argv.index("--tol") + 1]) if "--tol" in argv else 0.03
+    line, rec, table = recompute(tagdir)
+    pairs, dev, ok = compare(line, rec, tol)
+    print(json.dumps({"tag": tagdir, "tolerance": tol, "ok": ok, "recomputed": rec, "bench_line": pairs,
+                      "rel_dev": {k: None if v is None else round(v, 4) for k, v in dev.items()}, "kernels": table}, indent=1))
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    raise SystemExit(main(sys.argv))

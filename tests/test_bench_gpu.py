@@ -25,7 +25,7 @@ def _one_json_line(stdout):
 
 def test_single_process_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                        "--pages-per-step", "3"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+                        "--pages-per-step", "3", "--e2e-pages", "6"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = _one_json_line(r.stdout)
     assert line["steps"] == 2 and line["warmup"] == 1 and line["dtype"] == "f32"
@@ -35,7 +35,15 @@ def test_single_process_line():
     assert "error" not in sec, sec
     assert sec["aru_bf16_mfma"]["pages_per_s"] > 0 and sec["heading_net_plus_swt_fusion"]["pages_per_s"] > 0
     assert sec["visual_gnn_vn7e2_shape"]["step_kernel"] == "mfma_lds" and sec["visual_gnn_vn7e2_shape"]["us_per_page"] > 0
+    assert sec["visual_gnn_vn7e2_shape"]["us_per_page_grouped"] > 0 and sec["geometric_gnn_7_features"]["us_per_page"] > 0
+    assert sec["e2e_files"]["page_xml_written"] == 6 and sec["e2e_files"]["pages_per_s"] > 0
     assert all("executed_tflops" in k for k in line["kernels"])
+    # the headline step carries the VISUAL relation net (BASELINE configs[3]: mixed_gnn_vn7e2), and the roofline block both timings
+    assert line["config"]["relation_net"] == "visual" and "mixed_gnn_vn7e2" in line["config"]["workload"]
+    r = line["roofline"]
+    assert r["frac_in_situ"] and r["frac_isolated"] and r["whole_page_executed_frac"] > 0
+    assert r["frac"] == r["frac_in_situ"] and r["frac_in_situ"] <= r["frac_isolated"] * 1.05
+    assert r["kernel"] in {k["kernel"] for k in line["kernels"]} and "<" in "".join(k["kernel"] for k in line["kernels"])
 
 
 def test_rccl_path_with_one_rank_keeps_stdout_clean():
@@ -45,3 +53,22 @@ def test_rccl_path_with_one_rank_keeps_stdout_clean():
                         "--no-cpu-baseline", "--no-secondary", "--pages-per-step", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     _one_json_line(r.stdout)
+
+
+def test_two_ranks_on_the_one_gpu():
+    """the N > 1 branch of bench.py (rank-dependent page seeds, weight broadcast from rank 0, barrier brackets,
+    max-over-ranks, pages = world x B x steps) had only ever run with one rank.  Two ranks through torch.distributed.run, both
+    pinned to device 0 (ASEP_BENCH_DEVICE) -- RCCL cannot form a communicator of two ranks on one device, so the collective
+    backend of this test is gloo; the ranks are started by torchrun before anything touches the GPU."""
+    env = dict(os.environ, ASEP_BENCH_DEVICE="0", ASEP_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-secondary", "--pages-per-step", "2", "--kernel-timing", "none"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["sharding"] == "pages over 2 rank(s)" and line["cpu_baseline"] is None
+    # value = pages of BOTH ranks / slowest rank's time
+    assert abs(line["value"] - 2 * 2 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-2 * line["value"]
