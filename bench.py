@@ -58,8 +58,11 @@ def parse_args():
                     help="f32 = BASELINE configs[1] (the headline); bf16 = configs[4] 'bf16 convs': bf16 MFMA operands, "
                          "fp32 accumulation / storage, probability maps within 2e-2 (reported with dtype bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-steps", type=int, default=3,
+                    help="steps per HIP-event pass (scripts/profile_bench.sh uses many event-timed and few plain steps, so that "
+                         "rocprofv3's per-kernel averages cover the launches the events bracket)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="same as --kernel-timing none")
-    ap.add_argument("--e2e-pages", type=int, default=96,
+    ap.add_argument("--e2e-pages", type=int, default=192,
                     help="scans of the files-in / files-out secondary figure (separator CLI path with host workers; 0 = skip)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements (bf16 variant, heading net + stroke-width fusion, visual GNN)")
@@ -410,39 +413,59 @@ def main():
     #      rocprofv3 sees), "isolated" = everything serialised on one stream, nothing beside the bracketed kernel ----------
     peak_tf = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
 
-    def kernel_pass(mode, with_gnn):
-        lib.asep_aru_profile(h_aru, mode)
-        n = max(1, min(args.steps, 3))
+    h_bb = gnn._backbones[dev_index].handle(dev_index) if visual else None
+
+    def kernel_pass(mode):
+        """One event-timed pass.  mode 3 (in situ): the real schedule, both handles recording.  mode 1 (isolated): the net on one
+        stream, then the relation nets' grouped call, each alone on the chip.  A kernel's record sums ALL its launches of a step
+        by name -- the page net's and the (much smaller) ones of the relation nets' backbone -- which is exactly the population
+        rocprofv3 averages over, so the two can be compared without a name table."""
+        handles = [h_aru] + ([h_bb] if h_bb else [])
+        for h in handles:
+            lib.asep_aru_profile(h, mode)
+        n = max(1, args.event_steps)
         for _ in range(n):
-            step(with_gnn=with_gnn)
-        torch.cuda.synchronize()
-        buf = C.create_string_buffer(1 << 16)
-        _lib.check(lib.asep_aru_profile_report(h_aru, buf, len(buf)), "asep_aru_profile_report")
-        lib.asep_aru_profile(h_aru, 0)
-        ks = json.loads(buf.value.decode())
-        for k in ks:
+            if mode == 3:
+                step()
+            else:
+                step(with_gnn=False)
+                torch.cuda.synchronize()
+                if visual:
+                    _lib.check(lib.asep_gnn_forward_visual_batch_dev(h_gnn, B, vpages, vh, vw, VP, gnn_stream), "visual batch")
+            torch.cuda.synchronize()
+        merged, main_calls = {}, {}
+        for h in handles:
+            buf = C.create_string_buffer(1 << 16)
+            _lib.check(lib.asep_aru_profile_report(h, buf, len(buf)), "asep_aru_profile_report")
+            lib.asep_aru_profile(h, 0)
+            for k in json.loads(buf.value.decode()):
+                if h == h_aru:
+                    main_calls[k["kernel"]] = k["calls"]
+                m = merged.setdefault(k["kernel"], {"kernel": k["kernel"], "calls": 0, "total_ms": 0.0, "flops": 0.0})
+                m["calls"] += k["calls"]; m["total_ms"] += k["total_ms"]; m["flops"] += k["flops"]
+        for k in merged.values():
             k["avg_us"] = 1e3 * k["total_ms"] / k["calls"]
             k["tflops"] = k["flops"] / (k["total_ms"] * 1e-3) / 1e12 if k["total_ms"] > 0 else 0.0
             # Winograd F(2x2,3x3) kernels are credited with the direct-convolution FLOPs of their layers (the algorithmic
             # work) but execute 2.25x fewer multiplications on the MFMA: report both
             k["executed_flops"] = k["flops"] / 2.25 if "wino" in k["kernel"] else k["flops"]
             k["executed_tflops"] = k["tflops"] / 2.25 if "wino" in k["kernel"] else k["tflops"]
-        return {k["kernel"]: k for k in ks}, n
+        return merged, n, main_calls
 
     roofline = None
     kernels = []
     if rank == 0 and args.kernel_timing != "none":
         iso = situ = None
         if args.kernel_timing in ("both", "isolated"):
-            iso, n_prof = kernel_pass(1, False)
+            iso, n_prof, main_calls = kernel_pass(1)
         if args.kernel_timing in ("both", "in-situ"):
-            situ, n_prof = kernel_pass(3, True)
+            situ, n_prof, main_calls = kernel_pass(3)
         base = iso or situ                          # the dominant kernel is chosen on the isolated times when both exist
         kernels = sorted(base.values(), key=lambda k: -k["total_ms"])
         dom = kernels[0]
         d_iso, d_situ = (iso or {}).get(dom["kernel"]), (situ or {}).get(dom["kernel"])
         lead = d_situ or d_iso                      # `achieved` / `frac` are the in-situ figures when measured (the lower ones)
-        groups = next((k["calls"] for k in kernels if k["kernel"].startswith("res8") and "_up_" in k["kernel"]), dom["calls"])
+        groups = next((c for name, c in main_calls.items() if name.startswith("res8") and "_up_" in name), dom["calls"])
         exec_flops_page = sum(k["executed_flops"] for k in kernels) / (B * n_prof)
         # `achieved` counts the multiply-adds the kernel EXECUTES (a Winograd kernel's direct-convolution credit is in
         # `algorithmic_tflops`).  The fp32 level-0 kernels (res8v_*) issue v_pk_fma_f32 instead of MFMAs: on gfx950 both use
@@ -457,16 +480,20 @@ def main():
             "avg_launch_us": round(lead["avg_us"], 2),
             "avg_launch_us_in_situ": round(d_situ["avg_us"], 2) if d_situ else None,
             "avg_launch_us_isolated": round(d_iso["avg_us"], 2) if d_iso else None,
+            "launches_per_step": dom["calls"] / n_prof,
+            "launch_population": "all launches of this kernel in a step: the page net's and the relation nets' backbone's"
+                                 if visual else "all launches of this kernel in a step",
             "algorithmic_tflops": round(lead["tflops"], 3),
             "pipe": "valu v_pk_fma_f32" if dom["kernel"].startswith("res8v") else "mfma",
             "flops_per_launch": dom["flops"] / dom["calls"],
             "executed_flops_per_launch": dom["executed_flops"] / dom["calls"],
             "share_of_gpu_time": round(dom["total_ms"] / sum(k["total_ms"] for k in kernels), 4),
             "event_timed_steps": n_prof * ((iso is not None) + (situ is not None)),
-            # a launch carries at most 12 problems = 4 pages x 3 scales; the level-0 block kernels are launched exactly once
-            # per such group (a multi-layer kernel like conv_wino_kernel<4,false> several times), so they count the groups
+            # a launch of the page net carries at most 12 problems = 4 pages x 3 scales; the level-0 block kernels are launched
+            # exactly once per such group, so they count the groups
             "pages_per_launch": B * n_prof / groups,
-            # the whole page against the same peak: executed FLOPs of ALL ARU-Net kernels of a page x pages/s of the timed region
+            # the whole page against the same peak: executed FLOPs of ALL ARU-Net kernels of a page (incl. the relation net's
+            # backbone) x pages/s of the timed region
             "whole_page_executed_gflop": round(exec_flops_page / 1e9, 2),
             "whole_page_executed_tflops": round(exec_flops_page * value / world / 1e12, 3),
             "whole_page_executed_frac": round(exec_flops_page * value / world / 1e12 / peak_tf, 4),
@@ -478,28 +505,23 @@ def main():
                 tj_all = json.load(open(tp))
                 tj = tj_all["kernels"].get(dom["kernel"])
                 # the counters cannot be read from inside this process: the figure comes from the committed rocprofv3 --pmc
-                # summary of the same workload, scaled to this run's pages per launch
-                if tj and tj_all.get("dtype", "f32") == args.dtype:
-                    ppl = tj_all.get("pages_per_launch", 4)
-                    mine = roofline["pages_per_launch"]
-                    roofline["traffic"] = tj["bytes_per_launch"] * mine / ppl
-                    roofline["traffic_source"] = (f"offline: {tj_all.get('source')} (commit {tj_all.get('commit', 'n/a')}, "
-                                                  f"{ppl} pages per launch there, scaled x{mine / ppl:g})")
+                # summary of the SAME workload (same pages per step, same relation net, same dtype: the same launch population)
+                same = (tj_all.get("dtype") == args.dtype and tj_all.get("pages_per_step") == B and
+                        tj_all.get("relation_net") == ("none" if args.no_gnn else args.gnn) and (tj_all.get("height"), tj_all.get("width")) == (H, W))
+                if tj and same:
+                    roofline["traffic"] = tj["bytes_per_launch"]
+                    roofline["traffic_source"] = f"offline: {tj_all.get('source')} (commit {tj_all.get('commit', 'n/a')}, same workload)"
                     # the same launch against the other roof (HBM ~ 8 TB/s)
                     roofline["hbm_tb_per_s"] = round(roofline["traffic"] / (lead["avg_us"] * 1e-6) / 1e12, 3)
                     roofline["hbm_frac"] = round(roofline["hbm_tb_per_s"] / (PEAK_HBM_GBS / 1e3), 4)
-                    if tj_all.get("page_bytes"):
-                        roofline["whole_page_traffic_gb"] = round(tj_all["page_bytes"] / 1e9, 2)
-                        roofline["whole_page_hbm_frac"] = round(tj_all["page_bytes"] * value / world / 1e9 / PEAK_HBM_GBS, 4)
+                    roofline["whole_page_traffic_gb"] = round(tj_all["page_bytes"] / 1e9, 2)
+                    roofline["whole_page_hbm_frac"] = round(tj_all["page_bytes"] * value / world / 1e9 / PEAK_HBM_GBS, 4)
             except Exception:
                 pass
         for k in kernels:
-            o = (situ or {}).get(k["kernel"])
-            k["avg_us_in_situ"] = o["avg_us"] if (o and iso) else (k["avg_us"] if situ and not iso else None)
-            if not iso:
-                k["avg_us_isolated"] = None
-            else:
-                k["avg_us_isolated"] = k["avg_us"]
+            o_s, o_i = (situ or {}).get(k["kernel"]), (iso or {}).get(k["kernel"])
+            k["avg_us_in_situ"] = o_s["avg_us"] if o_s else None
+            k["avg_us_isolated"] = o_i["avg_us"] if o_i else None
 
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary and not args.no_gnn:

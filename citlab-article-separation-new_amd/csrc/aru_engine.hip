@@ -8,6 +8,7 @@
 #include "aru_kernels.h"
 #include "res8_kernels.h"
 #include "res8v_kernels.h"
+#include "bf16_kernels.h"
 #include "asep_common.h"
 
 using namespace asep;
@@ -15,9 +16,11 @@ using namespace asep;
 namespace {
 
 struct Tensor {
-    float* p = nullptr;
+    float* p = nullptr;    // bf: the buffer holds bf16 (2 bytes per element; native bf16 path), accessed through bp()
     int H = 0, W = 0, C = 0;
+    bool bf = false;
     size_t count() const { return (size_t)H * W * C; }
+    bf16_t* bp() const { return reinterpret_cast<bf16_t*>(p); }
 };
 
 // A convolution whose weights are packed as the A operand of v_mfma_f32_16x16x4_f32.
@@ -32,6 +35,10 @@ struct PackedConv {
     float* d_wino = nullptr;   // Winograd F(2x2,3x3) transformed weights U = G g G^T, packed [g][pos][mtile][lane][4]
     float* d_wv = nullptr;     // scalar-operand filters of the vector-ALU kernels: deconv 16 -> 8 [tap][ci][co] (deconv8v_kernel),
                                // 4x4 conv 32 -> 1 [tap][ci] (conv_c1out_kernel)
+    // native bf16 path (bf16_kernels.h): A fragments of v_mfma_f32_16x16x32_bf16, 8 bf16 per lane
+    int bmode = -1;            // convb / deconvb MODE (0: Cin 8, 1: Cin 16, 2: Cin % 32 == 0); -1: not packed
+    int bchunks = 0;
+    bf16_t* d_wb = nullptr;    // conv: [chunk][mtile][lane][8]; deconv: MODE 2 [G][tap][mtile][lane][8], MODE 1 [frag 0..5][mtile][lane][8]
 };
 
 struct DirectConv {        // Cin == 1 first layers
@@ -51,6 +58,8 @@ int upload(const std::vector<float>& h, float** d) {
 struct asep_aru {
     asep_aru_cfg cfg{};
     std::map<std::string, PackedConv> convs;   // keyed by variable scope, e.g. "aru_net/featMapG/unet_down_1/convR_0"
+    struct ResB { int C = 0; bf16_t* d_w = nullptr; float* d_b = nullptr; };
+    std::map<std::string, ResB> resb;          // bf16 path: fused residual-block tails (8- / 16-channel levels), keyed by block scope
     DirectConv det_first, att_first;
     // fused level-0 residual blocks (feat_root == 8, res_depth == 3): pixel-pair MFMA fragments
     float* d_r8_down_wr = nullptr;   // [3][6][64][4]
@@ -103,7 +112,8 @@ struct asep_aru {
     hipStream_t host_stream = nullptr;   // transfers + forward of the host-pointer entry point (created on first use)
     bool use_xcd_sched = true;     // ASEP_XCD_SCHED=0: identity tile order in the persistent fused kernels
     std::map<std::string, const int32_t*> sched_cache;
-    bool bf16 = false;             // cfg.compute_dtype == 1: bf16 MFMA operands, fp32 accumulation and storage
+    bool bf16 = false;             // cfg.compute_dtype == 1: native bf16 data path (bf16_kernels.h): bf16 activations in HBM / LDS,
+                                   // v_mfma_f32_16x16x32_bf16 with fp32 accumulation; fp32 image in, fp32 probabilities out
     bool wino_reg = true;          // ASEP_WINO_REG=0: LDS-image Winograd kernel also for the 32-channel level
     bool use_winograd = true;      // ASEP_WINOGRAD=0 selects the direct implicit-GEMM kernels everywhere
     bool big_tile2 = true;         // ASEP_BIGTILE2=0: 8 x 32 double-buffered blocks for 32 -> 16 convs without residual operand
@@ -177,6 +187,8 @@ inline std::string tb(bool b) { return b ? "true" : "false"; }
 inline std::string ti(int i) { return std::to_string(i); }
 
 // ---- weight packing -----------------------------------------------------------------------------
+int pack_conv_bf(asep_aru* m, PackedConv& pc, const HostTensor& w);   // bf16 fragments (native bf16 path), defined further down
+
 // conv   W[kh][kw][cin][cout]  (layers.py:219);  deconv W[kh][kw][cout][cin] (layers.py:352, ARU_v1.py:257)
 int pack_conv(asep_aru* m, const std::map<std::string, HostTensor>& blob, const std::string& scope,
               const char* bias_name, bool deconv) {
@@ -280,6 +292,10 @@ int pack_conv(asep_aru* m, const std::map<std::string, HostTensor>& blob, const 
         if (rc) return rc;
         m->owned.push_back(pc.d_wv);
     }
+    if (m->bf16) {
+        rc = pack_conv_bf(m, pc, w);
+        if (rc) return rc;
+    }
     m->convs[scope] = pc;
     return ASEP_OK;
 }
@@ -343,27 +359,15 @@ void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, int tot
     const bool has_res = res_op || KH != 3;      // (the four-blocks-per-CU variant exists for 3x3 only: 4x4 needs 140 VGPRs)
     if constexpr (KW == 4) {
         if (pc.c12) {                                        // one m-tile, one channel group: 16 x 32 tiles, single LDS buffer
-            if (m->bf16) ASEP_CONV_LAUNCH(KH, KW, 1, false, 16, false, true, true, 2);
-            else ASEP_CONV_LAUNCH(KH, KW, 1, false, 16, false, false, true, 2);
+            ASEP_CONV_LAUNCH(KH, KW, 1, false, 16, false, false, true, 2);
             return;
         }
     }
     if constexpr (KH == 3) {
         if (pc.c8 && big_tile && !res_op) {                  // 8 -> 16 (level-1 conv1): 16 x 32-pixel blocks, four per CU
-            if (m->bf16) ASEP_CONV_LAUNCH(3, 3, 1, true, 16, false, true, false, 4);
-            else ASEP_CONV_LAUNCH(3, 3, 1, true, 16, false, false, false, 4);
+            ASEP_CONV_LAUNCH(3, 3, 1, true, 16, false, false, false, 4);
             return;
         }
-    }
-    if (m->bf16) {
-        if (pc.c8) ASEP_CONV_LAUNCH(KH, KW, 1, true, CONV_TH, true, true, false, 2);
-        else if (mt == 1 && big_tile && !has_res) ASEP_CONV_LAUNCH(3, 3, 1, false, 16, false, true, false, 4);
-        else if (mt == 1 && big_tile) ASEP_CONV_LAUNCH(KH, KW, 1, false, 16, false, true, false, 2);
-        else if (mt == 4) ASEP_CONV_LAUNCH(KH, KW, 4, false, CONV_TH, true, true, false, 2);
-        else if (mt == 2 && !res_op) ASEP_CONV_LAUNCH(KH, KW, 2, false, CONV_TH, true, true, false, 3);
-        else if (mt == 2) ASEP_CONV_LAUNCH(KH, KW, 2, false, CONV_TH, true, true, false, 2);
-        else ASEP_CONV_LAUNCH(KH, KW, 1, false, CONV_TH, true, true, false, 2);
-        return;
     }
     if (pc.c8) ASEP_CONV_LAUNCH(KH, KW, 1, true, CONV_TH, true, false, false, 2);
     else if (mt == 1 && big_tile && !has_res) ASEP_CONV_LAUNCH(3, 3, 1, false, 16, false, false, false, 4);
@@ -396,7 +400,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
         set_error("conv %s: unsupported kernel size %dx%d", scope.c_str(), pc.kh, pc.kw);
         throw ArgError();
     }
-    if (pc.d_wv && pc.cout == 1 && m->r8_valu && !m->bf16 && !in1 && !res && !pooled) {
+    if (pc.d_wv && pc.cout == 1 && m->r8_valu && !in1 && !res && !pooled) {
         // single output channel (attention conv4): one pixel per thread on the vector ALU
         TL out1;
         for (const Tensor& t : in0) out1.push_back(new_tensor(m, t.H, t.W, 1));
@@ -424,9 +428,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
         }
         return out1;
     }
-    // bf16 MFMAs are so much faster that the LDS-bound Winograd kernels only pay at 128 channels (and they amplify the
-    // bf16 rounding): the bf16 variant takes the direct kernels below that
-    const bool wino = pc.d_wino && m->use_winograd && (!m->bf16 || pc.mtiles >= 8) && (pc.mtiles > 1 || (m->wino16 && m->wino_reg));
+    const bool wino = pc.d_wino && m->use_winograd && (pc.mtiles > 1 || (m->wino16 && m->wino_reg));
     const int wino_mt = pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1);
     const bool fuse_pool = pooled && m->fuse_pool && pc.cout % 4 == 0 && (!wino || (wino_mt <= 2 && m->wino_reg));
     TL out;
@@ -488,20 +490,15 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             dim3 grid(wt, ny);
             std::string pname;
             if (mt == 1) pname = "conv_winor_kernel<false,1,true>";
-            else if (mt == 2 && m->wino_reg) pname = m->bf16 ? "conv_winor_kernel<true,2,true>" : (!res ? "conv_winor_kernel<false,2,false>" : "conv_winor_kernel<false,2,true>");
-            else pname = "conv_wino_kernel" + targs({ti(mt), tb(m->bf16)});
+            else if (mt == 2 && m->wino_reg) pname = !res ? "conv_winor_kernel<false,2,false>" : "conv_winor_kernel<false,2,true>";
+            else pname = "conv_wino_kernel" + targs({ti(mt), tb(false)});
             ProfScope ps(m, pname, flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
             if (mt == 1) {
                 hipLaunchKernelGGL((conv_winor_kernel<false, 1, true>), grid, dim3(256), 0, m->stream, a);
             } else if (mt == 2 && m->wino_reg) {
                 // register-resident variant: a wave per (tile row, m-tile); grid.y counts pairs of m-tiles
-                if (m->bf16) hipLaunchKernelGGL((conv_winor_kernel<true, 2, true>), grid, dim3(256), 0, m->stream, a);
-                else if (!res) hipLaunchKernelGGL((conv_winor_kernel<false, 2, false>), grid, dim3(256), 0, m->stream, a);
+                if (!res) hipLaunchKernelGGL((conv_winor_kernel<false, 2, false>), grid, dim3(256), 0, m->stream, a);
                 else hipLaunchKernelGGL((conv_winor_kernel<false, 2, true>), grid, dim3(256), 0, m->stream, a);
-            } else if (m->bf16) {
-                if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4, true>), grid, dim3(256), 0, m->stream, a);
-                else if (mt == 2) hipLaunchKernelGGL((conv_wino_kernel<2, true>), grid, dim3(256), 0, m->stream, a);
-                else hipLaunchKernelGGL((conv_wino_kernel<1, true>), grid, dim3(256), 0, m->stream, a);
             } else if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4>), grid, dim3(256), 0, m->stream, a);
             else if (mt == 2) hipLaunchKernelGGL((conv_wino_kernel<2>), grid, dim3(256), 0, m->stream, a);
             else hipLaunchKernelGGL((conv_wino_kernel<1>), grid, dim3(256), 0, m->stream, a);
@@ -530,7 +527,7 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
         out.push_back(new_tensor(m, like[i].H, like[i].W, pc.cout));
     }
     const int mt = pc.mtiles % 2 == 0 ? 2 : 1;
-    const bool valu = pc.d_wv && m->r8_valu && !m->bf16;     // level 0, fp32: one input position per thread on the vector ALU
+    const bool valu = pc.d_wv && m->r8_valu;                 // level 0: one input position per thread on the vector ALU
     for (size_t b0 = 0; b0 < in.size(); b0 += MAXP) {
         const size_t b1 = std::min(in.size(), b0 + MAXP);
         ConvArgs a{};
@@ -553,15 +550,12 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
         a.relu_in = 0; a.relu_out = relu_out;
         dim3 grid(tiles, pc.mtiles / mt);
-        const std::string dname = valu ? std::string("deconv8v_kernel") : "deconv_mfma_kernel" + targs({ti(mt), tb(m->bf16)});
+        const std::string dname = valu ? std::string("deconv8v_kernel") : "deconv_mfma_kernel" + targs({ti(mt), tb(false)});
         TL sub(in.begin() + b0, in.begin() + b1);
         ProfScope ps(m, dname, flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
         if (valu) {
             a.wpk = (const f32x4*)pc.d_wv;
             hipLaunchKernelGGL(deconv8v_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
-        } else if (m->bf16) {
-            if (mt == 2) hipLaunchKernelGGL((deconv_mfma_kernel<2, true>), grid, dim3(256), 0, m->stream, a);
-            else hipLaunchKernelGGL((deconv_mfma_kernel<1, true>), grid, dim3(256), 0, m->stream, a);
         } else if (mt == 2) hipLaunchKernelGGL((deconv_mfma_kernel<2>), grid, dim3(256), 0, m->stream, a);
         else hipLaunchKernelGGL((deconv_mfma_kernel<1>), grid, dim3(256), 0, m->stream, a);
     }
@@ -714,14 +708,12 @@ int pack_res8(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
         m->owned.push_back(m->d_r8_up_w1); m->owned.push_back(m->d_r8_up_wr);
         m->owned.push_back(m->d_r8_up_br); m->owned.push_back(m->d_r8_up_b1);
         if (hipFuncSetAttribute((const void*)res8_up_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)res8_up_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess ||
             hipFuncSetAttribute((const void*)res8v_up_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess) {
             set_error("cannot reserve %zu bytes of LDS for the fused up block", R8_UP_LDS);
             return ASEP_ERR_HIP;
         }
     }
     if (hipFuncSetAttribute((const void*)res8_down_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)res8_down_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)res8v_down_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess) {
         set_error("cannot reserve %zu bytes of LDS for the fused residual block", R8_DOWN_LDS);
         return ASEP_ERR_HIP;
@@ -791,15 +783,14 @@ void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>&
         a.nprob = (int)(b1 - b0);
         a.total_tiles = tiles;
         a.w1 = m->det_first.d_w; a.b1 = m->det_first.d_b;
-        bool valu = m->r8_valu && !m->bf16;      // fp32: vector-ALU kernels (32-bit element offsets: < 2^29 pixels per tensor)
+        bool valu = m->r8_valu;                  // vector-ALU kernels (32-bit element offsets: < 2^29 pixels per tensor)
         for (size_t i = b0; i < b1; ++i) valu = valu && (size_t)imgs[i].H * imgs[i].W < ((size_t)1 << 28);
         a.wr = (const f32x4*)(valu ? m->d_r8v_down_wr : m->d_r8_down_wr); a.br = m->d_r8_down_br;
         TL sub(imgs.begin() + b0, imgs.begin() + b1);
-        const std::string pname = valu ? std::string("res8v_down_kernel") : "res8_down_kernel" + targs({tb(m->bf16)});
+        const std::string pname = valu ? std::string("res8v_down_kernel") : std::string("res8_down_kernel<false>");
         ProfScope ps(m, pname, flops, "unet_down_0 (conv1+3xconvR+add+pool) " + dims_of(sub));
         a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH * R8_NP);
-        if (m->bf16) hipLaunchKernelGGL(res8_down_kernel<true>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
-        else if (valu) hipLaunchKernelGGL(res8v_down_kernel, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
+        if (valu) hipLaunchKernelGGL(res8v_down_kernel, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
         else hipLaunchKernelGGL(res8_down_kernel<false>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
     }
 }
@@ -824,18 +815,347 @@ TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
         }
         a.nprob = (int)(b1 - b0);
         a.total_tiles = tiles;
-        bool valu = m->r8_valu && !m->bf16;      // fp32: vector-ALU kernels (32-bit element offsets: < 2^29 pixels per tensor)
+        bool valu = m->r8_valu;                  // vector-ALU kernels (32-bit element offsets: < 2^29 pixels per tensor)
         for (size_t i = b0; i < b1; ++i) valu = valu && (size_t)skip[i].H * skip[i].W < ((size_t)1 << 28);
         a.w1 = valu ? m->d_r8v_up_w1 : m->d_r8_up_w1; a.b1 = m->d_r8_up_b1;
         a.wr = (const f32x4*)(valu ? m->d_r8v_up_wr : m->d_r8_up_wr); a.br = m->d_r8_up_br;
         TL sub(skip.begin() + b0, skip.begin() + b1);
-        const std::string pname = valu ? std::string("res8v_up_kernel") : "res8_up_kernel" + targs({tb(m->bf16)});
+        const std::string pname = valu ? std::string("res8v_up_kernel") : std::string("res8_up_kernel<false>");
         ProfScope ps(m, pname, flops, "unet_up_0 (conv1[16->8]+3xconvR+add) " + dims_of(sub));
         a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH * R8_NP);
         const dim3 grid(std::min(tiles, m->num_cus));
-        if (m->bf16) hipLaunchKernelGGL(res8_up_kernel<true>, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
-        else if (valu) hipLaunchKernelGGL(res8v_up_kernel, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
+        if (valu) hipLaunchKernelGGL(res8v_up_kernel, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
         else hipLaunchKernelGGL(res8_up_kernel<false>, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
+    }
+    return out;
+}
+
+// ================================================================================================
+// Native bf16 data path (cfg.compute_dtype == 1): packing and launchers of bf16_kernels.h
+// ================================================================================================
+bf16_t f2bf(float f) {                                 // round-to-nearest-even like v_cvt_pk_bf16_f32 (weights have no NaN)
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+int upload_bf(const std::vector<bf16_t>& h, bf16_t** d) {
+    ASEP_HIP_CHECK(hipMalloc((void**)d, std::max<size_t>(h.size(), 8) * sizeof(bf16_t)));
+    ASEP_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+    return ASEP_OK;
+}
+
+// A fragments of a conv for convb_kernel / resb_tail_kernel.  W(tap, ci, co) = weight or 0 outside the filter.
+// mode 0: chunk = ky, k = 8 kx + ci (kx = 3: zero);  mode 1: chunk c, k = 16 (tap - 2c) + ci;  mode 2: chunk = G taps + tap, k = ci - 32 G
+template <class WF>
+void pack_frags_conv(int mode, int kh, int kw, int cin, int mtiles, WF W, std::vector<bf16_t>& dst, int* nchunks) {
+    const int taps = kh * kw;
+    const int chunks = mode == 0 ? kh : (mode == 1 ? (taps + 1) / 2 : (cin / 32) * taps);
+    *nchunks = chunks;
+    for (int ch = 0; ch < chunks; ++ch)
+        for (int mt = 0; mt < mtiles; ++mt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int kk = lane >> 4, co = mt * 16 + (lane & 15);
+                    int tap, ci;
+                    if (mode == 0) { tap = kk < kw ? ch * kw + kk : -1; ci = j; }
+                    else if (mode == 1) { tap = 2 * ch + (kk >> 1); ci = (kk & 1) * 8 + j; if (tap >= taps) tap = -1; }
+                    else { const int G = ch / taps; tap = ch % taps; ci = 32 * G + kk * 8 + j; }
+                    dst.push_back(f2bf(tap < 0 ? 0.f : W(tap, ci, co)));
+                }
+}
+
+int conv_bmode(int cin) { return cin == 8 ? 0 : (cin == 16 ? 1 : (cin % 32 == 0 ? 2 : -1)); }
+
+// bf16 fragments of one packed conv / deconv (called from pack_conv when the model is bf16)
+int pack_conv_bf(asep_aru* m, PackedConv& pc, const HostTensor& w) {
+    const int taps = pc.kh * pc.kw;
+    auto W = [&](int tap, int ci, int co) -> float {
+        if (ci >= pc.cin || co >= pc.cout || tap >= taps) return 0.f;
+        return pc.deconv ? w.data[((size_t)tap * pc.cout + co) * pc.cin + ci] : w.data[((size_t)tap * pc.cin + ci) * pc.cout + co];
+    };
+    std::vector<bf16_t> pk;
+    if (!pc.deconv) {
+        // the 12-channel output of the attention head is stored as a 16-channel plane (4 zero channels): Cin 12 -> mode 1
+        const int cin_eff = pc.cin == 12 ? 16 : pc.cin;
+        pc.bmode = conv_bmode(cin_eff);
+        if (pc.bmode < 0 || (pc.bmode == 0 && pc.kh != 3)) return ASEP_OK;      // not served by convb (refused at run time if it is needed)
+        pack_frags_conv(pc.bmode, pc.kh, pc.kw, cin_eff, pc.mtiles, W, pk, &pc.bchunks);
+    } else {
+        pc.bmode = pc.cin == 16 ? 1 : (pc.cin % 32 == 0 ? 2 : -1);
+        if (pc.bmode < 0 || pc.kh != 3 || pc.kw != 3) { pc.bmode = -1; return ASEP_OK; }
+        if (pc.bmode == 2) {
+            const int G = pc.cin / 32;
+            pc.bchunks = G * 9;
+            for (int g = 0; g < G; ++g)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int mt = 0; mt < pc.mtiles; ++mt)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j)
+                                pk.push_back(f2bf(W(tap, 32 * g + (lane >> 4) * 8 + j, mt * 16 + (lane & 15))));
+        } else {
+            // fragment f: dy = f >= 4; class (py, px) = dy ? (0, f & 1) : (f >> 1, f & 1); k = 16 dx + ci
+            pc.bchunks = 6;
+            for (int f = 0; f < 6; ++f)
+                for (int mt = 0; mt < pc.mtiles; ++mt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int kk = lane >> 4, dx = kk >> 1, ci = (kk & 1) * 8 + j, co = mt * 16 + (lane & 15);
+                            const int dy = f >= 4, py = dy ? 0 : (f >> 1), px = f & 1;
+                            const int ky = py ? 1 : (dy ? 2 : 0);
+                            const int kx = px ? (dx ? -1 : 1) : (dx ? 2 : 0);
+                            pk.push_back(f2bf(kx < 0 ? 0.f : W(ky * 3 + kx, ci, co)));
+                        }
+        }
+    }
+    int rc = upload_bf(pk, &pc.d_wb);
+    if (rc) return rc;
+    m->owned.push_back(pc.d_wb);
+    return ASEP_OK;
+}
+
+// the three convR filters of a residual block for resb_tail_kernel<C>: [3][CPC][64][8] + biases [3][C]
+int pack_resb(asep_aru* m, const std::map<std::string, HostTensor>& blob, const std::string& scope, int C) {
+    std::vector<bf16_t> pk;
+    std::vector<float> br;
+    for (int r = 0; r < 3; ++r) {
+        auto wi = blob.find(scope + "/convR_" + std::to_string(r) + "/weights");
+        auto bi = blob.find(scope + "/convR_" + std::to_string(r) + "/biases");
+        if (wi == blob.end() || bi == blob.end()) { set_error("weights: missing %s/convR_%d", scope.c_str(), r); return ASEP_ERR_WEIGHTS; }
+        const HostTensor& w = wi->second;
+        if (w.dims.size() != 4 || w.dims[0] != 3 || w.dims[1] != 3 || w.dims[2] != C || w.dims[3] != C) return ASEP_OK;   // not this shape: layer-by-layer
+        auto W = [&](int tap, int ci, int co) -> float { return (ci < C && co < C) ? w.data[((size_t)tap * C + ci) * C + co] : 0.f; };
+        int nch = 0;
+        pack_frags_conv(C == 8 ? 0 : 1, 3, 3, C, 1, W, pk, &nch);
+        br.insert(br.end(), bi->second.data.begin(), bi->second.data.end());
+    }
+    asep_aru::ResB rb;
+    rb.C = C;
+    int rc = upload_bf(pk, &rb.d_w);
+    if (!rc) rc = upload(br, &rb.d_b);
+    if (rc) return rc;
+    m->owned.push_back(rb.d_w);
+    m->owned.push_back(rb.d_b);
+    m->resb[scope] = rb;
+    return ASEP_OK;
+}
+
+Tensor new_tensor_bf(asep_aru* m, int H, int W, int C) {
+    Tensor t;
+    t.H = H; t.W = W; t.C = C; t.bf = true;
+    t.p = (float*)m->cur->pool.get(t.count() * sizeof(bf16_t));
+    return t;
+}
+
+#define ASEP_CONVB_LAUNCH(KH_, KW_, MODE_, MT_, TH_, MB_)                                                              \
+    do {                                                                                                               \
+        ps.set_name("convb_kernel" + targs({ti(KH_), ti(KW_), ti(MODE_), ti(MT_), ti(TH_), ti(MB_)}));                 \
+        hipLaunchKernelGGL((convb_kernel<KH_, KW_, MODE_, MT_, TH_, MB_>), grid, dim3(256), 0, m->stream, a);          \
+    } while (0)
+
+// stride-1 SAME conv of the bf16 path.  pooled != nullptr: the epilogue also writes maxpool2 of the output (always fused here);
+// keep_full = false: only the pooled tensor is stored; pool_f32: the pooled tensor is fp32 (input of conv_c1out_kernel)
+TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1, bool relu_in, bool relu_out, const TL* res,
+             TL* pooled = nullptr, bool keep_full = true, bool pool_f32 = false) {
+    auto it = m->convs.find(scope);
+    if (it == m->convs.end()) { set_error("internal: conv %s not packed", scope.c_str()); throw ArgError(); }
+    const PackedConv& pc = it->second;
+    const int cin = in0[0].C + (in1 ? (*in1)[0].C : 0);
+    const int cin_w = pc.cin == 12 ? 16 : pc.cin;           // attention conv2 reads the head's zero-padded 16-channel plane
+    if (cin != cin_w || !in0[0].bf) { set_error("internal: conv %s expects %d bf16 channels, got %d", scope.c_str(), cin_w, cin); throw ArgError(); }
+    if (pc.bmode < 0 || !pc.d_wb || !((pc.kh == 3 && pc.kw == 3) || (pc.kh == 4 && pc.kw == 4)) || in0[0].C % 8 != 0 || pc.cout % 8 != 0) {
+        set_error("conv %s (%dx%d, %d -> %d channels) is not served by the bf16 kernels", scope.c_str(), pc.kh, pc.kw, pc.cin, pc.cout);
+        throw ArgError();
+    }
+    const int mt = pc.mtiles >= 4 ? 4 : pc.mtiles;
+    if (pc.mtiles % mt != 0 || mt == 3) { set_error("conv %s: %d output tiles not instantiated", scope.c_str(), pc.mtiles); throw ArgError(); }
+    const int th = mt == 4 ? 8 : 16;
+    TL out;
+    if (keep_full || !pooled)
+        for (const Tensor& t : in0) out.push_back(new_tensor_bf(m, t.H, t.W, pc.cout));
+    if (pooled) {
+        pooled->clear();
+        for (const Tensor& t : in0) {
+            Tensor q = pool_f32 ? new_tensor(m, cdiv(t.H, 2), cdiv(t.W, 2), pc.cout) : new_tensor_bf(m, cdiv(t.H, 2), cdiv(t.W, 2), pc.cout);
+            pooled->push_back(q);
+        }
+    }
+    for (size_t b0 = 0; b0 < in0.size(); b0 += MAXP) {
+        const size_t b1 = std::min(in0.size(), b0 + MAXP);
+        ConvBArgs a{};
+        int tiles = 0;
+        double flops = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            ConvBProb& p = a.p[i - b0];
+            p.in0 = in0[i].bp(); p.in1 = in1 ? (*in1)[i].bp() : nullptr; p.res = res ? (*res)[i].bp() : nullptr;
+            p.out = out.empty() ? nullptr : out[i].bp();
+            p.pool = pooled ? (void*)(*pooled)[i].p : nullptr;
+            p.H = in0[i].H; p.W = in0[i].W;
+            p.tiles_x = cdiv(in0[i].W, 32);
+            p.tile_begin = tiles;
+            tiles += p.tiles_x * cdiv(in0[i].H, th);
+            flops += 2.0 * in0[i].H * in0[i].W * pc.kh * pc.kw * (double)pc.cin * pc.cout;
+        }
+        a.nprob = (int)(b1 - b0);
+        a.wpk = (const u32x4*)pc.d_wb; a.bias = pc.d_b;
+        a.c0 = in0[0].C; a.c1 = in1 ? (*in1)[0].C : 0;
+        a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = cin / 32;
+        a.relu_in = relu_in; a.relu_out = relu_out; a.skip_full = pooled && !keep_full; a.pool_f32 = pool_f32;
+        dim3 grid(tiles, pc.mtiles / mt);
+        TL sub(in0.begin() + b0, in0.begin() + b1);
+        ProfScope ps(m, "convb_kernel", flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
+        const int key = pc.kh * 100 + pc.bmode * 10 + mt;
+        switch (key) {
+            case 301: ASEP_CONVB_LAUNCH(3, 3, 0, 1, 16, 2); break;
+            case 302: ASEP_CONVB_LAUNCH(3, 3, 0, 2, 16, 2); break;
+            case 304: ASEP_CONVB_LAUNCH(3, 3, 0, 4, 8, 2); break;
+            case 311: ASEP_CONVB_LAUNCH(3, 3, 1, 1, 16, 2); break;
+            case 312: ASEP_CONVB_LAUNCH(3, 3, 1, 2, 16, 2); break;
+            case 314: ASEP_CONVB_LAUNCH(3, 3, 1, 4, 8, 2); break;
+            case 321: ASEP_CONVB_LAUNCH(3, 3, 2, 1, 16, 2); break;
+            case 322: ASEP_CONVB_LAUNCH(3, 3, 2, 2, 16, 2); break;
+            case 324: ASEP_CONVB_LAUNCH(3, 3, 2, 4, 8, 2); break;
+            case 411: ASEP_CONVB_LAUNCH(4, 4, 1, 1, 16, 2); break;
+            case 412: ASEP_CONVB_LAUNCH(4, 4, 1, 2, 16, 2); break;
+            case 414: ASEP_CONVB_LAUNCH(4, 4, 1, 4, 8, 2); break;
+            case 421: ASEP_CONVB_LAUNCH(4, 4, 2, 1, 16, 2); break;
+            case 422: ASEP_CONVB_LAUNCH(4, 4, 2, 2, 16, 2); break;
+            case 424: ASEP_CONVB_LAUNCH(4, 4, 2, 4, 8, 2); break;
+            default: set_error("conv %s: bf16 kernel variant %d not instantiated", scope.c_str(), key); throw ArgError();
+        }
+    }
+    return out;
+}
+
+// fused tail of a residual block (3 x convR + t + ReLU [+ pool]) for the 8- / 16-channel levels
+bool has_resb(asep_aru* m, const std::string& scope) { return m->resb.count(scope) != 0; }
+
+TL run_resb_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled) {
+    const asep_aru::ResB& rb = m->resb.at(scope);
+    if (t[0].C != rb.C || !t[0].bf) { set_error("internal: residual tail %s expects %d bf16 channels", scope.c_str(), rb.C); throw ArgError(); }
+    TL out;
+    for (const Tensor& x : t) out.push_back(new_tensor_bf(m, x.H, x.W, rb.C));
+    if (pooled) {
+        pooled->clear();
+        for (const Tensor& x : t) pooled->push_back(new_tensor_bf(m, cdiv(x.H, 2), cdiv(x.W, 2), rb.C));
+    }
+    for (size_t b0 = 0; b0 < t.size(); b0 += MAXP) {
+        const size_t b1 = std::min(t.size(), b0 + MAXP);
+        ResBArgs a{};
+        int tiles = 0;
+        double flops = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            ResBProb& p = a.p[i - b0];
+            p.t = t[i].bp(); p.out = out[i].bp(); p.pool = pooled ? (*pooled)[i].bp() : nullptr;
+            p.H = t[i].H; p.W = t[i].W;
+            p.tiles_x = cdiv(t[i].W, RB_TW);
+            p.tile_begin = tiles;
+            tiles += p.tiles_x * cdiv(t[i].H, RB_TH);
+            flops += 2.0 * t[i].H * t[i].W * 3 * 9.0 * rb.C * rb.C;
+        }
+        a.nprob = (int)(b1 - b0);
+        a.wpk = (const u32x4*)rb.d_w; a.bias = rb.d_b;
+        TL sub(t.begin() + b0, t.begin() + b1);
+        ProfScope ps(m, "resb_tail_kernel" + targs({ti(rb.C)}), flops, scope + " (3xconvR+add" + (pooled ? "+pool) " : ") ") + dims_of(sub));
+        if (rb.C == 8) hipLaunchKernelGGL(resb_tail_kernel<8>, dim3(tiles), dim3(256), 0, m->stream, a);
+        else hipLaunchKernelGGL(resb_tail_kernel<16>, dim3(tiles), dim3(256), 0, m->stream, a);
+    }
+    return out;
+}
+
+TL run_deconvb(asep_aru* m, const std::string& scope, const TL& in, const TL& like, bool relu_out) {
+    auto it = m->convs.find(scope);
+    if (it == m->convs.end()) { set_error("internal: deconv %s not packed", scope.c_str()); throw ArgError(); }
+    const PackedConv& pc = it->second;
+    if (pc.bmode < 1 || !pc.d_wb || in[0].C != pc.cin || !in[0].bf || pc.cout % 8 != 0) {
+        set_error("deconv %s (%d -> %d channels) is not served by the bf16 kernels", scope.c_str(), pc.cin, pc.cout);
+        throw ArgError();
+    }
+    TL out;
+    for (size_t i = 0; i < in.size(); ++i) {
+        if (cdiv(like[i].H, 2) != in[i].H || cdiv(like[i].W, 2) != in[i].W) {
+            set_error("deconv %s: output %dx%d incompatible with input %dx%d", scope.c_str(), like[i].H, like[i].W, in[i].H, in[i].W);
+            throw ArgError();
+        }
+        out.push_back(new_tensor_bf(m, like[i].H, like[i].W, pc.cout));
+    }
+    const int mt = pc.mtiles % 2 == 0 ? 2 : 1;
+    for (size_t b0 = 0; b0 < in.size(); b0 += MAXP) {
+        const size_t b1 = std::min(in.size(), b0 + MAXP);
+        DeconvBArgs a{};
+        int tiles = 0;
+        double flops = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            DeconvBProb& p = a.p[i - b0];
+            p.in = in[i].bp(); p.out = out[i].bp();
+            p.Hi = in[i].H; p.Wi = in[i].W; p.Ho = out[i].H; p.Wo = out[i].W;
+            p.pbh = std::max((in[i].H - 1) * 2 + 3 - out[i].H, 0) / 2;
+            p.pbw = std::max((in[i].W - 1) * 2 + 3 - out[i].W, 0) / 2;
+            p.tiles_x = cdiv(in[i].W, DCB_TW);
+            p.tile_begin = tiles;
+            tiles += p.tiles_x * cdiv(in[i].H, DCB_TH);
+            flops += 2.0 * in[i].H * in[i].W * 9.0 * pc.cin * pc.cout;
+        }
+        a.nprob = (int)(b1 - b0);
+        a.wpk = (const u32x4*)pc.d_wb; a.bias = pc.d_b;
+        a.cin = pc.cin; a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.cin / 32; a.relu_out = relu_out;
+        dim3 grid(tiles, pc.mtiles / mt);
+        TL sub(in.begin() + b0, in.begin() + b1);
+        ProfScope ps(m, "deconvb_kernel" + targs({ti(pc.bmode), ti(mt)}), flops,
+                     scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
+        if (pc.bmode == 1 && mt == 1) hipLaunchKernelGGL((deconvb_kernel<1, 1>), grid, dim3(256), 0, m->stream, a);
+        else if (pc.bmode == 1) hipLaunchKernelGGL((deconvb_kernel<1, 2>), grid, dim3(256), 0, m->stream, a);
+        else if (mt == 1) hipLaunchKernelGGL((deconvb_kernel<2, 1>), grid, dim3(256), 0, m->stream, a);
+        else hipLaunchKernelGGL((deconvb_kernel<2, 2>), grid, dim3(256), 0, m->stream, a);
+    }
+    return out;
+}
+
+// first layer of the feature CNN on the bf16 path: fp32 image -> bf16 [H,W,8] (pre-ReLU t of unet_down_0)
+TL run_direct_bf(asep_aru* m, const DirectConv& dc, const TL& imgs, const std::vector<const float*>& stats) {
+    if (dc.k != 3 || dc.cout != 8) { set_error("bf16 path: first-layer conv k=%d cout=%d not instantiated", dc.k, dc.cout); throw ArgError(); }
+    TL out;
+    for (const Tensor& t : imgs) out.push_back(new_tensor_bf(m, t.H, t.W, dc.cout));
+    for (size_t b0 = 0; b0 < imgs.size(); b0 += MAXP) {
+        const size_t b1 = std::min(imgs.size(), b0 + MAXP);
+        C1Args a{};
+        int tiles = 0;
+        double flops = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            C1Prob& p = a.p[i - b0];
+            p.img = imgs[i].p; p.out = out[i].p; p.stats = stats.empty() ? nullptr : stats[i];
+            p.H = imgs[i].H; p.W = imgs[i].W;
+            p.tiles_x = cdiv(imgs[i].W, 64);
+            p.tile_begin = tiles;
+            tiles += p.tiles_x * cdiv(imgs[i].H, 4);
+            flops += 2.0 * imgs[i].H * imgs[i].W * dc.k * dc.k * dc.cout;
+        }
+        a.nprob = (int)(b1 - b0);
+        a.w = dc.d_w; a.bias = dc.d_b; a.relu = 0;
+        ProfScope ps(m, "conv_c1_kernel<3,8,true>", flops);
+        hipLaunchKernelGGL((conv_c1_kernel<3, 8, true>), dim3(tiles), dim3(256), 0, m->stream, a);
+    }
+    return out;
+}
+
+TL run_chansum_bf(asep_aru* m, const TL& in) {
+    TL out;
+    for (const Tensor& t : in) out.push_back(new_tensor(m, t.H, t.W, 1));
+    for (size_t b0 = 0; b0 < in.size(); b0 += MAXP) {
+        const size_t b1 = std::min(in.size(), b0 + MAXP);
+        PoolBArgs a{};
+        int blocks = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            PoolBProb& p = a.p[i - b0];
+            p.in = in[i].bp(); p.out = out[i].p; p.H = in[i].H; p.W = in[i].W;
+            p.blk_begin = blocks;
+            blocks += (int)(((size_t)in[i].H * in[i].W + POOL_ITEMS - 1) / POOL_ITEMS);
+        }
+        a.nprob = (int)(b1 - b0);
+        a.C = in[0].C;
+        ProfScope ps(m, "chansumb_kernel", 0.0);
+        hipLaunchKernelGGL(chansumb_kernel, dim3(blocks), dim3(256), 0, m->stream, a);
     }
     return out;
 }
@@ -843,12 +1163,14 @@ TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
 // ---- network schedule (ARU_v1.py), evaluated for all problems in lock step ---------------------------------
 // residual block: conv1 (identity) -> t ; relu ; (res_depth-1) x conv+relu ; conv (identity) ; +t ; relu
 TL res_block_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled = nullptr) {
+    if (m->bf16 && has_resb(m, scope)) return run_resb_tail(m, scope, t, pooled);      // one kernel for the whole tail
     TL r = t;
     const int rd = m->cfg.res_depth;
     for (int i = 0; i < rd; ++i) {
         const bool last = (i == rd - 1);
-        r = run_conv(m, scope + "/convR_" + std::to_string(i), r, nullptr, /*relu_in=*/i == 0,
-                     /*relu_out=*/true, last ? &t : nullptr, last ? pooled : nullptr);
+        const std::string sc = scope + "/convR_" + std::to_string(i);
+        r = m->bf16 ? run_convb(m, sc, r, nullptr, /*relu_in=*/i == 0, /*relu_out=*/true, last ? &t : nullptr, last ? pooled : nullptr)
+                    : run_conv(m, sc, r, nullptr, /*relu_in=*/i == 0, /*relu_out=*/true, last ? &t : nullptr, last ? pooled : nullptr);
     }
     return r;
 }
@@ -863,6 +1185,16 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
     };
     for (int l = 0; l < n; ++l) {
         const std::string scope = "aru_net/featMapG/unet_down_" + std::to_string(l);
+        if (m->bf16) {
+            // native bf16 path: conv1 -> t (bf16), then the block tail (one kernel at 8 / 16 channels, three convs above)
+            TL t = (l == 0) ? run_direct_bf(m, m->det_first, imgs, stats) : run_convb(m, scope + "/conv1", u, nullptr, false, false, nullptr);
+            TL pooled;
+            TL d = res_block_tail(m, scope, t, l < n - 1 ? &pooled : nullptr);
+            skips.push_back(d);
+            publish(d, "_unet_down_" + std::to_string(l) + "_conv");
+            u = (l < n - 1) ? pooled : d;
+            continue;
+        }
         if (l == 0 && m->use_fused8 && m->d_r8_down_wr) {
             TL d, pooled;
             run_res8_down(m, imgs, stats, n > 1, &d, &pooled);
@@ -882,9 +1214,12 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
     for (int l = n - 2; l >= 0; --l) {
         const std::string scope = "aru_net/featMapG/unet_up_" + std::to_string(l);
         const TL& skip = skips[l];
-        TL v = run_deconv(m, scope + "/deconv", u, skip, true);
+        TL v = m->bf16 ? run_deconvb(m, scope + "/deconv", u, skip, true) : run_deconv(m, scope + "/deconv", u, skip, true);
         publish(v, "_unet_up_" + std::to_string(l) + "_deconv");
-        if (l == 0 && m->use_fused8 && m->d_r8_up_w1) {
+        if (m->bf16) {
+            TL t = run_convb(m, scope + "/conv1", skip, &v, false, false, nullptr);   // concat [skip, deconv]
+            u = res_block_tail(m, scope, t);
+        } else if (l == 0 && m->use_fused8 && m->d_r8_up_w1) {
             u = run_res8_up(m, skip, v);
         } else {
             TL t = run_conv(m, scope + "/conv1", skip, &v, false, false, nullptr);   // concat [skip, deconv]
@@ -898,9 +1233,11 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
 TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) {
     const std::string p = "aru_net/attMapG/attPart/conv";
     TL y;
+    if (m->bf16 && !(m->d_att_head && m->use_fused8)) { set_error("bf16 path: attention head 4x4 / 12 channels expected"); throw ArgError(); }
     if (m->d_att_head && m->use_fused8) {
         // conv1 + ReLU + pool1 fused (the full-resolution 12-channel tensor is never materialised)
-        for (const Tensor& t : imgs) y.push_back(new_tensor(m, cdiv(t.H, 2), cdiv(t.W, 2), 12));
+        // (bf16 path: the head writes a 16-channel bf16 plane, channels 12..15 zero)
+        for (const Tensor& t : imgs) y.push_back(m->bf16 ? new_tensor_bf(m, cdiv(t.H, 2), cdiv(t.W, 2), 16) : new_tensor(m, cdiv(t.H, 2), cdiv(t.W, 2), 12));
         for (size_t b0 = 0; b0 < imgs.size(); b0 += MAXP) {
             const size_t b1 = std::min(imgs.size(), b0 + MAXP);
             AttHeadArgs a{};
@@ -917,10 +1254,12 @@ TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) 
             }
             a.nprob = (int)(b1 - b0);
             a.wpk = (const f32x4*)m->d_att_head; a.bias = m->att_first.d_b; a.w = m->att_first.d_w;
-            bool valu = m->r8_valu && !m->bf16;              // fp32: vector-ALU form (32-bit output offsets, see run_res8_down)
+            bool valu = m->r8_valu || m->bf16;               // vector-ALU form (32-bit output offsets, see run_res8_down)
             for (size_t i = b0; i < b1; ++i) valu = valu && (size_t)imgs[i].H * imgs[i].W < ((size_t)1 << 28);
-            ProfScope ps(m, valu ? "att_headv_kernel" : "att_head_kernel", flops);
-            if (valu) hipLaunchKernelGGL(att_headv_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
+            if (m->bf16 && !valu) { set_error("bf16 path: image too large for the attention head kernel"); throw ArgError(); }
+            ProfScope ps(m, m->bf16 ? "att_headv_kernel<true>" : (valu ? "att_headv_kernel<false>" : "att_head_kernel"), flops);
+            if (m->bf16) hipLaunchKernelGGL(att_headv_kernel<true>, dim3(tiles), dim3(256), 0, m->stream, a);
+            else if (valu) hipLaunchKernelGGL(att_headv_kernel<false>, dim3(tiles), dim3(256), 0, m->stream, a);
             else hipLaunchKernelGGL(att_head_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
         }
     } else {
@@ -928,6 +1267,14 @@ TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) 
         y = run_pool(m, y, POOL_MAX);
     }
     TL pooled;
+    if (m->bf16) {
+        run_convb(m, p + "2", y, nullptr, false, true, nullptr, &pooled, /*keep_full=*/false);
+        y = pooled;
+        // the last pooled tensor (1/8 resolution, 32 channels) is written as fp32: conv4 is the fp32 vector-ALU kernel
+        run_convb(m, p + "3", y, nullptr, false, true, nullptr, &pooled, /*keep_full=*/false, /*pool_f32=*/true);
+        y = pooled;
+        return run_conv(m, p + "4", y, nullptr, false, true, nullptr);
+    }
     run_conv(m, p + "2", y, nullptr, false, true, nullptr, &pooled, /*keep_full=*/false);   // conv + ReLU + pool in one kernel
     y = pooled;
     run_conv(m, p + "3", y, nullptr, false, true, nullptr, &pooled, /*keep_full=*/false);
@@ -1010,7 +1357,7 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
             TL coarse;
             for (int b = 0; b < B; ++b)
                 for (int s = 1; s < nsc; ++s) coarse.push_back(feat[b * nsc + s]);
-            fsum = run_pool(m, coarse, POOL_CHANSUM);
+            fsum = m->bf16 ? run_chansum_bf(m, coarse) : run_pool(m, coarse, POOL_CHANSUM);
         }
         for (int b = 0; b < B; ++b) {
             CombineArgs ca{};
@@ -1036,14 +1383,20 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
             ca.thr255 = (double)threshold * 255.0;
             ca.softmax = cfg.apply_softmax;
             dim3 grid(cdiv(W, COMBINE_TW), cdiv(H, 16));
-            ProfScope ps(m, "combine_kernel" + targs({ti(cfg.feat_root), ti(cfg.n_classes)}), 2.0 * H * W * 16.0 * cfg.feat_root * cfg.n_classes);
+            ProfScope ps(m, "combine_kernel" + targs({ti(cfg.feat_root), ti(cfg.n_classes), tb(m->bf16)}), 2.0 * H * W * 16.0 * cfg.feat_root * cfg.n_classes);
 #define ASEP_COMB(FR, NC)                                                                          \
-    if (cfg.feat_root == FR && cfg.n_classes == NC) {                                              \
-        hipLaunchKernelGGL((combine_kernel<FR, NC>), grid, dim3(256), 0, stream, ca);              \
+    if (cfg.feat_root == FR && cfg.n_classes == NC && !m->bf16) {                                  \
+        hipLaunchKernelGGL((combine_kernel<FR, NC, false>), grid, dim3(256), 0, stream, ca);       \
     } else
+#define ASEP_COMBB(NC)                                                                             \
+    if (cfg.feat_root == 8 && cfg.n_classes == NC && m->bf16) {                                    \
+        hipLaunchKernelGGL((combine_kernel<8, NC, true>), grid, dim3(256), 0, stream, ca);         \
+    } else
+            ASEP_COMBB(1) ASEP_COMBB(2) ASEP_COMBB(3) ASEP_COMBB(4)
             ASEP_COMB(8, 1) ASEP_COMB(8, 2) ASEP_COMB(8, 3) ASEP_COMB(8, 4) ASEP_COMB(16, 2)
             { set_error("combine: feat_root=%d n_classes=%d not instantiated", cfg.feat_root, cfg.n_classes); return ASEP_ERR_UNSUPPORTED; }
 #undef ASEP_COMB
+#undef ASEP_COMBB
         }
         ASEP_HIP_CHECK(hipGetLastError());
     } catch (const HipError&) {
@@ -1108,6 +1461,7 @@ int aru_endpoint_dev(asep_aru* m, const char* name, const float** d_ptr, int dim
     if (!m || !name || !d_ptr) { set_error("aru_endpoint_dev: bad argument"); return ASEP_ERR_ARG; }
     auto it = m->endpoints.find(name);
     if (it == m->endpoints.end()) { set_error("backbone has no end point '%s' (run a forward first)", name); return ASEP_ERR_ARG; }
+    if (it->second.bf) { set_error("end point '%s' is bf16 (compute_dtype 1): the relation net's backbone must be fp32", name); return ASEP_ERR_UNSUPPORTED; }
     *d_ptr = it->second.p;
     if (dims) { dims[0] = it->second.H; dims[1] = it->second.W; dims[2] = it->second.C; }
     return ASEP_OK;
@@ -1196,7 +1550,14 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
         for (int r = 0; r < cfg->res_depth && !rc; ++r)
             rc = pack_conv(m.get(), blob, s + "/convR_" + std::to_string(r), "biases", false);
     }
-    if (!rc && cfg->feat_root == 8 && cfg->res_depth == 3 && m->det_first.k == 3) rc = pack_res8(m.get(), blob);
+    if (!rc && !m->bf16 && cfg->feat_root == 8 && cfg->res_depth == 3 && m->det_first.k == 3) rc = pack_res8(m.get(), blob);
+    if (!rc && m->bf16 && cfg->res_depth == 3)
+        for (int l = 0; l < n && !rc; ++l) {
+            const int f = cfg->feat_root << l;
+            if (f != 8 && f != 16) continue;
+            rc = pack_resb(m.get(), blob, "aru_net/featMapG/unet_down_" + std::to_string(l), f);
+            if (!rc && l < n - 1) rc = pack_resb(m.get(), blob, "aru_net/featMapG/unet_up_" + std::to_string(l), f);
+        }
     if (rc) return nullptr;
     {
         hipDeviceProp_t prop;
@@ -1332,6 +1693,15 @@ long asep_aru_get_endpoint(asep_aru* m, const char* name, float* out, size_t max
     if (!out) return (long)t.count();
     if (max_floats < t.count()) { set_error("asep_aru_get_endpoint: buffer too small"); return ASEP_ERR_ARG; }
     ASEP_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (t.bf) {                                             // bf16 tensor: widened on the host
+        std::vector<bf16_t> tmp(t.count());
+        ASEP_HIP_CHECK(hipMemcpy(tmp.data(), t.p, t.count() * sizeof(bf16_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tmp.size(); ++i) {
+            const uint32_t u = (uint32_t)tmp[i] << 16;
+            memcpy(out + i, &u, 4);
+        }
+        return (long)t.count();
+    }
     ASEP_HIP_CHECK(hipMemcpy(out, t.p, t.count() * sizeof(float), hipMemcpyDeviceToHost));
     return (long)t.count();
     ASEP_GUARD_END

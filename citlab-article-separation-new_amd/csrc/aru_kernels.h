@@ -33,6 +33,10 @@ __device__ __forceinline__ s16x4 bf16pack(f32x4 v) {
     const u32x2 p = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
     return __builtin_bit_cast(s16x4, p);
 }
+// two floats -> two bf16 (round-to-nearest-even) in one dword: the storage format of the native bf16 path (bf16_kernels.h)
+__device__ __forceinline__ unsigned bf16x2_of(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
 __device__ __forceinline__ f32x4 mfma_bf16(s16x4 a, s16x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
@@ -1116,7 +1120,8 @@ struct C1Args {
     int relu;
 };
 
-template <int K, int COUT>
+// OUTBF: the output is written as bf16 (native bf16 path; COUT % 8 == 0)
+template <int K, int COUT, bool OUTBF = false>
 __global__ __launch_bounds__(256) void conv_c1_kernel(const C1Args a) {
     __shared__ float sw[K * K * COUT + COUT];
     for (int i = threadIdx.x; i < K * K * COUT; i += 256) sw[i] = a.w[i];
@@ -1150,16 +1155,24 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const C1Args a) {
             for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v, sw[(ky * K + kx) * COUT + c], acc[c]);
         }
     }
-    float* o = P.out + ((size_t)y * W + x) * COUT;
 #pragma unroll
-    for (int c = 0; c < COUT; c += 4) {
-        f32x4 v;
+    for (int c = 0; c < COUT; ++c) {
+        const float s = acc[c] + sw[K * K * COUT + c];
+        acc[c] = a.relu ? fmaxf(s, 0.f) : s;
+    }
+    if constexpr (OUTBF) {
+        static_assert(!OUTBF || COUT % 8 == 0, "bf16 output: whole 16-byte units");
+        unsigned short* o = reinterpret_cast<unsigned short*>(P.out) + ((size_t)y * W + x) * COUT;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float s = acc[c + r] + sw[K * K * COUT + c + r];
-            v[r] = a.relu ? fmaxf(s, 0.f) : s;
+        for (int c = 0; c < COUT; c += 8) {
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<u32x4_t*>(o + c) = u32x4_t{bf16x2_of(acc[c], acc[c + 1]), bf16x2_of(acc[c + 2], acc[c + 3]),
+                                                         bf16x2_of(acc[c + 4], acc[c + 5]), bf16x2_of(acc[c + 6], acc[c + 7])};
         }
-        *reinterpret_cast<f32x4*>(o + c) = v;
+    } else {
+        float* o = P.out + ((size_t)y * W + x) * COUT;
+#pragma unroll
+        for (int c = 0; c < COUT; c += 4) *reinterpret_cast<f32x4*>(o + c) = f32x4{acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
     }
 }
 
@@ -1386,8 +1399,10 @@ struct CombineArgs {
 };
 
 constexpr int COMBINE_TW = 32;   // tile width of combine_kernel (16 rows)
-template <int FR, int NC>
+// F0BF: the scale-0 feature map is bf16 (native bf16 path): one 16-byte load per pixel, widened to fp32 in registers
+template <int FR, int NC, bool F0BF = false>
 __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
+    static_assert(!F0BF || FR == 8, "bf16 feature map: 8 channels = one 16-byte record");
     // 32 x 16 pixel tile, two horizontally adjacent pixels per thread (their 4 x 5 pixel window is read from LDS once: the
     // kernel is bound by LDS reads, 32 x 16 B per pixel in the one-pixel form)
     constexpr int TW = COMBINE_TW, T = 16, LW = TW + 3, L = T + 3;     // 4x4 SAME: pad 1 before, 2 after
@@ -1415,9 +1430,16 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
         const int pix = min(tid + i * 256, L * LW - 1);
         const int ly = pix / LW, lx = pix - ly * LW;
         const int gy = min(max(y0 - 1 + ly, 0), a.H - 1), gx = min(max(x0 - 1 + lx, 0), a.W - 1);
-        const float* f = a.f0 + ((size_t)gy * a.W + gx) * FR;
+        if constexpr (F0BF) {
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t q = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const unsigned short*>(a.f0) + ((size_t)gy * a.W + gx) * FR);
+            fv[i][0] = f32x4{__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
+            fv[i][FR / 4 - 1] = f32x4{__uint_as_float(q.z << 16), __uint_as_float(q.z & 0xffff0000u), __uint_as_float(q.w << 16), __uint_as_float(q.w & 0xffff0000u)};
+        } else {
+            const float* f = a.f0 + ((size_t)gy * a.W + gx) * FR;
 #pragma unroll
-        for (int c4 = 0; c4 < FR / 4; ++c4) fv[i][c4] = *reinterpret_cast<const f32x4*>(f + c4 * 4);
+            for (int c4 = 0; c4 < FR / 4; ++c4) fv[i][c4] = *reinterpret_cast<const f32x4*>(f + c4 * 4);
+        }
 #pragma unroll
         for (int s = 0; s < MAX_SCALES; ++s) {
             avv[i][s] = 0.f; fsv[i][s] = 0.f;

@@ -619,6 +619,9 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 // outputs x 12 channels = 24 packed accumulators, 96 v_pk_fma_f32 per tap row with the filter row in scalar registers and
 // the two image rows of the step in registers; the pool is 2 x v_max3 per channel inside the thread, no cross-lane traffic.
 // ------------------------------------------------------------------------------------------------
+// OUTBF (native bf16 path): the pooled pixel is written as 16 bf16 = 12 channels + 4 zeros (32 bytes), the 16-channel plane the
+// next conv's MFMA K chunks expect (bf16_kernels.h)
+template <bool OUTBF = false>
 __global__ __launch_bounds__(256) void att_headv_kernel(const AttHeadArgs a) {
     constexpr int LH = ATT_TH + 3, LW = ATT_TW + 4;          // SAME for 4x4: 1 before, 2 after (+1 col of slack)
     __shared__ __attribute__((aligned(16))) float img[LH * LW];
@@ -712,10 +715,17 @@ __global__ __launch_bounds__(256) void att_headv_kernel(const AttHeadArgs a) {
             m[2 * q + 1] = pool(acc[0][q].y, acc[1][q].y, acc[2][q].y, acc[3][q].y);
         }
         if (gy < H && gx < W) {
-            float* o = P.out + ((unsigned)(gy >> 1) * Wp + (unsigned)(gx >> 1)) * 12u;
-            *reinterpret_cast<f32x4*>(o) = f32x4{m[0], m[1], m[2], m[3]};
-            *reinterpret_cast<f32x4*>(o + 4) = f32x4{m[4], m[5], m[6], m[7]};
-            *reinterpret_cast<f32x4*>(o + 8) = f32x4{m[8], m[9], m[10], m[11]};
+            if constexpr (OUTBF) {
+                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                unsigned short* o = reinterpret_cast<unsigned short*>(P.out) + ((unsigned)(gy >> 1) * Wp + (unsigned)(gx >> 1)) * 16u;
+                *reinterpret_cast<u32x4_t*>(o) = u32x4_t{bf16x2_of(m[0], m[1]), bf16x2_of(m[2], m[3]), bf16x2_of(m[4], m[5]), bf16x2_of(m[6], m[7])};
+                *reinterpret_cast<u32x4_t*>(o + 8) = u32x4_t{bf16x2_of(m[8], m[9]), bf16x2_of(m[10], m[11]), 0u, 0u};
+            } else {
+                float* o = P.out + ((unsigned)(gy >> 1) * Wp + (unsigned)(gx >> 1)) * 12u;
+                *reinterpret_cast<f32x4*>(o) = f32x4{m[0], m[1], m[2], m[3]};
+                *reinterpret_cast<f32x4*>(o + 4) = f32x4{m[4], m[5], m[6], m[7]};
+                *reinterpret_cast<f32x4*>(o + 8) = f32x4{m[8], m[9], m[10], m[11]};
+            }
         }
     }
 }

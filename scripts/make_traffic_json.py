@@ -53,6 +53,8 @@ def main():
     steps_total = line["warmup"] + line["steps"] + line["roofline"].get("event_timed_steps", 0)
     kernels, page_bytes = traffic_table(s, steps_total * B)
     out = {"source": f"{tagdir}/pmc_summary.json", "commit": commit, "pages_per_launch": ppl, "dtype": line["dtype"],
+           "pages_per_step": B, "relation_net": line["config"]["relation_net"], "height": line["config"]["height"],
+           "width": line["config"]["width"],
            "unit": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024, mean over dispatches (scripts/profile_bench.sh)",
            "page_bytes": page_bytes, "pages_in_profiled_run": steps_total * B, "kernels": kernels}
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_per_kernel.json")

@@ -9,10 +9,12 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# 4 pages per step = one launch group per layer, the same launch shape as the default 16-page step (4 groups of 4 pages);
+# the default 16 pages per step: the same launch population as the un-traced default run (4 groups of 4 pages + the relation
+# nets' grouped backbone), so per-kernel averages need no scaling;
 # --kernel-timing in-situ: every launch of the traced process runs in the real schedule (side stream + relation nets), so
 # rocprofv3's AverageNs and the line's HIP-event averages describe the same launches (scripts/roofline_from_profiles.py)
-BENCH="python3 $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-secondary --pages-per-step 4 --kernel-timing in-situ $*"
+# 1 warm-up + 1 plain step, then 10 event-timed steps: 10 of the 12 steps rocprofv3 averages over are the ones the events bracket
+BENCH="python3 $R/bench.py --steps 1 --warmup 1 --event-steps 10 --no-cpu-baseline --no-secondary --kernel-timing in-situ $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > /dev/null 2> $OUT/pmc_write.log
