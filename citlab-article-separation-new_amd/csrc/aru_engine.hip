@@ -121,6 +121,7 @@ struct asep_aru {
     bool fuse_pool = true;         // ASEP_FUSE_POOL=0: separate maxpool2_kernel after every conv
     bool wino16 = false;           // ASEP_WINO16=1: register-resident Winograd also at the 16-channel level (measured: 99 vs
                                    // 103 TFLOP/s-equivalent for the direct kernels, parity-green; kept as an experiment switch)
+    bool bf_th8 = true;            // ASEP_BF_TH8=0: 16 x 32 instead of 8 x 32 pixel blocks for the 32-channel bf16 convs
     bool profiling = false;
     bool prof_detail = false;      // per-layer names (scope + spatial size) instead of per-kernel names
     bool prof_in_situ = false;     // keep the attention side stream while recording (times include what shares the chip)
@@ -948,10 +949,10 @@ Tensor new_tensor_bf(asep_aru* m, int H, int W, int C) {
     return t;
 }
 
-#define ASEP_CONVB_LAUNCH(KH_, KW_, MODE_, MT_, TH_, MB_)                                                              \
+#define ASEP_CONVB_LAUNCH(KH_, KW_, MODE_, MT_, WM_, TH_, MB_)                                                         \
     do {                                                                                                               \
-        ps.set_name("convb_kernel" + targs({ti(KH_), ti(KW_), ti(MODE_), ti(MT_), ti(TH_), ti(MB_)}));                 \
-        hipLaunchKernelGGL((convb_kernel<KH_, KW_, MODE_, MT_, TH_, MB_>), grid, dim3(256), 0, m->stream, a);          \
+        ps.set_name("convb_kernel" + targs({ti(KH_), ti(KW_), ti(MODE_), ti(MT_), ti(WM_), ti(TH_), ti(MB_)}));        \
+        hipLaunchKernelGGL((convb_kernel<KH_, KW_, MODE_, MT_, WM_, TH_, MB_>), grid, dim3(256), 0, m->stream, a);     \
     } while (0)
 
 // stride-1 SAME conv of the bf16 path.  pooled != nullptr: the epilogue also writes maxpool2 of the output (always fused here);
@@ -968,9 +969,11 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
         set_error("conv %s (%dx%d, %d -> %d channels) is not served by the bf16 kernels", scope.c_str(), pc.kh, pc.kw, pc.cin, pc.cout);
         throw ArgError();
     }
-    const int mt = pc.mtiles >= 4 ? 4 : pc.mtiles;
-    if (pc.mtiles % mt != 0 || mt == 3) { set_error("conv %s: %d output tiles not instantiated", scope.c_str(), pc.mtiles); throw ArgError(); }
-    const int th = mt == 4 ? 8 : 16;
+    // output-channel tiles per block: 1 (cout 8 / 16), 2 (cout 32: one wave row, 16 x 32 pixels), 4 (cout >= 64: two wave
+    // rows of two m-tiles, 8 x 32 pixels)
+    const int mtb = pc.mtiles >= 4 ? 4 : pc.mtiles;
+    if (pc.mtiles % mtb != 0 || mtb == 3) { set_error("conv %s: %d output tiles not instantiated", scope.c_str(), pc.mtiles); throw ArgError(); }
+    const int th = (mtb == 4 || (mtb == 2 && pc.bmode == 2 && m->bf_th8)) ? 8 : 16;
     TL out;
     if (keep_full || !pooled)
         for (const Tensor& t : in0) out.push_back(new_tensor_bf(m, t.H, t.W, pc.cout));
@@ -1002,26 +1005,27 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
         a.c0 = in0[0].C; a.c1 = in1 ? (*in1)[0].C : 0;
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = cin / 32;
         a.relu_in = relu_in; a.relu_out = relu_out; a.skip_full = pooled && !keep_full; a.pool_f32 = pool_f32;
-        dim3 grid(tiles, pc.mtiles / mt);
+        dim3 grid(tiles, pc.mtiles / mtb);
         TL sub(in0.begin() + b0, in0.begin() + b1);
         ProfScope ps(m, "convb_kernel", flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
-        const int key = pc.kh * 100 + pc.bmode * 10 + mt;
+        const int key = pc.kh * 100 + pc.bmode * 10 + mtb + (th == 8 && mtb == 2 ? 1000 : 0);
         switch (key) {
-            case 301: ASEP_CONVB_LAUNCH(3, 3, 0, 1, 16, 2); break;
-            case 302: ASEP_CONVB_LAUNCH(3, 3, 0, 2, 16, 2); break;
-            case 304: ASEP_CONVB_LAUNCH(3, 3, 0, 4, 8, 2); break;
-            case 311: ASEP_CONVB_LAUNCH(3, 3, 1, 1, 16, 2); break;
-            case 312: ASEP_CONVB_LAUNCH(3, 3, 1, 2, 16, 2); break;
-            case 314: ASEP_CONVB_LAUNCH(3, 3, 1, 4, 8, 2); break;
-            case 321: ASEP_CONVB_LAUNCH(3, 3, 2, 1, 16, 2); break;
-            case 322: ASEP_CONVB_LAUNCH(3, 3, 2, 2, 16, 2); break;
-            case 324: ASEP_CONVB_LAUNCH(3, 3, 2, 4, 8, 2); break;
-            case 411: ASEP_CONVB_LAUNCH(4, 4, 1, 1, 16, 2); break;
-            case 412: ASEP_CONVB_LAUNCH(4, 4, 1, 2, 16, 2); break;
-            case 414: ASEP_CONVB_LAUNCH(4, 4, 1, 4, 8, 2); break;
-            case 421: ASEP_CONVB_LAUNCH(4, 4, 2, 1, 16, 2); break;
-            case 422: ASEP_CONVB_LAUNCH(4, 4, 2, 2, 16, 2); break;
-            case 424: ASEP_CONVB_LAUNCH(4, 4, 2, 4, 8, 2); break;
+            case 1322: ASEP_CONVB_LAUNCH(3, 3, 2, 2, 1, 8, 4); break;
+            case 301: ASEP_CONVB_LAUNCH(3, 3, 0, 1, 1, 16, 3); break;
+            case 302: ASEP_CONVB_LAUNCH(3, 3, 0, 2, 1, 16, 3); break;
+            case 304: ASEP_CONVB_LAUNCH(3, 3, 0, 2, 2, 8, 3); break;
+            case 311: ASEP_CONVB_LAUNCH(3, 3, 1, 1, 1, 16, 3); break;
+            case 312: ASEP_CONVB_LAUNCH(3, 3, 1, 2, 1, 16, 3); break;
+            case 314: ASEP_CONVB_LAUNCH(3, 3, 1, 2, 2, 8, 3); break;
+            case 321: ASEP_CONVB_LAUNCH(3, 3, 2, 1, 1, 16, 3); break;
+            case 322: ASEP_CONVB_LAUNCH(3, 3, 2, 2, 1, 16, 3); break;
+            case 324: ASEP_CONVB_LAUNCH(3, 3, 2, 2, 2, 8, 3); break;
+            case 411: ASEP_CONVB_LAUNCH(4, 4, 1, 1, 1, 16, 3); break;
+            case 412: ASEP_CONVB_LAUNCH(4, 4, 1, 2, 1, 16, 3); break;
+            case 414: ASEP_CONVB_LAUNCH(4, 4, 1, 2, 2, 8, 3); break;
+            case 421: ASEP_CONVB_LAUNCH(4, 4, 2, 1, 1, 16, 2); break;
+            case 422: ASEP_CONVB_LAUNCH(4, 4, 2, 2, 1, 16, 2); break;
+            case 424: ASEP_CONVB_LAUNCH(4, 4, 2, 2, 2, 8, 2); break;
             default: set_error("conv %s: bf16 kernel variant %d not instantiated", scope.c_str(), key); throw ArgError();
         }
     }
@@ -1505,6 +1509,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BIGTILE")) m->big_tile = atoi(e) != 0;
     if (const char* e = getenv("ASEP_SIDE_STREAM")) m->use_side_stream = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_BF_TH8")) m->bf_th8 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_LANES")) m->num_lanes = std::max(1, std::min(4, atoi(e)));
     for (int l = 0; l < m->num_lanes; ++l) {
         std::unique_ptr<asep_aru::Lane> L(new asep_aru::Lane());

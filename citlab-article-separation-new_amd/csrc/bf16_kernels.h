@@ -47,7 +47,7 @@ __device__ __forceinline__ f32x4 mfma_bf16_k32(u32x4 a, u32x4 b, f32x4 c) {
 //   MODE 0: Cin == 8,  3x3: one 16-byte plane; K chunk = filter row ky: 4 x-consecutive pixels x 8 ch (4th = zero weights)
 //   MODE 1: Cin == 16: one 32-byte plane;       K chunk = two consecutive taps x 16 ch
 //   MODE 2: Cin % 32 == 0: stages of 32 channels = two 32-byte planes; K chunk = (tap, 32-channel group)
-// Block = 256 threads = TH x 32 output pixels; wave w owns n-tiles id = w NT + n: row id >> 1, column block id & 1.
+// Block = 256 threads = TH x 32 output pixels x 16 MT WM output channels.
 // ------------------------------------------------------------------------------------------------
 struct ConvBProb {
     const bf16_t* in0;
@@ -68,10 +68,16 @@ struct ConvBArgs {
     int relu_in, relu_out, skip_full, pool_f32;
 };
 
-template <int KH, int KW, int MODE, int MT, int TH, int MINB>
+// Waves: WM along the output channels x 4 / WM along the pixels; wave (wm, wn) owns m-tiles wm MT .. and n-tiles id = wn NT + n
+// (row id >> 1, column block id & 1).  The A fragments (weights) of a stage are copied to LDS ONCE per block next to the halo
+// tile and read from there by all waves: fetched per wave from L2 (first cut of this kernel) they cost 4 KB per 16 MFMAs and
+// wave = the whole vector-memory path of a CU, and every chunk waited for an L2 round trip.
+template <int KH, int KW, int MODE, int MT, int WM, int TH, int MINB>
 __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
     static_assert(MODE != 0 || (KH == 3 && KW == 3), "MODE 0 is the 3x3 conv with 8 input channels");
-    constexpr int TW = 32, NT = TH / 2;
+    static_assert(WM == 1 || WM == 2, "one or two waves along the output channels");
+    constexpr int TW = 32, WN = 4 / WM, NT = TH * 2 / WN, MTB = MT * WM;
+    static_assert(NT % 4 == 0, "a wave owns whole row pairs (fused 2x2 pool)");
     constexpr int LH = TH + KH - 1, LW = TW + KW - 1 + (MODE == 0 ? 1 : 0);     // MODE 0 reads a 4th (zero-weight) column
     constexpr int PT = (KH - 1) / 2, PL = (KW - 1) / 2;                         // TF SAME: pad_before = (k-1)/2
     constexpr int TAPS = KH * KW;
@@ -80,18 +86,20 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
     constexpr int PLANE = LH * LW * PXB;
     constexpr int NPL = MODE == 2 ? 2 : 1;
     constexpr int CPS = MODE == 0 ? KH : (MODE == 1 ? (TAPS + 1) / 2 : TAPS);   // K chunks per stage
-    constexpr int NU = LH * LW * SUBS;
-    constexpr int NLOAD = (NU + 255) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NPL * PLANE];
+    constexpr int NU = LH * LW * SUBS, NLOAD = (NU + 255) / 256;
+    constexpr int NWU = CPS * MTB * 64, NWLOAD = (NWU + 255) / 256;             // 16-byte units of a stage's A fragments
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPL * PLANE + NWU * 16];
+    unsigned char* const wlds = lds + NPL * PLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
+    const int wm = WM == 2 ? (wave & 1) : 0, wn = WM == 2 ? (wave >> 1) : wave;
     int pi = 0;
     while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
     const ConvBProb& P = a.p[pi];
     const int tile = blockIdx.x - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-    const int x0 = tx * TW, y0 = ty * TH, mt0 = blockIdx.y * MT;
+    const int x0 = tx * TW, y0 = ty * TH, mtb0 = blockIdx.y * MTB, mt0 = mtb0 + wm * MT;
     const int H = P.H, W = P.W;
 
     f32x4 acc[MT][NT];
@@ -100,11 +108,23 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // halo loader: requests first (clamped, always valid addresses), zero padding / ReLU when the registers go to LDS
-    u32x4 st[NLOAD];
-    unsigned stmask = 0;
-    auto stage_load = [&](int g) {
-        stmask = 0;
+    // byte offset of (row, col + j) of each n-tile of this wave, plus the lane's channel half / plane
+    int nbase[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int id = wn * NT + n;
+        nbase[n] = ((id >> 1) * LW + (id & 1) * 16 + j) * PXB + (MODE == 0 ? kk * 16 : (kk & 1) * 16 + (MODE == 2 ? (kk >> 1) * PLANE : 0));
+    }
+    const int ngroups = MODE == 2 ? a.groups : 1;
+    const u32x4* __restrict__ wsrc = a.wpk + (size_t)mtb0 * 64;
+    const size_t wstride = (size_t)a.mtiles * 64;
+    const int mt_have = min(MTB, a.mtiles - mtb0);            // m-tiles of this block that exist (cout 8 / 16: one of MTB)
+
+    for (int g = 0; g < ngroups; ++g) {
+        // ---- stage g: halo tile of 32 (16, 8) input channels + the stage's A fragments -> LDS.  Requests first (clamped,
+        //      always valid addresses); zero padding / ReLU when the registers go to LDS ----
+        u32x4 st[NLOAD];
+        unsigned stmask = 0;
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             const int u = min(tid + i * 256, NU - 1);
@@ -119,8 +139,20 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
             st[i] = *reinterpret_cast<const u32x4*>(src + ((size_t)cy * W + cx) * cs);
             stmask |= ((gy >= 0 && gy < H && gx >= 0 && gx < W) ? 1u : 0u) << i;
         }
-    };
-    auto stage_store = [&]() {
+        if (g > 0) __syncthreads();                          // the previous stage's readers are done
+        // A fragments: global -> LDS without registers (global_load_lds_dwordx4: one wave-instruction copies 1 KB, lane i to
+        // base + 16 i); whole waves, NWU is a multiple of 64
+#pragma unroll
+        for (int i = 0; i < NWLOAD; ++i) {
+            const int u0 = i * 256 + wave * 64;              // wave-uniform
+            if (u0 < NWU) {
+                const int u = u0 + lane;
+                const int t = u / (MTB * 64), r = u - t * (MTB * 64);
+                const u32x4* gsrc = wsrc + (size_t)(g * CPS + t) * wstride + min(r, mt_have * 64 - 1);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                                 (__attribute__((address_space(3))) void*)(wlds + u0 * 16), 16, 0, 0);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             const int u = tid + i * 256;
@@ -131,58 +163,43 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
                 *reinterpret_cast<u32x4*>(lds + (sub >> 1) * PLANE + pix * PXB + (sub & 1) * 16) = v;
             }
         }
-    };
-
-    // byte offset of (row, col + j) of each n-tile of this wave, plus the lane's channel half / plane
-    int nbase[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int id = wave * NT + n;
-        nbase[n] = ((id >> 1) * LW + (id & 1) * 16 + j) * PXB + (MODE == 0 ? kk * 16 : (kk & 1) * 16 + (MODE == 2 ? (kk >> 1) * PLANE : 0));
-    }
-    const int ngroups = MODE == 2 ? a.groups : 1;
-    const int nchunks = ngroups * CPS;
-    const u32x4* __restrict__ wbase = a.wpk + (size_t)mt0 * 64 + lane;
-    const size_t wstride = (size_t)a.mtiles * 64;
-
-    stage_load(0);
-    u32x4 af[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) af[m] = wbase[(size_t)m * 64];
-    for (int g = 0; g < ngroups; ++g) {
-        if (g > 0) __syncthreads();                          // the previous stage's readers are done
-        stage_store();
         __syncthreads();
-        if (g + 1 < ngroups) stage_load(g + 1);              // the next stage's loads fly during this stage's MFMAs
+        auto chunk = [&](int t, int toff) {
+            u32x4 af[MT], bfr[NT];
 #pragma unroll
-        for (int t = 0; t < CPS; ++t) {
-            const int chunk = g * CPS + t;
-            u32x4 an[MT];
-            const size_t nx = (size_t)min(chunk + 1, nchunks - 1) * wstride;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) an[m] = wbase[nx + (size_t)m * 64];
-            int toff;
-            if constexpr (MODE == 0) {
-                toff = t * LW * PXB;                         // filter row t; the lane's kx = kk is in nbase
-            } else if constexpr (MODE == 1) {
-                int tap = 2 * t + (kk >> 1);
-                tap = tap < TAPS ? tap : TAPS - 1;           // padded slot: zero weights, finite data
-                const int ky = tap / KW, kx = tap - ky * KW;
-                toff = (ky * LW + kx) * PXB;
-            } else {
-                constexpr int dummy = 0; (void)dummy;
-                const int ky = t / KW, kx = t - ky * KW;
-                toff = (ky * LW + kx) * PXB;
-            }
-            u32x4 bfr[NT];
+            for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const u32x4*>(wlds + ((t * MTB + wm * MT + m) * 64 + lane) * 16);
 #pragma unroll
             for (int n = 0; n < NT; ++n) bfr[n] = *reinterpret_cast<const u32x4*>(lds + nbase[n] + toff);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[m][n] = mfma_bf16_k32(af[m], bfr[n], acc[m][n]);
+        };
+        if constexpr (MODE == 0) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) af[m] = an[m];
+            for (int t = 0; t < CPS; ++t) chunk(t, t * LW * PXB);        // filter row t; the lane's kx = kk is in nbase
+        } else if constexpr (MODE == 1) {
+#pragma unroll
+            for (int t = 0; t < CPS; ++t) {
+                int tap = 2 * t + (kk >> 1);
+                tap = tap < TAPS ? tap : TAPS - 1;                       // padded slot: zero weights, finite data
+                const int ky = tap / KW, kx = tap - ky * KW;
+                chunk(t, (ky * LW + kx) * PXB);
+            }
+        } else {
+            // one filter row per iteration of a rolled loop: fully unrolled, all 9 (16) chunks' fragment reads are hoisted to the
+            // front and the kernel needs ~250 VGPRs (one block per SIMD)
+            if constexpr (MT * NT >= 16) {                   // 40 registers of fragments per chunk: one chunk per iteration
+#pragma unroll 1
+                for (int ky = 0; ky < KH; ++ky)
+#pragma unroll 1
+                    for (int kx = 0; kx < KW; ++kx) chunk(ky * KW + kx, (ky * LW + kx) * PXB);
+            } else {
+#pragma unroll 1
+                for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < KW; ++kx) chunk(ky * KW + kx, (ky * LW + kx) * PXB);
+            }
         }
     }
 
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
         const f32x4 b4 = cok ? *reinterpret_cast<const f32x4*>(a.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const int id = wave * NT + n;
+            const int id = wn * NT + n;
             const int y = y0 + (id >> 1), x = x0 + (id & 1) * 16 + j;
             const bool ok = cok && y < H && x < W;
             const size_t p = ((size_t)min(y, H - 1) * W + min(x, W - 1)) * cout + (cok ? c : 0);
@@ -213,7 +230,7 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 if (n & 2) continue;
-                const int id = wave * NT + n;
+                const int id = wn * NT + n;
                 const int y = y0 + (id >> 1), x = x0 + (id & 1) * 16 + j;
                 f32x4 mm = (y + 1 < H) ? max4(acc[m][n], acc[m][n + 2]) : acc[m][n];
                 const f32x4 nb = f32x4{lane_xor1(mm.x), lane_xor1(mm.y), lane_xor1(mm.z), lane_xor1(mm.w)};
