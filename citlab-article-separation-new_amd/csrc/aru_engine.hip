@@ -60,6 +60,16 @@ struct asep_aru {
     std::map<std::string, PackedConv> convs;   // keyed by variable scope, e.g. "aru_net/featMapG/unet_down_1/convR_0"
     struct ResB { int C = 0; bf16_t* d_w = nullptr; float* d_b = nullptr; };
     std::map<std::string, ResB> resb;          // bf16 path: fused residual-block tails (8- / 16-channel levels), keyed by block scope
+    // bf16 path, whole level-0 blocks in one kernel each (res8b_kernel): pixel-pair A fragments
+    bf16_t* d_r8b_down_w = nullptr;  // [3 convs][3 ky][64][8]
+    float* d_r8b_down_b = nullptr;   // [3][8]
+    bf16_t* d_r8b_up_w1 = nullptr;   // conv1 of unet_up_0 [3 ky][2 halves][64][8]
+    bf16_t* d_r8f_down_w1 = nullptr; // conv1 of unet_down_0 as ONE pair fragment [64][8] (k = window row / column, res8f_kernel)
+    bool use_r8f = true;             // ASEP_BF_R8F=0: res8b_kernel for every tile
+    bf16_t* d_r8b_up_w = nullptr;    // [3][3][64][8]
+    float* d_r8b_up_b = nullptr;     // [3][8]
+    float* d_r8b_up_b1 = nullptr;    // [8]
+    bool use_r8b = true;             // ASEP_BF_R8B=0: conv1 + resb_tail_kernel<8> instead
     DirectConv det_first, att_first;
     // fused level-0 residual blocks (feat_root == 8, res_depth == 3): pixel-pair MFMA fragments
     float* d_r8_down_wr = nullptr;   // [3][6][64][4]
@@ -942,6 +952,130 @@ int pack_resb(asep_aru* m, const std::map<std::string, HostTensor>& blob, const 
     return ASEP_OK;
 }
 
+// pixel-pair A fragments of a 3x3 conv with 8 output channels for res8b_kernel: row m = (pixel parity e, cout), one fragment
+// per filter row (and per half of the 4-pixel window when there are 16 input channels): k = 8 kk + j.
+//   cin 8:  window pixel p = kk, ci = j;   cin 16: window pixel p = 2 half + (kk >> 1), ci = 8 (kk & 1) + j;   kx = p - e
+void pack_pair_frags(const HostTensor& w, int cin, std::vector<bf16_t>& dst) {
+    const int halves = cin == 16 ? 2 : 1;
+    for (int ky = 0; ky < 3; ++ky)
+        for (int hf = 0; hf < halves; ++hf)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int m = lane & 15, kk = lane >> 4, e = m >> 3, co = m & 7;
+                    const int p = cin == 16 ? 2 * hf + (kk >> 1) : kk;
+                    const int ci = cin == 16 ? (kk & 1) * 8 + j : j;
+                    const int kx = p - e;
+                    dst.push_back(f2bf((kx >= 0 && kx <= 2) ? w.data[(((size_t)ky * 3 + kx) * cin + ci) * 8 + co] : 0.f));
+                }
+}
+
+int pack_res8b(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
+    auto tail = [&](const std::string& scope, bf16_t** d_w, float** d_b) -> int {
+        std::vector<bf16_t> pk;
+        std::vector<float> br;
+        for (int r = 0; r < 3; ++r) {
+            auto wi = blob.find(scope + "/convR_" + std::to_string(r) + "/weights");
+            auto bi = blob.find(scope + "/convR_" + std::to_string(r) + "/biases");
+            if (wi == blob.end() || bi == blob.end()) { set_error("weights: missing %s/convR_%d", scope.c_str(), r); return ASEP_ERR_WEIGHTS; }
+            const HostTensor& w = wi->second;
+            if (w.dims.size() != 4 || w.dims[0] != 3 || w.dims[1] != 3 || w.dims[2] != 8 || w.dims[3] != 8) return 1;   // other shape: generic kernels
+            pack_pair_frags(w, 8, pk);
+            br.insert(br.end(), bi->second.data.begin(), bi->second.data.end());
+        }
+        int rc = upload_bf(pk, d_w);
+        if (!rc) rc = upload(br, d_b);
+        if (rc) return rc;
+        m->owned.push_back(*d_w);
+        m->owned.push_back(*d_b);
+        return ASEP_OK;
+    };
+    int rc = tail("aru_net/featMapG/unet_down_0", &m->d_r8b_down_w, &m->d_r8b_down_b);
+    if (rc == 1) { m->d_r8b_down_w = nullptr; return ASEP_OK; }
+    if (rc) return rc;
+    {
+        // conv1 (1 -> 8) as one pair fragment: row m = (parity e, cout); k = 8 kk + jj: window row 2 kk + (jj >> 2) (kk < 2), column jj & 3
+        auto w1 = blob.find("aru_net/featMapG/unet_down_0/conv1/weights");
+        if (w1 != blob.end() && w1->second.dims.size() == 4 && w1->second.dims[0] == 3 && w1->second.dims[1] == 3 && w1->second.dims[2] == 1 &&
+            w1->second.dims[3] == 8) {
+            std::vector<bf16_t> pk;
+            for (int lane = 0; lane < 64; ++lane)
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int mrow = lane & 15, kk = lane >> 4, e = mrow >> 3, co = mrow & 7;
+                    const int ky = 2 * kk + (jj >> 2), kx = (jj & 3) - e;
+                    pk.push_back(f2bf((kk < 2 && ky <= 2 && kx >= 0 && kx <= 2) ? w1->second.data[(size_t)(ky * 3 + kx) * 8 + co] : 0.f));
+                }
+            rc = upload_bf(pk, &m->d_r8f_down_w1);
+            if (rc) return rc;
+            m->owned.push_back(m->d_r8f_down_w1);
+        }
+    }
+    if (m->cfg.scale_space_num > 1) {
+        const std::string u = "aru_net/featMapG/unet_up_0";
+        auto w1 = blob.find(u + "/conv1/weights");
+        auto b1 = blob.find(u + "/conv1/biases");
+        if (w1 == blob.end() || b1 == blob.end()) { set_error("weights: missing %s/conv1", u.c_str()); return ASEP_ERR_WEIGHTS; }
+        const HostTensor& w = w1->second;
+        if (w.dims.size() != 4 || w.dims[0] != 3 || w.dims[1] != 3 || w.dims[2] != 16 || w.dims[3] != 8) return ASEP_OK;
+        rc = tail(u, &m->d_r8b_up_w, &m->d_r8b_up_b);
+        if (rc == 1) { m->d_r8b_up_w = nullptr; return ASEP_OK; }
+        if (rc) return rc;
+        std::vector<bf16_t> pk;
+        pack_pair_frags(w, 16, pk);
+        rc = upload_bf(pk, &m->d_r8b_up_w1);
+        if (!rc) rc = upload(b1->second.data, &m->d_r8b_up_b1);
+        if (rc) return rc;
+        m->owned.push_back(m->d_r8b_up_w1);
+        m->owned.push_back(m->d_r8b_up_b1);
+    }
+    return ASEP_OK;
+}
+
+Tensor new_tensor_bf(asep_aru* m, int H, int W, int C);
+
+// whole level-0 blocks of the bf16 path (res8b_kernel)
+void run_res8b(asep_aru* m, bool up, const TL& a0, const TL* a1, const std::vector<const float*>& stats, bool want_pool, TL* d_out, TL* pool_out) {
+    for (const Tensor& t : a0) {
+        d_out->push_back(new_tensor_bf(m, t.H, t.W, 8));
+        if (want_pool) pool_out->push_back(new_tensor_bf(m, cdiv(t.H, 2), cdiv(t.W, 2), 8));
+    }
+    for (size_t b0 = 0; b0 < a0.size(); b0 += MAXP) {
+        const size_t b1 = std::min(a0.size(), b0 + MAXP);
+        Res8BArgs a{};
+        int tiles = 0;
+        double flops = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            Res8BProb& p = a.p[i - b0];
+            if (up) { p.skip = a0[i].bp(); p.dec = (*a1)[i].bp(); }
+            else { p.img = a0[i].p; p.stats = stats.empty() ? nullptr : stats[i]; }
+            p.out = (*d_out)[i].bp(); p.pool = want_pool ? (*pool_out)[i].bp() : nullptr;
+            p.H = a0[i].H; p.W = a0[i].W;
+            p.tiles_x = cdiv(a0[i].W, 32);
+            p.tile_begin = tiles;
+            tiles += p.tiles_x * cdiv(a0[i].H, 16);
+            flops += 2.0 * a0[i].H * a0[i].W * (9.0 * (up ? 16 : 1) * 8 + 3 * 9.0 * 64);
+        }
+        a.nprob = (int)(b1 - b0);
+        if (up) { a.w1pk = (const u32x4*)m->d_r8b_up_w1; a.b1 = m->d_r8b_up_b1; a.wpk = (const u32x4*)m->d_r8b_up_w; a.bias = m->d_r8b_up_b; }
+        else { a.w1 = m->det_first.d_w; a.b1 = m->det_first.d_b; a.wpk = (const u32x4*)m->d_r8b_down_w; a.bias = m->d_r8b_down_b; }
+        TL sub(a0.begin() + b0, a0.begin() + b1);
+        const std::string what = (up ? "unet_up_0 (conv1[16->8]+3xconvR+add) " : "unet_down_0 (conv1+3xconvR+add+pool) ") + dims_of(sub);
+        const bool fast = m->use_r8f && (up || m->d_r8f_down_w1);
+        if (fast) {
+            // interior tiles (their 24 x 40 input window inside the image): the lean kernel; it returns at once on border tiles,
+            // res8b_kernel (border_only) on interior ones.  The FLOPs are credited to the first launch.
+            Res8BArgs f = a;
+            if (!up) f.w1pk = (const u32x4*)m->d_r8f_down_w1;
+            ProfScope ps(m, up ? "res8f_kernel<true>" : "res8f_kernel<false>", flops, what);
+            if (up) hipLaunchKernelGGL(res8f_kernel<true>, dim3(tiles), dim3(256), 0, m->stream, f);
+            else hipLaunchKernelGGL(res8f_kernel<false>, dim3(tiles), dim3(256), 0, m->stream, f);
+        }
+        a.border_only = fast ? 1 : 0;
+        ProfScope ps(m, up ? "res8b_kernel<true>" : "res8b_kernel<false>", fast ? 0.0 : flops, what + (fast ? " border tiles" : ""));
+        if (up) hipLaunchKernelGGL(res8b_kernel<true>, dim3(tiles), dim3(256), 0, m->stream, a);
+        else hipLaunchKernelGGL(res8b_kernel<false>, dim3(tiles), dim3(256), 0, m->stream, a);
+    }
+}
+
 Tensor new_tensor_bf(asep_aru* m, int H, int W, int C) {
     Tensor t;
     t.H = H; t.W = W; t.C = C; t.bf = true;
@@ -1189,6 +1323,14 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
     };
     for (int l = 0; l < n; ++l) {
         const std::string scope = "aru_net/featMapG/unet_down_" + std::to_string(l);
+        if (m->bf16 && l == 0 && m->use_r8b && m->d_r8b_down_w && m->det_first.k == 3 && m->det_first.cout == 8) {
+            TL d, pooled;                                    // the whole block in one kernel: image -> d0 (+ pool)
+            run_res8b(m, false, imgs, nullptr, stats, n > 1, &d, &pooled);
+            skips.push_back(d);
+            publish(d, "_unet_down_0_conv");
+            u = n > 1 ? pooled : d;
+            continue;
+        }
         if (m->bf16) {
             // native bf16 path: conv1 -> t (bf16), then the block tail (one kernel at 8 / 16 channels, three convs above)
             TL t = (l == 0) ? run_direct_bf(m, m->det_first, imgs, stats) : run_convb(m, scope + "/conv1", u, nullptr, false, false, nullptr);
@@ -1220,7 +1362,11 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
         const TL& skip = skips[l];
         TL v = m->bf16 ? run_deconvb(m, scope + "/deconv", u, skip, true) : run_deconv(m, scope + "/deconv", u, skip, true);
         publish(v, "_unet_up_" + std::to_string(l) + "_deconv");
-        if (m->bf16) {
+        if (m->bf16 && l == 0 && m->use_r8b && m->d_r8b_up_w1) {
+            TL d, none;                                      // conv1 over [skip, deconv] + the tail in one kernel
+            run_res8b(m, true, skip, &v, {}, false, &d, &none);
+            u = d;
+        } else if (m->bf16) {
             TL t = run_convb(m, scope + "/conv1", skip, &v, false, false, nullptr);   // concat [skip, deconv]
             u = res_block_tail(m, scope, t);
         } else if (l == 0 && m->use_fused8 && m->d_r8_up_w1) {
@@ -1510,6 +1656,8 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_BIGTILE")) m->big_tile = atoi(e) != 0;
     if (const char* e = getenv("ASEP_SIDE_STREAM")) m->use_side_stream = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_TH8")) m->bf_th8 = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_BF_R8B")) m->use_r8b = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_BF_R8F")) m->use_r8f = atoi(e) != 0;
     if (const char* e = getenv("ASEP_LANES")) m->num_lanes = std::max(1, std::min(4, atoi(e)));
     for (int l = 0; l < m->num_lanes; ++l) {
         std::unique_ptr<asep_aru::Lane> L(new asep_aru::Lane());
@@ -1556,6 +1704,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
             rc = pack_conv(m.get(), blob, s + "/convR_" + std::to_string(r), "biases", false);
     }
     if (!rc && !m->bf16 && cfg->feat_root == 8 && cfg->res_depth == 3 && m->det_first.k == 3) rc = pack_res8(m.get(), blob);
+    if (!rc && m->bf16 && cfg->res_depth == 3 && cfg->feat_root == 8) rc = pack_res8b(m.get(), blob);
     if (!rc && m->bf16 && cfg->res_depth == 3)
         for (int l = 0; l < n && !rc; ++l) {
             const int f = cfg->feat_root << l;

@@ -16,6 +16,8 @@
 // channels (32 bytes per pixel): the ds_read_b128 lane groups of gfx950 ({0-3,12-15,20-27}, ...) then hit 64 distinct banks
 // (MI355X_MICROARCH.md, LDS table) -- no swizzle needed, unlike the 64-byte fp32 records of the fp32 path.
 #pragma once
+#include <type_traits>
+
 #include "aru_kernels.h"
 
 namespace asep {
@@ -554,6 +556,484 @@ __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
         const int y = 2 * Y0 - P.pbh + orow, x = 2 * X0 - P.pbw + ocol;
         if (y >= 0 && y < P.Ho && x >= 0 && x < P.Wo && sub * 8 < nvalid)
             *reinterpret_cast<u32x4*>(P.out + ((size_t)y * P.Wo + x) * a.cout + mt0 * 16 + sub * 8) = *reinterpret_cast<const u32x4*>(otile + u * 16);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// res8b_kernel<UP>: a WHOLE level-0 residual block (8 channels) of the bf16 path in one kernel.
+//   UP = false (unet_down_0, ARU_v1.py:208-245): t = conv3x3(image, 1 -> 8); r = relu(t); r = relu(convR_0 r); r = relu(convR_1 r);
+//                d0 = relu(convR_2 r + t); also maxpool2(d0).         HBM: fp32 image in, bf16 d0 + pool out.
+//   UP = true  (unet_up_0, ARU_v1.py:251-292): t = conv3x3([skip, deconv], 16 -> 8), then the same tail.   HBM: 2 x 8 ch in, 8 out.
+// (layer by layer the block moves 5 / 6 tensors of 4500 x 3000 x 8 through HBM; the level holds 60 % of the net's activation bytes)
+// Block = 16 x 32 output pixels.  All 8 -> 8 products use the PIXEL-PAIR mapping: M = 2 adjacent pixels x 8 output channels,
+// N = 16 pairs (32 consecutive pixels of the flattened stage region), K = one filter row = 4 window pixels x 8 channels, so a conv
+// is 3 MFMAs per 32 pixels with 75 % of the multipliers useful, every lane of the D tile holds 4 channels of one pixel, and a
+// lane's B fragment is still ONE 16-byte LDS read (window pixel 2n + kk).  conv1 of the up block is the same with K = 4 pixels x
+// 16 channels = two MFMAs per filter row; conv1 of the down block (one input channel) runs on the vector ALU.
+// Regions (flattened, row-major): t 22 x 38 -> stage 1 20 x 36 -> stage 2 18 x 34 -> out 16 x 32; positions outside the image hold
+// zeros (SAME padding of every conv); the pre-ReLU t of the centre goes to its own LDS tile for the residual add.
+// ------------------------------------------------------------------------------------------------
+struct Res8BProb {
+    const float* img;      // DOWN: [H,W] fp32 image (pyramid level)
+    const float* stats;    // DOWN: {mean, 1/std} or nullptr
+    const bf16_t* skip;    // UP: [H,W,8]
+    const bf16_t* dec;     // UP: [H,W,8] deconv output
+    bf16_t* out;           // [H,W,8]
+    bf16_t* pool;          // DOWN: maxpool2(out) or nullptr
+    int H, W;
+    int tiles_x, tile_begin;
+};
+struct Res8BArgs {
+    Res8BProb p[MAXP];
+    int nprob;
+    const float* w1;       // DOWN: conv1 [9][8] fp32
+    const float* b1;       // conv1 bias [8]
+    const u32x4* w1pk;     // UP: conv1 pair fragments [ky 3][half 2][64 lanes] x 16 bytes; res8f_kernel DOWN: [64 lanes] (bf16 conv1)
+    int border_only;       // res8b_kernel: skip the tiles res8f_kernel serves (interior tiles)
+    const u32x4* wpk;      // tail: [3 convs][ky 3][64 lanes] x 16 bytes
+    const float* bias;     // tail biases [3][8]
+};
+
+template <bool UP>
+__global__ __launch_bounds__(256, UP ? 3 : 4) void res8b_kernel(const Res8BArgs a) {
+    constexpr int TH = 16, TW = 32;
+    constexpr int H0 = TH + 6, W0 = TW + 6, H1 = TH + 4, W1 = TW + 4, H2 = TH + 2, W2 = TW + 2;
+    constexpr int IH = TH + 8, IW = TW + 8;                   // conv1's input tile (halo 4)
+    constexpr int SLACK = 4;                                  // pixels a zero-weight window column / a clamped tail lane may read past a region
+    constexpr int R0B = (H0 * W0 + SLACK) * 16, R1B = (H1 * W1 + SLACK) * 16, TCB = TH * TW * 16;
+    constexpr int INB = UP ? (IH * IW + SLACK) * 32 : IH * IW * 4;
+    // stage 1's result may take the place of conv1's input tile (dead by then)
+    constexpr int R1_OFF = 0, IN_OFF = 0, R0_OFF = (INB > R1B ? INB : R1B), TC_OFF = R0_OFF + R0B;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[TC_OFF + TCB];
+    unsigned char* const r0 = lds + R0_OFF;
+    unsigned char* const r1 = lds + R1_OFF;
+    unsigned char* const tc = lds + TC_OFF;
+    unsigned char* const in = lds + IN_OFF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4, e = kk >> 1, ch = (kk & 1) * 4;     // D layout: pixel parity e, channels ch .. ch + 3
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    const Res8BProb& P = a.p[pi];
+    const int tile = blockIdx.x - P.tile_begin;
+    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int H = P.H, W = P.W;
+    // the whole conv1 input window lies inside the image: no position of any stage needs the zero test
+    const bool interior = y0 - 4 >= 0 && y0 + TH + 4 <= H && x0 - 4 >= 0 && x0 + TW + 4 <= W;
+    if (interior && a.border_only) return;
+
+    // ---- conv1 input tile -> LDS ----
+    if constexpr (UP) {
+        constexpr int NU = IH * IW * 2, NLOAD = (NU + 255) / 256;
+        u32x4 st[NLOAD];
+        unsigned mask = 0;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int u = min(tid + i * 256, NU - 1);
+            const int pix = u >> 1, sub = u & 1;
+            const int ly = pix / IW, lx = pix - ly * IW;
+            const int gy = y0 - 4 + ly, gx = x0 - 4 + lx;
+            const bf16_t* __restrict__ src = sub ? P.dec : P.skip;
+            st[i] = *reinterpret_cast<const u32x4*>(src + ((size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * 8);
+            mask |= ((gy >= 0 && gy < H && gx >= 0 && gx < W) ? 1u : 0u) << i;
+        }
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int u = tid + i * 256;
+            if (u < NU) *reinterpret_cast<u32x4*>(in + u * 16) = ((mask >> i) & 1u) ? st[i] : u32x4{0u, 0u, 0u, 0u};
+        }
+        if (tid < 2 * SLACK) *reinterpret_cast<u32x4*>(in + (NU + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
+    } else {
+        constexpr int NLOAD = (IH * IW + 255) / 256;
+        float st[NLOAD];
+        float mean = 0.f, inv = 1.f;
+        if (P.stats) { mean = P.stats[0]; inv = P.stats[1]; }
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int u = min(tid + i * 256, IH * IW - 1);
+            const int ly = u / IW, lx = u - ly * IW;
+            st[i] = P.img[(size_t)min(max(y0 - 4 + ly, 0), H - 1) * W + min(max(x0 - 4 + lx, 0), W - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int u = tid + i * 256;
+            if (u < IH * IW) {
+                const int ly = u / IW, lx = u - ly * IW;
+                const int gy = y0 - 4 + ly, gx = x0 - 4 + lx;
+                reinterpret_cast<float*>(in)[u] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (st[i] - mean) * inv : 0.f;
+            }
+        }
+    }
+    if (tid < SLACK) *reinterpret_cast<u32x4*>(r0 + (H0 * W0 + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
+    const u32x4* __restrict__ wl = a.wpk + lane;
+    u32x4 af[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) af[t] = wl[t * 64];           // convR_0's fragments fly during conv1
+    __syncthreads();
+
+    // ---- conv1 -> relu(t) over the 22 x 38 region (r0), raw t of the centre (tc) ----
+    if constexpr (UP) {
+        u32x4 a1[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) a1[t] = a.w1pk[t * 64 + lane];
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b1 + ch);
+        constexpr int NPIX = H0 * W0;
+        // the lane's pixel q = 32 tl + 2 j + e walks the flattened region in steps of 128: (py, px) are updated incrementally
+        // (no division in the loop); the pair of its B operand starts at q - e in the same row (the region widths are even)
+        auto conv1_loop = [&](auto interior_c) {
+            constexpr bool INT = decltype(interior_c)::value;
+            int q = wave * 32 + 2 * j + e;
+            int py = q / W0, px = q - py * W0;
+            for (; q - 2 * j - e < NPIX; q += 128) {
+                const int cpy = q < NPIX ? py : H0 - 1, cpx = q < NPIX ? px : W0 - 2 + e;   // tail tile: clamp to the last pair
+                const int base = (cpy * IW + cpx - e) * 32 + (kk >> 1) * 32 + (kk & 1) * 16;
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+                        acc = mfma_bf16_k32(a1[ky * 2 + hf], *reinterpret_cast<const u32x4*>(in + base + (ky * IW + 2 * hf) * 32), acc);
+                f32x4 v = acc + b4;
+                if constexpr (!INT) {
+                    const int gy = y0 - 3 + py, gx = x0 - 3 + px;
+                    if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                if (q < NPIX) {
+                    *reinterpret_cast<u32x2*>(r0 + q * 16 + ch * 2) = pack_bf16x4(relu4(v));
+                    const int cy = py - 3, cx = px - 3;
+                    if ((unsigned)cy < (unsigned)TH && (unsigned)cx < (unsigned)TW) *reinterpret_cast<u32x2*>(tc + (cy * TW + cx) * 16 + ch * 2) = pack_bf16x4(v);
+                }
+                px += 128 % W0; py += 128 / W0;
+                if (px >= W0) { px -= W0; ++py; }
+            }
+        };
+        if (interior) conv1_loop(std::true_type{}); else conv1_loop(std::false_type{});
+    } else {
+        typedef const float __attribute__((address_space(4)))* cptr;
+        cptr w1 = (cptr)a.w1;
+        cptr b1 = (cptr)a.b1;
+        const float* img = reinterpret_cast<const float*>(in);
+        for (int p = tid; p < H0 * W0; p += 256) {
+            const int ly = p / W0, lx = p - ly * W0;
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = b1[c];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float x = img[(ly + ky) * IW + lx + kx];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = fmaf(x, w1[(ky * 3 + kx) * 8 + c], v[c]);
+                }
+            const int gy = y0 - 3 + ly, gx = x0 - 3 + lx;
+            const bool inside = interior || (gy >= 0 && gy < H && gx >= 0 && gx < W);
+            if (!inside) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = 0.f;
+            }
+            const u32x4 raw = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            *reinterpret_cast<u32x4*>(r0 + p * 16) = relu_bf16x8(raw);
+            const int cy = ly - 3, cx = lx - 3;
+            if (cy >= 0 && cy < TH && cx >= 0 && cx < TW) *reinterpret_cast<u32x4*>(tc + (cy * TW + cx) * 16) = raw;
+        }
+    }
+    __syncthreads();
+    if (tid < SLACK) *reinterpret_cast<u32x4*>(r1 + (H1 * W1 + tid) * 16) = u32x4{0u, 0u, 0u, 0u};   // (r1 may overlay conv1's input)
+
+    // ---- stages 1 and 2: LDS -> LDS, n-tile = 32 consecutive pixels (16 pairs) of the flattened output region ----
+    auto mid_stage = [&](auto interior_c, const unsigned char* src, auto win_c, unsigned char* dst, auto ho_c, int halo, const float* bias) {
+        constexpr bool INT = decltype(interior_c)::value;
+        constexpr int WIN = decltype(win_c)::value, HO = decltype(ho_c)::value, WO = WIN - 2, npix = HO * WO;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + ch);
+        int q = wave * 32 + 2 * j + e;
+        int py = q / WO, px = q - py * WO;
+        for (; q - 2 * j - e < npix; q += 128) {
+            const int cpy = q < npix ? py : HO - 1, cpx = q < npix ? px : WO - 2 + e;      // tail tile: clamp to the last pair
+            const int base = (cpy * WIN + cpx - e + kk) * 16;                  // window pixel kk of the pair's 4-pixel window, filter row 0
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) acc = mfma_bf16_k32(af[ky], *reinterpret_cast<const u32x4*>(src + base + ky * WIN * 16), acc);
+            f32x4 v = relu4(acc + b4);
+            if constexpr (!INT) {
+                const int gy = y0 - halo + py, gx = x0 - halo + px;
+                if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (q < npix) *reinterpret_cast<u32x2*>(dst + q * 16 + ch * 2) = pack_bf16x4(v);
+            px += 128 % WO; py += 128 / WO;
+            if (px >= WO) { px -= WO; ++py; }
+        }
+    };
+    auto mid = [&](const unsigned char* src, auto win_c, unsigned char* dst, auto ho_c, int halo, const float* bias) {
+        if (interior) mid_stage(std::true_type{}, src, win_c, dst, ho_c, halo, bias);
+        else mid_stage(std::false_type{}, src, win_c, dst, ho_c, halo, bias);
+    };
+    mid(r0, std::integral_constant<int, W0>{}, r1, std::integral_constant<int, H1>{}, 2, a.bias);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) af[t] = wl[(3 + t) * 64];
+    __syncthreads();
+    mid(r1, std::integral_constant<int, W1>{}, r0, std::integral_constant<int, H2>{}, 1, a.bias + 8);   // the t region is dead: its space takes stage 2's result
+#pragma unroll
+    for (int t = 0; t < 3; ++t) af[t] = wl[(6 + t) * 64];
+    __syncthreads();
+
+    // ---- stage 3: one n-tile = one row of the output tile; a wave takes row pairs (2x2 pool in registers) ----
+    {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 16 + ch);
+        const int Wp = (W + 1) >> 1;
+        const int x = x0 + 2 * j + e;
+        for (int rp = wave; rp < TH / 2; rp += 4) {
+            f32x4 v2[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int oy = 2 * rp + r;
+                const int base = (oy * W2 + 2 * j + kk) * 16;
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) acc = mfma_bf16_k32(af[ky], *reinterpret_cast<const u32x4*>(r0 + base + ky * W2 * 16), acc);
+                const f32x4 tres = unpack_bf16x4(*reinterpret_cast<const u32x2*>(tc + (oy * TW + 2 * j + e) * 16 + ch * 2));
+                const f32x4 v = relu4(acc + b4 + tres);
+                const u32x2 pk = pack_bf16x4(v);
+                v2[r] = unpack_bf16x4(pk);
+                const int y = y0 + oy;
+                if (y < H && x < W) *reinterpret_cast<u32x2*>(P.out + ((size_t)y * W + x) * 8 + ch) = pk;
+            }
+            if (P.pool) {
+                // window = rows y, y + 1 (registers) x pixels 2j, 2j + 1 (this lane and lane ^ 32); out-of-image members are excluded
+                const int y = y0 + 2 * rp;
+                f32x4 mm = (y + 1 < H) ? max4(v2[0], v2[1]) : v2[0];
+                const bool xin = x < W;
+                f32x4 lo, hi;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float mine = xin ? mm[c] : -INFINITY;
+                    lo[c] = from_lower_half(mine);
+                    hi[c] = from_upper_half(mine);
+                }
+                mm = max4(lo, hi);
+                if (e == 0 && y < H && x < W) *reinterpret_cast<u32x2*>(P.pool + ((size_t)(y >> 1) * Wp + (x >> 1)) * 8 + ch) = pack_bf16x4(mm);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// res8f_kernel<UP>: the same block for INTERIOR tiles (the whole 24 x 40 input window inside the image: ~96 % of the tiles of
+// a 3000 x 4500 page), written for instruction count.  res8b_kernel issued ~5300 instructions per tile for 178 MFMAs (SQ
+// counters: 20 vector instructions per MFMA, the vector ALU issuing 80 % of the SIMD cycles with four waves per SIMD): its
+// flattened n-tiles need a division, clamps and an inside-the-image test per tile, conv1 of the down block ran as 72 FMAs per
+// pixel.  Here an n-tile is a ROW of a stage region (32 pixels = 16 pairs; the 2 .. 6 remaining pixels of several rows are
+// gathered into "remainder" tiles), so every LDS address is a per-lane constant plus a compile-time offset, no position is
+// outside the image, the bias is the accumulators' initial value, ReLU is one v_pk_max_i16 per two values AFTER the rounding
+// to bf16, and conv1 of the down block is ONE MFMA per 32 pixels on the image tile held as bf16 (K = 3 x 4 window values).
+// Border tiles are left to res8b_kernel (Res8BArgs::mode).
+// ------------------------------------------------------------------------------------------------
+template <bool UP>
+__global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs a) {
+    constexpr int TH = 16, TW = 32;
+    constexpr int H0 = TH + 6, W0 = TW + 6, H1 = TH + 4, W1 = TW + 4, W2 = TW + 2;
+    constexpr int IH = TH + 8, IW = TW + 8;
+    constexpr int INB = UP ? IH * IW * 32 : 2048;             // DOWN: bf16 image tile, (IH + 1) x IW x 2 bytes
+    constexpr int R1B = H1 * W1 * 16, R0B = H0 * W0 * 16, TCB = TH * TW * 16;
+    constexpr int R1_OFF = UP ? 0 : INB, R0_OFF = UP ? INB : INB + R1B, TC_OFF = R0_OFF + R0B;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[TC_OFF + TCB];
+    unsigned char* const in = lds;
+    unsigned char* const r1 = lds + R1_OFF;
+    unsigned char* const r0 = lds + R0_OFF;
+    unsigned char* const tc = lds + TC_OFF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4, e = kk >> 1, ch = (kk & 1) * 4;     // D layout: pixel parity e, channels ch .. ch + 3
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    const Res8BProb& P = a.p[pi];
+    const int tile = blockIdx.x - P.tile_begin;
+    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int H = P.H, W = P.W;
+    if (!(y0 - 4 >= 0 && y0 + TH + 4 <= H && x0 - 4 >= 0 && x0 + TW + 4 <= W)) return;      // border tile: res8b_kernel's
+
+    // ---- conv1 input tile -> LDS (no padding: the window is inside the image) ----
+    if constexpr (UP) {
+        constexpr int NU = IH * IW * 2, NLOAD = (NU + 255) / 256;
+        u32x4 st[NLOAD];
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int u = min(tid + i * 256, NU - 1);
+            const int pix = u >> 1, sub = u & 1;
+            const int ly = pix / IW, lx = pix - ly * IW;
+            st[i] = *reinterpret_cast<const u32x4*>((sub ? P.dec : P.skip) + ((size_t)(y0 - 4 + ly) * W + x0 - 4 + lx) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int u = tid + i * 256;
+            if (u < NU) *reinterpret_cast<u32x4*>(in + u * 16) = st[i];
+        }
+    } else {
+        constexpr int NLOAD = (IH * IW + 255) / 256;
+        float st[NLOAD];
+        float mean = 0.f, inv = 1.f;
+        if (P.stats) { mean = P.stats[0]; inv = P.stats[1]; }
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int u = min(tid + i * 256, IH * IW - 1);
+            const int ly = u / IW, lx = u - ly * IW;
+            st[i] = P.img[(size_t)(y0 - 4 + ly) * W + x0 - 4 + lx];
+        }
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int u = tid + i * 256;
+            if (u < IH * IW) reinterpret_cast<bf16_t*>(in)[u] = (bf16_t)(pack_bf16x2((st[i] - mean) * inv, 0.f) & 0xffffu);
+        }
+        if (tid < IW / 2) reinterpret_cast<unsigned*>(in)[IH * IW / 2 + tid] = 0u;     // row IH: read with zero weights, must be finite
+    }
+    const u32x4* __restrict__ wl = a.wpk + lane;
+    u32x4 af[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) af[t] = wl[t * 64];           // convR_0's fragments fly during conv1
+
+    // remainder tiles: lane j -> (row rr of the tile's row group, pair pc) for PR pairs per row
+    const int j3 = j / 3, rr3 = min(j3, 4), pc3 = j - j3 * 3;  // conv1 / region 0: 6 pixels = 3 pairs, 5 rows per tile (lane 15 idle)
+    const int rr2 = j >> 1, pc2 = j & 1;                      // stage 1: 4 pixels = 2 pairs, 8 rows per tile
+    const int c = 2 * j + e;                                  // the lane's pixel column in a main tile
+    auto relu_pk = [](u32x2 p) { return u32x2{relu_bf16x2(p.x), relu_bf16x2(p.y)}; };
+    __syncthreads();
+
+    // ---- conv1: relu(t) over the 22 x 38 region (r0), raw t of the centre 16 x 32 (tc) ----
+    {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b1 + ch);
+        u32x4 a1[UP ? 6 : 1];
+#pragma unroll
+        for (int t = 0; t < (UP ? 6 : 1); ++t) a1[t] = a.w1pk[t * 64 + lane];
+        // window of the pair whose first pixel is (row, col) of region 0 = input-tile pixels (row .. row + 2, col .. col + 3)
+        auto conv1 = [&](int row, int col) {
+            f32x4 acc = b4;
+            if constexpr (UP) {
+                const unsigned char* p = in + (row * IW * 32 + (col + (kk >> 1)) * 32 + (kk & 1) * 16);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) acc = mfma_bf16_k32(a1[ky * 2 + hf], *reinterpret_cast<const u32x4*>(p + (ky * IW + 2 * hf) * 32), acc);
+            } else {
+                // k = 8 kk + jj: lane group kk holds window rows 2 kk, 2 kk + 1 (jj >> 2), columns jj & 3 (groups 2, 3: zero weights)
+                const unsigned* p = reinterpret_cast<const unsigned*>(in + ((row + 2 * (kk & 1)) * IW + col) * 2);
+                const u32x4 b = u32x4{p[0], p[1], p[IW / 2], p[IW / 2 + 1]};
+                acc = mfma_bf16_k32(a1[0], b, acc);
+            }
+            return acc;
+        };
+        // (per-lane base pointers + compile-time offsets: the addresses of the unrolled tiles are immediates)
+        unsigned char* const d0 = r0 + (wave * W0 + c) * 16 + ch * 2;
+        unsigned char* const dt = tc + ((wave - 3) * TW + c - 3) * 16 + ch * 2;
+#pragma unroll
+        for (int i = 0; i < (H0 + 3) / 4; ++i) {
+            const int r = wave + 4 * i;
+            if (r < H0) {
+                const u32x2 raw = pack_bf16x4(conv1(r, 2 * j));
+                *reinterpret_cast<u32x2*>(d0 + i * 4 * W0 * 16) = relu_pk(raw);
+                if (r >= 3 && r < 3 + TH && c >= 3) *reinterpret_cast<u32x2*>(dt + i * 4 * TW * 16) = raw;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                         // 5 remainder tiles of 5 rows (22 rows): waves 0 .. 3, then wave 0 again
+            const int t = wave + 4 * i;
+            if (t * 5 < H0) {
+                const int row = t * 5 + rr3, rowc = min(row, H0 - 1), col = 32 + 2 * pc3;
+                const u32x2 raw = pack_bf16x4(conv1(rowc, col));
+                if (row < H0 && j3 < 5) {
+                    *reinterpret_cast<u32x2*>(r0 + (row * W0 + col + e) * 16 + ch * 2) = relu_pk(raw);
+                    if (row >= 3 && row < 3 + TH && col + e < 3 + TW) *reinterpret_cast<u32x2*>(tc + ((row - 3) * TW + col + e - 3) * 16 + ch * 2) = raw;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stages 1 and 2 (LDS -> LDS): main tile = row r, columns 0 .. 31; remainder tiles = columns 32 .. WO - 1 of 16 / PR rows.
+    //      Tiles are processed in PAIRS: both tiles' fragment reads first, their MFMAs interleaved (two independent accumulator
+    //      chains), both epilogues -- written tile by tile the compiler serialises read -> wait -> MFMA chain -> epilogue per tile
+    //      and a wave has nothing to overlap its LDS / MFMA latencies with ----
+    auto conv8x2 = [&](const unsigned char* pa, const unsigned char* pb, int pitch, f32x4 c0, f32x4& ra, f32x4& rb) {
+        u32x4 fa[3], fb[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) { fa[ky] = *reinterpret_cast<const u32x4*>(pa + ky * pitch); fb[ky] = *reinterpret_cast<const u32x4*>(pb + ky * pitch); }
+        ra = c0; rb = c0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) { ra = mfma_bf16_k32(af[ky], fa[ky], ra); rb = mfma_bf16_k32(af[ky], fb[ky], rb); }
+    };
+    {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + ch);
+        const unsigned char* const sb = r0 + (wave * W0 + 2 * j + kk) * 16;
+        unsigned char* const db = r1 + (wave * W1 + c) * 16 + ch * 2;
+        // 20 rows: 5 main tiles per wave (i = 0 .. 4) + 3 remainder tiles of 8 rows (columns 32 .. 35; waves 0 .. 2)
+        const int row = wave * 8 + rr2, rowc = min(row, H1 - 1), col = 32 + 2 * pc2;
+        const unsigned char* const sr = r0 + (rowc * W0 + col + kk) * 16;
+        f32x4 va, vb;
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            conv8x2(sb + i * 4 * W0 * 16, sb + (i + 1) * 4 * W0 * 16, W0 * 16, b4, va, vb);
+            *reinterpret_cast<u32x2*>(db + i * 4 * W1 * 16) = relu_pk(pack_bf16x4(va));
+            *reinterpret_cast<u32x2*>(db + (i + 1) * 4 * W1 * 16) = relu_pk(pack_bf16x4(vb));
+        }
+        conv8x2(sb + 16 * W0 * 16, sr, W0 * 16, b4, va, vb);
+        *reinterpret_cast<u32x2*>(db + 16 * W1 * 16) = relu_pk(pack_bf16x4(va));
+        if (wave < 3 && row < H1) *reinterpret_cast<u32x2*>(r1 + (row * W1 + col + e) * 16 + ch * 2) = relu_pk(pack_bf16x4(vb));
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) af[t] = wl[(3 + t) * 64];
+    __syncthreads();
+    {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 8 + ch);
+        constexpr int HO = TH + 2;                            // 18 rows of 34: stage 2's result takes region 0's place (dead)
+        const unsigned char* const sb = r1 + (wave * W1 + 2 * j + kk) * 16;
+        unsigned char* const db = r0 + (wave * W2 + c) * 16 + ch * 2;
+        // 18 rows: 4 main tiles per wave + rows 16, 17 (waves 0, 1) + 2 remainder tiles of 16 rows (columns 32, 33; waves 2, 3):
+        // every wave has exactly one "fifth" tile
+        const int row = (wave - 2) * 16 + j, rowc = min(max(row, 0), HO - 1);
+        const unsigned char* const s5 = wave < 2 ? sb + 16 * W1 * 16 : r1 + (rowc * W1 + 32 + kk) * 16;
+        unsigned char* const d5 = wave < 2 ? db + 16 * W2 * 16 : r0 + (rowc * W2 + 32 + e) * 16 + ch * 2;
+        f32x4 va, vb;
+        conv8x2(sb, sb + 4 * W1 * 16, W1 * 16, b4, va, vb);
+        *reinterpret_cast<u32x2*>(db) = relu_pk(pack_bf16x4(va));
+        *reinterpret_cast<u32x2*>(db + 4 * W2 * 16) = relu_pk(pack_bf16x4(vb));
+        conv8x2(sb + 8 * W1 * 16, sb + 12 * W1 * 16, W1 * 16, b4, va, vb);
+        *reinterpret_cast<u32x2*>(db + 8 * W2 * 16) = relu_pk(pack_bf16x4(va));
+        *reinterpret_cast<u32x2*>(db + 12 * W2 * 16) = relu_pk(pack_bf16x4(vb));
+        conv8x2(s5, s5, W1 * 16, b4, va, vb);
+        if (wave < 2 || row < HO) *reinterpret_cast<u32x2*>(d5) = relu_pk(pack_bf16x4(va));
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) af[t] = wl[(6 + t) * 64];
+    __syncthreads();
+
+    // ---- stage 3: one tile = one row of the output tile; a wave takes row pairs (2x2 pool in registers) ----
+    {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 16 + ch);
+        const int Wp = (W + 1) >> 1;
+        bf16_t* __restrict__ out = P.out + ((size_t)(y0 + 2 * wave) * W + x0 + c) * 8 + ch;
+        const unsigned char* const sb = r0 + (2 * wave * W2 + 2 * j + kk) * 16;
+        const unsigned char* const tb = tc + (2 * wave * TW + c) * 16 + ch * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rp = wave + 4 * i;
+            f32x4 v2[2];
+            conv8x2(sb + 8 * i * W2 * 16, sb + (8 * i + 1) * W2 * 16, W2 * 16, b4, v2[0], v2[1]);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                // ReLU after the rounding: one v_pk_max_i16 per two values
+                const u32x2 pk = relu_pk(pack_bf16x4(v2[r] + unpack_bf16x4(*reinterpret_cast<const u32x2*>(tb + (8 * i + r) * TW * 16))));
+                v2[r] = unpack_bf16x4(pk);
+                *reinterpret_cast<u32x2*>(out + (size_t)(8 * i + r) * W * 8) = pk;
+            }
+            if (P.pool) {
+                f32x4 mm = max4(v2[0], v2[1]), lo, hi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { lo[q] = from_lower_half(mm[q]); hi[q] = from_upper_half(mm[q]); }
+                mm = max4(lo, hi);
+                if (e == 0) *reinterpret_cast<u32x2*>(P.pool + ((size_t)((y0 >> 1) + rp) * Wp + (x0 >> 1) + j) * 8 + ch) = pack_bf16x4(mm);
+            }
+        }
     }
 }
 
