@@ -1085,8 +1085,13 @@ Tensor new_tensor_bf(asep_aru* m, int H, int W, int C) {
 
 #define ASEP_CONVB_LAUNCH(KH_, KW_, MODE_, MT_, WM_, TH_, MB_)                                                         \
     do {                                                                                                               \
-        ps.set_name("convb_kernel" + targs({ti(KH_), ti(KW_), ti(MODE_), ti(MT_), ti(WM_), ti(TH_), ti(MB_)}));        \
-        hipLaunchKernelGGL((convb_kernel<KH_, KW_, MODE_, MT_, WM_, TH_, MB_>), grid, dim3(256), 0, m->stream, a);     \
+        ps.set_name("convb_kernel" + targs({ti(KH_), ti(KW_), ti(MODE_), ti(MT_), ti(WM_), ti(TH_), ti(MB_), tb(false)})); \
+        hipLaunchKernelGGL((convb_kernel<KH_, KW_, MODE_, MT_, WM_, TH_, MB_, false>), grid, dim3(256), 0, m->stream, a); \
+    } while (0)
+#define ASEP_CONVB_LAUNCH_RES(KH_, KW_, MODE_, MT_, WM_, TH_, MB_)                                                     \
+    do {                                                                                                               \
+        ps.set_name("convb_kernel" + targs({ti(KH_), ti(KW_), ti(MODE_), ti(MT_), ti(WM_), ti(TH_), ti(MB_), tb(true)})); \
+        hipLaunchKernelGGL((convb_kernel<KH_, KW_, MODE_, MT_, WM_, TH_, MB_, true>), grid, dim3(256), 0, m->stream, a); \
     } while (0)
 
 // stride-1 SAME conv of the bf16 path.  pooled != nullptr: the epilogue also writes maxpool2 of the output (always fused here);
@@ -1142,8 +1147,11 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
         dim3 grid(tiles, pc.mtiles / mtb);
         TL sub(in0.begin() + b0, in0.begin() + b1);
         ProfScope ps(m, "convb_kernel", flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
-        const int key = pc.kh * 100 + pc.bmode * 10 + mtb + (th == 8 && mtb == 2 ? 1000 : 0);
+        const int key = pc.kh * 100 + pc.bmode * 10 + mtb + (th == 8 && mtb == 2 ? 1000 : 0) + (res && pc.bmode == 2 && pc.kh == 3 && mtb >= 2 ? 2000 : 0);
         switch (key) {
+            case 3322: ASEP_CONVB_LAUNCH_RES(3, 3, 2, 2, 1, 8, 3); break;       // residual operand prefetched (32- and >= 64-channel convR_2)
+            case 2322: ASEP_CONVB_LAUNCH_RES(3, 3, 2, 2, 1, 16, 2); break;
+            case 2324: ASEP_CONVB_LAUNCH_RES(3, 3, 2, 2, 2, 8, 2); break;
             case 1322: ASEP_CONVB_LAUNCH(3, 3, 2, 2, 1, 8, 4); break;
             case 301: ASEP_CONVB_LAUNCH(3, 3, 0, 1, 1, 16, 3); break;
             case 302: ASEP_CONVB_LAUNCH(3, 3, 0, 2, 1, 16, 3); break;
@@ -1219,6 +1227,7 @@ TL run_deconvb(asep_aru* m, const std::string& scope, const TL& in, const TL& li
         out.push_back(new_tensor_bf(m, like[i].H, like[i].W, pc.cout));
     }
     const int mt = pc.mtiles % 2 == 0 ? 2 : 1;
+    const int dth = 8;                                       // input rows per block (16 rows for one m-tile measured slower: 148 -> 187 us at level 0)
     for (size_t b0 = 0; b0 < in.size(); b0 += MAXP) {
         const size_t b1 = std::min(in.size(), b0 + MAXP);
         DeconvBArgs a{};
@@ -1232,7 +1241,7 @@ TL run_deconvb(asep_aru* m, const std::string& scope, const TL& in, const TL& li
             p.pbw = std::max((in[i].W - 1) * 2 + 3 - out[i].W, 0) / 2;
             p.tiles_x = cdiv(in[i].W, DCB_TW);
             p.tile_begin = tiles;
-            tiles += p.tiles_x * cdiv(in[i].H, DCB_TH);
+            tiles += p.tiles_x * cdiv(in[i].H, dth);
             flops += 2.0 * in[i].H * in[i].W * 9.0 * pc.cin * pc.cout;
         }
         a.nprob = (int)(b1 - b0);
@@ -1240,12 +1249,12 @@ TL run_deconvb(asep_aru* m, const std::string& scope, const TL& in, const TL& li
         a.cin = pc.cin; a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.cin / 32; a.relu_out = relu_out;
         dim3 grid(tiles, pc.mtiles / mt);
         TL sub(in.begin() + b0, in.begin() + b1);
-        ProfScope ps(m, "deconvb_kernel" + targs({ti(pc.bmode), ti(mt)}), flops,
+        ProfScope ps(m, "deconvb_kernel" + targs({ti(pc.bmode), ti(mt), ti(dth)}), flops,
                      scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
-        if (pc.bmode == 1 && mt == 1) hipLaunchKernelGGL((deconvb_kernel<1, 1>), grid, dim3(256), 0, m->stream, a);
-        else if (pc.bmode == 1) hipLaunchKernelGGL((deconvb_kernel<1, 2>), grid, dim3(256), 0, m->stream, a);
-        else if (mt == 1) hipLaunchKernelGGL((deconvb_kernel<2, 1>), grid, dim3(256), 0, m->stream, a);
-        else hipLaunchKernelGGL((deconvb_kernel<2, 2>), grid, dim3(256), 0, m->stream, a);
+        if (pc.bmode == 1 && mt == 1) hipLaunchKernelGGL((deconvb_kernel<1, 1, 8>), grid, dim3(256), 0, m->stream, a);
+        else if (pc.bmode == 1) hipLaunchKernelGGL((deconvb_kernel<1, 2, 8>), grid, dim3(256), 0, m->stream, a);
+        else if (mt == 1) hipLaunchKernelGGL((deconvb_kernel<2, 1, 8>), grid, dim3(256), 0, m->stream, a);
+        else hipLaunchKernelGGL((deconvb_kernel<2, 2, 8>), grid, dim3(256), 0, m->stream, a);
     }
     return out;
 }

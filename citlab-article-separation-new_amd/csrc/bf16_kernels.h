@@ -74,7 +74,9 @@ struct ConvBArgs {
 // (row id >> 1, column block id & 1).  The A fragments (weights) of a stage are copied to LDS ONCE per block next to the halo
 // tile and read from there by all waves: fetched per wave from L2 (first cut of this kernel) they cost 4 KB per 16 MFMAs and
 // wave = the whole vector-memory path of a CU, and every chunk waited for an L2 round trip.
-template <int KH, int KW, int MODE, int MT, int WM, int TH, int MINB>
+// RESP: the layer has a residual operand; its values are requested BEFORE the last stage's MFMAs (2 MT NT registers) instead of
+// in the epilogue, where their HBM latency was exposed (a residual layer took 74 us against 42 us for its twin without one).
+template <int KH, int KW, int MODE, int MT, int WM, int TH, int MINB, bool RESP = false>
 __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
     static_assert(MODE != 0 || (KH == 3 && KW == 3), "MODE 0 is the 3x3 conv with 8 input channels");
     static_assert(WM == 1 || WM == 2, "one or two waves along the output channels");
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
         nbase[n] = ((id >> 1) * LW + (id & 1) * 16 + j) * PXB + (MODE == 0 ? kk * 16 : (kk & 1) * 16 + (MODE == 2 ? (kk >> 1) * PLANE : 0));
     }
     const int ngroups = MODE == 2 ? a.groups : 1;
+    u32x2 resv[RESP ? MT : 1][RESP ? NT : 1];
     const u32x4* __restrict__ wsrc = a.wpk + (size_t)mtb0 * 64;
     const size_t wstride = (size_t)a.mtiles * 64;
     const int mt_have = min(MTB, a.mtiles - mtb0);            // m-tiles of this block that exist (cout 8 / 16: one of MTB)
@@ -166,6 +169,20 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
             }
         }
         __syncthreads();
+        if constexpr (RESP) {
+            if (g + 1 == ngroups) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int c = (mt0 + m) * 16 + kk * 4;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int id = wn * NT + n;
+                        const int y = min(y0 + (id >> 1), H - 1), x = min(x0 + (id & 1) * 16 + j, W - 1);
+                        resv[m][n] = *reinterpret_cast<const u32x2*>(P.res + ((size_t)y * W + x) * a.cout + (c < a.cout ? c : 0));
+                    }
+                }
+            }
+        }
         auto chunk = [&](int t, int toff) {
             u32x4 af[MT], bfr[NT];
 #pragma unroll
@@ -220,7 +237,8 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
             const bool ok = cok && y < H && x < W;
             const size_t p = ((size_t)min(y, H - 1) * W + min(x, W - 1)) * cout + (cok ? c : 0);
             f32x4 v = acc[m][n] + b4;
-            if (P.res) v += unpack_bf16x4(*reinterpret_cast<const u32x2*>(P.res + p));
+            if constexpr (RESP) v += unpack_bf16x4(resv[m][n]);
+            else if (P.res) v += unpack_bf16x4(*reinterpret_cast<const u32x2*>(P.res + p));
             if (a.relu_out) v = relu4(v);
             // the pool takes its maximum over the ROUNDED values (what a separate pool kernel would read back)
             const u32x2 pk = pack_bf16x4(v);
@@ -414,7 +432,7 @@ __global__ __launch_bounds__(256, C == 8 ? 4 : 3) void resb_tail_kernel(const Re
 // (parity classes) of input-grid position (Y, X) take 4 / 2 / 2 / 1 taps from the positions (Y - dy, X - dx), dy, dx in {0,1}:
 // an n-tile = 16 consecutive X of one Y, 4 accumulators (classes) per m-tile, the 4 shifted B fragments shared by the classes.
 //   MODE 1 (Cin == 16): K chunk = (dy, both dx) x 16 channels.   MODE 2 (Cin % 32 == 0): K chunk = (shift, 32-channel group).
-// Block = 8 x 16 input positions = 16 x 32 output pixels x 16 MT channels, which leave through an LDS tile as whole rows.
+// Block = TH x 16 input positions = 2 TH x 32 output pixels x 16 MT channels, which leave through an LDS tile as whole rows.
 // ------------------------------------------------------------------------------------------------
 struct DeconvBProb {
     const bf16_t* in;      // [Hi,Wi,cin]
@@ -431,11 +449,11 @@ struct DeconvBArgs {
     int cin, cout, mtiles, groups;
     int relu_out;
 };
-constexpr int DCB_TH = 8, DCB_TW = 16;                        // input positions per block
+constexpr int DCB_TW = 16;                                    // input columns per block; rows: template parameter TH (8 or 16)
 
-template <int MODE, int MT>
+template <int MODE, int MT, int DCB_TH>
 __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
-    constexpr int LH = DCB_TH + 1, LW = DCB_TW + 1;
+    constexpr int LH = DCB_TH + 1, LW = DCB_TW + 1, RW = DCB_TH / 4;              // RW input rows per wave
     constexpr int PLANE = LH * LW * 32;
     constexpr int NPL = MODE == 2 ? 2 : 1;
     constexpr int SUBS = MODE == 2 ? 4 : 2;
@@ -455,10 +473,10 @@ __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
     const int X0 = tx * DCB_TW, Y0 = ty * DCB_TH, mt0 = blockIdx.y * MT;
     const int Hi = P.Hi, Wi = P.Wi, cin = a.cin;
 
-    // n-tile = one input row of the tile (16 positions); wave w owns rows w and w + 4; classes c = 2 py + px
-    f32x4 acc[2][4][MT];
+    // n-tile = one input row of the tile (16 positions); wave w owns rows w, w + 4, ...; classes c = 2 py + px
+    f32x4 acc[RW][4][MT];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < RW; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -491,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < RW; ++r) {
             const int Yl = wave + 4 * r;                       // local input row of this n-tile
             if constexpr (MODE == 2) {
                 const u32x4* __restrict__ wg = wbase + (size_t)g * 9 * wstride;
@@ -535,14 +553,17 @@ __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
         const int c = (mt0 + m) * 16 + kk * 4;
         const f32x4 b4 = c < a.cout ? *reinterpret_cast<const f32x4*>(a.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < RW; ++r) {
             const int Yl = wave + 4 * r;
 #pragma unroll
             for (int cls = 0; cls < 4; ++cls) {
                 f32x4 v = acc[r][cls][m] + b4;
                 if (a.relu_out) v = relu4(v);
-                const int orow = 2 * Yl + (cls >> 1), ocol = 2 * j + (cls & 1);
-                *reinterpret_cast<u32x2*>(otile + ((orow * 2 * DCB_TW + ocol) * OC + m * 16 + kk * 4) * 2) = pack_bf16x4(v);
+                // 16-byte unit S = pixel * UPP + channel quad pair, stored at S ^ ((pixel >> 1) & 7): the 16 lanes of a store (pixels
+                // 2 j + px, fixed channels) would otherwise be 64 / 128 bytes apart = 8- / 16-way bank conflicts (74 % of the LDS cycles)
+                const int orow = 2 * Yl + (cls >> 1), ocol = 2 * j + (cls & 1), pix = orow * 2 * DCB_TW + ocol;
+                const int S = (pix * (OC / 8) + m * 2 + (kk >> 1)) ^ ((pix >> 1) & 7);
+                *reinterpret_cast<u32x2*>(otile + S * 16 + (kk & 1) * 8) = pack_bf16x4(v);
             }
         }
     }
@@ -555,7 +576,8 @@ __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
         const int orow = pix / (2 * DCB_TW), ocol = pix - orow * (2 * DCB_TW);
         const int y = 2 * Y0 - P.pbh + orow, x = 2 * X0 - P.pbw + ocol;
         if (y >= 0 && y < P.Ho && x >= 0 && x < P.Wo && sub * 8 < nvalid)
-            *reinterpret_cast<u32x4*>(P.out + ((size_t)y * P.Wo + x) * a.cout + mt0 * 16 + sub * 8) = *reinterpret_cast<const u32x4*>(otile + u * 16);
+            *reinterpret_cast<u32x4*>(P.out + ((size_t)y * P.Wo + x) * a.cout + mt0 * 16 + sub * 8) =
+                *reinterpret_cast<const u32x4*>(otile + (u ^ ((pix >> 1) & 7)) * 16);
     }
 }
 
