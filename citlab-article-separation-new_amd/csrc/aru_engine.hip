@@ -1059,20 +1059,18 @@ void run_res8b(asep_aru* m, bool up, const TL& a0, const TL* a1, const std::vect
         else { a.w1 = m->det_first.d_w; a.b1 = m->det_first.d_b; a.wpk = (const u32x4*)m->d_r8b_down_w; a.bias = m->d_r8b_down_b; }
         TL sub(a0.begin() + b0, a0.begin() + b1);
         const std::string what = (up ? "unet_up_0 (conv1[16->8]+3xconvR+add) " : "unet_down_0 (conv1+3xconvR+add+pool) ") + dims_of(sub);
-        const bool fast = m->use_r8f && (up || m->d_r8f_down_w1);
-        if (fast) {
-            // interior tiles (their 24 x 40 input window inside the image): the lean kernel; it returns at once on border tiles,
-            // res8b_kernel (border_only) on interior ones.  The FLOPs are credited to the first launch.
+        if (m->use_r8f && (up || m->d_r8f_down_w1)) {
+            // lean form for interior tiles (their 24 x 40 input window inside the image), general form for border tiles, one launch
             Res8BArgs f = a;
             if (!up) f.w1pk = (const u32x4*)m->d_r8f_down_w1;
             ProfScope ps(m, up ? "res8f_kernel<true>" : "res8f_kernel<false>", flops, what);
             if (up) hipLaunchKernelGGL(res8f_kernel<true>, dim3(tiles), dim3(256), 0, m->stream, f);
             else hipLaunchKernelGGL(res8f_kernel<false>, dim3(tiles), dim3(256), 0, m->stream, f);
+        } else {
+            ProfScope ps(m, up ? "res8b_kernel<true>" : "res8b_kernel<false>", flops, what);
+            if (up) hipLaunchKernelGGL(res8b_kernel<true>, dim3(tiles), dim3(256), 0, m->stream, a);
+            else hipLaunchKernelGGL(res8b_kernel<false>, dim3(tiles), dim3(256), 0, m->stream, a);
         }
-        a.border_only = fast ? 1 : 0;
-        ProfScope ps(m, up ? "res8b_kernel<true>" : "res8b_kernel<false>", fast ? 0.0 : flops, what + (fast ? " border tiles" : ""));
-        if (up) hipLaunchKernelGGL(res8b_kernel<true>, dim3(tiles), dim3(256), 0, m->stream, a);
-        else hipLaunchKernelGGL(res8b_kernel<false>, dim3(tiles), dim3(256), 0, m->stream, a);
     }
 }
 
@@ -1203,9 +1201,15 @@ TL run_resb_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled)
         a.nprob = (int)(b1 - b0);
         a.wpk = (const u32x4*)rb.d_w; a.bias = rb.d_b;
         TL sub(t.begin() + b0, t.begin() + b1);
-        ProfScope ps(m, "resb_tail_kernel" + targs({ti(rb.C)}), flops, scope + " (3xconvR+add" + (pooled ? "+pool) " : ") ") + dims_of(sub));
-        if (rb.C == 8) hipLaunchKernelGGL(resb_tail_kernel<8>, dim3(tiles), dim3(256), 0, m->stream, a);
-        else hipLaunchKernelGGL(resb_tail_kernel<16>, dim3(tiles), dim3(256), 0, m->stream, a);
+        const std::string what = scope + " (3xconvR+add" + (pooled ? "+pool) " : ") ") + dims_of(sub);
+        if (rb.C == 16 && m->use_r8f) {                      // lean form for interior tiles, general form for border tiles, one launch
+            ProfScope ps(m, "res16f_kernel", flops, what);
+            hipLaunchKernelGGL(res16f_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
+        } else {
+            ProfScope ps(m, "resb_tail_kernel" + targs({ti(rb.C)}), flops, what);
+            if (rb.C == 8) hipLaunchKernelGGL(resb_tail_kernel<8>, dim3(tiles), dim3(256), 0, m->stream, a);
+            else hipLaunchKernelGGL(resb_tail_kernel<16>, dim3(tiles), dim3(256), 0, m->stream, a);
+        }
     }
     return out;
 }

@@ -290,25 +290,25 @@ struct ResBArgs {
 constexpr int RB_TH = 16, RB_TW = 32;
 
 template <int C>
-__global__ __launch_bounds__(256, C == 8 ? 4 : 3) void resb_tail_kernel(const ResBArgs a) {
+struct ResBLayout {
+    static constexpr int PXB = C * 2, SLACK = 4;
+    static constexpr int R0B = ((RB_TH + 6) * (RB_TW + 6) + SLACK) * PXB, R1B = ((RB_TH + 4) * (RB_TW + 4) + SLACK) * PXB, BYTES = R0B + R1B;
+};
+
+// the tail of one tile (any position; `lds` holds ResBLayout<C>::BYTES)
+template <int C>
+__device__ __forceinline__ void resb_tail_tile(const ResBArgs& a, const ResBProb& P, int x0, int y0, unsigned char* lds) {
     static_assert(C == 8 || C == 16, "8- and 16-channel levels");
     constexpr int PXB = C * 2;
     constexpr int CPC = C == 8 ? 3 : 5;                       // K chunks per conv (C == 8: filter rows; C == 16: tap pairs)
     constexpr int H0 = RB_TH + 6, W0 = RB_TW + 6, H1 = RB_TH + 4, W1 = RB_TW + 4, H2 = RB_TH + 2, W2 = RB_TW + 2;
-    constexpr int SLACK = 4;                                  // pixels a padded tap / a clamped tail lane may read past a region
-    constexpr int R0B = (H0 * W0 + SLACK) * PXB, R1B = (H1 * W1 + SLACK) * PXB;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[R0B + R1B];
+    constexpr int SLACK = ResBLayout<C>::SLACK;               // pixels a padded tap / a clamped tail lane may read past a region
+    constexpr int R0B = ResBLayout<C>::R0B;
     unsigned char* const r0 = lds;
     unsigned char* const r1 = lds + R0B;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
-    int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
-    const ResBProb& P = a.p[pi];
-    const int tile = blockIdx.x - P.tile_begin;
-    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-    const int x0 = tx * RB_TW, y0 = ty * RB_TH;
     const int H = P.H, W = P.W;
 
     // ---- relu(t) halo tile -> r0 (zero outside the image); slack pixels zeroed ----
@@ -422,6 +422,186 @@ __global__ __launch_bounds__(256, C == 8 ? 4 : 3) void resb_tail_kernel(const Re
                     *reinterpret_cast<u32x2*>(P.pool + ((size_t)(y >> 1) * Wp + (x >> 1)) * C + kk * 4) = pack_bf16x4(mm);
             }
         }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256, C == 8 ? 4 : 3) void resb_tail_kernel(const ResBArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[ResBLayout<C>::BYTES];
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    const ResBProb& P = a.p[pi];
+    const int tile = blockIdx.x - P.tile_begin;
+    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    resb_tail_tile<C>(a, P, tx * RB_TW, ty * RB_TH, lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// res16f_kernel: resb_tail_kernel<16> for INTERIOR tiles (the 22 x 38 window of t inside the image), written for instruction count
+// like res8f_kernel: an n-tile is 16 pixels of one ROW of a stage region (two per row + "remainder" tiles that gather columns
+// 32 .. of several rows), every LDS address is a per-lane constant plus a compile-time offset, no inside-the-image tests, the bias
+// is the accumulators' initial value, ReLU after the rounding (v_pk_max_i16), the residual operand is requested at the start.
+// Border tiles take resb_tail_tile<16> (the general form) inside the same launch.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
+    constexpr int C = 16, PXB = 32, CPC = 5;
+    constexpr int TH = RB_TH, TW = RB_TW;
+    constexpr int H0 = TH + 6, W0 = TW + 6, H1 = TH + 4, W1 = TW + 4, H2 = TH + 2, W2 = TW + 2;
+    constexpr int R0B = H0 * W0 * PXB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[ResBLayout<16>::BYTES];      // (the general form's layout is the larger one)
+    unsigned char* const r0 = lds;
+    unsigned char* const r1 = lds + R0B;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    const ResBProb& P = a.p[pi];
+    const int tile = blockIdx.x - P.tile_begin;
+    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int H = P.H, W = P.W;
+    if (!(y0 - 3 >= 0 && y0 + TH + 3 <= H && x0 - 3 >= 0 && x0 + TW + 3 <= W)) {             // border tile: the general form
+        resb_tail_tile<16>(a, P, x0, y0, lds);
+        return;
+    }
+
+    // ---- relu(t) halo tile -> r0 ----
+    {
+        constexpr int NU = H0 * W0 * 2, NLOAD = (NU + 255) / 256;
+        u32x4 st[NLOAD];
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int u = min(tid + i * 256, NU - 1);
+            const int pix = u >> 1, sub = u & 1;
+            const int ly = pix / W0, lx = pix - ly * W0;
+            st[i] = *reinterpret_cast<const u32x4*>(P.t + ((size_t)(y0 - 3 + ly) * W + x0 - 3 + lx) * C + sub * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int u = tid + i * 256;
+            if (u < NU) *reinterpret_cast<u32x4*>(r0 + u * 16) = relu_bf16x8(st[i]);
+        }
+    }
+    // residual operand of stage 3 (pre-ReLU t of the lane's 8 output pixels): requested now, used at the very end
+    const bf16_t* __restrict__ tres = P.t + ((size_t)(y0 + 2 * wave) * W + x0 + j) * C + kk * 4;
+    u32x2 resv[2][2][2];                                       // [row pair i][row r][column block]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) resv[i][r][cb] = *reinterpret_cast<const u32x2*>(tres + ((size_t)(8 * i + r) * W + cb * 16) * C);
+    const u32x4* __restrict__ wl = a.wpk + lane;
+    u32x4 af[CPC];
+#pragma unroll
+    for (int t = 0; t < CPC; ++t) af[t] = wl[t * 64];
+    // the lane's tap of K chunk t (two taps per chunk: lane groups 0, 1 the first, 2, 3 the second) as a pixel offset in a region
+    // that is WIN pixels wide
+    auto tap_px = [&](int t, int WIN) {
+        int tap = 2 * t + (kk >> 1);
+        tap = tap < 9 ? tap : 8;                              // padded slot of the last chunk: zero weights, finite data
+        const int ky = tap / 3, kx = tap - ky * 3;
+        return ky * WIN + kx;
+    };
+    auto relu_pk = [](u32x2 p) { return u32x2{relu_bf16x2(p.x), relu_bf16x2(p.y)}; };
+    // two tiles at once: all fragment reads, then the MFMAs of the two accumulator chains interleaved
+    auto conv16x2 = [&](const unsigned char* src, const int* bA, int offA, const int* bB, int offB, f32x4 c0, f32x4& ra, f32x4& rb) {
+        u32x4 fa[CPC], fb[CPC];
+#pragma unroll
+        for (int t = 0; t < CPC; ++t) { fa[t] = *reinterpret_cast<const u32x4*>(src + bA[t] + offA); fb[t] = *reinterpret_cast<const u32x4*>(src + bB[t] + offB); }
+        ra = c0; rb = c0;
+#pragma unroll
+        for (int t = 0; t < CPC; ++t) { ra = mfma_bf16_k32(af[t], fa[t], ra); rb = mfma_bf16_k32(af[t], fb[t], rb); }
+    };
+    __syncthreads();
+
+    // ---- stage 1: r0 (22 x 38) -> r1 (20 x 36).  Rows wave + 4 i, two main tiles each; 5 remainder tiles of 4 rows x 4 columns ----
+    {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + kk * 4);
+        int bm[CPC], br[CPC];
+        const int rr = j >> 2, xc = j & 3;                    // remainder tile: lane j -> row rr of 4, column 32 + xc
+#pragma unroll
+        for (int t = 0; t < CPC; ++t) {
+            bm[t] = (wave * W0 + j + tap_px(t, W0)) * PXB + (kk & 1) * 16;
+            br[t] = ((wave * 4 + rr) * W0 + 32 + xc + tap_px(t, W0)) * PXB + (kk & 1) * 16;
+        }
+        unsigned char* const dm = r1 + (wave * W1 + j) * PXB + kk * 8;
+        f32x4 va, vb;
+#pragma unroll
+        for (int i = 0; i < H1 / 4; ++i) {
+            conv16x2(r0, bm, i * 4 * W0 * PXB, bm, i * 4 * W0 * PXB + 16 * PXB, b4, va, vb);
+            *reinterpret_cast<u32x2*>(dm + i * 4 * W1 * PXB) = relu_pk(pack_bf16x4(va));
+            *reinterpret_cast<u32x2*>(dm + i * 4 * W1 * PXB + 16 * PXB) = relu_pk(pack_bf16x4(vb));
+        }
+        // remainder tiles 0 .. 3 (rows 4 wave ..) by every wave, tile 4 (rows 16 .. 19) by wave 0
+        conv16x2(r0, br, 0, br, (16 - 4 * wave) * W0 * PXB, b4, va, vb);
+        *reinterpret_cast<u32x2*>(r1 + ((wave * 4 + rr) * W1 + 32 + xc) * PXB + kk * 8) = relu_pk(pack_bf16x4(va));
+        if (wave == 0) *reinterpret_cast<u32x2*>(r1 + ((16 + rr) * W1 + 32 + xc) * PXB + kk * 8) = relu_pk(pack_bf16x4(vb));
+    }
+#pragma unroll
+    for (int t = 0; t < CPC; ++t) af[t] = wl[(CPC + t) * 64];
+    __syncthreads();
+    // ---- stage 2: r1 (20 x 36) -> r0 as 18 x 34.  4 full rows per wave + rows 16, 17 (waves 0, 1); 3 remainder tiles of 8 rows x 2
+    //      columns (waves 1 .. 3; wave 3's covers rows 16, 17 only) ----
+    {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + C + kk * 4);
+        int bm[CPC], br[CPC];
+        const int rr = j >> 1, xc = j & 1, rt = wave - 1;     // remainder tile rt: rows 8 rt + rr
+        const int rrow = min(max(8 * rt + rr, 0), H2 - 1);
+#pragma unroll
+        for (int t = 0; t < CPC; ++t) {
+            bm[t] = (wave * W1 + j + tap_px(t, W1)) * PXB + (kk & 1) * 16;
+            br[t] = (rrow * W1 + 32 + xc + tap_px(t, W1)) * PXB + (kk & 1) * 16;
+        }
+        unsigned char* const dm = r0 + (wave * W2 + j) * PXB + kk * 8;
+        f32x4 va, vb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            conv16x2(r1, bm, i * 4 * W1 * PXB, bm, i * 4 * W1 * PXB + 16 * PXB, b4, va, vb);
+            *reinterpret_cast<u32x2*>(dm + i * 4 * W2 * PXB) = relu_pk(pack_bf16x4(va));
+            *reinterpret_cast<u32x2*>(dm + i * 4 * W2 * PXB + 16 * PXB) = relu_pk(pack_bf16x4(vb));
+        }
+        if (wave < 2) {
+            conv16x2(r1, bm, 16 * W1 * PXB, bm, 16 * W1 * PXB + 16 * PXB, b4, va, vb);
+            *reinterpret_cast<u32x2*>(dm + 16 * W2 * PXB) = relu_pk(pack_bf16x4(va));
+            *reinterpret_cast<u32x2*>(dm + 16 * W2 * PXB + 16 * PXB) = relu_pk(pack_bf16x4(vb));
+        }
+        if (wave >= 1) {
+            conv16x2(r1, br, 0, br, 0, b4, va, vb);
+            if (8 * rt + rr < H2) *reinterpret_cast<u32x2*>(r0 + (rrow * W2 + 32 + xc) * PXB + kk * 8) = relu_pk(pack_bf16x4(va));
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < CPC; ++t) af[t] = wl[(2 * CPC + t) * 64];
+    __syncthreads();
+    // ---- stage 3: r0 (18 x 34) -> HBM; a wave takes row pairs 2 (wave + 4 i), both column blocks (2x2 pool in registers) ----
+    {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 2 * C + kk * 4);
+        int bm[CPC];
+#pragma unroll
+        for (int t = 0; t < CPC; ++t) bm[t] = (2 * wave * W2 + j + tap_px(t, W2)) * PXB + (kk & 1) * 16;
+        bf16_t* __restrict__ out = P.out + ((size_t)(y0 + 2 * wave) * W + x0 + j) * C + kk * 4;
+        const int Wp = (W + 1) >> 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                f32x4 v2[2];
+                conv16x2(r0, bm, (8 * i) * W2 * PXB + cb * 16 * PXB, bm, (8 * i + 1) * W2 * PXB + cb * 16 * PXB, b4, v2[0], v2[1]);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const u32x2 pk = relu_pk(pack_bf16x4(v2[r] + unpack_bf16x4(resv[i][r][cb])));
+                    v2[r] = unpack_bf16x4(pk);
+                    *reinterpret_cast<u32x2*>(out + ((size_t)(8 * i + r) * W + cb * 16) * C) = pk;
+                }
+                if (P.pool) {
+                    f32x4 mm = max4(v2[0], v2[1]);
+                    mm = max4(mm, f32x4{lane_xor1(mm.x), lane_xor1(mm.y), lane_xor1(mm.z), lane_xor1(mm.w)});
+                    if ((j & 1) == 0)
+                        *reinterpret_cast<u32x2*>(P.pool + ((size_t)((y0 >> 1) + wave + 4 * i) * Wp + ((x0 + cb * 16 + j) >> 1)) * C + kk * 4) = pack_bf16x4(mm);
+                }
+            }
     }
 }
 
@@ -611,22 +791,27 @@ struct Res8BArgs {
     const float* w1;       // DOWN: conv1 [9][8] fp32
     const float* b1;       // conv1 bias [8]
     const u32x4* w1pk;     // UP: conv1 pair fragments [ky 3][half 2][64 lanes] x 16 bytes; res8f_kernel DOWN: [64 lanes] (bf16 conv1)
-    int border_only;       // res8b_kernel: skip the tiles res8f_kernel serves (interior tiles)
     const u32x4* wpk;      // tail: [3 convs][ky 3][64 lanes] x 16 bytes
     const float* bias;     // tail biases [3][8]
 };
 
 template <bool UP>
-__global__ __launch_bounds__(256, UP ? 3 : 4) void res8b_kernel(const Res8BArgs a) {
+struct Res8BLayout {
+    static constexpr int TH = 16, TW = 32, SLACK = 4;
+    static constexpr int R0B = ((TH + 6) * (TW + 6) + SLACK) * 16, R1B = ((TH + 4) * (TW + 4) + SLACK) * 16, TCB = TH * TW * 16;
+    static constexpr int INB = UP ? ((TH + 8) * (TW + 8) + SLACK) * 32 : (TH + 8) * (TW + 8) * 4;
+    // stage 1's result may take the place of conv1's input tile (dead by then)
+    static constexpr int R0_OFF = (INB > R1B ? INB : R1B), TC_OFF = R0_OFF + R0B, BYTES = TC_OFF + TCB;
+};
+
+// the block of one tile (any position; `lds` holds Res8BLayout<UP>::BYTES)
+template <bool UP>
+__device__ __forceinline__ void res8b_tile(const Res8BArgs& a, const Res8BProb& P, int x0, int y0, unsigned char* lds) {
     constexpr int TH = 16, TW = 32;
     constexpr int H0 = TH + 6, W0 = TW + 6, H1 = TH + 4, W1 = TW + 4, H2 = TH + 2, W2 = TW + 2;
     constexpr int IH = TH + 8, IW = TW + 8;                   // conv1's input tile (halo 4)
-    constexpr int SLACK = 4;                                  // pixels a zero-weight window column / a clamped tail lane may read past a region
-    constexpr int R0B = (H0 * W0 + SLACK) * 16, R1B = (H1 * W1 + SLACK) * 16, TCB = TH * TW * 16;
-    constexpr int INB = UP ? (IH * IW + SLACK) * 32 : IH * IW * 4;
-    // stage 1's result may take the place of conv1's input tile (dead by then)
-    constexpr int R1_OFF = 0, IN_OFF = 0, R0_OFF = (INB > R1B ? INB : R1B), TC_OFF = R0_OFF + R0B;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[TC_OFF + TCB];
+    constexpr int SLACK = Res8BLayout<UP>::SLACK;             // pixels a zero-weight window column / a clamped tail lane may read past a region
+    constexpr int R1_OFF = 0, IN_OFF = 0, R0_OFF = Res8BLayout<UP>::R0_OFF, TC_OFF = Res8BLayout<UP>::TC_OFF;
     unsigned char* const r0 = lds + R0_OFF;
     unsigned char* const r1 = lds + R1_OFF;
     unsigned char* const tc = lds + TC_OFF;
@@ -634,16 +819,9 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8b_kernel(const Res8BArgs 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4, e = kk >> 1, ch = (kk & 1) * 4;     // D layout: pixel parity e, channels ch .. ch + 3
-    int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
-    const Res8BProb& P = a.p[pi];
-    const int tile = blockIdx.x - P.tile_begin;
-    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-    const int x0 = tx * TW, y0 = ty * TH;
     const int H = P.H, W = P.W;
     // the whole conv1 input window lies inside the image: no position of any stage needs the zero test
     const bool interior = y0 - 4 >= 0 && y0 + TH + 4 <= H && x0 - 4 >= 0 && x0 + TW + 4 <= W;
-    if (interior && a.border_only) return;
 
     // ---- conv1 input tile -> LDS ----
     if constexpr (UP) {
@@ -840,6 +1018,17 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8b_kernel(const Res8BArgs 
     }
 }
 
+template <bool UP>
+__global__ __launch_bounds__(256, UP ? 3 : 4) void res8b_kernel(const Res8BArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[Res8BLayout<UP>::BYTES];
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    const Res8BProb& P = a.p[pi];
+    const int tile = blockIdx.x - P.tile_begin;
+    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    res8b_tile<UP>(a, P, tx * 32, ty * 16, lds);
+}
+
 // ------------------------------------------------------------------------------------------------
 // res8f_kernel<UP>: the same block for INTERIOR tiles (the whole 24 x 40 input window inside the image: ~96 % of the tiles of
 // a 3000 x 4500 page), written for instruction count.  res8b_kernel issued ~5300 instructions per tile for 178 MFMAs (SQ
@@ -849,7 +1038,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8b_kernel(const Res8BArgs 
 // gathered into "remainder" tiles), so every LDS address is a per-lane constant plus a compile-time offset, no position is
 // outside the image, the bias is the accumulators' initial value, ReLU is one v_pk_max_i16 per two values AFTER the rounding
 // to bf16, and conv1 of the down block is ONE MFMA per 32 pixels on the image tile held as bf16 (K = 3 x 4 window values).
-// Border tiles are left to res8b_kernel (Res8BArgs::mode).
+// Border tiles take res8b_tile (the general form) inside the same launch.
 // ------------------------------------------------------------------------------------------------
 template <bool UP>
 __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs a) {
@@ -859,7 +1048,8 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     constexpr int INB = UP ? IH * IW * 32 : 2048;             // DOWN: bf16 image tile, (IH + 1) x IW x 2 bytes
     constexpr int R1B = H1 * W1 * 16, R0B = H0 * W0 * 16, TCB = TH * TW * 16;
     constexpr int R1_OFF = UP ? 0 : INB, R0_OFF = UP ? INB : INB + R1B, TC_OFF = R0_OFF + R0B;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[TC_OFF + TCB];
+    constexpr int LDSB = TC_OFF + TCB > Res8BLayout<UP>::BYTES ? TC_OFF + TCB : Res8BLayout<UP>::BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
     unsigned char* const in = lds;
     unsigned char* const r1 = lds + R1_OFF;
     unsigned char* const r0 = lds + R0_OFF;
@@ -874,7 +1064,10 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
     const int H = P.H, W = P.W;
-    if (!(y0 - 4 >= 0 && y0 + TH + 4 <= H && x0 - 4 >= 0 && x0 + TW + 4 <= W)) return;      // border tile: res8b_kernel's
+    if (!(y0 - 4 >= 0 && y0 + TH + 4 <= H && x0 - 4 >= 0 && x0 + TW + 4 <= W)) {             // border tile: the general form
+        res8b_tile<UP>(a, P, x0, y0, lds);
+        return;
+    }
 
     // ---- conv1 input tile -> LDS (no padding: the window is inside the image) ----
     if constexpr (UP) {
