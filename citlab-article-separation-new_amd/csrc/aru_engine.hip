@@ -132,6 +132,7 @@ struct asep_aru {
     bool wino16 = false;           // ASEP_WINO16=1: register-resident Winograd also at the 16-channel level (measured: 99 vs
                                    // 103 TFLOP/s-equivalent for the direct kernels, parity-green; kept as an experiment switch)
     bool bf_th8 = true;            // ASEP_BF_TH8=0: 16 x 32 instead of 8 x 32 pixel blocks for the 32-channel bf16 convs
+    int bf_mtb = 4;                // ASEP_BF_MTB=2: 32 instead of 64 output channels per block at >= 64 channels
     bool profiling = false;
     bool prof_detail = false;      // per-layer names (scope + spatial size) instead of per-kernel names
     bool prof_in_situ = false;     // keep the attention side stream while recording (times include what shares the chip)
@@ -1108,7 +1109,7 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
     }
     // output-channel tiles per block: 1 (cout 8 / 16), 2 (cout 32: one wave row, 16 x 32 pixels), 4 (cout >= 64: two wave
     // rows of two m-tiles, 8 x 32 pixels)
-    const int mtb = pc.mtiles >= 4 ? 4 : pc.mtiles;
+    const int mtb = pc.mtiles >= 4 ? m->bf_mtb : pc.mtiles;
     if (pc.mtiles % mtb != 0 || mtb == 3) { set_error("conv %s: %d output tiles not instantiated", scope.c_str(), pc.mtiles); throw ArgError(); }
     const int th = (mtb == 4 || (mtb == 2 && pc.bmode == 2 && m->bf_th8)) ? 8 : 16;
     TL out;
@@ -1669,6 +1670,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_BIGTILE")) m->big_tile = atoi(e) != 0;
     if (const char* e = getenv("ASEP_SIDE_STREAM")) m->use_side_stream = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_TH8")) m->bf_th8 = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_BF_MTB")) m->bf_mtb = atoi(e) == 2 ? 2 : 4;
     if (const char* e = getenv("ASEP_BF_R8B")) m->use_r8b = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_R8F")) m->use_r8f = atoi(e) != 0;
     if (const char* e = getenv("ASEP_LANES")) m->num_lanes = std::max(1, std::min(4, atoi(e)));

@@ -38,6 +38,10 @@ __device__ __forceinline__ f32x4 unpack_bf16x4(u32x2 p) {
 __device__ __forceinline__ unsigned relu_bf16x2(unsigned x) {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, x), s16x2{0, 0}));
 }
+// max of two packed pairs of NON-NEGATIVE bf16 (the integer order of their bit patterns is their float order): v_pk_max_i16
+__device__ __forceinline__ unsigned pkmax_u16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
 __device__ __forceinline__ u32x4 relu_bf16x8(u32x4 v) { return u32x4{relu_bf16x2(v.x), relu_bf16x2(v.y), relu_bf16x2(v.z), relu_bf16x2(v.w)}; }
 __device__ __forceinline__ f32x4 mfma_bf16_k32(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -106,11 +110,16 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
     const int x0 = tx * TW, y0 = ty * TH, mtb0 = blockIdx.y * MTB, mt0 = mtb0 + wm * MT;
     const int H = P.H, W = P.W;
 
+    // the bias is the accumulators' initial value (rows of channels beyond cout: zero)
+    const int cout = a.cout;
     f32x4 acc[MT][NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m) {
+        const int c = (mt0 + m) * 16 + kk * 4;
+        const f32x4 b4 = c < cout ? *reinterpret_cast<const f32x4*>(a.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NT; ++n) acc[m][n] = b4;
+    }
 
     // byte offset of (row, col + j) of each n-tile of this wave, plus the lane's channel half / plane
     int nbase[NT];
@@ -125,24 +134,34 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
     const size_t wstride = (size_t)a.mtiles * 64;
     const int mt_have = min(MTB, a.mtiles - mtb0);            // m-tiles of this block that exist (cout 8 / 16: one of MTB)
 
-    for (int g = 0; g < ngroups; ++g) {
-        // ---- stage g: halo tile of 32 (16, 8) input channels + the stage's A fragments -> LDS.  Requests first (clamped,
-        //      always valid addresses); zero padding / ReLU when the registers go to LDS ----
-        u32x4 st[NLOAD];
-        unsigned stmask = 0;
+    // halo loader: the thread's NLOAD (pixel, 16-byte sub-block) slots do not depend on the stage: image pixel index (clamped
+    // into the image: always a valid address), LDS byte offset and the inside-the-image mask are computed ONCE (the per-stage
+    // loop had a division, four clamps and a 64-bit multiply per slot: the blocks are short, DESIGN lesson 9)
+    int spix[NLOAD], slds[NLOAD];
+    unsigned stmask = 0;
 #pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-            const int u = min(tid + i * 256, NU - 1);
-            const int pix = u / SUBS, sub = u - pix * SUBS;
-            const int ly = pix / LW, lx = pix - ly * LW;
-            const int gy = y0 - PT + ly, gx = x0 - PL + lx;
-            const int c = g * 32 + sub * 8;
+    for (int i = 0; i < NLOAD; ++i) {
+        const int u = min(tid + i * 256, NU - 1);
+        const int pix = u / SUBS, sub = u - pix * SUBS;
+        const int ly = pix / LW, lx = pix - ly * LW;
+        const int gy = y0 - PT + ly, gx = x0 - PL + lx;
+        spix[i] = min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1);
+        slds[i] = (sub >> 1) * PLANE + pix * PXB + (sub & 1) * 16;
+        stmask |= ((gy >= 0 && gy < H && gx >= 0 && gx < W && tid + i * 256 < NU) ? 1u : 0u) << i;
+    }
+    const int sub0 = (tid % SUBS) * 8;                        // (256 is a multiple of SUBS: the sub-block is the same for all slots)
+
+    for (int g = 0; g < ngroups; ++g) {
+        // ---- stage g: halo tile of 32 (16, 8) input channels + the stage's A fragments -> LDS.  Requests first; zero padding /
+        //      ReLU when the registers go to LDS ----
+        u32x4 st[NLOAD];
+        {
+            const int c = g * 32 + sub0;
             const bool from0 = c < a.c0;
             const bf16_t* __restrict__ src = from0 ? P.in0 + c : P.in1 + (c - a.c0);
             const int cs = from0 ? a.c0 : a.c1;
-            const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-            st[i] = *reinterpret_cast<const u32x4*>(src + ((size_t)cy * W + cx) * cs);
-            stmask |= ((gy >= 0 && gy < H && gx >= 0 && gx < W) ? 1u : 0u) << i;
+#pragma unroll
+            for (int i = 0; i < NLOAD; ++i) st[i] = *reinterpret_cast<const u32x4*>(src + (size_t)spix[i] * cs);
         }
         if (g > 0) __syncthreads();                          // the previous stage's readers are done
         // A fragments: global -> LDS without registers (global_load_lds_dwordx4: one wave-instruction copies 1 KB, lane i to
@@ -160,12 +179,10 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
-            const int u = tid + i * 256;
-            if (u < NU) {
-                const int pix = u / SUBS, sub = u - pix * SUBS;
+            if (i * 256 + 255 < NU || tid + i * 256 < NU) {
                 u32x4 v = ((stmask >> i) & 1u) ? st[i] : u32x4{0u, 0u, 0u, 0u};
                 if (a.relu_in) v = relu_bf16x8(v);
-                *reinterpret_cast<u32x4*>(lds + (sub >> 1) * PLANE + pix * PXB + (sub & 1) * 16) = v;
+                *reinterpret_cast<u32x4*>(lds + slds[i]) = v;
             }
         }
         __syncthreads();
@@ -223,20 +240,52 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
     }
 
     // ---- epilogue: lane = pixel (column block, j), 4 consecutive output channels 16 (mt0 + m) + 4 kk ----
-    const int cout = a.cout;
     const int Wp = (W + 1) >> 1;
+    if (y0 + TH <= H && x0 + TW <= W && (mtb0 + MTB) * 16 <= cout && a.relu_out && !a.pool_f32) {
+        // the output tile lies inside the image, whole m-tiles, ReLU layer (every layer but the block-opening conv1): per-lane base
+        // pointers + row strides instead of a bounds test, two clamps and a 64-bit multiply per accumulator; ReLU AFTER the rounding
+        // (one v_pk_max_i16 per two values); the pool compares the bf16 bit patterns (non-negative values: integer order = float order)
+        const size_t lane0 = ((size_t)(y0 + wn * (NT / 2)) * W + x0 + j) * cout + mt0 * 16 + kk * 4;
+        bf16_t* __restrict__ ob = P.out + lane0;
+        const bf16_t* __restrict__ rb = P.res + lane0;
+        bf16_t* __restrict__ pb = (bf16_t*)P.pool + ((size_t)((y0 >> 1) + wn * (NT / 4)) * Wp + ((x0 + j) >> 1)) * cout + mt0 * 16 + kk * 4;
+        const size_t rs = (size_t)W * cout, prs = (size_t)Wp * cout;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            u32x2 pk[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const size_t off = (size_t)(n >> 1) * rs + (n & 1) * 16 * cout + m * 16;
+                f32x4 v = acc[m][n];
+                if constexpr (RESP) v += unpack_bf16x4(resv[m][n]);
+                else if (P.res) v += unpack_bf16x4(*reinterpret_cast<const u32x2*>(rb + off));
+                const u32x2 q = pack_bf16x4(v);
+                pk[n] = u32x2{relu_bf16x2(q.x), relu_bf16x2(q.y)};
+                if (!a.skip_full) *reinterpret_cast<u32x2*>(ob + off) = pk[n];
+            }
+            if (P.pool) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    if (n & 2) continue;
+                    u32x2 mm = u32x2{pkmax_u16(pk[n].x, pk[n + 2].x), pkmax_u16(pk[n].y, pk[n + 2].y)};
+                    mm = u32x2{pkmax_u16(mm.x, __float_as_uint(lane_xor1(__uint_as_float(mm.x)))), pkmax_u16(mm.y, __float_as_uint(lane_xor1(__uint_as_float(mm.y))))};
+                    if ((j & 1) == 0) *reinterpret_cast<u32x2*>(pb + (size_t)(n >> 2) * prs + (n & 1) * 8 * cout + m * 16) = mm;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int c = (mt0 + m) * 16 + kk * 4;
         const bool cok = c < cout;                           // cout is a multiple of 4
-        const f32x4 b4 = cok ? *reinterpret_cast<const f32x4*>(a.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int id = wn * NT + n;
             const int y = y0 + (id >> 1), x = x0 + (id & 1) * 16 + j;
             const bool ok = cok && y < H && x < W;
             const size_t p = ((size_t)min(y, H - 1) * W + min(x, W - 1)) * cout + (cok ? c : 0);
-            f32x4 v = acc[m][n] + b4;
+            f32x4 v = acc[m][n];
             if constexpr (RESP) v += unpack_bf16x4(resv[m][n]);
             else if (P.res) v += unpack_bf16x4(*reinterpret_cast<const u32x2*>(P.res + p));
             if (a.relu_out) v = relu4(v);
