@@ -161,7 +161,13 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
             const bf16_t* __restrict__ src = from0 ? P.in0 + c : P.in1 + (c - a.c0);
             const int cs = from0 ? a.c0 : a.c1;
 #pragma unroll
-            for (int i = 0; i < NLOAD; ++i) st[i] = *reinterpret_cast<const u32x4*>(src + (size_t)spix[i] * cs);
+            for (int i = 0; i < NLOAD; ++i) {
+#if defined(CONVB_ABL) && (CONVB_ABL & 1)
+                st[i] = u32x4{(unsigned)spix[i], 0u, 0u, 0u};      // timing experiment: no halo loads
+#else
+                st[i] = *reinterpret_cast<const u32x4*>(src + (size_t)spix[i] * cs);
+#endif
+            }
         }
         if (g > 0) __syncthreads();                          // the previous stage's readers are done
         // A fragments: global -> LDS without registers (global_load_lds_dwordx4: one wave-instruction copies 1 KB, lane i to
@@ -169,7 +175,11 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
 #pragma unroll
         for (int i = 0; i < NWLOAD; ++i) {
             const int u0 = i * 256 + wave * 64;              // wave-uniform
+#if defined(CONVB_ABL) && (CONVB_ABL & 2)
+            if (false) {                                     // timing experiment: no weight copies
+#else
             if (u0 < NWU) {
+#endif
                 const int u = u0 + lane;
                 const int t = u / (MTB * 64), r = u - t * (MTB * 64);
                 const u32x4* gsrc = wsrc + (size_t)(g * CPS + t) * wstride + min(r, mt_have * 64 - 1);
