@@ -478,7 +478,9 @@ def _read_layer_tail(graph, layer, op):
             raise IOError(f"{c['name']}: batch-norm statistics are not constants")
         gamma, beta, mean, var = parts
         eps = c["attr"].get("epsilon")
-        eps = 1e-3 if eps is None else float(eps)
+        eps = 1e-4 if eps is None else float(eps)             # the op's registered default (a graph written with
+                                                              # strip_default_attrs omits it; 1e-3 is the Keras LAYER default and
+                                                              # is always written out because it differs)
         scale = gamma / np.sqrt(var + eps)
         shift = beta - mean * scale
         cur = c

@@ -1,0 +1,279 @@
+"""General (slanted) polygons against rectilinear separator regions -- the part of shapely / GEOS that
+``separator_region_to_page_writer.py:154-227`` needs for text lines whose outline is NOT axis-parallel:
+
+    difference_parts(ring, rects)      ``Polygon(ring).difference(separator)`` -> the connected parts' exterior rings
+    intersection_area(ring, convex)    ``a.intersection(b).area`` for a convex ``b`` (a word quadrilateral)
+    point_in_ring(pt, ring)            inside or on the boundary
+
+The separator is a rectilinear region, i.e. a union of disjoint axis-parallel rectangles (``rect_geometry.Region.rectangles``),
+so every cut runs along a line x = c or y = c: a simple polygon is split by such a line exactly (crossings sorted along the
+line and paired), the pieces outside a rectangle are collected (left of it, right of it, above and below its column), and at
+the end pieces that share a boundary segment of positive length are merged again by cancelling opposite edges -- what remains
+are the rings of the connected parts.  Coordinates on the cut lines are exact; the other coordinate of a cut point on a slanted
+edge is one floating-point interpolation, computed once and shared by both sides.
+"""
+from collections import defaultdict
+
+
+def ring_area2(ring):
+    """twice the signed area (positive: counter-clockwise in a y-up frame)"""
+    s = 0.0
+    n = len(ring)
+    for i in range(n):
+        x0, y0 = ring[i]
+        x1, y1 = ring[(i + 1) % n]
+        s += x0 * y1 - x1 * y0
+    return s
+
+
+def _open(ring):
+    pts = [(float(x), float(y)) for x, y in ring]
+    if len(pts) > 1 and pts[0] == pts[-1]:
+        pts = pts[:-1]
+    out = []
+    for p in pts:                                           # drop repeated points
+        if not out or p != out[-1]:
+            out.append(p)
+    if len(out) > 1 and out[0] == out[-1]:
+        out.pop()
+    return out
+
+
+def split_by_line(ring, axis, c):
+    """Split the simple polygon ``ring`` (open list of points) along the line ``coordinate[axis] == c``.
+    -> (polygons with coordinate <= c, polygons with coordinate >= c).  Points ON the line count as the upper side, so an edge
+    that runs along the line belongs to the upper polygons."""
+    n = len(ring)
+    if n < 3:
+        return [], []
+    side = [1 if p[axis] >= c else -1 for p in ring]
+    if all(s > 0 for s in side):
+        return [], [list(ring)]
+    if all(s < 0 for s in side):
+        return [list(ring)], []
+    # the ring with crossing points inserted; a crossing belongs to both sides
+    seq = []                                                # (point, side: -1 / +1 / 0 = crossing)
+    for i in range(n):
+        p, q = ring[i], ring[(i + 1) % n]
+        seq.append((p, side[i]))
+        if side[i] != side[(i + 1) % n]:
+            t = (c - p[axis]) / (q[axis] - p[axis])
+            o = p[1 - axis] + (q[1 - axis] - p[1 - axis]) * t
+            x = (c, o) if axis == 0 else (o, c)
+            seq.append((x, 0))
+    cross = [k for k, (_, s) in enumerate(seq) if s == 0]
+    order = sorted(cross, key=lambda k: seq[k][0][1 - axis])
+    partner = {}
+    for a in range(0, len(order) - 1, 2):                   # consecutive crossings along the line bound one interior interval
+        partner[order[a]] = order[a + 1]
+        partner[order[a + 1]] = order[a]
+    m = len(seq)
+
+    def trace(want):
+        polys, used = [], set()
+        for start in range(m):
+            if seq[start][1] != want or start in used:
+                continue
+            poly, k = [], start
+            while True:
+                pt, s = seq[k]
+                if s == want:
+                    if k in used:
+                        break
+                    used.add(k)
+                    poly.append(pt)
+                    k = (k + 1) % m
+                elif s == 0:
+                    poly.append(pt)
+                    j = partner.get(k)
+                    if j is None:                           # odd crossing count (touching): stop this loop
+                        break
+                    poly.append(seq[j][0])
+                    k = (j + 1) % m
+                else:                                       # ran onto the other side: a crossing was missed
+                    break
+                if k == start:
+                    break
+            poly = _open(poly)
+            if len(poly) >= 3 and abs(ring_area2(poly)) > 0.0:
+                polys.append(poly)
+        return polys
+
+    return trace(-1), trace(1)
+
+
+def subtract_rect(ring, rect):
+    """pieces of the polygon outside the axis-parallel rectangle (x0, y0, x1, y1); their interiors are disjoint"""
+    x0, y0, x1, y1 = rect
+    out = []
+    left, rest = split_by_line(ring, 0, x0)
+    out += left
+    for r in rest:
+        mid, right = split_by_line(r, 0, x1)
+        out += right
+        for q in mid:
+            top, low = split_by_line(q, 1, y0)
+            out += top
+            for w in low:
+                _, below = split_by_line(w, 1, y1)
+                out += below
+    return out
+
+
+def _merge(pieces):
+    """union of pieces with disjoint interiors that may share boundary segments along axis-parallel lines: opposite edges
+    cancel, the remaining edges are chained into rings; -> exterior rings of the connected parts (counter-clockwise)"""
+    pieces = [p if ring_area2(p) > 0 else p[::-1] for p in pieces]
+    xs, ys = defaultdict(set), defaultdict(set)             # vertices on every vertical / horizontal line
+    for p in pieces:
+        for x, y in p:
+            xs[x].add(y)
+            ys[y].add(x)
+    edges = defaultdict(int)
+    for p in pieces:
+        n = len(p)
+        for i in range(n):
+            a, b = p[i], p[(i + 1) % n]
+            pts = [a, b]
+            if a[0] == b[0]:                                # vertical edge: split at every vertex that lies inside it
+                lo, hi = sorted((a[1], b[1]))
+                mids = sorted(v for v in xs[a[0]] if lo < v < hi)
+                pts = [a] + [(a[0], v) for v in (mids if a[1] < b[1] else mids[::-1])] + [b]
+            elif a[1] == b[1]:
+                lo, hi = sorted((a[0], b[0]))
+                mids = sorted(v for v in ys[a[1]] if lo < v < hi)
+                pts = [a] + [(v, a[1]) for v in (mids if a[0] < b[0] else mids[::-1])] + [b]
+            for u, v in zip(pts[:-1], pts[1:]):
+                if edges.get((v, u), 0) > 0:
+                    edges[(v, u)] -= 1
+                else:
+                    edges[(u, v)] += 1
+    nxt = defaultdict(list)
+    for (u, v), k in edges.items():
+        for _ in range(k):
+            nxt[u].append(v)
+    rings = []
+    while True:
+        start = next((u for u, vs in nxt.items() if vs), None)
+        if start is None:
+            break
+        ring, u = [], start
+        while nxt[u]:
+            ring.append(u)
+            u = nxt[u].pop()
+            if u == start:
+                break
+        if len(ring) >= 3:
+            rings.append(ring)
+    out, holes = [], []
+    for r in rings:                                          # drop collinear points (cut points on straight edges)
+        clean = []
+        n = len(r)
+        for i in range(n):
+            a, b, c = r[i - 1], r[i], r[(i + 1) % n]
+            cross = (b[0] - a[0]) * (c[1] - b[1]) - (b[1] - a[1]) * (c[0] - b[0])
+            scale = (abs(b[0] - a[0]) + abs(b[1] - a[1])) * (abs(c[0] - b[0]) + abs(c[1] - b[1]))
+            if abs(cross) > 1e-12 * scale:                   # (a cut point on a slanted edge is collinear up to one rounding)
+                clean.append(b)
+        if len(clean) >= 3 and ring_area2(clean) > 0:
+            out.append(clean)
+        elif len(clean) >= 3:                                # a clockwise ring is a hole of a part (the writers use exteriors only)
+            holes.append(clean)
+    return out, holes
+
+
+def difference_parts(ring, rects, with_holes=False):
+    """``Polygon(ring).difference(union of rects)`` -> exterior rings of its connected parts, ordered left to right (then top to
+    bottom), each starting at its top-left-most vertex (``with_holes``: also the list of hole rings, clockwise)"""
+    poly = _open(ring)
+    if len(poly) < 3:
+        return ([], []) if with_holes else []
+    pieces = [poly]
+    for rect in rects:
+        pieces = [q for p in pieces for q in subtract_rect(p, rect)]
+        if not pieces:
+            return ([], []) if with_holes else []
+    parts, holes = _merge(pieces)
+    out = []
+    for p in parts:
+        k = min(range(len(p)), key=lambda i: (p[i][1], p[i][0]))
+        out.append(p[k:] + p[:k])
+    out.sort(key=lambda p: (min(x for x, _ in p), min(y for _, y in p)))
+    return (out, holes) if with_holes else out
+
+
+def is_convex(ring):
+    pts = _open(ring)
+    n = len(pts)
+    if n < 3:
+        return False
+    sign = 0
+    for i in range(n):
+        a, b, c = pts[i], pts[(i + 1) % n], pts[(i + 2) % n]
+        z = (b[0] - a[0]) * (c[1] - b[1]) - (b[1] - a[1]) * (c[0] - b[0])
+        if z != 0:
+            if sign and (z > 0) != (sign > 0):
+                return False
+            sign = 1 if z > 0 else -1
+    return sign != 0
+
+
+def intersection_area(ring, convex):
+    """area of ``ring`` (any simple polygon) inside the CONVEX polygon ``convex`` (Sutherland-Hodgman: degenerate bridges of a
+    concave subject have zero area)"""
+    subj = _open(ring)
+    clip = _open(convex)
+    if ring_area2(clip) < 0:
+        clip = clip[::-1]
+    for i in range(len(clip)):
+        a, b = clip[i], clip[(i + 1) % len(clip)]
+        inside = lambda p: (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0]) >= 0
+        out = []
+        for k in range(len(subj)):
+            p, q = subj[k], subj[(k + 1) % len(subj)]
+            ip, iq = inside(p), inside(q)
+            if ip:
+                out.append(p)
+            if ip != iq:
+                d = (b[0] - a[0]) * (q[1] - p[1]) - (b[1] - a[1]) * (q[0] - p[0])
+                t = ((b[0] - a[0]) * (a[1] - p[1]) - (b[1] - a[1]) * (a[0] - p[0])) / d
+                out.append((p[0] + (q[0] - p[0]) * t, p[1] + (q[1] - p[1]) * t))
+        subj = out
+        if len(subj) < 3:
+            return 0.0
+    return abs(ring_area2(subj)) / 2.0
+
+
+def point_in_ring(pt, ring):
+    """inside or on the boundary"""
+    x, y = float(pt[0]), float(pt[1])
+    pts = _open(ring)
+    inside = False
+    n = len(pts)
+    for i in range(n):
+        (x0, y0), (x1, y1) = pts[i], pts[(i + 1) % n]
+        cross = (x1 - x0) * (y - y0) - (y1 - y0) * (x - x0)
+        if cross == 0 and min(x0, x1) <= x <= max(x0, x1) and min(y0, y1) <= y <= max(y0, y1):
+            return True
+        if (y0 > y) != (y1 > y) and x < x0 + (x1 - x0) * (y - y0) / (y1 - y0):
+            inside = not inside
+    return inside
+
+
+def polyline_meets_ring(points, ring):
+    """``LineString.intersects(Polygon)``: a vertex of the line inside the polygon, or a segment crossing its boundary"""
+    pts = [(float(x), float(y)) for x, y in points]
+    if any(point_in_ring(p, ring) for p in pts):
+        return True
+    poly = _open(ring)
+
+    def seg_cross(p, q, a, b):
+        def o(u, v, w):
+            return (v[0] - u[0]) * (w[1] - u[1]) - (v[1] - u[1]) * (w[0] - u[0])
+        d1, d2, d3, d4 = o(a, b, p), o(a, b, q), o(p, q, a), o(p, q, b)
+        return (d1 > 0) != (d2 > 0) and (d3 > 0) != (d4 > 0) and d1 != 0 and d2 != 0 and d3 != 0 and d4 != 0
+    for p, q in zip(pts[:-1], pts[1:]):
+        for i in range(len(poly)):
+            if seg_cross(p, q, poly[i], poly[(i + 1) % len(poly)]):
+                return True
+    return False

@@ -7,7 +7,8 @@
 this build): text lines that a VERTICAL separator runs through are cut into the parts left and right of it (``:156-227``),
 words and text follow the part they overlap most, the baseline is cut with the line and parts without a baseline piece
 are dropped; separator polygons with holes larger than 1000 px^2 are cut at the holes (``:30-70,329-337``).  A text line
-whose outline is not rectilinear is left as it is (logged) -- the one deviation, it needs a general polygon clipper.
+whose outline is slanted goes through ``poly_clip.py`` (general simple polygon minus the separator's rectangles; the cut points on
+slanted edges are rounded to integers like every PAGE coordinate).
 Where GEOS' output order is an implementation detail (parts of a MultiPolygon, ring start vertex) parts are ordered left
 to right and rings start at their top-left corner, running clockwise on screen.
 """
@@ -17,6 +18,7 @@ import os
 from .image_io import get_image_dimensions
 from .net_post_processing_helper import get_scaling_factor
 from .page_xml import Page
+from . import poly_clip
 from .rect_geometry import Region, clip_polyline_outside, cut_at_holes, is_rectilinear, polyline_touches
 
 SEPARATOR_REGION = "SeparatorRegion"
@@ -67,34 +69,54 @@ class SeparatorRegionToPageWriter(RegionToPageWriter):
         if sep.is_empty():
             return lines
         out = []
+        rects = sep.rectangles()
         for line in lines:
-            if not is_rectilinear(line.surr_p):
-                logging.warning("text line %s is not rectilinear: not cut at vertical separators", line.id)
-                out.append(line)
-                continue
-            outline = Region.from_rings([line.surr_p])
-            if sep.contains(outline):                        # swallowed by the separator: the line disappears (:172-174)
-                continue
-            if not outline.overlaps(sep):
-                out.append(line)
-                continue
-            parts = outline.difference(sep).polygons()
-            part_regions = [Region.from_rings(p) for p in parts]
+            rectilinear = is_rectilinear(line.surr_p)
+            if rectilinear:
+                outline = Region.from_rings([line.surr_p])
+                if sep.contains(outline):                    # swallowed by the separator: the line disappears (:172-174)
+                    continue
+                if not outline.overlaps(sep):
+                    out.append(line)
+                    continue
+                parts = [p[0] for p in outline.difference(sep).polygons()]
+                part_regions = [Region.from_rings([p]) for p in parts]
+                part_area = lambda k, ring: (Region.from_rings([ring]) if is_rectilinear(ring) else Region.box(*_bbox(ring))) \
+                    .intersection(part_regions[k]).area
+                meets = lambda piece, k: _polyline_in(piece, part_regions[k])
+            else:
+                # slanted outline: general polygon minus the separator's rectangles (poly_clip.py)
+                if len(line.surr_p) < 3:
+                    out.append(line)
+                    continue
+                parts = poly_clip.difference_parts(line.surr_p, rects)
+                area0 = abs(poly_clip.ring_area2(poly_clip._open(line.surr_p))) / 2.0
+                area1 = sum(abs(poly_clip.ring_area2(p)) for p in parts) / 2.0
+                if not parts:                                # swallowed by the separator
+                    continue
+                if area1 >= area0 * (1.0 - 1e-12):           # no area lost: the separator does not run through the line
+                    out.append(line)
+                    continue
+                # a word goes to the part it overlaps most: exact for convex words (quadrilaterals), bounding box otherwise
+                part_area = lambda k, ring: poly_clip.intersection_area(parts[k], ring if poly_clip.is_convex(ring) else _box_ring(ring))
+                meets = lambda piece, k: poly_clip.polyline_meets_ring(piece, parts[k])
             words = [[] for _ in parts]
             if len(parts) != 1:
                 for word in line.words:                      # a word goes to the part it overlaps most (:190-197)
-                    wreg = Region.from_rings([word.surr_p]) if is_rectilinear(word.surr_p) else \
-                        Region.box(*_bbox(word.surr_p))
-                    areas = [wreg.intersection(pr).area for pr in part_regions]
+                    if len(word.surr_p) < 3:                 # a word without an outline overlaps nothing: argmax of zeros = part 0
+                        words[0].append(word)
+                        continue
+                    areas = [part_area(k, word.surr_p) for k in range(len(parts))]
                     words[max(range(len(parts)), key=lambda k: areas[k])].append(word)
             else:
                 words[0] = list(line.words)
-            # baseline pieces -> the first part they run through; parts without a piece are dropped (:203-224)
+            # every baseline piece goes to the FIRST part it meets, a later piece of the same part replaces an earlier one;
+            # parts without a piece are dropped (:203-224, _get_parent_region :146-152)
             pieces = clip_polyline_outside(line.baseline, sep) if line.baseline else []
             owner = {}
             for piece in pieces:
-                for k, pr in enumerate(part_regions):
-                    if k not in owner and _polyline_in(piece, pr):
+                for k in range(len(parts)):
+                    if meets(piece, k):
                         owner[k] = piece
                         break
             if not line.baseline:
@@ -104,7 +126,8 @@ class SeparatorRegionToPageWriter(RegionToPageWriter):
                 if len(parts) != 1 and line.words:
                     text = " ".join(w.text for w in words[k])
                 new_id = line.id if len(parts) == 1 else f"{line.id}_{k + 1}"
-                out.append(line.split_copy(new_id, parts[k][0], owner[k], words[k], text))
+                ring = parts[k] if rectilinear else [(_num(x), _num(y)) for x, y in parts[k] + parts[k][:1]]      # closed like the others
+                out.append(line.split_copy(new_id, ring, owner[k], words[k], text))
         return out
 
     def merge_regions(self, remove_holes=True):
@@ -144,6 +167,18 @@ def _as_rings(polygon):
     if polygon and isinstance(polygon[0], (list, tuple)) and polygon[0] and isinstance(polygon[0][0], (list, tuple)):
         return [list(r) for r in polygon]
     return [list(polygon)]
+
+
+def _box_ring(points):
+    x0, y0, x1, y1 = _bbox(points)
+    return [(x0, y0), (x1, y0), (x1, y1), (x0, y1)]
+
+
+def _num(v):
+    """PAGE coordinates are integers: a cut point on a slanted edge is rounded (half away from zero like ``int(round(v))`` of
+    polygon.py), a value that is integral stays as it is"""
+    r = round(v)
+    return int(r) if abs(v - r) < 1e-9 else int(v + 0.5) if v >= 0 else -int(-v + 0.5)
 
 
 def _bbox(points):

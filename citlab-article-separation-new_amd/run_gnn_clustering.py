@@ -118,29 +118,30 @@ def gnn_clustering(json_paths, flags, device="0"):
     return results
 
 
-def _worker(json_paths, argv, device, q):
+def _worker(json_paths, argv, device, q, index=0):
     try:
         flags = build_parser().parse_known_args(argv)[0]
-        q.put(("ok", gnn_clustering(json_paths, flags, device)))
+        q.put((index, "ok", gnn_clustering(json_paths, flags, device)))
     except Exception as e:  # surfaced to the parent instead of being dropped
-        q.put(("err", repr(e)))
+        q.put((index, "err", repr(e)))
 
 
 def _collect_results(procs, q):
-    """One ("ok" | "err", payload) message per worker; a worker that ends without one is an error."""
+    """One (worker index, "ok" | "err", payload) message per worker.  A worker that ends WITHOUT having posted its message is an
+    error (native crash, OOM kill, HIP abort: fail the run, do not hang); a worker that posted its result and then exits
+    non-zero (a crash at interpreter / HIP teardown) is not -- its pages are done."""
     out, errors = [], []
-    pending = len(procs)
-    while pending:
+    reported = set()
+    while len(reported) < len(procs):
         try:
-            status, payload = q.get(timeout=1.0)
+            index, status, payload = q.get(timeout=1.0)
         except queue.Empty:
-            # a worker that died without posting (native crash, OOM kill, HIP abort) must fail the run, not hang it
-            dead = [pr for pr in procs if not pr.is_alive() and pr.exitcode not in (0, None)]
+            dead = [k for k, pr in enumerate(procs) if k not in reported and not pr.is_alive() and pr.exitcode not in (0, None)]
             if dead and q.empty():
-                errors.extend(f"worker pid {pr.pid} ended with exit code {pr.exitcode} without a result" for pr in dead)
+                errors.extend(f"worker {k} (pid {procs[k].pid}) ended with exit code {procs[k].exitcode} without a result" for k in dead)
                 break
             continue
-        pending -= 1
+        reported.add(index)
         (out.extend if status == "ok" else errors.append)(payload)
     for pr in procs:
         if errors and pr.is_alive():
@@ -161,7 +162,7 @@ def main(argv=None):
     q = ctx.Queue()
     procs = []
     for k, part in enumerate(split_list(json_paths, flags.num_workers)):
-        pr = ctx.Process(target=_worker, args=(part, argv, devices[k % len(devices)], q))
+        pr = ctx.Process(target=_worker, args=(part, argv, devices[k % len(devices)], q, k))
         pr.start()
         procs.append(pr)
     out, errors = _collect_results(procs, q)

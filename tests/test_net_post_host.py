@@ -91,11 +91,32 @@ def test_worker_that_dies_without_result_fails_the_run_instead_of_hanging():
     for pr in procs:
         pr.start()
     out, errors = cli._collect_results(procs, q)
-    assert out == ["fine"] and len(errors) == 1 and "exit code 3" in errors[0]
+    assert out == ["fine"] and len(errors) == 1 and "exit code 3" in errors[0] and "worker 1" in errors[0]
+    # a worker that POSTED its result and then exits non-zero (a crash at teardown) is not a failure, and it must
+    # not get the healthy worker that is still running terminated
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_post_ok_then_crash, args=(q,)), ctx.Process(target=_post_ok_late, args=(q,))]
+    for pr in procs:
+        pr.start()
+    out, errors = cli._collect_results(procs, q)
+    assert sorted(out) == ["early", "late"] and errors == []
 
 
 def _post_ok(q):
-    q.put(("ok", ["fine"]))
+    q.put((0, "ok", ["fine"]))
+
+
+def _post_ok_then_crash(q):
+    q.put((0, "ok", ["early"]))
+    q.close()
+    q.join_thread()
+    os._exit(7)
+
+
+def _post_ok_late(q):
+    import time
+    time.sleep(2.5)
+    q.put((1, "ok", ["late"]))
 
 
 def test_cli_sub_lists_match_reference_arithmetic():

@@ -59,7 +59,7 @@ def test_text_lines_are_cut_at_a_vertical_separator(tmp_path):
     page = _run(tmp_path, {"SeparatorRegion_vertical": [[VSEP]]})
     r1, r2 = page.get_text_regions()
     got = {tl.id: tl for tl in r1.text_lines}
-    assert [tl.id for tl in r1.text_lines] == ["A_1", "A_2", "B", "D_1", "D_2", "E", "F"]        # C is swallowed
+    assert [tl.id for tl in r1.text_lines] == ["A_1", "A_2", "B", "D_1", "D_2", "E_1", "E_2", "F"]        # C is swallowed
     a1, a2 = got["A_1"], got["A_2"]
     assert a1.surr_p == [(10, 10), (98, 10), (98, 40), (10, 40), (10, 10)]
     assert a2.surr_p == [(102, 10), (200, 10), (200, 40), (102, 40), (102, 10)]
@@ -76,8 +76,13 @@ def test_text_lines_are_cut_at_a_vertical_separator(tmp_path):
     assert d2.surr_p == [(102, 130), (200, 130), (200, 150), (120, 150), (120, 170), (102, 170), (102, 130)]
     assert d1.baseline == [(10, 165), (98, 165)] and d2.baseline == [(102, 165), (120, 165), (200, 145)]
     assert d1.text == "no words here" and d2.text == "no words here"          # no Word elements: text is copied (:199-201)
-    # a line that is not rectilinear is left alone; a line that only touches the separator is not cut
-    assert got["E"].surr_p == [(10, 180), (200, 185), (200, 215), (10, 210)]
+    # a SLANTED line is cut too (general polygon clipping, poly_clip.py): top edge y = 180 + 5 (x - 10) / 190 -> 182.32 / 182.42 at
+    # x = 98 / 102, bottom edge 30 lower; baseline y = 205 + 5 (x - 10) / 190 -> 207.32 / 207.42; PAGE coordinates are integers
+    e1, e2 = got["E_1"], got["E_2"]
+    assert e1.surr_p == [(10, 180), (98, 182), (98, 212), (10, 210), (10, 180)]
+    assert e2.surr_p == [(102, 182), (200, 185), (200, 215), (102, 212), (102, 182)]
+    assert e1.baseline == [(10, 205), (98, 207)] and e2.baseline == [(102, 207), (200, 210)]
+    # a line that only touches the separator is not cut
     assert got["F"].surr_p == [(102, 220), (200, 220), (200, 250), (102, 250)]
     assert [tl.id for tl in r2.text_lines] == ["G"]
     seps = page.get_regions()["SeparatorRegion"]
@@ -161,3 +166,64 @@ def test_polyline_clipping():
     assert rg.clip_polyline_outside([(0, 0), (200, 100)], sep) == [[(0, 0), (98, 49)], [(102, 51), (200, 100)]]
     assert rg.ring_line_centroid([(0, 0), (4, 0), (4, 2), (0, 2)]) == (2.0, 1.0)
     assert not rg.is_rectilinear([(0, 0), (4, 1), (4, 2), (0, 2)]) and rg.is_rectilinear(VSEP)
+
+
+def test_general_polygon_difference_hand_cases():
+    """poly_clip.py: slanted outlines against rectilinear separators, expected rings and areas derived by hand"""
+    from citlab_article_separation_new_amd import poly_clip as pc
+
+    def same(got, want):                                               # cut points on slanted edges are one float interpolation
+        return len(got) == len(want) and all(len(g) == len(w) and np.allclose(g, w, rtol=0, atol=1e-9) for g, w in zip(got, want))
+    quad = [(0, 0), (100, 10), (100, 40), (0, 30)]                     # parallelogram: width 100, height 30, area 3000
+    # (1) separator through the whole line: two parts; top edge y = x / 10, bottom edge y = 30 + x / 10
+    parts = pc.difference_parts(quad, [(48.0, -10.0, 52.0, 100.0)])
+    assert same(parts, [[(0.0, 0.0), (48.0, 4.8), (48.0, 34.8), (0.0, 30.0)], [(52.0, 5.2), (100.0, 10.0), (100.0, 40.0), (52.0, 35.2)]])
+    assert abs(sum(pc.ring_area2(p) for p in parts) / 2 - (3000 - 4 * 30)) < 1e-9
+    # (2) separator that ends inside the line: ONE part with a notch (the pieces left / right / below the rectangle are merged)
+    parts = pc.difference_parts(quad, [(48.0, -10.0, 52.0, 20.0)])
+    assert same(parts, [[(0.0, 0.0), (48.0, 4.8), (48.0, 20.0), (52.0, 20.0), (52.0, 5.2), (100.0, 10.0), (100.0, 40.0), (0.0, 30.0)]])
+    assert abs(pc.ring_area2(parts[0]) / 2 - (3000 - 60)) < 1e-9        # notch: x in [48, 52], y from x / 10 to 20 -> 80 - 20
+    # (3) two rectangles of one separator region (an L): the line is cut by the vertical bar only
+    parts = pc.difference_parts(quad, [(48.0, -10.0, 52.0, 50.0), (52.0, 45.0, 90.0, 50.0)])
+    assert len(parts) == 2 and parts[0][0] == (0.0, 0.0) and np.allclose(parts[1][0], (52.0, 5.2))
+    # (4) swallowed / untouched
+    assert pc.difference_parts(quad, [(-5.0, -5.0, 105.0, 45.0)]) == []
+    assert same(pc.difference_parts(quad, [(200.0, 0.0, 210.0, 50.0)]), [[(0.0, 0.0), (100.0, 10.0), (100.0, 40.0), (0.0, 30.0)]])
+    # (5) a concave outline (a "U") cut across both arms: three parts, not one polygon with zero-width bridges
+    u = [(0, 0), (30, 0), (30, 60), (70, 60), (70, 0), (100, 0), (100, 100), (0, 100)]
+    parts = pc.difference_parts(u, [(-10.0, 20.0, 110.0, 30.0)])
+    assert sorted(round(pc.ring_area2(p) / 2) for p in parts) == [600, 600, 100 * 100 - 40 * 60 - 600 - 600 - 2 * 300]
+    # intersection area with a convex (slanted) word box and the point / poly-line predicates
+    word = [(40, 0), (60, 2), (60, 42), (40, 40)]
+    left, right = pc.difference_parts(quad, [(48.0, -10.0, 52.0, 100.0)])
+    assert abs(pc.intersection_area(left, word) - 8 * 30) < 1e-9 and abs(pc.intersection_area(right, word) - 8 * 30) < 1e-9
+    assert pc.is_convex(word) and not pc.is_convex(u)
+    assert pc.point_in_ring((48, 20), left) and pc.point_in_ring((10, 5), left) and not pc.point_in_ring((50, 20), left)
+    assert pc.polyline_meets_ring([(-5, 15), (20, 18)], left) and not pc.polyline_meets_ring([(60, 20), (90, 25)], left)
+
+
+def test_general_polygon_difference_conserves_area():
+    """random convex and star-shaped polygons minus random disjoint rectangles: area(parts) + area(polygon within the rectangles)
+    == area(polygon) (the rectangles are convex: their share is an exact Sutherland-Hodgman clip)"""
+    from citlab_article_separation_new_amd import poly_clip as pc
+    rng = np.random.default_rng(5)
+    for trial in range(60):
+        n = int(rng.integers(3, 9))
+        ang = np.sort(rng.random(n) * 2 * np.pi)
+        rad = (40 + 30 * rng.random(n)) if trial % 2 else np.full(n, 60.0)
+        poly = [(100 + r * np.cos(a), 100 + r * np.sin(a)) for a, r in zip(ang, rad)]
+        if abs(pc.ring_area2(poly)) < 1e-6:
+            continue
+        rects = []
+        x = 40.0
+        for _ in range(int(rng.integers(1, 4))):               # disjoint rectangles, left to right
+            x0 = x + rng.random() * 30
+            x1 = x0 + 2 + rng.random() * 15
+            y0 = 30 + rng.random() * 100
+            rects.append((x0, y0, x1, y0 + 5 + rng.random() * 120))
+            x = x1 + 1
+        parts, holes = pc.difference_parts(poly, rects, with_holes=True)       # (a rectangle inside the polygon leaves a hole)
+        kept = (sum(pc.ring_area2(p) for p in parts) + sum(pc.ring_area2(h) for h in holes)) / 2
+        cut = sum(pc.intersection_area(poly, [(a, b), (c, b), (c, d), (a, d)]) for a, b, c, d in rects)
+        assert abs(kept + cut - abs(pc.ring_area2(poly)) / 2) < 1e-6, (trial, kept, cut)
+        assert all(pc.ring_area2(p) > 0 for p in parts)
