@@ -49,6 +49,8 @@ class GnnConfig:
     classifier_hidden: List[int] = field(default_factory=lambda: [64, 32])
     num_classes: int = 2
     undirected_graph: bool = True
+    # graph_gnn.py:20,102-109: > 0: the (concatenated) node features go through ff_layer(tanh) to this width before the GNN
+    compress_node_feature_dim: int = 0
     # visual branch (GraphRelation image_input); 0 maps -> disabled
     visual_dims: List[int] = field(default_factory=list)   # layer_compressed_dim per feature map
     # feature_map_generation_params from_layer (layer_depth -1): backbone end points, e.g. scale_0_unet_up_2_conv
@@ -75,8 +77,14 @@ class GnnConfig:
         return out
 
     @property
-    def u_dim(self) -> int:
+    def u_in_dim(self) -> int:
+        """width of the node features as fed (geometric + compressed visual dims)"""
         return self.node_feature_dim + sum(self.visual_dims)
+
+    @property
+    def u_dim(self) -> int:
+        """width of the node features the message / update functions see"""
+        return self.compress_node_feature_dim if self.compress_node_feature_dim > 0 else self.u_in_dim
 
     @property
     def message_in_dim(self) -> int:

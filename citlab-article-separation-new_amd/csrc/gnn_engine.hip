@@ -41,6 +41,10 @@ struct asep_gnn {
     int* d_rowptr = nullptr;
     hipStream_t stream = nullptr;
     // visual branch (graph_relation.py:84-139): backbone + per-map compression layers
+    // graph_gnn.py:102-109 compress_node_feature_dim: fed features [N, Uin] -> tanh(Wc x + bc) [N, U]; Uin == U when off
+    int Uin = 0;
+    float* Wc = nullptr;
+    float* bc = nullptr;
     std::map<std::string, HostTensor> vis_blob;      // visual_node_feature_compression_fm_<i>/dense/{weights,bias}
     asep_aru* backbone = nullptr;                    // not owned
     std::vector<std::string> vis_names;
@@ -208,6 +212,11 @@ int forward_impl(asep_gnn* g, int N, int E, const int32_t* d_edges, const float*
     float* x = (float*)g->pool.get((size_t)N * I * 4);
     float* Pt = (float*)g->pool.get((size_t)N * c.cls_hidden1 * 4);
     float* Qt = (float*)g->pool.get((size_t)N * c.cls_hidden1 * 4);
+    if (g->Wc) {                                             // compress_node_feature_dim: the fed features -> tanh(Wc x + bc)
+        float* uc = (float*)g->pool.get((size_t)N * g->U * 4);
+        hipLaunchKernelGGL(gnn_compress_kernel, dim3(cdiv(N * g->U, 256)), dim3(256), 0, s, d_u, N, g->Uin, g->Wc, g->bc, g->U, uc);
+        d_u = uc;
+    }
     float* upad = nullptr;
     const int mode = g->use_step ? g->mode : STEP_GENERIC;
     if (mode == STEP_BIG) {
@@ -277,7 +286,7 @@ int forward_impl(asep_gnn* g, int N, int E, const int32_t* d_edges, const float*
 // on s; d_ug [N, U - visual dims] -> d_u [N, U]
 int visual_rois_dev(asep_gnn* g, int N, const float* d_ug, const std::string& prefix, const float* d_reg, int P,
                     const int32_t* d_np, float* d_u, hipStream_t s) {
-    const int U = g->U, ug = U - g->vis_total;
+    const int U = g->Uin, ug = U - g->vis_total;            // width of the FED (concatenated) features
     if (ug > 0) hipLaunchKernelGGL(gnn_copy_cols_kernel, dim3(cdiv(N * ug, 256)), dim3(256), 0, s, d_ug, N, ug, d_u, U);
     int col = ug;
     for (size_t i = 0; i < g->vis_names.size(); ++i) {
@@ -313,7 +322,7 @@ int visual_features_dev(asep_gnn* g, int N, const float* d_ug, const float* d_im
     g->vis_pool.begin();
     const int ncls = std::max(1, aru_num_classes(g->backbone));
     float* d_bo = (float*)g->vis_pool.get((size_t)h * w * ncls * sizeof(float));   // backbone logits (not used by the graph)
-    int rc = reserve_u_cat(g, (size_t)N * g->U);
+    int rc = reserve_u_cat(g, (size_t)N * g->Uin);
     if (rc) return rc;
     rc = asep_aru_forward_dev(g->backbone, d_img, h, w, d_bo, nullptr, nullptr, 0.f, s);
     if (rc) return rc;
@@ -354,6 +363,7 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
     const int H = g->H = cfg->hidden_dim, I = g->I = cfg->interaction_dim, Hm = g->Hm = cfg->interaction_hidden;
     g->K = 4 * U + Ed + 4 * H;
     g->V = I + H + U;
+    g->Uin = cfg->compress_input_dim > 0 ? cfg->compress_input_dim : U;
     if (((size_t)g->K + Hm + I) * sizeof(float) > 60 * 1024) { set_error("asep_gnn_load: edge-MLP input width %d too large", g->K); return nullptr; }
     const std::string m = MSG, u = UPD, c = CLS;
     int rc = upload_named(g->owned, blob, m + "/fully_connected_layer_h1/weights", {g->K, Hm}, &g->W1);
@@ -371,6 +381,10 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
     if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_layer_h2/bias", {cfg->cls_hidden2}, &g->cb2);
     if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_logit_layer_out/weights", {cfg->cls_hidden2, cfg->num_classes}, &g->C3);
     if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_logit_layer_out/bias", {cfg->num_classes}, &g->cb3);
+    if (!rc && cfg->compress_input_dim > 0) {
+        rc = upload_named(g->owned, blob, "GraphLSTM1/compress_input/ff_compress_input/weights", {g->Uin, U}, &g->Wc);
+        if (!rc) rc = upload_named(g->owned, blob, "GraphLSTM1/compress_input/ff_compress_input/bias", {U}, &g->bc);
+    }
     if (rc) return nullptr;
     for (auto& kv : blob)
         if (kv.first.rfind("visual_node_feature_compression_fm_", 0) == 0) g->vis_blob[kv.first] = kv.second;
@@ -420,7 +434,7 @@ int asep_gnn_forward(asep_gnn* g, int N, int E, const int32_t* edges, const floa
     if (E > 0 && (rc = check_indices("interacting_nodes", edges, (size_t)E, N))) return rc;
     if (relations && R > 0 && (rc = check_indices("relations", relations, (size_t)R, N))) return rc;
     // grow-only device staging in the handle: seven hipMalloc / hipFree pairs per page would cost more than the GNN
-    const size_t ne = (size_t)E * 2, nu = (size_t)N * g->U, nf = (size_t)E * g->Ed;
+    const size_t ne = (size_t)E * 2, nu = (size_t)N * g->Uin, nf = (size_t)E * g->Ed;      // (features as fed: width Uin)
     const size_t nr = relations ? (size_t)R * 2 : 0, no = (size_t)R * g->cfg.num_classes;
     g->host_stage.begin();
     int32_t* d_e = (int32_t*)g->host_stage.get(std::max<size_t>(ne, 1) * sizeof(int32_t));
@@ -516,8 +530,8 @@ int asep_gnn_attach_backbone(asep_gnn* g, asep_aru* backbone, int n_maps, const 
         g->vis_C.push_back(C); g->vis_d.push_back(w->second.dims[1]);
         g->vis_total += w->second.dims[1];
     }
-    if (g->vis_total >= g->U + 1) {
-        set_error("asep_gnn_attach_backbone: %d visual dims exceed node_feature_dim %d", g->vis_total, g->U);
+    if (g->vis_total >= g->Uin + 1) {
+        set_error("asep_gnn_attach_backbone: %d visual dims exceed the fed node feature width %d", g->vis_total, g->Uin);
         g->free_visual();
         return ASEP_ERR_ARG;
     }
@@ -532,7 +546,7 @@ int asep_gnn_forward_visual_dev(asep_gnn* g, int N, int E, const int32_t* d_edge
                                 void* stream) {
     ASEP_GUARD_BEGIN
     if (!g || !g->backbone) { set_error("asep_gnn_forward_visual_dev: no backbone attached"); return ASEP_ERR_ARG; }
-    const int ug = g->U - g->vis_total;
+    const int ug = g->Uin - g->vis_total;
     if (N < 1 || h < 1 || w < 1 || P < 1 || !d_image || !d_regions || !d_num_points || (ug > 0 && !d_node_feat) ||
         (E > 0 && !d_edges) || (R > 0 && !d_probs_out) || (g->Ed > 0 && E > 0 && !d_edge_feat)) {
         set_error("asep_gnn_forward_visual_dev: bad argument");
@@ -549,7 +563,7 @@ int asep_gnn_forward_visual_batch_dev(asep_gnn* g, int n_pages, const asep_gnn_p
     ASEP_GUARD_BEGIN
     if (!g || !g->backbone) { set_error("asep_gnn_forward_visual_batch_dev: no backbone attached"); return ASEP_ERR_ARG; }
     if (n_pages < 1 || !pages || h < 1 || w < 1 || P < 1) { set_error("asep_gnn_forward_visual_batch_dev: bad argument"); return ASEP_ERR_ARG; }
-    const int ug = g->U - g->vis_total;
+    const int ug = g->Uin - g->vis_total;
     size_t nu = 0;
     for (int b = 0; b < n_pages; ++b) {
         const asep_gnn_page& q = pages[b];
@@ -558,7 +572,7 @@ int asep_gnn_forward_visual_batch_dev(asep_gnn* g, int n_pages, const asep_gnn_p
             set_error("asep_gnn_forward_visual_batch_dev: bad argument in page %d", b);
             return ASEP_ERR_ARG;
         }
-        nu += (size_t)q.N * g->U;
+        nu += (size_t)q.N * g->Uin;
     }
     hipStream_t s = (hipStream_t)stream;
     g->vis_pool.begin();
@@ -582,7 +596,7 @@ int asep_gnn_forward_visual_batch_dev(asep_gnn* g, int n_pages, const asep_gnn_p
         if (rc) return rc;
         rc = forward_impl(g, q.N, q.E, q.d_edges, d_u, q.d_edge_feat, q.R, q.d_relations, q.d_probs_out, s);
         if (rc) return rc;
-        d_u += (size_t)q.N * g->U;
+        d_u += (size_t)q.N * g->Uin;
     }
     return ASEP_OK;
     ASEP_GUARD_END
@@ -593,7 +607,7 @@ int asep_gnn_forward_visual(asep_gnn* g, int N, int E, const int32_t* edges, con
                             int R, const int32_t* relations, float* probs_out) {
     ASEP_GUARD_BEGIN
     if (!g || !g->backbone) { set_error("asep_gnn_forward_visual: no backbone attached"); return ASEP_ERR_ARG; }
-    const int U = g->U, ug = U - g->vis_total;
+    const int U = g->Uin, ug = U - g->vis_total;
     if (N < 1 || E < 0 || R < 0 || h < 1 || w < 1 || P < 1 || !image || !regions || !num_points || (ug > 0 && !node_feat) ||
         (E > 0 && !edges) || (R > 0 && !probs_out)) { set_error("asep_gnn_forward_visual: bad argument"); return ASEP_ERR_ARG; }
     int rc;
@@ -628,7 +642,7 @@ int asep_gnn_forward_visual(asep_gnn* g, int N, int E, const int32_t* edges, con
 int asep_gnn_get_node_features(asep_gnn* g, float* out, size_t max_floats) {
     ASEP_GUARD_BEGIN
     if (!g || !out || !g->d_u_cat) { set_error("asep_gnn_get_node_features: no visual forward has run"); return ASEP_ERR_ARG; }
-    const size_t n = (size_t)g->N * g->U;
+    const size_t n = (size_t)g->N * g->Uin;
     if (max_floats < n) { set_error("asep_gnn_get_node_features: buffer too small"); return ASEP_ERR_ARG; }
     ASEP_HIP_CHECK(hipStreamSynchronize(g->stream));
     ASEP_HIP_CHECK(hipMemcpy(out, g->d_u_cat, n * sizeof(float), hipMemcpyDeviceToHost));

@@ -827,6 +827,18 @@ __global__ void __launch_bounds__(256) gnn_roi_compress_kernel(RoiArgs a) {
     }
 }
 
+// graph_gnn.py:102-109 compress_node_feature_dim: y[n][d] = tanh(b[d] + sum_k x[n][k] W[k][d])  (layers.ff_layer with tanh)
+__global__ void __launch_bounds__(256)
+gnn_compress_kernel(const float* __restrict__ x, int N, int K, const float* __restrict__ W, const float* __restrict__ b, int D,
+                    float* __restrict__ y) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * D) return;
+    const int n = i / D, d = i - n * D;
+    float s = b[d];
+    for (int k = 0; k < K; ++k) s = fmaf(x[(size_t)n * K + k], W[(size_t)k * D + d], s);
+    y[i] = tanhf(s);
+}
+
 // copies the geometric node features into the first `ug` columns of the concatenated node feature matrix
 __global__ void __launch_bounds__(256)
 gnn_copy_cols_kernel(const float* __restrict__ src, int N, int ug, float* __restrict__ dst, int ustride) {

@@ -56,7 +56,8 @@ class GnnGraph:
                 raise _lib.AsepError("engine supports one interaction hidden layer and two classifier hidden layers")
             cfg = _lib.GnnCfg(c.u_dim, c.edge_feature_dim, c.num_transition_steps, c.hidden_dim,
                               c.interaction_dim, c.interaction_hidden[0], c.classifier_hidden[0],
-                              c.classifier_hidden[1], c.num_classes, int(c.undirected_graph))
+                              c.classifier_hidden[1], c.num_classes, int(c.undirected_graph),
+                              c.u_in_dim if c.compress_node_feature_dim > 0 else 0)
             blob = self.blob()
             h = lib.asep_gnn_load(blob, len(blob), C.byref(cfg))
             if not h:
@@ -89,18 +90,21 @@ class GnnGraph:
             pass
 
 
-def load_graph(pb_path, visual_layers=None) -> GnnGraph:
+def load_graph(pb_path, visual_layers=None, num_transition_steps=None) -> GnnGraph:
     """gnn/io.py:12-25.  Accepts a TF1 frozen graph (``*.pb``, decoded without TensorFlow by ``pb_import.py``)
     or the engine's ``*.asepw`` container (+ ``.json`` side-car).  ``visual_layers`` names the backbone end points
     of a graph exported with ``--image_input`` (``--feature_map_generation_params from_layer=[...]``); the names
-    are not recoverable from the constants alone, the default is ``scale_0_unet_up_<level>_conv`` per map."""
+    are not recoverable from the constants alone, the default is ``scale_0_unet_up_<level>_conv`` per map.
+    ``num_transition_steps`` is read from the op graph (one edge-MLP MatMul per step); only a constants-only container
+    without that structure needs it passed in."""
     if isinstance(pb_path, GnnGraph):
         return pb_path
     if not os.path.isfile(pb_path):
         raise IOError(f"No such model file: {pb_path}")
     if str(pb_path).endswith(".pb"):
         from . import pb_import
-        tensors, cfg = pb_import.gnn_from_nodes(pb_import.read_graph(pb_path), visual_layers=visual_layers)
+        tensors, cfg = pb_import.gnn_from_nodes(pb_import.read_graph(pb_path), visual_layers=visual_layers,
+                                                num_transition_steps=num_transition_steps)
         return GnnGraph(tensors, cfg, pb_path)
     tensors, meta = load_weights(pb_path)
     cfg = GnnConfig(**(meta or {}).get("gnn_cfg", {}))
@@ -273,7 +277,7 @@ def step_mode(graph: GnnGraph, device=0) -> str:
 def gnn_node_features(graph: GnnGraph, num_nodes, device=0):
     """Concatenated [geometric | visual] node features of the last visual forward (tests)."""
     lib = _lib.init_device(device)
-    out = np.empty((int(num_nodes), graph.cfg.u_dim), dtype=np.float32)
+    out = np.empty((int(num_nodes), graph.cfg.u_in_dim), dtype=np.float32)
     _lib.check(lib.asep_gnn_get_node_features(graph.handle(device), out.ctypes.data, out.size),
                "asep_gnn_get_node_features")
     return out

@@ -737,7 +737,47 @@ def aru_from_nodes(nodes, num_scales_att=None, apply_softmax=None):
     return tensors, cfg
 
 
-def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None):
+_PASS_THROUGH = ("Identity", "Enter", "Switch", "Merge", "NextIteration", "Exit", "StopGradient", "PlaceholderWithDefault")
+
+
+def _find_key(consts, suffix):
+    hits = [k for k in consts if k == suffix or k.endswith("/" + suffix)]
+    hits.sort(key=len)
+    return hits[0] if hits else None
+
+
+def _count_matmul_users(nodes, const_name):
+    """MatMul ops that read the constant ``const_name`` (through /read identities and the Enter ops of a while loop): the edge
+    MLP of the message function is built once per transition step (graph_gnn.py:134-157 unrolls the steps in Python, the
+    variables are shared with AUTO_REUSE, message_fn_chunk.py:356-363), so this is ``num_transition_steps``."""
+    users = {}
+    for n in nodes:
+        for r in n.get("input", []):
+            base = r.lstrip("^").split(":")[0]
+            users.setdefault(base, []).append(n)
+    seen, todo, hits = {const_name}, [const_name], set()
+    while todo:
+        cur = todo.pop()
+        for n in users.get(cur, []):
+            if n["op"] in ("MatMul", "BatchMatMul", "BatchMatMulV2"):
+                hits.add(n["name"])
+            elif n["op"] in _PASS_THROUGH and n["name"] not in seen:
+                seen.add(n["name"])
+                todo.append(n["name"])
+    return len(hits)
+
+
+def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None, num_transition_steps=None):
+    """GraphDef of a relation net (model_relation.py / graph_relation.py / graph_gnn.py) -> (tensors, GnnConfig).
+
+    Widths come from the constants' shapes; the options an exporter can bake into the graph are read from its STRUCTURE and
+    either served or refused with the reason (never silently assumed):
+      num_transition_steps (graph_gnn.py:19)        = number of MatMul ops on the edge MLP's first layer; a constants-only
+                                                      container carries it as ``asep_meta/num_transition_steps`` or takes the argument
+      compress_node_feature_dim (graph_gnn.py:20)   = GraphLSTM1/compress_input/ff_compress_input/weights present -> served
+      output_type add / concat (graph_gnn.py:23)    = GraphLSTM1/dense/weights present, or a classifier input wider than 2 x hidden -> refused
+      use_attention / heads (message_fn_chunk.py:35-41) = .../calculation_unnormalized_attention_values/... or .../head_1/... -> refused
+    """
     consts = const_tensors(nodes)
     pref = ("GraphLSTM1/message_fn_default/head_0/calculation_interaction_features/concat_u_and_h/"
             "interaction_features")
@@ -745,15 +785,58 @@ def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None):
     wu = _find(consts, "GraphLSTM1/update_function_LSTM/ingate_activation/dense/weights")
     if w1 is None or wu is None:
         raise IOError("no GNN variables (GraphLSTM1/...) among the graph constants")
+    if any("/message_fn_default/head_1/" in k for k in consts):
+        raise IOError("the graph has several attention heads (message_fn_chunk.py:37, num_attention_heads > 1): not supported, the "
+                      "engine implements the single-head, degree-normalised aggregation (message_fn_chunk.py:369-386)")
+    if any("calculation_unnormalized_attention_values" in k for k in consts):
+        raise IOError("the graph aggregates with learned attention (message_fn_chunk.py:35,203-216 use_attention=True): not "
+                      "supported, the engine implements the degree-normalised sum of the reference's default")
+    if _find(consts, "GraphLSTM1/dense/weights") is not None:
+        raise IOError("the graph adds a projection of the input features to the final hidden state (graph_gnn.py:160-163 "
+                      "output_type='add_final_hidden_and_input'): not supported")
     hidden = int(wu.shape[1])
-    u_dim = int(wu.shape[0]) - 2 * hidden                       # v = [x, h, u]
+    w2 = _find(consts, pref + "/fully_connected_logit_layer_out/weights")
+    inter = int(w2.shape[1]) if w2 is not None else hidden
+    u_dim = int(wu.shape[0]) - inter - hidden                  # v = [x, h, u]: u = the width the message / update functions see
     e_dim = int(w1.shape[0]) - 4 * u_dim - 4 * hidden
+    if u_dim < 0 or e_dim < 0:
+        raise IOError(f"inconsistent GNN constant shapes: update input {wu.shape[0]}, edge MLP input {w1.shape[0]}, hidden {hidden}")
+    wcmp = _find(consts, "GraphLSTM1/compress_input/ff_compress_input/weights")
+    compress = 0
+    u_in = u_dim
+    if wcmp is not None:
+        if int(wcmp.shape[1]) != u_dim:
+            raise IOError(f"compress_input layer maps to {wcmp.shape[1]} features, the GNN reads {u_dim}")
+        compress, u_in = u_dim, int(wcmp.shape[0])
+    wc1 = _find(consts, "Classification/logits/fully_connected_layer_h1/weights")
+    wo = _find(consts, "Classification/logits/fully_connected_logit_layer_out/weights")
+    first = wc1 if wc1 is not None else wo
+    if first is None:
+        raise IOError("no classifier (Classification/logits/...) among the graph constants")
+    if int(first.shape[0]) != 2 * hidden:
+        how = ("graph_gnn.py:164-166 output_type='concat_final_hidden_and_input'" if int(first.shape[0]) == 2 * (hidden + u_in)
+               else "unknown layout")
+        raise IOError(f"the pair classifier reads {first.shape[0]} features per pair, 2 x hidden = {2 * hidden} expected ({how}): "
+                      "not supported")
+    # ---- number of transition steps: from the op graph, the container's metadata or the caller
+    steps_graph = _count_matmul_users(nodes, _find_key(consts, pref + "/fully_connected_layer_h1/weights"))
+    meta = _find(consts, "asep_meta/num_transition_steps")
+    if steps_graph > 0:
+        steps = steps_graph
+        if num_transition_steps is not None and int(num_transition_steps) != steps:
+            raise IOError(f"num_transition_steps={num_transition_steps} given, the graph unrolls {steps} transition steps")
+    elif meta is not None:
+        steps = int(np.asarray(meta).reshape(-1)[0])
+    elif num_transition_steps is not None:
+        steps = int(num_transition_steps)
+    else:
+        raise IOError("the container holds the GNN constants but no op graph: the number of transition steps (graph_gnn.py:19) is "
+                      "not derivable from shared weights; pass num_transition_steps (or export with asep_meta/num_transition_steps)")
     cls_hidden = []
     i = 1
     while _find(consts, f"Classification/logits/fully_connected_layer_h{i}/weights") is not None:
         cls_hidden.append(int(_find(consts, f"Classification/logits/fully_connected_layer_h{i}/weights").shape[1]))
         i += 1
-    wo = _find(consts, "Classification/logits/fully_connected_logit_layer_out/weights")
     vis_kw = {}
     if any("visual_node_feature_compression" in k for k in consts):
         # graph exported with --image_input (graph_relation.py:17-37): backbone + one compression layer per map
@@ -779,10 +862,14 @@ def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None):
         backbone = {k: v for k, v in bcfg.to_dict().items() if k not in ("apply_softmax", "mvn")}
         backbone["mvn"] = bool(bcfg.mvn)
         vis_kw = dict(visual_dims=dims, visual_layers=list(visual_layers), mvn=mvn, backbone=backbone)
-        u_dim -= sum(dims)
-    cfg = GnnConfig(node_feature_dim=u_dim, edge_feature_dim=e_dim, hidden_dim=hidden, interaction_dim=hidden,
+        u_in -= sum(dims)
+        if u_in < 0:
+            raise IOError(f"the visual compression layers produce {sum(dims)} features, the GNN is fed {u_in + sum(dims)}")
+    cfg = GnnConfig(node_feature_dim=u_in, edge_feature_dim=e_dim, num_transition_steps=steps, hidden_dim=hidden,
+                    interaction_dim=inter,
                     interaction_hidden=[int(w1.shape[1])], classifier_hidden=cls_hidden,
-                    num_classes=int(wo.shape[1]), undirected_graph=undirected_graph, **vis_kw)
+                    num_classes=int(wo.shape[1]), undirected_graph=undirected_graph, compress_node_feature_dim=compress,
+                    **vis_kw)
     if vis_kw and cfg.visual_channels() != chans:
         raise IOError(f"visual_layers {cfg.visual_layers} have {cfg.visual_channels()} channels, the compression "
                       f"layers expect {chans}")
@@ -846,8 +933,12 @@ def encode_graphdef(nodes):
     return bytes(out)
 
 
-def weights_to_graphdef(tensors, prefix="graph/", extra_nodes=()):
+def weights_to_graphdef(tensors, prefix="graph/", extra_nodes=(), meta=None):
+    """constants-only container; ``meta`` ({"num_transition_steps": 3, ...}) becomes int32 constants ``asep_meta/<key>`` (what the op
+    graph of a real export says structurally and shared weights cannot)"""
     nodes = [{"name": "inImg", "op": "Placeholder"}]
+    for k, v in (meta or {}).items():
+        nodes.append({"name": prefix + "asep_meta/" + k, "op": "Const", "value": np.asarray([int(v)], np.int32)})
     for i, (name, arr) in enumerate(tensors.items()):
         nodes.append({"name": prefix + name, "op": "Const", "value": np.asarray(arr, np.float32), "packed": i % 2 == 1})
         nodes.append({"name": prefix + name + "/read", "op": "Identity", "input": [prefix + name]})

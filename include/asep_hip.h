@@ -124,6 +124,9 @@ typedef struct asep_gnn_cfg {
     int32_t cls_hidden2;           /* 32 */
     int32_t num_classes;           /* 2 (<= 16) */
     int32_t undirected_graph;      /* 1 */
+    int32_t compress_input_dim;    /* graph_gnn.py:20,102-109 compress_node_feature_dim: 0 = off; > 0: node features are FED with this
+                                      width and go through tanh(W x + b) (GraphLSTM1/compress_input/ff_compress_input/{weights,bias})
+                                      to node_feature_dim before the message passing */
 } asep_gnn_cfg;
 
 typedef struct asep_gnn asep_gnn;

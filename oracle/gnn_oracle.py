@@ -74,6 +74,9 @@ def forward(num_nodes, edges, node_feat, edge_feat, relations, w, cfg, dtype=np.
     N = int(num_nodes)
     w = {k: v.astype(dtype) for k, v in w.items()}
     u = np.asarray(node_feat, dtype=dtype).reshape(N, -1)
+    if getattr(cfg, "compress_node_feature_dim", 0) > 0:            # graph_gnn.py:102-109: ff_layer(tanh) on the fed features
+        u = np.tanh(u @ w["GraphLSTM1/compress_input/ff_compress_input/weights"]
+                    + w["GraphLSTM1/compress_input/ff_compress_input/bias"]).astype(dtype)
     ce, cf = correct_edges(edges, edge_feat, N, cfg.undirected_graph)
     cf = cf.astype(dtype) if cf is not None else np.zeros((ce.shape[0], 0), dtype)
     frm, to = ce[:, 0], ce[:, 1]

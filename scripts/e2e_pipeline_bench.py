@@ -66,7 +66,7 @@ try:
     extra.append({"name": "output", "op": "Softmax", "input": ["graph/aru_net/logit/logits"]})
     for name, seed in (("sep.pb", 21), ("head.pb", 22)):
         (root / name).write_bytes(pb_import.weights_to_graphdef(init_aru_weights(acfg, seed, logit_scale=0.05), "graph/", extra))
-    (root / "gnn.pb").write_bytes(pb_import.weights_to_graphdef(init_gnn_weights(GnnConfig(), 23), "graph/"))
+    (root / "gnn.pb").write_bytes(pb_import.weights_to_graphdef(init_gnn_weights(GnnConfig(), 23), "graph/", meta={"num_transition_steps": 3}))
     print(f"{n_pages} pages {W}x{H}, {n_regions} text regions in total")
 
     def timed(label, fn):

@@ -93,7 +93,7 @@ def test_full_chain(tmp_path):
     column = np.array([i % 3 for i in range(15)])
     gw = gnn_cases.calibrate_l1_classifier(init_gnn_weights(gcfg, 23, bias_jitter=0.05), gcfg, 15, ref[1], ref[3][:, keep],
                                            ref[4], column[:, None] == column[None, :], wrong_side=0.2, seed=5)
-    (tmp_path / "gnn.pb").write_bytes(pb_import.weights_to_graphdef(gw, "graph/"))
+    (tmp_path / "gnn.pb").write_bytes(pb_import.weights_to_graphdef(gw, "graph/", meta={"num_transition_steps": 3}))
     # 4. GNN + clustering with masking
     jl = tmp_path / "eval.lst"
     jl.write_text(str(jpath) + "\n")

@@ -38,7 +38,7 @@ def test_cli_end_to_end_article_ids_identical(tmp_path):
     g0, w, cfg, _ = gac.build(case)
     model = tmp_path / "model" / "export"
     model.mkdir(parents=True)
-    (model / "gnn_best_2026.pb").write_bytes(pb_import.weights_to_graphdef(w, "graph/"))
+    (model / "gnn_best_2026.pb").write_bytes(pb_import.weights_to_graphdef(w, "graph/", meta={"num_transition_steps": 3}))
     data = tmp_path / "data"
     (data / "page").mkdir(parents=True)
     (data / "json15d2bb").mkdir()

@@ -68,7 +68,7 @@ def test_session_mirror_with_image_feeds_and_pb_roundtrip(tmp_path):
     cfg, w, _ = _setup(mvn=True, layers=("scale_0_unet_up_1_conv", "scale_0_unet_down_2_conv"), dims=(16, 8), seed=5)
     extra = [{"name": "graph/map/per_image_standardization/Mean", "op": "Mean"}]
     pb = tmp_path / "gnn_visual.pb"
-    pb.write_bytes(pb_import.weights_to_graphdef(w, "graph/", extra))
+    pb.write_bytes(pb_import.weights_to_graphdef(w, "graph/", extra, meta={"num_transition_steps": cfg.num_transition_steps}))
     # the importer cannot know the from_layer names: defaults assume up-path outputs ...
     g_default = gnn_io.load_graph(str(pb))
     assert g_default.cfg.visual_layers == ["scale_0_unet_up_1_conv", "scale_0_unet_up_2_conv"]

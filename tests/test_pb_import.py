@@ -38,7 +38,7 @@ def test_gnn_roundtrip_and_load_graph(tmp_path):
     cfg = GnnConfig()
     w = init_gnn_weights(cfg, 9, bias_jitter=0.03)
     p = tmp_path / "gnn.pb"
-    p.write_bytes(pb_import.weights_to_graphdef(w, "graph/"))
+    p.write_bytes(pb_import.weights_to_graphdef(w, "graph/", meta={"num_transition_steps": 3}))
     g = gnn_io.load_graph(str(p))
     assert g.cfg.node_feature_dim == 7 and g.cfg.edge_feature_dim == 2 and g.cfg.classifier_hidden == [64, 32]
     assert all(np.array_equal(g.tensors[k], w[k]) for k in w)

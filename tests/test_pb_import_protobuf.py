@@ -225,3 +225,75 @@ def test_constants_only_container_never_defaults():
         pb_import.aru_from_nodes(nodes, num_scales_att=3)
     tensors, got = pb_import.aru_from_nodes(nodes, num_scales_att=3, apply_softmax=False)
     assert got.num_scales_att == 3 and got.apply_softmax is False
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# relation net: the exporter's options are read from the graph's structure (never silently assumed)
+# ------------------------------------------------------------------------------------------------------------------
+def _gnn_nodes(cfg, steps, extra=None, seed=3):
+    import tf_gnn_graph
+    from citlab_article_separation_new_amd.weights import init_gnn_weights
+    ns = tp.build_messages()
+    w = init_gnn_weights(cfg, seed, bias_jitter=0.02)
+    g = tf_gnn_graph.build(ns, w, steps, extra_consts=extra)
+    return pb_import.parse_graphdef(g.SerializeToString()), w
+
+
+@pytest.mark.parametrize("steps", [1, 2, 3, 4])
+def test_gnn_transition_steps_are_counted_from_the_op_graph(steps):
+    from citlab_article_separation_new_amd.config import GnnConfig
+    nodes, w = _gnn_nodes(GnnConfig(), steps)
+    tensors, cfg = pb_import.gnn_from_nodes(nodes)
+    assert cfg.num_transition_steps == steps and cfg.node_feature_dim == 7 and cfg.edge_feature_dim == 2
+    assert cfg.compress_node_feature_dim == 0 and cfg.classifier_hidden == [64, 32] and cfg.interaction_dim == 32
+    assert all(np.array_equal(tensors[k], w[k]) for k in w)
+    with pytest.raises(IOError, match="unrolls"):
+        pb_import.gnn_from_nodes(nodes, num_transition_steps=steps + 1)
+
+
+def test_gnn_compression_layer_is_detected_and_loaded():
+    from citlab_article_separation_new_amd.config import GnnConfig
+    src = GnnConfig(node_feature_dim=15, compress_node_feature_dim=6, num_transition_steps=2, hidden_dim=24, interaction_dim=20,
+                    interaction_hidden=[28], classifier_hidden=[40, 12])
+    nodes, w = _gnn_nodes(src, 2)
+    tensors, cfg = pb_import.gnn_from_nodes(nodes)
+    assert (cfg.node_feature_dim, cfg.compress_node_feature_dim, cfg.u_dim, cfg.u_in_dim) == (15, 6, 6, 15)
+    assert (cfg.hidden_dim, cfg.interaction_dim, cfg.interaction_hidden, cfg.classifier_hidden) == (24, 20, [28], [40, 12])
+    assert cfg.num_transition_steps == 2
+    assert tensors["GraphLSTM1/compress_input/ff_compress_input/weights"].shape == (15, 6)
+    assert set(tensors) == set(w)
+
+
+def test_gnn_options_the_engine_does_not_serve_are_refused_with_the_reason():
+    from citlab_article_separation_new_amd.config import GnnConfig
+    att = "GraphLSTM1/message_fn_default/head_0/calculation_unnormalized_attention_values/attention_values/fully_connected_layer_h1/weights"
+    nodes, _ = _gnn_nodes(GnnConfig(), 3, extra={att: np.zeros((30, 16))})
+    with pytest.raises(IOError, match="use_attention"):
+        pb_import.gnn_from_nodes(nodes)
+    head1 = ("GraphLSTM1/message_fn_default/head_1/calculation_interaction_features/concat_u_and_h/interaction_features/"
+             "fully_connected_layer_h1/weights")
+    nodes, _ = _gnn_nodes(GnnConfig(), 3, extra={head1: np.zeros((158, 32))})
+    with pytest.raises(IOError, match="attention heads"):
+        pb_import.gnn_from_nodes(nodes)
+    nodes, _ = _gnn_nodes(GnnConfig(), 3, extra={"GraphLSTM1/dense/weights": np.zeros((7, 32))})
+    with pytest.raises(IOError, match="add_final_hidden_and_input"):
+        pb_import.gnn_from_nodes(nodes)
+    # output_type concat: the pair classifier reads 2 x (hidden + u) features
+    nodes, w = _gnn_nodes(GnnConfig(), 3)
+    for n in nodes:
+        if n["name"].endswith("Classification/logits/fully_connected_layer_h1/weights"):
+            n["value"] = np.zeros((2 * (32 + 7), 64), np.float32)
+    with pytest.raises(IOError, match="concat_final_hidden_and_input"):
+        pb_import.gnn_from_nodes(nodes)
+
+
+def test_gnn_constants_only_container_needs_the_step_count():
+    from citlab_article_separation_new_amd.config import GnnConfig
+    from citlab_article_separation_new_amd.weights import init_gnn_weights
+    w = init_gnn_weights(GnnConfig(), 1)
+    nodes = pb_import.parse_graphdef(pb_import.weights_to_graphdef(w, "graph/"))
+    with pytest.raises(IOError, match="num_transition_steps"):
+        pb_import.gnn_from_nodes(nodes)
+    assert pb_import.gnn_from_nodes(nodes, num_transition_steps=5)[1].num_transition_steps == 5
+    nodes = pb_import.parse_graphdef(pb_import.weights_to_graphdef(w, "graph/", meta={"num_transition_steps": 2}))
+    assert pb_import.gnn_from_nodes(nodes)[1].num_transition_steps == 2

@@ -1,0 +1,78 @@
+"""TEST INFRASTRUCTURE: the relation net's op graph the way TensorFlow 1.x freezes it -- as far as an importer can tell the
+exporter's options apart (``/root/reference/article_separation/gnn/model/graph/graph_gnn.py:19-23,102-109,134-166``,
+``message_fn_chunk.py:35-41,167-176,356-363,420-422``):
+
+  * every variable is a Const + ``/read`` Identity, created ONCE (the transition steps share weights, AUTO_REUSE);
+  * the transition steps are unrolled in Python: step t has its own ops; the edge MLP runs inside the chunking ``tf.while_loop``
+    of MessageFnChunk, so its MatMul reads the weights through an ``Enter`` op: ONE MatMul on ``fully_connected_layer_h1/weights``
+    per step -- the only place ``num_transition_steps`` is visible in a frozen graph;
+  * ``compress_node_feature_dim`` adds ``GraphLSTM1/compress_input/ff_compress_input/{weights,bias}`` + MatMul / BiasAdd / Tanh;
+  * ``use_attention`` adds ``.../head_k/calculation_unnormalized_attention_values/...`` variables, ``num_attention_heads`` > 1 the
+    scopes ``head_1``, ...; ``output_type='add_final_hidden_and_input'`` an un-named ``GraphLSTM1/dense/weights`` (no bias),
+    ``'concat_final_hidden_and_input'`` a pair classifier that is 2 x u wider.
+The graph is serialised by google.protobuf (tests/tf_graphdef_proto.py), not by the product's encoder; only structure the importer
+reads is modelled (data-flow ops between the MatMuls are abbreviated)."""
+import numpy as np
+
+import tf_graphdef_proto as tp
+
+F32 = tp.DType(tp.DT_FLOAT)
+MSG = "GraphLSTM1/message_fn_default/head_0/calculation_interaction_features/concat_u_and_h/interaction_features"
+UPD = "GraphLSTM1/update_function_LSTM"
+CLS = "Classification/logits"
+
+
+def build(ns, weights, num_transition_steps, prefix="graph/", extra_consts=None):
+    nodes, made = [], set()
+
+    def add(name, op, inputs=(), **attrs):
+        nodes.append(tp.node(ns, name, op, inputs, **attrs))
+        return name
+
+    def var(name):
+        full = prefix + name
+        if full not in made:
+            made.add(full)
+            arr = np.asarray(weights[name], np.float32)
+            nodes.append(tp.node(ns, full, "Const", (), dtype=F32, value=arr))
+            add(full + "/read", "Identity", [full], T=F32)
+        return full + "/read"
+
+    for ph in ("num_nodes", "interacting_nodes", "node_features", "edge_features", "relations_to_consider_belong_to_same_instance"):
+        add(ph, "Placeholder", dtype=F32)
+    u = "node_features"
+    if "GraphLSTM1/compress_input/ff_compress_input/weights" in weights:
+        s = prefix + "GraphLSTM1/compress_input/ff_compress_input"
+        u = add(s + "/Tanh", "Tanh", [add(s + "/BiasAdd", "BiasAdd", [add(s + "/MatMul", "MatMul", [u, var("GraphLSTM1/compress_input/ff_compress_input/weights")], T=F32),
+                                                                  var("GraphLSTM1/compress_input/ff_compress_input/bias")], T=F32)], T=F32)
+    h = add(prefix + "GraphLSTM1/zeros", "Fill", ["num_nodes"], T=F32)
+    for t in range(num_transition_steps):
+        sfx = "" if t == 0 else f"_{t}"
+        loop = prefix + f"GraphLSTM1/message_fn_default{sfx}/head_0/while"
+        z = add(loop + "/concat", "ConcatV2", [u, h, "edge_features"], T=F32, N=3)
+        x = z
+        for layer in ("fully_connected_layer_h1", "fully_connected_logit_layer_out"):
+            enter_w = add(f"{loop}/{layer}/MatMul/Enter", "Enter", [var(f"{MSG}/{layer}/weights")], T=F32, frame_name=loop, is_constant=True)
+            enter_b = add(f"{loop}/{layer}/BiasAdd/Enter", "Enter", [var(f"{MSG}/{layer}/bias")], T=F32, frame_name=loop, is_constant=True)
+            x = add(f"{loop}/{layer}/BiasAdd", "BiasAdd", [add(f"{loop}/{layer}/MatMul", "MatMul", [x, enter_w], T=F32), enter_b], T=F32)
+        gates = []
+        for g in ("ingate", "outgate", "forgetgate", "cellinput"):
+            s = prefix + f"{UPD}{sfx}/{g}_activation/dense"
+            gates.append(add(s + "/BiasAdd", "BiasAdd", [add(s + "/MatMul", "MatMul", [x, var(f"{UPD}/{g}_activation/dense/weights")], T=F32),
+                                                          var(f"{UPD}/{g}_activation/dense/bias")], T=F32))
+        h = add(prefix + f"{UPD}{sfx}/mul_2", "Mul", gates[:2], T=F32)
+    x = h
+    i = 1
+    while f"{CLS}/fully_connected_layer_h{i}/weights" in weights:
+        s = prefix + f"{CLS}/fully_connected_layer_h{i}"
+        x = add(s + "/Relu", "Relu", [add(s + "/BiasAdd", "BiasAdd", [add(s + "/MatMul", "MatMul", [x, var(f"{CLS}/fully_connected_layer_h{i}/weights")], T=F32),
+                                                                      var(f"{CLS}/fully_connected_layer_h{i}/bias")], T=F32)], T=F32)
+        i += 1
+    s = prefix + f"{CLS}/fully_connected_logit_layer_out"
+    x = add(s + "/BiasAdd", "BiasAdd", [add(s + "/MatMul", "MatMul", [x, var(f"{CLS}/fully_connected_logit_layer_out/weights")], T=F32),
+                                        var(f"{CLS}/fully_connected_logit_layer_out/bias")], T=F32)
+    add("output_belong_to_same_instance", "Softmax", [x], T=F32)
+    for name, arr in (extra_consts or {}).items():             # variables of options the engine does not serve
+        nodes.append(tp.node(ns, prefix + name, "Const", (), dtype=F32, value=np.asarray(arr, np.float32)))
+        add(prefix + name + "/read", "Identity", [prefix + name], T=F32)
+    return tp.graphdef(ns, nodes)
