@@ -82,6 +82,46 @@ def test_whole_page_bf16_vs_oracle(whole_page):
     g.close()
 
 
+def test_whole_page_fp32_end_points_and_logits_with_unit_logit_scale():
+    """the whole-frame gate above is on probabilities of weights with logit_scale = 0.05 (small logits compress a
+    feature-map error ~20x before the 1e-4 gate).  Here: reference-rule weights (logit_scale = 1), EVERY end point of the
+    3000 x 4500 frame within 2e-5 * max|ref| (the gate tests/test_aru_gpu.py applies up to 259 x 131), the LOGITS within the same
+    relative gate, and the probabilities within 1e-4."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper, synth
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    from oracle import aru_oracle
+    cfg = AruConfig()
+    w = init_aru_weights(cfg, 4321, bias_jitter=0.05, logit_scale=1.0)
+    page = synth.synth_page(1, W, H).astype(np.float32) / 255.0
+    ref, inter = aru_oracle.forward_torch(page, w, cfg, return_intermediates=True)
+    g = helper.AruGraph(w, cfg)
+    out = helper.get_net_output(page, g, "0")
+    worst = ("", 0.0)
+    for name in sorted(inter):
+        if not (name.startswith("scale_") or name.startswith("att_")):
+            continue
+        got = helper.get_endpoint(g, name)
+        want = inter[name]
+        assert got.shape == want.shape, name
+        rel = float(np.abs(got - want).max()) / max(1.0, float(np.abs(want).max()))
+        worst = max(worst, (name, rel), key=lambda t: t[1])
+        assert rel <= 2e-5, (name, rel)
+        del got
+    perr = float(np.abs(out - ref).max())
+    g.close()
+    # logits: the same net without the class softmax
+    cfg_l = AruConfig(apply_softmax=False)
+    gl = helper.AruGraph(w, cfg_l)
+    logits = helper.get_net_output(page, gl, "0")
+    lref = inter["logits"]
+    lrel = float(np.abs(logits - lref).max()) / max(1.0, float(np.abs(lref).max()))
+    gl.close()
+    print(f"\nfp32 whole frame, logit_scale 1: worst end point {worst[0]} rel {worst[1]:.2e}; logits max|l| {np.abs(lref).max():.2f} "
+          f"rel {lrel:.2e}; max|dp| = {perr:.2e}; saturated pixels (p > 0.999): {(ref.max(axis=2) > 0.999).mean():.1%}")
+    assert lrel <= 2e-5 and perr <= 1e-4
+
+
 def test_c1_crop_512x768_through_the_separator_cli(tmp_path):
     """BASELINE configs[0]: one 512 x 768 crop, --fixed_height 768 so that the net sees the crop itself."""
     from citlab_article_separation_new_amd import image_io, pb_import, polygonize, synth

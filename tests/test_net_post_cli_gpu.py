@@ -1,7 +1,9 @@
 """End to end on the GPU through the reference's CLI surface (run_net_post_processing.py --mode separator|heading):
 image file + frozen graph (.pb) -> PAGE-XML.  The fused device path (uint8 upload -> resize/gray -> ARU-Net -> uint8
 + threshold epilogue -> CC filter / openings) must give exactly what the reference's step-by-step sequence gives
-when each step is evaluated separately (net through get_net_output, classical steps by the CPU oracle)."""
+when EVERY step is evaluated by the CPU oracle (net: oracle/aru_oracle.py on the weights of the .pb; classical steps:
+oracle/classical_oracle.py; heading fusion rule: restated in this file from heading_net_post_processor.py:94-195).
+Nothing on the expected side comes from the engine."""
 import numpy as np
 import pytest
 from PIL import Image
@@ -64,10 +66,15 @@ def test_separator_cli_matches_stepwise_reference_sequence(tmp_path, fixed_heigh
     # step-by-step sequence of separator_net_post_processor.py:141-151 (oracle for the classical steps)
     _, grey, sc = co.scale_and_gray(img, fixed_height, 1.0)
     graph = helper.load_graph(pb)
-    prob = helper.get_net_output(grey, graph, "0")
+    from oracle import aru_oracle
+    prob = aru_oracle.forward_torch(grey.astype(np.float32), graph.tensors, graph.cfg)      # the ORACLE's net output
     thr = round(float(np.median(prob[:, :, 0])), 3)                 # random weights: put the threshold mid-range
-    net_u8 = np.array(prob * 255, dtype=np.uint8)
-    mask = helper.apply_threshold(net_u8, thr)
+    net_u8 = aru_oracle.to_uint8(prob)
+    mask = aru_oracle.apply_threshold(net_u8, thr)
+    # (the engine's probabilities differ from the oracle's by ~1e-7, so a uint8 value can flip by one where p * 255 sits on an
+    # integer: the engine's uint8 map may differ in at most a handful of pixels, none of them at the threshold)
+    eng_u8 = np.array(helper.get_net_output(grey, graph, "0") * 255, dtype=np.uint8)
+    assert (eng_u8 != net_u8).mean() <= 1e-4 and np.array_equal(helper.apply_threshold(eng_u8, thr), mask)
     post = co.separator_post_process(mask)
     assert 0.02 < (mask[:, :, 0] > 0).mean() < 0.98
     # expected PAGE-XML: the writer fed with the ORACLE-side polygons on a copy of the input page (text lines a
@@ -107,31 +114,55 @@ def test_heading_cli_matches_stepwise_reference_sequence(tmp_path):
     img = image_io.load_image_bgr(str(data / "p0.png"))
     _, grey, sc = co.scale_and_gray(img, 450, 1.0)
     graph = helper.load_graph(pb)
-    net_u8 = np.array(helper.get_net_output(grey, graph, "0") * 255, dtype=np.uint8)
+    from oracle import aru_oracle
+    net_u8 = aru_oracle.to_uint8(aru_oracle.forward_torch(grey.astype(np.float32), graph.tensors, graph.cfg))
     swt = co.swt_distance_transform(img)
-    # expected tags: the same fusion code fed with oracle-side feature images, written to a scratch copy
-    ref_dir = tmp_path / "ref"
-    (ref_dir / "page").mkdir(parents=True)
-    (ref_dir / "p0.png").write_bytes((data / "p0.png").read_bytes())
-    (ref_dir / "page" / "p0.xml").write_text((data / "page" / "p0.xml").read_text())
-    proc = HeadingNetPostProcessor([], pb, 450, 1.0, {'net': 0.8, 'stroke_width': 0.0, 'text_height': 0.2}, 0.4,
-                                   {'net_thresh': 1.0, 'stroke_width_thresh': 1.0, 'text_height_thresh': 0.9,
-                                    'sw_th_thresh': 0.9}, 0.8)
-    proc.to_page_xml(str(ref_dir / "page" / "p0.xml"), str(ref_dir / "p0.png"), net_u8[:, :, 0] / 255, swt)
-    ref = Page(str(ref_dir / "page" / "p0.xml.xml"))
+    # expected tags: the fusion rule of heading_net_post_processor.py:94-195 restated HERE on oracle-side per-line measurements
+    # (CLI constants: weights net 0.8 / stroke width 0.0 / text height 0.2; OR-thresholds 1.0 / 1.0 / 0.9 / 0.9; heading iff
+    # confidence > 0.4; region heading iff >= 0.8 of its lines; run_net_post_processing.py:15-23)
+    from collections import Counter
+    page_in = Page(str(data / "page" / "p0.xml"))
+    lines_in = page_in.get_textlines()
+    net_map = net_u8[:, :, 0] / 255
+    sw, th, netp = {}, {}, {}
+    for tl in lines_in:
+        sw[tl.id], th[tl.id] = co.swt_features_textline(swt, tl.get_bounding_box())
+        xs = [int(sc * x) for x, _ in tl.surr_p]
+        ys = [int(sc * y) for _, y in tl.surr_p]
+        netp[tl.id] = co.net_prob_textline(net_map, (min(xs), min(ys), max(xs) - min(xs) + 1, max(ys) - min(ys) + 1))
+    sw_mode = Counter(sw.values()).most_common(1)[0][0]
+    th_mode = Counter(th.values()).most_common(1)[0][0]
+    dsw = {k: v - sw_mode for k, v in sw.items()}
+    dth = {k: v - th_mode for k, v in th.items()}
+
+    def unit(v, lo, hi):                                             # scale_to_new_interval(.., 0, 1), :50-63
+        return v if hi - lo == 0 else (v - lo) / (hi - lo)
+    want_lines = {}
+    for tl in lines_in:
+        c_sw = unit(dsw[tl.id], min(dsw.values()), max(dsw.values()))
+        c_th = unit(dth[tl.id], min(dth.values()), max(dth.values()))
+        if c_sw >= 1.0 or c_th >= 0.9 or (c_sw + c_th) / 2 >= 0.9 or netp[tl.id] >= 1.0:
+            conf = 1.0
+        else:
+            conf = 0.8 * netp[tl.id] + 0.0 * c_sw + 0.2 * c_th
+        want_lines[tl.id] = "heading" if conf > 0.4 else None
+    want_regions = {}
+    for r in page_in.get_text_regions():
+        n_head = sum(1 for tl in r.text_lines if want_lines[tl.id] == "heading")
+        want_regions[r.id] = "heading" if r.text_lines and n_head / len(r.text_lines) >= 0.8 else "paragraph"
+    assert "heading" in want_lines.values() and None in want_lines.values()        # the case discriminates
 
     rc = cli.main(["--path_to_image_list", lst, "--path_to_pb", pb, "--mode", "heading", "--fixed_height", "450",
                    "--num_processes", "1"])
     assert rc == 0
     out = Page(str(data / "page" / "p0.xml.xml"))
-    assert [(t.id, t.get_semantic_type()) for t in out.get_textlines()] == \
-           [(t.id, t.get_semantic_type()) for t in ref.get_textlines()]
-    assert [(r.id, r.region_type) for r in out.get_text_regions()] == \
-           [(r.id, r.region_type) for r in ref.get_text_regions()]
-    assert {r.region_type for r in out.get_text_regions()} <= {"heading", "paragraph"}
-    # the two device-side inputs of the fusion are the oracle's, bit for bit
+    assert {t.id: t.get_semantic_type() for t in out.get_textlines()} == want_lines
+    assert {r.id: r.region_type for r in out.get_text_regions()} == want_regions
+    # the two device-side inputs of the fusion against the oracle's: the distance transform bit for bit, the uint8 net map up to
+    # isolated +-1 flips where p * 255 sits on an integer (the probabilities agree to ~1e-7)
     hp = HeadingNetPostProcessor([str(data / "p0.png")], pb, 450, 1.0)
-    assert np.array_equal(hp.heading_probability(img), net_u8)
+    eng = hp.heading_probability(img)
+    assert (eng != net_u8).mean() <= 1e-4 and int(np.abs(eng.astype(int) - net_u8.astype(int)).max()) <= 1
     assert np.array_equal(hp.SWT.distance_transform(img), swt)
 
 
