@@ -31,6 +31,21 @@ constexpr int R8V_FILTER = R8V_WINO ? 768 : 576;
 // The kernels take Res8Args like the MFMA kernels; the filters behind w1 (UP) and wr are in scalar layout instead of
 // pixel-pair fragments: UP w1 = [2 sources][R8V_FILTER], wr = [3][R8V_FILTER] floats.
 
+// Float offset of the 16-byte piece (pixel x of the row, channel half hf) inside an LDS row, for the vector-ALU kernels.  The
+// layout idea is r8_px's (res8_kernels.h: the four pieces of a 64-byte pixel-pair record permuted by the pair index P = x >> 1),
+// but the permutation is chosen for THIS access pattern: a thread reads the same piece of pair P = p + const, p = lane & 31, and
+// a ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (MI355X_MICROARCH.md, LDS table) -- not
+// in runs of 16 consecutive lanes.  With r8_px's term (P >> 1) & 3 lanes 12..15 and 20..23 (and 0..3 / 24..27) of a group meet
+// in the same bank quad: SQ_LDS_BANK_CONFLICT was 37-41 % of SQ_LDS_IDX_ACTIVE in res8v_down / res8v_up (profiles/r2t).  The
+// term below, bit 2 of P | (bit 1 ^ bit 3 of P) << 1, gives 16 distinct bank quads per group for every window offset (exhaustive
+// check over the XOR-linear candidates: scripts/ubench/lds_swizzle_search.py; none is conflict-free for the 8-lane groups of the
+// ds_write_b128 as well -- the stores, 4 against 24 reads per stage, stay 2-way in half of their groups).
+__device__ __forceinline__ int r8v_px(int x, int hf) {
+    const int P = x >> 1;
+    const int g = ((P >> 2) & 1) | ((((P >> 1) ^ (P >> 3)) & 1) << 1);
+    return (P << 4) + (((((x & 1) << 1) | hf) ^ g) << 2);
+}
+
 __device__ __forceinline__ f32x4 r8v_ld(r8v_lds p) { return *reinterpret_cast<const f32x4 __attribute__((address_space(3)))*>(p); }
 __device__ __forceinline__ void r8v_st(r8v_lds p, f32x4 v) { *reinterpret_cast<f32x4 __attribute__((address_space(3)))*>(p) = v; }
 
@@ -209,7 +224,7 @@ __device__ __forceinline__ f32x4 r8v_upper4(f32x4 v) {
 // a stage with first output column c0 reads pixels c0 - 1 + 2p + i (i = 0..3) = entries c0 - 1 + i.  Computed once per kernel.
 __device__ __forceinline__ void r8v_pixel_offsets(int tid, int (&poff)[7][2]) {
 #pragma unroll
-    for (int j = 0; j < 7; ++j) { poff[j][0] = r8_px(2 * (tid & 31) + j, 0) * 4; poff[j][1] = r8_px(2 * (tid & 31) + j, 1) * 4; }
+    for (int j = 0; j < 7; ++j) { poff[j][0] = r8v_px(2 * (tid & 31) + j, 0) * 4; poff[j][1] = r8v_px(2 * (tid & 31) + j, 1) * 4; }
 }
 // the eight address registers of a window: row_bytes = byte offset of the first input row from the LDS base.  Laundered
 // so that the compiler keeps the sums in registers (re-associated, every LDS access would pay a v_add of its own: the
@@ -392,8 +407,8 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
                 f32x4 lo = ok ? f32x4{acc[0], acc[1], acc[2], acc[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
                 f32x4 hi = ok ? f32x4{acc[4], acc[5], acc[6], acc[7]} : f32x4{0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4*>(T + r * R8_PITCH * 8 + r8_px(c, 0)) = lo;
-                *reinterpret_cast<f32x4*>(T + r * R8_PITCH * 8 + r8_px(c, 1)) = hi;
+                *reinterpret_cast<f32x4*>(T + r * R8_PITCH * 8 + r8v_px(c, 0)) = lo;
+                *reinterpret_cast<f32x4*>(T + r * R8_PITCH * 8 + r8v_px(c, 1)) = hi;
             }
             __syncthreads();
             res8v_stage<true, false, false>(sm, T, 1, R0, 2, first ? 2 : 6, first ? 20 : 16, 2, wr, a.br, tid, poff, interior, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
@@ -433,7 +448,7 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     constexpr int NPF = R8_FH / 3;
     f32x4 pf[NPF];
     const int rg = tid / ROWV, cs = tid - rg * ROWV;
-    const int pf_dst = (rg * R8_PITCH * 8 + r8_px(cs >> 1, cs & 1)) * 4;      // byte offset of the thread's piece in tile row rg
+    const int pf_dst = (rg * R8_PITCH * 8 + r8v_px(cs >> 1, cs & 1)) * 4;      // byte offset of the thread's piece in tile row rg
     // carried: only frame rows 6..23 are needed (conv1 then reads rows 6..23 only), i.e. k >= 2.  ONE code path for
     // both kinds of frame (a run-time predicate, not two call sites): with two, the register allocator gave the eight
     // destinations different registers per path, and the wait-count pass then made the following stage wait for the
