@@ -132,6 +132,7 @@ struct asep_aru {
     bool wino16 = false;           // ASEP_WINO16=1: register-resident Winograd also at the 16-channel level (measured: 99 vs
                                    // 103 TFLOP/s-equivalent for the direct kernels, parity-green; kept as an experiment switch)
     bool bf_th8 = true;            // ASEP_BF_TH8=0: 16 x 32 instead of 8 x 32 pixel blocks for the 32-channel bf16 convs
+    bool bf_w8 = true;             // ASEP_BF_W8=0: four instead of eight waves per block in the >= 64-channel bf16 convs
     int bf_mtb = 4;                // ASEP_BF_MTB=2: 32 instead of 64 output channels per block at >= 64 channels
     bool profiling = false;
     bool prof_detail = false;      // per-layer names (scope + spatial size) instead of per-kernel names
@@ -1084,13 +1085,18 @@ Tensor new_tensor_bf(asep_aru* m, int H, int W, int C) {
 
 #define ASEP_CONVB_LAUNCH(KH_, KW_, MODE_, MT_, WM_, TH_, MB_)                                                         \
     do {                                                                                                               \
-        ps.set_name("convb_kernel" + targs({ti(KH_), ti(KW_), ti(MODE_), ti(MT_), ti(WM_), ti(TH_), ti(MB_), tb(false)})); \
-        hipLaunchKernelGGL((convb_kernel<KH_, KW_, MODE_, MT_, WM_, TH_, MB_, false>), grid, dim3(256), 0, m->stream, a); \
+        ps.set_name("convb_kernel" + targs({ti(KH_), ti(KW_), ti(MODE_), ti(MT_), ti(WM_), ti(TH_), ti(MB_), tb(false), ti(4)})); \
+        hipLaunchKernelGGL((convb_kernel<KH_, KW_, MODE_, MT_, WM_, TH_, MB_, false, 4>), grid, dim3(256), 0, m->stream, a); \
+    } while (0)
+#define ASEP_CONVB_LAUNCH8(KH_, KW_, MODE_, MT_, WM_, TH_, MB_, RES_)                                                  \
+    do {                                                                                                               \
+        ps.set_name("convb_kernel" + targs({ti(KH_), ti(KW_), ti(MODE_), ti(MT_), ti(WM_), ti(TH_), ti(MB_), tb(RES_), ti(8)})); \
+        hipLaunchKernelGGL((convb_kernel<KH_, KW_, MODE_, MT_, WM_, TH_, MB_, RES_, 8>), grid, dim3(512), 0, m->stream, a); \
     } while (0)
 #define ASEP_CONVB_LAUNCH_RES(KH_, KW_, MODE_, MT_, WM_, TH_, MB_)                                                     \
     do {                                                                                                               \
-        ps.set_name("convb_kernel" + targs({ti(KH_), ti(KW_), ti(MODE_), ti(MT_), ti(WM_), ti(TH_), ti(MB_), tb(true)})); \
-        hipLaunchKernelGGL((convb_kernel<KH_, KW_, MODE_, MT_, WM_, TH_, MB_, true>), grid, dim3(256), 0, m->stream, a); \
+        ps.set_name("convb_kernel" + targs({ti(KH_), ti(KW_), ti(MODE_), ti(MT_), ti(WM_), ti(TH_), ti(MB_), tb(true), ti(4)})); \
+        hipLaunchKernelGGL((convb_kernel<KH_, KW_, MODE_, MT_, WM_, TH_, MB_, true, 4>), grid, dim3(256), 0, m->stream, a); \
     } while (0)
 
 // stride-1 SAME conv of the bf16 path.  pooled != nullptr: the epilogue also writes maxpool2 of the output (always fused here);
@@ -1150,7 +1156,7 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
         switch (key) {
             case 3322: ASEP_CONVB_LAUNCH_RES(3, 3, 2, 2, 1, 8, 3); break;       // residual operand prefetched (32- and >= 64-channel convR_2)
             case 2322: ASEP_CONVB_LAUNCH_RES(3, 3, 2, 2, 1, 16, 2); break;
-            case 2324: ASEP_CONVB_LAUNCH_RES(3, 3, 2, 2, 2, 8, 2); break;
+            case 2324: ASEP_CONVB_LAUNCH_RES(3, 3, 2, 2, 2, 8, 2); break;       // (eight waves: 146 registers = one block per CU, 46 -> 52 us)
             case 1322: ASEP_CONVB_LAUNCH(3, 3, 2, 2, 1, 8, 4); break;
             case 301: ASEP_CONVB_LAUNCH(3, 3, 0, 1, 1, 16, 3); break;
             case 302: ASEP_CONVB_LAUNCH(3, 3, 0, 2, 1, 16, 3); break;
@@ -1160,7 +1166,7 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
             case 314: ASEP_CONVB_LAUNCH(3, 3, 1, 2, 2, 8, 3); break;
             case 321: ASEP_CONVB_LAUNCH(3, 3, 2, 1, 1, 16, 3); break;
             case 322: ASEP_CONVB_LAUNCH(3, 3, 2, 2, 1, 16, 3); break;
-            case 324: ASEP_CONVB_LAUNCH(3, 3, 2, 2, 2, 8, 3); break;
+            case 324: if (m->bf_w8) ASEP_CONVB_LAUNCH8(3, 3, 2, 2, 2, 8, 2, false); else ASEP_CONVB_LAUNCH(3, 3, 2, 2, 2, 8, 3); break;
             case 411: ASEP_CONVB_LAUNCH(4, 4, 1, 1, 1, 16, 3); break;
             case 412: ASEP_CONVB_LAUNCH(4, 4, 1, 2, 1, 16, 3); break;
             case 414: ASEP_CONVB_LAUNCH(4, 4, 1, 2, 2, 8, 3); break;
@@ -1671,6 +1677,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_SIDE_STREAM")) m->use_side_stream = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_TH8")) m->bf_th8 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_MTB")) m->bf_mtb = atoi(e) == 2 ? 2 : 4;
+    if (const char* e = getenv("ASEP_BF_W8")) m->bf_w8 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_R8B")) m->use_r8b = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_R8F")) m->use_r8f = atoi(e) != 0;
     if (const char* e = getenv("ASEP_LANES")) m->num_lanes = std::max(1, std::min(4, atoi(e)));

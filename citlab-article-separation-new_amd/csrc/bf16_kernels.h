@@ -80,11 +80,14 @@ struct ConvBArgs {
 // wave = the whole vector-memory path of a CU, and every chunk waited for an L2 round trip.
 // RESP: the layer has a residual operand; its values are requested BEFORE the last stage's MFMAs (2 MT NT registers) instead of
 // in the epilogue, where their HBM latency was exposed (a residual layer took 74 us against 42 us for its twin without one).
-template <int KH, int KW, int MODE, int MT, int WM, int TH, int MINB, bool RESP = false>
-__global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
+// NW = waves per block (4, or 8 for the >= 64-channel layers: twice the waves per CU over the same LDS tile -- those layers are
+// short chains of dependent LDS reads and MFMAs, more waves overlap them).
+template <int KH, int KW, int MODE, int MT, int WM, int TH, int MINB, bool RESP = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a) {
+    constexpr int NTH = 64 * NW;
     static_assert(MODE != 0 || (KH == 3 && KW == 3), "MODE 0 is the 3x3 conv with 8 input channels");
     static_assert(WM == 1 || WM == 2, "one or two waves along the output channels");
-    constexpr int TW = 32, WN = 4 / WM, NT = TH * 2 / WN, MTB = MT * WM;
+    constexpr int TW = 32, WN = NW / WM, NT = TH * 2 / WN, MTB = MT * WM;
     static_assert(NT % 4 == 0, "a wave owns whole row pairs (fused 2x2 pool)");
     constexpr int LH = TH + KH - 1, LW = TW + KW - 1 + (MODE == 0 ? 1 : 0);     // MODE 0 reads a 4th (zero-weight) column
     constexpr int PT = (KH - 1) / 2, PL = (KW - 1) / 2;                         // TF SAME: pad_before = (k-1)/2
@@ -94,8 +97,8 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
     constexpr int PLANE = LH * LW * PXB;
     constexpr int NPL = MODE == 2 ? 2 : 1;
     constexpr int CPS = MODE == 0 ? KH : (MODE == 1 ? (TAPS + 1) / 2 : TAPS);   // K chunks per stage
-    constexpr int NU = LH * LW * SUBS, NLOAD = (NU + 255) / 256;
-    constexpr int NWU = CPS * MTB * 64, NWLOAD = (NWU + 255) / 256;             // 16-byte units of a stage's A fragments
+    constexpr int NU = LH * LW * SUBS, NLOAD = (NU + NTH - 1) / NTH;
+    constexpr int NWU = CPS * MTB * 64, NWLOAD = (NWU + NTH - 1) / NTH;             // 16-byte units of a stage's A fragments
     __shared__ __attribute__((aligned(16))) unsigned char lds[NPL * PLANE + NWU * 16];
     unsigned char* const wlds = lds + NPL * PLANE;
 
@@ -141,15 +144,15 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
     unsigned stmask = 0;
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
-        const int u = min(tid + i * 256, NU - 1);
+        const int u = min(tid + i * NTH, NU - 1);
         const int pix = u / SUBS, sub = u - pix * SUBS;
         const int ly = pix / LW, lx = pix - ly * LW;
         const int gy = y0 - PT + ly, gx = x0 - PL + lx;
         spix[i] = min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1);
         slds[i] = (sub >> 1) * PLANE + pix * PXB + (sub & 1) * 16;
-        stmask |= ((gy >= 0 && gy < H && gx >= 0 && gx < W && tid + i * 256 < NU) ? 1u : 0u) << i;
+        stmask |= ((gy >= 0 && gy < H && gx >= 0 && gx < W && tid + i * NTH < NU) ? 1u : 0u) << i;
     }
-    const int sub0 = (tid % SUBS) * 8;                        // (256 is a multiple of SUBS: the sub-block is the same for all slots)
+    const int sub0 = (tid % SUBS) * 8;                        // (the block size is a multiple of SUBS: the sub-block is the same for all slots)
 
     for (int g = 0; g < ngroups; ++g) {
         // ---- stage g: halo tile of 32 (16, 8) input channels + the stage's A fragments -> LDS.  Requests first; zero padding /
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
         // base + 16 i); whole waves, NWU is a multiple of 64
 #pragma unroll
         for (int i = 0; i < NWLOAD; ++i) {
-            const int u0 = i * 256 + wave * 64;              // wave-uniform
+            const int u0 = i * NTH + wave * 64;              // wave-uniform
 #if defined(CONVB_ABL) && (CONVB_ABL & 2)
             if (false) {                                     // timing experiment: no weight copies
 #else
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256, MINB) void convb_kernel(const ConvBArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
-            if (i * 256 + 255 < NU || tid + i * 256 < NU) {
+            if (i * NTH + NTH - 1 < NU || tid + i * NTH < NU) {
                 u32x4 v = ((stmask >> i) & 1u) ? st[i] : u32x4{0u, 0u, 0u, 0u};
                 if (a.relu_in) v = relu_bf16x8(v);
                 *reinterpret_cast<u32x4*>(lds + slds[i]) = v;
