@@ -34,6 +34,7 @@ METRIC = "newspaper pages/sec (ARU-Net seg + GNN relation) at 3000x4500 px"
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # same guide: dense bf16 matrix peak (not the 2:1-sparsity headline)
 PEAK_HBM_GBS = 8000.0
+ACHIEVABLE_HBM_GBS = 6300.0         # same guide: float4 copy, 79 % of the 8 TB/s peak
 
 
 def parse_args():
@@ -499,7 +500,7 @@ def main():
             "whole_page_executed_frac": round(exec_flops_page * value / world / 1e12 / peak_tf, 4),
             "traffic": None, "traffic_source": None,
         }
-        tp = os.path.join(ROOT, "profiles", "traffic_per_kernel.json")
+        tp = os.path.join(ROOT, "profiles", "traffic_per_kernel.json" if args.dtype == "f32" else f"traffic_per_kernel_{args.dtype}.json")
         if os.path.exists(tp):      # HBM bytes/launch from separate rocprofv3 --pmc passes (profiles/README.md, scripts/make_traffic_json.py)
             try:
                 tj_all = json.load(open(tp))
@@ -516,6 +517,20 @@ def main():
                     roofline["hbm_frac"] = round(roofline["hbm_tb_per_s"] / (PEAK_HBM_GBS / 1e3), 4)
                     roofline["whole_page_traffic_gb"] = round(tj_all["page_bytes"] / 1e9, 2)
                     roofline["whole_page_hbm_frac"] = round(tj_all["page_bytes"] * value / world / 1e9 / PEAK_HBM_GBS, 4)
+                    if args.dtype == "bf16":
+                        # the bf16 data path is HBM-bound by design (activations are the bytes; the MFMA peak is 16x the fp32 one):
+                        # the block's primary figures are the HBM ones, the matrix-core figures move to "mfma"
+                        roofline["mfma"] = {"achieved": roofline["achieved"], "peak": roofline["peak"], "unit": "TFLOP/s",
+                                            "frac": roofline["frac"], "frac_in_situ": roofline["frac_in_situ"],
+                                            "frac_isolated": roofline["frac_isolated"],
+                                            "whole_page_executed_frac": roofline["whole_page_executed_frac"]}
+                        gbs = roofline["traffic"] / (lead["avg_us"] * 1e-6) / 1e9
+                        roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                         "frac": round(gbs / PEAK_HBM_GBS, 4), "achievable_peak": ACHIEVABLE_HBM_GBS,
+                                         "frac_of_achievable": round(gbs / ACHIEVABLE_HBM_GBS, 4)})
+                        if d_situ and d_iso:
+                            roofline["frac_in_situ"] = round(roofline["traffic"] / (d_situ["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)
+                            roofline["frac_isolated"] = round(roofline["traffic"] / (d_iso["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)
             except Exception:
                 pass
         for k in kernels:

@@ -57,7 +57,8 @@ def main():
            "width": line["config"]["width"],
            "unit": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024, mean over dispatches (scripts/profile_bench.sh)",
            "page_bytes": page_bytes, "pages_in_profiled_run": steps_total * B, "kernels": kernels}
-    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_per_kernel.json")
+    name = "traffic_per_kernel.json" if line["dtype"] == "f32" else f"traffic_per_kernel_{line['dtype']}.json"
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", name)
     json.dump(out, open(dst, "w"), indent=1)
     print(dst, len(kernels), "kernels;", f"{page_bytes / 1e9:.2f} GB per page")
 

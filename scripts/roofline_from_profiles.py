@@ -47,7 +47,8 @@ def recompute(tagdir):
     avg_us = stats[k]["avg_ns"] / 1e3
     lk = {q["kernel"]: q for q in line["kernels"]}
     exec_fl = r["executed_flops_per_launch"]
-    peak = r["peak"]
+    hbm_bound = r["bound"] == "hbm"                            # bf16 lines: the primary figures are bytes / s, the matrix ones under "mfma"
+    peak = r["mfma"]["peak"] if hbm_bound else r["peak"]
     achieved = exec_fl / (avg_us * 1e-6) / 1e12
     # whole page: executed FLOPs of all ARU-Net kernels per page (Winograd kernels execute 1/2.25 of their direct-conv credit)
     ev_steps = max(1, r.get("event_timed_steps", 1))
@@ -55,8 +56,8 @@ def recompute(tagdir):
     out = {
         "kernel": k,
         "avg_launch_us": avg_us,
-        "achieved": achieved,
-        "frac": achieved / peak,
+        "mfma_achieved" if hbm_bound else "achieved": achieved,
+        "mfma_frac" if hbm_bound else "frac": achieved / peak,
         "whole_page_executed_gflop": exec_page / 1e9,
         "whole_page_executed_frac": exec_page * line["value"] / line["n_gpus"] / 1e12 / peak,
     }
@@ -64,6 +65,9 @@ def recompute(tagdir):
         out["traffic"] = kernels[k]["bytes_per_launch"]
         out["hbm_tb_per_s"] = out["traffic"] / (avg_us * 1e-6) / 1e12
         out["hbm_frac"] = out["hbm_tb_per_s"] / (PEAK_HBM_GBS / 1e3)
+        if hbm_bound:
+            out["achieved"] = out["hbm_tb_per_s"] * 1e3
+            out["frac"] = out["hbm_frac"]
     out["whole_page_traffic_gb"] = page_bytes / 1e9
     out["whole_page_hbm_frac"] = page_bytes * line["value"] / line["n_gpus"] / 1e9 / PEAK_HBM_GBS
     # chip time per page by rocprofv3 (sum of all asep:: kernel durations; streams overlap, so this is >= the wall time per page)
@@ -82,8 +86,14 @@ def recompute(tagdir):
 
 def compare(line, rec, tol):
     r = line["roofline"]
-    pairs = {"avg_launch_us": r.get("avg_launch_us_in_situ") or r["avg_launch_us"], "achieved": r["achieved"], "frac": r["frac"],
+    pairs = {"avg_launch_us": r.get("avg_launch_us_in_situ") or r["avg_launch_us"],
              "whole_page_executed_gflop": r["whole_page_executed_gflop"], "whole_page_executed_frac": r["whole_page_executed_frac"]}
+    if r["bound"] == "hbm":
+        pairs.update({"mfma_achieved": r["mfma"]["achieved"], "mfma_frac": r["mfma"]["frac"]})
+        if "achieved" in rec:
+            pairs.update({"achieved": r["achieved"], "frac": r["frac"]})
+    else:
+        pairs.update({"achieved": r["achieved"], "frac": r["frac"]})
     for f in ("traffic", "hbm_tb_per_s", "hbm_frac", "whole_page_traffic_gb", "whole_page_hbm_frac"):
         if r.get(f) is not None and f in rec:
             pairs[f] = r[f]
