@@ -1,0 +1,67 @@
+"""The `roofline` block of the bench line must follow from the rocprofv3 summaries committed under profiles/ (VERDICT r2, next #1):
+scripts/roofline_from_profiles.py recomputes it from kernel_stats.csv (launch durations), pmc_summary.json (FETCH_SIZE / WRITE_SIZE,
+FETCH doubled: the gfx950 correction of MI355X_MICROARCH.md) and the FLOP totals of the line, and the two must agree to 3 %.
+Runs on the committed summaries of the fp32 headline build and of the bf16 build (CPU only)."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import make_traffic_json  # noqa: E402
+import roofline_from_profiles as rfp  # noqa: E402
+
+TAGS = [t for t in ("r3f", "r3f_bf16") if os.path.exists(os.path.join(ROOT, "profiles", t, "kernel_stats.csv"))]
+
+
+def test_kernel_keys_are_the_full_rocprof_names():
+    key = make_traffic_json.kernel_key
+    assert key("void asep::conv_mfma_kernel<3, 3, 1, false, 16, false, false, false, 4>(asep::ConvArgs)") == \
+        "conv_mfma_kernel<3,3,1,false,16,false,false,false,4>"
+    assert key("void asep::conv_mfma_kernel<3, 3, 1, false, 16, false, false, false, 2>(asep::ConvArgs)") != \
+        key("void asep::conv_mfma_kernel<3, 3, 1, false, 16, false, false, false, 4>(asep::ConvArgs)")       # r2: these two collided
+    assert key("asep::res8v_up_kernel(asep::Res8Args)") == "res8v_up_kernel"
+    assert key("void asep::combine_kernel<8, 2, false>(asep::CombineArgs)") == "combine_kernel<8,2,false>"
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_roofline_block_is_reproducible_from_the_committed_summaries(tag):
+    tagdir = os.path.join(ROOT, "profiles", tag)
+    line, rec, table = rfp.recompute(tagdir)
+    pairs, dev, ok = rfp.compare(line, rec, 0.03)
+    assert ok, {k: (pairs[k], rec[k], dev[k]) for k in pairs}
+    r = line["roofline"]
+    # the compared set covers the launch time, the achieved rate and fraction, the PMC traffic and the whole-page figures
+    assert {"avg_launch_us", "achieved", "frac", "traffic", "hbm_frac", "whole_page_executed_frac", "whole_page_traffic_gb"} <= set(pairs)
+    assert r["timing"] == "in situ" and r["kernel"] in {t["kernel"] for t in table}
+    # the table joins every engine-side kernel name with a rocprofv3 row (no name table in between)
+    engine = {k["kernel"] for k in line["kernels"]}
+    assert engine <= {t["kernel"] for t in table}, engine - {t["kernel"] for t in table}
+    # sanity against the definitions: traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 of the dominant kernel's PMC rows
+    pmc = json.load(open(os.path.join(tagdir, "pmc_summary.json")))
+    f = next(v for k, v in pmc["FETCH_SIZE"].items() if make_traffic_json.kernel_key(k) == r["kernel"])
+    w = next(v for k, v in pmc["WRITE_SIZE"].items() if make_traffic_json.kernel_key(k) == r["kernel"])
+    assert abs((2 * f["avg_per_dispatch"] + w["avg_per_dispatch"]) * 1024 / r["traffic"] - 1) < 1e-6
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_untraced_line_of_the_same_build_uses_the_same_traffic_table(tag):
+    """profiles/<tag>/bench.json is the default (un-traced) run: its traffic fields come from the table of the traced build and its
+    fractions are arithmetic on its own timings (launch time x traffic -> TB/s -> fraction of 8 TB/s)."""
+    line = rfp.load_line(os.path.join(ROOT, "profiles", tag, "bench.json"))
+    r = line["roofline"]
+    assert r["traffic"] and r["frac_in_situ"] and r["frac_isolated"] and r["whole_page_executed_frac"]
+    tb_s = r["traffic"] / (r["avg_launch_us"] * 1e-6) / 1e12
+    if r["bound"] == "hbm":
+        assert abs(tb_s * 1e3 / r["achieved"] - 1) < 2e-3 and abs(r["achieved"] / r["peak"] / r["frac"] - 1) < 2e-3
+        assert r["mfma"]["peak"] == 2500.0
+    else:
+        assert abs(tb_s / r["hbm_tb_per_s"] - 1) < 2e-3 and abs(r["achieved"] / r["peak"] / r["frac"] - 1) < 2e-3
+        assert r["peak"] == 157.3
+    assert line["config"]["timed_region_s"] >= 8.0
+
+
+def test_summaries_are_committed():
+    assert TAGS, "profiles/r3f (and r3f_bf16) with kernel_stats.csv / pmc_summary.json / bench_under_trace.json / bench.json expected"
