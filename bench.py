@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--event-steps", type=int, default=3,
                     help="steps per HIP-event pass (scripts/profile_bench.sh uses many event-timed and few plain steps, so that "
                          "rocprofv3's per-kernel averages cover the launches the events bracket)")
+    ap.add_argument("--dominant", default=None,
+                    help="report the roofline block for THIS kernel (scripts/profile_round.sh passes the kernel the un-traced default "
+                         "line named, so that the traced line and the rocprofv3 summaries describe the same kernel)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="same as --kernel-timing none")
     ap.add_argument("--e2e-pages", type=int, default=192,
                     help="scans of the files-in / files-out secondary figure (separator CLI path with host workers; 0 = skip)")
@@ -463,7 +466,7 @@ def main():
             situ, n_prof, main_calls = kernel_pass(3)
         base = iso or situ                          # the dominant kernel is chosen on the isolated times when both exist
         kernels = sorted(base.values(), key=lambda k: -k["total_ms"])
-        dom = kernels[0]
+        dom = next((k for k in kernels if k["kernel"] == args.dominant), kernels[0])
         d_iso, d_situ = (iso or {}).get(dom["kernel"]), (situ or {}).get(dom["kernel"])
         lead = d_situ or d_iso                      # `achieved` / `frac` are the in-situ figures when measured (the lower ones)
         groups = next((c for name, c in main_calls.items() if name.startswith("res8") and "_up_" in name), dom["calls"])
