@@ -162,11 +162,14 @@ def e2e_files(args, dev):
         dt = time.perf_counter() - t0
         n_xml = len([f for f in os.listdir(os.path.join(tmp, "page")) if f.endswith(".xml.xml")])
     graph.close()
+    first = proc.first_page_seconds or 0.0
     return {"pages_per_s": round(n / dt, 2), "ms_per_page": round(1e3 * dt / n, 2), "scans": n, "host_workers": workers,
+            "first_page_s": round(first, 2), "steady_pages_per_s": round((n - 1) / max(dt - first, 1e-9), 2),
             "page_xml_written": n_xml, "gpu_owner_device_stage_share": round(proc.device_seconds / dt, 3),
             "gpu_owner_waiting_for_decode_share": round(proc.wait_seconds / dt, 3),
             "note": f"separator CLI path, --fixed_height {H} (net on the full {W}x{H} page): PNG files -> {workers} decode / XML "
-                    f"worker processes around ONE GPU owner -> PAGE-XML files; worker start-up inside the timed region; "
+                    f"worker processes around ONE GPU owner -> PAGE-XML files; worker start-up (first_page_s: process spawn, page-locking of the decode slots, first decode) inside pages_per_s, excluded from "
+                    f"steady_pages_per_s; "
                     f"box has {os.cpu_count()} logical CPUs"}
 
 

@@ -1200,28 +1200,39 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
             }
             return acc;
         };
-        // (per-lane base pointers + compile-time offsets: the addresses of the unrolled tiles are immediates)
-        unsigned char* const d0 = r0 + (wave * W0 + c) * 16 + ch * 2;
-        unsigned char* const dt = tc + ((wave - 3) * TW + c - 3) * 16 + ch * 2;
+        // Tiles are processed in PAIRS (A, B), and their results leave as WHOLE pixels: a lane holds 4 of its pixel's 8 channels,
+        // the other 4 sit in lane ^ 16; v_permlane16_swap trades them so that lanes kk = 0 / 2 hold the whole pixel of tile A and
+        // lanes kk = 1 / 3 the whole pixel of tile B: ONE ds_write_b128 per lane and tile pair instead of two ds_write_b64 whose
+        // 16 lanes of a store group sat 32 bytes apart (4-way bank conflicts: SQ_LDS_BANK_CONFLICT was 52 % of the LDS cycles and
+        // the LDS 70 % busy).  (per-lane base pointers + compile-time offsets: the addresses of the unrolled tiles are immediates)
+        const bool isB = kk & 1;
+        auto whole = [&](u32x2 pa, u32x2 pb) {                      // -> the lane's pixel record (tile A's for even kk, B's for odd)
+            const auto s0 = __builtin_amdgcn_permlane16_swap(pa.x, pb.x, false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
+            return u32x4{s0[0], s1[0], s0[1], s1[1]};
+        };
+        unsigned char* const d0 = r0 + (wave * W0 + c) * 16;
+        unsigned char* const dt = tc + ((wave - 3) * TW + c - 3) * 16;
 #pragma unroll
-        for (int i = 0; i < (H0 + 3) / 4; ++i) {
-            const int r = wave + 4 * i;
+        for (int i = 0; i < (H0 + 3) / 4; i += 2) {                 // rows wave + 4 i (A) and wave + 4 (i + 1) (B)
+            const int rA = wave + 4 * i, rB = rA + 4;
+            const u32x2 rawA = pack_bf16x4(conv1(rA, 2 * j)), rawB = pack_bf16x4(conv1(min(rB, H0 - 1), 2 * j));
+            const int r = isB ? rB : rA, off = isB ? (i + 1) * 4 : i * 4;
+            const u32x4 raw = whole(rawA, rawB), rl = whole(relu_pk(rawA), relu_pk(rawB));
             if (r < H0) {
-                const u32x2 raw = pack_bf16x4(conv1(r, 2 * j));
-                *reinterpret_cast<u32x2*>(d0 + i * 4 * W0 * 16) = relu_pk(raw);
-                if (r >= 3 && r < 3 + TH && c >= 3) *reinterpret_cast<u32x2*>(dt + i * 4 * TW * 16) = raw;
+                *reinterpret_cast<u32x4*>(d0 + off * W0 * 16) = rl;
+                if (r >= 3 && r < 3 + TH && c >= 3) *reinterpret_cast<u32x4*>(dt + off * TW * 16) = raw;
             }
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {                         // 5 remainder tiles of 5 rows (22 rows): waves 0 .. 3, then wave 0 again
-            const int t = wave + 4 * i;
-            if (t * 5 < H0) {
-                const int row = t * 5 + rr3, rowc = min(row, H0 - 1), col = 32 + 2 * pc3;
-                const u32x2 raw = pack_bf16x4(conv1(rowc, col));
-                if (row < H0 && j3 < 5) {
-                    *reinterpret_cast<u32x2*>(r0 + (row * W0 + col + e) * 16 + ch * 2) = relu_pk(raw);
-                    if (row >= 3 && row < 3 + TH && col + e < 3 + TW) *reinterpret_cast<u32x2*>(tc + ((row - 3) * TW + col + e - 3) * 16 + ch * 2) = raw;
-                }
+        {                                                           // 5 remainder tiles of 5 rows: tile wave (A), tile wave + 4 (B: wave 0 only)
+            const int tA = wave, tB = wave + 4;
+            const int rowA = tA * 5 + rr3, rowB = tB * 5 + rr3, col = 32 + 2 * pc3;
+            const u32x2 rawA = pack_bf16x4(conv1(min(rowA, H0 - 1), col)), rawB = pack_bf16x4(conv1(min(rowB, H0 - 1), col));
+            const int row = isB ? rowB : rowA;
+            const u32x4 raw = whole(rawA, rawB), rl = whole(relu_pk(rawA), relu_pk(rawB));
+            if (row < H0 && j3 < 5) {
+                *reinterpret_cast<u32x4*>(r0 + (row * W0 + col + e) * 16) = rl;
+                if (row >= 3 && row < 3 + TH && col + e < 3 + TW) *reinterpret_cast<u32x4*>(tc + ((row - 3) * TW + col + e - 3) * 16) = raw;
             }
         }
     }
@@ -1239,23 +1250,31 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) { ra = mfma_bf16_k32(af[ky], fa[ky], ra); rb = mfma_bf16_k32(af[ky], fb[ky], rb); }
     };
+    const bool isB = kk & 1;
+    // ReLU'd whole-pixel record of the lane's tile of a pair (see conv1)
+    auto whole_relu = [&](f32x4 va, f32x4 vb) {
+        const u32x2 pa = relu_pk(pack_bf16x4(va)), pb = relu_pk(pack_bf16x4(vb));
+        const auto s0 = __builtin_amdgcn_permlane16_swap(pa.x, pb.x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
+        return u32x4{s0[0], s1[0], s0[1], s1[1]};
+    };
     {
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + ch);
         const unsigned char* const sb = r0 + (wave * W0 + 2 * j + kk) * 16;
-        unsigned char* const db = r1 + (wave * W1 + c) * 16 + ch * 2;
         // 20 rows: 5 main tiles per wave (i = 0 .. 4) + 3 remainder tiles of 8 rows (columns 32 .. 35; waves 0 .. 2)
         const int row = wave * 8 + rr2, rowc = min(row, H1 - 1), col = 32 + 2 * pc2;
         const unsigned char* const sr = r0 + (rowc * W0 + col + kk) * 16;
+        unsigned char* const db = r1 + ((wave + (isB ? 4 : 0)) * W1 + c) * 16;          // the lane's tile of a pair: rows wave + 4 i / + 4 (i + 1)
         f32x4 va, vb;
 #pragma unroll
         for (int i = 0; i < 4; i += 2) {
             conv8x2(sb + i * 4 * W0 * 16, sb + (i + 1) * 4 * W0 * 16, W0 * 16, b4, va, vb);
-            *reinterpret_cast<u32x2*>(db + i * 4 * W1 * 16) = relu_pk(pack_bf16x4(va));
-            *reinterpret_cast<u32x2*>(db + (i + 1) * 4 * W1 * 16) = relu_pk(pack_bf16x4(vb));
+            *reinterpret_cast<u32x4*>(db + i * 4 * W1 * 16) = whole_relu(va, vb);
         }
-        conv8x2(sb + 16 * W0 * 16, sr, W0 * 16, b4, va, vb);
-        *reinterpret_cast<u32x2*>(db + 16 * W1 * 16) = relu_pk(pack_bf16x4(va));
-        if (wave < 3 && row < H1) *reinterpret_cast<u32x2*>(r1 + (row * W1 + col + e) * 16 + ch * 2) = relu_pk(pack_bf16x4(vb));
+        conv8x2(sb + 16 * W0 * 16, sr, W0 * 16, b4, va, vb);                            // A: row wave + 16; B: the remainder tile
+        const u32x4 rec = whole_relu(va, vb);
+        if (!isB) *reinterpret_cast<u32x4*>(r1 + ((wave + 16) * W1 + c) * 16) = rec;
+        else if (wave < 3 && row < H1) *reinterpret_cast<u32x4*>(r1 + (row * W1 + col + e) * 16) = rec;
     }
 #pragma unroll
     for (int t = 0; t < 3; ++t) af[t] = wl[(3 + t) * 64];
@@ -1264,21 +1283,20 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 8 + ch);
         constexpr int HO = TH + 2;                            // 18 rows of 34: stage 2's result takes region 0's place (dead)
         const unsigned char* const sb = r1 + (wave * W1 + 2 * j + kk) * 16;
-        unsigned char* const db = r0 + (wave * W2 + c) * 16 + ch * 2;
+        unsigned char* const db = r0 + ((wave + (isB ? 4 : 0)) * W2 + c) * 16;
         // 18 rows: 4 main tiles per wave + rows 16, 17 (waves 0, 1) + 2 remainder tiles of 16 rows (columns 32, 33; waves 2, 3):
-        // every wave has exactly one "fifth" tile
+        // every wave has exactly one "fifth" tile (computed twice to keep the pair form; only the A lanes store it)
         const int row = (wave - 2) * 16 + j, rowc = min(max(row, 0), HO - 1);
         const unsigned char* const s5 = wave < 2 ? sb + 16 * W1 * 16 : r1 + (rowc * W1 + 32 + kk) * 16;
-        unsigned char* const d5 = wave < 2 ? db + 16 * W2 * 16 : r0 + (rowc * W2 + 32 + e) * 16 + ch * 2;
+        unsigned char* const d5 = wave < 2 ? r0 + ((wave + 16) * W2 + c) * 16 : r0 + (rowc * W2 + 32 + e) * 16;
         f32x4 va, vb;
         conv8x2(sb, sb + 4 * W1 * 16, W1 * 16, b4, va, vb);
-        *reinterpret_cast<u32x2*>(db) = relu_pk(pack_bf16x4(va));
-        *reinterpret_cast<u32x2*>(db + 4 * W2 * 16) = relu_pk(pack_bf16x4(vb));
+        *reinterpret_cast<u32x4*>(db) = whole_relu(va, vb);
         conv8x2(sb + 8 * W1 * 16, sb + 12 * W1 * 16, W1 * 16, b4, va, vb);
-        *reinterpret_cast<u32x2*>(db + 8 * W2 * 16) = relu_pk(pack_bf16x4(va));
-        *reinterpret_cast<u32x2*>(db + 12 * W2 * 16) = relu_pk(pack_bf16x4(vb));
+        *reinterpret_cast<u32x4*>(db + 8 * W2 * 16) = whole_relu(va, vb);
         conv8x2(s5, s5, W1 * 16, b4, va, vb);
-        if (wave < 2 || row < HO) *reinterpret_cast<u32x2*>(d5) = relu_pk(pack_bf16x4(va));
+        const u32x4 rec = whole_relu(va, vb);
+        if (!isB && (wave < 2 || row < HO)) *reinterpret_cast<u32x4*>(d5) = rec;
     }
 #pragma unroll
     for (int t = 0; t < 3; ++t) af[t] = wl[(6 + t) * 64];

@@ -31,6 +31,7 @@ class RegionNetPostProcessor:
         self.host_workers = host_workers
         self.device_seconds = 0.0      # wall time this process spent inside the device stages (upload .. results back)
         self.wait_seconds = 0.0        # ... waiting for the next decoded image
+        self.first_page_seconds = None # run() start -> first decoded image in hand (worker start-up, slot page-locking)
         self.host_seconds = 0.0        # ... chaining polygon rings / handing the page to the writers
         self.fixed_height = fixed_height
         self.scaling_factor = scaling_factor
@@ -152,9 +153,11 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
         reg, unreg = pin_callbacks(self.device) if pipelined else (None, None)
         decode = DecodePool(self.image_paths, self.host_workers if pipelined else 0, register=reg, unregister=unreg)
         with WritePool(self.host_workers if pipelined else 0) as writers:
-            t_prev = time.perf_counter()
+            t_prev = t_run = time.perf_counter()
             for image_path, image in decode:
                 t_dev = time.perf_counter()
+                if self.first_page_seconds is None:          # worker start-up + slot page-locking + the first decode
+                    self.first_page_seconds = t_dev - t_run
                 self.wait_seconds += t_dev - t_prev
                 masks, sc, extras = self.separator_masks(image, edges_only=not self.keep_outputs)
                 t_host = time.perf_counter()
