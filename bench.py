@@ -316,7 +316,9 @@ def main():
     H, W, B = args.height, args.width, args.pages_per_step
     visual = args.gnn == "visual" and not args.no_gnn
     aru_cfg = AruConfig(compute_dtype=args.dtype)
-    gnn_cfg = GnnConfig(visual_dims=[16, 16, 16], mvn=True, visual_layers=VISUAL_LAYERS) if visual else GnnConfig()
+    # --dtype bf16 = configs[4] "bf16 convs": the relation net's conv backbone runs on the bf16 kernels too (graph stays fp32)
+    gnn_cfg = (GnnConfig(visual_dims=[16, 16, 16], mvn=True, visual_layers=VISUAL_LAYERS, backbone={"compute_dtype": args.dtype})
+               if visual else GnnConfig())
 
     # ---- weights: rank 0 creates them, every other rank receives the blob over RCCL (the only collective) ----
     if rank == 0:
@@ -558,8 +560,8 @@ def main():
         if args.no_gnn:
             rel = "ARU-Net only (diagnostic)"
         elif visual:
-            rel = ("+ per page the relation net BASELINE configs[3] names (mixed_gnn_vn7e2 = VISUAL net: RU backbone on the page at "
-                   f"{vw}x{vh} + ROI max / compression to 3x16 visual features + graph with 55 node features, 200 nodes / 20k edges / "
+            rel = ("+ per page the relation net BASELINE configs[3] names (mixed_gnn_vn7e2 = VISUAL net: RU backbone "
+                   f"({'bf16 convs' if args.dtype == 'bf16' else 'fp32'}) on the page at {vw}x{vh} + ROI max / compression to 3x16 visual features + graph with 55 node features, 200 nodes / 20k edges / "
                    "40k pairs), the step's relation nets as one grouped call on a second stream")
         else:
             rel = "+ geometric 7-feature relation graph per page (200 nodes / 20k edges / 40k pairs; diagnostic: not the net configs[3] names)"

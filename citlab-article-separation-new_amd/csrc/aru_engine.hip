@@ -1627,12 +1627,13 @@ double flops_impl(const asep_aru_cfg& cfg, int H, int W) {
 
 namespace asep {
 
-int aru_endpoint_dev(asep_aru* m, const char* name, const float** d_ptr, int dims[3]) {
+int aru_endpoint_dev(asep_aru* m, const char* name, const float** d_ptr, int dims[3], int* is_bf16) {
     if (!m || !name || !d_ptr) { set_error("aru_endpoint_dev: bad argument"); return ASEP_ERR_ARG; }
     auto it = m->endpoints.find(name);
     if (it == m->endpoints.end()) { set_error("backbone has no end point '%s' (run a forward first)", name); return ASEP_ERR_ARG; }
-    if (it->second.bf) { set_error("end point '%s' is bf16 (compute_dtype 1): the relation net's backbone must be fp32", name); return ASEP_ERR_UNSUPPORTED; }
-    *d_ptr = it->second.p;
+    if (it->second.bf && !is_bf16) { set_error("end point '%s' is bf16 (compute_dtype 1) and the caller reads fp32 maps", name); return ASEP_ERR_UNSUPPORTED; }
+    if (is_bf16) *is_bf16 = it->second.bf ? 1 : 0;
+    *d_ptr = it->second.p;                                  // bf16 maps: the same address, 2 bytes per value
     if (dims) { dims[0] = it->second.H; dims[1] = it->second.W; dims[2] = it->second.C; }
     return ASEP_OK;
 }

@@ -93,7 +93,7 @@ private:
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Device pointer + {H, W, C} of a named end point of the last ARU forward (aru_engine.hip); library-internal.
-int aru_endpoint_dev(asep_aru* m, const char* name, const float** d_ptr, int dims[3]);
+int aru_endpoint_dev(asep_aru* m, const char* name, const float** d_ptr, int dims[3], int* is_bf16 = nullptr);
 // Number of channels the end point `name` will have for this model's configuration, or -1 if unknown.
 int aru_endpoint_channels(const asep_aru* m, const char* name);
 // Number of output classes (channels of the logits / probability map) of the model.

@@ -292,14 +292,16 @@ int visual_rois_dev(asep_gnn* g, int N, const float* d_ug, const std::string& pr
     for (size_t i = 0; i < g->vis_names.size(); ++i) {
         const float* fm = nullptr;
         int dims[3];
-        int rc = aru_endpoint_dev(g->backbone, (prefix + g->vis_names[i]).c_str(), &fm, dims);
+        int bf = 0;                                         // a bf16 backbone (compute_dtype 1) hands over bf16 maps
+        int rc = aru_endpoint_dev(g->backbone, (prefix + g->vis_names[i]).c_str(), &fm, dims, &bf);
         if (rc) return rc;
         if (dims[2] != g->vis_C[i]) { set_error("end point %s has %d channels, expected %d", g->vis_names[i].c_str(), dims[2], g->vis_C[i]); return ASEP_ERR_ARG; }
         RoiArgs a{};
         a.fm = fm; a.fh = dims[0]; a.fw = dims[1]; a.C = dims[2];
         a.regions = d_reg; a.P = P; a.npts = d_np; a.Wc = g->vis_W[i]; a.bc = g->vis_b[i]; a.d = g->vis_d[i];
         a.u_out = d_u; a.ustride = U; a.col0 = col; a.vmax_out = nullptr;
-        hipLaunchKernelGGL(gnn_roi_compress_kernel, dim3(N), dim3(256), 0, s, a);
+        if (bf) hipLaunchKernelGGL(gnn_roi_compress_kernel<true>, dim3(N), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(gnn_roi_compress_kernel<false>, dim3(N), dim3(256), 0, s, a);
         col += g->vis_d[i];
     }
     ASEP_HIP_CHECK(hipGetLastError());

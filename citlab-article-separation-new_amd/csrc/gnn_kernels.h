@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void gnn_pair_cls_generic_kernel(const PairGen
 // -> ff(ReLU) compression -> columns [col0, col0 + d) of the node feature matrix.
 // ---------------------------------------------------------------------------------------------------------------
 struct RoiArgs {
-    const float* fm;          // [fh, fw, C] NHWC
+    const float* fm;          // [fh, fw, C] NHWC; fp32, or bf16 (2 bytes per value) for gnn_roi_compress_kernel<true>
     int fh, fw, C;
     const float* regions;     // [N, 2, P]: row 0 = x, row 1 = y, relative to the image size
     int P;
@@ -772,7 +772,14 @@ struct RoiArgs {
     float* vmax_out;          // optional [N, C] (tests)
 };
 
+template <bool BF>
 __global__ void __launch_bounds__(256) gnn_roi_compress_kernel(RoiArgs a) {
+    // value i of the map (a bf16 value widens exactly; the maximum of a region is therefore the same value the fp32 form of a
+    // bf16-rounded map would give)
+    auto fmv = [&](size_t i) -> float {
+        if constexpr (BF) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(a.fm)[i] << 16);
+        else return a.fm[i];
+    };
     __shared__ float red[256];
     __shared__ float vmax[256];
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -800,8 +807,8 @@ __global__ void __launch_bounds__(256) gnn_roi_compress_kernel(RoiArgs a) {
         // a thread keeps one channel: rows of nx*C contiguous floats are read coalesced
         const int rowlen = nx * C;
         for (int y = 0; y < ny; ++y) {
-            const float* row = a.fm + ((size_t)(y0 + y) * a.fw + x0) * C;
-            for (int i = tid; i < rowlen; i += 256) m = fmaxf(m, row[i]);
+            const size_t row = ((size_t)(y0 + y) * a.fw + x0) * C;
+            for (int i = tid; i < rowlen; i += 256) m = fmaxf(m, fmv(row + i));
         }
         red[tid] = m;
         __syncthreads();
@@ -814,7 +821,7 @@ __global__ void __launch_bounds__(256) gnn_roi_compress_kernel(RoiArgs a) {
         for (int c = tid; c < C; c += 256) {
             float v = -INFINITY;
             for (int y = 0; y < ny; ++y)
-                for (int x = 0; x < nx; ++x) v = fmaxf(v, a.fm[((size_t)(y0 + y) * a.fw + x0 + x) * C + c]);
+                for (int x = 0; x < nx; ++x) v = fmaxf(v, fmv(((size_t)(y0 + y) * a.fw + x0 + x) * C + c));
             vmax[c] = v;
         }
     }

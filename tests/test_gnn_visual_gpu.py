@@ -8,11 +8,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _setup(mvn=False, node_dim=7, layers=("scale_0_unet_up_2_conv", "scale_0_unet_up_1_conv", "scale_0_unet_up_0_conv"),
-           dims=(16, 16, 16), seed=11):
+           dims=(16, 16, 16), seed=11, backbone=None):
     from citlab_article_separation_new_amd.config import GnnConfig
     from citlab_article_separation_new_amd.gnn_io import GnnGraph
     from citlab_article_separation_new_amd.weights import init_gnn_weights
-    cfg = GnnConfig(node_feature_dim=node_dim, visual_dims=list(dims), visual_layers=list(layers), mvn=mvn)
+    cfg = GnnConfig(node_feature_dim=node_dim, visual_dims=list(dims), visual_layers=list(layers), mvn=mvn,
+                    backbone=dict(backbone or {}))
     w = init_gnn_weights(cfg, seed, bias_jitter=0.05)
     return cfg, w, GnnGraph(w, cfg)
 
@@ -59,6 +60,33 @@ def test_visual_forward_matches_oracle(mvn):
     assert (ref_u[:, 7:] > 0).any()                                  # the compression ReLU is not dead everywhere
     assert np.abs(probs - ref_probs).max() <= 1e-5                   # fp32 tolerance of the GNN tests
     assert probs.shape == (N * N, 2)
+
+
+def test_visual_forward_with_a_bf16_backbone_stays_within_the_bf16_tolerance():
+    """BASELINE configs[4] ("bf16 convs") for the relation net: ``backbone={"compute_dtype": "bf16"}`` runs the RU backbone
+    on the bf16 kernels and the ROI kernel reads the bf16 end points (gnn_roi_compress_kernel<true>); compression, graph and
+    classifier stay fp32.  Gates: the geometric columns are untouched, the visual node features within 2e-2 of the fp32
+    oracle relative to the largest feature (the whole-frame bf16 gate of the page net), the relation
+    probabilities within 2e-2 absolute."""
+    from citlab_article_separation_new_amd import gnn_io, synth
+    from oracle import gnn_oracle
+    cfg, w, graph = _setup(mvn=True, backbone={"compute_dtype": "bf16"})
+    rng = np.random.default_rng(3)
+    N = 30
+    g = synth.synth_graph(1, N=N, n_pairs=80, node_dim=7)
+    img, regions, npts = _page(rng, N, 200, 136)
+    probs = gnn_io.gnn_forward_visual(graph, N, g["interacting_nodes"], g["node_features"], g["edge_features"], img,
+                                      regions, npts)
+    u = gnn_io.gnn_node_features(graph, N)
+    ref_probs, ref_u = gnn_oracle.forward_visual(N, g["interacting_nodes"], g["node_features"], g["edge_features"],
+                                                 img, regions, npts, None, w, cfg)
+    du, dp = float(np.abs(u - ref_u).max()), float(np.abs(probs - ref_probs).max())
+    print("bf16 backbone: max |du| =", du, "max |u| =", float(np.abs(ref_u).max()), "max |dp| =", dp)
+    assert np.array_equal(u[:, :7], ref_u[:, :7])
+    assert du <= 2e-2 * max(1.0, float(np.abs(ref_u).max()))
+    assert du > 0.0                                                   # the bf16 kernels did run (fp32 would agree to ~1e-6)
+    assert dp <= 2e-2
+    graph.close()
 
 
 def test_session_mirror_with_image_feeds_and_pb_roundtrip(tmp_path):
