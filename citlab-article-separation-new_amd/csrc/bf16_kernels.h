@@ -554,6 +554,10 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) resv[i][r][cb] = *reinterpret_cast<const u32x2*>(tres + ((size_t)(8 * i + r) * W + cb * 16) * C);
+    // biases of the three stages: requested now -- read where a stage begins (behind its barrier) each is an exposed L2 round trip
+    f32x4 biasw[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) biasw[t] = *reinterpret_cast<const f32x4*>(a.bias + t * C + kk * 4);
     const u32x4* __restrict__ wl = a.wpk + lane;
     u32x4 af[CPC];
 #pragma unroll
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
 
     // ---- stage 1: r0 (22 x 38) -> r1 (20 x 36).  Rows wave + 4 i, two main tiles each; 5 remainder tiles of 4 rows x 4 columns ----
     {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + kk * 4);
+        const f32x4 b4 = biasw[0];
         int bm[CPC], br[CPC];
         const int rr = j >> 2, xc = j & 3;                    // remainder tile: lane j -> row rr of 4, column 32 + xc
 #pragma unroll
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
     // ---- stage 2: r1 (20 x 36) -> r0 as 18 x 34.  4 full rows per wave + rows 16, 17 (waves 0, 1); 3 remainder tiles of 8 rows x 2
     //      columns (waves 1 .. 3; wave 3's covers rows 16, 17 only) ----
     {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + C + kk * 4);
+        const f32x4 b4 = biasw[1];
         int bm[CPC], br[CPC];
         const int rr = j >> 1, xc = j & 1, rt = wave - 1;     // remainder tile rt: rows 8 rt + rr
         const int rrow = min(max(8 * rt + rr, 0), H2 - 1);
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
     __syncthreads();
     // ---- stage 3: r0 (18 x 34) -> HBM; a wave takes row pairs 2 (wave + 4 i), both column blocks (2x2 pool in registers) ----
     {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 2 * C + kk * 4);
+        const f32x4 b4 = biasw[2];
         int bm[CPC];
 #pragma unroll
         for (int t = 0; t < CPC; ++t) bm[t] = (2 * wave * W2 + j + tap_px(t, W2)) * PXB + (kk & 1) * 16;
@@ -651,17 +655,18 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
             for (int cb = 0; cb < 2; ++cb) {
                 f32x4 v2[2];
                 conv16x2(r0, bm, (8 * i) * W2 * PXB + cb * 16 * PXB, bm, (8 * i + 1) * W2 * PXB + cb * 16 * PXB, b4, v2[0], v2[1]);
+                u32x2 pk[2];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    const u32x2 pk = relu_pk(pack_bf16x4(v2[r] + unpack_bf16x4(resv[i][r][cb])));
-                    v2[r] = unpack_bf16x4(pk);
-                    *reinterpret_cast<u32x2*>(out + ((size_t)(8 * i + r) * W + cb * 16) * C) = pk;
+                    pk[r] = relu_pk(pack_bf16x4(v2[r] + unpack_bf16x4(resv[i][r][cb])));
+                    *reinterpret_cast<u32x2*>(out + ((size_t)(8 * i + r) * W + cb * 16) * C) = pk[r];
                 }
                 if (P.pool) {
-                    f32x4 mm = max4(v2[0], v2[1]);
-                    mm = max4(mm, f32x4{lane_xor1(mm.x), lane_xor1(mm.y), lane_xor1(mm.z), lane_xor1(mm.w)});
+                    // 2 x 2 max on the packed values (non-negative bf16 order like their bit patterns): rows, then the neighbour lane
+                    const unsigned m0 = pkmax_u16(pk[0].x, pk[1].x), m1 = pkmax_u16(pk[0].y, pk[1].y);
+                    const unsigned n0 = __float_as_uint(lane_xor1(__uint_as_float(m0))), n1 = __float_as_uint(lane_xor1(__uint_as_float(m1)));
                     if ((j & 1) == 0)
-                        *reinterpret_cast<u32x2*>(P.pool + ((size_t)((y0 >> 1) + wave + 4 * i) * Wp + ((x0 + cb * 16 + j) >> 1)) * C + kk * 4) = pack_bf16x4(mm);
+                        *reinterpret_cast<u32x2*>(P.pool + ((size_t)((y0 >> 1) + wave + 4 * i) * Wp + ((x0 + cb * 16 + j) >> 1)) * C + kk * 4) = u32x2{pkmax_u16(m0, n0), pkmax_u16(m1, n1)};
                 }
             }
     }
@@ -1165,6 +1170,14 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
         }
         if (tid < IW / 2) reinterpret_cast<unsigned*>(in)[IH * IW / 2 + tid] = 0u;     // row IH: read with zero weights, must be finite
     }
+    // biases: requested at the kernel's start -- read where a stage begins (behind its barrier) each one is an exposed L2 round trip
+    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(a.b1 + ch);
+    f32x4 biasw[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) biasw[t] = *reinterpret_cast<const f32x4*>(a.bias + 8 * t + ch);
+    u32x4 a1[UP ? 6 : 1];                                    // conv1's A fragments, likewise
+#pragma unroll
+    for (int t = 0; t < (UP ? 6 : 1); ++t) a1[t] = a.w1pk[t * 64 + lane];
     const u32x4* __restrict__ wl = a.wpk + lane;
     u32x4 af[3];
 #pragma unroll
@@ -1179,10 +1192,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
 
     // ---- conv1: relu(t) over the 22 x 38 region (r0), raw t of the centre 16 x 32 (tc) ----
     {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b1 + ch);
-        u32x4 a1[UP ? 6 : 1];
-#pragma unroll
-        for (int t = 0; t < (UP ? 6 : 1); ++t) a1[t] = a.w1pk[t * 64 + lane];
+        const f32x4 b4 = bias1;
         // window of the pair whose first pixel is (row, col) of region 0 = input-tile pixels (row .. row + 2, col .. col + 3)
         auto conv1 = [&](int row, int col) {
             f32x4 acc = b4;
@@ -1259,7 +1269,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
         return u32x4{s0[0], s1[0], s0[1], s1[1]};
     };
     {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + ch);
+        const f32x4 b4 = biasw[0];
         const unsigned char* const sb = r0 + (wave * W0 + 2 * j + kk) * 16;
         // 20 rows: 5 main tiles per wave (i = 0 .. 4) + 3 remainder tiles of 8 rows (columns 32 .. 35; waves 0 .. 2)
         const int row = wave * 8 + rr2, rowc = min(row, H1 - 1), col = 32 + 2 * pc2;
@@ -1280,7 +1290,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     for (int t = 0; t < 3; ++t) af[t] = wl[(3 + t) * 64];
     __syncthreads();
     {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 8 + ch);
+        const f32x4 b4 = biasw[1];
         constexpr int HO = TH + 2;                            // 18 rows of 34: stage 2's result takes region 0's place (dead)
         const unsigned char* const sb = r1 + (wave * W1 + 2 * j + kk) * 16;
         unsigned char* const db = r0 + ((wave + (isB ? 4 : 0)) * W2 + c) * 16;
@@ -1304,7 +1314,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
 
     // ---- stage 3: one tile = one row of the output tile; a wave takes row pairs (2x2 pool in registers) ----
     {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 16 + ch);
+        const f32x4 b4 = biasw[2];
         const int Wp = (W + 1) >> 1;
         bf16_t* __restrict__ out = P.out + ((size_t)(y0 + 2 * wave) * W + x0 + c) * 8 + ch;
         const unsigned char* const sb = r0 + (2 * wave * W2 + 2 * j + kk) * 16;
@@ -1314,19 +1324,21 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
             const int rp = wave + 4 * i;
             f32x4 v2[2];
             conv8x2(sb + 8 * i * W2 * 16, sb + (8 * i + 1) * W2 * 16, W2 * 16, b4, v2[0], v2[1]);
+            u32x2 pk[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 // ReLU after the rounding: one v_pk_max_i16 per two values
-                const u32x2 pk = relu_pk(pack_bf16x4(v2[r] + unpack_bf16x4(*reinterpret_cast<const u32x2*>(tb + (8 * i + r) * TW * 16))));
-                v2[r] = unpack_bf16x4(pk);
-                *reinterpret_cast<u32x2*>(out + (size_t)(8 * i + r) * W * 8) = pk;
+                pk[r] = relu_pk(pack_bf16x4(v2[r] + unpack_bf16x4(*reinterpret_cast<const u32x2*>(tb + (8 * i + r) * TW * 16))));
+                *reinterpret_cast<u32x2*>(out + (size_t)(8 * i + r) * W * 8) = pk[r];
             }
             if (P.pool) {
-                f32x4 mm = max4(v2[0], v2[1]), lo, hi;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { lo[q] = from_lower_half(mm[q]); hi[q] = from_upper_half(mm[q]); }
-                mm = max4(lo, hi);
-                if (e == 0) *reinterpret_cast<u32x2*>(P.pool + ((size_t)((y0 >> 1) + rp) * Wp + (x0 >> 1) + j) * 8 + ch) = pack_bf16x4(mm);
+                // 2 x 2 max on the PACKED values (non-negative bf16 order like their bit patterns: v_pk_max_i16): the two rows, then the
+                // pixel pair (lane ^ 32) through v_permlane32_swap.  (Unpacked to fp32 the pool cost 45 vector instructions per row
+                // pair -- fmaxf canonicalises both operands -- of a kernel that is bound by the vector instructions it issues.)
+                const unsigned m0 = pkmax_u16(pk[0].x, pk[1].x), m1 = pkmax_u16(pk[0].y, pk[1].y);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(m0, m0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(m1, m1, false, false);
+                if (e == 0) *reinterpret_cast<u32x2*>(P.pool + ((size_t)((y0 >> 1) + rp) * Wp + (x0 >> 1) + j) * 8 + ch) = u32x2{pkmax_u16(s0[0], s0[1]), pkmax_u16(s1[0], s1[1])};
             }
         }
     }
