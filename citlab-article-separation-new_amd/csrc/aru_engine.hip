@@ -1928,3 +1928,10 @@ double asep_aru_flops(const asep_aru* m, int H, int W) {
 }
 
 }  // extern "C"
+
+#if defined(R8F_TRACE)
+// debug builds only (see R8F_MARK in bf16_kernels.h); not part of include/asep_hip.h
+extern "C" int asep_debug_r8f_trace(int up, unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(asep::g_r8f_trace), sizeof(unsigned long long) * n, (size_t)(up ? 1 : 0) * 4096 * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+#endif

@@ -1107,6 +1107,15 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8b_kernel(const Res8BArgs 
 // to bf16, and conv1 of the down block is ONE MFMA per 32 pixels on the image tile held as bf16 (K = 3 x 4 window values).
 // Border tiles take res8b_tile (the general form) inside the same launch.
 // ------------------------------------------------------------------------------------------------
+// Debug builds (-DR8F_TRACE -DR8F_TRACE_TID=<thread>): s_memtime stamps of one thread of every 8th block at the phase boundaries,
+// read back through asep_debug_r8f_trace (aru_engine.hip) by scripts/gpu_r8f_trace.py.  This is how the kernel's time was split
+// into "window from HBM / conv1 / stages / stores" (DESIGN lesson 20); compiled out otherwise.
+#if defined(R8F_TRACE)
+__device__ unsigned long long g_r8f_trace[2][4096 * 12];
+#define R8F_MARK(i) do { if ((blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 4096 && tid == R8F_TRACE_TID) g_r8f_trace[UP ? 1 : 0][(blockIdx.x >> 3) * 12 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define R8F_MARK(i) do { } while (0)
+#endif
 template <bool UP>
 __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs a) {
     constexpr int TH = 16, TW = 32;
@@ -1123,6 +1132,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     unsigned char* const tc = lds + TC_OFF;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    R8F_MARK(0);
     const int j = lane & 15, kk = lane >> 4, e = kk >> 1, ch = (kk & 1) * 4;     // D layout: pixel parity e, channels ch .. ch + 3
     int pi = 0;
     while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
@@ -1131,6 +1141,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
     const int H = P.H, W = P.W;
+    R8F_MARK(1);
     if (!(y0 - 4 >= 0 && y0 + TH + 4 <= H && x0 - 4 >= 0 && x0 + TW + 4 <= W)) {             // border tile: the general form
         res8b_tile<UP>(a, P, x0, y0, lds);
         return;
@@ -1170,6 +1181,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
         }
         if (tid < IW / 2) reinterpret_cast<unsigned*>(in)[IH * IW / 2 + tid] = 0u;     // row IH: read with zero weights, must be finite
     }
+    R8F_MARK(2);
     // biases: requested at the kernel's start -- read where a stage begins (behind its barrier) each one is an exposed L2 round trip
     const f32x4 bias1 = *reinterpret_cast<const f32x4*>(a.b1 + ch);
     f32x4 biasw[3];
@@ -1189,6 +1201,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     const int c = 2 * j + e;                                  // the lane's pixel column in a main tile
     auto relu_pk = [](u32x2 p) { return u32x2{relu_bf16x2(p.x), relu_bf16x2(p.y)}; };
     __syncthreads();
+    R8F_MARK(3);
 
     // ---- conv1: relu(t) over the 22 x 38 region (r0), raw t of the centre 16 x 32 (tc) ----
     {
@@ -1246,7 +1259,9 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
             }
         }
     }
+    R8F_MARK(4);
     __syncthreads();
+    R8F_MARK(5);
 
     // ---- stages 1 and 2 (LDS -> LDS): main tile = row r, columns 0 .. 31; remainder tiles = columns 32 .. WO - 1 of 16 / PR rows.
     //      Tiles are processed in PAIRS: both tiles' fragment reads first, their MFMAs interleaved (two independent accumulator
@@ -1288,7 +1303,9 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     }
 #pragma unroll
     for (int t = 0; t < 3; ++t) af[t] = wl[(3 + t) * 64];
+    R8F_MARK(6);
     __syncthreads();
+    R8F_MARK(7);
     {
         const f32x4 b4 = biasw[1];
         constexpr int HO = TH + 2;                            // 18 rows of 34: stage 2's result takes region 0's place (dead)
@@ -1310,7 +1327,9 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     }
 #pragma unroll
     for (int t = 0; t < 3; ++t) af[t] = wl[(6 + t) * 64];
+    R8F_MARK(8);
     __syncthreads();
+    R8F_MARK(9);
 
     // ---- stage 3: one tile = one row of the output tile; a wave takes row pairs (2x2 pool in registers) ----
     {
@@ -1342,6 +1361,11 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
             }
         }
     }
+    R8F_MARK(10);
+#if defined(R8F_TRACE)
+    __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): the tile's stores have left
+#endif
+    R8F_MARK(11);
 }
 
 // channel sum [H,W,8] bf16 -> [H,W] fp32 (upsample_simple's channel-summing half; same association as chansum_kernel)

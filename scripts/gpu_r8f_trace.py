@@ -1,5 +1,7 @@
 """Development aid: phase time stamps (s_memtime) of sampled res8f_kernel blocks.  Needs a library built with -DR8F_TRACE
-(ASEP_HIP_LIB=...): python scripts/gpu_r8f_trace.py [H W]"""
+(make CXXFLAGS+="-DR8F_TRACE -DR8F_TRACE_TID=0" into a separate .so, ASEP_HIP_LIB=<that .so>): python scripts/gpu_r8f_trace.py [H W]
+Ticks are shader clocks (~2 GHz under load).  Round-3 reading at 4500 x 3000 (DESIGN lesson 20): a block of res8f_kernel<true> lives
+18.5 k ticks: 5.5 k waiting for its input window, 4.7 k in conv1, 2.0 - 2.2 k per tail stage."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -18,15 +20,14 @@ torch.cuda.synchronize()
 names = ["entry->located", "located->window in regs+LDS writes issued", "->barrier 1 passed", "conv1", "barrier 2", "stage 1", "barrier 3",
          "stage 2", "barrier 4", "stage 3 (stores issued)", "stores drained"]
 for up in (0, 1):
-    n = 4096 * 16
+    n = 4096 * 12
     buf = (C.c_ulonglong * n)()
     rc = lib.asep_debug_r8f_trace(up, buf, n)
-    a = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 16).astype(np.int64)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 12).astype(np.int64)
     ok = (a[:, 0] > 0) & (a[:, 11] > a[:, 0])            # interior tiles that ran all marks
     a = a[ok]
     print(f"res8f_kernel<{bool(up)}>: rc {rc}, {len(a)} sampled interior blocks; span of the samples {a[:, 11].max() - a[:, 0].min()} ticks")
-    print(f"   block: entry -> end of the interior walk {np.mean(a[:, 13] - a[:, 12]):.0f}, -> exit {np.mean(a[:, 14] - a[:, 13]):.0f} ticks; whole launch (first entry -> last exit) {a[:, 14].max() - a[:, 12].min()} ticks")
-    d = np.diff(a[:, :12], axis=1)
+    d = np.diff(a, axis=1)
     for i, nm in enumerate(names):
         print(f"   {nm:45s} mean {d[:, i].mean():8.0f}  median {np.median(d[:, i]):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
     life = a[:, 11] - a[:, 0]
