@@ -159,7 +159,9 @@ double asep_gnn_flops(const asep_gnn* g, int N, int E_corrected, int R);
  * handle loaded from the `aru_net/...` tensors of the same frozen graph (graph 'RU'/'ARU', mvn per the GNN's flag,
  * apply_softmax 0); endpoint_names are the `feature_map_generation_params from_layer` entries (layer_depth -1),
  * e.g. "scale_0_unet_up_2_conv".  The compression layers visual_node_feature_compression_fm_<i>/dense/{weights,bias} come from
- * the GNN's own weight blob.  cfg.node_feature_dim counts geometric + compressed visual dims (e.g. 7 + 3*16). */
+ * the GNN's own weight blob.  cfg.node_feature_dim counts geometric + compressed visual dims (e.g. 7 + 3*16).
+ * The backbone may be loaded with compute_dtype 1 (bf16, BASELINE configs[4]): the ROI kernel then reads its bf16 end points;
+ * compression layers, graph and classifier stay fp32. */
 int asep_gnn_attach_backbone(asep_gnn* g, asep_aru* backbone, int n_maps, const char* const* endpoint_names);
 
 /* run_gnn_clustering.py:259-269 with the image feeds: node_feat [N, node_feature_dim - visual dims],
