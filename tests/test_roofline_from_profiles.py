@@ -13,7 +13,14 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import make_traffic_json  # noqa: E402
 import roofline_from_profiles as rfp  # noqa: E402
 
-TAGS = [t for t in ("r3f", "r3f_bf16") if os.path.exists(os.path.join(ROOT, "profiles", t, "kernel_stats.csv"))]
+# every round-3 measurement point that carries the full set of summaries (profiles/r3*: fp32 headline builds and their bf16 twins)
+TAGS = sorted(t for t in os.listdir(os.path.join(ROOT, "profiles"))
+              if t.startswith("r3") and all(os.path.exists(os.path.join(ROOT, "profiles", t, f))
+                                            for f in ("kernel_stats.csv", "pmc_summary.json", "bench_under_trace.json", "bench.json")))
+
+
+def test_there_are_committed_summaries_to_check():
+    assert any(t.endswith("_bf16") for t in TAGS) and any(not t.endswith("_bf16") for t in TAGS), TAGS
 
 
 def test_kernel_keys_are_the_full_rocprof_names():
@@ -43,7 +50,9 @@ def test_roofline_block_is_reproducible_from_the_committed_summaries(tag):
     pmc = json.load(open(os.path.join(tagdir, "pmc_summary.json")))
     f = next(v for k, v in pmc["FETCH_SIZE"].items() if make_traffic_json.kernel_key(k) == r["kernel"])
     w = next(v for k, v in pmc["WRITE_SIZE"].items() if make_traffic_json.kernel_key(k) == r["kernel"])
-    assert abs((2 * f["avg_per_dispatch"] + w["avg_per_dispatch"]) * 1024 / r["traffic"] - 1) < 1e-6
+    # (the traced line carries the table of the FIRST profile pass of scripts/profile_round.sh, the directory holds the second
+    # pass's counters: the same build and command, equal to ~1e-4)
+    assert abs((2 * f["avg_per_dispatch"] + w["avg_per_dispatch"]) * 1024 / r["traffic"] - 1) < 1e-3
 
 
 @pytest.mark.parametrize("tag", TAGS)
@@ -60,8 +69,9 @@ def test_untraced_line_of_the_same_build_uses_the_same_traffic_table(tag):
     else:
         assert abs(tb_s / r["hbm_tb_per_s"] - 1) < 2e-3 and abs(r["achieved"] / r["peak"] / r["frac"] - 1) < 2e-3
         assert r["peak"] == 157.3
-    assert line["config"]["timed_region_s"] >= 8.0
+    # default run: 80 steps x 16 pages = 1280 pages -- >= 8 s of timed region at the fp32 rate, >= 3 s at the bf16 rate
+    assert line["config"]["timed_region_s"] >= (8.0 if line["dtype"] == "f32" else 3.0)
 
 
 def test_summaries_are_committed():
-    assert TAGS, "profiles/r3f (and r3f_bf16) with kernel_stats.csv / pmc_summary.json / bench_under_trace.json / bench.json expected"
+    assert TAGS, "profiles/r3* with kernel_stats.csv / pmc_summary.json / bench_under_trace.json / bench.json expected"
