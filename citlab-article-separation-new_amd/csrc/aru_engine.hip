@@ -1935,3 +1935,10 @@ extern "C" int asep_debug_r8f_trace(int up, unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(asep::g_r8f_trace), sizeof(unsigned long long) * n, (size_t)(up ? 1 : 0) * 4096 * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
 }
 #endif
+
+#if defined(CVB_TRACE)
+// debug builds only (see CVB_MARK in bf16_kernels.h); not part of include/asep_hip.h
+extern "C" int asep_debug_cvb_trace(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(asep::g_cvb_trace), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#endif

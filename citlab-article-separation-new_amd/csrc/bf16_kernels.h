@@ -82,6 +82,14 @@ struct ConvBArgs {
 // in the epilogue, where their HBM latency was exposed (a residual layer took 74 us against 42 us for its twin without one).
 // NW = waves per block (4, or 8 for the >= 64-channel layers: twice the waves per CU over the same LDS tile -- those layers are
 // short chains of dependent LDS reads and MFMAs, more waves overlap them).
+// Debug builds (-DCVB_TRACE): s_memtime stamps of thread 0 of every 4th block of the 8-wave >= 64-channel instantiation, read back
+// through asep_debug_cvb_trace by scripts/gpu_cvb_trace.py (DESIGN lesson 22); compiled out otherwise.
+#if defined(CVB_TRACE)
+__device__ unsigned long long g_cvb_trace[4096 * 8];
+#define CVB_MARK(i) do { if (NW == 8 && MODE == 2 && !RESP && blockIdx.y == 0 && (blockIdx.x & 3) == 0 && (blockIdx.x >> 2) < 4096 && tid == 0) g_cvb_trace[(blockIdx.x >> 2) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CVB_MARK(i) do { } while (0)
+#endif
 template <int KH, int KW, int MODE, int MT, int WM, int TH, int MINB, bool RESP = false, int NW = 4>
 __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a) {
     constexpr int NTH = 64 * NW;
@@ -104,6 +112,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
+    CVB_MARK(0);
     const int wm = WM == 2 ? (wave & 1) : 0, wn = WM == 2 ? (wave >> 1) : wave;
     int pi = 0;
     while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
@@ -154,6 +163,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
     }
     const int sub0 = (tid % SUBS) * 8;                        // (the block size is a multiple of SUBS: the sub-block is the same for all slots)
 
+    CVB_MARK(1);
     for (int g = 0; g < ngroups; ++g) {
         // ---- stage g: halo tile of 32 (16, 8) input channels + the stage's A fragments -> LDS.  Requests first; zero padding /
         //      ReLU when the registers go to LDS ----
@@ -199,6 +209,8 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
             }
         }
         __syncthreads();
+        if (g == 0) CVB_MARK(2);
+        if (g + 1 == ngroups) CVB_MARK(4);
         if constexpr (RESP) {
             if (g + 1 == ngroups) {
 #pragma unroll
@@ -250,6 +262,8 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
                     for (int kx = 0; kx < KW; ++kx) chunk(ky * KW + kx, (ky * LW + kx) * PXB);
             }
         }
+        if (g == 0) CVB_MARK(3);
+        if (g + 1 == ngroups) CVB_MARK(5);
     }
 
     // ---- epilogue: lane = pixel (column block, j), 4 consecutive output channels 16 (mt0 + m) + 4 kk ----
@@ -286,6 +300,11 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
                 }
             }
         }
+        CVB_MARK(6);
+#if defined(CVB_TRACE)
+        __builtin_amdgcn_s_waitcnt(0x0f70);                  // vmcnt(0): the tile's stores have left
+#endif
+        CVB_MARK(7);
         return;
     }
 #pragma unroll
