@@ -18,7 +18,7 @@ class AsepError(RuntimeError):
 class AruCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "channels", "n_classes", "feat_root", "scale_space_num", "res_depth", "num_scales_att",
-        "use_attention", "mvn", "apply_softmax", "compute_dtype")]
+        "use_attention", "mvn", "apply_softmax", "compute_dtype", "activation", "plain_u")]
 
 
 class GnnCfg(C.Structure):

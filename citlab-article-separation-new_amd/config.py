@@ -12,7 +12,7 @@ from typing import List
 
 @dataclass
 class AruConfig:
-    graph: str = "ARU"            # 'U' is not supported; 'RU' (no attention) or 'ARU'
+    graph: str = "ARU"            # 'U' (plain conv1 + conv2 blocks), 'RU' (residual blocks) or 'ARU' (+ attention), ARU_v1.py:92-97
     channels: int = 1             # image channels (the attention branch needs 1)
     n_classes: int = 2
     feat_root: int = 8
@@ -21,6 +21,7 @@ class AruConfig:
     num_scales_att: int = 3
     filter_size: int = 3
     pool_size: int = 2
+    activation_name: str = "relu"  # ARU_v1.py:43,70-75: 'relu', 'elu' or 'leaky' (leak 0.1, layers.py:10-30)
     mvn: bool = False
     apply_softmax: bool = True    # export-time class softmax -> 'output:0'
     # 'f32' (v_mfma_f32_16x16x4_f32, the reference's precision) or 'bf16' (BASELINE config 5: bf16 MFMA operands,
@@ -30,6 +31,18 @@ class AruConfig:
     @property
     def use_attention(self) -> bool:
         return "ARU" in self.graph
+
+    @property
+    def use_residual(self) -> bool:
+        return "RU" in self.graph                 # ARU_v1.py:94-95 ('U' alone: conv1 + conv2 blocks)
+
+    @property
+    def activation_code(self) -> int:
+        """asep_aru_cfg.activation"""
+        try:
+            return {"relu": 0, "elu": 1, "leaky": 2}[self.activation_name]
+        except KeyError:
+            raise ValueError(f"activation_name must be 'relu', 'elu' or 'leaky' (ARU_v1.py:43), got {self.activation_name!r}")
 
     def feat(self, level: int) -> int:
         return self.feat_root * (self.pool_size ** level)

@@ -1320,6 +1320,48 @@ TL run_chansum_bf(asep_aru* m, const TL& in) {
 
 // ---- network schedule (ARU_v1.py), evaluated for all problems in lock step ---------------------------------
 // residual block: conv1 (identity) -> t ; relu ; (res_depth-1) x conv+relu ; conv (identity) ; +t ; relu
+// ---- graph variants (asep_aru_cfg.activation != 0 and / or plain_u; fp32 path only): the layer kernels store pre-activation values,
+//      act_kernel follows (on the pooled tensor too: the activations are increasing, the fused 2x2 max commutes with them) ----
+void apply_act(asep_aru* m, TL& l) {
+    if (l.empty()) return;
+    for (size_t b0 = 0; b0 < l.size(); b0 += MAXP) {
+        const size_t b1 = std::min(l.size(), b0 + MAXP);
+        PoolArgs a{};
+        int blocks = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            PoolProb& p = a.p[i - b0];
+            p.in = l[i].p; p.out = l[i].p; p.H = p.Ho = l[i].H; p.W = p.Wo = l[i].W;
+            p.blk_begin = blocks;
+            blocks += (int)((l[i].count() + (size_t)POOL_ITEMS * 4 - 1) / ((size_t)POOL_ITEMS * 4));
+        }
+        a.nprob = (int)(b1 - b0);
+        a.C = l[0].C;
+        ProfScope ps(m, "act_kernel", 0.0);
+        hipLaunchKernelGGL(act_kernel, dim3(blocks), dim3(256), 0, m->stream, a, m->cfg.activation);
+    }
+}
+// conv / deconv / first conv followed by the graph's activation (act = false: identity layers)
+TL conv_act(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1, bool relu_in, bool act, const TL* res,
+            TL* pooled = nullptr, bool keep_full = true) {
+    if (m->cfg.activation == 0 || !act) return run_conv(m, scope, in0, in1, relu_in, act, res, pooled, keep_full);
+    TL out = run_conv(m, scope, in0, in1, relu_in, false, res, pooled, keep_full);
+    apply_act(m, out);
+    if (pooled) apply_act(m, *pooled);
+    return out;
+}
+TL deconv_act(asep_aru* m, const std::string& scope, const TL& in, const TL& like) {
+    if (m->cfg.activation == 0) return run_deconv(m, scope, in, like, true);
+    TL out = run_deconv(m, scope, in, like, false);
+    apply_act(m, out);
+    return out;
+}
+TL direct_act(asep_aru* m, const DirectConv& dc, const TL& imgs, bool act, const std::vector<const float*>& stats) {
+    if (m->cfg.activation == 0 || !act) return run_direct(m, dc, imgs, act, stats);
+    TL out = run_direct(m, dc, imgs, false, stats);
+    apply_act(m, out);
+    return out;
+}
+
 TL res_block_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled = nullptr) {
     if (m->bf16 && has_resb(m, scope)) return run_resb_tail(m, scope, t, pooled);      // one kernel for the whole tail
     TL r = t;
@@ -1327,8 +1369,9 @@ TL res_block_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled
     for (int i = 0; i < rd; ++i) {
         const bool last = (i == rd - 1);
         const std::string sc = scope + "/convR_" + std::to_string(i);
+        // (relu_in of the first conv: the ReLU between conv1 and convR_0 -- a ReLU in every activation variant, ARU_v1.py:214)
         r = m->bf16 ? run_convb(m, sc, r, nullptr, /*relu_in=*/i == 0, /*relu_out=*/true, last ? &t : nullptr, last ? pooled : nullptr)
-                    : run_conv(m, sc, r, nullptr, /*relu_in=*/i == 0, /*relu_out=*/true, last ? &t : nullptr, last ? pooled : nullptr);
+                    : conv_act(m, sc, r, nullptr, /*relu_in=*/i == 0, /*act=*/true, last ? &t : nullptr, last ? pooled : nullptr);
     }
     return r;
 }
@@ -1369,10 +1412,15 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
             u = n > 1 ? pooled : d;
             continue;
         }
-        TL t = (l == 0) ? run_direct(m, m->det_first, imgs, false, stats)
-                        : run_conv(m, scope + "/conv1", u, nullptr, false, false, nullptr);
-        TL pooled;
-        TL d = res_block_tail(m, scope, t, l < n - 1 ? &pooled : nullptr);    // the block's last conv also emits maxpool2(d)
+        TL pooled, d;
+        if (m->cfg.plain_u) {                                // graph 'U': conv1 + conv2, both activated (ARU_v1.py:228-233)
+            TL c1 = (l == 0) ? direct_act(m, m->det_first, imgs, true, stats) : conv_act(m, scope + "/conv1", u, nullptr, false, true, nullptr);
+            d = conv_act(m, scope + "/conv2", c1, nullptr, false, true, nullptr, l < n - 1 ? &pooled : nullptr);
+        } else {
+            TL t = (l == 0) ? run_direct(m, m->det_first, imgs, false, stats)
+                            : run_conv(m, scope + "/conv1", u, nullptr, false, false, nullptr);
+            d = res_block_tail(m, scope, t, l < n - 1 ? &pooled : nullptr);    // the block's last conv also emits maxpool2(d)
+        }
         skips.push_back(d);
         publish(d, "_unet_down_" + std::to_string(l) + "_conv");
         u = (l < n - 1) ? pooled : d;
@@ -1380,7 +1428,7 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
     for (int l = n - 2; l >= 0; --l) {
         const std::string scope = "aru_net/featMapG/unet_up_" + std::to_string(l);
         const TL& skip = skips[l];
-        TL v = m->bf16 ? run_deconvb(m, scope + "/deconv", u, skip, true) : run_deconv(m, scope + "/deconv", u, skip, true);
+        TL v = m->bf16 ? run_deconvb(m, scope + "/deconv", u, skip, true) : deconv_act(m, scope + "/deconv", u, skip);
         publish(v, "_unet_up_" + std::to_string(l) + "_deconv");
         if (m->bf16 && l == 0 && m->use_r8b && m->d_r8b_up_w1) {
             TL d, none;                                      // conv1 over [skip, deconv] + the tail in one kernel
@@ -1391,6 +1439,9 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
             u = res_block_tail(m, scope, t);
         } else if (l == 0 && m->use_fused8 && m->d_r8_up_w1) {
             u = run_res8_up(m, skip, v);
+        } else if (m->cfg.plain_u) {                         // ARU_v1.py:283-288
+            TL c1 = conv_act(m, scope + "/conv1", skip, &v, false, true, nullptr);
+            u = conv_act(m, scope + "/conv2", c1, nullptr, false, true, nullptr);
         } else {
             TL t = run_conv(m, scope + "/conv1", skip, &v, false, false, nullptr);   // concat [skip, deconv]
             u = res_block_tail(m, scope, t);
@@ -1433,7 +1484,7 @@ TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) 
             else hipLaunchKernelGGL(att_head_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
         }
     } else {
-        y = run_direct(m, m->att_first, imgs, true, stats);
+        y = direct_act(m, m->att_first, imgs, true, stats);
         y = run_pool(m, y, POOL_MAX);
     }
     TL pooled;
@@ -1445,11 +1496,11 @@ TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) 
         y = pooled;
         return run_conv(m, p + "4", y, nullptr, false, true, nullptr);
     }
-    run_conv(m, p + "2", y, nullptr, false, true, nullptr, &pooled, /*keep_full=*/false);   // conv + ReLU + pool in one kernel
+    conv_act(m, p + "2", y, nullptr, false, true, nullptr, &pooled, /*keep_full=*/false);   // conv + ReLU + pool in one kernel
     y = pooled;
-    run_conv(m, p + "3", y, nullptr, false, true, nullptr, &pooled, /*keep_full=*/false);
+    conv_act(m, p + "3", y, nullptr, false, true, nullptr, &pooled, /*keep_full=*/false);
     y = pooled;
-    y = run_conv(m, p + "4", y, nullptr, false, true, nullptr);
+    y = conv_act(m, p + "4", y, nullptr, false, true, nullptr);
     return y;
 }
 
@@ -1660,6 +1711,13 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (cfg->channels != 1) { set_error("asep_aru_load: only 1-channel input is supported (ARU_v1.py:115)"); return nullptr; }
     if (cfg->compute_dtype != 0 && cfg->compute_dtype != 1) { set_error("asep_aru_load: compute_dtype %d unknown (0 = fp32, 1 = bf16 MFMA)", cfg->compute_dtype); return nullptr; }
     if (cfg->scale_space_num < 1 || cfg->res_depth < 1) { set_error("asep_aru_load: bad cfg"); return nullptr; }
+    if (cfg->activation < 0 || cfg->activation > 2) { set_error("asep_aru_load: activation %d unknown (0 = relu, 1 = elu, 2 = leaky)", cfg->activation); return nullptr; }
+    const bool variant = cfg->activation != 0 || cfg->plain_u != 0;
+    if (variant && cfg->compute_dtype == 1) {
+        set_error("asep_aru_load: the bf16 path serves the ReLU residual graphs (RU / ARU) only; load elu / leaky / 'U' nets with compute_dtype 0");
+        return nullptr;
+    }
+    if (cfg->plain_u && cfg->use_attention) { set_error("asep_aru_load: graph 'U' has no attention branch (ARU_v1.py:92-97)"); return nullptr; }
     std::map<std::string, HostTensor> blob;
     if (!parse_blob(weight_blob, nbytes, blob)) return nullptr;
     std::unique_ptr<asep_aru> m(new asep_aru());
@@ -1672,6 +1730,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_C12")) m->use_c12 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BIGTILE2")) m->big_tile2 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;
+    if (variant) m->use_fused8 = false;                      // the fused level-0 blocks / attention head are ReLU residual kernels
     if (const char* e = getenv("ASEP_R8_VALU")) m->r8_valu = atoi(e) != 0;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BIGTILE")) m->big_tile = atoi(e) != 0;
@@ -1716,6 +1775,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     for (int l = 0; l < n && !rc; ++l) {
         const std::string s = "aru_net/featMapG/unet_down_" + std::to_string(l);
         if (l > 0) rc = pack_conv(m.get(), blob, s + "/conv1", "biases", false);
+        if (cfg->plain_u) { if (!rc) rc = pack_conv(m.get(), blob, s + "/conv2", "biases", false); continue; }
         for (int r = 0; r < cfg->res_depth && !rc; ++r)
             rc = pack_conv(m.get(), blob, s + "/convR_" + std::to_string(r), "biases", false);
     }
@@ -1723,10 +1783,11 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
         const std::string s = "aru_net/featMapG/unet_up_" + std::to_string(l);
         rc = pack_conv(m.get(), blob, s + "/deconv", "bias", true);
         if (!rc) rc = pack_conv(m.get(), blob, s + "/conv1", "biases", false);
+        if (cfg->plain_u) { if (!rc) rc = pack_conv(m.get(), blob, s + "/conv2", "biases", false); continue; }
         for (int r = 0; r < cfg->res_depth && !rc; ++r)
             rc = pack_conv(m.get(), blob, s + "/convR_" + std::to_string(r), "biases", false);
     }
-    if (!rc && !m->bf16 && cfg->feat_root == 8 && cfg->res_depth == 3 && m->det_first.k == 3) rc = pack_res8(m.get(), blob);
+    if (!rc && !variant && !m->bf16 && cfg->feat_root == 8 && cfg->res_depth == 3 && m->det_first.k == 3) rc = pack_res8(m.get(), blob);
     if (!rc && m->bf16 && cfg->res_depth == 3 && cfg->feat_root == 8) rc = pack_res8b(m.get(), blob);
     if (!rc && m->bf16 && cfg->res_depth == 3)
         for (int l = 0; l < n && !rc; ++l) {

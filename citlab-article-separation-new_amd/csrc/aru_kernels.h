@@ -1293,6 +1293,33 @@ struct PoolArgs {
 };
 constexpr int POOL_ITEMS = 1024;
 
+// In-place activation of the non-ReLU graph variants (ARU_v1.py:70-75; asep_aru_cfg.activation): 1 = elu (tf.nn.elu: x > 0 ? x :
+// exp(x) - 1, Eigen functor), 2 = leaky (layers.py:10-30: max(0, x) + 0.1 min(0, x)).  These nets run layer by layer (no fused blocks): the conv
+// kernels store the pre-activation value and this kernel follows; both functions are increasing, so a 2x2 max pool taken in the
+// conv's epilogue commutes with them (the pooled tensor gets the same pass).  p[].in == p[].out, Ho x Wo x C values each.
+__global__ __launch_bounds__(256) void act_kernel(const PoolArgs a, int mode) {
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].blk_begin) ++pi;
+    const PoolProb& P = a.p[pi];
+    const size_t total = (size_t)P.Ho * P.Wo * a.C;
+    const size_t base = (size_t)(blockIdx.x - P.blk_begin) * POOL_ITEMS * 4;
+    for (int k = 0; k < POOL_ITEMS / 256; ++k) {
+        const size_t i = base + ((size_t)k * 256 + threadIdx.x) * 4;
+        if (i >= total) break;
+        if (i + 4 <= total) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(P.out + i);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = mode == 1 ? (v[q] > 0.f ? v[q] : expf(v[q]) - 1.f) : fmaxf(v[q], 0.f) + 0.1f * fminf(v[q], 0.f);
+            *reinterpret_cast<f32x4*>(P.out + i) = v;
+        } else {
+            for (size_t q = i; q < total; ++q) {
+                const float x = P.out[q];
+                P.out[q] = mode == 1 ? (x > 0.f ? x : expf(x) - 1.f) : fmaxf(x, 0.f) + 0.1f * fminf(x, 0.f);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void maxpool2_kernel(const PoolArgs a) {
     int pi = 0;
     while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].blk_begin) ++pi;

@@ -49,7 +49,7 @@ class AruGraph:
                 raise ValueError(f"compute_dtype must be 'f32' or 'bf16', got {c.compute_dtype!r}")
             cfg = _lib.AruCfg(c.channels, c.n_classes, c.feat_root, c.scale_space_num, c.res_depth,
                               c.num_scales_att, int(c.use_attention), int(c.mvn), int(c.apply_softmax),
-                              1 if c.compute_dtype == "bf16" else 0)
+                              1 if c.compute_dtype == "bf16" else 0, c.activation_code, 0 if c.use_residual else 1)
             blob = self.blob()
             h = lib.asep_aru_load(blob, len(blob), C.byref(cfg))
             if not h:

@@ -42,9 +42,13 @@ def aru_tensor_shapes(cfg: AruConfig) -> "OrderedDict[str, tuple]":
         p = f"aru_net/featMapG/unet_down_{l}"
         shapes[p + "/conv1/weights"] = (k, k, last, f)
         shapes[p + "/conv1/biases"] = (f,)
-        for r in range(cfg.res_depth):
-            shapes[p + f"/convR_{r}/weights"] = (k, k, f, f)
-            shapes[p + f"/convR_{r}/biases"] = (f,)
+        if cfg.use_residual:
+            for r in range(cfg.res_depth):
+                shapes[p + f"/convR_{r}/weights"] = (k, k, f, f)
+                shapes[p + f"/convR_{r}/biases"] = (f,)
+        else:                                                      # graph 'U': ARU_v1.py:228-233
+            shapes[p + "/conv2/weights"] = (k, k, f, f)
+            shapes[p + "/conv2/biases"] = (f,)
         last = f
     for l in range(cfg.scale_space_num - 2, -1, -1):                # ARU_v1.py:251-292
         f = cfg.feat(l)
@@ -53,9 +57,13 @@ def aru_tensor_shapes(cfg: AruConfig) -> "OrderedDict[str, tuple]":
         shapes[p + "/deconv/bias"] = (f,)
         shapes[p + "/conv1/weights"] = (k, k, 2 * f, f)
         shapes[p + "/conv1/biases"] = (f,)
-        for r in range(cfg.res_depth):
-            shapes[p + f"/convR_{r}/weights"] = (k, k, f, f)
-            shapes[p + f"/convR_{r}/biases"] = (f,)
+        if cfg.use_residual:
+            for r in range(cfg.res_depth):
+                shapes[p + f"/convR_{r}/weights"] = (k, k, f, f)
+                shapes[p + f"/convR_{r}/biases"] = (f,)
+        else:                                                      # ARU_v1.py:283-288
+            shapes[p + "/conv2/weights"] = (k, k, f, f)
+            shapes[p + "/conv2/biases"] = (f,)
         last = f
     shapes["aru_net/logit/class/weights"] = (4, 4, cfg.feat_root, cfg.n_classes)   # ARU_v1.py:158
     shapes["aru_net/logit/class/biases"] = (cfg.n_classes,)

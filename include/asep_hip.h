@@ -64,6 +64,11 @@ typedef struct asep_aru_cfg {
     int32_t mvn;               /* per-image standardisation of the input */
     int32_t apply_softmax;     /* export-time class softmax */
     int32_t compute_dtype;     /* 0 = fp32 (f32 MFMA), 1 = bf16 MFMA with fp32 accumulation */
+    int32_t activation;        /* ARU_v1.py:70-75 activation_name: 0 = relu, 1 = elu, 2 = leaky (leak 0.1, layers.py:10-30).  It is the
+                                  activation of the convR / conv2 layers, of the block ends, the deconvolutions and the attention CNN; the
+                                  ReLU between conv1 and convR_0 of a residual block is a ReLU in every variant (ARU_v1.py:214,268) */
+    int32_t plain_u;           /* 1 = graph 'U' (ARU_v1.py:228-233,283-288): every block is conv1 + conv2 with the activation, no
+                                  residual add, tensors <block>/conv2/{weights,biases} instead of convR_<i>; 0 = residual blocks (RU / ARU) */
 } asep_aru_cfg;
 
 typedef struct asep_aru asep_aru;

@@ -123,6 +123,18 @@ def relu(x):
     return np.maximum(x, 0)
 
 
+def activation_fn(name):
+    """ARU_v1.py:70-75: the graph's activation -- layers.relu, layers.elu (tf.nn.elu: x > 0 ? x : exp(x) - 1) or layers.leaky_relu
+    (layers.py:10-30: max(0, x) + 0.1 * min(0, x))."""
+    if name == "relu":
+        return relu
+    if name == "elu":
+        return lambda x: np.where(x > 0, x, np.exp(np.minimum(x, 0)) - 1).astype(x.dtype)
+    if name == "leaky":
+        return lambda x: (np.maximum(x, 0) + x.dtype.type(0.1) * np.minimum(x, 0)).astype(x.dtype)
+    raise ValueError(f"activation_name {name!r} (ARU_v1.py:43: relu, elu, leaky)")
+
+
 def softmax(x, axis=-1):
     m = x.max(axis=axis, keepdims=True)
     e = np.exp(x - m)
@@ -139,25 +151,34 @@ def per_image_standardization(x):
 # ----------------------------------------------------------------------------------------------
 # network (numpy)
 # ----------------------------------------------------------------------------------------------
-def _res_block(x, w, prefix, res_depth):
-    """ARU_v1.py:212-227 / :266-281.  conv1 (identity) -> save -> relu -> (res_depth-1) x conv+relu
-    -> conv (identity) -> add -> relu."""
+def _res_block(x, w, prefix, res_depth, act=relu):
+    """ARU_v1.py:212-227 / :266-281.  conv1 (identity) -> save -> relu (ALWAYS relu, :214) -> (res_depth-1) x conv+act
+    -> conv (identity) -> add -> act."""
     t = conv2d_same(x, w[prefix + "/conv1/weights"], w[prefix + "/conv1/biases"])
     r = relu(t)
     for a in range(res_depth):
         r = conv2d_same(r, w[prefix + f"/convR_{a}/weights"], w[prefix + f"/convR_{a}/biases"])
         if a < res_depth - 1:
-            r = relu(r)
-    return relu(r + t)
+            r = act(r)
+    return act(r + t)
+
+
+def _plain_block(x, w, prefix, act):
+    """ARU_v1.py:228-233 / :283-288 (graph 'U'): conv1 + act -> conv2 + act."""
+    c1 = act(conv2d_same(x, w[prefix + "/conv1/weights"], w[prefix + "/conv1/biases"]))
+    return act(conv2d_same(c1, w[prefix + "/conv2/weights"], w[prefix + "/conv2/biases"]))
 
 
 def det_cnn(x, w, cfg, end_points=None, sc=0):
-    """ARU_v1.py:186-294 (useResidual=True)."""
+    """ARU_v1.py:186-294."""
     n = cfg.scale_space_num
+    act = activation_fn(getattr(cfg, "activation_name", "relu"))
+    residual = getattr(cfg, "use_residual", True)
+    block = (lambda y, p: _res_block(y, w, p, cfg.res_depth, act)) if residual else (lambda y, p: _plain_block(y, w, p, act))
     skips = []
     u = x
     for l in range(n):
-        d = _res_block(u, w, f"aru_net/featMapG/unet_down_{l}", cfg.res_depth)
+        d = block(u, f"aru_net/featMapG/unet_down_{l}")
         skips.append(d)
         if end_points is not None:
             end_points[f"scale_{sc}_unet_down_{l}_conv"] = d
@@ -165,26 +186,26 @@ def det_cnn(x, w, cfg, end_points=None, sc=0):
     for l in range(n - 2, -1, -1):
         p = f"aru_net/featMapG/unet_up_{l}"
         skip = skips[l]
-        v = relu(deconv2d(u, w[p + "/deconv/weights"], w[p + "/deconv/bias"], skip.shape[:2], cfg.pool_size))
+        v = act(deconv2d(u, w[p + "/deconv/weights"], w[p + "/deconv/bias"], skip.shape[:2], cfg.pool_size))
         if end_points is not None:
             end_points[f"scale_{sc}_unet_up_{l}_deconv"] = v
         c = np.concatenate([skip, v], axis=2)                      # skip first (ARU_v1.py:264)
-        u = _res_block(c, w, p, cfg.res_depth)
+        u = block(c, p)
         if end_points is not None:
             end_points[f"scale_{sc}_unet_up_{l}_conv"] = u
     return u
 
 
-def att_cnn(x, w):
-    """ARU_v1.py:165-184: 4x4 conv 12 -> pool -> 16 -> pool -> 32 -> pool -> 4x4 conv 1, all ReLU."""
+def att_cnn(x, w, act=relu):
+    """ARU_v1.py:165-184: 4x4 conv 12 -> pool -> 16 -> pool -> 32 -> pool -> 4x4 conv 1, all with the graph's activation."""
     p = "aru_net/attMapG/attPart/conv"
-    y = relu(conv2d_same(x, w[p + "1/weights"], w[p + "1/biases"]))
+    y = act(conv2d_same(x, w[p + "1/weights"], w[p + "1/biases"]))
     y = max_pool2(y)
-    y = relu(conv2d_same(y, w[p + "2/weights"], w[p + "2/biases"]))
+    y = act(conv2d_same(y, w[p + "2/weights"], w[p + "2/biases"]))
     y = max_pool2(y)
-    y = relu(conv2d_same(y, w[p + "3/weights"], w[p + "3/biases"]))
+    y = act(conv2d_same(y, w[p + "3/weights"], w[p + "3/biases"]))
     y = max_pool2(y)
-    y = relu(conv2d_same(y, w[p + "4/weights"], w[p + "4/biases"]))
+    y = act(conv2d_same(y, w[p + "4/weights"], w[p + "4/biases"]))
     return y
 
 
@@ -207,7 +228,7 @@ def forward_numpy(image, w, cfg, dtype=np.float32, return_intermediates=False):
         att = []
         up = 8
         for s in range(cfg.num_scales_att):                        # ARU_v1.py:113-118
-            a = att_cnn(scales[s], w)
+            a = att_cnn(scales[s], w, activation_fn(getattr(cfg, "activation_name", "relu")))
             inter[f"att_{s}"] = a
             att.append(upsample_simple(a, (H, W), up)[:, :, :1])   # out shape = input shape (1 ch)
             up *= 2
@@ -295,14 +316,26 @@ def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermedia
         def conv(x, p, bias_name="biases"):
             return batch_norm(_t_conv(x, tw[p + "/weights"], tw[p + "/" + bias_name], F, torch), p)
 
+        act_name = getattr(cfg, "activation_name", "relu")
+        if act_name == "relu":
+            act = F.relu
+        elif act_name == "elu":
+            act = lambda y: torch.where(y > 0, y, torch.exp(torch.clamp(y, max=0)) - 1)      # tf.nn.elu
+        elif act_name == "leaky":
+            act = lambda y: torch.clamp(y, min=0) + 0.1 * torch.clamp(y, max=0)              # layers.py:10-30
+        else:
+            raise ValueError(f"activation_name {act_name!r}")
+
         def block(x, p):
+            if not getattr(cfg, "use_residual", True):       # graph 'U' (ARU_v1.py:228-233)
+                return act(conv(act(conv(x, p + "/conv1")), p + "/conv2"))
             t = conv(x, p + "/conv1")
-            r = F.relu(t)
+            r = F.relu(t)                                    # always a ReLU (ARU_v1.py:214)
             for a in range(cfg.res_depth):
                 r = conv(r, p + f"/convR_{a}")
                 if a < cfg.res_depth - 1:
-                    r = F.relu(r)
-            return F.relu(r + t)
+                    r = act(r)
+            return act(r + t)
 
         def det(x, sc):
             n = cfg.scale_space_num
@@ -316,8 +349,8 @@ def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermedia
             for l in range(n - 2, -1, -1):
                 p = f"aru_net/featMapG/unet_up_{l}"
                 skip = skips[l]
-                v = F.relu(batch_norm(_t_deconv(u, tw[p + "/deconv/weights"], tw[p + "/deconv/bias"],
-                                                skip.shape[2:], cfg.pool_size, F, torch), p + "/deconv"))
+                v = act(batch_norm(_t_deconv(u, tw[p + "/deconv/weights"], tw[p + "/deconv/bias"],
+                                             skip.shape[2:], cfg.pool_size, F, torch), p + "/deconv"))
                 inter[f"scale_{sc}_unet_up_{l}_deconv"] = v
                 u = block(torch.cat([skip, v], dim=1), p)
                 inter[f"scale_{sc}_unet_up_{l}_conv"] = u
@@ -325,13 +358,13 @@ def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermedia
 
         def att(x):
             p = "aru_net/attMapG/attPart/conv"
-            y = F.relu(conv(x, p + "1"))
+            y = act(conv(x, p + "1"))
             y = F.max_pool2d(y, 2, 2, ceil_mode=True)
-            y = F.relu(conv(y, p + "2"))
+            y = act(conv(y, p + "2"))
             y = F.max_pool2d(y, 2, 2, ceil_mode=True)
-            y = F.relu(conv(y, p + "3"))
+            y = act(conv(y, p + "3"))
             y = F.max_pool2d(y, 2, 2, ceil_mode=True)
-            return F.relu(conv(y, p + "4"))
+            return act(conv(y, p + "4"))
 
         if cfg.mvn:
             mean = x.mean()

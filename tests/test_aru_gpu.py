@@ -138,6 +138,44 @@ def test_non_default_hyper_parameters(kw):
     assert np.abs(out - ref).max() <= PROB_TOL
 
 
+@pytest.mark.parametrize("kw", [
+    {"activation_name": "elu"}, {"activation_name": "leaky"},                       # ARU_v1.py:70-75
+    {"graph": "RU", "activation_name": "elu"},
+    {"graph": "U"}, {"graph": "U", "activation_name": "leaky"}, {"graph": "U", "activation_name": "elu", "scale_space_num": 3},
+], ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
+@pytest.mark.parametrize("H,W", [(150, 131), (37, 53)])
+def test_graph_variants_elu_leaky_and_plain_u(kw, H, W):
+    """ARU_v1.py:43,70-75 (activation_name elu / leaky: convR / conv2 layers, block ends, deconvolutions and the attention CNN; the
+    ReLU behind conv1 of a residual block stays a ReLU) and graph 'U' (:228-233,:283-288: conv1 + conv2 blocks, no residual add, no
+    attention).  The engine runs these nets layer by layer with act_kernel behind the convolutions; every end point and the
+    probabilities must meet the fp32 gates of the default graph."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from oracle import aru_oracle
+    cfg, w, graph = _setup(kw, seed=5)
+    assert ("unet_down_0/conv2/weights" in "".join(w)) == (kw.get("graph") == "U")
+    img = _image(H, W, 31)
+    ref, inter = aru_oracle.forward_torch(img, w, cfg, return_intermediates=True)
+    out = helper.get_net_output(img, graph, "0")
+    neg = 0
+    for name in sorted(inter):
+        if name.startswith("scale_") or name.startswith("att_"):
+            got, want = helper.get_endpoint(graph, name), inter[name]
+            assert got.shape == want.shape, name
+            assert float(np.abs(got - want).max()) <= 2e-5 * max(1.0, float(np.abs(want).max())), name
+            neg += int((want < 0).sum())
+    if kw.get("activation_name", "relu") != "relu":
+        assert neg > 0                                       # the negative branch of the activation was exercised
+    assert float(np.abs(out - ref).max()) <= PROB_TOL
+    graph.close()
+
+
+def test_variants_are_refused_by_the_bf16_path():
+    from citlab_article_separation_new_amd import _lib, net_post_processing_helper as helper
+    cfg, w, graph = _setup({"activation_name": "elu", "compute_dtype": "bf16"})
+    with pytest.raises(_lib.AsepError, match="bf16 path serves the ReLU residual graphs"):
+        helper.get_net_output(_image(32, 32, 0), graph, "0")
+
+
 def test_unsupported_width_is_rejected_loudly():
     from citlab_article_separation_new_amd import _lib, net_post_processing_helper as helper
     cfg, w, graph = _setup({"feat_root": 4})

@@ -29,6 +29,48 @@ def test_numpy_and_torch_oracles_agree(H, W):
     assert np.abs(a - c).max() < 5e-6          # fp32 vs fp64: the tolerance budget of the GPU test
 
 
+@pytest.mark.parametrize("kw", [{"activation_name": "elu"}, {"activation_name": "leaky"}, {"graph": "U"},
+                                {"graph": "U", "activation_name": "leaky"}, {"graph": "RU", "activation_name": "elu"}],
+                         ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
+def test_numpy_and_torch_oracles_agree_on_the_graph_variants(kw):
+    """ARU_v1.py:43,70-75 (elu / leaky) and graph 'U' (:228-233): the two oracle implementations restate them independently"""
+    cfg, w = _cfg_w(seed=7, **kw)
+    assert ("aru_net/featMapG/unet_down_0/conv2/weights" in w) == (kw.get("graph") == "U")
+    assert not any("attMapG" in k for k in w) or cfg.graph == "ARU"
+    img = np.random.default_rng(11).random((45, 38)).astype(np.float32)
+    a, ia = O.forward_numpy(img, w, cfg, return_intermediates=True)
+    b, ib = O.forward_torch(img, w, cfg, return_intermediates=True)
+    assert np.abs(a - b).max() < 5e-6
+    for k in ia:
+        assert np.abs(ia[k] - ib[k]).max() < 2e-5 * max(1.0, np.abs(ia[k]).max()), k
+    if kw.get("activation_name", "relu") != "relu":
+        assert min(float(v.min()) for k, v in ia.items() if k.startswith("scale_")) < 0      # the negative branch is reached
+
+
+def test_activation_functions_on_hand_values():
+    """layers.py:10-30 leaky_relu = max(0, x) + 0.1 min(0, x); tf.nn.elu = x for x > 0, exp(x) - 1 otherwise"""
+    x = np.array([-2.0, -0.5, 0.0, 0.5, 3.0], np.float32)
+    assert np.allclose(O.activation_fn("leaky")(x), [-0.2, -0.05, 0.0, 0.5, 3.0], atol=1e-7)
+    assert np.allclose(O.activation_fn("elu")(x), [np.exp(-2.0) - 1, np.exp(-0.5) - 1, 0.0, 0.5, 3.0], atol=1e-7)
+    assert np.array_equal(O.activation_fn("relu")(x), [0, 0, 0, 0.5, 3.0])
+    with pytest.raises(ValueError):
+        O.activation_fn("selu")
+
+
+def test_residual_block_keeps_the_relu_behind_conv1_in_every_variant():
+    """ARU_v1.py:214: `x = layers.relu(x)` after conv1 is not the graph's activation.  A block whose conv1 output is negative
+    everywhere must therefore feed zeros into convR_0 even with elu."""
+    f = 2
+    w = {"b/conv1/weights": np.zeros((3, 3, 1, f), np.float32), "b/conv1/biases": np.full(f, -1.0, np.float32)}
+    for r in range(3):
+        w[f"b/convR_{r}/weights"] = np.ones((3, 3, f, f), np.float32)
+        w[f"b/convR_{r}/biases"] = np.zeros(f, np.float32)
+    x = np.ones((5, 5, 1), np.float32)
+    out = O._res_block(x, w, "b", 3, O.activation_fn("elu"))
+    # t = -1 everywhere, relu(t) = 0 -> all convR outputs 0 -> elu(0 + t) = exp(-1) - 1
+    assert np.allclose(out, np.exp(-1.0) - 1, atol=1e-6)
+
+
 def test_same_padding_rule():
     assert O.same_pad(3) == (1, 1)
     assert O.same_pad(4) == (1, 2)             # even kernel: one before, two after (SURVEY A.3)
