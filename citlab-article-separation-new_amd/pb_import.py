@@ -295,6 +295,12 @@ def aru_from_constants(nodes, num_scales_att=None, apply_softmax=None):
     res_depth = 0
     while _find(consts, f"aru_net/featMapG/unet_down_0/convR_{res_depth}/weights") is not None:
         res_depth += 1
+    plain_u = res_depth == 0 and _find(consts, "aru_net/featMapG/unet_down_0/conv2/weights") is not None   # graph 'U'
+    act = _find(consts, "asep_meta/activation")             # written by weights_to_graphdef(meta={"activation": code}); absent: relu,
+    try:                                                    # ARU_v1.py:43's default (the constants cannot tell)
+        activation_name = ("relu", "elu", "leaky")[int(np.asarray(act).reshape(-1)[0])] if act is not None else "relu"
+    except IndexError:
+        raise IOError("asep_meta/activation must be 0 (relu), 1 (elu) or 2 (leaky)")
     w0 = _find(consts, "aru_net/featMapG/unet_down_0/conv1/weights")
     wl = _find(consts, "aru_net/logit/class/weights")
     if wl is None:
@@ -309,8 +315,8 @@ def aru_from_constants(nodes, num_scales_att=None, apply_softmax=None):
         apply_softmax = _hint_softmax(nodes)
         if apply_softmax is None:
             raise IOError("the graph has no 'output' node: pass apply_softmax explicitly")
-    cfg = AruConfig(graph="ARU" if use_att else "RU", channels=int(w0.shape[2]), n_classes=int(wl.shape[3]),
-                    feat_root=int(w0.shape[3]), scale_space_num=levels, res_depth=res_depth,
+    cfg = AruConfig(graph="ARU" if use_att else ("U" if plain_u else "RU"), channels=int(w0.shape[2]), n_classes=int(wl.shape[3]),
+                    feat_root=int(w0.shape[3]), scale_space_num=levels, res_depth=3 if plain_u else res_depth, activation_name=activation_name,
                     num_scales_att=int(num_scales_att), filter_size=int(w0.shape[0]),
                     mvn=any("aru_net/mvn" in n["name"] for n in nodes), apply_softmax=bool(apply_softmax))
     tensors = OrderedDict()
@@ -335,12 +341,54 @@ _ADD_OPS = ("Add", "AddV2", "BiasAdd")
 _KNOWN_OPS = set(_PASS_OPS + _SHAPE_OPS + _BN_OPS + _ADD_OPS + (
     "Placeholder", "Const", "Fill", "Conv2D", "Conv2DBackpropInput", "Relu", "MaxPool", "AvgPool", "ConcatV2", "Softmax",
     "Split", "SplitV", "Mul", "AddN", "StridedSlice", "Pack"))
+# the activations of the ARU_v1 variants (ARU_v1.py:70-75): tf.nn.elu, and layers.leaky_relu's composite
+# maximum(0, x) + leak * minimum(0, x) (layers.py:10-30; tf.nn.leaky_relu's fused op is accepted too)
+_ACT_VARIANT_OPS = {"elu": {"Elu"}, "leaky": {"Maximum", "Minimum", "LeakyRelu"}}
 _MVN_OPS = {"Mean", "Square", "Sqrt", "Rsqrt", "Sub", "RealDiv", "Maximum", "Enter", "Exit", "Merge", "Switch",
             "NextIteration", "LoopCond", "Less", "LogicalAnd", "Range", "TensorArrayV3", "TensorArrayReadV3",
             "TensorArrayWriteV3", "TensorArrayScatterV3", "TensorArrayGatherV3", "TensorArraySizeV3",
             "TensorArrayUnstack", "Cast", "Reshape", "Squeeze", "ExpandDims"}
-_UNSUPPORTED_ACT = {"Elu": "elu", "LeakyRelu": "leaky", "Selu": "selu", "Relu6": "relu6", "Tanh": "tanh",
-                    "Sigmoid": "sigmoid"}
+_UNSUPPORTED_ACT = {"Selu": "selu", "Relu6": "relu6", "Tanh": "tanh", "Sigmoid": "sigmoid"}
+LEAK = 0.1                                                  # layers.py:10: the engine's act_kernel implements this slope only
+
+
+def _activation_of(graph, path, ops_on_path, mvn):
+    """'relu', 'elu' or 'leaky' from the activation ops between inImg and output; mixtures other than ARU_v1's own (the ReLU
+    behind conv1 of every residual block, ARU_v1.py:214) and leaks other than 0.1 are refused"""
+    has_elu = "Elu" in ops_on_path
+    has_leaky = "Minimum" in ops_on_path or "LeakyRelu" in ops_on_path
+    if has_elu and has_leaky:
+        raise IOError("Elu and leaky-ReLU ops on the same path: not an ARU_v1 graph (ARU_v1.py:70-75 picks one activation)")
+    if has_elu:
+        return "elu"
+    if not has_leaky:
+        if "Maximum" in ops_on_path and not mvn:
+            raise IOError("Maximum ops on the path without the Minimum half of layers.leaky_relu (layers.py:10-30)")
+        return "relu"
+    for n in path:
+        if n["op"] == "LeakyRelu":
+            alpha = n["attr"].get("alpha")
+            alpha = 0.2 if alpha is None else float(alpha)  # the op's registered default
+            if abs(alpha - LEAK) > 1e-6:
+                raise IOError(f"{n['name']}: LeakyRelu alpha {alpha}; the engine implements leak {LEAK} (layers.py:10)")
+        elif n["op"] == "Minimum":
+            # leak * minimum(0, x): the Minimum compares with the constant 0 and its only consumer multiplies by the leak
+            consts = [graph.const_of(r)[1] for r in n["input"] if not r.startswith("^")]
+            if not any(c is not None and c.size == 1 and float(c.reshape(-1)[0]) == 0.0 for c in consts):
+                raise IOError(f"{n['name']}: Minimum without a constant 0 operand is not layers.leaky_relu (layers.py:10-30)")
+            cons = graph.data_consumers(n)
+            leak = None
+            if len(cons) == 1 and cons[0]["op"] == "Mul":
+                for r in cons[0]["input"]:
+                    if not r.startswith("^") and graph.base(r) != n["name"]:
+                        _, v = graph.const_of(r)
+                        if v is not None and v.size == 1:
+                            leak = float(v.reshape(-1)[0])
+            if leak is None:
+                raise IOError(f"{n['name']}: no constant leak factor behind the Minimum (layers.py:10-30)")
+            if abs(leak - LEAK) > 1e-6:
+                raise IOError(f"{n['name']}: leak {leak}; the engine implements leak {LEAK} (layers.py:10)")
+    return "leaky"
 
 
 class _Layer:
@@ -566,9 +614,10 @@ def aru_from_topology(nodes, input_name="inImg", output_name="output"):
     ops_on_path = {n["op"] for n in path}
     bad_act = sorted(_UNSUPPORTED_ACT[o] for o in ops_on_path if o in _UNSUPPORTED_ACT)
     if bad_act:
-        raise IOError(f"activation {bad_act} on the path: the engine implements ARU_v1 with relu only (ARU_v1.py:70-75)")
+        raise IOError(f"activation {bad_act} on the path: ARU_v1 knows relu, elu and leaky (ARU_v1.py:70-75)")
     mvn = bool(ops_on_path & {"Enter", "Mean", "Sqrt", "Rsqrt", "RealDiv"})
-    unknown = sorted(ops_on_path - _KNOWN_OPS - (_MVN_OPS if mvn else set()))
+    activation_name = _activation_of(graph, path, ops_on_path, mvn)
+    unknown = sorted(ops_on_path - _KNOWN_OPS - (_MVN_OPS if mvn else set()) - _ACT_VARIANT_OPS.get(activation_name, set()))
     if unknown:
         raise IOError(f"ops {unknown} between {input_name} and {output_name} are not part of the ARU_v1 family")
     for n in path:
@@ -648,9 +697,25 @@ def aru_from_topology(nodes, input_name="inImg", output_name="output"):
         softmax, node = True, graph.skip_pass(graph.src(node["input"][0]))
     if node is not last.ops[0] and node is not _read_layer_tail(graph, last, last.ops[0])[0]:
         raise IOError(f"'{output_name}' is not the (softmax of the) classification layer but {node['op']} {node['name']}")
-    cfg = AruConfig(graph="ARU" if att else "RU", channels=channels, n_classes=last.cout, feat_root=feat_root,
-                    scale_space_num=n_levels, res_depth=res_depth, num_scales_att=n_scales, filter_size=k, mvn=mvn,
-                    apply_softmax=softmax)
+    # graph 'U' (ARU_v1.py:228-233: conv1 + conv2 per block, no residual add) has the layer list of a residual graph with
+    # res_depth 1; the wiring tells them apart: in 'U' the block's output is conv2 alone, in 'RU' the sum conv1 + convR_0
+    plain_u = False
+    if res_depth == 1 and not att and len(det) > 1:
+        nxt = det[2] if len(det) > 2 else last               # the layer that consumes the first block's output
+        plain_u = nxt.preds == {det[1].filter_name}
+    cfg = AruConfig(graph="ARU" if att else ("U" if plain_u else "RU"), channels=channels, n_classes=last.cout, feat_root=feat_root,
+                    scale_space_num=n_levels, res_depth=3 if plain_u else res_depth, num_scales_att=n_scales, filter_size=k, mvn=mvn,
+                    apply_softmax=softmax, activation_name=activation_name)
+    if activation_name != "relu" and not plain_u:
+        # ARU_v1.py:214,268: the activation behind conv1 of a residual block is layers.relu in every variant -- one Relu op per
+        # block and pyramid scale, and no other
+        want_relu = (n_levels + n_dec) * n_scales
+        n_relu = sum(1 for n in path if n["op"] == "Relu")
+        if n_relu != want_relu:
+            raise IOError(f"{n_relu} Relu ops beside the {activation_name} activations; ARU_v1 has exactly one per residual block "
+                          f"and scale ({want_relu}: the ReLU behind conv1, ARU_v1.py:214) -- the activations are not placed like ARU_v1's")
+    elif activation_name != "relu" and any(n["op"] == "Relu" for n in path):
+        raise IOError(f"Relu ops in a 'U' graph with {activation_name} activations (ARU_v1.py:228-233 uses the graph's activation only)")
     # assign by position and verify the skip / residual wiring against the template
     names = list(aru_tensor_shapes(cfg))
     wnames = [n for n in names if n.endswith("/weights")]
@@ -689,15 +754,25 @@ def _check_wiring(cfg, ordered, name_of):
     want = {}
     block_out = None                                        # layers whose sum is the previous block's output
     det = "aru_net/featMapG/"
+    plain_u = not cfg.use_residual                          # ARU_v1.py:228-233,283-288: conv1 -> conv2, the block's output is conv2
     for l in range(n):
         s = f"{det}unet_down_{l}"
         want[s + "/conv1"] = set(block_out or ())
+        if plain_u:
+            want[s + "/conv2"] = {s + "/conv1"}
+            block_out = {s + "/conv2"}
+            continue
         for r in range(R):
             want[s + f"/convR_{r}"] = {s + ("/conv1" if r == 0 else f"/convR_{r - 1}")}
         block_out = {s + "/conv1", s + f"/convR_{R - 1}"}
     for l in range(n - 2, -1, -1):
         s, skip = f"{det}unet_up_{l}", f"{det}unet_down_{l}"
         want[s + "/deconv"] = set(block_out)
+        if plain_u:
+            want[s + "/conv1"] = {s + "/deconv", skip + "/conv2"}
+            want[s + "/conv2"] = {s + "/conv1"}
+            block_out = {s + "/conv2"}
+            continue
         want[s + "/conv1"] = {s + "/deconv", skip + "/conv1", skip + f"/convR_{R - 1}"}
         for r in range(R):
             want[s + f"/convR_{r}"] = {s + ("/conv1" if r == 0 else f"/convR_{r - 1}")}
@@ -712,8 +787,7 @@ def _check_wiring(cfg, ordered, name_of):
     want["aru_net/logit/class"] = logit_in
     for scope, preds in want.items():
         if got.get(scope) != preds:
-            raise IOError(f"{scope} is fed by {sorted(got.get(scope, ()))} in the graph, ARU_v1 wires it to {sorted(preds)} "
-                          f"(non-residual 'U' graphs and other variants are not supported)")
+            raise IOError(f"{scope} is fed by {sorted(got.get(scope, ()))} in the graph, ARU_v1 ('{cfg.graph}') wires it to {sorted(preds)}")
 
 
 def aru_from_nodes(nodes, num_scales_att=None, apply_softmax=None):

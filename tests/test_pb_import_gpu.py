@@ -44,6 +44,30 @@ def test_foreign_frozen_graph_loads_and_matches_oracle(tmp_path, variant):
     graph.close()
 
 
+@pytest.mark.parametrize("kw", [{"activation_name": "elu"}, {"activation_name": "leaky"}, {"graph": "U", "activation_name": "leaky"},
+                                {"graph": "U"}], ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
+def test_foreign_frozen_graph_of_an_aru_variant_loads_and_matches_oracle(tmp_path, kw):
+    """ARU_v1.py:43,70-75,228-233: elu / leaky activations and the non-residual 'U' graph, frozen with hashed scope names: recognised
+    from the op graph, run by the engine's layer-by-layer path, compared with the oracle on the original weights."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    from oracle import aru_oracle
+    cfg = AruConfig(**kw)
+    w = init_aru_weights(cfg, 37, bias_jitter=0.05, logit_scale=0.05)
+    pb = tmp_path / "variant_net.pb"
+    pb.write_bytes(tf_aru_graph.build_aru_pb(w, cfg, rename=_hashed))
+    graph = helper.load_graph(str(pb))
+    assert graph.cfg.graph == cfg.graph and graph.cfg.activation_name == cfg.activation_name
+    img = np.random.default_rng(9).random((131, 207), dtype=np.float32)
+    out = helper.get_net_output(img, graph, "0")
+    ref = aru_oracle.forward_torch(img, w, cfg)
+    err = float(np.abs(out - ref).max())
+    print(f"\n{kw}: max|d| = {err:.2e}")
+    assert err <= 1e-4
+    graph.close()
+
+
 @pytest.mark.parametrize("steps,compress", [(2, 0), (4, 0), (2, 6)])
 def test_relation_net_options_read_from_the_op_graph_match_the_oracle(tmp_path, steps, compress):
     """a GraphDef laid out like a TF1 export (tests/tf_gnn_graph.py, serialised by google.protobuf) with a

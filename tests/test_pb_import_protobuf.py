@@ -159,7 +159,10 @@ def test_refuses_what_it_cannot_map():
     w = init_aru_weights(cfg, 1)
     good = tf_aru_graph.build_aru_pb(w, cfg)
     pb_import.aru_from_nodes(pb_import.parse_graphdef(good))
-    with pytest.raises(IOError, match="relu only"):
+    with pytest.raises(IOError, match="knows relu, elu and leaky"):
+        pb_import.aru_from_nodes(pb_import.parse_graphdef(tf_aru_graph.build_aru_pb(w, cfg, activation="Selu")))
+    # Elu EVERYWHERE, also behind conv1 of the residual blocks where ARU_v1 always has a ReLU (ARU_v1.py:214): not ARU_v1's placement
+    with pytest.raises(IOError, match="not placed like ARU_v1"):
         pb_import.aru_from_nodes(pb_import.parse_graphdef(tf_aru_graph.build_aru_pb(w, cfg, activation="Elu")))
 
     def nchw(g, ns):
@@ -213,6 +216,51 @@ def test_refuses_what_it_cannot_map():
         out.name = "probs"
     with pytest.raises(IOError, match="inImg"):
         pb_import.aru_from_nodes(_edit(good, drop_output))
+
+
+@pytest.mark.parametrize("kw", [
+    {"activation_name": "elu"}, {"activation_name": "leaky"}, {"graph": "RU", "activation_name": "leaky", "res_depth": 1},
+    {"graph": "U"}, {"graph": "U", "activation_name": "elu"}, {"graph": "U", "activation_name": "leaky", "scale_space_num": 1},
+    {"graph": "RU", "res_depth": 1},                         # same layer list as 'U': only the wiring tells them apart
+], ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
+def test_graph_variants_are_recognised_from_the_op_graph(kw):
+    """ARU_v1.py:43,70-75 / :92-97,:228-233: activation elu (Elu op) / leaky (layers.leaky_relu's maximum(0, x) + 0.1 minimum(0, x)
+    composite) and the non-residual 'U' graph, written like a TF1 export with hashed scope names: the importer names the variant
+    from ops and wiring alone and returns the weights under the engine's names."""
+    cfg = AruConfig(**{"scale_space_num": 3, "num_scales_att": 2, **kw})
+    w = init_aru_weights(cfg, 17, bias_jitter=0.05)
+    nodes = pb_import.parse_graphdef(tf_aru_graph.build_aru_pb(w, cfg, rename=_hashed))
+    tensors, got = pb_import.aru_from_nodes(nodes)
+    assert got.graph == cfg.graph and got.activation_name == cfg.activation_name
+    assert got.scale_space_num == cfg.scale_space_num and got.use_residual == cfg.use_residual
+    if cfg.use_residual:
+        assert got.res_depth == cfg.res_depth
+    assert list(tensors) == list(w)
+    for k in w:
+        assert np.array_equal(tensors[k], w[k]), k
+
+
+def test_leaky_relu_with_another_slope_is_refused():
+    cfg = AruConfig(graph="RU", scale_space_num=2, activation_name="leaky")
+    w = init_aru_weights(cfg, 3)
+    b = tf_aru_graph.AruGraphBuilder(tp.build_messages(), w, cfg)
+    b.leak = 0.2
+    with pytest.raises(IOError, match="leak 0.2"):
+        pb_import.aru_from_nodes(pb_import.parse_graphdef(b.build()))
+
+
+def test_constants_only_container_carries_the_variant():
+    """names tell 'U' (conv2 instead of convR_<i>); the activation is an asep_meta constant (absent = relu, ARU_v1.py:43)"""
+    cfg = AruConfig(graph="U", activation_name="leaky", scale_space_num=2)
+    w = init_aru_weights(cfg, 5)
+    extra = [{"name": "output", "op": "Softmax", "input": ["inImg"]}]
+    nodes = pb_import.parse_graphdef(pb_import.weights_to_graphdef(w, "graph/", extra, meta={"activation": cfg.activation_code}))
+    tensors, got = pb_import.aru_from_nodes(nodes)
+    assert got.graph == "U" and got.activation_name == "leaky" and list(tensors) == list(w)
+    nodes = pb_import.parse_graphdef(pb_import.weights_to_graphdef(w, "graph/", extra))
+    assert pb_import.aru_from_nodes(nodes)[1].activation_name == "relu"
+    with pytest.raises(IOError, match="asep_meta/activation"):
+        pb_import.aru_from_nodes(pb_import.parse_graphdef(pb_import.weights_to_graphdef(w, "graph/", extra, meta={"activation": 7})))
 
 
 def test_constants_only_container_never_defaults():

@@ -27,6 +27,7 @@ class AruGraphBuilder:
         self.add_op, self.bias_op, self.read_identities = add_op, bias_op, read_identities
         self.enc, self.output_softmax, self.activation = tensor_encoding, output_softmax, activation
         self.nodes, self.uid = [], 0
+        self.leak = 0.1                                     # layers.py:10
 
     # ---- node helpers ------------------------------------------------------------------------------------------
     def add(self, name, op, inputs=(), **attrs):
@@ -99,8 +100,23 @@ class AruGraphBuilder:
                 y = self.add(f"{s}/{tag}bn/mul", "Mul", [y, f"{s}/bn/gamma"], T=F32)
                 y = self.add(f"{s}/{tag}bn/add", self.add_op, [y, f"{s}/bn/shift"], T=F32)
         if act:
-            y = self.add(f"{s}/{tag}activation", self.activation, [y], T=F32)
+            y = self.act(y, f"{s}/{tag}activation")
         return y
+
+    def act(self, y, name):
+        """the graph's activation (ARU_v1.py:70-75) as TF writes it: Relu / Elu ops, or layers.leaky_relu's composite
+        maximum(0, x) + leak * minimum(0, x) (layers.py:10-30).  `activation` != "Relu" (constructor) overrides the op type."""
+        kind = getattr(self.cfg, "activation_name", "relu")
+        if self.activation != "Relu" or kind == "relu":
+            return self.add(name, self.activation, [y], T=F32)
+        if kind == "elu":
+            return self.add(name, "Elu", [y], T=F32)
+        zero = self.const(self.fresh(name + "/zero"), np.array(0.0, np.float32))
+        leak = self.const(self.fresh(name + "/leak"), np.array(self.leak, np.float32))
+        hi = self.add(name + "/Maximum", "Maximum", [zero, y], T=F32)
+        lo = self.add(name + "/Minimum", "Minimum", [zero, y], T=F32)
+        lo = self.add(name + "/Mul", "Mul", [leak, lo], T=F32)
+        return self.add(name + "/add", self.add_op, [hi, lo], T=F32)
 
     def pool(self, x, name, op):
         return self.add(name, op, [x], T=F32, ksize=[1, 2, 2, 1], strides=[1, 2, 2, 1], padding="SAME", data_format="NHWC")
@@ -123,13 +139,16 @@ class AruGraphBuilder:
         return x
 
     def res_block(self, x, scope, tag):
+        if not getattr(self.cfg, "use_residual", True):     # graph 'U' (ARU_v1.py:228-233): conv1 + conv2, both activated
+            return self.conv(self.conv(x, f"{scope}/conv1", tag, act=True), f"{scope}/conv2", tag, act=True)
         R = self.cfg.res_depth
         orig = self.conv(x, f"{scope}/conv1", tag, act=False)
-        x = self.add(self.rename(f"{scope}/{tag}activation"), self.activation, [orig], T=F32)
+        # ARU_v1.py:214: layers.relu, whatever the graph's activation is
+        x = self.add(self.rename(f"{scope}/{tag}activation"), self.activation if self.activation != "Relu" else "Relu", [orig], T=F32)
         for r in range(R):
             x = self.conv(x, f"{scope}/convR_{r}", tag, act=r < R - 1)
         x = self.add(self.rename(f"{scope}/{tag}add"), self.add_op, [x, orig], T=F32)
-        return self.add(self.rename(f"{scope}/{tag}activation_out"), self.activation, [x], T=F32)
+        return self.act(x, self.rename(f"{scope}/{tag}activation_out"))
 
     def det_cnn(self, x, sc):
         tag = f"s{sc}_" if sc else ""
