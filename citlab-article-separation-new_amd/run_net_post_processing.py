@@ -9,6 +9,7 @@ the reference's (``:64-72``) and dealt round-robin to the GPU owners.
 """
 import argparse
 import multiprocessing as mp
+import os
 
 from .path_util import load_list_file
 
@@ -91,15 +92,23 @@ def main(argv=None):
     n_gpus = torch.cuda.device_count()
     if n_gpus <= 0:
         raise _lib.AsepError("no HIP device visible: the MI355X (gfx950) engine has no CPU fallback")
-    n_workers = max(1, min(n_gpus, len(sub_lists)))                 # GPU owners
+    # one GPU-owning process per visible device; ASEP_GPU_OWNERS="0,0,1" names the device of every owner instead (more than one
+    # owner per device, or a subset of the devices -- also how the multi-owner path is tested on a one-GPU box)
+    devices = list(range(n_gpus))
+    if os.environ.get("ASEP_GPU_OWNERS"):
+        devices = [int(x) for x in os.environ["ASEP_GPU_OWNERS"].split(",") if x.strip() != ""]
+        bad = [d for d in devices if not 0 <= d < n_gpus]
+        if bad or not devices:
+            raise _lib.AsepError(f"ASEP_GPU_OWNERS={os.environ['ASEP_GPU_OWNERS']!r}: device ids must be in 0..{n_gpus - 1}")
+    n_workers = max(1, min(len(devices), len(sub_lists)))           # GPU owners
     host_workers = max(1, args.num_processes) // n_workers            # decode / XML workers per owner (<= 1: inline)
     per_worker = [sub_lists[i::n_workers] for i in range(n_workers)]
     if n_workers == 1:
-        _worker(mode, per_worker[0], args.path_to_pb, fixed_height, args.scaling_factor, args.threshold, 0, host_workers)
+        _worker(mode, per_worker[0], args.path_to_pb, fixed_height, args.scaling_factor, args.threshold, devices[0], host_workers)
         return 0
     ctx = mp.get_context("spawn")
     procs = [ctx.Process(target=_worker, args=(mode, per_worker[i], args.path_to_pb, fixed_height,
-                                               args.scaling_factor, args.threshold, i, host_workers))
+                                               args.scaling_factor, args.threshold, devices[i], host_workers))
              for i in range(n_workers)]
     for p in procs:
         p.start()

@@ -199,3 +199,37 @@ def test_host_workers_write_the_same_files_as_the_inline_run(tmp_path, mode):
             f.unlink()
     assert outs[1] == outs[6]
     assert all(("SeparatorRegion" in v) if mode == "separator" else ("TextLine" in v) for v in outs[6].values())
+
+
+def test_two_gpu_owner_processes_write_the_same_files_as_one(tmp_path, monkeypatch):
+    """run_net_post_processing.py:94-110 with more than one GPU owner: the image list is split over spawned
+    owner processes, each with its own model instance and its share of the host workers.  The test box has one GPU, so both
+    owners are put on device 0 (ASEP_GPU_OWNERS); files must equal those of the single-owner run."""
+    import re
+    import shutil
+    from citlab_article_separation_new_amd import run_net_post_processing as cli
+    from citlab_article_separation_new_amd import synth
+    pb, _, data = _setup(tmp_path)
+    names = []
+    for k in range(6):
+        name = f"m{k}"
+        Image.fromarray(synth.synth_page(40 + k, W=600, H=900)).save(data / f"{name}.png")
+        shutil.copy(data / "page" / "p0.xml", data / "page" / f"{name}.xml")
+        names.append(name)
+    lst = tmp_path / "six.lst"
+    lst.write_text("\n".join(str(data / f"{n}.png") for n in names) + "\n")
+    outs = {}
+    for owners in ("0", "0,0"):
+        monkeypatch.setenv("ASEP_GPU_OWNERS", owners)
+        assert cli.main(["--path_to_image_list", str(lst), "--path_to_pb", pb, "--mode", "separator", "--fixed_height", "450",
+                         "--threshold", "0.5", "--num_processes", "4"]) == 0
+        outs[owners] = {}
+        for n in names:
+            f = data / "page" / f"{n}.xml.xml"
+            outs[owners][n] = re.sub(r"<LastChange>[^<]*</LastChange>", "", f.read_text())
+            f.unlink()
+    assert outs["0"] == outs["0,0"] and len(outs["0,0"]) == 6
+    monkeypatch.setenv("ASEP_GPU_OWNERS", "3")
+    from citlab_article_separation_new_amd import _lib
+    with pytest.raises(_lib.AsepError, match="ASEP_GPU_OWNERS"):
+        cli.main(["--path_to_image_list", str(lst), "--path_to_pb", pb, "--mode", "separator", "--num_processes", "2"])
