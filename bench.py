@@ -66,7 +66,7 @@ def parse_args():
                     help="report the roofline block for THIS kernel (scripts/profile_round.sh passes the kernel the un-traced default "
                          "line named, so that the traced line and the rocprofv3 summaries describe the same kernel)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="same as --kernel-timing none")
-    ap.add_argument("--e2e-pages", type=int, default=192,
+    ap.add_argument("--e2e-pages", type=int, default=384,
                     help="scans of the files-in / files-out secondary figure (separator CLI path with host workers; 0 = skip)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements (bf16 variant, heading net + stroke-width fusion, visual GNN)")

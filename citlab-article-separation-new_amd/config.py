@@ -64,6 +64,9 @@ class GnnConfig:
     undirected_graph: bool = True
     # graph_gnn.py:20,102-109: > 0: the (concatenated) node features go through ff_layer(tanh) to this width before the GNN
     compress_node_feature_dim: int = 0
+    # graph_gnn.py:23,158-166: 'hidden', 'add_final_hidden_and_input' (h += x W) or 'concat_final_hidden_and_input' ([h | x]); x = the
+    # node features as fed
+    output_type: str = "hidden"
     # visual branch (GraphRelation image_input); 0 maps -> disabled
     visual_dims: List[int] = field(default_factory=list)   # layer_compressed_dim per feature map
     # feature_map_generation_params from_layer (layer_depth -1): backbone end points, e.g. scale_0_unet_up_2_conv
@@ -88,6 +91,20 @@ class GnnConfig:
                 raise ValueError(f"'{name}' is not a feature-map end point of the ARU_v1 backbone")
             out.append(bc.feat(int(m.group(2))))
         return out
+
+    @property
+    def output_type_code(self) -> int:
+        """asep_gnn_cfg.output_type"""
+        try:
+            return {"hidden": 0, "add_final_hidden_and_input": 1, "concat_final_hidden_and_input": 2}[self.output_type]
+        except KeyError:
+            raise ValueError(f"output_type {self.output_type!r} (graph_gnn.py:23: hidden, add_final_hidden_and_input, "
+                             f"concat_final_hidden_and_input)")
+
+    @property
+    def classifier_node_dim(self) -> int:
+        """width of the node vectors the pair classifier concatenates"""
+        return self.hidden_dim + (self.u_in_dim if self.output_type_code == 2 else 0)
 
     @property
     def u_in_dim(self) -> int:

@@ -52,6 +52,7 @@ struct asep_gnn {
     std::vector<void*> vis_owned;
     std::vector<int> vis_C, vis_d;
     int vis_total = 0;
+    float* Wout = nullptr;                           // output_type 1: GraphLSTM1/dense/weights [Uin, H]
     float* d_u_cat = nullptr;                        // concatenated node features of the last visual forward (own buffer)
     size_t u_cat_cap = 0;
     void free_visual() {
@@ -212,6 +213,7 @@ int forward_impl(asep_gnn* g, int N, int E, const int32_t* d_edges, const float*
     float* x = (float*)g->pool.get((size_t)N * I * 4);
     float* Pt = (float*)g->pool.get((size_t)N * c.cls_hidden1 * 4);
     float* Qt = (float*)g->pool.get((size_t)N * c.cls_hidden1 * 4);
+    const float* d_fed = d_u;                                // node features as fed (output_type add / concat read these)
     if (g->Wc) {                                             // compress_node_feature_dim: the fed features -> tanh(Wc x + bc)
         float* uc = (float*)g->pool.get((size_t)N * g->U * 4);
         hipLaunchKernelGGL(gnn_compress_kernel, dim3(cdiv(N * g->U, 256)), dim3(256), 0, s, d_u, N, g->Uin, g->Wc, g->bc, g->U, uc);
@@ -263,9 +265,18 @@ int forward_impl(asep_gnn* g, int N, int E, const int32_t* d_edges, const float*
         cur ^= 1;
     }
     g->d_h = h[cur];
+    const float* hcls = h[cur];                              // what the pair classifier reads, and its width
+    int Hc = H;
+    if (c.output_type != 0) {                                // graph_gnn.py:158-166
+        Hc = c.output_type == 2 ? H + g->Uin : H;
+        float* y = (float*)g->pool.get((size_t)N * Hc * 4);
+        hipLaunchKernelGGL(gnn_output_type_kernel, dim3(cdiv(N * Hc, 256)), dim3(256), 0, s, h[cur], d_fed, N, H, g->Uin, g->Wout,
+                           c.output_type, y);
+        hcls = y;
+    }
     if (R > 0) {
         hipLaunchKernelGGL(gnn_pair_pre_kernel, dim3(std::min(cdiv(N * c.cls_hidden1, 256), 1024)), dim3(256), 0, s,
-                           h[cur], N, H, g->C1, c.cls_hidden1, Pt, Qt);
+                           hcls, N, Hc, g->C1, c.cls_hidden1, Pt, Qt);
         PairArgs pa{};
         pa.Pt = Pt; pa.Qt = Qt; pa.b1 = g->cb1; pa.W2 = g->C2; pa.b2 = g->cb2; pa.W3 = g->C3; pa.b3 = g->cb3;
         pa.rel = d_rel; pa.out = d_out; pa.N = N; pa.R = R;
@@ -377,7 +388,10 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
         rc = upload_named(g->owned, blob, u + "/" + gates[q] + "_activation/dense/weights", {g->V, H}, &g->Wg[q]);
         if (!rc) rc = upload_named(g->owned, blob, u + "/" + gates[q] + "_activation/dense/bias", {H}, &g->bg[q]);
     }
-    if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_layer_h1/weights", {2 * H, cfg->cls_hidden1}, &g->C1);
+    if (cfg->output_type < 0 || cfg->output_type > 2) { set_error("asep_gnn_load: output_type %d unknown (0 hidden, 1 add, 2 concat)", cfg->output_type); return nullptr; }
+    const int Hc = cfg->output_type == 2 ? H + g->Uin : H;   // width of the node vectors the classifier pairs up
+    if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_layer_h1/weights", {2 * Hc, cfg->cls_hidden1}, &g->C1);
+    if (!rc && cfg->output_type == 1) rc = upload_named(g->owned, blob, "GraphLSTM1/dense/weights", {g->Uin, H}, &g->Wout);
     if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_layer_h1/bias", {cfg->cls_hidden1}, &g->cb1);
     if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_layer_h2/weights", {cfg->cls_hidden1, cfg->cls_hidden2}, &g->C2);
     if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_layer_h2/bias", {cfg->cls_hidden2}, &g->cb2);

@@ -846,6 +846,24 @@ gnn_compress_kernel(const float* __restrict__ x, int N, int K, const float* __re
     y[i] = tanhf(s);
 }
 
+// graph_gnn.py:158-166 output_type: 1 = h[n][d] += sum_k x[n][k] W[k][d] (ff_layer without bias / activation), written to y [N, D];
+// 2 = y[n] = [h[n] | x[n]] (width D + K)
+__global__ void __launch_bounds__(256)
+gnn_output_type_kernel(const float* __restrict__ h, const float* __restrict__ x, int N, int D, int K, const float* __restrict__ W,
+                       int mode, float* __restrict__ y) {
+    const int wid = mode == 1 ? D : D + K;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * wid) return;
+    const int n = i / wid, d = i - n * wid;
+    if (mode == 1) {
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s = fmaf(x[(size_t)n * K + k], W[(size_t)k * D + d], s);
+        y[i] = h[(size_t)n * D + d] + s;
+    } else {
+        y[i] = d < D ? h[(size_t)n * D + d] : x[(size_t)n * K + d - D];
+    }
+}
+
 // copies the geometric node features into the first `ug` columns of the concatenated node feature matrix
 __global__ void __launch_bounds__(256)
 gnn_copy_cols_kernel(const float* __restrict__ src, int N, int ug, float* __restrict__ dst, int ustride) {

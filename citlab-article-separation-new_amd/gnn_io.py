@@ -57,7 +57,7 @@ class GnnGraph:
             cfg = _lib.GnnCfg(c.u_dim, c.edge_feature_dim, c.num_transition_steps, c.hidden_dim,
                               c.interaction_dim, c.interaction_hidden[0], c.classifier_hidden[0],
                               c.classifier_hidden[1], c.num_classes, int(c.undirected_graph),
-                              c.u_in_dim if c.compress_node_feature_dim > 0 else 0)
+                              c.u_in_dim if c.compress_node_feature_dim > 0 else 0, c.output_type_code)
             blob = self.blob()
             h = lib.asep_gnn_load(blob, len(blob), C.byref(cfg))
             if not h:

@@ -254,5 +254,7 @@ def pin_callbacks(device=0):
 
 
 def host_workers_default():
-    """host workers per GPU owner when the CLI does not say: enough to hide a ~110 ms decode behind a ~10 ms GPU stage"""
-    return max(1, min(12, (os.cpu_count() or 2) // 2))
+    """host workers per GPU owner when the caller does not say: enough to hide a ~110 ms PNG decode (+ the PAGE-XML write) behind
+    a ~9 ms GPU stage -- 12 workers feed 70 pages/s, 24 feed 84 (768 scans of 3000 x 4500, profiles/README r3) -- and few enough
+    that eight owners fit a 256-CPU box"""
+    return max(1, min(24, (os.cpu_count() or 2) // 4))

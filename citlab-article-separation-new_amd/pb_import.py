@@ -849,7 +849,7 @@ def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None, num_transit
       num_transition_steps (graph_gnn.py:19)        = number of MatMul ops on the edge MLP's first layer; a constants-only
                                                       container carries it as ``asep_meta/num_transition_steps`` or takes the argument
       compress_node_feature_dim (graph_gnn.py:20)   = GraphLSTM1/compress_input/ff_compress_input/weights present -> served
-      output_type add / concat (graph_gnn.py:23)    = GraphLSTM1/dense/weights present, or a classifier input wider than 2 x hidden -> refused
+      output_type add / concat (graph_gnn.py:23)    = GraphLSTM1/dense/weights present / a classifier input of 2 x (hidden + fed width) -> served
       use_attention / heads (message_fn_chunk.py:35-41) = .../calculation_unnormalized_attention_values/... or .../head_1/... -> refused
     """
     consts = const_tensors(nodes)
@@ -865,9 +865,7 @@ def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None, num_transit
     if any("calculation_unnormalized_attention_values" in k for k in consts):
         raise IOError("the graph aggregates with learned attention (message_fn_chunk.py:35,203-216 use_attention=True): not "
                       "supported, the engine implements the degree-normalised sum of the reference's default")
-    if _find(consts, "GraphLSTM1/dense/weights") is not None:
-        raise IOError("the graph adds a projection of the input features to the final hidden state (graph_gnn.py:160-163 "
-                      "output_type='add_final_hidden_and_input'): not supported")
+    w_add = _find(consts, "GraphLSTM1/dense/weights")       # graph_gnn.py:160-163 output_type='add_final_hidden_and_input'
     hidden = int(wu.shape[1])
     w2 = _find(consts, pref + "/fully_connected_logit_layer_out/weights")
     inter = int(w2.shape[1]) if w2 is not None else hidden
@@ -887,11 +885,17 @@ def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None, num_transit
     first = wc1 if wc1 is not None else wo
     if first is None:
         raise IOError("no classifier (Classification/logits/...) among the graph constants")
-    if int(first.shape[0]) != 2 * hidden:
-        how = ("graph_gnn.py:164-166 output_type='concat_final_hidden_and_input'" if int(first.shape[0]) == 2 * (hidden + u_in)
-               else "unknown layout")
-        raise IOError(f"the pair classifier reads {first.shape[0]} features per pair, 2 x hidden = {2 * hidden} expected ({how}): "
-                      "not supported")
+    output_type = "hidden"
+    if w_add is not None:
+        if tuple(w_add.shape) != (u_in, hidden):
+            raise IOError(f"GraphLSTM1/dense/weights is {tuple(w_add.shape)}, output_type='add_final_hidden_and_input' "
+                          f"(graph_gnn.py:160-163) projects the {u_in} fed features to {hidden}")
+        output_type = "add_final_hidden_and_input"
+    if int(first.shape[0]) == 2 * (hidden + u_in) and u_in > 0 and w_add is None:
+        output_type = "concat_final_hidden_and_input"       # graph_gnn.py:164-166: the classifier pairs up [h | x]
+    elif int(first.shape[0]) != 2 * hidden:
+        raise IOError(f"the pair classifier reads {first.shape[0]} features per pair; 2 x hidden = {2 * hidden} or, with "
+                      f"output_type='concat_final_hidden_and_input', 2 x (hidden + {u_in}) expected")
     # ---- number of transition steps: from the op graph, the container's metadata or the caller
     steps_graph = _count_matmul_users(nodes, _find_key(consts, pref + "/fully_connected_layer_h1/weights"))
     meta = _find(consts, "asep_meta/num_transition_steps")
@@ -943,7 +947,7 @@ def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None, num_transit
                     interaction_dim=inter,
                     interaction_hidden=[int(w1.shape[1])], classifier_hidden=cls_hidden,
                     num_classes=int(wo.shape[1]), undirected_graph=undirected_graph, compress_node_feature_dim=compress,
-                    **vis_kw)
+                    output_type=output_type, **vis_kw)
     if vis_kw and cfg.visual_channels() != chans:
         raise IOError(f"visual_layers {cfg.visual_layers} have {cfg.visual_channels()} channels, the compression "
                       f"layers expect {chans}")

@@ -100,7 +100,9 @@ def gnn_tensor_shapes(cfg: GnnConfig) -> "OrderedDict[str, tuple]":
     for g in GATES:                                                 # update_fn_lstm.py:55-66
         shapes[f"{_UPD}/{g}_activation/dense/weights"] = (cfg.update_in_dim, cfg.hidden_dim)
         shapes[f"{_UPD}/{g}_activation/dense/bias"] = (cfg.hidden_dim,)
-    d_in = 2 * cfg.hidden_dim                                       # graph_relation.py:253-266
+    if cfg.output_type_code == 1:                                   # graph_gnn.py:160-163: ff_layer(no bias) under the GNN's scope
+        shapes["GraphLSTM1/dense/weights"] = (cfg.u_in_dim, cfg.hidden_dim)
+    d_in = 2 * cfg.classifier_node_dim                               # graph_relation.py:253-266 (graph_gnn.py:164-166: [h | x])
     for i, h in enumerate(cfg.classifier_hidden, start=1):
         shapes[f"{_CLS}/fully_connected_layer_h{i}/weights"] = (d_in, h)
         shapes[f"{_CLS}/fully_connected_layer_h{i}/bias"] = (h,)

@@ -132,6 +132,10 @@ typedef struct asep_gnn_cfg {
     int32_t compress_input_dim;    /* graph_gnn.py:20,102-109 compress_node_feature_dim: 0 = off; > 0: node features are FED with this
                                       width and go through tanh(W x + b) (GraphLSTM1/compress_input/ff_compress_input/{weights,bias})
                                       to node_feature_dim before the message passing */
+    int32_t output_type;           /* graph_gnn.py:23,158-166: 0 = 'hidden' (the classifier reads the final hidden states), 1 =
+                                      'add_final_hidden_and_input' (h += x W, GraphLSTM1/dense/weights [fed width, hidden], no bias), 2 =
+                                      'concat_final_hidden_and_input' (the classifier reads [h | x]: its first layer has 2 (hidden + fed
+                                      width) rows); x = the node features AS FED (before compress_input) */
 } asep_gnn_cfg;
 
 typedef struct asep_gnn asep_gnn;

@@ -74,6 +74,7 @@ def forward(num_nodes, edges, node_feat, edge_feat, relations, w, cfg, dtype=np.
     N = int(num_nodes)
     w = {k: v.astype(dtype) for k, v in w.items()}
     u = np.asarray(node_feat, dtype=dtype).reshape(N, -1)
+    fed = u                                                          # inputs['node_features'] (graph_gnn.py:158-166 reads these)
     if getattr(cfg, "compress_node_feature_dim", 0) > 0:            # graph_gnn.py:102-109: ff_layer(tanh) on the fed features
         u = np.tanh(u @ w["GraphLSTM1/compress_input/ff_compress_input/weights"]
                     + w["GraphLSTM1/compress_input/ff_compress_input/bias"]).astype(dtype)
@@ -105,8 +106,16 @@ def forward(num_nodes, edges, node_feat, edge_feat, relations, w, cfg, dtype=np.
         g_g = np.tanh(gate["cellinput"])
         c = f_g * c + i_g * g_g                                      # update_fn_lstm.py:74-76
         h = o_g * np.tanh(c)
+    out_type = getattr(cfg, "output_type", "hidden")
+    hc = h
+    if out_type == "add_final_hidden_and_input":                     # graph_gnn.py:160-163: out += ff_layer(x, no bias, no activation)
+        hc = (h + fed @ w["GraphLSTM1/dense/weights"]).astype(dtype)
+    elif out_type == "concat_final_hidden_and_input":                # graph_gnn.py:164-166
+        hc = np.concatenate([h, fed], axis=1)
+    elif out_type != "hidden":
+        raise ValueError(f"output_type {out_type!r}")
     rel = build_full_relations(N) if relations is None else np.asarray(relations, dtype=np.int64).reshape(-1, 2)
-    feat = np.concatenate([h[rel[:, 0]], h[rel[:, 1]]], axis=1)
+    feat = np.concatenate([hc[rel[:, 0]], hc[rel[:, 1]]], axis=1)
     for i in range(1, len(cfg.classifier_hidden) + 1):
         feat = np.maximum(feat @ w[f"{CLS}/fully_connected_layer_h{i}/weights"]
                           + w[f"{CLS}/fully_connected_layer_h{i}/bias"], 0)

@@ -142,6 +142,12 @@ def test_permutation_equivariance():
     (dict(hidden_dim=16, interaction_dim=24, interaction_hidden=[40]), "generic"),
     (dict(hidden_dim=48, interaction_dim=32, interaction_hidden=[32], edge_feature_dim=5), "generic"),
     (dict(classifier_hidden=[48, 20], num_classes=3), "mfma_registers"),      # generic pair classifier
+    # graph_gnn.py:23,158-166 output_type: h += x W / the classifier pairs up [h | x]
+    (dict(output_type="add_final_hidden_and_input"), "mfma_registers"),
+    (dict(output_type="concat_final_hidden_and_input"), "mfma_registers"),
+    (dict(output_type="concat_final_hidden_and_input", node_feature_dim=15, compress_node_feature_dim=6, hidden_dim=24,
+          interaction_dim=20, interaction_hidden=[28]), "generic"),            # x = the features as FED, before compress_input
+    (dict(output_type="add_final_hidden_and_input", node_feature_dim=20, classifier_hidden=[40, 12]), "mfma_lds"),
 ])
 def test_hyper_parameters_other_than_the_defaults(kw, mode):
     """message_fn_chunk.py:13-40, trainer_rel.py:15-17: every width is a free parameter of the reference; the engine picks

@@ -63,3 +63,32 @@ def test_permutation_equivariance_of_the_oracle():
     inv = np.argsort(perm)
     p1 = G.forward(N, inv[edges], u[perm], ef, None, w, cfg, dtype=np.float64)[:, 1].reshape(N, N)
     assert np.abs(p1 - p0[np.ix_(perm, perm)]).max() < 1e-12
+
+
+def test_output_types_on_a_hand_case():
+    """graph_gnn.py:158-166: 'add' = h + x W (no bias), 'concat' = [h | x]; with zero classifier weights on the h part the
+    probabilities depend on x alone and can be computed by hand"""
+    from citlab_article_separation_new_amd.config import GnnConfig
+    from citlab_article_separation_new_amd.weights import init_gnn_weights
+    from oracle import gnn_oracle as G
+    N = 3
+    edges = np.array([[0, 1], [1, 2]], np.int32)
+    u = np.array([[1.0, 0, 0, 0, 0, 0, 0], [0, 2.0, 0, 0, 0, 0, 0], [0, 0, 3.0, 0, 0, 0, 0]], np.float32)
+    ef = np.zeros((2, 2), np.float32)
+    cfg = GnnConfig(output_type="concat_final_hidden_and_input", classifier_hidden=[], num_classes=2)
+    w = init_gnn_weights(cfg, 1)
+    H, U = cfg.hidden_dim, 7
+    wo = np.zeros((2 * (H + U), 2), np.float32)
+    wo[H + 0, 1] = 1.0                                       # class-1 logit = x_a[0] (feature 0 of the first node of the pair)
+    w["Classification/logits/fully_connected_logit_layer_out/weights"] = wo
+    w["Classification/logits/fully_connected_logit_layer_out/bias"] = np.zeros(2, np.float32)
+    p = G.forward(N, edges, u, ef, None, w, cfg).reshape(N, N, 2)
+    assert np.allclose(p[0, :, 1], 1 / (1 + np.exp(-1.0)), atol=1e-6) and np.allclose(p[1:, :, 1], 0.5, atol=1e-6)
+    cfg = GnnConfig(output_type="add_final_hidden_and_input", classifier_hidden=[], num_classes=2)
+    w = init_gnn_weights(cfg, 1)
+    assert w["GraphLSTM1/dense/weights"].shape == (U, H)
+    p0, h = G.forward(N, edges, u, ef, None, w, cfg, return_hidden=True)
+    w2 = dict(w); w2["GraphLSTM1/dense/weights"] = np.zeros((U, H), np.float32)
+    p1 = G.forward(N, edges, u, ef, None, w2, GnnConfig(classifier_hidden=[], num_classes=2))
+    p2 = G.forward(N, edges, u, ef, None, w2, cfg)
+    assert np.array_equal(p1, p2) and np.abs(p0 - p1).max() > 1e-4      # a zero projection is the plain output; a random one is not

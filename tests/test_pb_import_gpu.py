@@ -68,6 +68,30 @@ def test_foreign_frozen_graph_of_an_aru_variant_loads_and_matches_oracle(tmp_pat
     graph.close()
 
 
+@pytest.mark.parametrize("output_type", ["add_final_hidden_and_input", "concat_final_hidden_and_input"])
+def test_relation_net_output_type_read_from_the_graph_matches_the_oracle(tmp_path, output_type):
+    """graph_gnn.py:23,158-166: output_type add / concat of a TF1-layout export load without a hint and give the oracle's
+    probabilities"""
+    import tf_gnn_graph
+    import tf_graphdef_proto as tp
+    from citlab_article_separation_new_amd import gnn_io, synth
+    from citlab_article_separation_new_amd.config import GnnConfig
+    from citlab_article_separation_new_amd.weights import init_gnn_weights
+    from oracle import gnn_oracle
+    src = GnnConfig(output_type=output_type)
+    w = init_gnn_weights(src, 19, bias_jitter=0.05)
+    pb = tmp_path / "rel_out.pb"
+    pb.write_bytes(tf_gnn_graph.build(tp.build_messages(), w, 3).SerializeToString())
+    graph = gnn_io.load_graph(str(pb))
+    assert graph.cfg.output_type == output_type
+    N = 40
+    g = synth.synth_graph(3, N=N, n_pairs=150, node_dim=7)
+    probs = gnn_io.gnn_forward(graph, N, g["interacting_nodes"], g["node_features"], g["edge_features"])
+    ref = gnn_oracle.forward(N, g["interacting_nodes"], g["node_features"], g["edge_features"], None, w, src)
+    assert float(np.abs(probs - ref).max()) <= 1e-5
+    graph.close()
+
+
 @pytest.mark.parametrize("steps,compress", [(2, 0), (4, 0), (2, 6)])
 def test_relation_net_options_read_from_the_op_graph_match_the_oracle(tmp_path, steps, compress):
     """a GraphDef laid out like a TF1 export (tests/tf_gnn_graph.py, serialised by google.protobuf) with a

@@ -323,16 +323,31 @@ def test_gnn_options_the_engine_does_not_serve_are_refused_with_the_reason():
     nodes, _ = _gnn_nodes(GnnConfig(), 3, extra={head1: np.zeros((158, 32))})
     with pytest.raises(IOError, match="attention heads"):
         pb_import.gnn_from_nodes(nodes)
-    nodes, _ = _gnn_nodes(GnnConfig(), 3, extra={"GraphLSTM1/dense/weights": np.zeros((7, 32))})
+    # a projection of the wrong shape under the add-output's name
+    nodes, _ = _gnn_nodes(GnnConfig(), 3, extra={"GraphLSTM1/dense/weights": np.zeros((9, 32))})
     with pytest.raises(IOError, match="add_final_hidden_and_input"):
         pb_import.gnn_from_nodes(nodes)
-    # output_type concat: the pair classifier reads 2 x (hidden + u) features
+    # a classifier that reads neither 2 x hidden nor 2 x (hidden + fed width)
     nodes, w = _gnn_nodes(GnnConfig(), 3)
     for n in nodes:
         if n["name"].endswith("Classification/logits/fully_connected_layer_h1/weights"):
-            n["value"] = np.zeros((2 * (32 + 7), 64), np.float32)
-    with pytest.raises(IOError, match="concat_final_hidden_and_input"):
+            n["value"] = np.zeros((2 * (32 + 5), 64), np.float32)
+    with pytest.raises(IOError, match="pair classifier reads"):
         pb_import.gnn_from_nodes(nodes)
+
+
+@pytest.mark.parametrize("output_type", ["add_final_hidden_and_input", "concat_final_hidden_and_input"])
+def test_gnn_output_type_is_read_from_the_constants(output_type):
+    """graph_gnn.py:23,158-166: 'add' leaves GraphLSTM1/dense/weights [fed width, hidden] (no bias) in the graph, 'concat' a pair
+    classifier whose first layer has 2 x (hidden + fed width) rows"""
+    from citlab_article_separation_new_amd.config import GnnConfig
+    src = GnnConfig(output_type=output_type, num_transition_steps=2)
+    nodes, w = _gnn_nodes(src, 2)
+    tensors, cfg = pb_import.gnn_from_nodes(nodes)
+    assert cfg.output_type == output_type and cfg.num_transition_steps == 2
+    assert list(tensors) == list(w) and all(np.array_equal(tensors[k], w[k]) for k in w)
+    assert ("GraphLSTM1/dense/weights" in tensors) == (output_type.startswith("add"))
+    assert tensors["Classification/logits/fully_connected_layer_h1/weights"].shape[0] == 2 * cfg.classifier_node_dim
 
 
 def test_gnn_constants_only_container_needs_the_step_count():

@@ -62,6 +62,11 @@ def build(ns, weights, num_transition_steps, prefix="graph/", extra_consts=None)
                                                           var(f"{UPD}/{g}_activation/dense/bias")], T=F32))
         h = add(prefix + f"{UPD}{sfx}/mul_2", "Mul", gates[:2], T=F32)
     x = h
+    if "GraphLSTM1/dense/weights" in weights:                 # graph_gnn.py:160-163 output_type='add_final_hidden_and_input'
+        s = prefix + "GraphLSTM1/dense"
+        x = add(prefix + "GraphLSTM1/add", "Add", [h, add(s + "/Wx", "MatMul", ["node_features", var("GraphLSTM1/dense/weights")], T=F32)], T=F32)
+    elif weights[f"{CLS}/fully_connected_layer_h1/weights"].shape[0] != 2 * weights[f"{UPD}/ingate_activation/dense/weights"].shape[1]:
+        x = add(prefix + "GraphLSTM1/concat", "ConcatV2", [h, "node_features"], T=F32, N=2)     # graph_gnn.py:164-166
     i = 1
     while f"{CLS}/fully_connected_layer_h{i}/weights" in weights:
         s = prefix + f"{CLS}/fully_connected_layer_h{i}"
