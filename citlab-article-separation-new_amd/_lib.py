@@ -24,7 +24,7 @@ class AruCfg(C.Structure):
 class GnnCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "node_feature_dim", "edge_feature_dim", "num_transition_steps", "hidden_dim", "interaction_dim",
-        "interaction_hidden", "cls_hidden1", "cls_hidden2", "num_classes", "undirected_graph", "compress_input_dim", "output_type")]
+        "interaction_hidden", "cls_hidden1", "cls_hidden2", "num_classes", "undirected_graph", "compress_input_dim", "output_type", "attention_heads", "attention_merge", "attention_hidden")]
 
 
 class GnnPage(C.Structure):

@@ -67,6 +67,11 @@ class GnnConfig:
     # graph_gnn.py:23,158-166: 'hidden', 'add_final_hidden_and_input' (h += x W) or 'concat_final_hidden_and_input' ([h | x]); x = the
     # node features as fed
     output_type: str = "hidden"
+    # message_fn_chunk.py:35-41: learned attention over the in-edges instead of the degree-normalised sum (the default, False)
+    use_attention: bool = False
+    num_attention_heads: int = 1
+    multihead_attention_merge_type: str = "concat"        # 'concat' (x_dim = interaction_dim // heads) or 'average'
+    attention_hidden: List[int] = field(default_factory=lambda: [16])   # num_hidden_units_attention_fct
     # visual branch (GraphRelation image_input); 0 maps -> disabled
     visual_dims: List[int] = field(default_factory=list)   # layer_compressed_dim per feature map
     # feature_map_generation_params from_layer (layer_depth -1): backbone end points, e.g. scale_0_unet_up_2_conv
@@ -91,6 +96,18 @@ class GnnConfig:
                 raise ValueError(f"'{name}' is not a feature-map end point of the ARU_v1 backbone")
             out.append(bc.feat(int(m.group(2))))
         return out
+
+    @property
+    def heads(self) -> int:
+        """message_fn_chunk.py:167-169: one head without attention"""
+        return self.num_attention_heads if self.use_attention else 1
+
+    @property
+    def head_interaction_dim(self) -> int:
+        """message_fn_chunk.py:68-72: x_dim of one head"""
+        if self.use_attention and self.multihead_attention_merge_type == "concat":
+            return self.interaction_dim // self.num_attention_heads
+        return self.interaction_dim
 
     @property
     def output_type_code(self) -> int:
@@ -122,7 +139,14 @@ class GnnConfig:
 
     @property
     def update_in_dim(self) -> int:
-        return self.interaction_dim + self.hidden_dim + self.u_dim
+        return self.message_out_dim + self.hidden_dim + self.u_dim
+
+    @property
+    def message_out_dim(self) -> int:
+        """width of x (message_fn_chunk.py:229-241): heads * x_dim for 'concat', x_dim for 'average' / no attention"""
+        if self.use_attention and self.multihead_attention_merge_type == "concat":
+            return self.heads * self.head_interaction_dim
+        return self.interaction_dim
 
     def to_dict(self):
         return asdict(self)

@@ -53,6 +53,8 @@ struct asep_gnn {
     std::vector<int> vis_C, vis_d;
     int vis_total = 0;
     float* Wout = nullptr;                           // output_type 1: GraphLSTM1/dense/weights [Uin, H]
+    AttHeadW att_w[GNN_MAX_HEADS] = {};              // attention_heads > 0: per-head interaction + attention MLPs
+    int att_xd = 0;                                  // interaction width per head
     float* d_u_cat = nullptr;                        // concatenated node features of the last visual forward (own buffer)
     size_t u_cat_cap = 0;
     void free_visual() {
@@ -219,6 +221,23 @@ int forward_impl(asep_gnn* g, int N, int E, const int32_t* d_edges, const float*
         hipLaunchKernelGGL(gnn_compress_kernel, dim3(cdiv(N * g->U, 256)), dim3(256), 0, s, d_u, N, g->Uin, g->Wc, g->bc, g->U, uc);
         d_u = uc;
     }
+    // attention-weighted aggregation: edge index of every csr entry + per-edge interaction features / attention values
+    int* att_eidx = nullptr;
+    float *att_M = nullptr, *att_A = nullptr, *att_S = nullptr;
+    const size_t att_maxE = (size_t)(c.undirected_graph ? 2 : 1) * std::max(E, 1);
+    if (c.attention_heads > 0) {
+        if ((size_t)N * N > 100000) {
+            set_error("asep_gnn_forward: attention-weighted aggregation on %d nodes: the reference splits the interactions into chunks of "
+                      "100000 / N target nodes (message_fn_chunk.py:77-78) and pairs attention values within a chunk; only the one-chunk "
+                      "case (N <= 316) is implemented", N);
+            return ASEP_ERR_UNSUPPORTED;
+        }
+        att_eidx = (int*)g->pool.get(att_maxE * sizeof(int));
+        att_M = (float*)g->pool.get(att_maxE * c.attention_heads * g->att_xd * sizeof(float));
+        att_A = (float*)g->pool.get(att_maxE * c.attention_heads * sizeof(float));
+        att_S = (float*)g->pool.get(att_maxE * c.attention_heads * sizeof(float));
+        hipLaunchKernelGGL(edge_rank_kernel, dim3(N), dim3(64), 0, s, eb.colptr, eb.tsrc, eb.rowptr, eb.sorted, N, att_eidx);
+    }
     float* upad = nullptr;
     const int mode = g->use_step ? g->mode : STEP_GENERIC;
     if (mode == STEP_BIG) {
@@ -249,6 +268,23 @@ int forward_impl(asep_gnn* g, int N, int E, const int32_t* d_edges, const float*
             sa.N = N; sa.U = g->U; sa.Upad = g->Upad; sa.Ed = g->Ed; sa.E = std::max(E, 1); sa.nch = g->nch;
             sa.qdesc = g->qdesc;
             hipLaunchKernelGGL(gnn_step_big_kernel, dim3(N), dim3(256), g->big_lds, s, sa);
+        } else if (c.attention_heads > 0) {
+            MsgAttArgs aa{};
+            aa.u = d_u; aa.h = h[cur]; aa.ef = d_ef; aa.tptr = eb.colptr; aa.tsrc = eb.tsrc; aa.tfirst = eb.tfirst; aa.eidx = att_eidx;
+            for (int k = 0; k < c.attention_heads; ++k) aa.hd[k] = g->att_w[k];
+            aa.M = att_M; aa.A = att_A;
+            aa.N = N; aa.U = g->U; aa.Ed = g->Ed; aa.E = std::max(E, 1); aa.H = H; aa.Hm = g->Hm; aa.Ha = c.attention_hidden;
+            aa.xd = g->att_xd; aa.heads = c.attention_heads; aa.Etot = (int)att_maxE;
+            const size_t lds = ((size_t)g->K + std::max(g->Hm, c.attention_hidden)) * sizeof(float);
+            hipLaunchKernelGGL(gnn_msg_att_kernel, dim3(N), dim3(256), lds, s, aa);
+            hipLaunchKernelGGL(gnn_att_softmax_kernel, dim3(N), dim3(64), 0, s, eb.colptr, att_eidx, att_A, c.attention_heads, (int)att_maxE, att_S);
+            hipLaunchKernelGGL(gnn_att_aggregate_kernel, dim3(N), dim3(64), 0, s, eb.colptr, att_eidx, att_S, att_M, c.attention_heads,
+                               g->att_xd, (int)att_maxE, c.attention_merge, x);
+            LstmGenArgs la{};
+            la.x = x; la.h_in = h[cur]; la.c_in = cs[cur]; la.u = d_u;
+            for (int q = 0; q < 4; ++q) { la.Wg[q] = g->Wg[q]; la.bg[q] = g->bg[q]; }
+            la.h_out = h[cur ^ 1]; la.c_out = cs[cur ^ 1]; la.N = N; la.U = g->U; la.H = H; la.I = I;
+            hipLaunchKernelGGL(gnn_lstm_generic_kernel, dim3(cdiv(N * H, 256)), dim3(256), 0, s, la);
         } else {
             MsgGenArgs ma{};
             ma.u = d_u; ma.h = h[cur]; ma.ef = d_ef; ma.tptr = eb.colptr; ma.tsrc = eb.tsrc; ma.tfirst = eb.tfirst;
@@ -379,10 +415,41 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
     g->Uin = cfg->compress_input_dim > 0 ? cfg->compress_input_dim : U;
     if (((size_t)g->K + Hm + I) * sizeof(float) > 60 * 1024) { set_error("asep_gnn_load: edge-MLP input width %d too large", g->K); return nullptr; }
     const std::string m = MSG, u = UPD, c = CLS;
-    int rc = upload_named(g->owned, blob, m + "/fully_connected_layer_h1/weights", {g->K, Hm}, &g->W1);
-    if (!rc) rc = upload_named(g->owned, blob, m + "/fully_connected_layer_h1/bias", {Hm}, &g->b1);
-    if (!rc) rc = upload_named(g->owned, blob, m + "/fully_connected_logit_layer_out/weights", {Hm, I}, &g->W2);
-    if (!rc) rc = upload_named(g->owned, blob, m + "/fully_connected_logit_layer_out/bias", {I}, &g->b2);
+    const int heads = cfg->attention_heads;
+    int rc = ASEP_OK;
+    if (heads < 0 || heads > GNN_MAX_HEADS || (heads > 0 && (cfg->attention_hidden < 1 || (cfg->attention_merge != 0 && cfg->attention_merge != 1)))) {
+        set_error("asep_gnn_load: bad attention configuration (heads %d of at most %d, hidden %d, merge %d)", heads, GNN_MAX_HEADS,
+                  cfg->attention_hidden, cfg->attention_merge);
+        return nullptr;
+    }
+    if (heads > 0) {
+        // message_fn_chunk.py:69-72: x_dim = interaction_dim // heads for 'concat' (the LSTM then reads heads * x_dim columns)
+        if (cfg->attention_merge == 0 && I % heads != 0) {
+            set_error("asep_gnn_load: interaction_dim %d is not a multiple of %d attention heads (merge 'concat')", I, heads);
+            return nullptr;
+        }
+        g->att_xd = cfg->attention_merge == 0 ? I / heads : I;
+        for (int k = 0; k < heads && !rc; ++k) {
+            const std::string hk = "GraphLSTM1/message_fn_default/head_" + std::to_string(k) + "/";
+            const std::string mi = hk + "calculation_interaction_features/concat_u_and_h/interaction_features";
+            const std::string ma = hk + "calculation_unnormalized_attention_values/calculation_interaction_features/concat_u_and_h/interaction_features";
+            float* p[8] = {};
+            rc = upload_named(g->owned, blob, mi + "/fully_connected_layer_h1/weights", {g->K, Hm}, &p[0]);
+            if (!rc) rc = upload_named(g->owned, blob, mi + "/fully_connected_layer_h1/bias", {Hm}, &p[1]);
+            if (!rc) rc = upload_named(g->owned, blob, mi + "/fully_connected_logit_layer_out/weights", {Hm, g->att_xd}, &p[2]);
+            if (!rc) rc = upload_named(g->owned, blob, mi + "/fully_connected_logit_layer_out/bias", {g->att_xd}, &p[3]);
+            if (!rc) rc = upload_named(g->owned, blob, ma + "/fully_connected_layer_h1/weights", {g->K, cfg->attention_hidden}, &p[4]);
+            if (!rc) rc = upload_named(g->owned, blob, ma + "/fully_connected_layer_h1/bias", {cfg->attention_hidden}, &p[5]);
+            if (!rc) rc = upload_named(g->owned, blob, ma + "/fully_connected_logit_layer_out/weights", {cfg->attention_hidden, 1}, &p[6]);
+            if (!rc) rc = upload_named(g->owned, blob, ma + "/fully_connected_logit_layer_out/bias", {1}, &p[7]);
+            g->att_w[k] = AttHeadW{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]};
+        }
+    } else {
+        rc = upload_named(g->owned, blob, m + "/fully_connected_layer_h1/weights", {g->K, Hm}, &g->W1);
+        if (!rc) rc = upload_named(g->owned, blob, m + "/fully_connected_layer_h1/bias", {Hm}, &g->b1);
+        if (!rc) rc = upload_named(g->owned, blob, m + "/fully_connected_logit_layer_out/weights", {Hm, I}, &g->W2);
+        if (!rc) rc = upload_named(g->owned, blob, m + "/fully_connected_logit_layer_out/bias", {I}, &g->b2);
+    }
     const char* gates[4] = {"ingate", "outgate", "forgetgate", "cellinput"};
     for (int q = 0; q < 4 && !rc; ++q) {
         rc = upload_named(g->owned, blob, u + "/" + gates[q] + "_activation/dense/weights", {g->V, H}, &g->Wg[q]);
@@ -405,7 +472,7 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
     for (auto& kv : blob)
         if (kv.first.rfind("visual_node_feature_compression_fm_", 0) == 0) g->vis_blob[kv.first] = kv.second;
     if (const char* ev = getenv("ASEP_GNN_STEP")) g->use_step = atoi(ev) != 0;
-    const bool default_widths = H == GNN_H && I == GNN_H && Hm == GNN_H;
+    const bool default_widths = H == GNN_H && I == GNN_H && Hm == GNN_H && heads == 0;
     g->mode = STEP_GENERIC;
     if (default_widths && Ed <= 4) {
         if (U <= 8) {

@@ -561,6 +561,137 @@ __global__ __launch_bounds__(256) void gnn_message_generic_kernel(const MsgGenAr
     for (int o = tid; o < a.I; o += 256) a.x[(size_t)tgt * a.I + o] = deg > 0 ? acc[o] / (float)deg : 0.f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Attention-weighted aggregation (message_fn_chunk.py:35-41,167-245,420-454; use_attention = True): per head k an interaction MLP
+// (tanh output, x_dim = interaction_dim / heads for 'concat', interaction_dim for 'average') and an attention MLP (one output, no
+// output activation) over the same z; the unnormalised values are put into a sparse [from, to] tensor, TRANSPOSED, soft-maxed
+// over its rows (= over the in-edges of a target) and read back with `.values` -- i.e. in (to, from) order -- and multiplied
+// element by element with the interaction features, which are in (from, to) order: interaction e gets the e-th soft-max value of
+// the (to, from)-sorted list.  That pairing is restated literally here (for an undirected graph it is the attention of the
+// REVERSE edge): csr position p <-> (to, from) order, edge index e <-> (from, to) order, eidx[p] = the edge at csr position p.
+// Three launches per transition step, one workgroup per target node, plain FMA loops (these nets are the exception).
+// ------------------------------------------------------------------------------------------------
+// eidx[p] of csr entry p = (tsrc[p] -> t): binary search of t in row tsrc[p] of the (from, to)-sorted list
+__global__ __launch_bounds__(64) void edge_rank_kernel(const int* __restrict__ colptr, const int* __restrict__ tsrc, const int* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ sorted_edges, int N, int* __restrict__ eidx) {
+    const int t = blockIdx.x;
+    for (int p = colptr[t] + threadIdx.x; p < colptr[t + 1]; p += 64) {
+        const int s = tsrc[p];
+        int lo = rowptr[s], hi = rowptr[s + 1] - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sorted_edges[2 * mid + 1] < t) lo = mid + 1; else hi = mid;
+        }
+        eidx[p] = lo;
+    }
+}
+
+constexpr int GNN_MAX_HEADS = 8;
+struct AttHeadW { const float *W1, *b1, *W2, *b2, *A1, *ab1, *A2, *ab2; };
+struct MsgAttArgs {
+    const float* u; const float* h; const float* ef;
+    const int* tptr; const int* tsrc; const int* tfirst; const int* eidx;
+    AttHeadW hd[GNN_MAX_HEADS];
+    float* M;            // [E', heads * xd] interaction features by edge index e
+    float* A;            // [heads][E'] unnormalised attention values by edge index e
+    int N, U, Ed, E, H, Hm, Ha, xd, heads, Etot;
+};
+// per target t, per in-edge p: z, then for every head m = tanh(MLP_int(z)) -> M[eidx[p]], a = MLP_att(z) -> A[head][eidx[p]]
+__global__ __launch_bounds__(256) void gnn_msg_att_kernel(const MsgAttArgs a) {
+    extern __shared__ float smg[];
+    const int K = 4 * a.U + a.Ed + 4 * a.H;
+    float* z = smg;                 // K
+    float* hid = z + K;             // max(Hm, Ha)
+    const int tid = threadIdx.x, tgt = blockIdx.x;
+    const int beg = a.tptr[tgt], end = a.tptr[tgt + 1];
+    const float* uj = a.u + (size_t)tgt * a.U;
+    const float* hj = a.h + (size_t)tgt * a.H;
+    for (int p = beg; p < end; ++p) {
+        const int i = a.tsrc[p], e = a.eidx[p];
+        const float* ui = a.u + (size_t)i * a.U;
+        const float* hi = a.h + (size_t)i * a.H;
+        const float* efr = a.ef + (size_t)(a.tfirst[p] % a.E) * a.Ed;
+        __syncthreads();
+        for (int k = tid; k < a.U; k += 256) {
+            const float vi = ui[k], vj = uj[k], d = vj - vi;
+            z[k] = vi; z[a.U + k] = vj; z[2 * a.U + k] = d; z[3 * a.U + k] = d * d;
+        }
+        for (int k = tid; k < a.Ed; k += 256) z[4 * a.U + k] = efr[k];
+        for (int k = tid; k < a.H; k += 256) {
+            const float vi = hi[k], vj = hj[k], d = vj - vi;
+            float* zh = z + 4 * a.U + a.Ed;
+            zh[k] = vi; zh[a.H + k] = vj; zh[2 * a.H + k] = d; zh[3 * a.H + k] = d * d;
+        }
+        for (int hdi = 0; hdi < a.heads; ++hdi) {
+            const AttHeadW& w = a.hd[hdi];
+            __syncthreads();
+            for (int o = tid; o < a.Hm; o += 256) {
+                float s = w.b1[o];
+                for (int k = 0; k < K; ++k) s = fmaf(z[k], w.W1[(size_t)k * a.Hm + o], s);
+                hid[o] = fmaxf(s, 0.f);
+            }
+            __syncthreads();
+            for (int o = tid; o < a.xd; o += 256) {
+                float s = w.b2[o];
+                for (int k = 0; k < a.Hm; ++k) s = fmaf(hid[k], w.W2[(size_t)k * a.xd + o], s);
+                a.M[(size_t)e * a.heads * a.xd + hdi * a.xd + o] = tanhf(s);
+            }
+            __syncthreads();
+            for (int o = tid; o < a.Ha; o += 256) {
+                float s = w.ab1[o];
+                for (int k = 0; k < K; ++k) s = fmaf(z[k], w.A1[(size_t)k * a.Ha + o], s);
+                hid[o] = fmaxf(s, 0.f);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                float s = w.ab2[0];
+                for (int k = 0; k < a.Ha; ++k) s = fmaf(hid[k], w.A2[k], s);
+                a.A[(size_t)hdi * a.Etot + e] = s;
+            }
+        }
+    }
+}
+// tf.sparse.softmax over the rows of the transposed tensor: per target t and head, over its csr entries p -> S[head][p]
+__global__ __launch_bounds__(64) void gnn_att_softmax_kernel(const int* __restrict__ tptr, const int* __restrict__ eidx, const float* __restrict__ A,
+                                                            int heads, int Etot, float* __restrict__ S) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int beg = tptr[t], end = tptr[t + 1];
+    for (int hdi = 0; hdi < heads; ++hdi) {
+        const float* Ah = A + (size_t)hdi * Etot;
+        float mx = -INFINITY;
+        for (int p = beg + lane; p < end; p += 64) mx = fmaxf(mx, Ah[eidx[p]]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float den = 0.f;
+        for (int p = beg + lane; p < end; p += 64) den += expf(Ah[eidx[p]] - mx);
+        for (int o = 32; o > 0; o >>= 1) den += __shfl_xor(den, o);
+        for (int p = beg + lane; p < end; p += 64) S[(size_t)hdi * Etot + p] = expf(Ah[eidx[p]] - mx) / den;
+    }
+}
+// x[t] = merge over heads of sum over in-edges e of S[head][e] * M[e][head]  -- S indexed by the EDGE index (the pairing above);
+// merge 'concat' (heads * xd = I columns) or 'average' (xd = I, mean over heads)
+__global__ __launch_bounds__(64) void gnn_att_aggregate_kernel(const int* __restrict__ tptr, const int* __restrict__ eidx, const float* __restrict__ S,
+                                                              const float* __restrict__ M, int heads, int xd, int Etot, int average,
+                                                              float* __restrict__ x) {
+    const int t = blockIdx.x;
+    const int beg = tptr[t], end = tptr[t + 1];
+    const int I = average ? xd : heads * xd;
+    for (int o = threadIdx.x; o < I; o += 64) {
+        float acc = 0.f;
+        if (average) {
+            for (int hdi = 0; hdi < heads; ++hdi) {
+                float s = 0.f;
+                for (int p = beg; p < end; ++p) { const int e = eidx[p]; s = fmaf(S[(size_t)hdi * Etot + e], M[(size_t)e * heads * xd + hdi * xd + o], s); }
+                acc += s;
+            }
+            acc /= (float)heads;
+        } else {
+            const int hdi = o / xd;
+            for (int p = beg; p < end; ++p) { const int e = eidx[p]; acc = fmaf(S[(size_t)hdi * Etot + e], M[(size_t)e * heads * xd + o], acc); }
+        }
+        x[(size_t)t * I + o] = acc;
+    }
+}
+
 struct LstmGenArgs {
     const float* x; const float* h_in; const float* c_in; const float* u;
     const float* Wg[4]; const float* bg[4];     // [I + H + U, H], [H]

@@ -52,12 +52,17 @@ class GnnGraph:
         if device_id not in self._handles:
             lib = _lib.init_device(device_id)
             c = self.cfg
+            if c.use_attention and len(c.attention_hidden) != 1:
+                raise _lib.AsepError("engine supports one hidden layer in the attention MLP (num_hidden_units_attention_fct)")
             if len(c.interaction_hidden) != 1 or len(c.classifier_hidden) != 2:
                 raise _lib.AsepError("engine supports one interaction hidden layer and two classifier hidden layers")
             cfg = _lib.GnnCfg(c.u_dim, c.edge_feature_dim, c.num_transition_steps, c.hidden_dim,
                               c.interaction_dim, c.interaction_hidden[0], c.classifier_hidden[0],
                               c.classifier_hidden[1], c.num_classes, int(c.undirected_graph),
-                              c.u_in_dim if c.compress_node_feature_dim > 0 else 0, c.output_type_code)
+                              c.u_in_dim if c.compress_node_feature_dim > 0 else 0, c.output_type_code,
+                              c.num_attention_heads if c.use_attention else 0,
+                              {"concat": 0, "average": 1}[c.multihead_attention_merge_type],
+                              c.attention_hidden[0] if c.use_attention else 0)
             blob = self.blob()
             h = lib.asep_gnn_load(blob, len(blob), C.byref(cfg))
             if not h:

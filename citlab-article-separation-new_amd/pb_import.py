@@ -850,7 +850,8 @@ def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None, num_transit
                                                       container carries it as ``asep_meta/num_transition_steps`` or takes the argument
       compress_node_feature_dim (graph_gnn.py:20)   = GraphLSTM1/compress_input/ff_compress_input/weights present -> served
       output_type add / concat (graph_gnn.py:23)    = GraphLSTM1/dense/weights present / a classifier input of 2 x (hidden + fed width) -> served
-      use_attention / heads (message_fn_chunk.py:35-41) = .../calculation_unnormalized_attention_values/... or .../head_1/... -> refused
+      use_attention / heads / merge (message_fn_chunk.py:35-41) = .../head_<k>/calculation_unnormalized_attention_values/... variables,
+                                                      AddN (average) or ConcatV2 (concat) of the heads -> served (graphs of <= 316 nodes)
     """
     consts = const_tensors(nodes)
     pref = ("GraphLSTM1/message_fn_default/head_0/calculation_interaction_features/concat_u_and_h/"
@@ -859,16 +860,36 @@ def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None, num_transit
     wu = _find(consts, "GraphLSTM1/update_function_LSTM/ingate_activation/dense/weights")
     if w1 is None or wu is None:
         raise IOError("no GNN variables (GraphLSTM1/...) among the graph constants")
-    if any("/message_fn_default/head_1/" in k for k in consts):
-        raise IOError("the graph has several attention heads (message_fn_chunk.py:37, num_attention_heads > 1): not supported, the "
-                      "engine implements the single-head, degree-normalised aggregation (message_fn_chunk.py:369-386)")
-    if any("calculation_unnormalized_attention_values" in k for k in consts):
-        raise IOError("the graph aggregates with learned attention (message_fn_chunk.py:35,203-216 use_attention=True): not "
-                      "supported, the engine implements the degree-normalised sum of the reference's default")
+    # ---- attention (message_fn_chunk.py:35-41,167-245): heads = number of head_<k> scopes, use_attention = the attention MLP's
+    #      variables exist, merge type = how the op graph combines the heads (AddN / RealDiv = 'average', ConcatV2 = 'concat';
+    #      a constants-only container says it in asep_meta/attention_merge_average)
+    heads = 0
+    while any(f"/message_fn_default/head_{heads}/" in k for k in consts):
+        heads += 1
+    att_pref = ("GraphLSTM1/message_fn_default/head_0/calculation_unnormalized_attention_values/calculation_interaction_features/"
+                "concat_u_and_h/interaction_features")
+    wa1 = _find(consts, att_pref + "/fully_connected_layer_h1/weights")
+    use_attention = wa1 is not None
+    if not use_attention and any("calculation_unnormalized_attention_values" in k for k in consts):
+        raise IOError("attention variables (calculation_unnormalized_attention_values) under an unexpected scope; expected "
+                      + att_pref)
+    if heads > 1 and not use_attention:
+        raise IOError("several head_<k> scopes without attention variables: message_fn_chunk.py:167-169 builds one head then")
+    merge = "concat"
+    if use_attention:
+        meta_avg = _find(consts, "asep_meta/attention_merge_average")
+        if meta_avg is not None:
+            merge = "average" if int(np.asarray(meta_avg).reshape(-1)[0]) else "concat"
+        elif any(n["op"] == "AddN" and "message_fn_default" in n["name"] for n in nodes):
+            merge = "average"                               # message_fn_chunk.py:229-233 tf.add_n(...) / num_attention_heads
+        if _find(consts, att_pref + "/fully_connected_layer_h2/weights") is not None:
+            raise IOError("the attention MLP has more than one hidden layer (num_hidden_units_attention_fct): the engine serves one")
     w_add = _find(consts, "GraphLSTM1/dense/weights")       # graph_gnn.py:160-163 output_type='add_final_hidden_and_input'
     hidden = int(wu.shape[1])
     w2 = _find(consts, pref + "/fully_connected_logit_layer_out/weights")
     inter = int(w2.shape[1]) if w2 is not None else hidden
+    if use_attention and merge == "concat":
+        inter *= heads                                      # message_fn_chunk.py:69-72,234-237: x = concat of heads x x_dim columns
     u_dim = int(wu.shape[0]) - inter - hidden                  # v = [x, h, u]: u = the width the message / update functions see
     e_dim = int(w1.shape[0]) - 4 * u_dim - 4 * hidden
     if u_dim < 0 or e_dim < 0:
@@ -947,7 +968,9 @@ def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None, num_transit
                     interaction_dim=inter,
                     interaction_hidden=[int(w1.shape[1])], classifier_hidden=cls_hidden,
                     num_classes=int(wo.shape[1]), undirected_graph=undirected_graph, compress_node_feature_dim=compress,
-                    output_type=output_type, **vis_kw)
+                    output_type=output_type, use_attention=use_attention, num_attention_heads=max(heads, 1) if use_attention else 1,
+                    multihead_attention_merge_type=merge,
+                    attention_hidden=[int(wa1.shape[1])] if use_attention else [16], **vis_kw)
     if vis_kw and cfg.visual_channels() != chans:
         raise IOError(f"visual_layers {cfg.visual_layers} have {cfg.visual_channels()} channels, the compression "
                       f"layers expect {chans}")

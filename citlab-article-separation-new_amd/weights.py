@@ -77,6 +77,13 @@ _CLS = "Classification/logits"
 GATES = ("ingate", "outgate", "forgetgate", "cellinput")
 
 
+def attention_scope(head: int) -> str:
+    """variable scope of head k's attention MLP (message_fn_chunk.py:422 inside :174 inside :166; _get_interaction_features adds
+    'calculation_interaction_features', _calculate_interaction_features_1 'concat_u_and_h', layers.mlp 'interaction_features')"""
+    return (f"GraphLSTM1/message_fn_default/head_{head}/calculation_unnormalized_attention_values/"
+            "calculation_interaction_features/concat_u_and_h/interaction_features")
+
+
 def gnn_tensor_shapes(cfg: GnnConfig) -> "OrderedDict[str, tuple]":
     shapes = OrderedDict()
     if cfg.visual_dims:
@@ -90,13 +97,24 @@ def gnn_tensor_shapes(cfg: GnnConfig) -> "OrderedDict[str, tuple]":
     if cfg.compress_node_feature_dim > 0:                           # graph_gnn.py:102-109 (scope GraphLSTM1/compress_input)
         shapes["GraphLSTM1/compress_input/ff_compress_input/weights"] = (cfg.u_in_dim, cfg.compress_node_feature_dim)
         shapes["GraphLSTM1/compress_input/ff_compress_input/bias"] = (cfg.compress_node_feature_dim,)
-    d_in = cfg.message_in_dim
-    for i, h in enumerate(cfg.interaction_hidden, start=1):         # layers.py:477-480
-        shapes[f"{_MSG}/fully_connected_layer_h{i}/weights"] = (d_in, h)
-        shapes[f"{_MSG}/fully_connected_layer_h{i}/bias"] = (h,)
-        d_in = h
-    shapes[f"{_MSG}/fully_connected_logit_layer_out/weights"] = (d_in, cfg.interaction_dim)
-    shapes[f"{_MSG}/fully_connected_logit_layer_out/bias"] = (cfg.interaction_dim,)
+    for k in range(cfg.heads):                                      # message_fn_chunk.py:172-176: one scope per attention head
+        msg = _MSG.replace("head_0", f"head_{k}")
+        d_in = cfg.message_in_dim
+        for i, h in enumerate(cfg.interaction_hidden, start=1):     # layers.py:477-480
+            shapes[f"{msg}/fully_connected_layer_h{i}/weights"] = (d_in, h)
+            shapes[f"{msg}/fully_connected_layer_h{i}/bias"] = (h,)
+            d_in = h
+        shapes[f"{msg}/fully_connected_logit_layer_out/weights"] = (d_in, cfg.head_interaction_dim)
+        shapes[f"{msg}/fully_connected_logit_layer_out/bias"] = (cfg.head_interaction_dim,)
+        if cfg.use_attention:                                       # message_fn_chunk.py:420-446: the attention MLP, one output
+            att = attention_scope(k)
+            d_in = cfg.message_in_dim
+            for i, h in enumerate(cfg.attention_hidden, start=1):
+                shapes[f"{att}/fully_connected_layer_h{i}/weights"] = (d_in, h)
+                shapes[f"{att}/fully_connected_layer_h{i}/bias"] = (h,)
+                d_in = h
+            shapes[f"{att}/fully_connected_logit_layer_out/weights"] = (d_in, 1)
+            shapes[f"{att}/fully_connected_logit_layer_out/bias"] = (1,)
     for g in GATES:                                                 # update_fn_lstm.py:55-66
         shapes[f"{_UPD}/{g}_activation/dense/weights"] = (cfg.update_in_dim, cfg.hidden_dim)
         shapes[f"{_UPD}/{g}_activation/dense/bias"] = (cfg.hidden_dim,)

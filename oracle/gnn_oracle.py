@@ -68,6 +68,28 @@ def _softmax(x):
     return e / e.sum(axis=-1, keepdims=True)
 
 
+def _transposed_sparse_softmax_values(a_un, frm, to, N):
+    """message_fn_chunk.py:203-211,448-452 restated literally: the unnormalised values sit in a sparse [from, to] tensor (indices =
+    the interactions, which are sorted by from * N + to); it is TRANSPOSED, soft-maxed over its last axis (for every `to`: over its
+    in-edges) and ``.values`` is taken -- the values of the transposed tensor in ITS row-major order, i.e. sorted by (to, from).
+    The caller multiplies them element by element with the interaction features, which are in (from, to) order: interaction e gets
+    the e-th value of the (to, from)-sorted list (for an undirected graph: the attention of the reverse edge, normalised over the
+    in-edges of `from`)."""
+    order = np.lexsort((frm, to))                                    # positions of the transposed tensor: (to, from) ascending
+    vals = np.asarray(a_un, np.float64)[order]
+    rows = np.asarray(to)[order]
+    out = np.empty_like(vals)
+    start = 0
+    while start < len(vals):                                         # tf.sparse.softmax: per row over the stored entries
+        stop = start
+        while stop < len(vals) and rows[stop] == rows[start]:
+            stop += 1
+        e = np.exp(vals[start:stop] - vals[start:stop].max())
+        out[start:stop] = e / e.sum()
+        start = stop
+    return out                                                       # .values: NOT permuted back
+
+
 def forward(num_nodes, edges, node_feat, edge_feat, relations, w, cfg, dtype=np.float32,
             return_hidden=False):
     """== sess.run('output_belong_to_same_instance:0') at batch size 1 -> probs [R, num_classes]."""
@@ -90,15 +112,37 @@ def forward(num_nodes, edges, node_feat, edge_feat, relations, w, cfg, dtype=np.
         dh = h[to] - h[frm]
         # order fixed by message_fn_chunk.py:313-350: u_from,u_to,u_diff,u_sq | edge | h_from,h_to,h_diff,h_sq
         z = np.concatenate([u[frm], u[to], du, du * du, cf, h[frm], h[to], dh, dh * dh], axis=1)
-        hid = z
-        for i in range(1, len(cfg.interaction_hidden) + 1):
-            hid = np.maximum(hid @ w[f"{MSG}/fully_connected_layer_h{i}/weights"]
-                             + w[f"{MSG}/fully_connected_layer_h{i}/bias"], 0)
-        m = np.tanh(hid @ w[f"{MSG}/fully_connected_logit_layer_out/weights"]
-                    + w[f"{MSG}/fully_connected_logit_layer_out/bias"])
-        x = np.zeros((N, cfg.interaction_dim), dtype)
-        if len(to):
-            np.add.at(x, to, m * (1.0 / deg[to])[:, None].astype(dtype))
+        use_att = bool(getattr(cfg, "use_attention", False))
+        heads = int(getattr(cfg, "num_attention_heads", 1)) if use_att else 1
+        per_head = []
+        for k in range(heads):                                       # message_fn_chunk.py:172-224
+            msg = MSG.replace("head_0", f"head_{k}")
+            hid = z
+            for i in range(1, len(cfg.interaction_hidden) + 1):
+                hid = np.maximum(hid @ w[f"{msg}/fully_connected_layer_h{i}/weights"]
+                                 + w[f"{msg}/fully_connected_layer_h{i}/bias"], 0)
+            m = np.tanh(hid @ w[f"{msg}/fully_connected_logit_layer_out/weights"]
+                        + w[f"{msg}/fully_connected_logit_layer_out/bias"])
+            if use_att:
+                att = (f"GraphLSTM1/message_fn_default/head_{k}/calculation_unnormalized_attention_values/"
+                       "calculation_interaction_features/concat_u_and_h/interaction_features")
+                hid = z
+                for i in range(1, len(cfg.attention_hidden) + 1):
+                    hid = np.maximum(hid @ w[f"{att}/fully_connected_layer_h{i}/weights"]
+                                     + w[f"{att}/fully_connected_layer_h{i}/bias"], 0)
+                a_un = (hid @ w[f"{att}/fully_connected_logit_layer_out/weights"]
+                        + w[f"{att}/fully_connected_logit_layer_out/bias"])[:, 0]                 # :446 squeeze
+                weights_e = _transposed_sparse_softmax_values(a_un, frm, to, N).astype(dtype)     # :203-211
+            else:
+                weights_e = (1.0 / deg[to]).astype(dtype) if len(to) else np.zeros(0, dtype)      # :369-386
+            xk = np.zeros((N, m.shape[1]), dtype)
+            if len(to):
+                np.add.at(xk, to, m * weights_e[:, None])            # :398-417: sparse [from, to] summed over axis 0
+            per_head.append(xk)
+        if not use_att or getattr(cfg, "multihead_attention_merge_type", "concat") == "average":
+            x = (sum(per_head) / dtype(heads)).astype(dtype)          # :229-233
+        else:
+            x = np.concatenate(per_head, axis=1)                      # :234-237
         v = np.concatenate([x, h, u], axis=1)                        # update_fn_lstm.py:41-50
         gate = {g: v @ w[f"{UPD}/{g}_activation/dense/weights"] + w[f"{UPD}/{g}_activation/dense/bias"]
                 for g in ("ingate", "outgate", "forgetgate", "cellinput")}

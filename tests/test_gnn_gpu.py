@@ -148,6 +148,13 @@ def test_permutation_equivariance():
     (dict(output_type="concat_final_hidden_and_input", node_feature_dim=15, compress_node_feature_dim=6, hidden_dim=24,
           interaction_dim=20, interaction_hidden=[28]), "generic"),            # x = the features as FED, before compress_input
     (dict(output_type="add_final_hidden_and_input", node_feature_dim=20, classifier_hidden=[40, 12]), "mfma_lds"),
+    # message_fn_chunk.py:35-41,199-245: learned attention over the in-edges, one / several heads, both merge types; directed graph:
+    # the (to, from) <-> (from, to) pairing of the reference is then not the reverse edge
+    (dict(use_attention=True), "generic"),
+    (dict(use_attention=True, num_attention_heads=4), "generic"),
+    (dict(use_attention=True, num_attention_heads=2, multihead_attention_merge_type="average", attention_hidden=[12]), "generic"),
+    (dict(use_attention=True, num_attention_heads=2, undirected_graph=False, hidden_dim=24, interaction_dim=20,
+          interaction_hidden=[28], num_transition_steps=2), "generic"),
 ])
 def test_hyper_parameters_other_than_the_defaults(kw, mode):
     """message_fn_chunk.py:13-40, trainer_rel.py:15-17: every width is a free parameter of the reference; the engine picks
@@ -165,6 +172,22 @@ def test_hyper_parameters_other_than_the_defaults(kw, mode):
     h = gnn_io.gnn_hidden(graph, N)
     assert h.shape == href.shape and float(np.abs(h - href).max()) <= PROB_TOL
     assert probs.shape == (N * N, cfg.num_classes) and float(np.abs(probs - ref).max()) <= PROB_TOL
+    graph.close()
+
+
+def test_attention_nets_beyond_one_interaction_chunk_are_refused():
+    """message_fn_chunk.py:77-78: the reference processes the interactions in chunks of 100000 // N target nodes and pairs the
+    attention values within a chunk; the engine implements the one-chunk case and says so beyond it"""
+    from citlab_article_separation_new_amd import _lib, gnn_io
+    cfg, w, graph = _setup(seed=5, use_attention=True)
+    rng = np.random.default_rng(1)
+    N = 317
+    edges, u, ef = _random_graph(rng, N, 400)
+    with pytest.raises(_lib.AsepError, match="one-chunk"):
+        gnn_io.gnn_forward(graph, N, edges, u, ef)
+    N = 316
+    edges, u, ef = _random_graph(rng, N, 400)
+    assert gnn_io.gnn_forward(graph, N, edges, u, ef).shape == (N * N, 2)
     graph.close()
 
 

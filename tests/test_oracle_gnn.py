@@ -92,3 +92,43 @@ def test_output_types_on_a_hand_case():
     p1 = G.forward(N, edges, u, ef, None, w2, GnnConfig(classifier_hidden=[], num_classes=2))
     p2 = G.forward(N, edges, u, ef, None, w2, cfg)
     assert np.array_equal(p1, p2) and np.abs(p0 - p1).max() > 1e-4      # a zero projection is the plain output; a random one is not
+
+
+def test_attention_values_are_paired_like_the_reference_does():
+    """message_fn_chunk.py:203-211,448-452: values of softmax(transpose(sparse [from, to])) are read in (to, from) order and
+    multiplied with the interaction features in (from, to) order.  Hand case, directed edges 0->1, 0->2, 1->2 (sorted by from, to):
+    the transposed tensor has rows to=1: {from 0}, to=2: {from 0, from 1}; its values in row-major order are
+    [softmax over {a01}] = [1], then softmax over {a02, a12}.  So interaction 0 (0->1) is weighted 1, interaction 1 (0->2) gets
+    softmax(a02, a12)[0] and interaction 2 (1->2) softmax(a02, a12)[1] -- here the orders coincide; with the edge 2->0 added the
+    (to, from) order starts with it and every weight moves one place."""
+    from oracle import gnn_oracle as G
+    frm, to = np.array([0, 0, 1]), np.array([1, 2, 2])
+    a = np.array([0.3, 1.0, 2.0])
+    s = np.exp([1.0, 2.0]) / np.exp([1.0, 2.0]).sum()
+    assert np.allclose(G._transposed_sparse_softmax_values(a, frm, to, 3), [1.0, s[0], s[1]])
+    # edges sorted by (from, to): 0->1, 0->2, 1->2, 2->0 ; transposed order (to, from): (0<-2), (1<-0), (2<-0), (2<-1)
+    frm, to = np.array([0, 0, 1, 2]), np.array([1, 2, 2, 0])
+    a = np.array([0.3, 1.0, 2.0, -1.0])
+    got = G._transposed_sparse_softmax_values(a, frm, to, 3)
+    assert np.allclose(got, [1.0, 1.0, s[0], s[1]])          # interaction 0 (0->1) gets the value of (0<-2), interaction 1 that of (1<-0), ...
+
+
+def test_single_head_attention_with_constant_scores_is_the_balanced_sum():
+    """with a zero attention MLP every in-edge of a node gets 1 / indegree: on an UNDIRECTED graph (where the pairing of the values
+    is the reverse edge, whose target's in-degree equals ... only for regular graphs) -- so use a regular graph: a ring"""
+    from citlab_article_separation_new_amd.config import GnnConfig
+    from citlab_article_separation_new_amd.weights import init_gnn_weights, attention_scope
+    from oracle import gnn_oracle as G
+    N = 8
+    edges = np.array([[i, (i + 1) % N] for i in range(N)], np.int32)       # ring: every node has in-degree 2 after symmetrisation
+    rng = np.random.default_rng(0)
+    u, ef = rng.random((N, 7), dtype=np.float32), rng.random((N, 2), dtype=np.float32)
+    plain = GnnConfig()
+    att = GnnConfig(use_attention=True)
+    w = init_gnn_weights(att, 2, bias_jitter=0.05)
+    for k in w:
+        if k.startswith(attention_scope(0)):
+            w[k] = np.zeros_like(w[k])
+    p_att = G.forward(N, edges, u, ef, None, w, att)
+    p_plain = G.forward(N, edges, u, ef, None, {k: v for k, v in w.items() if "unnormalized_attention" not in k}, plain)
+    assert np.abs(p_att - p_plain).max() < 1e-6

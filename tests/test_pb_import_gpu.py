@@ -68,6 +68,33 @@ def test_foreign_frozen_graph_of_an_aru_variant_loads_and_matches_oracle(tmp_pat
     graph.close()
 
 
+@pytest.mark.parametrize("kw,merge_concat", [(dict(use_attention=True, num_attention_heads=4), True),
+                                             (dict(use_attention=True, num_attention_heads=2, multihead_attention_merge_type="average"), False)],
+                         ids=["four_heads_concat", "two_heads_average"])
+def test_relation_net_with_attention_read_from_the_graph_matches_the_oracle(tmp_path, kw, merge_concat):
+    """message_fn_chunk.py:35-41,199-245: a TF1-layout export of an attention net loads without hints (heads, merge type, widths from
+    the graph) and gives the oracle's probabilities"""
+    import tf_gnn_graph
+    import tf_graphdef_proto as tp
+    from citlab_article_separation_new_amd import gnn_io, synth
+    from citlab_article_separation_new_amd.config import GnnConfig
+    from citlab_article_separation_new_amd.weights import init_gnn_weights
+    from oracle import gnn_oracle
+    src = GnnConfig(**kw)
+    w = init_gnn_weights(src, 23, bias_jitter=0.05)
+    pb = tmp_path / "rel_att.pb"
+    pb.write_bytes(tf_gnn_graph.build(tp.build_messages(), w, 3, merge_concat=merge_concat).SerializeToString())
+    graph = gnn_io.load_graph(str(pb))
+    assert graph.cfg.use_attention and graph.cfg.num_attention_heads == src.num_attention_heads
+    assert graph.cfg.multihead_attention_merge_type == src.multihead_attention_merge_type
+    N = 50
+    g = synth.synth_graph(4, N=N, n_pairs=200, node_dim=7)
+    probs = gnn_io.gnn_forward(graph, N, g["interacting_nodes"], g["node_features"], g["edge_features"])
+    ref = gnn_oracle.forward(N, g["interacting_nodes"], g["node_features"], g["edge_features"], None, w, src)
+    assert float(np.abs(probs - ref).max()) <= 1e-5
+    graph.close()
+
+
 @pytest.mark.parametrize("output_type", ["add_final_hidden_and_input", "concat_final_hidden_and_input"])
 def test_relation_net_output_type_read_from_the_graph_matches_the_oracle(tmp_path, output_type):
     """graph_gnn.py:23,158-166: output_type add / concat of a TF1-layout export load without a hint and give the oracle's

@@ -314,14 +314,22 @@ def test_gnn_compression_layer_is_detected_and_loaded():
 
 def test_gnn_options_the_engine_does_not_serve_are_refused_with_the_reason():
     from citlab_article_separation_new_amd.config import GnnConfig
+    # attention variables under a scope the reference does not produce
     att = "GraphLSTM1/message_fn_default/head_0/calculation_unnormalized_attention_values/attention_values/fully_connected_layer_h1/weights"
     nodes, _ = _gnn_nodes(GnnConfig(), 3, extra={att: np.zeros((30, 16))})
-    with pytest.raises(IOError, match="use_attention"):
+    with pytest.raises(IOError, match="unexpected scope"):
         pb_import.gnn_from_nodes(nodes)
+    # a second head without attention (message_fn_chunk.py:167-169 builds one head then)
     head1 = ("GraphLSTM1/message_fn_default/head_1/calculation_interaction_features/concat_u_and_h/interaction_features/"
              "fully_connected_layer_h1/weights")
     nodes, _ = _gnn_nodes(GnnConfig(), 3, extra={head1: np.zeros((158, 32))})
-    with pytest.raises(IOError, match="attention heads"):
+    with pytest.raises(IOError, match="without attention variables"):
+        pb_import.gnn_from_nodes(nodes)
+    # two hidden layers in the attention MLP
+    h2 = ("GraphLSTM1/message_fn_default/head_0/calculation_unnormalized_attention_values/calculation_interaction_features/"
+          "concat_u_and_h/interaction_features/fully_connected_layer_h2/weights")
+    nodes, _ = _gnn_nodes(GnnConfig(use_attention=True), 3, extra={h2: np.zeros((16, 8))})
+    with pytest.raises(IOError, match="more than one hidden layer"):
         pb_import.gnn_from_nodes(nodes)
     # a projection of the wrong shape under the add-output's name
     nodes, _ = _gnn_nodes(GnnConfig(), 3, extra={"GraphLSTM1/dense/weights": np.zeros((9, 32))})
@@ -348,6 +356,26 @@ def test_gnn_output_type_is_read_from_the_constants(output_type):
     assert list(tensors) == list(w) and all(np.array_equal(tensors[k], w[k]) for k in w)
     assert ("GraphLSTM1/dense/weights" in tensors) == (output_type.startswith("add"))
     assert tensors["Classification/logits/fully_connected_layer_h1/weights"].shape[0] == 2 * cfg.classifier_node_dim
+
+
+@pytest.mark.parametrize("kw,merge_concat", [
+    (dict(use_attention=True), None), (dict(use_attention=True, num_attention_heads=4), True),
+    (dict(use_attention=True, num_attention_heads=2, multihead_attention_merge_type="average", attention_hidden=[12]), False),
+], ids=["one_head", "four_heads_concat", "two_heads_average"])
+def test_gnn_attention_options_are_read_from_the_graph(kw, merge_concat):
+    """message_fn_chunk.py:35-41: use_attention from the attention MLP's variables, the number of heads from the head_<k> scopes, the
+    merge type from the op that combines the heads (ConcatV2 / AddN), the attention MLP's width from its weights"""
+    import tf_gnn_graph
+    from citlab_article_separation_new_amd.config import GnnConfig
+    from citlab_article_separation_new_amd.weights import init_gnn_weights
+    src = GnnConfig(**kw)
+    w = init_gnn_weights(src, 5, bias_jitter=0.02)
+    g = tf_gnn_graph.build(tp.build_messages(), w, 3, merge_concat=merge_concat)
+    tensors, cfg = pb_import.gnn_from_nodes(pb_import.parse_graphdef(g.SerializeToString()))
+    assert cfg.use_attention and cfg.num_attention_heads == src.num_attention_heads
+    assert cfg.multihead_attention_merge_type == src.multihead_attention_merge_type or src.num_attention_heads == 1
+    assert cfg.attention_hidden == src.attention_hidden and cfg.interaction_dim == 32 and cfg.node_feature_dim == 7
+    assert list(tensors) == list(w) and all(np.array_equal(tensors[k], w[k]) for k in w)
 
 
 def test_gnn_constants_only_container_needs_the_step_count():

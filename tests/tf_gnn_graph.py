@@ -22,7 +22,7 @@ UPD = "GraphLSTM1/update_function_LSTM"
 CLS = "Classification/logits"
 
 
-def build(ns, weights, num_transition_steps, prefix="graph/", extra_consts=None):
+def build(ns, weights, num_transition_steps, prefix="graph/", extra_consts=None, merge_concat=None):
     nodes, made = [], set()
 
     def add(name, op, inputs=(), **attrs):
@@ -55,6 +55,36 @@ def build(ns, weights, num_transition_steps, prefix="graph/", extra_consts=None)
             enter_w = add(f"{loop}/{layer}/MatMul/Enter", "Enter", [var(f"{MSG}/{layer}/weights")], T=F32, frame_name=loop, is_constant=True)
             enter_b = add(f"{loop}/{layer}/BiasAdd/Enter", "Enter", [var(f"{MSG}/{layer}/bias")], T=F32, frame_name=loop, is_constant=True)
             x = add(f"{loop}/{layer}/BiasAdd", "BiasAdd", [add(f"{loop}/{layer}/MatMul", "MatMul", [x, enter_w], T=F32), enter_b], T=F32)
+        # further attention heads / the attention MLPs (message_fn_chunk.py:172-224): their variables, one MatMul each
+        head_out = [x]
+        k = 0
+        while True:
+            msg_k = MSG.replace("head_0", f"head_{k}")
+            att_k = f"GraphLSTM1/message_fn_default/head_{k}/calculation_unnormalized_attention_values/calculation_interaction_features/concat_u_and_h/interaction_features"
+            if k > 0:
+                if f"{msg_k}/fully_connected_layer_h1/weights" not in weights:
+                    break
+                y = z
+                for layer in ("fully_connected_layer_h1", "fully_connected_logit_layer_out"):
+                    y = add(f"{loop}/head_{k}/{layer}/BiasAdd", "BiasAdd", [add(f"{loop}/head_{k}/{layer}/MatMul", "MatMul", [y, var(f"{msg_k}/{layer}/weights")], T=F32),
+                                                                               var(f"{msg_k}/{layer}/bias")], T=F32)
+                head_out.append(y)
+            if f"{att_k}/fully_connected_layer_h1/weights" in weights:
+                y = z
+                for layer in ("fully_connected_layer_h1", "fully_connected_logit_layer_out"):
+                    y = add(f"{loop}/head_{k}/att/{layer}/BiasAdd", "BiasAdd", [add(f"{loop}/head_{k}/att/{layer}/MatMul", "MatMul", [y, var(f"{att_k}/{layer}/weights")], T=F32),
+                                                                                   var(f"{att_k}/{layer}/bias")], T=F32)
+                head_out[-1] = add(f"{loop}/head_{k}/mul", "Mul", [head_out[-1], y], T=F32)
+            k += 1
+        if len(head_out) > 1:
+            concat = merge_concat if merge_concat is not None else True
+            if concat:
+                x = add(prefix + f"GraphLSTM1/message_fn_default{sfx}/concat", "ConcatV2", head_out, T=F32, N=len(head_out))
+            else:                                             # message_fn_chunk.py:229-233
+                x = add(prefix + f"GraphLSTM1/message_fn_default{sfx}/truediv", "RealDiv",
+                        [add(prefix + f"GraphLSTM1/message_fn_default{sfx}/AddN", "AddN", head_out, T=F32, N=len(head_out))], T=F32)
+        else:
+            x = head_out[0]
         gates = []
         for g in ("ingate", "outgate", "forgetgate", "cellinput"):
             s = prefix + f"{UPD}{sfx}/{g}_activation/dense"
