@@ -1831,7 +1831,8 @@ void asep_aru_free(asep_aru* m) { delete m; }
 static int forward_lanes(asep_aru* m, int n_pages, const float* const* d_imgs, int H, int W, float* const* d_outs,
                          uint8_t* const* d_u8, uint8_t* const* d_mask, float threshold, hipStream_t stream) {
     m->endpoints.clear();
-    const int nl = (m->profiling || n_pages < 2) ? 1 : std::min<int>((int)m->lanes.size(), n_pages);
+    // (per-launch profiling in the isolated mode brackets one kernel at a time: one lane; the in-situ mode keeps the real schedule)
+    const int nl = ((m->profiling && !m->prof_in_situ) || n_pages < 2) ? 1 : std::min<int>((int)m->lanes.size(), n_pages);
     asep_aru::Lane& L0 = *m->lanes[0];
     L0.s = stream;
     if (nl == 1) return forward_impl(m, L0, 0, n_pages, d_imgs, H, W, d_outs, d_u8, d_mask, threshold);

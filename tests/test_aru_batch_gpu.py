@@ -8,8 +8,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_batch_equals_single_pages_and_oracle():
+@pytest.mark.parametrize("lanes", ["1", "2", "3"])
+def test_batch_equals_single_pages_and_oracle(lanes, monkeypatch):
+    """(ASEP_LANES = n: the pages of a call are split over n stream sets that run concurrently -- same kernels per page, so the
+    results stay bit-identical to the single-page call)"""
     import torch
+    monkeypatch.setenv("ASEP_LANES", lanes)                 # read when the engine is created
     from citlab_article_separation_new_amd import _lib, net_post_processing_helper as helper
     from citlab_article_separation_new_amd.config import AruConfig
     from citlab_article_separation_new_amd.weights import init_aru_weights
