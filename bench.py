@@ -28,7 +28,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
+
+# torch is imported in main(), not here: the files-in / files-out leg starts decode worker processes with the "spawn" method, and a
+# spawned child re-imports THIS module as __mp_main__ -- with `import torch` at the top every one of the 24 workers paid for it
+# (start-up, memory, a thread pool per worker) and the leg ran at 36 instead of 68 pages/s
+torch = None
 
 METRIC = "newspaper pages/sec (ARU-Net seg + GNN relation) at 3000x4500 px"
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
@@ -68,6 +72,8 @@ def parse_args():
     ap.add_argument("--no-kernel-timing", action="store_true", help="same as --kernel-timing none")
     ap.add_argument("--e2e-pages", type=int, default=384,
                     help="scans of the files-in / files-out secondary figure (separator CLI path with host workers; 0 = skip)")
+    ap.add_argument("--e2e-leg", action="store_true", help=argparse.SUPPRESS)      # internal: run only the e2e_files leg, print its JSON
+    ap.add_argument("--e2e-device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements (bf16 variant, heading net + stroke-width fusion, visual GNN)")
     ap.add_argument("--cpu-sample-height", type=int, default=0,
@@ -130,7 +136,7 @@ def _timed(fn, iters, warmup=1):
 VISUAL_LAYERS = ["scale_0_unet_up_2_conv", "scale_0_unet_up_1_conv", "scale_0_unet_up_0_conv"]
 
 
-def e2e_files(args, dev):
+def e2e_files(args, dev_index):
     """Files in, files out through the separator CLI path (SeparatorNetPostProcessor = run_net_post_processing.py --mode
     separator --fixed_height 4500): PNG scans on disk -> decode in host workers -> GPU stages -> PAGE-XML files.  Four real
     files, the rest links to them (each with its own PAGE-XML output)."""
@@ -155,8 +161,8 @@ def e2e_files(args, dev):
             else:
                 os.symlink(os.path.join(tmp, f"p{k % 4:03d}.png"), q)
             paths.append(q)
-        SeparatorNetPostProcessor(paths[:2], graph, H, 1.0, 0.5, str(dev.index or 0), host_workers=0).run()    # warm-up
-        proc = SeparatorNetPostProcessor(paths, graph, H, 1.0, 0.5, str(dev.index or 0), host_workers=workers)
+        SeparatorNetPostProcessor(paths[:2], graph, H, 1.0, 0.5, str(dev_index), host_workers=0).run()    # warm-up
+        proc = SeparatorNetPostProcessor(paths, graph, H, 1.0, 0.5, str(dev_index), host_workers=workers)
         t0 = time.perf_counter()
         proc.run()
         dt = time.perf_counter() - t0
@@ -259,14 +265,25 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
         gg.close()
         # ---- files in, files out ----
         if args.e2e_pages > 0:
-            out["e2e_files"] = e2e_files(args, dev)
+            # in a child process of its own, so that the leg's worker processes do not inherit this process's module state
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--e2e-leg", "--e2e-pages", str(args.e2e_pages), "--height", str(args.height),
+                   "--width", str(args.width), "--e2e-device", str(dev.index or 0)]
+            r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, text=True, timeout=1800)
+            lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+            out["e2e_files"] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": f"e2e leg exited with {r.returncode}"}
     except Exception as e:  # a secondary figure must never take the headline line down
         out["error"] = repr(e)
     return out
 
 
 def main():
+    global torch
     args = parse_args()
+    if args.e2e_leg:                                         # child process of the secondary files-in / files-out figure
+        print(json.dumps(e2e_files(args, args.e2e_device)))
+        return
+    import torch
     if args.no_kernel_timing:
         args.kernel_timing = "none"
     world = int(os.environ.get("WORLD_SIZE", "1"))
