@@ -110,9 +110,12 @@ def load_graph(pb_path, visual_layers=None, num_transition_steps=None) -> GnnGra
         from . import pb_import
         tensors, cfg = pb_import.gnn_from_nodes(pb_import.read_graph(pb_path), visual_layers=visual_layers,
                                                 num_transition_steps=num_transition_steps)
-        return GnnGraph(tensors, cfg, pb_path)
-    tensors, meta = load_weights(pb_path)
-    cfg = GnnConfig(**(meta or {}).get("gnn_cfg", {}))
+    else:
+        tensors, meta = load_weights(pb_path)
+        cfg = GnnConfig(**(meta or {}).get("gnn_cfg", {}))
+    if cfg.visual_dims:                                      # ASEP_COMPUTE_DTYPE: the conv backbone of the visual branch (graph stays fp32)
+        from .net_post_processing_helper import compute_dtype_from_env
+        cfg.backbone = dict(cfg.backbone, compute_dtype=compute_dtype_from_env(cfg.backbone.get("compute_dtype", "f32")))
     return GnnGraph(tensors, cfg, pb_path)
 
 

@@ -85,10 +85,23 @@ def load_graph(path_to_pb) -> AruGraph:
     if str(path_to_pb).endswith(".pb"):
         from . import pb_import
         tensors, cfg = pb_import.aru_from_nodes(pb_import.read_graph(path_to_pb))
-        return AruGraph(tensors, cfg, path_to_pb)
-    tensors, meta = load_weights(path_to_pb)
-    cfg = AruConfig(**(meta or {}).get("aru_cfg", {}))
+    else:
+        tensors, meta = load_weights(path_to_pb)
+        cfg = AruConfig(**(meta or {}).get("aru_cfg", {}))
+    cfg.compute_dtype = compute_dtype_from_env(cfg.compute_dtype)
     return AruGraph(tensors, cfg, path_to_pb)
+
+
+def compute_dtype_from_env(default: str) -> str:
+    """ASEP_COMPUTE_DTYPE=bf16|f32 selects the engine's arithmetic for models loaded from FILES (the reference's command lines have
+    no flag for it: BASELINE configs[4] runs the same CLIs with "bf16 convs").  The precision is an engine option, not a
+    property of the weights; unset = what the model's side-car says, else fp32."""
+    v = os.environ.get("ASEP_COMPUTE_DTYPE", "").strip().lower()
+    if not v:
+        return default
+    if v not in ("f32", "bf16"):
+        raise ValueError(f"ASEP_COMPUTE_DTYPE must be 'f32' or 'bf16', got {v!r}")
+    return v
 
 
 def _device_of(gpu_device) -> int:

@@ -233,3 +233,29 @@ def test_two_gpu_owner_processes_write_the_same_files_as_one(tmp_path, monkeypat
     from citlab_article_separation_new_amd import _lib
     with pytest.raises(_lib.AsepError, match="ASEP_GPU_OWNERS"):
         cli.main(["--path_to_image_list", str(lst), "--path_to_pb", pb, "--mode", "separator", "--num_processes", "2"])
+
+
+def test_compute_dtype_switch_for_models_loaded_from_files(tmp_path, monkeypatch):
+    """BASELINE configs[4] runs the reference's command lines with "bf16 convs": ASEP_COMPUTE_DTYPE=bf16 makes load_graph hand
+    the bf16 engine path the same file; the separator CLI then writes PAGE-XML from it, the probabilities stay within the bf16
+    gate (2e-2) of the fp32 ones and are not identical to them (the switch did something)."""
+    from citlab_article_separation_new_amd import image_io, net_post_processing_helper as helper, run_net_post_processing as cli
+    from oracle import classical_oracle as co
+    pb, lst, data = _setup(tmp_path)
+    _, grey, _ = co.scale_and_gray(image_io.load_image_bgr(str(data / "p0.png")), 450, 1.0)
+    g32 = helper.load_graph(pb)
+    p32 = helper.get_net_output(grey, g32, "0")
+    g32.close()
+    monkeypatch.setenv("ASEP_COMPUTE_DTYPE", "bf16")
+    g16 = helper.load_graph(pb)
+    assert g16.cfg.compute_dtype == "bf16"
+    p16 = helper.get_net_output(grey, g16, "0")
+    g16.close()
+    d = float(np.abs(p16 - p32).max())
+    assert 0.0 < d <= 2e-2, d
+    assert cli.main(["--path_to_image_list", str(lst), "--path_to_pb", pb, "--mode", "separator", "--fixed_height", "450",
+                     "--threshold", "0.5", "--num_processes", "1"]) == 0
+    assert (data / "page" / "p0.xml.xml").exists()
+    monkeypatch.setenv("ASEP_COMPUTE_DTYPE", "fp16")
+    with pytest.raises(ValueError, match="ASEP_COMPUTE_DTYPE"):
+        helper.load_graph(pb)
