@@ -148,7 +148,7 @@ def e2e_files(args, dev_index):
     from citlab_article_separation_new_amd.separator_net_post_processor import SeparatorNetPostProcessor
     from citlab_article_separation_new_amd.weights import init_aru_weights
     H, W, n = args.height, args.width, args.e2e_pages
-    cfg = AruConfig()
+    cfg = AruConfig(compute_dtype=args.dtype)
     graph = helper.AruGraph(init_aru_weights(cfg, 21, logit_scale=0.05), cfg)
     workers = host_workers_default()
     with tempfile.TemporaryDirectory(prefix="asep_e2e_") as tmp:
@@ -173,6 +173,7 @@ def e2e_files(args, dev_index):
             "first_page_s": round(first, 2), "steady_pages_per_s": round((n - 1) / max(dt - first, 1e-9), 2),
             "page_xml_written": n_xml, "gpu_owner_device_stage_share": round(proc.device_seconds / dt, 3),
             "gpu_owner_waiting_for_decode_share": round(proc.wait_seconds / dt, 3),
+            "dtype": args.dtype,
             "note": f"separator CLI path, --fixed_height {H} (net on the full {W}x{H} page): PNG files -> {workers} decode / XML "
                     f"worker processes around ONE GPU owner -> PAGE-XML files; worker start-up (first_page_s: process spawn, page-locking of the decode slots, first decode) inside pages_per_s, excluded from "
                     f"steady_pages_per_s; "
@@ -268,7 +269,7 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
             # in a child process of its own, so that the leg's worker processes do not inherit this process's module state
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), "--e2e-leg", "--e2e-pages", str(args.e2e_pages), "--height", str(args.height),
-                   "--width", str(args.width), "--e2e-device", str(dev.index or 0)]
+                   "--width", str(args.width), "--e2e-device", str(dev.index or 0), "--dtype", args.dtype]
             r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, text=True, timeout=1800)
             lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
             out["e2e_files"] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": f"e2e leg exited with {r.returncode}"}
