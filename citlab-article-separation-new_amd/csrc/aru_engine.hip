@@ -1604,20 +1604,29 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
             ca.thr255 = (double)threshold * 255.0;
             ca.softmax = cfg.apply_softmax;
             dim3 grid(cdiv(W, COMBINE_TW), cdiv(H, 16));
-            ProfScope ps(m, "combine_kernel" + targs({ti(cfg.feat_root), ti(cfg.n_classes), tb(m->bf16)}), 2.0 * H * W * 16.0 * cfg.feat_root * cfg.n_classes);
+            // number of scales as a template constant (1 = no attention, 3 = the default ARU-Net) with 32-bit offsets, for tensors
+            // below 4 GB; anything else takes the run-time form
+            const bool small = (size_t)H * W * std::max(cfg.feat_root, cfg.n_classes) * sizeof(float) < ((size_t)1 << 32);
+            const int nsct = small && (nsc == 1 || nsc == 3) ? nsc : 0;
+            ProfScope ps(m, "combine_kernel" + targs({ti(cfg.feat_root), ti(cfg.n_classes), tb(m->bf16), ti(nsct)}), 2.0 * H * W * 16.0 * cfg.feat_root * cfg.n_classes);
+#define ASEP_COMB_N(FR, NC, BF)                                                                    \
+        if (nsct == 3) hipLaunchKernelGGL((combine_kernel<FR, NC, BF, 3>), grid, dim3(256), 0, stream, ca);      \
+        else if (nsct == 1) hipLaunchKernelGGL((combine_kernel<FR, NC, BF, 1>), grid, dim3(256), 0, stream, ca); \
+        else hipLaunchKernelGGL((combine_kernel<FR, NC, BF, 0>), grid, dim3(256), 0, stream, ca);
 #define ASEP_COMB(FR, NC)                                                                          \
     if (cfg.feat_root == FR && cfg.n_classes == NC && !m->bf16) {                                  \
-        hipLaunchKernelGGL((combine_kernel<FR, NC, false>), grid, dim3(256), 0, stream, ca);       \
+        ASEP_COMB_N(FR, NC, false)                                                                 \
     } else
 #define ASEP_COMBB(NC)                                                                             \
     if (cfg.feat_root == 8 && cfg.n_classes == NC && m->bf16) {                                    \
-        hipLaunchKernelGGL((combine_kernel<8, NC, true>), grid, dim3(256), 0, stream, ca);         \
+        ASEP_COMB_N(8, NC, true)                                                                   \
     } else
             ASEP_COMBB(1) ASEP_COMBB(2) ASEP_COMBB(3) ASEP_COMBB(4)
             ASEP_COMB(8, 1) ASEP_COMB(8, 2) ASEP_COMB(8, 3) ASEP_COMB(8, 4) ASEP_COMB(16, 2)
             { set_error("combine: feat_root=%d n_classes=%d not instantiated", cfg.feat_root, cfg.n_classes); return ASEP_ERR_UNSUPPORTED; }
 #undef ASEP_COMB
 #undef ASEP_COMBB
+#undef ASEP_COMB_N
         }
         ASEP_HIP_CHECK(hipGetLastError());
     } catch (const HipError&) {

@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace asep {
 
@@ -1427,8 +1428,15 @@ struct CombineArgs {
 
 constexpr int COMBINE_TW = 32;   // tile width of combine_kernel (16 rows)
 // F0BF: the scale-0 feature map is bf16 (native bf16 path): one 16-byte load per pixel, widened to fp32 in registers
-template <int FR, int NC, bool F0BF = false>
+// NSCT: number of scales as a compile-time constant (1 = no attention, 3 = the default net; 0 = run-time a.nsc).  The first phase
+// of this kernel was 850 vector instructions per thread against 460 in the logits conv: five scale iterations of which two are
+// dead at run time but paid for in selects and moves, and 64-bit index arithmetic (mad_i64 / ashr / lshl_add_u64) for fifteen
+// gathers.  With NSCT the dead iterations vanish, and the specialised forms index with 32-bit offsets from the (scalar) base
+// pointers -- the host selects them only for tensors below 4 GB.
+template <int FR, int NC, bool F0BF = false, int NSCT = 0>
 __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
+    const int nsc = NSCT ? NSCT : a.nsc;
+    typedef typename std::conditional<NSCT != 0, unsigned, size_t>::type idx_t;
     static_assert(!F0BF || FR == 8, "bf16 feature map: 8 channels = one 16-byte record");
     // 32 x 16 pixel tile, two horizontally adjacent pixels per thread (their 4 x 5 pixel window is read from LDS once: the
     // kernel is bound by LDS reads, 32 x 16 B per pixel in the one-pixel form)
@@ -1459,23 +1467,23 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
         const int gy = min(max(y0 - 1 + ly, 0), a.H - 1), gx = min(max(x0 - 1 + lx, 0), a.W - 1);
         if constexpr (F0BF) {
             typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-            const u32x4_t q = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const unsigned short*>(a.f0) + ((size_t)gy * a.W + gx) * FR);
+            const u32x4_t q = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const unsigned short*>(a.f0) + ((idx_t)gy * a.W + gx) * FR);
             fv[i][0] = f32x4{__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
             fv[i][FR / 4 - 1] = f32x4{__uint_as_float(q.z << 16), __uint_as_float(q.z & 0xffff0000u), __uint_as_float(q.w << 16), __uint_as_float(q.w & 0xffff0000u)};
         } else {
-            const float* f = a.f0 + ((size_t)gy * a.W + gx) * FR;
+            const float* f = a.f0 + ((idx_t)gy * a.W + gx) * FR;
 #pragma unroll
             for (int c4 = 0; c4 < FR / 4; ++c4) fv[i][c4] = *reinterpret_cast<const f32x4*>(f + c4 * 4);
         }
 #pragma unroll
         for (int s = 0; s < MAX_SCALES; ++s) {
             avv[i][s] = 0.f; fsv[i][s] = 0.f;
-            if (a.nsc > 1 && s < a.nsc) {
+            if (nsc > 1 && s < nsc) {
                 const int ay = (gy + a.aph[s]) >> a.ash[s], ax = (gx + a.apw[s]) >> a.ash[s];
-                avv[i][s] = a.att[s][(size_t)ay * a.aw[s] + ax];
+                avv[i][s] = a.att[s][(idx_t)ay * a.aw[s] + ax];
                 if (s >= 1) {
                     const int fy = (gy + a.fph[s]) >> a.fsh[s], fx = (gx + a.fpw[s]) >> a.fsh[s];
-                    fsv[i][s] = a.fsum[s][(size_t)fy * a.fw[s] + fx];
+                    fsv[i][s] = a.fsum[s][(idx_t)fy * a.fw[s] + fx];
                 }
             }
         }
@@ -1490,7 +1498,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
 #pragma unroll
         for (int c = 0; c < FR; ++c) v[c] = 0.f;
         if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-            if (a.nsc <= 1) {
+            if (nsc <= 1) {
 #pragma unroll
                 for (int c = 0; c < FR; ++c) v[c] = fv[i][c >> 2][c & 3];
             } else {
@@ -1499,16 +1507,16 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
                 float av[MAX_SCALES], mx = -INFINITY;
 #pragma unroll
                 for (int s = 0; s < MAX_SCALES; ++s)
-                    if (s < a.nsc) { av[s] = avv[i][s]; mx = fmaxf(mx, av[s]); }
+                    if (s < nsc) { av[s] = avv[i][s]; mx = fmaxf(mx, av[s]); }
                 float den = 0.f;
 #pragma unroll
                 for (int s = 0; s < MAX_SCALES; ++s)
-                    if (s < a.nsc) { av[s] = expf(av[s] - mx); den += av[s]; }
+                    if (s < nsc) { av[s] = __expf(av[s] - mx); den += av[s]; }     // (v_exp_f32: arguments <= 0, weights in [0, 1]: 1 ulp of the result is far inside the gates)
                 const float inv = 1.f / den;
                 float add = 0.f;
 #pragma unroll
                 for (int s = 1; s < MAX_SCALES; ++s)
-                    if (s < a.nsc) add += fsv[i][s] * (av[s] * inv);
+                    if (s < nsc) add += fsv[i][s] * (av[s] * inv);
                 const float w0 = av[0] * inv;
 #pragma unroll
                 for (int c = 0; c < FR; ++c) v[c] = fv[i][c >> 2][c & 3] * w0 + add;
@@ -1596,7 +1604,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
 #pragma unroll
             for (int k = 0; k < NC; ++k) lg[q][k] = lg[q][k] / den;
         }
-        const size_t p = ((size_t)y * a.W + x) * NC;
+        const idx_t p = ((idx_t)y * a.W + x) * NC;
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             a.out[p + k] = lg[q][k];
