@@ -751,19 +751,55 @@ __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
     const int ngroups = MODE == 2 ? a.groups : 1;
     const u32x4* __restrict__ wbase = a.wpk + (size_t)mt0 * 64 + lane;
     const size_t wstride = (size_t)a.mtiles * 64;
+    // Requests first, all of them: bias, (MODE 1) the six A fragments, then the input tile.  As first written the block was a chain of
+    // five dependent round trips -- each input load sat in its own "inside the image?" branch with its own wait (the zero-padding
+    // select had been merged into the load), the fragments were fetched between the MFMAs and the bias in the epilogue -- for twelve
+    // MFMAs per wave.
+    f32x4 bias4[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int c = (mt0 + m) * 16 + kk * 4;
+        bias4[m] = *reinterpret_cast<const f32x4*>(a.bias + (c < a.cout ? c : 0));
+        if (c >= a.cout) bias4[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    u32x4 wf[MODE == 1 ? 6 : 1][MT];
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int f = 0; f < 6; ++f)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) wf[f][m] = wbase[(size_t)f * wstride + (size_t)m * 64];
+    }
+    // the thread's input slots: clamped pixel index (always a valid address) + inside-the-image mask, computed once
+    int spix[NLOAD];
+    unsigned mask = 0;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+        const int u = min(tid + i * 256, NU - 1);
+        const int pix = u / SUBS;
+        const int ly = pix / LW, lx = pix - ly * LW;
+        const int gy = Y0 - 1 + ly, gx = X0 - 1 + lx;
+        spix[i] = min(max(gy, 0), Hi - 1) * Wi + min(max(gx, 0), Wi - 1);
+        mask |= ((gy >= 0 && gy < Hi && gx >= 0 && gx < Wi) ? 1u : 0u) << i;
+    }
+    const int sub8 = (tid % SUBS) * 8;                          // (256 is a multiple of SUBS: the sub-block is the same for all slots)
     for (int g = 0; g < ngroups; ++g) {
         // input tile with one halo row / column at the top / left: LDS (ly, lx) = input (Y0 - 1 + ly, X0 - 1 + lx)
         u32x4 st[NLOAD];
-        unsigned mask = 0;
 #pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-            const int u = min(tid + i * 256, NU - 1);
-            const int pix = u / SUBS, sub = u - pix * SUBS;
-            const int ly = pix / LW, lx = pix - ly * LW;
-            const int gy = Y0 - 1 + ly, gx = X0 - 1 + lx;
-            st[i] = *reinterpret_cast<const u32x4*>(P.in + ((size_t)min(max(gy, 0), Hi - 1) * Wi + min(max(gx, 0), Wi - 1)) * cin + g * 32 + sub * 8);
-            mask |= ((gy >= 0 && gy < Hi && gx >= 0 && gx < Wi) ? 1u : 0u) << i;
+        for (int i = 0; i < NLOAD; ++i) st[i] = *reinterpret_cast<const u32x4*>(P.in + (size_t)spix[i] * cin + g * 32 + sub8);
+        // MODE 2, one m-tile: the group's nine fragments, requested with the tile (32 -> 16 level: 64 -> 51 us; with two m-tiles the 72
+        // registers cost half the occupancy and the layers did not gain: those fetch their fragments between the MFMAs)
+        constexpr bool PRE = MODE == 2 && MT == 1;
+        u32x4 wt[PRE ? 9 : 1][MT];
+        const u32x4* __restrict__ wg = wbase + (size_t)g * 9 * wstride;
+        if constexpr (PRE) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) wt[t][m] = wg[(size_t)t * wstride + (size_t)m * 64];
         }
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) asm volatile("" : "+v"(st[i]));      // every request is out before the first value is touched
         if (g > 0) __syncthreads();
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
@@ -778,7 +814,6 @@ __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
         for (int r = 0; r < RW; ++r) {
             const int Yl = wave + 4 * r;                       // local input row of this n-tile
             if constexpr (MODE == 2) {
-                const u32x4* __restrict__ wg = wbase + (size_t)g * 9 * wstride;
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -793,7 +828,8 @@ __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
                                 const int ky = py ? 1 : (dy ? 2 : 0), kx = px ? 1 : (dx ? 2 : 0);
 #pragma unroll
                                 for (int m = 0; m < MT; ++m)
-                                    acc[r][2 * py + px][m] = mfma_bf16_k32(wg[(size_t)(ky * 3 + kx) * wstride + (size_t)m * 64], b, acc[r][2 * py + px][m]);
+                                    acc[r][2 * py + px][m] = mfma_bf16_k32(PRE ? wt[PRE ? ky * 3 + kx : 0][m] : wg[(size_t)(ky * 3 + kx) * wstride + (size_t)m * 64], b,
+                                                                          acc[r][2 * py + px][m]);
                             }
                         }
                     }
@@ -806,8 +842,7 @@ __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
                     for (int f = (dy ? 4 : 0); f < (dy ? 6 : 4); ++f) {
                         const int cls = dy ? (f & 1) : f;
 #pragma unroll
-                        for (int m = 0; m < MT; ++m)
-                            acc[r][cls][m] = mfma_bf16_k32(wbase[(size_t)f * wstride + (size_t)m * 64], b, acc[r][cls][m]);
+                        for (int m = 0; m < MT; ++m) acc[r][cls][m] = mfma_bf16_k32(wf[f][m], b, acc[r][cls][m]);
                     }
                 }
             }
@@ -816,8 +851,7 @@ __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
     // ---- accumulators -> bias, ReLU, bf16 -> output tile [16][32][OC] in LDS ----
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const int c = (mt0 + m) * 16 + kk * 4;
-        const f32x4 b4 = c < a.cout ? *reinterpret_cast<const f32x4*>(a.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 b4 = bias4[m];
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const int Yl = wave + 4 * r;
