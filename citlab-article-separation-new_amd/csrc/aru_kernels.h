@@ -1355,6 +1355,36 @@ __global__ __launch_bounds__(256) void avgpool2_c1_kernel(const PoolArgs a) {
     const int H = P.H, W = P.W, Wo = P.Wo;
     const size_t total = (size_t)P.Ho * Wo;
     const size_t base = (size_t)(blockIdx.x - P.blk_begin) * POOL_ITEMS;
+    // (32-bit index arithmetic where the tensor allows it: the 64-bit % and / of the general form cost ~200 instructions per pixel;
+    // the four window values of the thread's pixels are requested from clamped addresses before the first sum)
+    if (total < ((size_t)1 << 30) && (size_t)H * W < ((size_t)1 << 31)) {
+        float v[POOL_ITEMS / 256][4];
+        int cnt[POOL_ITEMS / 256];
+#pragma unroll
+        for (int k = 0; k < POOL_ITEMS / 256; ++k) {
+            const unsigned i = min((unsigned)base + k * 256 + threadIdx.x, (unsigned)total - 1);
+            const unsigned y = i / (unsigned)Wo, x = i - y * (unsigned)Wo;
+            const int y1 = min((int)(2 * y + 1), H - 1), x1 = min((int)(2 * x + 1), W - 1);
+            cnt[k] = ((2 * y + 1 < (unsigned)H) ? 2 : 1) * ((2 * x + 1 < (unsigned)W) ? 2 : 1);
+            v[k][0] = P.in[(2 * y) * (unsigned)W + 2 * x];
+            v[k][1] = P.in[(2 * y) * (unsigned)W + x1];
+            v[k][2] = P.in[(unsigned)y1 * (unsigned)W + 2 * x];
+            v[k][3] = P.in[(unsigned)y1 * (unsigned)W + x1];
+        }
+#pragma unroll
+        for (int k = 0; k < POOL_ITEMS / 256; ++k) {
+            const size_t i = base + k * 256 + threadIdx.x;
+            if (i >= total) break;
+            const unsigned y = (unsigned)i / (unsigned)Wo, x = (unsigned)i - y * (unsigned)Wo;
+            // same association as the general loop: ((v00 + v01) + v10) + v11 over the window values that exist
+            float s = v[k][0];
+            const bool xin = 2 * x + 1 < (unsigned)W, yin = 2 * y + 1 < (unsigned)H;
+            if (xin) s += v[k][1];
+            if (yin) { s += v[k][2]; if (xin) s += v[k][3]; }
+            P.out[i] = s / (float)cnt[k];
+        }
+        return;
+    }
     for (int k = 0; k < POOL_ITEMS / 256; ++k) {
         const size_t i = base + k * 256 + threadIdx.x;
         if (i >= total) break;

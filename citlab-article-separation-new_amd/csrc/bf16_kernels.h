@@ -1439,6 +1439,23 @@ __global__ __launch_bounds__(256) void chansumb_kernel(const PoolBArgs a) {
     const PoolBProb& P = a.p[pi];
     const size_t total = (size_t)P.H * P.W;
     const size_t base = (size_t)(blockIdx.x - P.blk_begin) * POOL_ITEMS;
+    if (a.C == 8) {
+        // the usual case: one 16-byte load per pixel, the thread's four pixels requested before the first sum (one round trip, not four)
+        u32x4 v[POOL_ITEMS / 256];
+#pragma unroll
+        for (int k = 0; k < POOL_ITEMS / 256; ++k) {
+            const size_t i = min(base + k * 256 + threadIdx.x, total - 1);
+            v[k] = *reinterpret_cast<const u32x4*>(P.in + i * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < POOL_ITEMS / 256; ++k) {
+            const size_t i = base + k * 256 + threadIdx.x;
+            if (i >= total) break;
+            const f32x4 lo = unpack_bf16x4(u32x2{v[k].x, v[k].y}), hi = unpack_bf16x4(u32x2{v[k].z, v[k].w});
+            P.out[i] = (((((((0.f + lo.x) + lo.y) + lo.z) + lo.w) + hi.x) + hi.y) + hi.z) + hi.w;
+        }
+        return;
+    }
     for (int k = 0; k < POOL_ITEMS / 256; ++k) {
         const size_t i = base + k * 256 + threadIdx.x;
         if (i >= total) break;
