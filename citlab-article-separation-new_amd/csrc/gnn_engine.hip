@@ -223,20 +223,19 @@ int forward_impl(asep_gnn* g, int N, int E, const int32_t* d_edges, const float*
     }
     // attention-weighted aggregation: edge index of every csr entry + per-edge interaction features / attention values
     int* att_eidx = nullptr;
+    int* att_widx = nullptr;
     float *att_M = nullptr, *att_A = nullptr, *att_S = nullptr;
     const size_t att_maxE = (size_t)(c.undirected_graph ? 2 : 1) * std::max(E, 1);
     if (c.attention_heads > 0) {
-        if ((size_t)N * N > 100000) {
-            set_error("asep_gnn_forward: attention-weighted aggregation on %d nodes: the reference splits the interactions into chunks of "
-                      "100000 / N target nodes (message_fn_chunk.py:77-78) and pairs attention values within a chunk; only the one-chunk "
-                      "case (N <= 316) is implemented", N);
-            return ASEP_ERR_UNSUPPORTED;
-        }
         att_eidx = (int*)g->pool.get(att_maxE * sizeof(int));
         att_M = (float*)g->pool.get(att_maxE * c.attention_heads * g->att_xd * sizeof(float));
         att_A = (float*)g->pool.get(att_maxE * c.attention_heads * sizeof(float));
         att_S = (float*)g->pool.get(att_maxE * c.attention_heads * sizeof(float));
+        att_widx = (int*)g->pool.get(att_maxE * sizeof(int));
         hipLaunchKernelGGL(edge_rank_kernel, dim3(N), dim3(64), 0, s, eb.colptr, eb.tsrc, eb.rowptr, eb.sorted, N, att_eidx);
+        const int chunk_nodes = std::max(1, 100000 / N);      // message_fn_chunk.py:77-78
+        hipLaunchKernelGGL(edge_chunk_rank_kernel, dim3(cdiv(N, chunk_nodes)), dim3(256), 0, s, eb.sorted, eb.rowptr, eb.colptr, N, chunk_nodes,
+                           att_widx);
     }
     float* upad = nullptr;
     const int mode = g->use_step ? g->mode : STEP_GENERIC;
@@ -278,7 +277,7 @@ int forward_impl(asep_gnn* g, int N, int E, const int32_t* d_edges, const float*
             const size_t lds = ((size_t)g->K + std::max(g->Hm, c.attention_hidden)) * sizeof(float);
             hipLaunchKernelGGL(gnn_msg_att_kernel, dim3(N), dim3(256), lds, s, aa);
             hipLaunchKernelGGL(gnn_att_softmax_kernel, dim3(N), dim3(64), 0, s, eb.colptr, att_eidx, att_A, c.attention_heads, (int)att_maxE, att_S);
-            hipLaunchKernelGGL(gnn_att_aggregate_kernel, dim3(N), dim3(64), 0, s, eb.colptr, att_eidx, att_S, att_M, c.attention_heads,
+            hipLaunchKernelGGL(gnn_att_aggregate_kernel, dim3(N), dim3(64), 0, s, eb.colptr, att_eidx, att_widx, att_S, att_M, c.attention_heads,
                                g->att_xd, (int)att_maxE, c.attention_merge, x);
             LstmGenArgs la{};
             la.x = x; la.h_in = h[cur]; la.c_in = cs[cur]; la.u = d_u;

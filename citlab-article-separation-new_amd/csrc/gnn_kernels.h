@@ -586,6 +586,36 @@ __global__ __launch_bounds__(64) void edge_rank_kernel(const int* __restrict__ c
     }
 }
 
+// Interaction chunks (message_fn_chunk.py:76-110): the reference runs the message function once per chunk of S = max(1, 100000 / N)
+// target nodes on the interactions that end in the chunk.  Inside a chunk the value pairing above is between the chunk's
+// (to, from)-sorted list -- csr positions tptr[c S] ... -- and its (from, to)-sorted list -- the chunk's edges in edge-index order.
+// widx[e] = tptr[c S] + (number of edges e' < e that end in chunk c): the csr position whose soft-max value edge e is multiplied
+// with (one chunk: widx[e] = e).  One workgroup per chunk scans the edge list.
+__global__ __launch_bounds__(256) void edge_chunk_rank_kernel(const int32_t* __restrict__ sorted_edges, const int* __restrict__ rowptr,
+                                                            const int* __restrict__ colptr, int N, int S, int* __restrict__ widx) {
+    __shared__ int wsum[4];
+    __shared__ int carry;
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Etot = rowptr[N], lo = c * S, hi = min(N, lo + S);
+    if (tid == 0) carry = colptr[lo];
+    __syncthreads();
+    for (int e0 = 0; e0 < Etot; e0 += 256) {
+        const int e = e0 + tid;
+        const int t = e < Etot ? sorted_edges[2 * e + 1] : -1;
+        const bool in = t >= lo && t < hi;
+        const unsigned long long m = __ballot(in);
+        const int before = __popcll(m & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int base = carry;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        if (in) widx[e] = base + before;
+        __syncthreads();
+        if (tid == 0) carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+}
+
 constexpr int GNN_MAX_HEADS = 8;
 struct AttHeadW { const float *W1, *b1, *W2, *b2, *A1, *ab1, *A2, *ab2; };
 struct MsgAttArgs {
@@ -667,11 +697,11 @@ __global__ __launch_bounds__(64) void gnn_att_softmax_kernel(const int* __restri
         for (int p = beg + lane; p < end; p += 64) S[(size_t)hdi * Etot + p] = expf(Ah[eidx[p]] - mx) / den;
     }
 }
-// x[t] = merge over heads of sum over in-edges e of S[head][e] * M[e][head]  -- S indexed by the EDGE index (the pairing above);
+// x[t] = merge over heads of sum over in-edges e of S[head][widx[e]] * M[e][head]  -- the pairing above (widx[e] = e in the one-chunk case);
 // merge 'concat' (heads * xd = I columns) or 'average' (xd = I, mean over heads)
-__global__ __launch_bounds__(64) void gnn_att_aggregate_kernel(const int* __restrict__ tptr, const int* __restrict__ eidx, const float* __restrict__ S,
-                                                              const float* __restrict__ M, int heads, int xd, int Etot, int average,
-                                                              float* __restrict__ x) {
+__global__ __launch_bounds__(64) void gnn_att_aggregate_kernel(const int* __restrict__ tptr, const int* __restrict__ eidx, const int* __restrict__ widx,
+                                                              const float* __restrict__ S, const float* __restrict__ M, int heads, int xd, int Etot,
+                                                              int average, float* __restrict__ x) {
     const int t = blockIdx.x;
     const int beg = tptr[t], end = tptr[t + 1];
     const int I = average ? xd : heads * xd;
@@ -680,13 +710,13 @@ __global__ __launch_bounds__(64) void gnn_att_aggregate_kernel(const int* __rest
         if (average) {
             for (int hdi = 0; hdi < heads; ++hdi) {
                 float s = 0.f;
-                for (int p = beg; p < end; ++p) { const int e = eidx[p]; s = fmaf(S[(size_t)hdi * Etot + e], M[(size_t)e * heads * xd + hdi * xd + o], s); }
+                for (int p = beg; p < end; ++p) { const int e = eidx[p]; s = fmaf(S[(size_t)hdi * Etot + widx[e]], M[(size_t)e * heads * xd + hdi * xd + o], s); }
                 acc += s;
             }
             acc /= (float)heads;
         } else {
             const int hdi = o / xd;
-            for (int p = beg; p < end; ++p) { const int e = eidx[p]; acc = fmaf(S[(size_t)hdi * Etot + e], M[(size_t)e * heads * xd + o], acc); }
+            for (int p = beg; p < end; ++p) { const int e = eidx[p]; acc = fmaf(S[(size_t)hdi * Etot + widx[e]], M[(size_t)e * heads * xd + o], acc); }
         }
         x[(size_t)t * I + o] = acc;
     }

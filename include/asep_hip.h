@@ -138,8 +138,8 @@ typedef struct asep_gnn_cfg {
                                       width) rows); x = the node features AS FED (before compress_input) */
     int32_t attention_heads;       /* message_fn_chunk.py:35-41 use_attention: 0 = off (degree-normalised sum, the reference's default);
                                       k >= 1 = learned attention with k heads (head_<i>/calculation_interaction_features/... and
-                                      head_<i>/calculation_unnormalized_attention_values/... MLPs).  Graphs of at most 316 nodes (one
-                                      interaction chunk, message_fn_chunk.py:77-78) */
+                                      head_<i>/calculation_unnormalized_attention_values/... MLPs); the reference's chunking of the
+                                      interactions by target-node ranges (message_fn_chunk.py:76-110) is reproduced */
     int32_t attention_merge;       /* multihead_attention_merge_type: 0 = 'concat' (x_dim = interaction_dim / heads), 1 = 'average' */
     int32_t attention_hidden;      /* num_hidden_units_attention_fct (one layer, 16) */
 } asep_gnn_cfg;

@@ -132,7 +132,16 @@ def forward(num_nodes, edges, node_feat, edge_feat, relations, w, cfg, dtype=np.
                                      + w[f"{att}/fully_connected_layer_h{i}/bias"], 0)
                 a_un = (hid @ w[f"{att}/fully_connected_logit_layer_out/weights"]
                         + w[f"{att}/fully_connected_logit_layer_out/bias"])[:, 0]                 # :446 squeeze
-                weights_e = _transposed_sparse_softmax_values(a_un, frm, to, N).astype(dtype)     # :203-211
+                # :76-110: the message function runs once per CHUNK of 100000 // N target nodes (all of them for N <= 316) on the
+                # interactions that end in the chunk, and the per-chunk results are added; the soft-max rows (in-edges of a target)
+                # are complete inside a chunk, but the value pairing below happens among the chunk's interactions only
+                weights_e = np.zeros(len(to), np.float64)
+                chunk_nodes = max(1, 100000 // N)
+                for c0 in range(0, N, chunk_nodes):
+                    sel = np.nonzero((to >= c0) & (to < c0 + chunk_nodes))[0]           # keeps the (from, to) order
+                    if len(sel):
+                        weights_e[sel] = _transposed_sparse_softmax_values(a_un[sel], frm[sel], to[sel], N)    # :203-211
+                weights_e = weights_e.astype(dtype)
             else:
                 weights_e = (1.0 / deg[to]).astype(dtype) if len(to) else np.zeros(0, dtype)      # :369-386
             xk = np.zeros((N, m.shape[1]), dtype)

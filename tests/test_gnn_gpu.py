@@ -175,19 +175,19 @@ def test_hyper_parameters_other_than_the_defaults(kw, mode):
     graph.close()
 
 
-def test_attention_nets_beyond_one_interaction_chunk_are_refused():
-    """message_fn_chunk.py:77-78: the reference processes the interactions in chunks of 100000 // N target nodes and pairs the
-    attention values within a chunk; the engine implements the one-chunk case and says so beyond it"""
-    from citlab_article_separation_new_amd import _lib, gnn_io
-    cfg, w, graph = _setup(seed=5, use_attention=True)
-    rng = np.random.default_rng(1)
-    N = 317
-    edges, u, ef = _random_graph(rng, N, 400)
-    with pytest.raises(_lib.AsepError, match="one-chunk"):
-        gnn_io.gnn_forward(graph, N, edges, u, ef)
-    N = 316
-    edges, u, ef = _random_graph(rng, N, 400)
-    assert gnn_io.gnn_forward(graph, N, edges, u, ef).shape == (N * N, 2)
+@pytest.mark.parametrize("N,E,undirected", [(317, 900, True), (400, 2500, True), (523, 1500, False)])
+def test_attention_nets_on_graphs_of_several_interaction_chunks(N, E, undirected):
+    """message_fn_chunk.py:76-110: the reference runs the message function per chunk of 100000 // N target nodes and pairs the attention
+    values with the interactions INSIDE a chunk; beyond 316 nodes there are several chunks (N = 400: 250 nodes per chunk)"""
+    from citlab_article_separation_new_amd import gnn_io
+    from oracle import gnn_oracle
+    cfg, w, graph = _setup(seed=5, use_attention=True, num_attention_heads=2, undirected_graph=undirected)
+    rng = np.random.default_rng(N)
+    edges, u, ef = _random_graph(rng, N, E)
+    rel = rng.integers(0, N, size=(3000, 2)).astype(np.int32)
+    probs = gnn_io.gnn_forward(graph, N, edges, u, ef, rel)
+    ref = gnn_oracle.forward(N, edges, u, ef, rel, w, cfg)
+    assert probs.shape == ref.shape and float(np.abs(probs - ref).max()) <= PROB_TOL
     graph.close()
 
 
