@@ -66,6 +66,7 @@ struct asep_aru {
     bf16_t* d_r8b_up_w1 = nullptr;   // conv1 of unet_up_0 [3 ky][2 halves][64][8]
     bf16_t* d_r8f_down_w1 = nullptr; // conv1 of unet_down_0 as ONE pair fragment [64][8] (k = window row / column, res8f_kernel)
     bool use_r8f = true;             // ASEP_BF_R8F=0: res8b_kernel for every tile
+    bool use_res32 = true;           // ASEP_BF_RES32=0: the 32-channel residual tails layer by layer (convb_kernel)
     bf16_t* d_r8b_up_w = nullptr;    // [3][3][64][8]
     float* d_r8b_up_b = nullptr;     // [3][8]
     float* d_r8b_up_b1 = nullptr;    // [8]
@@ -940,7 +941,8 @@ int pack_resb(asep_aru* m, const std::map<std::string, HostTensor>& blob, const 
         if (w.dims.size() != 4 || w.dims[0] != 3 || w.dims[1] != 3 || w.dims[2] != C || w.dims[3] != C) return ASEP_OK;   // not this shape: layer-by-layer
         auto W = [&](int tap, int ci, int co) -> float { return (ci < C && co < C) ? w.data[((size_t)tap * C + ci) * C + co] : 0.f; };
         int nch = 0;
-        pack_frags_conv(C == 8 ? 0 : 1, 3, 3, C, 1, W, pk, &nch);
+        if (C == 32) pack_frags_conv(2, 3, 3, 32, 2, W, pk, &nch);          // [9 taps][2 m-tiles][64 lanes] (res32_tail_kernel)
+        else pack_frags_conv(C == 8 ? 0 : 1, 3, 3, C, 1, W, pk, &nch);
         br.insert(br.end(), bi->second.data.begin(), bi->second.data.end());
     }
     asep_aru::ResB rb;
@@ -1209,7 +1211,16 @@ TL run_resb_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled)
         a.wpk = (const u32x4*)rb.d_w; a.bias = rb.d_b;
         TL sub(t.begin() + b0, t.begin() + b1);
         const std::string what = scope + " (3xconvR+add" + (pooled ? "+pool) " : ") ") + dims_of(sub);
-        if (rb.C == 16 && m->use_r8f) {                      // lean form for interior tiles, general form for border tiles, one launch
+        if (rb.C == 32) {
+            static bool attr = false;
+            if (!attr) {
+                ASEP_HIP_CHECK_THROW(hipFuncSetAttribute((const void*)res32_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Res32Layout::BYTES));
+                attr = true;
+            }
+            ProfScope ps(m, "res32_tail_kernel", flops, what);
+            a.ntiles = tiles;
+            hipLaunchKernelGGL(res32_tail_kernel, dim3(std::min(tiles, m->num_cus)), dim3(512), Res32Layout::BYTES, m->stream, a);
+        } else if (rb.C == 16 && m->use_r8f) {                      // lean form for interior tiles, general form for border tiles, one launch
             ProfScope ps(m, "res16f_kernel", flops, what);
             hipLaunchKernelGGL(res16f_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
         } else {
@@ -1749,6 +1760,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_BF_W8")) m->bf_w8 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_R8B")) m->use_r8b = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_R8F")) m->use_r8f = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_BF_RES32")) m->use_res32 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_LANES")) m->num_lanes = std::max(1, std::min(4, atoi(e)));
     for (int l = 0; l < m->num_lanes; ++l) {
         std::unique_ptr<asep_aru::Lane> L(new asep_aru::Lane());
@@ -1801,7 +1813,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (!rc && m->bf16 && cfg->res_depth == 3)
         for (int l = 0; l < n && !rc; ++l) {
             const int f = cfg->feat_root << l;
-            if (f != 8 && f != 16) continue;
+            if (f != 8 && f != 16 && !(f == 32 && m->use_res32)) continue;
             rc = pack_resb(m.get(), blob, "aru_net/featMapG/unet_down_" + std::to_string(l), f);
             if (!rc && l < n - 1) rc = pack_resb(m.get(), blob, "aru_net/featMapG/unet_up_" + std::to_string(l), f);
         }

@@ -367,6 +367,7 @@ struct ResBArgs {
     int nprob;
     const u32x4* wpk;      // [3 convs][CPC chunks][64 lanes] x 16 bytes
     const float* bias;     // [3][C]
+    int ntiles;            // res32_tail_kernel: all problems' tiles (its resident blocks walk them)
 };
 constexpr int RB_TH = 16, RB_TW = 32;
 
@@ -515,6 +516,213 @@ __global__ __launch_bounds__(256, C == 8 ? 4 : 3) void resb_tail_kernel(const Re
     const int tile = blockIdx.x - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
     resb_tail_tile<C>(a, P, tx * RB_TW, ty * RB_TH, lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// res32_tail_kernel: the tail of a residual block at 32 channels (level 2) in one kernel -- resb_tail_tile's general form (flattened
+// n-tiles of 16 pixels over the stage regions, zeros outside the image) with two m-tiles, K chunk = one tap x 32 channels, the
+// regions stored as two planes of 16 channels (32 bytes per pixel: a lane's B fragment is one conflict-free ds_read_b128, as in
+// convb_kernel MODE 2), eight waves per block over 100 KB of LDS (one block per CU).  Layer by layer these three convolutions
+// run at the HBM rate (the 32-channel layers move 563 MB per 4-page launch at 4.7 TB/s, lesson 22); fused they read t and write
+// the output once.  An n-tile carries 18 MFMAs, so the general form's index arithmetic per n-tile is affordable here (at 8 / 16
+// channels it was not: res8f / res16f).
+// ------------------------------------------------------------------------------------------------
+struct Res32Layout {
+    static constexpr int C = 32, SLACK = 4;
+    static constexpr int H0 = RB_TH + 6, W0 = RB_TW + 6, H1 = RB_TH + 4, W1 = RB_TW + 4, H2 = RB_TH + 2, W2 = RB_TW + 2;
+    static constexpr int P0 = (H0 * W0 + SLACK) * 32, P1 = (H1 * W1 + SLACK) * 32;     // bytes of one 16-channel plane of region 0 / 1
+    static constexpr int WB = 3 * 9 * 2 * 64 * 16;            // the three convs' A fragments: [conv][tap][m-tile][lane] x 16 bytes = 54 KB
+    static constexpr int W_OFF = 2 * P0 + 2 * P1, BYTES = W_OFF + WB;
+};
+// One resident block per CU walks the tiles blockIdx.x, + gridDim.x, ...: the A fragments of the three convolutions are copied to LDS
+// once (LDS-DMA) and a stage's 18 fragments come from there into registers (as one-shot blocks fetching them from L2 per stage the
+// kernel ran at the speed of the three separate layers: with one 100 KB block per CU nothing covered the per-stage round trips and
+// the 53 KB fill); the next tile's window is requested into registers right after the current one went to LDS.
+__global__ __launch_bounds__(512, 1) void res32_tail_kernel(const ResBArgs a) {
+    typedef Res32Layout L;
+    constexpr int C = 32, NW = 8, NTH = 512;
+    constexpr int H0 = L::H0, W0 = L::W0, H1 = L::H1, W1 = L::W1, H2 = L::H2, W2 = L::W2, P0 = L::P0, P1 = L::P1, SLACK = L::SLACK;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* const r0 = lds;                            // region 0 (22 x 38), later stage 2's result (18 x 34): planes at +0, +P0
+    unsigned char* const r1 = lds + 2 * P0;                   // region 1 (20 x 36): planes at +0, +P1
+    const unsigned char* const wl = lds + L::W_OFF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    if ((int)blockIdx.x >= a.ntiles) return;
+
+    // ---- once per block: A fragments -> LDS, biases -> registers, slack pixels zeroed ----
+    {
+        constexpr int NWU = L::WB / 16;                       // 16-byte units: a multiple of 64
+        for (int u0 = wave * 64; u0 < NWU; u0 += NTH)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.wpk + u0 + lane),
+                                             (__attribute__((address_space(3))) void*)(lds + L::W_OFF + u0 * 16), 16, 0, 0);
+    }
+    f32x4 biasw[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) biasw[t][m] = *reinterpret_cast<const f32x4*>(a.bias + t * C + m * 16 + kk * 4);
+    if (tid < SLACK * 4) {                                    // slack pixels behind the regions: read by clamped tail lanes, must be finite
+        const int pl = (tid >> 1) & 1, off = (tid >> 2) * 32 + (tid & 1) * 16;
+        *reinterpret_cast<u32x4*>(r0 + pl * P0 + H0 * W0 * 32 + off) = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(r1 + pl * P1 + H1 * W1 * 32 + off) = u32x4{0u, 0u, 0u, 0u};
+    }
+    // byte offset of the lane's share of tap t (8 of the pixel's 32 channels: plane kk >> 1, half kk & 1) of a 3x3 window in a region
+    // WIN pixels wide whose planes are PL bytes apart
+    auto tap_off = [&](int t, int WIN, int PL) { return ((t / 3) * WIN + (t % 3)) * 32 + (kk & 1) * 16 + (kk >> 1) * PL; };
+    u32x4 af[9][2];
+    auto stage_weights = [&](int st) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) af[t][m] = *reinterpret_cast<const u32x4*>(wl + (((st * 9 + t) * 2 + m) * 64 + lane) * 16);
+    };
+
+    // ---- the tile walk; the halo tile of relu(t) of the NEXT tile is requested while the current one is computed ----
+    constexpr int NU = H0 * W0 * 4, NLOAD = (NU + NTH - 1) / NTH;
+    const int sub = tid & 3;                                  // (512 is a multiple of 4: the channel block is the same for all slots)
+    u32x4 st[NLOAD];
+    unsigned mask = 0;
+    auto locate = [&](int t, int& pi, int& x0, int& y0) {
+        pi = 0;
+        while (pi + 1 < a.nprob && t >= a.p[pi + 1].tile_begin) ++pi;
+        const int tile = t - a.p[pi].tile_begin;
+        const int ty = tile / a.p[pi].tiles_x, tx = tile - ty * a.p[pi].tiles_x;
+        x0 = tx * RB_TW; y0 = ty * RB_TH;
+    };
+    auto request = [&](int pi, int x0, int y0) {
+        const ResBProb& P = a.p[pi];
+        mask = 0;
+        int spix[NLOAD];
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int u = min(tid + i * NTH, NU - 1);
+            const int pix = u >> 2;
+            const int ly = pix / W0, lx = pix - ly * W0;
+            const int gy = y0 - 3 + ly, gx = x0 - 3 + lx;
+            spix[i] = min(max(gy, 0), P.H - 1) * P.W + min(max(gx, 0), P.W - 1);
+            mask |= ((gy >= 0 && gy < P.H && gx >= 0 && gx < P.W) ? 1u : 0u) << i;
+        }
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) st[i] = *reinterpret_cast<const u32x4*>(P.t + (size_t)spix[i] * C + sub * 8);
+    };
+    __syncthreads();                                          // the fragments (copied by all waves) are in LDS
+    int t = blockIdx.x, pi, x0, y0;
+    locate(t, pi, x0, y0);
+    request(pi, x0, y0);
+    while (true) {
+    const ResBProb& P = a.p[pi];
+    const int H = P.H, W = P.W;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+        const int u = tid + i * NTH;
+        if (u < NU)
+            *reinterpret_cast<u32x4*>(r0 + (sub >> 1) * P0 + (u >> 2) * 32 + (sub & 1) * 16) = ((mask >> i) & 1u) ? relu_bf16x8(st[i]) : u32x4{0u, 0u, 0u, 0u};
+    }
+    const int xc = x0, yc = y0;                               // this tile; (t, pi, x0, y0) move on to the next one
+    t += gridDim.x;
+    const bool more = t < a.ntiles;
+    if (more) { locate(t, pi, x0, y0); request(pi, x0, y0); }
+    // residual operand of stage 3 (pre-ReLU t of the wave's two output units): requested now, used at the very end (fetched inside
+    // stage 3 each unit waited for an HBM round trip behind its MFMAs)
+    u32x2 resv[2][2][2];                                      // [unit][row][m-tile]
+#pragma unroll
+    for (int ui = 0; ui < 2; ++ui) {
+        const int u = wave + ui * NW, oy = 2 * (u >> 1), ox = (u & 1) * 16 + j;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const size_t p = ((size_t)min(yc + oy + r, H - 1) * W + min(xc + ox, W - 1)) * C + kk * 4;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) resv[ui][r][m] = *reinterpret_cast<const u32x2*>(P.t + p + m * 16);
+        }
+    }
+    stage_weights(0);
+    __syncthreads();
+
+    // ---- stages 1 and 2: LDS -> LDS ----
+    auto mid_stage = [&](const unsigned char* src, int WIN, int SPL, unsigned char* dst, int DPL, int HO, int WO, int halo, int sg) {
+        const int npix = HO * WO;
+        for (int tl = wave; tl * 16 < npix; tl += NW) {
+            const int q = tl * 16 + j, qc = min(q, npix - 1);
+            const int oy = qc / WO, ox = qc - oy * WO;
+            const unsigned char* base = src + (oy * WIN + ox) * 32;
+            u32x4 bfr[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) bfr[k] = *reinterpret_cast<const u32x4*>(base + tap_off(k, WIN, SPL));
+            f32x4 acc[2] = {biasw[sg][0], biasw[sg][1]};
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m] = mfma_bf16_k32(af[k][m], bfr[k], acc[m]);
+            const int gy = yc - halo + oy, gx = xc - halo + ox;
+            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            if (q < npix) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const u32x2 pk = pack_bf16x4(acc[m]);
+                    *reinterpret_cast<u32x2*>(dst + m * DPL + q * 32 + kk * 8) = inside ? u32x2{relu_bf16x2(pk.x), relu_bf16x2(pk.y)} : u32x2{0u, 0u};
+                }
+            }
+        }
+    };
+    mid_stage(r0, W0, P0, r1, P1, H1, W1, 2, 0);
+    stage_weights(1);
+    __syncthreads();
+    mid_stage(r1, W1, P1, r0, P0, H2, W2, 1, 1);              // region 0 (the input tile) is dead: its planes take stage 2's result
+    stage_weights(2);
+    __syncthreads();
+
+    // ---- stage 3: LDS -> registers -> HBM.  Unit = (row pair, 16-column block): both rows in registers for the pool ----
+    {
+        const int Wp = (W + 1) >> 1;
+        static_assert((RB_TH / 2) * 2 == 2 * NW, "two output units per wave");
+#pragma unroll
+        for (int ui = 0; ui < 2; ++ui) {
+            const int u = wave + ui * NW;
+            const int rp = u >> 1, cb = u & 1;
+            const int oy = 2 * rp, ox = cb * 16 + j;
+            f32x4 acc2[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const unsigned char* base = r0 + ((oy + r) * W2 + ox) * 32;
+                u32x4 bfr[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) bfr[k] = *reinterpret_cast<const u32x4*>(base + tap_off(k, W2, P0));
+                acc2[r][0] = biasw[2][0]; acc2[r][1] = biasw[2][1];
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc2[r][m] = mfma_bf16_k32(af[k][m], bfr[k], acc2[r][m]);
+            }
+            const int x = xc + ox;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                u32x2 pk[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int y = yc + oy + r;
+                    const size_t p = ((size_t)min(y, H - 1) * W + min(x, W - 1)) * C + m * 16 + kk * 4;
+                    const f32x4 v = acc2[r][m] + unpack_bf16x4(resv[ui][r][m]);
+                    const u32x2 q = pack_bf16x4(v);
+                    pk[r] = u32x2{relu_bf16x2(q.x), relu_bf16x2(q.y)};
+                    if (y < H && x < W) *reinterpret_cast<u32x2*>(P.out + p) = pk[r];
+                }
+                if (P.pool) {
+                    // 2 x 2 max on the packed values (non-negative bf16 order like their bit patterns); ceil mode at the right / bottom border
+                    const int y = yc + oy;
+                    u32x2 mm = (y + 1 < H) ? u32x2{pkmax_u16(pk[0].x, pk[1].x), pkmax_u16(pk[0].y, pk[1].y)} : pk[0];
+                    const u32x2 nb = u32x2{__float_as_uint(lane_xor1(__uint_as_float(mm.x))), __float_as_uint(lane_xor1(__uint_as_float(mm.y)))};
+                    if (x + 1 < W) mm = u32x2{pkmax_u16(mm.x, nb.x), pkmax_u16(mm.y, nb.y)};
+                    if ((j & 1) == 0 && y < H && x < W)
+                        *reinterpret_cast<u32x2*>(P.pool + ((size_t)(y >> 1) * Wp + (x >> 1)) * C + m * 16 + kk * 4) = mm;
+                }
+            }
+        }
+    }
+    if (!more) break;
+    __syncthreads();                                          // stage 3's readers of region 0 are done: the next tile may overwrite it
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -123,6 +123,30 @@ def test_medium_pages_interior_and_border_tiles(H, W, graph):
     g.close()
 
 
+@pytest.mark.parametrize("H,W", [(203, 310), (64, 96), (37, 53)])
+def test_bf16_fused_level2_tail_equals_the_layer_by_layer_form(H, W, monkeypatch):
+    """res32_tail_kernel (three 32 -> 32 convolutions + residual + ReLU (+ pool) of a level-2 block in one persistent kernel) rounds
+    to bf16 at the same points as the three convb_kernel launches it replaces (ASEP_BF_RES32=0) and sums its K chunks in the same
+    order: the level-2 end points -- interior and border tiles, all three scales -- and everything behind them must be identical."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    cfg = AruConfig(compute_dtype="bf16")
+    w = init_aru_weights(cfg, 99, bias_jitter=0.05, logit_scale=0.05)
+    img = np.random.default_rng(H).random((H, W), dtype=np.float32)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ASEP_BF_RES32", flag)            # read when the engine is created
+        g = helper.AruGraph(w, cfg)
+        out = helper.get_net_output(img, g, "0")
+        res[flag] = (out, {n: helper.get_endpoint(g, n) for n in ("scale_0_unet_down_2_conv", "scale_1_unet_down_2_conv",
+                                                                 "scale_2_unet_up_2_conv", "scale_0_unet_up_2_conv", "scale_0_unet_down_3_conv")})
+        g.close()
+    for n in res["1"][1]:
+        assert np.array_equal(res["1"][1][n], res["0"][1][n]), n
+    assert np.array_equal(res["1"][0], res["0"][0])
+
+
 def test_bf16_variant_medium_page_within_stated_tolerance():
     """bf16 MFMA operands (fp32 accumulation and storage): direct kernels up to 64 channels, Winograd at 128; the stated
     tolerance of the bf16 variant is 2e-2 on the probabilities."""
