@@ -173,9 +173,10 @@ def e2e_files(args, dev_index):
             "first_page_s": round(first, 2), "steady_pages_per_s": round((n - 1) / max(dt - first, 1e-9), 2),
             "page_xml_written": n_xml, "gpu_owner_device_stage_share": round(proc.device_seconds / dt, 3),
             "gpu_owner_waiting_for_decode_share": round(proc.wait_seconds / dt, 3),
+            "gpu_owner_ring_chaining_share": round(proc.host_seconds / dt, 3),
             "dtype": args.dtype,
             "note": f"separator CLI path, --fixed_height {H} (net on the full {W}x{H} page): PNG files -> {workers} decode / XML "
-                    f"worker processes around ONE GPU owner -> PAGE-XML files; worker start-up (first_page_s: process spawn, page-locking of the decode slots, first decode) inside pages_per_s, excluded from "
+                    f"worker processes around ONE GPU owner (one page behind the GPU: page n+1 is uploaded and queued before page n's segments are waited for; device_stage = upload + queueing + waiting for results) -> PAGE-XML files; worker start-up (first_page_s: process spawn, page-locking of the decode slots, first decode) inside pages_per_s, excluded from "
                     f"steady_pages_per_s; "
                     f"box has {os.cpu_count()} logical CPUs"}
 
@@ -487,7 +488,10 @@ def main():
             iso, n_prof, main_calls = kernel_pass(1)
         if args.kernel_timing in ("both", "in-situ"):
             situ, n_prof, main_calls = kernel_pass(3)
-        base = iso or situ                          # the dominant kernel is chosen on the isolated times when both exist
+        # the dominant kernel = the largest summed launch time of the real schedule, i.e. the first row of rocprofv3's
+        # kernel_stats.csv of the same command (the isolated totals of the two leading families lie within 1 % of each other
+        # and would let the choice flip from run to run)
+        base = situ or iso
         kernels = sorted(base.values(), key=lambda k: -k["total_ms"])
         dom = next((k for k in kernels if k["kernel"] == args.dominant), kernels[0])
         d_iso, d_situ = (iso or {}).get(dom["kernel"]), (situ or {}).get(dom["kernel"])

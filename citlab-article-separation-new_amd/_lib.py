@@ -82,6 +82,10 @@ SIGNATURES = {
                                           C.c_int, _P, _P, _P]),
     "asep_post_boundary_segments": (C.c_long, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_long]),
     "asep_post_boundary_segments_dev": (C.c_long, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_long, _P]),
+    "asep_post_boundary_segments_enqueue_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_long, _P,
+                                                          _P]),
+    "asep_prep_gray_u8_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "asep_post_box_sums_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "asep_swt_distance_transform": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.POINTER(C.c_int32), _P]),
     "asep_swt_distance_transform_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "asep_swt_line_features": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),

@@ -525,6 +525,28 @@ long asep_post_boundary_segments_dev(asep_post* p, const uint8_t* d_mask, int H,
     POST_GUARD_END
 }
 
+int asep_post_boundary_segments_enqueue_dev(asep_post* p, const uint8_t* d_mask, int H, int W, int value,
+                                            int32_t* d_starts, int32_t* d_ends, long capacity,
+                                            unsigned long long* d_totals, void* stream) {
+    if (!p || !d_mask || !d_totals || capacity < 0 || (capacity > 0 && (!d_starts || !d_ends))) {
+        set_error("asep_post_boundary_segments_enqueue_dev: bad arguments");
+        return ASEP_ERR_ARG;
+    }
+    if (int rc = check_image("asep_post_boundary_segments_enqueue_dev", H, W)) return rc;
+    if ((size_t)(H + 1) * (W + 1) * 4 > 0x7fffffffull) {
+        set_error("asep_post_boundary_segments_enqueue_dev: image too large for 32-bit vertex keys");
+        return ASEP_ERR_UNSUPPORTED;
+    }
+    POST_GUARD_BEGIN
+    hipStream_t st = (hipStream_t)stream;
+    ASEP_HIP_CHECK(hipMemsetAsync(d_totals, 0, 2 * sizeof(unsigned long long), st));
+    post_boundary_segments_kernel<<<blocks_for((size_t)H * W), 256, 0, st>>>(d_mask, H, W, value, d_starts, d_ends,
+                                                                             (unsigned long long)capacity, d_totals);
+    ASEP_HIP_CHECK(hipGetLastError());
+    return ASEP_OK;
+    POST_GUARD_END
+}
+
 long asep_post_boundary_segments(asep_post* p, const uint8_t* mask, int H, int W, int value, int32_t* out_starts,
                                  int32_t* out_ends, long capacity) {
     if (!p || !mask || capacity < 0 || (capacity > 0 && (!out_starts || !out_ends))) {
@@ -605,6 +627,51 @@ int asep_swt_line_features_dev(asep_post* p, const uint8_t* d_swt, int H, int W,
     ASEP_HIP_CHECK(hipMemcpyAsync(out_height, d_h, (size_t)n_lines * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     ASEP_HIP_CHECK(hipMemcpyAsync(out_flag, d_f, (size_t)n_lines * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     ASEP_HIP_CHECK(hipStreamSynchronize(st));
+    return ASEP_OK;
+    POST_GUARD_END
+}
+
+int asep_prep_gray_u8_dev(asep_post* p, const uint8_t* d_bgr, int H, int W, uint8_t* d_out, void* stream) {
+    if (!p || !d_bgr || !d_out) {
+        set_error("asep_prep_gray_u8_dev: null argument");
+        return ASEP_ERR_ARG;
+    }
+    if (int rc = check_image("asep_prep_gray_u8_dev", H, W)) return rc;
+    POST_GUARD_BEGIN
+    const size_t n = (size_t)H * W;
+    post_gray_u8_kernel<<<blocks_for((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(d_bgr, n, d_out);
+    ASEP_HIP_CHECK(hipGetLastError());
+    return ASEP_OK;
+    POST_GUARD_END
+}
+
+int asep_post_box_sums_dev(asep_post* p, const uint8_t* d_img, int H, int W, int pix_stride, int channel, int n_boxes,
+                           const int32_t* boxes, int64_t* out_sums, void* stream) {
+    if (!p || !d_img || n_boxes < 0 || (n_boxes > 0 && (!boxes || !out_sums)) || pix_stride < 1 || channel < 0 ||
+        channel >= pix_stride) {
+        set_error("asep_post_box_sums_dev: bad arguments");
+        return ASEP_ERR_ARG;
+    }
+    if (int rc = check_image("asep_post_box_sums_dev", H, W)) return rc;
+    if (n_boxes == 0) return ASEP_OK;
+    POST_GUARD_BEGIN
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<PostBox> hb(n_boxes);
+    for (int i = 0; i < n_boxes; ++i) {
+        // numpy slicing semantics of img[y0:y1, x0:x1] for non-negative bounds: clipped to the image
+        PostBox b{boxes[4 * i + 0], boxes[4 * i + 1], boxes[4 * i + 2], boxes[4 * i + 3]};
+        b.x0 = std::min(std::max(b.x0, 0), W); b.x1 = std::min(std::max(b.x1, 0), W);
+        b.y0 = std::min(std::max(b.y0, 0), H); b.y1 = std::min(std::max(b.y1, 0), H);
+        hb[i] = b;
+    }
+    p->pool.begin();
+    PostBox* d_boxes = (PostBox*)p->pool.get((size_t)n_boxes * sizeof(PostBox));
+    unsigned long long* d_sums = (unsigned long long*)p->pool.get((size_t)n_boxes * sizeof(unsigned long long));
+    ASEP_HIP_CHECK(hipMemcpyAsync(d_boxes, hb.data(), (size_t)n_boxes * sizeof(PostBox), hipMemcpyHostToDevice, st));
+    post_box_sums_kernel<<<n_boxes, 256, 0, st>>>(d_img, W, pix_stride, channel, d_boxes, d_sums);
+    ASEP_HIP_CHECK(hipGetLastError());
+    ASEP_HIP_CHECK(hipMemcpyAsync(out_sums, d_sums, (size_t)n_boxes * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    ASEP_HIP_CHECK(hipStreamSynchronize(st));          // hb is stack-owned and the sums are the caller's next input
     return ASEP_OK;
     POST_GUARD_END
 }

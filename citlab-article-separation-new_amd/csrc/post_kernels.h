@@ -599,6 +599,53 @@ post_boundary_segments_kernel(const uint8_t* __restrict__ mask, int H, int W, in
 
 
 // --------------------------------------------------------------------------------------------------------------
+// a11: the heading pipeline's two other per-page reductions, so that neither the decoded scan nor the net output has to
+// visit the host a second time:
+//   post_gray_u8_kernel    cv2.imread(path, IMREAD_GRAYSCALE) of a decoded BGR image (swt_dist_trafo.py:19): OpenCV's
+//                          fixed-point weights (B 3735 + G 19235 + R 9798 + 2^14) >> 15, four pixels per thread
+//   post_box_sums_kernel   heading_net_post_processor.py:247-270: the sum of one channel of the uint8 net output over a
+//                          text line's bounding box, as an exact integer (one workgroup per box, a wave per row)
+// --------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+post_gray_u8_kernel(const uint8_t* __restrict__ bgr, size_t n, uint8_t* __restrict__ out) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;            // four pixels = 12 bytes in, 4 bytes out
+    auto gray = [](unsigned b, unsigned g, unsigned r) -> unsigned { return (b * 3735u + g * 19235u + r * 9798u + 16384u) >> 15; };
+    if (q * 4 + 4 <= n && (((size_t)bgr | (size_t)out) & 3) == 0) {
+        const uint32_t* src = (const uint32_t*)(bgr + q * 12);
+        const uint32_t a = src[0], b = src[1], c = src[2];
+        const unsigned p0 = gray(a & 255, (a >> 8) & 255, (a >> 16) & 255);
+        const unsigned p1 = gray(a >> 24, b & 255, (b >> 8) & 255);
+        const unsigned p2 = gray((b >> 16) & 255, b >> 24, c & 255);
+        const unsigned p3 = gray((c >> 8) & 255, (c >> 16) & 255, c >> 24);
+        *(uint32_t*)(out + q * 4) = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+    } else {
+        for (size_t i = q * 4; i < n && i < q * 4 + 4; ++i) out[i] = (uint8_t)gray(bgr[3 * i], bgr[3 * i + 1], bgr[3 * i + 2]);
+    }
+}
+
+struct PostBox { int x0, y0, x1, y1; };           // rows [y0, y1), columns [x0, x1), already clipped to the image
+
+__global__ void __launch_bounds__(256)
+post_box_sums_kernel(const uint8_t* __restrict__ img, int W, int pix_stride, int channel, const PostBox* __restrict__ boxes,
+                     unsigned long long* __restrict__ sums) {
+    __shared__ unsigned long long part[4];
+    const PostBox b = boxes[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long s = 0;
+    for (int y = b.y0 + wave; y < b.y1; y += 4) {
+        const uint8_t* row = img + ((size_t)y * W) * pix_stride + channel;
+        unsigned r = 0;                                                  // a row of at most 2^24 pixels fits 32 bits
+        for (int x = b.x0 + lane; x < b.x1; x += 64) r += row[(size_t)x * pix_stride];
+        s += r;
+    }
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+
+// --------------------------------------------------------------------------------------------------------------
 // a11 / f4: per text line statistics on the stroke-width image (heading_net_post_processor.py:218-245,
 // feature_generation.py:106-159): inside the line's crop, 8-connected components of the non-zero pixels ->
 // bounding boxes -> reject (w < 3 or h < 3 or w > 500 or h > 500, then w/h > 8 or h/w > 8) -> per accepted

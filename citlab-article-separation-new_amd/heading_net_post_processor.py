@@ -282,6 +282,105 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
                                                 d_u8.data_ptr(), None, 0.0, sp), "asep_aru_forward_dev")
             return d_u8.cpu().numpy()
 
+    def enqueue_page(self, image):
+        """Queue the device stages of one decoded page -- upload (copy stream, complete on return), resize + gray + heading
+        net with uint8 epilogue (:285-288), full-size gray + stroke-width distance transform (swt_dist_trafo.py:18-29) --
+        and return a ticket for :meth:`collect_page`.  Neither the net output nor the distance transform leaves HBM."""
+        import torch
+        dev = self.device
+        lib = _lib.init_device(dev)
+        tdev = torch.device("cuda", dev)
+        image = np.require(image, dtype=np.uint8, requirements=['C', 'W'])   # Pillow hands out read-only views
+        if image.ndim == 2:
+            image = image[:, :, None]
+        H, W, Cn = image.shape
+        sc = get_scaling_factor(H, W, self.scaling_factor, fixed_height=self.fixed_height)
+        h, w = image_ops.scaled_size(H, W, sc)
+        ncls = self.pb_graph.cfg.n_classes
+        _, ws = image_ops._workspace(dev)
+        t = {"sc": sc, "size": (h, w, ncls), "device": dev}
+        with torch.cuda.device(tdev):
+            stream = torch.cuda.current_stream(tdev)
+            sp = C.c_void_p(stream.cuda_stream)
+            if getattr(self, "_copy_stream", None) is None or self._copy_stream.device != tdev:
+                self._copy_stream = torch.cuda.Stream(tdev)
+                self._side_stream = torch.cuda.Stream(tdev)
+            with torch.cuda.stream(self._copy_stream):
+                d_img = torch.from_numpy(image).to(tdev, non_blocking=True)
+            self._copy_stream.synchronize()
+            d_img.record_stream(stream)
+            if self.weight_dict['net'] > 0:
+                d_gray = torch.empty((h, w), dtype=torch.float32, device=tdev)
+                _lib.check(lib.asep_prep_scale_gray_dev(ws, d_img.data_ptr(), H, W, Cn, float(sc), None,
+                                                        d_gray.data_ptr(), sp), "asep_prep_scale_gray_dev")
+                d_out = torch.empty((h, w, ncls), dtype=torch.float32, device=tdev)
+                d_u8 = torch.empty((h, w, ncls), dtype=torch.uint8, device=tdev)
+                _lib.check(lib.asep_aru_forward_dev(self.pb_graph.handle(dev), d_gray.data_ptr(), h, w, d_out.data_ptr(),
+                                                    d_u8.data_ptr(), None, 0.0, sp), "asep_aru_forward_dev")
+                t["d_u8"] = d_u8
+                t["keep"] = (d_gray, d_out)
+            if Cn == 1:
+                d_g8 = d_img
+            else:
+                d_g8 = torch.empty((H, W), dtype=torch.uint8, device=tdev)
+                _lib.check(lib.asep_prep_gray_u8_dev(ws, d_img.data_ptr(), H, W, d_g8.data_ptr(), sp), "asep_prep_gray_u8_dev")
+            d_swt = torch.empty((H, W), dtype=torch.uint8, device=tdev)
+            _lib.check(lib.asep_swt_distance_transform_dev(ws, d_g8.data_ptr(), H, W, d_swt.data_ptr(), sp),
+                       "asep_swt_distance_transform_dev")
+            t["swt"] = image_ops.DeviceImage(d_swt, dev)
+            t["inputs"] = (d_img, d_g8)
+            t["done"] = torch.cuda.Event()
+            t["done"].record(stream)
+        return t
+
+    def collect_page(self, t, text_lines):
+        """The three per-line measurements of :94-119 for a ticket of :meth:`enqueue_page`, taken on a side stream while the
+        next page's kernels run: stroke width and text height from the device-resident distance transform, the mean net
+        confidence from exact integer box sums of the uint8 net output (``sum / 255 / (width * height)``: the reference sums
+        ``uint8 / 255`` in float64, which differs by rounding in the last bits only)."""
+        import torch
+        dev = t["device"]
+        tdev = torch.device("cuda", dev)
+        h, w, ncls = t["size"]
+        sc = t["sc"]
+        stroke_width_dict, height_dict, net_prob_dict = {}, {}, {}
+        with_coords = [tl for tl in text_lines if tl.surr_p]
+        with torch.cuda.device(tdev):
+            side = self._side_stream
+            side.wait_event(t["done"])
+            sp = C.c_void_p(side.cuda_stream)
+            boxes = []
+            for tl in with_coords:
+                x, y, bw, bh = tl.get_bounding_box()
+                boxes.append([x, y, x + bw + 1, y + bh + 1])            # the crop [ya:yb+1, xa:xb+1] of :232-236
+            sws, hts = image_ops.swt_line_features(t["swt"], boxes, device=dev, stream=sp, lane=1)
+            probs = np.zeros(len(with_coords))
+            if "d_u8" in t and with_coords:
+                nboxes, nominal = [], []
+                for tl in with_coords:                                   # :247-270
+                    pts = rescale_points(tl.surr_p, sc)
+                    xs = [p[0] for p in pts]
+                    ys = [p[1] for p in pts]
+                    xa, ya = min(xs), min(ys)
+                    width, height = max(xs) - xa + 1, max(ys) - ya + 1
+                    y0, y1, _ = slice(ya, ya + height).indices(h)       # what numpy makes of net_output[ya:ya+height, xa:xa+width]
+                    x0, x1, _ = slice(xa, xa + width).indices(w)
+                    nboxes.append([x0, y0, max(x0, x1), max(y0, y1)])
+                    nominal.append(width * height)
+                sums = image_ops.box_sums_dev(t["d_u8"].data_ptr(), (h, w, ncls), nboxes, channel=0, device=dev, stream=sp,
+                                              lane=1)
+                probs = sums / 255 / np.asarray(nominal, dtype=np.float64)
+            else:
+                side.synchronize()
+        batched = {tl.id: (sws[i], int(hts[i]), probs[i]) for i, tl in enumerate(with_coords)}
+        for text_line in text_lines:
+            stroke_width, height, prob = batched[text_line.id] if text_line.surr_p else (0, 0, 0)
+            stroke_width_dict[text_line.id] = stroke_width
+            height_dict[text_line.id] = height
+            net_prob_dict[text_line.id] = prob if "d_u8" in t else 0
+        t.clear()
+        return stroke_width_dict, height_dict, net_prob_dict
+
     def run(self, gpu_device='0'):
         """:272-303."""
         self.gpu_devices = gpu_device
@@ -310,7 +409,28 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
                             geometry[nxt] = parsers.submit(read_line_geometry, get_page_path(nxt))
                 if pipelined:
                     prefetch_geometry(2 * n_workers)
+                pending = None
+
+                def finish(image_path, ticket):
+                    # the GPU owner only measures; parsing happened in a worker, fusion + tags + XML go to a worker
+                    page_path = get_page_path(image_path)
+                    lines = geometry.pop(image_path).result()
+                    prefetch_geometry(1)
+                    if lines is None:                       # no PAGE-XML yet: the writer creates an empty one
+                        lines = []
+                    values = self.collect_page(ticket, [LineGeometry(i, p) for i, p in lines])
+                    writers.submit(write_heading_page, page_path, image_path, self.fixed_height, self.scaling_factor,
+                                   [{k: float(v) for k, v in d.items()} for d in values], self.weight_dict, self.threshold,
+                                   self.thresh_dict, self.text_line_percentage)
+
                 for image_path, image in DecodePool(self.image_paths, n_workers, register=reg, unregister=unreg):
+                    if pipelined:
+                        # one page behind the GPU: page n+1 is uploaded and queued before page n's lines are measured
+                        ticket = self.enqueue_page(image)
+                        if pending is not None:
+                            finish(*pending)
+                        pending = (image_path, ticket)
+                        continue
                     if self.weight_dict['net'] > 0:
                         net_output = self.heading_probability(image)
                         net_output_post = self.post_process(net_output)
@@ -320,19 +440,10 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
                     else:
                         net_output_post = None
                     swt_feature_image = self.SWT.distance_transform(image, on_device=True)
-                    page_path = get_page_path(image_path)
-                    lines = geometry.pop(image_path).result() if pipelined else None
-                    if pipelined:
-                        prefetch_geometry(1)
-                    if lines is None:                       # inline, or no PAGE-XML yet (the writer creates one)
-                        new_page_objects.append(self.to_page_xml(page_path, image_path, net_output_post, swt_feature_image))
-                        continue
-                    # the GPU owner only measures; parsing happened in a worker, fusion + tags + XML go to a worker
-                    sc = get_scaling_factor(image.shape[0], image.shape[1], self.scaling_factor, self.fixed_height)
-                    values = self.line_values([LineGeometry(i, p) for i, p in lines], sc, net_output_post, swt_feature_image)
-                    writers.submit(write_heading_page, page_path, image_path, self.fixed_height, self.scaling_factor,
-                                   [{k: float(v) for k, v in d.items()} for d in values], self.weight_dict, self.threshold,
-                                   self.thresh_dict, self.text_line_percentage)
+                    new_page_objects.append(self.to_page_xml(get_page_path(image_path), image_path, net_output_post,
+                                                             swt_feature_image))
+                if pending is not None:
+                    finish(*pending)
             finally:
                 if pipelined:
                     parsers.shutdown()

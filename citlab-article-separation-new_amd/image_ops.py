@@ -23,14 +23,17 @@ MORPH_ERODE, MORPH_DILATE, MORPH_OPEN, MORPH_CLOSE = 0, 1, 2, 3
 _workspaces = {}
 
 
-def _workspace(device=0):
+def _workspace(device=0, lane=0):
+    """the classical stages' scratch arena of a device; ``lane`` > 0: a second arena for calls that run on another stream
+    beside the first (an arena is reused call after call in stream order, so one arena must not serve two streams)"""
     lib = _lib.init_device(device)
-    if device not in _workspaces:
+    key = device if lane == 0 else (device, lane)
+    if key not in _workspaces:
         h = lib.asep_post_create()
         if not h:
             raise _lib.AsepError("asep_post_create failed: " + _lib.last_error())
-        _workspaces[device] = h
-    return lib, _workspaces[device]
+        _workspaces[key] = h
+    return lib, _workspaces[key]
 
 
 def scaled_size(H, W, sc):
@@ -215,7 +218,22 @@ def _line_features_host(swt, box):
     return (float(np.median(vals)) if vals else 0.0), height
 
 
-def swt_line_features(swt, boxes, device=0, d_swt_ptr=None, shape=None, stream=None):
+def box_sums_dev(d_img_ptr, shape, boxes, channel=0, device=0, stream=None, lane=0):
+    """exact sums of ``img[y0:y1, x0:x1, channel]`` for a device-resident uint8 image [H,W,C] (or [H,W]); ``boxes`` =
+    [[x0, y0, x1, y1], ...] with non-negative bounds -> int64 [L]  (heading_net_post_processor.py:247-270)"""
+    boxes = np.ascontiguousarray(np.asarray(boxes, dtype=np.int32).reshape(-1, 4))
+    out = np.zeros(boxes.shape[0], dtype=np.int64)
+    if boxes.shape[0] == 0:
+        return out
+    H, W = shape[0], shape[1]
+    stride = shape[2] if len(shape) > 2 else 1
+    lib, ws = _workspace(device, lane)
+    _lib.check(lib.asep_post_box_sums_dev(ws, d_img_ptr, H, W, stride, int(channel), boxes.shape[0], boxes.ctypes.data,
+                                          out.ctypes.data, stream), "asep_post_box_sums_dev")
+    return out
+
+
+def swt_line_features(swt, boxes, device=0, d_swt_ptr=None, shape=None, stream=None, lane=0):
     """Stroke width (median of the per-component maxima) and text height (largest component height) of every text
     line crop ``swt[y0:y1, x0:x1]``; ``boxes`` = [[x0, y0, x1, y1], ...].  ``swt`` may be a host uint8 image, or
     None together with ``d_swt_ptr`` / ``shape`` for a device-resident image (``swt`` is then fetched lazily, only if
@@ -227,7 +245,7 @@ def swt_line_features(swt, boxes, device=0, d_swt_ptr=None, shape=None, stream=N
     flag = np.zeros(n, dtype=np.int32)
     if n == 0:
         return sw.astype(np.float64), hh
-    lib, ws = _workspace(device)
+    lib, ws = _workspace(device, lane)
     if isinstance(swt, DeviceImage):
         d_swt_ptr, shape, dimg = swt.ptr, swt.shape, swt
         swt = dimg.numpy

@@ -96,11 +96,15 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
         return write_separator_page(page_path, image_path, self.fixed_height, self.scaling_factor, polygons_dict)
 
     # -- the fused device path ---------------------------------------------------------------------------------
-    def separator_masks(self, image, edges_only=False):
-        """decoded image (uint8 [H,W,3] BGR or [H,W]) -> ({"horizontal", "vertical"} uint8 [h,w], sc, extras).
+    SEGMENT_CAPACITY = 1 << 14         # boundary segments per mask copied back without asking (a page has a few hundred)
 
-        Same arithmetic as load_and_scale_image -> get_net_output -> uint8(x*255) -> apply_threshold -> post_process
-        (:141-151), executed without leaving HBM."""
+    def enqueue_page(self, image, edges_only=True):
+        """Queue the device stages of one decoded page and return a ticket for :meth:`collect_page`.
+
+        The upload runs on a copy stream (beside the previous page's kernels) and is complete on return, so the caller may
+        recycle ``image``; everything behind it -- resize + gray, ARU-Net, CC filter / openings, boundary segments, the copy
+        of the segment keys into page-locked host memory -- is only enqueued.  Same arithmetic as load_and_scale_image ->
+        get_net_output -> uint8(x*255) -> apply_threshold -> post_process (:141-151), executed without leaving HBM."""
         import torch
         dev = self.device
         lib = _lib.init_device(dev)
@@ -113,10 +117,16 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
         h, w = image_ops.scaled_size(H, W, sc)
         ncls = self.pb_graph.cfg.n_classes
         _, ws = image_ops._workspace(dev)
+        t = {"sc": sc, "size": (h, w), "edges_only": edges_only, "device": dev}
         with torch.cuda.device(tdev):
             stream = torch.cuda.current_stream(tdev)
             sp = C.c_void_p(stream.cuda_stream)
-            d_img = torch.from_numpy(image).to(tdev, non_blocking=False)
+            if getattr(self, "_copy_stream", None) is None or self._copy_stream.device != tdev:
+                self._copy_stream = torch.cuda.Stream(tdev)
+            with torch.cuda.stream(self._copy_stream):
+                d_img = torch.from_numpy(image).to(tdev, non_blocking=True)
+            self._copy_stream.synchronize()
+            d_img.record_stream(stream)
             d_gray = torch.empty((h, w), dtype=torch.float32, device=tdev)
             _lib.check(lib.asep_prep_scale_gray_dev(ws, d_img.data_ptr(), H, W, Cn, float(sc), None,
                                                     d_gray.data_ptr(), sp), "asep_prep_scale_gray_dev")
@@ -133,20 +143,97 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
             d_vt = torch.empty((h, w), dtype=torch.uint8, device=tdev)
             _lib.check(lib.asep_post_separator_dev(ws, d_mask.data_ptr(), h, w, ncls, 0, min_size, k_h, k_v, k_c,
                                                    d_hz.data_ptr(), d_vt.data_ptr(), sp), "asep_post_separator_dev")
+            t["masks"] = {"horizontal": d_hz, "vertical": d_vt}
             if edges_only:
                 # polygon extraction needs only the boundary segments: the masks stay in HBM
-                masks = {"horizontal": image_ops.boundary_segments_dev(d_hz.data_ptr(), h, w, 255, dev, sp),
-                         "vertical": image_ops.boundary_segments_dev(d_vt.data_ptr(), h, w, 255, dev, sp)}
+                cap = self.SEGMENT_CAPACITY
+                d_keys = torch.empty((2, 2, cap), dtype=torch.int32, device=tdev)
+                d_tot = torch.empty((2, 2), dtype=torch.int64, device=tdev)
+                for i, d_m in enumerate((d_hz, d_vt)):
+                    _lib.check(lib.asep_post_boundary_segments_enqueue_dev(
+                        ws, d_m.data_ptr(), h, w, 255, d_keys[i, 0].data_ptr(), d_keys[i, 1].data_ptr(), cap,
+                        d_tot[i].data_ptr(), sp), "asep_post_boundary_segments_enqueue_dev")
+                t["h_keys"] = torch.empty((2, 2, cap), dtype=torch.int32, pin_memory=True)
+                t["h_tot"] = torch.empty((2, 2), dtype=torch.int64, pin_memory=True)
+                t["h_tot"].copy_(d_tot, non_blocking=True)
+                t["h_keys"].copy_(d_keys, non_blocking=True)
             else:
-                masks = {"horizontal": d_hz.cpu().numpy(), "vertical": d_vt.cpu().numpy()}
-            extras = {"net_output_u8": d_u8.cpu().numpy()} if self.keep_outputs else {}
-            extras["size"] = (h, w)
+                t["h_masks"] = {k: torch.empty((h, w), dtype=torch.uint8, pin_memory=True) for k in t["masks"]}
+                for k, d_m in t["masks"].items():
+                    t["h_masks"][k].copy_(d_m, non_blocking=True)
+            if self.keep_outputs:
+                t["h_u8"] = torch.empty((h, w, ncls), dtype=torch.uint8, pin_memory=True)
+                t["h_u8"].copy_(d_u8, non_blocking=True)
+            t["done"] = torch.cuda.Event()
+            t["done"].record(stream)
+            t["keep"] = (d_gray, d_out, d_u8, d_mask)          # alive until the page is collected
+        return t
+
+    def collect_page(self, t):
+        """wait for a ticket of :meth:`enqueue_page` -> ({"horizontal", "vertical"}, sc, extras): uint8 [h,w] masks, or with
+        ``edges_only`` the (starts, ends) segment keys of ``asep_post_boundary_segments``"""
+        import torch
+        t["done"].synchronize()
+        h, w = t["size"]
+        if t["edges_only"]:
+            masks = {}
+            tot = t["h_tot"].numpy()
+            for i, name in enumerate(("horizontal", "vertical")):
+                n_s, n_e = int(tot[i, 0]), int(tot[i, 1])
+                if n_s != n_e:
+                    raise _lib.AsepError(f"boundary segments: {n_s} starts but {n_e} ends")
+                if n_s > self.SEGMENT_CAPACITY:               # an unusually ragged mask: ask again with room for all of it
+                    tdev = torch.device("cuda", t["device"])
+                    with torch.cuda.device(tdev):
+                        sp = C.c_void_p(torch.cuda.current_stream(tdev).cuda_stream)
+                        masks[name] = image_ops.boundary_segments_dev(t["masks"][name].data_ptr(), h, w, 255, t["device"],
+                                                                      sp, capacity=n_s)
+                else:
+                    keys = t["h_keys"][i, :, :n_s].numpy()
+                    masks[name] = (keys[0].copy(), keys[1].copy())
+        else:
+            masks = {k: v.numpy().copy() for k, v in t["h_masks"].items()}
+        extras = {"net_output_u8": t["h_u8"].numpy().copy()} if "h_u8" in t else {}
+        extras["size"] = (h, w)
+        sc = t["sc"]
+        t.clear()
         return masks, sc, extras
+
+    def separator_masks(self, image, edges_only=False):
+        """decoded image (uint8 [H,W,3] BGR or [H,W]) -> ({"horizontal", "vertical"} uint8 [h,w], sc, extras)"""
+        return self.collect_page(self.enqueue_page(image, edges_only=edges_only))
+
+    def _finish_page(self, image_path, ticket, writers, pipelined, page_objects):
+        t_dev = time.perf_counter()
+        masks, sc, extras = self.collect_page(ticket)
+        t_host = time.perf_counter()
+        self.device_seconds += t_host - t_dev
+        polygons_dict = {}
+        if self.keep_outputs:
+            self.net_outputs.append(extras["net_output_u8"])
+            self.net_outputs_post.append(masks)
+            for separator_type, net_output_post in masks.items():
+                polygons_dict.update(self.to_polygons(net_output_post, separator_type))
+        else:
+            h, w = extras["size"]
+            for separator_type, (starts, ends) in masks.items():
+                polygons_dict[SEPARATOR_REGION + "_" + separator_type] = \
+                    polygonize.shapes_from_segments(starts, ends, h, w, connectivity=8)
+        polygons_dict = self.rescale_polygons(polygons_dict, scaling_factor=1 / sc)
+        if pipelined:
+            writers.submit(write_separator_page, get_page_path(image_path), image_path, self.fixed_height,
+                           self.scaling_factor, polygons_dict)
+        else:
+            page_objects.append(self.to_page_xml(get_page_path(image_path), image_path=image_path,
+                                                 polygons_dict=polygons_dict))
+        self.host_seconds += time.perf_counter() - t_host
 
     def run(self):
         """:135-159.  With ``host_workers`` > 1 the images are decoded ahead of the GPU by worker processes (DMA-able
         shared-memory slots) and the PAGE-XML files are written behind it; the GPU-owning process only runs the device
-        stages and chains the polygon rings."""
+        stages and chains the polygon rings -- one page behind the GPU: page n+1 is uploaded and queued before page n's
+        segments are waited for, so the chip does not idle while the host chains rings (``device_seconds`` = upload +
+        queueing + waiting for results, ``host_seconds`` = chaining and handing over)."""
         from .host_pipeline import DecodePool, WritePool, pin_callbacks
         page_objects = []
         pipelined = self.host_workers > 1 and not self.keep_outputs
@@ -154,34 +241,20 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
         decode = DecodePool(self.image_paths, self.host_workers if pipelined else 0, register=reg, unregister=unreg)
         with WritePool(self.host_workers if pipelined else 0) as writers:
             t_prev = t_run = time.perf_counter()
+            pending = None
             for image_path, image in decode:
                 t_dev = time.perf_counter()
                 if self.first_page_seconds is None:          # worker start-up + slot page-locking + the first decode
                     self.first_page_seconds = t_dev - t_run
                 self.wait_seconds += t_dev - t_prev
-                masks, sc, extras = self.separator_masks(image, edges_only=not self.keep_outputs)
-                t_host = time.perf_counter()
-                self.device_seconds += t_host - t_dev
-                polygons_dict = {}
-                if self.keep_outputs:
-                    self.net_outputs.append(extras["net_output_u8"])
-                    self.net_outputs_post.append(masks)
-                    for separator_type, net_output_post in masks.items():
-                        polygons_dict.update(self.to_polygons(net_output_post, separator_type))
-                else:
-                    h, w = extras["size"]
-                    for separator_type, (starts, ends) in masks.items():
-                        polygons_dict[SEPARATOR_REGION + "_" + separator_type] = \
-                            polygonize.shapes_from_segments(starts, ends, h, w, connectivity=8)
-                polygons_dict = self.rescale_polygons(polygons_dict, scaling_factor=1 / sc)
-                if pipelined:
-                    writers.submit(write_separator_page, get_page_path(image_path), image_path, self.fixed_height,
-                                   self.scaling_factor, polygons_dict)
-                else:
-                    page_objects.append(self.to_page_xml(get_page_path(image_path), image_path=image_path,
-                                                         polygons_dict=polygons_dict))
+                ticket = self.enqueue_page(image, edges_only=not self.keep_outputs)
+                self.device_seconds += time.perf_counter() - t_dev
+                if pending is not None:
+                    self._finish_page(*pending, writers, pipelined, page_objects)
+                pending = (image_path, ticket)
                 t_prev = time.perf_counter()
-                self.host_seconds += t_prev - t_host
+            if pending is not None:
+                self._finish_page(*pending, writers, pipelined, page_objects)
         return page_objects
 
 

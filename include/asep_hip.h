@@ -270,6 +270,26 @@ long asep_post_boundary_segments(asep_post* p, const uint8_t* mask, int H, int W
                                  int32_t* out_ends, long capacity);
 long asep_post_boundary_segments_dev(asep_post* p, const uint8_t* d_mask, int H, int W, int value, int32_t* d_starts,
                                      int32_t* d_ends, long capacity, void* stream);
+/* The same without the host round trip, for a caller that keeps more than one page in flight: the kernel is
+ * enqueued on `stream` and the two counts (starts, ends; equal on success, either may exceed `capacity`) are left in
+ * d_totals[0..1] (device memory, caller-owned).  Nothing is synchronised: the caller copies d_totals and the first
+ * min(total, capacity) keys back in stream order and falls back to asep_post_boundary_segments_dev with larger
+ * buffers when total > capacity. */
+int asep_post_boundary_segments_enqueue_dev(asep_post* p, const uint8_t* d_mask, int H, int W, int value,
+                                            int32_t* d_starts, int32_t* d_ends, long capacity,
+                                            unsigned long long* d_totals, void* stream);
+
+/* cv2.imread(path, IMREAD_GRAYSCALE) of an image that is already decoded and on the device (swt_dist_trafo.py:19):
+ * d_bgr uint8 [H,W,3] in B,G,R order -> d_out uint8 [H,W] with OpenCV's fixed-point weights
+ * (B*3735 + G*19235 + R*9798 + 16384) >> 15.  Enqueued on `stream`, nothing is synchronised. */
+int asep_prep_gray_u8_dev(asep_post* p, const uint8_t* d_bgr, int H, int W, uint8_t* d_out, void* stream);
+
+/* heading_net_post_processor.py:247-270 (get_net_prob_for_text_line) without the net output leaving the device:
+ * out_sums[i] = sum of d_img[y0:y1, x0:x1, channel] over box i = {x0, y0, x1, y1} (clipped to the image like a numpy
+ * slice with non-negative bounds), d_img uint8 [H,W,pix_stride].  Exact integers; the caller divides by 255 and by
+ * the nominal box size.  boxes and out_sums are host pointers; returns after the sums have arrived. */
+int asep_post_box_sums_dev(asep_post* p, const uint8_t* d_img, int H, int W, int pix_stride, int channel, int n_boxes,
+                           const int32_t* boxes, int64_t* out_sums, void* stream);
 
 /* swt_dist_trafo.py:18-29 distance_transform without the file decode: gray uint8 [H,W] -> 255-gray ->
  * GaussianBlur 5x5 -> Otsu -> exact Euclidean distance to the nearest zero pixel -> astype(uint8).

@@ -211,6 +211,37 @@ def test_boundary_segments_page_sized_and_capacity_retry():
     assert s0.size == 0 and polygonize.shapes_from_segments(s0, e0, 50, 60) == []
 
 
+def test_boundary_segments_enqueue_form_equals_the_synchronous_one():
+    """asep_post_boundary_segments_enqueue_dev leaves counts and keys on the device without a host round trip: two masks
+    queued back to back give the key sets of the synchronous entry point; a capacity that is too small is reported by the
+    counts (which may exceed it) and never written past"""
+    import ctypes as C
+    import torch
+    from citlab_article_separation_new_amd import _lib, image_ops
+    rng = np.random.default_rng(11)
+    masks = [_separator_mask(rng, 300, 200, noise=0.002), _separator_mask(rng, 300, 200, noise=0.02)]
+    lib, ws = image_ops._workspace(0)
+    dev = torch.device("cuda", 0)
+    sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    cap = 1 << 10
+    d_masks = [torch.from_numpy(m).to(dev) for m in masks]
+    d_keys = torch.full((2, 2, cap + 8), -7, dtype=torch.int32, device=dev)
+    d_tot = torch.empty((2, 2), dtype=torch.int64, device=dev)
+    for i, d_m in enumerate(d_masks):
+        _lib.check(lib.asep_post_boundary_segments_enqueue_dev(ws, d_m.data_ptr(), 300, 200, 255, d_keys[i, 0].data_ptr(),
+                                                               d_keys[i, 1].data_ptr(), cap, d_tot[i].data_ptr(), sp), "enqueue")
+    tot, keys = d_tot.cpu().numpy(), d_keys.cpu().numpy()
+    assert (keys[:, :, cap:] == -7).all()                    # nothing beyond the capacity
+    for i, m in enumerate(masks):
+        starts, ends = image_ops.boundary_segments(m, 255)
+        assert tot[i, 0] == tot[i, 1] == starts.size
+        if starts.size <= cap:
+            assert np.array_equal(np.sort(keys[i, 0, :starts.size]), np.sort(starts))
+            assert np.array_equal(np.sort(keys[i, 1, :ends.size]), np.sort(ends))
+    assert tot[0, 0] <= cap < tot[1, 0]                      # both branches were exercised
+    assert lib.asep_post_boundary_segments_enqueue_dev(ws, d_masks[0].data_ptr(), 300, 200, 255, None, None, cap, None, sp) < 0
+
+
 def _line_boxes(rng, H, W, n):
     boxes = []
     for _ in range(n):

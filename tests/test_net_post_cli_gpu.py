@@ -259,3 +259,31 @@ def test_compute_dtype_switch_for_models_loaded_from_files(tmp_path, monkeypatch
     monkeypatch.setenv("ASEP_COMPUTE_DTYPE", "fp16")
     with pytest.raises(ValueError, match="ASEP_COMPUTE_DTYPE"):
         helper.load_graph(pb)
+
+
+def test_pages_in_flight_give_the_masks_of_the_page_by_page_form(tmp_path, monkeypatch):
+    """SeparatorNetPostProcessor.enqueue_page / collect_page (the owner runs one page behind the GPU): three pages queued
+    before the first is collected give the segments of the synchronous separator_masks; with a segment capacity of 4 every
+    mask takes the ask-again branch and still gives them"""
+    from citlab_article_separation_new_amd import polygonize, synth
+    from citlab_article_separation_new_amd.separator_net_post_processor import SeparatorNetPostProcessor
+    from citlab_article_separation_new_amd import image_io, net_post_processing_helper as helper
+    from oracle import classical_oracle as co
+    pb, lst, data = _setup(tmp_path)
+    pages = [synth.synth_page(30 + k, W=500 + 40 * k, H=700 + 30 * k) for k in range(3)]
+    _, grey, _ = co.scale_and_gray(image_io.load_image_bgr(str(data / "p0.png")), 450, 1.0)
+    thr = round(float(np.median(helper.get_net_output(grey, helper.load_graph(pb), "0")[:, :, 0])), 3)
+    proc = SeparatorNetPostProcessor([], pb, 450, 1.0, thr, "0")
+    want = []
+    for p in pages:
+        masks, sc, extras = proc.separator_masks(p, edges_only=False)
+        want.append(({k: polygonize.shapes(m, value=255, connectivity=8) for k, m in masks.items()}, sc, extras["size"]))
+    assert any(v for w, _, _ in want for v in w.values())
+    for cap in (SeparatorNetPostProcessor.SEGMENT_CAPACITY, 4):
+        monkeypatch.setattr(SeparatorNetPostProcessor, "SEGMENT_CAPACITY", cap)
+        tickets = [proc.enqueue_page(p, edges_only=True) for p in pages]
+        for t, (polys, sc, size) in zip(tickets, want):
+            masks, sc2, extras = proc.collect_page(t)
+            assert sc2 == sc and extras["size"] == size
+            for k, (starts, ends) in masks.items():
+                assert polygonize.shapes_from_segments(starts, ends, size[0], size[1], connectivity=8) == polys[k]
