@@ -283,7 +283,7 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
             return d_u8.cpu().numpy()
 
     def enqueue_page(self, image):
-        """Queue the device stages of one decoded page -- upload (copy stream, complete on return), resize + gray + heading
+        """Queue the device stages of one decoded page (``image`` stays valid until the ticket is collected) -- upload, resize + gray + heading
         net with uint8 epilogue (:285-288), full-size gray + stroke-width distance transform (swt_dist_trafo.py:18-29) --
         and return a ticket for :meth:`collect_page`.  Neither the net output nor the distance transform leaves HBM."""
         import torch
@@ -302,13 +302,14 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
         with torch.cuda.device(tdev):
             stream = torch.cuda.current_stream(tdev)
             sp = C.c_void_p(stream.cuda_stream)
-            if getattr(self, "_copy_stream", None) is None or self._copy_stream.device != tdev:
-                self._copy_stream = torch.cuda.Stream(tdev)
+            if getattr(self, "_side_stream", None) is None or self._side_stream.device != tdev:
                 self._side_stream = torch.cuda.Stream(tdev)
-            with torch.cuda.stream(self._copy_stream):
-                d_img = torch.from_numpy(image).to(tdev, non_blocking=True)
-            self._copy_stream.synchronize()
-            d_img.record_stream(stream)
+            # the upload is queued like everything else (a page is 0.3 ms of PCIe; a copy on a second stream ended up behind the
+            # engine's kernels in a shared hardware queue and made the host wait for them): ``image`` must stay valid until the
+            # page is collected -- DecodePool(hold=2) guarantees that for its slots, pageable arrays are staged by the runtime
+            # before the call returns
+            d_img = torch.empty((H, W, Cn), dtype=torch.uint8, device=tdev)
+            d_img.copy_(torch.from_numpy(image), non_blocking=True)
             if self.weight_dict['net'] > 0:
                 d_gray = torch.empty((h, w), dtype=torch.float32, device=tdev)
                 _lib.check(lib.asep_prep_scale_gray_dev(ws, d_img.data_ptr(), H, W, Cn, float(sc), None,
@@ -388,7 +389,7 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
         new_page_objects = []
         # images are decoded ahead of the GPU by worker processes when host_workers > 1 (host_pipeline.py); the fusion
         # itself needs the device again (per-line statistics), so the PAGE-XML part stays in this process
-        from .host_pipeline import DecodePool, WritePool, pin_callbacks
+        from .host_pipeline import DecodePool, WritePool, pin_callbacks, single_threaded_children
         from .net_post_processing_helper import get_scaling_factor
         pipelined = getattr(self, "host_workers", 0) > 1 and not self.keep_outputs
         reg, unreg = pin_callbacks(self.device) if pipelined else (None, None)
@@ -406,7 +407,8 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
                     for _ in range(k):
                         nxt = next(ahead, None)
                         if nxt is not None:
-                            geometry[nxt] = parsers.submit(read_line_geometry, get_page_path(nxt))
+                            with single_threaded_children():
+                                geometry[nxt] = parsers.submit(read_line_geometry, get_page_path(nxt))
                 if pipelined:
                     prefetch_geometry(2 * n_workers)
                 pending = None
@@ -423,7 +425,7 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
                                    [{k: float(v) for k, v in d.items()} for d in values], self.weight_dict, self.threshold,
                                    self.thresh_dict, self.text_line_percentage)
 
-                for image_path, image in DecodePool(self.image_paths, n_workers, register=reg, unregister=unreg):
+                for image_path, image in DecodePool(self.image_paths, n_workers, register=reg, unregister=unreg, hold=2):
                     if pipelined:
                         # one page behind the GPU: page n+1 is uploaded and queued before page n's lines are measured
                         ticket = self.enqueue_page(image)

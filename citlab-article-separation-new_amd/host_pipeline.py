@@ -13,9 +13,13 @@ GPU -> XML one after the other leaves the GPU idle > 90 % of the time.  The refe
 Both keep the order of the image list; with ``n_workers <= 1`` everything runs inline in the calling process (the
 behaviour of round 1, and what the unit tests use).  Workers never touch the GPU and do not import torch.
 """
+import contextlib
 import multiprocessing as mp
 import os
 import queue
+import sys
+import threading
+import time
 import traceback
 from multiprocessing import shared_memory
 
@@ -43,6 +47,26 @@ def needed_slot_bytes(paths, default=SLOT_BYTES, limit=SLOT_BYTES_MAX, probe=64)
     if need == 0:
         need = default
     return min(limit, (need + (1 << 20) - 1) >> 20 << 20)
+
+
+_THREAD_ENV = ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")
+
+
+@contextlib.contextmanager
+def single_threaded_children():
+    """Processes spawned inside inherit *_NUM_THREADS = 1: a decode / XML worker does no linear algebra, and numpy's BLAS
+    otherwise creates one thread per core at import -- on a 256-CPU box that is most of a worker's start-up time when dozens
+    of them start at once."""
+    old = {k: os.environ.get(k) for k in _THREAD_ENV}
+    os.environ.update({k: "1" for k in _THREAD_ENV})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def _resolve_loader(name):
@@ -84,18 +108,22 @@ def _decode_worker(tasks, ready, loader_name):
 class DecodePool:
     """Iterate ``(path, image)`` over ``paths`` in order while ``n_workers`` processes decode ahead.
 
-    ``image`` is a numpy view into a shared-memory slot: valid until the next item is requested.  ``register`` /
+    ``image`` is a numpy view into a shared-memory slot: valid until the next item is requested (``hold`` = 2: until the one
+    after the next is requested).  ``register`` /
     ``unregister`` (optional callables ``(address, nbytes)``) page-lock the slots for DMA uploads.  ``slot_bytes`` None:
     sized from the image headers (``needed_slot_bytes``).  An image that does not fit its slot is decoded inline by the
     owner; if the shared-memory slots cannot be created (a small /dev/shm) the whole list is decoded inline; if a worker
     process dies (OOM kill, SIGBUS, decoder crash) the iteration raises instead of waiting for its page forever."""
 
     def __init__(self, paths, n_workers=0, loader="load_image_bgr", n_slots=None, slot_bytes=None,
-                 register=None, unregister=None, strict_slots=False):
+                 register=None, unregister=None, strict_slots=False, hold=1):
         self.paths = list(paths)
         self.n_workers = max(0, int(n_workers)) if len(self.paths) > 1 else 0
         self.loader = loader
-        self.n_slots = n_slots or max(2, self.n_workers + 2)
+        # hold = 2: an image stays valid while the NEXT one is in the consumer's hands too (a consumer that queues the
+        # upload of page n+1 behind page n's kernels and only then waits for page n)
+        self.hold = max(1, int(hold))
+        self.n_slots = n_slots or max(2, self.n_workers + 1 + self.hold)
         self.slot_bytes = slot_bytes
         self.strict_slots = strict_slots                    # True: an image beyond the slot is an IOError (tests)
         self.inline_decodes = 0                             # pages the owner had to decode itself
@@ -112,42 +140,76 @@ class DecodePool:
             return
         load = _resolve_loader(self.loader)
         slot_bytes = self.slot_bytes or needed_slot_bytes(self.paths)
-        slots = []
-        try:
-            for _ in range(self.n_slots):
-                s = shared_memory.SharedMemory(create=True, size=slot_bytes)
-                slots.append(s)
-                np.ndarray((s.size,), np.uint8, buffer=s.buf)[::4096] = 0     # touch every page now: a /dev/shm that is too
-                                                                               # small fails here, not as SIGBUS in a worker
-        except (OSError, MemoryError, ValueError):
-            for s in slots:
-                s.close()
-                s.unlink()
-            self.inline_decodes = len(self.paths)
-            yield from self._inline()
-            return
         ctx = mp.get_context("spawn")                       # the owner may have initialised HIP: never fork it
         # one task queue per worker: the owner knows which worker holds which page, so a dead worker's pages can be named
         tasks, ready = [ctx.Queue() for _ in range(self.n_workers)], ctx.Queue()
-        registered = []
+        slots, registered = [], []
         procs = [ctx.Process(target=_decode_worker, args=(tasks[i], ready, self.loader), daemon=True)
                  for i in range(self.n_workers)]
-        try:
+        free = []
+
+        def add_slot():
+            """one more shared-memory slot, touched (a /dev/shm that is too small fails here, not as SIGBUS in a worker) and
+            page-locked; False when the host has no room for it"""
+            try:
+                s = shared_memory.SharedMemory(create=True, size=slot_bytes)
+            except (OSError, MemoryError, ValueError):
+                return False
+            try:
+                fd = getattr(s, "_fd", -1)
+                if fd >= 0 and hasattr(os, "posix_fallocate"):
+                    os.posix_fallocate(fd, 0, s.size)       # reserves the pages (ENOSPC now) without faulting each one in
+                else:
+                    np.ndarray((s.size,), np.uint8, buffer=s.buf)[::4096] = 0
+            except (OSError, MemoryError, ValueError):
+                s.close()
+                s.unlink()
+                return False
             if self._register:
-                for s in slots:
-                    addr = np.ndarray((1,), np.uint8, buffer=s.buf).ctypes.data
-                    if self._register(addr, s.size):
-                        registered.append(addr)
-            for p in procs:
-                p.start()
-            free = list(range(self.n_slots))
+                addr = np.ndarray((1,), np.uint8, buffer=s.buf).ctypes.data
+                if self._register(addr, s.size):
+                    registered.append(addr)
+            slots.append(s)
+            free.append(len(slots) - 1)                     # (list.append is atomic: the preparer thread may be the caller)
+            return True
+
+        def prepare_rest():
+            """preparer thread: the remaining slots, while the first pages are already being decoded and consumed (reserving and
+            page-locking a slot takes tens of milliseconds; both calls release the interpreter lock)"""
+            while len(slots) < self.n_slots and not stop_preparing:
+                if not add_slot():                          # the host has no room for more: run with the slots there are
+                    self.n_slots = len(slots)
+                    break
+
+        inline_instead = False
+        preparer, stop_preparing = None, []
+        trace = os.environ.get("ASEP_POOL_TRACE") == "1"     # start-up timeline on stderr (scripts/e2e_feed_bench.py)
+        t_start = time.perf_counter()
+
+        def mark(what):
+            if trace:
+                print(f"[DecodePool] {time.perf_counter() - t_start:7.3f} s  {what}", file=sys.stderr, flush=True)
+        try:
+            # the workers start first and import while the owner prepares slots; a slot is given out as soon as it exists, the
+            # remaining ones are created while the first pages are being decoded
+            with single_threaded_children():
+                for p in procs:
+                    p.start()
+            mark(f"{len(procs)} workers started")
+            while len(slots) < self.hold + 1:               # the fewest slots the consumer's contract needs
+                if not add_slot():
+                    inline_instead = True
+                    break
+            if not inline_instead and len(self.paths) > len(slots):
+                preparer = threading.Thread(target=prepare_rest, daemon=True)
+                preparer.start()
             slot_of, done, next_task, next_out = {}, {}, 0, 0
             outstanding = [set() for _ in procs]            # pages handed to each worker and not yet reported
             worker_of = {}
-            held = None
+            held = []                                       # slots of the last `hold` pages handed out, oldest first
             n = len(self.paths)
-            while next_out < n:
-                while free and next_task < n:               # keep every free slot busy
+            while next_out < n and not inline_instead:
+                while free and next_task < n:               # keep every slot that exists busy
                     k = free.pop()
                     slot_of[next_task] = k
                     wi = min(range(len(procs)), key=lambda i: len(outstanding[i]))
@@ -157,8 +219,11 @@ class DecodePool:
                     next_task += 1
                 while next_out not in done:
                     try:
-                        seq, shape, dtype, err = ready.get(timeout=1.0)
+                        # (a short wait while slots are still being prepared: new ones are handed out as they appear)
+                        seq, shape, dtype, err = ready.get(timeout=0.005 if preparer and preparer.is_alive() else 1.0)
                     except queue.Empty:
+                        if free and next_task < n:
+                            break
                         dead = [i for i, p in enumerate(procs) if not p.is_alive() and outstanding[i]]
                         if dead:                            # a worker died holding pages: they would never arrive
                             lost = sorted(self.paths[q] for i in dead for q in outstanding[i])
@@ -167,10 +232,14 @@ class DecodePool:
                         continue
                     outstanding[worker_of.pop(seq)].discard(seq)
                     done[seq] = (shape, dtype, err)
+                if next_out not in done:                    # left the wait to hand out a slot that has just appeared
+                    continue
                 shape, dtype, err = done.pop(next_out)
-                if held is not None:                        # the previous page's slot is free again
-                    free.append(held)
-                held = slot_of.pop(next_out)
+                if next_out < 3:
+                    mark(f"page {next_out} decoded ({len(slots)} slots exist, {next_task} pages handed out)")
+                if len(held) >= self.hold:                  # the oldest page still held gives its slot back
+                    free.append(held.pop(0))
+                held.append(slot_of.pop(next_out))
                 if err == _TOO_BIG and not self.strict_slots:
                     self.inline_decodes += 1
                     img = load(self.paths[next_out])        # the owner decodes what no slot can hold
@@ -178,11 +247,14 @@ class DecodePool:
                     raise IOError("image decode failed: " + (f"{self.paths[next_out]}: decoded image exceeds the "
                                                              f"{slot_bytes}-byte slot" if err == _TOO_BIG else err))
                 else:
-                    img = np.ndarray(shape, np.dtype(dtype), buffer=slots[held].buf)
+                    img = np.ndarray(shape, np.dtype(dtype), buffer=slots[held[-1]].buf)
                 yield self.paths[next_out], img
                 del img
                 next_out += 1
         finally:
+            stop_preparing.append(True)
+            if preparer:
+                preparer.join()
             for q in tasks:
                 q.put(None)
             for p in procs:
@@ -195,6 +267,9 @@ class DecodePool:
             for s in slots:
                 s.close()
                 s.unlink()
+        if inline_instead:                                  # no room for the shared-memory slots (a small /dev/shm)
+            self.inline_decodes = len(self.paths)
+            yield from self._inline()
 
 
 def _run_task(fn_module, fn_name, args):
@@ -218,7 +293,8 @@ class WritePool:
         if self._pool is None:
             from concurrent.futures import ProcessPoolExecutor
             self._pool = ProcessPoolExecutor(self.n_workers, mp_context=mp.get_context("spawn"))
-        self._futures.append(self._pool.submit(_run_task, fn.__module__, fn.__name__, args))
+        with single_threaded_children():                     # (the executor spawns its processes inside submit, on demand)
+            self._futures.append(self._pool.submit(_run_task, fn.__module__, fn.__name__, args))
         if len(self._futures) > 4 * self.n_workers:         # bounded backlog: surface errors early
             self._futures.pop(0).result()
 

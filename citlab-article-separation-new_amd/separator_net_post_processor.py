@@ -33,6 +33,7 @@ class RegionNetPostProcessor:
         self.wait_seconds = 0.0        # ... waiting for the next decoded image
         self.first_page_seconds = None # run() start -> first decoded image in hand (worker start-up, slot page-locking)
         self.host_seconds = 0.0        # ... chaining polygon rings / handing the page to the writers
+        self.result_seconds = 0.0      # part of device_seconds: waiting for the previous page's results
         self.fixed_height = fixed_height
         self.scaling_factor = scaling_factor
         self.threshold = threshold
@@ -101,9 +102,8 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
     def enqueue_page(self, image, edges_only=True):
         """Queue the device stages of one decoded page and return a ticket for :meth:`collect_page`.
 
-        The upload runs on a copy stream (beside the previous page's kernels) and is complete on return, so the caller may
-        recycle ``image``; everything behind it -- resize + gray, ARU-Net, CC filter / openings, boundary segments, the copy
-        of the segment keys into page-locked host memory -- is only enqueued.  Same arithmetic as load_and_scale_image ->
+        Everything is only enqueued -- upload, resize + gray, ARU-Net, CC filter / openings, boundary segments, the copy of
+        the segment keys into page-locked host memory -- so ``image`` has to stay valid until the ticket is collected.  Same arithmetic as load_and_scale_image ->
         get_net_output -> uint8(x*255) -> apply_threshold -> post_process (:141-151), executed without leaving HBM."""
         import torch
         dev = self.device
@@ -121,12 +121,12 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
         with torch.cuda.device(tdev):
             stream = torch.cuda.current_stream(tdev)
             sp = C.c_void_p(stream.cuda_stream)
-            if getattr(self, "_copy_stream", None) is None or self._copy_stream.device != tdev:
-                self._copy_stream = torch.cuda.Stream(tdev)
-            with torch.cuda.stream(self._copy_stream):
-                d_img = torch.from_numpy(image).to(tdev, non_blocking=True)
-            self._copy_stream.synchronize()
-            d_img.record_stream(stream)
+            # the upload is queued like everything else (a page is 0.3 ms of PCIe; a copy on a second stream ended up behind the
+            # engine's kernels in a shared hardware queue and made the host wait for them): ``image`` must stay valid until the
+            # page is collected -- DecodePool(hold=2) guarantees that for its slots, pageable arrays are staged by the runtime
+            # before the call returns
+            d_img = torch.empty((H, W, Cn), dtype=torch.uint8, device=tdev)
+            d_img.copy_(torch.from_numpy(image), non_blocking=True)
             d_gray = torch.empty((h, w), dtype=torch.float32, device=tdev)
             _lib.check(lib.asep_prep_scale_gray_dev(ws, d_img.data_ptr(), H, W, Cn, float(sc), None,
                                                     d_gray.data_ptr(), sp), "asep_prep_scale_gray_dev")
@@ -166,14 +166,16 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
                 t["h_u8"].copy_(d_u8, non_blocking=True)
             t["done"] = torch.cuda.Event()
             t["done"].record(stream)
-            t["keep"] = (d_gray, d_out, d_u8, d_mask)          # alive until the page is collected
+            t["keep"] = (d_img, d_gray, d_out, d_u8, d_mask)          # alive until the page is collected
         return t
 
     def collect_page(self, t):
         """wait for a ticket of :meth:`enqueue_page` -> ({"horizontal", "vertical"}, sc, extras): uint8 [h,w] masks, or with
         ``edges_only`` the (starts, ends) segment keys of ``asep_post_boundary_segments``"""
         import torch
+        t_res = time.perf_counter()
         t["done"].synchronize()
+        self.result_seconds += time.perf_counter() - t_res
         h, w = t["size"]
         if t["edges_only"]:
             masks = {}
@@ -238,7 +240,7 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
         page_objects = []
         pipelined = self.host_workers > 1 and not self.keep_outputs
         reg, unreg = pin_callbacks(self.device) if pipelined else (None, None)
-        decode = DecodePool(self.image_paths, self.host_workers if pipelined else 0, register=reg, unregister=unreg)
+        decode = DecodePool(self.image_paths, self.host_workers if pipelined else 0, register=reg, unregister=unreg, hold=2)
         with WritePool(self.host_workers if pipelined else 0) as writers:
             t_prev = t_run = time.perf_counter()
             pending = None

@@ -58,7 +58,8 @@ def main():
             print(f"separator CLI path, fixed_height {fixed_height}, host_workers {hw:2d}: {n_run / dt:6.2f} pages/s "
                   f"({dt / n_run * 1e3:6.1f} ms/page incl. worker start-up); GPU owner: device stages {proc.device_seconds / dt:5.1%} "
                   f"({proc.device_seconds / n_run * 1e3:.1f} ms/page), waiting for decoded images {proc.wait_seconds / dt:5.1%}, "
-                  f"rings + hand-over {proc.host_seconds / dt:5.1%}; {n_xml} PAGE-XML files written")
+                  f"rings + hand-over {proc.host_seconds / dt:5.1%}; {n_xml} PAGE-XML files written; per page: result wait {proc.result_seconds / n_run * 1e3:.2f} ms, first page after "
+                  f"{proc.first_page_seconds:.2f} s")
         # ---- heading mode: needs PAGE-XML with text lines; parsing and writing happen in workers, the owner measures ----
         from citlab_article_separation_new_amd.heading_net_post_processor import HeadingNetPostProcessor
         rng = np.random.default_rng(0)

@@ -242,6 +242,54 @@ def test_boundary_segments_enqueue_form_equals_the_synchronous_one():
     assert lib.asep_post_boundary_segments_enqueue_dev(ws, d_masks[0].data_ptr(), 300, 200, 255, None, None, cap, None, sp) < 0
 
 
+@pytest.mark.parametrize("H,W", [(1, 1), (7, 5), (64, 64), (333, 257), (900, 601)])
+def test_gray_u8_on_the_device_equals_the_fixed_point_formula(H, W):
+    """asep_prep_gray_u8_dev = cv2.imread(path, IMREAD_GRAYSCALE) of a decoded BGR image: (B 3735 + G 19235 + R 9798 + 2^14) >> 15,
+    also for pixel counts that are not a multiple of the four a thread converts and for saturated colours"""
+    import ctypes as C
+    import torch
+    from citlab_article_separation_new_amd import _lib, image_ops
+    from citlab_article_separation_new_amd.heading_net_post_processor import bgr_to_gray_u8
+    rng = np.random.default_rng(H * 31 + W)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    img.reshape(-1, 3)[: min(8, H * W)] = [[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [254, 255, 255],
+                                           [1, 1, 1], [128, 127, 129]][: min(8, H * W)]
+    lib, ws = image_ops._workspace(0)
+    dev = torch.device("cuda", 0)
+    sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    d_img = torch.from_numpy(img).to(dev)
+    d_out = torch.full((H * W + 16,), 201, dtype=torch.uint8, device=dev)
+    _lib.check(lib.asep_prep_gray_u8_dev(ws, d_img.data_ptr(), H, W, d_out.data_ptr(), sp), "asep_prep_gray_u8_dev")
+    out = d_out.cpu().numpy()
+    assert np.array_equal(out[: H * W].reshape(H, W), bgr_to_gray_u8(img))
+    assert (out[H * W:] == 201).all()
+    assert lib.asep_prep_gray_u8_dev(ws, None, H, W, d_out.data_ptr(), sp) < 0
+
+
+def test_box_sums_on_the_device_are_the_numpy_slice_sums():
+    """asep_post_box_sums_dev: exact integer sums of img[y0:y1, x0:x1, channel], boxes clipped like numpy slices with
+    non-negative bounds (beyond the image, empty, one pixel, the whole image), any channel of an interleaved image"""
+    import torch
+    from citlab_article_separation_new_amd import _lib, image_ops
+    rng = np.random.default_rng(5)
+    H, W = 700, 530
+    for C_ in (1, 2, 3):
+        img = rng.integers(0, 256, (H, W, C_), dtype=np.uint8)
+        img[100:400, 50:500] = 255                              # a saturated block: 135000 x 255 needs more than 24 bits
+        boxes = [[0, 0, W, H], [50, 100, 500, 400], [3, 4, 4, 5], [10, 10, 10, 40], [500, 650, 900, 900], [W, H, W + 5, H + 5],
+                 [20, 30, 10, 20]]
+        boxes += [[int(x), int(y), int(x + w), int(y + h)] for x, y, w, h in
+                  zip(rng.integers(0, W, 40), rng.integers(0, H, 40), rng.integers(1, 300, 40), rng.integers(1, 80, 40))]
+        d_img = torch.from_numpy(img).to("cuda:0")
+        for ch in range(C_):
+            got = image_ops.box_sums_dev(d_img.data_ptr(), img.shape, boxes, channel=ch)
+            want = [int(img[y0:max(y0, y1), x0:max(x0, x1), ch].astype(np.int64).sum()) for x0, y0, x1, y1 in boxes]
+            assert got.dtype == np.int64 and got.tolist() == want
+    assert image_ops.box_sums_dev(d_img.data_ptr(), img.shape, []).size == 0
+    with pytest.raises(_lib.AsepError):
+        image_ops.box_sums_dev(d_img.data_ptr(), img.shape, boxes, channel=3)
+
+
 def _line_boxes(rng, H, W, n):
     boxes = []
     for _ in range(n):

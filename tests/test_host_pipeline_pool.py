@@ -33,10 +33,34 @@ def test_decode_pool_keeps_order_and_pixels(tmp_path):
     assert [p for p, _ in got] == paths
     for (_, img), ref in zip(got, want):
         assert img.dtype == np.uint8 and np.array_equal(img, ref)
-    assert len(pinned) == pool.n_slots and sorted(released) == sorted(a for a, _ in pinned)
+    # (slots beyond the first two are prepared by a thread while pages are already consumed: a short list may end before all exist)
+    assert 2 <= len(pinned) <= pool.n_slots and sorted(released) == sorted(a for a, _ in pinned)
     # inline mode gives the same
     inline = [img for _, img in host_pipeline.DecodePool(paths, n_workers=0)]
     assert all(np.array_equal(a, b) for a, b in zip(inline, want))
+
+
+def test_hold_two_keeps_the_previous_image_valid(tmp_path):
+    """hold = 2 (the GPU owner queues page n+1's upload before it waits for page n): an image handed out is still intact while
+    the next one is in the consumer's hands -- with the fewest slots that allows (hold + 1) and more pages than slots, so every
+    slot is recycled several times"""
+    rng = np.random.default_rng(1)
+    paths, want = [], []
+    for k in range(9):
+        arr = rng.integers(0, 255, (30, 40 + k), dtype=np.uint8)
+        p = tmp_path / f"h{k}.png"
+        Image.fromarray(arr).save(p)
+        paths.append(str(p))
+        want.append(arr)
+    pool = host_pipeline.DecodePool(paths, n_workers=2, slot_bytes=1 << 14, n_slots=3, hold=2)
+    assert host_pipeline.DecodePool(paths, n_workers=4, hold=2).n_slots == 7
+    prev = None
+    for k, (p, img) in enumerate(pool):
+        assert np.array_equal(img, want[k])
+        if prev is not None:
+            assert np.array_equal(prev, want[k - 1])         # a view into its slot, not a copy
+        prev = img
+    assert k == 8
 
 
 def test_decode_pool_reports_failures(tmp_path):

@@ -287,3 +287,43 @@ def test_pages_in_flight_give_the_masks_of_the_page_by_page_form(tmp_path, monke
             assert sc2 == sc and extras["size"] == size
             for k, (starts, ends) in masks.items():
                 assert polygonize.shapes_from_segments(starts, ends, size[0], size[1], connectivity=8) == polys[k]
+
+
+@pytest.mark.parametrize("color", [False, True])
+def test_heading_pages_in_flight_give_the_measurements_of_the_page_by_page_form(tmp_path, color):
+    """HeadingNetPostProcessor.enqueue_page / collect_page (one page behind the GPU; net output and distance transform stay in
+    HBM, gray conversion and box sums on the device) against the step-by-step form on the host -- oracle net output,
+    oracle distance transform, numpy slice sums: stroke widths and heights identical, net confidences to 1e-12 (integer sum / 255
+    instead of a float64 sum of uint8 / 255).  Lines beyond the page border and a line without outline included."""
+    from citlab_article_separation_new_amd import image_io, net_post_processing_helper as helper
+    from citlab_article_separation_new_amd.heading_net_post_processor import HeadingNetPostProcessor, LineGeometry
+    from oracle import aru_oracle, classical_oracle as co
+    pb, lst, data = _setup(tmp_path, color=color)
+    graph = helper.load_graph(pb)
+    base = image_io.load_image_bgr(str(data / "p0.png"))
+    pages = [base, np.ascontiguousarray(base[:700, :500]), np.ascontiguousarray(base[::-1])]
+    lines = [LineGeometry(f"l{i}", [(x0, y0), (x1, y0), (x1, y1), (x0, y1)])
+             for i, (x0, y0, x1, y1) in enumerate([(60, 70 + 60 * k, 300, 110 + 60 * k) for k in range(6)]
+                                                  + [(320, 80, 560, 170), (450, 600, 640, 720), (0, 0, 30, 12), (10, 20, 11, 21)])]
+    lines.append(LineGeometry("none", []))
+    hp = HeadingNetPostProcessor([], pb, 450, 1.0, weight_dict={"net": 0.8, "stroke_width": 0.0, "text_height": 0.2})
+    hp.gpu_devices = "0"
+    tickets = [hp.enqueue_page(p) for p in pages]                       # three pages queued before the first is measured
+    for img, t in zip(pages, tickets):
+        sw, th, netp = hp.collect_page(t, lines)
+        _, grey, sc = co.scale_and_gray(img, 450, 1.0)
+        net_map = aru_oracle.to_uint8(aru_oracle.forward_torch(grey.astype(np.float32), graph.tensors, graph.cfg))[:, :, 0] / 255
+        swt = co.swt_distance_transform(img)
+        assert set(sw) == set(th) == set(netp) == {l.id for l in lines}
+        assert (sw["none"], th["none"], netp["none"]) == (0, 0, 0)
+        n_pos = 0
+        for l in lines[:-1]:
+            w_sw, w_th = co.swt_features_textline(swt, l.get_bounding_box())
+            assert (sw[l.id], th[l.id]) == (w_sw, w_th), l.id
+            xs = [int(sc * x) for x, _ in l.surr_p]
+            ys = [int(sc * y) for _, y in l.surr_p]
+            want = co.net_prob_textline(net_map, (min(xs), min(ys), max(xs) - min(xs) + 1, max(ys) - min(ys) + 1))
+            # the engine's uint8 map may differ from the oracle's by isolated +-1 flips (p * 255 on an integer): <= 1e-4 of the pixels
+            assert abs(netp[l.id] - want) <= 1e-4 / 255 + 1e-12, (l.id, netp[l.id], want)
+            n_pos += want > 0
+        assert n_pos >= 5
