@@ -88,7 +88,9 @@ def run_cpu_baseline(args):
     oracle on one graph: visual net incl. its backbone on 683 x 1024, or the geometric net).
     pages/s = P * (rows/H page) / slowest worker."""
     import subprocess
-    cores = os.cpu_count() or 1
+    from citlab_article_separation_new_amd.host_util import effective_cpus
+    logical = os.cpu_count() or 1
+    cores = effective_cpus()                       # affinity mask and cgroup quota: what this container may actually use
     threads = min(16, cores)                       # torch-CPU convs of this net stop scaling at ~16 threads
     workers = max(1, min(8, (cores // 2 or 1) // threads)) if cores > threads else 1
     rows = args.cpu_sample_height or (args.height if cores >= 64 else max(256, args.height // 3))
@@ -110,8 +112,9 @@ def run_cpu_baseline(args):
     t_page = max(r["t_aru"] / frac + r["t_gnn"] for r in res)      # slowest worker (scaled to a whole page if a band)
     used = threads * len(res)
     return {
-        "value": round(len(res) / t_page, 5), "unit": "pages/s", "cores": used, "cores_of": cores, "kind": "port",
-        "sample": (f"{used} of the box's {cores} logical CPUs: {len(res)} worker processes x {threads} threads, each: torch-CPU "
+        "value": round(len(res) / t_page, 5), "unit": "pages/s", "cores": used, "cores_of": cores, "logical_cpus": logical, "kind": "port",
+        "sample": (f"{used} of the {cores} CPUs this container may use (the box has {logical} logical CPUs"
+                   + (f", cgroup quota {cores}" if cores < logical else "") + f"): {len(res)} worker processes x {threads} threads, each: torch-CPU "
                    "fp32 ARU-Net oracle on "
                    + (f"one whole synthetic {args.width}x{args.height}px scan" if rows >= args.height else
                       f"a {args.width}x{rows}px band of a synthetic scan (scaled x{1 / frac:.2f} to a page)")
@@ -145,6 +148,7 @@ def e2e_files(args, dev_index):
     from citlab_article_separation_new_amd import net_post_processing_helper as helper, synth
     from citlab_article_separation_new_amd.config import AruConfig
     from citlab_article_separation_new_amd.host_pipeline import host_workers_default
+    from citlab_article_separation_new_amd.host_util import effective_cpus
     from citlab_article_separation_new_amd.separator_net_post_processor import SeparatorNetPostProcessor
     from citlab_article_separation_new_amd.weights import init_aru_weights
     H, W, n = args.height, args.width, args.e2e_pages
@@ -178,7 +182,8 @@ def e2e_files(args, dev_index):
             "note": f"separator CLI path, --fixed_height {H} (net on the full {W}x{H} page): PNG files -> {workers} decode / XML "
                     f"worker processes around ONE GPU owner (one page behind the GPU: page n+1 is uploaded and queued before page n's segments are waited for; device_stage = upload + queueing + waiting for results) -> PAGE-XML files; worker start-up (first_page_s: process spawn, page-locking of the decode slots, first decode) inside pages_per_s, excluded from "
                     f"steady_pages_per_s; "
-                    f"box has {os.cpu_count()} logical CPUs"}
+                    f"box has {os.cpu_count()} logical CPUs, this container may use {effective_cpus()} (affinity / cgroup quota): "
+                    f"a PNG decode of one scan costs ~0.11 CPU-seconds, so the host side is the bound below ~9 CPUs per 80 pages/s"}
 
 
 def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages):

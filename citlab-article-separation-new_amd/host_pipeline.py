@@ -252,6 +252,7 @@ class DecodePool:
                 del img
                 next_out += 1
         finally:
+            mark("last page handed out")
             stop_preparing.append(True)
             if preparer:
                 preparer.join()
@@ -267,6 +268,7 @@ class DecodePool:
             for s in slots:
                 s.close()
                 s.unlink()
+            mark("workers joined, slots released")
         if inline_instead:                                  # no room for the shared-memory slots (a small /dev/shm)
             self.inline_decodes = len(self.paths)
             yield from self._inline()
@@ -331,6 +333,10 @@ def pin_callbacks(device=0):
 
 def host_workers_default():
     """host workers per GPU owner when the caller does not say: enough to hide a ~110 ms PNG decode (+ the PAGE-XML write) behind
-    a ~9 ms GPU stage -- 12 workers feed 70 pages/s, 24 feed 84 (768 scans of 3000 x 4500, profiles/README r3) -- and few enough
-    that eight owners fit a 256-CPU box"""
-    return max(1, min(24, (os.cpu_count() or 2) // 4))
+    a ~9 ms GPU stage, few enough that eight owners fit a 256-CPU box, and sized by what the container may use
+    (``effective_cpus``), not by the machine: on a box of this pool (256 logical CPUs under a cgroup quota of 16) 14 workers
+    feed 83 pages/s and 24 feed 94 -- the workers also wait for files and queues, so 1.5 per CPU is the better fill -- and
+    beyond that the quota throttles the whole group, the owner included"""
+    from .host_util import effective_cpus
+    cpus = effective_cpus()
+    return max(1, min(24, cpus // 4 if cpus >= 96 else cpus * 3 // 2))

@@ -41,8 +41,11 @@ class AruGraph:
             self._blob = pack_blob(self.tensors)
         return self._blob
 
-    def handle(self, device_id: int = 0):
-        if device_id not in self._handles:
+    def handle(self, device_id: int = 0, lane: int = 0):
+        """the model instance on a device; ``lane`` > 0: a further instance (own activation arena and side streams) for a
+        caller that runs pages on several streams at once"""
+        key = device_id if lane == 0 else (device_id, lane)
+        if key not in self._handles:
             lib = _lib.init_device(device_id)
             c = self.cfg
             if c.compute_dtype not in ("f32", "bf16"):
@@ -54,8 +57,8 @@ class AruGraph:
             h = lib.asep_aru_load(blob, len(blob), C.byref(cfg))
             if not h:
                 raise _lib.AsepError("asep_aru_load failed: " + _lib.last_error())
-            self._handles[device_id] = h
-        return self._handles[device_id]
+            self._handles[key] = h
+        return self._handles[key]
 
     def close(self):
         if self._handles:

@@ -98,8 +98,20 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
 
     # -- the fused device path ---------------------------------------------------------------------------------
     SEGMENT_CAPACITY = 1 << 14         # boundary segments per mask copied back without asking (a page has a few hundred)
+    PAGE_LANES = 2                     # pages in flight of the pipelined run() (= streams / model instances / scratch arenas)
 
-    def enqueue_page(self, image, edges_only=True):
+    def _lane_stream(self, tdev, lane):
+        """lane 0 works on the caller's current stream; further lanes own a stream (and, below, a model instance and a scratch
+        arena), so that pages of different lanes share the chip"""
+        import torch
+        if lane == 0:
+            return torch.cuda.current_stream(tdev)
+        streams = self.__dict__.setdefault("_lane_streams", {})
+        if (tdev.index, lane) not in streams:
+            streams[(tdev.index, lane)] = torch.cuda.Stream(tdev)
+        return streams[(tdev.index, lane)]
+
+    def enqueue_page(self, image, edges_only=True, lane=0):
         """Queue the device stages of one decoded page and return a ticket for :meth:`collect_page`.
 
         Everything is only enqueued -- upload, resize + gray, ARU-Net, CC filter / openings, boundary segments, the copy of
@@ -116,9 +128,9 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
         sc = get_scaling_factor(H, W, self.scaling_factor, fixed_height=self.fixed_height)
         h, w = image_ops.scaled_size(H, W, sc)
         ncls = self.pb_graph.cfg.n_classes
-        _, ws = image_ops._workspace(dev)
+        _, ws = image_ops._workspace(dev, lane)
         t = {"sc": sc, "size": (h, w), "edges_only": edges_only, "device": dev}
-        with torch.cuda.device(tdev):
+        with torch.cuda.device(tdev), torch.cuda.stream(self._lane_stream(tdev, lane)):
             stream = torch.cuda.current_stream(tdev)
             sp = C.c_void_p(stream.cuda_stream)
             # the upload is queued like everything else (a page is 0.3 ms of PCIe; a copy on a second stream ended up behind the
@@ -127,13 +139,15 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
             # before the call returns
             d_img = torch.empty((H, W, Cn), dtype=torch.uint8, device=tdev)
             d_img.copy_(torch.from_numpy(image), non_blocking=True)
+            t["uploaded"] = torch.cuda.Event()
+            t["uploaded"].record(stream)
             d_gray = torch.empty((h, w), dtype=torch.float32, device=tdev)
             _lib.check(lib.asep_prep_scale_gray_dev(ws, d_img.data_ptr(), H, W, Cn, float(sc), None,
                                                     d_gray.data_ptr(), sp), "asep_prep_scale_gray_dev")
             d_out = torch.empty((h, w, ncls), dtype=torch.float32, device=tdev)
             d_u8 = torch.empty((h, w, ncls), dtype=torch.uint8, device=tdev)
             d_mask = torch.empty((h, w, ncls), dtype=torch.uint8, device=tdev)
-            _lib.check(lib.asep_aru_forward_dev(self.pb_graph.handle(dev), d_gray.data_ptr(), h, w, d_out.data_ptr(),
+            _lib.check(lib.asep_aru_forward_dev(self.pb_graph.handle(dev, lane), d_gray.data_ptr(), h, w, d_out.data_ptr(),
                                                 d_u8.data_ptr(), d_mask.data_ptr(), float(self.threshold), sp),
                        "asep_aru_forward_dev")
             size = h * w
@@ -233,8 +247,8 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
     def run(self):
         """:135-159.  With ``host_workers`` > 1 the images are decoded ahead of the GPU by worker processes (DMA-able
         shared-memory slots) and the PAGE-XML files are written behind it; the GPU-owning process only runs the device
-        stages and chains the polygon rings -- one page behind the GPU: page n+1 is uploaded and queued before page n's
-        segments are waited for, so the chip does not idle while the host chains rings (``device_seconds`` = upload +
+        stages and chains the polygon rings -- PAGE_LANES - 1 pages behind the GPU: the next pages are uploaded and queued
+        before a page's segments are waited for, so the chip does not idle while the host chains rings (``device_seconds`` =
         queueing + waiting for results, ``host_seconds`` = chaining and handing over)."""
         from .host_pipeline import DecodePool, WritePool, pin_callbacks
         page_objects = []
@@ -243,20 +257,26 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
         decode = DecodePool(self.image_paths, self.host_workers if pipelined else 0, register=reg, unregister=unreg, hold=2)
         with WritePool(self.host_workers if pipelined else 0) as writers:
             t_prev = t_run = time.perf_counter()
-            pending = None
+            pending, n_enqueued = [], 0
+            lanes = self.PAGE_LANES if pipelined else 1
             for image_path, image in decode:
                 t_dev = time.perf_counter()
                 if self.first_page_seconds is None:          # worker start-up + slot page-locking + the first decode
                     self.first_page_seconds = t_dev - t_run
                 self.wait_seconds += t_dev - t_prev
-                ticket = self.enqueue_page(image, edges_only=not self.keep_outputs)
+                # pipelined: consecutive pages alternate between lanes (streams, model instances, scratch arenas): the chip works
+                # on the next pages' nets while a page's classical stages -- small kernels that do not fill it -- run, and
+                # while this process chains rings.  A lane's previous page has been collected before the lane is used again.
+                ticket = self.enqueue_page(image, edges_only=not self.keep_outputs, lane=n_enqueued % lanes)
+                n_enqueued += 1
                 self.device_seconds += time.perf_counter() - t_dev
-                if pending is not None:
-                    self._finish_page(*pending, writers, pipelined, page_objects)
-                pending = (image_path, ticket)
+                pending.append((image_path, ticket))
+                if len(pending) >= max(2, lanes):
+                    self._finish_page(*pending.pop(0), writers, pipelined, page_objects)
+                ticket["uploaded"].synchronize()             # (long done) the image's slot may be recycled from here on
                 t_prev = time.perf_counter()
-            if pending is not None:
-                self._finish_page(*pending, writers, pipelined, page_objects)
+            for item in pending:
+                self._finish_page(*item, writers, pipelined, page_objects)
         return page_objects
 
 

@@ -123,3 +123,26 @@ def test_write_pool_runs_tasks_and_surfaces_errors(tmp_path):
     with host_pipeline.WritePool(0) as w:                    # inline
         w.submit(_touch, str(tmp_path / "inline.txt"), "i")
     assert (tmp_path / "inline.txt").read_text() == "i"
+
+
+def test_effective_cpus_honours_the_cgroup_quota(tmp_path):
+    """os.cpu_count() counts the machine; the pools are sized by what the container may use (cgroup v2 cpu.max, v1 cfs quota)"""
+    from citlab_article_separation_new_amd import host_util
+    allowed = len(os.sched_getaffinity(0))
+    v2 = tmp_path / "v2"
+    v2.mkdir()
+    (v2 / "cpu.max").write_text("150000 100000\n")
+    assert host_util.effective_cpus(str(v2)) == min(allowed, 1)
+    (v2 / "cpu.max").write_text("1600000 100000\n")
+    assert host_util.effective_cpus(str(v2)) == min(allowed, 16)
+    (v2 / "cpu.max").write_text("max 100000\n")
+    assert host_util.effective_cpus(str(v2)) == allowed
+    v1 = tmp_path / "v1"
+    (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("300000\n")
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert host_util.effective_cpus(str(v1)) == min(allowed, 3)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    assert host_util.effective_cpus(str(v1)) == allowed
+    assert host_util.effective_cpus(str(tmp_path / "none")) == allowed
+    assert 1 <= host_pipeline.host_workers_default() <= 24

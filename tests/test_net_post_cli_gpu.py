@@ -281,7 +281,7 @@ def test_pages_in_flight_give_the_masks_of_the_page_by_page_form(tmp_path, monke
     assert any(v for w, _, _ in want for v in w.values())
     for cap in (SeparatorNetPostProcessor.SEGMENT_CAPACITY, 4):
         monkeypatch.setattr(SeparatorNetPostProcessor, "SEGMENT_CAPACITY", cap)
-        tickets = [proc.enqueue_page(p, edges_only=True) for p in pages]
+        tickets = [proc.enqueue_page(p, edges_only=True, lane=k % 2) for k, p in enumerate(pages)]      # two lanes, as run() does
         for t, (polys, sc, size) in zip(tickets, want):
             masks, sc2, extras = proc.collect_page(t)
             assert sc2 == sc and extras["size"] == size
