@@ -568,9 +568,8 @@ def main():
                         roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                          "frac": round(gbs / PEAK_HBM_GBS, 4), "achievable_peak": ACHIEVABLE_HBM_GBS,
                                          "frac_of_achievable": round(gbs / ACHIEVABLE_HBM_GBS, 4)})
-                        if d_situ and d_iso:
-                            roofline["frac_in_situ"] = round(roofline["traffic"] / (d_situ["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)
-                            roofline["frac_isolated"] = round(roofline["traffic"] / (d_iso["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)
+                        for name, d in (("frac_in_situ", d_situ), ("frac_isolated", d_iso)):      # against the HBM roof like `frac`
+                            roofline[name] = round(roofline["traffic"] / (d["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if d else None
             except Exception:
                 pass
         for k in kernels:
