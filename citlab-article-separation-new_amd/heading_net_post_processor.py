@@ -310,6 +310,8 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
             # before the call returns
             d_img = torch.empty((H, W, Cn), dtype=torch.uint8, device=tdev)
             d_img.copy_(torch.from_numpy(image), non_blocking=True)
+            t["uploaded"] = torch.cuda.Event()
+            t["uploaded"].record(stream)
             if self.weight_dict['net'] > 0:
                 d_gray = torch.empty((h, w), dtype=torch.float32, device=tdev)
                 _lib.check(lib.asep_prep_scale_gray_dev(ws, d_img.data_ptr(), H, W, Cn, float(sc), None,
