@@ -72,6 +72,8 @@ def parse_args():
     ap.add_argument("--no-kernel-timing", action="store_true", help="same as --kernel-timing none")
     ap.add_argument("--e2e-pages", type=int, default=384,
                     help="scans of the files-in / files-out secondary figure (separator CLI path with host workers; 0 = skip)")
+    ap.add_argument("--e2e-heading-pages", type=int, default=192,
+                    help="scans of the heading command line inside the files-in / files-out leg (0 = skip)")
     ap.add_argument("--e2e-leg", action="store_true", help=argparse.SUPPRESS)      # internal: run only the e2e_files leg, print its JSON
     ap.add_argument("--e2e-device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-secondary", action="store_true",
@@ -171,6 +173,31 @@ def e2e_files(args, dev_index):
         proc.run()
         dt = time.perf_counter() - t0
         n_xml = len([f for f in os.listdir(os.path.join(tmp, "page")) if f.endswith(".xml.xml")])
+        # the heading command line on the same scans (BASELINE configs[2] as files): PAGE-XML with ~700 text lines per page in,
+        # heading tags out; the net on the full page like the separator leg
+        heading = None
+        if args.e2e_heading_pages > 0:
+            from citlab_article_separation_new_amd.heading_net_post_processor import HeadingNetPostProcessor
+            nh = min(n, args.e2e_heading_pages)
+            for f in os.listdir(os.path.join(tmp, "page")):
+                os.remove(os.path.join(tmp, "page", f))
+            n_lines = [synth.synth_page_xml(os.path.join(tmp, "page", f"p{k:03d}.xml"), W, H, k % 4) for k in range(nh)]
+            wd = {'net': 0.8, 'stroke_width': 0.0, 'text_height': 0.2}           # run_net_post_processing.py:15-23
+            td = {'net_thresh': 1.0, 'stroke_width_thresh': 1.0, 'text_height_thresh': 0.9, 'sw_th_thresh': 0.9}
+            hp = HeadingNetPostProcessor(paths[:2], graph, H, 1.0, wd, 0.4, td, 0.8)
+            hp.host_workers = 0
+            hp.run(gpu_device=str(dev_index))                                    # warm-up
+            hp = HeadingNetPostProcessor(paths[:nh], graph, H, 1.0, wd, 0.4, td, 0.8)
+            hp.host_workers = workers
+            t0 = time.perf_counter()
+            hp.run(gpu_device=str(dev_index))
+            dth = time.perf_counter() - t0
+            n_hx = len([f for f in os.listdir(os.path.join(tmp, "page")) if f.endswith(".xml.xml")])
+            heading = {"pages_per_s": round(nh / dth, 2), "ms_per_page": round(1e3 * dth / nh, 2), "scans": nh,
+                       "text_lines_per_page": int(np.mean(n_lines)), "page_xml_written": n_hx,
+                       "note": f"heading CLI path, --fixed_height {H}: PNG + PAGE-XML files -> decode / parse / write workers around "
+                               "one GPU owner (net, gray conversion, stroke-width transform, per-line statistics and box sums on "
+                               "the device) -> PAGE-XML with heading tags; worker start-up included"}
     graph.close()
     first = proc.first_page_seconds or 0.0
     return {"pages_per_s": round(n / dt, 2), "ms_per_page": round(1e3 * dt / n, 2), "scans": n, "host_workers": workers,
@@ -178,7 +205,7 @@ def e2e_files(args, dev_index):
             "page_xml_written": n_xml, "gpu_owner_device_stage_share": round(proc.device_seconds / dt, 3),
             "gpu_owner_waiting_for_decode_share": round(proc.wait_seconds / dt, 3),
             "gpu_owner_ring_chaining_share": round(proc.host_seconds / dt, 3),
-            "dtype": args.dtype,
+            "dtype": args.dtype, "heading": heading,
             "note": f"separator CLI path, --fixed_height {H} (net on the full {W}x{H} page): PNG files -> {workers} decode / XML "
                     f"worker processes around ONE GPU owner (one page behind the GPU: page n+1 is uploaded and queued before page n's segments are waited for; device_stage = upload + queueing + waiting for results) -> PAGE-XML files; worker start-up (first_page_s: process spawn, page-locking of the decode slots, first decode) inside pages_per_s, excluded from "
                     f"steady_pages_per_s; "
@@ -274,7 +301,7 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
         if args.e2e_pages > 0:
             # in a child process of its own, so that the leg's worker processes do not inherit this process's module state
             import subprocess
-            cmd = [sys.executable, os.path.abspath(__file__), "--e2e-leg", "--e2e-pages", str(args.e2e_pages), "--height", str(args.height),
+            cmd = [sys.executable, os.path.abspath(__file__), "--e2e-leg", "--e2e-pages", str(args.e2e_pages), "--e2e-heading-pages", str(args.e2e_heading_pages), "--height", str(args.height),
                    "--width", str(args.width), "--e2e-device", str(dev.index or 0), "--dtype", args.dtype]
             r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, text=True, timeout=1800)
             lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]

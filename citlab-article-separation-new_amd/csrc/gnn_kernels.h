@@ -964,7 +964,48 @@ __global__ void __launch_bounds__(256) gnn_roi_compress_kernel(RoiArgs a) {
     const int nx = max(x1 - x0 + 1, 1), ny = max(y1 - y0 + 1, 1);
     const int C = a.C;
     float m = -INFINITY;
-    if (256 % C == 0) {
+    constexpr int VEC = BF ? 8 : 4;                            // values per 16-byte load
+    const int groups = C / VEC;                                // channel groups of VEC: a lane's group is lane % groups
+    if (C % VEC == 0 && groups <= 8 && (groups & (groups - 1)) == 0 && ((size_t)a.fm & 15) == 0) {
+        // 16-byte loads: a thread keeps VEC consecutive channels (the same ones for every vector it visits, because its vector
+        // index advances by 256 and 256 * VEC is a multiple of C); maxima are exact, so the result is that of the scalar form
+        float mv[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) mv[k] = -INFINITY;
+        const int rowvec = nx * C / VEC;
+        for (int y = 0; y < ny; ++y) {
+            const uint4* row = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.fm) +
+                                                              ((size_t)(y0 + y) * a.fw + x0) * C * (BF ? 2 : 4));
+            for (int i = tid; i < rowvec; i += 256) {
+                const uint4 q = row[i];
+                if constexpr (BF) {
+                    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        mv[2 * k] = fmaxf(mv[2 * k], __uint_as_float(w[k] << 16));
+                        mv[2 * k + 1] = fmaxf(mv[2 * k + 1], __uint_as_float(w[k] & 0xffff0000u));
+                    }
+                } else {
+                    mv[0] = fmaxf(mv[0], __uint_as_float(q.x)); mv[1] = fmaxf(mv[1], __uint_as_float(q.y));
+                    mv[2] = fmaxf(mv[2], __uint_as_float(q.z)); mv[3] = fmaxf(mv[3], __uint_as_float(q.w));
+                }
+            }
+        }
+        // lanes of one group first (xor distances that are multiples of `groups`), then the four waves through 1 KB of LDS:
+        // the kernel keeps its LDS footprint small enough to share a CU with the page net's 155 KB blocks
+        __shared__ float wred[4][8][VEC];
+        for (int off = groups; off < 64; off <<= 1)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) mv[k] = fmaxf(mv[k], __shfl_xor(mv[k], off));
+        if ((tid & 63) < groups)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) wred[tid >> 6][tid & 63][k] = mv[k];
+        __syncthreads();
+        if (tid < C) {
+            const int g = tid / VEC, slot = tid % VEC;
+            vmax[tid] = fmaxf(fmaxf(wred[0][g][slot], wred[1][g][slot]), fmaxf(wred[2][g][slot], wred[3][g][slot]));
+        }
+    } else if (256 % C == 0) {
         // a thread keeps one channel: rows of nx*C contiguous floats are read coalesced
         const int rowlen = nx * C;
         for (int y = 0; y < ny; ++y) {

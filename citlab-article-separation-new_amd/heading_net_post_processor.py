@@ -147,13 +147,37 @@ class LineGeometry:
         return min(xs), min(ys), max(xs) - min(xs) + 1, max(ys) - min(ys) + 1
 
 
+def line_boxes(text_lines):
+    """(ids, bounding boxes int64 [L,4] = xmin, ymin, xmax, ymax of each outline, has-outline bool [L]) of text lines in order:
+    all the per-line measurements need (outline coordinates are integers, page_xml.parse_points)"""
+    ids = [tl.id for tl in text_lines]
+    boxes = np.zeros((len(ids), 4), dtype=np.int64)
+    has = np.zeros(len(ids), dtype=bool)
+    for i, tl in enumerate(text_lines):
+        if tl.surr_p:
+            xs = [p[0] for p in tl.surr_p]
+            ys = [p[1] for p in tl.surr_p]
+            boxes[i] = (min(xs), min(ys), max(xs), max(ys))
+            has[i] = True
+    return ids, boxes, has
+
+
 def read_line_geometry(page_path):
-    """worker task: (id, outline) of every text line of a PAGE-XML in document order, or None if the file is missing"""
+    """worker task: ``line_boxes`` of every text line of a PAGE-XML in document order, or None if the file is missing"""
     import os
     from .page_xml import Page
     if not os.path.exists(page_path):
         return None
-    return [(tl.id, tl.surr_p) for tl in Page(page_path).get_textlines()]
+    return line_boxes(Page(page_path).get_textlines())
+
+
+def _slice_bounds(start, length, size):
+    """what numpy makes of ``a[start:start + length]`` on an axis of ``size`` (negative indices count from the end): the bounds
+    of ``slice(start, start + length).indices(size)`` for int64 arrays -> (first, last + 1 >= first)"""
+    stop = start + length
+    first = np.where(start < 0, np.maximum(start + size, 0), np.minimum(start, size))
+    last = np.where(stop < 0, np.maximum(stop + size, 0), np.minimum(stop, size))
+    return first, np.maximum(last, first)
 
 
 def write_heading_page(page_path, image_path, fixed_height, scaling_factor, values, weight_dict, threshold, thresh_dict,
@@ -337,52 +361,47 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
         return t
 
     def collect_page(self, t, text_lines):
-        """The three per-line measurements of :94-119 for a ticket of :meth:`enqueue_page`, taken on a side stream while the
-        next page's kernels run: stroke width and text height from the device-resident distance transform, the mean net
-        confidence from exact integer box sums of the uint8 net output (``sum / 255 / (width * height)``: the reference sums
-        ``uint8 / 255`` in float64, which differs by rounding in the last bits only)."""
+        """:meth:`collect_boxes` for text-line objects (``id``, ``surr_p``)"""
+        return self.collect_boxes(t, *line_boxes(text_lines))
+
+    def collect_boxes(self, t, ids, boxes, has):
+        """The three per-line measurements of :94-119 for a ticket of :meth:`enqueue_page` and the lines' bounding boxes
+        (``line_boxes``), taken on a side stream while the next page's kernels run: stroke width and text height from the
+        device-resident distance transform (:218-245, the crop [ymin : ymax + 2, xmin : xmax + 2]), the mean net confidence
+        (:247-270) from exact integer box sums of the uint8 net output: ``sum / 255 / (width * height)`` -- the reference sums
+        ``uint8 / 255`` in float64, which differs by rounding in the last bits only.  The box of the rescaled outline is the
+        rescaled box of the outline (``int(x * sc)`` is monotone), so only the four extremes of a line are needed; everything
+        per line is array arithmetic.  -> (stroke widths, text heights, net confidences), dicts by line id"""
         import torch
         dev = t["device"]
         tdev = torch.device("cuda", dev)
         h, w, ncls = t["size"]
         sc = t["sc"]
-        stroke_width_dict, height_dict, net_prob_dict = {}, {}, {}
-        with_coords = [tl for tl in text_lines if tl.surr_p]
+        sel = np.flatnonzero(has)
+        bx = boxes[sel]
+        sw = np.zeros(len(ids))
+        ht = np.zeros(len(ids), dtype=np.int64)
+        prob = np.zeros(len(ids))
         with torch.cuda.device(tdev):
             side = self._side_stream
             side.wait_event(t["done"])
             sp = C.c_void_p(side.cuda_stream)
-            boxes = []
-            for tl in with_coords:
-                x, y, bw, bh = tl.get_bounding_box()
-                boxes.append([x, y, x + bw + 1, y + bh + 1])            # the crop [ya:yb+1, xa:xb+1] of :232-236
-            sws, hts = image_ops.swt_line_features(t["swt"], boxes, device=dev, stream=sp, lane=1)
-            probs = np.zeros(len(with_coords))
-            if "d_u8" in t and with_coords:
-                nboxes, nominal = [], []
-                for tl in with_coords:                                   # :247-270
-                    pts = rescale_points(tl.surr_p, sc)
-                    xs = [p[0] for p in pts]
-                    ys = [p[1] for p in pts]
-                    xa, ya = min(xs), min(ys)
-                    width, height = max(xs) - xa + 1, max(ys) - ya + 1
-                    y0, y1, _ = slice(ya, ya + height).indices(h)       # what numpy makes of net_output[ya:ya+height, xa:xa+width]
-                    x0, x1, _ = slice(xa, xa + width).indices(w)
-                    nboxes.append([x0, y0, max(x0, x1), max(y0, y1)])
-                    nominal.append(width * height)
-                sums = image_ops.box_sums_dev(t["d_u8"].data_ptr(), (h, w, ncls), nboxes, channel=0, device=dev, stream=sp,
-                                              lane=1)
-                probs = sums / 255 / np.asarray(nominal, dtype=np.float64)
+            crop = np.stack([bx[:, 0], bx[:, 1], bx[:, 2] + 2, bx[:, 3] + 2], axis=1) if len(sel) else np.zeros((0, 4), np.int64)
+            sws, hts = image_ops.swt_line_features(t["swt"], crop, device=dev, stream=sp, lane=1)
+            sw[sel], ht[sel] = sws, hts
+            if "d_u8" in t and len(sel):
+                lo = (bx[:, :2] * sc).astype(np.int64)                  # rescale_points: int(p * sc), truncation towards zero
+                hi = (bx[:, 2:] * sc).astype(np.int64)
+                size = hi - lo + 1                                      # nominal width, height
+                x0, x1 = _slice_bounds(lo[:, 0], size[:, 0], w)
+                y0, y1 = _slice_bounds(lo[:, 1], size[:, 1], h)
+                sums = image_ops.box_sums_dev(t["d_u8"].data_ptr(), (h, w, ncls), np.stack([x0, y0, x1, y1], axis=1), channel=0,
+                                              device=dev, stream=sp, lane=1)
+                prob[sel] = sums / 255 / (size[:, 0] * size[:, 1]).astype(np.float64)
             else:
                 side.synchronize()
-        batched = {tl.id: (sws[i], int(hts[i]), probs[i]) for i, tl in enumerate(with_coords)}
-        for text_line in text_lines:
-            stroke_width, height, prob = batched[text_line.id] if text_line.surr_p else (0, 0, 0)
-            stroke_width_dict[text_line.id] = stroke_width
-            height_dict[text_line.id] = height
-            net_prob_dict[text_line.id] = prob if "d_u8" in t else 0
         t.clear()
-        return stroke_width_dict, height_dict, net_prob_dict
+        return dict(zip(ids, sw.tolist())), dict(zip(ids, ht.tolist())), dict(zip(ids, prob.tolist()))
 
     def run(self, gpu_device='0'):
         """:272-303."""
@@ -413,7 +432,7 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
                                 geometry[nxt] = parsers.submit(read_line_geometry, get_page_path(nxt))
                 if pipelined:
                     prefetch_geometry(2 * n_workers)
-                pending = None
+                pending = []
 
                 def finish(image_path, ticket):
                     # the GPU owner only measures; parsing happened in a worker, fusion + tags + XML go to a worker
@@ -421,19 +440,21 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
                     lines = geometry.pop(image_path).result()
                     prefetch_geometry(1)
                     if lines is None:                       # no PAGE-XML yet: the writer creates an empty one
-                        lines = []
-                    values = self.collect_page(ticket, [LineGeometry(i, p) for i, p in lines])
+                        lines = ([], np.zeros((0, 4), np.int64), np.zeros(0, bool))
+                    values = self.collect_boxes(ticket, *lines)
                     writers.submit(write_heading_page, page_path, image_path, self.fixed_height, self.scaling_factor,
-                                   [{k: float(v) for k, v in d.items()} for d in values], self.weight_dict, self.threshold,
-                                   self.thresh_dict, self.text_line_percentage)
+                                   list(values), self.weight_dict, self.threshold, self.thresh_dict, self.text_line_percentage)
 
-                for image_path, image in DecodePool(self.image_paths, n_workers, register=reg, unregister=unreg, hold=2):
+                ahead_pages = 2                               # pages queued behind the one whose lines are being measured
+                for image_path, image in DecodePool(self.image_paths, n_workers, register=reg, unregister=unreg,
+                                                    hold=ahead_pages + 1):
                     if pipelined:
-                        # one page behind the GPU: page n+1 is uploaded and queued before page n's lines are measured
-                        ticket = self.enqueue_page(image)
-                        if pending is not None:
-                            finish(*pending)
-                        pending = (image_path, ticket)
+                        # behind the GPU: the next pages are uploaded and queued before a page's lines are measured (the
+                        # measuring calls wait for their small kernels; the chip has the next nets to work on meanwhile).  An image
+                        # stays valid for ahead_pages + 1 iterations, i.e. until its own page has been collected.
+                        pending.append((image_path, self.enqueue_page(image)))
+                        if len(pending) > ahead_pages:
+                            finish(*pending.pop(0))
                         continue
                     if self.weight_dict['net'] > 0:
                         net_output = self.heading_probability(image)
@@ -446,8 +467,8 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
                     swt_feature_image = self.SWT.distance_transform(image, on_device=True)
                     new_page_objects.append(self.to_page_xml(get_page_path(image_path), image_path, net_output_post,
                                                              swt_feature_image))
-                if pending is not None:
-                    finish(*pending)
+                for item in pending:
+                    finish(*item)
             finally:
                 if pipelined:
                     parsers.shutdown()

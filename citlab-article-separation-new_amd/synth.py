@@ -118,3 +118,32 @@ def synth_graph(k: int = 0, N: int = 200, n_pairs: int = 10000, node_dim: int = 
     node_feat = rng.random((N, node_dim), dtype=np.float32)
     edge_feat = (rng.random((n_pairs, edge_dim)) < 0.15).astype(np.float32)
     return {"num_nodes": N, "interacting_nodes": edges, "node_features": node_feat, "edge_features": edge_feat}
+
+
+def synth_page_xml(path, W: int = 3000, H: int = 4500, k: int = 0, columns: int = 6):
+    """A PAGE-XML with the text lines of a newspaper page for the heading pipeline's benchmarks: ``columns`` columns of text
+    regions of 4-12 lines each, about 700 lines on 3000 x 4500 (every line with outline and baseline).  -> number of lines"""
+    rng = np.random.default_rng(1000 + k)
+    colw = (W - 120 - (columns - 1) * 40) // columns
+    regs, rid, n_lines = [], 0, 0
+    for c in range(columns):
+        x0, y = 60 + c * (colw + 40), 60
+        while y < H - 300:
+            nl, pitch = int(rng.integers(4, 13)), int(rng.integers(28, 37))
+            y1 = y + nl * pitch
+            lines = "".join(
+                f'<TextLine id="r{rid}l{i}"><Coords points="{x0},{y + i * pitch} {x0 + colw},{y + i * pitch} '
+                f'{x0 + colw},{y + (i + 1) * pitch - 4} {x0},{y + (i + 1) * pitch - 4}"/>'
+                f'<Baseline points="{x0},{y + (i + 1) * pitch - 8} {x0 + colw},{y + (i + 1) * pitch - 8}"/></TextLine>'
+                for i in range(nl))
+            regs.append(f'<TextRegion id="r{rid}"><Coords points="{x0},{y} {x0 + colw},{y} {x0 + colw},{y1} {x0},{y1}"/>'
+                        + lines + '</TextRegion>')
+            rid += 1
+            n_lines += nl
+            y = y1 + int(rng.integers(20, 60))
+    with open(path, "w") as f:
+        f.write('<?xml version="1.0" encoding="UTF-8"?>\n<PcGts xmlns="http://schema.primaresearch.org/PAGE/gts/'
+                'pagecontent/2013-07-15"><Metadata><Creator>t</Creator><Created>2020-01-01T00:00:00</Created>'
+                '<LastChange>2020-01-01T00:00:00</LastChange></Metadata>'
+                f'<Page imageFilename="x.png" imageWidth="{W}" imageHeight="{H}">' + "".join(regs) + '</Page></PcGts>')
+    return n_lines

@@ -229,3 +229,39 @@ def test_swt_component_cleaning():
     boxes = s.connected_components_cv(img)
     assert sorted(boxes) == [(10, 5, 6, 10), (45, 20, 30, 3), (50, 6, 2, 2)]
     assert s.clean_connected_components(boxes) == [(10, 5, 6, 10)]
+
+
+def test_line_box_arithmetic_equals_the_per_point_form():
+    """The heading owner measures from the four extremes of a text line (heading_net_post_processor.line_boxes, array arithmetic)
+    instead of from its points (heading_net_post_processor.py:218-270 of the reference): the box of the rescaled outline is the
+    rescaled box (int() truncation is monotone, also for negative coordinates), and the clipped crop is what numpy makes of
+    net_output[ya:ya+height, xa:xa+width] -- negative starts counting from the end included."""
+    from citlab_article_separation_new_amd.heading_net_post_processor import LineGeometry, _slice_bounds, line_boxes
+    from citlab_article_separation_new_amd.host_util import rescale_points
+    rng = np.random.default_rng(4)
+    lines = []
+    for k in range(300):
+        n = int(rng.integers(1, 9))
+        lines.append(LineGeometry(f"l{k}", [(int(x), int(y)) for x, y in rng.integers(-40, 700, (n, 2))]))
+    lines.insert(7, LineGeometry("empty", []))
+    ids, boxes, has = line_boxes(lines)
+    assert ids == [l.id for l in lines] and not has[7] and has.sum() == 300 and boxes.dtype == np.int64
+    for sc in (0.2, 1 / 3, 0.75, 1.0, 1.37):
+        lo = (boxes[:, :2] * sc).astype(np.int64)
+        hi = (boxes[:, 2:] * sc).astype(np.int64)
+        size = hi - lo + 1
+        for h, w in ((120, 90), (500, 400), (1000, 1000)):
+            x0, x1 = _slice_bounds(lo[:, 0], size[:, 0], w)
+            y0, y1 = _slice_bounds(lo[:, 1], size[:, 1], h)
+            for i, l in enumerate(lines):
+                if not l.surr_p:
+                    continue
+                x, y, bw, bh = l.get_bounding_box()
+                assert (x, y, x + bw + 1, y + bh + 1) == (boxes[i, 0], boxes[i, 1], boxes[i, 2] + 2, boxes[i, 3] + 2)
+                pts = rescale_points(l.surr_p, sc)
+                xs, ys = [p[0] for p in pts], [p[1] for p in pts]
+                xa, ya, width, height = min(xs), min(ys), max(xs) - min(xs) + 1, max(ys) - min(ys) + 1
+                assert (xa, ya, width, height) == (lo[i, 0], lo[i, 1], size[i, 0], size[i, 1])
+                ys0, ys1, _ = slice(ya, ya + height).indices(h)
+                xs0, xs1, _ = slice(xa, xa + width).indices(w)
+                assert (xs0, max(xs0, xs1), ys0, max(ys0, ys1)) == (x0[i], x1[i], y0[i], y1[i])
