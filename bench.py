@@ -557,7 +557,7 @@ def main():
             "executed_flops_per_launch": dom["executed_flops"] / dom["calls"],
             "share_of_gpu_time": round(dom["total_ms"] / sum(k["total_ms"] for k in kernels), 4),
             "event_timed_steps": n_prof * ((iso is not None) + (situ is not None)),
-            # a launch of the page net carries at most MAXP = 24 problems = 8 pages x 3 scales; the level-0 block kernels are launched
+            # a launch of the page net carries at most 12 problems = 4 pages x 3 scales; the level-0 block kernels are launched
             # exactly once per such group, so they count the groups
             "pages_per_launch": B * n_prof / groups,
             # the whole page against the same peak: executed FLOPs of ALL ARU-Net kernels of a page (incl. the relation net's

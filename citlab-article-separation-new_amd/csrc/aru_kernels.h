@@ -56,7 +56,7 @@ __device__ __forceinline__ f32x4 mfma_bf16(s16x4 a, s16x4 b, f32x4 c) {
 // ------------------------------------------------------------------------------------------------
 // One launch covers the same layer of several independent "problems" (pages x scale-space levels share
 // the layer's weights): blockIdx.x walks the concatenated tile lists, blockIdx.y the output-channel blocks.
-constexpr int MAXP = 24;   // 8 pages x 3 scale-space levels: one lane's half of a 16-page step in ONE launch (ConvArgs = 1.8 KB of kernarg)
+constexpr int MAXP = 12;
 struct ConvProb {
     const float* in0;      // source 0, NHWC with c0 channels
     const float* in1;      // source 1 (channel concat behind source 0) or nullptr

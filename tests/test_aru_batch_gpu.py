@@ -23,7 +23,7 @@ def test_batch_equals_single_pages_and_oracle(lanes, monkeypatch):
     graph = helper.AruGraph(w, cfg)
     lib = _lib.init_device(0)
     h = graph.handle(0)
-    H, W, B = 75, 131, 9                      # 9 pages x 3 scales = 27 problems > MAXP (24): exercises launch splitting
+    H, W, B = 75, 131, 5                      # 5 pages x 3 scales = 15 problems > MAXP (12): exercises launch splitting
     rng = np.random.default_rng(0)
     pages = [rng.random((H, W), dtype=np.float32) for _ in range(B)]
     d_in = [torch.from_numpy(p).cuda() for p in pages]
