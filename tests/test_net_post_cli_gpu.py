@@ -327,3 +327,27 @@ def test_heading_pages_in_flight_give_the_measurements_of_the_page_by_page_form(
             assert abs(netp[l.id] - want) <= 1e-4 / 255 + 1e-12, (l.id, netp[l.id], want)
             n_pos += want > 0
         assert n_pos >= 5
+
+
+@pytest.mark.parametrize("mode", ["separator", "heading"])
+def test_unreadable_scan_in_a_pipelined_run_raises_instead_of_hanging(tmp_path, mode):
+    """a corrupt file in the middle of the list with host workers around the GPU owner (pages in flight on the device, tickets
+    pending): the decode worker's error reaches the caller as an IOError naming the file; nothing waits forever"""
+    import shutil
+    from citlab_article_separation_new_amd import run_net_post_processing as cli
+    from citlab_article_separation_new_amd import synth
+    pb, _, data = _setup(tmp_path)
+    names = []
+    for k in range(6):
+        name = f"e{k}"
+        if k == 3:
+            (data / f"{name}.png").write_bytes(b"\x89PNG\r\n\x1a\n" + b"not an image" * 10)
+        else:
+            Image.fromarray(synth.synth_page(20 + k, W=400, H=600)).save(data / f"{name}.png")
+        shutil.copy(data / "page" / "p0.xml", data / "page" / f"{name}.xml")
+        names.append(name)
+    lst = tmp_path / "six.lst"
+    lst.write_text("\n".join(str(data / f"{n}.png") for n in names) + "\n")
+    with pytest.raises(IOError, match="e3.png"):
+        cli.main(["--path_to_image_list", str(lst), "--path_to_pb", pb, "--mode", mode, "--fixed_height", "300",
+                  "--num_processes", "4"])
