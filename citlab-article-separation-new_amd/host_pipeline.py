@@ -322,8 +322,12 @@ def pin_callbacks(device=0):
     """(register, unregister) for DecodePool that page-lock a host range with the engine's C ABI"""
     from . import _lib
     lib = _lib.init_device(device)
+    seen = threading.local()
 
     def register(addr, nbytes):
+        if not getattr(seen, "device_set", False):          # the slot preparer is a thread of its own: HIP's current device is
+            lib.asep_init(device)                           # per thread, and an owner of GPU k must not touch GPU 0
+            seen.device_set = True
         return lib.asep_host_register(addr, nbytes) == 0
 
     def unregister(addr):
