@@ -533,7 +533,10 @@ def main():
         dom = next((k for k in kernels if k["kernel"] == args.dominant), kernels[0])
         d_iso, d_situ = (iso or {}).get(dom["kernel"]), (situ or {}).get(dom["kernel"])
         lead = d_situ or d_iso                      # `achieved` / `frac` are the in-situ figures when measured (the lower ones)
-        groups = next((c for name, c in main_calls.items() if name.startswith("res8") and "_up_" in name), dom["calls"])
+        # (the level-0 up block of the PAGE net -- res8v_up_kernel / res8_up_kernel in fp32, res8f_kernel<true> / res8b in bf16 -- is
+        # launched exactly once per group of pages: its call count in the page net's own profile counts the groups)
+        groups = next((c for name, c in main_calls.items()
+                       if name.startswith("res8") and ("_up_" in name or name.endswith("<true>"))), dom["calls"])
         exec_flops_page = sum(k["executed_flops"] for k in kernels) / (B * n_prof)
         # `achieved` counts the multiply-adds the kernel EXECUTES (a Winograd kernel's direct-convolution credit is in
         # `algorithmic_tflops`).  The fp32 level-0 kernels (res8v_*) issue v_pk_fma_f32 instead of MFMAs: on gfx950 both use
