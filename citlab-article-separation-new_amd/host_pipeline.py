@@ -14,6 +14,7 @@ Both keep the order of the image list; with ``n_workers <= 1`` everything runs i
 behaviour of round 1, and what the unit tests use).  Workers never touch the GPU and do not import torch.
 """
 import contextlib
+import errno
 import multiprocessing as mp
 import os
 import queue
@@ -157,9 +158,15 @@ class DecodePool:
                 return False
             try:
                 fd = getattr(s, "_fd", -1)
+                reserved = False
                 if fd >= 0 and hasattr(os, "posix_fallocate"):
-                    os.posix_fallocate(fd, 0, s.size)       # reserves the pages (ENOSPC now) without faulting each one in
-                else:
+                    try:
+                        os.posix_fallocate(fd, 0, s.size)   # reserves the pages (ENOSPC now) without faulting each one in
+                        reserved = True
+                    except OSError as e:
+                        if e.errno in (errno.ENOSPC, errno.ENOMEM, errno.EDQUOT):
+                            raise                           # (anything else: this file system cannot preallocate -- touch instead)
+                if not reserved:
                     np.ndarray((s.size,), np.uint8, buffer=s.buf)[::4096] = 0
             except (OSError, MemoryError, ValueError):
                 s.close()
