@@ -146,3 +146,24 @@ def test_effective_cpus_honours_the_cgroup_quota(tmp_path):
     assert host_util.effective_cpus(str(v1)) == allowed
     assert host_util.effective_cpus(str(tmp_path / "none")) == allowed
     assert 1 <= host_pipeline.host_workers_default() <= 24
+
+
+def test_workers_are_spawned_with_single_threaded_blas_and_the_environment_is_restored(monkeypatch):
+    """numpy's BLAS creates a thread per core at import; decode / XML workers do no linear algebra and start with
+    *_NUM_THREADS = 1 (on a 256-CPU box that was most of their start-up time) -- the parent's own settings come back afterwards"""
+    monkeypatch.setenv("OMP_NUM_THREADS", "7")
+    monkeypatch.delenv("OPENBLAS_NUM_THREADS", raising=False)
+    with host_pipeline.single_threaded_children():
+        assert os.environ["OMP_NUM_THREADS"] == os.environ["OPENBLAS_NUM_THREADS"] == os.environ["MKL_NUM_THREADS"] == "1"
+        import multiprocessing as mp
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        p = ctx.Process(target=_report_env, args=(q,))
+        p.start()
+        assert q.get(timeout=60) == ("1", "1")
+        p.join()
+    assert os.environ["OMP_NUM_THREADS"] == "7" and "OPENBLAS_NUM_THREADS" not in os.environ
+
+
+def _report_env(q):
+    q.put((os.environ.get("OMP_NUM_THREADS"), os.environ.get("OPENBLAS_NUM_THREADS")))
