@@ -72,7 +72,7 @@ def parse_args():
     ap.add_argument("--no-kernel-timing", action="store_true", help="same as --kernel-timing none")
     ap.add_argument("--e2e-pages", type=int, default=384,
                     help="scans of the files-in / files-out secondary figure (separator CLI path with host workers; 0 = skip)")
-    ap.add_argument("--e2e-heading-pages", type=int, default=192,
+    ap.add_argument("--e2e-heading-pages", type=int, default=384,
                     help="scans of the heading command line inside the files-in / files-out leg (0 = skip)")
     ap.add_argument("--e2e-leg", action="store_true", help=argparse.SUPPRESS)      # internal: run only the e2e_files leg, print its JSON
     ap.add_argument("--e2e-device", type=int, default=0, help=argparse.SUPPRESS)

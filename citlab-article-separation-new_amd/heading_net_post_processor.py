@@ -306,7 +306,18 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
                                                 d_u8.data_ptr(), None, 0.0, sp), "asep_aru_forward_dev")
             return d_u8.cpu().numpy()
 
-    def enqueue_page(self, image):
+    PAGE_LANES = 2                     # lanes of the pipelined run(): stream, model instance and scratch arena each
+
+    def _lane_stream(self, tdev, lane):
+        import torch
+        if lane == 0:
+            return torch.cuda.current_stream(tdev)
+        streams = self.__dict__.setdefault("_lane_streams", {})
+        if (tdev.index, lane) not in streams:
+            streams[(tdev.index, lane)] = torch.cuda.Stream(tdev)
+        return streams[(tdev.index, lane)]
+
+    def enqueue_page(self, image, lane=0):
         """Queue the device stages of one decoded page (``image`` stays valid until the ticket is collected) -- upload, resize + gray + heading
         net with uint8 epilogue (:285-288), full-size gray + stroke-width distance transform (swt_dist_trafo.py:18-29) --
         and return a ticket for :meth:`collect_page`.  Neither the net output nor the distance transform leaves HBM."""
@@ -321,9 +332,9 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
         sc = get_scaling_factor(H, W, self.scaling_factor, fixed_height=self.fixed_height)
         h, w = image_ops.scaled_size(H, W, sc)
         ncls = self.pb_graph.cfg.n_classes
-        _, ws = image_ops._workspace(dev)
+        _, ws = image_ops._workspace(dev, 0 if lane == 0 else 10 + lane)     # (arena 1 belongs to collect_boxes' side stream)
         t = {"sc": sc, "size": (h, w, ncls), "device": dev}
-        with torch.cuda.device(tdev):
+        with torch.cuda.device(tdev), torch.cuda.stream(self._lane_stream(tdev, lane)):
             stream = torch.cuda.current_stream(tdev)
             sp = C.c_void_p(stream.cuda_stream)
             if getattr(self, "_side_stream", None) is None or self._side_stream.device != tdev:
@@ -342,7 +353,7 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
                                                         d_gray.data_ptr(), sp), "asep_prep_scale_gray_dev")
                 d_out = torch.empty((h, w, ncls), dtype=torch.float32, device=tdev)
                 d_u8 = torch.empty((h, w, ncls), dtype=torch.uint8, device=tdev)
-                _lib.check(lib.asep_aru_forward_dev(self.pb_graph.handle(dev), d_gray.data_ptr(), h, w, d_out.data_ptr(),
+                _lib.check(lib.asep_aru_forward_dev(self.pb_graph.handle(dev, lane), d_gray.data_ptr(), h, w, d_out.data_ptr(),
                                                     d_u8.data_ptr(), None, 0.0, sp), "asep_aru_forward_dev")
                 t["d_u8"] = d_u8
                 t["keep"] = (d_gray, d_out)
@@ -432,7 +443,7 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
                                 geometry[nxt] = parsers.submit(read_line_geometry, get_page_path(nxt))
                 if pipelined:
                     prefetch_geometry(2 * n_workers)
-                pending = []
+                pending, n_enqueued = [], 0
 
                 def finish(image_path, ticket):
                     # the GPU owner only measures; parsing happened in a worker, fusion + tags + XML go to a worker
@@ -452,7 +463,8 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
                         # behind the GPU: the next pages are uploaded and queued before a page's lines are measured (the
                         # measuring calls wait for their small kernels; the chip has the next nets to work on meanwhile).  An image
                         # stays valid for ahead_pages + 1 iterations, i.e. until its own page has been collected.
-                        pending.append((image_path, self.enqueue_page(image)))
+                        pending.append((image_path, self.enqueue_page(image, lane=n_enqueued % self.PAGE_LANES)))
+                        n_enqueued += 1
                         if len(pending) > ahead_pages:
                             finish(*pending.pop(0))
                         continue

@@ -308,7 +308,7 @@ def test_heading_pages_in_flight_give_the_measurements_of_the_page_by_page_form(
     lines.append(LineGeometry("none", []))
     hp = HeadingNetPostProcessor([], pb, 450, 1.0, weight_dict={"net": 0.8, "stroke_width": 0.0, "text_height": 0.2})
     hp.gpu_devices = "0"
-    tickets = [hp.enqueue_page(p) for p in pages]                       # three pages queued before the first is measured
+    tickets = [hp.enqueue_page(p, lane=k % 2) for k, p in enumerate(pages)]   # three pages queued (two lanes) before the first is measured
     for img, t in zip(pages, tickets):
         sw, th, netp = hp.collect_page(t, lines)
         _, grey, sc = co.scale_and_gray(img, 450, 1.0)
