@@ -6,8 +6,9 @@
 
 Same flags (``run_gnn_clustering.py:19-73``), same per-page loop (``:237-300``): json -> feed dict -> engine ->
 confidences [N,N] -> (optional json) -> TextblockClustering -> ``<out_dir>/.../clustering/<info>/<name>_clustering.xml``.
-Pages are sharded over ``--num_workers`` processes, worker k on GPU ``gpu_devices[k % len]`` (the reference forks
-``mp.Process`` per sub-list, ``:322-340``).  Worker errors are surfaced (the reference drops them).
+``--num_workers`` > 1: that many host worker processes prepare feeds ahead of / cluster and write behind one GPU-owning process
+per entry of ``--gpu_devices`` (the reference forks one session-owning ``mp.Process`` per sub-list, ``:322-340``).  Worker errors
+are surfaced (the reference drops them).
 """
 import logging
 import multiprocessing as mp
@@ -71,57 +72,147 @@ def resolve_model_path(flags):
     return pb or get_path_from_exportdir(flags.model_dir, "*best*.pb", "_gpu.pb")
 
 
-def gnn_clustering(json_paths, flags, device="0"):
-    from . import gnn_io, gnn_results
-    from .clustering import TextblockClustering
-    from .gnn_input import InputGNN
+def _prepare_page(input_fn, flags, json_path):
+    """:237-262 for one page: json (+ scan for a graph exported with image_input) -> (PAGE-XML path, feed dict, number of nodes), or
+    None if the json does not exist"""
+    page_path = get_page_from_json_path(json_path)
+    if not os.path.isfile(json_path):
+        logging.warning(f"No json file found to given pageXML {page_path}. Skipping.")
+        return None
+    image = None
+    if flags.image_input:
+        from PIL import Image
+        from .path_util import get_img_from_json_path
+        with Image.open(get_img_from_json_path(json_path)) as im:       # input_dataset.py:279-280
+            image = np.asarray(im.convert("L"), dtype=np.float32)
+    feed = input_fn.feed_from_json(json_path, image)
+    n = feed["node_features:0"].shape[1] if "node_features:0" in feed else int(feed["num_nodes:0"][0])
+    return page_path, feed, n
+
+
+def _finish_page(tb, flags, output, n, page_path):
+    """:269-300 for one page: net output -> confidences [N,N] -> (masks, json) -> clustering -> PAGE-XML with article ids;
+    -> path of the written file, or None with --save_conf only_conf"""
+    from . import gnn_results
+    confidences = gnn_results.confidences_from_output(output, n)
+    if flags.mask_heading_separated_confs or flags.mask_horizontally_separated_confs:      # :279-281
+        from .feature_generation import mask_horizontally_separated_confs
+        confidences = mask_horizontally_separated_confs(confidences, page_path,
+                                                        mask_heading=flags.mask_heading_separated_confs,
+                                                        mask_horizontal=flags.mask_horizontally_separated_confs)
+    if flags.save_conf != "no_conf":
+        gnn_results.save_conf_to_json(confidences, page_path, flags.out_dir)
+        if flags.save_conf == "only_conf":
+            return None
+    tb.set_confs(confidences)
+    tb.calc(method=flags.clustering_method)
+    return gnn_results.save_clustering_to_page(tb.tb_labels, page_path, flags.out_dir, info=tb.get_info(flags.clustering_method))
+
+
+def _load_session(flags, device):
+    from . import gnn_io
     graph = gnn_io.load_graph(resolve_model_path(flags), visual_layers=flags.visual_layers or None)
     if graph.cfg.visual_dims and not flags.image_input:
         raise ValueError("this model was exported with image_input: pass --image_input True")
+    return gnn_io.GnnSession(graph, device)
+
+
+def gnn_clustering(json_paths, flags, device="0"):
+    from .clustering import TextblockClustering
+    from .gnn_input import InputGNN
+    sess = _load_session(flags, device)
     input_fn = InputGNN(flags)
     tb = TextblockClustering(flags)
-    sess = gnn_io.GnnSession(graph, device)
     results = []
     t0 = time.time()
     for count, json_path in enumerate(list(json_paths)):
         if flags.batch_limiter != -1 and flags.batch_limiter <= count:
             break
-        page_path = get_page_from_json_path(json_path)
-        if not os.path.isfile(json_path):
-            logging.warning(f"No json file found to given pageXML {page_path}. Skipping.")
+        page = _prepare_page(input_fn, flags, json_path)
+        if page is None:
             continue
-        image = None
-        if flags.image_input:
-            from PIL import Image
-            from .path_util import get_img_from_json_path
-            with Image.open(get_img_from_json_path(json_path)) as im:       # input_dataset.py:279-280
-                image = np.asarray(im.convert("L"), dtype=np.float32)
-        feed = input_fn.feed_from_json(json_path, image)
+        page_path, feed, n = page
         output = sess.run("output_belong_to_same_instance:0", feed_dict=feed)
-        n = feed["node_features:0"].shape[1] if "node_features:0" in feed else int(feed["num_nodes:0"][0])
-        confidences = gnn_results.confidences_from_output(output, n)
-        if flags.mask_heading_separated_confs or flags.mask_horizontally_separated_confs:      # :279-281
-            from .feature_generation import mask_horizontally_separated_confs
-            confidences = mask_horizontally_separated_confs(confidences, page_path,
-                                                            mask_heading=flags.mask_heading_separated_confs,
-                                                            mask_horizontal=flags.mask_horizontally_separated_confs)
-        if flags.save_conf != "no_conf":
-            gnn_results.save_conf_to_json(confidences, page_path, flags.out_dir)
-            if flags.save_conf == "only_conf":
-                continue
-        tb.set_confs(confidences)
-        tb.calc(method=flags.clustering_method)
-        out = gnn_results.save_clustering_to_page(tb.tb_labels, page_path, flags.out_dir,
-                                                  info=tb.get_info(flags.clustering_method))
-        results.append(out)
+        out = _finish_page(tb, flags, output, n, page_path)
+        if out is not None:
+            results.append(out)
     logging.info(f"Time: {time.time() - t0:.2f} seconds")
     return results
 
 
-def _worker(json_paths, argv, device, q, index=0):
+# ---- host workers around one GPU owner ------------------------------------------------------------------------------------------
+# The forward of a page is 0.1 - 0.7 ms; everything else of the loop above is host work (json, scan decode and resize, clustering,
+# PAGE-XML: 50 - 200 ms per page).  With --num_workers > 1 the pages of a GPU go through worker processes that prepare feeds ahead
+# of the owner and cluster / write behind it; the owner only runs the sessions, in list order.
+_task_state = {}
+
+
+def _task_objects(argv):
+    key = tuple(argv)
+    if key not in _task_state:
+        from .clustering import TextblockClustering
+        from .gnn_input import InputGNN
+        flags = build_parser().parse_known_args(list(argv))[0]
+        _task_state[key] = (flags, InputGNN(flags), TextblockClustering(flags))
+    return _task_state[key]
+
+
+def _prepare_task(argv, json_path):
+    flags, input_fn, _ = _task_objects(argv)
+    return _prepare_page(input_fn, flags, json_path)
+
+
+def _finish_task(argv, output, n, page_path):
+    flags, _, tb = _task_objects(argv)
+    return _finish_page(tb, flags, output, n, page_path)
+
+
+def gnn_clustering_pipelined(json_paths, argv, device="0", host_workers=2):
+    from concurrent.futures import ProcessPoolExecutor
+    from .host_pipeline import single_threaded_children
+    flags = build_parser().parse_known_args(list(argv))[0]
+    json_paths = list(json_paths)
+    if flags.batch_limiter != -1:
+        json_paths = json_paths[:max(0, flags.batch_limiter)]
+    t0 = time.time()
+    results = []
+    with ProcessPoolExecutor(max(1, host_workers), mp_context=mp.get_context("spawn")) as pool:
+        def submit(fn, *args):
+            with single_threaded_children():                # (the executor spawns its processes inside submit, on demand)
+                return pool.submit(fn, list(argv), *args)
+        ahead = 2 * max(1, host_workers)
+        prepared = [submit(_prepare_task, p) for p in json_paths[:ahead]]   # the workers start on the first pages while the
+        sess = _load_session(flags, device)                                  # owner imports the engine and loads the model
+        finishing = []
+        for k in range(len(json_paths)):
+            page = prepared[k].result()
+            prepared[k] = None
+            if k + ahead < len(json_paths):
+                prepared.append(submit(_prepare_task, json_paths[k + ahead]))
+            if page is None:
+                continue
+            page_path, feed, n = page
+            output = sess.run("output_belong_to_same_instance:0", feed_dict=feed)
+            finishing.append(submit(_finish_task, output, n, page_path))
+            while len(finishing) > 4 * max(1, host_workers):                 # bounded backlog: surface errors early
+                out = finishing.pop(0).result()
+                if out is not None:
+                    results.append(out)
+        for f in finishing:
+            out = f.result()
+            if out is not None:
+                results.append(out)
+    logging.info(f"Time: {time.time() - t0:.2f} seconds")
+    return results
+
+
+def _worker(json_paths, argv, device, q, index=0, host_workers=0):
     try:
-        flags = build_parser().parse_known_args(argv)[0]
-        q.put((index, "ok", gnn_clustering(json_paths, flags, device)))
+        if host_workers > 1:
+            q.put((index, "ok", gnn_clustering_pipelined(json_paths, argv, device, host_workers)))
+        else:
+            flags = build_parser().parse_known_args(argv)[0]
+            q.put((index, "ok", gnn_clustering(json_paths, flags, device)))
     except Exception as e:  # surfaced to the parent instead of being dropped
         q.put((index, "err", repr(e)))
 
@@ -158,11 +249,18 @@ def main(argv=None):
     devices = [str(d) for d in flags.gpu_devices] or ["0"]
     if flags.num_workers <= 1:
         return gnn_clustering(json_paths, flags, devices[0])
+    # --num_workers = HOST workers (feeds ahead of / clustering and PAGE-XML behind the GPU owners), split evenly over one
+    # GPU-owning process per device -- like --num_processes of run_net_post_processing; the reference forks one session-owning
+    # process per sub-list (:322-340), which on one GPU means N HIP contexts and N model copies for 0.1 ms of work per page
+    n_owners = max(1, min(len(devices), flags.num_workers, len(json_paths) or 1))
+    host_workers = max(1, flags.num_workers // n_owners)
+    if n_owners == 1:
+        return gnn_clustering_pipelined(json_paths, argv, devices[0], host_workers)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = []
-    for k, part in enumerate(split_list(json_paths, flags.num_workers)):
-        pr = ctx.Process(target=_worker, args=(part, argv, devices[k % len(devices)], q, k))
+    for k, part in enumerate(split_list(json_paths, n_owners)):
+        pr = ctx.Process(target=_worker, args=(part, argv, devices[k], q, k, host_workers))
         pr.start()
         procs.append(pr)
     out, errors = _collect_results(procs, q)

@@ -23,10 +23,11 @@ def _write_page(path, n_regions):
                     'imageWidth="3000" imageHeight="4500">' + "".join(regs) + '</Page></PcGts>')
 
 
-@pytest.mark.parametrize("workers", [1, 2])
-def test_cli_end_to_end_article_ids_identical(tmp_path, workers):
-    """(workers = 2: run_gnn_clustering.py's page fan-out over worker processes, worker k on gpu_devices[k % len] -- both on the
-    one test GPU; the results are collected by worker index)"""
+@pytest.mark.parametrize("workers,devices", [(1, ["0"]), (2, ["0"]), (4, ["0", "0"])])
+def test_cli_end_to_end_article_ids_identical(tmp_path, workers, devices):
+    """(workers = 2: two host worker processes prepare feeds ahead of / cluster and write behind ONE GPU owner; workers = 4 on two
+    device entries: two GPU-owning processes -- both on the one test GPU -- with two host workers each, results collected by
+    owner index)"""
     from citlab_article_separation_new_amd import pb_import, run_gnn_clustering, synth
     from citlab_article_separation_new_amd.clustering import TextblockClustering
     from citlab_article_separation_new_amd.page_xml import Page
@@ -81,7 +82,7 @@ def test_cli_end_to_end_article_ids_identical(tmp_path, workers):
         outs = run_gnn_clustering.main([
             "--model_dir", str(tmp_path / "model"), "--eval_list", str(lst), "--out_dir", "out", "--save_conf", "with_conf",
             "--input_params", "node_feature_dim=15", "edge_feature_dim=2", "node_input_feature_mask=" + str(mask).replace(" ", ""),
-            "--clustering_method", "dbscan", "--gpu_devices", "0"] + (["--num_workers", str(workers)] if workers > 1 else []))
+            "--clustering_method", "dbscan", "--gpu_devices"] + devices + (["--num_workers", str(workers)] if workers > 1 else []))
     finally:
         os.chdir(cwd)
     assert len(outs) == 3
