@@ -74,6 +74,8 @@ def parse_args():
                     help="scans of the files-in / files-out secondary figure (separator CLI path with host workers; 0 = skip)")
     ap.add_argument("--e2e-heading-pages", type=int, default=384,
                     help="scans of the heading command line inside the files-in / files-out leg (0 = skip)")
+    ap.add_argument("--e2e-gnn-pages", type=int, default=384,
+                    help="pages of the relation net's command line inside the files-in / files-out leg (0 = skip)")
     ap.add_argument("--e2e-leg", action="store_true", help=argparse.SUPPRESS)      # internal: run only the e2e_files leg, print its JSON
     ap.add_argument("--e2e-device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-secondary", action="store_true",
@@ -199,13 +201,34 @@ def e2e_files(args, dev_index):
                                "one GPU owner (net, gray conversion, stroke-width transform, per-line statistics and box sums on "
                                "the device) -> PAGE-XML with heading tags; worker start-up included"}
     graph.close()
+    # the relation net's command line (BASELINE configs[3] as files): graph jsons + the scans + PAGE-XML in, article ids out
+    gnn_cli = None
+    if args.e2e_gnn_pages > 0 and not args.no_gnn:
+        from citlab_article_separation_new_amd import run_gnn_clustering
+        os.environ["ASEP_COMPUTE_DTYPE"] = args.dtype                        # conv backbone of a model loaded from a file
+        ng = args.e2e_gnn_pages
+        with tempfile.TemporaryDirectory(prefix="asep_e2e_gnn_") as tg:
+            argv = synth.write_gnn_cli_inputs(tg, ng, visual=args.gnn == "visual", W=W, H=H)
+            cwd = os.getcwd()
+            os.chdir(tg)                                                     # outputs are placed relative to the cwd, like the reference
+            try:
+                t0 = time.perf_counter()
+                outs = run_gnn_clustering.main(argv + ["--out_dir", "out", "--gpu_devices", str(dev_index), "--num_workers", str(workers)])
+                dtg = time.perf_counter() - t0
+            finally:
+                os.chdir(cwd)
+        gnn_cli = {"pages_per_s": round(len(outs) / dtg, 2), "ms_per_page": round(1e3 * dtg / max(len(outs), 1), 2), "pages": len(outs),
+                   "relation_net": args.gnn,
+                   "note": f"run_gnn_clustering, {workers} host workers around one GPU owner: graph json (200 text blocks, ~20k directed edges)"
+                           + (" + PNG scan (decode, TF1 bilinear resize to 683x1024)" if args.gnn == "visual" else "")
+                           + " + PAGE-XML -> relation net -> dbscan -> PAGE-XML with article ids; model load and worker start-up included"}
     first = proc.first_page_seconds or 0.0
     return {"pages_per_s": round(n / dt, 2), "ms_per_page": round(1e3 * dt / n, 2), "scans": n, "host_workers": workers,
             "first_page_s": round(first, 2), "steady_pages_per_s": round((n - 1) / max(dt - first, 1e-9), 2),
             "page_xml_written": n_xml, "gpu_owner_device_stage_share": round(proc.device_seconds / dt, 3),
             "gpu_owner_waiting_for_decode_share": round(proc.wait_seconds / dt, 3),
             "gpu_owner_ring_chaining_share": round(proc.host_seconds / dt, 3),
-            "dtype": args.dtype, "heading": heading,
+            "dtype": args.dtype, "heading": heading, "gnn_clustering": gnn_cli,
             "note": f"separator CLI path, --fixed_height {H} (net on the full {W}x{H} page): PNG files -> {workers} decode / XML "
                     f"worker processes around ONE GPU owner (one page behind the GPU: page n+1 is uploaded and queued before page n's segments are waited for; device_stage = upload + queueing + waiting for results) -> PAGE-XML files; worker start-up (first_page_s: process spawn, page-locking of the decode slots, first decode) inside pages_per_s, excluded from "
                     f"steady_pages_per_s; "
@@ -301,7 +324,7 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
         if args.e2e_pages > 0:
             # in a child process of its own, so that the leg's worker processes do not inherit this process's module state
             import subprocess
-            cmd = [sys.executable, os.path.abspath(__file__), "--e2e-leg", "--e2e-pages", str(args.e2e_pages), "--e2e-heading-pages", str(args.e2e_heading_pages), "--height", str(args.height),
+            cmd = [sys.executable, os.path.abspath(__file__), "--e2e-leg", "--e2e-pages", str(args.e2e_pages), "--e2e-heading-pages", str(args.e2e_heading_pages), "--e2e-gnn-pages", str(args.e2e_gnn_pages), "--gnn", args.gnn, "--height", str(args.height),
                    "--width", str(args.width), "--e2e-device", str(dev.index or 0), "--dtype", args.dtype]
             r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, text=True, timeout=1800)
             lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]

@@ -147,3 +147,72 @@ def synth_page_xml(path, W: int = 3000, H: int = 4500, k: int = 0, columns: int 
                 '<LastChange>2020-01-01T00:00:00</LastChange></Metadata>'
                 f'<Page imageFilename="x.png" imageWidth="{W}" imageHeight="{H}">' + "".join(regs) + '</Page></PcGts>')
     return n_lines
+
+
+GNN_VISUAL_LAYERS = ["scale_0_unet_up_2_conv", "scale_0_unet_up_1_conv", "scale_0_unet_up_0_conv"]
+GNN_FEATURE_MASK = [1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1]          # the 7 of the 15 json features the nets read
+
+
+def write_gnn_cli_inputs(root, n_pages, visual=True, W: int = 3000, H: int = 4500, N: int = 200):
+    """Inputs of the relation net's command line for benchmarks: a frozen graph (random weights, the visual net BASELINE
+    configs[3] names or the geometric one), per page a graph json of ``N`` text blocks / ~20k directed edges (+ the scan for the
+    visual net) and a PAGE-XML with ``N`` text regions.  Four distinct pages, the rest links to them.
+    -> argv for ``run_gnn_clustering.main`` (without --num_workers / --out_dir)"""
+    import json
+    import os
+    from PIL import Image
+    from . import pb_import
+    from .config import GnnConfig
+    from .weights import init_gnn_weights
+    cfg = GnnConfig(node_feature_dim=7, visual_dims=[16, 16, 16] if visual else [], visual_layers=GNN_VISUAL_LAYERS if visual else [])
+    w = init_gnn_weights(cfg, 3, bias_jitter=0.05)
+    keep = [i for i, m in enumerate(GNN_FEATURE_MASK) if m]
+    os.makedirs(os.path.join(root, "model", "export"))
+    with open(os.path.join(root, "model", "export", "gnn_best_1.pb"), "wb") as f:
+        f.write(pb_import.weights_to_graphdef(w, "graph/", meta={"num_transition_steps": cfg.num_transition_steps}))
+    data = os.path.join(root, "data")
+    os.makedirs(os.path.join(data, "page"))
+    os.makedirs(os.path.join(data, "json15d2bb"))
+    jsons = []
+    for k in range(n_pages):
+        name = f"p{k:03d}"
+        if k < 4:
+            g = synth_graph(k, N=N, n_pairs=10000, node_dim=7)
+            feats15 = np.zeros((N, 15), np.float32)
+            feats15[:, keep] = g["node_features"]
+            d = {"num_nodes": N, "interacting_nodes": g["interacting_nodes"].tolist(),
+                 "num_interacting_nodes": int(g["interacting_nodes"].shape[0]), "node_features": feats15.tolist(),
+                 "edge_features": g["edge_features"].tolist(), "gt_relations": [], "gt_num_relations": 0}
+            if visual:
+                page = cached_synth_page(k, W, H)
+                _, regions, npts = visual_inputs(page, N, k)
+                d["visual_regions_nodes"] = np.asarray(regions).tolist()
+                d["num_points_visual_regions_nodes"] = np.asarray(npts).tolist()
+                Image.fromarray(page).save(os.path.join(data, f"{name}.png"), compress_level=1)
+            with open(os.path.join(data, "json15d2bb", f"{name}.json"), "w") as f:
+                json.dump(d, f)
+        else:
+            os.symlink(os.path.join(data, "json15d2bb", f"p{k % 4:03d}.json"), os.path.join(data, "json15d2bb", f"{name}.json"))
+            if visual:
+                os.symlink(os.path.join(data, f"p{k % 4:03d}.png"), os.path.join(data, f"{name}.png"))
+        regs = []
+        for i in range(N):
+            x, y = 60 + (i % 5) * 580, 60 + (i // 5) * 105
+            regs.append(f'<TextRegion id="tr{i}"><Coords points="{x},{y} {x+540},{y} {x+540},{y+90} {x},{y+90}"/>'
+                        + "".join(f'<TextLine id="tr{i}l{j}"><Coords points="{x},{y+30*j} {x+540},{y+30*j} {x+540},{y+30*j+28} '
+                                  f'{x},{y+30*j+28}"/></TextLine>' for j in range(3)) + '</TextRegion>')
+        with open(os.path.join(data, "page", f"{name}.xml"), "w") as f:
+            f.write('<?xml version="1.0" encoding="UTF-8"?>\n<PcGts xmlns="http://schema.primaresearch.org/PAGE/gts/'
+                    'pagecontent/2013-07-15"><Metadata><Creator>t</Creator><Created>2020-01-01T00:00:00</Created>'
+                    '<LastChange>2020-01-01T00:00:00</LastChange></Metadata><Page imageFilename="x.png" '
+                    f'imageWidth="{W}" imageHeight="{H}">' + "".join(regs) + '</Page></PcGts>')
+        jsons.append(os.path.join(data, "json15d2bb", f"{name}.json"))
+    lst = os.path.join(root, "eval.lst")
+    with open(lst, "w") as f:
+        f.write("\n".join(jsons) + "\n")
+    argv = ["--model_dir", os.path.join(root, "model"), "--eval_list", lst, "--input_params", "node_feature_dim=15",
+            "edge_feature_dim=2", "node_input_feature_mask=" + str(GNN_FEATURE_MASK).replace(" ", ""), "--clustering_method",
+            "dbscan"]
+    if visual:
+        argv += ["--image_input", "True", "--visual_layers"] + GNN_VISUAL_LAYERS
+    return argv
