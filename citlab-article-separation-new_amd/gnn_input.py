@@ -71,7 +71,9 @@ def compute_new_size(height, width, min_dimension, max_dimension):
 
 def resize_bilinear_tf1(image, new_h, new_w):
     """tf.image.resize(BILINEAR, align_corners=False) of TF 1.x: src = dst * (in/out), clamped at the border."""
-    img = np.asarray(image, dtype=np.float32)
+    img = np.asarray(image)
+    if img.dtype not in (np.uint8, np.float32):                # (uint8 pixels widen exactly: they are gathered first, converted after)
+        img = img.astype(np.float32)
     H, W = img.shape[:2]
     ys = np.arange(new_h, dtype=np.float32) * np.float32(H / new_h)
     xs = np.arange(new_w, dtype=np.float32) * np.float32(W / new_w)
@@ -80,8 +82,10 @@ def resize_bilinear_tf1(image, new_h, new_w):
     wy = (ys - y0).astype(np.float32)[:, None, None]; wx = (xs - x0).astype(np.float32)[None, :, None]
     if img.ndim == 2:
         img = img[:, :, None]
-    top = img[y0][:, x0] * (1 - wx) + img[y0][:, x1] * wx
-    bot = img[y1][:, x0] * (1 - wx) + img[y1][:, x1] * wx
+    r0, r1 = img[y0], img[y1]
+    f = lambda a: a.astype(np.float32, copy=False)
+    top = f(r0[:, x0]) * (1 - wx) + f(r0[:, x1]) * wx
+    bot = f(r1[:, x0]) * (1 - wx) + f(r1[:, x1]) * wx
     return (top * (1 - wy) + bot * wy).astype(np.float32)
 
 
@@ -124,7 +128,7 @@ class InputGNN(object):
             ef = d["edge_features"].reshape(int(d["num_interacting_nodes"]), -1)
             feed["edge_features:0"] = self._masked(ef, "edge").astype(np.float32)[None]
         if getattr(self._flags, "image_input", False) and image is not None:
-            img = np.asarray(image, dtype=np.float32)
+            img = np.asarray(image)                                  # uint8 as decoded, or float32 (values 0..255 either way)
             if img.ndim == 2:
                 img = img[:, :, None]
             nh, nw = compute_new_size(img.shape[0], img.shape[1], self.input_params["resize_min_dim"],

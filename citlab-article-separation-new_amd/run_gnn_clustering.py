@@ -84,7 +84,7 @@ def _prepare_page(input_fn, flags, json_path):
         from PIL import Image
         from .path_util import get_img_from_json_path
         with Image.open(get_img_from_json_path(json_path)) as im:       # input_dataset.py:279-280
-            image = np.asarray(im.convert("L"), dtype=np.float32)
+            image = np.asarray(im.convert("L"))                          # uint8; widened after the resize's gathers
     feed = input_fn.feed_from_json(json_path, image)
     n = feed["node_features:0"].shape[1] if "node_features:0" in feed else int(feed["num_nodes:0"][0])
     return page_path, feed, n
