@@ -9,6 +9,11 @@ Grayscale files are kept single-channel: ``cv2.imread`` would replicate the chan
 equal channels returns the value itself (3735 + 19235 + 9798 = 2^15), so the net input is identical.
 JPEG decoders differ between libjpeg builds by +-1 in places; PNG / TIFF inputs are bit-identical.
 """
+import ctypes as C
+import os
+import struct
+import zlib
+
 import numpy as np
 from PIL import Image, ImageOps
 
@@ -25,12 +30,84 @@ def get_image_dimensions(image_path):
 _DEEP_GRAY = ("I;16", "I;16L", "I;16B", "I;16N", "I")      # Pillow modes of 16-bit (and wider) single-channel files
 
 
+# ---- plain 8-bit PNG scans: zlib + un-filtering in C (csrc/host_png.c), everything else through Pillow -------------------------
+_HOST_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libasep_host.so")
+_host = None
+
+
+def _host_lib():
+    """libasep_host.so (include/asep_host.h), or False if it has not been built: the decode then stays with Pillow"""
+    global _host
+    if _host is None:
+        try:
+            lib = C.CDLL(_HOST_LIB)
+            lib.asep_png_unfilter.restype = C.c_long
+            lib.asep_png_unfilter.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p]
+            lib.asep_rgb_to_bgr.restype = None
+            lib.asep_rgb_to_bgr.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+            _host = lib
+        except OSError:
+            _host = False
+    return _host
+
+
+_PNG_SIGNATURE = b"\x89PNG\r\n\x1a\n"
+# ancillary chunks that change what cv2.imread / Pillow hand out (transparency, orientation): such files go through Pillow
+_PNG_NOT_PLAIN = (b"tRNS", b"eXIf", b"PLTE", b"acTL")
+
+
+def _load_png_plain(path):
+    """8-bit gray or RGB, non-interlaced PNG -> uint8 [H,W] or [H,W,3] BGR, exactly what Pillow decodes; None for every other
+    flavour (palette, alpha, 16 bit, interlaced, transparency / EXIF chunks, damaged files -- Pillow reports those)."""
+    lib = _host_lib()
+    if not lib:
+        return None
+    with open(path, "rb") as f:
+        raw = f.read()
+    if raw[:8] != _PNG_SIGNATURE or len(raw) < 33 or raw[12:16] != b"IHDR":
+        return None
+    width, height, depth, colour, compression, filt, interlace = struct.unpack(">IIBBBBB", raw[16:29])
+    if depth != 8 or colour not in (0, 2) or compression or filt or interlace or not width or not height:
+        return None
+    pos, parts = 8, []
+    while pos + 12 <= len(raw):
+        length, kind = struct.unpack(">I4s", raw[pos:pos + 8])
+        if kind in _PNG_NOT_PLAIN:
+            return None
+        if kind == b"IDAT":
+            parts.append(raw[pos + 8:pos + 8 + length])
+        elif kind == b"IEND":
+            break
+        pos += 12 + length
+    bpp = 1 if colour == 0 else 3
+    stride = width * bpp
+    try:
+        data = zlib.decompress(parts[0] if len(parts) == 1 else b"".join(parts))
+    except zlib.error:
+        return None
+    if len(data) != height * (stride + 1):
+        return None
+    out = np.empty((height, width) if bpp == 1 else (height, width, 3), dtype=np.uint8)
+    if bpp == 1:
+        rc = lib.asep_png_unfilter(data, height, stride, 1, out.ctypes.data)
+    else:
+        rgb = np.empty((height, width, 3), dtype=np.uint8)
+        rc = lib.asep_png_unfilter(data, height, stride, 3, rgb.ctypes.data)
+        if rc == 0:
+            lib.asep_rgb_to_bgr(rgb.ctypes.data, height * width, out.ctypes.data)
+    return out if rc == 0 else None
+
+
 def load_image_bgr(path_to_image):
     """uint8 [H,W,3] in BGR order, or uint8 [H,W] for single-channel files.
 
     Like ``cv2.imread`` with its default flags: the EXIF orientation is applied, an alpha channel is dropped, palette
     files are expanded, and 16-bit samples are reduced to their high byte (libpng's ``strip_16``; Pillow's own
     ``convert('L')`` would clip everything above 255 to white instead)."""
+    if str(path_to_image).lower().endswith(".png"):
+        plain = _load_png_plain(path_to_image)
+        if plain is not None:
+            return plain
     with Image.open(path_to_image) as im:
         im = ImageOps.exif_transpose(im)
         if im.mode in _DEEP_GRAY:

@@ -28,6 +28,22 @@ def test_library_exports_every_declared_symbol(repo_root):
     assert lib.asep_device_count() >= 0
 
 
+def test_host_library_exports_every_declared_symbol(repo_root):
+    """include/asep_host.h (plain C helper of the scan decode, csrc/host_png.c -> libasep_host.so)"""
+    import ctypes as C
+    src = open(os.path.join(repo_root, "include", "asep_host.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(asep_[a-z0-9_]+)\s*\(", src))
+    assert names == {"asep_png_unfilter", "asep_rgb_to_bgr"}
+    path = os.path.join(repo_root, "citlab-article-separation-new_amd", "csrc", "libasep_host.so")
+    if not os.path.exists(path):
+        import __graft_entry__ as g
+        g.build()
+    lib = C.CDLL(path)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/asep_host.h but not exported"
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a GPU the product path must fail loudly instead of computing on the CPU."""
     import torch

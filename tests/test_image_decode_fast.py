@@ -1,0 +1,108 @@
+"""image_io's plain-PNG path (zlib + csrc/host_png.c un-filtering through include/asep_host.h) against Pillow: bit-identical pixels
+for 8-bit gray / RGB files of every row-filter mix, and a clean hand-over to Pillow for every other PNG flavour."""
+import io
+import struct
+import zlib
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from citlab_article_separation_new_amd import image_io
+
+
+def _png(width, height, colour, rows_with_filter):
+    """a PNG written by hand: rows_with_filter = [(filter type, filtered bytes)], one IDAT per ~1000 bytes"""
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xffffffff)
+    raw = b"".join(bytes([ft]) + bytes(row) for ft, row in rows_with_filter)
+    comp = zlib.compress(raw, 6)
+    idats = b"".join(chunk(b"IDAT", comp[i:i + 1000]) for i in range(0, len(comp), 1000))
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, 8, colour, 0, 0, 0)) + idats + chunk(b"IEND", b"")
+
+
+def _filter_rows(img, bpp, types):
+    """forward PNG filters (specification 9.2) of an image [H, W*bpp] uint8 with the given filter type per row"""
+    H, S = img.shape
+    out = []
+    prev = np.zeros(S, np.int32)
+    for y in range(H):
+        cur = img[y].astype(np.int32)
+        left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if S > bpp else np.zeros(S, np.int32)
+        upleft = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]]) if S > bpp else np.zeros(S, np.int32)
+        ft = types[y]
+        if ft == 0:
+            f = cur
+        elif ft == 1:
+            f = cur - left
+        elif ft == 2:
+            f = cur - prev
+        elif ft == 3:
+            f = cur - ((left + prev) >> 1)
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            f = cur - pred
+        out.append((ft, (f & 255).astype(np.uint8)))
+        prev = cur
+    return out
+
+
+@pytest.mark.skipif(not image_io._host_lib(), reason="libasep_host.so not built")
+@pytest.mark.parametrize("W,H,bpp", [(1, 1, 1), (2, 3, 1), (3, 9, 1), (4, 8, 1), (61, 37, 1), (300, 257, 1), (1, 5, 3), (2, 2, 3),
+                                     (57, 41, 3), (128, 130, 3)])
+@pytest.mark.parametrize("mix", ["paeth", "all", "runs"])
+def test_hand_written_png_of_every_filter_mix_decodes_like_pillow(tmp_path, W, H, bpp, mix):
+    rng = np.random.default_rng(W * 1000 + H * 7 + bpp)
+    img = rng.integers(0, 256, (H, W * bpp), dtype=np.uint8)
+    img[H // 2:, : (W * bpp) // 2] = 255                       # flat areas: ties in the Paeth predictor
+    if mix == "paeth":
+        types = [4] * H                                        # what Pillow's encoder writes: exercises the 4-row wavefront
+    elif mix == "all":
+        types = [int(t) for t in rng.integers(0, 5, H)]
+    else:
+        types = ([4] * 5 + [1] + [4] * 3 + [2, 0, 3] + [4] * 9)[:H] + [4] * max(0, H - 21)
+    data = _png(W, H, 0 if bpp == 1 else 2, _filter_rows(img, bpp, types))
+    p = tmp_path / "t.png"
+    p.write_bytes(data)
+    want = np.asarray(Image.open(io.BytesIO(data)))
+    assert np.array_equal(want.reshape(H, W * bpp), img)       # the hand-written file is a valid PNG of `img`
+    got = image_io._load_png_plain(str(p))
+    assert got is not None and got.dtype == np.uint8
+    assert np.array_equal(got, want if bpp == 1 else want[:, :, ::-1])
+    assert np.array_equal(image_io.load_image_bgr(str(p)), got)
+
+
+@pytest.mark.skipif(not image_io._host_lib(), reason="libasep_host.so not built")
+def test_pillow_written_scans_and_the_flavours_left_to_pillow(tmp_path):
+    rng = np.random.default_rng(1)
+    gray = rng.integers(0, 256, (211, 333), dtype=np.uint8)
+    rgb = rng.integers(0, 256, (97, 101, 3), dtype=np.uint8)
+    for k, (arr, level) in enumerate([(gray, 1), (gray, 9), (rgb, 1), (rgb, 6)]):
+        p = tmp_path / f"w{k}.png"
+        Image.fromarray(arr).save(p, compress_level=level)
+        got = image_io._load_png_plain(str(p))
+        assert got is not None and np.array_equal(got, arr if arr.ndim == 2 else arr[:, :, ::-1])
+    # everything else is None here and decoded by Pillow: palette, alpha, 16 bit, 1 bit, transparency chunk, not a PNG, damaged
+    others = {
+        "pal.png": Image.fromarray(gray).convert("P"),
+        "rgba.png": Image.fromarray(np.dstack([rgb, rgb[:, :, 0]])),
+        "la.png": Image.fromarray(gray).convert("LA"),
+        "deep.png": Image.fromarray((gray.astype(np.uint16) << 8) | 3),
+        "bilevel.png": Image.fromarray(gray > 128),
+    }
+    for name, im in others.items():
+        im.save(tmp_path / name)
+        assert image_io._load_png_plain(str(tmp_path / name)) is None, name
+        assert image_io.load_image_bgr(str(tmp_path / name)).dtype == np.uint8
+    Image.fromarray(rgb).save(tmp_path / "trns.png", transparency=(1, 2, 3))
+    assert image_io._load_png_plain(str(tmp_path / "trns.png")) is None
+    (tmp_path / "no.png").write_bytes(b"\xff\xd8\xff not a png")
+    assert image_io._load_png_plain(str(tmp_path / "no.png")) is None
+    good = (tmp_path / "w0.png").read_bytes()
+    (tmp_path / "cut.png").write_bytes(good[: len(good) // 2])
+    assert image_io._load_png_plain(str(tmp_path / "cut.png")) is None
+    bad_filter = _png(4, 2, 0, [(0, [1, 2, 3, 4]), (7, [1, 2, 3, 4])])
+    (tmp_path / "f7.png").write_bytes(bad_filter)
+    assert image_io._load_png_plain(str(tmp_path / "f7.png")) is None
