@@ -44,8 +44,9 @@ ACHIEVABLE_HBM_GBS = 6300.0         # same guide: float4 copy, 79 % of the 8 TB/
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=80,
-                    help="timed steps (80 x 16 pages = 1280 pages: a timed region of >= 10 s)")
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps; default 80 (x 16 pages = 1280 pages: a timed region of >= 10 s at the fp32 rate), 240 with "
+                         "--dtype bf16 (>= 8 s at its rate)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pages-per-step", type=int, default=16,
                     help="pages per rank and step (16 x 20 steps = 320 pages: a timed region of ~3 s, long enough for "
@@ -83,7 +84,10 @@ def parse_args():
     ap.add_argument("--cpu-sample-height", type=int, default=0,
                     help="rows of a page for the CPU baseline (0 = one whole page per worker on boxes with >= 64 cores, "
                          "a third of a page on smaller ones)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 240 if args.dtype == "bf16" else 80
+    return args
 
 
 def run_cpu_baseline(args):
