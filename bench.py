@@ -237,7 +237,7 @@ def e2e_files(args, dev_index):
                     f"worker processes around ONE GPU owner (one page behind the GPU: page n+1 is uploaded and queued before page n's segments are waited for; device_stage = upload + queueing + waiting for results) -> PAGE-XML files; worker start-up (first_page_s: process spawn, page-locking of the decode slots, first decode) inside pages_per_s, excluded from "
                     f"steady_pages_per_s; "
                     f"box has {os.cpu_count()} logical CPUs, this container may use {effective_cpus()} (affinity / cgroup quota): "
-                    f"a PNG decode of one scan costs ~0.06 CPU-seconds (zlib + csrc/host_png.c; 0.11 through Pillow), the PAGE-XML ~0.03"}
+                    f"a PNG decode of one scan costs ~0.045 CPU-seconds (libdeflate / zlib + csrc/host_png.c; 0.11 through Pillow), the PAGE-XML ~0.03"}
 
 
 def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages):

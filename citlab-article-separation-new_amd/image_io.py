@@ -12,6 +12,7 @@ JPEG decoders differ between libjpeg builds by +-1 in places; PNG / TIFF inputs 
 import ctypes as C
 import os
 import struct
+import threading
 import zlib
 
 import numpy as np
@@ -51,6 +52,44 @@ def _host_lib():
     return _host
 
 
+_deflate = None
+_deflate_state = threading.local()
+
+
+def _inflate(stream, nbytes):
+    """zlib stream -> uint8 array of exactly ``nbytes`` (None if it is damaged or has another length): libdeflate when the system
+    has it (libdeflate.so.0 ships with this image; about twice the speed of zlib's inflate on scan data), else zlib"""
+    global _deflate
+    if _deflate is None:
+        try:
+            lib = C.CDLL("libdeflate.so.0")
+            lib.libdeflate_alloc_decompressor.restype = C.c_void_p
+            lib.libdeflate_zlib_decompress.restype = C.c_int
+            lib.libdeflate_zlib_decompress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                       C.POINTER(C.c_size_t)]
+            _deflate = lib
+        except (OSError, AttributeError):
+            _deflate = False
+    if _deflate:
+        d = getattr(_deflate_state, "d", None)
+        if d is None:
+            d = _deflate_state.d = _deflate.libdeflate_alloc_decompressor()     # one per thread, kept for the process's life
+        if d:
+            out = np.empty(nbytes, dtype=np.uint8)
+            got = C.c_size_t(0)
+            rc = _deflate.libdeflate_zlib_decompress(d, stream, len(stream), out.ctypes.data, nbytes, C.byref(got))
+            if rc == 0 and got.value == nbytes:
+                return out
+            if rc in (1, 2):                                # LIBDEFLATE_BAD_DATA, SHORT_OUTPUT: not the image the header announces
+                return None
+            # (3 = INSUFFICIENT_SPACE: more data than announced -- zlib below agrees or refuses)
+    try:
+        data = zlib.decompress(stream)
+    except zlib.error:
+        return None
+    return np.frombuffer(data, dtype=np.uint8) if len(data) == nbytes else None
+
+
 _PNG_SIGNATURE = b"\x89PNG\r\n\x1a\n"
 # ancillary chunks that change what cv2.imread / Pillow hand out (transparency, orientation): such files go through Pillow
 _PNG_NOT_PLAIN = (b"tRNS", b"eXIf", b"PLTE", b"acTL")
@@ -81,18 +120,17 @@ def _load_png_plain(path):
         pos += 12 + length
     bpp = 1 if colour == 0 else 3
     stride = width * bpp
-    try:
-        data = zlib.decompress(parts[0] if len(parts) == 1 else b"".join(parts))
-    except zlib.error:
+    if not parts:
         return None
-    if len(data) != height * (stride + 1):
+    data = _inflate(parts[0] if len(parts) == 1 else b"".join(parts), height * (stride + 1))
+    if data is None:
         return None
     out = np.empty((height, width) if bpp == 1 else (height, width, 3), dtype=np.uint8)
     if bpp == 1:
-        rc = lib.asep_png_unfilter(data, height, stride, 1, out.ctypes.data)
+        rc = lib.asep_png_unfilter(data.ctypes.data, height, stride, 1, out.ctypes.data)
     else:
         rgb = np.empty((height, width, 3), dtype=np.uint8)
-        rc = lib.asep_png_unfilter(data, height, stride, 3, rgb.ctypes.data)
+        rc = lib.asep_png_unfilter(data.ctypes.data, height, stride, 3, rgb.ctypes.data)
         if rc == 0:
             lib.asep_rgb_to_bgr(rgb.ctypes.data, height * width, out.ctypes.data)
     return out if rc == 0 else None

@@ -106,3 +106,25 @@ def test_pillow_written_scans_and_the_flavours_left_to_pillow(tmp_path):
     bad_filter = _png(4, 2, 0, [(0, [1, 2, 3, 4]), (7, [1, 2, 3, 4])])
     (tmp_path / "f7.png").write_bytes(bad_filter)
     assert image_io._load_png_plain(str(tmp_path / "f7.png")) is None
+
+
+@pytest.mark.skipif(not image_io._host_lib(), reason="libasep_host.so not built")
+@pytest.mark.parametrize("use_libdeflate", [True, False])
+def test_both_inflate_paths_give_the_same_pixels(tmp_path, monkeypatch, use_libdeflate):
+    """the zlib stream goes through libdeflate when the system has it and through zlib otherwise: same pixels, same refusals"""
+    if use_libdeflate:
+        image_io._inflate(zlib.compress(b"x"), 1)
+        if not image_io._deflate:
+            pytest.skip("no libdeflate.so.0 on this system")
+    else:
+        monkeypatch.setattr(image_io, "_deflate", False)
+    rng = np.random.default_rng(9)
+    arr = rng.integers(0, 256, (301, 203), dtype=np.uint8)
+    Image.fromarray(arr).save(tmp_path / "a.png", compress_level=3)
+    assert np.array_equal(image_io._load_png_plain(str(tmp_path / "a.png")), arr)
+    good = (tmp_path / "a.png").read_bytes()
+    (tmp_path / "cut.png").write_bytes(good[: len(good) * 2 // 3])
+    assert image_io._load_png_plain(str(tmp_path / "cut.png")) is None
+    assert image_io._inflate(zlib.compress(b"abcdef"), 6).tobytes() == b"abcdef"
+    assert image_io._inflate(zlib.compress(b"abcdef"), 5) is None and image_io._inflate(zlib.compress(b"abcdef"), 7) is None
+    assert image_io._inflate(b"not a zlib stream", 4) is None
