@@ -105,6 +105,9 @@ def _load_png_plain(path):
         raw = f.read()
     if raw[:8] != _PNG_SIGNATURE or len(raw) < 33 or raw[12:16] != b"IHDR":
         return None
+    if zlib.crc32(raw[12:29]) & 0xffffffff != struct.unpack(">I", raw[29:33])[0]:
+        return None                                         # damaged header: Pillow reports it (the pixel data carries zlib's own
+                                                            # Adler-32, which the inflate step verifies)
     width, height, depth, colour, compression, filt, interlace = struct.unpack(">IIBBBBB", raw[16:29])
     if depth != 8 or colour not in (0, 2) or compression or filt or interlace or not width or not height:
         return None

@@ -128,3 +128,21 @@ def test_both_inflate_paths_give_the_same_pixels(tmp_path, monkeypatch, use_libd
     assert image_io._inflate(zlib.compress(b"abcdef"), 6).tobytes() == b"abcdef"
     assert image_io._inflate(zlib.compress(b"abcdef"), 5) is None and image_io._inflate(zlib.compress(b"abcdef"), 7) is None
     assert image_io._inflate(b"not a zlib stream", 4) is None
+
+
+@pytest.mark.skipif(not image_io._host_lib(), reason="libasep_host.so not built")
+def test_damaged_header_or_pixel_data_is_left_to_pillow(tmp_path):
+    """a flipped byte in IHDR (chunk CRC) or in the compressed pixel data (zlib's Adler-32) is not decoded silently"""
+    arr = np.random.default_rng(2).integers(0, 256, (64, 80), dtype=np.uint8)
+    Image.fromarray(arr).save(tmp_path / "ok.png")
+    good = bytearray((tmp_path / "ok.png").read_bytes())
+    assert np.array_equal(image_io._load_png_plain(str(tmp_path / "ok.png")), arr)
+    bad = bytearray(good)
+    bad[19] ^= 1                                            # width
+    (tmp_path / "hdr.png").write_bytes(bytes(bad))
+    assert image_io._load_png_plain(str(tmp_path / "hdr.png")) is None
+    bad = bytearray(good)
+    i = bytes(good).index(b"IDAT") + 4 + 40
+    bad[i] ^= 0x10
+    (tmp_path / "pix.png").write_bytes(bytes(bad))
+    assert image_io._load_png_plain(str(tmp_path / "pix.png")) is None
