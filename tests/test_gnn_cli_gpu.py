@@ -97,3 +97,26 @@ def test_cli_end_to_end_article_ids_identical(tmp_path, workers, devices):
                    for r in page.get_regions()["TextRegion"] for tl in r.text_lines)
     conf_files = [f for _, _, fs in os.walk(tmp_path) for f in fs if f.endswith("_confidences.json")]
     assert len(conf_files) == 3
+
+
+def test_pipelined_run_surfaces_a_damaged_json_and_skips_a_missing_one(tmp_path):
+    """host workers around the GPU owner (--num_workers 3): a json that does not exist is skipped with a warning like in the
+    reference's loop (:244-247), a damaged one fails the run with the worker's error instead of hanging or being dropped"""
+    from citlab_article_separation_new_amd import run_gnn_clustering, synth
+    argv = synth.write_gnn_cli_inputs(str(tmp_path), 5, visual=False, N=30)
+    lst = argv[argv.index("--eval_list") + 1]
+    jsons = [p for p in open(lst).read().split("\n") if p]
+    missing = str(tmp_path / "data" / "json15d2bb" / "p999.json")
+    (tmp_path / "data" / "page" / "p999.xml").write_text((tmp_path / "data" / "page" / "p000.xml").read_text())
+    open(lst, "w").write("\n".join(jsons[:2] + [missing] + jsons[2:]) + "\n")
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        outs = run_gnn_clustering.main(argv + ["--out_dir", "out", "--gpu_devices", "0", "--num_workers", "3"])
+        assert len(outs) == 5 and all(o.endswith("_clustering.xml") for o in outs)
+        os.remove(jsons[3])                                   # (a link to p003's file ... replace it by garbage)
+        open(jsons[3], "w").write('{"num_nodes": 30, "interacting_nodes": [[0, 1]')
+        with pytest.raises(Exception):
+            run_gnn_clustering.main(argv + ["--out_dir", "out2", "--gpu_devices", "0", "--num_workers", "3"])
+    finally:
+        os.chdir(cwd)
