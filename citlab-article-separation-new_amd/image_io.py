@@ -57,7 +57,8 @@ _deflate_state = threading.local()
 
 
 def _inflate(stream, nbytes):
-    """zlib stream -> uint8 array of exactly ``nbytes`` (None if it is damaged or has another length): libdeflate when the system
+    """zlib stream -> uint8 array of exactly ``nbytes``, valid until the calling thread's next call (None if the stream is damaged
+    or has another length): libdeflate when the system
     has it (libdeflate.so.0 ships with this image; about twice the speed of zlib's inflate on scan data), else zlib"""
     global _deflate
     if _deflate is None:
@@ -75,7 +76,9 @@ def _inflate(stream, nbytes):
         if d is None:
             d = _deflate_state.d = _deflate.libdeflate_alloc_decompressor()     # one per thread, kept for the process's life
         if d:
-            out = np.empty(nbytes, dtype=np.uint8)
+            out = getattr(_deflate_state, "buf", None)       # scratch of the calling thread, reused from scan to scan (the
+            if out is None or out.size != nbytes:            # caller un-filters out of it at once and keeps no reference)
+                out = _deflate_state.buf = np.empty(nbytes, dtype=np.uint8)
             got = C.c_size_t(0)
             rc = _deflate.libdeflate_zlib_decompress(d, stream, len(stream), out.ctypes.data, nbytes, C.byref(got))
             if rc == 0 and got.value == nbytes:
