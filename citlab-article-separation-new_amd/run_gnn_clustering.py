@@ -82,9 +82,15 @@ def _prepare_page(input_fn, flags, json_path):
     image = None
     if flags.image_input:
         from PIL import Image
+        from . import image_io
         from .path_util import get_img_from_json_path
-        with Image.open(get_img_from_json_path(json_path)) as im:       # input_dataset.py:279-280
-            image = np.asarray(im.convert("L"))                          # uint8; widened after the resize's gathers
+        img_path = get_img_from_json_path(json_path)
+        # input_dataset.py:279-280: the scan as mode "L".  A plain 8-bit GRAY png is that already (image_io's fast decode);
+        # colour files go through Pillow's own luma conversion, which is not OpenCV's
+        image = image_io._load_png_plain(img_path) if img_path.lower().endswith(".png") else None
+        if image is None or image.ndim != 2:
+            with Image.open(img_path) as im:
+                image = np.asarray(im.convert("L"))                      # uint8; widened after the resize's gathers
     feed = input_fn.feed_from_json(json_path, image)
     n = feed["node_features:0"].shape[1] if "node_features:0" in feed else int(feed["num_nodes:0"][0])
     return page_path, feed, n
