@@ -133,6 +133,17 @@ def run_cpu_baseline(args):
     }
 
 
+def rank_kernels(iso, situ):
+    """kernel records ({name: {"kernel", "total_ms", ...}}) of the isolated and / or the in-situ pass -> list, largest summed launch
+    time first: ranked on the isolated totals; if the two leaders lie within 5 % of each other there, the in-situ totals decide"""
+    base = iso or situ
+    kernels = sorted(base.values(), key=lambda k: -k["total_ms"])
+    if iso and situ and len(kernels) > 1 and kernels[1]["total_ms"] > 0.95 * kernels[0]["total_ms"]:
+        lead2 = sorted(kernels[:2], key=lambda k: -situ.get(k["kernel"], k)["total_ms"])
+        kernels = lead2 + kernels[2:]
+    return kernels
+
+
 def _timed(fn, iters, warmup=1):
     for _ in range(warmup):
         fn()
@@ -552,11 +563,7 @@ def main():
         # ranking is taken from the isolated totals -- unless the two leaders lie within 5 % of each other there (fp32: the
         # Winograd family 72 x 0.32 ms against the level-0 up block 6 x 3.86 ms per step), where the in-situ totals decide; in
         # every committed profile the result is also the first row of rocprofv3's kernel_stats.csv of the same command.
-        base = iso or situ
-        kernels = sorted(base.values(), key=lambda k: -k["total_ms"])
-        if iso and situ and len(kernels) > 1 and kernels[1]["total_ms"] > 0.95 * kernels[0]["total_ms"]:
-            lead2 = sorted(kernels[:2], key=lambda k: -situ.get(k["kernel"], k)["total_ms"])
-            kernels = lead2 + kernels[2:]
+        kernels = rank_kernels(iso, situ)
         dom = next((k for k in kernels if k["kernel"] == args.dominant), kernels[0])
         d_iso, d_situ = (iso or {}).get(dom["kernel"]), (situ or {}).get(dom["kernel"])
         lead = d_situ or d_iso                      # `achieved` / `frac` are the in-situ figures when measured (the lower ones)

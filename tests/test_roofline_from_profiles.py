@@ -76,3 +76,21 @@ def test_untraced_line_of_the_same_build_uses_the_same_traffic_table(tag):
 
 def test_summaries_are_committed():
     assert TAGS, "profiles/r3* with kernel_stats.csv / pmc_summary.json / bench_under_trace.json / bench.json expected"
+
+
+def test_dominant_kernel_rule():
+    """bench.rank_kernels: the isolated totals rank; a tie of the two leaders within 5 % is decided by the in-situ totals -- with the
+    fp32 numbers of profiles/r3k (Winograd family 216 x 0.319 ms against the level-0 up block 18 x 3.858 ms) and the bf16 ones"""
+    import bench
+    rec = lambda name, calls, avg_us: {"kernel": name, "calls": calls, "total_ms": calls * avg_us * 1e-3}
+    iso = {k["kernel"]: k for k in (rec("conv_wino_kernel<4,false>", 216, 319.13), rec("res8v_up_kernel", 18, 3857.94),
+                                    rec("res8v_down_kernel", 18, 2700.41))}
+    situ = {k["kernel"]: k for k in (rec("conv_wino_kernel<4,false>", 216, 527.24), rec("res8v_up_kernel", 18, 4003.94),
+                                     rec("res8v_down_kernel", 18, 4750.26))}
+    assert iso["res8v_up_kernel"]["total_ms"] > iso["conv_wino_kernel<4,false>"]["total_ms"]            # the near-tie ...
+    assert [k["kernel"] for k in bench.rank_kernels(iso, situ)][:2] == ["conv_wino_kernel<4,false>", "res8v_up_kernel"]   # ... resolved
+    assert bench.rank_kernels(iso, None)[0]["kernel"] == "res8v_up_kernel"
+    assert bench.rank_kernels(None, situ)[0]["kernel"] == "conv_wino_kernel<4,false>"
+    iso_b = {k["kernel"]: k for k in (rec("res8f_kernel<true>", 18, 1079.5), rec("convb", 162, 84.35), rec("res8f_kernel<false>", 18, 683.6))}
+    situ_b = {k["kernel"]: k for k in (rec("res8f_kernel<true>", 18, 1203.6), rec("convb", 162, 114.7), rec("res8f_kernel<false>", 18, 1340.4))}
+    assert bench.rank_kernels(iso_b, situ_b)[0]["kernel"] == "res8f_kernel<true>"       # no tie: the event-inflated in-situ sum of <false> does not count
