@@ -511,7 +511,7 @@ long asep_post_boundary_segments_dev(asep_post* p, const uint8_t* d_mask, int H,
     p->pool.begin();
     unsigned long long* counter = (unsigned long long*)p->pool.get(2 * sizeof(unsigned long long));
     ASEP_HIP_CHECK(hipMemsetAsync(counter, 0, 2 * sizeof(unsigned long long), st));
-    post_boundary_segments_kernel<<<blocks_for((size_t)H * W), 256, 0, st>>>(d_mask, H, W, value, d_starts, d_ends,
+    post_boundary_segments_kernel<<<blocks_for(((size_t)H * W + 15) / 16), 256, 0, st>>>(d_mask, H, W, value, d_starts, d_ends,
                                                                              (unsigned long long)capacity, counter);
     ASEP_HIP_CHECK(hipGetLastError());
     unsigned long long total[2] = {0, 0};
@@ -540,7 +540,7 @@ int asep_post_boundary_segments_enqueue_dev(asep_post* p, const uint8_t* d_mask,
     POST_GUARD_BEGIN
     hipStream_t st = (hipStream_t)stream;
     ASEP_HIP_CHECK(hipMemsetAsync(d_totals, 0, 2 * sizeof(unsigned long long), st));
-    post_boundary_segments_kernel<<<blocks_for((size_t)H * W), 256, 0, st>>>(d_mask, H, W, value, d_starts, d_ends,
+    post_boundary_segments_kernel<<<blocks_for(((size_t)H * W + 15) / 16), 256, 0, st>>>(d_mask, H, W, value, d_starts, d_ends,
                                                                              (unsigned long long)capacity, d_totals);
     ASEP_HIP_CHECK(hipGetLastError());
     return ASEP_OK;

@@ -560,41 +560,67 @@ __global__ void __launch_bounds__(256)
 post_boundary_segments_kernel(const uint8_t* __restrict__ mask, int H, int W, int value, int32_t* __restrict__ starts,
                               int32_t* __restrict__ ends, unsigned long long capacity,
                               unsigned long long* __restrict__ counter) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    int sk[4], ek[4];
-    int ns = 0, ne = 0;
-    if (i < (size_t)H * W && mask[i] == value) {
-        const int y = (int)(i / W), x = (int)(i % W);
-        auto fg = [&](int yy, int xx) -> bool {
-            return yy >= 0 && yy < H && xx >= 0 && xx < W && mask[(size_t)yy * W + xx] == value;
-        };
-        const bool n = fg(y - 1, x), s = fg(y + 1, x), w = fg(y, x - 1), e = fg(y, x + 1);
-        const bool nw = fg(y - 1, x - 1), nev = fg(y - 1, x + 1), sw = fg(y + 1, x - 1), se = fg(y + 1, x + 1);
-        const int VW = W + 1;
-        if (!n) {                                                 // top side, +x: (x, y) -> (x+1, y)
-            if (!(w && !nw)) sk[ns++] = (y * VW + x) * 4 + 0;
-            if (!(e && !nev)) ek[ne++] = (y * VW + x + 1) * 4 + 0;
+    // a thread owns 16 consecutive pixels (one 16-byte load when the mask is aligned); a separator mask is almost empty, and a
+    // wave whose 1024 pixels hold no foreground leaves at once -- only the others walk their pixels, all lanes together, because the
+    // appends are wave-wide scans
+    const size_t n = (size_t)H * W;
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    uint8_t px[16];
+    bool any = false;
+    if (i0 + 16 <= n && ((size_t)mask & 15) == 0) {
+        const uint4 q = *reinterpret_cast<const uint4*>(mask + i0);
+        const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            px[k] = (uint8_t)(w4[k >> 2] >> (8 * (k & 3)));
+            any |= px[k] == value;
         }
-        if (!e) {                                                 // right side, +y: (x+1, y) -> (x+1, y+1)
-            if (!(n && !nev)) sk[ns++] = (y * VW + x + 1) * 4 + 1;
-            if (!(s && !se)) ek[ne++] = ((y + 1) * VW + x + 1) * 4 + 1;
-        }
-        if (!s) {                                                 // bottom side, -x: (x+1, y+1) -> (x, y+1)
-            if (!(e && !se)) sk[ns++] = ((y + 1) * VW + x + 1) * 4 + 2;
-            if (!(w && !sw)) ek[ne++] = ((y + 1) * VW + x) * 4 + 2;
-        }
-        if (!w) {                                                 // left side, -y: (x, y+1) -> (x, y)
-            if (!(s && !sw)) sk[ns++] = ((y + 1) * VW + x) * 4 + 3;
-            if (!(n && !nw)) ek[ne++] = (y * VW + x) * 4 + 3;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            px[k] = (i0 + k < n && mask[i0 + k] == value) ? (uint8_t)value : (uint8_t)~value;
+            any |= i0 + k < n && px[k] == value;
         }
     }
-    unsigned long long o;
-    post_wave_append(ns, counter, o);
-    for (int k = 0; k < ns; ++k, ++o)
-        if (o < capacity) starts[o] = sk[k];
-    post_wave_append(ne, counter + 1, o);
-    for (int k = 0; k < ne; ++k, ++o)
-        if (o < capacity) ends[o] = ek[k];
+    if (__ballot(any) == 0) return;
+    const int VW = W + 1;
+    for (int k = 0; k < 16; ++k) {
+        const size_t i = i0 + k;
+        int sk[4], ek[4];
+        int ns = 0, ne = 0;
+        if (i < n && px[k] == value) {
+            const int y = (int)(i / W), x = (int)(i % W);
+            auto fg = [&](int yy, int xx) -> bool {
+                return yy >= 0 && yy < H && xx >= 0 && xx < W && mask[(size_t)yy * W + xx] == value;
+            };
+            const bool nn = fg(y - 1, x), s = fg(y + 1, x), w = fg(y, x - 1), e = fg(y, x + 1);
+            const bool nw = fg(y - 1, x - 1), nev = fg(y - 1, x + 1), sw = fg(y + 1, x - 1), se = fg(y + 1, x + 1);
+            if (!nn) {                                                // top side, +x: (x, y) -> (x+1, y)
+                if (!(w && !nw)) sk[ns++] = (y * VW + x) * 4 + 0;
+                if (!(e && !nev)) ek[ne++] = (y * VW + x + 1) * 4 + 0;
+            }
+            if (!e) {                                                 // right side, +y: (x+1, y) -> (x+1, y+1)
+                if (!(nn && !nev)) sk[ns++] = (y * VW + x + 1) * 4 + 1;
+                if (!(s && !se)) ek[ne++] = ((y + 1) * VW + x + 1) * 4 + 1;
+            }
+            if (!s) {                                                 // bottom side, -x: (x+1, y+1) -> (x, y+1)
+                if (!(e && !se)) sk[ns++] = ((y + 1) * VW + x + 1) * 4 + 2;
+                if (!(w && !sw)) ek[ne++] = ((y + 1) * VW + x) * 4 + 2;
+            }
+            if (!w) {                                                 // left side, -y: (x, y+1) -> (x, y)
+                if (!(s && !sw)) sk[ns++] = ((y + 1) * VW + x) * 4 + 3;
+                if (!(nn && !nw)) ek[ne++] = (y * VW + x) * 4 + 3;
+            }
+        }
+        if (__ballot(ns | ne) == 0) continue;                         // (wave-uniform: nobody has anything at this position)
+        unsigned long long o;
+        post_wave_append(ns, counter, o);
+        for (int q = 0; q < ns; ++q, ++o)
+            if (o < capacity) starts[o] = sk[q];
+        post_wave_append(ne, counter + 1, o);
+        for (int q = 0; q < ne; ++q, ++o)
+            if (o < capacity) ends[o] = ek[q];
+    }
 }
 
 
