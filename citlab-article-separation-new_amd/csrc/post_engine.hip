@@ -621,7 +621,10 @@ int asep_swt_line_features_dev(asep_post* p, const uint8_t* d_swt, int H, int W,
     ASEP_HIP_CHECK(hipMemcpyAsync(d_boxes, hb.data(), (size_t)n_lines * sizeof(SwtLineBox), hipMemcpyHostToDevice, st));
     ASEP_HIP_CHECK(hipMemcpyAsync(d_ofs, ofs.data(), (size_t)n_lines * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
     ASEP_HIP_CHECK(hipStreamSynchronize(st));          // hb / ofs are stack-owned: finish the copies before they die
-    swt_line_features_kernel<<<n_lines, 256, 0, st>>>(d_swt, W, d_boxes, d_ofs, d_scratch, d_sw, d_h, d_f);
+    static const bool lds_ok = hipFuncSetAttribute((const void*)swt_line_features_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   SWTL_LDS_PIXELS * (int)sizeof(int32_t)) == hipSuccess;
+    if (!lds_ok) { set_error("asep_swt_line_features_dev: cannot reserve the label tile in LDS"); return ASEP_ERR_HIP; }
+    swt_line_features_kernel<<<n_lines, 256, SWTL_LDS_PIXELS * sizeof(int32_t), st>>>(d_swt, W, d_boxes, d_ofs, d_scratch, d_sw, d_h, d_f);
     ASEP_HIP_CHECK(hipGetLastError());
     ASEP_HIP_CHECK(hipMemcpyAsync(out_stroke_width, d_sw, (size_t)n_lines * sizeof(float), hipMemcpyDeviceToHost, st));
     ASEP_HIP_CHECK(hipMemcpyAsync(out_height, d_h, (size_t)n_lines * sizeof(int32_t), hipMemcpyDeviceToHost, st));
