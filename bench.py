@@ -3,7 +3,9 @@
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-  (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
+  (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  Started WITHOUT that environment
+  (`python bench.py --gpus 8`), the process starts the N ranks itself -- torch.distributed.run as a CHILD process, before
+  anything here has touched the GPU -- and relays the child's one JSON line and exit code (spawn_ranks).
 
 A "step" = one pass of the hot path over one batch of `--pages-per-step` device-resident pages on every rank:
 per page one ARU-Net forward (fp32, fused uint8/threshold epilogue) + one forward of the VISUAL relation net
@@ -79,6 +81,9 @@ def parse_args():
                     help="pages of the relation net's command line inside the files-in / files-out leg (0 = skip)")
     ap.add_argument("--e2e-leg", action="store_true", help=argparse.SUPPRESS)      # internal: run only the e2e_files leg, print its JSON
     ap.add_argument("--e2e-device", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--bf16-steps", type=int, default=160,
+                    help="timed steps of the secondary bf16 full step (configs[4]: bf16 ARU-Net + visual relation net with bf16 backbone; "
+                         "160 x 16 pages >= 5 s at its rate; 0 = skip)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements (bf16 variant, heading net + stroke-width fusion, visual GNN)")
     ap.add_argument("--cpu-sample-height", type=int, default=0,
@@ -88,6 +93,27 @@ def parse_args():
     if args.steps is None:
         args.steps = 240 if args.dtype == "bf16" else 80
     return args
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1) without a torchrun environment: start the ranks as a child process (never an exec of
+    this one; nothing in this process has initialised the GPU yet), relay its single JSON line and its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                                 # a free rendezvous port (two runs on one box must not collide)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif r.returncode == 0:
+        print(r.stdout, file=sys.stderr)
+        return 1
+    return r.returncode
 
 
 def run_cpu_baseline(args):
@@ -119,9 +145,13 @@ def run_cpu_baseline(args):
     frac = rows / args.height
     t_page = max(r["t_aru"] / frac + r["t_gnn"] for r in res)      # slowest worker (scaled to a whole page if a band)
     used = threads * len(res)
+    short = (f"{len(res)}x{threads} threads: torch-CPU fp32 ARU-Net oracle on "
+             + (f"one {args.width}x{args.height} scan" if rows >= args.height else f"a {args.width}x{rows} band (x{1 / frac:.2f})")
+             + ("" if args.no_gnn else (" + visual relation-net oracle" if args.gnn == "visual" else " + numpy GNN oracle")))
     return {
         "value": round(len(res) / t_page, 5), "unit": "pages/s", "cores": used, "cores_of": cores, "logical_cpus": logical, "kind": "port",
-        "sample": (f"{used} of the {cores} CPUs this container may use (the box has {logical} logical CPUs"
+        "sample": short[:118],
+        "sample_detail": (f"{used} of the {cores} CPUs this container may use (the box has {logical} logical CPUs"
                    + (f", cgroup quota {cores}" if cores < logical else "") + f"): {len(res)} worker processes x {threads} threads, each: torch-CPU "
                    "fp32 ARU-Net oracle on "
                    + (f"one whole synthetic {args.width}x{args.height}px scan" if rows >= args.height else
@@ -335,6 +365,29 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
         out["geometric_gnn_7_features"] = {"us_per_page": round(1e6 * dt, 1), "dtype": "f32",
                                            "note": "the relation net without image input (round-2 headline workload), alone on the chip"}
         gg.close()
+        # ---- BASELINE configs[4] as a whole step: bf16 ARU-Net + the visual relation net with its backbone on the bf16 kernels, the
+        #      same step / timing code as the headline, in a child process of its own (>= 5 s timed at its rate), with its roofline ----
+        if args.dtype == "f32" and args.bf16_steps > 0:
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "bf16", "--steps", str(args.bf16_steps), "--warmup", "2",
+                   "--pages-per-step", str(args.pages_per_step), "--height", str(H), "--width", str(W), "--gnn", args.gnn,
+                   "--no-cpu-baseline", "--no-secondary", "--event-steps", "2"]
+            env = dict(os.environ, ASEP_BENCH_DEVICE=str(dev.index or 0))
+            r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True, timeout=1200)
+            lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and lines:
+                q = json.loads(lines[-1])
+                rr, rd = q["roofline"] or {}, q.get("roofline_detail") or {}
+                out["bf16_full_step"] = {
+                    "pages_per_s": q["value"], "ms_per_step": q["ms_per_step"], "steps": q["steps"], "timed_region_s": q["config"]["timed_region_s"],
+                    "dtype": "bf16", "workload": q["config"]["workload"],
+                    "roofline": {k: rr.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes",
+                                                        "hbm_frac", "mfma_frac", "whole_page_traffic_gb", "whole_page_hbm_frac",
+                                                        "whole_page_executed_frac", "avg_launch_us", "timing", "traffic_source")},
+                    "whole_page_algorithmic_gb": rd.get("whole_page_algorithmic_gb"),
+                    "note": "same step as the headline with --dtype bf16 (child process; this process's fp32 buffers stay allocated beside it)"}
+            else:
+                out["bf16_full_step"] = {"error": f"bf16 child exited with {r.returncode}"}
         # ---- files in, files out ----
         if args.e2e_pages > 0:
             # in a child process of its own, so that the leg's worker processes do not inherit this process's module state
@@ -349,12 +402,92 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
     return out
 
 
+def build_roofline(args, dom, d_iso, d_situ, kernels, exec_flops_page, pages_per_s_gpu, peak_tf, pages_per_launch, n_prof, visual, B, H, W):
+    """-> (roofline, roofline_detail).  `roofline` holds at most 20 keys, the HBM ones before the event-timing details (a record that
+    keeps the first keys of a nested object keeps the informative ones); everything else goes to `roofline_detail`.
+      fp32: bound "mfma": achieved = EXECUTED TFLOP/s of the dominant kernel (a Winograd kernel executes 1/2.25 of its direct-
+            convolution credit; `algorithmic_frac` carries the credit), against 157.3 TFLOP/s.
+      bf16: bound "hbm": achieved = ALGORITHMIC bytes per launch (inputs read once, outputs written once: the engine's shape
+            arithmetic, asep_aru_profile_report "bytes") / average launch duration, against 8 TB/s.
+    `traffic` = HBM bytes per launch by the PMC counters ((2 FETCH_SIZE + WRITE_SIZE) * 1024, separate rocprofv3 --pmc passes of the
+    same workload, profiles/traffic_per_kernel*.json); traffic / algorithmic_bytes > 1 is re-fetched halo."""
+    lead = d_situ or d_iso                      # `achieved` / `frac` are the in-situ figures when measured (the lower ones)
+    hbm_bound = args.dtype == "bf16"
+    calls = dom["calls"]
+    algo_bytes = dom["bytes"] / calls
+    rate = (lambda d: d["algo_gbs"]) if hbm_bound else (lambda d: d["executed_tflops"])
+    peak = PEAK_HBM_GBS if hbm_bound else peak_tf
+    total_ms = sum(k["total_ms"] for k in kernels)
+    r = {
+        "bound": "hbm" if hbm_bound else "mfma", "kernel": dom["kernel"],
+        "achieved": round(rate(lead), 1 if hbm_bound else 3), "peak": peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+        "frac": round(rate(lead) / peak, 4),
+        "traffic": None, "algorithmic_bytes": round(algo_bytes), "hbm_frac": None,
+        "whole_page_traffic_gb": None, "whole_page_hbm_frac": None,
+        "timing": "in situ" if d_situ else "isolated",
+        "frac_in_situ": round(rate(d_situ) / peak, 4) if d_situ else None,
+        "frac_isolated": round(rate(d_iso) / peak, 4) if d_iso else None,
+        ("mfma_frac" if hbm_bound else "algorithmic_frac"): round((lead["executed_tflops"] if hbm_bound else lead["tflops"]) / peak_tf, 4),
+        "avg_launch_us": round(lead["avg_us"], 2),
+        "launches_per_step": calls / n_prof,
+        "whole_page_executed_frac": round(exec_flops_page * pages_per_s_gpu / 1e12 / peak_tf, 4),
+        "share_of_gpu_time": round(dom["total_ms"] / total_ms, 4),
+        "traffic_source": None,
+    }
+    detail = {
+        "layout": 4,
+        "avg_launch_us_in_situ": round(d_situ["avg_us"], 2) if d_situ else None,
+        "avg_launch_us_isolated": round(d_iso["avg_us"], 2) if d_iso else None,
+        "launch_population": "all launches of this kernel in a step" + (": the page net's and the relation nets' backbone's" if visual else ""),
+        "pipe": "valu v_pk_fma_f32" if dom["kernel"].startswith("res8v") else "mfma",
+        "flops_per_launch": dom["flops"] / calls, "executed_flops_per_launch": dom["executed_flops"] / calls,
+        "algorithmic_tflops": round(lead["tflops"], 3), "executed_tflops": round(lead["executed_tflops"], 3),
+        "algorithmic_gbs": round(lead["algo_gbs"], 1),
+        "event_timed_steps": n_prof * ((d_iso is not None) + (d_situ is not None)),
+        # a launch of the page net carries at most 12 problems = 4 pages x 3 scales; the level-0 block kernels are launched
+        # exactly once per such group, so they count the groups
+        "pages_per_launch": pages_per_launch,
+        # the whole page against the MFMA peak: executed FLOPs of ALL ARU-Net kernels of a page (incl. the relation net's backbone)
+        "whole_page_executed_gflop": round(exec_flops_page / 1e9, 2),
+        "whole_page_executed_tflops": round(exec_flops_page * pages_per_s_gpu / 1e12, 3),
+        "whole_page_algorithmic_gb": round(sum(k["bytes"] for k in kernels) / (B * n_prof) / 1e9, 3),
+        "mfma_peak": peak_tf, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_achievable_gbs": ACHIEVABLE_HBM_GBS,
+    }
+    tp = os.path.join(ROOT, "profiles", "traffic_per_kernel.json" if args.dtype == "f32" else f"traffic_per_kernel_{args.dtype}.json")
+    # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md, scripts/make_traffic_json.py).  The counters cannot
+    # be read from inside this process: the figure comes from the committed summary of the SAME workload (same pages per step, same
+    # relation net, same dtype and page size = the same launch population); anything else is reported as the reason, not as a number
+    try:
+        tj_all = json.load(open(tp))
+        want = {"dtype": args.dtype, "pages_per_step": B, "relation_net": "none" if args.no_gnn else args.gnn, "height": H, "width": W}
+        diff = {k: (tj_all.get(k), v) for k, v in want.items() if tj_all.get(k) != v}
+        tj = tj_all["kernels"].get(dom["kernel"])
+        if diff:
+            r["traffic_source"] = ("no counters for this workload: " + ", ".join(f"{k} {a} != {b}" for k, (a, b) in diff.items()))[:118]
+        elif not tj:
+            r["traffic_source"] = f"{os.path.basename(tp)} has no row for this kernel"
+        else:
+            r["traffic"] = round(tj["bytes_per_launch"])
+            r["traffic_source"] = f"offline PMC: {tj_all.get('source')} @ {tj_all.get('commit', 'n/a')}"[:118]
+            tbs = r["traffic"] / (lead["avg_us"] * 1e-6) / 1e12
+            r["hbm_frac"] = round(tbs / (PEAK_HBM_GBS / 1e3), 4)
+            r["whole_page_traffic_gb"] = round(tj_all["page_bytes"] / 1e9, 2)
+            r["whole_page_hbm_frac"] = round(tj_all["page_bytes"] * pages_per_s_gpu / 1e9 / PEAK_HBM_GBS, 4)
+            detail["hbm_tb_per_s"] = round(tbs, 3)
+            detail["traffic_over_algorithmic"] = round(r["traffic"] / algo_bytes, 3) if algo_bytes else None
+    except Exception as e:  # noqa: BLE001 -- the line must say why the counters are missing
+        r["traffic_source"] = f"{os.path.basename(tp)}: {e!r}"[:118]
+    return r, detail
+
+
 def main():
     global torch
     args = parse_args()
     if args.e2e_leg:                                         # child process of the secondary files-in / files-out figure
         print(json.dumps(e2e_files(args, args.e2e_device)))
         return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:     # no torchrun environment: start the ranks ourselves (a child process)
+        raise SystemExit(spawn_ranks(args))
     import torch
     if args.no_kernel_timing:
         args.kernel_timing = "none"
@@ -362,8 +495,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU")
     # ASEP_BENCH_FORCE_DIST=1 runs the RCCL code path (init, weight broadcast, barrier, max-reduction) with one rank too
     distributed = world > 1 or os.environ.get("ASEP_BENCH_FORCE_DIST") == "1"
 
@@ -375,8 +507,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
-    # ASEP_BENCH_DEVICE pins every rank to one device (two-rank test of the N > 1 code path on a one-GPU box)
-    dev_index = int(os.environ["ASEP_BENCH_DEVICE"]) if "ASEP_BENCH_DEVICE" in os.environ else local_rank
+    # ASEP_BENCH_DEVICE pins every rank to one device (two-rank test of the N > 1 code path on a one-GPU box); a box with fewer
+    # devices than ranks deals the ranks round-robin over what it has (the line then says so: config.devices)
+    ndev = max(1, torch.cuda.device_count())
+    dev_index = int(os.environ["ASEP_BENCH_DEVICE"]) if "ASEP_BENCH_DEVICE" in os.environ else local_rank % ndev
+    ranks_share_devices = world > 1 and ("ASEP_BENCH_DEVICE" in os.environ or ndev < world)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     stdout_fd = None
@@ -390,7 +525,7 @@ def main():
         os.dup2(2, 1)
         # two ranks on one device (ASEP_BENCH_DEVICE) cannot form an RCCL communicator: that test uses gloo for the
         # broadcast / barrier / max-reduction, everything else is the same code
-        backend = os.environ.get("ASEP_BENCH_BACKEND", "nccl")
+        backend = os.environ.get("ASEP_BENCH_BACKEND", "gloo" if ranks_share_devices else "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -539,8 +674,8 @@ def main():
             for k in json.loads(buf.value.decode()):
                 if h == h_aru:
                     main_calls[k["kernel"]] = k["calls"]
-                m = merged.setdefault(k["kernel"], {"kernel": k["kernel"], "calls": 0, "total_ms": 0.0, "flops": 0.0})
-                m["calls"] += k["calls"]; m["total_ms"] += k["total_ms"]; m["flops"] += k["flops"]
+                m = merged.setdefault(k["kernel"], {"kernel": k["kernel"], "calls": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0})
+                m["calls"] += k["calls"]; m["total_ms"] += k["total_ms"]; m["flops"] += k["flops"]; m["bytes"] += k.get("bytes", 0.0)
         for k in merged.values():
             k["avg_us"] = 1e3 * k["total_ms"] / k["calls"]
             k["tflops"] = k["flops"] / (k["total_ms"] * 1e-3) / 1e12 if k["total_ms"] > 0 else 0.0
@@ -548,9 +683,11 @@ def main():
             # work) but execute 2.25x fewer multiplications on the MFMA: report both
             k["executed_flops"] = k["flops"] / 2.25 if "wino" in k["kernel"] else k["flops"]
             k["executed_tflops"] = k["tflops"] / 2.25 if "wino" in k["kernel"] else k["tflops"]
+            # ALGORITHMIC bytes per launch (every input read once, every output written once: the engine's shape arithmetic) / time
+            k["algo_gbs"] = k["bytes"] / (k["total_ms"] * 1e-3) / 1e9 if k["total_ms"] > 0 else 0.0
         return merged, n, main_calls
 
-    roofline = None
+    roofline = roofline_detail = None
     kernels = []
     if rank == 0 and args.kernel_timing != "none":
         iso = situ = None
@@ -566,76 +703,13 @@ def main():
         kernels = rank_kernels(iso, situ)
         dom = next((k for k in kernels if k["kernel"] == args.dominant), kernels[0])
         d_iso, d_situ = (iso or {}).get(dom["kernel"]), (situ or {}).get(dom["kernel"])
-        lead = d_situ or d_iso                      # `achieved` / `frac` are the in-situ figures when measured (the lower ones)
         # (the level-0 up block of the PAGE net -- res8v_up_kernel / res8_up_kernel in fp32, res8f_kernel<true> / res8b in bf16 -- is
         # launched exactly once per group of pages: its call count in the page net's own profile counts the groups)
         groups = next((c for name, c in main_calls.items()
                        if name.startswith("res8") and ("_up_" in name or name.endswith("<true>"))), dom["calls"])
         exec_flops_page = sum(k["executed_flops"] for k in kernels) / (B * n_prof)
-        # `achieved` counts the multiply-adds the kernel EXECUTES (a Winograd kernel's direct-convolution credit is in
-        # `algorithmic_tflops`).  The fp32 level-0 kernels (res8v_*) issue v_pk_fma_f32 instead of MFMAs: on gfx950 both use
-        # the same fp32 datapath and have the same peak (scripts/ubench/mfma_valu_coissue.hip), so the bound keeps its name.
-        roofline = {
-            "bound": "mfma", "kernel": dom["kernel"],
-            "achieved": round(lead["executed_tflops"], 3), "peak": peak_tf, "unit": "TFLOP/s",
-            "frac": round(lead["executed_tflops"] / peak_tf, 4),
-            "timing": "in situ" if d_situ else "isolated",
-            "frac_in_situ": round(d_situ["executed_tflops"] / peak_tf, 4) if d_situ else None,
-            "frac_isolated": round(d_iso["executed_tflops"] / peak_tf, 4) if d_iso else None,
-            "avg_launch_us": round(lead["avg_us"], 2),
-            "avg_launch_us_in_situ": round(d_situ["avg_us"], 2) if d_situ else None,
-            "avg_launch_us_isolated": round(d_iso["avg_us"], 2) if d_iso else None,
-            "launches_per_step": dom["calls"] / n_prof,
-            "launch_population": "all launches of this kernel in a step: the page net's and the relation nets' backbone's"
-                                 if visual else "all launches of this kernel in a step",
-            "algorithmic_tflops": round(lead["tflops"], 3),
-            "pipe": "valu v_pk_fma_f32" if dom["kernel"].startswith("res8v") else "mfma",
-            "flops_per_launch": dom["flops"] / dom["calls"],
-            "executed_flops_per_launch": dom["executed_flops"] / dom["calls"],
-            "share_of_gpu_time": round(dom["total_ms"] / sum(k["total_ms"] for k in kernels), 4),
-            "event_timed_steps": n_prof * ((iso is not None) + (situ is not None)),
-            # a launch of the page net carries at most 12 problems = 4 pages x 3 scales; the level-0 block kernels are launched
-            # exactly once per such group, so they count the groups
-            "pages_per_launch": B * n_prof / groups,
-            # the whole page against the same peak: executed FLOPs of ALL ARU-Net kernels of a page (incl. the relation net's
-            # backbone) x pages/s of the timed region
-            "whole_page_executed_gflop": round(exec_flops_page / 1e9, 2),
-            "whole_page_executed_tflops": round(exec_flops_page * value / world / 1e12, 3),
-            "whole_page_executed_frac": round(exec_flops_page * value / world / 1e12 / peak_tf, 4),
-            "traffic": None, "traffic_source": None,
-        }
-        tp = os.path.join(ROOT, "profiles", "traffic_per_kernel.json" if args.dtype == "f32" else f"traffic_per_kernel_{args.dtype}.json")
-        if os.path.exists(tp):      # HBM bytes/launch from separate rocprofv3 --pmc passes (profiles/README.md, scripts/make_traffic_json.py)
-            try:
-                tj_all = json.load(open(tp))
-                tj = tj_all["kernels"].get(dom["kernel"])
-                # the counters cannot be read from inside this process: the figure comes from the committed rocprofv3 --pmc
-                # summary of the SAME workload (same pages per step, same relation net, same dtype: the same launch population)
-                same = (tj_all.get("dtype") == args.dtype and tj_all.get("pages_per_step") == B and
-                        tj_all.get("relation_net") == ("none" if args.no_gnn else args.gnn) and (tj_all.get("height"), tj_all.get("width")) == (H, W))
-                if tj and same:
-                    roofline["traffic"] = tj["bytes_per_launch"]
-                    roofline["traffic_source"] = f"offline: {tj_all.get('source')} (commit {tj_all.get('commit', 'n/a')}, same workload)"
-                    # the same launch against the other roof (HBM ~ 8 TB/s)
-                    roofline["hbm_tb_per_s"] = round(roofline["traffic"] / (lead["avg_us"] * 1e-6) / 1e12, 3)
-                    roofline["hbm_frac"] = round(roofline["hbm_tb_per_s"] / (PEAK_HBM_GBS / 1e3), 4)
-                    roofline["whole_page_traffic_gb"] = round(tj_all["page_bytes"] / 1e9, 2)
-                    roofline["whole_page_hbm_frac"] = round(tj_all["page_bytes"] * value / world / 1e9 / PEAK_HBM_GBS, 4)
-                    if args.dtype == "bf16":
-                        # the bf16 data path is HBM-bound by design (activations are the bytes; the MFMA peak is 16x the fp32 one):
-                        # the block's primary figures are the HBM ones, the matrix-core figures move to "mfma"
-                        roofline["mfma"] = {"achieved": roofline["achieved"], "peak": roofline["peak"], "unit": "TFLOP/s",
-                                            "frac": roofline["frac"], "frac_in_situ": roofline["frac_in_situ"],
-                                            "frac_isolated": roofline["frac_isolated"],
-                                            "whole_page_executed_frac": roofline["whole_page_executed_frac"]}
-                        gbs = roofline["traffic"] / (lead["avg_us"] * 1e-6) / 1e9
-                        roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                         "frac": round(gbs / PEAK_HBM_GBS, 4), "achievable_peak": ACHIEVABLE_HBM_GBS,
-                                         "frac_of_achievable": round(gbs / ACHIEVABLE_HBM_GBS, 4)})
-                        for name, d in (("frac_in_situ", d_situ), ("frac_isolated", d_iso)):      # against the HBM roof like `frac`
-                            roofline[name] = round(roofline["traffic"] / (d["avg_us"] * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if d else None
-            except Exception:
-                pass
+        roofline, roofline_detail = build_roofline(args, dom, d_iso, d_situ, kernels, exec_flops_page, value / world, peak_tf,
+                                                   B * n_prof / groups, n_prof, visual, B, H, W)
         for k in kernels:
             o_s, o_i = (situ or {}).get(k["kernel"]), (iso or {}).get(k["kernel"])
             k["avg_us_in_situ"] = o_s["avg_us"] if o_s else None
@@ -665,23 +739,29 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {
-                "workload": (("BASELINE configs[1]: ARU-Net separator detection on 3000x4500 px pages, fp32, "
-                              if args.dtype == "f32" else
-                              "BASELINE configs[4] precision (bf16 activations / MFMA convs, fp32 accumulate): ARU-Net separator "
-                              "detection on 3000x4500 px pages, ") + rel),
+                # (short on purpose: records that cut strings at 120 characters keep it whole; the long form is workload_detail)
+                "workload": (("configs[1] fp32" if args.dtype == "f32" else "configs[4] bf16 convs") + f": ARU-Net on {W}x{H} pages + "
+                             + ("no relation net" if args.no_gnn else
+                                ("configs[3] visual GNN (mixed_gnn_vn7e2)" if visual else "geometric GNN") + " per page")),
+                "workload_detail": (("BASELINE configs[1]: ARU-Net separator detection on 3000x4500 px pages, fp32, "
+                                     if args.dtype == "f32" else
+                                     "BASELINE configs[4] precision (bf16 activations / MFMA convs, fp32 accumulate): ARU-Net separator "
+                                     "detection on 3000x4500 px pages, ") + rel),
                 "height": H, "width": W, "pages_per_step_per_gpu": B, "sharding": f"pages over {world} rank(s)",
+                "devices": ndev if not ranks_share_devices else f"{min(ndev, world)} (ranks share devices: {world} ranks)",
                 "relation_net": "none" if args.no_gnn else args.gnn,
                 "timed_region_s": round(dt, 3),
                 "aru_cfg": "ARU featRoot=8 levels=5 res_depth=3 att_scales=3 n_classes=2",
                 "gflop_per_page": round(flops_page / 1e9, 2),
                 "whole_page_tflops_per_gpu": round(flops_page * value / world / 1e12, 3),
             },
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "roofline_detail": roofline_detail,
             "kernels": [{"kernel": k["kernel"], "calls": k["calls"], "avg_us": round(k["avg_us"], 2),
                          "avg_us_in_situ": None if k.get("avg_us_in_situ") is None else round(k["avg_us_in_situ"], 2),
                          "avg_us_isolated": None if k.get("avg_us_isolated") is None else round(k["avg_us_isolated"], 2),
                          "flops": k["flops"], "tflops": round(k["tflops"], 2), "executed_tflops": round(k["executed_tflops"], 2),
-                         "executed_frac_of_peak": round(k["executed_tflops"] / peak_tf, 4)}
+                         "executed_frac_of_peak": round(k["executed_tflops"] / peak_tf, 4),
+                         "bytes": k["bytes"], "algorithmic_gbs": round(k["algo_gbs"], 1)}
                         for k in kernels],
             "secondary": secondary,
         }

@@ -15,15 +15,25 @@ class AsepError(RuntimeError):
     pass
 
 
-class AruCfg(C.Structure):
+ABI_VERSION = 4          # ASEP_ABI_VERSION of include/asep_hip.h this table was written against
+
+
+class _SizedCfg(C.Structure):
+    """configuration structs start with their own size (``struct_size``): filled in here, checked by the load functions"""
+
+    def __init__(self, *args, **kw):
+        super().__init__(C.sizeof(type(self)), *args, **kw)
+
+
+class AruCfg(_SizedCfg):
     _fields_ = [(n, C.c_int32) for n in (
-        "channels", "n_classes", "feat_root", "scale_space_num", "res_depth", "num_scales_att",
+        "struct_size", "channels", "n_classes", "feat_root", "scale_space_num", "res_depth", "num_scales_att",
         "use_attention", "mvn", "apply_softmax", "compute_dtype", "activation", "plain_u")]
 
 
-class GnnCfg(C.Structure):
+class GnnCfg(_SizedCfg):
     _fields_ = [(n, C.c_int32) for n in (
-        "node_feature_dim", "edge_feature_dim", "num_transition_steps", "hidden_dim", "interaction_dim",
+        "struct_size", "node_feature_dim", "edge_feature_dim", "num_transition_steps", "hidden_dim", "interaction_dim",
         "interaction_hidden", "cls_hidden1", "cls_hidden2", "num_classes", "undirected_graph", "compress_input_dim", "output_type", "attention_heads", "attention_merge", "attention_hidden")]
 
 
@@ -41,6 +51,7 @@ SIGNATURES = {
     "asep_init": (C.c_int, [C.c_int]),
     "asep_last_error": (C.c_char_p, []),
     "asep_version": (C.c_char_p, []),
+    "asep_abi_version": (C.c_int, []),
     "asep_aru_load": (_P, [_P, C.c_size_t, C.POINTER(AruCfg)]),
     "asep_aru_free": (None, [_P]),
     "asep_aru_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_float]),
@@ -115,6 +126,9 @@ def load_library(path: str = None):
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    if lib.asep_abi_version() != ABI_VERSION:
+        raise AsepError(f"{path} implements ABI version {lib.asep_abi_version()}, this binding was written against {ABI_VERSION}: "
+                        f"rebuild the library (make -C {os.path.dirname(LIB_PATH)})")
     _lib = lib
     return lib
 

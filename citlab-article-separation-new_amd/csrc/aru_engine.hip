@@ -116,7 +116,7 @@ struct asep_aru {
     std::vector<void*> owned;
 
     // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
-    struct ProfRec { int kid; double flops; hipEvent_t a, b; };
+    struct ProfRec { int kid; double flops, bytes; hipEvent_t a, b; };
     int num_cus = 256;
     bool big_tile = true;          // ASEP_BIGTILE=0 disables the 16x32 single-buffer variant
     BufferPool host_stage;         // device staging of the host-pointer entry point (grow-only)
@@ -176,6 +176,8 @@ struct ProfScope {
     hipEvent_t a = nullptr, b = nullptr;
     bool on = false;
     double flops;
+    double bytes = 0;          // ALGORITHMIC HBM bytes of the launch: every input tensor read once, every output written once, the filter
+                               // once (SURVEY.md section 8d per-unit figure x the units of the launch); set by the launcher
     std::string name, detail;
     ProfScope(asep_aru* m_, const std::string& name_, double flops_, const std::string& detail_ = std::string())
         : m(m_), flops(flops_), name(name_), detail(detail_) {
@@ -189,7 +191,7 @@ struct ProfScope {
     ~ProfScope() {
         if (!on) return;
         (void)hipEventRecord(b, m->stream);
-        m->prof_recs.push_back({m->prof_kid(m->prof_detail && !detail.empty() ? name + " " + detail : name), flops, a, b});
+        m->prof_recs.push_back({m->prof_kid(m->prof_detail && !detail.empty() ? name + " " + detail : name), flops, bytes, a, b});
     }
 };
 std::string targs(std::initializer_list<std::string> l) {
@@ -348,6 +350,8 @@ Tensor new_tensor(asep_aru* m, int H, int W, int C) {
     return t;
 }
 
+inline double tbytes(const Tensor& t) { return (double)t.count() * (t.bf ? 2.0 : 4.0); }
+
 std::string dims_of(const TL& l) {
     std::string d;
     for (size_t i = 0; i < l.size() && i < 3; ++i) d += (i ? "+" : "") + std::to_string(l[i].H) + "x" + std::to_string(l[i].W);
@@ -363,11 +367,12 @@ std::string dims_of(const TL& l) {
     } while (0)
 
 template <int KH, int KW>
-void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, int total_tiles, double flops,
+void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, int total_tiles, double flops, double bytes,
                    const std::string& scope, const TL& in0, bool big_tile) {
     const int mt = pc.c8 ? 1 : (pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1));
     dim3 grid(total_tiles, pc.mtiles / mt);
     ProfScope ps(m, "conv_mfma_kernel", flops, scope + " " + dims_of(in0) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
+    ps.bytes = bytes;
     hipStream_t s = m->stream;
     const bool res_op = a.p[0].res != nullptr;
     const bool has_res = res_op || KH != 3;      // (the four-blocks-per-CU variant exists for 3x3 only: 4x4 needs 140 VGPRs)
@@ -422,7 +427,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             const size_t b1 = std::min(in0.size(), b0 + MAXP);
             ConvArgs a{};
             int tiles = 0;
-            double flops = 0;
+            double flops = 0, bytes = 0;
             for (size_t i = b0; i < b1; ++i) {
                 ConvProb& p = a.p[i - b0];
                 p.in0 = in0[i].p; p.out = out1[i].p;
@@ -431,6 +436,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
                 p.tile_begin = tiles;
                 tiles += p.tiles_x * cdiv(in0[i].H, C1O_T);
                 flops += 2.0 * in0[i].H * in0[i].W * 16.0 * pc.cin;
+                bytes += tbytes(in0[i]) + tbytes(out1[i]);
             }
             a.nprob = (int)(b1 - b0);
             a.total_tiles = tiles;
@@ -438,6 +444,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             a.wpk = (const f32x4*)pc.d_wv; a.bias = pc.d_b;
             a.relu_in = relu_in; a.relu_out = relu_out;
             ProfScope ps(m, "conv_c1out_kernel", flops, scope);
+            ps.bytes = bytes;
             hipLaunchKernelGGL(conv_c1out_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
         }
         return out1;
@@ -461,7 +468,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
         const size_t b1 = std::min(in0.size(), b0 + MAXP);
         ConvArgs a{};
         int tiles = 0;
-        double flops = 0;
+        double flops = 0, bytes = (double)pc.kh * pc.kw * pc.cin * pc.cout * 4.0;
         for (size_t i = b0; i < b1; ++i) {
             ConvProb& p = a.p[i - b0];
             p.in0 = in0[i].p; p.in1 = in1 ? (*in1)[i].p : nullptr; p.res = res ? (*res)[i].p : nullptr;
@@ -472,6 +479,8 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             p.tile_begin = tiles;
             tiles += p.tiles_x * cdiv(in0[i].H, th);
             flops += 2.0 * in0[i].H * in0[i].W * pc.kh * pc.kw * (double)pc.cin * pc.cout;
+            bytes += tbytes(in0[i]) + (in1 ? tbytes((*in1)[i]) : 0.0) + (res ? tbytes((*res)[i]) : 0.0) + (out.empty() ? 0.0 : tbytes(out[i])) +
+                     (fuse_pool ? tbytes((*pooled)[i]) : 0.0);
         }
         a.nprob = (int)(b1 - b0);
         a.total_tiles = tiles;
@@ -507,6 +516,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             else if (mt == 2 && m->wino_reg) pname = !res ? "conv_winor_kernel<false,2,false>" : "conv_winor_kernel<false,2,true>";
             else pname = "conv_wino_kernel" + targs({ti(mt), tb(false)});
             ProfScope ps(m, pname, flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
+            ps.bytes = bytes;
             if (mt == 1) {
                 hipLaunchKernelGGL((conv_winor_kernel<false, 1, true>), grid, dim3(256), 0, m->stream, a);
             } else if (mt == 2 && m->wino_reg) {
@@ -516,8 +526,8 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             } else if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4>), grid, dim3(256), 0, m->stream, a);
             else if (mt == 2) hipLaunchKernelGGL((conv_wino_kernel<2>), grid, dim3(256), 0, m->stream, a);
             else hipLaunchKernelGGL((conv_wino_kernel<1>), grid, dim3(256), 0, m->stream, a);
-        } else if (pc.kh == 3) launch_conv_k<3, 3>(m, pc, a, tiles, flops, scope, sub, big_tile);
-        else launch_conv_k<4, 4>(m, pc, a, tiles, flops, scope, sub, big_tile);
+        } else if (pc.kh == 3) launch_conv_k<3, 3>(m, pc, a, tiles, flops, bytes, scope, sub, big_tile);
+        else launch_conv_k<4, 4>(m, pc, a, tiles, flops, bytes, scope, sub, big_tile);
     }
     if (pooled && !fuse_pool) *pooled = run_pool(m, out, POOL_MAX);
     return out;
@@ -546,7 +556,7 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
         const size_t b1 = std::min(in.size(), b0 + MAXP);
         ConvArgs a{};
         int tiles = 0;
-        double flops = 0;
+        double flops = 0, bytes = 9.0 * pc.cin * pc.cout * 4.0;
         for (size_t i = b0; i < b1; ++i) {
             ConvProb& p = a.p[i - b0];
             p.in0 = in[i].p; p.in1 = nullptr; p.res = nullptr; p.out = out[i].p;
@@ -557,6 +567,7 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
             p.tile_begin = tiles;
             tiles += p.tiles_x * cdiv(in[i].H, valu ? DCV_T : DC_TH);
             flops += 2.0 * in[i].H * in[i].W * 9.0 * pc.cin * pc.cout;
+            bytes += tbytes(in[i]) + tbytes(out[i]);
         }
         a.nprob = (int)(b1 - b0);
         a.c0 = in[0].C; a.c1 = 0;
@@ -567,6 +578,7 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
         const std::string dname = valu ? std::string("deconv8v_kernel") : "deconv_mfma_kernel" + targs({ti(mt), tb(false)});
         TL sub(in.begin() + b0, in.begin() + b1);
         ProfScope ps(m, dname, flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
+        ps.bytes = bytes;
         if (valu) {
             a.wpk = (const f32x4*)pc.d_wv;
             hipLaunchKernelGGL(deconv8v_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
@@ -584,7 +596,7 @@ TL run_direct(asep_aru* m, const DirectConv& dc, const TL& imgs, bool relu, cons
         const size_t b1 = std::min(imgs.size(), b0 + MAXP);
         C1Args a{};
         int tiles = 0;
-        double flops = 0;
+        double flops = 0, bytes = 0;
         for (size_t i = b0; i < b1; ++i) {
             C1Prob& p = a.p[i - b0];
             p.img = imgs[i].p; p.out = out[i].p; p.stats = stats.empty() ? nullptr : stats[i];
@@ -593,10 +605,12 @@ TL run_direct(asep_aru* m, const DirectConv& dc, const TL& imgs, bool relu, cons
             p.tile_begin = tiles;
             tiles += p.tiles_x * cdiv(imgs[i].H, 4);
             flops += 2.0 * imgs[i].H * imgs[i].W * dc.k * dc.k * dc.cout;
+            bytes += tbytes(imgs[i]) + tbytes(out[i]);
         }
         a.nprob = (int)(b1 - b0);
         a.w = dc.d_w; a.bias = dc.d_b; a.relu = relu ? 1 : 0;
         ProfScope ps(m, "conv_c1_kernel<" + std::to_string(dc.k) + "," + std::to_string(dc.cout) + ">", flops);
+        ps.bytes = bytes;
         dim3 grid(tiles);
         if (dc.k == 3 && dc.cout == 8) hipLaunchKernelGGL((conv_c1_kernel<3, 8>), grid, dim3(256), 0, m->stream, a);
         else if (dc.k == 3 && dc.cout == 16) hipLaunchKernelGGL((conv_c1_kernel<3, 16>), grid, dim3(256), 0, m->stream, a);
@@ -616,7 +630,9 @@ TL run_pool(asep_aru* m, const TL& in, PoolKind kind) {
         const size_t b1 = std::min(in.size(), b0 + MAXP);
         PoolArgs a{};
         int blocks = 0;
+        double bytes = 0;
         for (size_t i = b0; i < b1; ++i) {
+            bytes += tbytes(in[i]) + tbytes(out[i]);
             PoolProb& p = a.p[i - b0];
             p.in = in[i].p; p.out = out[i].p; p.H = in[i].H; p.W = in[i].W; p.Ho = out[i].H; p.Wo = out[i].W;
             p.blk_begin = blocks;
@@ -626,6 +642,7 @@ TL run_pool(asep_aru* m, const TL& in, PoolKind kind) {
         a.nprob = (int)(b1 - b0);
         a.C = in[0].C;
         ProfScope ps(m, kind == POOL_MAX ? "maxpool2_kernel" : (kind == POOL_AVG_C1 ? "avgpool2_c1_kernel" : "chansum_kernel"), 0.0);
+        ps.bytes = bytes;
         if (kind == POOL_MAX) hipLaunchKernelGGL(maxpool2_kernel, dim3(blocks), dim3(256), 0, m->stream, a);
         else if (kind == POOL_AVG_C1) hipLaunchKernelGGL(avgpool2_c1_kernel, dim3(blocks), dim3(256), 0, m->stream, a);
         else hipLaunchKernelGGL(chansum_kernel, dim3(blocks), dim3(256), 0, m->stream, a);
@@ -742,36 +759,59 @@ int pack_res8(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
 // chunks, and the k-th unit of work (k = block + i * grid) takes the (k / 8)-th tile of chunk k % 8: the 32 blocks of
 // an XCD work on spatially adjacent tiles at the same time, and on the rows just below right after, so the 8-row /
 // 14-column halo overlap of neighbouring tiles is served by that XCD's L2 instead of being fetched again.
-const int32_t* tile_schedule(asep_aru* m, const Res8Args& a, int nblocks, int unit_h) {
-    if (!m->use_xcd_sched || nblocks % 8 != 0 || a.total_tiles < 2 * nblocks) return nullptr;
-    std::string key = std::to_string(nblocks) + "/" + std::to_string(unit_h);
-    for (int i = 0; i < a.nprob; ++i) key += ":" + std::to_string(a.p[i].tiles_x) + "x" + std::to_string((a.p[i].H + unit_h - 1) / unit_h);
+struct TileDims { int tx, ty, begin; };
+
+// units -> tiles for the problems' tile grids `probs` (tile numbers begin + ty * tx + x, `total` tiles in all).  The table has
+// `total` entries, or with pad8 the next multiple of 8 (surplus units hold -1: launches whose grid.y counts channel blocks keep
+// "tile t runs on XCD t % 8" for every y that way).  One-shot kernels launch one block per unit (sched_tile, bf16_kernels.h).
+const int32_t* xcd_schedule(asep_aru* m, const std::vector<TileDims>& probs, int total, bool pad8, int* n_units = nullptr) {
+    const int units = pad8 ? (total + 7) / 8 * 8 : total;
+    if (n_units) *n_units = units;
+    std::string key = pad8 ? "p" : "u";
+    for (const TileDims& q : probs) key += ":" + std::to_string(q.tx) + "x" + std::to_string(q.ty);
     auto it = m->sched_cache.find(key);
     if (it != m->sched_cache.end()) return it->second;
     std::vector<int32_t> order;
-    order.reserve(a.total_tiles);
-    for (int i = 0; i < a.nprob; ++i) {
-        const int TX = a.p[i].tiles_x, TY = (a.p[i].H + unit_h - 1) / unit_h, base = a.p[i].tile_begin;
-        for (int gc = 0; gc * 8 < TX; ++gc)
-            for (int gr = 0; gr * 4 < TY; ++gr)
+    order.reserve(total);
+    for (const TileDims& q : probs)
+        for (int gc = 0; gc * 8 < q.tx; ++gc)
+            for (int gr = 0; gr * 4 < q.ty; ++gr)
                 for (int r = 0; r < 4; ++r)
                     for (int c = 0; c < 8; ++c) {
                         const int ty = gr * 4 + r, tx = gc * 8 + c;
-                        if (ty < TY && tx < TX) order.push_back(base + ty * TX + tx);
+                        if (ty < q.ty && tx < q.tx) order.push_back(q.begin + ty * q.tx + tx);
                     }
-    }
-    const int T = a.total_tiles;
-    std::vector<int32_t> sched(T);
+    if ((int)order.size() != total) return nullptr;
+    std::vector<int32_t> sched(units);
     int off[9];
     off[0] = 0;
-    for (int x = 0; x < 8; ++x) off[x + 1] = off[x] + (T - x + 7) / 8;
-    for (int k = 0; k < T; ++k) sched[k] = order[off[k % 8] + k / 8];
+    for (int x = 0; x < 8; ++x) off[x + 1] = off[x] + (total - x + 7) / 8;
+    for (int k = 0; k < units; ++k) sched[k] = k / 8 < off[k % 8 + 1] - off[k % 8] ? order[off[k % 8] + k / 8] : -1;
     int32_t* d = nullptr;
-    if (hipMalloc((void**)&d, (size_t)T * sizeof(int32_t)) != hipSuccess) return nullptr;
-    if (hipMemcpy(d, sched.data(), (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    if (hipMalloc((void**)&d, (size_t)units * sizeof(int32_t)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, sched.data(), (size_t)units * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
     m->owned.push_back(d);
     m->sched_cache[key] = d;
     return d;
+}
+
+// the persistent fp32 level-0 kernels: nblocks resident blocks, unit k = block + i * nblocks
+const int32_t* tile_schedule(asep_aru* m, const Res8Args& a, int nblocks, int unit_h) {
+    if (!m->use_xcd_sched || nblocks % 8 != 0 || a.total_tiles < 2 * nblocks) return nullptr;
+    std::vector<TileDims> probs;
+    for (int i = 0; i < a.nprob; ++i) probs.push_back({a.p[i].tiles_x, (a.p[i].H + unit_h - 1) / unit_h, a.p[i].tile_begin});
+    return xcd_schedule(m, probs, a.total_tiles, false);
+}
+
+// one-shot kernels (one block per tile): worth a table from a few waves of blocks per XCD on
+template <class Args>
+const int32_t* oneshot_schedule(asep_aru* m, const Args& a, int th, int total, bool pad8, int* n_units,
+                                int (*height)(const Args&, int)) {
+    if (n_units) *n_units = total;
+    if (!m->use_xcd_sched || total < 8 * 64) return nullptr;
+    std::vector<TileDims> probs;
+    for (int i = 0; i < a.nprob; ++i) probs.push_back({a.p[i].tiles_x, (height(a, i) + th - 1) / th, a.p[i].tile_begin});
+    return xcd_schedule(m, probs, total, pad8, n_units);
 }
 
 void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats, bool want_pool, TL* d_out, TL* pool_out) {
@@ -783,8 +823,9 @@ void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>&
         const size_t b1 = std::min(imgs.size(), b0 + MAXP);
         Res8Args a{};
         int tiles = 0;
-        double flops = 0;
+        double flops = 0, bytes = 0;
         for (size_t i = b0; i < b1; ++i) {
+            bytes += tbytes(imgs[i]) + tbytes((*d_out)[i]) + (want_pool ? tbytes((*pool_out)[i]) : 0.0);
             Res8Prob& p = a.p[i - b0];
             p.img = imgs[i].p; p.in1 = nullptr; p.stats = stats.empty() ? nullptr : stats[i];
             p.out = (*d_out)[i].p; p.pool = want_pool ? (*pool_out)[i].p : nullptr;
@@ -803,6 +844,7 @@ void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>&
         TL sub(imgs.begin() + b0, imgs.begin() + b1);
         const std::string pname = valu ? std::string("res8v_down_kernel") : std::string("res8_down_kernel<false>");
         ProfScope ps(m, pname, flops, "unet_down_0 (conv1+3xconvR+add+pool) " + dims_of(sub));
+        ps.bytes = bytes;
         a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH * R8_NP);
         if (valu) hipLaunchKernelGGL(res8v_down_kernel, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
         else hipLaunchKernelGGL(res8_down_kernel<false>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
@@ -817,8 +859,9 @@ TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
         const size_t b1 = std::min(skip.size(), b0 + MAXP);
         Res8Args a{};
         int tiles = 0;
-        double flops = 0;
+        double flops = 0, bytes = 0;
         for (size_t i = b0; i < b1; ++i) {
+            bytes += tbytes(skip[i]) + tbytes(v[i]) + tbytes(out[i]);
             Res8Prob& p = a.p[i - b0];
             p.img = skip[i].p; p.in1 = v[i].p; p.stats = nullptr; p.out = out[i].p; p.pool = nullptr;
             p.H = skip[i].H; p.W = skip[i].W;
@@ -836,6 +879,7 @@ TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
         TL sub(skip.begin() + b0, skip.begin() + b1);
         const std::string pname = valu ? std::string("res8v_up_kernel") : std::string("res8_up_kernel<false>");
         ProfScope ps(m, pname, flops, "unet_up_0 (conv1[16->8]+3xconvR+add) " + dims_of(sub));
+        ps.bytes = bytes;
         a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH * R8_NP);
         const dim3 grid(std::min(tiles, m->num_cus));
         if (valu) hipLaunchKernelGGL(res8v_up_kernel, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
@@ -1046,8 +1090,9 @@ void run_res8b(asep_aru* m, bool up, const TL& a0, const TL* a1, const std::vect
         const size_t b1 = std::min(a0.size(), b0 + MAXP);
         Res8BArgs a{};
         int tiles = 0;
-        double flops = 0;
+        double flops = 0, bytes = 0;
         for (size_t i = b0; i < b1; ++i) {
+            bytes += tbytes(a0[i]) + (up ? tbytes((*a1)[i]) : 0.0) + tbytes((*d_out)[i]) + (want_pool ? tbytes((*pool_out)[i]) : 0.0);
             Res8BProb& p = a.p[i - b0];
             if (up) { p.skip = a0[i].bp(); p.dec = (*a1)[i].bp(); }
             else { p.img = a0[i].p; p.stats = stats.empty() ? nullptr : stats[i]; }
@@ -1062,16 +1107,19 @@ void run_res8b(asep_aru* m, bool up, const TL& a0, const TL* a1, const std::vect
         if (up) { a.w1pk = (const u32x4*)m->d_r8b_up_w1; a.b1 = m->d_r8b_up_b1; a.wpk = (const u32x4*)m->d_r8b_up_w; a.bias = m->d_r8b_up_b; }
         else { a.w1 = m->det_first.d_w; a.b1 = m->det_first.d_b; a.wpk = (const u32x4*)m->d_r8b_down_w; a.bias = m->d_r8b_down_b; }
         TL sub(a0.begin() + b0, a0.begin() + b1);
+        a.sched = oneshot_schedule<Res8BArgs>(m, a, 16, tiles, false, nullptr, [](const Res8BArgs& q, int i) { return q.p[i].H; });
         const std::string what = (up ? "unet_up_0 (conv1[16->8]+3xconvR+add) " : "unet_down_0 (conv1+3xconvR+add+pool) ") + dims_of(sub);
         if (m->use_r8f && (up || m->d_r8f_down_w1)) {
             // lean form for interior tiles (their 24 x 40 input window inside the image), general form for border tiles, one launch
             Res8BArgs f = a;
             if (!up) f.w1pk = (const u32x4*)m->d_r8f_down_w1;
             ProfScope ps(m, up ? "res8f_kernel<true>" : "res8f_kernel<false>", flops, what);
+            ps.bytes = bytes;
             if (up) hipLaunchKernelGGL(res8f_kernel<true>, dim3(tiles), dim3(256), 0, m->stream, f);
             else hipLaunchKernelGGL(res8f_kernel<false>, dim3(tiles), dim3(256), 0, m->stream, f);
         } else {
             ProfScope ps(m, up ? "res8b_kernel<true>" : "res8b_kernel<false>", flops, what);
+            ps.bytes = bytes;
             if (up) hipLaunchKernelGGL(res8b_kernel<true>, dim3(tiles), dim3(256), 0, m->stream, a);
             else hipLaunchKernelGGL(res8b_kernel<false>, dim3(tiles), dim3(256), 0, m->stream, a);
         }
@@ -1134,8 +1182,10 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
         const size_t b1 = std::min(in0.size(), b0 + MAXP);
         ConvBArgs a{};
         int tiles = 0;
-        double flops = 0;
+        double flops = 0, bytes = (double)pc.kh * pc.kw * pc.cin * pc.cout * 2.0;
         for (size_t i = b0; i < b1; ++i) {
+            bytes += tbytes(in0[i]) + (in1 ? tbytes((*in1)[i]) : 0.0) + (res ? tbytes((*res)[i]) : 0.0) + (out.empty() ? 0.0 : tbytes(out[i])) +
+                     (pooled ? tbytes((*pooled)[i]) : 0.0);
             ConvBProb& p = a.p[i - b0];
             p.in0 = in0[i].bp(); p.in1 = in1 ? (*in1)[i].bp() : nullptr; p.res = res ? (*res)[i].bp() : nullptr;
             p.out = out.empty() ? nullptr : out[i].bp();
@@ -1151,9 +1201,12 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
         a.c0 = in0[0].C; a.c1 = in1 ? (*in1)[0].C : 0;
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = cin / 32;
         a.relu_in = relu_in; a.relu_out = relu_out; a.skip_full = pooled && !keep_full; a.pool_f32 = pool_f32;
-        dim3 grid(tiles, pc.mtiles / mtb);
+        int units = tiles;
+        a.sched = oneshot_schedule<ConvBArgs>(m, a, th, tiles, pc.mtiles / mtb > 1, &units, [](const ConvBArgs& q, int i) { return q.p[i].H; });
+        dim3 grid(units, pc.mtiles / mtb);
         TL sub(in0.begin() + b0, in0.begin() + b1);
         ProfScope ps(m, "convb_kernel", flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
+        ps.bytes = bytes;
         const int key = pc.kh * 100 + pc.bmode * 10 + mtb + (th == 8 && mtb == 2 ? 1000 : 0) + (res && pc.bmode == 2 && pc.kh == 3 && mtb >= 2 ? 2000 : 0);
         switch (key) {
             case 3322: ASEP_CONVB_LAUNCH_RES(3, 3, 2, 2, 1, 8, 3); break;       // residual operand prefetched (32- and >= 64-channel convR_2)
@@ -1197,8 +1250,9 @@ TL run_resb_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled)
         const size_t b1 = std::min(t.size(), b0 + MAXP);
         ResBArgs a{};
         int tiles = 0;
-        double flops = 0;
+        double flops = 0, bytes = 3.0 * 9.0 * rb.C * rb.C * 2.0;
         for (size_t i = b0; i < b1; ++i) {
+            bytes += tbytes(t[i]) + tbytes(out[i]) + (pooled ? tbytes((*pooled)[i]) : 0.0);
             ResBProb& p = a.p[i - b0];
             p.t = t[i].bp(); p.out = out[i].bp(); p.pool = pooled ? (*pooled)[i].bp() : nullptr;
             p.H = t[i].H; p.W = t[i].W;
@@ -1209,6 +1263,7 @@ TL run_resb_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled)
         }
         a.nprob = (int)(b1 - b0);
         a.wpk = (const u32x4*)rb.d_w; a.bias = rb.d_b;
+        a.sched = oneshot_schedule<ResBArgs>(m, a, RB_TH, tiles, false, nullptr, [](const ResBArgs& q, int i) { return q.p[i].H; });
         TL sub(t.begin() + b0, t.begin() + b1);
         const std::string what = scope + " (3xconvR+add" + (pooled ? "+pool) " : ") ") + dims_of(sub);
         if (rb.C == 32) {
@@ -1218,13 +1273,16 @@ TL run_resb_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled)
                 attr = true;
             }
             ProfScope ps(m, "res32_tail_kernel", flops, what);
+            ps.bytes = bytes;
             a.ntiles = tiles;
             hipLaunchKernelGGL(res32_tail_kernel, dim3(std::min(tiles, m->num_cus)), dim3(512), Res32Layout::BYTES, m->stream, a);
         } else if (rb.C == 16 && m->use_r8f) {                      // lean form for interior tiles, general form for border tiles, one launch
             ProfScope ps(m, "res16f_kernel", flops, what);
+            ps.bytes = bytes;
             hipLaunchKernelGGL(res16f_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
         } else {
             ProfScope ps(m, "resb_tail_kernel" + targs({ti(rb.C)}), flops, what);
+            ps.bytes = bytes;
             if (rb.C == 8) hipLaunchKernelGGL(resb_tail_kernel<8>, dim3(tiles), dim3(256), 0, m->stream, a);
             else hipLaunchKernelGGL(resb_tail_kernel<16>, dim3(tiles), dim3(256), 0, m->stream, a);
         }
@@ -1254,8 +1312,9 @@ TL run_deconvb(asep_aru* m, const std::string& scope, const TL& in, const TL& li
         const size_t b1 = std::min(in.size(), b0 + MAXP);
         DeconvBArgs a{};
         int tiles = 0;
-        double flops = 0;
+        double flops = 0, bytes = 9.0 * pc.cin * pc.cout * 2.0;
         for (size_t i = b0; i < b1; ++i) {
+            bytes += tbytes(in[i]) + tbytes(out[i]);
             DeconvBProb& p = a.p[i - b0];
             p.in = in[i].bp(); p.out = out[i].bp();
             p.Hi = in[i].H; p.Wi = in[i].W; p.Ho = out[i].H; p.Wo = out[i].W;
@@ -1269,10 +1328,13 @@ TL run_deconvb(asep_aru* m, const std::string& scope, const TL& in, const TL& li
         a.nprob = (int)(b1 - b0);
         a.wpk = (const u32x4*)pc.d_wb; a.bias = pc.d_b;
         a.cin = pc.cin; a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.cin / 32; a.relu_out = relu_out;
-        dim3 grid(tiles, pc.mtiles / mt);
+        int units = tiles;
+        a.sched = oneshot_schedule<DeconvBArgs>(m, a, dth, tiles, pc.mtiles / mt > 1, &units, [](const DeconvBArgs& q, int i) { return q.p[i].Hi; });
+        dim3 grid(units, pc.mtiles / mt);
         TL sub(in.begin() + b0, in.begin() + b1);
         ProfScope ps(m, "deconvb_kernel" + targs({ti(pc.bmode), ti(mt), ti(dth)}), flops,
                      scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
+        ps.bytes = bytes;
         if (pc.bmode == 1 && mt == 1) hipLaunchKernelGGL((deconvb_kernel<1, 1, 8>), grid, dim3(256), 0, m->stream, a);
         else if (pc.bmode == 1) hipLaunchKernelGGL((deconvb_kernel<1, 2, 8>), grid, dim3(256), 0, m->stream, a);
         else if (mt == 1) hipLaunchKernelGGL((deconvb_kernel<2, 1, 8>), grid, dim3(256), 0, m->stream, a);
@@ -1290,8 +1352,9 @@ TL run_direct_bf(asep_aru* m, const DirectConv& dc, const TL& imgs, const std::v
         const size_t b1 = std::min(imgs.size(), b0 + MAXP);
         C1Args a{};
         int tiles = 0;
-        double flops = 0;
+        double flops = 0, bytes = 0;
         for (size_t i = b0; i < b1; ++i) {
+            bytes += tbytes(imgs[i]) + tbytes(out[i]);
             C1Prob& p = a.p[i - b0];
             p.img = imgs[i].p; p.out = out[i].p; p.stats = stats.empty() ? nullptr : stats[i];
             p.H = imgs[i].H; p.W = imgs[i].W;
@@ -1303,6 +1366,7 @@ TL run_direct_bf(asep_aru* m, const DirectConv& dc, const TL& imgs, const std::v
         a.nprob = (int)(b1 - b0);
         a.w = dc.d_w; a.bias = dc.d_b; a.relu = 0;
         ProfScope ps(m, "conv_c1_kernel<3,8,true>", flops);
+        ps.bytes = bytes;
         hipLaunchKernelGGL((conv_c1_kernel<3, 8, true>), dim3(tiles), dim3(256), 0, m->stream, a);
     }
     return out;
@@ -1315,7 +1379,9 @@ TL run_chansum_bf(asep_aru* m, const TL& in) {
         const size_t b1 = std::min(in.size(), b0 + MAXP);
         PoolBArgs a{};
         int blocks = 0;
+        double bytes = 0;
         for (size_t i = b0; i < b1; ++i) {
+            bytes += tbytes(in[i]) + tbytes(out[i]);
             PoolBProb& p = a.p[i - b0];
             p.in = in[i].bp(); p.out = out[i].p; p.H = in[i].H; p.W = in[i].W;
             p.blk_begin = blocks;
@@ -1324,6 +1390,7 @@ TL run_chansum_bf(asep_aru* m, const TL& in) {
         a.nprob = (int)(b1 - b0);
         a.C = in[0].C;
         ProfScope ps(m, "chansumb_kernel", 0.0);
+        ps.bytes = bytes;
         hipLaunchKernelGGL(chansumb_kernel, dim3(blocks), dim3(256), 0, m->stream, a);
     }
     return out;
@@ -1339,7 +1406,9 @@ void apply_act(asep_aru* m, TL& l) {
         const size_t b1 = std::min(l.size(), b0 + MAXP);
         PoolArgs a{};
         int blocks = 0;
+        double bytes = 0;
         for (size_t i = b0; i < b1; ++i) {
+            bytes += 2.0 * tbytes(l[i]);
             PoolProb& p = a.p[i - b0];
             p.in = l[i].p; p.out = l[i].p; p.H = p.Ho = l[i].H; p.W = p.Wo = l[i].W;
             p.blk_begin = blocks;
@@ -1348,6 +1417,7 @@ void apply_act(asep_aru* m, TL& l) {
         a.nprob = (int)(b1 - b0);
         a.C = l[0].C;
         ProfScope ps(m, "act_kernel", 0.0);
+        ps.bytes = bytes;
         hipLaunchKernelGGL(act_kernel, dim3(blocks), dim3(256), 0, m->stream, a, m->cfg.activation);
     }
 }
@@ -1474,8 +1544,9 @@ TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) 
             const size_t b1 = std::min(imgs.size(), b0 + MAXP);
             AttHeadArgs a{};
             int tiles = 0;
-            double flops = 0;
+            double flops = 0, bytes = 0;
             for (size_t i = b0; i < b1; ++i) {
+                bytes += tbytes(imgs[i]) + tbytes(y[i]);
                 C1Prob& q = a.p[i - b0];
                 q.img = imgs[i].p; q.out = y[i].p; q.stats = stats.empty() ? nullptr : stats[i];
                 q.H = imgs[i].H; q.W = imgs[i].W;
@@ -1490,6 +1561,7 @@ TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) 
             for (size_t i = b0; i < b1; ++i) valu = valu && (size_t)imgs[i].H * imgs[i].W < ((size_t)1 << 28);
             if (m->bf16 && !valu) { set_error("bf16 path: image too large for the attention head kernel"); throw ArgError(); }
             ProfScope ps(m, m->bf16 ? "att_headv_kernel<true>" : (valu ? "att_headv_kernel<false>" : "att_head_kernel"), flops);
+            ps.bytes = bytes;
             if (m->bf16) hipLaunchKernelGGL(att_headv_kernel<true>, dim3(tiles), dim3(256), 0, m->stream, a);
             else if (valu) hipLaunchKernelGGL(att_headv_kernel<false>, dim3(tiles), dim3(256), 0, m->stream, a);
             else hipLaunchKernelGGL(att_head_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
@@ -1614,12 +1686,19 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
             ca.out = d_outs[b]; ca.out_u8 = d_u8s ? d_u8s[b] : nullptr; ca.out_mask = d_masks ? d_masks[b] : nullptr;
             ca.thr255 = (double)threshold * 255.0;
             ca.softmax = cfg.apply_softmax;
-            dim3 grid(cdiv(W, COMBINE_TW), cdiv(H, 16));
+            ca.tiles_x = cdiv(W, COMBINE_TW);
+            const int ctiles = ca.tiles_x * cdiv(H, 16);
+            ca.sched = (m->use_xcd_sched && ctiles >= 8 * 64) ? xcd_schedule(m, {{ca.tiles_x, cdiv(H, 16), 0}}, ctiles, false) : nullptr;
+            dim3 grid(ctiles);
             // number of scales as a template constant (1 = no attention, 3 = the default ARU-Net) with 32-bit offsets, for tensors
             // below 4 GB; anything else takes the run-time form
             const bool small = (size_t)H * W * std::max(cfg.feat_root, cfg.n_classes) * sizeof(float) < ((size_t)1 << 32);
             const int nsct = small && (nsc == 1 || nsc == 3) ? nsc : 0;
             ProfScope ps(m, "combine_kernel" + targs({ti(cfg.feat_root), ti(cfg.n_classes), tb(m->bf16), ti(nsct)}), 2.0 * H * W * 16.0 * cfg.feat_root * cfg.n_classes);
+            // scale-0 feature map + per further scale its channel sum + the attention maps in; probabilities (+ uint8 / threshold images) out
+            ps.bytes = tbytes(feat[b * nsc]) + (double)H * W * cfg.n_classes * (4.0 + (ca.out_u8 ? 1.0 : 0.0) + (ca.out_mask ? 1.0 : 0.0));
+            for (int s2 = 1; s2 < nsc; ++s2) ps.bytes += tbytes(fsum[b * (nsc - 1) + (s2 - 1)]);
+            for (int s2 = 0; s2 < nsc && cfg.use_attention; ++s2) ps.bytes += tbytes(att[b * nsc + s2]);
 #define ASEP_COMB_N(FR, NC, BF)                                                                    \
         if (nsct == 3) hipLaunchKernelGGL((combine_kernel<FR, NC, BF, 3>), grid, dim3(256), 0, stream, ca);      \
         else if (nsct == 1) hipLaunchKernelGGL((combine_kernel<FR, NC, BF, 1>), grid, dim3(256), 0, stream, ca); \
@@ -1728,6 +1807,11 @@ extern "C" {
 asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_cfg* cfg) {
     ASEP_GUARD_BEGIN
     if (!cfg || !weight_blob) { set_error("asep_aru_load: null argument"); return nullptr; }
+    if (cfg->struct_size != (int32_t)sizeof(asep_aru_cfg)) {
+        set_error("asep_aru_load: cfg.struct_size is %d, this library's asep_aru_cfg has %zu bytes (ABI version %d): the binding was "
+                  "written against another include/asep_hip.h", cfg->struct_size, sizeof(asep_aru_cfg), ASEP_ABI_VERSION);
+        return nullptr;
+    }
     if (cfg->channels != 1) { set_error("asep_aru_load: only 1-channel input is supported (ARU_v1.py:115)"); return nullptr; }
     if (cfg->compute_dtype != 0 && cfg->compute_dtype != 1) { set_error("asep_aru_load: compute_dtype %d unknown (0 = fp32, 1 = bf16 MFMA)", cfg->compute_dtype); return nullptr; }
     if (cfg->scale_space_num < 1 || cfg->res_depth < 1) { set_error("asep_aru_load: bad cfg"); return nullptr; }
@@ -1983,19 +2067,19 @@ long asep_aru_profile_report(asep_aru* m, char* buf, size_t buflen) {
     if (!m || !buf || buflen < 2) { set_error("asep_aru_profile_report: bad argument"); return ASEP_ERR_ARG; }
     ASEP_HIP_CHECK(hipStreamSynchronize(m->stream));
     const size_t nk = m->prof_names.size();
-    std::vector<double> ms(nk, 0.0), fl(nk, 0.0);
+    std::vector<double> ms(nk, 0.0), fl(nk, 0.0), by(nk, 0.0);
     std::vector<long> calls(nk, 0);
     for (const auto& r : m->prof_recs) {
         float t = 0.f;
         ASEP_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
-        ms[r.kid] += t; fl[r.kid] += r.flops; calls[r.kid] += 1;
+        ms[r.kid] += t; fl[r.kid] += r.flops; by[r.kid] += r.bytes; calls[r.kid] += 1;
     }
     std::string js = "[";
     for (size_t i = 0; i < nk; ++i) {
         if (!calls[i]) continue;
         char line[512];
-        snprintf(line, sizeof(line), "%s{\"kernel\":\"%s\",\"calls\":%ld,\"total_ms\":%.6f,\"flops\":%.6e}",
-                 js.size() > 1 ? "," : "", m->prof_names[i].c_str(), calls[i], ms[i], fl[i]);
+        snprintf(line, sizeof(line), "%s{\"kernel\":\"%s\",\"calls\":%ld,\"total_ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e}",
+                 js.size() > 1 ? "," : "", m->prof_names[i].c_str(), calls[i], ms[i], fl[i], by[i]);
         js += line;
     }
     js += "]";

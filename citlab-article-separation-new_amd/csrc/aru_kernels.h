@@ -1454,6 +1454,8 @@ struct CombineArgs {
     uint8_t* out_mask;               // optional
     double thr255;
     int softmax;
+    int tiles_x;                     // 32-pixel tile columns; the grid is one-dimensional: tile = sched ? sched[block] : block
+    const int32_t* sched;            // XCD-aware block -> tile table (aru_engine.hip, xcd_schedule) or nullptr
 };
 
 constexpr int COMBINE_TW = 32;   // tile width of combine_kernel (16 rows)
@@ -1481,7 +1483,9 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
     };
     __shared__ float swl[16 * FR * NC + NC];
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * T;
+    const int bid = a.sched ? a.sched[blockIdx.x] : (int)blockIdx.x;
+    const int tyb = bid / a.tiles_x;
+    const int x0 = (bid - tyb * a.tiles_x) * TW, y0 = tyb * T;
     if (tid < NC) swl[16 * FR * NC + tid] = a.bl[tid];
 
     // phase 1 in two sweeps over the thread's (at most NPX) window pixels: ALL loads first -- feature pixel, attention

@@ -91,7 +91,8 @@ size_t BufferPool::total_bytes() const {
 extern "C" {
 
 const char* asep_last_error(void) { return asep::get_error(); }
-const char* asep_version(void) { return "asep_hip 0.1 (gfx950)"; }
+const char* asep_version(void) { return "asep_hip 0.4 (gfx950)"; }
+int asep_abi_version(void) { return ASEP_ABI_VERSION; }
 
 int asep_device_count(void) {
     int n = 0;

@@ -47,6 +47,14 @@ __device__ __forceinline__ f32x4 mfma_bf16_k32(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// XCD-aware block -> tile map of the one-shot kernels (aru_engine.hip, xcd_schedule): workgroup b of a launch runs on XCD b % 8 and
+// every XCD has its own L2, so row-major tile numbers put the tiles that share a halo on eight different L2s and each of them
+// fetches the overlap from HBM (res8f_kernel<true>: 3.36 GB fetched for 1.57 GB of input, rocprofv3 FETCH_SIZE, round 3).  With the
+// table the blocks of one XCD walk ONE compact region of the page in 4 x 8 super-tile order.  nullptr = identity; a negative
+// entry = padding block (grids whose y dimension counts channel blocks are padded to a multiple of 8 so that the XCD of a tile
+// does not depend on blockIdx.y).
+__device__ __forceinline__ int sched_tile(const int32_t* __restrict__ sched) { return sched ? sched[blockIdx.x] : (int)blockIdx.x; }
+
 // ------------------------------------------------------------------------------------------------
 // convb_kernel: stride-1 SAME convolution (3x3 or 4x4), bf16 in / out, optional channel concat [in0, in1], residual,
 // ReLU on the input and / or output, 2x2 max pool of the output.
@@ -72,6 +80,7 @@ struct ConvBArgs {
     int c0, c1;            // channels of in0 / in1 (multiples of 8)
     int cout, mtiles, groups;
     int relu_in, relu_out, skip_full, pool_f32;
+    const int32_t* sched;  // block -> tile (sched_tile) or nullptr
 };
 
 // Waves: WM along the output channels x 4 / WM along the pixels; wave (wm, wn) owns m-tiles wm MT .. and n-tiles id = wn NT + n
@@ -114,10 +123,12 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
     const int j = lane & 15, kk = lane >> 4;
     CVB_MARK(0);
     const int wm = WM == 2 ? (wave & 1) : 0, wn = WM == 2 ? (wave >> 1) : wave;
+    const int bid = sched_tile(a.sched);
+    if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
     const ConvBProb& P = a.p[pi];
-    const int tile = blockIdx.x - P.tile_begin;
+    const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
     const int x0 = tx * TW, y0 = ty * TH, mtb0 = blockIdx.y * MTB, mt0 = mtb0 + wm * MT;
     const int H = P.H, W = P.W;
@@ -368,6 +379,7 @@ struct ResBArgs {
     const u32x4* wpk;      // [3 convs][CPC chunks][64 lanes] x 16 bytes
     const float* bias;     // [3][C]
     int ntiles;            // res32_tail_kernel: all problems' tiles (its resident blocks walk them)
+    const int32_t* sched;  // block (res32_tail_kernel: work unit) -> tile (sched_tile) or nullptr
 };
 constexpr int RB_TH = 16, RB_TW = 32;
 
@@ -509,11 +521,12 @@ __device__ __forceinline__ void resb_tail_tile(const ResBArgs& a, const ResBProb
 
 template <int C>
 __global__ __launch_bounds__(256, C == 8 ? 4 : 3) void resb_tail_kernel(const ResBArgs a) {
+    const int bid = sched_tile(a.sched);
     __shared__ __attribute__((aligned(16))) unsigned char lds[ResBLayout<C>::BYTES];
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
     const ResBProb& P = a.p[pi];
-    const int tile = blockIdx.x - P.tile_begin;
+    const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
     resb_tail_tile<C>(a, P, tx * RB_TW, ty * RB_TH, lds);
 }
@@ -584,7 +597,8 @@ __global__ __launch_bounds__(512, 1) void res32_tail_kernel(const ResBArgs a) {
     const int sub = tid & 3;                                  // (512 is a multiple of 4: the channel block is the same for all slots)
     u32x4 st[NLOAD];
     unsigned mask = 0;
-    auto locate = [&](int t, int& pi, int& x0, int& y0) {
+    auto locate = [&](int unit, int& pi, int& x0, int& y0) {
+        const int t = a.sched ? a.sched[unit] : unit;
         pi = 0;
         while (pi + 1 < a.nprob && t >= a.p[pi + 1].tile_begin) ++pi;
         const int tile = t - a.p[pi].tile_begin;
@@ -743,10 +757,11 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
+    const int bid = sched_tile(a.sched);
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
     const ResBProb& P = a.p[pi];
-    const int tile = blockIdx.x - P.tile_begin;
+    const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
     const int H = P.H, W = P.W;
@@ -922,6 +937,7 @@ struct DeconvBArgs {
     const float* bias;
     int cin, cout, mtiles, groups;
     int relu_out;
+    const int32_t* sched;  // block -> tile (sched_tile) or nullptr
 };
 constexpr int DCB_TW = 16;                                    // input columns per block; rows: template parameter TH (8 or 16)
 
@@ -939,10 +955,12 @@ __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
+    const int bid = sched_tile(a.sched);
+    if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
     const DeconvBProb& P = a.p[pi];
-    const int tile = blockIdx.x - P.tile_begin;
+    const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
     const int X0 = tx * DCB_TW, Y0 = ty * DCB_TH, mt0 = blockIdx.y * MT;
     const int Hi = P.Hi, Wi = P.Wi, cin = a.cin;
@@ -1121,6 +1139,7 @@ struct Res8BArgs {
     const u32x4* w1pk;     // UP: conv1 pair fragments [ky 3][half 2][64 lanes] x 16 bytes; res8f_kernel DOWN: [64 lanes] (bf16 conv1)
     const u32x4* wpk;      // tail: [3 convs][ky 3][64 lanes] x 16 bytes
     const float* bias;     // tail biases [3][8]
+    const int32_t* sched;  // block -> tile (sched_tile) or nullptr
 };
 
 template <bool UP>
@@ -1349,10 +1368,11 @@ __device__ __forceinline__ void res8b_tile(const Res8BArgs& a, const Res8BProb& 
 template <bool UP>
 __global__ __launch_bounds__(256, UP ? 3 : 4) void res8b_kernel(const Res8BArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[Res8BLayout<UP>::BYTES];
+    const int bid = sched_tile(a.sched);
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
     const Res8BProb& P = a.p[pi];
-    const int tile = blockIdx.x - P.tile_begin;
+    const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
     res8b_tile<UP>(a, P, tx * 32, ty * 16, lds);
 }
@@ -1395,10 +1415,11 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     R8F_MARK(0);
     const int j = lane & 15, kk = lane >> 4, e = kk >> 1, ch = (kk & 1) * 4;     // D layout: pixel parity e, channels ch .. ch + 3
+    const int bid = sched_tile(a.sched);
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
     const Res8BProb& P = a.p[pi];
-    const int tile = blockIdx.x - P.tile_begin;
+    const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
     const int H = P.H, W = P.W;

@@ -397,6 +397,11 @@ extern "C" {
 asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_cfg* cfg) {
     ASEP_GUARD_BEGIN
     if (!cfg || !weight_blob) { set_error("asep_gnn_load: null argument"); return nullptr; }
+    if (cfg->struct_size != (int32_t)sizeof(asep_gnn_cfg)) {
+        set_error("asep_gnn_load: cfg.struct_size is %d, this library's asep_gnn_cfg has %zu bytes (ABI version %d): the binding was "
+                  "written against another include/asep_hip.h", cfg->struct_size, sizeof(asep_gnn_cfg), ASEP_ABI_VERSION);
+        return nullptr;
+    }
     if (cfg->node_feature_dim < 1 || cfg->edge_feature_dim < 0 || cfg->num_transition_steps < 0 || cfg->hidden_dim < 1 ||
         cfg->interaction_dim < 1 || cfg->interaction_hidden < 1 || cfg->cls_hidden1 < 1 || cfg->cls_hidden2 < 1 ||
         cfg->num_classes < 1 || cfg->num_classes > 16) {

@@ -42,6 +42,12 @@ int asep_device_count(void);
 int asep_init(int device_id);                 /* hipSetDevice + arch check (gfx950) */
 const char* asep_last_error(void);
 const char* asep_version(void);
+/* Version of THIS header's struct layouts and signatures (ASEP_ABI_VERSION of the build).  A binding checks it once after
+ * dlopen; independently of it every configuration struct starts with its own size in bytes (`struct_size`), and the load
+ * functions refuse a struct whose size is not the one the library was built with -- a caller written against an older or newer
+ * header gets ASEP_ERR_ARG + a message instead of fields read from whatever follows its struct on the stack. */
+#define ASEP_ABI_VERSION 4
+int asep_abi_version(void);
 
 /* Page-locked host memory.  The host-pointer entry points (asep_aru_forward, asep_gnn_forward ...) copy with
  * asynchronous transfers on one stream: from / to page-locked buffers these are DMAs at link speed, from / to ordinary
@@ -54,6 +60,7 @@ int asep_host_unregister(void* p);
 
 /* ---- ARU-Net (ARU_v1.py:35-43 hyper-parameters) ---------------------------------------------- */
 typedef struct asep_aru_cfg {
+    int32_t struct_size;       /* = sizeof(asep_aru_cfg) of the header the caller was compiled / written against */
     int32_t channels;          /* image channels, 1 */
     int32_t n_classes;
     int32_t feat_root;         /* 8 */
@@ -119,6 +126,7 @@ double asep_aru_flops(const asep_aru* m, int H, int W);
 
 /* ---- GNN relation predictor ------------------------------------------------------------------ */
 typedef struct asep_gnn_cfg {
+    int32_t struct_size;           /* = sizeof(asep_gnn_cfg) of the header the caller was compiled / written against */
     int32_t node_feature_dim;      /* u (after masking), e.g. 7 */
     int32_t edge_feature_dim;      /* e, e.g. 2 */
     int32_t num_transition_steps;  /* 3 */

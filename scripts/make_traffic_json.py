@@ -48,9 +48,10 @@ def main():
     s = json.load(open(os.path.join(tagdir, "pmc_summary.json")))
     line = json.loads(open(os.path.join(tagdir, "bench_under_trace.json")).read().strip().splitlines()[-1])
     # pages of the profiled process: (warm-up + timed + event-timed steps) x pages per step
-    ppl = line["roofline"]["pages_per_launch"]
+    rb = {**(line.get("roofline_detail") or {}), **line["roofline"]}          # round 4: detail keys live beside the slim block
+    ppl = rb["pages_per_launch"]
     B = line["config"]["pages_per_step_per_gpu"]
-    steps_total = line["warmup"] + line["steps"] + line["roofline"].get("event_timed_steps", 0)
+    steps_total = line["warmup"] + line["steps"] + rb.get("event_timed_steps", 0)
     kernels, page_bytes = traffic_table(s, steps_total * B)
     out = {"source": f"{tagdir}/pmc_summary.json", "commit": commit, "pages_per_launch": ppl, "dtype": line["dtype"],
            "pages_per_step": B, "relation_net": line["config"]["relation_net"], "height": line["config"]["height"],

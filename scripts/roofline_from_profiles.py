@@ -30,9 +30,16 @@ def load_line(path):
     return json.loads(open(path).read().strip().splitlines()[-1])
 
 
+def block(line):
+    """the line's roofline figures as one dict: round 4 split them into `roofline` (<= 20 keys, what a truncating record keeps) and
+    `roofline_detail`; rounds 2-3 had one block"""
+    return {**(line.get("roofline_detail") or {}), **line["roofline"]}
+
+
 def recompute(tagdir):
     line = load_line(os.path.join(tagdir, "bench_under_trace.json"))
-    r = line["roofline"]
+    r = block(line)
+    layout4 = r.get("layout", 3) >= 4
     stats = {}
     for row in csv.DictReader(open(os.path.join(tagdir, "kernel_stats.csv"))):
         if "asep::" in row["Name"]:
@@ -48,7 +55,7 @@ def recompute(tagdir):
     lk = {q["kernel"]: q for q in line["kernels"]}
     exec_fl = r["executed_flops_per_launch"]
     hbm_bound = r["bound"] == "hbm"                            # bf16 lines: the primary figures are bytes / s, the matrix ones under "mfma"
-    peak = r["mfma"]["peak"] if hbm_bound else r["peak"]
+    peak = (r["mfma_peak"] if layout4 else r["mfma"]["peak"]) if hbm_bound else r["peak"]
     achieved = exec_fl / (avg_us * 1e-6) / 1e12
     # whole page: executed FLOPs of all ARU-Net kernels per page (Winograd kernels execute 1/2.25 of their direct-conv credit)
     ev_steps = max(1, r.get("event_timed_steps", 1))
@@ -65,9 +72,12 @@ def recompute(tagdir):
         out["traffic"] = kernels[k]["bytes_per_launch"]
         out["hbm_tb_per_s"] = out["traffic"] / (avg_us * 1e-6) / 1e12
         out["hbm_frac"] = out["hbm_tb_per_s"] / (PEAK_HBM_GBS / 1e3)
-        if hbm_bound:
+        if hbm_bound and not layout4:                          # round 3: the bf16 block priced the COUNTER bytes
             out["achieved"] = out["hbm_tb_per_s"] * 1e3
             out["frac"] = out["hbm_frac"]
+    if hbm_bound and layout4:                                  # round 4: ALGORITHMIC bytes per launch / rocprofv3's launch time
+        out["achieved"] = r["algorithmic_bytes"] / (avg_us * 1e-6) / 1e9
+        out["frac"] = out["achieved"] / PEAK_HBM_GBS
     out["whole_page_traffic_gb"] = page_bytes / 1e9
     out["whole_page_hbm_frac"] = page_bytes * line["value"] / line["n_gpus"] / 1e9 / PEAK_HBM_GBS
     # chip time per page by rocprofv3 (sum of all asep:: kernel durations; streams overlap, so this is >= the wall time per page)
@@ -85,11 +95,14 @@ def recompute(tagdir):
 
 
 def compare(line, rec, tol):
-    r = line["roofline"]
+    r = block(line)
     pairs = {"avg_launch_us": r.get("avg_launch_us_in_situ") or r["avg_launch_us"],
              "whole_page_executed_gflop": r["whole_page_executed_gflop"], "whole_page_executed_frac": r["whole_page_executed_frac"]}
     if r["bound"] == "hbm":
-        pairs.update({"mfma_achieved": r["mfma"]["achieved"], "mfma_frac": r["mfma"]["frac"]})
+        if r.get("layout", 3) >= 4:
+            pairs.update({"mfma_achieved": r["executed_tflops"], "mfma_frac": r["mfma_frac"]})
+        else:
+            pairs.update({"mfma_achieved": r["mfma"]["achieved"], "mfma_frac": r["mfma"]["frac"]})
         if "achieved" in rec:
             pairs.update({"achieved": r["achieved"], "frac": r["frac"]})
     else:

@@ -28,6 +28,70 @@ def test_library_exports_every_declared_symbol(repo_root):
     assert lib.asep_device_count() >= 0
 
 
+def _header_struct_fields(repo_root, name):
+    """field names of `typedef struct <name> { ... } <name>;` in include/asep_hip.h, in order (all are int32_t)"""
+    src = open(os.path.join(repo_root, "include", "asep_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    body = re.search(r"typedef\s+struct\s+%s\s*\{(.*?)\}\s*%s\s*;" % (name, name), src, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        typ, names = decl.split(None, 1)
+        assert typ == "int32_t", f"{name}: the ctypes mirrors assume int32_t fields, found {decl!r}"
+        fields += [n.strip() for n in names.split(",")]
+    return fields
+
+
+def test_cfg_structs_match_the_header_field_by_field(repo_root):
+    """the header gained two fields and a hand-written binding kept the old struct -- the callee read 8 bytes of
+    stack.  The ctypes mirrors must list the header's fields in the header's order, and every struct starts with its size."""
+    import ctypes as C
+    from citlab_article_separation_new_amd import _lib
+    for cname, cls in (("asep_aru_cfg", _lib.AruCfg), ("asep_gnn_cfg", _lib.GnnCfg)):
+        want = _header_struct_fields(repo_root, cname)
+        assert [f[0] for f in cls._fields_] == want, cname
+        assert want[0] == "struct_size" and all(f[1] is C.c_int32 for f in cls._fields_)
+        assert cls().struct_size == C.sizeof(cls) == 4 * len(want)          # filled in by the constructor
+    src = open(os.path.join(repo_root, "include", "asep_hip.h")).read()
+    assert int(re.search(r"#define\s+ASEP_ABI_VERSION\s+(\d+)", src).group(1)) == _lib.ABI_VERSION
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    assert _lib.load_library().asep_abi_version() == _lib.ABI_VERSION
+
+
+def integration_md_stub(repo_root):
+    """the ctypes stub of INTEGRATION.md section 1, executed: -> its namespace (lib, AruCfg, load_graph, get_net_output)"""
+    text = open(os.path.join(repo_root, "INTEGRATION.md")).read()
+    sec = text[text.index("## 1. ARU-Net seam"):text.index("## 2. GNN seam")]
+    blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
+    code = next(b for b in blocks if "C.CDLL(" in b)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(repo_root)                      # the document's library path is relative to the repository root
+    try:
+        exec(compile(code, "INTEGRATION.md#1", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    return ns
+
+
+def test_integration_md_stub_loads_and_matches_the_header(repo_root):
+    """the document's hand-written binding is code: it must load the built library, pass its ABI check and declare the struct the
+    header declares (load only: no compute call without a GPU)"""
+    import ctypes as C
+    from citlab_article_separation_new_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    ns = integration_md_stub(repo_root)
+    assert [f[0] for f in ns["AruCfg"]._fields_] == _header_struct_fields(repo_root, "asep_aru_cfg")
+    assert C.sizeof(ns["AruCfg"]) == C.sizeof(_lib.AruCfg)
+    assert callable(ns["load_graph"]) and callable(ns["get_net_output"])
+
+
 def test_host_library_exports_every_declared_symbol(repo_root):
     """include/asep_host.h (plain C helper of the scan decode, csrc/host_png.c -> libasep_host.so)"""
     import ctypes as C

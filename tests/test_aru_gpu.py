@@ -221,3 +221,37 @@ def test_fused_pool_and_dense_12_channel_mode_match_their_plain_forms(H, W, monk
         graph.close()
     assert np.array_equal(outs["default"], outs["plain_pool"])
     assert float(np.abs(outs["default"] - outs["padded_c12"]).max()) <= 1e-5
+
+
+def test_integration_md_stub_runs_the_net(tmp_path):
+    """INTEGRATION.md section 1 is code: its hand-written ctypes binding (own struct, own argtypes) loads a weight container and
+    runs the net; the result must be the oracle's.  A struct of another size is refused with a message (a
+    10-field struct against the 12-field ABI read stack garbage)."""
+    import ctypes as C
+    import os
+    import sys
+    from citlab_article_separation_new_amd.weights import pack_blob
+    from oracle import aru_oracle
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_abi_and_weights import integration_md_stub
+    repo_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ns = integration_md_stub(repo_root)
+    cfg, w, graph = _setup()
+    graph.close()
+    blob_path = tmp_path / "m.asepw"
+    blob_path.write_bytes(pack_blob(w))
+    h = ns["load_graph"](str(blob_path))
+    img = _image(96, 64, 11)
+    out = ns["get_net_output"](img, h)
+    ref = aru_oracle.forward_torch(img, w, cfg)
+    assert float(np.abs(out - ref).max()) <= PROB_TOL
+    ns["lib"].asep_aru_free.argtypes = [C.c_void_p]
+    ns["lib"].asep_aru_free(h)
+
+    class OldCfg(C.Structure):                      # round 2's ten-field struct (what INTEGRATION.md showed until round 3)
+        _fields_ = [(n, C.c_int32) for n in ("channels", "n_classes", "feat_root", "scale_space_num", "res_depth", "num_scales_att",
+                                             "use_attention", "mvn", "apply_softmax", "compute_dtype")]
+    blob = blob_path.read_bytes()
+    old = OldCfg(1, 2, 8, 5, 3, 3, 1, 0, 1, 0)
+    assert not ns["lib"].asep_aru_load(blob, len(blob), C.byref(old))
+    assert b"struct_size" in ns["lib"].asep_last_error()

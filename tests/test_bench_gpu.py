@@ -13,6 +13,14 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "data", "config", "roofline"}
 
 
+def _free_port():
+    """a port nobody listens on right now (fixed ports collide between concurrent sessions / stale listeners)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _one_json_line(stdout):
     lines = [l for l in stdout.splitlines() if l.strip()]
     assert len(lines) == 1, f"stdout must hold exactly one line, got {len(lines)}: {lines[:3]}"
@@ -20,16 +28,23 @@ def _one_json_line(stdout):
     assert KEYS <= set(line), KEYS - set(line)
     assert line["unit"] == "pages/s" and line["value"] > 0 and line["n_gpus"] == 1 and line["scaling"] == "weak"
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+    # what a record keeps when it cuts nested objects at 24 keys and strings at 120 characters
+    assert len(line["roofline"]) <= 20 and list(line["roofline"]).index("whole_page_hbm_frac") < 12
+    assert len(line["config"]["workload"]) < 120 and all(len(v) < 120 for v in line["roofline"].values() if isinstance(v, str))
     return line
+
+
+def r_src(line):
+    return line["roofline"]["traffic_source"]
 
 
 def test_single_process_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                        "--pages-per-step", "3", "--e2e-pages", "6"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+                        "--pages-per-step", "3", "--e2e-pages", "6", "--bf16-steps", "3"], cwd=ROOT, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-2000:]
     line = _one_json_line(r.stdout)
     assert line["steps"] == 2 and line["warmup"] == 1 and line["dtype"] == "f32"
-    assert line["config"]["pages_per_step_per_gpu"] == 3 and line["roofline"]["pages_per_launch"] == 3.0
+    assert line["config"]["pages_per_step_per_gpu"] == 3 and line["roofline_detail"]["pages_per_launch"] == 3.0
     # secondary figures (bf16 variant, heading net + stroke-width fusion, the visual relation net) ride on the same line
     sec = line["secondary"]
     assert "error" not in sec, sec
@@ -37,9 +52,19 @@ def test_single_process_line():
     assert sec["visual_gnn_vn7e2_shape"]["step_kernel"] == "mfma_lds" and sec["visual_gnn_vn7e2_shape"]["us_per_page"] > 0
     assert sec["visual_gnn_vn7e2_shape"]["us_per_page_grouped"] > 0 and sec["geometric_gnn_7_features"]["us_per_page"] > 0
     assert sec["e2e_files"]["page_xml_written"] == 6 and sec["e2e_files"]["pages_per_s"] > 0
+    # BASELINE configs[4] as a whole step (bf16 ARU-Net + visual relation net with a bf16 backbone), priced against HBM by algorithmic bytes
+    b16 = sec["bf16_full_step"]
+    assert "error" not in b16, b16
+    assert b16["pages_per_s"] > 0 and b16["steps"] == 3 and b16["roofline"]["bound"] == "hbm" and b16["roofline"]["unit"] == "GB/s"
+    assert b16["roofline"]["algorithmic_bytes"] > 0 and 0 < b16["roofline"]["frac"] < 1 and b16["whole_page_algorithmic_gb"] > 1
     assert all("executed_tflops" in k for k in line["kernels"])
     # the headline step carries the VISUAL relation net (BASELINE configs[3]: mixed_gnn_vn7e2), and the roofline block both timings
     assert line["config"]["relation_net"] == "visual" and "mixed_gnn_vn7e2" in line["config"]["workload"]
+    assert line["config"]["devices"] >= 1 and "mixed_gnn_vn7e2" in line["config"]["workload_detail"]
+    # algorithmic bytes of every launch (the engine's shape arithmetic) ride on the kernel table
+    assert all(k["bytes"] > 0 for k in line["kernels"] if k["kernel"].startswith(("conv", "res8", "deconv", "combine")))
+    # three pages at pages-per-step 3 are not the workload the committed counters were taken on: the line says so instead of a number
+    assert r_src(line) and line["roofline"]["traffic"] is None
     r = line["roofline"]
     assert r["frac_in_situ"] and r["frac_isolated"] and r["whole_page_executed_frac"] > 0
     assert r["frac"] == r["frac_in_situ"] and r["frac_in_situ"] <= r["frac_isolated"] * 1.05
@@ -49,7 +74,7 @@ def test_single_process_line():
 def test_rccl_path_with_one_rank_keeps_stdout_clean():
     env = dict(os.environ, ASEP_BENCH_FORCE_DIST="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                        "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
                         "--no-cpu-baseline", "--no-secondary", "--pages-per-step", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     _one_json_line(r.stdout)
@@ -62,7 +87,7 @@ def test_two_ranks_on_the_one_gpu():
     backend of this test is gloo; the ranks are started by torchrun before anything touches the GPU."""
     env = dict(os.environ, ASEP_BENCH_DEVICE="0", ASEP_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--no-cpu-baseline", "--no-secondary", "--pages-per-step", "2", "--kernel-timing", "none"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -71,4 +96,22 @@ def test_two_ranks_on_the_one_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["sharding"] == "pages over 2 rank(s)" and line["cpu_baseline"] is None
     # value = pages of BOTH ranks / slowest rank's time
+    assert abs(line["value"] - 2 * 2 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-2 * line["value"]
+
+
+def test_gpus_2_without_a_torchrun_environment_starts_its_own_ranks():
+    """VERDICT r3 next #1a: `python bench.py --gpus N` with WORLD_SIZE unset used to exit with a message; the scaling run may be
+    started exactly like that.  The parent spawns torch.distributed.run as a child before touching the GPU and relays the child's
+    one line and exit code.  On this one-GPU box the two ranks share device 0 (dealt round-robin over the visible devices, gloo
+    for the broadcast / barrier / max-reduction because RCCL cannot form a communicator of two ranks on one device)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-secondary", "--pages-per-step", "2", "--kernel-timing", "none"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:3]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["sharding"] == "pages over 2 rank(s)" and line["cpu_baseline"] is None
+    assert "ranks share devices" in str(line["config"]["devices"])
     assert abs(line["value"] - 2 * 2 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-2 * line["value"]

@@ -82,12 +82,11 @@ def test_whole_page_bf16_vs_oracle(whole_page):
     g.close()
 
 
-def test_whole_page_fp32_end_points_and_logits_with_unit_logit_scale():
-    """VERDICT r2 weak #8: the whole-frame gate above is on probabilities of weights with logit_scale = 0.05 (small logits compress a
-    feature-map error ~20x before the 1e-4 gate).  Here: reference-rule weights (logit_scale = 1), EVERY end point of the
-    3000 x 4500 frame within 2e-5 * max|ref| (the gate tests/test_aru_gpu.py applies up to 259 x 131), the LOGITS within the same
-    relative gate, and the probabilities within 1e-4."""
-    from citlab_article_separation_new_amd import net_post_processing_helper as helper, synth
+@pytest.fixture(scope="module")
+def unit_scale_page():
+    """page 1, reference-rule weights (logit_scale = 1: saturating class softmax) and the oracle's end points for the whole frame
+    (one oracle run serves the fp32 and the bf16 end-point tests)"""
+    from citlab_article_separation_new_amd import synth
     from citlab_article_separation_new_amd.config import AruConfig
     from citlab_article_separation_new_amd.weights import init_aru_weights
     from oracle import aru_oracle
@@ -95,6 +94,74 @@ def test_whole_page_fp32_end_points_and_logits_with_unit_logit_scale():
     w = init_aru_weights(cfg, 4321, bias_jitter=0.05, logit_scale=1.0)
     page = synth.synth_page(1, W, H).astype(np.float32) / 255.0
     ref, inter = aru_oracle.forward_torch(page, w, cfg, return_intermediates=True)
+    return page, w, cfg, ref, inter
+
+
+# what the bf16 path holds on a whole 3000 x 4500 frame with unit logit scale (measured values in DESIGN section 2; gates ~1.5x above)
+BF16_ENDPOINT_GATE = 4e-2        # max|d| / max|ref| per end point (fp32: 2e-5)
+BF16_ENDPOINT_RMS_GATE = 5e-3    # rms(d) / max|ref| per end point
+BF16_LOGIT_GATE = 4e-2           # max|d logits| / max|logits|
+BF16_PROB_GATE = 6e-2            # max|dp| with a saturating softmax (the stated 2e-2 is the gate of the logit_scale 0.05 weights)
+BF16_U8_RATE_GATE = 0.30         # share of uint8 values that differ from the oracle's (truncation: any |dp| > 1/255 can flip one)
+BF16_MASK_RATE_GATE = 2e-3       # share of threshold-mask pixels (thr 0.5) that differ
+
+
+def test_whole_page_bf16_end_points_logits_and_masks_with_unit_logit_scale(unit_scale_page):
+    """the bf16 path was gated on probabilities of logit_scale = 0.05 weights only (a feature error is
+    compressed ~20x there).  Same whole frame and weights as the fp32 test below: EVERY end point against the fp32 oracle relative to
+    max|ref| (max and rms), the logits, and -- with the saturating softmax of unit-scale logits -- the probabilities, the uint8
+    truncation and the threshold mask the separator post-processor consumes (separator_net_post_processor.py:141-157), each with an
+    asserted bound."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from citlab_article_separation_new_amd.config import AruConfig
+    from oracle import aru_oracle
+    page, w, cfg, ref, inter = unit_scale_page
+    g = helper.AruGraph(w, AruConfig(compute_dtype="bf16"))
+    out, u8, mask = helper.get_net_output_fused(page, g, "0", want_u8=True, threshold=0.5)
+    worst, worst_rms = ("", 0.0), ("", 0.0)
+    rows = []
+    for name in sorted(inter):
+        if not (name.startswith("scale_") or name.startswith("att_")):
+            continue
+        got = helper.get_endpoint(g, name)
+        want = inter[name]
+        assert got.shape == want.shape, name
+        scale = max(1.0, float(np.abs(want).max()))
+        d = got - want
+        rel, rms = float(np.abs(d).max()) / scale, float(np.sqrt(np.mean(d.astype(np.float64) ** 2))) / scale
+        rows.append((name, rel, rms))
+        worst, worst_rms = max(worst, (name, rel), key=lambda t: t[1]), max(worst_rms, (name, rms), key=lambda t: t[1])
+        del got, d
+    g.close()
+    gl = helper.AruGraph(w, AruConfig(compute_dtype="bf16", apply_softmax=False))
+    logits = helper.get_net_output(page, gl, "0")
+    gl.close()
+    lref = inter["logits"]
+    lrel = float(np.abs(logits - lref).max()) / max(1.0, float(np.abs(lref).max()))
+    perr = float(np.abs(out - ref).max())
+    u8_ref = aru_oracle.to_uint8(ref)
+    u8_rate = float((u8 != u8_ref).mean())
+    u8_step = int(np.abs(u8.astype(np.int16) - u8_ref.astype(np.int16)).max())
+    m_rate = float((mask != aru_oracle.apply_threshold(u8_ref, 0.5)).mean())
+    print("\nbf16 whole frame, logit_scale 1: " + "; ".join(f"{n} {a:.1e}/{b:.1e}" for n, a, b in rows))
+    print(f"bf16 whole frame, logit_scale 1: worst end point max {worst[0]} {worst[1]:.2e}, rms {worst_rms[0]} {worst_rms[1]:.2e}; logits rel "
+          f"{lrel:.2e}; max|dp| = {perr:.2e}; uint8 mismatch rate {u8_rate:.3e} (max step {u8_step}); mask mismatch rate @0.5 = {m_rate:.3e}")
+    assert all(rel <= BF16_ENDPOINT_GATE for _, rel, _ in rows), worst
+    assert all(rms <= BF16_ENDPOINT_RMS_GATE for _, _, rms in rows), worst_rms
+    assert lrel <= BF16_LOGIT_GATE and 1e-6 < perr <= BF16_PROB_GATE
+    assert u8_rate <= BF16_U8_RATE_GATE and m_rate <= BF16_MASK_RATE_GATE
+    # the fused epilogue is exactly uint8(p * 255) / apply_threshold of the engine's own float output, in bf16 too
+    assert np.array_equal(u8, aru_oracle.to_uint8(out)) and np.array_equal(mask, aru_oracle.apply_threshold(u8, 0.5))
+
+
+def test_whole_page_fp32_end_points_and_logits_with_unit_logit_scale(unit_scale_page):
+    """VERDICT r2 weak #8: the whole-frame gate above is on probabilities of weights with logit_scale = 0.05 (small logits compress a
+    feature-map error ~20x before the 1e-4 gate).  Here: reference-rule weights (logit_scale = 1), EVERY end point of the
+    3000 x 4500 frame within 2e-5 * max|ref| (the gate tests/test_aru_gpu.py applies up to 259 x 131), the LOGITS within the same
+    relative gate, and the probabilities within 1e-4."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from citlab_article_separation_new_amd.config import AruConfig
+    page, w, cfg, ref, inter = unit_scale_page
     g = helper.AruGraph(w, cfg)
     out = helper.get_net_output(page, g, "0")
     worst = ("", 0.0)

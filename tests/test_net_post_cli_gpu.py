@@ -261,6 +261,65 @@ def test_compute_dtype_switch_for_models_loaded_from_files(tmp_path, monkeypatch
         helper.load_graph(pb)
 
 
+def _raster(polys, H, W):
+    """union of simple polygons (lists of (x, y) vertices on the pixel grid) as a boolean image; both sides of a comparison go
+    through this same rasteriser, so its edge convention cancels"""
+    from PIL import ImageDraw
+    img = Image.new("1", (W, H), 0)
+    d = ImageDraw.Draw(img)
+    for pts in polys:
+        if len(pts) >= 3:
+            d.polygon([(float(x), float(y)) for x, y in pts], fill=1)
+    return np.array(img, dtype=bool)
+
+
+def test_bf16_separator_cli_polygons_against_the_oracle(tmp_path, monkeypatch):
+    """the bf16 command line was checked on probabilities only.  Here its PRODUCT: the separator regions the bf16
+    CLI writes for a page, against the regions of the reference's step sequence (separator_net_post_processor.py:141-157)
+    evaluated by the fp32 oracle at every step -- same number of regions per orientation, and the rasterised regions overlap
+    with IoU >= 0.99.  Weights with unit logit scale (a saturating class softmax, like a trained net's), threshold 0.5."""
+    from citlab_article_separation_new_amd import image_io, polygonize, synth
+    from citlab_article_separation_new_amd import run_net_post_processing as cli
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.host_util import rescale_points
+    from citlab_article_separation_new_amd.page_xml import Page
+    from citlab_article_separation_new_amd.region_to_page_writer import SeparatorRegionToPageWriter
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    from oracle import aru_oracle, classical_oracle as co
+    Wp, Hp = 1000, 1500
+    cfg = AruConfig()
+    w = init_aru_weights(cfg, 4321, bias_jitter=0.05, logit_scale=1.0)
+    pb = tmp_path / "separator_aru_unit.pb"
+    pb.write_bytes(tf_aru_graph.build_aru_pb(w, cfg))
+    data = tmp_path / "data"
+    (data / "page").mkdir(parents=True)
+    Image.fromarray(synth.synth_page(5, W=Wp, H=Hp)).save(data / "q0.png")
+    lst = tmp_path / "q.lst"
+    lst.write_text(str(data / "q0.png") + "\n")
+    _, grey, sc = co.scale_and_gray(image_io.load_image_bgr(str(data / "q0.png")), Hp, 1.0)
+    prob = aru_oracle.forward_torch(grey.astype(np.float32), w, cfg)
+    post = co.separator_post_process(aru_oracle.apply_threshold(aru_oracle.to_uint8(prob), 0.5))
+    polygons = {f"SeparatorRegion_{o}": [[rescale_points(r, 1 / sc) for r in poly] for poly in polygonize.shapes(post[o])]
+                for o in ("horizontal", "vertical")}
+    writer = SeparatorRegionToPageWriter(str(tmp_path / "none.xml"), str(data / "q0.png"), Hp, 1.0, polygons)
+    writer.merge_regions()
+    want = [(r.get_orientation(), r.points) for r in writer.page_object.get_regions()["SeparatorRegion"]]
+    monkeypatch.setenv("ASEP_COMPUTE_DTYPE", "bf16")
+    assert cli.main(["--path_to_image_list", str(lst), "--path_to_pb", str(pb), "--mode", "separator", "--fixed_height", str(Hp),
+                     "--threshold", "0.5", "--num_processes", "1"]) == 0
+    got = [(r.get_orientation(), r.points) for r in Page(str(data / "page" / "q0.xml.xml")).get_regions()["SeparatorRegion"]]
+    report = {}
+    for o in ("horizontal", "vertical"):
+        a, b = [p for k, p in want if k == o], [p for k, p in got if k == o]
+        ra, rb = _raster(a, Hp, Wp), _raster(b, Hp, Wp)
+        iou = float((ra & rb).sum()) / max(1, int((ra | rb).sum()))
+        report[o] = (len(a), len(b), round(iou, 5), int(ra.sum()))
+    print("\nbf16 separator CLI vs oracle regions (count oracle, count bf16, IoU, oracle pixels):", report)
+    assert sum(v[0] for v in report.values()) >= 20, "the page must hold a meaningful number of separator regions"
+    for o, (na, nb, iou, px) in report.items():
+        assert na == nb and iou >= 0.99, (o, na, nb, iou)
+
+
 def test_pages_in_flight_give_the_masks_of_the_page_by_page_form(tmp_path, monkeypatch):
     """SeparatorNetPostProcessor.enqueue_page / collect_page (the owner runs one page behind the GPU): three pages queued
     before the first is collected give the segments of the synchronous separator_masks; with a segment capacity of 4 every

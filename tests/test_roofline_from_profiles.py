@@ -15,7 +15,7 @@ import roofline_from_profiles as rfp  # noqa: E402
 
 # every round-3 measurement point that carries the full set of summaries (profiles/r3*: fp32 headline builds and their bf16 twins)
 TAGS = sorted(t for t in os.listdir(os.path.join(ROOT, "profiles"))
-              if t.startswith("r3") and all(os.path.exists(os.path.join(ROOT, "profiles", t, f))
+              if t.startswith(("r3", "r4")) and all(os.path.exists(os.path.join(ROOT, "profiles", t, f))
                                             for f in ("kernel_stats.csv", "pmc_summary.json", "bench_under_trace.json", "bench.json")))
 
 
@@ -39,7 +39,7 @@ def test_roofline_block_is_reproducible_from_the_committed_summaries(tag):
     line, rec, table = rfp.recompute(tagdir)
     pairs, dev, ok = rfp.compare(line, rec, 0.03)
     assert ok, {k: (pairs[k], rec[k], dev[k]) for k in pairs}
-    r = line["roofline"]
+    r = rfp.block(line)
     # the compared set covers the launch time, the achieved rate and fraction, the PMC traffic and the whole-page figures
     assert {"avg_launch_us", "achieved", "frac", "traffic", "hbm_frac", "whole_page_executed_frac", "whole_page_traffic_gb"} <= set(pairs)
     assert r["timing"] == "in situ" and r["kernel"] in {t["kernel"] for t in table}
@@ -60,10 +60,17 @@ def test_untraced_line_of_the_same_build_uses_the_same_traffic_table(tag):
     """profiles/<tag>/bench.json is the default (un-traced) run: its traffic fields come from the table of the traced build and its
     fractions are arithmetic on its own timings (launch time x traffic -> TB/s -> fraction of 8 TB/s)."""
     line = rfp.load_line(os.path.join(ROOT, "profiles", tag, "bench.json"))
-    r = line["roofline"]
+    r = rfp.block(line)
     assert r["traffic"] and r["frac_in_situ"] and r["frac_isolated"] and r["whole_page_executed_frac"]
     tb_s = r["traffic"] / (r["avg_launch_us"] * 1e-6) / 1e12
-    if r["bound"] == "hbm":
+    if r.get("layout", 3) >= 4:
+        # round 4: `achieved` of a bf16 line = ALGORITHMIC bytes per launch / launch time; the counter bytes give hbm_frac in both dtypes
+        assert len(line["roofline"]) <= 20 and abs(tb_s / 8.0 / r["hbm_frac"] - 1) < 2e-3
+        assert abs(r["achieved"] / r["peak"] / r["frac"] - 1) < 2e-3
+        if r["bound"] == "hbm":
+            assert abs(r["algorithmic_bytes"] / (r["avg_launch_us"] * 1e-6) / 1e9 / r["achieved"] - 1) < 2e-3 and r["mfma_peak"] == 2500.0
+            assert r["traffic"] >= 0.98 * r["algorithmic_bytes"]          # the counters cannot see less than what must move
+    elif r["bound"] == "hbm":
         assert abs(tb_s * 1e3 / r["achieved"] - 1) < 2e-3 and abs(r["achieved"] / r["peak"] / r["frac"] - 1) < 2e-3
         assert r["mfma"]["peak"] == 2500.0
     else:
