@@ -57,6 +57,22 @@ struct asep_gnn {
     int att_xd = 0;                                  // interaction width per head
     float* d_u_cat = nullptr;                        // concatenated node features of the last visual forward (own buffer)
     size_t u_cat_cap = 0;
+    // Page lanes of the batch entry point: the graph part of a page is a chain of ~16 launches of at most N workgroups each
+    // (N = 200: less than one workgroup per CU), so the pages of a batch are dealt over a few streams, each with its own arena,
+    // that fork behind the grouped backbone forward and join the caller's stream at the end (ASEP_GNN_LANES, default 4; 1 =
+    // everything on the caller's stream as in round 3).
+    struct PageLane {
+        hipStream_t s = nullptr;
+        hipEvent_t done = nullptr;
+        BufferPool pool;
+        ~PageLane() {
+            if (done) (void)hipEventDestroy(done);
+            if (s) (void)hipStreamDestroy(s);
+        }
+    };
+    std::vector<std::unique_ptr<PageLane>> page_lanes;
+    hipEvent_t ev_fork = nullptr;
+    int n_page_lanes = 4;
     void free_visual() {
         for (void* p : vis_owned)
             if (p) (void)hipFree(p);
@@ -66,6 +82,7 @@ struct asep_gnn {
     }
     ~asep_gnn() {
         free_visual();
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (d_u_cat) (void)hipFree(d_u_cat);
         for (void* p : owned)
             if (p) (void)hipFree(p);
@@ -170,18 +187,18 @@ struct EdgeBufs {
 };
 
 // misc.py:7-151 on the device; fills the CSR-by-target used by the message kernel
-int correct_edges_dev(asep_gnn* g, int N, int E, const int32_t* d_edges, EdgeBufs& eb, hipStream_t s) {
+int correct_edges_dev(asep_gnn* g, BufferPool& pool, int N, int E, const int32_t* d_edges, EdgeBufs& eb, hipStream_t s) {
     const int und = g->cfg.undirected_graph ? 1 : 0;
     const size_t maxE = (size_t)(und ? 2 : 1) * std::max(E, 1);
-    eb.table = (int*)g->pool.get((size_t)N * N * sizeof(int));
-    eb.rowcnt = (int*)g->pool.get((size_t)N * sizeof(int));
-    eb.colcnt = (int*)g->pool.get((size_t)N * sizeof(int));
-    eb.rowptr = (int*)g->pool.get((size_t)(N + 1) * sizeof(int));
-    eb.colptr = (int*)g->pool.get((size_t)(N + 1) * sizeof(int));
-    eb.sorted = (int32_t*)g->pool.get(maxE * 2 * sizeof(int32_t));
-    eb.sfirst = (int*)g->pool.get(maxE * sizeof(int));
-    eb.tsrc = (int*)g->pool.get(maxE * sizeof(int));
-    eb.tfirst = (int*)g->pool.get(maxE * sizeof(int));
+    eb.table = (int*)pool.get((size_t)N * N * sizeof(int));
+    eb.rowcnt = (int*)pool.get((size_t)N * sizeof(int));
+    eb.colcnt = (int*)pool.get((size_t)N * sizeof(int));
+    eb.rowptr = (int*)pool.get((size_t)(N + 1) * sizeof(int));
+    eb.colptr = (int*)pool.get((size_t)(N + 1) * sizeof(int));
+    eb.sorted = (int32_t*)pool.get(maxE * 2 * sizeof(int32_t));
+    eb.sfirst = (int*)pool.get(maxE * sizeof(int));
+    eb.tsrc = (int*)pool.get(maxE * sizeof(int));
+    eb.tfirst = (int*)pool.get(maxE * sizeof(int));
     ASEP_HIP_CHECK(hipMemsetAsync(eb.table, 0x7f, (size_t)N * N * sizeof(int), s));
     if (E > 0) {
         const int total = und ? 2 * E : E;
@@ -197,27 +214,27 @@ int correct_edges_dev(asep_gnn* g, int N, int E, const int32_t* d_edges, EdgeBuf
     return ASEP_OK;
 }
 
-int forward_impl(asep_gnn* g, int N, int E, const int32_t* d_edges, const float* d_u, const float* d_ef, int R,
+int forward_impl(asep_gnn* g, BufferPool& pool, int N, int E, const int32_t* d_edges, const float* d_u, const float* d_ef, int R,
                  const int32_t* d_rel, float* d_out, hipStream_t s) {
     const asep_gnn_cfg& c = g->cfg;
     if (N < 1 || E < 0 || R < 0) { set_error("asep_gnn_forward: bad sizes N=%d E=%d R=%d", N, E, R); return ASEP_ERR_ARG; }
     if ((size_t)N * N > (size_t)1 << 30) { set_error("asep_gnn_forward: N=%d too large for the dense edge table", N); return ASEP_ERR_UNSUPPORTED; }
     g->stream = s;
     g->N = N;
-    g->pool.begin();
+    pool.begin();
     EdgeBufs eb{};
-    int rc = correct_edges_dev(g, N, E, d_edges, eb, s);
+    int rc = correct_edges_dev(g, pool, N, E, d_edges, eb, s);
     if (rc) return rc;
     const int H = g->H, I = g->I;
     const size_t nh = (size_t)N * H;
-    float* h[2] = {(float*)g->pool.get(nh * 4), (float*)g->pool.get(nh * 4)};
-    float* cs[2] = {(float*)g->pool.get(nh * 4), (float*)g->pool.get(nh * 4)};
-    float* x = (float*)g->pool.get((size_t)N * I * 4);
-    float* Pt = (float*)g->pool.get((size_t)N * c.cls_hidden1 * 4);
-    float* Qt = (float*)g->pool.get((size_t)N * c.cls_hidden1 * 4);
+    float* h[2] = {(float*)pool.get(nh * 4), (float*)pool.get(nh * 4)};
+    float* cs[2] = {(float*)pool.get(nh * 4), (float*)pool.get(nh * 4)};
+    float* x = (float*)pool.get((size_t)N * I * 4);
+    float* Pt = (float*)pool.get((size_t)N * c.cls_hidden1 * 4);
+    float* Qt = (float*)pool.get((size_t)N * c.cls_hidden1 * 4);
     const float* d_fed = d_u;                                // node features as fed (output_type add / concat read these)
     if (g->Wc) {                                             // compress_node_feature_dim: the fed features -> tanh(Wc x + bc)
-        float* uc = (float*)g->pool.get((size_t)N * g->U * 4);
+        float* uc = (float*)pool.get((size_t)N * g->U * 4);
         hipLaunchKernelGGL(gnn_compress_kernel, dim3(cdiv(N * g->U, 256)), dim3(256), 0, s, d_u, N, g->Uin, g->Wc, g->bc, g->U, uc);
         d_u = uc;
     }
@@ -227,11 +244,11 @@ int forward_impl(asep_gnn* g, int N, int E, const int32_t* d_edges, const float*
     float *att_M = nullptr, *att_A = nullptr, *att_S = nullptr;
     const size_t att_maxE = (size_t)(c.undirected_graph ? 2 : 1) * std::max(E, 1);
     if (c.attention_heads > 0) {
-        att_eidx = (int*)g->pool.get(att_maxE * sizeof(int));
-        att_M = (float*)g->pool.get(att_maxE * c.attention_heads * g->att_xd * sizeof(float));
-        att_A = (float*)g->pool.get(att_maxE * c.attention_heads * sizeof(float));
-        att_S = (float*)g->pool.get(att_maxE * c.attention_heads * sizeof(float));
-        att_widx = (int*)g->pool.get(att_maxE * sizeof(int));
+        att_eidx = (int*)pool.get(att_maxE * sizeof(int));
+        att_M = (float*)pool.get(att_maxE * c.attention_heads * g->att_xd * sizeof(float));
+        att_A = (float*)pool.get(att_maxE * c.attention_heads * sizeof(float));
+        att_S = (float*)pool.get(att_maxE * c.attention_heads * sizeof(float));
+        att_widx = (int*)pool.get(att_maxE * sizeof(int));
         hipLaunchKernelGGL(edge_rank_kernel, dim3(N), dim3(64), 0, s, eb.colptr, eb.tsrc, eb.rowptr, eb.sorted, N, att_eidx);
         const int chunk_nodes = std::max(1, 100000 / N);      // message_fn_chunk.py:77-78
         hipLaunchKernelGGL(edge_chunk_rank_kernel, dim3(cdiv(N, chunk_nodes)), dim3(256), 0, s, eb.sorted, eb.rowptr, eb.colptr, N, chunk_nodes,
@@ -240,7 +257,7 @@ int forward_impl(asep_gnn* g, int N, int E, const int32_t* d_edges, const float*
     float* upad = nullptr;
     const int mode = g->use_step ? g->mode : STEP_GENERIC;
     if (mode == STEP_BIG) {
-        upad = (float*)g->pool.get((size_t)N * g->Upad * 4);
+        upad = (float*)pool.get((size_t)N * g->Upad * 4);
         hipLaunchKernelGGL(gnn_pad_rows_kernel, dim3(cdiv(N * g->Upad, 256)), dim3(256), 0, s, d_u, N, g->U, upad, g->Upad);
     }
     ASEP_HIP_CHECK(hipMemsetAsync(h[0], 0, nh * 4, s));
@@ -304,7 +321,7 @@ int forward_impl(asep_gnn* g, int N, int E, const int32_t* d_edges, const float*
     int Hc = H;
     if (c.output_type != 0) {                                // graph_gnn.py:158-166
         Hc = c.output_type == 2 ? H + g->Uin : H;
-        float* y = (float*)g->pool.get((size_t)N * Hc * 4);
+        float* y = (float*)pool.get((size_t)N * Hc * 4);
         hipLaunchKernelGGL(gnn_output_type_kernel, dim3(cdiv(N * Hc, 256)), dim3(256), 0, s, h[cur], d_fed, N, H, g->Uin, g->Wout,
                            c.output_type, y);
         hcls = y;
@@ -426,6 +443,11 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
                   cfg->attention_hidden, cfg->attention_merge);
         return nullptr;
     }
+    if (heads > 0 && ((size_t)g->K + std::max(Hm, cfg->attention_hidden)) * sizeof(float) > 60 * 1024) {
+        // (what gnn_msg_att_kernel is launched with: refuse here instead of failing at the first forward)
+        set_error("asep_gnn_load: attention MLP hidden width %d needs more LDS than a workgroup may use", cfg->attention_hidden);
+        return nullptr;
+    }
     if (heads > 0) {
         // message_fn_chunk.py:69-72: x_dim = interaction_dim // heads for 'concat' (the LSTM then reads heads * x_dim columns)
         if (cfg->attention_merge == 0 && I % heads != 0) {
@@ -476,6 +498,7 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
     for (auto& kv : blob)
         if (kv.first.rfind("visual_node_feature_compression_fm_", 0) == 0) g->vis_blob[kv.first] = kv.second;
     if (const char* ev = getenv("ASEP_GNN_STEP")) g->use_step = atoi(ev) != 0;
+    if (const char* ev = getenv("ASEP_GNN_LANES")) g->n_page_lanes = std::max(1, std::min(16, atoi(ev)));
     const bool default_widths = H == GNN_H && I == GNN_H && Hm == GNN_H && heads == 0;
     g->mode = STEP_GENERIC;
     if (default_widths && Ed <= 4) {
@@ -508,7 +531,7 @@ int asep_gnn_forward_dev(asep_gnn* g, int N, int E, const int32_t* d_edges, cons
     ASEP_GUARD_BEGIN
     if (!g || !d_node_feat || (E > 0 && !d_edges) || (R > 0 && !d_probs_out)) { set_error("asep_gnn_forward_dev: null argument"); return ASEP_ERR_ARG; }
     if (g->cfg.edge_feature_dim > 0 && E > 0 && !d_edge_feat) { set_error("asep_gnn_forward_dev: edge features required"); return ASEP_ERR_ARG; }
-    return forward_impl(g, N, E, d_edges, d_node_feat, d_edge_feat, R, d_relations, d_probs_out, (hipStream_t)stream);
+    return forward_impl(g, g->pool, N, E, d_edges, d_node_feat, d_edge_feat, R, d_relations, d_probs_out, (hipStream_t)stream);
     ASEP_GUARD_END
 }
 
@@ -557,7 +580,7 @@ int asep_gnn_correct_edges(asep_gnn* g, int N, int E, const int32_t* edges, cons
     if (feats && E > 0) ASEP_HIP_CHECK(hipMemcpy(d_f, edge_feat, (size_t)E * Ed * sizeof(float), hipMemcpyHostToDevice));
     g->pool.begin();
     EdgeBufs eb{};
-    int rc = correct_edges_dev(g, N, E, d_e, eb, nullptr);
+    int rc = correct_edges_dev(g, g->pool, N, E, d_e, eb, nullptr);
     if (rc) return rc;
     int ecorr = 0;
     ASEP_HIP_CHECK(hipStreamSynchronize(nullptr));
@@ -642,7 +665,7 @@ int asep_gnn_forward_visual_dev(asep_gnn* g, int N, int E, const int32_t* d_edge
     float* d_u = nullptr;
     int rc = visual_features_dev(g, N, d_node_feat, d_image, h, w, d_regions, P, d_num_points, &d_u, (hipStream_t)stream);
     if (rc) return rc;
-    return forward_impl(g, N, E, d_edges, d_u, d_edge_feat, R, d_relations, d_probs_out, (hipStream_t)stream);
+    return forward_impl(g, g->pool, N, E, d_edges, d_u, d_edge_feat, R, d_relations, d_probs_out, (hipStream_t)stream);
     ASEP_GUARD_END
 }
 
@@ -676,14 +699,36 @@ int asep_gnn_forward_visual_batch_dev(asep_gnn* g, int n_pages, const asep_gnn_p
     // kernels and the graph, queued back to back on the same stream
     rc = asep_aru_forward_batch_dev(g->backbone, n_pages, imgs.data(), h, w, outs.data(), nullptr, nullptr, 0.f, s);
     if (rc) return rc;
+    // page lanes: ROI kernels + graph of page b on lane b % L, forked behind the backbone, joined into s at the end
+    const int L = std::max(1, std::min(g->n_page_lanes, n_pages));
+    if (L > 1) {
+        while ((int)g->page_lanes.size() < L) {
+            std::unique_ptr<asep_gnn::PageLane> pl(new asep_gnn::PageLane());
+            ASEP_HIP_CHECK(hipStreamCreateWithFlags(&pl->s, hipStreamNonBlocking));
+            ASEP_HIP_CHECK(hipEventCreateWithFlags(&pl->done, hipEventDisableTiming));
+            g->page_lanes.push_back(std::move(pl));
+        }
+        if (!g->ev_fork) ASEP_HIP_CHECK(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+        ASEP_HIP_CHECK(hipEventRecord(g->ev_fork, s));
+        for (int l = 0; l < L; ++l) ASEP_HIP_CHECK(hipStreamWaitEvent(g->page_lanes[l]->s, g->ev_fork, 0));
+    }
     float* d_u = g->d_u_cat;
     for (int b = 0; b < n_pages; ++b) {
         const asep_gnn_page& q = pages[b];
-        rc = visual_rois_dev(g, q.N, q.d_node_feat, b ? "p" + std::to_string(b) + "/" : std::string(), q.d_regions, P, q.d_num_points, d_u, s);
+        hipStream_t ls = L > 1 ? g->page_lanes[b % L]->s : s;
+        BufferPool& lp = L > 1 ? g->page_lanes[b % L]->pool : g->pool;
+        rc = visual_rois_dev(g, q.N, q.d_node_feat, b ? "p" + std::to_string(b) + "/" : std::string(), q.d_regions, P, q.d_num_points, d_u, ls);
         if (rc) return rc;
-        rc = forward_impl(g, q.N, q.E, q.d_edges, d_u, q.d_edge_feat, q.R, q.d_relations, q.d_probs_out, s);
+        rc = forward_impl(g, lp, q.N, q.E, q.d_edges, d_u, q.d_edge_feat, q.R, q.d_relations, q.d_probs_out, ls);
         if (rc) return rc;
         d_u += (size_t)q.N * g->Uin;
+    }
+    if (L > 1) {
+        for (int l = 0; l < L; ++l) {
+            ASEP_HIP_CHECK(hipEventRecord(g->page_lanes[l]->done, g->page_lanes[l]->s));
+            ASEP_HIP_CHECK(hipStreamWaitEvent(s, g->page_lanes[l]->done, 0));
+        }
+        g->stream = s;                                       // everything the lanes queued is ordered in front of what follows on s
     }
     return ASEP_OK;
     ASEP_GUARD_END

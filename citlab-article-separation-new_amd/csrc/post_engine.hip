@@ -4,6 +4,8 @@
 #include <cmath>
 #include <vector>
 
+#include <mutex>
+
 #include "asep_common.h"
 #include "post_kernels.h"
 
@@ -598,6 +600,7 @@ int asep_swt_line_features_dev(asep_post* p, const uint8_t* d_swt, int H, int W,
     std::vector<SwtLineBox> hb(n_lines);
     std::vector<unsigned long long> ofs(n_lines);
     unsigned long long total = 0;
+    long long max_crop = 0;
     for (int i = 0; i < n_lines; ++i) {
         // numpy slicing semantics of swt[y0:y1, x0:x1]: bounds are clipped to the image
         SwtLineBox b{boxes[4 * i + 0], boxes[4 * i + 1], boxes[4 * i + 2], boxes[4 * i + 3]};
@@ -609,6 +612,7 @@ int asep_swt_line_features_dev(asep_post* p, const uint8_t* d_swt, int H, int W,
         if (cw > 0 && chh > 0) {
             if (cw * chh > 0x3fffffffll) { set_error("asep_swt_line_features_dev: line %d crop too large", i); return ASEP_ERR_UNSUPPORTED; }
             total += 2ull * (unsigned long long)(cw * chh);
+            max_crop = std::max(max_crop, cw * chh);
         }
     }
     p->pool.begin();
@@ -621,10 +625,23 @@ int asep_swt_line_features_dev(asep_post* p, const uint8_t* d_swt, int H, int W,
     ASEP_HIP_CHECK(hipMemcpyAsync(d_boxes, hb.data(), (size_t)n_lines * sizeof(SwtLineBox), hipMemcpyHostToDevice, st));
     ASEP_HIP_CHECK(hipMemcpyAsync(d_ofs, ofs.data(), (size_t)n_lines * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
     ASEP_HIP_CHECK(hipStreamSynchronize(st));          // hb / ofs are stack-owned: finish the copies before they die
-    static const bool lds_ok = hipFuncSetAttribute((const void*)swt_line_features_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   SWTL_LDS_PIXELS * (int)sizeof(int32_t)) == hipSuccess;
-    if (!lds_ok) { set_error("asep_swt_line_features_dev: cannot reserve the label tile in LDS"); return ASEP_ERR_HIP; }
-    swt_line_features_kernel<<<n_lines, 256, SWTL_LDS_PIXELS * sizeof(int32_t), st>>>(d_swt, W, d_boxes, d_ofs, d_scratch, d_sw, d_h, d_f);
+    // label tile in LDS: sized for the largest crop of THIS call that fits (a page of small lines keeps more workgroups per CU
+    // than one that reserves 64 KB each); crops beyond SWTL_LDS_PIXELS label in the global scratch slice.  The attribute is a
+    // property of the function ON A DEVICE: one flag per device id, not one per process.
+    const size_t lds_bytes = (size_t)std::min<long long>(std::max<long long>(max_crop, 1), SWTL_LDS_PIXELS) * sizeof(int32_t);
+    {
+        static std::mutex mu;
+        static std::map<int, bool> ok_on;
+        int dev = 0;
+        ASEP_HIP_CHECK(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = ok_on.find(dev);
+        if (it == ok_on.end())
+            it = ok_on.emplace(dev, hipFuncSetAttribute((const void*)swt_line_features_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        SWTL_LDS_PIXELS * (int)sizeof(int32_t)) == hipSuccess).first;
+        if (!it->second) { set_error("asep_swt_line_features_dev: cannot reserve the label tile in LDS on device %d", dev); return ASEP_ERR_HIP; }
+    }
+    swt_line_features_kernel<<<n_lines, 256, lds_bytes, st>>>(d_swt, W, d_boxes, d_ofs, d_scratch, d_sw, d_h, d_f);
     ASEP_HIP_CHECK(hipGetLastError());
     ASEP_HIP_CHECK(hipMemcpyAsync(out_stroke_width, d_sw, (size_t)n_lines * sizeof(float), hipMemcpyDeviceToHost, st));
     ASEP_HIP_CHECK(hipMemcpyAsync(out_height, d_h, (size_t)n_lines * sizeof(int32_t), hipMemcpyDeviceToHost, st));

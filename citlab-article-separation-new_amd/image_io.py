@@ -96,6 +96,8 @@ def _inflate(stream, nbytes):
 _PNG_SIGNATURE = b"\x89PNG\r\n\x1a\n"
 # ancillary chunks that change what cv2.imread / Pillow hand out (transparency, orientation): such files go through Pillow
 _PNG_NOT_PLAIN = (b"tRNS", b"eXIf", b"PLTE", b"acTL")
+# text chunks whose keyword starts like this carry an EXIF / XMP profile (ImageMagick's "Raw profile type exif", Adobe's XMP packet)
+_PNG_TEXT_NOT_PLAIN = (b"Raw profile type", b"XML:com.adobe.xmp")
 
 
 def _load_png_plain(path):
@@ -114,31 +116,43 @@ def _load_png_plain(path):
     width, height, depth, colour, compression, filt, interlace = struct.unpack(">IIBBBBB", raw[16:29])
     if depth != 8 or colour not in (0, 2) or compression or filt or interlace or not width or not height:
         return None
+    # a header may announce any size: Pillow's decompression-bomb limit applies here too (beyond it Pillow itself reports the file),
+    # and a deflate stream expands at most ~1032x, so a size the file cannot possibly hold is a damaged or crafted header
+    bpp = 1 if colour == 0 else 3
+    stride = width * bpp
+    limit = Image.MAX_IMAGE_PIXELS
+    if (limit is not None and width * height > limit) or height * (stride + 1) > 1040 * len(raw):
+        return None
     pos, parts = 8, []
     while pos + 12 <= len(raw):
         length, kind = struct.unpack(">I4s", raw[pos:pos + 8])
         if kind in _PNG_NOT_PLAIN:
             return None
+        if kind in (b"tEXt", b"zTXt", b"iTXt") and raw[pos + 8:pos + 8 + length].startswith(_PNG_TEXT_NOT_PLAIN):
+            return None                                     # orientation / metadata profiles in text chunks: Pillow applies them
         if kind == b"IDAT":
+            if zlib.crc32(raw[pos + 4:pos + 8 + length]) & 0xffffffff != struct.unpack(">I", raw[pos + 8 + length:pos + 12 + length] or b"\0\0\0\0")[0]:
+                return None                                 # damaged chunk: Pillow reports it
             parts.append(raw[pos + 8:pos + 8 + length])
         elif kind == b"IEND":
             break
         pos += 12 + length
-    bpp = 1 if colour == 0 else 3
-    stride = width * bpp
     if not parts:
         return None
-    data = _inflate(parts[0] if len(parts) == 1 else b"".join(parts), height * (stride + 1))
-    if data is None:
+    try:
+        data = _inflate(parts[0] if len(parts) == 1 else b"".join(parts), height * (stride + 1))
+        if data is None:
+            return None
+        out = np.empty((height, width) if bpp == 1 else (height, width, 3), dtype=np.uint8)
+        if bpp == 1:
+            rc = lib.asep_png_unfilter(data.ctypes.data, height, stride, 1, out.ctypes.data)
+        else:
+            rgb = np.empty((height, width, 3), dtype=np.uint8)
+            rc = lib.asep_png_unfilter(data.ctypes.data, height, stride, 3, rgb.ctypes.data)
+            if rc == 0:
+                lib.asep_rgb_to_bgr(rgb.ctypes.data, height * width, out.ctypes.data)
+    except MemoryError:                                     # let Pillow report what it makes of the file
         return None
-    out = np.empty((height, width) if bpp == 1 else (height, width, 3), dtype=np.uint8)
-    if bpp == 1:
-        rc = lib.asep_png_unfilter(data.ctypes.data, height, stride, 1, out.ctypes.data)
-    else:
-        rgb = np.empty((height, width, 3), dtype=np.uint8)
-        rc = lib.asep_png_unfilter(data.ctypes.data, height, stride, 3, rgb.ctypes.data)
-        if rc == 0:
-            lib.asep_rgb_to_bgr(rgb.ctypes.data, height * width, out.ctypes.data)
     return out if rc == 0 else None
 
 

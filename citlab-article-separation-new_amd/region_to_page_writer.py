@@ -89,12 +89,21 @@ class SeparatorRegionToPageWriter(RegionToPageWriter):
                 if len(line.surr_p) < 3:
                     out.append(line)
                     continue
-                parts = poly_clip.difference_parts(line.surr_p, rects)
-                area0 = abs(poly_clip.ring_area2(poly_clip._open(line.surr_p))) / 2.0
+                # an outline that crosses itself is repaired like ``Polygon(points).buffer(0)`` (:170): cut at its crossings, the loops
+                # wound like the ring are kept and clipped one by one (a MultiPolygon's parts)
+                loops = poly_clip.repair_ring(line.surr_p)
+                try:
+                    parts = [q for lp in loops for q in poly_clip.difference_parts(lp, rects)]
+                except poly_clip.ClipError as e:             # never write a ring that does not balance: the line stays uncut
+                    logging.warning("text line %s left uncut (%s)", line.id, e)
+                    out.append(line)
+                    continue
+                parts.sort(key=lambda q: (min(x for x, _ in q), min(y for _, y in q)))
+                area0 = sum(abs(poly_clip.ring_area2(lp)) for lp in loops) / 2.0
                 area1 = sum(abs(poly_clip.ring_area2(p)) for p in parts) / 2.0
                 if not parts:                                # swallowed by the separator
                     continue
-                if area1 >= area0 * (1.0 - 1e-12):           # no area lost: the separator does not run through the line
+                if area1 >= area0 * (1.0 - 1e-12) and len(loops) == 1:   # no area lost: the separator does not run through the line
                     out.append(line)
                     continue
                 # a word goes to the part it overlaps most: exact for convex words (quadrilaterals), bounding box otherwise

@@ -94,16 +94,30 @@ def unit_scale_page():
     w = init_aru_weights(cfg, 4321, bias_jitter=0.05, logit_scale=1.0)
     page = synth.synth_page(1, W, H).astype(np.float32) / 255.0
     ref, inter = aru_oracle.forward_torch(page, w, cfg, return_intermediates=True)
+    # Random weights with unit logit scale saturate (p > 0.999 on 99.9 % of the page): every threshold mask would be trivially
+    # equal.  The class bias is shifted by the median logit margin, so that p = 0.5 splits the page in two halves -- the most
+    # sensitive mask a threshold can produce.  Only the last layer's bias changes: the oracle's logits move by the same constant and
+    # every other end point is untouched, so no second oracle run is needed.
+    margin = float(np.median(inter["logits"][:, :, 0] - inter["logits"][:, :, 1]))
+    w = dict(w)
+    b = w["aru_net/logit/class/biases"].copy()
+    b[0] -= np.float32(margin)
+    w["aru_net/logit/class/biases"] = b
+    inter["logits"] = inter["logits"] - np.array([np.float32(margin), 0], dtype=np.float32)
+    z = inter["logits"] - inter["logits"].max(axis=2, keepdims=True)
+    e = np.exp(z.astype(np.float32))
+    ref = (e / e.sum(axis=2, keepdims=True)).astype(np.float32)
+    assert 0.45 < float((ref[:, :, 0] > 0.5).mean()) < 0.55
     return page, w, cfg, ref, inter
 
 
 # what the bf16 path holds on a whole 3000 x 4500 frame with unit logit scale (measured values in DESIGN section 2; gates ~1.5x above)
-BF16_ENDPOINT_GATE = 4e-2        # max|d| / max|ref| per end point (fp32: 2e-5)
-BF16_ENDPOINT_RMS_GATE = 5e-3    # rms(d) / max|ref| per end point
-BF16_LOGIT_GATE = 4e-2           # max|d logits| / max|logits|
-BF16_PROB_GATE = 6e-2            # max|dp| with a saturating softmax (the stated 2e-2 is the gate of the logit_scale 0.05 weights)
-BF16_U8_RATE_GATE = 0.30         # share of uint8 values that differ from the oracle's (truncation: any |dp| > 1/255 can flip one)
-BF16_MASK_RATE_GATE = 2e-3       # share of threshold-mask pixels (thr 0.5) that differ
+BF16_ENDPOINT_GATE = 3e-2        # max|d| / max|ref| per end point (measured 8e-3 .. 2.1e-2; fp32: 2e-5)
+BF16_ENDPOINT_RMS_GATE = 5e-3    # rms(d) / max|ref| per end point (measured 1e-3 .. 3.4e-3)
+BF16_LOGIT_GATE = 2e-2           # max|d logits| / max|logits| (measured 1.1e-2 at max|logit| 31)
+BF16_PROB_GATE = 0.12            # max|dp|: a logit error of 0.34 at p = 0.5 is dp = 0.085 (the stated 2e-2 is the gate of logit_scale 0.05 weights)
+BF16_U8_RATE_GATE = 0.05         # share of uint8 values that differ from the oracle's (truncation: any |dp| > 1/255 can flip one)
+BF16_MASK_RATE_GATE = 1e-2       # share of threshold-mask pixels that differ at p = 0.5 on a mask that splits the page in halves
 
 
 def test_whole_page_bf16_end_points_logits_and_masks_with_unit_logit_scale(unit_scale_page):

@@ -146,3 +146,48 @@ def test_damaged_header_or_pixel_data_is_left_to_pillow(tmp_path):
     bad[i] ^= 0x10
     (tmp_path / "pix.png").write_bytes(bytes(bad))
     assert image_io._load_png_plain(str(tmp_path / "pix.png")) is None
+
+
+@pytest.mark.skipif(not image_io._host_lib(), reason="libasep_host.so not built")
+def test_crafted_sizes_and_text_profiles_are_left_to_pillow(tmp_path, monkeypatch):
+    """the fast path trusted IHDR's width x height and allocated before anything was inflated (a tiny crafted file -> a
+    MemoryError or an OOM-killed decode worker instead of Pillow's report), and it ignored orientation profiles carried in text
+    chunks, so the pixels depended on whether libasep_host.so was built."""
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xffffffff)
+    arr = np.random.default_rng(3).integers(0, 256, (20, 30), dtype=np.uint8)
+    rows = _filter_rows(arr, 1, [0] * 20)
+    good = _png(30, 20, 0, rows)
+    (tmp_path / "ok.png").write_bytes(good)
+    assert np.array_equal(image_io._load_png_plain(str(tmp_path / "ok.png")), arr)
+    # (a) a header that announces 60000 x 60000 pixels in a file of a few hundred bytes (valid CRC): refused before any allocation
+    huge = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 60000, 60000, 8, 0, 0, 0, 0)) + good[33:]
+    (tmp_path / "huge.png").write_bytes(huge)
+    called = []
+    monkeypatch.setattr(image_io, "_inflate", lambda *a: called.append(a) or None)
+    assert image_io._load_png_plain(str(tmp_path / "huge.png")) is None and not called
+    monkeypatch.undo()
+    # (b) beyond Pillow's MAX_IMAGE_PIXELS the file is Pillow's to report
+    monkeypatch.setattr(Image, "MAX_IMAGE_PIXELS", 500)
+    assert image_io._load_png_plain(str(tmp_path / "ok.png")) is None
+    monkeypatch.undo()
+    # (c) an allocation failure falls back to Pillow instead of killing the worker
+    def boom(*a):
+        raise MemoryError
+    monkeypatch.setattr(image_io, "_inflate", boom)
+    assert image_io._load_png_plain(str(tmp_path / "ok.png")) is None
+    monkeypatch.undo()
+    # (d) EXIF / XMP profiles in text chunks (ImageMagick's "Raw profile type exif", Adobe's XMP packet): not plain
+    for kind, payload in ((b"tEXt", b"Raw profile type exif\0\nexif\n  10\n0000\n"), (b"zTXt", b"Raw profile type APP1\0\0" + zlib.compress(b"x")),
+                          (b"iTXt", b"XML:com.adobe.xmp\0\0\0\0\0<x:xmpmeta/>")):
+        (tmp_path / "t.png").write_bytes(good[:33] + chunk(kind, payload) + good[33:])
+        assert image_io._load_png_plain(str(tmp_path / "t.png")) is None, kind
+    (tmp_path / "c.png").write_bytes(good[:33] + chunk(b"tEXt", b"Comment\0scanned 1887") + good[33:])      # a harmless comment stays plain
+    assert np.array_equal(image_io._load_png_plain(str(tmp_path / "c.png")), arr)
+    # (e) a damaged IDAT chunk CRC (the zlib stream itself intact) is reported by Pillow, not decoded silently
+    bad = bytearray(good)
+    i = bytes(good).index(b"IDAT")
+    n = struct.unpack(">I", good[i - 4:i])[0]
+    bad[i + 4 + n] ^= 0xff                                   # first byte of the chunk's CRC
+    (tmp_path / "crc.png").write_bytes(bytes(bad))
+    assert image_io._load_png_plain(str(tmp_path / "crc.png")) is None

@@ -261,6 +261,11 @@ def test_compute_dtype_switch_for_models_loaded_from_files(tmp_path, monkeypatch
         helper.load_graph(pb)
 
 
+# what the bf16 command line holds against the fp32 oracle's regions on a mask cut through the MIDDLE of the net's output (no margin)
+BF16_REGION_IOU = 0.97
+BF16_REGION_COUNT_TOL = 0.05
+
+
 def _raster(polys, H, W):
     """union of simple polygons (lists of (x, y) vertices on the pixel grid) as a boolean image; both sides of a comparison go
     through this same rasteriser, so its edge convention cancels"""
@@ -290,14 +295,21 @@ def test_bf16_separator_cli_polygons_against_the_oracle(tmp_path, monkeypatch):
     cfg = AruConfig()
     w = init_aru_weights(cfg, 4321, bias_jitter=0.05, logit_scale=1.0)
     pb = tmp_path / "separator_aru_unit.pb"
-    pb.write_bytes(tf_aru_graph.build_aru_pb(w, cfg))
     data = tmp_path / "data"
     (data / "page").mkdir(parents=True)
     Image.fromarray(synth.synth_page(5, W=Wp, H=Hp)).save(data / "q0.png")
     lst = tmp_path / "q.lst"
     lst.write_text(str(data / "q0.png") + "\n")
     _, grey, sc = co.scale_and_gray(image_io.load_image_bgr(str(data / "q0.png")), Hp, 1.0)
+    # random unit-scale weights saturate: shift the separator class's bias by the median logit margin of this page, so that the
+    # threshold 0.5 cuts through the middle of the net's output (the most sensitive mask; a trained net has far more margin)
+    _, inter = aru_oracle.forward_torch(grey.astype(np.float32), w, cfg, return_intermediates=True)
+    b = w["aru_net/logit/class/biases"].copy()
+    b[0] -= np.float32(np.median(inter["logits"][:, :, 0] - inter["logits"][:, :, 1]))
+    w["aru_net/logit/class/biases"] = b
+    pb.write_bytes(tf_aru_graph.build_aru_pb(w, cfg))
     prob = aru_oracle.forward_torch(grey.astype(np.float32), w, cfg)
+    assert 0.4 < float((prob[:, :, 0] > 0.5).mean()) < 0.6
     post = co.separator_post_process(aru_oracle.apply_threshold(aru_oracle.to_uint8(prob), 0.5))
     polygons = {f"SeparatorRegion_{o}": [[rescale_points(r, 1 / sc) for r in poly] for poly in polygonize.shapes(post[o])]
                 for o in ("horizontal", "vertical")}
@@ -317,7 +329,7 @@ def test_bf16_separator_cli_polygons_against_the_oracle(tmp_path, monkeypatch):
     print("\nbf16 separator CLI vs oracle regions (count oracle, count bf16, IoU, oracle pixels):", report)
     assert sum(v[0] for v in report.values()) >= 20, "the page must hold a meaningful number of separator regions"
     for o, (na, nb, iou, px) in report.items():
-        assert na == nb and iou >= 0.99, (o, na, nb, iou)
+        assert abs(na - nb) <= max(1, round(BF16_REGION_COUNT_TOL * na)) and iou >= BF16_REGION_IOU, (o, na, nb, iou)
 
 
 def test_pages_in_flight_give_the_masks_of_the_page_by_page_form(tmp_path, monkeypatch):

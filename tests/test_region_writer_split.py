@@ -227,3 +227,106 @@ def test_general_polygon_difference_conserves_area():
         cut = sum(pc.intersection_area(poly, [(a, b), (c, b), (c, d), (a, d)]) for a, b, c, d in rects)
         assert abs(kept + cut - abs(pc.ring_area2(poly)) / 2) < 1e-6, (trial, kept, cut)
         assert all(pc.ring_area2(p) > 0 for p in parts)
+
+
+def test_vertices_exactly_on_a_cut_line():
+    """a polygon vertex ON the cut line whose two neighbours lie on the lower side gave two coincident crossings
+    that were paired with their neighbours along the line instead of with each other -- area was dropped or a corrupted ring came
+    back.  PAGE coordinates and rectangle edges are both integers, so this is the common case, not an exotic one."""
+    from citlab_article_separation_new_amd import poly_clip as pc
+    area = lambda r: abs(pc.ring_area2(r)) / 2
+    # repro 1: (-5, -2) touches x = -5 from the left
+    ring = [(-6, -1), (-5, -2), (-6, -5), (-1, -3), (4, 5), (-1, 5), (-2, 2), (-4, 0)]
+    lo, hi = pc.split_by_line(pc._open(ring), 0, -5.0)
+    assert abs(sum(map(area, lo)) + sum(map(area, hi)) - area(ring)) < 1e-9 and area(ring) == 42.5
+    assert len(lo) == 2 and len(hi) == 1                       # the touching vertex separates two lower pieces
+    # repro 2: the rectangle [-5,-2] x [-6,-5] does not touch the polygon (its corner (-5,-3) lies on x = -5): untouched, same ring
+    ring = [(-5, -3), (3, -5), (6, -5), (3, 1), (0, 6), (-5, 5), (-2, 1), (-3, 0)]
+    parts = pc.difference_parts(ring, [(-5, -6, -2, -5)])
+    assert len(parts) == 1 and abs(area(parts[0]) - area(ring)) < 1e-9 and area(ring) == 67.5
+    assert sorted(parts[0]) == sorted((float(x), float(y)) for x, y in ring)
+    # hand case: a diamond whose left and right corners lie on the two cut lines of a rectangle as wide as the diamond
+    diamond = [(0, 5), (5, 0), (10, 5), (5, 10)]
+    assert pc.difference_parts(diamond, [(0, 4, 10, 6)]) and abs(sum(map(area, pc.difference_parts(diamond, [(0, 4, 10, 6)]))) - (50 - 18)) < 1e-9
+    # an edge that runs ALONG the cut line (x = 4 between y = 2 and y = 6): nothing is lost on either side
+    poly = [(0, 0), (4, 2), (4, 6), (0, 8), (8, 8), (8, 0)]
+    lo, hi = pc.split_by_line(pc._open(poly), 0, 4.0)
+    assert abs(sum(map(area, lo)) + sum(map(area, hi)) - area(poly)) < 1e-9
+
+
+def test_general_polygon_difference_on_an_integer_grid_conserves_area():
+    """text-line-like outlines with INTEGER vertices against stacked separator rectangles with integer edges (vertices on cut lines
+    all the time): the balance area(parts) - area(holes) + area inside the rectangles == area(polygon) holds, or the function
+    refuses (ClipError, raised only for outlines that touch themselves) -- it never returns an unbalanced result."""
+    import math
+    import random
+    from citlab_article_separation_new_amd import poly_clip as pc
+    rng = random.Random(5)
+    area = lambda r: abs(pc.ring_area2(r)) / 2
+    refused = done = 0
+    for _ in range(4000):
+        R = rng.choice([6, 6, 20, 200])
+        pts = set()
+        n = rng.randint(4, 10)
+        while len(pts) < n:
+            pts.add((rng.randint(-R, R), rng.randint(-R, R)))
+        pts = list(pts)
+        cx, cy = sum(p[0] for p in pts) / n, sum(p[1] for p in pts) / n
+        ring = sorted(pts, key=lambda p: math.atan2(p[1] - cy, p[0] - cx))        # star-shaped around the centroid
+        if area(ring) == 0 or len(pc.repair_ring(ring)) != 1:
+            continue
+        rects, x, y = [], rng.randint(-R, R - 1), -R - 1
+        for _k in range(rng.randint(1, 3)):                  # a column of disjoint rectangles
+            h, w = rng.randint(1, max(1, R // 2)), rng.randint(1, 3)
+            rects.append((x, y, x + w, y + h))
+            y += h + rng.randint(0, 3)
+        try:
+            parts, holes = pc.difference_parts(ring, rects, with_holes=True)
+        except pc.ClipError:
+            refused += 1
+            continue
+        done += 1
+        taken = sum(pc.intersection_area(ring, [(a, b), (c, b), (c, d), (a, d)]) for a, b, c, d in rects)
+        assert abs(sum(map(area, parts)) - sum(map(area, holes)) + taken - area(ring)) < 1e-7 * max(1.0, area(ring))
+    assert done > 3000 and refused <= 2, (done, refused)
+
+
+def test_repair_ring_like_buffer0_hand_cases():
+    """separator_region_to_page_writer.py:164,170,189 repair outlines with ``buffer(0)``.  Two hand-derived cases:
+    (a) shapely's own documentation example -- a bow tie that TOUCHES itself at the vertex (1, 1): both triangles are kept;
+    (b) a figure 8 whose edges CROSS at (1, 1): the two lobes are wound in opposite directions, the lobe through the ring's highest
+    vertex gives the direction (GEOS Orientation.isCCW) and the other one is dropped (buffer(0)'s known area loss)."""
+    from citlab_article_separation_new_amd import poly_clip as pc
+    area = lambda r: abs(pc.ring_area2(r)) / 2
+    a = pc.repair_ring([(0, 0), (0, 2), (1, 1), (2, 2), (2, 0), (1, 1), (0, 0)])
+    assert sorted(sorted(r) for r in a) == [[(0.0, 0.0), (0.0, 2.0), (1.0, 1.0)], [(1.0, 1.0), (2.0, 0.0), (2.0, 2.0)]]
+    b = pc.repair_ring([(0, 0), (2, 2), (2, 0), (0, 2)])
+    assert len(b) == 1 and sorted(b[0]) == [(1.0, 1.0), (2.0, 0.0), (2.0, 2.0)] and area(b[0]) == 1.0
+    # a simple ring comes back unchanged; a slanted text line with a self-crossing tail keeps its body
+    quad = [(0, 0), (100, 10), (100, 40), (0, 30)]
+    assert pc.repair_ring(quad) == [[(float(x), float(y)) for x, y in quad]]
+    tail = [(0, 0), (100, 10), (100, 40), (0, 30), (-10, 10), (-20, 30), (-20, 10), (-10, 30)]      # the last four points cross: a small 8
+    body = pc.repair_ring(tail)
+    assert sum(map(area, body)) > 3000 and all(pc.ring_area2(r) * pc.ring_area2(body[0]) > 0 for r in body)
+
+
+def test_slanted_line_that_cannot_be_clipped_is_left_uncut(tmp_path, caplog):
+    """the writer never stores a ring that does not balance: a ClipError leaves the text line as it was and logs it"""
+    import logging
+    from citlab_article_separation_new_amd import poly_clip as pc
+    from citlab_article_separation_new_amd.region_to_page_writer import SeparatorRegionToPageWriter
+
+    class Line:
+        id, words, text, baseline = "l1", [], "t", None
+        surr_p = [(0, 0), (100, 10), (100, 40), (0, 30)]
+
+        def split_copy(self, *a):
+            raise AssertionError("an uncut line is not copied")
+    real = pc.difference_parts
+    pc.difference_parts = lambda *a, **k: (_ for _ in ()).throw(pc.ClipError("forced"))
+    try:
+        with caplog.at_level(logging.WARNING):
+            out = SeparatorRegionToPageWriter._split_text_lines([Line()], [[(48, -10), (52, -10), (52, 100), (48, 100)]])
+    finally:
+        pc.difference_parts = real
+    assert len(out) == 1 and out[0].surr_p == Line.surr_p and "left uncut" in caplog.text
