@@ -15,7 +15,8 @@ class AsepError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4          # ASEP_ABI_VERSION of include/asep_hip.h this table was written against
+MLP_MAX_HIDDEN = 4       # GNN_MLP_MAX (csrc/gnn_kernels.h): hidden layers of the interaction / attention / classifier MLPs
+ABI_VERSION = 5          # ASEP_ABI_VERSION of include/asep_hip.h this table was written against
 
 
 class _SizedCfg(C.Structure):
@@ -34,14 +35,16 @@ class AruCfg(_SizedCfg):
 class GnnCfg(_SizedCfg):
     _fields_ = [(n, C.c_int32) for n in (
         "struct_size", "node_feature_dim", "edge_feature_dim", "num_transition_steps", "hidden_dim", "interaction_dim",
-        "interaction_hidden", "cls_hidden1", "cls_hidden2", "num_classes", "undirected_graph", "compress_input_dim", "output_type", "attention_heads", "attention_merge", "attention_hidden")]
+        "interaction_hidden", "cls_hidden1", "cls_hidden2", "num_classes", "undirected_graph", "compress_input_dim", "output_type", "attention_heads", "attention_merge", "attention_hidden",
+        "aggregation_type", "interaction_hidden2", "interaction_hidden3", "interaction_hidden4", "attention_hidden2", "attention_hidden3",
+        "attention_hidden4", "cls_hidden3", "cls_hidden4", "lstm_use_hidden", "lstm_use_input", "visual_edge_dims")]
 
 
 class GnnPage(C.Structure):
     """asep_gnn_page (include/asep_hip.h): one page of asep_gnn_forward_visual_batch_dev, device addresses"""
     _fields_ = [("N", C.c_int32), ("E", C.c_int32), ("R", C.c_int32), ("d_edges", C.c_void_p), ("d_node_feat", C.c_void_p),
                 ("d_edge_feat", C.c_void_p), ("d_image", C.c_void_p), ("d_regions", C.c_void_p), ("d_num_points", C.c_void_p),
-                ("d_relations", C.c_void_p), ("d_probs_out", C.c_void_p)]
+                ("d_edge_regions", C.c_void_p), ("d_edge_num_points", C.c_void_p), ("d_relations", C.c_void_p), ("d_probs_out", C.c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/asep_hip.h one to one
@@ -73,9 +76,9 @@ SIGNATURES = {
     "asep_gnn_get_hidden": (C.c_int, [_P, _P, C.c_size_t]),
     "asep_gnn_flops": (C.c_double, [_P, C.c_int, C.c_int, C.c_int]),
     "asep_gnn_attach_backbone": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_char_p)]),
-    "asep_gnn_forward_visual": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P,
+    "asep_gnn_forward_visual": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P,
                                           C.c_int, _P, _P]),
-    "asep_gnn_forward_visual_dev": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P,
+    "asep_gnn_forward_visual_dev": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P,
                                               C.c_int, _P, _P, _P]),
     "asep_gnn_forward_visual_batch_dev": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "asep_gnn_step_mode": (C.c_int, [_P]),

@@ -72,6 +72,13 @@ class GnnConfig:
     num_attention_heads: int = 1
     multihead_attention_merge_type: str = "concat"        # 'concat' (x_dim = interaction_dim // heads) or 'average'
     attention_hidden: List[int] = field(default_factory=lambda: [16])   # num_hidden_units_attention_fct
+    aggregation_type: str = "sum"     # message_fn_chunk.py:16,57-62: 'sum' (tf.sparse.reduce_sum) or 'max' (tf.sparse.reduce_max)
+    # update_fn_lstm.py:13-16,43-50: which tensors the four gates read besides x
+    incorporate_hidden_features_in_update: bool = True
+    incorporate_node_input_features_in_update: bool = True
+    # graph_relation.py:141-172 assign_visual_features_to_edges: ROI features of every interaction's region, compressed like the
+    # nodes' (same layer_compressed_dim per feature map), appended to the fed edge features
+    visual_edges: bool = False
     # visual branch (GraphRelation image_input); 0 maps -> disabled
     visual_dims: List[int] = field(default_factory=list)   # layer_compressed_dim per feature map
     # feature_map_generation_params from_layer (layer_depth -1): backbone end points, e.g. scale_0_unet_up_2_conv
@@ -134,12 +141,30 @@ class GnnConfig:
         return self.compress_node_feature_dim if self.compress_node_feature_dim > 0 else self.u_in_dim
 
     @property
+    def visual_edge_dim(self) -> int:
+        return sum(self.visual_dims) if self.visual_edges else 0
+
+    @property
+    def edge_in_dim(self) -> int:
+        """width of the edge features the message function sees: fed (geometric) + compressed visual edge dims"""
+        return self.edge_feature_dim + self.visual_edge_dim
+
+    @property
+    def aggregation_code(self) -> int:
+        """asep_gnn_cfg.aggregation_type"""
+        try:
+            return {"sum": 0, "max": 1}[self.aggregation_type]
+        except KeyError:
+            raise ValueError(f"aggregation_type {self.aggregation_type!r} (message_fn_chunk.py:57-62: 'sum' or 'max')")
+
+    @property
     def message_in_dim(self) -> int:
-        return 4 * self.u_dim + self.edge_feature_dim + 4 * self.hidden_dim
+        return 4 * self.u_dim + self.edge_in_dim + 4 * self.hidden_dim
 
     @property
     def update_in_dim(self) -> int:
-        return self.message_out_dim + self.hidden_dim + self.u_dim
+        return (self.message_out_dim + (self.hidden_dim if self.incorporate_hidden_features_in_update else 0)
+                + (self.u_dim if self.incorporate_node_input_features_in_update else 0))
 
     @property
     def message_out_dim(self) -> int:

@@ -20,10 +20,17 @@ struct asep_gnn {
     asep_gnn_cfg cfg{};
     int U = 0, Ed = 0, H = 0, I = 0, Hm = 0;   // node / edge feature widths, hidden, interaction, MLP hidden
     int K = 0, V = 0;                 // message-MLP input width, LSTM input width
-    float *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr;
+    float *b1 = nullptr, *b2 = nullptr;          // biases of the default one-hidden-layer edge MLP (fused step kernels)
+    MlpW msg{};                       // the interaction MLP (no attention): [K] -> hidden ... -> [I]
+    int msg_maxh = 0;                 // widest hidden layer of the interaction / attention MLPs
     float* Wg[4] = {nullptr, nullptr, nullptr, nullptr};
     float* bg[4] = {nullptr, nullptr, nullptr, nullptr};
     float *C1 = nullptr, *cb1 = nullptr, *C2 = nullptr, *cb2 = nullptr, *C3 = nullptr, *cb3 = nullptr;
+    MlpW cls_rest{};                  // classifier layers behind the first hidden one: [cls_hidden1] -> ... -> [num_classes]
+    int cls_maxw = 0;
+    bool cls_fast = false;            // 64, 32 -> 2: gnn_pair_cls_kernel<64,32,2>
+    int Iout = 0;                     // width of x (message_fn_chunk.py:229-241): heads * x_dim for 'concat', interaction_dim otherwise
+    int Ed_fed = 0;                   // width of the edge features as FED (Ed minus the visual edge dims)
     // fused MFMA step kernels: permuted W1 / W2 fragments + quad descriptors
     float *A1 = nullptr, *A2 = nullptr;
     unsigned char* qdesc = nullptr;
@@ -54,13 +61,22 @@ struct asep_gnn {
     int vis_total = 0;
     float* Wout = nullptr;                           // output_type 1: GraphLSTM1/dense/weights [Uin, H]
     AttHeadW att_w[GNN_MAX_HEADS] = {};              // attention_heads > 0: per-head interaction + attention MLPs
+    AttHeadW* d_att_w = nullptr;                     // the same in device memory (kernel argument of gnn_msg_att_kernel)
     int att_xd = 0;                                  // interaction width per head
+    // visual EDGE features (graph_relation.py:141-172): compression layers per feature map, concatenated behind the fed edge features
+    std::vector<float*> vise_W, vise_b;
+    std::vector<int> vise_d;
+    int vise_total = 0;
+    float* d_ef_cat = nullptr;                       // [E, Ed] per page of the last visual forward (own buffer)
+    size_t ef_cat_cap = 0;
     float* d_u_cat = nullptr;                        // concatenated node features of the last visual forward (own buffer)
     size_t u_cat_cap = 0;
-    // Page lanes of the batch entry point: the graph part of a page is a chain of ~16 launches of at most N workgroups each
-    // (N = 200: less than one workgroup per CU), so the pages of a batch are dealt over a few streams, each with its own arena,
-    // that fork behind the grouped backbone forward and join the caller's stream at the end (ASEP_GNN_LANES, default 4; 1 =
-    // everything on the caller's stream as in round 3).
+    // Page lanes of the batch entry point (ASEP_GNN_LANES, default 1 = everything on the caller's stream): the graph part of a page
+    // is a chain of ~16 launches of at most N workgroups each (N = 200: less than one workgroup per CU), so the pages of a batch CAN
+    // be dealt over several streams, each with its own arena, that fork behind the grouped backbone forward and join the caller's
+    // stream at the end.  Measured in round 4 (profiles/README.md, r4b): slower -- 412.2 -> 403.1 pages/s (bf16), 121.3 -> 119.9
+    // (fp32) with 4 lanes, the same with 8: the graph chains already run beside the page net's kernels on their own stream, and
+    // four of them at once take more issue slots from those kernels than the shorter chain gives back.  Kept as a switch.
     struct PageLane {
         hipStream_t s = nullptr;
         hipEvent_t done = nullptr;
@@ -72,18 +88,20 @@ struct asep_gnn {
     };
     std::vector<std::unique_ptr<PageLane>> page_lanes;
     hipEvent_t ev_fork = nullptr;
-    int n_page_lanes = 4;
+    int n_page_lanes = 1;
     void free_visual() {
         for (void* p : vis_owned)
             if (p) (void)hipFree(p);
         vis_owned.clear(); vis_W.clear(); vis_b.clear(); vis_names.clear(); vis_C.clear(); vis_d.clear();
-        vis_total = 0;
+        vise_W.clear(); vise_b.clear(); vise_d.clear();
+        vis_total = 0; vise_total = 0;
         backbone = nullptr;
     }
     ~asep_gnn() {
         free_visual();
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (d_u_cat) (void)hipFree(d_u_cat);
+        if (d_ef_cat) (void)hipFree(d_ef_cat);
         for (void* p : owned)
             if (p) (void)hipFree(p);
     }
@@ -119,6 +137,43 @@ int upload_vec(asep_gnn* g, const std::vector<T>& v, T** d) {
     g->owned.push_back(*d);
     ASEP_HIP_CHECK(hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return ASEP_OK;
+}
+
+// An MLP of layers.py:468-490 under `scope`: fully_connected_layer_h<i> for the hidden widths, fully_connected_logit_layer_out
+int upload_mlp(asep_gnn* g, const std::map<std::string, HostTensor>& blob, const std::string& scope, int d_in,
+               const std::vector<int>& hidden, int d_out, MlpW* m, int first_layer = 0) {
+    // first_layer = 1: the first hidden layer is held elsewhere (classifier: evaluated per node); dims[0] = its width
+    if ((int)hidden.size() > GNN_MLP_MAX) { set_error("%s: %zu hidden layers, at most %d are served", scope.c_str(), hidden.size(), GNN_MLP_MAX); return ASEP_ERR_UNSUPPORTED; }
+    *m = MlpW{};
+    int cur = d_in, l = 0;
+    for (size_t i = 0; i < hidden.size(); ++i) {
+        if ((int)i >= first_layer) {
+            const std::string ly = scope + "/fully_connected_layer_h" + std::to_string(i + 1);
+            float *W = nullptr, *b = nullptr;
+            int rc = upload_named(g->owned, blob, ly + "/weights", {cur, hidden[i]}, &W);
+            if (!rc) rc = upload_named(g->owned, blob, ly + "/bias", {hidden[i]}, &b);
+            if (rc) return rc;
+            m->W[l] = W; m->b[l] = b; m->dims[l] = cur; ++l;
+        }
+        cur = hidden[i];
+    }
+    float *W = nullptr, *b = nullptr;
+    int rc = upload_named(g->owned, blob, scope + "/fully_connected_logit_layer_out/weights", {cur, d_out}, &W);
+    if (!rc) rc = upload_named(g->owned, blob, scope + "/fully_connected_logit_layer_out/bias", {d_out}, &b);
+    if (rc) return rc;
+    m->W[l] = W; m->b[l] = b; m->dims[l] = cur; ++l;
+    m->dims[l] = d_out;
+    m->nl = l;
+    return ASEP_OK;
+}
+
+std::vector<int> hidden_list(std::initializer_list<int> v) {      // the non-zero prefix of a cfg's hidden-width fields
+    std::vector<int> out;
+    for (int x : v) {
+        if (x <= 0) break;
+        out.push_back(x);
+    }
+    return out;
 }
 
 // K axis of the edge MLP permuted into quads of four consecutive features (gnn_kernels.h): fragments + descriptors
@@ -229,7 +284,7 @@ int forward_impl(asep_gnn* g, BufferPool& pool, int N, int E, const int32_t* d_e
     const size_t nh = (size_t)N * H;
     float* h[2] = {(float*)pool.get(nh * 4), (float*)pool.get(nh * 4)};
     float* cs[2] = {(float*)pool.get(nh * 4), (float*)pool.get(nh * 4)};
-    float* x = (float*)pool.get((size_t)N * I * 4);
+    float* x = (float*)pool.get((size_t)N * std::max(I, g->Iout) * 4);
     float* Pt = (float*)pool.get((size_t)N * c.cls_hidden1 * 4);
     float* Qt = (float*)pool.get((size_t)N * c.cls_hidden1 * 4);
     const float* d_fed = d_u;                                // node features as fed (output_type add / concat read these)
@@ -287,31 +342,30 @@ int forward_impl(asep_gnn* g, BufferPool& pool, int N, int E, const int32_t* d_e
         } else if (c.attention_heads > 0) {
             MsgAttArgs aa{};
             aa.u = d_u; aa.h = h[cur]; aa.ef = d_ef; aa.tptr = eb.colptr; aa.tsrc = eb.tsrc; aa.tfirst = eb.tfirst; aa.eidx = att_eidx;
-            for (int k = 0; k < c.attention_heads; ++k) aa.hd[k] = g->att_w[k];
+            aa.hd = g->d_att_w;
             aa.M = att_M; aa.A = att_A;
-            aa.N = N; aa.U = g->U; aa.Ed = g->Ed; aa.E = std::max(E, 1); aa.H = H; aa.Hm = g->Hm; aa.Ha = c.attention_hidden;
-            aa.xd = g->att_xd; aa.heads = c.attention_heads; aa.Etot = (int)att_maxE;
-            const size_t lds = ((size_t)g->K + std::max(g->Hm, c.attention_hidden)) * sizeof(float);
+            aa.N = N; aa.U = g->U; aa.Ed = g->Ed; aa.E = std::max(E, 1); aa.H = H;
+            aa.xd = g->att_xd; aa.heads = c.attention_heads; aa.Etot = (int)att_maxE; aa.maxh = g->msg_maxh;
+            const size_t lds = ((size_t)g->K + 2 * (size_t)g->msg_maxh) * sizeof(float);
             hipLaunchKernelGGL(gnn_msg_att_kernel, dim3(N), dim3(256), lds, s, aa);
             hipLaunchKernelGGL(gnn_att_softmax_kernel, dim3(N), dim3(64), 0, s, eb.colptr, att_eidx, att_A, c.attention_heads, (int)att_maxE, att_S);
             hipLaunchKernelGGL(gnn_att_aggregate_kernel, dim3(N), dim3(64), 0, s, eb.colptr, att_eidx, att_widx, att_S, att_M, c.attention_heads,
-                               g->att_xd, (int)att_maxE, c.attention_merge, x);
-            LstmGenArgs la{};
-            la.x = x; la.h_in = h[cur]; la.c_in = cs[cur]; la.u = d_u;
-            for (int q = 0; q < 4; ++q) { la.Wg[q] = g->Wg[q]; la.bg[q] = g->bg[q]; }
-            la.h_out = h[cur ^ 1]; la.c_out = cs[cur ^ 1]; la.N = N; la.U = g->U; la.H = H; la.I = I;
-            hipLaunchKernelGGL(gnn_lstm_generic_kernel, dim3(cdiv(N * H, 256)), dim3(256), 0, s, la);
+                               g->att_xd, (int)att_maxE, c.attention_merge, c.aggregation_type, x);
         } else {
             MsgGenArgs ma{};
             ma.u = d_u; ma.h = h[cur]; ma.ef = d_ef; ma.tptr = eb.colptr; ma.tsrc = eb.tsrc; ma.tfirst = eb.tfirst;
-            ma.W1 = g->W1; ma.b1 = g->b1; ma.W2 = g->W2; ma.b2 = g->b2; ma.x = x;
-            ma.N = N; ma.U = g->U; ma.Ed = g->Ed; ma.E = std::max(E, 1); ma.H = H; ma.Hm = g->Hm; ma.I = I;
-            const size_t lds = ((size_t)g->K + g->Hm + I) * sizeof(float);
+            ma.mlp = g->msg; ma.x = x;
+            ma.N = N; ma.U = g->U; ma.Ed = g->Ed; ma.E = std::max(E, 1); ma.H = H; ma.I = I; ma.maxh = g->msg_maxh;
+            ma.agg_max = c.aggregation_type;
+            const size_t lds = ((size_t)g->K + 2 * (size_t)g->msg_maxh + I) * sizeof(float);
             hipLaunchKernelGGL(gnn_message_generic_kernel, dim3(N), dim3(256), lds, s, ma);
+        }
+        if (mode == STEP_GENERIC) {                          // (the fused step kernels contain the LSTM update)
             LstmGenArgs la{};
             la.x = x; la.h_in = h[cur]; la.c_in = cs[cur]; la.u = d_u;
             for (int q = 0; q < 4; ++q) { la.Wg[q] = g->Wg[q]; la.bg[q] = g->bg[q]; }
-            la.h_out = h[cur ^ 1]; la.c_out = cs[cur ^ 1]; la.N = N; la.U = g->U; la.H = H; la.I = I;
+            la.h_out = h[cur ^ 1]; la.c_out = cs[cur ^ 1]; la.N = N; la.U = g->U; la.H = H; la.I = g->Iout;
+            la.use_h = c.lstm_use_hidden; la.use_u = c.lstm_use_input;
             hipLaunchKernelGGL(gnn_lstm_generic_kernel, dim3(cdiv(N * H, 256)), dim3(256), 0, s, la);
         }
         cur ^= 1;
@@ -329,15 +383,16 @@ int forward_impl(asep_gnn* g, BufferPool& pool, int N, int E, const int32_t* d_e
     if (R > 0) {
         hipLaunchKernelGGL(gnn_pair_pre_kernel, dim3(std::min(cdiv(N * c.cls_hidden1, 256), 1024)), dim3(256), 0, s,
                            hcls, N, Hc, g->C1, c.cls_hidden1, Pt, Qt);
-        PairArgs pa{};
-        pa.Pt = Pt; pa.Qt = Qt; pa.b1 = g->cb1; pa.W2 = g->C2; pa.b2 = g->cb2; pa.W3 = g->C3; pa.b3 = g->cb3;
-        pa.rel = d_rel; pa.out = d_out; pa.N = N; pa.R = R;
-        dim3 grid(cdiv(R, 256));
-        if (c.cls_hidden1 == 64 && c.cls_hidden2 == 32 && c.num_classes == 2) {
-            hipLaunchKernelGGL((gnn_pair_cls_kernel<64, 32, 2>), grid, dim3(256), 0, s, pa);
+        if (g->cls_fast) {
+            PairArgs pa{};
+            pa.Pt = Pt; pa.Qt = Qt; pa.b1 = g->cb1; pa.W2 = g->C2; pa.b2 = g->cb2; pa.W3 = g->C3; pa.b3 = g->cb3;
+            pa.rel = d_rel; pa.out = d_out; pa.N = N; pa.R = R;
+            hipLaunchKernelGGL((gnn_pair_cls_kernel<64, 32, 2>), dim3(cdiv(R, 256)), dim3(256), 0, s, pa);
         } else {
-            PairGenArgs pg{pa, c.cls_hidden1, c.cls_hidden2, c.num_classes};
-            hipLaunchKernelGGL(gnn_pair_cls_generic_kernel, grid, dim3(256), 0, s, pg);
+            PairGenArgs pg{};
+            pg.Pt = Pt; pg.Qt = Qt; pg.b1 = g->cb1; pg.rest = g->cls_rest; pg.rel = d_rel; pg.out = d_out; pg.N = N; pg.R = R;
+            pg.maxw = g->cls_maxw;
+            hipLaunchKernelGGL(gnn_pair_cls_generic_kernel, dim3(cdiv(R, PAIRG_P)), dim3(256), 2 * (size_t)PAIRG_P * g->cls_maxw * sizeof(float), s, pg);
         }
     }
     ASEP_HIP_CHECK(hipGetLastError());
@@ -368,6 +423,42 @@ int visual_rois_dev(asep_gnn* g, int N, const float* d_ug, const std::string& pr
         col += g->vis_d[i];
     }
     ASEP_HIP_CHECK(hipGetLastError());
+    return ASEP_OK;
+}
+
+// graph_relation.py:141-172 + misc.py:384-470: the same ROI max + compression for the E interactions' regions; the compressed
+// features go behind the fed edge features: d_ef_fed [E, Ed_fed] -> d_ef [E, Ed]
+int visual_edge_rois_dev(asep_gnn* g, int E, const float* d_ef_fed, const std::string& prefix, const float* d_reg, int P,
+                         const int32_t* d_np, float* d_ef, hipStream_t s) {
+    if (E < 1) return ASEP_OK;
+    const int Ed = g->Ed, ef = g->Ed_fed;
+    if (ef > 0) hipLaunchKernelGGL(gnn_copy_cols_kernel, dim3(cdiv(E * ef, 256)), dim3(256), 0, s, d_ef_fed, E, ef, d_ef, Ed);
+    int col = ef;
+    for (size_t i = 0; i < g->vis_names.size(); ++i) {
+        const float* fm = nullptr;
+        int dims[3];
+        int bf = 0;
+        int rc = aru_endpoint_dev(g->backbone, (prefix + g->vis_names[i]).c_str(), &fm, dims, &bf);
+        if (rc) return rc;
+        RoiArgs a{};
+        a.fm = fm; a.fh = dims[0]; a.fw = dims[1]; a.C = dims[2];
+        a.regions = d_reg; a.P = P; a.npts = d_np; a.Wc = g->vise_W[i]; a.bc = g->vise_b[i]; a.d = g->vise_d[i];
+        a.u_out = d_ef; a.ustride = Ed; a.col0 = col; a.vmax_out = nullptr;
+        if (bf) hipLaunchKernelGGL(gnn_roi_compress_kernel<true>, dim3(E), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(gnn_roi_compress_kernel<false>, dim3(E), dim3(256), 0, s, a);
+        col += g->vise_d[i];
+    }
+    ASEP_HIP_CHECK(hipGetLastError());
+    return ASEP_OK;
+}
+
+int reserve_ef_cat(asep_gnn* g, size_t n) {
+    if (g->ef_cat_cap < n) {
+        if (g->d_ef_cat) (void)hipFree(g->d_ef_cat);
+        g->d_ef_cat = nullptr; g->ef_cat_cap = 0;
+        ASEP_HIP_CHECK(hipMalloc((void**)&g->d_ef_cat, n * sizeof(float)));
+        g->ef_cat_cap = n;
+    }
     return ASEP_OK;
 }
 
@@ -420,21 +511,29 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
         return nullptr;
     }
     if (cfg->node_feature_dim < 1 || cfg->edge_feature_dim < 0 || cfg->num_transition_steps < 0 || cfg->hidden_dim < 1 ||
-        cfg->interaction_dim < 1 || cfg->interaction_hidden < 1 || cfg->cls_hidden1 < 1 || cfg->cls_hidden2 < 1 ||
-        cfg->num_classes < 1 || cfg->num_classes > 16) {
+        cfg->interaction_dim < 1 || cfg->interaction_hidden < 1 || cfg->cls_hidden1 < 1 || cfg->cls_hidden2 < 0 ||
+        cfg->num_classes < 1 || cfg->num_classes > 16 || cfg->visual_edge_dims < 0 || cfg->visual_edge_dims > cfg->edge_feature_dim) {
         set_error("asep_gnn_load: bad cfg");
+        return nullptr;
+    }
+    if (cfg->aggregation_type != 0 && cfg->aggregation_type != 1) {
+        set_error("asep_gnn_load: aggregation_type %d unknown (0 = 'sum', 1 = 'max'; message_fn_chunk.py:57-62)", cfg->aggregation_type);
         return nullptr;
     }
     std::map<std::string, HostTensor> blob;
     if (!parse_blob(weight_blob, nbytes, blob)) return nullptr;
     std::unique_ptr<asep_gnn> g(new asep_gnn());
     g->cfg = *cfg;
+    g->cfg.lstm_use_hidden = cfg->lstm_use_hidden != 0;
+    g->cfg.lstm_use_input = cfg->lstm_use_input != 0;
     const int U = g->U = cfg->node_feature_dim, Ed = g->Ed = cfg->edge_feature_dim;
     const int H = g->H = cfg->hidden_dim, I = g->I = cfg->interaction_dim, Hm = g->Hm = cfg->interaction_hidden;
+    g->Ed_fed = Ed - cfg->visual_edge_dims;
     g->K = 4 * U + Ed + 4 * H;
-    g->V = I + H + U;
     g->Uin = cfg->compress_input_dim > 0 ? cfg->compress_input_dim : U;
-    if (((size_t)g->K + Hm + I) * sizeof(float) > 60 * 1024) { set_error("asep_gnn_load: edge-MLP input width %d too large", g->K); return nullptr; }
+    const std::vector<int> ih = hidden_list({cfg->interaction_hidden, cfg->interaction_hidden2, cfg->interaction_hidden3, cfg->interaction_hidden4});
+    const std::vector<int> ah = hidden_list({cfg->attention_hidden, cfg->attention_hidden2, cfg->attention_hidden3, cfg->attention_hidden4});
+    const std::vector<int> ch = hidden_list({cfg->cls_hidden1, cfg->cls_hidden2, cfg->cls_hidden3, cfg->cls_hidden4});
     const std::string m = MSG, u = UPD, c = CLS;
     const int heads = cfg->attention_heads;
     int rc = ASEP_OK;
@@ -443,11 +542,14 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
                   cfg->attention_hidden, cfg->attention_merge);
         return nullptr;
     }
-    if (heads > 0 && ((size_t)g->K + std::max(Hm, cfg->attention_hidden)) * sizeof(float) > 60 * 1024) {
-        // (what gnn_msg_att_kernel is launched with: refuse here instead of failing at the first forward)
-        set_error("asep_gnn_load: attention MLP hidden width %d needs more LDS than a workgroup may use", cfg->attention_hidden);
+    g->msg_maxh = *std::max_element(ih.begin(), ih.end());
+    if (heads > 0) g->msg_maxh = std::max(g->msg_maxh, *std::max_element(ah.begin(), ah.end()));
+    // LDS of the generic message kernels: z + two scratch vectors (+ the accumulators); refused here, not at the first forward
+    if (((size_t)g->K + 2 * (size_t)g->msg_maxh + I) * sizeof(float) > 60 * 1024) {
+        set_error("asep_gnn_load: edge-MLP input width %d with hidden layers up to %d needs more LDS than a workgroup may use", g->K, g->msg_maxh);
         return nullptr;
     }
+    g->Iout = I;
     if (heads > 0) {
         // message_fn_chunk.py:69-72: x_dim = interaction_dim // heads for 'concat' (the LSTM then reads heads * x_dim columns)
         if (cfg->attention_merge == 0 && I % heads != 0) {
@@ -455,27 +557,23 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
             return nullptr;
         }
         g->att_xd = cfg->attention_merge == 0 ? I / heads : I;
+        g->Iout = cfg->attention_merge == 0 ? heads * g->att_xd : I;
         for (int k = 0; k < heads && !rc; ++k) {
             const std::string hk = "GraphLSTM1/message_fn_default/head_" + std::to_string(k) + "/";
             const std::string mi = hk + "calculation_interaction_features/concat_u_and_h/interaction_features";
             const std::string ma = hk + "calculation_unnormalized_attention_values/calculation_interaction_features/concat_u_and_h/interaction_features";
-            float* p[8] = {};
-            rc = upload_named(g->owned, blob, mi + "/fully_connected_layer_h1/weights", {g->K, Hm}, &p[0]);
-            if (!rc) rc = upload_named(g->owned, blob, mi + "/fully_connected_layer_h1/bias", {Hm}, &p[1]);
-            if (!rc) rc = upload_named(g->owned, blob, mi + "/fully_connected_logit_layer_out/weights", {Hm, g->att_xd}, &p[2]);
-            if (!rc) rc = upload_named(g->owned, blob, mi + "/fully_connected_logit_layer_out/bias", {g->att_xd}, &p[3]);
-            if (!rc) rc = upload_named(g->owned, blob, ma + "/fully_connected_layer_h1/weights", {g->K, cfg->attention_hidden}, &p[4]);
-            if (!rc) rc = upload_named(g->owned, blob, ma + "/fully_connected_layer_h1/bias", {cfg->attention_hidden}, &p[5]);
-            if (!rc) rc = upload_named(g->owned, blob, ma + "/fully_connected_logit_layer_out/weights", {cfg->attention_hidden, 1}, &p[6]);
-            if (!rc) rc = upload_named(g->owned, blob, ma + "/fully_connected_logit_layer_out/bias", {1}, &p[7]);
-            g->att_w[k] = AttHeadW{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]};
+            rc = upload_mlp(g.get(), blob, mi, g->K, ih, g->att_xd, &g->att_w[k].inter);
+            if (!rc) rc = upload_mlp(g.get(), blob, ma, g->K, ah, 1, &g->att_w[k].att);
+        }
+        if (!rc) {
+            std::vector<AttHeadW> hw(g->att_w, g->att_w + heads);
+            rc = upload_vec(g.get(), hw, &g->d_att_w);
         }
     } else {
-        rc = upload_named(g->owned, blob, m + "/fully_connected_layer_h1/weights", {g->K, Hm}, &g->W1);
-        if (!rc) rc = upload_named(g->owned, blob, m + "/fully_connected_layer_h1/bias", {Hm}, &g->b1);
-        if (!rc) rc = upload_named(g->owned, blob, m + "/fully_connected_logit_layer_out/weights", {Hm, I}, &g->W2);
-        if (!rc) rc = upload_named(g->owned, blob, m + "/fully_connected_logit_layer_out/bias", {I}, &g->b2);
+        rc = upload_mlp(g.get(), blob, m, g->K, ih, I, &g->msg);
+        if (!rc && ih.size() == 1) { g->b1 = const_cast<float*>(g->msg.b[0]); g->b2 = const_cast<float*>(g->msg.b[1]); }
     }
+    g->V = g->Iout + (g->cfg.lstm_use_hidden ? H : 0) + (g->cfg.lstm_use_input ? U : 0);      // update_fn_lstm.py:41-50
     const char* gates[4] = {"ingate", "outgate", "forgetgate", "cellinput"};
     for (int q = 0; q < 4 && !rc; ++q) {
         rc = upload_named(g->owned, blob, u + "/" + gates[q] + "_activation/dense/weights", {g->V, H}, &g->Wg[q]);
@@ -486,20 +584,32 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
     if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_layer_h1/weights", {2 * Hc, cfg->cls_hidden1}, &g->C1);
     if (!rc && cfg->output_type == 1) rc = upload_named(g->owned, blob, "GraphLSTM1/dense/weights", {g->Uin, H}, &g->Wout);
     if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_layer_h1/bias", {cfg->cls_hidden1}, &g->cb1);
-    if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_layer_h2/weights", {cfg->cls_hidden1, cfg->cls_hidden2}, &g->C2);
-    if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_layer_h2/bias", {cfg->cls_hidden2}, &g->cb2);
-    if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_logit_layer_out/weights", {cfg->cls_hidden2, cfg->num_classes}, &g->C3);
-    if (!rc) rc = upload_named(g->owned, blob, c + "/fully_connected_logit_layer_out/bias", {cfg->num_classes}, &g->cb3);
+    if (!rc) rc = upload_mlp(g.get(), blob, c, 2 * Hc, ch, cfg->num_classes, &g->cls_rest, /*first_layer=*/1);
+    if (!rc) {
+        g->cls_maxw = std::max(cfg->num_classes, *std::max_element(ch.begin(), ch.end()));
+        g->cls_fast = ch.size() == 2 && ch[0] == 64 && ch[1] == 32 && cfg->num_classes == 2;
+        if (g->cls_fast) {                                   // the specialised kernel's operand names
+            g->C2 = const_cast<float*>(g->cls_rest.W[0]); g->cb2 = const_cast<float*>(g->cls_rest.b[0]);
+            g->C3 = const_cast<float*>(g->cls_rest.W[1]); g->cb3 = const_cast<float*>(g->cls_rest.b[1]);
+        }
+        if (2 * (size_t)PAIRG_P * g->cls_maxw * sizeof(float) > 60 * 1024) {
+            set_error("asep_gnn_load: classifier layers up to %d wide need more LDS than a workgroup may use", g->cls_maxw);
+            return nullptr;
+        }
+    }
     if (!rc && cfg->compress_input_dim > 0) {
         rc = upload_named(g->owned, blob, "GraphLSTM1/compress_input/ff_compress_input/weights", {g->Uin, U}, &g->Wc);
         if (!rc) rc = upload_named(g->owned, blob, "GraphLSTM1/compress_input/ff_compress_input/bias", {U}, &g->bc);
     }
     if (rc) return nullptr;
     for (auto& kv : blob)
-        if (kv.first.rfind("visual_node_feature_compression_fm_", 0) == 0) g->vis_blob[kv.first] = kv.second;
+        if (kv.first.rfind("visual_node_feature_compression_fm_", 0) == 0 || kv.first.rfind("visual_edge_feature_compression_fm_", 0) == 0)
+            g->vis_blob[kv.first] = kv.second;
     if (const char* ev = getenv("ASEP_GNN_STEP")) g->use_step = atoi(ev) != 0;
     if (const char* ev = getenv("ASEP_GNN_LANES")) g->n_page_lanes = std::max(1, std::min(16, atoi(ev)));
-    const bool default_widths = H == GNN_H && I == GNN_H && Hm == GNN_H && heads == 0;
+    // the fused MFMA step kernels serve the reference's defaults: widths 32 / [32] / 32, degree-normalised SUM, both LSTM inputs
+    const bool default_widths = H == GNN_H && I == GNN_H && Hm == GNN_H && ih.size() == 1 && heads == 0 && cfg->aggregation_type == 0 &&
+                                g->cfg.lstm_use_hidden && g->cfg.lstm_use_input;
     g->mode = STEP_GENERIC;
     if (default_widths && Ed <= 4) {
         if (U <= 8) {
@@ -515,8 +625,11 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
                 g->mode = STEP_BIG;
         }
     }
-    const size_t lds = ((size_t)g->K + Hm + I) * sizeof(float);
-    if (hipFuncSetAttribute((const void*)gnn_message_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    const size_t lds = ((size_t)g->K + 2 * (size_t)g->msg_maxh + I) * sizeof(float);
+    if (hipFuncSetAttribute((const void*)gnn_message_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gnn_msg_att_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gnn_pair_cls_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(2 * (size_t)PAIRG_P * g->cls_maxw * sizeof(float))) != hipSuccess) {
         set_error("asep_gnn_load: cannot reserve %zu bytes of LDS", lds);
         return nullptr;
     }
@@ -531,6 +644,7 @@ int asep_gnn_forward_dev(asep_gnn* g, int N, int E, const int32_t* d_edges, cons
     ASEP_GUARD_BEGIN
     if (!g || !d_node_feat || (E > 0 && !d_edges) || (R > 0 && !d_probs_out)) { set_error("asep_gnn_forward_dev: null argument"); return ASEP_ERR_ARG; }
     if (g->cfg.edge_feature_dim > 0 && E > 0 && !d_edge_feat) { set_error("asep_gnn_forward_dev: edge features required"); return ASEP_ERR_ARG; }
+    if (g->cfg.visual_edge_dims > 0) { set_error("asep_gnn_forward_dev: this graph assigns visual features to edges: use asep_gnn_forward_visual*"); return ASEP_ERR_ARG; }
     return forward_impl(g, g->pool, N, E, d_edges, d_node_feat, d_edge_feat, R, d_relations, d_probs_out, (hipStream_t)stream);
     ASEP_GUARD_END
 }
@@ -539,6 +653,7 @@ int asep_gnn_forward(asep_gnn* g, int N, int E, const int32_t* edges, const floa
                      int R, const int32_t* relations, float* probs_out) {
     ASEP_GUARD_BEGIN
     if (!g || !node_feat || (E > 0 && !edges) || (R > 0 && !probs_out)) { set_error("asep_gnn_forward: null argument"); return ASEP_ERR_ARG; }
+    if (g->cfg.visual_edge_dims > 0) { set_error("asep_gnn_forward: this graph assigns visual features to edges: use asep_gnn_forward_visual*"); return ASEP_ERR_ARG; }
     if (N < 1 || E < 0 || R < 0) { set_error("asep_gnn_forward: bad sizes N=%d E=%d R=%d", N, E, R); return ASEP_ERR_ARG; }
     int rc;
     if (E > 0 && (rc = check_indices("interacting_nodes", edges, (size_t)E, N))) return rc;
@@ -640,6 +755,30 @@ int asep_gnn_attach_backbone(asep_gnn* g, asep_aru* backbone, int n_maps, const 
         g->vis_C.push_back(C); g->vis_d.push_back(w->second.dims[1]);
         g->vis_total += w->second.dims[1];
     }
+    if (g->cfg.visual_edge_dims > 0) {                     // assign_visual_features_to_edges: one compression layer per feature map
+        for (int i = 0; i < n_maps; ++i) {
+            const std::string scope = "visual_edge_feature_compression_fm_" + std::to_string(i) + "/dense/";
+            auto w = g->vis_blob.find(scope + "weights"), b = g->vis_blob.find(scope + "bias");
+            if (w == g->vis_blob.end() || b == g->vis_blob.end()) { set_error("weights: missing tensor %sweights|bias", scope.c_str()); g->free_visual(); return ASEP_ERR_WEIGHTS; }
+            if (w->second.dims.size() != 2 || w->second.dims[0] != g->vis_C[i] || b->second.dims.size() != 1 || b->second.dims[0] != w->second.dims[1]) {
+                set_error("weights: %sweights must be [%d, d] with a matching bias", scope.c_str(), g->vis_C[i]);
+                g->free_visual();
+                return ASEP_ERR_WEIGHTS;
+            }
+            float *dW = nullptr, *db = nullptr;
+            int rc = upload_named(g->vis_owned, g->vis_blob, scope + "weights", w->second.dims, &dW);
+            if (!rc) rc = upload_named(g->vis_owned, g->vis_blob, scope + "bias", b->second.dims, &db);
+            if (rc) { g->free_visual(); return rc; }
+            g->vise_W.push_back(dW); g->vise_b.push_back(db); g->vise_d.push_back(w->second.dims[1]);
+            g->vise_total += w->second.dims[1];
+        }
+        if (g->vise_total != g->cfg.visual_edge_dims) {
+            set_error("asep_gnn_attach_backbone: the visual edge compression layers are %d wide in all, cfg.visual_edge_dims says %d", g->vise_total,
+                      g->cfg.visual_edge_dims);
+            g->free_visual();
+            return ASEP_ERR_ARG;
+        }
+    }
     if (g->vis_total >= g->Uin + 1) {
         set_error("asep_gnn_attach_backbone: %d visual dims exceed the fed node feature width %d", g->vis_total, g->Uin);
         g->free_visual();
@@ -652,19 +791,26 @@ int asep_gnn_attach_backbone(asep_gnn* g, asep_aru* backbone, int n_maps, const 
 
 int asep_gnn_forward_visual_dev(asep_gnn* g, int N, int E, const int32_t* d_edges, const float* d_node_feat,
                                 const float* d_edge_feat, const float* d_image, int h, int w, const float* d_regions, int P,
-                                const int32_t* d_num_points, int R, const int32_t* d_relations, float* d_probs_out,
-                                void* stream) {
+                                const int32_t* d_num_points, const float* d_edge_regions, const int32_t* d_edge_num_points,
+                                int R, const int32_t* d_relations, float* d_probs_out, void* stream) {
     ASEP_GUARD_BEGIN
     if (!g || !g->backbone) { set_error("asep_gnn_forward_visual_dev: no backbone attached"); return ASEP_ERR_ARG; }
     const int ug = g->Uin - g->vis_total;
     if (N < 1 || h < 1 || w < 1 || P < 1 || !d_image || !d_regions || !d_num_points || (ug > 0 && !d_node_feat) ||
-        (E > 0 && !d_edges) || (R > 0 && !d_probs_out) || (g->Ed > 0 && E > 0 && !d_edge_feat)) {
+        (E > 0 && !d_edges) || (R > 0 && !d_probs_out) || (g->Ed_fed > 0 && E > 0 && !d_edge_feat) ||
+        (g->vise_total > 0 && E > 0 && (!d_edge_regions || !d_edge_num_points))) {
         set_error("asep_gnn_forward_visual_dev: bad argument");
         return ASEP_ERR_ARG;
     }
     float* d_u = nullptr;
     int rc = visual_features_dev(g, N, d_node_feat, d_image, h, w, d_regions, P, d_num_points, &d_u, (hipStream_t)stream);
     if (rc) return rc;
+    if (g->vise_total > 0 && E > 0) {
+        rc = reserve_ef_cat(g, (size_t)E * g->Ed);
+        if (!rc) rc = visual_edge_rois_dev(g, E, d_edge_feat, std::string(), d_edge_regions, P, d_edge_num_points, g->d_ef_cat, (hipStream_t)stream);
+        if (rc) return rc;
+        d_edge_feat = g->d_ef_cat;
+    }
     return forward_impl(g, g->pool, N, E, d_edges, d_u, d_edge_feat, R, d_relations, d_probs_out, (hipStream_t)stream);
     ASEP_GUARD_END
 }
@@ -674,15 +820,17 @@ int asep_gnn_forward_visual_batch_dev(asep_gnn* g, int n_pages, const asep_gnn_p
     if (!g || !g->backbone) { set_error("asep_gnn_forward_visual_batch_dev: no backbone attached"); return ASEP_ERR_ARG; }
     if (n_pages < 1 || !pages || h < 1 || w < 1 || P < 1) { set_error("asep_gnn_forward_visual_batch_dev: bad argument"); return ASEP_ERR_ARG; }
     const int ug = g->Uin - g->vis_total;
-    size_t nu = 0;
+    size_t nu = 0, nef = 0;
     for (int b = 0; b < n_pages; ++b) {
         const asep_gnn_page& q = pages[b];
         if (q.N < 1 || !q.d_image || !q.d_regions || !q.d_num_points || (ug > 0 && !q.d_node_feat) || (q.E > 0 && !q.d_edges) ||
-            (q.R > 0 && !q.d_probs_out) || (g->Ed > 0 && q.E > 0 && !q.d_edge_feat)) {
+            (q.R > 0 && !q.d_probs_out) || (g->Ed_fed > 0 && q.E > 0 && !q.d_edge_feat) ||
+            (g->vise_total > 0 && q.E > 0 && (!q.d_edge_regions || !q.d_edge_num_points))) {
             set_error("asep_gnn_forward_visual_batch_dev: bad argument in page %d", b);
             return ASEP_ERR_ARG;
         }
         nu += (size_t)q.N * g->Uin;
+        if (g->vise_total > 0) nef += (size_t)q.E * g->Ed;
     }
     hipStream_t s = (hipStream_t)stream;
     g->vis_pool.begin();
@@ -694,6 +842,7 @@ int asep_gnn_forward_visual_batch_dev(asep_gnn* g, int n_pages, const asep_gnn_p
         outs[b] = (float*)g->vis_pool.get((size_t)h * w * ncls * sizeof(float));      // backbone logits (not used by the graph)
     }
     int rc = reserve_u_cat(g, nu);
+    if (!rc && nef) rc = reserve_ef_cat(g, nef);
     if (rc) return rc;
     // ONE grouped backbone forward for all pages (every layer is one launch over the page list), then per page the ROI
     // kernels and the graph, queued back to back on the same stream
@@ -713,13 +862,22 @@ int asep_gnn_forward_visual_batch_dev(asep_gnn* g, int n_pages, const asep_gnn_p
         for (int l = 0; l < L; ++l) ASEP_HIP_CHECK(hipStreamWaitEvent(g->page_lanes[l]->s, g->ev_fork, 0));
     }
     float* d_u = g->d_u_cat;
+    float* d_efc = g->d_ef_cat;
     for (int b = 0; b < n_pages; ++b) {
         const asep_gnn_page& q = pages[b];
         hipStream_t ls = L > 1 ? g->page_lanes[b % L]->s : s;
         BufferPool& lp = L > 1 ? g->page_lanes[b % L]->pool : g->pool;
-        rc = visual_rois_dev(g, q.N, q.d_node_feat, b ? "p" + std::to_string(b) + "/" : std::string(), q.d_regions, P, q.d_num_points, d_u, ls);
+        const std::string prefix = b ? "p" + std::to_string(b) + "/" : std::string();
+        rc = visual_rois_dev(g, q.N, q.d_node_feat, prefix, q.d_regions, P, q.d_num_points, d_u, ls);
         if (rc) return rc;
-        rc = forward_impl(g, lp, q.N, q.E, q.d_edges, d_u, q.d_edge_feat, q.R, q.d_relations, q.d_probs_out, ls);
+        const float* d_ef = q.d_edge_feat;
+        if (g->vise_total > 0 && q.E > 0) {
+            rc = visual_edge_rois_dev(g, q.E, q.d_edge_feat, prefix, q.d_edge_regions, P, q.d_edge_num_points, d_efc, ls);
+            if (rc) return rc;
+            d_ef = d_efc;
+            d_efc += (size_t)q.E * g->Ed;
+        }
+        rc = forward_impl(g, lp, q.N, q.E, q.d_edges, d_u, d_ef, q.R, q.d_relations, q.d_probs_out, ls);
         if (rc) return rc;
         d_u += (size_t)q.N * g->Uin;
     }
@@ -736,7 +894,7 @@ int asep_gnn_forward_visual_batch_dev(asep_gnn* g, int n_pages, const asep_gnn_p
 
 int asep_gnn_forward_visual(asep_gnn* g, int N, int E, const int32_t* edges, const float* node_feat, const float* edge_feat,
                             const float* image, int h, int w, const float* regions, int P, const int32_t* num_points,
-                            int R, const int32_t* relations, float* probs_out) {
+                            const float* edge_regions, const int32_t* edge_num_points, int R, const int32_t* relations, float* probs_out) {
     ASEP_GUARD_BEGIN
     if (!g || !g->backbone) { set_error("asep_gnn_forward_visual: no backbone attached"); return ASEP_ERR_ARG; }
     const int U = g->Uin, ug = U - g->vis_total;
@@ -745,7 +903,9 @@ int asep_gnn_forward_visual(asep_gnn* g, int N, int E, const int32_t* edges, con
     int rc;
     if (E > 0 && (rc = check_indices("interacting_nodes", edges, (size_t)E, N))) return rc;
     if (relations && R > 0 && (rc = check_indices("relations", relations, (size_t)R, N))) return rc;
-    const size_t ne = (size_t)E * 2, nug = (size_t)N * ug, nf = edge_feat ? (size_t)E * g->Ed : 0;
+    const size_t ne = (size_t)E * 2, nug = (size_t)N * ug, nf = edge_feat ? (size_t)E * g->Ed_fed : 0;
+    const bool vedges = g->vise_total > 0 && E > 0;
+    if (vedges && (!edge_regions || !edge_num_points)) { set_error("asep_gnn_forward_visual: this graph assigns visual features to edges: edge_regions / edge_num_points required"); return ASEP_ERR_ARG; }
     const size_t nr = relations ? (size_t)R * 2 : 0, no = (size_t)R * g->cfg.num_classes, ni = (size_t)h * w;
     const size_t nreg = (size_t)N * 2 * P;
     auto up = [&](const void* src, size_t bytes) -> void* {          // grow-only staging + async copy on the null stream
@@ -761,9 +921,11 @@ int asep_gnn_forward_visual(asep_gnn* g, int N, int E, const int32_t* edges, con
     float* d_img = (float*)up(image, ni * 4);
     float* d_reg = (float*)up(regions, nreg * 4);
     int32_t* d_np = (int32_t*)up(num_points, (size_t)N * 4);
+    float* d_ereg = (float*)up(vedges ? edge_regions : nullptr, vedges ? (size_t)E * 2 * P * 4 : 0);
+    int32_t* d_enp = (int32_t*)up(vedges ? edge_num_points : nullptr, vedges ? (size_t)E * 4 : 0);
     float* d_o = (float*)up(nullptr, no * 4);
     rc = asep_gnn_forward_visual_dev(g, N, E, ne ? d_e : nullptr, nug ? d_ug : nullptr, nf ? d_f : nullptr, d_img, h, w, d_reg,
-                                     P, d_np, R, nr ? d_r : nullptr, d_o, nullptr);
+                                     P, d_np, vedges ? d_ereg : nullptr, vedges ? d_enp : nullptr, R, nr ? d_r : nullptr, d_o, nullptr);
     if (rc) return rc;
     if (R > 0) ASEP_HIP_CHECK(hipMemcpyAsync(probs_out, d_o, no * sizeof(float), hipMemcpyDeviceToHost, nullptr));
     ASEP_HIP_CHECK(hipStreamSynchronize(nullptr));
@@ -785,10 +947,17 @@ int asep_gnn_get_node_features(asep_gnn* g, float* out, size_t max_floats) {
 double asep_gnn_flops(const asep_gnn* g, int N, int E_corrected, int R) {
     if (!g) return 0.0;
     const asep_gnn_cfg& c = g->cfg;
-    double mac = (double)c.num_transition_steps *
-                 ((double)E_corrected * ((double)g->K * g->Hm + (double)g->Hm * g->I) + (double)N * 4.0 * g->V * g->H);
-    mac += (double)R * ((double)2 * g->H * c.cls_hidden1 + (double)c.cls_hidden1 * c.cls_hidden2 +
-                        (double)c.cls_hidden2 * c.num_classes);
+    auto mlp_mac = [](const MlpW& m) {
+        double s = 0;
+        for (int l = 0; l < m.nl; ++l) s += (double)m.dims[l] * m.dims[l + 1];
+        return s;
+    };
+    double per_edge = 0;
+    if (c.attention_heads > 0)
+        for (int k = 0; k < c.attention_heads; ++k) per_edge += mlp_mac(g->att_w[k].inter) + mlp_mac(g->att_w[k].att);
+    else per_edge = mlp_mac(g->msg);
+    double mac = (double)c.num_transition_steps * ((double)E_corrected * per_edge + (double)N * 4.0 * g->V * g->H);
+    mac += (double)R * ((double)2 * g->H * c.cls_hidden1 + mlp_mac(g->cls_rest));
     return 2.0 * mac;
 }
 

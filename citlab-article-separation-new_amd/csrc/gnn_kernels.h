@@ -507,53 +507,85 @@ __global__ __launch_bounds__(256) void gnn_pad_rows_kernel(const float* __restri
 // than 32; message_fn_chunk.py:13-40): plain FMA loops, one workgroup per target node / node.  Correct for any
 // width; the MFMA kernels above are the path for the reference's default widths.
 // ------------------------------------------------------------------------------------------------
+// An MLP of the reference (layers.py:468-490 mlp): hidden layers fully_connected_layer_h<i> (ReLU) + fully_connected_logit_layer_out.
+// num_hidden_units_interaction_fct / num_hidden_units_attention_fct (message_fn_chunk.py:24,40) and the classifier's
+// num_hidden_units (graph_relation.py:196) are LISTS: up to GNN_MLP_MAX hidden layers are served here.
+constexpr int GNN_MLP_MAX = 4;
+struct MlpW {
+    const float* W[GNN_MLP_MAX + 1];    // dense layer l: [dims[l], dims[l + 1]], row = input unit
+    const float* b[GNN_MLP_MAX + 1];
+    int dims[GNN_MLP_MAX + 2];          // dims[0] = input width, dims[nl] = output width
+    int nl;                             // dense layers = hidden layers + 1
+};
+// the hidden layers on the LDS vector `in` (all 256 threads of the block): relu(W x + b) layer by layer through two scratch
+// vectors; -> the last hidden activations (width dims[nl - 1]); ends behind a barrier
+__device__ __forceinline__ const float* mlp_hidden(const MlpW& m, const float* in, float* bufA, float* bufB, int tid) {
+    const float* cur = in;
+    for (int l = 0; l + 1 < m.nl; ++l) {
+        float* out = (l & 1) ? bufB : bufA;
+        const int din = m.dims[l], dout = m.dims[l + 1];
+        for (int o = tid; o < dout; o += 256) {
+            float s = m.b[l][o];
+            for (int k = 0; k < din; ++k) s = fmaf(cur[k], m.W[l][(size_t)k * dout + o], s);
+            out[o] = fmaxf(s, 0.f);
+        }
+        __syncthreads();
+        cur = out;
+    }
+    return cur;
+}
+// z of one interaction (message_fn_chunk.py:313-350: u_from, u_to, u_diff, u_sq | edge | h_from, h_to, h_diff, h_sq) -> LDS
+__device__ __forceinline__ void build_z(float* z, const float* ui, const float* uj, const float* hi, const float* hj, const float* efr,
+                                        int U, int Ed, int H, int tid) {
+    for (int k = tid; k < U; k += 256) {
+        const float vi = ui[k], vj = uj[k], d = vj - vi;
+        z[k] = vi; z[U + k] = vj; z[2 * U + k] = d; z[3 * U + k] = d * d;
+    }
+    for (int k = tid; k < Ed; k += 256) z[4 * U + k] = efr[k];
+    for (int k = tid; k < H; k += 256) {
+        const float vi = hi[k], vj = hj[k], d = vj - vi;
+        float* zh = z + 4 * U + Ed;
+        zh[k] = vi; zh[H + k] = vj; zh[2 * H + k] = d; zh[3 * H + k] = d * d;
+    }
+}
+
 struct MsgGenArgs {
     const float* u; const float* h; const float* ef;
     const int* tptr; const int* tsrc; const int* tfirst;
-    const float* W1; const float* b1;   // [K, Hm], [Hm]
-    const float* W2; const float* b2;   // [Hm, I], [I]
+    MlpW mlp;                           // [K] -> hidden ... -> [I], tanh output
     float* x;                           // [N, I]
-    int N, U, Ed, E, H, Hm, I;
+    int N, U, Ed, E, H, I;
+    int maxh;                           // widest hidden layer (size of each scratch vector)
+    int agg_max;                        // message_fn_chunk.py:16,57-62 aggregation_type: 0 = 'sum' (tf.sparse.reduce_sum), 1 = 'max'
 };
 
+// Balanced neighbour weighting (no attention): every interaction is scaled by 1 / indegree(target) and the scaled features are
+// aggregated over the target's in-edges -- 'sum': their sum; 'max' (tf.sparse.reduce_max over the stored entries only: a target
+// without in-edges gets 0, a target with in-edges may get a negative value): max_e (m_e / deg) = (max_e m_e) / deg, deg > 0.
 __global__ __launch_bounds__(256) void gnn_message_generic_kernel(const MsgGenArgs a) {
     extern __shared__ float smg[];
     const int K = 4 * a.U + a.Ed + 4 * a.H;
     float* z = smg;                 // K
-    float* hid = z + K;             // Hm
-    float* acc = hid + a.Hm;        // I
+    float* bufA = z + K;            // maxh
+    float* bufB = bufA + a.maxh;    // maxh
+    float* acc = bufB + a.maxh;     // I
     const int tid = threadIdx.x, tgt = blockIdx.x;
     const int beg = a.tptr[tgt], end = a.tptr[tgt + 1];
-    for (int o = tid; o < a.I; o += 256) acc[o] = 0.f;
+    for (int o = tid; o < a.I; o += 256) acc[o] = a.agg_max ? -INFINITY : 0.f;
     const float* uj = a.u + (size_t)tgt * a.U;
     const float* hj = a.h + (size_t)tgt * a.H;
+    const int nl = a.mlp.nl, dlast = a.mlp.dims[nl - 1];
     for (int e = beg; e < end; ++e) {
         const int i = a.tsrc[e];
-        const float* ui = a.u + (size_t)i * a.U;
-        const float* hi = a.h + (size_t)i * a.H;
-        const float* efr = a.ef + (size_t)(a.tfirst[e] % a.E) * a.Ed;
         __syncthreads();
-        for (int k = tid; k < a.U; k += 256) {
-            const float vi = ui[k], vj = uj[k], d = vj - vi;
-            z[k] = vi; z[a.U + k] = vj; z[2 * a.U + k] = d; z[3 * a.U + k] = d * d;
-        }
-        for (int k = tid; k < a.Ed; k += 256) z[4 * a.U + k] = efr[k];
-        for (int k = tid; k < a.H; k += 256) {
-            const float vi = hi[k], vj = hj[k], d = vj - vi;
-            float* zh = z + 4 * a.U + a.Ed;
-            zh[k] = vi; zh[a.H + k] = vj; zh[2 * a.H + k] = d; zh[3 * a.H + k] = d * d;
-        }
+        build_z(z, a.u + (size_t)i * a.U, uj, a.h + (size_t)i * a.H, hj, a.ef + (size_t)(a.tfirst[e] % a.E) * a.Ed, a.U, a.Ed, a.H, tid);
         __syncthreads();
-        for (int o = tid; o < a.Hm; o += 256) {
-            float s = a.b1[o];
-            for (int k = 0; k < K; ++k) s = fmaf(z[k], a.W1[(size_t)k * a.Hm + o], s);
-            hid[o] = fmaxf(s, 0.f);
-        }
-        __syncthreads();
+        const float* hid = mlp_hidden(a.mlp, z, bufA, bufB, tid);
         for (int o = tid; o < a.I; o += 256) {
-            float s = a.b2[o];
-            for (int k = 0; k < a.Hm; ++k) s = fmaf(hid[k], a.W2[(size_t)k * a.I + o], s);
-            acc[o] += tanhf(s);
+            float s = a.mlp.b[nl - 1][o];
+            for (int k = 0; k < dlast; ++k) s = fmaf(hid[k], a.mlp.W[nl - 1][(size_t)k * a.I + o], s);
+            const float m = tanhf(s);
+            acc[o] = a.agg_max ? fmaxf(acc[o], m) : acc[o] + m;
         }
     }
     __syncthreads();
@@ -617,67 +649,51 @@ __global__ __launch_bounds__(256) void edge_chunk_rank_kernel(const int32_t* __r
 }
 
 constexpr int GNN_MAX_HEADS = 8;
-struct AttHeadW { const float *W1, *b1, *W2, *b2, *A1, *ab1, *A2, *ab2; };
+struct AttHeadW { MlpW inter, att; };     // interaction MLP ([K] -> ... -> [xd], tanh) and attention MLP ([K] -> ... -> [1], linear)
 struct MsgAttArgs {
     const float* u; const float* h; const float* ef;
     const int* tptr; const int* tsrc; const int* tfirst; const int* eidx;
-    AttHeadW hd[GNN_MAX_HEADS];
+    const AttHeadW* hd;  // [heads] in device memory (eight heads of two five-layer MLPs do not fit the kernel-argument segment)
     float* M;            // [E', heads * xd] interaction features by edge index e
     float* A;            // [heads][E'] unnormalised attention values by edge index e
-    int N, U, Ed, E, H, Hm, Ha, xd, heads, Etot;
+    int N, U, Ed, E, H, xd, heads, Etot;
+    int maxh;            // widest hidden layer of any of the MLPs
 };
 // per target t, per in-edge p: z, then for every head m = tanh(MLP_int(z)) -> M[eidx[p]], a = MLP_att(z) -> A[head][eidx[p]]
 __global__ __launch_bounds__(256) void gnn_msg_att_kernel(const MsgAttArgs a) {
     extern __shared__ float smg[];
     const int K = 4 * a.U + a.Ed + 4 * a.H;
     float* z = smg;                 // K
-    float* hid = z + K;             // max(Hm, Ha)
+    float* bufA = z + K;            // maxh
+    float* bufB = bufA + a.maxh;    // maxh
     const int tid = threadIdx.x, tgt = blockIdx.x;
     const int beg = a.tptr[tgt], end = a.tptr[tgt + 1];
     const float* uj = a.u + (size_t)tgt * a.U;
     const float* hj = a.h + (size_t)tgt * a.H;
     for (int p = beg; p < end; ++p) {
         const int i = a.tsrc[p], e = a.eidx[p];
-        const float* ui = a.u + (size_t)i * a.U;
-        const float* hi = a.h + (size_t)i * a.H;
-        const float* efr = a.ef + (size_t)(a.tfirst[p] % a.E) * a.Ed;
         __syncthreads();
-        for (int k = tid; k < a.U; k += 256) {
-            const float vi = ui[k], vj = uj[k], d = vj - vi;
-            z[k] = vi; z[a.U + k] = vj; z[2 * a.U + k] = d; z[3 * a.U + k] = d * d;
-        }
-        for (int k = tid; k < a.Ed; k += 256) z[4 * a.U + k] = efr[k];
-        for (int k = tid; k < a.H; k += 256) {
-            const float vi = hi[k], vj = hj[k], d = vj - vi;
-            float* zh = z + 4 * a.U + a.Ed;
-            zh[k] = vi; zh[a.H + k] = vj; zh[2 * a.H + k] = d; zh[3 * a.H + k] = d * d;
-        }
+        build_z(z, a.u + (size_t)i * a.U, uj, a.h + (size_t)i * a.H, hj, a.ef + (size_t)(a.tfirst[p] % a.E) * a.Ed, a.U, a.Ed, a.H, tid);
+        __syncthreads();
         for (int hdi = 0; hdi < a.heads; ++hdi) {
-            const AttHeadW& w = a.hd[hdi];
-            __syncthreads();
-            for (int o = tid; o < a.Hm; o += 256) {
-                float s = w.b1[o];
-                for (int k = 0; k < K; ++k) s = fmaf(z[k], w.W1[(size_t)k * a.Hm + o], s);
-                hid[o] = fmaxf(s, 0.f);
-            }
-            __syncthreads();
+            const MlpW& wi = a.hd[hdi].inter;
+            const MlpW& wa = a.hd[hdi].att;
+            const float* hid = mlp_hidden(wi, z, bufA, bufB, tid);
+            const int li = wi.nl - 1, di = wi.dims[li];
             for (int o = tid; o < a.xd; o += 256) {
-                float s = w.b2[o];
-                for (int k = 0; k < a.Hm; ++k) s = fmaf(hid[k], w.W2[(size_t)k * a.xd + o], s);
+                float s = wi.b[li][o];
+                for (int k = 0; k < di; ++k) s = fmaf(hid[k], wi.W[li][(size_t)k * a.xd + o], s);
                 a.M[(size_t)e * a.heads * a.xd + hdi * a.xd + o] = tanhf(s);
             }
             __syncthreads();
-            for (int o = tid; o < a.Ha; o += 256) {
-                float s = w.ab1[o];
-                for (int k = 0; k < K; ++k) s = fmaf(z[k], w.A1[(size_t)k * a.Ha + o], s);
-                hid[o] = fmaxf(s, 0.f);
-            }
-            __syncthreads();
+            hid = mlp_hidden(wa, z, bufA, bufB, tid);
+            const int la = wa.nl - 1, da = wa.dims[la];
             if (tid == 0) {
-                float s = w.ab2[0];
-                for (int k = 0; k < a.Ha; ++k) s = fmaf(hid[k], w.A2[k], s);
+                float s = wa.b[la][0];
+                for (int k = 0; k < da; ++k) s = fmaf(hid[k], wa.W[la][k], s);
                 a.A[(size_t)hdi * a.Etot + e] = s;
             }
+            __syncthreads();
         }
     }
 }
@@ -701,22 +717,28 @@ __global__ __launch_bounds__(64) void gnn_att_softmax_kernel(const int* __restri
 // merge 'concat' (heads * xd = I columns) or 'average' (xd = I, mean over heads)
 __global__ __launch_bounds__(64) void gnn_att_aggregate_kernel(const int* __restrict__ tptr, const int* __restrict__ eidx, const int* __restrict__ widx,
                                                               const float* __restrict__ S, const float* __restrict__ M, int heads, int xd, int Etot,
-                                                              int average, float* __restrict__ x) {
+                                                              int average, int agg_max, float* __restrict__ x) {
     const int t = blockIdx.x;
     const int beg = tptr[t], end = tptr[t + 1];
     const int I = average ? xd : heads * xd;
+    // agg_max (aggregation_type 'max'): the maximum of the attenuated features over the in-edges instead of their sum; 0 without in-edges
+    auto head_col = [&](int hdi, int col) {
+        if (agg_max) {
+            float m = -INFINITY;
+            for (int p = beg; p < end; ++p) { const int e = eidx[p]; m = fmaxf(m, S[(size_t)hdi * Etot + widx[e]] * M[(size_t)e * heads * xd + col]); }
+            return end > beg ? m : 0.f;
+        }
+        float s = 0.f;
+        for (int p = beg; p < end; ++p) { const int e = eidx[p]; s = fmaf(S[(size_t)hdi * Etot + widx[e]], M[(size_t)e * heads * xd + col], s); }
+        return s;
+    };
     for (int o = threadIdx.x; o < I; o += 64) {
         float acc = 0.f;
         if (average) {
-            for (int hdi = 0; hdi < heads; ++hdi) {
-                float s = 0.f;
-                for (int p = beg; p < end; ++p) { const int e = eidx[p]; s = fmaf(S[(size_t)hdi * Etot + widx[e]], M[(size_t)e * heads * xd + hdi * xd + o], s); }
-                acc += s;
-            }
+            for (int hdi = 0; hdi < heads; ++hdi) acc += head_col(hdi, hdi * xd + o);
             acc /= (float)heads;
         } else {
-            const int hdi = o / xd;
-            for (int p = beg; p < end; ++p) { const int e = eidx[p]; acc = fmaf(S[(size_t)hdi * Etot + widx[e]], M[(size_t)e * heads * xd + o], acc); }
+            acc = head_col(o / xd, o);
         }
         x[(size_t)t * I + o] = acc;
     }
@@ -724,9 +746,10 @@ __global__ __launch_bounds__(64) void gnn_att_aggregate_kernel(const int* __rest
 
 struct LstmGenArgs {
     const float* x; const float* h_in; const float* c_in; const float* u;
-    const float* Wg[4]; const float* bg[4];     // [I + H + U, H], [H]
+    const float* Wg[4]; const float* bg[4];     // [I + (use_h ? H : 0) + (use_u ? U : 0), H], [H]
     float* h_out; float* c_out;
     int N, U, H, I;
+    int use_h, use_u;    // update_fn_lstm.py:13-16,43-50: incorporate_hidden_features_in_update / incorporate_node_input_features_in_update
 };
 
 __global__ __launch_bounds__(256) void gnn_lstm_generic_kernel(const LstmGenArgs a) {
@@ -742,12 +765,17 @@ __global__ __launch_bounds__(256) void gnn_lstm_generic_kernel(const LstmGenArgs
     for (int k = 0; k < a.I; ++k)
 #pragma unroll
         for (int q = 0; q < 4; ++q) g[q] = fmaf(xr[k], a.Wg[q][(size_t)k * a.H + o], g[q]);
-    for (int k = 0; k < a.H; ++k)
+    int row = a.I;
+    if (a.use_h) {
+        for (int k = 0; k < a.H; ++k)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) g[q] = fmaf(hr[k], a.Wg[q][(size_t)(a.I + k) * a.H + o], g[q]);
-    for (int k = 0; k < a.U; ++k)
+            for (int q = 0; q < 4; ++q) g[q] = fmaf(hr[k], a.Wg[q][(size_t)(row + k) * a.H + o], g[q]);
+        row += a.H;
+    }
+    if (a.use_u)
+        for (int k = 0; k < a.U; ++k)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) g[q] = fmaf(ur[k], a.Wg[q][(size_t)(a.I + a.H + k) * a.H + o], g[q]);
+            for (int q = 0; q < 4; ++q) g[q] = fmaf(ur[k], a.Wg[q][(size_t)(row + k) * a.H + o], g[q]);
     const float ig = gsig(g[0]), og = gsig(g[1]), fg = gsig(g[2]), cg = tanhf(g[3]);
     const float c = fg * a.c_in[idx] + ig * cg;
     a.c_out[idx] = c;
@@ -880,37 +908,57 @@ __global__ __launch_bounds__(256) void gnn_pair_cls_kernel(const PairArgs a) {
 // any classifier widths (trainer_rel.py:17 num_hidden_units is a free parameter): one thread per pair, the second
 // layer recomputes the first layer's activations per output unit (L1-resident P / Q columns) -- a fallback
 struct PairGenArgs {
-    PairArgs p;
-    int H1, H2, NC;
+    const float* Pt; const float* Qt;   // [h1][N]: the first hidden layer's two halves, evaluated per node (gnn_pair_pre_kernel)
+    const float* b1;                    // [h1]
+    MlpW rest;                          // the layers behind the first hidden one: [h1] -> ... -> [NC] (nl >= 1)
+    const int32_t* rel;                 // [R,2] or nullptr = all ordered pairs row major
+    float* out;                         // [R,NC]
+    int N, R, maxw;                     // maxw = widest layer (row pitch of the two scratch tiles)
 };
+constexpr int PAIRG_P = 32;             // pairs per block; 8 threads per pair
 
-__global__ __launch_bounds__(256) void gnn_pair_cls_generic_kernel(const PairGenArgs g) {
-    const PairArgs& a = g.p;
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= a.R) return;
-    int na, nb;
-    if (a.rel) { na = a.rel[2 * r]; nb = a.rel[2 * r + 1]; }
-    else { na = r / a.N; nb = r - na * a.N; }
-    float lg[16];
-    if ((unsigned)na >= (unsigned)a.N || (unsigned)nb >= (unsigned)a.N) {
-        for (int c = 0; c < g.NC; ++c) a.out[(size_t)r * g.NC + c] = __builtin_nanf("");
-        return;
+// any number of hidden layers of any width (graph_relation.py:196 num_hidden_units is a free list): 32 pairs per block, the
+// activations of a layer in an LDS tile [pair][unit], 8 threads of a pair share the units of the next layer -- a fallback
+__global__ __launch_bounds__(256) void gnn_pair_cls_generic_kernel(const PairGenArgs a) {
+    extern __shared__ float spg[];
+    float* cur = spg;                                   // [PAIRG_P][maxw]
+    float* nxt = spg + PAIRG_P * a.maxw;
+    const int tid = threadIdx.x, pl = tid >> 3, sub = tid & 7;
+    const int r = blockIdx.x * PAIRG_P + pl;
+    const int NC = a.rest.dims[a.rest.nl];
+    int na = -1, nb = -1;
+    if (r < a.R) {
+        if (a.rel) { na = a.rel[2 * r]; nb = a.rel[2 * r + 1]; }
+        else { na = r / a.N; nb = r - na * a.N; }
     }
-    for (int c = 0; c < g.NC; ++c) lg[c] = a.b3[c];
-    for (int k = 0; k < g.H2; ++k) {
-        float s = a.b2[k];
-        for (int d = 0; d < g.H1; ++d) {
-            const float v = fmaxf(a.Pt[(size_t)d * a.N + na] + a.Qt[(size_t)d * a.N + nb] + a.b1[d], 0.f);
-            s = fmaf(v, a.W2[(size_t)d * g.H2 + k], s);
+    const bool valid = r < a.R && (unsigned)na < (unsigned)a.N && (unsigned)nb < (unsigned)a.N;
+    const int h1 = a.rest.dims[0];
+    for (int d = sub; d < h1; d += 8)
+        cur[pl * a.maxw + d] = valid ? fmaxf(a.Pt[(size_t)d * a.N + na] + a.Qt[(size_t)d * a.N + nb] + a.b1[d], 0.f) : 0.f;
+    __syncthreads();
+    for (int l = 0; l < a.rest.nl; ++l) {
+        const int din = a.rest.dims[l], dout = a.rest.dims[l + 1];
+        const bool last = l == a.rest.nl - 1;
+        for (int o = sub; o < dout; o += 8) {
+            float s = a.rest.b[l][o];
+            for (int k = 0; k < din; ++k) s = fmaf(cur[pl * a.maxw + k], a.rest.W[l][(size_t)k * dout + o], s);
+            nxt[pl * a.maxw + o] = last ? s : fmaxf(s, 0.f);
         }
-        s = fmaxf(s, 0.f);
-        for (int c = 0; c < g.NC; ++c) lg[c] = fmaf(s, a.W3[(size_t)k * g.NC + c], lg[c]);
+        __syncthreads();
+        float* t = cur; cur = nxt; nxt = t;
     }
-    float mx = lg[0];
-    for (int c = 1; c < g.NC; ++c) mx = fmaxf(mx, lg[c]);
-    float den = 0.f;
-    for (int c = 0; c < g.NC; ++c) { lg[c] = expf(lg[c] - mx); den += lg[c]; }
-    for (int c = 0; c < g.NC; ++c) a.out[(size_t)r * g.NC + c] = lg[c] / den;
+    if (sub == 0 && r < a.R) {
+        if (!valid) {                                   // a pair that names no node: visible, not UB
+            for (int c = 0; c < NC; ++c) a.out[(size_t)r * NC + c] = __builtin_nanf("");
+            return;
+        }
+        const float* lg = cur + pl * a.maxw;
+        float mx = lg[0];
+        for (int c = 1; c < NC; ++c) mx = fmaxf(mx, lg[c]);
+        float den = 0.f;
+        for (int c = 0; c < NC; ++c) den += expf(lg[c] - mx);
+        for (int c = 0; c < NC; ++c) a.out[(size_t)r * NC + c] = expf(lg[c] - mx) / den;
+    }
 }
 
 

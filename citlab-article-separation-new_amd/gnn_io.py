@@ -52,17 +52,25 @@ class GnnGraph:
         if device_id not in self._handles:
             lib = _lib.init_device(device_id)
             c = self.cfg
-            if c.use_attention and len(c.attention_hidden) != 1:
-                raise _lib.AsepError("engine supports one hidden layer in the attention MLP (num_hidden_units_attention_fct)")
-            if len(c.interaction_hidden) != 1 or len(c.classifier_hidden) != 2:
-                raise _lib.AsepError("engine supports one interaction hidden layer and two classifier hidden layers")
-            cfg = _lib.GnnCfg(c.u_dim, c.edge_feature_dim, c.num_transition_steps, c.hidden_dim,
-                              c.interaction_dim, c.interaction_hidden[0], c.classifier_hidden[0],
-                              c.classifier_hidden[1], c.num_classes, int(c.undirected_graph),
+            def widths(name, lst, lo, hi=_lib.MLP_MAX_HIDDEN):
+                """the hidden-width list of an MLP as `hi` struct fields (0 = absent)"""
+                lst = [int(v) for v in lst]
+                if not lo <= len(lst) <= hi or any(v < 1 for v in lst):
+                    raise _lib.AsepError(f"{name} = {lst}: the engine serves {lo} to {hi} hidden layers of positive width")
+                return lst + [0] * (hi - len(lst))
+            ih = widths("num_hidden_units_interaction_fct", c.interaction_hidden, 1)
+            ah = widths("num_hidden_units_attention_fct", c.attention_hidden, 1) if c.use_attention else [0, 0, 0, 0]
+            ch = widths("num_hidden_units (classifier)", c.classifier_hidden, 1)
+            if c.visual_edges and not c.visual_dims:
+                raise _lib.AsepError("visual_edges needs the visual branch (visual_dims / visual_layers)")
+            cfg = _lib.GnnCfg(c.u_dim, c.edge_in_dim, c.num_transition_steps, c.hidden_dim,
+                              c.interaction_dim, ih[0], ch[0], ch[1], c.num_classes, int(c.undirected_graph),
                               c.u_in_dim if c.compress_node_feature_dim > 0 else 0, c.output_type_code,
                               c.num_attention_heads if c.use_attention else 0,
-                              {"concat": 0, "average": 1}[c.multihead_attention_merge_type],
-                              c.attention_hidden[0] if c.use_attention else 0)
+                              {"concat": 0, "average": 1}[c.multihead_attention_merge_type], ah[0],
+                              c.aggregation_code, ih[1], ih[2], ih[3], ah[1], ah[2], ah[3], ch[2], ch[3],
+                              int(c.incorporate_hidden_features_in_update), int(c.incorporate_node_input_features_in_update),
+                              c.visual_edge_dim)
             blob = self.blob()
             h = lib.asep_gnn_load(blob, len(blob), C.byref(cfg))
             if not h:
@@ -183,7 +191,15 @@ class GnnSession:
                 image = image[:int(ish[0]), :int(ish[1])]
             regions = np.asarray(feed["visual_regions_nodes:0"], dtype=np.float32)[0][:N]
             npts = np.asarray(feed["num_points_visual_regions_nodes:0"], dtype=np.int32)[0][:N]
-            probs = gnn_forward_visual(self.graph, N, edges, u, ef, image, regions, npts, rel, self.device)
+            eregions = enpts = None
+            if cfg.visual_edges:                            # graph_relation.py:141-146
+                for k in ("visual_regions_edges:0", "num_points_visual_regions_edges:0"):
+                    if k not in feed:
+                        raise KeyError(f"this graph assigns visual features to edges: feed_dict lacks {k}")
+                eregions = np.asarray(feed["visual_regions_edges:0"], dtype=np.float32)[0][:E]
+                enpts = np.asarray(feed["num_points_visual_regions_edges:0"], dtype=np.int32)[0][:E]
+            probs = gnn_forward_visual(self.graph, N, edges, u, ef, image, regions, npts, rel, self.device,
+                                       edge_regions=eregions, edge_num_points=enpts)
         else:
             probs = gnn_forward(self.graph, N, edges, u, ef, rel, self.device)
         return probs[None]
@@ -210,9 +226,10 @@ def gnn_forward(graph: GnnGraph, num_nodes, edges, node_feat, edge_feat, relatio
 
 
 def gnn_forward_visual(graph: GnnGraph, num_nodes, edges, node_feat, edge_feat, image, regions, num_points,
-                       relations=None, device=0):
+                       relations=None, device=0, edge_regions=None, edge_num_points=None):
     """graph_relation.py:84-139 + GNN: image float32 [h,w(,1)] as fed (0..255), regions [N,2,P] relative
-    coordinates, num_points [N] -> probabilities [R, num_classes]."""
+    coordinates, num_points [N] -> probabilities [R, num_classes].  ``edge_regions`` [E,2,P] / ``edge_num_points`` [E]: the
+    interactions' regions of a graph with ``visual_edges`` (graph_relation.py:141-172)."""
     lib = _lib.init_device(device)
     cfg = graph.cfg
     N = int(num_nodes)
@@ -230,6 +247,16 @@ def gnn_forward_visual(graph: GnnGraph, num_nodes, edges, node_feat, edge_feat, 
     if reg.ndim != 3 or reg.shape[0] != N or reg.shape[1] != 2:
         raise ValueError(f"visual_regions_nodes must be [N, 2, P], got {reg.shape}")
     npts = np.ascontiguousarray(num_points, dtype=np.int32).reshape(N)
+    ereg_p = enp_p = None
+    if cfg.visual_edges:
+        if edge_regions is None or edge_num_points is None:
+            raise ValueError("this graph assigns visual features to edges: edge_regions / edge_num_points required")
+        ereg = np.ascontiguousarray(edge_regions, dtype=np.float32)
+        if ereg.shape != (E, 2, reg.shape[2]):
+            raise ValueError(f"visual_regions_edges must be [E, 2, P] = {(E, 2, reg.shape[2])}, got {ereg.shape}")
+        enp = np.ascontiguousarray(edge_num_points, dtype=np.int32).reshape(E)
+        if E:
+            ereg_p, enp_p = ereg.ctypes.data, enp.ctypes.data
     if relations is None:
         R, rel_p = N * N, None
     else:
@@ -238,21 +265,23 @@ def gnn_forward_visual(graph: GnnGraph, num_nodes, edges, node_feat, edge_feat, 
     out = np.empty((R, cfg.num_classes), dtype=np.float32)
     rc = lib.asep_gnn_forward_visual(graph.handle(device), N, E, edges.ctypes.data if E else None,
                                      u.ctypes.data if u.size else None,
-                                     ef.ctypes.data if (ef is not None and E) else None, img.ctypes.data,
-                                     img.shape[0], img.shape[1], reg.ctypes.data, reg.shape[2], npts.ctypes.data, R,
-                                     rel_p, out.ctypes.data)
+                                     ef.ctypes.data if (ef is not None and ef.size and E) else None, img.ctypes.data,
+                                     img.shape[0], img.shape[1], reg.ctypes.data, reg.shape[2], npts.ctypes.data,
+                                     ereg_p, enp_p, R, rel_p, out.ctypes.data)
     _lib.check(rc, "asep_gnn_forward_visual")
     return out
 
 
 def gnn_forward_visual_dev(graph: GnnGraph, num_nodes, num_edges, d_edges, d_node_feat, d_edge_feat, d_image, h, w, d_regions,
-                           num_region_points, d_num_points, num_relations, d_relations, d_probs_out, stream=None, device=0):
+                           num_region_points, d_num_points, num_relations, d_relations, d_probs_out, stream=None, device=0,
+                           d_edge_regions=None, d_edge_num_points=None):
     """``asep_gnn_forward_visual_dev``: every array is a device address (int), nothing is synchronised -- the call returns
     once backbone, ROI kernels and the graph are queued on ``stream`` (a hipStream_t handle as int, None = null stream)."""
     lib = _lib.init_device(device)
     rc = lib.asep_gnn_forward_visual_dev(graph.handle(device), int(num_nodes), int(num_edges), d_edges, d_node_feat,
                                          d_edge_feat, d_image, int(h), int(w), d_regions, int(num_region_points),
-                                         d_num_points, int(num_relations), d_relations, d_probs_out, stream)
+                                         d_num_points, d_edge_regions, d_edge_num_points, int(num_relations), d_relations,
+                                         d_probs_out, stream)
     _lib.check(rc, "asep_gnn_forward_visual_dev")
 
 

@@ -852,6 +852,13 @@ def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None, num_transit
       output_type add / concat (graph_gnn.py:23)    = GraphLSTM1/dense/weights present / a classifier input of 2 x (hidden + fed width) -> served
       use_attention / heads / merge (message_fn_chunk.py:35-41) = .../head_<k>/calculation_unnormalized_attention_values/... variables,
                                                       AddN (average) or ConcatV2 (concat) of the heads -> served (graphs of <= 316 nodes)
+      aggregation_type (message_fn_chunk.py:16,57-62) = the op that reduces the sparse [from, to] tensor of attenuated features:
+                                                      SparseReduceMax -> 'max', else 'sum' -> both served
+      num_hidden_units_interaction_fct / _attention_fct / classifier num_hidden_units (lists) = the fully_connected_layer_h<i> variables
+                                                      of each MLP -> up to four hidden layers served, more refused
+      incorporate_*_in_update (update_fn_lstm.py:13-16,43-50) = number of tensors the gates' ConcatV2 joins, checked against the gate
+                                                      weights' input width x + [h] + [u] -> served; an ambiguous layout is refused
+      assign_visual_features_to_edges (graph_relation.py:141-172) = visual_edge_feature_compression_fm_<i> variables -> served
     """
     consts = const_tensors(nodes)
     pref = ("GraphLSTM1/message_fn_default/head_0/calculation_interaction_features/concat_u_and_h/"
@@ -882,19 +889,85 @@ def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None, num_transit
             merge = "average" if int(np.asarray(meta_avg).reshape(-1)[0]) else "concat"
         elif any(n["op"] == "AddN" and "message_fn_default" in n["name"] for n in nodes):
             merge = "average"                               # message_fn_chunk.py:229-233 tf.add_n(...) / num_attention_heads
-        if _find(consts, att_pref + "/fully_connected_layer_h2/weights") is not None:
-            raise IOError("the attention MLP has more than one hidden layer (num_hidden_units_attention_fct): the engine serves one")
+
+    def hidden_widths(scope, what):
+        """widths of the fully_connected_layer_h<i> variables under ``scope`` (layers.py:477-480)"""
+        out = []
+        while _find(consts, f"{scope}/fully_connected_layer_h{len(out) + 1}/weights") is not None:
+            out.append(int(_find(consts, f"{scope}/fully_connected_layer_h{len(out) + 1}/weights").shape[1]))
+        if len(out) > 4:
+            raise IOError(f"{what} has {len(out)} hidden layers: the engine serves up to four")
+        return out
+    int_hidden = hidden_widths(pref, "the interaction MLP (num_hidden_units_interaction_fct)")
+    att_hidden = hidden_widths(att_pref, "the attention MLP (num_hidden_units_attention_fct)") if use_attention else [16]
+    # ---- aggregation (message_fn_chunk.py:57-62,398-417): tf.sparse.reduce_max / reduce_sum of the attenuated features (the degree
+    #      count of the balanced weighting is always a SparseReduceSum); a constants-only container says it in asep_meta/aggregation_max
+    meta_agg = _find(consts, "asep_meta/aggregation_max")
+    if meta_agg is not None:
+        aggregation = "max" if int(np.asarray(meta_agg).reshape(-1)[0]) else "sum"
+    else:
+        aggregation = "max" if any(n["op"] == "SparseReduceMax" and "message_fn_default" in n["name"] for n in nodes) else "sum"
     w_add = _find(consts, "GraphLSTM1/dense/weights")       # graph_gnn.py:160-163 output_type='add_final_hidden_and_input'
     hidden = int(wu.shape[1])
     w2 = _find(consts, pref + "/fully_connected_logit_layer_out/weights")
     inter = int(w2.shape[1]) if w2 is not None else hidden
     if use_attention and merge == "concat":
         inter *= heads                                      # message_fn_chunk.py:69-72,234-237: x = concat of heads x x_dim columns
-    u_dim = int(wu.shape[0]) - inter - hidden                  # v = [x, h, u]: u = the width the message / update functions see
+    wcmp = _find(consts, "GraphLSTM1/compress_input/ff_compress_input/weights")
+    # ---- what the LSTM gates read (update_fn_lstm.py:41-50): v = [x] + [h] + [u].  The gates' ConcatV2 says how many tensors are
+    #      joined; which ones follows from the widths.  u is known independently when the graph carries the node_features
+    #      placeholder's static shape or a compress_input layer; a layout that cannot be told apart is refused.
+    v_dim = int(wu.shape[0])
+    fed_ph = next((n for n in nodes if n["op"] == "Placeholder" and n["name"].split("/")[-1] == "node_features"), None)
+    ph_dim = None
+    if fed_ph is not None and isinstance(fed_ph["attr"].get("shape"), tuple) and fed_ph["attr"]["shape"][1]:
+        last = fed_ph["attr"]["shape"][1][-1]
+        ph_dim = int(last) if last is not None and int(last) > 0 else None
+    vis_total = 0
+    k = 0
+    while _find(consts, f"visual_node_feature_compression_fm_{k}/dense/weights") is not None:
+        vis_total += int(_find(consts, f"visual_node_feature_compression_fm_{k}/dense/weights").shape[1])
+        k += 1
+    u_known = int(wcmp.shape[1]) if wcmp is not None else (ph_dim + vis_total if ph_dim is not None else None)
+    gate_cat = next((n for n in nodes if n["op"] == "ConcatV2" and "update_function_LSTM" in n["name"] and "ingate_activation" in n["name"]), None)
+    n_join = int(gate_cat["attr"].get("N", 3)) if gate_cat is not None else None
+    meta_h, meta_u = _find(consts, "asep_meta/lstm_use_hidden"), _find(consts, "asep_meta/lstm_use_input")
+    if meta_h is not None or meta_u is not None:
+        use_h = bool(int(np.asarray(meta_h).reshape(-1)[0])) if meta_h is not None else True
+        use_u = bool(int(np.asarray(meta_u).reshape(-1)[0])) if meta_u is not None else True
+    elif n_join is None or n_join == 3:
+        use_h = use_u = True
+    elif n_join == 1:
+        use_h = use_u = False
+    elif n_join == 2:
+        rest = v_dim - inter
+        if u_known is None:
+            raise IOError("the LSTM gates join two tensors (one of incorporate_hidden_features_in_update / "
+                          "incorporate_node_input_features_in_update is off, update_fn_lstm.py:43-50) and the graph does not say how wide "
+                          "the node features are: cannot tell which")
+        if rest == hidden and rest != u_known:
+            use_h, use_u = True, False
+        elif rest == u_known and rest != hidden:
+            use_h, use_u = False, True
+        else:
+            raise IOError(f"the LSTM gates read {v_dim} = x ({inter}) + {rest} values: neither clearly h ({hidden}) nor u ({u_known})")
+    else:
+        raise IOError(f"the LSTM gates join {n_join} tensors; update_fn_lstm.py:41-50 joins x, [h], [u]")
+    if use_u:
+        u_dim = v_dim - inter - (hidden if use_h else 0)
+    elif u_known is not None:
+        u_dim = u_known
+    else:
+        raise IOError("the gates do not read the node features and the graph does not say how wide they are (no node_features shape, no "
+                      "compress_input layer)")
+    if v_dim != inter + (hidden if use_h else 0) + (u_dim if use_u else 0) or u_dim < 0:
+        raise IOError(f"LSTM gate input width {v_dim} is not x ({inter})" + (f" + h ({hidden})" if use_h else "") + (f" + u ({u_dim})" if use_u else ""))
+    if u_known is not None and u_known != u_dim:
+        raise IOError(f"the gates' input width says {u_dim} node features, the graph feeds {u_known} "
+                      "(update_fn_lstm.py:41-50: v = [x, h, u])")
     e_dim = int(w1.shape[0]) - 4 * u_dim - 4 * hidden
     if u_dim < 0 or e_dim < 0:
         raise IOError(f"inconsistent GNN constant shapes: update input {wu.shape[0]}, edge MLP input {w1.shape[0]}, hidden {hidden}")
-    wcmp = _find(consts, "GraphLSTM1/compress_input/ff_compress_input/weights")
     compress = 0
     u_in = u_dim
     if wcmp is not None:
@@ -931,11 +1004,10 @@ def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None, num_transit
     else:
         raise IOError("the container holds the GNN constants but no op graph: the number of transition steps (graph_gnn.py:19) is "
                       "not derivable from shared weights; pass num_transition_steps (or export with asep_meta/num_transition_steps)")
-    cls_hidden = []
-    i = 1
-    while _find(consts, f"Classification/logits/fully_connected_layer_h{i}/weights") is not None:
-        cls_hidden.append(int(_find(consts, f"Classification/logits/fully_connected_layer_h{i}/weights").shape[1]))
-        i += 1
+    cls_hidden = hidden_widths("Classification/logits", "the pair classifier (num_hidden_units)")
+    if not cls_hidden:
+        raise IOError("the pair classifier has no hidden layer (graph_relation.py:196 num_hidden_units): the engine evaluates the first "
+                      "hidden layer per node and needs one")
     vis_kw = {}
     if any("visual_node_feature_compression" in k for k in consts):
         # graph exported with --image_input (graph_relation.py:17-37): backbone + one compression layer per map
@@ -964,13 +1036,27 @@ def gnn_from_nodes(nodes, undirected_graph=True, visual_layers=None, num_transit
         u_in -= sum(dims)
         if u_in < 0:
             raise IOError(f"the visual compression layers produce {sum(dims)} features, the GNN is fed {u_in + sum(dims)}")
+        if any("visual_edge_feature_compression" in k for k in consts):
+            # graph_relation.py:141-172 assign_visual_features_to_edges: the same feature maps and compressed widths (misc.py:384-470)
+            edims = []
+            while _find(consts, f"visual_edge_feature_compression_fm_{len(edims)}/dense/weights") is not None:
+                edims.append(int(_find(consts, f"visual_edge_feature_compression_fm_{len(edims)}/dense/weights").shape[1]))
+            if edims != dims:
+                raise IOError(f"visual edge compression layers {edims} differ from the node ones {dims}: both come from layer_compressed_dim")
+            vis_kw["visual_edges"] = True
+            e_dim -= sum(edims)
+            if e_dim < 0:
+                raise IOError(f"the visual edge compression layers produce {sum(edims)} features, the edge MLP reads {e_dim + sum(edims)} edge features")
+    elif any("visual_edge_feature_compression" in k for k in consts):
+        raise IOError("visual EDGE compression layers without the node ones: graph_relation.py builds both from the same feature maps")
     cfg = GnnConfig(node_feature_dim=u_in, edge_feature_dim=e_dim, num_transition_steps=steps, hidden_dim=hidden,
                     interaction_dim=inter,
-                    interaction_hidden=[int(w1.shape[1])], classifier_hidden=cls_hidden,
+                    interaction_hidden=int_hidden, classifier_hidden=cls_hidden, aggregation_type=aggregation,
+                    incorporate_hidden_features_in_update=use_h, incorporate_node_input_features_in_update=use_u,
                     num_classes=int(wo.shape[1]), undirected_graph=undirected_graph, compress_node_feature_dim=compress,
                     output_type=output_type, use_attention=use_attention, num_attention_heads=max(heads, 1) if use_attention else 1,
                     multihead_attention_merge_type=merge,
-                    attention_hidden=[int(wa1.shape[1])] if use_attention else [16], **vis_kw)
+                    attention_hidden=att_hidden, **vis_kw)
     if vis_kw and cfg.visual_channels() != chans:
         raise IOError(f"visual_layers {cfg.visual_layers} have {cfg.visual_channels()} channels, the compression "
                       f"layers expect {chans}")

@@ -94,6 +94,10 @@ def gnn_tensor_shapes(cfg: GnnConfig) -> "OrderedDict[str, tuple]":
         for i, (c, d) in enumerate(zip(cfg.visual_channels(), cfg.visual_dims)):      # misc.py:365-368
             shapes[f"visual_node_feature_compression_fm_{i}/dense/weights"] = (c, d)
             shapes[f"visual_node_feature_compression_fm_{i}/dense/bias"] = (d,)
+        if cfg.visual_edges:                                        # misc.py:465-468: the edges' own compression layers
+            for i, (c, d) in enumerate(zip(cfg.visual_channels(), cfg.visual_dims)):
+                shapes[f"visual_edge_feature_compression_fm_{i}/dense/weights"] = (c, d)
+                shapes[f"visual_edge_feature_compression_fm_{i}/dense/bias"] = (d,)
     if cfg.compress_node_feature_dim > 0:                           # graph_gnn.py:102-109 (scope GraphLSTM1/compress_input)
         shapes["GraphLSTM1/compress_input/ff_compress_input/weights"] = (cfg.u_in_dim, cfg.compress_node_feature_dim)
         shapes["GraphLSTM1/compress_input/ff_compress_input/bias"] = (cfg.compress_node_feature_dim,)

@@ -46,7 +46,7 @@ const char* asep_version(void);
  * dlopen; independently of it every configuration struct starts with its own size in bytes (`struct_size`), and the load
  * functions refuse a struct whose size is not the one the library was built with -- a caller written against an older or newer
  * header gets ASEP_ERR_ARG + a message instead of fields read from whatever follows its struct on the stack. */
-#define ASEP_ABI_VERSION 4
+#define ASEP_ABI_VERSION 5
 int asep_abi_version(void);
 
 /* Page-locked host memory.  The host-pointer entry points (asep_aru_forward, asep_gnn_forward ...) copy with
@@ -128,13 +128,13 @@ double asep_aru_flops(const asep_aru* m, int H, int W);
 typedef struct asep_gnn_cfg {
     int32_t struct_size;           /* = sizeof(asep_gnn_cfg) of the header the caller was compiled / written against */
     int32_t node_feature_dim;      /* u (after masking), e.g. 7 */
-    int32_t edge_feature_dim;      /* e, e.g. 2 */
+    int32_t edge_feature_dim;      /* e, e.g. 2; counts the fed (geometric) + compressed visual edge dims (visual_edge_dims) */
     int32_t num_transition_steps;  /* 3 */
     int32_t hidden_dim;            /* 32 (any width; the fused MFMA kernels serve 32/32/32) */
     int32_t interaction_dim;       /* 32 */
-    int32_t interaction_hidden;    /* one hidden layer of this width (32) */
-    int32_t cls_hidden1;           /* 64 (any widths; 64,32 -> 2 has a specialised kernel) */
-    int32_t cls_hidden2;           /* 32 */
+    int32_t interaction_hidden;    /* first hidden layer of the interaction MLP (32); further layers: interaction_hidden2..4 below */
+    int32_t cls_hidden1;           /* classifier num_hidden_units (graph_relation.py:196), first entry: 64 (64,32 -> 2 has a specialised kernel) */
+    int32_t cls_hidden2;           /* 32; 0 = the classifier has ONE hidden layer */
     int32_t num_classes;           /* 2 (<= 16) */
     int32_t undirected_graph;      /* 1 */
     int32_t compress_input_dim;    /* graph_gnn.py:20,102-109 compress_node_feature_dim: 0 = off; > 0: node features are FED with this
@@ -149,7 +149,23 @@ typedef struct asep_gnn_cfg {
                                       head_<i>/calculation_unnormalized_attention_values/... MLPs); the reference's chunking of the
                                       interactions by target-node ranges (message_fn_chunk.py:76-110) is reproduced */
     int32_t attention_merge;       /* multihead_attention_merge_type: 0 = 'concat' (x_dim = interaction_dim / heads), 1 = 'average' */
-    int32_t attention_hidden;      /* num_hidden_units_attention_fct (one layer, 16) */
+    int32_t attention_hidden;      /* num_hidden_units_attention_fct, first entry (16); further layers: attention_hidden2..4 below */
+    /* ---- ABI 5 ---- */
+    int32_t aggregation_type;      /* message_fn_chunk.py:16,57-62: 0 = 'sum' (tf.sparse.reduce_sum, the default), 1 = 'max'
+                                      (tf.sparse.reduce_max over the stored entries: a node without in-edges gets 0) */
+    int32_t interaction_hidden2;   /* num_hidden_units_interaction_fct is a list (message_fn_chunk.py:24): entries 2..4, 0 = absent */
+    int32_t interaction_hidden3;
+    int32_t interaction_hidden4;
+    int32_t attention_hidden2;     /* num_hidden_units_attention_fct entries 2..4 (message_fn_chunk.py:40), 0 = absent */
+    int32_t attention_hidden3;
+    int32_t attention_hidden4;
+    int32_t cls_hidden3;           /* classifier hidden layers 3, 4; 0 = absent */
+    int32_t cls_hidden4;
+    int32_t lstm_use_hidden;       /* update_fn_lstm.py:13-16,43-50 incorporate_hidden_features_in_update (default 1): h is an input of the gates */
+    int32_t lstm_use_input;        /* incorporate_node_input_features_in_update (default 1): the node features are an input of the gates */
+    int32_t visual_edge_dims;      /* graph_relation.py:141-172 assign_visual_features_to_edges: total width of the compressed visual EDGE
+                                      features (ROI max over the backbone end points of every interaction's region ->
+                                      visual_edge_feature_compression_fm_<i>/dense) appended to the fed edge features; 0 = off */
 } asep_gnn_cfg;
 
 typedef struct asep_gnn asep_gnn;
@@ -189,17 +205,23 @@ int asep_gnn_attach_backbone(asep_gnn* g, asep_aru* backbone, int n_maps, const 
 
 /* run_gnn_clustering.py:259-269 with the image feeds: node_feat [N, node_feature_dim - visual dims],
  * image float32 [h,w] (0..255 as fed, input_dataset.py:279-280), regions [N,2,P] relative coordinates (row 0 = x,
- * row 1 = y), num_points [N].  Backbone -> ROI max -> compression -> concat -> GNN -> probabilities [R, classes]. */
+ * row 1 = y), num_points [N].  Backbone -> ROI max -> compression -> concat -> GNN -> probabilities [R, classes].
+ * edge_regions [E,2,P] / edge_num_points [E] ('visual_regions_edges', 'num_points_visual_regions_edges'): the regions of the
+ * interactions of a graph exported with assign_visual_features_to_edges (cfg.visual_edge_dims > 0; NULL otherwise): their
+ * compressed ROI maxima are appended to edge_feat [E, edge_feature_dim - visual_edge_dims] BEFORE the edge correction, which
+ * keeps the first occurrence's features like every other edge feature. */
 int asep_gnn_forward_visual(asep_gnn* g, int N, int E, const int32_t* edges, const float* node_feat,
                             const float* edge_feat, const float* image, int h, int w, const float* regions, int P,
-                            const int32_t* num_points, int R, const int32_t* relations, float* probs_out);
+                            const int32_t* num_points, const float* edge_regions, const int32_t* edge_num_points,
+                            int R, const int32_t* relations, float* probs_out);
 
 /* The same with every array already in HBM (image [h,w] float32 included), launched on `stream` without any host
  * synchronisation: backbone, ROI kernels and the graph are queued back to back.  Index arrays are not validated here:
  * an edge that names a node outside 0..N-1 is ignored, a relation that does yields NaN probabilities. */
 int asep_gnn_forward_visual_dev(asep_gnn* g, int N, int E, const int32_t* d_edges, const float* d_node_feat,
                                 const float* d_edge_feat, const float* d_image, int h, int w, const float* d_regions,
-                                int P, const int32_t* d_num_points, int R, const int32_t* d_relations,
+                                int P, const int32_t* d_num_points, const float* d_edge_regions,
+                                const int32_t* d_edge_num_points, int R, const int32_t* d_relations,
                                 float* d_probs_out, void* stream);
 
 /* A batch of pages through the visual net (bench.py's step; a GPU owner that holds several decoded pages): the backbones
@@ -215,6 +237,8 @@ typedef struct asep_gnn_page {
     const float* d_image;          /* [h,w] */
     const float* d_regions;        /* [N,2,P] */
     const int32_t* d_num_points;   /* [N] */
+    const float* d_edge_regions;   /* [E,2,P] or NULL (cfg.visual_edge_dims == 0) */
+    const int32_t* d_edge_num_points; /* [E] or NULL */
     const int32_t* d_relations;    /* [R,2] or NULL = all N*N ordered pairs (then R must be N*N) */
     float* d_probs_out;            /* [R, num_classes] */
 } asep_gnn_page;

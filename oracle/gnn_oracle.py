@@ -145,14 +145,30 @@ def forward(num_nodes, edges, node_feat, edge_feat, relations, w, cfg, dtype=np.
             else:
                 weights_e = (1.0 / deg[to]).astype(dtype) if len(to) else np.zeros(0, dtype)      # :369-386
             xk = np.zeros((N, m.shape[1]), dtype)
-            if len(to):
-                np.add.at(xk, to, m * weights_e[:, None])            # :398-417: sparse [from, to] summed over axis 0
+            att_feat = m * weights_e[:, None] if len(to) else m       # :214 attenuated interaction features
+            agg = getattr(cfg, "aggregation_type", "sum")
+            if len(to) and agg == "sum":
+                np.add.at(xk, to, att_feat)                           # :398-417: sparse [from, to], tf.sparse.reduce_sum over axis 0
+            elif len(to) and agg == "max":
+                # :57-62 tf.sparse.reduce_max over axis 0: the maximum over the STORED entries of a column (the implicit zeros do not
+                # take part, so a target's value may be negative); a column without entries reduces to 0
+                filled = np.full_like(xk, -np.inf)
+                np.maximum.at(filled, to, att_feat)
+                has = np.bincount(to, minlength=N) > 0
+                xk[has] = filled[has]
+            elif len(to):
+                raise ValueError(f"aggregation_type {agg!r}")
             per_head.append(xk)
         if not use_att or getattr(cfg, "multihead_attention_merge_type", "concat") == "average":
             x = (sum(per_head) / dtype(heads)).astype(dtype)          # :229-233
         else:
             x = np.concatenate(per_head, axis=1)                      # :234-237
-        v = np.concatenate([x, h, u], axis=1)                        # update_fn_lstm.py:41-50
+        parts = [x]                                                   # update_fn_lstm.py:41-50
+        if getattr(cfg, "incorporate_hidden_features_in_update", True):
+            parts.append(h)
+        if getattr(cfg, "incorporate_node_input_features_in_update", True):
+            parts.append(u)
+        v = np.concatenate(parts, axis=1)
         gate = {g: v @ w[f"{UPD}/{g}_activation/dense/weights"] + w[f"{UPD}/{g}_activation/dense/bias"]
                 for g in ("ingate", "outgate", "forgetgate", "cellinput")}
         i_g, o_g, f_g = _sigmoid(gate["ingate"]), _sigmoid(gate["outgate"]), _sigmoid(gate["forgetgate"])
@@ -179,7 +195,7 @@ def forward(num_nodes, edges, node_feat, edge_feat, relations, w, cfg, dtype=np.
     return probs
 
 
-def visual_node_features(image, regions, num_points, w, cfg, return_maps=False):
+def visual_node_features(image, regions, num_points, w, cfg, return_maps=False, scope_kind="node"):
     """graph_relation.py:84-127 + misc.py:249-381 at batch size 1 -> [N, sum(layer_compressed_dim)] float32.
 
     image [h,w] float32 as fed (0..255) -> (normalize_image when cfg.mvn: per-image standardisation over the true
@@ -214,7 +230,7 @@ def visual_node_features(image, regions, num_points, w, cfg, return_maps=False):
             y1 = max(min(int(np.floor(np.float32(ymax) * np.float32(fh))), fh - 1), 0)
             nx, ny = max(x1 - x0 + 1, 1), max(y1 - y0 + 1, 1)
             vmax[n] = fm[y0:y0 + ny, x0:x0 + nx].max(axis=(0, 1))
-        scope = f"visual_node_feature_compression_fm_{i}/dense"
+        scope = f"visual_{scope_kind}_feature_compression_fm_{i}/dense"        # misc.py:365 / :467
         feats.append(np.maximum(vmax @ w[scope + "/weights"].astype(np.float32)
                                 + w[scope + "/bias"].astype(np.float32), 0).astype(np.float32))
         maps.append(vmax)
@@ -222,11 +238,20 @@ def visual_node_features(image, regions, num_points, w, cfg, return_maps=False):
     return (out, maps) if return_maps else out
 
 
-def forward_visual(num_nodes, edges, node_feat, edge_feat, image, regions, num_points, relations, w, cfg):
-    """== sess.run('output_belong_to_same_instance:0') of a graph exported with image_input, batch size 1."""
+def forward_visual(num_nodes, edges, node_feat, edge_feat, image, regions, num_points, relations, w, cfg,
+                   edge_regions=None, edge_num_points=None):
+    """== sess.run('output_belong_to_same_instance:0') of a graph exported with image_input, batch size 1.
+    cfg.visual_edges (graph_relation.py:141-172, misc.py:384-470): the same ROI max on the interactions' regions, compressed by the
+    visual_edge_feature_compression_fm_<i> layers, concatenated behind the fed edge features BEFORE the GNN (whose edge correction
+    then keeps the first occurrence's features)."""
     N = int(num_nodes)
     vis = visual_node_features(image, regions, num_points, w, cfg)
     geo = np.asarray(node_feat, dtype=np.float32).reshape(N, -1) if node_feat is not None else np.zeros((N, 0), np.float32)
     u = np.concatenate([geo, vis], axis=1)
+    if getattr(cfg, "visual_edges", False):
+        E = np.asarray(edges).reshape(-1, 2).shape[0]
+        evis = visual_node_features(image, edge_regions, edge_num_points, w, cfg, scope_kind="edge")
+        egeo = np.asarray(edge_feat, dtype=np.float32).reshape(E, -1) if edge_feat is not None else np.zeros((E, 0), np.float32)
+        edge_feat = np.concatenate([egeo, evis], axis=1)
     probs = forward(N, edges, u, edge_feat, relations, w, cfg)
     return probs, u

@@ -155,6 +155,21 @@ def test_permutation_equivariance():
     (dict(use_attention=True, num_attention_heads=2, multihead_attention_merge_type="average", attention_hidden=[12]), "generic"),
     (dict(use_attention=True, num_attention_heads=2, undirected_graph=False, hidden_dim=24, interaction_dim=20,
           interaction_hidden=[28], num_transition_steps=2), "generic"),
+    # round 4 -- message_fn_chunk.py:16,57-62 aggregation_type='max' (tf.sparse.reduce_max), with and without attention
+    (dict(aggregation_type="max"), "generic"),
+    (dict(aggregation_type="max", undirected_graph=False, node_feature_dim=20), "generic"),
+    (dict(aggregation_type="max", use_attention=True, num_attention_heads=2), "generic"),
+    (dict(aggregation_type="max", use_attention=True, num_attention_heads=2, multihead_attention_merge_type="average"), "generic"),
+    # num_hidden_units_* are lists (message_fn_chunk.py:24,40; graph_relation.py:196): several hidden layers per MLP
+    (dict(interaction_hidden=[32, 32]), "generic"),
+    (dict(interaction_hidden=[40, 24, 16], classifier_hidden=[48, 20, 12]), "generic"),
+    (dict(classifier_hidden=[48]), "mfma_registers"),                          # one hidden layer
+    (dict(classifier_hidden=[64, 32, 16, 8], num_classes=3, node_feature_dim=20), "mfma_lds"),
+    (dict(use_attention=True, num_attention_heads=2, attention_hidden=[16, 8], interaction_hidden=[24, 20]), "generic"),
+    # update_fn_lstm.py:13-16,43-50: the gates read x alone / x + h / x + u
+    (dict(incorporate_node_input_features_in_update=False), "generic"),
+    (dict(incorporate_hidden_features_in_update=False), "generic"),
+    (dict(incorporate_hidden_features_in_update=False, incorporate_node_input_features_in_update=False, aggregation_type="max"), "generic"),
 ])
 def test_hyper_parameters_other_than_the_defaults(kw, mode):
     """message_fn_chunk.py:13-40, trainer_rel.py:15-17: every width is a free parameter of the reference; the engine picks

@@ -1,5 +1,6 @@
 """GNN oracle: hand-checkable edge-correction cases (misc.py:7-151) and structural properties."""
 import numpy as np
+import pytest
 
 from oracle import gnn_oracle as G
 
@@ -132,3 +133,58 @@ def test_single_head_attention_with_constant_scores_is_the_balanced_sum():
     p_att = G.forward(N, edges, u, ef, None, w, att)
     p_plain = G.forward(N, edges, u, ef, None, {k: v for k, v in w.items() if "unnormalized_attention" not in k}, plain)
     assert np.abs(p_att - p_plain).max() < 1e-6
+
+
+def test_max_aggregation_on_a_hand_case():
+    """message_fn_chunk.py:16,57-62,398-417 aggregation_type='max' = tf.sparse.reduce_max over axis 0 of the sparse [from, to] tensor
+    of attenuated features: per target the maximum over its STORED in-edges (implicit zeros do not take part: a negative maximum
+    stays negative), 0 for a target without in-edges.  Directed graph 0->2, 1->2, 0->1; node 0 has no in-edge.
+    With the LSTM gates reading x alone (both incorporate_* off) and a first step from h = 0, x is recoverable from the cell state."""
+    from citlab_article_separation_new_amd.config import GnnConfig
+    from citlab_article_separation_new_amd.weights import init_gnn_weights
+    from oracle import gnn_oracle as G
+    N = 3
+    edges = np.array([[0, 2], [1, 2], [0, 1]], np.int32)
+    rng = np.random.default_rng(0)
+    u = rng.normal(size=(N, 7)).astype(np.float32)
+    ef = rng.normal(size=(3, 2)).astype(np.float32)
+    base = dict(undirected_graph=False, num_transition_steps=1, incorporate_hidden_features_in_update=False,
+                incorporate_node_input_features_in_update=False)
+    cfg_max, cfg_sum = GnnConfig(aggregation_type="max", **base), GnnConfig(**base)
+    w = init_gnn_weights(cfg_sum, 4, bias_jitter=0.3)
+    assert w["GraphLSTM1/update_function_LSTM/ingate_activation/dense/weights"].shape == (32, 32)       # x alone
+    # the messages by hand: m_e = tanh(MLP(z_e)), attenuated by 1 / indegree(target)
+    ce, cf = G.correct_edges(edges, ef, N, False)
+    assert ce.tolist() == [[0, 1], [0, 2], [1, 2]]
+    frm, to = ce[:, 0], ce[:, 1]
+    h0 = np.zeros((N, 32), np.float32)
+    du = u[to] - u[frm]
+    z = np.concatenate([u[frm], u[to], du, du * du, cf, h0[frm], h0[to], h0[frm], h0[frm]], axis=1)
+    hid = np.maximum(z @ w[G.MSG + "/fully_connected_layer_h1/weights"] + w[G.MSG + "/fully_connected_layer_h1/bias"], 0)
+    m = np.tanh(hid @ w[G.MSG + "/fully_connected_logit_layer_out/weights"] + w[G.MSG + "/fully_connected_logit_layer_out/bias"])
+    x_max = np.stack([np.zeros(32), m[0] / 1.0, np.maximum(m[1], m[2]) / 2.0]).astype(np.float32)
+    x_sum = np.stack([np.zeros(32), m[0] / 1.0, (m[1] + m[2]) / 2.0]).astype(np.float32)
+    assert (np.maximum(m[1], m[2]) < 0).any(), "the case must contain a negative maximum (stored entries only)"
+
+    def hidden_from_x(x):
+        gate = {g: x @ w[f"{G.UPD}/{g}_activation/dense/weights"] + w[f"{G.UPD}/{g}_activation/dense/bias"]
+                for g in ("ingate", "outgate", "cellinput")}
+        sig = lambda v: 1 / (1 + np.exp(-v))
+        return sig(gate["outgate"]) * np.tanh(sig(gate["ingate"]) * np.tanh(gate["cellinput"]))
+    _, h_max = G.forward(N, edges, u, ef, None, w, cfg_max, return_hidden=True)
+    _, h_sum = G.forward(N, edges, u, ef, None, w, cfg_sum, return_hidden=True)
+    assert np.allclose(h_max, hidden_from_x(x_max), atol=1e-6) and np.allclose(h_sum, hidden_from_x(x_sum), atol=1e-6)
+    assert np.abs(h_max[2] - h_sum[2]).max() > 1e-4 and np.allclose(h_max[:2], h_sum[:2])     # one in-edge: max = sum; none: 0
+    with pytest.raises(ValueError):
+        G.forward(N, edges, u, ef, None, w, GnnConfig(aggregation_type="mean", **base))
+
+
+def test_lstm_input_flags_change_the_gate_width():
+    """update_fn_lstm.py:13-16,43-50: v = [x] + [h] + [u]"""
+    from citlab_article_separation_new_amd.config import GnnConfig
+    from citlab_article_separation_new_amd.weights import gnn_tensor_shapes
+    k = "GraphLSTM1/update_function_LSTM/forgetgate_activation/dense/weights"
+    assert gnn_tensor_shapes(GnnConfig())[k] == (32 + 32 + 7, 32)
+    assert gnn_tensor_shapes(GnnConfig(incorporate_hidden_features_in_update=False))[k] == (32 + 7, 32)
+    assert gnn_tensor_shapes(GnnConfig(incorporate_node_input_features_in_update=False))[k] == (64, 32)
+    assert gnn_tensor_shapes(GnnConfig(incorporate_hidden_features_in_update=False, incorporate_node_input_features_in_update=False))[k] == (32, 32)

@@ -22,7 +22,19 @@ UPD = "GraphLSTM1/update_function_LSTM"
 CLS = "Classification/logits"
 
 
-def build(ns, weights, num_transition_steps, prefix="graph/", extra_consts=None, merge_concat=None):
+def _mlp_layers(weights, scope):
+    """layer names of an MLP of layers.py:468-490 as far as ``weights`` holds them: hidden layers h1, h2, ... + the output layer"""
+    out = []
+    while f"{scope}/fully_connected_layer_h{len(out) + 1}/weights" in weights:
+        out.append(f"fully_connected_layer_h{len(out) + 1}")
+    return out + ["fully_connected_logit_layer_out"]
+
+
+def build(ns, weights, num_transition_steps, prefix="graph/", extra_consts=None, merge_concat=None, aggregation="sum",
+          lstm_inputs=(True, True), node_feature_dim=None):
+    """aggregation: 'sum' / 'max' -> the SparseReduceSum / SparseReduceMax op of message_fn_chunk.py:398-417 (inside its map_fn loop);
+    lstm_inputs = (incorporate_hidden_features_in_update, incorporate_node_input_features_in_update): which tensors the gates' ConcatV2
+    joins behind x (update_fn_lstm.py:41-50); node_feature_dim: static last dimension of the node_features placeholder"""
     nodes, made = [], set()
 
     def add(name, op, inputs=(), **attrs):
@@ -39,7 +51,10 @@ def build(ns, weights, num_transition_steps, prefix="graph/", extra_consts=None,
         return full + "/read"
 
     for ph in ("num_nodes", "interacting_nodes", "node_features", "edge_features", "relations_to_consider_belong_to_same_instance"):
-        add(ph, "Placeholder", dtype=F32)
+        if ph == "node_features" and node_feature_dim is not None:
+            add(ph, "Placeholder", dtype=F32, shape=tp.Shape(-1, -1, node_feature_dim))
+        else:
+            add(ph, "Placeholder", dtype=F32)
     u = "node_features"
     if "GraphLSTM1/compress_input/ff_compress_input/weights" in weights:
         s = prefix + "GraphLSTM1/compress_input/ff_compress_input"
@@ -51,7 +66,7 @@ def build(ns, weights, num_transition_steps, prefix="graph/", extra_consts=None,
         loop = prefix + f"GraphLSTM1/message_fn_default{sfx}/head_0/while"
         z = add(loop + "/concat", "ConcatV2", [u, h, "edge_features"], T=F32, N=3)
         x = z
-        for layer in ("fully_connected_layer_h1", "fully_connected_logit_layer_out"):
+        for layer in _mlp_layers(weights, MSG):
             enter_w = add(f"{loop}/{layer}/MatMul/Enter", "Enter", [var(f"{MSG}/{layer}/weights")], T=F32, frame_name=loop, is_constant=True)
             enter_b = add(f"{loop}/{layer}/BiasAdd/Enter", "Enter", [var(f"{MSG}/{layer}/bias")], T=F32, frame_name=loop, is_constant=True)
             x = add(f"{loop}/{layer}/BiasAdd", "BiasAdd", [add(f"{loop}/{layer}/MatMul", "MatMul", [x, enter_w], T=F32), enter_b], T=F32)
@@ -65,17 +80,22 @@ def build(ns, weights, num_transition_steps, prefix="graph/", extra_consts=None,
                 if f"{msg_k}/fully_connected_layer_h1/weights" not in weights:
                     break
                 y = z
-                for layer in ("fully_connected_layer_h1", "fully_connected_logit_layer_out"):
+                for layer in _mlp_layers(weights, msg_k):
                     y = add(f"{loop}/head_{k}/{layer}/BiasAdd", "BiasAdd", [add(f"{loop}/head_{k}/{layer}/MatMul", "MatMul", [y, var(f"{msg_k}/{layer}/weights")], T=F32),
                                                                                var(f"{msg_k}/{layer}/bias")], T=F32)
                 head_out.append(y)
             if f"{att_k}/fully_connected_layer_h1/weights" in weights:
                 y = z
-                for layer in ("fully_connected_layer_h1", "fully_connected_logit_layer_out"):
+                for layer in _mlp_layers(weights, att_k):
                     y = add(f"{loop}/head_{k}/att/{layer}/BiasAdd", "BiasAdd", [add(f"{loop}/head_{k}/att/{layer}/MatMul", "MatMul", [y, var(f"{att_k}/{layer}/weights")], T=F32),
                                                                                    var(f"{att_k}/{layer}/bias")], T=F32)
                 head_out[-1] = add(f"{loop}/head_{k}/mul", "Mul", [head_out[-1], y], T=F32)
             k += 1
+        # message_fn_chunk.py:398-417: per feature component a sparse [from, to] tensor reduced over axis 0 (inside a map_fn loop); the
+        # degree count of the balanced weighting is a SparseReduceSum of its own (:369-386)
+        add(f"{loop}/SparseReduceSum", "SparseReduceSum", ["interacting_nodes"], T=F32)
+        red = "SparseReduceMax" if aggregation == "max" else "SparseReduceSum"
+        head_out = [add(f"{loop}/head_{i}/map/while/{red}", red, [y], T=F32) for i, y in enumerate(head_out)]
         if len(head_out) > 1:
             concat = merge_concat if merge_concat is not None else True
             if concat:
@@ -86,9 +106,11 @@ def build(ns, weights, num_transition_steps, prefix="graph/", extra_consts=None,
         else:
             x = head_out[0]
         gates = []
+        joined = [x] + ([h] if lstm_inputs[0] else []) + ([u] if lstm_inputs[1] else [])
         for g in ("ingate", "outgate", "forgetgate", "cellinput"):
             s = prefix + f"{UPD}{sfx}/{g}_activation/dense"
-            gates.append(add(s + "/BiasAdd", "BiasAdd", [add(s + "/MatMul", "MatMul", [x, var(f"{UPD}/{g}_activation/dense/weights")], T=F32),
+            v = add(prefix + f"{UPD}{sfx}/{g}_activation/concat", "ConcatV2", joined, T=F32, N=len(joined))     # update_fn_lstm.py:93
+            gates.append(add(s + "/BiasAdd", "BiasAdd", [add(s + "/MatMul", "MatMul", [v, var(f"{UPD}/{g}_activation/dense/weights")], T=F32),
                                                           var(f"{UPD}/{g}_activation/dense/bias")], T=F32))
         h = add(prefix + f"{UPD}{sfx}/mul_2", "Mul", gates[:2], T=F32)
     x = h
