@@ -405,8 +405,10 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
 def build_roofline(args, dom, d_iso, d_situ, kernels, exec_flops_page, pages_per_s_gpu, peak_tf, pages_per_launch, n_prof, visual, B, H, W):
     """-> (roofline, roofline_detail).  `roofline` holds at most 20 keys, the HBM ones before the event-timing details (a record that
     keeps the first keys of a nested object keeps the informative ones); everything else goes to `roofline_detail`.
-      fp32: bound "mfma": achieved = EXECUTED TFLOP/s of the dominant kernel (a Winograd kernel executes 1/2.25 of its direct-
-            convolution credit; `algorithmic_frac` carries the credit), against 157.3 TFLOP/s.
+      fp32: bound "mfma": achieved = ALGORITHMIC TFLOP/s of the dominant kernel -- the direct-convolution FLOPs 2 H W k^2 Cin Cout of
+            its layers / its average launch duration -- against 157.3 TFLOP/s.  A Winograd F(2x2,3x3) kernel
+            EXECUTES 1/2.25 of that on the matrix cores: `executed_frac` carries the executed rate (rounds 1-3 reported that one as
+            `frac`), and an isolated Winograd launch can exceed 1.0 algorithmically -- that is what the transform buys.
       bf16: bound "hbm": achieved = ALGORITHMIC bytes per launch (inputs read once, outputs written once: the engine's shape
             arithmetic, asep_aru_profile_report "bytes") / average launch duration, against 8 TB/s.
     `traffic` = HBM bytes per launch by the PMC counters ((2 FETCH_SIZE + WRITE_SIZE) * 1024, separate rocprofv3 --pmc passes of the
@@ -415,7 +417,7 @@ def build_roofline(args, dom, d_iso, d_situ, kernels, exec_flops_page, pages_per
     hbm_bound = args.dtype == "bf16"
     calls = dom["calls"]
     algo_bytes = dom["bytes"] / calls
-    rate = (lambda d: d["algo_gbs"]) if hbm_bound else (lambda d: d["executed_tflops"])
+    rate = (lambda d: d["algo_gbs"]) if hbm_bound else (lambda d: d["tflops"])
     peak = PEAK_HBM_GBS if hbm_bound else peak_tf
     total_ms = sum(k["total_ms"] for k in kernels)
     r = {
@@ -427,7 +429,7 @@ def build_roofline(args, dom, d_iso, d_situ, kernels, exec_flops_page, pages_per
         "timing": "in situ" if d_situ else "isolated",
         "frac_in_situ": round(rate(d_situ) / peak, 4) if d_situ else None,
         "frac_isolated": round(rate(d_iso) / peak, 4) if d_iso else None,
-        ("mfma_frac" if hbm_bound else "algorithmic_frac"): round((lead["executed_tflops"] if hbm_bound else lead["tflops"]) / peak_tf, 4),
+        ("mfma_frac" if hbm_bound else "executed_frac"): round(lead["executed_tflops"] / peak_tf, 4),
         "avg_launch_us": round(lead["avg_us"], 2),
         "launches_per_step": calls / n_prof,
         "whole_page_executed_frac": round(exec_flops_page * pages_per_s_gpu / 1e12 / peak_tf, 4),

@@ -340,6 +340,61 @@ int pack_direct(asep_aru* m, const std::map<std::string, HostTensor>& blob, cons
     return ASEP_OK;
 }
 
+struct TileDims { int tx, ty, begin; };
+
+// units -> tiles for the problems' tile grids `probs` (tile numbers begin + ty * tx + x, `total` tiles in all).  The table has
+// `total` entries, or with pad8 the next multiple of 8 (surplus units hold -1: launches whose grid.y counts channel blocks keep
+// "tile t runs on XCD t % 8" for every y that way).  One-shot kernels launch one block per unit (sched_tile, bf16_kernels.h).
+const int32_t* xcd_schedule(asep_aru* m, const std::vector<TileDims>& probs, int total, bool pad8, int* n_units = nullptr) {
+    const int units = pad8 ? (total + 7) / 8 * 8 : total;
+    if (n_units) *n_units = units;
+    std::string key = pad8 ? "p" : "u";
+    for (const TileDims& q : probs) key += ":" + std::to_string(q.tx) + "x" + std::to_string(q.ty);
+    auto it = m->sched_cache.find(key);
+    if (it != m->sched_cache.end()) return it->second;
+    std::vector<int32_t> order;
+    order.reserve(total);
+    for (const TileDims& q : probs)
+        for (int gc = 0; gc * 8 < q.tx; ++gc)
+            for (int gr = 0; gr * 4 < q.ty; ++gr)
+                for (int r = 0; r < 4; ++r)
+                    for (int c = 0; c < 8; ++c) {
+                        const int ty = gr * 4 + r, tx = gc * 8 + c;
+                        if (ty < q.ty && tx < q.tx) order.push_back(q.begin + ty * q.tx + tx);
+                    }
+    if ((int)order.size() != total) return nullptr;
+    std::vector<int32_t> sched(units);
+    int off[9];
+    off[0] = 0;
+    for (int x = 0; x < 8; ++x) off[x + 1] = off[x] + (total - x + 7) / 8;
+    for (int k = 0; k < units; ++k) sched[k] = k / 8 < off[k % 8 + 1] - off[k % 8] ? order[off[k % 8] + k / 8] : -1;
+    int32_t* d = nullptr;
+    if (hipMalloc((void**)&d, (size_t)units * sizeof(int32_t)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, sched.data(), (size_t)units * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    m->owned.push_back(d);
+    m->sched_cache[key] = d;
+    return d;
+}
+
+// the persistent fp32 level-0 kernels: nblocks resident blocks, unit k = block + i * nblocks
+const int32_t* tile_schedule(asep_aru* m, const Res8Args& a, int nblocks, int unit_h) {
+    if (!m->use_xcd_sched || nblocks % 8 != 0 || a.total_tiles < 2 * nblocks) return nullptr;
+    std::vector<TileDims> probs;
+    for (int i = 0; i < a.nprob; ++i) probs.push_back({a.p[i].tiles_x, (a.p[i].H + unit_h - 1) / unit_h, a.p[i].tile_begin});
+    return xcd_schedule(m, probs, a.total_tiles, false);
+}
+
+// one-shot kernels (one block per tile): worth a table from a few waves of blocks per XCD on
+template <class Args>
+const int32_t* oneshot_schedule(asep_aru* m, const Args& a, int th, int total, bool pad8, int* n_units,
+                                int (*height)(const Args&, int)) {
+    if (n_units) *n_units = total;
+    if (!m->use_xcd_sched || total < 8 * 64) return nullptr;
+    std::vector<TileDims> probs;
+    for (int i = 0; i < a.nprob; ++i) probs.push_back({a.p[i].tiles_x, (height(a, i) + th - 1) / th, a.p[i].tile_begin});
+    return xcd_schedule(m, probs, total, pad8, n_units);
+}
+
 // ---- kernel launchers: every launch covers one layer of a LIST of problems (pages x scales) -----------------
 typedef std::vector<Tensor> TL;
 
@@ -359,6 +414,12 @@ std::string dims_of(const TL& l) {
     return d;
 }
 
+// XCD-aware table of a launch over ConvArgs problems whose tiles are th input rows high (tiles_x / tile_begin already set); grids whose
+// y dimension counts output-channel blocks are padded to a multiple of 8 tiles (units) so that a tile's XCD does not depend on y
+const int32_t* conv_schedule(asep_aru* m, const ConvArgs& a, int th, int total, bool pad8, int* n_units) {
+    return oneshot_schedule<ConvArgs>(m, a, th, total, pad8, n_units, [](const ConvArgs& q, int i) { return q.p[i].H; });
+}
+
 // launches conv_mfma_kernel<...> and gives the profiler record that instantiation's exact name
 #define ASEP_CONV_LAUNCH(KH_, KW_, MT_, C8_, TH_, DB_, BF_, C12_, MB_)                                                   \
     do {                                                                                                                 \
@@ -370,7 +431,7 @@ template <int KH, int KW>
 void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, int total_tiles, double flops, double bytes,
                    const std::string& scope, const TL& in0, bool big_tile) {
     const int mt = pc.c8 ? 1 : (pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1));
-    dim3 grid(total_tiles, pc.mtiles / mt);
+    dim3 grid(total_tiles, pc.mtiles / mt);                  // (total_tiles = the schedule's units: padded to 8 when grid.y > 1)
     ProfScope ps(m, "conv_mfma_kernel", flops, scope + " " + dims_of(in0) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
     ps.bytes = bytes;
     hipStream_t s = m->stream;
@@ -443,6 +504,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             a.c0 = pc.cin; a.cout = 1;
             a.wpk = (const f32x4*)pc.d_wv; a.bias = pc.d_b;
             a.relu_in = relu_in; a.relu_out = relu_out;
+            a.sched = conv_schedule(m, a, C1O_T, tiles, false, nullptr);
             ProfScope ps(m, "conv_c1out_kernel", flops, scope);
             ps.bytes = bytes;
             hipLaunchKernelGGL(conv_c1out_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
@@ -510,7 +572,9 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             }
             a.total_tiles = wt;
             const int ny = pc.mtiles / mt;
-            dim3 grid(wt, ny);
+            int wunits = wt;
+            a.sched = conv_schedule(m, a, mt == 1 ? 2 * WINO_TH : WINO_TH, wt, ny > 1, &wunits);
+            dim3 grid(wunits, ny);
             std::string pname;
             if (mt == 1) pname = "conv_winor_kernel<false,1,true>";
             else if (mt == 2 && m->wino_reg) pname = !res ? "conv_winor_kernel<false,2,false>" : "conv_winor_kernel<false,2,true>";
@@ -526,8 +590,13 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             } else if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4>), grid, dim3(256), 0, m->stream, a);
             else if (mt == 2) hipLaunchKernelGGL((conv_wino_kernel<2>), grid, dim3(256), 0, m->stream, a);
             else hipLaunchKernelGGL((conv_wino_kernel<1>), grid, dim3(256), 0, m->stream, a);
-        } else if (pc.kh == 3) launch_conv_k<3, 3>(m, pc, a, tiles, flops, bytes, scope, sub, big_tile);
-        else launch_conv_k<4, 4>(m, pc, a, tiles, flops, bytes, scope, sub, big_tile);
+        } else {
+            const int mtk = pc.c8 ? 1 : (pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1));
+            int units = tiles;
+            a.sched = conv_schedule(m, a, th, tiles, pc.mtiles / mtk > 1, &units);
+            if (pc.kh == 3) launch_conv_k<3, 3>(m, pc, a, units, flops, bytes, scope, sub, big_tile);
+            else launch_conv_k<4, 4>(m, pc, a, units, flops, bytes, scope, sub, big_tile);
+        }
     }
     if (pooled && !fuse_pool) *pooled = run_pool(m, out, POOL_MAX);
     return out;
@@ -574,7 +643,9 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
         a.wpk = (const f32x4*)pc.d_w; a.bias = pc.d_b;
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
         a.relu_in = 0; a.relu_out = relu_out;
-        dim3 grid(tiles, pc.mtiles / mt);
+        int units = tiles;
+        a.sched = conv_schedule(m, a, valu ? DCV_T : DC_TH, tiles, !valu && pc.mtiles / mt > 1, &units);
+        dim3 grid(units, pc.mtiles / mt);
         const std::string dname = valu ? std::string("deconv8v_kernel") : "deconv_mfma_kernel" + targs({ti(mt), tb(false)});
         TL sub(in.begin() + b0, in.begin() + b1);
         ProfScope ps(m, dname, flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
@@ -759,61 +830,6 @@ int pack_res8(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
 // chunks, and the k-th unit of work (k = block + i * grid) takes the (k / 8)-th tile of chunk k % 8: the 32 blocks of
 // an XCD work on spatially adjacent tiles at the same time, and on the rows just below right after, so the 8-row /
 // 14-column halo overlap of neighbouring tiles is served by that XCD's L2 instead of being fetched again.
-struct TileDims { int tx, ty, begin; };
-
-// units -> tiles for the problems' tile grids `probs` (tile numbers begin + ty * tx + x, `total` tiles in all).  The table has
-// `total` entries, or with pad8 the next multiple of 8 (surplus units hold -1: launches whose grid.y counts channel blocks keep
-// "tile t runs on XCD t % 8" for every y that way).  One-shot kernels launch one block per unit (sched_tile, bf16_kernels.h).
-const int32_t* xcd_schedule(asep_aru* m, const std::vector<TileDims>& probs, int total, bool pad8, int* n_units = nullptr) {
-    const int units = pad8 ? (total + 7) / 8 * 8 : total;
-    if (n_units) *n_units = units;
-    std::string key = pad8 ? "p" : "u";
-    for (const TileDims& q : probs) key += ":" + std::to_string(q.tx) + "x" + std::to_string(q.ty);
-    auto it = m->sched_cache.find(key);
-    if (it != m->sched_cache.end()) return it->second;
-    std::vector<int32_t> order;
-    order.reserve(total);
-    for (const TileDims& q : probs)
-        for (int gc = 0; gc * 8 < q.tx; ++gc)
-            for (int gr = 0; gr * 4 < q.ty; ++gr)
-                for (int r = 0; r < 4; ++r)
-                    for (int c = 0; c < 8; ++c) {
-                        const int ty = gr * 4 + r, tx = gc * 8 + c;
-                        if (ty < q.ty && tx < q.tx) order.push_back(q.begin + ty * q.tx + tx);
-                    }
-    if ((int)order.size() != total) return nullptr;
-    std::vector<int32_t> sched(units);
-    int off[9];
-    off[0] = 0;
-    for (int x = 0; x < 8; ++x) off[x + 1] = off[x] + (total - x + 7) / 8;
-    for (int k = 0; k < units; ++k) sched[k] = k / 8 < off[k % 8 + 1] - off[k % 8] ? order[off[k % 8] + k / 8] : -1;
-    int32_t* d = nullptr;
-    if (hipMalloc((void**)&d, (size_t)units * sizeof(int32_t)) != hipSuccess) return nullptr;
-    if (hipMemcpy(d, sched.data(), (size_t)units * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
-    m->owned.push_back(d);
-    m->sched_cache[key] = d;
-    return d;
-}
-
-// the persistent fp32 level-0 kernels: nblocks resident blocks, unit k = block + i * nblocks
-const int32_t* tile_schedule(asep_aru* m, const Res8Args& a, int nblocks, int unit_h) {
-    if (!m->use_xcd_sched || nblocks % 8 != 0 || a.total_tiles < 2 * nblocks) return nullptr;
-    std::vector<TileDims> probs;
-    for (int i = 0; i < a.nprob; ++i) probs.push_back({a.p[i].tiles_x, (a.p[i].H + unit_h - 1) / unit_h, a.p[i].tile_begin});
-    return xcd_schedule(m, probs, a.total_tiles, false);
-}
-
-// one-shot kernels (one block per tile): worth a table from a few waves of blocks per XCD on
-template <class Args>
-const int32_t* oneshot_schedule(asep_aru* m, const Args& a, int th, int total, bool pad8, int* n_units,
-                                int (*height)(const Args&, int)) {
-    if (n_units) *n_units = total;
-    if (!m->use_xcd_sched || total < 8 * 64) return nullptr;
-    std::vector<TileDims> probs;
-    for (int i = 0; i < a.nprob; ++i) probs.push_back({a.p[i].tiles_x, (height(a, i) + th - 1) / th, a.p[i].tile_begin});
-    return xcd_schedule(m, probs, total, pad8, n_units);
-}
-
 void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats, bool want_pool, TL* d_out, TL* pool_out) {
     for (const Tensor& t : imgs) {
         d_out->push_back(new_tensor(m, t.H, t.W, 8));

@@ -82,7 +82,16 @@ struct ConvArgs {
     int relu_in;           // apply ReLU while staging the input (pre-activation tensors)
     int relu_out;
     int skip_full;         // with p[].pool: do not store the unpooled output (nobody reads it)
+    const int32_t* sched;  // XCD-aware block -> tile table (sched_tile) or nullptr
 };
+
+// XCD-aware block -> tile map of the one-shot kernels (aru_engine.hip, xcd_schedule): workgroup b of a launch runs on XCD b % 8 and
+// every XCD has its own L2, so row-major tile numbers put the tiles that share a halo on eight different L2s and each of them
+// fetches the overlap from HBM (res8f_kernel<true>: 3.36 GB fetched for 1.57 GB of input, rocprofv3 FETCH_SIZE, round 3).  With the
+// table the blocks of one XCD walk ONE compact region of the page in 4 x 8 super-tile order.  nullptr = identity; a negative
+// entry = padding block (grids whose y dimension counts channel blocks are padded to a multiple of 8 so that the XCD of a tile
+// does not depend on blockIdx.y).
+__device__ __forceinline__ int sched_tile(const int32_t* __restrict__ sched) { return sched ? sched[blockIdx.x] : (int)blockIdx.x; }
 
 constexpr int CONV_TH = 8;
 constexpr int CONV_TW = 32;
@@ -165,10 +174,12 @@ __global__ __launch_bounds__(256, MINB) void conv_mfma_kernel(const ConvArgs a) 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
+    const int bid = sched_tile(a.sched);
+    if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
     const ConvProb& P = a.p[pi];
-    const int tile = blockIdx.x - P.tile_begin;
+    const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
     const int x0 = tx * TW, y0 = ty * TH, mt0 = blockIdx.y * MT;
     const int H = P.H, W = P.W;
@@ -493,10 +504,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 #endif
     WINO_MARK();   // 0 start
     const int j = lane & 15, kk = lane >> 4;
+    const int bid = sched_tile(a.sched);
+    if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
     const ConvProb& P = a.p[pi];
-    const int tile = blockIdx.x - P.tile_begin;
+    const int tile = bid - P.tile_begin;
     const int tyb = tile / P.tiles_x, txb = tile - tyb * P.tiles_x;
     const int x0 = txb * TW, y0 = tyb * TH, mt0 = blockIdx.y * MT;
     const int H = P.H, W = P.W;
@@ -761,10 +774,12 @@ __global__ __launch_bounds__(256, RESP ? 2 : 3) void conv_winor_kernel(const Con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, kk = lane >> 4;
     const int n = wave % NTR, mh = wave / NTR;
+    const int bid = sched_tile(a.sched);
+    if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
     const ConvProb& P = a.p[pi];
-    const int tile = blockIdx.x - P.tile_begin;
+    const int tile = bid - P.tile_begin;
     const int tyb = tile / P.tiles_x, txb = tile - tyb * P.tiles_x;
     const int x0 = txb * TW, y0 = tyb * TH, mt = blockIdx.y * MH + mh;     // this wave's 16-channel output tile
     const int H = P.H, W = P.W;
@@ -931,10 +946,12 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
+    const int bid = sched_tile(a.sched);
+    if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
     const ConvProb& P = a.p[pi];
-    const int tile = blockIdx.x - P.tile_begin;
+    const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
     const int qx0 = tx * TW, qy0 = ty * TH, mt0 = blockIdx.y * MT;
 

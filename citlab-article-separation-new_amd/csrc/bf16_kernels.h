@@ -47,14 +47,6 @@ __device__ __forceinline__ f32x4 mfma_bf16_k32(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// XCD-aware block -> tile map of the one-shot kernels (aru_engine.hip, xcd_schedule): workgroup b of a launch runs on XCD b % 8 and
-// every XCD has its own L2, so row-major tile numbers put the tiles that share a halo on eight different L2s and each of them
-// fetches the overlap from HBM (res8f_kernel<true>: 3.36 GB fetched for 1.57 GB of input, rocprofv3 FETCH_SIZE, round 3).  With the
-// table the blocks of one XCD walk ONE compact region of the page in 4 x 8 super-tile order.  nullptr = identity; a negative
-// entry = padding block (grids whose y dimension counts channel blocks are padded to a multiple of 8 so that the XCD of a tile
-// does not depend on blockIdx.y).
-__device__ __forceinline__ int sched_tile(const int32_t* __restrict__ sched) { return sched ? sched[blockIdx.x] : (int)blockIdx.x; }
-
 // ------------------------------------------------------------------------------------------------
 // convb_kernel: stride-1 SAME convolution (3x3 or 4x4), bf16 in / out, optional channel concat [in0, in1], residual,
 // ReLU on the input and / or output, 2x2 max pool of the output.

@@ -289,10 +289,26 @@ def _t_upsample(x, out_hw, up, torch):
     return s[:, :, iy][:, :, :, ix]                                # [1,1,Ho,Wo]; caller broadcasts
 
 
-def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermediates=False, bn=None):
+def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermediates=False, bn=None, storage="f32", teacher=None):
     """``bn``: optional {layer scope: (gamma, beta, moving_mean, moving_variance, epsilon)} -- inference-mode batch
     normalisation applied UNFOLDED between bias and activation (layers.py:241-242 ``batchNorm`` switch); the importer
-    folds it into the weights, this is the independent evaluation it is compared with."""
+    folds it into the weights, this is the independent evaluation it is compared with.
+
+    ``storage="bf16"``: the SAME graph with the roundings of the engine's bf16 data path (BASELINE configs[4] "bf16 convs";
+    csrc/bf16_kernels.h): the filters of the feature CNN and of the attention CNN's conv2 / conv3 are rounded to
+    bfloat16 (round to nearest even), every tensor those layers -- and the deconvolutions and the attention head -- write is rounded to
+    bfloat16 after bias and residual add (ReLU / max pool commute with the rounding), the feature CNN's first layer reads the
+    (standardised) image rounded to bfloat16; sums stay fp32, and so do biases, the attention head's and conv4's filters, the
+    channel sums, the blend over the scales, the logits layer and the soft-maxes.  This is NOT the reference's arithmetic (that is
+    ``storage="f32"``): it is the checker that tells a wrong bf16 kernel from bf16 rounding -- against it the engine's bf16 path has
+    to agree far more closely than the 2e-2 it is allowed against the fp32 graph (tests/test_full_frame_gpu.py).
+
+    ``teacher``: {end-point name: [H,W,C] array} -- "teacher forcing": every end point is still computed (and returned in the
+    intermediates) from its inputs, but then REPLACED by the teacher's tensor before anything downstream reads it.  With the engine's
+    own end points as the teacher, each returned end point is what the oracle makes of the ENGINE's upstream tensors, i.e. the
+    comparison isolates one block (conv1 + residual tail, or one deconvolution) instead of letting forty layers of flipped roundings
+    pile up -- two bf16 evaluations of the whole net that differ only in summation order drift apart almost as far as bf16 drifts
+    from fp32 (measured: rms 2.0e-3 of max|ref| against 3.4e-3), block by block they agree to a bfloat16 step on a few elements."""
     import torch
     import torch.nn.functional as F
     if num_threads:
@@ -306,6 +322,29 @@ def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermedia
         tw = {k: torch.as_tensor(v).to(dtype) for k, v in w.items()}
         H, W = x.shape[2], x.shape[3]
         inter = {}
+        if storage not in ("f32", "bf16"):
+            raise ValueError(f"storage {storage!r}")
+        emu = storage == "bf16"
+
+        def force(name, t):
+            """record the oracle's value of an end point, hand the teacher's on to the layers downstream"""
+            inter[name] = t
+            if teacher is not None and name in teacher:
+                tt = torch.as_tensor(np.asarray(teacher[name])).to(dtype)
+                tt = tt.permute(2, 0, 1)[None].contiguous()
+                if tt.shape != t.shape:
+                    raise ValueError(f"teacher tensor {name}: shape {tuple(tt.shape)}, the graph has {tuple(t.shape)}")
+                return tt
+            return t
+        q = (lambda t: t.to(torch.bfloat16).to(dtype)) if emu else (lambda t: t)      # torch rounds to nearest even
+        if emu:
+            if getattr(cfg, "activation_name", "relu") != "relu" or not getattr(cfg, "use_residual", True):
+                raise ValueError("the bf16 data path serves the ReLU residual graphs (RU / ARU) only")
+            for k in list(tw):
+                bf_filter = (k.startswith("aru_net/featMapG/") or k.startswith("aru_net/attMapG/attPart/conv2")
+                             or k.startswith("aru_net/attMapG/attPart/conv3"))
+                if bf_filter and k.endswith("/weights"):
+                    tw[k] = q(tw[k])
 
         def batch_norm(y, p):
             if not bn or p not in bn:
@@ -329,40 +368,38 @@ def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermedia
         def block(x, p):
             if not getattr(cfg, "use_residual", True):       # graph 'U' (ARU_v1.py:228-233)
                 return act(conv(act(conv(x, p + "/conv1")), p + "/conv2"))
-            t = conv(x, p + "/conv1")
+            t = q(conv(x, p + "/conv1"))
             r = F.relu(t)                                    # always a ReLU (ARU_v1.py:214)
             for a in range(cfg.res_depth):
                 r = conv(r, p + f"/convR_{a}")
                 if a < cfg.res_depth - 1:
-                    r = act(r)
-            return act(r + t)
+                    r = act(q(r))
+            return act(q(r + t))
 
         def det(x, sc):
             n = cfg.scale_space_num
             skips = []
-            u = x
+            u = q(x)                                         # bf16 path: conv1 of the first block reads the image as bfloat16
             for l in range(n):
-                d = block(u, f"aru_net/featMapG/unet_down_{l}")
+                d = force(f"scale_{sc}_unet_down_{l}_conv", block(u, f"aru_net/featMapG/unet_down_{l}"))
                 skips.append(d)
-                inter[f"scale_{sc}_unet_down_{l}_conv"] = d
                 u = F.max_pool2d(d, 2, 2, ceil_mode=True) if l < n - 1 else d
             for l in range(n - 2, -1, -1):
                 p = f"aru_net/featMapG/unet_up_{l}"
                 skip = skips[l]
-                v = act(batch_norm(_t_deconv(u, tw[p + "/deconv/weights"], tw[p + "/deconv/bias"],
-                                             skip.shape[2:], cfg.pool_size, F, torch), p + "/deconv"))
-                inter[f"scale_{sc}_unet_up_{l}_deconv"] = v
-                u = block(torch.cat([skip, v], dim=1), p)
-                inter[f"scale_{sc}_unet_up_{l}_conv"] = u
+                v = act(q(batch_norm(_t_deconv(u, tw[p + "/deconv/weights"], tw[p + "/deconv/bias"],
+                                               skip.shape[2:], cfg.pool_size, F, torch), p + "/deconv")))
+                v = force(f"scale_{sc}_unet_up_{l}_deconv", v)
+                u = force(f"scale_{sc}_unet_up_{l}_conv", block(torch.cat([skip, v], dim=1), p))
             return u
 
         def att(x):
             p = "aru_net/attMapG/attPart/conv"
-            y = act(conv(x, p + "1"))
+            y = act(q(conv(x, p + "1")))                     # (bf16 path: fp32 head, its pooled output stored as bfloat16)
             y = F.max_pool2d(y, 2, 2, ceil_mode=True)
-            y = act(conv(y, p + "2"))
+            y = act(q(conv(y, p + "2")))
             y = F.max_pool2d(y, 2, 2, ceil_mode=True)
-            y = act(conv(y, p + "3"))
+            y = act(q(conv(y, p + "3")))
             y = F.max_pool2d(y, 2, 2, ceil_mode=True)
             return act(conv(y, p + "4"))
 
@@ -377,8 +414,7 @@ def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermedia
             atts = []
             up = 8
             for s in range(cfg.num_scales_att):
-                a = att(scales[s])
-                inter[f"att_{s}"] = a
+                a = force(f"att_{s}", att(scales[s]))
                 atts.append(_t_upsample(a, (H, W), up, torch))
                 up *= 2
         feats = [det(x, 0)]

@@ -56,7 +56,8 @@ def recompute(tagdir):
     exec_fl = r["executed_flops_per_launch"]
     hbm_bound = r["bound"] == "hbm"                            # bf16 lines: the primary figures are bytes / s, the matrix ones under "mfma"
     peak = (r["mfma_peak"] if layout4 else r["mfma"]["peak"]) if hbm_bound else r["peak"]
-    achieved = exec_fl / (avg_us * 1e-6) / 1e12
+    # round 4 (layout 4), fp32: `achieved` is the ALGORITHMIC rate (direct-convolution FLOPs of the launch); before: the executed one
+    achieved = (r["flops_per_launch"] if layout4 and not hbm_bound else exec_fl) / (avg_us * 1e-6) / 1e12
     # whole page: executed FLOPs of all ARU-Net kernels per page (Winograd kernels execute 1/2.25 of their direct-conv credit)
     ev_steps = max(1, r.get("event_timed_steps", 1))
     exec_page = sum((q["flops"] / 2.25 if "wino" in q["kernel"] else q["flops"]) for q in line["kernels"]) / (B * ev_steps)

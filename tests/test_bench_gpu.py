@@ -68,6 +68,7 @@ def test_single_process_line():
     r = line["roofline"]
     assert r["frac_in_situ"] and r["frac_isolated"] and r["whole_page_executed_frac"] > 0
     assert r["frac"] == r["frac_in_situ"] and r["frac_in_situ"] <= r["frac_isolated"] * 1.05
+    assert 0 < r["executed_frac"] <= r["frac"]               # a Winograd kernel executes less than its direct-convolution credit
     assert r["kernel"] in {k["kernel"] for k in line["kernels"]} and "<" in "".join(k["kernel"] for k in line["kernels"])
 
 

@@ -149,3 +149,55 @@ def test_uint8_and_threshold_consumers():
     assert u.tolist() == [[[0, 12], [12, 12], [254, 255]]]
     assert O.apply_threshold(u, 0.05).tolist() == [[[0, 0], [0, 0], [255, 255]]]
     assert O.apply_threshold(p, 0.05).tolist() == [[[0, 0], [0, 255], [255, 255]]]
+
+
+def test_bf16_rounding_oracle_rounds_what_the_engine_stores():
+    """forward_torch(storage="bf16") (the checker of the engine's bf16 path): every tensor a bf16 kernel writes is representable in
+    bfloat16, fp32 tensors (attention maps, logits, probabilities) are not forced to be, the result stays within bf16 error of the
+    fp32 graph, and the fp32 graph itself is untouched by the option's existence."""
+    import torch
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    from oracle import aru_oracle
+    cfg = AruConfig()
+    w = init_aru_weights(cfg, 7, bias_jitter=0.05, logit_scale=1.0)
+    img = np.random.default_rng(1).random((72, 56), dtype=np.float32)
+    p32, i32 = aru_oracle.forward_torch(img, w, cfg, return_intermediates=True)
+    p16, i16 = aru_oracle.forward_torch(img, w, cfg, return_intermediates=True, storage="bf16")
+    is_bf16 = lambda a: np.array_equal(torch.as_tensor(a).to(torch.bfloat16).to(torch.float32).numpy(), a)
+    for name, t in i16.items():
+        if name.startswith("scale_"):
+            assert is_bf16(t), name
+    assert not is_bf16(i16["logits"]) and not is_bf16(i16["att_0"]) and not is_bf16(i32["scale_0_unet_down_0_conv"])
+    for name in i32:
+        if name.startswith("scale_") or name.startswith("att_"):
+            rel = np.abs(i16[name] - i32[name]).max() / max(1.0, np.abs(i32[name]).max())
+            assert 1e-5 < rel < 3e-2, (name, rel)
+    assert np.array_equal(p32, aru_oracle.forward_torch(img, w, cfg))
+    with pytest.raises(ValueError):
+        aru_oracle.forward_torch(img, w, cfg, storage="fp16")
+    with pytest.raises(ValueError):
+        aru_oracle.forward_torch(img, init_aru_weights(AruConfig(activation_name="elu"), 7), AruConfig(activation_name="elu"), storage="bf16")
+
+
+def test_teacher_forcing_isolates_one_block():
+    """forward_torch(teacher=...): every end point is computed from the TEACHER's upstream end points.  With the oracle's own end
+    points as the teacher nothing changes; with a teacher that is wrong in ONE tensor only the end points that read it directly differ
+    (the block behind it and the deconvolution / concat that take it as their input), the rest of the net does not see it."""
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    from oracle import aru_oracle
+    cfg = AruConfig(scale_space_num=3, num_scales_att=2)
+    w = init_aru_weights(cfg, 9, bias_jitter=0.05)
+    img = np.random.default_rng(2).random((40, 48), dtype=np.float32)
+    p0, i0 = aru_oracle.forward_torch(img, w, cfg, return_intermediates=True)
+    p1, i1 = aru_oracle.forward_torch(img, w, cfg, return_intermediates=True, teacher=i0)
+    assert np.array_equal(p0, p1) and all(np.array_equal(i0[k], i1[k]) for k in i0)
+    bad = dict(i0)
+    bad["scale_0_unet_down_1_conv"] = i0["scale_0_unet_down_1_conv"] + 1.0
+    _, i2 = aru_oracle.forward_torch(img, w, cfg, return_intermediates=True, teacher=bad)
+    changed = {k for k in i0 if (k.startswith("scale_") or k.startswith("att_")) and not np.array_equal(i0[k], i2[k])}
+    # readers of down_1: the next down block, and the up block of level 1 (skip connection); everything else is forced back
+    assert changed == {"scale_0_unet_down_2_conv", "scale_0_unet_up_1_conv"}, changed
+    with pytest.raises(ValueError, match="shape"):
+        aru_oracle.forward_torch(img, w, cfg, teacher={"scale_0_unet_down_0_conv": np.zeros((3, 3, 8), np.float32)})
