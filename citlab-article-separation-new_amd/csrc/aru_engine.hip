@@ -65,6 +65,7 @@ struct asep_aru {
     float* d_r8b_down_b = nullptr;   // [3][8]
     bf16_t* d_r8b_up_w1 = nullptr;   // conv1 of unet_up_0 [3 ky][2 halves][64][8]
     bf16_t* d_r8f_down_w1 = nullptr; // conv1 of unet_down_0 as ONE pair fragment [64][8] (k = window row / column, res8f_kernel)
+    float* d_r8b_down_w1r = nullptr; // the same filter [9][8] as fp32 values rounded to bfloat16 (border tiles, res8b_tile)
     bool use_r8f = true;             // ASEP_BF_R8F=0: res8b_kernel for every tile
     bool use_res32 = true;           // ASEP_BF_RES32=0: the 32-channel residual tails layer by layer (convb_kernel)
     bf16_t* d_r8b_up_w = nullptr;    // [3][3][64][8]
@@ -122,6 +123,8 @@ struct asep_aru {
     BufferPool host_stage;         // device staging of the host-pointer entry point (grow-only)
     hipStream_t host_stream = nullptr;   // transfers + forward of the host-pointer entry point (created on first use)
     bool use_xcd_sched = true;     // ASEP_XCD_SCHED=0: identity tile order in the persistent fused kernels
+    int xcd_oneshot = 2;           // ASEP_XCD_ONESHOT: block -> tile map of the one-shot kernels: 0 = identity, 1 = super-tile table,
+                                   // 2 = arithmetic bands (XcdMap, aru_kernels.h)
     std::map<std::string, const int32_t*> sched_cache;
     bool bf16 = false;             // cfg.compute_dtype == 1: native bf16 data path (bf16_kernels.h): bf16 activations in HBM / LDS,
                                    // v_mfma_f32_16x16x32_bf16 with fp32 accumulation; fp32 image in, fp32 probabilities out
@@ -384,15 +387,21 @@ const int32_t* tile_schedule(asep_aru* m, const Res8Args& a, int nblocks, int un
     return xcd_schedule(m, probs, a.total_tiles, false);
 }
 
-// one-shot kernels (one block per tile): worth a table from a few waves of blocks per XCD on
+// one-shot kernels (one block per tile): worth a map from a few waves of blocks per XCD on.  *n_units = blocks to launch along x.
 template <class Args>
-const int32_t* oneshot_schedule(asep_aru* m, const Args& a, int th, int total, bool pad8, int* n_units,
-                                int (*height)(const Args&, int)) {
+XcdMap oneshot_map(asep_aru* m, const Args& a, int th, int total, bool pad8, int* n_units, int (*height)(const Args&, int)) {
+    XcdMap xm{nullptr, 0, total};
     if (n_units) *n_units = total;
-    if (!m->use_xcd_sched || total < 8 * 64) return nullptr;
+    if (!m->use_xcd_sched || m->xcd_oneshot == 0 || total < 8 * 64) return xm;
+    if (m->xcd_oneshot == 2) {                               // arithmetic bands: the grid is always padded to eight equal chunks
+        xm.chunk = (total + 7) / 8;
+        if (n_units) *n_units = 8 * xm.chunk;
+        return xm;
+    }
     std::vector<TileDims> probs;
     for (int i = 0; i < a.nprob; ++i) probs.push_back({a.p[i].tiles_x, (height(a, i) + th - 1) / th, a.p[i].tile_begin});
-    return xcd_schedule(m, probs, total, pad8, n_units);
+    xm.table = xcd_schedule(m, probs, total, pad8, n_units);
+    return xm;
 }
 
 // ---- kernel launchers: every launch covers one layer of a LIST of problems (pages x scales) -----------------
@@ -416,8 +425,8 @@ std::string dims_of(const TL& l) {
 
 // XCD-aware table of a launch over ConvArgs problems whose tiles are th input rows high (tiles_x / tile_begin already set); grids whose
 // y dimension counts output-channel blocks are padded to a multiple of 8 tiles (units) so that a tile's XCD does not depend on y
-const int32_t* conv_schedule(asep_aru* m, const ConvArgs& a, int th, int total, bool pad8, int* n_units) {
-    return oneshot_schedule<ConvArgs>(m, a, th, total, pad8, n_units, [](const ConvArgs& q, int i) { return q.p[i].H; });
+XcdMap conv_schedule(asep_aru* m, const ConvArgs& a, int th, int total, bool pad8, int* n_units) {
+    return oneshot_map<ConvArgs>(m, a, th, total, pad8, n_units, [](const ConvArgs& q, int i) { return q.p[i].H; });
 }
 
 // launches conv_mfma_kernel<...> and gives the profiler record that instantiation's exact name
@@ -504,10 +513,11 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             a.c0 = pc.cin; a.cout = 1;
             a.wpk = (const f32x4*)pc.d_wv; a.bias = pc.d_b;
             a.relu_in = relu_in; a.relu_out = relu_out;
-            a.sched = conv_schedule(m, a, C1O_T, tiles, false, nullptr);
+            int units = tiles;
+            a.xm = conv_schedule(m, a, C1O_T, tiles, false, &units);
             ProfScope ps(m, "conv_c1out_kernel", flops, scope);
             ps.bytes = bytes;
-            hipLaunchKernelGGL(conv_c1out_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
+            hipLaunchKernelGGL(conv_c1out_kernel, dim3(units), dim3(256), 0, m->stream, a);
         }
         return out1;
     }
@@ -573,7 +583,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             a.total_tiles = wt;
             const int ny = pc.mtiles / mt;
             int wunits = wt;
-            a.sched = conv_schedule(m, a, mt == 1 ? 2 * WINO_TH : WINO_TH, wt, ny > 1, &wunits);
+            a.xm = conv_schedule(m, a, mt == 1 ? 2 * WINO_TH : WINO_TH, wt, ny > 1, &wunits);
             dim3 grid(wunits, ny);
             std::string pname;
             if (mt == 1) pname = "conv_winor_kernel<false,1,true>";
@@ -593,7 +603,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
         } else {
             const int mtk = pc.c8 ? 1 : (pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1));
             int units = tiles;
-            a.sched = conv_schedule(m, a, th, tiles, pc.mtiles / mtk > 1, &units);
+            a.xm = conv_schedule(m, a, th, tiles, pc.mtiles / mtk > 1, &units);
             if (pc.kh == 3) launch_conv_k<3, 3>(m, pc, a, units, flops, bytes, scope, sub, big_tile);
             else launch_conv_k<4, 4>(m, pc, a, units, flops, bytes, scope, sub, big_tile);
         }
@@ -644,7 +654,7 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
         a.relu_in = 0; a.relu_out = relu_out;
         int units = tiles;
-        a.sched = conv_schedule(m, a, valu ? DCV_T : DC_TH, tiles, !valu && pc.mtiles / mt > 1, &units);
+        a.xm = conv_schedule(m, a, valu ? DCV_T : DC_TH, tiles, !valu && pc.mtiles / mt > 1, &units);
         dim3 grid(units, pc.mtiles / mt);
         const std::string dname = valu ? std::string("deconv8v_kernel") : "deconv_mfma_kernel" + targs({ti(mt), tb(false)});
         TL sub(in.begin() + b0, in.begin() + b1);
@@ -652,7 +662,7 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
         ps.bytes = bytes;
         if (valu) {
             a.wpk = (const f32x4*)pc.d_wv;
-            hipLaunchKernelGGL(deconv8v_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
+            hipLaunchKernelGGL(deconv8v_kernel, dim3(units), dim3(256), 0, m->stream, a);
         } else if (mt == 2) hipLaunchKernelGGL((deconv_mfma_kernel<2>), grid, dim3(256), 0, m->stream, a);
         else hipLaunchKernelGGL((deconv_mfma_kernel<1>), grid, dim3(256), 0, m->stream, a);
     }
@@ -1071,6 +1081,14 @@ int pack_res8b(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
             rc = upload_bf(pk, &m->d_r8f_down_w1);
             if (rc) return rc;
             m->owned.push_back(m->d_r8f_down_w1);
+            std::vector<float> wr(w1->second.data.size());
+            for (size_t i = 0; i < wr.size(); ++i) {
+                const uint32_t u = (uint32_t)f2bf(w1->second.data[i]) << 16;
+                memcpy(&wr[i], &u, 4);
+            }
+            rc = upload(wr, &m->d_r8b_down_w1r);
+            if (rc) return rc;
+            m->owned.push_back(m->d_r8b_down_w1r);
         }
     }
     if (m->cfg.scale_space_num > 1) {
@@ -1121,9 +1139,10 @@ void run_res8b(asep_aru* m, bool up, const TL& a0, const TL* a1, const std::vect
         }
         a.nprob = (int)(b1 - b0);
         if (up) { a.w1pk = (const u32x4*)m->d_r8b_up_w1; a.b1 = m->d_r8b_up_b1; a.wpk = (const u32x4*)m->d_r8b_up_w; a.bias = m->d_r8b_up_b; }
-        else { a.w1 = m->det_first.d_w; a.b1 = m->det_first.d_b; a.wpk = (const u32x4*)m->d_r8b_down_w; a.bias = m->d_r8b_down_b; }
+        else { a.w1 = m->d_r8b_down_w1r ? m->d_r8b_down_w1r : m->det_first.d_w; a.b1 = m->det_first.d_b; a.wpk = (const u32x4*)m->d_r8b_down_w; a.bias = m->d_r8b_down_b; }
         TL sub(a0.begin() + b0, a0.begin() + b1);
-        a.sched = oneshot_schedule<Res8BArgs>(m, a, 16, tiles, false, nullptr, [](const Res8BArgs& q, int i) { return q.p[i].H; });
+        int units = tiles;
+        a.xm = oneshot_map<Res8BArgs>(m, a, 16, tiles, false, &units, [](const Res8BArgs& q, int i) { return q.p[i].H; });
         const std::string what = (up ? "unet_up_0 (conv1[16->8]+3xconvR+add) " : "unet_down_0 (conv1+3xconvR+add+pool) ") + dims_of(sub);
         if (m->use_r8f && (up || m->d_r8f_down_w1)) {
             // lean form for interior tiles (their 24 x 40 input window inside the image), general form for border tiles, one launch
@@ -1131,13 +1150,13 @@ void run_res8b(asep_aru* m, bool up, const TL& a0, const TL* a1, const std::vect
             if (!up) f.w1pk = (const u32x4*)m->d_r8f_down_w1;
             ProfScope ps(m, up ? "res8f_kernel<true>" : "res8f_kernel<false>", flops, what);
             ps.bytes = bytes;
-            if (up) hipLaunchKernelGGL(res8f_kernel<true>, dim3(tiles), dim3(256), 0, m->stream, f);
-            else hipLaunchKernelGGL(res8f_kernel<false>, dim3(tiles), dim3(256), 0, m->stream, f);
+            if (up) hipLaunchKernelGGL(res8f_kernel<true>, dim3(units), dim3(256), 0, m->stream, f);
+            else hipLaunchKernelGGL(res8f_kernel<false>, dim3(units), dim3(256), 0, m->stream, f);
         } else {
             ProfScope ps(m, up ? "res8b_kernel<true>" : "res8b_kernel<false>", flops, what);
             ps.bytes = bytes;
-            if (up) hipLaunchKernelGGL(res8b_kernel<true>, dim3(tiles), dim3(256), 0, m->stream, a);
-            else hipLaunchKernelGGL(res8b_kernel<false>, dim3(tiles), dim3(256), 0, m->stream, a);
+            if (up) hipLaunchKernelGGL(res8b_kernel<true>, dim3(units), dim3(256), 0, m->stream, a);
+            else hipLaunchKernelGGL(res8b_kernel<false>, dim3(units), dim3(256), 0, m->stream, a);
         }
     }
 }
@@ -1218,7 +1237,7 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = cin / 32;
         a.relu_in = relu_in; a.relu_out = relu_out; a.skip_full = pooled && !keep_full; a.pool_f32 = pool_f32;
         int units = tiles;
-        a.sched = oneshot_schedule<ConvBArgs>(m, a, th, tiles, pc.mtiles / mtb > 1, &units, [](const ConvBArgs& q, int i) { return q.p[i].H; });
+        a.xm = oneshot_map<ConvBArgs>(m, a, th, tiles, pc.mtiles / mtb > 1, &units, [](const ConvBArgs& q, int i) { return q.p[i].H; });
         dim3 grid(units, pc.mtiles / mtb);
         TL sub(in0.begin() + b0, in0.begin() + b1);
         ProfScope ps(m, "convb_kernel", flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
@@ -1279,7 +1298,14 @@ TL run_resb_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled)
         }
         a.nprob = (int)(b1 - b0);
         a.wpk = (const u32x4*)rb.d_w; a.bias = rb.d_b;
-        a.sched = oneshot_schedule<ResBArgs>(m, a, RB_TH, tiles, false, nullptr, [](const ResBArgs& q, int i) { return q.p[i].H; });
+        int units = tiles;
+        if (rb.C == 32) {                                    // persistent kernel: table (its units are walked with a grid stride)
+            std::vector<TileDims> probs;
+            for (int i = 0; i < a.nprob; ++i) probs.push_back({a.p[i].tiles_x, cdiv(a.p[i].H, RB_TH), a.p[i].tile_begin});
+            a.sched = (m->use_xcd_sched && m->xcd_oneshot && tiles >= 8 * 64) ? xcd_schedule(m, probs, tiles, false) : nullptr;
+        } else {
+            a.xm = oneshot_map<ResBArgs>(m, a, RB_TH, tiles, false, &units, [](const ResBArgs& q, int i) { return q.p[i].H; });
+        }
         TL sub(t.begin() + b0, t.begin() + b1);
         const std::string what = scope + " (3xconvR+add" + (pooled ? "+pool) " : ") ") + dims_of(sub);
         if (rb.C == 32) {
@@ -1295,12 +1321,12 @@ TL run_resb_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled)
         } else if (rb.C == 16 && m->use_r8f) {                      // lean form for interior tiles, general form for border tiles, one launch
             ProfScope ps(m, "res16f_kernel", flops, what);
             ps.bytes = bytes;
-            hipLaunchKernelGGL(res16f_kernel, dim3(tiles), dim3(256), 0, m->stream, a);
+            hipLaunchKernelGGL(res16f_kernel, dim3(units), dim3(256), 0, m->stream, a);
         } else {
             ProfScope ps(m, "resb_tail_kernel" + targs({ti(rb.C)}), flops, what);
             ps.bytes = bytes;
-            if (rb.C == 8) hipLaunchKernelGGL(resb_tail_kernel<8>, dim3(tiles), dim3(256), 0, m->stream, a);
-            else hipLaunchKernelGGL(resb_tail_kernel<16>, dim3(tiles), dim3(256), 0, m->stream, a);
+            if (rb.C == 8) hipLaunchKernelGGL(resb_tail_kernel<8>, dim3(units), dim3(256), 0, m->stream, a);
+            else hipLaunchKernelGGL(resb_tail_kernel<16>, dim3(units), dim3(256), 0, m->stream, a);
         }
     }
     return out;
@@ -1345,7 +1371,7 @@ TL run_deconvb(asep_aru* m, const std::string& scope, const TL& in, const TL& li
         a.wpk = (const u32x4*)pc.d_wb; a.bias = pc.d_b;
         a.cin = pc.cin; a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.cin / 32; a.relu_out = relu_out;
         int units = tiles;
-        a.sched = oneshot_schedule<DeconvBArgs>(m, a, dth, tiles, pc.mtiles / mt > 1, &units, [](const DeconvBArgs& q, int i) { return q.p[i].Hi; });
+        a.xm = oneshot_map<DeconvBArgs>(m, a, dth, tiles, pc.mtiles / mt > 1, &units, [](const DeconvBArgs& q, int i) { return q.p[i].Hi; });
         dim3 grid(units, pc.mtiles / mt);
         TL sub(in.begin() + b0, in.begin() + b1);
         ProfScope ps(m, "deconvb_kernel" + targs({ti(pc.bmode), ti(mt), ti(dth)}), flops,
@@ -1704,8 +1730,13 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
             ca.softmax = cfg.apply_softmax;
             ca.tiles_x = cdiv(W, COMBINE_TW);
             const int ctiles = ca.tiles_x * cdiv(H, 16);
-            ca.sched = (m->use_xcd_sched && ctiles >= 8 * 64) ? xcd_schedule(m, {{ca.tiles_x, cdiv(H, 16), 0}}, ctiles, false) : nullptr;
-            dim3 grid(ctiles);
+            ca.xm = XcdMap{nullptr, 0, ctiles};
+            int cunits = ctiles;
+            if (m->use_xcd_sched && ctiles >= 8 * 64) {
+                if (m->xcd_oneshot == 2) { ca.xm.chunk = (ctiles + 7) / 8; cunits = 8 * ca.xm.chunk; }
+                else if (m->xcd_oneshot == 1) ca.xm.table = xcd_schedule(m, {{ca.tiles_x, cdiv(H, 16), 0}}, ctiles, false);
+            }
+            dim3 grid(cunits);
             // number of scales as a template constant (1 = no attention, 3 = the default ARU-Net) with 32-bit offsets, for tensors
             // below 4 GB; anything else takes the run-time form
             const bool small = (size_t)H * W * std::max(cfg.feat_root, cfg.n_classes) * sizeof(float) < ((size_t)1 << 32);
@@ -1853,6 +1884,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (variant) m->use_fused8 = false;                      // the fused level-0 blocks / attention head are ReLU residual kernels
     if (const char* e = getenv("ASEP_R8_VALU")) m->r8_valu = atoi(e) != 0;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_XCD_ONESHOT")) m->xcd_oneshot = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("ASEP_BIGTILE")) m->big_tile = atoi(e) != 0;
     if (const char* e = getenv("ASEP_SIDE_STREAM")) m->use_side_stream = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_TH8")) m->bf_th8 = atoi(e) != 0;

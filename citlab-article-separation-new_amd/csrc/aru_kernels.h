@@ -53,6 +53,29 @@ __device__ __forceinline__ f32x4 mfma_bf16(s16x4 a, s16x4 b, f32x4 c) {
 //               are 48 contiguous floats = 3 chunks with no padding: chunk = (ky, c), slot s -> float 16c + s of that run
 //               (kx = (16c + s) / 12, channel (16c + s) % 12): 12 instead of 16 chunks
 // One lane's 16-byte LDS read / 16-byte weight load therefore feeds four MFMAs.
+// XCD-aware block -> tile map of the one-shot kernels (aru_engine.hip, oneshot_map): workgroup b of a launch runs on XCD b % 8 and
+// every XCD has its own L2, so row-major tile numbers put the tiles that share a halo on eight different L2s and each of them
+// fetches the overlap from HBM (res8f_kernel<true>: 3.36 GB fetched for 1.57 GB of input, rocprofv3 FETCH_SIZE, round 3).
+//   table: unit -> tile, the tiles of every problem in 4 x 8 super-tile order cut into eight chunks (one scalar load per block:
+//          the tile's address arithmetic waits for it -- measured, that costs what the saved traffic of kernels that are not
+//          HBM-bound gives back, and more);
+//   chunk: the arithmetic form -- XCD x takes the x-th eighth of the ROW-MAJOR tile list (a horizontal band of the pages), block
+//          b = tile (b & 7) * chunk + (b >> 3); grids are padded to 8 * chunk blocks, blocks beyond the last tile leave at once.
+//          No memory access; left / right halos are shared inside the band, the row above is one band row back in the same L2.
+// Neither: identity.  A negative result = padding block.
+struct XcdMap {
+    const int32_t* table;
+    int chunk, total;
+};
+__device__ __forceinline__ int sched_tile(const XcdMap& x) {
+    if (x.table) return x.table[blockIdx.x];
+    if (x.chunk) {
+        const int t = (int)(blockIdx.x & 7) * x.chunk + (int)(blockIdx.x >> 3);
+        return t < x.total ? t : -1;
+    }
+    return (int)blockIdx.x;
+}
+
 // ------------------------------------------------------------------------------------------------
 // One launch covers the same layer of several independent "problems" (pages x scale-space levels share
 // the layer's weights): blockIdx.x walks the concatenated tile lists, blockIdx.y the output-channel blocks.
@@ -82,16 +105,8 @@ struct ConvArgs {
     int relu_in;           // apply ReLU while staging the input (pre-activation tensors)
     int relu_out;
     int skip_full;         // with p[].pool: do not store the unpooled output (nobody reads it)
-    const int32_t* sched;  // XCD-aware block -> tile table (sched_tile) or nullptr
+    XcdMap xm;             // XCD-aware block -> tile map (sched_tile)
 };
-
-// XCD-aware block -> tile map of the one-shot kernels (aru_engine.hip, xcd_schedule): workgroup b of a launch runs on XCD b % 8 and
-// every XCD has its own L2, so row-major tile numbers put the tiles that share a halo on eight different L2s and each of them
-// fetches the overlap from HBM (res8f_kernel<true>: 3.36 GB fetched for 1.57 GB of input, rocprofv3 FETCH_SIZE, round 3).  With the
-// table the blocks of one XCD walk ONE compact region of the page in 4 x 8 super-tile order.  nullptr = identity; a negative
-// entry = padding block (grids whose y dimension counts channel blocks are padded to a multiple of 8 so that the XCD of a tile
-// does not depend on blockIdx.y).
-__device__ __forceinline__ int sched_tile(const int32_t* __restrict__ sched) { return sched ? sched[blockIdx.x] : (int)blockIdx.x; }
 
 constexpr int CONV_TH = 8;
 constexpr int CONV_TW = 32;
@@ -174,7 +189,7 @@ __global__ __launch_bounds__(256, MINB) void conv_mfma_kernel(const ConvArgs a) 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
-    const int bid = sched_tile(a.sched);
+    const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
     while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
@@ -504,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 #endif
     WINO_MARK();   // 0 start
     const int j = lane & 15, kk = lane >> 4;
-    const int bid = sched_tile(a.sched);
+    const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
     while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
@@ -774,7 +789,7 @@ __global__ __launch_bounds__(256, RESP ? 2 : 3) void conv_winor_kernel(const Con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, kk = lane >> 4;
     const int n = wave % NTR, mh = wave / NTR;
-    const int bid = sched_tile(a.sched);
+    const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
     while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
@@ -946,7 +961,7 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
-    const int bid = sched_tile(a.sched);
+    const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
     while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
@@ -1471,8 +1486,8 @@ struct CombineArgs {
     uint8_t* out_mask;               // optional
     double thr255;
     int softmax;
-    int tiles_x;                     // 32-pixel tile columns; the grid is one-dimensional: tile = sched ? sched[block] : block
-    const int32_t* sched;            // XCD-aware block -> tile table (aru_engine.hip, xcd_schedule) or nullptr
+    int tiles_x;                     // 32-pixel tile columns; the grid is one-dimensional
+    XcdMap xm;                       // XCD-aware block -> tile map (sched_tile)
 };
 
 constexpr int COMBINE_TW = 32;   // tile width of combine_kernel (16 rows)
@@ -1500,7 +1515,8 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
     };
     __shared__ float swl[16 * FR * NC + NC];
     const int tid = threadIdx.x;
-    const int bid = a.sched ? a.sched[blockIdx.x] : (int)blockIdx.x;
+    const int bid = sched_tile(a.xm);
+    if (bid < 0) return;
     const int tyb = bid / a.tiles_x;
     const int x0 = (bid - tyb * a.tiles_x) * TW, y0 = tyb * T;
     if (tid < NC) swl[16 * FR * NC + tid] = a.bl[tid];

@@ -31,6 +31,8 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 __device__ __forceinline__ u32x2 pack_bf16x4(f32x4 v) { return u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}; }
+// a float rounded to bfloat16 (nearest even) and widened again
+__device__ __forceinline__ float round_bf16(float v) { return __uint_as_float(pack_bf16x2(v, 0.f) << 16); }
 __device__ __forceinline__ f32x4 unpack_bf16x4(u32x2 p) {
     return f32x4{__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xffff0000u), __uint_as_float(p.y << 16), __uint_as_float(p.y & 0xffff0000u)};
 }
@@ -72,7 +74,7 @@ struct ConvBArgs {
     int c0, c1;            // channels of in0 / in1 (multiples of 8)
     int cout, mtiles, groups;
     int relu_in, relu_out, skip_full, pool_f32;
-    const int32_t* sched;  // block -> tile (sched_tile) or nullptr
+    XcdMap xm;             // XCD-aware block -> tile map (sched_tile)
 };
 
 // Waves: WM along the output channels x 4 / WM along the pixels; wave (wm, wn) owns m-tiles wm MT .. and n-tiles id = wn NT + n
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
     const int j = lane & 15, kk = lane >> 4;
     CVB_MARK(0);
     const int wm = WM == 2 ? (wave & 1) : 0, wn = WM == 2 ? (wave >> 1) : wave;
-    const int bid = sched_tile(a.sched);
+    const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
     while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
@@ -371,7 +373,8 @@ struct ResBArgs {
     const u32x4* wpk;      // [3 convs][CPC chunks][64 lanes] x 16 bytes
     const float* bias;     // [3][C]
     int ntiles;            // res32_tail_kernel: all problems' tiles (its resident blocks walk them)
-    const int32_t* sched;  // block (res32_tail_kernel: work unit) -> tile (sched_tile) or nullptr
+    XcdMap xm;             // XCD-aware block -> tile map (sched_tile)
+    const int32_t* sched;  // res32_tail_kernel (persistent): work unit -> tile table or nullptr
 };
 constexpr int RB_TH = 16, RB_TW = 32;
 
@@ -513,8 +516,9 @@ __device__ __forceinline__ void resb_tail_tile(const ResBArgs& a, const ResBProb
 
 template <int C>
 __global__ __launch_bounds__(256, C == 8 ? 4 : 3) void resb_tail_kernel(const ResBArgs a) {
-    const int bid = sched_tile(a.sched);
+    const int bid = sched_tile(a.xm);
     __shared__ __attribute__((aligned(16))) unsigned char lds[ResBLayout<C>::BYTES];
+    if (bid < 0) return;
     int pi = 0;
     while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
     const ResBProb& P = a.p[pi];
@@ -749,7 +753,8 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
-    const int bid = sched_tile(a.sched);
+    const int bid = sched_tile(a.xm);
+    if (bid < 0) return;
     int pi = 0;
     while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
     const ResBProb& P = a.p[pi];
@@ -929,7 +934,7 @@ struct DeconvBArgs {
     const float* bias;
     int cin, cout, mtiles, groups;
     int relu_out;
-    const int32_t* sched;  // block -> tile (sched_tile) or nullptr
+    XcdMap xm;             // XCD-aware block -> tile map (sched_tile)
 };
 constexpr int DCB_TW = 16;                                    // input columns per block; rows: template parameter TH (8 or 16)
 
@@ -947,7 +952,7 @@ __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
-    const int bid = sched_tile(a.sched);
+    const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
     while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
@@ -1126,12 +1131,12 @@ struct Res8BProb {
 struct Res8BArgs {
     Res8BProb p[MAXP];
     int nprob;
-    const float* w1;       // DOWN: conv1 [9][8] fp32
+    const float* w1;       // DOWN: conv1 [9][8] fp32 values rounded to bfloat16 (border tiles; the interior tiles' fragment is w1pk)
     const float* b1;       // conv1 bias [8]
     const u32x4* w1pk;     // UP: conv1 pair fragments [ky 3][half 2][64 lanes] x 16 bytes; res8f_kernel DOWN: [64 lanes] (bf16 conv1)
     const u32x4* wpk;      // tail: [3 convs][ky 3][64 lanes] x 16 bytes
     const float* bias;     // tail biases [3][8]
-    const int32_t* sched;  // block -> tile (sched_tile) or nullptr
+    XcdMap xm;             // XCD-aware block -> tile map (sched_tile)
 };
 
 template <bool UP>
@@ -1200,7 +1205,10 @@ __device__ __forceinline__ void res8b_tile(const Res8BArgs& a, const Res8BProb& 
             if (u < IH * IW) {
                 const int ly = u / IW, lx = u - ly * IW;
                 const int gy = y0 - 4 + ly, gx = x0 - 4 + lx;
-                reinterpret_cast<float*>(in)[u] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (st[i] - mean) * inv : 0.f;
+                // the (standardised) image as bfloat16, like the interior tiles' MFMA form reads it (res8f_kernel): the first layer is
+                // ONE function of the page, not one per tile kind -- no seam between border and interior tiles (a.w1 holds the filter
+                // rounded to bfloat16 as well; products of two bfloat16 are exact in fp32, only the order of the sum differs)
+                reinterpret_cast<float*>(in)[u] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? round_bf16((st[i] - mean) * inv) : 0.f;
             }
         }
     }
@@ -1360,7 +1368,8 @@ __device__ __forceinline__ void res8b_tile(const Res8BArgs& a, const Res8BProb& 
 template <bool UP>
 __global__ __launch_bounds__(256, UP ? 3 : 4) void res8b_kernel(const Res8BArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[Res8BLayout<UP>::BYTES];
-    const int bid = sched_tile(a.sched);
+    const int bid = sched_tile(a.xm);
+    if (bid < 0) return;
     int pi = 0;
     while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
     const Res8BProb& P = a.p[pi];
@@ -1407,7 +1416,8 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     R8F_MARK(0);
     const int j = lane & 15, kk = lane >> 4, e = kk >> 1, ch = (kk & 1) * 4;     // D layout: pixel parity e, channels ch .. ch + 3
-    const int bid = sched_tile(a.sched);
+    const int bid = sched_tile(a.xm);
+    if (bid < 0) return;
     int pi = 0;
     while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
     const Res8BProb& P = a.p[pi];

@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256) void deconv8v_kernel(const ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * T * 2 * T * 8];
     static_assert(L * L * 16 <= 2 * T * 2 * T * 8, "input tile must fit");
     const int tid = threadIdx.x;
-    const int bid = sched_tile(a.sched);
+    const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
     while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256) void conv_c1out_kernel(const ConvArgs a) {
     constexpr int T = C1O_T, L = T + 3, CIN = 32, Q = CIN / 4;   // 4x4 SAME: pad 1 before, 2 after
     __shared__ __attribute__((aligned(16))) float lds[L * L * CIN];
     const int tid = threadIdx.x;
-    const int bid = sched_tile(a.sched);
+    const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
     while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
