@@ -114,7 +114,7 @@ def unit_scale_page():
 # what the bf16 path holds on a whole 3000 x 4500 frame with unit logit scale (measured values in DESIGN section 2; gates ~1.5x above)
 BF16_ENDPOINT_GATE = 3e-2        # max|d| / max|ref| per end point (measured 8e-3 .. 2.1e-2; fp32: 2e-5)
 BF16_ENDPOINT_RMS_GATE = 5e-3    # rms(d) / max|ref| per end point (measured 1e-3 .. 3.4e-3)
-BF16_LOGIT_GATE = 2e-2           # max|d logits| / max|logits| (measured 1.4e-2 at max|logit| 31, i.e. 0.44 in the logit margin)
+BF16_LOGIT_GATE = 2.5e-2         # max|d logits| / max|logits| (measured 1.4e-2 .. 1.6e-2 at max|logit| 24 .. 31, i.e. ~0.4 in the logit margin)
 BF16_PROB_GATE = 0.15            # max|dp| (measured 0.099): a margin error of 0.44 at p = 0.5 is dp = 0.11 (the stated 2e-2 is the gate of
                                  # logit_scale 0.05 weights, whose margins -- and margin errors -- are 20x smaller)
 BF16_MASK_RATE_GATE = 1.2e-2     # share of threshold-mask pixels that differ at p = 0.5 on a mask WITHOUT margin: the threshold cuts the
@@ -178,8 +178,9 @@ def test_whole_page_bf16_end_points_logits_and_masks_with_unit_logit_scale(unit_
     assert np.array_equal(u8, aru_oracle.to_uint8(out)) and np.array_equal(mask, aru_oracle.apply_threshold(u8, 0.5))
 
 
-BF16_BLOCK_FRAME_MAX_GATE = 8e-3        # whole frame, block by block against the oracle with the engine's roundings: max|d| / max|ref|
-BF16_BLOCK_FRAME_RMS_GATE = 4e-4        # rms(d) / max|ref| (free running against the same oracle: 2.0e-3; against the fp32 oracle: 3.4e-3)
+BF16_BLOCK_FRAME_MAX_GATE = 1.2e-2      # whole frame, block by block against the oracle with the engine's roundings: max|d| / max|ref|
+                                        # (measured 7.5e-3: two bfloat16 steps of the largest value of one tensor)
+BF16_BLOCK_FRAME_RMS_GATE = 2e-4        # rms(d) / max|ref| (measured 1.0e-4; free running against the same oracle: 2.0e-3; fp32 oracle: 3.4e-3)
 
 
 def test_whole_page_bf16_block_by_block_against_the_oracle_with_the_same_roundings(unit_scale_page):
