@@ -133,6 +133,7 @@ struct asep_aru {
     bool big_tile2 = true;         // ASEP_BIGTILE2=0: 8 x 32 double-buffered blocks for 32 -> 16 convs without residual operand
     bool use_c12 = true;           // ASEP_C12=0: 12-channel inputs padded to a 16-channel group (read when the weights are packed)
     bool fuse_pool = true;         // ASEP_FUSE_POOL=0: separate maxpool2_kernel after every conv
+    bool fuse_act = true;          // ASEP_FUSE_ACT=0: elu / leaky of the graph variants as a separate act_kernel pass behind every conv
     bool wino16 = false;           // ASEP_WINO16=1: register-resident Winograd also at the 16-channel level (measured: 99 vs
                                    // 103 TFLOP/s-equivalent for the direct kernels, parity-green; kept as an experiment switch)
     bool bf_th8 = true;            // ASEP_BF_TH8=0: 16 x 32 instead of 8 x 32 pixel blocks for the 32-channel bf16 convs
@@ -476,7 +477,7 @@ TL run_pool(asep_aru* m, const TL& in, PoolKind kind);
 // reads only the pooled tensor (attention CNN), so the unpooled one is not stored (and the returned list is empty) when the
 // pool is fused.
 TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1, bool relu_in, bool relu_out,
-            const TL* res, TL* pooled = nullptr, bool keep_full = true) {
+            const TL* res, TL* pooled = nullptr, bool keep_full = true, int act = 0) {
     auto it = m->convs.find(scope);
     if (it == m->convs.end()) { set_error("internal: conv %s not packed", scope.c_str()); throw ArgError(); }
     const PackedConv& pc = it->second;
@@ -512,7 +513,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             a.total_tiles = tiles;
             a.c0 = pc.cin; a.cout = 1;
             a.wpk = (const f32x4*)pc.d_wv; a.bias = pc.d_b;
-            a.relu_in = relu_in; a.relu_out = relu_out;
+            a.relu_in = relu_in; a.relu_out = relu_out; a.act = act;
             int units = tiles;
             a.xm = conv_schedule(m, a, C1O_T, tiles, false, &units);
             ProfScope ps(m, "conv_c1out_kernel", flops, scope);
@@ -559,7 +560,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
         a.c0 = in0[0].C; a.c1 = in1 ? (*in1)[0].C : 0;
         a.wpk = (const f32x4*)pc.d_w; a.bias = pc.d_b;
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
-        a.relu_in = relu_in; a.relu_out = relu_out;
+        a.relu_in = relu_in; a.relu_out = relu_out; a.act = act;
         a.skip_full = fuse_pool && !keep_full;
         TL sub(in0.begin() + b0, in0.begin() + b1);
         if (wino) {
@@ -613,7 +614,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
 }
 
 // conv2d_transpose 3x3 stride 2 SAME to the spatial sizes of `like` (ARU_v1.py:255-259)
-TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& like, bool relu_out) {
+TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& like, bool relu_out, int act = 0) {
     auto it = m->convs.find(scope);
     if (it == m->convs.end()) { set_error("internal: deconv %s not packed", scope.c_str()); throw ArgError(); }
     const PackedConv& pc = it->second;
@@ -652,7 +653,7 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
         a.c0 = in[0].C; a.c1 = 0;
         a.wpk = (const f32x4*)pc.d_w; a.bias = pc.d_b;
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
-        a.relu_in = 0; a.relu_out = relu_out;
+        a.relu_in = 0; a.relu_out = relu_out; a.act = act;
         int units = tiles;
         a.xm = conv_schedule(m, a, valu ? DCV_T : DC_TH, tiles, !valu && pc.mtiles / mt > 1, &units);
         dim3 grid(units, pc.mtiles / mt);
@@ -670,7 +671,7 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
 }
 
 // first layer (Cin == 1); stats[i] = per-problem {mean, 1/std} pointer or nullptr
-TL run_direct(asep_aru* m, const DirectConv& dc, const TL& imgs, bool relu, const std::vector<const float*>& stats) {
+TL run_direct(asep_aru* m, const DirectConv& dc, const TL& imgs, bool relu, const std::vector<const float*>& stats, int act = 0) {
     TL out;
     for (const Tensor& t : imgs) out.push_back(new_tensor(m, t.H, t.W, dc.cout));
     for (size_t b0 = 0; b0 < imgs.size(); b0 += MAXP) {
@@ -689,7 +690,7 @@ TL run_direct(asep_aru* m, const DirectConv& dc, const TL& imgs, bool relu, cons
             bytes += tbytes(imgs[i]) + tbytes(out[i]);
         }
         a.nprob = (int)(b1 - b0);
-        a.w = dc.d_w; a.bias = dc.d_b; a.relu = relu ? 1 : 0;
+        a.w = dc.d_w; a.bias = dc.d_b; a.relu = relu ? 1 : 0; a.act = act;
         ProfScope ps(m, "conv_c1_kernel<" + std::to_string(dc.k) + "," + std::to_string(dc.cout) + ">", flops);
         ps.bytes = bytes;
         dim3 grid(tiles);
@@ -1463,10 +1464,14 @@ void apply_act(asep_aru* m, TL& l) {
         hipLaunchKernelGGL(act_kernel, dim3(blocks), dim3(256), 0, m->stream, a, m->cfg.activation);
     }
 }
-// conv / deconv / first conv followed by the graph's activation (act = false: identity layers)
+// conv / deconv / first conv followed by the graph's activation (act = false: identity layers).  Round 4: elu / leaky are applied in the
+// epilogue of the producing kernel (ConvArgs::act: the same arithmetic as act_kernel, so the results are bit-identical to the separate pass
+// of round 3, which ASEP_FUSE_ACT=0 still selects): a variant's layer is one launch and one write instead of launch + read + write.
+// The fused 2x2 max pool sees the ACTIVATED values (both functions are increasing: the same as activating the pooled maximum).
 TL conv_act(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1, bool relu_in, bool act, const TL* res,
             TL* pooled = nullptr, bool keep_full = true) {
     if (m->cfg.activation == 0 || !act) return run_conv(m, scope, in0, in1, relu_in, act, res, pooled, keep_full);
+    if (m->fuse_act) return run_conv(m, scope, in0, in1, relu_in, false, res, pooled, keep_full, m->cfg.activation);
     TL out = run_conv(m, scope, in0, in1, relu_in, false, res, pooled, keep_full);
     apply_act(m, out);
     if (pooled) apply_act(m, *pooled);
@@ -1474,12 +1479,14 @@ TL conv_act(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
 }
 TL deconv_act(asep_aru* m, const std::string& scope, const TL& in, const TL& like) {
     if (m->cfg.activation == 0) return run_deconv(m, scope, in, like, true);
+    if (m->fuse_act) return run_deconv(m, scope, in, like, false, m->cfg.activation);
     TL out = run_deconv(m, scope, in, like, false);
     apply_act(m, out);
     return out;
 }
 TL direct_act(asep_aru* m, const DirectConv& dc, const TL& imgs, bool act, const std::vector<const float*>& stats) {
     if (m->cfg.activation == 0 || !act) return run_direct(m, dc, imgs, act, stats);
+    if (m->fuse_act) return run_direct(m, dc, imgs, false, stats, m->cfg.activation);
     TL out = run_direct(m, dc, imgs, false, stats);
     apply_act(m, out);
     return out;
@@ -1878,6 +1885,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_WINO_REG")) m->wino_reg = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO16")) m->wino16 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSE_POOL")) m->fuse_pool = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_FUSE_ACT")) m->fuse_act = atoi(e) != 0;
     if (const char* e = getenv("ASEP_C12")) m->use_c12 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BIGTILE2")) m->big_tile2 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;

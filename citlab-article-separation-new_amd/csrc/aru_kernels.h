@@ -104,6 +104,8 @@ struct ConvArgs {
     int groups;            // number of 16-channel input groups (C16 mode)
     int relu_in;           // apply ReLU while staging the input (pre-activation tensors)
     int relu_out;
+    int act;               // graph variants (asep_aru_cfg.activation; relu_out is 0 then): 1 = elu, 2 = leaky (0.1) applied to the output.
+                           // The ReLU graphs' fast epilogues are not touched: a launch with act != 0 takes the general ones.
     int skip_full;         // with p[].pool: do not store the unpooled output (nobody reads it)
     XcdMap xm;             // XCD-aware block -> tile map (sched_tile)
 };
@@ -111,6 +113,13 @@ struct ConvArgs {
 constexpr int CONV_TH = 8;
 constexpr int CONV_TW = 32;
 constexpr int CONV_NT = 4;     // n-tiles (16 pixels each) per wave; 4 waves -> 256 pixels per block
+
+// the non-ReLU activations of ARU_v1.py:70-75, fused behind a convolution: 1 = elu (tf.nn.elu: x > 0 ? x : exp(x) - 1), 2 = leaky
+// (layers.py:10-30: max(0, x) + 0.1 min(0, x)) -- the arithmetic of act_kernel, so fused and separate passes give the same bits
+__device__ __forceinline__ float act1(float x, int mode) {
+    return mode == 1 ? (x > 0.f ? x : expf(x) - 1.f) : fmaxf(x, 0.f) + 0.1f * fminf(x, 0.f);
+}
+__device__ __forceinline__ f32x4 act4(f32x4 v, int mode) { return f32x4{act1(v.x, mode), act1(v.y, mode), act1(v.z, mode), act1(v.w, mode)}; }
 
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(256, MINB) void conv_mfma_kernel(const ConvArgs a) 
     // ---- epilogue: D layout col = lane&15 -> pixel, row = 4*(lane>>4)+reg -> output channel ----
     float* __restrict__ out = P.out;
     const float* __restrict__ res = P.res;
-    if (interior && a.cout % 16 == 0) {
+    if (interior && a.cout % 16 == 0 && !a.act) {
         // interior tile, whole 16-channel output tiles: no bounds tests, one base pointer
         const int relu_o = a.relu_out ? 0 : (int)0x80000000;
         const size_t p00 = (size_t)(y0 + ((wave * NT) >> 1)) * P.Wo + x0 + j;   // NT is even: n-tile 0 of a wave is column block 0
@@ -438,6 +447,7 @@ __global__ __launch_bounds__(256, MINB) void conv_mfma_kernel(const ConvArgs a) 
                     if (res) v += *reinterpret_cast<const f32x4*>(res + p * a.cout + c);
                 }
                 if (a.relu_out) v = relu4(v);
+                else if (a.act) v = act4(v, a.act);
                 acc[m][n] = v;
                 if (!a.skip_full) *reinterpret_cast<f32x4*>(out + p * a.cout + c) = v;
             } else {
@@ -445,6 +455,7 @@ __global__ __launch_bounds__(256, MINB) void conv_mfma_kernel(const ConvArgs a) 
                     float s = v[r] + a.bias[c + r];
                     if (res) s += res[p * a.cout + c + r];
                     if (a.relu_out) s = fmaxf(s, 0.f);
+                    else if (a.act) s = act1(s, a.act);
                     out[p * a.cout + c + r] = s;
                 }
             }
@@ -752,6 +763,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
                           *reinterpret_cast<const f32x4*>(a.bias + co);
                 if (res) v += rv[i];
                 if (a.relu_out) v = relu4(v);
+                else if (a.act) v = act4(v, a.act);
                 *reinterpret_cast<f32x4*>(out + ((size_t)yy * P.Wo + xx) * a.cout + co) = v;
             }
         }
@@ -927,6 +939,7 @@ __global__ __launch_bounds__(256, RESP ? 2 : 3) void conv_winor_kernel(const Con
         for (int dx = 0; dx < 2; ++dx) {
             const int yy = oy + dy, xx = ox + dx;
             y[dy][dx] = imax4(y[dy][dx] + rv[dy * 2 + dx], relu_o);
+            if (a.act) y[dy][dx] = act4(y[dy][dx], a.act);
             if (yy < P.Ho && xx < P.Wo && !a.skip_full) {
                 const size_t pp = ((size_t)yy * P.Wo + xx) * a.cout + co;
                 *reinterpret_cast<f32x4*>(P.out + pp) = y[dy][dx];
@@ -1065,7 +1078,7 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
     }
 
     // tiles whose 16 x 32 output pixels all exist and whose channels fill the lanes' quads: no bounds tests
-    if (2 * qy0 - P.pbh >= 0 && 2 * (qy0 + TH) - P.pbh <= P.Ho && 2 * qx0 - P.pbw >= 0 && 2 * (qx0 + TW) - P.pbw <= P.Wo && a.cout % 16 == 0) {
+    if (2 * qy0 - P.pbh >= 0 && 2 * (qy0 + TH) - P.pbh <= P.Ho && 2 * qx0 - P.pbw >= 0 && 2 * (qx0 + TW) - P.pbw <= P.Wo && a.cout % 16 == 0 && !a.act) {
         const int relu_o = a.relu_out ? 0 : (int)0x80000000;
         const size_t p00 = (size_t)(2 * (qy0 + wave * NT) - P.pbh) * P.Wo + 2 * (qx0 + j) - P.pbw;
 #pragma unroll
@@ -1086,7 +1099,7 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
         // lanes kk = 0, 1 (cross-lane move), so that one store instruction writes 16 pixel pairs x 8 channels = 1 KB
         // contiguous with all 64 lanes instead of two half-empty ones with 32-byte pieces at a 64-byte stride.
         if (a.cout == 8 && mt0 == 0 && 2 * qy0 - P.pbh >= 0 && 2 * (qy0 + TH) - P.pbh <= P.Ho && 2 * qx0 - P.pbw >= 0 &&
-            2 * (qx0 + TW) - P.pbw <= P.Wo) {
+            2 * (qx0 + TW) - P.pbw <= P.Wo && !a.act) {
             const int relu_o = a.relu_out ? 0 : (int)0x80000000;
             const int hi = kk >> 1;
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + (kk & 1) * 4);
@@ -1120,11 +1133,13 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
                 if (c + 3 < a.cout) {
                     v += *reinterpret_cast<const f32x4*>(a.bias + c);
                     if (a.relu_out) v = relu4(v);
+                    else if (a.act) v = act4(v, a.act);
                     *reinterpret_cast<f32x4*>(P.out + p * a.cout + c) = v;
                 } else {
                     for (int r = 0; r < 4 && c + r < a.cout; ++r) {
                         float s = v[r] + a.bias[c + r];
                         if (a.relu_out) s = fmaxf(s, 0.f);
+                        else if (a.act) s = act1(s, a.act);
                         P.out[p * a.cout + c + r] = s;
                     }
                 }
@@ -1151,6 +1166,7 @@ struct C1Args {
     const float* w;        // [K*K][COUT]
     const float* bias;     // [COUT]
     int relu;
+    int act;               // graph variants: 1 = elu, 2 = leaky behind the conv (relu is 0 then)
 };
 
 // OUTBF: the output is written as bf16 (native bf16 path; COUT % 8 == 0)
@@ -1191,7 +1207,7 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const C1Args a) {
 #pragma unroll
     for (int c = 0; c < COUT; ++c) {
         const float s = acc[c] + sw[K * K * COUT + c];
-        acc[c] = a.relu ? fmaxf(s, 0.f) : s;
+        acc[c] = a.relu ? fmaxf(s, 0.f) : (a.act ? act1(s, a.act) : s);
     }
     if constexpr (OUTBF) {
         static_assert(!OUTBF || COUT % 8 == 0, "bf16 output: whole 16-byte units");

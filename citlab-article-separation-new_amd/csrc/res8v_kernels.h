@@ -850,8 +850,10 @@ __global__ __launch_bounds__(256) void deconv8v_kernel(const ConvArgs a) {
     for (int cls = 0; cls < 4; ++cls) {
         float* o = lds + ((2 * qy + (cls >> 1)) * (2 * T) + 2 * qx) * 8;
         const int k = (cls & 1) * 2, sw = (qx >> 1) & 3;
-        *reinterpret_cast<f32x4*>(o + ((k ^ sw) << 2)) = imax4(r8v_lo(acc[cls]), relu_o);
-        *reinterpret_cast<f32x4*>(o + (((k + 1) ^ sw) << 2)) = imax4(r8v_hi(acc[cls]), relu_o);
+        f32x4 vlo = imax4(r8v_lo(acc[cls]), relu_o), vhi = imax4(r8v_hi(acc[cls]), relu_o);
+        if (a.act) { vlo = act4(vlo, a.act); vhi = act4(vhi, a.act); }      // graph variants (elu / leaky): uniform branch, not taken by ReLU nets
+        *reinterpret_cast<f32x4*>(o + ((k ^ sw) << 2)) = vlo;
+        *reinterpret_cast<f32x4*>(o + (((k + 1) ^ sw) << 2)) = vhi;
     }
     __syncthreads();
     const int oy0 = 2 * qy0 - P.pbh, ox0 = 2 * qx0 - P.pbw;   // image coordinates of the output tile's origin
@@ -935,6 +937,7 @@ __global__ __launch_bounds__(256) void conv_c1out_kernel(const ConvArgs a) {
     if (x >= W || y >= H) return;
     float s = ((acc0.x + acc0.y) + (acc1.x + acc1.y)) + a.bias[0];
     if (a.relu_out) s = fmaxf(s, 0.f);
+    else if (a.act) s = act1(s, a.act);
     P.out[(size_t)y * W + x] = s;
 }
 

@@ -169,6 +169,27 @@ def test_graph_variants_elu_leaky_and_plain_u(kw, H, W):
     graph.close()
 
 
+@pytest.mark.parametrize("kw", [{"activation_name": "elu"}, {"activation_name": "leaky"}, {"graph": "U", "activation_name": "leaky"}],
+                         ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
+def test_fused_activation_of_the_variants_is_the_separate_pass_bit_for_bit(kw, monkeypatch):
+    """round 4: elu / leaky are applied in the epilogue of the producing kernel (ConvArgs::act, C1Args::act) instead of by an
+    act_kernel pass behind it; same arithmetic on the same values, so ASEP_FUSE_ACT=0 (the round-3 form) must give the same bits --
+    on a size with interior AND border tiles (the fused form routes a variant's launches through the general epilogues)."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    img = _image(300, 270, 3)
+    outs, eps = [], []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ASEP_FUSE_ACT", flag)
+        cfg, w, graph = _setup(kw, seed=8)
+        outs.append(helper.get_net_output(img, graph, "0"))
+        eps.append({n: helper.get_endpoint(graph, n) for n in ("scale_0_unet_down_0_conv", "scale_0_unet_down_2_conv", "scale_0_unet_up_0_deconv",
+                                                               "scale_0_unet_up_0_conv")})
+        graph.close()
+    assert np.array_equal(outs[0], outs[1])
+    assert all(np.array_equal(eps[0][n], eps[1][n]) for n in eps[0])
+    assert (eps[0]["scale_0_unet_up_0_deconv"] < 0).any()        # negative branch exercised
+
+
 def test_variants_are_refused_by_the_bf16_path():
     from citlab_article_separation_new_amd import _lib, net_post_processing_helper as helper
     cfg, w, graph = _setup({"activation_name": "elu", "compute_dtype": "bf16"})
