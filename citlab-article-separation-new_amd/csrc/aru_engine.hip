@@ -86,6 +86,7 @@ struct asep_aru {
     float* d_r8v_up_wr = nullptr;    // [3][R8V_FILTER]
     bool r8_valu = true;             // fp32 only; ASEP_R8_VALU=0 runs the fp32 MFMA variants instead
     bool use_fused8 = true;          // ASEP_FUSED8=0 falls back to the layer-by-layer kernels
+    bool fused8_wanted = true;       // what ASEP_FUSED8 said (use_fused8 is also switched off for the graph variants)
     float* d_att_head = nullptr;     // A fragment of attPart/conv1 for att_head_kernel (12 output channels, 4x4 taps)
     float* d_logit_w = nullptr;
     float* d_logit_b = nullptr;
@@ -1585,7 +1586,10 @@ TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) 
     const std::string p = "aru_net/attMapG/attPart/conv";
     TL y;
     if (m->bf16 && !(m->d_att_head && m->use_fused8)) { set_error("bf16 path: attention head 4x4 / 12 channels expected"); throw ArgError(); }
-    if (m->d_att_head && m->use_fused8) {
+    // the fused head (conv1 + activation + pool, one pooled pixel per thread) also serves the elu / leaky variants (round 4): the pool
+    // is taken on the pre-activation values, the activation on the maximum
+    const bool head_variant = m->d_att_head && !m->use_fused8 && m->fused8_wanted && m->fuse_act && m->cfg.activation != 0 && m->r8_valu && !m->bf16;
+    if (m->d_att_head && (m->use_fused8 || head_variant)) {
         // conv1 + ReLU + pool1 fused (the full-resolution 12-channel tensor is never materialised)
         // (bf16 path: the head writes a 16-channel bf16 plane, channels 12..15 zero)
         for (const Tensor& t : imgs) y.push_back(m->bf16 ? new_tensor_bf(m, cdiv(t.H, 2), cdiv(t.W, 2), 16) : new_tensor(m, cdiv(t.H, 2), cdiv(t.W, 2), 12));
@@ -1605,10 +1609,11 @@ TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) 
                 flops += 2.0 * imgs[i].H * imgs[i].W * 16.0 * 12;
             }
             a.nprob = (int)(b1 - b0);
-            a.wpk = (const f32x4*)m->d_att_head; a.bias = m->att_first.d_b; a.w = m->att_first.d_w;
+            a.wpk = (const f32x4*)m->d_att_head; a.bias = m->att_first.d_b; a.w = m->att_first.d_w; a.act = m->cfg.activation;
             bool valu = m->r8_valu || m->bf16;               // vector-ALU form (32-bit output offsets, see run_res8_down)
             for (size_t i = b0; i < b1; ++i) valu = valu && (size_t)imgs[i].H * imgs[i].W < ((size_t)1 << 28);
             if (m->bf16 && !valu) { set_error("bf16 path: image too large for the attention head kernel"); throw ArgError(); }
+            if (head_variant && !valu) { set_error("attention head of an elu / leaky graph: image too large for the vector-ALU kernel"); throw ArgError(); }
             ProfScope ps(m, m->bf16 ? "att_headv_kernel<true>" : (valu ? "att_headv_kernel<false>" : "att_head_kernel"), flops);
             ps.bytes = bytes;
             if (m->bf16) hipLaunchKernelGGL(att_headv_kernel<true>, dim3(tiles), dim3(256), 0, m->stream, a);
@@ -1889,6 +1894,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_C12")) m->use_c12 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BIGTILE2")) m->big_tile2 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;
+    m->fused8_wanted = m->use_fused8;
     if (variant) m->use_fused8 = false;                      // the fused level-0 blocks / attention head are ReLU residual kernels
     if (const char* e = getenv("ASEP_R8_VALU")) m->r8_valu = atoi(e) != 0;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;

@@ -1238,6 +1238,7 @@ struct AttHeadArgs {
     const f32x4* wpk;      // [64 lanes] A fragment: row = cout (12 real), slots = taps
     const float* bias;     // [12]
     const float* w;        // [16 taps][12] (att_headv_kernel: scalar operands)
+    int act;               // att_headv_kernel, graph variants: 0 = ReLU, 1 = elu, 2 = leaky (applied to the pooled maximum: both are increasing)
 };
 
 __global__ __launch_bounds__(256) void att_head_kernel(const AttHeadArgs a) {

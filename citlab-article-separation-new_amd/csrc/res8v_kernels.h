@@ -708,9 +708,11 @@ __global__ __launch_bounds__(256) void att_headv_kernel(const AttHeadArgs a) {
         asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]));   // the FMAs stay here (see r8v_conv_direct)
         const int gy = y0 + ly, gx = x0 + lx;
         if (!interior) {
-            // relu(max over the window's pixels inside the image) = max(..., 0): a pixel outside contributes 0
+            // relu(max over the window's pixels inside the image) = max(..., 0): a pixel outside contributes 0 (graph variants: -inf,
+            // their activation of the maximum over the pixels inside follows below)
             const bool okx = gx + 1 < W, oky = gy + 1 < H;
-            const f32x2 z = f32x2{0.f, 0.f};
+            const float zv = a.act ? -INFINITY : 0.f;
+            const f32x2 z = f32x2{zv, zv};
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
                 acc[1][q] = okx ? acc[1][q] : z;
@@ -724,10 +726,18 @@ __global__ __launch_bounds__(256) void att_headv_kernel(const AttHeadArgs a) {
             const int i = max(max(max(__float_as_int(a0), __float_as_int(a1)), __float_as_int(a2)), max(__float_as_int(a3), 0));
             return __int_as_float(i);
         };
+        if (a.act) {                                           // elu / leaky: act(max(window)) = max(act(window)), fmaxf on the floats
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            m[2 * q] = pool(acc[0][q].x, acc[1][q].x, acc[2][q].x, acc[3][q].x);
-            m[2 * q + 1] = pool(acc[0][q].y, acc[1][q].y, acc[2][q].y, acc[3][q].y);
+            for (int q = 0; q < 6; ++q) {
+                m[2 * q] = act1(fmaxf(fmaxf(acc[0][q].x, acc[1][q].x), fmaxf(acc[2][q].x, acc[3][q].x)), a.act);
+                m[2 * q + 1] = act1(fmaxf(fmaxf(acc[0][q].y, acc[1][q].y), fmaxf(acc[2][q].y, acc[3][q].y)), a.act);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                m[2 * q] = pool(acc[0][q].x, acc[1][q].x, acc[2][q].x, acc[3][q].x);
+                m[2 * q + 1] = pool(acc[0][q].y, acc[1][q].y, acc[2][q].y, acc[3][q].y);
+            }
         }
         if (gy < H && gx < W) {
             if constexpr (OUTBF) {
