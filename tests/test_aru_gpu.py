@@ -178,6 +178,9 @@ def test_fused_activation_of_the_variants_is_the_separate_pass_bit_for_bit(kw, m
     from citlab_article_separation_new_amd import net_post_processing_helper as helper
     img = _image(300, 270, 3)
     outs, eps = [], []
+    # (ASEP_FUSED8=0: the attention head as conv1 + pool in both runs -- its fused vector-ALU form, which an elu / leaky graph takes
+    # since round 4 as well, sums the taps in another order; it is held to the oracle by test_graph_variants_elu_leaky_and_plain_u)
+    monkeypatch.setenv("ASEP_FUSED8", "0")
     for flag in ("1", "0"):
         monkeypatch.setenv("ASEP_FUSE_ACT", flag)
         cfg, w, graph = _setup(kw, seed=8)
@@ -188,6 +191,14 @@ def test_fused_activation_of_the_variants_is_the_separate_pass_bit_for_bit(kw, m
     assert np.array_equal(outs[0], outs[1])
     assert all(np.array_equal(eps[0][n], eps[1][n]) for n in eps[0])
     assert (eps[0]["scale_0_unet_up_0_deconv"] < 0).any()        # negative branch exercised
+    if kw.get("graph") != "U":
+        # the fused head (default) against the unfused one: same function, other summation order
+        monkeypatch.delenv("ASEP_FUSED8")
+        monkeypatch.setenv("ASEP_FUSE_ACT", "1")
+        cfg, w, graph = _setup(kw, seed=8)
+        out_head = helper.get_net_output(img, graph, "0")
+        graph.close()
+        assert 0.0 < float(np.abs(out_head - outs[0]).max()) <= 1e-5
 
 
 def test_variants_are_refused_by_the_bf16_path():
