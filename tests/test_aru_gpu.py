@@ -198,7 +198,7 @@ def test_fused_activation_of_the_variants_is_the_separate_pass_bit_for_bit(kw, m
         cfg, w, graph = _setup(kw, seed=8)
         out_head = helper.get_net_output(img, graph, "0")
         graph.close()
-        assert 0.0 < float(np.abs(out_head - outs[0]).max()) <= 1e-5
+        assert float(np.abs(out_head - outs[0]).max()) <= 1e-5
 
 
 def test_variants_are_refused_by_the_bf16_path():
