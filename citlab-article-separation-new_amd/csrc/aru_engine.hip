@@ -9,6 +9,7 @@
 #include "res8_kernels.h"
 #include "res8v_kernels.h"
 #include "bf16_kernels.h"
+#include "split_kernels.h"
 #include "asep_common.h"
 
 using namespace asep;
@@ -39,6 +40,9 @@ struct PackedConv {
     int bmode = -1;            // convb / deconvb MODE (0: Cin 8, 1: Cin 16, 2: Cin % 32 == 0); -1: not packed
     int bchunks = 0;
     bf16_t* d_wb = nullptr;    // conv: [chunk][mtile][lane][8]; deconv: MODE 2 [G][tap][mtile][lane][8], MODE 1 [frag 0..5][mtile][lane][8]
+    // fp32 with split products (split_kernels.h): the filter as three bf16 parts, [chunk][part h, m, l][mtile][lane][8]
+    int smode = -1;            // 1: Cin 12 / 16 (chunk = two taps), 2: Cin % 32 == 0 (chunk = tap x 32 channels); -1: not packed
+    bf16_t* d_ws = nullptr;
 };
 
 struct DirectConv {        // Cin == 1 first layers
@@ -111,7 +115,7 @@ struct asep_aru {
     };
     std::vector<std::unique_ptr<Lane>> lanes;
     Lane* cur = nullptr;
-    int num_lanes = 1;                   // ASEP_LANES (2 lanes measured +0.4 %: the launches already fill the chip)
+    int num_lanes = 1;                   // ASEP_LANES: page lanes of a batch call (r4j: 1 / 2 / 3 / 4 lanes = 119.3 / 121.2 / 120.3 / 115.8 pages/s fp32, 417.9 / 422.3 / 417.0 / 369.9 bf16; two lanes double every in-situ launch duration for that +1.5 %, so one is the default)
     std::map<std::string, Tensor> endpoints;
     hipStream_t stream = nullptr;
     bool use_side_stream = true;         // ASEP_SIDE_STREAM=0 serialises everything on the caller's stream
@@ -129,6 +133,9 @@ struct asep_aru {
     std::map<std::string, const int32_t*> sched_cache;
     bool bf16 = false;             // cfg.compute_dtype == 1: native bf16 data path (bf16_kernels.h): bf16 activations in HBM / LDS,
                                    // v_mfma_f32_16x16x32_bf16 with fp32 accumulation; fp32 image in, fp32 probabilities out
+    bool split = false;            // cfg.compute_dtype == 2 (or ASEP_F32_SPLIT=1 with compute_dtype 0): fp32 tensors and accumulation, every product of the
+                                   // convolutions with >= 12 input channels as six bf16 x bf16 partial products (split_kernels.h)
+    bool split_th16 = true;        // ASEP_SPLIT_TH16=0: 8 x 32 instead of 16 x 32 blocks for the 16-channel split-product layers
     bool wino_reg = true;          // ASEP_WINO_REG=0: LDS-image Winograd kernel also for the 32-channel level
     bool use_winograd = true;      // ASEP_WINOGRAD=0 selects the direct implicit-GEMM kernels everywhere
     bool big_tile2 = true;         // ASEP_BIGTILE2=0: 8 x 32 double-buffered blocks for 32 -> 16 convs without residual operand
@@ -209,6 +216,7 @@ inline std::string ti(int i) { return std::to_string(i); }
 
 // ---- weight packing -----------------------------------------------------------------------------
 int pack_conv_bf(asep_aru* m, PackedConv& pc, const HostTensor& w);   // bf16 fragments (native bf16 path), defined further down
+int pack_conv_split(asep_aru* m, PackedConv& pc, const HostTensor& w);   // three-part bf16 fragments (split_kernels.h)
 
 // conv   W[kh][kw][cin][cout]  (layers.py:219);  deconv W[kh][kw][cout][cin] (layers.py:352, ARU_v1.py:257)
 int pack_conv(asep_aru* m, const std::map<std::string, HostTensor>& blob, const std::string& scope,
@@ -315,6 +323,10 @@ int pack_conv(asep_aru* m, const std::map<std::string, HostTensor>& blob, const 
     }
     if (m->bf16) {
         rc = pack_conv_bf(m, pc, w);
+        if (rc) return rc;
+    }
+    if (m->split && !deconv) {
+        rc = pack_conv_split(m, pc, w);
         if (rc) return rc;
     }
     m->convs[scope] = pc;
@@ -469,9 +481,79 @@ void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, int tot
     else ASEP_CONV_LAUNCH(KH, KW, 1, false, CONV_TH, true, false, false, 2);
 }
 
-// stride-1 SAME conv on the (optionally concatenated) inputs of every problem
 enum PoolKind { POOL_MAX, POOL_AVG_C1, POOL_CHANSUM };
 TL run_pool(asep_aru* m, const TL& in, PoolKind kind);
+
+// launches convs_kernel<...> under that instantiation's name
+#define ASEP_CONVS_LAUNCH(KH_, KW_, C16_, MT_, TH_, MB_)                                                              \
+    do {                                                                                                              \
+        ps.set_name("convs_kernel" + targs({ti(KH_), ti(KW_), tb(C16_), ti(MT_), ti(TH_), ti(MB_)}));                 \
+        hipLaunchKernelGGL((convs_kernel<KH_, KW_, C16_, MT_, TH_, MB_>), grid, dim3(256), 0, m->stream, a);          \
+    } while (0)
+
+// a conv layer on the split-product kernel (split_kernels.h): same operands and results as run_conv's fp32 kernels
+TL run_conv_split(asep_aru* m, const PackedConv& pc, const std::string& scope, const TL& in0, const TL* in1, bool relu_in, bool relu_out,
+                  const TL* res, TL* pooled, bool keep_full, int act) {
+    const bool fuse_pool = pooled && m->fuse_pool;
+    TL out;
+    if (keep_full || !fuse_pool)
+        for (const Tensor& t : in0) out.push_back(new_tensor(m, t.H, t.W, pc.cout));
+    if (fuse_pool) {
+        pooled->clear();
+        for (const Tensor& t : in0) pooled->push_back(new_tensor(m, (t.H + 1) / 2, (t.W + 1) / 2, pc.cout));
+    }
+    const bool c16 = pc.smode == 1;
+    const int mt = (pc.mtiles % 4 == 0 && !c16) ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1);
+    const int th = (c16 && pc.kh == 3 && mt == 1 && m->split_th16) ? 16 : 8;
+    for (size_t b0 = 0; b0 < in0.size(); b0 += MAXP) {
+        const size_t b1 = std::min(in0.size(), b0 + MAXP);
+        ConvArgs a{};
+        int tiles = 0;
+        double flops = 0, bytes = (double)pc.kh * pc.kw * pc.cin * pc.cout * 4.0;
+        for (size_t i = b0; i < b1; ++i) {
+            ConvProb& p = a.p[i - b0];
+            p.in0 = in0[i].p; p.in1 = in1 ? (*in1)[i].p : nullptr; p.res = res ? (*res)[i].p : nullptr;
+            p.out = out.empty() ? nullptr : out[i].p;
+            p.pool = fuse_pool ? (*pooled)[i].p : nullptr;
+            p.H = p.Ho = in0[i].H; p.W = p.Wo = in0[i].W;
+            p.tiles_x = (in0[i].W + 31) / 32;
+            p.tile_begin = tiles;
+            tiles += p.tiles_x * ((in0[i].H + th - 1) / th);
+            flops += 2.0 * in0[i].H * in0[i].W * pc.kh * pc.kw * (double)pc.cin * pc.cout;
+            bytes += tbytes(in0[i]) + (in1 ? tbytes((*in1)[i]) : 0.0) + (res ? tbytes((*res)[i]) : 0.0) + (out.empty() ? 0.0 : tbytes(out[i])) +
+                     (fuse_pool ? tbytes((*pooled)[i]) : 0.0);
+        }
+        a.nprob = (int)(b1 - b0);
+        a.total_tiles = tiles;
+        a.c0 = in0[0].C; a.c1 = in1 ? (*in1)[0].C : 0;
+        a.wpk = (const f32x4*)pc.d_ws; a.bias = pc.d_b;
+        a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.cin / 32;
+        a.relu_in = relu_in; a.relu_out = relu_out; a.act = act;
+        a.skip_full = fuse_pool && !keep_full;
+        int units = tiles;
+        a.xm = conv_schedule(m, a, th, tiles, pc.mtiles / mt > 1, &units);
+        dim3 grid(units, pc.mtiles / mt);
+        TL sub(in0.begin() + b0, in0.begin() + b1);
+        ProfScope ps(m, "convs_kernel", flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
+        ps.bytes = bytes;
+        if (pc.kh == 3) {
+            if (c16 && th == 16) ASEP_CONVS_LAUNCH(3, 3, true, 1, 16, 2);
+            else if (c16 && mt == 2) ASEP_CONVS_LAUNCH(3, 3, true, 2, 8, 3);
+            else if (c16) ASEP_CONVS_LAUNCH(3, 3, true, 1, 8, 3);
+            else if (mt == 4) ASEP_CONVS_LAUNCH(3, 3, false, 4, 8, 2);
+            else if (mt == 2) ASEP_CONVS_LAUNCH(3, 3, false, 2, 8, 2);
+            else ASEP_CONVS_LAUNCH(3, 3, false, 1, 8, 2);
+        } else {
+            if (c16 && mt == 2) ASEP_CONVS_LAUNCH(4, 4, true, 2, 8, 2);
+            else if (c16) ASEP_CONVS_LAUNCH(4, 4, true, 1, 8, 2);
+            else { set_error("conv %s: 4x4 filters with %d input channels are not served by the split-product kernel", scope.c_str(), pc.cin); throw ArgError(); }
+        }
+    }
+    if (pooled && !fuse_pool) *pooled = run_pool(m, out, POOL_MAX);
+    return out;
+}
+
+// stride-1 SAME conv on the (optionally concatenated) inputs of every problem
 
 // pooled != nullptr: also produce maxpool2 of the output.  The direct kernels and the register-resident Winograd kernel take
 // the 2x2 max in their epilogue (ConvProb::pool); the others are followed by maxpool2_kernel.  keep_full = false: the caller
@@ -523,6 +605,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
         }
         return out1;
     }
+    if (m->split && pc.d_ws) return run_conv_split(m, pc, scope, in0, in1, relu_in, relu_out, res, pooled, keep_full, act);
     const bool wino = pc.d_wino && m->use_winograd && (pc.mtiles > 1 || (m->wino16 && m->wino_reg));
     const int wino_mt = pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1);
     const bool fuse_pool = pooled && m->fuse_pool && pc.cout % 4 == 0 && (!wino || (wino_mt <= 2 && m->wino_reg));
@@ -998,6 +1081,41 @@ int pack_conv_bf(asep_aru* m, PackedConv& pc, const HostTensor& w) {
     int rc = upload_bf(pk, &pc.d_wb);
     if (rc) return rc;
     m->owned.push_back(pc.d_wb);
+    return ASEP_OK;
+}
+
+// fp32 filter -> its three bfloat16 parts (round to nearest at every cut: w = h + m + l exactly), in convs_kernel's fragment order
+int pack_conv_split(asep_aru* m, PackedConv& pc, const HostTensor& w) {
+    const int taps = pc.kh * pc.kw;
+    if (!((pc.kh == 3 && pc.kw == 3) || (pc.kh == 4 && pc.kw == 4)) || pc.cout % 16 != 0) return ASEP_OK;
+    pc.smode = (pc.cin == 16 || pc.cin == 12) ? 1 : (pc.cin % 32 == 0 ? 2 : -1);
+    if (pc.smode < 0) return ASEP_OK;
+    auto W = [&](int tap, int ci, int co) -> float {
+        if (ci >= pc.cin || co >= pc.cout || tap >= taps) return 0.f;
+        return w.data[((size_t)tap * pc.cin + ci) * pc.cout + co];
+    };
+    auto bfval = [](bf16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+    const int chunks = pc.smode == 1 ? (taps + 1) / 2 : (pc.cin / 32) * taps;
+    std::vector<bf16_t> pk((size_t)chunks * 3 * pc.mtiles * 64 * 8);
+    for (int ch = 0; ch < chunks; ++ch)
+        for (int mt = 0; mt < pc.mtiles; ++mt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int kk = lane >> 4, co = mt * 16 + (lane & 15);
+                    int tap, ci;
+                    if (pc.smode == 1) { tap = 2 * ch + (kk >> 1); ci = (kk & 1) * 8 + j; if (tap >= taps) tap = -1; }
+                    else { const int G = ch / taps; tap = ch % taps; ci = 32 * G + kk * 8 + j; }
+                    const float v = tap < 0 ? 0.f : W(tap, ci, co);
+                    const bf16_t h = f2bf(v);
+                    const float r = v - bfval(h);
+                    const bf16_t mm = f2bf(r);
+                    const bf16_t l = f2bf(r - bfval(mm));
+                    const bf16_t part[3] = {h, mm, l};
+                    for (int s = 0; s < 3; ++s) pk[((((size_t)ch * 3 + s) * pc.mtiles + mt) * 64 + lane) * 8 + j] = part[s];
+                }
+    int rc = upload_bf(pk, &pc.d_ws);
+    if (rc) return rc;
+    m->owned.push_back(pc.d_ws);
     return ASEP_OK;
 }
 
@@ -1872,7 +1990,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
         return nullptr;
     }
     if (cfg->channels != 1) { set_error("asep_aru_load: only 1-channel input is supported (ARU_v1.py:115)"); return nullptr; }
-    if (cfg->compute_dtype != 0 && cfg->compute_dtype != 1) { set_error("asep_aru_load: compute_dtype %d unknown (0 = fp32, 1 = bf16 MFMA)", cfg->compute_dtype); return nullptr; }
+    if (cfg->compute_dtype < 0 || cfg->compute_dtype > 2) { set_error("asep_aru_load: compute_dtype %d unknown (0 = fp32, 1 = bf16 MFMA, 2 = fp32 with split bf16 products)", cfg->compute_dtype); return nullptr; }
     if (cfg->scale_space_num < 1 || cfg->res_depth < 1) { set_error("asep_aru_load: bad cfg"); return nullptr; }
     if (cfg->activation < 0 || cfg->activation > 2) { set_error("asep_aru_load: activation %d unknown (0 = relu, 1 = elu, 2 = leaky)", cfg->activation); return nullptr; }
     const bool variant = cfg->activation != 0 || cfg->plain_u != 0;
@@ -1886,6 +2004,9 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     std::unique_ptr<asep_aru> m(new asep_aru());
     m->cfg = *cfg;
     m->bf16 = cfg->compute_dtype == 1;
+    m->split = cfg->compute_dtype == 2;
+    if (const char* e = getenv("ASEP_F32_SPLIT")) m->split = !m->bf16 && atoi(e) != 0;
+    if (const char* e = getenv("ASEP_SPLIT_TH16")) m->split_th16 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO_REG")) m->wino_reg = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO16")) m->wino16 = atoi(e) != 0;

@@ -21,6 +21,12 @@ from .config import AruConfig
 from .weights import load_weights, pack_blob
 
 
+# asep_aru_cfg.compute_dtype (include/asep_hip.h): "f32" = fp32 tensors and fp32 products; "bf16" = bf16 tensors and products, fp32 accumulation;
+# "f32s" = fp32 tensors and accumulation, every product of the wide convolutions as six bf16 x bf16 partial products of the three-way
+# bfloat16 split of both factors (csrc/split_kernels.h) -- fp32 results on the bf16 matrix pipeline
+COMPUTE_DTYPES = {"f32": 0, "bf16": 1, "f32s": 2}
+
+
 class AruGraph:
     """What ``load_graph`` returns in place of a ``tf.Graph``: named weights + hyper-parameters.
     Device handles are created lazily per GPU (one model instance per (process, device))."""
@@ -48,11 +54,11 @@ class AruGraph:
         if key not in self._handles:
             lib = _lib.init_device(device_id)
             c = self.cfg
-            if c.compute_dtype not in ("f32", "bf16"):
-                raise ValueError(f"compute_dtype must be 'f32' or 'bf16', got {c.compute_dtype!r}")
+            if c.compute_dtype not in COMPUTE_DTYPES:
+                raise ValueError(f"compute_dtype must be one of {sorted(COMPUTE_DTYPES)}, got {c.compute_dtype!r}")
             cfg = _lib.AruCfg(c.channels, c.n_classes, c.feat_root, c.scale_space_num, c.res_depth,
                               c.num_scales_att, int(c.use_attention), int(c.mvn), int(c.apply_softmax),
-                              1 if c.compute_dtype == "bf16" else 0, c.activation_code, 0 if c.use_residual else 1)
+                              COMPUTE_DTYPES[c.compute_dtype], c.activation_code, 0 if c.use_residual else 1)
             blob = self.blob()
             h = lib.asep_aru_load(blob, len(blob), C.byref(cfg))
             if not h:
@@ -96,14 +102,14 @@ def load_graph(path_to_pb) -> AruGraph:
 
 
 def compute_dtype_from_env(default: str) -> str:
-    """ASEP_COMPUTE_DTYPE=bf16|f32 selects the engine's arithmetic for models loaded from FILES (the reference's command lines have
+    """ASEP_COMPUTE_DTYPE=bf16|f32|f32s selects the engine's arithmetic for models loaded from FILES (the reference's command lines have
     no flag for it: BASELINE configs[4] runs the same CLIs with "bf16 convs").  The precision is an engine option, not a
     property of the weights; unset = what the model's side-car says, else fp32."""
     v = os.environ.get("ASEP_COMPUTE_DTYPE", "").strip().lower()
     if not v:
         return default
-    if v not in ("f32", "bf16"):
-        raise ValueError(f"ASEP_COMPUTE_DTYPE must be 'f32' or 'bf16', got {v!r}")
+    if v not in COMPUTE_DTYPES:
+        raise ValueError(f"ASEP_COMPUTE_DTYPE must be one of {sorted(COMPUTE_DTYPES)}, got {v!r}")
     return v
 
 

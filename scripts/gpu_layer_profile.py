@@ -17,7 +17,13 @@ g = helper.AruGraph(init_aru_weights(cfg, 1234), cfg)
 lib = _lib.init_device(0); h = g.handle(0)
 img = torch.rand(H, W, device='cuda'); out = torch.empty(H, W, cfg.n_classes, device='cuda')
 s = torch.cuda.current_stream().cuda_stream
-def step(): _lib.check(lib.asep_aru_forward_dev(h, img.data_ptr(), H, W, out.data_ptr(), None, None, 0.05, s), "fwd")
+NP = int(os.environ.get("ASEP_LAYER_PROFILE_PAGES", "1"))                # pages per call (the bench step runs 4 pages per launch)
+outs = [torch.empty(H, W, cfg.n_classes, device='cuda') for _ in range(NP)]
+Arr = C.c_void_p * NP
+p_img, p_out = Arr(*[img.data_ptr()] * NP), Arr(*[o.data_ptr() for o in outs])
+def step():
+    if NP == 1: _lib.check(lib.asep_aru_forward_dev(h, img.data_ptr(), H, W, out.data_ptr(), None, None, 0.05, s), "fwd")
+    else: _lib.check(lib.asep_aru_forward_batch_dev(h, NP, p_img, H, W, p_out, None, None, 0.05, s), "fwd")
 step(); step(); torch.cuda.synchronize()
 samples, order, flops = {}, [], {}
 buf = C.create_string_buffer(1 << 20)
@@ -33,7 +39,8 @@ for _ in range(passes):
         flops[k["kernel"]] = (k["flops"] / k["calls"], k["calls"], k.get("bytes", 0.0) / k["calls"])
 lib.asep_aru_profile(h, 0)
 tot = sum(statistics.median(v) * flops[k][1] for k, v in samples.items())
-print(f"total {tot:.3f} ms/page (sum of per-layer medians over {passes} passes, {dtype}" + (f", {kw}" if kw else "") + ")")
+tot /= NP
+print(f"total {tot:.3f} ms/page ({NP} page(s) per call; sum of per-layer medians over {passes} passes, {dtype}" + (f", {kw}" if kw else "") + ")")
 for k in order:
     v = samples[k]
     ms = statistics.median(v); tf = flops[k][0] / (ms * 1e-3) / 1e12 if ms > 0 else 0
