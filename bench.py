@@ -62,7 +62,7 @@ def parse_args():
     ap.add_argument("--kernel-timing", choices=["both", "in-situ", "isolated", "none"], default="both",
                     help="HIP-event per-kernel passes after the timed region (in-situ only under rocprofv3, so that every launch of "
                          "the traced process runs in the same schedule)")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f32s"], default="f32",
                     help="f32 = BASELINE configs[1] (the headline); bf16 = configs[4] 'bf16 convs': bf16 MFMA operands, "
                          "fp32 accumulation / storage, probability maps within 2e-2 (reported with dtype bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -84,6 +84,8 @@ def parse_args():
     ap.add_argument("--bf16-steps", type=int, default=160,
                     help="timed steps of the secondary bf16 full step (configs[4]: bf16 ARU-Net + visual relation net with bf16 backbone; "
                          "160 x 16 pages >= 5 s at its rate; 0 = skip)")
+    ap.add_argument("--split-steps", type=int, default=60,
+                    help="timed steps of the secondary fp32 step with split products (compute_dtype f32s; 60 x 16 pages >= 6 s at its rate; 0 = skip)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements (bf16 variant, heading net + stroke-width fusion, visual GNN)")
     ap.add_argument("--cpu-sample-height", type=int, default=0,
@@ -388,6 +390,29 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
                     "note": "same step as the headline with --dtype bf16 (child process; this process's fp32 buffers stay allocated beside it)"}
             else:
                 out["bf16_full_step"] = {"error": f"bf16 child exited with {r.returncode}"}
+        # ---- the headline step with fp32 SPLIT products (compute_dtype "f32s", csrc/split_kernels.h: fp32 tensors and accumulation, the
+        #      products of the >= 12-channel convolutions as six bf16 x bf16 partial products; same fp32 parity gates) -- not the headline
+        #      itself because the multiplications run on the bf16 matrix pipeline: reported beside it, the same timing code, own process ----
+        if args.dtype == "f32" and args.split_steps > 0:
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "f32s", "--steps", str(args.split_steps), "--warmup", "2",
+                   "--pages-per-step", str(args.pages_per_step), "--height", str(H), "--width", str(W), "--gnn", args.gnn,
+                   "--no-cpu-baseline", "--no-secondary", "--event-steps", "2"]
+            env = dict(os.environ, ASEP_BENCH_DEVICE=str(dev.index or 0))
+            r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True, timeout=1200)
+            lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and lines:
+                q = json.loads(lines[-1])
+                rr = q["roofline"] or {}
+                out["f32_split_full_step"] = {
+                    "pages_per_s": q["value"], "ms_per_step": q["ms_per_step"], "steps": q["steps"], "timed_region_s": q["config"]["timed_region_s"],
+                    "dtype": "f32s", "workload": q["config"]["workload"],
+                    "roofline": {k: rr.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "executed_frac", "bf16_mfma_frac",
+                                                        "avg_launch_us", "timing", "share_of_gpu_time", "whole_page_executed_frac")},
+                    "note": "the headline step with compute_dtype f32s: fp32 tensors / accumulation / results (fp32 parity gates, tests/test_split_gpu.py), "
+                            "products of the >= 12-channel convolutions as 6 bf16 MFMAs on the 3-way split of both factors; child process"}
+            else:
+                out["f32_split_full_step"] = {"error": f"f32s child exited with {r.returncode}"}
         # ---- files in, files out ----
         if args.e2e_pages > 0:
             # in a child process of its own, so that the leg's worker processes do not inherit this process's module state
@@ -430,6 +455,7 @@ def build_roofline(args, dom, d_iso, d_situ, kernels, exec_flops_page, pages_per
         "frac_in_situ": round(rate(d_situ) / peak, 4) if d_situ else None,
         "frac_isolated": round(rate(d_iso) / peak, 4) if d_iso else None,
         ("mfma_frac" if hbm_bound else "executed_frac"): round(lead["executed_tflops"] / peak_tf, 4),
+        **({"bf16_mfma_frac": round(lead.get("bf16_tflops", 0.0) / PEAK_BF16_MFMA_TFLOPS, 4)} if args.dtype == "f32s" else {}),
         "avg_launch_us": round(lead["avg_us"], 2),
         "launches_per_step": calls / n_prof,
         "whole_page_executed_frac": round(exec_flops_page * pages_per_s_gpu / 1e12 / peak_tf, 4),
@@ -646,7 +672,8 @@ def main():
     # ---- per-kernel timing with HIP events on the launch streams (same workload, separate passes so that the events do not
     #      perturb `value`): "in situ" = the real schedule (attention branch on its side stream, relation nets on theirs: what
     #      rocprofv3 sees), "isolated" = everything serialised on one stream, nothing beside the bracketed kernel ----------
-    peak_tf = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+    peak_tf = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS   # (f32s: fp32-equivalent FLOPs against the fp32 matrix peak;
+                                                                                         #  what its kernels execute on the bf16 pipe is bf16_mfma_frac)
 
     h_bb = gnn._backbones[dev_index].handle(dev_index) if visual else None
 
@@ -685,6 +712,9 @@ def main():
             # work) but execute 2.25x fewer multiplications on the MFMA: report both
             k["executed_flops"] = k["flops"] / 2.25 if "wino" in k["kernel"] else k["flops"]
             k["executed_tflops"] = k["tflops"] / 2.25 if "wino" in k["kernel"] else k["tflops"]
+            # split-product kernels (f32s): every fp32 product is SIX bf16 products on the bf16 pipe; executed_* stays the fp32-equivalent
+            # figure (1 x), bf16_tflops is what the bf16 matrix pipeline executes
+            k["bf16_tflops"] = 6.0 * k["tflops"] if k["kernel"].startswith(("convs_kernel", "res8s_kernel")) else 0.0
             # ALGORITHMIC bytes per launch (every input read once, every output written once: the engine's shape arithmetic) / time
             k["algo_gbs"] = k["bytes"] / (k["total_ms"] * 1e-3) / 1e9 if k["total_ms"] > 0 else 0.0
         return merged, n, main_calls
@@ -742,11 +772,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {
                 # (short on purpose: records that cut strings at 120 characters keep it whole; the long form is workload_detail)
-                "workload": (("configs[1] fp32" if args.dtype == "f32" else "configs[4] bf16 convs") + f": ARU-Net on {W}x{H} pages + "
+                "workload": (({"f32": "configs[1] fp32", "bf16": "configs[4] bf16 convs", "f32s": "configs[1] fp32, split bf16 products"}[args.dtype]) + f": ARU-Net on {W}x{H} pages + "
                              + ("no relation net" if args.no_gnn else
                                 ("configs[3] visual GNN (mixed_gnn_vn7e2)" if visual else "geometric GNN") + " per page")),
                 "workload_detail": (("BASELINE configs[1]: ARU-Net separator detection on 3000x4500 px pages, fp32, "
                                      if args.dtype == "f32" else
+                                     "BASELINE configs[1] with split products (fp32 tensors / accumulation / results; products of the wide convolutions "
+                                     "as 6 bf16 MFMAs on the 3-way bfloat16 split of both factors): ARU-Net separator detection on 3000x4500 px pages, "
+                                     if args.dtype == "f32s" else
                                      "BASELINE configs[4] precision (bf16 activations / MFMA convs, fp32 accumulate): ARU-Net separator "
                                      "detection on 3000x4500 px pages, ") + rel),
                 "height": H, "width": W, "pages_per_step_per_gpu": B, "sharding": f"pages over {world} rank(s)",

@@ -24,8 +24,10 @@ class AruConfig:
     activation_name: str = "relu"  # ARU_v1.py:43,70-75: 'relu', 'elu' or 'leaky' (leak 0.1, layers.py:10-30)
     mvn: bool = False
     apply_softmax: bool = True    # export-time class softmax -> 'output:0'
-    # 'f32' (v_mfma_f32_16x16x4_f32, the reference's precision) or 'bf16' (BASELINE config 5: bf16 MFMA operands,
-    # fp32 accumulation, fp32 activations in HBM); an engine option, not a property of the weights
+    # 'f32' (v_mfma_f32_16x16x4_f32, the reference's precision), 'bf16' (BASELINE config 5: bf16 tensors and MFMA operands,
+    # fp32 accumulation) or 'f32s' (fp32 tensors and accumulation; the products of the wide convolutions as six bf16 x bf16
+    # partial products of the three-way bfloat16 split of both factors -- fp32 results, held to the fp32 gates);
+    # an engine option, not a property of the weights
     compute_dtype: str = "f32"
 
     @property

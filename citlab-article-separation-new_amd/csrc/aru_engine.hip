@@ -135,6 +135,11 @@ struct asep_aru {
                                    // v_mfma_f32_16x16x32_bf16 with fp32 accumulation; fp32 image in, fp32 probabilities out
     bool split = false;            // cfg.compute_dtype == 2 (or ASEP_F32_SPLIT=1 with compute_dtype 0): fp32 tensors and accumulation, every product of the
                                    // convolutions with >= 12 input channels as six bf16 x bf16 partial products (split_kernels.h)
+    bf16_t* d_r8s_down_w = nullptr; // split-product level-0 blocks (res8s_kernel): tail fragments [conv][ky][part][lane][8]
+    bf16_t* d_r8s_up_w = nullptr;
+    bf16_t* d_r8s_up_w1 = nullptr;  // up block conv1: [half][ky][part][lane][8]
+    bool split_l0 = false;         // ASEP_SPLIT_L0=1: the level-0 blocks on res8s_kernel too (measured SLOWER than res8v_*: 1.97 + 1.07 against 1.43 + 1.02 ms
+                                   // per page; scripts/r4_r8s_dbg.sh: an 8 x 26-pixel block spends most of its time outside the MFMAs -- DESIGN_LESSONS 32)
     bool split_th16 = true;        // ASEP_SPLIT_TH16=0: 8 x 32 instead of 16 x 32 blocks for the 16-channel split-product layers
     bool wino_reg = true;          // ASEP_WINO_REG=0: LDS-image Winograd kernel also for the 32-channel level
     bool use_winograd = true;      // ASEP_WINOGRAD=0 selects the direct implicit-GEMM kernels everywhere
@@ -925,10 +930,57 @@ int pack_res8(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
 // chunks, and the k-th unit of work (k = block + i * grid) takes the (k / 8)-th tile of chunk k % 8: the 32 blocks of
 // an XCD work on spatially adjacent tiles at the same time, and on the rows just below right after, so the 8-row /
 // 14-column halo overlap of neighbouring tiles is served by that XCD's L2 instead of being fetched again.
+// res8s_kernel addresses its 8-channel tensors with 32-bit element offsets
+bool res8s_fits(const TL& l) {
+    for (const Tensor& t : l)
+        if ((size_t)t.H * t.W >= ((size_t)1 << 28)) return false;
+    return true;
+}
+
+// the level-0 blocks on res8s_kernel (split products): in0 = images (DOWN) / skip (UP), in1 = deconv output (UP)
+template <bool UP>
+void launch_res8s(asep_aru* m, const TL& in0, const TL* in1, const std::vector<const float*>& stats, const TL& out, const TL* pool) {
+    for (size_t b0 = 0; b0 < in0.size(); b0 += MAXP) {
+        const size_t b1 = std::min(in0.size(), b0 + MAXP);
+        Res8SArgs a{};
+        int tiles = 0;
+        double flops = 0, bytes = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            bytes += tbytes(in0[i]) + (in1 ? tbytes((*in1)[i]) : 0.0) + tbytes(out[i]) + (pool ? tbytes((*pool)[i]) : 0.0);
+            Res8Prob& p = a.p[i - b0];
+            p.img = in0[i].p; p.in1 = in1 ? (*in1)[i].p : nullptr; p.stats = stats.empty() ? nullptr : stats[i];
+            p.out = out[i].p; p.pool = pool ? (*pool)[i].p : nullptr;
+            p.H = in0[i].H; p.W = in0[i].W;
+            p.tiles_x = cdiv(in0[i].W, R8S_TW);
+            p.tile_begin = tiles;
+            tiles += p.tiles_x * cdiv(in0[i].H, R8S_TH);
+            flops += 2.0 * in0[i].H * in0[i].W * (9.0 * (UP ? 16 : 1) * 8 + 3 * 9.0 * 64);
+        }
+        a.nprob = (int)(b1 - b0);
+        a.w1 = UP ? nullptr : m->det_first.d_w;
+        a.b1 = UP ? m->d_r8_up_b1 : m->det_first.d_b;
+        a.w1s = (const u32x4*)m->d_r8s_up_w1;
+        a.wrs = (const u32x4*)(UP ? m->d_r8s_up_w : m->d_r8s_down_w);
+        a.br = UP ? m->d_r8_up_br : m->d_r8_down_br;
+        if (const char* e = getenv("ASEP_R8S_DBG")) a.dbg = atoi(e);
+        int units = tiles;
+        a.xm = oneshot_map<Res8SArgs>(m, a, R8S_TH, tiles, false, &units, [](const Res8SArgs& q, int i) { return q.p[i].H; });
+        TL sub(in0.begin() + b0, in0.begin() + b1);
+        ProfScope ps(m, UP ? "res8s_kernel<true>" : "res8s_kernel<false>", flops,
+                     std::string(UP ? "unet_up_0 (conv1[16->8]+3xconvR+add) " : "unet_down_0 (conv1+3xconvR+add+pool) ") + dims_of(sub));
+        ps.bytes = bytes;
+        hipLaunchKernelGGL(res8s_kernel<UP>, dim3(units), dim3(256), 0, m->stream, a);
+    }
+}
+
 void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats, bool want_pool, TL* d_out, TL* pool_out) {
     for (const Tensor& t : imgs) {
         d_out->push_back(new_tensor(m, t.H, t.W, 8));
         if (want_pool) pool_out->push_back(new_tensor(m, cdiv(t.H, 2), cdiv(t.W, 2), 8));
+    }
+    if (m->split && m->d_r8s_down_w && res8s_fits(imgs)) {
+        launch_res8s<false>(m, imgs, nullptr, stats, *d_out, want_pool ? pool_out : nullptr);
+        return;
     }
     for (size_t b0 = 0; b0 < imgs.size(); b0 += MAXP) {
         const size_t b1 = std::min(imgs.size(), b0 + MAXP);
@@ -966,6 +1018,10 @@ void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>&
 TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
     TL out;
     for (const Tensor& t : skip) out.push_back(new_tensor(m, t.H, t.W, 8));
+    if (m->split && m->d_r8s_up_w1 && res8s_fits(skip)) {
+        launch_res8s<true>(m, skip, &v, {}, out, nullptr);
+        return out;
+    }
     for (size_t b0 = 0; b0 < skip.size(); b0 += MAXP) {
         const size_t b1 = std::min(skip.size(), b0 + MAXP);
         Res8Args a{};
@@ -1116,6 +1172,64 @@ int pack_conv_split(asep_aru* m, PackedConv& pc, const HostTensor& w) {
     int rc = upload_bf(pk, &pc.d_ws);
     if (rc) return rc;
     m->owned.push_back(pc.d_ws);
+    return ASEP_OK;
+}
+
+// pixel-pair A fragments (pack_pair_frags, cin 8 form) of input channels c_off .. c_off + 7 of a 3x3 filter with 8 output channels, as three
+// bf16 parts: [ky][part][lane][8]
+void pack_pair_frags_split(const HostTensor& w, int cin, int c_off, std::vector<bf16_t>& dst) {
+    auto bfval = [](bf16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+    const size_t base = dst.size();
+    dst.resize(base + 3 * 3 * 64 * 8);
+    for (int ky = 0; ky < 3; ++ky)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int mrow = lane & 15, kk = lane >> 4, e = mrow >> 3, co = mrow & 7;
+                const int kx = kk - e;
+                const float v = (kx >= 0 && kx <= 2) ? w.data[(((size_t)ky * 3 + kx) * cin + c_off + j) * 8 + co] : 0.f;
+                const bf16_t h = f2bf(v);
+                const float r = v - bfval(h);
+                const bf16_t mm = f2bf(r);
+                const bf16_t part[3] = {h, mm, f2bf(r - bfval(mm))};
+                for (int s2 = 0; s2 < 3; ++s2) dst[base + (((size_t)ky * 3 + s2) * 64 + lane) * 8 + j] = part[s2];
+            }
+}
+
+// filters of the split-product level-0 blocks (res8s_kernel); shapes other than the 8-channel residual blocks: nothing packed, res8v_* / layers
+int pack_res8s(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
+    auto tail = [&](const std::string& scope, bf16_t** d_w) -> int {
+        std::vector<bf16_t> pk;
+        for (int r = 0; r < 3; ++r) {
+            auto wi = blob.find(scope + "/convR_" + std::to_string(r) + "/weights");
+            if (wi == blob.end()) return 1;
+            const HostTensor& w = wi->second;
+            if (w.dims.size() != 4 || w.dims[0] != 3 || w.dims[1] != 3 || w.dims[2] != 8 || w.dims[3] != 8) return 1;
+            pack_pair_frags_split(w, 8, 0, pk);
+        }
+        int rc = upload_bf(pk, d_w);
+        if (rc) return rc;
+        m->owned.push_back(*d_w);
+        return ASEP_OK;
+    };
+    int rc = tail("aru_net/featMapG/unet_down_0", &m->d_r8s_down_w);
+    if (rc == 1) { m->d_r8s_down_w = nullptr; return ASEP_OK; }
+    if (rc) return rc;
+    if (m->cfg.scale_space_num > 1) {
+        const std::string u = "aru_net/featMapG/unet_up_0";
+        auto w1 = blob.find(u + "/conv1/weights");
+        if (w1 == blob.end()) return ASEP_OK;
+        const HostTensor& w = w1->second;
+        if (w.dims.size() != 4 || w.dims[0] != 3 || w.dims[1] != 3 || w.dims[2] != 16 || w.dims[3] != 8) return ASEP_OK;
+        rc = tail(u, &m->d_r8s_up_w);
+        if (rc == 1) { m->d_r8s_up_w = nullptr; return ASEP_OK; }
+        if (rc) return rc;
+        std::vector<bf16_t> pk;
+        pack_pair_frags_split(w, 16, 0, pk);
+        pack_pair_frags_split(w, 16, 8, pk);
+        rc = upload_bf(pk, &m->d_r8s_up_w1);
+        if (rc) return rc;
+        m->owned.push_back(m->d_r8s_up_w1);
+    }
     return ASEP_OK;
 }
 
@@ -2007,6 +2121,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     m->split = cfg->compute_dtype == 2;
     if (const char* e = getenv("ASEP_F32_SPLIT")) m->split = !m->bf16 && atoi(e) != 0;
     if (const char* e = getenv("ASEP_SPLIT_TH16")) m->split_th16 = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_SPLIT_L0")) m->split_l0 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO_REG")) m->wino_reg = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO16")) m->wino16 = atoi(e) != 0;
@@ -2077,6 +2192,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     }
     if (!rc && !variant && !m->bf16 && cfg->feat_root == 8 && cfg->res_depth == 3 && m->det_first.k == 3) rc = pack_res8(m.get(), blob);
     if (!rc && m->bf16 && cfg->res_depth == 3 && cfg->feat_root == 8) rc = pack_res8b(m.get(), blob);
+    if (!rc && m->split && m->split_l0 && !variant && cfg->res_depth == 3 && cfg->feat_root == 8) rc = pack_res8s(m.get(), blob);
     if (!rc && m->bf16 && cfg->res_depth == 3)
         for (int l = 0; l < n && !rc; ++l) {
             const int f = cfg->feat_root << l;

@@ -70,7 +70,9 @@ typedef struct asep_aru_cfg {
     int32_t use_attention;     /* graph contains 'ARU' */
     int32_t mvn;               /* per-image standardisation of the input */
     int32_t apply_softmax;     /* export-time class softmax */
-    int32_t compute_dtype;     /* 0 = fp32 (f32 MFMA), 1 = bf16 MFMA with fp32 accumulation */
+    int32_t compute_dtype;     /* 0 = fp32 (f32 MFMA), 1 = bf16 tensors + bf16 MFMA with fp32 accumulation, 2 = fp32 tensors and accumulation with
+                                  SPLIT products: x = xh + xm + xl, w = wh + wm + wl (bfloat16 parts, exact), x w as the six largest of the nine
+                                  bf16 products on the bf16 MFMA (dropped terms <= 2^-23 |x w|): fp32 results, the fp32 parity gates */
     int32_t activation;        /* ARU_v1.py:70-75 activation_name: 0 = relu, 1 = elu, 2 = leaky (leak 0.1, layers.py:10-30).  It is the
                                   activation of the convR / conv2 layers, of the block ends, the deconvolutions and the attention CNN; the
                                   ReLU between conv1 and convR_0 of a residual block is a ReLU in every variant (ARU_v1.py:214,268) */

@@ -54,15 +54,18 @@ def _report(tag, out, ref, thr):
     return float(err.max()), u8_rate, u8_max, m_rate
 
 
-def test_whole_page_fp32_vs_oracle(whole_page):
+@pytest.mark.parametrize("dtype", ["f32", "f32s"])
+def test_whole_page_fp32_vs_oracle(whole_page, dtype):
+    """(f32s: fp32 tensors and accumulation, the wide convolutions' products as six bf16 x bf16 partial products of the three-way split of
+    both factors -- csrc/split_kernels.h; held to the fp32 gates, not to the bf16 ones)"""
     from citlab_article_separation_new_amd import net_post_processing_helper as helper
     from citlab_article_separation_new_amd.config import AruConfig
     from oracle import aru_oracle
     page, w, ref = whole_page
-    g = helper.AruGraph(w, AruConfig())
+    g = helper.AruGraph(w, AruConfig(compute_dtype=dtype))
     thr = round(float(np.median(ref[:, :, 0])), 3)
     out, u8, mask = helper.get_net_output_fused(page, g, "0", want_u8=True, threshold=thr)
-    err, u8_rate, u8_max, m_rate = _report("fp32", out, ref, thr)
+    err, u8_rate, u8_max, m_rate = _report(dtype, out, ref, thr)
     assert err <= 1e-4
     assert u8_max <= 1 and u8_rate <= 2e-3 and m_rate <= 2e-3
     # the fused epilogue is exactly uint8(p * 255) / apply_threshold of the engine's own float output
@@ -216,7 +219,8 @@ def test_whole_page_bf16_block_by_block_against_the_oracle_with_the_same_roundin
     assert worst[1] <= BF16_BLOCK_FRAME_MAX_GATE and worst_rms[2] <= BF16_BLOCK_FRAME_RMS_GATE
 
 
-def test_whole_page_fp32_end_points_and_logits_with_unit_logit_scale(unit_scale_page):
+@pytest.mark.parametrize("dtype", ["f32", "f32s"])
+def test_whole_page_fp32_end_points_and_logits_with_unit_logit_scale(unit_scale_page, dtype):
     """the whole-frame gate above is on probabilities of weights with logit_scale = 0.05 (small logits compress a
     feature-map error ~20x before the 1e-4 gate).  Here: reference-rule weights (logit_scale = 1), EVERY end point of the
     3000 x 4500 frame within 2e-5 * max|ref| (the gate tests/test_aru_gpu.py applies up to 259 x 131), the LOGITS within the same
@@ -224,7 +228,7 @@ def test_whole_page_fp32_end_points_and_logits_with_unit_logit_scale(unit_scale_
     from citlab_article_separation_new_amd import net_post_processing_helper as helper
     from citlab_article_separation_new_amd.config import AruConfig
     page, w, cfg, ref, inter = unit_scale_page
-    g = helper.AruGraph(w, cfg)
+    g = helper.AruGraph(w, AruConfig(compute_dtype=dtype))
     out = helper.get_net_output(page, g, "0")
     worst = ("", 0.0)
     for name in sorted(inter):
@@ -240,13 +244,13 @@ def test_whole_page_fp32_end_points_and_logits_with_unit_logit_scale(unit_scale_
     perr = float(np.abs(out - ref).max())
     g.close()
     # logits: the same net without the class softmax
-    cfg_l = AruConfig(apply_softmax=False)
+    cfg_l = AruConfig(apply_softmax=False, compute_dtype=dtype)
     gl = helper.AruGraph(w, cfg_l)
     logits = helper.get_net_output(page, gl, "0")
     lref = inter["logits"]
     lrel = float(np.abs(logits - lref).max()) / max(1.0, float(np.abs(lref).max()))
     gl.close()
-    print(f"\nfp32 whole frame, logit_scale 1: worst end point {worst[0]} rel {worst[1]:.2e}; logits max|l| {np.abs(lref).max():.2f} "
+    print(f"\n{dtype} whole frame, logit_scale 1: worst end point {worst[0]} rel {worst[1]:.2e}; logits max|l| {np.abs(lref).max():.2f} "
           f"rel {lrel:.2e}; max|dp| = {perr:.2e}; saturated pixels (p > 0.999): {(ref.max(axis=2) > 0.999).mean():.1%}")
     assert lrel <= 2e-5 and perr <= 1e-4
 
