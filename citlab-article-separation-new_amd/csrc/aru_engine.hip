@@ -43,6 +43,7 @@ struct PackedConv {
     // fp32 with split products (split_kernels.h): the filter as three bf16 parts, [chunk][part h, m, l][mtile][lane][8]
     int smode = -1;            // 1: Cin 12 / 16 (chunk = two taps), 2: Cin % 32 == 0 (chunk = tap x 32 channels); -1: not packed
     bf16_t* d_ws = nullptr;
+    bf16_t* d_ws16 = nullptr;  // 3x3, Cin % 16 == 0, Cin >= 32: stages of 16 channels, chunk = two taps (convs16_kernel): [stage][chunk 5][part][mtile][lane][8]
 };
 
 struct DirectConv {        // Cin == 1 first layers
@@ -140,6 +141,9 @@ struct asep_aru {
     bf16_t* d_r8s_up_w1 = nullptr;  // up block conv1: [half][ky][part][lane][8]
     bool split_l0 = false;         // ASEP_SPLIT_L0=1: the level-0 blocks on res8s_kernel too (measured SLOWER than res8v_*: 1.97 + 1.07 against 1.43 + 1.02 ms
                                    // per page; scripts/r4_r8s_dbg.sh: an 8 x 26-pixel block spends most of its time outside the MFMAs -- DESIGN_LESSONS 32)
+    int split_alds_mode = 1;       // ASEP_SPLIT_ALDS: 0 = convs_kernel for every split-product layer, 1 = convs16_kernel (A fragments through LDS) for the
+                                   // >= 32-channel layers with one m-tile of output channels, 2 = for all >= 32-channel 3x3 layers        // ASEP_SPLIT_ALDS=0: the >= 32-channel split-product layers on convs_kernel (A fragments from L2 per wave) instead of
+                                   // convs16_kernel (through LDS)
     bool split_th16 = true;        // ASEP_SPLIT_TH16=0: 8 x 32 instead of 16 x 32 blocks for the 16-channel split-product layers
     bool wino_reg = true;          // ASEP_WINO_REG=0: LDS-image Winograd kernel also for the 32-channel level
     bool use_winograd = true;      // ASEP_WINOGRAD=0 selects the direct implicit-GEMM kernels everywhere
@@ -508,6 +512,11 @@ TL run_conv_split(asep_aru* m, const PackedConv& pc, const std::string& scope, c
         for (const Tensor& t : in0) pooled->push_back(new_tensor(m, (t.H + 1) / 2, (t.W + 1) / 2, pc.cout));
     }
     const bool c16 = pc.smode == 1;
+    // (measured, 4 pages per launch: 32 -> 16 1230 -> 930 us on convs16_kernel, but 64 -> 64 378 -> 405 and 32 -> 32 431 -> 534: with more than one
+    //  m-tile the barrier per chunk and the 16-channel stages cost more than the shared fragments save; ASEP_SPLIT_ALDS=2 forces it everywhere.
+    //  The same kernel with the fragments fetched per wave (ALDS = false; 16-channel stages + halo prefetch only) spills and was slower still:
+    //  521 / 527 us for those two layers -- not instantiated)
+    const bool alds = m->split_alds_mode && pc.d_ws16 && (pc.mtiles == 1 || m->split_alds_mode == 2);
     const int mt = (pc.mtiles % 4 == 0 && !c16) ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1);
     const int th = (c16 && pc.kh == 3 && mt == 1 && m->split_th16) ? 16 : 8;
     for (size_t b0 = 0; b0 < in0.size(); b0 += MAXP) {
@@ -531,17 +540,23 @@ TL run_conv_split(asep_aru* m, const PackedConv& pc, const std::string& scope, c
         a.nprob = (int)(b1 - b0);
         a.total_tiles = tiles;
         a.c0 = in0[0].C; a.c1 = in1 ? (*in1)[0].C : 0;
-        a.wpk = (const f32x4*)pc.d_ws; a.bias = pc.d_b;
-        a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.cin / 32;
+        a.wpk = (const f32x4*)(alds ? pc.d_ws16 : pc.d_ws); a.bias = pc.d_b;
+        a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = alds ? pc.cin / 16 : pc.cin / 32;
         a.relu_in = relu_in; a.relu_out = relu_out; a.act = act;
         a.skip_full = fuse_pool && !keep_full;
+        if (const char* e = getenv("ASEP_CONVS_DBG")) a.dbg = atoi(e);
         int units = tiles;
         a.xm = conv_schedule(m, a, th, tiles, pc.mtiles / mt > 1, &units);
         dim3 grid(units, pc.mtiles / mt);
         TL sub(in0.begin() + b0, in0.begin() + b1);
         ProfScope ps(m, "convs_kernel", flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
         ps.bytes = bytes;
-        if (pc.kh == 3) {
+        if (alds) {
+            ps.set_name("convs16_kernel" + targs({ti(mt), ti(8), ti(mt == 4 ? 2 : 3), tb(true)}));
+            if (mt == 4) hipLaunchKernelGGL((convs16_kernel<4, 8, 2, true>), grid, dim3(256), 0, m->stream, a);
+            else if (mt == 2) hipLaunchKernelGGL((convs16_kernel<2, 8, 3, true>), grid, dim3(256), 0, m->stream, a);
+            else hipLaunchKernelGGL((convs16_kernel<1, 8, 3, true>), grid, dim3(256), 0, m->stream, a);
+        } else if (pc.kh == 3) {
             if (c16 && th == 16) ASEP_CONVS_LAUNCH(3, 3, true, 1, 16, 2);
             else if (c16 && mt == 2) ASEP_CONVS_LAUNCH(3, 3, true, 2, 8, 3);
             else if (c16) ASEP_CONVS_LAUNCH(3, 3, true, 1, 8, 3);
@@ -1172,6 +1187,28 @@ int pack_conv_split(asep_aru* m, PackedConv& pc, const HostTensor& w) {
     int rc = upload_bf(pk, &pc.d_ws);
     if (rc) return rc;
     m->owned.push_back(pc.d_ws);
+    if (pc.kh == 3 && pc.kw == 3 && pc.cin % 16 == 0 && pc.cin >= 32) {
+        const int stages = pc.cin / 16;
+        std::vector<bf16_t> pk16((size_t)stages * 5 * 3 * pc.mtiles * 64 * 8);
+        for (int g = 0; g < stages; ++g)
+            for (int t = 0; t < 5; ++t)
+                for (int mt = 0; mt < pc.mtiles; ++mt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int kk = lane >> 4, co = mt * 16 + (lane & 15);
+                            const int tap = 2 * t + (kk >> 1), ci = 16 * g + (kk & 1) * 8 + j;
+                            const float v = tap < taps ? W(tap, ci, co) : 0.f;
+                            const bf16_t h = f2bf(v);
+                            const float r = v - bfval(h);
+                            const bf16_t mm = f2bf(r);
+                            const bf16_t part[3] = {h, mm, f2bf(r - bfval(mm))};
+                            for (int s = 0; s < 3; ++s)
+                                pk16[(((((size_t)g * 5 + t) * 3 + s) * pc.mtiles + mt) * 64 + lane) * 8 + j] = part[s];
+                        }
+        rc = upload_bf(pk16, &pc.d_ws16);
+        if (rc) return rc;
+        m->owned.push_back(pc.d_ws16);
+    }
     return ASEP_OK;
 }
 
@@ -2122,6 +2159,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_F32_SPLIT")) m->split = !m->bf16 && atoi(e) != 0;
     if (const char* e = getenv("ASEP_SPLIT_TH16")) m->split_th16 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_SPLIT_L0")) m->split_l0 = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_SPLIT_ALDS")) m->split_alds_mode = atoi(e);
     if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO_REG")) m->wino_reg = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO16")) m->wino16 = atoi(e) != 0;

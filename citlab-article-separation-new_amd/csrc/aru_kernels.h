@@ -108,6 +108,8 @@ struct ConvArgs {
                            // The ReLU graphs' fast epilogues are not touched: a launch with act != 0 takes the general ones.
     int skip_full;         // with p[].pool: do not store the unpooled output (nobody reads it)
     XcdMap xm;             // XCD-aware block -> tile map (sched_tile)
+    int dbg;               // timing experiments of convs_kernel (ASEP_CONVS_DBG; results are wrong): 1 every chunk reads chunk 0's A fragments,
+                           // 2 no split while staging, 4 no MFMAs
 };
 
 constexpr int CONV_TH = 8;

@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256, MINB) void convs_kernel(const ConvArgs a) {
                     if (!((stmask >> i) & 1u)) v0 = v1 = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (a.relu_in) { v0 = relu4(v0); v1 = relu4(v1); }
                     u32x4 h, mm, l;
-                    split3_x8(v0, v1, h, mm, l);
+                    if (a.dbg & 2) { h = mm = l = __builtin_bit_cast(u32x4, v0); }
+                    else split3_x8(v0, v1, h, mm, l);
                     *reinterpret_cast<u32x4*>(lds + slds[i]) = h;
                     *reinterpret_cast<u32x4*>(lds + PART + slds[i]) = mm;
                     *reinterpret_cast<u32x4*>(lds + 2 * PART + slds[i]) = l;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256, MINB) void convs_kernel(const ConvArgs a) {
             __syncthreads();
         }
         auto chunk = [&](int toff) {
-            fetch(min(q + 1, nchunks - 1), afn);
+            fetch((a.dbg & 1) ? 0 : min(q + 1, nchunks - 1), afn);
             __builtin_amdgcn_sched_barrier(0);                // the next chunk's A fragments are REQUESTED here, a chunk of MFMAs ahead of their use
 #pragma unroll
             for (int nh = 0; nh < NT; nh += NH) {
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(256, MINB) void convs_kernel(const ConvArgs a) {
                     bm[n] = *reinterpret_cast<const u32x4*>(p + PART);
                     bl[n] = *reinterpret_cast<const u32x4*>(p + 2 * PART);
                 }
+                if (a.dbg & 4) continue;
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -251,6 +253,235 @@ __global__ __launch_bounds__(256, MINB) void convs_kernel(const ConvArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// convs16_kernel: the 3x3 layers with >= 32 input channels, A fragments through LDS.
+// convs_kernel's waves fetch their A fragments from L2 themselves: with all output channels of a 64-channel layer in every wave that is
+// 12 KB per wave and chunk, 8 waves per CU = 64 B per clock -- the whole throughput of the CU's vector memory path, hit or miss (timing
+// experiments: without any MFMA the kernel still took 60 % of its time, scripts/r4_convs_dbg.sh).  Here the block copies a chunk's fragments to
+// LDS ONCE (global_load_lds, no registers, double buffered, one barrier per chunk) and its four waves read them from there; to make
+// room the stages are 16 input channels wide (K chunk = two taps x 16 channels, 5 chunks for the 9 taps: 10 % of the MFMA slots idle)
+// and the next stage's halo tile is requested while the current one is multiplied.
+//   a.wpk = pack_conv_split mode 3: [stage (16 channels)][chunk 5][part 3][m-tile][lane] x 16 bytes.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int TH, int MINB, bool ALDS>
+__global__ __launch_bounds__(256, MINB) void convs16_kernel(const ConvArgs a) {
+    constexpr int KH = 3, KW = 3, TW = 32, NT = TH * 2 / 4;
+    static_assert(NT == 4, "8 x 32 tiles: a wave owns two rows");
+    constexpr int LH = TH + KH - 1, LW = TW + KW - 1, PT = 1, PL = 1, TAPS = 9, CPS = 5;
+    constexpr int PART = LH * LW * 32;                                          // one part: a 32-byte plane (16 channels) per pixel
+    constexpr int NU = LH * LW * 2, NLOAD = (NU + 255) / 256;                   // 8-channel units of a stage's halo tile
+    constexpr int ABUF = ALDS ? 3 * MT * 1024 : 0;                              // a chunk's A fragments: [part][m-tile][lane] x 16 bytes
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PART + 2 * ABUF + 16];
+    unsigned char* const albs = lds + 3 * PART;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int bid = sched_tile(a.xm);
+    if (bid < 0) return;
+    int pi = 0;
+    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
+    const ConvProb& P = a.p[pi];
+    const int tile = bid - P.tile_begin;
+    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH, mt0 = blockIdx.y * MT;
+    const int H = P.H, W = P.W, cout = a.cout;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int c = (mt0 + m) * 16 + kk * 4;
+        const f32x4 b4 = c < cout ? *reinterpret_cast<const f32x4*>(a.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = b4;
+    }
+    int nbase[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int id = wave * NT + n;
+        nbase[n] = ((id >> 1) * LW + (id & 1) * 16 + j) * 32 + (kk & 1) * 16;
+    }
+    if (P.res) {                                              // the residual joins the accumulators' initial value (see convs_kernel)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int c = (mt0 + m) * 16 + kk * 4;
+            if (c < cout) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int id = wave * NT + n;
+                    const int y = min(y0 + (id >> 1), H - 1), x = min(x0 + (id & 1) * 16 + j, W - 1);
+                    acc[m][n] += *reinterpret_cast<const f32x4*>(P.res + ((size_t)y * W + x) * cout + c);
+                }
+            }
+        }
+    }
+    // chunk q's A fragments -> LDS buffer q & 1: unit f = part * MT + m (1 KB = one wave-wide copy), dealt to the waves
+    const int nstages = a.groups, nchunks = nstages * CPS;
+    const u32x4* __restrict__ wsrc = reinterpret_cast<const u32x4*>(a.wpk) + (size_t)mt0 * 64 + lane;
+    const size_t wpart = (size_t)a.mtiles * 64;
+    // ALDS = false: every wave fetches its fragments itself, one chunk ahead (convs_kernel's form; no barrier inside a stage)
+    u32x4 afr[ALDS ? 1 : 3][ALDS ? 1 : MT], afn[ALDS ? 1 : 3][ALDS ? 1 : MT];
+    auto fetch = [&](int q, auto& dst) {
+        const u32x4* __restrict__ s0 = wsrc + (size_t)q * 3 * wpart;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) dst[s][m] = s0[s * wpart + m * 64];
+    };
+    auto copy_a = [&](int q) {
+        if constexpr (!ALDS) return;
+        const u32x4* __restrict__ s0 = wsrc + (size_t)q * 3 * wpart;
+        unsigned char* const dst = albs + (q & 1) * ABUF;
+#pragma unroll
+        for (int f0 = 0; f0 < 3 * MT; f0 += 4) {
+            const int f = f0 + wave;                          // wave-uniform
+            if (f < 3 * MT) {
+                const int s = f / MT, m = f - s * MT;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + s * wpart + m * 64),
+                                                 (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // halo loader slots (pixel, 8-channel unit)
+    int spix[NLOAD], slds[NLOAD];
+    unsigned stmask = 0;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+        const int u = min(tid + i * 256, NU - 1);
+        const int pix = u >> 1, sub = u & 1;
+        const int ly = pix / LW, lx = pix - ly * LW;
+        const int gy = y0 - PT + ly, gx = x0 - PL + lx;
+        spix[i] = min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1);
+        slds[i] = pix * 32 + sub * 16;
+        stmask |= ((gy >= 0 && gy < H && gx >= 0 && gx < W && tid + i * 256 < NU) ? 1u : 0u) << i;
+    }
+    const int sub0 = (tid & 1) * 8;
+    f32x4 st0[NLOAD], st1[NLOAD];
+    auto request = [&](int g) {                               // stage g's halo tile -> registers
+        const int c = g * 16 + sub0;
+        const bool from0 = c < a.c0;
+        const float* __restrict__ src = from0 ? P.in0 + c : P.in1 + (c - a.c0);
+        const int cs = from0 ? a.c0 : a.c1;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const float* p = src + (size_t)spix[i] * cs;
+            st0[i] = *reinterpret_cast<const f32x4*>(p);
+            st1[i] = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+    };
+    auto deposit = [&]() {                                    // registers -> the three part planes
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            if (i * 256 + 255 < NU || tid + i * 256 < NU) {
+                f32x4 v0 = st0[i], v1 = st1[i];
+                if (!((stmask >> i) & 1u)) v0 = v1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.relu_in) { v0 = relu4(v0); v1 = relu4(v1); }
+                u32x4 h, mm, l;
+                split3_x8(v0, v1, h, mm, l);
+                *reinterpret_cast<u32x4*>(lds + slds[i]) = h;
+                *reinterpret_cast<u32x4*>(lds + PART + slds[i]) = mm;
+                *reinterpret_cast<u32x4*>(lds + 2 * PART + slds[i]) = l;
+            }
+        }
+    };
+    request(0);
+    copy_a(0);
+    if constexpr (!ALDS) fetch(0, afr);
+    deposit();
+    if constexpr (ALDS) __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's share of chunk 0's fragments has landed
+    __syncthreads();
+
+    int q = 0;
+    for (int g = 0; g < nstages; ++g) {
+        if (g + 1 < nstages) request(g + 1);                  // in flight during this stage's MFMAs
+#pragma unroll
+        for (int t = 0; t < CPS; ++t) {
+            if constexpr (ALDS) { if (q + 1 < nchunks) copy_a(q + 1); }
+            else { fetch(min(q + 1, nchunks - 1), afn); __builtin_amdgcn_sched_barrier(0); }
+            const int ta = 2 * t, tb = 2 * t + 1 < TAPS ? 2 * t + 1 : TAPS - 1;           // padded slot: zero weights, finite data
+            const int oa = ((ta / KW) * LW + ta % KW) * 32, ob = ((tb / KW) * LW + tb % KW) * 32;
+            const int toff = (kk >> 1) ? ob : oa;
+            const unsigned char* const ab = albs + (q & 1) * ABUF + lane * 16;
+            u32x4 af[3][MT];
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    if constexpr (ALDS) af[s][m] = *reinterpret_cast<const u32x4*>(ab + (s * MT + m) * 1024);
+                    else af[s][m] = afr[s][m];
+                }
+            u32x4 bh[NT], bm[NT], bl[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const unsigned char* p = lds + nbase[n] + toff;
+                bh[n] = *reinterpret_cast<const u32x4*>(p);
+                bm[n] = *reinterpret_cast<const u32x4*>(p + PART);
+                bl[n] = *reinterpret_cast<const u32x4*>(p + 2 * PART);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    f32x4 c = acc[m][n];
+                    c = mfma_bf16_k32(af[2][m], bh[n], c);            // smallest terms first
+                    c = mfma_bf16_k32(af[0][m], bl[n], c);
+                    c = mfma_bf16_k32(af[1][m], bm[n], c);
+                    c = mfma_bf16_k32(af[1][m], bh[n], c);
+                    c = mfma_bf16_k32(af[0][m], bm[n], c);
+                    c = mfma_bf16_k32(af[0][m], bh[n], c);
+                    acc[m][n] = c;
+                }
+            ++q;
+            if constexpr (ALDS) {
+                if (t + 1 < CPS) {
+                    __builtin_amdgcn_s_waitcnt(0x0f70);      // the next chunk's fragments (and, once, the next halo tile) have landed
+                    __syncthreads();                          // ... for every wave; this chunk's buffer may be overwritten
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) afr[s][m] = afn[s][m];
+            }
+        }
+        if (g + 1 < nstages) {
+            __syncthreads();                                  // the stage's B fragments are read
+            deposit();
+            if constexpr (ALDS) __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (as convs_kernel) ----
+    const int Wp = (W + 1) >> 1;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int c = (mt0 + m) * 16 + kk * 4;
+        const bool cok = c < cout;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int id = wave * NT + n;
+            const int y = y0 + (id >> 1), x = x0 + (id & 1) * 16 + j;
+            const bool ok = cok && y < H && x < W;
+            const size_t p = ((size_t)min(y, H - 1) * W + min(x, W - 1)) * cout + (cok ? c : 0);
+            f32x4 v = acc[m][n];
+            if (a.relu_out) v = relu4(v);
+            else if (a.act) v = act4(v, a.act);
+            acc[m][n] = v;
+            if (ok && !a.skip_full) *reinterpret_cast<f32x4*>(P.out + p) = v;
+        }
+        if (P.pool) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                if (n & 2) continue;
+                const int id = wave * NT + n;
+                const int y = y0 + (id >> 1), x = x0 + (id & 1) * 16 + j;
+                pool2_store(acc[m][n], acc[m][n + 2], y + 1 < H, x + 1 < W, (j & 1) == 0 && cok && y < H && x < W,
+                            P.pool + ((size_t)(y >> 1) * Wp + (x >> 1)) * cout + (cok ? c : 0));
+            }
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // res8s_kernel<UP>: a WHOLE level-0 residual block (8 channels) with split products, fp32 tensors in HBM.

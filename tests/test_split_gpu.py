@@ -56,9 +56,10 @@ def test_split_products_match_the_oracle_at_the_fp32_gates(H, W):
 
 
 @pytest.mark.parametrize("H,W", [(250, 333), (515, 260)])
-def test_split_products_agree_with_the_plain_fp32_path(H, W):
+def test_split_products_agree_with_the_plain_fp32_path(H, W, monkeypatch):
     """unit logit scale, every end point and the logits: the two fp32 paths of the engine differ by the order of their sums and by the
     split's dropped terms (<= 2^-23 of a product) only"""
+    monkeypatch.delenv("ASEP_F32_SPLIT", raising=False)        # (the switch would put the fp32 model on the split kernels too)
     from citlab_article_separation_new_amd import net_post_processing_helper as helper
     from citlab_article_separation_new_amd.config import AruConfig
     cfg, w, gs = _setup({"apply_softmax": False}, logit_scale=1.0)
@@ -114,6 +115,22 @@ def test_batched_pages_equal_single_pages():
     torch.cuda.synchronize()
     for b in range(B):
         assert np.array_equal(d_out[b].cpu().numpy(), helper.get_net_output(pages[b], graph, "0")), b
+    graph.close()
+
+
+@pytest.mark.parametrize("H,W", [(150, 131), (64, 300)])
+def test_a_fragments_through_lds_for_every_wide_layer(H, W, monkeypatch):
+    """ASEP_SPLIT_ALDS=2: convs16_kernel (16-channel stages, a chunk's A fragments copied to LDS once per block) for every 3x3 layer with >= 32
+    input channels, not only for those with one m-tile of output channels"""
+    monkeypatch.setenv("ASEP_SPLIT_ALDS", "2")
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from oracle import aru_oracle
+    cfg, w, graph = _setup()
+    img = _image(H, W, 5)
+    ref, inter = aru_oracle.forward_torch(img, w, cfg, return_intermediates=True)
+    out = helper.get_net_output(img, graph, "0")
+    _check_endpoints(helper, graph, inter)
+    assert float(np.abs(out - ref).max()) <= PROB_TOL
     graph.close()
 
 
