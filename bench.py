@@ -481,6 +481,8 @@ def build_roofline(args, dom, d_iso, d_situ, kernels, exec_flops_page, pages_per
         "whole_page_algorithmic_gb": round(sum(k["bytes"] for k in kernels) / (B * n_prof) / 1e9, 3),
         "mfma_peak": peak_tf, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_achievable_gbs": ACHIEVABLE_HBM_GBS,
     }
+    if args.dtype == "f32s":                    # (20 keys at most: the bf16 pipe's share takes the place of the launch count, which moves to the detail)
+        detail["launches_per_step"] = r.pop("launches_per_step")
     tp = os.path.join(ROOT, "profiles", "traffic_per_kernel.json" if args.dtype == "f32" else f"traffic_per_kernel_{args.dtype}.json")
     # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md, scripts/make_traffic_json.py).  The counters cannot
     # be read from inside this process: the figure comes from the committed summary of the SAME workload (same pages per step, same

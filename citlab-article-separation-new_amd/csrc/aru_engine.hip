@@ -139,8 +139,10 @@ struct asep_aru {
     bf16_t* d_r8s_down_w = nullptr; // split-product level-0 blocks (res8s_kernel): tail fragments [conv][ky][part][lane][8]
     bf16_t* d_r8s_up_w = nullptr;
     bf16_t* d_r8s_up_w1 = nullptr;  // up block conv1: [half][ky][part][lane][8]
-    bool split_l0 = false;         // ASEP_SPLIT_L0=1: the level-0 blocks on res8s_kernel too (measured SLOWER than res8v_*: 1.97 + 1.07 against 1.43 + 1.02 ms
+    int split_l0 = 0;              // ASEP_SPLIT_L0=1: the level-0 blocks on res8s_kernel too (measured SLOWER than res8v_*: 1.97 + 1.07 against 1.43 + 1.02 ms
                                    // per page; scripts/r4_r8s_dbg.sh: an 8 x 26-pixel block spends most of its time outside the MFMAs -- DESIGN_LESSONS 32)
+    int convs_dbg = 0, r8s_dbg = 0; // ASEP_CONVS_DBG / ASEP_R8S_DBG (read at load): timing experiments that drop one ingredient of a split-product kernel
+                                   // (scripts/r4_convs_dbg.sh, scripts/r4_r8s_dbg.sh; the results are wrong on purpose)
     int split_alds_mode = 1;       // ASEP_SPLIT_ALDS: 0 = convs_kernel for every split-product layer, 1 = convs16_kernel (A fragments through LDS) for the
                                    // >= 32-channel layers with one m-tile of output channels, 2 = for all >= 32-channel 3x3 layers        // ASEP_SPLIT_ALDS=0: the >= 32-channel split-product layers on convs_kernel (A fragments from L2 per wave) instead of
                                    // convs16_kernel (through LDS)
@@ -544,7 +546,7 @@ TL run_conv_split(asep_aru* m, const PackedConv& pc, const std::string& scope, c
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = alds ? pc.cin / 16 : pc.cin / 32;
         a.relu_in = relu_in; a.relu_out = relu_out; a.act = act;
         a.skip_full = fuse_pool && !keep_full;
-        if (const char* e = getenv("ASEP_CONVS_DBG")) a.dbg = atoi(e);
+        a.dbg = m->convs_dbg;
         int units = tiles;
         a.xm = conv_schedule(m, a, th, tiles, pc.mtiles / mt > 1, &units);
         dim3 grid(units, pc.mtiles / mt);
@@ -977,7 +979,7 @@ void launch_res8s(asep_aru* m, const TL& in0, const TL* in1, const std::vector<c
         a.w1s = (const u32x4*)m->d_r8s_up_w1;
         a.wrs = (const u32x4*)(UP ? m->d_r8s_up_w : m->d_r8s_down_w);
         a.br = UP ? m->d_r8_up_br : m->d_r8_down_br;
-        if (const char* e = getenv("ASEP_R8S_DBG")) a.dbg = atoi(e);
+        a.dbg = m->r8s_dbg;
         int units = tiles;
         a.xm = oneshot_map<Res8SArgs>(m, a, R8S_TH, tiles, false, &units, [](const Res8SArgs& q, int i) { return q.p[i].H; });
         TL sub(in0.begin() + b0, in0.begin() + b1);
@@ -2158,8 +2160,10 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     m->split = cfg->compute_dtype == 2;
     if (const char* e = getenv("ASEP_F32_SPLIT")) m->split = !m->bf16 && atoi(e) != 0;
     if (const char* e = getenv("ASEP_SPLIT_TH16")) m->split_th16 = atoi(e) != 0;
-    if (const char* e = getenv("ASEP_SPLIT_L0")) m->split_l0 = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_SPLIT_L0")) m->split_l0 = atoi(e);
     if (const char* e = getenv("ASEP_SPLIT_ALDS")) m->split_alds_mode = atoi(e);
+    if (const char* e = getenv("ASEP_CONVS_DBG")) m->convs_dbg = atoi(e);
+    if (const char* e = getenv("ASEP_R8S_DBG")) m->r8s_dbg = atoi(e);
     if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO_REG")) m->wino_reg = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO16")) m->wino16 = atoi(e) != 0;

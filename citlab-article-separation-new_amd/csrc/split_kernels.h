@@ -790,4 +790,5 @@ __global__ __launch_bounds__(256, 3) void res8s_kernel(const Res8SArgs a) {
     }
 }
 
+
 }  // namespace asep

@@ -56,6 +56,35 @@ def _kernel(name, calls, avg_us, flops, byts, wino=False):
     return k
 
 
+def test_split_product_line_keeps_the_block_at_twenty_keys_and_names_the_bf16_share():
+    """--dtype f32s: fp32-equivalent FLOPs against the fp32 matrix peak (`frac`), and what the kernel executes on the bf16 pipe (six
+    bf16 products per fp32 product) against the bf16 peak (`bf16_mfma_frac`)"""
+    args = types.SimpleNamespace(dtype="f32s", no_gnn=False, gnn="visual")
+    dom = _kernel("convs_kernel<3,3,false,4,8,2>", 216, 300.0, 56.76e9, 0.374e9)
+    dom["bf16_tflops"] = 6.0 * dom["tflops"]
+    other = _kernel("res8v_up_kernel", 18, 3900.0, 282.9e9, 4.7e9)
+    r, d = bench.build_roofline(args, dom, dom, dom, [dom, other], 400e9, 135.0, bench.PEAK_F32_MFMA_TFLOPS, 4.0, 3, True, 16, 4500, 3000)
+    assert len(r) <= 20 and r["bound"] == "mfma" and r["peak"] == bench.PEAK_F32_MFMA_TFLOPS
+    assert abs(r["bf16_mfma_frac"] - 6.0 * r["achieved"] / bench.PEAK_BF16_MFMA_TFLOPS) < 1e-3 and d["launches_per_step"] == 72
+    import sys as _sys
+    old = _sys.argv
+    try:
+        _sys.argv = ["bench.py", "--dtype", "f32s"]
+        a = bench.parse_args()
+    finally:
+        _sys.argv = old
+    assert a.dtype == "f32s" and a.split_steps > 0 and a.steps == 80
+
+
+def test_compute_dtype_names_of_the_python_side_match_the_header():
+    import re
+    from citlab_article_separation_new_amd.net_post_processing_helper import COMPUTE_DTYPES
+    hdr = open(os.path.join(ROOT, "include", "asep_hip.h")).read()
+    m = re.search(r"int32_t compute_dtype;\s*/\*(.*?)\*/", hdr, re.S)
+    assert m and "0 = fp32" in m.group(1) and "1 = bf16" in m.group(1) and "2 = fp32 tensors" in m.group(1)
+    assert COMPUTE_DTYPES == {"f32": 0, "bf16": 1, "f32s": 2}
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_roofline_block_shape_and_arithmetic(dtype, monkeypatch):
     args = types.SimpleNamespace(dtype=dtype, no_gnn=False, gnn="visual")

@@ -134,7 +134,7 @@ def test_a_fragments_through_lds_for_every_wide_layer(H, W, monkeypatch):
     graph.close()
 
 
-@pytest.mark.parametrize("H,W", [(200, 150), (67, 131), (9, 27)])
+@pytest.mark.parametrize("H,W", [(200, 150), (67, 131), (9, 27), (300, 420)])
 def test_level0_blocks_on_the_split_kernel(H, W, monkeypatch):
     """ASEP_SPLIT_L0=1: res8s_kernel (the 8-channel residual blocks with split products; off by default -- slower than the vector-ALU
     kernels, DESIGN_LESSONS 32) gives the fp32 results too"""
