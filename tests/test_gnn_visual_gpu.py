@@ -89,6 +89,30 @@ def test_visual_forward_with_a_bf16_backbone_stays_within_the_bf16_tolerance():
     graph.close()
 
 
+def test_visual_forward_with_a_split_product_backbone_holds_the_fp32_gates():
+    """``backbone={"compute_dtype": "f32s"}``: the RU backbone's wide convolutions on the split-product kernels (fp32 tensors and results,
+    csrc/split_kernels.h) -- the fp32 tolerances of test_visual_forward_matches_oracle apply unchanged"""
+    from citlab_article_separation_new_amd import gnn_io, synth
+    from oracle import gnn_oracle
+    cfg, w, graph = _setup(mvn=True, backbone={"compute_dtype": "f32s"})
+    _, _, graph32 = _setup(mvn=True)
+    rng = np.random.default_rng(3)
+    N = 30
+    g = synth.synth_graph(1, N=N, n_pairs=80, node_dim=7)
+    img, regions, npts = _page(rng, N, 200, 136)
+    probs = gnn_io.gnn_forward_visual(graph, N, g["interacting_nodes"], g["node_features"], g["edge_features"], img, regions, npts)
+    u = gnn_io.gnn_node_features(graph, N)
+    ref_probs, ref_u = gnn_oracle.forward_visual(N, g["interacting_nodes"], g["node_features"], g["edge_features"],
+                                                 img, regions, npts, None, w, cfg)
+    du, dp = float(np.abs(u - ref_u).max()), float(np.abs(probs - ref_probs).max())
+    print("f32s backbone: max |du| =", du, "max |u| =", float(np.abs(ref_u).max()), "max |dp| =", dp)
+    assert np.array_equal(u[:, :7], ref_u[:, :7])
+    assert du <= 1e-4 * max(1.0, float(np.abs(ref_u).max())) and dp <= 1e-5
+    gnn_io.gnn_forward_visual(graph32, N, g["interacting_nodes"], g["node_features"], g["edge_features"], img, regions, npts)
+    assert not np.array_equal(gnn_io.gnn_node_features(graph32, N), u)              # the split kernels did run
+    graph.close(); graph32.close()
+
+
 def test_session_mirror_with_image_feeds_and_pb_roundtrip(tmp_path):
     from citlab_article_separation_new_amd import gnn_io, pb_import, synth
     from citlab_article_separation_new_amd.gnn_input import build_full_relations

@@ -259,6 +259,18 @@ def test_compute_dtype_switch_for_models_loaded_from_files(tmp_path, monkeypatch
     monkeypatch.setenv("ASEP_COMPUTE_DTYPE", "fp16")
     with pytest.raises(ValueError, match="ASEP_COMPUTE_DTYPE"):
         helper.load_graph(pb)
+    # fp32 with split products: the same file, fp32 results (the fp32 tolerance against the plain fp32 path), the same command line
+    monkeypatch.setenv("ASEP_COMPUTE_DTYPE", "f32s")
+    gs = helper.load_graph(pb)
+    assert gs.cfg.compute_dtype == "f32s"
+    ps = helper.get_net_output(grey, gs, "0")
+    gs.close()
+    ds = float(np.abs(ps - p32).max())
+    assert 0.0 < ds <= 1e-5, ds
+    (data / "page" / "p0.xml.xml").unlink()
+    assert cli.main(["--path_to_image_list", str(lst), "--path_to_pb", pb, "--mode", "separator", "--fixed_height", "450",
+                     "--threshold", "0.5", "--num_processes", "1"]) == 0
+    assert (data / "page" / "p0.xml.xml").exists()
 
 
 # what the bf16 command line holds against the fp32 oracle's regions on a mask cut through the MIDDLE of the net's output (no margin)
