@@ -789,6 +789,8 @@ def main():
                 "relation_net": "none" if args.no_gnn else args.gnn,
                 "timed_region_s": round(dt, 3),
                 "aru_cfg": "ARU featRoot=8 levels=5 res_depth=3 att_scales=3 n_classes=2",
+                # engine / bench switches of the environment this line was measured under (none = the defaults the documents describe)
+                "engine_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("ASEP_") and k != "ASEP_BENCH_DEVICE"},
                 "gflop_per_page": round(flops_page / 1e9, 2),
                 "whole_page_tflops_per_gpu": round(flops_page * value / world / 1e12, 3),
             },
