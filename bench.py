@@ -800,7 +800,9 @@ def main():
                          "avg_us_isolated": None if k.get("avg_us_isolated") is None else round(k["avg_us_isolated"], 2),
                          "flops": k["flops"], "tflops": round(k["tflops"], 2), "executed_tflops": round(k["executed_tflops"], 2),
                          "executed_frac_of_peak": round(k["executed_tflops"] / peak_tf, 4),
-                         "bytes": k["bytes"], "algorithmic_gbs": round(k["algo_gbs"], 1)}
+                         "bytes": k["bytes"], "algorithmic_gbs": round(k["algo_gbs"], 1),
+                         # split-product kernels: six bf16 products per fp32 product, against the bf16 matrix peak
+                         **({"bf16_mfma_frac": round(k["bf16_tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)} if k.get("bf16_tflops") else {})}
                         for k in kernels],
             "secondary": secondary,
         }
