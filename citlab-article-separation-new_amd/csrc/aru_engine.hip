@@ -147,8 +147,6 @@ struct asep_aru {
                                    // >= 32-channel layers with one m-tile of output channels, 2 = for all >= 32-channel 3x3 layers        // ASEP_SPLIT_ALDS=0: the >= 32-channel split-product layers on convs_kernel (A fragments from L2 per wave) instead of
                                    // convs16_kernel (through LDS)
     bool split_th16 = true;        // ASEP_SPLIT_TH16=0: 8 x 32 instead of 16 x 32 blocks for the 16-channel split-product layers
-    bool res_init = true;          // ASEP_RES_INIT=0: 16-channel layers with a residual operand on the two-blocks-per-CU variant (residual prefetched into
-                                   // registers) instead of the four-block one (residual = the accumulators' initial value)
     bool wino_reg = true;          // ASEP_WINO_REG=0: LDS-image Winograd kernel also for the 32-channel level
     bool use_winograd = true;      // ASEP_WINOGRAD=0 selects the direct implicit-GEMM kernels everywhere
     bool big_tile2 = true;         // ASEP_BIGTILE2=0: 8 x 32 double-buffered blocks for 32 -> 16 convs without residual operand
@@ -486,7 +484,7 @@ void launch_conv_k(asep_aru* m, const PackedConv& pc, const ConvArgs& a, int tot
         }
     }
     if (pc.c8) ASEP_CONV_LAUNCH(KH, KW, 1, true, CONV_TH, true, false, false, 2);
-    else if (mt == 1 && big_tile && (!has_res || (KH == 3 && m->res_init))) ASEP_CONV_LAUNCH(3, 3, 1, false, 16, false, false, false, 4);   // (a residual operand: the accumulators' initial value)
+    else if (mt == 1 && big_tile && !has_res) ASEP_CONV_LAUNCH(3, 3, 1, false, 16, false, false, false, 4);
     else if (mt == 1 && big_tile) ASEP_CONV_LAUNCH(KH, KW, 1, false, 16, false, false, false, 2);
     else if (mt == 4) ASEP_CONV_LAUNCH(KH, KW, 4, false, CONV_TH, true, false, false, 2);
     else if (mt == 2 && !res_op) ASEP_CONV_LAUNCH(KH, KW, 2, false, CONV_TH, true, false, false, 3);   // no residual prefetch: three blocks per CU
@@ -2167,7 +2165,6 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_CONVS_DBG")) m->convs_dbg = atoi(e);
     if (const char* e = getenv("ASEP_R8S_DBG")) m->r8s_dbg = atoi(e);
     if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
-    if (const char* e = getenv("ASEP_RES_INIT")) m->res_init = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO_REG")) m->wino_reg = atoi(e) != 0;
     if (const char* e = getenv("ASEP_WINO16")) m->wino16 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSE_POOL")) m->fuse_pool = atoi(e) != 0;

@@ -320,23 +320,6 @@ __global__ __launch_bounds__(256, MINB) void conv_mfma_kernel(const ConvArgs a) 
             }
         }
     }
-    // four-blocks-per-CU variant (no registers for a prefetch): the residual operand IS the accumulators' initial value -- its loads fly with
-    // the first halo tile and cost no register beyond the accumulators (round 4, from split_kernels.h; such layers ran on the two-block variant)
-    constexpr bool RES_INIT = MINB == 4;
-    if constexpr (RES_INIT) {
-        if (P.res) {                                          // (channels of a last, partial quad are added in the epilogue's scalar tail)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int id = wave * NT + n;
-                const int y = min(y0 + (id >> 1), P.Ho - 1), x = min(x0 + (id & 1) * 16 + j, P.Wo - 1);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int c = (mt0 + m) * 16 + kk * 4;
-                    if (c + 3 < a.cout) acc[m][n] = *reinterpret_cast<const f32x4*>(P.res + ((size_t)y * P.Wo + x) * a.cout + c);
-                }
-            }
-        }
-    }
     stage_store(0);
     __syncthreads();
 
@@ -424,7 +407,7 @@ __global__ __launch_bounds__(256, MINB) void conv_mfma_kernel(const ConvArgs a) 
                 f32x4 v = acc[m][n] + b4;
                 if constexpr (RES_PREFETCH) {
                     if (res) v += resv[m][n];
-                } else if constexpr (!RES_INIT) {
+                } else {
                     if (res) v += *reinterpret_cast<const f32x4*>(rp + d);
                 }
                 v = imax4(v, relu_o);
@@ -462,7 +445,7 @@ __global__ __launch_bounds__(256, MINB) void conv_mfma_kernel(const ConvArgs a) 
                 v += *reinterpret_cast<const f32x4*>(a.bias + c);
                 if constexpr (RES_PREFETCH) {
                     if (res) v += resv[m][n];
-                } else if constexpr (!RES_INIT) {
+                } else {
                     if (res) v += *reinterpret_cast<const f32x4*>(res + p * a.cout + c);
                 }
                 if (a.relu_out) v = relu4(v);
