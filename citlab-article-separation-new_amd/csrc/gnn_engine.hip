@@ -89,6 +89,10 @@ struct asep_gnn {
     std::vector<std::unique_ptr<PageLane>> page_lanes;
     hipEvent_t ev_fork = nullptr;
     int n_page_lanes = 1;
+    bool batch_graph = false;         // ASEP_GNN_BATCH=1: the pages of asep_gnn_forward_visual_batch_dev stage by stage (forward_batch_impl: ROI kernels, steps,
+                                      // classifier as ONE launch over the pages) instead of one after the other.  Measured (profiles/r4_ab, r4k): 240 -> 90 launches
+                                      // per 16-page call, bit-identical results, step rate unchanged (fp32 120.5 -> 120.8, bf16 419.3 -> 417.9 pages/s): the graph
+                                      // chains already hide behind the page net on their own stream -- off by default
     void free_visual() {
         for (void* p : vis_owned)
             if (p) (void)hipFree(p);
@@ -399,6 +403,128 @@ int forward_impl(asep_gnn* g, BufferPool& pool, int N, int E, const int32_t* d_e
     return ASEP_OK;
 }
 
+// ---- several pages' graphs, stage by stage (asep_gnn_forward_visual_batch_dev) --------------------------------------------------
+// The graph of one page is ~15 launches of at most 200 workgroups whose duration is the latency of ONE workgroup's work (a transition
+// step: 60-100 us for 200 nodes); sixteen pages one after the other are 48 such step launches per call.  Here every stage that is a
+// fused kernel runs ONCE for all pages (blockIdx.y = page, GnnBatch): the ROI kernels per feature map, the transition steps, the pair
+// classifier.  Same kernel bodies on the same values: bit-identical to the page-by-page form (tests/test_gnn_visual_gpu.py).
+struct GraphCtx {
+    int N = 0, E = 0, R = 0;
+    const float* d_u = nullptr;       // node features the steps read (compressed if the model compresses)
+    const float* d_fed = nullptr;     // as fed
+    const float* d_ef = nullptr;
+    const int32_t* d_rel = nullptr;
+    const int32_t* d_edges_in = nullptr;
+    float* d_out = nullptr;
+    EdgeBufs eb{};
+    float* h[2] = {nullptr, nullptr};
+    float* cs[2] = {nullptr, nullptr};
+    float *Pt = nullptr, *Qt = nullptr, *upad = nullptr;
+};
+
+bool graph_batch_eligible(const asep_gnn* g) {
+    const int mode = g->use_step ? g->mode : STEP_GENERIC;
+    return (mode == STEP_BIG || mode == STEP_SMALL) && g->cfg.attention_heads == 0 && g->cfg.output_type == 0 && !g->Wc;
+}
+
+// n <= GNN_BATCH pages: edges / buffers per page, then the steps and the classifier as batched launches.  The pool is NOT reset between pages.
+int forward_batch_impl(asep_gnn* g, BufferPool& pool, int n, GraphCtx* cx, hipStream_t s) {
+    const asep_gnn_cfg& c = g->cfg;
+    const int H = g->H;
+    const int mode = g->use_step ? g->mode : STEP_GENERIC;
+    int maxN = 0, maxR = 0;
+    for (int b = 0; b < n; ++b) {
+        GraphCtx& q = cx[b];
+        if (q.N < 1 || q.E < 0 || q.R < 0) { set_error("asep_gnn_forward: bad sizes N=%d E=%d R=%d", q.N, q.E, q.R); return ASEP_ERR_ARG; }
+        if ((size_t)q.N * q.N > (size_t)1 << 30) { set_error("asep_gnn_forward: N=%d too large for the dense edge table", q.N); return ASEP_ERR_UNSUPPORTED; }
+        int rc = correct_edges_dev(g, pool, q.N, q.E, q.d_edges_in, q.eb, s);
+        if (rc) return rc;
+        const size_t nh = (size_t)q.N * H;
+        q.h[0] = (float*)pool.get(nh * 4); q.h[1] = (float*)pool.get(nh * 4);
+        q.cs[0] = (float*)pool.get(nh * 4); q.cs[1] = (float*)pool.get(nh * 4);
+        q.Pt = (float*)pool.get((size_t)q.N * c.cls_hidden1 * 4);
+        q.Qt = (float*)pool.get((size_t)q.N * c.cls_hidden1 * 4);
+        if (mode == STEP_BIG) {
+            q.upad = (float*)pool.get((size_t)q.N * g->Upad * 4);
+            hipLaunchKernelGGL(gnn_pad_rows_kernel, dim3(cdiv(q.N * g->Upad, 256)), dim3(256), 0, s, q.d_u, q.N, g->U, q.upad, g->Upad);
+        }
+        ASEP_HIP_CHECK(hipMemsetAsync(q.h[0], 0, nh * 4, s));
+        ASEP_HIP_CHECK(hipMemsetAsync(q.cs[0], 0, nh * 4, s));
+        maxN = std::max(maxN, q.N);
+        maxR = std::max(maxR, q.R);
+    }
+    int cur = 0;
+    for (int t = 0; t < c.num_transition_steps; ++t) {
+        if (mode == STEP_BIG) {
+            GnnBatch<StepBigArgs> ba{};
+            for (int b = 0; b < n; ++b) {
+                GraphCtx& q = cx[b];
+                StepBigArgs& sa = ba.p[b];
+                sa.u = q.upad; sa.h_in = q.h[cur]; sa.c_in = q.cs[cur]; sa.ef = q.d_ef;
+                sa.tptr = q.eb.colptr; sa.tsrc = q.eb.tsrc; sa.tfirst = q.eb.tfirst;
+                sa.A1 = (const gf32x4*)g->A1; sa.A2 = (const gf32x4*)g->A2; sa.b1 = g->b1; sa.b2 = g->b2;
+                for (int k = 0; k < 4; ++k) { sa.Wg[k] = g->Wg[k]; sa.bg[k] = g->bg[k]; }
+                sa.h_out = q.h[cur ^ 1]; sa.c_out = q.cs[cur ^ 1];
+                sa.N = q.N; sa.U = g->U; sa.Upad = g->Upad; sa.Ed = g->Ed; sa.E = std::max(q.E, 1); sa.nch = g->nch;
+                sa.qdesc = g->qdesc;
+                ba.nx[b] = q.N;
+            }
+            hipLaunchKernelGGL(gnn_step_big_kernel_batch, dim3(maxN, n), dim3(256), g->big_lds, s, ba);
+        } else {
+            GnnBatch<StepArgs> ba{};
+            for (int b = 0; b < n; ++b) {
+                GraphCtx& q = cx[b];
+                StepArgs& sa = ba.p[b];
+                sa.u = q.d_u; sa.h_in = q.h[cur]; sa.c_in = q.cs[cur]; sa.ef = q.d_ef;
+                sa.tptr = q.eb.colptr; sa.tsrc = q.eb.tsrc; sa.tfirst = q.eb.tfirst;
+                sa.A1 = (const gf32x4*)g->A1; sa.A2 = (const gf32x4*)g->A2; sa.b1 = g->b1; sa.b2 = g->b2;
+                for (int k = 0; k < 4; ++k) { sa.Wg[k] = g->Wg[k]; sa.bg[k] = g->bg[k]; }
+                sa.h_out = q.h[cur ^ 1]; sa.c_out = q.cs[cur ^ 1];
+                sa.N = q.N; sa.U = g->U; sa.Ed = g->Ed; sa.E = std::max(q.E, 1); sa.nch = g->nch;
+                sa.qdesc = g->qdesc;
+                ba.nx[b] = q.N;
+            }
+            hipLaunchKernelGGL(gnn_step_kernel_batch, dim3(maxN, n), dim3(256), 0, s, ba);
+        }
+        cur ^= 1;
+    }
+    g->d_h = cx[n - 1].h[cur];
+    g->N = cx[n - 1].N;
+    if (maxR > 0) {
+        GnnBatch<PairPreArgs> bp{};
+        int maxpre = 0;
+        for (int b = 0; b < n; ++b) {
+            GraphCtx& q = cx[b];
+            bp.p[b] = PairPreArgs{q.h[cur], q.N, H, g->C1, c.cls_hidden1, q.Pt, q.Qt};
+            bp.nx[b] = q.R > 0 ? std::min(cdiv(q.N * c.cls_hidden1, 256), 1024) : 0;
+            maxpre = std::max(maxpre, bp.nx[b]);
+        }
+        hipLaunchKernelGGL(gnn_pair_pre_kernel_batch, dim3(maxpre, n), dim3(256), 0, s, bp);
+        if (g->cls_fast) {
+            GnnBatch<PairArgs> ba{};
+            for (int b = 0; b < n; ++b) {
+                GraphCtx& q = cx[b];
+                PairArgs& pa = ba.p[b];
+                pa.Pt = q.Pt; pa.Qt = q.Qt; pa.b1 = g->cb1; pa.W2 = g->C2; pa.b2 = g->cb2; pa.W3 = g->C3; pa.b3 = g->cb3;
+                pa.rel = q.d_rel; pa.out = q.d_out; pa.N = q.N; pa.R = q.R;
+                ba.nx[b] = cdiv(q.R, 256);
+            }
+            hipLaunchKernelGGL((gnn_pair_cls_kernel_batch<64, 32, 2>), dim3(cdiv(maxR, 256), n), dim3(256), 0, s, ba);
+        } else {
+            for (int b = 0; b < n; ++b) {
+                GraphCtx& q = cx[b];
+                if (q.R < 1) continue;
+                PairGenArgs pg{};
+                pg.Pt = q.Pt; pg.Qt = q.Qt; pg.b1 = g->cb1; pg.rest = g->cls_rest; pg.rel = q.d_rel; pg.out = q.d_out; pg.N = q.N; pg.R = q.R;
+                pg.maxw = g->cls_maxw;
+                hipLaunchKernelGGL(gnn_pair_cls_generic_kernel, dim3(cdiv(q.R, PAIRG_P)), dim3(256), 2 * (size_t)PAIRG_P * g->cls_maxw * sizeof(float), s, pg);
+            }
+        }
+    }
+    ASEP_HIP_CHECK(hipGetLastError());
+    return ASEP_OK;
+}
+
 // graph_relation.py:84-139 in front of the graph: backbone, ROI max + compression per feature map, concatenation.
 // ROI max + compression of one page's nodes from the backbone end points "<prefix><name>" of the forward that is queued
 // on s; d_ug [N, U - visual dims] -> d_u [N, U]
@@ -606,6 +732,7 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
         if (kv.first.rfind("visual_node_feature_compression_fm_", 0) == 0 || kv.first.rfind("visual_edge_feature_compression_fm_", 0) == 0)
             g->vis_blob[kv.first] = kv.second;
     if (const char* ev = getenv("ASEP_GNN_STEP")) g->use_step = atoi(ev) != 0;
+    if (const char* ev = getenv("ASEP_GNN_BATCH")) g->batch_graph = atoi(ev) != 0;
     if (const char* ev = getenv("ASEP_GNN_LANES")) g->n_page_lanes = std::max(1, std::min(16, atoi(ev)));
     // the fused MFMA step kernels serve the reference's defaults: widths 32 / [32] / 32, degree-normalised SUM, both LSTM inputs
     const bool default_widths = H == GNN_H && I == GNN_H && Hm == GNN_H && ih.size() == 1 && heads == 0 && cfg->aggregation_type == 0 &&
@@ -863,6 +990,56 @@ int asep_gnn_forward_visual_batch_dev(asep_gnn* g, int n_pages, const asep_gnn_p
     }
     float* d_u = g->d_u_cat;
     float* d_efc = g->d_ef_cat;
+    if (L == 1 && g->batch_graph && n_pages > 1 && g->vise_total == 0 && graph_batch_eligible(g)) {
+        // stage by stage over all pages (forward_batch_impl): ROI kernels per feature map, steps, classifier as one launch each
+        const int U = g->Uin, ugc = U - g->vis_total;
+        g->stream = s;
+        g->pool.begin();
+        for (int b0 = 0; b0 < n_pages; b0 += GNN_BATCH) {
+            const int nb = std::min(GNN_BATCH, n_pages - b0);
+            GraphCtx cx[GNN_BATCH];
+            int maxN = 0;
+            float* du = d_u;
+            for (int b = 0; b < nb; ++b) {
+                const asep_gnn_page& q = pages[b0 + b];
+                if (ugc > 0) hipLaunchKernelGGL(gnn_copy_cols_kernel, dim3(cdiv(q.N * ugc, 256)), dim3(256), 0, s, q.d_node_feat, q.N, ugc, du, U);
+                cx[b].N = q.N; cx[b].E = q.E; cx[b].R = q.R;
+                cx[b].d_u = du; cx[b].d_fed = du; cx[b].d_ef = q.d_edge_feat;
+                cx[b].d_edges_in = q.d_edges; cx[b].d_rel = q.d_relations; cx[b].d_out = q.d_probs_out;
+                du += (size_t)q.N * U;
+                maxN = std::max(maxN, q.N);
+            }
+            int col = ugc;
+            for (size_t i = 0; i < g->vis_names.size(); ++i) {
+                GnnBatch<RoiArgs> ba{};
+                int any_bf = -1;
+                for (int b = 0; b < nb; ++b) {
+                    const asep_gnn_page& q = pages[b0 + b];
+                    const std::string prefix = (b0 + b) ? "p" + std::to_string(b0 + b) + "/" : std::string();
+                    const float* fm = nullptr;
+                    int dims[3];
+                    int bf = 0;
+                    rc = aru_endpoint_dev(g->backbone, (prefix + g->vis_names[i]).c_str(), &fm, dims, &bf);
+                    if (rc) return rc;
+                    if (dims[2] != g->vis_C[i]) { set_error("end point %s has %d channels, expected %d", g->vis_names[i].c_str(), dims[2], g->vis_C[i]); return ASEP_ERR_ARG; }
+                    if (any_bf >= 0 && any_bf != bf) { set_error("end points of one call differ in precision"); return ASEP_ERR_ARG; }
+                    any_bf = bf;
+                    RoiArgs& a = ba.p[b];
+                    a.fm = fm; a.fh = dims[0]; a.fw = dims[1]; a.C = dims[2];
+                    a.regions = q.d_regions; a.P = P; a.npts = q.d_num_points; a.Wc = g->vis_W[i]; a.bc = g->vis_b[i]; a.d = g->vis_d[i];
+                    a.u_out = const_cast<float*>(cx[b].d_u); a.ustride = U; a.col0 = col; a.vmax_out = nullptr;
+                    ba.nx[b] = q.N;
+                }
+                if (any_bf) hipLaunchKernelGGL(gnn_roi_compress_kernel_batch<true>, dim3(maxN, nb), dim3(256), 0, s, ba);
+                else hipLaunchKernelGGL(gnn_roi_compress_kernel_batch<false>, dim3(maxN, nb), dim3(256), 0, s, ba);
+                col += g->vis_d[i];
+            }
+            rc = forward_batch_impl(g, g->pool, nb, cx, s);
+            if (rc) return rc;
+            d_u = du;
+        }
+        return ASEP_OK;
+    }
     for (int b = 0; b < n_pages; ++b) {
         const asep_gnn_page& q = pages[b];
         hipStream_t ls = L > 1 ? g->page_lanes[b % L]->s : s;

@@ -200,6 +200,15 @@ typedef float gf32x4 __attribute__((ext_vector_type(4)));
 enum { GQ_ZERO = 0, GQ_UI, GQ_UJ, GQ_DU, GQ_DU2, GQ_EF, GQ_HI, GQ_HJ, GQ_DH, GQ_DH2 };
 constexpr int GNN_MAXCH = 16;          // K chunks of 16 slots (U <= 8, Ed <= 4 -> 11 chunks)
 
+// Several pages' launches of one graph kernel as ONE launch (asep_gnn_forward_visual_batch_dev): blockIdx.y = page, p[page] = the arguments the
+// per-page launch would get, nx[page] = its grid size along x (blocks beyond it leave at once).  By value in the kernel arguments (< 4 KB).
+constexpr int GNN_BATCH = 16;
+template <class A>
+struct GnnBatch {
+    A p[GNN_BATCH];
+    int nx[GNN_BATCH];
+};
+
 struct StepArgs {
     const float* u; const float* h_in; const float* c_in; const float* ef;
     const int* tptr; const int* tsrc; const int* tfirst;
@@ -214,13 +223,13 @@ struct StepArgs {
 
 __device__ __forceinline__ float gsig(float v) { return 1.f / (1.f + expf(-v)); }
 
-__global__ __launch_bounds__(256) void gnn_step_kernel(const StepArgs a) {
+__device__ __forceinline__ void gnn_step_kernel_body(const StepArgs& a, const int bx, const int gx) {
     __shared__ float xs[4][32];
     __shared__ float vs[32 + 32 + 64];
     __shared__ float gs[4][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
-    const int tgt = blockIdx.x;
+    const int tgt = bx;
     const int beg = a.tptr[tgt], end = a.tptr[tgt + 1];
     const int U = a.U, Ed = a.Ed;
 
@@ -343,6 +352,12 @@ __global__ __launch_bounds__(256) void gnn_step_kernel(const StepArgs a) {
         a.h_out[(size_t)tgt * 32 + tid] = og * tanhf(c);
     }
 }
+__global__ __launch_bounds__(256) void gnn_step_kernel(const StepArgs a) { gnn_step_kernel_body(a, (int)blockIdx.x, (int)gridDim.x); }
+__global__ __launch_bounds__(256) void gnn_step_kernel_batch(const GnnBatch<StepArgs> b) {
+    if ((int)blockIdx.x >= b.nx[blockIdx.y]) return;
+    gnn_step_kernel_body(b.p[blockIdx.y], (int)blockIdx.x, b.nx[blockIdx.y]);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // The same fused step for WIDE node features (visual branch: 7 geometric + 3 x 16 visual = 55 features, K = 350;
@@ -364,7 +379,7 @@ struct StepBigArgs {
     const unsigned char* qdesc;    // [nch*4][4]
 };
 
-__global__ __launch_bounds__(256) void gnn_step_big_kernel(const StepBigArgs a) {
+__device__ __forceinline__ void gnn_step_big_kernel_body(const StepBigArgs& a, const int bx, const int gx) {
     extern __shared__ __attribute__((aligned(16))) float sm_big[];
     gf32x4* A1s = reinterpret_cast<gf32x4*>(sm_big);                   // [nch][2][64]
     float* trow = sm_big + (size_t)a.nch * 2 * 64 * 4;                  // target row: [Upad] u | [32] h
@@ -372,7 +387,7 @@ __global__ __launch_bounds__(256) void gnn_step_big_kernel(const StepBigArgs a) 
     __shared__ float gs[4][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
-    const int tgt = blockIdx.x;
+    const int tgt = bx;
     const int beg = a.tptr[tgt], end = a.tptr[tgt + 1];
     const int Upad = a.Upad, Ed = a.Ed, nch = a.nch;
     const int ntiles = (end - beg + 15) >> 4;
@@ -493,6 +508,12 @@ __global__ __launch_bounds__(256) void gnn_step_big_kernel(const StepBigArgs a) 
         a.h_out[(size_t)tgt * 32 + tid] = og * tanhf(c);
     }
 }
+__global__ __launch_bounds__(256) void gnn_step_big_kernel(const StepBigArgs a) { gnn_step_big_kernel_body(a, (int)blockIdx.x, (int)gridDim.x); }
+__global__ __launch_bounds__(256) void gnn_step_big_kernel_batch(const GnnBatch<StepBigArgs> b) {
+    if ((int)blockIdx.x >= b.nx[blockIdx.y]) return;
+    gnn_step_big_kernel_body(b.p[blockIdx.y], (int)blockIdx.x, b.nx[blockIdx.y]);
+}
+
 
 // zero-padded copy of the node features: [N, U] -> [N, Upad]
 __global__ __launch_bounds__(256) void gnn_pad_rows_kernel(const float* __restrict__ src, int N, int U, float* __restrict__ dst, int Upad) {
@@ -846,6 +867,26 @@ __global__ __launch_bounds__(256) void gnn_pair_pre_kernel(const float* __restri
     }
 }
 
+struct PairPreArgs {
+    const float* h; int N, H; const float* W1; int H1; float* Pt; float* Qt;
+};
+// gnn_pair_pre_kernel for several pages (GnnBatch): the same grid-stride loop per page, nx[page] blocks
+__global__ __launch_bounds__(256) void gnn_pair_pre_kernel_batch(const GnnBatch<PairPreArgs> b) {
+    if ((int)blockIdx.x >= b.nx[blockIdx.y]) return;
+    const PairPreArgs& a = b.p[blockIdx.y];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.N * a.H1; i += b.nx[blockIdx.y] * 256) {
+        const int n = i % a.N, k = i / a.N;
+        float p = 0.f, q = 0.f;
+        for (int d = 0; d < a.H; ++d) {
+            const float hv = a.h[(size_t)n * a.H + d];
+            p = fmaf(hv, a.W1[d * a.H1 + k], p);
+            q = fmaf(hv, a.W1[(a.H + d) * a.H1 + k], q);
+        }
+        a.Pt[(size_t)k * a.N + n] = p;
+        a.Qt[(size_t)k * a.N + n] = q;
+    }
+}
+
 struct PairArgs {
     const float* Pt; const float* Qt;   // [H1][N]
     const float* b1;                    // [H1]
@@ -857,7 +898,7 @@ struct PairArgs {
 };
 
 template <int H1, int H2, int NC>
-__global__ __launch_bounds__(256) void gnn_pair_cls_kernel(const PairArgs a) {
+__device__ __forceinline__ void gnn_pair_cls_kernel_body(const PairArgs& a, const int bx, const int gx) {
     __shared__ __attribute__((aligned(16))) float W2s[H1 * H2];
     __shared__ float misc[H1 + H2 + H2 * NC + NC];
     float* b1s = misc; float* b2s = b1s + H1; float* W3s = b2s + H2; float* b3s = W3s + H2 * NC;
@@ -868,7 +909,7 @@ __global__ __launch_bounds__(256) void gnn_pair_cls_kernel(const PairArgs a) {
     for (int i = tid; i < H2 * NC; i += 256) W3s[i] = a.W3[i];
     for (int i = tid; i < NC; i += 256) b3s[i] = a.b3[i];
     __syncthreads();
-    const int r = blockIdx.x * 256 + tid;
+    const int r = bx * 256 + tid;
     if (r >= a.R) return;
     int na, nb;
     if (a.rel) { na = a.rel[2 * r]; nb = a.rel[2 * r + 1]; }
@@ -904,6 +945,14 @@ __global__ __launch_bounds__(256) void gnn_pair_cls_kernel(const PairArgs a) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) a.out[(size_t)r * NC + c] = lg[c] / den;
 }
+template <int H1, int H2, int NC>
+__global__ __launch_bounds__(256) void gnn_pair_cls_kernel(const PairArgs a) { gnn_pair_cls_kernel_body<H1, H2, NC>(a, (int)blockIdx.x, (int)gridDim.x); }
+template <int H1, int H2, int NC>
+__global__ __launch_bounds__(256) void gnn_pair_cls_kernel_batch(const GnnBatch<PairArgs> b) {
+    if ((int)blockIdx.x >= b.nx[blockIdx.y]) return;
+    gnn_pair_cls_kernel_body<H1, H2, NC>(b.p[blockIdx.y], (int)blockIdx.x, b.nx[blockIdx.y]);
+}
+
 
 // any classifier widths (trainer_rel.py:17 num_hidden_units is a free parameter): one thread per pair, the second
 // layer recomputes the first layer's activations per output unit (L1-resident P / Q columns) -- a fallback
@@ -982,7 +1031,7 @@ struct RoiArgs {
 };
 
 template <bool BF>
-__global__ void __launch_bounds__(256) gnn_roi_compress_kernel(RoiArgs a) {
+__device__ __forceinline__ void gnn_roi_compress_kernel_body(const RoiArgs& a, const int bx, const int gx) {
     // value i of the map (a bf16 value widens exactly; the maximum of a region is therefore the same value the fp32 form of a
     // bf16-rounded map would give)
     auto fmv = [&](size_t i) -> float {
@@ -991,7 +1040,7 @@ __global__ void __launch_bounds__(256) gnn_roi_compress_kernel(RoiArgs a) {
     };
     __shared__ float red[256];
     __shared__ float vmax[256];
-    const int n = blockIdx.x, tid = threadIdx.x;
+    const int n = bx, tid = threadIdx.x;
     const int np = min(a.npts[n], a.P);
     float xmin = 0.f, xmax = 0.f, ymin = 0.f, ymax = 0.f;     // misc.py:503-508: no points -> zeros
     if (np > 0) {
@@ -1083,6 +1132,14 @@ __global__ void __launch_bounds__(256) gnn_roi_compress_kernel(RoiArgs a) {
         a.u_out[(size_t)n * a.ustride + a.col0 + j] = fmaxf(acc, 0.f);
     }
 }
+template <bool BF>
+__global__ __launch_bounds__(256) void gnn_roi_compress_kernel(const RoiArgs a) { gnn_roi_compress_kernel_body<BF>(a, (int)blockIdx.x, (int)gridDim.x); }
+template <bool BF>
+__global__ __launch_bounds__(256) void gnn_roi_compress_kernel_batch(const GnnBatch<RoiArgs> b) {
+    if ((int)blockIdx.x >= b.nx[blockIdx.y]) return;
+    gnn_roi_compress_kernel_body<BF>(b.p[blockIdx.y], (int)blockIdx.x, b.nx[blockIdx.y]);
+}
+
 
 // graph_gnn.py:102-109 compress_node_feature_dim: y[n][d] = tanh(b[d] + sum_k x[n][k] W[k][d])  (layers.ff_layer with tanh)
 __global__ void __launch_bounds__(256)
