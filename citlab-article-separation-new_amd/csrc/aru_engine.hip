@@ -92,6 +92,7 @@ struct asep_aru {
     bool r8_valu = true;             // fp32 only; ASEP_R8_VALU=0 runs the fp32 MFMA variants instead
     bool use_fused8 = true;          // ASEP_FUSED8=0 falls back to the layer-by-layer kernels
     bool fused8_wanted = true;       // what ASEP_FUSED8 said (use_fused8 is also switched off for the graph variants)
+    bool fused8_var = false;         // elu / leaky RESIDUAL graphs: the level-0 blocks on res8v_*_kernel<activation> (round 4; ASEP_FUSED8_VAR=0: layer by layer)
     float* d_att_head = nullptr;     // A fragment of attPart/conv1 for att_head_kernel (12 output channels, 4x4 taps)
     float* d_logit_w = nullptr;
     float* d_logit_b = nullptr;
@@ -927,13 +928,17 @@ int pack_res8(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
         m->owned.push_back(m->d_r8_up_w1); m->owned.push_back(m->d_r8_up_wr);
         m->owned.push_back(m->d_r8_up_br); m->owned.push_back(m->d_r8_up_b1);
         if (hipFuncSetAttribute((const void*)res8_up_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)res8v_up_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess) {
+            hipFuncSetAttribute((const void*)res8v_up_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)res8v_up_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)res8v_up_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_UP_LDS) != hipSuccess) {
             set_error("cannot reserve %zu bytes of LDS for the fused up block", R8_UP_LDS);
             return ASEP_ERR_HIP;
         }
     }
     if (hipFuncSetAttribute((const void*)res8_down_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess ||
-        hipFuncSetAttribute((const void*)res8v_down_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess) {
+        hipFuncSetAttribute((const void*)res8v_down_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)res8v_down_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)res8v_down_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R8_DOWN_LDS) != hipSuccess) {
         set_error("cannot reserve %zu bytes of LDS for the fused residual block", R8_DOWN_LDS);
         return ASEP_ERR_HIP;
     }
@@ -947,6 +952,13 @@ int pack_res8(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
 // chunks, and the k-th unit of work (k = block + i * grid) takes the (k / 8)-th tile of chunk k % 8: the 32 blocks of
 // an XCD work on spatially adjacent tiles at the same time, and on the rows just below right after, so the 8-row /
 // 14-column halo overlap of neighbouring tiles is served by that XCD's L2 instead of being fetched again.
+// the vector-ALU level-0 kernels address their tensors with 32-bit element offsets (< 2^28 pixels per tensor)
+bool r8v_fits(const TL& l) {
+    for (const Tensor& t : l)
+        if ((size_t)t.H * t.W >= ((size_t)1 << 28)) return false;
+    return true;
+}
+
 // res8s_kernel addresses its 8-channel tensors with 32-bit element offsets
 bool res8s_fits(const TL& l) {
     for (const Tensor& t : l)
@@ -1026,8 +1038,13 @@ void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>&
         ProfScope ps(m, pname, flops, "unet_down_0 (conv1+3xconvR+add+pool) " + dims_of(sub));
         ps.bytes = bytes;
         a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH * R8_NP);
-        if (valu) hipLaunchKernelGGL(res8v_down_kernel, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
-        else hipLaunchKernelGGL(res8_down_kernel<false>, dim3(std::min(tiles, m->num_cus)), dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
+        const dim3 gd(std::min(tiles, m->num_cus));
+        const int actv = m->cfg.activation;                  // graph variants (fused8_var): the same block with elu / leaky (vector-ALU form only)
+        if (actv && !valu) { set_error("level-0 block of an elu / leaky graph: image too large for the vector-ALU kernel"); throw ArgError(); }
+        if (valu && actv == 1) { ps.set_name("res8v_down_kernel<1>"); hipLaunchKernelGGL(res8v_down_kernel<1>, gd, dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a); }
+        else if (valu && actv == 2) { ps.set_name("res8v_down_kernel<2>"); hipLaunchKernelGGL(res8v_down_kernel<2>, gd, dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a); }
+        else if (valu) hipLaunchKernelGGL(res8v_down_kernel<0>, gd, dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
+        else hipLaunchKernelGGL(res8_down_kernel<false>, gd, dim3(R8_THREADS), R8_DOWN_LDS, m->stream, a);
     }
 }
 
@@ -1066,7 +1083,11 @@ TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
         ps.bytes = bytes;
         a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH * R8_NP);
         const dim3 grid(std::min(tiles, m->num_cus));
-        if (valu) hipLaunchKernelGGL(res8v_up_kernel, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
+        const int actv = m->cfg.activation;
+        if (actv && !valu) { set_error("level-0 block of an elu / leaky graph: image too large for the vector-ALU kernel"); throw ArgError(); }
+        if (valu && actv == 1) { ps.set_name("res8v_up_kernel<1>"); hipLaunchKernelGGL(res8v_up_kernel<1>, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a); }
+        else if (valu && actv == 2) { ps.set_name("res8v_up_kernel<2>"); hipLaunchKernelGGL(res8v_up_kernel<2>, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a); }
+        else if (valu) hipLaunchKernelGGL(res8v_up_kernel<0>, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
         else hipLaunchKernelGGL(res8_up_kernel<false>, grid, dim3(R8_THREADS), R8_UP_LDS, m->stream, a);
     }
     return out;
@@ -1806,7 +1827,7 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
             u = (l < n - 1) ? pooled : d;
             continue;
         }
-        if (l == 0 && m->use_fused8 && m->d_r8_down_wr) {
+        if (l == 0 && (m->use_fused8 || (m->fused8_var && r8v_fits(imgs))) && m->d_r8_down_wr) {
             TL d, pooled;
             run_res8_down(m, imgs, stats, n > 1, &d, &pooled);
             skips.push_back(d);
@@ -1839,7 +1860,7 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
         } else if (m->bf16) {
             TL t = run_convb(m, scope + "/conv1", skip, &v, false, false, nullptr);   // concat [skip, deconv]
             u = res_block_tail(m, scope, t);
-        } else if (l == 0 && m->use_fused8 && m->d_r8_up_w1) {
+        } else if (l == 0 && (m->use_fused8 || (m->fused8_var && r8v_fits(skip))) && m->d_r8_up_w1) {
             u = run_res8_up(m, skip, v);
         } else if (m->cfg.plain_u) {                         // ARU_v1.py:283-288
             TL c1 = conv_act(m, scope + "/conv1", skip, &v, false, true, nullptr);
@@ -2175,6 +2196,8 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     m->fused8_wanted = m->use_fused8;
     if (variant) m->use_fused8 = false;                      // the fused level-0 blocks / attention head are ReLU residual kernels
     if (const char* e = getenv("ASEP_R8_VALU")) m->r8_valu = atoi(e) != 0;
+    m->fused8_var = variant && !cfg->plain_u && cfg->activation != 0 && m->fused8_wanted && m->r8_valu && m->fuse_act && !m->bf16;
+    if (const char* e = getenv("ASEP_FUSED8_VAR")) m->fused8_var = m->fused8_var && atoi(e) != 0;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;
     if (const char* e = getenv("ASEP_XCD_ONESHOT")) m->xcd_oneshot = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("ASEP_BIGTILE")) m->big_tile = atoi(e) != 0;
@@ -2232,7 +2255,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
         for (int r = 0; r < cfg->res_depth && !rc; ++r)
             rc = pack_conv(m.get(), blob, s + "/convR_" + std::to_string(r), "biases", false);
     }
-    if (!rc && !variant && !m->bf16 && cfg->feat_root == 8 && cfg->res_depth == 3 && m->det_first.k == 3) rc = pack_res8(m.get(), blob);
+    if (!rc && (!variant || m->fused8_var) && !m->bf16 && cfg->feat_root == 8 && cfg->res_depth == 3 && m->det_first.k == 3) rc = pack_res8(m.get(), blob);
     if (!rc && m->bf16 && cfg->res_depth == 3 && cfg->feat_root == 8) rc = pack_res8b(m.get(), blob);
     if (!rc && m->split && m->split_l0 && !variant && cfg->res_depth == 3 && cfg->feat_root == 8) rc = pack_res8s(m.get(), blob);
     if (!rc && m->bf16 && cfg->res_depth == 3)

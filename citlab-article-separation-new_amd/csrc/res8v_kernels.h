@@ -46,6 +46,13 @@ __device__ __forceinline__ int r8v_px(int x, int hf) {
     return (P << 4) + (((((x & 1) << 1) | hf) ^ g) << 2);
 }
 
+// the block's activation: ReLU on the bit patterns (ACT 0, the shipped graphs' fast path), or elu (1) / leaky (2) of the graph variants
+// (ARU_v1.py:70-75; act4 of aru_kernels.h: the arithmetic of the layer-by-layer form)
+template <int ACT>
+__device__ __forceinline__ f32x4 r8v_act(f32x4 v) {
+    if constexpr (ACT == 0) return relu4i(v);
+    else return act4(v, ACT);
+}
 __device__ __forceinline__ f32x4 r8v_ld(r8v_lds p) { return *reinterpret_cast<const f32x4 __attribute__((address_space(3)))*>(p); }
 __device__ __forceinline__ void r8v_st(r8v_lds p, f32x4 v) { *reinterpret_cast<f32x4 __attribute__((address_space(3)))*>(p) = v; }
 
@@ -68,7 +75,7 @@ __device__ __forceinline__ void r8v_fma(f32x2& acc, f32x2 pair, f32x2 w) {
 // row-half's four input pieces requested; left to the compiler the request goes out BEFORE the wait, which then covers
 // it.  The double buffer is 2 x 16 SGPRs: the kernels carry ~40 scalars of their own and the file has 102 (with 2 x 32
 // the allocator spilled weights to VGPR lanes, thousands of v_readlane); the stage time is the same (6.0 k cycles).
-template <bool RELU_IN>
+template <bool RELU_IN, int ACT = 0>
 __device__ __forceinline__ void r8v_conv_direct(const r8v_lds (&a)[4][2], r8v_cptr wl,
                                          f32x2 (&acc0)[4], f32x2 (&acc1)[4]) {
     float wc[16], wn[16];
@@ -92,7 +99,7 @@ __device__ __forceinline__ void r8v_conv_direct(const r8v_lds (&a)[4][2], r8v_cp
             for (int i = 0; i < 4; ++i) dB[i] = *reinterpret_cast<const f32x4 __attribute__((address_space(3)))*>(a[i][hf2] + ky2 * R8_PITCH * 32);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (RELU_IN && kx == 0 && ch == 0) {
+        if (RELU_IN && kx == 0 && ch == 0) {               // (the ReLU behind conv1 of a residual block is a ReLU in every graph variant: ARU_v1.py:212-216)
 #pragma unroll
             for (int i = 0; i < 4; ++i) dA[i] = relu4i(dA[i]);
         }
@@ -141,7 +148,7 @@ __device__ __forceinline__ void r8v_mul(f32x2& acc, f32x2 pair, f32x2 w) {
 // stage 1 6.5 -> 6.1 k: the waits now come every 8 FMAs), res8v_down 3.76 -> 3.69 ms; but the UP block's five filters grow
 // from 11.5 to 15.4 KB, which no longer fits the 16 KB scalar data cache: its second conv1 half went from 5.8 to 9.1 k
 // cycles, the last stage from 6.8 to 9.7 k, the kernel from 5.40 to 6.33 ms.  Not used (-DR8V_WINO=1 builds it).
-template <bool RELU_IN>
+template <bool RELU_IN, int ACT = 0>
 __device__ __forceinline__ void r8v_conv_wino(const r8v_lds (&a)[4][2], r8v_cptr wl,
                                               f32x2 (&acc0)[4], f32x2 (&acc1)[4]) {
     constexpr int GS = R8V_WINO_GS, NG = 768 / GS, GPR = 128 / GS;           // groups per (ky, hf) row-half
@@ -207,10 +214,10 @@ __device__ __forceinline__ void r8v_conv_wino(const r8v_lds (&a)[4][2], r8v_cptr
     asm volatile("" : "+v"(acc0[0]), "+v"(acc0[1]), "+v"(acc0[2]), "+v"(acc0[3]), "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]));
 }
 
-template <bool RELU_IN>
+template <bool RELU_IN, int ACT = 0>
 __device__ __forceinline__ void r8v_conv(const r8v_lds (&a)[4][2], r8v_cptr wl, f32x2 (&acc0)[4], f32x2 (&acc1)[4]) {
-    if constexpr (R8V_WINO) r8v_conv_wino<RELU_IN>(a, wl, acc0, acc1);
-    else r8v_conv_direct<RELU_IN>(a, wl, acc0, acc1);
+    if constexpr (R8V_WINO) r8v_conv_wino<RELU_IN, ACT>(a, wl, acc0, acc1);
+    else r8v_conv_direct<RELU_IN, ACT>(a, wl, acc0, acc1);
 }
 
 __device__ __forceinline__ f32x4 r8v_lo(const f32x2 (&a)[4]) { return f32x4{a[0].x, a[0].y, a[1].x, a[1].y}; }
@@ -242,7 +249,7 @@ __device__ __forceinline__ void r8v_window(r8v_lds (&a)[4][2], float* sm, const 
 // [row_start, row_start + nrows) x columns [out_c0, out_c0 + 64): thread -> (row tid >> 5 (+16), pixels out_c0 + 2 (tid & 31), +1).
 // FINAL: add T centre, ReLU, store the OW valid columns to global (+ 2x2 max pool).  Otherwise ReLU into OUT, zero outside
 // the image (= the SAME padding of the next convolution).  interior (scalar): the whole frame lies inside the image.
-template <bool RELU_IN, bool FINAL, bool POOL>
+template <bool RELU_IN, bool FINAL, bool POOL, int ACT = 0>
 __device__ __forceinline__ void res8v_stage(float* __restrict__ sm, const float* __restrict__ IN, int in_r0, float* __restrict__ OUT, int out_r0,
                                             int row_start, int nrows, int out_c0, const float* __restrict__ w,
                                             const float* __restrict__ bias, int tid, const int (&poff)[7][2], bool interior,
@@ -263,11 +270,11 @@ __device__ __forceinline__ void res8v_stage(float* __restrict__ sm, const float*
         const int row = row_start + r;               // frame row
         r8v_lds a[4][2];
         r8v_window(a, sm, poff, out_c0 - 1, ((int)(IN - sm) + (row - 1 - in_r0) * R8_PITCH * 8) * 4);
-        r8v_conv<RELU_IN>(a, wl, acc0, acc1);
+        r8v_conv<RELU_IN, ACT>(a, wl, acc0, acc1);
         const int gy = fy0 + row;
         f32x4 p0l = r8v_lo(acc0), p0h = r8v_hi(acc0), p1l = r8v_lo(acc1), p1h = r8v_hi(acc1);
         if (!FINAL) {
-            p0l = relu4i(p0l); p0h = relu4i(p0h); p1l = relu4i(p1l); p1h = relu4i(p1h);
+            p0l = r8v_act<ACT>(p0l); p0h = r8v_act<ACT>(p0h); p1l = r8v_act<ACT>(p1l); p1h = r8v_act<ACT>(p1h);
             if (!interior) {
                 const bool oky = gy >= 0 && gy < H;
                 const bool ok0 = oky && gx >= 0 && gx < W, ok1 = oky && gx + 1 >= 0 && gx + 1 < W;
@@ -279,10 +286,10 @@ __device__ __forceinline__ void res8v_stage(float* __restrict__ sm, const float*
             r8v_st(a[2][0] + d_out, p1l);
             r8v_st(a[2][1] + d_out, p1h);
         } else {
-            p0l = relu4i(p0l + r8v_ld(a[1][0] + d_t));
-            p0h = relu4i(p0h + r8v_ld(a[1][1] + d_t));
-            p1l = relu4i(p1l + r8v_ld(a[2][0] + d_t));
-            p1h = relu4i(p1h + r8v_ld(a[2][1] + d_t));
+            p0l = r8v_act<ACT>(p0l + r8v_ld(a[1][0] + d_t));
+            p0h = r8v_act<ACT>(p0h + r8v_ld(a[1][1] + d_t));
+            p1l = r8v_act<ACT>(p1l + r8v_ld(a[2][0] + d_t));
+            p1h = r8v_act<ACT>(p1h + r8v_ld(a[2][1] + d_t));
             // only the OW valid columns of the tile (frame columns 4 .. 4+OW-1) are stored; gy >= 0 and gx >= 0 there.
             // Element offsets fit 32 bits (the launcher sends larger tensors to the MFMA kernels).
             const bool oky = interior || gy < H;
@@ -308,6 +315,7 @@ __device__ __forceinline__ void res8v_stage(float* __restrict__ sm, const float*
 }
 
 // DOWN block of level 0: image (1 channel) -> d0 [H,W,8] (+ maxpool2)
+template <int ACT = 0>
 __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void res8v_down_kernel(const Res8Args a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const float* wr = reinterpret_cast<const float*>(a.wr);
@@ -411,13 +419,13 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 *reinterpret_cast<f32x4*>(T + r * R8_PITCH * 8 + r8v_px(c, 1)) = hi;
             }
             __syncthreads();
-            res8v_stage<true, false, false>(sm, T, 1, R0, 2, first ? 2 : 6, first ? 20 : 16, 2, wr, a.br, tid, poff, interior, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            res8v_stage<true, false, false, ACT>(sm, T, 1, R0, 2, first ? 2 : 6, first ? 20 : 16, 2, wr, a.br, tid, poff, interior, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
             __syncthreads();
-            res8v_stage<false, false, false>(sm, R0, 2, R1, 3, first ? 3 : 5, first ? 18 : 16, 3, wr + R8V_FILTER, a.br + 8, tid, poff, interior, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            res8v_stage<false, false, false, ACT>(sm, R0, 2, R1, 3, first ? 3 : 5, first ? 18 : 16, 3, wr + R8V_FILTER, a.br + 8, tid, poff, interior, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
             __syncthreads();
             if (more_passes) image_load(tile_id, pass + 1);
             else if (has_next) image_load(next_id, 0);
-            res8v_stage<false, true, true>(sm, R1, 3, nullptr, 4, 4, 16, 4, wr + 2 * R8V_FILTER, a.br + 16, tid, poff, interior, fy0, fx0, H, W, T, 1, P.out, P.pool);
+            res8v_stage<false, true, true, ACT>(sm, R1, 3, nullptr, 4, 4, 16, 4, wr + 2 * R8V_FILTER, a.br + 16, tid, poff, interior, fy0, fx0, H, W, T, 1, P.out, P.pool);
         }
         tile_id = next_id;
     }
@@ -426,6 +434,7 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 // UP block of level 0 (ARU_v1.py:262-281): t = conv1(concat[skip, deconv]) ; 3 x convR ; + t ; ReLU.
 // The 16-channel concatenation is consumed as two 8-channel passes through one LDS input tile (skip, then the
 // deconvolution output) that accumulate into the same registers; afterwards that tile buffer holds r1.
+template <int ACT = 0>
 __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void res8v_up_kernel(const Res8Args a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const float* wr = reinterpret_cast<const float*>(a.wr);
@@ -584,11 +593,11 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             R8_MARK();   // 7 t written
             __syncthreads();
             R8_MARK();   // 8
-            res8v_stage<true, false, false>(sm, T, 1, R0, 2, first ? 2 : 6, first ? 20 : 16, 2, wr, a.br, tid, poff, interior, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            res8v_stage<true, false, false, ACT>(sm, T, 1, R0, 2, first ? 2 : 6, first ? 20 : 16, 2, wr, a.br, tid, poff, interior, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
             R8_MARK();   // 9 stage0 done
             __syncthreads();
             R8_MARK();   // 10
-            res8v_stage<false, false, false>(sm, R0, 2, Pb, 3, first ? 3 : 5, first ? 18 : 16, 3, wr + R8V_FILTER, a.br + 8, tid, poff, interior, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
+            res8v_stage<false, false, false, ACT>(sm, R0, 2, Pb, 3, first ? 3 : 5, first ? 18 : 16, 3, wr + R8V_FILTER, a.br + 8, tid, poff, interior, fy0, fx0, H, W, nullptr, 0, nullptr, nullptr);
             if (!first) {
                 // r1 rows 3,4 of this frame = rows 19,20 of the previous one (the tile buffer is free of conv1 readers here)
                 for (int i = tid; i < 2 * ROWV; i += R8_THREADS)
@@ -616,7 +625,7 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 tile_load(g, H_, W_, qy0, qx0, more_passes);
             }
             R8_MARK();   // 13 prefetch issued
-            res8v_stage<false, true, false>(sm, Pb, 3, nullptr, 4, 4, 16, 4, wr + 2 * R8V_FILTER, a.br + 16, tid, poff, interior, fy0, fx0, H, W, T, 1, P.out, nullptr);
+            res8v_stage<false, true, false, ACT>(sm, Pb, 3, nullptr, 4, 4, 16, 4, wr + 2 * R8V_FILTER, a.br + 16, tid, poff, interior, fy0, fx0, H, W, T, 1, P.out, nullptr);
             R8_MARK();   // 14 stage2 done
         }
         tile_id = next_id;
