@@ -407,6 +407,7 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
                 out["f32_split_full_step"] = {
                     "pages_per_s": q["value"], "ms_per_step": q["ms_per_step"], "steps": q["steps"], "timed_region_s": q["config"]["timed_region_s"],
                     "dtype": "f32s", "workload": q["config"]["workload"],
+                    "agreement_with_plain_fp32": q["config"].get("agreement_with_plain_fp32"),
                     "roofline": {k: rr.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "executed_frac", "bf16_mfma_frac",
                                                         "avg_launch_us", "timing", "share_of_gpu_time", "whole_page_executed_frac")},
                     "note": "the headline step with compute_dtype f32s: fp32 tensors / accumulation / results (fp32 parity gates, tests/test_split_gpu.py), "
@@ -753,6 +754,25 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary and not args.no_gnn:
         secondary = secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, (gnn, vpages, vh, vw, VP) if visual else None)
 
+    # --dtype f32s: the step's own outputs against the plain fp32 kernels of the same library on the same pages (in the measured process, after
+    # the timed region): what "fp32 with split products" means for THIS run's numbers, not only for the test suite's
+    agreement = None
+    if rank == 0 and args.dtype == "f32s":
+        step(with_gnn=False)
+        torch.cuda.synchronize()
+        g32 = AruGraph(aru.tensors, AruConfig(compute_dtype="f32"))
+        ref32 = torch.empty(H, W, ncls, device=dev)
+        worst, flips = 0.0, 0
+        for k in range(min(B, 2)):
+            _lib.check(lib.asep_aru_forward_dev(g32.handle(dev_index), imgs[k].data_ptr(), H, W, ref32.data_ptr(), None, None, 0.05, stream), "asep_aru_forward_dev")
+            torch.cuda.synchronize()
+            worst = max(worst, float((out_prob[k] - ref32).abs().max()))
+            flips += int(((out_prob[k] * 255.0).to(torch.uint8) != (ref32 * 255.0).to(torch.uint8)).sum())
+        agreement = {"pages": min(B, 2), "max_abs_dp_vs_plain_fp32_kernels": worst, "uint8_values_that_differ": flips,
+                     "of": min(B, 2) * H * W * ncls, "gate_of_the_fp32_parity_tests": 1e-4}
+        g32.close()
+        del ref32
+
     if rank == 0:
         gnn_flops = 0.0
         if not args.no_gnn:
@@ -788,6 +808,7 @@ def main():
                 "devices": ndev if not ranks_share_devices else f"{min(ndev, world)} (ranks share devices: {world} ranks)",
                 "relation_net": "none" if args.no_gnn else args.gnn,
                 "timed_region_s": round(dt, 3),
+                **({"agreement_with_plain_fp32": agreement} if agreement else {}),
                 "aru_cfg": "ARU featRoot=8 levels=5 res_depth=3 att_scales=3 n_classes=2",
                 # engine / bench switches of the environment this line was measured under (none = the defaults the documents describe)
                 "engine_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("ASEP_") and k != "ASEP_BENCH_DEVICE"},
