@@ -81,6 +81,27 @@ def test_split_products_agree_with_the_plain_fp32_path(H, W, monkeypatch):
     gs.close(); gf.close()
 
 
+def test_split_products_at_tile_boundaries_against_the_plain_path():
+    """sizes around the kernels' tile edges (8 / 16 rows, 32 / 26 columns at every pyramid level) and ragged ones: f32s against the engine's plain
+    fp32 path on logits of a unit-logit-scale net (no oracle run: 16 sizes in a few seconds)"""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from citlab_article_separation_new_amd.config import AruConfig
+    cfg, w, gs = _setup({"apply_softmax": False}, logit_scale=1.0)
+    gf = helper.AruGraph(w, AruConfig(apply_softmax=False))
+    rng = np.random.default_rng(123)
+    sizes = [(128, 128), (129, 127), (256, 512), (257, 513), (255, 511), (16, 32), (17, 33), (15, 31), (64, 26), (63, 27), (8, 300), (300, 8)]
+    sizes += [(int(rng.integers(1, 400)), int(rng.integers(1, 400))) for _ in range(4)]
+    worst = (None, 0.0)
+    for H, W in sizes:
+        img = _image(H, W, H * 7 + W)
+        ls, lf = helper.get_net_output(img, gs, "0"), helper.get_net_output(img, gf, "0")
+        rel = float(np.abs(ls - lf).max()) / max(1.0, float(np.abs(lf).max()))
+        worst = max(worst, ((H, W), rel), key=lambda t: t[1])
+        assert rel <= AGREE_GATE, ((H, W), rel)
+    print(f"\nf32s vs f32 engine over {len(sizes)} sizes: worst {worst[0]} {worst[1]:.2e}")
+    gs.close(); gf.close()
+
+
 @pytest.mark.parametrize("kw", [
     {"feat_root": 16}, {"res_depth": 2}, {"scale_space_num": 3}, {"scale_space_num": 6, "num_scales_att": 5}, {"n_classes": 3},
     {"scale_space_num": 1, "graph": "RU"}, {"activation_name": "elu"}, {"graph": "U", "activation_name": "leaky"},
