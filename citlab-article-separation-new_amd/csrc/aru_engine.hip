@@ -1438,7 +1438,9 @@ void run_res8b(asep_aru* m, bool up, const TL& a0, const TL* a1, const std::vect
         int units = tiles;
         a.xm = oneshot_map<Res8BArgs>(m, a, 16, tiles, false, &units, [](const Res8BArgs& q, int i) { return q.p[i].H; });
         const std::string what = (up ? "unet_up_0 (conv1[16->8]+3xconvR+add) " : "unet_down_0 (conv1+3xconvR+add+pool) ") + dims_of(sub);
-        if (m->use_r8f && (up || m->d_r8f_down_w1)) {
+        bool small = true;                                   // res8f_kernel addresses its tensors with 32-bit byte offsets (16 bytes per pixel)
+        for (size_t i = b0; i < b1; ++i) small = small && (size_t)a0[i].H * a0[i].W < ((size_t)1 << 28);
+        if (m->use_r8f && small && (up || m->d_r8f_down_w1)) {
             // lean form for interior tiles (their 24 x 40 input window inside the image), general form for border tiles, one launch
             Res8BArgs f = a;
             if (!up) f.w1pk = (const u32x4*)m->d_r8f_down_w1;

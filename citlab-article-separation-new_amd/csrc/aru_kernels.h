@@ -80,6 +80,24 @@ __device__ __forceinline__ int sched_tile(const XcdMap& x) {
 // One launch covers the same layer of several independent "problems" (pages x scale-space levels share
 // the layer's weights): blockIdx.x walks the concatenated tile lists, blockIdx.y the output-channel blocks.
 constexpr int MAXP = 12;
+// Problem of work unit t in a launch whose problems' unit ranges start at a.p[i].tile_begin (increasing with i): the index is a
+// COUNT over all starts, so the scalar loads are requested together and answered in one round trip.  (The search loop this replaces
+// -- while (bid >= a.p[pi + 1].tile_begin) ++pi -- compiled to one s_load + s_waitcnt per step: up to eleven dependent scalar-cache
+// round trips at the head of every block of a 12-problem launch, in kernels whose blocks live 5-10 us.)
+template <class Args>
+__device__ __forceinline__ int prob_of_tile(const Args& a, int t) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXP; ++i) pi += (int)((unsigned)((i - a.nprob) & ~(t - a.p[i].tile_begin)) >> 31);   // i < nprob && t >= start, on the sign bits (scalar ALU)
+    return pi;
+}
+template <class Args>
+__device__ __forceinline__ int prob_of_blk(const Args& a, int t) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAXP; ++i) pi += (int)((unsigned)((i - a.nprob) & ~(t - a.p[i].blk_begin)) >> 31);   // i < nprob && t >= start, on the sign bits (scalar ALU)
+    return pi;
+}
 struct ConvProb {
     const float* in0;      // source 0, NHWC with c0 channels
     const float* in1;      // source 1 (channel concat behind source 0) or nullptr
@@ -203,7 +221,7 @@ __global__ __launch_bounds__(256, MINB) void conv_mfma_kernel(const ConvArgs a) 
     const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, bid);
     const ConvProb& P = a.p[pi];
     const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
@@ -535,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
     const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, bid);
     const ConvProb& P = a.p[pi];
     const int tile = bid - P.tile_begin;
     const int tyb = tile / P.tiles_x, txb = tile - tyb * P.tiles_x;
@@ -806,7 +824,7 @@ __global__ __launch_bounds__(256, RESP ? 2 : 3) void conv_winor_kernel(const Con
     const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, bid);
     const ConvProb& P = a.p[pi];
     const int tile = bid - P.tile_begin;
     const int tyb = tile / P.tiles_x, txb = tile - tyb * P.tiles_x;
@@ -979,7 +997,7 @@ __global__ __launch_bounds__(256, 2) void deconv_mfma_kernel(const ConvArgs a) {
     const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, bid);
     const ConvProb& P = a.p[pi];
     const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
@@ -1179,7 +1197,7 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const C1Args a) {
     for (int i = threadIdx.x; i < COUT; i += 256) sw[K * K * COUT + i] = a.bias[i];
     __syncthreads();
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, (int)blockIdx.x);
     const C1Prob& P = a.p[pi];
     const int tile = blockIdx.x - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
@@ -1249,7 +1267,7 @@ __global__ __launch_bounds__(256) void att_head_kernel(const AttHeadArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, (int)blockIdx.x);
     const C1Prob& P = a.p[pi];
     const int tile = blockIdx.x - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
@@ -1351,7 +1369,7 @@ constexpr int POOL_ITEMS = 1024;
 // conv's epilogue commutes with them (the pooled tensor gets the same pass).  p[].in == p[].out, Ho x Wo x C values each.
 __global__ __launch_bounds__(256) void act_kernel(const PoolArgs a, int mode) {
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].blk_begin) ++pi;
+    pi = prob_of_blk(a, (int)blockIdx.x);
     const PoolProb& P = a.p[pi];
     const size_t total = (size_t)P.Ho * P.Wo * a.C;
     const size_t base = (size_t)(blockIdx.x - P.blk_begin) * POOL_ITEMS * 4;
@@ -1374,7 +1392,7 @@ __global__ __launch_bounds__(256) void act_kernel(const PoolArgs a, int mode) {
 
 __global__ __launch_bounds__(256) void maxpool2_kernel(const PoolArgs a) {
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].blk_begin) ++pi;
+    pi = prob_of_blk(a, (int)blockIdx.x);
     const PoolProb& P = a.p[pi];
     const int C = a.C, c4n = C >> 2, H = P.H, W = P.W, Wo = P.Wo;
     const size_t total = (size_t)P.Ho * Wo * c4n;
@@ -1401,7 +1419,7 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const PoolArgs a) {
 // single-channel average pool; divisor = number of valid elements (tf.nn.avg_pool2d SAME)
 __global__ __launch_bounds__(256) void avgpool2_c1_kernel(const PoolArgs a) {
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].blk_begin) ++pi;
+    pi = prob_of_blk(a, (int)blockIdx.x);
     const PoolProb& P = a.p[pi];
     const int H = P.H, W = P.W, Wo = P.Wo;
     const size_t total = (size_t)P.Ho * Wo;
@@ -1454,7 +1472,7 @@ __global__ __launch_bounds__(256) void avgpool2_c1_kernel(const PoolArgs a) {
 // channel sum [H,W,C] -> [H,W]  (the channel-summing half of upsample_simple, layers.py:716-720)
 __global__ __launch_bounds__(256) void chansum_kernel(const PoolArgs a) {
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].blk_begin) ++pi;
+    pi = prob_of_blk(a, (int)blockIdx.x);
     const PoolProb& P = a.p[pi];
     const size_t total = (size_t)P.H * P.W;
     const size_t base = (size_t)(blockIdx.x - P.blk_begin) * POOL_ITEMS;

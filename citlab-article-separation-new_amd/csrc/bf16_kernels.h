@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
     const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, bid);
     const ConvBProb& P = a.p[pi];
     const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256, C == 8 ? 4 : 3) void resb_tail_kernel(const Re
     __shared__ __attribute__((aligned(16))) unsigned char lds[ResBLayout<C>::BYTES];
     if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, bid);
     const ResBProb& P = a.p[pi];
     const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(512, 1) void res32_tail_kernel(const ResBArgs a) {
     auto locate = [&](int unit, int& pi, int& x0, int& y0) {
         const int t = a.sched ? a.sched[unit] : unit;
         pi = 0;
-        while (pi + 1 < a.nprob && t >= a.p[pi + 1].tile_begin) ++pi;
+        pi = prob_of_tile(a, t);
         const int tile = t - a.p[pi].tile_begin;
         const int ty = tile / a.p[pi].tiles_x, tx = tile - ty * a.p[pi].tiles_x;
         x0 = tx * RB_TW; y0 = ty * RB_TH;
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
     const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, bid);
     const ResBProb& P = a.p[pi];
     const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
     const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, bid);
     const DeconvBProb& P = a.p[pi];
     const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
@@ -1371,7 +1371,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8b_kernel(const Res8BArgs 
     const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, bid);
     const Res8BProb& P = a.p[pi];
     const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
@@ -1419,7 +1419,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, bid);
     const Res8BProb& P = a.p[pi];
     const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
@@ -1431,53 +1431,60 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
         return;
     }
 
-    // ---- conv1 input tile -> LDS (no padding: the window is inside the image) ----
-    if constexpr (UP) {
-        constexpr int NU = IH * IW * 2, NLOAD = (NU + 255) / 256;
-        u32x4 st[NLOAD];
-#pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-            const int u = min(tid + i * 256, NU - 1);
-            const int pix = u >> 1, sub = u & 1;
-            const int ly = pix / IW, lx = pix - ly * IW;
-            st[i] = *reinterpret_cast<const u32x4*>((sub ? P.dec : P.skip) + ((size_t)(y0 - 4 + ly) * W + x0 - 4 + lx) * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-            const int u = tid + i * 256;
-            if (u < NU) *reinterpret_cast<u32x4*>(in + u * 16) = st[i];
-        }
-    } else {
-        constexpr int NLOAD = (IH * IW + 255) / 256;
-        float st[NLOAD];
-        float mean = 0.f, inv = 1.f;
-        if (P.stats) { mean = P.stats[0]; inv = P.stats[1]; }
-#pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-            const int u = min(tid + i * 256, IH * IW - 1);
-            const int ly = u / IW, lx = u - ly * IW;
-            st[i] = P.img[(size_t)(y0 - 4 + ly) * W + x0 - 4 + lx];
-        }
-#pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-            const int u = tid + i * 256;
-            if (u < IH * IW) reinterpret_cast<bf16_t*>(in)[u] = (bf16_t)(pack_bf16x2((st[i] - mean) * inv, 0.f) & 0xffffu);
-        }
-        if (tid < IW / 2) reinterpret_cast<unsigned*>(in)[IH * IW / 2 + tid] = 0u;     // row IH: read with zero weights, must be finite
-    }
-    R8F_MARK(2);
-    // biases: requested at the kernel's start -- read where a stage begins (behind its barrier) each one is an exposed L2 round trip
+    // ---- requests, cheapest-to-wait-for first: the biases and the A fragments of conv1 / convR_0 (L2 hits, needed right behind the first
+    //      barrier: requested behind the input window they used to arrive after it), then the conv1 input window.  Threads 0 .. 239 own
+    //      column t % 40 of the window rows t / 40 + 6 k: ONE division per thread, uniform base pointers + 32-bit byte offsets (the
+    //      tensors of a launch lie below 4 GB: run_res8b checks), LDS addresses = per-thread base + immediates.  (First cut: slot u =
+    //      tid + 256 i with a division per slot and the source pointer selected per lane -- the compiler LOADED the pointer from the
+    //      argument block through a vector address, one dependent L2 round trip in front of every window load.) ----
     const f32x4 bias1 = *reinterpret_cast<const f32x4*>(a.b1 + ch);
     f32x4 biasw[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) biasw[t] = *reinterpret_cast<const f32x4*>(a.bias + 8 * t + ch);
-    u32x4 a1[UP ? 6 : 1];                                    // conv1's A fragments, likewise
+    u32x4 a1[UP ? 6 : 1];
 #pragma unroll
     for (int t = 0; t < (UP ? 6 : 1); ++t) a1[t] = a.w1pk[t * 64 + lane];
     const u32x4* __restrict__ wl = a.wpk + lane;
-    u32x4 af[3];
+    u32x4 af[3], ag[3];                                      // the fragments of the current / the next convR (requested a stage ahead)
 #pragma unroll
-    for (int t = 0; t < 3; ++t) af[t] = wl[t * 64];           // convR_0's fragments fly during conv1
+    for (int t = 0; t < 3; ++t) af[t] = wl[t * 64];
+    const int lr = tid / IW, lc = tid - lr * IW;              // (threads 240 .. 255: row 6, clamped below, nothing stored)
+    const bool ldr = tid < 6 * IW;
+    const unsigned wu = (unsigned)W;
+    if constexpr (UP) {
+        const unsigned goff = ((unsigned)(y0 - 4 + (ldr ? lr : 0)) * wu + (unsigned)(x0 - 4 + lc)) * 16u, gstep = 6u * wu * 16u;
+        const unsigned char* __restrict__ sk = reinterpret_cast<const unsigned char*>(P.skip);
+        const unsigned char* __restrict__ dc = reinterpret_cast<const unsigned char*>(P.dec);
+        u32x4 st[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            st[2 * k] = *reinterpret_cast<const u32x4*>(sk + (goff + k * gstep));
+            st[2 * k + 1] = *reinterpret_cast<const u32x4*>(dc + (goff + k * gstep));
+        }
+        unsigned char* const dst = in + (lr * IW + lc) * 32;
+        if (ldr) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                *reinterpret_cast<u32x4*>(dst + k * 6 * IW * 32) = st[2 * k];
+                *reinterpret_cast<u32x4*>(dst + k * 6 * IW * 32 + 16) = st[2 * k + 1];
+            }
+        }
+    } else {
+        const unsigned goff = ((unsigned)(y0 - 4 + (ldr ? lr : 0)) * wu + (unsigned)(x0 - 4 + lc)) * 4u, gstep = 6u * wu * 4u;
+        const unsigned char* __restrict__ im = reinterpret_cast<const unsigned char*>(P.img);
+        float st[4];
+        float mean = 0.f, inv = 1.f;
+        if (P.stats) { mean = P.stats[0]; inv = P.stats[1]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st[k] = *reinterpret_cast<const float*>(im + (goff + k * gstep));
+        bf16_t* const dst = reinterpret_cast<bf16_t*>(in) + lr * IW + lc;
+        if (ldr) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dst[k * 6 * IW] = (bf16_t)(pack_bf16x2((st[k] - mean) * inv, 0.f) & 0xffffu);
+        }
+        if (tid < IW / 2) reinterpret_cast<unsigned*>(in)[IH * IW / 2 + tid] = 0u;     // row IH: read with zero weights, must be finite
+    }
+    R8F_MARK(2);
 
     // remainder tiles: lane j -> (row rr of the tile's row group, pair pc) for PR pairs per row
     const int j3 = j / 3, rr3 = min(j3, 4), pc3 = j - j3 * 3;  // conv1 / region 0: 6 pixels = 3 pairs, 5 rows per tile (lane 15 idle)
@@ -1486,6 +1493,10 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     auto relu_pk = [](u32x2 p) { return u32x2{relu_bf16x2(p.x), relu_bf16x2(p.y)}; };
     __syncthreads();
     R8F_MARK(3);
+    // convR_1's fragments: requested a whole stage before their first use (requested behind stage 1's MFMAs, as the first cut did, the
+    // first MFMA of every stage waited for an L2 round trip)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) ag[t] = wl[(3 + t) * 64];
 
     // ---- conv1: relu(t) over the 22 x 38 region (r0), raw t of the centre 16 x 32 (tc) ----
     {
@@ -1525,7 +1536,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
             const int rA = wave + 4 * i, rB = rA + 4;
             const u32x2 rawA = pack_bf16x4(conv1(rA, 2 * j)), rawB = pack_bf16x4(conv1(min(rB, H0 - 1), 2 * j));
             const int r = isB ? rB : rA, off = isB ? (i + 1) * 4 : i * 4;
-            const u32x4 raw = whole(rawA, rawB), rl = whole(relu_pk(rawA), relu_pk(rawB));
+            const u32x4 raw = whole(rawA, rawB), rl = relu_bf16x8(raw);     // (ReLU of the traded record: two swaps per tile pair, not four)
             if (r < H0) {
                 *reinterpret_cast<u32x4*>(d0 + off * W0 * 16) = rl;
                 if (r >= 3 && r < 3 + TH && c >= 3) *reinterpret_cast<u32x4*>(dt + off * TW * 16) = raw;
@@ -1536,7 +1547,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
             const int rowA = tA * 5 + rr3, rowB = tB * 5 + rr3, col = 32 + 2 * pc3;
             const u32x2 rawA = pack_bf16x4(conv1(min(rowA, H0 - 1), col)), rawB = pack_bf16x4(conv1(min(rowB, H0 - 1), col));
             const int row = isB ? rowB : rowA;
-            const u32x4 raw = whole(rawA, rawB), rl = whole(relu_pk(rawA), relu_pk(rawB));
+            const u32x4 raw = whole(rawA, rawB), rl = relu_bf16x8(raw);
             if (row < H0 && j3 < 5) {
                 *reinterpret_cast<u32x4*>(r0 + (row * W0 + col + e) * 16) = rl;
                 if (row >= 3 && row < 3 + TH && col + e < 3 + TW) *reinterpret_cast<u32x4*>(tc + ((row - 3) * TW + col + e - 3) * 16) = raw;
@@ -1551,7 +1562,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     //      Tiles are processed in PAIRS: both tiles' fragment reads first, their MFMAs interleaved (two independent accumulator
     //      chains), both epilogues -- written tile by tile the compiler serialises read -> wait -> MFMA chain -> epilogue per tile
     //      and a wave has nothing to overlap its LDS / MFMA latencies with ----
-    auto conv8x2 = [&](const unsigned char* pa, const unsigned char* pb, int pitch, f32x4 c0, f32x4& ra, f32x4& rb) {
+    auto conv8x2 = [&](const u32x4 (&af)[3], const unsigned char* pa, const unsigned char* pb, int pitch, f32x4 c0, f32x4& ra, f32x4& rb) {
         u32x4 fa[3], fb[3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) { fa[ky] = *reinterpret_cast<const u32x4*>(pa + ky * pitch); fb[ky] = *reinterpret_cast<const u32x4*>(pb + ky * pitch); }
@@ -1577,19 +1588,19 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
         f32x4 va, vb;
 #pragma unroll
         for (int i = 0; i < 4; i += 2) {
-            conv8x2(sb + i * 4 * W0 * 16, sb + (i + 1) * 4 * W0 * 16, W0 * 16, b4, va, vb);
+            conv8x2(af, sb + i * 4 * W0 * 16, sb + (i + 1) * 4 * W0 * 16, W0 * 16, b4, va, vb);
             *reinterpret_cast<u32x4*>(db + i * 4 * W1 * 16) = whole_relu(va, vb);
         }
-        conv8x2(sb + 16 * W0 * 16, sr, W0 * 16, b4, va, vb);                            // A: row wave + 16; B: the remainder tile
+        conv8x2(af, sb + 16 * W0 * 16, sr, W0 * 16, b4, va, vb);                            // A: row wave + 16; B: the remainder tile
         const u32x4 rec = whole_relu(va, vb);
         if (!isB) *reinterpret_cast<u32x4*>(r1 + ((wave + 16) * W1 + c) * 16) = rec;
         else if (wave < 3 && row < H1) *reinterpret_cast<u32x4*>(r1 + (row * W1 + col + e) * 16) = rec;
     }
-#pragma unroll
-    for (int t = 0; t < 3; ++t) af[t] = wl[(3 + t) * 64];
     R8F_MARK(6);
     __syncthreads();
     R8F_MARK(7);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) af[t] = wl[(6 + t) * 64];     // convR_2's, a stage ahead (stage 1 was af's last reader)
     {
         const f32x4 b4 = biasw[1];
         constexpr int HO = TH + 2;                            // 18 rows of 34: stage 2's result takes region 0's place (dead)
@@ -1601,16 +1612,14 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
         const unsigned char* const s5 = wave < 2 ? sb + 16 * W1 * 16 : r1 + (rowc * W1 + 32 + kk) * 16;
         unsigned char* const d5 = wave < 2 ? r0 + ((wave + 16) * W2 + c) * 16 : r0 + (rowc * W2 + 32 + e) * 16;
         f32x4 va, vb;
-        conv8x2(sb, sb + 4 * W1 * 16, W1 * 16, b4, va, vb);
+        conv8x2(ag, sb, sb + 4 * W1 * 16, W1 * 16, b4, va, vb);
         *reinterpret_cast<u32x4*>(db) = whole_relu(va, vb);
-        conv8x2(sb + 8 * W1 * 16, sb + 12 * W1 * 16, W1 * 16, b4, va, vb);
+        conv8x2(ag, sb + 8 * W1 * 16, sb + 12 * W1 * 16, W1 * 16, b4, va, vb);
         *reinterpret_cast<u32x4*>(db + 8 * W2 * 16) = whole_relu(va, vb);
-        conv8x2(s5, s5, W1 * 16, b4, va, vb);
+        conv8x2(ag, s5, s5, W1 * 16, b4, va, vb);
         const u32x4 rec = whole_relu(va, vb);
         if (!isB && (wave < 2 || row < HO)) *reinterpret_cast<u32x4*>(d5) = rec;
     }
-#pragma unroll
-    for (int t = 0; t < 3; ++t) af[t] = wl[(6 + t) * 64];
     R8F_MARK(8);
     __syncthreads();
     R8F_MARK(9);
@@ -1619,20 +1628,23 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     {
         const f32x4 b4 = biasw[2];
         const int Wp = (W + 1) >> 1;
-        bf16_t* __restrict__ out = P.out + ((size_t)(y0 + 2 * wave) * W + x0 + c) * 8 + ch;
+        // (uniform base pointers + 32-bit byte offsets: the row steps are scalar adds, not 64-bit vector multiply-adds)
+        unsigned char* __restrict__ const outb = reinterpret_cast<unsigned char*>(P.out);
+        unsigned char* __restrict__ const poolb = reinterpret_cast<unsigned char*>(P.pool);
+        const unsigned ooff = (((unsigned)(y0 + 2 * wave) * wu + (unsigned)(x0 + c)) * 8u + (unsigned)ch) * 2u, orow = wu * 16u;
+        const unsigned poff = (((unsigned)((y0 >> 1) + wave) * (unsigned)Wp + (unsigned)((x0 >> 1) + j)) * 8u + (unsigned)ch) * 2u, prow = (unsigned)Wp * 16u;
         const unsigned char* const sb = r0 + (2 * wave * W2 + 2 * j + kk) * 16;
         const unsigned char* const tb = tc + (2 * wave * TW + c) * 16 + ch * 2;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int rp = wave + 4 * i;
             f32x4 v2[2];
-            conv8x2(sb + 8 * i * W2 * 16, sb + (8 * i + 1) * W2 * 16, W2 * 16, b4, v2[0], v2[1]);
+            conv8x2(af, sb + 8 * i * W2 * 16, sb + (8 * i + 1) * W2 * 16, W2 * 16, b4, v2[0], v2[1]);
             u32x2 pk[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 // ReLU after the rounding: one v_pk_max_i16 per two values
                 pk[r] = relu_pk(pack_bf16x4(v2[r] + unpack_bf16x4(*reinterpret_cast<const u32x2*>(tb + (8 * i + r) * TW * 16))));
-                *reinterpret_cast<u32x2*>(out + (size_t)(8 * i + r) * W * 8) = pk[r];
+                *reinterpret_cast<u32x2*>(outb + (ooff + (unsigned)(8 * i + r) * orow)) = pk[r];
             }
             if (P.pool) {
                 // 2 x 2 max on the PACKED values (non-negative bf16 order like their bit patterns: v_pk_max_i16): the two rows, then the
@@ -1641,7 +1653,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
                 const unsigned m0 = pkmax_u16(pk[0].x, pk[1].x), m1 = pkmax_u16(pk[0].y, pk[1].y);
                 const auto s0 = __builtin_amdgcn_permlane32_swap(m0, m0, false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(m1, m1, false, false);
-                if (e == 0) *reinterpret_cast<u32x2*>(P.pool + ((size_t)((y0 >> 1) + rp) * Wp + (x0 >> 1) + j) * 8 + ch) = u32x2{pkmax_u16(s0[0], s0[1]), pkmax_u16(s1[0], s1[1])};
+                if (e == 0) *reinterpret_cast<u32x2*>(poolb + (poff + (unsigned)(4 * i) * prow)) = u32x2{pkmax_u16(s0[0], s0[1]), pkmax_u16(s1[0], s1[1])};
             }
         }
     }
@@ -1666,7 +1678,7 @@ struct PoolBArgs {
 };
 __global__ __launch_bounds__(256) void chansumb_kernel(const PoolBArgs a) {
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].blk_begin) ++pi;
+    pi = prob_of_blk(a, (int)blockIdx.x);
     const PoolBProb& P = a.p[pi];
     const size_t total = (size_t)P.H * P.W;
     const size_t base = (size_t)(blockIdx.x - P.blk_begin) * POOL_ITEMS;

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     // frame = one 24-row window of a work unit: (tile, pass) -> image rows [(tyb * NP + pass) * OH - 4, +24)
     auto image_load = [&](int tile_id, int pass) {          // next frame's image values -> registers (in flight under the stages)
         int pi = 0;
-        while (pi + 1 < a.nprob && tile_id >= a.p[pi + 1].tile_begin) ++pi;
+        pi = prob_of_tile(a, tile_id);
         const Res8Prob& Q = a.p[pi];
         const int t = tile_id - Q.tile_begin;
         const int tyb = t / Q.tiles_x, txb = t - tyb * Q.tiles_x;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const bool has_next = k + (int)gridDim.x < a.total_tiles;
         const int next_id = has_next ? res8_tile_of(a, k + gridDim.x) : 0;   // requested a whole tile ahead of its use
         int pi = 0;
-        while (pi + 1 < a.nprob && tile_id >= a.p[pi + 1].tile_begin) ++pi;
+        pi = prob_of_tile(a, tile_id);
         const Res8Prob& P = a.p[pi];
         const int t = tile_id - P.tile_begin;
         const int tyb = t / P.tiles_x, txb = t - tyb * P.tiles_x;
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const bool has_next = k + (int)gridDim.x < a.total_tiles;
         const int next_id = has_next ? res8_tile_of(a, k + gridDim.x) : 0;   // requested a whole tile ahead of its use
         int pi = 0;
-        while (pi + 1 < a.nprob && tile_id >= a.p[pi + 1].tile_begin) ++pi;
+        pi = prob_of_tile(a, tile_id);
         const Res8Prob& P = a.p[pi];
         const int t = tile_id - P.tile_begin;
         const int tyb = t / P.tiles_x, txb = t - tyb * P.tiles_x;
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void att_headv_kernel(const AttHeadArgs a) {
     __shared__ __attribute__((aligned(16))) float img[LH * LW];
     const int tid = threadIdx.x;
     int pi = 0;
-    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, (int)blockIdx.x);
     const C1Prob& P = a.p[pi];
     const int tile = blockIdx.x - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(256) void deconv8v_kernel(const ConvArgs a) {
     const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, bid);
     const ConvProb& P = a.p[pi];
     const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(256) void conv_c1out_kernel(const ConvArgs a) {
     const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, bid);
     const ConvProb& P = a.p[pi];
     const int tile = bid - P.tile_begin;
     const int ty0 = tile / P.tiles_x, tx0 = tile - ty0 * P.tiles_x;

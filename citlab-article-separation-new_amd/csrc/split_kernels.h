@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, MINB) void convs_kernel(const ConvArgs a) {
     const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, bid);
     const ConvProb& P = a.p[pi];
     const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, MINB) void convs16_kernel(const ConvArgs a) {
     const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, bid);
     const ConvProb& P = a.p[pi];
     const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256, 3) void res8s_kernel(const Res8SArgs a) {
     const int bid = sched_tile(a.xm);
     if (bid < 0) return;
     int pi = 0;
-    while (pi + 1 < a.nprob && bid >= a.p[pi + 1].tile_begin) ++pi;
+    pi = prob_of_tile(a, bid);
     const Res8Prob& Pr = a.p[pi];
     const int tile = bid - Pr.tile_begin;
     const int ty = tile / Pr.tiles_x, tx = tile - ty * Pr.tiles_x;
