@@ -62,10 +62,18 @@ def parse_args():
     ap.add_argument("--kernel-timing", choices=["both", "in-situ", "isolated", "none"], default="both",
                     help="HIP-event per-kernel passes after the timed region (in-situ only under rocprofv3, so that every launch of "
                          "the traced process runs in the same schedule)")
-    ap.add_argument("--dtype", choices=["f32", "bf16", "f32s"], default="f32",
-                    help="f32 = BASELINE configs[1] (the headline); bf16 = configs[4] 'bf16 convs': bf16 MFMA operands, "
-                         "fp32 accumulation / storage, probability maps within 2e-2 (reported with dtype bf16)")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f32s"], default="f32s",
+                    help="f32s = BASELINE configs[1] on the fp32 engine's default arithmetic (the headline since round 5): fp32 tensors, "
+                         "fp32 accumulation, fp32 results, every product of the >= 12-channel convolutions as 6 bf16 MFMAs of the exact "
+                         "3-way bfloat16 split of both factors -- held to the fp32 parity gates; f32 = the same step on the plain fp32 "
+                         "MFMA / Winograd kernels (secondary.plain_f32_full_step); bf16 = configs[4] 'bf16 convs': bf16 tensors and MFMA "
+                         "operands, fp32 accumulation, probability maps within 2e-2 (reported with dtype bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", metavar="OUT.json", default=None,
+                    help="ONLY the CPU baseline by BASELINE.md section 3's protocol, no GPU work: whole pages from PNG files through every stage "
+                         "(decode, scale + gray, ARU-Net oracle, uint8 / threshold, CC filter + openings, polygon rings, PAGE-XML) and graphs "
+                         "through the relation-net oracle, clustering and PAGE-XML; 1 warm-up + 8 pages + 64 graphs, per-stage wall clock "
+                         "(~10 minutes on 16 CPUs) -> OUT.json (committed as profiles/r5_cpu_baseline.json; the default line cites it)")
     ap.add_argument("--event-steps", type=int, default=3,
                     help="steps per HIP-event pass (scripts/profile_bench.sh uses many event-timed and few plain steps, so that "
                          "rocprofv3's per-kernel averages cover the launches the events bracket)")
@@ -79,13 +87,16 @@ def parse_args():
                     help="scans of the heading command line inside the files-in / files-out leg (0 = skip)")
     ap.add_argument("--e2e-gnn-pages", type=int, default=384,
                     help="pages of the relation net's command line inside the files-in / files-out leg (0 = skip)")
+    ap.add_argument("--e2e-n-pages-per-owner", type=int, default=96,
+                    help="--gpus N > 1: scans per GPU owner of the N-owner files-in / files-out leg (secondary.e2e_files_n; 0 = skip)")
+    ap.add_argument("--e2e-n-leg", type=int, default=0, help=argparse.SUPPRESS)    # internal: run only the N-owner leg with this many owners
     ap.add_argument("--e2e-leg", action="store_true", help=argparse.SUPPRESS)      # internal: run only the e2e_files leg, print its JSON
     ap.add_argument("--e2e-device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--bf16-steps", type=int, default=160,
                     help="timed steps of the secondary bf16 full step (configs[4]: bf16 ARU-Net + visual relation net with bf16 backbone; "
                          "160 x 16 pages >= 5 s at its rate; 0 = skip)")
-    ap.add_argument("--split-steps", type=int, default=60,
-                    help="timed steps of the secondary fp32 step with split products (compute_dtype f32s; 60 x 16 pages >= 6 s at its rate; 0 = skip)")
+    ap.add_argument("--plain-steps", type=int, default=50,
+                    help="timed steps of the secondary step on the PLAIN fp32 kernels (compute_dtype f32; 50 x 16 pages >= 6 s at its rate; 0 = skip)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements (bf16 variant, heading net + stroke-width fusion, visual GNN)")
     ap.add_argument("--cpu-sample-height", type=int, default=0,
@@ -150,9 +161,16 @@ def run_cpu_baseline(args):
     short = (f"{len(res)}x{threads} threads: torch-CPU fp32 ARU-Net oracle on "
              + (f"one {args.width}x{args.height} scan" if rows >= args.height else f"a {args.width}x{rows} band (x{1 / frac:.2f})")
              + ("" if args.no_gnn else (" + visual relation-net oracle" if args.gnn == "visual" else " + numpy GNN oracle")))
+    full = None
+    try:                                           # the committed full-protocol run (bench.py --cpu-baseline-full), cited beside the band sample
+        fq = json.load(open(os.path.join(ROOT, "profiles", "r5_cpu_baseline.json")))
+        full = {"file": "profiles/r5_cpu_baseline.json", "pages_per_s_end_to_end": fq["pages_per_s_end_to_end"], "cores": fq["cores"],
+                "seconds_per_page_by_stage": fq["seconds_per_page_by_stage"], "seconds_per_graph_by_stage": fq["seconds_per_graph_by_stage"]}
+    except (OSError, KeyError, ValueError):
+        pass
     return {
         "value": round(len(res) / t_page, 5), "unit": "pages/s", "cores": used, "cores_of": cores, "logical_cpus": logical, "kind": "port",
-        "sample": short[:118],
+        "sample": short[:118], "full_protocol": full,
         "sample_detail": (f"{used} of the {cores} CPUs this container may use (the box has {logical} logical CPUs"
                    + (f", cgroup quota {cores}" if cores < logical else "") + f"): {len(res)} worker processes x {threads} threads, each: torch-CPU "
                    "fp32 ARU-Net oracle on "
@@ -163,6 +181,27 @@ def run_cpu_baseline(args):
                    + f"; no decode / post-processing; slowest worker {t_page:.2f}s/page (relation net "
                    f"{max(r['t_gnn'] for r in res):.2f}s); {wall:.1f}s wall incl. start-up and page generation"),
     }
+
+
+def run_cpu_baseline_full(args):
+    """the CPU restatement of the whole pipeline on whole pages and graphs, per stage (oracle/cpu_worker.py --full)."""
+    import subprocess
+    from citlab_article_separation_new_amd.host_util import effective_cpus
+    cores = effective_cpus()
+    threads = min(16, cores)
+    cmd = [sys.executable, "-m", "oracle.cpu_worker", "--full", "--threads", str(threads), "--pages", "8", "--graphs", "64",
+           "--width", str(args.width), "--height", str(args.height)]
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, text=True, timeout=7200)
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise SystemExit(f"oracle.cpu_worker --full exited with {r.returncode}")
+    q = json.loads(lines[-1])
+    q.update({"kind": "port", "unit": "pages/s", "value": q["pages_per_s_end_to_end"], "cores": threads, "cores_of": cores, "logical_cpus": os.cpu_count(),
+              "wall_s": round(time.perf_counter() - t0, 1), "height": args.height, "width": args.width,
+              "protocol": "BASELINE.md section 3: 1 warm-up + 8 whole pages from PNG files (decode .. PAGE-XML) + 64 graphs of 200 text blocks (json .. "
+                          "PAGE-XML with article ids), one process, torch-CPU / numpy oracles, per-stage wall clock; pages/s = 1 / (s per page + s per graph)"})
+    return q
 
 
 def rank_kernels(iso, situ):
@@ -283,6 +322,61 @@ def e2e_files(args, dev_index):
                     f"a PNG decode of one scan costs ~0.045 CPU-seconds (libdeflate / zlib + csrc/host_png.c; 0.11 through Pillow), the PAGE-XML ~0.03"}
 
 
+def e2e_files_n(args, n_owners):
+    """Files in, files out with N GPU OWNERS (what a --gpus N run would otherwise not show: the device-resident step shards perfectly, the
+    files-in / files-out path is fed by host CPUs): `run_net_post_processing --mode separator` on n_owners x --e2e-n-pages-per-owner PNG
+    scans, one GPU-owning process per device (ASEP_BENCH_OWNERS="0,0" puts several owners on one device: the two-owners-on-one-GPU test),
+    the container's CPU quota split evenly into host workers -- the reference's fan-out (run_net_post_processing.py:61-82) with owners
+    instead of sessions.  Runs as a child of rank 0 after the timed region; the command line spawns its owners itself."""
+    import tempfile
+    from PIL import Image
+    from citlab_article_separation_new_amd import run_net_post_processing as cli, synth
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.host_util import effective_cpus
+    from citlab_article_separation_new_amd.weights import init_aru_weights, save_weights
+    H, W = args.height, args.width
+    n = n_owners * args.e2e_n_pages_per_owner
+    cpus = effective_cpus()
+    workers = max(n_owners, cpus - n_owners)                  # host workers in total: the quota minus one CPU per owner process
+    cfg = AruConfig(compute_dtype=args.dtype)
+    with tempfile.TemporaryDirectory(prefix="asep_e2e_n_") as tmp:
+        os.makedirs(os.path.join(tmp, "page"))
+        os.makedirs(os.path.join(tmp, "stats"))
+        model = os.path.join(tmp, "separator.asepw")
+        save_weights(model, init_aru_weights(cfg, 21, logit_scale=0.05), {"aru_cfg": cfg.to_dict()})
+        paths = []
+        for k in range(n):
+            q = os.path.join(tmp, f"p{k:04d}.png")
+            if k < 4:
+                Image.fromarray(synth.cached_synth_page(k, W, H)).save(q, compress_level=1)
+            else:
+                os.symlink(os.path.join(tmp, f"p{k % 4:04d}.png"), q)
+            paths.append(q)
+        lst = os.path.join(tmp, "images.lst")
+        with open(lst, "w") as f:
+            f.write("\n".join(paths) + "\n")
+        os.environ["ASEP_OWNER_STATS_DIR"] = os.path.join(tmp, "stats")
+        os.environ["ASEP_COMPUTE_DTYPE"] = args.dtype
+        if os.environ.get("ASEP_BENCH_OWNERS"):
+            os.environ["ASEP_GPU_OWNERS"] = os.environ["ASEP_BENCH_OWNERS"]
+        t0 = time.perf_counter()
+        rc = cli.main(["--path_to_image_list", lst, "--path_to_pb", model, "--mode", "separator", "--fixed_height", str(H),
+                       "--threshold", "0.5", "--num_processes", str(workers)])
+        dt = time.perf_counter() - t0
+        n_xml = len([f for f in os.listdir(os.path.join(tmp, "page")) if f.endswith(".xml.xml")])
+        owners = [json.load(open(os.path.join(tmp, "stats", f))) for f in sorted(os.listdir(os.path.join(tmp, "stats")))]
+    share = lambda key: round(sum(o[key] or 0.0 for o in owners) / max(sum(o["seconds"] for o in owners), 1e-9), 3)
+    return {"rc": rc, "pages_per_s": round(n / dt, 2), "ms_per_page": round(1e3 * dt / n, 2), "scans": n, "page_xml_written": n_xml,
+            "gpu_owners": len(owners), "owner_devices": [o["device"] for o in owners], "host_workers_total": workers,
+            "host_workers_per_owner": owners[0]["host_workers"] if owners else None, "cpus_this_container_may_use": cpus,
+            "logical_cpus": os.cpu_count(), "pages_per_s_per_owner": [round(o["pages"] / o["seconds"], 2) for o in owners],
+            "owner_device_stage_share": share("device_seconds"), "owner_waiting_for_decode_share": share("wait_seconds"),
+            "owner_ring_chaining_share": share("host_seconds"), "dtype": args.dtype,
+            "note": f"run_net_post_processing --mode separator --fixed_height {H} on {n} PNG scans: {len(owners)} GPU-owning processes x "
+                    f"{owners[0]['host_workers'] if owners else 0} decode / PAGE-XML workers each (CPU quota {cpus} split evenly), model load and worker "
+                    "start-up included; shares = owners' wall time inside the device stages / waiting for a decoded scan / chaining rings"}
+
+
 def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages):
     """Not the headline: the other BASELINE.json configs on the same box, each a short timed loop after the main
     measurement (device-resident inputs, same conventions).
@@ -304,16 +398,30 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
     p_img, p_out, p_u8 = Arr(*[t.data_ptr() for t in imgs[:B2]]), Arr(*[t.data_ptr() for t in prob]), Arr(*[t.data_ptr() for t in u8])
     try:
         # ---- the other precision ----
-        other = "bf16" if args.dtype == "f32" else "f32"
+        other = "bf16" if args.dtype != "bf16" else "f32s"
         cfg16 = AruConfig(compute_dtype=other)
         g16 = AruGraph(init_aru_weights(cfg16, 1234), cfg16)
         h16 = g16.handle(dev.index or 0)
         dt = _timed(lambda: _lib.check(lib.asep_aru_forward_batch_dev(h16, B2, p_img, H, W, p_out, p_u8, None, 0.05, s), other), 8, warmup=2)
-        out["aru_bf16_mfma" if other == "bf16" else "aru_f32"] = {
+        out["aru_bf16_mfma" if other == "bf16" else "aru_f32s"] = {
             "pages_per_s": round(B2 / dt, 2), "ms_per_page": round(1e3 * dt / B2, 3), "dtype": other,
             "note": ("BASELINE configs[4] precision; probability maps within 2e-2 of the fp32 oracle (tests/test_full_frame_gpu.py); "
                      if other == "bf16" else "") + "ARU-Net alone, no relation net beside it"}
         g16.close()
+        # ---- the UPSTREAM ARU-Net layout (ARU_v1.py:35-43: 6 levels, 5 attention scales; SURVEY 8d: the shipped .pb's true cfg is unknown),
+        #      ARU-Net alone on the same pages, both arithmetics (parity at this size: tests/test_full_frame_gpu.py) ----
+        up = {}
+        for dt6 in (("f32s", "bf16") if args.dtype != "f32" else ("f32", "bf16")):
+            cfg6 = AruConfig(scale_space_num=6, num_scales_att=5, compute_dtype=dt6)
+            g6 = AruGraph(init_aru_weights(cfg6, 1234), cfg6)
+            h6 = g6.handle(dev.index or 0)
+            dt = _timed(lambda: _lib.check(lib.asep_aru_forward_batch_dev(h6, B2, p_img, H, W, p_out, p_u8, None, 0.05, s), "upstream layout"), 6, warmup=2)
+            gf = lib.asep_aru_flops(h6, H, W) / 1e9
+            up[dt6] = {"pages_per_s": round(B2 / dt, 2), "ms_per_page": round(1e3 * dt / B2, 3), "gflop_per_page": round(gf, 1),
+                       "tflops": round(gf * B2 / dt / 1e3, 1)}
+            g6.close()
+        out["upstream_layout_6x5"] = dict(up, note="ARU-Net alone with scale_space_num 6 / num_scales_att 5 (the upstream paper layout), "
+                                                   f"{B2} pages per call at {W}x{H}; the default line's net is 5 / 3")
         # ---- heading pipeline on one page: net + SWT + per-line features ----
         cfg = AruConfig()
         gh = AruGraph(init_aru_weights(cfg, 22), cfg)
@@ -369,7 +477,7 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
         gg.close()
         # ---- BASELINE configs[4] as a whole step: bf16 ARU-Net + the visual relation net with its backbone on the bf16 kernels, the
         #      same step / timing code as the headline, in a child process of its own (>= 5 s timed at its rate), with its roofline ----
-        if args.dtype == "f32" and args.bf16_steps > 0:
+        if args.dtype == "f32s" and args.bf16_steps > 0:
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "bf16", "--steps", str(args.bf16_steps), "--warmup", "2",
                    "--pages-per-step", str(args.pages_per_step), "--height", str(H), "--width", str(W), "--gnn", args.gnn,
@@ -390,12 +498,13 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
                     "note": "same step as the headline with --dtype bf16 (child process; this process's fp32 buffers stay allocated beside it)"}
             else:
                 out["bf16_full_step"] = {"error": f"bf16 child exited with {r.returncode}"}
-        # ---- the headline step with fp32 SPLIT products (compute_dtype "f32s", csrc/split_kernels.h: fp32 tensors and accumulation, the
-        #      products of the >= 12-channel convolutions as six bf16 x bf16 partial products; same fp32 parity gates) -- not the headline
-        #      itself because the multiplications run on the bf16 matrix pipeline: reported beside it, the same timing code, own process ----
-        if args.dtype == "f32" and args.split_steps > 0:
+        # ---- the headline step on the PLAIN fp32 kernels (compute_dtype "f32": v_mfma_f32_16x16x4_f32 / Winograd / vector ALU, what rounds 1-4
+        #      reported as the headline): same step, same timing code, own process.  The headline itself runs the fp32 engine's default
+        #      arithmetic since round 5 (compute_dtype "f32s", csrc/split_kernels.h: fp32 tensors / accumulation / results, every product of the
+        #      >= 12-channel convolutions as six bf16 x bf16 partial products of the exact 3-way split; the same fp32 parity gates) ----
+        if args.dtype == "f32s" and args.plain_steps > 0:
             import subprocess
-            cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "f32s", "--steps", str(args.split_steps), "--warmup", "2",
+            cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "f32", "--steps", str(args.plain_steps), "--warmup", "2",
                    "--pages-per-step", str(args.pages_per_step), "--height", str(H), "--width", str(W), "--gnn", args.gnn,
                    "--no-cpu-baseline", "--no-secondary", "--event-steps", "2"]
             env = dict(os.environ, ASEP_BENCH_DEVICE=str(dev.index or 0))
@@ -404,16 +513,15 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
             if r.returncode == 0 and lines:
                 q = json.loads(lines[-1])
                 rr = q["roofline"] or {}
-                out["f32_split_full_step"] = {
+                out["plain_f32_full_step"] = {
                     "pages_per_s": q["value"], "ms_per_step": q["ms_per_step"], "steps": q["steps"], "timed_region_s": q["config"]["timed_region_s"],
-                    "dtype": "f32s", "workload": q["config"]["workload"],
-                    "agreement_with_plain_fp32": q["config"].get("agreement_with_plain_fp32"),
-                    "roofline": {k: rr.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "executed_frac", "bf16_mfma_frac",
-                                                        "avg_launch_us", "timing", "share_of_gpu_time", "whole_page_executed_frac")},
-                    "note": "the headline step with compute_dtype f32s: fp32 tensors / accumulation / results (fp32 parity gates, tests/test_split_gpu.py), "
-                            "products of the >= 12-channel convolutions as 6 bf16 MFMAs on the 3-way split of both factors; child process"}
+                    "dtype": "f32", "workload": q["config"]["workload"],
+                    "roofline": {k: rr.get(k) for k in ("bound", "kernel", "pipe", "achieved", "peak", "unit", "frac", "algorithmic_tflops",
+                                                        "algorithmic_over_peak", "avg_launch_us", "timing", "share_of_gpu_time",
+                                                        "whole_page_executed_frac")},
+                    "note": "the headline step with compute_dtype f32: every product on the fp32 matrix / vector pipes (the rounds 1-4 headline); child process"}
             else:
-                out["f32_split_full_step"] = {"error": f"f32s child exited with {r.returncode}"}
+                out["plain_f32_full_step"] = {"error": f"f32 child exited with {r.returncode}"}
         # ---- files in, files out ----
         if args.e2e_pages > 0:
             # in a child process of its own, so that the leg's worker processes do not inherit this process's module state
@@ -428,13 +536,30 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
     return out
 
 
-def build_roofline(args, dom, d_iso, d_situ, kernels, exec_flops_page, pages_per_s_gpu, peak_tf, pages_per_launch, n_prof, visual, B, H, W):
+def pipe_of(kernel, dtype):
+    """-> (pipe, peak in TFLOP/s of fp32-equivalent products) of a kernel of the ARU-Net engine.
+    fp32 MFMA and the fp32 vector ALU are ONE datapath on gfx950 (157.3 TFLOP/s either way, DESIGN lesson 15); a split-product kernel
+    executes SIX bf16 MFMA products per fp32 product, so its fp32-equivalent peak is the dense bf16 peak / 6; the bf16 path's
+    convolutions run at the dense bf16 peak."""
+    if kernel.startswith(("convs_kernel", "convs16_kernel")):
+        return "bf16 MFMA, 6 split products per fp32 product", PEAK_BF16_MFMA_TFLOPS / 6.0
+    if dtype == "bf16" and kernel.startswith(("convb_kernel", "deconvb_kernel", "res8f_kernel", "res8b_kernel", "res16f_kernel", "res32_tail_kernel",
+                                               "resb_tail_kernel")):
+        return "bf16 MFMA", PEAK_BF16_MFMA_TFLOPS
+    if kernel.startswith(("res8v_", "deconv8v_kernel", "att_headv_kernel", "conv_c1out_kernel", "conv_c1_kernel", "combine_kernel")):
+        return "fp32 vector ALU (v_pk_fma_f32: the fp32 MFMA's datapath and peak)", PEAK_F32_MFMA_TFLOPS
+    return "fp32 MFMA", PEAK_F32_MFMA_TFLOPS
+
+
+def build_roofline(args, dom, d_iso, d_situ, kernels, exec_flops_page, pages_per_s_gpu, peak_tf, pages_per_launch, n_prof, visual, B, H, W,
+                   pipe_seconds_page=None):
     """-> (roofline, roofline_detail).  `roofline` holds at most 20 keys, the HBM ones before the event-timing details (a record that
     keeps the first keys of a nested object keeps the informative ones); everything else goes to `roofline_detail`.
-      fp32: bound "mfma": achieved = ALGORITHMIC TFLOP/s of the dominant kernel -- the direct-convolution FLOPs 2 H W k^2 Cin Cout of
-            its layers / its average launch duration -- against 157.3 TFLOP/s.  A Winograd F(2x2,3x3) kernel
-            EXECUTES 1/2.25 of that on the matrix cores: `executed_frac` carries the executed rate (rounds 1-3 reported that one as
-            `frac`), and an isolated Winograd launch can exceed 1.0 algorithmically -- that is what the transform buys.
+      f32s / f32 (layout 5, round 5): bound "mfma": achieved = EXECUTED TFLOP/s of the dominant kernel (fp32-equivalent products it
+            really multiplies / its average launch duration: a Winograd F(2x2,3x3) kernel executes 1/2.25 of its direct-convolution
+            credit) against the peak of the pipe that kernel runs on (`pipe`, `peak`: 157.3 for the fp32 MFMA and the fp32 vector
+            ALU, 2500 / 6 for a split-product kernel) -- never above 1.  The direct-convolution rate (SURVEY.md section 8d's
+            2 H W k^2 Cin Cout / time) is carried beside it as `algorithmic_tflops` / `algorithmic_over_peak` (round 4 had it in `frac`).
       bf16: bound "hbm": achieved = ALGORITHMIC bytes per launch (inputs read once, outputs written once: the engine's shape
             arithmetic, asep_aru_profile_report "bytes") / average launch duration, against 8 TB/s.
     `traffic` = HBM bytes per launch by the PMC counters ((2 FETCH_SIZE + WRITE_SIZE) * 1024, separate rocprofv3 --pmc passes of the
@@ -443,47 +568,53 @@ def build_roofline(args, dom, d_iso, d_situ, kernels, exec_flops_page, pages_per
     hbm_bound = args.dtype == "bf16"
     calls = dom["calls"]
     algo_bytes = dom["bytes"] / calls
-    rate = (lambda d: d["algo_gbs"]) if hbm_bound else (lambda d: d["tflops"])
-    peak = PEAK_HBM_GBS if hbm_bound else peak_tf
+    pipe, pipe_peak = pipe_of(dom["kernel"], args.dtype)
+    rate = (lambda d: d["algo_gbs"]) if hbm_bound else (lambda d: d["executed_tflops"])
+    peak = PEAK_HBM_GBS if hbm_bound else pipe_peak
     total_ms = sum(k["total_ms"] for k in kernels)
+    if pipe_seconds_page is None:               # (callers without per-kernel pipes: everything priced against peak_tf)
+        pipe_seconds_page = exec_flops_page / (peak_tf * 1e12)
     r = {
         "bound": "hbm" if hbm_bound else "mfma", "kernel": dom["kernel"],
-        "achieved": round(rate(lead), 1 if hbm_bound else 3), "peak": peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+        "achieved": round(rate(lead), 1 if hbm_bound else 3), "peak": round(peak, 2), "unit": "GB/s" if hbm_bound else "TFLOP/s",
         "frac": round(rate(lead) / peak, 4),
         "traffic": None, "algorithmic_bytes": round(algo_bytes), "hbm_frac": None,
         "whole_page_traffic_gb": None, "whole_page_hbm_frac": None,
         "timing": "in situ" if d_situ else "isolated",
         "frac_in_situ": round(rate(d_situ) / peak, 4) if d_situ else None,
         "frac_isolated": round(rate(d_iso) / peak, 4) if d_iso else None,
-        ("mfma_frac" if hbm_bound else "executed_frac"): round(lead["executed_tflops"] / peak_tf, 4),
-        **({"bf16_mfma_frac": round(lead.get("bf16_tflops", 0.0) / PEAK_BF16_MFMA_TFLOPS, 4)} if args.dtype == "f32s" else {}),
+        **({"mfma_frac": round(lead["executed_tflops"] / peak_tf, 4)} if hbm_bound else
+           {"pipe": pipe[:118], "algorithmic_tflops": round(lead["tflops"], 3)}),
         "avg_launch_us": round(lead["avg_us"], 2),
-        "launches_per_step": calls / n_prof,
-        "whole_page_executed_frac": round(exec_flops_page * pages_per_s_gpu / 1e12 / peak_tf, 4),
+        **({"launches_per_step": calls / n_prof} if hbm_bound else {}),
+        # the whole page: the time its kernels' executed products would take with every pipe at its peak / the measured time per page
+        "whole_page_executed_frac": round(pipe_seconds_page * pages_per_s_gpu, 4),
         "share_of_gpu_time": round(dom["total_ms"] / total_ms, 4),
         "traffic_source": None,
     }
     detail = {
-        "layout": 4,
+        "layout": 5,
         "avg_launch_us_in_situ": round(d_situ["avg_us"], 2) if d_situ else None,
         "avg_launch_us_isolated": round(d_iso["avg_us"], 2) if d_iso else None,
         "launch_population": "all launches of this kernel in a step" + (": the page net's and the relation nets' backbone's" if visual else ""),
-        "pipe": "valu v_pk_fma_f32" if dom["kernel"].startswith("res8v") else "mfma",
+        "pipe": pipe, "pipe_peak_tflops": round(pipe_peak, 2),
         "flops_per_launch": dom["flops"] / calls, "executed_flops_per_launch": dom["executed_flops"] / calls,
         "algorithmic_tflops": round(lead["tflops"], 3), "executed_tflops": round(lead["executed_tflops"], 3),
+        # the direct-convolution credit of the kernel over its pipe's peak: above 1 is what a Winograd transform buys, not a roofline figure
+        "algorithmic_over_peak": round(lead["tflops"] / pipe_peak, 4),
         "algorithmic_gbs": round(lead["algo_gbs"], 1),
         "event_timed_steps": n_prof * ((d_iso is not None) + (d_situ is not None)),
+        "launches_per_step": calls / n_prof,
         # a launch of the page net carries at most 12 problems = 4 pages x 3 scales; the level-0 block kernels are launched
         # exactly once per such group, so they count the groups
         "pages_per_launch": pages_per_launch,
-        # the whole page against the MFMA peak: executed FLOPs of ALL ARU-Net kernels of a page (incl. the relation net's backbone)
+        # executed FLOPs (fp32-equivalent products) of ALL ARU-Net kernels of a page (incl. the relation net's backbone)
         "whole_page_executed_gflop": round(exec_flops_page / 1e9, 2),
         "whole_page_executed_tflops": round(exec_flops_page * pages_per_s_gpu / 1e12, 3),
+        "whole_page_pipe_seconds_at_peak": pipe_seconds_page,
         "whole_page_algorithmic_gb": round(sum(k["bytes"] for k in kernels) / (B * n_prof) / 1e9, 3),
         "mfma_peak": peak_tf, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_achievable_gbs": ACHIEVABLE_HBM_GBS,
     }
-    if args.dtype == "f32s":                    # (20 keys at most: the bf16 pipe's share takes the place of the launch count, which moves to the detail)
-        detail["launches_per_step"] = r.pop("launches_per_step")
     tp = os.path.join(ROOT, "profiles", "traffic_per_kernel.json" if args.dtype == "f32" else f"traffic_per_kernel_{args.dtype}.json")
     # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md, scripts/make_traffic_json.py).  The counters cannot
     # be read from inside this process: the figure comes from the committed summary of the SAME workload (same pages per step, same
@@ -516,6 +647,15 @@ def main():
     args = parse_args()
     if args.e2e_leg:                                         # child process of the secondary files-in / files-out figure
         print(json.dumps(e2e_files(args, args.e2e_device)))
+        return
+    if args.cpu_baseline_full:                               # the optional full-protocol CPU baseline: no GPU work in this mode
+        q = run_cpu_baseline_full(args)
+        with open(args.cpu_baseline_full, "w") as f:
+            json.dump(q, f, indent=1)
+        print(json.dumps(q))
+        return
+    if args.e2e_n_leg:                                       # child process of the N-owner files-in / files-out figure (--gpus N)
+        print(json.dumps(e2e_files_n(args, args.e2e_n_leg)))
         return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:     # no torchrun environment: start the ranks ourselves (a child process)
         raise SystemExit(spawn_ranks(args))
@@ -717,7 +857,8 @@ def main():
             k["executed_tflops"] = k["tflops"] / 2.25 if "wino" in k["kernel"] else k["tflops"]
             # split-product kernels (f32s): every fp32 product is SIX bf16 products on the bf16 pipe; executed_* stays the fp32-equivalent
             # figure (1 x), bf16_tflops is what the bf16 matrix pipeline executes
-            k["bf16_tflops"] = 6.0 * k["tflops"] if k["kernel"].startswith(("convs_kernel", "res8s_kernel")) else 0.0
+            k["bf16_tflops"] = 6.0 * k["tflops"] if k["kernel"].startswith(("convs_kernel", "convs16_kernel")) else 0.0
+            k["pipe"], k["pipe_peak"] = pipe_of(k["kernel"], args.dtype)
             # ALGORITHMIC bytes per launch (every input read once, every output written once: the engine's shape arithmetic) / time
             k["algo_gbs"] = k["bytes"] / (k["total_ms"] * 1e-3) / 1e9 if k["total_ms"] > 0 else 0.0
         return merged, n, main_calls
@@ -743,8 +884,9 @@ def main():
         groups = next((c for name, c in main_calls.items()
                        if name.startswith("res8") and ("_up_" in name or name.endswith("<true>"))), dom["calls"])
         exec_flops_page = sum(k["executed_flops"] for k in kernels) / (B * n_prof)
+        pipe_seconds_page = sum(k["executed_flops"] / (k["pipe_peak"] * 1e12) for k in kernels) / (B * n_prof)
         roofline, roofline_detail = build_roofline(args, dom, d_iso, d_situ, kernels, exec_flops_page, value / world, peak_tf,
-                                                   B * n_prof / groups, n_prof, visual, B, H, W)
+                                                   B * n_prof / groups, n_prof, visual, B, H, W, pipe_seconds_page)
         for k in kernels:
             o_s, o_i = (situ or {}).get(k["kernel"]), (iso or {}).get(k["kernel"])
             k["avg_us_in_situ"] = o_s["avg_us"] if o_s else None
@@ -753,6 +895,25 @@ def main():
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary and not args.no_gnn:
         secondary = secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, (gnn, vpages, vh, vw, VP) if visual else None)
+
+    # --gpus N: the files-in / files-out path with N GPU owners, as a child of rank 0 (the other ranks wait at the final barrier; their
+    # buffers stay allocated -- 288 GB per device leave room for both)
+    if rank == 0 and world > 1 and not args.no_secondary and args.e2e_n_pages_per_owner > 0:
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--e2e-n-leg", str(world), "--e2e-n-pages-per-owner", str(args.e2e_n_pages_per_owner),
+               "--height", str(H), "--width", str(W), "--dtype", args.dtype]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE",
+                                                                  "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+        if ranks_share_devices:                                  # (test boxes: the owners share the devices the ranks share)
+            env["ASEP_BENCH_OWNERS"] = ",".join(str(int(os.environ["ASEP_BENCH_DEVICE"]) if "ASEP_BENCH_DEVICE" in os.environ else r % ndev)
+                                                for r in range(world))
+        try:
+            r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True, timeout=1500)
+            lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+            leg = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": f"N-owner leg exited with {r.returncode}"}
+        except Exception as e:  # noqa: BLE001 -- a secondary figure must never take the headline line down
+            leg = {"error": repr(e)}
+        secondary = dict(secondary or {}, e2e_files_n=leg)
 
     # --dtype f32s: the step's own outputs against the plain fp32 kernels of the same library on the same pages (in the measured process, after
     # the timed region): what "fp32 with split products" means for THIS run's numbers, not only for the test suite's
@@ -784,7 +945,7 @@ def main():
             rel = "ARU-Net only (diagnostic)"
         elif visual:
             rel = ("+ per page the relation net BASELINE configs[3] names (mixed_gnn_vn7e2 = VISUAL net: RU backbone "
-                   f"({'bf16 convs' if args.dtype == 'bf16' else 'fp32'}) on the page at {vw}x{vh} + ROI max / compression to 3x16 visual features + graph with 55 node features, 200 nodes / 20k edges / "
+                   f"({'bf16 convs' if args.dtype == 'bf16' else 'fp32, like the page net'}) on the page at {vw}x{vh} + ROI max / compression to 3x16 visual features + graph with 55 node features, 200 nodes / 20k edges / "
                    "40k pairs), the step's relation nets as one grouped call on a second stream")
         else:
             rel = "+ geometric 7-feature relation graph per page (200 nodes / 20k edges / 40k pairs; diagnostic: not the net configs[3] names)"
@@ -794,12 +955,20 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {
                 # (short on purpose: records that cut strings at 120 characters keep it whole; the long form is workload_detail)
-                "workload": (({"f32": "configs[1] fp32", "bf16": "configs[4] bf16 convs", "f32s": "configs[1] fp32, split bf16 products"}[args.dtype]) + f": ARU-Net on {W}x{H} pages + "
+                "workload": (({"f32": "configs[1] fp32", "bf16": "configs[4] bf16 convs", "f32s": "configs[1] fp32 (split products)"}[args.dtype]) + f": ARU-Net on {W}x{H} pages + "
                              + ("no relation net" if args.no_gnn else
                                 ("configs[3] visual GNN (mixed_gnn_vn7e2)" if visual else "geometric GNN") + " per page")),
-                "workload_detail": (("BASELINE configs[1]: ARU-Net separator detection on 3000x4500 px pages, fp32, "
+                # what the dtype label stands for
+                "arithmetic": {"f32s": "fp32 tensors / fp32 accumulate / fp32 results; products of the >= 12-channel convolutions = 6 bf16 MFMAs of "
+                                       "the exact 3-way bfloat16 split of both factors (dropped terms <= 2^-23 |x w|); level 0, first / last layers, "
+                                       "deconvolutions: fp32 FMA / fp32 MFMA; held to the fp32 parity gates (tests/test_full_frame_gpu.py)",
+                               "f32": "fp32 tensors; every product on the fp32 MFMA (v_mfma_f32_16x16x4_f32, Winograd F(2x2,3x3) from 32 channels) or "
+                                      "the fp32 vector ALU (level 0)",
+                               "bf16": "bf16 tensors and MFMA operands (v_mfma_f32_16x16x32_bf16), fp32 accumulate; image, attention maps, logits and "
+                                       "probabilities fp32"}[args.dtype],
+                "workload_detail": (("BASELINE configs[1]: ARU-Net separator detection on 3000x4500 px pages, fp32 (plain fp32 MFMA / vector-ALU kernels), "
                                      if args.dtype == "f32" else
-                                     "BASELINE configs[1] with split products (fp32 tensors / accumulation / results; products of the wide convolutions "
+                                     "BASELINE configs[1], fp32 engine default (fp32 tensors / accumulation / results; products of the wide convolutions "
                                      "as 6 bf16 MFMAs on the 3-way bfloat16 split of both factors): ARU-Net separator detection on 3000x4500 px pages, "
                                      if args.dtype == "f32s" else
                                      "BASELINE configs[4] precision (bf16 activations / MFMA convs, fp32 accumulate): ARU-Net separator "
@@ -809,7 +978,7 @@ def main():
                 "relation_net": "none" if args.no_gnn else args.gnn,
                 "timed_region_s": round(dt, 3),
                 **({"agreement_with_plain_fp32": agreement} if agreement else {}),
-                "aru_cfg": "ARU featRoot=8 levels=5 res_depth=3 att_scales=3 n_classes=2",
+                "aru_cfg": "ARU featRoot=8 levels=5 res_depth=3 att_scales=3 n_classes=2 (secondary.upstream_layout_6x5: levels=6 att_scales=5)",
                 # engine / bench switches of the environment this line was measured under (none = the defaults the documents describe)
                 "engine_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("ASEP_") and k != "ASEP_BENCH_DEVICE"},
                 "gflop_per_page": round(flops_page / 1e9, 2),
@@ -820,7 +989,7 @@ def main():
                          "avg_us_in_situ": None if k.get("avg_us_in_situ") is None else round(k["avg_us_in_situ"], 2),
                          "avg_us_isolated": None if k.get("avg_us_isolated") is None else round(k["avg_us_isolated"], 2),
                          "flops": k["flops"], "tflops": round(k["tflops"], 2), "executed_tflops": round(k["executed_tflops"], 2),
-                         "executed_frac_of_peak": round(k["executed_tflops"] / peak_tf, 4),
+                         "pipe_peak_tflops": round(k["pipe_peak"], 2), "executed_frac_of_pipe_peak": round(k["executed_tflops"] / k["pipe_peak"], 4),
                          "bytes": k["bytes"], "algorithmic_gbs": round(k["algo_gbs"], 1),
                          # split-product kernels: six bf16 products per fp32 product, against the bf16 matrix peak
                          **({"bf16_mfma_frac": round(k["bf16_tflops"] / PEAK_BF16_MFMA_TFLOPS, 4)} if k.get("bf16_tflops") else {})}

@@ -24,11 +24,13 @@ class AruConfig:
     activation_name: str = "relu"  # ARU_v1.py:43,70-75: 'relu', 'elu' or 'leaky' (leak 0.1, layers.py:10-30)
     mvn: bool = False
     apply_softmax: bool = True    # export-time class softmax -> 'output:0'
-    # 'f32' (v_mfma_f32_16x16x4_f32, the reference's precision), 'bf16' (BASELINE config 5: bf16 tensors and MFMA operands,
-    # fp32 accumulation) or 'f32s' (fp32 tensors and accumulation; the products of the wide convolutions as six bf16 x bf16
-    # partial products of the three-way bfloat16 split of both factors -- fp32 results, held to the fp32 gates);
-    # an engine option, not a property of the weights
-    compute_dtype: str = "f32"
+    # The engine's arithmetic -- an engine option, not a property of the weights:
+    #   'f32s' (default since round 5): fp32 tensors, fp32 accumulation, fp32 results; the products of the convolutions with >= 12 input
+    #           channels as six bf16 x bf16 partial products of the exact three-way bfloat16 split of both factors (dropped terms
+    #           <= 2^-23 |x w|); level 0, first / last layers and deconvolutions on the fp32 FMA / MFMA.  Held to the fp32 parity gates.
+    #   'f32':  every product on the fp32 pipes (v_mfma_f32_16x16x4_f32, Winograd F(2x2,3x3) from 32 channels, v_pk_fma_f32 at level 0)
+    #   'bf16': BASELINE configs[4] "bf16 convs": bf16 tensors and MFMA operands, fp32 accumulation (its own, wider gates)
+    compute_dtype: str = "f32s"
 
     @property
     def use_attention(self) -> bool:

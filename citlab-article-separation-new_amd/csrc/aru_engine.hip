@@ -71,12 +71,10 @@ struct asep_aru {
     bf16_t* d_r8b_up_w1 = nullptr;   // conv1 of unet_up_0 [3 ky][2 halves][64][8]
     bf16_t* d_r8f_down_w1 = nullptr; // conv1 of unet_down_0 as ONE pair fragment [64][8] (k = window row / column, res8f_kernel)
     float* d_r8b_down_w1r = nullptr; // the same filter [9][8] as fp32 values rounded to bfloat16 (border tiles, res8b_tile)
-    bool use_r8f = true;             // ASEP_BF_R8F=0: res8b_kernel for every tile
     bool use_res32 = true;           // ASEP_BF_RES32=0: the 32-channel residual tails layer by layer (convb_kernel)
     bf16_t* d_r8b_up_w = nullptr;    // [3][3][64][8]
     float* d_r8b_up_b = nullptr;     // [3][8]
     float* d_r8b_up_b1 = nullptr;    // [8]
-    bool use_r8b = true;             // ASEP_BF_R8B=0: conv1 + resb_tail_kernel<8> instead
     DirectConv det_first, att_first;
     // fused level-0 residual blocks (feat_root == 8, res_depth == 3): pixel-pair MFMA fragments
     float* d_r8_down_wr = nullptr;   // [3][6][64][4]
@@ -92,7 +90,7 @@ struct asep_aru {
     bool r8_valu = true;             // fp32 only; ASEP_R8_VALU=0 runs the fp32 MFMA variants instead
     bool use_fused8 = true;          // ASEP_FUSED8=0 falls back to the layer-by-layer kernels
     bool fused8_wanted = true;       // what ASEP_FUSED8 said (use_fused8 is also switched off for the graph variants)
-    bool fused8_var = false;         // elu / leaky RESIDUAL graphs: the level-0 blocks on res8v_*_kernel<activation> (round 4; ASEP_FUSED8_VAR=0: layer by layer)
+    bool fused8_var = false;         // elu / leaky RESIDUAL graphs: the level-0 blocks on res8v_*_kernel<activation> (round 4)
     float* d_att_head = nullptr;     // A fragment of attPart/conv1 for att_head_kernel (12 output channels, 4x4 taps)
     float* d_logit_w = nullptr;
     float* d_logit_b = nullptr;
@@ -117,48 +115,25 @@ struct asep_aru {
     };
     std::vector<std::unique_ptr<Lane>> lanes;
     Lane* cur = nullptr;
-    int num_lanes = 1;                   // ASEP_LANES: page lanes of a batch call (r4j: 1 / 2 / 3 / 4 lanes = 119.3 / 121.2 / 120.3 / 115.8 pages/s fp32, 417.9 / 422.3 / 417.0 / 369.9 bf16; two lanes double every in-situ launch duration for that +1.5 %, so one is the default)
+    int num_lanes = 1;                   // ASEP_LANES: page lanes of a batch call (r4j: 1 / 2 / 3 / 4 lanes = 119.3 / 121.2 / 120.3 / 115.8 pages/s fp32, 417.9 / 422.3 / 417.0 / 369.9 bf16)
     std::map<std::string, Tensor> endpoints;
     hipStream_t stream = nullptr;
-    bool use_side_stream = true;         // ASEP_SIDE_STREAM=0 serialises everything on the caller's stream
     std::vector<void*> owned;
 
     // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
     struct ProfRec { int kid; double flops, bytes; hipEvent_t a, b; };
     int num_cus = 256;
-    bool big_tile = true;          // ASEP_BIGTILE=0 disables the 16x32 single-buffer variant
     BufferPool host_stage;         // device staging of the host-pointer entry point (grow-only)
     hipStream_t host_stream = nullptr;   // transfers + forward of the host-pointer entry point (created on first use)
-    bool use_xcd_sched = true;     // ASEP_XCD_SCHED=0: identity tile order in the persistent fused kernels
-    int xcd_oneshot = 2;           // ASEP_XCD_ONESHOT: block -> tile map of the one-shot kernels: 0 = identity, 1 = super-tile table,
-                                   // 2 = arithmetic bands (XcdMap, aru_kernels.h)
+    bool use_xcd_sched = true;     // ASEP_XCD_SCHED=0: identity tile order (persistent kernels: no tile table; one-shot kernels: no XCD bands)
     std::map<std::string, const int32_t*> sched_cache;
     bool bf16 = false;             // cfg.compute_dtype == 1: native bf16 data path (bf16_kernels.h): bf16 activations in HBM / LDS,
                                    // v_mfma_f32_16x16x32_bf16 with fp32 accumulation; fp32 image in, fp32 probabilities out
-    bool split = false;            // cfg.compute_dtype == 2 (or ASEP_F32_SPLIT=1 with compute_dtype 0): fp32 tensors and accumulation, every product of the
-                                   // convolutions with >= 12 input channels as six bf16 x bf16 partial products (split_kernels.h)
-    bf16_t* d_r8s_down_w = nullptr; // split-product level-0 blocks (res8s_kernel): tail fragments [conv][ky][part][lane][8]
-    bf16_t* d_r8s_up_w = nullptr;
-    bf16_t* d_r8s_up_w1 = nullptr;  // up block conv1: [half][ky][part][lane][8]
-    int split_l0 = 0;              // ASEP_SPLIT_L0=1: the level-0 blocks on res8s_kernel too (measured SLOWER than res8v_*: 1.97 + 1.07 against 1.43 + 1.02 ms
-                                   // per page; scripts/r4_r8s_dbg.sh: an 8 x 26-pixel block spends most of its time outside the MFMAs -- DESIGN_LESSONS 32)
-    int convs_dbg = 0, r8s_dbg = 0; // ASEP_CONVS_DBG / ASEP_R8S_DBG (read at load): timing experiments that drop one ingredient of a split-product kernel
-                                   // (scripts/r4_convs_dbg.sh, scripts/r4_r8s_dbg.sh; the results are wrong on purpose)
-    int split_alds_mode = 1;       // ASEP_SPLIT_ALDS: 0 = convs_kernel for every split-product layer, 1 = convs16_kernel (A fragments through LDS) for the
-                                   // >= 32-channel layers with one m-tile of output channels, 2 = for all >= 32-channel 3x3 layers        // ASEP_SPLIT_ALDS=0: the >= 32-channel split-product layers on convs_kernel (A fragments from L2 per wave) instead of
-                                   // convs16_kernel (through LDS)
-    bool split_th16 = true;        // ASEP_SPLIT_TH16=0: 8 x 32 instead of 16 x 32 blocks for the 16-channel split-product layers
-    bool wino_reg = true;          // ASEP_WINO_REG=0: LDS-image Winograd kernel also for the 32-channel level
-    bool use_winograd = true;      // ASEP_WINOGRAD=0 selects the direct implicit-GEMM kernels everywhere
-    bool big_tile2 = true;         // ASEP_BIGTILE2=0: 8 x 32 double-buffered blocks for 32 -> 16 convs without residual operand
+    bool split = false;            // cfg.compute_dtype == 2: fp32 tensors and accumulation, every product of the convolutions with >= 12 input channels
+                                   // as six bf16 x bf16 partial products (split_kernels.h).  Level 0 stays on the vector-ALU blocks (DESIGN_LESSONS 32)
     bool use_c12 = true;           // ASEP_C12=0: 12-channel inputs padded to a 16-channel group (read when the weights are packed)
     bool fuse_pool = true;         // ASEP_FUSE_POOL=0: separate maxpool2_kernel after every conv
     bool fuse_act = true;          // ASEP_FUSE_ACT=0: elu / leaky of the graph variants as a separate act_kernel pass behind every conv
-    bool wino16 = false;           // ASEP_WINO16=1: register-resident Winograd also at the 16-channel level (measured: 99 vs
-                                   // 103 TFLOP/s-equivalent for the direct kernels, parity-green; kept as an experiment switch)
-    bool bf_th8 = true;            // ASEP_BF_TH8=0: 16 x 32 instead of 8 x 32 pixel blocks for the 32-channel bf16 convs
-    bool bf_w8 = true;             // ASEP_BF_W8=0: four instead of eight waves per block in the >= 64-channel bf16 convs
-    int bf_mtb = 4;                // ASEP_BF_MTB=2: 32 instead of 64 output channels per block at >= 64 channels
     bool profiling = false;
     bool prof_detail = false;      // per-layer names (scope + spatial size) instead of per-kernel names
     bool prof_in_situ = false;     // keep the attention side stream while recording (times include what shares the chip)
@@ -371,13 +346,11 @@ int pack_direct(asep_aru* m, const std::map<std::string, HostTensor>& blob, cons
 
 struct TileDims { int tx, ty, begin; };
 
-// units -> tiles for the problems' tile grids `probs` (tile numbers begin + ty * tx + x, `total` tiles in all).  The table has
-// `total` entries, or with pad8 the next multiple of 8 (surplus units hold -1: launches whose grid.y counts channel blocks keep
-// "tile t runs on XCD t % 8" for every y that way).  One-shot kernels launch one block per unit (sched_tile, bf16_kernels.h).
-const int32_t* xcd_schedule(asep_aru* m, const std::vector<TileDims>& probs, int total, bool pad8, int* n_units = nullptr) {
-    const int units = pad8 ? (total + 7) / 8 * 8 : total;
-    if (n_units) *n_units = units;
-    std::string key = pad8 ? "p" : "u";
+// work unit -> tile table of the PERSISTENT kernels (res8v_*, res32_tail_kernel: resident blocks walk the units with a grid stride) for the
+// problems' tile grids `probs` (tile numbers begin + ty * tx + x, `total` tiles in all): the tiles of every problem in 4 x 8 super-tile
+// order, cut into eight chunks, unit k = the (k / 8)-th tile of chunk k mod 8 (block b runs on XCD b mod 8).  nullptr on failure: identity.
+const int32_t* xcd_schedule(asep_aru* m, const std::vector<TileDims>& probs, int total) {
+    std::string key = "u";
     for (const TileDims& q : probs) key += ":" + std::to_string(q.tx) + "x" + std::to_string(q.ty);
     auto it = m->sched_cache.find(key);
     if (it != m->sched_cache.end()) return it->second;
@@ -392,14 +365,14 @@ const int32_t* xcd_schedule(asep_aru* m, const std::vector<TileDims>& probs, int
                         if (ty < q.ty && tx < q.tx) order.push_back(q.begin + ty * q.tx + tx);
                     }
     if ((int)order.size() != total) return nullptr;
-    std::vector<int32_t> sched(units);
+    std::vector<int32_t> sched(total);
     int off[9];
     off[0] = 0;
     for (int x = 0; x < 8; ++x) off[x + 1] = off[x] + (total - x + 7) / 8;
-    for (int k = 0; k < units; ++k) sched[k] = k / 8 < off[k % 8 + 1] - off[k % 8] ? order[off[k % 8] + k / 8] : -1;
+    for (int k = 0; k < total; ++k) sched[k] = order[off[k % 8] + k / 8];
     int32_t* d = nullptr;
-    if (hipMalloc((void**)&d, (size_t)units * sizeof(int32_t)) != hipSuccess) return nullptr;
-    if (hipMemcpy(d, sched.data(), (size_t)units * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    if (hipMalloc((void**)&d, (size_t)total * sizeof(int32_t)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, sched.data(), (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
     m->owned.push_back(d);
     m->sched_cache[key] = d;
     return d;
@@ -410,23 +383,17 @@ const int32_t* tile_schedule(asep_aru* m, const Res8Args& a, int nblocks, int un
     if (!m->use_xcd_sched || nblocks % 8 != 0 || a.total_tiles < 2 * nblocks) return nullptr;
     std::vector<TileDims> probs;
     for (int i = 0; i < a.nprob; ++i) probs.push_back({a.p[i].tiles_x, (a.p[i].H + unit_h - 1) / unit_h, a.p[i].tile_begin});
-    return xcd_schedule(m, probs, a.total_tiles, false);
+    return xcd_schedule(m, probs, a.total_tiles);
 }
 
-// one-shot kernels (one block per tile): worth a map from a few waves of blocks per XCD on.  *n_units = blocks to launch along x.
-template <class Args>
-XcdMap oneshot_map(asep_aru* m, const Args& a, int th, int total, bool pad8, int* n_units, int (*height)(const Args&, int)) {
-    XcdMap xm{nullptr, 0, total};
+// one-shot kernels (one block per tile): XCD bands (XcdMap, aru_kernels.h) from a few waves of blocks per XCD on.  *n_units = blocks to launch
+// along x (the grid is padded to eight equal chunks; surplus blocks leave at once).
+XcdMap oneshot_map(asep_aru* m, int total, int* n_units) {
+    XcdMap xm{0, total};
     if (n_units) *n_units = total;
-    if (!m->use_xcd_sched || m->xcd_oneshot == 0 || total < 8 * 64) return xm;
-    if (m->xcd_oneshot == 2) {                               // arithmetic bands: the grid is always padded to eight equal chunks
-        xm.chunk = (total + 7) / 8;
-        if (n_units) *n_units = 8 * xm.chunk;
-        return xm;
-    }
-    std::vector<TileDims> probs;
-    for (int i = 0; i < a.nprob; ++i) probs.push_back({a.p[i].tiles_x, (height(a, i) + th - 1) / th, a.p[i].tile_begin});
-    xm.table = xcd_schedule(m, probs, total, pad8, n_units);
+    if (!m->use_xcd_sched || total < 8 * 64) return xm;
+    xm.chunk = (total + 7) / 8;
+    if (n_units) *n_units = 8 * xm.chunk;
     return xm;
 }
 
@@ -447,12 +414,6 @@ std::string dims_of(const TL& l) {
     for (size_t i = 0; i < l.size() && i < 3; ++i) d += (i ? "+" : "") + std::to_string(l[i].H) + "x" + std::to_string(l[i].W);
     if (l.size() > 3) d += "+..(" + std::to_string(l.size()) + ")";
     return d;
-}
-
-// XCD-aware table of a launch over ConvArgs problems whose tiles are th input rows high (tiles_x / tile_begin already set); grids whose
-// y dimension counts output-channel blocks are padded to a multiple of 8 tiles (units) so that a tile's XCD does not depend on y
-XcdMap conv_schedule(asep_aru* m, const ConvArgs& a, int th, int total, bool pad8, int* n_units) {
-    return oneshot_map<ConvArgs>(m, a, th, total, pad8, n_units, [](const ConvArgs& q, int i) { return q.p[i].H; });
 }
 
 // launches conv_mfma_kernel<...> and gives the profiler record that instantiation's exact name
@@ -516,12 +477,12 @@ TL run_conv_split(asep_aru* m, const PackedConv& pc, const std::string& scope, c
     }
     const bool c16 = pc.smode == 1;
     // (measured, 4 pages per launch: 32 -> 16 1230 -> 930 us on convs16_kernel, but 64 -> 64 378 -> 405 and 32 -> 32 431 -> 534: with more than one
-    //  m-tile the barrier per chunk and the 16-channel stages cost more than the shared fragments save; ASEP_SPLIT_ALDS=2 forces it everywhere.
+    //  m-tile the barrier per chunk and the 16-channel stages cost more than the shared fragments save: one-m-tile layers only.
     //  The same kernel with the fragments fetched per wave (ALDS = false; 16-channel stages + halo prefetch only) spills and was slower still:
     //  521 / 527 us for those two layers -- not instantiated)
-    const bool alds = m->split_alds_mode && pc.d_ws16 && (pc.mtiles == 1 || m->split_alds_mode == 2);
+    const bool alds = pc.d_ws16 && pc.mtiles == 1;
     const int mt = (pc.mtiles % 4 == 0 && !c16) ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1);
-    const int th = (c16 && pc.kh == 3 && mt == 1 && m->split_th16) ? 16 : 8;
+    const int th = (c16 && pc.kh == 3 && mt == 1) ? 16 : 8;
     for (size_t b0 = 0; b0 < in0.size(); b0 += MAXP) {
         const size_t b1 = std::min(in0.size(), b0 + MAXP);
         ConvArgs a{};
@@ -547,18 +508,15 @@ TL run_conv_split(asep_aru* m, const PackedConv& pc, const std::string& scope, c
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = alds ? pc.cin / 16 : pc.cin / 32;
         a.relu_in = relu_in; a.relu_out = relu_out; a.act = act;
         a.skip_full = fuse_pool && !keep_full;
-        a.dbg = m->convs_dbg;
         int units = tiles;
-        a.xm = conv_schedule(m, a, th, tiles, pc.mtiles / mt > 1, &units);
+        a.xm = oneshot_map(m, tiles, &units);
         dim3 grid(units, pc.mtiles / mt);
         TL sub(in0.begin() + b0, in0.begin() + b1);
         ProfScope ps(m, "convs_kernel", flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
         ps.bytes = bytes;
-        if (alds) {
-            ps.set_name("convs16_kernel" + targs({ti(mt), ti(8), ti(mt == 4 ? 2 : 3), tb(true)}));
-            if (mt == 4) hipLaunchKernelGGL((convs16_kernel<4, 8, 2, true>), grid, dim3(256), 0, m->stream, a);
-            else if (mt == 2) hipLaunchKernelGGL((convs16_kernel<2, 8, 3, true>), grid, dim3(256), 0, m->stream, a);
-            else hipLaunchKernelGGL((convs16_kernel<1, 8, 3, true>), grid, dim3(256), 0, m->stream, a);
+        if (alds) {                                          // (one m-tile: mt == 1)
+            ps.set_name("convs16_kernel<1,8,3,true>");
+            hipLaunchKernelGGL((convs16_kernel<1, 8, 3, true>), grid, dim3(256), 0, m->stream, a);
         } else if (pc.kh == 3) {
             if (c16 && th == 16) ASEP_CONVS_LAUNCH(3, 3, true, 1, 16, 2);
             else if (c16 && mt == 2) ASEP_CONVS_LAUNCH(3, 3, true, 2, 8, 3);
@@ -569,7 +527,7 @@ TL run_conv_split(asep_aru* m, const PackedConv& pc, const std::string& scope, c
         } else {
             if (c16 && mt == 2) ASEP_CONVS_LAUNCH(4, 4, true, 2, 8, 2);
             else if (c16) ASEP_CONVS_LAUNCH(4, 4, true, 1, 8, 2);
-            else { set_error("conv %s: 4x4 filters with %d input channels are not served by the split-product kernel", scope.c_str(), pc.cin); throw ArgError(); }
+            else { set_error("internal: conv %s (4x4, %d input channels) was packed for the split-product kernel", scope.c_str(), pc.cin); throw ArgError(); }
         }
     }
     if (pooled && !fuse_pool) *pooled = run_pool(m, out, POOL_MAX);
@@ -621,7 +579,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             a.wpk = (const f32x4*)pc.d_wv; a.bias = pc.d_b;
             a.relu_in = relu_in; a.relu_out = relu_out; a.act = act;
             int units = tiles;
-            a.xm = conv_schedule(m, a, C1O_T, tiles, false, &units);
+            a.xm = oneshot_map(m, tiles, &units);
             ProfScope ps(m, "conv_c1out_kernel", flops, scope);
             ps.bytes = bytes;
             hipLaunchKernelGGL(conv_c1out_kernel, dim3(units), dim3(256), 0, m->stream, a);
@@ -629,9 +587,9 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
         return out1;
     }
     if (m->split && pc.d_ws) return run_conv_split(m, pc, scope, in0, in1, relu_in, relu_out, res, pooled, keep_full, act);
-    const bool wino = pc.d_wino && m->use_winograd && (pc.mtiles > 1 || (m->wino16 && m->wino_reg));
+    const bool wino = pc.d_wino && pc.mtiles > 1;            // (Winograd pays from 32 output channels: DESIGN_LESSONS 4, 16)
     const int wino_mt = pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1);
-    const bool fuse_pool = pooled && m->fuse_pool && pc.cout % 4 == 0 && (!wino || (wino_mt <= 2 && m->wino_reg));
+    const bool fuse_pool = pooled && m->fuse_pool && pc.cout % 4 == 0 && (!wino || wino_mt <= 2);
     TL out;
     if (keep_full || !fuse_pool)
         for (const Tensor& t : in0) out.push_back(new_tensor(m, t.H, t.W, pc.cout));
@@ -642,7 +600,7 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
     // single channel group, one 16-channel output tile: 16 x 32 pixel blocks, single LDS buffer (more MFMA work per
     // block against the fixed load latency of these short blocks)
     // (two channel groups only for the residual-free 3x3 variant: four blocks per CU hide the refill of its single LDS buffer)
-    const bool big_tile = !wino && (!pc.c8 || (pc.kh == 3 && !res && m->big_tile2)) && (pc.groups == 1 || (pc.groups == 2 && !res && pc.kh == 3 && m->big_tile2)) && pc.mtiles == 1 && (m->big_tile || pc.c12);
+    const bool big_tile = !wino && (!pc.c8 || (pc.kh == 3 && !res)) && (pc.groups == 1 || (pc.groups == 2 && !res && pc.kh == 3)) && pc.mtiles == 1;
     const int th = big_tile ? 16 : CONV_TH;
     for (size_t b0 = 0; b0 < in0.size(); b0 += MAXP) {
         const size_t b1 = std::min(in0.size(), b0 + MAXP);
@@ -691,27 +649,24 @@ TL run_conv(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1,
             a.total_tiles = wt;
             const int ny = pc.mtiles / mt;
             int wunits = wt;
-            a.xm = conv_schedule(m, a, mt == 1 ? 2 * WINO_TH : WINO_TH, wt, ny > 1, &wunits);
+            a.xm = oneshot_map(m, wt, &wunits);
             dim3 grid(wunits, ny);
             std::string pname;
             if (mt == 1) pname = "conv_winor_kernel<false,1,true>";
-            else if (mt == 2 && m->wino_reg) pname = !res ? "conv_winor_kernel<false,2,false>" : "conv_winor_kernel<false,2,true>";
+            else if (mt == 2) pname = !res ? "conv_winor_kernel<false,2,false>" : "conv_winor_kernel<false,2,true>";
             else pname = "conv_wino_kernel" + targs({ti(mt), tb(false)});
             ProfScope ps(m, pname, flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
             ps.bytes = bytes;
             if (mt == 1) {
                 hipLaunchKernelGGL((conv_winor_kernel<false, 1, true>), grid, dim3(256), 0, m->stream, a);
-            } else if (mt == 2 && m->wino_reg) {
+            } else if (mt == 2) {
                 // register-resident variant: a wave per (tile row, m-tile); grid.y counts pairs of m-tiles
                 if (!res) hipLaunchKernelGGL((conv_winor_kernel<false, 2, false>), grid, dim3(256), 0, m->stream, a);
                 else hipLaunchKernelGGL((conv_winor_kernel<false, 2, true>), grid, dim3(256), 0, m->stream, a);
-            } else if (mt == 4) hipLaunchKernelGGL((conv_wino_kernel<4>), grid, dim3(256), 0, m->stream, a);
-            else if (mt == 2) hipLaunchKernelGGL((conv_wino_kernel<2>), grid, dim3(256), 0, m->stream, a);
-            else hipLaunchKernelGGL((conv_wino_kernel<1>), grid, dim3(256), 0, m->stream, a);
+            } else hipLaunchKernelGGL((conv_wino_kernel<4>), grid, dim3(256), 0, m->stream, a);
         } else {
-            const int mtk = pc.c8 ? 1 : (pc.mtiles % 4 == 0 ? 4 : (pc.mtiles % 2 == 0 ? 2 : 1));
             int units = tiles;
-            a.xm = conv_schedule(m, a, th, tiles, pc.mtiles / mtk > 1, &units);
+            a.xm = oneshot_map(m, tiles, &units);
             if (pc.kh == 3) launch_conv_k<3, 3>(m, pc, a, units, flops, bytes, scope, sub, big_tile);
             else launch_conv_k<4, 4>(m, pc, a, units, flops, bytes, scope, sub, big_tile);
         }
@@ -762,7 +717,7 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.groups;
         a.relu_in = 0; a.relu_out = relu_out; a.act = act;
         int units = tiles;
-        a.xm = conv_schedule(m, a, valu ? DCV_T : DC_TH, tiles, !valu && pc.mtiles / mt > 1, &units);
+        a.xm = oneshot_map(m, tiles, &units);
         dim3 grid(units, pc.mtiles / mt);
         const std::string dname = valu ? std::string("deconv8v_kernel") : "deconv_mfma_kernel" + targs({ti(mt), tb(false)});
         TL sub(in.begin() + b0, in.begin() + b1);
@@ -959,57 +914,10 @@ bool r8v_fits(const TL& l) {
     return true;
 }
 
-// res8s_kernel addresses its 8-channel tensors with 32-bit element offsets
-bool res8s_fits(const TL& l) {
-    for (const Tensor& t : l)
-        if ((size_t)t.H * t.W >= ((size_t)1 << 28)) return false;
-    return true;
-}
-
-// the level-0 blocks on res8s_kernel (split products): in0 = images (DOWN) / skip (UP), in1 = deconv output (UP)
-template <bool UP>
-void launch_res8s(asep_aru* m, const TL& in0, const TL* in1, const std::vector<const float*>& stats, const TL& out, const TL* pool) {
-    for (size_t b0 = 0; b0 < in0.size(); b0 += MAXP) {
-        const size_t b1 = std::min(in0.size(), b0 + MAXP);
-        Res8SArgs a{};
-        int tiles = 0;
-        double flops = 0, bytes = 0;
-        for (size_t i = b0; i < b1; ++i) {
-            bytes += tbytes(in0[i]) + (in1 ? tbytes((*in1)[i]) : 0.0) + tbytes(out[i]) + (pool ? tbytes((*pool)[i]) : 0.0);
-            Res8Prob& p = a.p[i - b0];
-            p.img = in0[i].p; p.in1 = in1 ? (*in1)[i].p : nullptr; p.stats = stats.empty() ? nullptr : stats[i];
-            p.out = out[i].p; p.pool = pool ? (*pool)[i].p : nullptr;
-            p.H = in0[i].H; p.W = in0[i].W;
-            p.tiles_x = cdiv(in0[i].W, R8S_TW);
-            p.tile_begin = tiles;
-            tiles += p.tiles_x * cdiv(in0[i].H, R8S_TH);
-            flops += 2.0 * in0[i].H * in0[i].W * (9.0 * (UP ? 16 : 1) * 8 + 3 * 9.0 * 64);
-        }
-        a.nprob = (int)(b1 - b0);
-        a.w1 = UP ? nullptr : m->det_first.d_w;
-        a.b1 = UP ? m->d_r8_up_b1 : m->det_first.d_b;
-        a.w1s = (const u32x4*)m->d_r8s_up_w1;
-        a.wrs = (const u32x4*)(UP ? m->d_r8s_up_w : m->d_r8s_down_w);
-        a.br = UP ? m->d_r8_up_br : m->d_r8_down_br;
-        a.dbg = m->r8s_dbg;
-        int units = tiles;
-        a.xm = oneshot_map<Res8SArgs>(m, a, R8S_TH, tiles, false, &units, [](const Res8SArgs& q, int i) { return q.p[i].H; });
-        TL sub(in0.begin() + b0, in0.begin() + b1);
-        ProfScope ps(m, UP ? "res8s_kernel<true>" : "res8s_kernel<false>", flops,
-                     std::string(UP ? "unet_up_0 (conv1[16->8]+3xconvR+add) " : "unet_down_0 (conv1+3xconvR+add+pool) ") + dims_of(sub));
-        ps.bytes = bytes;
-        hipLaunchKernelGGL(res8s_kernel<UP>, dim3(units), dim3(256), 0, m->stream, a);
-    }
-}
-
 void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats, bool want_pool, TL* d_out, TL* pool_out) {
     for (const Tensor& t : imgs) {
         d_out->push_back(new_tensor(m, t.H, t.W, 8));
         if (want_pool) pool_out->push_back(new_tensor(m, cdiv(t.H, 2), cdiv(t.W, 2), 8));
-    }
-    if (m->split && m->d_r8s_down_w && res8s_fits(imgs)) {
-        launch_res8s<false>(m, imgs, nullptr, stats, *d_out, want_pool ? pool_out : nullptr);
-        return;
     }
     for (size_t b0 = 0; b0 < imgs.size(); b0 += MAXP) {
         const size_t b1 = std::min(imgs.size(), b0 + MAXP);
@@ -1034,7 +942,7 @@ void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>&
         for (size_t i = b0; i < b1; ++i) valu = valu && (size_t)imgs[i].H * imgs[i].W < ((size_t)1 << 28);
         a.wr = (const f32x4*)(valu ? m->d_r8v_down_wr : m->d_r8_down_wr); a.br = m->d_r8_down_br;
         TL sub(imgs.begin() + b0, imgs.begin() + b1);
-        const std::string pname = valu ? std::string("res8v_down_kernel") : std::string("res8_down_kernel<false>");
+        const std::string pname = valu ? std::string("res8v_down_kernel<0>") : std::string("res8_down_kernel<false>");   // (rocprofv3's names: template arguments spelled out)
         ProfScope ps(m, pname, flops, "unet_down_0 (conv1+3xconvR+add+pool) " + dims_of(sub));
         ps.bytes = bytes;
         a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH * R8_NP);
@@ -1052,10 +960,6 @@ void run_res8_down(asep_aru* m, const TL& imgs, const std::vector<const float*>&
 TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
     TL out;
     for (const Tensor& t : skip) out.push_back(new_tensor(m, t.H, t.W, 8));
-    if (m->split && m->d_r8s_up_w1 && res8s_fits(skip)) {
-        launch_res8s<true>(m, skip, &v, {}, out, nullptr);
-        return out;
-    }
     for (size_t b0 = 0; b0 < skip.size(); b0 += MAXP) {
         const size_t b1 = std::min(skip.size(), b0 + MAXP);
         Res8Args a{};
@@ -1078,7 +982,7 @@ TL run_res8_up(asep_aru* m, const TL& skip, const TL& v) {
         a.w1 = valu ? m->d_r8v_up_w1 : m->d_r8_up_w1; a.b1 = m->d_r8_up_b1;
         a.wr = (const f32x4*)(valu ? m->d_r8v_up_wr : m->d_r8_up_wr); a.br = m->d_r8_up_br;
         TL sub(skip.begin() + b0, skip.begin() + b1);
-        const std::string pname = valu ? std::string("res8v_up_kernel") : std::string("res8_up_kernel<false>");
+        const std::string pname = valu ? std::string("res8v_up_kernel<0>") : std::string("res8_up_kernel<false>");
         ProfScope ps(m, pname, flops, "unet_up_0 (conv1[16->8]+3xconvR+add) " + dims_of(sub));
         ps.bytes = bytes;
         a.sched = tile_schedule(m, a, std::min(tiles, m->num_cus), R8_OH * R8_NP);
@@ -1183,6 +1087,7 @@ int pack_conv_split(asep_aru* m, PackedConv& pc, const HostTensor& w) {
     const int taps = pc.kh * pc.kw;
     if (!((pc.kh == 3 && pc.kw == 3) || (pc.kh == 4 && pc.kw == 4)) || pc.cout % 16 != 0) return ASEP_OK;
     pc.smode = (pc.cin == 16 || pc.cin == 12) ? 1 : (pc.cin % 32 == 0 ? 2 : -1);
+    if (pc.smode == 2 && pc.kh != 3) pc.smode = -1;          // 4x4 filters are instantiated for the 12- / 16-channel form only: such a layer keeps the fp32 MFMA kernel
     if (pc.smode < 0) return ASEP_OK;
     auto W = [&](int tap, int ci, int co) -> float {
         if (ci >= pc.cin || co >= pc.cout || tap >= taps) return 0.f;
@@ -1231,64 +1136,6 @@ int pack_conv_split(asep_aru* m, PackedConv& pc, const HostTensor& w) {
         rc = upload_bf(pk16, &pc.d_ws16);
         if (rc) return rc;
         m->owned.push_back(pc.d_ws16);
-    }
-    return ASEP_OK;
-}
-
-// pixel-pair A fragments (pack_pair_frags, cin 8 form) of input channels c_off .. c_off + 7 of a 3x3 filter with 8 output channels, as three
-// bf16 parts: [ky][part][lane][8]
-void pack_pair_frags_split(const HostTensor& w, int cin, int c_off, std::vector<bf16_t>& dst) {
-    auto bfval = [](bf16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
-    const size_t base = dst.size();
-    dst.resize(base + 3 * 3 * 64 * 8);
-    for (int ky = 0; ky < 3; ++ky)
-        for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < 8; ++j) {
-                const int mrow = lane & 15, kk = lane >> 4, e = mrow >> 3, co = mrow & 7;
-                const int kx = kk - e;
-                const float v = (kx >= 0 && kx <= 2) ? w.data[(((size_t)ky * 3 + kx) * cin + c_off + j) * 8 + co] : 0.f;
-                const bf16_t h = f2bf(v);
-                const float r = v - bfval(h);
-                const bf16_t mm = f2bf(r);
-                const bf16_t part[3] = {h, mm, f2bf(r - bfval(mm))};
-                for (int s2 = 0; s2 < 3; ++s2) dst[base + (((size_t)ky * 3 + s2) * 64 + lane) * 8 + j] = part[s2];
-            }
-}
-
-// filters of the split-product level-0 blocks (res8s_kernel); shapes other than the 8-channel residual blocks: nothing packed, res8v_* / layers
-int pack_res8s(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
-    auto tail = [&](const std::string& scope, bf16_t** d_w) -> int {
-        std::vector<bf16_t> pk;
-        for (int r = 0; r < 3; ++r) {
-            auto wi = blob.find(scope + "/convR_" + std::to_string(r) + "/weights");
-            if (wi == blob.end()) return 1;
-            const HostTensor& w = wi->second;
-            if (w.dims.size() != 4 || w.dims[0] != 3 || w.dims[1] != 3 || w.dims[2] != 8 || w.dims[3] != 8) return 1;
-            pack_pair_frags_split(w, 8, 0, pk);
-        }
-        int rc = upload_bf(pk, d_w);
-        if (rc) return rc;
-        m->owned.push_back(*d_w);
-        return ASEP_OK;
-    };
-    int rc = tail("aru_net/featMapG/unet_down_0", &m->d_r8s_down_w);
-    if (rc == 1) { m->d_r8s_down_w = nullptr; return ASEP_OK; }
-    if (rc) return rc;
-    if (m->cfg.scale_space_num > 1) {
-        const std::string u = "aru_net/featMapG/unet_up_0";
-        auto w1 = blob.find(u + "/conv1/weights");
-        if (w1 == blob.end()) return ASEP_OK;
-        const HostTensor& w = w1->second;
-        if (w.dims.size() != 4 || w.dims[0] != 3 || w.dims[1] != 3 || w.dims[2] != 16 || w.dims[3] != 8) return ASEP_OK;
-        rc = tail(u, &m->d_r8s_up_w);
-        if (rc == 1) { m->d_r8s_up_w = nullptr; return ASEP_OK; }
-        if (rc) return rc;
-        std::vector<bf16_t> pk;
-        pack_pair_frags_split(w, 16, 0, pk);
-        pack_pair_frags_split(w, 16, 8, pk);
-        rc = upload_bf(pk, &m->d_r8s_up_w1);
-        if (rc) return rc;
-        m->owned.push_back(m->d_r8s_up_w1);
     }
     return ASEP_OK;
 }
@@ -1436,11 +1283,11 @@ void run_res8b(asep_aru* m, bool up, const TL& a0, const TL* a1, const std::vect
         else { a.w1 = m->d_r8b_down_w1r ? m->d_r8b_down_w1r : m->det_first.d_w; a.b1 = m->det_first.d_b; a.wpk = (const u32x4*)m->d_r8b_down_w; a.bias = m->d_r8b_down_b; }
         TL sub(a0.begin() + b0, a0.begin() + b1);
         int units = tiles;
-        a.xm = oneshot_map<Res8BArgs>(m, a, 16, tiles, false, &units, [](const Res8BArgs& q, int i) { return q.p[i].H; });
+        a.xm = oneshot_map(m, tiles, &units);
         const std::string what = (up ? "unet_up_0 (conv1[16->8]+3xconvR+add) " : "unet_down_0 (conv1+3xconvR+add+pool) ") + dims_of(sub);
         bool small = true;                                   // res8f_kernel addresses its tensors with 32-bit byte offsets (16 bytes per pixel)
         for (size_t i = b0; i < b1; ++i) small = small && (size_t)a0[i].H * a0[i].W < ((size_t)1 << 28);
-        if (m->use_r8f && small && (up || m->d_r8f_down_w1)) {
+        if (small && (up || m->d_r8f_down_w1)) {
             // lean form for interior tiles (their 24 x 40 input window inside the image), general form for border tiles, one launch
             Res8BArgs f = a;
             if (!up) f.w1pk = (const u32x4*)m->d_r8f_down_w1;
@@ -1496,9 +1343,9 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
     }
     // output-channel tiles per block: 1 (cout 8 / 16), 2 (cout 32: one wave row, 16 x 32 pixels), 4 (cout >= 64: two wave
     // rows of two m-tiles, 8 x 32 pixels)
-    const int mtb = pc.mtiles >= 4 ? m->bf_mtb : pc.mtiles;
+    const int mtb = pc.mtiles >= 4 ? 4 : pc.mtiles;
     if (pc.mtiles % mtb != 0 || mtb == 3) { set_error("conv %s: %d output tiles not instantiated", scope.c_str(), pc.mtiles); throw ArgError(); }
-    const int th = (mtb == 4 || (mtb == 2 && pc.bmode == 2 && m->bf_th8)) ? 8 : 16;
+    const int th = (mtb == 4 || (mtb == 2 && pc.bmode == 2)) ? 8 : 16;
     TL out;
     if (keep_full || !pooled)
         for (const Tensor& t : in0) out.push_back(new_tensor_bf(m, t.H, t.W, pc.cout));
@@ -1533,7 +1380,7 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = cin / 32;
         a.relu_in = relu_in; a.relu_out = relu_out; a.skip_full = pooled && !keep_full; a.pool_f32 = pool_f32;
         int units = tiles;
-        a.xm = oneshot_map<ConvBArgs>(m, a, th, tiles, pc.mtiles / mtb > 1, &units, [](const ConvBArgs& q, int i) { return q.p[i].H; });
+        a.xm = oneshot_map(m, tiles, &units);
         dim3 grid(units, pc.mtiles / mtb);
         TL sub(in0.begin() + b0, in0.begin() + b1);
         ProfScope ps(m, "convb_kernel", flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
@@ -1552,7 +1399,7 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
             case 314: ASEP_CONVB_LAUNCH(3, 3, 1, 2, 2, 8, 3); break;
             case 321: ASEP_CONVB_LAUNCH(3, 3, 2, 1, 1, 16, 3); break;
             case 322: ASEP_CONVB_LAUNCH(3, 3, 2, 2, 1, 16, 3); break;
-            case 324: if (m->bf_w8) ASEP_CONVB_LAUNCH8(3, 3, 2, 2, 2, 8, 2, false); else ASEP_CONVB_LAUNCH(3, 3, 2, 2, 2, 8, 3); break;
+            case 324: ASEP_CONVB_LAUNCH8(3, 3, 2, 2, 2, 8, 2, false); break;   // >= 64 channels: eight waves over the same LDS tile
             case 411: ASEP_CONVB_LAUNCH(4, 4, 1, 1, 1, 16, 3); break;
             case 412: ASEP_CONVB_LAUNCH(4, 4, 1, 2, 1, 16, 3); break;
             case 414: ASEP_CONVB_LAUNCH(4, 4, 1, 2, 2, 8, 3); break;
@@ -1598,11 +1445,13 @@ TL run_resb_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled)
         if (rb.C == 32) {                                    // persistent kernel: table (its units are walked with a grid stride)
             std::vector<TileDims> probs;
             for (int i = 0; i < a.nprob; ++i) probs.push_back({a.p[i].tiles_x, cdiv(a.p[i].H, RB_TH), a.p[i].tile_begin});
-            a.sched = (m->use_xcd_sched && m->xcd_oneshot && tiles >= 8 * 64) ? xcd_schedule(m, probs, tiles, false) : nullptr;
+            a.sched = (m->use_xcd_sched && tiles >= 8 * 64) ? xcd_schedule(m, probs, tiles) : nullptr;
         } else {
-            a.xm = oneshot_map<ResBArgs>(m, a, RB_TH, tiles, false, &units, [](const ResBArgs& q, int i) { return q.p[i].H; });
+            a.xm = oneshot_map(m, tiles, &units);
         }
         TL sub(t.begin() + b0, t.begin() + b1);
+        bool small16 = true;                                 // res16f_kernel addresses its tensors with 32-bit byte offsets (32 bytes per pixel)
+        for (const Tensor& x : sub) small16 = small16 && (size_t)x.H * x.W < ((size_t)1 << 27);
         const std::string what = scope + " (3xconvR+add" + (pooled ? "+pool) " : ") ") + dims_of(sub);
         if (rb.C == 32) {
             static bool attr = false;
@@ -1614,7 +1463,7 @@ TL run_resb_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled)
             ps.bytes = bytes;
             a.ntiles = tiles;
             hipLaunchKernelGGL(res32_tail_kernel, dim3(std::min(tiles, m->num_cus)), dim3(512), Res32Layout::BYTES, m->stream, a);
-        } else if (rb.C == 16 && m->use_r8f) {                      // lean form for interior tiles, general form for border tiles, one launch
+        } else if (rb.C == 16 && small16) {            // lean form for interior tiles, general form for border tiles, one launch
             ProfScope ps(m, "res16f_kernel", flops, what);
             ps.bytes = bytes;
             hipLaunchKernelGGL(res16f_kernel, dim3(units), dim3(256), 0, m->stream, a);
@@ -1667,7 +1516,7 @@ TL run_deconvb(asep_aru* m, const std::string& scope, const TL& in, const TL& li
         a.wpk = (const u32x4*)pc.d_wb; a.bias = pc.d_b;
         a.cin = pc.cin; a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.cin / 32; a.relu_out = relu_out;
         int units = tiles;
-        a.xm = oneshot_map<DeconvBArgs>(m, a, dth, tiles, pc.mtiles / mt > 1, &units, [](const DeconvBArgs& q, int i) { return q.p[i].Hi; });
+        a.xm = oneshot_map(m, tiles, &units);
         dim3 grid(units, pc.mtiles / mt);
         TL sub(in.begin() + b0, in.begin() + b1);
         ProfScope ps(m, "deconvb_kernel" + targs({ti(pc.bmode), ti(mt), ti(dth)}), flops,
@@ -1811,7 +1660,7 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
     };
     for (int l = 0; l < n; ++l) {
         const std::string scope = "aru_net/featMapG/unet_down_" + std::to_string(l);
-        if (m->bf16 && l == 0 && m->use_r8b && m->d_r8b_down_w && m->det_first.k == 3 && m->det_first.cout == 8) {
+        if (m->bf16 && l == 0 && m->d_r8b_down_w && m->det_first.k == 3 && m->det_first.cout == 8) {
             TL d, pooled;                                    // the whole block in one kernel: image -> d0 (+ pool)
             run_res8b(m, false, imgs, nullptr, stats, n > 1, &d, &pooled);
             skips.push_back(d);
@@ -1855,7 +1704,7 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
         const TL& skip = skips[l];
         TL v = m->bf16 ? run_deconvb(m, scope + "/deconv", u, skip, true) : deconv_act(m, scope + "/deconv", u, skip);
         publish(v, "_unet_up_" + std::to_string(l) + "_deconv");
-        if (m->bf16 && l == 0 && m->use_r8b && m->d_r8b_up_w1) {
+        if (m->bf16 && l == 0 && m->d_r8b_up_w1) {
             TL d, none;                                      // conv1 over [skip, deconv] + the tail in one kernel
             run_res8b(m, true, skip, &v, {}, false, &d, &none);
             u = d;
@@ -1986,7 +1835,7 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
             // the attention CNN is a chain of small launches that cannot fill the chip: run it on a side stream next
             // to the feature branch (fork after the pyramid, join before the combine).  Per-launch profiling keeps
             // everything on one stream so that kernel times are not inflated by the overlap.
-            if (m->use_side_stream && (!m->profiling || m->prof_in_situ) && L.side) {
+            if ((!m->profiling || m->prof_in_situ) && L.side) {
                 ASEP_HIP_CHECK(hipEventRecord(L.ev_fork, stream));
                 ASEP_HIP_CHECK(hipStreamWaitEvent(L.side, L.ev_fork, 0));
                 m->stream = L.side;
@@ -2036,12 +1885,8 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
             ca.softmax = cfg.apply_softmax;
             ca.tiles_x = cdiv(W, COMBINE_TW);
             const int ctiles = ca.tiles_x * cdiv(H, 16);
-            ca.xm = XcdMap{nullptr, 0, ctiles};
             int cunits = ctiles;
-            if (m->use_xcd_sched && ctiles >= 8 * 64) {
-                if (m->xcd_oneshot == 2) { ca.xm.chunk = (ctiles + 7) / 8; cunits = 8 * ca.xm.chunk; }
-                else if (m->xcd_oneshot == 1) ca.xm.table = xcd_schedule(m, {{ca.tiles_x, cdiv(H, 16), 0}}, ctiles, false);
-            }
+            ca.xm = oneshot_map(m, ctiles, &cunits);
             dim3 grid(cunits);
             // number of scales as a template constant (1 = no attention, 3 = the default ARU-Net) with 32-bit offsets, for tensors
             // below 4 GB; anything else takes the run-time form
@@ -2181,34 +2026,18 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     m->cfg = *cfg;
     m->bf16 = cfg->compute_dtype == 1;
     m->split = cfg->compute_dtype == 2;
-    if (const char* e = getenv("ASEP_F32_SPLIT")) m->split = !m->bf16 && atoi(e) != 0;
-    if (const char* e = getenv("ASEP_SPLIT_TH16")) m->split_th16 = atoi(e) != 0;
-    if (const char* e = getenv("ASEP_SPLIT_L0")) m->split_l0 = atoi(e);
-    if (const char* e = getenv("ASEP_SPLIT_ALDS")) m->split_alds_mode = atoi(e);
-    if (const char* e = getenv("ASEP_CONVS_DBG")) m->convs_dbg = atoi(e);
-    if (const char* e = getenv("ASEP_R8S_DBG")) m->r8s_dbg = atoi(e);
-    if (const char* e = getenv("ASEP_WINOGRAD")) m->use_winograd = atoi(e) != 0;
-    if (const char* e = getenv("ASEP_WINO_REG")) m->wino_reg = atoi(e) != 0;
-    if (const char* e = getenv("ASEP_WINO16")) m->wino16 = atoi(e) != 0;
+    // Engine switches (environment, read at load): each selects an INDEPENDENT implementation of the same arithmetic that the test suite
+    // compares with the default one (fused against unfused, vector-ALU against MFMA form), or a schedule knob of the bench; the switches of
+    // experiments that lost left the tree in round 5 (table: DESIGN.md section 4.5).
     if (const char* e = getenv("ASEP_FUSE_POOL")) m->fuse_pool = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSE_ACT")) m->fuse_act = atoi(e) != 0;
     if (const char* e = getenv("ASEP_C12")) m->use_c12 = atoi(e) != 0;
-    if (const char* e = getenv("ASEP_BIGTILE2")) m->big_tile2 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_FUSED8")) m->use_fused8 = atoi(e) != 0;
     m->fused8_wanted = m->use_fused8;
     if (variant) m->use_fused8 = false;                      // the fused level-0 blocks / attention head are ReLU residual kernels
     if (const char* e = getenv("ASEP_R8_VALU")) m->r8_valu = atoi(e) != 0;
     m->fused8_var = variant && !cfg->plain_u && cfg->activation != 0 && m->fused8_wanted && m->r8_valu && m->fuse_act && !m->bf16;
-    if (const char* e = getenv("ASEP_FUSED8_VAR")) m->fused8_var = m->fused8_var && atoi(e) != 0;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;
-    if (const char* e = getenv("ASEP_XCD_ONESHOT")) m->xcd_oneshot = std::max(0, std::min(2, atoi(e)));
-    if (const char* e = getenv("ASEP_BIGTILE")) m->big_tile = atoi(e) != 0;
-    if (const char* e = getenv("ASEP_SIDE_STREAM")) m->use_side_stream = atoi(e) != 0;
-    if (const char* e = getenv("ASEP_BF_TH8")) m->bf_th8 = atoi(e) != 0;
-    if (const char* e = getenv("ASEP_BF_MTB")) m->bf_mtb = atoi(e) == 2 ? 2 : 4;
-    if (const char* e = getenv("ASEP_BF_W8")) m->bf_w8 = atoi(e) != 0;
-    if (const char* e = getenv("ASEP_BF_R8B")) m->use_r8b = atoi(e) != 0;
-    if (const char* e = getenv("ASEP_BF_R8F")) m->use_r8f = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_RES32")) m->use_res32 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_LANES")) m->num_lanes = std::max(1, std::min(4, atoi(e)));
     for (int l = 0; l < m->num_lanes; ++l) {
@@ -2259,7 +2088,6 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     }
     if (!rc && (!variant || m->fused8_var) && !m->bf16 && cfg->feat_root == 8 && cfg->res_depth == 3 && m->det_first.k == 3) rc = pack_res8(m.get(), blob);
     if (!rc && m->bf16 && cfg->res_depth == 3 && cfg->feat_root == 8) rc = pack_res8b(m.get(), blob);
-    if (!rc && m->split && m->split_l0 && !variant && cfg->res_depth == 3 && cfg->feat_root == 8) rc = pack_res8s(m.get(), blob);
     if (!rc && m->bf16 && cfg->res_depth == 3)
         for (int l = 0; l < n && !rc; ++l) {
             const int f = cfg->feat_root << l;

@@ -64,11 +64,12 @@ __device__ __forceinline__ f32x4 mfma_bf16(s16x4 a, s16x4 b, f32x4 c) {
 //          No memory access; left / right halos are shared inside the band, the row above is one band row back in the same L2.
 // Neither: identity.  A negative result = padding block.
 struct XcdMap {
-    const int32_t* table;
-    int chunk, total;
+    int chunk, total;      // chunk = ceil(total / 8), or 0: identity order
 };
+// XCD x (workgroup b runs on XCD b mod 8) takes the x-th eighth of the row-major tile list: left / right halos are shared inside the band,
+// the rows above are one band row back in the same 4 MB L2.  Pure arithmetic: a table lookup at the head of a 5-10 us block cost 1.4 % of
+// the step (DESIGN_LESSONS.md 27).  The grid is padded to 8 chunk blocks; surplus blocks leave at once.
 __device__ __forceinline__ int sched_tile(const XcdMap& x) {
-    if (x.table) return x.table[blockIdx.x];
     if (x.chunk) {
         const int t = (int)(blockIdx.x & 7) * x.chunk + (int)(blockIdx.x >> 3);
         return t < x.total ? t : -1;
@@ -79,6 +80,17 @@ __device__ __forceinline__ int sched_tile(const XcdMap& x) {
 // ------------------------------------------------------------------------------------------------
 // One launch covers the same layer of several independent "problems" (pages x scale-space levels share
 // the layer's weights): blockIdx.x walks the concatenated tile lists, blockIdx.y the output-channel blocks.
+// Channel concat [in0, in1]: the source of channel c as ONE base pointer + an offset selected per lane.  Written as a select between
+// the two pointers (`from0 ? P.in0 + c : P.in1 + (c - c0)`) the compiler selects between their ADDRESSES in the argument block and loads
+// the chosen pointer through a vector address -- a dependent memory round trip in front of every halo load of every stage (found in the
+// ISA of convb_kernel / res8f_kernel, round 5).  The distance of the two tensors is a scalar; the select is on integers, the base keeps
+// its address space (global_load, not flat_load).
+template <class T>
+__device__ __forceinline__ const T* concat_src(const T* in0, const T* in1, int c, int c0) {
+    const long d10 = (long)(reinterpret_cast<uintptr_t>(in1) - reinterpret_cast<uintptr_t>(in0));      // bytes (unused when there is no in1)
+    const long off = c < c0 ? (long)c * (long)sizeof(T) : d10 + (long)(c - c0) * (long)sizeof(T);
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(in0) + off);
+}
 constexpr int MAXP = 12;
 // Problem of work unit t in a launch whose problems' unit ranges start at a.p[i].tile_begin (increasing with i): the index is a
 // COUNT over all starts, so the scalar loads are requested together and answered in one round trip.  (The search loop this replaces
@@ -89,6 +101,15 @@ __device__ __forceinline__ int prob_of_tile(const Args& a, int t) {
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < MAXP; ++i) pi += (int)((unsigned)((i - a.nprob) & ~(t - a.p[i].tile_begin)) >> 31);   // i < nprob && t >= start, on the sign bits (scalar ALU)
+    return pi;
+}
+// The search form, for the PERSISTENT level-0 kernels (res8v_* / res8_*): they look a problem up once per work unit inside their tile loop,
+// most units lie in the first problems, and their filters live in the 16 KB scalar data cache (DESIGN_LESSONS 16) -- the count form's eleven
+// argument-block lines per lookup evicted them (res8v_up_kernel +5.4 %, round 5); here the walk stops at the first start beyond t.
+template <class Args>
+__device__ __forceinline__ int prob_of_tile_search(const Args& a, int t) {
+    int pi = 0;
+    while (pi + 1 < a.nprob && t >= a.p[pi + 1].tile_begin) ++pi;
     return pi;
 }
 template <class Args>
@@ -126,8 +147,6 @@ struct ConvArgs {
                            // The ReLU graphs' fast epilogues are not touched: a launch with act != 0 takes the general ones.
     int skip_full;         // with p[].pool: do not store the unpooled output (nobody reads it)
     XcdMap xm;             // XCD-aware block -> tile map (sched_tile)
-    int dbg;               // timing experiments of convs_kernel (ASEP_CONVS_DBG; results are wrong): 1 every chunk reads chunk 0's A fragments,
-                           // 2 no split while staging, 4 no MFMAs
 };
 
 constexpr int CONV_TH = 8;
@@ -590,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
     auto halo_load = [&](int g) {
         const int c = g * 16 + sub0 * 4;
         const bool from0 = c < a.c0;
-        const float* __restrict__ src = from0 ? P.in0 + c : P.in1 + (c - a.c0);
+        const float* __restrict__ src = concat_src(P.in0, P.in1, c, a.c0);
         const int cs = from0 ? a.c0 : a.c1;
         int hy = hy0, hx = hx0;
         stmask = 0;
@@ -841,7 +860,7 @@ __global__ __launch_bounds__(256, RESP ? 2 : 3) void conv_winor_kernel(const Con
     auto halo_load = [&](int g) {
         const int c = g * 16 + sub0 * 4;
         const bool from0 = c < a.c0;
-        const float* __restrict__ src = from0 ? P.in0 + c : P.in1 + (c - a.c0);
+        const float* __restrict__ src = concat_src(P.in0, P.in1, c, a.c0);
         const int cs = from0 ? a.c0 : a.c1;
         int hy = hy0, hx = hx0;
         stmask = 0;

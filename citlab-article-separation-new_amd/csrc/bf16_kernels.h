@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
         {
             const int c = g * 32 + sub0;
             const bool from0 = c < a.c0;
-            const bf16_t* __restrict__ src = from0 ? P.in0 + c : P.in1 + (c - a.c0);
+            const bf16_t* __restrict__ src = concat_src(P.in0, P.in1, c, a.c0);
             const int cs = from0 ? a.c0 : a.c1;
 #pragma unroll
             for (int i = 0; i < NLOAD; ++i) {
@@ -767,40 +767,45 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
         return;
     }
 
-    // ---- relu(t) halo tile -> r0 ----
-    {
-        constexpr int NU = H0 * W0 * 2, NLOAD = (NU + 255) / 256;
-        u32x4 st[NLOAD];
+    // ---- requests, cheapest-to-wait-for first (as in res8f_kernel): biases and convR_0's fragments (L2 hits, needed right behind the first
+    //      barrier), the residual operand of stage 3, then the 22 x 38 halo tile.  Threads 0 .. 227 own the 16-byte unit t % 76 of the tile
+    //      rows t / 76 + 3 k (a row = 38 pixels x 32 bytes, contiguous in HBM): one division per thread, a uniform base pointer + 32-bit byte
+    //      offsets (run_resb_tail keeps tensors of 2^27 pixels and more on the general kernel), LDS addresses = base + immediates ----
+    f32x4 biasw[3];
 #pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-            const int u = min(tid + i * 256, NU - 1);
-            const int pix = u >> 1, sub = u & 1;
-            const int ly = pix / W0, lx = pix - ly * W0;
-            st[i] = *reinterpret_cast<const u32x4*>(P.t + ((size_t)(y0 - 3 + ly) * W + x0 - 3 + lx) * C + sub * 8);
-        }
+    for (int t = 0; t < 3; ++t) biasw[t] = *reinterpret_cast<const f32x4*>(a.bias + t * C + kk * 4);
+    const u32x4* __restrict__ wl = a.wpk + lane;
+    u32x4 af[CPC], ag[CPC];                                    // the fragments of the current / the next conv (requested a stage ahead)
 #pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-            const int u = tid + i * 256;
-            if (u < NU) *reinterpret_cast<u32x4*>(r0 + u * 16) = relu_bf16x8(st[i]);
-        }
-    }
+    for (int t = 0; t < CPC; ++t) af[t] = wl[t * 64];
+    const unsigned char* __restrict__ const tb8 = reinterpret_cast<const unsigned char*>(P.t);
+    const unsigned wu = (unsigned)W;
     // residual operand of stage 3 (pre-ReLU t of the lane's 8 output pixels): requested now, used at the very end
-    const bf16_t* __restrict__ tres = P.t + ((size_t)(y0 + 2 * wave) * W + x0 + j) * C + kk * 4;
+    const unsigned roff = (((unsigned)(y0 + 2 * wave) * wu + (unsigned)(x0 + j)) * C + kk * 4) * 2u, rrow = wu * C * 2u;
     u32x2 resv[2][2][2];                                       // [row pair i][row r][column block]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) resv[i][r][cb] = *reinterpret_cast<const u32x2*>(tres + ((size_t)(8 * i + r) * W + cb * 16) * C);
-    // biases of the three stages: requested now -- read where a stage begins (behind its barrier) each is an exposed L2 round trip
-    f32x4 biasw[3];
+            for (int cb = 0; cb < 2; ++cb) resv[i][r][cb] = *reinterpret_cast<const u32x2*>(tb8 + (roff + (unsigned)(8 * i + r) * rrow + cb * 16 * C * 2));
+    {
+        constexpr int UPR = W0 * 2, LR = 3, NK = (H0 + LR - 1) / LR;      // 76 units per row, 3 rows per pass, 8 passes (the last one: row 21 only)
+        const int lr = tid / UPR, lc = tid - lr * UPR;
+        const bool ldr = tid < LR * UPR;
+        const unsigned goff = ((unsigned)(y0 - 3 + (ldr ? lr : 0)) * wu + (unsigned)(x0 - 3)) * (C * 2u) + (unsigned)lc * 16u, gstep = LR * wu * (C * 2u);
+        // (pass NK - 1 covers rows 21 .. 23 of which only row 21 exists: its rows 22, 23 re-read row 21 -- inside the image -- and store nothing)
+        const unsigned glast = ((unsigned)(y0 - 3 + H0 - 1) * wu + (unsigned)(x0 - 3)) * (C * 2u) + (unsigned)lc * 16u;
+        u32x4 st[NK];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) biasw[t] = *reinterpret_cast<const f32x4*>(a.bias + t * C + kk * 4);
-    const u32x4* __restrict__ wl = a.wpk + lane;
-    u32x4 af[CPC];
+        for (int k = 0; k < NK; ++k) st[k] = *reinterpret_cast<const u32x4*>(tb8 + ((k + 1) * LR <= H0 ? goff + k * gstep : glast));
+        unsigned char* const dst = r0 + (lr * UPR + lc) * 16;
+        if (ldr) {
 #pragma unroll
-    for (int t = 0; t < CPC; ++t) af[t] = wl[t * 64];
+            for (int k = 0; k < NK; ++k)
+                if ((k + 1) * LR <= H0 || lr + k * LR < H0) *reinterpret_cast<u32x4*>(dst + k * LR * UPR * 16) = relu_bf16x8(st[k]);
+        }
+    }
     // the lane's tap of K chunk t (two taps per chunk: lane groups 0, 1 the first, 2, 3 the second) as a pixel offset in a region
     // that is WIN pixels wide
     auto tap_px = [&](int t, int WIN) {
@@ -811,7 +816,7 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
     };
     auto relu_pk = [](u32x2 p) { return u32x2{relu_bf16x2(p.x), relu_bf16x2(p.y)}; };
     // two tiles at once: all fragment reads, then the MFMAs of the two accumulator chains interleaved
-    auto conv16x2 = [&](const unsigned char* src, const int* bA, int offA, const int* bB, int offB, f32x4 c0, f32x4& ra, f32x4& rb) {
+    auto conv16x2 = [&](const u32x4 (&af)[CPC], const unsigned char* src, const int* bA, int offA, const int* bB, int offB, f32x4 c0, f32x4& ra, f32x4& rb) {
         u32x4 fa[CPC], fb[CPC];
 #pragma unroll
         for (int t = 0; t < CPC; ++t) { fa[t] = *reinterpret_cast<const u32x4*>(src + bA[t] + offA); fb[t] = *reinterpret_cast<const u32x4*>(src + bB[t] + offB); }
@@ -820,6 +825,10 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
         for (int t = 0; t < CPC; ++t) { ra = mfma_bf16_k32(af[t], fa[t], ra); rb = mfma_bf16_k32(af[t], fb[t], rb); }
     };
     __syncthreads();
+    // convR_1's fragments: requested a whole stage before their first use (requested behind a stage's MFMAs, the next stage's first MFMA
+    // waited for an L2 round trip)
+#pragma unroll
+    for (int t = 0; t < CPC; ++t) ag[t] = wl[(CPC + t) * 64];
 
     // ---- stage 1: r0 (22 x 38) -> r1 (20 x 36).  Rows wave + 4 i, two main tiles each; 5 remainder tiles of 4 rows x 4 columns ----
     {
@@ -835,18 +844,18 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
         f32x4 va, vb;
 #pragma unroll
         for (int i = 0; i < H1 / 4; ++i) {
-            conv16x2(r0, bm, i * 4 * W0 * PXB, bm, i * 4 * W0 * PXB + 16 * PXB, b4, va, vb);
+            conv16x2(af, r0, bm, i * 4 * W0 * PXB, bm, i * 4 * W0 * PXB + 16 * PXB, b4, va, vb);
             *reinterpret_cast<u32x2*>(dm + i * 4 * W1 * PXB) = relu_pk(pack_bf16x4(va));
             *reinterpret_cast<u32x2*>(dm + i * 4 * W1 * PXB + 16 * PXB) = relu_pk(pack_bf16x4(vb));
         }
         // remainder tiles 0 .. 3 (rows 4 wave ..) by every wave, tile 4 (rows 16 .. 19) by wave 0
-        conv16x2(r0, br, 0, br, (16 - 4 * wave) * W0 * PXB, b4, va, vb);
+        conv16x2(af, r0, br, 0, br, (16 - 4 * wave) * W0 * PXB, b4, va, vb);
         *reinterpret_cast<u32x2*>(r1 + ((wave * 4 + rr) * W1 + 32 + xc) * PXB + kk * 8) = relu_pk(pack_bf16x4(va));
         if (wave == 0) *reinterpret_cast<u32x2*>(r1 + ((16 + rr) * W1 + 32 + xc) * PXB + kk * 8) = relu_pk(pack_bf16x4(vb));
     }
-#pragma unroll
-    for (int t = 0; t < CPC; ++t) af[t] = wl[(CPC + t) * 64];
     __syncthreads();
+#pragma unroll
+    for (int t = 0; t < CPC; ++t) af[t] = wl[(2 * CPC + t) * 64];   // convR_2's, a stage ahead (stage 1 was af's last reader)
     // ---- stage 2: r1 (20 x 36) -> r0 as 18 x 34.  4 full rows per wave + rows 16, 17 (waves 0, 1); 3 remainder tiles of 8 rows x 2
     //      columns (waves 1 .. 3; wave 3's covers rows 16, 17 only) ----
     {
@@ -863,22 +872,20 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
         f32x4 va, vb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            conv16x2(r1, bm, i * 4 * W1 * PXB, bm, i * 4 * W1 * PXB + 16 * PXB, b4, va, vb);
+            conv16x2(ag, r1, bm, i * 4 * W1 * PXB, bm, i * 4 * W1 * PXB + 16 * PXB, b4, va, vb);
             *reinterpret_cast<u32x2*>(dm + i * 4 * W2 * PXB) = relu_pk(pack_bf16x4(va));
             *reinterpret_cast<u32x2*>(dm + i * 4 * W2 * PXB + 16 * PXB) = relu_pk(pack_bf16x4(vb));
         }
         if (wave < 2) {
-            conv16x2(r1, bm, 16 * W1 * PXB, bm, 16 * W1 * PXB + 16 * PXB, b4, va, vb);
+            conv16x2(ag, r1, bm, 16 * W1 * PXB, bm, 16 * W1 * PXB + 16 * PXB, b4, va, vb);
             *reinterpret_cast<u32x2*>(dm + 16 * W2 * PXB) = relu_pk(pack_bf16x4(va));
             *reinterpret_cast<u32x2*>(dm + 16 * W2 * PXB + 16 * PXB) = relu_pk(pack_bf16x4(vb));
         }
         if (wave >= 1) {
-            conv16x2(r1, br, 0, br, 0, b4, va, vb);
+            conv16x2(ag, r1, br, 0, br, 0, b4, va, vb);
             if (8 * rt + rr < H2) *reinterpret_cast<u32x2*>(r0 + (rrow * W2 + 32 + xc) * PXB + kk * 8) = relu_pk(pack_bf16x4(va));
         }
     }
-#pragma unroll
-    for (int t = 0; t < CPC; ++t) af[t] = wl[(2 * CPC + t) * 64];
     __syncthreads();
     // ---- stage 3: r0 (18 x 34) -> HBM; a wave takes row pairs 2 (wave + 4 i), both column blocks (2x2 pool in registers) ----
     {
@@ -886,26 +893,29 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
         int bm[CPC];
 #pragma unroll
         for (int t = 0; t < CPC; ++t) bm[t] = (2 * wave * W2 + j + tap_px(t, W2)) * PXB + (kk & 1) * 16;
-        bf16_t* __restrict__ out = P.out + ((size_t)(y0 + 2 * wave) * W + x0 + j) * C + kk * 4;
+        // (uniform base pointers + 32-bit byte offsets: the row steps are scalar adds)
+        unsigned char* __restrict__ const outb = reinterpret_cast<unsigned char*>(P.out);
+        unsigned char* __restrict__ const poolb = reinterpret_cast<unsigned char*>(P.pool);
         const int Wp = (W + 1) >> 1;
+        const unsigned poff = (((unsigned)((y0 >> 1) + wave) * (unsigned)Wp + (unsigned)((x0 + j) >> 1)) * C + kk * 4) * 2u, prow = (unsigned)Wp * C * 2u;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
                 f32x4 v2[2];
-                conv16x2(r0, bm, (8 * i) * W2 * PXB + cb * 16 * PXB, bm, (8 * i + 1) * W2 * PXB + cb * 16 * PXB, b4, v2[0], v2[1]);
+                conv16x2(af, r0, bm, (8 * i) * W2 * PXB + cb * 16 * PXB, bm, (8 * i + 1) * W2 * PXB + cb * 16 * PXB, b4, v2[0], v2[1]);
                 u32x2 pk[2];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     pk[r] = relu_pk(pack_bf16x4(v2[r] + unpack_bf16x4(resv[i][r][cb])));
-                    *reinterpret_cast<u32x2*>(out + ((size_t)(8 * i + r) * W + cb * 16) * C) = pk[r];
+                    *reinterpret_cast<u32x2*>(outb + (roff + (unsigned)(8 * i + r) * rrow + cb * 16 * C * 2)) = pk[r];    // (the residual operand's offsets)
                 }
                 if (P.pool) {
                     // 2 x 2 max on the packed values (non-negative bf16 order like their bit patterns): rows, then the neighbour lane
                     const unsigned m0 = pkmax_u16(pk[0].x, pk[1].x), m1 = pkmax_u16(pk[0].y, pk[1].y);
                     const unsigned n0 = __float_as_uint(lane_xor1(__uint_as_float(m0))), n1 = __float_as_uint(lane_xor1(__uint_as_float(m1)));
                     if ((j & 1) == 0)
-                        *reinterpret_cast<u32x2*>(P.pool + ((size_t)((y0 >> 1) + wave + 4 * i) * Wp + ((x0 + cb * 16 + j) >> 1)) * C + kk * 4) = u32x2{pkmax_u16(m0, n0), pkmax_u16(m1, n1)};
+                        *reinterpret_cast<u32x2*>(poolb + (poff + (unsigned)(4 * i) * prow + cb * 8 * C * 2)) = u32x2{pkmax_u16(m0, n0), pkmax_u16(m1, n1)};
                 }
             }
     }
@@ -1172,13 +1182,14 @@ __device__ __forceinline__ void res8b_tile(const Res8BArgs& a, const Res8BProb& 
         constexpr int NU = IH * IW * 2, NLOAD = (NU + 255) / 256;
         u32x4 st[NLOAD];
         unsigned mask = 0;
+
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             const int u = min(tid + i * 256, NU - 1);
             const int pix = u >> 1, sub = u & 1;
             const int ly = pix / IW, lx = pix - ly * IW;
             const int gy = y0 - 4 + ly, gx = x0 - 4 + lx;
-            const bf16_t* __restrict__ src = sub ? P.dec : P.skip;
+            const bf16_t* __restrict__ src = concat_src(P.skip, P.dec, sub, 1);                 // sub 0: skip, sub 1: dec
             st[i] = *reinterpret_cast<const u32x4*>(src + ((size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * 8);
             mask |= ((gy >= 0 && gy < H && gx >= 0 && gx < W) ? 1u : 0u) << i;
         }

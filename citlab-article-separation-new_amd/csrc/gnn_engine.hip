@@ -403,6 +403,7 @@ int forward_impl(asep_gnn* g, BufferPool& pool, int N, int E, const int32_t* d_e
     return ASEP_OK;
 }
 
+#ifdef ASEP_ABLATION
 // ---- several pages' graphs, stage by stage (asep_gnn_forward_visual_batch_dev) --------------------------------------------------
 // The graph of one page is ~15 launches of at most 200 workgroups whose duration is the latency of ONE workgroup's work (a transition
 // step: 60-100 us for 200 nodes); sixteen pages one after the other are 48 such step launches per call.  Here every stage that is a
@@ -524,6 +525,7 @@ int forward_batch_impl(asep_gnn* g, BufferPool& pool, int n, GraphCtx* cx, hipSt
     ASEP_HIP_CHECK(hipGetLastError());
     return ASEP_OK;
 }
+#endif
 
 // graph_relation.py:84-139 in front of the graph: backbone, ROI max + compression per feature map, concatenation.
 // ROI max + compression of one page's nodes from the backbone end points "<prefix><name>" of the forward that is queued
@@ -732,8 +734,9 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
         if (kv.first.rfind("visual_node_feature_compression_fm_", 0) == 0 || kv.first.rfind("visual_edge_feature_compression_fm_", 0) == 0)
             g->vis_blob[kv.first] = kv.second;
     if (const char* ev = getenv("ASEP_GNN_STEP")) g->use_step = atoi(ev) != 0;
-    if (const char* ev = getenv("ASEP_GNN_BATCH")) g->batch_graph = atoi(ev) != 0;
-    if (const char* ev = getenv("ASEP_GNN_LANES")) g->n_page_lanes = std::max(1, std::min(16, atoi(ev)));
+#ifdef ASEP_ABLATION   // measured and not adopted (DESIGN_LESSONS 28, 36); `make ABLATION=1` builds them for scripts/r4_ab.sh
+    if (const char* ev = getenv("ASEP_GNN_BATCH")) g->batch_graph = atoi(ev) != 0; if (const char* e2 = getenv("ASEP_GNN_LANES")) g->n_page_lanes = std::max(1, std::min(16, atoi(e2)));
+#endif
     // the fused MFMA step kernels serve the reference's defaults: widths 32 / [32] / 32, degree-normalised SUM, both LSTM inputs
     const bool default_widths = H == GNN_H && I == GNN_H && Hm == GNN_H && ih.size() == 1 && heads == 0 && cfg->aggregation_type == 0 &&
                                 g->cfg.lstm_use_hidden && g->cfg.lstm_use_input;
@@ -990,6 +993,7 @@ int asep_gnn_forward_visual_batch_dev(asep_gnn* g, int n_pages, const asep_gnn_p
     }
     float* d_u = g->d_u_cat;
     float* d_efc = g->d_ef_cat;
+#ifdef ASEP_ABLATION
     if (L == 1 && g->batch_graph && n_pages > 1 && g->vise_total == 0 && graph_batch_eligible(g)) {
         // stage by stage over all pages (forward_batch_impl): ROI kernels per feature map, steps, classifier as one launch each
         const int U = g->Uin, ugc = U - g->vis_total;
@@ -1040,6 +1044,7 @@ int asep_gnn_forward_visual_batch_dev(asep_gnn* g, int n_pages, const asep_gnn_p
         }
         return ASEP_OK;
     }
+#endif
     for (int b = 0; b < n_pages; ++b) {
         const asep_gnn_page& q = pages[b];
         hipStream_t ls = L > 1 ? g->page_lanes[b % L]->s : s;

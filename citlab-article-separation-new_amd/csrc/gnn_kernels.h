@@ -200,6 +200,7 @@ typedef float gf32x4 __attribute__((ext_vector_type(4)));
 enum { GQ_ZERO = 0, GQ_UI, GQ_UJ, GQ_DU, GQ_DU2, GQ_EF, GQ_HI, GQ_HJ, GQ_DH, GQ_DH2 };
 constexpr int GNN_MAXCH = 16;          // K chunks of 16 slots (U <= 8, Ed <= 4 -> 11 chunks)
 
+#ifdef ASEP_ABLATION   // (make ABLATION=1: the stage-by-stage form of the batched relation nets, measured and not adopted -- DESIGN_LESSONS 36)
 // Several pages' launches of one graph kernel as ONE launch (asep_gnn_forward_visual_batch_dev): blockIdx.y = page, p[page] = the arguments the
 // per-page launch would get, nx[page] = its grid size along x (blocks beyond it leave at once).  By value in the kernel arguments (< 4 KB).
 constexpr int GNN_BATCH = 16;
@@ -208,6 +209,7 @@ struct GnnBatch {
     A p[GNN_BATCH];
     int nx[GNN_BATCH];
 };
+#endif
 
 struct StepArgs {
     const float* u; const float* h_in; const float* c_in; const float* ef;
@@ -353,10 +355,12 @@ __device__ __forceinline__ void gnn_step_kernel_body(const StepArgs& a, const in
     }
 }
 __global__ __launch_bounds__(256) void gnn_step_kernel(const StepArgs a) { gnn_step_kernel_body(a, (int)blockIdx.x, (int)gridDim.x); }
+#ifdef ASEP_ABLATION
 __global__ __launch_bounds__(256) void gnn_step_kernel_batch(const GnnBatch<StepArgs> b) {
     if ((int)blockIdx.x >= b.nx[blockIdx.y]) return;
     gnn_step_kernel_body(b.p[blockIdx.y], (int)blockIdx.x, b.nx[blockIdx.y]);
 }
+#endif
 
 
 // ------------------------------------------------------------------------------------------------
@@ -509,10 +513,12 @@ __device__ __forceinline__ void gnn_step_big_kernel_body(const StepBigArgs& a, c
     }
 }
 __global__ __launch_bounds__(256) void gnn_step_big_kernel(const StepBigArgs a) { gnn_step_big_kernel_body(a, (int)blockIdx.x, (int)gridDim.x); }
+#ifdef ASEP_ABLATION
 __global__ __launch_bounds__(256) void gnn_step_big_kernel_batch(const GnnBatch<StepBigArgs> b) {
     if ((int)blockIdx.x >= b.nx[blockIdx.y]) return;
     gnn_step_big_kernel_body(b.p[blockIdx.y], (int)blockIdx.x, b.nx[blockIdx.y]);
 }
+#endif
 
 
 // zero-padded copy of the node features: [N, U] -> [N, Upad]
@@ -870,6 +876,7 @@ __global__ __launch_bounds__(256) void gnn_pair_pre_kernel(const float* __restri
 struct PairPreArgs {
     const float* h; int N, H; const float* W1; int H1; float* Pt; float* Qt;
 };
+#ifdef ASEP_ABLATION
 // gnn_pair_pre_kernel for several pages (GnnBatch): the same grid-stride loop per page, nx[page] blocks
 __global__ __launch_bounds__(256) void gnn_pair_pre_kernel_batch(const GnnBatch<PairPreArgs> b) {
     if ((int)blockIdx.x >= b.nx[blockIdx.y]) return;
@@ -886,6 +893,7 @@ __global__ __launch_bounds__(256) void gnn_pair_pre_kernel_batch(const GnnBatch<
         a.Qt[(size_t)k * a.N + n] = q;
     }
 }
+#endif
 
 struct PairArgs {
     const float* Pt; const float* Qt;   // [H1][N]
@@ -947,11 +955,13 @@ __device__ __forceinline__ void gnn_pair_cls_kernel_body(const PairArgs& a, cons
 }
 template <int H1, int H2, int NC>
 __global__ __launch_bounds__(256) void gnn_pair_cls_kernel(const PairArgs a) { gnn_pair_cls_kernel_body<H1, H2, NC>(a, (int)blockIdx.x, (int)gridDim.x); }
+#ifdef ASEP_ABLATION
 template <int H1, int H2, int NC>
 __global__ __launch_bounds__(256) void gnn_pair_cls_kernel_batch(const GnnBatch<PairArgs> b) {
     if ((int)blockIdx.x >= b.nx[blockIdx.y]) return;
     gnn_pair_cls_kernel_body<H1, H2, NC>(b.p[blockIdx.y], (int)blockIdx.x, b.nx[blockIdx.y]);
 }
+#endif
 
 
 // any classifier widths (trainer_rel.py:17 num_hidden_units is a free parameter): one thread per pair, the second
@@ -1134,11 +1144,13 @@ __device__ __forceinline__ void gnn_roi_compress_kernel_body(const RoiArgs& a, c
 }
 template <bool BF>
 __global__ __launch_bounds__(256) void gnn_roi_compress_kernel(const RoiArgs a) { gnn_roi_compress_kernel_body<BF>(a, (int)blockIdx.x, (int)gridDim.x); }
+#ifdef ASEP_ABLATION
 template <bool BF>
 __global__ __launch_bounds__(256) void gnn_roi_compress_kernel_batch(const GnnBatch<RoiArgs> b) {
     if ((int)blockIdx.x >= b.nx[blockIdx.y]) return;
     gnn_roi_compress_kernel_body<BF>(b.p[blockIdx.y], (int)blockIdx.x, b.nx[blockIdx.y]);
 }
+#endif
 
 
 // graph_gnn.py:102-109 compress_node_feature_dim: y[n][d] = tanh(b[d] + sum_k x[n][k] W[k][d])  (layers.ff_layer with tanh)

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     // frame = one 24-row window of a work unit: (tile, pass) -> image rows [(tyb * NP + pass) * OH - 4, +24)
     auto image_load = [&](int tile_id, int pass) {          // next frame's image values -> registers (in flight under the MFMA stages)
         int pi = 0;
-        pi = prob_of_tile(a, tile_id);
+        pi = prob_of_tile_search(a, tile_id);
         const Res8Prob& Q = a.p[pi];
         const int t = tile_id - Q.tile_begin;
         const int tyb = t / Q.tiles_x, txb = t - tyb * Q.tiles_x;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const bool has_next = k + (int)gridDim.x < a.total_tiles;
         const int next_id = has_next ? res8_tile_of(a, k + gridDim.x) : 0;   // requested a whole tile ahead of its use
         int pi = 0;
-        pi = prob_of_tile(a, tile_id);
+        pi = prob_of_tile_search(a, tile_id);
         const Res8Prob& P = a.p[pi];
         const int t = tile_id - P.tile_begin;
         const int tyb = t / P.tiles_x, txb = t - tyb * P.tiles_x;
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(R8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const bool has_next = k + (int)gridDim.x < a.total_tiles;
         const int next_id = has_next ? res8_tile_of(a, k + gridDim.x) : 0;   // requested a whole tile ahead of its use
         int pi = 0;
-        pi = prob_of_tile(a, tile_id);
+        pi = prob_of_tile_search(a, tile_id);
         const Res8Prob& P = a.p[pi];
         const int t = tile_id - P.tile_begin;
         const int tyb = t / P.tiles_x, txb = t - tyb * P.tiles_x;

@@ -123,7 +123,7 @@ def load_graph(pb_path, visual_layers=None, num_transition_steps=None) -> GnnGra
         cfg = GnnConfig(**(meta or {}).get("gnn_cfg", {}))
     if cfg.visual_dims:                                      # ASEP_COMPUTE_DTYPE: the conv backbone of the visual branch (graph stays fp32)
         from .net_post_processing_helper import compute_dtype_from_env
-        cfg.backbone = dict(cfg.backbone, compute_dtype=compute_dtype_from_env(cfg.backbone.get("compute_dtype", "f32")))
+        cfg.backbone = dict(cfg.backbone, compute_dtype=compute_dtype_from_env(cfg.backbone.get("compute_dtype", cfg.backbone_cfg().compute_dtype)))
     return GnnGraph(tensors, cfg, pb_path)
 
 

@@ -18,8 +18,25 @@ MAX_SUBLIST_SIZE = 50
 
 def run_separator(image_list, path_to_pb, fixed_height, scaling_factor, threshold, gpu_devices='0', host_workers=0):
     from .separator_net_post_processor import SeparatorNetPostProcessor
-    SeparatorNetPostProcessor(image_list, path_to_pb, fixed_height, scaling_factor, threshold,
-                              gpu_devices=gpu_devices, host_workers=host_workers).run()
+    import time
+    proc = SeparatorNetPostProcessor(image_list, path_to_pb, fixed_height, scaling_factor, threshold,
+                                     gpu_devices=gpu_devices, host_workers=host_workers)
+    t0 = time.perf_counter()
+    proc.run()
+    _owner_stats(gpu_devices, len(image_list), time.perf_counter() - t0, host_workers, proc)
+
+
+def _owner_stats(gpu, n_pages, seconds, host_workers, proc):
+    """ASEP_OWNER_STATS_DIR=<dir>: every GPU owner leaves <dir>/owner_<pid>.json -- where its wall time went (bench.py's files-in / files-out
+    legs read them; the reference has no such output, so nothing is written unless asked for)."""
+    d = os.environ.get("ASEP_OWNER_STATS_DIR")
+    if not d:
+        return
+    import json
+    with open(os.path.join(d, f"owner_{os.getpid()}.json"), "w") as f:
+        json.dump({"device": str(gpu), "pages": n_pages, "seconds": seconds, "host_workers": host_workers,
+                   "device_seconds": getattr(proc, "device_seconds", None), "wait_seconds": getattr(proc, "wait_seconds", None),
+                   "host_seconds": getattr(proc, "host_seconds", None), "first_page_seconds": getattr(proc, "first_page_seconds", None)}, f)
 
 
 def run_heading(image_list, path_to_pb, fixed_height=900, scaling_factor=1, is_heading_threshold=0.4,

@@ -6,6 +6,11 @@ wall time as JSON.  bench.py starts several of these side by side, mirroring the
 (run_net_post_processing.py:61-82: ProcessPoolExecutor over page sub-lists).
 
     python -m oracle.cpu_worker --threads 16 --page 0 --rows 1500 --width 3000 --height 4500 [--gnn]
+
+--full (bench.py --cpu-baseline-full; BASELINE.md section 3's protocol): whole pages FROM FILES through every stage of the reference's
+pipeline, per-stage wall clock: PNG decode (Pillow) -> scale + gray -> ARU-Net oracle -> uint8 / threshold -> separator post-processing
+(CC filter, openings) + polygon rings -> PAGE-XML write; then the relation net on graphs: json load -> visual relation-net oracle ->
+confidences -> DBSCAN clustering -> PAGE-XML with article ids.  1 warm-up page / graph, then --pages pages and --graphs graphs.
 """
 import argparse
 import json
@@ -16,8 +21,110 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def full_protocol(a):
+    """-> dict of per-stage seconds (summed over the measured pages / graphs) and end-to-end rates"""
+    import tempfile
+    import numpy as np
+    import torch
+    from PIL import Image
+    torch.set_num_threads(a.threads)
+    from citlab_article_separation_new_amd import polygonize, synth
+    from citlab_article_separation_new_amd.config import AruConfig, GnnConfig
+    from citlab_article_separation_new_amd.host_util import rescale_points
+    from citlab_article_separation_new_amd.region_to_page_writer import SeparatorRegionToPageWriter
+    from citlab_article_separation_new_amd.weights import init_aru_weights, init_gnn_weights
+    from citlab_article_separation_new_amd.clustering import TextblockClustering
+    from citlab_article_separation_new_amd import gnn_results
+    from oracle import aru_oracle, classical_oracle as co, gnn_oracle
+    H, W = a.height, a.width
+    cfg = AruConfig()
+    w = init_aru_weights(cfg, 1234, logit_scale=0.05)
+    st = {k: 0.0 for k in ("decode", "scale_gray", "net", "uint8_threshold", "post_processing", "polygons", "page_xml")}
+    t_all = 0.0
+    with tempfile.TemporaryDirectory(prefix="asep_cpu_full_") as tmp:
+        os.makedirs(os.path.join(tmp, "page"))
+        files = []
+        for k in range(4):
+            q = os.path.join(tmp, f"p{k}.png")
+            Image.fromarray(synth.cached_synth_page(k, W, H)).save(q, compress_level=1)
+            files.append(q)
+        for n in range(-1, a.pages):                            # page -1: warm-up, not counted
+            path = files[n % 4]
+            T = [time.perf_counter()]
+            bgr = np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1]
+            T.append(time.perf_counter())
+            _, grey, sc = co.scale_and_gray(bgr, H, 1.0)
+            T.append(time.perf_counter())
+            prob = aru_oracle.forward_torch(grey.astype(np.float32), w, cfg)
+            T.append(time.perf_counter())
+            mask = aru_oracle.apply_threshold(aru_oracle.to_uint8(prob), 0.5)
+            T.append(time.perf_counter())
+            post = co.separator_post_process(mask)
+            T.append(time.perf_counter())
+            polygons = {f"SeparatorRegion_{o}": [[rescale_points(r, 1 / sc) for r in poly] for poly in polygonize.shapes(post[o])]
+                        for o in ("horizontal", "vertical")}
+            T.append(time.perf_counter())
+            wr = SeparatorRegionToPageWriter(os.path.join(tmp, "page", f"none{n}.xml"), path, H, 1.0, polygons)
+            wr.merge_regions()
+            wr.save_page_xml(os.path.join(tmp, "page", f"out{n}.xml"))
+            T.append(time.perf_counter())
+            if n >= 0:
+                for key, d in zip(st, np.diff(T)):
+                    st[key] += float(d)
+                t_all += T[-1] - T[0]
+        # ---- relation net: graphs of 200 text blocks / ~20k directed edges, visual net (backbone on 683 x 1024) ----
+        gs = {k: 0.0 for k in ("json", "relation_net", "clustering", "page_xml")}
+        tg_all = 0.0
+        gcfg = GnnConfig(visual_dims=[16, 16, 16], mvn=True,
+                         visual_layers=["scale_0_unet_up_2_conv", "scale_0_unet_up_1_conv", "scale_0_unet_up_0_conv"])
+        gw = init_gnn_weights(gcfg, 1234)
+        argv = synth.write_gnn_cli_inputs(os.path.join(tmp, "gnn"), 4, visual=True, W=W, H=H)
+        data = os.path.join(tmp, "gnn", "data")
+        import json as _json
+
+        class _F:
+            clustering_params = {}
+        os.makedirs(os.path.join(tmp, "gnn", "out"), exist_ok=True)
+        inputs = {}
+        for k in range(4):                                          # (the arrays the jsons hold + the resized page image: generated outside the timing)
+            g = synth.synth_graph(k)
+            inputs[k] = (g,) + tuple(synth.visual_inputs(synth.cached_synth_page(k, W, H), g["num_nodes"], k))
+        for n in range(-1, a.graphs):
+            k = n % 4
+            T = [time.perf_counter()]
+            d = _json.load(open(os.path.join(data, "json15d2bb", f"p{k:03d}.json")))
+            _ = (np.asarray(d["interacting_nodes"]), np.asarray(d["node_features"], np.float32), np.asarray(d["edge_features"], np.float32))
+            g, small, regions, npts = inputs[k]
+            T.append(time.perf_counter())
+            probs, _ = gnn_oracle.forward_visual(g["num_nodes"], g["interacting_nodes"], g["node_features"], g["edge_features"], small, regions,
+                                                 npts, None, gw, gcfg)
+            T.append(time.perf_counter())
+            conf = gnn_results.confidences_from_output(probs[None], g["num_nodes"])
+            tb = TextblockClustering(_F())
+            tb.set_confs(np.asarray(conf, dtype=np.float64))
+            tb.calc("dbscan")
+            T.append(time.perf_counter())
+            xml = os.path.join(data, "page", f"p{k:03d}.xml")
+            if os.path.exists(xml):
+                gnn_results.save_clustering_to_page([int(l) for l in tb.tb_labels], xml, os.path.join(tmp, "gnn", "out"))
+            T.append(time.perf_counter())
+            if n >= 0:
+                for key, dd in zip(gs, np.diff(T)):
+                    gs[key] += float(dd)
+                tg_all += T[-1] - T[0]
+    per_page = t_all / a.pages + tg_all / a.graphs
+    return {"threads": a.threads, "pages": a.pages, "graphs": a.graphs,
+            "seconds_per_page_by_stage": {k: round(v / a.pages, 4) for k, v in st.items()},
+            "seconds_per_graph_by_stage": {k: round(v / a.graphs, 4) for k, v in gs.items()},
+            "seconds_per_page_segmentation": round(t_all / a.pages, 3), "seconds_per_page_relation": round(tg_all / a.graphs, 3),
+            "pages_per_s_end_to_end": round(1.0 / per_page, 5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--pages", type=int, default=8)
+    ap.add_argument("--graphs", type=int, default=64)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--page", type=int, default=0)
     ap.add_argument("--rows", type=int, default=1500)
@@ -27,6 +134,9 @@ def main():
     ap.add_argument("--visual", action="store_true", help="the visual relation net (backbone on 683 x 1024 + 55 features)")
     a = ap.parse_args()
     os.environ["OMP_NUM_THREADS"] = str(a.threads)
+    if a.full:
+        print(json.dumps(full_protocol(a)), flush=True)
+        return
     import numpy as np
     import torch
     torch.set_num_threads(a.threads)

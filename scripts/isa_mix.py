@@ -70,7 +70,7 @@ def kernels(text):
 def demangle(names):
     import subprocess
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), text=True, stdout=subprocess.PIPE).stdout.splitlines()
+        out = subprocess.run(["c++filt"], input="\n".join(names), text=True, stdout=subprocess.PIPE).stdout.splitlines()
         return dict(zip(names, out))
     except OSError:
         return {n: n for n in names}

@@ -1,13 +1,14 @@
 #!/bin/bash
-# One measurement point of a build on the GPU box: rocprofv3 summaries + bench lines of the fp32 headline, of the bf16 variant and of fp32 with split products.
-#   scripts/profile_round.sh <tag> <commit>      ->  gpurun_out/<tag>/, gpurun_out/<tag>_bf16/, gpurun_out/<tag>_f32s/, gpurun_out/traffic_per_kernel*.json
+# One measurement point of a build on the GPU box: rocprofv3 summaries + bench lines of the headline (fp32 engine default, f32s), of the bf16
+# variant and of the plain fp32 kernels.  Started through scripts/profile_round_submit.sh, which refuses a dirty tree and passes HEAD's hash.
+#   scripts/profile_round.sh <tag> <commit>      ->  gpurun_out/<tag>/, gpurun_out/<tag>_bf16/, gpurun_out/<tag>_f32/, gpurun_out/traffic_per_kernel*.json
 # The profile script runs twice per dtype: the second traced bench line then carries the PMC traffic of the first (same build).
 set -u
 TAG=${1:-r3}
 COMMIT=${2:-n/a}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-for T in "$TAG:" "${TAG}_bf16:--dtype bf16" "${TAG}_f32s:--dtype f32s"; do
+for T in "$TAG:" "${TAG}_bf16:--dtype bf16" "${TAG}_f32:--dtype f32"; do
     D=${T%%:*}; FL=${T#*:}
     mkdir -p gpurun_out/$D
     # the un-traced default line names the dominant kernel; the traced runs report the same one
@@ -18,11 +19,11 @@ for T in "$TAG:" "${TAG}_bf16:--dtype bf16" "${TAG}_f32s:--dtype f32s"; do
         python3 scripts/make_traffic_json.py gpurun_out/$D $COMMIT > gpurun_out/$D/traffic.log 2>&1
     done
     python3 bench.py $FL > gpurun_out/$D/bench.json 2> gpurun_out/$D/bench.err
-    DT=f32; [ -n "$FL" ] && DT=${FL#--dtype }
+    DT=f32s; [ -n "$FL" ] && DT=${FL#--dtype }
     python3 scripts/gpu_layer_profile.py 4500 3000 $DT > gpurun_out/$D/layers_one_page.log 2>&1
 done
 cp profiles/traffic_per_kernel*.json gpurun_out/
 bash scripts/pmc_instruction_mix.sh ${TAG}_mix > gpurun_out/${TAG}_mix.log 2>&1
 bash scripts/pmc_instruction_mix.sh ${TAG}_mix_bf16 "--dtype=bf16" > gpurun_out/${TAG}_mix_bf16.log 2>&1
-bash scripts/pmc_instruction_mix.sh ${TAG}_mix_f32s "--dtype=f32s" > gpurun_out/${TAG}_mix_f32s.log 2>&1
+bash scripts/pmc_instruction_mix.sh ${TAG}_mix_f32 "--dtype=f32" > gpurun_out/${TAG}_mix_f32.log 2>&1
 tail -2 gpurun_out/$TAG/bench.err

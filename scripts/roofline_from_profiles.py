@@ -56,8 +56,10 @@ def recompute(tagdir):
     exec_fl = r["executed_flops_per_launch"]
     hbm_bound = r["bound"] == "hbm"                            # bf16 lines: the primary figures are bytes / s, the matrix ones under "mfma"
     peak = (r["mfma_peak"] if layout4 else r["mfma"]["peak"]) if hbm_bound else r["peak"]
-    # round 4 (layout 4), fp32: `achieved` is the ALGORITHMIC rate (direct-convolution FLOPs of the launch); before: the executed one
-    achieved = (r["flops_per_launch"] if layout4 and not hbm_bound else exec_fl) / (avg_us * 1e-6) / 1e12
+    # round 4 (layout 4), fp32: `achieved` is the ALGORITHMIC rate (direct-convolution FLOPs of the launch); before it, and again from
+    # round 5 (layout 5): the executed one -- layout 5 prices it against the peak of the pipe the kernel runs on (`peak` of the line)
+    layout5 = r.get("layout", 3) >= 5
+    achieved = (r["flops_per_launch"] if layout4 and not layout5 and not hbm_bound else exec_fl) / (avg_us * 1e-6) / 1e12
     # whole page: executed FLOPs of all ARU-Net kernels per page (Winograd kernels execute 1/2.25 of their direct-conv credit)
     ev_steps = max(1, r.get("event_timed_steps", 1))
     exec_page = sum((q["flops"] / 2.25 if "wino" in q["kernel"] else q["flops"]) for q in line["kernels"]) / (B * ev_steps)
@@ -69,6 +71,10 @@ def recompute(tagdir):
         "whole_page_executed_gflop": exec_page / 1e9,
         "whole_page_executed_frac": exec_page * line["value"] / line["n_gpus"] / 1e12 / peak,
     }
+    if layout5:
+        # the whole page: executed products of every kernel over its own pipe's peak (seconds at peak per page) x pages / s
+        pipe_s = sum((q["flops"] / 2.25 if "wino" in q["kernel"] else q["flops"]) / (q["pipe_peak_tflops"] * 1e12) for q in line["kernels"]) / (B * ev_steps)
+        out["whole_page_executed_frac"] = pipe_s * line["value"] / line["n_gpus"]
     if k in kernels:
         out["traffic"] = kernels[k]["bytes_per_launch"]
         out["hbm_tb_per_s"] = out["traffic"] / (avg_us * 1e-6) / 1e12

@@ -40,10 +40,15 @@ def r_src(line):
 
 def test_single_process_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                        "--pages-per-step", "3", "--e2e-pages", "6", "--bf16-steps", "3"], cwd=ROOT, capture_output=True, text=True, timeout=1200)
+                        "--pages-per-step", "3", "--e2e-pages", "6", "--bf16-steps", "3", "--plain-steps", "2"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     line = _one_json_line(r.stdout)
-    assert line["steps"] == 2 and line["warmup"] == 1 and line["dtype"] == "f32"
+    # round 5: the default line is the fp32 engine's default arithmetic (f32s), spelled out in config.arithmetic; the plain fp32 kernels' step
+    # rides beside it as secondary.plain_f32_full_step
+    assert line["steps"] == 2 and line["warmup"] == 1 and line["dtype"] == "f32s" and "6 bf16 MFMAs" in line["config"]["arithmetic"]
+    ag = line["config"]["agreement_with_plain_fp32"]
+    assert ag["max_abs_dp_vs_plain_fp32_kernels"] <= 1e-5 and ag["uint8_values_that_differ"] <= 1e-4 * ag["of"]
     assert line["config"]["pages_per_step_per_gpu"] == 3 and line["roofline_detail"]["pages_per_launch"] == 3.0
     # secondary figures (bf16 variant, heading net + stroke-width fusion, the visual relation net) ride on the same line
     sec = line["secondary"]
@@ -57,7 +62,12 @@ def test_single_process_line():
     assert "error" not in b16, b16
     assert b16["pages_per_s"] > 0 and b16["steps"] == 3 and b16["roofline"]["bound"] == "hbm" and b16["roofline"]["unit"] == "GB/s"
     assert b16["roofline"]["algorithmic_bytes"] > 0 and 0 < b16["roofline"]["frac"] < 1 and b16["whole_page_algorithmic_gb"] > 1
-    assert all("executed_tflops" in k for k in line["kernels"])
+    p32 = sec["plain_f32_full_step"]
+    assert "error" not in p32, p32
+    assert p32["pages_per_s"] > 0 and p32["steps"] == 2 and p32["dtype"] == "f32" and 0 < p32["roofline"]["frac"] <= 1.0
+    up = sec["upstream_layout_6x5"]
+    assert up["f32s"]["pages_per_s"] > 0 and up["bf16"]["pages_per_s"] > up["f32s"]["pages_per_s"] and 1000 < up["f32s"]["gflop_per_page"] < 1120
+    assert all("executed_tflops" in k and 0 <= k["executed_frac_of_pipe_peak"] <= 1.0 for k in line["kernels"])
     # the headline step carries the VISUAL relation net (BASELINE configs[3]: mixed_gnn_vn7e2), and the roofline block both timings
     assert line["config"]["relation_net"] == "visual" and "mixed_gnn_vn7e2" in line["config"]["workload"]
     assert line["config"]["devices"] >= 1 and "mixed_gnn_vn7e2" in line["config"]["workload_detail"]
@@ -68,7 +78,8 @@ def test_single_process_line():
     r = line["roofline"]
     assert r["frac_in_situ"] and r["frac_isolated"] and r["whole_page_executed_frac"] > 0
     assert r["frac"] == r["frac_in_situ"] and r["frac_in_situ"] <= r["frac_isolated"] * 1.05
-    assert 0 < r["executed_frac"] <= r["frac"]               # a Winograd kernel executes less than its direct-convolution credit
+    assert 0 < r["frac"] <= 1.0 and r["frac_isolated"] <= 1.0 and r["peak"] in (157.3, 416.67) and r["pipe"]   # executed products over the kernel's own pipe
+    assert r["algorithmic_tflops"] >= r["achieved"] - 1e-3
     assert r["kernel"] in {k["kernel"] for k in line["kernels"]} and "<" in "".join(k["kernel"] for k in line["kernels"])
 
 
@@ -116,3 +127,23 @@ def test_gpus_2_without_a_torchrun_environment_starts_its_own_ranks():
     assert line["n_gpus"] == 2 and line["config"]["sharding"] == "pages over 2 rank(s)" and line["cpu_baseline"] is None
     assert "ranks share devices" in str(line["config"]["devices"])
     assert abs(line["value"] - 2 * 2 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-2 * line["value"]
+
+
+def test_gpus_2_reports_the_files_leg_with_two_gpu_owners():
+    """VERDICT r4 missing #3 / next #5: a --gpus N run times device-resident pages only, and what decides the 1 -> N curve files in / files
+    out is the host.  With --gpus N rank 0 also runs the separator command line with N GPU owners x (CPU quota / N) host workers on
+    N x --e2e-n-pages-per-owner scans and reports it as secondary.e2e_files_n.  Here: two ranks and two owners on the one GPU of the box."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ASEP_BENCH_DEVICE"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--pages-per-step", "2", "--kernel-timing", "none", "--e2e-n-pages-per-owner", "12"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, lines[:3]
+    line = json.loads(lines[0])
+    leg = line["secondary"]["e2e_files_n"]
+    assert "error" not in leg, leg
+    assert leg["rc"] == 0 and leg["gpu_owners"] == 2 and leg["owner_devices"] == ["0", "0"] and leg["scans"] == 24 and leg["page_xml_written"] == 24
+    assert leg["pages_per_s"] > 0 and len(leg["pages_per_s_per_owner"]) == 2 and 0 < leg["owner_device_stage_share"] <= 1.0
+    assert leg["host_workers_per_owner"] * 2 <= leg["cpus_this_container_may_use"]

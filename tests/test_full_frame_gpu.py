@@ -255,6 +255,66 @@ def test_whole_page_fp32_end_points_and_logits_with_unit_logit_scale(unit_scale_
     assert lrel <= 2e-5 and perr <= 1e-4
 
 
+@pytest.fixture(scope="module")
+def upstream_layout_page():
+    """The UPSTREAM ARU-Net layout (ARU_v1.py:35-43 defaults of the paper's net: scale_space_num = 6, num_scales_att = 5; 1060 GFLOP per
+    3000 x 4500 page) -- SURVEY section 8d asks for it because the shipped .pb's true cfg is unknown (nets/README.md:1-7).  Page 2,
+    reference-rule weights (unit logit scale), the oracle's end points for the whole frame: the 256-channel level (141 x 94 at scale 0 down to
+    9 x 6 at scale 4) finally sees more than one tile."""
+    from citlab_article_separation_new_amd import synth
+    from citlab_article_separation_new_amd.config import AruConfig
+    from citlab_article_separation_new_amd.weights import init_aru_weights
+    from oracle import aru_oracle
+    cfg = AruConfig(scale_space_num=6, num_scales_att=5)
+    w = init_aru_weights(cfg, 6565, bias_jitter=0.05, logit_scale=1.0)
+    page = synth.synth_page(2, W, H).astype(np.float32) / 255.0
+    ref, inter = aru_oracle.forward_torch(page, w, cfg, return_intermediates=True)
+    return page, w, cfg, ref, inter
+
+
+@pytest.mark.parametrize("dtype", ["f32s", "f32", "bf16"])
+def test_upstream_layout_6_levels_5_attention_scales_whole_frame(upstream_layout_page, dtype):
+    """VERDICT r4 missing #1 / next #3: the 6-level / 5-scale layout at full size.  fp32 arithmetics: every end point within 2e-5 max|ref|, logits
+    within 2e-5, probabilities within 1e-4 -- the gates of the 5 / 3 layout; bf16: its end-point / logit gates."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from citlab_article_separation_new_amd.config import AruConfig
+    page, w, cfg, ref, inter = upstream_layout_page
+    kw = dict(scale_space_num=6, num_scales_att=5, compute_dtype=dtype)
+    g = helper.AruGraph(w, AruConfig(**kw))
+    out = helper.get_net_output(page, g, "0")
+    rows = []
+    for name in sorted(inter):
+        if not (name.startswith("scale_") or name.startswith("att_")):
+            continue
+        got = helper.get_endpoint(g, name)
+        want = inter[name]
+        assert got.shape == want.shape, name
+        scale = max(1.0, float(np.abs(want).max()))
+        d = got - want
+        rows.append((name, float(np.abs(d).max()) / scale, float(np.sqrt(np.mean(d.astype(np.float64) ** 2))) / scale))
+        del got, d
+    g.close()
+    gl = helper.AruGraph(w, AruConfig(apply_softmax=False, **kw))
+    logits = helper.get_net_output(page, gl, "0")
+    gl.close()
+    lref = inter["logits"]
+    lrel = float(np.abs(logits - lref).max()) / max(1.0, float(np.abs(lref).max()))
+    perr = float(np.abs(out - ref).max())
+    worst, worst_rms = max(rows, key=lambda t: t[1]), max(rows, key=lambda t: t[2])
+    n256 = [r for r in rows if "_unet_down_5_" in r[0]]
+    print(f"\n{dtype} upstream layout (6 levels, 5 attention scales) whole frame: {len(rows)} end points, worst max {worst[0]} {worst[1]:.2e}, worst rms "
+          f"{worst_rms[0]} {worst_rms[2]:.2e}; 256-channel level: {max(r[1] for r in n256):.2e}; logits rel {lrel:.2e} (max|l| {np.abs(lref).max():.1f}); "
+          f"max|dp| {perr:.2e}")
+    assert len(n256) == 5 and inter["scale_0_unet_down_5_conv"].shape == (141, 94, 256)
+    if dtype == "bf16":
+        assert all(r[1] <= BF16_ENDPOINT_GATE for r in rows), worst
+        assert all(r[2] <= BF16_ENDPOINT_RMS_GATE for r in rows), worst_rms
+        assert lrel <= BF16_LOGIT_GATE and perr <= BF16_PROB_GATE
+    else:
+        assert all(r[1] <= 2e-5 for r in rows), worst
+        assert lrel <= 2e-5 and perr <= 1e-4
+
+
 def test_c1_crop_512x768_through_the_separator_cli(tmp_path):
     """BASELINE configs[0]: one 512 x 768 crop, --fixed_height 768 so that the net sees the crop itself."""
     from citlab_article_separation_new_amd import image_io, pb_import, polygonize, synth

@@ -95,7 +95,7 @@ def test_visual_forward_with_a_split_product_backbone_holds_the_fp32_gates():
     from citlab_article_separation_new_amd import gnn_io, synth
     from oracle import gnn_oracle
     cfg, w, graph = _setup(mvn=True, backbone={"compute_dtype": "f32s"})
-    _, _, graph32 = _setup(mvn=True)
+    _, _, graph32 = _setup(mvn=True, backbone={"compute_dtype": "f32"})            # the plain fp32 kernels
     rng = np.random.default_rng(3)
     N = 30
     g = synth.synth_graph(1, N=N, n_pairs=80, node_dim=7)
@@ -226,15 +226,13 @@ def test_reattach_and_feature_readback_are_stable():
     graph.close()
 
 
-@pytest.mark.parametrize("stage_by_stage", ["0", "1"])
-def test_batched_visual_forward_equals_the_single_page_calls(stage_by_stage, monkeypatch):
+def test_batched_visual_forward_equals_the_single_page_calls():
     """asep_gnn_forward_visual_batch_dev (bench.py's step): the backbones of all pages as one grouped forward, then ROI
     kernels + graph per page.  Pages with different graphs / images / node counts must come out exactly as from
     asep_gnn_forward_visual (bit-identical: same kernels on the same values), and page 0 also matches the oracle."""
     import torch
     from citlab_article_separation_new_amd import gnn_io, synth
     from oracle import gnn_oracle
-    monkeypatch.setenv("ASEP_GNN_BATCH", stage_by_stage)    # 1: forward_batch_impl (one launch per graph stage over the pages), read at model load
     cfg, w, graph = _setup(mvn=True)
     rng = np.random.default_rng(29)
     h, wd = 160, 112

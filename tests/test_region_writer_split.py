@@ -330,3 +330,36 @@ def test_slanted_line_that_cannot_be_clipped_is_left_uncut(tmp_path, caplog):
     finally:
         pc.difference_parts = real
     assert len(out) == 1 and out[0].surr_p == Line.surr_p and "left uncut" in caplog.text
+
+
+def test_fuzz_integer_rings_against_a_rectangle_never_leave_a_line_uncut():
+    """a fuzz of integer-coordinate star polygons against one rectangle was reported to raise ClipError in ~0.1 % of the cases
+    (a text line then keeps its outline across the separator).  On the writer's path -- ``repair_ring`` first, as
+    region_to_page_writer.py does, then ``difference_parts`` -- 9 000 seeded rings here, 52 000 when the finding was looked into (simple stars with every vertex on the integer grid,
+    and rings with random radii that cross themselves) raise none, and the pieces conserve the area of the repaired loops.  (Rings that
+    cross themselves handed to ``difference_parts`` WITHOUT the repair do fail its area check -- that is the guard working: 1.8 % of
+    such rings in the same fuzz.)"""
+    import math
+    from citlab_article_separation_new_amd import poly_clip
+    rect = (30, 30, 50, 45)
+    n_cases = 0
+    for seed in range(3):
+        rng = np.random.default_rng(1000 + seed)
+        for _ in range(1500):
+            k = 2 * int(rng.integers(4, 9))
+            star = [(int(round(40 + (rng.integers(10, 30) if i % 2 == 0 else rng.integers(3, 9)) * math.cos(2 * math.pi * i / k))),
+                     int(round(40 + (rng.integers(10, 30) if i % 2 == 0 else rng.integers(3, 9)) * math.sin(2 * math.pi * i / k)))) for i in range(k)]
+            m = int(rng.integers(5, 16))
+            ang = np.sort(rng.uniform(0, 2 * math.pi, m))
+            wild = [(int(round(40 + r * math.cos(a))), int(round(40 + r * math.sin(a)))) for a, r in zip(ang, rng.integers(2, 30, m))]
+            for ring in (star, wild):
+                ring = [p for i, p in enumerate(ring) if p != ring[i - 1]]
+                if len(ring) < 3 or poly_clip.ring_area2(ring) == 0:
+                    continue
+                loops = poly_clip.repair_ring(ring)
+                for lp in loops:
+                    parts = poly_clip.difference_parts(lp, [rect])           # raises ClipError if the crossings do not pair / the area does not balance
+                    left = sum(abs(poly_clip.ring_area2(q)) for q in parts) / 2.0
+                    assert left <= abs(poly_clip.ring_area2(lp)) / 2.0 + 1e-6
+                n_cases += 1
+    assert n_cases > 8000

@@ -15,7 +15,7 @@ import roofline_from_profiles as rfp  # noqa: E402
 
 # every round-3 measurement point that carries the full set of summaries (profiles/r3*: fp32 headline builds and their bf16 twins)
 TAGS = sorted(t for t in os.listdir(os.path.join(ROOT, "profiles"))
-              if t.startswith(("r3", "r4")) and all(os.path.exists(os.path.join(ROOT, "profiles", t, f))
+              if t.startswith(("r3", "r4", "r5")) and all(os.path.exists(os.path.join(ROOT, "profiles", t, f))
                                             for f in ("kernel_stats.csv", "pmc_summary.json", "bench_under_trace.json", "bench.json")))
 
 

@@ -56,14 +56,13 @@ def test_split_products_match_the_oracle_at_the_fp32_gates(H, W):
 
 
 @pytest.mark.parametrize("H,W", [(250, 333), (515, 260)])
-def test_split_products_agree_with_the_plain_fp32_path(H, W, monkeypatch):
+def test_split_products_agree_with_the_plain_fp32_path(H, W):
     """unit logit scale, every end point and the logits: the two fp32 paths of the engine differ by the order of their sums and by the
     split's dropped terms (<= 2^-23 of a product) only"""
-    monkeypatch.delenv("ASEP_F32_SPLIT", raising=False)        # (the switch would put the fp32 model on the split kernels too)
     from citlab_article_separation_new_amd import net_post_processing_helper as helper
     from citlab_article_separation_new_amd.config import AruConfig
     cfg, w, gs = _setup({"apply_softmax": False}, logit_scale=1.0)
-    gf = helper.AruGraph(w, AruConfig(apply_softmax=False))
+    gf = helper.AruGraph(w, AruConfig(apply_softmax=False, compute_dtype="f32"))       # the plain fp32 MFMA / Winograd kernels
     img = _image(H, W, 77)
     ls, lf = helper.get_net_output(img, gs, "0"), helper.get_net_output(img, gf, "0")
     from oracle import aru_oracle
@@ -87,7 +86,7 @@ def test_split_products_at_tile_boundaries_against_the_plain_path():
     from citlab_article_separation_new_amd import net_post_processing_helper as helper
     from citlab_article_separation_new_amd.config import AruConfig
     cfg, w, gs = _setup({"apply_softmax": False}, logit_scale=1.0)
-    gf = helper.AruGraph(w, AruConfig(apply_softmax=False))
+    gf = helper.AruGraph(w, AruConfig(apply_softmax=False, compute_dtype="f32"))       # the plain fp32 MFMA / Winograd kernels
     rng = np.random.default_rng(123)
     sizes = [(128, 128), (129, 127), (256, 512), (257, 513), (255, 511), (16, 32), (17, 33), (15, 31), (64, 26), (63, 27), (8, 300), (300, 8)]
     sizes += [(int(rng.integers(1, 400)), int(rng.integers(1, 400))) for _ in range(4)]
@@ -139,51 +138,19 @@ def test_batched_pages_equal_single_pages():
     graph.close()
 
 
-@pytest.mark.parametrize("H,W", [(150, 131), (64, 300)])
-def test_a_fragments_through_lds_for_every_wide_layer(H, W, monkeypatch):
-    """ASEP_SPLIT_ALDS=2: convs16_kernel (16-channel stages, a chunk's A fragments copied to LDS once per block) for every 3x3 layer with >= 32
-    input channels, not only for those with one m-tile of output channels"""
-    monkeypatch.setenv("ASEP_SPLIT_ALDS", "2")
-    from citlab_article_separation_new_amd import net_post_processing_helper as helper
-    from oracle import aru_oracle
-    cfg, w, graph = _setup()
-    img = _image(H, W, 5)
-    ref, inter = aru_oracle.forward_torch(img, w, cfg, return_intermediates=True)
-    out = helper.get_net_output(img, graph, "0")
-    _check_endpoints(helper, graph, inter)
-    assert float(np.abs(out - ref).max()) <= PROB_TOL
-    graph.close()
-
-
-@pytest.mark.parametrize("H,W", [(200, 150), (67, 131), (9, 27), (300, 420)])
-def test_level0_blocks_on_the_split_kernel(H, W, monkeypatch):
-    """ASEP_SPLIT_L0=1: res8s_kernel (the 8-channel residual blocks with split products; off by default -- slower than the vector-ALU
-    kernels, DESIGN_LESSONS 32) gives the fp32 results too"""
-    monkeypatch.setenv("ASEP_SPLIT_L0", "1")
-    from citlab_article_separation_new_amd import net_post_processing_helper as helper
-    from oracle import aru_oracle
-    cfg, w, graph = _setup()
-    img = _image(H, W, 5)
-    ref, inter = aru_oracle.forward_torch(img, w, cfg, return_intermediates=True)
-    out = helper.get_net_output(img, graph, "0")
-    _check_endpoints(helper, graph, inter)
-    assert float(np.abs(out - ref).max()) <= PROB_TOL
-    graph.close()
-
-
-def test_the_bf16_option_is_untouched_by_the_switch(monkeypatch):
-    """ASEP_F32_SPLIT is an fp32 switch: a bf16 model keeps its own kernels"""
-    monkeypatch.setenv("ASEP_F32_SPLIT", "1")
+def test_f32s_is_the_default_arithmetic_of_an_fp32_model():
+    """AruConfig() selects compute_dtype "f32s" since round 5 (the fp32 engine's default); "f32" selects the plain fp32 kernels, and the two
+    really are different kernels (outputs within the agreement gate, not identical)"""
     from citlab_article_separation_new_amd import net_post_processing_helper as helper
     from citlab_article_separation_new_amd.config import AruConfig
     from citlab_article_separation_new_amd.weights import init_aru_weights
-    cfg = AruConfig(compute_dtype="bf16")
-    w = init_aru_weights(cfg, 1234, bias_jitter=0.05, logit_scale=0.05)
-    g = helper.AruGraph(w, cfg)
-    img = _image(64, 80, 1)
-    a = helper.get_net_output(img, g, "0")
-    g.close()
-    monkeypatch.delenv("ASEP_F32_SPLIT")
-    g2 = helper.AruGraph(w, cfg)
-    assert np.array_equal(a, helper.get_net_output(img, g2, "0"))
-    g2.close()
+    assert AruConfig().compute_dtype == "f32s"
+    w = init_aru_weights(AruConfig(), 5, bias_jitter=0.05, logit_scale=1.0)
+    gd, gs, gf = (helper.AruGraph(w, AruConfig(apply_softmax=False)), helper.AruGraph(w, AruConfig(apply_softmax=False, compute_dtype="f32s")),
+                  helper.AruGraph(w, AruConfig(apply_softmax=False, compute_dtype="f32")))
+    img = _image(150, 200, 3)
+    ld, ls, lf = (helper.get_net_output(img, g, "0") for g in (gd, gs, gf))
+    assert np.array_equal(ld, ls) and not np.array_equal(ls, lf)
+    assert float(np.abs(ls - lf).max()) / max(1.0, float(np.abs(lf).max())) <= AGREE_GATE
+    for g in (gd, gs, gf):
+        g.close()
