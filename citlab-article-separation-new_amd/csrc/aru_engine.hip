@@ -1329,8 +1329,12 @@ Tensor new_tensor_bf(asep_aru* m, int H, int W, int C) {
 
 // stride-1 SAME conv of the bf16 path.  pooled != nullptr: the epilogue also writes maxpool2 of the output (always fused here);
 // keep_full = false: only the pooled tensor is stored; pool_f32: the pooled tensor is fp32 (input of conv_c1out_kernel)
+// relu_out = true on an elu / leaky graph (cfg.activation != 0): the layer's activation is that function (ConvBArgs::act), applied to the
+// fp32 sums before the rounding; relu_out = false: identity (block-opening conv1)
 TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1, bool relu_in, bool relu_out, const TL* res,
              TL* pooled = nullptr, bool keep_full = true, bool pool_f32 = false) {
+    const int act = relu_out ? m->cfg.activation : 0;
+    if (act) relu_out = false;
     auto it = m->convs.find(scope);
     if (it == m->convs.end()) { set_error("internal: conv %s not packed", scope.c_str()); throw ArgError(); }
     const PackedConv& pc = it->second;
@@ -1378,7 +1382,7 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
         a.wpk = (const u32x4*)pc.d_wb; a.bias = pc.d_b;
         a.c0 = in0[0].C; a.c1 = in1 ? (*in1)[0].C : 0;
         a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = cin / 32;
-        a.relu_in = relu_in; a.relu_out = relu_out; a.skip_full = pooled && !keep_full; a.pool_f32 = pool_f32;
+        a.relu_in = relu_in; a.relu_out = relu_out; a.act = act; a.skip_full = pooled && !keep_full; a.pool_f32 = pool_f32;
         int units = tiles;
         a.xm = oneshot_map(m, tiles, &units);
         dim3 grid(units, pc.mtiles / mtb);
@@ -1478,6 +1482,8 @@ TL run_resb_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled)
 }
 
 TL run_deconvb(asep_aru* m, const std::string& scope, const TL& in, const TL& like, bool relu_out) {
+    const int act = relu_out ? m->cfg.activation : 0;        // (elu / leaky graphs: the deconvolution's activation, layers.py:342-367)
+    if (act) relu_out = false;
     auto it = m->convs.find(scope);
     if (it == m->convs.end()) { set_error("internal: deconv %s not packed", scope.c_str()); throw ArgError(); }
     const PackedConv& pc = it->second;
@@ -1514,7 +1520,7 @@ TL run_deconvb(asep_aru* m, const std::string& scope, const TL& in, const TL& li
         }
         a.nprob = (int)(b1 - b0);
         a.wpk = (const u32x4*)pc.d_wb; a.bias = pc.d_b;
-        a.cin = pc.cin; a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.cin / 32; a.relu_out = relu_out;
+        a.cin = pc.cin; a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.cin / 32; a.relu_out = relu_out; a.act = act;
         int units = tiles;
         a.xm = oneshot_map(m, tiles, &units);
         dim3 grid(units, pc.mtiles / mt);
@@ -1531,7 +1537,7 @@ TL run_deconvb(asep_aru* m, const std::string& scope, const TL& in, const TL& li
 }
 
 // first layer of the feature CNN on the bf16 path: fp32 image -> bf16 [H,W,8] (pre-ReLU t of unet_down_0)
-TL run_direct_bf(asep_aru* m, const DirectConv& dc, const TL& imgs, const std::vector<const float*>& stats) {
+TL run_direct_bf(asep_aru* m, const DirectConv& dc, const TL& imgs, const std::vector<const float*>& stats, bool activated = false) {
     if (dc.k != 3 || dc.cout != 8) { set_error("bf16 path: first-layer conv k=%d cout=%d not instantiated", dc.k, dc.cout); throw ArgError(); }
     TL out;
     for (const Tensor& t : imgs) out.push_back(new_tensor_bf(m, t.H, t.W, dc.cout));
@@ -1551,7 +1557,7 @@ TL run_direct_bf(asep_aru* m, const DirectConv& dc, const TL& imgs, const std::v
             flops += 2.0 * imgs[i].H * imgs[i].W * dc.k * dc.k * dc.cout;
         }
         a.nprob = (int)(b1 - b0);
-        a.w = dc.d_w; a.bias = dc.d_b; a.relu = 0;
+        a.w = dc.d_w; a.bias = dc.d_b; a.relu = (activated && m->cfg.activation == 0) ? 1 : 0; a.act = activated ? m->cfg.activation : 0;
         ProfScope ps(m, "conv_c1_kernel<3,8,true>", flops);
         ps.bytes = bytes;
         hipLaunchKernelGGL((conv_c1_kernel<3, 8, true>), dim3(tiles), dim3(256), 0, m->stream, a);
@@ -1668,6 +1674,15 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
             u = n > 1 ? pooled : d;
             continue;
         }
+        if (m->bf16 && m->cfg.plain_u) {                     // graph 'U' (ARU_v1.py:228-233): conv1 + conv2, both activated, layer by layer
+            TL c1 = (l == 0) ? run_direct_bf(m, m->det_first, imgs, stats, true) : run_convb(m, scope + "/conv1", u, nullptr, false, true, nullptr);
+            TL pooled;
+            TL d = run_convb(m, scope + "/conv2", c1, nullptr, false, true, nullptr, l < n - 1 ? &pooled : nullptr);
+            skips.push_back(d);
+            publish(d, "_unet_down_" + std::to_string(l) + "_conv");
+            u = (l < n - 1) ? pooled : d;
+            continue;
+        }
         if (m->bf16) {
             // native bf16 path: conv1 -> t (bf16), then the block tail (one kernel at 8 / 16 channels, three convs above)
             TL t = (l == 0) ? run_direct_bf(m, m->det_first, imgs, stats) : run_convb(m, scope + "/conv1", u, nullptr, false, false, nullptr);
@@ -1708,6 +1723,9 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
             TL d, none;                                      // conv1 over [skip, deconv] + the tail in one kernel
             run_res8b(m, true, skip, &v, {}, false, &d, &none);
             u = d;
+        } else if (m->bf16 && m->cfg.plain_u) {              // ARU_v1.py:283-288
+            TL c1 = run_convb(m, scope + "/conv1", skip, &v, false, true, nullptr);
+            u = run_convb(m, scope + "/conv2", c1, nullptr, false, true, nullptr);
         } else if (m->bf16) {
             TL t = run_convb(m, scope + "/conv1", skip, &v, false, false, nullptr);   // concat [skip, deconv]
             u = res_block_tail(m, scope, t);
@@ -1728,11 +1746,11 @@ TL det_cnn(asep_aru* m, const TL& imgs, const std::vector<std::string>& names, c
 TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) {
     const std::string p = "aru_net/attMapG/attPart/conv";
     TL y;
-    if (m->bf16 && !(m->d_att_head && m->use_fused8)) { set_error("bf16 path: attention head 4x4 / 12 channels expected"); throw ArgError(); }
+    if (m->bf16 && !m->d_att_head) { set_error("bf16 path: attention head 4x4 / 12 channels expected"); throw ArgError(); }
     // the fused head (conv1 + activation + pool, one pooled pixel per thread) also serves the elu / leaky variants (round 4): the pool
     // is taken on the pre-activation values, the activation on the maximum
     const bool head_variant = m->d_att_head && !m->use_fused8 && m->fused8_wanted && m->fuse_act && m->cfg.activation != 0 && m->r8_valu && !m->bf16;
-    if (m->d_att_head && (m->use_fused8 || head_variant)) {
+    if (m->d_att_head && (m->use_fused8 || head_variant || m->bf16)) {
         // conv1 + ReLU + pool1 fused (the full-resolution 12-channel tensor is never materialised)
         // (bf16 path: the head writes a 16-channel bf16 plane, channels 12..15 zero)
         for (const Tensor& t : imgs) y.push_back(m->bf16 ? new_tensor_bf(m, cdiv(t.H, 2), cdiv(t.W, 2), 16) : new_tensor(m, cdiv(t.H, 2), cdiv(t.W, 2), 12));
@@ -1774,7 +1792,7 @@ TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) 
         // the last pooled tensor (1/8 resolution, 32 channels) is written as fp32: conv4 is the fp32 vector-ALU kernel
         run_convb(m, p + "3", y, nullptr, false, true, nullptr, &pooled, /*keep_full=*/false, /*pool_f32=*/true);
         y = pooled;
-        return run_conv(m, p + "4", y, nullptr, false, true, nullptr);
+        return conv_act(m, p + "4", y, nullptr, false, true, nullptr);       // (fp32 vector-ALU kernel; the graph's activation)
     }
     conv_act(m, p + "2", y, nullptr, false, true, nullptr, &pooled, /*keep_full=*/false);   // conv + ReLU + pool in one kernel
     y = pooled;
@@ -2015,10 +2033,6 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (cfg->scale_space_num < 1 || cfg->res_depth < 1) { set_error("asep_aru_load: bad cfg"); return nullptr; }
     if (cfg->activation < 0 || cfg->activation > 2) { set_error("asep_aru_load: activation %d unknown (0 = relu, 1 = elu, 2 = leaky)", cfg->activation); return nullptr; }
     const bool variant = cfg->activation != 0 || cfg->plain_u != 0;
-    if (variant && cfg->compute_dtype == 1) {
-        set_error("asep_aru_load: the bf16 path serves the ReLU residual graphs (RU / ARU) only; load elu / leaky / 'U' nets with compute_dtype 0");
-        return nullptr;
-    }
     if (cfg->plain_u && cfg->use_attention) { set_error("asep_aru_load: graph 'U' has no attention branch (ARU_v1.py:92-97)"); return nullptr; }
     std::map<std::string, HostTensor> blob;
     if (!parse_blob(weight_blob, nbytes, blob)) return nullptr;
@@ -2087,8 +2101,10 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
             rc = pack_conv(m.get(), blob, s + "/convR_" + std::to_string(r), "biases", false);
     }
     if (!rc && (!variant || m->fused8_var) && !m->bf16 && cfg->feat_root == 8 && cfg->res_depth == 3 && m->det_first.k == 3) rc = pack_res8(m.get(), blob);
-    if (!rc && m->bf16 && cfg->res_depth == 3 && cfg->feat_root == 8) rc = pack_res8b(m.get(), blob);
-    if (!rc && m->bf16 && cfg->res_depth == 3)
+    // (bf16 path, elu / leaky / 'U' graphs -- round 5: layer by layer on convb_kernel / deconvb_kernel with the activation in their general
+    //  epilogues; the fused blocks below bake the ReLU into packed-bf16 maxima and serve the ReLU residual graphs)
+    if (!rc && m->bf16 && !variant && cfg->res_depth == 3 && cfg->feat_root == 8) rc = pack_res8b(m.get(), blob);
+    if (!rc && m->bf16 && !variant && cfg->res_depth == 3)
         for (int l = 0; l < n && !rc; ++l) {
             const int f = cfg->feat_root << l;
             if (f != 8 && f != 16 && !(f == 32 && m->use_res32)) continue;

@@ -74,6 +74,8 @@ struct ConvBArgs {
     int c0, c1;            // channels of in0 / in1 (multiples of 8)
     int cout, mtiles, groups;
     int relu_in, relu_out, skip_full, pool_f32;
+    int act;               // graph variants (asep_aru_cfg.activation; relu_out is 0 then): 1 = elu, 2 = leaky (0.1), applied to the fp32 sums before
+                           // the rounding to bf16 (round 5).  Such a launch takes the general epilogue; the ReLU graphs' fast one is untouched.
     XcdMap xm;             // XCD-aware block -> tile map (sched_tile)
 };
 
@@ -326,6 +328,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
             if constexpr (RESP) v += unpack_bf16x4(resv[m][n]);
             else if (P.res) v += unpack_bf16x4(*reinterpret_cast<const u32x2*>(P.res + p));
             if (a.relu_out) v = relu4(v);
+            else if (a.act) v = act4(v, a.act);
             // the pool takes its maximum over the ROUNDED values (what a separate pool kernel would read back)
             const u32x2 pk = pack_bf16x4(v);
             acc[m][n] = unpack_bf16x4(pk);
@@ -944,6 +947,7 @@ struct DeconvBArgs {
     const float* bias;
     int cin, cout, mtiles, groups;
     int relu_out;
+    int act;               // graph variants: 1 = elu, 2 = leaky on the fp32 sums (relu_out is 0 then)
     XcdMap xm;             // XCD-aware block -> tile map (sched_tile)
 };
 constexpr int DCB_TW = 16;                                    // input columns per block; rows: template parameter TH (8 or 16)
@@ -1092,6 +1096,7 @@ __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
             for (int cls = 0; cls < 4; ++cls) {
                 f32x4 v = acc[r][cls][m] + b4;
                 if (a.relu_out) v = relu4(v);
+                else if (a.act) v = act4(v, a.act);
                 // 16-byte unit S = pixel * UPP + channel quad pair, stored at S ^ ((pixel >> 1) & 7): the 16 lanes of a store (pixels
                 // 2 j + px, fixed channels) would otherwise be 64 / 128 bytes apart = 8- / 16-way bank conflicts (74 % of the LDS cycles)
                 const int orow = 2 * Yl + (cls >> 1), ocol = 2 * j + (cls & 1), pix = orow * 2 * DCB_TW + ocol;
