@@ -1212,7 +1212,10 @@ struct C1Args {
 template <int K, int COUT, bool OUTBF = false>
 __global__ __launch_bounds__(256) void conv_c1_kernel(const C1Args a) {
     __shared__ float sw[K * K * COUT + COUT];
-    for (int i = threadIdx.x; i < K * K * COUT; i += 256) sw[i] = a.w[i];
+    // OUTBF (first layer of a bf16 net outside the fused level-0 block): image and filter as bfloat16, like res8f_kernel / res8b_tile read them --
+    // the first layer of the bf16 data path is ONE function whichever kernel evaluates it (products of two bfloat16 are exact in fp32)
+    auto rbf = [](float v) { return OUTBF ? __uint_as_float(bf16x2_of(v, 0.f) << 16) : v; };
+    for (int i = threadIdx.x; i < K * K * COUT; i += 256) sw[i] = rbf(a.w[i]);
     for (int i = threadIdx.x; i < COUT; i += 256) sw[K * K * COUT + i] = a.bias[i];
     __syncthreads();
     int pi = 0;
@@ -1238,7 +1241,7 @@ __global__ __launch_bounds__(256) void conv_c1_kernel(const C1Args a) {
         for (int kx = 0; kx < K; ++kx) {
             const int gx = x + kx - PB;
             float v = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = (img[(size_t)gy * W + gx] - mean) * inv;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = rbf((img[(size_t)gy * W + gx] - mean) * inv);
 #pragma unroll
             for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v, sw[(ky * K + kx) * COUT + c], acc[c]);
         }

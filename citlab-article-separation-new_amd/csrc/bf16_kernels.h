@@ -1545,17 +1545,20 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
             const auto s1 = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
             return u32x4{s0[0], s1[0], s0[1], s1[1]};
         };
-        unsigned char* const d0 = r0 + (wave * W0 + c) * 16;
-        unsigned char* const dt = tc + ((wave - 3) * TW + c - 3) * 16;
+        // A pair = two ADJACENT rows (2 p, 2 p + 1), p = wave + 4 ii: their windows share two of three input rows, and with rB = rA + 1 written
+        // as a constant offset the compiler merges the identical fragment reads (8 ds_read_b128 per pair instead of 12; first cut: rows r, r + 4)
+        const int rl0 = 2 * wave + (isB ? 1 : 0);                   // the lane's row of pair `wave`
+        unsigned char* const d0 = r0 + (rl0 * W0 + c) * 16;
+        unsigned char* const dt = tc + ((rl0 - 3) * TW + c - 3) * 16;
 #pragma unroll
-        for (int i = 0; i < (H0 + 3) / 4; i += 2) {                 // rows wave + 4 i (A) and wave + 4 (i + 1) (B)
-            const int rA = wave + 4 * i, rB = rA + 4;
-            const u32x2 rawA = pack_bf16x4(conv1(rA, 2 * j)), rawB = pack_bf16x4(conv1(min(rB, H0 - 1), 2 * j));
-            const int r = isB ? rB : rA, off = isB ? (i + 1) * 4 : i * 4;
+        for (int ii = 0; ii < 3; ++ii) {                            // pairs wave, wave + 4, wave + 8 (pair 11 = rows 22, 23 does not exist: wave 3)
+            const int rA = ii < 2 ? 2 * wave + 8 * ii : min(2 * wave + 16, H0 - 2);
+            const u32x2 rawA = pack_bf16x4(conv1(rA, 2 * j)), rawB = pack_bf16x4(conv1(rA + 1, 2 * j));
+            const int r = rl0 + 8 * ii;
             const u32x4 raw = whole(rawA, rawB), rl = relu_bf16x8(raw);     // (ReLU of the traded record: two swaps per tile pair, not four)
-            if (r < H0) {
-                *reinterpret_cast<u32x4*>(d0 + off * W0 * 16) = rl;
-                if (r >= 3 && r < 3 + TH && c >= 3) *reinterpret_cast<u32x4*>(dt + off * TW * 16) = raw;
+            if (ii < 2 || r < H0) {
+                *reinterpret_cast<u32x4*>(d0 + ii * 8 * W0 * 16) = rl;
+                if (r >= 3 && r < 3 + TH && c >= 3) *reinterpret_cast<u32x4*>(dt + ii * 8 * TW * 16) = raw;
             }
         }
         {                                                           // 5 remainder tiles of 5 rows: tile wave (A), tile wave + 4 (B: wave 0 only)
@@ -1596,21 +1599,27 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     };
     {
         const f32x4 b4 = biasw[0];
-        const unsigned char* const sb = r0 + (wave * W0 + 2 * j + kk) * 16;
-        // 20 rows: 5 main tiles per wave (i = 0 .. 4) + 3 remainder tiles of 8 rows (columns 32 .. 35; waves 0 .. 2)
-        const int row = wave * 8 + rr2, rowc = min(row, H1 - 1), col = 32 + 2 * pc2;
-        const unsigned char* const sr = r0 + (rowc * W0 + col + kk) * 16;
-        unsigned char* const db = r1 + ((wave + (isB ? 4 : 0)) * W1 + c) * 16;          // the lane's tile of a pair: rows wave + 4 i / + 4 (i + 1)
+        // 20 rows = 10 pairs of adjacent rows (pairs wave, wave + 4 by every wave; 8, 9 by waves 0, 1) + 3 remainder tiles of 8 rows (columns
+        // 32 .. 35; tiles 0, 1 by wave 2, tile 2 by wave 3): three pair slots per wave
+        const unsigned char* const sb = r0 + (2 * wave * W0 + 2 * j + kk) * 16;
+        const int rl0 = 2 * wave + (isB ? 1 : 0);
+        unsigned char* const db = r1 + (rl0 * W1 + c) * 16;
         f32x4 va, vb;
 #pragma unroll
-        for (int i = 0; i < 4; i += 2) {
-            conv8x2(af, sb + i * 4 * W0 * 16, sb + (i + 1) * 4 * W0 * 16, W0 * 16, b4, va, vb);
-            *reinterpret_cast<u32x4*>(db + i * 4 * W1 * 16) = whole_relu(va, vb);
+        for (int ii = 0; ii < 2; ++ii) {
+            conv8x2(af, sb + ii * 8 * W0 * 16, sb + (ii * 8 + 1) * W0 * 16, W0 * 16, b4, va, vb);
+            *reinterpret_cast<u32x4*>(db + ii * 8 * W1 * 16) = whole_relu(va, vb);
         }
-        conv8x2(af, sb + 16 * W0 * 16, sr, W0 * 16, b4, va, vb);                            // A: row wave + 16; B: the remainder tile
+        const bool main3 = wave < 2;                                // (wave-uniform)
+        const int tl = (wave - 2) * 2, col = 32 + 2 * pc2;          // remainder tiles tl (A), tl + 1 (B)
+        const int rowA = min(tl * 8 + rr2, H1 - 1), rowB = min((tl + 1) * 8 + rr2, H1 - 1);
+        const unsigned char* const pa3 = main3 ? sb + 16 * W0 * 16 : r0 + (rowA * W0 + col + kk) * 16;
+        const unsigned char* const pb3 = main3 ? sb + 17 * W0 * 16 : r0 + (rowB * W0 + col + kk) * 16;
+        conv8x2(af, pa3, pb3, W0 * 16, b4, va, vb);
         const u32x4 rec = whole_relu(va, vb);
-        if (!isB) *reinterpret_cast<u32x4*>(r1 + ((wave + 16) * W1 + c) * 16) = rec;
-        else if (wave < 3 && row < H1) *reinterpret_cast<u32x4*>(r1 + (row * W1 + col + e) * 16) = rec;
+        const int trow = (tl + (isB ? 1 : 0)) * 8 + rr2;            // the lane's row of its remainder tile
+        if (main3) *reinterpret_cast<u32x4*>(db + 16 * W1 * 16) = rec;
+        else if (trow < H1 && tl + (isB ? 1 : 0) < 3) *reinterpret_cast<u32x4*>(r1 + (trow * W1 + col + e) * 16) = rec;
     }
     R8F_MARK(6);
     __syncthreads();
@@ -1620,21 +1629,26 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     {
         const f32x4 b4 = biasw[1];
         constexpr int HO = TH + 2;                            // 18 rows of 34: stage 2's result takes region 0's place (dead)
-        const unsigned char* const sb = r1 + (wave * W1 + 2 * j + kk) * 16;
-        unsigned char* const db = r0 + ((wave + (isB ? 4 : 0)) * W2 + c) * 16;
-        // 18 rows: 4 main tiles per wave + rows 16, 17 (waves 0, 1) + 2 remainder tiles of 16 rows (columns 32, 33; waves 2, 3):
-        // every wave has exactly one "fifth" tile (computed twice to keep the pair form; only the A lanes store it)
-        const int row = (wave - 2) * 16 + j, rowc = min(max(row, 0), HO - 1);
-        const unsigned char* const s5 = wave < 2 ? sb + 16 * W1 * 16 : r1 + (rowc * W1 + 32 + kk) * 16;
-        unsigned char* const d5 = wave < 2 ? r0 + ((wave + 16) * W2 + c) * 16 : r0 + (rowc * W2 + 32 + e) * 16;
+        // 18 rows = 9 pairs of adjacent rows (pairs wave, wave + 4 by every wave, pair 8 by wave 0) + 2 remainder tiles of 16 rows (columns 32,
+        // 33: one pair per row; both by wave 1)
+        const unsigned char* const sb = r1 + (2 * wave * W1 + 2 * j + kk) * 16;
+        const int rl0 = 2 * wave + (isB ? 1 : 0);
+        unsigned char* const db = r0 + (rl0 * W2 + c) * 16;
         f32x4 va, vb;
-        conv8x2(ag, sb, sb + 4 * W1 * 16, W1 * 16, b4, va, vb);
-        *reinterpret_cast<u32x4*>(db) = whole_relu(va, vb);
-        conv8x2(ag, sb + 8 * W1 * 16, sb + 12 * W1 * 16, W1 * 16, b4, va, vb);
-        *reinterpret_cast<u32x4*>(db + 8 * W2 * 16) = whole_relu(va, vb);
-        conv8x2(ag, s5, s5, W1 * 16, b4, va, vb);
-        const u32x4 rec = whole_relu(va, vb);
-        if (!isB && (wave < 2 || row < HO)) *reinterpret_cast<u32x4*>(d5) = rec;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            conv8x2(ag, sb + ii * 8 * W1 * 16, sb + (ii * 8 + 1) * W1 * 16, W1 * 16, b4, va, vb);
+            *reinterpret_cast<u32x4*>(db + ii * 8 * W2 * 16) = whole_relu(va, vb);
+        }
+        if (wave < 2) {                                       // (wave-uniform)
+            const int trow = (isB ? 16 : 0) + j;              // remainder tile 0: rows 0 .. 15, tile 1: rows 16, 17
+            const unsigned char* const pa3 = wave == 0 ? sb + 16 * W1 * 16 : r1 + (j * W1 + 32 + kk) * 16;
+            const unsigned char* const pb3 = wave == 0 ? sb + 17 * W1 * 16 : r1 + (min(16 + j, HO - 1) * W1 + 32 + kk) * 16;
+            conv8x2(ag, pa3, pb3, W1 * 16, b4, va, vb);
+            const u32x4 rec = whole_relu(va, vb);
+            if (wave == 0) *reinterpret_cast<u32x4*>(db + 16 * W2 * 16) = rec;
+            else if (trow < HO) *reinterpret_cast<u32x4*>(r0 + (trow * W2 + 32 + e) * 16) = rec;
+        }
     }
     R8F_MARK(8);
     __syncthreads();

@@ -338,8 +338,6 @@ def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermedia
             return t
         q = (lambda t: t.to(torch.bfloat16).to(dtype)) if emu else (lambda t: t)      # torch rounds to nearest even
         if emu:
-            if getattr(cfg, "activation_name", "relu") != "relu" or not getattr(cfg, "use_residual", True):
-                raise ValueError("the bf16 data path serves the ReLU residual graphs (RU / ARU) only")
             for k in list(tw):
                 bf_filter = (k.startswith("aru_net/featMapG/") or k.startswith("aru_net/attMapG/attPart/conv2")
                              or k.startswith("aru_net/attMapG/attPart/conv3"))
@@ -365,16 +363,20 @@ def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermedia
         else:
             raise ValueError(f"activation_name {act_name!r}")
 
+        # a stored tensor of the bf16 data path = round(activation(fp32 sums)): the engine applies the activation to the fp32 accumulators and
+        # rounds once (for ReLU the order does not matter -- rounding is monotone and keeps the sign --, for elu / leaky it does: round 5)
+        aq = lambda y: q(act(y))
+
         def block(x, p):
             if not getattr(cfg, "use_residual", True):       # graph 'U' (ARU_v1.py:228-233)
-                return act(conv(act(conv(x, p + "/conv1")), p + "/conv2"))
+                return aq(conv(aq(conv(x, p + "/conv1")), p + "/conv2"))
             t = q(conv(x, p + "/conv1"))
             r = F.relu(t)                                    # always a ReLU (ARU_v1.py:214)
             for a in range(cfg.res_depth):
                 r = conv(r, p + f"/convR_{a}")
                 if a < cfg.res_depth - 1:
-                    r = act(q(r))
-            return act(q(r + t))
+                    r = aq(r)
+            return aq(r + t)
 
         def det(x, sc):
             n = cfg.scale_space_num
@@ -387,19 +389,19 @@ def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermedia
             for l in range(n - 2, -1, -1):
                 p = f"aru_net/featMapG/unet_up_{l}"
                 skip = skips[l]
-                v = act(q(batch_norm(_t_deconv(u, tw[p + "/deconv/weights"], tw[p + "/deconv/bias"],
-                                               skip.shape[2:], cfg.pool_size, F, torch), p + "/deconv")))
+                v = aq(batch_norm(_t_deconv(u, tw[p + "/deconv/weights"], tw[p + "/deconv/bias"],
+                                            skip.shape[2:], cfg.pool_size, F, torch), p + "/deconv"))
                 v = force(f"scale_{sc}_unet_up_{l}_deconv", v)
                 u = force(f"scale_{sc}_unet_up_{l}_conv", block(torch.cat([skip, v], dim=1), p))
             return u
 
         def att(x):
             p = "aru_net/attMapG/attPart/conv"
-            y = act(q(conv(x, p + "1")))                     # (bf16 path: fp32 head, its pooled output stored as bfloat16)
+            y = aq(conv(x, p + "1"))                         # (bf16 path: fp32 head, its pooled output stored as bfloat16)
             y = F.max_pool2d(y, 2, 2, ceil_mode=True)
-            y = act(q(conv(y, p + "2")))
+            y = aq(conv(y, p + "2"))
             y = F.max_pool2d(y, 2, 2, ceil_mode=True)
-            y = act(q(conv(y, p + "3")))
+            y = aq(conv(y, p + "3"))
             y = F.max_pool2d(y, 2, 2, ceil_mode=True)
             return act(conv(y, p + "4"))
 
