@@ -1392,7 +1392,6 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
         const int key = pc.kh * 100 + pc.bmode * 10 + mtb + (th == 8 && mtb == 2 ? 1000 : 0) + (res && pc.bmode == 2 && pc.kh == 3 && mtb >= 2 ? 2000 : 0);
         switch (key) {
             case 3322: ASEP_CONVB_LAUNCH_RES(3, 3, 2, 2, 1, 8, 3); break;       // residual operand prefetched (32- and >= 64-channel convR_2)
-            case 2322: ASEP_CONVB_LAUNCH_RES(3, 3, 2, 2, 1, 16, 2); break;
             case 2324: ASEP_CONVB_LAUNCH_RES(3, 3, 2, 2, 2, 8, 2); break;       // (eight waves: 146 registers = one block per CU, 46 -> 52 us)
             case 1322: ASEP_CONVB_LAUNCH(3, 3, 2, 2, 1, 8, 4); break;
             case 301: ASEP_CONVB_LAUNCH(3, 3, 0, 1, 1, 16, 3); break;
@@ -1402,14 +1401,13 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
             case 312: ASEP_CONVB_LAUNCH(3, 3, 1, 2, 1, 16, 3); break;
             case 314: ASEP_CONVB_LAUNCH(3, 3, 1, 2, 2, 8, 3); break;
             case 321: ASEP_CONVB_LAUNCH(3, 3, 2, 1, 1, 16, 3); break;
-            case 322: ASEP_CONVB_LAUNCH(3, 3, 2, 2, 1, 16, 3); break;
             case 324: ASEP_CONVB_LAUNCH8(3, 3, 2, 2, 2, 8, 2, false); break;   // >= 64 channels: eight waves over the same LDS tile
             case 411: ASEP_CONVB_LAUNCH(4, 4, 1, 1, 1, 16, 3); break;
             case 412: ASEP_CONVB_LAUNCH(4, 4, 1, 2, 1, 16, 3); break;
             case 414: ASEP_CONVB_LAUNCH(4, 4, 1, 2, 2, 8, 3); break;
             case 421: ASEP_CONVB_LAUNCH(4, 4, 2, 1, 1, 16, 2); break;
             case 422: ASEP_CONVB_LAUNCH(4, 4, 2, 2, 1, 16, 2); break;
-            case 424: ASEP_CONVB_LAUNCH(4, 4, 2, 2, 2, 8, 2); break;
+            case 424: ASEP_CONVB_LAUNCH(4, 4, 2, 2, 2, 8, 1); break;       // (16 taps x 4 m-tiles of fragments: one block per CU is what its registers allow)
             default: set_error("conv %s: bf16 kernel variant %d not instantiated", scope.c_str(), key); throw ArgError();
         }
     }

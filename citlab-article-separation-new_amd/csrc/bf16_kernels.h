@@ -173,7 +173,9 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
     CVB_MARK(1);
     for (int g = 0; g < ngroups; ++g) {
         // ---- stage g: halo tile of 32 (16, 8) input channels + the stage's A fragments -> LDS.  Requests first; zero padding /
-        //      ReLU when the registers go to LDS ----
+        //      ReLU when the registers go to LDS.  (Requesting stage g + 1's tile behind the barrier that releases stage g's MFMAs -- the same
+        //      registers, dead while they run -- was measured in round 5: the 64- / 128-channel layers unchanged, two level-1 / 2 layers 4-7 %
+        //      slower; DESIGN_LESSONS 41) ----
         u32x4 st[NLOAD];
         {
             const int c = g * 32 + sub0;
@@ -181,13 +183,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
             const bf16_t* __restrict__ src = concat_src(P.in0, P.in1, c, a.c0);
             const int cs = from0 ? a.c0 : a.c1;
 #pragma unroll
-            for (int i = 0; i < NLOAD; ++i) {
-#if defined(CONVB_ABL) && (CONVB_ABL & 1)
-                st[i] = u32x4{(unsigned)spix[i], 0u, 0u, 0u};      // timing experiment: no halo loads
-#else
-                st[i] = *reinterpret_cast<const u32x4*>(src + (size_t)spix[i] * cs);
-#endif
-            }
+            for (int i = 0; i < NLOAD; ++i) st[i] = *reinterpret_cast<const u32x4*>(src + (size_t)spix[i] * cs);
         }
         if (g > 0) __syncthreads();                          // the previous stage's readers are done
         // A fragments: global -> LDS without registers (global_load_lds_dwordx4: one wave-instruction copies 1 KB, lane i to
@@ -195,11 +191,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
 #pragma unroll
         for (int i = 0; i < NWLOAD; ++i) {
             const int u0 = i * NTH + wave * 64;              // wave-uniform
-#if defined(CONVB_ABL) && (CONVB_ABL & 2)
-            if (false) {                                     // timing experiment: no weight copies
-#else
             if (u0 < NWU) {
-#endif
                 const int u = u0 + lane;
                 const int t = u / (MTB * 64), r = u - t * (MTB * 64);
                 const u32x4* gsrc = wsrc + (size_t)(g * CPS + t) * wstride + min(r, mt_have * 64 - 1);
