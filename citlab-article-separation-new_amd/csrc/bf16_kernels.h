@@ -1406,6 +1406,20 @@ __device__ unsigned long long g_r8f_trace[2][4096 * 12];
 #else
 #define R8F_MARK(i) do { } while (0)
 #endif
+// Ablation builds (make ABL=<bits>, never the product: scripts/r5_abl.sh): wrong results on purpose, to price one resource of the kernel at a time.
+//   1 stage fragment reads: one LDS read per tile instead of three   2 conv1 (UP) reads: one instead of six   4 no MFMAs (one v_add each)
+//   8 no lane trade / ReLU in the stage epilogues   16 conv1 (UP) reads with the stages' conflict-free address pattern
+#ifndef R8F_ABL
+#define R8F_ABL 0
+#endif
+__device__ __forceinline__ f32x4 r8f_mf(u32x4 a, u32x4 b, f32x4 c) {
+#if R8F_ABL & 4
+    c.x += __uint_as_float(b.x & 0x3f800000u) + __uint_as_float(a.x & 0x3f800000u);
+    return c;
+#else
+    return mfma_bf16_k32(a, b, c);
+#endif
+}
 template <bool UP>
 __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs a) {
     constexpr int TH = 16, TW = 32;
@@ -1513,16 +1527,26 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
         auto conv1 = [&](int row, int col) {
             f32x4 acc = b4;
             if constexpr (UP) {
+#if R8F_ABL & 16
+                const unsigned char* p = in + (row * IW * 32 + (col + kk) * 16);
+#else
                 const unsigned char* p = in + (row * IW * 32 + (col + (kk >> 1)) * 32 + (kk & 1) * 16);
+#endif
+#if R8F_ABL & 2
+                const u32x4 b0 = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) acc = r8f_mf(a1[t], b0, acc);
+#else
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) acc = mfma_bf16_k32(a1[ky * 2 + hf], *reinterpret_cast<const u32x4*>(p + (ky * IW + 2 * hf) * 32), acc);
+                    for (int hf = 0; hf < 2; ++hf) acc = r8f_mf(a1[ky * 2 + hf], *reinterpret_cast<const u32x4*>(p + (ky * IW + 2 * hf) * 32), acc);
+#endif
             } else {
                 // k = 8 kk + jj: lane group kk holds window rows 2 kk, 2 kk + 1 (jj >> 2), columns jj & 3 (groups 2, 3: zero weights)
                 const unsigned* p = reinterpret_cast<const unsigned*>(in + ((row + 2 * (kk & 1)) * IW + col) * 2);
                 const u32x4 b = u32x4{p[0], p[1], p[IW / 2], p[IW / 2 + 1]};
-                acc = mfma_bf16_k32(a1[0], b, acc);
+                acc = r8f_mf(a1[0], b, acc);
             }
             return acc;
         };
@@ -1576,15 +1600,22 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     auto conv8x2 = [&](const u32x4 (&af)[3], const unsigned char* pa, const unsigned char* pb, int pitch, f32x4 c0, f32x4& ra, f32x4& rb) {
         u32x4 fa[3], fb[3];
 #pragma unroll
+#if R8F_ABL & 1
+        for (int ky = 0; ky < 3; ++ky) { fa[ky] = *reinterpret_cast<const u32x4*>(pa); fb[ky] = *reinterpret_cast<const u32x4*>(pb); }
+#else
         for (int ky = 0; ky < 3; ++ky) { fa[ky] = *reinterpret_cast<const u32x4*>(pa + ky * pitch); fb[ky] = *reinterpret_cast<const u32x4*>(pb + ky * pitch); }
+#endif
         ra = c0; rb = c0;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) { ra = mfma_bf16_k32(af[ky], fa[ky], ra); rb = mfma_bf16_k32(af[ky], fb[ky], rb); }
+        for (int ky = 0; ky < 3; ++ky) { ra = r8f_mf(af[ky], fa[ky], ra); rb = r8f_mf(af[ky], fb[ky], rb); }
     };
     const bool isB = kk & 1;
     // ReLU'd whole-pixel record of the lane's tile of a pair (see conv1)
     auto whole_relu = [&](f32x4 va, f32x4 vb) {
         const u32x2 pa = relu_pk(pack_bf16x4(va)), pb = relu_pk(pack_bf16x4(vb));
+#if R8F_ABL & 8
+        return u32x4{pa.x, pa.y, pb.x, pb.y};
+#endif
         const auto s0 = __builtin_amdgcn_permlane16_swap(pa.x, pb.x, false, false);
         const auto s1 = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
         return u32x4{s0[0], s1[0], s0[1], s1[1]};
