@@ -1406,20 +1406,6 @@ __device__ unsigned long long g_r8f_trace[2][4096 * 12];
 #else
 #define R8F_MARK(i) do { } while (0)
 #endif
-// Ablation builds (make ABL=<bits>, never the product: scripts/r5_abl.sh): wrong results on purpose, to price one resource of the kernel at a time.
-//   1 stage fragment reads: one LDS read per tile instead of three   2 conv1 (UP) reads: one instead of six   4 no MFMAs (one v_add each)
-//   8 no lane trade / ReLU in the stage epilogues   16 conv1 (UP) reads with the stages' conflict-free address pattern
-#ifndef R8F_ABL
-#define R8F_ABL 0
-#endif
-__device__ __forceinline__ f32x4 r8f_mf(u32x4 a, u32x4 b, f32x4 c) {
-#if R8F_ABL & 4
-    c.x += __uint_as_float(b.x & 0x3f800000u) + __uint_as_float(a.x & 0x3f800000u);
-    return c;
-#else
-    return mfma_bf16_k32(a, b, c);
-#endif
-}
 template <bool UP>
 __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs a) {
     constexpr int TH = 16, TW = 32;
@@ -1520,106 +1506,108 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
 #pragma unroll
     for (int t = 0; t < 3; ++t) ag[t] = wl[(3 + t) * 64];
 
+    // ---- Every phase below is SOFTWARE-PIPELINED over its pair slots (round 5): a slot = two tiles = its fragment reads, 6 (conv1 UP: 12) MFMAs, the
+    //      epilogue (round, ReLU, lane trade, one 16-byte store).  Written slot by slot, the compiler must keep slot s + 1's LDS reads behind slot
+    //      s's LDS stores (it cannot see that source and destination regions differ), so a wave ran read -> wait -> MFMAs -> wait -> epilogue ->
+    //      store, and only the other waves of the SIMD covered its latencies (ISA of the first cut: two exposed LDS round trips and 10-20 cycles
+    //      of s_nop behind the MFMAs per slot).  Here the reads of slot s + 1 are issued BEFORE the MFMAs of slot s and the epilogue of slot s - 1
+    //      stands beside the MFMAs of slot s: simple vector instructions hide under a bf16 MFMA of the same wave, two to three per MFMA
+    //      (scripts/ubench/bf16mfma_epilogue_coissue.hip).  Source and destination of every phase are different LDS regions. ----
+    const bool isB = kk & 1;
+    // the lane's whole-pixel record of a tile pair: a lane holds 4 of its pixel's 8 channels, the other 4 sit in lane ^ 16; v_permlane16_swap
+    // trades them so that lanes kk = 0 / 2 hold the whole pixel of tile A and lanes kk = 1 / 3 that of tile B -- ONE ds_write_b128 per lane and
+    // pair instead of two ds_write_b64 whose 16 lanes sat 32 bytes apart (4-way bank conflicts)
+    auto whole = [&](u32x2 pa, u32x2 pb) {
+        const auto s0 = __builtin_amdgcn_permlane16_swap(pa.x, pb.x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
+        return u32x4{s0[0], s1[0], s0[1], s1[1]};
+    };
+
     // ---- conv1: relu(t) over the 22 x 38 region (r0), raw t of the centre 16 x 32 (tc) ----
     {
-        const f32x4 b4 = bias1;
-        // window of the pair whose first pixel is (row, col) of region 0 = input-tile pixels (row .. row + 2, col .. col + 3)
-        auto conv1 = [&](int row, int col) {
-            f32x4 acc = b4;
+        constexpr int NF = UP ? 6 : 1;
+        struct C1F { u32x4 a[NF], b[NF]; };
+        // fragments of the pairs whose first pixels are (rowA, colA) / (rowB, colB) of region 0 = input-tile pixels (row .. row + 2, col .. col + 3)
+        auto c1_load = [&](C1F& f, int rowA, int colA, int rowB, int colB) {
             if constexpr (UP) {
-#if R8F_ABL & 16
-                const unsigned char* p = in + (row * IW * 32 + (col + kk) * 16);
-#else
-                const unsigned char* p = in + (row * IW * 32 + (col + (kk >> 1)) * 32 + (kk & 1) * 16);
-#endif
-#if R8F_ABL & 2
-                const u32x4 b0 = *reinterpret_cast<const u32x4*>(p);
-#pragma unroll
-                for (int t = 0; t < 6; ++t) acc = r8f_mf(a1[t], b0, acc);
-#else
+                const unsigned char* pa = in + (rowA * IW * 32 + (colA + (kk >> 1)) * 32 + (kk & 1) * 16);
+                const unsigned char* pb = in + (rowB * IW * 32 + (colB + (kk >> 1)) * 32 + (kk & 1) * 16);
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) acc = r8f_mf(a1[ky * 2 + hf], *reinterpret_cast<const u32x4*>(p + (ky * IW + 2 * hf) * 32), acc);
-#endif
+                    for (int hf = 0; hf < 2; ++hf) {
+                        f.a[ky * 2 + hf] = *reinterpret_cast<const u32x4*>(pa + (ky * IW + 2 * hf) * 32);
+                        f.b[ky * 2 + hf] = *reinterpret_cast<const u32x4*>(pb + (ky * IW + 2 * hf) * 32);
+                    }
             } else {
                 // k = 8 kk + jj: lane group kk holds window rows 2 kk, 2 kk + 1 (jj >> 2), columns jj & 3 (groups 2, 3: zero weights)
-                const unsigned* p = reinterpret_cast<const unsigned*>(in + ((row + 2 * (kk & 1)) * IW + col) * 2);
-                const u32x4 b = u32x4{p[0], p[1], p[IW / 2], p[IW / 2 + 1]};
-                acc = r8f_mf(a1[0], b, acc);
+                const unsigned* pa = reinterpret_cast<const unsigned*>(in + ((rowA + 2 * (kk & 1)) * IW + colA) * 2);
+                const unsigned* pb = reinterpret_cast<const unsigned*>(in + ((rowB + 2 * (kk & 1)) * IW + colB) * 2);
+                f.a[0] = u32x4{pa[0], pa[1], pa[IW / 2], pa[IW / 2 + 1]};
+                f.b[0] = u32x4{pb[0], pb[1], pb[IW / 2], pb[IW / 2 + 1]};
             }
-            return acc;
         };
-        // Tiles are processed in PAIRS (A, B), and their results leave as WHOLE pixels: a lane holds 4 of its pixel's 8 channels,
-        // the other 4 sit in lane ^ 16; v_permlane16_swap trades them so that lanes kk = 0 / 2 hold the whole pixel of tile A and
-        // lanes kk = 1 / 3 the whole pixel of tile B: ONE ds_write_b128 per lane and tile pair instead of two ds_write_b64 whose
-        // 16 lanes of a store group sat 32 bytes apart (4-way bank conflicts: SQ_LDS_BANK_CONFLICT was 52 % of the LDS cycles and
-        // the LDS 70 % busy).  (per-lane base pointers + compile-time offsets: the addresses of the unrolled tiles are immediates)
-        const bool isB = kk & 1;
-        auto whole = [&](u32x2 pa, u32x2 pb) {                      // -> the lane's pixel record (tile A's for even kk, B's for odd)
-            const auto s0 = __builtin_amdgcn_permlane16_swap(pa.x, pb.x, false, false);
-            const auto s1 = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
-            return u32x4{s0[0], s1[0], s0[1], s1[1]};
+        auto c1_mm = [&](const C1F& f, f32x4& ra, f32x4& rb) {
+            ra = bias1; rb = bias1;
+#pragma unroll
+            for (int t = 0; t < NF; ++t) { ra = mfma_bf16_k32(a1[t], f.a[t], ra); rb = mfma_bf16_k32(a1[t], f.b[t], rb); }
         };
-        // A pair = two ADJACENT rows (2 p, 2 p + 1), p = wave + 4 ii: their windows share two of three input rows, and with rB = rA + 1 written
-        // as a constant offset the compiler merges the identical fragment reads (8 ds_read_b128 per pair instead of 12; first cut: rows r, r + 4)
+        // A main pair = two ADJACENT rows (2 p, 2 p + 1), p = wave + 4 ii, columns 0 .. 31: their windows share two of three input rows (the
+        // identical fragment reads are merged: 8 ds_read_b128 per pair instead of 12); pair 11 = rows 22, 23 does not exist (wave 3, ii = 2)
         const int rl0 = 2 * wave + (isB ? 1 : 0);                   // the lane's row of pair `wave`
         unsigned char* const d0 = r0 + (rl0 * W0 + c) * 16;
         unsigned char* const dt = tc + ((rl0 - 3) * TW + c - 3) * 16;
-#pragma unroll
-        for (int ii = 0; ii < 3; ++ii) {                            // pairs wave, wave + 4, wave + 8 (pair 11 = rows 22, 23 does not exist: wave 3)
-            const int rA = ii < 2 ? 2 * wave + 8 * ii : min(2 * wave + 16, H0 - 2);
-            const u32x2 rawA = pack_bf16x4(conv1(rA, 2 * j)), rawB = pack_bf16x4(conv1(rA + 1, 2 * j));
+        auto c1_store_main = [&](f32x4 va, f32x4 vb, int ii) {
+            const u32x4 raw = whole(pack_bf16x4(va), pack_bf16x4(vb)), rl = relu_bf16x8(raw);   // (ReLU of the traded record: two swaps per pair, not four)
             const int r = rl0 + 8 * ii;
-            const u32x4 raw = whole(rawA, rawB), rl = relu_bf16x8(raw);     // (ReLU of the traded record: two swaps per tile pair, not four)
             if (ii < 2 || r < H0) {
                 *reinterpret_cast<u32x4*>(d0 + ii * 8 * W0 * 16) = rl;
                 if (r >= 3 && r < 3 + TH && c >= 3) *reinterpret_cast<u32x4*>(dt + ii * 8 * TW * 16) = raw;
             }
-        }
-        {                                                           // 5 remainder tiles of 5 rows: tile wave (A), tile wave + 4 (B: wave 0 only)
-            const int tA = wave, tB = wave + 4;
-            const int rowA = tA * 5 + rr3, rowB = tB * 5 + rr3, col = 32 + 2 * pc3;
-            const u32x2 rawA = pack_bf16x4(conv1(min(rowA, H0 - 1), col)), rawB = pack_bf16x4(conv1(min(rowB, H0 - 1), col));
-            const int row = isB ? rowB : rowA;
-            const u32x4 raw = whole(rawA, rawB), rl = relu_bf16x8(raw);
+        };
+        // 5 remainder tiles of 5 rows (columns 32 .. 37: 3 pairs per row): tile wave (A), tile wave + 4 (B: wave 0 only)
+        const int rowA3 = wave * 5 + rr3, rowB3 = (wave + 4) * 5 + rr3, col3 = 32 + 2 * pc3;
+        auto c1_store_rem = [&](f32x4 va, f32x4 vb) {
+            const u32x4 raw = whole(pack_bf16x4(va), pack_bf16x4(vb)), rl = relu_bf16x8(raw);
+            const int row = isB ? rowB3 : rowA3;
             if (row < H0 && j3 < 5) {
-                *reinterpret_cast<u32x4*>(r0 + (row * W0 + col + e) * 16) = rl;
-                if (row >= 3 && row < 3 + TH && col + e < 3 + TW) *reinterpret_cast<u32x4*>(tc + ((row - 3) * TW + col + e - 3) * 16) = raw;
+                *reinterpret_cast<u32x4*>(r0 + (row * W0 + col3 + e) * 16) = rl;
+                if (row >= 3 && row < 3 + TH && col3 + e < 3 + TW) *reinterpret_cast<u32x4*>(tc + ((row - 3) * TW + col3 + e - 3) * 16) = raw;
             }
-        }
+        };
+        const int rA2 = min(2 * wave + 16, H0 - 2);
+        C1F f0, f1;
+        f32x4 va0, vb0, va1, vb1;
+        c1_load(f0, 2 * wave, 2 * j, 2 * wave + 1, 2 * j);
+        c1_load(f1, 2 * wave + 8, 2 * j, 2 * wave + 9, 2 * j);
+        c1_mm(f0, va0, vb0);
+        c1_load(f0, rA2, 2 * j, rA2 + 1, 2 * j);
+        c1_mm(f1, va1, vb1);
+        c1_store_main(va0, vb0, 0);
+        c1_load(f1, min(rowA3, H0 - 1), col3, min(rowB3, H0 - 1), col3);
+        c1_mm(f0, va0, vb0);
+        c1_store_main(va1, vb1, 1);
+        c1_mm(f1, va1, vb1);
+        c1_store_main(va0, vb0, 2);
+        c1_store_rem(va1, vb1);
     }
     R8F_MARK(4);
     __syncthreads();
     R8F_MARK(5);
 
-    // ---- stages 1 and 2 (LDS -> LDS): main tile = row r, columns 0 .. 31; remainder tiles = columns 32 .. WO - 1 of 16 / PR rows.
-    //      Tiles are processed in PAIRS: both tiles' fragment reads first, their MFMAs interleaved (two independent accumulator
-    //      chains), both epilogues -- written tile by tile the compiler serialises read -> wait -> MFMA chain -> epilogue per tile
-    //      and a wave has nothing to overlap its LDS / MFMA latencies with ----
-    auto conv8x2 = [&](const u32x4 (&af)[3], const unsigned char* pa, const unsigned char* pb, int pitch, f32x4 c0, f32x4& ra, f32x4& rb) {
-        u32x4 fa[3], fb[3];
+    // ---- stages 1 and 2 (LDS -> LDS): main tile = row r, columns 0 .. 31; remainder tiles = columns 32 .. WO - 1 of 16 / PR rows ----
+    struct SF { u32x4 a[3], b[3]; };
+    auto st_load = [&](SF& f, const unsigned char* pa, const unsigned char* pb, int pitch) {
 #pragma unroll
-#if R8F_ABL & 1
-        for (int ky = 0; ky < 3; ++ky) { fa[ky] = *reinterpret_cast<const u32x4*>(pa); fb[ky] = *reinterpret_cast<const u32x4*>(pb); }
-#else
-        for (int ky = 0; ky < 3; ++ky) { fa[ky] = *reinterpret_cast<const u32x4*>(pa + ky * pitch); fb[ky] = *reinterpret_cast<const u32x4*>(pb + ky * pitch); }
-#endif
+        for (int ky = 0; ky < 3; ++ky) { f.a[ky] = *reinterpret_cast<const u32x4*>(pa + ky * pitch); f.b[ky] = *reinterpret_cast<const u32x4*>(pb + ky * pitch); }
+    };
+    auto st_mm = [&](const u32x4 (&w)[3], const SF& f, f32x4 c0, f32x4& ra, f32x4& rb) {
         ra = c0; rb = c0;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) { ra = r8f_mf(af[ky], fa[ky], ra); rb = r8f_mf(af[ky], fb[ky], rb); }
+        for (int ky = 0; ky < 3; ++ky) { ra = mfma_bf16_k32(w[ky], f.a[ky], ra); rb = mfma_bf16_k32(w[ky], f.b[ky], rb); }
     };
-    const bool isB = kk & 1;
-    // ReLU'd whole-pixel record of the lane's tile of a pair (see conv1)
-    auto whole_relu = [&](f32x4 va, f32x4 vb) {
-        const u32x2 pa = relu_pk(pack_bf16x4(va)), pb = relu_pk(pack_bf16x4(vb));
-#if R8F_ABL & 8
-        return u32x4{pa.x, pa.y, pb.x, pb.y};
-#endif
-        const auto s0 = __builtin_amdgcn_permlane16_swap(pa.x, pb.x, false, false);
-        const auto s1 = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
-        return u32x4{s0[0], s1[0], s0[1], s1[1]};
-    };
+    // ReLU'd whole-pixel record of the lane's tile of a pair (ReLU on the packed values: one v_pk_max_i16 per two)
+    auto whole_relu = [&](f32x4 va, f32x4 vb) { return whole(relu_pk(pack_bf16x4(va)), relu_pk(pack_bf16x4(vb))); };
     {
         const f32x4 b4 = biasw[0];
         // 20 rows = 10 pairs of adjacent rows (pairs wave, wave + 4 by every wave; 8, 9 by waves 0, 1) + 3 remainder tiles of 8 rows (columns
@@ -1627,22 +1615,26 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
         const unsigned char* const sb = r0 + (2 * wave * W0 + 2 * j + kk) * 16;
         const int rl0 = 2 * wave + (isB ? 1 : 0);
         unsigned char* const db = r1 + (rl0 * W1 + c) * 16;
-        f32x4 va, vb;
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            conv8x2(af, sb + ii * 8 * W0 * 16, sb + (ii * 8 + 1) * W0 * 16, W0 * 16, b4, va, vb);
-            *reinterpret_cast<u32x4*>(db + ii * 8 * W1 * 16) = whole_relu(va, vb);
-        }
         const bool main3 = wave < 2;                                // (wave-uniform)
         const int tl = (wave - 2) * 2, col = 32 + 2 * pc2;          // remainder tiles tl (A), tl + 1 (B)
         const int rowA = min(tl * 8 + rr2, H1 - 1), rowB = min((tl + 1) * 8 + rr2, H1 - 1);
         const unsigned char* const pa3 = main3 ? sb + 16 * W0 * 16 : r0 + (rowA * W0 + col + kk) * 16;
         const unsigned char* const pb3 = main3 ? sb + 17 * W0 * 16 : r0 + (rowB * W0 + col + kk) * 16;
-        conv8x2(af, pa3, pb3, W0 * 16, b4, va, vb);
-        const u32x4 rec = whole_relu(va, vb);
         const int trow = (tl + (isB ? 1 : 0)) * 8 + rr2;            // the lane's row of its remainder tile
-        if (main3) *reinterpret_cast<u32x4*>(db + 16 * W1 * 16) = rec;
-        else if (trow < H1 && tl + (isB ? 1 : 0) < 3) *reinterpret_cast<u32x4*>(r1 + (trow * W1 + col + e) * 16) = rec;
+        unsigned char* const d3 = main3 ? db + 16 * W1 * 16 : r1 + (trow * W1 + col + e) * 16;
+        const bool st3 = main3 || (trow < H1 && tl + (isB ? 1 : 0) < 3);
+        SF f0, f1;
+        f32x4 va0, vb0, va1, vb1;
+        st_load(f0, sb, sb + W0 * 16, W0 * 16);
+        st_load(f1, sb + 8 * W0 * 16, sb + 9 * W0 * 16, W0 * 16);
+        st_mm(af, f0, b4, va0, vb0);
+        st_load(f0, pa3, pb3, W0 * 16);
+        st_mm(af, f1, b4, va1, vb1);
+        *reinterpret_cast<u32x4*>(db) = whole_relu(va0, vb0);
+        st_mm(af, f0, b4, va0, vb0);
+        *reinterpret_cast<u32x4*>(db + 8 * W1 * 16) = whole_relu(va1, vb1);
+        const u32x4 rec = whole_relu(va0, vb0);
+        if (st3) *reinterpret_cast<u32x4*>(d3) = rec;
     }
     R8F_MARK(6);
     __syncthreads();
@@ -1653,24 +1645,30 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
         const f32x4 b4 = biasw[1];
         constexpr int HO = TH + 2;                            // 18 rows of 34: stage 2's result takes region 0's place (dead)
         // 18 rows = 9 pairs of adjacent rows (pairs wave, wave + 4 by every wave, pair 8 by wave 0) + 2 remainder tiles of 16 rows (columns 32,
-        // 33: one pair per row; both by wave 1)
+        // 33: one pair per row; both by wave 1): waves 0, 1 have a third slot
         const unsigned char* const sb = r1 + (2 * wave * W1 + 2 * j + kk) * 16;
         const int rl0 = 2 * wave + (isB ? 1 : 0);
         unsigned char* const db = r0 + (rl0 * W2 + c) * 16;
-        f32x4 va, vb;
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            conv8x2(ag, sb + ii * 8 * W1 * 16, sb + (ii * 8 + 1) * W1 * 16, W1 * 16, b4, va, vb);
-            *reinterpret_cast<u32x4*>(db + ii * 8 * W2 * 16) = whole_relu(va, vb);
-        }
-        if (wave < 2) {                                       // (wave-uniform)
-            const int trow = (isB ? 16 : 0) + j;              // remainder tile 0: rows 0 .. 15, tile 1: rows 16, 17
-            const unsigned char* const pa3 = wave == 0 ? sb + 16 * W1 * 16 : r1 + (j * W1 + 32 + kk) * 16;
-            const unsigned char* const pb3 = wave == 0 ? sb + 17 * W1 * 16 : r1 + (min(16 + j, HO - 1) * W1 + 32 + kk) * 16;
-            conv8x2(ag, pa3, pb3, W1 * 16, b4, va, vb);
-            const u32x4 rec = whole_relu(va, vb);
-            if (wave == 0) *reinterpret_cast<u32x4*>(db + 16 * W2 * 16) = rec;
-            else if (trow < HO) *reinterpret_cast<u32x4*>(r0 + (trow * W2 + 32 + e) * 16) = rec;
+        const int trow = (isB ? 16 : 0) + j;                  // remainder tile 0: rows 0 .. 15, tile 1: rows 16, 17
+        const unsigned char* const pa3 = wave == 0 ? sb + 16 * W1 * 16 : r1 + (j * W1 + 32 + kk) * 16;
+        const unsigned char* const pb3 = wave == 0 ? sb + 17 * W1 * 16 : r1 + (min(16 + j, HO - 1) * W1 + 32 + kk) * 16;
+        unsigned char* const d3 = wave == 0 ? db + 16 * W2 * 16 : r0 + (trow * W2 + 32 + e) * 16;
+        const bool st3 = wave == 0 || trow < HO;
+        SF f0, f1;
+        f32x4 va0, vb0, va1, vb1;
+        st_load(f0, sb, sb + W1 * 16, W1 * 16);
+        st_load(f1, sb + 8 * W1 * 16, sb + 9 * W1 * 16, W1 * 16);
+        st_mm(ag, f0, b4, va0, vb0);
+        if (wave < 2) st_load(f0, pa3, pb3, W1 * 16);         // (wave-uniform)
+        st_mm(ag, f1, b4, va1, vb1);
+        *reinterpret_cast<u32x4*>(db) = whole_relu(va0, vb0);
+        if (wave < 2) {
+            st_mm(ag, f0, b4, va0, vb0);
+            *reinterpret_cast<u32x4*>(db + 8 * W2 * 16) = whole_relu(va1, vb1);
+            const u32x4 rec = whole_relu(va0, vb0);
+            if (st3) *reinterpret_cast<u32x4*>(d3) = rec;
+        } else {
+            *reinterpret_cast<u32x4*>(db + 8 * W2 * 16) = whole_relu(va1, vb1);
         }
     }
     R8F_MARK(8);
@@ -1688,15 +1686,19 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
         const unsigned poff = (((unsigned)((y0 >> 1) + wave) * (unsigned)Wp + (unsigned)((x0 >> 1) + j)) * 8u + (unsigned)ch) * 2u, prow = (unsigned)Wp * 16u;
         const unsigned char* const sb = r0 + (2 * wave * W2 + 2 * j + kk) * 16;
         const unsigned char* const tb = tc + (2 * wave * TW + c) * 16 + ch * 2;
+        SF f0, f1;
+        u32x2 t0[2], t1[2];                                   // the residual operand (raw t) of the two slots' rows
+        f32x4 v0[2], v1[2];
+        st_load(f0, sb, sb + W2 * 16, W2 * 16);
+        st_load(f1, sb + 8 * W2 * 16, sb + 9 * W2 * 16, W2 * 16);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f32x4 v2[2];
-            conv8x2(af, sb + 8 * i * W2 * 16, sb + (8 * i + 1) * W2 * 16, W2 * 16, b4, v2[0], v2[1]);
+        for (int r = 0; r < 2; ++r) { t0[r] = *reinterpret_cast<const u32x2*>(tb + r * TW * 16); t1[r] = *reinterpret_cast<const u32x2*>(tb + (8 + r) * TW * 16); }
+        auto finish = [&](const f32x4 (&v2)[2], const u32x2 (&tr)[2], int i) {
             u32x2 pk[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 // ReLU after the rounding: one v_pk_max_i16 per two values
-                pk[r] = relu_pk(pack_bf16x4(v2[r] + unpack_bf16x4(*reinterpret_cast<const u32x2*>(tb + (8 * i + r) * TW * 16))));
+                pk[r] = relu_pk(pack_bf16x4(v2[r] + unpack_bf16x4(tr[r])));
                 *reinterpret_cast<u32x2*>(outb + (ooff + (unsigned)(8 * i + r) * orow)) = pk[r];
             }
             if (P.pool) {
@@ -1708,7 +1710,11 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
                 const auto s1 = __builtin_amdgcn_permlane32_swap(m1, m1, false, false);
                 if (e == 0) *reinterpret_cast<u32x2*>(poolb + (poff + (unsigned)(4 * i) * prow)) = u32x2{pkmax_u16(s0[0], s0[1]), pkmax_u16(s1[0], s1[1])};
             }
-        }
+        };
+        st_mm(af, f0, b4, v0[0], v0[1]);
+        st_mm(af, f1, b4, v1[0], v1[1]);
+        finish(v0, t0, 0);
+        finish(v1, t1, 1);
     }
     R8F_MARK(10);
 #if defined(R8F_TRACE)
