@@ -1821,11 +1821,11 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
             level0.push_back(img);
             const float* st = nullptr;
             if (cfg.mvn) {
-                double* sums = (double*)L.pool.get(2 * sizeof(double));
+                const int nparts = grid_1d((img.count() + 3) / 4);        // 16-byte loads: a thread takes four values per step
+                double* sums = (double*)L.pool.get(2 * (size_t)nparts * sizeof(double));
                 float* stt = (float*)L.pool.get(2 * sizeof(float));
-                ASEP_HIP_CHECK(hipMemsetAsync(sums, 0, 2 * sizeof(double), stream));
-                hipLaunchKernelGGL(moments_kernel, dim3(grid_1d(img.count())), dim3(256), 0, stream, img.p, img.count(), sums);
-                hipLaunchKernelGGL(moments_finish_kernel, dim3(1), dim3(1), 0, stream, sums, img.count(), stt);
+                hipLaunchKernelGGL(moments_kernel, dim3(nparts), dim3(256), 0, stream, img.p, img.count(), sums);
+                hipLaunchKernelGGL(moments_finish_kernel, dim3(1), dim3(256), 0, stream, sums, nparts, img.count(), stt);
                 st = stt;
             }
             stats0.push_back(st);

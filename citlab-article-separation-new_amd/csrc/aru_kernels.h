@@ -1334,13 +1334,30 @@ __global__ __launch_bounds__(256) void att_head_kernel(const AttHeadArgs a) {
     (void)Hp;
 }
 
-// mean / E[x^2] partial sums for per-image standardisation (double accumulation on the host side)
+// mean / E[x^2] partial sums for per-image standardisation (double accumulation; the host side divides).  16-byte loads and four independent
+// accumulator pairs per thread: the first cut read one float per thread and iteration and ran at 1 TB/s (56 us for a 3000 x 4500 page, once per
+// page and step: 2.5 % of the bf16 step).
 __global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ x, size_t n, double* __restrict__ sums) {
     double s = 0.0, s2 = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const double v = x[i];
-        s += v;
-        s2 += v * v;
+    const size_t t0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x);
+        const size_t n4 = n >> 2;
+        double a[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+        for (size_t i = t0; i < n4; i += stride) {
+            const f32x4 v = x4[i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const double d = v[c]; a[c] += d; q[c] += d * d; }
+        }
+        s = (a[0] + a[1]) + (a[2] + a[3]);
+        s2 = (q[0] + q[1]) + (q[2] + q[3]);
+        for (size_t i = (n4 << 2) + t0; i < n; i += stride) { const double d = x[i]; s += d; s2 += d * d; }
+    } else {
+        for (size_t i = t0; i < n; i += stride) {
+            const double v = x[i];
+            s += v;
+            s2 += v * v;
+        }
     }
     __shared__ double sh[2][256];
     sh[0][threadIdx.x] = s;
@@ -1353,19 +1370,37 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ 
         }
         __syncthreads();
     }
+    // one partial pair per block, summed in a fixed order by moments_finish_kernel (first cut: two fp64 atomicAdds per block on ONE address --
+    // 4096 serialised L2 atomics per page -- and a memset launch in front of them)
     if (threadIdx.x == 0) {
-        atomicAdd(&sums[0], sh[0][0]);
-        atomicAdd(&sums[1], sh[1][0]);
+        sums[2 * blockIdx.x] = sh[0][0];
+        sums[2 * blockIdx.x + 1] = sh[1][0];
     }
 }
 
-__global__ void moments_finish_kernel(const double* __restrict__ sums, size_t n, float* __restrict__ stats) {
-    const double mean = sums[0] / (double)n;
-    double var = sums[1] / (double)n - mean * mean;
-    if (var < 0) var = 0;
-    const float sd = fmaxf((float)sqrt(var), 1e-4f);
-    stats[0] = (float)mean;
-    stats[1] = 1.0f / sd;
+// one block of 256 threads: partial pairs [nparts][2] -> {mean, 1 / max(sd, 1e-4)}
+__global__ __launch_bounds__(256) void moments_finish_kernel(const double* __restrict__ parts, int nparts, size_t n, float* __restrict__ stats) {
+    double s = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) { s += parts[2 * i]; s2 += parts[2 * i + 1]; }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean = sh[0][0] / (double)n;
+        double var = sh[1][0] / (double)n - mean * mean;
+        if (var < 0) var = 0;
+        const float sd = fmaxf((float)sqrt(var), 1e-4f);
+        stats[0] = (float)mean;
+        stats[1] = 1.0f / sd;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -17,6 +17,7 @@
 // (MI355X_MICROARCH.md, LDS table) -- no swizzle needed, unlike the 64-byte fp32 records of the fp32 path.
 #pragma once
 #include <type_traits>
+#include <utility>
 
 #include "aru_kernels.h"
 
@@ -47,6 +48,40 @@ __device__ __forceinline__ unsigned pkmax_u16(unsigned a, unsigned b) {
 __device__ __forceinline__ u32x4 relu_bf16x8(u32x4 v) { return u32x4{relu_bf16x2(v.x), relu_bf16x2(v.y), relu_bf16x2(v.z), relu_bf16x2(v.w)}; }
 __device__ __forceinline__ f32x4 mfma_bf16_k32(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Software pipeline over the PAIR SLOTS of a fused block's phase (res8f / res16f / res32_tail; round 5).  A slot = two tiles (two independent
+// accumulator chains) = CP fragment reads each, 2 CP MFMAs, an epilogue (round, ReLU, LDS or HBM store).  Written slot by slot the compiler has
+// to keep slot s + 1's LDS reads behind slot s's LDS stores (it cannot see that a phase's source and destination regions differ), so a wave ran
+// read -> wait -> MFMAs -> wait -> epilogue -> store and only the other waves of its SIMD covered the latencies.  Here slot s + 2's reads are
+// issued behind slot s's MFMAs (their registers are free then) and slot s - 1's epilogue stands beside slot s's MFMAs: simple vector instructions
+// hide under a bf16 MFMA of the same wave, two to three per MFMA (scripts/ubench/bf16mfma_epilogue_coissue.hip).
+//   ld(integral_constant<int, s>, FragPair&): issue slot s's reads;   st(integral_constant<int, s>, ra, rb): slot s's epilogue.
+// ------------------------------------------------------------------------------------------------
+template <int CP> struct FragPair { u32x4 a[CP], b[CP]; };
+template <int I> using ic = std::integral_constant<int, I>;
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(ic<I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+template <int CP>
+__device__ __forceinline__ void mm_pair(const u32x4 (&w)[CP], const FragPair<CP>& f, f32x4 c0, f32x4& ra, f32x4& rb) {
+    ra = c0; rb = c0;
+#pragma unroll
+    for (int t = 0; t < CP; ++t) { ra = mfma_bf16_k32(w[t], f.a[t], ra); rb = mfma_bf16_k32(w[t], f.b[t], rb); }
+}
+template <int NS, int CP, class LD, class ST>
+__device__ __forceinline__ void pipe_slots(const u32x4 (&w)[CP], f32x4 c0, LD&& ld, ST&& st) {
+    FragPair<CP> f[2];
+    f32x4 ra[2], rb[2];
+    ld(ic<0>{}, f[0]);
+    if constexpr (NS > 1) ld(ic<1>{}, f[1]);
+    static_for<NS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        mm_pair<CP>(w, f[s & 1], c0, ra[s & 1], rb[s & 1]);
+        if constexpr (s + 2 < NS) ld(ic<s + 2>{}, f[s & 1]);
+        if constexpr (s >= 1) st(ic<s - 1>{}, ra[(s - 1) & 1], rb[(s - 1) & 1]);
+    });
+    st(ic<NS - 1>{}, ra[(NS - 1) & 1], rb[(NS - 1) & 1]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -810,24 +845,17 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
         return ky * WIN + kx;
     };
     auto relu_pk = [](u32x2 p) { return u32x2{relu_bf16x2(p.x), relu_bf16x2(p.y)}; };
-    // two tiles at once: all fragment reads, then the MFMAs of the two accumulator chains interleaved
-    auto conv16x2 = [&](const u32x4 (&af)[CPC], const unsigned char* src, const int* bA, int offA, const int* bB, int offB, f32x4 c0, f32x4& ra, f32x4& rb) {
-        u32x4 fa[CPC], fb[CPC];
-#pragma unroll
-        for (int t = 0; t < CPC; ++t) { fa[t] = *reinterpret_cast<const u32x4*>(src + bA[t] + offA); fb[t] = *reinterpret_cast<const u32x4*>(src + bB[t] + offB); }
-        ra = c0; rb = c0;
-#pragma unroll
-        for (int t = 0; t < CPC; ++t) { ra = mfma_bf16_k32(af[t], fa[t], ra); rb = mfma_bf16_k32(af[t], fb[t], rb); }
-    };
+    typedef FragPair<CPC> Fr;
+    static_assert(H1 == 20 && H2 == 18, "slot lists of the stages below");
     __syncthreads();
     // convR_1's fragments: requested a whole stage before their first use (requested behind a stage's MFMAs, the next stage's first MFMA
     // waited for an L2 round trip)
 #pragma unroll
     for (int t = 0; t < CPC; ++t) ag[t] = wl[(CPC + t) * 64];
 
-    // ---- stage 1: r0 (22 x 38) -> r1 (20 x 36).  Rows wave + 4 i, two main tiles each; 5 remainder tiles of 4 rows x 4 columns ----
+    // ---- stage 1: r0 (22 x 38) -> r1 (20 x 36).  Six pair slots per wave: rows wave + 4 s (s < 5), both 16-column halves; slot 5 = the
+    //      wave's remainder tile (4 rows x 4 columns: rows 4 wave .., columns 32 .. 35) and, for wave 0, remainder tile 4 (rows 16 .. 19) ----
     {
-        const f32x4 b4 = biasw[0];
         int bm[CPC], br[CPC];
         const int rr = j >> 2, xc = j & 3;                    // remainder tile: lane j -> row rr of 4, column 32 + xc
 #pragma unroll
@@ -836,55 +864,80 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
             br[t] = ((wave * 4 + rr) * W0 + 32 + xc + tap_px(t, W0)) * PXB + (kk & 1) * 16;
         }
         unsigned char* const dm = r1 + (wave * W1 + j) * PXB + kk * 8;
-        f32x4 va, vb;
+        const int offB5 = (16 - 4 * wave) * W0 * PXB;
+        pipe_slots<6, CPC>(af, biasw[0],
+            [&](auto sc, Fr& f) {
+                constexpr int s = decltype(sc)::value;
 #pragma unroll
-        for (int i = 0; i < H1 / 4; ++i) {
-            conv16x2(af, r0, bm, i * 4 * W0 * PXB, bm, i * 4 * W0 * PXB + 16 * PXB, b4, va, vb);
-            *reinterpret_cast<u32x2*>(dm + i * 4 * W1 * PXB) = relu_pk(pack_bf16x4(va));
-            *reinterpret_cast<u32x2*>(dm + i * 4 * W1 * PXB + 16 * PXB) = relu_pk(pack_bf16x4(vb));
-        }
-        // remainder tiles 0 .. 3 (rows 4 wave ..) by every wave, tile 4 (rows 16 .. 19) by wave 0
-        conv16x2(af, r0, br, 0, br, (16 - 4 * wave) * W0 * PXB, b4, va, vb);
-        *reinterpret_cast<u32x2*>(r1 + ((wave * 4 + rr) * W1 + 32 + xc) * PXB + kk * 8) = relu_pk(pack_bf16x4(va));
-        if (wave == 0) *reinterpret_cast<u32x2*>(r1 + ((16 + rr) * W1 + 32 + xc) * PXB + kk * 8) = relu_pk(pack_bf16x4(vb));
+                for (int t = 0; t < CPC; ++t) {
+                    if constexpr (s < 5) {
+                        f.a[t] = *reinterpret_cast<const u32x4*>(r0 + bm[t] + s * 4 * W0 * PXB);
+                        f.b[t] = *reinterpret_cast<const u32x4*>(r0 + bm[t] + s * 4 * W0 * PXB + 16 * PXB);
+                    } else {
+                        f.a[t] = *reinterpret_cast<const u32x4*>(r0 + br[t]);
+                        f.b[t] = *reinterpret_cast<const u32x4*>(r0 + br[t] + offB5);
+                    }
+                }
+            },
+            [&](auto sc, f32x4 va, f32x4 vb) {
+                constexpr int s = decltype(sc)::value;
+                if constexpr (s < 5) {
+                    *reinterpret_cast<u32x2*>(dm + s * 4 * W1 * PXB) = relu_pk(pack_bf16x4(va));
+                    *reinterpret_cast<u32x2*>(dm + s * 4 * W1 * PXB + 16 * PXB) = relu_pk(pack_bf16x4(vb));
+                } else {
+                    *reinterpret_cast<u32x2*>(r1 + ((wave * 4 + rr) * W1 + 32 + xc) * PXB + kk * 8) = relu_pk(pack_bf16x4(va));
+                    if (wave == 0) *reinterpret_cast<u32x2*>(r1 + ((16 + rr) * W1 + 32 + xc) * PXB + kk * 8) = relu_pk(pack_bf16x4(vb));
+                }
+            });
     }
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < CPC; ++t) af[t] = wl[(2 * CPC + t) * 64];   // convR_2's, a stage ahead (stage 1 was af's last reader)
-    // ---- stage 2: r1 (20 x 36) -> r0 as 18 x 34.  4 full rows per wave + rows 16, 17 (waves 0, 1); 3 remainder tiles of 8 rows x 2
-    //      columns (waves 1 .. 3; wave 3's covers rows 16, 17 only) ----
+    // ---- stage 2: r1 (20 x 36) -> r0 as 18 x 34.  Five pair slots per wave: rows wave + 4 s (s < 4), both halves; slot 4 = row 16 + wave
+    //      (waves 0, 1) or two of the three remainder tiles (8 rows x 2 columns; wave 2: tiles 0, 1, wave 3: tile 2 = rows 16, 17) ----
     {
-        const f32x4 b4 = biasw[1];
-        int bm[CPC], br[CPC];
-        const int rr = j >> 1, xc = j & 1, rt = wave - 1;     // remainder tile rt: rows 8 rt + rr
-        const int rrow = min(max(8 * rt + rr, 0), H2 - 1);
+        int bm[CPC], b4a[CPC], b4b[CPC];
+        const int rr = j >> 1, xc = j & 1;
+        const bool m4 = wave < 2;                             // (wave-uniform)
+        const int rtA = 2 * (wave - 2), rowA = min(max(8 * rtA + rr, 0), H2 - 1), rowB = min(max(8 * rtA + 8 + rr, 0), H2 - 1);
 #pragma unroll
         for (int t = 0; t < CPC; ++t) {
             bm[t] = (wave * W1 + j + tap_px(t, W1)) * PXB + (kk & 1) * 16;
-            br[t] = (rrow * W1 + 32 + xc + tap_px(t, W1)) * PXB + (kk & 1) * 16;
+            b4a[t] = m4 ? bm[t] + 16 * W1 * PXB : (rowA * W1 + 32 + xc + tap_px(t, W1)) * PXB + (kk & 1) * 16;
+            b4b[t] = m4 ? bm[t] + 16 * W1 * PXB + 16 * PXB : (rowB * W1 + 32 + xc + tap_px(t, W1)) * PXB + (kk & 1) * 16;
         }
         unsigned char* const dm = r0 + (wave * W2 + j) * PXB + kk * 8;
-        f32x4 va, vb;
+        unsigned char* const d4a = m4 ? dm + 16 * W2 * PXB : r0 + (rowA * W2 + 32 + xc) * PXB + kk * 8;
+        unsigned char* const d4b = m4 ? dm + 16 * W2 * PXB + 16 * PXB : r0 + (rowB * W2 + 32 + xc) * PXB + kk * 8;
+        const bool ok4a = m4 || 8 * rtA + rr < H2, ok4b = m4 || wave == 2;
+        pipe_slots<5, CPC>(ag, biasw[1],
+            [&](auto sc, Fr& f) {
+                constexpr int s = decltype(sc)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            conv16x2(ag, r1, bm, i * 4 * W1 * PXB, bm, i * 4 * W1 * PXB + 16 * PXB, b4, va, vb);
-            *reinterpret_cast<u32x2*>(dm + i * 4 * W2 * PXB) = relu_pk(pack_bf16x4(va));
-            *reinterpret_cast<u32x2*>(dm + i * 4 * W2 * PXB + 16 * PXB) = relu_pk(pack_bf16x4(vb));
-        }
-        if (wave < 2) {
-            conv16x2(ag, r1, bm, 16 * W1 * PXB, bm, 16 * W1 * PXB + 16 * PXB, b4, va, vb);
-            *reinterpret_cast<u32x2*>(dm + 16 * W2 * PXB) = relu_pk(pack_bf16x4(va));
-            *reinterpret_cast<u32x2*>(dm + 16 * W2 * PXB + 16 * PXB) = relu_pk(pack_bf16x4(vb));
-        }
-        if (wave >= 1) {
-            conv16x2(ag, r1, br, 0, br, 0, b4, va, vb);
-            if (8 * rt + rr < H2) *reinterpret_cast<u32x2*>(r0 + (rrow * W2 + 32 + xc) * PXB + kk * 8) = relu_pk(pack_bf16x4(va));
-        }
+                for (int t = 0; t < CPC; ++t) {
+                    if constexpr (s < 4) {
+                        f.a[t] = *reinterpret_cast<const u32x4*>(r1 + bm[t] + s * 4 * W1 * PXB);
+                        f.b[t] = *reinterpret_cast<const u32x4*>(r1 + bm[t] + s * 4 * W1 * PXB + 16 * PXB);
+                    } else {
+                        f.a[t] = *reinterpret_cast<const u32x4*>(r1 + b4a[t]);
+                        f.b[t] = *reinterpret_cast<const u32x4*>(r1 + b4b[t]);
+                    }
+                }
+            },
+            [&](auto sc, f32x4 va, f32x4 vb) {
+                constexpr int s = decltype(sc)::value;
+                if constexpr (s < 4) {
+                    *reinterpret_cast<u32x2*>(dm + s * 4 * W2 * PXB) = relu_pk(pack_bf16x4(va));
+                    *reinterpret_cast<u32x2*>(dm + s * 4 * W2 * PXB + 16 * PXB) = relu_pk(pack_bf16x4(vb));
+                } else {
+                    if (ok4a) *reinterpret_cast<u32x2*>(d4a) = relu_pk(pack_bf16x4(va));
+                    if (ok4b) *reinterpret_cast<u32x2*>(d4b) = relu_pk(pack_bf16x4(vb));
+                }
+            });
     }
     __syncthreads();
-    // ---- stage 3: r0 (18 x 34) -> HBM; a wave takes row pairs 2 (wave + 4 i), both column blocks (2x2 pool in registers) ----
+    // ---- stage 3: r0 (18 x 34) -> HBM; a wave takes row pairs 2 (wave + 4 i), both column blocks (2x2 pool in registers): four pair slots ----
     {
-        const f32x4 b4 = biasw[2];
         int bm[CPC];
 #pragma unroll
         for (int t = 0; t < CPC; ++t) bm[t] = (2 * wave * W2 + j + tap_px(t, W2)) * PXB + (kk & 1) * 16;
@@ -893,12 +946,18 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
         unsigned char* __restrict__ const poolb = reinterpret_cast<unsigned char*>(P.pool);
         const int Wp = (W + 1) >> 1;
         const unsigned poff = (((unsigned)((y0 >> 1) + wave) * (unsigned)Wp + (unsigned)((x0 + j) >> 1)) * C + kk * 4) * 2u, prow = (unsigned)Wp * C * 2u;
+        pipe_slots<4, CPC>(af, biasw[2],
+            [&](auto sc, Fr& f) {
+                constexpr int s = decltype(sc)::value, i = s >> 1, cb = s & 1;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                f32x4 v2[2];
-                conv16x2(af, r0, bm, (8 * i) * W2 * PXB + cb * 16 * PXB, bm, (8 * i + 1) * W2 * PXB + cb * 16 * PXB, b4, v2[0], v2[1]);
+                for (int t = 0; t < CPC; ++t) {
+                    f.a[t] = *reinterpret_cast<const u32x4*>(r0 + bm[t] + (8 * i) * W2 * PXB + cb * 16 * PXB);
+                    f.b[t] = *reinterpret_cast<const u32x4*>(r0 + bm[t] + (8 * i + 1) * W2 * PXB + cb * 16 * PXB);
+                }
+            },
+            [&](auto sc, f32x4 va, f32x4 vb) {
+                constexpr int s = decltype(sc)::value, i = s >> 1, cb = s & 1;
+                const f32x4 v2[2] = {va, vb};
                 u32x2 pk[2];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
@@ -912,7 +971,7 @@ __global__ __launch_bounds__(256, 3) void res16f_kernel(const ResBArgs a) {
                     if ((j & 1) == 0)
                         *reinterpret_cast<u32x2*>(poolb + (poff + (unsigned)(4 * i) * prow + cb * 8 * C * 2)) = u32x2{pkmax_u16(m0, n0), pkmax_u16(m1, n1)};
                 }
-            }
+            });
     }
 }
 
