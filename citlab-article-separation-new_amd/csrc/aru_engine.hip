@@ -92,6 +92,7 @@ struct asep_aru {
     bool fused8_wanted = true;       // what ASEP_FUSED8 said (use_fused8 is also switched off for the graph variants)
     bool fused8_var = false;         // elu / leaky RESIDUAL graphs: the level-0 blocks on res8v_*_kernel<activation> (round 4)
     float* d_att_head = nullptr;     // A fragment of attPart/conv1 for att_head_kernel (12 output channels, 4x4 taps)
+    bf16_t* d_att_headb = nullptr;   // the same as ONE bf16 fragment [64][8] (att_headb_kernel, bf16 path)
     float* d_logit_w = nullptr;
     float* d_logit_b = nullptr;
     float* d_stats = nullptr;      // mvn {mean, 1/std}
@@ -1752,7 +1753,32 @@ TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) 
         // conv1 + ReLU + pool1 fused (the full-resolution 12-channel tensor is never materialised)
         // (bf16 path: the head writes a 16-channel bf16 plane, channels 12..15 zero)
         for (const Tensor& t : imgs) y.push_back(m->bf16 ? new_tensor_bf(m, cdiv(t.H, 2), cdiv(t.W, 2), 16) : new_tensor(m, cdiv(t.H, 2), cdiv(t.W, 2), 12));
-        for (size_t b0 = 0; b0 < imgs.size(); b0 += MAXP) {
+        const bool headb = m->bf16 && m->d_att_headb && m->cfg.activation == 0;
+        for (size_t b0 = 0; headb && b0 < imgs.size(); b0 += MAXP) {
+            // bf16 path, ReLU graph: the head on the bf16 MFMA (image and filter as bfloat16 like the feature CNN's first layer)
+            const size_t b1 = std::min(imgs.size(), b0 + MAXP);
+            AttHeadBArgs a{};
+            int tiles = 0;
+            double flops = 0, bytes = 0;
+            for (size_t i = b0; i < b1; ++i) {
+                bytes += tbytes(imgs[i]) + tbytes(y[i]);
+                C1Prob& q = a.p[i - b0];
+                q.img = imgs[i].p; q.out = y[i].p; q.stats = stats.empty() ? nullptr : stats[i];
+                q.H = imgs[i].H; q.W = imgs[i].W;
+                q.tiles_x = cdiv(imgs[i].W, ATTB_TW);
+                q.tile_begin = tiles;
+                tiles += q.tiles_x * cdiv(imgs[i].H, ATTB_TH);
+                flops += 2.0 * imgs[i].H * imgs[i].W * 16.0 * 12;
+            }
+            a.nprob = (int)(b1 - b0);
+            a.wpk = (const u32x4*)m->d_att_headb; a.bias = m->att_first.d_b;
+            int units = tiles;
+            a.xm = oneshot_map(m, tiles, &units);
+            ProfScope ps(m, "att_headb_kernel", flops);
+            ps.bytes = bytes;
+            hipLaunchKernelGGL(att_headb_kernel, dim3(units), dim3(256), 0, m->stream, a);
+        }
+        for (size_t b0 = 0; !headb && b0 < imgs.size(); b0 += MAXP) {
             const size_t b1 = std::min(imgs.size(), b0 + MAXP);
             AttHeadArgs a{};
             int tiles = 0;
@@ -2078,6 +2104,15 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
                 }
             rc = upload(pk, &m->d_att_head);
             if (!rc) m->owned.push_back(m->d_att_head);
+            if (!rc && m->bf16) {                            // att_headb_kernel: k = 8 kk + 4 r + c <-> tap (2 kk + r, c) for kk < 2, zero rows / slots elsewhere
+                std::vector<bf16_t> pb(64 * 8, 0);
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = lane & 15, kk = lane >> 4;
+                    for (int i = 0; i < 8 && kk < 2 && co < 12; ++i) pb[lane * 8 + i] = f2bf(w.data[(size_t)((2 * kk + (i >> 2)) * 4 + (i & 3)) * 12 + co]);
+                }
+                rc = upload_bf(pb, &m->d_att_headb);
+                if (!rc) m->owned.push_back(m->d_att_headb);
+            }
         }
         for (int i = 2; i <= 4 && !rc; ++i)
             rc = pack_conv(m.get(), blob, "aru_net/attMapG/attPart/conv" + std::to_string(i), "biases", false);

@@ -1782,6 +1782,131 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     R8F_MARK(11);
 }
 
+// ------------------------------------------------------------------------------------------------
+// att_headb_kernel: the attention CNN's head (ARU_v1.py:173-175: 4x4 conv 1 -> 12 + ReLU + 2x2 max pool) of the bf16 path on the bf16 MFMA
+// (round 5; until then the fp32 vector-ALU kernel att_headv_kernel<true> served both paths: 384 packed FMAs per pooled pixel, 89 us per page
+// against 35 us of HBM time).  Like conv1 of res8f_kernel<false> the layer reads the (standardised) image ROUNDED TO BFLOAT16 and its filter
+// rounded to bfloat16; products are exact in fp32, sums fp32.  One MFMA per 16 pixels: M = 12 (of 16) output channels, N = 16 consecutive pixels
+// of a row, K = 16 taps (lane group kk < 2: filter rows 2 kk, 2 kk + 1, four columns each; groups 2, 3: zero weights).
+// Block = 16 x 64 output pixels (8 x 32 pooled), image tile 19 x 68 as bf16 in LDS (2.6 KB).  A wave takes rows 4 w .. 4 w + 3: a slot = the two
+// rows of a pool window x 16 columns; the lane reads THREE image rows (rows r .. r + 2 serve both conv rows) as three dwords each and shifts
+// odd columns into place with v_alignbit (a window starts at any column: 2-byte alignment).  Epilogue on the bit patterns: max3(a, b, 0) of the
+// two rows, max with lane ^ 1 (DPP), round, one 8-byte store per even lane: the pooled pixel leaves as the 16-channel bf16 plane (12 + 4 zeros;
+// the zero-weight rows of the fragment and a zero bias produce the zeros) the next conv's K chunks expect.  ReLU graphs only (elu / leaky keep
+// att_headv_kernel).
+// ------------------------------------------------------------------------------------------------
+constexpr int ATTB_TH = 16, ATTB_TW = 64;
+struct AttHeadBArgs {
+    C1Prob p[MAXP];        // img, out = pooled [ceil(H/2), ceil(W/2), 16] bf16 (passed as float*), stats, H, W, tiles_x, tile_begin
+    int nprob;
+    const u32x4* wpk;      // [64 lanes] x 16 bytes: A fragment, row = output channel (12 real), k = 8 kk + 4 r + c <-> tap (2 kk + r, c), kk < 2
+    const float* bias;     // [12]
+    XcdMap xm;
+};
+__global__ __launch_bounds__(256, 4) void att_headb_kernel(const AttHeadBArgs a) {
+    constexpr int TH = ATTB_TH, TW = ATTB_TW, LH = TH + 3, LW = TW + 4;      // SAME for 4x4: 1 before, 2 after (+ 1 column: dword pairs)
+    __shared__ __attribute__((aligned(16))) unsigned short img[LH * LW + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int bid = sched_tile(a.xm);
+    if (bid < 0) return;
+    const int pi = prob_of_tile(a, bid);
+    const C1Prob& P = a.p[pi];
+    const int tile = bid - P.tile_begin;
+    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int H = P.H, W = P.W;
+    const u32x4 af[1] = {a.wpk[lane]};
+    f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (kk < 3) b4 = *reinterpret_cast<const f32x4*>(a.bias + 4 * kk);
+    float mean = 0.f, inv = 1.f;
+    if (P.stats) { mean = P.stats[0]; inv = P.stats[1]; }
+    if (y0 >= 1 && y0 + TH + 2 <= H && x0 >= 1 && x0 + TW + 3 <= W) {
+        // the whole image tile inside the image (all but the border tiles): threads 0 .. 203 own column t % 68 of the tile rows t / 68 + 3 k -- one
+        // division per thread, no clamps, no inside test (the general form below: a division, four clamps and a test per element)
+        constexpr int NK = (LH + 2) / 3;
+        const int lr = tid / LW, lc = tid - lr * LW;
+        const bool ldr = tid < 3 * LW;
+        const float* __restrict__ src = P.img + (size_t)(y0 - 1 + (ldr ? lr : 0)) * W + (x0 - 1 + lc);
+        float st[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) st[k] = src[(size_t)min(3 * k, LH - 1 - (ldr ? lr : 0)) * W];
+        if (ldr) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+                if (3 * k + 2 < LH || lr + 3 * k < LH) img[(lr + 3 * k) * LW + lc] = (unsigned short)(pack_bf16x2((st[k] - mean) * inv, 0.f) & 0xffffu);
+        }
+    } else {   // requests first, LDS writes afterwards
+        constexpr int NSL = (LH * LW + 255) / 256;
+        float st[NSL];
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            const int i = min(tid + k * 256, LH * LW - 1);
+            const int r = i / LW, c = i - r * LW;
+            st[k] = P.img[(size_t)min(max(y0 - 1 + r, 0), H - 1) * W + min(max(x0 - 1 + c, 0), W - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            const int i = tid + k * 256;
+            if (i < LH * LW) {
+                const int r = i / LW, c = i - r * LW;
+                const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+                img[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (unsigned short)(pack_bf16x2((st[k] - mean) * inv, 0.f) & 0xffffu) : (unsigned short)0;
+            }
+        }
+    }
+    if (tid < 8) img[LH * LW + tid] = 0;                      // (slack behind the last row: finite data for any over-read)
+    __syncthreads();
+    const bool interior = y0 + TH <= H && x0 + TW <= W;       // every 2x2 window of the tile is complete
+    const unsigned Wp = (unsigned)(W + 1) >> 1;
+    const unsigned sh = (unsigned)(j & 1) * 16u;
+    // the lane's dword of (tile row 4 wave + 2 (kk & 1), window column j) -- slots add (2 rp) rows and 16 cb columns
+    const unsigned* const base = reinterpret_cast<const unsigned*>(img) + ((4 * wave + 2 * (kk & 1)) * LW + j) / 2;
+    // pooled pixel of slot (rp, cb): (y0 / 2 + 2 wave + rp, x0 / 2 + 8 cb + j / 2): a uniform base pointer + 32-bit element offsets (the pooled
+    // plane of a page is far below 2^31 elements)
+    unsigned short* __restrict__ const ob = reinterpret_cast<unsigned short*>(P.out);
+    const unsigned obase = ((unsigned)((y0 >> 1) + 2 * wave) * Wp + (unsigned)((x0 >> 1) + (j >> 1))) * 16u + 4u * (unsigned)kk, orow = Wp * 16u;
+    const bool even = (j & 1) == 0;
+    typedef FragPair<1> Fr;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    pipe_slots<8, 1>(af, b4,
+        [&](auto sc, Fr& f) {
+            constexpr int s = decltype(sc)::value, rp = s >> 2, cb = s & 3;
+            const unsigned* p = base + (2 * rp * LW + 16 * cb) / 2;
+            unsigned v[3][2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const unsigned d0 = p[r * (LW / 2)], d1 = p[r * (LW / 2) + 1], d2 = p[r * (LW / 2) + 2];
+                v[r][0] = __builtin_amdgcn_alignbit(d1, d0, sh);
+                v[r][1] = __builtin_amdgcn_alignbit(d2, d1, sh);
+            }
+            f.a[0] = u32x4{v[0][0], v[0][1], v[1][0], v[1][1]};
+            f.b[0] = u32x4{v[1][0], v[1][1], v[2][0], v[2][1]};
+        },
+        [&](auto sc, f32x4 va, f32x4 vb) {
+            constexpr int s = decltype(sc)::value, rp = s >> 2, cb = s & 3;
+            i32x4 ia = __builtin_bit_cast(i32x4, va), ib = __builtin_bit_cast(i32x4, vb);
+            bool ok = even;
+            if (!interior) {                                  // a conv output outside the image contributes 0 = what the ReLU leaves of it anyway
+                const int gy = y0 + 4 * wave + 2 * rp, gx = x0 + 16 * cb + j;
+                if (gx >= W) { ia = i32x4{0, 0, 0, 0}; ib = ia; }
+                if (gy + 1 >= H) ib = i32x4{0, 0, 0, 0};
+                ok = ok && gy < H && gx < W;
+            }
+            // relu(max over the window) on the bit patterns (a negative float is a negative int): max3(a, b, 0), then the column partner
+            int m[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int t = max(max(ia[c], ib[c]), 0);
+                m[c] = max(t, __builtin_amdgcn_update_dpp(0, t, 0xB1, 0xF, 0xF, true));
+            }
+            if (ok) {
+                const u32x2 pk = u32x2{pack_bf16x2(__int_as_float(m[0]), __int_as_float(m[1])), pack_bf16x2(__int_as_float(m[2]), __int_as_float(m[3]))};
+                *reinterpret_cast<u32x2*>(ob + (obase + (unsigned)rp * orow + (unsigned)(cb * 8 * 16))) = pk;
+            }
+        });
+}
+
 // channel sum [H,W,8] bf16 -> [H,W] fp32 (upsample_simple's channel-summing half; same association as chansum_kernel)
 struct PoolBProb {
     const bf16_t* in;

@@ -298,7 +298,8 @@ def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermedia
     csrc/bf16_kernels.h): the filters of the feature CNN and of the attention CNN's conv2 / conv3 are rounded to
     bfloat16 (round to nearest even), every tensor those layers -- and the deconvolutions and the attention head -- write is rounded to
     bfloat16 after bias and residual add (ReLU / max pool commute with the rounding), the feature CNN's first layer reads the
-    (standardised) image rounded to bfloat16; sums stay fp32, and so do biases, the attention head's and conv4's filters, the
+    (standardised) image rounded to bfloat16 -- and so does, in ReLU graphs, the attention head with its filter rounded to bfloat16
+    (att_headb_kernel, round 5; elu / leaky graphs keep the fp32 head); sums stay fp32, and so do biases, conv4's filter, the
     channel sums, the blend over the scales, the logits layer and the soft-maxes.  This is NOT the reference's arithmetic (that is
     ``storage="f32"``): it is the checker that tells a wrong bf16 kernel from bf16 rounding -- against it the engine's bf16 path has
     to agree far more closely than the 2e-2 it is allowed against the fp32 graph (tests/test_full_frame_gpu.py).
@@ -337,10 +338,12 @@ def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermedia
                 return tt
             return t
         q = (lambda t: t.to(torch.bfloat16).to(dtype)) if emu else (lambda t: t)      # torch rounds to nearest even
+        bf_head = emu and getattr(cfg, "activation_name", "relu") == "relu"       # the attention head on the bf16 MFMA (ReLU graphs)
         if emu:
             for k in list(tw):
                 bf_filter = (k.startswith("aru_net/featMapG/") or k.startswith("aru_net/attMapG/attPart/conv2")
-                             or k.startswith("aru_net/attMapG/attPart/conv3"))
+                             or k.startswith("aru_net/attMapG/attPart/conv3")
+                             or (bf_head and k.startswith("aru_net/attMapG/attPart/conv1/")))
                 if bf_filter and k.endswith("/weights"):
                     tw[k] = q(tw[k])
 
@@ -397,7 +400,7 @@ def forward_torch(image, w, cfg, num_threads=None, dtype=None, return_intermedia
 
         def att(x):
             p = "aru_net/attMapG/attPart/conv"
-            y = aq(conv(x, p + "1"))                         # (bf16 path: fp32 head, its pooled output stored as bfloat16)
+            y = aq(conv(q(x) if bf_head else x, p + "1"))    # (bf16 path: the pooled output stored as bfloat16; ReLU graphs: image and filter as bfloat16)
             y = F.max_pool2d(y, 2, 2, ceil_mode=True)
             y = aq(conv(y, p + "2"))
             y = F.max_pool2d(y, 2, 2, ceil_mode=True)
