@@ -1390,10 +1390,12 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
         TL sub(in0.begin() + b0, in0.begin() + b1);
         ProfScope ps(m, "convb_kernel", flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
         ps.bytes = bytes;
-        const int key = pc.kh * 100 + pc.bmode * 10 + mtb + (th == 8 && mtb == 2 ? 1000 : 0) + (res && pc.bmode == 2 && pc.kh == 3 && mtb >= 2 ? 2000 : 0);
+        bool res32 = res != nullptr;                          // the RESP kernels address the residual operand with 32-bit byte offsets
+        for (size_t i = b0; res && i < b1; ++i) res32 = res32 && tbytes((*res)[i]) < 4294967296.0;
+        const int key = pc.kh * 100 + pc.bmode * 10 + mtb + (th == 8 && mtb == 2 ? 1000 : 0) + (res32 && pc.bmode == 2 && pc.kh == 3 && mtb >= 2 ? 2000 : 0);
         switch (key) {
-            case 3322: ASEP_CONVB_LAUNCH_RES(3, 3, 2, 2, 1, 8, 3); break;       // residual operand prefetched (32- and >= 64-channel convR_2)
-            case 2324: ASEP_CONVB_LAUNCH_RES(3, 3, 2, 2, 2, 8, 2); break;       // (eight waves: 146 registers = one block per CU, 46 -> 52 us)
+            case 3322: ASEP_CONVB_LAUNCH_RES(3, 3, 2, 2, 1, 8, 3); break;       // residual operand in the initial value (32- and >= 64-channel convR_2)
+            case 2324: ASEP_CONVB_LAUNCH8(3, 3, 2, 2, 2, 8, 2, true); break;    // (the residual is part of the accumulators' initial value: the eight-wave form's registers)
             case 1322: ASEP_CONVB_LAUNCH(3, 3, 2, 2, 1, 8, 4); break;
             case 301: ASEP_CONVB_LAUNCH(3, 3, 0, 1, 1, 16, 3); break;
             case 302: ASEP_CONVB_LAUNCH(3, 3, 0, 2, 1, 16, 3); break;

@@ -118,8 +118,10 @@ struct ConvBArgs {
 // (row id >> 1, column block id & 1).  The A fragments (weights) of a stage are copied to LDS ONCE per block next to the halo
 // tile and read from there by all waves: fetched per wave from L2 (first cut of this kernel) they cost 4 KB per 16 MFMAs and
 // wave = the whole vector-memory path of a CU, and every chunk waited for an L2 round trip.
-// RESP: the layer has a residual operand; its values are requested BEFORE the last stage's MFMAs (2 MT NT registers) instead of
-// in the epilogue, where their HBM latency was exposed (a residual layer took 74 us against 42 us for its twin without one).
+// RESP: the layer has a residual operand; its values are requested at the very start and become part of the accumulators' INITIAL value
+// (bias + residual) behind the first barrier -- no registers held through the MFMA loops, no exposed latency (first cut: fetched in the epilogue,
+// a residual layer took 74 us against 42 us for its twin without one; second: requested before the last stage's MFMAs into 2 MT NT registers,
+// which kept the eight-wave form at one block per CU and the >= 64-channel convR_2 layers on the four-wave kernel: 160 against 117 us).
 // NW = waves per block (4, or 8 for the >= 64-channel layers: twice the waves per CU over the same LDS tile -- those layers are
 // short chains of dependent LDS reads and MFMAs, more waves overlap them).
 // Debug builds (-DCVB_TRACE): s_memtime stamps of thread 0 of every 4th block of the 8-wave >= 64-channel instantiation, read back
@@ -184,6 +186,23 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
     }
     const int ngroups = MODE == 2 ? a.groups : 1;
     u32x2 resv[RESP ? MT : 1][RESP ? NT : 1];
+    if constexpr (RESP) {
+        // (a uniform base + 32-bit byte offsets -- run_convb keeps residual tensors of 4 GB and more on the kernels without RESP --: written with
+        // the epilogue's 64-bit address arithmetic the compiler shared it with the output addresses and kept 16 registers alive across the MFMA loops)
+        const unsigned char* __restrict__ const rbase = reinterpret_cast<const unsigned char*>(P.res);
+        const unsigned pxb = (unsigned)cout * 2u;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int c = (mt0 + m) * 16 + kk * 4;
+            const unsigned cb = c < cout ? (unsigned)c * 2u : 0u;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int id = wn * NT + n;
+                const unsigned y = (unsigned)min(y0 + (id >> 1), H - 1), x = (unsigned)min(x0 + (id & 1) * 16 + j, W - 1);
+                resv[m][n] = *reinterpret_cast<const u32x2*>(rbase + ((y * (unsigned)W + x) * pxb + cb));
+            }
+        }
+    }
     const u32x4* __restrict__ wsrc = a.wpk + (size_t)mtb0 * 64;
     const size_t wstride = (size_t)a.mtiles * 64;
     const int mt_have = min(MTB, a.mtiles - mtb0);            // m-tiles of this block that exist (cout 8 / 16: one of MTB)
@@ -205,6 +224,12 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
     }
     const int sub0 = (tid % SUBS) * 8;                        // (the block size is a multiple of SUBS: the sub-block is the same for all slots)
 
+    if constexpr (RESP) {                                    // (requested before the tile loader's index arithmetic above)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] += unpack_bf16x4(resv[m][n]);
+    }
     CVB_MARK(1);
     for (int g = 0; g < ngroups; ++g) {
         // ---- stage g: halo tile of 32 (16, 8) input channels + the stage's A fragments -> LDS.  Requests first; zero padding /
@@ -245,20 +270,6 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
         __syncthreads();
         if (g == 0) CVB_MARK(2);
         if (g + 1 == ngroups) CVB_MARK(4);
-        if constexpr (RESP) {
-            if (g + 1 == ngroups) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int c = (mt0 + m) * 16 + kk * 4;
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        const int id = wn * NT + n;
-                        const int y = min(y0 + (id >> 1), H - 1), x = min(x0 + (id & 1) * 16 + j, W - 1);
-                        resv[m][n] = *reinterpret_cast<const u32x2*>(P.res + ((size_t)y * W + x) * a.cout + (c < a.cout ? c : 0));
-                    }
-                }
-            }
-        }
         auto chunk = [&](int t, int toff) {
             u32x4 af[MT], bfr[NT];
 #pragma unroll
@@ -318,8 +329,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
             for (int n = 0; n < NT; ++n) {
                 const size_t off = (size_t)(n >> 1) * rs + (n & 1) * 16 * cout + m * 16;
                 f32x4 v = acc[m][n];
-                if constexpr (RESP) v += unpack_bf16x4(resv[m][n]);
-                else if (P.res) v += unpack_bf16x4(*reinterpret_cast<const u32x2*>(rb + off));
+                if constexpr (!RESP) { if (P.res) v += unpack_bf16x4(*reinterpret_cast<const u32x2*>(rb + off)); }
                 const u32x2 q = pack_bf16x4(v);
                 pk[n] = u32x2{relu_bf16x2(q.x), relu_bf16x2(q.y)};
                 if (!a.skip_full) *reinterpret_cast<u32x2*>(ob + off) = pk[n];
@@ -352,8 +362,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
             const bool ok = cok && y < H && x < W;
             const size_t p = ((size_t)min(y, H - 1) * W + min(x, W - 1)) * cout + (cok ? c : 0);
             f32x4 v = acc[m][n];
-            if constexpr (RESP) v += unpack_bf16x4(resv[m][n]);
-            else if (P.res) v += unpack_bf16x4(*reinterpret_cast<const u32x2*>(P.res + p));
+            if constexpr (!RESP) { if (P.res) v += unpack_bf16x4(*reinterpret_cast<const u32x2*>(P.res + p)); }
             if (a.relu_out) v = relu4(v);
             else if (a.act) v = act4(v, a.act);
             // the pool takes its maximum over the ROUNDED values (what a separate pool kernel would read back)
