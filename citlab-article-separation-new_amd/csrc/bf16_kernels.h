@@ -689,21 +689,32 @@ __global__ __launch_bounds__(512, 1) void res32_tail_kernel(const ResBArgs a) {
     stage_weights(0);
     __syncthreads();
 
-    // ---- stages 1 and 2: LDS -> LDS ----
+    // ---- stages 1 and 2: LDS -> LDS.  The wave's tiles tl = wave, wave + 8, ...: ALL nine B fragments of a tile are requested together (one LDS
+    //      round trip per tile; the first cut's schedule fetched them two at a time between the MFMA pairs -- five exposed round trips per tile with
+    //      two waves per SIMD to cover them), and the NEXT tile's are requested behind the current tile's MFMAs, in front of its epilogue and
+    //      stores (written in that order by hand: the compiler cannot move LDS reads over LDS stores) ----
     auto mid_stage = [&](const unsigned char* src, int WIN, int SPL, unsigned char* dst, int DPL, int HO, int WO, int halo, int sg) {
         const int npix = HO * WO;
+        u32x4 bfr[9];
+        auto request = [&](int tl) {
+            const int qc = min(tl * 16 + j, npix - 1);
+            const int oy = qc / WO, ox = qc - oy * WO;
+            const unsigned char* base = src + (oy * WIN + ox) * 32;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) bfr[k] = *reinterpret_cast<const u32x4*>(base + tap_off(k, WIN, SPL));
+        };
+        request(wave);
         for (int tl = wave; tl * 16 < npix; tl += NW) {
             const int q = tl * 16 + j, qc = min(q, npix - 1);
             const int oy = qc / WO, ox = qc - oy * WO;
-            const unsigned char* base = src + (oy * WIN + ox) * 32;
-            u32x4 bfr[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) bfr[k] = *reinterpret_cast<const u32x4*>(base + tap_off(k, WIN, SPL));
             f32x4 acc[2] = {biasw[sg][0], biasw[sg][1]};
+            __builtin_amdgcn_sched_barrier(0);               // (the requests stay in front of the MFMAs)
 #pragma unroll
             for (int k = 0; k < 9; ++k)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) acc[m] = mfma_bf16_k32(af[k][m], bfr[k], acc[m]);
+            if ((tl + NW) * 16 < npix) request(tl + NW);      // (wave-uniform)
+            __builtin_amdgcn_sched_barrier(0);
             const int gy = yc - halo + oy, gx = xc - halo + ox;
             const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
             if (q < npix) {
@@ -722,52 +733,58 @@ __global__ __launch_bounds__(512, 1) void res32_tail_kernel(const ResBArgs a) {
     stage_weights(2);
     __syncthreads();
 
-    // ---- stage 3: LDS -> registers -> HBM.  Unit = (row pair, 16-column block): both rows in registers for the pool ----
+    // ---- stage 3: LDS -> registers -> HBM.  Unit = (row pair, 16-column block): both rows in registers for the pool.  Four steps (unit, row) per
+    //      wave, pipelined like the stages above: a row's nine fragments in one request, the next row's behind the current row's MFMAs ----
     {
         const int Wp = (W + 1) >> 1;
         static_assert((RB_TH / 2) * 2 == 2 * NW, "two output units per wave");
+        u32x4 bfr[9];
+        auto request = [&](int step) {
+            const int u = wave + (step >> 1) * NW;
+            const unsigned char* base = r0 + ((2 * (u >> 1) + (step & 1)) * W2 + (u & 1) * 16 + j) * 32;
 #pragma unroll
-        for (int ui = 0; ui < 2; ++ui) {
-            const int u = wave + ui * NW;
-            const int rp = u >> 1, cb = u & 1;
-            const int oy = 2 * rp, ox = cb * 16 + j;
-            f32x4 acc2[2][2];
+            for (int k = 0; k < 9; ++k) bfr[k] = *reinterpret_cast<const u32x4*>(base + tap_off(k, W2, P0));
+        };
+        request(0);
+        f32x4 acc2[2][2];
+        static_for<4>([&](auto sc) {
+            constexpr int step = decltype(sc)::value, ui = step >> 1, r = step & 1;
+            acc2[r][0] = biasw[2][0]; acc2[r][1] = biasw[2][1];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const unsigned char* base = r0 + ((oy + r) * W2 + ox) * 32;
-                u32x4 bfr[9];
+            for (int k = 0; k < 9; ++k)
 #pragma unroll
-                for (int k = 0; k < 9; ++k) bfr[k] = *reinterpret_cast<const u32x4*>(base + tap_off(k, W2, P0));
-                acc2[r][0] = biasw[2][0]; acc2[r][1] = biasw[2][1];
+                for (int m = 0; m < 2; ++m) acc2[r][m] = mfma_bf16_k32(af[k][m], bfr[k], acc2[r][m]);
+            if constexpr (step < 3) request(step + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (r == 1) {
+                const int u = wave + ui * NW;
+                const int oy = 2 * (u >> 1), ox = (u & 1) * 16 + j;
+                const int x = xc + ox;
 #pragma unroll
-                for (int k = 0; k < 9; ++k)
+                for (int m = 0; m < 2; ++m) {
+                    u32x2 pk[2];
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) acc2[r][m] = mfma_bf16_k32(af[k][m], bfr[k], acc2[r][m]);
-            }
-            const int x = xc + ox;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                u32x2 pk[2];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int y = yc + oy + r;
-                    const size_t p = ((size_t)min(y, H - 1) * W + min(x, W - 1)) * C + m * 16 + kk * 4;
-                    const f32x4 v = acc2[r][m] + unpack_bf16x4(resv[ui][r][m]);
-                    const u32x2 q = pack_bf16x4(v);
-                    pk[r] = u32x2{relu_bf16x2(q.x), relu_bf16x2(q.y)};
-                    if (y < H && x < W) *reinterpret_cast<u32x2*>(P.out + p) = pk[r];
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const int y = yc + oy + rr;
+                        const size_t p = ((size_t)min(y, H - 1) * W + min(x, W - 1)) * C + m * 16 + kk * 4;
+                        const f32x4 v = acc2[rr][m] + unpack_bf16x4(resv[ui][rr][m]);
+                        const u32x2 q = pack_bf16x4(v);
+                        pk[rr] = u32x2{relu_bf16x2(q.x), relu_bf16x2(q.y)};
+                        if (y < H && x < W) *reinterpret_cast<u32x2*>(P.out + p) = pk[rr];
+                    }
+                    if (P.pool) {
+                        // 2 x 2 max on the packed values (non-negative bf16 order like their bit patterns); ceil mode at the right / bottom border
+                        const int y = yc + oy;
+                        u32x2 mm = (y + 1 < H) ? u32x2{pkmax_u16(pk[0].x, pk[1].x), pkmax_u16(pk[0].y, pk[1].y)} : pk[0];
+                        const u32x2 nb = u32x2{__float_as_uint(lane_xor1(__uint_as_float(mm.x))), __float_as_uint(lane_xor1(__uint_as_float(mm.y)))};
+                        if (x + 1 < W) mm = u32x2{pkmax_u16(mm.x, nb.x), pkmax_u16(mm.y, nb.y)};
+                        if ((j & 1) == 0 && y < H && x < W)
+                            *reinterpret_cast<u32x2*>(P.pool + ((size_t)(y >> 1) * Wp + (x >> 1)) * C + m * 16 + kk * 4) = mm;
+                    }
                 }
-                if (P.pool) {
-                    // 2 x 2 max on the packed values (non-negative bf16 order like their bit patterns); ceil mode at the right / bottom border
-                    const int y = yc + oy;
-                    u32x2 mm = (y + 1 < H) ? u32x2{pkmax_u16(pk[0].x, pk[1].x), pkmax_u16(pk[0].y, pk[1].y)} : pk[0];
-                    const u32x2 nb = u32x2{__float_as_uint(lane_xor1(__uint_as_float(mm.x))), __float_as_uint(lane_xor1(__uint_as_float(mm.y)))};
-                    if (x + 1 < W) mm = u32x2{pkmax_u16(mm.x, nb.x), pkmax_u16(mm.y, nb.y)};
-                    if ((j & 1) == 0 && y < H && x < W)
-                        *reinterpret_cast<u32x2*>(P.pool + ((size_t)(y >> 1) * Wp + (x >> 1)) * C + m * 16 + kk * 4) = mm;
-                }
             }
-        }
+        });
     }
     if (!more) break;
     __syncthreads();                                          // stage 3's readers of region 0 are done: the next tile may overwrite it
