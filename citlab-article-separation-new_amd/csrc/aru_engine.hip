@@ -95,6 +95,7 @@ struct asep_aru {
     bf16_t* d_att_headb = nullptr;   // the same as ONE bf16 fragment [64][8] (att_headb_kernel, bf16 path)
     float* d_logit_w = nullptr;
     float* d_logit_b = nullptr;
+    float* d_logit_wd = nullptr;     // two classes: [16][feat_root] class-1 minus class-0 filter + the bias difference (combine_kernel behind a soft-max)
     float* d_stats = nullptr;      // mvn {mean, 1/std}
     double* d_sums = nullptr;
     // A lane = one in-order chain of launches (stream + its buffer pool + a side stream for the attention branch).
@@ -1924,6 +1925,7 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
                 ca.fph[s] = (f.H * up - H) / 2; ca.fpw[s] = (f.W * up - W) / 2;
             }
             ca.wl = m->d_logit_w; ca.bl = m->d_logit_b;
+            ca.wd = (cfg.apply_softmax && cfg.n_classes == 2) ? m->d_logit_wd : nullptr;
             ca.out = d_outs[b]; ca.out_u8 = d_u8s ? d_u8s[b] : nullptr; ca.out_mask = d_masks ? d_masks[b] : nullptr;
             ca.thr255 = (double)threshold * 255.0;
             ca.softmax = cfg.apply_softmax;
@@ -2164,6 +2166,14 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (upload(lw->second.data, &m->d_logit_w) || upload(lb->second.data, &m->d_logit_b)) return nullptr;
     m->owned.push_back(m->d_logit_w);
     m->owned.push_back(m->d_logit_b);
+    if (cfg->n_classes == 2) {
+        const std::vector<float>& w = lw->second.data;       // [4][4][feat_root][2]
+        std::vector<float> wd((size_t)16 * cfg->feat_root + 1);
+        for (size_t i = 0; i < (size_t)16 * cfg->feat_root; ++i) wd[i] = w[2 * i + 1] - w[2 * i];
+        wd.back() = lb->second.data[1] - lb->second.data[0];
+        if (upload(wd, &m->d_logit_wd)) return nullptr;
+        m->owned.push_back(m->d_logit_wd);
+    }
     if (hipMalloc((void**)&m->d_stats, 2 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&m->d_sums, 2 * sizeof(double)) != hipSuccess) {
         set_error("asep_aru_load: hipMalloc failed");

@@ -1575,6 +1575,7 @@ struct CombineArgs {
     int H, W;
     const float* wl;                 // [4*4][FR][NC]
     const float* bl;                 // [NC]
+    const float* wd;                 // NC == 2 with soft-max: [4*4][FR] class-1 minus class-0 filter, [16 FR] = bias difference; or nullptr
     float* out;                      // [H,W,NC] probabilities (or logits)
     uint8_t* out_u8;                 // optional
     uint8_t* out_mask;               // optional
@@ -1698,9 +1699,62 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
 #pragma unroll
         for (int k = 0; k < NC; ++k) lg[q][k] = swl[16 * FR * NC + k];
     if constexpr (NC == 2 && FR % 4 == 0) {
+      typedef const float __attribute__((address_space(4)))* cptr;
+      if (a.wd) {
+        // two classes behind a soft-max: only the DIFFERENCE of the logits decides (p1 = 1 / (1 + exp(l0 - l1))), so the conv runs with the
+        // difference filter -- half the multiplications (64 packed FMAs per pixel instead of 128: the kernel is bound by its vector
+        // instructions).  A packed accumulator = two channels of a quad; the larger class gets 1 / (1 + e), the smaller e / (1 + e) with
+        // e = exp(-|d|) -- the soft-max's own form (exp(l - max) / sum), its argument rounded once more (d is a sum over the difference
+        // filter, not the difference of two sums).
+        f32x2 l2[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) l2[q][0] = l2[q][1] = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            f32x4 v[5][FR / 4];                                   // the row's five window pixels
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int c4 = 0; c4 < FR / 4; ++c4) v[i][c4] = *reinterpret_cast<const f32x4*>(m + mi(ty + ky, 2 * tx + i, c4));
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                cptr wp = (cptr)(a.wd + (ky * 4 + kx) * FR);
+#pragma unroll
+                for (int c4 = 0; c4 < FR / 4; ++c4) {
+                    const f32x2 w01 = f32x2{wp[c4 * 4 + 0], wp[c4 * 4 + 1]}, w23 = f32x2{wp[c4 * 4 + 2], wp[c4 * 4 + 3]};
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const f32x4 d = v[kx + q][c4];
+                        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(l2[q][0]) : "v"(f32x2{d.x, d.y}), "s"(w01));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(l2[q][1]) : "v"(f32x2{d.z, d.w}), "s"(w23));
+                    }
+                }
+            }
+        }
+        const float bd = ((cptr)a.wd)[16 * FR];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int x = xb + q;
+            if (x >= a.W) break;
+            const f32x2 t = l2[q][0] + l2[q][1];
+            const float d = (t.x + t.y) + bd;                     // l1 - l0
+            const float e = expf(-fabsf(d)), big = 1.f / (1.f + e), small = e / (1.f + e);
+            const float pr[2] = {d > 0.f ? small : big, d > 0.f ? big : small};
+            const idx_t p = ((idx_t)y * a.W + x) * NC;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                a.out[p + k] = pr[k];
+                if (a.out_u8 || a.out_mask) {
+                    const uint8_t u = (uint8_t)(pr[k] * 255.0f);          // np.array(p*255, dtype=uint8)
+                    if (a.out_u8) a.out_u8[p + k] = u;
+                    if (a.out_mask) a.out_mask[p + k] = ((double)u > a.thr255) ? 255 : 0;
+                }
+            }
+        }
+        return;
+      }
         // the two classes are one packed accumulator; four independent chains per pixel (one per channel of a quad) are
         // summed at the end.  Weights: uniform addresses -> scalar loads, SGPR operands of the FMAs.
-        typedef const float __attribute__((address_space(4)))* cptr;
         f32x2 l2[2][4];
 #pragma unroll
         for (int q = 0; q < 2; ++q) { l2[q][0] = f32x2{lg[q][0], lg[q][1]}; l2[q][1] = l2[q][2] = l2[q][3] = f32x2{0.f, 0.f}; }

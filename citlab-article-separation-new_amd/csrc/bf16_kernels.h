@@ -749,7 +749,8 @@ __global__ __launch_bounds__(512, 1) void res32_tail_kernel(const ResBArgs a) {
         f32x4 acc2[2][2];
         static_for<4>([&](auto sc) {
             constexpr int step = decltype(sc)::value, ui = step >> 1, r = step & 1;
-            acc2[r][0] = biasw[2][0]; acc2[r][1] = biasw[2][1];
+            // (bias + residual operand as the initial value: the order of convb_kernel's RESP form, which the layer-by-layer twin of this block uses)
+            acc2[r][0] = biasw[2][0] + unpack_bf16x4(resv[ui][r][0]); acc2[r][1] = biasw[2][1] + unpack_bf16x4(resv[ui][r][1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 9; ++k)
@@ -768,8 +769,7 @@ __global__ __launch_bounds__(512, 1) void res32_tail_kernel(const ResBArgs a) {
                     for (int rr = 0; rr < 2; ++rr) {
                         const int y = yc + oy + rr;
                         const size_t p = ((size_t)min(y, H - 1) * W + min(x, W - 1)) * C + m * 16 + kk * 4;
-                        const f32x4 v = acc2[rr][m] + unpack_bf16x4(resv[ui][rr][m]);
-                        const u32x2 q = pack_bf16x4(v);
+                        const u32x2 q = pack_bf16x4(acc2[rr][m]);
                         pk[rr] = u32x2{relu_bf16x2(q.x), relu_bf16x2(q.y)};
                         if (y < H && x < W) *reinterpret_cast<u32x2*>(P.out + p) = pk[rr];
                     }
