@@ -40,6 +40,7 @@ struct PackedConv {
     int bmode = -1;            // convb / deconvb MODE (0: Cin 8, 1: Cin 16, 2: Cin % 32 == 0); -1: not packed
     int bchunks = 0;
     bf16_t* d_wb = nullptr;    // conv: [chunk][mtile][lane][8]; deconv: MODE 2 [G][tap][mtile][lane][8], MODE 1 [frag 0..5][mtile][lane][8]
+    bf16_t* d_wb8 = nullptr;   // deconv 16 -> 8 (level 0): the three class-pair fragments of deconvb8_kernel [3][lane][8]
     // fp32 with split products (split_kernels.h): the filter as three bf16 parts, [chunk][part h, m, l][mtile][lane][8]
     int smode = -1;            // 1: Cin 12 / 16 (chunk = two taps), 2: Cin % 32 == 0 (chunk = tap x 32 channels); -1: not packed
     bf16_t* d_ws = nullptr;
@@ -1081,6 +1082,22 @@ int pack_conv_bf(asep_aru* m, PackedConv& pc, const HostTensor& w) {
     int rc = upload_bf(pk, &pc.d_wb);
     if (rc) return rc;
     m->owned.push_back(pc.d_wb);
+    if (pc.deconv && pc.bmode == 1 && pc.cout == 8) {
+        // deconvb8_kernel: fragment q = (dy = 0, py = 0), (dy = 0, py = 1), (dy = 1, py = 0); row m = 8 px + co; k = 16 dx + ci
+        std::vector<bf16_t> p8;
+        for (int q = 0; q < 3; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int kk = lane >> 4, dx = kk >> 1, ci = (kk & 1) * 8 + j, mrow = lane & 15, px = mrow >> 3, co = mrow & 7;
+                    const int dy = q == 2, py = q == 1;
+                    const int ky = py ? 1 : (dy ? 2 : 0);
+                    const int kx = px ? (dx ? -1 : 1) : (dx ? 2 : 0);
+                    p8.push_back(f2bf(kx < 0 ? 0.f : W(ky * 3 + kx, ci, co)));
+                }
+        rc = upload_bf(p8, &pc.d_wb8);
+        if (rc) return rc;
+        m->owned.push_back(pc.d_wb8);
+    }
     return ASEP_OK;
 }
 
@@ -1502,7 +1519,9 @@ TL run_deconvb(asep_aru* m, const std::string& scope, const TL& in, const TL& li
         out.push_back(new_tensor_bf(m, like[i].H, like[i].W, pc.cout));
     }
     const int mt = pc.mtiles % 2 == 0 ? 2 : 1;
-    const int dth = 8;                                       // input rows per block (16 rows for one m-tile measured slower: 148 -> 187 us at level 0)
+    const bool d8 = pc.d_wb8 && relu_out && !act;           // level 0 (16 -> 8): no LDS, whole pixels straight to HBM
+    const int dth = d8 ? D8_RW : 8;                          // input rows per block (16 rows for one m-tile measured slower: 148 -> 187 us at level 0)
+    const int dtw = d8 ? D8_TW : DCB_TW;
     for (size_t b0 = 0; b0 < in.size(); b0 += MAXP) {
         const size_t b1 = std::min(in.size(), b0 + MAXP);
         DeconvBArgs a{};
@@ -1515,22 +1534,23 @@ TL run_deconvb(asep_aru* m, const std::string& scope, const TL& in, const TL& li
             p.Hi = in[i].H; p.Wi = in[i].W; p.Ho = out[i].H; p.Wo = out[i].W;
             p.pbh = std::max((in[i].H - 1) * 2 + 3 - out[i].H, 0) / 2;
             p.pbw = std::max((in[i].W - 1) * 2 + 3 - out[i].W, 0) / 2;
-            p.tiles_x = cdiv(in[i].W, DCB_TW);
+            p.tiles_x = cdiv(in[i].W, dtw);
             p.tile_begin = tiles;
             tiles += p.tiles_x * cdiv(in[i].H, dth);
             flops += 2.0 * in[i].H * in[i].W * 9.0 * pc.cin * pc.cout;
         }
         a.nprob = (int)(b1 - b0);
-        a.wpk = (const u32x4*)pc.d_wb; a.bias = pc.d_b;
+        a.wpk = (const u32x4*)(d8 ? pc.d_wb8 : pc.d_wb); a.bias = pc.d_b;
         a.cin = pc.cin; a.cout = pc.cout; a.mtiles = pc.mtiles; a.groups = pc.cin / 32; a.relu_out = relu_out; a.act = act;
         int units = tiles;
         a.xm = oneshot_map(m, tiles, &units);
         dim3 grid(units, pc.mtiles / mt);
         TL sub(in.begin() + b0, in.begin() + b1);
-        ProfScope ps(m, "deconvb_kernel" + targs({ti(pc.bmode), ti(mt), ti(dth)}), flops,
+        ProfScope ps(m, d8 ? std::string("deconvb8_kernel") : "deconvb_kernel" + targs({ti(pc.bmode), ti(mt), ti(dth)}), flops,
                      scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
         ps.bytes = bytes;
-        if (pc.bmode == 1 && mt == 1) hipLaunchKernelGGL((deconvb_kernel<1, 1, 8>), grid, dim3(256), 0, m->stream, a);
+        if (d8) hipLaunchKernelGGL(deconvb8_kernel, dim3(units), dim3(256), 0, m->stream, a);
+        else if (pc.bmode == 1 && mt == 1) hipLaunchKernelGGL((deconvb_kernel<1, 1, 8>), grid, dim3(256), 0, m->stream, a);
         else if (pc.bmode == 1) hipLaunchKernelGGL((deconvb_kernel<1, 2, 8>), grid, dim3(256), 0, m->stream, a);
         else if (mt == 1) hipLaunchKernelGGL((deconvb_kernel<2, 1, 8>), grid, dim3(256), 0, m->stream, a);
         else hipLaunchKernelGGL((deconvb_kernel<2, 2, 8>), grid, dim3(256), 0, m->stream, a);

@@ -1197,6 +1197,69 @@ __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// deconvb8_kernel: the level-0 deconvolution (16 -> 8 channels, 3x3, stride 2, SAME, bias + ReLU) without LDS and without barriers (round 5).
+// deconvb_kernel<1, 1, 8> ran it with 16-row m-tiles of which 8 rows are padding (half of every epilogue instruction and of the output tile's
+// LDS traffic wasted), staged the input through LDS for twelve MFMAs per wave and the output through a second tile to write whole rows: 106 us
+// per page for 324 MB (65 us of HBM time).  Here an m-tile = the TWO parity classes px = 0 / 1 of a row class py x 8 channels (rows 0 .. 7:
+// px = 0, rows 8 .. 15: px = 1), so three MFMAs serve an input row (py = 0 <- rows Y and Y - 1, py = 1 <- row Y) and a lane of the D tile holds
+// 4 channels of output pixel 2 j + (kk >> 1); v_permlane16_swap between the py = 0 and py = 1 results makes whole pixels (16 bytes per lane: the
+// 32 lanes of a row write 512 contiguous bytes), which go straight to HBM.  The B fragment of input row Y (16 positions, lane group kk: position
+// j - (kk >> 1), channel half kk & 1) is ONE 16-byte global load per lane and serves rows Y and Y + 1: a wave walks D8_RW consecutive rows of a
+// 16-column block with D8_RW + 1 loads, all requested up front.  ReLU graphs (elu / leaky keep deconvb_kernel).
+// ------------------------------------------------------------------------------------------------
+constexpr int D8_RW = 8, D8_TW = 64;                          // input rows per wave / input columns per block (four waves side by side)
+__global__ __launch_bounds__(256, 4) void deconvb8_kernel(const DeconvBArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int bid = sched_tile(a.xm);
+    if (bid < 0) return;
+    const int pi = prob_of_tile(a, bid);
+    const DeconvBProb& P = a.p[pi];
+    const int tile = bid - P.tile_begin;
+    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const int X0 = tx * D8_TW + wave * 16, Y0 = ty * D8_RW;
+    const int Hi = P.Hi, Wi = P.Wi;
+    if (X0 >= Wi) return;
+    const u32x4 wq0 = a.wpk[lane], wq1 = a.wpk[64 + lane], wq2 = a.wpk[128 + lane];
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + (kk & 1) * 4);
+    // the wave's D8_RW + 1 fragments: input rows Y0 - 1 .. Y0 + D8_RW - 1, position X0 + j - (kk >> 1), 8 of its 16 channels
+    const int xi = X0 + j - (kk >> 1);
+    const bool interior = Y0 >= 1 && Y0 + D8_RW <= Hi && X0 >= 1 && X0 + 16 <= Wi;        // (wave-uniform)
+    u32x4 fr[D8_RW + 1];
+    if (interior) {
+        const unsigned char* __restrict__ src = reinterpret_cast<const unsigned char*>(P.in) + (((size_t)(Y0 - 1) * Wi + xi) * 16 + (kk & 1) * 8) * 2;
+        const size_t rs = (size_t)Wi * 32;
+#pragma unroll
+        for (int r = 0; r <= D8_RW; ++r) fr[r] = *reinterpret_cast<const u32x4*>(src + r * rs);
+    } else {
+        const bool xok = xi >= 0 && xi < Wi;
+        const int xc = min(max(xi, 0), Wi - 1);
+#pragma unroll
+        for (int r = 0; r <= D8_RW; ++r) {
+            const int y = Y0 - 1 + r;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(P.in + ((size_t)min(max(y, 0), Hi - 1) * Wi + xc) * 16 + (kk & 1) * 8);
+            fr[r] = (xok && y >= 0 && y < Hi) ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    // the lane's output pixel of input row Y: (2 Y - pbh + (kk & 1), 2 (X0 + j) - pbw + (kk >> 1)) -- row class py = kk & 1 after the lane trade
+    const int ox = 2 * (X0 + j) - P.pbw + (kk >> 1);
+    const bool oxok = ox >= 0 && ox < P.Wo && X0 + j < Wi;
+    bf16_t* __restrict__ const ob = P.out;
+#pragma unroll
+    for (int r = 0; r < D8_RW; ++r) {
+        f32x4 acc0 = mfma_bf16_k32(wq0, fr[r + 1], b4);       // py = 0: filter row 0 from input row Y ...
+        f32x4 acc1 = mfma_bf16_k32(wq1, fr[r + 1], b4);       // py = 1: filter row 1 from input row Y
+        acc0 = mfma_bf16_k32(wq2, fr[r], acc0);               // ... and filter row 2 from input row Y - 1
+        const u32x2 p0 = pack_bf16x4(acc0), p1 = pack_bf16x4(acc1);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
+        const u32x4 rec = relu_bf16x8(u32x4{s0[0], s1[0], s0[1], s1[1]});
+        const int oy = 2 * (Y0 + r) - P.pbh + (kk & 1);
+        if (oxok && oy >= 0 && oy < P.Ho && Y0 + r < Hi) *reinterpret_cast<u32x4*>(ob + ((size_t)oy * P.Wo + ox) * 8) = rec;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // res8b_kernel<UP>: a WHOLE level-0 residual block (8 channels) of the bf16 path in one kernel.
 //   UP = false (unet_down_0, ARU_v1.py:208-245): t = conv3x3(image, 1 -> 8); r = relu(t); r = relu(convR_0 r); r = relu(convR_1 r);
 //                d0 = relu(convR_2 r + t); also maxpool2(d0).         HBM: fp32 image in, bf16 d0 + pool out.
