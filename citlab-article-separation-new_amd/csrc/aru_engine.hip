@@ -118,7 +118,9 @@ struct asep_aru {
     };
     std::vector<std::unique_ptr<Lane>> lanes;
     Lane* cur = nullptr;
-    int num_lanes = 1;                   // ASEP_LANES: page lanes of a batch call (r4j: 1 / 2 / 3 / 4 lanes = 119.3 / 121.2 / 120.3 / 115.8 pages/s fp32, 417.9 / 422.3 / 417.0 / 369.9 bf16)
+    bool lanes_forced = false;           // ASEP_LANES given: split any batch of >= 2 pages
+    int num_lanes = 2;                   // page lanes of a batch call of >= 8 pages (ASEP_LANES overrides; r4j: 1 / 2 / 3 / 4 lanes = 119.3 / 121.2 / 120.3 / 115.8 pages/s fp32,
+                                         // 417.9 / 422.3 / 417.0 / 369.9 bf16; round 5, after the kernels' latency diet: 1 / 2 / 3 = 467 / 477 / 478 bf16, 137.6 / 139.8 f32s)
     std::map<std::string, Tensor> endpoints;
     hipStream_t stream = nullptr;
     std::vector<void*> owned;
@@ -2101,7 +2103,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     m->fused8_var = variant && !cfg->plain_u && cfg->activation != 0 && m->fused8_wanted && m->r8_valu && m->fuse_act && !m->bf16;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_RES32")) m->use_res32 = atoi(e) != 0;
-    if (const char* e = getenv("ASEP_LANES")) m->num_lanes = std::max(1, std::min(4, atoi(e)));
+    if (const char* e = getenv("ASEP_LANES")) { m->num_lanes = std::max(1, std::min(4, atoi(e))); m->lanes_forced = true; }
     for (int l = 0; l < m->num_lanes; ++l) {
         std::unique_ptr<asep_aru::Lane> L(new asep_aru::Lane());
         bool ok = hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking) == hipSuccess &&
@@ -2212,7 +2214,10 @@ static int forward_lanes(asep_aru* m, int n_pages, const float* const* d_imgs, i
                          uint8_t* const* d_u8, uint8_t* const* d_mask, float threshold, hipStream_t stream) {
     m->endpoints.clear();
     // (per-launch profiling in the isolated mode brackets one kernel at a time: one lane; the in-situ mode keeps the real schedule)
-    const int nl = ((m->profiling && !m->prof_in_situ) || n_pages < 2) ? 1 : std::min<int>((int)m->lanes.size(), n_pages);
+    // a lane takes at least four pages (= one full 12-problem launch per layer with three scales): fewer pages per launch cost the deep levels
+    // more than a second lane returns; ASEP_LANES (lanes_forced) keeps the plain split for the measurement scripts and tests
+    const int by_pages = m->lanes_forced ? n_pages : n_pages / 4;
+    const int nl = ((m->profiling && !m->prof_in_situ) || n_pages < 2) ? 1 : std::max(1, std::min<int>((int)m->lanes.size(), by_pages));
     asep_aru::Lane& L0 = *m->lanes[0];
     L0.s = stream;
     if (nl == 1) return forward_impl(m, L0, 0, n_pages, d_imgs, H, W, d_outs, d_u8, d_mask, threshold);
