@@ -119,8 +119,10 @@ struct asep_aru {
     std::vector<std::unique_ptr<Lane>> lanes;
     Lane* cur = nullptr;
     bool lanes_forced = false;           // ASEP_LANES given: split any batch of >= 2 pages
-    int num_lanes = 2;                   // page lanes of a batch call of >= 8 pages (ASEP_LANES overrides; r4j: 1 / 2 / 3 / 4 lanes = 119.3 / 121.2 / 120.3 / 115.8 pages/s fp32,
-                                         // 417.9 / 422.3 / 417.0 / 369.9 bf16; round 5, after the kernels' latency diet: 1 / 2 / 3 = 467 / 477 / 478 bf16, 137.6 / 139.8 f32s)
+    int num_lanes = 1;                   // ASEP_LANES: page lanes of a batch call (r4j: 1 / 2 / 3 / 4 lanes = 119.3 / 121.2 / 120.3 / 115.8 pages/s fp32, 417.9 / 422.3 / 417.0 /
+                                         // 369.9 bf16; round 5: 1 / 2 / 3 = 467 / 477 / 478 bf16, 137.6 / 139.8 f32s -- two lanes fill the launch tails, but two launches of a
+                                         // kernel then share the chip and each takes twice as long: the per-launch roofline of the bench line would describe the sharing, not
+                                         // the kernel.  One lane stays the default; DESIGN_LESSONS 47)
     std::map<std::string, Tensor> endpoints;
     hipStream_t stream = nullptr;
     std::vector<void*> owned;
