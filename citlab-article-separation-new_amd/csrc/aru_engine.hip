@@ -70,6 +70,7 @@ struct asep_aru {
     bf16_t* d_r8b_down_w = nullptr;  // [3 convs][3 ky][64][8]
     float* d_r8b_down_b = nullptr;   // [3][8]
     bf16_t* d_r8b_up_w1 = nullptr;   // conv1 of unet_up_0 [3 ky][2 halves][64][8]
+    bf16_t* d_r8f_up_w1 = nullptr;   // the same for res8f_kernel's planar input tile [3 ky][2 sources][64][8]: k = 8 (window pixel kk) + channel of the source
     bf16_t* d_r8f_down_w1 = nullptr; // conv1 of unet_down_0 as ONE pair fragment [64][8] (k = window row / column, res8f_kernel)
     float* d_r8b_down_w1r = nullptr; // the same filter [9][8] as fp32 values rounded to bfloat16 (border tiles, res8b_tile)
     bool use_res32 = true;           // ASEP_BF_RES32=0: the 32-channel residual tails layer by layer (convb_kernel)
@@ -1272,6 +1273,18 @@ int pack_res8b(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
         if (rc) return rc;
         m->owned.push_back(m->d_r8b_up_w1);
         m->owned.push_back(m->d_r8b_up_b1);
+        // res8f_kernel (interior tiles) keeps skip and deconv as two 16-byte planes: fragment (ky, source), k = 8 kk + j <-> window pixel kk, channel 8 source + j
+        std::vector<bf16_t> pf;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int src = 0; src < 2; ++src)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int mrow = lane & 15, kk = lane >> 4, e = mrow >> 3, co = mrow & 7, kx = kk - e;
+                        pf.push_back(f2bf((kx >= 0 && kx <= 2) ? w.data[(((size_t)ky * 3 + kx) * 16 + src * 8 + j) * 8 + co] : 0.f));
+                    }
+        rc = upload_bf(pf, &m->d_r8f_up_w1);
+        if (rc) return rc;
+        m->owned.push_back(m->d_r8f_up_w1);
     }
     return ASEP_OK;
 }
@@ -1314,6 +1327,7 @@ void run_res8b(asep_aru* m, bool up, const TL& a0, const TL* a1, const std::vect
             // lean form for interior tiles (their 24 x 40 input window inside the image), general form for border tiles, one launch
             Res8BArgs f = a;
             if (!up) f.w1pk = (const u32x4*)m->d_r8f_down_w1;
+            else f.w1pf = (const u32x4*)m->d_r8f_up_w1;
             ProfScope ps(m, up ? "res8f_kernel<true>" : "res8f_kernel<false>", flops, what);
             ps.bytes = bytes;
             if (up) hipLaunchKernelGGL(res8f_kernel<true>, dim3(units), dim3(256), 0, m->stream, f);

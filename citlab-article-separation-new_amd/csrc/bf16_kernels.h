@@ -1289,6 +1289,7 @@ struct Res8BArgs {
     const float* w1;       // DOWN: conv1 [9][8] fp32 values rounded to bfloat16 (border tiles; the interior tiles' fragment is w1pk)
     const float* b1;       // conv1 bias [8]
     const u32x4* w1pk;     // UP: conv1 pair fragments [ky 3][half 2][64 lanes] x 16 bytes; res8f_kernel DOWN: [64 lanes] (bf16 conv1)
+    const u32x4* w1pf;     // res8f_kernel UP (interior tiles, planar input tile): [ky 3][source 2][64 lanes] x 16 bytes, k = 8 (window pixel) + channel of the source
     const u32x4* wpk;      // tail: [3 convs][ky 3][64 lanes] x 16 bytes
     const float* bias;     // tail biases [3][8]
     XcdMap xm;             // XCD-aware block -> tile map (sched_tile)
@@ -1560,6 +1561,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     constexpr int H0 = TH + 6, W0 = TW + 6, H1 = TH + 4, W1 = TW + 4, W2 = TW + 2;
     constexpr int IH = TH + 8, IW = TW + 8;
     constexpr int INB = UP ? IH * IW * 32 : 2048;             // DOWN: bf16 image tile, (IH + 1) x IW x 2 bytes
+    constexpr int INPL = IH * IW * 16;                        // UP: bytes of one plane of the input tile (plane 0: skip, plane 1: deconv)
     constexpr int R1B = H1 * W1 * 16, R0B = H0 * W0 * 16, TCB = TH * TW * 16;
     constexpr int R1_OFF = UP ? 0 : INB, R0_OFF = UP ? INB : INB + R1B, TC_OFF = R0_OFF + R0B;
     constexpr int LDSB = TC_OFF + TCB > Res8BLayout<UP>::BYTES ? TC_OFF + TCB : Res8BLayout<UP>::BYTES;
@@ -1599,7 +1601,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
     for (int t = 0; t < 3; ++t) biasw[t] = *reinterpret_cast<const f32x4*>(a.bias + 8 * t + ch);
     u32x4 a1[UP ? 6 : 1];
 #pragma unroll
-    for (int t = 0; t < (UP ? 6 : 1); ++t) a1[t] = a.w1pk[t * 64 + lane];
+    for (int t = 0; t < (UP ? 6 : 1); ++t) a1[t] = (UP ? a.w1pf : a.w1pk)[t * 64 + lane];
     const u32x4* __restrict__ wl = a.wpk + lane;
     u32x4 af[3], ag[3];                                      // the fragments of the current / the next convR (requested a stage ahead)
 #pragma unroll
@@ -1617,12 +1619,14 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
             st[2 * k] = *reinterpret_cast<const u32x4*>(sk + (goff + k * gstep));
             st[2 * k + 1] = *reinterpret_cast<const u32x4*>(dc + (goff + k * gstep));
         }
-        unsigned char* const dst = in + (lr * IW + lc) * 32;
+        // two PLANES of 16 bytes per pixel (skip, deconv), not 32-byte pixel records: a store instruction then writes 64 consecutive 16-byte units
+        // (55 instead of 130 ticks per instruction and wave, lesson 44) and conv1's fragment reads take the stages' conflict-free pattern
+        unsigned char* const dst = in + (lr * IW + lc) * 16;
         if (ldr) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                *reinterpret_cast<u32x4*>(dst + k * 6 * IW * 32) = st[2 * k];
-                *reinterpret_cast<u32x4*>(dst + k * 6 * IW * 32 + 16) = st[2 * k + 1];
+                *reinterpret_cast<u32x4*>(dst + k * 6 * IW * 16) = st[2 * k];
+                *reinterpret_cast<u32x4*>(dst + INPL + k * 6 * IW * 16) = st[2 * k + 1];
             }
         }
     } else {
@@ -1678,14 +1682,15 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8f_kernel(const Res8BArgs 
         // fragments of the pairs whose first pixels are (rowA, colA) / (rowB, colB) of region 0 = input-tile pixels (row .. row + 2, col .. col + 3)
         auto c1_load = [&](C1F& f, int rowA, int colA, int rowB, int colB) {
             if constexpr (UP) {
-                const unsigned char* pa = in + (rowA * IW * 32 + (colA + (kk >> 1)) * 32 + (kk & 1) * 16);
-                const unsigned char* pb = in + (rowB * IW * 32 + (colB + (kk >> 1)) * 32 + (kk & 1) * 16);
+                // fragment (ky, source): the lane's window pixel kk of filter row ky in the source's plane
+                const unsigned char* pa = in + (rowA * IW + colA + kk) * 16;
+                const unsigned char* pb = in + (rowB * IW + colB + kk) * 16;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) {
-                        f.a[ky * 2 + hf] = *reinterpret_cast<const u32x4*>(pa + (ky * IW + 2 * hf) * 32);
-                        f.b[ky * 2 + hf] = *reinterpret_cast<const u32x4*>(pb + (ky * IW + 2 * hf) * 32);
+                    for (int src = 0; src < 2; ++src) {
+                        f.a[ky * 2 + src] = *reinterpret_cast<const u32x4*>(pa + src * INPL + ky * IW * 16);
+                        f.b[ky * 2 + src] = *reinterpret_cast<const u32x4*>(pb + src * INPL + ky * IW * 16);
                     }
             } else {
                 // k = 8 kk + jj: lane group kk holds window rows 2 kk, 2 kk + 1 (jj >> 2), columns jj & 3 (groups 2, 3: zero weights)
