@@ -18,6 +18,16 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* cyc, float* out) {
     const unsigned a16 = (unsigned)((wave & 3) * 16384 + lane * 16), a8 = (unsigned)((wave & 3) * 16384 + lane * 8), a4 = (unsigned)((wave & 3) * 16384 + lane * 4);
     // stride-32 pattern of a 32-byte-per-pixel tile (a lane's 16-byte half of its pixel): the conv1 (UP) / res16f access shape
     const unsigned a32 = (unsigned)((wave & 3) * 16384 + (lane & 15) * 64 + (lane >> 4) * 16);
+    // res16f / convb MODE 1 patterns (32 bytes per pixel): read = pixel j + (kk >> 1), half kk & 1; D-fragment store = pixel j, 8 bytes at kk * 8
+    const unsigned a16r = (unsigned)((wave & 3) * 16384 + ((lane & 15) + (lane >> 5)) * 32 + ((lane >> 4) & 1) * 16);
+    const unsigned a16w = (unsigned)((wave & 3) * 16384 + (lane & 15) * 32 + (lane >> 4) * 8);
+    // the planar alternative: plane kk & 1 (8 KB apart), pixel j + (kk >> 1), 16 bytes; store: plane kk >> 1, pixel j, 8 bytes at (kk & 1) * 8
+    const unsigned a16rp = (unsigned)((wave & 3) * 16384 + ((lane >> 4) & 1) * 8192 + ((lane & 15) + (lane >> 5)) * 16);
+    const unsigned a16wp = (unsigned)((wave & 3) * 16384 + (lane >> 5) * 8192 + (lane & 15) * 16 + ((lane >> 4) & 1) * 8);
+    // res8f whole-pixel store of a tile pair: lane (j, kk) -> row kk & 1, pixel 2 j + (kk >> 1), 16 bytes; and the parity-planar alternative
+    // (pixel p in plane p & 1 at index p >> 1): row kk & 1, plane kk >> 1, index j
+    const unsigned a8w = (unsigned)((wave & 3) * 16384 + ((lane >> 4) & 1) * 608 + (lane & 15) * 32 + (lane >> 5) * 16);
+    const unsigned a8wp = (unsigned)((wave & 3) * 16384 + ((lane >> 4) & 1) * 608 + (lane >> 5) * 304 + (lane & 15) * 16);
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < N_IT; ++it) {
 #pragma unroll
@@ -30,6 +40,12 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* cyc, float* out) {
             else if constexpr (OP == 5) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r1) : "v"(a4), "n"(u * 256));
             else if constexpr (OP == 6) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r4) : "v"(a32), "n"(u * 1024));
             else if constexpr (OP == 7) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a32), "v"(v), "n"(u * 1024));
+            else if constexpr (OP == 8) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r4) : "v"(a16r), "n"(u * 256));
+            else if constexpr (OP == 9) asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a16w), "v"(u32x2{v.x, v.y}), "n"(u * 256));
+            else if constexpr (OP == 10) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r4) : "v"(a16rp), "n"(u * 128));
+            else if constexpr (OP == 12) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a8w), "v"(v), "n"(u * 1216));
+            else if constexpr (OP == 13) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a8wp), "v"(v), "n"(u * 1216));
+            else if constexpr (OP == 11) asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a16wp), "v"(u32x2{v.x, v.y}), "n"(u * 128));
         }
         asm volatile("s_waitcnt lgkmcnt(0)");
     }
@@ -53,6 +69,9 @@ int main() {
     printf("ticks = s_memtime (100 MHz): RATIOS between rows are what counts\n");
     run<0>("ds_write_b128 (contiguous)", 16, c, d); run<1>("ds_write_b64", 8, c, d); run<2>("ds_write_b32", 4, c, d);
     run<3>("ds_read_b128 (contiguous)", 16, c, d); run<4>("ds_read_b64", 8, c, d); run<5>("ds_read_b32", 4, c, d);
-    run<6>("ds_read_b128 (16 B of 32 B pixels)", 16, c, d); run<7>("ds_write_b128 (16 B of 32 B pixels)", 16, c, d);
+    run<6>("ds_read_b128 (16 B of 64 B pairs)", 16, c, d); run<7>("ds_write_b128 (16 B of 64 B pairs)", 16, c, d);
+    run<8>("ds_read_b128 res16f B fragment", 16, c, d); run<10>("ds_read_b128 the same, planar", 16, c, d);
+    run<12>("ds_write_b128 res8f pixel records", 16, c, d); run<13>("ds_write_b128 the same, parity planes", 16, c, d);
+    run<9>("ds_write_b64 res16f D fragment", 8, c, d); run<11>("ds_write_b64 the same, planar", 8, c, d);
     return 0;
 }
