@@ -522,6 +522,27 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
                     "note": "the headline step with compute_dtype f32: every product on the fp32 matrix / vector pipes (the rounds 1-4 headline); child process"}
             else:
                 out["plain_f32_full_step"] = {"error": f"f32 child exited with {r.returncode}"}
+        # ---- the same steps on TWO page lanes (ASEP_LANES=2: the pages of a call on two stream sets).  Faster by 1.5-2 % since round 5 -- and not the
+        #      default: two launches of a kernel then share the chip, each takes twice as long, and a per-launch roofline (this line's, rocprofv3's
+        #      AverageNs) would describe the sharing instead of the kernel (DESIGN_LESSONS 47).  Throughput only, no event passes. ----
+        if args.dtype == "f32s" and args.bf16_steps > 0 and "ASEP_LANES" not in os.environ:
+            import subprocess
+            lanes = {}
+            for dt, st in (("f32s", max(10, args.steps // 3)), ("bf16", max(20, args.bf16_steps // 2))):
+                cmd = [sys.executable, os.path.abspath(__file__), "--dtype", dt, "--steps", str(st), "--warmup", "2",
+                       "--pages-per-step", str(args.pages_per_step), "--height", str(H), "--width", str(W), "--gnn", args.gnn,
+                       "--no-cpu-baseline", "--no-secondary", "--kernel-timing", "none"]
+                env = dict(os.environ, ASEP_BENCH_DEVICE=str(dev.index or 0), ASEP_LANES="2")
+                r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True, timeout=1200)
+                lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+                if r.returncode == 0 and lines:
+                    q = json.loads(lines[-1])
+                    lanes[dt] = {"pages_per_s": q["value"], "ms_per_step": q["ms_per_step"], "steps": q["steps"]}
+                else:
+                    lanes[dt] = {"error": f"child exited with {r.returncode}"}
+            lanes["note"] = ("the headline step and the bf16 step with ASEP_LANES=2 (child processes; throughput only). One lane is the default because "
+                             "concurrent launches of one kernel double its per-launch duration, the quantity the roofline block is defined on")
+            out["two_page_lanes_full_step"] = lanes
         # ---- files in, files out ----
         if args.e2e_pages > 0:
             # in a child process of its own, so that the leg's worker processes do not inherit this process's module state

@@ -65,6 +65,8 @@ def test_single_process_line():
     p32 = sec["plain_f32_full_step"]
     assert "error" not in p32, p32
     assert p32["pages_per_s"] > 0 and p32["steps"] == 2 and p32["dtype"] == "f32" and 0 < p32["roofline"]["frac"] <= 1.0
+    tl = sec["two_page_lanes_full_step"]                  # round 5: the same steps with ASEP_LANES=2 (throughput only; one lane is the default, DESIGN_LESSONS 47)
+    assert tl["f32s"]["pages_per_s"] > 0 and tl["bf16"]["pages_per_s"] > 0 and "per-launch" in tl["note"]
     up = sec["upstream_layout_6x5"]
     assert up["f32s"]["pages_per_s"] > 0 and up["bf16"]["pages_per_s"] > up["f32s"]["pages_per_s"] and 1000 < up["f32s"]["gflop_per_page"] < 1120
     assert all("executed_tflops" in k and 0 <= k["executed_frac_of_pipe_peak"] <= 1.0 for k in line["kernels"])
