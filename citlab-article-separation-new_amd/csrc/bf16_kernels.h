@@ -245,20 +245,6 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
 #pragma unroll
             for (int i = 0; i < NLOAD; ++i) st[i] = *reinterpret_cast<const u32x4*>(src + (size_t)spix[i] * cs);
         }
-#if defined(CVB_WREG)
-        // experiment: the A fragments through registers (global_load_dwordx4 + ds_write_b128) instead of LDS-DMA
-        u32x4 wreg[NWLOAD];
-#pragma unroll
-        for (int i = 0; i < NWLOAD; ++i) {
-            const int u = min(i * NTH + tid, NWU - 1);
-            const int t = u / (MTB * 64), r = u - t * (MTB * 64);
-            wreg[i] = wsrc[(size_t)(g * CPS + t) * wstride + min(r, mt_have * 64 - 1)];
-        }
-        if (g > 0) __syncthreads();                          // the previous stage's readers are done
-#pragma unroll
-        for (int i = 0; i < NWLOAD; ++i)
-            if (i * NTH + tid < NWU) *reinterpret_cast<u32x4*>(wlds + (i * NTH + tid) * 16) = wreg[i];
-#else
         if (g > 0) __syncthreads();                          // the previous stage's readers are done
         // A fragments: global -> LDS without registers (global_load_lds_dwordx4: one wave-instruction copies 1 KB, lane i to
         // base + 16 i); whole waves, NWU is a multiple of 64
@@ -273,7 +259,6 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
                                                  (__attribute__((address_space(3))) void*)(wlds + u0 * 16), 16, 0, 0);
             }
         }
-#endif
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             if (i * NTH + NTH - 1 < NU || tid + i * NTH < NU) {
