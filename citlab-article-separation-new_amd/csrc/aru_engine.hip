@@ -9,7 +9,6 @@
 #include "res8_kernels.h"
 #include "res8v_kernels.h"
 #include "bf16_kernels.h"
-#include "convw_kernels.h"
 #include "split_kernels.h"
 #include "asep_common.h"
 
@@ -75,7 +74,6 @@ struct asep_aru {
     bf16_t* d_r8f_down_w1 = nullptr; // conv1 of unet_down_0 as ONE pair fragment [64][8] (k = window row / column, res8f_kernel)
     float* d_r8b_down_w1r = nullptr; // the same filter [9][8] as fp32 values rounded to bfloat16 (border tiles, res8b_tile)
     bool use_res32 = true;           // ASEP_BF_RES32=0: the 32-channel residual tails layer by layer (convb_kernel)
-    bool use_convw = true;           // ASEP_BF_CONVW=0: the 64-output-channel layers on convb_kernel's eight-wave form (A/B; convw_kernels.h)
     bf16_t* d_r8b_up_w = nullptr;    // [3][3][64][8]
     float* d_r8b_up_b = nullptr;     // [3][8]
     float* d_r8b_up_b1 = nullptr;    // [8]
@@ -1428,27 +1426,6 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
         TL sub(in0.begin() + b0, in0.begin() + b1);
         ProfScope ps(m, "convb_kernel", flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
         ps.bytes = bytes;
-        // 64 output channels, 32 / 64 input channels, 3x3, ReLU graphs: the whole filter resident in LDS, one persistent block per CU (convw_kernels.h)
-        bool convw = m->use_convw && mtb == 4 && pc.mtiles == 4 && pc.bmode == 2 && pc.kh == 3 && pc.kw == 3 && cin <= 64 && !act && !pool_f32;
-        for (size_t i = b0; convw && res && i < b1; ++i) convw = tbytes((*res)[i]) < 4294967296.0;
-        if (convw) {
-            static bool attr = false;
-            if (!attr) {
-                ASEP_HIP_CHECK_THROW(hipFuncSetAttribute((const void*)convw_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvWLayout::BYTES));
-                ASEP_HIP_CHECK_THROW(hipFuncSetAttribute((const void*)convw_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvWLayout::BYTES));
-                ASEP_HIP_CHECK_THROW(hipFuncSetAttribute((const void*)convw_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvWLayout::BYTES));
-                ASEP_HIP_CHECK_THROW(hipFuncSetAttribute((const void*)convw_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvWLayout::BYTES));
-                attr = true;
-            }
-            ps.set_name("convw_kernel" + targs({tb(res != nullptr), tb(relu_in)}));
-            if (!a.xm.chunk) { a.xm.chunk = cdiv(tiles, 8); a.xm.total = tiles; }
-            const dim3 pgrid(std::max(8, std::min((m->num_cus / 8) * 8, 8 * a.xm.chunk)));
-            if (res && relu_in) hipLaunchKernelGGL((convw_kernel<true, true>), pgrid, dim3(CW_NTH), ConvWLayout::BYTES, m->stream, a);
-            else if (res) hipLaunchKernelGGL((convw_kernel<true, false>), pgrid, dim3(CW_NTH), ConvWLayout::BYTES, m->stream, a);
-            else if (relu_in) hipLaunchKernelGGL((convw_kernel<false, true>), pgrid, dim3(CW_NTH), ConvWLayout::BYTES, m->stream, a);
-            else hipLaunchKernelGGL((convw_kernel<false, false>), pgrid, dim3(CW_NTH), ConvWLayout::BYTES, m->stream, a);
-            continue;
-        }
         bool res32 = res != nullptr;                          // the RESP kernels address the residual operand with 32-bit byte offsets
         for (size_t i = b0; res && i < b1; ++i) res32 = res32 && tbytes((*res)[i]) < 4294967296.0;
         const int key = pc.kh * 100 + pc.bmode * 10 + mtb + (th == 8 && mtb == 2 ? 1000 : 0) + (res32 && pc.bmode == 2 && pc.kh == 3 && mtb >= 2 ? 2000 : 0);
@@ -2142,7 +2119,6 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     m->fused8_var = variant && !cfg->plain_u && cfg->activation != 0 && m->fused8_wanted && m->r8_valu && m->fuse_act && !m->bf16;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_RES32")) m->use_res32 = atoi(e) != 0;
-    if (const char* e = getenv("ASEP_BF_CONVW")) m->use_convw = atoi(e) != 0;
     if (const char* e = getenv("ASEP_LANES")) { m->num_lanes = std::max(1, std::min(4, atoi(e))); m->lanes_forced = true; }
     for (int l = 0; l < m->num_lanes; ++l) {
         std::unique_ptr<asep_aru::Lane> L(new asep_aru::Lane());
