@@ -40,6 +40,9 @@ METRIC = "newspaper pages/sec (ARU-Net seg + GNN relation) at 3000x4500 px"
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # same guide: dense bf16 matrix peak (not the 2:1-sparsity headline)
 PEAK_HBM_GBS = 8000.0
+# ASEP_* names the Python side / this script reads (not engine switches)
+HOST_VARIABLES = {"ASEP_HIP_LIB", "ASEP_COMPUTE_DTYPE", "ASEP_GPU_OWNERS", "ASEP_OWNER_STATS_DIR", "ASEP_BENCH_DEVICE", "ASEP_BENCH_BACKEND",
+                  "ASEP_BENCH_FORCE_DIST", "ASEP_BENCH_OWNERS", "ASEP_LAYER_PROFILE_CFG", "ASEP_LAYER_PROFILE_PAGES", "ASEP_POOL_TRACE"}
 ACHIEVABLE_HBM_GBS = 6300.0         # same guide: float4 copy, 79 % of the 8 TB/s peak
 
 
@@ -204,15 +207,61 @@ def run_cpu_baseline_full(args):
     return q
 
 
+# The fused level-0 residual blocks are ONE design instantiated for the two directions of the U (down: image in, pool out; up: the
+# concatenation [skip, deconv] in): they are ranked and reported as one entry, "a+b" (under the isolated
+# ranking the up block led, under rocprofv3's the down block, and the line printed the figure of whichever it had picked).
+LEVEL0_FAMILIES = (("res8v_down_kernel", "res8v_up_kernel"), ("res8_down_kernel", "res8_up_kernel"), ("res8f_kernel<false>", "res8f_kernel<true>"),
+                   ("res8b_kernel<false>", "res8b_kernel<true>"))
+
+
+def family_members(kernel, names):
+    """-> the kernels of `names` that are reported together with `kernel` (itself alone for everything but the level-0 blocks)"""
+    for fam in LEVEL0_FAMILIES:
+        if kernel.startswith(fam):
+            tail = kernel[len(next(f for f in fam if kernel.startswith(f))):]          # e.g. "<0>": the activation of the res8v blocks
+            return sorted(n for n in names if n.startswith(fam) and n[len(next(f for f in fam if n.startswith(f))):] == tail)
+    return [kernel]
+
+
+def merge_records(recs):
+    """kernel records of one pass -> one record "a+b": summed launches, time, FLOPs and bytes; rates and the mean launch recomputed"""
+    if len(recs) == 1:
+        return dict(recs[0])
+    m = {"kernel": "+".join(r["kernel"] for r in recs), "members": [r["kernel"] for r in recs]}
+    for key in ("calls", "total_ms", "flops", "bytes", "executed_flops"):
+        m[key] = sum(r.get(key, 0.0) for r in recs)
+    sec = m["total_ms"] * 1e-3
+    m["avg_us"] = 1e3 * m["total_ms"] / m["calls"]
+    m["tflops"] = m["flops"] / sec / 1e12 if sec > 0 else 0.0
+    m["executed_tflops"] = m["executed_flops"] / sec / 1e12 if sec > 0 else 0.0
+    m["algo_gbs"] = m["bytes"] / sec / 1e9 if sec > 0 else 0.0
+    for key in ("pipe", "pipe_peak", "bf16_tflops"):
+        if key in recs[0]:
+            m[key] = recs[0][key]
+    return m
+
+
 def rank_kernels(iso, situ):
-    """kernel records ({name: {"kernel", "total_ms", ...}}) of the isolated and / or the in-situ pass -> list, largest summed launch
-    time first: ranked on the isolated totals; if the two leaders lie within 5 % of each other there, the in-situ totals decide"""
-    base = iso or situ
-    kernels = sorted(base.values(), key=lambda k: -k["total_ms"])
-    if iso and situ and len(kernels) > 1 and kernels[1]["total_ms"] > 0.95 * kernels[0]["total_ms"]:
-        lead2 = sorted(kernels[:2], key=lambda k: -situ.get(k["kernel"], k)["total_ms"])
-        kernels = lead2 + kernels[2:]
-    return kernels
+    """kernel records ({name: {"kernel", "total_ms", ...}}) of the isolated and / or the in-situ pass -> list of ENTRIES (a kernel, or
+    the two level-0 blocks as one "a+b" entry), largest summed launch time first.  Ranked IN SITU when that pass exists (round 6; the
+    isolated figures ride beside it): rounds 3-5 ranked on the isolated totals and printed the in-situ figure of the kernel that led THERE."""
+    base = situ or iso
+    seen, entries = set(), []
+    for name in base:
+        if name in seen:
+            continue
+        mem = family_members(name, list(base))
+        seen.update(mem)
+        entries.append(merge_records([base[n] for n in mem]))
+    return sorted(entries, key=lambda k: -k["total_ms"])
+
+
+def entry_of(records, entry):
+    """the same entry (kernel or "a+b") built from another pass's records, or None"""
+    if not records:
+        return None
+    mem = entry.get("members") or [entry["kernel"]]
+    return merge_records([records[n] for n in mem]) if all(n in records for n in mem) else None
 
 
 def _timed(fn, iters, warmup=1):
@@ -522,9 +571,9 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
                     "note": "the headline step with compute_dtype f32: every product on the fp32 matrix / vector pipes (the rounds 1-4 headline); child process"}
             else:
                 out["plain_f32_full_step"] = {"error": f"f32 child exited with {r.returncode}"}
-        # ---- the same steps on TWO page lanes (ASEP_LANES=2: the pages of a call on two stream sets).  Faster by 1.5-2 % since round 5 -- and not the
-        #      default: two launches of a kernel then share the chip, each takes twice as long, and a per-launch roofline (this line's, rocprofv3's
-        #      AverageNs) would describe the sharing instead of the kernel (DESIGN_LESSONS 47).  Throughput only, no event passes. ----
+        # ---- the same steps on ONE page lane (ASEP_LANES=1: rounds 1-5's default schedule).  Two lanes are the default since round 6 (the round-5
+        #      driver run: f32s 135.8 -> 138.4, bf16 469.6 -> 487.5, outputs bit-identical); the roofline block's per-launch figures come from
+        #      one-lane event passes either way (DESIGN_LESSONS 47, 49).  Throughput only, no event passes. ----
         if args.dtype == "f32s" and args.bf16_steps > 0 and "ASEP_LANES" not in os.environ:
             import subprocess
             lanes = {}
@@ -532,7 +581,7 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
                 cmd = [sys.executable, os.path.abspath(__file__), "--dtype", dt, "--steps", str(st), "--warmup", "2",
                        "--pages-per-step", str(args.pages_per_step), "--height", str(H), "--width", str(W), "--gnn", args.gnn,
                        "--no-cpu-baseline", "--no-secondary", "--kernel-timing", "none"]
-                env = dict(os.environ, ASEP_BENCH_DEVICE=str(dev.index or 0), ASEP_LANES="2")
+                env = dict(os.environ, ASEP_BENCH_DEVICE=str(dev.index or 0), ASEP_LANES="1")
                 r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True, timeout=1200)
                 lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
                 if r.returncode == 0 and lines:
@@ -540,9 +589,9 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
                     lanes[dt] = {"pages_per_s": q["value"], "ms_per_step": q["ms_per_step"], "steps": q["steps"]}
                 else:
                     lanes[dt] = {"error": f"child exited with {r.returncode}"}
-            lanes["note"] = ("the headline step and the bf16 step with ASEP_LANES=2 (child processes; throughput only). One lane is the default because "
-                             "concurrent launches of one kernel double its per-launch duration, the quantity the roofline block is defined on")
-            out["two_page_lanes_full_step"] = lanes
+            lanes["note"] = ("the headline step and the bf16 step with ASEP_LANES=1 (child processes; throughput only): the schedule of rounds 1-5. "
+                             "The default is two page lanes for calls of >= 8 pages")
+            out["one_page_lane_full_step"] = lanes
         # ---- files in, files out ----
         if args.e2e_pages > 0:
             # in a child process of its own, so that the leg's worker processes do not inherit this process's module state
@@ -557,6 +606,24 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
     return out
 
 
+# every kernel of csrc/bf16_kernels.h that multiplies on v_mfma_f32_16x16x32_bf16 (tests/test_bench_host.py holds this list against the
+# __global__ functions of that header: a new kernel that is missing here would be priced against the fp32 peak, 16 x too kind -- ADVICE r5)
+BF16_MFMA_KERNELS = ("convb_kernel", "deconvb_kernel", "deconvb8_kernel", "res8f_kernel", "res8b_kernel", "res16f_kernel", "res32_tail_kernel",
+                     "resb_tail_kernel", "att_headb_kernel")
+# `roofline.bound` names the pipe the dominant kernel is priced against
+BOUND_OF_PIPE = {"bf16 MFMA": "mfma_bf16", "fp32 MFMA": "mfma_fp32"}
+
+
+def bound_of(pipe, hbm_bound):
+    if hbm_bound:
+        return "hbm"
+    if pipe.startswith("fp32 vector ALU"):
+        return "valu_fp32"
+    if pipe.startswith("bf16 MFMA, 6 split"):
+        return "mfma_bf16_split6"
+    return BOUND_OF_PIPE.get(pipe, "mfma")
+
+
 def pipe_of(kernel, dtype):
     """-> (pipe, peak in TFLOP/s of fp32-equivalent products) of a kernel of the ARU-Net engine.
     fp32 MFMA and the fp32 vector ALU are ONE datapath on gfx950 (157.3 TFLOP/s either way, DESIGN lesson 15); a split-product kernel
@@ -564,8 +631,7 @@ def pipe_of(kernel, dtype):
     convolutions run at the dense bf16 peak."""
     if kernel.startswith(("convs_kernel", "convs16_kernel")):
         return "bf16 MFMA, 6 split products per fp32 product", PEAK_BF16_MFMA_TFLOPS / 6.0
-    if dtype == "bf16" and kernel.startswith(("convb_kernel", "deconvb_kernel", "res8f_kernel", "res8b_kernel", "res16f_kernel", "res32_tail_kernel",
-                                               "resb_tail_kernel")):
+    if dtype == "bf16" and kernel.startswith(BF16_MFMA_KERNELS):
         return "bf16 MFMA", PEAK_BF16_MFMA_TFLOPS
     if kernel.startswith(("res8v_", "deconv8v_kernel", "att_headv_kernel", "conv_c1out_kernel", "conv_c1_kernel", "combine_kernel")):
         return "fp32 vector ALU (v_pk_fma_f32: the fp32 MFMA's datapath and peak)", PEAK_F32_MFMA_TFLOPS
@@ -589,19 +655,19 @@ def build_roofline(args, dom, d_iso, d_situ, kernels, exec_flops_page, pages_per
     hbm_bound = args.dtype == "bf16"
     calls = dom["calls"]
     algo_bytes = dom["bytes"] / calls
-    pipe, pipe_peak = pipe_of(dom["kernel"], args.dtype)
+    pipe, pipe_peak = pipe_of((dom.get("members") or [dom["kernel"]])[0], args.dtype)
     rate = (lambda d: d["algo_gbs"]) if hbm_bound else (lambda d: d["executed_tflops"])
     peak = PEAK_HBM_GBS if hbm_bound else pipe_peak
     total_ms = sum(k["total_ms"] for k in kernels)
     if pipe_seconds_page is None:               # (callers without per-kernel pipes: everything priced against peak_tf)
         pipe_seconds_page = exec_flops_page / (peak_tf * 1e12)
     r = {
-        "bound": "hbm" if hbm_bound else "mfma", "kernel": dom["kernel"],
+        "bound": bound_of(pipe, hbm_bound), "kernel": dom["kernel"],
         "achieved": round(rate(lead), 1 if hbm_bound else 3), "peak": round(peak, 2), "unit": "GB/s" if hbm_bound else "TFLOP/s",
         "frac": round(rate(lead) / peak, 4),
         "traffic": None, "algorithmic_bytes": round(algo_bytes), "hbm_frac": None,
         "whole_page_traffic_gb": None, "whole_page_hbm_frac": None,
-        "timing": "in situ" if d_situ else "isolated",
+        "timing": ("in situ, one page lane (event passes run on one lane)" if d_situ else "isolated"),
         "frac_in_situ": round(rate(d_situ) / peak, 4) if d_situ else None,
         "frac_isolated": round(rate(d_iso) / peak, 4) if d_iso else None,
         **({"mfma_frac": round(lead["executed_tflops"] / peak_tf, 4)} if hbm_bound else
@@ -614,7 +680,7 @@ def build_roofline(args, dom, d_iso, d_situ, kernels, exec_flops_page, pages_per
         "traffic_source": None,
     }
     detail = {
-        "layout": 5,
+        "layout": 6,
         "avg_launch_us_in_situ": round(d_situ["avg_us"], 2) if d_situ else None,
         "avg_launch_us_isolated": round(d_iso["avg_us"], 2) if d_iso else None,
         "launch_population": "all launches of this kernel in a step" + (": the page net's and the relation nets' backbone's" if visual else ""),
@@ -636,6 +702,11 @@ def build_roofline(args, dom, d_iso, d_situ, kernels, exec_flops_page, pages_per
         "whole_page_algorithmic_gb": round(sum(k["bytes"] for k in kernels) / (B * n_prof) / 1e9, 3),
         "mfma_peak": peak_tf, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_achievable_gbs": ACHIEVABLE_HBM_GBS,
     }
+    if dom.get("members"):                            # the level-0 blocks as one entry: each member's own figures
+        by_name = {k["kernel"]: k for k in kernels}
+        detail["members"] = [{"kernel": n, "calls": by_name[n]["calls"], "avg_us": round(by_name[n]["avg_us"], 2),
+                              "frac": round((by_name[n]["algo_gbs"] if hbm_bound else by_name[n]["executed_tflops"]) / peak, 4)}
+                             for n in dom["members"] if n in by_name]
     tp = os.path.join(ROOT, "profiles", "traffic_per_kernel.json" if args.dtype == "f32" else f"traffic_per_kernel_{args.dtype}.json")
     # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md, scripts/make_traffic_json.py).  The counters cannot
     # be read from inside this process: the figure comes from the committed summary of the SAME workload (same pages per step, same
@@ -644,14 +715,21 @@ def build_roofline(args, dom, d_iso, d_situ, kernels, exec_flops_page, pages_per
         tj_all = json.load(open(tp))
         want = {"dtype": args.dtype, "pages_per_step": B, "relation_net": "none" if args.no_gnn else args.gnn, "height": H, "width": W}
         diff = {k: (tj_all.get(k), v) for k, v in want.items() if tj_all.get(k) != v}
-        tj = tj_all["kernels"].get(dom["kernel"])
+        mem = dom.get("members") or [dom["kernel"]]
+        tjs = [tj_all["kernels"].get(n) for n in mem]
+        tj = None
+        if all(tjs):                                  # an "a+b" entry: the mean launch of the family, weighted by the counted dispatches
+            nd = sum(t["dispatches"] for t in tjs)
+            tj = {"bytes_per_launch": sum(t["bytes_per_launch"] * t["dispatches"] for t in tjs) / nd}
         if diff:
             r["traffic_source"] = ("no counters for this workload: " + ", ".join(f"{k} {a} != {b}" for k, (a, b) in diff.items()))[:118]
         elif not tj:
             r["traffic_source"] = f"{os.path.basename(tp)} has no row for this kernel"
         else:
             r["traffic"] = round(tj["bytes_per_launch"])
-            r["traffic_source"] = f"offline PMC: {tj_all.get('source')} @ {tj_all.get('commit', 'n/a')}"[:118]
+            src = str(tj_all.get("source"))
+            tracked = src.startswith("profiles/") and os.path.exists(os.path.join(ROOT, src))
+            r["traffic_source"] = (f"offline PMC: {src} @ {tj_all.get('commit', 'n/a')}" + ("" if tracked else " (being collected)"))[:118]
             tbs = r["traffic"] / (lead["avg_us"] * 1e-6) / 1e12
             r["hbm_frac"] = round(tbs / (PEAK_HBM_GBS / 1e3), 4)
             r["whole_page_traffic_gb"] = round(tj_all["page_bytes"] / 1e9, 2)
@@ -867,15 +945,18 @@ def main():
             for k in json.loads(buf.value.decode()):
                 if h == h_aru:
                     main_calls[k["kernel"]] = k["calls"]
-                m = merged.setdefault(k["kernel"], {"kernel": k["kernel"], "calls": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0})
+                m = merged.setdefault(k["kernel"], {"kernel": k["kernel"], "calls": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0, "xflops": 0.0})
                 m["calls"] += k["calls"]; m["total_ms"] += k["total_ms"]; m["flops"] += k["flops"]; m["bytes"] += k.get("bytes", 0.0)
+                m["xflops"] += k.get("executed_flops", k["flops"])
         for k in merged.values():
             k["avg_us"] = 1e3 * k["total_ms"] / k["calls"]
             k["tflops"] = k["flops"] / (k["total_ms"] * 1e-3) / 1e12 if k["total_ms"] > 0 else 0.0
             # Winograd F(2x2,3x3) kernels are credited with the direct-convolution FLOPs of their layers (the algorithmic
             # work) but execute 2.25x fewer multiplications on the MFMA: report both
-            k["executed_flops"] = k["flops"] / 2.25 if "wino" in k["kernel"] else k["flops"]
-            k["executed_tflops"] = k["tflops"] / 2.25 if "wino" in k["kernel"] else k["tflops"]
+            # (other kernels that execute fewer products than their credit say so themselves: the engine's "executed_flops", e.g. the
+            #  logits conv of combine_kernel on the difference filter of two classes behind a soft-max -- ADVICE r5)
+            k["executed_flops"] = k["xflops"] / 2.25 if "wino" in k["kernel"] else k["xflops"]
+            k["executed_tflops"] = k["executed_flops"] / (k["total_ms"] * 1e-3) / 1e12 if k["total_ms"] > 0 else 0.0
             # split-product kernels (f32s): every fp32 product is SIX bf16 products on the bf16 pipe; executed_* stays the fp32-equivalent
             # figure (1 x), bf16_tflops is what the bf16 matrix pipeline executes
             k["bf16_tflops"] = 6.0 * k["tflops"] if k["kernel"].startswith(("convs_kernel", "convs16_kernel")) else 0.0
@@ -892,14 +973,14 @@ def main():
             iso, n_prof, main_calls = kernel_pass(1)
         if args.kernel_timing in ("both", "in-situ"):
             situ, n_prof, main_calls = kernel_pass(3)
-        # the dominant kernel = the largest summed launch time.  The isolated pass times a kernel exactly (nothing beside it), the
-        # in-situ pass includes what a launch waits behind other streams' work (an event pair brackets queueing as well), so the
-        # ranking is taken from the isolated totals -- unless the two leaders lie within 5 % of each other there (fp32: the
-        # Winograd family 72 x 0.32 ms against the level-0 up block 6 x 3.86 ms per step), where the in-situ totals decide; in
-        # every committed profile the result is also the first row of rocprofv3's kernel_stats.csv of the same command.
-        kernels = rank_kernels(iso, situ)
-        dom = next((k for k in kernels if k["kernel"] == args.dominant), kernels[0])
-        d_iso, d_situ = (iso or {}).get(dom["kernel"]), (situ or {}).get(dom["kernel"])
+        # the dominant entry = the largest summed launch time IN SITU (the real schedule on one page lane: attention branch on its side
+        # stream, relation nets beside the page net), the two level-0 blocks counted as one entry; its isolated figures ride beside it.
+        # (An event pair in situ brackets what a launch waits behind other streams' work as well; rocprofv3's tracer serialises part of
+        # that overlap, so its per-kernel averages lie between the isolated and the in-situ ones: DESIGN.md section 5.)
+        entries = rank_kernels(iso, situ)
+        kernels = sorted((situ or iso).values(), key=lambda k: -k["total_ms"])          # the per-kernel table of the line
+        dom = next((k for k in entries if k["kernel"] == args.dominant), entries[0])
+        d_iso, d_situ = entry_of(iso, dom), entry_of(situ, dom)
         # (the level-0 up block of the PAGE net -- res8v_up_kernel / res8_up_kernel in fp32, res8f_kernel<true> / res8b in bf16 -- is
         # launched exactly once per group of pages: its call count in the page net's own profile counts the groups)
         groups = next((c for name, c in main_calls.items()
@@ -962,6 +1043,7 @@ def main():
             if visual:
                 gnn_flops += lib.asep_aru_flops(gnn._backbones[dev_index].handle(dev_index), vh, vw)
         flops_page = lib.asep_aru_flops(h_aru, H, W) + gnn_flops
+        engine_reads = set(lib.asep_engine_switches().decode().split())
         if args.no_gnn:
             rel = "ARU-Net only (diagnostic)"
         elif visual:
@@ -1001,7 +1083,9 @@ def main():
                 **({"agreement_with_plain_fp32": agreement} if agreement else {}),
                 "aru_cfg": "ARU featRoot=8 levels=5 res_depth=3 att_scales=3 n_classes=2 (secondary.upstream_layout_6x5: levels=6 att_scales=5)",
                 # engine / bench switches of the environment this line was measured under (none = the defaults the documents describe)
-                "engine_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("ASEP_") and k != "ASEP_BENCH_DEVICE"},
+                # (only what this build of the library reads, asep_engine_switches(); a set-but-ignored ASEP_* name is listed apart)
+                "engine_switches": {k: v for k, v in sorted(os.environ.items()) if k in engine_reads},
+                "ignored_asep_variables": sorted(k for k in os.environ if k.startswith("ASEP_") and k not in engine_reads and k not in HOST_VARIABLES),
                 "gflop_per_page": round(flops_page / 1e9, 2),
                 "whole_page_tflops_per_gpu": round(flops_page * value / world / 1e12, 3),
             },
@@ -1009,7 +1093,7 @@ def main():
             "kernels": [{"kernel": k["kernel"], "calls": k["calls"], "avg_us": round(k["avg_us"], 2),
                          "avg_us_in_situ": None if k.get("avg_us_in_situ") is None else round(k["avg_us_in_situ"], 2),
                          "avg_us_isolated": None if k.get("avg_us_isolated") is None else round(k["avg_us_isolated"], 2),
-                         "flops": k["flops"], "tflops": round(k["tflops"], 2), "executed_tflops": round(k["executed_tflops"], 2),
+                         "flops": k["flops"], "executed_flops": k["executed_flops"], "tflops": round(k["tflops"], 2), "executed_tflops": round(k["executed_tflops"], 2),
                          "pipe_peak_tflops": round(k["pipe_peak"], 2), "executed_frac_of_pipe_peak": round(k["executed_tflops"] / k["pipe_peak"], 4),
                          "bytes": k["bytes"], "algorithmic_gbs": round(k["algo_gbs"], 1),
                          # split-product kernels: six bf16 products per fp32 product, against the bf16 matrix peak

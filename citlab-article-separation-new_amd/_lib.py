@@ -16,7 +16,7 @@ class AsepError(RuntimeError):
 
 
 MLP_MAX_HIDDEN = 4       # GNN_MLP_MAX (csrc/gnn_kernels.h): hidden layers of the interaction / attention / classifier MLPs
-ABI_VERSION = 5          # ASEP_ABI_VERSION of include/asep_hip.h this table was written against
+ABI_VERSION = 6          # ASEP_ABI_VERSION of include/asep_hip.h this table was written against
 
 
 class _SizedCfg(C.Structure):
@@ -55,6 +55,7 @@ SIGNATURES = {
     "asep_last_error": (C.c_char_p, []),
     "asep_version": (C.c_char_p, []),
     "asep_abi_version": (C.c_int, []),
+    "asep_engine_switches": (C.c_char_p, []),
     "asep_aru_load": (_P, [_P, C.c_size_t, C.POINTER(AruCfg)]),
     "asep_aru_free": (None, [_P]),
     "asep_aru_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_float]),

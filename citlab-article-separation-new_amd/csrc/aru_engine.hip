@@ -120,16 +120,19 @@ struct asep_aru {
     std::vector<std::unique_ptr<Lane>> lanes;
     Lane* cur = nullptr;
     bool lanes_forced = false;           // ASEP_LANES given: split any batch of >= 2 pages
-    int num_lanes = 1;                   // ASEP_LANES: page lanes of a batch call (r4j: 1 / 2 / 3 / 4 lanes = 119.3 / 121.2 / 120.3 / 115.8 pages/s fp32, 417.9 / 422.3 / 417.0 /
-                                         // 369.9 bf16; round 5: 1 / 2 / 3 = 467 / 477 / 478 bf16, 137.6 / 139.8 f32s -- two lanes fill the launch tails, but two launches of a
-                                         // kernel then share the chip and each takes twice as long: the per-launch roofline of the bench line would describe the sharing, not
-                                         // the kernel.  One lane stays the default; DESIGN_LESSONS 47)
+    int num_lanes = 2;                   // page lanes of a batch call (ASEP_LANES overrides).  Two lanes since round 6: two independent chains fill each other's launch
+                                         // tails (r4j: 1 / 2 / 3 / 4 lanes = 119.3 / 121.2 / 120.3 / 115.8 pages/s fp32; round 5: 1 / 2 / 3 = 467 / 477 / 478 bf16, 137.6 / 139.8
+                                         // f32s; the round-5 driver run: f32s 135.8 -> 138.4, bf16 469.6 -> 487.5, outputs bit-identical).  A lane takes at least four pages, so
+                                         // calls of fewer than eight pages stay on one lane.  Two launches of one kernel then share the chip and each takes about twice as long,
+                                         // so a per-launch figure must not be taken from that schedule: while a handle records launch times (asep_aru_profile, any mode) its
+                                         // calls run on ONE lane -- the bench line's roofline block and rocprofv3's averages of the event-timed steps describe a kernel, not the
+                                         // sharing (DESIGN_LESSONS 47, 49)
     std::map<std::string, Tensor> endpoints;
     hipStream_t stream = nullptr;
     std::vector<void*> owned;
 
     // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
-    struct ProfRec { int kid; double flops, bytes; hipEvent_t a, b; };
+    struct ProfRec { int kid; double flops, bytes, xflops; hipEvent_t a, b; };
     int num_cus = 256;
     BufferPool host_stage;         // device staging of the host-pointer entry point (grow-only)
     hipStream_t host_stream = nullptr;   // transfers + forward of the host-pointer entry point (created on first use)
@@ -183,6 +186,7 @@ struct ProfScope {
     hipEvent_t a = nullptr, b = nullptr;
     bool on = false;
     double flops;
+    double xflops = -1;        // EXECUTED FLOPs where they differ from the algorithmic credit (< 0: the same)
     double bytes = 0;          // ALGORITHMIC HBM bytes of the launch: every input tensor read once, every output written once, the filter
                                // once (SURVEY.md section 8d per-unit figure x the units of the launch); set by the launcher
     std::string name, detail;
@@ -198,7 +202,7 @@ struct ProfScope {
     ~ProfScope() {
         if (!on) return;
         (void)hipEventRecord(b, m->stream);
-        m->prof_recs.push_back({m->prof_kid(m->prof_detail && !detail.empty() ? name + " " + detail : name), flops, bytes, a, b});
+        m->prof_recs.push_back({m->prof_kid(m->prof_detail && !detail.empty() ? name + " " + detail : name), flops, bytes, xflops < 0 ? flops : xflops, a, b});
     }
 };
 std::string targs(std::initializer_list<std::string> l) {
@@ -1794,7 +1798,10 @@ TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) 
         // conv1 + ReLU + pool1 fused (the full-resolution 12-channel tensor is never materialised)
         // (bf16 path: the head writes a 16-channel bf16 plane, channels 12..15 zero)
         for (const Tensor& t : imgs) y.push_back(m->bf16 ? new_tensor_bf(m, cdiv(t.H, 2), cdiv(t.W, 2), 16) : new_tensor(m, cdiv(t.H, 2), cdiv(t.W, 2), 12));
-        const bool headb = m->bf16 && m->d_att_headb && m->cfg.activation == 0;
+        bool headb = m->bf16 && m->d_att_headb && m->cfg.activation == 0;
+        // (att_headb_kernel addresses the pooled plane with 32-bit element offsets: images of 2^28 pixels and more take the vector-ALU head below,
+        //  which refuses them with an error instead of wrapping)
+        for (const Tensor& t : imgs) headb = headb && (size_t)t.H * t.W < ((size_t)1 << 28);
         for (size_t b0 = 0; headb && b0 < imgs.size(); b0 += MAXP) {
             // bf16 path, ReLU graph: the head on the bf16 MFMA (image and filter as bfloat16 like the feature CNN's first layer)
             const size_t b1 = std::min(imgs.size(), b0 + MAXP);
@@ -1979,6 +1986,7 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
             ProfScope ps(m, "combine_kernel" + targs({ti(cfg.feat_root), ti(cfg.n_classes), tb(m->bf16), ti(nsct)}), 2.0 * H * W * 16.0 * cfg.feat_root * cfg.n_classes);
             // scale-0 feature map + per further scale its channel sum + the attention maps in; probabilities (+ uint8 / threshold images) out
             ps.bytes = tbytes(feat[b * nsc]) + (double)H * W * cfg.n_classes * (4.0 + (ca.out_u8 ? 1.0 : 0.0) + (ca.out_mask ? 1.0 : 0.0));
+            if (ca.wd) ps.xflops = 2.0 * H * W * 16.0 * cfg.feat_root;   // two classes behind a soft-max: the logits conv runs on the difference filter (half the products)
             for (int s2 = 1; s2 < nsc; ++s2) ps.bytes += tbytes(fsum[b * (nsc - 1) + (s2 - 1)]);
             for (int s2 = 0; s2 < nsc && cfg.use_attention; ++s2) ps.bytes += tbytes(att[b * nsc + s2]);
 #define ASEP_COMB_N(FR, NC, BF)                                                                    \
@@ -2102,6 +2110,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (cfg->plain_u && cfg->use_attention) { set_error("asep_aru_load: graph 'U' has no attention branch (ARU_v1.py:92-97)"); return nullptr; }
     std::map<std::string, HostTensor> blob;
     if (!parse_blob(weight_blob, nbytes, blob)) return nullptr;
+    warn_ignored_switches();
     std::unique_ptr<asep_aru> m(new asep_aru());
     m->cfg = *cfg;
     m->bf16 = cfg->compute_dtype == 1;
@@ -2229,11 +2238,12 @@ void asep_aru_free(asep_aru* m) { delete m; }
 static int forward_lanes(asep_aru* m, int n_pages, const float* const* d_imgs, int H, int W, float* const* d_outs,
                          uint8_t* const* d_u8, uint8_t* const* d_mask, float threshold, hipStream_t stream) {
     m->endpoints.clear();
-    // (per-launch profiling in the isolated mode brackets one kernel at a time: one lane; the in-situ mode keeps the real schedule)
+    // (per-launch profiling runs on one lane in every mode: the isolated mode brackets one kernel at a time, the in-situ mode keeps the side
+    //  stream and whatever the caller runs beside the net, but not a second launch of the SAME kernel beside the bracketed one)
     // a lane takes at least four pages (= one full 12-problem launch per layer with three scales): fewer pages per launch cost the deep levels
     // more than a second lane returns; ASEP_LANES (lanes_forced) keeps the plain split for the measurement scripts and tests
     const int by_pages = m->lanes_forced ? n_pages : n_pages / 4;
-    const int nl = ((m->profiling && !m->prof_in_situ) || n_pages < 2) ? 1 : std::max(1, std::min<int>((int)m->lanes.size(), by_pages));
+    const int nl = (m->profiling || n_pages < 2) ? 1 : std::max(1, std::min<int>((int)m->lanes.size(), by_pages));
     asep_aru::Lane& L0 = *m->lanes[0];
     L0.s = stream;
     if (nl == 1) return forward_impl(m, L0, 0, n_pages, d_imgs, H, W, d_outs, d_u8, d_mask, threshold);
@@ -2363,19 +2373,19 @@ long asep_aru_profile_report(asep_aru* m, char* buf, size_t buflen) {
     if (!m || !buf || buflen < 2) { set_error("asep_aru_profile_report: bad argument"); return ASEP_ERR_ARG; }
     ASEP_HIP_CHECK(hipStreamSynchronize(m->stream));
     const size_t nk = m->prof_names.size();
-    std::vector<double> ms(nk, 0.0), fl(nk, 0.0), by(nk, 0.0);
+    std::vector<double> ms(nk, 0.0), fl(nk, 0.0), by(nk, 0.0), xf(nk, 0.0);
     std::vector<long> calls(nk, 0);
     for (const auto& r : m->prof_recs) {
         float t = 0.f;
         ASEP_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
-        ms[r.kid] += t; fl[r.kid] += r.flops; by[r.kid] += r.bytes; calls[r.kid] += 1;
+        ms[r.kid] += t; fl[r.kid] += r.flops; by[r.kid] += r.bytes; xf[r.kid] += r.xflops; calls[r.kid] += 1;
     }
     std::string js = "[";
     for (size_t i = 0; i < nk; ++i) {
         if (!calls[i]) continue;
         char line[512];
-        snprintf(line, sizeof(line), "%s{\"kernel\":\"%s\",\"calls\":%ld,\"total_ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e}",
-                 js.size() > 1 ? "," : "", m->prof_names[i].c_str(), calls[i], ms[i], fl[i], by[i]);
+        snprintf(line, sizeof(line), "%s{\"kernel\":\"%s\",\"calls\":%ld,\"total_ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e,\"executed_flops\":%.6e}",
+                 js.size() > 1 ? "," : "", m->prof_names[i].c_str(), calls[i], ms[i], fl[i], by[i], xf[i]);
         js += line;
     }
     js += "]";

@@ -17,6 +17,7 @@ namespace asep {
 
 void set_error(const char* fmt, ...);
 const char* get_error();
+void warn_ignored_switches();   // stderr, once per process: ASEP_* switches of earlier rounds that this build no longer reads
 
 #define ASEP_HIP_CHECK(expr)                                                                    \
     do {                                                                                        \

@@ -1,5 +1,6 @@
 // Runtime entry points and shared helpers of libasep_hip.so.
 #include "asep_common.h"
+#include <cstdlib>
 
 namespace asep {
 
@@ -12,6 +13,25 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 const char* get_error() { return g_err; }
+
+// Engine switches of earlier rounds whose experiments left the tree, and the two that only an ABLATION build reads:
+// a script or a log that still sets one of them measures the DEFAULT path.  Said once per process on stderr when a model is loaded.
+void warn_ignored_switches() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    static const char* const gone[] = {
+        "ASEP_F32_SPLIT", "ASEP_SPLIT_L0", "ASEP_SPLIT_ALDS", "ASEP_SPLIT_TH16", "ASEP_WINOGRAD", "ASEP_WINO_REG", "ASEP_WINO16", "ASEP_BIGTILE",
+        "ASEP_BIGTILE2", "ASEP_XCD_ONESHOT", "ASEP_SIDE_STREAM", "ASEP_FUSED8_VAR", "ASEP_BF_TH8", "ASEP_BF_MTB", "ASEP_BF_W8", "ASEP_BF_R8B",
+        "ASEP_BF_R8F", "ASEP_CONVS_DBG", "ASEP_R8S_DBG", "ASEP_MAXP24",
+#ifndef ASEP_ABLATION
+        "ASEP_GNN_BATCH", "ASEP_GNN_LANES",
+#endif
+    };
+    for (const char* name : gone)
+        if (getenv(name))
+            fprintf(stderr, "libasep_hip: %s is set but is not a switch of this build (ignored; asep_engine_switches() lists what is read)\n", name);
+}
 
 bool parse_blob(const void* blob, size_t nbytes, std::map<std::string, HostTensor>& out) {
     const uint8_t* p = (const uint8_t*)blob;
@@ -91,7 +111,16 @@ size_t BufferPool::total_bytes() const {
 extern "C" {
 
 const char* asep_last_error(void) { return asep::get_error(); }
-const char* asep_version(void) { return "asep_hip 0.4 (gfx950)"; }
+const char* asep_version(void) { return "asep_hip 0.5 (gfx950)"; }
+
+// The environment switches this BUILD reads, one name per line.
+const char* asep_engine_switches(void) {
+    return "ASEP_FUSE_POOL\nASEP_FUSE_ACT\nASEP_C12\nASEP_FUSED8\nASEP_R8_VALU\nASEP_XCD_SCHED\nASEP_BF_RES32\nASEP_LANES\nASEP_GNN_STEP\nASEP_GNN_FACTOR"
+#ifdef ASEP_ABLATION
+           "\nASEP_GNN_BATCH\nASEP_GNN_LANES"
+#endif
+        ;
+}
 int asep_abi_version(void) { return ASEP_ABI_VERSION; }
 
 int asep_device_count(void) {

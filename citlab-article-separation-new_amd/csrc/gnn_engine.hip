@@ -733,6 +733,7 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
     for (auto& kv : blob)
         if (kv.first.rfind("visual_node_feature_compression_fm_", 0) == 0 || kv.first.rfind("visual_edge_feature_compression_fm_", 0) == 0)
             g->vis_blob[kv.first] = kv.second;
+    warn_ignored_switches();
     if (const char* ev = getenv("ASEP_GNN_STEP")) g->use_step = atoi(ev) != 0;
 #ifdef ASEP_ABLATION   // measured and not adopted (DESIGN_LESSONS 28, 36); `make ABLATION=1` builds them for scripts/r4_ab.sh
     if (const char* ev = getenv("ASEP_GNN_BATCH")) g->batch_graph = atoi(ev) != 0; if (const char* e2 = getenv("ASEP_GNN_LANES")) g->n_page_lanes = std::max(1, std::min(16, atoi(e2)));

@@ -46,8 +46,12 @@ const char* asep_version(void);
  * dlopen; independently of it every configuration struct starts with its own size in bytes (`struct_size`), and the load
  * functions refuse a struct whose size is not the one the library was built with -- a caller written against an older or newer
  * header gets ASEP_ERR_ARG + a message instead of fields read from whatever follows its struct on the stack. */
-#define ASEP_ABI_VERSION 5
+#define ASEP_ABI_VERSION 6
 int asep_abi_version(void);
+/* ABI 6: the environment switches this build of the library reads when a model is loaded (one name per line).
+ * Anything else in the environment is not a switch: a caller that records the switches a measurement ran under (bench.py) filters
+ * against this list, and the library names a set-but-ignored switch of an earlier round once on stderr. */
+const char* asep_engine_switches(void);
 
 /* Page-locked host memory.  The host-pointer entry points (asep_aru_forward, asep_gnn_forward ...) copy with
  * asynchronous transfers on one stream: from / to page-locked buffers these are DMAs at link speed, from / to ordinary

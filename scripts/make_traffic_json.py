@@ -53,7 +53,8 @@ def main():
     B = line["config"]["pages_per_step_per_gpu"]
     steps_total = line["warmup"] + line["steps"] + rb.get("event_timed_steps", 0)
     kernels, page_bytes = traffic_table(s, steps_total * B)
-    out = {"source": f"{tagdir}/pmc_summary.json", "commit": commit, "pages_per_launch": ppl, "dtype": line["dtype"],
+    # `source` names where the summary is COMMITTED (profiles/<tag>/, copied there from the box's gpurun_out/<tag>/): a reader of the repo can open it
+    out = {"source": f"profiles/{os.path.basename(tagdir)}/pmc_summary.json", "commit": commit, "pages_per_launch": ppl, "dtype": line["dtype"],
            "pages_per_step": B, "relation_net": line["config"]["relation_net"], "height": line["config"]["height"],
            "width": line["config"]["width"],
            "unit": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024, mean over dispatches (scripts/profile_bench.sh)",

@@ -49,9 +49,11 @@ def recompute(tagdir):
     pages = (line["warmup"] + line["steps"] + r.get("event_timed_steps", 0)) * B
     kernels, page_bytes = traffic_table(json.load(open(os.path.join(tagdir, "pmc_summary.json"))), pages)
     k = r["kernel"]
-    if k not in stats:
-        raise SystemExit(f"{k} not in kernel_stats.csv (have: {sorted(stats)[:6]} ...)")
-    avg_us = stats[k]["avg_ns"] / 1e3
+    mem = k.split("+")                                         # round 6: the two level-0 blocks are reported as one entry "a+b": the family's mean launch
+    for n in mem:
+        if n not in stats:
+            raise SystemExit(f"{n} not in kernel_stats.csv (have: {sorted(stats)[:6]} ...)")
+    avg_us = sum(stats[n]["total_ns"] for n in mem) / sum(stats[n]["calls"] for n in mem) / 1e3
     lk = {q["kernel"]: q for q in line["kernels"]}
     exec_fl = r["executed_flops_per_launch"]
     hbm_bound = r["bound"] == "hbm"                            # bf16 lines: the primary figures are bytes / s, the matrix ones under "mfma"
@@ -62,7 +64,9 @@ def recompute(tagdir):
     achieved = (r["flops_per_launch"] if layout4 and not layout5 and not hbm_bound else exec_fl) / (avg_us * 1e-6) / 1e12
     # whole page: executed FLOPs of all ARU-Net kernels per page (Winograd kernels execute 1/2.25 of their direct-conv credit)
     ev_steps = max(1, r.get("event_timed_steps", 1))
-    exec_page = sum((q["flops"] / 2.25 if "wino" in q["kernel"] else q["flops"]) for q in line["kernels"]) / (B * ev_steps)
+    # (layout 6: the line carries every kernel's executed FLOPs itself -- combine_kernel on the difference filter executes half its credit)
+    xfl = lambda q: q["executed_flops"] if "executed_flops" in q else (q["flops"] / 2.25 if "wino" in q["kernel"] else q["flops"])
+    exec_page = sum(xfl(q) for q in line["kernels"]) / (B * ev_steps)
     out = {
         "kernel": k,
         "avg_launch_us": avg_us,
@@ -73,10 +77,10 @@ def recompute(tagdir):
     }
     if layout5:
         # the whole page: executed products of every kernel over its own pipe's peak (seconds at peak per page) x pages / s
-        pipe_s = sum((q["flops"] / 2.25 if "wino" in q["kernel"] else q["flops"]) / (q["pipe_peak_tflops"] * 1e12) for q in line["kernels"]) / (B * ev_steps)
+        pipe_s = sum(xfl(q) / (q["pipe_peak_tflops"] * 1e12) for q in line["kernels"]) / (B * ev_steps)
         out["whole_page_executed_frac"] = pipe_s * line["value"] / line["n_gpus"]
-    if k in kernels:
-        out["traffic"] = kernels[k]["bytes_per_launch"]
+    if all(n in kernels for n in mem):
+        out["traffic"] = sum(kernels[n]["bytes_per_launch"] * kernels[n]["dispatches"] for n in mem) / sum(kernels[n]["dispatches"] for n in mem)
         out["hbm_tb_per_s"] = out["traffic"] / (avg_us * 1e-6) / 1e12
         out["hbm_frac"] = out["hbm_tb_per_s"] / (PEAK_HBM_GBS / 1e3)
         if hbm_bound and not layout4:                          # round 3: the bf16 block priced the COUNTER bytes

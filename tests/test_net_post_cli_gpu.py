@@ -394,7 +394,7 @@ def test_heading_pages_in_flight_give_the_measurements_of_the_page_by_page_form(
     assert graph.cfg.compute_dtype == dtype
     base = image_io.load_image_bgr(str(data / "p0.png"))
     pages = [base, np.ascontiguousarray(base[:700, :500]), np.ascontiguousarray(base[::-1])]
-    worst_steps, worst_rate = 0.0, 0.0
+    worst_steps, worst_rate, total_steps, total_area = 0.0, 0.0, 0.0, 0
     lines = [LineGeometry(f"l{i}", [(x0, y0), (x1, y0), (x1, y1), (x0, y1)])
              for i, (x0, y0, x1, y1) in enumerate([(60, 70 + 60 * k, 300, 110 + 60 * k) for k in range(6)]
                                                   + [(320, 80, 560, 170), (450, 600, 640, 720), (0, 0, 30, 12), (10, 20, 11, 21)])]
@@ -422,14 +422,21 @@ def test_heading_pages_in_flight_give_the_measurements_of_the_page_by_page_form(
             # MEAN of a box moves by whole pixel steps: one step in a 10^4-pixel box is already 1e-4 of its pixels.  Rounds 3-4 gated every box
             # at 1e-4, i.e. at ONE step -- a gate both fp32 arithmetics sit on (round 4: one box of the f32s run at two steps = 1.7e-4, the f32
             # run at one): it is sized in steps now -- at most three per box (Poisson tail of a 1.4e-5 rate over 2e4 pixels: 3e-3 per box for
-            # two, 3e-4 for three) -- and the sum over all boxes of a run at the whole-frame rate times ten.
+            # two, 3e-4 for three) for the split-product arithmetic, ONE for the plain fp32 kernels (where rounds 3-5 measured at most one: a
+            # +-1..2 LSB regression of combine_kernel must not hide behind the f32s allowance) -- and the sum over all boxes of a
+            # run at the whole-frame rate times ten (asserted below).
             area = max(1, min(bw, net_map.shape[1]) * min(bh, net_map.shape[0]))
             steps = abs(netp[l.id] - want) * 255 * area
             worst_steps, worst_rate = max(worst_steps, steps), max(worst_rate, steps / area)
-            assert steps <= 3.0 + 1e-6, (l.id, netp[l.id], want, area, steps)
+            assert steps <= (3.0 if dtype == "f32s" else 1.0) + 1e-6, (l.id, netp[l.id], want, area, steps)
+            total_steps, total_area = total_steps + steps, total_area + area
             n_pos += want > 0
         assert n_pos >= 5
-    print(f"\nheading line boxes ({dtype}, color={color}): worst box {worst_steps:.2f} uint8 steps off, worst rate {worst_rate:.2e} of a box's pixels")
+    # the run-level gate: all boxes of the three pages together at ten times the whole-frame uint8 mismatch rate (1.4e-5 of the pixels,
+    # tests/test_full_frame_gpu.py), and never less than two steps
+    assert total_steps <= max(2.0, 10 * 1.4e-5 * total_area) + 1e-6, (total_steps, total_area)
+    print(f"\nheading line boxes ({dtype}, color={color}): worst box {worst_steps:.2f} uint8 steps off, worst rate {worst_rate:.2e} of a box's pixels, "
+          f"run: {total_steps:.1f} steps over {total_area} box pixels = {total_steps / max(total_area, 1):.2e}")
 
 
 @pytest.mark.parametrize("mode", ["separator", "heading"])
