@@ -6,6 +6,9 @@
 //   STEP_SMALL  gnn_step_kernel      widths 32/32/32, U <= 8, Ed <= 4: W1 fragments in registers (the 7-feature nets)
 //   STEP_BIG    gnn_step_big_kernel  widths 32/32/32, U <= 120, Ed <= 4: W1 fragments in LDS (visual nets, U = 55)
 //   STEP_GENERIC  gnn_message_generic_kernel + gnn_lstm_generic_kernel: any widths (plain FMA loops)
+// Round 6: for the widths of STEP_SMALL / STEP_BIG the default is the FACTORED step (gnn_fact_pre_kernel once per page +
+// gnn_step_fact_kernel per step: per-node terms of the edge MLP's first layer per node, K = 32 per edge and step); ASEP_GNN_FACTOR=0
+// keeps the unfactored kernels (the tests compare the two).
 #include <algorithm>
 #include <memory>
 
@@ -14,7 +17,7 @@
 
 using namespace asep;
 
-enum { STEP_GENERIC = 0, STEP_SMALL = 1, STEP_BIG = 2 };
+enum { STEP_GENERIC = 0, STEP_SMALL = 1, STEP_BIG = 2, STEP_FACT = 3 };
 
 struct asep_gnn {
     asep_gnn_cfg cfg{};
@@ -38,6 +41,9 @@ struct asep_gnn {
     int mode = STEP_GENERIC;
     size_t big_lds = 0;
     bool use_step = true;             // ASEP_GNN_STEP=0 selects the separate (generic) message / LSTM kernels
+    bool use_fact = true;             // ASEP_GNN_FACTOR=0: the unfactored fused step kernels (STEP_SMALL / STEP_BIG)
+    float *Wuu = nullptr, *Wde = nullptr, *Whh = nullptr, *A1f = nullptr;   // factored first layer (gnn_kernels.h, "The FACTORED step")
+    size_t fact_pre_lds = 0, fact_lds = 0;
     std::vector<void*> owned;
     BufferPool pool;                  // buffers of one forward (requested in a fixed order)
     BufferPool vis_pool;              // buffers of the visual stage in front of it
@@ -240,6 +246,39 @@ int pack_step_fragments(asep_gnn* g, const std::map<std::string, HostTensor>& bl
     return rc;
 }
 
+// The factored first layer of the edge MLP (gnn_kernels.h): W1's row blocks [Wa Wb Wc Wd | We | Wf Wg Wh Wi] combined in double
+int pack_fact(asep_gnn* g, const std::map<std::string, HostTensor>& blob) {
+    const int U = g->U, Ed = g->Ed;
+    const std::string m = MSG;
+    const HostTensor& W1 = blob.find(m + "/fully_connected_layer_h1/weights")->second;            // [K,32]
+    auto w = [&](int row, int o) -> double { return (double)W1.data[(size_t)row * GNN_H + o]; };
+    const int ha = 4 * U + Ed;                                   // first row of Wf
+    std::vector<float> wuu((size_t)std::max(U, 1) * 64), wde((size_t)std::max(U + Ed, 1) * 32), whh((size_t)32 * 64), a1((size_t)2 * 2 * 64 * 4);
+    for (int k = 0; k < U; ++k)
+        for (int o = 0; o < 32; ++o) {
+            wuu[(size_t)k * 64 + o] = (float)(w(k, o) - w(2 * U + k, o));                  // Wa - Wc
+            wuu[(size_t)k * 64 + 32 + o] = (float)(w(U + k, o) + w(2 * U + k, o));         // Wb + Wc
+            wde[(size_t)k * 32 + o] = (float)w(3 * U + k, o);                              // Wd
+        }
+    for (int k = 0; k < Ed; ++k)
+        for (int o = 0; o < 32; ++o) wde[(size_t)(U + k) * 32 + o] = (float)w(4 * U + k, o);   // We
+    for (int k = 0; k < 32; ++k)
+        for (int o = 0; o < 32; ++o) {
+            whh[(size_t)k * 64 + o] = (float)(w(ha + k, o) - w(ha + 64 + k, o));           // Wf - Wh
+            whh[(size_t)k * 64 + 32 + o] = (float)(w(ha + 32 + k, o) + w(ha + 64 + k, o)); // Wg + Wh
+        }
+    for (int c = 0; c < 2; ++c)                                   // Wi as A fragments: slot 16 c + 4 kk + r, unit 16 mt + i
+        for (int mt = 0; mt < 2; ++mt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r)
+                    a1[(((size_t)c * 2 + mt) * 64 + lane) * 4 + r] = (float)w(ha + 96 + 16 * c + 4 * (lane >> 4) + r, 16 * mt + (lane & 15));
+    int rc = upload_vec(g, wuu, &g->Wuu);
+    if (!rc) rc = upload_vec(g, wde, &g->Wde);
+    if (!rc) rc = upload_vec(g, whh, &g->Whh);
+    if (!rc) rc = upload_vec(g, a1, &g->A1f);
+    return rc;
+}
+
 struct EdgeBufs {
     int* table; int* rowcnt; int* colcnt; int* rowptr; int* colptr;
     int32_t* sorted; int* sfirst; int* tsrc; int* tfirst;
@@ -271,6 +310,12 @@ int correct_edges_dev(asep_gnn* g, BufferPool& pool, int N, int E, const int32_t
     ASEP_HIP_CHECK(hipGetLastError());
     g->d_rowptr = eb.rowptr;
     return ASEP_OK;
+}
+
+// the step kernel of this model under the switches: the factored form wherever a fused step kernel serves the widths
+inline int step_mode_of(const asep_gnn* g) {
+    if (!g->use_step || g->mode == STEP_GENERIC) return STEP_GENERIC;
+    return g->use_fact && g->A1f ? STEP_FACT : g->mode;
 }
 
 int forward_impl(asep_gnn* g, BufferPool& pool, int N, int E, const int32_t* d_edges, const float* d_u, const float* d_ef, int R,
@@ -314,16 +359,39 @@ int forward_impl(asep_gnn* g, BufferPool& pool, int N, int E, const int32_t* d_e
                            att_widx);
     }
     float* upad = nullptr;
-    const int mode = g->use_step ? g->mode : STEP_GENERIC;
+    const int mode = step_mode_of(g);
     if (mode == STEP_BIG) {
         upad = (float*)pool.get((size_t)N * g->Upad * 4);
         hipLaunchKernelGGL(gnn_pad_rows_kernel, dim3(cdiv(N * g->Upad, 256)), dim3(256), 0, s, d_u, N, g->U, upad, g->Upad);
+    }
+    float *fPu = nullptr, *fP[2] = {nullptr, nullptr}, *fC = nullptr;
+    if (mode == STEP_FACT && c.num_transition_steps > 0) {     // the step-independent parts of the edge MLP's first layer, once per page
+        fPu = (float*)pool.get((size_t)N * 64 * 4);
+        fP[0] = (float*)pool.get((size_t)N * 64 * 4);
+        fP[1] = (float*)pool.get((size_t)N * 64 * 4);
+        fC = (float*)pool.get(att_maxE * 32 * 4);
+        FactPreArgs fa{};
+        fa.u = d_u; fa.ef = d_ef; fa.tptr = eb.colptr; fa.tsrc = eb.tsrc; fa.tfirst = eb.tfirst;
+        fa.Wuu = g->Wuu; fa.Wde = g->Wde; fa.b1 = g->b1; fa.Pu = fPu; fa.C = fC;
+        fa.N = N; fa.U = g->U; fa.Ed = g->Ed; fa.E = std::max(E, 1);
+        hipLaunchKernelGGL(gnn_fact_pre_kernel, dim3(N), dim3(256), g->fact_pre_lds, s, fa);
     }
     ASEP_HIP_CHECK(hipMemsetAsync(h[0], 0, nh * 4, s));
     ASEP_HIP_CHECK(hipMemsetAsync(cs[0], 0, nh * 4, s));
     int cur = 0;
     for (int t = 0; t < c.num_transition_steps; ++t) {
-        if (mode == STEP_SMALL) {
+        if (mode == STEP_FACT) {
+            StepFactArgs sa{};
+            sa.u = d_u; sa.h_in = h[cur]; sa.c_in = cs[cur]; sa.tptr = eb.colptr; sa.tsrc = eb.tsrc;
+            sa.P_in = t == 0 ? fPu : fP[t & 1];                // h = 0 in front of the first step: the rows are their u halves
+            sa.Pu = fPu; sa.C = fC;
+            sa.A1 = (const gf32x4*)g->A1f; sa.A2 = (const gf32x4*)g->A2; sa.b2 = g->b2; sa.Whh = g->Whh;
+            for (int q = 0; q < 4; ++q) { sa.Wg[q] = g->Wg[q]; sa.bg[q] = g->bg[q]; }
+            sa.h_out = h[cur ^ 1]; sa.c_out = cs[cur ^ 1];
+            sa.P_out = t + 1 < c.num_transition_steps ? fP[(t + 1) & 1] : nullptr;
+            sa.N = N; sa.U = g->U;
+            hipLaunchKernelGGL(gnn_step_fact_kernel, dim3(N), dim3(256), g->fact_lds, s, sa);
+        } else if (mode == STEP_SMALL) {
             StepArgs sa{};
             sa.u = d_u; sa.h_in = h[cur]; sa.c_in = cs[cur]; sa.ef = d_ef;
             sa.tptr = eb.colptr; sa.tsrc = eb.tsrc; sa.tfirst = eb.tfirst;
@@ -735,6 +803,7 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
             g->vis_blob[kv.first] = kv.second;
     warn_ignored_switches();
     if (const char* ev = getenv("ASEP_GNN_STEP")) g->use_step = atoi(ev) != 0;
+    if (const char* ev = getenv("ASEP_GNN_FACTOR")) g->use_fact = atoi(ev) != 0;
 #ifdef ASEP_ABLATION   // measured and not adopted (DESIGN_LESSONS 28, 36); `make ABLATION=1` builds them for scripts/r4_ab.sh
     if (const char* ev = getenv("ASEP_GNN_BATCH")) g->batch_graph = atoi(ev) != 0; if (const char* e2 = getenv("ASEP_GNN_LANES")) g->n_page_lanes = std::max(1, std::min(16, atoi(e2)));
 #endif
@@ -754,6 +823,13 @@ asep_gnn* asep_gnn_load(const void* weight_blob, size_t nbytes, const asep_gnn_c
             if (g->big_lds <= 150 * 1024 &&
                 hipFuncSetAttribute((const void*)gnn_step_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->big_lds) == hipSuccess)
                 g->mode = STEP_BIG;
+        }
+    }
+    if (g->mode != STEP_GENERIC) {                          // the factored step for the same widths (any U whose filters fit the pre kernel's LDS)
+        g->fact_pre_lds = ((size_t)(U + Ed) * 32 + U) * sizeof(float);
+        g->fact_lds = (size_t)(64 + U) * sizeof(float);
+        if (g->fact_pre_lds <= 60 * 1024) {
+            if (pack_fact(g.get(), blob)) return nullptr;
         }
     }
     const size_t lds = ((size_t)g->K + 2 * (size_t)g->msg_maxh + I) * sizeof(float);
@@ -854,7 +930,7 @@ int asep_gnn_get_hidden(asep_gnn* g, float* out, size_t max_floats) {
     ASEP_GUARD_END
 }
 
-int asep_gnn_step_mode(const asep_gnn* g) { return g ? (g->use_step ? g->mode : STEP_GENERIC) : ASEP_ERR_ARG; }
+int asep_gnn_step_mode(const asep_gnn* g) { return g ? step_mode_of(g) : ASEP_ERR_ARG; }
 
 int asep_gnn_attach_backbone(asep_gnn* g, asep_aru* backbone, int n_maps, const char* const* endpoint_names) {
     ASEP_GUARD_BEGIN

@@ -521,6 +521,210 @@ __global__ __launch_bounds__(256) void gnn_step_big_kernel_batch(const GnnBatch<
 #endif
 
 
+// ------------------------------------------------------------------------------------------------
+// The FACTORED step (round 6; the default for the reference's widths, any U).  The first layer of the edge MLP is linear in
+//   z = [u_f, u_t, u_t - u_f, (u_t - u_f)^2, e, h_f, h_t, h_t - h_f, (h_t - h_f)^2]        (message_fn_chunk.py:266-350; f = from, t = to),
+// and with W1's row blocks Wa .. Wi in that order
+//   z W1 = u_f (Wa - Wc) + h_f (Wf - Wh)            per SOURCE node:  Pf[f]   (its u half once per page, its h half per step)
+//        + u_t (Wb + Wc) + h_t (Wg + Wh) + b1       per TARGET node:  Pt[t]
+//        + (u_t - u_f)^2 Wd + e We                  per edge, the same in all T steps:  C[e]   (once per page, CSR-by-target order)
+//        + (h_t - h_f)^2 Wi                         per edge and step: K = 32 instead of 4 U + Ed + 128 (350 for the visual nets).
+// A step's edge work is then 16 + 16 MFMAs per tile of 16 edges (were 176 + 16 at U = 55) with both layers' fragments in registers (no
+// LDS staging of W1: 45 KB per workgroup before), and three 128-byte row gathers per edge (Pf[f], h[f], C[e]; were two rows of 87 floats).
+// The pair classifier has used the same factorisation since round 2 (gnn_pair_pre_kernel).  Same one-workgroup-per-target segmented
+// sum, no atomics.  Sums are associated differently from the unfactored kernels (which stay in the tree: ASEP_GNN_FACTOR=0): both are held
+// to 1e-5 against the fp64 oracle, and the factored filters are formed in double on the host.
+// ------------------------------------------------------------------------------------------------
+struct FactPreArgs {
+    const float* u;        // [N, U]
+    const float* ef;       // [E, Ed]
+    const int* tptr; const int* tsrc; const int* tfirst;
+    const float* Wuu;      // [U][64]: columns 0..31 Wa - Wc, 32..63 Wb + Wc
+    const float* Wde;      // [U + Ed][32]: Wd, then We
+    const float* b1;
+    float* Pu;             // [N][64]: u (Wa - Wc) | u (Wb + Wc) + b1
+    float* C;              // [E'][32]
+    int N, U, Ed, E;
+};
+
+// one workgroup per target node: its Pu row, then C for its in-edges (32 edges x 8 threads x 4 outputs at a time)
+__global__ __launch_bounds__(256) void gnn_fact_pre_kernel(const FactPreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm_pre[];
+    float* Ws = sm_pre;                                   // [(U + Ed)][32]
+    float* ut = sm_pre + (size_t)(a.U + a.Ed) * 32;       // [U] the target's features
+    const int tid = threadIdx.x, tgt = blockIdx.x;
+    const int U = a.U, Ed = a.Ed;
+    const int beg = a.tptr[tgt], end = a.tptr[tgt + 1];
+    for (int i = tid; i < (U + Ed) * 32; i += 256) Ws[i] = a.Wde[i];
+    for (int i = tid; i < U; i += 256) ut[i] = a.u[(size_t)tgt * U + i];
+    __syncthreads();
+    if (tid < 64) {
+        float acc = tid >= 32 ? a.b1[tid - 32] : 0.f;
+        for (int k = 0; k < U; ++k) acc = fmaf(ut[k], a.Wuu[k * 64 + tid], acc);
+        a.Pu[(size_t)tgt * 64 + tid] = acc;
+    }
+    const int le = tid >> 3, oq = (tid & 7) * 4;
+    for (int base = beg; base < end; base += 32) {
+        const int e = base + le;
+        if (e >= end) continue;
+        const float* uf = a.u + (size_t)a.tsrc[e] * U;
+        const float* efr = a.ef + (size_t)(a.tfirst[e] % a.E) * Ed;
+        gf32x4 acc = gf32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < U; ++k) {
+            const float d = ut[k] - uf[k];
+            acc += (d * d) * *reinterpret_cast<const gf32x4*>(Ws + k * 32 + oq);
+        }
+        for (int k = 0; k < Ed; ++k) acc += efr[k] * *reinterpret_cast<const gf32x4*>(Ws + (U + k) * 32 + oq);
+        *reinterpret_cast<gf32x4*>(a.C + (size_t)e * 32 + oq) = acc;
+    }
+}
+
+struct StepFactArgs {
+    const float* u;        // [N, U] (LSTM input)
+    const float* h_in; const float* c_in;
+    const int* tptr; const int* tsrc;
+    const float* P_in;     // [N][64] this step's Pf | Pt (step 0: Pu itself, h = 0)
+    const float* Pu;       // [N][64]
+    const float* C;        // [E'][32]
+    const gf32x4* A1;      // Wi fragments [2 chunks][2 m-tiles][64 lanes]
+    const gf32x4* A2;      // W2 fragments [2][2][64]
+    const float* b2;
+    const float* Whh;      // [32][64]: columns 0..31 Wf - Wh, 32..63 Wg + Wh
+    const float* Wg[4]; const float* bg[4];
+    float* h_out; float* c_out;
+    float* P_out;          // next step's [N][64], or null behind the last step
+    int N, U;
+};
+
+__global__ __launch_bounds__(256) void gnn_step_fact_kernel(const StepFactArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm_fact[];
+    float* vs = sm_fact;                                  // [32 x | 32 h | U u] of the target: the LSTM's input row
+    __shared__ float xs[4][32];
+    __shared__ float gs[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int tgt = blockIdx.x;
+    const int beg = a.tptr[tgt], end = a.tptr[tgt + 1];
+    const int U = a.U;
+    const int ntiles = (end - beg + 15) >> 4;
+    if (tid < 32) vs[32 + tid] = a.h_in[(size_t)tgt * 32 + tid];
+    for (int i = tid; i < U; i += 256) vs[64 + i] = a.u[(size_t)tgt * U + i];
+
+    gf32x4 xacc[2] = {gf32x4{0.f, 0.f, 0.f, 0.f}, gf32x4{0.f, 0.f, 0.f, 0.f}};
+    if (wave < ntiles) {
+        gf32x4 A1[2][2], A2[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            A1[c][0] = a.A1[(c * 2 + 0) * 64 + lane]; A1[c][1] = a.A1[(c * 2 + 1) * 64 + lane];
+            A2[c][0] = a.A2[(c * 2 + 0) * 64 + lane]; A2[c][1] = a.A2[(c * 2 + 1) * 64 + lane];
+        }
+        const gf32x4 b2v[2] = {*reinterpret_cast<const gf32x4*>(a.b2 + kk * 4), *reinterpret_cast<const gf32x4*>(a.b2 + 16 + kk * 4)};
+        const float* htp = a.h_in + (size_t)tgt * 32;
+        const gf32x4 ht[2] = {*reinterpret_cast<const gf32x4*>(htp + kk * 4), *reinterpret_cast<const gf32x4*>(htp + 16 + kk * 4)};
+        const float* ptp = a.P_in + (size_t)tgt * 64 + 32;
+        const gf32x4 pt[2] = {*reinterpret_cast<const gf32x4*>(ptp + kk * 4), *reinterpret_cast<const gf32x4*>(ptp + 16 + kk * 4)};
+        // a tile's three row gathers; the next tile's are requested before this tile's MFMAs
+        auto gather = [&](int t, gf32x4 (&hs)[2], gf32x4 (&acc)[2], bool& valid) {
+            const int e = beg + t * 16 + j;
+            valid = e < end;
+            const int ec = valid ? e : beg;                           // padded columns read a real edge, masked later
+            const int src = a.tsrc[ec];
+            const float* hsp = a.h_in + (size_t)src * 32;
+            const float* pfp = a.P_in + (size_t)src * 64;
+            const float* cep = a.C + (size_t)ec * 32;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                hs[m] = *reinterpret_cast<const gf32x4*>(hsp + 16 * m + kk * 4);
+                acc[m] = *reinterpret_cast<const gf32x4*>(pfp + 16 * m + kk * 4) + *reinterpret_cast<const gf32x4*>(cep + 16 * m + kk * 4);
+            }
+        };
+        gf32x4 hs[2], acc1[2];
+        bool valid;
+        gather(wave, hs, acc1, valid);
+        for (int t = wave; t < ntiles; t += 4) {
+            gf32x4 nhs[2] = {hs[0], hs[1]}, nacc[2] = {acc1[0], acc1[1]};
+            bool nvalid = false;
+            if (t + 4 < ntiles) gather(t + 4, nhs, nacc, nvalid);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc1[m] += pt[m];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const gf32x4 dd = ht[c] - hs[c];
+                const gf32x4 z = dd * dd;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[c][0][r], z[r], acc1[0], 0, 0, 0);
+                    acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[c][1][r], z[r], acc1[1], 0, 0, 0);
+                }
+            }
+            gf32x4 hid[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                hid[m] = acc1[m];
+                hid[m].x = fmaxf(hid[m].x, 0.f); hid[m].y = fmaxf(hid[m].y, 0.f); hid[m].z = fmaxf(hid[m].z, 0.f); hid[m].w = fmaxf(hid[m].w, 0.f);
+            }
+            gf32x4 acc2[2] = {b2v[0], b2v[1]};
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[c][0][r], hid[c][r], acc2[0], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[c][1][r], hid[c][r], acc2[1], 0, 0, 0);
+                }
+            if (valid) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    xacc[m].x += tanhf(acc2[m].x); xacc[m].y += tanhf(acc2[m].y); xacc[m].z += tanhf(acc2[m].z); xacc[m].w += tanhf(acc2[m].w);
+                }
+            }
+            hs[0] = nhs[0]; hs[1] = nhs[1]; acc1[0] = nacc[0]; acc1[1] = nacc[1]; valid = nvalid;
+        }
+    }
+    // ---- sum over the 16 edge columns (lanes j), then over the 4 waves ----
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = xacc[m][r];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (j == 0) xs[wave][16 * m + 4 * kk + r] = v;
+        }
+    __syncthreads();
+    if (tid < 32) {
+        const int deg = end - beg;
+        const float s = xs[0][tid] + xs[1][tid] + xs[2][tid] + xs[3][tid];
+        vs[tid] = deg > 0 ? s / (float)deg : 0.f;                    // a_ij = 1 / indeg(j)
+    }
+    __syncthreads();
+    // ---- LSTM update of node tgt: v = [x, h, u]; gate order ingate, outgate, forgetgate, cellinput (update_fn_lstm.py:41-76) ----
+    if (tid < 128) {
+        const int q = tid >> 5, o = tid & 31;
+        const float* Wq = a.Wg[q];
+        float g = a.bg[q][o];
+        const int V = 64 + U;
+        for (int k = 0; k < V; ++k) g = fmaf(vs[k], Wq[k * 32 + o], g);
+        gs[q][o] = g;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const float ig = gsig(gs[0][tid]), og = gsig(gs[1][tid]), fg = gsig(gs[2][tid]), cg = tanhf(gs[3][tid]);
+        const float c = fg * a.c_in[(size_t)tgt * 32 + tid] + ig * cg;
+        const float hn = og * tanhf(c);
+        a.c_out[(size_t)tgt * 32 + tid] = c;
+        a.h_out[(size_t)tgt * 32 + tid] = hn;
+        xs[0][tid] = hn;
+    }
+    if (!a.P_out) return;
+    __syncthreads();
+    // ---- the node's rows of the NEXT step: Pf = u (Wa - Wc) + h' (Wf - Wh),  Pt = u (Wb + Wc) + b1 + h' (Wg + Wh) ----
+    if (tid < 64) {
+        float acc = a.Pu[(size_t)tgt * 64 + tid];
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) acc = fmaf(xs[0][k], a.Whh[k * 64 + tid], acc);
+        a.P_out[(size_t)tgt * 64 + tid] = acc;
+    }
+}
+
 // zero-padded copy of the node features: [N, U] -> [N, Upad]
 __global__ __launch_bounds__(256) void gnn_pad_rows_kernel(const float* __restrict__ src, int N, int U, float* __restrict__ dst, int Upad) {
     const int i = blockIdx.x * 256 + threadIdx.x;

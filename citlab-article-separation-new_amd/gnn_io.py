@@ -302,7 +302,7 @@ def gnn_forward_visual_batch_dev(graph: GnnGraph, pages, h, w, num_region_points
     return pages
 
 
-STEP_MODES = {0: "generic", 1: "mfma_registers", 2: "mfma_lds"}
+STEP_MODES = {0: "generic", 1: "mfma_registers", 2: "mfma_lds", 3: "factored"}
 
 
 def step_mode(graph: GnnGraph, device=0) -> str:

@@ -253,7 +253,9 @@ int asep_gnn_forward_visual_batch_dev(asep_gnn* g, int n_pages, const asep_gnn_p
 
 /* Which message-passing kernel the handle uses: 0 = generic FMA kernels (any widths), 1 = fused MFMA step with the
  * edge-MLP filter in registers (widths 32, node_feature_dim <= 8), 2 = fused MFMA step with the filter in LDS (widths 32,
- * node_feature_dim <= 120: the visual nets). */
+ * node_feature_dim <= 120: the visual nets), 3 (ABI 6, the default wherever 1 or 2 would serve) = the FACTORED fused step: the per-node
+ * terms of the edge MLP's first layer once per node, its step-independent per-edge term once per page, K = 32 per edge and step
+ * (ASEP_GNN_FACTOR=0 keeps 1 / 2). */
 int asep_gnn_step_mode(const asep_gnn* g);
 
 /* Concatenated node features [N, node_feature_dim] of the last asep_gnn_forward_visual[_dev] (tests). */

@@ -135,19 +135,19 @@ def test_permutation_equivariance():
 
 
 @pytest.mark.parametrize("kw,mode", [
-    (dict(), "mfma_registers"),
-    (dict(node_feature_dim=20), "mfma_lds"),                                   # wide node features without an image
-    (dict(node_feature_dim=55, edge_feature_dim=4), "mfma_lds"),
-    (dict(node_feature_dim=9, edge_feature_dim=0), "mfma_lds"),
+    (dict(), "factored"),
+    (dict(node_feature_dim=20), "factored"),                                   # wide node features without an image
+    (dict(node_feature_dim=55, edge_feature_dim=4), "factored"),
+    (dict(node_feature_dim=9, edge_feature_dim=0), "factored"),
     (dict(hidden_dim=16, interaction_dim=24, interaction_hidden=[40]), "generic"),
     (dict(hidden_dim=48, interaction_dim=32, interaction_hidden=[32], edge_feature_dim=5), "generic"),
-    (dict(classifier_hidden=[48, 20], num_classes=3), "mfma_registers"),      # generic pair classifier
+    (dict(classifier_hidden=[48, 20], num_classes=3), "factored"),      # generic pair classifier
     # graph_gnn.py:23,158-166 output_type: h += x W / the classifier pairs up [h | x]
-    (dict(output_type="add_final_hidden_and_input"), "mfma_registers"),
-    (dict(output_type="concat_final_hidden_and_input"), "mfma_registers"),
+    (dict(output_type="add_final_hidden_and_input"), "factored"),
+    (dict(output_type="concat_final_hidden_and_input"), "factored"),
     (dict(output_type="concat_final_hidden_and_input", node_feature_dim=15, compress_node_feature_dim=6, hidden_dim=24,
           interaction_dim=20, interaction_hidden=[28]), "generic"),            # x = the features as FED, before compress_input
-    (dict(output_type="add_final_hidden_and_input", node_feature_dim=20, classifier_hidden=[40, 12]), "mfma_lds"),
+    (dict(output_type="add_final_hidden_and_input", node_feature_dim=20, classifier_hidden=[40, 12]), "factored"),
     # message_fn_chunk.py:35-41,199-245: learned attention over the in-edges, one / several heads, both merge types; directed graph:
     # the (to, from) <-> (from, to) pairing of the reference is then not the reverse edge
     (dict(use_attention=True), "generic"),
@@ -163,8 +163,8 @@ def test_permutation_equivariance():
     # num_hidden_units_* are lists (message_fn_chunk.py:24,40; graph_relation.py:196): several hidden layers per MLP
     (dict(interaction_hidden=[32, 32]), "generic"),
     (dict(interaction_hidden=[40, 24, 16], classifier_hidden=[48, 20, 12]), "generic"),
-    (dict(classifier_hidden=[48]), "mfma_registers"),                          # one hidden layer
-    (dict(classifier_hidden=[64, 32, 16, 8], num_classes=3, node_feature_dim=20), "mfma_lds"),
+    (dict(classifier_hidden=[48]), "factored"),                          # one hidden layer
+    (dict(classifier_hidden=[64, 32, 16, 8], num_classes=3, node_feature_dim=20), "factored"),
     (dict(use_attention=True, num_attention_heads=2, attention_hidden=[16, 8], interaction_hidden=[24, 20]), "generic"),
     # update_fn_lstm.py:13-16,43-50: the gates read x alone / x + h / x + u
     (dict(incorporate_node_input_features_in_update=False), "generic"),
@@ -173,7 +173,7 @@ def test_permutation_equivariance():
 ])
 def test_hyper_parameters_other_than_the_defaults(kw, mode):
     """message_fn_chunk.py:13-40, trainer_rel.py:15-17: every width is a free parameter of the reference; the engine picks
-    the fused MFMA step where the widths allow it and plain FMA kernels elsewhere -- all against the oracle."""
+    the fused MFMA step (round 6: its factored form) where the widths allow it and plain FMA kernels elsewhere -- all against the oracle."""
     from citlab_article_separation_new_amd import gnn_io
     from oracle import gnn_oracle
     cfg, w, graph = _setup(seed=17, **kw)
@@ -223,3 +223,40 @@ def test_index_arrays_are_validated_at_the_host_entry():
     ok = gnn_io.gnn_forward(graph, 10, edges, u, ef, np.array([[0, 1], [9, 9]], np.int32))
     assert ok.shape == (2, 2) and np.isfinite(ok).all()
     graph.close()
+
+
+@pytest.mark.parametrize("kw,unfactored", [
+    (dict(), "mfma_registers"),
+    (dict(node_feature_dim=55, edge_feature_dim=4), "mfma_lds"),
+    (dict(node_feature_dim=9, edge_feature_dim=0, num_transition_steps=1), "mfma_lds"),
+    (dict(node_feature_dim=20, undirected_graph=False, num_transition_steps=5), "mfma_lds"),
+])
+def test_factored_step_against_the_unfactored_kernels_and_the_fp64_oracle(kw, unfactored, monkeypatch):
+    """round 6: the edge MLP's first layer as per-node terms + a per-edge constant + a K = 32 per-edge-and-step term
+    (message_fn_chunk.py:266-363 is linear in u_from, u_to, u_to - u_from, h_from, h_to, h_to - h_from).  Three implementations of the same
+    arithmetic on one graph with isolated nodes, duplicate / reversed edges and in-degrees from 0 to > 64: the factored step (default), the
+    unfactored fused kernels (ASEP_GNN_FACTOR=0) and the generic FMA kernels (ASEP_GNN_STEP=0) -- each within 1e-5 of the fp64 oracle."""
+    from citlab_article_separation_new_amd import gnn_io
+    from oracle import gnn_oracle
+    rng = np.random.default_rng(11)
+    N, E = 90, 1400
+    outs = {}
+    for name, env in (("factored", {}), (unfactored, {"ASEP_GNN_FACTOR": "0"}), ("generic", {"ASEP_GNN_STEP": "0"})):
+        for k in ("ASEP_GNN_FACTOR", "ASEP_GNN_STEP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)                          # read when the model is loaded
+        cfg, w, graph = _setup(seed=23, **kw)
+        assert gnn_io.step_mode(graph) == name
+        if not outs:
+            edges, u, ef = _random_graph(rng, N, E, node_dim=cfg.node_feature_dim, edge_dim=max(cfg.edge_feature_dim, 1))
+            edges[:200, 1] = 5                                # one target with a long in-edge list (several tiles per wave)
+            edges[edges == 17] = 3                            # node 17 isolated
+            ef = ef if cfg.edge_feature_dim else None
+            ref, href = gnn_oracle.forward(N, edges, u, ef, None, w, cfg, dtype=np.float64, return_hidden=True)
+        probs = gnn_io.gnn_forward(graph, N, edges, u, ef)
+        h = gnn_io.gnn_hidden(graph, N)
+        assert float(np.abs(h - href).max()) <= PROB_TOL and float(np.abs(probs - ref).max()) <= PROB_TOL, name
+        outs[name] = (probs, h)
+        graph.close()
+    assert float(np.abs(outs["factored"][1] - outs[unfactored][1]).max()) <= 5e-6

@@ -171,7 +171,7 @@ def test_visual_net_at_c4_size_uses_the_mfma_step_and_matches_oracle():
     from citlab_article_separation_new_amd import gnn_io, synth
     from oracle import gnn_oracle
     cfg, w, graph = _setup(mvn=True)
-    assert gnn_io.step_mode(graph) == "mfma_lds"
+    assert gnn_io.step_mode(graph) == "factored"
     rng = np.random.default_rng(13)
     N = 200
     g = synth.synth_graph(0, N=N, n_pairs=10000, node_dim=7)
