@@ -376,8 +376,10 @@ int forward_impl(asep_gnn* g, BufferPool& pool, int N, int E, const int32_t* d_e
         fa.N = N; fa.U = g->U; fa.Ed = g->Ed; fa.E = std::max(E, 1);
         hipLaunchKernelGGL(gnn_fact_pre_kernel, dim3(N), dim3(256), g->fact_pre_lds, s, fa);
     }
-    ASEP_HIP_CHECK(hipMemsetAsync(h[0], 0, nh * 4, s));
-    ASEP_HIP_CHECK(hipMemsetAsync(cs[0], 0, nh * 4, s));
+    if (mode != STEP_FACT || c.num_transition_steps == 0) {  // (the factored step's first launch does not read h / c: no memsets)
+        ASEP_HIP_CHECK(hipMemsetAsync(h[0], 0, nh * 4, s));
+        ASEP_HIP_CHECK(hipMemsetAsync(cs[0], 0, nh * 4, s));
+    }
     int cur = 0;
     for (int t = 0; t < c.num_transition_steps; ++t) {
         if (mode == STEP_FACT) {
@@ -389,7 +391,7 @@ int forward_impl(asep_gnn* g, BufferPool& pool, int N, int E, const int32_t* d_e
             for (int q = 0; q < 4; ++q) { sa.Wg[q] = g->Wg[q]; sa.bg[q] = g->bg[q]; }
             sa.h_out = h[cur ^ 1]; sa.c_out = cs[cur ^ 1];
             sa.P_out = t + 1 < c.num_transition_steps ? fP[(t + 1) & 1] : nullptr;
-            sa.N = N; sa.U = g->U;
+            sa.N = N; sa.U = g->U; sa.first = t == 0;
             hipLaunchKernelGGL(gnn_step_fact_kernel, dim3(N), dim3(256), g->fact_lds, s, sa);
         } else if (mode == STEP_SMALL) {
             StepArgs sa{};

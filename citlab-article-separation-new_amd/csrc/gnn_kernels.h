@@ -570,7 +570,18 @@ __global__ __launch_bounds__(256) void gnn_fact_pre_kernel(const FactPreArgs a) 
         const float* uf = a.u + (size_t)a.tsrc[e] * U;
         const float* efr = a.ef + (size_t)(a.tfirst[e] % a.E) * Ed;
         gf32x4 acc = gf32x4{0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < U; ++k) {
+        int k = 0;
+        for (; k + 8 <= U; k += 8) {                                  // the source row eight values at a time: all eight loads in flight together
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = uf[k + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float d = ut[k + q] - v[q];
+                acc += (d * d) * *reinterpret_cast<const gf32x4*>(Ws + (k + q) * 32 + oq);
+            }
+        }
+        for (; k < U; ++k) {
             const float d = ut[k] - uf[k];
             acc += (d * d) * *reinterpret_cast<const gf32x4*>(Ws + k * 32 + oq);
         }
@@ -594,6 +605,7 @@ struct StepFactArgs {
     float* h_out; float* c_out;
     float* P_out;          // next step's [N][64], or null behind the last step
     int N, U;
+    int first;             // the first step: h and c are zero (not read: no memset in front of the steps)
 };
 
 __global__ __launch_bounds__(256) void gnn_step_fact_kernel(const StepFactArgs a) {
@@ -607,7 +619,8 @@ __global__ __launch_bounds__(256) void gnn_step_fact_kernel(const StepFactArgs a
     const int beg = a.tptr[tgt], end = a.tptr[tgt + 1];
     const int U = a.U;
     const int ntiles = (end - beg + 15) >> 4;
-    if (tid < 32) vs[32 + tid] = a.h_in[(size_t)tgt * 32 + tid];
+    const bool first = a.first != 0;
+    if (tid < 32) vs[32 + tid] = first ? 0.f : a.h_in[(size_t)tgt * 32 + tid];
     for (int i = tid; i < U; i += 256) vs[64 + i] = a.u[(size_t)tgt * U + i];
 
     gf32x4 xacc[2] = {gf32x4{0.f, 0.f, 0.f, 0.f}, gf32x4{0.f, 0.f, 0.f, 0.f}};
@@ -620,7 +633,8 @@ __global__ __launch_bounds__(256) void gnn_step_fact_kernel(const StepFactArgs a
         }
         const gf32x4 b2v[2] = {*reinterpret_cast<const gf32x4*>(a.b2 + kk * 4), *reinterpret_cast<const gf32x4*>(a.b2 + 16 + kk * 4)};
         const float* htp = a.h_in + (size_t)tgt * 32;
-        const gf32x4 ht[2] = {*reinterpret_cast<const gf32x4*>(htp + kk * 4), *reinterpret_cast<const gf32x4*>(htp + 16 + kk * 4)};
+        const gf32x4 zero4 = gf32x4{0.f, 0.f, 0.f, 0.f};
+        const gf32x4 ht[2] = {first ? zero4 : *reinterpret_cast<const gf32x4*>(htp + kk * 4), first ? zero4 : *reinterpret_cast<const gf32x4*>(htp + 16 + kk * 4)};
         const float* ptp = a.P_in + (size_t)tgt * 64 + 32;
         const gf32x4 pt[2] = {*reinterpret_cast<const gf32x4*>(ptp + kk * 4), *reinterpret_cast<const gf32x4*>(ptp + 16 + kk * 4)};
         // a tile's three row gathers; the next tile's are requested before this tile's MFMAs
@@ -634,7 +648,7 @@ __global__ __launch_bounds__(256) void gnn_step_fact_kernel(const StepFactArgs a
             const float* cep = a.C + (size_t)ec * 32;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                hs[m] = *reinterpret_cast<const gf32x4*>(hsp + 16 * m + kk * 4);
+                hs[m] = first ? zero4 : *reinterpret_cast<const gf32x4*>(hsp + 16 * m + kk * 4);
                 acc[m] = *reinterpret_cast<const gf32x4*>(pfp + 16 * m + kk * 4) + *reinterpret_cast<const gf32x4*>(cep + 16 * m + kk * 4);
             }
         };
@@ -708,7 +722,7 @@ __global__ __launch_bounds__(256) void gnn_step_fact_kernel(const StepFactArgs a
     __syncthreads();
     if (tid < 32) {
         const float ig = gsig(gs[0][tid]), og = gsig(gs[1][tid]), fg = gsig(gs[2][tid]), cg = tanhf(gs[3][tid]);
-        const float c = fg * a.c_in[(size_t)tgt * 32 + tid] + ig * cg;
+        const float c = (first ? 0.f : fg * a.c_in[(size_t)tgt * 32 + tid]) + ig * cg;
         const float hn = og * tanhf(c);
         a.c_out[(size_t)tgt * 32 + tid] = c;
         a.h_out[(size_t)tgt * 32 + tid] = hn;

@@ -15,7 +15,7 @@ import roofline_from_profiles as rfp  # noqa: E402
 
 # every round-3 measurement point that carries the full set of summaries (profiles/r3*: fp32 headline builds and their bf16 twins)
 TAGS = sorted(t for t in os.listdir(os.path.join(ROOT, "profiles"))
-              if t.startswith(("r3", "r4", "r5")) and all(os.path.exists(os.path.join(ROOT, "profiles", t, f))
+              if t.startswith(("r3", "r4", "r5", "r6")) and all(os.path.exists(os.path.join(ROOT, "profiles", t, f))
                                             for f in ("kernel_stats.csv", "pmc_summary.json", "bench_under_trace.json", "bench.json")))
 
 
@@ -42,17 +42,20 @@ def test_roofline_block_is_reproducible_from_the_committed_summaries(tag):
     r = rfp.block(line)
     # the compared set covers the launch time, the achieved rate and fraction, the PMC traffic and the whole-page figures
     assert {"avg_launch_us", "achieved", "frac", "traffic", "hbm_frac", "whole_page_executed_frac", "whole_page_traffic_gb"} <= set(pairs)
-    assert r["timing"] == "in situ" and r["kernel"] in {t["kernel"] for t in table}
+    mem = r["kernel"].split("+")                             # round 6: the two level-0 blocks as one entry "down+up"
+    assert r["timing"].startswith("in situ") and set(mem) <= {t["kernel"] for t in table}
     # the table joins every engine-side kernel name with a rocprofv3 row (no name table in between)
     engine = {k["kernel"] for k in line["kernels"]}
     assert engine <= {t["kernel"] for t in table}, engine - {t["kernel"] for t in table}
     # sanity against the definitions: traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 of the dominant kernel's PMC rows
     pmc = json.load(open(os.path.join(tagdir, "pmc_summary.json")))
-    f = next(v for k, v in pmc["FETCH_SIZE"].items() if make_traffic_json.kernel_key(k) == r["kernel"])
-    w = next(v for k, v in pmc["WRITE_SIZE"].items() if make_traffic_json.kernel_key(k) == r["kernel"])
+    fs = [v for k, v in pmc["FETCH_SIZE"].items() if make_traffic_json.kernel_key(k) in mem]
+    ws = [v for k, v in pmc["WRITE_SIZE"].items() if make_traffic_json.kernel_key(k) in mem]
+    assert len(fs) == len(ws) == len(mem)
     # (the traced line carries the table of the FIRST profile pass of scripts/profile_round.sh, the directory holds the second
     # pass's counters: the same build and command, equal to a few 1e-4 .. 1e-3)
-    assert abs((2 * f["avg_per_dispatch"] + w["avg_per_dispatch"]) * 1024 / r["traffic"] - 1) < 5e-3
+    mean = sum((2 * f["sum"] + w["sum"]) * 1024 for f, w in zip(fs, ws)) / sum(f["dispatches"] for f in fs)
+    assert abs(mean / r["traffic"] - 1) < 5e-3
 
 
 @pytest.mark.parametrize("tag", TAGS)
