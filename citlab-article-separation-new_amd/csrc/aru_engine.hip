@@ -9,6 +9,7 @@
 #include "res8_kernels.h"
 #include "res8v_kernels.h"
 #include "bf16_kernels.h"
+#include "res8w_kernels.h"
 #include "split_kernels.h"
 #include "asep_common.h"
 
@@ -74,6 +75,7 @@ struct asep_aru {
     bf16_t* d_r8f_down_w1 = nullptr; // conv1 of unet_down_0 as ONE pair fragment [64][8] (k = window row / column, res8f_kernel)
     float* d_r8b_down_w1r = nullptr; // the same filter [9][8] as fp32 values rounded to bfloat16 (border tiles, res8b_tile)
     bool use_res32 = true;           // ASEP_BF_RES32=0: the 32-channel residual tails layer by layer (convb_kernel)
+    bool use_walk = true;            // ASEP_BF_WALK=0: the level-0 UP block as 16 x 32 tiles (res8f_kernel) instead of the column-strip walker (res8w_kernels.h)
     bf16_t* d_r8b_up_w = nullptr;    // [3][3][64][8]
     float* d_r8b_up_b = nullptr;     // [3][8]
     float* d_r8b_up_b1 = nullptr;    // [8]
@@ -1294,13 +1296,96 @@ int pack_res8b(asep_aru* m, const std::map<std::string, HostTensor>& blob) {
 }
 
 Tensor new_tensor_bf(asep_aru* m, int H, int W, int C);
+void run_res8b_tiles(asep_aru* m, bool up, const TL& a0, const TL* a1, const std::vector<const float*>& stats, bool want_pool, const TL& outs, const TL* pool_out);
 
 // whole level-0 blocks of the bf16 path (res8b_kernel)
+// The level-0 UP block of the pages the strip walker serves (res8w_kernels.h): one launch of walker items (one wave each) + one launch of
+// the border tiles around the walkers' regions.  `outs` are the pages' output tensors.
+void run_res8w_up(asep_aru* m, const TL& skip, const TL& dec, const TL& outs) {
+    for (size_t b0 = 0; b0 < skip.size(); b0 += MAXP) {
+        const size_t b1 = std::min(skip.size(), b0 + MAXP);
+        Res8WArgs wa{};
+        Res8WBArgs ba{};
+        double flops = 0, bytes = 0, wshare = 0;
+        long strip_rows = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            Res8WProb& p = wa.p[i - b0];
+            p.skip = skip[i].bp(); p.dec = dec[i].bp(); p.out = outs[i].bp();
+            p.H = skip[i].H; p.W = skip[i].W;
+            p.n_strips = (p.W - 4 - R8W_X0) / R8W_TW;
+            p.y_end = R8W_Y0 + 2 * ((p.H - 4 - R8W_Y0) / 2);
+            strip_rows += (long)p.n_strips * (p.y_end - R8W_Y0);
+            bytes += tbytes(skip[i]) + tbytes(dec[i]) + tbytes(outs[i]);
+            flops += 2.0 * p.H * p.W * (9.0 * 16 * 8 + 3 * 9.0 * 64);
+            wshare += (double)p.n_strips * R8W_TW * (p.y_end - R8W_Y0);
+        }
+        // rows of an item: ~6 items per resident wave of the chip (seven waves per CU), so that the hardware's block dispatch balances the tail;
+        // an item's head and tail cost about two iterations' worth of halo rows
+        const long slots = 7L * m->num_cus;
+        int band = (int)std::min<long>(256, std::max<long>(32, strip_rows / (6 * slots)));
+        band = (band + 1) & ~1;
+        int items = 0, btiles = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            Res8WProb& p = wa.p[i - b0];
+            p.band = band;
+            p.tile_begin = items;
+            items += p.n_strips * cdiv(p.y_end - R8W_Y0, band);
+            Res8BProb& q = ba.b.p[i - b0];
+            q.skip = p.skip; q.dec = p.dec; q.out = p.out; q.pool = nullptr; q.H = p.H; q.W = p.W;
+            q.tile_begin = btiles;
+            ba.nbx[i - b0] = cdiv(p.W, 32); ba.nby[i - b0] = cdiv(p.y_end - R8W_Y0, 16);
+            ba.y_end[i - b0] = p.y_end; ba.xr[i - b0] = R8W_X0 + R8W_TW * p.n_strips;
+            btiles += 2 * ba.nbx[i - b0] + 2 * ba.nby[i - b0];
+        }
+        wa.nprob = ba.b.nprob = (int)(b1 - b0);
+        wa.b1 = m->d_r8b_up_b1; wa.w1pf = (const u32x4*)m->d_r8f_up_w1; wa.wpk = (const u32x4*)m->d_r8b_up_w; wa.bias = m->d_r8b_up_b;
+        ba.b.w1pk = (const u32x4*)m->d_r8b_up_w1; ba.b.b1 = m->d_r8b_up_b1; ba.b.wpk = (const u32x4*)m->d_r8b_up_w; ba.b.bias = m->d_r8b_up_b;
+        TL sub(skip.begin() + b0, skip.begin() + b1);
+        const std::string what = "unet_up_0 (conv1[16->8]+3xconvR+add) " + dims_of(sub);
+        double area = 0;
+        for (size_t i = b0; i < b1; ++i) area += (double)skip[i].H * skip[i].W;
+        const double wf = wshare / area;                     // the walker's share of the pages' pixels
+        int units = items;
+        wa.xm = oneshot_map(m, items, &units);
+        {
+            ProfScope ps(m, "res8w_kernel", flops * wf, what);
+            ps.bytes = bytes * wf;
+            hipLaunchKernelGGL(res8w_kernel, dim3(units), dim3(64), 0, m->stream, wa);
+        }
+        {
+            ProfScope ps(m, "res8wb_kernel<true>", flops * (1.0 - wf), what);
+            ps.bytes = bytes * (1.0 - wf);
+            hipLaunchKernelGGL(res8wb_kernel<true>, dim3(btiles), dim3(256), 0, m->stream, ba);
+        }
+    }
+}
+
 void run_res8b(asep_aru* m, bool up, const TL& a0, const TL* a1, const std::vector<const float*>& stats, bool want_pool, TL* d_out, TL* pool_out) {
     for (const Tensor& t : a0) {
         d_out->push_back(new_tensor_bf(m, t.H, t.W, 8));
         if (want_pool) pool_out->push_back(new_tensor_bf(m, cdiv(t.H, 2), cdiv(t.W, 2), 8));
     }
+    if (up && m->use_walk && m->d_r8f_up_w1) {
+        // pages with room for at least four strips and two tile rows of walker region go to the strip walker, the others stay on the tile kernels
+        TL ws, wd, wo, rs, rd, ro;
+        for (size_t i = 0; i < a0.size(); ++i) {
+            const Tensor& t = a0[i];
+            const bool fits = (t.W - 4 - R8W_X0) / R8W_TW >= 4 && t.H - 4 - R8W_Y0 >= 32 && (size_t)t.H * t.W < ((size_t)1 << 28);
+            (fits ? ws : rs).push_back(t); (fits ? wd : rd).push_back((*a1)[i]); (fits ? wo : ro).push_back((*d_out)[i]);
+        }
+        if (!ws.empty()) {
+            run_res8w_up(m, ws, wd, wo);
+            if (rs.empty()) return;
+            run_res8b_tiles(m, up, rs, &rd, stats, false, ro, nullptr);
+            return;
+        }
+    }
+    run_res8b_tiles(m, up, a0, a1, stats, want_pool, *d_out, pool_out);
+}
+
+// the tile kernels (res8f_kernel for interior tiles + res8b_tile for border tiles in one launch) on the given output tensors
+void run_res8b_tiles(asep_aru* m, bool up, const TL& a0, const TL* a1, const std::vector<const float*>& stats, bool want_pool, const TL& outs, const TL* pool_out) {
+    const TL* d_out = &outs;
     for (size_t b0 = 0; b0 < a0.size(); b0 += MAXP) {
         const size_t b1 = std::min(a0.size(), b0 + MAXP);
         Res8BArgs a{};
@@ -2128,6 +2213,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     m->fused8_var = variant && !cfg->plain_u && cfg->activation != 0 && m->fused8_wanted && m->r8_valu && m->fuse_act && !m->bf16;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_RES32")) m->use_res32 = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_BF_WALK")) m->use_walk = atoi(e) != 0;
     if (const char* e = getenv("ASEP_LANES")) { m->num_lanes = std::max(1, std::min(4, atoi(e))); m->lanes_forced = true; }
     for (int l = 0; l < m->num_lanes; ++l) {
         std::unique_ptr<asep_aru::Lane> L(new asep_aru::Lane());

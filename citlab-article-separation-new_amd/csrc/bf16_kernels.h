@@ -1305,8 +1305,9 @@ struct Res8BLayout {
 };
 
 // the block of one tile (any position; `lds` holds Res8BLayout<UP>::BYTES)
+// (ymax / xmax: stores are clipped to rows < ymax, columns < xmax -- the border tiles of res8wb_kernel, whose neighbours belong to the strip walker)
 template <bool UP>
-__device__ __forceinline__ void res8b_tile(const Res8BArgs& a, const Res8BProb& P, int x0, int y0, unsigned char* lds) {
+__device__ __forceinline__ void res8b_tile(const Res8BArgs& a, const Res8BProb& P, int x0, int y0, unsigned char* lds, int ymax = 1 << 30, int xmax = 1 << 30) {
     constexpr int TH = 16, TW = 32;
     constexpr int H0 = TH + 6, W0 = TW + 6, H1 = TH + 4, W1 = TW + 4, H2 = TH + 2, W2 = TW + 2;
     constexpr int IH = TH + 8, IW = TW + 8;                   // conv1's input tile (halo 4)
@@ -1487,6 +1488,7 @@ __device__ __forceinline__ void res8b_tile(const Res8BArgs& a, const Res8BProb& 
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 16 + ch);
         const int Wp = (W + 1) >> 1;
         const int x = x0 + 2 * j + e;
+        const int Hs = min(H, ymax), Ws = min(W, xmax);      // (even clip bounds: a 2 x 2 pool window lies on one side)
         for (int rp = wave; rp < TH / 2; rp += 4) {
             f32x4 v2[2];
 #pragma unroll
@@ -1501,7 +1503,7 @@ __device__ __forceinline__ void res8b_tile(const Res8BArgs& a, const Res8BProb& 
                 const u32x2 pk = pack_bf16x4(v);
                 v2[r] = unpack_bf16x4(pk);
                 const int y = y0 + oy;
-                if (y < H && x < W) *reinterpret_cast<u32x2*>(P.out + ((size_t)y * W + x) * 8 + ch) = pk;
+                if (y < Hs && x < Ws) *reinterpret_cast<u32x2*>(P.out + ((size_t)y * W + x) * 8 + ch) = pk;
             }
             if (P.pool) {
                 // window = rows y, y + 1 (registers) x pixels 2j, 2j + 1 (this lane and lane ^ 32); out-of-image members are excluded
@@ -1516,7 +1518,7 @@ __device__ __forceinline__ void res8b_tile(const Res8BArgs& a, const Res8BProb& 
                     hi[c] = from_upper_half(mine);
                 }
                 mm = max4(lo, hi);
-                if (e == 0 && y < H && x < W) *reinterpret_cast<u32x2*>(P.pool + ((size_t)(y >> 1) * Wp + (x >> 1)) * 8 + ch) = pack_bf16x4(mm);
+                if (e == 0 && y < Hs && x < Ws) *reinterpret_cast<u32x2*>(P.pool + ((size_t)(y >> 1) * Wp + (x >> 1)) * 8 + ch) = pack_bf16x4(mm);
             }
         }
     }

@@ -1,0 +1,261 @@
+// res8w_kernel: the level-0 UP block of the bf16 path (conv1 over [skip, deconv] 16 -> 8, three 8 -> 8 convolutions, + t, ReLU:
+// ARU_v1.py:251-292 at level 0) as a COLUMN-STRIP WALKER -- round 6, the form DESIGN section 7.2 and the round-5 review named.
+//
+// res8f_kernel (bf16_kernels.h) computes a 16 x 32-pixel tile per block: window from HBM -> barrier -> conv1 -> barrier -> three
+// stages with a barrier each -> stores; four waves meet five times per tile, every phase has two or three pair slots per wave (a
+// software pipeline that is mostly fill and drain), the 24 x 40 window is requested when the block starts (2-4 us of HBM latency that
+// only the other two blocks of the CU cover), and the stacked 3 x 3 convolutions recompute 1.31 x the block's outputs in their halos.
+// Its SIMDs issue 43 % of the time (317 us per 3000 x 4500 page against 130 us of MFMA + vector issue).
+//
+// Here ONE WAVE walks DOWN a strip of 24 output columns, two rows per iteration, and keeps a rolling window of every stage in its own
+// LDS rings -- no other wave ever reads them, so there is NO barrier and no cross-wave dependency anywhere in the kernel:
+//   * iteration k runs one pair slot of EVERY stage on data that earlier iterations left in the rings: conv1 on rows a, a + 1, stage 1
+//     three rows behind it, stage 2 three rows behind stage 1, stage 3 three rows behind stage 2.  The four slots of an iteration are
+//     independent of each other: their fragment reads are issued together, their MFMAs and epilogues interleave freely -- a steady
+//     state with no fill and drain except at the ends of a strip segment;
+//   * every stage region is ONE MFMA tile wide: 30 / 28 / 26 / 24 pixels = 15 / 14 / 13 / 12 of the 16 pixel pairs of the pixel-pair
+//     mapping (M = 2 pixels x 8 channels, K = one filter row = 4 window pixels x 8 channels, N = 16 pairs; bf16_kernels.h): no
+//     remainder tiles, every LDS address is a per-lane constant + a wave-uniform ring offset;
+//   * no vertical halo is recomputed (only 3 + 2 + 1 rows at the head and tail of a segment of ~200 rows); the horizontal one is
+//     (30 + 28 + 26) / (3 x 24) = 1.17 x on the stages: 15 MFMAs per 2 x 24 output pixels = 320 per 512 (res8f: 339);
+//   * the input rows arrive by LDS-DMA (global_load_lds_dwordx4: one instruction = two rows of one source plane, no registers) D row
+//     pairs ahead of conv1, retired by a counted s_waitcnt vmcnt; the output rows leave as the stage-3 epilogue produces them.
+// Per wave: 21 KB of LDS (input ring 8 rows x 2 planes x 32 pixels, rings of 6 rows for the three intermediate stages, 12 rows of the
+// raw conv1 result for the residual add) -> seven independent waves per CU.  The accumulation order of every output value is that of
+// res8f_kernel (bias as the accumulators' initial value, filter rows 0, 1, 2; conv1: (row, source) pairs in the same order): results
+// are BIT-IDENTICAL to res8f_kernel's wherever both run their lean form (tests/test_aru_gpu.py).
+//
+// The walker covers columns [32, 32 + 24 n) x rows [16, y_end) of a page (its 4-pixel window margins inside the image); the frame
+// around it -- one 32-pixel tile column left, the rest right, one 16-row tile row at the top, the rest at the bottom -- is computed by
+// res8wb_kernel with the general tile function res8b_tile (zero tests, clipped stores).  Pages too small for a strip stay on res8f_kernel.
+#pragma once
+#include "bf16_kernels.h"
+
+namespace asep {
+
+constexpr int R8W_TW = 24;             // output columns of a strip
+constexpr int R8W_D = 4;               // input row pairs in flight ahead of conv1 (the input ring has D + 1 pair slots)
+constexpr int R8W_X0 = 32, R8W_Y0 = 16;   // the walker's region starts here (one border tile column / row in front of it)
+
+struct Res8WProb {
+    const bf16_t* skip;    // [H,W,8]
+    const bf16_t* dec;     // [H,W,8] deconv output
+    bf16_t* out;           // [H,W,8]
+    int H, W;
+    int n_strips;          // strips at x0 = 32 + 24 s
+    int band;              // output rows of an item (even)
+    int y_end;             // the walker's rows end here (even, <= H - 4)
+    int tile_begin;        // first ITEM of this problem in the launch (items: band-major, the strips of a band side by side)
+};
+struct Res8WArgs {
+    Res8WProb p[MAXP];
+    int nprob;
+    const float* b1;       // conv1 bias [8]
+    const u32x4* w1pf;     // conv1 pair fragments for the planar input tile [ky 3][source 2][64 lanes] x 16 bytes
+    const u32x4* wpk;      // tail: [3 convs][ky 3][64 lanes] x 16 bytes
+    const float* bias;     // tail biases [3][8]
+    XcdMap xm;
+};
+
+template <int N>
+__device__ __forceinline__ void r8w_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void r8w_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// (x + d) mod N for a ring counter x in [0, N) and -N <= d < N, on the scalar unit
+__device__ __forceinline__ int r8w_wrap(int x, int d, int N) {
+    int v = x + d;
+    v += v < 0 ? N : 0;
+    v -= v >= N ? N : 0;
+    return v;
+}
+
+__global__ __launch_bounds__(64, 2) void res8w_kernel(const Res8WArgs a) {
+    constexpr int TW = R8W_TW, D = R8W_D, M = D + 1;
+    constexpr int IW = TW + 8, W0 = TW + 6, W1 = TW + 4, W2 = TW + 2;          // 32, 30, 28, 26 pixels
+    constexpr int N0 = 6, N1 = 6, N2 = 6, NT = 12;                             // ring rows
+    constexpr int INPL = 2 * M * IW * 16;                                      // bytes of one plane of the input ring
+    // (a fragment read of lanes j >= the tile's pairs runs up to 8 pixels past its row: into the next row or the next region, never past tc)
+    constexpr int IN_OFF = 0, R0_OFF = 2 * INPL, R1_OFF = R0_OFF + N0 * W0 * 16, R2_OFF = R1_OFF + N1 * W1 * 16,
+                  TC_OFF = R2_OFF + N2 * W2 * 16, TRASH = TC_OFF + NT * TW * 16, LDSB = TRASH + 16;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
+    unsigned char* const in = lds + IN_OFF;
+    unsigned char* const r0 = lds + R0_OFF;
+    unsigned char* const r1 = lds + R1_OFF;
+    unsigned char* const r2 = lds + R2_OFF;
+    unsigned char* const tc = lds + TC_OFF;
+
+    const int lane = threadIdx.x;
+    const int j = lane & 15, kk = lane >> 4, e = kk >> 1, ch = (kk & 1) * 4;   // D layout: pixel parity e, channels ch .. ch + 3
+    const int isB = kk & 1;
+    const int c = 2 * j + e;                                                  // the lane's pixel column in a tile
+    const int item = sched_tile(a.xm);
+    if (item < 0) return;
+    const int pi = prob_of_tile(a, item);
+    const Res8WProb& P = a.p[pi];
+    const int li = item - P.tile_begin;
+    const int bi = li / P.n_strips, si = li - bi * P.n_strips;
+    const int x0 = R8W_X0 + TW * si;
+    const int Ya = R8W_Y0 + bi * P.band;
+    const int nb = min(P.band, P.y_end - Ya);                                 // output rows of this item (even)
+    const unsigned wu = (unsigned)P.W;
+
+    // ---- filters and biases (L2 hits; once per segment of ~100 iterations) ----
+    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(a.b1 + ch);
+    f32x4 biasw[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) biasw[t] = *reinterpret_cast<const f32x4*>(a.bias + 8 * t + ch);
+    u32x4 a1[6], w[3][3];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) a1[t] = a.w1pf[t * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) w[s][t] = a.wpk[(s * 3 + t) * 64 + lane];
+
+    // ---- the input ring: pair p = image rows Ya - 4 + 2 p, + 1 in slot p mod M of both planes; lane -> (row of the pair, pixel).
+    //      conv1 of iteration k reads pairs k, k + 1; pair k + 1 + D is requested when those reads have RETURNED (it takes pair k's slot):
+    //      D pairs = D x 2 KB are in flight per wave most of the time -- the kernel's rate is bytes in flight / memory latency ----
+    const unsigned char* __restrict__ const sk = reinterpret_cast<const unsigned char*>(P.skip);
+    const unsigned char* __restrict__ const dc = reinterpret_cast<const unsigned char*>(P.dec);
+    const unsigned goff0 = ((unsigned)(Ya - 4 + (lane >> 5)) * wu + (unsigned)(x0 - 4 + (lane & 31))) * 16u, gpair = 2u * wu * 16u;
+    const int p_last = nb / 2 + 3;
+    auto dma = [&](int p, int slot) {                        // (wave-uniform)
+        const unsigned go = goff0 + (unsigned)p * gpair;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sk + go),
+                                         (__attribute__((address_space(3))) void*)(in + slot * 2 * IW * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dc + go),
+                                         (__attribute__((address_space(3))) void*)(in + INPL + slot * 2 * IW * 16), 16, 0, 0);
+    };
+#pragma unroll
+    for (int p = 0; p <= D; ++p) dma(p, p);                  // (p_last >= 4; D + 1 = M slots)
+
+    const int lcol = (2 * j + kk) * 16;                      // the lane's window pixel kk of pair j in a source row
+    auto whole = [&](u32x2 pa, u32x2 pb) {                   // lanes kk = 0 / 2 end with the whole pixel of tile A, kk = 1 / 3 with that of tile B
+        const auto s0 = __builtin_amdgcn_permlane16_swap(pa.x, pb.x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
+        return u32x4{s0[0], s1[0], s0[1], s1[1]};
+    };
+    auto relu_pk = [](u32x2 p) { return u32x2{relu_bf16x2(p.x), relu_bf16x2(p.y)}; };
+    unsigned char* __restrict__ const outb = reinterpret_cast<unsigned char*>(P.out);
+    const unsigned ooff0 = (((unsigned)(Ya - 12) * wu + (unsigned)(x0 + c)) * 8u + (unsigned)ch) * 2u, orow = wu * 16u;
+    // lanes beyond a region's pairs store into a 16-byte dump (an address select instead of a divergent branch around every store)
+    const int col0 = j < W0 / 2 ? R0_OFF + c * 16 : TRASH, col1 = j < W1 / 2 ? R1_OFF + c * 16 : TRASH, col2 = j < W2 / 2 ? R2_OFF + c * 16 : TRASH;
+    const int colt = (c >= 3 && c < 3 + TW) ? TC_OFF + (c - 3) * 16 : TRASH;
+    const bool ost = j < TW / 2;
+
+    // ring counters of the iteration: k mod M, 2 k mod 6, 2 k mod 12
+    int im = 0, i6 = 0, i12 = 0;
+    auto iteration = [&](auto steady_c, int k) {
+        constexpr bool ST = decltype(steady_c)::value;       // every stage active, a request every iteration: one straight block
+        const bool do_c1 = ST || k < nb / 2 + 3, do_s1 = ST || (k >= 2 && k < nb / 2 + 4), do_s2 = ST || (k >= 4 && k < nb / 2 + 5), do_s3 = ST || k >= 6;
+        const bool issue = ST || k + 1 + D <= p_last;
+        // ---- fragment reads of the three stages (everything they read was written by earlier iterations) ----
+        u32x4 inr[4][2], q0[4], q1[4], q2[4];
+        u32x2 tr[2];
+        if (do_s1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) q0[q] = *reinterpret_cast<const u32x4*>(r0 + r8w_wrap(i6, q - 3, N0) * W0 * 16 + lcol);
+        }
+        if (do_s2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) q1[q] = *reinterpret_cast<const u32x4*>(r1 + r8w_wrap(i6, q - 6, N1) * W1 * 16 + lcol);
+        }
+        if (do_s3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) q2[q] = *reinterpret_cast<const u32x4*>(r2 + r8w_wrap(i6, (q - 9) % N2, N2) * W2 * 16 + lcol);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) tr[r] = *reinterpret_cast<const u32x2*>(tc + r8w_wrap(i12, r - 8, NT) * TW * 16 + c * 16 + ch * 2);
+        }
+        // ---- the wait that retires pair k + 1 (requested in iteration k - D behind that iteration's stores), then conv1's reads ----
+        if (do_c1) {
+            // operations issued behind pair k + 1's request: 2 stores + 2 requests per iteration k - D + 1 .. k - 1
+            if (ST) r8w_wait_vm<4 * D - 4>();
+            else if (issue) r8w_wait_vm<2 * D - 2>();        // (head of a segment: no stores yet, or fewer)
+            else r8w_wait_vm<0>();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int off = (r8w_wrap(im, q >> 1, M) * 2 + (q & 1)) * IW * 16;
+                inr[q][0] = *reinterpret_cast<const u32x4*>(in + off + lcol);
+                inr[q][1] = *reinterpret_cast<const u32x4*>(in + INPL + off + lcol);
+            }
+        }
+        // ---- stages 1 and 2: ring rows 2 k - 2, 2 k - 1 of r1 / 2 k - 5, 2 k - 4 of r2 ----
+        auto stage = [&](const u32x4 (&wf)[3], const u32x4 (&q)[4], f32x4 b4, int col, int rtop, int nring, int wreg) {
+            f32x4 ra = b4, rb = b4;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) { ra = mfma_bf16_k32(wf[ky], q[ky], ra); rb = mfma_bf16_k32(wf[ky], q[ky + 1], rb); }
+            const u32x4 rec = whole(relu_pk(pack_bf16x4(ra)), relu_pk(pack_bf16x4(rb)));
+            const int o0 = r8w_wrap(i6, rtop, nring) * wreg * 16, o1 = r8w_wrap(i6, rtop + 1, nring) * wreg * 16;
+            *reinterpret_cast<u32x4*>(lds + col + (isB ? o1 : o0)) = rec;
+        };
+        if (do_s1) stage(w[0], q0, biasw[0], col1, -2, N1, W1);
+        if (do_s2) stage(w[1], q1, biasw[1], col2, -5, N2, W2);
+        // ---- stage 3: output rows Ya - 12 + 2 k, + 1: + raw t, ReLU after the rounding, 8 bytes per lane and row ----
+        if (do_s3) {
+            f32x4 v[2] = {biasw[2], biasw[2]};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) { v[0] = mfma_bf16_k32(w[2][ky], q2[ky], v[0]); v[1] = mfma_bf16_k32(w[2][ky], q2[ky + 1], v[1]); }
+            const unsigned oo = ooff0 + (unsigned)(2 * k) * orow;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const u32x2 pk = relu_pk(pack_bf16x4(v[r] + unpack_bf16x4(tr[r])));
+                if (ost) *reinterpret_cast<u32x2*>(outb + (oo + (unsigned)r * orow)) = pk;
+            }
+        }
+        // ---- conv1: rows 2 k + 1, 2 k + 2 of relu(t) -> r0, raw t -> tc; its reads have returned: pair k's slot takes the next request ----
+        if (do_c1) {
+            r8w_wait_lds();
+            if (issue) dma(k + 1 + D, im);
+            f32x4 ra = bias1, rb = bias1;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int src = 0; src < 2; ++src) {
+                    ra = mfma_bf16_k32(a1[ky * 2 + src], inr[ky][src], ra);
+                    rb = mfma_bf16_k32(a1[ky * 2 + src], inr[ky + 1][src], rb);
+                }
+            const u32x4 raw = whole(pack_bf16x4(ra), pack_bf16x4(rb)), rl = relu_bf16x8(raw);
+            const int o0 = r8w_wrap(i6, 1, N0) * W0 * 16, o1 = r8w_wrap(i6, 2, N0) * W0 * 16;
+            *reinterpret_cast<u32x4*>(lds + col0 + (isB ? o1 : o0)) = rl;
+            const int t0 = r8w_wrap(i12, 1, NT) * TW * 16, t1 = r8w_wrap(i12, 2, NT) * TW * 16;
+            *reinterpret_cast<u32x4*>(lds + colt + (isB ? t1 : t0)) = raw;          // (rows outside the item's output rows are never read)
+        }
+        im = im + 1 == M ? 0 : im + 1;
+        i6 = i6 == 4 ? 0 : i6 + 2;
+        i12 = i12 == 10 ? 0 : i12 + 2;
+    };
+
+    const int K = nb / 2 + 6;
+    // steady iterations: all four stages active and a request issued: 6 <= k, k + 1 + D <= p_last (= nb / 2 + 3)
+    const int k_steady_end = nb / 2 + 3 - D;                 // (exclusive)
+    int k = 0;
+    // (the steady wait counts the stores of iterations k - D + 1 .. k - 1: the first D - 1 iterations with stores take the general form)
+    for (; k < min(5 + D, K); ++k) iteration(std::false_type{}, k);
+    for (; k < k_steady_end; ++k) iteration(std::true_type{}, k);
+    for (; k < K; ++k) iteration(std::false_type{}, k);
+}
+
+// ---- the frame around the walker's region: general tiles with clipped stores --------------------------------------------------
+struct Res8WBArgs {
+    Res8BArgs b;           // p[i].tile_begin = first border tile of problem i; tiles_x unused
+    int nbx[MAXP];         // tiles of a full-width row: ceil(W / 32)
+    int nby[MAXP];         // tiles of a side column: ceil((y_end - 16) / 16)
+    int y_end[MAXP];
+    int xr[MAXP];          // first column behind the strips: 32 + 24 n_strips
+};
+template <bool UP>
+__global__ __launch_bounds__(256, UP ? 3 : 4) void res8wb_kernel(const Res8WBArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[Res8BLayout<UP>::BYTES];
+    const int bid = (int)blockIdx.x;
+    const int pi = prob_of_tile(a.b, bid);
+    const Res8BProb& P = a.b.p[pi];
+    const int t = bid - P.tile_begin;
+    const int nbx = a.nbx[pi], nby = a.nby[pi], ye = a.y_end[pi], xr = a.xr[pi];
+    int x0, y0, ymax, xmax;
+    if (t < nbx) { x0 = 32 * t; y0 = 0; ymax = R8W_Y0; xmax = P.W; }                                  // top row
+    else if (t < 2 * nbx) { x0 = 32 * (t - nbx); y0 = ye; ymax = P.H; xmax = P.W; }                   // bottom rows
+    else if (t < 2 * nbx + nby) { x0 = 0; y0 = R8W_Y0 + 16 * (t - 2 * nbx); ymax = ye; xmax = R8W_X0; }   // left column
+    else { x0 = xr; y0 = R8W_Y0 + 16 * (t - 2 * nbx - nby); ymax = ye; xmax = P.W; }                  // right columns
+    res8b_tile<UP>(a.b, P, x0, y0, lds, ymax, xmax);
+}
+
+}  // namespace asep

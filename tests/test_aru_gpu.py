@@ -374,3 +374,46 @@ def test_bf16_path_against_the_oracle_with_the_same_roundings(H, W):
           f"{bm[0]} {bm[1]:.2e}, rms {br[0]} {br[2]:.2e}; max|dp| {perr:.2e} (against the fp32 oracle {perr32:.2e})")
     assert fm[1] <= BF16_EMU_ENDPOINT_GATE and fr[2] <= BF16_EMU_ENDPOINT_RMS_GATE and perr <= BF16_EMU_PROB_GATE
     assert bm[1] <= BF16_BLOCK_MAX_GATE and br[2] <= BF16_BLOCK_RMS_GATE, (bm, br)
+
+
+@pytest.mark.parametrize("H,W", [(250, 333), (96, 200), (52, 132), (53, 155), (300, 135), (611, 477)])
+def test_level0_up_block_strip_walker_against_the_tile_kernel_and_the_oracle(H, W, monkeypatch):
+    """round 6: the bf16 level-0 UP block as a column-strip walker (res8w_kernels.h: one wave per 24-column strip, rolling
+    rows of every stage in its own LDS rings, no barrier) + border tiles around the walkers' region, against (a) the 16 x 32-tile kernel
+    (ASEP_BF_WALK=0): BIT-IDENTICAL wherever both evaluate the lean form (bias as the accumulators' initial value, same order of the filter
+    rows), a rounding flip at most where one side's tile is a border tile (res8b_tile adds the bias behind the sum); (b) the oracle with the
+    engine's roundings, block by block.  Sizes: first / last strip widths of every residue, one and several bands, pages whose coarser
+    scales stay on the tile kernel (the walker needs four strips and two tile rows)."""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    from oracle import aru_oracle
+    name = "scale_0_unet_up_0_conv"
+    img = _image(H, W, 77)
+    res = {}
+    for walk in ("1", "0"):
+        monkeypatch.setenv("ASEP_BF_WALK", walk)               # read when the engine is created
+        cfg, w, graph = _setup({"compute_dtype": "bf16"}, seed=9)
+        res[walk] = (helper.get_net_output(img, graph, "0"), helper.get_endpoint(graph, name),
+                     {n: helper.get_endpoint(graph, n) for n in ("scale_0_unet_down_0_conv", "scale_0_unet_up_1_conv", name)})
+        graph.close()
+    (p1, e1, eng), (p0, e0, _) = res["1"], res["0"]
+    assert e1.shape == e0.shape == (H, W, 8)
+    # the walker's region, and the tile kernel's interior tiles (whole 24 x 40 window inside the image)
+    ys, xs = np.arange(H)[:, None], np.arange(W)[None, :]
+    n_strips, y_end = (W - 4 - 32) // 24, 16 + 2 * ((H - 4 - 16) // 2)
+    walker = (ys >= 16) & (ys < y_end) & (xs >= 32) & (xs < 32 + 24 * n_strips)
+    ty0, tx0 = (ys // 16) * 16, (xs // 32) * 32
+    lean_tile = (ty0 - 4 >= 0) & (ty0 + 20 <= H) & (tx0 - 4 >= 0) & (tx0 + 36 <= W)
+    both = walker & lean_tile
+    assert both.sum() > 0.3 * H * W or H < 64
+    diff = (e1 != e0).any(axis=2)
+    assert not (diff & both).any(), f"{int((diff & both).sum())} pixels differ where both kernels run their lean form"
+    # elsewhere: a bfloat16 step here and there (bias added behind the sum instead of in front of it)
+    scale = max(1.0, float(np.abs(e0).max()))
+    assert float(np.abs(e1 - e0).max()) <= 2.0 ** -7 * scale and diff.mean() <= 0.02
+    assert float(np.abs(p1 - p0).max()) <= 2e-3
+    # (b) the block against the oracle with the engine's roundings, from the engine's own upstream end points
+    cfg32 = type(cfg)(**{**cfg.to_dict(), "compute_dtype": "f32"})
+    _, forced = aru_oracle.forward_torch(img, w, cfg32, return_intermediates=True, storage="bf16", teacher=eng)
+    d = e1 - forced[name]
+    sc = max(1.0, float(np.abs(forced[name]).max()))
+    assert float(np.abs(d).max()) / sc <= BF16_BLOCK_MAX_GATE and float(np.sqrt(np.mean(d.astype(np.float64) ** 2))) / sc <= BF16_BLOCK_RMS_GATE
