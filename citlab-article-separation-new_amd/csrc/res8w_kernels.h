@@ -33,8 +33,11 @@
 
 namespace asep {
 
+#ifndef R8W_DEPTH
+#define R8W_DEPTH 2
+#endif
 constexpr int R8W_TW = 24;             // output columns of a strip
-constexpr int R8W_D = 4;               // input row pairs in flight ahead of conv1 (the input ring has D + 1 pair slots)
+constexpr int R8W_D = R8W_DEPTH;               // input row pairs in flight ahead of conv1 (the input ring has D + 1 pair slots)
 constexpr int R8W_X0 = 32, R8W_Y0 = 16;   // the walker's region starts here (one border tile column / row in front of it)
 
 struct Res8WProb {
@@ -57,9 +60,22 @@ struct Res8WArgs {
     XcdMap xm;
 };
 
+// Ablation builds (scripts/r5_abl_build.sh R8W_ABL <bits>; WRONG RESULTS ON PURPOSE, never the product): 1 no wait for the input requests,
+// 2 no output stores, 4 a vector add in place of every MFMA, 8 no input requests, 16 no LDS stores of the stage results
+#ifndef R8W_ABL
+#define R8W_ABL 0
+#endif
 template <int N>
-__device__ __forceinline__ void r8w_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void r8w_wait_vm() { if (!(R8W_ABL & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ f32x4 r8w_mm(u32x4 a, u32x4 b, f32x4 c) {
+    if (R8W_ABL & 4) return c + f32x4{__uint_as_float(a.x ^ b.x), __uint_as_float(a.y ^ b.y), 0.f, 0.f};
+    return mfma_bf16_k32(a, b, c);
+}
 __device__ __forceinline__ void r8w_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// LDS bank swizzle of a row's 16-byte pixel units: unit u is kept at u ^ ((u >> 4) & 1).  The sixteen lanes of a fragment read take units
+// 2 j + kk (j = 0 .. 15): unswizzled, lanes j and j + 8 share a bank quad (stride 32 bytes over 256 bytes of banks: the 2-way conflicts
+// the SQ counters showed in res8f_kernel, 0.29-0.38 of the LDS cycles); swizzled, the upper eight take the other parity.
+__device__ __forceinline__ int r8w_swz(int u) { return u ^ ((u >> 4) & 1); }
 // (x + d) mod N for a ring counter x in [0, N) and -N <= d < N, on the scalar unit
 __device__ __forceinline__ int r8w_wrap(int x, int d, int N) {
     int v = x + d;
@@ -116,10 +132,12 @@ __global__ __launch_bounds__(64, 2) void res8w_kernel(const Res8WArgs a) {
     //      D pairs = D x 2 KB are in flight per wave most of the time -- the kernel's rate is bytes in flight / memory latency ----
     const unsigned char* __restrict__ const sk = reinterpret_cast<const unsigned char*>(P.skip);
     const unsigned char* __restrict__ const dc = reinterpret_cast<const unsigned char*>(P.dec);
-    const unsigned goff0 = ((unsigned)(Ya - 4 + (lane >> 5)) * wu + (unsigned)(x0 - 4 + (lane & 31))) * 16u, gpair = 2u * wu * 16u;
+    // (the ring is written lane-linear by the DMA: lane l lands in unit l & 31 of its row, so it FETCHES the pixel whose swizzled place that is)
+    const unsigned goff0 = ((unsigned)(Ya - 4 + (lane >> 5)) * wu + (unsigned)(x0 - 4 + r8w_swz(lane & 31))) * 16u, gpair = 2u * wu * 16u;
     const int p_last = nb / 2 + 3;
     auto dma = [&](int p, int slot) {                        // (wave-uniform)
         const unsigned go = goff0 + (unsigned)p * gpair;
+        if (R8W_ABL & 8) return;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sk + go),
                                          (__attribute__((address_space(3))) void*)(in + slot * 2 * IW * 16), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dc + go),
@@ -128,7 +146,7 @@ __global__ __launch_bounds__(64, 2) void res8w_kernel(const Res8WArgs a) {
 #pragma unroll
     for (int p = 0; p <= D; ++p) dma(p, p);                  // (p_last >= 4; D + 1 = M slots)
 
-    const int lcol = (2 * j + kk) * 16;                      // the lane's window pixel kk of pair j in a source row
+    const int lcol = r8w_swz(2 * j + kk) * 16;               // the lane's window pixel kk of pair j in a source row
     auto whole = [&](u32x2 pa, u32x2 pb) {                   // lanes kk = 0 / 2 end with the whole pixel of tile A, kk = 1 / 3 with that of tile B
         const auto s0 = __builtin_amdgcn_permlane16_swap(pa.x, pb.x, false, false);
         const auto s1 = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
@@ -138,14 +156,19 @@ __global__ __launch_bounds__(64, 2) void res8w_kernel(const Res8WArgs a) {
     unsigned char* __restrict__ const outb = reinterpret_cast<unsigned char*>(P.out);
     const unsigned ooff0 = (((unsigned)(Ya - 12) * wu + (unsigned)(x0 + c)) * 8u + (unsigned)ch) * 2u, orow = wu * 16u;
     // lanes beyond a region's pairs store into a 16-byte dump (an address select instead of a divergent branch around every store)
-    const int col0 = j < W0 / 2 ? R0_OFF + c * 16 : TRASH, col1 = j < W1 / 2 ? R1_OFF + c * 16 : TRASH, col2 = j < W2 / 2 ? R2_OFF + c * 16 : TRASH;
-    const int colt = (c >= 3 && c < 3 + TW) ? TC_OFF + (c - 3) * 16 : TRASH;
+    const int cs = r8w_swz(c) * 16;
+    const int col0 = j < W0 / 2 ? R0_OFF + cs : TRASH, col1 = j < W1 / 2 ? R1_OFF + cs : TRASH, col2 = j < W2 / 2 ? R2_OFF + cs : TRASH;
+    const int colt = (c >= 3 && c < 3 + TW) ? TC_OFF + r8w_swz(c - 3) * 16 : TRASH;
+    const int tcol = r8w_swz(c) * 16 + ch * 2;               // stage 3 reads the lane's half of raw t at its output column
     const bool ost = j < TW / 2;
 
-    // ring counters of the iteration: k mod M, 2 k mod 6, 2 k mod 12
-    int im = 0, i6 = 0, i12 = 0;
-    auto iteration = [&](auto steady_c, int k) {
-        constexpr bool ST = decltype(steady_c)::value;       // every stage active, a request every iteration: one straight block
+    // ring counters of the iteration: k mod M, 2 k mod 6, 2 k mod 12 (run time in the general form, compile time in the steady one)
+    static_assert(6 % M == 0, "the steady form is unrolled over 6 iterations: every ring position repeats with that period");
+    int rim = 0, ri6 = 0, ri12 = 0;
+    auto iteration = [&](auto phase_c, int k) {
+        constexpr int PH = decltype(phase_c)::value;         // >= 0: k mod 6 of a STEADY iteration (every stage active, a request issued): every LDS
+        constexpr bool ST = PH >= 0;                         // address is a per-lane constant + an immediate, the body one straight block
+        const int im = ST ? PH % M : rim, i6 = ST ? (2 * PH) % 6 : ri6, i12 = ST ? (2 * PH) % 12 : ri12;
         const bool do_c1 = ST || k < nb / 2 + 3, do_s1 = ST || (k >= 2 && k < nb / 2 + 4), do_s2 = ST || (k >= 4 && k < nb / 2 + 5), do_s3 = ST || k >= 6;
         const bool issue = ST || k + 1 + D <= p_last;
         // ---- fragment reads of the three stages (everything they read was written by earlier iterations) ----
@@ -163,7 +186,7 @@ __global__ __launch_bounds__(64, 2) void res8w_kernel(const Res8WArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) q2[q] = *reinterpret_cast<const u32x4*>(r2 + r8w_wrap(i6, (q - 9) % N2, N2) * W2 * 16 + lcol);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) tr[r] = *reinterpret_cast<const u32x2*>(tc + r8w_wrap(i12, r - 8, NT) * TW * 16 + c * 16 + ch * 2);
+            for (int r = 0; r < 2; ++r) tr[r] = *reinterpret_cast<const u32x2*>(tc + r8w_wrap(i12, r - 8, NT) * TW * 16 + tcol);
         }
         // ---- the wait that retires pair k + 1 (requested in iteration k - D behind that iteration's stores), then conv1's reads ----
         if (do_c1) {
@@ -182,10 +205,10 @@ __global__ __launch_bounds__(64, 2) void res8w_kernel(const Res8WArgs a) {
         auto stage = [&](const u32x4 (&wf)[3], const u32x4 (&q)[4], f32x4 b4, int col, int rtop, int nring, int wreg) {
             f32x4 ra = b4, rb = b4;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) { ra = mfma_bf16_k32(wf[ky], q[ky], ra); rb = mfma_bf16_k32(wf[ky], q[ky + 1], rb); }
+            for (int ky = 0; ky < 3; ++ky) { ra = r8w_mm(wf[ky], q[ky], ra); rb = r8w_mm(wf[ky], q[ky + 1], rb); }
             const u32x4 rec = whole(relu_pk(pack_bf16x4(ra)), relu_pk(pack_bf16x4(rb)));
             const int o0 = r8w_wrap(i6, rtop, nring) * wreg * 16, o1 = r8w_wrap(i6, rtop + 1, nring) * wreg * 16;
-            *reinterpret_cast<u32x4*>(lds + col + (isB ? o1 : o0)) = rec;
+            if (!(R8W_ABL & 16) || rec.x == 0x12345678u) *reinterpret_cast<u32x4*>(lds + col + (isB ? o1 : o0)) = rec;
         };
         if (do_s1) stage(w[0], q0, biasw[0], col1, -2, N1, W1);
         if (do_s2) stage(w[1], q1, biasw[1], col2, -5, N2, W2);
@@ -193,12 +216,12 @@ __global__ __launch_bounds__(64, 2) void res8w_kernel(const Res8WArgs a) {
         if (do_s3) {
             f32x4 v[2] = {biasw[2], biasw[2]};
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) { v[0] = mfma_bf16_k32(w[2][ky], q2[ky], v[0]); v[1] = mfma_bf16_k32(w[2][ky], q2[ky + 1], v[1]); }
+            for (int ky = 0; ky < 3; ++ky) { v[0] = r8w_mm(w[2][ky], q2[ky], v[0]); v[1] = r8w_mm(w[2][ky], q2[ky + 1], v[1]); }
             const unsigned oo = ooff0 + (unsigned)(2 * k) * orow;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const u32x2 pk = relu_pk(pack_bf16x4(v[r] + unpack_bf16x4(tr[r])));
-                if (ost) *reinterpret_cast<u32x2*>(outb + (oo + (unsigned)r * orow)) = pk;
+                if (ost && (!(R8W_ABL & 2) || pk.x == 0x12345678u)) *reinterpret_cast<u32x2*>(outb + (oo + (unsigned)r * orow)) = pk;
             }
         }
         // ---- conv1: rows 2 k + 1, 2 k + 2 of relu(t) -> r0, raw t -> tc; its reads have returned: pair k's slot takes the next request ----
@@ -210,28 +233,31 @@ __global__ __launch_bounds__(64, 2) void res8w_kernel(const Res8WArgs a) {
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int src = 0; src < 2; ++src) {
-                    ra = mfma_bf16_k32(a1[ky * 2 + src], inr[ky][src], ra);
-                    rb = mfma_bf16_k32(a1[ky * 2 + src], inr[ky + 1][src], rb);
+                    ra = r8w_mm(a1[ky * 2 + src], inr[ky][src], ra);
+                    rb = r8w_mm(a1[ky * 2 + src], inr[ky + 1][src], rb);
                 }
             const u32x4 raw = whole(pack_bf16x4(ra), pack_bf16x4(rb)), rl = relu_bf16x8(raw);
             const int o0 = r8w_wrap(i6, 1, N0) * W0 * 16, o1 = r8w_wrap(i6, 2, N0) * W0 * 16;
-            *reinterpret_cast<u32x4*>(lds + col0 + (isB ? o1 : o0)) = rl;
+            if (!(R8W_ABL & 16) || rl.x == 0x12345678u) *reinterpret_cast<u32x4*>(lds + col0 + (isB ? o1 : o0)) = rl;
             const int t0 = r8w_wrap(i12, 1, NT) * TW * 16, t1 = r8w_wrap(i12, 2, NT) * TW * 16;
-            *reinterpret_cast<u32x4*>(lds + colt + (isB ? t1 : t0)) = raw;          // (rows outside the item's output rows are never read)
+            if (!(R8W_ABL & 16) || raw.x == 0x12345678u) *reinterpret_cast<u32x4*>(lds + colt + (isB ? t1 : t0)) = raw;          // (rows outside the item's output rows are never read)
         }
-        im = im + 1 == M ? 0 : im + 1;
-        i6 = i6 == 4 ? 0 : i6 + 2;
-        i12 = i12 == 10 ? 0 : i12 + 2;
+        if (!ST) {
+            rim = rim + 1 == M ? 0 : rim + 1;
+            ri6 = ri6 == 4 ? 0 : ri6 + 2;
+            ri12 = ri12 == 10 ? 0 : ri12 + 2;
+        }
     };
 
     const int K = nb / 2 + 6;
-    // steady iterations: all four stages active and a request issued: 6 <= k, k + 1 + D <= p_last (= nb / 2 + 3)
+    // steady iterations: all four stages active, a request issued and D - 1 iterations with stores behind them: 5 + D <= k, k + 1 + D <= p_last
     const int k_steady_end = nb / 2 + 3 - D;                 // (exclusive)
+    constexpr int K0 = 5 + D;                                // first steady iteration; groups of six start at K0 + 6 g
     int k = 0;
-    // (the steady wait counts the stores of iterations k - D + 1 .. k - 1: the first D - 1 iterations with stores take the general form)
-    for (; k < min(5 + D, K); ++k) iteration(std::false_type{}, k);
-    for (; k < k_steady_end; ++k) iteration(std::true_type{}, k);
-    for (; k < K; ++k) iteration(std::false_type{}, k);
+    for (; k < min(K0, K); ++k) iteration(ic<-1>{}, k);
+    for (; k + 6 <= k_steady_end; k += 6)
+        static_for<6>([&](auto u) { iteration(ic<(K0 + decltype(u)::value) % 6>{}, k + decltype(u)::value); });
+    for (; k < K; ++k) iteration(ic<-1>{}, k);
 }
 
 // ---- the frame around the walker's region: general tiles with clipped stores --------------------------------------------------
