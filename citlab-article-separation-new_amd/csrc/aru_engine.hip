@@ -75,7 +75,8 @@ struct asep_aru {
     bf16_t* d_r8f_down_w1 = nullptr; // conv1 of unet_down_0 as ONE pair fragment [64][8] (k = window row / column, res8f_kernel)
     float* d_r8b_down_w1r = nullptr; // the same filter [9][8] as fp32 values rounded to bfloat16 (border tiles, res8b_tile)
     bool use_res32 = true;           // ASEP_BF_RES32=0: the 32-channel residual tails layer by layer (convb_kernel)
-    bool use_walk = true;            // ASEP_BF_WALK=0: the level-0 UP block as 16 x 32 tiles (res8f_kernel) instead of the column-strip walker (res8w_kernels.h)
+    int walk_mode = 1;               // ASEP_BF_WALK: 1 both level-0 blocks on the walkers (default), 2 the UP block only, 0 neither
+    bool use_walk = true;            // ASEP_BF_WALK=0: the level-0 blocks as 16 x 32 tiles (res8f_kernel) instead of the column-strip walkers (res8w_kernels.h)
     bf16_t* d_r8b_up_w = nullptr;    // [3][3][64][8]
     float* d_r8b_up_b = nullptr;     // [3][8]
     float* d_r8b_up_b1 = nullptr;    // [8]
@@ -109,13 +110,18 @@ struct asep_aru {
         bool own_stream = false;
         hipStream_t side = nullptr;
         hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_begin = nullptr, ev_done = nullptr;
+        hipStream_t bside = nullptr;     // the border tiles of the strip walkers run beside the walkers (run_res8w); not the attention branch's
+        hipEvent_t ev_bfork = nullptr, ev_bjoin = nullptr;   // stream: its chain is busy while the level-0 down block runs
         BufferPool pool;
         ~Lane() {
             if (ev_fork) (void)hipEventDestroy(ev_fork);
+            if (ev_bfork) (void)hipEventDestroy(ev_bfork);
+            if (ev_bjoin) (void)hipEventDestroy(ev_bjoin);
             if (ev_join) (void)hipEventDestroy(ev_join);
             if (ev_begin) (void)hipEventDestroy(ev_begin);
             if (ev_done) (void)hipEventDestroy(ev_done);
             if (side) (void)hipStreamDestroy(side);
+            if (bside) (void)hipStreamDestroy(bside);
             if (own_stream && s) (void)hipStreamDestroy(s);
         }
     };
@@ -1299,31 +1305,37 @@ Tensor new_tensor_bf(asep_aru* m, int H, int W, int C);
 void run_res8b_tiles(asep_aru* m, bool up, const TL& a0, const TL* a1, const std::vector<const float*>& stats, bool want_pool, const TL& outs, const TL* pool_out);
 
 // whole level-0 blocks of the bf16 path (res8b_kernel)
-// The level-0 UP block of the pages the strip walker serves (res8w_kernels.h): one launch of walker items (one wave each) + one launch of
-// the border tiles around the walkers' regions.  `outs` are the pages' output tensors.
-void run_res8w_up(asep_aru* m, const TL& skip, const TL& dec, const TL& outs) {
-    for (size_t b0 = 0; b0 < skip.size(); b0 += MAXP) {
-        const size_t b1 = std::min(skip.size(), b0 + MAXP);
+// A level-0 block (up: [skip, deconv] in; down: the fp32 image in, pool out) of the pages the strip walker serves (res8w_kernels.h): one launch of
+// walker items (one wave each) + one launch of the border tiles around the walkers' regions.  `outs` / `pools` are the pages' output tensors.
+void run_res8w(asep_aru* m, bool up, const TL& in0, const TL* dec, const std::vector<const float*>& stats, const TL& outs, const TL* pools) {
+    for (size_t b0 = 0; b0 < in0.size(); b0 += MAXP) {
+        const size_t b1 = std::min(in0.size(), b0 + MAXP);
         Res8WArgs wa{};
         Res8WBArgs ba{};
         double flops = 0, bytes = 0, wshare = 0;
         long strip_rows = 0;
         for (size_t i = b0; i < b1; ++i) {
             Res8WProb& p = wa.p[i - b0];
-            p.skip = skip[i].bp(); p.dec = dec[i].bp(); p.out = outs[i].bp();
-            p.H = skip[i].H; p.W = skip[i].W;
+            if (up) { p.skip = in0[i].bp(); p.dec = (*dec)[i].bp(); }
+            else { p.img = in0[i].p; p.stats = stats.empty() ? nullptr : stats[i]; p.pool = pools ? (*pools)[i].bp() : nullptr; }
+            p.out = outs[i].bp();
+            p.H = in0[i].H; p.W = in0[i].W;
             p.n_strips = (p.W - 4 - R8W_X0) / R8W_TW;
             p.y_end = R8W_Y0 + 2 * ((p.H - 4 - R8W_Y0) / 2);
             strip_rows += (long)p.n_strips * (p.y_end - R8W_Y0);
-            bytes += tbytes(skip[i]) + tbytes(dec[i]) + tbytes(outs[i]);
-            flops += 2.0 * p.H * p.W * (9.0 * 16 * 8 + 3 * 9.0 * 64);
+            bytes += tbytes(in0[i]) + (up ? tbytes((*dec)[i]) : 0.0) + tbytes(outs[i]) + (pools ? tbytes((*pools)[i]) : 0.0);
+            flops += 2.0 * p.H * p.W * (9.0 * (up ? 16 : 1) * 8 + 3 * 9.0 * 64);
             wshare += (double)p.n_strips * R8W_TW * (p.y_end - R8W_Y0);
         }
-        // rows of an item: ~6 items per resident wave of the chip (seven waves per CU), so that the hardware's block dispatch balances the tail;
-        // an item's head and tail cost about two iterations' worth of halo rows
-        const long slots = 7L * m->num_cus;
+        // rows of an item: ~6 items per resident wave of the chip (eight waves per CU), so that the hardware's block dispatch balances the tail;
+        // an item's head and tail cost about fifteen iterations of the general form (profiles/r6_walk: 64 / 128 / 256 / 400 / 800 rows per item =
+        // 952 / 798 / 747 / 752 / 739 us per 4-page launch)
+        const long slots = 8L * m->num_cus;
         int band = (int)std::min<long>(256, std::max<long>(32, strip_rows / (6 * slots)));
         band = (band + 1) & ~1;
+#ifdef ASEP_ABLATION
+        if (const char* e = getenv("ASEP_BF_WALK_BAND")) band = std::max(2, atoi(e) & ~1);      // (measurement knob of ablation builds)
+#endif
         int items = 0, btiles = 0;
         for (size_t i = b0; i < b1; ++i) {
             Res8WProb& p = wa.p[i - b0];
@@ -1331,31 +1343,50 @@ void run_res8w_up(asep_aru* m, const TL& skip, const TL& dec, const TL& outs) {
             p.tile_begin = items;
             items += p.n_strips * cdiv(p.y_end - R8W_Y0, band);
             Res8BProb& q = ba.b.p[i - b0];
-            q.skip = p.skip; q.dec = p.dec; q.out = p.out; q.pool = nullptr; q.H = p.H; q.W = p.W;
+            q.skip = p.skip; q.dec = p.dec; q.img = p.img; q.stats = p.stats; q.out = p.out; q.pool = p.pool; q.H = p.H; q.W = p.W;
             q.tile_begin = btiles;
             ba.nbx[i - b0] = cdiv(p.W, 32); ba.nby[i - b0] = cdiv(p.y_end - R8W_Y0, 16);
             ba.y_end[i - b0] = p.y_end; ba.xr[i - b0] = R8W_X0 + R8W_TW * p.n_strips;
             btiles += 2 * ba.nbx[i - b0] + 2 * ba.nby[i - b0];
         }
         wa.nprob = ba.b.nprob = (int)(b1 - b0);
-        wa.b1 = m->d_r8b_up_b1; wa.w1pf = (const u32x4*)m->d_r8f_up_w1; wa.wpk = (const u32x4*)m->d_r8b_up_w; wa.bias = m->d_r8b_up_b;
-        ba.b.w1pk = (const u32x4*)m->d_r8b_up_w1; ba.b.b1 = m->d_r8b_up_b1; ba.b.wpk = (const u32x4*)m->d_r8b_up_w; ba.b.bias = m->d_r8b_up_b;
-        TL sub(skip.begin() + b0, skip.begin() + b1);
-        const std::string what = "unet_up_0 (conv1[16->8]+3xconvR+add) " + dims_of(sub);
+        if (up) {
+            wa.b1 = m->d_r8b_up_b1; wa.w1pf = (const u32x4*)m->d_r8f_up_w1; wa.wpk = (const u32x4*)m->d_r8b_up_w; wa.bias = m->d_r8b_up_b;
+            ba.b.w1pk = (const u32x4*)m->d_r8b_up_w1; ba.b.b1 = m->d_r8b_up_b1; ba.b.wpk = (const u32x4*)m->d_r8b_up_w; ba.b.bias = m->d_r8b_up_b;
+        } else {
+            wa.b1 = m->det_first.d_b; wa.w1pf = (const u32x4*)m->d_r8f_down_w1; wa.wpk = (const u32x4*)m->d_r8b_down_w; wa.bias = m->d_r8b_down_b;
+            ba.b.w1 = m->d_r8b_down_w1r ? m->d_r8b_down_w1r : m->det_first.d_w; ba.b.b1 = m->det_first.d_b; ba.b.wpk = (const u32x4*)m->d_r8b_down_w; ba.b.bias = m->d_r8b_down_b;
+        }
+        TL sub(in0.begin() + b0, in0.begin() + b1);
+        const std::string what = (up ? "unet_up_0 (conv1[16->8]+3xconvR+add) " : "unet_down_0 (conv1+3xconvR+add+pool) ") + dims_of(sub);
         double area = 0;
-        for (size_t i = b0; i < b1; ++i) area += (double)skip[i].H * skip[i].W;
+        for (size_t i = b0; i < b1; ++i) area += (double)in0[i].H * in0[i].W;
         const double wf = wshare / area;                     // the walker's share of the pages' pixels
         int units = items;
         wa.xm = oneshot_map(m, items, &units);
-        {
-            ProfScope ps(m, "res8w_kernel", flops * wf, what);
-            ps.bytes = bytes * wf;
-            hipLaunchKernelGGL(res8w_kernel, dim3(units), dim3(64), 0, m->stream, wa);
+        // the border tiles (4 % of the pixels in 256-thread blocks) run BESIDE the walkers on a stream of their own: they fill the walkers' tail.
+        // While launch times are recorded everything stays on one stream.
+        asep_aru::Lane& L = *m->cur;
+        const bool beside = !m->profiling && L.bside;
+        if (beside) {
+            ASEP_HIP_CHECK_THROW(hipEventRecord(L.ev_bfork, m->stream));
+            ASEP_HIP_CHECK_THROW(hipStreamWaitEvent(L.bside, L.ev_bfork, 0));
         }
         {
-            ProfScope ps(m, "res8wb_kernel<true>", flops * (1.0 - wf), what);
+            ProfScope ps(m, up ? "res8w_kernel<true>" : "res8w_kernel<false>", flops * wf, what);
+            ps.bytes = bytes * wf;
+            if (up) hipLaunchKernelGGL(res8w_kernel<true>, dim3(units), dim3(64), 0, m->stream, wa);
+            else hipLaunchKernelGGL(res8w_kernel<false>, dim3(units), dim3(64), 0, m->stream, wa);
+        }
+        {
+            ProfScope ps(m, up ? "res8wb_kernel<true>" : "res8wb_kernel<false>", flops * (1.0 - wf), what);
             ps.bytes = bytes * (1.0 - wf);
-            hipLaunchKernelGGL(res8wb_kernel<true>, dim3(btiles), dim3(256), 0, m->stream, ba);
+            if (up) hipLaunchKernelGGL(res8wb_kernel<true>, dim3(btiles), dim3(256), 0, beside ? L.bside : m->stream, ba);
+            else hipLaunchKernelGGL(res8wb_kernel<false>, dim3(btiles), dim3(256), 0, beside ? L.bside : m->stream, ba);
+        }
+        if (beside) {
+            ASEP_HIP_CHECK_THROW(hipEventRecord(L.ev_bjoin, L.bside));
+            ASEP_HIP_CHECK_THROW(hipStreamWaitEvent(m->stream, L.ev_bjoin, 0));
         }
     }
 }
@@ -1365,18 +1396,22 @@ void run_res8b(asep_aru* m, bool up, const TL& a0, const TL* a1, const std::vect
         d_out->push_back(new_tensor_bf(m, t.H, t.W, 8));
         if (want_pool) pool_out->push_back(new_tensor_bf(m, cdiv(t.H, 2), cdiv(t.W, 2), 8));
     }
-    if (up && m->use_walk && m->d_r8f_up_w1) {
+    if (m->use_walk && (up || m->walk_mode == 1) && (up ? m->d_r8f_up_w1 != nullptr : m->d_r8f_down_w1 != nullptr)) {
         // pages with room for at least four strips and two tile rows of walker region go to the strip walker, the others stay on the tile kernels
-        TL ws, wd, wo, rs, rd, ro;
+        TL ws, wd, wo, wp, rs, rd, ro, rp;
+        std::vector<const float*> wst, rst;
         for (size_t i = 0; i < a0.size(); ++i) {
             const Tensor& t = a0[i];
             const bool fits = (t.W - 4 - R8W_X0) / R8W_TW >= 4 && t.H - 4 - R8W_Y0 >= 32 && (size_t)t.H * t.W < ((size_t)1 << 28);
-            (fits ? ws : rs).push_back(t); (fits ? wd : rd).push_back((*a1)[i]); (fits ? wo : ro).push_back((*d_out)[i]);
+            (fits ? ws : rs).push_back(t);
+            if (up) (fits ? wd : rd).push_back((*a1)[i]);
+            (fits ? wo : ro).push_back((*d_out)[i]);
+            if (want_pool) (fits ? wp : rp).push_back((*pool_out)[i]);
+            if (!stats.empty()) (fits ? wst : rst).push_back(stats[i]);
         }
         if (!ws.empty()) {
-            run_res8w_up(m, ws, wd, wo);
-            if (rs.empty()) return;
-            run_res8b_tiles(m, up, rs, &rd, stats, false, ro, nullptr);
+            run_res8w(m, up, ws, up ? &wd : nullptr, wst, wo, want_pool ? &wp : nullptr);
+            if (!rs.empty()) run_res8b_tiles(m, up, rs, up ? &rd : nullptr, rst, want_pool, ro, want_pool ? &rp : nullptr);
             return;
         }
     }
@@ -2213,12 +2248,15 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     m->fused8_var = variant && !cfg->plain_u && cfg->activation != 0 && m->fused8_wanted && m->r8_valu && m->fuse_act && !m->bf16;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_RES32")) m->use_res32 = atoi(e) != 0;
-    if (const char* e = getenv("ASEP_BF_WALK")) m->use_walk = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_BF_WALK")) { m->walk_mode = atoi(e); m->use_walk = m->walk_mode != 0; }
     if (const char* e = getenv("ASEP_LANES")) { m->num_lanes = std::max(1, std::min(4, atoi(e))); m->lanes_forced = true; }
     for (int l = 0; l < m->num_lanes; ++l) {
         std::unique_ptr<asep_aru::Lane> L(new asep_aru::Lane());
         bool ok = hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&L->bside, hipStreamNonBlocking) == hipSuccess &&
                   hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&L->ev_bfork, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&L->ev_bjoin, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&L->ev_join, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&L->ev_begin, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&L->ev_done, hipEventDisableTiming) == hipSuccess;
