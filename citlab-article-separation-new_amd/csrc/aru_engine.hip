@@ -1995,7 +1995,7 @@ TL att_cnn(asep_aru* m, const TL& imgs, const std::vector<const float*>& stats) 
 }
 
 // B pages of identical size through the net; problems = pages x scales
-int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* const* d_imgs, int H, int W,
+int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* const* d_imgs, const int32_t* Hs, const int32_t* Ws,
                  float* const* d_outs, uint8_t* const* d_u8s, uint8_t* const* d_masks, float threshold) {
     const asep_aru_cfg& cfg = m->cfg;
     hipStream_t stream = L.s;
@@ -2011,7 +2011,7 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
         for (int b = 0; b < B; ++b) {
             Tensor img;
             img.p = const_cast<float*>(d_imgs[b]);
-            img.H = H; img.W = W; img.C = 1;
+            img.H = Hs[b]; img.W = Ws[b]; img.C = 1;            // (pages of a call may differ in size: every launch carries per-problem dims)
             level0.push_back(img);
             const float* st = nullptr;
             if (cfg.mvn) {
@@ -2071,6 +2071,7 @@ int forward_impl(asep_aru* m, asep_aru::Lane& L, int page0, int B, const float* 
             fsum = m->bf16 ? run_chansum_bf(m, coarse) : run_pool(m, coarse, POOL_CHANSUM);
         }
         for (int b = 0; b < B; ++b) {
+            const int H = Hs[b], W = Ws[b];
             CombineArgs ca{};
             ca.nsc = nsc; ca.H = H; ca.W = W;
             ca.f0 = feat[b * nsc].p;
@@ -2359,7 +2360,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
 void asep_aru_free(asep_aru* m) { delete m; }
 
 // splits the pages over the lanes (lane 0 = the caller's stream), forks / joins with events
-static int forward_lanes(asep_aru* m, int n_pages, const float* const* d_imgs, int H, int W, float* const* d_outs,
+static int forward_lanes(asep_aru* m, int n_pages, const float* const* d_imgs, const int32_t* Hs, const int32_t* Ws, float* const* d_outs,
                          uint8_t* const* d_u8, uint8_t* const* d_mask, float threshold, hipStream_t stream) {
     m->endpoints.clear();
     // (per-launch profiling runs on one lane in every mode: the isolated mode brackets one kernel at a time, the in-situ mode keeps the side
@@ -2370,14 +2371,14 @@ static int forward_lanes(asep_aru* m, int n_pages, const float* const* d_imgs, i
     const int nl = (m->profiling || n_pages < 2) ? 1 : std::max(1, std::min<int>((int)m->lanes.size(), by_pages));
     asep_aru::Lane& L0 = *m->lanes[0];
     L0.s = stream;
-    if (nl == 1) return forward_impl(m, L0, 0, n_pages, d_imgs, H, W, d_outs, d_u8, d_mask, threshold);
+    if (nl == 1) return forward_impl(m, L0, 0, n_pages, d_imgs, Hs, Ws, d_outs, d_u8, d_mask, threshold);
     ASEP_HIP_CHECK(hipEventRecord(L0.ev_begin, stream));
     int page0 = 0;
     for (int l = 0; l < nl; ++l) {
         asep_aru::Lane& L = *m->lanes[l];
         const int cnt = n_pages / nl + (l < n_pages % nl ? 1 : 0);
         if (l > 0) ASEP_HIP_CHECK(hipStreamWaitEvent(L.s, L0.ev_begin, 0));
-        int rc = forward_impl(m, L, page0, cnt, d_imgs + page0, H, W, d_outs + page0, d_u8 ? d_u8 + page0 : nullptr,
+        int rc = forward_impl(m, L, page0, cnt, d_imgs + page0, Hs + page0, Ws + page0, d_outs + page0, d_u8 ? d_u8 + page0 : nullptr,
                               d_mask ? d_mask + page0 : nullptr, threshold);
         if (rc) return rc;
         if (l > 0) {
@@ -2394,7 +2395,8 @@ int asep_aru_forward_dev(asep_aru* m, const float* d_img, int H, int W, float* d
                          uint8_t* d_out_mask, float threshold, void* stream) {
     ASEP_GUARD_BEGIN
     if (!m || !d_img || !d_out || H < 1 || W < 1) { set_error("asep_aru_forward_dev: bad argument"); return ASEP_ERR_ARG; }
-    return forward_lanes(m, 1, &d_img, H, W, &d_out, d_out_u8 ? &d_out_u8 : nullptr, d_out_mask ? &d_out_mask : nullptr,
+    const int32_t h1 = H, w1 = W;
+    return forward_lanes(m, 1, &d_img, &h1, &w1, &d_out, d_out_u8 ? &d_out_u8 : nullptr, d_out_mask ? &d_out_mask : nullptr,
                          threshold, (hipStream_t)stream);
     ASEP_GUARD_END
 }
@@ -2406,6 +2408,23 @@ int asep_aru_forward_batch_dev(asep_aru* m, int n_pages, const float* const* d_i
     for (int b = 0; b < n_pages; ++b)
         if (!d_imgs[b] || !d_outs[b] || (d_out_u8 && !d_out_u8[b]) || (d_out_mask && !d_out_mask[b])) {
             set_error("asep_aru_forward_batch_dev: null page pointer at %d", b);
+            return ASEP_ERR_ARG;
+        }
+    const std::vector<int32_t> hs(n_pages, H), ws(n_pages, W);
+    return forward_lanes(m, n_pages, d_imgs, hs.data(), ws.data(), d_outs, d_out_u8, d_out_mask, threshold, (hipStream_t)stream);
+    ASEP_GUARD_END
+}
+
+// ABI 6: the same for pages of DIFFERENT sizes (the reference runs page by page on whatever size --fixed_height / --scaling_factor leave:
+// ARU_v1.py:64, run_net_post_processing.py:61-82; real scans differ in width).  Every grouped launch already carries per-problem dims (the
+// three scales of a page), so pages of any sizes share the launches of a layer.
+int asep_aru_forward_batch_dev2(asep_aru* m, int n_pages, const float* const* d_imgs, const int32_t* H, const int32_t* W, float* const* d_outs,
+                                uint8_t* const* d_out_u8, uint8_t* const* d_out_mask, float threshold, void* stream) {
+    ASEP_GUARD_BEGIN
+    if (!m || !d_imgs || !d_outs || !H || !W || n_pages < 1) { set_error("asep_aru_forward_batch_dev2: bad argument"); return ASEP_ERR_ARG; }
+    for (int b = 0; b < n_pages; ++b)
+        if (!d_imgs[b] || !d_outs[b] || (d_out_u8 && !d_out_u8[b]) || (d_out_mask && !d_out_mask[b]) || H[b] < 1 || W[b] < 1) {
+            set_error("asep_aru_forward_batch_dev2: null page pointer or empty page at %d", b);
             return ASEP_ERR_ARG;
         }
     return forward_lanes(m, n_pages, d_imgs, H, W, d_outs, d_out_u8, d_out_mask, threshold, (hipStream_t)stream);

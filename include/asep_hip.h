@@ -112,6 +112,13 @@ int asep_aru_forward_dev(asep_aru* m, const float* d_img, int H, int W,
 int asep_aru_forward_batch_dev(asep_aru* m, int n_pages, const float* const* d_imgs, int H, int W,
                                float* const* d_outs, uint8_t* const* d_out_u8, uint8_t* const* d_out_mask,
                                float threshold, void* stream);
+/* ABI 6: asep_aru_forward_batch_dev for pages of DIFFERENT sizes: H[b] x W[b] is page b's size, d_imgs[b] / d_outs[b] / d_out_u8[b] /
+ * d_out_mask[b] its buffers ([H[b], W[b]] fp32 in; [H[b], W[b], n_classes] out).  Replaces the reference's page-by-page loop over scans of
+ * arbitrary size (run_net_post_processing.py:61-82 -> get_net_output per scan, ARU_v1.py:64 `inImg` [1, None, None, 1]); results are those
+ * of the single-page calls bit for bit.  The pages of a call share every layer's launches. */
+int asep_aru_forward_batch_dev2(asep_aru* m, int n_pages, const float* const* d_imgs, const int32_t* H, const int32_t* W,
+                                float* const* d_outs, uint8_t* const* d_out_u8, uint8_t* const* d_out_mask, float threshold,
+                                void* stream);
 
 /* Named intermediate tensors of the last forward (tests / GNN visual branch): copies the NHWC fp32
  * tensor `name` (e.g. "scale_0_unet_up_0_conv", ARU_v1.py:11-29 end-point names) to host.
