@@ -111,8 +111,17 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
             streams[(tdev.index, lane)] = torch.cuda.Stream(tdev)
         return streams[(tdev.index, lane)]
 
+    PAGE_GROUP = 4                     # pages per batched net call of the pipelined run() (asep_aru_forward_batch_dev2: any sizes)
+
     def enqueue_page(self, image, edges_only=True, lane=0):
-        """Queue the device stages of one decoded page and return a ticket for :meth:`collect_page`.
+        """One page = a group of one (see :meth:`enqueue_group`)."""
+        return self.enqueue_group([image], edges_only=edges_only, lane=lane)[0]
+
+    def enqueue_group(self, images, edges_only=True, lane=0):
+        """Queue the device stages of up to PAGE_GROUP decoded pages -- of ANY sizes -- and return their tickets for :meth:`collect_page`.
+        Uploads and resize + gray per page, then ONE batched net call for the group (round 6, asep_aru_forward_batch_dev2: the pages share every
+        layer's launches, so the deep levels see 12 problems per launch like the device-resident bench instead of 3), then the classical
+        stages per page.  Same arithmetic as the single-page form, bit for bit.
 
         Everything is only enqueued -- upload, resize + gray, ARU-Net, CC filter / openings, boundary segments, the copy of
         the segment keys into page-locked host memory -- so ``image`` has to stay valid until the ticket is collected.  Same arithmetic as load_and_scale_image ->
@@ -121,67 +130,84 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
         dev = self.device
         lib = _lib.init_device(dev)
         tdev = torch.device("cuda", dev)
-        image = np.require(image, dtype=np.uint8, requirements=['C', 'W'])   # Pillow hands out read-only views
-        if image.ndim == 2:
-            image = image[:, :, None]
-        H, W, Cn = image.shape
-        sc = get_scaling_factor(H, W, self.scaling_factor, fixed_height=self.fixed_height)
-        h, w = image_ops.scaled_size(H, W, sc)
         ncls = self.pb_graph.cfg.n_classes
         _, ws = image_ops._workspace(dev, lane)
-        t = {"sc": sc, "size": (h, w), "edges_only": edges_only, "device": dev}
+        tickets = []
         with torch.cuda.device(tdev), torch.cuda.stream(self._lane_stream(tdev, lane)):
             stream = torch.cuda.current_stream(tdev)
             sp = C.c_void_p(stream.cuda_stream)
-            # the upload is queued like everything else (a page is 0.3 ms of PCIe; a copy on a second stream ended up behind the
-            # engine's kernels in a shared hardware queue and made the host wait for them): ``image`` must stay valid until the
-            # page is collected -- DecodePool(hold=2) guarantees that for its slots, pageable arrays are staged by the runtime
-            # before the call returns
-            d_img = torch.empty((H, W, Cn), dtype=torch.uint8, device=tdev)
-            d_img.copy_(torch.from_numpy(image), non_blocking=True)
-            t["uploaded"] = torch.cuda.Event()
-            t["uploaded"].record(stream)
-            d_gray = torch.empty((h, w), dtype=torch.float32, device=tdev)
-            _lib.check(lib.asep_prep_scale_gray_dev(ws, d_img.data_ptr(), H, W, Cn, float(sc), None,
-                                                    d_gray.data_ptr(), sp), "asep_prep_scale_gray_dev")
-            d_out = torch.empty((h, w, ncls), dtype=torch.float32, device=tdev)
-            d_u8 = torch.empty((h, w, ncls), dtype=torch.uint8, device=tdev)
-            d_mask = torch.empty((h, w, ncls), dtype=torch.uint8, device=tdev)
-            _lib.check(lib.asep_aru_forward_dev(self.pb_graph.handle(dev, lane), d_gray.data_ptr(), h, w, d_out.data_ptr(),
-                                                d_u8.data_ptr(), d_mask.data_ptr(), float(self.threshold), sp),
-                       "asep_aru_forward_dev")
-            size = h * w
-            min_size = int(size * (1 / size * 100))
-            k_h, k_v, k_c = image_ops.separator_kernel_sizes(h, w)
-            d_hz = torch.empty((h, w), dtype=torch.uint8, device=tdev)
-            d_vt = torch.empty((h, w), dtype=torch.uint8, device=tdev)
-            _lib.check(lib.asep_post_separator_dev(ws, d_mask.data_ptr(), h, w, ncls, 0, min_size, k_h, k_v, k_c,
-                                                   d_hz.data_ptr(), d_vt.data_ptr(), sp), "asep_post_separator_dev")
-            t["masks"] = {"horizontal": d_hz, "vertical": d_vt}
-            if edges_only:
-                # polygon extraction needs only the boundary segments: the masks stay in HBM
-                cap = self.SEGMENT_CAPACITY
-                d_keys = torch.empty((2, 2, cap), dtype=torch.int32, device=tdev)
-                d_tot = torch.empty((2, 2), dtype=torch.int64, device=tdev)
-                for i, d_m in enumerate((d_hz, d_vt)):
-                    _lib.check(lib.asep_post_boundary_segments_enqueue_dev(
-                        ws, d_m.data_ptr(), h, w, 255, d_keys[i, 0].data_ptr(), d_keys[i, 1].data_ptr(), cap,
-                        d_tot[i].data_ptr(), sp), "asep_post_boundary_segments_enqueue_dev")
-                t["h_keys"] = torch.empty((2, 2, cap), dtype=torch.int32, pin_memory=True)
-                t["h_tot"] = torch.empty((2, 2), dtype=torch.int64, pin_memory=True)
-                t["h_tot"].copy_(d_tot, non_blocking=True)
-                t["h_keys"].copy_(d_keys, non_blocking=True)
+            for image in images:
+                image = np.require(image, dtype=np.uint8, requirements=['C', 'W'])   # Pillow hands out read-only views
+                if image.ndim == 2:
+                    image = image[:, :, None]
+                H, W, Cn = image.shape
+                sc = get_scaling_factor(H, W, self.scaling_factor, fixed_height=self.fixed_height)
+                h, w = image_ops.scaled_size(H, W, sc)
+                t = {"sc": sc, "size": (h, w), "edges_only": edges_only, "device": dev}
+                # the upload is queued like everything else (a page is 0.3 ms of PCIe; a copy on a second stream ended up behind the
+                # engine's kernels in a shared hardware queue and made the host wait for them): ``image`` must stay valid until the
+                # page's upload has run -- DecodePool(hold=...) guarantees that for its slots, pageable arrays are staged by the runtime
+                # before the call returns
+                d_img = torch.empty((H, W, Cn), dtype=torch.uint8, device=tdev)
+                d_img.copy_(torch.from_numpy(image), non_blocking=True)
+                t["uploaded"] = torch.cuda.Event()
+                t["uploaded"].record(stream)
+                d_gray = torch.empty((h, w), dtype=torch.float32, device=tdev)
+                _lib.check(lib.asep_prep_scale_gray_dev(ws, d_img.data_ptr(), H, W, Cn, float(sc), None,
+                                                        d_gray.data_ptr(), sp), "asep_prep_scale_gray_dev")
+                d_out = torch.empty((h, w, ncls), dtype=torch.float32, device=tdev)
+                d_u8 = torch.empty((h, w, ncls), dtype=torch.uint8, device=tdev)
+                d_mask = torch.empty((h, w, ncls), dtype=torch.uint8, device=tdev)
+                t["keep"] = (d_img, d_gray, d_out, d_u8, d_mask)          # alive until the page is collected
+                tickets.append(t)
+            n = len(tickets)
+            handle = self.pb_graph.handle(dev, lane)
+            if n == 1:
+                d_img, d_gray, d_out, d_u8, d_mask = tickets[0]["keep"]
+                h, w = tickets[0]["size"]
+                _lib.check(lib.asep_aru_forward_dev(handle, d_gray.data_ptr(), h, w, d_out.data_ptr(), d_u8.data_ptr(), d_mask.data_ptr(),
+                                                    float(self.threshold), sp), "asep_aru_forward_dev")
             else:
-                t["h_masks"] = {k: torch.empty((h, w), dtype=torch.uint8, pin_memory=True) for k in t["masks"]}
-                for k, d_m in t["masks"].items():
-                    t["h_masks"][k].copy_(d_m, non_blocking=True)
-            if self.keep_outputs:
-                t["h_u8"] = torch.empty((h, w, ncls), dtype=torch.uint8, pin_memory=True)
-                t["h_u8"].copy_(d_u8, non_blocking=True)
-            t["done"] = torch.cuda.Event()
-            t["done"].record(stream)
-            t["keep"] = (d_img, d_gray, d_out, d_u8, d_mask)          # alive until the page is collected
-        return t
+                Arr, Ints = C.c_void_p * n, C.c_int32 * n
+                keep = [t["keep"] for t in tickets]
+                _lib.check(lib.asep_aru_forward_batch_dev2(
+                    handle, n, Arr(*[k[1].data_ptr() for k in keep]), Ints(*[t["size"][0] for t in tickets]), Ints(*[t["size"][1] for t in tickets]),
+                    Arr(*[k[2].data_ptr() for k in keep]), Arr(*[k[3].data_ptr() for k in keep]), Arr(*[k[4].data_ptr() for k in keep]),
+                    float(self.threshold), sp), "asep_aru_forward_batch_dev2")
+            for t in tickets:
+                d_img, d_gray, d_out, d_u8, d_mask = t["keep"]
+                h, w = t["size"]
+                size = h * w
+                min_size = int(size * (1 / size * 100))
+                k_h, k_v, k_c = image_ops.separator_kernel_sizes(h, w)
+                d_hz = torch.empty((h, w), dtype=torch.uint8, device=tdev)
+                d_vt = torch.empty((h, w), dtype=torch.uint8, device=tdev)
+                _lib.check(lib.asep_post_separator_dev(ws, d_mask.data_ptr(), h, w, ncls, 0, min_size, k_h, k_v, k_c,
+                                                       d_hz.data_ptr(), d_vt.data_ptr(), sp), "asep_post_separator_dev")
+                t["masks"] = {"horizontal": d_hz, "vertical": d_vt}
+                if edges_only:
+                    # polygon extraction needs only the boundary segments: the masks stay in HBM
+                    cap = self.SEGMENT_CAPACITY
+                    d_keys = torch.empty((2, 2, cap), dtype=torch.int32, device=tdev)
+                    d_tot = torch.empty((2, 2), dtype=torch.int64, device=tdev)
+                    for i, d_m in enumerate((d_hz, d_vt)):
+                        _lib.check(lib.asep_post_boundary_segments_enqueue_dev(
+                            ws, d_m.data_ptr(), h, w, 255, d_keys[i, 0].data_ptr(), d_keys[i, 1].data_ptr(), cap,
+                            d_tot[i].data_ptr(), sp), "asep_post_boundary_segments_enqueue_dev")
+                    t["h_keys"] = torch.empty((2, 2, cap), dtype=torch.int32, pin_memory=True)
+                    t["h_tot"] = torch.empty((2, 2), dtype=torch.int64, pin_memory=True)
+                    t["h_tot"].copy_(d_tot, non_blocking=True)
+                    t["h_keys"].copy_(d_keys, non_blocking=True)
+                else:
+                    t["h_masks"] = {k: torch.empty((h, w), dtype=torch.uint8, pin_memory=True) for k in t["masks"]}
+                    for k, d_m in t["masks"].items():
+                        t["h_masks"][k].copy_(d_m, non_blocking=True)
+                if self.keep_outputs:
+                    t["h_u8"] = torch.empty((h, w, ncls), dtype=torch.uint8, pin_memory=True)
+                    t["h_u8"].copy_(d_u8, non_blocking=True)
+                t["done"] = torch.cuda.Event()
+                t["done"].record(stream)
+        return tickets
 
     def collect_page(self, t):
         """wait for a ticket of :meth:`enqueue_page` -> ({"horizontal", "vertical"}, sc, extras): uint8 [h,w] masks, or with
@@ -254,27 +280,43 @@ class SeparatorNetPostProcessor(RegionNetPostProcessor):
         page_objects = []
         pipelined = self.host_workers > 1 and not self.keep_outputs
         reg, unreg = pin_callbacks(self.device) if pipelined else (None, None)
-        decode = DecodePool(self.image_paths, self.host_workers if pipelined else 0, register=reg, unregister=unreg, hold=2)
+        group = self.PAGE_GROUP if pipelined else 1
+        decode = DecodePool(self.image_paths, self.host_workers if pipelined else 0, register=reg, unregister=unreg, hold=group + 1)
         with WritePool(self.host_workers if pipelined else 0) as writers:
             t_prev = t_run = time.perf_counter()
-            pending, n_enqueued = [], 0
+            pending, n_groups = [], 0
             lanes = self.PAGE_LANES if pipelined else 1
-            for image_path, image in decode:
+            batch = []
+
+            def flush():
+                """the decoded pages waiting in ``batch`` as ONE group on the next lane; a lane's previous group has been collected before"""
+                nonlocal n_groups, t_prev
+                t_dev = time.perf_counter()
+                tickets = self.enqueue_group([img for _, img in batch], edges_only=not self.keep_outputs, lane=n_groups % lanes)
+                n_groups += 1
+                self.device_seconds += time.perf_counter() - t_dev
+                pending.extend((path, t) for (path, _), t in zip(batch, tickets))
+                while len(pending) > max(1, (lanes - 1) * group):    # (the newest group stays in flight while older pages' rings are chained)
+                    self._finish_page(*pending.pop(0), writers, pipelined, page_objects)
+                tickets[-1]["uploaded"].synchronize()        # (long done) the images' slots may be recycled from here on
+                batch.clear()
+                t_prev = time.perf_counter()
+
+            n_paths = len(self.image_paths)
+            for n_seen, (image_path, image) in enumerate(decode, 1):
                 t_dev = time.perf_counter()
                 if self.first_page_seconds is None:          # worker start-up + slot page-locking + the first decode
                     self.first_page_seconds = t_dev - t_run
                 self.wait_seconds += t_dev - t_prev
-                # pipelined: consecutive pages alternate between lanes (streams, model instances, scratch arenas): the chip works
-                # on the next pages' nets while a page's classical stages -- small kernels that do not fill it -- run, and
-                # while this process chains rings.  A lane's previous page has been collected before the lane is used again.
-                ticket = self.enqueue_page(image, edges_only=not self.keep_outputs, lane=n_enqueued % lanes)
-                n_enqueued += 1
-                self.device_seconds += time.perf_counter() - t_dev
-                pending.append((image_path, ticket))
-                if len(pending) >= max(2, lanes):
-                    self._finish_page(*pending.pop(0), writers, pipelined, page_objects)
-                ticket["uploaded"].synchronize()             # (long done) the image's slot may be recycled from here on
-                t_prev = time.perf_counter()
+                # pipelined: PAGE_GROUP consecutive pages per batched net call, consecutive groups on alternating lanes (streams, model
+                # instances, scratch arenas): the chip works on the next group's nets while a group's classical stages -- small kernels that do
+                # not fill it -- run, and while this process chains rings
+                batch.append((image_path, image))
+                if len(batch) >= group or n_seen == n_paths:   # (the last pages are uploaded HERE: the pool releases its slots when it ends)
+                    flush()
+                else:
+                    t_prev = time.perf_counter()
+            assert not batch
             for item in pending:
                 self._finish_page(*item, writers, pipelined, page_objects)
         return page_objects

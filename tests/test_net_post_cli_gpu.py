@@ -378,6 +378,32 @@ def test_pages_in_flight_give_the_masks_of_the_page_by_page_form(tmp_path, monke
                 assert polygonize.shapes_from_segments(starts, ends, size[0], size[1], connectivity=8) == polys[k]
 
 
+def test_a_group_of_pages_of_different_sizes_in_one_net_call_gives_the_masks_of_the_page_by_page_form(tmp_path):
+    """round 6: SeparatorNetPostProcessor.enqueue_group -- the pipelined owner runs PAGE_GROUP decoded pages, whatever their sizes after
+    --fixed_height, through ONE batched net call (asep_aru_forward_batch_dev2) with the classical stages per page behind it: the segments
+    of every page are those of the synchronous page-by-page form"""
+    from citlab_article_separation_new_amd import polygonize, synth
+    from citlab_article_separation_new_amd.separator_net_post_processor import SeparatorNetPostProcessor
+    from citlab_article_separation_new_amd import image_io, net_post_processing_helper as helper
+    from oracle import classical_oracle as co
+    pb, lst, data = _setup(tmp_path)
+    pages = [synth.synth_page(40 + k, W=[500, 610, 380, 540][k], H=[700, 660, 720, 700][k]) for k in range(4)]   # widths differ at height 450
+    _, grey, _ = co.scale_and_gray(image_io.load_image_bgr(str(data / "p0.png")), 450, 1.0)
+    thr = round(float(np.median(helper.get_net_output(grey, helper.load_graph(pb), "0")[:, :, 0])), 3)
+    proc = SeparatorNetPostProcessor([], pb, 450, 1.0, thr, "0")
+    want = []
+    for p in pages:
+        masks, sc, extras = proc.separator_masks(p, edges_only=False)
+        want.append(({k: polygonize.shapes(m, value=255, connectivity=8) for k, m in masks.items()}, sc, extras["size"]))
+    assert len({w[2] for w in want}) >= 3 and any(v for w, _, _ in want for v in w.values())
+    tickets = proc.enqueue_group(pages, edges_only=True, lane=1)
+    for t, (polys, sc, size) in zip(tickets, want):
+        masks, sc2, extras = proc.collect_page(t)
+        assert sc2 == sc and extras["size"] == size
+        for k, (starts, ends) in masks.items():
+            assert polygonize.shapes_from_segments(starts, ends, size[0], size[1], connectivity=8) == polys[k]
+
+
 @pytest.mark.parametrize("dtype", ["f32s", "f32"])
 @pytest.mark.parametrize("color", [False, True])
 def test_heading_pages_in_flight_give_the_measurements_of_the_page_by_page_form(tmp_path, color, dtype, monkeypatch):
