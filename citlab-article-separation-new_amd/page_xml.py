@@ -11,6 +11,7 @@ written back in place, so untouched content of the file survives a round trip.
 """
 import copy
 import datetime
+import io
 import re
 import xml.etree.ElementTree as ET
 
@@ -20,6 +21,28 @@ CREATOR = "CITlab"
 REGION_TYPES = ("TextRegion", "ImageRegion", "LineDrawingRegion", "GraphicRegion", "TableRegion", "ChartRegion",
                 "SeparatorRegion", "MathsRegion", "ChemRegion", "MusicRegion", "AdvertRegion", "NoiseRegion",
                 "UnknownRegion")
+
+
+_SEP_MARK = "AsepSeparatorRegionsHere"
+
+
+def _escape_attrib(text):
+    """xml.etree.ElementTree._escape_attrib"""
+    if "&" in text:
+        text = text.replace("&", "&amp;")
+    if "<" in text:
+        text = text.replace("<", "&lt;")
+    if ">" in text:
+        text = text.replace(">", "&gt;")
+    if "\"" in text:
+        text = text.replace("\"", "&quot;")
+    if "\r" in text:
+        text = text.replace("\r", "&#13;")
+    if "\n" in text:
+        text = text.replace("\n", "&#10;")
+    if "\t" in text:
+        text = text.replace("\t", "&#09;")
+    return text
 
 
 class PageXmlException(Exception):
@@ -221,6 +244,38 @@ class Page:
         if self.page_node is None:
             raise PageXmlException("no <Page> element")
 
+    # The DOM behind two properties: separator regions added by add_separator_region wait as (id, custom, points) records and are spliced into
+    # the serialised text by write_page_xml (a page of the separator command line carries thousands of them: ElementTree nodes cost 13 us each to
+    # build, indent and serialise, a formatted record 1 us).  Anything that READS the DOM goes through `tree` / `page_node` and finds real nodes.
+    @property
+    def tree(self):
+        self._materialize()
+        return self._tree
+
+    @tree.setter
+    def tree(self, value):
+        self._tree = value
+
+    @property
+    def page_node(self):
+        self._materialize()
+        return self._page_node
+
+    @page_node.setter
+    def page_node(self, value):
+        self._page_node = value
+
+    def _materialize(self):
+        pending = self.__dict__.get("_sep_fast")
+        if pending:
+            self._sep_fast = []
+            for rid, custom, points in pending:
+                attrib = {"id": rid}
+                if custom:
+                    attrib["custom"] = custom
+                node = ET.SubElement(self._page_node, self._q("SeparatorRegion"), attrib)
+                ET.SubElement(node, self._q("Coords"), {"points": points})
+
     # -- helpers -------------------------------------------------------------------------------
     def _q(self, tag):
         return "{%s}%s" % (self.ns, tag) if self.ns else tag
@@ -245,11 +300,12 @@ class Page:
 
     # -- queries -------------------------------------------------------------------------------
     def get_image_resolution(self):
-        return int(self.page_node.get("imageWidth")), int(self.page_node.get("imageHeight"))
+        return int(self._page_node.get("imageWidth")), int(self._page_node.get("imageHeight"))
 
     def get_text_regions(self, text_region_type=None):
         """Document order of './/TextRegion' (nested regions included), page.py:479-506."""
-        regs = [TextRegion(n, self) for n in self.page_node.iter(self._q("TextRegion"))]
+        # (readers of text regions / lines do not need the waiting separator records as nodes: `_page_node`)
+        regs = [TextRegion(n, self) for n in self._page_node.iter(self._q("TextRegion"))]
         if text_region_type:
             regs = [r for r in regs if r.region_type == text_region_type]
         return regs
@@ -270,17 +326,25 @@ class Page:
         return out
 
     def get_textlines(self):
-        return [TextLine(n, self) for n in self.page_node.iter(self._q("TextLine"))]
+        return [TextLine(n, self) for n in self._page_node.iter(self._q("TextLine"))]
 
     def get_ids(self):
-        return {n.get("id") for n in self.tree.getroot().iter() if n.get("id")}
+        return {n.get("id") for n in self._tree.getroot().iter() if n.get("id")} | {r[0] for r in self.__dict__.get("_sep_fast") or ()}
 
     def get_unique_id(self, page_object_name, ids=None):
         """page.py:464-477: smallest free '<name>_<n>', n >= 1 (the reference gives up after n = 1000)."""
-        ids = self.get_ids() if ids is None else ids
-        i = 1
+        if ids is None:
+            ids = self.get_ids()
+            i = 1
+        else:
+            # a caller's id set only grows (add_separator_region): the smallest free number never decreases, so the search resumes where
+            # the last one ended -- a page with thousands of separator regions paid a quadratic walk here (round 6)
+            hints = self.__dict__.setdefault("_id_hints", {})
+            i = hints.get((page_object_name, id(ids)), 1)
         while f"{page_object_name}_{i}" in ids:
             i += 1
+        if "_id_hints" in self.__dict__ and ids is not None and (page_object_name, id(ids)) in self._id_hints or ids is getattr(self, "_sep_ids", None):
+            self.__dict__.setdefault("_id_hints", {})[(page_object_name, id(ids))] = i
         return f"{page_object_name}_{i}"
 
     # -- modification --------------------------------------------------------------------------
@@ -298,29 +362,59 @@ class Page:
         for n in list(self.page_node.iter(self._q(region_type))):
             parents[n].remove(n)
         self._sep_ids = None
+        self.__dict__.pop("_id_hints", None)
 
     def add_separator_region(self, points, orientation):
-        """separator_region_to_page_writer.py:340-358: id 'SeparatorRegion_<n>', custom structure {orientation:...}."""
+        """separator_region_to_page_writer.py:340-358: id 'SeparatorRegion_<n>' (the smallest free n), custom structure {orientation:...}.
+        The region waits as a record (see `tree`); its id is final."""
         if getattr(self, "_sep_ids", None) is None:
             self._sep_ids = self.get_ids()               # one DOM walk per batch of additions
-        rid = self.get_unique_id("SeparatorRegion", self._sep_ids)
-        self._sep_ids.add(rid)
-        attrib = {"id": rid}
-        if orientation:
-            attrib["custom"] = format_custom_attr({"structure": {"orientation": orientation}})
-        node = ET.SubElement(self.page_node, self._q("SeparatorRegion"), attrib)
-        ET.SubElement(node, self._q("Coords"), {"points": format_points(points)})
+            self._sep_next = 1
+        ids, n = self._sep_ids, self._sep_next
+        while f"SeparatorRegion_{n}" in ids:             # (ids only grow: the smallest free number never decreases)
+            n += 1
+        rid = f"SeparatorRegion_{n}"
+        ids.add(rid)
+        self._sep_next = n + 1
+        cache = self.__dict__.setdefault("_sep_custom", {})
+        if orientation not in cache:
+            cache[orientation] = format_custom_attr({"structure": {"orientation": orientation}}) if orientation else None
+        self.__dict__.setdefault("_sep_fast", []).append((rid, cache[orientation], format_points(points)))
         return rid
 
     def write_page_xml(self, save_path, creator=CREATOR, comments=None):
-        md = self.tree.getroot().find(self._q("Metadata"))
+        pending = self.__dict__.get("_sep_fast") or []
+        tree, page_node = self._tree, self._page_node        # (not the properties: the waiting records are spliced in as text below)
+        md = tree.getroot().find(self._q("Metadata"))
         if md is not None:
             lc = md.find(self._q("LastChange"))
             if lc is None:
                 lc = ET.SubElement(md, self._q("LastChange"))
             lc.text = datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%M:%S")
+        mark = ET.SubElement(page_node, self._q(_SEP_MARK)) if pending else None
         try:
-            ET.indent(self.tree, space="  ")
-        except AttributeError:  # pragma: no cover (python < 3.9)
-            pass
-        self.tree.write(save_path, encoding="UTF-8", xml_declaration=True)
+            try:
+                ET.indent(tree, space="  ")
+            except AttributeError:  # pragma: no cover (python < 3.9)
+                pass
+            if not pending:
+                tree.write(save_path, encoding="UTF-8", xml_declaration=True)
+                return
+            buf = io.BytesIO()
+            tree.write(buf, encoding="UTF-8", xml_declaration=True)
+        finally:
+            if mark is not None:
+                page_node.remove(mark)
+        # the records exactly as ElementTree would have written their nodes (children of <Page>: four spaces, their <Coords>: six)
+        esc = _escape_attrib
+        block = "".join(
+            f'    <SeparatorRegion id="{esc(rid)}"' + (f' custom="{esc(custom)}"' if custom else "") +
+            f'>\n      <Coords points="{esc(points)}" />\n    </SeparatorRegion>\n' for rid, custom, points in pending).encode("utf-8")
+        text = buf.getvalue()
+        needle = ("    <%s />\n" % _SEP_MARK).encode("utf-8")
+        if text.count(needle) != 1:                          # (a namespace prefix, a missing indent: write it the slow way)
+            self._materialize()
+            self._tree.write(save_path, encoding="UTF-8", xml_declaration=True)
+            return
+        with open(save_path, "wb") as f:
+            f.write(text.replace(needle, block, 1))

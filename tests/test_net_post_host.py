@@ -265,3 +265,52 @@ def test_line_box_arithmetic_equals_the_per_point_form():
                 ys0, ys1, _ = slice(ya, ya + height).indices(h)
                 xs0, xs1, _ = slice(xa, xa + width).indices(w)
                 assert (xs0, max(xs0, xs1), ys0, max(ys0, ys1)) == (x0[i], x1[i], y0[i], y1[i])
+
+
+def test_separator_regions_written_as_records_give_the_bytes_of_the_element_tree_writer(tmp_path):
+    """round 6: add_separator_region keeps the regions as (id, custom, points) records and write_page_xml splices them
+    into the serialised text -- byte for byte what ElementTree writes for real nodes, on an empty page, behind text regions, with and without
+    orientation, after ids that are already taken; a reader of the DOM in between finds real nodes"""
+    from citlab_article_separation_new_amd import page_xml
+    rng = np.random.default_rng(3)
+
+    def build(fast, with_text, taken):
+        if with_text:
+            src = tmp_path / "in.xml"
+            src.write_text('<?xml version="1.0" encoding="UTF-8"?>\n<PcGts xmlns="http://schema.primaresearch.org/PAGE/gts/pagecontent/2013-07-15">'
+                           '<Metadata><Creator>x</Creator><Created>2020-01-01T00:00:00</Created><LastChange>2020-01-01T00:00:00</LastChange></Metadata>'
+                           '<Page imageFilename="a.png" imageWidth="300" imageHeight="400"><TextRegion id="r1"><Coords points="1,2 30,2 30,40 1,40"/>'
+                           '<TextLine id="l1"><Coords points="1,2 30,2 30,10 1,10"/><Baseline points="1,9 30,9"/><TextEquiv><Unicode>a &amp; b</Unicode></TextEquiv>'
+                           '</TextLine></TextRegion>' + ('<SeparatorRegion id="SeparatorRegion_2"><Coords points="5,5 6,6 7,7"/></SeparatorRegion>' if taken else '')
+                           + '</Page></PcGts>')
+            page = page_xml.Page(str(src))
+        else:
+            page = page_xml.Page(creator_name="t", img_filename="a.png", img_w=300, img_h=400)
+        r = np.random.default_rng(5)
+        ids = []
+        for k in range(40):
+            pts = [(int(a), int(b)) for a, b in r.integers(0, 300, (int(r.integers(3, 7)), 2))]
+            ids.append(page.add_separator_region(pts, [None, "horizontal", "vertical"][k % 3]))
+        if not fast:
+            page._materialize()                              # real ElementTree nodes: the writer's plain path
+            assert not page.__dict__.get("_sep_fast")
+        out = tmp_path / ("fast.xml" if fast else "slow.xml")
+        page.write_page_xml(str(out))
+        data = re.sub(rb"<LastChange>[^<]*</LastChange>", b"", out.read_bytes())
+        data = re.sub(rb"<Created>[^<]*</Created>", b"", data)
+        return data, ids, page
+    import re
+    for with_text in (False, True):
+        for taken in ((False, True) if with_text else (False,)):
+            fast, ids_f, page = build(True, with_text, taken)
+            slow, ids_s, _ = build(False, with_text, taken)
+            assert fast == slow and ids_f == ids_s and fast.count(b"<SeparatorRegion ") == 40 + (1 if taken else 0)
+            assert ("SeparatorRegion_2" not in ids_f) == taken and ids_f[0] == "SeparatorRegion_1"
+            # a second write gives the same file; reading the DOM afterwards finds the regions as nodes, and a third write still agrees
+            again = tmp_path / "again.xml"
+            page.write_page_xml(str(again))
+            strip = lambda b: re.sub(rb"<Created>[^<]*</Created>", b"", re.sub(rb"<LastChange>[^<]*</LastChange>", b"", b))
+            assert strip(again.read_bytes()) == fast
+            assert len(page.get_regions()["SeparatorRegion"]) == 40 + (1 if taken else 0)
+            page.write_page_xml(str(again))
+            assert strip(again.read_bytes()) == fast
