@@ -996,6 +996,11 @@ def main():
 
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary and not args.no_gnn:
+        # the secondary figures start GPU processes of this one's size (plain fp32 step: 96 GB of arenas): this process gives its arenas back first
+        # (the model stays loaded; the agreement check below rebuilds what it needs)
+        torch.cuda.synchronize()
+        for h in [h_aru] + ([h_bb] if h_bb else []):
+            _lib.check(lib.asep_aru_trim(h), "asep_aru_trim")
         secondary = secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, (gnn, vpages, vh, vw, VP) if visual else None)
 
     # --gpus N: the files-in / files-out path with N GPU owners, as a child of rank 0 (the other ranks wait at the final barrier; their

@@ -61,6 +61,7 @@ SIGNATURES = {
     "asep_aru_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_float]),
     "asep_aru_forward_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_float, _P]),
     "asep_aru_forward_batch_dev": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, C.c_float, _P]),
+    "asep_aru_trim": (C.c_int, [_P]),
     "asep_aru_forward_batch_dev2": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_float, _P]),
     "asep_aru_get_endpoint": (C.c_long, [_P, C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_int32)]),
     "asep_aru_profile": (C.c_int, [_P, C.c_int]),

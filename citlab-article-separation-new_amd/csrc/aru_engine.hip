@@ -127,6 +127,7 @@ struct asep_aru {
     };
     std::vector<std::unique_ptr<Lane>> lanes;
     Lane* cur = nullptr;
+    int last_nl = 0;                     // lanes of the previous call: a call with another count releases every lane's arena first (below)
     bool lanes_forced = false;           // ASEP_LANES given: split any batch of >= 2 pages
     int num_lanes = 2;                   // page lanes of a batch call (ASEP_LANES overrides).  Two lanes since round 6: two independent chains fill each other's launch
                                          // tails (r4j: 1 / 2 / 3 / 4 lanes = 119.3 / 121.2 / 120.3 / 115.8 pages/s fp32; round 5: 1 / 2 / 3 = 467 / 477 / 478 bf16, 137.6 / 139.8
@@ -2371,6 +2372,15 @@ static int forward_lanes(asep_aru* m, int n_pages, const float* const* d_imgs, c
     const int nl = (m->profiling || n_pages < 2) ? 1 : std::max(1, std::min<int>((int)m->lanes.size(), by_pages));
     asep_aru::Lane& L0 = *m->lanes[0];
     L0.s = stream;
+    // A lane's arena keeps the buffers of the largest call it has served.  When the number of lanes of a call changes (16 pages on two lanes, then
+    // the same 16 pages on one lane while launch times are recorded) the arenas would add up to 1.5 x the pages in flight -- 144 GB instead of 96 for
+    // 16 fp32 pages, and a second process of the same size beside it no longer fits into 288 GB (round 6: the children of the default bench line
+    // ran out of memory).  A change of the lane count therefore releases every arena first (hipFree waits for the device: nothing is in use).
+    if (nl != m->last_nl && n_pages > 1) {
+        if (m->last_nl != 0)
+            for (auto& Lp : m->lanes) Lp->pool.release();
+        m->last_nl = nl;
+    }
     if (nl == 1) return forward_impl(m, L0, 0, n_pages, d_imgs, Hs, Ws, d_outs, d_u8, d_mask, threshold);
     ASEP_HIP_CHECK(hipEventRecord(L0.ev_begin, stream));
     int page0 = 0;
@@ -2497,6 +2507,20 @@ long asep_aru_get_endpoint(asep_aru* m, const char* name, float* out, size_t max
     }
     ASEP_HIP_CHECK(hipMemcpy(out, t.p, t.count() * sizeof(float), hipMemcpyDeviceToHost));
     return (long)t.count();
+    ASEP_GUARD_END
+}
+
+// ABI 6: give the handle's device arenas back (they are rebuilt by the next forward call): a process that holds a model and starts another
+// GPU process of its size beside it calls this first
+int asep_aru_trim(asep_aru* m) {
+    ASEP_GUARD_BEGIN
+    if (!m) { set_error("asep_aru_trim: null handle"); return ASEP_ERR_ARG; }
+    ASEP_HIP_CHECK(hipDeviceSynchronize());
+    m->endpoints.clear();
+    for (auto& Lp : m->lanes) Lp->pool.release();
+    m->host_stage.release();
+    m->last_nl = 0;
+    return ASEP_OK;
     ASEP_GUARD_END
 }
 

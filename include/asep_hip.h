@@ -125,6 +125,10 @@ int asep_aru_forward_batch_dev2(asep_aru* m, int n_pages, const float* const* d_
  * Returns the number of floats written, or a negative error; dims receives {H, W, C}. */
 long asep_aru_get_endpoint(asep_aru* m, const char* name, float* out, size_t max_floats, int32_t dims[3]);
 
+/* ABI 6: release the handle's device arenas (intermediate tensors of the largest call served so far: ~6 GB per 3000 x 4500 fp32 page in flight);
+ * the next forward call rebuilds them.  For a process that keeps a model loaded while another GPU process of its size runs beside it. */
+int asep_aru_trim(asep_aru* m);
+
 /* Per-launch timing with HIP events recorded on the launch stream (measurement aid for bench.py).
  * asep_aru_profile(m,1) clears the records and starts recording; (m,0) stops.  Mode 1 serialises the net on the
  * launch stream (isolated kernel times), mode 2 additionally names every layer, mode 3 keeps the attention side
