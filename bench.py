@@ -210,8 +210,8 @@ def run_cpu_baseline_full(args):
 # The fused level-0 residual blocks are ONE design instantiated for the two directions of the U (down: image in, pool out; up: the
 # concatenation [skip, deconv] in): they are ranked and reported as one entry, "a+b" (under the isolated
 # ranking the up block led, under rocprofv3's the down block, and the line printed the figure of whichever it had picked).
-LEVEL0_FAMILIES = (("res8v_down_kernel", "res8v_up_kernel"), ("res8_down_kernel", "res8_up_kernel"), ("res8f_kernel<false>", "res8f_kernel<true>"),
-                   ("res8b_kernel<false>", "res8b_kernel<true>"))
+LEVEL0_FAMILIES = (("res8v_down_kernel", "res8v_up_kernel"), ("res8_down_kernel", "res8_up_kernel"), ("res8w_kernel<false>", "res8w_kernel<true>"),
+                   ("res8f_kernel<false>", "res8f_kernel<true>"), ("res8b_kernel<false>", "res8b_kernel<true>"))
 
 
 def family_members(kernel, names):
@@ -608,7 +608,7 @@ def secondary_measurements(args, lib, dev, imgs, pages_u8, graphs, visual_pages)
 
 # every kernel of csrc/bf16_kernels.h that multiplies on v_mfma_f32_16x16x32_bf16 (tests/test_bench_host.py holds this list against the
 # __global__ functions of that header: a new kernel that is missing here would be priced against the fp32 peak, 16 x too kind -- ADVICE r5)
-BF16_MFMA_KERNELS = ("convb_kernel", "deconvb_kernel", "deconvb8_kernel", "res8f_kernel", "res8b_kernel", "res16f_kernel", "res32_tail_kernel",
+BF16_MFMA_KERNELS = ("convb_kernel", "deconvb_kernel", "deconvb8_kernel", "res8f_kernel", "res8b_kernel", "res8w_kernel", "res8wb_kernel", "res16f_kernel", "res32_tail_kernel",
                      "resb_tail_kernel", "att_headb_kernel")
 # `roofline.bound` names the pipe the dominant kernel is priced against
 BOUND_OF_PIPE = {"bf16 MFMA": "mfma_bf16", "fp32 MFMA": "mfma_fp32"}

@@ -14,6 +14,11 @@ cd /tmp && export TMPDIR=/tmp
 # --kernel-timing in-situ: every launch of the traced process runs in the real schedule (side stream + relation nets), so
 # rocprofv3's AverageNs and the line's HIP-event averages describe the same launches (scripts/roofline_from_profiles.py)
 # 1 warm-up + 1 plain step, then 10 event-timed steps: 10 of the 12 steps rocprofv3 averages over are the ones the events bracket
+# ASEP_LANES=1 (round 6): the product splits calls of >= 8 pages over two page lanes, and two launches of a kernel that share the chip take about twice as
+# long each; a handle that records launch times runs on one lane anyway, but the warm-up and the plain step of this command would not -- with them on two
+# lanes rocprofv3's AverageNs sat 5-20 % above the HIP-event averages of the same run (profiles/r6final first cut).  The whole traced process on one lane:
+# both sources describe the same launches.  (The un-traced default lines, bench_first.json / bench.json, run the product's default.)
+export ASEP_LANES=1
 BENCH="python3 $R/bench.py --steps 1 --warmup 1 --event-steps 10 --no-cpu-baseline --no-secondary --kernel-timing in-situ $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > /dev/null 2> $OUT/pmc_fetch.log
