@@ -126,8 +126,10 @@ def compare(line, rec, tol):
     # launches are queued between them) is inside the HIP-event figure and outside rocprofv3's: the fields that divide by the launch
     # time get 6 % there (profiles/r4b: 518.5 us by events against 492.0 us by rocprofv3 for 864 launches), everything else keeps `tol`
     timed = {"avg_launch_us", "achieved", "frac", "mfma_achieved", "mfma_frac", "hbm_tb_per_s", "hbm_frac"}
+    # (a launch of ~80 us -- the bf16 line's deep-level convolutions, round 6 -- pays the same ~5 us of event records: 8 % below 150 us)
     short = pairs["avg_launch_us"] < 1000.0
-    ok = all(d is not None and abs(d) <= (max(tol, 0.06) if short and f in timed else tol) for f, d in dev.items())
+    short_tol = 0.08 if pairs["avg_launch_us"] < 150.0 else 0.06
+    ok = all(d is not None and abs(d) <= (max(tol, short_tol) if short and f in timed else tol) for f, d in dev.items())
     return pairs, dev, ok
 
 

@@ -145,7 +145,7 @@ def test_dominant_kernel_is_ranked_in_situ_and_the_traffic_label_names_a_tracked
                                 True, 16, 4500, 3000)
     assert r["bound"] == "valu_fp32" and r["frac_in_situ"] < r["frac_isolated"] and [m["kernel"] for m in d["members"]] == top[0]["members"]
     assert r["traffic"] is not None and d["members"][0]["frac"] < d["members"][1]["frac"]        # the down block is the one the side stream slows
-    for dtype, name in (("f32s", "res8v_up_kernel<0>"), ("bf16", "res8f_kernel<true>"), ("f32", "conv_wino_kernel<4,false>")):
+    for dtype, name in (("f32s", "res8v_up_kernel<0>"), ("bf16", "res8w_kernel<true>"), ("f32", "conv_wino_kernel<4,false>")):
         args = types.SimpleNamespace(dtype=dtype, no_gnn=False, gnn="visual")
         dom = _kernel(name, 18, 1000.0, 282.9e9, 2.3575e9)
         dom["pipe"], dom["pipe_peak"] = bench.pipe_of(name, dtype)
