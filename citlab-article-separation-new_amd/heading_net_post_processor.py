@@ -317,59 +317,83 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
             streams[(tdev.index, lane)] = torch.cuda.Stream(tdev)
         return streams[(tdev.index, lane)]
 
+    PAGE_GROUP = 4                     # pages per batched net call of the pipelined run() (asep_aru_forward_batch_dev2: any sizes)
+
     def enqueue_page(self, image, lane=0):
-        """Queue the device stages of one decoded page (``image`` stays valid until the ticket is collected) -- upload, resize + gray + heading
-        net with uint8 epilogue (:285-288), full-size gray + stroke-width distance transform (swt_dist_trafo.py:18-29) --
-        and return a ticket for :meth:`collect_page`.  Neither the net output nor the distance transform leaves HBM."""
+        """One page = a group of one (see :meth:`enqueue_group`)."""
+        return self.enqueue_group([image], lane=lane)[0]
+
+    def enqueue_group(self, images, lane=0):
+        """Queue the device stages of up to PAGE_GROUP decoded pages of any sizes (``images`` stay valid until their uploads have run) -- uploads,
+        resize + gray per page, ONE batched heading-net call for the group with uint8 epilogue (:285-288; round 6: the pages share every layer's
+        launches), then per page full-size gray + stroke-width distance transform (swt_dist_trafo.py:18-29) -- and return the tickets for
+        :meth:`collect_page`.  Neither the net output nor the distance transform leaves HBM."""
         import torch
         dev = self.device
         lib = _lib.init_device(dev)
         tdev = torch.device("cuda", dev)
-        image = np.require(image, dtype=np.uint8, requirements=['C', 'W'])   # Pillow hands out read-only views
-        if image.ndim == 2:
-            image = image[:, :, None]
-        H, W, Cn = image.shape
-        sc = get_scaling_factor(H, W, self.scaling_factor, fixed_height=self.fixed_height)
-        h, w = image_ops.scaled_size(H, W, sc)
         ncls = self.pb_graph.cfg.n_classes
         _, ws = image_ops._workspace(dev, 0 if lane == 0 else 10 + lane)     # (arena 1 belongs to collect_boxes' side stream)
-        t = {"sc": sc, "size": (h, w, ncls), "device": dev}
+        tickets = []
         with torch.cuda.device(tdev), torch.cuda.stream(self._lane_stream(tdev, lane)):
             stream = torch.cuda.current_stream(tdev)
             sp = C.c_void_p(stream.cuda_stream)
             if getattr(self, "_side_stream", None) is None or self._side_stream.device != tdev:
                 self._side_stream = torch.cuda.Stream(tdev)
-            # the upload is queued like everything else (a page is 0.3 ms of PCIe; a copy on a second stream ended up behind the
-            # engine's kernels in a shared hardware queue and made the host wait for them): ``image`` must stay valid until the
-            # page is collected -- DecodePool(hold=2) guarantees that for its slots, pageable arrays are staged by the runtime
-            # before the call returns
-            d_img = torch.empty((H, W, Cn), dtype=torch.uint8, device=tdev)
-            d_img.copy_(torch.from_numpy(image), non_blocking=True)
-            t["uploaded"] = torch.cuda.Event()
-            t["uploaded"].record(stream)
-            if self.weight_dict['net'] > 0:
-                d_gray = torch.empty((h, w), dtype=torch.float32, device=tdev)
-                _lib.check(lib.asep_prep_scale_gray_dev(ws, d_img.data_ptr(), H, W, Cn, float(sc), None,
-                                                        d_gray.data_ptr(), sp), "asep_prep_scale_gray_dev")
-                d_out = torch.empty((h, w, ncls), dtype=torch.float32, device=tdev)
-                d_u8 = torch.empty((h, w, ncls), dtype=torch.uint8, device=tdev)
-                _lib.check(lib.asep_aru_forward_dev(self.pb_graph.handle(dev, lane), d_gray.data_ptr(), h, w, d_out.data_ptr(),
-                                                    d_u8.data_ptr(), None, 0.0, sp), "asep_aru_forward_dev")
-                t["d_u8"] = d_u8
-                t["keep"] = (d_gray, d_out)
-            if Cn == 1:
-                d_g8 = d_img
-            else:
-                d_g8 = torch.empty((H, W), dtype=torch.uint8, device=tdev)
-                _lib.check(lib.asep_prep_gray_u8_dev(ws, d_img.data_ptr(), H, W, d_g8.data_ptr(), sp), "asep_prep_gray_u8_dev")
-            d_swt = torch.empty((H, W), dtype=torch.uint8, device=tdev)
-            _lib.check(lib.asep_swt_distance_transform_dev(ws, d_g8.data_ptr(), H, W, d_swt.data_ptr(), sp),
-                       "asep_swt_distance_transform_dev")
-            t["swt"] = image_ops.DeviceImage(d_swt, dev)
-            t["inputs"] = (d_img, d_g8)
-            t["done"] = torch.cuda.Event()
-            t["done"].record(stream)
-        return t
+            use_net = self.weight_dict['net'] > 0
+            for image in images:
+                image = np.require(image, dtype=np.uint8, requirements=['C', 'W'])   # Pillow hands out read-only views
+                if image.ndim == 2:
+                    image = image[:, :, None]
+                H, W, Cn = image.shape
+                sc = get_scaling_factor(H, W, self.scaling_factor, fixed_height=self.fixed_height)
+                h, w = image_ops.scaled_size(H, W, sc)
+                t = {"sc": sc, "size": (h, w, ncls), "device": dev, "full": (H, W, Cn)}
+                # the upload is queued like everything else (a page is 0.3 ms of PCIe; a copy on a second stream ended up behind the
+                # engine's kernels in a shared hardware queue and made the host wait for them): ``image`` must stay valid until its
+                # upload has run -- DecodePool(hold=...) guarantees that for its slots, pageable arrays are staged by the runtime
+                # before the call returns
+                d_img = torch.empty((H, W, Cn), dtype=torch.uint8, device=tdev)
+                d_img.copy_(torch.from_numpy(image), non_blocking=True)
+                t["uploaded"] = torch.cuda.Event()
+                t["uploaded"].record(stream)
+                t["d_img"] = d_img
+                if use_net:
+                    d_gray = torch.empty((h, w), dtype=torch.float32, device=tdev)
+                    _lib.check(lib.asep_prep_scale_gray_dev(ws, d_img.data_ptr(), H, W, Cn, float(sc), None,
+                                                            d_gray.data_ptr(), sp), "asep_prep_scale_gray_dev")
+                    t["d_u8"] = torch.empty((h, w, ncls), dtype=torch.uint8, device=tdev)
+                    t["keep"] = (d_gray, torch.empty((h, w, ncls), dtype=torch.float32, device=tdev))
+                tickets.append(t)
+            if use_net:
+                n = len(tickets)
+                handle = self.pb_graph.handle(dev, lane)
+                if n == 1:
+                    t = tickets[0]
+                    _lib.check(lib.asep_aru_forward_dev(handle, t["keep"][0].data_ptr(), t["size"][0], t["size"][1], t["keep"][1].data_ptr(),
+                                                        t["d_u8"].data_ptr(), None, 0.0, sp), "asep_aru_forward_dev")
+                else:
+                    Arr, Ints = C.c_void_p * n, C.c_int32 * n
+                    _lib.check(lib.asep_aru_forward_batch_dev2(
+                        handle, n, Arr(*[t["keep"][0].data_ptr() for t in tickets]), Ints(*[t["size"][0] for t in tickets]),
+                        Ints(*[t["size"][1] for t in tickets]), Arr(*[t["keep"][1].data_ptr() for t in tickets]),
+                        Arr(*[t["d_u8"].data_ptr() for t in tickets]), None, 0.0, sp), "asep_aru_forward_batch_dev2")
+            for t in tickets:
+                H, W, Cn = t.pop("full")
+                d_img = t.pop("d_img")
+                if Cn == 1:
+                    d_g8 = d_img
+                else:
+                    d_g8 = torch.empty((H, W), dtype=torch.uint8, device=tdev)
+                    _lib.check(lib.asep_prep_gray_u8_dev(ws, d_img.data_ptr(), H, W, d_g8.data_ptr(), sp), "asep_prep_gray_u8_dev")
+                d_swt = torch.empty((H, W), dtype=torch.uint8, device=tdev)
+                _lib.check(lib.asep_swt_distance_transform_dev(ws, d_g8.data_ptr(), H, W, d_swt.data_ptr(), sp),
+                           "asep_swt_distance_transform_dev")
+                t["swt"] = image_ops.DeviceImage(d_swt, dev)
+                t["inputs"] = (d_img, d_g8)
+                t["done"] = torch.cuda.Event()
+                t["done"].record(stream)
+        return tickets
 
     def collect_page(self, t, text_lines):
         """:meth:`collect_boxes` for text-line objects (``id``, ``surr_p``)"""
@@ -456,17 +480,24 @@ class HeadingNetPostProcessor(RegionNetPostProcessor):
                     writers.submit(write_heading_page, page_path, image_path, self.fixed_height, self.scaling_factor,
                                    list(values), self.weight_dict, self.threshold, self.thresh_dict, self.text_line_percentage)
 
-                ahead_pages = 2                               # pages queued behind the one whose lines are being measured
-                for image_path, image in DecodePool(self.image_paths, n_workers, register=reg, unregister=unreg,
-                                                    hold=ahead_pages + 1):
+                group = self.PAGE_GROUP if pipelined else 1
+                keep = max(2, (self.PAGE_LANES - 1) * group)  # pages queued behind the one whose lines are being measured
+                batch, n_groups, n_paths = [], 0, len(self.image_paths)
+                for n_seen, (image_path, image) in enumerate(DecodePool(self.image_paths, n_workers, register=reg, unregister=unreg,
+                                                                         hold=group + 1 if pipelined else 3), 1):
                     if pipelined:
-                        # behind the GPU: the next pages are uploaded and queued before a page's lines are measured (the
-                        # measuring calls wait for their small kernels; the chip has the next nets to work on meanwhile).  An image
-                        # stays valid for ahead_pages + 1 iterations, i.e. until its own page has been collected.
-                        pending.append((image_path, self.enqueue_page(image, lane=n_enqueued % self.PAGE_LANES)))
-                        n_enqueued += 1
-                        if len(pending) > ahead_pages:
-                            finish(*pending.pop(0))
+                        # behind the GPU: PAGE_GROUP decoded pages go through ONE batched net call, consecutive groups on alternating lanes; the next
+                        # group is uploaded and queued before a page's lines are measured (the measuring calls wait for their small kernels; the chip
+                        # has the next nets to work on meanwhile).  The last pages are uploaded HERE: the pool releases its slots when it ends.
+                        batch.append((image_path, image))
+                        if len(batch) >= group or n_seen == n_paths:
+                            tickets = self.enqueue_group([img for _, img in batch], lane=n_groups % self.PAGE_LANES)
+                            n_groups += 1
+                            pending.extend((pth, t) for (pth, _), t in zip(batch, tickets))
+                            while len(pending) > keep:
+                                finish(*pending.pop(0))
+                            tickets[-1]["uploaded"].synchronize()    # the images' slots may be recycled from here on
+                            batch.clear()
                         continue
                     if self.weight_dict['net'] > 0:
                         net_output = self.heading_probability(image)

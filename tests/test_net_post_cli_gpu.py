@@ -487,3 +487,23 @@ def test_unreadable_scan_in_a_pipelined_run_raises_instead_of_hanging(tmp_path, 
     with pytest.raises(IOError, match="e3.png"):
         cli.main(["--path_to_image_list", str(lst), "--path_to_pb", pb, "--mode", mode, "--fixed_height", "300",
                   "--num_processes", "4"])
+
+
+@pytest.mark.parametrize("color", [False, True])
+def test_a_group_of_heading_pages_of_different_sizes_gives_the_measurements_of_the_single_pages(tmp_path, color):
+    """round 6: HeadingNetPostProcessor.enqueue_group -- PAGE_GROUP decoded pages of whatever sizes through ONE batched net call
+    (asep_aru_forward_batch_dev2), gray conversion + distance transform per page behind it: every line's three measurements equal those of the
+    single-page form exactly"""
+    from citlab_article_separation_new_amd import image_io
+    from citlab_article_separation_new_amd.heading_net_post_processor import HeadingNetPostProcessor, LineGeometry
+    pb, lst, data = _setup(tmp_path, color=color)
+    base = image_io.load_image_bgr(str(data / "p0.png"))
+    pages = [base, np.ascontiguousarray(base[:700, :500]), np.ascontiguousarray(base[::-1]), np.ascontiguousarray(base[100:, 40:])]
+    lines = [LineGeometry(f"l{i}", [(x0, y0), (x1, y0), (x1, y1), (x0, y1)])
+             for i, (x0, y0, x1, y1) in enumerate([(60, 70 + 60 * k, 300, 110 + 60 * k) for k in range(6)] + [(320, 80, 460, 170), (0, 0, 30, 12)])]
+    lines.append(LineGeometry("none", []))
+    hp = HeadingNetPostProcessor([], pb, 450, 1.0, weight_dict={"net": 0.8, "stroke_width": 0.0, "text_height": 0.2})
+    hp.gpu_devices = "0"
+    want = [hp.collect_page(hp.enqueue_page(p), lines) for p in pages]
+    got = [hp.collect_page(t, lines) for t in hp.enqueue_group(pages, lane=1)]
+    assert got == want and any(v > 0 for v in want[0][2].values())
