@@ -10,6 +10,7 @@
 #include "res8v_kernels.h"
 #include "bf16_kernels.h"
 #include "res8w_kernels.h"
+#include "convr_kernels.h"
 #include "split_kernels.h"
 #include "asep_common.h"
 
@@ -76,6 +77,8 @@ struct asep_aru {
     float* d_r8b_down_w1r = nullptr; // the same filter [9][8] as fp32 values rounded to bfloat16 (border tiles, res8b_tile)
     bool use_res32 = true;           // ASEP_BF_RES32=0: the 32-channel residual tails layer by layer (convb_kernel)
     int walk_mode = 1;               // ASEP_BF_WALK: 1 both level-0 blocks on the walkers (default), 2 the UP block only, 0 neither
+    bool use_convr = true;           // ASEP_BF_CONVR=0: the 64 -> 64 layers on convb_kernel instead of the register-resident form (convr_kernels.h)
+    unsigned char* d_zero_trash = nullptr;   // 16 zero bytes (padding source of convr_kernel) + 4 KB behind them that nobody reads (its dump)
     bool use_walk = true;            // ASEP_BF_WALK=0: the level-0 blocks as 16 x 32 tiles (res8f_kernel) instead of the column-strip walkers (res8w_kernels.h)
     bf16_t* d_r8b_up_w = nullptr;    // [3][3][64][8]
     float* d_r8b_up_b = nullptr;     // [3][8]
@@ -1489,6 +1492,40 @@ Tensor new_tensor_bf(asep_aru* m, int H, int W, int C) {
         hipLaunchKernelGGL((convb_kernel<KH_, KW_, MODE_, MT_, WM_, TH_, MB_, true, 4>), grid, dim3(256), 0, m->stream, a); \
     } while (0)
 
+// the 64 -> 64 3x3 layers with the filter in registers (convr_kernels.h): one wave per SIMD, a wave = the pipeline of a 32-column strip
+TL run_convr(asep_aru* m, const std::string& scope, const PackedConv& pc, const TL& in0, bool relu_in, bool relu_out) {
+    TL out;
+    for (const Tensor& t : in0) out.push_back(new_tensor_bf(m, t.H, t.W, 64));
+    for (size_t b0 = 0; b0 < in0.size(); b0 += MAXP) {
+        const size_t b1 = std::min(in0.size(), b0 + MAXP);
+        ConvRArgs a{};
+        int total = 0;
+        double flops = 0, bytes = 9.0 * 64 * 64 * 2.0;
+        for (size_t i = b0; i < b1; ++i) {
+            bytes += tbytes(in0[i]) + tbytes(out[i]);
+            ConvRProb& p = a.p[i - b0];
+            p.in = in0[i].bp(); p.res = nullptr; p.out = out[i].bp();
+            p.H = in0[i].H; p.W = in0[i].W; p.strips = cdiv(in0[i].W, 32); p.begin = total;
+            total += p.strips * p.H;
+            flops += 2.0 * in0[i].H * in0[i].W * 9.0 * 64.0 * 64.0;
+        }
+        a.nprob = (int)(b1 - b0); a.total = total;
+        a.wpk = (const u32x4*)pc.d_wb; a.bias = pc.d_b;
+        a.zero = m->d_zero_trash; a.trash = m->d_zero_trash + 1024;
+        // one wave per SIMD; a wave's range = total / waves rows (never fewer than 8: a range starts with three rows of latency)
+        const int blocks = std::max(1, std::min(m->num_cus, total / 32));
+        TL sub(in0.begin() + b0, in0.begin() + b1);
+        ProfScope ps(m, "convr_kernel", flops, scope + " " + dims_of(sub) + " 64->64");
+        ps.bytes = bytes;
+        ps.set_name("convr_kernel" + targs({tb(relu_in), tb(relu_out)}));
+        if (relu_in && relu_out) hipLaunchKernelGGL((convr_kernel<true, true>), dim3(blocks), dim3(256), 0, m->stream, a);
+        else if (relu_in) hipLaunchKernelGGL((convr_kernel<true, false>), dim3(blocks), dim3(256), 0, m->stream, a);
+        else if (relu_out) hipLaunchKernelGGL((convr_kernel<false, true>), dim3(blocks), dim3(256), 0, m->stream, a);
+        else hipLaunchKernelGGL((convr_kernel<false, false>), dim3(blocks), dim3(256), 0, m->stream, a);
+    }
+    return out;
+}
+
 // stride-1 SAME conv of the bf16 path.  pooled != nullptr: the epilogue also writes maxpool2 of the output (always fused here);
 // keep_full = false: only the pooled tensor is stored; pool_f32: the pooled tensor is fp32 (input of conv_c1out_kernel)
 // relu_out = true on an elu / leaky graph (cfg.activation != 0): the layer's activation is that function (ConvBArgs::act), applied to the
@@ -1509,6 +1546,8 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
     }
     // output-channel tiles per block: 1 (cout 8 / 16), 2 (cout 32: one wave row, 16 x 32 pixels), 4 (cout >= 64: two wave
     // rows of two m-tiles, 8 x 32 pixels)
+    if (m->use_convr && pc.kh == 3 && pc.kw == 3 && pc.bmode == 2 && !in1 && in0[0].C == 64 && pc.cout == 64 && pc.mtiles == 4 && !res && !pooled && !act)
+        return run_convr(m, scope, pc, in0, relu_in, relu_out);
     const int mtb = pc.mtiles >= 4 ? 4 : pc.mtiles;
     if (pc.mtiles % mtb != 0 || mtb == 3) { set_error("conv %s: %d output tiles not instantiated", scope.c_str(), pc.mtiles); throw ArgError(); }
     const int th = (mtb == 4 || (mtb == 2 && pc.bmode == 2)) ? 8 : 16;
@@ -2250,6 +2289,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     m->fused8_var = variant && !cfg->plain_u && cfg->activation != 0 && m->fused8_wanted && m->r8_valu && m->fuse_act && !m->bf16;
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_RES32")) m->use_res32 = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_BF_CONVR")) m->use_convr = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_WALK")) { m->walk_mode = atoi(e); m->use_walk = m->walk_mode != 0; }
     if (const char* e = getenv("ASEP_LANES")) { m->num_lanes = std::max(1, std::min(4, atoi(e))); m->lanes_forced = true; }
     for (int l = 0; l < m->num_lanes; ++l) {
@@ -2354,6 +2394,11 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     }
     m->owned.push_back(m->d_stats);
     m->owned.push_back(m->d_sums);
+    if (hipMalloc((void**)&m->d_zero_trash, 8192) != hipSuccess || hipMemset(m->d_zero_trash, 0, 8192) != hipSuccess) {
+        set_error("asep_aru_load: hipMalloc failed");
+        return nullptr;
+    }
+    m->owned.push_back(m->d_zero_trash);
     return m.release();
     ASEP_GUARD_END_PTR
 }
