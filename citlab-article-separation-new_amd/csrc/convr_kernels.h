@@ -68,12 +68,13 @@ __device__ __forceinline__ void cvr_mfma_done(f32x4 (&acc)[4][2]) {
 
 template <bool RELU_IN, bool RELU_OUT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void convr_kernel(const ConvRArgs a) {
-    constexpr int NR = 8, PLB = 34 * 32, ROWB = 4 * PLB, WAVEB = NR * ROWB;        // 1088, 4352, 34816 bytes
+    constexpr int NR = 8, ROWB = 34 * 128, RINGB = NR * ROWB, STGB = 32 * 128, WAVEB = RINGB + STGB;   // 4352, 34816, 4096, 38912 bytes
     constexpr int NDMA = 5;                                                         // 272 16-byte units per row: 4 full wave-instructions + 16 lanes
-    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WAVEB];          // 139264 bytes
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WAVEB];          // 155648 bytes
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, kk = lane >> 4;
     unsigned char* const ring = lds + wave * WAVEB;
+    unsigned char* const stg = ring + RINGB;                                        // the output row on its way from accumulator layout to whole pixels
 
     // ---- the layer's A fragments and biases: registers for the life of the wave ----
     // 64 of the 72 fragments are DEFINED in the accumulator half of the register file (loads into AGPR tuples, inline asm: a value the compiler
@@ -99,16 +100,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int lo = (int)((long long)a.total * wid / nwv);
     const int hi = (int)((long long)a.total * (wid + 1) / nwv);
 
-    // the lane's place in a row image: unit u = k 64 + lane -> plane q = u / 68, pixel (u % 68) >> 1, channel block 2 q + (u & 1)
+    // A row's LDS image: pixel p of the strip's 34 at 128 p, its eight 16-byte channel blocks s at (s ^ (p & 6)) 16 -- whole pixels, so that eight
+    // consecutive lanes of a request fetch one 128-byte line (the first cut kept convb_kernel's planes of 32 bytes per pixel: four requests per
+    // line, 3.0 TB/s), permuted so that a fragment read (lane (j, kk): pixel j + kx, block 4 g + kk) is conflict-free on the real ds_read_b128
+    // lane groups (exhaustive search over the XOR-linear maps, like r8v_px's).  DMA unit u = k 64 + lane -> pixel u >> 3, block (u & 7) ^ (p & 6).
     int dpx[NDMA], dch[NDMA];
 #pragma unroll
     for (int k = 0; k < NDMA; ++k) {
-        const int u = k * 64 + lane, q = u / 68, v = u - q * 68;
-        dpx[k] = v >> 1;
-        dch[k] = (2 * q + (v & 1)) * 16;                                           // byte offset of the 8 channels inside a pixel's 128 bytes
+        const int u = k * 64 + lane;
+        dpx[k] = u >> 3;
+        dch[k] = ((u & 7) ^ (dpx[k] & 6)) * 16;
     }
-    const int lanebase = (kk >> 1) * PLB + j * 32 + (kk & 1) * 16;
+    // fragment addresses inside a row image: [kx][g]; the second n-tile is 2048 bytes further
+    int fb[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) fb[kx][g] = (kx + j) * 128 + (((4 * g + kk) ^ ((kx + j) & 6)) * 16);
+    // staging: lane (j, kk) writes its 8 bytes (m-tile m, n-tile nt) of pixel 16 nt + j at 8-byte block ((4 m + kk) ^ ((j & 7) << 1)) of the pixel's
+    // 128 (two lanes per bank pair instead of sixteen); read back linearly: lane l of instruction t gets the 16-byte block (l & 7) ^ ((l >> 3) & 7)
+    // of pixel 8 t + (l >> 3), so eight lanes store one 128-byte line
+    unsigned swb[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        swb[m] = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(stg + j * 128 + (((4 * m + kk) ^ ((j & 7) << 1)) * 8));
+    const unsigned srd = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(stg + lane * 16);
+    const int gpx = lane >> 3, gl = gpx * 128 + (((lane & 7) ^ (gpx & 7)) * 16);
     const unsigned char* const zero = reinterpret_cast<const unsigned char*>(a.zero);
+    unsigned char* const trash = reinterpret_cast<unsigned char*>(a.trash) + lane * 16;
 
     while (lo < hi) {
         int pi = 0;
@@ -160,29 +179,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             relu_row(0);
             relu_row(1);
         }
-        // output addressing: lane = pixel x0 + 16 nt + j, channels 16 m + 4 kk .. + 3
+        // output addressing (whole pixels): lane -> pixel x0 + 8 t + (lane >> 3) of the row, its 16-byte block
         unsigned char* const outb = reinterpret_cast<unsigned char*>(P.out);
-        const bool ok0 = x0 + j < W, ok1 = x0 + 16 + j < W;
-        size_t ooff = ((size_t)r0 * W + x0 + j) * 128 + kk * 8;
+        bool okt[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) okt[t] = x0 + 8 * t + gpx < W;
+        // (a pointer in registers before the loop: an address built from the problem's scalars inside it made hipcc drain lgkmcnt -- the fragment
+        // reads in flight -- in front of the stores, for a scalar load it could not prove finished)
+        unsigned char* optr = outb + ((size_t)r0 * W + x0) * 128 + gl;              // of the row whose epilogue runs next
+        asm volatile("" : "+v"(optr));
         const size_t orow = (size_t)W * 128;
-        unsigned char* const trash = reinterpret_cast<unsigned char*>(a.trash) + lane * 8;
 
-#pragma unroll 1
-        for (int i = 0; i < n; ++i) {
+        // ---- the epilogue of a row, in four pieces that stand between the MFMAs of the NEXT row (two accumulator sets take turns): round + ReLU on
+        //      the packed values + 8-byte stores into the staging rows | the staged row read back as whole pixels | 16-byte stores ----
+        u32x4 st[4];
+        auto ep_pack = [&](f32x4 (&acc)[4][2], int m) {
+            u32x2 q0 = pack_bf16x4(acc[m][0]), q1 = pack_bf16x4(acc[m][1]);
+            if constexpr (RELU_OUT) {
+                q0 = u32x2{relu_bf16x2(q0.x), relu_bf16x2(q0.y)};
+                q1 = u32x2{relu_bf16x2(q1.x), relu_bf16x2(q1.y)};
+            }
+            *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(swb[m]) = q0;
+            *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(swb[m] + 2048) = q1;
+        };
+        auto ep_read = [&]() {
+            cvr_lds_read<0>(st[0], srd); cvr_lds_read<1024>(st[1], srd); cvr_lds_read<2048>(st[2], srd); cvr_lds_read<3072>(st[3], srd);
+        };
+        auto ep_store = [&](bool valid) {                                           // valid: wave-uniform (the first row of a range has no predecessor)
+            if (CVR_ABL & 2) return;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                unsigned char* const o = (valid && okt[t]) ? optr + t * 1024 : trash;
+                *reinterpret_cast<u32x4*>(o) = st[t];
+            }
+            optr += valid ? orow : 0;
+        };
+
+        f32x4 acc0[4][2], acc1[4][2];
+        auto row = [&](int i, f32x4 (&acc)[4][2], f32x4 (&accp)[4][2]) {
             request(i + NR - 1);                                                    // into the slot row i - 1 has left
             cvr_wait_vm<(NR - 3) * NDMA>();                                         // rows .. i + 2 have landed; i + 3 .. i + 7 may be in flight
             if constexpr (RELU_IN) relu_row(i + 2);
-            unsigned rb[3];                                                         // LDS byte addresses of the lane's place in rows i, i + 1, i + 2
+            unsigned rb[3][3][2];                                                   // LDS byte addresses: [row i + ky][kx][g]
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-                rb[k] = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(ring + ((i + k) & (NR - 1)) * ROWB + lanebase);
-            f32x4 acc[4][2];
+            for (int ky = 0; ky < 3; ++ky) {
+                const unsigned rowa = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(ring + ((i + ky) & (NR - 1)) * ROWB);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) rb[ky][kx][g] = rowa + fb[kx][g];
+            }
             u32x4 bq[3][2];
             auto ldb = [&](auto cc, u32x4 (&b)[2]) {
                 constexpr int c = decltype(cc)::value, g = c / 9, t = c - g * 9, ky = t / 3, kx = t - ky * 3;
                 if (CVR_ABL & 16) { b[0] = u32x4{(unsigned)c, 0u, 0u, 0u}; b[1] = b[0]; return; }
-                cvr_lds_read<g * 2 * PLB + kx * 32>(b[0], rb[ky]);
-                cvr_lds_read<g * 2 * PLB + kx * 32 + 16 * 32>(b[1], rb[ky]);
+                cvr_lds_read<0>(b[0], rb[ky][kx][g]);
+                cvr_lds_read<2048>(b[1], rb[ky][kx][g]);
             };
             // the fragment reads run two chunks ahead of their MFMAs (three buffers)
             ldb(ic<0>{}, bq[0]);
@@ -192,9 +244,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if constexpr (c + 2 < 18) ldb(ic<c + 2>{}, bq[(c + 2) % 3]);
                 if (!(CVR_ABL & 16)) cvr_lds_wait<(c + 2 < 18 ? 4 : (c + 1 < 18 ? 2 : 0))>(bq[c % 3][0], bq[c % 3][1]);
                 static_for<4>([&](auto mc) {
-                    constexpr int m = decltype(mc)::value, i = c * 4 + m;
-                    constexpr bool AG = i < NAA;
-                    const u32x4& Af = AG ? Aa[AG ? i : 0] : Av[AG ? 0 : i - NAA];
+                    constexpr int m = decltype(mc)::value, ia = c * 4 + m;
+                    constexpr bool AG = ia < NAA;
+                    const u32x4& Af = AG ? Aa[AG ? ia : 0] : Av[AG ? 0 : ia - NAA];
                     if (CVR_ABL & 4) {
                         if (c == 0) { acc[m][0] = bias[m]; acc[m][1] = bias[m]; }
                         acc[m][0] += f32x4{__uint_as_float(bq[c % 3][0].x), 0.f, 0.f, 0.f};
@@ -207,25 +259,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         cvr_mfma<AG>(acc[m][1], Af, bq[c % 3][1]);
                     }
                 });
-            });
-            if (!(CVR_ABL & 4)) cvr_mfma_done(acc);
-            // ---- epilogue: round, ReLU on the packed values, 8-byte stores (lanes beyond the last column: into the dump) ----
-            unsigned char* const o0 = ok0 ? outb + ooff : trash;
-            unsigned char* const o1 = ok1 ? outb + ooff + 16 * 128 : trash;
-            ooff += orow;
-            if (!(CVR_ABL & 2)) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    u32x2 q0 = pack_bf16x4(acc[m][0]), q1 = pack_bf16x4(acc[m][1]);
-                    if constexpr (RELU_OUT) {
-                        q0 = u32x2{relu_bf16x2(q0.x), relu_bf16x2(q0.y)};
-                        q1 = u32x2{relu_bf16x2(q1.x), relu_bf16x2(q1.y)};
-                    }
-                    *reinterpret_cast<u32x2*>(o0 + m * 32) = q0;
-                    *reinterpret_cast<u32x2*>(o1 + m * 32) = q1;
+                // the previous row's epilogue (its MFMAs ended at least a chunk ago: no wait states needed)
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (c == 1) { ep_pack(accp, 0); ep_pack(accp, 1); }
+                if constexpr (c == 3) { ep_pack(accp, 2); ep_pack(accp, 3); }
+                if constexpr (c == 5) ep_read();
+                if constexpr (c == 9) {
+                    // (LDS operations return in order: behind the staged reads stand the fragment reads of chunks 8 .. 11)
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]));
+                    ep_store(i > 0);
                 }
-            }
+                if constexpr (c == 1 || c == 3 || c == 5 || c == 9) __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+#pragma unroll 1
+        for (int i = 0; i < n; i += 2) {
+            row(i, acc0, acc1);
+            if (i + 1 >= n) break;
+            row(i + 1, acc1, acc0);
         }
+        // the last row's epilogue
+        auto flush = [&](f32x4 (&acc)[4][2]) {
+            if (!(CVR_ABL & 4)) cvr_mfma_done(acc);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) ep_pack(acc, m);
+            ep_read();
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]));
+            ep_store(true);
+        };
+        if (n & 1) flush(acc0); else flush(acc1);
     }
 }
 
