@@ -1493,7 +1493,7 @@ Tensor new_tensor_bf(asep_aru* m, int H, int W, int C) {
     } while (0)
 
 // the 64 -> 64 3x3 layers with the filter in registers (convr_kernels.h): one wave per SIMD, a wave = the pipeline of a 32-column strip
-TL run_convr(asep_aru* m, const std::string& scope, const PackedConv& pc, const TL& in0, bool relu_in, bool relu_out) {
+TL run_convr(asep_aru* m, const std::string& scope, const PackedConv& pc, const TL& in0, bool relu_in, bool relu_out, const TL* res) {
     TL out;
     for (const Tensor& t : in0) out.push_back(new_tensor_bf(m, t.H, t.W, 64));
     for (size_t b0 = 0; b0 < in0.size(); b0 += MAXP) {
@@ -1502,23 +1502,24 @@ TL run_convr(asep_aru* m, const std::string& scope, const PackedConv& pc, const 
         int total = 0;
         double flops = 0, bytes = 9.0 * 64 * 64 * 2.0;
         for (size_t i = b0; i < b1; ++i) {
-            bytes += tbytes(in0[i]) + tbytes(out[i]);
+            bytes += tbytes(in0[i]) + tbytes(out[i]) + (res ? tbytes((*res)[i]) : 0.0);
             ConvRProb& p = a.p[i - b0];
-            p.in = in0[i].bp(); p.res = nullptr; p.out = out[i].bp();
+            p.in = in0[i].bp(); p.res = res ? (*res)[i].bp() : nullptr; p.out = out[i].bp();
             p.H = in0[i].H; p.W = in0[i].W; p.strips = cdiv(in0[i].W, 32); p.begin = total;
             total += p.strips * p.H;
             flops += 2.0 * in0[i].H * in0[i].W * 9.0 * 64.0 * 64.0;
         }
         a.nprob = (int)(b1 - b0); a.total = total;
         a.wpk = (const u32x4*)pc.d_wb; a.bias = pc.d_b;
-        a.zero = m->d_zero_trash; a.trash = m->d_zero_trash + 1024;
+        a.zero = m->d_zero_trash;
         // one wave per SIMD; a wave's range = total / waves rows (never fewer than 8: a range starts with three rows of latency)
         const int blocks = std::max(1, std::min(m->num_cus, total / 32));
         TL sub(in0.begin() + b0, in0.begin() + b1);
         ProfScope ps(m, "convr_kernel", flops, scope + " " + dims_of(sub) + " 64->64");
         ps.bytes = bytes;
-        ps.set_name("convr_kernel" + targs({tb(relu_in), tb(relu_out)}));
-        if (relu_in && relu_out) hipLaunchKernelGGL((convr_kernel<true, true>), dim3(blocks), dim3(256), 0, m->stream, a);
+        ps.set_name("convr_kernel" + targs({tb(relu_in), tb(relu_out), tb(res != nullptr)}));
+        if (res) hipLaunchKernelGGL((convr_kernel<false, true, true>), dim3(blocks), dim3(256), 0, m->stream, a);
+        else if (relu_in && relu_out) hipLaunchKernelGGL((convr_kernel<true, true>), dim3(blocks), dim3(256), 0, m->stream, a);
         else if (relu_in) hipLaunchKernelGGL((convr_kernel<true, false>), dim3(blocks), dim3(256), 0, m->stream, a);
         else if (relu_out) hipLaunchKernelGGL((convr_kernel<false, true>), dim3(blocks), dim3(256), 0, m->stream, a);
         else hipLaunchKernelGGL((convr_kernel<false, false>), dim3(blocks), dim3(256), 0, m->stream, a);
@@ -1546,8 +1547,9 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
     }
     // output-channel tiles per block: 1 (cout 8 / 16), 2 (cout 32: one wave row, 16 x 32 pixels), 4 (cout >= 64: two wave
     // rows of two m-tiles, 8 x 32 pixels)
-    if (m->use_convr && pc.kh == 3 && pc.kw == 3 && pc.bmode == 2 && !in1 && in0[0].C == 64 && pc.cout == 64 && pc.mtiles == 4 && !res && !pooled && !act)
-        return run_convr(m, scope, pc, in0, relu_in, relu_out);
+    if (m->use_convr && pc.kh == 3 && pc.kw == 3 && pc.bmode == 2 && !in1 && in0[0].C == 64 && pc.cout == 64 && pc.mtiles == 4 && !pooled && !act &&
+        (!res || (!relu_in && relu_out)))
+        return run_convr(m, scope, pc, in0, relu_in, relu_out, res);
     const int mtb = pc.mtiles >= 4 ? 4 : pc.mtiles;
     if (pc.mtiles % mtb != 0 || mtb == 3) { set_error("conv %s: %d output tiles not instantiated", scope.c_str(), pc.mtiles); throw ArgError(); }
     const int th = (mtb == 4 || (mtb == 2 && pc.bmode == 2)) ? 8 : 16;
@@ -2621,6 +2623,11 @@ extern "C" int asep_debug_r8f_trace(int up, unsigned long long* out, int n) {
 }
 #endif
 
+#if defined(CVR_TRACE)
+extern "C" int asep_debug_cvr_trace(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(asep::g_cvr_trace), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#endif
 #if defined(CVB_TRACE)
 // debug builds only (see CVB_MARK in bf16_kernels.h); not part of include/asep_hip.h
 extern "C" int asep_debug_cvb_trace(unsigned long long* out, int n) {
