@@ -161,7 +161,7 @@ def test_every_bf16_mfma_kernel_of_the_bf16_header_is_priced_against_the_bf16_pi
     __global__ function of csrc/bf16_kernels.h that issues v_mfma_f32_16x16x32_bf16 must map to the bf16 pipe with --dtype bf16."""
     import re
     mfma, all_names = [], []
-    for fname in ("bf16_kernels.h", "res8w_kernels.h"):
+    for fname in ("bf16_kernels.h", "res8w_kernels.h", "convr_kernels.h"):
         src = open(os.path.join(ROOT, "citlab-article-separation-new_amd", "csrc", fname)).read()
         names = re.findall(r"__global__[^\n]*?void\s+(\w+)\s*\(", src)
         all_names += names
@@ -169,10 +169,10 @@ def test_every_bf16_mfma_kernel_of_the_bf16_header_is_priced_against_the_bf16_pi
             body = src[src.index(n + "("):]
             nxt = re.search(r"\n__global__", body[10:])
             body = body[:nxt.start() + 10] if nxt else body
-            if "mfma" in body or "r8w_mm" in body or "mm_pair" in body or "_tile<" in body or "_tile(" in body:
+            if "mfma" in body or "r8w_mm" in body or "cvr_mfma" in body or "mm_pair" in body or "_tile<" in body or "_tile(" in body:
                 mfma.append(n)
     assert len(all_names) >= 12, all_names
-    assert {"deconvb8_kernel", "att_headb_kernel", "res8f_kernel", "convb_kernel", "res8w_kernel", "res8wb_kernel"} <= set(mfma), mfma
+    assert {"deconvb8_kernel", "att_headb_kernel", "res8f_kernel", "convb_kernel", "res8w_kernel", "res8wb_kernel", "convr_kernel"} <= set(mfma), mfma
     for n in mfma:
         pipe, peak = bench.pipe_of(n + "<1,2>", "bf16")
         assert pipe == "bf16 MFMA" and peak == bench.PEAK_BF16_MFMA_TFLOPS, n
