@@ -450,12 +450,13 @@ def test_up_block_strip_walker_is_bit_identical_to_the_tile_kernel_on_identical_
     assert float(np.abs(e1 - e0).max()) <= 2.0 ** -7 * max(1.0, float(np.abs(e0).max())) and diff.mean() <= 0.02
 
 
-@pytest.mark.parametrize("H,W", [(250, 333), (611, 477), (96, 200), (1100, 908), (777, 1290)])
+@pytest.mark.parametrize("H,W", [(250, 333), (611, 477), (96, 200), (1100, 908), (777, 1290), (16, 16), (24, 40), (40, 530), (300, 17)])
 def test_the_64_channel_layers_with_the_filter_in_registers_are_bit_identical_to_convb_kernel(H, W, monkeypatch):
     """round 6: convr_kernel (csrc/convr_kernels.h: the layer's 72 A fragments in the registers of one wave per SIMD, a wave =
     the pipeline of a 32-column strip, rows by LDS-DMA, zero padding by source address) keeps convb_kernel's accumulation order: every end point of
     the net and the probabilities must be BIT-IDENTICAL to the run with ASEP_BF_CONVR=0.  Sizes: level-3 maps of 32 x 42 (two strips, the second
-    10 columns wide) ... 162 x 98 pixels (ranges that cross strip ends), all three scales of the pyramid in one launch."""
+    10 columns wide) ... 162 x 98 pixels (ranges that cross strip ends), all three scales of the pyramid in one launch; maps of 2 x 2, 3 x 5, 5 x 67 and
+    38 x 3 pixels (ranges of one and two rows, a single partial strip).  The RES form (unet_up_3/convR_2) is in every one of them."""
     from citlab_article_separation_new_amd import net_post_processing_helper as helper
     names = ["scale_0_unet_down_3_conv", "scale_0_unet_up_3_conv", "scale_1_unet_down_3_conv", "scale_2_unet_up_3_conv", "scale_0_unet_up_0_conv"]
     img = _image(H, W, 91)
