@@ -1586,6 +1586,9 @@ struct CombineArgs {
 };
 
 constexpr int COMBINE_TW = 32;   // tile width of combine_kernel (16 rows)
+#ifndef CMB_ABL
+#define CMB_ABL 0                // ablation builds (WRONG RESULTS ON PURPOSE): 1 no attention / channel-sum gathers, 2 no uint8 / threshold stores, 4 no probability stores, 8 no feature loads
+#endif
 // F0BF: the scale-0 feature map is bf16 (native bf16 path): one 16-byte load per pixel, widened to fp32 in registers
 // NSCT: number of scales as a compile-time constant (1 = no attention, 3 = the default net; 0 = run-time a.nsc).  The first phase
 // of this kernel was 850 vector instructions per thread against 460 in the logits conv: five scale iterations of which two are
@@ -1622,6 +1625,10 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
     constexpr int NPX = (L * LW + 255) / 256;
     f32x4 fv[NPX][FR / 4];
     float avv[NPX][MAX_SCALES], fsv[NPX][MAX_SCALES];
+    // (Round 6, measured and not kept: the tile's coarse maps -- at most 4 x 6 attention values and 11 x 19 channel sums per map under a 19 x 35
+    // window -- staged in LDS first and read there by the window pixels instead of five 4-byte global gathers per pixel: 114 -> 133 us per page,
+    // although the kernel WITHOUT the gathers takes 97: the second index computation, the extra barrier and 25 LDS reads per thread cost more than
+    // gathers that hit in L1 / L2.  profiles/r6_combine/)
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
         const int pix = min(tid + i * 256, L * LW - 1);
@@ -1629,7 +1636,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
         const int gy = min(max(y0 - 1 + ly, 0), a.H - 1), gx = min(max(x0 - 1 + lx, 0), a.W - 1);
         if constexpr (F0BF) {
             typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-            const u32x4_t q = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const unsigned short*>(a.f0) + ((idx_t)gy * a.W + gx) * FR);
+            const u32x4_t q = (CMB_ABL & 8) ? u32x4_t{(unsigned)gx, 0u, 0u, 0u} : *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const unsigned short*>(a.f0) + ((idx_t)gy * a.W + gx) * FR);
             fv[i][0] = f32x4{__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
             fv[i][FR / 4 - 1] = f32x4{__uint_as_float(q.z << 16), __uint_as_float(q.z & 0xffff0000u), __uint_as_float(q.w << 16), __uint_as_float(q.w & 0xffff0000u)};
         } else {
@@ -1640,7 +1647,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
 #pragma unroll
         for (int s = 0; s < MAX_SCALES; ++s) {
             avv[i][s] = 0.f; fsv[i][s] = 0.f;
-            if (nsc > 1 && s < nsc) {
+            if (nsc > 1 && s < nsc && !(CMB_ABL & 1)) {
                 const int ay = (gy + a.aph[s]) >> a.ash[s], ax = (gx + a.apw[s]) >> a.ash[s];
                 avv[i][s] = a.att[s][(idx_t)ay * a.aw[s] + ax];
                 if (s >= 1) {
@@ -1732,23 +1739,39 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineArgs a) {
             }
         }
         const float bd = ((cptr)a.wd)[16 * FR];
+        // the thread's two pixels x two classes are 16 consecutive bytes of the probability map (4 of the uint8 / threshold images): ONE store each
+        // (round 6: four 4-byte and eight 1-byte stores per thread before; 118 -> 114 us per page -- the kernel without ANY store takes 66:
+        // profiles/r6_combine/ablation_combine_kernel.txt).  Addresses are 8-byte (2-byte) aligned: enough for the hardware's multi-dword stores.
+        float pr[2][2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int x = xb + q;
-            if (x >= a.W) break;
             const f32x2 t = l2[q][0] + l2[q][1];
             const float d = (t.x + t.y) + bd;                     // l1 - l0
             const float e = expf(-fabsf(d)), big = 1.f / (1.f + e), small = e / (1.f + e);
-            const float pr[2] = {d > 0.f ? small : big, d > 0.f ? big : small};
-            const idx_t p = ((idx_t)y * a.W + x) * NC;
+            pr[q][0] = d > 0.f ? small : big;
+            pr[q][1] = d > 0.f ? big : small;
+        }
+        const idx_t p = ((idx_t)y * a.W + xb) * NC;
+        const bool both = xb + 1 < a.W;
+        uint8_t u[2][2];
 #pragma unroll
-            for (int k = 0; k < NC; ++k) {
-                a.out[p + k] = pr[k];
-                if (a.out_u8 || a.out_mask) {
-                    const uint8_t u = (uint8_t)(pr[k] * 255.0f);          // np.array(p*255, dtype=uint8)
-                    if (a.out_u8) a.out_u8[p + k] = u;
-                    if (a.out_mask) a.out_mask[p + k] = ((double)u > a.thr255) ? 255 : 0;
-                }
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) u[q][k] = (uint8_t)(pr[q][k] * 255.0f);                // np.array(p*255, dtype=uint8)
+        if (!(CMB_ABL & 4)) {
+            if (both) *reinterpret_cast<f32x4*>(a.out + p) = f32x4{pr[0][0], pr[0][1], pr[1][0], pr[1][1]};
+            else *reinterpret_cast<f32x2*>(a.out + p) = f32x2{pr[0][0], pr[0][1]};
+        }
+        if (!(CMB_ABL & 2)) {
+            if (a.out_u8) {
+                *reinterpret_cast<unsigned short*>(a.out_u8 + p) = (unsigned short)(u[0][0] | (u[0][1] << 8));
+                if (both) *reinterpret_cast<unsigned short*>(a.out_u8 + p + 2) = (unsigned short)(u[1][0] | (u[1][1] << 8));
+            }
+            if (a.out_mask) {
+                const double thr = a.thr255;
+                auto mk = [&](uint8_t v) { return ((double)v > thr) ? 255u : 0u; };
+                *reinterpret_cast<unsigned short*>(a.out_mask + p) = (unsigned short)(mk(u[0][0]) | (mk(u[0][1]) << 8));
+                if (both) *reinterpret_cast<unsigned short*>(a.out_mask + p + 2) = (unsigned short)(mk(u[1][0]) | (mk(u[1][1]) << 8));
             }
         }
         return;

@@ -297,8 +297,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             rq[m][1] = *reinterpret_cast<const __attribute__((address_space(3))) u32x2*>(swb[m] + STGB + 2048);
         }
     };
-    auto res_init = [&](auto nc, f32x4 (&acc)[4][2]) {                              // acc = bias + residual (convb_kernel's order: b4, then += residual)
-        constexpr int N = decltype(nc)::value;
+    auto res_init = [&](auto, f32x4 (&acc)[4][2]) {                                 // acc = bias + residual (convb_kernel's order: b4, then += residual)
         // (ordinary loads: hipcc waits for them -- and with them for the fragment reads in flight, once per row; as asm reads with a counted wait
         // the last of the eight came back wrong in every other row)
 #pragma unroll

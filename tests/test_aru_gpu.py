@@ -470,3 +470,4 @@ def test_the_64_channel_layers_with_the_filter_in_registers_are_bit_identical_to
     for n in names:
         assert e1[n].shape == e0[n].shape and np.array_equal(e1[n], e0[n]), (n, int((e1[n] != e0[n]).sum()))
     assert np.array_equal(p1, p0)
+
