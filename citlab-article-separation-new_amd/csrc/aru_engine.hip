@@ -79,6 +79,8 @@ struct asep_aru {
     int walk_mode = 1;               // ASEP_BF_WALK: 1 both level-0 blocks on the walkers (default), 2 the UP block only, 0 neither
     bool use_convr = true;           // ASEP_BF_CONVR=0: the 64 -> 64 layers on convb_kernel instead of the register-resident form (convr_kernels.h)
     unsigned char* d_zero_trash = nullptr;   // 16 zero bytes (padding source of convr_kernel) + 4 KB behind them that nobody reads (its dump)
+    int fused_act = 0;               // bf16 engine, elu / leaky RESIDUAL graphs (round 6): the level-0 blocks and the 16-channel tails on the general fused forms
+                                     // res8b_kernel<UP, ACT> / resb_tail_kernel<16, ACT> (activation on the fp32 sums before the rounding); 0: ReLU graph, or layer by layer
     bool use_walk = true;            // ASEP_BF_WALK=0: the level-0 blocks as 16 x 32 tiles (res8f_kernel) instead of the column-strip walkers (res8w_kernels.h)
     bf16_t* d_r8b_up_w = nullptr;    // [3][3][64][8]
     float* d_r8b_up_b = nullptr;     // [3][8]
@@ -1400,7 +1402,7 @@ void run_res8b(asep_aru* m, bool up, const TL& a0, const TL* a1, const std::vect
         d_out->push_back(new_tensor_bf(m, t.H, t.W, 8));
         if (want_pool) pool_out->push_back(new_tensor_bf(m, cdiv(t.H, 2), cdiv(t.W, 2), 8));
     }
-    if (m->use_walk && (up || m->walk_mode == 1) && (up ? m->d_r8f_up_w1 != nullptr : m->d_r8f_down_w1 != nullptr)) {
+    if (!m->fused_act && m->use_walk && (up || m->walk_mode == 1) && (up ? m->d_r8f_up_w1 != nullptr : m->d_r8f_down_w1 != nullptr)) {
         // pages with room for at least four strips and two tile rows of walker region go to the strip walker, the others stay on the tile kernels
         TL ws, wd, wo, wp, rs, rd, ro, rp;
         std::vector<const float*> wst, rst;
@@ -1451,7 +1453,14 @@ void run_res8b_tiles(asep_aru* m, bool up, const TL& a0, const TL* a1, const std
         const std::string what = (up ? "unet_up_0 (conv1[16->8]+3xconvR+add) " : "unet_down_0 (conv1+3xconvR+add+pool) ") + dims_of(sub);
         bool small = true;                                   // res8f_kernel addresses its tensors with 32-bit byte offsets (16 bytes per pixel)
         for (size_t i = b0; i < b1; ++i) small = small && (size_t)a0[i].H * a0[i].W < ((size_t)1 << 28);
-        if (small && (up || m->d_r8f_down_w1)) {
+        if (m->fused_act) {                                  // elu / leaky: the general form for every tile
+            ProfScope ps(m, std::string("res8b_kernel") + targs({tb(up), ti(m->fused_act)}), flops, what);
+            ps.bytes = bytes;
+            if (up && m->fused_act == 1) hipLaunchKernelGGL((res8b_kernel<true, 1>), dim3(units), dim3(256), 0, m->stream, a);
+            else if (up) hipLaunchKernelGGL((res8b_kernel<true, 2>), dim3(units), dim3(256), 0, m->stream, a);
+            else if (m->fused_act == 1) hipLaunchKernelGGL((res8b_kernel<false, 1>), dim3(units), dim3(256), 0, m->stream, a);
+            else hipLaunchKernelGGL((res8b_kernel<false, 2>), dim3(units), dim3(256), 0, m->stream, a);
+        } else if (small && (up || m->d_r8f_down_w1)) {
             // lean form for interior tiles (their 24 x 40 input window inside the image), general form for border tiles, one launch
             Res8BArgs f = a;
             if (!up) f.w1pk = (const u32x4*)m->d_r8f_down_w1;
@@ -1670,6 +1679,13 @@ TL run_resb_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled)
             ps.bytes = bytes;
             a.ntiles = tiles;
             hipLaunchKernelGGL(res32_tail_kernel, dim3(std::min(tiles, m->num_cus)), dim3(512), Res32Layout::BYTES, m->stream, a);
+        } else if (m->fused_act) {                     // elu / leaky: the general form
+            ProfScope ps(m, "resb_tail_kernel" + targs({ti(rb.C), ti(m->fused_act)}), flops, what);
+            ps.bytes = bytes;
+            if (rb.C == 8 && m->fused_act == 1) hipLaunchKernelGGL((resb_tail_kernel<8, 1>), dim3(units), dim3(256), 0, m->stream, a);
+            else if (rb.C == 8) hipLaunchKernelGGL((resb_tail_kernel<8, 2>), dim3(units), dim3(256), 0, m->stream, a);
+            else if (m->fused_act == 1) hipLaunchKernelGGL((resb_tail_kernel<16, 1>), dim3(units), dim3(256), 0, m->stream, a);
+            else hipLaunchKernelGGL((resb_tail_kernel<16, 2>), dim3(units), dim3(256), 0, m->stream, a);
         } else if (rb.C == 16 && small16) {            // lean form for interior tiles, general form for border tiles, one launch
             ProfScope ps(m, "res16f_kernel", flops, what);
             ps.bytes = bytes;
@@ -2355,11 +2371,16 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (!rc && (!variant || m->fused8_var) && !m->bf16 && cfg->feat_root == 8 && cfg->res_depth == 3 && m->det_first.k == 3) rc = pack_res8(m.get(), blob);
     // (bf16 path, elu / leaky / 'U' graphs -- round 5: layer by layer on convb_kernel / deconvb_kernel with the activation in their general
     //  epilogues; the fused blocks below bake the ReLU into packed-bf16 maxima and serve the ReLU residual graphs)
-    if (!rc && m->bf16 && !variant && cfg->res_depth == 3 && cfg->feat_root == 8) rc = pack_res8b(m.get(), blob);
-    if (!rc && m->bf16 && !variant && cfg->res_depth == 3)
+    // (round 6: the elu / leaky RESIDUAL graphs take the GENERAL fused forms of the 8- and 16-channel levels -- res8b_tile / resb_tail_tile apply the
+    //  activation to fp32 values and take float maxima in their pools, a template parameter serves them; the lean forms, the walkers and the
+    //  32-channel tail stay the ReLU graphs')
+    m->fused_act = (m->bf16 && variant && !cfg->plain_u && cfg->activation != 0 && m->fused8_wanted && m->fuse_act) ? cfg->activation : 0;
+    const bool fusedb = m->bf16 && (!variant || m->fused_act);
+    if (!rc && fusedb && cfg->res_depth == 3 && cfg->feat_root == 8) rc = pack_res8b(m.get(), blob);
+    if (!rc && fusedb && cfg->res_depth == 3)
         for (int l = 0; l < n && !rc; ++l) {
             const int f = cfg->feat_root << l;
-            if (f != 8 && f != 16 && !(f == 32 && m->use_res32)) continue;
+            if (f != 8 && f != 16 && !(f == 32 && m->use_res32 && !m->fused_act)) continue;
             rc = pack_resb(m.get(), blob, "aru_net/featMapG/unet_down_" + std::to_string(l), f);
             if (!rc && l < n - 1) rc = pack_resb(m.get(), blob, "aru_net/featMapG/unet_up_" + std::to_string(l), f);
         }

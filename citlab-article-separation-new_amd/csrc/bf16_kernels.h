@@ -424,7 +424,8 @@ struct ResBLayout {
 };
 
 // the tail of one tile (any position; `lds` holds ResBLayout<C>::BYTES)
-template <int C>
+// ACT: the block's activation (0 ReLU; 1 elu / 2 leaky of the graph variants: on the fp32 sums before the one rounding, like the layer-by-layer path)
+template <int C, int ACT = 0>
 __device__ __forceinline__ void resb_tail_tile(const ResBArgs& a, const ResBProb& P, int x0, int y0, unsigned char* lds) {
     static_assert(C == 8 || C == 16, "8- and 16-channel levels");
     constexpr int PXB = C * 2;
@@ -496,7 +497,7 @@ __device__ __forceinline__ void resb_tail_tile(const ResBArgs& a, const ResBProb
             for (int t = 0; t < CPC; ++t) acc = mfma_bf16_k32(af[t], bfr[t], acc);
             const int gy = y0 - halo + oy, gx = x0 - halo + ox;
             const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const f32x4 v = inside ? relu4(acc + b4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 v = inside ? (ACT ? act4(acc + b4, ACT) : relu4(acc + b4)) : f32x4{0.f, 0.f, 0.f, 0.f};
             if (q < npix && (C == 16 || kk < 2)) *reinterpret_cast<u32x2*>(dst + q * PXB + kk * 8) = pack_bf16x4(v);
         }
     };
@@ -536,7 +537,7 @@ __device__ __forceinline__ void resb_tail_tile(const ResBArgs& a, const ResBProb
                 const int y = y0 + oy + r;
                 const size_t p = ((size_t)min(y, H - 1) * W + min(x, W - 1)) * C + (cok ? kk * 4 : 0);
                 f32x4 v = acc2[r] + b4 + unpack_bf16x4(*reinterpret_cast<const u32x2*>(P.t + p));
-                v = relu4(v);
+                v = ACT ? act4(v, ACT) : relu4(v);
                 const u32x2 pk = pack_bf16x4(v);
                 acc2[r] = unpack_bf16x4(pk);
                 if (cok && y < H && x < W) *reinterpret_cast<u32x2*>(P.out + p) = pk;
@@ -553,7 +554,7 @@ __device__ __forceinline__ void resb_tail_tile(const ResBArgs& a, const ResBProb
     }
 }
 
-template <int C>
+template <int C, int ACT = 0>
 __global__ __launch_bounds__(256, C == 8 ? 4 : 3) void resb_tail_kernel(const ResBArgs a) {
     const int bid = sched_tile(a.xm);
     __shared__ __attribute__((aligned(16))) unsigned char lds[ResBLayout<C>::BYTES];
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(256, C == 8 ? 4 : 3) void resb_tail_kernel(const Re
     const ResBProb& P = a.p[pi];
     const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-    resb_tail_tile<C>(a, P, tx * RB_TW, ty * RB_TH, lds);
+    resb_tail_tile<C, ACT>(a, P, tx * RB_TW, ty * RB_TH, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1306,7 +1307,7 @@ struct Res8BLayout {
 
 // the block of one tile (any position; `lds` holds Res8BLayout<UP>::BYTES)
 // (ymax / xmax: stores are clipped to rows < ymax, columns < xmax -- the border tiles of res8wb_kernel, whose neighbours belong to the strip walker)
-template <bool UP>
+template <bool UP, int ACT = 0>
 __device__ __forceinline__ void res8b_tile(const Res8BArgs& a, const Res8BProb& P, int x0, int y0, unsigned char* lds, int ymax = 1 << 30, int xmax = 1 << 30) {
     constexpr int TH = 16, TW = 32;
     constexpr int H0 = TH + 6, W0 = TW + 6, H1 = TH + 4, W1 = TW + 4, H2 = TH + 2, W2 = TW + 2;
@@ -1460,7 +1461,7 @@ __device__ __forceinline__ void res8b_tile(const Res8BArgs& a, const Res8BProb& 
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) acc = mfma_bf16_k32(af[ky], *reinterpret_cast<const u32x4*>(src + base + ky * WIN * 16), acc);
-            f32x4 v = relu4(acc + b4);
+            f32x4 v = ACT ? act4(acc + b4, ACT) : relu4(acc + b4);
             if constexpr (!INT) {
                 const int gy = y0 - halo + py, gx = x0 - halo + px;
                 if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1499,7 +1500,7 @@ __device__ __forceinline__ void res8b_tile(const Res8BArgs& a, const Res8BProb& 
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) acc = mfma_bf16_k32(af[ky], *reinterpret_cast<const u32x4*>(r0 + base + ky * W2 * 16), acc);
                 const f32x4 tres = unpack_bf16x4(*reinterpret_cast<const u32x2*>(tc + (oy * TW + 2 * j + e) * 16 + ch * 2));
-                const f32x4 v = relu4(acc + b4 + tres);
+                const f32x4 v = ACT ? act4(acc + b4 + tres, ACT) : relu4(acc + b4 + tres);
                 const u32x2 pk = pack_bf16x4(v);
                 v2[r] = unpack_bf16x4(pk);
                 const int y = y0 + oy;
@@ -1524,7 +1525,7 @@ __device__ __forceinline__ void res8b_tile(const Res8BArgs& a, const Res8BProb& 
     }
 }
 
-template <bool UP>
+template <bool UP, int ACT = 0>
 __global__ __launch_bounds__(256, UP ? 3 : 4) void res8b_kernel(const Res8BArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[Res8BLayout<UP>::BYTES];
     const int bid = sched_tile(a.xm);
@@ -1534,7 +1535,7 @@ __global__ __launch_bounds__(256, UP ? 3 : 4) void res8b_kernel(const Res8BArgs 
     const Res8BProb& P = a.p[pi];
     const int tile = bid - P.tile_begin;
     const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-    res8b_tile<UP>(a, P, tx * 32, ty * 16, lds);
+    res8b_tile<UP, ACT>(a, P, tx * 32, ty * 16, lds);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -471,3 +471,32 @@ def test_the_64_channel_layers_with_the_filter_in_registers_are_bit_identical_to
         assert e1[n].shape == e0[n].shape and np.array_equal(e1[n], e0[n]), (n, int((e1[n] != e0[n]).sum()))
     assert np.array_equal(p1, p0)
 
+
+
+@pytest.mark.parametrize("act", ["elu", "leaky"])
+@pytest.mark.parametrize("H,W", [(250, 333), (97, 200)])
+def test_elu_and_leaky_graphs_on_the_fused_general_blocks_of_the_bf16_engine(act, H, W, monkeypatch):
+    """round 6: the elu / leaky RESIDUAL graphs run their level-0 blocks on res8b_kernel<UP, ACT> and their 16-channel tails
+    on resb_tail_kernel<16, ACT> (the general tile forms: activation on the fp32 sums before the one rounding, float maxima in the pool) instead of
+    layer by layer (ASEP_FUSED8=0).  Both evaluate the same graph with the same roundings; the fused forms add the bias behind the sum where
+    convb_kernel starts from it -- a bfloat16 step on a few values, no more.  (The block-by-block gates against the oracle with the engine's
+    roundings are test_graph_variants_on_the_bf16_path's and hold for the fused forms: they are what that test runs now.)"""
+    from citlab_article_separation_new_amd import net_post_processing_helper as helper
+    names = ["scale_0_unet_down_0_conv", "scale_0_unet_down_1_conv", "scale_0_unet_up_1_conv", "scale_0_unet_up_0_conv", "scale_1_unet_up_0_conv"]
+    img = _image(H, W, 57)
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("ASEP_FUSED8", fused)
+        cfg, w, graph = _setup({"compute_dtype": "bf16", "activation_name": act}, seed=14)
+        p = helper.get_net_output(img, graph, "0")
+        res[fused] = (p, {n: helper.get_endpoint(graph, n) for n in names})
+        graph.close()
+    (p1, e1), (p0, e0) = res["1"], res["0"]
+    assert (e0["scale_0_unet_down_0_conv"] < 0).any()           # the negative branch of the activation is exercised
+    d0 = e1["scale_0_unet_down_0_conv"] - e0["scale_0_unet_down_0_conv"]
+    sc = max(1.0, float(np.abs(e0["scale_0_unet_down_0_conv"]).max()))
+    assert float(np.abs(d0).max()) <= 2.0 ** -7 * sc and float((d0 != 0).mean()) <= 0.02      # the first block reads the same image in both runs
+    for n in names[1:]:
+        sc = max(1.0, float(np.abs(e0[n]).max()))
+        assert float(np.abs(e1[n] - e0[n]).max()) <= BF16_EMU_ENDPOINT_GATE * sc, n    # (free running: flipped roundings pile up over the layers)
+    assert float(np.abs(p1 - p0).max()) <= 6e-3                  # (two bf16 evaluations drift apart about as far as each drifts from fp32: 3.4e-3 measured)
