@@ -1670,15 +1670,20 @@ TL run_resb_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled)
         for (const Tensor& x : sub) small16 = small16 && (size_t)x.H * x.W < ((size_t)1 << 27);
         const std::string what = scope + " (3xconvR+add" + (pooled ? "+pool) " : ") ") + dims_of(sub);
         if (rb.C == 32) {
-            static bool attr = false;
-            if (!attr) {
-                ASEP_HIP_CHECK_THROW(hipFuncSetAttribute((const void*)res32_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Res32Layout::BYTES));
-                attr = true;
+            static bool attr[3] = {false, false, false};
+            const int act = m->fused_act;
+            const void* fn = act == 1 ? (const void*)res32_tail_kernel<1> : act == 2 ? (const void*)res32_tail_kernel<2> : (const void*)res32_tail_kernel<0>;
+            if (!attr[act]) {
+                ASEP_HIP_CHECK_THROW(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Res32Layout::BYTES));
+                attr[act] = true;
             }
-            ProfScope ps(m, "res32_tail_kernel", flops, what);
+            ProfScope ps(m, act ? "res32_tail_kernel" + targs({ti(act)}) : std::string("res32_tail_kernel"), flops, what);
             ps.bytes = bytes;
             a.ntiles = tiles;
-            hipLaunchKernelGGL(res32_tail_kernel, dim3(std::min(tiles, m->num_cus)), dim3(512), Res32Layout::BYTES, m->stream, a);
+            const dim3 g32(std::min(tiles, m->num_cus));
+            if (act == 1) hipLaunchKernelGGL(res32_tail_kernel<1>, g32, dim3(512), Res32Layout::BYTES, m->stream, a);
+            else if (act == 2) hipLaunchKernelGGL(res32_tail_kernel<2>, g32, dim3(512), Res32Layout::BYTES, m->stream, a);
+            else hipLaunchKernelGGL(res32_tail_kernel<0>, g32, dim3(512), Res32Layout::BYTES, m->stream, a);
         } else if (m->fused_act) {                     // elu / leaky: the general form
             ProfScope ps(m, "resb_tail_kernel" + targs({ti(rb.C), ti(m->fused_act)}), flops, what);
             ps.bytes = bytes;
@@ -2372,15 +2377,15 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     // (bf16 path, elu / leaky / 'U' graphs -- round 5: layer by layer on convb_kernel / deconvb_kernel with the activation in their general
     //  epilogues; the fused blocks below bake the ReLU into packed-bf16 maxima and serve the ReLU residual graphs)
     // (round 6: the elu / leaky RESIDUAL graphs take the GENERAL fused forms of the 8- and 16-channel levels -- res8b_tile / resb_tail_tile apply the
-    //  activation to fp32 values and take float maxima in their pools, a template parameter serves them; the lean forms, the walkers and the
-    //  32-channel tail stay the ReLU graphs')
+    //  activation to fp32 values and take float maxima in their pools, a template parameter serves them; the 32-channel tail the same way; the lean forms and
+    //  the walkers stay the ReLU graphs')
     m->fused_act = (m->bf16 && variant && !cfg->plain_u && cfg->activation != 0 && m->fused8_wanted && m->fuse_act) ? cfg->activation : 0;
     const bool fusedb = m->bf16 && (!variant || m->fused_act);
     if (!rc && fusedb && cfg->res_depth == 3 && cfg->feat_root == 8) rc = pack_res8b(m.get(), blob);
     if (!rc && fusedb && cfg->res_depth == 3)
         for (int l = 0; l < n && !rc; ++l) {
             const int f = cfg->feat_root << l;
-            if (f != 8 && f != 16 && !(f == 32 && m->use_res32 && !m->fused_act)) continue;
+            if (f != 8 && f != 16 && !(f == 32 && m->use_res32)) continue;
             rc = pack_resb(m.get(), blob, "aru_net/featMapG/unet_down_" + std::to_string(l), f);
             if (!rc && l < n - 1) rc = pack_resb(m.get(), blob, "aru_net/featMapG/unet_up_" + std::to_string(l), f);
         }

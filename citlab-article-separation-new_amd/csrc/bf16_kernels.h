@@ -37,6 +37,12 @@ __device__ __forceinline__ float round_bf16(float v) { return __uint_as_float(pa
 __device__ __forceinline__ f32x4 unpack_bf16x4(u32x2 p) {
     return f32x4{__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xffff0000u), __uint_as_float(p.y << 16), __uint_as_float(p.y & 0xffff0000u)};
 }
+// The graph variants' activations for the bf16 kernels: act4 of aru_kernels.h with the HARDWARE exponential (v_exp_f32, 1 ulp) in elu -- its result is rounded
+// to bfloat16 (2^-9) right behind it; expf's ~20 instructions per value were 0.13-0.15 ms per level-0 block (round 6: elu page 3.50 -> see profiles/r6_variants)
+__device__ __forceinline__ float act1b(float x, int mode) {
+    return mode == 1 ? (x > 0.f ? x : __expf(x) - 1.f) : fmaxf(x, 0.f) + 0.1f * fminf(x, 0.f);
+}
+__device__ __forceinline__ f32x4 act4b(f32x4 v, int mode) { return f32x4{act1b(v.x, mode), act1b(v.y, mode), act1b(v.z, mode), act1b(v.w, mode)}; }
 // ReLU on two packed bf16: a negative bf16 is a negative int16 (v_pk_max_i16 with 0)
 __device__ __forceinline__ unsigned relu_bf16x2(unsigned x) {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, x), s16x2{0, 0}));
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void convb_kernel(const ConvBArgs a)
             f32x4 v = acc[m][n];
             if constexpr (!RESP) { if (P.res) v += unpack_bf16x4(*reinterpret_cast<const u32x2*>(P.res + p)); }
             if (a.relu_out) v = relu4(v);
-            else if (a.act) v = act4(v, a.act);
+            else if (a.act) v = act4b(v, a.act);
             // the pool takes its maximum over the ROUNDED values (what a separate pool kernel would read back)
             const u32x2 pk = pack_bf16x4(v);
             acc[m][n] = unpack_bf16x4(pk);
@@ -497,7 +503,7 @@ __device__ __forceinline__ void resb_tail_tile(const ResBArgs& a, const ResBProb
             for (int t = 0; t < CPC; ++t) acc = mfma_bf16_k32(af[t], bfr[t], acc);
             const int gy = y0 - halo + oy, gx = x0 - halo + ox;
             const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const f32x4 v = inside ? (ACT ? act4(acc + b4, ACT) : relu4(acc + b4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 v = inside ? (ACT ? act4b(acc + b4, ACT) : relu4(acc + b4)) : f32x4{0.f, 0.f, 0.f, 0.f};
             if (q < npix && (C == 16 || kk < 2)) *reinterpret_cast<u32x2*>(dst + q * PXB + kk * 8) = pack_bf16x4(v);
         }
     };
@@ -537,7 +543,7 @@ __device__ __forceinline__ void resb_tail_tile(const ResBArgs& a, const ResBProb
                 const int y = y0 + oy + r;
                 const size_t p = ((size_t)min(y, H - 1) * W + min(x, W - 1)) * C + (cok ? kk * 4 : 0);
                 f32x4 v = acc2[r] + b4 + unpack_bf16x4(*reinterpret_cast<const u32x2*>(P.t + p));
-                v = ACT ? act4(v, ACT) : relu4(v);
+                v = ACT ? act4b(v, ACT) : relu4(v);
                 const u32x2 pk = pack_bf16x4(v);
                 acc2[r] = unpack_bf16x4(pk);
                 if (cok && y < H && x < W) *reinterpret_cast<u32x2*>(P.out + p) = pk;
@@ -587,6 +593,8 @@ struct Res32Layout {
 // once (LDS-DMA) and a stage's 18 fragments come from there into registers (as one-shot blocks fetching them from L2 per stage the
 // kernel ran at the speed of the three separate layers: with one 100 KB block per CU nothing covered the per-stage round trips and
 // the 53 KB fill); the next tile's window is requested into registers right after the current one went to LDS.
+// ACT (round 6): 0 = the ReLU graphs (ReLU and pool on the packed values); 1 elu / 2 leaky: the activation on the fp32 sums before the rounding, float maxima in the pool
+template <int ACT = 0>
 __global__ __launch_bounds__(512, 1) void res32_tail_kernel(const ResBArgs a) {
     typedef Res32Layout L;
     constexpr int C = 32, NW = 8, NTH = 512;
@@ -721,8 +729,8 @@ __global__ __launch_bounds__(512, 1) void res32_tail_kernel(const ResBArgs a) {
             if (q < npix) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const u32x2 pk = pack_bf16x4(acc[m]);
-                    *reinterpret_cast<u32x2*>(dst + m * DPL + q * 32 + kk * 8) = inside ? u32x2{relu_bf16x2(pk.x), relu_bf16x2(pk.y)} : u32x2{0u, 0u};
+                    const u32x2 pk = pack_bf16x4(ACT ? act4b(acc[m], ACT) : acc[m]);
+                    *reinterpret_cast<u32x2*>(dst + m * DPL + q * 32 + kk * 8) = inside ? (ACT ? pk : u32x2{relu_bf16x2(pk.x), relu_bf16x2(pk.y)}) : u32x2{0u, 0u};
                 }
             }
         }
@@ -770,16 +778,24 @@ __global__ __launch_bounds__(512, 1) void res32_tail_kernel(const ResBArgs a) {
                     for (int rr = 0; rr < 2; ++rr) {
                         const int y = yc + oy + rr;
                         const size_t p = ((size_t)min(y, H - 1) * W + min(x, W - 1)) * C + m * 16 + kk * 4;
-                        const u32x2 q = pack_bf16x4(acc2[rr][m]);
-                        pk[rr] = u32x2{relu_bf16x2(q.x), relu_bf16x2(q.y)};
+                        const u32x2 q = pack_bf16x4(ACT ? act4b(acc2[rr][m], ACT) : acc2[rr][m]);
+                        pk[rr] = ACT ? q : u32x2{relu_bf16x2(q.x), relu_bf16x2(q.y)};
                         if (y < H && x < W) *reinterpret_cast<u32x2*>(P.out + p) = pk[rr];
                     }
                     if (P.pool) {
                         // 2 x 2 max on the packed values (non-negative bf16 order like their bit patterns); ceil mode at the right / bottom border
                         const int y = yc + oy;
-                        u32x2 mm = (y + 1 < H) ? u32x2{pkmax_u16(pk[0].x, pk[1].x), pkmax_u16(pk[0].y, pk[1].y)} : pk[0];
-                        const u32x2 nb = u32x2{__float_as_uint(lane_xor1(__uint_as_float(mm.x))), __float_as_uint(lane_xor1(__uint_as_float(mm.y)))};
-                        if (x + 1 < W) mm = u32x2{pkmax_u16(mm.x, nb.x), pkmax_u16(mm.y, nb.y)};
+                        u32x2 mm;
+                        if constexpr (ACT != 0) {                // (values of either sign: maxima of the floats the packed values are)
+                            f32x4 fm = (y + 1 < H) ? max4(unpack_bf16x4(pk[0]), unpack_bf16x4(pk[1])) : unpack_bf16x4(pk[0]);
+                            const f32x4 fn = f32x4{lane_xor1(fm.x), lane_xor1(fm.y), lane_xor1(fm.z), lane_xor1(fm.w)};
+                            if (x + 1 < W) fm = max4(fm, fn);
+                            mm = pack_bf16x4(fm);
+                        } else {
+                            mm = (y + 1 < H) ? u32x2{pkmax_u16(pk[0].x, pk[1].x), pkmax_u16(pk[0].y, pk[1].y)} : pk[0];
+                            const u32x2 nb = u32x2{__float_as_uint(lane_xor1(__uint_as_float(mm.x))), __float_as_uint(lane_xor1(__uint_as_float(mm.y)))};
+                            if (x + 1 < W) mm = u32x2{pkmax_u16(mm.x, nb.x), pkmax_u16(mm.y, nb.y)};
+                        }
                         if ((j & 1) == 0 && y < H && x < W)
                             *reinterpret_cast<u32x2*>(P.pool + ((size_t)(y >> 1) * Wp + (x >> 1)) * C + m * 16 + kk * 4) = mm;
                     }
@@ -1174,7 +1190,7 @@ __global__ __launch_bounds__(256, 2) void deconvb_kernel(const DeconvBArgs a) {
             for (int cls = 0; cls < 4; ++cls) {
                 f32x4 v = acc[r][cls][m] + b4;
                 if (a.relu_out) v = relu4(v);
-                else if (a.act) v = act4(v, a.act);
+                else if (a.act) v = act4b(v, a.act);
                 // 16-byte unit S = pixel * UPP + channel quad pair, stored at S ^ ((pixel >> 1) & 7): the 16 lanes of a store (pixels
                 // 2 j + px, fixed channels) would otherwise be 64 / 128 bytes apart = 8- / 16-way bank conflicts (74 % of the LDS cycles)
                 const int orow = 2 * Yl + (cls >> 1), ocol = 2 * j + (cls & 1), pix = orow * 2 * DCB_TW + ocol;
@@ -1461,7 +1477,7 @@ __device__ __forceinline__ void res8b_tile(const Res8BArgs& a, const Res8BProb& 
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) acc = mfma_bf16_k32(af[ky], *reinterpret_cast<const u32x4*>(src + base + ky * WIN * 16), acc);
-            f32x4 v = ACT ? act4(acc + b4, ACT) : relu4(acc + b4);
+            f32x4 v = ACT ? act4b(acc + b4, ACT) : relu4(acc + b4);
             if constexpr (!INT) {
                 const int gy = y0 - halo + py, gx = x0 - halo + px;
                 if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1500,7 +1516,7 @@ __device__ __forceinline__ void res8b_tile(const Res8BArgs& a, const Res8BProb& 
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) acc = mfma_bf16_k32(af[ky], *reinterpret_cast<const u32x4*>(r0 + base + ky * W2 * 16), acc);
                 const f32x4 tres = unpack_bf16x4(*reinterpret_cast<const u32x2*>(tc + (oy * TW + 2 * j + e) * 16 + ch * 2));
-                const f32x4 v = ACT ? act4(acc + b4 + tres, ACT) : relu4(acc + b4 + tres);
+                const f32x4 v = ACT ? act4b(acc + b4 + tres, ACT) : relu4(acc + b4 + tres);
                 const u32x2 pk = pack_bf16x4(v);
                 v2[r] = unpack_bf16x4(pk);
                 const int y = y0 + oy;
