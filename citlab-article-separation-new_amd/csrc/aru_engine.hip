@@ -1470,7 +1470,7 @@ void run_res8b_tiles(asep_aru* m, bool up, const TL& a0, const TL* a1, const std
             if (up) hipLaunchKernelGGL(res8f_kernel<true>, dim3(units), dim3(256), 0, m->stream, f);
             else hipLaunchKernelGGL(res8f_kernel<false>, dim3(units), dim3(256), 0, m->stream, f);
         } else {
-            ProfScope ps(m, up ? "res8b_kernel<true>" : "res8b_kernel<false>", flops, what);
+            ProfScope ps(m, up ? "res8b_kernel<true,0>" : "res8b_kernel<false,0>", flops, what);
             ps.bytes = bytes;
             if (up) hipLaunchKernelGGL(res8b_kernel<true>, dim3(units), dim3(256), 0, m->stream, a);
             else hipLaunchKernelGGL(res8b_kernel<false>, dim3(units), dim3(256), 0, m->stream, a);
@@ -1677,7 +1677,7 @@ TL run_resb_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled)
                 ASEP_HIP_CHECK_THROW(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Res32Layout::BYTES));
                 attr[act] = true;
             }
-            ProfScope ps(m, act ? "res32_tail_kernel" + targs({ti(act)}) : std::string("res32_tail_kernel"), flops, what);
+            ProfScope ps(m, "res32_tail_kernel" + targs({ti(act)}), flops, what);
             ps.bytes = bytes;
             a.ntiles = tiles;
             const dim3 g32(std::min(tiles, m->num_cus));
@@ -1696,7 +1696,7 @@ TL run_resb_tail(asep_aru* m, const std::string& scope, const TL& t, TL* pooled)
             ps.bytes = bytes;
             hipLaunchKernelGGL(res16f_kernel, dim3(units), dim3(256), 0, m->stream, a);
         } else {
-            ProfScope ps(m, "resb_tail_kernel" + targs({ti(rb.C)}), flops, what);
+            ProfScope ps(m, "resb_tail_kernel" + targs({ti(rb.C), ti(0)}), flops, what);
             ps.bytes = bytes;
             if (rb.C == 8) hipLaunchKernelGGL(resb_tail_kernel<8>, dim3(units), dim3(256), 0, m->stream, a);
             else hipLaunchKernelGGL(resb_tail_kernel<16>, dim3(units), dim3(256), 0, m->stream, a);
