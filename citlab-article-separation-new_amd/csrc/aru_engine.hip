@@ -1501,6 +1501,30 @@ Tensor new_tensor_bf(asep_aru* m, int H, int W, int C) {
         hipLaunchKernelGGL((convb_kernel<KH_, KW_, MODE_, MT_, WM_, TH_, MB_, true, 4>), grid, dim3(256), 0, m->stream, a); \
     } while (0)
 
+// maxpool2 of a ReLU layer's bf16 output (behind convr_kernel's RES form)
+TL run_maxpool2b(asep_aru* m, const TL& in) {
+    TL out;
+    for (const Tensor& t : in) out.push_back(new_tensor_bf(m, cdiv(t.H, 2), cdiv(t.W, 2), t.C));
+    for (size_t b0 = 0; b0 < in.size(); b0 += MAXP) {
+        const size_t b1 = std::min(in.size(), b0 + MAXP);
+        MaxPoolBArgs a{};
+        int blocks = 0;
+        double bytes = 0;
+        for (size_t i = b0; i < b1; ++i) {
+            bytes += tbytes(in[i]) + tbytes(out[i]);
+            MaxPoolBProb& p = a.p[i - b0];
+            p.in = in[i].bp(); p.out = out[i].bp(); p.H = in[i].H; p.W = in[i].W;
+            p.blk_begin = blocks;
+            blocks += (int)((out[i].count() / 8 + 255) / 256);
+        }
+        a.nprob = (int)(b1 - b0); a.C = in[0].C;
+        ProfScope ps(m, "maxpool2b_kernel", 0.0);
+        ps.bytes = bytes;
+        hipLaunchKernelGGL(maxpool2b_kernel, dim3(blocks), dim3(256), 0, m->stream, a);
+    }
+    return out;
+}
+
 // the 64 -> 64 3x3 layers with the filter in registers (convr_kernels.h): one wave per SIMD, a wave = the pipeline of a 32-column strip
 TL run_convr(asep_aru* m, const std::string& scope, const PackedConv& pc, const TL& in0, bool relu_in, bool relu_out, const TL* res) {
     TL out;
@@ -1556,9 +1580,14 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
     }
     // output-channel tiles per block: 1 (cout 8 / 16), 2 (cout 32: one wave row, 16 x 32 pixels), 4 (cout >= 64: two wave
     // rows of two m-tiles, 8 x 32 pixels)
-    if (m->use_convr && pc.kh == 3 && pc.kw == 3 && pc.bmode == 2 && !in1 && in0[0].C == 64 && pc.cout == 64 && pc.mtiles == 4 && !pooled && !act &&
-        (!res || (!relu_in && relu_out)))
-        return run_convr(m, scope, pc, in0, relu_in, relu_out, res);
+    if (m->use_convr && pc.kh == 3 && pc.kw == 3 && pc.bmode == 2 && !in1 && in0[0].C == 64 && pc.cout == 64 && pc.mtiles == 4 && !act &&
+        (!res || (!relu_in && relu_out)) && (!pooled || (relu_out && keep_full && !pool_f32))) {
+        TL out = run_convr(m, scope, pc, in0, relu_in, relu_out, res);
+        // (the block-closing layer of unet_down_3 also pools: convr_kernel has no fused pool; a ReLU output's 2 x 2 maxima are taken from the stored
+        // tensor -- the same values convb_kernel's epilogue compares -- by a streaming kernel: 100 + 41 us against 160)
+        if (pooled) *pooled = run_maxpool2b(m, out);
+        return out;
+    }
     const int mtb = pc.mtiles >= 4 ? 4 : pc.mtiles;
     if (pc.mtiles % mtb != 0 || mtb == 3) { set_error("conv %s: %d output tiles not instantiated", scope.c_str(), pc.mtiles); throw ArgError(); }
     const int th = (mtb == 4 || (mtb == 2 && pc.bmode == 2)) ? 8 : 16;

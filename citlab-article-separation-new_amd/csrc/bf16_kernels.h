@@ -2021,6 +2021,36 @@ __global__ __launch_bounds__(256, 4) void att_headb_kernel(const AttHeadBArgs a)
 }
 
 // channel sum [H,W,8] bf16 -> [H,W] fp32 (upsample_simple's channel-summing half; same association as chansum_kernel)
+// maxpool2 (ceil mode) of a bf16 NHWC tensor of NON-NEGATIVE values (a ReLU layer's output): the integer order of the bit patterns is the float order
+// (v_pk_max_i16-free: pkmax_u16).  Behind convr_kernel's RES form, which has no fused pool (unet_down_3/convR_2).  One thread = 8 channels of one output pixel.
+struct MaxPoolBProb {
+    const bf16_t* in;
+    bf16_t* out;
+    int H, W;              // input size; output ceil(H / 2) x ceil(W / 2)
+    int blk_begin, pad_;
+};
+struct MaxPoolBArgs {
+    MaxPoolBProb p[MAXP];
+    int nprob, C;          // C % 8 == 0
+};
+__global__ __launch_bounds__(256) void maxpool2b_kernel(const MaxPoolBArgs a) {
+    int pi = 0;
+    while (pi + 1 < a.nprob && (int)blockIdx.x >= a.p[pi + 1].blk_begin) ++pi;
+    const MaxPoolBProb& P = a.p[pi];
+    const int c8 = a.C >> 3, Ho = (P.H + 1) >> 1, Wo = (P.W + 1) >> 1;
+    const unsigned item = (blockIdx.x - P.blk_begin) * 256u + threadIdx.x;
+    if (item >= (unsigned)Ho * Wo * c8) return;
+    const unsigned pix = item / c8, c = item - pix * c8;
+    const unsigned oy = pix / Wo, ox = pix - oy * Wo;
+    const unsigned y0 = 2 * oy, x0 = 2 * ox, y1 = min(y0 + 1, (unsigned)P.H - 1), x1 = min(x0 + 1, (unsigned)P.W - 1);
+    const u32x4* in = reinterpret_cast<const u32x4*>(P.in);
+    const u32x4 v00 = in[((size_t)y0 * P.W + x0) * c8 + c], v01 = in[((size_t)y0 * P.W + x1) * c8 + c];
+    const u32x4 v10 = in[((size_t)y1 * P.W + x0) * c8 + c], v11 = in[((size_t)y1 * P.W + x1) * c8 + c];
+    auto mx = [](unsigned p, unsigned q) { return pkmax_u16(p, q); };
+    reinterpret_cast<u32x4*>(P.out)[(size_t)pix * c8 + c] = u32x4{mx(mx(v00.x, v01.x), mx(v10.x, v11.x)), mx(mx(v00.y, v01.y), mx(v10.y, v11.y)),
+                                                                  mx(mx(v00.z, v01.z), mx(v10.z, v11.z)), mx(mx(v00.w, v01.w), mx(v10.w, v11.w))};
+}
+
 struct PoolBProb {
     const bf16_t* in;
     float* out;
