@@ -1533,14 +1533,15 @@ TL run_convr(asep_aru* m, const std::string& scope, const PackedConv& pc, const 
         const size_t b1 = std::min(in0.size(), b0 + MAXP);
         ConvRArgs a{};
         int total = 0;
-        double flops = 0, bytes = 9.0 * 64 * 64 * 2.0;
+        const int cin = in0[0].C;
+        double flops = 0, bytes = 9.0 * cin * 64 * 2.0;
         for (size_t i = b0; i < b1; ++i) {
             bytes += tbytes(in0[i]) + tbytes(out[i]) + (res ? tbytes((*res)[i]) : 0.0);
             ConvRProb& p = a.p[i - b0];
             p.in = in0[i].bp(); p.res = res ? (*res)[i].bp() : nullptr; p.out = out[i].bp();
             p.H = in0[i].H; p.W = in0[i].W; p.strips = cdiv(in0[i].W, 32); p.begin = total;
             total += p.strips * p.H;
-            flops += 2.0 * in0[i].H * in0[i].W * 9.0 * 64.0 * 64.0;
+            flops += 2.0 * in0[i].H * in0[i].W * 9.0 * cin * 64.0;
         }
         a.nprob = (int)(b1 - b0); a.total = total;
         a.wpk = (const u32x4*)pc.d_wb; a.bias = pc.d_b;
@@ -1548,10 +1549,11 @@ TL run_convr(asep_aru* m, const std::string& scope, const PackedConv& pc, const 
         // one wave per SIMD; a wave's range = total / waves rows (never fewer than 8: a range starts with three rows of latency)
         const int blocks = std::max(1, std::min(m->num_cus, total / 32));
         TL sub(in0.begin() + b0, in0.begin() + b1);
-        ProfScope ps(m, "convr_kernel", flops, scope + " " + dims_of(sub) + " 64->64");
+        ProfScope ps(m, "convr_kernel", flops, scope + " " + dims_of(sub) + " " + std::to_string(cin) + "->64");
         ps.bytes = bytes;
-        ps.set_name("convr_kernel" + targs({tb(relu_in), tb(relu_out), tb(res != nullptr)}));
-        if (res) hipLaunchKernelGGL((convr_kernel<false, true, true>), dim3(blocks), dim3(256), 0, m->stream, a);
+        ps.set_name("convr_kernel" + targs({tb(relu_in), tb(relu_out), tb(res != nullptr), ti(cin)}));
+        if (cin == 32) hipLaunchKernelGGL((convr_kernel<false, false, false, 32>), dim3(blocks), dim3(256), 0, m->stream, a);
+        else if (res) hipLaunchKernelGGL((convr_kernel<false, true, true>), dim3(blocks), dim3(256), 0, m->stream, a);
         else if (relu_in && relu_out) hipLaunchKernelGGL((convr_kernel<true, true>), dim3(blocks), dim3(256), 0, m->stream, a);
         else if (relu_in) hipLaunchKernelGGL((convr_kernel<true, false>), dim3(blocks), dim3(256), 0, m->stream, a);
         else if (relu_out) hipLaunchKernelGGL((convr_kernel<false, true>), dim3(blocks), dim3(256), 0, m->stream, a);
@@ -1580,8 +1582,9 @@ TL run_convb(asep_aru* m, const std::string& scope, const TL& in0, const TL* in1
     }
     // output-channel tiles per block: 1 (cout 8 / 16), 2 (cout 32: one wave row, 16 x 32 pixels), 4 (cout >= 64: two wave
     // rows of two m-tiles, 8 x 32 pixels)
-    if (m->use_convr && pc.kh == 3 && pc.kw == 3 && pc.bmode == 2 && !in1 && in0[0].C == 64 && pc.cout == 64 && pc.mtiles == 4 && !act &&
-        (!res || (!relu_in && relu_out)) && (!pooled || (relu_out && keep_full && !pool_f32))) {
+    if (m->use_convr && pc.kh == 3 && pc.kw == 3 && pc.bmode == 2 && !in1 && pc.cout == 64 && pc.mtiles == 4 && !act &&
+        ((in0[0].C == 64 && (!res || (!relu_in && relu_out)) && (!pooled || (relu_out && keep_full && !pool_f32))) ||
+         (in0[0].C == 32 && !res && !pooled && !relu_in && !relu_out))) {
         TL out = run_convr(m, scope, pc, in0, relu_in, relu_out, res);
         // (the block-closing layer of unet_down_3 also pools: convr_kernel has no fused pool; a ReLU output's 2 x 2 maxima are taken from the stored
         // tensor -- the same values convb_kernel's epilogue compares -- by a streaming kernel: 100 + 41 us against 160)

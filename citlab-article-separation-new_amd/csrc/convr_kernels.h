@@ -1,4 +1,4 @@
-// convr_kernel: the 64 -> 64 3x3 layers of the bf16 path with the WHOLE FILTER IN REGISTERS (round 6; the form the round-5 review left open).
+// convr_kernel: the 64 -> 64 (and the 32 -> 64) 3x3 layers of the bf16 path with the WHOLE FILTER IN REGISTERS (round 6; the form the round-5 review left open).
 //
 // convb_kernel re-reads a layer's A fragments (72 KB for 64 -> 64) from L2 into LDS for every 8 x 32-pixel tile and reads them from LDS again for
 // every 8 MFMAs; lesson 48: 37 % of these layers is fill time, three single-block pipelines lost to the two-block one-shot kernel.  Here a wave
@@ -73,9 +73,10 @@ __device__ __forceinline__ void cvr_mfma_first(f32x4& acc, const u32x4& A, const
 // LDS reads as asm statements with their waits counted by hand (hipcc drains lgkmcnt to 0 in front of the first asm statement that uses a read's
 // result).  LDS operations of a wave return in order.  cvr_frag: the two fragments of a K chunk (n-tiles 0 / 1) from row base (scalar) + the lane's
 // place (vector); before chunk c the reads of chunks c + 1, c + 2 (four) may stay in flight.
+template <int NT1>                                          // byte offset of the second n-tile: 16 pixels
 __device__ __forceinline__ void cvr_frag(u32x4& b0, u32x4& b1, unsigned rowbase, unsigned place) {
     unsigned tmp;
-    asm volatile("v_add_u32 %2, %3, %4\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:2048" : "=v"(b0), "=v"(b1), "=&v"(tmp) : "s"(rowbase), "v"(place));
+    asm volatile("v_add_u32 %2, %3, %4\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%5" : "=v"(b0), "=v"(b1), "=&v"(tmp) : "s"(rowbase), "v"(place), "n"(NT1));
 }
 template <int OFF>
 __device__ __forceinline__ void cvr_lds_read(u32x4& b, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b) : "v"(addr), "n"(OFF)); }
@@ -88,14 +89,18 @@ __device__ __forceinline__ void cvr_mfma_done(f32x4 (&acc)[4][2]) {
     asm volatile("s_nop 11" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
 }
 
-template <bool RELU_IN, bool RELU_OUT, bool RES = false>
+// CIN: input channels, 64 (two stages of 32: 72 A fragments) or 32 (unet_down_3/conv1: 36 fragments, 64-byte pixels in the ring)
+template <bool RELU_IN, bool RELU_OUT, bool RES = false, int CIN = 64>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void convr_kernel(const ConvRArgs a) {
     // RES (the block-closing convR_2: out = relu(conv(r) + t)): the residual row t arrives by four more requests per row in a staging row of its
     // own and becomes the accumulators' INITIAL value (bias + t, convb_kernel's RESP order) while the previous row's MFMAs run; loads return in
     // order, so its wait is the input rows' wait: a ring of five rows (nothing in flight behind the wait; the ring's depth does not show in the
     // layer's time, profiles/r6_convr)
-    constexpr int NR = RES ? 5 : CVR_NR, ROWB = 34 * 128, RINGB = NR * ROWB, STGB = 32 * 128, WAVEB = RINGB + STGB + (RES ? STGB : 0);
-    constexpr int NDMA = 5;                                                         // 272 16-byte units per row: 4 full wave-instructions + 16 lanes
+    static_assert(CIN == 64 || (CIN == 32 && !RELU_IN && !RES), "64 input channels, or the block-opening 32 -> 64 conv1");
+    constexpr int G = CIN / 32, NCH = 9 * G, PXB = CIN * 2, UPP = PXB / 16;           // stages, K chunks per row, bytes / 16-byte blocks per input pixel
+    constexpr int NR = RES ? 5 : CVR_NR, ROWB = 34 * PXB, RINGB = NR * ROWB, STGB = 32 * 128, WAVEB = RINGB + STGB + (RES ? STGB : 0);
+    constexpr int NU = 34 * UPP;                                                    // 16-byte units of a row image: 272 / 136
+    constexpr int NDMA = (NU + 63) / 64;                                            // 5 (4 full wave-instructions + 16 lanes) / 3 (2 + 8 lanes)
     __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WAVEB];          // 155648 bytes (RES: 119808)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, kk = lane >> 4;
@@ -118,15 +123,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int k = 0; k < NDMA; ++k) {
         const int u = k * 64 + lane;
-        dpx[k] = u >> 3;
-        dch[k] = ((u & 7) ^ (dpx[k] & 6)) * 16;
+        dpx[k] = u / UPP;
+        // (CIN 32: four blocks per pixel, block b at b ^ 2 (bit 2 of p): the same search, for 64-byte pixels)
+        dch[k] = CIN == 64 ? ((u & 7) ^ (dpx[k] & 6)) * 16 : ((u & 3) ^ (((dpx[k] >> 2) & 1) << 1)) * 16;
     }
     // the lane's place inside a row image for a fragment read: [kx][g]; the second n-tile is 2048 bytes further
     unsigned fb[3][2];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) fb[kx][g] = (unsigned)((kx + j) * 128 + (((4 * g + kk) ^ ((kx + j) & 6)) * 16));
+        for (int g = 0; g < 2; ++g)
+            fb[kx][g] = CIN == 64 ? (unsigned)((kx + j) * 128 + (((4 * g + kk) ^ ((kx + j) & 6)) * 16))
+                                  : (unsigned)((kx + j) * 64 + ((kk ^ ((((kx + j) >> 2) & 1) << 1)) * 16));
     // staging: lane (j, kk) writes its 8 bytes (m-tile m, n-tile nt) of pixel 16 nt + j at 8-byte block ((4 m + kk) ^ ((j & 7) << 1)) of the pixel's
     // 128 (two lanes per bank pair instead of sixteen); read back linearly: lane l of instruction t gets the 16-byte block (l & 7) ^ ((l >> 3) & 7)
     // of pixel 8 t + (l >> 3), so eight lanes store one 128-byte line
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto request_row = [&](int t) {
         const int y = r0 - 1 + t;
         const bool rowok = y >= 0 && y < H && t <= n + 1;                           // (wave-uniform)
-        rq_base = rowok ? inb + (size_t)y * W * 128 : zero;
+        rq_base = rowok ? inb + (size_t)y * W * PXB : zero;
         rq_mask = rowok ? ~0u : 0u;
         rq_dst = ((unsigned)t % NR) * ROWB;
     };
@@ -195,8 +203,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int k = 0; k < NDMA; ++k) {
             const int gx = x0 - 1 + dpx[k];
-            colok[k] = gx >= 0 && gx < W && k * 64 + lane < 272;
-            voff[k] = colok[k] ? (unsigned)(gx * 128 + dch[k]) : 0u;
+            colok[k] = gx >= 0 && gx < W && k * 64 + lane < NU;
+            voff[k] = colok[k] ? (unsigned)(gx * PXB + dch[k]) : 0u;
         }
         if (x0 == 0 || x0 + 33 > W) {                                               // a strip at the image's left / right edge: zero columns
             if (again) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the previous range's last requests have landed)
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int slot = 0; slot < NR; ++slot)
 #pragma unroll
                 for (int k = 0; k < NDMA; ++k)
-                    if (!colok[k] && k * 64 + lane < 272) *reinterpret_cast<u32x4*>(ring + slot * ROWB + k * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+                    if (!colok[k] && k * 64 + lane < NU) *reinterpret_cast<u32x4*>(ring + slot * ROWB + k * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) okt[t] = x0 + 8 * t + gpx < W;
@@ -224,10 +232,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         u32x4 v[NDMA];
 #pragma unroll
         for (int k = 0; k < NDMA; ++k)
-            if (k < NDMA - 1 || lane < 16) v[k] = *reinterpret_cast<const u32x4*>(rp + k * 1024);
+            if (k * 64 + lane < NU) v[k] = *reinterpret_cast<const u32x4*>(rp + k * 1024);
 #pragma unroll
         for (int k = 0; k < NDMA; ++k)
-            if (k < NDMA - 1 || lane < 16) *reinterpret_cast<u32x4*>(rp + k * 1024) = relu_bf16x8(v[k]);
+            if (k * 64 + lane < NU) *reinterpret_cast<u32x4*>(rp + k * 1024) = relu_bf16x8(v[k]);
     };
 
     // the first range's rows are requested BEFORE the filter is loaded (the loads behind them return in order: one wait covers both)
@@ -237,14 +245,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // 64 of the 72 fragments are DEFINED in the accumulator half of the register file (loads into AGPR tuples, inline asm: a value the compiler
     // defines lives in a VGPR first, 288 of them do not fit 256, and what it then "spills" to AGPRs it copies back in front of every use:
     // 120 v_accvgpr_mov / _read per row in the first cut); the MFMAs take them from there.  The last 8 are ordinary values.
-    constexpr int NAA = 64;
-    u32x4 Aa[NAA], Av[72 - NAA];
+    constexpr int NA = NCH * 4, NAA = NA < 64 ? NA : 64;
+    u32x4 Aa[NAA], Av[NA > NAA ? NA - NAA : 1];
     {
         const u32x4* wl = a.wpk + lane;
 #pragma unroll
         for (int i = 0; i < NAA; ++i) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(Aa[i]) : "v"(wl + i * 64) : "memory");
 #pragma unroll
-        for (int i = NAA; i < 72; ++i) Av[i - NAA] = wl[i * 64];
+        for (int i = NAA; i < NA; ++i) Av[i - NAA] = wl[i * 64];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < NAA; ++i) asm volatile("" : "+a"(Aa[i]));                 // (the uses below stay behind the wait)
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto frag = [&](auto cc, const unsigned (&sb)[4], int dk, u32x4 (&b)[2]) {      // chunk c of the row whose first ring row is sb[dk]
         constexpr int c = decltype(cc)::value, g = c / 9, t = c - g * 9, ky = t / 3, kx = t - ky * 3;
         if (CVR_ABL & 16) { b[0] = u32x4{(unsigned)c, 0u, 0u, 0u}; b[1] = b[0]; return; }
-        cvr_frag(b[0], b[1], sb[dk + ky], fb[kx][g]);
+        cvr_frag<16 * PXB>(b[0], b[1], sb[dk + ky], fb[kx][g]);
     };
     u32x4 rr4;
     u32x2 rq[4][2];
@@ -311,10 +319,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int k = 0; k < 4; ++k) sb[k] = ringa + ((unsigned)(i + k) % NR) * ROWB;
         const unsigned rra = sb[3] + (unsigned)lane * 16u;
-        static_for<18>([&](auto cc) {
+        static_for<NCH>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
-            if constexpr (c + 2 < 18) frag(ic<c + 2>{}, sb, 0, bq[(c + 2) % 3]);
-            else frag(ic<c + 2 - 18>{}, sb, 1, bq[(c + 2) % 3]);                     // (ky = 0 of the next row: ring row i + 1)
+            if constexpr (c + 2 < NCH) frag(ic<c + 2>{}, sb, 0, bq[(c + 2) % 3]);
+            else frag(ic<c + 2 - NCH>{}, sb, 1, bq[(c + 2) % 3]);                     // (ky = 0 of the next row: ring row i + 1)
             if (!(CVR_ABL & 16)) cvr_lds_wait<4>(bq[c % 3][0], bq[c % 3][1]);
             static_for<4>([&](auto mc) {
                 constexpr int m = decltype(mc)::value, ia = c * 4 + m;
@@ -364,9 +372,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int k = 0; k < 4; ++k) *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(rra + k * 1024) = relu_bf16x8(st[k]);
                 if (lane < 16) *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(rra + 4096) = relu_bf16x8(rr4);
             }
-            if constexpr (c == 6) request_row(i + NR - 1);                          // into the slot row i - 1 has left
-            if constexpr (c >= 7 && c < 7 + NDMA) request_piece(c - 7);
-            if constexpr (c <= 2 || (c >= 4 && c < 7 + NDMA) || (RES && c < 16)) __builtin_amdgcn_sched_barrier(0);
+            constexpr int RQ0 = NCH == 18 ? 7 : 5;                                  // (nine chunks: the requests right behind the stores)
+            if constexpr (c == RQ0 - 1) request_row(i + NR - 1);                    // into the slot row i - 1 has left
+            if constexpr (c >= RQ0 && c < RQ0 + NDMA) request_piece(c - RQ0);
+            if constexpr (c <= 2 || (c >= 4 && c < RQ0 + NDMA) || (RES && c < 16)) __builtin_amdgcn_sched_barrier(0);
         });
         // No asm read may be in flight where hipcc is free to move registers (the loop's edges: the two row bodies use the accumulator sets and,
         // if its allocation says so, the fragment buffers in different registers, and a v_mov of a read's destination before the data has landed
