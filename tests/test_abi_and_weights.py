@@ -170,3 +170,34 @@ def test_load_graph_accepts_container_and_rejects_pb(tmp_path):
     with pytest.raises(IOError):
         helper.load_graph(str(tmp_path / "x.pb"))
     assert helper.get_scaling_factor(4500, 3000, 1.0, fixed_height=1500) == pytest.approx(1 / 3)
+
+
+def test_every_environment_switch_the_sources_read_is_listed_and_documented():
+    """asep_engine_switches() (ABI 6) and DESIGN.md section 4.5 name exactly what the product build reads: every getenv("ASEP_...") of csrc/*.hip
+    outside an ASEP_ABLATION block must be in the function's list and in the table (bench.py records only listed names as engine switches)."""
+    import glob
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(ROOT, "citlab-article-separation-new_amd", "csrc")
+    read, ablation_only = set(), set()
+    for path in glob.glob(os.path.join(csrc, "*.hip")):
+        depth_abl = 0
+        for line in open(path):
+            s = line.strip()
+            if s.startswith("#ifdef ASEP_ABLATION") or s.startswith("#if defined(ASEP_ABLATION)"):
+                depth_abl += 1
+            elif s.startswith("#endif") and depth_abl:
+                depth_abl -= 1
+            for name in re.findall(r'getenv\("(ASEP_[A-Z0-9_]+)"\)', line):
+                (ablation_only if depth_abl else read).add(name)
+    common = open(os.path.join(csrc, "asep_common.hip")).read()
+    body = common[common.index("const char* asep_engine_switches(void)"):]
+    body = body[:body.index("int asep_abi_version")]
+    product = body[:body.index("#ifdef ASEP_ABLATION")] if "#ifdef ASEP_ABLATION" in body else body
+    listed = set(re.findall(r"ASEP_[A-Z0-9_]+", product)) - {"ASEP_ABLATION"}
+    assert read, "no switches found: the scan is broken"
+    assert read == listed, (sorted(read - listed), sorted(listed - read))
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    sec = design[design.index("### 4.5 Engine switches"):design.index("## 5. Measurement")]
+    missing = [n for n in sorted(read) if "`" + n not in sec]
+    assert not missing, missing
+    assert not (ablation_only & listed)
