@@ -629,7 +629,7 @@ def pipe_of(kernel, dtype):
     fp32 MFMA and the fp32 vector ALU are ONE datapath on gfx950 (157.3 TFLOP/s either way, DESIGN lesson 15); a split-product kernel
     executes SIX bf16 MFMA products per fp32 product, so its fp32-equivalent peak is the dense bf16 peak / 6; the bf16 path's
     convolutions run at the dense bf16 peak."""
-    if kernel.startswith(("convs_kernel", "convs16_kernel")):
+    if kernel.startswith(("convs_kernel", "convs16_kernel", "deconvs_kernel")):
         return "bf16 MFMA, 6 split products per fp32 product", PEAK_BF16_MFMA_TFLOPS / 6.0
     if dtype == "bf16" and kernel.startswith(BF16_MFMA_KERNELS):
         return "bf16 MFMA", PEAK_BF16_MFMA_TFLOPS
@@ -959,7 +959,7 @@ def main():
             k["executed_tflops"] = k["executed_flops"] / (k["total_ms"] * 1e-3) / 1e12 if k["total_ms"] > 0 else 0.0
             # split-product kernels (f32s): every fp32 product is SIX bf16 products on the bf16 pipe; executed_* stays the fp32-equivalent
             # figure (1 x), bf16_tflops is what the bf16 matrix pipeline executes
-            k["bf16_tflops"] = 6.0 * k["tflops"] if k["kernel"].startswith(("convs_kernel", "convs16_kernel")) else 0.0
+            k["bf16_tflops"] = 6.0 * k["tflops"] if k["kernel"].startswith(("convs_kernel", "convs16_kernel", "deconvs_kernel")) else 0.0
             k["pipe"], k["pipe_peak"] = pipe_of(k["kernel"], args.dtype)
             # ALGORITHMIC bytes per launch (every input read once, every output written once: the engine's shape arithmetic) / time
             k["algo_gbs"] = k["bytes"] / (k["total_ms"] * 1e-3) / 1e9 if k["total_ms"] > 0 else 0.0

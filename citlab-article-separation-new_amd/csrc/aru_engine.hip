@@ -77,6 +77,7 @@ struct asep_aru {
     float* d_r8b_down_w1r = nullptr; // the same filter [9][8] as fp32 values rounded to bfloat16 (border tiles, res8b_tile)
     bool use_res32 = true;           // ASEP_BF_RES32=0: the 32-channel residual tails layer by layer (convb_kernel)
     int walk_mode = 1;               // ASEP_BF_WALK: 1 both level-0 blocks on the walkers (default), 2 the UP block only, 0 neither
+    bool use_deconvs = true;         // ASEP_SPLIT_DECONV=0: the deconvolutions of the f32s engine on the fp32 MFMA (deconv_mfma_kernel) instead of split products
     bool use_convr = true;           // ASEP_BF_CONVR=0: the 64 -> 64 layers on convb_kernel instead of the register-resident form (convr_kernels.h)
     unsigned char* d_zero_trash = nullptr;   // 16 zero bytes (padding source of convr_kernel) + 4 KB behind them that nobody reads (its dump)
     int fused_act = 0;               // bf16 engine, elu / leaky RESIDUAL graphs (round 6): the level-0 blocks and the 16-channel tails on the general fused forms
@@ -230,6 +231,7 @@ inline std::string ti(int i) { return std::to_string(i); }
 // ---- weight packing -----------------------------------------------------------------------------
 int pack_conv_bf(asep_aru* m, PackedConv& pc, const HostTensor& w);   // bf16 fragments (native bf16 path), defined further down
 int pack_conv_split(asep_aru* m, PackedConv& pc, const HostTensor& w);   // three-part bf16 fragments (split_kernels.h)
+int pack_deconv_split(asep_aru* m, PackedConv& pc, const HostTensor& w); // the same for deconvs_kernel
 
 // conv   W[kh][kw][cin][cout]  (layers.py:219);  deconv W[kh][kw][cout][cin] (layers.py:352, ARU_v1.py:257)
 int pack_conv(asep_aru* m, const std::map<std::string, HostTensor>& blob, const std::string& scope,
@@ -340,6 +342,10 @@ int pack_conv(asep_aru* m, const std::map<std::string, HostTensor>& blob, const 
     }
     if (m->split && !deconv) {
         rc = pack_conv_split(m, pc, w);
+        if (rc) return rc;
+    }
+    if (m->split && deconv) {
+        rc = pack_deconv_split(m, pc, w);
         if (rc) return rc;
     }
     m->convs[scope] = pc;
@@ -720,6 +726,7 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
     }
     const int mt = pc.mtiles % 2 == 0 ? 2 : 1;
     const bool valu = pc.d_wv && m->r8_valu;                 // level 0: one input position per thread on the vector ALU
+    const bool splitd = m->split && m->use_deconvs && pc.d_ws && pc.smode == 2 && !valu;   // >= 32 input channels: split products (deconvs_kernel)
     for (size_t b0 = 0; b0 < in.size(); b0 += MAXP) {
         const size_t b1 = std::min(in.size(), b0 + MAXP);
         ConvArgs a{};
@@ -745,13 +752,17 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
         int units = tiles;
         a.xm = oneshot_map(m, tiles, &units);
         dim3 grid(units, pc.mtiles / mt);
-        const std::string dname = valu ? std::string("deconv8v_kernel") : "deconv_mfma_kernel" + targs({ti(mt), tb(false)});
+        const std::string dname = valu ? std::string("deconv8v_kernel") : (splitd ? "deconvs_kernel" + targs({ti(mt)}) : "deconv_mfma_kernel" + targs({ti(mt), tb(false)}));
         TL sub(in.begin() + b0, in.begin() + b1);
         ProfScope ps(m, dname, flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
         ps.bytes = bytes;
         if (valu) {
             a.wpk = (const f32x4*)pc.d_wv;
             hipLaunchKernelGGL(deconv8v_kernel, dim3(units), dim3(256), 0, m->stream, a);
+        } else if (splitd) {
+            a.wpk = (const f32x4*)pc.d_ws; a.groups = pc.cin / 32;
+            if (mt == 2) hipLaunchKernelGGL((deconvs_kernel<2>), grid, dim3(256), 0, m->stream, a);
+            else hipLaunchKernelGGL((deconvs_kernel<1>), grid, dim3(256), 0, m->stream, a);
         } else if (mt == 2) hipLaunchKernelGGL((deconv_mfma_kernel<2>), grid, dim3(256), 0, m->stream, a);
         else hipLaunchKernelGGL((deconv_mfma_kernel<1>), grid, dim3(256), 0, m->stream, a);
     }
@@ -1179,6 +1190,32 @@ int pack_conv_split(asep_aru* m, PackedConv& pc, const HostTensor& w) {
         if (rc) return rc;
         m->owned.push_back(pc.d_ws16);
     }
+    return ASEP_OK;
+}
+
+// a 3x3 deconvolution filter with Cin % 32 == 0 as three bfloat16 parts for deconvs_kernel: [stage of 32 channels][tap][part h, m, l][m-tile][lane][8]
+int pack_deconv_split(asep_aru* m, PackedConv& pc, const HostTensor& w) {
+    if (pc.kh != 3 || pc.kw != 3 || pc.cin % 32 != 0 || pc.cout % 16 != 0) return ASEP_OK;      // (level 0, 16 -> 8: deconv8v_kernel)
+    auto W = [&](int tap, int ci, int co) -> float { return w.data[((size_t)tap * pc.cout + co) * pc.cin + ci]; };
+    auto bfval = [](bf16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+    const int G = pc.cin / 32;
+    std::vector<bf16_t> pk((size_t)G * 9 * 3 * pc.mtiles * 64 * 8);
+    for (int g = 0; g < G; ++g)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int mt = 0; mt < pc.mtiles; ++mt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = W(tap, 32 * g + (lane >> 4) * 8 + j, mt * 16 + (lane & 15));
+                        const bf16_t h = f2bf(v);
+                        const float r = v - bfval(h);
+                        const bf16_t mm = f2bf(r);
+                        const bf16_t part[3] = {h, mm, f2bf(r - bfval(mm))};
+                        for (int s = 0; s < 3; ++s) pk[(((((size_t)g * 9 + tap) * 3 + s) * pc.mtiles + mt) * 64 + lane) * 8 + j] = part[s];
+                    }
+    int rc = upload_bf(pk, &pc.d_ws);
+    if (rc) return rc;
+    m->owned.push_back(pc.d_ws);
+    pc.smode = 2;
     return ASEP_OK;
 }
 
@@ -2345,6 +2382,7 @@ asep_aru* asep_aru_load(const void* weight_blob, size_t nbytes, const asep_aru_c
     if (const char* e = getenv("ASEP_XCD_SCHED")) m->use_xcd_sched = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_RES32")) m->use_res32 = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_CONVR")) m->use_convr = atoi(e) != 0;
+    if (const char* e = getenv("ASEP_SPLIT_DECONV")) m->use_deconvs = atoi(e) != 0;
     if (const char* e = getenv("ASEP_BF_WALK")) { m->walk_mode = atoi(e); m->use_walk = m->walk_mode != 0; }
     if (const char* e = getenv("ASEP_LANES")) { m->num_lanes = std::max(1, std::min(4, atoi(e))); m->lanes_forced = true; }
     for (int l = 0; l < m->num_lanes; ++l) {

@@ -115,7 +115,7 @@ const char* asep_version(void) { return "asep_hip 0.5 (gfx950)"; }
 
 // The environment switches this BUILD reads, one name per line.
 const char* asep_engine_switches(void) {
-    return "ASEP_FUSE_POOL\nASEP_FUSE_ACT\nASEP_C12\nASEP_FUSED8\nASEP_R8_VALU\nASEP_XCD_SCHED\nASEP_BF_RES32\nASEP_BF_WALK\nASEP_BF_CONVR\nASEP_LANES\nASEP_GNN_STEP\nASEP_GNN_FACTOR"
+    return "ASEP_FUSE_POOL\nASEP_FUSE_ACT\nASEP_C12\nASEP_FUSED8\nASEP_R8_VALU\nASEP_XCD_SCHED\nASEP_BF_RES32\nASEP_BF_WALK\nASEP_BF_CONVR\nASEP_SPLIT_DECONV\nASEP_LANES\nASEP_GNN_STEP\nASEP_GNN_FACTOR"
 #ifdef ASEP_ABLATION
            "\nASEP_GNN_BATCH\nASEP_GNN_LANES"
 #endif

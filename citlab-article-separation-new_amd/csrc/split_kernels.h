@@ -484,4 +484,153 @@ __global__ __launch_bounds__(256, MINB) void convs16_kernel(const ConvArgs a) {
 // (Level 0 on split products -- res8s_kernel, one-shot and persistent -- was built in round 4, is correct and is SLOWER than the
 //  vector-ALU blocks of res8v_kernels.h (DESIGN_LESSONS.md 32); it left the tree in round 5, git history keeps it: 545c6ae .. 7d11314.)
 
+
+// ------------------------------------------------------------------------------------------------
+// deconvs_kernel: the 3x3 stride-2 SAME transposed convolutions of the levels with >= 32 input channels (unet_up_1 .. : 32 -> 16, 64 -> 32, 128 -> 64)
+// on SPLIT PRODUCTS (round 6; layers.py:342-367 deconv2d + bias + activation, the semantics of deconv_mfma_kernel).  These three layers ran on the fp32 MFMA
+// (63-90 TFLOP/s: 643 + 477 + 456 us per 4-page launch of a 7.1 ms page) while their tensors move in 340 + 170 + 85 us at 5 TB/s.
+// Structure of deconvb_kernel MODE 2: a block = DS_TH x 16 INPUT positions (their 2 DS_TH x 32 output pixels), wave w owns input rows w, w + 4, ...;
+// an n-tile = 16 positions of one input row; output class c = 2 py + px of an input position (Y, X) is output pixel (2 Y - pbh + py, 2 X - pbw + px)
+//     = sum over (dy, dx) in {0, 1}^2 of  in(Y - dy, X - dx) . W[ky][kx],   ky = py ? 1 : (dy ? 2 : 0) (py = 1 has no dy = 1 term), kx alike;
+// per stage of 32 input channels the (DS_TH + 1) x 17 halo tile is read as fp32, cut into its three bfloat16 parts (split3_x8) and stored as three sets of
+// two 16-channel planes; a (dy, dx) step reads ONE B fragment triple and feeds up to four classes x MT m-tiles x six MFMAs (h h, h m, m h, m m, h l, l h).
+// a.wpk = pack_deconv_split's [stage][tap][part h, m, l][m-tile][lane] x 16 bytes; a.groups = stages of 32 channels.  Results: fp32, bias, ReLU or the
+// variants' activation, 16-byte stores of a lane's four channels.
+// ------------------------------------------------------------------------------------------------
+constexpr int DS_TH = 8, DS_TW = 16;
+template <int MT>
+__global__ __launch_bounds__(256, 2) void deconvs_kernel(const ConvArgs a) {
+    constexpr int LH = DS_TH + 1, LW = DS_TW + 1, RW = DS_TH / 4;
+    constexpr int PLANE = LH * LW * 32, PART = 2 * PLANE;
+    constexpr int NU = LH * LW * 4, NLOAD = (NU + 255) / 256;                       // 8-channel units of a stage's halo tile
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PART];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kk = lane >> 4;
+    const int bid = sched_tile(a.xm);
+    if (bid < 0) return;
+    int pi = 0;
+    pi = prob_of_tile(a, bid);
+    const ConvProb& P = a.p[pi];
+    const int tile = bid - P.tile_begin;
+    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const int X0 = tx * DS_TW, Y0 = ty * DS_TH, mt0 = blockIdx.y * MT;
+    const int Hi = P.H, Wi = P.W, cin = a.c0;
+
+    f32x4 acc[RW][4][MT];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[r][c][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bias4[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int c = (mt0 + m) * 16 + kk * 4;
+        bias4[m] = *reinterpret_cast<const f32x4*>(a.bias + (c < a.cout ? c : 0));
+        if (c >= a.cout) bias4[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const u32x4* __restrict__ wbase = reinterpret_cast<const u32x4*>(a.wpk) + (size_t)mt0 * 64 + lane;
+    const size_t wstride = (size_t)a.mtiles * 64;                                   // one (stage, tap, part) of all m-tiles
+
+    int spix[NLOAD];
+    unsigned mask = 0;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+        const int u = min(tid + i * 256, NU - 1);
+        const int pix = u >> 2;
+        const int ly = pix / LW, lx = pix - ly * LW;
+        const int gy = Y0 - 1 + ly, gx = X0 - 1 + lx;
+        spix[i] = min(max(gy, 0), Hi - 1) * Wi + min(max(gx, 0), Wi - 1);
+        mask |= ((gy >= 0 && gy < Hi && gx >= 0 && gx < Wi) ? 1u : 0u) << i;
+    }
+    const int sub8 = (tid & 3) * 8;                                                 // (256 is a multiple of 4: the thread's 8-channel unit is the same for all its slots)
+    for (int g = 0; g < a.groups; ++g) {
+        f32x4 st[NLOAD][2];
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const float* src = P.in0 + (size_t)spix[i] * cin + g * 32 + sub8;
+            st[i][0] = *reinterpret_cast<const f32x4*>(src);
+            st[i][1] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+        if (g > 0) __syncthreads();                                                 // the previous stage's readers are done
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int u = tid + i * 256;
+            if (u < NU) {
+                const int pix = u >> 2, sub = u & 3;
+                u32x4 ph, pm, pl;
+                split3_x8(st[i][0], st[i][1], ph, pm, pl);
+                if (!((mask >> i) & 1u)) ph = pm = pl = u32x4{0u, 0u, 0u, 0u};
+                unsigned char* d = lds + (sub >> 1) * PLANE + pix * 32 + (sub & 1) * 16;
+                *reinterpret_cast<u32x4*>(d) = ph;
+                *reinterpret_cast<u32x4*>(d + PART) = pm;
+                *reinterpret_cast<u32x4*>(d + 2 * PART) = pl;
+            }
+        }
+        __syncthreads();
+        const u32x4* __restrict__ wg = wbase + (size_t)g * 9 * 3 * wstride;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+                    if (dy == 1 && py == 1) continue;
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        if (dx == 1 && px == 1) continue;
+                        const int ky = py ? 1 : (dy ? 2 : 0), kx = px ? 1 : (dx ? 2 : 0), tap = ky * 3 + kx;
+                        // the tap's A fragments (three parts x MT m-tiles) serve both rows of the wave
+                        u32x4 ah[MT], am[MT], al[MT];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            ah[m] = wg[((size_t)tap * 3 + 0) * wstride + (size_t)m * 64];
+                            am[m] = wg[((size_t)tap * 3 + 1) * wstride + (size_t)m * 64];
+                            al[m] = wg[((size_t)tap * 3 + 2) * wstride + (size_t)m * 64];
+                        }
+#pragma unroll
+                        for (int r = 0; r < RW; ++r) {
+                            const int Yl = wave + 4 * r;
+                            const unsigned char* bp = lds + (kk >> 1) * PLANE + ((Yl + 1 - dy) * LW + (j + 1 - dx)) * 32 + (kk & 1) * 16;
+                            const u32x4 bh = *reinterpret_cast<const u32x4*>(bp), bm = *reinterpret_cast<const u32x4*>(bp + PART),
+                                        bl = *reinterpret_cast<const u32x4*>(bp + 2 * PART);
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+                                f32x4 c = acc[r][2 * py + px][m];
+                                // (small terms first)
+                                c = mfma_bf16_k32(al[m], bh, c);
+                                c = mfma_bf16_k32(ah[m], bl, c);
+                                c = mfma_bf16_k32(am[m], bm, c);
+                                c = mfma_bf16_k32(am[m], bh, c);
+                                c = mfma_bf16_k32(ah[m], bm, c);
+                                c = mfma_bf16_k32(ah[m], bh, c);
+                                acc[r][2 * py + px][m] = c;
+                            }
+                        }
+                    }
+                }
+    }
+    // ---- epilogue: lane = input position (Yl, j), 4 consecutive output channels 16 (mt0 + m) + 4 kk of each of its four output pixels ----
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int c = (mt0 + m) * 16 + kk * 4;
+        if (c >= a.cout) continue;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int Yl = wave + 4 * r;
+#pragma unroll
+            for (int cls = 0; cls < 4; ++cls) {
+                const int y = 2 * (Y0 + Yl) - P.pbh + (cls >> 1), x = 2 * (X0 + j) - P.pbw + (cls & 1);
+                f32x4 v = acc[r][cls][m] + bias4[m];
+                if (a.relu_out) v = relu4(v);
+                else if (a.act) v = act4(v, a.act);
+                if (Y0 + Yl < Hi && X0 + j < Wi && y >= 0 && y < P.Ho && x >= 0 && x < P.Wo)
+                    *reinterpret_cast<f32x4*>(P.out + ((size_t)y * P.Wo + x) * a.cout + c) = v;
+            }
+        }
+    }
+}
+
 }  // namespace asep
