@@ -726,6 +726,9 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
     }
     const int mt = pc.mtiles % 2 == 0 ? 2 : 1;
     const bool valu = pc.d_wv && m->r8_valu;                 // level 0: one input position per thread on the vector ALU
+#ifndef DS_ROWS
+#define DS_ROWS 8                  // input rows per block of deconvs_kernel (16: 280 / 310 / 477 us against 260 / 312 / 440)
+#endif
     const bool splitd = m->split && m->use_deconvs && pc.d_ws && pc.smode == 2 && !valu;   // >= 32 input channels: split products (deconvs_kernel)
     for (size_t b0 = 0; b0 < in.size(); b0 += MAXP) {
         const size_t b1 = std::min(in.size(), b0 + MAXP);
@@ -740,7 +743,7 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
             p.pbw = std::max((in[i].W - 1) * 2 + 3 - out[i].W, 0) / 2;
             p.tiles_x = cdiv(in[i].W, valu ? DCV_T : DC_TW);
             p.tile_begin = tiles;
-            tiles += p.tiles_x * cdiv(in[i].H, valu ? DCV_T : DC_TH);
+            tiles += p.tiles_x * cdiv(in[i].H, valu ? DCV_T : (splitd ? DS_ROWS : DC_TH));
             flops += 2.0 * in[i].H * in[i].W * 9.0 * pc.cin * pc.cout;
             bytes += tbytes(in[i]) + tbytes(out[i]);
         }
@@ -752,7 +755,7 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
         int units = tiles;
         a.xm = oneshot_map(m, tiles, &units);
         dim3 grid(units, pc.mtiles / mt);
-        const std::string dname = valu ? std::string("deconv8v_kernel") : (splitd ? "deconvs_kernel" + targs({ti(mt)}) : "deconv_mfma_kernel" + targs({ti(mt), tb(false)}));
+        const std::string dname = valu ? std::string("deconv8v_kernel") : (splitd ? "deconvs_kernel" + targs({ti(mt), ti(DS_ROWS)}) : "deconv_mfma_kernel" + targs({ti(mt), tb(false)}));
         TL sub(in.begin() + b0, in.begin() + b1);
         ProfScope ps(m, dname, flops, scope + " " + dims_of(sub) + " " + std::to_string(pc.cin) + "->" + std::to_string(pc.cout));
         ps.bytes = bytes;
@@ -761,8 +764,8 @@ TL run_deconv(asep_aru* m, const std::string& scope, const TL& in, const TL& lik
             hipLaunchKernelGGL(deconv8v_kernel, dim3(units), dim3(256), 0, m->stream, a);
         } else if (splitd) {
             a.wpk = (const f32x4*)pc.d_ws; a.groups = pc.cin / 32;
-            if (mt == 2) hipLaunchKernelGGL((deconvs_kernel<2>), grid, dim3(256), 0, m->stream, a);
-            else hipLaunchKernelGGL((deconvs_kernel<1>), grid, dim3(256), 0, m->stream, a);
+            if (mt == 2) hipLaunchKernelGGL((deconvs_kernel<2, DS_ROWS>), grid, dim3(256), 0, m->stream, a);
+            else hipLaunchKernelGGL((deconvs_kernel<1, DS_ROWS>), grid, dim3(256), 0, m->stream, a);
         } else if (mt == 2) hipLaunchKernelGGL((deconv_mfma_kernel<2>), grid, dim3(256), 0, m->stream, a);
         else hipLaunchKernelGGL((deconv_mfma_kernel<1>), grid, dim3(256), 0, m->stream, a);
     }

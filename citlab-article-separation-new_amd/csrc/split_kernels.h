@@ -497,8 +497,8 @@ __global__ __launch_bounds__(256, MINB) void convs16_kernel(const ConvArgs a) {
 // a.wpk = pack_deconv_split's [stage][tap][part h, m, l][m-tile][lane] x 16 bytes; a.groups = stages of 32 channels.  Results: fp32, bias, ReLU or the
 // variants' activation, 16-byte stores of a lane's four channels.
 // ------------------------------------------------------------------------------------------------
-constexpr int DS_TH = 8, DS_TW = 16;
-template <int MT>
+constexpr int DS_TW = 16;
+template <int MT, int DS_TH>
 __global__ __launch_bounds__(256, 2) void deconvs_kernel(const ConvArgs a) {
     constexpr int LH = DS_TH + 1, LW = DS_TW + 1, RW = DS_TH / 4;
     constexpr int PLANE = LH * LW * 32, PART = 2 * PLANE;
